@@ -1,0 +1,182 @@
+/*
+ * mloam_hip.h -- C-ABI of the MI355X-native (gfx950) scan-to-map hot path of M-LOAM.
+ *
+ * One shared library (libmloam_hip.so, hand-written HIP kernels) behind plain C entry points: opaque context,
+ * plain pointers and sizes, int status (0 = ok, negative = error; text via mlh_last_error). No exceptions cross
+ * the boundary. A context owns one HIP stream and all device buffers; distinct contexts may be used from
+ * different threads concurrently (FeatureExtract::extractCloud is called from NUM_OF_LASER OpenMP threads,
+ * estimator/src/estimator/estimator.cpp:249-263 -> one context per thread), a single context is not re-entrant.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the M-LOAM source tree).
+ * Pose / parameter blocks are double[7] = [tx ty tz qx qy qz qw] exactly as the reference's Ceres parameter
+ * blocks (estimator/src/factor/lidar_map_factor.hpp:46-47).
+ *
+ * Pointer arguments marked HOST are host memory, DEV are device memory on the context's device. Points are read
+ * through (base, stride_bytes): x,y,z are 3 consecutive floats at the start of each record, so pcl::PointXYZI
+ * (32 B), pcl::PointXYZIWithCov (48 B, mloam_pcl/include/mloam_pcl/point_with_cov.hpp:45-53) and packed float4
+ * clouds can all be passed without repacking on the caller side.
+ */
+#ifndef MLOAM_HIP_H
+#define MLOAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mlh_ctx mlh_ctx;
+
+enum { MLH_SURF = 0, MLH_CORNER = 1 };              /* feature / map kind ('s' / 'c' in PointPlaneFeature::type_) */
+enum { MLH_MEM_HOST = 0, MLH_MEM_DEVICE = 1 };
+
+/* status codes */
+enum {
+    MLH_OK = 0,
+    MLH_ERR_INVALID = -1,     /* bad argument */
+    MLH_ERR_HIP = -2,         /* a HIP runtime call failed */
+    MLH_ERR_STATE = -3,       /* call order violated (e.g. match before map_set) */
+    MLH_ERR_NOMEM = -4,
+    MLH_ERR_UNSUPPORTED = -5
+};
+
+/* flags for mlh_match_linearize / solver options */
+enum {
+    MLH_FLAG_CHECK_FOV = 1u << 0,   /* CHECK_FOV argument of match*FromMap (feature_extract.hpp:696-715) */
+    MLH_FLAG_WITH_UA = 1u << 1,     /* with_ua_flag: weight from the feature's own covariance (lidar_mapper_keyframe.cpp:541-544) */
+    MLH_FLAG_NO_LOSS = 1u << 2      /* reduce un-corrected rows (ActiveFeatureSelection's H, lidar_mapper.h:162-164) */
+};
+
+/* ---------------------------------------------------------------- context */
+int mlh_create(mlh_ctx **out, int device_id);
+void mlh_destroy(mlh_ctx *ctx);
+const char *mlh_last_error(const mlh_ctx *ctx);
+const char *mlh_version(void);
+/* the context's HIP stream (hipStream_t), for callers that interleave their own device work */
+void *mlh_stream(mlh_ctx *ctx);
+int mlh_synchronize(mlh_ctx *ctx);
+
+/* ---------------------------------------------------------------- per-kernel timing (HIP events on the context's stream)
+ * When enabled, every launch of the named kernels is bracketed by hipEventRecord on the context's stream; the
+ * accumulated duration / launch count are read back with mlh_profile_get. Kernel ids: */
+enum { MLH_K_MATCH = 0, MLH_K_LINEARIZE = 1, MLH_K_SOLVE = 2, MLH_K_GRID_BUILD = 3, MLH_K_EXTRACT = 4, MLH_K_COUNT = 5 };
+int mlh_profile_enable(mlh_ctx *ctx, int on);
+int mlh_profile_reset(mlh_ctx *ctx);
+int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
+
+/* ---------------------------------------------------------------- (a1-a3) FeatureExtract::extractCloud
+ * replaces FeatureExtract::extractCloud(const PointICloud&, const ScanInfo&, cloudFeature&)
+ *   estimator/src/featureExtract/feature_extract.cpp:118-297, declared feature_extract.hpp:74.
+ * The cloud is ring-major; scan_start[r]/scan_end[r] are ScanInfo::scan_start_ind_/scan_end_ind_
+ * (already inset by +5/-6, image_segmenter.hpp:385-387).
+ *
+ * mlh_scan_upload   stages one cloud (+ring table) in HBM             [HOST or DEV source]
+ * mlh_extract_run   curvature (cpp:133-142), per-sector sort + greedy labelling (cpp:152-265), index lists
+ * mlh_extract_fetch copies results back: label[n] in {2,1,0,-1} (cloud_label), curvature[n], and the four index
+ *                   lists in the reference's emission order: 0 corner_points_sharp, 1 corner_points_less_sharp,
+ *                   2 surf_points_flat, 3 surf_points_less_flat BEFORE the per-ring VoxelGrid (positions with
+ *                   label<=0, cpp:258-264). Any output pointer may be NULL.
+ */
+int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, const int *scan_start, const int *scan_end,
+                    int n_rings, int mem);
+int mlh_extract_run(mlh_ctx *ctx);
+int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4]);
+
+/* ---------------------------------------------------------------- (a5) local map index
+ * replaces pcl::KdTreeFLANN<PointT>::setInputCloud(cloud) as used at
+ *   estimator/src/lidarMapper/lidar_mapper_keyframe.cpp:433-434 (and estimator.cpp:1095-1109, 1230-1233).
+ * Builds a dense cell grid (cell edge just above sqrt(min_match_sq_dis), so the 27-cell neighbourhood is exact for
+ * the acceptance test "5th neighbour sq-dist < min_match_sq_dis", feature_extract.hpp:667/814) over the cloud
+ * and keeps the points cell-sorted in HBM as float4 {x, y, z, original index}.
+ * mlh_map_rebuild re-runs the index build on the resident cloud (the reference rebuilds every frame).
+ */
+int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, float min_match_sq_dis, int mem);
+int mlh_map_rebuild(mlh_ctx *ctx, int kind);
+/* exact k-NN against the resident map (pcl::KdTreeFLANN::nearestKSearch role; feature_extract.hpp:666, 813):
+ * queries are xyz triples (HOST), outputs idx[nq*k] (original map indices, ascending distance, ties by index) and
+ * sqdist[nq*k]; slots beyond the number of points found inside the 27-cell neighbourhood are -1 / +inf. k = 5. */
+int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int32_t *idx, float *sqdist);
+
+/* ---------------------------------------------------------------- scan features (the cloud_data / laser_cloud argument)
+ * stages a feature cloud (PointIWithCov role). cov_offset_bytes: byte offset of cov_vec[6] (cxx cxy cxz cyy cyz czz, f32)
+ * inside a record, or -1 when the records carry no covariance (then trace = 0 -> weight 1, lidar_map_factor.hpp:41).
+ * intensity_offset_bytes: byte offset of the f32 intensity (= LiDAR index, visualization.cpp:48), or -1.
+ */
+int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes,
+                     int cov_offset_bytes, int mem);
+
+/* ---------------------------------------------------------------- (a4, a6-a11, a15) match + linearise + reduce
+ * replaces, for every staged feature of `kind`, at pose `pose`:
+ *   pointAssociateToMap                         estimator/src/utility/utility.h:103-117
+ *   FeatureExtract::match{Surf,Corner}PointFromMap / match{Surf,Corner}FromMap   feature_extract.hpp:379-883
+ *   LidarMapPlaneNormFactor / LidarMapEdgeFactor ctor + Evaluate                  lidar_map_factor.hpp:28-71, 132-174
+ *   ActiveFeatureSelection::evaluateFeatJacobianMatching                           lidar_mapper.h:130-174
+ *   the J^T J / J^T r accumulation of evalHessian / Ceres' evaluator              lidar_mapper_keyframe.cpp:575-581, 1160-1169
+ * Dense outputs (HOST, nullable), in feature order:
+ *   valid[m]  1 when the feature found a correspondence (the bool return of match*PointFromMap)
+ *   coeffs[m*6]  PointPlaneFeature::coeffs_ : surf = (n_hat, d, 0, 0); corner = (X1, X2)
+ *   r[m], J[m*6] the factor's residual and first 6 Jacobian columns (weighted by sqrt_info, NOT loss-corrected)
+ * Reduced outputs (HOST, nullable): JtJ[36] row-major, Jtr[6], cost (sum 0.5*rho), n_valid -- rows are Huber-corrected
+ * as Ceres' ResidualBlock::Evaluate does (huber_delta <= 0 or MLH_FLAG_NO_LOSS: trivial loss).
+ */
+int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neigh, uint32_t flags,
+                        float min_match_sq_dis, float min_plane_dis, double huber_delta, double cov_measurement_trace,
+                        uint8_t *valid, double *coeffs, double *r, double *J,
+                        double *JtJ, double *Jtr, double *cost, int32_t *n_valid);
+
+/* Re-linearise the correspondences found by the last mlh_match_linearize of `kind` at a new pose
+ * (what ceres::Solve does on every LM iteration: CostFunction::Evaluate on fixed factors). Same outputs. */
+int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, double huber_delta, double cov_measurement_trace,
+                  double *r, double *J, double *JtJ, double *Jtr, double *cost, int32_t *n_valid);
+
+/* ---------------------------------------------------------------- (a16, a17) device-resident solvers
+ * Common options. */
+typedef struct mlh_solver_opts {
+    float min_match_sq_dis;          /* MIN_MATCH_SQ_DIS, parameters.cpp:232 */
+    float min_plane_dis;             /* MIN_PLANE_DIS,    parameters.cpp:233 */
+    double huber_delta;              /* ceres::HuberLoss(0.1), lidar_mapper_keyframe.cpp:443 */
+    double map_eig_thre;             /* MAP_EIG_THRE, evalDegenracy, lidar_mapper_keyframe.cpp:1178-1189 */
+    double cov_measurement_trace;    /* trace(COV_MEASUREMENT) used when with_ua is off (cpp:543-544) */
+    uint32_t flags;                  /* MLH_FLAG_WITH_UA | MLH_FLAG_CHECK_FOV */
+    int max_outer;                   /* max_iter = 2, cpp:439 */
+    int max_lm_iterations;           /* options.max_num_iterations = 30, cpp:590 */
+} mlh_solver_opts;
+void mlh_solver_opts_default(mlh_solver_opts *o);
+
+/* per-iteration record written by the solvers (HOST array provided by the caller) */
+typedef struct mlh_iter_stat {
+    int32_t n_surf, n_corner;        /* matched features of each kind */
+    int32_t is_degenerate;
+    int32_t lm_iterations;           /* scan2map only */
+    int32_t successful_steps;        /* scan2map only */
+    int32_t termination;             /* scan2map only: 0 max-iters 1 gradient 2 parameter 3 function 4 failure */
+    double cost;                     /* cost at the linearisation point (GN) / initial cost (scan2map) */
+    double final_cost;               /* scan2map only */
+    double eigval[6];
+    double H[36];                    /* J^T J at the start of the iteration (evalHessian) */
+    double g[6];
+    double pose_after[7];
+} mlh_iter_stat;
+
+/* n_iters Gauss-Newton iterations, entirely on the device (no host round trip inside): per iteration re-match both
+ * kinds at the current pose, linearise with Huber correction, reduce J^T J / J^T r, evalDegenracy
+ * (lidar_mapper_keyframe.cpp:1172-1204), solve H d = -g, pose <- PoseLocalParameterization::Plus(pose, V_update d)
+ * (pose_local_parameterization.cpp:26-45). This is BASELINE.json's "GN iteration". stats may be NULL. */
+int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
+
+/* scan2MapOptimization(): max_outer x { match all features (wo_gf), evalHessian + evalDegenracy, Levenberg-Marquardt
+ * (Ceres trust-region semantics, <= max_lm_iterations) on fixed correspondences }, device-resident.
+ * replaces lidar_mapper_keyframe.cpp:423-639 for gf_method "wo_gf". stats: max_outer records. */
+int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
+
+/* host-side helpers mirroring the reference's small functions (no GPU work) */
+/* PoseLocalParameterization::Plus with V_update_ (row-major 6x6; NULL = identity) */
+int mlh_pose_plus(const double x[7], const double delta[6], const double *V_update, double x_plus_delta[7]);
+/* evalDegenracy: eigenvalues ascending, V_update = (V_f^T)^-1 V_p^T, returns 1 when degenerate */
+int mlh_eval_degeneracy(const double H[36], double eig_thre, double eigval[6], double V_update[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLOAM_HIP_H */

@@ -1,0 +1,289 @@
+"""m-loam_amd -- MI355X-native (gfx950) scan-to-map hot path of M-LOAM.
+
+The product is ``lib/libmloam_hip.so`` (hand-written HIP kernels behind the C-ABI of ``include/mloam_hip.h``) plus the
+C++ facade under ``host/`` that mirrors the reference's ``FeatureExtract`` / factor / ``PoseLocalParameterization``
+interfaces. This module is the thin ctypes harness the tests and ``bench.py`` use to call through that C-ABI; it
+contains no compute and no CPU fallback: if the HIP library is missing or no GPU is visible it raises.
+
+Import with ``importlib.import_module("m-loam_amd")`` (the directory name carries a hyphen).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmloam_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mloam_hip.h")
+
+SURF, CORNER = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
+K_MATCH, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = 0, 1, 2, 3, 4
+
+
+class MlhError(RuntimeError):
+    pass
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("min_match_sq_dis", C.c_float), ("min_plane_dis", C.c_float), ("huber_delta", C.c_double),
+                ("map_eig_thre", C.c_double), ("cov_measurement_trace", C.c_double), ("flags", C.c_uint32),
+                ("max_outer", C.c_int), ("max_lm_iterations", C.c_int)]
+
+
+class IterStat(C.Structure):
+    _fields_ = [("n_surf", C.c_int32), ("n_corner", C.c_int32), ("is_degenerate", C.c_int32), ("lm_iterations", C.c_int32),
+                ("successful_steps", C.c_int32), ("termination", C.c_int32), ("cost", C.c_double), ("final_cost", C.c_double),
+                ("eigval", C.c_double * 6), ("H", C.c_double * 36), ("g", C.c_double * 6), ("pose_after", C.c_double * 7)]
+
+    def as_dict(self):
+        return dict(n_surf=self.n_surf, n_corner=self.n_corner, is_degenerate=bool(self.is_degenerate),
+                    lm_iterations=self.lm_iterations, successful_steps=self.successful_steps, termination=self.termination,
+                    cost=self.cost, final_cost=self.final_cost, eigval=np.array(self.eigval), H=np.array(self.H).reshape(6, 6),
+                    g=np.array(self.g), pose_after=np.array(self.pose_after))
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmloam_hip.so; raises MlhError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MlhError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cf, cd = C.c_void_p, C.c_int, C.c_float, C.c_double
+    lib.mlh_create.argtypes = [C.POINTER(vp), ci]
+    lib.mlh_destroy.argtypes = [vp]
+    lib.mlh_destroy.restype = None
+    lib.mlh_last_error.argtypes = [vp]
+    lib.mlh_last_error.restype = C.c_char_p
+    lib.mlh_version.restype = C.c_char_p
+    lib.mlh_stream.argtypes = [vp]
+    lib.mlh_stream.restype = vp
+    lib.mlh_synchronize.argtypes = [vp]
+    lib.mlh_profile_enable.argtypes = [vp, ci]
+    lib.mlh_profile_reset.argtypes = [vp]
+    lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
+    lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, vp, vp, ci, ci]
+    lib.mlh_extract_run.argtypes = [vp]
+    lib.mlh_extract_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
+    lib.mlh_map_rebuild.argtypes = [vp, ci]
+    lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
+    lib.mlh_features_set.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci]
+    lib.mlh_match_linearize.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, cd, cd, vp, vp, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
+    lib.mlh_linearize.argtypes = [vp, ci, vp, C.c_uint32, cd, cd, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
+    lib.mlh_solver_opts_default.argtypes = [C.POINTER(SolverOpts)]
+    lib.mlh_solver_opts_default.restype = None
+    lib.mlh_gn_solve.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), vp]
+    lib.mlh_scan2map.argtypes = [vp, vp, C.POINTER(SolverOpts), vp]
+    lib.mlh_pose_plus.argtypes = [vp, vp, vp, vp]
+    lib.mlh_eval_degeneracy.argtypes = [vp, cd, vp, vp]
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
+    "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
+    "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch",
+    "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set",
+    "mlh_match_linearize", "mlh_linearize", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
+    "mlh_pose_plus", "mlh_eval_degeneracy",
+]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _src(points):
+    """(pointer, stride_bytes, n, mem, keepalive) for a numpy array (host) or a torch CUDA tensor (device)."""
+    if isinstance(points, np.ndarray):
+        a = np.ascontiguousarray(points, np.float32)
+        return a.ctypes.data_as(C.c_void_p), a.shape[1] * 4, a.shape[0], MEM_HOST, a
+    # torch tensor on the GPU
+    t = points.contiguous()
+    assert t.is_cuda and t.dtype.itemsize == 4
+    return C.c_void_p(t.data_ptr()), t.shape[1] * 4, t.shape[0], MEM_DEVICE, t
+
+
+def default_opts(**kw) -> SolverOpts:
+    o = SolverOpts()
+    load_library().mlh_solver_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    """One mlh_ctx (one HIP stream, device-resident buffers)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.mlh_create(C.byref(h), device)
+        if rc != 0:
+            raise MlhError(f"mlh_create failed ({rc}): no usable HIP device {device}")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mlh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MlhError(f"mlh error {rc}: {self.lib.mlh_last_error(self.h).decode()}")
+
+    def stream(self):
+        return self.lib.mlh_stream(self.h)
+
+    def synchronize(self):
+        self._ck(self.lib.mlh_synchronize(self.h))
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self._ck(self.lib.mlh_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.lib.mlh_profile_reset(self.h))
+
+    def profile_get(self, kernel_id):
+        ms, n = C.c_double(0), C.c_longlong(0)
+        self._ck(self.lib.mlh_profile_get(self.h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- extraction
+    def scan_upload(self, points, scan_start, scan_end):
+        ptr, stride, n, mem, keep = _src(points)
+        if mem == MEM_HOST:
+            ss = np.ascontiguousarray(scan_start, np.int32)
+            se = np.ascontiguousarray(scan_end, np.int32)
+            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, n, _p(ss), _p(se), len(ss), mem))
+        else:
+            ss, se = scan_start.contiguous(), scan_end.contiguous()
+            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
+        self._scan_n = n
+
+    def extract_run(self):
+        self._ck(self.lib.mlh_extract_run(self.h))
+
+    def extract_fetch(self):
+        n = self._scan_n
+        label = np.zeros(n, np.int32)
+        curv = np.zeros(n, np.float32)
+        picked = np.zeros(n, np.int32)
+        lists = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[l.ctypes.data_as(C.c_void_p) for l in lists])
+        cnt = (C.c_int32 * 4)()
+        self._ck(self.lib.mlh_extract_fetch(self.h, _p(label), _p(curv), _p(picked), ptrs, cnt))
+        names = ["sharp", "less_sharp", "flat", "less_flat_raw"]
+        out = dict(label=label, curvature=curv, picked=picked)
+        for i, nm in enumerate(names):
+            out[nm] = lists[i][:cnt[i]].copy()
+        return out
+
+    def extract(self, points, scan_start, scan_end):
+        self.scan_upload(points, scan_start, scan_end)
+        self.extract_run()
+        return self.extract_fetch()
+
+    # ---- map / features
+    def map_set(self, kind, points, min_match_sq_dis=1.0):
+        ptr, stride, n, mem, keep = _src(points)
+        self._ck(self.lib.mlh_map_set(self.h, kind, ptr, stride, n, min_match_sq_dis, mem))
+
+    def map_rebuild(self, kind):
+        self._ck(self.lib.mlh_map_rebuild(self.h, kind))
+
+    def knn(self, kind, queries, k=5):
+        q = np.ascontiguousarray(queries[:, :3], np.float32)
+        idx = np.zeros((q.shape[0], k), np.int32)
+        d2 = np.zeros((q.shape[0], k), np.float32)
+        self._ck(self.lib.mlh_knn(self.h, kind, _p(q), q.shape[0], k, _p(idx), _p(d2)))
+        return idx, d2
+
+    def features_set(self, kind, points):
+        """points: (m, 4) [x y z intensity] or (m, 11) [x y z intensity cov6 trace] (compact PointXYZIWithCov)."""
+        ptr, stride, n, mem, keep = _src(points)
+        ncol = stride // 4
+        self._ck(self.lib.mlh_features_set(self.h, kind, ptr, stride, n, 12 if ncol >= 4 else -1, 16 if ncol >= 10 else -1, mem))
+        self._m = getattr(self, "_m", {})
+        self._m[kind] = n
+
+    # ---- host-driven evaluation
+    def match_linearize(self, kind, pose, flags=0, min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1,
+                        cov_measurement_trace=0.0075, dense=True):
+        m = self._m[kind]
+        pose = np.ascontiguousarray(pose, np.float64)
+        valid = np.zeros(m, np.uint8)
+        coeffs = np.zeros((m, 6), np.float64)
+        r = np.zeros(m) if dense else None
+        J = np.zeros((m, 6)) if dense else None
+        H = np.zeros((6, 6))
+        g = np.zeros(6)
+        cost, cnt = C.c_double(0), C.c_int32(0)
+        self._ck(self.lib.mlh_match_linearize(self.h, kind, _p(pose), 5, flags, min_match_sq_dis, min_plane_dis, huber_delta,
+                                              cov_measurement_trace, _p(valid), _p(coeffs), _p(r), _p(J), _p(H), _p(g),
+                                              C.byref(cost), C.byref(cnt)))
+        return dict(valid=valid, coeffs=coeffs, r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)
+
+    def linearize(self, kind, pose, flags=0, huber_delta=0.1, cov_measurement_trace=0.0075, dense=True):
+        m = self._m[kind]
+        pose = np.ascontiguousarray(pose, np.float64)
+        r = np.zeros(m) if dense else None
+        J = np.zeros((m, 6)) if dense else None
+        H = np.zeros((6, 6))
+        g = np.zeros(6)
+        cost, cnt = C.c_double(0), C.c_int32(0)
+        self._ck(self.lib.mlh_linearize(self.h, kind, _p(pose), flags, huber_delta, cov_measurement_trace, _p(r), _p(J), _p(H), _p(g),
+                                        C.byref(cost), C.byref(cnt)))
+        return dict(r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)
+
+    # ---- device-resident solvers
+    def gn_solve(self, pose, n_iters, opts: SolverOpts | None = None, want_stats=True):
+        opts = opts or default_opts()
+        pose = np.ascontiguousarray(pose, np.float64).copy()
+        stats = (IterStat * n_iters)() if want_stats else None
+        self._ck(self.lib.mlh_gn_solve(self.h, _p(pose), n_iters, C.byref(opts), C.cast(stats, C.c_void_p) if want_stats else None))
+        return pose, ([s.as_dict() for s in stats] if want_stats else None)
+
+    def scan2map(self, pose, opts: SolverOpts | None = None):
+        opts = opts or default_opts()
+        pose = np.ascontiguousarray(pose, np.float64).copy()
+        stats = (IterStat * opts.max_outer)()
+        self._ck(self.lib.mlh_scan2map(self.h, _p(pose), C.byref(opts), C.cast(stats, C.c_void_p)))
+        return pose, [s.as_dict() for s in stats]
+
+
+def pose_plus(x, delta, V_update=None):
+    x = np.ascontiguousarray(x, np.float64)
+    d = np.ascontiguousarray(delta, np.float64)
+    V = None if V_update is None else np.ascontiguousarray(V_update, np.float64)
+    out = np.zeros(7)
+    rc = load_library().mlh_pose_plus(_p(x), _p(d), _p(V), _p(out))
+    if rc:
+        raise MlhError(f"mlh_pose_plus failed ({rc})")
+    return out
+
+
+def eval_degeneracy(H, eig_thre=100.0):
+    H = np.ascontiguousarray(H, np.float64)
+    ev = np.zeros(6)
+    V = np.zeros((6, 6))
+    deg = load_library().mlh_eval_degeneracy(_p(H), eig_thre, _p(ev), _p(V))
+    return dict(eigval=ev, V_update=V, is_degenerate=bool(deg))

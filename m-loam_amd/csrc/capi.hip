@@ -1,0 +1,551 @@
+// extern "C" surface of libmloam_hip.so (see include/mloam_hip.h for the contract and the reference interfaces each
+// entry point replaces). Host logic only: staging, launch sequencing, result unpacking.
+#include "ctx.hpp"
+#include "dev_math.hpp"
+#include <cmath>
+#include <new>
+
+namespace mlh {
+
+int fail(mlh_ctx *ctx, int code, const char *what, hipError_t e)
+{
+    if (ctx) {
+        ctx->err = what ? what : "";
+        if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+static hipEvent_t prof_event(mlh_ctx *ctx)
+{
+    Profile &p = ctx->prof;
+    if (!p.pool.empty()) { hipEvent_t e = p.pool.back(); p.pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(mlh_ctx *ctx, int id)
+{
+    if (!ctx->prof.on) return;
+    Profile::Pending pd;
+    pd.id = id; pd.a = prof_event(ctx); pd.b = nullptr;
+    (void)hipEventRecord(pd.a, ctx->stream);
+    ctx->prof.pending.push_back(pd);
+}
+
+void prof_end(mlh_ctx *ctx, int id)
+{
+    if (!ctx->prof.on || ctx->prof.pending.empty()) return;
+    Profile::Pending &pd = ctx->prof.pending.back();
+    if (pd.id != id || pd.b) return;
+    pd.b = prof_event(ctx);
+    (void)hipEventRecord(pd.b, ctx->stream);
+}
+
+void prof_collect(mlh_ctx *ctx)
+{
+    Profile &p = ctx->prof;
+    for (auto &pd : p.pending) {
+        if (pd.a && pd.b) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pd.b) == hipSuccess && hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
+                p.total_ms[pd.id] += ms;
+                p.launches[pd.id] += 1;
+            }
+        }
+        if (pd.a) p.pool.push_back(pd.a);
+        if (pd.b) p.pool.push_back(pd.b);
+    }
+    p.pending.clear();
+}
+
+// AoS records (stride bytes) -> float4 {x,y,z,w}; w = f32 at w_off, or the record index (as int bits) when w_off == -2, or 0
+__global__ __launch_bounds__(256) void pack_points_kernel(const unsigned char *__restrict__ src, int stride, int n, int w_off,
+                                                          int cov_off, float4 *__restrict__ out, float4 *__restrict__ covd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *rec = reinterpret_cast<const float *>(src + size_t(i) * stride);
+    float4 p;
+    p.x = rec[0]; p.y = rec[1]; p.z = rec[2];
+    if (w_off == -2) p.w = __int_as_float(i);
+    else if (w_off >= 0) p.w = *reinterpret_cast<const float *>(src + size_t(i) * stride + w_off);
+    else p.w = 0.f;
+    out[i] = p;
+    if (covd) {
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cov_off >= 0) {
+            const float *cv = reinterpret_cast<const float *>(src + size_t(i) * stride + cov_off);
+            c.x = cv[0]; c.y = cv[3]; c.z = cv[5];
+        }
+        covd[i] = c;
+    }
+}
+
+static int stage_points(mlh_ctx *ctx, const void *points, int stride, int n, int mem, int w_off, int cov_off, DevBuf &dst, DevBuf *covd,
+                        DevBuf &tmp)
+{
+    if (!points || n <= 0 || stride < 12 || (stride & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer (null, n <= 0, or stride not a multiple of 4 >= 12)");
+    MLH_HIP(ctx, dst.ensure(sizeof(float4) * size_t(n)));
+    if (covd) MLH_HIP(ctx, covd->ensure(sizeof(float4) * size_t(n)));
+    const unsigned char *src = static_cast<const unsigned char *>(points);
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, tmp.ensure(size_t(n) * stride));
+        MLH_HIP(ctx, hipMemcpyAsync(tmp.p, points, size_t(n) * stride, hipMemcpyHostToDevice, ctx->stream));
+        src = tmp.as<unsigned char>();
+    }
+    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride, n, w_off, cov_off,
+                       dst.as<float4>(), covd ? covd->as<float4>() : nullptr);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+static int ensure_state(mlh_ctx *ctx, int n_stats)
+{
+    if (!ctx->state.p) {
+        MLH_HIP(ctx, ctx->state.ensure(sizeof(SolverState)));
+        MLH_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(SolverState), ctx->stream));
+    }
+    if (n_stats > 0) MLH_HIP(ctx, ctx->stats.ensure(sizeof(IterStatDev) * size_t(n_stats)));
+    return MLH_OK;
+}
+
+static int upload_pose(mlh_ctx *ctx, const double pose[7])
+{
+    // identity V_update, pose into x and cand
+    SolverState h;
+    std::memset(&h, 0, sizeof(h));
+    for (int i = 0; i < 7; ++i) { h.x[i] = pose[i]; h.cand[i] = pose[i]; }
+    for (int i = 0; i < 6; ++i) h.V[i * 6 + i] = 1.0;
+    MLH_HIP(ctx, hipMemcpyAsync(ctx->state.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack object
+    return MLH_OK;
+}
+
+static void copy_stat(const IterStatDev &d, mlh_iter_stat &o)
+{
+    o.n_surf = d.n_surf; o.n_corner = d.n_corner; o.is_degenerate = d.is_degenerate; o.lm_iterations = d.lm_iterations;
+    o.successful_steps = d.successful_steps; o.termination = d.termination; o.cost = d.cost; o.final_cost = d.final_cost;
+    std::memcpy(o.eigval, d.eigval, sizeof(o.eigval));
+    std::memcpy(o.H, d.H, sizeof(o.H));
+    std::memcpy(o.g, d.g, sizeof(o.g));
+    std::memcpy(o.pose_after, d.pose_after, sizeof(o.pose_after));
+}
+
+}  // namespace mlh
+
+using namespace mlh;
+
+extern "C" {
+
+const char *mlh_version(void) { return "mloam_hip 0.1 (gfx950)"; }
+
+int mlh_create(mlh_ctx **out, int device_id)
+{
+    if (!out) return MLH_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MLH_ERR_HIP;
+    if (device_id < 0 || device_id >= count) return MLH_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return MLH_ERR_HIP;
+    mlh_ctx *c = new (std::nothrow) mlh_ctx;
+    if (!c) return MLH_ERR_NOMEM;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
+    *out = c;
+    return MLH_OK;
+}
+
+void mlh_destroy(mlh_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_collect(ctx);
+    for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+        MapGrid &m = ctx->map[k];
+        m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release();
+        FeatSet &f = ctx->feat[k];
+        f.pts.release(); f.covd.release(); f.corr.release(); f.r.release(); f.J.release(); f.partials.release();
+    }
+    ScanBuf &s = ctx->scan;
+    s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
+    s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
+    for (int i = 0; i < 4; ++i) s.lists[i].release();
+    ctx->state.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mlh_last_error(const mlh_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void *mlh_stream(mlh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int mlh_synchronize(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return MLH_OK;
+}
+
+int mlh_profile_enable(mlh_ctx *ctx, int on)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    ctx->prof.on = on != 0;
+    return MLH_OK;
+}
+
+int mlh_profile_reset(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int i = 0; i < MLH_K_COUNT; ++i) { ctx->prof.total_ms[i] = 0; ctx->prof.launches[i] = 0; }
+    return MLH_OK;
+}
+
+int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *launches)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= MLH_K_COUNT) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (total_ms) *total_ms = ctx->prof.total_ms[kernel_id];
+    if (launches) *launches = ctx->prof.launches[kernel_id];
+    return MLH_OK;
+}
+
+// ---------------------------------------------------------------- extraction
+int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, const int *scan_start, const int *scan_end,
+                    int n_rings, int mem)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    if (!scan_start || !scan_end || n_rings <= 0) return fail(ctx, MLH_ERR_INVALID, "bad ring table");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    ScanBuf &sb = ctx->scan;
+    sb.extracted = false;
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, -1, -1, sb.pts, nullptr, ctx->tmp);
+    if (rc) return rc;
+    std::vector<int> hs(n_rings), he(n_rings);
+    if (mem == MLH_MEM_HOST) {
+        std::memcpy(hs.data(), scan_start, sizeof(int) * n_rings);
+        std::memcpy(he.data(), scan_end, sizeof(int) * n_rings);
+    } else {
+        MLH_HIP(ctx, hipMemcpyAsync(hs.data(), scan_start, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(he.data(), scan_end, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // rings are labelled by independent workgroups: that is exact only when the neighbour-suppression reach (+-5) of one
+    // ring cannot touch another ring's labelled span, which the ImageSegmenter insets (+5 / -6) guarantee.
+    int max_len = 0, prev_end = -1000000;
+    for (int r = 0; r < n_rings; ++r) {
+        if (he[r] - hs[r] < 6) continue;   // skipped by the extractor (cpp:155)
+        if (hs[r] < 5 || he[r] + 5 > n) return fail(ctx, MLH_ERR_INVALID, "scan_start/scan_end must be inset by 5 from the cloud ends");
+        if (hs[r] <= prev_end + 4) return fail(ctx, MLH_ERR_UNSUPPORTED, "rings must be ascending and separated by the +5/-6 insets of ScanInfo");
+        prev_end = he[r];
+        max_len = std::max(max_len, he[r] - hs[r]);
+    }
+    MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(n_rings)));
+    MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(n_rings)));
+    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hs.data(), sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, he.data(), sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sb.n = n; sb.n_rings = n_rings; sb.max_ring_len = max_len;
+    return MLH_OK;
+}
+
+int mlh_extract_run(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return extract_run(ctx);
+}
+
+int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4])
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    ScanBuf &sb = ctx->scan;
+    if (!sb.extracted) return fail(ctx, MLH_ERR_STATE, "extract_run has not been called");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int totals[4] = {0, 0, 0, 0};
+    MLH_HIP(ctx, hipMemcpyAsync(totals, sb.totals.p, sizeof(totals), hipMemcpyDeviceToHost, st));
+    if (label) MLH_HIP(ctx, hipMemcpyAsync(label, sb.label.p, sizeof(int) * size_t(sb.n), hipMemcpyDeviceToHost, st));
+    if (curvature) MLH_HIP(ctx, hipMemcpyAsync(curvature, sb.curvature.p, sizeof(float) * size_t(sb.n), hipMemcpyDeviceToHost, st));
+    if (picked) MLH_HIP(ctx, hipMemcpyAsync(picked, sb.picked.p, sizeof(int) * size_t(sb.n), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) {
+        if (n_out) n_out[i] = totals[i];
+        if (idx_out && idx_out[i] && totals[i] > 0)
+            MLH_HIP(ctx, hipMemcpyAsync(idx_out[i], sb.lists[i].p, sizeof(int) * size_t(totals[i]), hipMemcpyDeviceToHost, st));
+    }
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    prof_collect(ctx);
+    return MLH_OK;
+}
+
+// ---------------------------------------------------------------- map
+int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, float min_match_sq_dis, int mem)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    if (!(min_match_sq_dis > 0.f)) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis must be positive");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MapGrid &g = ctx->map[kind];
+    g.built = false;
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, -2, -1, g.raw, nullptr, ctx->tmp);
+    if (rc) return rc;
+    g.n = n;
+    g.min_match_sq_dis = min_match_sq_dis;
+    rc = grid_build(ctx, g, min_match_sq_dis, true);
+    if (rc) return rc;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->feat[kind].matched = false;
+    return MLH_OK;
+}
+
+int mlh_map_rebuild(mlh_ctx *ctx, int kind)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    MapGrid &g = ctx->map[kind];
+    if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return grid_build(ctx, g, g.min_match_sq_dis, false);
+}
+
+int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int32_t *idx, float *sqdist)
+{
+    if (!ctx || kind < 0 || kind > 1 || !queries_xyz || !idx || !sqdist) return MLH_ERR_INVALID;
+    if (k != 5) return fail(ctx, MLH_ERR_UNSUPPORTED, "only k = 5 is implemented");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return knn_launch(ctx, kind, queries_xyz, nq, idx, sqdist);
+}
+
+// ---------------------------------------------------------------- features
+int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes,
+                     int cov_offset_bytes, int mem)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    FeatSet &f = ctx->feat[kind];
+    f.matched = false;
+    f.m = 0;
+    if (cov_offset_bytes >= 0 && cov_offset_bytes + 24 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "cov_offset_bytes + 24 exceeds the record stride");
+    if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset exceeds the record stride");
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, cov_offset_bytes,
+                          f.pts, &f.covd, ctx->tmp);
+    if (rc) return rc;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f.m = n;
+    f.has_cov = cov_offset_bytes >= 0;
+    return MLH_OK;
+}
+
+// ---------------------------------------------------------------- host-driven match / linearise
+static int fetch_dense_and_reduced(mlh_ctx *ctx, int kind, bool want_corr, uint8_t *valid, double *coeffs, double *r, double *J,
+                                   double *JtJ, double *Jtr, double *cost, int32_t *n_valid)
+{
+    FeatSet &f = ctx->feat[kind];
+    hipStream_t st = ctx->stream;
+    std::vector<Corr> hc;
+    if (want_corr && (valid || coeffs)) {
+        hc.resize(f.m);
+        MLH_HIP(ctx, hipMemcpyAsync(hc.data(), f.corr.p, sizeof(Corr) * size_t(f.m), hipMemcpyDeviceToHost, st));
+    }
+    if (r) MLH_HIP(ctx, hipMemcpyAsync(r, f.r.p, sizeof(double) * size_t(f.m), hipMemcpyDeviceToHost, st));
+    if (J) MLH_HIP(ctx, hipMemcpyAsync(J, f.J.p, sizeof(double) * 6 * size_t(f.m), hipMemcpyDeviceToHost, st));
+    SolverState hs;
+    MLH_HIP(ctx, hipMemcpyAsync(&hs, ctx->state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    prof_collect(ctx);
+    if (!hc.empty()) {
+        for (int i = 0; i < f.m; ++i) {
+            if (valid) valid[i] = hc[i].valid ? 1 : 0;
+            if (coeffs) for (int k = 0; k < 6; ++k) coeffs[size_t(i) * 6 + k] = double(hc[i].c[k]);
+        }
+    }
+    if (JtJ) {
+        int q = 0;
+        for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { JtJ[i * 6 + j] = hs.ne[q]; JtJ[j * 6 + i] = hs.ne[q]; ++q; }
+    }
+    if (Jtr) for (int i = 0; i < 6; ++i) Jtr[i] = hs.ne[NE_G + i];
+    if (cost) *cost = hs.ne[NE_COST];
+    if (n_valid) *n_valid = int(hs.ne[NE_CNT] + 0.5);
+    return MLH_OK;
+}
+
+int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neigh, uint32_t flags,
+                        float min_match_sq_dis, float min_plane_dis, double huber_delta, double cov_measurement_trace,
+                        uint8_t *valid, double *coeffs, double *r, double *J,
+                        double *JtJ, double *Jtr, double *cost, int32_t *n_valid)
+{
+    if (!ctx || kind < 0 || kind > 1 || !pose) return MLH_ERR_INVALID;
+    if (k_neigh != 5) return fail(ctx, MLH_ERR_UNSUPPORTED, "only N_NEIGH = 5 is implemented");
+    if ((r == nullptr) != (J == nullptr)) return fail(ctx, MLH_ERR_INVALID, "r and J must be requested together");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, pose))) return rc;
+    MatchArgs a;
+    a.kind = kind; a.flags = flags; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
+    a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
+    if ((rc = match_launch(ctx, a))) return rc;
+    if ((rc = reduce_only_launch(ctx, 1 << kind))) return rc;
+    return fetch_dense_and_reduced(ctx, kind, true, valid, coeffs, r, J, JtJ, Jtr, cost, n_valid);
+}
+
+int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, double huber_delta, double cov_measurement_trace,
+                  double *r, double *J, double *JtJ, double *Jtr, double *cost, int32_t *n_valid)
+{
+    if (!ctx || kind < 0 || kind > 1 || !pose) return MLH_ERR_INVALID;
+    if ((r == nullptr) != (J == nullptr)) return fail(ctx, MLH_ERR_INVALID, "r and J must be requested together");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, pose))) return rc;
+    MatchArgs a;
+    a.kind = kind; a.flags = flags; a.min_match_sq_dis = 0.f; a.min_plane_dis = 0.f;
+    a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
+    if ((rc = linearize_launch(ctx, a))) return rc;
+    if ((rc = reduce_only_launch(ctx, 1 << kind))) return rc;
+    return fetch_dense_and_reduced(ctx, kind, false, nullptr, nullptr, r, J, JtJ, Jtr, cost, n_valid);
+}
+
+// ---------------------------------------------------------------- device-resident solvers
+void mlh_solver_opts_default(mlh_solver_opts *o)
+{
+    if (!o) return;
+    o->min_match_sq_dis = 1.0f;
+    o->min_plane_dis = 0.2f;
+    o->huber_delta = 0.1;
+    o->map_eig_thre = 100.0;
+    o->cov_measurement_trace = 0.0075;
+    o->flags = 0;
+    o->max_outer = 2;
+    o->max_lm_iterations = 30;
+}
+
+static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind, int pose_sel)
+{
+    MatchArgs a;
+    a.kind = kind; a.flags = o->flags & (MLH_FLAG_CHECK_FOV | MLH_FLAG_WITH_UA);
+    a.min_match_sq_dis = o->min_match_sq_dis; a.min_plane_dis = o->min_plane_dis;
+    a.huber_delta = o->huber_delta; a.cov_measurement_trace = o->cov_measurement_trace; a.dense = false; a.pose_sel = pose_sel;
+    return a;
+}
+
+static int fetch_pose_and_stats(mlh_ctx *ctx, double pose[7], mlh_iter_stat *stats, int n_stats)
+{
+    SolverState hs;
+    std::vector<IterStatDev> hd(stats ? n_stats : 0);
+    MLH_HIP(ctx, hipMemcpyAsync(&hs, ctx->state.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    if (stats && n_stats > 0)
+        MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * size_t(n_stats), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int i = 0; i < 7; ++i) pose[i] = hs.x[i];
+    for (int i = 0; stats && i < n_stats; ++i) copy_stat(hd[i], stats[i]);
+    return MLH_OK;
+}
+
+int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats)
+{
+    if (!ctx || !pose_inout || !opts || n_iters <= 0) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, n_iters);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, pose_inout))) return rc;
+    const bool have[2] = {ctx->feat[0].m > 0 && ctx->map[0].built, ctx->feat[1].m > 0 && ctx->map[1].built};
+    if (!have[0] && !have[1]) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    for (int it = 0; it < n_iters; ++it) {
+        for (int k = 0; k < 2; ++k)
+            if (have[k] && (rc = match_launch(ctx, args_from_opts(opts, k, 0)))) return rc;
+        if ((rc = gn_update_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;
+    }
+    return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);
+}
+
+int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
+{
+    if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, opts->max_outer);
+    if (rc) return rc;
+    // scan2MapOptimization runs only when the map has > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429)
+    if (!(ctx->map[MLH_SURF].built && ctx->map[MLH_CORNER].built && ctx->map[MLH_SURF].n > 50 && ctx->map[MLH_CORNER].n > 10)) {
+        if (stats) std::memset(stats, 0, sizeof(mlh_iter_stat) * size_t(opts->max_outer));
+        return MLH_OK;
+    }
+    if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
+    if ((rc = upload_pose(ctx, pose_inout))) return rc;
+    const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
+    for (int outer = 0; outer < opts->max_outer; ++outer) {
+        for (int k = 0; k < 2; ++k)
+            if ((rc = match_launch(ctx, args_from_opts(opts, k, 0)))) return rc;
+        if ((rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
+        for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
+            for (int j = it; j < std::min(it + chunk, opts->max_lm_iterations); ++j) {
+                for (int k = 0; k < 2; ++k)
+                    if ((rc = linearize_launch(ctx, args_from_opts(opts, k, 1)))) return rc;
+                if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+            }
+            int done = 0;
+            MLH_HIP(ctx, hipMemcpyAsync(&done, &ctx->state.as<SolverState>()->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (done) break;
+        }
+        if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
+    }
+    return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
+}
+
+// ---------------------------------------------------------------- small host helpers
+int mlh_pose_plus(const double x[7], const double delta[6], const double *V_update, double x_plus_delta[7])
+{
+    if (!x || !delta || !x_plus_delta) return MLH_ERR_INVALID;
+    pose_plus(x, delta, V_update, x_plus_delta);
+    return MLH_OK;
+}
+
+int mlh_eval_degeneracy(const double H[36], double eig_thre, double eigval[6], double V_update[36])
+{
+    if (!H || !eigval || !V_update) return MLH_ERR_INVALID;
+    // cyclic Jacobi on the host (same procedure as the device kernel)
+    double a[36], V[36];
+    for (int i = 0; i < 36; ++i) a[i] = H[i];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < 6; ++i) { dg += a[i * 6 + i] * a[i * 6 + i]; for (int j = i + 1; j < 6; ++j) off += a[i * 6 + j] * a[i * 6 + j]; }
+        if (off <= 1e-32 * dg || off == 0.0) break;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double apq = a[p * 6 + q];
+                if (apq == 0.0) continue;
+                double theta = (a[q * 6 + q] - a[p * 6 + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; ++k) { double u = a[k * 6 + p], v = a[k * 6 + q]; a[k * 6 + p] = c * u - s * v; a[k * 6 + q] = s * u + c * v; }
+                for (int k = 0; k < 6; ++k) { double u = a[p * 6 + k], v = a[q * 6 + k]; a[p * 6 + k] = c * u - s * v; a[q * 6 + k] = s * u + c * v; }
+                for (int k = 0; k < 6; ++k) { double u = V[k * 6 + p], v = V[k * 6 + q]; V[k * 6 + p] = c * u - s * v; V[k * 6 + q] = s * u + c * v; }
+            }
+    }
+    int order[6] = {0, 1, 2, 3, 4, 5};
+    for (int i = 0; i < 5; ++i) for (int j = i + 1; j < 6; ++j) if (a[order[j] * 7] < a[order[i] * 7]) std::swap(order[i], order[j]);
+    bool deg = false, stop = false;
+    bool keep[6];
+    for (int j = 0; j < 6; ++j) {
+        eigval[j] = a[order[j] * 7];
+        if (!stop && eigval[j] < eig_thre) { keep[j] = false; deg = true; } else { keep[j] = true; stop = true; }
+    }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+            if (deg) { for (int j = 0; j < 6; ++j) if (keep[j]) s += V[r * 6 + order[j]] * V[c * 6 + order[j]]; }
+            else s = (r == c) ? 1.0 : 0.0;
+            V_update[r * 6 + c] = s;
+        }
+    return deg ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// Internal definitions shared by the translation units of libmloam_hip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/mloam_hip.h"
+
+namespace mlh {
+
+// ---------------------------------------------------------------- device-side records
+// local-map cell grid (dense, x fastest). Cell edge h is a hair above sqrt(min_match_sq_dis) so that every map point
+// within the acceptance radius of a query lies in the query's 27-cell neighbourhood.
+struct GridDev {
+    const float4 *sorted;     // cell-sorted points {x,y,z, original index (int bits)}
+    const float4 *raw;        // the same points in original order
+    const int *cell_start;    // ncell + 1 exclusive prefix of per-cell counts
+    float ox, oy, oz, inv_h;
+    int nx, ny, nz, n;
+};
+
+// what the match kernel keeps per feature for later re-linearisation (LM iterations on fixed correspondences)
+struct __attribute__((aligned(16))) Corr {
+    float c[6];        // surf: n_hat(3), d, 0, 0 ; corner: X1(3), X2(3)   (all exactly f32-valued in the reference)
+    int valid;
+    int pad;           // the f64 weight is recomputed from the feature's covariance diagonal on every evaluation
+};
+
+// packed normal equations: 21 upper-triangular J^T J entries, 6 J^T r, cost, count; padded to 32
+constexpr int NE_H = 0, NE_G = 21, NE_COST = 27, NE_CNT = 28, NE_STRIDE = 32;
+
+// device-resident optimiser state (one per context)
+struct SolverState {
+    double x[7];             // current pose [t, q(xyzw)]
+    double cand[7];          // candidate pose (LM)
+    double V[36];            // PoseLocalParameterization::V_update_
+    double ne[NE_STRIDE];    // normal equations at x
+    double diag[6];          // LM diagonal (Jacobi-scaled)
+    double S[6];             // Jacobi scaling 1/(1+sqrt(H_ii)) from iteration zero
+    double radius, decrease_factor;
+    double model_cost_change;
+    double gmax;
+    int reuse_diagonal;
+    int iteration;
+    int done;
+    int termination;
+    int num_successful;
+    int num_invalid;
+    int evaluations;
+    int pad;
+};
+
+struct IterStatDev {        // mirrors mlh_iter_stat, written by the device-side update kernels
+    int n_surf, n_corner, is_degenerate, lm_iterations, successful_steps, termination;
+    double cost, final_cost;
+    double eigval[6];
+    double H[36];
+    double g[6];
+    double pose_after[7];
+};
+
+// ---------------------------------------------------------------- host-side containers
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct MapGrid {
+    DevBuf raw, sorted, cell_id, cell_start, cell_fill, block_sums, bounds;
+    int n = 0;
+    float ox = 0, oy = 0, oz = 0, h = 1.f, inv_h = 1.f;
+    int nx = 0, ny = 0, nz = 0;
+    long long ncell = 0;
+    float min_match_sq_dis = 1.0f;
+    bool built = false;
+    GridDev dev() const
+    {
+        GridDev g;
+        g.sorted = sorted.as<float4>(); g.raw = raw.as<float4>(); g.cell_start = cell_start.as<int>();
+        g.ox = ox; g.oy = oy; g.oz = oz; g.inv_h = inv_h; g.nx = nx; g.ny = ny; g.nz = nz; g.n = n;
+        return g;
+    }
+};
+
+struct FeatSet {
+    DevBuf pts;        // float4 {x,y,z,intensity}
+    DevBuf covd;       // float4 {cxx, cyy, czz, 0}  (diagonal of the f32 cov_vec)
+    DevBuf corr;       // Corr per feature
+    DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
+    DevBuf partials;   // NE_STRIDE doubles per block
+    int m = 0;
+    bool has_cov = false;
+    bool matched = false;
+    int n_blocks = 0;
+};
+
+struct ScanBuf {
+    DevBuf pts;            // float4 {x,y,z,intensity}
+    DevBuf start, end;     // per ring
+    DevBuf curvature, label, picked;
+    DevBuf stage;          // per-ring staged picks
+    DevBuf ring_counts;    // 4 counts per ring
+    DevBuf ring_offsets;   // 4 exclusive offsets per ring (+ totals)
+    DevBuf lists[4];
+    DevBuf totals;         // 4 ints
+    int n = 0, n_rings = 0;
+    int max_ring_len = 0;  // max over rings of (scan_end - scan_start)
+    bool extracted = false;
+};
+
+struct Profile {
+    bool on = false;
+    double total_ms[MLH_K_COUNT] = {0};
+    long long launches[MLH_K_COUNT] = {0};
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace mlh
+
+struct mlh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    mlh::MapGrid map[2];
+    mlh::FeatSet feat[2];
+    mlh::ScanBuf scan;
+    mlh::DevBuf state;       // SolverState
+    mlh::DevBuf stats;       // IterStatDev[...]
+    mlh::DevBuf knn_q, knn_idx, knn_d;
+    mlh::DevBuf tmp;         // H2D staging of caller records before packing
+    mlh::Profile prof;
+};
+
+namespace mlh {
+
+int fail(mlh_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
+
+#define MLH_HIP(ctx, expr)                                                         \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) return ::mlh::fail((ctx), MLH_ERR_HIP, #expr, _e);   \
+    } while (0)
+
+// profiling brackets (HIP events on the context's stream)
+void prof_begin(mlh_ctx *ctx, int id);
+void prof_end(mlh_ctx *ctx, int id);
+void prof_collect(mlh_ctx *ctx);
+
+// extract.hip
+int extract_run(mlh_ctx *ctx);
+// grid.hip
+int grid_build(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis, bool recompute_bounds);
+// match.hip
+struct MatchArgs {
+    int kind;
+    uint32_t flags;
+    float min_match_sq_dis, min_plane_dis;
+    double huber_delta, cov_measurement_trace;
+    bool dense;          // also write r / J per feature
+    int pose_sel;        // 0: SolverState::x, 1: SolverState::cand
+};
+int match_launch(mlh_ctx *ctx, const MatchArgs &a);
+int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
+int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
+// solver.hip
+int reduce_only_launch(mlh_ctx *ctx, int kind_mask);
+int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
+int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot);
+int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot);
+int lm_finish_launch(mlh_ctx *ctx, int stat_slot);
+
+}  // namespace mlh

@@ -1,0 +1,277 @@
+"""Seeded synthetic scenes, local maps and multi-LiDAR scans for the scan-to-map hot path.
+
+This is input generation only (numpy): the shapes follow SURVEY.md 8(d) -- a ground plane plus
+axis-aligned "buildings", a surf map on a jittered MAP_SURF_RES grid, a corner map along box edges at
+MAP_CORNER_RES, and ring-major ray-cast scans with ``scan_start = ring_begin + 5`` /
+``scan_end = ring_end - 6`` exactly as ImageSegmenter hands them to ``FeatureExtract::extractCloud``
+(reference: estimator/src/imageSegmenter/image_segmenter.hpp:385-387). Extrinsics are the ``body_T_laser``
+rows of estimator/config/config_realvehicle_hercules.yaml:56-59; fused clouds carry ``intensity = lidar index``
+(estimator/src/utility/visualization.cpp:48).
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+# qx qy qz qw px py pz  (config_realvehicle_hercules.yaml, "PS-calib" rows)
+HERCULES_BODY_T_LASER = np.array([
+    [0, 0, 0, 1, 0, 0, 0],
+    [-0.0169, 0.0575, 0.0195, 0.998, 0.5355, 0.0393, -1.131],
+    [-0.1118, 0.1894, 0.6845, 0.6951, 0.5116, 0.6440, -0.904],
+    [0.0745, 0.1312, -0.7449, 0.6496, 0.4406, -0.628, -1.0295],
+], dtype=np.float64)
+
+SENSOR_HEIGHT = 2.2  # m above the ground plane (keeps the lower LiDARs of the rig above z = 0)
+
+
+def quat_to_rot(q):
+    """q = (x, y, z, w) -> 3x3 (same element formulas as Eigen::Quaterniond::toRotationMatrix)."""
+    x, y, z, w = q
+    n = np.sqrt(x * x + y * y + z * z + w * w)
+    x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def rotvec_to_quat(rv):
+    rv = np.asarray(rv, dtype=np.float64)
+    th = np.linalg.norm(rv)
+    if th < 1e-12:
+        return np.array([0.0, 0.0, 0.0, 1.0])
+    ax = rv / th
+    s = np.sin(th / 2)
+    return np.array([ax[0] * s, ax[1] * s, ax[2] * s, np.cos(th / 2)])
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz,
+    ])
+
+
+def pose_to_mat(pose7):
+    """[tx ty tz qx qy qz qw] -> 4x4."""
+    T = np.eye(4)
+    T[:3, :3] = quat_to_rot(pose7[3:7])
+    T[:3, 3] = pose7[:3]
+    return T
+
+
+@dataclasses.dataclass
+class Scene:
+    L: float                 # ground plane is [-L/2, L/2]^2 at z = 0
+    boxes: np.ndarray        # (B, 6): xmin ymin zmin xmax ymax zmax
+    seed: int
+
+
+def make_scene(L: float, n_boxes: int, seed: int = 42, clear_radius: float = 8.0) -> Scene:
+    rng = np.random.default_rng(seed)
+    boxes = []
+    tries = 0
+    while len(boxes) < n_boxes and tries < 200000:
+        tries += 1
+        sx, sy = rng.uniform(5, 30, size=2)
+        h = rng.uniform(3, 20)
+        cx, cy = rng.uniform(-L / 2 + 16, L / 2 - 16, size=2)
+        b = np.array([cx - sx / 2, cy - sy / 2, 0.0, cx + sx / 2, cy + sy / 2, h])
+        # keep the sensor neighbourhood free
+        dx = max(b[0] - 0.0, 0.0 - b[3], 0.0)
+        dy = max(b[1] - 0.0, 0.0 - b[4], 0.0)
+        if np.hypot(dx, dy) < clear_radius:
+            continue
+        ok = True
+        for o in boxes:
+            if not (b[3] + 1.0 < o[0] or o[3] + 1.0 < b[0] or b[4] + 1.0 < o[1] or o[4] + 1.0 < b[1]):
+                ok = False
+                break
+        if ok:
+            boxes.append(b)
+    return Scene(L=L, boxes=np.array(boxes).reshape(-1, 6), seed=seed)
+
+
+def voxel_mean(points: np.ndarray, leaf: float) -> np.ndarray:
+    """One centroid per occupied voxel (all columns averaged), ordered by voxel key. Data preparation only."""
+    if len(points) == 0:
+        return points.copy()
+    ijk = np.floor(points[:, :3].astype(np.float64) / leaf).astype(np.int64)
+    ijk -= ijk.min(axis=0)
+    dims = ijk.max(axis=0) + 1
+    key = ijk[:, 0] + dims[0] * (ijk[:, 1] + dims[1] * ijk[:, 2])
+    uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    out = np.zeros((len(uniq), points.shape[1]), dtype=np.float64)
+    for c in range(points.shape[1]):
+        out[:, c] = np.bincount(inv, weights=points[:, c].astype(np.float64), minlength=len(uniq)) / cnt
+    return out.astype(points.dtype)
+
+
+def sample_maps(scene: Scene, surf_res: float = 0.4, corner_res: float = 0.2, seed: int = 42,
+                noise: float = 0.01):
+    """Returns (surf_map (Ns,3) f32, corner_map (Nc,3) f32) in the map frame, voxel-thinned at the map resolutions."""
+    rng = np.random.default_rng(seed + 1000)
+    L = scene.L
+    surf = []
+    # ground
+    g = np.arange(-L / 2 + surf_res / 2, L / 2, surf_res)
+    gx, gy = np.meshgrid(g, g, indexing="ij")
+    gx = gx.ravel() + rng.uniform(-0.1, 0.1, gx.size)
+    gy = gy.ravel() + rng.uniform(-0.1, 0.1, gy.size)
+    keep = np.ones(gx.size, dtype=bool)
+    for b in scene.boxes:
+        keep &= ~((gx > b[0]) & (gx < b[3]) & (gy > b[1]) & (gy < b[4]))
+    gz = rng.normal(0.0, noise, gx.size)
+    surf.append(np.stack([gx[keep], gy[keep], gz[keep]], axis=1))
+    corner = []
+    for b in scene.boxes:
+        x0, y0, _, x1, y1, h = b
+        # walls
+        for (ax, fixed, lo, hi) in ((0, y0, x0, x1), (0, y1, x0, x1), (1, x0, y0, y1), (1, x1, y0, y1)):
+            u = np.arange(lo + surf_res / 2, hi, surf_res)
+            z = np.arange(surf_res / 2, h, surf_res)
+            uu, zz = np.meshgrid(u, z, indexing="ij")
+            uu = uu.ravel() + rng.uniform(-0.1, 0.1, uu.size)
+            zz = zz.ravel() + rng.uniform(-0.1, 0.1, zz.size)
+            nn = fixed + rng.normal(0.0, noise, uu.size)
+            if ax == 0:
+                surf.append(np.stack([uu, nn, zz], axis=1))
+            else:
+                surf.append(np.stack([nn, uu, zz], axis=1))
+        # roof
+        u = np.arange(x0 + surf_res / 2, x1, surf_res)
+        v = np.arange(y0 + surf_res / 2, y1, surf_res)
+        uu, vv = np.meshgrid(u, v, indexing="ij")
+        uu = uu.ravel() + rng.uniform(-0.1, 0.1, uu.size)
+        vv = vv.ravel() + rng.uniform(-0.1, 0.1, vv.size)
+        surf.append(np.stack([uu, vv, h + rng.normal(0.0, noise, uu.size)], axis=1))
+        # vertical edges
+        for (ex, ey) in ((x0, y0), (x0, y1), (x1, y0), (x1, y1)):
+            z = np.arange(corner_res / 2, h, corner_res)
+            e = np.stack([np.full_like(z, ex), np.full_like(z, ey), z], axis=1)
+            corner.append(e + rng.normal(0.0, noise, e.shape))
+        # roof edges
+        for (p0, p1) in (((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1)), ((x0, y1), (x0, y0))):
+            ln = np.hypot(p1[0] - p0[0], p1[1] - p0[1])
+            s = np.arange(corner_res / 2, ln, corner_res) / ln
+            e = np.stack([p0[0] + s * (p1[0] - p0[0]), p0[1] + s * (p1[1] - p0[1]), np.full_like(s, h)], axis=1)
+            corner.append(e + rng.normal(0.0, noise, e.shape))
+    surf = np.concatenate(surf).astype(np.float32)
+    corner = np.concatenate(corner).astype(np.float32) if corner else np.zeros((0, 3), np.float32)
+    surf = voxel_mean(surf, surf_res)
+    corner = voxel_mean(corner, corner_res)
+    return np.ascontiguousarray(surf), np.ascontiguousarray(corner)
+
+
+def _raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: float) -> np.ndarray:
+    """Nearest hit distance per ray against the ground plane and the boxes (inf when none)."""
+    n = dirs.shape[0]
+    t_hit = np.full(n, np.inf)
+    dz = dirs[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(dz < -1e-9, -origin[2] / dz, np.inf)
+    px = origin[0] + tg * dirs[:, 0]
+    py = origin[1] + tg * dirs[:, 1]
+    okg = np.isfinite(tg) & (np.abs(px) <= scene.L / 2) & (np.abs(py) <= scene.L / 2)
+    t_hit = np.where(okg, tg, t_hit)
+    # only boxes that can be reached
+    B = scene.boxes
+    if len(B):
+        c = 0.5 * (B[:, :2] + B[:, 3:5])
+        r = 0.5 * np.hypot(B[:, 3] - B[:, 0], B[:, 4] - B[:, 1])
+        near = np.hypot(c[:, 0] - origin[0], c[:, 1] - origin[1]) - r < max_range
+        B = B[near]
+    chunk = 32768
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dirs
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        iv = inv[s:e, None, :]                                   # (c,1,3)
+        t0 = (B[None, :, 0:3] - origin[None, None, :]) * iv      # (c,B,3)
+        t1 = (B[None, :, 3:6] - origin[None, None, :]) * iv
+        tmin = np.minimum(t0, t1).max(axis=2)
+        tmax = np.maximum(t0, t1).min(axis=2)
+        hit = (tmax >= np.maximum(tmin, 0.0)) & (tmin > 0.0)
+        tb = np.where(hit, tmin, np.inf).min(axis=1) if B.shape[0] else np.full(e - s, np.inf)
+        t_hit[s:e] = np.minimum(t_hit[s:e], tb)
+    return t_hit
+
+
+@dataclasses.dataclass
+class Scan:
+    points: np.ndarray       # (n, 4) f32, ring-major, LiDAR frame; column 3 = 0 (the extractor ignores it)
+    scan_start: np.ndarray   # (n_rings,) int32
+    scan_end: np.ndarray     # (n_rings,) int32
+    n_rings: int
+
+
+def simulate_scan(scene: Scene, pose_w_body: np.ndarray, body_T_laser: np.ndarray, n_rings: int, n_cols: int = 1800,
+                  seed: int = 7, range_noise: float = 0.02, max_range: float = 100.0) -> Scan:
+    """Ray-cast one LiDAR. pose_w_body / body_T_laser are [tx ty tz qx qy qz qw] / [qx qy qz qw px py pz] rows."""
+    rng = np.random.default_rng(seed)
+    if n_rings == 16:
+        elev = np.deg2rad(np.linspace(-15.0, 15.0, n_rings))
+    else:
+        elev = np.deg2rad(np.linspace(-24.8, 2.0, n_rings))
+    azim = -2.0 * np.pi * np.arange(n_cols) / n_cols
+    T_wb = pose_to_mat(pose_w_body)
+    T_bl = np.eye(4)
+    T_bl[:3, :3] = quat_to_rot(body_T_laser[:4])
+    T_bl[:3, 3] = body_T_laser[4:7]
+    T_wl = T_wb @ T_bl
+    ce, se = np.cos(elev)[:, None], np.sin(elev)[:, None]
+    d_l = np.stack([ce * np.cos(azim)[None, :], ce * np.sin(azim)[None, :], np.broadcast_to(se, (n_rings, n_cols))], axis=2)
+    d_l = d_l.reshape(-1, 3)
+    d_w = d_l @ T_wl[:3, :3].T
+    t = _raycast(scene, T_wl[:3, 3], d_w, max_range)
+    t = t + rng.normal(0.0, range_noise, t.shape)
+    ok = np.isfinite(t) & (t < max_range) & (t > 0.8)
+    pts = (d_l * np.where(ok, t, 0.0)[:, None]).astype(np.float32)
+    ok = ok.reshape(n_rings, n_cols)
+    pts = pts.reshape(n_rings, n_cols, 3)
+    out, starts, ends = [], [], []
+    off = 0
+    for r in range(n_rings):
+        p = pts[r][ok[r]]
+        out.append(p)
+        starts.append(off + 5)
+        ends.append(off + len(p) - 6)
+        off += len(p)
+    xyz = np.concatenate(out) if out else np.zeros((0, 3), np.float32)
+    points = np.zeros((len(xyz), 4), np.float32)
+    points[:, :3] = xyz
+    return Scan(points=np.ascontiguousarray(points), scan_start=np.array(starts, np.int32),
+                scan_end=np.array(ends, np.int32), n_rings=n_rings)
+
+
+def transform_points(points_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
+    return (points_xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+
+
+def perturbed_pose(gt_pose7: np.ndarray, seed: int = 43, dt: float = 0.2, drot_deg: float = 2.0) -> np.ndarray:
+    """Ground truth perturbed by t ~ U[-dt,dt]^3, rotation vector ~ U[-drot,drot]^3."""
+    rng = np.random.default_rng(seed)
+    t = gt_pose7[:3] + rng.uniform(-dt, dt, 3)
+    rv = np.deg2rad(rng.uniform(-drot_deg, drot_deg, 3))
+    q = quat_mul(gt_pose7[3:7], rotvec_to_quat(rv))
+    q /= np.linalg.norm(q)
+    return np.concatenate([t, q])
+
+
+# target map sizes -> (L, n_boxes) found so that the voxel-thinned surf+corner map is close to the target
+SCENE_PRESETS = {
+    "50k": dict(L=80.0, n_boxes=4),
+    "500k": dict(L=210.0, n_boxes=60),
+    "1M": dict(L=300.0, n_boxes=120),
+    "2M": dict(L=420.0, n_boxes=250),
+    "4M": dict(L=600.0, n_boxes=500),
+}
+
+
+def gt_body_pose() -> np.ndarray:
+    return np.array([0.0, 0.0, SENSOR_HEIGHT, 0.0, 0.0, 0.0, 1.0])

@@ -1,0 +1,454 @@
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
+// See mapper.hpp for the list of reference functions restated here.
+#include "mapper.hpp"
+#include "linalg.hpp"
+#include <queue>
+#include <numeric>
+#include <cstring>
+#include <cstdio>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace orc {
+
+static inline void add_outer(double H[36], const double j[6])
+{
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[r * 6 + c] += j[r] * j[c];
+}
+
+void evaluate_problem(const std::vector<ResidualBlock> &blocks, const double x[7], double huber_delta,
+                      NormalEq &ne, bool with_jacobian)
+{
+    std::memset(&ne, 0, sizeof(ne));
+    for (const ResidualBlock &b : blocks) {
+        double r, J[7];
+        if (b.type == 's') plane_norm_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, &r, with_jacobian ? J : nullptr);
+        else edge_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, &r, with_jacobian ? J : nullptr);
+        double rho[3];
+        huber_evaluate(huber_delta, r * r, rho);
+        ne.cost += 0.5 * rho[0];
+        ne.n++;
+        if (with_jacobian) {
+            // Corrector with rho'' <= 0: residual and Jacobian scaled by sqrt(rho')
+            double s = std::sqrt(rho[1]);
+            r *= s;
+            for (int k = 0; k < 6; ++k) J[k] *= s;
+            add_outer(ne.H, J);
+            for (int k = 0; k < 6; ++k) ne.g[k] += J[k] * r;
+        }
+    }
+}
+
+void eval_degeneracy(const double H[36], double eig_thre, Degeneracy &out)
+{
+    jacobi_eig_sym_d(H, 6, out.eigval, out.eigvec);
+    double Vp[36];
+    std::memcpy(Vp, out.eigvec, sizeof(Vp));
+    out.is_degenerate = false;
+    for (int j = 0; j < 6; ++j) {
+        if (out.eigval[j] < eig_thre) {
+            for (int r = 0; r < 6; ++r) Vp[r * 6 + j] = 0.0;
+            out.is_degenerate = true;
+        } else break;
+    }
+    // mat_P = (V_f^T)^-1 * V_p^T   (lidar_mapper_keyframe.cpp:1192)
+    double Vft[36], Vft_inv[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Vft[r * 6 + c] = out.eigvec[c * 6 + r];
+    inverse_d(Vft, 6, Vft_inv);
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += Vft_inv[r * 6 + k] * Vp[c * 6 + k];   // V_p^T(k,c) = Vp(c,k)
+            out.V_update[r * 6 + c] = s;
+        }
+    if (!out.is_degenerate) {   // V_update_ stays Identity (setParameter) unless degenerate
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) out.V_update[r * 6 + c] = (r == c) ? 1.0 : 0.0;
+    }
+}
+
+void ceres_like_solve(const std::vector<ResidualBlock> &blocks, double x[7], const double V_update[36],
+                      double huber_delta, int max_num_iterations, SolveSummary &sum)
+{
+    sum = SolveSummary();
+    const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+    const double min_relative_decrease = 1e-3;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double max_radius = 1e16, min_radius = 1e-32;
+    double radius = 1e4, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int num_consecutive_invalid = 0;
+
+    NormalEq ne;
+    evaluate_problem(blocks, x, huber_delta, ne, true);
+    sum.num_evaluations++;
+    sum.initial_cost = sum.final_cost = ne.cost;
+    double S[6];
+    for (int i = 0; i < 6; ++i) S[i] = 1.0 / (1.0 + std::sqrt(ne.H[i * 6 + i]));
+
+    auto gradient_max_norm = [&](const NormalEq &e) {
+        double neg_g[6], xp[7];
+        for (int i = 0; i < 6; ++i) neg_g[i] = -e.g[i];
+        pose_plus(x, neg_g, V_update, xp);
+        double m = 0.0;
+        for (int i = 0; i < 7; ++i) m = std::max(m, std::fabs(x[i] - xp[i]));
+        return m;
+    };
+    double gmax = gradient_max_norm(ne);
+    double diag[6] = {0, 0, 0, 0, 0, 0};
+    int iteration = 0;
+    while (true) {
+        if (iteration >= max_num_iterations) { sum.termination = 0; break; }
+        if (gmax <= gradient_tolerance) { sum.termination = 1; break; }
+        if (radius <= min_radius) { sum.termination = 4; break; }
+        iteration++;
+        sum.num_iterations = iteration;
+
+        double A[36], gs[6];
+        for (int r = 0; r < 6; ++r) {
+            gs[r] = S[r] * ne.g[r];
+            for (int c = 0; c < 6; ++c) A[r * 6 + c] = S[r] * ne.H[r * 6 + c] * S[c];
+        }
+        if (!reuse_diagonal)
+            for (int i = 0; i < 6; ++i) diag[i] = std::min(std::max(A[i * 6 + i], min_lm_diagonal), max_lm_diagonal);
+        double lhs[36];
+        std::memcpy(lhs, A, sizeof(lhs));
+        for (int i = 0; i < 6; ++i) lhs[i * 6 + i] += diag[i] / radius;
+        double y[6], step[6];
+        bool ok = chol_solve_d(lhs, gs, 6, y);
+        reuse_diagonal = true;
+        bool step_valid = false;
+        double model_cost_change = 0.0;
+        if (ok) {
+            for (int i = 0; i < 6; ++i) step[i] = -y[i];
+            double sg = 0.0, sAs = 0.0;
+            for (int r = 0; r < 6; ++r) {
+                sg += step[r] * gs[r];
+                double t = 0.0;
+                for (int c = 0; c < 6; ++c) t += A[r * 6 + c] * step[c];
+                sAs += step[r] * t;
+            }
+            model_cost_change = -(sg + 0.5 * sAs);
+            step_valid = model_cost_change > 0.0;
+        }
+        if (!step_valid) {
+            if (++num_consecutive_invalid >= 5) { sum.termination = 4; break; }
+            radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            continue;
+        }
+        num_consecutive_invalid = 0;
+        double delta[6], cand[7];
+        for (int i = 0; i < 6; ++i) delta[i] = step[i] * S[i];
+        pose_plus(x, delta, V_update, cand);
+        NormalEq ce;
+        evaluate_problem(blocks, cand, huber_delta, ce, true);   // Ceres evaluates cost only here and J after acceptance
+        sum.num_evaluations++;
+        double step_norm = 0.0, x_norm = 0.0;
+        for (int i = 0; i < 7; ++i) { step_norm += (x[i] - cand[i]) * (x[i] - cand[i]); x_norm += x[i] * x[i]; }
+        step_norm = std::sqrt(step_norm); x_norm = std::sqrt(x_norm);
+        if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { sum.termination = 2; break; }
+        double cost_change = ne.cost - ce.cost;
+        if (std::fabs(cost_change) <= function_tolerance * ne.cost) { sum.termination = 3; break; }
+        double relative_decrease = cost_change / model_cost_change;
+        if (relative_decrease > min_relative_decrease) {
+            std::memcpy(x, cand, sizeof(double) * 7);
+            ne = ce;
+            sum.num_successful_steps++;
+            sum.final_cost = ne.cost;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+            radius = std::min(max_radius, radius);
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+            gmax = gradient_max_norm(ne);
+        } else {
+            radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+        }
+    }
+}
+
+// lidar_mapper.h:130-174: weighted, NOT loss-corrected 1x6 Jacobian at pose_local
+static void evaluate_feat_jacobian_matching(const Pose &pose_local, Feature &feature, double cov_trace)
+{
+    double param[7] = {pose_local.t.x, pose_local.t.y, pose_local.t.z, pose_local.q.x, pose_local.q.y, pose_local.q.z, pose_local.q.w};
+    double res, jaco[7];
+    double sqrt_info = sqrt_info_from_trace(cov_trace);
+    if (feature.type == 's') plane_norm_factor_evaluate(feature.point, feature.coeffs, sqrt_info, param, &res, jaco);
+    else if (feature.type == 'c') edge_factor_evaluate(feature.point, feature.coeffs, sqrt_info, param, &res, jaco);
+    else return;
+    for (int k = 0; k < 6; ++k) feature.jaco[k] = jaco[k];
+}
+
+static inline bool match_one(const MapCloud &map, const FeatureCloud &cloud, size_t que_idx, const Pose &pose_local,
+                             Feature &f, char feature_type, const MatchParams &mp)
+{
+    if (feature_type == 's') return match_surf_point_from_map(map, cloud.at(que_idx), pose_local, f, que_idx, 5, false, mp);
+    if (feature_type == 'c') return match_corner_point_from_map(map, cloud.at(que_idx), pose_local, f, que_idx, 5, false, mp);
+    return false;
+}
+
+void eval_full_hessian(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose_local, char feature_type,
+                       double mat_H[36], int &feat_num, const MatchParams &mp)
+{
+    for (size_t i = 0; i < (size_t)cloud.n; i++) {
+        Feature f;
+        if (!match_one(map, cloud, i, pose_local, f, feature_type, mp)) continue;
+        evaluate_feat_jacobian_matching(pose_local, f, cloud.cov_trace(i));
+        add_outer(mat_H, f.jaco);
+        feat_num++;
+    }
+}
+
+namespace {
+struct FeatureWithScore {   // parameters.h:177-191
+    size_t idx; double score; double jaco[6];
+    bool operator<(const FeatureWithScore &o) const { return score < o.score; }
+};
+inline size_t rand_uniform(std::mt19937 &rng, size_t lo, size_t hi)
+{
+    std::uniform_int_distribution<size_t> d(lo, hi);   // RandomGeneratorInt::geneRandUniform
+    return d(rng);
+}
+}  // namespace
+
+void good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose_local,
+                           std::vector<Feature> &all_features, std::vector<size_t> &sel_feature_idx,
+                           char feature_type, const SelectParams &sp, double sub_mat_H[36],
+                           const MatchParams &mp, std::mt19937 &rng)
+{
+    const size_t num_all_features = cloud.n;
+    all_features.assign(num_all_features, Feature());
+    std::vector<size_t> all_feature_idx(num_all_features);
+    std::vector<int> feature_visited(num_all_features, -1);
+    std::iota(all_feature_idx.begin(), all_feature_idx.end(), 0);
+    size_t num_use_features = static_cast<size_t>(num_all_features * sp.gf_ratio);
+    sel_feature_idx.assign(num_use_features, 0);
+    size_t num_sel_features = 0;
+    const std::string &gf_method = sp.gf_method;
+    const size_t MAX_RANDOM_QUEUE_TIME = 20;
+
+    auto match_and_jac = [&](size_t que_idx) -> bool {
+        bool b = match_one(map, cloud, que_idx, pose_local, all_features[que_idx], feature_type, mp);
+        if (b) evaluate_feat_jacobian_matching(pose_local, all_features[que_idx], cloud.cov_trace(que_idx));
+        return b;
+    };
+
+    if (gf_method == "wo_gf") {
+        for (size_t j = 0; j < all_feature_idx.size(); j++) {
+            size_t que_idx = all_feature_idx[j];
+            if (match_and_jac(que_idx)) {
+                add_outer(sub_mat_H, all_features[que_idx].jaco);
+                if (num_sel_features >= sel_feature_idx.size()) sel_feature_idx.resize(num_sel_features + 1);   // gf_ratio < 1 with wo_gf overruns in the reference
+                sel_feature_idx[num_sel_features++] = que_idx;
+            }
+        }
+    } else if (gf_method == "rnd") {
+        while (true) {
+            if (num_sel_features >= num_use_features || all_feature_idx.size() == 0) break;
+            size_t j = rand_uniform(rng, 0, all_feature_idx.size() - 1);
+            size_t que_idx = all_feature_idx[j];
+            if (match_and_jac(que_idx)) {
+                add_outer(sub_mat_H, all_features[que_idx].jaco);
+                sel_feature_idx[num_sel_features++] = que_idx;
+            }
+            all_feature_idx.erase(all_feature_idx.begin() + j);
+        }
+    } else if (gf_method == "fps") {
+        if (num_all_features > 0) {
+            size_t k = rand_uniform(rng, 0, all_feature_idx.size() - 1);
+            feature_visited[k] = 1;
+            size_t cnt_visited = 1;
+            const float *point_old = cloud.at(k);
+            // the starting point is matched but its Jacobian is neither evaluated nor accumulated (lidar_mapper.h:356-386)
+            if (match_one(map, cloud, k, pose_local, all_features[k], feature_type, mp) && num_use_features > 0)
+                sel_feature_idx[num_sel_features++] = k;
+            std::vector<float> dist(num_all_features, 1e5);
+            while (true) {
+                // the reference leaves this loop through a 20 ms wall-clock cut-off; deterministic exit instead
+                if (num_sel_features >= num_use_features || cnt_visited >= num_all_features) break;
+                float best_d = -1;
+                size_t best_j = 1;
+                for (size_t j = 0; j < num_all_features; j++) {
+                    if (feature_visited[j] == 1) continue;
+                    const float *pn = cloud.at(j);
+                    float ddx = point_old[0] - pn[0], ddy = point_old[1] - pn[1], ddz = point_old[2] - pn[2];
+                    float d = std::sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+                    float d2 = std::min(d, dist[j]);
+                    dist[j] = d2;
+                    best_j = d2 > best_d ? j : best_j;
+                    best_d = d2 > best_d ? d2 : best_d;
+                }
+                size_t que_idx = best_j;
+                point_old = cloud.at(que_idx);
+                feature_visited[que_idx] = 1;
+                cnt_visited++;
+                if (match_and_jac(que_idx)) {
+                    add_outer(sub_mat_H, all_features[que_idx].jaco);
+                    sel_feature_idx[num_sel_features++] = que_idx;
+                }
+            }
+        }
+    } else if (gf_method == "gd_fix" || gf_method == "gd_float") {
+        size_t num_rnd_que = 0;
+        while (true) {
+            if (num_sel_features >= num_use_features || all_feature_idx.size() == 0) break;
+            size_t size_rnd_subset = static_cast<size_t>(1.0 * num_all_features / num_use_features);
+            std::priority_queue<FeatureWithScore, std::vector<FeatureWithScore>, std::less<FeatureWithScore>> heap_subset;
+            bool lost = false;
+            while (true) {
+                if (all_feature_idx.size() == 0) break;
+                num_rnd_que = 0;
+                size_t j = 0;
+                while (num_rnd_que < MAX_RANDOM_QUEUE_TIME) {
+                    j = rand_uniform(rng, 0, all_feature_idx.size() - 1);
+                    if (feature_visited[j] < int(num_sel_features)) {
+                        feature_visited[j] = int(num_sel_features);
+                        break;
+                    }
+                    num_rnd_que++;
+                }
+                if (num_rnd_que >= MAX_RANDOM_QUEUE_TIME) break;
+                size_t que_idx = all_feature_idx[j];
+                if (all_features[que_idx].type == 'n') {
+                    if (!match_and_jac(que_idx)) {
+                        all_feature_idx.erase(all_feature_idx.begin() + j);
+                        feature_visited.erase(feature_visited.begin() + j);
+                        continue;
+                    }
+                }
+                const double *jaco = all_features[que_idx].jaco;
+                double Ht[36];
+                std::memcpy(Ht, sub_mat_H, sizeof(Ht));
+                add_outer(Ht, jaco);
+                FeatureWithScore fws;
+                fws.idx = que_idx; fws.score = logdet_chol_d(Ht, 6);
+                std::memcpy(fws.jaco, jaco, sizeof(fws.jaco));
+                heap_subset.push(fws);
+                if (heap_subset.size() >= size_rnd_subset) {
+                    const FeatureWithScore &top = heap_subset.top();
+                    auto iter = std::find(all_feature_idx.begin(), all_feature_idx.end(), top.idx);
+                    if (iter == all_feature_idx.end()) { lost = true; break; }
+                    add_outer(sub_mat_H, top.jaco);
+                    size_t position = iter - all_feature_idx.begin();
+                    all_feature_idx.erase(all_feature_idx.begin() + position);
+                    feature_visited.erase(feature_visited.begin() + position);
+                    sel_feature_idx[num_sel_features++] = top.idx;
+                    break;
+                }
+            }
+            if (num_rnd_que >= MAX_RANDOM_QUEUE_TIME || lost) break;
+        }
+    }
+    sel_feature_idx.resize(num_sel_features);
+}
+
+static void build_blocks(const std::vector<Feature> &all_surf, const std::vector<size_t> &sel_surf, const FeatureCloud &surf,
+                         const std::vector<Feature> &all_corner, const std::vector<size_t> &sel_corner, const FeatureCloud &corner,
+                         const MapperParams &prm, std::vector<ResidualBlock> &blocks)
+{
+    blocks.clear();
+    blocks.reserve(sel_surf.size() + sel_corner.size());
+    for (size_t fid : sel_surf) {   // cpp:537-548
+        const Feature &f = all_surf[fid];
+        ResidualBlock b;
+        b.type = 's';
+        std::memcpy(b.point, f.point, sizeof(b.point));
+        std::memcpy(b.coeffs, f.coeffs, sizeof(b.coeffs));
+        b.sqrt_info = sqrt_info_from_trace(prm.with_ua ? surf.cov_trace(f.idx) : prm.cov_measurement_trace);
+        blocks.push_back(b);
+    }
+    for (size_t fid : sel_corner) {   // cpp:551-571
+        const Feature &f = all_corner[fid];
+        ResidualBlock b;
+        b.type = 'c';
+        std::memcpy(b.point, f.point, sizeof(b.point));
+        std::memcpy(b.coeffs, f.coeffs, sizeof(b.coeffs));
+        b.sqrt_info = sqrt_info_from_trace(prm.with_ua ? corner.cov_trace(f.idx) : prm.cov_measurement_trace);
+        blocks.push_back(b);
+    }
+}
+
+void scan2map_optimization(const MapCloud &surf_map, const MapCloud &corner_map,
+                           const FeatureCloud &surf, const FeatureCloud &corner,
+                           const double pose_init[7], const MapperParams &prm, Scan2MapResult &res)
+{
+    res = Scan2MapResult();
+    std::memcpy(res.pose, pose_init, sizeof(double) * 7);
+    std::memset(res.H_final, 0, sizeof(res.H_final));
+    if (!(surf_map.n > 50 && corner_map.n > 10)) return;   // cpp:429
+    std::mt19937 rng((uint32_t)prm.sel.seed);
+    for (int iter_cnt = 0; iter_cnt < prm.max_outer; iter_cnt++) {
+        OuterStat st;
+        Pose pose_wmap_curr = pose_from_param(res.pose);
+        std::vector<Feature> all_surf, all_corner;
+        std::vector<size_t> sel_surf, sel_corner;
+        double sub_H[36];
+        for (int i = 0; i < 36; ++i) sub_H[i] = (i % 7 == 0) ? 1e-6 : 0.0;
+        good_feature_matching(corner_map, corner, pose_wmap_curr, all_corner, sel_corner, 'c', prm.sel, sub_H, prm.mp, rng);
+        for (int i = 0; i < 36; ++i) sub_H[i] = (i % 7 == 0) ? 1e-6 : 0.0;
+        good_feature_matching(surf_map, surf, pose_wmap_curr, all_surf, sel_surf, 's', prm.sel, sub_H, prm.mp, rng);
+        st.n_surf_sel = (int)sel_surf.size();
+        st.n_corner_sel = (int)sel_corner.size();
+        std::vector<ResidualBlock> blocks;
+        build_blocks(all_surf, sel_surf, surf, all_corner, sel_corner, corner, prm, blocks);
+
+        NormalEq ne;
+        evaluate_problem(blocks, res.pose, prm.huber_delta, ne, true);   // problem.Evaluate -> evalHessian (cpp:575-581)
+        std::memcpy(st.H0, ne.H, sizeof(st.H0));
+        if (ne.n == 0) std::memset(st.H0, 0, sizeof(st.H0));
+        eval_degeneracy(st.H0, prm.map_eig_thre, st.deg);
+        ceres_like_solve(blocks, res.pose, st.deg.V_update, prm.huber_delta, prm.max_lm_iterations, st.solve);
+        if (iter_cnt == prm.max_outer - 1 && prm.with_ua) {
+            NormalEq nf;
+            evaluate_problem(blocks, res.pose, prm.huber_delta, nf, true);
+            std::memcpy(res.H_final, nf.H, sizeof(res.H_final));
+        }
+        std::memcpy(st.pose_after, res.pose, sizeof(st.pose_after));
+        res.outer.push_back(st);
+    }
+}
+
+static void match_all_parallel(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose, char type,
+                               const MatchParams &mp, std::vector<Feature> &feats, std::vector<uint8_t> &ok, int n_threads)
+{
+    feats.assign(cloud.n, Feature());
+    ok.assign(cloud.n, 0);
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 256) if (n_threads > 1)
+    for (int i = 0; i < cloud.n; ++i)
+        ok[i] = match_one(map, cloud, i, pose, feats[i], type, mp) ? 1 : 0;
+}
+
+void gn_iteration(const MapCloud &surf_map, const MapCloud &corner_map, const FeatureCloud &surf, const FeatureCloud &corner,
+                  double x[7], const MapperParams &prm, GnIterStat &st, int n_threads)
+{
+    Pose pose = pose_from_param(x);
+    std::vector<Feature> fs, fc;
+    std::vector<uint8_t> oks, okc;
+    match_all_parallel(surf_map, surf, pose, 's', prm.mp, fs, oks, n_threads);
+    match_all_parallel(corner_map, corner, pose, 'c', prm.mp, fc, okc, n_threads);
+    std::vector<size_t> sel_s, sel_c;
+    for (int i = 0; i < surf.n; ++i) if (oks[i]) sel_s.push_back(i);
+    for (int i = 0; i < corner.n; ++i) if (okc[i]) sel_c.push_back(i);
+    st.n_surf = (int)sel_s.size();
+    st.n_corner = (int)sel_c.size();
+    std::vector<ResidualBlock> blocks;
+    build_blocks(fs, sel_s, surf, fc, sel_c, corner, prm, blocks);
+    evaluate_problem(blocks, x, prm.huber_delta, st.ne, true);
+    eval_degeneracy(st.ne.H, prm.map_eig_thre, st.deg);
+    double rhs[6], d[6];
+    for (int i = 0; i < 6; ++i) rhs[i] = -st.ne.g[i];
+    bool ok = chol_solve_d(st.ne.H, rhs, 6, d);
+    if (!ok) {
+        double Hd[36];
+        std::memcpy(Hd, st.ne.H, sizeof(Hd));
+        for (int i = 0; i < 6; ++i) Hd[i * 6 + i] += 1e-6;
+        ok = chol_solve_d(Hd, rhs, 6, d);
+    }
+    if (ok) {
+        double xn[7];
+        pose_plus(x, d, st.deg.V_update, xn);
+        std::memcpy(x, xn, sizeof(xn));
+    }
+    std::memcpy(st.pose_after, x, sizeof(st.pose_after));
+}
+
+}  // namespace orc

@@ -1,0 +1,282 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (oracle/libmloam_oracle.so).
+
+Only tests/, bench.py's ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` import this module, and only as
+the checker / reported CPU baseline. PARITY UNPINNED: see oracle/linalg.hpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmloam_oracle.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+GF_METHODS = {"wo_gf": 0, "rnd": 1, "fps": 2, "gd_fix": 3, "gd_float": 4}
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp")) or f == "Makefile"]
+    stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_map_create.restype = C.c_void_p
+        _lib.orc_map_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        _lib.orc_map_destroy.argtypes = [C.c_void_p]
+        _lib.orc_map_rebuild_seconds.restype = C.c_double
+        _lib.orc_map_rebuild_seconds.argtypes = [C.c_void_p]
+        _lib.orc_logdet.restype = C.c_double
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def mapper_params(min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1, map_eig_thre=100.0, with_ua=False,
+                  cov_measurement_trace=0.0075, max_outer=2, max_lm_iterations=30, gf_method="wo_gf", gf_ratio=1.0, seed=0):
+    return np.array([min_match_sq_dis, min_plane_dis, huber_delta, map_eig_thre, float(with_ua), cov_measurement_trace,
+                     max_outer, max_lm_iterations, GF_METHODS[gf_method], gf_ratio, seed], dtype=np.float64)
+
+
+def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray):
+    """FeatureExtract::extractCloud. points (n,4) f32 ring-major."""
+    L = lib()
+    pts = np.ascontiguousarray(points, np.float32)
+    n = pts.shape[0]
+    ss = np.ascontiguousarray(scan_start, np.int32)
+    se = np.ascontiguousarray(scan_end, np.int32)
+    curv = np.zeros(n, np.float32)
+    label = np.zeros(n, np.int32)
+    picked = np.zeros(n, np.int32)
+    bufs = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+    cnts = [C.c_int(0) for _ in range(5)]
+    lf_ds = np.zeros((max(n, 1), 4), np.float32)
+    ties = C.c_long(0)
+    L.orc_extract(_ptr(pts), n, _ptr(ss), _ptr(se), len(ss), _ptr(curv), _ptr(label), _ptr(picked),
+                  _ptr(bufs[0]), C.byref(cnts[0]), _ptr(bufs[1]), C.byref(cnts[1]), _ptr(bufs[2]), C.byref(cnts[2]),
+                  _ptr(bufs[3]), C.byref(cnts[3]), _ptr(lf_ds), C.byref(cnts[4]), C.byref(ties))
+    return dict(curvature=curv, label=label, picked=picked,
+                sharp=bufs[0][:cnts[0].value].copy(), less_sharp=bufs[1][:cnts[1].value].copy(),
+                flat=bufs[2][:cnts[2].value].copy(), less_flat_raw=bufs[3][:cnts[3].value].copy(),
+                less_flat_ds=lf_ds[:cnts[4].value].copy(), n_ties=ties.value)
+
+
+def voxel_grid(points: np.ndarray, leaf: float) -> np.ndarray:
+    L = lib()
+    pts = np.ascontiguousarray(points, np.float32)
+    out = np.zeros_like(pts)
+    cnt = C.c_int(0)
+    L.orc_voxel_grid(_ptr(pts), pts.shape[0], C.c_float(leaf), _ptr(out), C.byref(cnt))
+    return out[:cnt.value].copy()
+
+
+class Map:
+    """A map cloud + exact kNN index (the pcl::KdTreeFLANN role)."""
+
+    def __init__(self, pts: np.ndarray):
+        self.pts = np.ascontiguousarray(pts, np.float32)
+        assert self.pts.ndim == 2 and self.pts.shape[1] >= 3
+        self.h = C.c_void_p(lib().orc_map_create(_ptr(self.pts), self.pts.shape[1], self.pts.shape[0]))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_map_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def rebuild_seconds(self) -> float:
+        return lib().orc_map_rebuild_seconds(self.h)
+
+    def knn(self, queries: np.ndarray, k: int = 5):
+        q = np.ascontiguousarray(queries[:, :3], np.float32)
+        idx = np.zeros((q.shape[0], k), np.int32)
+        d2 = np.zeros((q.shape[0], k), np.float32)
+        lib().orc_knn(self.h, _ptr(q), q.shape[0], k, _ptr(idx), _ptr(d2))
+        return idx, d2
+
+    def match(self, kind: str, feats: np.ndarray, pose7, n_neigh=5, check_fov=False, min_match_sq_dis=1.0, min_plane_dis=0.2):
+        f = np.ascontiguousarray(feats, np.float32)
+        n = f.shape[0]
+        valid = np.zeros(n, np.uint8)
+        coeffs = np.zeros((n, 6), np.float64)
+        pose = np.ascontiguousarray(pose7, np.float64)
+        lib().orc_match(self.h, C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _ptr(pose), n_neigh, int(check_fov),
+                        C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(valid), _ptr(coeffs))
+        return valid, coeffs
+
+
+def factor_eval(kind: str, point, coeff, cov_trace: float, pose7):
+    point = np.ascontiguousarray(point, np.float64)
+    coeff = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    pose = np.ascontiguousarray(pose7, np.float64)
+    r = np.zeros(1)
+    J = np.zeros(7)
+    lib().orc_factor_eval(C.c_char(kind.encode()), _ptr(point), _ptr(coeff), C.c_double(cov_trace), _ptr(pose), _ptr(r), _ptr(J))
+    return r[0], J
+
+
+def pose_plus(x, delta, V_update=None):
+    x = np.ascontiguousarray(x, np.float64)
+    d = np.ascontiguousarray(delta, np.float64)
+    V = np.ascontiguousarray(np.eye(6) if V_update is None else V_update, np.float64)
+    out = np.zeros(7)
+    lib().orc_pose_plus(_ptr(x), _ptr(d), _ptr(V), _ptr(out))
+    return out
+
+
+def huber(a: float, s: float):
+    rho = np.zeros(3)
+    lib().orc_huber(C.c_double(a), C.c_double(s), _ptr(rho))
+    return rho
+
+
+def linearize(kind: str, feats, cov_trace, pose7, valid, coeffs, huber_delta=0.1):
+    f = np.ascontiguousarray(feats, np.float32)
+    n = f.shape[0]
+    ct = None if cov_trace is None else np.ascontiguousarray(cov_trace, np.float64)
+    pose = np.ascontiguousarray(pose7, np.float64)
+    valid = np.ascontiguousarray(valid, np.uint8)
+    coeffs = np.ascontiguousarray(coeffs, np.float64)
+    r = np.zeros(n)
+    J = np.zeros((n, 6))
+    H = np.zeros((6, 6))
+    g = np.zeros(6)
+    cost = C.c_double(0)
+    cnt = C.c_int(0)
+    lib().orc_linearize(C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _ptr(ct), _ptr(pose), _ptr(valid), _ptr(coeffs),
+                        C.c_double(huber_delta), _ptr(r), _ptr(J), _ptr(H), _ptr(g), C.byref(cost), C.byref(cnt))
+    return dict(r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)
+
+
+def eval_degeneracy(H, eig_thre=100.0):
+    H = np.ascontiguousarray(H, np.float64)
+    ev = np.zeros(6)
+    V = np.zeros((6, 6))
+    P = np.zeros((6, 6))
+    deg = C.c_int(0)
+    lib().orc_eval_degeneracy(_ptr(H), C.c_double(eig_thre), _ptr(ev), _ptr(V), _ptr(P), C.byref(deg))
+    return dict(eigval=ev, eigvec=V, V_update=P, is_degenerate=bool(deg.value))
+
+
+def _cov_off(feats):
+    return 4 if feats.shape[1] >= 10 else -1
+
+
+def scan2map(surf_map: Map, corner_map: Map, surf, corner, pose_init, prm):
+    s = np.ascontiguousarray(surf, np.float32)
+    c = np.ascontiguousarray(corner, np.float32)
+    p0 = np.ascontiguousarray(pose_init, np.float64)
+    prm = np.ascontiguousarray(prm, np.float64)
+    pose = np.zeros(7)
+    stats = np.zeros((16, 64))
+    n_outer = C.c_int(0)
+    Hf = np.zeros((6, 6))
+    lib().orc_scan2map(surf_map.h, corner_map.h, _ptr(s), s.shape[1], s.shape[0], _cov_off(s),
+                       _ptr(c), c.shape[1], c.shape[0], _cov_off(c), _ptr(p0), _ptr(prm), _ptr(pose), _ptr(stats),
+                       C.byref(n_outer), _ptr(Hf))
+    outer = []
+    for i in range(n_outer.value):
+        o = stats[i]
+        outer.append(dict(n_surf_sel=int(o[0]), n_corner_sel=int(o[1]), lm_iterations=int(o[2]), successful_steps=int(o[3]),
+                          initial_cost=o[4], final_cost=o[5], termination=int(o[6]), is_degenerate=bool(o[7]),
+                          eigval=o[8:14].copy(), pose_after=o[14:21].copy(), H0=o[21:57].reshape(6, 6).copy(),
+                          evaluations=int(o[57])))
+    return dict(pose=pose, outer=outer, H_final=Hf)
+
+
+def good_feature_matching(map_: Map, kind: str, feats, pose7, prm):
+    f = np.ascontiguousarray(feats, np.float32)
+    n = f.shape[0]
+    pose = np.ascontiguousarray(pose7, np.float64)
+    prm = np.ascontiguousarray(prm, np.float64)
+    sel = np.zeros(max(n, 1), np.int32)
+    nsel = C.c_int(0)
+    H = np.zeros((6, 6))
+    matched = np.zeros(n, np.uint8)
+    jaco = np.zeros((n, 6))
+    lib().orc_good_feature_matching(map_.h, C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _cov_off(f), _ptr(pose), _ptr(prm),
+                                    _ptr(sel), C.byref(nsel), _ptr(H), _ptr(matched), _ptr(jaco))
+    return dict(sel=sel[:nsel.value].copy(), H=H, matched=matched, jaco=jaco)
+
+
+def gn_iterations(surf_map: Map, corner_map: Map, surf, corner, pose_init, prm, n_iters=5, n_threads=1):
+    s = np.ascontiguousarray(surf, np.float32)
+    c = np.ascontiguousarray(corner, np.float32)
+    pose = np.ascontiguousarray(pose_init, np.float64).copy()
+    prm = np.ascontiguousarray(prm, np.float64)
+    stats = np.zeros((n_iters, 48))
+    secs = C.c_double(0)
+    lib().orc_gn_iterations(surf_map.h, corner_map.h, _ptr(s), s.shape[1], s.shape[0], _cov_off(s),
+                            _ptr(c), c.shape[1], c.shape[0], _cov_off(c), _ptr(pose), _ptr(prm), n_iters, n_threads,
+                            _ptr(stats), C.byref(secs))
+    iters = []
+    for o in stats:
+        H = np.zeros((6, 6))
+        q = 17
+        for r in range(6):
+            for cc in range(r, 6):
+                H[r, cc] = H[cc, r] = o[q]
+                q += 1
+        iters.append(dict(n_surf=int(o[0]), n_corner=int(o[1]), cost=o[2], is_degenerate=bool(o[3]),
+                          pose_after=o[4:11].copy(), g=o[11:17].copy(), H=H))
+    return dict(pose=pose, iters=iters, seconds=secs.value)
+
+
+def eig3f(A):
+    A = np.ascontiguousarray(A, np.float32)
+    val = np.zeros(3, np.float32)
+    vec = np.zeros((3, 3), np.float32)
+    rc = lib().orc_eig3f(_ptr(A), _ptr(val), _ptr(vec))
+    return val, vec, rc
+
+
+def qr_solve(A, b):
+    A = np.ascontiguousarray(A, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    x = np.zeros(3, np.float32)
+    lib().orc_qr_solve(_ptr(A), _ptr(b), A.shape[0], _ptr(x))
+    return x
+
+
+def logdet(A):
+    A = np.ascontiguousarray(A, np.float64)
+    return lib().orc_logdet(_ptr(A), A.shape[0])
+
+
+def eval_point_uncertainty(xyz, pose7, cov_pose, cov_meas):
+    p = np.ascontiguousarray(xyz, np.float32)
+    pose = np.ascontiguousarray(pose7, np.float64)
+    cp = np.ascontiguousarray(cov_pose, np.float64)
+    cm = np.ascontiguousarray(cov_meas, np.float64)
+    out = np.zeros((p.shape[0], 3, 3))
+    lib().orc_eval_point_uncertainty(_ptr(p), p.shape[0], p.shape[1], _ptr(pose), _ptr(cp), _ptr(cm), _ptr(out))
+    return out
+
+
+def voxel_grid_cov(pts11, leaf, trace_threshold):
+    p = np.ascontiguousarray(pts11, np.float32)
+    assert p.shape[1] == 11
+    out = np.zeros_like(p)
+    cnt = C.c_int(0)
+    lib().orc_voxel_grid_cov(_ptr(p), p.shape[0], C.c_float(leaf), C.c_float(trace_threshold), _ptr(out), C.byref(cnt))
+    return out[:cnt.value].copy()

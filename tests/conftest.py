@@ -1,0 +1,80 @@
+"""Shared fixtures. GPU tests are marked @pytest.mark.gpu and call the HIP path through the C-ABI; everything else runs
+on CPU (oracle vs golden vectors / independent numpy-scipy cross-checks, host logic, ABI symbol checks)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def mla():
+    return importlib.import_module("m-loam_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("m-loam_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle as O
+    O.build()
+    return O
+
+
+def _make_case(synth, preset, n_rings, n_lidars, seed=42):
+    """Scene + maps + per-LiDAR scans + (oracle-free) feature clouds for the mapper."""
+    sc = synth.make_scene(seed=seed, **synth.SCENE_PRESETS[preset])
+    surf_map, corner_map = synth.sample_maps(sc, seed=seed)
+    gt = synth.gt_body_pose()
+    scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], n_rings, seed=7 + i) for i in range(n_lidars)]
+    return dict(scene=sc, surf_map=surf_map, corner_map=corner_map, gt=gt, scans=scans, p0=synth.perturbed_pose(gt, seed=43))
+
+
+@pytest.fixture(scope="session")
+def case16(synth):
+    """BASELINE config 1: one 16-ring x 1800 scan, ~50k-point planar map."""
+    return _make_case(synth, "50k", 16, 1)
+
+
+def features_from_extraction(synth, scans, extract_fn):
+    """Fuse per-LiDAR extraction results into the mapper's two feature clouds (reference-LiDAR frame, intensity = LiDAR id,
+    visualization.cpp:40-52), then thin them at MAP_SURF_RES / MAP_CORNER_RES as downsampleCurrentScan does."""
+    surf, corner = [], []
+    for i, sc in enumerate(scans):
+        ex = extract_fn(sc)
+        T = np.eye(4)
+        T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4])
+        T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]
+        cpts = sc.points[ex["less_sharp"]][:, :3]
+        spts = ex["less_flat_ds"][:, :3] if "less_flat_ds" in ex else sc.points[ex["less_flat_raw"]][:, :3]
+        c = np.zeros((len(cpts), 4), np.float32)
+        c[:, :3] = synth.transform_points(cpts, T)
+        c[:, 3] = i
+        s = np.zeros((len(spts), 4), np.float32)
+        s[:, :3] = synth.transform_points(spts, T)
+        s[:, 3] = i
+        surf.append(s)
+        corner.append(c)
+    surf = synth.voxel_mean(np.concatenate(surf), 0.4)
+    corner = synth.voxel_mean(np.concatenate(corner), 0.2)
+    surf[:, 3] = np.round(surf[:, 3])
+    corner[:, 3] = np.round(corner[:, 3])
+    return np.ascontiguousarray(surf), np.ascontiguousarray(corner)
+
+
+@pytest.fixture(scope="session")
+def feats16(synth, orc, case16):
+    return features_from_extraction(synth, case16["scans"], lambda s: orc.extract(s.points, s.scan_start, s.scan_end))
