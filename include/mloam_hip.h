@@ -60,8 +60,19 @@ int mlh_synchronize(mlh_ctx *ctx);
 /* ---------------------------------------------------------------- per-kernel timing (HIP events on the context's stream)
  * When enabled, every launch of the named kernels is bracketed by hipEventRecord on the context's stream; the
  * accumulated duration / launch count are read back with mlh_profile_get. Kernel ids: */
-enum { MLH_K_MATCH = 0, MLH_K_LINEARIZE = 1, MLH_K_SOLVE = 2, MLH_K_GRID_BUILD = 3, MLH_K_EXTRACT = 4, MLH_K_COUNT = 5 };
-int mlh_profile_enable(mlh_ctx *ctx, int on);
+enum {
+    MLH_K_KNN_SURF = 0,      /* correspondence kernel (exact 5-NN), surf features   -- the roofline kernel */
+    MLH_K_KNN_CORNER = 1,
+    MLH_K_FIT_SURF = 2,      /* fit + gates + residual/Jacobian + J^T J reduction    */
+    MLH_K_FIT_CORNER = 3,
+    MLH_K_LINEARIZE = 4,     /* re-linearisation on stored correspondences (LM)      */
+    MLH_K_SOLVE = 5,         /* partial-sum reduction + degeneracy + 6x6 solve + Plus */
+    MLH_K_GRID_BUILD = 6,    /* local-map index build                                 */
+    MLH_K_EXTRACT = 7,       /* extractCloud                                          */
+    MLH_K_COUNT = 8
+};
+/* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
+int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);
 int mlh_profile_reset(mlh_ctx *ctx);
 int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
 
@@ -169,6 +180,23 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
  * (Ceres trust-region semantics, <= max_lm_iterations) on fixed correspondences }, device-resident.
  * replaces lidar_mapper_keyframe.cpp:423-639 for gf_method "wo_gf". stats: max_outer records. */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
+
+/* ---------------------------------------------------------------- (e) multi-GPU: map shards + one all-reduce per iteration
+ * One process (context) per GPU. The local map is partitioned spatially: rank g stages only the map points of its
+ * region plus a halo >= sqrt(min_match_sq_dis) (mlh_map_set on that subset), and OWNS the features whose map-frame
+ * position p = pointAssociateToMap(feature) satisfies  lo.xyz . p + lo.w >= 0  and  hi.xyz . p + hi.w < 0
+ * (either plane may be NULL = unbounded; evaluated in f32 as ((a*x + b*y) + c*z) + d, so neighbouring ranks that share a
+ * plane take complementary decisions and every feature has exactly one owner). Features a rank does not own contribute
+ * nothing on that rank. Because every map point within the acceptance radius of an owned feature is local, the 5-NN /
+ * gate decisions are identical to the unsharded ones.
+ * mlh_comm_init joins the ranks (RCCL, dlopen'ed): the device-resident solvers then sum the packed normal equations
+ * (32 doubles: 21 J^T J + 6 J^T r + cost + counts) with ONE ncclAllReduce per evaluation on the context's stream, and
+ * every rank applies the identical 6x6 solve / Plus redundantly (no pose broadcast). */
+int mlh_shard_set(mlh_ctx *ctx, const float *lo_plane4, const float *hi_plane4);
+int mlh_comm_unique_id(void *out_128_bytes);
+int mlh_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *unique_id_128_bytes);
+/* in-place sum of n doubles (HOST buffer) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */
+int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n);
 
 /* host-side helpers mirroring the reference's small functions (no GPU work) */
 /* PoseLocalParameterization::Plus with V_update_ (row-major 6x6; NULL = identity) */

@@ -21,7 +21,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mloam_hip.h")
 SURF, CORNER = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
-K_MATCH, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = 0, 1, 2, 3, 4
+K_KNN_SURF, K_KNN_CORNER, K_FIT_SURF, K_FIT_CORNER, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = range(8)
+K_ALL = 0xFF
 
 
 class MlhError(RuntimeError):
@@ -83,6 +84,10 @@ def load_library():
     lib.mlh_solver_opts_default.restype = None
     lib.mlh_gn_solve.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), vp]
     lib.mlh_scan2map.argtypes = [vp, vp, C.POINTER(SolverOpts), vp]
+    lib.mlh_shard_set.argtypes = [vp, vp, vp]
+    lib.mlh_comm_unique_id.argtypes = [vp]
+    lib.mlh_comm_init.argtypes = [vp, ci, ci, vp]
+    lib.mlh_allreduce_f64.argtypes = [vp, vp, ci]
     lib.mlh_pose_plus.argtypes = [vp, vp, vp, vp]
     lib.mlh_eval_degeneracy.argtypes = [vp, cd, vp, vp]
     _lib = lib
@@ -95,6 +100,7 @@ EXPORTED_SYMBOLS = [
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set",
     "mlh_match_linearize", "mlh_linearize", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
+    "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
 
@@ -156,8 +162,11 @@ class Context:
         self._ck(self.lib.mlh_synchronize(self.h))
 
     # ---- profiling
-    def profile_enable(self, on=True):
-        self._ck(self.lib.mlh_profile_enable(self.h, int(on)))
+    def profile_enable(self, kernel_mask=K_ALL):
+        """kernel_mask: bit k brackets launches of kernel id k with HIP events (0/False = off, True = all)."""
+        if kernel_mask is True:
+            kernel_mask = K_ALL
+        self._ck(self.lib.mlh_profile_enable(self.h, int(kernel_mask)))
 
     def profile_reset(self):
         self._ck(self.lib.mlh_profile_reset(self.h))
@@ -225,6 +234,21 @@ class Context:
         self._m = getattr(self, "_m", {})
         self._m[kind] = n
 
+    # ---- multi-GPU
+    def shard_set(self, lo_plane=None, hi_plane=None):
+        lo = None if lo_plane is None else np.ascontiguousarray(lo_plane, np.float32)
+        hi = None if hi_plane is None else np.ascontiguousarray(hi_plane, np.float32)
+        self._ck(self.lib.mlh_shard_set(self.h, _p(lo), _p(hi)))
+
+    def comm_init(self, n_ranks, rank, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._ck(self.lib.mlh_comm_init(self.h, n_ranks, rank, C.cast(buf, C.c_void_p)))
+
+    def allreduce_f64(self, arr):
+        a = np.ascontiguousarray(arr, np.float64).copy()
+        self._ck(self.lib.mlh_allreduce_f64(self.h, _p(a), a.size))
+        return a
+
     # ---- host-driven evaluation
     def match_linearize(self, kind, pose, flags=0, min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1,
                         cov_measurement_trace=0.0075, dense=True):
@@ -268,6 +292,14 @@ class Context:
         stats = (IterStat * opts.max_outer)()
         self._ck(self.lib.mlh_scan2map(self.h, _p(pose), C.byref(opts), C.cast(stats, C.c_void_p)))
         return pose, [s.as_dict() for s in stats]
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    rc = load_library().mlh_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise MlhError(f"mlh_comm_unique_id failed ({rc}): librccl not loadable?")
+    return buf.raw
 
 
 def pose_plus(x, delta, V_update=None):

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libmloam_hip.so")
-SOURCES = ["capi.hip", "grid.hip", "match.hip", "solver.hip", "extract.hip"]
+SOURCES = ["capi.hip", "grid.hip", "match.hip", "solver.hip", "extract.hip", "comm.hip"]
 HEADERS = ["ctx.hpp", "dev_math.hpp", os.path.join("..", "..", "include", "mloam_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not os.path.exists(LIB):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -27,7 +27,7 @@ static hipEvent_t prof_event(mlh_ctx *ctx)
 
 void prof_begin(mlh_ctx *ctx, int id)
 {
-    if (!ctx->prof.on) return;
+    if (!(ctx->prof.mask & (1u << id))) return;
     Profile::Pending pd;
     pd.id = id; pd.a = prof_event(ctx); pd.b = nullptr;
     (void)hipEventRecord(pd.a, ctx->stream);
@@ -36,7 +36,7 @@ void prof_begin(mlh_ctx *ctx, int id)
 
 void prof_end(mlh_ctx *ctx, int id)
 {
-    if (!ctx->prof.on || ctx->prof.pending.empty()) return;
+    if (!(ctx->prof.mask & (1u << id)) || ctx->prof.pending.empty()) return;
     Profile::Pending &pd = ctx->prof.pending.back();
     if (pd.id != id || pd.b) return;
     pd.b = prof_event(ctx);
@@ -168,13 +168,14 @@ void mlh_destroy(mlh_ctx *ctx)
         MapGrid &m = ctx->map[k];
         m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release();
         FeatSet &f = ctx->feat[k];
-        f.pts.release(); f.covd.release(); f.corr.release(); f.r.release(); f.J.release(); f.partials.release();
+        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release(); f.partials.release();
     }
     ScanBuf &s = ctx->scan;
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     ctx->state.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
+    comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -190,10 +191,10 @@ int mlh_synchronize(mlh_ctx *ctx)
     return MLH_OK;
 }
 
-int mlh_profile_enable(mlh_ctx *ctx, int on)
+int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask)
 {
     if (!ctx) return MLH_ERR_INVALID;
-    ctx->prof.on = on != 0;
+    ctx->prof.mask = unsigned(kernel_mask) & ((1u << MLH_K_COUNT) - 1u);
     return MLH_OK;
 }
 
@@ -390,7 +391,7 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
     a.kind = kind; a.flags = flags; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
     if ((rc = match_launch(ctx, a))) return rc;
-    if ((rc = reduce_only_launch(ctx, 1 << kind))) return rc;
+    if ((rc = reduce_only_launch(ctx, 1 << kind, 0))) return rc;
     return fetch_dense_and_reduced(ctx, kind, true, valid, coeffs, r, J, JtJ, Jtr, cost, n_valid);
 }
 
@@ -407,7 +408,7 @@ int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, 
     a.kind = kind; a.flags = flags; a.min_match_sq_dis = 0.f; a.min_plane_dis = 0.f;
     a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
     if ((rc = linearize_launch(ctx, a))) return rc;
-    if ((rc = reduce_only_launch(ctx, 1 << kind))) return rc;
+    if ((rc = reduce_only_launch(ctx, 1 << kind, 0))) return rc;
     return fetch_dense_and_reduced(ctx, kind, false, nullptr, nullptr, r, J, JtJ, Jtr, cost, n_valid);
 }
 

@@ -37,6 +37,7 @@ struct SolverState {
     double cand[7];          // candidate pose (LM)
     double V[36];            // PoseLocalParameterization::V_update_
     double ne[NE_STRIDE];    // normal equations at x
+    double ce[NE_STRIDE];    // normal equations at cand (multi-GPU: all-reduced before lm_step consumes them)
     double diag[6];          // LM diagonal (Jacobi-scaled)
     double S[6];             // Jacobi scaling 1/(1+sqrt(H_ii)) from iteration zero
     double radius, decrease_factor;
@@ -99,6 +100,7 @@ struct FeatSet {
     DevBuf pts;        // float4 {x,y,z,intensity}
     DevBuf covd;       // float4 {cxx, cyy, czz, 0}  (diagonal of the f32 cov_vec)
     DevBuf corr;       // Corr per feature
+    DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
     DevBuf partials;   // NE_STRIDE doubles per block
     int m = 0;
@@ -122,7 +124,7 @@ struct ScanBuf {
 };
 
 struct Profile {
-    bool on = false;
+    unsigned mask = 0;     // bit k: bracket launches of kernel id k
     double total_ms[MLH_K_COUNT] = {0};
     long long launches[MLH_K_COUNT] = {0};
     struct Pending { int id; hipEvent_t a, b; };
@@ -143,6 +145,11 @@ struct mlh_ctx {
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
+    // multi-GPU
+    bool shard_lo = false, shard_hi = false;
+    float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
+    void *comm = nullptr;    // ncclComm_t
+    int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };
 
@@ -178,8 +185,11 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
 // solver.hip
-int reduce_only_launch(mlh_ctx *ctx, int kind_mask);
+int reduce_only_launch(mlh_ctx *ctx, int kind_mask, int to_ce);
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
+// comm.hip
+int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
+void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream
 int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot);
 int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot);
 int lm_finish_launch(mlh_ctx *ctx, int stat_slot);

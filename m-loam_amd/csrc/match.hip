@@ -1,23 +1,20 @@
 // Correspondence + linearisation kernels for gfx950 (the roofline kernels of the scan-to-map path).
 //
-// match_linearize_kernel<KIND, G>  -- per feature: pointAssociateToMap (utility.h:103-117) -> exact 5-NN in the local-map
-//   cell grid (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813) -> line fit (3x3 scatter + f32
-//   eigen-solver, hpp:669-783) or plane fit (5x3 column-pivoted QR, hpp:816-878) with the reference's gates -> residual and
-//   1x6 Jacobian of LidarMapEdgeFactor / LidarMapPlaneNormFactor (lidar_map_factor.hpp:44-71, 143-174) -> Huber
-//   correction (Ceres corrector, rho''<=0 branch) -> block reduction of the packed normal equations.
-// linearize_kernel<KIND>           -- the same evaluation on the correspondences stored by the match kernel
-//   (what ceres::Solve does per LM iteration).
-//
-// Work decomposition (wave = 64 lanes, workgroup = 256 threads = 256 features):
-//   phase 0  lane-per-feature: transform the feature into the map frame (f64 -> f32), stage in LDS
-//   phase 1  G lanes per feature (G = 8): the 9 x-runs of the 27-cell neighbourhood are scanned with consecutive lanes on
-//            consecutive float4 points (coalesced 16 B/lane), each lane keeps a sorted top-5 of 64-bit (dist,index) keys,
-//            the group merges with a 5-round shuffle tournament; the 5 neighbours are staged in LDS (stride 15 floats:
-//            conflict-free for the lane-per-feature reads of phase 2)
-//   phase 2  lane-per-feature: fit + gates + residual/Jacobian in registers, then wavefront-shuffle + LDS reduction of
-//            21+6+2 doubles per workgroup -> one partial record per workgroup (no atomics, deterministic).
-// blockIdx -> feature tile mapping is XCD-aware: consecutive tiles go to the same XCD (blockIdx % 8), so each XCD's L2
-// holds one contiguous eighth of the (spatially coherent) feature list's map neighbourhood.
+// knn_features_kernel        -- per feature: pointAssociateToMap (utility.h:103-117) -> exact 5-NN in the local-map cell grid
+//   (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813). 32 lanes (half a wavefront) per feature:
+//   lane = (x-run of the 27-cell neighbourhood, sub-lane), all 9 runs in flight at once, consecutive sub-lanes on
+//   consecutive float4 points; each lane keeps a sorted top-5 of 64-bit (distance bits, map index) keys, the group merges with
+//   a 5-round shuffle tournament; the 5 winners' coordinates + squared distances go to HBM (80 B/feature).
+//   HBM/L2-bound: ~(16 + 72 + 16*C + 80 + 80) bytes per feature, C = candidates in the 27 cells.
+// fit_linearize_kernel<KIND> -- one lane per feature: line fit (3x3 scatter + f32 eigen-solver, hpp:669-783) or plane fit
+//   (5x3 column-pivoted QR, hpp:816-878) with the reference's gates -> residual and 1x6 Jacobian of LidarMapEdgeFactor /
+//   LidarMapPlaneNormFactor (lidar_map_factor.hpp:44-71, 143-174) -> Huber correction (Ceres corrector, rho''<=0 branch)
+//   -> wavefront-shuffle + LDS reduction of the 21+6+2 packed normal-equation sums -> one partial record per workgroup
+//   (no atomics, deterministic).
+// linearize_kernel<KIND>     -- the same evaluation on the correspondences stored by the fit kernel (what ceres::Solve
+//   does per LM iteration).
+// blockIdx -> tile mapping is XCD-aware: consecutive tiles go to the same XCD (blockIdx % 8), so each XCD's L2 holds one
+// contiguous eighth of the (spatially coherent) feature list's map neighbourhood.
 #include "ctx.hpp"
 #include "dev_math.hpp"
 #include <cfloat>
@@ -55,44 +52,39 @@ __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int
     return fminf(fmaxf(f, -2.f), float(n + 1));   // also squashes NaN/inf before the int conversion
 }
 
-// exact 5-NN of (qx,qy,qz) by a group of G lanes; on return every lane of the group holds the 5 keys ascending.
-template <int G>
-__device__ __forceinline__ void knn5_group(const GridDev &g, float qx, float qy, float qz, int gl, unsigned long long (&out)[5])
+// exact 5-NN of (qx,qy,qz) by a group of 32 lanes (half a wavefront); on return every lane holds the 5 keys ascending.
+// Lane gl < 27 works on x-run r = gl / 3 of the 27-cell neighbourhood (the 3 x-adjacent cells of one (dy,dz) are one
+// contiguous range of the cell-sorted array) as sub-lane s = gl % 3: consecutive sub-lanes read consecutive float4 points.
+// All 9 runs are in flight at once, so a query costs ~3 dependent memory round trips (cell_start, candidates, neighbours).
+__device__ __forceinline__ void knn5_group32(const GridDev &g, float qx, float qy, float qz, int gl, unsigned long long (&out)[5])
 {
     unsigned long long k[5] = {KEY_INF, KEY_INF, KEY_INF, KEY_INF, KEY_INF};
     const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
     const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
     const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    constexpr int RPL = (9 + G - 1) / G;   // rows per lane
-    int rb[RPL], re[RPL];
-#pragma unroll
-    for (int s = 0; s < RPL; ++s) {
-        int r = gl + s * G;
-        int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
-        bool ok = (r < 9) && (x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz);
-        int row = ok ? (z * g.ny + y) * g.nx : 0;
-        rb[s] = ok ? g.cell_start[row + x0] : 0;
-        re[s] = ok ? g.cell_start[row + x1 + 1] : 0;
+    const int r = gl / 3, sl = gl - r * 3;
+    const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
+    const bool ok = (gl < 27) && (x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz);
+    int b = 0, e = 0;
+    if (ok) {
+        const int row = (z * g.ny + y) * g.nx;
+        b = g.cell_start[row + x0];
+        e = g.cell_start[row + x1 + 1];
     }
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int b = __shfl(rb[r / G], r % G, G);
-        const int e = __shfl(re[r / G], r % G, G);
-        for (int j = b + gl; j < e; j += 2 * G) {
-            const float4 p0 = g.sorted[j];
-            const bool h1 = (j + G) < e;
-            const float4 p1 = g.sorted[h1 ? j + G : j];
-            {
-                float dx = p0.x - qx, dy = p0.y - qy, dz = p0.z - qz;
-                float d = dx * dx; d += dy * dy; d += dz * dz;
-                key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p0.w));
-            }
-            if (h1) {
-                float dx = p1.x - qx, dy = p1.y - qy, dz = p1.z - qz;
-                float d = dx * dx; d += dy * dy; d += dz * dz;
-                key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p1.w));
-            }
+    for (int j = b + sl; j < e; j += 6) {
+        const float4 p0 = g.sorted[j];
+        const bool h1 = (j + 3) < e;
+        const float4 p1 = g.sorted[h1 ? j + 3 : j];
+        {
+            float dx = p0.x - qx, dy = p0.y - qy, dz = p0.z - qz;
+            float d = dx * dx; d += dy * dy; d += dz * dz;
+            key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p0.w));
+        }
+        if (h1) {
+            float dx = p1.x - qx, dy = p1.y - qy, dz = p1.z - qz;
+            float d = dx * dx; d += dy * dy; d += dz * dz;
+            key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p1.w));
         }
     }
     // tournament merge: 5 rounds of group-min over the lanes' current heads
@@ -100,7 +92,7 @@ __device__ __forceinline__ void knn5_group(const GridDev &g, float qx, float qy,
     for (int t = 0; t < 5; ++t) {
         unsigned long long m = k[0];
 #pragma unroll
-        for (int off = 1; off < G; off <<= 1) {
+        for (int off = 1; off < 32; off <<= 1) {
             unsigned long long o = shfl_xor_u64(m, off);
             m = o < m ? o : m;
         }
@@ -252,6 +244,7 @@ struct KParams {
     GridDev grid;
     const float4 *feat;      // {x,y,z,intensity}
     const float4 *covd;      // {cxx,cyy,czz,_} or null
+    float4 *nbr;             // 5 per feature: {x,y,z, sq-dist} of the k-th neighbour (w = +inf when missing)
     Corr *corr;
     double *r_out;           // nullable
     double *J_out;           // nullable
@@ -261,111 +254,123 @@ struct KParams {
     uint32_t flags;
     float min_match_sq_dis, min_plane_dis;
     double huber_delta, cov_measurement_trace;
+    int has_lo, has_hi;      // multi-GPU ownership half-spaces (mlh_shard_set)
+    float lo[4], hi[4];
 };
 
-template <int KIND, int G>
-__global__ __launch_bounds__(TPB) void match_linearize_kernel(KParams P)
+// pointAssociateToMap (utility.h:103-117): f64 q*p + t, stored to f32
+__device__ __forceinline__ void associate_to_map(const q4 &q, const d3 &t, const float4 &fp, float &sx, float &sy, float &sz)
 {
-    __shared__ float s_sel[TPB * 3];
-    __shared__ float s_nb[TPB * 15];
-    __shared__ float s_d5[TPB];
-    __shared__ double s_red[4 * 32];
+    d3 w = qrot(q, d3{double(fp.x), double(fp.y), double(fp.z)});
+    sx = float(w.x + t.x); sy = float(w.y + t.y); sz = float(w.z + t.z);
+}
+
+__device__ __forceinline__ bool owns(const KParams &P, float sx, float sy, float sz)
+{
+    bool own = true;
+    if (P.has_lo) own = own && ((((P.lo[0] * sx + P.lo[1] * sy) + P.lo[2] * sz) + P.lo[3]) >= 0.f);
+    if (P.has_hi) own = own && ((((P.hi[0] * sx + P.hi[1] * sy) + P.hi[2] * sz) + P.hi[3]) < 0.f);
+    return own;
+}
+
+// ---- correspondence kernel: 32 lanes per feature, 8 features per workgroup
+constexpr int KNN_FPB = TPB / 32;
+
+__global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
+{
     const int tile = xcd_tile(P.n_tiles);
     if (tile >= P.n_tiles) return;
-    const int tid = threadIdx.x;
-    const int f = tile * TPB + tid;
+    const int grp = threadIdx.x >> 5, gl = threadIdx.x & 31;
+    const int f = tile * KNN_FPB + grp;
+    if (f >= P.m) return;
     const double *pose = P.pose_sel ? P.state->cand : P.state->x;
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
-
-    // phase 0: pointAssociateToMap
-    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < P.m) {
-        fp = P.feat[f];
-        d3 w = qrot(q, d3{double(fp.x), double(fp.y), double(fp.z)});
-        s_sel[tid * 3 + 0] = float(w.x + t.x);
-        s_sel[tid * 3 + 1] = float(w.y + t.y);
-        s_sel[tid * 3 + 2] = float(w.z + t.z);
-    }
-    __syncthreads();
-
-    // phase 1: G lanes per feature
-    {
-        constexpr int NG = TPB / G;
-        const int grp = tid / G, gl = tid % G;
-        for (int it = 0; it < G; ++it) {
-            const int lf = it * NG + grp;                 // local feature handled by this group now
-            const bool act = (tile * TPB + lf) < P.m;     // uniform across the group
-            unsigned long long keys[5];
-            if (act) {
-                knn5_group<G>(P.grid, s_sel[lf * 3 + 0], s_sel[lf * 3 + 1], s_sel[lf * 3 + 2], gl, keys);
-#pragma unroll
-                for (int tt = 0; tt < 5; ++tt) {
-                    if ((tt % G) == gl) {
-                        const unsigned long long kk = keys[tt];
-                        if (kk != KEY_INF) {
-                            const float4 np = P.grid.raw[(unsigned)kk];
-                            s_nb[lf * 15 + tt * 3 + 0] = np.x;
-                            s_nb[lf * 15 + tt * 3 + 1] = np.y;
-                            s_nb[lf * 15 + tt * 3 + 2] = np.z;
-                        }
-                    }
-                }
-                if (gl == 0) s_d5[lf] = __uint_as_float((unsigned)(keys[4] >> 32));
-            }
+    const float4 fp = P.feat[f];
+    float sx, sy, sz;
+    associate_to_map(q, t, fp, sx, sy, sz);
+    if (!owns(P, sx, sy, sz)) return;     // uniform over the 32-lane group
+    unsigned long long keys[5];
+    knn5_group32(P.grid, sx, sy, sz, gl, keys);
+    if (gl < 5) {
+        unsigned long long kk = keys[0];
+        if (gl == 1) kk = keys[1]; else if (gl == 2) kk = keys[2]; else if (gl == 3) kk = keys[3]; else if (gl == 4) kk = keys[4];
+        float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
+        if (kk != KEY_INF) {
+            const float4 np = P.grid.raw[(unsigned)kk];
+            o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
         }
+        P.nbr[size_t(f) * 5 + gl] = o;
     }
-    __syncthreads();
+}
 
-    // phase 2: lane-per-feature fit + residual
+// ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature
+template <int KIND>
+__global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
+{
+    __shared__ double s_red[4 * 32];
+    const int tile = xcd_tile(P.n_tiles);
+    if (tile >= P.n_tiles) return;
+    const int f = tile * TPB + threadIdx.x;
+    const double *pose = P.pose_sel ? P.state->cand : P.state->x;
+    const q4 q{pose[3], pose[4], pose[5], pose[6]};
+    const d3 t{pose[0], pose[1], pose[2]};
     bool valid = false;
     Lin L;
     L.r = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (f < P.m && s_d5[tid] < P.min_match_sq_dis) {
-        float ax[5], ay[5], az[5];
+    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < P.m) {
+        fp = P.feat[f];
+        float sx, sy, sz;
+        associate_to_map(q, t, fp, sx, sy, sz);
+        if (owns(P, sx, sy, sz)) {
+            const float4 *nb = P.nbr + size_t(f) * 5;
+            const float4 n4 = nb[4];
+            if (n4.w < P.min_match_sq_dis) {     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
+                float ax[5], ay[5], az[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { ax[j] = s_nb[tid * 15 + j * 3 + 0]; ay[j] = s_nb[tid * 15 + j * 3 + 1]; az[j] = s_nb[tid * 15 + j * 3 + 2]; }
-        if (KIND == MLH_SURF) {
-            float nx, ny, nz;
-            plane_fit_qr_f<5>(ax, ay, az, nx, ny, nz);
-            float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-            float negative_OA_dot_norm = 1 / nn;
-            float z = nx * nx + ny * ny + nz * nz;
-            if (z > 0.f) { float s = sqrtf(z); nx /= s; ny /= s; nz /= s; }
-            bool plane_valid = true;
+                for (int j = 0; j < 4; ++j) { const float4 v = nb[j]; ax[j] = v.x; ay[j] = v.y; az[j] = v.z; }
+                ax[4] = n4.x; ay[4] = n4.y; az[4] = n4.z;
+                if (KIND == MLH_SURF) {
+                    float nx, ny, nz;
+                    plane_fit_qr_f<5>(ax, ay, az, nx, ny, nz);
+                    float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+                    float negative_OA_dot_norm = 1 / nn;
+                    float z = nx * nx + ny * ny + nz * nz;
+                    if (z > 0.f) { float s = sqrtf(z); nx /= s; ny /= s; nz /= s; }
+                    bool plane_valid = true;
 #pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (fabsf(nx * ax[j] + ny * ay[j] + nz * az[j] + negative_OA_dot_norm) > P.min_plane_dis) plane_valid = false;
-            if (plane_valid) {
-                coef[0] = nx; coef[1] = ny; coef[2] = nz; coef[3] = negative_OA_dot_norm;
-                valid = true;
-            }
-        } else {
-            float cx = 0.f, cy = 0.f, cz = 0.f;
+                    for (int j = 0; j < 5; ++j)
+                        if (fabsf(nx * ax[j] + ny * ay[j] + nz * az[j] + negative_OA_dot_norm) > P.min_plane_dis) plane_valid = false;
+                    if (plane_valid) {
+                        coef[0] = nx; coef[1] = ny; coef[2] = nz; coef[3] = negative_OA_dot_norm;
+                        valid = true;
+                    }
+                } else {
+                    float cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
-            cx /= 5.0f; cy /= 5.0f; cz /= 5.0f;
-            float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+                    for (int j = 0; j < 5; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
+                    cx /= 5.0f; cy /= 5.0f; cz /= 5.0f;
+                    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                float t0 = ax[j] - cx, t1 = ay[j] - cy, t2 = az[j] - cz;
-                c00 += t0 * t0; c10 += t1 * t0; c11 += t1 * t1; c20 += t2 * t0; c21 += t2 * t1; c22 += t2 * t2;
-            }
-            float l0, l1, l2, vx, vy, vz;
-            eig3_largest_f(c00, c10, c11, c20, c21, c22, l0, l1, l2, vx, vy, vz);
-            if (l2 > 3 * l1) {
-                coef[0] = 0.1f * vx + cx; coef[1] = 0.1f * vy + cy; coef[2] = 0.1f * vz + cz;
-                coef[3] = -0.1f * vx + cx; coef[4] = -0.1f * vy + cy; coef[5] = -0.1f * vz + cz;
-                valid = true;
+                    for (int j = 0; j < 5; ++j) {
+                        float t0 = ax[j] - cx, t1 = ay[j] - cy, t2 = az[j] - cz;
+                        c00 += t0 * t0; c10 += t1 * t0; c11 += t1 * t1; c20 += t2 * t0; c21 += t2 * t1; c22 += t2 * t2;
+                    }
+                    float l0, l1, l2, vx, vy, vz;
+                    eig3_largest_f(c00, c10, c11, c20, c21, c22, l0, l1, l2, vx, vy, vz);
+                    if (l2 > 3 * l1) {
+                        coef[0] = 0.1f * vx + cx; coef[1] = 0.1f * vy + cy; coef[2] = 0.1f * vz + cz;
+                        coef[3] = -0.1f * vx + cx; coef[4] = -0.1f * vy + cy; coef[5] = -0.1f * vz + cz;
+                        valid = true;
+                    }
+                }
+                if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
             }
         }
-        if (valid && (P.flags & MLH_FLAG_CHECK_FOV))
-            valid = in_laser_fov(q, t, s_sel[tid * 3 + 0], s_sel[tid * 3 + 1], s_sel[tid * 3 + 2]);
-    }
-    if (f < P.m) {
         Corr c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) c.c[i] = coef[i];
@@ -439,16 +444,15 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, s_red, P.partials + size_t(tile) * NE_STRIDE);
 }
 
-template <int G>
-__global__ __launch_bounds__(TPB) void knn_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
-                                                  float *__restrict__ d2)
+// stand-alone exact 5-NN for mlh_knn (queries already in the map frame)
+__global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
+                                                          float *__restrict__ d2)
 {
-    constexpr int NG = TPB / G;
-    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int qi = blockIdx.x * NG + grp;
+    const int grp = threadIdx.x >> 5, gl = threadIdx.x & 31;
+    const int qi = blockIdx.x * KNN_FPB + grp;
     if (qi >= nq) return;
     unsigned long long keys[5];
-    knn5_group<G>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, keys);
+    knn5_group32(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, keys);
     if (gl == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -469,6 +473,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     const int n_tiles = (fs.m + TPB - 1) / TPB;
     hipError_t e;
     if ((e = fs.corr.ensure(sizeof(Corr) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc corr", e);
+    if ((e = fs.nbr.ensure(sizeof(float4) * 5 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc nbr", e);
     if ((e = fs.partials.ensure(sizeof(double) * NE_STRIDE * size_t(n_tiles))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
     if (a.dense) {
         if ((e = fs.r.ensure(sizeof(double) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc r", e);
@@ -479,6 +484,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.feat = fs.pts.as<float4>();
     P.covd = fs.has_cov ? fs.covd.as<float4>() : nullptr;
     P.corr = fs.corr.as<Corr>();
+    P.nbr = fs.nbr.as<float4>();
     P.r_out = a.dense ? fs.r.as<double>() : nullptr;
     P.J_out = a.dense ? fs.J.as<double>() : nullptr;
     P.partials = fs.partials.as<double>();
@@ -491,6 +497,9 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.min_plane_dis = a.min_plane_dis;
     P.huber_delta = a.huber_delta;
     P.cov_measurement_trace = a.cov_measurement_trace;
+    P.has_lo = ctx->shard_lo ? 1 : 0;
+    P.has_hi = ctx->shard_hi ? 1 : 0;
+    for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     return MLH_OK;
 }
 
@@ -502,11 +511,18 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     // the cell edge was derived from the acceptance radius given at map_set; a larger radius here would break exactness
     const MapGrid &mg = ctx->map[a.kind];
     if (std::sqrt(a.min_match_sq_dis) > mg.h) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis exceeds the value the map grid was built for");
-    const int grid = ((P.n_tiles + 7) / 8) * 8;
-    prof_begin(ctx, MLH_K_MATCH);
-    if (a.kind == MLH_SURF) hipLaunchKernelGGL((match_linearize_kernel<MLH_SURF, 8>), dim3(grid), dim3(TPB), 0, ctx->stream, P);
-    else hipLaunchKernelGGL((match_linearize_kernel<MLH_CORNER, 8>), dim3(grid), dim3(TPB), 0, ctx->stream, P);
-    prof_end(ctx, MLH_K_MATCH);
+    // kernel A: correspondences (32 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
+    KParams PA = P;
+    PA.n_tiles = (P.m + KNN_FPB - 1) / KNN_FPB;
+    const int grid_a = ((PA.n_tiles + 7) / 8) * 8;
+    const int grid_b = ((P.n_tiles + 7) / 8) * 8;
+    prof_begin(ctx, a.kind == MLH_SURF ? MLH_K_KNN_SURF : MLH_K_KNN_CORNER);
+    hipLaunchKernelGGL(knn_features_kernel, dim3(grid_a), dim3(TPB), 0, ctx->stream, PA);
+    prof_end(ctx, a.kind == MLH_SURF ? MLH_K_KNN_SURF : MLH_K_KNN_CORNER);
+    prof_begin(ctx, a.kind == MLH_SURF ? MLH_K_FIT_SURF : MLH_K_FIT_CORNER);
+    if (a.kind == MLH_SURF) hipLaunchKernelGGL((fit_linearize_kernel<MLH_SURF>), dim3(grid_b), dim3(TPB), 0, ctx->stream, P);
+    else hipLaunchKernelGGL((fit_linearize_kernel<MLH_CORNER>), dim3(grid_b), dim3(TPB), 0, ctx->stream, P);
+    prof_end(ctx, a.kind == MLH_SURF ? MLH_K_FIT_SURF : MLH_K_FIT_CORNER);
     MLH_HIP(ctx, hipGetLastError());
     ctx->feat[a.kind].matched = true;
     return MLH_OK;
@@ -536,9 +552,8 @@ int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx
     MLH_HIP(ctx, ctx->knn_idx.ensure(sizeof(int) * 5 * size_t(nq)));
     MLH_HIP(ctx, ctx->knn_d.ensure(sizeof(float) * 5 * size_t(nq)));
     MLH_HIP(ctx, hipMemcpyAsync(ctx->knn_q.p, q_host, sizeof(float) * 3 * size_t(nq), hipMemcpyHostToDevice, ctx->stream));
-    constexpr int G = 8;
-    const int grid = (nq + (TPB / G) - 1) / (TPB / G);
-    hipLaunchKernelGGL((knn_kernel<G>), dim3(grid), dim3(TPB), 0, ctx->stream, mg.dev(), ctx->knn_q.as<float>(), nq,
+    const int grid = (nq + KNN_FPB - 1) / KNN_FPB;
+    hipLaunchKernelGGL(knn_queries_kernel, dim3(grid), dim3(TPB), 0, ctx->stream, mg.dev(), ctx->knn_q.as<float>(), nq,
                        ctx->knn_idx.as<int>(), ctx->knn_d.as<float>());
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(idx, ctx->knn_idx.p, sizeof(int) * 5 * size_t(nq), hipMemcpyDeviceToHost, ctx->stream));

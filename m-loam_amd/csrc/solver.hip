@@ -37,12 +37,32 @@ __device__ void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, do
         if (c == NE_CNT) { cnt2[0] = t0; cnt2[1] = t1; }
     }
     __syncthreads();
+    if (threadIdx.x == 0) { ne[NE_CNT + 1] = cnt2[0]; ne[NE_CNT + 2] = cnt2[1]; }
+    __syncthreads();
 }
 
-__device__ inline void unpack_H(const double *ne, double *H)
+// either sum this rank's partials, or (multi-GPU) take the already all-reduced record from the solver state
+__device__ void gather_ne(const SumArgs &a, const SolverState *S, int pre_reduced, double *ne, double *cnt2, double *scratch)
 {
-    int q = 0;
-    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { H[i * 6 + j] = ne[q]; H[j * 6 + i] = ne[q]; ++q; }
+    if (pre_reduced) {
+        if (threadIdx.x < NE_STRIDE) ne[threadIdx.x] = S->ne[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) { cnt2[0] = ne[NE_CNT + 1]; cnt2[1] = ne[NE_CNT + 2]; }
+        __syncthreads();
+    } else {
+        sum_partials(a, ne, cnt2, scratch);
+    }
+}
+
+__device__ __forceinline__ void unpack_H(const double *ne, double (&H)[36])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            const int q = i * 6 - (i * (i - 1)) / 2 + (j - i);   // packed upper-triangular index
+            H[i * 6 + j] = ne[q]; H[j * 6 + i] = ne[q];
+        }
 }
 
 // cyclic Jacobi, eigenvalues ascending, eigenvectors in the columns of V (row-major 6x6)
@@ -92,7 +112,7 @@ __device__ void jacobi6(const double *Hin, double *ev, double *V)
 
 // evalDegenracy: zero the eigenvectors below the threshold (ascending, stop at the first one above),
 // V_update = (V_f^T)^-1 V_p^T = V_f V_p^T for orthonormal V_f; identity when nothing is degenerate.
-__device__ bool eval_degeneracy_dev(const double *H, double thre, double *ev, double *Vupd)
+__device__ __noinline__ bool eval_degeneracy_dev(const double *H, double thre, double *ev, double *Vupd)
 {
     double Vf[36];
     jacobi6(H, ev, Vf);
@@ -112,34 +132,72 @@ __device__ bool eval_degeneracy_dev(const double *H, double thre, double *ev, do
     return deg;
 }
 
-__device__ bool chol6_solve(const double *A, const double *b, double *x)
+// Cholesky factor / solve of a 6x6 SPD system, fully unrolled so that A, L, y live in registers (no scratch).
+__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36])
 {
-    double L[36];
-    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double s = A[j * 6 + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
-        if (!(s > 0.0)) return false;
-        double ljj = sqrt(s);
+        ok = ok && (s > 0.0);
+        const double ljj = sqrt(s);
         L[j * 6 + j] = ljj;
+#pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = A[i * 6 + j];
+#pragma unroll
             for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
             L[i * 6 + j] = t / ljj;
         }
     }
+    return ok;
+}
+
+__device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
+{
+    double L[36];
+    if (!chol6_factor(A, L)) return false;
     double y[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
         y[i] = s / L[i * 6 + i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
+#pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
         x[i] = s / L[i * 6 + i];
     }
     return true;
+}
+
+// evalDegenracy with a fast path: H - thre*I positive definite  <=>  lambda_min > thre  =>  nothing is degenerate and
+// V_update = I; the eigen-decomposition is only run when that test fails or when the eigenvalues are wanted for the
+// per-iteration record (the reference logs them, lidar_mapper_keyframe.cpp:1190-1193).
+__device__ bool degeneracy(const double (&H)[36], double thre, bool need_eig, double (&ev)[6], double (&Vupd)[36])
+{
+    if (!need_eig) {
+        double A[36], L[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A[i] = H[i];
+        const double sh = thre * (1.0 + 1e-9);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i * 6 + i] -= sh;
+        if (chol6_factor(A, L)) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) Vupd[i] = ((i % 7) == 0) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ev[i] = 0.0;
+            return false;
+        }
+    }
+    return eval_degeneracy_dev(H, thre, ev, Vupd);
 }
 
 __device__ void write_stat_common(IterStatDev *st, const double *ne, const double *cnt2, const double *H, const double *ev, bool deg)
@@ -152,26 +210,30 @@ __device__ void write_stat_common(IterStatDev *st, const double *ne, const doubl
     for (int i = 0; i < 36; ++i) st->H[i] = H[i];
 }
 
-__global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState *S, double eig_thre, IterStatDev *stat)
+__global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState *S, double eig_thre, IterStatDev *stat, int pre_reduced)
 {
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
-    sum_partials(sa, ne, cnt2, scratch);
+    gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
     double H[36], ev[6], V[36];
     unpack_H(ne, H);
-    bool deg = eval_degeneracy_dev(H, eig_thre, ev, V);
+    const bool deg = degeneracy(H, eig_thre, stat != nullptr, ev, V);
     double rhs[6], d[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
     bool ok = chol6_solve(H, rhs, d);
     if (!ok) {
         double Hd[36];
-        for (int i = 0; i < 36; ++i) Hd[i] = H[i];
-        for (int i = 0; i < 6; ++i) Hd[i * 6 + i] += 1e-6;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) Hd[i] = H[i] + (((i % 7) == 0) ? 1e-6 : 0.0);
         ok = chol6_solve(Hd, rhs, d);
     }
     if (ok) {
-        double xn[7];
-        pose_plus(S->x, d, V, xn);
+        double xc[7], xn[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xc[i] = S->x[i];
+        pose_plus(xc, d, V, xn);
+#pragma unroll
         for (int i = 0; i < 7; ++i) S->x[i] = xn[i];
     }
     for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
@@ -185,11 +247,11 @@ __global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState 
 }
 
 // reduce only: S->ne <- sum of partials (used by the host-driven mlh_match_linearize / mlh_linearize)
-__global__ __launch_bounds__(256) void reduce_only_kernel(SumArgs sa, SolverState *S)
+__global__ __launch_bounds__(256) void reduce_only_kernel(SumArgs sa, SolverState *S, int to_ce)
 {
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
     sum_partials(sa, ne, cnt2, scratch);
-    if (threadIdx.x < NE_STRIDE) S->ne[threadIdx.x] = ne[threadIdx.x];
+    if (threadIdx.x < NE_STRIDE) (to_ce ? S->ce : S->ne)[threadIdx.x] = ne[threadIdx.x];
 }
 
 // ---------------------------------------------------------------- Levenberg-Marquardt (Ceres trust-region semantics)
@@ -252,10 +314,10 @@ __device__ void lm_propose(SolverState *S, int max_it)
     }
 }
 
-__global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat)
+__global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat, int pre_reduced)
 {
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
-    sum_partials(sa, ne, cnt2, scratch);
+    gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
     double H[36], ev[6], V[36];
     unpack_H(ne, H);
@@ -273,11 +335,16 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *
     lm_propose(S, max_it);
 }
 
-__global__ __launch_bounds__(256) void lm_step_kernel(SumArgs sa, SolverState *S, int max_it)
+__global__ __launch_bounds__(256) void lm_step_kernel(SumArgs sa, SolverState *S, int max_it, int pre_reduced)
 {
     __shared__ double ce[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
     if (S->done) return;
-    sum_partials(sa, ce, cnt2, scratch);
+    if (pre_reduced) {
+        if (threadIdx.x < NE_STRIDE) ce[threadIdx.x] = S->ce[threadIdx.x];
+        __syncthreads();
+    } else {
+        sum_partials(sa, ce, cnt2, scratch);
+    }
     if (threadIdx.x != 0) return;
     S->evaluations++;
     double step_norm = 0.0, x_norm = 0.0;
@@ -332,18 +399,32 @@ static IterStatDev *stat_ptr(mlh_ctx *ctx, int slot)
     return slot >= 0 ? ctx->stats.as<IterStatDev>() + slot : nullptr;
 }
 
-int reduce_only_launch(mlh_ctx *ctx, int kind_mask)
+int reduce_only_launch(mlh_ctx *ctx, int kind_mask, int to_ce)
 {
-    hipLaunchKernelGGL(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, kind_mask), ctx->state.as<SolverState>());
+    hipLaunchKernelGGL(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, kind_mask), ctx->state.as<SolverState>(), to_ce);
     MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+// multi-GPU: local reduce -> one all-reduce of the 32-double record -> the update kernel consumes the reduced record
+static int pre_reduce(mlh_ctx *ctx, int to_ce, int &pre_reduced)
+{
+    pre_reduced = 0;
+    if (!ctx->comm) return MLH_OK;
+    int rc = reduce_only_launch(ctx, 3, to_ce);
+    if (rc) return rc;
+    if ((rc = comm_allreduce_state(ctx, to_ce))) return rc;
+    pre_reduced = 1;
     return MLH_OK;
 }
 
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
 {
+    int pre = 0, rc = pre_reduce(ctx, 0, pre);
+    if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
     hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(),
-                       map_eig_thre, stat_ptr(ctx, stat_slot));
+                       map_eig_thre, stat_ptr(ctx, stat_slot), pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -351,9 +432,11 @@ int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
 
 int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot)
 {
+    int pre = 0, rc = pre_reduce(ctx, 0, pre);
+    if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
     hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(),
-                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot));
+                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -362,8 +445,10 @@ int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int s
 int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot)
 {
     (void)stat_slot;
+    int pre = 0, rc = pre_reduce(ctx, 1, pre);
+    if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(), max_iterations);
+    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(), max_iterations, pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
