@@ -1,0 +1,97 @@
+// Exercises the C++ facade end to end on binary inputs written by the python test harness (tests/test_gpu_facade.py):
+//   <dir>/scan.f32 (n x 4), <dir>/rings.i32 (2 x n_rings: starts then ends), <dir>/surf_map.f32, <dir>/corner_map.f32 (n x 3),
+//   <dir>/surf.f32, <dir>/corner.f32 (m x 4: x y z lidar-id), <dir>/pose.f64 (7)
+// and writes <dir>/out_labels.i32, <dir>/out_pose.f64 (7), <dir>/out_counts.i32 (per outer: n_surf, n_corner, lm_iterations),
+// <dir>/out_valid_surf.u8 (batch matchSurfFromMap at the initial pose).
+#include "mloam_facade.hpp"
+#include <cstdio>
+#include <fstream>
+
+using namespace mloam_hip;
+
+template <typename T>
+static std::vector<T> read_file(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw Error("cannot open " + path);
+    size_t bytes = (size_t)f.tellg();
+    std::vector<T> v(bytes / sizeof(T));
+    f.seekg(0);
+    f.read(reinterpret_cast<char *>(v.data()), bytes);
+    return v;
+}
+template <typename T>
+static void write_file(const std::string &path, const std::vector<T> &v)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(v.data()), sizeof(T) * v.size());
+}
+
+static PointICovCloud cov_cloud(const std::vector<float> &a, int cols)
+{
+    PointICovCloud c;
+    for (size_t i = 0; i + cols <= a.size(); i += cols) {
+        PointIWithCov p;
+        p.x = a[i]; p.y = a[i + 1]; p.z = a[i + 2];
+        p.intensity = cols > 3 ? a[i + 3] : 0.f;
+        c.push_back(p);
+    }
+    return c;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 2; }
+    const std::string d = std::string(argv[1]) + "/";
+    try {
+        Device dev(0);
+        // --- extractCloud
+        auto scan = read_file<float>(d + "scan.f32");
+        auto rings = read_file<int>(d + "rings.i32");
+        const int n_rings = (int)rings.size() / 2;
+        PointICloud cloud;
+        for (size_t i = 0; i + 4 <= scan.size(); i += 4) { PointI p; p.x = scan[i]; p.y = scan[i + 1]; p.z = scan[i + 2]; p.intensity = scan[i + 3]; cloud.push_back(p); }
+        ScanInfo info(n_rings, false);
+        for (int r = 0; r < n_rings; ++r) { info.scan_start_ind_[r] = rings[r]; info.scan_end_ind_[r] = rings[n_rings + r]; }
+        FeatureExtract f_extract(dev);
+        cloudFeature cf;
+        f_extract.extractCloud(cloud, info, cf);
+        write_file(d + "out_labels.i32", f_extract.cloudLabel());
+        std::printf("extract: sharp %zu less_sharp %zu flat %zu less_flat %zu\n", cf["corner_points_sharp"].size(),
+                    cf["corner_points_less_sharp"].size(), cf["surf_points_flat"].size(), cf["surf_points_less_flat"].size());
+        // --- batch matching through the FeatureExtract signature
+        PointICovCloud surf_map = cov_cloud(read_file<float>(d + "surf_map.f32"), 3), corner_map = cov_cloud(read_file<float>(d + "corner_map.f32"), 3);
+        PointICovCloud surf = cov_cloud(read_file<float>(d + "surf.f32"), 4), corner = cov_cloud(read_file<float>(d + "corner.f32"), 4);
+        auto pv = read_file<double>(d + "pose.f64");
+        Pose pose;
+        pose.fromParam(pv.data());
+        MapIndex<PointIWithCov> kd_surf(dev, MLH_SURF);
+        kd_surf.setInputCloud(surf_map);
+        std::vector<PointPlaneFeature> feats;
+        f_extract.matchSurfFromMap(kd_surf, surf_map, surf, pose, feats, 5, false);
+        std::vector<uint8_t> valid(surf.size(), 0);
+        for (const auto &f : feats) valid[f.idx_] = 1;
+        write_file(d + "out_valid_surf.u8", valid);
+        std::printf("matchSurfFromMap: %zu of %zu\n", feats.size(), surf.size());
+        // --- scan2MapOptimization
+        Scan2MapReport rep;
+        scan2MapOptimization(dev, surf_map, corner_map, surf, corner, pose, false, &rep);
+        double out[7];
+        pose.toParam(out);
+        write_file(d + "out_pose.f64", std::vector<double>(out, out + 7));
+        std::vector<int> counts;
+        for (const auto &s : rep.outer) { counts.push_back(s.n_surf); counts.push_back(s.n_corner); counts.push_back(s.lm_iterations); }
+        write_file(d + "out_counts.i32", counts);
+        std::printf("scan2map pose: %.9f %.9f %.9f  %.9f %.9f %.9f %.9f\n", out[0], out[1], out[2], out[3], out[4], out[5], out[6]);
+        // --- PoseLocalParameterization sanity
+        PoseLocalParameterization lp;
+        lp.setParameter();
+        double dx[6] = {0.01, 0, 0, 0, 0, 0.02}, xp[7];
+        lp.Plus(out, dx, xp);
+        std::printf("plus ok %d\n", (int)(xp[0] > out[0]));
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "facade_selftest failed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,355 @@
+// C++ facade over the C-ABI (include/mloam_hip.h) that keeps M-LOAM's host-side API surface for the scan-to-map hot path,
+// so the mapper / estimator sources can switch to the MI355X path by swapping includes.
+//
+// Mirrored reference interfaces (names, argument meaning, output ordering and error behaviour):
+//   FeatureExtract::extractCloud / match{Surf,Corner}FromMap / match{Surf,Corner}PointFromMap
+//                                         estimator/src/featureExtract/feature_extract.hpp:56-128
+//   pcl::KdTreeFLANN<PointT>::setInputCloud (the object handed to the match functions)     lidar_mapper_keyframe.cpp:433-434
+//   PointPlaneFeature, ScanInfo, cloudFeature                                              estimator/src/estimator/parameters.h:161-207
+//   Pose (q_, t_)                                                                           estimator/src/estimator/pose.h:38-66
+//   PoseLocalParameterization {Plus, ComputeJacobian, GlobalSize, LocalSize, setParameter, is_degenerate_, V_update_}
+//                                         estimator/src/factor/pose_local_parameterization.h:21-32
+//   evalDegenracy(mat_H, local_parameterization)                                            lidar_mapper_keyframe.cpp:1172-1204
+//   scan2MapOptimization()                                                                  lidar_mapper_keyframe.cpp:423-639
+//   ceres::CostFunction::Evaluate(double const* const*, double*, double**) for the map factors  lidar_map_factor.hpp:44,143
+//
+// The image this was developed in has no PCL / Eigen / Ceres, so the few types the signatures need are declared here with the
+// reference's field names and memory layout (pcl::PointXYZI is 32 bytes, pcl::PointXYZIWithCov 48 bytes); inside the
+// reference tree, define MLOAM_FACADE_USE_PCL_TYPES and the real headers' types are used instead (same layouts).
+// All heavy work goes through libmloam_hip.so; this header contains no numerical fallback.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mloam_hip.h"
+
+namespace mloam_hip {
+
+// ------------------------------------------------------------------ point / cloud types (layout-compatible stand-ins)
+#ifndef MLOAM_FACADE_USE_PCL_TYPES
+struct alignas(16) PointI {           // pcl::PointXYZI: float data[4]; float intensity; pad[3]  -> 32 bytes
+    float x = 0, y = 0, z = 0, pad_ = 1.f;
+    float intensity = 0, pad2_[3] = {0, 0, 0};
+};
+struct alignas(16) PointIWithCov {    // pcl::PointXYZIWithCov (mloam_pcl/point_with_cov.hpp:45-53) -> 48 bytes
+    float x = 0, y = 0, z = 0, pad_ = 1.f;
+    float intensity = 0;
+    float cov_vec[6] = {0, 0, 0, 0, 0, 0};   // cxx cxy cxz cyy cyz czz
+    float cov_trace = 0;
+};
+template <typename PointT>
+struct PointCloud {
+    std::vector<PointT> points;
+    size_t size() const { return points.size(); }
+    void push_back(const PointT &p) { points.push_back(p); }
+    void clear() { points.clear(); }
+    const PointT &operator[](size_t i) const { return points[i]; }
+    PointT &operator[](size_t i) { return points[i]; }
+};
+#endif
+static_assert(sizeof(PointI) == 32, "pcl::PointXYZI layout");
+static_assert(sizeof(PointIWithCov) == 48, "pcl::PointXYZIWithCov layout");
+typedef PointCloud<PointI> PointICloud;
+typedef PointCloud<PointIWithCov> PointICovCloud;
+typedef std::map<std::string, PointICloud> cloudFeature;   // parameters.h:161
+
+template <typename PointT> struct point_traits;
+template <> struct point_traits<PointI> { static constexpr int intensity_off = 16, cov_off = -1; };
+template <> struct point_traits<PointIWithCov> { static constexpr int intensity_off = 16, cov_off = 20; };
+
+struct Quat { double w = 1, x = 0, y = 0, z = 0; };       // Eigen::Quaterniond accessor order w,x,y,z
+struct Vec3 { double v[3] = {0, 0, 0}; double &operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
+
+class Pose {                                              // pose.h:38-66 (q_, t_ only: what the hot path reads)
+public:
+    Quat q_;
+    Vec3 t_;
+    std::array<double, 36> cov_{};                        // pose_wmap_curr.cov_ = cov_mapping (cpp:631)
+    void toParam(double p[7]) const { p[0] = t_(0); p[1] = t_(1); p[2] = t_(2); p[3] = q_.x; p[4] = q_.y; p[5] = q_.z; p[6] = q_.w; }
+    void fromParam(const double p[7]) { t_(0) = p[0]; t_(1) = p[1]; t_(2) = p[2]; q_.x = p[3]; q_.y = p[4]; q_.z = p[5]; q_.w = p[6]; }
+};
+
+class PointPlaneFeature {                                 // parameters.h:163-175
+public:
+    PointPlaneFeature() : idx_(0), laser_idx_(0), type_('n') {}
+    size_t idx_, laser_idx_;
+    std::array<double, 3> point_{};
+    std::vector<double> coeffs_;                          // Eigen::VectorXd: 4 for 's', 6 for 'c'
+    std::vector<double> jaco_;                            // 1x6
+    char type_;
+};
+
+class ScanInfo {                                          // parameters.h:193-207
+public:
+    ScanInfo(const int &n_scan, const bool &segment_flag) : segment_flag_(segment_flag) { scan_start_ind_.resize(n_scan); scan_end_ind_.resize(n_scan); }
+    std::vector<int> scan_start_ind_, scan_end_ind_;
+    bool segment_flag_;
+    std::vector<bool> ground_flag_;
+};
+
+// hot-path globals of parameters.h that the match functions read (MIN_MATCH_SQ_DIS, MIN_PLANE_DIS, ...)
+struct Params {
+    float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;
+    double MAP_EIG_THRE = 100.0, HUBER_DELTA = 0.1, COV_MEASUREMENT_TRACE = 0.0075;
+    int N_SCANS = 16;
+};
+inline Params &params() { static Params p; return p; }
+
+class Error : public std::runtime_error { public: using std::runtime_error::runtime_error; };
+
+// ------------------------------------------------------------------ one device context (RAII)
+class Device {
+public:
+    explicit Device(int device_id = 0)
+    {
+        int rc = mlh_create(&ctx_, device_id);
+        if (rc != MLH_OK) throw Error("mlh_create failed: no usable MI355X / HIP device (the product path has no CPU fallback)");
+    }
+    ~Device() { mlh_destroy(ctx_); }
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    mlh_ctx *ctx() const { return ctx_; }
+    void check(int rc) const { if (rc != MLH_OK) throw Error(std::string("mloam_hip: ") + mlh_last_error(ctx_)); }
+private:
+    mlh_ctx *ctx_ = nullptr;
+};
+
+// ------------------------------------------------------------------ the "kd-tree" handed to the match functions
+// Mirrors pcl::KdTreeFLANN<PointT>: setInputCloud(cloud) (re)builds the index. kind selects which of the context's two
+// resident maps this object stands for (the mapper keeps kdtree_surf_from_map / kdtree_corner_from_map, cpp:59-62).
+template <typename PointT>
+class MapIndex {
+public:
+    MapIndex(Device &dev, int kind) : dev_(dev), kind_(kind) {}
+    void setInputCloud(const PointCloud<PointT> &cloud)
+    {
+        if (cloud.size() == 0) throw Error("setInputCloud: empty cloud");
+        dev_.check(mlh_map_set(dev_.ctx(), kind_, cloud.points.data(), (int)sizeof(PointT), (int)cloud.size(), params().MIN_MATCH_SQ_DIS, MLH_MEM_HOST));
+        n_ = cloud.size();
+    }
+    // nearestKSearch for k = 5 (feature_extract.hpp:666): indices into the cloud given to setInputCloud
+    int nearestKSearch(const PointT &p, int k, std::vector<int> &idx, std::vector<float> &sqd) const
+    {
+        idx.assign(k, -1); sqd.assign(k, 0.f);
+        const float q[3] = {p.x, p.y, p.z};
+        dev_.check(mlh_knn(dev_.ctx(), kind_, q, 1, k, idx.data(), sqd.data()));
+        int found = 0;
+        for (int i = 0; i < k; ++i) if (idx[i] >= 0) ++found;
+        return found;
+    }
+    Device &device() const { return dev_; }
+    int kind() const { return kind_; }
+    size_t size() const { return n_; }
+private:
+    Device &dev_;
+    int kind_;
+    size_t n_ = 0;
+};
+
+// ------------------------------------------------------------------ FeatureExtract
+class FeatureExtract {
+public:
+    explicit FeatureExtract(Device &dev) : dev_(dev) {}
+
+    // feature_extract.cpp:118-297. Output keys and ordering as the reference (cpp:281-285); "surf_points_less_flat" holds
+    // the label<=0 points BEFORE the per-ring 0.2 m VoxelGrid (cpp:266-271: the voxel thinning is a row of the "next" table).
+    // Re-entrancy: the reference calls this concurrently from NUM_OF_LASER OpenMP threads on one object
+    // (estimator.cpp:249-263); here use one FeatureExtract (one Device) per thread.
+    void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature)
+    {
+        const int n = (int)laser_cloud_in.size();
+        const int rings = (int)scan_info.scan_start_ind_.size();
+        dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), n, scan_info.scan_start_ind_.data(),
+                                   scan_info.scan_end_ind_.data(), rings, MLH_MEM_HOST));
+        dev_.check(mlh_extract_run(dev_.ctx()));
+        std::vector<int32_t> lists[4];
+        int32_t *ptrs[4];
+        int32_t counts[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) { lists[i].resize(n > 0 ? n : 1); ptrs[i] = lists[i].data(); }
+        labels_.resize(n);
+        dev_.check(mlh_extract_fetch(dev_.ctx(), labels_.data(), nullptr, nullptr, ptrs, counts));
+        cloud_feature.clear();
+        cloud_feature["laser_cloud"] = laser_cloud_in;
+        static const char *names[4] = {"corner_points_sharp", "corner_points_less_sharp", "surf_points_flat", "surf_points_less_flat"};
+        for (int i = 0; i < 4; ++i) {
+            PointICloud &c = cloud_feature[names[i]];
+            c.points.reserve(counts[i]);
+            for (int k = 0; k < counts[i]; ++k) c.push_back(laser_cloud_in.points[lists[i][k]]);
+        }
+    }
+    const std::vector<int32_t> &cloudLabel() const { return labels_; }   // cloud_label[] of the last extractCloud
+
+    // feature_extract.hpp:542-643 / 379-538: batch matching, matches compacted in input order
+    template <typename PointT>
+    void matchSurfFromMap(const MapIndex<PointT> &kdtree_surf_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
+                          const Pose &pose_local, std::vector<PointPlaneFeature> &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { matchFromMap(kdtree_surf_from_map, cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 's'); }
+
+    template <typename PointT>
+    void matchCornerFromMap(const MapIndex<PointT> &kdtree_corner_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
+                            const Pose &pose_local, std::vector<PointPlaneFeature> &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { matchFromMap(kdtree_corner_from_map, cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 'c'); }
+
+    // feature_extract.hpp:646-883: single-point versions (one-element batch; prefer the batch calls)
+    template <typename PointT>
+    bool matchSurfPointFromMap(const MapIndex<PointT> &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
+                               PointPlaneFeature &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { return matchPoint(kdtree, cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 's'); }
+
+    template <typename PointT>
+    bool matchCornerPointFromMap(const MapIndex<PointT> &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
+                                 PointPlaneFeature &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { return matchPoint(kdtree, cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 'c'); }
+
+private:
+    template <typename PointT>
+    void matchFromMap(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_data, const Pose &pose_local,
+                      std::vector<PointPlaneFeature> &features, size_t n_neigh, bool check_fov, char type)
+    {
+        features.clear();
+        const int m = (int)cloud_data.size();
+        if (m == 0) return;
+        Device &dev = kd.device();
+        dev.check(mlh_features_set(dev.ctx(), kd.kind(), cloud_data.points.data(), (int)sizeof(PointT), m, point_traits<PointT>::intensity_off,
+                                   point_traits<PointT>::cov_off, MLH_MEM_HOST));
+        double pose[7];
+        pose_local.toParam(pose);
+        std::vector<uint8_t> valid(m);
+        std::vector<double> coeffs(size_t(m) * 6), r(m), J(size_t(m) * 6);
+        const Params &P = params();
+        dev.check(mlh_match_linearize(dev.ctx(), kd.kind(), pose, (int)n_neigh, (check_fov ? MLH_FLAG_CHECK_FOV : 0u) | MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS,
+                                      P.MIN_MATCH_SQ_DIS, P.MIN_PLANE_DIS, 0.0, P.COV_MEASUREMENT_TRACE, valid.data(), coeffs.data(), r.data(), J.data(),
+                                      nullptr, nullptr, nullptr, nullptr));
+        for (int i = 0; i < m; ++i) {
+            if (!valid[i]) continue;
+            PointPlaneFeature f;
+            f.idx_ = i;
+            f.point_ = {double(cloud_data.points[i].x), double(cloud_data.points[i].y), double(cloud_data.points[i].z)};
+            f.coeffs_.assign(coeffs.begin() + size_t(i) * 6, coeffs.begin() + size_t(i) * 6 + (type == 's' ? 4 : 6));
+            f.jaco_.assign(J.begin() + size_t(i) * 6, J.begin() + size_t(i) * 6 + 6);   // what evaluateFeatJacobianMatching stores (lidar_mapper.h:162-164)
+            f.laser_idx_ = (size_t)cloud_data.points[i].intensity;
+            f.type_ = type;
+            features.push_back(f);
+        }
+    }
+    template <typename PointT>
+    bool matchPoint(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
+                    PointPlaneFeature &feature, size_t idx, size_t n_neigh, bool check_fov, char type)
+    {
+        PointCloud<PointT> one;
+        one.push_back(point_ori);
+        std::vector<PointPlaneFeature> out;
+        if (type == 's') matchSurfFromMap(kd, cloud_map, one, pose_local, out, n_neigh, check_fov);
+        else matchCornerFromMap(kd, cloud_map, one, pose_local, out, n_neigh, check_fov);
+        if (out.empty()) return false;
+        feature = out[0];
+        feature.idx_ = idx;
+        return true;
+    }
+    Device &dev_;
+    std::vector<int32_t> labels_;
+};
+
+// ------------------------------------------------------------------ PoseLocalParameterization (host side of the GN step)
+class PoseLocalParameterization {
+public:
+    bool Plus(const double *x, const double *delta, double *x_plus_delta) const { return mlh_pose_plus(x, delta, V_update_.data(), x_plus_delta) == MLH_OK; }
+    bool ComputeJacobian(const double * /*x*/, double *jacobian) const   // [I6; 0], row-major 7x6
+    {
+        std::memset(jacobian, 0, sizeof(double) * 42);
+        for (int i = 0; i < 6; ++i) jacobian[i * 6 + i] = 1.0;
+        return true;
+    }
+    int GlobalSize() const { return 7; }
+    int LocalSize() const { return 6; }
+    void setParameter()
+    {
+        is_degenerate_ = false;
+        V_update_.fill(0.0);
+        for (int i = 0; i < 6; ++i) V_update_[i * 6 + i] = 1.0;
+    }
+    bool is_degenerate_ = false;
+    std::array<double, 36> V_update_{};   // row-major 6x6
+};
+
+// lidar_mapper_keyframe.cpp:1172-1204
+inline void evalDegenracy(const std::array<double, 36> &mat_H, PoseLocalParameterization *local_parameterization, std::array<double, 6> *mat_E = nullptr)
+{
+    double ev[6], V[36];
+    int deg = mlh_eval_degeneracy(mat_H.data(), params().MAP_EIG_THRE, ev, V);
+    if (mat_E) std::memcpy(mat_E->data(), ev, sizeof(ev));
+    if (deg > 0) {
+        local_parameterization->is_degenerate_ = true;
+        std::memcpy(local_parameterization->V_update_.data(), V, sizeof(V));
+    }
+}
+
+// ------------------------------------------------------------------ a Ceres-shaped aggregate cost function
+// One residual block for ALL features of a kind: Evaluate() runs the linearise kernel on the correspondences of the last
+// match at parameters[0] and returns m residuals and the m x 7 row-major Jacobian -- what m LidarMap{PlaneNorm,Edge}Factor
+// blocks (lidar_map_factor.hpp:26-235) return one by one. Inside the reference tree derive it from ceres::CostFunction
+// (set_num_residuals(m), mutable_parameter_block_sizes()->push_back(7)).
+class LidarMapBatchFactor {
+public:
+    LidarMapBatchFactor(Device &dev, int kind, int m, bool with_ua) : dev_(dev), kind_(kind), m_(m), with_ua_(with_ua), r_(m), J_(size_t(m) * 6) {}
+    int num_residuals() const { return m_; }
+    bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const
+    {
+        int rc = mlh_linearize(dev_.ctx(), kind_, parameters[0], (with_ua_ ? MLH_FLAG_WITH_UA : 0u) | MLH_FLAG_NO_LOSS, 0.0,
+                               params().COV_MEASUREMENT_TRACE, r_.data(), J_.data(), nullptr, nullptr, nullptr, nullptr);
+        if (rc != MLH_OK) return false;
+        std::memcpy(residuals, r_.data(), sizeof(double) * m_);
+        if (jacobians && jacobians[0]) {
+            for (int i = 0; i < m_; ++i) {
+                std::memcpy(jacobians[0] + size_t(i) * 7, J_.data() + size_t(i) * 6, sizeof(double) * 6);
+                jacobians[0][size_t(i) * 7 + 6] = 0.0;
+            }
+        }
+        return true;
+    }
+private:
+    Device &dev_;
+    int kind_, m_;
+    bool with_ua_;
+    mutable std::vector<double> r_, J_;
+};
+
+// ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
+struct Scan2MapReport {
+    std::vector<mlh_iter_stat> outer;   // one per outer iteration: matched counts, H, eigenvalues, LM iterations, costs
+};
+
+// Replaces the body of scan2MapOptimization (lidar_mapper_keyframe.cpp:423-639): index build for both maps, max_iter x
+// { match all features, evalHessian + evalDegenracy, Levenberg-Marquardt with Ceres' trust-region semantics }, all on the GPU.
+inline void scan2MapOptimization(Device &dev, const PointICovCloud &laser_cloud_surf_from_map_cov_ds, const PointICovCloud &laser_cloud_corner_from_map_cov_ds,
+                                 const PointICovCloud &laser_cloud_surf_cov, const PointICovCloud &laser_cloud_corner_cov, Pose &pose_wmap_curr,
+                                 bool with_ua_flag, Scan2MapReport *report = nullptr, int max_iter = 2)
+{
+    const Params &P = params();
+    if (!(laser_cloud_surf_from_map_cov_ds.size() > 50 && laser_cloud_corner_from_map_cov_ds.size() > 10)) {   // cpp:429
+        pose_wmap_curr.cov_.fill(0.0);
+        return;
+    }
+    MapIndex<PointIWithCov> kdtree_surf_from_map(dev, MLH_SURF), kdtree_corner_from_map(dev, MLH_CORNER);
+    kdtree_surf_from_map.setInputCloud(laser_cloud_surf_from_map_cov_ds);       // cpp:433
+    kdtree_corner_from_map.setInputCloud(laser_cloud_corner_from_map_cov_ds);   // cpp:434
+    dev.check(mlh_features_set(dev.ctx(), MLH_SURF, laser_cloud_surf_cov.points.data(), 48, (int)laser_cloud_surf_cov.size(), 16, 20, MLH_MEM_HOST));
+    dev.check(mlh_features_set(dev.ctx(), MLH_CORNER, laser_cloud_corner_cov.points.data(), 48, (int)laser_cloud_corner_cov.size(), 16, 20, MLH_MEM_HOST));
+    mlh_solver_opts o;
+    mlh_solver_opts_default(&o);
+    o.min_match_sq_dis = P.MIN_MATCH_SQ_DIS; o.min_plane_dis = P.MIN_PLANE_DIS; o.huber_delta = P.HUBER_DELTA; o.map_eig_thre = P.MAP_EIG_THRE;
+    o.cov_measurement_trace = P.COV_MEASUREMENT_TRACE; o.flags = with_ua_flag ? MLH_FLAG_WITH_UA : 0u; o.max_outer = max_iter;
+    double pose[7];
+    pose_wmap_curr.toParam(pose);
+    std::vector<mlh_iter_stat> stats(max_iter);
+    dev.check(mlh_scan2map(dev.ctx(), pose, &o, stats.data()));
+    pose_wmap_curr.fromParam(pose);
+    if (report) report->outer = stats;
+}
+
+}  // namespace mloam_hip

@@ -175,8 +175,8 @@ def _raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: floa
     dz = dirs[:, 2]
     with np.errstate(divide="ignore", invalid="ignore"):
         tg = np.where(dz < -1e-9, -origin[2] / dz, np.inf)
-    px = origin[0] + tg * dirs[:, 0]
-    py = origin[1] + tg * dirs[:, 1]
+        px = origin[0] + tg * dirs[:, 0]
+        py = origin[1] + tg * dirs[:, 1]
     okg = np.isfinite(tg) & (np.abs(px) <= scene.L / 2) & (np.abs(py) <= scene.L / 2)
     t_hit = np.where(okg, tg, t_hit)
     # only boxes that can be reached

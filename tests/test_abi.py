@@ -1,0 +1,68 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/mloam_hip.h declares; host-only entry points
+agree with the oracle; with no GPU the context constructor fails loudly (no CPU fallback in the product path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def _declared_symbols(header_path):
+    txt = open(header_path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(mla):
+    lib = mla.load_library()
+    declared = _declared_symbols(mla.HEADER_PATH)
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(mla.EXPORTED_SYMBOLS) == declared
+
+
+def test_version_and_structs(mla):
+    lib = mla.load_library()
+    assert b"gfx950" in lib.mlh_version()
+    o = mla.default_opts()
+    assert (o.min_match_sq_dis, o.min_plane_dis, o.huber_delta, o.map_eig_thre, o.max_outer, o.max_lm_iterations) == (1.0, pytest.approx(0.2), 0.1, 100.0, 2, 30)
+    assert ctypes.sizeof(mla.IterStat) == 6 * 4 + 8 * (2 + 6 + 36 + 6 + 7)
+
+
+def test_host_helpers_match_oracle(mla, orc):
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x = np.concatenate([rng.normal(size=3), q])
+    d = rng.normal(size=6) * 0.1
+    np.testing.assert_allclose(mla.pose_plus(x, d), orc.pose_plus(x, d), atol=1e-15)
+    Qm, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+    H = Qm @ np.diag([3.0, 50.0, 200.0, 1e3, 1e4, 1e5]) @ Qm.T
+    a, b = mla.eval_degeneracy(H, 100.0), orc.eval_degeneracy(H, 100.0)
+    assert a["is_degenerate"] and b["is_degenerate"]
+    np.testing.assert_allclose(a["eigval"], b["eigval"], rtol=1e-10)
+    np.testing.assert_allclose(a["V_update"], b["V_update"], atol=1e-9)
+    np.testing.assert_allclose(mla.pose_plus(x, d, a["V_update"]), orc.pose_plus(x, d, b["V_update"]), atol=1e-12)
+
+
+def test_no_cpu_fallback(mla):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mla.MlhError):
+        mla.Context(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """the product path must never import, link or load anything under oracle/"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "m-loam_amd")
+    for dp, _, files in os.walk(pkg):
+        if os.sep + "build" in dp or os.sep + "lib" in dp or "__pycache__" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("oracle-free", ""), os.path.join(dp, f)

@@ -1,0 +1,39 @@
+"""The C++ facade (m-loam_amd/host/mloam_facade.hpp: FeatureExtract / MapIndex / scan2MapOptimization with the reference's
+signatures) gives the same answers as the oracle, through a real C++ executable linked against libmloam_hip.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_facade_selftest(tmp_path, orc, case16, feats16):
+    exe = os.path.join(ROOT, "m-loam_amd", "host", "facade_selftest")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe), "-s"], check=True)
+    sc = case16["scans"][0]
+    d = str(tmp_path)
+    sc.points.astype(np.float32).tofile(os.path.join(d, "scan.f32"))
+    np.concatenate([sc.scan_start, sc.scan_end]).astype(np.int32).tofile(os.path.join(d, "rings.i32"))
+    case16["surf_map"].astype(np.float32).tofile(os.path.join(d, "surf_map.f32"))
+    case16["corner_map"].astype(np.float32).tofile(os.path.join(d, "corner_map.f32"))
+    feats16[0].astype(np.float32).tofile(os.path.join(d, "surf.f32"))
+    feats16[1].astype(np.float32).tofile(os.path.join(d, "corner.f32"))
+    case16["p0"].astype(np.float64).tofile(os.path.join(d, "pose.f64"))
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    labels = np.fromfile(os.path.join(d, "out_labels.i32"), np.int32)
+    ref = orc.extract(sc.points, sc.scan_start, sc.scan_end)
+    assert np.array_equal(labels, ref["label"])
+    valid = np.fromfile(os.path.join(d, "out_valid_surf.u8"), np.uint8)
+    v, _ = orc.Map(case16["surf_map"]).match("s", feats16[0], case16["p0"])
+    assert np.array_equal(valid, v)
+    pose = np.fromfile(os.path.join(d, "out_pose.f64"), np.float64)
+    s2m = orc.scan2map(orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"]), feats16[0], feats16[1], case16["p0"], orc.mapper_params())
+    assert np.linalg.norm(pose[:3] - s2m["pose"][:3]) < 1e-7 and np.linalg.norm(pose[3:] - s2m["pose"][3:]) < 1e-7
+    counts = np.fromfile(os.path.join(d, "out_counts.i32"), np.int32).reshape(-1, 3)
+    for c, o in zip(counts, s2m["outer"]):
+        assert tuple(c) == (o["n_surf_sel"], o["n_corner_sel"], o["lm_iterations"])

@@ -1,0 +1,95 @@
+"""N > 1 path on CPU: world_size-2 gloo. Each rank keeps only its wedge of the local map (+ halo), owns the features whose
+map-frame position lies in its wedge, evaluates them with the CPU oracle, and the packed normal equations are all-reduced.
+The result must equal the unsharded evaluation: same correspondences, same sums (SURVEY 8e exactness argument)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    import conftest
+    synth = importlib.import_module("m-loam_amd.synth")
+    shard = importlib.import_module("m-loam_amd.shard")
+    case = conftest._make_case(synth, "50k", 16, 1)
+    feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+    p0 = case["p0"]
+    center = p0[:2]
+    packed = np.zeros(32)
+    valid_all = []
+    for kind, cloud, f in (("s", case["surf_map"], feats[0]), ("c", case["corner_map"], feats[1])):
+        keep = shard.shard_points_mask(cloud, center, world, rank)
+        local = np.ascontiguousarray(cloud[keep])
+        own = shard.owned_mask(synth.transform_points(f[:, :3], synth.pose_to_mat(p0)), *shard.wedge_planes(center, world, rank))
+        valid, coeffs = O.Map(local).match(kind, f, p0)
+        valid = (valid.astype(bool) & own).astype(np.uint8)
+        lin = O.linearize(kind, f, np.full(len(f), 0.0075), p0, valid, coeffs)
+        iu = np.triu_indices(6)
+        packed[:21] += lin["H"][iu]
+        packed[21:27] += lin["g"]
+        packed[27] += lin["cost"]
+        packed[28] += lin["count"]
+        valid_all.append(valid)
+    t = torch.from_numpy(packed)
+    dist.all_reduce(t)
+    owned = torch.from_numpy(np.concatenate(valid_all).astype(np.int64))
+    dist.all_reduce(owned)
+    if rank == 0:
+        q.put((t.numpy().copy(), owned.numpy().copy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_normal_equations_equal_unsharded(orc, synth, case16, feats16, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    packed, owned = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded reference
+    ref = np.zeros(32)
+    valids = []
+    for kind, cloud, f in (("s", case16["surf_map"], feats16[0]), ("c", case16["corner_map"], feats16[1])):
+        valid, coeffs = orc.Map(cloud).match(kind, f, case16["p0"])
+        lin = orc.linearize(kind, f, np.full(len(f), 0.0075), case16["p0"], valid, coeffs)
+        iu = np.triu_indices(6)
+        ref[:21] += lin["H"][iu]
+        ref[21:27] += lin["g"]
+        ref[27] += lin["cost"]
+        ref[28] += lin["count"]
+        valids.append(valid)
+    assert np.array_equal(owned, np.concatenate(valids).astype(np.int64)), "a feature was matched by zero or several ranks"
+    assert packed[28] == ref[28]
+    np.testing.assert_allclose(packed[:28], ref[:28], rtol=1e-11, atol=1e-9)
+
+
+def test_wedges_tile_the_plane(synth):
+    shard = importlib.import_module("m-loam_amd.shard")
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-100, 100, (200000, 3)).astype(np.float32)
+    for n in (2, 3, 4, 8):
+        own = sum(shard.owned_mask(pts, *shard.wedge_planes((0.3, -0.2), n, r)).astype(int) for r in range(n))
+        assert own.min() == 1 and own.max() == 1
+        # halo: every point within 1 m of an owned point's position is staged by the owner
+        r0 = shard.owned_mask(pts, *shard.wedge_planes((0.3, -0.2), n, 0))
+        staged = shard.shard_points_mask(pts, (0.3, -0.2), n, 0, halo=1.1)
+        assert np.all(staged[r0])
