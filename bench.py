@@ -173,8 +173,7 @@ def main():
 
     def step():
         if not args.no_map_rebuild:
-            ctx.map_rebuild(mla.SURF)
-            ctx.map_rebuild(mla.CORNER)
+            ctx.map_rebuild(mla.ALL_KINDS)
         return ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)[0]
 
     def sync_all():
@@ -186,7 +185,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region (2 events per launch)
-    ctx.profile_enable((1 << mla.K_KNN_SURF) if args.profile_events else 0)
+    ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
     ctx.profile_reset()
     sync_all()
     t_start = time.perf_counter()
@@ -194,7 +193,7 @@ def main():
         pose = step()
     sync_all()
     elapsed = time.perf_counter() - t_start
-    knn_ms, knn_n = ctx.profile_get(mla.K_KNN_SURF)
+    knn_ms, knn_n = ctx.profile_get(mla.K_KNN)
     ctx.profile_enable(0)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -213,30 +212,34 @@ def main():
         step()
     sync_all()
     ms_per_step_all_events = 1e3 * (time.perf_counter() - t1) / n_prof
-    prof = {k: ctx.profile_get(k) for k in range(8)}
+    prof = {k: ctx.profile_get(k) for k in range(6)}
     ctx.profile_enable(0)
 
-    # --- roofline of the dominant kernel (surf match+linearise), algorithmic bytes per launch / measured duration
+    # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
+    #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)
     h = float(np.sqrt(opts.min_match_sq_dis)) * 1.001
     Tm = synth.pose_to_mat(p0)
-    own = shard.owned_mask(synth.transform_points(surf[:, :3], Tm), *shard.wedge_planes(center, world, rank)) if world > 1 else np.ones(len(surf), bool)
-    cbar = mean_candidates(local_surf_map, synth.transform_points(surf[own][:, :3], Tm), h)
-    n_own = int(own.sum())
-    # correspondence kernel, per feature: 16 B feature record; per OWNED feature additionally 18 cell_start words (72 B)
-    # + 16 B x C-bar candidate points + 5 neighbour re-fetches (80 B) + 5 float4 neighbour records written (80 B)
-    bytes_per_launch = len(surf) * 16.0 + n_own * (72 + 16.0 * cbar + 80 + 80)
-    k_ms, k_n = knn_ms, knn_n
+    planes = shard.wedge_planes(center, world, rank)
+    bytes_per_launch, cbars, n_owned = 0.0, {}, {}
+    for name, feats, lmap in (("surf", surf, local_surf_map), ("corner", corner, local_corner_map)):
+        fm = synth.transform_points(feats[:, :3], Tm)
+        own = shard.owned_mask(fm, *planes) if world > 1 else np.ones(len(feats), bool)
+        cb = mean_candidates(lmap, fm[own], h)
+        cbars[name], n_owned[name] = round(cb, 2), int(own.sum())
+        # per feature: 16 B feature record; per OWNED feature additionally 18 cell_start words (72 B) + 16 B x C-bar candidate
+        # points + 5 neighbour re-fetches (80 B) + 5 float4 neighbour records written (80 B)
+        bytes_per_launch += len(feats) * 16.0 + int(own.sum()) * (72 + 16.0 * cb + 80 + 80)
     roofline = None
-    if k_n > 0:
-        dur_s = 1e-3 * k_ms / k_n
+    if knn_n > 0:
+        dur_s = 1e-3 * knn_ms / knn_n
         ach = bytes_per_launch / dur_s / 1e9
-        roofline = dict(bound="hbm", kernel="knn_features_kernel (surf map)", achieved=round(ach, 2), peak=8000.0, unit="GB/s",
-                        frac=round(ach / 8000.0, 5), traffic=None, avg_kernel_us=round(1e6 * dur_s, 3), launches=int(k_n),
-                        algorithmic_bytes_per_launch=int(bytes_per_launch), mean_candidates_per_feature=round(cbar, 2),
-                        floor_132B_per_feature_GBps=round(len(surf) * 132 / dur_s / 1e9, 2),
-                        note="map (<= 64 MB) is L2/Infinity-Cache resident: measured HBM bytes are far below the algorithmic bytes; "
+        roofline = dict(bound="hbm", kernel="knn_features_kernel (surf + corner)", achieved=round(ach, 2), peak=8000.0, unit="GB/s",
+                        frac=round(ach / 8000.0, 5), traffic=None, avg_kernel_us=round(1e6 * dur_s, 3), launches=int(knn_n),
+                        algorithmic_bytes_per_launch=int(bytes_per_launch), mean_candidates_per_feature=cbars, owned_features=n_owned,
+                        floor_132B_per_feature_GBps=round(m_total * 132 / dur_s / 1e9, 2),
+                        note="map (<= 128 MB) is L2/Infinity-Cache resident: measured HBM bytes are far below the algorithmic bytes; "
                              "PMC traffic is collected offline with rocprofv3 --pmc (profiles/)")
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_match_surf.json")
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_knn.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
@@ -261,9 +264,9 @@ def main():
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
-                                         for name, k in (("knn_surf", mla.K_KNN_SURF), ("knn_corner", mla.K_KNN_CORNER),
-                                                         ("fit_linearize_surf", mla.K_FIT_SURF), ("fit_linearize_corner", mla.K_FIT_CORNER),
-                                                         ("reduce_solve", mla.K_SOLVE), ("map_index_build", mla.K_GRID_BUILD))},
+                                         for name, k in (("knn_features (surf+corner)", mla.K_KNN),
+                                                         ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
+                                                         ("map_index_build (both maps, 6 launches)", mla.K_GRID_BUILD))},
                    extract_ms_per_lidar_scan=[round(x, 4) for x in extract_ms],
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    final_pose=[round(float(x), 9) for x in pose],

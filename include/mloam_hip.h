@@ -29,6 +29,7 @@ extern "C" {
 typedef struct mlh_ctx mlh_ctx;
 
 enum { MLH_SURF = 0, MLH_CORNER = 1 };              /* feature / map kind ('s' / 'c' in PointPlaneFeature::type_) */
+#define MLH_ALL_KINDS (-1)                          /* mlh_map_rebuild: both maps in one set of launches */
 enum { MLH_MEM_HOST = 0, MLH_MEM_DEVICE = 1 };
 
 /* status codes */
@@ -58,18 +59,17 @@ void *mlh_stream(mlh_ctx *ctx);
 int mlh_synchronize(mlh_ctx *ctx);
 
 /* ---------------------------------------------------------------- per-kernel timing (HIP events on the context's stream)
- * When enabled, every launch of the named kernels is bracketed by hipEventRecord on the context's stream; the
- * accumulated duration / launch count are read back with mlh_profile_get. Kernel ids: */
+ * Single-kernel ids (KNN, FIT, LINEARIZE) are timed with the dispatch's own start/stop timestamps (hipExtLaunchKernelGGL with
+ * start/stop events: the same clock rocprofv3 reports); multi-kernel ids (SOLVE, GRID_BUILD, EXTRACT) are bracketed with
+ * hipEventRecord on the context's stream. Durations / launch counts are read back with mlh_profile_get. Kernel ids: */
 enum {
-    MLH_K_KNN_SURF = 0,      /* correspondence kernel (exact 5-NN), surf features   -- the roofline kernel */
-    MLH_K_KNN_CORNER = 1,
-    MLH_K_FIT_SURF = 2,      /* fit + gates + residual/Jacobian + J^T J reduction    */
-    MLH_K_FIT_CORNER = 3,
-    MLH_K_LINEARIZE = 4,     /* re-linearisation on stored correspondences (LM)      */
-    MLH_K_SOLVE = 5,         /* partial-sum reduction + degeneracy + 6x6 solve + Plus */
-    MLH_K_GRID_BUILD = 6,    /* local-map index build                                 */
-    MLH_K_EXTRACT = 7,       /* extractCloud                                          */
-    MLH_K_COUNT = 8
+    MLH_K_KNN = 0,           /* correspondence kernel (exact 5-NN, surf + corner features in one launch) -- the roofline kernel */
+    MLH_K_FIT = 1,           /* fit + gates + residual/Jacobian + J^T J reduction (+ fused GN solve in its last workgroup)     */
+    MLH_K_LINEARIZE = 2,     /* re-linearisation on stored correspondences (LM iterations)                                     */
+    MLH_K_SOLVE = 3,         /* stand-alone partial-sum reduction + degeneracy + 6x6 solve / LM step kernels                   */
+    MLH_K_GRID_BUILD = 4,    /* local-map index build (all kernels of one build)                                               */
+    MLH_K_EXTRACT = 5,       /* extractCloud (all kernels of one extraction)                                                   */
+    MLH_K_COUNT = 6
 };
 /* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);
@@ -100,7 +100,8 @@ int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *p
  * Builds a dense cell grid (cell edge just above sqrt(min_match_sq_dis), so the 27-cell neighbourhood is exact for
  * the acceptance test "5th neighbour sq-dist < min_match_sq_dis", feature_extract.hpp:667/814) over the cloud
  * and keeps the points cell-sorted in HBM as float4 {x, y, z, original index}.
- * mlh_map_rebuild re-runs the index build on the resident cloud (the reference rebuilds every frame).
+ * mlh_map_rebuild re-runs the index build on the resident cloud(s) (the reference rebuilds every frame); kind may be
+ * MLH_ALL_KINDS to rebuild both maps in one set of fused launches.
  */
 int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);

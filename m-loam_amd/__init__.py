@@ -19,10 +19,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmloam_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mloam_hip.h")
 
 SURF, CORNER = 0, 1
+ALL_KINDS = -1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
-K_KNN_SURF, K_KNN_CORNER, K_FIT_SURF, K_FIT_CORNER, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = range(8)
-K_ALL = 0xFF
+K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = range(6)
+K_ALL = 0x3F
 
 
 class MlhError(RuntimeError):

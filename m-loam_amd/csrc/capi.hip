@@ -43,6 +43,17 @@ void prof_end(mlh_ctx *ctx, int id)
     (void)hipEventRecord(pd.b, ctx->stream);
 }
 
+bool prof_kernel_events(mlh_ctx *ctx, int id, hipEvent_t *start, hipEvent_t *stop)
+{
+    if (!(ctx->prof.mask & (1u << id))) return false;
+    Profile::Pending pd;
+    pd.id = id; pd.a = prof_event(ctx); pd.b = prof_event(ctx);
+    if (!pd.a || !pd.b) return false;
+    ctx->prof.pending.push_back(pd);
+    *start = pd.a; *stop = pd.b;
+    return true;
+}
+
 void prof_collect(mlh_ctx *ctx)
 {
     Profile &p = ctx->prof;
@@ -113,13 +124,14 @@ static int ensure_state(mlh_ctx *ctx, int n_stats)
 
 static int upload_pose(mlh_ctx *ctx, const double pose[7])
 {
-    // identity V_update, pose into x and cand
-    SolverState h;
+    // identity V_update, pose into x and cand; staged through a pinned buffer so the copy is truly asynchronous
+    if (!ctx->h_state) MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, sizeof(SolverState), hipHostMallocDefault));
+    else MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the previous upload may still be reading the staging buffer
+    SolverState &h = *static_cast<SolverState *>(ctx->h_state);
     std::memset(&h, 0, sizeof(h));
     for (int i = 0; i < 7; ++i) { h.x[i] = pose[i]; h.cand[i] = pose[i]; }
     for (int i = 0; i < 6; ++i) h.V[i * 6 + i] = 1.0;
     MLH_HIP(ctx, hipMemcpyAsync(ctx->state.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack object
     return MLH_OK;
 }
 
@@ -168,14 +180,15 @@ void mlh_destroy(mlh_ctx *ctx)
         MapGrid &m = ctx->map[k];
         m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release();
         FeatSet &f = ctx->feat[k];
-        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release(); f.partials.release();
+        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release();
     }
     ScanBuf &s = ctx->scan;
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
-    ctx->state.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
+    ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
     comm_destroy(ctx);
+    if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -298,7 +311,7 @@ int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, in
     if (rc) return rc;
     g.n = n;
     g.min_match_sq_dis = min_match_sq_dis;
-    rc = grid_build(ctx, g, min_match_sq_dis, true);
+    rc = grid_build(ctx, 1 << kind, true);
     if (rc) return rc;
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->feat[kind].matched = false;
@@ -307,11 +320,9 @@ int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, in
 
 int mlh_map_rebuild(mlh_ctx *ctx, int kind)
 {
-    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
-    MapGrid &g = ctx->map[kind];
-    if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+    if (!ctx || kind < MLH_ALL_KINDS || kind > 1) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    return grid_build(ctx, g, g.min_match_sq_dis, false);
+    return grid_build(ctx, kind == MLH_ALL_KINDS ? 3 : (1 << kind), false);
 }
 
 int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int32_t *idx, float *sqdist)
@@ -388,10 +399,10 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
     if (rc) return rc;
     if ((rc = upload_pose(ctx, pose))) return rc;
     MatchArgs a;
-    a.kind = kind; a.flags = flags; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
+    a.kind_mask = 1 << kind; a.flags = flags; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
     if ((rc = match_launch(ctx, a))) return rc;
-    if ((rc = reduce_only_launch(ctx, 1 << kind, 0))) return rc;
+    if ((rc = reduce_only_launch(ctx, 0))) return rc;
     return fetch_dense_and_reduced(ctx, kind, true, valid, coeffs, r, J, JtJ, Jtr, cost, n_valid);
 }
 
@@ -405,10 +416,10 @@ int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, 
     if (rc) return rc;
     if ((rc = upload_pose(ctx, pose))) return rc;
     MatchArgs a;
-    a.kind = kind; a.flags = flags; a.min_match_sq_dis = 0.f; a.min_plane_dis = 0.f;
+    a.kind_mask = 1 << kind; a.flags = flags; a.min_match_sq_dis = 0.f; a.min_plane_dis = 0.f;
     a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
     if ((rc = linearize_launch(ctx, a))) return rc;
-    if ((rc = reduce_only_launch(ctx, 1 << kind, 0))) return rc;
+    if ((rc = reduce_only_launch(ctx, 0))) return rc;
     return fetch_dense_and_reduced(ctx, kind, false, nullptr, nullptr, r, J, JtJ, Jtr, cost, n_valid);
 }
 
@@ -426,10 +437,10 @@ void mlh_solver_opts_default(mlh_solver_opts *o)
     o->max_lm_iterations = 30;
 }
 
-static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind, int pose_sel)
+static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pose_sel)
 {
     MatchArgs a;
-    a.kind = kind; a.flags = o->flags & (MLH_FLAG_CHECK_FOV | MLH_FLAG_WITH_UA);
+    a.kind_mask = kind_mask; a.map_eig_thre = o->map_eig_thre; a.flags = o->flags & (MLH_FLAG_CHECK_FOV | MLH_FLAG_WITH_UA);
     a.min_match_sq_dis = o->min_match_sq_dis; a.min_plane_dis = o->min_plane_dis;
     a.huber_delta = o->huber_delta; a.cov_measurement_trace = o->cov_measurement_trace; a.dense = false; a.pose_sel = pose_sel;
     return a;
@@ -456,12 +467,19 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
     int rc = ensure_state(ctx, n_iters);
     if (rc) return rc;
     if ((rc = upload_pose(ctx, pose_inout))) return rc;
-    const bool have[2] = {ctx->feat[0].m > 0 && ctx->map[0].built, ctx->feat[1].m > 0 && ctx->map[1].built};
-    if (!have[0] && !have[1]) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
+    if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
     for (int it = 0; it < n_iters; ++it) {
-        for (int k = 0; k < 2; ++k)
-            if (have[k] && (rc = match_launch(ctx, args_from_opts(opts, k, 0)))) return rc;
-        if ((rc = gn_update_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;
+        MatchArgs a = args_from_opts(opts, mask, 0);
+        if (!ctx->comm) {
+            // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose
+            a.finish = 1;
+            a.stat_slot = stats ? it : -1;
+            if ((rc = match_launch(ctx, a))) return rc;
+        } else {
+            if ((rc = match_launch(ctx, a))) return rc;
+            if ((rc = gn_update_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;   // local reduce + all-reduce + solve
+        }
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);
 }
@@ -481,13 +499,11 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     if ((rc = upload_pose(ctx, pose_inout))) return rc;
     const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
     for (int outer = 0; outer < opts->max_outer; ++outer) {
-        for (int k = 0; k < 2; ++k)
-            if ((rc = match_launch(ctx, args_from_opts(opts, k, 0)))) return rc;
+        if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
         if ((rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
             for (int j = it; j < std::min(it + chunk, opts->max_lm_iterations); ++j) {
-                for (int k = 0; k < 2; ++k)
-                    if ((rc = linearize_launch(ctx, args_from_opts(opts, k, 1)))) return rc;
+                if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 1)))) return rc;
                 if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
             }
             int done = 0;

@@ -90,7 +90,7 @@ struct MapGrid {
     GridDev dev() const
     {
         GridDev g;
-        g.sorted = sorted.as<float4>(); g.raw = raw.as<float4>(); g.cell_start = cell_start.as<int>();
+        g.sorted = sorted.as<float4>(); g.raw = raw.as<float4>(); g.cell_start = cell_start.as<int>() + 3;   // see grid.hip: cell_start + 1 is 16-byte aligned
         g.ox = ox; g.oy = oy; g.oz = oz; g.inv_h = inv_h; g.nx = nx; g.ny = ny; g.nz = nz; g.n = n;
         return g;
     }
@@ -102,11 +102,9 @@ struct FeatSet {
     DevBuf corr;       // Corr per feature
     DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
-    DevBuf partials;   // NE_STRIDE doubles per block
     int m = 0;
     bool has_cov = false;
     bool matched = false;
-    int n_blocks = 0;
 };
 
 struct ScanBuf {
@@ -142,9 +140,13 @@ struct mlh_ctx {
     mlh::FeatSet feat[2];
     mlh::ScanBuf scan;
     mlh::DevBuf state;       // SolverState
+    mlh::DevBuf partials;    // NE_STRIDE doubles per fit/linearise tile (surf tiles, then corner tiles)
+    int n_partial_tiles = 0;
+    mlh::DevBuf ticket;      // arrival counter of the fused GN finish
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
+    void *h_state = nullptr; // pinned staging for the solver-state upload
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
@@ -167,25 +169,30 @@ int fail(mlh_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 void prof_begin(mlh_ctx *ctx, int id);
 void prof_end(mlh_ctx *ctx, int id);
 void prof_collect(mlh_ctx *ctx);
+// events whose timestamps come from the dispatch itself (hipExtLaunchKernelGGL); false when kernel id is not profiled
+bool prof_kernel_events(mlh_ctx *ctx, int id, hipEvent_t *start, hipEvent_t *stop);
 
 // extract.hip
 int extract_run(mlh_ctx *ctx);
 // grid.hip
-int grid_build(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis, bool recompute_bounds);
+int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 // match.hip
 struct MatchArgs {
-    int kind;
-    uint32_t flags;
-    float min_match_sq_dis, min_plane_dis;
-    double huber_delta, cov_measurement_trace;
-    bool dense;          // also write r / J per feature
-    int pose_sel;        // 0: SolverState::x, 1: SolverState::cand
+    int kind_mask = 3;   // bit MLH_SURF, bit MLH_CORNER: which feature kinds take part in the launch
+    uint32_t flags = 0;
+    float min_match_sq_dis = 1.f, min_plane_dis = 0.2f;
+    double huber_delta = 0.1, cov_measurement_trace = 0.0075;
+    bool dense = false;  // also write r / J per feature
+    int pose_sel = 0;    // 0: SolverState::x, 1: SolverState::cand
+    int finish = 0;      // 1: the fit kernel's last workgroup completes the GN iteration (reduce + solve + Plus)
+    double map_eig_thre = 100.0;
+    int stat_slot = -1;
 };
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
 // solver.hip
-int reduce_only_launch(mlh_ctx *ctx, int kind_mask, int to_ce);
+int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 // comm.hip
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);

@@ -4,8 +4,11 @@
 //
 // Layout in HBM: raw[n] and sorted[n] as float4 {x, y, z, original index}; cell_start[ncell+1] (int32, exclusive prefix),
 // cells ordered x fastest so the 3 x-adjacent cells of a query form ONE contiguous run of `sorted` (9 runs per query).
-// Kernels (all streaming, HBM-bound): bounds (16 B/pt read), count (16 B read + 4 B write + 1 atomic), 3-phase exclusive
-// scan over the cells (8 B/cell), scatter (16 B + 4 B read, 16 B write, 1 atomic).
+// One build = 6 launches for BOTH maps together (zero, count, 3-phase exclusive scan, scatter); all streaming:
+//   count   16 B/pt read + 1 atomic      scan   8 B/cell      scatter   16 B read + 16 B written + 1 atomic per point
+// The count lands in cell_start[c+1]; the in-place exclusive scan turns that slot into start[c]; the scatter's
+// atomicAdd(&cell_start[c+1], 1) hands out positions and leaves start[c] + count[c] = start[c+1] behind -- so the array ends
+// up being exactly the exclusive prefix the queries read, without a second cursor array or a second clear.
 #include "ctx.hpp"
 #include <cmath>
 #include <climits>
@@ -55,29 +58,55 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float4 *__restrict__ 
     }
 }
 
-__device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int n)
-{
-    float f = floorf((v - o) * inv_h);
-    f = fminf(fmaxf(f, 0.f), float(n - 1));
-    return int(f);
-}
-
-__global__ __launch_bounds__(256) void cell_count_kernel(const float4 *__restrict__ pts, int n, float ox, float oy, float oz,
-                                                         float inv_h, int nx, int ny, int nz,
-                                                         int *__restrict__ cell_id, int *__restrict__ cell_cnt)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 p = pts[i];
-        int cx = cell_coord(p.x, ox, inv_h, nx), cy = cell_coord(p.y, oy, inv_h, ny), cz = cell_coord(p.z, oz, inv_h, nz);
-        int c = (cz * ny + cy) * nx + cx;
-        cell_id[i] = c;
-        atomicAdd(&cell_cnt[c], 1);
-    }
-}
-
-// ---- exclusive scan, 2048 items per block (256 threads x 8)
+// ---- one job per map; kernels take both jobs and split their grid between them
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
+
+struct GridJob {
+    const float4 *raw;
+    float4 *sorted;
+    int *cell_start;       // ncell + 1
+    int *block_sums;
+    int n;
+    int ncell;
+    float ox, oy, oz, inv_h;
+    int nx, ny, nz;
+    int nb_pts;            // workgroups streaming the points
+    int nb_scan;           // workgroups scanning the cells
+};
+struct GridJobs { GridJob j[2]; };
+
+__device__ __forceinline__ int cell_of(const GridJob &J, const float4 &p)
+{
+    float fx = fminf(fmaxf(floorf((p.x - J.ox) * J.inv_h), 0.f), float(J.nx - 1));
+    float fy = fminf(fmaxf(floorf((p.y - J.oy) * J.inv_h), 0.f), float(J.ny - 1));
+    float fz = fminf(fmaxf(floorf((p.z - J.oz) * J.inv_h), 0.f), float(J.nz - 1));
+    return (int(fz) * J.ny + int(fy)) * J.nx + int(fx);
+}
+
+// cell_start lives 3 ints into its allocation, so A = cell_start + 1 (the array the scan works on) is 16-byte aligned
+__global__ __launch_bounds__(256) void zero_cells_kernel(GridJobs G)
+{
+    const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
+    int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
+    const int base4 = b * (SCAN_CHUNK / 4) + threadIdx.x * 2;           // in int4 units
+    const int n4 = (J.ncell + 3) / 4;                                    // allocation is padded to a multiple of 4 (+4)
+    const int4 z = make_int4(0, 0, 0, 0);
+    if (base4 < n4) A4[base4] = z;
+    if (base4 + 1 < n4) A4[base4 + 1] = z;
+    if (b == 0 && threadIdx.x == 0) J.cell_start[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
+{
+    const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
+    for (int i = b * 256 + threadIdx.x; i < J.n; i += J.nb_pts * 256)
+        atomicAdd(&J.cell_start[cell_of(J, J.raw[i]) + 1], 1);
+}
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &total)
 {
@@ -98,104 +127,141 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &to
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(256) void scan_local_kernel(const int *__restrict__ in, long long n, int *__restrict__ out,
-                                                         int *__restrict__ block_sums)
+// in-place exclusive scan of A[i] = cell_start[i + 1], i in [0, ncell): chunk-local part (8 ints = 2 x int4 per thread)
+__global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
 {
     __shared__ int lds[4];
-    long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS], s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
+    int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
+    const int base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    const int n_pad = ((J.ncell + 3) / 4) * 4;                           // padded tail holds zeros
+    int4 v0 = make_int4(0, 0, 0, 0), v1 = v0;
+    if (base < n_pad) v0 = A4[base / 4];
+    if (base + 4 < n_pad) v1 = A4[base / 4 + 1];
+    const int s = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
     int total;
     int ex = block_exclusive_scan_256(s, lds, total);
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    int4 o0, o1;
+    o0.x = ex; ex += v0.x; o0.y = ex; ex += v0.y; o0.z = ex; ex += v0.z; o0.w = ex; ex += v0.w;
+    o1.x = ex; ex += v1.x; o1.y = ex; ex += v1.y; o1.z = ex; ex += v1.z; o1.w = ex;
+    if (base < n_pad) A4[base / 4] = o0;
+    if (base + 4 < n_pad) A4[base / 4 + 1] = o1;
+    if (threadIdx.x == 0) J.block_sums[b] = total;
 }
 
-__global__ __launch_bounds__(256) void scan_sums_kernel(int *__restrict__ block_sums, int nb)
+__global__ __launch_bounds__(256) void scan_sums_kernel(GridJobs G)
 {
     __shared__ int lds[4];
+    const GridJob &J = G.j[blockIdx.x];
     int carry = 0;
-    for (int start = 0; start < nb; start += 256) {
+    for (int start = 0; start < J.nb_scan; start += 256) {
         int i = start + threadIdx.x;
-        int v = (i < nb) ? block_sums[i] : 0;
+        int v = (i < J.nb_scan) ? J.block_sums[i] : 0;
         int total;
         int ex = block_exclusive_scan_256(v, lds, total);
-        if (i < nb) block_sums[i] = carry + ex;
+        if (i < J.nb_scan) J.block_sums[i] = carry + ex;
         carry += total;
     }
 }
 
-__global__ __launch_bounds__(256) void scan_add_kernel(int *__restrict__ out, long long n, const int *__restrict__ block_sums,
-                                                       int n_points)
+__global__ __launch_bounds__(256) void scan_add_kernel(GridJobs G)
 {
-    long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * SCAN_ITEMS;
-    int add = block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) out[base + k] += add;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = n_points;
+    const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
+    if (b == 0) return;                                                  // first chunk: offset 0
+    int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
+    const int add = J.block_sums[b];
+    const int base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    const int n_pad = ((J.ncell + 3) / 4) * 4;
+    if (base < n_pad) { int4 v = A4[base / 4]; v.x += add; v.y += add; v.z += add; v.w += add; A4[base / 4] = v; }
+    if (base + 4 < n_pad) { int4 v = A4[base / 4 + 1]; v.x += add; v.y += add; v.z += add; v.w += add; A4[base / 4 + 1] = v; }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(const float4 *__restrict__ raw, int n, const int *__restrict__ cell_id,
-                                                      const int *__restrict__ cell_start, int *__restrict__ cursor,
-                                                      float4 *__restrict__ sorted)
+__global__ __launch_bounds__(256) void scatter_kernel(GridJobs G)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int c = cell_id[i];
-        int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
-        sorted[pos] = raw[i];
+    const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
+    for (int i = b * 256 + threadIdx.x; i < J.n; i += J.nb_pts * 256) {
+        const float4 p = J.raw[i];
+        const int pos = atomicAdd(&J.cell_start[cell_of(J, p) + 1], 1);
+        J.sorted[pos] = p;
     }
 }
 
-int grid_build(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis, bool recompute_bounds)
+static int compute_bounds(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis)
 {
     hipStream_t st = ctx->stream;
     const int n = g.n;
-    if (n <= 0) return fail(ctx, MLH_ERR_INVALID, "map cloud is empty");
     const int grid_pts = std::min((n + 255) / 256, 2048);
-    if (recompute_bounds) {
-        MLH_HIP(ctx, g.bounds.ensure(6 * sizeof(int)));
-        hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(64), 0, st, g.bounds.as<int>());
-        hipLaunchKernelGGL(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), n, g.bounds.as<int>());
-        int hb[6];
-        MLH_HIP(ctx, hipMemcpyAsync(hb, g.bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
-        MLH_HIP(ctx, hipStreamSynchronize(st));
-        float mn[3], mx[3];
-        for (int d = 0; d < 3; ++d) { mn[d] = key_to_float(hb[d]); mx[d] = key_to_float(hb[3 + d]); }
-        for (int d = 0; d < 3; ++d)
-            if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) return fail(ctx, MLH_ERR_INVALID, "map cloud has non-finite coordinates");
-        g.h = std::sqrt(min_match_sq_dis) * 1.001f;
-        g.inv_h = 1.0f / g.h;
-        g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-        g.nx = int(std::floor((mx[0] - g.ox) * g.inv_h)) + 1;
-        g.ny = int(std::floor((mx[1] - g.oy) * g.inv_h)) + 1;
-        g.nz = int(std::floor((mx[2] - g.oz) * g.inv_h)) + 1;
-        g.ncell = (long long)g.nx * g.ny * g.nz;
-        if (g.ncell >= (1ll << 31) - SCAN_CHUNK) return fail(ctx, MLH_ERR_UNSUPPORTED, "map extent needs more than 2^31 cells");
-    }
-    const long long ncell = g.ncell;
-    const int nb = int((ncell + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    MLH_HIP(ctx, g.bounds.ensure(6 * sizeof(int)));
+    hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(64), 0, st, g.bounds.as<int>());
+    hipLaunchKernelGGL(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), n, g.bounds.as<int>());
+    int hb[6];
+    MLH_HIP(ctx, hipMemcpyAsync(hb, g.bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    float mn[3], mx[3];
+    for (int d = 0; d < 3; ++d) { mn[d] = key_to_float(hb[d]); mx[d] = key_to_float(hb[3 + d]); }
+    for (int d = 0; d < 3; ++d)
+        if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) return fail(ctx, MLH_ERR_INVALID, "map cloud has non-finite coordinates");
+    g.h = std::sqrt(min_match_sq_dis) * 1.001f;
+    g.inv_h = 1.0f / g.h;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.nx = int(std::floor((mx[0] - g.ox) * g.inv_h)) + 1;
+    g.ny = int(std::floor((mx[1] - g.oy) * g.inv_h)) + 1;
+    g.nz = int(std::floor((mx[2] - g.oz) * g.inv_h)) + 1;
+    g.ncell = (long long)g.nx * g.ny * g.nz;
+    if (g.ncell >= (1ll << 31) - 2 * SCAN_CHUNK) return fail(ctx, MLH_ERR_UNSUPPORTED, "map extent needs more than 2^31 cells");
+    const int nb = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);   // covers ncell + 1 entries
     MLH_HIP(ctx, g.sorted.ensure(sizeof(float4) * size_t(n)));
-    MLH_HIP(ctx, g.cell_id.ensure(sizeof(int) * size_t(n)));
-    MLH_HIP(ctx, g.cell_start.ensure(sizeof(int) * size_t(ncell + 1)));
-    MLH_HIP(ctx, g.cell_fill.ensure(sizeof(int) * size_t(ncell)));
+    MLH_HIP(ctx, g.cell_start.ensure(sizeof(int) * size_t(g.ncell + 16)));   // 3 ints of lead-in (alignment of cell_start + 1) + padded tail
     MLH_HIP(ctx, g.block_sums.ensure(sizeof(int) * size_t(nb + 1)));
+    return MLH_OK;
+}
 
+static GridJob make_job(const MapGrid &g)
+{
+    GridJob J;
+    std::memset(&J, 0, sizeof(J));
+    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.cell_start = g.cell_start.as<int>() + 3; J.block_sums = g.block_sums.as<int>();
+    J.n = g.n; J.ncell = int(g.ncell); J.ox = g.ox; J.oy = g.oy; J.oz = g.oz; J.inv_h = g.inv_h; J.nx = g.nx; J.ny = g.ny; J.nz = g.nz;
+    J.nb_pts = std::min((g.n + 255) / 256, 4096);
+    J.nb_scan = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
+    return J;
+}
+
+// (re)builds the index of the maps selected by kind_mask in one set of launches
+int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds)
+{
+    hipStream_t st = ctx->stream;
+    GridJobs G;
+    std::memset(&G, 0, sizeof(G));
+    int nj = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!(kind_mask & (1 << k))) continue;
+        MapGrid &g = ctx->map[k];
+        if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+        if (recompute_bounds) {
+            int rc = compute_bounds(ctx, g, g.min_match_sq_dis);
+            if (rc) return rc;
+        }
+        G.j[nj++] = make_job(g);
+    }
+    if (nj == 0) return MLH_OK;
+    const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);
-    MLH_HIP(ctx, hipMemsetAsync(g.cell_fill.p, 0, sizeof(int) * size_t(ncell), st));
-    hipLaunchKernelGGL(cell_count_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), n, g.ox, g.oy, g.oz, g.inv_h,
-                       g.nx, g.ny, g.nz, g.cell_id.as<int>(), g.cell_fill.as<int>());
-    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, st, g.cell_fill.as<int>(), ncell, g.cell_start.as<int>(),
-                       g.block_sums.as<int>());
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, g.block_sums.as<int>(), nb);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, g.cell_start.as<int>(), ncell, g.block_sums.as<int>(), n);
-    MLH_HIP(ctx, hipMemsetAsync(g.cell_fill.p, 0, sizeof(int) * size_t(ncell), st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), n, g.cell_id.as<int>(),
-                       g.cell_start.as<int>(), g.cell_fill.as<int>(), g.sorted.as<float4>());
+    hipLaunchKernelGGL(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     prof_end(ctx, MLH_K_GRID_BUILD);
     MLH_HIP(ctx, hipGetLastError());
-    g.built = true;
+    for (int k = 0; k < 2; ++k) if (kind_mask & (1 << k)) ctx->map[k].built = true;
     return MLH_OK;
 }
 

@@ -1,10 +1,11 @@
 // Correspondence + linearisation kernels for gfx950 (the roofline kernels of the scan-to-map path).
 //
 // knn_features_kernel        -- per feature: pointAssociateToMap (utility.h:103-117) -> exact 5-NN in the local-map cell grid
-//   (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813). 32 lanes (half a wavefront) per feature:
-//   lane = (x-run of the 27-cell neighbourhood, sub-lane), all 9 runs in flight at once, consecutive sub-lanes on
-//   consecutive float4 points; each lane keeps a sorted top-5 of 64-bit (distance bits, map index) keys, the group merges with
-//   a 5-round shuffle tournament; the 5 winners' coordinates + squared distances go to HBM (80 B/feature).
+//   (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813). 8 lanes per feature (8 features per wavefront):
+//   the 9 x-runs of the 27-cell neighbourhood are concatenated and the lanes stride over the flat candidate list (balanced,
+//   coalesced 16 B/lane); queries with fewer than 5 candidates leave after the 18 cell_start words; each lane keeps a sorted
+//   top-5 of 64-bit (distance bits, map index) keys, the group merges with a 5-round shuffle tournament; the 5 winners'
+//   coordinates + squared distances go to HBM (80 B/feature).
 //   HBM/L2-bound: ~(16 + 72 + 16*C + 80 + 80) bytes per feature, C = candidates in the 27 cells.
 // fit_linearize_kernel<KIND> -- one lane per feature: line fit (3x3 scatter + f32 eigen-solver, hpp:669-783) or plane fit
 //   (5x3 column-pivoted QR, hpp:816-878) with the reference's gates -> residual and 1x6 Jacobian of LidarMapEdgeFactor /
@@ -17,6 +18,8 @@
 // contiguous eighth of the (spatially coherent) feature list's map neighbourhood.
 #include "ctx.hpp"
 #include "dev_math.hpp"
+#include "solver_dev.hpp"
+#include <hip/hip_ext.h>
 #include <cfloat>
 
 namespace mlh {
@@ -52,39 +55,72 @@ __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int
     return fminf(fmaxf(f, -2.f), float(n + 1));   // also squashes NaN/inf before the int conversion
 }
 
-// exact 5-NN of (qx,qy,qz) by a group of 32 lanes (half a wavefront); on return every lane holds the 5 keys ascending.
-// Lane gl < 27 works on x-run r = gl / 3 of the 27-cell neighbourhood (the 3 x-adjacent cells of one (dy,dz) are one
-// contiguous range of the cell-sorted array) as sub-lane s = gl % 3: consecutive sub-lanes read consecutive float4 points.
-// All 9 runs are in flight at once, so a query costs ~3 dependent memory round trips (cell_start, candidates, neighbours).
-__device__ __forceinline__ void knn5_group32(const GridDev &g, float qx, float qy, float qz, int gl, unsigned long long (&out)[5])
+// exact 5-NN of (qx,qy,qz) by a group of 8 lanes (8 queries per wavefront); on return every lane holds the 5 keys ascending.
+// The 27-cell neighbourhood is 9 x-runs (the 3 x-adjacent cells of one (dy,dz) are one contiguous range of the cell-sorted
+// array). Lane r fetches the bounds of run r (lane 0 also run 8); a 3-step shuffle scan gives the run offsets, which go to
+// LDS; the lanes then stride over the FLAT concatenation of the 9 runs (lane l takes candidates l, l+8, ...), so the work
+// is balanced whatever the per-run occupancy, consecutive lanes read consecutive float4 points, and a query with fewer than
+// 5 candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
+// lds_run: 20 ints per group: [0..9] prefix offsets of the runs (10 entries), [10..18] base index of each run.
+__device__ __forceinline__ void knn5_group8(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[5])
 {
     unsigned long long k[5] = {KEY_INF, KEY_INF, KEY_INF, KEY_INF, KEY_INF};
     const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
     const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
     const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    const int r = gl / 3, sl = gl - r * 3;
-    const int y = cy + (r % 3) - 1, z = cz + (r / 3) - 1;
-    const bool ok = (gl < 27) && (x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz);
-    int b = 0, e = 0;
-    if (ok) {
-        const int row = (z * g.ny + y) * g.nx;
-        b = g.cell_start[row + x0];
-        e = g.cell_start[row + x1 + 1];
-    }
-    for (int j = b + sl; j < e; j += 6) {
-        const float4 p0 = g.sorted[j];
-        const bool h1 = (j + 3) < e;
-        const float4 p1 = g.sorted[h1 ? j + 3 : j];
-        {
-            float dx = p0.x - qx, dy = p0.y - qy, dz = p0.z - qz;
-            float d = dx * dx; d += dy * dy; d += dz * dz;
-            key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p0.w));
+    int b = 0, e = 0, b8 = 0, e8 = 0;
+    {
+        const int y = cy + (gl % 3) - 1, z = cz + (gl / 3) - 1;
+        if ((x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+            const int row = (z * g.ny + y) * g.nx;
+            b = g.cell_start[row + x0];
+            e = g.cell_start[row + x1 + 1];
         }
-        if (h1) {
-            float dx = p1.x - qx, dy = p1.y - qy, dz = p1.z - qz;
-            float d = dx * dx; d += dy * dy; d += dz * dz;
-            key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p1.w));
+        const int y8 = cy + 1, z8 = cz + 1;       // run 8 = (dy, dz) = (+1, +1)
+        if (gl == 0 && (x0 <= x1) && (y8 < g.ny) && (z8 < g.nz) && (y8 >= 0) && (z8 >= 0)) {
+            const int row = (z8 * g.ny + y8) * g.nx;
+            b8 = g.cell_start[row + x0];
+            e8 = g.cell_start[row + x1 + 1];
+        }
+    }
+    const int len = e - b;
+    int incl = len;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const int t = __shfl_up(incl, off, 8);
+        if (gl >= off) incl += t;
+    }
+    const int len8 = __shfl(e8 - b8, 0, 8);
+    const int total = __shfl(incl, 7, 8) + len8;
+    if (total >= 5) {                                  // uniform over the group
+        lds_run[gl] = incl - len;                      // prefix[r]
+        lds_run[10 + gl] = b;                          // base[r]
+        if (gl == 0) { lds_run[8] = total - len8; lds_run[9] = total; lds_run[18] = b8; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int cr = 0, hi = lds_run[1], base = lds_run[10], lo = 0;
+        // 4 candidates per lane per trip: the 4 addresses depend only on the run table, so the 4 loads are in flight together
+        for (int j = gl; j < total; j += 32) {
+            float4 p[4];
+            bool v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + 8 * u;
+                v[u] = jj < total;
+                if (v[u]) {
+                    while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[10 + cr]; }
+                    p[u] = g.sorted[base + (jj - lo)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (v[u]) {
+                    float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+                    float d = dx * dx; d += dy * dy; d += dz * dz;
+                    key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
+                }
+            }
         }
     }
     // tournament merge: 5 rounds of group-min over the lanes' current heads
@@ -92,7 +128,7 @@ __device__ __forceinline__ void knn5_group32(const GridDev &g, float qx, float q
     for (int t = 0; t < 5; ++t) {
         unsigned long long m = k[0];
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
+        for (int off = 1; off < 8; off <<= 1) {
             unsigned long long o = shfl_xor_u64(m, off);
             m = o < m ? o : m;
         }
@@ -168,7 +204,7 @@ __device__ __forceinline__ void eval_edge(const d3 &p, const float (&c)[6], doub
 }
 
 // accumulate one (possibly invalid) row and reduce the 29 sums over the workgroup -> partials[tile]
-__device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, double *lds_red /*4*32*/,
+__device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, int kind, double *lds_red /*4*32*/,
                                             double *__restrict__ partial_out)
 {
     double acc[29];
@@ -215,7 +251,8 @@ __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delt
     __syncthreads();
     if (threadIdx.x < 32) {
         double v = 0.0;
-        if (threadIdx.x < 29) v = ((lds_red[threadIdx.x] + lds_red[32 + threadIdx.x]) + lds_red[64 + threadIdx.x]) + lds_red[96 + threadIdx.x];
+        const int src = (threadIdx.x == NE_CNT + 1 + kind) ? NE_CNT : threadIdx.x;   // per-kind count mirrors the count column
+        if (src < 29) v = ((lds_red[src] + lds_red[32 + src]) + lds_red[64 + src]) + lds_red[96 + src];
         partial_out[threadIdx.x] = v;
     }
 }
@@ -240,7 +277,7 @@ __device__ __forceinline__ bool in_laser_fov(const q4 &q, const d3 &t, float sx,
     return check1 < 0 && check2 > 0;
 }
 
-struct KParams {
+struct KindP {
     GridDev grid;
     const float4 *feat;      // {x,y,z,intensity}
     const float4 *covd;      // {cxx,cyy,czz,_} or null
@@ -248,14 +285,26 @@ struct KParams {
     Corr *corr;
     double *r_out;           // nullable
     double *J_out;           // nullable
-    double *partials;
-    const SolverState *state;
-    int m, n_tiles, pose_sel;
+    int m;
+    int tiles_a;             // correspondence-kernel tiles (8 features each)
+    int tiles_b;             // fit / linearise tiles (256 features each)
+};
+
+struct KParams {
+    KindP k[2];              // [MLH_SURF], [MLH_CORNER]; m = 0 when a kind is not part of the launch
+    double *partials;        // tiles_b(surf) + tiles_b(corner) records
+    SolverState *state;
+    int pose_sel;
     uint32_t flags;
     float min_match_sq_dis, min_plane_dis;
     double huber_delta, cov_measurement_trace;
     int has_lo, has_hi;      // multi-GPU ownership half-spaces (mlh_shard_set)
     float lo[4], hi[4];
+    // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose
+    int finish;              // 0: none, 1: GN
+    unsigned *ticket;
+    double eig_thre;
+    IterStatDev *stat;
 };
 
 // pointAssociateToMap (utility.h:103-117): f64 q*p + t, stored to f32
@@ -273,44 +322,127 @@ __device__ __forceinline__ bool owns(const KParams &P, float sx, float sy, float
     return own;
 }
 
-// ---- correspondence kernel: 32 lanes per feature, 8 features per workgroup
-constexpr int KNN_FPB = TPB / 32;
+// ---- correspondence kernel: 8 lanes per feature, 32 features per workgroup, both feature kinds in one launch
+constexpr int KNN_G = 8;
+constexpr int KNN_FPB = TPB / KNN_G;
 
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
-    const int tile = xcd_tile(P.n_tiles);
-    if (tile >= P.n_tiles) return;
-    const int grp = threadIdx.x >> 5, gl = threadIdx.x & 31;
+    __shared__ int s_run[KNN_FPB * 20];
+    const int total = P.k[0].tiles_a + P.k[1].tiles_a;
+    int tile = xcd_tile(total);
+    if (tile >= total) return;
+    const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
+    if (kind) tile -= P.k[0].tiles_a;
+    const KindP &K = P.k[kind];
+    const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
     const int f = tile * KNN_FPB + grp;
-    if (f >= P.m) return;
+    if (f >= K.m) return;
     const double *pose = P.pose_sel ? P.state->cand : P.state->x;
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
-    const float4 fp = P.feat[f];
+    const float4 fp = K.feat[f];
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
-    if (!owns(P, sx, sy, sz)) return;     // uniform over the 32-lane group
+    if (!owns(P, sx, sy, sz)) return;     // uniform over the 8-lane group
     unsigned long long keys[5];
-    knn5_group32(P.grid, sx, sy, sz, gl, keys);
+    knn5_group8(K.grid, sx, sy, sz, gl, s_run + grp * 20, keys);
     if (gl < 5) {
         unsigned long long kk = keys[0];
         if (gl == 1) kk = keys[1]; else if (gl == 2) kk = keys[2]; else if (gl == 3) kk = keys[3]; else if (gl == 4) kk = keys[4];
         float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
         if (kk != KEY_INF) {
-            const float4 np = P.grid.raw[(unsigned)kk];
+            const float4 np = K.grid.raw[(unsigned)kk];
             o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
         }
-        P.nbr[size_t(f) * 5 + gl] = o;
+        K.nbr[size_t(f) * 5 + gl] = o;
     }
 }
 
-// ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature
-template <int KIND>
+// the reference's plane fit + gate (feature_extract.hpp:816-840)
+__device__ __forceinline__ bool fit_plane(const float (&ax)[5], const float (&ay)[5], const float (&az)[5], float min_plane_dis, float (&coef)[6])
+{
+    float nx, ny, nz;
+    plane_fit_qr_f<5>(ax, ay, az, nx, ny, nz);
+    float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+    float negative_OA_dot_norm = 1 / nn;
+    float z = nx * nx + ny * ny + nz * nz;
+    if (z > 0.f) { float s = sqrtf(z); nx /= s; ny /= s; nz /= s; }
+    bool plane_valid = true;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        if (fabsf(nx * ax[j] + ny * ay[j] + nz * az[j] + negative_OA_dot_norm) > min_plane_dis) plane_valid = false;
+    coef[0] = nx; coef[1] = ny; coef[2] = nz; coef[3] = negative_OA_dot_norm;
+    return plane_valid;
+}
+
+// the reference's line fit + test (feature_extract.hpp:669-693, 767-777)
+__device__ __forceinline__ bool fit_line(const float (&ax)[5], const float (&ay)[5], const float (&az)[5], float (&coef)[6])
+{
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
+    cx /= 5.0f; cy /= 5.0f; cz /= 5.0f;
+    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        float t0 = ax[j] - cx, t1 = ay[j] - cy, t2 = az[j] - cz;
+        c00 += t0 * t0; c10 += t1 * t0; c11 += t1 * t1; c20 += t2 * t0; c21 += t2 * t1; c22 += t2 * t2;
+    }
+    float l0, l1, l2, vx, vy, vz;
+    eig3_largest_f(c00, c10, c11, c20, c21, c22, l0, l1, l2, vx, vy, vz);
+    coef[0] = 0.1f * vx + cx; coef[1] = 0.1f * vy + cy; coef[2] = 0.1f * vz + cz;
+    coef[3] = -0.1f * vx + cx; coef[4] = -0.1f * vy + cy; coef[5] = -0.1f * vz + cz;
+    return l2 > 3 * l1;
+}
+
+__device__ __forceinline__ double feature_weight(const KParams &P, const KindP &K, int f)
+{
+    double trace = P.cov_measurement_trace;
+    if ((P.flags & MLH_FLAG_WITH_UA)) {
+        trace = 0.0;
+        if (K.covd) { float4 cd = K.covd[f]; trace = (double(cd.x) + double(cd.y)) + double(cd.z); }
+    }
+    return sqrt_info_of(trace);
+}
+
+// Fused tail: the last workgroup to arrive (agent-scope release/acquire around an atomic ticket) sums all partial records in
+// fixed order, runs evalDegenracy + the 6x6 solve + Plus and re-arms the ticket: a GN iteration costs two launches.
+__device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tiles)
+{
+    __shared__ int s_last;
+    __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[8 * 32];   // f_scratch doubles as the Jacobi work area (DEG_WORK <= 256)
+    __syncthreads();                               // this workgroup's partial record is written
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = atomicAdd(P.ticket, 1u);
+        s_last = (tk == unsigned(total_tiles - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    SumArgs sa;
+    sa.p = P.partials;
+    sa.nb = total_tiles;
+    sum_partials(sa, f_ne, f_cnt2, f_scratch);
+    if (threadIdx.x < 2) {
+        gn_finish2(f_ne, f_cnt2, P.state, P.eig_thre, P.stat, f_scratch);
+        if (threadIdx.x == 0) *P.ticket = 0u;
+    }
+}
+
+// ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature, both kinds in one launch
 __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
-    const int tile = xcd_tile(P.n_tiles);
-    if (tile >= P.n_tiles) return;
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = xcd_tile(total);
+    if (gtile >= total) return;
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const KindP &K = P.k[kind];
     const int f = tile * TPB + threadIdx.x;
     const double *pose = P.pose_sel ? P.state->cand : P.state->x;
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
@@ -322,94 +454,61 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < P.m) {
-        fp = P.feat[f];
+    if (f < K.m) {
+        fp = K.feat[f];
         float sx, sy, sz;
         associate_to_map(q, t, fp, sx, sy, sz);
         if (owns(P, sx, sy, sz)) {
-            const float4 *nb = P.nbr + size_t(f) * 5;
+            const float4 *nb = K.nbr + size_t(f) * 5;
             const float4 n4 = nb[4];
             if (n4.w < P.min_match_sq_dis) {     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
                 float ax[5], ay[5], az[5];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float4 v = nb[j]; ax[j] = v.x; ay[j] = v.y; az[j] = v.z; }
                 ax[4] = n4.x; ay[4] = n4.y; az[4] = n4.z;
-                if (KIND == MLH_SURF) {
-                    float nx, ny, nz;
-                    plane_fit_qr_f<5>(ax, ay, az, nx, ny, nz);
-                    float nn = sqrtf(nx * nx + ny * ny + nz * nz);
-                    float negative_OA_dot_norm = 1 / nn;
-                    float z = nx * nx + ny * ny + nz * nz;
-                    if (z > 0.f) { float s = sqrtf(z); nx /= s; ny /= s; nz /= s; }
-                    bool plane_valid = true;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j)
-                        if (fabsf(nx * ax[j] + ny * ay[j] + nz * az[j] + negative_OA_dot_norm) > P.min_plane_dis) plane_valid = false;
-                    if (plane_valid) {
-                        coef[0] = nx; coef[1] = ny; coef[2] = nz; coef[3] = negative_OA_dot_norm;
-                        valid = true;
-                    }
-                } else {
-                    float cx = 0.f, cy = 0.f, cz = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
-                    cx /= 5.0f; cy /= 5.0f; cz /= 5.0f;
-                    float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) {
-                        float t0 = ax[j] - cx, t1 = ay[j] - cy, t2 = az[j] - cz;
-                        c00 += t0 * t0; c10 += t1 * t0; c11 += t1 * t1; c20 += t2 * t0; c21 += t2 * t1; c22 += t2 * t2;
-                    }
-                    float l0, l1, l2, vx, vy, vz;
-                    eig3_largest_f(c00, c10, c11, c20, c21, c22, l0, l1, l2, vx, vy, vz);
-                    if (l2 > 3 * l1) {
-                        coef[0] = 0.1f * vx + cx; coef[1] = 0.1f * vy + cy; coef[2] = 0.1f * vz + cz;
-                        coef[3] = -0.1f * vx + cx; coef[4] = -0.1f * vy + cy; coef[5] = -0.1f * vz + cz;
-                        valid = true;
-                    }
-                }
+                if (kind == MLH_SURF) valid = fit_plane(ax, ay, az, P.min_plane_dis, coef);
+                else valid = fit_line(ax, ay, az, coef);
                 if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
             }
         }
         Corr c;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c.c[i] = coef[i];
+        for (int i = 0; i < 6; ++i) c.c[i] = valid ? coef[i] : 0.f;
         c.valid = valid ? 1 : 0;
         c.pad = 0;
-        P.corr[f] = c;
+        K.corr[f] = c;
     }
     if (valid) {
-        double trace = P.cov_measurement_trace;
-        if ((P.flags & MLH_FLAG_WITH_UA)) {
-            trace = 0.0;
-            if (P.covd) { float4 cd = P.covd[f]; trace = (double(cd.x) + double(cd.y)) + double(cd.z); }
-        }
-        const double w = sqrt_info_of(trace);
+        const double w = feature_weight(P, K, f);
         double R[9];
         qtorot(q, R);
         const d3 p{double(fp.x), double(fp.y), double(fp.z)};
-        if (KIND == MLH_SURF) eval_plane(p, coef, w, q, t, R, L);
+        if (kind == MLH_SURF) eval_plane(p, coef, w, q, t, R, L);
         else eval_edge(p, coef, w, q, t, R, L);
     }
-    if (P.r_out && f < P.m) {
-        P.r_out[f] = L.r;
+    if (K.r_out && f < K.m) {
+        K.r_out[f] = L.r;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) P.J_out[size_t(f) * 6 + i] = L.J[i];
+        for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
-    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, s_red, P.partials + size_t(tile) * NE_STRIDE);
+    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    if (P.finish) fused_gn_finish(P, total);
 }
 
-template <int KIND>
 __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
-    const int tile = xcd_tile(P.n_tiles);
-    if (tile >= P.n_tiles) return;
-    const int f = tile * TPB + threadIdx.x;
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = xcd_tile(total);
+    if (gtile >= total) return;
     if (P.state->done) {   // the device-side LM loop has terminated: keep the partials defined, do no work
-        if (threadIdx.x < 32) P.partials[size_t(tile) * NE_STRIDE + threadIdx.x] = 0.0;
+        if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
         return;
     }
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const KindP &K = P.k[kind];
+    const int f = tile * TPB + threadIdx.x;
     const double *pose = P.pose_sel ? P.state->cand : P.state->x;
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
@@ -418,41 +517,37 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     L.r = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
-    if (f < P.m) {
-        const Corr c = P.corr[f];
+    if (f < K.m) {
+        const Corr c = K.corr[f];
         if (c.valid) {
             valid = true;
-            const float4 fp = P.feat[f];
-            double trace = P.cov_measurement_trace;
-            if ((P.flags & MLH_FLAG_WITH_UA)) {
-                trace = 0.0;
-                if (P.covd) { float4 cd = P.covd[f]; trace = (double(cd.x) + double(cd.y)) + double(cd.z); }
-            }
-            const double w = sqrt_info_of(trace);
+            const float4 fp = K.feat[f];
+            const double w = feature_weight(P, K, f);
             double R[9];
             qtorot(q, R);
             const d3 p{double(fp.x), double(fp.y), double(fp.z)};
-            if (KIND == MLH_SURF) eval_plane(p, c.c, w, q, t, R, L);
+            if (kind == MLH_SURF) eval_plane(p, c.c, w, q, t, R, L);
             else eval_edge(p, c.c, w, q, t, R, L);
         }
     }
-    if (P.r_out && f < P.m) {
-        P.r_out[f] = L.r;
+    if (K.r_out && f < K.m) {
+        K.r_out[f] = L.r;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) P.J_out[size_t(f) * 6 + i] = L.J[i];
+        for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
-    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, s_red, P.partials + size_t(tile) * NE_STRIDE);
+    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
 }
 
 // stand-alone exact 5-NN for mlh_knn (queries already in the map frame)
 __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
                                                           float *__restrict__ d2)
 {
-    const int grp = threadIdx.x >> 5, gl = threadIdx.x & 31;
+    __shared__ int s_run[KNN_FPB * 20];
+    const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
     const int qi = blockIdx.x * KNN_FPB + grp;
     if (qi >= nq) return;
     unsigned long long keys[5];
-    knn5_group32(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, keys);
+    knn5_group8(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
     if (gl == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -466,31 +561,47 @@ __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const fl
 // ---------------------------------------------------------------- host launchers
 static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
 {
-    FeatSet &fs = ctx->feat[a.kind];
-    MapGrid &mg = ctx->map[a.kind];
-    if (!mg.built) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
-    if (fs.m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set has not been called for this kind");
-    const int n_tiles = (fs.m + TPB - 1) / TPB;
-    hipError_t e;
-    if ((e = fs.corr.ensure(sizeof(Corr) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc corr", e);
-    if ((e = fs.nbr.ensure(sizeof(float4) * 5 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc nbr", e);
-    if ((e = fs.partials.ensure(sizeof(double) * NE_STRIDE * size_t(n_tiles))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
-    if (a.dense) {
-        if ((e = fs.r.ensure(sizeof(double) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc r", e);
-        if ((e = fs.J.ensure(sizeof(double) * 6 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc J", e);
+    std::memset(&P, 0, sizeof(P));
+    int tiles_b_total = 0;
+    for (int k = 0; k < 2; ++k) {
+        KindP &K = P.k[k];
+        if (!(a.kind_mask & (1 << k))) continue;
+        FeatSet &fs = ctx->feat[k];
+        MapGrid &mg = ctx->map[k];
+        if (!mg.built) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+        if (fs.m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set has not been called for this kind");
+        // the cell edge was derived from the acceptance radius given at map_set; a larger radius here would break exactness
+        if (a.min_match_sq_dis > 0.f && std::sqrt(a.min_match_sq_dis) > mg.h)
+            return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis exceeds the value the map grid was built for");
+        hipError_t e;
+        if ((e = fs.corr.ensure(sizeof(Corr) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc corr", e);
+        if ((e = fs.nbr.ensure(sizeof(float4) * 5 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc nbr", e);
+        if (a.dense) {
+            if ((e = fs.r.ensure(sizeof(double) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc r", e);
+            if ((e = fs.J.ensure(sizeof(double) * 6 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc J", e);
+        }
+        K.grid = mg.dev();
+        K.feat = fs.pts.as<float4>();
+        K.covd = fs.has_cov ? fs.covd.as<float4>() : nullptr;
+        K.nbr = fs.nbr.as<float4>();
+        K.corr = fs.corr.as<Corr>();
+        K.r_out = a.dense ? fs.r.as<double>() : nullptr;
+        K.J_out = a.dense ? fs.J.as<double>() : nullptr;
+        K.m = fs.m;
+        K.tiles_a = (fs.m + KNN_FPB - 1) / KNN_FPB;
+        K.tiles_b = (fs.m + TPB - 1) / TPB;
+        tiles_b_total += K.tiles_b;
     }
-    fs.n_blocks = n_tiles;
-    P.grid = mg.dev();
-    P.feat = fs.pts.as<float4>();
-    P.covd = fs.has_cov ? fs.covd.as<float4>() : nullptr;
-    P.corr = fs.corr.as<Corr>();
-    P.nbr = fs.nbr.as<float4>();
-    P.r_out = a.dense ? fs.r.as<double>() : nullptr;
-    P.J_out = a.dense ? fs.J.as<double>() : nullptr;
-    P.partials = fs.partials.as<double>();
+    if (tiles_b_total == 0) return fail(ctx, MLH_ERR_STATE, "no map/features staged for the requested kinds");
+    hipError_t e;
+    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
+    if (!ctx->ticket.p) {
+        if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
+        if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
+    }
+    ctx->n_partial_tiles = tiles_b_total;
+    P.partials = ctx->partials.as<double>();
     P.state = ctx->state.as<SolverState>();
-    P.m = fs.m;
-    P.n_tiles = n_tiles;
     P.pose_sel = a.pose_sel;
     P.flags = a.flags;
     P.min_match_sq_dis = a.min_match_sq_dis;
@@ -500,7 +611,21 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.has_lo = ctx->shard_lo ? 1 : 0;
     P.has_hi = ctx->shard_hi ? 1 : 0;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
+    P.finish = a.finish;
+    P.ticket = ctx->ticket.as<unsigned>();
+    P.eig_thre = a.map_eig_thre;
+    P.stat = (a.stat_slot >= 0) ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     return MLH_OK;
+}
+
+template <typename Kern>
+static void launch_timed(mlh_ctx *ctx, int kid, Kern kern, int grid, const KParams &P)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (prof_kernel_events(ctx, kid, &a, &b))
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, a, b, 0, P);   // start/stop = the dispatch's own timestamps
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, P);
 }
 
 int match_launch(mlh_ctx *ctx, const MatchArgs &a)
@@ -508,37 +633,25 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     KParams P;
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
-    // the cell edge was derived from the acceptance radius given at map_set; a larger radius here would break exactness
-    const MapGrid &mg = ctx->map[a.kind];
-    if (std::sqrt(a.min_match_sq_dis) > mg.h) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis exceeds the value the map grid was built for");
     // kernel A: correspondences (32 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
-    KParams PA = P;
-    PA.n_tiles = (P.m + KNN_FPB - 1) / KNN_FPB;
-    const int grid_a = ((PA.n_tiles + 7) / 8) * 8;
-    const int grid_b = ((P.n_tiles + 7) / 8) * 8;
-    prof_begin(ctx, a.kind == MLH_SURF ? MLH_K_KNN_SURF : MLH_K_KNN_CORNER);
-    hipLaunchKernelGGL(knn_features_kernel, dim3(grid_a), dim3(TPB), 0, ctx->stream, PA);
-    prof_end(ctx, a.kind == MLH_SURF ? MLH_K_KNN_SURF : MLH_K_KNN_CORNER);
-    prof_begin(ctx, a.kind == MLH_SURF ? MLH_K_FIT_SURF : MLH_K_FIT_CORNER);
-    if (a.kind == MLH_SURF) hipLaunchKernelGGL((fit_linearize_kernel<MLH_SURF>), dim3(grid_b), dim3(TPB), 0, ctx->stream, P);
-    else hipLaunchKernelGGL((fit_linearize_kernel<MLH_CORNER>), dim3(grid_b), dim3(TPB), 0, ctx->stream, P);
-    prof_end(ctx, a.kind == MLH_SURF ? MLH_K_FIT_SURF : MLH_K_FIT_CORNER);
+    const int grid_a = ((P.k[0].tiles_a + P.k[1].tiles_a + 7) / 8) * 8;
+    const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
+    launch_timed(ctx, MLH_K_KNN, knn_features_kernel, grid_a, P);
+    launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
-    ctx->feat[a.kind].matched = true;
+    for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
     return MLH_OK;
 }
 
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a)
 {
-    if (!ctx->feat[a.kind].matched) return fail(ctx, MLH_ERR_STATE, "linearize needs a previous match of this kind");
+    for (int k = 0; k < 2; ++k)
+        if ((a.kind_mask & (1 << k)) && !ctx->feat[k].matched) return fail(ctx, MLH_ERR_STATE, "linearize needs a previous match of this kind");
     KParams P;
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
-    const int grid = ((P.n_tiles + 7) / 8) * 8;
-    prof_begin(ctx, MLH_K_LINEARIZE);
-    if (a.kind == MLH_SURF) hipLaunchKernelGGL((linearize_kernel<MLH_SURF>), dim3(grid), dim3(TPB), 0, ctx->stream, P);
-    else hipLaunchKernelGGL((linearize_kernel<MLH_CORNER>), dim3(grid), dim3(TPB), 0, ctx->stream, P);
-    prof_end(ctx, MLH_K_LINEARIZE);
+    const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
+    launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

@@ -10,246 +10,22 @@
 //                       lidar_mapper_keyframe.cpp:586-596 (DENSE_SCHUR on a single block == dense 6x6 solve).
 #include "ctx.hpp"
 #include "dev_math.hpp"
+#include "solver_dev.hpp"
 
 namespace mlh {
 
-struct SumArgs {
-    const double *p[2];
-    int nb[2];
-};
-
-// 256 threads: column c = tid & 31, slice s = tid >> 5 sums tiles s, s+8, ...; slices combined in fixed order.
-__device__ void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS 2*8*32*/)
-{
-    const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        double v = 0.0;
-        if (a.p[k]) for (int b = s; b < a.nb[k]; b += 8) v += a.p[k][size_t(b) * NE_STRIDE + c];
-        scratch[(k * 8 + s) * 32 + c] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { t0 += scratch[(0 * 8 + q) * 32 + c]; t1 += scratch[(1 * 8 + q) * 32 + c]; }
-        ne[c] = t0 + t1;
-        if (c == NE_CNT) { cnt2[0] = t0; cnt2[1] = t1; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { ne[NE_CNT + 1] = cnt2[0]; ne[NE_CNT + 2] = cnt2[1]; }
-    __syncthreads();
-}
-
-// either sum this rank's partials, or (multi-GPU) take the already all-reduced record from the solver state
-__device__ void gather_ne(const SumArgs &a, const SolverState *S, int pre_reduced, double *ne, double *cnt2, double *scratch)
-{
-    if (pre_reduced) {
-        if (threadIdx.x < NE_STRIDE) ne[threadIdx.x] = S->ne[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 0) { cnt2[0] = ne[NE_CNT + 1]; cnt2[1] = ne[NE_CNT + 2]; }
-        __syncthreads();
-    } else {
-        sum_partials(a, ne, cnt2, scratch);
-    }
-}
-
-__device__ __forceinline__ void unpack_H(const double *ne, double (&H)[36])
-{
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            const int q = i * 6 - (i * (i - 1)) / 2 + (j - i);   // packed upper-triangular index
-            H[i * 6 + j] = ne[q]; H[j * 6 + i] = ne[q];
-        }
-}
-
-// cyclic Jacobi, eigenvalues ascending, eigenvectors in the columns of V (row-major 6x6)
-__device__ void jacobi6(const double *Hin, double *ev, double *V)
-{
-    double a[36];
-    for (int i = 0; i < 36; ++i) a[i] = Hin[i];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int i = 0; i < 6; ++i) { dg += a[i * 6 + i] * a[i * 6 + i]; for (int j = i + 1; j < 6; ++j) off += a[i * 6 + j] * a[i * 6 + j]; }
-        if (off <= 1e-32 * dg || off == 0.0) break;
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                double apq = a[p * 6 + q];
-                if (apq == 0.0) continue;
-                double theta = (a[q * 6 + q] - a[p * 6 + p]) / (2.0 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 6; ++k) {
-                    double akp = a[k * 6 + p], akq = a[k * 6 + q];
-                    a[k * 6 + p] = c * akp - s * akq;
-                    a[k * 6 + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    double apk = a[p * 6 + k], aqk = a[q * 6 + k];
-                    a[p * 6 + k] = c * apk - s * aqk;
-                    a[q * 6 + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
-                    V[k * 6 + p] = c * vkp - s * vkq;
-                    V[k * 6 + q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    for (int i = 0; i < 6; ++i) ev[i] = a[i * 6 + i];
-    for (int i = 0; i < 5; ++i) {
-        int k = i;
-        for (int j = i + 1; j < 6; ++j) if (ev[j] < ev[k]) k = j;
-        if (k != i) {
-            double t = ev[i]; ev[i] = ev[k]; ev[k] = t;
-            for (int r = 0; r < 6; ++r) { double u = V[r * 6 + i]; V[r * 6 + i] = V[r * 6 + k]; V[r * 6 + k] = u; }
-        }
-    }
-}
-
-// evalDegenracy: zero the eigenvectors below the threshold (ascending, stop at the first one above),
-// V_update = (V_f^T)^-1 V_p^T = V_f V_p^T for orthonormal V_f; identity when nothing is degenerate.
-__device__ __noinline__ bool eval_degeneracy_dev(const double *H, double thre, double *ev, double *Vupd)
-{
-    double Vf[36];
-    jacobi6(H, ev, Vf);
-    bool keep[6];
-    bool deg = false, stop = false;
-    for (int j = 0; j < 6; ++j) {
-        if (!stop && ev[j] < thre) { keep[j] = false; deg = true; }
-        else { keep[j] = true; stop = true; }
-    }
-    for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 6; ++c) {
-            double s = 0.0;
-            if (deg) { for (int j = 0; j < 6; ++j) if (keep[j]) s += Vf[r * 6 + j] * Vf[c * 6 + j]; }
-            else s = (r == c) ? 1.0 : 0.0;
-            Vupd[r * 6 + c] = s;
-        }
-    return deg;
-}
-
-// Cholesky factor / solve of a 6x6 SPD system, fully unrolled so that A, L, y live in registers (no scratch).
-__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36])
-{
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double s = A[j * 6 + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
-        ok = ok && (s > 0.0);
-        const double ljj = sqrt(s);
-        L[j * 6 + j] = ljj;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-            double t = A[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = t / ljj;
-        }
-    }
-    return ok;
-}
-
-__device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
-{
-    double L[36];
-    if (!chol6_factor(A, L)) return false;
-    double y[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double s = b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
-    }
-    return true;
-}
-
-// evalDegenracy with a fast path: H - thre*I positive definite  <=>  lambda_min > thre  =>  nothing is degenerate and
-// V_update = I; the eigen-decomposition is only run when that test fails or when the eigenvalues are wanted for the
-// per-iteration record (the reference logs them, lidar_mapper_keyframe.cpp:1190-1193).
-__device__ bool degeneracy(const double (&H)[36], double thre, bool need_eig, double (&ev)[6], double (&Vupd)[36])
-{
-    if (!need_eig) {
-        double A[36], L[36];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) A[i] = H[i];
-        const double sh = thre * (1.0 + 1e-9);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) A[i * 6 + i] -= sh;
-        if (chol6_factor(A, L)) {
-#pragma unroll
-            for (int i = 0; i < 36; ++i) Vupd[i] = ((i % 7) == 0) ? 1.0 : 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ev[i] = 0.0;
-            return false;
-        }
-    }
-    return eval_degeneracy_dev(H, thre, ev, Vupd);
-}
-
-__device__ void write_stat_common(IterStatDev *st, const double *ne, const double *cnt2, const double *H, const double *ev, bool deg)
-{
-    st->n_surf = int(cnt2[0] + 0.5);
-    st->n_corner = int(cnt2[1] + 0.5);
-    st->is_degenerate = deg ? 1 : 0;
-    st->cost = ne[NE_COST];
-    for (int i = 0; i < 6; ++i) { st->eigval[i] = ev[i]; st->g[i] = ne[NE_G + i]; }
-    for (int i = 0; i < 36; ++i) st->H[i] = H[i];
-}
-
 __global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState *S, double eig_thre, IterStatDev *stat, int pre_reduced)
 {
-    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
+    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
-    if (threadIdx.x != 0) return;
-    double H[36], ev[6], V[36];
-    unpack_H(ne, H);
-    const bool deg = degeneracy(H, eig_thre, stat != nullptr, ev, V);
-    double rhs[6], d[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
-    bool ok = chol6_solve(H, rhs, d);
-    if (!ok) {
-        double Hd[36];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) Hd[i] = H[i] + (((i % 7) == 0) ? 1e-6 : 0.0);
-        ok = chol6_solve(Hd, rhs, d);
-    }
-    if (ok) {
-        double xc[7], xn[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) xc[i] = S->x[i];
-        pose_plus(xc, d, V, xn);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) S->x[i] = xn[i];
-    }
-    for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
-    for (int i = 0; i < 36; ++i) S->V[i] = V[i];
-    if (stat) {
-        write_stat_common(stat, ne, cnt2, H, ev, deg);
-        stat->final_cost = ne[NE_COST];
-        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = 0;
-        for (int i = 0; i < 7; ++i) stat->pose_after[i] = S->x[i];
-    }
+    if (threadIdx.x >= 2) return;
+    gn_finish2(ne, cnt2, S, eig_thre, stat, scratch);
 }
 
 // reduce only: S->ne <- sum of partials (used by the host-driven mlh_match_linearize / mlh_linearize)
 __global__ __launch_bounds__(256) void reduce_only_kernel(SumArgs sa, SolverState *S, int to_ce)
 {
-    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
+    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     sum_partials(sa, ne, cnt2, scratch);
     if (threadIdx.x < NE_STRIDE) (to_ce ? S->ce : S->ne)[threadIdx.x] = ne[threadIdx.x];
 }
@@ -316,20 +92,21 @@ __device__ void lm_propose(SolverState *S, int max_it)
 
 __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat, int pre_reduced)
 {
-    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
+    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
-    double H[36], ev[6], V[36];
-    unpack_H(ne, H);
-    bool deg = eval_degeneracy_dev(H, eig_thre, ev, V);
+    bool deg = eval_degeneracy_mem(ne, eig_thre, scratch);
     for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
-    for (int i = 0; i < 36; ++i) S->V[i] = V[i];
-    for (int i = 0; i < 6; ++i) S->S[i] = 1.0 / (1.0 + sqrt(H[i * 6 + i]));
+    for (int i = 0; i < 36; ++i) S->V[i] = scratch[78 + i];
+    {
+        int q = 0;
+        for (int i = 0; i < 6; ++i) { S->S[i] = 1.0 / (1.0 + sqrt(ne[q])); q += 6 - i; }   // Jacobi scaling from diag(J^T J)
+    }
     S->radius = 1e4; S->decrease_factor = 2.0; S->reuse_diagonal = 0;
     S->iteration = 0; S->done = 0; S->termination = 0; S->num_successful = 0; S->num_invalid = 0; S->evaluations = 1;
     S->gmax = gradient_max_norm(S);
     if (stat) {
-        write_stat_common(stat, ne, cnt2, H, ev, deg);
+        write_stat_common(stat, ne, cnt2, scratch + 72, deg);
         stat->final_cost = ne[NE_COST];
     }
     lm_propose(S, max_it);
@@ -337,7 +114,7 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *
 
 __global__ __launch_bounds__(256) void lm_step_kernel(SumArgs sa, SolverState *S, int max_it, int pre_reduced)
 {
-    __shared__ double ce[NE_STRIDE], cnt2[2], scratch[2 * 8 * 32];
+    __shared__ double ce[NE_STRIDE], cnt2[2], scratch[8 * 32];
     if (S->done) return;
     if (pre_reduced) {
         if (threadIdx.x < NE_STRIDE) ce[threadIdx.x] = S->ce[threadIdx.x];
@@ -382,15 +159,11 @@ __global__ void lm_finish_kernel(const SolverState *S, IterStatDev *stat)
 }
 
 // ---------------------------------------------------------------- host launchers
-static SumArgs make_sum_args(mlh_ctx *ctx, int kind_mask)
+static SumArgs make_sum_args(mlh_ctx *ctx)
 {
     SumArgs sa;
-    for (int k = 0; k < 2; ++k) {
-        const FeatSet &fs = ctx->feat[k];
-        bool use = (kind_mask & (1 << k)) && fs.m > 0 && fs.n_blocks > 0 && fs.partials.p;
-        sa.p[k] = use ? fs.partials.as<double>() : nullptr;
-        sa.nb[k] = use ? fs.n_blocks : 0;
-    }
+    sa.p = ctx->partials.as<double>();
+    sa.nb = ctx->n_partial_tiles;
     return sa;
 }
 
@@ -399,9 +172,9 @@ static IterStatDev *stat_ptr(mlh_ctx *ctx, int slot)
     return slot >= 0 ? ctx->stats.as<IterStatDev>() + slot : nullptr;
 }
 
-int reduce_only_launch(mlh_ctx *ctx, int kind_mask, int to_ce)
+int reduce_only_launch(mlh_ctx *ctx, int to_ce)
 {
-    hipLaunchKernelGGL(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, kind_mask), ctx->state.as<SolverState>(), to_ce);
+    hipLaunchKernelGGL(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), to_ce);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -411,7 +184,7 @@ static int pre_reduce(mlh_ctx *ctx, int to_ce, int &pre_reduced)
 {
     pre_reduced = 0;
     if (!ctx->comm) return MLH_OK;
-    int rc = reduce_only_launch(ctx, 3, to_ce);
+    int rc = reduce_only_launch(ctx, to_ce);
     if (rc) return rc;
     if ((rc = comm_allreduce_state(ctx, to_ce))) return rc;
     pre_reduced = 1;
@@ -423,7 +196,7 @@ int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
     int pre = 0, rc = pre_reduce(ctx, 0, pre);
     if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(),
+    hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
                        map_eig_thre, stat_ptr(ctx, stat_slot), pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
@@ -435,7 +208,7 @@ int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int s
     int pre = 0, rc = pre_reduce(ctx, 0, pre);
     if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(),
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
                        map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
@@ -448,7 +221,7 @@ int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot)
     int pre = 0, rc = pre_reduce(ctx, 1, pre);
     if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx, 3), ctx->state.as<SolverState>(), max_iterations, pre);
+    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), max_iterations, pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

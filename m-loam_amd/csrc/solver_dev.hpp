@@ -1,0 +1,260 @@
+// Device-side pieces of the optimiser shared by solver.hip (stand-alone update kernels) and match.hip (the fit kernel's
+// last-arriving workgroup finishes the Gauss-Newton iteration itself): fixed-order summation of the per-tile partial normal
+// equations, evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204), register-resident 6x6 Cholesky, the GN step.
+#pragma once
+#include "ctx.hpp"
+#include "dev_math.hpp"
+
+namespace mlh {
+
+struct SumArgs {
+    const double *p;   // per-tile partial records (NE_STRIDE doubles each), surf tiles first, then corner tiles
+    int nb;
+};
+
+// 256 threads: column c = tid & 31, slice s = tid >> 5 sums tiles s, s+8, ...; the 8 slices are combined in fixed order.
+// Record layout: [0..20] J^T J upper, [21..26] J^T r, [27] cost, [28] count, [29] surf count, [30] corner count.
+__device__ inline void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS 8*32*/)
+{
+    const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+    double v = 0.0;
+    if (a.p) {
+        // fixed association: tiles s, s+8, ... in four interleaved chains (loads of a trip are independent -> in flight together)
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int b = s;
+        for (; b + 24 < a.nb; b += 32) {
+            const double t0 = a.p[size_t(b) * NE_STRIDE + c], t1 = a.p[size_t(b + 8) * NE_STRIDE + c];
+            const double t2 = a.p[size_t(b + 16) * NE_STRIDE + c], t3 = a.p[size_t(b + 24) * NE_STRIDE + c];
+            v0 += t0; v1 += t1; v2 += t2; v3 += t3;
+        }
+        for (; b < a.nb; b += 8) v0 += a.p[size_t(b) * NE_STRIDE + c];
+        v = (v0 + v1) + (v2 + v3);
+    }
+    scratch[s * 32 + c] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += scratch[q * 32 + c];
+        ne[c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt2[0] = ne[NE_CNT + 1]; cnt2[1] = ne[NE_CNT + 2]; }
+    __syncthreads();
+}
+
+// either sum this rank's partials, or (multi-GPU) take the already all-reduced record from the solver state
+__device__ inline void gather_ne(const SumArgs &a, const SolverState *S, int pre_reduced, double *ne, double *cnt2, double *scratch)
+{
+    if (pre_reduced) {
+        if (threadIdx.x < NE_STRIDE) ne[threadIdx.x] = S->ne[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) { cnt2[0] = ne[NE_CNT + 1]; cnt2[1] = ne[NE_CNT + 2]; }
+        __syncthreads();
+    } else {
+        sum_partials(a, ne, cnt2, scratch);
+    }
+}
+
+__device__ __forceinline__ void unpack_H(const double *ne, double (&H)[36])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            const int q = i * 6 - (i * (i - 1)) / 2 + (j - i);   // packed upper-triangular index
+            H[i * 6 + j] = ne[q]; H[j * 6 + i] = ne[q];
+        }
+}
+
+// cyclic Jacobi, eigenvalues ascending, eigenvectors in the columns of V (row-major 6x6).
+// `a` (36) and `V` (36) must be in LDS (or global): they are indexed dynamically, and keeping them out of private memory
+// keeps the calling kernels free of scratch. One lane runs this; it is the rare path (degenerate geometry or stats requested).
+__device__ __noinline__ void jacobi6_mem(double *a, double *V, double *ev)
+{
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < 6; ++i) { dg += a[i * 6 + i] * a[i * 6 + i]; for (int j = i + 1; j < 6; ++j) off += a[i * 6 + j] * a[i * 6 + j]; }
+        if (off <= 1e-32 * dg || off == 0.0) break;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double apq = a[p * 6 + q];
+                if (apq == 0.0) continue;
+                double theta = (a[q * 6 + q] - a[p * 6 + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; ++k) {
+                    double akp = a[k * 6 + p], akq = a[k * 6 + q];
+                    a[k * 6 + p] = c * akp - s * akq;
+                    a[k * 6 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double apk = a[p * 6 + k], aqk = a[q * 6 + k];
+                    a[p * 6 + k] = c * apk - s * aqk;
+                    a[q * 6 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
+                    V[k * 6 + p] = c * vkp - s * vkq;
+                    V[k * 6 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 6; ++i) ev[i] = a[i * 6 + i];
+    for (int i = 0; i < 5; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 6; ++j) if (ev[j] < ev[k]) k = j;
+        if (k != i) {
+            double t = ev[i]; ev[i] = ev[k]; ev[k] = t;
+            for (int r = 0; r < 6; ++r) { double u = V[r * 6 + i]; V[r * 6 + i] = V[r * 6 + k]; V[r * 6 + k] = u; }
+        }
+    }
+}
+
+// evalDegenracy: zero the eigenvectors below the threshold (ascending, stop at the first one above),
+// V_update = (V_f^T)^-1 V_p^T = V_f V_p^T for orthonormal V_f; identity when nothing is degenerate.
+// work: 36 + 36 + 6 + 36 doubles of LDS/global scratch space; results: work[72..77] = eigenvalues, work[78..113] = V_update.
+constexpr int DEG_WORK = 36 + 36 + 6 + 36;
+__device__ __noinline__ bool eval_degeneracy_mem(const double *ne, double thre, double *work)
+{
+    double *a = work, *Vf = work + 36, *ev = work + 72, *Vupd = work + 78;
+    int q = 0;
+    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { a[i * 6 + j] = ne[q]; a[j * 6 + i] = ne[q]; ++q; }
+    jacobi6_mem(a, Vf, ev);
+    bool deg = false, stop = false;
+    int first_kept = 6;
+    for (int j = 0; j < 6; ++j) {
+        if (!stop && ev[j] < thre) deg = true;
+        else { if (!stop) first_kept = j; stop = true; }
+    }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            double s = 0.0;
+            if (deg) { for (int j = first_kept; j < 6; ++j) s += Vf[r * 6 + j] * Vf[c * 6 + j]; }
+            else s = (r == c) ? 1.0 : 0.0;
+            Vupd[r * 6 + c] = s;
+        }
+    return deg;
+}
+
+// Cholesky factor / solve of a 6x6 SPD system, fully unrolled so that A, L, y live in registers (no scratch).
+__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36])
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+        ok = ok && (s > 0.0);
+        const double ljj = sqrt(s);
+        L[j * 6 + j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = t / ljj;
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
+{
+    double L[36];
+    if (!chol6_factor(A, L)) return false;
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    return true;
+}
+
+__device__ __noinline__ void write_stat_common(IterStatDev *st, const double *ne, const double *cnt2, const double *ev, bool deg)
+{
+    st->n_surf = int(cnt2[0] + 0.5);
+    st->n_corner = int(cnt2[1] + 0.5);
+    st->is_degenerate = deg ? 1 : 0;
+    st->cost = ne[NE_COST];
+    for (int i = 0; i < 6; ++i) { st->eigval[i] = ev[i]; st->g[i] = ne[NE_G + i]; }
+    int q = 0;
+    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { st->H[i * 6 + j] = ne[q]; st->H[j * 6 + i] = ne[q]; ++q; }
+}
+
+
+// The tail of a Gauss-Newton iteration: evalDegenracy -> solve H d = -g -> x <- Plus(x, V_update d).
+// Called by lanes 0 and 1 of one wavefront (converged): both run the same register-resident Cholesky factorisation in
+// lock-step -- lane 0 on H (for the solve), lane 1 on H - thre*I (positive definite <=> lambda_min > thre <=> nothing is
+// degenerate) -- so the degeneracy test costs no extra time. Lane 0 then finishes. `ne` / `cnt2`: the reduced record in LDS.
+__device__ inline void gn_finish2(const double *ne, const double *cnt2, SolverState *S, double eig_thre, IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
+{
+    const int lane = threadIdx.x & 63;
+    double H[36], A[36], L[36];
+    unpack_H(ne, H);
+    const double sh = (lane == 1) ? eig_thre * (1.0 + 1e-9) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = H[i] - (((i % 7) == 0) ? sh : 0.0);
+    const bool pd = chol6_factor(A, L);
+    const bool not_degenerate_fast = __shfl(pd ? 1 : 0, 1) != 0;
+    if (lane != 0) return;
+    bool deg = false;
+    const bool slow = !(stat == nullptr && not_degenerate_fast);
+    if (slow) deg = eval_degeneracy_mem(ne, eig_thre, work);
+    double d[6];
+    bool ok = pd;
+    if (ok) {
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double s = -ne[NE_G + i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+            y[i] = s / L[i * 6 + i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * d[k];
+            d[i] = s / L[i * 6 + i];
+        }
+    } else {
+        double Hd[36], rhs[6];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) Hd[i] = H[i] + (((i % 7) == 0) ? 1e-6 : 0.0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
+        ok = chol6_solve(Hd, rhs, d);
+    }
+    if (ok) {
+        double xc[7], xn[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xc[i] = S->x[i];
+        pose_plus(xc, d, slow ? work + 78 : nullptr, xn);   // V_update = I on the fast path
+#pragma unroll
+        for (int i = 0; i < 7; ++i) S->x[i] = xn[i];
+    }
+    for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
+    for (int i = 0; i < 36; ++i) S->V[i] = slow ? work[78 + i] : (((i % 7) == 0) ? 1.0 : 0.0);
+    if (stat) {
+        write_stat_common(stat, ne, cnt2, work + 72, deg);
+        stat->final_cost = ne[NE_COST];
+        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = 0;
+        for (int i = 0; i < 7; ++i) stat->pose_after[i] = S->x[i];
+    }
+}
+
+}  // namespace mlh
