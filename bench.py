@@ -44,7 +44,7 @@ def build_workload(synth, preset, seed=42):
     return sc, surf_map, corner_map, gt, scans
 
 
-def fuse_features(synth, scans, extracted):
+def fuse_features(synth, scans, extracted, thin=True):
     """per-LiDAR extraction results -> the mapper's two feature clouds (reference-LiDAR frame, intensity = LiDAR id,
     visualization.cpp:40-52), thinned at MAP_SURF_RES / MAP_CORNER_RES as downsampleCurrentScan does."""
     surf, corner = [], []
@@ -54,14 +54,16 @@ def fuse_features(synth, scans, extracted):
         T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]
         for lst, key, res in ((corner, "less_sharp", None), (surf, "less_flat_raw", 0.2)):
             pts = sc.points[ex[key]][:, :3]
-            if res:   # the per-ring 0.2 m VoxelGrid of extractCloud (cpp:266-271), as data preparation here
+            if res and thin:   # the per-ring 0.2 m VoxelGrid of extractCloud (cpp:266-271), as data preparation here
                 pts = synth.voxel_mean(pts, res)
             a = np.zeros((len(pts), 4), np.float32)
             a[:, :3] = synth.transform_points(pts, T)
             a[:, 3] = i
             lst.append(a)
-    surf = synth.voxel_mean(np.concatenate(surf), 0.4)
-    corner = synth.voxel_mean(np.concatenate(corner), 0.2)
+    surf, corner = np.concatenate(surf), np.concatenate(corner)
+    if thin:
+        surf = synth.voxel_mean(surf, 0.4)
+        corner = synth.voxel_mean(corner, 0.2)
     surf[:, 3] = np.round(surf[:, 3])
     corner[:, 3] = np.round(corner[:, 3])
     return np.ascontiguousarray(surf), np.ascontiguousarray(corner)
@@ -95,6 +97,8 @@ def main():
     ap.add_argument("--no-map-rebuild", action="store_true", help="leave the map index build out of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dense-features", action="store_true",
+                    help="supplementary saturation run: do NOT thin the scan features at MAP_SURF_RES/MAP_CORNER_RES (not BASELINE's workload)")
     ap.add_argument("--profile-events", type=int, default=1,
                     help="1: HIP-event bracket the dominant kernel (surf correspondence) inside the timed region; 0: none")
     args = ap.parse_args()
@@ -141,7 +145,7 @@ def main():
         ctx.profile_enable(0)
         extract_ms.append(ms / max(n, 1))
         extracted.append(ctx.extract_fetch())
-    surf, corner = fuse_features(synth, scans, extracted)
+    surf, corner = fuse_features(synth, scans, extracted, thin=not args.dense_features)
     n_scan_points = int(sum(len(s.points) for s in scans))
 
     # --- map shards (N > 1): angular wedges around the predicted sensor position, halo 1.1 m
@@ -243,7 +247,7 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("workload") == f"{N_LIDARS}x{N_RINGS}_vs_{preset}" and world == 1:
+                if pmc.get("workload") == f"{N_LIDARS}x{N_RINGS}_vs_{preset}" and world == 1 and not args.dense_features:
                     roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = pmc.get("source")
             except Exception:
@@ -258,6 +262,7 @@ def main():
                    config=dict(workload=f"{N_LIDARS}x{N_RINGS}-ring synthetic scan ({n_scan_points} pts) vs {preset} local map "
                                         f"({len(surf_map) + len(corner_map)} pts), {GN_ITERS} GN iters/frame, re-matched every iteration",
                                features_surf=len(surf), features_corner=len(corner), gn_iters_per_step=GN_ITERS,
+                               scan_features_thinned=not args.dense_features,
                                map_index_rebuilt_every_step=not args.no_map_rebuild,
                                parallelism=("1 GPU" if world == 1 else f"map sharded in {world} angular wedges + RCCL all-reduce of 32 f64/iter"),
                                hip_events_in_timed_region=("dominant kernel only" if args.profile_events else "none")),
