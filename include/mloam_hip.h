@@ -142,6 +142,20 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
 int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, double huber_delta, double cov_measurement_trace,
                   double *r, double *J, double *JtJ, double *Jtr, double *cost, int32_t *n_valid);
 
+/* ---------------------------------------------------------------- (a13) good-feature selection
+ * replaces ActiveFeatureSelection::goodFeatureMatching (estimator/src/lidarMapper/lidar_mapper.h:229-573).
+ * ALL features of `kind` are matched and their weighted, un-corrected 1x6 Jacobians evaluated on the GPU in one pass
+ * (what match*PointFromMap + evaluateFeatJacobianMatching produce one feature at a time, lidar_mapper.h:130-174, 483-521); the
+ * inherently sequential selection loop -- rnd / fps / stochastic-greedy logdet (gd_fix, gd_float) -- then runs on the host
+ * over those rows with the reference's draw sequence (std::mt19937 + uniform_int_distribution, common/random_generator.hpp:53;
+ * the MAX_FEATURE_SELECT_TIME wall-clock cut-off is not applied). sub_mat_H must come in as the reference initialises it
+ * (1e-6 * I, cpp:505/520) and returns H + sum j^T j of the selected rows. On return only the selected features stay valid
+ * on the device, so mlh_linearize / the LM of mlh_scan2map see exactly the residual blocks the reference would add. */
+enum { MLH_GF_WO = 0, MLH_GF_RND = 1, MLH_GF_FPS = 2, MLH_GF_GD_FIX = 3, MLH_GF_GD_FLOAT = 4 };
+int mlh_good_feature_matching(mlh_ctx *ctx, int kind, const double pose[7], int gf_method, double gf_ratio, uint64_t seed,
+                              float min_match_sq_dis, float min_plane_dis, int32_t *sel_idx, int32_t *n_sel,
+                              double sub_mat_H[36], uint8_t *matched);
+
 /* ---------------------------------------------------------------- (a16, a17) device-resident solvers
  * Common options. */
 typedef struct mlh_solver_opts {
@@ -153,6 +167,9 @@ typedef struct mlh_solver_opts {
     uint32_t flags;                  /* MLH_FLAG_WITH_UA | MLH_FLAG_CHECK_FOV */
     int max_outer;                   /* max_iter = 2, cpp:439 */
     int max_lm_iterations;           /* options.max_num_iterations = 30, cpp:590 */
+    int gf_method;                   /* FLAGS_gf_method: MLH_GF_* (lidar_mapper.h:89); mlh_scan2map only */
+    double gf_ratio;                 /* gf_ratio_cur (cpp:474-492) */
+    uint64_t gf_seed;                /* the reference seeds its mt19937 from std::random_device; fixed here */
 } mlh_solver_opts;
 void mlh_solver_opts_default(mlh_solver_opts *o);
 
@@ -177,9 +194,10 @@ typedef struct mlh_iter_stat {
  * (pose_local_parameterization.cpp:26-45). This is BASELINE.json's "GN iteration". stats may be NULL. */
 int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
 
-/* scan2MapOptimization(): max_outer x { match all features (wo_gf), evalHessian + evalDegenracy, Levenberg-Marquardt
- * (Ceres trust-region semantics, <= max_lm_iterations) on fixed correspondences }, device-resident.
- * replaces lidar_mapper_keyframe.cpp:423-639 for gf_method "wo_gf". stats: max_outer records. */
+/* scan2MapOptimization(): max_outer x { goodFeatureMatching (corner, then surf; wo_gf = all matched features),
+ * evalHessian + evalDegenracy, Levenberg-Marquardt (Ceres trust-region semantics, <= max_lm_iterations) on the selected,
+ * fixed correspondences }. Device-resident for wo_gf; the other gf methods add one host round trip per outer iteration for
+ * the selection loop. replaces lidar_mapper_keyframe.cpp:423-639. stats: max_outer records. */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
 
 /* ---------------------------------------------------------------- (e) multi-GPU: map shards + one all-reduce per iteration

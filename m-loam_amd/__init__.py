@@ -22,6 +22,7 @@ SURF, CORNER = 0, 1
 ALL_KINDS = -1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
+GF_METHODS = {"wo_gf": 0, "rnd": 1, "fps": 2, "gd_fix": 3, "gd_float": 4}
 K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = range(6)
 K_ALL = 0x3F
 
@@ -33,7 +34,8 @@ class MlhError(RuntimeError):
 class SolverOpts(C.Structure):
     _fields_ = [("min_match_sq_dis", C.c_float), ("min_plane_dis", C.c_float), ("huber_delta", C.c_double),
                 ("map_eig_thre", C.c_double), ("cov_measurement_trace", C.c_double), ("flags", C.c_uint32),
-                ("max_outer", C.c_int), ("max_lm_iterations", C.c_int)]
+                ("max_outer", C.c_int), ("max_lm_iterations", C.c_int), ("gf_method", C.c_int), ("gf_ratio", C.c_double),
+                ("gf_seed", C.c_uint64)]
 
 
 class IterStat(C.Structure):
@@ -81,6 +83,7 @@ def load_library():
     lib.mlh_features_set.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci]
     lib.mlh_match_linearize.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, cd, cd, vp, vp, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_linearize.argtypes = [vp, ci, vp, C.c_uint32, cd, cd, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
+    lib.mlh_good_feature_matching.argtypes = [vp, ci, vp, ci, cd, C.c_uint64, cf, cf, vp, C.POINTER(C.c_int32), vp, vp]
     lib.mlh_solver_opts_default.argtypes = [C.POINTER(SolverOpts)]
     lib.mlh_solver_opts_default.restype = None
     lib.mlh_gn_solve.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), vp]
@@ -100,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set",
-    "mlh_match_linearize", "mlh_linearize", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
+    "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
@@ -278,6 +281,17 @@ class Context:
         self._ck(self.lib.mlh_linearize(self.h, kind, _p(pose), flags, huber_delta, cov_measurement_trace, _p(r), _p(J), _p(H), _p(g),
                                         C.byref(cost), C.byref(cnt)))
         return dict(r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)
+
+    def good_feature_matching(self, kind, pose, gf_method="gd_fix", gf_ratio=0.2, seed=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+        m = self._m[kind]
+        pose = np.ascontiguousarray(pose, np.float64)
+        sel = np.zeros(max(m, 1), np.int32)
+        n_sel = C.c_int32(0)
+        H = np.eye(6) * 1e-6
+        matched = np.zeros(m, np.uint8)
+        self._ck(self.lib.mlh_good_feature_matching(self.h, kind, _p(pose), GF_METHODS[gf_method], gf_ratio, seed, min_match_sq_dis,
+                                                    min_plane_dis, _p(sel), C.byref(n_sel), _p(H), _p(matched)))
+        return dict(sel=sel[:n_sel.value].copy(), H=H, matched=matched)
 
     # ---- device-resident solvers
     def gn_solve(self, pose, n_iters, opts: SolverOpts | None = None, want_stats=True):

@@ -2,8 +2,10 @@
 // entry point replaces). Host logic only: staging, launch sequencing, result unpacking.
 #include "ctx.hpp"
 #include "dev_math.hpp"
+#include <algorithm>
 #include <cmath>
 #include <new>
+#include <random>
 
 namespace mlh {
 
@@ -435,6 +437,9 @@ void mlh_solver_opts_default(mlh_solver_opts *o)
     o->flags = 0;
     o->max_outer = 2;
     o->max_lm_iterations = 30;
+    o->gf_method = MLH_GF_WO;
+    o->gf_ratio = 1.0;
+    o->gf_seed = 0;
 }
 
 static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pose_sel)
@@ -498,8 +503,22 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
     if ((rc = upload_pose(ctx, pose_inout))) return rc;
     const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
+    std::mt19937 rng((uint32_t)opts->gf_seed);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
-        if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
+        if (opts->gf_method == MLH_GF_WO) {
+            if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
+        } else {
+            // goodFeatureMatching for corners, then surfs (cpp:503-533), each against a fresh 1e-6*I; then the evaluation of the
+            // selected residual blocks at the current pose (problem.Evaluate, cpp:575-581)
+            std::vector<int32_t> sel;
+            for (int kind : {MLH_CORNER, MLH_SURF}) {
+                double Hsel[36];
+                for (int i = 0; i < 36; ++i) Hsel[i] = (i % 7 == 0) ? 1e-6 : 0.0;
+                if ((rc = good_feature_select(ctx, kind, opts->gf_method, opts->gf_ratio, rng, opts->min_match_sq_dis, opts->min_plane_dis,
+                                              sel, Hsel, nullptr))) return rc;
+            }
+            if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
+        }
         if ((rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
             for (int j = it; j < std::min(it + chunk, opts->max_lm_iterations); ++j) {
@@ -514,6 +533,23 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
+}
+
+int mlh_good_feature_matching(mlh_ctx *ctx, int kind, const double pose[7], int gf_method, double gf_ratio, uint64_t seed,
+                              float min_match_sq_dis, float min_plane_dis, int32_t *sel_idx, int32_t *n_sel,
+                              double sub_mat_H[36], uint8_t *matched)
+{
+    if (!ctx || kind < 0 || kind > 1 || !pose || !sel_idx || !n_sel || !sub_mat_H) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, pose))) return rc;
+    std::mt19937 rng((uint32_t)seed);
+    std::vector<int32_t> sel;
+    if ((rc = good_feature_select(ctx, kind, gf_method, gf_ratio, rng, min_match_sq_dis, min_plane_dis, sel, sub_mat_H, matched))) return rc;
+    *n_sel = (int32_t)sel.size();
+    std::copy(sel.begin(), sel.end(), sel_idx);
+    return MLH_OK;
 }
 
 // ---------------------------------------------------------------- small host helpers

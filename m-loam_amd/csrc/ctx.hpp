@@ -191,6 +191,12 @@ struct MatchArgs {
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
+// select.hip
+}  // namespace mlh
+#include <random>
+namespace mlh {
+int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
+                        float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
 // solver.hip
 int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);

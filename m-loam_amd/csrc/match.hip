@@ -501,7 +501,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     const int total = P.k[0].tiles_b + P.k[1].tiles_b;
     const int gtile = xcd_tile(total);
     if (gtile >= total) return;
-    if (P.state->done) {   // the device-side LM loop has terminated: keep the partials defined, do no work
+    if (P.pose_sel && P.state->done) {   // candidate evaluation after the device-side LM loop has terminated: keep the partials defined, do no work
         if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
         return;
     }

@@ -230,3 +230,33 @@ def test_rccl_single_rank_path(mla, orc, case16, feats16):
     assert np.array_equal(red, np.arange(29, dtype=np.float64))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("method", ["rnd", "fps", "gd_fix"])
+def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
+    """BASELINE config 5 building block: same seed -> the same selected features and information matrix as the oracle's
+    restatement of ActiveFeatureSelection::goodFeatureMatching (lidar_mapper.h:229-573)."""
+    surf = feats16[0]
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    ctx.features_set(mla.SURF, surf)
+    got = ctx.good_feature_matching(mla.SURF, case16["p0"], gf_method=method, gf_ratio=0.2, seed=11)
+    ref = orc.good_feature_matching(orc.Map(case16["surf_map"]), "s", surf, case16["p0"],
+                                    orc.mapper_params(gf_method=method, gf_ratio=0.2, seed=11))
+    assert np.array_equal(got["sel"], ref["sel"])
+    np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-9, atol=1e-9)
+    # after the call only the selected correspondences are live on the device
+    lin = ctx.linearize(mla.SURF, case16["p0"])
+    assert lin["count"] == len(ref["sel"])
+
+
+def test_scan2map_with_greedy_selection_parity(ctx, mla, orc, case16, feats16):
+    _stage(ctx, mla, case16, feats16)
+    opts = mla.default_opts(gf_method=mla.GF_METHODS["gd_fix"], gf_ratio=0.2, gf_seed=5)
+    pose, stats = ctx.scan2map(case16["p0"], opts)
+    ref = orc.scan2map(orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"]), feats16[0], feats16[1], case16["p0"],
+                       orc.mapper_params(gf_method="gd_fix", gf_ratio=0.2, seed=5))
+    for s, r in zip(stats, ref["outer"]):
+        assert (s["n_surf"], s["n_corner"]) == (r["n_surf_sel"], r["n_corner_sel"])
+        assert s["lm_iterations"] == r["lm_iterations"] and s["termination"] == r["termination"]
+    dt, dr = _pose_err(pose, ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)
