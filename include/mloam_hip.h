@@ -93,6 +93,21 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, c
                     int n_rings, int mem);
 int mlh_extract_run(mlh_ctx *ctx);
 int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4]);
+/* (a3) the per-ring pcl::VoxelGrid(leaf = 0.2 m) extractCloud applies to the less-flat points of every ring
+ * (feature_extract.cpp:266-271): run after mlh_extract_run; fetch returns "surf_points_less_flat" as the reference emits it
+ * (ring asc, voxel index asc; x y z intensity centroids). Within a voxel the members are summed in scan order (PCL sums them in
+ * the order an unstable std::sort left them: equal up to f32 rounding of the sum). */
+int mlh_extract_voxel_run(mlh_ctx *ctx, float leaf);
+int mlh_extract_fetch_voxel(mlh_ctx *ctx, float *xyzi_out, int32_t *n_out);
+
+/* (a18) per-point uncertainty of downsampleCurrentScan (lidar_mapper_keyframe.cpp:375-418): for every point (intensity =
+ * LiDAR index n) Sigma_p = evalPointUncertainty(pose_ext[n]^-1 * p, pose_ext[n])  (associate_uct.hpp:196-215) with
+ * cov_input = diag(ext_covs[n] (6x6), cov_measurement (3x3)). Outputs the f32 cov_vec[6] of PointXYZIWithCov per point and
+ * keep[i] = 0 where trace > trace_threshold (TRACE_THRESHOLD_MAPPING; <= 0 keeps everything); the caller appends the kept
+ * points in order, as the reference's loop does. */
+int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                          const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
+                          double trace_threshold, float *cov_vec_out, int32_t *keep_out);
 
 /* ---------------------------------------------------------------- (a5) local map index
  * replaces pcl::KdTreeFLANN<PointT>::setInputCloud(cloud) as used at

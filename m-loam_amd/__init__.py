@@ -77,6 +77,9 @@ def load_library():
     lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, vp, vp, ci, ci]
     lib.mlh_extract_run.argtypes = [vp]
     lib.mlh_extract_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.mlh_extract_voxel_run.argtypes = [vp, cf]
+    lib.mlh_extract_fetch_voxel.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    lib.mlh_point_uncertainty.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, cd, vp, vp]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_rebuild.argtypes = [vp, ci]
     lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
@@ -101,7 +104,8 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
-    "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch",
+    "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
+    "mlh_point_uncertainty",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -210,10 +214,32 @@ class Context:
             out[nm] = lists[i][:cnt[i]].copy()
         return out
 
-    def extract(self, points, scan_start, scan_end):
+    def extract(self, points, scan_start, scan_end, voxel_leaf=None):
         self.scan_upload(points, scan_start, scan_end)
         self.extract_run()
-        return self.extract_fetch()
+        out = self.extract_fetch()
+        if voxel_leaf:
+            out["less_flat_ds"] = self.extract_voxel(voxel_leaf)
+        return out
+
+    def extract_voxel(self, leaf=0.2):
+        """surf_points_less_flat after the per-ring VoxelGrid (feature_extract.cpp:266-271)."""
+        self._ck(self.lib.mlh_extract_voxel_run(self.h, leaf))
+        buf = np.zeros((max(self._scan_n, 1), 4), np.float32)
+        n = C.c_int32(0)
+        self._ck(self.lib.mlh_extract_fetch_voxel(self.h, _p(buf), C.byref(n)))
+        return buf[:n.value].copy()
+
+    def point_uncertainty(self, points, ext_poses, ext_covs, cov_measurement, trace_threshold=0.0):
+        """points (n, >=4) [x y z lidar-id ...] -> (cov_vec (n, 6) f32, keep (n,) bool)."""
+        ptr, stride, n, mem, keep = _src(points)
+        ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7)
+        ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
+        cm = np.ascontiguousarray(cov_measurement, np.float64).reshape(9)
+        cov = np.zeros((n, 6), np.float32)
+        kp = np.zeros(n, np.int32)
+        self._ck(self.lib.mlh_point_uncertainty(self.h, ptr, stride, n, 12, mem, _p(ep), _p(ec), ep.shape[0], _p(cm), trace_threshold, _p(cov), _p(kp)))
+        return cov, kp.astype(bool)
 
     # ---- map / features
     def map_set(self, kind, points, min_match_sq_dis=1.0):

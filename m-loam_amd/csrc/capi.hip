@@ -188,6 +188,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
+    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -241,6 +242,7 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, c
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     ScanBuf &sb = ctx->scan;
     sb.extracted = false;
+    sb.voxelised = false;
     int rc = stage_points(ctx, points, stride_bytes, n, mem, -1, -1, sb.pts, nullptr, ctx->tmp);
     if (rc) return rc;
     std::vector<int> hs(n_rings), he(n_rings);
@@ -299,6 +301,41 @@ int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *p
     MLH_HIP(ctx, hipStreamSynchronize(st));
     prof_collect(ctx);
     return MLH_OK;
+}
+
+int mlh_extract_voxel_run(mlh_ctx *ctx, float leaf)
+{
+    if (!ctx || !(leaf > 0.f)) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return ring_voxel_run(ctx, leaf);
+}
+
+int mlh_extract_fetch_voxel(mlh_ctx *ctx, float *xyzi_out, int32_t *n_out)
+{
+    if (!ctx || !n_out) return MLH_ERR_INVALID;
+    ScanBuf &sb = ctx->scan;
+    if (!sb.voxelised) return fail(ctx, MLH_ERR_STATE, "extract_voxel_run has not been called");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int total = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(&total, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    if (xyzi_out && total > 0) {
+        MLH_HIP(ctx, hipMemcpyAsync(xyzi_out, sb.vox_out.p, sizeof(float4) * size_t(total), hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    prof_collect(ctx);
+    return MLH_OK;
+}
+
+int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                          const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
+                          double trace_threshold, float *cov_vec_out, int32_t *keep_out)
+{
+    if (!ctx || !ext_poses || !ext_covs || !cov_measurement || !cov_vec_out || !keep_out) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return point_uncertainty_run(ctx, points, stride_bytes, n, intensity_offset_bytes, mem, ext_poses, ext_covs, n_lidar, cov_measurement,
+                                 trace_threshold, cov_vec_out, keep_out);
 }
 
 // ---------------------------------------------------------------- map

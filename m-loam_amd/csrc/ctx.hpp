@@ -116,6 +116,8 @@ struct ScanBuf {
     DevBuf ring_offsets;   // 4 exclusive offsets per ring (+ totals)
     DevBuf lists[4];
     DevBuf totals;         // 4 ints
+    DevBuf vox_stage, vox_out, ring_vox;   // per-ring VoxelGrid of the less-flat points
+    bool voxelised = false;
     int n = 0, n_rings = 0;
     int max_ring_len = 0;  // max over rings of (scan_end - scan_start)
     bool extracted = false;
@@ -147,6 +149,7 @@ struct mlh_ctx {
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
     void *h_state = nullptr; // pinned staging for the solver-state upload
+    mlh::DevBuf uct_buf;     // point-uncertainty scratch
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
@@ -174,6 +177,10 @@ bool prof_kernel_events(mlh_ctx *ctx, int id, hipEvent_t *start, hipEvent_t *sto
 
 // extract.hip
 int extract_run(mlh_ctx *ctx);
+// voxel.hip
+int ring_voxel_run(mlh_ctx *ctx, float leaf);
+int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
+                          const double *ext_covs, int n_lidar, const double cov_meas[9], double trace_thr, float *cov6_host, int *keep_host);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 // match.hip

@@ -260,3 +260,41 @@ def test_scan2map_with_greedy_selection_parity(ctx, mla, orc, case16, feats16):
         assert s["lm_iterations"] == r["lm_iterations"] and s["termination"] == r["termination"]
     dt, dr = _pose_err(pose, ref["pose"])
     assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
+def test_per_ring_voxel_grid_parity(ctx, orc, case16):
+    """row a3: the per-ring pcl::VoxelGrid(0.2) on the less-flat points. Voxel set / order identical to the oracle; centroids
+    equal up to the f32 rounding of a differently ordered sum (PCL sums in the order an unstable std::sort leaves)."""
+    sc = case16["scans"][0]
+    got = ctx.extract(sc.points, sc.scan_start, sc.scan_end, voxel_leaf=0.2)["less_flat_ds"]
+    ref = orc.extract(sc.points, sc.scan_start, sc.scan_end)["less_flat_ds"]
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
+    # most voxels hold 1-2 points (order-independent sums): the large majority of the words are bit-identical
+    assert np.mean(got.view(np.uint32) == ref.view(np.uint32)) > 0.9
+
+
+def test_point_uncertainty_parity(ctx, mla, orc, synth, feats16):
+    rng = np.random.default_rng(3)
+    pts = feats16[0][:4000].copy()
+    pts[:, 3] = rng.integers(0, 4, len(pts))
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])   # -> [t, q]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    cov_ext = np.diag([0.0025, 0.0025, 0.0025, 0.00030461, 0.00030461, 0.00030461])
+    covs = np.stack([np.zeros((6, 6)), cov_ext, cov_ext * 4, cov_ext * 9])
+    meas = np.diag([0.0025] * 3)
+    cov, keep = ctx.point_uncertainty(pts, ext, covs, meas, trace_threshold=0.6)
+    for n in range(4):
+        m = pts[:, 3] == n
+        # the oracle evaluates evalPointUncertainty(point_sel, pose_ext) with point_sel = pose_ext^-1 * p (f32)
+        q = ext[n][3:]
+        R = synth.quat_to_rot(q)
+        sel = ((pts[m, :3].astype(np.float64) - ext[n][:3]) @ R).astype(np.float32)
+        ref = orc.eval_point_uncertainty(sel, ext[n], covs[n], meas)
+        ref6 = np.stack([ref[:, 0, 0], ref[:, 0, 1], ref[:, 0, 2], ref[:, 1, 1], ref[:, 1, 2], ref[:, 2, 2]], axis=1)
+        np.testing.assert_allclose(cov[m], ref6, rtol=2e-5, atol=1e-7)
+        tr = ref[:, 0, 0] + ref[:, 1, 1] + ref[:, 2, 2]
+        clear = np.abs(tr - 0.6) > 1e-4
+        assert np.array_equal(keep[m][clear], (tr <= 0.6)[clear])
+    assert 0 < keep.sum() < len(keep)
