@@ -133,6 +133,14 @@ int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int
 int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes,
                      int cov_offset_bytes, int mem);
 
+/* Pose blocks (a19, BASELINE config 4: online extrinsic calibration). The estimator's calibration problem
+ * (estimator.cpp:656-780, buildCalibMap :1067-1157) gives every LiDAR its own 7-parameter block: the reference LiDAR's features
+ * constrain the body pose (LidarPureOdom* blocks with the pivot and the reference extrinsic held constant), LiDAR n's features
+ * constrain its extrinsic alone (LidarOnlineCalib{PlaneNorm,Edge}Factor, lidar_online_calib_factor.hpp:24-165 -- the same
+ * residual/Jacobian form as the map factors with sqrt_info = 1). Stage the feature cloud of block 0, 1, ... in ascending order;
+ * every block starts on a 256-feature boundary in HBM so that a workgroup never straddles two pose blocks. */
+int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points, int stride_bytes, int n, int cov_offset_bytes, int mem);
+
 /* ---------------------------------------------------------------- (a4, a6-a11, a15) match + linearise + reduce
  * replaces, for every staged feature of `kind`, at pose `pose`:
  *   pointAssociateToMap                         estimator/src/utility/utility.h:103-117
@@ -208,6 +216,22 @@ typedef struct mlh_iter_stat {
  * (lidar_mapper_keyframe.cpp:1172-1204), solve H d = -g, pose <- PoseLocalParameterization::Plus(pose, V_update d)
  * (pose_local_parameterization.cpp:26-45). This is BASELINE.json's "GN iteration". stats may be NULL. */
 int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
+
+/* Per-block options of mlh_gn_solve_blocks. k_neigh: N_NEIGH of the block's correspondences (5 for the reference LiDAR, 10 for
+ * the others in buildCalibMap, estimator.cpp:1135); eig_thre / freeze: degeneracy handling -- freeze = 0 projects the weak
+ * directions out (evalDegenracy, estimator.cpp:1608-1636), freeze = 1 leaves the block untouched when lambda_min < eig_thre
+ * (the extrinsic branch, estimator.cpp:1662-1676, without its frame-count state). */
+typedef struct mlh_block_opts {
+    int n_blocks;
+    int k_neigh[8];
+    double eig_thre[8];
+    int freeze[8];
+} mlh_block_opts;
+/* n_iters GN iterations on n_blocks independent pose blocks (poses_inout: n_blocks x 7), one correspondence + one fit launch
+ * per iteration for all blocks and both feature kinds. stats: n_iters x n_blocks records (iteration-major), may be NULL;
+ * termination = 1 in a record marks a frozen block. Multi-LiDAR features must have been staged with mlh_features_set_block. */
+int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const mlh_solver_opts *opts, const mlh_block_opts *block_opts,
+                        mlh_iter_stat *stats);
 
 /* scan2MapOptimization(): max_outer x { goodFeatureMatching (corner, then surf; wo_gf = all matched features),
  * evalHessian + evalDegenracy, Levenberg-Marquardt (Ceres trust-region semantics, <= max_lm_iterations) on the selected,

@@ -38,6 +38,10 @@ class SolverOpts(C.Structure):
                 ("gf_seed", C.c_uint64)]
 
 
+class BlockOpts(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("k_neigh", C.c_int * 8), ("eig_thre", C.c_double * 8), ("freeze", C.c_int * 8)]
+
+
 class IterStat(C.Structure):
     _fields_ = [("n_surf", C.c_int32), ("n_corner", C.c_int32), ("is_degenerate", C.c_int32), ("lm_iterations", C.c_int32),
                 ("successful_steps", C.c_int32), ("termination", C.c_int32), ("cost", C.c_double), ("final_cost", C.c_double),
@@ -84,6 +88,8 @@ def load_library():
     lib.mlh_map_rebuild.argtypes = [vp, ci]
     lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
     lib.mlh_features_set.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci]
+    lib.mlh_features_set_block.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci]
+    lib.mlh_gn_solve_blocks.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), C.POINTER(BlockOpts), vp]
     lib.mlh_match_linearize.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, cd, cd, vp, vp, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_linearize.argtypes = [vp, ci, vp, C.c_uint32, cd, cd, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_good_feature_matching.argtypes = [vp, ci, vp, ci, cd, C.c_uint64, cf, cf, vp, C.POINTER(C.c_int32), vp, vp]
@@ -106,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty",
-    "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set",
+    "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -263,6 +269,25 @@ class Context:
         self._ck(self.lib.mlh_features_set(self.h, kind, ptr, stride, n, 12 if ncol >= 4 else -1, 16 if ncol >= 10 else -1, mem))
         self._m = getattr(self, "_m", {})
         self._m[kind] = n
+
+    def features_set_blocks(self, kind, clouds):
+        """clouds: list of (m_b, >=3) arrays, one per pose block (block 0 = body pose, block n = extrinsic of LiDAR n)."""
+        for b, pts in enumerate(clouds):
+            ptr, stride, n, mem, keep = _src(pts)
+            self._ck(self.lib.mlh_features_set_block(self.h, kind, b, ptr, stride, n, 16 if stride // 4 >= 10 else -1, mem))
+
+    def gn_solve_blocks(self, poses, n_iters, k_neigh, eig_thre, freeze, opts: SolverOpts | None = None, want_stats=True):
+        opts = opts or default_opts()
+        poses = np.ascontiguousarray(poses, np.float64).copy().reshape(-1, 7)
+        nb = poses.shape[0]
+        bo = BlockOpts()
+        bo.n_blocks = nb
+        for b in range(nb):
+            bo.k_neigh[b] = int(k_neigh[b]); bo.eig_thre[b] = float(eig_thre[b]); bo.freeze[b] = int(freeze[b])
+        stats = (IterStat * (n_iters * nb))() if want_stats else None
+        self._ck(self.lib.mlh_gn_solve_blocks(self.h, _p(poses), n_iters, C.byref(opts), C.byref(bo), C.cast(stats, C.c_void_p) if want_stats else None))
+        st = [[stats[it * nb + b].as_dict() for b in range(nb)] for it in range(n_iters)] if want_stats else None
+        return poses, st
 
     # ---- multi-GPU
     def shard_set(self, lo_plane=None, hi_plane=None):

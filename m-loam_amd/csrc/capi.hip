@@ -373,6 +373,64 @@ int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int
 }
 
 // ---------------------------------------------------------------- features
+// marks the padding slots between two pose blocks (intensity < 0 = "not a feature")
+__global__ void pad_fill_kernel(float4 *pts, float4 *covd, int from, int to)
+{
+    const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < to) { pts[i] = make_float4(0.f, 0.f, 0.f, -1.f); covd[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+}
+
+// AoS records -> float4 at an offset; the stored w is the pose-block id (>= 0)
+__global__ __launch_bounds__(256) void pack_block_kernel(const unsigned char *__restrict__ src, int stride, int n, int cov_off, float wval,
+                                                         float4 *__restrict__ out, float4 *__restrict__ covd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *rec = reinterpret_cast<const float *>(src + size_t(i) * stride);
+    out[i] = make_float4(rec[0], rec[1], rec[2], wval);
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cov_off >= 0) {
+        const float *cv = reinterpret_cast<const float *>(src + size_t(i) * stride + cov_off);
+        c.x = cv[0]; c.y = cv[3]; c.z = cv[5];
+    }
+    covd[i] = c;
+}
+
+int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points, int stride_bytes, int n, int cov_offset_bytes, int mem)
+{
+    if (!ctx || kind < 0 || kind > 1 || block < 0 || block >= 8) return MLH_ERR_INVALID;
+    if (!points || n <= 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer");
+    if (cov_offset_bytes >= 0 && cov_offset_bytes + 24 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "cov_offset_bytes + 24 exceeds the record stride");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    FeatSet &f = ctx->feat[kind];
+    if (block == 0) { f.m = 0; f.n_blocks = 0; f.has_cov = false; }
+    if (block != f.n_blocks) return fail(ctx, MLH_ERR_STATE, "pose blocks must be staged in ascending order starting at 0");
+    f.matched = false;
+    const int start = block == 0 ? 0 : ((f.m + 255) / 256) * 256;     // blocks begin on fit-tile boundaries
+    const size_t total = size_t(start) + size_t(n);
+    MLH_HIP(ctx, f.pts.grow(sizeof(float4) * total, sizeof(float4) * size_t(f.m), ctx->stream));
+    MLH_HIP(ctx, f.covd.grow(sizeof(float4) * total, sizeof(float4) * size_t(f.m), ctx->stream));
+    if (start > f.m)
+        hipLaunchKernelGGL(pad_fill_kernel, dim3((start - f.m + 255) / 256), dim3(256), 0, ctx->stream, f.pts.as<float4>(), f.covd.as<float4>(), f.m, start);
+    const unsigned char *src = static_cast<const unsigned char *>(points);
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, ctx->tmp.ensure(size_t(n) * stride_bytes));
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, size_t(n) * stride_bytes, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->tmp.as<unsigned char>();
+    }
+    hipLaunchKernelGGL(pack_block_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride_bytes, n, cov_offset_bytes, float(block),
+                       f.pts.as<float4>() + start, f.covd.as<float4>() + start);
+    MLH_HIP(ctx, hipGetLastError());
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f.blk_start[block] = start;
+    f.blk_real[block] = n;
+    f.m = int(total);
+    f.n_blocks = block + 1;
+    for (int b = f.n_blocks; b <= 8; ++b) f.blk_start[b] = f.m;
+    f.has_cov = f.has_cov || cov_offset_bytes >= 0;
+    return MLH_OK;
+}
+
 int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes,
                      int cov_offset_bytes, int mem)
 {
@@ -383,11 +441,15 @@ int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_byte
     f.m = 0;
     if (cov_offset_bytes >= 0 && cov_offset_bytes + 24 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "cov_offset_bytes + 24 exceeds the record stride");
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset exceeds the record stride");
-    int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, cov_offset_bytes,
-                          f.pts, &f.covd, ctx->tmp);
+    (void)intensity_offset_bytes;   // the LiDAR index is not needed by the single-pose path; the slot marks padding in block mode
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, -1, cov_offset_bytes, f.pts, &f.covd, ctx->tmp);
     if (rc) return rc;
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     f.m = n;
+    f.n_blocks = 1;
+    f.blk_start[0] = 0;
+    f.blk_real[0] = n;
+    for (int b = 1; b <= 8; ++b) f.blk_start[b] = n;
     f.has_cov = cov_offset_bytes >= 0;
     return MLH_OK;
 }
@@ -482,7 +544,7 @@ void mlh_solver_opts_default(mlh_solver_opts *o)
 static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pose_sel)
 {
     MatchArgs a;
-    a.kind_mask = kind_mask; a.map_eig_thre = o->map_eig_thre; a.flags = o->flags & (MLH_FLAG_CHECK_FOV | MLH_FLAG_WITH_UA);
+    a.kind_mask = kind_mask; a.eig_thre[0] = o->map_eig_thre; a.flags = o->flags & (MLH_FLAG_CHECK_FOV | MLH_FLAG_WITH_UA);
     a.min_match_sq_dis = o->min_match_sq_dis; a.min_plane_dis = o->min_plane_dis;
     a.huber_delta = o->huber_delta; a.cov_measurement_trace = o->cov_measurement_trace; a.dense = false; a.pose_sel = pose_sel;
     return a;
@@ -524,6 +586,40 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
         }
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);
+}
+
+int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const mlh_solver_opts *opts, const mlh_block_opts *bo,
+                        mlh_iter_stat *stats)
+{
+    if (!ctx || !poses_inout || !opts || !bo || n_iters <= 0 || bo->n_blocks <= 0 || bo->n_blocks > 8) return MLH_ERR_INVALID;
+    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "pose-block mode is single-GPU in this round");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    const int nb = bo->n_blocks;
+    int rc = ensure_state(ctx, n_iters * nb);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, poses_inout))) return rc;
+    SolverState *S = ctx->state.as<SolverState>();
+    if (nb > 1) MLH_HIP(ctx, hipMemcpyAsync(&S->xb[1][0], poses_inout + 7, sizeof(double) * 7 * (nb - 1), hipMemcpyHostToDevice, ctx->stream));
+    const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
+    if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    for (int it = 0; it < n_iters; ++it) {
+        MatchArgs a = args_from_opts(opts, mask, 0);
+        a.n_blocks = nb;
+        for (int b = 0; b < nb; ++b) { a.k_neigh[b] = bo->k_neigh[b]; a.eig_thre[b] = bo->eig_thre[b]; a.freeze[b] = bo->freeze[b]; }
+        a.finish = 1;
+        a.stat_slot = stats ? it * nb : -1;
+        if ((rc = match_launch(ctx, a))) return rc;
+    }
+    SolverState hs;
+    std::vector<IterStatDev> hd(stats ? size_t(n_iters) * nb : 0);
+    MLH_HIP(ctx, hipMemcpyAsync(&hs, ctx->state.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * hd.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    for (int i = 0; i < 7; ++i) poses_inout[i] = hs.x[i];
+    for (int b = 1; b < nb; ++b) for (int i = 0; i < 7; ++i) poses_inout[7 * b + i] = hs.xb[b][i];
+    for (size_t i = 0; stats && i < hd.size(); ++i) copy_stat(hd[i], stats[i]);
+    return MLH_OK;
 }
 
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)

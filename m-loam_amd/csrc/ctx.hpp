@@ -35,6 +35,7 @@ constexpr int NE_H = 0, NE_G = 21, NE_COST = 27, NE_CNT = 28, NE_STRIDE = 32;
 struct SolverState {
     double x[7];             // current pose [t, q(xyzw)]
     double cand[7];          // candidate pose (LM)
+    double xb[8][7];         // poses of the additional blocks (config 4: extrinsics); xb[0] unused (block 0 is x)
     double V[36];            // PoseLocalParameterization::V_update_
     double ne[NE_STRIDE];    // normal equations at x
     double ce[NE_STRIDE];    // normal equations at cand (multi-GPU: all-reduced before lm_step consumes them)
@@ -66,6 +67,19 @@ struct IterStatDev {        // mirrors mlh_iter_stat, written by the device-side
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // grow to `bytes`, preserving the first `keep` bytes (device-to-device copy on `st`)
+    hipError_t grow(size_t bytes, size_t keep, hipStream_t st)
+    {
+        if (bytes <= cap) return hipSuccess;
+        void *np = nullptr;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&np, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) { e = hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e; e = hipStreamSynchronize(st); if (e != hipSuccess) return e; }
+        if (p) (void)hipFree(p);
+        p = np; cap = want;
+        return hipSuccess;
+    }
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
@@ -102,7 +116,11 @@ struct FeatSet {
     DevBuf corr;       // Corr per feature
     DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
-    int m = 0;
+    int m = 0;             // feature slots (real + padding between pose blocks)
+    int n_blocks = 1;
+    int blk_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int blk_real[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // real features per block
+    int nbr_stride = 5;
     bool has_cov = false;
     bool matched = false;
 };
@@ -192,8 +210,11 @@ struct MatchArgs {
     bool dense = false;  // also write r / J per feature
     int pose_sel = 0;    // 0: SolverState::x, 1: SolverState::cand
     int finish = 0;      // 1: the fit kernel's last workgroup completes the GN iteration (reduce + solve + Plus)
-    double map_eig_thre = 100.0;
     int stat_slot = -1;
+    int n_blocks = 1;    // pose blocks
+    int k_neigh[8] = {5, 5, 5, 5, 5, 5, 5, 5};
+    double eig_thre[8] = {100, 100, 100, 100, 100, 100, 100, 100};
+    int freeze[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);

@@ -25,6 +25,8 @@
 namespace mlh {
 
 constexpr int TPB = 256;
+constexpr int KNN_G = 8;              // lanes per query in the correspondence kernel
+constexpr int KNN_FPB = TPB / KNN_G;  // queries per workgroup
 constexpr unsigned long long KEY_INF = 0x7f800000ffffffffull;   // (+inf, max index)
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
@@ -35,12 +37,13 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ void key_insert(unsigned long long (&k)[5], unsigned long long key)
+template <int K>
+__device__ __forceinline__ void key_insert(unsigned long long (&k)[K], unsigned long long key)
 {
-    if (key < k[4]) {
-        k[4] = key;
+    if (key < k[K - 1]) {
+        k[K - 1] = key;
 #pragma unroll
-        for (int i = 4; i > 0; --i) {
+        for (int i = K - 1; i > 0; --i) {
             unsigned long long a = k[i - 1], b = k[i];
             bool sw = b < a;
             k[i - 1] = sw ? b : a;
@@ -55,16 +58,20 @@ __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int
     return fminf(fmaxf(f, -2.f), float(n + 1));   // also squashes NaN/inf before the int conversion
 }
 
-// exact 5-NN of (qx,qy,qz) by a group of 8 lanes (8 queries per wavefront); on return every lane holds the 5 keys ascending.
+// exact K-NN (K = 5, or 10 for buildCalibMap's non-reference LiDARs) of (qx,qy,qz) by a group of 8 lanes (8 queries per
+// wavefront); on return every lane holds the K keys ascending.
 // The 27-cell neighbourhood is 9 x-runs (the 3 x-adjacent cells of one (dy,dz) are one contiguous range of the cell-sorted
 // array). Lane r fetches the bounds of run r (lane 0 also run 8); a 3-step shuffle scan gives the run offsets, which go to
 // LDS; the lanes then stride over the FLAT concatenation of the 9 runs (lane l takes candidates l, l+8, ...), so the work
 // is balanced whatever the per-run occupancy, consecutive lanes read consecutive float4 points, and a query with fewer than
-// 5 candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
+// K candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
 // lds_run: 20 ints per group: [0..9] prefix offsets of the runs (10 entries), [10..18] base index of each run.
-__device__ __forceinline__ void knn5_group8(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[5])
+template <int K>
+__device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[K])
 {
-    unsigned long long k[5] = {KEY_INF, KEY_INF, KEY_INF, KEY_INF, KEY_INF};
+    unsigned long long k[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = KEY_INF;
     const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
     const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
     const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
@@ -93,7 +100,7 @@ __device__ __forceinline__ void knn5_group8(const GridDev &g, float qx, float qy
     }
     const int len8 = __shfl(e8 - b8, 0, 8);
     const int total = __shfl(incl, 7, 8) + len8;
-    if (total >= 5) {                                  // uniform over the group
+    if (total >= K) {                                  // uniform over the group
         lds_run[gl] = incl - len;                      // prefix[r]
         lds_run[10 + gl] = b;                          // base[r]
         if (gl == 0) { lds_run[8] = total - len8; lds_run[9] = total; lds_run[18] = b8; }
@@ -118,14 +125,14 @@ __device__ __forceinline__ void knn5_group8(const GridDev &g, float qx, float qy
                 if (v[u]) {
                     float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
                     float d = dx * dx; d += dy * dy; d += dz * dz;
-                    key_insert(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
+                    key_insert<K>(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
                 }
             }
         }
     }
-    // tournament merge: 5 rounds of group-min over the lanes' current heads
+    // tournament merge: K rounds of group-min over the lanes' current heads
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < K; ++t) {
         unsigned long long m = k[0];
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) {
@@ -133,7 +140,11 @@ __device__ __forceinline__ void knn5_group8(const GridDev &g, float qx, float qy
             m = o < m ? o : m;
         }
         out[t] = m;
-        if (k[0] == m && m != KEY_INF) { k[0] = k[1]; k[1] = k[2]; k[2] = k[3]; k[3] = k[4]; k[4] = KEY_INF; }
+        if (k[0] == m && m != KEY_INF) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) k[i] = k[i + 1];
+            k[K - 1] = KEY_INF;
+        }
     }
 }
 
@@ -277,17 +288,21 @@ __device__ __forceinline__ bool in_laser_fov(const q4 &q, const d3 &t, float sx,
     return check1 < 0 && check2 > 0;
 }
 
+constexpr int MAX_BLOCKS = 8;
+
 struct KindP {
     GridDev grid;
-    const float4 *feat;      // {x,y,z,intensity}
+    const float4 *feat;      // {x,y,z,intensity}; intensity < 0 marks a padding slot between pose blocks
     const float4 *covd;      // {cxx,cyy,czz,_} or null
-    float4 *nbr;             // 5 per feature: {x,y,z, sq-dist} of the k-th neighbour (w = +inf when missing)
+    float4 *nbr;             // nbr_stride per feature: {x,y,z, sq-dist} of the k-th neighbour (w = +inf when missing)
     Corr *corr;
     double *r_out;           // nullable
     double *J_out;           // nullable
-    int m;
-    int tiles_a;             // correspondence-kernel tiles (8 features each)
+    int m;                   // feature slots (real + padding)
+    int tiles_a;             // correspondence-kernel tiles (32 features each)
     int tiles_b;             // fit / linearise tiles (256 features each)
+    int nbr_stride;          // max K over the blocks
+    int blk_start[MAX_BLOCKS + 1];   // first slot of every pose block (multiples of 256), blk_start[n_blocks] = m
 };
 
 struct KParams {
@@ -300,12 +315,28 @@ struct KParams {
     double huber_delta, cov_measurement_trace;
     int has_lo, has_hi;      // multi-GPU ownership half-spaces (mlh_shard_set)
     float lo[4], hi[4];
-    // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose
+    // pose blocks (BASELINE config 4: block 0 = body pose, block n = extrinsic of LiDAR n; 1 block otherwise)
+    int n_blocks;
+    int kb[MAX_BLOCKS];      // N_NEIGH per block (5 or 10)
+    double thre_b[MAX_BLOCKS];   // eigen threshold per block
+    int freeze_b[MAX_BLOCKS];    // 0: project the degenerate directions out (evalDegenracy); 1: do not update the block at all
+    // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose(s)
     int finish;              // 0: none, 1: GN
     unsigned *ticket;
-    double eig_thre;
-    IterStatDev *stat;
+    IterStatDev *stat;       // n_blocks consecutive records, or null
 };
+
+__device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
+{
+    int b = 0;
+    for (int i = 1; i < n_blocks; ++i) if (f >= K.blk_start[i]) b = i;
+    return b;
+}
+
+__device__ __forceinline__ const double *block_pose(const KParams &P, int b)
+{
+    return b == 0 ? (P.pose_sel ? P.state->cand : P.state->x) : P.state->xb[b];
+}
 
 // pointAssociateToMap (utility.h:103-117): f64 q*p + t, stored to f32
 __device__ __forceinline__ void associate_to_map(const q4 &q, const d3 &t, const float4 &fp, float &sx, float &sy, float &sz)
@@ -323,8 +354,25 @@ __device__ __forceinline__ bool owns(const KParams &P, float sx, float sy, float
 }
 
 // ---- correspondence kernel: 8 lanes per feature, 32 features per workgroup, both feature kinds in one launch
-constexpr int KNN_G = 8;
-constexpr int KNN_FPB = TPB / KNN_G;
+
+template <int K>
+__device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run)
+{
+    unsigned long long keys[K];
+    knn_group8<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        if ((t % KNN_G) == gl) {
+            const unsigned long long kk = keys[t];
+            float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
+            if (kk != KEY_INF) {
+                const float4 np = Kd.grid.raw[(unsigned)kk];
+                o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
+            }
+            Kd.nbr[size_t(f) * Kd.nbr_stride + t] = o;
+        }
+    }
+}
 
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
@@ -338,54 +386,49 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
     const int f = tile * KNN_FPB + grp;
     if (f >= K.m) return;
-    const double *pose = P.pose_sel ? P.state->cand : P.state->x;
+    const float4 fp = K.feat[f];
+    if (fp.w < 0.f) return;               // padding slot
+    const int b = block_of_slot(K, P.n_blocks, f);
+    const double *pose = block_pose(P, b);
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
-    const float4 fp = K.feat[f];
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
     if (!owns(P, sx, sy, sz)) return;     // uniform over the 8-lane group
-    unsigned long long keys[5];
-    knn5_group8(K.grid, sx, sy, sz, gl, s_run + grp * 20, keys);
-    if (gl < 5) {
-        unsigned long long kk = keys[0];
-        if (gl == 1) kk = keys[1]; else if (gl == 2) kk = keys[2]; else if (gl == 3) kk = keys[3]; else if (gl == 4) kk = keys[4];
-        float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
-        if (kk != KEY_INF) {
-            const float4 np = K.grid.raw[(unsigned)kk];
-            o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
-        }
-        K.nbr[size_t(f) * 5 + gl] = o;
-    }
+    if (P.kb[b] == 10) knn_feature<10>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
+    else knn_feature<5>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
 }
 
 // the reference's plane fit + gate (feature_extract.hpp:816-840)
-__device__ __forceinline__ bool fit_plane(const float (&ax)[5], const float (&ay)[5], const float (&az)[5], float min_plane_dis, float (&coef)[6])
+template <int K>
+__device__ __forceinline__ bool fit_plane(const float (&ax)[K], const float (&ay)[K], const float (&az)[K], float min_plane_dis, float (&coef)[6])
 {
     float nx, ny, nz;
-    plane_fit_qr_f<5>(ax, ay, az, nx, ny, nz);
+    plane_fit_qr_f<K>(ax, ay, az, nx, ny, nz);
     float nn = sqrtf(nx * nx + ny * ny + nz * nz);
     float negative_OA_dot_norm = 1 / nn;
     float z = nx * nx + ny * ny + nz * nz;
     if (z > 0.f) { float s = sqrtf(z); nx /= s; ny /= s; nz /= s; }
     bool plane_valid = true;
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < K; ++j)
         if (fabsf(nx * ax[j] + ny * ay[j] + nz * az[j] + negative_OA_dot_norm) > min_plane_dis) plane_valid = false;
     coef[0] = nx; coef[1] = ny; coef[2] = nz; coef[3] = negative_OA_dot_norm;
     return plane_valid;
 }
 
 // the reference's line fit + test (feature_extract.hpp:669-693, 767-777)
-__device__ __forceinline__ bool fit_line(const float (&ax)[5], const float (&ay)[5], const float (&az)[5], float (&coef)[6])
+template <int K>
+__device__ __forceinline__ bool fit_line(const float (&ax)[K], const float (&ay)[K], const float (&az)[K], float (&coef)[6])
 {
     float cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
-    cx /= 5.0f; cy /= 5.0f; cz /= 5.0f;
+    for (int j = 0; j < K; ++j) { cx += ax[j]; cy += ay[j]; cz += az[j]; }
+    const float kf = float(K);
+    cx /= kf; cy /= kf; cz /= kf;
     float c00 = 0.f, c10 = 0.f, c11 = 0.f, c20 = 0.f, c21 = 0.f, c22 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < K; ++j) {
         float t0 = ax[j] - cx, t1 = ay[j] - cy, t2 = az[j] - cz;
         c00 += t0 * t0; c10 += t1 * t0; c11 += t1 * t1; c20 += t2 * t0; c21 += t2 * t1; c22 += t2 * t2;
     }
@@ -406,8 +449,9 @@ __device__ __forceinline__ double feature_weight(const KParams &P, const KindP &
     return sqrt_info_of(trace);
 }
 
-// Fused tail: the last workgroup to arrive (agent-scope release/acquire around an atomic ticket) sums all partial records in
-// fixed order, runs evalDegenracy + the 6x6 solve + Plus and re-arms the ticket: a GN iteration costs two launches.
+// Fused tail: the last workgroup to arrive (agent-scope release/acquire around an atomic ticket) sums the partial records
+// in fixed order, runs the degeneracy test + the 6x6 solve + Plus for every pose block and re-arms the ticket: a GN iteration
+// costs two launches.
 __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tiles)
 {
     __shared__ int s_last;
@@ -423,14 +467,33 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     if (!s_last) return;
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
-    SumArgs sa;
-    sa.p = P.partials;
-    sa.nb = total_tiles;
-    sum_partials(sa, f_ne, f_cnt2, f_scratch);
-    if (threadIdx.x < 2) {
-        gn_finish2(f_ne, f_cnt2, P.state, P.eig_thre, P.stat, f_scratch);
-        if (threadIdx.x == 0) *P.ticket = 0u;
+    for (int b = 0; b < P.n_blocks; ++b) {
+        SumArgs sa;
+        sa.p = P.partials;
+        sa.lo[0] = P.k[0].m > 0 ? P.k[0].blk_start[b] / TPB : 0;
+        sa.hi[0] = P.k[0].m > 0 ? (P.k[0].blk_start[b + 1] + TPB - 1) / TPB : 0;
+        sa.lo[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? P.k[1].blk_start[b] / TPB : 0);
+        sa.hi[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? (P.k[1].blk_start[b + 1] + TPB - 1) / TPB : 0);
+        sum_partials(sa, f_ne, f_cnt2, f_scratch);
+        if (threadIdx.x < 2)
+            gn_finish2(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], b == 0 ? P.state : nullptr, P.thre_b[b], P.freeze_b[b],
+                       P.stat ? P.stat + b : nullptr, f_scratch);
+        __syncthreads();
     }
+    if (threadIdx.x == 0) *P.ticket = 0u;
+}
+
+template <int K>
+__device__ __forceinline__ bool fit_feature(const KParams &P, const KindP &Kd, int kind, int f, float (&coef)[6])
+{
+    const float4 *nb = Kd.nbr + size_t(f) * Kd.nbr_stride;
+    const float4 last = nb[K - 1];
+    if (!(last.w < P.min_match_sq_dis)) return false;     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
+    float ax[K], ay[K], az[K];
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) { const float4 v = nb[j]; ax[j] = v.x; ay[j] = v.y; az[j] = v.z; }
+    ax[K - 1] = last.x; ay[K - 1] = last.y; az[K - 1] = last.z;
+    return kind == MLH_SURF ? fit_plane<K>(ax, ay, az, P.min_plane_dis, coef) : fit_line<K>(ax, ay, az, coef);
 }
 
 // ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature, both kinds in one launch
@@ -444,7 +507,8 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
     const KindP &K = P.k[kind];
     const int f = tile * TPB + threadIdx.x;
-    const double *pose = P.pose_sel ? P.state->cand : P.state->x;
+    const int b = block_of_slot(K, P.n_blocks, tile * TPB);       // uniform over the workgroup (blocks start on tile boundaries)
+    const double *pose = block_pose(P, b);
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
     bool valid = false;
@@ -453,23 +517,14 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 #pragma unroll
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 fp = make_float4(0.f, 0.f, 0.f, -1.f);
     if (f < K.m) {
         fp = K.feat[f];
         float sx, sy, sz;
         associate_to_map(q, t, fp, sx, sy, sz);
-        if (owns(P, sx, sy, sz)) {
-            const float4 *nb = K.nbr + size_t(f) * 5;
-            const float4 n4 = nb[4];
-            if (n4.w < P.min_match_sq_dis) {     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
-                float ax[5], ay[5], az[5];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float4 v = nb[j]; ax[j] = v.x; ay[j] = v.y; az[j] = v.z; }
-                ax[4] = n4.x; ay[4] = n4.y; az[4] = n4.z;
-                if (kind == MLH_SURF) valid = fit_plane(ax, ay, az, P.min_plane_dis, coef);
-                else valid = fit_line(ax, ay, az, coef);
-                if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
-            }
+        if (fp.w >= 0.f && owns(P, sx, sy, sz)) {
+            valid = (P.kb[b] == 10) ? fit_feature<10>(P, K, kind, f, coef) : fit_feature<5>(P, K, kind, f, coef);
+            if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
         }
         Corr c;
 #pragma unroll
@@ -509,7 +564,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
     const KindP &K = P.k[kind];
     const int f = tile * TPB + threadIdx.x;
-    const double *pose = P.pose_sel ? P.state->cand : P.state->x;
+    const double *pose = block_pose(P, block_of_slot(K, P.n_blocks, tile * TPB));
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
     bool valid = false;
@@ -547,7 +602,7 @@ __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const fl
     const int qi = blockIdx.x * KNN_FPB + grp;
     if (qi >= nq) return;
     unsigned long long keys[5];
-    knn5_group8(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
+    knn_group8<5>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
     if (gl == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -563,6 +618,14 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
 {
     std::memset(&P, 0, sizeof(P));
     int tiles_b_total = 0;
+    P.n_blocks = a.n_blocks > 0 ? a.n_blocks : 1;
+    int kmax = 5;
+    for (int b = 0; b < P.n_blocks; ++b) {
+        P.kb[b] = a.k_neigh[b] == 10 ? 10 : 5;
+        P.thre_b[b] = a.eig_thre[b];
+        P.freeze_b[b] = a.freeze[b];
+        kmax = std::max(kmax, P.kb[b]);
+    }
     for (int k = 0; k < 2; ++k) {
         KindP &K = P.k[k];
         if (!(a.kind_mask & (1 << k))) continue;
@@ -570,12 +633,14 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         MapGrid &mg = ctx->map[k];
         if (!mg.built) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
         if (fs.m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set has not been called for this kind");
+        if (fs.n_blocks != P.n_blocks) return fail(ctx, MLH_ERR_STATE, "the staged features hold a different number of pose blocks than requested");
         // the cell edge was derived from the acceptance radius given at map_set; a larger radius here would break exactness
         if (a.min_match_sq_dis > 0.f && std::sqrt(a.min_match_sq_dis) > mg.h)
             return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis exceeds the value the map grid was built for");
         hipError_t e;
         if ((e = fs.corr.ensure(sizeof(Corr) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc corr", e);
-        if ((e = fs.nbr.ensure(sizeof(float4) * 5 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc nbr", e);
+        if (fs.nbr_stride < kmax) { fs.nbr.release(); fs.nbr_stride = kmax; }
+        if ((e = fs.nbr.ensure(sizeof(float4) * size_t(fs.nbr_stride) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc nbr", e);
         if (a.dense) {
             if ((e = fs.r.ensure(sizeof(double) * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc r", e);
             if ((e = fs.J.ensure(sizeof(double) * 6 * size_t(fs.m))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc J", e);
@@ -590,6 +655,8 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         K.m = fs.m;
         K.tiles_a = (fs.m + KNN_FPB - 1) / KNN_FPB;
         K.tiles_b = (fs.m + TPB - 1) / TPB;
+        K.nbr_stride = fs.nbr_stride;
+        for (int b = 0; b <= MAX_BLOCKS; ++b) K.blk_start[b] = fs.blk_start[std::min(b, fs.n_blocks)];
         tiles_b_total += K.tiles_b;
     }
     if (tiles_b_total == 0) return fail(ctx, MLH_ERR_STATE, "no map/features staged for the requested kinds");
@@ -613,7 +680,6 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
     P.ticket = ctx->ticket.as<unsigned>();
-    P.eig_thre = a.map_eig_thre;
     P.stat = (a.stat_slot >= 0) ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     return MLH_OK;
 }

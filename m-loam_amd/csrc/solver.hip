@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState 
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x >= 2) return;
-    gn_finish2(ne, cnt2, S, eig_thre, stat, scratch);
+    gn_finish2(ne, cnt2, S->x, S, eig_thre, 0, stat, scratch);
 }
 
 // reduce only: S->ne <- sum of partials (used by the host-driven mlh_match_linearize / mlh_linearize)
@@ -163,7 +163,8 @@ static SumArgs make_sum_args(mlh_ctx *ctx)
 {
     SumArgs sa;
     sa.p = ctx->partials.as<double>();
-    sa.nb = ctx->n_partial_tiles;
+    sa.lo[0] = 0; sa.hi[0] = ctx->n_partial_tiles;
+    sa.lo[1] = 0; sa.hi[1] = 0;
     return sa;
 }
 

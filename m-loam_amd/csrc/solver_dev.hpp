@@ -9,26 +9,29 @@ namespace mlh {
 
 struct SumArgs {
     const double *p;   // per-tile partial records (NE_STRIDE doubles each), surf tiles first, then corner tiles
-    int nb;
+    int lo[2], hi[2];  // two tile ranges [lo, hi) summed in this order (a pose block's surf tiles, then its corner tiles)
 };
 
-// 256 threads: column c = tid & 31, slice s = tid >> 5 sums tiles s, s+8, ...; the 8 slices are combined in fixed order.
+// 256 threads: column c = tid & 31, slice s = tid >> 5 sums every 8th tile of the ranges; the 8 slices are combined in fixed order.
 // Record layout: [0..20] J^T J upper, [21..26] J^T r, [27] cost, [28] count, [29] surf count, [30] corner count.
 __device__ inline void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS 8*32*/)
 {
     const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
     if (a.p) {
-        // fixed association: tiles s, s+8, ... in four interleaved chains (loads of a trip are independent -> in flight together)
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int b = s;
-        for (; b + 24 < a.nb; b += 32) {
-            const double t0 = a.p[size_t(b) * NE_STRIDE + c], t1 = a.p[size_t(b + 8) * NE_STRIDE + c];
-            const double t2 = a.p[size_t(b + 16) * NE_STRIDE + c], t3 = a.p[size_t(b + 24) * NE_STRIDE + c];
-            v0 += t0; v1 += t1; v2 += t2; v3 += t3;
+        // fixed association: four interleaved chains per range (the loads of a trip are independent -> in flight together)
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            int b = a.lo[rg] + s;
+            for (; b + 24 < a.hi[rg]; b += 32) {
+                const double t0 = a.p[size_t(b) * NE_STRIDE + c], t1 = a.p[size_t(b + 8) * NE_STRIDE + c];
+                const double t2 = a.p[size_t(b + 16) * NE_STRIDE + c], t3 = a.p[size_t(b + 24) * NE_STRIDE + c];
+                v0 += t0; v1 += t1; v2 += t2; v3 += t3;
+            }
+            for (; b < a.hi[rg]; b += 8) v0 += a.p[size_t(b) * NE_STRIDE + c];
+            v += (v0 + v1) + (v2 + v3);
         }
-        for (; b < a.nb; b += 8) v0 += a.p[size_t(b) * NE_STRIDE + c];
-        v = (v0 + v1) + (v2 + v3);
     }
     scratch[s * 32 + c] = v;
     __syncthreads();
@@ -195,11 +198,15 @@ __device__ __noinline__ void write_stat_common(IterStatDev *st, const double *ne
 }
 
 
-// The tail of a Gauss-Newton iteration: evalDegenracy -> solve H d = -g -> x <- Plus(x, V_update d).
+// The tail of a Gauss-Newton iteration for one pose block: degeneracy test -> solve H d = -g -> x <- Plus(x, V_update d).
 // Called by lanes 0 and 1 of one wavefront (converged): both run the same register-resident Cholesky factorisation in
 // lock-step -- lane 0 on H (for the solve), lane 1 on H - thre*I (positive definite <=> lambda_min > thre <=> nothing is
-// degenerate) -- so the degeneracy test costs no extra time. Lane 0 then finishes. `ne` / `cnt2`: the reduced record in LDS.
-__device__ inline void gn_finish2(const double *ne, const double *cnt2, SolverState *S, double eig_thre, IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
+// degenerate) -- so the degeneracy test costs no extra time. Lane 0 then finishes.
+//   freeze = 0: evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204): project the weak directions out of the update
+//   freeze = 1: an extrinsic block whose lambda_min is below the threshold is not updated at all (estimator.cpp:1662-1676)
+// `ne` / `cnt2`: the reduced record in LDS; x: the block's pose; S (nullable): the solver state that mirrors block 0.
+__device__ inline void gn_finish2(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
+                                  IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
 {
     const int lane = threadIdx.x & 63;
     double H[36], A[36], L[36];
@@ -213,6 +220,7 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, SolverSt
     bool deg = false;
     const bool slow = !(stat == nullptr && not_degenerate_fast);
     if (slow) deg = eval_degeneracy_mem(ne, eig_thre, work);
+    const bool frozen = freeze && (slow ? deg : false);
     double d[6];
     bool ok = pd;
     if (ok) {
@@ -239,21 +247,23 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, SolverSt
         for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
         ok = chol6_solve(Hd, rhs, d);
     }
-    if (ok) {
+    if (ok && !frozen) {
         double xc[7], xn[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) xc[i] = S->x[i];
+        for (int i = 0; i < 7; ++i) xc[i] = x[i];
         pose_plus(xc, d, slow ? work + 78 : nullptr, xn);   // V_update = I on the fast path
 #pragma unroll
-        for (int i = 0; i < 7; ++i) S->x[i] = xn[i];
+        for (int i = 0; i < 7; ++i) x[i] = xn[i];
     }
-    for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
-    for (int i = 0; i < 36; ++i) S->V[i] = slow ? work[78 + i] : (((i % 7) == 0) ? 1.0 : 0.0);
+    if (S) {
+        for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
+        for (int i = 0; i < 36; ++i) S->V[i] = slow ? work[78 + i] : (((i % 7) == 0) ? 1.0 : 0.0);
+    }
     if (stat) {
         write_stat_common(stat, ne, cnt2, work + 72, deg);
         stat->final_cost = ne[NE_COST];
-        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = 0;
-        for (int i = 0; i < 7; ++i) stat->pose_after[i] = S->x[i];
+        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = frozen ? 1 : 0;
+        for (int i = 0; i < 7; ++i) stat->pose_after[i] = x[i];
     }
 }
 

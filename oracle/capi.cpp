@@ -168,7 +168,8 @@ static FeatureCloud make_fc(const float *feats, int stride, int n, int cov_off)
 static MapperParams make_params(const double *prm)
 {
     // prm: [min_match_sq_dis, min_plane_dis, huber_delta, map_eig_thre, with_ua, cov_measurement_trace,
-    //       max_outer, max_lm_iterations, gf_method(0 wo_gf,1 rnd,2 fps,3 gd_fix,4 gd_float), gf_ratio, seed]
+    //       max_outer, max_lm_iterations, gf_method(0 wo_gf,1 rnd,2 fps,3 gd_fix,4 gd_float), gf_ratio, seed,
+    //       n_neigh, check_fov, freeze_when_degenerate]
     MapperParams p;
     p.mp.min_match_sq_dis = (float)prm[0];
     p.mp.min_plane_dis = (float)prm[1];
@@ -182,6 +183,9 @@ static MapperParams make_params(const double *prm)
     p.sel.gf_method = names[(int)prm[8]];
     p.sel.gf_ratio = prm[9];
     p.sel.seed = (uint64_t)prm[10];
+    p.n_neigh = (int)prm[11];
+    p.check_fov = prm[12] != 0.0;
+    p.freeze_when_degenerate = prm[13] != 0.0;
     return p;
 }
 
@@ -270,6 +274,15 @@ int orc_gn_iterations(void *surf_map, void *corner_map, const float *surf, int s
         }
     }
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+// pure-odometry factor (3 pose blocks); J: 3 x 7
+int orc_pure_odom_eval(char type, const double *point, const double *coeff, double sqrt_info, const double *pivot, const double *pose_i,
+                       const double *ext, double *residual, double *J21)
+{
+    if (type == 's') pure_odom_plane_evaluate(point, coeff, sqrt_info, pivot, pose_i, ext, residual, J21, J21 + 7, J21 + 14);
+    else pure_odom_edge_evaluate(point, coeff, sqrt_info, pivot, pose_i, ext, residual, J21, J21 + 7, J21 + 14);
     return 0;
 }
 

@@ -408,13 +408,16 @@ void scan2map_optimization(const MapCloud &surf_map, const MapCloud &corner_map,
 }
 
 static void match_all_parallel(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose, char type,
-                               const MatchParams &mp, std::vector<Feature> &feats, std::vector<uint8_t> &ok, int n_threads)
+                               const MapperParams &prm, std::vector<Feature> &feats, std::vector<uint8_t> &ok, int n_threads)
 {
     feats.assign(cloud.n, Feature());
     ok.assign(cloud.n, 0);
 #pragma omp parallel for num_threads(n_threads) schedule(dynamic, 256) if (n_threads > 1)
-    for (int i = 0; i < cloud.n; ++i)
-        ok[i] = match_one(map, cloud, i, pose, feats[i], type, mp) ? 1 : 0;
+    for (int i = 0; i < cloud.n; ++i) {
+        bool b = (type == 's') ? match_surf_point_from_map(map, cloud.at(i), pose, feats[i], i, prm.n_neigh, prm.check_fov, prm.mp)
+                               : match_corner_point_from_map(map, cloud.at(i), pose, feats[i], i, prm.n_neigh, prm.check_fov, prm.mp);
+        ok[i] = b ? 1 : 0;
+    }
 }
 
 void gn_iteration(const MapCloud &surf_map, const MapCloud &corner_map, const FeatureCloud &surf, const FeatureCloud &corner,
@@ -423,8 +426,8 @@ void gn_iteration(const MapCloud &surf_map, const MapCloud &corner_map, const Fe
     Pose pose = pose_from_param(x);
     std::vector<Feature> fs, fc;
     std::vector<uint8_t> oks, okc;
-    match_all_parallel(surf_map, surf, pose, 's', prm.mp, fs, oks, n_threads);
-    match_all_parallel(corner_map, corner, pose, 'c', prm.mp, fc, okc, n_threads);
+    match_all_parallel(surf_map, surf, pose, 's', prm, fs, oks, n_threads);
+    match_all_parallel(corner_map, corner, pose, 'c', prm, fc, okc, n_threads);
     std::vector<size_t> sel_s, sel_c;
     for (int i = 0; i < surf.n; ++i) if (oks[i]) sel_s.push_back(i);
     for (int i = 0; i < corner.n; ++i) if (okc[i]) sel_c.push_back(i);
@@ -434,6 +437,7 @@ void gn_iteration(const MapCloud &surf_map, const MapCloud &corner_map, const Fe
     build_blocks(fs, sel_s, surf, fc, sel_c, corner, prm, blocks);
     evaluate_problem(blocks, x, prm.huber_delta, st.ne, true);
     eval_degeneracy(st.ne.H, prm.map_eig_thre, st.deg);
+    if (prm.freeze_when_degenerate && st.deg.is_degenerate) std::memset(st.deg.V_update, 0, sizeof(st.deg.V_update));
     double rhs[6], d[6];
     for (int i = 0; i < 6; ++i) rhs[i] = -st.ne.g[i];
     bool ok = chol_solve_d(st.ne.H, rhs, 6, d);

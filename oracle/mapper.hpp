@@ -96,6 +96,12 @@ struct MapperParams {
     int max_outer = 2;                 // cpp:439
     int max_lm_iterations = 30;        // cpp:590
     SelectParams sel;
+    // per-block options of the odometry-side clients (BASELINE config 4): buildCalibMap matches the reference LiDAR with
+    // N_NEIGH = 5 and the others with N_NEIGH = 10, CHECK_FOV = true (estimator.cpp:1135-1149); an extrinsic block whose
+    // information is too weak is not updated (V_update_ = 0, estimator.cpp:1662-1676) instead of being projected.
+    int n_neigh = 5;
+    bool check_fov = false;
+    bool freeze_when_degenerate = false;
 };
 
 struct OuterStat {

@@ -51,9 +51,11 @@ def _ptr(a):
 
 
 def mapper_params(min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1, map_eig_thre=100.0, with_ua=False,
-                  cov_measurement_trace=0.0075, max_outer=2, max_lm_iterations=30, gf_method="wo_gf", gf_ratio=1.0, seed=0):
+                  cov_measurement_trace=0.0075, max_outer=2, max_lm_iterations=30, gf_method="wo_gf", gf_ratio=1.0, seed=0,
+                  n_neigh=5, check_fov=False, freeze_when_degenerate=False):
     return np.array([min_match_sq_dis, min_plane_dis, huber_delta, map_eig_thre, float(with_ua), cov_measurement_trace,
-                     max_outer, max_lm_iterations, GF_METHODS[gf_method], gf_ratio, seed], dtype=np.float64)
+                     max_outer, max_lm_iterations, GF_METHODS[gf_method], gf_ratio, seed, n_neigh, float(check_fov),
+                     float(freeze_when_degenerate)], dtype=np.float64)
 
 
 def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray):
@@ -240,6 +242,16 @@ def gn_iterations(surf_map: Map, corner_map: Map, surf, corner, pose_init, prm, 
         iters.append(dict(n_surf=int(o[0]), n_corner=int(o[1]), cost=o[2], is_degenerate=bool(o[3]),
                           pose_after=o[4:11].copy(), g=o[11:17].copy(), H=H))
     return dict(pose=pose, iters=iters, seconds=secs.value)
+
+
+def pure_odom_eval(kind: str, point, coeff, pivot, pose_i, ext, sqrt_info=1.0):
+    point = np.ascontiguousarray(point, np.float64)
+    coeff = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    pv, pi, pe = (np.ascontiguousarray(a, np.float64) for a in (pivot, pose_i, ext))
+    r = np.zeros(1)
+    J = np.zeros((3, 7))
+    lib().orc_pure_odom_eval(C.c_char(kind.encode()), _ptr(point), _ptr(coeff), C.c_double(sqrt_info), _ptr(pv), _ptr(pi), _ptr(pe), _ptr(r), _ptr(J))
+    return r[0], J
 
 
 def eig3f(A):

@@ -298,3 +298,49 @@ def test_point_uncertainty_parity(ctx, mla, orc, synth, feats16):
         clear = np.abs(tr - 0.6) > 1e-4
         assert np.array_equal(keep[m][clear], (tr <= 0.6)[clear])
     assert 0 < keep.sum() < len(keep)
+
+
+def test_pose_blocks_config4_parity(mla, orc, synth, case16):
+    """BASELINE config 4 structure: one pose block per LiDAR (block 0 = body pose from the reference LiDAR with N_NEIGH 5,
+    blocks 1..3 = the other LiDARs with N_NEIGH 10, CHECK_FOV on, frozen when degenerate), all blocks and both feature kinds
+    in the same two launches per GN iteration. Each block must reproduce the oracle's single-block iteration on its own cloud."""
+    import conftest
+    case = conftest._make_case(synth, "50k", 16, 4)
+    surf_b, corner_b, poses0 = [], [], []
+    rng = np.random.default_rng(9)
+    for i, sc in enumerate(case["scans"]):
+        ex = orc.extract(sc.points, sc.scan_start, sc.scan_end)
+        c = np.zeros((len(ex["less_sharp"]), 4), np.float32)
+        c[:, :3] = sc.points[ex["less_sharp"]][:, :3]
+        s = ex["less_flat_ds"].copy()
+        surf_b.append(np.ascontiguousarray(synth.voxel_mean(s, 0.4)))
+        corner_b.append(np.ascontiguousarray(synth.voxel_mean(c, 0.2)))
+        # pose of LiDAR i in the map frame, perturbed
+        T = synth.pose_to_mat(case["gt"]) @ np.block([[synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4]), synth.HERCULES_BODY_T_LASER[i][4:7, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+        # rotation matrix -> quaternion through the perturbation helper
+        w = np.sqrt(max(0.0, 1 + T[0, 0] + T[1, 1] + T[2, 2])) / 2
+        q = np.array([(T[2, 1] - T[1, 2]) / (4 * w), (T[0, 2] - T[2, 0]) / (4 * w), (T[1, 0] - T[0, 1]) / (4 * w), w])
+        gt_i = np.concatenate([T[:3, 3], q / np.linalg.norm(q)])
+        poses0.append(synth.perturbed_pose(gt_i, seed=50 + i, dt=0.1, drot_deg=1.0))
+    poses0 = np.array(poses0)
+    k_neigh, thre, freeze = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
+    ctx = mla.Context(0)
+    ctx.map_set(mla.SURF, case["surf_map"])
+    ctx.map_set(mla.CORNER, case["corner_map"])
+    ctx.features_set_blocks(mla.SURF, surf_b)
+    ctx.features_set_blocks(mla.CORNER, corner_b)
+    opts = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+    n_it = 3
+    poses, stats = ctx.gn_solve_blocks(poses0, n_it, k_neigh, thre, freeze, opts)
+    ms, mc = orc.Map(case["surf_map"]), orc.Map(case["corner_map"])
+    for b in range(4):
+        prm = orc.mapper_params(huber_delta=1.0, map_eig_thre=thre[b], n_neigh=k_neigh[b], check_fov=True, freeze_when_degenerate=bool(freeze[b]))
+        ref = orc.gn_iterations(ms, mc, surf_b[b], corner_b[b], poses0[b], prm, n_it)
+        for it in range(n_it):
+            s, r = stats[it][b], ref["iters"][it]
+            assert (s["n_surf"], s["n_corner"]) == (r["n_surf"], r["n_corner"]), (b, it)
+            np.testing.assert_allclose(s["H"], r["H"], rtol=1e-8, atol=1e-6)
+            assert s["is_degenerate"] == r["is_degenerate"]
+        dt, dr = _pose_err(poses[b], ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
+    ctx.close()
