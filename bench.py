@@ -154,6 +154,11 @@ def main():
         ms_ = shard.shard_points_mask(surf_map, center, world, rank)
         mc_ = shard.shard_points_mask(corner_map, center, world, rank)
         local_surf_map, local_corner_map = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
+        far = np.full((1, 3), 1.0e6, np.float32)     # a wedge without any map point still needs a (never matched) record
+        if len(local_surf_map) == 0:
+            local_surf_map = far
+        if len(local_corner_map) == 0:
+            local_corner_map = far
         lo, hi = shard.wedge_planes(center, world, rank)
         ctx.shard_set(lo, hi)
         uid = [mla.comm_unique_id() if rank == 0 else None]

@@ -581,8 +581,12 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
             a.stat_slot = stats ? it : -1;
             if ((rc = match_launch(ctx, a))) return rc;
         } else {
+            // multi-GPU: the fit kernel's last workgroup leaves this rank's sums in the solver state, then ONE all-reduce of
+            // 32 doubles, then every rank runs the identical solve
+            a.finish = 2;
             if ((rc = match_launch(ctx, a))) return rc;
-            if ((rc = gn_update_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;   // local reduce + all-reduce + solve
+            if ((rc = comm_allreduce_state(ctx, 0))) return rc;
+            if ((rc = gn_update_prereduced_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;
         }
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);

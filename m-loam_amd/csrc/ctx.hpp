@@ -228,6 +228,7 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
 // solver.hip
 int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
+int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 // comm.hip
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
 void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream

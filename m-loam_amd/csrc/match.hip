@@ -321,7 +321,7 @@ struct KParams {
     double thre_b[MAX_BLOCKS];   // eigen threshold per block
     int freeze_b[MAX_BLOCKS];    // 0: project the degenerate directions out (evalDegenracy); 1: do not update the block at all
     // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose(s)
-    int finish;              // 0: none, 1: GN
+    int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU)
     unsigned *ticket;
     IterStatDev *stat;       // n_blocks consecutive records, or null
 };
@@ -467,6 +467,16 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     if (!s_last) return;
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
+    if (P.finish == 2) {
+        // multi-GPU: only the local reduction happens here; the all-reduce and the (redundant, identical) solve follow
+        SumArgs sa;
+        sa.p = P.partials;
+        sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
+        sum_partials(sa, f_ne, f_cnt2, f_scratch);
+        if (threadIdx.x < NE_STRIDE) P.state->ne[threadIdx.x] = f_ne[threadIdx.x];
+        if (threadIdx.x == 0) *P.ticket = 0u;
+        return;
+    }
     for (int b = 0; b < P.n_blocks; ++b) {
         SumArgs sa;
         sa.p = P.partials;

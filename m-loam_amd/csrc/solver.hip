@@ -204,6 +204,16 @@ int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
     return MLH_OK;
 }
 
+int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
+{
+    prof_begin(ctx, MLH_K_SOLVE);
+    hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
+                       map_eig_thre, stat_ptr(ctx, stat_slot), 1);
+    prof_end(ctx, MLH_K_SOLVE);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
 int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot)
 {
     int pre = 0, rc = pre_reduce(ctx, 0, pre);
