@@ -1,0 +1,131 @@
+"""Edge cases of the HIP path against the oracle: skipped / ragged / very long rings, tiny and non-tile-multiple feature sets,
+queries with no neighbours, maps too small to match, call-order and argument errors through the C-ABI status codes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(mla):
+    c = mla.Context(0)
+    yield c
+    c.close()
+
+
+def _ring_scan(rng, lens, noise=0.02):
+    """ragged synthetic rings: points on a noisy circle-ish polyline so that curvatures are generic (no ties)"""
+    pts, starts, ends, off = [], [], [], 0
+    for r, n in enumerate(lens):
+        a = np.linspace(0, 2 * np.pi, n, endpoint=False)
+        rad = 8.0 + 3.0 * np.sin(3 * a + r) + (np.abs(np.sin(5 * a)) > 0.95) * 2.0 + rng.normal(0, noise, n)
+        p = np.stack([rad * np.cos(a), rad * np.sin(a), np.full(n, 0.3 * r) + rng.normal(0, noise, n), np.zeros(n)], axis=1)
+        pts.append(p)
+        starts.append(off + 5)
+        ends.append(off + n - 6)
+        off += n
+    return np.concatenate(pts).astype(np.float32), np.array(starts, np.int32), np.array(ends, np.int32)
+
+
+def _check_extract(ctx, orc, pts, ss, se):
+    ref = orc.extract(pts, ss, se)
+    assert ref["n_ties"] == 0
+    got = ctx.extract(pts, ss, se, voxel_leaf=0.2)
+    assert np.array_equal(got["curvature"].view(np.uint32), ref["curvature"].view(np.uint32))
+    assert np.array_equal(got["label"], ref["label"])
+    assert np.array_equal(got["picked"], ref["picked"])
+    for k in ("sharp", "less_sharp", "flat", "less_flat_raw"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["less_flat_ds"].shape == ref["less_flat_ds"].shape
+    np.testing.assert_allclose(got["less_flat_ds"], ref["less_flat_ds"], rtol=2e-6, atol=2e-6)
+
+
+def test_extract_ragged_and_skipped_rings(ctx, orc):
+    rng = np.random.default_rng(0)
+    # ring lengths: a skipped one (end - start < 6 <=> n < 17), the minimum processed one, odd sizes, one long ring
+    _check_extract(ctx, orc, *_ring_scan(rng, [16, 17, 23, 64, 301, 1800, 40, 777]))
+
+
+def test_extract_4000_column_rings(ctx, orc):
+    """config_realvehicle_kitti.yaml: horizon_scan 4000 -> ~130 KB of LDS per ring workgroup"""
+    rng = np.random.default_rng(1)
+    _check_extract(ctx, orc, *_ring_scan(rng, [4000, 3990, 4000]))
+
+
+def test_extract_rejects_bad_ring_tables(ctx, mla):
+    rng = np.random.default_rng(2)
+    pts, ss, se = _ring_scan(rng, [100, 100])
+    with pytest.raises(mla.MlhError):          # not inset from the cloud ends
+        ctx.scan_upload(pts, np.array([0, 105], np.int32), se)
+    with pytest.raises(mla.MlhError):          # rings closer than the +5/-6 insets: suppression of one could reach the other
+        ctx.scan_upload(pts, np.array([5, 96], np.int32), np.array([94, 194], np.int32))
+
+
+@pytest.mark.parametrize("m", [1, 7, 33, 255, 257, 1000])
+def test_small_and_ragged_feature_counts(ctx, mla, orc, case16, feats16, m):
+    surf = np.ascontiguousarray(feats16[0][:m])
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    ctx.features_set(mla.SURF, surf)
+    got = ctx.match_linearize(mla.SURF, case16["p0"])
+    valid, coeffs = orc.Map(case16["surf_map"]).match("s", surf, case16["p0"])
+    assert np.array_equal(got["valid"], valid)
+    ref = orc.linearize("s", surf, np.full(m, 0.0075), case16["p0"], valid, coeffs)
+    np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-9, atol=1e-8)
+    assert got["count"] == ref["count"]
+
+
+def test_queries_without_neighbours_and_tiny_maps(ctx, mla, orc, case16, feats16):
+    # features far outside the map extent: no candidate cell at all
+    far = feats16[0][:300].copy()
+    far[:, :3] += 5000.0
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    ctx.features_set(mla.SURF, far)
+    out = ctx.match_linearize(mla.SURF, case16["p0"])
+    assert out["count"] == 0 and not out["valid"].any() and np.all(out["H"] == 0)
+    idx, d2 = ctx.knn(mla.SURF, far[:10, :3])
+    assert np.all(idx == -1) and np.all(np.isinf(d2))
+    # a map with fewer than 5 points can never produce a correspondence
+    tiny = case16["surf_map"][:4].copy()
+    ctx.map_set(mla.SURF, tiny)
+    ctx.features_set(mla.SURF, feats16[0][:500])
+    out = ctx.match_linearize(mla.SURF, case16["p0"])
+    assert out["count"] == 0
+    # exactly 5 coplanar points: the one query in their middle matches, as in the oracle
+    five = np.array([[0, 0, 0], [0.3, 0, 0], [0, 0.3, 0], [0.3, 0.3, 0.001], [0.15, 0.15, 0]], np.float32) + np.float32(10.0)
+    q = np.array([[10.1, 10.1, 10.05, 0]], np.float32)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    ctx.map_set(mla.SURF, five)
+    ctx.features_set(mla.SURF, q)
+    out = ctx.match_linearize(mla.SURF, ident)
+    v, c = orc.Map(five).match("s", q, ident)
+    assert np.array_equal(out["valid"], v) and v[0] == 1
+    assert np.array_equal(out["coeffs"].astype(np.float32).view(np.uint32), c.astype(np.float32).view(np.uint32))
+
+
+def test_scan2map_needs_a_minimum_map(mla, case16, feats16):
+    """scan2MapOptimization does nothing unless the map holds > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429)"""
+    c = mla.Context(0)
+    c.map_set(mla.SURF, case16["surf_map"][:40])
+    c.map_set(mla.CORNER, case16["corner_map"])
+    c.features_set(mla.SURF, feats16[0])
+    c.features_set(mla.CORNER, feats16[1])
+    pose, stats = c.scan2map(case16["p0"])
+    assert np.array_equal(pose, case16["p0"])
+    assert all(s["n_surf"] == 0 for s in stats)
+    c.close()
+
+
+def test_status_codes(mla, case16, feats16):
+    c = mla.Context(0)
+    with pytest.raises(mla.MlhError, match="map_set"):
+        c.features_set(mla.SURF, feats16[0])
+        c.match_linearize(mla.SURF, case16["p0"])
+    c.map_set(mla.SURF, case16["surf_map"])
+    with pytest.raises(mla.MlhError, match="exceeds"):      # acceptance radius larger than the grid was built for
+        c.match_linearize(mla.SURF, case16["p0"], min_match_sq_dis=4.0)
+    with pytest.raises(mla.MlhError):                        # stride not a multiple of 4 / too small
+        c._ck(c.lib.mlh_map_set(c.h, mla.SURF, case16["surf_map"].ctypes.data, 10, 100, 1.0, mla.MEM_HOST))
+    with pytest.raises(mla.MlhError, match="extract"):
+        c._scan_n = 10
+        c.extract_fetch()
+    c.close()
