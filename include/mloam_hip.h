@@ -109,6 +109,17 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
                           const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
                           double trace_threshold, float *cov_vec_out, int32_t *keep_out);
 
+/* ---------------------------------------------------------------- (f1) covariance-aware voxel thinning
+ * replaces pcl::VoxelGridCovarianceMLOAM<PointT>::filter (mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp:68-457),
+ * the filter that produces the voxel-thinned local map (lidar_mapper_keyframe.cpp:343-347) and thins the scan features
+ * (cpp:359-368). cov_offset_bytes >= 0 selects the covariance branch (PointXYZIWithCov, :296-333): members with |trace| >=
+ * trace_threshold are dropped, w = trace_threshold - trace, mu = sum w p / sum w, cov = sum w^2 cov_i / (sum w)^2, intensity of the
+ * heaviest member, trace recomputed; otherwise the plain branch (PointXYZI, :392-420): xyz mean, intensity of the last member.
+ * Output (HOST, capacity n records) uses the input's record layout and is ordered by voxel index like the reference's.
+ * Members of a voxel are accumulated in input order (the reference: in the order its unstable sort left them). */
+int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
+                     int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem);
+
 /* ---------------------------------------------------------------- (a5) local map index
  * replaces pcl::KdTreeFLANN<PointT>::setInputCloud(cloud) as used at
  *   estimator/src/lidarMapper/lidar_mapper_keyframe.cpp:433-434 (and estimator.cpp:1095-1109, 1230-1233).

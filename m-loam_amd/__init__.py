@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmloam_hip.so")
+LIB_PATH = os.environ.get("MLOAM_HIP_LIB") or os.path.join(_HERE, "lib", "libmloam_hip.so")   # override: instrumented debug builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mloam_hip.h")
 
 SURF, CORNER = 0, 1
@@ -84,6 +84,7 @@ def load_library():
     lib.mlh_extract_voxel_run.argtypes = [vp, cf]
     lib.mlh_extract_fetch_voxel.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     lib.mlh_point_uncertainty.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, cd, vp, vp]
+    lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_rebuild.argtypes = [vp, ci]
     lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty",
+    "mlh_point_uncertainty", "mlh_voxel_filter",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -246,6 +247,16 @@ class Context:
         kp = np.zeros(n, np.int32)
         self._ck(self.lib.mlh_point_uncertainty(self.h, ptr, stride, n, 12, mem, _p(ep), _p(ec), ep.shape[0], _p(cm), trace_threshold, _p(cov), _p(kp)))
         return cov, kp.astype(bool)
+
+    def voxel_filter(self, points, leaf, trace_threshold=0.0):
+        """VoxelGridCovarianceMLOAM: points (n, 4) [x y z intensity] -> plain branch; (n, 11) [x y z i cov6 trace] -> covariance branch."""
+        a = np.ascontiguousarray(points, np.float32)
+        n, ncol = a.shape
+        out = np.zeros_like(a)
+        cnt = C.c_int32(0)
+        cov_off, tr_off = (16, 40) if ncol >= 11 else (-1, -1)
+        self._ck(self.lib.mlh_voxel_filter(self.h, _p(a), ncol * 4, n, 12 if ncol >= 4 else -1, cov_off, tr_off, leaf, trace_threshold, _p(out), C.byref(cnt), MEM_HOST))
+        return out[:cnt.value].copy()
 
     # ---- map / features
     def map_set(self, kind, points, min_match_sq_dis=1.0):

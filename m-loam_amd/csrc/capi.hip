@@ -189,6 +189,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
+    { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -336,6 +337,15 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return point_uncertainty_run(ctx, points, stride_bytes, n, intensity_offset_bytes, mem, ext_poses, ext_covs, n_lidar, cov_measurement,
                                  trace_threshold, cov_vec_out, keep_out);
+}
+
+int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
+                     int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return voxel_filter_run(ctx, points, stride_bytes, n, intensity_offset_bytes, cov_offset_bytes, trace_offset_bytes, leaf, trace_threshold,
+                            out, n_out, mem);
 }
 
 // ---------------------------------------------------------------- map

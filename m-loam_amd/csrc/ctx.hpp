@@ -141,6 +141,10 @@ struct ScanBuf {
     bool extracted = false;
 };
 
+struct VoxBuf {   // scratch of mlh_voxel_filter
+    DevBuf in, bounds, cell, vox_of, sorted_idx, leader, out, sums, total;
+};
+
 struct Profile {
     unsigned mask = 0;     // bit k: bracket launches of kernel id k
     double total_ms[MLH_K_COUNT] = {0};
@@ -168,6 +172,7 @@ struct mlh_ctx {
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
     void *h_state = nullptr; // pinned staging for the solver-state upload
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
+    mlh::VoxBuf vox;
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
@@ -199,6 +204,9 @@ int extract_run(mlh_ctx *ctx);
 int ring_voxel_run(mlh_ctx *ctx, float leaf);
 int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
                           const double *ext_covs, int n_lidar, const double cov_meas[9], double trace_thr, float *cov6_host, int *keep_host);
+// voxelgrid.hip
+int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
+                     float trace_thr, void *out_host, int *n_out, int mem);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 // match.hip

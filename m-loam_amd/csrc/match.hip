@@ -25,6 +25,19 @@
 namespace mlh {
 
 constexpr int TPB = 256;
+
+// Debug build only (-DMLH_STAGE_CLOCK): per-workgroup stage timestamps (100 MHz wall clock) of the fit kernel, read back
+// by mlh_debug_stage_clock. Never compiled into the product library.
+#ifdef MLH_STAGE_CLOCK
+__device__ unsigned long long g_stage_clk[4096 * 8];
+#define MLH_STAGE(tile, i)                                                                   \
+    do {                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        if (threadIdx.x == 0 && (tile) < 4096) g_stage_clk[(tile) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MLH_STAGE(tile, i) do { } while (0)
+#endif
 constexpr int KNN_G = 8;              // lanes per query in the correspondence kernel
 constexpr int KNN_FPB = TPB / KNN_G;  // queries per workgroup
 constexpr unsigned long long KEY_INF = 0x7f800000ffffffffull;   // (+inf, max index)
@@ -218,7 +231,7 @@ __device__ __forceinline__ void eval_edge(const d3 &p, const float (&c)[6], doub
 __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, int kind, double *lds_red /*4*32*/,
                                             double *__restrict__ partial_out)
 {
-    double acc[29];
+    double acc[32];
     if (valid) {
         double s = L.r * L.r, rho0 = s, rho1 = 1.0;
         if (!no_loss && huber_delta > 0.0) {
@@ -247,18 +260,28 @@ __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delt
 #pragma unroll
         for (int i = 0; i < 29; ++i) acc[i] = 0.0;
     }
-#pragma unroll
-    for (int i = 0; i < 29; ++i) {
-        double v = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        acc[i] = v;
-    }
+    acc[29] = acc[30] = acc[31] = 0.0;
+    // transposed butterfly: at each step a lane keeps one half of its values and trades the other half with its partner, so the
+    // wavefront total of value i ends up in lanes 2i and 2i+1 after 16+8+4+2+1+1 = 32 exchanges (a plain per-value butterfly
+    // takes 29*6 = 174). Fixed tree -> deterministic sums.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 29; ++i) lds_red[wave * 32 + i] = acc[i];
+#define MLH_RED_STEP(H, MASK)                                              \
+    {                                                                      \
+        const bool up = (lane & (MASK)) != 0;                              \
+        _Pragma("unroll") for (int i = 0; i < (H); ++i) {                  \
+            const double keep = up ? acc[i + (H)] : acc[i];                \
+            const double send = up ? acc[i] : acc[i + (H)];                \
+            acc[i] = keep + __shfl_xor(send, (MASK));                      \
+        }                                                                  \
     }
+    MLH_RED_STEP(16, 32)
+    MLH_RED_STEP(8, 16)
+    MLH_RED_STEP(4, 8)
+    MLH_RED_STEP(2, 4)
+    MLH_RED_STEP(1, 2)
+#undef MLH_RED_STEP
+    acc[0] += __shfl_xor(acc[0], 1);
+    if ((lane & 1) == 0) lds_red[wave * 32 + (lane >> 1)] = acc[0];
     __syncthreads();
     if (threadIdx.x < 32) {
         double v = 0.0;
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
     const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
     const KindP &K = P.k[kind];
+    MLH_STAGE(gtile, 0);
     const int f = tile * TPB + threadIdx.x;
     const int b = block_of_slot(K, P.n_blocks, tile * TPB);       // uniform over the workgroup (blocks start on tile boundaries)
     const double *pose = block_pose(P, b);
@@ -543,6 +567,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
         c.pad = 0;
         K.corr[f] = c;
     }
+    MLH_STAGE(gtile, 1);
     if (valid) {
         const double w = feature_weight(P, K, f);
         double R[9];
@@ -556,9 +581,21 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 #pragma unroll
         for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
+    MLH_STAGE(gtile, 2);
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    MLH_STAGE(gtile, 3);
     if (P.finish) fused_gn_finish(P, total);
+    MLH_STAGE(gtile, 4);
 }
+
+#ifdef MLH_STAGE_CLOCK
+}  // namespace mlh
+extern "C" int mlh_debug_stage_clock(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk), sizeof(unsigned long long) * size_t(n_words));
+}
+namespace mlh {
+#endif
 
 __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 {

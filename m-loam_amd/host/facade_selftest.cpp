@@ -83,6 +83,17 @@ int main(int argc, char **argv)
         for (const auto &s : rep.outer) { counts.push_back(s.n_surf); counts.push_back(s.n_corner); counts.push_back(s.lm_iterations); }
         write_file(d + "out_counts.i32", counts);
         std::printf("scan2map pose: %.9f %.9f %.9f  %.9f %.9f %.9f %.9f\n", out[0], out[1], out[2], out[3], out[4], out[5], out[6]);
+        // --- VoxelGridCovarianceMLOAM through the reference's setter names
+        VoxelGridCovarianceMLOAM<PointIWithCov> down_size_filter_surf_map_cov(dev);
+        down_size_filter_surf_map_cov.setLeafSize(0.8f, 0.8f, 0.8f);
+        down_size_filter_surf_map_cov.setTraceThreshold(1.0f);
+        down_size_filter_surf_map_cov.setInputCloud(surf_map);
+        PointICovCloud surf_map_ds;
+        down_size_filter_surf_map_cov.filter(surf_map_ds);
+        std::vector<float> ds;
+        for (const auto &q : surf_map_ds.points) { ds.push_back(q.x); ds.push_back(q.y); ds.push_back(q.z); ds.push_back(q.intensity); for (int k = 0; k < 6; ++k) ds.push_back(q.cov_vec[k]); ds.push_back(q.cov_trace); }
+        write_file(d + "out_map_ds.f32", ds);
+        std::printf("voxel filter: %zu -> %zu\n", surf_map.size(), surf_map_ds.size());
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

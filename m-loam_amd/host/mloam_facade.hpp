@@ -151,6 +151,41 @@ private:
     size_t n_ = 0;
 };
 
+// ------------------------------------------------------------------ pcl::VoxelGridCovarianceMLOAM<PointT>
+// The covariance-aware voxel filter (mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam.h:95-399): same setter names, setInputCloud
+// takes the cloud by reference instead of a boost::shared_ptr. PointIWithCov selects the covariance branch, PointI the plain one
+// (the `cov_index >= 0` test of voxel_grid_covariance_mloam_impl.hpp:286).
+template <typename PointT> struct VoxelFields;
+template <> struct VoxelFields<PointI> { static constexpr int intensity = 16, cov = -1, trace = -1; };
+template <> struct VoxelFields<PointIWithCov> { static constexpr int intensity = 16, cov = 20, trace = 44; };
+
+template <typename PointT>
+class VoxelGridCovarianceMLOAM {
+public:
+    explicit VoxelGridCovarianceMLOAM(Device &dev) : dev_(dev) {}
+    void setLeafSize(float lx, float ly, float lz)
+    {
+        if (lx != ly || lx != lz) throw Error("VoxelGridCovarianceMLOAM: cubic leaves only (every call site of the reference uses them)");
+        leaf_ = lx;
+    }
+    void setTraceThreshold(const float trace_threshold) { trace_threshold_ = trace_threshold; }   // .h:349
+    void setInputCloud(const PointCloud<PointT> &cloud) { input_ = &cloud; }
+    void filter(PointCloud<PointT> &output)
+    {
+        if (!input_ || input_->size() == 0) { output.points.clear(); return; }   // "No input dataset given" -> empty output (impl.hpp:71-77)
+        std::vector<PointT> out(input_->size());
+        int32_t n_out = 0;
+        dev_.check(mlh_voxel_filter(dev_.ctx(), input_->points.data(), (int)sizeof(PointT), (int)input_->size(), VoxelFields<PointT>::intensity,
+                                    VoxelFields<PointT>::cov, VoxelFields<PointT>::trace, leaf_, trace_threshold_, out.data(), &n_out, MLH_MEM_HOST));
+        out.resize(n_out);
+        output.points.assign(out.begin(), out.end());
+    }
+private:
+    Device &dev_;
+    const PointCloud<PointT> *input_ = nullptr;
+    float leaf_ = 0.4f, trace_threshold_ = 2.0f;   // .h:102
+};
+
 // ------------------------------------------------------------------ FeatureExtract
 class FeatureExtract {
 public:

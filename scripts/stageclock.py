@@ -1,0 +1,42 @@
+"""Per-stage timestamps of fit_linearize_kernel on the bench workload (debug build, scripts/build_stageclock.sh).
+Usage: MLOAM_HIP_LIB=m-loam_amd/lib/libmloam_hip_dbg.so python scripts/stageclock.py"""
+import ctypes as C, importlib, os, sys, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+mla = importlib.import_module("m-loam_amd")
+synth = importlib.import_module("m-loam_amd.synth")
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "500k")
+p0 = synth.perturbed_pose(gt, seed=43)
+ctx = mla.Context(0)
+ex = []
+for s in scans:
+    ctx.scan_upload(s.points, s.scan_start, s.scan_end); ctx.extract_run(); ex.append(ctx.extract_fetch())
+surf, corner = bench.fuse_features(synth, scans, ex)
+ctx.map_set(mla.SURF, surf_map); ctx.map_set(mla.CORNER, corner_map)
+ctx.features_set(mla.SURF, surf); ctx.features_set(mla.CORNER, corner)
+opts = mla.default_opts()
+for _ in range(5):
+    ctx.gn_solve(p0, 5, opts, want_stats=False)
+ctx.synchronize()
+ctx.gn_solve(p0, 1, opts, want_stats=False)
+ctx.synchronize()
+lib = mla.load_library()
+n_tiles = (len(surf) + 255) // 256 + (len(corner) + 255) // 256
+buf = (C.c_ulonglong * (n_tiles * 8))()
+lib.mlh_debug_stage_clock.argtypes = [C.c_void_p, C.c_int]
+assert lib.mlh_debug_stage_clock(buf, n_tiles * 8) == 0
+t = np.frombuffer(buf, np.uint64).reshape(n_tiles, 8).astype(np.int64)[:, :5]
+t0 = t[:, 0].min()
+rel = (t - t0) * 0.01     # us
+print("tiles", n_tiles, "surf", len(surf), "corner", len(corner))
+names = ["start", "fit done", "eval done", "reduce done", "finish done"]
+for i, nm in enumerate(names):
+    print(f"{nm:12s} min {rel[:, i].min():7.2f} med {np.median(rel[:, i]):7.2f} max {rel[:, i].max():7.2f} us")
+d = np.diff(rel, axis=1)
+for i, nm in enumerate(["fit", "eval", "reduce", "finish"]):
+    print(f"stage {nm:7s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
+last = np.argmax(rel[:, 4])
+print("last tile", last, "stages", rel[last])

@@ -37,3 +37,10 @@ def test_facade_selftest(tmp_path, orc, case16, feats16):
     counts = np.fromfile(os.path.join(d, "out_counts.i32"), np.int32).reshape(-1, 3)
     for c, o in zip(counts, s2m["outer"]):
         assert tuple(c) == (o["n_surf_sel"], o["n_corner_sel"], o["lm_iterations"])
+    # VoxelGridCovarianceMLOAM facade: 48-byte PointXYZIWithCov records in and out
+    ds = np.fromfile(os.path.join(d, "out_map_ds.f32"), np.float32).reshape(-1, 11)
+    m11 = np.zeros((len(case16["surf_map"]), 11), np.float32)
+    m11[:, :3] = case16["surf_map"][:, :3]
+    ref = orc.voxel_grid_cov(m11, 0.8, 1.0)
+    assert ds.shape == ref.shape
+    np.testing.assert_allclose(ds, ref, rtol=2e-6, atol=2e-6)

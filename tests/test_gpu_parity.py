@@ -344,3 +344,51 @@ def test_pose_blocks_config4_parity(mla, orc, synth, case16):
         dt, dr = _pose_err(poses[b], ref["pose"])
         assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
     ctx.close()
+
+
+def test_voxel_filter_covariance_parity(ctx, orc, synth, case16):
+    """(f1) VoxelGridCovarianceMLOAM: voxel membership, output order and count are exact (integer work); the weighted sums differ from
+    the reference's only by the order members are added inside a voxel (the reference's std::sort is unstable), so values are compared to
+    2e-6 relative, and voxels with a single member must agree bit for bit."""
+    rng = np.random.default_rng(11)
+    base = case16["surf_map"][:30000, :3]
+    xyz = np.concatenate([base, base + rng.normal(0, 0.1, base.shape).astype(np.float32)])[rng.permutation(2 * len(base))]
+    n = len(xyz)
+    pts = np.zeros((n, 11), np.float32)
+    pts[:, :3] = xyz
+    pts[:, 3] = rng.integers(0, 4, n)
+    sd = rng.uniform(0.01, 0.9, (n, 3)).astype(np.float32)
+    pts[:, 4] = sd[:, 0] ** 2; pts[:, 7] = sd[:, 1] ** 2; pts[:, 9] = sd[:, 2] ** 2
+    pts[:, 5] = 0.1 * sd[:, 0] * sd[:, 1]; pts[:, 6] = -0.05 * sd[:, 0] * sd[:, 2]; pts[:, 8] = 0.02 * sd[:, 1] * sd[:, 2]
+    pts[:, 10] = pts[:, 4] + pts[:, 7] + pts[:, 9]
+    for leaf, thr in ((0.4, 1.0), (0.8, 0.5), (2.0, 1.0)):
+        got = ctx.voxel_filter(pts, leaf, thr)
+        ref = orc.voxel_grid_cov(pts, leaf, thr)
+        assert got.shape == ref.shape and len(ref) < n
+        np.testing.assert_array_equal(got[:, 3], ref[:, 3])                         # intensity of the heaviest member: a selection
+        np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(got[:, 4:], ref[:, 4:], rtol=1e-5, atol=1e-9)
+        same = np.all(got.view(np.uint32) == ref.view(np.uint32), axis=1)
+        if leaf <= 0.4:
+            assert same.mean() > 0.5     # single-member voxels (most of them at this leaf) agree bit for bit
+    # every member above the trace threshold: the voxel survives with mu = 0 / 1 (weight_total forced to 1), as the reference
+    hot = pts[:2000].copy()
+    hot[:, 4] = 5.0
+    got = ctx.voxel_filter(hot, 0.4, 1.0)
+    ref = orc.voxel_grid_cov(hot, 0.4, 1.0)
+    np.testing.assert_array_equal(got, ref)
+    assert np.all(got[:, :3] == 0)
+
+
+def test_voxel_filter_plain_parity(ctx, orc, case16):
+    """PointXYZI branch (no covariance field): xyz mean over the members, intensity of the voxel's last member."""
+    xyz = case16["corner_map"][:30000, :3]
+    pts = np.concatenate([xyz, np.arange(len(xyz), dtype=np.float32)[:, None]], axis=1).astype(np.float32)
+    for leaf in (0.2, 0.4, 1.0):
+        got = ctx.voxel_filter(pts, leaf)
+        ref = orc.voxel_grid(pts, leaf)              # pcl::VoxelGrid<PointXYZI>: same centroid rule; intensity is averaged there
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)
+        assert np.isin(got[:, 3], pts[:, 3]).all()
+    one = ctx.voxel_filter(pts[:1], 0.4)
+    np.testing.assert_array_equal(one, pts[:1])
