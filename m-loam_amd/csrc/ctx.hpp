@@ -101,10 +101,13 @@ struct MapGrid {
     long long ncell = 0;
     float min_match_sq_dis = 1.0f;
     bool built = false;
+    int cur = 0;               // which of the two cell arrays (cell_start / cell_fill) holds the current index
+    bool twin_clean = false;   // the other one has been cleared for the next build
+    int *cells(int which) const { return (which ? cell_fill : cell_start).as<int>() + 3; }   // see grid.hip: cells + 1 is 16-byte aligned
     GridDev dev() const
     {
         GridDev g;
-        g.sorted = sorted.as<float4>(); g.raw = raw.as<float4>(); g.cell_start = cell_start.as<int>() + 3;   // see grid.hip: cell_start + 1 is 16-byte aligned
+        g.sorted = sorted.as<float4>(); g.raw = raw.as<float4>(); g.cell_start = cells(cur);
         g.ox = ox; g.oy = oy; g.oz = oz; g.inv_h = inv_h; g.nx = nx; g.ny = ny; g.nz = nz; g.n = n;
         return g;
     }

@@ -4,11 +4,14 @@
 //
 // Layout in HBM: raw[n] and sorted[n] as float4 {x, y, z, original index}; cell_start[ncell+1] (int32, exclusive prefix),
 // cells ordered x fastest so the 3 x-adjacent cells of a query form ONE contiguous run of `sorted` (9 runs per query).
-// One build = 6 launches for BOTH maps together (zero, count, 3-phase exclusive scan, scatter); all streaming:
-//   count   16 B/pt read + 1 atomic      scan   8 B/cell      scatter   16 B read + 16 B written + 1 atomic per point
-// The count lands in cell_start[c+1]; the in-place exclusive scan turns that slot into start[c]; the scatter's
-// atomicAdd(&cell_start[c+1], 1) hands out positions and leaves start[c] + count[c] = start[c+1] behind -- so the array ends
-// up being exactly the exclusive prefix the queries read, without a second cursor array or a second clear.
+// One steady-state build = 4 launches for BOTH maps together (count, chunk-local scan, add, scatter); all streaming:
+//   count   16 B/pt read + 1 returning atomic + 4 B rank      scan+add   16 B/cell + 4 B/cell (twin clear)
+//   scatter 16 B + 4 B read, 16 B written per point, no atomics
+// The count lands in cell_start[c+1] and the value the atomic returns is the point's rank inside its cell; the in-place
+// INCLUSIVE scan turns slot c+1 into start[c+1], so with cell_start[0] = 0 the array is the exclusive prefix the queries read
+// and the scatter writes to start[c] + rank. Two cell arrays alternate: the add pass of one build clears the other array,
+// so the next build starts from zeros without a clear launch; with few chunks (<= 4096) the add pass also sums the chunk
+// totals before it itself instead of a separate single-workgroup scan launch.
 #include "ctx.hpp"
 #include <cmath>
 #include <climits>
@@ -61,11 +64,14 @@ __global__ __launch_bounds__(256) void bounds_kernel(const float4 *__restrict__ 
 // ---- one job per map; kernels take both jobs and split their grid between them
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_CHUNK = 256 * SCAN_ITEMS;
+constexpr int FUSED_SUMS_MAX = 4096;   // chunk count up to which scan_add sums the chunk totals itself (no scan_sums launch)
 
 struct GridJob {
     const float4 *raw;
     float4 *sorted;
-    int *cell_start;       // ncell + 1
+    int *cell_start;       // ncell + 1: the array being built
+    int *cell_next;        // the twin array, cleared here for the NEXT build
+    int *rank;             // n: arrival rank of each point inside its cell
     int *block_sums;
     int n;
     int ncell;
@@ -73,6 +79,8 @@ struct GridJob {
     int nx, ny, nz;
     int nb_pts;            // workgroups streaming the points
     int nb_scan;           // workgroups scanning the cells
+    int need_zero;         // the array being built was not cleared by the previous build
+    int sums_scanned;      // block_sums already hold exclusive prefixes (large grids: scan_sums_kernel ran)
 };
 struct GridJobs { GridJob j[2]; };
 
@@ -85,27 +93,33 @@ __device__ __forceinline__ int cell_of(const GridJob &J, const float4 &p)
 }
 
 // cell_start lives 3 ints into its allocation, so A = cell_start + 1 (the array the scan works on) is 16-byte aligned
+__device__ __forceinline__ void zero_chunk(int *cells, int ncell, int b)
+{
+    int4 *A4 = reinterpret_cast<int4 *>(cells + 1);
+    const int base4 = b * (SCAN_CHUNK / 4) + threadIdx.x * 2;           // in int4 units
+    const int n4 = (ncell + 3) / 4;                                      // allocation is padded to a multiple of 4 (+4)
+    const int4 z = make_int4(0, 0, 0, 0);
+    if (base4 < n4) A4[base4] = z;
+    if (base4 + 1 < n4) A4[base4 + 1] = z;
+    if (b == 0 && threadIdx.x == 0) cells[0] = 0;
+}
+
 __global__ __launch_bounds__(256) void zero_cells_kernel(GridJobs G)
 {
     const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
     const GridJob &J = G.j[job];
-    const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
-    int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
-    const int base4 = b * (SCAN_CHUNK / 4) + threadIdx.x * 2;           // in int4 units
-    const int n4 = (J.ncell + 3) / 4;                                    // allocation is padded to a multiple of 4 (+4)
-    const int4 z = make_int4(0, 0, 0, 0);
-    if (base4 < n4) A4[base4] = z;
-    if (base4 + 1 < n4) A4[base4 + 1] = z;
-    if (b == 0 && threadIdx.x == 0) J.cell_start[0] = 0;
+    if (!J.need_zero) return;
+    zero_chunk(J.cell_start, J.ncell, job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x);
 }
 
+// per-cell counts land in cell_start[c + 1]; the value the atomic returns is the point's rank inside its cell
 __global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
 {
     const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
     for (int i = b * 256 + threadIdx.x; i < J.n; i += J.nb_pts * 256)
-        atomicAdd(&J.cell_start[cell_of(J, J.raw[i]) + 1], 1);
+        J.rank[i] = atomicAdd(&J.cell_start[cell_of(J, J.raw[i]) + 1], 1);
 }
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &total)
@@ -127,7 +141,8 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &to
     return base + incl - v;
 }
 
-// in-place exclusive scan of A[i] = cell_start[i + 1], i in [0, ncell): chunk-local part (8 ints = 2 x int4 per thread)
+// in-place INCLUSIVE scan of A[i] = cell_start[i + 1], i in [0, ncell): chunk-local part (8 ints = 2 x int4 per thread).
+// Inclusive, so that cell_start[c + 1] = start of cell c + 1 and (with cell_start[0] = 0) the array is the exclusive prefix.
 __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
 {
     __shared__ int lds[4];
@@ -144,17 +159,19 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     int total;
     int ex = block_exclusive_scan_256(s, lds, total);
     int4 o0, o1;
-    o0.x = ex; ex += v0.x; o0.y = ex; ex += v0.y; o0.z = ex; ex += v0.z; o0.w = ex; ex += v0.w;
-    o1.x = ex; ex += v1.x; o1.y = ex; ex += v1.y; o1.z = ex; ex += v1.z; o1.w = ex;
+    ex += v0.x; o0.x = ex; ex += v0.y; o0.y = ex; ex += v0.z; o0.z = ex; ex += v0.w; o0.w = ex;
+    ex += v1.x; o1.x = ex; ex += v1.y; o1.y = ex; ex += v1.z; o1.z = ex; ex += v1.w; o1.w = ex;
     if (base < n_pad) A4[base / 4] = o0;
     if (base + 4 < n_pad) A4[base / 4 + 1] = o1;
     if (threadIdx.x == 0) J.block_sums[b] = total;
 }
 
+// large grids only: exclusive scan of the chunk totals
 __global__ __launch_bounds__(256) void scan_sums_kernel(GridJobs G)
 {
     __shared__ int lds[4];
     const GridJob &J = G.j[blockIdx.x];
+    if (!J.sums_scanned) return;
     int carry = 0;
     for (int start = 0; start < J.nb_scan; start += 256) {
         int i = start + threadIdx.x;
@@ -166,20 +183,35 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(GridJobs G)
     }
 }
 
+// adds the totals of the preceding chunks (summed here when there are few chunks) and clears the twin array for the next build
 __global__ __launch_bounds__(256) void scan_add_kernel(GridJobs G)
 {
+    __shared__ int lds[4];
     const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
+    zero_chunk(J.cell_next, J.ncell, b);
+    int add;
+    if (J.sums_scanned) {
+        add = J.block_sums[b];
+    } else {
+        int s = 0;
+        for (int i = threadIdx.x; i < b; i += 256) s += J.block_sums[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+        __syncthreads();
+        add = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    }
     if (b == 0) return;                                                  // first chunk: offset 0
     int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
-    const int add = J.block_sums[b];
     const int base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     const int n_pad = ((J.ncell + 3) / 4) * 4;
     if (base < n_pad) { int4 v = A4[base / 4]; v.x += add; v.y += add; v.z += add; v.w += add; A4[base / 4] = v; }
     if (base + 4 < n_pad) { int4 v = A4[base / 4 + 1]; v.x += add; v.y += add; v.z += add; v.w += add; A4[base / 4 + 1] = v; }
 }
 
+// no atomics: position = start of the cell + the rank taken while counting
 __global__ __launch_bounds__(256) void scatter_kernel(GridJobs G)
 {
     const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
@@ -187,8 +219,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(GridJobs G)
     const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
     for (int i = b * 256 + threadIdx.x; i < J.n; i += J.nb_pts * 256) {
         const float4 p = J.raw[i];
-        const int pos = atomicAdd(&J.cell_start[cell_of(J, p) + 1], 1);
-        J.sorted[pos] = p;
+        const int r = J.rank[i];
+        J.sorted[J.cell_start[cell_of(J, p)] + r] = p;
     }
 }
 
@@ -218,18 +250,29 @@ static int compute_bounds(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis)
     const int nb = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);   // covers ncell + 1 entries
     MLH_HIP(ctx, g.sorted.ensure(sizeof(float4) * size_t(n)));
     MLH_HIP(ctx, g.cell_start.ensure(sizeof(int) * size_t(g.ncell + 16)));   // 3 ints of lead-in (alignment of cell_start + 1) + padded tail
+    MLH_HIP(ctx, g.cell_fill.ensure(sizeof(int) * size_t(g.ncell + 16)));    // the twin (cleared by one build for the next)
+    MLH_HIP(ctx, g.cell_id.ensure(sizeof(int) * size_t(n)));                 // per-point rank inside its cell
+    g.cur = 0;
+    g.twin_clean = false;
     MLH_HIP(ctx, g.block_sums.ensure(sizeof(int) * size_t(nb + 1)));
     return MLH_OK;
 }
 
-static GridJob make_job(const MapGrid &g)
+// the build goes into the twin of the array the queries currently read when that twin is clean, else into array 0 after a clear
+static GridJob make_job(MapGrid &g)
 {
     GridJob J;
     std::memset(&J, 0, sizeof(J));
-    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.cell_start = g.cell_start.as<int>() + 3; J.block_sums = g.block_sums.as<int>();
+    const int dst = g.twin_clean ? 1 - g.cur : 0;
+    J.need_zero = g.twin_clean ? 0 : 1;
+    g.cur = dst;
+    g.twin_clean = true;
+    J.cell_start = g.cells(dst); J.cell_next = g.cells(1 - dst); J.rank = g.cell_id.as<int>();
+    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.block_sums = g.block_sums.as<int>();
     J.n = g.n; J.ncell = int(g.ncell); J.ox = g.ox; J.oy = g.oy; J.oz = g.oz; J.inv_h = g.inv_h; J.nx = g.nx; J.ny = g.ny; J.nz = g.nz;
     J.nb_pts = std::min((g.n + 255) / 256, 4096);
     J.nb_scan = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
+    J.sums_scanned = J.nb_scan > FUSED_SUMS_MAX ? 1 : 0;
     return J;
 }
 
@@ -253,10 +296,10 @@ int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds)
     if (nj == 0) return MLH_OK;
     const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);
-    hipLaunchKernelGGL(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    if (G.j[0].need_zero || G.j[1].need_zero) hipLaunchKernelGGL(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb_scan), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
+    if (G.j[0].sums_scanned || G.j[1].sums_scanned) hipLaunchKernelGGL(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nb_scan), dim3(256), 0, st, G);
     hipLaunchKernelGGL(scatter_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     prof_end(ctx, MLH_K_GRID_BUILD);

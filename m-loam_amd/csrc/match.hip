@@ -35,11 +35,22 @@ __device__ unsigned long long g_stage_clk[4096 * 8];
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
         if (threadIdx.x == 0 && (tile) < 4096) g_stage_clk[(tile) * 8 + (i)] = wall_clock64(); \
     } while (0)
+__device__ unsigned long long g_stage_clk_knn[4096 * 8];
+#define MLH_KSTAGE(i)                                                                        \
+    do {                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stage_clk_knn[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
 #else
 #define MLH_STAGE(tile, i) do { } while (0)
+#define MLH_KSTAGE(i) do { } while (0)
 #endif
 constexpr int KNN_G = 8;              // lanes per query in the correspondence kernel
 constexpr int KNN_FPB = TPB / KNN_G;  // queries per workgroup
+#ifndef MLH_KNN_U
+#define MLH_KNN_U 4
+#endif
+constexpr int KNN_U = MLH_KNN_U;      // candidate loads in flight per lane
 constexpr unsigned long long KEY_INF = 0x7f800000ffffffffull;   // (+inf, max index)
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
@@ -104,6 +115,7 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
             e8 = g.cell_start[row + x1 + 1];
         }
     }
+    MLH_KSTAGE(2);
     const int len = e - b;
     int incl = len;
 #pragma unroll
@@ -120,12 +132,12 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int cr = 0, hi = lds_run[1], base = lds_run[10], lo = 0;
-        // 4 candidates per lane per trip: the 4 addresses depend only on the run table, so the 4 loads are in flight together
-        for (int j = gl; j < total; j += 32) {
-            float4 p[4];
-            bool v[4];
+        // KNN_U candidates per lane per trip: the addresses depend only on the run table, so the KNN_U loads are in flight together
+        for (int j = gl; j < total; j += 8 * KNN_U) {
+            float4 p[KNN_U];
+            bool v[KNN_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < KNN_U; ++u) {
                 const int jj = j + 8 * u;
                 v[u] = jj < total;
                 if (v[u]) {
@@ -134,7 +146,7 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < KNN_U; ++u) {
                 if (v[u]) {
                     float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
                     float d = dx * dx; d += dy * dy; d += dz * dz;
@@ -143,6 +155,7 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
             }
         }
     }
+    MLH_KSTAGE(3);
     // tournament merge: K rounds of group-min over the lanes' current heads
 #pragma unroll
     for (int t = 0; t < K; ++t) {
@@ -383,6 +396,7 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
 {
     unsigned long long keys[K];
     knn_group8<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    MLH_KSTAGE(4);
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         if ((t % KNN_G) == gl) {
@@ -395,6 +409,7 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
             Kd.nbr[size_t(f) * Kd.nbr_stride + t] = o;
         }
     }
+    MLH_KSTAGE(5);
 }
 
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
@@ -408,6 +423,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const KindP &K = P.k[kind];
     const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
     const int f = tile * KNN_FPB + grp;
+    MLH_KSTAGE(0);
     if (f >= K.m) return;
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
@@ -417,6 +433,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const d3 t{pose[0], pose[1], pose[2]};
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
+    MLH_KSTAGE(1);
     if (!owns(P, sx, sy, sz)) return;     // uniform over the 8-lane group
     if (P.kb[b] == 10) knn_feature<10>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
     else knn_feature<5>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
@@ -593,6 +610,10 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 extern "C" int mlh_debug_stage_clock(unsigned long long *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk), sizeof(unsigned long long) * size_t(n_words));
+}
+extern "C" int mlh_debug_stage_clock_knn(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_knn), sizeof(unsigned long long) * size_t(n_words));
 }
 namespace mlh {
 #endif

@@ -40,3 +40,22 @@ for i, nm in enumerate(["fit", "eval", "reduce", "finish"]):
     print(f"stage {nm:7s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
 last = np.argmax(rel[:, 4])
 print("last tile", last, "stages", rel[last])
+
+# ---- correspondence kernel
+n_wg = min(4096, (len(surf) + 31) // 32 + (len(corner) + 31) // 32)
+buf = (C.c_ulonglong * (n_wg * 8))()
+lib.mlh_debug_stage_clock_knn.argtypes = [C.c_void_p, C.c_int]
+assert lib.mlh_debug_stage_clock_knn(buf, n_wg * 8) == 0
+t = np.frombuffer(buf, np.uint64).reshape(n_wg, 8).astype(np.int64)[:, :6]
+ok = (t > 0).all(axis=1)        # workgroups whose thread 0 went through every stage (its feature had >= K candidates ...)
+print("knn workgroups", n_wg, "with all stages", int(ok.sum()))
+t0 = t[:, 0][t[:, 0] > 0].min()
+rel = (t - t0) * 0.01
+names = ["start", "transform", "run table", "candidates", "tournament", "gather+store"]
+for i, nm in enumerate(names):
+    col = rel[ok, i]
+    print(f"{nm:12s} min {col.min():7.2f} med {np.median(col):7.2f} max {col.max():7.2f} us")
+d = np.diff(rel[ok], axis=1)
+for i, nm in enumerate(names[1:]):
+    print(f"stage {nm:12s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
+print("start spread over all workgroups: max", rel[:, 0][t[:, 0] > 0].max())
