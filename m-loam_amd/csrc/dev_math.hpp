@@ -179,28 +179,28 @@ __device__ inline bool eig3_largest_f(float a00, float a10, float a11, float a20
         if (end == 0) break;
         iter++;
         if (iter > 90) { ok = false; break; }
-        float c, s;
-        if (end == 2 && s0 != 0.f) {
-            // unreduced 3x3 block: k = 0 then k = 1
-            float mu = wilkinson_mu_f(d1, d2, s1);
-            float x = d0 - mu, z = s0;
-            tri_rot_f(d0, d1, s0, x, z, c, s);
-            x = s0;
-            z = -s * s1;
-            s1 = c * s1;
-            rot_cols_f(q00, q10, q20, q01, q11, q21, c, s);
-            float zz = z;
-            tri_rot_f(d1, d2, s1, x, zz, c, s);
-            s0 = c * s0 - s * zz;
-            rot_cols_f(q01, q11, q21, q02, q12, q22, c, s);
-        } else if (end == 2) {
-            float mu = wilkinson_mu_f(d1, d2, s1);
-            tri_rot_f(d1, d2, s1, d1 - mu, s1, c, s);
-            rot_cols_f(q01, q11, q21, q02, q12, q22, c, s);
-        } else {
-            float mu = wilkinson_mu_f(d0, d1, s0);
+        // One implicit-shift QL/QR sweep on the unreduced block. Three cases: (A) the whole 3x3 (rotations on (0,1) then
+        // (1,2)), (B) the trailing 2x2, (C) the leading 2x2. Written as two predicated rotations instead of three branches,
+        // so lanes of a wavefront in different cases share the instruction stream; per lane the arithmetic (operands and
+        // order) is exactly that of its case.
+        const bool caseC = (end == 1);
+        const bool first01 = caseC || (s0 != 0.f);           // A or C: rotate (0,1) first
+        const bool caseA = (end == 2) && (s0 != 0.f);
+        const float mu = wilkinson_mu_f(caseC ? d0 : d1, caseC ? d1 : d2, caseC ? s0 : s1);
+        float c, s, x = d1 - mu, z = s1;                      // case B's rotation input
+        if (first01) {
             tri_rot_f(d0, d1, s0, d0 - mu, s0, c, s);
             rot_cols_f(q00, q10, q20, q01, q11, q21, c, s);
+            if (caseA) {                                      // the bulge to chase into (1,2)
+                x = s0;
+                z = -s * s1;
+                s1 = c * s1;
+            }
+        }
+        if (!caseC) {
+            tri_rot_f(d1, d2, s1, x, z, c, s);
+            if (caseA) s0 = c * s0 - s * z;
+            rot_cols_f(q01, q11, q21, q02, q12, q22, c, s);
         }
     }
     // selection sort ascending (swap eigenvalues and columns), as Eigen does when info == Success

@@ -505,6 +505,7 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     }
     __syncthreads();
     if (!s_last) return;
+    MLH_STAGE(4095, 0);
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     if (P.finish == 2) {
@@ -525,10 +526,12 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.lo[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? P.k[1].blk_start[b] / TPB : 0);
         sa.hi[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? (P.k[1].blk_start[b + 1] + TPB - 1) / TPB : 0);
         sum_partials(sa, f_ne, f_cnt2, f_scratch);
+        MLH_STAGE(4095, 1);
         if (threadIdx.x < 2)
             gn_finish2(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], b == 0 ? P.state : nullptr, P.thre_b[b], P.freeze_b[b],
                        P.stat ? P.stat + b : nullptr, f_scratch);
         __syncthreads();
+        MLH_STAGE(4095, 2);
     }
     if (threadIdx.x == 0) *P.ticket = 0u;
 }

@@ -19,19 +19,22 @@ __device__ inline void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRID
     const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
     if (a.p) {
-        // fixed association: four interleaved chains per range (the loads of a trip are independent -> in flight together)
+        // the two tile ranges (surf, corner) are walked as one list; 8 loads per trip are independent (in flight together) and
+        // feed four chains in a fixed association -> deterministic, and ~ntiles/64 round trips instead of one per tile
+        const int n0 = max(a.hi[0] - a.lo[0], 0), ntot = n0 + max(a.hi[1] - a.lo[1], 0);
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        for (int j = s; j < ntot; j += 64) {
+            double t[8];
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            int b = a.lo[rg] + s;
-            for (; b + 24 < a.hi[rg]; b += 32) {
-                const double t0 = a.p[size_t(b) * NE_STRIDE + c], t1 = a.p[size_t(b + 8) * NE_STRIDE + c];
-                const double t2 = a.p[size_t(b + 16) * NE_STRIDE + c], t3 = a.p[size_t(b + 24) * NE_STRIDE + c];
-                v0 += t0; v1 += t1; v2 += t2; v3 += t3;
+            for (int u = 0; u < 8; ++u) {
+                const int jj = j + 8 * u;
+                const int tile = jj < n0 ? a.lo[0] + jj : a.lo[1] + (jj - n0);
+                t[u] = jj < ntot ? a.p[size_t(tile) * NE_STRIDE + c] : 0.0;
             }
-            for (; b < a.hi[rg]; b += 8) v0 += a.p[size_t(b) * NE_STRIDE + c];
-            v += (v0 + v1) + (v2 + v3);
+            v0 += t[0]; v1 += t[1]; v2 += t[2]; v3 += t[3];
+            v0 += t[4]; v1 += t[5]; v2 += t[6]; v3 += t[7];
         }
+        v = (v0 + v1) + (v2 + v3);
     }
     scratch[s * 32 + c] = v;
     __syncthreads();
@@ -142,7 +145,9 @@ __device__ __noinline__ bool eval_degeneracy_mem(const double *ne, double thre, 
 }
 
 // Cholesky factor / solve of a 6x6 SPD system, fully unrolled so that A, L, y live in registers (no scratch).
-__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36])
+// The dependent chain is what costs time here (one lane, ~1 wavefront on the chip), so each column takes ONE long operation
+// -- r = rsqrt(s) -- and the column and the later substitutions multiply by it instead of dividing.
+__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36], double (&inv_d)[6])
 {
     bool ok = true;
 #pragma unroll
@@ -151,38 +156,45 @@ __device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
         ok = ok && (s > 0.0);
-        const double ljj = sqrt(s);
-        L[j * 6 + j] = ljj;
+        const double r = rsqrt(s);
+        inv_d[j] = r;
+        L[j * 6 + j] = s * r;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = A[i * 6 + j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = t / ljj;
+            L[i * 6 + j] = t * r;
         }
     }
     return ok;
 }
 
-__device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
+// L L^T x = b
+__device__ __forceinline__ void chol6_substitute(const double (&L)[36], const double (&inv_d)[6], const double (&b)[6], double (&x)[6])
 {
-    double L[36];
-    if (!chol6_factor(A, L)) return false;
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        y[i] = s * inv_d[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * inv_d[i];
     }
+}
+
+__device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
+{
+    double L[36], inv_d[6];
+    if (!chol6_factor(A, L, inv_d)) return false;
+    chol6_substitute(L, inv_d, b, x);
     return true;
 }
 
@@ -209,12 +221,15 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
                                   IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
 {
     const int lane = threadIdx.x & 63;
-    double H[36], A[36], L[36];
+    double xc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xc[i] = x[i];          // issued before the factorisation: the pose arrives while it runs
+    double H[36], A[36], L[36], inv_d[6];
     unpack_H(ne, H);
     const double sh = (lane == 1) ? eig_thre * (1.0 + 1e-9) : 0.0;
 #pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = H[i] - (((i % 7) == 0) ? sh : 0.0);
-    const bool pd = chol6_factor(A, L);
+    const bool pd = chol6_factor(A, L, inv_d);
     const bool not_degenerate_fast = __shfl(pd ? 1 : 0, 1) != 0;
     if (lane != 0) return;
     bool deg = false;
@@ -224,21 +239,10 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
     double d[6];
     bool ok = pd;
     if (ok) {
-        double y[6];
+        double rhs[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double s = -ne[NE_G + i];
-#pragma unroll
-            for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-            y[i] = s / L[i * 6 + i];
-        }
-#pragma unroll
-        for (int i = 5; i >= 0; --i) {
-            double s = y[i];
-#pragma unroll
-            for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * d[k];
-            d[i] = s / L[i * 6 + i];
-        }
+        for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
+        chol6_substitute(L, inv_d, rhs, d);
     } else {
         double Hd[36], rhs[6];
 #pragma unroll
@@ -248,9 +252,7 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
         ok = chol6_solve(Hd, rhs, d);
     }
     if (ok && !frozen) {
-        double xc[7], xn[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) xc[i] = x[i];
+        double xn[7];
         pose_plus(xc, d, slow ? work + 78 : nullptr, xn);   // V_update = I on the fast path
 #pragma unroll
         for (int i = 0; i < 7; ++i) x[i] = xn[i];

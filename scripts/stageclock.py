@@ -38,6 +38,10 @@ for i, nm in enumerate(names):
 d = np.diff(rel, axis=1)
 for i, nm in enumerate(["fit", "eval", "reduce", "finish"]):
     print(f"stage {nm:7s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
+buf2 = (C.c_ulonglong * (4096 * 8))()
+assert lib.mlh_debug_stage_clock(buf2, 4096 * 8) == 0
+fin = (np.frombuffer(buf2, np.uint64).reshape(4096, 8).astype(np.int64)[4095, :3] - t0) * 0.01
+print("finish (last workgroup): ticket won %.2f, partials summed %.2f, solved %.2f us" % tuple(fin))
 last = np.argmax(rel[:, 4])
 print("last tile", last, "stages", rel[last])
 
