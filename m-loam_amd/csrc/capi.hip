@@ -1,6 +1,7 @@
 // extern "C" surface of libmloam_hip.so (see include/mloam_hip.h for the contract and the reference interfaces each
 // entry point replaces). Host logic only: staging, launch sequencing, result unpacking.
 #include "ctx.hpp"
+#include <cstdlib>
 #include "dev_math.hpp"
 #include <algorithm>
 #include <cmath>
@@ -166,6 +167,7 @@ int mlh_create(mlh_ctx **out, int device_id)
     mlh_ctx *c = new (std::nothrow) mlh_ctx;
     if (!c) return MLH_ERR_NOMEM;
     c->device = device_id;
+    if (const char *e = std::getenv("MLH_KNN_LANES")) c->knn_lanes_override = std::atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
     *out = c;
     return MLH_OK;

@@ -176,6 +176,7 @@ struct mlh_ctx {
     void *h_state = nullptr; // pinned staging for the solver-state upload
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;
+    int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};

@@ -21,6 +21,7 @@
 #include "solver_dev.hpp"
 #include <hip/hip_ext.h>
 #include <cfloat>
+#include <cstdlib>
 
 namespace mlh {
 
@@ -45,8 +46,10 @@ __device__ unsigned long long g_stage_clk_knn[4096 * 8];
 #define MLH_STAGE(tile, i) do { } while (0)
 #define MLH_KSTAGE(i) do { } while (0)
 #endif
-constexpr int KNN_G = 8;              // lanes per query in the correspondence kernel
-constexpr int KNN_FPB = TPB / KNN_G;  // queries per workgroup
+// lanes per query in the correspondence kernel: 8 when the launch fills the chip on its own (throughput: one wavefront serves 8
+// queries), 16 when it does not (latency: a frame's ~20k thinned features leave most SIMDs idle with 8, and twice the lanes halve
+// the candidate trips of the queries in dense cells, which set the kernel's duration)
+constexpr int KNN_WIDE_LIMIT = 40000;  // total queries up to which a launch uses 16 lanes per query
 #ifndef MLH_KNN_U
 #define MLH_KNN_U 4
 #endif
@@ -60,6 +63,29 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     hi = __shfl_xor(hi, mask);
     return ((unsigned long long)hi << 32) | lo;
 }
+
+// DPP lane permutations (VALU latency, no LDS crossbar trip): the 3 (4) exchange partners that all-reduce a group of 8 (16) lanes
+constexpr int DPP_QUAD_SWAP1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each 8-lane half row
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i inside each 16-lane row
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long m)
+{
+    const unsigned long long o = dpp_u64<CTRL>(m);
+    return o < m ? o : m;
+}
+// row_shr:OFF with out-of-row lanes reading 0 (bound_ctrl)
+template <int OFF>
+__device__ __forceinline__ int dpp_row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true); }
 
 template <int K>
 __device__ __forceinline__ void key_insert(unsigned long long (&k)[K], unsigned long long key)
@@ -90,9 +116,10 @@ __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int
 // is balanced whatever the per-run occupancy, consecutive lanes read consecutive float4 points, and a query with fewer than
 // K candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
 // lds_run: 20 ints per group: [0..9] prefix offsets of the runs (10 entries), [10..18] base index of each run.
-template <int K>
-__device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[K])
+template <int K, int G>
+__device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[K])
 {
+    static_assert(G == 8 || G == 16, "group width");
     unsigned long long k[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) k[i] = KEY_INF;
@@ -103,13 +130,13 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
     int b = 0, e = 0, b8 = 0, e8 = 0;
     {
         const int y = cy + (gl % 3) - 1, z = cz + (gl / 3) - 1;
-        if ((x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+        if ((gl < 9) && (x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
             const int row = (z * g.ny + y) * g.nx;
             b = g.cell_start[row + x0];
             e = g.cell_start[row + x1 + 1];
         }
-        const int y8 = cy + 1, z8 = cz + 1;       // run 8 = (dy, dz) = (+1, +1)
-        if (gl == 0 && (x0 <= x1) && (y8 < g.ny) && (z8 < g.nz) && (y8 >= 0) && (z8 >= 0)) {
+        const int y8 = cy + 1, z8 = cz + 1;       // run 8 = (dy, dz) = (+1, +1): lane 0's second run when there are only 8 lanes
+        if (G == 8 && gl == 0 && (x0 <= x1) && (y8 < g.ny) && (z8 < g.nz) && (y8 >= 0) && (z8 >= 0)) {
             const int row = (z8 * g.ny + y8) * g.nx;
             b8 = g.cell_start[row + x0];
             e8 = g.cell_start[row + x1 + 1];
@@ -118,27 +145,31 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
     MLH_KSTAGE(2);
     const int len = e - b;
     int incl = len;
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        const int t = __shfl_up(incl, off, 8);
-        if (gl >= off) incl += t;
-    }
-    const int len8 = __shfl(e8 - b8, 0, 8);
-    const int total = __shfl(incl, 7, 8) + len8;
+    { const int t = dpp_row_shr<1>(incl); if (gl >= 1) incl += t; }
+    { const int t = dpp_row_shr<2>(incl); if (gl >= 2) incl += t; }
+    { const int t = dpp_row_shr<4>(incl); if (gl >= 4) incl += t; }
+    if (G == 16) { const int t = dpp_row_shr<8>(incl); if (gl >= 8) incl += t; }
+    const int len8 = (G == 8) ? __shfl(e8 - b8, 0, G) : 0;
+    const int total = __shfl(incl, G - 1, G) + len8;
     if (total >= K) {                                  // uniform over the group
-        lds_run[gl] = incl - len;                      // prefix[r]
-        lds_run[10 + gl] = b;                          // base[r]
-        if (gl == 0) { lds_run[8] = total - len8; lds_run[9] = total; lds_run[18] = b8; }
+        if (G == 8) {
+            lds_run[gl] = incl - len;                  // prefix[r]
+            lds_run[10 + gl] = b;                      // base[r]
+            if (gl == 0) { lds_run[8] = total - len8; lds_run[9] = total; lds_run[18] = b8; }
+        } else {
+            if (gl < 10) lds_run[gl] = incl - len;     // lane 9 holds no run: incl - len = total
+            if (gl < 9) lds_run[10 + gl] = b;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int cr = 0, hi = lds_run[1], base = lds_run[10], lo = 0;
         // KNN_U candidates per lane per trip: the addresses depend only on the run table, so the KNN_U loads are in flight together
-        for (int j = gl; j < total; j += 8 * KNN_U) {
+        for (int j = gl; j < total; j += G * KNN_U) {
             float4 p[KNN_U];
             bool v[KNN_U];
 #pragma unroll
             for (int u = 0; u < KNN_U; ++u) {
-                const int jj = j + 8 * u;
+                const int jj = j + G * u;
                 v[u] = jj < total;
                 if (v[u]) {
                     while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[10 + cr]; }
@@ -160,11 +191,10 @@ __device__ __forceinline__ void knn_group8(const GridDev &g, float qx, float qy,
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         unsigned long long m = k[0];
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            unsigned long long o = shfl_xor_u64(m, off);
-            m = o < m ? o : m;
-        }
+        m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
+        m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
+        m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
+        if (G == 16) m = dpp_min_u64<DPP_ROW_MIRROR>(m);
         out[t] = m;
         if (k[0] == m && m != KEY_INF) {
 #pragma unroll
@@ -357,6 +387,7 @@ struct KParams {
     double thre_b[MAX_BLOCKS];   // eigen threshold per block
     int freeze_b[MAX_BLOCKS];    // 0: project the degenerate directions out (evalDegenracy); 1: do not update the block at all
     // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose(s)
+    int knn_lanes;           // lanes per query of the correspondence kernel (8 or 16), chosen per launch
     int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU)
     unsigned *ticket;
     IterStatDev *stat;       // n_blocks consecutive records, or null
@@ -391,15 +422,15 @@ __device__ __forceinline__ bool owns(const KParams &P, float sx, float sy, float
 
 // ---- correspondence kernel: 8 lanes per feature, 32 features per workgroup, both feature kinds in one launch
 
-template <int K>
+template <int K, int G>
 __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run)
 {
     unsigned long long keys[K];
-    knn_group8<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    knn_group<K, G>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     MLH_KSTAGE(4);
 #pragma unroll
     for (int t = 0; t < K; ++t) {
-        if ((t % KNN_G) == gl) {
+        if ((t % G) == gl) {
             const unsigned long long kk = keys[t];
             float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
             if (kk != KEY_INF) {
@@ -412,17 +443,19 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
     MLH_KSTAGE(5);
 }
 
+template <int G>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
-    __shared__ int s_run[KNN_FPB * 20];
+    constexpr int FPB = TPB / G;          // queries per workgroup
+    __shared__ int s_run[FPB * 20];
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = xcd_tile(total);
     if (tile >= total) return;
     const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
     if (kind) tile -= P.k[0].tiles_a;
     const KindP &K = P.k[kind];
-    const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
-    const int f = tile * KNN_FPB + grp;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int f = tile * FPB + grp;
     MLH_KSTAGE(0);
     if (f >= K.m) return;
     const float4 fp = K.feat[f];
@@ -434,9 +467,9 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
-    if (!owns(P, sx, sy, sz)) return;     // uniform over the 8-lane group
-    if (P.kb[b] == 10) knn_feature<10>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
-    else knn_feature<5>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
+    if (!owns(P, sx, sy, sz)) return;     // uniform over the lane group
+    if (P.kb[b] == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
+    else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
 }
 
 // the reference's plane fit + gate (feature_extract.hpp:816-840)
@@ -668,12 +701,13 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
                                                           float *__restrict__ d2)
 {
-    __shared__ int s_run[KNN_FPB * 20];
-    const int grp = threadIdx.x / KNN_G, gl = threadIdx.x % KNN_G;
-    const int qi = blockIdx.x * KNN_FPB + grp;
+    constexpr int G = 8, FPB = TPB / G;
+    __shared__ int s_run[FPB * 20];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int qi = blockIdx.x * FPB + grp;
     if (qi >= nq) return;
     unsigned long long keys[5];
-    knn_group8<5>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
+    knn_group<5, G>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
     if (gl == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
@@ -696,6 +730,12 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         P.thre_b[b] = a.eig_thre[b];
         P.freeze_b[b] = a.freeze[b];
         kmax = std::max(kmax, P.kb[b]);
+    }
+    {
+        long long queries = 0;
+        for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) queries += ctx->feat[k].m;
+        P.knn_lanes = queries <= KNN_WIDE_LIMIT ? 16 : 8;
+        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) P.knn_lanes = ctx->knn_lanes_override;
     }
     for (int k = 0; k < 2; ++k) {
         KindP &K = P.k[k];
@@ -724,7 +764,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         K.r_out = a.dense ? fs.r.as<double>() : nullptr;
         K.J_out = a.dense ? fs.J.as<double>() : nullptr;
         K.m = fs.m;
-        K.tiles_a = (fs.m + KNN_FPB - 1) / KNN_FPB;
+        K.tiles_a = (fs.m + TPB / P.knn_lanes - 1) / (TPB / P.knn_lanes);
         K.tiles_b = (fs.m + TPB - 1) / TPB;
         K.nbr_stride = fs.nbr_stride;
         for (int b = 0; b <= MAX_BLOCKS; ++b) K.blk_start[b] = fs.blk_start[std::min(b, fs.n_blocks)];
@@ -773,7 +813,8 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     // kernel A: correspondences (32 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
     const int grid_a = ((P.k[0].tiles_a + P.k[1].tiles_a + 7) / 8) * 8;
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
-    launch_timed(ctx, MLH_K_KNN, knn_features_kernel, grid_a, P);
+    if (P.knn_lanes == 16) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16>, grid_a, P);
+    else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8>, grid_a, P);
     launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
@@ -802,7 +843,7 @@ int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx
     MLH_HIP(ctx, ctx->knn_idx.ensure(sizeof(int) * 5 * size_t(nq)));
     MLH_HIP(ctx, ctx->knn_d.ensure(sizeof(float) * 5 * size_t(nq)));
     MLH_HIP(ctx, hipMemcpyAsync(ctx->knn_q.p, q_host, sizeof(float) * 3 * size_t(nq), hipMemcpyHostToDevice, ctx->stream));
-    const int grid = (nq + KNN_FPB - 1) / KNN_FPB;
+    const int grid = (nq + TPB / 8 - 1) / (TPB / 8);
     hipLaunchKernelGGL(knn_queries_kernel, dim3(grid), dim3(TPB), 0, ctx->stream, mg.dev(), ctx->knn_q.as<float>(), nq,
                        ctx->knn_idx.as<int>(), ctx->knn_d.as<float>());
     MLH_HIP(ctx, hipGetLastError());

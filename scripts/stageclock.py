@@ -63,3 +63,11 @@ d = np.diff(rel[ok], axis=1)
 for i, nm in enumerate(names[1:]):
     print(f"stage {nm:12s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
 print("start spread over all workgroups: max", rel[:, 0][t[:, 0] > 0].max())
+order = np.argsort(-rel[:, 5])[:6]
+print("slowest knn workgroups (stage end times, us):")
+for w in order:
+    print(" wg", int(w), np.round(rel[w], 2))
+fast = np.argsort(rel[:, 5])[:3]
+for w in fast:
+    print(" fast wg", int(w), np.round(rel[w], 2))
+print("finish-time percentiles 50/90/99/100:", np.round(np.percentile(rel[ok, 5], [50, 90, 99, 100]), 2))

@@ -392,3 +392,21 @@ def test_voxel_filter_plain_parity(ctx, orc, case16):
         assert np.isin(got[:, 3], pts[:, 3]).all()
     one = ctx.voxel_filter(pts[:1], 0.4)
     np.testing.assert_array_equal(one, pts[:1])
+
+
+@pytest.mark.parametrize("lanes", [8, 16])
+def test_correspondence_lane_widths(mla, orc, case16, feats16, lanes, monkeypatch):
+    """The correspondence kernel runs with 8 lanes per query on chip-filling launches and 16 on small ones; both widths must
+    give the oracle's matches bit for bit (MLH_KNN_LANES pins the width of a context)."""
+    monkeypatch.setenv("MLH_KNN_LANES", str(lanes))
+    c = mla.Context(0)
+    try:
+        for kind, ch, cloud, feats in ((mla.SURF, "s", case16["surf_map"], feats16[0]), (mla.CORNER, "c", case16["corner_map"], feats16[1])):
+            c.map_set(kind, cloud)
+            c.features_set(kind, feats)
+            got = c.match_linearize(kind, case16["p0"])
+            valid, coeffs = orc.Map(cloud).match(ch, feats, case16["p0"])
+            assert np.array_equal(got["valid"], valid)
+            assert np.array_equal(got["coeffs"].astype(np.float32).view(np.uint32), coeffs.astype(np.float32).view(np.uint32))
+    finally:
+        c.close()
