@@ -116,9 +116,28 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
  * trace_threshold are dropped, w = trace_threshold - trace, mu = sum w p / sum w, cov = sum w^2 cov_i / (sum w)^2, intensity of the
  * heaviest member, trace recomputed; otherwise the plain branch (PointXYZI, :392-420): xyz mean, intensity of the last member.
  * Output (HOST, capacity n records) uses the input's record layout and is ordered by voxel index like the reference's.
- * Members of a voxel are accumulated in input order (the reference: in the order its unstable sort left them). */
+ * Members of a voxel are accumulated in input order (the reference: in the order its unstable sort left them).
+ * `mem` describes BOTH buffers: MLH_MEM_DEVICE takes device records and leaves the result in device memory (`out`), so a map
+ * assembled with mlh_cloud_uct_associate_to_map can be thinned and handed to mlh_map_set without leaving HBM. */
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem);
+
+/* (f1) cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158): moves one keyframe's feature cloud into the map frame while
+ * building the local map (extractSurroundingKeyFrames, cpp:254-354). Per point (intensity = LiDAR index n):
+ *   with_ua: point_sel = pose_ext[n]^-1 * p; Sigma = evalPointUncertainty(point_sel, pose_global (+) pose_ext[n]) where the
+ *            compound pose and its 6x6 covariance come from compoundPoseWithCov method 2 (associate_uct.hpp:90-147);
+ *            points with trace(Sigma) > trace_threshold are dropped;
+ *   always:  the record is copied, xyz <- pose_global * p (f64 math, f32 store), cov_vec <- Sigma (zeros without with_ua),
+ *            cov_trace <- trace.
+ * Output keeps the input order and record layout; `mem` describes both buffers (see mlh_voxel_filter).
+ * Covariance layout: 6x6 row-major over [translation, rotation], as Pose::cov_. */
+int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
+                                   int trace_offset_bytes, const double pose_global[7], const double cov_global[36], const double *ext_poses,
+                                   const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,
+                                   void *out, int32_t *n_out, int mem);
+/* compoundPoseWithCov(pose_1, pose_2, pose_cp, method = 2) (associate_uct.hpp:90-147), host arithmetic, f64 */
+int mlh_compound_pose_with_cov(const double pose_1[7], const double cov_1[36], const double pose_2[7], const double cov_2[36],
+                               double pose_cp[7], double cov_cp[36]);
 
 /* ---------------------------------------------------------------- (a5) local map index
  * replaces pcl::KdTreeFLANN<PointT>::setInputCloud(cloud) as used at

@@ -84,6 +84,9 @@ def load_library():
     lib.mlh_extract_voxel_run.argtypes = [vp, cf]
     lib.mlh_extract_fetch_voxel.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     lib.mlh_point_uncertainty.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, cd, vp, vp]
+    dp = C.POINTER(C.c_double)
+    lib.mlh_cloud_uct_associate_to_map.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, cd, vp, C.POINTER(C.c_int32), ci]
+    lib.mlh_compound_pose_with_cov.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_rebuild.argtypes = [vp, ci]
@@ -112,7 +115,7 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty", "mlh_voxel_filter",
+    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -248,6 +251,43 @@ class Context:
         self._ck(self.lib.mlh_point_uncertainty(self.h, ptr, stride, n, 12, mem, _p(ep), _p(ec), ep.shape[0], _p(cm), trace_threshold, _p(cov), _p(kp)))
         return cov, kp.astype(bool)
 
+    def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
+        """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""
+        a = np.ascontiguousarray(points11, np.float32)
+        assert a.shape[1] == 11
+        pg, cg = np.ascontiguousarray(pose_global, np.float64), np.ascontiguousarray(cov_global, np.float64)
+        e, ec = np.ascontiguousarray(ext, np.float64), np.ascontiguousarray(ext_cov, np.float64)
+        cm = np.ascontiguousarray(cov_meas, np.float64)
+        out = np.zeros_like(a)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_cloud_uct_associate_to_map(self.h, _p(a), 44, a.shape[0], 12, 16, 40, _p(pg), _p(cg), _p(e), _p(ec), e.shape[0],
+                                                         _p(cm), int(bool(with_ua)), float(trace_threshold), _p(out), C.byref(cnt), MEM_HOST))
+        return out[:cnt.value].copy()
+
+    def cloud_uct_associate_to_map_device(self, d_points11, d_out, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
+        """Device-resident variant: d_points11 / d_out are torch CUDA float32 tensors (n, 11); returns the number of records written."""
+        ptr, stride, n, mem, keep = _src(d_points11)
+        optr, ostride, on, omem, okeep = _src(d_out)
+        assert mem == MEM_DEVICE and omem == MEM_DEVICE and stride == 44 and ostride == 44 and on >= n
+        pg, cg = np.ascontiguousarray(pose_global, np.float64), np.ascontiguousarray(cov_global, np.float64)
+        e, ec = np.ascontiguousarray(ext, np.float64), np.ascontiguousarray(ext_cov, np.float64)
+        cm = np.ascontiguousarray(cov_meas, np.float64)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_cloud_uct_associate_to_map(self.h, ptr, 44, n, 12, 16, 40, _p(pg), _p(cg), _p(e), _p(ec), e.shape[0], _p(cm),
+                                                         int(bool(with_ua)), float(trace_threshold), optr, C.byref(cnt), MEM_DEVICE))
+        return cnt.value
+
+    def voxel_filter_device(self, d_points, d_out, leaf, trace_threshold=0.0):
+        """Device-resident VoxelGridCovarianceMLOAM: torch CUDA float32 (n, 4) or (n, 11) in, same layout out; returns the count."""
+        ptr, stride, n, mem, keep = _src(d_points)
+        optr, ostride, on, omem, okeep = _src(d_out)
+        assert mem == MEM_DEVICE and omem == MEM_DEVICE and stride == ostride and on >= n
+        ncol = stride // 4
+        cov_off, tr_off = (16, 40) if ncol >= 11 else (-1, -1)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_voxel_filter(self.h, ptr, stride, n, 12 if ncol >= 4 else -1, cov_off, tr_off, leaf, trace_threshold, optr, C.byref(cnt), MEM_DEVICE))
+        return cnt.value
+
     def voxel_filter(self, points, leaf, trace_threshold=0.0):
         """VoxelGridCovarianceMLOAM: points (n, 4) [x y z intensity] -> plain branch; (n, 11) [x y z i cov6 trace] -> covariance branch."""
         a = np.ascontiguousarray(points, np.float32)
@@ -369,6 +409,15 @@ class Context:
         stats = (IterStat * opts.max_outer)()
         self._ck(self.lib.mlh_scan2map(self.h, _p(pose), C.byref(opts), C.cast(stats, C.c_void_p)))
         return pose, [s.as_dict() for s in stats]
+
+
+def compound_pose_with_cov(pose1, cov1, pose2, cov2):
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose1, cov1, pose2, cov2)]
+    pose_cp, cov_cp = np.zeros(7), np.zeros((6, 6))
+    rc = load_library().mlh_compound_pose_with_cov(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(pose_cp), _p(cov_cp))
+    if rc:
+        raise MlhError(f"mlh_compound_pose_with_cov -> {rc}")
+    return pose_cp, cov_cp
 
 
 def comm_unique_id() -> bytes:

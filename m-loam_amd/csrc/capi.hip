@@ -341,6 +341,25 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
                                  trace_threshold, cov_vec_out, keep_out);
 }
 
+int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
+                                   int trace_offset_bytes, const double pose_global[7], const double cov_global[36], const double *ext_poses,
+                                   const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,
+                                   void *out, int32_t *n_out, int mem)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return cloud_uct_associate_run(ctx, points, stride_bytes, n, intensity_offset_bytes, cov_offset_bytes, trace_offset_bytes, pose_global,
+                                   cov_global, ext_poses, ext_covs, n_lidar, cov_measurement, with_ua, trace_threshold, out, n_out, mem);
+}
+
+int mlh_compound_pose_with_cov(const double pose_1[7], const double cov_1[36], const double pose_2[7], const double cov_2[36],
+                               double pose_cp[7], double cov_cp[36])
+{
+    if (!pose_1 || !cov_1 || !pose_2 || !cov_2 || !pose_cp || !cov_cp) return MLH_ERR_INVALID;
+    compound_pose_with_cov(pose_1, cov_1, pose_2, cov_2, pose_cp, cov_cp);
+    return MLH_OK;
+}
+
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem)
 {

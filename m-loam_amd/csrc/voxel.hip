@@ -202,8 +202,15 @@ struct UctArgs {
     int n_lidar;
     double meas[9];
     double trace_thr;           // <= 0: keep everything
-    float *cov6;                // n x 6 (f32 cov_vec)
+    float *cov6;                // n x 6 (f32 cov_vec), or null
     int *keep;                  // n
+    // cloudUCTAssociateToMap mode (rec_out != null): the uncertainty is evaluated with the compound pose of the point's LiDAR,
+    // the record is copied, moved to the map frame with gpose and receives cov_vec / cov_trace
+    const double *upose;        // n_lidar x 7: pose handed to evalPointUncertainty (= ext for downsampleCurrentScan)
+    const double *upose_cov;    // n_lidar x 36
+    unsigned char *rec_out;     // n staged records (input layout), or null
+    double gpose[7];
+    int cov_off, trace_off, with_ua;
 };
 
 __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
@@ -214,64 +221,97 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
     const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(i) * A.stride + A.intensity_off) : 0.f;
     int idx = int(inten);
     idx = idx < 0 ? 0 : (idx >= A.n_lidar ? A.n_lidar - 1 : idx);
-    const double *e = A.ext + idx * 7;
-    const q4 q{e[3], e[4], e[5], e[6]};
-    const d3 t{e[0], e[1], e[2]};
-    // point_sel = pose_ext^-1 * point_ori, through pointAssociateToMap (f64 math, f32 store) -- cpp:382
-    const q4 qi{-q.x, -q.y, -q.z, q.w};
-    const d3 mt = qrot(qi, t);
-    const d3 ps = qrot(qi, d3{double(rec[0]), double(rec[1]), double(rec[2])});
-    const float sel[3] = {float(ps.x - mt.x), float(ps.y - mt.y), float(ps.z - mt.z)};
-    // T * [p; 1]
-    double R[9];
-    qtorot(q, R);
-    const double p[3] = {double(sel[0]), double(sel[1]), double(sel[2])};
-    double tp[3];
+    double cov[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    if (A.with_ua) {
+        const double *e = A.ext + idx * 7;
+        const q4 qe{e[3], e[4], e[5], e[6]};
+        const d3 te{e[0], e[1], e[2]};
+        // point_sel = pose_ext^-1 * point_ori, through pointAssociateToMap (f64 math, f32 store) -- cpp:382 / cpp:1148
+        const q4 qi{-qe.x, -qe.y, -qe.z, qe.w};
+        const d3 mt = qrot(qi, te);
+        const d3 ps = qrot(qi, d3{double(rec[0]), double(rec[1]), double(rec[2])});
+        const float sel[3] = {float(ps.x - mt.x), float(ps.y - mt.y), float(ps.z - mt.z)};
+        const double *u = A.upose + idx * 7;
+        const q4 q{u[3], u[4], u[5], u[6]};
+        const d3 t{u[0], u[1], u[2]};
+        // T * [p; 1]
+        double R[9];
+        qtorot(q, R);
+        const double p[3] = {double(sel[0]), double(sel[1]), double(sel[2])};
+        double tp[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) tp[r] = R[r * 3 + 0] * p[0] + R[r * 3 + 1] * p[1] + R[r * 3 + 2] * p[2] + (r == 0 ? t.x : (r == 1 ? t.y : t.z));
-    // G = [ I | -[tp]x | R ]  (3 x 9)
-    double G[3][9];
+        for (int r = 0; r < 3; ++r) tp[r] = R[r * 3 + 0] * p[0] + R[r * 3 + 1] * p[1] + R[r * 3 + 2] * p[2] + (r == 0 ? t.x : (r == 1 ? t.y : t.z));
+        // G = [ I | -[tp]x | R ]  (3 x 9)
+        double G[3][9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { G[r][c] = (r == c) ? 1.0 : 0.0; G[r][6 + c] = R[r * 3 + c]; }
-    G[0][3] = 0.0;    G[0][4] = tp[2];  G[0][5] = -tp[1];
-    G[1][3] = -tp[2]; G[1][4] = 0.0;    G[1][5] = tp[0];
-    G[2][3] = tp[1];  G[2][4] = -tp[0]; G[2][5] = 0.0;
-    const double *Cp = A.ext_cov + idx * 36;
-    double GC[3][9];
+            for (int c = 0; c < 3; ++c) { G[r][c] = (r == c) ? 1.0 : 0.0; G[r][6 + c] = R[r * 3 + c]; }
+        G[0][3] = 0.0;    G[0][4] = tp[2];  G[0][5] = -tp[1];
+        G[1][3] = -tp[2]; G[1][4] = 0.0;    G[1][5] = tp[0];
+        G[2][3] = tp[1];  G[2][4] = -tp[0]; G[2][5] = 0.0;
+        const double *Cp = A.upose_cov + idx * 36;
+        double GC[3][9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            double s = 0.0;
+            for (int c = 0; c < 6; ++c) {
+                double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s += G[r][k] * Cp[k * 6 + c];
-            GC[r][c] = s;
+                for (int k = 0; k < 6; ++k) s += G[r][k] * Cp[k * 6 + c];
+                GC[r][c] = s;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += G[r][6 + k] * A.meas[k * 3 + c];
+                GC[r][6 + c] = s;
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0.0;
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s += G[r][6 + k] * A.meas[k * 3 + c];
-            GC[r][6 + c] = s;
-        }
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s += GC[r][k] * G[c][k];
+                cov[r][c] = s;
+            }
     }
-    double cov[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) s += GC[r][k] * G[c][k];
-            cov[r][c] = s;
-        }
     const double tr = cov[0][0] + cov[1][1] + cov[2][2];
-    A.keep[i] = (A.trace_thr > 0.0 && tr > A.trace_thr) ? 0 : 1;
-    float *o = A.cov6 + size_t(i) * 6;
-    o[0] = float(cov[0][0]); o[1] = float(cov[0][1]); o[2] = float(cov[0][2]);
-    o[3] = float(cov[1][1]); o[4] = float(cov[1][2]); o[5] = float(cov[2][2]);
+    const int keep = (A.with_ua && A.trace_thr > 0.0 && tr > A.trace_thr) ? 0 : 1;
+    A.keep[i] = keep;
+    const float c6[6] = {float(cov[0][0]), float(cov[0][1]), float(cov[0][2]), float(cov[1][1]), float(cov[1][2]), float(cov[2][2])};
+    if (A.cov6) {
+        float *o = A.cov6 + size_t(i) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = c6[k];
+    }
+    if (A.rec_out && keep) {
+        // point_cov = pose_global * point_ori with the new covariance (cpp:1152-1154); the other fields travel unchanged (po = pi)
+        unsigned char *o = A.rec_out + size_t(i) * A.stride;
+        for (int k = 0; k < A.stride / 4; ++k) reinterpret_cast<float *>(o)[k] = rec[k];
+        const d3 g = qrot(q4{A.gpose[3], A.gpose[4], A.gpose[5], A.gpose[6]}, d3{double(rec[0]), double(rec[1]), double(rec[2])});
+        float *ox = reinterpret_cast<float *>(o);
+        ox[0] = float(g.x + A.gpose[0]); ox[1] = float(g.y + A.gpose[1]); ox[2] = float(g.z + A.gpose[2]);
+        if (A.cov_off >= 0) {
+            float *oc = reinterpret_cast<float *>(o + A.cov_off);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) oc[k] = c6[k];
+        }
+        if (A.trace_off >= 0) *reinterpret_cast<float *>(o + A.trace_off) = float(tr);
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_records_kernel(const unsigned char *__restrict__ staged, const int *__restrict__ keep,
+                                                              const int *__restrict__ slot, int n, int stride, unsigned char *__restrict__ dst)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const float *s = reinterpret_cast<const float *>(staged + size_t(i) * stride);
+    float *d = reinterpret_cast<float *>(dst + size_t(slot[i]) * stride);
+    for (int k = 0; k < stride / 4; ++k) d[k] = s[k];
 }
 
 int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
@@ -296,11 +336,118 @@ int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, i
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.ext = d_ext; A.ext_cov = d_cov; A.n_lidar = n_lidar;
     for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas[i];
     A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = d_keep;
+    A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = 1;
+    for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
     hipLaunchKernelGGL(point_uncertainty_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(cov6_host, d_c6, sizeof(float) * 6 * size_t(n), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(keep_host, d_keep, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
+    return MLH_OK;
+}
+
+// ---------------------------------------------------------------- cloudUCTAssociateToMap
+namespace {
+struct M3 { double a[9]; };
+struct M6 { double a[36]; };
+M3 mul(const M3 &A, const M3 &B) { M3 C; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += A.a[r * 3 + k] * B.a[k * 3 + c]; C.a[r * 3 + c] = s; } return C; }
+M3 tr(const M3 &A) { M3 B; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B.a[r * 3 + c] = A.a[c * 3 + r]; return B; }
+M3 add(const M3 &A, const M3 &B) { M3 C; for (int i = 0; i < 9; ++i) C.a[i] = A.a[i] + B.a[i]; return C; }
+M6 mul(const M6 &A, const M6 &B) { M6 C; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += A.a[r * 6 + k] * B.a[k * 6 + c]; C.a[r * 6 + c] = s; } return C; }
+M6 tr(const M6 &A) { M6 B; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) B.a[r * 6 + c] = A.a[c * 6 + r]; return B; }
+M3 blk(const M6 &A, int r0, int c0) { M3 B; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B.a[r * 3 + c] = A.a[(r0 + r) * 6 + c0 + c]; return B; }
+void put(M6 &A, int r0, int c0, const M3 &B) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A.a[(r0 + r) * 6 + c0 + c] = B.a[r * 3 + c]; }
+// associate_uct.hpp:18-28: op1(B) = -tr(B) I + B;  op2(B, C) = op1(B) op1(C) + op1(C B)
+M3 op1(const M3 &B) { M3 A = B; const double t = B.a[0] + B.a[4] + B.a[8]; A.a[0] -= t; A.a[4] -= t; A.a[8] -= t; return A; }
+M3 op2(const M3 &B, const M3 &C) { return add(mul(op1(B), op1(C)), op1(mul(C, B))); }
+}  // namespace
+
+// compoundPoseWithCov, method 2 (associate_uct.hpp:90-147): pose_cp = pose_1 * pose_2 with the fourth-order covariance of the compound
+void compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pc[7], double cc[36])
+{
+    const q4 q1{p1[3], p1[4], p1[5], p1[6]}, q2{p2[3], p2[4], p2[5], p2[6]};
+    const q4 q = qmul(q1, q2);
+    const d3 rt = qrot(q1, d3{p2[0], p2[1], p2[2]});
+    pc[0] = rt.x + p1[0]; pc[1] = rt.y + p1[1]; pc[2] = rt.z + p1[2];
+    pc[3] = q.x; pc[4] = q.y; pc[5] = q.z; pc[6] = q.w;
+    M3 R, S;
+    qtorot(q1, R.a);
+    const double sk[9] = {0.0, -p1[2], p1[1], p1[2], 0.0, -p1[0], -p1[1], p1[0], 0.0};
+    for (int i = 0; i < 9; ++i) S.a[i] = sk[i];
+    M6 Ad{}, C1, C2;
+    put(Ad, 0, 0, R); put(Ad, 0, 3, mul(S, R)); put(Ad, 3, 3, R);
+    for (int i = 0; i < 36; ++i) { C1.a[i] = c1[i]; C2.a[i] = c2[i]; }
+    const M6 C2p = mul(mul(Ad, C2), tr(Ad));
+    const M3 rr1 = blk(C1, 0, 0), rp1 = blk(C1, 0, 3), pp1 = blk(C1, 3, 3);
+    const M3 rr2 = blk(C2p, 0, 0), rp2 = blk(C2p, 0, 3), pp2 = blk(C2p, 3, 3);
+    M6 A1{}, A2{}, B{};
+    put(A1, 0, 0, op1(pp1)); put(A1, 0, 3, op1(add(rp1, tr(rp1)))); put(A1, 3, 3, op1(pp1));
+    put(A2, 0, 0, op1(pp2)); put(A2, 0, 3, op1(add(rp2, tr(rp2)))); put(A2, 3, 3, op1(pp2));
+    const M3 Brr = add(add(add(op2(pp1, rr2), op2(tr(rp1), rp2)), op2(rp1, tr(rp2))), op2(rr1, pp2));
+    const M3 Brp = add(op2(pp1, tr(rp2)), op2(tr(rp1), pp2));
+    put(B, 0, 0, Brr); put(B, 0, 3, Brp); put(B, 3, 0, tr(Brp)); put(B, 3, 3, op2(pp1, pp2));
+    const M6 m1 = mul(A1, C2p), m2 = mul(C2p, tr(A1)), m3 = mul(A2, C1), m4 = mul(C1, tr(A2));
+    for (int i = 0; i < 36; ++i) cc[i] = C1.a[i] + C2p.a[i] + (((m1.a[i] + m2.a[i]) + m3.a[i]) + m4.a[i]) / 12 + B.a[i] / 4;
+}
+
+int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off,
+                            const double pose_global[7], const double cov_global[36], const double *ext_poses, const double *ext_covs,
+                            int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, void *out, int *n_out, int mem)
+{
+    if (!points || n <= 0 || stride < 12 || (stride & 3) || n_lidar <= 0 || n_lidar > 16 || !out || !n_out || !pose_global || !ext_poses)
+        return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    if (with_ua && (!cov_global || !ext_covs || !cov_meas)) return fail(ctx, MLH_ERR_INVALID, "with_ua needs the pose / extrinsic / measurement covariances");
+    hipStream_t st = ctx->stream;
+    const unsigned char *src = static_cast<const unsigned char *>(points);
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, ctx->tmp.ensure(size_t(n) * stride));
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, size_t(n) * stride, hipMemcpyHostToDevice, st));
+        src = ctx->tmp.as<unsigned char>();
+    }
+    // per-LiDAR constants: extrinsics (for pose_ext^-1), compound poses and their covariances
+    std::vector<double> h(size_t(n_lidar) * (7 + 7 + 36), 0.0);
+    double *h_ext = h.data(), *h_cp = h_ext + size_t(n_lidar) * 7, *h_cc = h_cp + size_t(n_lidar) * 7;
+    for (int l = 0; l < n_lidar; ++l) {
+        for (int i = 0; i < 7; ++i) h_ext[l * 7 + i] = ext_poses[l * 7 + i];
+        if (with_ua) compound_pose_with_cov(pose_global, cov_global, ext_poses + l * 7, ext_covs + l * 36, h_cp + l * 7, h_cc + l * 36);
+    }
+    VoxBuf &V = ctx->vox;
+    MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * h.size() + 64));
+    MLH_HIP(ctx, V.out.ensure(size_t(n) * stride));          // staged records
+    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n + 1)));   // keep flags
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 1)));   // output slots
+    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));
+    double *d_c = ctx->uct_buf.as<double>();
+    MLH_HIP(ctx, hipMemcpyAsync(d_c, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));                  // h is a local
+    UctArgs A;
+    A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.ext = d_c; A.ext_cov = nullptr; A.n_lidar = n_lidar;
+    for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
+    A.trace_thr = trace_thr; A.cov6 = nullptr; A.keep = V.leader.as<int>();
+    A.upose = d_c + size_t(n_lidar) * 7; A.upose_cov = d_c + size_t(n_lidar) * 14; A.rec_out = V.out.as<unsigned char>();
+    for (int i = 0; i < 7; ++i) A.gpose[i] = pose_global[i];
+    A.cov_off = cov_off; A.trace_off = trace_off; A.with_ua = with_ua ? 1 : 0;
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n), hipMemcpyDeviceToDevice, st));
+    int rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>());
+    if (rc) return rc;
+    unsigned char *dst = static_cast<unsigned char *>(out);
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, V.in.ensure(size_t(n) * stride));
+        dst = V.in.as<unsigned char>();
+    }
+    hipLaunchKernelGGL(compact_records_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), (const int *)V.leader.as<int>(),
+                       (const int *)V.vox_of.as<int>(), n, stride, dst);
+    MLH_HIP(ctx, hipGetLastError());
+    int total = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    *n_out = total;
+    if (mem == MLH_MEM_HOST && total > 0) {
+        MLH_HIP(ctx, hipMemcpyAsync(out, dst, size_t(total) * stride, hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+    }
     return MLH_OK;
 }
 

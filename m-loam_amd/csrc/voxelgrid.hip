@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void vscan_add_kernel(int *__restrict__ data, 
     for (int k = 0; k < VS_ITEMS; ++k) if (base + k < n) data[base + k] += add;
 }
 
-static int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, DevBuf &sums, int *grand_total)
+int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, DevBuf &sums, int *grand_total)
 {
     const int nb = int((n + VS_CHUNK - 1) / VS_CHUNK);
     MLH_HIP(ctx, sums.ensure(sizeof(int) * size_t(nb + 1)));
@@ -244,7 +244,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     }
     if (ext[0] * ext[1] * ext[2] > 2147483647ll) {
         // "Leaf size is too small for the input dataset": the reference returns the input cloud unchanged
-        MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
         *n_out = n;
         return MLH_OK;
@@ -278,7 +278,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     MLH_HIP(ctx, hipStreamSynchronize(st));
     *n_out = total;
     if (total > 0) {
-        MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
     }
     return MLH_OK;

@@ -316,4 +316,22 @@ int orc_voxel_grid_cov(const float *pts11, int n, float leaf, float trace_thresh
     return 0;
 }
 
+int orc_compound_pose_with_cov(const double *pose1, const double *cov1, const double *pose2, const double *cov2, double *pose_cp, double *cov_cp)
+{
+    compound_pose_with_cov(pose1, cov1, pose2, cov2, pose_cp, cov_cp);
+    return 0;
+}
+
+int orc_cloud_uct_associate_to_map(const float *pts11, int n, const double *pose_global, const double *cov_global, const double *ext,
+                                   const double *ext_cov, int n_laser, const double *cov_meas9, int with_ua, double trace_threshold,
+                                   float *out11, int *n_out)
+{
+    std::vector<PointICov> o;
+    cloud_uct_associate_to_map(reinterpret_cast<const PointICov *>(pts11), n, pose_global, cov_global, ext, ext_cov, n_laser, cov_meas9,
+                               with_ua != 0, trace_threshold, o);
+    std::memcpy(out11, o.data(), sizeof(PointICov) * o.size());
+    *n_out = (int)o.size();
+    return 0;
+}
+
 }  // extern "C"

@@ -292,3 +292,23 @@ def voxel_grid_cov(pts11, leaf, trace_threshold):
     cnt = C.c_int(0)
     lib().orc_voxel_grid_cov(_ptr(p), p.shape[0], C.c_float(leaf), C.c_float(trace_threshold), _ptr(out), C.byref(cnt))
     return out[:cnt.value].copy()
+
+
+def compound_pose_with_cov(pose1, cov1, pose2, cov2):
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose1, cov1, pose2, cov2)]
+    pose_cp, cov_cp = np.zeros(7), np.zeros((6, 6))
+    lib().orc_compound_pose_with_cov(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(pose_cp), _ptr(cov_cp))
+    return pose_cp, cov_cp
+
+
+def cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
+    p = np.ascontiguousarray(pts11, np.float32)
+    assert p.shape[1] == 11
+    pg, cg = np.ascontiguousarray(pose_global, np.float64), np.ascontiguousarray(cov_global, np.float64)
+    e, ec = np.ascontiguousarray(ext, np.float64), np.ascontiguousarray(ext_cov, np.float64)
+    cm = np.ascontiguousarray(cov_meas, np.float64)
+    out = np.zeros_like(p)
+    cnt = C.c_int(0)
+    lib().orc_cloud_uct_associate_to_map(_ptr(p), p.shape[0], _ptr(pg), _ptr(cg), _ptr(e), _ptr(ec), e.shape[0], _ptr(cm),
+                                         int(bool(with_ua)), C.c_double(trace_threshold), _ptr(out), C.byref(cnt))
+    return out[:cnt.value].copy()

@@ -66,3 +66,18 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("oracle-free", ""), os.path.join(dp, f)
+
+
+def test_compound_pose_with_cov_host(mla, orc):
+    """mlh_compound_pose_with_cov is host arithmetic (no GPU needed): it must agree with the oracle's restatement of
+    compoundPoseWithCov (associate_uct.hpp:90-147), which test_oracle_numerics pins against Monte-Carlo sampling."""
+    import numpy as np
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        p1 = np.concatenate([rng.uniform(-5, 5, 3), rng.normal(size=4)]); p1[3:] /= np.linalg.norm(p1[3:])
+        p2 = np.concatenate([rng.uniform(-1, 1, 3), rng.normal(size=4)]); p2[3:] /= np.linalg.norm(p2[3:])
+        A, B = rng.normal(size=(6, 6)), rng.normal(size=(6, 6))
+        c1, c2 = A @ A.T * 1e-4, B @ B.T * 1e-3
+        got, ref = mla.compound_pose_with_cov(p1, c1, p2, c2), orc.compound_pose_with_cov(p1, c1, p2, c2)
+        np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(got[1], ref[1], rtol=1e-12, atol=1e-18)

@@ -410,3 +410,91 @@ def test_correspondence_lane_widths(mla, orc, case16, feats16, lanes, monkeypatc
             assert np.array_equal(got["coeffs"].astype(np.float32).view(np.uint32), coeffs.astype(np.float32).view(np.uint32))
     finally:
         c.close()
+
+
+def _keyframe_cloud(rng, xyz, n_lidar):
+    pts = np.zeros((len(xyz), 11), np.float32)
+    pts[:, :3] = xyz
+    pts[:, 3] = rng.integers(0, n_lidar, len(xyz))
+    pts[:, 4:10] = rng.uniform(0, 1, (len(xyz), 6))       # stale covariance fields: must be overwritten
+    pts[:, 10] = 7.0
+    return pts
+
+
+def _uct_setup(synth, n_lidar=2):
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:n_lidar]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    cov_ext = np.stack([np.zeros((6, 6))] + [np.diag([0.0025] * 3 + [0.00030461] * 3) * (k + 1) for k in range(n_lidar - 1)])
+    rng = np.random.default_rng(21)
+    A = rng.normal(size=(6, 6))
+    cov_global = A @ A.T * 2e-5
+    pose_global = np.array([12.0, -7.5, 0.4, 0.01, -0.02, np.sin(0.4), np.cos(0.4)])
+    pose_global[3:] /= np.linalg.norm(pose_global[3:])
+    return ext, cov_ext, pose_global, cov_global, np.diag([0.0025] * 3)
+
+
+def test_cloud_uct_associate_to_map_parity(ctx, orc, synth, feats16):
+    """(f1) cloudUCTAssociateToMap: kept set and order exact, map-frame coordinates bit-exact (f64 math, f32 store), covariance
+    to f32 rounding of an f64 product whose summation order differs (rtol 2e-5)."""
+    rng = np.random.default_rng(4)
+    ext, cov_ext, pose_global, cov_global, meas = _uct_setup(synth)
+    pts = _keyframe_cloud(rng, feats16[0][:6000, :3] * np.float32(1.5), 2)
+    compound_tr = [np.trace(orc.compound_pose_with_cov(pose_global, cov_global, ext[l], cov_ext[l])[1]) for l in range(2)]
+    assert all(np.isfinite(compound_tr))
+    ref_all = orc.cloud_uct_associate_to_map(pts, pose_global, cov_global, ext, cov_ext, meas, True, 1e9)
+    thr = float(np.median(ref_all[:, 10]))                   # drops about half of the cloud
+    for with_ua, t in ((True, thr), (True, 1e9), (False, thr)):
+        got = ctx.cloud_uct_associate_to_map(pts, pose_global, cov_global, ext, cov_ext, meas, with_ua, t)
+        ref = orc.cloud_uct_associate_to_map(pts, pose_global, cov_global, ext, cov_ext, meas, with_ua, t)
+        clear = np.abs(ref_all[:, 10] - t) > 1e-6 * t
+        if clear.all() or not with_ua:
+            assert got.shape == ref.shape
+        else:                                                # a trace within rounding of the threshold may fall either way
+            assert abs(len(got) - len(ref)) <= int((~clear).sum())
+            continue
+        assert np.array_equal(got[:, :4].view(np.uint32), ref[:, :4].view(np.uint32))
+        np.testing.assert_allclose(got[:, 4:], ref[:, 4:], rtol=2e-5, atol=1e-9)
+        if not with_ua:
+            assert len(got) == len(pts) and not got[:, 4:].any()
+    assert 0 < len(ctx.cloud_uct_associate_to_map(pts, pose_global, cov_global, ext, cov_ext, meas, True, thr)) < len(pts)
+
+
+def test_local_map_assembled_on_device(mla, orc, synth, case16, feats16):
+    """The map can be born in HBM: keyframe clouds -> cloudUCTAssociateToMap -> VoxelGridCovarianceMLOAM -> map index, device
+    buffers throughout (MLH_MEM_DEVICE), must index exactly the cloud the host-buffer path produces."""
+    import torch
+    rng = np.random.default_rng(8)
+    ext, cov_ext, pose_global, cov_global, meas = _uct_setup(synth)
+    base = case16["surf_map"][:40000, :3]
+    kfs = [_keyframe_cloud(rng, base[i::3] + rng.normal(0, 0.05, base[i::3].shape).astype(np.float32), 2) for i in range(3)]
+    poses = [pose_global, pose_global + np.array([0.5, 0.2, 0, 0, 0, 0, 0]), pose_global + np.array([-0.4, 0.3, 0.05, 0, 0, 0, 0])]
+    c = mla.Context(0)
+    try:
+        # host-buffer path
+        host = np.concatenate([c.cloud_uct_associate_to_map(k, p, cov_global, ext, cov_ext, meas, True, 0.2) for k, p in zip(kfs, poses)])
+        host_ds = c.voxel_filter(host, 0.4, 0.2)
+        # device path: one accumulation buffer, records appended in place
+        total = sum(len(k) for k in kfs)
+        d_acc = torch.zeros((total, 11), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        fill = 0
+        for k, p in zip(kfs, poses):
+            d_in = torch.from_numpy(k).cuda()
+            torch.cuda.synchronize()
+            fill += c.cloud_uct_associate_to_map_device(d_in, d_acc[fill:], p, cov_global, ext, cov_ext, meas, True, 0.2)
+        assert fill == len(host)
+        d_ds = torch.zeros((fill, 11), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        n_ds = c.voxel_filter_device(d_acc[:fill], d_ds, 0.4, 0.2)
+        assert n_ds == len(host_ds)
+        np.testing.assert_array_equal(d_ds[:n_ds].cpu().numpy(), host_ds)
+        c.map_set(mla.SURF, d_ds[:n_ds])
+        qm = host_ds[rng.integers(0, len(host_ds), 500), :3] + rng.normal(0, 0.2, (500, 3)).astype(np.float32)
+        idx, d2 = c.knn(mla.SURF, qm.astype(np.float32))
+        ridx, rd2 = orc.Map(np.ascontiguousarray(host_ds[:, :3])).knn(qm.astype(np.float32))
+        within = rd2 < 1.0
+        assert within.sum() > 100
+        assert np.array_equal(idx[within], ridx[within]) and np.array_equal(d2[within].view(np.uint32), rd2[within].view(np.uint32))
+    finally:
+        c.close()

@@ -241,3 +241,56 @@ def test_pure_odom_factor_jacobians(orc, kind):
         r3, J3 = orc.factor_eval(kind, point, coeff, 0.0, pose_i)
         assert abs(r2 - r3) < 1e-12
         np.testing.assert_allclose(J2[1], J3, rtol=1e-10, atol=1e-12)
+
+
+def _so3_exp(phi):
+    th = np.linalg.norm(phi, axis=1)[:, None, None]
+    K = np.zeros((len(phi), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -phi[:, 2], phi[:, 1], phi[:, 2], -phi[:, 0], -phi[:, 1], phi[:, 0]
+    th = np.maximum(th, 1e-12)
+    I = np.eye(3)[None]
+    R = I + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+    J = I + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return R, J
+
+
+def test_compound_pose_with_cov_matches_monte_carlo(orc, synth):
+    """compoundPoseWithCov (associate_uct.hpp:90-147) is the 4th-order SE(3) pose-compounding formula with perturbations
+    xi = [rho, phi] applied on the left, T = exp(xi^) T_mean. Pin the restatement against sampling: the empirical covariance
+    of T1 T2 must agree with the formula (to sampling error), and clearly better than the first-order term alone would."""
+    rng = np.random.default_rng(5)
+    p1 = np.array([4.0, -2.0, 1.0, 0.0, 0.0, np.sin(0.35), np.cos(0.35)])
+    p2 = np.array([0.6, 0.3, -0.2, np.sin(0.1), 0.0, 0.0, np.cos(0.1)])
+    A = rng.normal(size=(6, 6)); c1 = A @ A.T * 2e-4
+    B = rng.normal(size=(6, 6)); c2 = B @ B.T * 3e-4
+    pose_cp, cov_cp = orc.compound_pose_with_cov(p1, c1, p2, c2)
+
+    def mats(p):
+        T = np.eye(4); T[:3, :3] = synth.quat_to_rot(p[3:]); T[:3, 3] = p[:3]
+        return T
+
+    T1, T2, Tc = mats(p1), mats(p2), mats(pose_cp)
+    np.testing.assert_allclose(Tc, T1 @ T2, atol=1e-12)
+    n = 400000
+
+    def sample(cov):
+        xi = rng.multivariate_normal(np.zeros(6), cov, size=n)
+        R, J = _so3_exp(xi[:, 3:])
+        T = np.tile(np.eye(4), (n, 1, 1))
+        T[:, :3, :3] = R
+        T[:, :3, 3] = (J @ xi[:, :3, None])[:, :, 0]
+        return T
+
+    S = (sample(c1) @ T1) @ (sample(c2) @ T2) @ np.linalg.inv(Tc)
+    # log of the residual transform (small): phi from the skew part, rho = J^-1 t
+    Rm = S[:, :3, :3]
+    cos = np.clip((np.trace(Rm, axis1=1, axis2=2) - 1) / 2, -1, 1)
+    th = np.arccos(cos)
+    w = np.stack([Rm[:, 2, 1] - Rm[:, 1, 2], Rm[:, 0, 2] - Rm[:, 2, 0], Rm[:, 1, 0] - Rm[:, 0, 1]], axis=1)
+    phi = w * (th / (2 * np.sin(np.maximum(th, 1e-12))))[:, None]
+    _, J = _so3_exp(phi)
+    rho = np.linalg.solve(J, S[:, :3, 3][:, :, None])[:, :, 0]
+    xi = np.concatenate([rho, phi], axis=1)
+    emp = xi.T @ xi / n
+    scale = np.sqrt(np.outer(np.diag(cov_cp), np.diag(cov_cp)))
+    assert np.max(np.abs(emp - cov_cp) / scale) < 0.02
