@@ -94,6 +94,21 @@ int main(int argc, char **argv)
         for (const auto &q : surf_map_ds.points) { ds.push_back(q.x); ds.push_back(q.y); ds.push_back(q.z); ds.push_back(q.intensity); for (int k = 0; k < 6; ++k) ds.push_back(q.cov_vec[k]); ds.push_back(q.cov_trace); }
         write_file(d + "out_map_ds.f32", ds);
         std::printf("voxel filter: %zu -> %zu\n", surf_map.size(), surf_map_ds.size());
+        // --- cloudUCTAssociateToMap with the reference's argument list
+        {
+            std::vector<Pose> pose_ext(2);
+            pose_ext[1].t_(0) = 0.1; pose_ext[1].t_(1) = -0.5; pose_ext[1].q_.z = 0.0998334166; pose_ext[1].q_.w = 0.9950041653;
+            for (int i = 0; i < 6; ++i) pose_ext[1].cov_[i * 6 + i] = i < 3 ? 0.0025 : 0.00030461;
+            Pose pose_global = pose;
+            for (int i = 0; i < 6; ++i) pose_global.cov_[i * 6 + i] = 1e-5;
+            PointICovCloud kf, kf_map;
+            for (size_t i = 0; i < surf.size(); ++i) { PointIWithCov q = surf[i]; q.intensity = float(i & 1); kf.push_back(q); }
+            cloudUCTAssociateToMap(dev, kf, kf_map, pose_global, pose_ext, true);
+            std::vector<float> km;
+            for (const auto &q : kf_map.points) { km.push_back(q.x); km.push_back(q.y); km.push_back(q.z); km.push_back(q.intensity); for (int k = 0; k < 6; ++k) km.push_back(q.cov_vec[k]); km.push_back(q.cov_trace); }
+            write_file(d + "out_kf_map.f32", km);
+            std::printf("cloudUCTAssociateToMap: %zu -> %zu\n", kf.size(), kf_map.size());
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

@@ -96,6 +96,8 @@ public:
 struct Params {
     float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;
     double MAP_EIG_THRE = 100.0, HUBER_DELTA = 0.1, COV_MEASUREMENT_TRACE = 0.0075;
+    double COV_MEASUREMENT[9] = {0.0025, 0, 0, 0, 0.0025, 0, 0, 0, 0.0025};   // config uct_measurement
+    double TRACE_THRESHOLD_MAPPING = 0.6;
     int N_SCANS = 16;
 };
 inline Params &params() { static Params p; return p; }
@@ -185,6 +187,40 @@ private:
     const PointCloud<PointT> *input_ = nullptr;
     float leaf_ = 0.4f, trace_threshold_ = 2.0f;   // .h:102
 };
+
+// ------------------------------------------------------------------ local-map assembly (lidar_mapper.h:118-119, associate_uct.hpp:90-147)
+// compoundPoseWithCov(pose_1, pose_2, pose_cp): method 2, the only one the mapper uses
+inline void compoundPoseWithCov(const Pose &pose_1, const Pose &pose_2, Pose &pose_cp)
+{
+    double p1[7], p2[7], pc[7];
+    pose_1.toParam(p1); pose_2.toParam(p2);
+    if (mlh_compound_pose_with_cov(p1, pose_1.cov_.data(), p2, pose_2.cov_.data(), pc, pose_cp.cov_.data()) != MLH_OK) throw Error("compoundPoseWithCov");
+    pose_cp.fromParam(pc);
+}
+
+// cloudUCTAssociateToMap(cloud_local, cloud_global, pose_global, pose_ext): the reference reads the globals with_ua_flag,
+// COV_MEASUREMENT and TRACE_THRESHOLD_MAPPING; here they are the last argument and params().
+inline void cloudUCTAssociateToMap(Device &dev, const PointICovCloud &cloud_local, PointICovCloud &cloud_global, const Pose &pose_global,
+                                   const std::vector<Pose> &pose_ext, bool with_ua_flag)
+{
+    cloud_global.points.clear();
+    if (cloud_local.size() == 0) return;
+    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
+    for (size_t n = 0; n < pose_ext.size(); ++n) {
+        pose_ext[n].toParam(ext.data() + n * 7);
+        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
+    }
+    double pg[7];
+    pose_global.toParam(pg);
+    std::vector<PointIWithCov> out(cloud_local.size());
+    int32_t n_out = 0;
+    dev.check(mlh_cloud_uct_associate_to_map(dev.ctx(), cloud_local.points.data(), (int)sizeof(PointIWithCov), (int)cloud_local.size(),
+                                             VoxelFields<PointIWithCov>::intensity, VoxelFields<PointIWithCov>::cov, VoxelFields<PointIWithCov>::trace,
+                                             pg, pose_global.cov_.data(), ext.data(), ext_cov.data(), (int)pose_ext.size(), params().COV_MEASUREMENT,
+                                             with_ua_flag ? 1 : 0, params().TRACE_THRESHOLD_MAPPING, out.data(), &n_out, MLH_MEM_HOST));
+    out.resize(n_out);
+    cloud_global.points.assign(out.begin(), out.end());
+}
 
 // ------------------------------------------------------------------ FeatureExtract
 class FeatureExtract {

@@ -44,3 +44,15 @@ def test_facade_selftest(tmp_path, orc, case16, feats16):
     ref = orc.voxel_grid_cov(m11, 0.8, 1.0)
     assert ds.shape == ref.shape
     np.testing.assert_allclose(ds, ref, rtol=2e-6, atol=2e-6)
+    # cloudUCTAssociateToMap facade (the self-test labels the surf features alternately LiDAR 0 / 1)
+    km = np.fromfile(os.path.join(d, "out_kf_map.f32"), np.float32).reshape(-1, 11)
+    kf = np.zeros((len(feats16[0]), 11), np.float32)
+    kf[:, :3] = feats16[0][:, :3]
+    kf[:, 3] = np.arange(len(kf)) & 1
+    ext = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.1, -0.5, 0, 0, 0, 0.0998334166, 0.9950041653]])
+    ext_cov = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    ref = orc.cloud_uct_associate_to_map(kf, pose, np.eye(6) * 1e-5,   # the self-test uses the pose scan2MapOptimization just refined
+                                         ext, ext_cov, np.diag([0.0025] * 3), True, 0.6)
+    assert km.shape == ref.shape
+    assert np.array_equal(km[:, :4].view(np.uint32), ref[:, :4].view(np.uint32))
+    np.testing.assert_allclose(km[:, 4:], ref[:, 4:], rtol=2e-5, atol=1e-9)
