@@ -122,6 +122,20 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem);
 
+/* ---------------------------------------------------------------- (a19) odometry-side three-block factors
+ * replaces the per-feature LidarPureOdomPlaneNormFactor / LidarPureOdomEdgeFactor objects Estimator::optimizeMap hands to Ceres
+ * (estimator.cpp:700-780) and their Evaluate (lidar_pure_odom_factor.hpp:38-102, 209-282): one residual + three 1x7 Jacobians
+ * (pivot pose, window pose i, extrinsic n), point moved with T_pivot^-1 T_i T_ext.
+ * mlh_pure_odom_set stages the factor table once per optimisation: type[i] 0 = plane ('s'), 1 = edge ('c'); points n x 3;
+ * coeffs n x 6 (plane: [n, d, -, -], edge: the two line points); sqrt_info may be NULL (= 1.0, as the reference constructs them);
+ * frame_idx / ext_idx select rows of the pose arrays given to mlh_pure_odom_evaluate.
+ * mlh_pure_odom_evaluate: residuals n; jacobians n x 21 row-major [pivot 1x7 | frame 1x7 | extrinsic 1x7] or NULL. The columns
+ * are the reference's expressions term by term (two of them are not exact derivatives; see m-loam_amd/csrc/odom.hip). */
+int mlh_pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
+                      const int32_t *frame_idx, const int32_t *ext_idx);
+int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
+                           double *residuals, double *jacobians);
+
 /* (f1) cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158): moves one keyframe's feature cloud into the map frame while
  * building the local map (extractSurroundingKeyFrames, cpp:254-354). Per point (intensity = LiDAR index n):
  *   with_ua: point_sel = pose_ext[n]^-1 * p; Sigma = evalPointUncertainty(point_sel, pose_global (+) pose_ext[n]) where the

@@ -87,6 +87,8 @@ def load_library():
     dp = C.POINTER(C.c_double)
     lib.mlh_cloud_uct_associate_to_map.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, cd, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_compound_pose_with_cov.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.mlh_pure_odom_evaluate.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_rebuild.argtypes = [vp, ci]
@@ -115,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -250,6 +252,21 @@ class Context:
         kp = np.zeros(n, np.int32)
         self._ck(self.lib.mlh_point_uncertainty(self.h, ptr, stride, n, 12, mem, _p(ep), _p(ec), ep.shape[0], _p(cm), trace_threshold, _p(cov), _p(kp)))
         return cov, kp.astype(bool)
+
+    def pure_odom_set(self, types, points, coeffs, frame_idx, ext_idx, sqrt_info=None):
+        t = np.ascontiguousarray(types, np.int32); fi = np.ascontiguousarray(frame_idx, np.int32); ei = np.ascontiguousarray(ext_idx, np.int32)
+        p = np.ascontiguousarray(points, np.float64); c = np.ascontiguousarray(coeffs, np.float64)
+        assert p.shape == (len(t), 3) and c.shape == (len(t), 6)
+        si = None if sqrt_info is None else np.ascontiguousarray(sqrt_info, np.float64)
+        self._ck(self.lib.mlh_pure_odom_set(self.h, len(t), _p(t), _p(p), _p(c), _p(si) if si is not None else None, _p(fi), _p(ei)))
+        self._n_odom = len(t)
+
+    def pure_odom_evaluate(self, pivot, frames, exts, want_jacobians=True):
+        pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7)
+        ex = np.ascontiguousarray(exts, np.float64).reshape(-1, 7)
+        r = np.zeros(self._n_odom); J = np.zeros((self._n_odom, 3, 7)) if want_jacobians else None
+        self._ck(self.lib.mlh_pure_odom_evaluate(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), _p(r), _p(J) if J is not None else None))
+        return r, J
 
     def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
         """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""

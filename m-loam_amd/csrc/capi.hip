@@ -191,6 +191,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
+    { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
     comm_destroy(ctx);
@@ -339,6 +340,22 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return point_uncertainty_run(ctx, points, stride_bytes, n, intensity_offset_bytes, mem, ext_poses, ext_covs, n_lidar, cov_measurement,
                                  trace_threshold, cov_vec_out, keep_out);
+}
+
+int mlh_pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
+                      const int32_t *frame_idx, const int32_t *ext_idx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return pure_odom_set(ctx, n, type, points, coeffs, sqrt_info, frame_idx, ext_idx);
+}
+
+int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
+                           double *residuals, double *jacobians)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return pure_odom_evaluate(ctx, pivot, frames, n_frames, exts, n_ext, residuals, jacobians);
 }
 
 int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,

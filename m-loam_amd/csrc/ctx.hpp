@@ -148,6 +148,11 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
     DevBuf in, bounds, cell, vox_of, sorted_idx, leader, out, sums, total;
 };
 
+struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
+    DevBuf tab, idx, poses, r, J;
+    int n = 0, max_frame = 0, max_ext = 0;
+};
+
 struct Profile {
     unsigned mask = 0;     // bit k: bracket launches of kernel id k
     double total_ms[MLH_K_COUNT] = {0};
@@ -176,6 +181,7 @@ struct mlh_ctx {
     void *h_state = nullptr; // pinned staging for the solver-state upload
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;
+    mlh::OdomSet odom;
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
@@ -208,6 +214,11 @@ int extract_run(mlh_ctx *ctx);
 int ring_voxel_run(mlh_ctx *ctx, float leaf);
 int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
                           const double *ext_covs, int n_lidar, const double cov_meas[9], double trace_thr, float *cov6_host, int *keep_host);
+// odom.hip
+int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
+                  const int32_t *frame_idx, const int32_t *ext_idx);
+int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
+                       double *residuals, double *jacobians);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
 // voxel.hip

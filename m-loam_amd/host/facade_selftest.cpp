@@ -109,6 +109,23 @@ int main(int argc, char **argv)
             write_file(d + "out_kf_map.f32", km);
             std::printf("cloudUCTAssociateToMap: %zu -> %zu\n", kf.size(), kf_map.size());
         }
+        // --- LidarPureOdomBatchFactor: the matched surf features as window factors over [pivot, 2 frames, 2 extrinsics]
+        {
+            LidarPureOdomBatchFactor cost(dev, 2, 2);
+            for (size_t i = 0; i < feats.size(); ++i) cost.add(feats[i], 1 + int(i % 2), int((i / 2) % 2));
+            double pivot[7] = {0.3, -0.2, 0.1, 0.0, 0.0, 0.0499791693, 0.9987502604}, f1[7], f2[7];
+            pose.toParam(f1); pose.toParam(f2); f2[0] += 0.25;
+            double e0[7] = {0, 0, 0, 0, 0, 0, 1}, e1[7] = {0.1, -0.5, 0.02, 0.0, 0.0, 0.0998334166, 0.9950041653};
+            const double *par[5] = {pivot, f1, f2, e0, e1};
+            const int nr = cost.num_residuals();
+            std::vector<double> res(nr), jac(size_t(nr) * 7 * 5);
+            double *jp[5];
+            for (int b = 0; b < 5; ++b) jp[b] = jac.data() + size_t(b) * nr * 7;
+            if (!cost.Evaluate(par, res.data(), jp)) throw Error("LidarPureOdomBatchFactor::Evaluate");
+            write_file(d + "out_odom_res.f64", res);
+            write_file(d + "out_odom_jac.f64", jac);
+            std::printf("LidarPureOdomBatchFactor: %d residuals\n", nr);
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

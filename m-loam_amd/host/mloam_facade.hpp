@@ -390,6 +390,58 @@ private:
     mutable std::vector<double> r_, J_;
 };
 
+// ------------------------------------------------------------------ the odometry window's LidarPureOdom factors as one cost function
+// Estimator::optimizeMap adds, for every window frame i > pivot, LiDAR n and matched feature, a LidarPureOdomPlaneNormFactor or
+// LidarPureOdomEdgeFactor over (para_pose_[0], para_pose_[i - pivot_idx], para_ex_pose_[n]) (estimator.cpp:700-780). This
+// aggregate stands for all of them: add(feature, frame, laser) while building the problem, then Evaluate() with the Ceres
+// contract over the parameter blocks [pivot, frame_1 .. frame_W, ext_0 .. ext_{L-1}] (each double[7]); jacobians[b] is
+// num_residuals x 7 row-major, rows of factors that do not touch block b are zero.
+class LidarPureOdomBatchFactor {
+public:
+    LidarPureOdomBatchFactor(Device &dev, int n_window_frames, int n_lasers) : dev_(dev), W_(n_window_frames), L_(n_lasers) {}
+    // feature: as produced by the match functions ('s': coeffs_ = [n, d]; 'c': coeffs_ = the two line points); s = sqrt_info (1.0 in the reference)
+    void add(const PointPlaneFeature &feature, int frame /*1..W*/, int laser /*0..L-1*/, double s = 1.0)
+    {
+        type_.push_back(feature.type_ == 's' ? 0 : 1);
+        for (int k = 0; k < 3; ++k) pts_.push_back(feature.point_[k]);
+        for (int k = 0; k < 6; ++k) coef_.push_back(k < (int)feature.coeffs_.size() ? feature.coeffs_[k] : 0.0);
+        s_.push_back(s); fi_.push_back(frame - 1); ei_.push_back(laser);
+        staged_ = false;
+    }
+    int num_residuals() const { return (int)type_.size(); }
+    int num_parameter_blocks() const { return 1 + W_ + L_; }
+    bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const
+    {
+        const int n = num_residuals();
+        if (n == 0) return true;
+        if (!staged_) {
+            if (mlh_pure_odom_set(dev_.ctx(), n, type_.data(), pts_.data(), coef_.data(), s_.data(), fi_.data(), ei_.data()) != MLH_OK) return false;
+            staged_ = true;
+            J_.resize(size_t(n) * 21);
+        }
+        std::vector<double> frames(size_t(W_) * 7), exts(size_t(L_) * 7);
+        for (int w = 0; w < W_; ++w) std::memcpy(frames.data() + w * 7, parameters[1 + w], sizeof(double) * 7);
+        for (int l = 0; l < L_; ++l) std::memcpy(exts.data() + l * 7, parameters[1 + W_ + l], sizeof(double) * 7);
+        if (mlh_pure_odom_evaluate(dev_.ctx(), parameters[0], frames.data(), W_, exts.data(), L_, residuals, jacobians ? J_.data() : nullptr) != MLH_OK) return false;
+        if (!jacobians) return true;
+        for (int b = 0; b < num_parameter_blocks(); ++b) if (jacobians[b]) std::memset(jacobians[b], 0, sizeof(double) * 7 * size_t(n));
+        for (int i = 0; i < n; ++i) {
+            const double *J = J_.data() + size_t(i) * 21;
+            if (jacobians[0]) std::memcpy(jacobians[0] + size_t(i) * 7, J, sizeof(double) * 7);
+            if (jacobians[1 + fi_[i]]) std::memcpy(jacobians[1 + fi_[i]] + size_t(i) * 7, J + 7, sizeof(double) * 7);
+            if (jacobians[1 + W_ + ei_[i]]) std::memcpy(jacobians[1 + W_ + ei_[i]] + size_t(i) * 7, J + 14, sizeof(double) * 7);
+        }
+        return true;
+    }
+private:
+    Device &dev_;
+    int W_, L_;
+    std::vector<int32_t> type_, fi_, ei_;
+    std::vector<double> pts_, coef_, s_;
+    mutable bool staged_ = false;
+    mutable std::vector<double> J_;
+};
+
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
     std::vector<mlh_iter_stat> outer;   // one per outer iteration: matched counts, H, eigenvalues, LM iterations, costs

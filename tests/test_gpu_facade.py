@@ -56,3 +56,23 @@ def test_facade_selftest(tmp_path, orc, case16, feats16):
     assert km.shape == ref.shape
     assert np.array_equal(km[:, :4].view(np.uint32), ref[:, :4].view(np.uint32))
     np.testing.assert_allclose(km[:, 4:], ref[:, 4:], rtol=2e-5, atol=1e-9)
+    # LidarPureOdomBatchFactor: Ceres-shaped Evaluate over [pivot, frame 1, frame 2, ext 0, ext 1]
+    res = np.fromfile(os.path.join(d, "out_odom_res.f64"), np.float64)
+    nr = len(res)
+    jac = np.fromfile(os.path.join(d, "out_odom_jac.f64"), np.float64).reshape(5, nr, 7)
+    vidx = np.flatnonzero(v)
+    assert nr == len(vidx)
+    _, coeffs = orc.Map(case16["surf_map"]).match("s", feats16[0], case16["p0"])
+    pivot = np.array([0.3, -0.2, 0.1, 0.0, 0.0, 0.0499791693, 0.9987502604])
+    f1 = pose.copy(); f2 = pose.copy(); f2[0] += 0.25
+    par = [pivot, f1, f2, np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.1, -0.5, 0.02, 0.0, 0.0, 0.0998334166, 0.9950041653])]
+    for i in range(0, nr, 11):
+        fb, eb = 1 + i % 2, 3 + (i // 2) % 2
+        rr, JJ = orc.pure_odom_eval("s", feats16[0][vidx[i], :3].astype(np.float64), coeffs[vidx[i], :4], pivot, par[fb], par[eb])
+        assert abs(res[i] - rr) < 1e-10
+        np.testing.assert_allclose(jac[0, i], JJ[0], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(jac[fb, i], JJ[1], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(jac[eb, i], JJ[2], rtol=1e-10, atol=1e-10)
+        for b in range(1, 5):
+            if b not in (fb, eb):
+                assert not jac[b, i].any()

@@ -498,3 +498,47 @@ def test_local_map_assembled_on_device(mla, orc, synth, case16, feats16):
         assert np.array_equal(idx[within], ridx[within]) and np.array_equal(d2[within].view(np.uint32), rd2[within].view(np.uint32))
     finally:
         c.close()
+
+
+def test_pure_odom_batch_parity(ctx, orc):
+    """(a19) LidarPureOdom{PlaneNorm,Edge}Factor::Evaluate for a whole window in one launch: residual and the three 1x7 Jacobians of
+    every factor against the oracle's per-factor restatement (f64, rtol 1e-12 -- same expressions, different association)."""
+    rng = np.random.default_rng(31)
+
+    def rand_pose(scale):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        return np.concatenate([rng.uniform(-scale, scale, 3), q])
+
+    n_frames, n_ext, n = 4, 3, 5000
+    pivot = rand_pose(20.0)
+    frames = np.stack([rand_pose(20.0) for _ in range(n_frames)])
+    exts = np.stack([rand_pose(1.0) for _ in range(n_ext)])
+    types = rng.integers(0, 2, n).astype(np.int32)
+    points = rng.uniform(-40, 40, (n, 3))
+    coeffs = np.zeros((n, 6))
+    for i in range(n):
+        if types[i] == 0:
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            coeffs[i, :3] = v; coeffs[i, 3] = rng.uniform(-5, 5)
+        else:
+            c = rng.uniform(-40, 40, 3); v = rng.normal(size=3); v /= np.linalg.norm(v)
+            coeffs[i, :3] = c + 0.1 * v; coeffs[i, 3:] = c - 0.1 * v
+    fi = rng.integers(0, n_frames, n).astype(np.int32)
+    ei = rng.integers(0, n_ext, n).astype(np.int32)
+    sq = rng.uniform(0.3, 1.0, n)
+    ctx.pure_odom_set(types, points, coeffs, fi, ei, sq)
+    r, J = ctx.pure_odom_evaluate(pivot, frames, exts)
+    for i in range(0, n, 7):
+        kind = "s" if types[i] == 0 else "c"
+        rr, JJ = orc.pure_odom_eval(kind, points[i], coeffs[i, :4] if kind == "s" else coeffs[i], pivot, frames[fi[i]], exts[ei[i]], sq[i])
+        assert abs(r[i] - rr) <= 1e-12 * max(1.0, abs(rr))
+        np.testing.assert_allclose(J[i], JJ, rtol=1e-11, atol=1e-11)
+    assert np.all(J[:, :, 6] == 0)
+    r2, J2 = ctx.pure_odom_evaluate(pivot, frames, exts, want_jacobians=False)
+    assert J2 is None and np.array_equal(r, r2)
+    # default weight 1.0 and the error paths
+    ctx.pure_odom_set(types[:10], points[:10], coeffs[:10], fi[:10], ei[:10])
+    r3, _ = ctx.pure_odom_evaluate(pivot, frames, exts)
+    np.testing.assert_allclose(r3, r[:10] / sq[:10], rtol=1e-13)
+    with pytest.raises(Exception):
+        ctx.pure_odom_evaluate(pivot, frames[: fi[:10].max()], exts)      # pose array shorter than the largest frame index
