@@ -145,10 +145,20 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
     MLH_KSTAGE(2);
     const int len = e - b;
     int incl = len;
-    { const int t = dpp_row_shr<1>(incl); if (gl >= 1) incl += t; }
-    { const int t = dpp_row_shr<2>(incl); if (gl >= 2) incl += t; }
-    { const int t = dpp_row_shr<4>(incl); if (gl >= 4) incl += t; }
-    if (G == 16) { const int t = dpp_row_shr<8>(incl); if (gl >= 8) incl += t; }
+    if (G == 16) {
+        // small launches are latency-bound: DPP row shifts / lane swaps (VALU latency) instead of ds_bpermute round trips
+        { const int t = dpp_row_shr<1>(incl); if (gl >= 1) incl += t; }
+        { const int t = dpp_row_shr<2>(incl); if (gl >= 2) incl += t; }
+        { const int t = dpp_row_shr<4>(incl); if (gl >= 4) incl += t; }
+        { const int t = dpp_row_shr<8>(incl); if (gl >= 8) incl += t; }
+    } else {
+        // chip-filling launches are issue-bound on the VALU: leave the exchanges to the LDS crossbar
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            const int t = __shfl_up(incl, off, G);
+            if (gl >= off) incl += t;
+        }
+    }
     const int len8 = (G == 8) ? __shfl(e8 - b8, 0, G) : 0;
     const int total = __shfl(incl, G - 1, G) + len8;
     if (total >= K) {                                  // uniform over the group
@@ -191,10 +201,18 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         unsigned long long m = k[0];
-        m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
-        m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
-        m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
-        if (G == 16) m = dpp_min_u64<DPP_ROW_MIRROR>(m);
+        if (G == 16) {
+            m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
+            m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
+            m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
+            m = dpp_min_u64<DPP_ROW_MIRROR>(m);
+        } else {
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                const unsigned long long o = shfl_xor_u64(m, off);
+                m = o < m ? o : m;
+            }
+        }
         out[t] = m;
         if (k[0] == m && m != KEY_INF) {
 #pragma unroll
@@ -443,7 +461,9 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
     MLH_KSTAGE(5);
 }
 
-template <int G>
+// MB = more than one pose block in the launch (config 4); without it the block bookkeeping (a per-lane block index and the
+// per-block K lookup it drags along) compiles away
+template <int G, bool MB>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     if (f >= K.m) return;
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
-    const int b = block_of_slot(K, P.n_blocks, f);
+    const int b = MB ? block_of_slot(K, P.n_blocks, f) : 0;
     const double *pose = block_pose(P, b);
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
     if (!owns(P, sx, sy, sz)) return;     // uniform over the lane group
-    if (P.kb[b] == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
+    if ((MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
     else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * 20);
 }
 
@@ -583,6 +603,9 @@ __device__ __forceinline__ bool fit_feature(const KParams &P, const KindP &Kd, i
 }
 
 // ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature, both kinds in one launch
+// KMAX = the largest N_NEIGH of the launch: with 5 (every mapper launch) the 10-neighbour fits are not compiled in, which halves
+// the kernel's register footprint (occupancy matters once a launch has more workgroups than the chip holds at once)
+template <int KMAX>
 __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
         float sx, sy, sz;
         associate_to_map(q, t, fp, sx, sy, sz);
         if (fp.w >= 0.f && owns(P, sx, sy, sz)) {
-            valid = (P.kb[b] == 10) ? fit_feature<10>(P, K, kind, f, coef) : fit_feature<5>(P, K, kind, f, coef);
+            valid = (KMAX == 10 && P.kb[b] == 10) ? fit_feature<KMAX>(P, K, kind, f, coef) : fit_feature<5>(P, K, kind, f, coef);
             if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
         }
         Corr c;
@@ -813,9 +836,13 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     // kernel A: correspondences (32 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
     const int grid_a = ((P.k[0].tiles_a + P.k[1].tiles_a + 7) / 8) * 8;
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
-    if (P.knn_lanes == 16) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16>, grid_a, P);
-    else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8>, grid_a, P);
-    launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel, grid_b, P);
+    const bool mb = P.n_blocks > 1;
+    if (P.knn_lanes == 16) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, false>, grid_a, P); }
+    else { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, false>, grid_a, P); }
+    bool k10 = false;
+    for (int b = 0; b < P.n_blocks; ++b) k10 = k10 || P.kb[b] == 10;
+    if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10>, grid_b, P);
+    else launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
     return MLH_OK;

@@ -144,58 +144,78 @@ __device__ __noinline__ bool eval_degeneracy_mem(const double *ne, double thre, 
     return deg;
 }
 
-// Cholesky factor / solve of a 6x6 SPD system, fully unrolled so that A, L, y live in registers (no scratch).
-// The dependent chain is what costs time here (one lane, ~1 wavefront on the chip), so each column takes ONE long operation
-// -- r = rsqrt(s) -- and the column and the later substitutions multiply by it instead of dividing.
-__device__ __forceinline__ bool chol6_factor(const double (&A)[36], double (&L)[36], double (&inv_d)[6])
+// Cholesky factor / solve of a 6x6 SPD system on the PACKED lower triangle (21 doubles, entry (i, j), i >= j, at i(i+1)/2 + j),
+// factorised in place and fully unrolled so everything lives in registers (no scratch): 42 VGPRs instead of the 144 a pair of
+// full matrices takes -- this code is inlined into the fit kernel's fused finish and would otherwise set that kernel's
+// register allocation. The dependent chain is what costs time here (one lane, ~1 wavefront on the chip), so each column takes
+// ONE long operation -- r = rsqrt(s) -- and the column and the later substitutions multiply by it instead of dividing.
+#define MLH_LT(i, j) ((i) * ((i) + 1) / 2 + (j))
+__device__ __forceinline__ bool chol6p_factor(double (&a)[21], double (&inv_d)[6])
 {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double s = A[j * 6 + j];
+        double s = a[MLH_LT(j, j)];
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+        for (int k = 0; k < j; ++k) s -= a[MLH_LT(j, k)] * a[MLH_LT(j, k)];
         ok = ok && (s > 0.0);
         const double r = rsqrt(s);
         inv_d[j] = r;
-        L[j * 6 + j] = s * r;
+        a[MLH_LT(j, j)] = s * r;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
-            double t = A[i * 6 + j];
+            double t = a[MLH_LT(i, j)];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = t * r;
+            for (int k = 0; k < j; ++k) t -= a[MLH_LT(i, k)] * a[MLH_LT(j, k)];
+            a[MLH_LT(i, j)] = t * r;
         }
     }
     return ok;
 }
 
 // L L^T x = b
-__device__ __forceinline__ void chol6_substitute(const double (&L)[36], const double (&inv_d)[6], const double (&b)[6], double (&x)[6])
+__device__ __forceinline__ void chol6p_substitute(const double (&L)[21], const double (&inv_d)[6], const double (&b)[6], double (&x)[6])
 {
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+        for (int k = 0; k < i; ++k) s -= L[MLH_LT(i, k)] * y[k];
         y[i] = s * inv_d[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
+        for (int k = i + 1; k < 6; ++k) s -= L[MLH_LT(k, i)] * x[k];
         x[i] = s * inv_d[i];
     }
 }
 
+// full row-major symmetric A (lower triangle read)
 __device__ __forceinline__ bool chol6_solve(const double (&A)[36], const double (&b)[6], double (&x)[6])
 {
-    double L[36], inv_d[6];
-    if (!chol6_factor(A, L, inv_d)) return false;
-    chol6_substitute(L, inv_d, b, x);
+    double a[21], inv_d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[MLH_LT(i, j)] = A[i * 6 + j];
+    if (!chol6p_factor(a, inv_d)) return false;
+    chol6p_substitute(a, inv_d, b, x);
     return true;
+}
+
+// packed lower triangle of H - shift*I from the reduced record (upper-packed J^T J at ne[0..20])
+__device__ __forceinline__ void pack_lower_from_ne(const double *ne, double shift, double (&a)[21])
+{
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const int q = j * 6 - (j * (j - 1)) / 2 + (i - j);   // upper-packed index of (j, i)
+            a[MLH_LT(i, j)] = ne[q] - ((i == j) ? shift : 0.0);
+        }
 }
 
 __device__ __noinline__ void write_stat_common(IterStatDev *st, const double *ne, const double *cnt2, const double *ev, bool deg)
@@ -224,32 +244,25 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
     double xc[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) xc[i] = x[i];          // issued before the factorisation: the pose arrives while it runs
-    double H[36], A[36], L[36], inv_d[6];
-    unpack_H(ne, H);
-    const double sh = (lane == 1) ? eig_thre * (1.0 + 1e-9) : 0.0;
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = H[i] - (((i % 7) == 0) ? sh : 0.0);
-    const bool pd = chol6_factor(A, L, inv_d);
+    double L[21], inv_d[6];
+    pack_lower_from_ne(ne, (lane == 1) ? eig_thre * (1.0 + 1e-9) : 0.0, L);
+    const bool pd = chol6p_factor(L, inv_d);
     const bool not_degenerate_fast = __shfl(pd ? 1 : 0, 1) != 0;
     if (lane != 0) return;
     bool deg = false;
     const bool slow = !(stat == nullptr && not_degenerate_fast);
     if (slow) deg = eval_degeneracy_mem(ne, eig_thre, work);
     const bool frozen = freeze && (slow ? deg : false);
-    double d[6];
+    double d[6], rhs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
     bool ok = pd;
     if (ok) {
-        double rhs[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
-        chol6_substitute(L, inv_d, rhs, d);
+        chol6p_substitute(L, inv_d, rhs, d);
     } else {
-        double Hd[36], rhs[6];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) Hd[i] = H[i] + (((i % 7) == 0) ? 1e-6 : 0.0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rhs[i] = -ne[NE_G + i];
-        ok = chol6_solve(Hd, rhs, d);
+        pack_lower_from_ne(ne, -1e-6, L);                  // H + 1e-6 I
+        ok = chol6p_factor(L, inv_d);
+        if (ok) chol6p_substitute(L, inv_d, rhs, d);
     }
     if (ok && !frozen) {
         double xn[7];
