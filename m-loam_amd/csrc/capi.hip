@@ -1,6 +1,7 @@
 // extern "C" surface of libmloam_hip.so (see include/mloam_hip.h for the contract and the reference interfaces each
 // entry point replaces). Host logic only: staging, launch sequencing, result unpacking.
 #include "ctx.hpp"
+#include <chrono>
 #include <cstdlib>
 #include "dev_math.hpp"
 #include <algorithm>
@@ -125,16 +126,84 @@ static int ensure_state(mlh_ctx *ctx, int n_stats)
     return MLH_OK;
 }
 
+// ---- host <-> device hand-over of the pose without copy engines or blocking waits
+// In: the pose travels in the kernel-argument segment of a one-wavefront launch that also resets the solver state (no staging
+// buffer, no hipMemcpyAsync set-up latency, nothing for the host to wait on). Out: a one-wavefront launch writes the pose(s) into
+// pinned host memory and then stores a sequence number with system-scope release; the host spins on that word (acquire) --
+// microseconds instead of the tens of microseconds an interrupt-driven hipStreamSynchronize wake-up costs per frame.
+struct PoseArg { double p[7]; };
+struct HostPublish {
+    double x[7];
+    double xb[8][7];
+    unsigned long long seq;
+};
+
+__global__ void init_state_kernel(SolverState *S, PoseArg pose)
+{
+    double *w = reinterpret_cast<double *>(S);
+    for (int i = threadIdx.x; i < int(sizeof(SolverState) / sizeof(double)); i += blockDim.x) w[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 7) { S->x[threadIdx.x] = pose.p[threadIdx.x]; S->cand[threadIdx.x] = pose.p[threadIdx.x]; }
+    if (threadIdx.x < 6) S->V[threadIdx.x * 7] = 1.0;
+}
+
+__global__ void set_block_pose_kernel(SolverState *S, int b, PoseArg pose)
+{
+    if (threadIdx.x < 7) S->xb[b][threadIdx.x] = pose.p[threadIdx.x];
+}
+
+__global__ void publish_kernel(const SolverState *S, HostPublish *h, unsigned long long seq)
+{
+    if (threadIdx.x < 7) h->x[threadIdx.x] = S->x[threadIdx.x];
+    if (threadIdx.x < 56) h->xb[threadIdx.x / 7][threadIdx.x % 7] = S->xb[threadIdx.x / 7][threadIdx.x % 7];
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static int upload_pose(mlh_ctx *ctx, const double pose[7])
 {
-    // identity V_update, pose into x and cand; staged through a pinned buffer so the copy is truly asynchronous
-    if (!ctx->h_state) MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, sizeof(SolverState), hipHostMallocDefault));
-    else MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the previous upload may still be reading the staging buffer
-    SolverState &h = *static_cast<SolverState *>(ctx->h_state);
-    std::memset(&h, 0, sizeof(h));
-    for (int i = 0; i < 7; ++i) { h.x[i] = pose[i]; h.cand[i] = pose[i]; }
-    for (int i = 0; i < 6; ++i) h.V[i * 6 + i] = 1.0;
-    MLH_HIP(ctx, hipMemcpyAsync(ctx->state.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    static_assert(sizeof(SolverState) % sizeof(double) == 0, "SolverState is cleared in doubles");
+    PoseArg a;
+    for (int i = 0; i < 7; ++i) a.p[i] = pose[i];
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), a);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+static int upload_block_pose(mlh_ctx *ctx, int b, const double pose[7])
+{
+    PoseArg a;
+    for (int i = 0; i < 7; ++i) a.p[i] = pose[i];
+    hipLaunchKernelGGL(set_block_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), b, a);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+// enqueue the publication of the pose(s) and wait for it; every kernel enqueued before has completed when this returns
+static int fetch_published(mlh_ctx *ctx, HostPublish &out)
+{
+    if (!ctx->h_state) {
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, sizeof(HostPublish), hipHostMallocDefault));
+        std::memset(ctx->h_state, 0, sizeof(HostPublish));
+    }
+    HostPublish *h = static_cast<HostPublish *>(ctx->h_state);
+    const unsigned long long seq = ++ctx->publish_seq;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), h, seq);
+    MLH_HIP(ctx, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+            // not the fast case (a long LM run, a profiler, a fault): fall back to the blocking wait, which also surfaces errors
+            MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "pose publication did not arrive");
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    out = *h;
     return MLH_OK;
 }
 
@@ -600,15 +669,22 @@ static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pos
 
 static int fetch_pose_and_stats(mlh_ctx *ctx, double pose[7], mlh_iter_stat *stats, int n_stats)
 {
+    if (!stats || n_stats <= 0) {
+        HostPublish hp;
+        int rc = fetch_published(ctx, hp);
+        if (rc) return rc;
+        if (!ctx->prof.pending.empty()) prof_collect(ctx);     // their events precede the publication in stream order: complete
+        for (int i = 0; i < 7; ++i) pose[i] = hp.x[i];
+        return MLH_OK;
+    }
     SolverState hs;
-    std::vector<IterStatDev> hd(stats ? n_stats : 0);
+    std::vector<IterStatDev> hd(n_stats);
     MLH_HIP(ctx, hipMemcpyAsync(&hs, ctx->state.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-    if (stats && n_stats > 0)
-        MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * size_t(n_stats), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * size_t(n_stats), hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     for (int i = 0; i < 7; ++i) pose[i] = hs.x[i];
-    for (int i = 0; stats && i < n_stats; ++i) copy_stat(hd[i], stats[i]);
+    for (int i = 0; i < n_stats; ++i) copy_stat(hd[i], stats[i]);
     return MLH_OK;
 }
 
@@ -650,8 +726,7 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
     int rc = ensure_state(ctx, n_iters * nb);
     if (rc) return rc;
     if ((rc = upload_pose(ctx, poses_inout))) return rc;
-    SolverState *S = ctx->state.as<SolverState>();
-    if (nb > 1) MLH_HIP(ctx, hipMemcpyAsync(&S->xb[1][0], poses_inout + 7, sizeof(double) * 7 * (nb - 1), hipMemcpyHostToDevice, ctx->stream));
+    for (int b = 1; b < nb; ++b) if ((rc = upload_block_pose(ctx, b, poses_inout + 7 * b))) return rc;
     const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
     if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
     for (int it = 0; it < n_iters; ++it) {
@@ -662,11 +737,11 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
         a.stat_slot = stats ? it * nb : -1;
         if ((rc = match_launch(ctx, a))) return rc;
     }
-    SolverState hs;
+    HostPublish hs;
     std::vector<IterStatDev> hd(stats ? size_t(n_iters) * nb : 0);
-    MLH_HIP(ctx, hipMemcpyAsync(&hs, ctx->state.p, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
     if (stats) MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * hd.size(), hipMemcpyDeviceToHost, ctx->stream));
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = fetch_published(ctx, hs))) return rc;
+    if (stats) MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     for (int i = 0; i < 7; ++i) poses_inout[i] = hs.x[i];
     for (int b = 1; b < nb; ++b) for (int i = 0; i < 7; ++i) poses_inout[7 * b + i] = hs.xb[b][i];

@@ -178,7 +178,8 @@ struct mlh_ctx {
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
-    void *h_state = nullptr; // pinned staging for the solver-state upload
+    void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
+    unsigned long long publish_seq = 0;
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;
     mlh::OdomSet odom;

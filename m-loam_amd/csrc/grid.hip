@@ -112,14 +112,33 @@ __global__ __launch_bounds__(256) void zero_cells_kernel(GridJobs G)
     zero_chunk(J.cell_start, J.ncell, job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x);
 }
 
-// per-cell counts land in cell_start[c + 1]; the value the atomic returns is the point's rank inside its cell
+// per-cell counts land in cell_start[c + 1]; the value the atomic returns is the point's rank inside its cell.
+// Device-scope atomics execute at the memory side on a multi-XCD part and bound this kernel, so lanes are merged first: the
+// map arrives ordered by voxel index, x fastest (it is the output of the voxel filter), i.e. neighbouring lanes usually fall
+// into the same cell -- every run of equal cells inside a wavefront issues ONE atomic for the whole run (a cloud in random
+// order degrades to one atomic per lane, as before).
 __global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
 {
     const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
-    for (int i = b * 256 + threadIdx.x; i < J.n; i += J.nb_pts * 256)
-        J.rank[i] = atomicAdd(&J.cell_start[cell_of(J, J.raw[i]) + 1], 1);
+    const int lane = threadIdx.x & 63;
+    for (int base = b * 256; base < J.n; base += J.nb_pts * 256) {       // uniform over the workgroup
+        const int i = base + threadIdx.x;
+        const bool valid = i < J.n;
+        const int c = valid ? cell_of(J, J.raw[i]) : -1 - lane;           // distinct negatives: never merged
+        const int prev = __shfl_up(c, 1);
+        const bool head = (lane == 0) || (c != prev);
+        const unsigned long long H = __ballot(head);
+        const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const int my_head = 63 - __clzll(H & upto);
+        const unsigned long long above = (my_head == 63) ? 0ull : (H & ~((2ull << my_head) - 1ull));
+        const int next = above ? (__ffsll((long long)above) - 1) : 64;
+        int first = 0;
+        if (head && valid) first = atomicAdd(&J.cell_start[c + 1], next - my_head);
+        first = __shfl(first, my_head);
+        if (valid) J.rank[i] = first + (lane - my_head);
+    }
 }
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &total)
