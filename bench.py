@@ -193,8 +193,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region (2 events per launch)
+    # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one of its GN_ITERS
+    # launches per step (the first iteration's), because an event pair costs ~6 us of queue time of its own -- bracketing all
+    # five would slow the measured step by ~17 %
     ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
+    ctx.profile_sample(GN_ITERS)
     ctx.profile_reset()
     sync_all()
     t_start = time.perf_counter()
@@ -204,6 +207,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     knn_ms, knn_n = ctx.profile_get(mla.K_KNN)
     ctx.profile_enable(0)
+    ctx.profile_sample(1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -270,13 +274,13 @@ def main():
                                scan_features_thinned=not args.dense_features,
                                map_index_rebuilt_every_step=not args.no_map_rebuild,
                                parallelism=("1 GPU" if world == 1 else f"map sharded in {world} angular wedges + RCCL all-reduce of 32 f64/iter"),
-                               hip_events_in_timed_region=("dominant kernel only" if args.profile_events else "none")),
+                               hip_events_in_timed_region=("dominant kernel, 1 launch per step" if args.profile_events else "none")),
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
-                                                         ("map_index_build (both maps, 6 launches)", mla.K_GRID_BUILD))},
+                                                         ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    extract_ms_per_lidar_scan=[round(x, 4) for x in extract_ms],
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    final_pose=[round(float(x), 9) for x in pose],

@@ -73,6 +73,8 @@ enum {
 };
 /* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);
+/* bracket only every n-th launch of a single-kernel id (an event pair costs host + queue time of its own); default 1 */
+int mlh_profile_sample(mlh_ctx *ctx, int every_n);
 int mlh_profile_reset(mlh_ctx *ctx);
 int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
 

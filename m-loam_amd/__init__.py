@@ -76,6 +76,7 @@ def load_library():
     lib.mlh_stream.restype = vp
     lib.mlh_synchronize.argtypes = [vp]
     lib.mlh_profile_enable.argtypes = [vp, ci]
+    lib.mlh_profile_sample.argtypes = [vp, ci]
     lib.mlh_profile_reset.argtypes = [vp]
     lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
     lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, vp, vp, ci, ci]
@@ -115,7 +116,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
-    "mlh_profile_enable", "mlh_profile_reset", "mlh_profile_get",
+    "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
@@ -187,6 +188,9 @@ class Context:
         if kernel_mask is True:
             kernel_mask = K_ALL
         self._ck(self.lib.mlh_profile_enable(self.h, int(kernel_mask)))
+
+    def profile_sample(self, every_n=1):
+        self._ck(self.lib.mlh_profile_sample(self.h, int(every_n)))
 
     def profile_reset(self):
         self._ck(self.lib.mlh_profile_reset(self.h))

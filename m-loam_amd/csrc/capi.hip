@@ -50,6 +50,7 @@ void prof_end(mlh_ctx *ctx, int id)
 bool prof_kernel_events(mlh_ctx *ctx, int id, hipEvent_t *start, hipEvent_t *stop)
 {
     if (!(ctx->prof.mask & (1u << id))) return false;
+    if ((ctx->prof.seen[id]++ % ctx->prof.every) != 0) return false;
     Profile::Pending pd;
     pd.id = id; pd.a = prof_event(ctx); pd.b = prof_event(ctx);
     if (!pd.a || !pd.b) return false;
@@ -132,12 +133,6 @@ static int ensure_state(mlh_ctx *ctx, int n_stats)
 // pinned host memory and then stores a sequence number with system-scope release; the host spins on that word (acquire) --
 // microseconds instead of the tens of microseconds an interrupt-driven hipStreamSynchronize wake-up costs per frame.
 struct PoseArg { double p[7]; };
-struct HostPublish {
-    double x[7];
-    double xb[8][7];
-    unsigned long long seq;
-};
-
 __global__ void init_state_kernel(SolverState *S, PoseArg pose)
 {
     double *w = reinterpret_cast<double *>(S);
@@ -179,17 +174,22 @@ static int upload_block_pose(mlh_ctx *ctx, int b, const double pose[7])
     return MLH_OK;
 }
 
-// enqueue the publication of the pose(s) and wait for it; every kernel enqueued before has completed when this returns
-static int fetch_published(mlh_ctx *ctx, HostPublish &out)
+// the pinned record and the next sequence number (allocated on first use)
+static int publish_slot(mlh_ctx *ctx, HostPublish **h, unsigned long long *seq)
 {
     if (!ctx->h_state) {
         MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, sizeof(HostPublish), hipHostMallocDefault));
         std::memset(ctx->h_state, 0, sizeof(HostPublish));
     }
+    *h = static_cast<HostPublish *>(ctx->h_state);
+    *seq = ++ctx->publish_seq;
+    return MLH_OK;
+}
+
+// spin until the device has stored `seq`; every kernel enqueued before the publishing one has completed when this returns
+static int wait_published(mlh_ctx *ctx, unsigned long long seq, HostPublish &out)
+{
     HostPublish *h = static_cast<HostPublish *>(ctx->h_state);
-    const unsigned long long seq = ++ctx->publish_seq;
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), h, seq);
-    MLH_HIP(ctx, hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -205,6 +205,18 @@ static int fetch_published(mlh_ctx *ctx, HostPublish &out)
     }
     out = *h;
     return MLH_OK;
+}
+
+// enqueue a stand-alone publication of the pose(s) and wait for it
+static int fetch_published(mlh_ctx *ctx, HostPublish &out)
+{
+    HostPublish *h;
+    unsigned long long seq;
+    int rc = publish_slot(ctx, &h, &seq);
+    if (rc) return rc;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), h, seq);
+    MLH_HIP(ctx, hipGetLastError());
+    return wait_published(ctx, seq, out);
 }
 
 static void copy_stat(const IterStatDev &d, mlh_iter_stat &o)
@@ -284,6 +296,14 @@ int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask)
 {
     if (!ctx) return MLH_ERR_INVALID;
     ctx->prof.mask = unsigned(kernel_mask) & ((1u << MLH_K_COUNT) - 1u);
+    return MLH_OK;
+}
+
+int mlh_profile_sample(mlh_ctx *ctx, int every_n)
+{
+    if (!ctx || every_n < 1) return MLH_ERR_INVALID;
+    ctx->prof.every = every_n;
+    for (int i = 0; i < MLH_K_COUNT; ++i) ctx->prof.seen[i] = 0;
     return MLH_OK;
 }
 
@@ -694,15 +714,24 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, n_iters);
     if (rc) return rc;
-    if ((rc = upload_pose(ctx, pose_inout))) return rc;
     const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
     if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    // the pose goes in with the first iteration's kernel arguments and (single GPU, no statistics wanted) comes back through
+    // pinned host memory written by the last iteration's finish: 2 launches per iteration and nothing else
+    unsigned long long seq = 0;
+    bool fused_publish = false;
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
+        if (it == 0) a.init_pose = pose_inout;
         if (!ctx->comm) {
             // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose
             a.finish = 1;
             a.stat_slot = stats ? it : -1;
+            if (it == n_iters - 1 && !stats) {
+                if ((rc = publish_slot(ctx, &a.publish, &seq))) return rc;
+                a.publish_seq = seq;
+                fused_publish = true;
+            }
             if ((rc = match_launch(ctx, a))) return rc;
         } else {
             // multi-GPU: the fit kernel's last workgroup leaves this rank's sums in the solver state, then ONE all-reduce of
@@ -712,6 +741,17 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
             if ((rc = comm_allreduce_state(ctx, 0))) return rc;
             if ((rc = gn_update_prereduced_launch(ctx, opts->map_eig_thre, stats ? it : -1))) return rc;
         }
+    }
+    if (fused_publish) {
+        HostPublish hp;
+        if ((rc = wait_published(ctx, seq, hp))) return rc;
+        if (!ctx->prof.pending.empty()) {
+            // the fit kernel that published may still be retiring: its own stop event (if one was requested) needs the stream to drain
+            if (ctx->prof.mask & ((1u << MLH_K_FIT) | (1u << MLH_K_SOLVE))) MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            prof_collect(ctx);
+        }
+        for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+        return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);
 }

@@ -54,6 +54,13 @@ struct SolverState {
     int pad;
 };
 
+// pinned host record the device writes the result pose(s) into; seq is stored last with system-scope release
+struct HostPublish {
+    double x[7];
+    double xb[8][7];
+    unsigned long long seq;
+};
+
 struct IterStatDev {        // mirrors mlh_iter_stat, written by the device-side update kernels
     int n_surf, n_corner, is_degenerate, lm_iterations, successful_steps, termination;
     double cost, final_cost;
@@ -155,6 +162,8 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
 
 struct Profile {
     unsigned mask = 0;     // bit k: bracket launches of kernel id k
+    int every = 1;         // bracket every n-th launch of a kernel id only (event pairs cost ~6 us of host/queue time each)
+    long long seen[MLH_K_COUNT] = {0};
     double total_ms[MLH_K_COUNT] = {0};
     long long launches[MLH_K_COUNT] = {0};
     struct Pending { int id; hipEvent_t a, b; };
@@ -245,6 +254,9 @@ struct MatchArgs {
     int k_neigh[8] = {5, 5, 5, 5, 5, 5, 5, 5};
     double eig_thre[8] = {100, 100, 100, 100, 100, 100, 100, 100};
     int freeze[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double *init_pose = nullptr;       // host: block 0's pose for this launch comes from the kernel arguments and is written to the state by the finish
+    HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
+    unsigned long long publish_seq = 0;
 };
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);

@@ -405,6 +405,10 @@ struct KParams {
     double thre_b[MAX_BLOCKS];   // eigen threshold per block
     int freeze_b[MAX_BLOCKS];    // 0: project the degenerate directions out (evalDegenracy); 1: do not update the block at all
     // fused Gauss-Newton finish: the last workgroup to arrive sums the partials, solves and updates the pose(s)
+    int use_init;            // block 0's pose is init_pose (first iteration of a solve: no separate upload launch)
+    double init_pose[7];
+    HostPublish *publish;    // the finish of the last iteration hands the result to the host through pinned memory
+    unsigned long long publish_seq;
     int knn_lanes;           // lanes per query of the correspondence kernel (8 or 16), chosen per launch
     int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU)
     unsigned *ticket;
@@ -421,6 +425,18 @@ __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f
 __device__ __forceinline__ const double *block_pose(const KParams &P, int b)
 {
     return b == 0 ? (P.pose_sel ? P.state->cand : P.state->x) : P.state->xb[b];
+}
+
+__device__ __forceinline__ void load_pose(const KParams &P, int b, q4 &q, d3 &t)
+{
+    if (P.use_init && b == 0) {            // uniform: straight from the kernel-argument segment
+        t = d3{P.init_pose[0], P.init_pose[1], P.init_pose[2]};
+        q = q4{P.init_pose[3], P.init_pose[4], P.init_pose[5], P.init_pose[6]};
+    } else {
+        const double *pose = block_pose(P, b);
+        t = d3{pose[0], pose[1], pose[2]};
+        q = q4{pose[3], pose[4], pose[5], pose[6]};
+    }
 }
 
 // pointAssociateToMap (utility.h:103-117): f64 q*p + t, stored to f32
@@ -481,9 +497,9 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
     const int b = MB ? block_of_slot(K, P.n_blocks, f) : 0;
-    const double *pose = block_pose(P, b);
-    const q4 q{pose[3], pose[4], pose[5], pose[6]};
-    const d3 t{pose[0], pose[1], pose[2]};
+    q4 q;
+    d3 t;
+    load_pose(P, b, q, t);
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
@@ -560,6 +576,7 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     if (!s_last) return;
     MLH_STAGE(4095, 0);
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (P.use_init && threadIdx.x < 7) P.state->x[threadIdx.x] = P.init_pose[threadIdx.x];   // the state's pose is born here
     __syncthreads();
     if (P.finish == 2) {
         // multi-GPU: only the local reduction happens here; the all-reduce and the (redundant, identical) solve follow
@@ -586,7 +603,14 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         __syncthreads();
         MLH_STAGE(4095, 2);
     }
-    if (threadIdx.x == 0) *P.ticket = 0u;
+    if (threadIdx.x == 0) {
+        *P.ticket = 0u;
+        if (P.publish) {
+            for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
+            for (int b = 1; b < P.n_blocks; ++b) for (int i = 0; i < 7; ++i) P.publish->xb[b][i] = P.state->xb[b][i];
+            __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int K>
@@ -618,9 +642,9 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     MLH_STAGE(gtile, 0);
     const int f = tile * TPB + threadIdx.x;
     const int b = block_of_slot(K, P.n_blocks, tile * TPB);       // uniform over the workgroup (blocks start on tile boundaries)
-    const double *pose = block_pose(P, b);
-    const q4 q{pose[3], pose[4], pose[5], pose[6]};
-    const d3 t{pose[0], pose[1], pose[2]};
+    q4 q;
+    d3 t;
+    load_pose(P, b, q, t);
     bool valid = false;
     Lin L;
     L.r = 0.0;
@@ -813,6 +837,10 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.has_hi = ctx->shard_hi ? 1 : 0;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
+    P.use_init = a.init_pose ? 1 : 0;
+    for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
+    P.publish = (a.finish == 1) ? a.publish : nullptr;
+    P.publish_seq = a.publish_seq;
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = (a.stat_slot >= 0) ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     return MLH_OK;
