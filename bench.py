@@ -228,6 +228,22 @@ def main():
     prof = {k: ctx.profile_get(k) for k in range(6)}
     ctx.profile_enable(0)
 
+    # supplementary: the reference's own per-frame call, scan2MapOptimization = index build + 2 outer x (match all, evalHessian +
+    # evalDegenracy, Ceres-shaped Levenberg-Marquardt <= 30 iterations) -- not `value`, reported beside it
+    s2m_ms = None
+    if world == 1:
+        for _ in range(3):
+            ctx.map_rebuild(mla.ALL_KINDS)
+            s2m_pose, s2m_stats = ctx.scan2map(p0, opts)
+        n_s2m = max(args.steps // 10, 5)
+        sync_all()
+        t2 = time.perf_counter()
+        for _ in range(n_s2m):
+            ctx.map_rebuild(mla.ALL_KINDS)
+            s2m_pose, s2m_stats = ctx.scan2map(p0, opts)
+        sync_all()
+        s2m_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
+
     # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
     #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)
     h = float(np.sqrt(opts.min_match_sq_dis)) * 1.001
@@ -285,6 +301,10 @@ def main():
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    final_pose=[round(float(x), 9) for x in pose],
                    roofline=roofline)
+        if s2m_ms is not None:
+            out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), lm_iterations=[int(st["lm_iterations"]) for st in s2m_stats],
+                                   note="supplementary: mlh_map_rebuild + mlh_scan2map (2 outer iterations, Ceres-shaped LM, Huber 0.1), "
+                                        "the call the reference makes once per frame (lidar_mapper_keyframe.cpp:423-639)")
 
     # --- CPU baseline: the oracle (port of the reference's CPU path), bounded sample, rank 0 at N = 1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -311,6 +331,14 @@ def main():
                                    all_cores=dict(cores=ncores, value=round(m_total * GN_ITERS / (r_all["seconds"] + tk_all), 1),
                                                   note="generous row: same code, OpenMP over features, kd-tree build still serial"),
                                    pose_agreement_m=float(np.linalg.norm(np.array(r["pose"][:3]) - np.array(pose[:3]))))
+        if "scan2map" in out:
+            import time as _t
+            t3 = _t.perf_counter()
+            tk3 = ms_.rebuild_seconds() + mc_.rebuild_seconds()
+            rs = O.scan2map(ms_, mc_, surf, corner, p0, prm)
+            out["scan2map"]["cpu_port_ms_per_frame"] = round(1e3 * (_t.perf_counter() - t3), 2)
+            out["scan2map"]["cpu_port_lm_iterations"] = [int(o["lm_iterations"]) for o in rs["outer"]]
+            out["scan2map"]["pose_agreement_m"] = float(np.linalg.norm(np.array(rs["pose"][:3]) - np.array(s2m_pose[:3])))
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -151,6 +151,7 @@ __global__ void publish_kernel(const SolverState *S, HostPublish *h, unsigned lo
 {
     if (threadIdx.x < 7) h->x[threadIdx.x] = S->x[threadIdx.x];
     if (threadIdx.x < 56) h->xb[threadIdx.x / 7][threadIdx.x % 7] = S->xb[threadIdx.x / 7][threadIdx.x % 7];
+    if (threadIdx.x == 63) h->done = S->done;
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -825,10 +826,9 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
                 if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 1)))) return rc;
                 if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
             }
-            int done = 0;
-            MLH_HIP(ctx, hipMemcpyAsync(&done, &ctx->state.as<SolverState>()->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (done) break;
+            HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
+            if ((rc = fetch_published(ctx, hp))) return rc;
+            if (hp.done) break;
         }
         if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
     }

@@ -58,6 +58,7 @@ struct SolverState {
 struct HostPublish {
     double x[7];
     double xb[8][7];
+    long long done;          // SolverState::done at publication (the LM driver polls it)
     unsigned long long seq;
 };
 
