@@ -240,7 +240,7 @@ def main():
         t2 = time.perf_counter()
         for _ in range(n_s2m):
             ctx.map_rebuild(mla.ALL_KINDS)
-            s2m_pose, s2m_stats = ctx.scan2map(p0, opts)
+            s2m_pose, _ = ctx.scan2map(p0, opts, want_stats=False)
         sync_all()
         s2m_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
 

@@ -282,7 +282,8 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
 /* scan2MapOptimization(): max_outer x { goodFeatureMatching (corner, then surf; wo_gf = all matched features),
  * evalHessian + evalDegenracy, Levenberg-Marquardt (Ceres trust-region semantics, <= max_lm_iterations) on the selected,
  * fixed correspondences }. Device-resident for wo_gf; the other gf methods add one host round trip per outer iteration for
- * the selection loop. replaces lidar_mapper_keyframe.cpp:423-639. stats: max_outer records. */
+ * the selection loop. replaces lidar_mapper_keyframe.cpp:423-639. stats: max_outer records, or NULL (then evalDegenracy takes
+ * the eigen-decomposition only when H - thre*I is not positive definite, i.e. when something IS degenerate). */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
 
 /* ---------------------------------------------------------------- (e) multi-GPU: map shards + one all-reduce per iteration

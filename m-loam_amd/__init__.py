@@ -424,9 +424,12 @@ class Context:
         self._ck(self.lib.mlh_gn_solve(self.h, _p(pose), n_iters, C.byref(opts), C.cast(stats, C.c_void_p) if want_stats else None))
         return pose, ([s.as_dict() for s in stats] if want_stats else None)
 
-    def scan2map(self, pose, opts: SolverOpts | None = None):
+    def scan2map(self, pose, opts: SolverOpts | None = None, want_stats=True):
         opts = opts or default_opts()
         pose = np.ascontiguousarray(pose, np.float64).copy()
+        if not want_stats:
+            self._ck(self.lib.mlh_scan2map(self.h, _p(pose), C.byref(opts), None))
+            return pose, None
         stats = (IterStat * opts.max_outer)()
         self._ck(self.lib.mlh_scan2map(self.h, _p(pose), C.byref(opts), C.cast(stats, C.c_void_p)))
         return pose, [s.as_dict() for s in stats]

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState 
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x >= 2) return;
-    gn_finish2(ne, cnt2, S->x, S, eig_thre, 0, stat, scratch);
+    gn_finish2<true>(ne, cnt2, S->x, S, eig_thre, 0, stat, scratch);
 }
 
 // reduce only: S->ne <- sum of partials (used by the host-driven mlh_match_linearize / mlh_linearize)
@@ -95,9 +95,17 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
-    bool deg = eval_degeneracy_mem(ne, eig_thre, scratch);
+    // evalDegenracy. Nobody asked for the eigenvalues (stat == null): H - thre*I positive definite <=> lambda_min > thre <=> nothing
+    // is degenerate, V_update = I -- one Cholesky factorisation instead of the eigen-decomposition; otherwise the full procedure.
+    bool deg = false, fast = false;
+    if (!stat) {
+        double L[21], inv_d[6];
+        pack_lower_from_ne(ne, eig_thre * (1.0 + 1e-9), L);
+        fast = chol6p_factor(L, inv_d);
+    }
+    if (!fast) deg = eval_degeneracy_reg(ne, eig_thre, scratch);
     for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
-    for (int i = 0; i < 36; ++i) S->V[i] = scratch[78 + i];
+    for (int i = 0; i < 36; ++i) S->V[i] = fast ? (((i % 7) == 0) ? 1.0 : 0.0) : scratch[78 + i];
     {
         int q = 0;
         for (int i = 0; i < 6; ++i) { S->S[i] = 1.0 / (1.0 + sqrt(ne[q])); q += 6 - i; }   // Jacobi scaling from diag(J^T J)

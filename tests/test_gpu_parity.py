@@ -542,3 +542,12 @@ def test_pure_odom_batch_parity(ctx, orc):
     np.testing.assert_allclose(r3, r[:10] / sq[:10], rtol=1e-13)
     with pytest.raises(Exception):
         ctx.pure_odom_evaluate(pivot, frames[: fi[:10].max()], exts)      # pose array shorter than the largest frame index
+
+
+def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
+    """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
+    _stage(ctx, mla, case16, feats16)
+    a, stats = ctx.scan2map(case16["p0"])
+    b, none = ctx.scan2map(case16["p0"], want_stats=False)
+    assert none is None and not any(s["is_degenerate"] for s in stats)
+    np.testing.assert_array_equal(a, b)
