@@ -197,7 +197,7 @@ def main():
     # launches per step (the first iteration's), because an event pair costs ~6 us of queue time of its own -- bracketing all
     # five would slow the measured step by ~17 %
     ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
-    ctx.profile_sample(GN_ITERS)
+    ctx.profile_sample(GN_ITERS + 1)
     ctx.profile_reset()
     sync_all()
     t_start = time.perf_counter()
