@@ -3,17 +3,30 @@
 //
 //   curvature_kernel  cpp:133-142  one thread per point, neighbours staged in LDS (21 B/point algorithmic HBM traffic);
 //                     f32 sum in the reference's exact left-to-right order, no FMA (-ffp-contract=off)
-//   label_kernel      cpp:152-265  one workgroup per ring: ring xyz + curvature + picked flags resident in LDS, all six
-//                     sectors sorted at once with a bitonic network on 64-bit (curvature, index) keys, then wave 0 runs the
-//                     greedy edge / flat walks: 64 sorted candidates are tested per step with a ballot, the first eligible
-//                     one is taken, its +-5 neighbour suppression is evaluated by 10 lanes with a ballot prefix. The walk is
-//                     sequential over sectors because suppression marks cross sector boundaries (cpp:201, 212).
+//   label_kernel      cpp:152-265  one workgroup (six wavefronts) per ring: ring xyz + curvature + picked flags resident in LDS;
+//                     wavefront j sorts sector j in registers with a wave-local bitonic network on 64-bit (curvature, index)
+//                     keys (lane-xor shuffles, no barriers); then wave 0 runs the
+//                     greedy edge / flat walks: 64 sorted candidates are tested per batch with a ballot, the first eligible
+//                     one is taken, its +-5 neighbour suppression comes from precomputed gap bits (two broadcast LDS words),
+//                     and the batch's other candidates are retired in registers. The walk is sequential over sectors
+//                     because suppression marks cross sector boundaries (cpp:201, 212).
 //   offsets_kernel    exclusive scan of the per-ring list sizes (emission order = ring asc, sector asc, pick order)
 //   emit_kernel       writes the four index lists; less-flat = positions with label <= 0 (cpp:258-264), stream-compacted.
 #include "ctx.hpp"
 #include <algorithm>
 
 namespace mlh {
+
+#ifdef MLH_STAGE_CLOCK
+__device__ unsigned long long g_stage_clk_label[256 * 8];
+#define MLH_LSTAGE(i)                                                                        \
+    do {                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_stage_clk_label[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MLH_LSTAGE(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void curvature_kernel(const float4 *__restrict__ pts, int n, float *__restrict__ curv,
                                                         int *__restrict__ label, int *__restrict__ picked)
@@ -61,21 +74,72 @@ __device__ __forceinline__ bool gap_exceeds(const float *sx, const float *sy, co
     return double(dx * dx + dy * dy + dz * dz) > 0.05;
 }
 
-// executed by all 64 lanes of wave 0; li = local index of the picked point
-__device__ __forceinline__ void suppress_neighbours(const float *sx, const float *sy, const float *sz, int *spicked, int li, int lane)
+constexpr int LTPB = 384;   // label kernel: six wavefronts, one per sector while sorting
+
+// Ascending bitonic sort of 64*KPL 64-bit keys held by ONE wavefront: lane l owns elements l*KPL .. l*KPL+KPL-1 in registers.
+// Exchange distances below KPL stay inside a lane (static register indices), the others are lane-xor shuffles: no LDS array,
+// no workgroup barrier -- the six sectors of a ring sort concurrently on six wavefronts.
+template <int KPL>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[KPL], int lane)
 {
-    bool gap = false;
-    if (lane < 5) gap = gap_exceeds(sx, sy, sz, li + lane + 1, li + lane);                // l = lane+1 : p[ind+l] - p[ind+l-1]
-    else if (lane >= 8 && lane < 13) gap = gap_exceeds(sx, sy, sz, li - (lane - 8) - 1, li - (lane - 8));   // l = -(lane-8)-1
-    const unsigned long long m = __ballot(gap);
-    const unsigned fwd = unsigned(m & 0x1full), bwd = unsigned((m >> 8) & 0x1full);
-    const int nf = fwd ? (__ffs(fwd) - 1) : 5;   // number of forward neighbours marked before the first gap
-    const int nb = bwd ? (__ffs(bwd) - 1) : 5;
-    if (lane < nf) spicked[li + lane + 1] = 1;
-    if (lane >= 8 && (lane - 8) < nb) spicked[li - (lane - 8) - 1] = 1;
+#pragma unroll
+    for (int k = 2; k <= 64 * KPL; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= KPL) {
+                const int lx = j / KPL;                          // partner lane = lane ^ lx
+                const bool lower = (lane & lx) == 0;
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    const bool up = (((lane * KPL + r) & k) == 0);
+                    const unsigned long long a = v[r];
+                    unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+                    lo = __shfl_xor(lo, lx); hi = __shfl_xor(hi, lx);
+                    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
+                    const bool take_min = (lower == up);
+                    v[r] = take_min ? (a < b ? a : b) : (a < b ? b : a);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    if ((r & j) == 0) {
+                        const bool up = (((lane * KPL + r) & k) == 0);
+                        const unsigned long long a = v[r], b = v[r | j];
+                        const bool sw = (a > b) == up;
+                        v[r] = sw ? b : a;
+                        v[r | j] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void label_kernel(LabelArgs A)
+// one sector: build the keys in registers, sort, store the sorted list to LDS for the walks
+template <int KPL>
+__device__ __forceinline__ void sort_sector(const float *sc, int sp, int len, unsigned long long *kj, int lane)
+{
+    unsigned long long v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int k = lane * KPL + r;
+        unsigned long long key = ~0ull;                          // padding sorts to the end
+        if (k < len) {
+            const int li = sp + k;
+            key = ((unsigned long long)__float_as_uint(sc[li]) << 32) | (unsigned)li;
+        }
+        v[r] = key;
+    }
+    wave_bitonic_sort<KPL>(v, lane);
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) kj[lane * KPL + r] = v[r];
+}
+
+// Suppression of a pick's +-5 neighbours (cpp:192-213, 233-254): how far the marks reach (nf forwards, nb backwards: up to the first
+// consecutive-point gap > 0.05, at most 5) depends only on the geometry, so it is tabulated for every position of the ring before
+// the walks (sext[t] = nf | nb << 4); a candidate lane brings its entry along and a pick costs no LDS read at all.
+
+__global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ring = blockIdx.x;
@@ -85,6 +149,7 @@ __global__ __launch_bounds__(256) void label_kernel(LabelArgs A)
         if (threadIdx.x < 4) rc[threadIdx.x] = 0;
         return;
     }
+    MLH_LSTAGE(0);
     const int span = e - s + 11;           // [s-5, e+5]
     const int g0 = s - 5;                  // global index of local 0
     const int P = A.sort_p;
@@ -95,10 +160,12 @@ __global__ __launch_bounds__(256) void label_kernel(LabelArgs A)
     int *spicked = reinterpret_cast<int *>(sc + A.max_span);
     int *slabel = spicked + A.max_span;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(slabel + A.max_span + ((A.max_span & 1) ? 1 : 0));
+    unsigned *sgap = reinterpret_cast<unsigned *>(keys + 6 * size_t(P));     // gap bits, (max_span + 64 + 383) / 32 + 4 words
+    unsigned char *sext = reinterpret_cast<unsigned char *>(sgap + (A.max_span + 64 + 383) / 32 + 4);   // suppression extents, max_span bytes
     __shared__ int s_stage[STAGE_STRIDE];
     __shared__ int s_cnt[4];
 
-    for (int t = threadIdx.x; t < span; t += 256) {
+    for (int t = threadIdx.x; t < span; t += LTPB) {
         float4 p = A.pts[g0 + t];
         sx[t] = p.x; sy[t] = p.y; sz[t] = p.z;
         sc[t] = A.curv[g0 + t];
@@ -114,101 +181,128 @@ __global__ __launch_bounds__(256) void label_kernel(LabelArgs A)
         ep[j] = s + (e - s) * (j + 1) / 6 - 1 - g0;
     }
     __syncthreads();
-    // keys: (curvature bits << 32) | local index, padded with all-ones
-    for (int t = threadIdx.x; t < 6 * P; t += 256) {
-        const int j = t / P, k = t - j * P;
-        const int len = ep[j] - sp[j] + 1;
-        unsigned long long key = ~0ull;
-        if (k < len) {
-            const int li = sp[j] + k;
-            key = ((unsigned long long)__float_as_uint(sc[li]) << 32) | (unsigned)li;
-        }
-        keys[t] = key;
+    MLH_LSTAGE(1);
+    // gap bits: bit t = squared distance between local t and t + 1 exceeds 0.05 (cpp:196, 206, 237, 247; the literal is a double)
+    for (int base = 0; base < span + 64; base += LTPB) {      // uniform trip count: every wavefront ballots 64 positions per trip
+        const int t = base + threadIdx.x;
+        const bool gap = (t + 1 < span) && gap_exceeds(sx, sy, sz, t + 1, t);
+        const unsigned long long m = __ballot(gap);
+        if ((threadIdx.x & 63) == 0) { sgap[t >> 5] = unsigned(m); sgap[(t >> 5) + 1] = unsigned(m >> 32); }
     }
     __syncthreads();
-    // bitonic sort, ascending, all sectors at once (segments of P are independent because every stride divides P)
-    const int half = 3 * P;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j cleared
-                const int ixj = i | j;
-                const bool up = (((i & (P - 1)) & k) == 0);             // ascending block (direction relative to the sector's segment)
-                unsigned long long a = keys[i], b = keys[ixj];
-                if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-            }
-            __syncthreads();
+    // suppression extents of every position that can be picked (local 5 .. span-6)
+    for (int t = threadIdx.x; t < span; t += LTPB) {
+        unsigned char ext = 0;
+        if (t >= 5 && t + 5 < span) {
+            const int b0 = t - 5;                                 // window: gap bits [t-5, t+4]
+            const unsigned long long w = (unsigned long long)sgap[b0 >> 5] | ((unsigned long long)sgap[(b0 >> 5) + 1] << 32);
+            const unsigned bits = unsigned(w >> (b0 & 31)) & 0x3ffu;
+            const unsigned fwd = (bits >> 5) & 31u, bwd = bits & 31u;   // fwd bit l-1: gap(t+l, t+l-1); bwd bit 5-l: gap(t-l, t-l+1)
+            const int nf = fwd ? (__ffs(fwd) - 1) : 5;
+            const int nb = bwd ? (4 - (31 - __clz(bwd))) : 5;
+            ext = (unsigned char)(nf | (nb << 4));
+        }
+        sext[t] = ext;
+    }
+    MLH_LSTAGE(2);
+    // sort: wavefront j sorts sector j in registers (keys: (curvature bits << 32) | local index), result to keys[j * P ..]
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int len = ep[wave] - sp[wave] + 1;
+        unsigned long long *kj = keys + wave * P;
+        switch (P >> 6) {
+        case 1: sort_sector<1>(sc, sp[wave], len, kj, lane); break;
+        case 2: sort_sector<2>(sc, sp[wave], len, kj, lane); break;
+        case 4: sort_sector<4>(sc, sp[wave], len, kj, lane); break;
+        case 8: sort_sector<8>(sc, sp[wave], len, kj, lane); break;
+        case 16: sort_sector<16>(sc, sp[wave], len, kj, lane); break;
+        default: sort_sector<32>(sc, sp[wave], len, kj, lane); break;
         }
     }
-    // greedy walks: wave 0 only
+    __syncthreads();
+    MLH_LSTAGE(3);
+    // greedy walks: wave 0 only. Per pick the loop does register work plus ONE predicated LDS store (the suppression marks):
+    // the picks themselves are parked in lane registers (lane p keeps the p-th pick) and labelled / staged after the walk.
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
+        const int off = lane - 5;                                  // lanes 0..10 cover the positions sel-5 .. sel+5
         int n_sharp = 0, n_less = 0, n_flat = 0;
         for (int j = 0; j < 6; ++j) {
             const int len = ep[j] - sp[j] + 1;
             const unsigned long long *kj = keys + j * P;
-            // ---- edge walk, descending curvature (cpp:166-215)
-            int largest_picked_num = 0;
+            // ---- edge walk, descending curvature (cpp:166-215): picks 1-2 sharp, 3-20 less sharp, the 21st candidate ends it unlabelled
+            int npick = 0, my_pick = 0;
             bool stop = false;
             for (int base = len - 1; base >= 0 && !stop; base -= 64) {
                 const int k = base - lane;
                 const int li = (k >= 0) ? int(unsigned(kj[k])) : 0;
                 const bool c_ok = (k >= 0) && (double(sc[li]) > 0.1);
-                while (true) {
-                    const bool elig = c_ok && (spicked[li] == 0);
-                    const unsigned long long m = __ballot(elig);
-                    if (!m) break;
+                const int ext = sext[li];
+                bool elig = c_ok && (spicked[li] == 0);            // one LDS look per batch; picks inside the batch retire lanes in registers
+                unsigned long long m = __ballot(elig);
+                while (m) {
+                    if (npick == 20) { stop = true; break; }
                     const int l = __ffsll((long long)m) - 1;
-                    const int sel = __shfl(li, l);
-                    largest_picked_num++;
-                    if (largest_picked_num <= 2) {
-                        if (lane == 0) { slabel[sel] = 2; s_stage[n_sharp] = sel + g0; s_stage[STAGE_SHARP + n_less] = sel + g0; }
-                        n_sharp++; n_less++;
-                    } else if (largest_picked_num <= 20) {
-                        if (lane == 0) { slabel[sel] = 1; s_stage[STAGE_SHARP + n_less] = sel + g0; }
-                        n_less++;
-                    } else { stop = true; break; }
-                    if (lane == 0) spicked[sel] = 1;
-                    suppress_neighbours(sx, sy, sz, spicked, sel, lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+                    const int sel = __builtin_amdgcn_readlane(li, l);
+                    const int xe = __builtin_amdgcn_readlane(ext, l);
+                    const int nf = xe & 15, nb = xe >> 4;
+                    my_pick = (lane == npick) ? sel : my_pick;
+                    npick++;
+                    if (lane < 11 && off >= -nb && off <= nf) spicked[sel + off] = 1;   // the pick and its neighbours up to the first gap
+                    elig = elig && !(li >= sel - nb && li <= sel + nf);
+                    m = __ballot(elig);
                 }
+                __builtin_amdgcn_wave_barrier();
                 // sorted descending: once a candidate fails c > 0.1 every later one fails too
                 const unsigned long long inb = __ballot(k >= 0);
                 if (__ballot(c_ok) != inb) stop = true;
             }
-            // ---- flat walk, ascending curvature (cpp:219-256)
-            int smallest_picked_num = 0;
+            if (lane < npick) {
+                slabel[my_pick] = (lane < 2) ? 2 : 1;
+                if (lane < 2) s_stage[n_sharp + lane] = my_pick + g0;
+                s_stage[STAGE_SHARP + n_less + lane] = my_pick + g0;
+            }
+            n_sharp += npick < 2 ? npick : 2;
+            n_less += npick;
+            // ---- flat walk, ascending curvature (cpp:219-256): 4 picks; the 4th is labelled but neither marked nor suppressing
+            int nfl = 0, my_flat = 0;
             stop = false;
             for (int base = 0; base < len && !stop; base += 64) {
                 const int k = base + lane;
                 const int li = (k < len) ? int(unsigned(kj[k])) : 0;
                 const bool c_ok = (k < len) && (double(sc[li]) < 0.1);
-                while (true) {
-                    const bool elig = c_ok && (spicked[li] == 0);
-                    const unsigned long long m = __ballot(elig);
-                    if (!m) break;
+                const int ext = sext[li];
+                bool elig = c_ok && (spicked[li] == 0);
+                unsigned long long m = __ballot(elig);
+                while (m) {
                     const int l = __ffsll((long long)m) - 1;
-                    const int sel = __shfl(li, l);
-                    if (lane == 0) { slabel[sel] = -1; s_stage[STAGE_SHARP + STAGE_LESS + n_flat] = sel + g0; }
-                    n_flat++;
-                    smallest_picked_num++;
-                    if (smallest_picked_num >= 4) { stop = true; break; }
-                    if (lane == 0) spicked[sel] = 1;
-                    suppress_neighbours(sx, sy, sz, spicked, sel, lane);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+                    const int sel = __builtin_amdgcn_readlane(li, l);
+                    my_flat = (lane == nfl) ? sel : my_flat;
+                    nfl++;
+                    if (nfl >= 4) { stop = true; break; }
+                    const int xe = __builtin_amdgcn_readlane(ext, l);
+                    const int nf = xe & 15, nb = xe >> 4;
+                    if (lane < 11 && off >= -nb && off <= nf) spicked[sel + off] = 1;
+                    elig = elig && !(li >= sel - nb && li <= sel + nf);
+                    m = __ballot(elig);
                 }
+                __builtin_amdgcn_wave_barrier();
                 const unsigned long long inb = __ballot(k < len);
                 if (__ballot(c_ok) != inb) stop = true;
             }
+            if (lane < nfl) {
+                slabel[my_flat] = -1;
+                s_stage[STAGE_SHARP + STAGE_LESS + n_flat + lane] = my_flat + g0;
+            }
+            n_flat += nfl;
         }
         if (lane == 0) { s_cnt[0] = n_sharp; s_cnt[1] = n_less; s_cnt[2] = n_flat; }
+        MLH_LSTAGE(4);
     }
     __syncthreads();
     // write back labels / picked, count less-flat (label <= 0 over [s, e-1])
     int my_lf = 0;
-    for (int t = threadIdx.x; t < span; t += 256) {
+    for (int t = threadIdx.x; t < span; t += LTPB) {
         const int gi = g0 + t;
         if (spicked[t]) A.picked[gi] = 1;
         if (gi >= s && gi <= e - 1) {
@@ -220,10 +314,20 @@ __global__ __launch_bounds__(256) void label_kernel(LabelArgs A)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) my_lf += __shfl_xor(my_lf, off);
     if ((threadIdx.x & 63) == 0 && my_lf) atomicAdd(&s_cnt[3], my_lf);
-    for (int t = threadIdx.x; t < STAGE_STRIDE; t += 256) A.stage[ring * STAGE_STRIDE + t] = s_stage[t];
+    for (int t = threadIdx.x; t < STAGE_STRIDE; t += LTPB) A.stage[ring * STAGE_STRIDE + t] = s_stage[t];
     __syncthreads();
     if (threadIdx.x < 4) rc[threadIdx.x] = s_cnt[threadIdx.x];
+    MLH_LSTAGE(5);
 }
+
+#ifdef MLH_STAGE_CLOCK
+}  // namespace mlh
+extern "C" int mlh_debug_stage_clock_label(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_label), sizeof(unsigned long long) * size_t(n_words));
+}
+namespace mlh {
+#endif
 
 // exclusive scan over rings of the 4 list sizes; single workgroup
 __global__ __launch_bounds__(256) void offsets_kernel(const int *__restrict__ ring_counts, int n_rings, int *__restrict__ ring_offsets,
@@ -299,7 +403,8 @@ int extract_run(mlh_ctx *ctx)
     int max_sector = (sb.max_ring_len + 5) / 6 + 1;
     int P = 64;
     while (P < max_sector) P <<= 1;
-    const size_t lds = sizeof(float) * 4 * size_t(max_span) + sizeof(int) * 2 * size_t(max_span) + 8 + sizeof(unsigned long long) * 6 * size_t(P);
+    const size_t lds = sizeof(float) * 4 * size_t(max_span) + sizeof(int) * 2 * size_t(max_span) + 8 + sizeof(unsigned long long) * 6 * size_t(P) +
+                       sizeof(unsigned) * (size_t(max_span + 64 + 383) / 32 + 4) + size_t(max_span) + 16;
     if (lds > 160 * 1024 - 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring too long for the LDS-resident label kernel");
     MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(label_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 
@@ -310,7 +415,8 @@ int extract_run(mlh_ctx *ctx)
     la.pts = sb.pts.as<float4>(); la.curv = sb.curvature.as<float>(); la.start = sb.start.as<int>(); la.end = sb.end.as<int>();
     la.label = sb.label.as<int>(); la.picked = sb.picked.as<int>(); la.stage = sb.stage.as<int>(); la.ring_counts = sb.ring_counts.as<int>();
     la.n = n; la.max_span = max_span; la.sort_p = P;
-    hipLaunchKernelGGL(label_kernel, dim3(R), dim3(256), lds, st, la);
+    if (P > 2048) return fail(ctx, MLH_ERR_UNSUPPORTED, "sector longer than 2048 points");
+    hipLaunchKernelGGL(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, st, sb.ring_counts.as<int>(), R, sb.ring_offsets.as<int>(), sb.totals.as<int>());
     EmitArgs ea;
     ea.start = sb.start.as<int>(); ea.end = sb.end.as<int>(); ea.label = sb.label.as<int>(); ea.stage = sb.stage.as<int>();
