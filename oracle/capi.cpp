@@ -4,6 +4,7 @@
 #include "feature_extract.hpp"
 #include "mapper.hpp"
 #include "uct.hpp"
+#include "tracker.hpp"
 #include "linalg.hpp"
 #include <cstring>
 #include <chrono>
@@ -331,6 +332,61 @@ int orc_cloud_uct_associate_to_map(const float *pts11, int n, const double *pose
                                with_ua != 0, trace_threshold, o);
     std::memcpy(out11, o.data(), sizeof(PointICov) * o.size());
     *n_out = (int)o.size();
+    return 0;
+}
+
+// ---- scan-to-scan tracker (next row 4)
+static TrackParams make_track_params(const double *p)
+{
+    TrackParams t;
+    t.distance_sq_threshold = float(p[0]); t.nearby_scan = float(p[1]); t.scan_period = float(p[2]); t.huber_delta = p[3];
+    t.max_outer = int(p[4]); t.max_lm_iterations = int(p[5]);
+    return t;
+}
+
+// kind 'c' / 's'; prev, cur: n x 4 [x y z ring]; outputs: valid[m], coeffs[m*6]
+int orc_track_match(char kind, const float *prev, int n_prev, const float *cur, int m, const double *pose7, const double *tprm,
+                    unsigned char *valid, double *coeffs)
+{
+    ScanCloud sc;
+    sc.set(prev, 4, n_prev);
+    const TrackParams tp = make_track_params(tprm);
+    std::vector<Feature> f;
+    if (kind == 'c') match_corner_from_scan(sc, cur, 4, m, pose_from_param(pose7), tp, f);
+    else match_surf_from_scan(sc, cur, 4, m, pose_from_param(pose7), tp, f);
+    std::memset(valid, 0, size_t(m));
+    std::memset(coeffs, 0, sizeof(double) * 6 * size_t(m));
+    for (const Feature &ft : f) { valid[ft.idx] = 1; std::memcpy(coeffs + ft.idx * 6, ft.coeffs, sizeof(double) * 6); }
+    return (int)f.size();
+}
+
+// type 'S' (scan plane, 1 residual) / 'E' (scan edge vector, 3 residuals); J: rows x 7
+int orc_scan_factor_eval(char type, const double *point, const double *coeff, double s, const double *pose7, double *residual, double *J)
+{
+    if (type == 'S') scan_plane_factor_evaluate(point, coeff, s, pose7, residual, J);
+    else scan_edge_vector_factor_evaluate(point, coeff, s, pose7, residual, J);
+    return 0;
+}
+
+// stats: per outer iteration 16 doubles: [0] n_corner [1] n_surf [2] solved [3] lm iterations [4] initial cost [5] final cost
+// [6] termination [7..13] pose_after
+int orc_track_cloud(const float *corner_last, int n_cl, const float *surf_last, int n_sl, const float *corner_sharp, int n_cs,
+                    const float *surf_flat, int n_sf, const double *pose_ini, const double *tprm, double *pose_out, double *stats, int *n_outer)
+{
+    ScanCloud cl, sl;
+    cl.set(corner_last, 4, n_cl);
+    sl.set(surf_last, 4, n_sl);
+    const TrackParams tp = make_track_params(tprm);
+    std::vector<TrackOuterStat> st;
+    track_cloud(cl, sl, corner_sharp, 4, n_cs, surf_flat, 4, n_sf, pose_ini, tp, pose_out, st);
+    *n_outer = (int)st.size();
+    for (size_t i = 0; i < st.size(); ++i) {
+        double *o = stats + i * 16;
+        std::memset(o, 0, sizeof(double) * 16);
+        o[0] = st[i].n_corner; o[1] = st[i].n_surf; o[2] = st[i].solved; o[3] = st[i].solve.num_iterations;
+        o[4] = st[i].solve.initial_cost; o[5] = st[i].solve.final_cost; o[6] = st[i].solve.termination;
+        for (int k = 0; k < 7; ++k) o[7 + k] = st[i].pose_after[k];
+    }
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
 // See mapper.hpp for the list of reference functions restated here.
 #include "mapper.hpp"
+#include "tracker.hpp"
 #include "linalg.hpp"
 #include <queue>
 #include <numeric>
@@ -22,20 +23,29 @@ void evaluate_problem(const std::vector<ResidualBlock> &blocks, const double x[7
 {
     std::memset(&ne, 0, sizeof(ne));
     for (const ResidualBlock &b : blocks) {
-        double r, J[7];
-        if (b.type == 's') plane_norm_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, &r, with_jacobian ? J : nullptr);
-        else edge_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, &r, with_jacobian ? J : nullptr);
+        // 's' / 'c': map factors (1 residual); 'S' / 'E': scan-to-scan factors of the tracker (1 / 3 residuals, sqrt_info carries s)
+        double r[3], J[21];
+        int rows = 1;
+        if (b.type == 's') plane_norm_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, r, with_jacobian ? J : nullptr);
+        else if (b.type == 'c') edge_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, r, with_jacobian ? J : nullptr);
+        else if (b.type == 'S') scan_plane_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, r, with_jacobian ? J : nullptr);
+        else { scan_edge_vector_factor_evaluate(b.point, b.coeffs, b.sqrt_info, x, r, with_jacobian ? J : nullptr); rows = 3; }
+        double sq = 0.0;
+        for (int q = 0; q < rows; ++q) sq += r[q] * r[q];
         double rho[3];
-        huber_evaluate(huber_delta, r * r, rho);
+        huber_evaluate(huber_delta, sq, rho);
         ne.cost += 0.5 * rho[0];
         ne.n++;
         if (with_jacobian) {
-            // Corrector with rho'' <= 0: residual and Jacobian scaled by sqrt(rho')
-            double s = std::sqrt(rho[1]);
-            r *= s;
-            for (int k = 0; k < 6; ++k) J[k] *= s;
-            add_outer(ne.H, J);
-            for (int k = 0; k < 6; ++k) ne.g[k] += J[k] * r;
+            // Corrector with rho'' <= 0: residuals and Jacobian rows of the block scaled by sqrt(rho')
+            const double s = std::sqrt(rho[1]);
+            for (int q = 0; q < rows; ++q) {
+                double *Jq = J + q * 7;
+                const double rq = r[q] * s;
+                for (int k = 0; k < 6; ++k) Jq[k] *= s;
+                add_outer(ne.H, Jq);
+                for (int k = 0; k < 6; ++k) ne.g[k] += Jq[k] * rq;
+            }
         }
     }
 }
@@ -453,6 +463,38 @@ void gn_iteration(const MapCloud &surf_map, const MapCloud &corner_map, const Fe
         std::memcpy(x, xn, sizeof(xn));
     }
     std::memcpy(st.pose_after, x, sizeof(st.pose_after));
+}
+
+// lidar_tracker.cpp:23-129: two rounds of { match sharp corners / flat surfs against the previous frame's less-sharp / less-flat
+// clouds at the current estimate, Ceres (Huber 0.1, <= 4 iterations, identity V_update) on the fixed correspondences }
+void track_cloud(const ScanCloud &corner_last, const ScanCloud &surf_last, const float *corner_sharp, size_t cs_stride, int n_corner,
+                 const float *surf_flat, size_t sf_stride, int n_surf, const double pose_ini[7], const TrackParams &tp, double pose_out[7],
+                 std::vector<TrackOuterStat> &stats)
+{
+    double x[7];
+    std::memcpy(x, pose_ini, sizeof(x));
+    double V[36];
+    for (int i = 0; i < 36; ++i) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    stats.clear();
+    for (int iter = 0; iter < tp.max_outer; ++iter) {
+        TrackOuterStat st;
+        const Pose pose_local = pose_from_param(x);
+        std::vector<Feature> cf, sf;
+        match_corner_from_scan(corner_last, corner_sharp, cs_stride, n_corner, pose_local, tp, cf);
+        match_surf_from_scan(surf_last, surf_flat, sf_stride, n_surf, pose_local, tp, sf);
+        st.n_corner = (int)cf.size(); st.n_surf = (int)sf.size();
+        if (cf.size() + sf.size() >= 10) {      // cpp:66-70: "less correspondence" -> continue
+            std::vector<ResidualBlock> blocks;
+            blocks.reserve(cf.size() + sf.size());
+            for (const Feature &f : sf) { ResidualBlock b; b.type = 'S'; std::memcpy(b.point, f.point, sizeof(b.point)); std::memcpy(b.coeffs, f.coeffs, sizeof(b.coeffs)); b.sqrt_info = 1.0; blocks.push_back(b); }
+            for (const Feature &f : cf) { ResidualBlock b; b.type = 'E'; std::memcpy(b.point, f.point, sizeof(b.point)); std::memcpy(b.coeffs, f.coeffs, sizeof(b.coeffs)); b.sqrt_info = 1.0; blocks.push_back(b); }
+            ceres_like_solve(blocks, x, V, tp.huber_delta, tp.max_lm_iterations, st.solve);
+            st.solved = true;
+        }
+        std::memcpy(st.pose_after, x, sizeof(x));
+        stats.push_back(st);
+    }
+    std::memcpy(pose_out, x, sizeof(x));
 }
 
 }  // namespace orc

@@ -312,3 +312,40 @@ def cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov, cov
     lib().orc_cloud_uct_associate_to_map(_ptr(p), p.shape[0], _ptr(pg), _ptr(cg), _ptr(e), _ptr(ec), e.shape[0], _ptr(cm),
                                          int(bool(with_ua)), C.c_double(trace_threshold), _ptr(out), C.byref(cnt))
     return out[:cnt.value].copy()
+
+
+def track_params(distance_sq_threshold=25.0, nearby_scan=2.5, scan_period=0.1, huber_delta=0.1, max_outer=2, max_lm_iterations=4):
+    return np.array([distance_sq_threshold, nearby_scan, scan_period, huber_delta, max_outer, max_lm_iterations], np.float64)
+
+
+def track_match(kind, prev4, cur4, pose7, tprm=None):
+    """matchCornerFromScan ('c') / matchSurfFromScan ('s'): prev4, cur4 rows [x y z ring]."""
+    prev = np.ascontiguousarray(prev4, np.float32); cur = np.ascontiguousarray(cur4, np.float32)
+    assert prev.shape[1] == 4 and cur.shape[1] == 4
+    pose = np.ascontiguousarray(pose7, np.float64)
+    tprm = track_params() if tprm is None else np.ascontiguousarray(tprm, np.float64)
+    valid = np.zeros(len(cur), np.uint8); coeffs = np.zeros((len(cur), 6))
+    lib().orc_track_match(C.c_char(kind.encode()), _ptr(prev), len(prev), _ptr(cur), len(cur), _ptr(pose), _ptr(tprm), _ptr(valid), _ptr(coeffs))
+    return valid, coeffs
+
+
+def scan_factor_eval(kind, point, coeff, pose7, s=1.0):
+    point = np.ascontiguousarray(point, np.float64)
+    coeff = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    pose = np.ascontiguousarray(pose7, np.float64)
+    rows = 1 if kind == "S" else 3
+    r = np.zeros(rows); J = np.zeros((rows, 7))
+    lib().orc_scan_factor_eval(C.c_char(kind.encode()), _ptr(point), _ptr(coeff), C.c_double(s), _ptr(pose), _ptr(r), _ptr(J))
+    return r, J
+
+
+def track_cloud(corner_last4, surf_last4, corner_sharp4, surf_flat4, pose_ini, tprm=None):
+    a = [np.ascontiguousarray(x, np.float32) for x in (corner_last4, surf_last4, corner_sharp4, surf_flat4)]
+    p0 = np.ascontiguousarray(pose_ini, np.float64)
+    tprm = track_params() if tprm is None else np.ascontiguousarray(tprm, np.float64)
+    pose = np.zeros(7); stats = np.zeros((8, 16)); n_outer = C.c_int(0)
+    lib().orc_track_cloud(_ptr(a[0]), len(a[0]), _ptr(a[1]), len(a[1]), _ptr(a[2]), len(a[2]), _ptr(a[3]), len(a[3]), _ptr(p0), _ptr(tprm),
+                          _ptr(pose), _ptr(stats), C.byref(n_outer))
+    outer = [dict(n_corner=int(o[0]), n_surf=int(o[1]), solved=bool(o[2]), lm_iterations=int(o[3]), initial_cost=o[4], final_cost=o[5],
+                  termination=int(o[6]), pose_after=o[7:14].copy()) for o in stats[:n_outer.value]]
+    return dict(pose=pose, outer=outer)

@@ -78,3 +78,34 @@ def features_from_extraction(synth, scans, extract_fn):
 @pytest.fixture(scope="session")
 def feats16(synth, orc, case16):
     return features_from_extraction(synth, case16["scans"], lambda s: orc.extract(s.points, s.scan_start, s.scan_end))
+
+
+@pytest.fixture(scope="session")
+def track_case(synth, orc):
+    """Two consecutive 16-ring scans of the 50k scene (intensity = ring id, as ImageSegmenter leaves it) and their LOAM features:
+    prev = less-sharp corners / voxel-thinned less-flat surfs, cur = sharp corners / flat surfs (lidar_tracker.cpp:30-38)."""
+    sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    gt0 = synth.gt_body_pose()
+    motion = np.array([0.35, -0.12, 0.02, 0.0, 0.0, np.sin(np.deg2rad(1.5) / 2), np.cos(np.deg2rad(1.5) / 2)])
+    T0 = synth.pose_to_mat(gt0)
+    T1 = T0 @ synth.pose_to_mat(motion)
+    gt1 = np.concatenate([T1[:3, 3], synth.rot_to_quat(T1[:3, :3])]) if hasattr(synth, "rot_to_quat") else None
+    if gt1 is None:
+        from scipy.spatial.transform import Rotation as Rot
+        gt1 = np.concatenate([T1[:3, 3], Rot.from_matrix(T1[:3, :3]).as_quat()])
+    out = {}
+    for name, pose, seed in (("prev", gt0, 7), ("cur", gt1, 11)):
+        scn = synth.simulate_scan(sc, pose, synth.HERCULES_BODY_T_LASER[0], 16, seed=seed)
+        ring = np.zeros(len(scn.points), np.float32)
+        begins = scn.scan_start - 5
+        for r in range(scn.n_rings):
+            e = begins[r + 1] if r + 1 < scn.n_rings else len(scn.points)
+            ring[begins[r]:e] = r
+        scn.points[:, 3] = ring
+        ex = orc.extract(scn.points, scn.scan_start, scn.scan_end)
+        out[name] = dict(scan=scn, ex=ex)
+    pts0, ex0 = out["prev"]["scan"].points, out["prev"]["ex"]
+    pts1, ex1 = out["cur"]["scan"].points, out["cur"]["ex"]
+    return dict(corner_last=np.ascontiguousarray(pts0[ex0["less_sharp"]]), surf_last=np.ascontiguousarray(ex0["less_flat_ds"][:, :4]),
+                corner_sharp=np.ascontiguousarray(pts1[ex1["sharp"]]), surf_flat=np.ascontiguousarray(pts1[ex1["flat"]]),
+                motion=motion, scans=(out["prev"]["scan"], out["cur"]["scan"]))

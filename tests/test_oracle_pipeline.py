@@ -154,3 +154,113 @@ def test_good_feature_selection_invariants(orc, case16, feats16, method):
         # greedy logdet selection beats a random subset of the same size on logdet(H)
         rnd = orc.good_feature_matching(m, "s", surf, case16["p0"], orc.mapper_params(gf_method="rnd", gf_ratio=0.2, seed=11))
         assert orc.logdet(sel["H"]) >= orc.logdet(rnd["H"]) - 1e-9
+
+
+def _brute_track_match(kind, prev, cur, pose, thr=25.0, nearby=2.5):
+    """Independent numpy statement of matchCornerFromScan / matchSurfFromScan: exhaustive 1-NN, then the two directional walks."""
+    R = None
+    from scipy.spatial.transform import Rotation as Rot
+    R = Rot.from_quat(pose[3:]).as_matrix()
+    sel = (cur[:, :3].astype(np.float64) @ R.T + pose[:3]).astype(np.float32)
+    ring = prev[:, 3].astype(np.int32)
+    valid = np.zeros(len(cur), np.uint8)
+    picks = -np.ones((len(cur), 3), np.int64)
+    P = prev[:, :3]
+    for i, s in enumerate(sel):
+        d = P - s
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        c = int(np.argmin(d2))
+        if not d2[c] < np.float32(thr):
+            continue
+        rid = ring[c]
+        best2, ind2, best3, ind3 = np.float32(thr), -1, np.float32(thr), -1
+        for j in range(c + 1, len(P)):
+            if kind == "c":
+                if ring[j] <= rid: continue
+                if ring[j] > rid + nearby: break
+                if d2[j] < best2: best2, ind2 = d2[j], j
+            else:
+                if ring[j] > rid + nearby: break
+                if ring[j] <= rid and d2[j] < best2: best2, ind2 = d2[j], j
+                elif ring[j] > rid and d2[j] < best3: best3, ind3 = d2[j], j
+        for j in range(c - 1, -1, -1):
+            if kind == "c":
+                if ring[j] >= rid: continue
+                if ring[j] < rid - nearby: break
+                if d2[j] < best2: best2, ind2 = d2[j], j
+            else:
+                if ring[j] < rid - nearby: break
+                if ring[j] >= rid and d2[j] < best2: best2, ind2 = d2[j], j
+                elif ring[j] < rid and d2[j] < best3: best3, ind3 = d2[j], j
+        ok = ind2 >= 0 if kind == "c" else (ind2 >= 0 and ind3 >= 0)
+        if ok:
+            valid[i] = 1
+            picks[i] = (c, ind2, ind3)
+    return valid, picks
+
+
+def test_track_match_against_brute_force(orc, track_case):
+    """matchCornerFromScan / matchSurfFromScan restatement vs an exhaustive numpy statement of the same rules."""
+    tc = track_case
+    pose = np.array([0.3, -0.1, 0.0, 0, 0, 0, 1.0])
+    for kind, prev, cur in (("c", tc["corner_last"], tc["corner_sharp"][:150]), ("s", tc["surf_last"], tc["surf_flat"][:120])):
+        valid, coeffs = orc.track_match(kind, prev, cur, pose)
+        bv, picks = _brute_track_match(kind, prev, cur, pose)
+        assert valid.sum() > 20
+        assert np.array_equal(valid, bv)
+        for i in np.flatnonzero(valid):
+            c, i2, i3 = picks[i]
+            if kind == "c":
+                np.testing.assert_array_equal(coeffs[i], np.concatenate([prev[c, :3], prev[i2, :3]]).astype(np.float64))
+            else:
+                a, b = prev[c, :3] - prev[i2, :3], prev[c, :3] - prev[i3, :3]
+                w = np.cross(a.astype(np.float64), b.astype(np.float64))
+                w /= np.linalg.norm(w)
+                np.testing.assert_allclose(coeffs[i, :3], w, atol=2e-5)
+                assert abs(coeffs[i, 3] + w @ prev[c, :3]) < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["S", "E"])
+def test_scan_factor_jacobians(orc, kind):
+    """LidarScanPlaneNormFactor / LidarScanEdgeFactorVector (lidar_scan_factor.hpp:24-64, 236-279): the reference's check() recipe
+    (t += eps e_k; q <- q * deltaQ(eps e_k)) as assertions."""
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pose = np.concatenate([rng.uniform(-2, 2, 3), q])
+        point = rng.uniform(-20, 20, 3)
+        if kind == "S":
+            n = rng.normal(size=3); n /= np.linalg.norm(n)
+            coeff = np.concatenate([n, [rng.uniform(-5, 5)]])
+        else:
+            c = rng.uniform(-20, 20, 3); v = rng.normal(size=3); v /= np.linalg.norm(v)
+            coeff = np.concatenate([c + 0.5 * v, c - 0.5 * v])
+        r, J = orc.scan_factor_eval(kind, point, coeff, pose)
+        assert np.all(J[:, 6] == 0)
+        eps = 1e-6
+        for k in range(6):
+            p = pose.copy()
+            if k < 3:
+                p[k] += eps
+            else:
+                d = np.zeros(3); d[k - 3] = eps
+                x, y, z, w = pose[3:]
+                dq = np.array([d[0] / 2, d[1] / 2, d[2] / 2, 1.0])
+                p[3:] = [w * dq[0] + x * dq[3] + y * dq[2] - z * dq[1], w * dq[1] - x * dq[2] + y * dq[3] + z * dq[0],
+                         w * dq[2] + x * dq[1] - y * dq[0] + z * dq[3], w * dq[3] - x * dq[0] - y * dq[1] - z * dq[2]]
+            r2, _ = orc.scan_factor_eval(kind, point, coeff, p)
+            num = (r2 - r) / eps
+            np.testing.assert_allclose(J[:, k], num, rtol=2e-4, atol=2e-4)
+
+
+def test_track_cloud_recovers_motion(orc, track_case):
+    """LidarTracker::trackCloud on two synthetic scans 0.37 m / 1.5 deg apart, from the identity: the estimate must land on the true
+    relative pose (range noise 2 cm -> a few cm / tenths of a degree)."""
+    tc = track_case
+    res = orc.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    assert len(res["outer"]) == 2 and all(o["solved"] for o in res["outer"])
+    assert res["outer"][0]["n_corner"] > 20 and res["outer"][0]["n_surf"] > 50
+    assert all(1 <= o["lm_iterations"] <= 4 for o in res["outer"])
+    assert np.linalg.norm(res["pose"][:3] - tc["motion"][:3]) < 0.08
+    q, qt = res["pose"][3:], tc["motion"][3:]
+    assert 2 * np.arccos(min(1.0, abs(q @ qt))) < np.deg2rad(0.5)
