@@ -286,6 +286,32 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
  * the eigen-decomposition only when H - thre*I is not positive definite, i.e. when something IS degenerate). */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
 
+/* ---------------------------------------------------------------- (f4) scan-to-scan odometry: LidarTracker::trackCloud
+ * replaces lidar_tracker.cpp:23-129 and the functions it drives: matchCornerFromScan / matchSurfFromScan
+ * (feature_extract.hpp:132-376; kd-tree 1-NN within DISTANCE_SQ_THRESHOLD, then the walks over the neighbouring scan lines),
+ * TransformToStart without distortion (utility.h:55-77), LidarScanPlaneNormFactor / LidarScanEdgeFactorVector
+ * (lidar_scan_factor.hpp:24-64, 236-279) under HuberLoss(0.1), ceres::Solve with max_num_iterations = 4, two rounds.
+ * kind MLH_CORNER: previous = "corner_points_less_sharp", current = "corner_points_sharp";
+ * kind MLH_SURF:   previous = "surf_points_less_flat",    current = "surf_points_flat"   (lidar_tracker.cpp:30-38).
+ * Previous-frame clouds must be ordered by ring id = int(intensity) (as extractCloud emits them); 0 <= id < 255. */
+typedef struct mlh_track_opts {
+    float distance_sq_threshold;     /* DISTANCE_SQ_THRESHOLD, config distance_sq_threshold (25) */
+    float nearby_scan;               /* NEARBY_SCAN, config nearby_scan (2.5) */
+    double huber_delta;              /* ceres::HuberLoss(0.1), lidar_tracker.cpp:45 */
+    int32_t max_outer;               /* 2, cpp:42 */
+    int32_t max_lm_iterations;       /* options.max_num_iterations = 4, cpp:113 */
+} mlh_track_opts;
+void mlh_track_opts_default(mlh_track_opts *o);
+/* stage the previous frame's cloud of one kind and build its index (pcl::KdTreeFLANN::setInputCloud, cpp:33-34) */
+int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                       float distance_sq_threshold);
+/* stage the current frame's features of one kind */
+int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int m, int intensity_offset_bytes, int mem);
+/* match*FromScan at `pose`: valid[m] and coeffs[m x 6] ('c': closest point, second point; 's': w, negative_OA_dot_norm, 0, 0); either may be NULL */
+int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs);
+/* trackCloud: pose_inout = pose_ini -> pose_prev_cur; stats: max_outer records (n_surf / n_corner = residual blocks) or NULL */
+int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats);
+
 /* ---------------------------------------------------------------- (e) multi-GPU: map shards + one all-reduce per iteration
  * One process (context) per GPU. The local map is partitioned spatially: rank g stages only the map points of its
  * region plus a halo >= sqrt(min_match_sq_dis) (mlh_map_set on that subset), and OWNS the features whose map-frame

@@ -42,6 +42,11 @@ class BlockOpts(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("k_neigh", C.c_int * 8), ("eig_thre", C.c_double * 8), ("freeze", C.c_int * 8)]
 
 
+class TrackOpts(C.Structure):
+    _fields_ = [("distance_sq_threshold", C.c_float), ("nearby_scan", C.c_float), ("huber_delta", C.c_double),
+                ("max_outer", C.c_int32), ("max_lm_iterations", C.c_int32)]
+
+
 class IterStat(C.Structure):
     _fields_ = [("n_surf", C.c_int32), ("n_corner", C.c_int32), ("is_degenerate", C.c_int32), ("lm_iterations", C.c_int32),
                 ("successful_steps", C.c_int32), ("termination", C.c_int32), ("cost", C.c_double), ("final_cost", C.c_double),
@@ -88,6 +93,12 @@ def load_library():
     dp = C.POINTER(C.c_double)
     lib.mlh_cloud_uct_associate_to_map.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, cd, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_compound_pose_with_cov.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mlh_track_opts_default.argtypes = [vp]
+    lib.mlh_track_opts_default.restype = None
+    lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
+    lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+    lib.mlh_track_match.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.mlh_track_cloud.argtypes = [vp, vp, vp, vp]
     lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.mlh_pure_odom_evaluate.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
@@ -118,7 +129,8 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
+    "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -139,6 +151,14 @@ def _src(points):
     t = points.contiguous()
     assert t.is_cuda and t.dtype.itemsize == 4
     return C.c_void_p(t.data_ptr()), t.shape[1] * 4, t.shape[0], MEM_DEVICE, t
+
+
+def default_track_opts(**kw) -> TrackOpts:
+    o = TrackOpts()
+    load_library().mlh_track_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
 
 
 def default_opts(**kw) -> SolverOpts:
@@ -256,6 +276,35 @@ class Context:
         kp = np.zeros(n, np.int32)
         self._ck(self.lib.mlh_point_uncertainty(self.h, ptr, stride, n, 12, mem, _p(ep), _p(ec), ep.shape[0], _p(cm), trace_threshold, _p(cov), _p(kp)))
         return cov, kp.astype(bool)
+
+    # ---- scan-to-scan odometry (LidarTracker)
+    def track_set_prev(self, kind, points4, distance_sq_threshold=25.0):
+        ptr, stride, n, mem, keep = _src(points4)
+        self._ck(self.lib.mlh_track_set_prev(self.h, kind, ptr, stride, n, 12, mem, distance_sq_threshold))
+
+    def track_set_cur(self, kind, points4):
+        ptr, stride, n, mem, keep = _src(points4)
+        self._ck(self.lib.mlh_track_set_cur(self.h, kind, ptr, stride, n, 12, mem))
+        self._m_track = getattr(self, "_m_track", {})
+        self._m_track[kind] = n
+
+    def track_match(self, kind, pose, opts=None):
+        opts = opts or default_track_opts()
+        pose = np.ascontiguousarray(pose, np.float64)
+        m = self._m_track[kind]
+        valid = np.zeros(m, np.uint8); coeffs = np.zeros((m, 6))
+        self._ck(self.lib.mlh_track_match(self.h, kind, _p(pose), C.byref(opts), _p(valid), _p(coeffs)))
+        return valid, coeffs
+
+    def track_cloud(self, pose_ini, opts=None, want_stats=True):
+        opts = opts or default_track_opts()
+        pose = np.ascontiguousarray(pose_ini, np.float64).copy()
+        if not want_stats:
+            self._ck(self.lib.mlh_track_cloud(self.h, _p(pose), C.byref(opts), None))
+            return pose, None
+        stats = (IterStat * opts.max_outer)()
+        self._ck(self.lib.mlh_track_cloud(self.h, _p(pose), C.byref(opts), C.cast(stats, C.c_void_p)))
+        return pose, [s.as_dict() for s in stats]
 
     def pure_odom_set(self, types, points, coeffs, frame_idx, ext_idx, sqrt_info=None):
         t = np.ascontiguousarray(types, np.int32); fi = np.ascontiguousarray(frame_idx, np.int32); ei = np.ascontiguousarray(ext_idx, np.int32)

@@ -273,6 +273,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
+    { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
@@ -829,6 +830,97 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
             HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
             if ((rc = fetch_published(ctx, hp))) return rc;
             if (hp.done) break;
+        }
+        if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
+    }
+    return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
+}
+
+// ---------------------------------------------------------------- scan-to-scan odometry (LidarTracker)
+void mlh_track_opts_default(mlh_track_opts *o)
+{
+    if (!o) return;
+    o->distance_sq_threshold = 25.0f; o->nearby_scan = 2.5f; o->huber_delta = 0.1; o->max_outer = 2; o->max_lm_iterations = 4;
+}
+
+static TrackArgs track_args(const mlh_track_opts *o, int pose_sel)
+{
+    TrackArgs a;
+    a.pose_sel = pose_sel; a.dist_sq_thr = o->distance_sq_threshold; a.nearby_scan = o->nearby_scan; a.huber_delta = o->huber_delta;
+    return a;
+}
+
+int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                       float distance_sq_threshold)
+{
+    if (!ctx || kind < 0 || kind > 1 || intensity_offset_bytes < 0 || !(distance_sq_threshold > 0.f)) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    TrackSet &T = ctx->track;
+    MapGrid &g = T.grid[kind];
+    g.built = false;
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, -2, -1, g.raw, nullptr, ctx->tmp);
+    if (rc) return rc;
+    const unsigned char *d_src = (mem == MLH_MEM_HOST) ? ctx->tmp.as<unsigned char>() : static_cast<const unsigned char *>(points);
+    if ((rc = track_set_prev_rings(ctx, kind, d_src, stride_bytes, n, intensity_offset_bytes))) return rc;
+    g.n = n;
+    g.min_match_sq_dis = distance_sq_threshold;
+    MapGrid *gp[1] = {&g};
+    if ((rc = grid_build_grids(ctx, gp, 1, true))) return rc;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLH_OK;
+}
+
+int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int m, int intensity_offset_bytes, int mem)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    TrackSet &T = ctx->track;
+    int rc = stage_points(ctx, points, stride_bytes, m, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, T.cur[kind], nullptr, ctx->tmp);
+    if (rc) return rc;
+    MLH_HIP(ctx, T.corr[kind].ensure(sizeof(Corr) * size_t(m)));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    T.m[kind] = m;
+    return MLH_OK;
+}
+
+int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs)
+{
+    if (!ctx || kind < 0 || kind > 1 || !pose || !opts) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    TrackArgs a = track_args(opts, 0);
+    a.init_pose = pose;
+    if ((rc = track_match_launch(ctx, 1 << kind, a))) return rc;
+    const int m = ctx->track.m[kind];
+    std::vector<Corr> hc(m);
+    MLH_HIP(ctx, hipMemcpyAsync(hc.data(), ctx->track.corr[kind].p, sizeof(Corr) * size_t(m), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < m; ++i) {
+        if (valid) valid[i] = hc[i].valid ? 1 : 0;
+        if (coeffs) for (int k = 0; k < 6; ++k) coeffs[size_t(i) * 6 + k] = double(hc[i].c[k]);
+    }
+    return MLH_OK;
+}
+
+int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats)
+{
+    if (!ctx || !pose_inout || !opts || opts->max_outer <= 0 || opts->max_lm_iterations <= 0) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    TrackSet &T = ctx->track;
+    if (!(T.grid[0].built && T.grid[1].built && T.m[0] > 0 && T.m[1] > 0)) return fail(ctx, MLH_ERR_STATE, "track_set_prev / track_set_cur are required for both kinds");
+    int rc = ensure_state(ctx, opts->max_outer);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, pose_inout))) return rc;
+    for (int outer = 0; outer < opts->max_outer; ++outer) {
+        // lidar_tracker.cpp:42-121: match at the current estimate, then Ceres on the fixed correspondences (Huber 0.1, <= 4 iterations,
+        // no degeneracy handling); fewer than 10 correspondences -> the round is skipped
+        if ((rc = track_match_launch(ctx, 3, track_args(opts, 0)))) return rc;
+        if ((rc = track_linearize_launch(ctx, 3, track_args(opts, 0)))) return rc;
+        if ((rc = lm_begin_launch(ctx, -1.0, opts->max_lm_iterations, stats ? outer : -1, 10))) return rc;
+        for (int it = 0; it < opts->max_lm_iterations; ++it) {
+            if ((rc = track_linearize_launch(ctx, 3, track_args(opts, 1)))) return rc;
+            if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
         }
         if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
     }

@@ -161,6 +161,19 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     int n = 0, max_frame = 0, max_ext = 0;
 };
 
+constexpr int TRACK_RING_SLOTS = 258;   // ring ids 0..255 (+ the slots the walks' upper bound can reach)
+struct TrackSet {   // scan-to-scan odometry (track.hip): previous frame's clouds + indices, current frame's features
+    MapGrid grid[2];
+    DevBuf ring[2], ring_start[2], cur[2], corr[2];
+    int m[2] = {0, 0};
+};
+struct TrackArgs {
+    int pose_sel = 0;
+    const double *init_pose = nullptr;
+    float dist_sq_thr = 25.f, nearby_scan = 2.5f;
+    double huber_delta = 0.1;
+};
+
 struct Profile {
     unsigned mask = 0;     // bit k: bracket launches of kernel id k
     int every = 1;         // bracket every n-th launch of a kernel id only (event pairs cost ~6 us of host/queue time each)
@@ -193,6 +206,7 @@ struct mlh_ctx {
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;
     mlh::OdomSet odom;
+    mlh::TrackSet track;
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
@@ -225,6 +239,10 @@ int extract_run(mlh_ctx *ctx);
 int ring_voxel_run(mlh_ctx *ctx, float leaf);
 int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
                           const double *ext_covs, int n_lidar, const double cov_meas[9], double trace_thr, float *cov6_host, int *keep_host);
+// track.hip
+int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off);
+int track_match_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
+int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 // odom.hip
 int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
                   const int32_t *frame_idx, const int32_t *ext_idx);
@@ -241,6 +259,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
                      float trace_thr, void *out_host, int *n_out, int mem);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
+int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);
 // match.hip
 struct MatchArgs {
     int kind_mask = 3;   // bit MLH_SURF, bit MLH_CORNER: which feature kinds take part in the launch
@@ -275,7 +294,7 @@ int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot
 // comm.hip
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
 void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream
-int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot);
+int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks = 0);
 int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot);
 int lm_finish_launch(mlh_ctx *ctx, int stat_slot);
 

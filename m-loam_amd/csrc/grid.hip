@@ -295,17 +295,16 @@ static GridJob make_job(MapGrid &g)
     return J;
 }
 
-// (re)builds the index of the maps selected by kind_mask in one set of launches
-int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds)
+// (re)builds the index of up to two point sets in one set of launches
+int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds)
 {
     hipStream_t st = ctx->stream;
     GridJobs G;
     std::memset(&G, 0, sizeof(G));
     int nj = 0;
-    for (int k = 0; k < 2; ++k) {
-        if (!(kind_mask & (1 << k))) continue;
-        MapGrid &g = ctx->map[k];
-        if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+    for (int k = 0; k < n_grids && k < 2; ++k) {
+        MapGrid &g = *grids[k];
+        if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "no points staged for this index");
         if (recompute_bounds) {
             int rc = compute_bounds(ctx, g, g.min_match_sq_dis);
             if (rc) return rc;
@@ -323,8 +322,21 @@ int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds)
     hipLaunchKernelGGL(scatter_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     prof_end(ctx, MLH_K_GRID_BUILD);
     MLH_HIP(ctx, hipGetLastError());
-    for (int k = 0; k < 2; ++k) if (kind_mask & (1 << k)) ctx->map[k].built = true;
+    for (int k = 0; k < nj; ++k) grids[k]->built = true;
     return MLH_OK;
+}
+
+// (re)builds the index of the maps selected by kind_mask
+int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds)
+{
+    MapGrid *g[2];
+    int n = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!(kind_mask & (1 << k))) continue;
+        if (ctx->map[k].n <= 0 || !ctx->map[k].raw.p) return fail(ctx, MLH_ERR_STATE, "map_set has not been called for this kind");
+        g[n++] = &ctx->map[k];
+    }
+    return grid_build_grids(ctx, g, n, recompute_bounds);
 }
 
 }  // namespace mlh

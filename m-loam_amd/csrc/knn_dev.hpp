@@ -1,0 +1,193 @@
+// Device-side building blocks shared by the correspondence kernels (match.hip: scan-to-map; track.hip: scan-to-scan):
+// 64-bit (distance bits, index) keys, DPP lane exchanges, the exact K-NN of one query by a group of 8 or 16 lanes over the
+// dense cell grid built by grid.hip.
+#pragma once
+#include "ctx.hpp"
+#include <cfloat>
+
+#ifndef MLH_KSTAGE
+#define MLH_KSTAGE(i) do { } while (0)
+#endif
+
+namespace mlh {
+
+constexpr int TPB = 256;
+
+// lanes per query in the correspondence kernel: 8 when the launch fills the chip on its own (throughput: one wavefront serves 8
+// queries), 16 when it does not (latency: a frame's ~20k thinned features leave most SIMDs idle with 8, and twice the lanes halve
+// the candidate trips of the queries in dense cells, which set the kernel's duration)
+constexpr int KNN_WIDE_LIMIT = 40000;  // total queries up to which a launch uses 16 lanes per query
+#ifndef MLH_KNN_U
+#define MLH_KNN_U 4
+#endif
+constexpr int KNN_U = MLH_KNN_U;      // candidate loads in flight per lane
+constexpr unsigned long long KEY_INF = 0x7f800000ffffffffull;   // (+inf, max index)
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// DPP lane permutations (VALU latency, no LDS crossbar trip): the 3 (4) exchange partners that all-reduce a group of 8 (16) lanes
+constexpr int DPP_QUAD_SWAP1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each 8-lane half row
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i inside each 16-lane row
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long m)
+{
+    const unsigned long long o = dpp_u64<CTRL>(m);
+    return o < m ? o : m;
+}
+// row_shr:OFF with out-of-row lanes reading 0 (bound_ctrl)
+template <int OFF>
+__device__ __forceinline__ int dpp_row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true); }
+
+template <int K>
+__device__ __forceinline__ void key_insert(unsigned long long (&k)[K], unsigned long long key)
+{
+    if (key < k[K - 1]) {
+        k[K - 1] = key;
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) {
+            unsigned long long a = k[i - 1], b = k[i];
+            bool sw = b < a;
+            k[i - 1] = sw ? b : a;
+            k[i] = sw ? a : b;
+        }
+    }
+}
+
+__device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int n)
+{
+    float f = floorf((v - o) * inv_h);
+    return fminf(fmaxf(f, -2.f), float(n + 1));   // also squashes NaN/inf before the int conversion
+}
+
+// exact K-NN (K = 5, or 10 for buildCalibMap's non-reference LiDARs) of (qx,qy,qz) by a group of 8 lanes (8 queries per
+// wavefront); on return every lane holds the K keys ascending.
+// The 27-cell neighbourhood is 9 x-runs (the 3 x-adjacent cells of one (dy,dz) are one contiguous range of the cell-sorted
+// array). Lane r fetches the bounds of run r (lane 0 also run 8); a 3-step shuffle scan gives the run offsets, which go to
+// LDS; the lanes then stride over the FLAT concatenation of the 9 runs (lane l takes candidates l, l+8, ...), so the work
+// is balanced whatever the per-run occupancy, consecutive lanes read consecutive float4 points, and a query with fewer than
+// K candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
+// lds_run: 20 ints per group: [0..9] prefix offsets of the runs (10 entries), [10..18] base index of each run.
+template <int K, int G>
+__device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[K])
+{
+    static_assert(G == 8 || G == 16, "group width");
+    unsigned long long k[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = KEY_INF;
+    const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
+    const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
+    const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    int b = 0, e = 0, b8 = 0, e8 = 0;
+    {
+        const int y = cy + (gl % 3) - 1, z = cz + (gl / 3) - 1;
+        if ((gl < 9) && (x0 <= x1) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+            const int row = (z * g.ny + y) * g.nx;
+            b = g.cell_start[row + x0];
+            e = g.cell_start[row + x1 + 1];
+        }
+        const int y8 = cy + 1, z8 = cz + 1;       // run 8 = (dy, dz) = (+1, +1): lane 0's second run when there are only 8 lanes
+        if (G == 8 && gl == 0 && (x0 <= x1) && (y8 < g.ny) && (z8 < g.nz) && (y8 >= 0) && (z8 >= 0)) {
+            const int row = (z8 * g.ny + y8) * g.nx;
+            b8 = g.cell_start[row + x0];
+            e8 = g.cell_start[row + x1 + 1];
+        }
+    }
+    MLH_KSTAGE(2);
+    const int len = e - b;
+    int incl = len;
+    if (G == 16) {
+        // small launches are latency-bound: DPP row shifts / lane swaps (VALU latency) instead of ds_bpermute round trips
+        { const int t = dpp_row_shr<1>(incl); if (gl >= 1) incl += t; }
+        { const int t = dpp_row_shr<2>(incl); if (gl >= 2) incl += t; }
+        { const int t = dpp_row_shr<4>(incl); if (gl >= 4) incl += t; }
+        { const int t = dpp_row_shr<8>(incl); if (gl >= 8) incl += t; }
+    } else {
+        // chip-filling launches are issue-bound on the VALU: leave the exchanges to the LDS crossbar
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            const int t = __shfl_up(incl, off, G);
+            if (gl >= off) incl += t;
+        }
+    }
+    const int len8 = (G == 8) ? __shfl(e8 - b8, 0, G) : 0;
+    const int total = __shfl(incl, G - 1, G) + len8;
+    if (total >= K) {                                  // uniform over the group
+        if (G == 8) {
+            lds_run[gl] = incl - len;                  // prefix[r]
+            lds_run[10 + gl] = b;                      // base[r]
+            if (gl == 0) { lds_run[8] = total - len8; lds_run[9] = total; lds_run[18] = b8; }
+        } else {
+            if (gl < 10) lds_run[gl] = incl - len;     // lane 9 holds no run: incl - len = total
+            if (gl < 9) lds_run[10 + gl] = b;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int cr = 0, hi = lds_run[1], base = lds_run[10], lo = 0;
+        // KNN_U candidates per lane per trip: the addresses depend only on the run table, so the KNN_U loads are in flight together
+        for (int j = gl; j < total; j += G * KNN_U) {
+            float4 p[KNN_U];
+            bool v[KNN_U];
+#pragma unroll
+            for (int u = 0; u < KNN_U; ++u) {
+                const int jj = j + G * u;
+                v[u] = jj < total;
+                if (v[u]) {
+                    while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[10 + cr]; }
+                    p[u] = g.sorted[base + (jj - lo)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KNN_U; ++u) {
+                if (v[u]) {
+                    float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+                    float d = dx * dx; d += dy * dy; d += dz * dz;
+                    key_insert<K>(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
+                }
+            }
+        }
+    }
+    MLH_KSTAGE(3);
+    // tournament merge: K rounds of group-min over the lanes' current heads
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        unsigned long long m = k[0];
+        if (G == 16) {
+            m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
+            m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
+            m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
+            m = dpp_min_u64<DPP_ROW_MIRROR>(m);
+        } else {
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                const unsigned long long o = shfl_xor_u64(m, off);
+                m = o < m ? o : m;
+            }
+        }
+        out[t] = m;
+        if (k[0] == m && m != KEY_INF) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) k[i] = k[i + 1];
+            k[K - 1] = KEY_INF;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-feature evaluation (registers only)
+}  // namespace mlh

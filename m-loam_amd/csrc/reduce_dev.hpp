@@ -1,0 +1,49 @@
+// Workgroup reduction of the packed normal-equation record (21 J^T J + 6 J^T r + cost + count, padded to 32 doubles) shared by
+// the scan-to-map and scan-to-scan linearisation kernels.
+#pragma once
+#include "ctx.hpp"
+
+namespace mlh {
+
+// blockIdx -> tile, XCD-aware: consecutive tiles go to the same XCD (workgroups are dealt round-robin over the 8 XCDs)
+__device__ __forceinline__ int xcd_tile(int n_tiles)
+{
+    const int per = (n_tiles + 7) >> 3;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
+// acc: this lane's 32 values (entries 29..31 zero). 256 threads. partial_out[0..31]: the workgroup's sums; slots 29 / 30 mirror the
+// count for feature kind 0 / 1.
+__device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double *lds_red /*4*32*/, double *__restrict__ partial_out)
+{
+    // transposed butterfly: at each step a lane keeps one half of its values and trades the other half with its partner, so the
+    // wavefront total of value i ends up in lanes 2i and 2i+1 after 16+8+4+2+1+1 = 32 exchanges (a plain per-value butterfly
+    // takes 29*6 = 174). Fixed tree -> deterministic sums.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#define MLH_RED_STEP(H, MASK)                                              \
+    {                                                                      \
+        const bool up = (lane & (MASK)) != 0;                              \
+        _Pragma("unroll") for (int i = 0; i < (H); ++i) {                  \
+            const double keep = up ? acc[i + (H)] : acc[i];                \
+            const double send = up ? acc[i] : acc[i + (H)];                \
+            acc[i] = keep + __shfl_xor(send, (MASK));                      \
+        }                                                                  \
+    }
+    MLH_RED_STEP(16, 32)
+    MLH_RED_STEP(8, 16)
+    MLH_RED_STEP(4, 8)
+    MLH_RED_STEP(2, 4)
+    MLH_RED_STEP(1, 2)
+#undef MLH_RED_STEP
+    acc[0] += __shfl_xor(acc[0], 1);
+    if ((lane & 1) == 0) lds_red[wave * 32 + (lane >> 1)] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double v = 0.0;
+        const int src = (threadIdx.x == NE_CNT + 1 + kind) ? NE_CNT : threadIdx.x;   // per-kind count mirrors the count column
+        if (src < 29) v = ((lds_red[src] + lds_red[32 + src]) + lds_red[64 + src]) + lds_red[96 + src];
+        partial_out[threadIdx.x] = v;
+    }
+}
+
+}  // namespace mlh

@@ -90,15 +90,17 @@ __device__ void lm_propose(SolverState *S, int max_it)
     }
 }
 
-__global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat, int pre_reduced)
+__global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat, int pre_reduced,
+                                                       int min_blocks)
 {
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
     // evalDegenracy. Nobody asked for the eigenvalues (stat == null): H - thre*I positive definite <=> lambda_min > thre <=> nothing
     // is degenerate, V_update = I -- one Cholesky factorisation instead of the eigen-decomposition; otherwise the full procedure.
-    bool deg = false, fast = false;
-    if (!stat) {
+    // eig_thre < 0: the caller has no degeneracy handling at all (LidarTracker: V_update stays the identity)
+    bool deg = false, fast = eig_thre < 0.0;
+    if (!fast && !stat) {
         double L[21], inv_d[6];
         pack_lower_from_ne(ne, eig_thre * (1.0 + 1e-9), L);
         fast = chol6p_factor(L, inv_d);
@@ -114,9 +116,12 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *
     S->iteration = 0; S->done = 0; S->termination = 0; S->num_successful = 0; S->num_invalid = 0; S->evaluations = 1;
     S->gmax = gradient_max_norm(S);
     if (stat) {
+        if (fast) for (int i = 0; i < 6; ++i) scratch[72 + i] = 0.0;     // no eigenvalues were computed
         write_stat_common(stat, ne, cnt2, scratch + 72, deg);
         stat->final_cost = ne[NE_COST];
     }
+    // too few residual blocks (lidar_tracker.cpp:66-70 "less correspondence": the round is skipped)
+    if (ne[NE_CNT] < double(min_blocks)) { S->done = 1; S->termination = 4; return; }
     lm_propose(S, max_it);
 }
 
@@ -222,13 +227,13 @@ int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot
     return MLH_OK;
 }
 
-int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot)
+int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks)
 {
     int pre = 0, rc = pre_reduce(ctx, 0, pre);
     if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
     hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
-                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre);
+                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre, min_blocks);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

@@ -1,0 +1,343 @@
+// Scan-to-scan odometry on gfx950 -- the caller side of the hot path:
+//   FeatureExtract::matchCornerFromScan / matchSurfFromScan   estimator/src/featureExtract/feature_extract.hpp:132-376
+//   TransformToStart (no distortion: s = 1)                   estimator/src/utility/utility.h:55-77
+//   LidarScanPlaneNormFactor / LidarScanEdgeFactorVector      estimator/src/factor/lidar_scan_factor.hpp:24-64, 236-279
+//   LidarTracker::trackCloud                                  estimator/src/lidarTracker/lidar_tracker.cpp:23-129
+//
+// track_match_kernel      16 lanes per current-frame feature: transform with the pose estimate, exact 1-NN in the previous frame's
+//                         cloud through the same dense cell grid as the mapper (cell edge = 1.001 * sqrt(DISTANCE_SQ_THRESHOLD), so the
+//                         27-cell search is exact for every accepted neighbour), then the reference's two directional walks over
+//                         the ring-ordered array. Because the cloud is ordered by ring, each walk is a contiguous index range
+//                         (ring_start table); the lanes stride over it and keep 64-bit (distance bits, walk position) keys, whose
+//                         minimum is exactly the element the sequential walk with its strict `<` would have kept.
+// track_linearize_kernel  one lane per feature: scan-plane (1 residual) or scan-edge-vector (3 residuals) rows at SolverState::x or
+//                         ::cand, Huber on the block's squared norm (Ceres corrector, rho'' <= 0 branch), packed normal equations
+//                         through the shared workgroup reduction -> partial records consumed by the LM kernels of solver.hip.
+// Small launches (a frame has ~2 k sharp/flat features): latency-bound by construction; nothing here is tuned beyond that.
+#include "ctx.hpp"
+#include "dev_math.hpp"
+#include "knn_dev.hpp"
+#include "reduce_dev.hpp"
+
+namespace mlh {
+
+constexpr int TRK_G = 16;                 // lanes per feature
+constexpr int TRK_FPB = TPB / TRK_G;
+constexpr unsigned BACKWARD_BIT = 0x40000000u;
+
+struct TrackKind {
+    GridDev grid;            // previous frame's cloud (raw[] in the original, ring-ordered order)
+    const int *ring;         // ring id of every previous-frame point
+    const int *ring_start;   // ring_start[r] = first index whose ring id is >= r   (0 .. max_ring + 1 valid, beyond: n)
+    int n_ring_slots;        // entries of ring_start
+    const float4 *cur;       // current frame's features {x, y, z, intensity}
+    Corr *corr;
+    int m, tiles_a, tiles_b;
+};
+
+struct TrackParamsDev {
+    TrackKind k[2];          // [MLH_SURF], [MLH_CORNER]
+    SolverState *state;
+    double *partials;
+    int pose_sel;            // 0: state->x, 1: state->cand
+    int use_init;
+    double init_pose[7];
+    float dist_sq_thr;
+    int nearby_floor;        // floor(NEARBY_SCAN): rings id - nf .. id + nf take part in the walks
+    double huber_delta;
+};
+
+__device__ __forceinline__ void track_pose(const TrackParamsDev &P, q4 &q, d3 &t)
+{
+    if (P.use_init) {
+        t = d3{P.init_pose[0], P.init_pose[1], P.init_pose[2]};
+        q = q4{P.init_pose[3], P.init_pose[4], P.init_pose[5], P.init_pose[6]};
+    } else {
+        const double *x = P.pose_sel ? P.state->cand : P.state->x;
+        t = d3{x[0], x[1], x[2]};
+        q = q4{x[3], x[4], x[5], x[6]};
+    }
+}
+
+__device__ __forceinline__ unsigned long long group_min16(unsigned long long m)
+{
+    m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
+    m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
+    m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
+    m = dpp_min_u64<DPP_ROW_MIRROR>(m);
+    return m;
+}
+
+// walk position -> array index
+__device__ __forceinline__ int walk_index(unsigned rank, int closest)
+{
+    return (rank & BACKWARD_BIT) ? closest - 1 - int(rank & ~BACKWARD_BIT) : closest + 1 + int(rank);
+}
+
+__global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
+{
+    __shared__ int s_run[TRK_FPB * 20];
+    const int total = P.k[0].tiles_a + P.k[1].tiles_a;
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
+    if (kind) tile -= P.k[0].tiles_a;
+    const TrackKind &K = P.k[kind];
+    const int grp = threadIdx.x / TRK_G, gl = threadIdx.x % TRK_G;
+    const int f = tile * TRK_FPB + grp;
+    if (f >= K.m) return;
+    q4 q;
+    d3 t;
+    track_pose(P, q, t);
+    const float4 fp = K.cur[f];
+    // TransformToStart without distortion: s = 1, slerp(1, q) = +-q (same rotation), f64 math, f32 store
+    const d3 r = qrot(q, d3{double(fp.x), double(fp.y), double(fp.z)});
+    const float sx = float(r.x + t.x), sy = float(r.y + t.y), sz = float(r.z + t.z);
+    unsigned long long nn[1];
+    knn_group<1, TRK_G>(K.grid, sx, sy, sz, gl, s_run + grp * 20, nn);
+    bool valid = false;
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float d1 = __uint_as_float(unsigned(nn[0] >> 32));
+    if (nn[0] != KEY_INF && d1 < P.dist_sq_thr) {                 // uniform over the group
+        const int closest = int(unsigned(nn[0]));
+        const int id = K.ring[closest];
+        const int r_hi = min(id + P.nearby_floor + 1, K.n_ring_slots - 1), r_lo = max(id - P.nearby_floor, 0);
+        const int fwd_end = K.ring_start[r_hi], bwd_begin = K.ring_start[r_lo];
+        const float4 *pts = K.grid.raw;
+        const unsigned long long thr_key = (unsigned long long)__float_as_uint(P.dist_sq_thr) << 32;   // strict `<` against the threshold
+        unsigned long long k2 = ~0ull, k3 = ~0ull;
+        // increasing index: closest+1 .. fwd_end-1
+        for (int j = closest + 1 + gl; j < fwd_end; j += TRK_G) {
+            const float4 p = pts[j];
+            const int rj = K.ring[j];
+            const float dd = (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | unsigned(j - closest - 1);
+            if (key < thr_key) {
+                if (kind == MLH_CORNER) { if (rj > id) k2 = key < k2 ? key : k2; }
+                else if (rj <= id) k2 = key < k2 ? key : k2;
+                else k3 = key < k3 ? key : k3;
+            }
+        }
+        // decreasing index: closest-1 .. bwd_begin
+        for (int j = closest - 1 - gl; j >= bwd_begin; j -= TRK_G) {
+            const float4 p = pts[j];
+            const int rj = K.ring[j];
+            const float dd = (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (BACKWARD_BIT | unsigned(closest - 1 - j));
+            if (key < thr_key) {
+                if (kind == MLH_CORNER) { if (rj < id) k2 = key < k2 ? key : k2; }
+                else if (rj >= id) k2 = key < k2 ? key : k2;
+                else k3 = key < k3 ? key : k3;
+            }
+        }
+        k2 = group_min16(k2);
+        k3 = group_min16(k3);
+        if (kind == MLH_CORNER) {
+            if (k2 != ~0ull) {
+                const float4 a = pts[closest], b = pts[walk_index(unsigned(k2), closest)];
+                c6[0] = a.x; c6[1] = a.y; c6[2] = a.z; c6[3] = b.x; c6[4] = b.y; c6[5] = b.z;
+                valid = true;
+            }
+        } else if (k2 != ~0ull && k3 != ~0ull) {
+            const float4 pj = pts[closest], pl = pts[walk_index(unsigned(k2), closest)], pm = pts[walk_index(unsigned(k3), closest)];
+            const float ax = pj.x - pl.x, ay = pj.y - pl.y, az = pj.z - pl.z, bx = pj.x - pm.x, by = pj.y - pm.y, bz = pj.z - pm.z;
+            float wx = ay * bz - az * by, wy = az * bx - ax * bz, wz = ax * by - ay * bx;
+            const float z = wx * wx + wy * wy + wz * wz;       // Eigen normalize(): only when the squared norm is positive
+            if (z > 0.f) { const float nrm = sqrtf(z); wx /= nrm; wy /= nrm; wz /= nrm; }
+            c6[0] = wx; c6[1] = wy; c6[2] = wz;
+            c6[3] = -(wx * pj.x + wy * pj.y + wz * pj.z);
+            valid = true;
+        }
+    }
+    if (gl == 0) {
+        Corr c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.c[i] = valid ? c6[i] : 0.f;
+        c.valid = valid ? 1 : 0;
+        c.pad = 0;
+        K.corr[f] = c;
+    }
+}
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 rowmul3(const V3 &a, const double (&M)[9])      // a^T M
+{
+    return {a.x * M[0] + a.y * M[3] + a.z * M[6], a.x * M[1] + a.y * M[4] + a.z * M[7], a.x * M[2] + a.y * M[5] + a.z * M[8]};
+}
+__device__ __forceinline__ V3 row_skew3(const V3 &a, const V3 &v)             // a^T [v]x
+{
+    return {a.y * v.z - a.z * v.y, a.z * v.x - a.x * v.z, a.x * v.y - a.y * v.x};
+}
+
+__global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
+{
+    __shared__ double s_red[4 * 32];
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = blockIdx.x;
+    if (gtile >= total) return;
+    if (P.pose_sel && P.state->done) {       // the LM loop has terminated: keep the partials defined, do no work
+        if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
+        return;
+    }
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const TrackKind &K = P.k[kind];
+    const int f = tile * TPB + threadIdx.x;
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    if (f < K.m) {
+        const Corr c = K.corr[f];
+        if (c.valid) {
+            q4 q;
+            d3 t;
+            track_pose(P, q, t);
+            const float4 fp = K.cur[f];
+            const V3 p{double(fp.x), double(fp.y), double(fp.z)};
+            double R[9];
+            qtorot(q, R);
+            const d3 rp = qrot(q, d3{p.x, p.y, p.z});
+            const V3 lp{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+            double res[3], J[3][6];
+            int rows;
+            if (kind == MLH_SURF) {
+                rows = 1;
+                const V3 w{double(c.c[0]), double(c.c[1]), double(c.c[2])};
+                res[0] = (w.x * lp.x + w.y * lp.y + w.z * lp.z) + double(c.c[3]);
+                const V3 jr = row_skew3(rowmul3(w, R), p);
+                J[0][0] = w.x; J[0][1] = w.y; J[0][2] = w.z; J[0][3] = -jr.x; J[0][4] = -jr.y; J[0][5] = -jr.z;
+            } else {
+                rows = 3;
+                const V3 la{double(c.c[0]), double(c.c[1]), double(c.c[2])}, lb{double(c.c[3]), double(c.c[4]), double(c.c[5])};
+                const V3 ba{lp.x - la.x, lp.y - la.y, lp.z - la.z}, bb{lp.x - lb.x, lp.y - lb.y, lp.z - lb.z};
+                const V3 nu{ba.y * bb.z - ba.z * bb.y, ba.z * bb.x - ba.x * bb.z, ba.x * bb.y - ba.y * bb.x};
+                const V3 de{la.x - lb.x, la.y - lb.y, la.z - lb.z};
+                const double den = sqrt(de.x * de.x + de.y * de.y + de.z * de.z);
+                res[0] = nu.x / den; res[1] = nu.y / den; res[2] = nu.z / den;
+                const double eta = 1.0 / den;
+                // rows of [de]x
+                const V3 sd[3] = {{0.0, -de.z, de.y}, {de.z, 0.0, -de.x}, {-de.y, de.x, 0.0}};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const V3 jr = row_skew3(rowmul3(sd[r], R), p);
+                    J[r][0] = -eta * sd[r].x; J[r][1] = -eta * sd[r].y; J[r][2] = -eta * sd[r].z;
+                    J[r][3] = eta * jr.x; J[r][4] = eta * jr.y; J[r][5] = eta * jr.z;
+                }
+            }
+            double sq = 0.0;
+            for (int r = 0; r < rows; ++r) sq += res[r] * res[r];
+            double rho0 = sq, rho1 = 1.0;
+            if (P.huber_delta > 0.0) {
+                const double b = P.huber_delta * P.huber_delta;
+                if (sq > b) {
+                    const double rr = sqrt(sq);
+                    rho0 = 2.0 * P.huber_delta * rr - b;
+                    rho1 = fmax(DBL_MIN, P.huber_delta / rr);
+                }
+            }
+            const double sc = sqrt(rho1);
+            for (int r = 0; r < rows; ++r) {
+                double Jr[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Jr[i] = J[r][i] * sc;
+                const double rr = res[r] * sc;
+                int qd = 0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = i; j < 6; ++j) acc[qd++] += Jr[i] * Jr[j];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc[NE_G + i] += Jr[i] * rr;
+            }
+            acc[NE_COST] = 0.5 * rho0;
+            acc[NE_CNT] = 1.0;
+        }
+    }
+    reduce_acc32(acc, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+}
+
+// ring ids + ring_start table of a previous-frame cloud; flags non-monotone / out-of-range ring ids
+__global__ __launch_bounds__(256) void track_rings_kernel(const unsigned char *src, int stride, int n, int intensity_off, int *ring, int *ring_start,
+                                                          int n_slots, int *bad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = int(*reinterpret_cast<const float *>(src + size_t(i) * stride + intensity_off));
+    const int prev = i > 0 ? int(*reinterpret_cast<const float *>(src + size_t(i - 1) * stride + intensity_off)) : -1;
+    ring[i] = r;
+    if (r < 0 || r >= n_slots - 1 || r < prev) { atomicOr(bad, 1); return; }
+    for (int k = prev + 1; k <= r; ++k) ring_start[k] = i;
+}
+
+__global__ void fill_int_kernel(int *p, int n, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off)
+{
+    TrackSet &T = ctx->track;
+    MLH_HIP(ctx, T.ring[kind].ensure(sizeof(int) * size_t(n)));
+    MLH_HIP(ctx, T.ring_start[kind].ensure(sizeof(int) * (TRACK_RING_SLOTS + 1)));
+    int *bad = T.ring_start[kind].as<int>() + TRACK_RING_SLOTS;
+    hipLaunchKernelGGL(fill_int_kernel, dim3((TRACK_RING_SLOTS + 255) / 256), dim3(256), 0, ctx->stream, T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, n);
+    MLH_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(track_rings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride, n, intensity_off, T.ring[kind].as<int>(),
+                       T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, bad);
+    MLH_HIP(ctx, hipGetLastError());
+    int hbad = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hbad) return fail(ctx, MLH_ERR_INVALID, "previous-frame cloud must be ordered by ring id (int(intensity) non-decreasing, 0 <= id < 255)");
+    return MLH_OK;
+}
+
+static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, TrackParamsDev &P)
+{
+    std::memset(&P, 0, sizeof(P));
+    TrackSet &T = ctx->track;
+    int tiles_b = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (!(kind_mask & (1 << k))) continue;
+        if (!T.grid[k].built || T.m[k] <= 0) return fail(ctx, MLH_ERR_STATE, "track_set_prev / track_set_cur have not been called for this kind");
+        if (a.dist_sq_thr > 0.f && std::sqrt(a.dist_sq_thr) > T.grid[k].h) return fail(ctx, MLH_ERR_INVALID, "distance_sq_threshold exceeds the value the index was built for");
+        TrackKind &K = P.k[k];
+        K.grid = T.grid[k].dev();
+        K.ring = T.ring[k].as<int>(); K.ring_start = T.ring_start[k].as<int>(); K.n_ring_slots = TRACK_RING_SLOTS;
+        K.cur = T.cur[k].as<float4>(); K.corr = T.corr[k].as<Corr>(); K.m = T.m[k];
+        K.tiles_a = (K.m + TRK_FPB - 1) / TRK_FPB; K.tiles_b = (K.m + TPB - 1) / TPB;
+        tiles_b += K.tiles_b;
+    }
+    if (!tiles_b) return fail(ctx, MLH_ERR_STATE, "no tracker features staged");
+    hipError_t e;
+    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
+    ctx->n_partial_tiles = tiles_b;
+    P.state = ctx->state.as<SolverState>(); P.partials = ctx->partials.as<double>();
+    P.pose_sel = a.pose_sel; P.use_init = a.init_pose ? 1 : 0;
+    for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
+    P.dist_sq_thr = a.dist_sq_thr; P.nearby_floor = int(std::floor(a.nearby_scan)); P.huber_delta = a.huber_delta;
+    return MLH_OK;
+}
+
+int track_match_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
+{
+    TrackParamsDev P;
+    int rc = fill_track_params(ctx, kind_mask, a, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(track_match_kernel, dim3(P.k[0].tiles_a + P.k[1].tiles_a), dim3(TPB), 0, ctx->stream, P);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
+{
+    TrackParamsDev P;
+    int rc = fill_track_params(ctx, kind_mask, a, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(track_linearize_kernel, dim3(P.k[0].tiles_b + P.k[1].tiles_b), dim3(TPB), 0, ctx->stream, P);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+}  // namespace mlh

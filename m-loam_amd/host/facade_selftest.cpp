@@ -126,6 +126,19 @@ int main(int argc, char **argv)
             write_file(d + "out_odom_jac.f64", jac);
             std::printf("LidarPureOdomBatchFactor: %d residuals\n", nr);
         }
+        // --- LidarTracker::trackCloud on the two tracker scans (files written by the test: [x y z ring] rows)
+        {
+            auto load = [&](const char *name) { PointICloud c; auto a = read_file<float>(d + name); for (size_t i = 0; i + 4 <= a.size(); i += 4) { PointI p; p.x = a[i]; p.y = a[i + 1]; p.z = a[i + 2]; p.intensity = a[i + 3]; c.push_back(p); } return c; };
+            cloudFeature prev_f, cur_f;
+            prev_f["corner_points_less_sharp"] = load("trk_corner_last.f32"); prev_f["surf_points_less_flat"] = load("trk_surf_last.f32");
+            cur_f["corner_points_sharp"] = load("trk_corner_sharp.f32"); cur_f["surf_points_flat"] = load("trk_surf_flat.f32");
+            LidarTracker tracker(dev);
+            const Pose pose_prev_cur = tracker.trackCloud(prev_f, cur_f, Pose());
+            double tp[7];
+            pose_prev_cur.toParam(tp);
+            write_file(d + "out_track_pose.f64", std::vector<double>(tp, tp + 7));
+            std::printf("trackCloud: %.6f %.6f %.6f\n", tp[0], tp[1], tp[2]);
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

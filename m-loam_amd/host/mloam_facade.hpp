@@ -442,6 +442,36 @@ private:
     mutable std::vector<double> J_;
 };
 
+// ------------------------------------------------------------------ LidarTracker (estimator/src/lidarTracker/lidar_tracker.h)
+// trackCloud(prev_cloud_feature, cur_cloud_feature, pose_ini) -> pose_prev_cur: scan-to-scan odometry of one LiDAR
+// (lidar_tracker.cpp:23-129). The clouds' intensity carries the ring id, as ImageSegmenter leaves it.
+class LidarTracker {
+public:
+    explicit LidarTracker(Device &dev) : dev_(dev) { mlh_track_opts_default(&opts_); }
+    mlh_track_opts &options() { return opts_; }       // DISTANCE_SQ_THRESHOLD, NEARBY_SCAN (parameters.cpp:226-227)
+    Pose trackCloud(const cloudFeature &prev_cloud_feature, const cloudFeature &cur_cloud_feature, const Pose &pose_ini)
+    {
+        const PointICloud &corner_last = prev_cloud_feature.find("corner_points_less_sharp")->second;
+        const PointICloud &surf_last = prev_cloud_feature.find("surf_points_less_flat")->second;
+        const PointICloud &corner_sharp = cur_cloud_feature.find("corner_points_sharp")->second;
+        const PointICloud &surf_flat = cur_cloud_feature.find("surf_points_flat")->second;
+        const int io = point_traits<PointI>::intensity_off, sz = (int)sizeof(PointI);
+        dev_.check(mlh_track_set_prev(dev_.ctx(), MLH_CORNER, corner_last.points.data(), sz, (int)corner_last.size(), io, MLH_MEM_HOST, opts_.distance_sq_threshold));
+        dev_.check(mlh_track_set_prev(dev_.ctx(), MLH_SURF, surf_last.points.data(), sz, (int)surf_last.size(), io, MLH_MEM_HOST, opts_.distance_sq_threshold));
+        dev_.check(mlh_track_set_cur(dev_.ctx(), MLH_CORNER, corner_sharp.points.data(), sz, (int)corner_sharp.size(), io, MLH_MEM_HOST));
+        dev_.check(mlh_track_set_cur(dev_.ctx(), MLH_SURF, surf_flat.points.data(), sz, (int)surf_flat.size(), io, MLH_MEM_HOST));
+        double p[7];
+        pose_ini.toParam(p);
+        dev_.check(mlh_track_cloud(dev_.ctx(), p, &opts_, nullptr));
+        Pose pose_prev_cur;
+        pose_prev_cur.fromParam(p);
+        return pose_prev_cur;
+    }
+private:
+    Device &dev_;
+    mlh_track_opts opts_;
+};
+
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
     std::vector<mlh_iter_stat> outer;   // one per outer iteration: matched counts, H, eigenvalues, LM iterations, costs

@@ -1,0 +1,40 @@
+"""Times LidarTracker::trackCloud (mlh_track_cloud) on two consecutive 64-ring synthetic scans, GPU vs the CPU oracle."""
+import importlib, os, sys, time, warnings
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as O
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+O.build()
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["500k"])
+gt0 = synth.gt_body_pose()
+motion = np.array([0.35, -0.12, 0.02, 0.0, 0.0, np.sin(np.deg2rad(0.75)), np.cos(np.deg2rad(0.75))])
+from scipy.spatial.transform import Rotation as Rot
+T1 = synth.pose_to_mat(gt0) @ synth.pose_to_mat(motion)
+gt1 = np.concatenate([T1[:3, 3], Rot.from_matrix(T1[:3, :3]).as_quat()])
+ctx = mla.Context(0)
+feats = {}
+for name, pose, seed in (("prev", gt0, 7), ("cur", gt1, 11)):
+    s = synth.simulate_scan(sc, pose, synth.HERCULES_BODY_T_LASER[0], 64, seed=seed)
+    begins = s.scan_start - 5
+    for r in range(s.n_rings):
+        e = begins[r + 1] if r + 1 < s.n_rings else len(s.points)
+        s.points[begins[r]:e, 3] = r
+    ctx.scan_upload(s.points, s.scan_start, s.scan_end); ctx.extract_run(); ex = ctx.extract_fetch()
+    lf = ctx.extract_voxel(0.2)
+    feats[name] = dict(pts=s.points, ex=ex, lf=lf)
+cl = np.ascontiguousarray(feats["prev"]["pts"][feats["prev"]["ex"]["less_sharp"]]); sl = np.ascontiguousarray(feats["prev"]["lf"][:, :4])
+cs = np.ascontiguousarray(feats["cur"]["pts"][feats["cur"]["ex"]["sharp"]]); sf = np.ascontiguousarray(feats["cur"]["pts"][feats["cur"]["ex"]["flat"]])
+print("prev corner/surf", len(cl), len(sl), "cur sharp/flat", len(cs), len(sf))
+p0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+def frame():
+    ctx.track_set_prev(mla.CORNER, cl); ctx.track_set_prev(mla.SURF, sl); ctx.track_set_cur(mla.CORNER, cs); ctx.track_set_cur(mla.SURF, sf)
+    return ctx.track_cloud(p0, want_stats=False)[0]
+for _ in range(3): pose = frame()
+t = time.perf_counter(); n = 20
+for _ in range(n): pose = frame()
+gpu_ms = 1e3 * (time.perf_counter() - t) / n
+t = time.perf_counter(); ref = O.track_cloud(cl, sl, cs, sf, p0); cpu_ms = 1e3 * (time.perf_counter() - t)
+print(f"trackCloud incl. staging + index build: GPU {gpu_ms:.3f} ms, CPU oracle {cpu_ms:.1f} ms; |dt| {np.linalg.norm(pose[:3]-ref['pose'][:3]):.2e}; motion error {np.linalg.norm(pose[:3]-motion[:3]):.3f} m")

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_facade_selftest(tmp_path, orc, case16, feats16):
+def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     exe = os.path.join(ROOT, "m-loam_amd", "host", "facade_selftest")
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.dirname(exe), "-s"], check=True)
@@ -23,6 +23,8 @@ def test_facade_selftest(tmp_path, orc, case16, feats16):
     feats16[0].astype(np.float32).tofile(os.path.join(d, "surf.f32"))
     feats16[1].astype(np.float32).tofile(os.path.join(d, "corner.f32"))
     case16["p0"].astype(np.float64).tofile(os.path.join(d, "pose.f64"))
+    for name in ("corner_last", "surf_last", "corner_sharp", "surf_flat"):
+        track_case[name].astype(np.float32).tofile(os.path.join(d, f"trk_{name}.f32"))
     r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
     labels = np.fromfile(os.path.join(d, "out_labels.i32"), np.int32)
@@ -76,3 +78,8 @@ def test_facade_selftest(tmp_path, orc, case16, feats16):
         for b in range(1, 5):
             if b not in (fb, eb):
                 assert not jac[b, i].any()
+    # LidarTracker::trackCloud facade
+    tp = np.fromfile(os.path.join(d, "out_track_pose.f64"), np.float64)
+    rt = orc.track_cloud(track_case["corner_last"], track_case["surf_last"], track_case["corner_sharp"], track_case["surf_flat"],
+                         np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    assert np.linalg.norm(tp[:3] - rt["pose"][:3]) < 1e-9 and np.linalg.norm(tp[3:] - rt["pose"][3:]) < 1e-9

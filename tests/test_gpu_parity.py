@@ -551,3 +551,45 @@ def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     b, none = ctx.scan2map(case16["p0"], want_stats=False)
     assert none is None and not any(s["is_degenerate"] for s in stats)
     np.testing.assert_array_equal(a, b)
+
+
+def test_track_match_parity(ctx, mla, orc, track_case):
+    """(f4) matchCornerFromScan / matchSurfFromScan: validity and the f32 coefficients bit for bit (1-NN, both directional walks with
+    their strict-< tie rule, the plane normal in f32)."""
+    tc = track_case
+    rng = np.random.default_rng(1)
+    for pose in (np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.3, -0.1, 0.02, 0.0, 0.0, 0.012, 0.99992800])):
+        pose[3:] /= np.linalg.norm(pose[3:])
+        for kind, ch, prev, cur in ((mla.CORNER, "c", tc["corner_last"], tc["corner_sharp"]), (mla.SURF, "s", tc["surf_last"], tc["surf_flat"])):
+            ctx.track_set_prev(kind, prev)
+            ctx.track_set_cur(kind, cur)
+            valid, coeffs = ctx.track_match(kind, pose)
+            rv, rc = orc.track_match(ch, prev, cur, pose)
+            assert rv.sum() > 30
+            assert np.array_equal(valid, rv)
+            assert np.array_equal(coeffs.astype(np.float32).view(np.uint32), rc.astype(np.float32).view(np.uint32))
+    # a cloud that is not ordered by ring id is refused
+    bad = tc["corner_last"].copy()
+    bad[5, 3] = 9
+    with pytest.raises(Exception):
+        ctx.track_set_prev(mla.CORNER, bad)
+
+
+def test_track_cloud_parity(ctx, mla, orc, track_case):
+    """(f4) LidarTracker::trackCloud: same correspondences, same LM iteration counts and termination, pose to 1e-9 of the oracle's
+    (north-star tolerance 1e-4 m / 1e-4 rad), and both recover the simulated motion."""
+    tc = track_case
+    ctx.track_set_prev(mla.CORNER, tc["corner_last"]); ctx.track_set_prev(mla.SURF, tc["surf_last"])
+    ctx.track_set_cur(mla.CORNER, tc["corner_sharp"]); ctx.track_set_cur(mla.SURF, tc["surf_flat"])
+    p0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    pose, stats = ctx.track_cloud(p0)
+    ref = orc.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], p0)
+    assert len(stats) == len(ref["outer"]) == 2
+    for s, o in zip(stats, ref["outer"]):
+        assert (s["n_corner"], s["n_surf"], s["lm_iterations"], s["termination"]) == (o["n_corner"], o["n_surf"], o["lm_iterations"], o["termination"])
+        assert abs(s["cost"] - o["initial_cost"]) <= 1e-9 * max(1.0, o["initial_cost"])
+        assert abs(s["final_cost"] - o["final_cost"]) <= 1e-9 * max(1.0, o["final_cost"])
+    assert max(_pose_err(pose, ref["pose"])) < 1e-9
+    assert np.linalg.norm(pose[:3] - tc["motion"][:3]) < 0.08
+    pose2, none = ctx.track_cloud(p0, want_stats=False)
+    assert none is None and max(_pose_err(pose2, pose)) < 1e-12
