@@ -242,7 +242,10 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         min_b[d] = int(std::floor(hb[d] * inv));
         div_b[d] = int(std::floor(hb[3 + d] * inv)) - min_b[d] + 1;
     }
-    if (ext[0] * ext[1] * ext[2] > 2147483647ll) {
+    // stepwise, so that the test itself cannot overflow 64 bits on absurd extents
+    const bool too_many = ext[0] > 2147483647ll || ext[1] > 2147483647ll || ext[2] > 2147483647ll || ext[0] * ext[1] > 2147483647ll ||
+                          ext[0] * ext[1] * ext[2] > 2147483647ll;
+    if (too_many) {
         // "Leaf size is too small for the input dataset": the reference returns the input cloud unchanged
         MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));

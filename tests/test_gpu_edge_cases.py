@@ -129,3 +129,67 @@ def test_status_codes(mla, case16, feats16):
         c._scan_n = 10
         c.extract_fetch()
     c.close()
+
+
+def test_voxel_filter_edge_cases(ctx, orc):
+    """VoxelGridCovarianceMLOAM: one point, all points in one voxel, every member over the trace threshold, leaf far too small for
+    the extent (the reference returns the input unchanged), bad arguments."""
+    one = np.array([[1.0, 2.0, 3.0, 7.0]], np.float32)
+    np.testing.assert_array_equal(ctx.voxel_filter(one, 0.4), one)
+    rng = np.random.default_rng(0)
+    blob = np.zeros((500, 11), np.float32)
+    blob[:, :3] = rng.uniform(10.0, 10.3, (500, 3))
+    blob[:, 3] = rng.integers(0, 3, 500)
+    blob[:, 4] = blob[:, 7] = blob[:, 9] = rng.uniform(0.005, 0.02, 500)     # distinct weights: with equal ones the reference's pick
+    blob[:, 10] = 3 * blob[:, 4]                                                # of the "heaviest" member depends on its unstable sort
+    got, ref = ctx.voxel_filter(blob, 0.4, 1.0), orc.voxel_grid_cov(blob, 0.4, 1.0)
+    assert len(got) == len(ref) <= 8
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    far = np.zeros((4, 4), np.float32)
+    far[1, 0] = 3.0e3; far[2, 1] = 3.0e3                            # (3e3 / 0.001)^2 voxels: the voxel index would overflow int32
+    np.testing.assert_array_equal(ctx.voxel_filter(far, 0.001), far)
+    with pytest.raises(Exception):
+        ctx.voxel_filter(np.zeros((0, 4), np.float32), 0.4)
+    with pytest.raises(Exception):
+        ctx.voxel_filter(one, 0.0)
+
+
+def test_association_and_odom_edge_cases(ctx, orc, synth):
+    """cloudUCTAssociateToMap with a threshold that drops everything / nothing; pure-odom table errors."""
+    rng = np.random.default_rng(2)
+    pts = np.zeros((300, 11), np.float32)
+    pts[:, :3] = rng.uniform(-20, 20, (300, 3))
+    pts[:, 3] = rng.integers(0, 2, 300)
+    ext = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.2, -0.4, 0.0, 0, 0, 0.0998334166, 0.9950041653]])
+    ext_cov = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.0003] * 3)])
+    pg, cg, meas = np.array([1.0, 2.0, 0.5, 0, 0, 0, 1.0]), np.eye(6) * 1e-6, np.diag([0.0025] * 3)
+    assert len(ctx.cloud_uct_associate_to_map(pts, pg, cg, ext, ext_cov, meas, True, 1e-9)) == 0
+    allp = ctx.cloud_uct_associate_to_map(pts, pg, cg, ext, ext_cov, meas, True, 1e9)
+    assert len(allp) == 300
+    np.testing.assert_allclose(allp[:, :3], pts[:, :3] + pg[:3].astype(np.float32), atol=1e-5)
+    with pytest.raises(Exception):
+        ctx.pure_odom_set(np.array([2], np.int32), np.zeros((1, 3)), np.zeros((1, 6)), np.array([0], np.int32), np.array([0], np.int32))
+    with pytest.raises(Exception):
+        ctx.pure_odom_set(np.array([0], np.int32), np.zeros((1, 3)), np.zeros((1, 6)), np.array([-1], np.int32), np.array([0], np.int32))
+
+
+def test_tracker_edge_cases(ctx, mla, orc, track_case):
+    """trackCloud with too few correspondences (threshold so small that nothing matches): both rounds are skipped and the pose
+    comes back unchanged, as the reference's `continue`; single-point clouds; a previous cloud confined to one ring."""
+    tc = track_case
+    ctx.track_set_prev(mla.CORNER, tc["corner_last"]); ctx.track_set_prev(mla.SURF, tc["surf_last"])   # index built for 25 m^2, queried with less
+    ctx.track_set_cur(mla.CORNER, tc["corner_sharp"]); ctx.track_set_cur(mla.SURF, tc["surf_flat"])
+    p0 = np.array([0.1, 0.2, 0.3, 0, 0, 0, 1.0])
+    pose, stats = ctx.track_cloud(p0, mla.default_track_opts(distance_sq_threshold=1e-6))
+    np.testing.assert_array_equal(pose, p0)
+    assert all(s["lm_iterations"] == 0 and s["n_corner"] + s["n_surf"] < 10 for s in stats)
+    # one ring only: the corner walk has no other ring to offer -> no corner correspondences; the surf walk needs a lower/higher ring too
+    ring0 = tc["corner_last"][tc["corner_last"][:, 3] == tc["corner_last"][0, 3]]
+    ctx.track_set_prev(mla.CORNER, ring0)
+    valid, _ = ctx.track_match(mla.CORNER, np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    rv, _ = orc.track_match("c", ring0, tc["corner_sharp"], np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    assert not valid.any() and not rv.any()
+    ctx.track_set_prev(mla.CORNER, tc["corner_last"][:1])
+    ctx.track_set_cur(mla.CORNER, tc["corner_sharp"][:1])
+    valid, _ = ctx.track_match(mla.CORNER, np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    assert not valid.any()
