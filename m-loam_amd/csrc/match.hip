@@ -1,18 +1,20 @@
 // Correspondence + linearisation kernels for gfx950 (the roofline kernels of the scan-to-map path).
 //
-// knn_features_kernel        -- per feature: pointAssociateToMap (utility.h:103-117) -> exact 5-NN in the local-map cell grid
-//   (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813). 8 lanes per feature (8 features per wavefront):
-//   the 9 x-runs of the 27-cell neighbourhood are concatenated and the lanes stride over the flat candidate list (balanced,
-//   coalesced 16 B/lane); queries with fewer than 5 candidates leave after the 18 cell_start words; each lane keeps a sorted
-//   top-5 of 64-bit (distance bits, map index) keys, the group merges with a 5-round shuffle tournament; the 5 winners'
-//   coordinates + squared distances go to HBM (80 B/feature).
-//   HBM/L2-bound: ~(16 + 72 + 16*C + 80 + 80) bytes per feature, C = candidates in the 27 cells.
-// fit_linearize_kernel<KIND> -- one lane per feature: line fit (3x3 scatter + f32 eigen-solver, hpp:669-783) or plane fit
-//   (5x3 column-pivoted QR, hpp:816-878) with the reference's gates -> residual and 1x6 Jacobian of LidarMapEdgeFactor /
+// knn_features_kernel<G, MB> -- per feature: pointAssociateToMap (utility.h:103-117) -> exact K-NN (K = 5, or 10 for buildCalibMap's
+//   non-reference LiDARs) in the local-map cell grid (the pcl::KdTreeFLANN::nearestKSearch role, feature_extract.hpp:666/813).
+//   G lanes per feature -- 16 on a frame-sized launch (latency regime), 8 on a chip-filling one (throughput regime); the group
+//   search itself lives in knn_dev.hpp: the 9 x-runs of the 27-cell neighbourhood are concatenated and the lanes stride over
+//   the flat candidate list (balanced, coalesced 16 B/lane); queries with fewer than K candidates leave after the 18 cell_start
+//   words; each lane keeps a sorted top-K of 64-bit (distance bits, map index) keys, the group merges with a K-round
+//   all-reduce-min tournament; the K winners' coordinates + squared distances go to HBM (16 K B/feature).
+//   HBM/L2-bound: ~(16 + 72 + 16*C + 16*K + 16*K) bytes per feature, C = candidates in the 27 cells.
+// fit_linearize_kernel<KMAX> -- one lane per feature: line fit (3x3 scatter + f32 eigen-solver, hpp:669-783) or plane fit
+//   (Kx3 column-pivoted QR, hpp:816-878) with the reference's gates -> residual and 1x6 Jacobian of LidarMapEdgeFactor /
 //   LidarMapPlaneNormFactor (lidar_map_factor.hpp:44-71, 143-174) -> Huber correction (Ceres corrector, rho''<=0 branch)
-//   -> wavefront-shuffle + LDS reduction of the 21+6+2 packed normal-equation sums -> one partial record per workgroup
-//   (no atomics, deterministic).
-// linearize_kernel<KIND>     -- the same evaluation on the correspondences stored by the fit kernel (what ceres::Solve
+//   -> transposed-butterfly + LDS reduction (reduce_dev.hpp) of the 21+6+2 packed normal-equation sums -> one partial record per
+//   workgroup (no atomics, deterministic) -> fused_gn_finish: the last workgroup to arrive completes the Gauss-Newton iteration
+//   (sum of the records, degeneracy test, 6x6 solve, Plus) and, on the last iteration, publishes the pose to pinned host memory.
+// linearize_kernel           -- the same evaluation on the correspondences stored by the fit kernel (what ceres::Solve
 //   does per LM iteration).
 // blockIdx -> tile mapping is XCD-aware: consecutive tiles go to the same XCD (blockIdx % 8), so each XCD's L2 holds one
 // contiguous eighth of the (spatially coherent) feature list's map neighbourhood.
