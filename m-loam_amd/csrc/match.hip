@@ -655,7 +655,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     KParams P;
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
-    // kernel A: correspondences (32 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
+    // kernel A: correspondences (8 or 16 lanes per feature); kernel B: fit + linearise + reduce (one lane per feature)
     const int grid_a = ((P.k[0].tiles_a + P.k[1].tiles_a + 7) / 8) * 8;
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
     const bool mb = P.n_blocks > 1;
