@@ -762,7 +762,6 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
                         mlh_iter_stat *stats)
 {
     if (!ctx || !poses_inout || !opts || !bo || n_iters <= 0 || bo->n_blocks <= 0 || bo->n_blocks > 8) return MLH_ERR_INVALID;
-    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "pose-block mode is single-GPU in this round");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     const int nb = bo->n_blocks;
     int rc = ensure_state(ctx, n_iters * nb);
@@ -775,9 +774,17 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
         MatchArgs a = args_from_opts(opts, mask, 0);
         a.n_blocks = nb;
         for (int b = 0; b < nb; ++b) { a.k_neigh[b] = bo->k_neigh[b]; a.eig_thre[b] = bo->eig_thre[b]; a.freeze[b] = bo->freeze[b]; }
-        a.finish = 1;
-        a.stat_slot = stats ? it * nb : -1;
-        if ((rc = match_launch(ctx, a))) return rc;
+        if (!ctx->comm) {
+            a.finish = 1;
+            a.stat_slot = stats ? it * nb : -1;
+            if ((rc = match_launch(ctx, a))) return rc;
+        } else {
+            // multi-GPU: per-block local sums in the fit kernel's last workgroup, ONE all-reduce of nb x 32 doubles, identical updates
+            a.finish = 2;
+            if ((rc = match_launch(ctx, a))) return rc;
+            if ((rc = comm_allreduce_blocks(ctx, nb))) return rc;
+            if ((rc = gn_update_blocks_prereduced_launch(ctx, nb, bo->eig_thre, bo->freeze, stats ? it * nb : -1))) return rc;
+        }
     }
     HostPublish hs;
     std::vector<IterStatDev> hd(stats ? size_t(n_iters) * nb : 0);

@@ -61,6 +61,16 @@ int comm_allreduce_state(mlh_ctx *ctx, int to_ce)
     return MLH_OK;
 }
 
+int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks)
+{
+    if (!ctx->comm) return MLH_OK;
+    SolverState *S = ctx->state.as<SolverState>();
+    double *buf = &S->neb[0][0];
+    int rc = rccl().all_reduce(buf, buf, size_t(NE_STRIDE) * size_t(n_blocks), /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
+    return MLH_OK;
+}
+
 void comm_destroy(mlh_ctx *ctx)
 {
     if (ctx->comm) { rccl().comm_destroy(ctx->comm); ctx->comm = nullptr; }

@@ -39,6 +39,7 @@ struct SolverState {
     double V[36];            // PoseLocalParameterization::V_update_
     double ne[NE_STRIDE];    // normal equations at x
     double ce[NE_STRIDE];    // normal equations at cand (multi-GPU: all-reduced before lm_step consumes them)
+    double neb[8][NE_STRIDE];   // multi-GPU pose-block mode: one record per block, all-reduced together
     double diag[6];          // LM diagonal (Jacobi-scaled)
     double S[6];             // Jacobi scaling 1/(1+sqrt(H_ii)) from iteration zero
     double radius, decrease_factor;
@@ -291,8 +292,10 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
 int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
+int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double *eig_thre, const int *freeze, int stat_slot);
 // comm.hip
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
+int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks);
 void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream
 int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks = 0);
 int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot);

@@ -374,11 +374,25 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     __syncthreads();
     if (P.finish == 2) {
         // multi-GPU: only the local reduction happens here; the all-reduce and the (redundant, identical) solve follow
-        SumArgs sa;
-        sa.p = P.partials;
-        sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
-        sum_partials(sa, f_ne, f_cnt2, f_scratch);
-        if (threadIdx.x < NE_STRIDE) P.state->ne[threadIdx.x] = f_ne[threadIdx.x];
+        if (P.n_blocks == 1) {
+            SumArgs sa;
+            sa.p = P.partials;
+            sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
+            sum_partials(sa, f_ne, f_cnt2, f_scratch);
+            if (threadIdx.x < NE_STRIDE) P.state->ne[threadIdx.x] = f_ne[threadIdx.x];
+        } else {
+            for (int b = 0; b < P.n_blocks; ++b) {         // one record per pose block, all-reduced in one message
+                SumArgs sa;
+                sa.p = P.partials;
+                sa.lo[0] = P.k[0].m > 0 ? P.k[0].blk_start[b] / TPB : 0;
+                sa.hi[0] = P.k[0].m > 0 ? (P.k[0].blk_start[b + 1] + TPB - 1) / TPB : 0;
+                sa.lo[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? P.k[1].blk_start[b] / TPB : 0);
+                sa.hi[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? (P.k[1].blk_start[b + 1] + TPB - 1) / TPB : 0);
+                sum_partials(sa, f_ne, f_cnt2, f_scratch);
+                if (threadIdx.x < NE_STRIDE) P.state->neb[b][threadIdx.x] = f_ne[threadIdx.x];
+                __syncthreads();
+            }
+        }
         if (threadIdx.x == 0) *P.ticket = 0u;
         return;
     }

@@ -22,6 +22,21 @@ __global__ __launch_bounds__(256) void gn_update_kernel(SumArgs sa, SolverState 
     gn_finish2<true>(ne, cnt2, S->x, S, eig_thre, 0, stat, scratch);
 }
 
+// multi-GPU pose-block mode: the per-block records arrive all-reduced in S->neb; every rank runs the identical per-block updates
+struct BlockUpd { int n; double thre[8]; int freeze[8]; };
+__global__ __launch_bounds__(256) void gn_update_blocks_kernel(SolverState *S, BlockUpd U, IterStatDev *stat)
+{
+    __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
+    for (int b = 0; b < U.n; ++b) {
+        if (threadIdx.x < NE_STRIDE) ne[threadIdx.x] = S->neb[b][threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) { cnt2[0] = ne[NE_CNT + 1]; cnt2[1] = ne[NE_CNT + 2]; }
+        __syncthreads();
+        if (threadIdx.x < 2) gn_finish2<true>(ne, cnt2, b == 0 ? S->x : S->xb[b], b == 0 ? S : nullptr, U.thre[b], U.freeze[b], stat ? stat + b : nullptr, scratch);
+        __syncthreads();
+    }
+}
+
 // reduce only: S->ne <- sum of partials (used by the host-driven mlh_match_linearize / mlh_linearize)
 __global__ __launch_bounds__(256) void reduce_only_kernel(SumArgs sa, SolverState *S, int to_ce)
 {
@@ -222,6 +237,18 @@ int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot
     prof_begin(ctx, MLH_K_SOLVE);
     hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
                        map_eig_thre, stat_ptr(ctx, stat_slot), 1);
+    prof_end(ctx, MLH_K_SOLVE);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double *eig_thre, const int *freeze, int stat_slot)
+{
+    BlockUpd U;
+    U.n = n_blocks;
+    for (int b = 0; b < 8; ++b) { U.thre[b] = b < n_blocks ? eig_thre[b] : 0.0; U.freeze[b] = b < n_blocks ? freeze[b] : 0; }
+    prof_begin(ctx, MLH_K_SOLVE);
+    hipLaunchKernelGGL(gn_update_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->state.as<SolverState>(), U, stat_ptr(ctx, stat_slot));
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

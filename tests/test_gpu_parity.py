@@ -228,6 +228,19 @@ def test_rccl_single_rank_path(mla, orc, case16, feats16):
     assert np.allclose(qa, qb, rtol=0, atol=1e-13)
     red = b.allreduce_f64(np.arange(29, dtype=np.float64))
     assert np.array_equal(red, np.arange(29, dtype=np.float64))
+    # pose-block mode (config 4) under the communicator: per-block records, one all-reduce, identical per-block updates
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    half_s, half_c = len(feats16[0]) // 2, len(feats16[1]) // 2
+    poses0 = np.stack([case16["p0"], case16["p0"]])
+    res = []
+    for c in (a, b):
+        c.features_set_blocks(mla.SURF, [feats16[0][:half_s], feats16[0][half_s:]])
+        c.features_set_blocks(mla.CORNER, [feats16[1][:half_c], feats16[1][half_c:]])
+        res.append(c.gn_solve_blocks(poses0, 3, [5, 10], [100.0, 100.0], [0, 1]))
+    assert np.allclose(res[0][0], res[1][0], rtol=0, atol=1e-13)
+    for it_a, it_b in zip(res[0][1], res[1][1]):
+        for x, y in zip(it_a, it_b):
+            assert (x["n_surf"], x["n_corner"], x["is_degenerate"]) == (y["n_surf"], y["n_corner"], y["is_degenerate"])
     a.close()
     b.close()
 
