@@ -84,15 +84,17 @@ int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *la
  * The cloud is ring-major; scan_start[r]/scan_end[r] are ScanInfo::scan_start_ind_/scan_end_ind_
  * (already inset by +5/-6, image_segmenter.hpp:385-387).
  *
- * mlh_scan_upload   stages one cloud (+ring table) in HBM             [HOST or DEV source]
+ * mlh_scan_upload   stages one cloud (+ring table) in HBM             [HOST or DEV source]; intensity_offset_bytes (-1: none) is the
+ *                   byte offset of the f32 intensity field the per-ring VoxelGrid averages with the coordinates (the tracker reads
+ *                   the ring id from it, image_segmenter.hpp:128)
  * mlh_extract_run   curvature (cpp:133-142), per-sector sort + greedy labelling (cpp:152-265), index lists
  * mlh_extract_fetch copies results back: label[n] in {2,1,0,-1} (cloud_label), curvature[n], and the four index
  *                   lists in the reference's emission order: 0 corner_points_sharp, 1 corner_points_less_sharp,
  *                   2 surf_points_flat, 3 surf_points_less_flat BEFORE the per-ring VoxelGrid (positions with
  *                   label<=0, cpp:258-264). Any output pointer may be NULL.
  */
-int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, const int *scan_start, const int *scan_end,
-                    int n_rings, int mem);
+int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, const int *scan_start,
+                    const int *scan_end, int n_rings, int mem);
 int mlh_extract_run(mlh_ctx *ctx);
 int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4]);
 /* (a3) the per-ring pcl::VoxelGrid(leaf = 0.2 m) extractCloud applies to the less-flat points of every ring

@@ -84,7 +84,7 @@ def load_library():
     lib.mlh_profile_sample.argtypes = [vp, ci]
     lib.mlh_profile_reset.argtypes = [vp]
     lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
-    lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, vp, vp, ci, ci]
+    lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci]
     lib.mlh_extract_run.argtypes = [vp]
     lib.mlh_extract_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.mlh_extract_voxel_run.argtypes = [vp, cf]
@@ -226,10 +226,10 @@ class Context:
         if mem == MEM_HOST:
             ss = np.ascontiguousarray(scan_start, np.int32)
             se = np.ascontiguousarray(scan_end, np.int32)
-            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, n, _p(ss), _p(se), len(ss), mem))
+            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, 12 if stride >= 16 else -1, n, _p(ss), _p(se), len(ss), mem))
         else:
             ss, se = scan_start.contiguous(), scan_end.contiguous()
-            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
+            self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, 12 if stride >= 16 else -1, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
         self._scan_n = n
 
     def extract_run(self):

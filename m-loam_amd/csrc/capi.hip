@@ -273,7 +273,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
-    { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.cur[k].release(); t.corr[k].release(); } }
+    { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
@@ -329,8 +329,8 @@ int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *la
 }
 
 // ---------------------------------------------------------------- extraction
-int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, const int *scan_start, const int *scan_end,
-                    int n_rings, int mem)
+int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, const int *scan_start,
+                    const int *scan_end, int n_rings, int mem)
 {
     if (!ctx) return MLH_ERR_INVALID;
     if (!scan_start || !scan_end || n_rings <= 0) return fail(ctx, MLH_ERR_INVALID, "bad ring table");
@@ -338,7 +338,8 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int n, c
     ScanBuf &sb = ctx->scan;
     sb.extracted = false;
     sb.voxelised = false;
-    int rc = stage_points(ctx, points, stride_bytes, n, mem, -1, -1, sb.pts, nullptr, ctx->tmp);
+    if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
+    int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, sb.pts, nullptr, ctx->tmp);
     if (rc) return rc;
     std::vector<int> hs(n_rings), he(n_rings);
     if (mem == MLH_MEM_HOST) {
@@ -868,9 +869,13 @@ int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_by
     int rc = stage_points(ctx, points, stride_bytes, n, mem, -2, -1, g.raw, nullptr, ctx->tmp);
     if (rc) return rc;
     const unsigned char *d_src = (mem == MLH_MEM_HOST) ? ctx->tmp.as<unsigned char>() : static_cast<const unsigned char *>(points);
+    // second copy in the original order with the ring id in w: what the scan-line walks stream over
+    MLH_HIP(ctx, T.walk[kind].ensure(sizeof(float4) * size_t(n)));
+    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride_bytes, n, intensity_offset_bytes, -1,
+                       T.walk[kind].as<float4>(), (float4 *)nullptr);
     if ((rc = track_set_prev_rings(ctx, kind, d_src, stride_bytes, n, intensity_offset_bytes))) return rc;
     g.n = n;
-    g.min_match_sq_dis = distance_sq_threshold;
+    g.min_match_sq_dis = distance_sq_threshold / float(TRACK_SHELLS * TRACK_SHELLS);   // cell edge = 1.001 * sqrt(thr) / TRACK_SHELLS
     MapGrid *gp[1] = {&g};
     if ((rc = grid_build_grids(ctx, gp, 1, true))) return rc;
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -162,10 +162,11 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     int n = 0, max_frame = 0, max_ext = 0;
 };
 
+constexpr int TRACK_SHELLS = 4;          // the tracker's index cells are 1/4 of its acceptance radius (track.hip: nearest_in_radius)
 constexpr int TRACK_RING_SLOTS = 258;   // ring ids 0..255 (+ the slots the walks' upper bound can reach)
 struct TrackSet {   // scan-to-scan odometry (track.hip): previous frame's clouds + indices, current frame's features
     MapGrid grid[2];
-    DevBuf ring[2], ring_start[2], cur[2], corr[2];
+    DevBuf ring[2], ring_start[2], walk[2], cur[2], corr[2];
     int m[2] = {0, 0};
 };
 struct TrackArgs {

@@ -140,19 +140,26 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         int cr = 0, hi = lds_run[1], base = lds_run[10], lo = 0;
-        // KNN_U candidates per lane per trip: the addresses depend only on the run table, so the KNN_U loads are in flight together
+        // KNN_U candidates per lane per trip. The addresses depend only on the run table, so they are resolved first (LDS look-ups,
+        // divergent control flow) and the KNN_U loads are then issued UNCONDITIONALLY, back to back (lanes past the end re-read
+        // element 0): with the loads inside the divergent address code the compiler drains vmcnt after every one of them and a trip
+        // costs KNN_U memory round trips instead of one.
         for (int j = gl; j < total; j += G * KNN_U) {
-            float4 p[KNN_U];
+            int addr[KNN_U];
             bool v[KNN_U];
 #pragma unroll
             for (int u = 0; u < KNN_U; ++u) {
                 const int jj = j + G * u;
                 v[u] = jj < total;
+                addr[u] = 0;
                 if (v[u]) {
                     while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[10 + cr]; }
-                    p[u] = g.sorted[base + (jj - lo)];
+                    addr[u] = base + (jj - lo);
                 }
             }
+            float4 p[KNN_U];
+#pragma unroll
+            for (int u = 0; u < KNN_U; ++u) p[u] = g.sorted[addr[u]];
 #pragma unroll
             for (int u = 0; u < KNN_U; ++u) {
                 if (v[u]) {

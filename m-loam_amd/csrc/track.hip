@@ -21,12 +21,24 @@
 
 namespace mlh {
 
+#ifdef MLH_STAGE_CLOCK
+__device__ unsigned long long g_stage_clk_track[4096 * 4];
+#define MLH_TSTAGE(i)                                                                        \
+    do {                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stage_clk_track[blockIdx.x * 4 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MLH_TSTAGE(i) do { } while (0)
+#endif
+
 constexpr int TRK_G = 16;                 // lanes per feature
 constexpr int TRK_FPB = TPB / TRK_G;
 constexpr unsigned BACKWARD_BIT = 0x40000000u;
 
 struct TrackKind {
-    GridDev grid;            // previous frame's cloud (raw[] in the original, ring-ordered order)
+    GridDev grid;            // previous frame's cloud, indexed
+    const float4 *walk;      // the same cloud in its original (ring-ordered) order: {x, y, z, ring id as float}
     const int *ring;         // ring id of every previous-frame point
     const int *ring_start;   // ring_start[r] = first index whose ring id is >= r   (0 .. max_ring + 1 valid, beyond: n)
     int n_ring_slots;        // entries of ring_start
@@ -43,6 +55,8 @@ struct TrackParamsDev {
     int use_init;
     double init_pose[7];
     float dist_sq_thr;
+    float cell_h;            // cell edge of the previous-frame indices (a quarter of the acceptance radius)
+    int shells;              // cube half-width (in cells) that covers the acceptance radius
     int nearby_floor;        // floor(NEARBY_SCAN): rings id - nf .. id + nf take part in the walks
     double huber_delta;
 };
@@ -74,9 +88,90 @@ __device__ __forceinline__ int walk_index(unsigned rank, int closest)
     return (rank & BACKWARD_BIT) ? closest - 1 - int(rank & ~BACKWARD_BIT) : closest + 1 + int(rank);
 }
 
+// Exact nearest neighbour within sqrt(thr) by a group of 16 lanes. The index cells are a quarter of the acceptance radius, so the
+// usual case (the neighbour of a tracked feature is decimetres away) costs one 27-cell search; a result closer than one cell edge is
+// provably the global one. Otherwise the search widens cube by cube (half-width s cells covers every point within s cell edges)
+// until the best candidate is inside the covered radius or the cube covers the acceptance radius.
+__device__ __forceinline__ unsigned long long nearest_in_radius(const GridDev &g, float h, int shells, float qx, float qy, float qz, int gl, int *lds_run)
+{
+    unsigned long long nn[1];
+    knn_group<1, TRK_G>(g, qx, qy, qz, gl, lds_run, nn);
+    unsigned long long best = nn[0];
+    if (best != KEY_INF && __uint_as_float(unsigned(best >> 32)) < h * h) return best;     // uniform over the group
+    const float fx = floorf((qx - g.ox) * g.inv_h), fy = floorf((qy - g.oy) * g.inv_h), fz = floorf((qz - g.oz) * g.inv_h);
+    const float lim = float(shells + 1);
+    const int cx = int(fminf(fmaxf(fx, -lim), float(g.nx) + lim)), cy = int(fminf(fmaxf(fy, -lim), float(g.ny) + lim)),
+              cz = int(fminf(fmaxf(fz, -lim), float(g.nz) + lim));
+    for (int s = 2; s <= shells; ++s) {
+        const int x0 = max(cx - s, 0), x1 = min(cx + s, g.nx - 1);
+        const int side = 2 * s + 1, n_rows = side * side;
+        unsigned long long mine = KEY_INF;
+        // 16 x-rows of the cube at a time, exactly as knn_group treats its 9: bounds by lane, prefix scan, run table in LDS, lanes
+        // striding over the flat concatenation with 4 loads in flight
+        for (int chunk = 0; chunk < n_rows; chunk += TRK_G) {
+            const int r = chunk + gl;
+            int b = 0, e = 0;
+            if (r < n_rows && x0 <= x1) {
+                const int y = cy + (r % side) - s, z = cz + (r / side) - s;
+                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                    const int row = (z * g.ny + y) * g.nx;
+                    b = g.cell_start[row + x0];
+                    e = g.cell_start[row + x1 + 1];
+                }
+            }
+            const int len = e - b;
+            int incl = len;
+            { const int t = dpp_row_shr<1>(incl); if (gl >= 1) incl += t; }
+            { const int t = dpp_row_shr<2>(incl); if (gl >= 2) incl += t; }
+            { const int t = dpp_row_shr<4>(incl); if (gl >= 4) incl += t; }
+            { const int t = dpp_row_shr<8>(incl); if (gl >= 8) incl += t; }
+            const int total = __shfl(incl, TRK_G - 1, TRK_G);
+            if (total > 0) {                                  // uniform over the group
+                __builtin_amdgcn_wave_barrier();
+                lds_run[gl] = incl - len;                     // prefix[r]
+                lds_run[17 + gl] = b;                         // base[r]
+                if (gl == 0) lds_run[16] = total;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                int cr = 0, hi = lds_run[1], base = lds_run[17], lo = 0;
+                for (int j = gl; j < total; j += TRK_G * 4) {
+                    int addr[4];
+                    bool v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int jj = j + TRK_G * u;
+                        v[u] = jj < total;
+                        addr[u] = 0;
+                        if (v[u]) {
+                            while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[17 + cr]; }
+                            addr[u] = base + (jj - lo);
+                        }
+                    }
+                    float4 p[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) p[u] = g.sorted[addr[u]];      // unconditional: all four in flight together
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (v[u]) {
+                            const float dx = p[u].x - qx, dy2 = p[u].y - qy, dz2 = p[u].z - qz;
+                            float d = dx * dx; d += dy2 * dy2; d += dz2 * dz2;
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+                            mine = key < mine ? key : mine;
+                        }
+                    }
+                }
+            }
+        }
+        best = group_min16(mine);
+        const float r = float(s) * h;
+        if (best != KEY_INF && __uint_as_float(unsigned(best >> 32)) < r * r) break;
+    }
+    return best;
+}
+
 __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
 {
-    __shared__ int s_run[TRK_FPB * 20];
+    __shared__ int s_run[TRK_FPB * 36];
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = blockIdx.x;
     if (tile >= total) return;
@@ -85,6 +180,7 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
     const TrackKind &K = P.k[kind];
     const int grp = threadIdx.x / TRK_G, gl = threadIdx.x % TRK_G;
     const int f = tile * TRK_FPB + grp;
+    MLH_TSTAGE(0);
     if (f >= K.m) return;
     q4 q;
     d3 t;
@@ -94,7 +190,8 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
     const d3 r = qrot(q, d3{double(fp.x), double(fp.y), double(fp.z)});
     const float sx = float(r.x + t.x), sy = float(r.y + t.y), sz = float(r.z + t.z);
     unsigned long long nn[1];
-    knn_group<1, TRK_G>(K.grid, sx, sy, sz, gl, s_run + grp * 20, nn);
+    nn[0] = nearest_in_radius(K.grid, P.cell_h, P.shells, sx, sy, sz, gl, s_run + grp * 36);
+    MLH_TSTAGE(1);
     bool valid = false;
     float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float d1 = __uint_as_float(unsigned(nn[0] >> 32));
@@ -103,35 +200,53 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
         const int id = K.ring[closest];
         const int r_hi = min(id + P.nearby_floor + 1, K.n_ring_slots - 1), r_lo = max(id - P.nearby_floor, 0);
         const int fwd_end = K.ring_start[r_hi], bwd_begin = K.ring_start[r_lo];
-        const float4 *pts = K.grid.raw;
+        const float4 *pts = K.walk;
         const unsigned long long thr_key = (unsigned long long)__float_as_uint(P.dist_sq_thr) << 32;   // strict `<` against the threshold
         unsigned long long k2 = ~0ull, k3 = ~0ull;
+        constexpr int WU = 8;                                      // loads in flight per lane: the walks are latency-bound otherwise
         // increasing index: closest+1 .. fwd_end-1
-        for (int j = closest + 1 + gl; j < fwd_end; j += TRK_G) {
-            const float4 p = pts[j];
-            const int rj = K.ring[j];
-            const float dd = (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | unsigned(j - closest - 1);
-            if (key < thr_key) {
-                if (kind == MLH_CORNER) { if (rj > id) k2 = key < k2 ? key : k2; }
-                else if (rj <= id) k2 = key < k2 ? key : k2;
-                else k3 = key < k3 ? key : k3;
+        for (int j0 = closest + 1 + gl; j0 < fwd_end; j0 += TRK_G * WU) {
+            float4 p[WU];
+#pragma unroll
+            for (int u = 0; u < WU; ++u) { const int j = j0 + TRK_G * u; if (j < fwd_end) p[u] = pts[j]; }
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int j = j0 + TRK_G * u;
+                if (j < fwd_end) {
+                    const int rj = int(p[u].w);
+                    const float dd = (p[u].x - sx) * (p[u].x - sx) + (p[u].y - sy) * (p[u].y - sy) + (p[u].z - sz) * (p[u].z - sz);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | unsigned(j - closest - 1);
+                    if (key < thr_key) {
+                        if (kind == MLH_CORNER) { if (rj > id) k2 = key < k2 ? key : k2; }
+                        else if (rj <= id) k2 = key < k2 ? key : k2;
+                        else k3 = key < k3 ? key : k3;
+                    }
+                }
             }
         }
         // decreasing index: closest-1 .. bwd_begin
-        for (int j = closest - 1 - gl; j >= bwd_begin; j -= TRK_G) {
-            const float4 p = pts[j];
-            const int rj = K.ring[j];
-            const float dd = (p.x - sx) * (p.x - sx) + (p.y - sy) * (p.y - sy) + (p.z - sz) * (p.z - sz);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (BACKWARD_BIT | unsigned(closest - 1 - j));
-            if (key < thr_key) {
-                if (kind == MLH_CORNER) { if (rj < id) k2 = key < k2 ? key : k2; }
-                else if (rj >= id) k2 = key < k2 ? key : k2;
-                else k3 = key < k3 ? key : k3;
+        for (int j0 = closest - 1 - gl; j0 >= bwd_begin; j0 -= TRK_G * WU) {
+            float4 p[WU];
+#pragma unroll
+            for (int u = 0; u < WU; ++u) { const int j = j0 - TRK_G * u; if (j >= bwd_begin) p[u] = pts[j]; }
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int j = j0 - TRK_G * u;
+                if (j >= bwd_begin) {
+                    const int rj = int(p[u].w);
+                    const float dd = (p[u].x - sx) * (p[u].x - sx) + (p[u].y - sy) * (p[u].y - sy) + (p[u].z - sz) * (p[u].z - sz);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (BACKWARD_BIT | unsigned(closest - 1 - j));
+                    if (key < thr_key) {
+                        if (kind == MLH_CORNER) { if (rj < id) k2 = key < k2 ? key : k2; }
+                        else if (rj >= id) k2 = key < k2 ? key : k2;
+                        else k3 = key < k3 ? key : k3;
+                    }
+                }
             }
         }
         k2 = group_min16(k2);
         k3 = group_min16(k3);
+        MLH_TSTAGE(2);
         if (kind == MLH_CORNER) {
             if (k2 != ~0ull) {
                 const float4 a = pts[closest], b = pts[walk_index(unsigned(k2), closest)];
@@ -157,7 +272,17 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
         c.pad = 0;
         K.corr[f] = c;
     }
+    MLH_TSTAGE(3);
 }
+
+#ifdef MLH_STAGE_CLOCK
+}  // namespace mlh
+extern "C" int mlh_debug_stage_clock_track(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_track), sizeof(unsigned long long) * size_t(n_words));
+}
+namespace mlh {
+#endif
 
 struct V3 { double x, y, z; };
 __device__ __forceinline__ V3 rowmul3(const V3 &a, const double (&M)[9])      // a^T M
@@ -301,10 +426,11 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     for (int k = 0; k < 2; ++k) {
         if (!(kind_mask & (1 << k))) continue;
         if (!T.grid[k].built || T.m[k] <= 0) return fail(ctx, MLH_ERR_STATE, "track_set_prev / track_set_cur have not been called for this kind");
-        if (a.dist_sq_thr > 0.f && std::sqrt(a.dist_sq_thr) > T.grid[k].h) return fail(ctx, MLH_ERR_INVALID, "distance_sq_threshold exceeds the value the index was built for");
+        if (a.dist_sq_thr > 0.f && std::sqrt(a.dist_sq_thr) > T.grid[k].h * float(TRACK_SHELLS)) return fail(ctx, MLH_ERR_INVALID, "distance_sq_threshold exceeds the value the index was built for");
+        P.cell_h = T.grid[k].h;
         TrackKind &K = P.k[k];
         K.grid = T.grid[k].dev();
-        K.ring = T.ring[k].as<int>(); K.ring_start = T.ring_start[k].as<int>(); K.n_ring_slots = TRACK_RING_SLOTS;
+        K.walk = T.walk[k].as<float4>(); K.ring = T.ring[k].as<int>(); K.ring_start = T.ring_start[k].as<int>(); K.n_ring_slots = TRACK_RING_SLOTS;
         K.cur = T.cur[k].as<float4>(); K.corr = T.corr[k].as<Corr>(); K.m = T.m[k];
         K.tiles_a = (K.m + TRK_FPB - 1) / TRK_FPB; K.tiles_b = (K.m + TPB - 1) / TPB;
         tiles_b += K.tiles_b;
@@ -316,6 +442,7 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     P.state = ctx->state.as<SolverState>(); P.partials = ctx->partials.as<double>();
     P.pose_sel = a.pose_sel; P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
+    P.shells = TRACK_SHELLS;
     P.dist_sq_thr = a.dist_sq_thr; P.nearby_floor = int(std::floor(a.nearby_scan)); P.huber_delta = a.huber_delta;
     return MLH_OK;
 }

@@ -235,7 +235,7 @@ public:
     {
         const int n = (int)laser_cloud_in.size();
         const int rings = (int)scan_info.scan_start_ind_.size();
-        dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), n, scan_info.scan_start_ind_.data(),
+        dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, n, scan_info.scan_start_ind_.data(),
                                    scan_info.scan_end_ind_.data(), rings, MLH_MEM_HOST));
         dev_.check(mlh_extract_run(dev_.ctx()));
         std::vector<int32_t> lists[4];

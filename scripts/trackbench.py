@@ -38,3 +38,30 @@ for _ in range(n): pose = frame()
 gpu_ms = 1e3 * (time.perf_counter() - t) / n
 t = time.perf_counter(); ref = O.track_cloud(cl, sl, cs, sf, p0); cpu_ms = 1e3 * (time.perf_counter() - t)
 print(f"trackCloud incl. staging + index build: GPU {gpu_ms:.3f} ms, CPU oracle {cpu_ms:.1f} ms; |dt| {np.linalg.norm(pose[:3]-ref['pose'][:3]):.2e}; motion error {np.linalg.norm(pose[:3]-motion[:3]):.3f} m")
+# component timing
+def tm(fn, n=20):
+    fn(); ctx.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    ctx.synchronize(); return 1e3 * (time.perf_counter() - t) / n
+print("set_prev corner %.3f ms, set_prev surf %.3f ms, set_cur corner %.3f, set_cur surf %.3f, track_cloud %.3f ms" % (
+    tm(lambda: ctx.track_set_prev(mla.CORNER, cl)), tm(lambda: ctx.track_set_prev(mla.SURF, sl)),
+    tm(lambda: ctx.track_set_cur(mla.CORNER, cs)), tm(lambda: ctx.track_set_cur(mla.SURF, sf)),
+    tm(lambda: ctx.track_cloud(p0, want_stats=False))))
+
+if os.environ.get("MLOAM_HIP_LIB"):
+    import ctypes as C
+    lib = mla.load_library()
+    ctx.track_cloud(p0, want_stats=False); ctx.synchronize()
+    nwg = (len(cs) + 15) // 16 + (len(sf) + 15) // 16
+    buf = (C.c_ulonglong * (nwg * 4))()
+    lib.mlh_debug_stage_clock_track.argtypes = [C.c_void_p, C.c_int]
+    assert lib.mlh_debug_stage_clock_track(buf, nwg * 4) == 0
+    t = np.frombuffer(buf, np.uint64).reshape(nwg, 4).astype(np.int64)
+    t0 = t[:, 0].min()
+    rel = (t - t0) * 0.01
+    ok = (t > 0).all(axis=1)
+    print("track_match workgroups", nwg, "complete", int(ok.sum()))
+    for i, nm in enumerate(["start", "nn done", "walks done", "end"]):
+        print(f"{nm:12s} med {np.median(rel[ok, i]):8.2f} max {rel[ok, i].max():8.2f} us")
+    w = np.argsort(-rel[:, 3])[:5]
+    print("slowest:", [(int(i), [round(float(x), 1) for x in rel[i]]) for i in w])

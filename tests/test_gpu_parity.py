@@ -287,6 +287,17 @@ def test_per_ring_voxel_grid_parity(ctx, orc, case16):
     assert np.mean(got.view(np.uint32) == ref.view(np.uint32)) > 0.9
 
 
+def test_per_ring_voxel_grid_carries_intensity(ctx, orc, track_case):
+    """The intensity field travels through extractCloud's VoxelGrid (averaged with the coordinates): with intensity = ring id, as
+    ImageSegmenter sets it, every thinned less-flat point keeps its ring -- what the scan-to-scan tracker reads."""
+    sc = track_case["scans"][0]
+    got = ctx.extract(sc.points, sc.scan_start, sc.scan_end, voxel_leaf=0.2)["less_flat_ds"]
+    ref = orc.extract(sc.points, sc.scan_start, sc.scan_end)["less_flat_ds"]
+    assert got.shape == ref.shape and ref[:, 3].max() == sc.n_rings - 1
+    np.testing.assert_array_equal(got[:, 3], ref[:, 3])
+    assert np.all(np.diff(got[:, 3]) >= 0)
+
+
 def test_point_uncertainty_parity(ctx, mla, orc, synth, feats16):
     rng = np.random.default_rng(3)
     pts = feats16[0][:4000].copy()
