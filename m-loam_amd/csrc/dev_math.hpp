@@ -437,10 +437,10 @@ __device__ inline void plane_fit_qr_f(const float (&ax)[ROWS], const float (&ay)
     } else if (nonzero_pivots == 1) {
         x0 = y[0] / c0[0];
     }
-    nx = ny = nz = 0.f;
-    if (p0 == 0) nx = x0; else if (p0 == 1) ny = x0; else nz = x0;
-    if (p1 == 0) nx = x1; else if (p1 == 1) ny = x1; else nz = x1;
-    if (p2 == 0) nx = x2; else if (p2 == 1) ny = x2; else nz = x2;
+    // (p0, p1, p2) is a permutation of (0, 1, 2): selects, so the three results stay in registers (no scratch round trip)
+    nx = (p0 == 0) ? x0 : ((p1 == 0) ? x1 : x2);
+    ny = (p0 == 1) ? x0 : ((p1 == 1) ? x1 : x2);
+    nz = (p0 == 2) ? x0 : ((p1 == 2) ? x1 : x2);
 }
 
 }  // namespace mlh

@@ -425,12 +425,15 @@ template <int K>
 __device__ __forceinline__ bool fit_feature(const KParams &P, const KindP &Kd, int kind, int f, float (&coef)[6])
 {
     const float4 *nb = Kd.nbr + size_t(f) * Kd.nbr_stride;
-    const float4 last = nb[K - 1];
-    if (!(last.w < P.min_match_sq_dis)) return false;     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
+    // all K neighbours are requested before the acceptance test looks at the last one: one memory round trip, not two (the few
+    // bytes wasted on rejected features are nothing next to a round trip on this kernel's critical path)
+    float4 v[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) v[j] = nb[j];
+    if (!(v[K - 1].w < P.min_match_sq_dis)) return false;     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
     float ax[K], ay[K], az[K];
 #pragma unroll
-    for (int j = 0; j < K - 1; ++j) { const float4 v = nb[j]; ax[j] = v.x; ay[j] = v.y; az[j] = v.z; }
-    ax[K - 1] = last.x; ay[K - 1] = last.y; az[K - 1] = last.z;
+    for (int j = 0; j < K; ++j) { ax[j] = v[j].x; ay[j] = v[j].y; az[j] = v[j].z; }
     return kind == MLH_SURF ? fit_plane<K>(ax, ay, az, P.min_plane_dis, coef) : fit_line<K>(ax, ay, az, coef);
 }
 
