@@ -38,11 +38,11 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(synth, preset, seed=42):
+def build_workload(synth, preset, seed=42, n_lidars=None):
     sc = synth.make_scene(seed=seed, **synth.SCENE_PRESETS[preset])
     surf_map, corner_map = synth.sample_maps(sc, seed=seed)
     gt = synth.gt_body_pose()
-    scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], N_RINGS, seed=7 + i) for i in range(N_LIDARS)]
+    scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], N_RINGS, seed=7 + i) for i in range(n_lidars or N_LIDARS)]
     return sc, surf_map, corner_map, gt, scans
 
 
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dense-features", action="store_true",
                     help="supplementary saturation run: do NOT thin the scan features at MAP_SURF_RES/MAP_CORNER_RES (not BASELINE's workload)")
+    ap.add_argument("--lidars", type=int, default=N_LIDARS, choices=[1, 2, 3, 4],
+                    help="supplementary: number of 64-ring LiDARs in the frame (BASELINE's metric is quoted on 2)")
     ap.add_argument("--profile-events", type=int, default=1,
                     help="1: HIP-event bracket the dominant kernel (surf correspondence) inside the timed region; 0: none")
     args = ap.parse_args()
@@ -129,7 +131,7 @@ def main():
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        sc, surf_map, corner_map, gt, scans = build_workload(synth, preset)
+        sc, surf_map, corner_map, gt, scans = build_workload(synth, preset, n_lidars=args.lidars)
     p0 = synth.perturbed_pose(gt, seed=43)
     ctx = mla.Context(local_rank)
 
@@ -178,7 +180,7 @@ def main():
     ctx.features_set(mla.CORNER, d_corner)
     opts = mla.default_opts()
     m_total = len(surf) + len(corner)
-    log(f"[rank {rank}] workload {N_LIDARS}x{N_RINGS} rings ({n_scan_points} pts) vs {preset} map "
+    log(f"[rank {rank}] workload {args.lidars}x{N_RINGS} rings ({n_scan_points} pts) vs {preset} map "
         f"(surf {len(surf_map)} corner {len(corner_map)}; local {len(local_surf_map)}/{len(local_corner_map)}), "
         f"features surf {len(surf)} corner {len(corner)}; setup {time.time() - t0:.1f}s")
 
@@ -286,7 +288,7 @@ def main():
                    value=round(value, 1), unit="features/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f32 search/fit + f64 residual/Jacobian/normal equations", data="synthetic",
-                   config=dict(workload=f"{N_LIDARS}x{N_RINGS}-ring synthetic scan ({n_scan_points} pts) vs {preset} local map "
+                   config=dict(workload=f"{args.lidars}x{N_RINGS}-ring synthetic scan ({n_scan_points} pts) vs {preset} local map "
                                         f"({len(surf_map) + len(corner_map)} pts), {GN_ITERS} GN iters/frame, re-matched every iteration",
                                features_surf=len(surf), features_corner=len(corner), gn_iters_per_step=GN_ITERS,
                                scan_features_thinned=not args.dense_features,
