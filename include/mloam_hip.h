@@ -113,6 +113,15 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
                           const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
                           double trace_threshold, float *cov_vec_out, int32_t *keep_out);
 
+/* (f2) downsampleCurrentScan for one feature kind (lidar_mapper_keyframe.cpp:356-421), device-resident: VoxelGridCovarianceMLOAM<PointI>
+ * at `leaf` (plain branch), then per thinned point (intensity = LiDAR index n) Sigma = evalPointUncertainty(pose_ext[n]^-1 * p,
+ * pose_ext[n]) and the trace gate (with_ua only; Sigma = 0 and no gate otherwise). The kept points BECOME the kind's feature set
+ * (as if handed to mlh_features_set with their covariance), so extraction output can flow into the solver without touching the
+ * host; features_out (HOST, n x 11 floats [x y z i cov6 trace], may be NULL) additionally returns them. */
+int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                                float leaf, const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
+                                int with_ua, double trace_threshold, float *features_out, int32_t *n_features);
+
 /* ---------------------------------------------------------------- (f1) covariance-aware voxel thinning
  * replaces pcl::VoxelGridCovarianceMLOAM<PointT>::filter (mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp:68-457),
  * the filter that produces the voxel-thinned local map (lidar_mapper_keyframe.cpp:343-347) and thins the scan features

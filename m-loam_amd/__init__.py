@@ -93,6 +93,7 @@ def load_library():
     dp = C.POINTER(C.c_double)
     lib.mlh_cloud_uct_associate_to_map.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, cd, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_compound_pose_with_cov.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mlh_downsample_current_scan.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf, vp, vp, ci, vp, ci, cd, vp, C.POINTER(C.c_int32)]
     lib.mlh_track_opts_default.argtypes = [vp]
     lib.mlh_track_opts_default.restype = None
     lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
@@ -129,7 +130,7 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
+    "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
@@ -320,6 +321,20 @@ class Context:
         r = np.zeros(self._n_odom); J = np.zeros((self._n_odom, 3, 7)) if want_jacobians else None
         self._ck(self.lib.mlh_pure_odom_evaluate(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), _p(r), _p(J) if J is not None else None))
         return r, J
+
+    def downsample_current_scan(self, kind, points4, leaf, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6):
+        """downsampleCurrentScan for one kind; the result becomes the kind's feature set and is also returned (m, 11)."""
+        ptr, stride, n, mem, keep = _src(points4)
+        ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7)
+        ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
+        cm = np.ascontiguousarray(cov_measurement, np.float64).reshape(9)
+        out = np.zeros((n, 11), np.float32)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_downsample_current_scan(self.h, kind, ptr, stride, n, 12, mem, leaf, _p(ep), _p(ec), len(ep), _p(cm), int(bool(with_ua)),
+                                                      float(trace_threshold), _p(out), C.byref(cnt)))
+        self._m = getattr(self, "_m", {})
+        self._m[kind] = cnt.value
+        return out[:cnt.value].copy()
 
     def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
         """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""

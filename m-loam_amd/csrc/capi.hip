@@ -594,6 +594,39 @@ int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_byte
     return MLH_OK;
 }
 
+// downsampleCurrentScan for one feature kind, device-resident: the result IS the kind's feature set
+int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                                float leaf, const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
+                                int with_ua, double trace_threshold, float *features_out, int32_t *n_features)
+{
+    if (!ctx || kind < 0 || kind > 1 || !n_features) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    FeatSet &f = ctx->feat[kind];
+    f.matched = false;
+    f.m = 0;
+    float *d_out = nullptr;
+    if (features_out) {
+        MLH_HIP(ctx, ctx->tmp.ensure(sizeof(float) * 11 * size_t(n > 0 ? n : 1)));
+        d_out = ctx->tmp.as<float>();
+    }
+    int m = 0;
+    int rc = downsample_current_scan_run(ctx, points, stride_bytes, n, intensity_offset_bytes, mem, leaf, ext_poses, ext_covs, n_lidar, cov_measurement,
+                                         with_ua, trace_threshold, f.pts, f.covd, d_out, &m);
+    if (rc) return rc;
+    if (features_out && m > 0) {
+        MLH_HIP(ctx, hipMemcpyAsync(features_out, d_out, sizeof(float) * 11 * size_t(m), hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_features = m;
+    f.m = m;
+    f.n_blocks = 1;
+    f.blk_start[0] = 0;
+    f.blk_real[0] = m;
+    for (int b = 1; b <= 8; ++b) f.blk_start[b] = m;
+    f.has_cov = true;
+    return MLH_OK;
+}
+
 // ---------------------------------------------------------------- host-driven match / linearise
 static int fetch_dense_and_reduced(mlh_ctx *ctx, int kind, bool want_corr, uint8_t *valid, double *coeffs, double *r, double *J,
                                    double *JtJ, double *Jtr, double *cost, int32_t *n_valid)

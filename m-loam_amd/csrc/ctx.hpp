@@ -254,6 +254,9 @@ int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
 // voxel.hip
 void compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pc[7], double cc[36]);
+int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, float leaf, const double *ext_poses,
+                                const double *ext_covs, int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, mlh::DevBuf &pts_out,
+                                mlh::DevBuf &covd_out, float *out11_dev, int *n_out);
 int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off,
                             const double pose_global[7], const double cov_global[36], const double *ext_poses, const double *ext_covs,
                             int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, void *out, int *n_out, int mem);

@@ -451,4 +451,73 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
     return MLH_OK;
 }
 
+// ---------------------------------------------------------------- downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421)
+__global__ __launch_bounds__(256) void features_from_kept_kernel(const unsigned char *__restrict__ recs, int stride, int intensity_off, int n,
+                                                                  const int *__restrict__ keep, const int *__restrict__ slot, const float *__restrict__ cov6,
+                                                                  float4 *__restrict__ pts, float4 *__restrict__ covd, float *__restrict__ out11)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const float *r = reinterpret_cast<const float *>(recs + size_t(i) * stride);
+    const float inten = intensity_off >= 0 ? *reinterpret_cast<const float *>(recs + size_t(i) * stride + intensity_off) : 0.f;
+    const float *c = cov6 + size_t(i) * 6;
+    const int s = slot[i];
+    pts[s] = make_float4(r[0], r[1], r[2], inten);
+    covd[s] = make_float4(c[0], c[3], c[5], 0.f);
+    if (out11) {
+        float *o = out11 + size_t(s) * 11;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = inten;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[4 + k] = c[k];
+        o[10] = c[0] + c[3] + c[5];
+    }
+}
+
+// voxel thinning (plain branch) -> per-point uncertainty -> trace gate -> the kind's feature set, all on the device.
+// out11_dev: optional device buffer (n x 11 floats) that receives the kept PointXYZIWithCov records [x y z i cov6 trace].
+int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, float leaf, const double *ext_poses,
+                                const double *ext_covs, int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, DevBuf &pts_out,
+                                DevBuf &covd_out, float *out11_dev, int *n_out)
+{
+    if (n_lidar <= 0 || n_lidar > 16 || !ext_poses || (with_ua && (!ext_covs || !cov_meas))) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    hipStream_t st = ctx->stream;
+    VoxBuf &V = ctx->vox;
+    int n_ds = 0;
+    int rc = voxel_filter_run(ctx, points, stride, n, intensity_off, -1, -1, leaf, 0.f, nullptr, &n_ds, mem);   // result in V.out
+    if (rc) return rc;
+    *n_out = 0;
+    if (n_ds <= 0) return MLH_OK;
+    MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * size_t(n_lidar) * 43 + sizeof(float) * 6 * size_t(n_ds) + 64));
+    double *d_ext = ctx->uct_buf.as<double>();
+    double *d_cov = d_ext + size_t(n_lidar) * 7;
+    float *d_c6 = reinterpret_cast<float *>(d_cov + size_t(n_lidar) * 36);
+    std::vector<double> zero(size_t(n_lidar) * 36, 0.0);
+    MLH_HIP(ctx, hipMemcpyAsync(d_ext, ext_poses, sizeof(double) * 7 * n_lidar, hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipMemcpyAsync(d_cov, ext_covs ? ext_covs : zero.data(), sizeof(double) * 36 * n_lidar, hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));       // the sources may be the caller's temporaries / `zero`
+    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n_ds + 1)));
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n_ds + 1)));
+    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));
+    UctArgs A;
+    A.src = V.out.as<unsigned char>(); A.stride = stride; A.n = n_ds; A.intensity_off = intensity_off; A.ext = d_ext; A.ext_cov = d_cov; A.n_lidar = n_lidar;
+    for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
+    A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = V.leader.as<int>();
+    A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = with_ua ? 1 : 0;
+    for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
+    const int nb = (n_ds + 255) / 256;
+    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n_ds), hipMemcpyDeviceToDevice, st));
+    if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n_ds, V.sums, V.total.as<int>()))) return rc;
+    MLH_HIP(ctx, pts_out.ensure(sizeof(float4) * size_t(n_ds)));
+    MLH_HIP(ctx, covd_out.ensure(sizeof(float4) * size_t(n_ds)));
+    hipLaunchKernelGGL(features_from_kept_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n_ds,
+                       (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(), (const float *)d_c6, pts_out.as<float4>(), covd_out.as<float4>(), out11_dev);
+    MLH_HIP(ctx, hipGetLastError());
+    int total = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    *n_out = total;
+    return MLH_OK;
+}
+
 }  // namespace mlh

@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, 
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
                      float trace_thr, void *out_host, int *n_out, int mem)
 {
-    if (!points || n <= 0 || stride < 12 || (stride & 3) || !(leaf > 0.f) || !out_host || !n_out) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    if (!points || n <= 0 || stride < 12 || (stride & 3) || !(leaf > 0.f) || !n_out) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    // out_host == nullptr: the thinned records stay in ctx->vox.out (device) for the caller's next kernel
     hipStream_t st = ctx->stream;
     VoxBuf &V = ctx->vox;
     const unsigned char *src = static_cast<const unsigned char *>(points);
@@ -247,7 +248,8 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
                           ext[0] * ext[1] * ext[2] > 2147483647ll;
     if (too_many) {
         // "Leaf size is too small for the input dataset": the reference returns the input cloud unchanged
-        MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+        if (!out_host) { MLH_HIP(ctx, V.out.ensure(size_t(n) * stride)); MLH_HIP(ctx, hipMemcpyAsync(V.out.p, src, size_t(n) * stride, hipMemcpyDeviceToDevice, st)); }
+        else MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
         *n_out = n;
         return MLH_OK;
@@ -280,7 +282,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
     *n_out = total;
-    if (total > 0) {
+    if (total > 0 && out_host) {
         MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
     }

@@ -222,6 +222,34 @@ inline void cloudUCTAssociateToMap(Device &dev, const PointICovCloud &cloud_loca
     cloud_global.points.assign(out.begin(), out.end());
 }
 
+// downsampleCurrentScan() for one feature cloud (lidar_mapper_keyframe.cpp:356-421): thin at `leaf`, attach the extrinsic-induced
+// covariance, drop what exceeds TRACE_THRESHOLD_MAPPING. The result is returned AND stays on the device as the kind's feature set,
+// so a following scan2map call needs no mlh_features_set for it.
+inline void downsampleCurrentScan(Device &dev, int kind, const PointICloud &laser_cloud_last, float leaf, const std::vector<Pose> &pose_ext,
+                                  bool with_ua_flag, PointICovCloud &laser_cloud_cov)
+{
+    laser_cloud_cov.points.clear();
+    if (laser_cloud_last.size() == 0) return;
+    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
+    for (size_t n = 0; n < pose_ext.size(); ++n) {
+        pose_ext[n].toParam(ext.data() + n * 7);
+        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
+    }
+    std::vector<float> out(laser_cloud_last.size() * 11);
+    int32_t m = 0;
+    dev.check(mlh_downsample_current_scan(dev.ctx(), kind, laser_cloud_last.points.data(), (int)sizeof(PointI), (int)laser_cloud_last.size(),
+                                          point_traits<PointI>::intensity_off, MLH_MEM_HOST, leaf, ext.data(), ext_cov.data(), (int)pose_ext.size(),
+                                          params().COV_MEASUREMENT, with_ua_flag ? 1 : 0, params().TRACE_THRESHOLD_MAPPING, out.data(), &m));
+    for (int i = 0; i < m; ++i) {
+        PointIWithCov p;
+        const float *o = out.data() + size_t(i) * 11;
+        p.x = o[0]; p.y = o[1]; p.z = o[2]; p.intensity = o[3];
+        for (int k = 0; k < 6; ++k) p.cov_vec[k] = o[4 + k];
+        p.cov_trace = o[10];
+        laser_cloud_cov.push_back(p);
+    }
+}
+
 // ------------------------------------------------------------------ FeatureExtract
 class FeatureExtract {
 public:

@@ -617,3 +617,48 @@ def test_track_cloud_parity(ctx, mla, orc, track_case):
     assert np.linalg.norm(pose[:3] - tc["motion"][:3]) < 0.08
     pose2, none = ctx.track_cloud(p0, want_stats=False)
     assert none is None and max(_pose_err(pose2, pose)) < 1e-12
+
+
+def test_downsample_current_scan_device_resident(ctx, mla, orc, synth, case16, feats16):
+    """(f2) downsampleCurrentScan as one device-resident call: voxel thinning -> evalPointUncertainty -> trace gate -> the kind's
+    feature set. Checked piecewise against the oracle, and the resulting feature set must behave exactly like the same points
+    handed over through mlh_features_set."""
+    rng = np.random.default_rng(12)
+    base = feats16[0][:, :3]
+    xyz = np.concatenate([base, base + rng.normal(0, 0.08, base.shape).astype(np.float32)])
+    pts = np.zeros((len(xyz), 4), np.float32)
+    pts[:, :3] = xyz
+    pts[:, 3] = (xyz[:, 0] > 0).astype(np.float32)            # LiDAR id constant per region: voxels do not mix ids
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3) * 30])
+    meas = np.diag([0.0025] * 3)
+    thr = 0.05
+    ds = ctx.voxel_filter(pts, 0.4)
+    got = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, True, thr)
+    keep_ref, cov_ref = [], []
+    for i, p in enumerate(ds):
+        n = int(p[3])
+        R = synth.quat_to_rot(ext[n][3:])
+        sel = ((p[:3].astype(np.float64) - ext[n][:3]) @ R).astype(np.float32)
+        c = orc.eval_point_uncertainty(sel[None, :], ext[n], covs[n], meas)[0]
+        keep_ref.append(np.trace(c) <= thr)
+        cov_ref.append([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+    keep_ref, cov_ref = np.array(keep_ref), np.array(cov_ref)
+    assert 0 < keep_ref.sum() < len(ds)
+    assert len(got) == keep_ref.sum()
+    np.testing.assert_array_equal(got[:, :4], ds[keep_ref])
+    np.testing.assert_allclose(got[:, 4:10], cov_ref[keep_ref], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(got[:, 10], cov_ref[keep_ref][:, [0, 3, 5]].sum(axis=1), rtol=2e-5)
+    # the device-resident feature set == the same records staged from the host
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    opts_flags = mla.FLAG_WITH_UA if hasattr(mla, "FLAG_WITH_UA") else 2
+    a = ctx.match_linearize(mla.SURF, case16["p0"], flags=opts_flags)
+    ctx.features_set(mla.SURF, got)
+    b = ctx.match_linearize(mla.SURF, case16["p0"], flags=opts_flags)
+    assert np.array_equal(a["valid"], b["valid"]) and a["count"] == b["count"]
+    np.testing.assert_array_equal(a["H"], b["H"])
+    # without uncertainty: nothing dropped, zero covariance
+    plain = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, False, thr)
+    assert len(plain) == len(ds) and not plain[:, 4:].any()
