@@ -53,6 +53,44 @@ inline size_t draw(std::mt19937 &rng, size_t lo, size_t hi)
     return d(rng);
 }
 
+// The reference keeps the not-yet-consumed feature slots in a std::vector it erases from (all_feature_idx, lidar_mapper.h:350,
+// 531-553): position j of that vector is always the (j+1)-th surviving ORIGINAL index, because it starts as 0..M-1 and only ever
+// loses elements. A Fenwick tree over "alive" flags answers the same three questions -- element at position j, position of an
+// element (the reference's std::find), erase -- in O(log M) instead of O(M) per operation, with identical results.
+class AlivePool {
+public:
+    explicit AlivePool(size_t n) : n_(n), alive_(n), t_(n + 1, 0), alive_flag_(n, 1)
+    {
+        for (size_t i = 1; i <= n; ++i) { t_[i] += 1; const size_t j = i + (i & (~i + 1)); if (j <= n) t_[j] += t_[i]; }
+        log_ = 1;
+        while ((size_t(1) << log_) <= n) ++log_;
+    }
+    size_t size() const { return alive_; }
+    bool empty() const { return alive_ == 0; }
+    // original index of the element at position j (0-based) among the survivors
+    size_t at(size_t j) const
+    {
+        size_t pos = 0, k = j + 1;
+        for (int b = log_; b >= 0; --b) {
+            const size_t nxt = pos + (size_t(1) << b);
+            if (nxt <= n_ && t_[nxt] < int(k)) { pos = nxt; k -= size_t(t_[nxt]); }
+        }
+        return pos;   // 0-based original index
+    }
+    bool contains(size_t idx) const { return alive_flag_[idx] != 0; }
+    void erase_index(size_t idx)
+    {
+        alive_flag_[idx] = 0;
+        --alive_;
+        for (size_t i = idx + 1; i <= n_; i += i & (~i + 1)) t_[i] -= 1;
+    }
+private:
+    size_t n_, alive_;
+    std::vector<int> t_;
+    std::vector<char> alive_flag_;
+    int log_;
+};
+
 struct Scored {   // FeatureWithScore (parameters.h:177-191): max-heap on the logdet score
     size_t idx;
     double score;
@@ -67,13 +105,12 @@ void select_wo_gf(const Rows &R, std::vector<size_t> &sel, double H[36])
 
 void select_rnd(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
-    std::vector<size_t> pool(R.corr.size());
-    std::iota(pool.begin(), pool.end(), 0);
+    AlivePool pool(R.corr.size());
     while (sel.size() < n_use && !pool.empty()) {
         const size_t j = draw(rng, 0, pool.size() - 1);
-        const size_t q = pool[j];
+        const size_t q = pool.at(j);
         if (R.matched(q)) { rank1_update(H, R.jaco(q)); sel.push_back(q); }
-        pool.erase(pool.begin() + j);
+        pool.erase_index(q);
     }
 }
 
@@ -113,9 +150,8 @@ void select_fps(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
 void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
     const size_t n_all = R.corr.size();
-    std::vector<size_t> pool(n_all);
-    std::iota(pool.begin(), pool.end(), 0);
-    std::vector<int> stamp(n_all, -1);        // feature_visited: last selection round in which the slot was drawn
+    AlivePool pool(n_all);
+    std::vector<int> stamp(n_all, -1);        // feature_visited, kept per ORIGINAL index (the reference erases it in lockstep with the pool)
     const size_t max_retry = 20;              // MAX_RANDOM_QUEUE_TIME
     size_t retries = 0;
     while (sel.size() < n_use && !pool.empty()) {
@@ -124,17 +160,16 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
         bool lost = false;
         while (!pool.empty()) {
             retries = 0;
-            size_t j = 0;
+            size_t q = 0;
             while (retries < max_retry) {
-                j = draw(rng, 0, pool.size() - 1);
-                if (stamp[j] < int(sel.size())) { stamp[j] = int(sel.size()); break; }
+                const size_t j = draw(rng, 0, pool.size() - 1);
+                q = pool.at(j);
+                if (stamp[q] < int(sel.size())) { stamp[q] = int(sel.size()); break; }
                 ++retries;
             }
             if (retries >= max_retry) break;
-            const size_t q = pool[j];
             if (!R.matched(q)) {              // "not found constraints or outlier constraints": forget the slot
-                pool.erase(pool.begin() + j);
-                stamp.erase(stamp.begin() + j);
+                pool.erase_index(q);
                 continue;
             }
             double Ht[36];
@@ -143,12 +178,9 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
             heap.push(Scored{q, logdet_cholesky6(Ht)});
             if (heap.size() >= subset) {
                 const Scored top = heap.top();
-                auto it = std::find(pool.begin(), pool.end(), top.idx);
-                if (it == pool.end()) { lost = true; break; }
+                if (!pool.contains(top.idx)) { lost = true; break; }     // the reference's std::find miss
                 rank1_update(H, R.jaco(top.idx));
-                const size_t pos = it - pool.begin();
-                pool.erase(pool.begin() + pos);
-                stamp.erase(stamp.begin() + pos);
+                pool.erase_index(top.idx);
                 sel.push_back(top.idx);
                 break;
             }
