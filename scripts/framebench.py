@@ -1,0 +1,87 @@
+"""One whole mapper frame, stage by stage: extractCloud for both LiDARs -> fusion (host glue) -> downsampleCurrentScan -> index build ->
+scan2MapOptimization, GPU path vs CPU oracle, with HOST buffers at every hand-over (the reference's ROS nodes exchange host clouds)."""
+import importlib, os, sys, time, warnings
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bench, oracle as O
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+O.build()
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "500k")
+p0 = synth.perturbed_pose(gt, seed=43)
+ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+for e in ext: e[3:] /= np.linalg.norm(e[3:])
+covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+meas = np.diag([0.0025] * 3)
+Ts = []
+for i in range(2):
+    T = np.eye(4); T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4]); T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]; Ts.append(T)
+ctx = mla.Context(0)
+ctx.map_set(mla.SURF, surf_map); ctx.map_set(mla.CORNER, corner_map)
+opts = mla.default_opts(flags=mla.FLAG_WITH_UA)
+
+def fuse(lists):
+    surf, corner = [], []
+    for i, (pts, less_sharp, less_flat_ds) in enumerate(lists):
+        for dst, xyz in ((corner, pts[less_sharp][:, :3]), (surf, less_flat_ds[:, :3])):
+            a = np.empty((len(xyz), 4), np.float32)
+            a[:, :3] = synth.transform_points(xyz, Ts[i]); a[:, 3] = i
+            dst.append(a)
+    return np.concatenate(surf), np.concatenate(corner)
+
+def gpu_frame(t):
+    lists = []
+    t0 = time.perf_counter()
+    for s in scans:
+        ctx.scan_upload(s.points, s.scan_start, s.scan_end); ctx.extract_run()
+        ex = ctx.extract_fetch(); lf = ctx.extract_voxel(0.2)
+        lists.append((s.points, ex["less_sharp"], lf))
+    t1 = time.perf_counter()
+    surf, corner = fuse(lists)
+    t2 = time.perf_counter()
+    ctx.downsample_current_scan(mla.SURF, surf, 0.4, ext, covs, meas, True, 0.6)
+    ctx.downsample_current_scan(mla.CORNER, corner, 0.2, ext, covs, meas, True, 0.6)
+    t3 = time.perf_counter()
+    ctx.map_rebuild(mla.ALL_KINDS)
+    pose, _ = ctx.scan2map(p0, opts, want_stats=False)
+    t4 = time.perf_counter()
+    for k, v in zip(("extract", "fuse(host)", "downsample", "scan2map"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)): t[k] = t.get(k, 0.0) + v
+    return pose, surf, corner
+
+for _ in range(3): gpu_frame({})
+tg = {}; n = 20
+for _ in range(n): pose, surf, corner = gpu_frame(tg)
+print("GPU path, ms per frame:", {k: round(1e3 * v / n, 3) for k, v in tg.items()}, "total %.3f" % (1e3 * sum(tg.values()) / n))
+
+tc = {}
+t0 = time.perf_counter()
+lists = []
+for s in scans:
+    ex = O.extract(s.points, s.scan_start, s.scan_end)
+    lists.append((s.points, ex["less_sharp"], ex["less_flat_ds"]))
+t1 = time.perf_counter()
+surf_c, corner_c = fuse(lists)
+t2 = time.perf_counter()
+feats = []
+for cloud, leaf in ((surf_c, 0.4), (corner_c, 0.2)):
+    ds = O.voxel_grid(cloud, leaf)      # pcl::VoxelGrid centroids (the plain branch differs only in which member's intensity survives)
+    ds[:, 3] = np.round(ds[:, 3])
+    out = np.zeros((len(ds), 11), np.float32); out[:, :4] = ds
+    for lid in range(2):
+        m = ds[:, 3] == lid
+        R = synth.quat_to_rot(ext[lid][3:])
+        sel = ((ds[m, :3].astype(np.float64) - ext[lid][:3]) @ R).astype(np.float32)
+        c = O.eval_point_uncertainty(sel, ext[lid], covs[lid], meas)
+        out[m, 4:10] = np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+    out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
+    feats.append(out[out[:, 10] <= 0.6])
+t3 = time.perf_counter()
+ms_, mc_ = O.Map(surf_map), O.Map(corner_map)
+tk = ms_.rebuild_seconds() + mc_.rebuild_seconds()
+ref = O.scan2map(ms_, mc_, feats[0], feats[1], p0, O.mapper_params(with_ua=True))
+t4 = time.perf_counter()
+print("CPU oracle, ms per frame:", {"extract": round(1e3 * (t1 - t0), 1), "fuse(host)": round(1e3 * (t2 - t1), 1), "downsample": round(1e3 * (t3 - t2), 1),
+      "kd-tree build": round(1e3 * tk, 1), "scan2map": round(1e3 * (t4 - t3) - 1e3 * tk, 1)}, "total %.1f" % (1e3 * (t4 - t0)))
+print("pose agreement |dt| %.2e m" % np.linalg.norm(pose[:3] - ref["pose"][:3]))
