@@ -294,7 +294,6 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
 // solver.hip
 int reduce_only_launch(mlh_ctx *ctx, int to_ce);
-int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double *eig_thre, const int *freeze, int stat_slot);
 // comm.hip

@@ -220,18 +220,6 @@ static int pre_reduce(mlh_ctx *ctx, int to_ce, int &pre_reduced)
     return MLH_OK;
 }
 
-int gn_update_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
-{
-    int pre = 0, rc = pre_reduce(ctx, 0, pre);
-    if (rc) return rc;
-    prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
-                       map_eig_thre, stat_ptr(ctx, stat_slot), pre);
-    prof_end(ctx, MLH_K_SOLVE);
-    MLH_HIP(ctx, hipGetLastError());
-    return MLH_OK;
-}
-
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
 {
     prof_begin(ctx, MLH_K_SOLVE);
