@@ -82,6 +82,10 @@ def feats16(synth, orc, case16):
 
 @pytest.fixture(scope="session")
 def track_case(synth, orc):
+    return _track_case(synth, orc)
+
+
+def _track_case(synth, orc):
     """Two consecutive 16-ring scans of the 50k scene (intensity = ring id, as ImageSegmenter leaves it) and their LOAM features:
     prev = less-sharp corners / voxel-thinned less-flat surfs, cur = sharp corners / flat surfs (lidar_tracker.cpp:30-38)."""
     sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])

@@ -26,9 +26,36 @@ vs, cs = ms.match("s", feats[0], case["p0"])
 vc, cc = mc.match("c", feats[1], case["p0"])
 r = O.scan2map(ms, mc, feats[0], feats[1], case["p0"], O.mapper_params())
 g = O.gn_iterations(ms, mc, feats[0], feats[1], case["p0"], O.mapper_params(), 5)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1.npz"),
-                    points_sha=hashlib.sha256(np.ascontiguousarray(sc.points).tobytes()).hexdigest(),
-                    label=ex["label"].astype(np.int8), less_sharp=ex["less_sharp"], flat=ex["flat"], sharp=ex["sharp"],
-                    valid_surf=vs, valid_corner=vc, coeff_surf=cs.astype(np.float32), coeff_corner=cc.astype(np.float32),
-                    scan2map_pose=r["pose"], gn5_pose=g["pose"])
+if "--rows-f-only" not in sys.argv:
+  np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1.npz"),
+                      points_sha=hashlib.sha256(np.ascontiguousarray(sc.points).tobytes()).hexdigest(),
+                      label=ex["label"].astype(np.int8), less_sharp=ex["less_sharp"], flat=ex["flat"], sharp=ex["sharp"],
+                      valid_surf=vs, valid_corner=vc, coeff_surf=cs.astype(np.float32), coeff_corner=cc.astype(np.float32),
+                      scan2map_pose=r["pose"], gn5_pose=g["pose"])
 print("wrote config1.npz", ex["n_ties"], vs.sum(), vc.sum(), r["pose"])
+
+# ---- second fixture: the rows built after the first one (tracker, covariance voxel filter, pose compounding, map association)
+tc = conftest._track_case(synth, O)
+tr = O.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], np.array([0, 0, 0, 0, 0, 0, 1.0]))
+tvc, tcc = O.track_match("c", tc["corner_last"], tc["corner_sharp"], np.array([0.3, -0.1, 0.02, 0, 0, 0, 1.0]))
+tvs, tcs = O.track_match("s", tc["surf_last"], tc["surf_flat"], np.array([0.3, -0.1, 0.02, 0, 0, 0, 1.0]))
+rng = np.random.default_rng(77)
+cloud = np.zeros((4000, 11), np.float32)
+cloud[:, :3] = rng.uniform(-8, 8, (4000, 3)) * np.array([1, 1, 0.1], np.float32)
+cloud[:, 3] = rng.integers(0, 2, 4000)
+sd = rng.uniform(0.01, 0.6, (4000, 3)).astype(np.float32)
+cloud[:, 4] = sd[:, 0] ** 2; cloud[:, 7] = sd[:, 1] ** 2; cloud[:, 9] = sd[:, 2] ** 2
+cloud[:, 10] = cloud[:, 4] + cloud[:, 7] + cloud[:, 9]
+vox = O.voxel_grid_cov(cloud, 0.8, 1.0)
+p1 = np.array([4.0, -2.0, 1.0, 0.0, 0.0, np.sin(0.35), np.cos(0.35)]); p2 = np.array([0.6, 0.3, -0.2, np.sin(0.1), 0.0, 0.0, np.cos(0.1)])
+c1 = np.diag([1e-4, 2e-4, 3e-4, 1e-5, 2e-5, 3e-5]); c2 = np.diag([2.5e-3] * 3 + [3e-4] * 3)
+pcp, ccp = O.compound_pose_with_cov(p1, c1, p2, c2)
+_ext, _extc = np.stack([np.array([0, 0, 0, 0, 0, 0, 1.0]), p2]), np.stack([np.zeros((6, 6)), c2])
+_all = O.cloud_uct_associate_to_map(cloud[:1000], p1, c1, _ext, _extc, np.diag([0.0025] * 3), True, 1e9)
+assoc_thr = float(np.sort(_all[:, 10])[600]) * (1 + 1e-4)      # keeps ~60 %, away from any trace value
+assoc = O.cloud_uct_associate_to_map(cloud[:1000], p1, c1, _ext, _extc, np.diag([0.0025] * 3), True, assoc_thr)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "rows_f.npz"),
+                    track_pose=tr["pose"], track_counts=np.array([[o["n_corner"], o["n_surf"], o["lm_iterations"]] for o in tr["outer"]]),
+                    track_valid_c=tvc, track_coeff_c=tcc.astype(np.float32), track_valid_s=tvs, track_coeff_s=tcs.astype(np.float32),
+                    vox_seed=77, vox_out=vox, compound_pose=pcp, compound_cov=ccp, assoc_thr=assoc_thr, assoc_out=assoc)
+print("wrote rows_f.npz", tr["pose"], len(vox), len(assoc))

@@ -264,3 +264,40 @@ def test_track_cloud_recovers_motion(orc, track_case):
     assert np.linalg.norm(res["pose"][:3] - tc["motion"][:3]) < 0.08
     q, qt = res["pose"][3:], tc["motion"][3:]
     assert 2 * np.arccos(min(1.0, abs(q @ qt))) < np.deg2rad(0.5)
+
+
+def _rows_f_inputs():
+    """the seeded inputs tests/golden/make_golden.py used for rows_f.npz"""
+    rng = np.random.default_rng(77)
+    cloud = np.zeros((4000, 11), np.float32)
+    cloud[:, :3] = rng.uniform(-8, 8, (4000, 3)) * np.array([1, 1, 0.1], np.float32)
+    cloud[:, 3] = rng.integers(0, 2, 4000)
+    sd = rng.uniform(0.01, 0.6, (4000, 3)).astype(np.float32)
+    cloud[:, 4] = sd[:, 0] ** 2; cloud[:, 7] = sd[:, 1] ** 2; cloud[:, 9] = sd[:, 2] ** 2
+    cloud[:, 10] = cloud[:, 4] + cloud[:, 7] + cloud[:, 9]
+    p1 = np.array([4.0, -2.0, 1.0, 0.0, 0.0, np.sin(0.35), np.cos(0.35)]); p2 = np.array([0.6, 0.3, -0.2, np.sin(0.1), 0.0, 0.0, np.cos(0.1)])
+    c1 = np.diag([1e-4, 2e-4, 3e-4, 1e-5, 2e-5, 3e-5]); c2 = np.diag([2.5e-3] * 3 + [3e-4] * 3)
+    ext, extc = np.stack([np.array([0, 0, 0, 0, 0, 0, 1.0]), p2]), np.stack([np.zeros((6, 6)), c2])
+    return cloud, p1, c1, p2, c2, ext, extc
+
+
+def test_oracle_matches_rows_f_fixture(orc, track_case):
+    """tests/golden/rows_f.npz: oracle outputs for the rows added after the first fixture (tracker, covariance voxel filter, pose
+    compounding, map association) -- regression pin for the oracle, yardstick for the GPU tests."""
+    g = np.load(os.path.join(GOLDEN, "rows_f.npz"))
+    tc = track_case
+    tr = orc.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    np.testing.assert_allclose(tr["pose"], g["track_pose"], rtol=0, atol=1e-12)
+    assert np.array_equal(np.array([[o["n_corner"], o["n_surf"], o["lm_iterations"]] for o in tr["outer"]]), g["track_counts"])
+    pm = np.array([0.3, -0.1, 0.02, 0, 0, 0, 1.0])
+    vc, cc = orc.track_match("c", tc["corner_last"], tc["corner_sharp"], pm)
+    vs, cs = orc.track_match("s", tc["surf_last"], tc["surf_flat"], pm)
+    assert np.array_equal(vc, g["track_valid_c"]) and np.array_equal(vs, g["track_valid_s"])
+    assert np.array_equal(cc.astype(np.float32), g["track_coeff_c"]) and np.array_equal(cs.astype(np.float32), g["track_coeff_s"])
+    cloud, p1, c1, p2, c2, ext, extc = _rows_f_inputs()
+    np.testing.assert_array_equal(orc.voxel_grid_cov(cloud, 0.8, 1.0), g["vox_out"])
+    pcp, ccp = orc.compound_pose_with_cov(p1, c1, p2, c2)
+    np.testing.assert_allclose(pcp, g["compound_pose"], atol=1e-15)
+    np.testing.assert_allclose(ccp, g["compound_cov"], rtol=1e-13, atol=1e-20)
+    np.testing.assert_array_equal(orc.cloud_uct_associate_to_map(cloud[:1000], p1, c1, ext, extc, np.diag([0.0025] * 3), True, float(g["assoc_thr"])),
+                                  g["assoc_out"])
