@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -499,6 +500,49 @@ private:
     Device &dev_;
     mlh_track_opts opts_;
 };
+
+// ------------------------------------------------------------------ ActiveFeatureSelection::evalFullHessian + the gf_ratio policy
+// evalFullHessian (lidar_mapper.h:176-227): match ALL features of a kind at pose_local and add their un-corrected, uncertainty-weighted
+// J^T J to mat_H; feat_num += matched features. The map index of `kind` and its features must be staged (MapIndex::setInputCloud,
+// mlh_features_set / downsampleCurrentScan).
+inline void evalFullHessian(Device &dev, int kind, const Pose &pose_local, double mat_H[36], int &feat_num)
+{
+    double p[7], JtJ[36];
+    pose_local.toParam(p);
+    int32_t n_valid = 0;
+    dev.check(mlh_match_linearize(dev.ctx(), kind, p, 5, MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, 0.0,
+                                  params().COV_MEASUREMENT_TRACE, nullptr, nullptr, nullptr, nullptr, JtJ, nullptr, nullptr, &n_valid));
+    for (int i = 0; i < 36; ++i) mat_H[i] += JtJ[i];
+    feat_num += n_valid;
+}
+
+// common::logDet(M, true) of a 6x6 (mloam_common/libs/include/common/algos/math.hpp:173-187): 2 * sum(log(diag(chol(M))))
+inline double logDet6(const double M[36])
+{
+    double L[36] = {0}, ld = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double s = M[j * 6 + j];
+        for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(s > 0.0)) return std::nan("");
+        const double ljj = std::sqrt(s);
+        L[j * 6 + j] = ljj;
+        ld += std::log(ljj);
+        for (int i = j + 1; i < 6; ++i) {
+            double t = M[i * 6 + j];
+            for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = t / ljj;
+        }
+    }
+    return 2.0 * ld;
+}
+
+// the every-10th-frame policy of scan2MapOptimization (lidar_mapper_keyframe.cpp:456-494): returns gf_ratio_cur
+inline double gfRatioPolicy(const std::string &gf_method, double gf_ratio_ini, double gf_deg_factor, double MAP_DEG_THRE)
+{
+    if (gf_method == "wo_gf") return 1.0;
+    if (gf_method == "gd_float") return gf_deg_factor > MAP_DEG_THRE ? gf_ratio_ini : 0.8;
+    return gf_ratio_ini;   // rnd, fps, gd_fix
+}
 
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
