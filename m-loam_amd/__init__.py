@@ -81,6 +81,7 @@ def load_library():
     lib.mlh_stream.restype = vp
     lib.mlh_synchronize.argtypes = [vp]
     lib.mlh_profile_enable.argtypes = [vp, ci]
+    lib.mlh_comm_finalize.argtypes = [vp]
     lib.mlh_profile_sample.argtypes = [vp, ci]
     lib.mlh_profile_reset.argtypes = [vp]
     lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
@@ -128,7 +129,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
-    "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
+    "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
@@ -426,6 +427,9 @@ class Context:
         return poses, st
 
     # ---- multi-GPU
+    def comm_finalize(self):
+        self._ck(self.lib.mlh_comm_finalize(self.h))
+
     def shard_set(self, lo_plane=None, hi_plane=None):
         lo = None if lo_plane is None else np.ascontiguousarray(lo_plane, np.float32)
         hi = None if hi_plane is None else np.ascontiguousarray(hi_plane, np.float32)

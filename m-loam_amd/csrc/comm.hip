@@ -124,6 +124,17 @@ int mlh_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *unique_id_128
     return MLH_OK;
 }
 
+int mlh_comm_finalize(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    comm_destroy(ctx);
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+    return MLH_OK;
+}
+
 int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n)
 {
     if (!ctx || !host_inout || n <= 0 || n > NE_STRIDE) return MLH_ERR_INVALID;
