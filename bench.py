@@ -166,13 +166,21 @@ def main():
             local_corner_map = far
         lo, hi = shard.wedge_planes(center, world, rank)
         comm_ok, comm_err = 1, ""
-        try:
-            ctx.shard_set(lo, hi)
-            uid = [mla.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(world, rank, uid[0])
-        except Exception as e:   # noqa: BLE001 -- reported in the JSON line, never silently
-            comm_ok, comm_err = 0, repr(e)
+        uid = [None]
+        if rank == 0:
+            try:
+                uid[0] = mla.comm_unique_id()
+            except Exception as e:   # noqa: BLE001 -- reported, never silent
+                comm_err = repr(e)
+        dist.broadcast_object_list(uid, src=0)      # always executed, so no rank is left waiting
+        if uid[0] is None:
+            comm_ok = 0
+        else:
+            try:
+                ctx.shard_set(lo, hi)
+                ctx.comm_init(world, rank, uid[0])
+            except Exception as e:   # noqa: BLE001
+                comm_ok, comm_err = 0, repr(e)
         flag = torch.tensor([comm_ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
