@@ -57,6 +57,11 @@ int main(int argc, char **argv)
         cloudFeature cf;
         f_extract.extractCloud(cloud, info, cf);
         write_file(d + "out_labels.i32", f_extract.cloudLabel());
+        {
+            std::vector<float> lf;
+            for (const auto &q : cf["surf_points_less_flat"].points) { lf.push_back(q.x); lf.push_back(q.y); lf.push_back(q.z); lf.push_back(q.intensity); }
+            write_file(d + "out_less_flat.f32", lf);
+        }
         std::printf("extract: sharp %zu less_sharp %zu flat %zu less_flat %zu\n", cf["corner_points_sharp"].size(),
                     cf["corner_points_less_sharp"].size(), cf["surf_points_flat"].size(), cf["surf_points_less_flat"].size());
         // --- batch matching through the FeatureExtract signature

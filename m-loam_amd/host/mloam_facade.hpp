@@ -256,8 +256,8 @@ class FeatureExtract {
 public:
     explicit FeatureExtract(Device &dev) : dev_(dev) {}
 
-    // feature_extract.cpp:118-297. Output keys and ordering as the reference (cpp:281-285); "surf_points_less_flat" holds
-    // the label<=0 points BEFORE the per-ring 0.2 m VoxelGrid (cpp:266-271: the voxel thinning is a row of the "next" table).
+    // feature_extract.cpp:118-297. Output keys and ordering as the reference (cpp:281-285), "surf_points_less_flat" thinned by the
+    // per-ring 0.2 m VoxelGrid (cpp:266-271) with the intensity field (ring id) averaged along, as PCL does.
     // Re-entrancy: the reference calls this concurrently from NUM_OF_LASER OpenMP threads on one object
     // (estimator.cpp:249-263); here use one FeatureExtract (one Device) per thread.
     void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature)
@@ -275,12 +275,20 @@ public:
         dev_.check(mlh_extract_fetch(dev_.ctx(), labels_.data(), nullptr, nullptr, ptrs, counts));
         cloud_feature.clear();
         cloud_feature["laser_cloud"] = laser_cloud_in;
-        static const char *names[4] = {"corner_points_sharp", "corner_points_less_sharp", "surf_points_flat", "surf_points_less_flat"};
-        for (int i = 0; i < 4; ++i) {
+        static const char *names[3] = {"corner_points_sharp", "corner_points_less_sharp", "surf_points_flat"};
+        for (int i = 0; i < 3; ++i) {
             PointICloud &c = cloud_feature[names[i]];
             c.points.reserve(counts[i]);
             for (int k = 0; k < counts[i]; ++k) c.push_back(laser_cloud_in.points[lists[i][k]]);
         }
+        // "surf_points_less_flat": the label <= 0 points after the per-ring 0.2 m pcl::VoxelGrid (cpp:266-271), ring by ring
+        dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
+        std::vector<float> vox(size_t(counts[3] > 0 ? counts[3] : 1) * 4);
+        int32_t n_vox = 0;
+        dev_.check(mlh_extract_fetch_voxel(dev_.ctx(), vox.data(), &n_vox));
+        PointICloud &lf = cloud_feature["surf_points_less_flat"];
+        lf.points.reserve(n_vox);
+        for (int k = 0; k < n_vox; ++k) { PointI p; p.x = vox[4 * k]; p.y = vox[4 * k + 1]; p.z = vox[4 * k + 2]; p.intensity = vox[4 * k + 3]; lf.push_back(p); }
     }
     const std::vector<int32_t> &cloudLabel() const { return labels_; }   // cloud_label[] of the last extractCloud
 

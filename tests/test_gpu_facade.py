@@ -30,6 +30,9 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     labels = np.fromfile(os.path.join(d, "out_labels.i32"), np.int32)
     ref = orc.extract(sc.points, sc.scan_start, sc.scan_end)
     assert np.array_equal(labels, ref["label"])
+    lf = np.fromfile(os.path.join(d, "out_less_flat.f32"), np.float32).reshape(-1, 4)      # extractCloud's thinned less-flat cloud
+    assert lf.shape == ref["less_flat_ds"].shape
+    np.testing.assert_allclose(lf, ref["less_flat_ds"], rtol=2e-6, atol=2e-6)
     valid = np.fromfile(os.path.join(d, "out_valid_surf.u8"), np.uint8)
     v, _ = orc.Map(case16["surf_map"]).match("s", feats16[0], case16["p0"])
     assert np.array_equal(valid, v)
