@@ -406,7 +406,7 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sum_partials(sa, f_ne, f_cnt2, f_scratch);
         MLH_STAGE(4095, 1);
         if (threadIdx.x < 2)
-            gn_finish2(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], b == 0 ? P.state : nullptr, P.thre_b[b], P.freeze_b[b],
+            gn_finish2(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], nullptr /* nothing downstream reads a mirror of ne / V_update in GN mode */, P.thre_b[b], P.freeze_b[b],
                        P.stat ? P.stat + b : nullptr, f_scratch);
         __syncthreads();
         MLH_STAGE(4095, 2);

@@ -19,20 +19,22 @@ __device__ inline void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRID
     const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
     if (a.p) {
-        // the two tile ranges (surf, corner) are walked as one list; 8 loads per trip are independent (in flight together) and
-        // feed four chains in a fixed association -> deterministic, and ~ntiles/64 round trips instead of one per tile
+        // the two tile ranges (surf, corner) are walked as one list; 12 loads per trip are independent (in flight together) and
+        // feed four chains in a fixed association -> deterministic, and ~ntiles/96 round trips instead of one per tile (a frame's
+        // ~80 tiles: one)
         const int n0 = max(a.hi[0] - a.lo[0], 0), ntot = n0 + max(a.hi[1] - a.lo[1], 0);
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        for (int j = s; j < ntot; j += 64) {
-            double t[8];
+        for (int j = s; j < ntot; j += 96) {
+            double t[12];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 12; ++u) {
                 const int jj = j + 8 * u;
                 const int tile = jj < n0 ? a.lo[0] + jj : a.lo[1] + (jj - n0);
                 t[u] = jj < ntot ? a.p[size_t(tile) * NE_STRIDE + c] : 0.0;
             }
             v0 += t[0]; v1 += t[1]; v2 += t[2]; v3 += t[3];
             v0 += t[4]; v1 += t[5]; v2 += t[6]; v3 += t[7];
+            v0 += t[8]; v1 += t[9]; v2 += t[10]; v3 += t[11];
         }
         v = (v0 + v1) + (v2 + v3);
     }
