@@ -844,11 +844,19 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         return MLH_OK;
     }
     if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
-    if ((rc = upload_pose(ctx, pose_inout))) return rc;
+    // one GPU, every feature used (wo_gf): the LM begin rides in the match launch and every LM step in its linearise launch -- an outer
+    // iteration is 2 + (LM iterations) launches, the pose goes in with the first launch's kernel arguments
+    const bool fused = !ctx->comm && opts->gf_method == MLH_GF_WO;
+    if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
     std::mt19937 rng((uint32_t)opts->gf_seed);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
-        if (opts->gf_method == MLH_GF_WO) {
+        if (fused) {
+            MatchArgs a = args_from_opts(opts, 3, 0);
+            a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
+            if (outer == 0) a.init_pose = pose_inout;
+            if ((rc = match_launch(ctx, a))) return rc;
+        } else if (opts->gf_method == MLH_GF_WO) {
             if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
         } else {
             // goodFeatureMatching for corners, then surfs (cpp:503-533), each against a fresh 1e-6*I; then the evaluation of the
@@ -862,17 +870,19 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
             }
             if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
         }
-        if ((rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
+        if (!fused && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
             for (int j = it; j < std::min(it + chunk, opts->max_lm_iterations); ++j) {
-                if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 1)))) return rc;
-                if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+                MatchArgs a = args_from_opts(opts, 3, 1);
+                if (fused) { a.finish = 4; a.lm_max_it = opts->max_lm_iterations; }
+                if ((rc = linearize_launch(ctx, a))) return rc;
+                if (!fused && (rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
             }
             HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
             if ((rc = fetch_published(ctx, hp))) return rc;
             if (hp.done) break;
         }
-        if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
+        if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
 }
@@ -967,7 +977,7 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
             if ((rc = track_linearize_launch(ctx, 3, track_args(opts, 1)))) return rc;
             if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
         }
-        if ((rc = lm_finish_launch(ctx, stats ? outer : -1))) return rc;
+        if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
 }

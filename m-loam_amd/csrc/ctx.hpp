@@ -273,7 +273,9 @@ struct MatchArgs {
     double huber_delta = 0.1, cov_measurement_trace = 0.0075;
     bool dense = false;  // also write r / J per feature
     int pose_sel = 0;    // 0: SolverState::x, 1: SolverState::cand
-    int finish = 0;      // 1: the fit kernel's last workgroup completes the GN iteration (reduce + solve + Plus)
+    int finish = 0;      // 1: the fit kernel's last workgroup completes the GN iteration (reduce + solve + Plus); 2: local reduce only;
+                         // 3 / 4: it runs the Levenberg-Marquardt begin (match_launch) / step (linearize_launch)
+    int lm_max_it = 30, lm_min_blocks = 0;
     int stat_slot = -1;
     int n_blocks = 1;    // pose blocks
     int k_neigh[8] = {5, 5, 5, 5, 5, 5, 5, 5};

@@ -204,7 +204,9 @@ struct KParams {
     HostPublish *publish;    // the finish of the last iteration hands the result to the host through pinned memory
     unsigned long long publish_seq;
     int knn_lanes;           // lanes per query of the correspondence kernel (8 or 16), chosen per launch
-    int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU)
+    int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU),
+                             // 3: Levenberg-Marquardt begin (fit kernel), 4: Levenberg-Marquardt step (linearize kernel)
+    int lm_max_it, lm_min_blocks;
     unsigned *ticket;
     IterStatDev *stat;       // n_blocks consecutive records, or null
 };
@@ -355,6 +357,7 @@ __device__ __forceinline__ double feature_weight(const KParams &P, const KindP &
 // Fused tail: the last workgroup to arrive (agent-scope release/acquire around an atomic ticket) sums the partial records
 // in fixed order, runs the degeneracy test + the 6x6 solve + Plus for every pose block and re-arms the ticket: a GN iteration
 // costs two launches.
+template <bool LM>
 __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tiles)
 {
     __shared__ int s_last;
@@ -372,6 +375,19 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (P.use_init && threadIdx.x < 7) P.state->x[threadIdx.x] = P.init_pose[threadIdx.x];   // the state's pose is born here
     __syncthreads();
+    if constexpr (LM) {
+        // scan2map on one GPU: the Levenberg-Marquardt begin / step of solver_dev.hpp runs right here, so an LM iteration is ONE launch
+        SumArgs sa;
+        sa.p = P.partials;
+        sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
+        sum_partials(sa, f_ne, f_cnt2, f_scratch);
+        if (threadIdx.x == 0) {
+            if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks);
+            else lm_step_body(f_ne, P.state, P.lm_max_it);
+            *P.ticket = 0u;
+        }
+        return;
+    }
     if (P.finish == 2) {
         // multi-GPU: only the local reduction happens here; the all-reduce and the (redundant, identical) solve follow
         if (P.n_blocks == 1) {
@@ -440,7 +456,7 @@ __device__ __forceinline__ bool fit_feature(const KParams &P, const KindP &Kd, i
 // ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature, both kinds in one launch
 // KMAX = the largest N_NEIGH of the launch: with 5 (every mapper launch) the 10-neighbour fits are not compiled in, which halves
 // the kernel's register footprint (occupancy matters once a launch has more workgroups than the chip holds at once)
-template <int KMAX>
+template <int KMAX, bool LM>
 __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     MLH_STAGE(gtile, 2);
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
     MLH_STAGE(gtile, 3);
-    if (P.finish) fused_gn_finish(P, total);
+    if (P.finish) fused_gn_finish<LM>(P, total);
     MLH_STAGE(gtile, 4);
 }
 
@@ -512,6 +528,7 @@ extern "C" int mlh_debug_stage_clock_knn(unsigned long long *out, int n_words)
 namespace mlh {
 #endif
 
+template <bool LM>
 __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
@@ -553,6 +570,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
         for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    if constexpr (LM) { if (P.finish == 4) fused_gn_finish<true>(P, total); }
 }
 
 // stand-alone exact 5-NN for mlh_knn (queries already in the map frame)
@@ -648,6 +666,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.has_hi = ctx->shard_hi ? 1 : 0;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
+    P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
     P.publish = (a.finish == 1) ? a.publish : nullptr;
@@ -680,8 +699,11 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     else { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, false>, grid_a, P); }
     bool k10 = false;
     for (int b = 0; b < P.n_blocks; ++b) k10 = k10 || P.kb[b] == 10;
-    if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10>, grid_b, P);
-    else launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5>, grid_b, P);
+    if (P.finish == 3) {
+        if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");
+        launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, true>, grid_b, P);
+    } else if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10, false>, grid_b, P);
+    else launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
     return MLH_OK;
@@ -695,7 +717,8 @@ int linearize_launch(mlh_ctx *ctx, const MatchArgs &a)
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
-    launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel, grid_b, P);
+    if (P.finish == 4) launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<true>, grid_b, P);
+    else launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

@@ -369,4 +369,129 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
     }
 }
 
+
+// ---------------------------------------------------------------- Levenberg-Marquardt (Ceres trust-region semantics)
+// Bodies of the LM begin / step, run by ONE thread after the record has been summed into LDS. They are device functions so
+// that both the stand-alone single-workgroup kernels (solver.hip: multi-GPU, tracker, good-feature paths) and the last-arriving
+// workgroup of the linearisation kernels (match.hip: scan2map on one GPU -- no extra launch per LM iteration) can run them.
+__device__ inline double gradient_max_norm(const SolverState *S)
+{
+    double ng[6], xp[7];
+    for (int i = 0; i < 6; ++i) ng[i] = -S->ne[NE_G + i];
+    pose_plus(S->x, ng, S->V, xp);
+    double m = 0.0;
+    for (int i = 0; i < 7; ++i) m = fmax(m, fabs(S->x[i] - xp[i]));
+    return m;
+}
+
+__device__ inline void lm_propose(SolverState *S, int max_it)
+{
+    while (true) {
+        if (S->iteration >= max_it) { S->done = 1; S->termination = 0; return; }
+        if (S->gmax <= 1e-10) { S->done = 1; S->termination = 1; return; }
+        if (S->radius <= 1e-32) { S->done = 1; S->termination = 4; return; }
+        S->iteration++;
+        double H[36], A[36], gs[6];
+        unpack_H(S->ne, H);
+        for (int r = 0; r < 6; ++r) {
+            gs[r] = S->S[r] * S->ne[NE_G + r];
+            for (int c = 0; c < 6; ++c) A[r * 6 + c] = S->S[r] * H[r * 6 + c] * S->S[c];
+        }
+        if (!S->reuse_diagonal)
+            for (int i = 0; i < 6; ++i) S->diag[i] = fmin(fmax(A[i * 6 + i], 1e-6), 1e32);
+        double lhs[36];
+        for (int i = 0; i < 36; ++i) lhs[i] = A[i];
+        for (int i = 0; i < 6; ++i) lhs[i * 6 + i] += S->diag[i] / S->radius;
+        double y[6], step[6];
+        bool ok = chol6_solve(lhs, gs, y);
+        S->reuse_diagonal = 1;
+        bool valid = false;
+        double mcc = 0.0;
+        if (ok) {
+            double sg = 0.0, sAs = 0.0;
+            for (int r = 0; r < 6; ++r) step[r] = -y[r];
+            for (int r = 0; r < 6; ++r) {
+                sg += step[r] * gs[r];
+                double t = 0.0;
+                for (int c = 0; c < 6; ++c) t += A[r * 6 + c] * step[c];
+                sAs += step[r] * t;
+            }
+            mcc = -(sg + 0.5 * sAs);
+            valid = mcc > 0.0;
+        }
+        if (!valid) {
+            if (++S->num_invalid >= 5) { S->done = 1; S->termination = 4; return; }
+            S->radius /= S->decrease_factor; S->decrease_factor *= 2.0; S->reuse_diagonal = 1;
+            continue;
+        }
+        S->num_invalid = 0;
+        double delta[6];
+        for (int i = 0; i < 6; ++i) delta[i] = step[i] * S->S[i];
+        pose_plus(S->x, delta, S->V, S->cand);
+        S->model_cost_change = mcc;
+        return;
+    }
+}
+
+// ne / cnt2 / scratch: LDS. eig_thre < 0: no degeneracy handling (V_update = I); stat may be null
+__device__ inline void lm_begin_body(const double *ne, const double *cnt2, double *scratch, SolverState *S, double eig_thre, int max_it,
+                                     IterStatDev *stat, int min_blocks)
+{
+    // evalDegenracy. Nobody asked for the eigenvalues (stat == null): H - thre*I positive definite <=> lambda_min > thre <=> nothing
+    // is degenerate, V_update = I -- one Cholesky factorisation instead of the eigen-decomposition; otherwise the full procedure.
+    // eig_thre < 0: the caller has no degeneracy handling at all (LidarTracker: V_update stays the identity)
+    bool deg = false, fast = eig_thre < 0.0;
+    if (!fast && !stat) {
+        double L[21], inv_d[6];
+        pack_lower_from_ne(ne, eig_thre * (1.0 + 1e-9), L);
+        fast = chol6p_factor(L, inv_d);
+    }
+    if (!fast) deg = eval_degeneracy_reg(ne, eig_thre, scratch);
+    for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ne[i];
+    for (int i = 0; i < 36; ++i) S->V[i] = fast ? (((i % 7) == 0) ? 1.0 : 0.0) : scratch[78 + i];
+    {
+        int q = 0;
+        for (int i = 0; i < 6; ++i) { S->S[i] = 1.0 / (1.0 + sqrt(ne[q])); q += 6 - i; }   // Jacobi scaling from diag(J^T J)
+    }
+    S->radius = 1e4; S->decrease_factor = 2.0; S->reuse_diagonal = 0;
+    S->iteration = 0; S->done = 0; S->termination = 0; S->num_successful = 0; S->num_invalid = 0; S->evaluations = 1;
+    S->gmax = gradient_max_norm(S);
+    if (stat) {
+        if (fast) for (int i = 0; i < 6; ++i) scratch[72 + i] = 0.0;     // no eigenvalues were computed
+        write_stat_common(stat, ne, cnt2, scratch + 72, deg);
+        stat->final_cost = ne[NE_COST];
+    }
+    // too few residual blocks (lidar_tracker.cpp:66-70 "less correspondence": the round is skipped)
+    if (ne[NE_CNT] < double(min_blocks)) { S->done = 1; S->termination = 4; return; }
+    lm_propose(S, max_it);
+}
+
+// ce: the summed record at the candidate pose (LDS)
+__device__ inline void lm_step_body(const double *ce, SolverState *S, int max_it)
+{
+    S->evaluations++;
+    double step_norm = 0.0, x_norm = 0.0;
+    for (int i = 0; i < 7; ++i) { double d = S->x[i] - S->cand[i]; step_norm += d * d; x_norm += S->x[i] * S->x[i]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { S->done = 1; S->termination = 2; return; }
+    const double x_cost = S->ne[NE_COST];
+    const double cost_change = x_cost - ce[NE_COST];
+    if (fabs(cost_change) <= 1e-6 * x_cost) { S->done = 1; S->termination = 3; return; }
+    const double rd = cost_change / S->model_cost_change;
+    if (rd > 1e-3) {
+        for (int i = 0; i < 7; ++i) S->x[i] = S->cand[i];
+        for (int i = 0; i < NE_STRIDE; ++i) S->ne[i] = ce[i];
+        S->num_successful++;
+        double t = 2.0 * rd - 1.0;
+        S->radius = S->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        S->radius = fmin(1e16, S->radius);
+        S->decrease_factor = 2.0;
+        S->reuse_diagonal = 0;
+        S->gmax = gradient_max_norm(S);
+    } else {
+        S->radius /= S->decrease_factor; S->decrease_factor *= 2.0; S->reuse_diagonal = 1;
+    }
+    lm_propose(S, max_it);
+}
+
 }  // namespace mlh
