@@ -318,6 +318,11 @@ int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_by
                        float distance_sq_threshold);
 /* stage the current frame's features of one kind */
 int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int m, int intensity_offset_bytes, int mem);
+/* device-to-device hand-over from the extractor of the SAME context (after mlh_extract_run, and mlh_extract_voxel_run for which = 1):
+ * which = 0: the scan's sharp corners / flat surfs become the current frame; which = 1: its less-sharp corners / voxel-thinned
+ * less-flat surfs become the previous frame (call it after mlh_track_cloud, for the next frame). The scan must have been uploaded
+ * with its intensity (ring id) field. */
+int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold);
 /* match*FromScan at `pose`: valid[m] and coeffs[m x 6] ('c': closest point, second point; 's': w, negative_OA_dot_norm, 0, 0); either may be NULL */
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs);
 /* trackCloud: pose_inout = pose_ini -> pose_prev_cur; stats: max_outer records (n_surf / n_corner = residual blocks) or NULL */

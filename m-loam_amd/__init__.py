@@ -99,6 +99,7 @@ def load_library():
     lib.mlh_track_opts_default.restype = None
     lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
     lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
+    lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
     lib.mlh_track_match.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.mlh_track_cloud.argtypes = [vp, vp, vp, vp]
     lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
@@ -132,7 +133,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -289,6 +290,10 @@ class Context:
         self._ck(self.lib.mlh_track_set_cur(self.h, kind, ptr, stride, n, 12, mem))
         self._m_track = getattr(self, "_m_track", {})
         self._m_track[kind] = n
+
+    def track_set_from_scan(self, which, distance_sq_threshold=25.0):
+        """which = 0: current frame <- this context's scan (sharp / flat); 1: previous frame <- (less sharp / thinned less flat)."""
+        self._ck(self.lib.mlh_track_set_from_scan(self.h, which, distance_sq_threshold))
 
     def track_match(self, kind, pose, opts=None):
         opts = opts or default_track_opts()

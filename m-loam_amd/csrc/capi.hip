@@ -938,6 +938,42 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
     return MLH_OK;
 }
 
+__global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__restrict__ pts, const int *__restrict__ list, int n, float4 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = pts[list[i]];
+}
+
+// the features of the scan the context holds become the tracker's current (which = 0: sharp corners, flat surfs) or previous
+// (which = 1: less-sharp corners, voxel-thinned less-flat surfs) frame, device to device
+int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold)
+{
+    if (!ctx || which < 0 || which > 1) return MLH_ERR_INVALID;
+    ScanBuf &sb = ctx->scan;
+    if (!sb.extracted) return fail(ctx, MLH_ERR_STATE, "extract_run has not been called");
+    if (which == 1 && !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "extract_voxel_run has not been called (the previous frame's surf cloud is the thinned one)");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int totals[4] = {0, 0, 0, 0}, n_vox = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(totals, sb.totals.p, sizeof(totals), hipMemcpyDeviceToHost, st));
+    if (which == 1) MLH_HIP(ctx, hipMemcpyAsync(&n_vox, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    const int corner_list = which == 0 ? 0 : 1;                 // corner_points_sharp / corner_points_less_sharp
+    const int n_corner = totals[corner_list], n_flat = totals[2];
+    if (n_corner <= 0 || (which == 0 ? n_flat : n_vox) <= 0) return fail(ctx, MLH_ERR_STATE, "the scan produced no features of one kind");
+    MLH_HIP(ctx, ctx->knn_q.ensure(sizeof(float4) * size_t(std::max(n_corner, n_flat))));     // gather scratch (not ctx->tmp: the staging calls may use that)
+    float4 *g = ctx->knn_q.as<float4>();
+    int rc;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((n_corner + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[corner_list].as<int>(), n_corner, g);
+    if (which == 0) {
+        if ((rc = mlh_track_set_cur(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE))) return rc;
+        hipLaunchKernelGGL(gather_points_kernel, dim3((n_flat + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[2].as<int>(), n_flat, g);
+        return mlh_track_set_cur(ctx, MLH_SURF, g, 16, n_flat, 12, MLH_MEM_DEVICE);
+    }
+    if ((rc = mlh_track_set_prev(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE, distance_sq_threshold))) return rc;
+    return mlh_track_set_prev(ctx, MLH_SURF, sb.vox_out.p, 16, n_vox, 12, MLH_MEM_DEVICE, distance_sq_threshold);
+}
+
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs)
 {
     if (!ctx || kind < 0 || kind > 1 || !pose || !opts) return MLH_ERR_INVALID;

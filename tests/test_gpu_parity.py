@@ -662,3 +662,26 @@ def test_downsample_current_scan_device_resident(ctx, mla, orc, synth, case16, f
     # without uncertainty: nothing dropped, zero covariance
     plain = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, False, thr)
     assert len(plain) == len(ds) and not plain[:, 4:].any()
+
+
+def test_front_end_stays_on_device(mla, orc, track_case):
+    """extractCloud -> LidarTracker::trackCloud without host hops: the scan held by the context feeds the tracker device to device
+    (mlh_track_set_from_scan) and gives exactly the pose of the host hand-over of the same GPU-extracted clouds."""
+    prev, cur = track_case["scans"]
+    p0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    c = mla.Context(0)
+    try:
+        c.scan_upload(prev.points, prev.scan_start, prev.scan_end); c.extract_run(); exp = c.extract_fetch(); lfp = c.extract_voxel(0.2)
+        c.track_set_from_scan(1)                      # previous frame <- this scan
+        c.scan_upload(cur.points, cur.scan_start, cur.scan_end); c.extract_run(); exc = c.extract_fetch()
+        c.track_set_from_scan(0)                      # current frame <- this scan
+        pose_dev, stats_dev = c.track_cloud(p0)
+        # host hand-over of the same clouds
+        c.track_set_prev(mla.CORNER, prev.points[exp["less_sharp"]]); c.track_set_prev(mla.SURF, lfp)
+        c.track_set_cur(mla.CORNER, cur.points[exc["sharp"]]); c.track_set_cur(mla.SURF, cur.points[exc["flat"]])
+        pose_host, stats_host = c.track_cloud(p0)
+        np.testing.assert_array_equal(pose_dev, pose_host)
+        assert [(s["n_corner"], s["n_surf"], s["lm_iterations"]) for s in stats_dev] == [(s["n_corner"], s["n_surf"], s["lm_iterations"]) for s in stats_host]
+        assert np.linalg.norm(pose_dev[:3] - track_case["motion"][:3]) < 0.08
+    finally:
+        c.close()
