@@ -323,6 +323,16 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
  * less-flat surfs become the previous frame (call it after mlh_track_cloud, for the next frame). The scan must have been uploaded
  * with its intensity (ring id) field. */
 int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold);
+/* The mapper's input clouds without leaving HBM. transformCloudFeature (estimator/src/utility/visualization.cpp:39-51) moves every
+ * LiDAR's features into the body frame and overwrites intensity with the LiDAR index before they are published to the mapper;
+ * mlh_fuse_add_scan does that for the scan the context holds (after mlh_extract_run + mlh_extract_voxel_run): its voxel-thinned
+ * less-flat points are appended to the fused SURF cloud, its less-sharp points to the fused CORNER cloud (float32: (r0 x + r1 y)
+ * + r2 z + t per row, R rounded once from the double quaternion). mlh_fused_cloud hands out the device pointer (float4 records
+ * {x,y,z,lidar}: stride 16, intensity offset 12) for mlh_downsample_current_scan(..., MLH_MEM_DEVICE); it stays valid until the
+ * next mlh_fuse_add_scan. ext_pose = [t(3), q(xyzw)] of the LiDAR in the body frame. */
+int mlh_fuse_reset(mlh_ctx *ctx);
+int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7]);
+int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n);
 /* match*FromScan at `pose`: valid[m] and coeffs[m x 6] ('c': closest point, second point; 's': w, negative_OA_dot_norm, 0, 0); either may be NULL */
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs);
 /* trackCloud: pose_inout = pose_ini -> pose_prev_cur; stats: max_outer records (n_surf / n_corner = residual blocks) or NULL */

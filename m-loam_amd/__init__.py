@@ -100,6 +100,9 @@ def load_library():
     lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
     lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
     lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
+    lib.mlh_fuse_reset.argtypes = [vp]
+    lib.mlh_fuse_add_scan.argtypes = [vp, ci, vp]
+    lib.mlh_fused_cloud.argtypes = [vp, ci, vp, vp]
     lib.mlh_track_match.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.mlh_track_cloud.argtypes = [vp, vp, vp, vp]
     lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
@@ -133,7 +136,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -145,8 +148,16 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class DeviceCloud:
+    """A device-resident cloud owned by the library (mlh_fused_cloud): pointer, record count, record stride in bytes."""
+    def __init__(self, ptr, n, stride=16):
+        self.ptr, self.n, self.stride = ptr, n, stride
+
+
 def _src(points):
-    """(pointer, stride_bytes, n, mem, keepalive) for a numpy array (host) or a torch CUDA tensor (device)."""
+    """(pointer, stride_bytes, n, mem, keepalive) for a numpy array (host), a torch CUDA tensor or a DeviceCloud (device)."""
+    if isinstance(points, DeviceCloud):
+        return C.c_void_p(points.ptr), points.stride, points.n, MEM_DEVICE, points
     if isinstance(points, np.ndarray):
         a = np.ascontiguousarray(points, np.float32)
         return a.ctypes.data_as(C.c_void_p), a.shape[1] * 4, a.shape[0], MEM_HOST, a
@@ -261,6 +272,10 @@ class Context:
             out["less_flat_ds"] = self.extract_voxel(voxel_leaf)
         return out
 
+    def extract_voxel_run(self, leaf=0.2):
+        """The per-ring VoxelGrid of the less-flat points, result kept on the device (for fuse_add_scan / track_set_from_scan)."""
+        self._ck(self.lib.mlh_extract_voxel_run(self.h, leaf))
+
     def extract_voxel(self, leaf=0.2):
         """surf_points_less_flat after the per-ring VoxelGrid (feature_extract.cpp:266-271)."""
         self._ck(self.lib.mlh_extract_voxel_run(self.h, leaf))
@@ -295,6 +310,19 @@ class Context:
         """which = 0: current frame <- this context's scan (sharp / flat); 1: previous frame <- (less sharp / thinned less flat)."""
         self._ck(self.lib.mlh_track_set_from_scan(self.h, which, distance_sq_threshold))
 
+    def fuse_reset(self):
+        self._ck(self.lib.mlh_fuse_reset(self.h))
+
+    def fuse_add_scan(self, lidar_idx, ext_pose):
+        """transformCloudFeature for the scan this context holds: append its mapping features, in the body frame, to the fused clouds."""
+        e = np.ascontiguousarray(ext_pose, np.float64).reshape(7)
+        self._ck(self.lib.mlh_fuse_add_scan(self.h, int(lidar_idx), _p(e)))
+
+    def fused_cloud(self, kind) -> "DeviceCloud":
+        ptr, n = C.c_void_p(), C.c_int32(0)
+        self._ck(self.lib.mlh_fused_cloud(self.h, kind, C.byref(ptr), C.byref(n)))
+        return DeviceCloud(ptr.value, n.value)
+
     def track_match(self, kind, pose, opts=None):
         opts = opts or default_track_opts()
         pose = np.ascontiguousarray(pose, np.float64)
@@ -328,19 +356,20 @@ class Context:
         self._ck(self.lib.mlh_pure_odom_evaluate(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), _p(r), _p(J) if J is not None else None))
         return r, J
 
-    def downsample_current_scan(self, kind, points4, leaf, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6):
-        """downsampleCurrentScan for one kind; the result becomes the kind's feature set and is also returned (m, 11)."""
+    def downsample_current_scan(self, kind, points4, leaf, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6, fetch=True):
+        """downsampleCurrentScan for one kind; the result becomes the kind's feature set and, with fetch, is also returned (m, 11)
+        (without: the number of features; nothing leaves the device)."""
         ptr, stride, n, mem, keep = _src(points4)
         ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7)
         ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
         cm = np.ascontiguousarray(cov_measurement, np.float64).reshape(9)
-        out = np.zeros((n, 11), np.float32)
+        out = np.zeros((n, 11), np.float32) if fetch else None
         cnt = C.c_int32(0)
         self._ck(self.lib.mlh_downsample_current_scan(self.h, kind, ptr, stride, n, 12, mem, leaf, _p(ep), _p(ec), len(ep), _p(cm), int(bool(with_ua)),
-                                                      float(trace_threshold), _p(out), C.byref(cnt)))
+                                                      float(trace_threshold), _p(out) if fetch else None, C.byref(cnt)))
         self._m = getattr(self, "_m", {})
         self._m[kind] = cnt.value
-        return out[:cnt.value].copy()
+        return out[:cnt.value].copy() if fetch else cnt.value
 
     def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
         """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""

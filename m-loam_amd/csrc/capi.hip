@@ -275,7 +275,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
-    { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
+    { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -972,6 +972,72 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
     }
     if ((rc = mlh_track_set_prev(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE, distance_sq_threshold))) return rc;
     return mlh_track_set_prev(ctx, MLH_SURF, sb.vox_out.p, 16, n_vox, 12, MLH_MEM_DEVICE, distance_sq_threshold);
+}
+
+// transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
+struct FuseXf { float r[9], t[3], id; };
+__global__ __launch_bounds__(256) void fuse_append_kernel(const float4 *__restrict__ pts, const int *__restrict__ list, int n, FuseXf xf, float4 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[list ? list[i] : i];
+    float4 o;
+    // products and sums kept separate (no contraction) so that the result is one well-defined float32 expression
+    o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], p.x), __fmul_rn(xf.r[1], p.y)), __fmul_rn(xf.r[2], p.z)), xf.t[0]);
+    o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], p.x), __fmul_rn(xf.r[4], p.y)), __fmul_rn(xf.r[5], p.z)), xf.t[1]);
+    o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], p.x), __fmul_rn(xf.r[7], p.y)), __fmul_rn(xf.r[8], p.z)), xf.t[2]);
+    o.w = xf.id;
+    out[i] = o;
+}
+
+int mlh_fuse_reset(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    ctx->fused_n[0] = ctx->fused_n[1] = 0;
+    return MLH_OK;
+}
+
+int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7])
+{
+    if (!ctx || !ext_pose || lidar_idx < 0) return MLH_ERR_INVALID;
+    ScanBuf &sb = ctx->scan;
+    if (!sb.extracted || !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "mlh_extract_run and mlh_extract_voxel_run come first");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int totals[4] = {0, 0, 0, 0}, n_vox = 0;
+    MLH_HIP(ctx, hipMemcpyAsync(totals, sb.totals.p, sizeof(totals), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(&n_vox, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    // rotation of the unit quaternion in double, rounded once to float: what Eigen::Matrix4f holds after `.cast<float>()`
+    const double tx = ext_pose[0], ty = ext_pose[1], tz = ext_pose[2], qx = ext_pose[3], qy = ext_pose[4], qz = ext_pose[5], qw = ext_pose[6];
+    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+    FuseXf xf;
+    for (int i = 0; i < 9; ++i) xf.r[i] = float(R[i]);
+    xf.t[0] = float(tx); xf.t[1] = float(ty); xf.t[2] = float(tz);
+    xf.id = float(lidar_idx);
+    const int add[2] = {n_vox, totals[1]};                         // surf <- thinned less-flat, corner <- less-sharp
+    const void *src[2] = {sb.vox_out.p, sb.pts.p};
+    const int *lst[2] = {nullptr, sb.lists[1].as<int>()};
+    for (int k = 0; k < 2; ++k) {
+        if (add[k] <= 0) continue;
+        const size_t have = size_t(ctx->fused_n[k]);
+        MLH_HIP(ctx, ctx->fused[k].grow(sizeof(float4) * (have + size_t(add[k])), sizeof(float4) * have, st));
+        hipLaunchKernelGGL(fuse_append_kernel, dim3((add[k] + 255) / 256), dim3(256), 0, st, (const float4 *)src[k], lst[k], add[k], xf,
+                           ctx->fused[k].as<float4>() + have);
+        ctx->fused_n[k] += add[k];
+    }
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n)
+{
+    if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
+    *device_points = ctx->fused[kind].p;
+    *n = ctx->fused_n[kind];
+    return MLH_OK;
 }
 
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs)

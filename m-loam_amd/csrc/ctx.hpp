@@ -154,7 +154,7 @@ struct ScanBuf {
 };
 
 struct VoxBuf {   // scratch of mlh_voxel_filter
-    DevBuf in, bounds, cell, vox_of, sorted_idx, leader, out, sums, total;
+    DevBuf in, bounds, cell, wpre, cnt, vox_of, sorted_idx, members, leader, out, sums, total;
 };
 
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
@@ -209,6 +209,8 @@ struct mlh_ctx {
     mlh::VoxBuf vox;
     mlh::OdomSet odom;
     mlh::TrackSet track;
+    mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
+    int fused_n[2] = {0, 0};
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;

@@ -13,6 +13,7 @@
 //   offsets_kernel    exclusive scan of the per-ring list sizes (emission order = ring asc, sector asc, pick order)
 //   emit_kernel       writes the four index lists; less-flat = positions with label <= 0 (cpp:258-264), stream-compacted.
 #include "ctx.hpp"
+#include "sort_dev.hpp"
 #include <algorithm>
 
 namespace mlh {
@@ -75,45 +76,6 @@ __device__ __forceinline__ bool gap_exceeds(const float *sx, const float *sy, co
 }
 
 constexpr int LTPB = 384;   // label kernel: six wavefronts, one per sector while sorting
-
-// Ascending bitonic sort of 64*KPL 64-bit keys held by ONE wavefront: lane l owns elements l*KPL .. l*KPL+KPL-1 in registers.
-// Exchange distances below KPL stay inside a lane (static register indices), the others are lane-xor shuffles: no LDS array,
-// no workgroup barrier -- the six sectors of a ring sort concurrently on six wavefronts.
-template <int KPL>
-__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[KPL], int lane)
-{
-#pragma unroll
-    for (int k = 2; k <= 64 * KPL; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= KPL) {
-                const int lx = j / KPL;                          // partner lane = lane ^ lx
-                const bool lower = (lane & lx) == 0;
-#pragma unroll
-                for (int r = 0; r < KPL; ++r) {
-                    const bool up = (((lane * KPL + r) & k) == 0);
-                    const unsigned long long a = v[r];
-                    unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
-                    lo = __shfl_xor(lo, lx); hi = __shfl_xor(hi, lx);
-                    const unsigned long long b = ((unsigned long long)hi << 32) | lo;
-                    const bool take_min = (lower == up);
-                    v[r] = take_min ? (a < b ? a : b) : (a < b ? b : a);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < KPL; ++r) {
-                    if ((r & j) == 0) {
-                        const bool up = (((lane * KPL + r) & k) == 0);
-                        const unsigned long long a = v[r], b = v[r | j];
-                        const bool sw = (a > b) == up;
-                        v[r] = sw ? b : a;
-                        v[r | j] = sw ? a : b;
-                    }
-                }
-            }
-        }
-    }
-}
 
 // one sector: build the keys in registers, sort, store the sorted list to LDS for the walks
 template <int KPL>

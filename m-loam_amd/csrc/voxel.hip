@@ -3,8 +3,9 @@
 // ring_voxel_kernel      the per-ring pcl::VoxelGrid<PointXYZI>(0.2 m) that closes FeatureExtract::extractCloud
 //                        (estimator/src/featureExtract/feature_extract.cpp:266-271; PCL 1.8.0 filters/impl/voxel_grid.hpp):
 //                        one workgroup per ring, the ring's less-flat points (label <= 0, cpp:258-264) are keyed with PCL's
-//                        voxel index (floor(x * inv_leaf) - min_b, x fastest), sorted in LDS on 64-bit (voxel, position) keys
-//                        with a bitonic network, and every voxel's members are averaged (CentroidPoint: f32 sums / count)
+//                        voxel index (floor(x * inv_leaf) - min_b, x fastest), sorted on 64-bit (voxel, position) keys by a
+//                        register-resident bitonic network (sort_dev.hpp: 1024 threads, only the cross-wavefront stages touch
+//                        LDS), and every voxel's members are averaged (CentroidPoint: f32 sums / count)
 //                        in position order. Output order = ring asc, voxel index asc, as the reference concatenates them.
 // point_uncertainty_kernel   evalPointUncertainty (estimator/src/lidarMapper/associate_uct.hpp:196-215) as used by
 //                        downsampleCurrentScan (lidar_mapper_keyframe.cpp:375-418): per point, Sigma_p = [G diag(Sigma_ext,
@@ -12,6 +13,7 @@
 //                        points whose trace exceeds TRACE_THRESHOLD_MAPPING are dropped (order-preserving compaction).
 #include "ctx.hpp"
 #include "dev_math.hpp"
+#include "sort_dev.hpp"
 #include <cfloat>
 
 namespace mlh {
@@ -25,143 +27,158 @@ struct RingVoxelArgs {
     float4 *stage;              // staged centroids, at the ring's offset in the less-flat list
     int *ring_vox;              // voxels per ring
     float leaf;
-    int sort_p;                 // power of two >= the longest less-flat run
 };
 
-__device__ __forceinline__ float block_reduce_minmax(float v, bool is_min, float *lds)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float o = __shfl_xor(v, off);
-        v = is_min ? fminf(v, o) : fmaxf(v, o);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    float r = lds[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) r = is_min ? fminf(r, lds[w]) : fmaxf(r, lds[w]);
-    return r;
-}
+constexpr int RV_TPB = 1024, RV_WAVES = RV_TPB / 64;
 
-__global__ __launch_bounds__(256) void ring_voxel_kernel(RingVoxelArgs A)
+// KPL keys per thread: a ring of up to 1024 * KPL less-flat points. PTS_IN_LDS: the ring's points are parked in LDS on the first
+// pass so that the centroid walks (a dependent chain per voxel) never go back to memory.
+template <int KPL, bool PTS_IN_LDS>
+__global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ float s_red[4];
-    __shared__ int s_scan[4];
-    __shared__ int s_total;
-    const int ring = blockIdx.x;
+    constexpr int N = RV_TPB * KPL;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+    float4 *spts = reinterpret_cast<float4 *>(keys + N);
+    __shared__ float s_red[RV_WAVES][6];
+    __shared__ int s_scan[RV_WAVES];
+    const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = A.ring_counts[ring * 4 + 3];
     const int off = A.ring_offsets[ring * 4 + 3];
-    if (n <= 0) { if (threadIdx.x == 0) A.ring_vox[ring] = 0; return; }
-    const int P = A.sort_p;
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);
+    if (n <= 0) { if (tid == 0) A.ring_vox[ring] = 0; return; }
     const float inv = 1.0f / A.leaf;
 
+    // the thread's KPL points (element t = tid * KPL + r of the ring's less-flat run), all loads in flight together
+    float4 p[KPL];
+    int gi[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) gi[r] = A.list3[off + min(tid * KPL + r, n - 1)];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) p[r] = A.pts[gi[r]];
     // bounds (getMinMax3D) -> min_b, div_b (voxel_grid.hpp)
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int t = threadIdx.x; t < n; t += 256) {
-        const float4 p = A.pts[A.list3[off + t]];
-        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        if (tid * KPL + r < n) {
+            m[0] = fminf(m[0], p[r].x); m[3] = fmaxf(m[3], p[r].x);
+            m[1] = fminf(m[1], p[r].y); m[4] = fmaxf(m[4], p[r].y);
+            m[2] = fminf(m[2], p[r].z); m[5] = fmaxf(m[5], p[r].z);
+            if (PTS_IN_LDS) spts[tid * KPL + r] = p[r];
+        }
     }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m[d] = fminf(m[d], __shfl_xor(m[d], o)); m[3 + d] = fmaxf(m[3 + d], __shfl_xor(m[3 + d], o)); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) s_red[wave][d] = m[d];
+    }
+    __syncthreads();
     int min_b[3], div_b[3];
     long long cells = 1;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const float lo = block_reduce_minmax(mn[d], true, s_red);
-        const float hi = block_reduce_minmax(mx[d], false, s_red);
+        float lo = s_red[0][d], hi = s_red[0][3 + d];
+#pragma unroll
+        for (int w = 1; w < RV_WAVES; ++w) { lo = fminf(lo, s_red[w][d]); hi = fmaxf(hi, s_red[w][3 + d]); }
         min_b[d] = int(floorf(lo * inv));
         div_b[d] = int(floorf(hi * inv)) - min_b[d] + 1;
         cells *= (long long)((hi - lo) * inv) + 1;
     }
     if (cells > 2147483647ll) {   // "Leaf size is too small for the input dataset": PCL returns the input unchanged
-        for (int t = threadIdx.x; t < n; t += 256) A.stage[off + t] = A.pts[A.list3[off + t]];
-        if (threadIdx.x == 0) A.ring_vox[ring] = n;
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) if (tid * KPL + r < n) A.stage[off + tid * KPL + r] = p[r];
+        if (tid == 0) A.ring_vox[ring] = n;
         return;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
     // keys: (voxel index << 32) | position in the ring's less-flat run; padding = all ones
-    for (int t = threadIdx.x; t < P; t += 256) {
-        unsigned long long key = ~0ull;
-        if (t < n) {
-            const float4 p = A.pts[A.list3[off + t]];
-            const int ijk0 = int(floorf(p.x * inv) - float(min_b[0]));
-            const int ijk1 = int(floorf(p.y * inv) - float(min_b[1]));
-            const int ijk2 = int(floorf(p.z * inv) - float(min_b[2]));
-            const unsigned idx = unsigned(ijk0 + ijk1 * mul1 + ijk2 * mul2);
-            key = ((unsigned long long)idx << 32) | unsigned(t);
-        }
-        keys[t] = key;
+    unsigned long long v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int t = tid * KPL + r;
+        const int ijk0 = int(floorf(p[r].x * inv) - float(min_b[0]));
+        const int ijk1 = int(floorf(p[r].y * inv) - float(min_b[1]));
+        const int ijk2 = int(floorf(p[r].z * inv) - float(min_b[2]));
+        const unsigned idx = unsigned(ijk0 + ijk1 * mul1 + ijk2 * mul2);
+        v[r] = t < n ? (((unsigned long long)idx << 32) | unsigned(t)) : ~0ull;
     }
+    block_bitonic_sort<KPL, RV_WAVES>(v, keys, tid);
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) keys[tid * KPL + r] = v[r];
     __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += 256) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int ixj = i | j;
-                const bool up = ((i & k) == 0) || (k == P);
-                unsigned long long a = keys[i], b = keys[ixj];
-                if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-            }
-            __syncthreads();
-        }
+    // every voxel start computes its centroid (members in position order); output slot = number of voxel starts before it
+    bool start[KPL];
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int e = tid * KPL + r;
+        const unsigned vox = unsigned(v[r] >> 32);
+        const unsigned prev = r > 0 ? unsigned(v[r > 0 ? r - 1 : 0] >> 32) : (e > 0 ? unsigned(keys[e - 1] >> 32) : ~vox);
+        start[r] = e < n && (e == 0 || prev != vox);
+        mine += start[r] ? 1 : 0;
     }
-    // every voxel start computes its centroid; output slot = number of voxel starts before it
-    if (threadIdx.x == 0) s_total = 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) s_scan[wave] = incl;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 256) {
-        const int t = c0 + threadIdx.x;
-        bool start = false;
-        unsigned vox = 0;
-        if (t < n) {
-            vox = unsigned(keys[t] >> 32);
-            start = (t == 0) || (unsigned(keys[t - 1] >> 32) != vox);
-        }
-        const unsigned long long m = __ballot(start);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_scan[wave] = __popcll(m);
-        __syncthreads();
-        int wbase = s_total;
-        for (int w = 0; w < wave; ++w) wbase += s_scan[w];
-        if (start) {
+    int slot = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < RV_WAVES; ++w) { const int c = s_scan[w]; slot += w < wave ? c : 0; total += c; }
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        if (start[r]) {
+            const unsigned vox = unsigned(v[r] >> 32);
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
             int cnt = 0;
-            for (int u = t; u < n && unsigned(keys[u] >> 32) == vox; ++u) {
-                const float4 p = A.pts[A.list3[off + int(unsigned(keys[u]))]];
-                sx += p.x; sy += p.y; sz += p.z; si += p.w;
+            for (int u = tid * KPL + r; u < n; ++u) {
+                const unsigned long long ku = keys[u];
+                if (unsigned(ku >> 32) != vox) break;
+                const int pos = int(unsigned(ku));
+                const float4 q = PTS_IN_LDS ? spts[pos] : A.pts[A.list3[off + pos]];
+                sx += q.x; sy += q.y; sz += q.z; si += q.w;
                 ++cnt;
             }
             const float fc = float(cnt);
-            A.stage[off + wbase + before] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            A.stage[off + slot] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+            ++slot;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_total += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-        __syncthreads();
     }
-    if (threadIdx.x == 0) A.ring_vox[ring] = s_total;
+    if (tid == 0) A.ring_vox[ring] = total;
 }
 
-// exclusive scan of the per-ring voxel counts (single workgroup) + total
-__global__ void ring_vox_offsets_kernel(const int *__restrict__ ring_vox, int n_rings, int *__restrict__ vox_off, int *__restrict__ total)
-{
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int r = 0; r < n_rings; ++r) { vox_off[r] = acc; acc += ring_vox[r]; }
-        *total = acc;
-    }
-}
-
+// concatenation of the rings' centroids (ring asc): every workgroup sums the counts of the rings before its own (a few dozen
+// words), the last one also publishes the total
 __global__ __launch_bounds__(256) void ring_vox_compact_kernel(const float4 *__restrict__ stage, const int *__restrict__ ring_offsets,
-                                                               const int *__restrict__ ring_vox, const int *__restrict__ vox_off,
+                                                               const int *__restrict__ ring_vox, int n_rings, int *__restrict__ total,
                                                                float4 *__restrict__ out)
 {
+    __shared__ int s_dst;
     const int ring = blockIdx.x;
-    const int n = ring_vox[ring], src = ring_offsets[ring * 4 + 3], dst = vox_off[ring];
+    if (threadIdx.x < 64) {
+        int acc = 0;
+        for (int r = threadIdx.x; r < ring; r += 64) acc += ring_vox[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (threadIdx.x == 0) s_dst = acc;
+    }
+    __syncthreads();
+    const int n = ring_vox[ring], src = ring_offsets[ring * 4 + 3], dst = s_dst;
+    if (threadIdx.x == 0 && ring == n_rings - 1) *total = dst + n;
     for (int t = threadIdx.x; t < n; t += 256) out[dst + t] = stage[src + t];
+}
+
+template <int KPL, bool PTS_IN_LDS>
+static hipError_t ring_voxel_launch(const RingVoxelArgs &A, int R, hipStream_t st)
+{
+    const size_t lds = size_t(RV_TPB) * KPL * (sizeof(unsigned long long) + (PTS_IN_LDS ? sizeof(float4) : 0));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ring_voxel_kernel<KPL, PTS_IN_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ring_voxel_kernel<KPL, PTS_IN_LDS>), dim3(R), dim3(RV_TPB), lds, st, A);
+    return hipSuccess;
 }
 
 int ring_voxel_run(mlh_ctx *ctx, float leaf)
@@ -173,20 +190,19 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     MLH_HIP(ctx, sb.vox_stage.ensure(sizeof(float4) * size_t(sb.n)));
     MLH_HIP(ctx, sb.vox_out.ensure(sizeof(float4) * size_t(sb.n)));
     MLH_HIP(ctx, sb.ring_vox.ensure(sizeof(int) * size_t(2 * R + 1)));
-    int P = 64;
-    while (P < sb.max_ring_len + 1) P <<= 1;
-    const size_t lds = sizeof(unsigned long long) * size_t(P);
-    if (lds > 150 * 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring too long for the LDS-resident voxel sort");
-    MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ring_voxel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    const int longest = sb.max_ring_len + 1;      // upper bound of a ring's less-flat count
     RingVoxelArgs A;
     A.pts = sb.pts.as<float4>(); A.list3 = sb.lists[3].as<int>(); A.ring_counts = sb.ring_counts.as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.stage = sb.vox_stage.as<float4>(); A.ring_vox = sb.ring_vox.as<int>();
-    A.leaf = leaf; A.sort_p = P;
+    A.leaf = leaf;
     prof_begin(ctx, MLH_K_EXTRACT);
-    hipLaunchKernelGGL(ring_voxel_kernel, dim3(R), dim3(256), lds, st, A);
-    hipLaunchKernelGGL(ring_vox_offsets_kernel, dim3(1), dim3(64), 0, st, sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + R, sb.ring_vox.as<int>() + 2 * R);
-    hipLaunchKernelGGL(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, sb.vox_stage.as<float4>(), sb.ring_offsets.as<int>(),
-                       sb.ring_vox.as<int>(), sb.ring_vox.as<int>() + R, sb.vox_out.as<float4>());
+    if (longest <= RV_TPB) MLH_HIP(ctx, (ring_voxel_launch<1, true>(A, R, st)));
+    else if (longest <= RV_TPB * 2) MLH_HIP(ctx, (ring_voxel_launch<2, true>(A, R, st)));
+    else if (longest <= RV_TPB * 4) MLH_HIP(ctx, (ring_voxel_launch<4, true>(A, R, st)));
+    else if (longest <= RV_TPB * 8) MLH_HIP(ctx, (ring_voxel_launch<8, false>(A, R, st)));
+    else return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
+    hipLaunchKernelGGL(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, (const float4 *)sb.vox_stage.as<float4>(), (const int *)sb.ring_offsets.as<int>(),
+                       (const int *)sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + 2 * R, sb.vox_out.as<float4>());
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
     sb.voxelised = true;
@@ -482,19 +498,21 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
     if (n_lidar <= 0 || n_lidar > 16 || !ext_poses || (with_ua && (!ext_covs || !cov_meas))) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
     hipStream_t st = ctx->stream;
     VoxBuf &V = ctx->vox;
-    int n_ds = 0;
-    int rc = voxel_filter_run(ctx, points, stride, n, intensity_off, -1, -1, leaf, 0.f, nullptr, &n_ds, mem);   // result in V.out
-    if (rc) return rc;
-    *n_out = 0;
-    if (n_ds <= 0) return MLH_OK;
-    MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * size_t(n_lidar) * 43 + sizeof(float) * 6 * size_t(n_ds) + 64));
+    if (n <= 0) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    // the extrinsics go first: the voxel filter's own synchronisations (bounds, count) then cover this upload as well, and the
+    // sources (the caller's temporaries / `zero`) are free again when it returns
+    MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * size_t(n_lidar) * 43 + sizeof(float) * 6 * size_t(n) + 64));
     double *d_ext = ctx->uct_buf.as<double>();
     double *d_cov = d_ext + size_t(n_lidar) * 7;
     float *d_c6 = reinterpret_cast<float *>(d_cov + size_t(n_lidar) * 36);
     std::vector<double> zero(size_t(n_lidar) * 36, 0.0);
     MLH_HIP(ctx, hipMemcpyAsync(d_ext, ext_poses, sizeof(double) * 7 * n_lidar, hipMemcpyHostToDevice, st));
     MLH_HIP(ctx, hipMemcpyAsync(d_cov, ext_covs ? ext_covs : zero.data(), sizeof(double) * 36 * n_lidar, hipMemcpyHostToDevice, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));       // the sources may be the caller's temporaries / `zero`
+    int n_ds = 0;
+    int rc = voxel_filter_run(ctx, points, stride, n, intensity_off, -1, -1, leaf, 0.f, nullptr, &n_ds, mem);   // result in V.out
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    *n_out = 0;
+    if (n_ds <= 0) return MLH_OK;
     MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n_ds + 1)));
     MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n_ds + 1)));
     MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));

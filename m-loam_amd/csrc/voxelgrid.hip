@@ -3,15 +3,16 @@
 // lidar_mapper_keyframe.cpp:343-347, 359-368).
 //
 // The reference sorts (voxel index, point index) pairs with std::sort and walks the runs. Here the voxel index (same f32
-// arithmetic: floor(x * inv_leaf) - min_b, x fastest) drives a counting sort over the dense voxel grid -- count, in-place
-// exclusive scan, scatter of POINT INDICES -- so no comparison sort is needed; the first sorted position of every occupied
-// voxel is its leader, a prefix sum over the leader flags gives the output slot (= ascending voxel index, the reference's
-// output order), and the leader sorts its few member indices and accumulates them in index order (deterministic; the
-// reference's order inside a voxel is whatever its unstable sort left, so sums agree up to f32 rounding).
+// arithmetic: floor(x * inv_leaf) - min_b, x fastest) sets one occupancy bit of the dense voxel grid; the number of set bits
+// below a voxel's bit (a popcount prefix sum over the words, 1/32 of the cells) IS its output slot (= ascending voxel index, the
+// reference's output order), a counting sort over the occupied slots groups the POINT INDICES, every member ranks itself
+// inside its voxel, and one thread per voxel accumulates the members in index order (deterministic; the reference's order
+// inside a voxel is whatever its unstable sort left, so sums agree up to f32 rounding). No comparison sort, no pass over an
+// int-per-cell grid: a 0.2 m grid over a 120 x 120 x 20 m scan is 36 M cells = 4.5 MB of bits.
 //   cov branch (:296-333)   w = thr - tr; |tr| >= thr dropped; mu = sum w p / sum w; cov = sum w^2 cov_i / (sum w)^2; intensity of the
 //                           heaviest member (first wins); trace recomputed from the diagonal
 //   plain branch (:392-420) xyz mean over the members, intensity of the last member
-// Streaming kernels: ~ (stride + 8) B/point per pass + 8 B/voxel for the scan.
+// Streaming kernels: ~ (stride + 8) B/point per pass + 1/8 B/cell (bits) + 8 B per 32 cells for the popcount scan.
 #include "ctx.hpp"
 #include <cfloat>
 #include <cmath>
@@ -86,22 +87,40 @@ int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, DevBuf &sums, in
     return MLH_OK;
 }
 
+// popcount scan: out[w] = number of set bits in mask[0..w)
+__global__ __launch_bounds__(256) void vscan_popc_local_kernel(const unsigned *__restrict__ mask, int *__restrict__ out, long long n, int *__restrict__ sums)
+{
+    __shared__ int lds[4];
+    const long long base = (long long)blockIdx.x * VS_CHUNK + threadIdx.x * VS_ITEMS;
+    int v[VS_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < VS_ITEMS; ++k) { v[k] = (base + k < n) ? __popc(mask[base + k]) : 0; s += v[k]; }
+    int total;
+    int ex = vblock_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < VS_ITEMS; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
 struct VoxArgs {
     const unsigned char *src;
     int stride, n, intensity_off, cov_off, trace_off;
     float inv_leaf;
     int min_b[3], mul1, mul2;
     float trace_thr;
-    int *vox_of;        // n: voxel index per point
-    int *cell;          // ncell + 1: counts -> starts (shifted by one as in grid.hip)
-    int *sorted_idx;    // n
-    int *leader;        // n: leader flags -> output slots
+    int *vox_of;        // n: voxel index per point, then its output slot
+    unsigned *mask;     // one occupancy bit per voxel of the dense grid
+    const int *wpre;    // set bits before each mask word
+    int *cnt;           // n + 2: members per output slot (shifted by one as in grid.hip) -> starts
+    int *sorted_idx;    // n: point indices grouped by slot, arrival order
+    int *members;       // n: the same, ascending inside every slot
+    const int *total;   // occupied voxels = output records
     unsigned char *out; // n_out records (same layout as the input)
 };
 
 __device__ __forceinline__ const float *vrec(const VoxArgs &A, int i) { return reinterpret_cast<const float *>(A.src + size_t(i) * A.stride); }
 
-__global__ __launch_bounds__(256) void vox_count_kernel(VoxArgs A)
+__global__ __launch_bounds__(256) void vox_mark_kernel(VoxArgs A)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
@@ -111,68 +130,95 @@ __global__ __launch_bounds__(256) void vox_count_kernel(VoxArgs A)
     const int ijk2 = int(floorf(p[2] * A.inv_leaf) - float(A.min_b[2]));
     const int v = ijk0 + ijk1 * A.mul1 + ijk2 * A.mul2;
     A.vox_of[i] = v;
-    atomicAdd(&A.cell[v + 1], 1);
+    atomicOr(&A.mask[v >> 5], 1u << (v & 31));
+    A.cnt[i] = 0;
+    if (i == 0) { A.cnt[A.n] = 0; A.cnt[A.n + 1] = 0; }
+}
+
+// output slot of a voxel = number of occupied voxels with a smaller index (ascending voxel index = the reference's output order)
+__global__ __launch_bounds__(256) void vox_slot_kernel(VoxArgs A)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const int v = A.vox_of[i], w = v >> 5;
+    const int s = A.wpre[w] + __popc(A.mask[w] & ((1u << (v & 31)) - 1u));
+    A.vox_of[i] = s;
+    atomicAdd(&A.cnt[s + 1], 1);
 }
 
 __global__ __launch_bounds__(256) void vox_scatter_kernel(VoxArgs A)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
-    const int pos = atomicAdd(&A.cell[A.vox_of[i] + 1], 1);
+    const int pos = atomicAdd(&A.cnt[A.vox_of[i] + 1], 1);
     A.sorted_idx[pos] = i;
 }
 
-// after the scatter cell[v] = start[v], cell[v+1] = end[v]
-__global__ __launch_bounds__(256) void vox_leader_kernel(VoxArgs A)
+// after the scatter cnt[s] = start[s], cnt[s+1] = end[s]. Every member finds its rank among its voxel's members (independent
+// loads over a short contiguous run) so that the aggregation can walk them in ascending point index without searching.
+__global__ __launch_bounds__(256) void vox_rank_kernel(VoxArgs A)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= A.n) return;
-    const int v = A.vox_of[A.sorted_idx[p]];
-    A.leader[p] = (p == A.cell[v]) ? 1 : 0;
+    const int id = A.sorted_idx[p];
+    const int s = A.vox_of[id];
+    const int b = A.cnt[s], e = A.cnt[s + 1];
+    int rank = 0;
+    for (int u = b; u < e; ++u) rank += (A.sorted_idx[u] < id) ? 1 : 0;
+    A.members[b + rank] = id;
 }
 
-__global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A, const int *__restrict__ slot /* exclusive scan of the leader flags */,
-                                                            const int *__restrict__ flag_total)
+constexpr int VAG = 4;   // member records in flight per voxel
+__global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= A.n) return;
-    const int v = A.vox_of[A.sorted_idx[p]];
-    const int b = A.cell[v];
-    if (p != b) return;
-    const int e = A.cell[v + 1];
-    (void)flag_total;
-    // member indices in ascending order: selection by repeated minimum (runs are short)
-    float mu[3] = {0.f, 0.f, 0.f}, ity = 0.f, cov[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, weight_total = 0.f, w_max = 0.f;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= *A.total) return;
+    const int b = A.cnt[s], e = A.cnt[s + 1];
+    float mu[3] = {0.f, 0.f, 0.f}, ity = 0.f, cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, weight_total = 0.f, w_max = 0.f;
     int cnt = 0;
-    int last = -1;
-    for (int k = b; k < e; ++k) {
-        int cur = 0x7fffffff;
-        for (int u = b; u < e; ++u) { const int id = A.sorted_idx[u]; if (id > last && id < cur) cur = id; }
-        last = cur;
-        const float *q = vrec(A, cur);
-        const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(cur) * A.stride + A.intensity_off) : 0.f;
-        if (A.cov_off >= 0) {
-            const float *c = reinterpret_cast<const float *>(A.src + size_t(cur) * A.stride + A.cov_off);
-            const float tr = c[0] + c[3] + c[5];
-            if (fabsf(tr) >= A.trace_thr) continue;
-            const float w = A.trace_thr - tr;
-            mu[0] += w * q[0]; mu[1] += w * q[1]; mu[2] += w * q[2];
-            ity = w > w_max ? inten : ity;
-            w_max = w > w_max ? w : w_max;
-            const float w2 = w * w;
+    const bool has_cov = A.cov_off >= 0, has_i = A.intensity_off >= 0;
+    for (int k = b; k < e; k += VAG) {
+        int id[VAG];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) cov[j] += w2 * c[j];
-            weight_total += w;
-        } else {
-            mu[0] += q[0]; mu[1] += q[1]; mu[2] += q[2];
-            ity = inten;                       // the last member's intensity
-            ++cnt;
+        for (int u = 0; u < VAG; ++u) id[u] = A.members[min(k + u, e - 1)];
+        float q[VAG][3], inten[VAG], c[VAG][6];
+#pragma unroll
+        for (int u = 0; u < VAG; ++u) {
+            const unsigned char *rec = A.src + size_t(id[u]) * A.stride;
+            const float *f = reinterpret_cast<const float *>(rec);
+            q[u][0] = f[0]; q[u][1] = f[1]; q[u][2] = f[2];
+            inten[u] = has_i ? *reinterpret_cast<const float *>(rec + A.intensity_off) : 0.f;
+            if (has_cov) {
+                const float *cc = reinterpret_cast<const float *>(rec + A.cov_off);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) c[u][j] = cc[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < VAG; ++u) {
+            if (k + u >= e) break;
+            if (has_cov) {
+                const float tr = c[u][0] + c[u][3] + c[u][5];
+                if (fabsf(tr) >= A.trace_thr) continue;
+                const float w = A.trace_thr - tr;
+                mu[0] += w * q[u][0]; mu[1] += w * q[u][1]; mu[2] += w * q[u][2];
+                ity = w > w_max ? inten[u] : ity;
+                w_max = w > w_max ? w : w_max;
+                const float w2 = w * w;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) cov[j] += w2 * c[u][j];
+                weight_total += w;
+            } else {
+                mu[0] += q[u][0]; mu[1] += q[u][1]; mu[2] += q[u][2];
+                ity = inten[u];                       // the last member's intensity
+                ++cnt;
+            }
         }
     }
-    unsigned char *o = A.out + size_t(slot[p]) * A.stride;
+    unsigned char *o = A.out + size_t(s) * A.stride;
     for (int j = 0; j < A.stride / 4; ++j) reinterpret_cast<float *>(o)[j] = 0.f;
     float *ox = reinterpret_cast<float *>(o);
-    if (A.cov_off >= 0) {
+    if (has_cov) {
         if (weight_total == 0.f) weight_total = 1.0f;
         ox[0] = mu[0] / weight_total; ox[1] = mu[1] / weight_total; ox[2] = mu[2] / weight_total;
         const float wt2 = weight_total * weight_total;
@@ -185,32 +231,35 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A, const int
         ox[0] = mu[0] / fc; ox[1] = mu[1] / fc; ox[2] = mu[2] / fc;
     }
     if (A.stride >= 16 && A.intensity_off != 12 && A.cov_off != 12 && A.trace_off != 12) ox[3] = 1.0f;   // PCL_ADD_POINT4D padding
-    if (A.intensity_off >= 0) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
+    if (has_i) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
 }
 
-__global__ void vbounds_init_kernel(float *b)
+// getMinMax3D: per-workgroup partial bounds (6 floats each); the host, which needs them for the grid extents anyway, folds them
+constexpr int VB_BLOCKS = 128;
+__global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, int stride, int n, float *partial)
 {
-    if (threadIdx.x < 3) b[threadIdx.x] = FLT_MAX;
-    else if (threadIdx.x < 6) b[threadIdx.x] = -FLT_MAX;
-}
-__device__ __forceinline__ void atomic_minf(float *a, float v) { if (v >= 0.f) atomicMin(reinterpret_cast<int *>(a), __float_as_int(v)); else atomicMax(reinterpret_cast<unsigned *>(a), __float_as_uint(v)); }
-__device__ __forceinline__ void atomic_maxf(float *a, float v) { if (v >= 0.f) atomicMax(reinterpret_cast<int *>(a), __float_as_int(v)); else atomicMin(reinterpret_cast<unsigned *>(a), __float_as_uint(v)); }
-__global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, int stride, int n, float *b)
-{
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    __shared__ float lds[4][6];
+    float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float *p = reinterpret_cast<const float *>(src + size_t(i) * stride);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { mn[d] = fminf(mn[d], p[d]); mx[d] = fmaxf(mx[d], p[d]); }
+        for (int d = 0; d < 3; ++d) { m[d] = fminf(m[d], p[d]); m[3 + d] = fmaxf(m[3 + d], p[d]); }
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off)); }
+        for (int off = 32; off > 0; off >>= 1) { m[d] = fminf(m[d], __shfl_xor(m[d], off)); m[3 + d] = fmaxf(m[3 + d], __shfl_xor(m[3 + d], off)); }
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { atomic_minf(&b[d], mn[d]); atomic_maxf(&b[3 + d], mx[d]); }
+        for (int d = 0; d < 6; ++d) lds[threadIdx.x >> 6][d] = m[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float r = lds[0][d];
+        for (int w = 1; w < 4; ++w) r = d < 3 ? fminf(r, lds[w][d]) : fmaxf(r, lds[w][d]);
+        partial[blockIdx.x * 6 + d] = r;
     }
 }
 
@@ -228,12 +277,14 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         src = V.in.as<unsigned char>();
     }
     // bounds -> min_b / div_b (getMinMax3D + the floor arithmetic of applyFilter :84-116)
-    MLH_HIP(ctx, V.bounds.ensure(sizeof(float) * 8));
-    hipLaunchKernelGGL(vbounds_init_kernel, dim3(1), dim3(64), 0, st, V.bounds.as<float>());
-    hipLaunchKernelGGL(vbounds_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
-    float hb[6];
-    MLH_HIP(ctx, hipMemcpyAsync(hb, V.bounds.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    const int vb = std::min((n + 255) / 256, VB_BLOCKS);
+    MLH_HIP(ctx, V.bounds.ensure(sizeof(float) * 6 * VB_BLOCKS));
+    hipLaunchKernelGGL(vbounds_kernel, dim3(vb), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
+    float hp[6 * VB_BLOCKS], hb[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    MLH_HIP(ctx, hipMemcpyAsync(hp, V.bounds.p, sizeof(float) * 6 * size_t(vb), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
+    for (int b = 0; b < vb; ++b)
+        for (int d = 0; d < 3; ++d) { hb[d] = std::fmin(hb[d], hp[b * 6 + d]); hb[3 + d] = std::fmax(hb[3 + d], hp[b * 6 + 3 + d]); }
     const float inv = 1.0f / leaf;
     long long ext[3];
     int min_b[3], div_b[3];
@@ -254,29 +305,39 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         *n_out = n;
         return MLH_OK;
     }
+    // The dense voxel grid exists only as one occupancy BIT per voxel (ncell / 8 bytes): a point's output slot is the number of set
+    // bits below its voxel's (popcount prefix per 32-voxel word + popcount inside the word), and the counting sort that groups the
+    // members runs over the at most n occupied slots instead of the ncell cells.
     const long long ncell = (long long)div_b[0] * div_b[1] * div_b[2];
-    MLH_HIP(ctx, V.cell.ensure(sizeof(int) * size_t(ncell + 2)));
-    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n)));
+    const long long nwords = (ncell + 31) / 32 + 1;
+    MLH_HIP(ctx, V.cell.ensure(sizeof(unsigned) * size_t(nwords)));
+    MLH_HIP(ctx, V.wpre.ensure(sizeof(int) * size_t(nwords)));
+    MLH_HIP(ctx, V.cnt.ensure(sizeof(int) * size_t(n + 2)));
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 1)));
     MLH_HIP(ctx, V.sorted_idx.ensure(sizeof(int) * size_t(n)));
-    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n + 1)));
+    MLH_HIP(ctx, V.members.ensure(sizeof(int) * size_t(n)));
     MLH_HIP(ctx, V.out.ensure(size_t(n) * stride));
     MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));
+    const int nbw = int((nwords + VS_CHUNK - 1) / VS_CHUNK);
+    MLH_HIP(ctx, V.sums.ensure(sizeof(int) * size_t(std::max(nbw, (n + VS_CHUNK - 1) / VS_CHUNK) + 1)));
     VoxArgs A;
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.cov_off = cov_off; A.trace_off = trace_off;
     A.inv_leaf = inv; A.min_b[0] = min_b[0]; A.min_b[1] = min_b[1]; A.min_b[2] = min_b[2];
     A.mul1 = div_b[0]; A.mul2 = div_b[0] * div_b[1];
-    A.trace_thr = trace_thr; A.vox_of = V.vox_of.as<int>(); A.cell = V.cell.as<int>(); A.sorted_idx = V.sorted_idx.as<int>();
-    A.leader = V.leader.as<int>(); A.out = V.out.as<unsigned char>();
+    A.trace_thr = trace_thr; A.vox_of = V.vox_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
+    A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
     const int nbp = (n + 255) / 256;
-    MLH_HIP(ctx, hipMemsetAsync(V.cell.p, 0, sizeof(int) * size_t(ncell + 2), st));
-    hipLaunchKernelGGL(vox_count_kernel, dim3(nbp), dim3(256), 0, st, A);
-    int rc = device_exclusive_scan(ctx, A.cell + 1, ncell, V.sums, nullptr);   // cell[v+1] <- start[v]
+    MLH_HIP(ctx, hipMemsetAsync(V.cell.p, 0, sizeof(unsigned) * size_t(nwords), st));
+    hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(vscan_popc_local_kernel, dim3(nbw), dim3(256), 0, st, (const unsigned *)A.mask, V.wpre.as<int>(), nwords, V.sums.as<int>());
+    hipLaunchKernelGGL(vscan_sums_kernel, dim3(1), dim3(256), 0, st, V.sums.as<int>(), nbw, V.total.as<int>());    // total = occupied voxels
+    hipLaunchKernelGGL(vscan_add_kernel, dim3(nbw), dim3(256), 0, st, V.wpre.as<int>(), nwords, (const int *)V.sums.as<int>());
+    hipLaunchKernelGGL(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
+    int rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cell[v+1] <- start[v+1]
-    hipLaunchKernelGGL(vox_leader_kernel, dim3(nbp), dim3(256), 0, st, A);
-    rc = device_exclusive_scan(ctx, A.leader, n, V.sums, V.total.as<int>());   // leader flags -> output slots, total = occupied voxels
-    if (rc) return rc;
-    hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A, (const int *)A.leader, (const int *)V.total.as<int>());
+    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
+    hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
     MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -314,6 +314,23 @@ def cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov, cov
     return out[:cnt.value].copy()
 
 
+def transform_cloud_feature(points4, ext_pose, lidar_idx):
+    """transformCloudFeature (estimator/src/utility/visualization.cpp:39-51): pcl::transformPointCloud with the float 4x4 of the
+    extrinsic, then intensity <- LiDAR index. float32 throughout, row sums left to right, translation last."""
+    p = np.ascontiguousarray(points4, np.float32)
+    t = np.asarray(ext_pose[:3], np.float64)
+    x, y, z, w = [float(v) for v in ext_pose[3:7]]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]).astype(np.float32)
+    tf = t.astype(np.float32)
+    out = np.empty((len(p), 4), np.float32)
+    for r in range(3):
+        out[:, r] = ((R[r, 0] * p[:, 0] + R[r, 1] * p[:, 1]) + R[r, 2] * p[:, 2]) + tf[r]
+    out[:, 3] = np.float32(lidar_idx)
+    return out
+
+
 def track_params(distance_sq_threshold=25.0, nearby_scan=2.5, scan_period=0.1, huber_delta=0.1, max_outer=2, max_lm_iterations=4):
     return np.array([distance_sq_threshold, nearby_scan, scan_period, huber_delta, max_outer, max_lm_iterations], np.float64)
 

@@ -52,6 +52,13 @@ def test_extract_4000_column_rings(ctx, orc):
     _check_extract(ctx, orc, *_ring_scan(rng, [4000, 3990, 4000]))
 
 
+@pytest.mark.parametrize("lens", [[900, 850, 1000], [2049, 2500], [4500, 4400]])
+def test_extract_ring_lengths_across_sort_widths(ctx, orc, lens):
+    """the per-ring voxel sort holds 1, 2, 4 or 8 keys per thread (rings of up to 1024, 2048, 4096, 8192 less-flat points)"""
+    rng = np.random.default_rng(len(lens) + lens[0])
+    _check_extract(ctx, orc, *_ring_scan(rng, lens))
+
+
 def test_extract_rejects_bad_ring_tables(ctx, mla):
     rng = np.random.default_rng(2)
     pts, ss, se = _ring_scan(rng, [100, 100])

@@ -685,3 +685,55 @@ def test_front_end_stays_on_device(mla, orc, track_case):
         assert np.linalg.norm(pose_dev[:3] - track_case["motion"][:3]) < 0.08
     finally:
         c.close()
+
+
+def _device_to_host(ptr, n_bytes):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = np.empty(n_bytes, np.uint8)
+    rc = hip.hipMemcpy(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(n_bytes), 2)   # hipMemcpyDeviceToHost
+    assert rc == 0
+    return buf
+
+
+def test_mapper_inputs_stay_on_device(mla, orc, synth, case16):
+    """extractCloud -> transformCloudFeature -> downsampleCurrentScan -> scan2MapOptimization without a host hop (mlh_fuse_*):
+    the fused clouds are bit-equal to the float32 restatement of transformCloudFeature on the host-fetched extraction results,
+    and the mapper pose equals the one of the host-staged hand-over of the same clouds."""
+    scans = case16["scans"] * 2                       # the same scan through two extrinsics: two LiDARs' worth of features
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    meas = np.diag([0.0025] * 3)
+    c = mla.Context(0)
+    try:
+        c.map_set(mla.SURF, case16["surf_map"]); c.map_set(mla.CORNER, case16["corner_map"])
+        c.fuse_reset()
+        ref_surf, ref_corner = [], []
+        for i, s in enumerate(scans):
+            c.scan_upload(s.points, s.scan_start, s.scan_end); c.extract_run()
+            ex = c.extract_fetch(); lf = c.extract_voxel(0.2)
+            c.fuse_add_scan(i, ext[i])
+            ref_surf.append(orc.transform_cloud_feature(lf, ext[i], i))
+            ref_corner.append(orc.transform_cloud_feature(s.points[ex["less_sharp"]], ext[i], i))
+        ref = {mla.SURF: np.concatenate(ref_surf), mla.CORNER: np.concatenate(ref_corner)}
+        for kind in (mla.SURF, mla.CORNER):
+            dc = c.fused_cloud(kind)
+            assert dc.n == len(ref[kind]) > 100
+            got = _device_to_host(dc.ptr, dc.n * 16).view(np.float32).reshape(-1, 4)
+            np.testing.assert_array_equal(got, ref[kind])
+        opts = mla.default_opts(flags=mla.FLAG_WITH_UA)
+        # device-resident hand-over
+        m_dev = [c.downsample_current_scan(k, c.fused_cloud(k), leaf, ext, covs, meas, True, 0.6, fetch=False) for k, leaf in ((mla.SURF, 0.4), (mla.CORNER, 0.2))]
+        pose_dev, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+        # host hand-over of the same clouds
+        f_host = [c.downsample_current_scan(k, ref[k], leaf, ext, covs, meas, True, 0.6) for k, leaf in ((mla.SURF, 0.4), (mla.CORNER, 0.2))]
+        pose_host, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+        assert m_dev == [len(f) for f in f_host]
+        np.testing.assert_array_equal(pose_dev, pose_host)
+        # a second frame reuses the buffers from the start
+        c.fuse_reset()
+        assert c.fused_cloud(mla.SURF).n == 0
+    finally:
+        c.close()
