@@ -329,9 +329,13 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
  * less-flat points are appended to the fused SURF cloud, its less-sharp points to the fused CORNER cloud (float32: (r0 x + r1 y)
  * + r2 z + t per row, R rounded once from the double quaternion). mlh_fused_cloud hands out the device pointer (float4 records
  * {x,y,z,lidar}: stride 16, intensity offset 12) for mlh_downsample_current_scan(..., MLH_MEM_DEVICE); it stays valid until the
- * next mlh_fuse_add_scan. ext_pose = [t(3), q(xyzw)] of the LiDAR in the body frame. */
+ * next mlh_fuse_add_*. ext_pose = [t(3), q(xyzw)] of the LiDAR in the body frame. mlh_fuse_add_rings takes rings [ring_begin,
+ * ring_end) of the scan only: several LiDARs uploaded as ONE scan (their rings back to back, one launch set for all of them)
+ * are appended one ring range at a time, each with its own extrinsic. The appends never wait for the host: the record counts live
+ * on the device and mlh_fused_cloud fetches them once. */
 int mlh_fuse_reset(mlh_ctx *ctx);
 int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7]);
+int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);
 int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n);
 /* match*FromScan at `pose`: valid[m] and coeffs[m x 6] ('c': closest point, second point; 's': w, negative_OA_dot_norm, 0, 0); either may be NULL */
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs);

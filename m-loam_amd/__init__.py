@@ -102,6 +102,7 @@ def load_library():
     lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
     lib.mlh_fuse_reset.argtypes = [vp]
     lib.mlh_fuse_add_scan.argtypes = [vp, ci, vp]
+    lib.mlh_fuse_add_rings.argtypes = [vp, ci, ci, ci, vp]
     lib.mlh_fused_cloud.argtypes = [vp, ci, vp, vp]
     lib.mlh_track_match.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.mlh_track_cloud.argtypes = [vp, vp, vp, vp]
@@ -136,7 +137,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -317,6 +318,11 @@ class Context:
         """transformCloudFeature for the scan this context holds: append its mapping features, in the body frame, to the fused clouds."""
         e = np.ascontiguousarray(ext_pose, np.float64).reshape(7)
         self._ck(self.lib.mlh_fuse_add_scan(self.h, int(lidar_idx), _p(e)))
+
+    def fuse_add_rings(self, ring_begin, ring_end, lidar_idx, ext_pose):
+        """The same for rings [ring_begin, ring_end) of a scan that holds several LiDARs back to back."""
+        e = np.ascontiguousarray(ext_pose, np.float64).reshape(7)
+        self._ck(self.lib.mlh_fuse_add_rings(self.h, int(ring_begin), int(ring_end), int(lidar_idx), _p(e)))
 
     def fused_cloud(self, kind) -> "DeviceCloud":
         ptr, n = C.c_void_p(), C.c_int32(0)

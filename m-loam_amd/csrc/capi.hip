@@ -272,7 +272,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
-    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release();
+    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
@@ -976,65 +976,99 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
 
 // transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
 struct FuseXf { float r[9], t[3], id; };
-__global__ __launch_bounds__(256) void fuse_append_kernel(const float4 *__restrict__ pts, const int *__restrict__ list, int n, FuseXf xf, float4 *__restrict__ out)
+struct FuseArgs {
+    const float4 *pts, *vox_out;
+    const int *list1, *ring_offsets, *vox_off;
+    int rb, re;                // rings [rb, re) of the scan
+    FuseXf xf;
+    float4 *out[2];            // fused surf / corner clouds
+    int *cnt;                  // their record counts
+};
+__global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
 {
+    const int kind = blockIdx.y;                       // 0: surf <- voxel-thinned less-flat, 1: corner <- less-sharp
+    const int b = kind == 0 ? A.vox_off[A.rb] : A.ring_offsets[A.rb * 4 + 1];
+    const int e = kind == 0 ? A.vox_off[A.re] : A.ring_offsets[A.re * 4 + 1];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[list ? list[i] : i];
+    if (i >= e - b) return;
+    const float4 p = kind == 0 ? A.vox_out[b + i] : A.pts[A.list1[b + i]];
+    const FuseXf &xf = A.xf;
     float4 o;
     // products and sums kept separate (no contraction) so that the result is one well-defined float32 expression
     o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], p.x), __fmul_rn(xf.r[1], p.y)), __fmul_rn(xf.r[2], p.z)), xf.t[0]);
     o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], p.x), __fmul_rn(xf.r[4], p.y)), __fmul_rn(xf.r[5], p.z)), xf.t[1]);
     o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], p.x), __fmul_rn(xf.r[7], p.y)), __fmul_rn(xf.r[8], p.z)), xf.t[2]);
     o.w = xf.id;
-    out[i] = o;
+    A.out[kind][A.cnt[kind] + i] = o;
+}
+// after the append (stream order): the counts move on
+__global__ void fuse_bump_kernel(const int *__restrict__ ring_offsets, const int *__restrict__ vox_off, int rb, int re, int *__restrict__ cnt)
+{
+    if (threadIdx.x == 0) cnt[0] += vox_off[re] - vox_off[rb];
+    if (threadIdx.x == 1) cnt[1] += ring_offsets[re * 4 + 1] - ring_offsets[rb * 4 + 1];
 }
 
 int mlh_fuse_reset(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MLH_HIP(ctx, ctx->fused_cnt.ensure(sizeof(int) * 2));
+    MLH_HIP(ctx, hipMemsetAsync(ctx->fused_cnt.p, 0, sizeof(int) * 2, ctx->stream));
     ctx->fused_n[0] = ctx->fused_n[1] = 0;
+    ctx->fused_bound[0] = ctx->fused_bound[1] = 0;
+    ctx->fused_dirty = false;
     return MLH_OK;
 }
 
-int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7])
+int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7])
 {
     if (!ctx || !ext_pose || lidar_idx < 0) return MLH_ERR_INVALID;
     ScanBuf &sb = ctx->scan;
     if (!sb.extracted || !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "mlh_extract_run and mlh_extract_voxel_run come first");
+    if (ring_begin < 0 || ring_end > sb.n_rings || ring_begin >= ring_end) return fail(ctx, MLH_ERR_INVALID, "bad ring range");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    int totals[4] = {0, 0, 0, 0}, n_vox = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(totals, sb.totals.p, sizeof(totals), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipMemcpyAsync(&n_vox, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    if (!ctx->fused_cnt.p) { int rc = mlh_fuse_reset(ctx); if (rc) return rc; }
     // rotation of the unit quaternion in double, rounded once to float: what Eigen::Matrix4f holds after `.cast<float>()`
     const double tx = ext_pose[0], ty = ext_pose[1], tz = ext_pose[2], qx = ext_pose[3], qy = ext_pose[4], qz = ext_pose[5], qw = ext_pose[6];
     const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
                          2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
                          2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
-    FuseXf xf;
-    for (int i = 0; i < 9; ++i) xf.r[i] = float(R[i]);
-    xf.t[0] = float(tx); xf.t[1] = float(ty); xf.t[2] = float(tz);
-    xf.id = float(lidar_idx);
-    const int add[2] = {n_vox, totals[1]};                         // surf <- thinned less-flat, corner <- less-sharp
-    const void *src[2] = {sb.vox_out.p, sb.pts.p};
-    const int *lst[2] = {nullptr, sb.lists[1].as<int>()};
+    FuseArgs A;
+    for (int i = 0; i < 9; ++i) A.xf.r[i] = float(R[i]);
+    A.xf.t[0] = float(tx); A.xf.t[1] = float(ty); A.xf.t[2] = float(tz);
+    A.xf.id = float(lidar_idx);
+    // the counts live on the device (no host round trip per scan); capacity follows a host-side upper bound: the scan's point count
     for (int k = 0; k < 2; ++k) {
-        if (add[k] <= 0) continue;
-        const size_t have = size_t(ctx->fused_n[k]);
-        MLH_HIP(ctx, ctx->fused[k].grow(sizeof(float4) * (have + size_t(add[k])), sizeof(float4) * have, st));
-        hipLaunchKernelGGL(fuse_append_kernel, dim3((add[k] + 255) / 256), dim3(256), 0, st, (const float4 *)src[k], lst[k], add[k], xf,
-                           ctx->fused[k].as<float4>() + have);
-        ctx->fused_n[k] += add[k];
+        MLH_HIP(ctx, ctx->fused[k].grow(sizeof(float4) * (ctx->fused_bound[k] + size_t(sb.n)), sizeof(float4) * ctx->fused_bound[k], st));
+        ctx->fused_bound[k] += size_t(sb.n);
+        A.out[k] = ctx->fused[k].as<float4>();
     }
+    A.pts = sb.pts.as<float4>(); A.vox_out = sb.vox_out.as<float4>(); A.list1 = sb.lists[1].as<int>();
+    A.ring_offsets = sb.ring_offsets.as<int>(); A.vox_off = sb.ring_vox.as<int>() + sb.n_rings;
+    A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>();
+    hipLaunchKernelGGL(fuse_append_kernel, dim3((sb.n + 255) / 256, 2), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(fuse_bump_kernel, dim3(1), dim3(64), 0, st, A.ring_offsets, A.vox_off, ring_begin, ring_end, A.cnt);
     MLH_HIP(ctx, hipGetLastError());
+    ctx->fused_dirty = true;
     return MLH_OK;
+}
+
+int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7])
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    return mlh_fuse_add_rings(ctx, 0, ctx->scan.n_rings, lidar_idx, ext_pose);
 }
 
 int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n)
 {
     if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
+    if (ctx->fused_dirty) {
+        MLH_HIP(ctx, hipSetDevice(ctx->device));
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->fused_n, ctx->fused_cnt.p, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fused_dirty = false;
+    }
     *device_points = ctx->fused[kind].p;
     *n = ctx->fused_n[kind];
     return MLH_OK;

@@ -210,7 +210,10 @@ struct mlh_ctx {
     mlh::OdomSet odom;
     mlh::TrackSet track;
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
-    int fused_n[2] = {0, 0};
+    int fused_n[2] = {0, 0};   // valid when !fused_dirty
+    mlh::DevBuf fused_cnt;   // the two record counts, device side (appends never wait for the host)
+    size_t fused_bound[2] = {0, 0};   // host-side upper bounds of the counts (capacity)
+    bool fused_dirty = false;
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;

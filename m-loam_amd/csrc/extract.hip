@@ -291,18 +291,25 @@ extern "C" int mlh_debug_stage_clock_label(unsigned long long *out, int n_words)
 namespace mlh {
 #endif
 
-// exclusive scan over rings of the 4 list sizes; single workgroup
+// exclusive scan over rings of the 4 list sizes; single workgroup. ring_offsets has n_rings + 1 rows: the last one = the totals.
+// The counts are staged in LDS by the whole workgroup so that the four serial scans do not wait on one memory round trip per ring.
 __global__ __launch_bounds__(256) void offsets_kernel(const int *__restrict__ ring_counts, int n_rings, int *__restrict__ ring_offsets,
                                                       int *__restrict__ totals)
 {
-    if (threadIdx.x < 4) {
-        int acc = 0;
-        for (int r = 0; r < n_rings; ++r) {
-            ring_offsets[r * 4 + threadIdx.x] = acc;
-            acc += ring_counts[r * 4 + threadIdx.x];
+    __shared__ int s_c[256 * 4];
+    int carry = 0;                                   // threads 0..3: running total of list threadIdx.x
+    for (int r0 = 0; r0 < n_rings; r0 += 256) {
+        const int rows = min(256, n_rings - r0);
+        for (int t = threadIdx.x; t < rows * 4; t += 256) s_c[t] = ring_counts[r0 * 4 + t];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            for (int r = 0; r < rows; ++r) { const int c = s_c[r * 4 + threadIdx.x]; s_c[r * 4 + threadIdx.x] = carry; carry += c; }
         }
-        totals[threadIdx.x] = acc;
+        __syncthreads();
+        for (int t = threadIdx.x; t < rows * 4; t += 256) ring_offsets[r0 * 4 + t] = s_c[t];
+        __syncthreads();
     }
+    if (threadIdx.x < 4) { totals[threadIdx.x] = carry; ring_offsets[n_rings * 4 + threadIdx.x] = carry; }
 }
 
 struct EmitArgs {
@@ -353,7 +360,7 @@ int extract_run(mlh_ctx *ctx)
     MLH_HIP(ctx, sb.picked.ensure(sizeof(int) * size_t(n)));
     MLH_HIP(ctx, sb.stage.ensure(sizeof(int) * STAGE_STRIDE * size_t(R)));
     MLH_HIP(ctx, sb.ring_counts.ensure(sizeof(int) * 4 * size_t(R)));
-    MLH_HIP(ctx, sb.ring_offsets.ensure(sizeof(int) * 4 * size_t(R)));
+    MLH_HIP(ctx, sb.ring_offsets.ensure(sizeof(int) * 4 * size_t(R + 1)));
     MLH_HIP(ctx, sb.totals.ensure(sizeof(int) * 4));
     MLH_HIP(ctx, sb.lists[0].ensure(sizeof(int) * STAGE_SHARP * size_t(R)));
     MLH_HIP(ctx, sb.lists[1].ensure(sizeof(int) * STAGE_LESS * size_t(R)));

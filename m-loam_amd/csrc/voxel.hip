@@ -151,9 +151,9 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
 }
 
 // concatenation of the rings' centroids (ring asc): every workgroup sums the counts of the rings before its own (a few dozen
-// words), the last one also publishes the total
+// words) and notes it in vox_off (ring_vox + n_rings; entry n_rings = the total)
 __global__ __launch_bounds__(256) void ring_vox_compact_kernel(const float4 *__restrict__ stage, const int *__restrict__ ring_offsets,
-                                                               const int *__restrict__ ring_vox, int n_rings, int *__restrict__ total,
+                                                               const int *__restrict__ ring_vox, int n_rings, int *__restrict__ vox_off /* n_rings + 1 */,
                                                                float4 *__restrict__ out)
 {
     __shared__ int s_dst;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void ring_vox_compact_kernel(const float4 *__r
     }
     __syncthreads();
     const int n = ring_vox[ring], src = ring_offsets[ring * 4 + 3], dst = s_dst;
-    if (threadIdx.x == 0 && ring == n_rings - 1) *total = dst + n;
+    if (threadIdx.x == 0) { vox_off[ring] = dst; if (ring == n_rings - 1) vox_off[n_rings] = dst + n; }
     for (int t = threadIdx.x; t < n; t += 256) out[dst + t] = stage[src + t];
 }
 
@@ -202,7 +202,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     else if (longest <= RV_TPB * 8) MLH_HIP(ctx, (ring_voxel_launch<8, false>(A, R, st)));
     else return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
     hipLaunchKernelGGL(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, (const float4 *)sb.vox_stage.as<float4>(), (const int *)sb.ring_offsets.as<int>(),
-                       (const int *)sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + 2 * R, sb.vox_out.as<float4>());
+                       (const int *)sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + R, sb.vox_out.as<float4>());
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
     sb.voxelised = true;

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(VoxArgs A)
     const int ijk2 = int(floorf(p[2] * A.inv_leaf) - float(A.min_b[2]));
     const int v = ijk0 + ijk1 * A.mul1 + ijk2 * A.mul2;
     A.vox_of[i] = v;
-    atomicOr(&A.mask[v >> 5], 1u << (v & 31));
+    // consecutive points of a scan line mostly share their voxel: one atomic per run of equal voxels inside the wavefront
+    const int prev = __shfl_up(v, 1);
+    if ((threadIdx.x & 63) == 0 || prev != v) atomicOr(&A.mask[v >> 5], 1u << (v & 31));
     A.cnt[i] = 0;
     if (i == 0) { A.cnt[A.n] = 0; A.cnt[A.n + 1] = 0; }
 }

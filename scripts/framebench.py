@@ -67,10 +67,37 @@ def gpu_frame_dev(t):
     for k, v in zip(("upload+extract+fuse", "downsample", "scan2map"), (t1 - t0, t3 - t1, t4 - t3)): t[k] = t.get(k, 0.0) + v
     return pose
 
+# both LiDARs as ONE scan (rings back to back): one launch set extracts them together
+both_pts = np.concatenate([s.points for s in scans])
+offs = np.cumsum([0] + [len(s.points) for s in scans])
+both_start = np.concatenate([s.scan_start + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
+both_end = np.concatenate([s.scan_end + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
+ring_ofs = np.cumsum([0] + [s.n_rings for s in scans])
+
+def gpu_frame_dev1(t):
+    t0 = time.perf_counter()
+    ctx.fuse_reset()
+    ctx.scan_upload(both_pts, both_start, both_end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
+    for i in range(len(scans)): ctx.fuse_add_rings(ring_ofs[i], ring_ofs[i + 1], i, ext[i])
+    t1 = time.perf_counter()
+    ctx.downsample_current_scan(mla.SURF, ctx.fused_cloud(mla.SURF), 0.4, ext, covs, meas, True, 0.6, fetch=False)
+    ctx.downsample_current_scan(mla.CORNER, ctx.fused_cloud(mla.CORNER), 0.2, ext, covs, meas, True, 0.6, fetch=False)
+    t3 = time.perf_counter()
+    ctx.map_rebuild(mla.ALL_KINDS)
+    pose, _ = ctx.scan2map(p0, opts, want_stats=False)
+    t4 = time.perf_counter()
+    for k, v in zip(("upload+extract+fuse", "downsample", "scan2map"), (t1 - t0, t3 - t1, t4 - t3)): t[k] = t.get(k, 0.0) + v
+    return pose
+
 for _ in range(3): gpu_frame_dev({})
 td = {}
 for _ in range(20): pose_dev = gpu_frame_dev(td)
 print("GPU path, device-resident hand-overs, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td.items()}, "total %.3f" % (1e3 * sum(td.values()) / 20))
+for _ in range(3): gpu_frame_dev1({})
+td1 = {}
+for _ in range(20): pose_dev1 = gpu_frame_dev1(td1)
+print("GPU path, device-resident, both LiDARs one launch set, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td1.items()}, "total %.3f" % (1e3 * sum(td1.values()) / 20),
+      "same pose as per-LiDAR launches:", bool(np.array_equal(pose_dev1, pose_dev)))
 if os.environ.get('FRAMEBENCH_DEV_ONLY'): sys.exit(0)
 for _ in range(3): gpu_frame({})
 tg = {}; n = 20

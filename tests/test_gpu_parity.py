@@ -737,3 +737,38 @@ def test_mapper_inputs_stay_on_device(mla, orc, synth, case16):
         assert c.fused_cloud(mla.SURF).n == 0
     finally:
         c.close()
+
+
+def test_fuse_ring_ranges_of_a_joint_scan(mla, orc, synth, case16):
+    """Two LiDARs uploaded as ONE scan (rings back to back) and fused one ring range at a time (mlh_fuse_add_rings) give exactly the
+    fused clouds of two separate scans: extraction is per ring, and the ranges cut the joint lists where the scans end."""
+    s = case16["scans"][0]
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    both = np.concatenate([s.points, s.points[::-1] * np.float32(1.0)])       # second LiDAR: the same rings traversed backwards
+    n1 = len(s.points)
+    # ring tables of the reversed copy: ring r of the original occupies [start-5, end+6) -> mirrored
+    rs, re_ = s.scan_start - 5, s.scan_end + 6
+    start2 = (n1 - re_)[::-1] + 5 + n1
+    end2 = (n1 - rs)[::-1] - 6 + n1
+    c = mla.Context(0)
+    try:
+        c.fuse_reset()
+        c.scan_upload(s.points, s.scan_start, s.scan_end); c.extract_run(); c.extract_voxel_run(0.2); c.fuse_add_scan(0, ext[0])
+        c.scan_upload(np.ascontiguousarray(both[n1:]), (start2 - n1).astype(np.int32), (end2 - n1).astype(np.int32)); c.extract_run(); c.extract_voxel_run(0.2)
+        c.fuse_add_scan(1, ext[1])
+        sep = {k: _device_to_host(c.fused_cloud(k).ptr, c.fused_cloud(k).n * 16).view(np.float32).reshape(-1, 4).copy() for k in (mla.SURF, mla.CORNER)}
+        c.fuse_reset()
+        c.scan_upload(both, np.concatenate([s.scan_start, start2]).astype(np.int32), np.concatenate([s.scan_end, end2]).astype(np.int32))
+        c.extract_run(); c.extract_voxel_run(0.2)
+        c.fuse_add_rings(0, s.n_rings, 0, ext[0]); c.fuse_add_rings(s.n_rings, 2 * s.n_rings, 1, ext[1])
+        for k in (mla.SURF, mla.CORNER):
+            dc = c.fused_cloud(k)
+            joint = _device_to_host(dc.ptr, dc.n * 16).view(np.float32).reshape(-1, 4)
+            assert len(sep[k]) > 100 and set(np.unique(sep[k][:, 3])) == {0.0, 1.0}
+            np.testing.assert_array_equal(joint, sep[k])
+        with pytest.raises(mla.MlhError):
+            c.fuse_add_rings(3, 3, 0, ext[0])
+    finally:
+        c.close()
