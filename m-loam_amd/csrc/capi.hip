@@ -272,7 +272,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
-    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release();
+    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release(); ctx->fused_part.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
@@ -610,8 +610,12 @@ int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int 
         d_out = ctx->tmp.as<float>();
     }
     int m = 0;
+    // a fused cloud of this context brings its exact bounding box along (mlh_fused_cloud): no bounds pass
+    const float *known_bounds = nullptr;
+    for (int k = 0; k < 2; ++k)
+        if (mem == MLH_MEM_DEVICE && !ctx->fused_dirty && n > 0 && points == ctx->fused[k].p && n == ctx->fused_n[k] && stride_bytes == 16) known_bounds = ctx->fused_minmax[k];
     int rc = downsample_current_scan_run(ctx, points, stride_bytes, n, intensity_offset_bytes, mem, leaf, ext_poses, ext_covs, n_lidar, cov_measurement,
-                                         with_ua, trace_threshold, f.pts, f.covd, d_out, &m);
+                                         with_ua, trace_threshold, f.pts, f.covd, d_out, &m, known_bounds);
     if (rc) return rc;
     if (features_out && m > 0) {
         MLH_HIP(ctx, hipMemcpyAsync(features_out, d_out, sizeof(float) * 11 * size_t(m), hipMemcpyDeviceToHost, ctx->stream));
@@ -983,23 +987,46 @@ struct FuseArgs {
     FuseXf xf;
     float4 *out[2];            // fused surf / corner clouds
     int *cnt;                  // their record counts
+    float *part;               // this append's partial bounds: [kind][FUSE_BLOCKS][6]
 };
+constexpr int FUSE_BLOCKS = 64;    // workgroups per kind: each leaves one partial bounding box of what it appended
 __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
 {
+    __shared__ float lds[4][6];
     const int kind = blockIdx.y;                       // 0: surf <- voxel-thinned less-flat, 1: corner <- less-sharp
     const int b = kind == 0 ? A.vox_off[A.rb] : A.ring_offsets[A.rb * 4 + 1];
     const int e = kind == 0 ? A.vox_off[A.re] : A.ring_offsets[A.re * 4 + 1];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= e - b) return;
-    const float4 p = kind == 0 ? A.vox_out[b + i] : A.pts[A.list1[b + i]];
+    const int base = A.cnt[kind];
     const FuseXf &xf = A.xf;
-    float4 o;
-    // products and sums kept separate (no contraction) so that the result is one well-defined float32 expression
-    o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], p.x), __fmul_rn(xf.r[1], p.y)), __fmul_rn(xf.r[2], p.z)), xf.t[0]);
-    o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], p.x), __fmul_rn(xf.r[4], p.y)), __fmul_rn(xf.r[5], p.z)), xf.t[1]);
-    o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], p.x), __fmul_rn(xf.r[7], p.y)), __fmul_rn(xf.r[8], p.z)), xf.t[2]);
-    o.w = xf.id;
-    A.out[kind][A.cnt[kind] + i] = o;
+    float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < e - b; i += FUSE_BLOCKS * 256) {
+        const float4 p = kind == 0 ? A.vox_out[b + i] : A.pts[A.list1[b + i]];
+        float4 o;
+        // products and sums kept separate (no contraction) so that the result is one well-defined float32 expression
+        o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], p.x), __fmul_rn(xf.r[1], p.y)), __fmul_rn(xf.r[2], p.z)), xf.t[0]);
+        o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], p.x), __fmul_rn(xf.r[4], p.y)), __fmul_rn(xf.r[5], p.z)), xf.t[1]);
+        o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], p.x), __fmul_rn(xf.r[7], p.y)), __fmul_rn(xf.r[8], p.z)), xf.t[2]);
+        o.w = xf.id;
+        A.out[kind][base + i] = o;
+        m[0] = fminf(m[0], o.x); m[1] = fminf(m[1], o.y); m[2] = fminf(m[2], o.z);
+        m[3] = fmaxf(m[3], o.x); m[4] = fmaxf(m[4], o.y); m[5] = fmaxf(m[5], o.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { m[d] = fminf(m[d], __shfl_xor(m[d], off)); m[3 + d] = fmaxf(m[3 + d], __shfl_xor(m[3 + d], off)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 6; ++d) lds[threadIdx.x >> 6][d] = m[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float r = lds[0][d];
+        for (int w = 1; w < 4; ++w) r = d < 3 ? fminf(r, lds[w][d]) : fmaxf(r, lds[w][d]);
+        A.part[(kind * FUSE_BLOCKS + blockIdx.x) * 6 + d] = r;
+    }
 }
 // after the append (stream order): the counts move on
 __global__ void fuse_bump_kernel(const int *__restrict__ ring_offsets, const int *__restrict__ vox_off, int rb, int re, int *__restrict__ cnt)
@@ -1016,6 +1043,8 @@ int mlh_fuse_reset(mlh_ctx *ctx)
     MLH_HIP(ctx, hipMemsetAsync(ctx->fused_cnt.p, 0, sizeof(int) * 2, ctx->stream));
     ctx->fused_n[0] = ctx->fused_n[1] = 0;
     ctx->fused_bound[0] = ctx->fused_bound[1] = 0;
+    ctx->fused_parts = 0;
+    for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
     ctx->fused_dirty = false;
     return MLH_OK;
 }
@@ -1047,7 +1076,11 @@ int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     A.pts = sb.pts.as<float4>(); A.vox_out = sb.vox_out.as<float4>(); A.list1 = sb.lists[1].as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.vox_off = sb.ring_vox.as<int>() + sb.n_rings;
     A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>();
-    hipLaunchKernelGGL(fuse_append_kernel, dim3((sb.n + 255) / 256, 2), dim3(256), 0, st, A);
+    const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
+    MLH_HIP(ctx, ctx->fused_part.grow(sizeof(float) * part_floats * size_t(ctx->fused_parts + 1), sizeof(float) * part_floats * size_t(ctx->fused_parts), st));
+    A.part = ctx->fused_part.as<float>() + part_floats * size_t(ctx->fused_parts);
+    ++ctx->fused_parts;
+    hipLaunchKernelGGL(fuse_append_kernel, dim3(FUSE_BLOCKS, 2), dim3(256), 0, st, A);
     hipLaunchKernelGGL(fuse_bump_kernel, dim3(1), dim3(64), 0, st, A.ring_offsets, A.vox_off, ring_begin, ring_end, A.cnt);
     MLH_HIP(ctx, hipGetLastError());
     ctx->fused_dirty = true;
@@ -1065,8 +1098,18 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
     if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
     if (ctx->fused_dirty) {
         MLH_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
+        std::vector<float> hp(part_floats * size_t(ctx->fused_parts));
         MLH_HIP(ctx, hipMemcpyAsync(ctx->fused_n, ctx->fused_cnt.p, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->fused_part.p, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
+        for (int a = 0; a < ctx->fused_parts; ++a)
+            for (int k = 0; k < 2; ++k)
+                for (int b = 0; b < FUSE_BLOCKS; ++b) {
+                    const float *q = hp.data() + (size_t(a) * 2 * FUSE_BLOCKS + size_t(k) * FUSE_BLOCKS + b) * 6;
+                    for (int d = 0; d < 3; ++d) { ctx->fused_minmax[k][d] = std::fmin(ctx->fused_minmax[k][d], q[d]); ctx->fused_minmax[k][3 + d] = std::fmax(ctx->fused_minmax[k][3 + d], q[3 + d]); }
+                }
         ctx->fused_dirty = false;
     }
     *device_points = ctx->fused[kind].p;

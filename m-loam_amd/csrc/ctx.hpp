@@ -214,6 +214,9 @@ struct mlh_ctx {
     mlh::DevBuf fused_cnt;   // the two record counts, device side (appends never wait for the host)
     size_t fused_bound[2] = {0, 0};   // host-side upper bounds of the counts (capacity)
     bool fused_dirty = false;
+    mlh::DevBuf fused_part;  // per-append, per-kind, per-workgroup partial bounds of the appended points
+    int fused_parts = 0;
+    float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
@@ -261,12 +264,12 @@ int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sum
 void compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pc[7], double cc[36]);
 int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, float leaf, const double *ext_poses,
                                 const double *ext_covs, int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, mlh::DevBuf &pts_out,
-                                mlh::DevBuf &covd_out, float *out11_dev, int *n_out);
+                                mlh::DevBuf &covd_out, float *out11_dev, int *n_out, const float *known_bounds = nullptr);
 int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off,
                             const double pose_global[7], const double cov_global[36], const double *ext_poses, const double *ext_covs,
                             int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, void *out, int *n_out, int mem);
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
-                     float trace_thr, void *out_host, int *n_out, int mem);
+                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds = nullptr, bool sync_total = true);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);

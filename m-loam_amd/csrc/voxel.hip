@@ -227,12 +227,14 @@ struct UctArgs {
     unsigned char *rec_out;     // n staged records (input layout), or null
     double gpose[7];
     int cov_off, trace_off, with_ua;
+    const int *n_dev = nullptr;  // optional device-side record count (<= n): the launch covers n, records past *n_dev are dropped
 };
 
 __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
+    if (A.n_dev && i >= *A.n_dev) { A.keep[i] = 0; return; }
     const float *rec = reinterpret_cast<const float *>(A.src + size_t(i) * A.stride);
     const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(i) * A.stride + A.intensity_off) : 0.f;
     int idx = int(inten);
@@ -440,7 +442,7 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.ext = d_c; A.ext_cov = nullptr; A.n_lidar = n_lidar;
     for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
     A.trace_thr = trace_thr; A.cov6 = nullptr; A.keep = V.leader.as<int>();
-    A.upose = d_c + size_t(n_lidar) * 7; A.upose_cov = d_c + size_t(n_lidar) * 14; A.rec_out = V.out.as<unsigned char>();
+    A.upose = d_c + size_t(n_lidar) * 7; A.upose_cov = d_c + size_t(n_lidar) * 14; A.rec_out = V.out.as<unsigned char>(); A.n_dev = nullptr;
     for (int i = 0; i < 7; ++i) A.gpose[i] = pose_global[i];
     A.cov_off = cov_off; A.trace_off = trace_off; A.with_ua = with_ua ? 1 : 0;
     const int nb = (n + 255) / 256;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void features_from_kept_kernel(const unsigned 
 // out11_dev: optional device buffer (n x 11 floats) that receives the kept PointXYZIWithCov records [x y z i cov6 trace].
 int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, float leaf, const double *ext_poses,
                                 const double *ext_covs, int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, DevBuf &pts_out,
-                                DevBuf &covd_out, float *out11_dev, int *n_out)
+                                DevBuf &covd_out, float *out11_dev, int *n_out, const float *known_bounds)
 {
     if (n_lidar <= 0 || n_lidar > 16 || !ext_poses || (with_ua && (!ext_covs || !cov_meas))) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
     hipStream_t st = ctx->stream;
@@ -508,31 +510,32 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
     std::vector<double> zero(size_t(n_lidar) * 36, 0.0);
     MLH_HIP(ctx, hipMemcpyAsync(d_ext, ext_poses, sizeof(double) * 7 * n_lidar, hipMemcpyHostToDevice, st));
     MLH_HIP(ctx, hipMemcpyAsync(d_cov, ext_covs ? ext_covs : zero.data(), sizeof(double) * 36 * n_lidar, hipMemcpyHostToDevice, st));
+    // the thinned records stay in V.out and their count on the device (V.total): everything downstream is launched over the
+    // upper bound n and guarded by that count, so the only host round trip left after the bounds is the final feature count
     int n_ds = 0;
-    int rc = voxel_filter_run(ctx, points, stride, n, intensity_off, -1, -1, leaf, 0.f, nullptr, &n_ds, mem);   // result in V.out
+    int rc = voxel_filter_run(ctx, points, stride, n, intensity_off, -1, -1, leaf, 0.f, nullptr, &n_ds, mem, known_bounds, false);
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     *n_out = 0;
-    if (n_ds <= 0) return MLH_OK;
-    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n_ds + 1)));
-    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n_ds + 1)));
-    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));
+    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n + 1)));
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 1)));
     UctArgs A;
-    A.src = V.out.as<unsigned char>(); A.stride = stride; A.n = n_ds; A.intensity_off = intensity_off; A.ext = d_ext; A.ext_cov = d_cov; A.n_lidar = n_lidar;
+    A.src = V.out.as<unsigned char>(); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.ext = d_ext; A.ext_cov = d_cov; A.n_lidar = n_lidar;
     for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
     A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = V.leader.as<int>();
     A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = with_ua ? 1 : 0;
+    A.n_dev = V.total.as<int>();
     for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
-    const int nb = (n_ds + 255) / 256;
+    const int nb = (n + 255) / 256;
     hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
-    MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n_ds), hipMemcpyDeviceToDevice, st));
-    if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n_ds, V.sums, V.total.as<int>()))) return rc;
-    MLH_HIP(ctx, pts_out.ensure(sizeof(float4) * size_t(n_ds)));
-    MLH_HIP(ctx, covd_out.ensure(sizeof(float4) * size_t(n_ds)));
-    hipLaunchKernelGGL(features_from_kept_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n_ds,
+    MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n), hipMemcpyDeviceToDevice, st));
+    if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>() + 1))) { (void)hipStreamSynchronize(st); return rc; }
+    MLH_HIP(ctx, pts_out.ensure(sizeof(float4) * size_t(n)));
+    MLH_HIP(ctx, covd_out.ensure(sizeof(float4) * size_t(n)));
+    hipLaunchKernelGGL(features_from_kept_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
                        (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(), (const float *)d_c6, pts_out.as<float4>(), covd_out.as<float4>(), out11_dev);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
     *n_out = total;
     return MLH_OK;

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, 
     }
 }
 
+// known_bounds: the exact min/max of the points if the caller already has them (skips the bounds pass and its round trip).
+// sync_total = false (only with out_host == nullptr): the record count stays on the device (V.total[0]); *n_out is left at -1.
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
-                     float trace_thr, void *out_host, int *n_out, int mem)
+                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds, bool sync_total)
 {
     if (!points || n <= 0 || stride < 12 || (stride & 3) || !(leaf > 0.f) || !n_out) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
     // out_host == nullptr: the thinned records stay in ctx->vox.out (device) for the caller's next kernel
@@ -279,14 +281,21 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         src = V.in.as<unsigned char>();
     }
     // bounds -> min_b / div_b (getMinMax3D + the floor arithmetic of applyFilter :84-116)
-    const int vb = std::min((n + 255) / 256, VB_BLOCKS);
-    MLH_HIP(ctx, V.bounds.ensure(sizeof(float) * 6 * VB_BLOCKS));
-    hipLaunchKernelGGL(vbounds_kernel, dim3(vb), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
-    float hp[6 * VB_BLOCKS], hb[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    MLH_HIP(ctx, hipMemcpyAsync(hp, V.bounds.p, sizeof(float) * 6 * size_t(vb), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
-    for (int b = 0; b < vb; ++b)
-        for (int d = 0; d < 3; ++d) { hb[d] = std::fmin(hb[d], hp[b * 6 + d]); hb[3 + d] = std::fmax(hb[3 + d], hp[b * 6 + 3 + d]); }
+    float hb[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (known_bounds) {
+        for (int d = 0; d < 6; ++d) hb[d] = known_bounds[d];
+    } else {
+        const int vb = std::min((n + 255) / 256, VB_BLOCKS);
+        MLH_HIP(ctx, V.bounds.ensure(sizeof(float) * 6 * VB_BLOCKS));
+        hipLaunchKernelGGL(vbounds_kernel, dim3(vb), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
+        float hp[6 * VB_BLOCKS];
+        MLH_HIP(ctx, hipMemcpyAsync(hp, V.bounds.p, sizeof(float) * 6 * size_t(vb), hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        for (int b = 0; b < vb; ++b)
+            for (int d = 0; d < 3; ++d) { hb[d] = std::fmin(hb[d], hp[b * 6 + d]); hb[3 + d] = std::fmax(hb[3 + d], hp[b * 6 + 3 + d]); }
+    }
+    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 2));
+    if (!sync_total && out_host) return fail(ctx, MLH_ERR_INVALID, "sync_total = false needs the device-resident result");
     const float inv = 1.0f / leaf;
     long long ext[3];
     int min_b[3], div_b[3];
@@ -301,7 +310,11 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
                           ext[0] * ext[1] * ext[2] > 2147483647ll;
     if (too_many) {
         // "Leaf size is too small for the input dataset": the reference returns the input cloud unchanged
-        if (!out_host) { MLH_HIP(ctx, V.out.ensure(size_t(n) * stride)); MLH_HIP(ctx, hipMemcpyAsync(V.out.p, src, size_t(n) * stride, hipMemcpyDeviceToDevice, st)); }
+        if (!out_host) {
+            MLH_HIP(ctx, V.out.ensure(size_t(n) * stride));
+            MLH_HIP(ctx, hipMemcpyAsync(V.out.p, src, size_t(n) * stride, hipMemcpyDeviceToDevice, st));
+            MLH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(V.total.p), n, 1, st));
+        }
         else MLH_HIP(ctx, hipMemcpyAsync(out_host, src, size_t(n) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
         *n_out = n;
@@ -341,6 +354,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
     hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
+    if (!sync_total) { *n_out = -1; return MLH_OK; }
     int total = 0;
     MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
