@@ -154,7 +154,7 @@ struct ScanBuf {
 };
 
 struct VoxBuf {   // scratch of mlh_voxel_filter
-    DevBuf in, bounds, cell, wpre, cnt, vox_of, sorted_idx, members, leader, out, sums, total;
+    DevBuf in, bounds, cell, wpre, cnt, vox_of, word_of, sorted_idx, members, leader, out, sums, total;
 };
 
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)

@@ -227,6 +227,7 @@ struct UctArgs {
     unsigned char *rec_out;     // n staged records (input layout), or null
     double gpose[7];
     int cov_off, trace_off, with_ua;
+    int *keep2 = nullptr;
     const int *n_dev = nullptr;  // optional device-side record count (<= n): the launch covers n, records past *n_dev are dropped
 };
 
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
-    if (A.n_dev && i >= *A.n_dev) { A.keep[i] = 0; return; }
+    if (A.n_dev && i >= *A.n_dev) { A.keep[i] = 0; if (A.keep2) A.keep2[i] = 0; return; }
     const float *rec = reinterpret_cast<const float *>(A.src + size_t(i) * A.stride);
     const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(i) * A.stride + A.intensity_off) : 0.f;
     int idx = int(inten);
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
     const double tr = cov[0][0] + cov[1][1] + cov[2][2];
     const int keep = (A.with_ua && A.trace_thr > 0.0 && tr > A.trace_thr) ? 0 : 1;
     A.keep[i] = keep;
+    if (A.keep2) A.keep2[i] = keep;       // a second copy for the in-place scan that turns the flags into output slots
     const float c6[6] = {float(cov[0][0]), float(cov[0][1]), float(cov[0][2]), float(cov[1][1]), float(cov[1][2]), float(cov[2][2])};
     if (A.cov6) {
         float *o = A.cov6 + size_t(i) * 6;
@@ -524,10 +526,10 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
     A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = V.leader.as<int>();
     A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = with_ua ? 1 : 0;
     A.n_dev = V.total.as<int>();
+    A.keep2 = V.vox_of.as<int>();
     for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
     const int nb = (n + 255) / 256;
     hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
-    MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n), hipMemcpyDeviceToDevice, st));
     if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>() + 1))) { (void)hipStreamSynchronize(st); return rc; }
     MLH_HIP(ctx, pts_out.ensure(sizeof(float4) * size_t(n)));
     MLH_HIP(ctx, covd_out.ensure(sizeof(float4) * size_t(n)));

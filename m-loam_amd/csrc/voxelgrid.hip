@@ -76,17 +76,6 @@ __global__ __launch_bounds__(256) void vscan_add_kernel(int *__restrict__ data, 
     for (int k = 0; k < VS_ITEMS; ++k) if (base + k < n) data[base + k] += add;
 }
 
-int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, DevBuf &sums, int *grand_total)
-{
-    const int nb = int((n + VS_CHUNK - 1) / VS_CHUNK);
-    MLH_HIP(ctx, sums.ensure(sizeof(int) * size_t(nb + 1)));
-    hipLaunchKernelGGL(vscan_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, data, n, sums.as<int>());
-    hipLaunchKernelGGL(vscan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums.as<int>(), nb, grand_total);
-    hipLaunchKernelGGL(vscan_add_kernel, dim3(nb), dim3(256), 0, ctx->stream, data, n, sums.as<int>());
-    MLH_HIP(ctx, hipGetLastError());
-    return MLH_OK;
-}
-
 // popcount scan: out[w] = number of set bits in mask[0..w)
 __global__ __launch_bounds__(256) void vscan_popc_local_kernel(const unsigned *__restrict__ mask, int *__restrict__ out, long long n, int *__restrict__ sums)
 {
@@ -102,6 +91,71 @@ __global__ __launch_bounds__(256) void vscan_popc_local_kernel(const unsigned *_
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
+// Two-launch variant for up to VS_DIRECT_BLOCKS chunks: chunk totals first, then every workgroup adds up the totals of the chunks
+// before its own (a few hundred words) and scans its chunk -- the data is read twice and written once, and the single-workgroup
+// middle launch disappears. POPC: the input is a bit mask and the scanned quantity its words' popcounts.
+constexpr int VS_DIRECT_BLOCKS = 1024;
+template <bool POPC>
+__device__ __forceinline__ int vs_item(const int *in, long long i) { return POPC ? __popc(reinterpret_cast<const unsigned *>(in)[i]) : in[i]; }
+template <bool POPC>
+__global__ __launch_bounds__(256) void vscan_reduce_kernel(const int *__restrict__ in, long long n, int *__restrict__ sums)
+{
+    __shared__ int lds[4];
+    const long long base = (long long)blockIdx.x * VS_CHUNK + threadIdx.x * VS_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < VS_ITEMS; ++k) s += (base + k < n) ? vs_item<POPC>(in, base + k) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+template <bool POPC>
+__global__ __launch_bounds__(256) void vscan_final_kernel(const int *in, int *out, long long n, const int *__restrict__ sums, int *__restrict__ grand_total)
+{
+    __shared__ int lds[4], lds_off[4];
+    int acc = 0;
+    for (int j = threadIdx.x; j < int(blockIdx.x); j += 256) acc += sums[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) lds_off[threadIdx.x >> 6] = acc;
+    const long long base = (long long)blockIdx.x * VS_CHUNK + threadIdx.x * VS_ITEMS;
+    int v[VS_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < VS_ITEMS; ++k) { v[k] = (base + k < n) ? vs_item<POPC>(in, base + k) : 0; s += v[k]; }
+    int total;
+    int ex = vblock_scan(s, lds, total);            // (its barriers also publish lds_off)
+    const int offset = lds_off[0] + lds_off[1] + lds_off[2] + lds_off[3];
+    ex += offset;
+#pragma unroll
+    for (int k = 0; k < VS_ITEMS; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+    if (grand_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand_total = offset + total;
+}
+
+template <bool POPC>
+static int scan_launch(mlh_ctx *ctx, const int *in, int *out, long long n, DevBuf &sums, int *grand_total)
+{
+    const int nb = int((n + VS_CHUNK - 1) / VS_CHUNK);
+    MLH_HIP(ctx, sums.ensure(sizeof(int) * size_t(nb + 1)));
+    if (nb <= VS_DIRECT_BLOCKS) {
+        hipLaunchKernelGGL(vscan_reduce_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, n, sums.as<int>());
+        hipLaunchKernelGGL(vscan_final_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, out, n, (const int *)sums.as<int>(), grand_total);
+    } else {
+        if (POPC) hipLaunchKernelGGL(vscan_popc_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned *>(in), out, n, sums.as<int>());
+        else hipLaunchKernelGGL(vscan_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, sums.as<int>());
+        hipLaunchKernelGGL(vscan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums.as<int>(), nb, grand_total);
+        hipLaunchKernelGGL(vscan_add_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, (const int *)sums.as<int>());
+    }
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, DevBuf &sums, int *grand_total)
+{
+    return scan_launch<false>(ctx, data, data, n, sums, grand_total);
+}
+
 struct VoxArgs {
     const unsigned char *src;
     int stride, n, intensity_off, cov_off, trace_off;
@@ -109,6 +163,7 @@ struct VoxArgs {
     int min_b[3], mul1, mul2;
     float trace_thr;
     int *vox_of;        // n: voxel index per point, then its output slot
+    int *word_of;       // n: the point's occupancy word (kept so that the words can be cleared again)
     unsigned *mask;     // one occupancy bit per voxel of the dense grid
     const int *wpre;    // set bits before each mask word
     int *cnt;           // n + 2: members per output slot (shifted by one as in grid.hip) -> starts
@@ -145,6 +200,7 @@ __global__ __launch_bounds__(256) void vox_slot_kernel(VoxArgs A)
     const int v = A.vox_of[i], w = v >> 5;
     const int s = A.wpre[w] + __popc(A.mask[w] & ((1u << (v & 31)) - 1u));
     A.vox_of[i] = s;
+    A.word_of[i] = w;
     atomicAdd(&A.cnt[s + 1], 1);
 }
 
@@ -154,6 +210,7 @@ __global__ __launch_bounds__(256) void vox_scatter_kernel(VoxArgs A)
     if (i >= A.n) return;
     const int pos = atomicAdd(&A.cnt[A.vox_of[i] + 1], 1);
     A.sorted_idx[pos] = i;
+    A.mask[A.word_of[i]] = 0u;          // every slot has been derived: leave the occupancy words clean for the next call
 }
 
 // after the scatter cnt[s] = start[s], cnt[s+1] = end[s]. Every member finds its rank among its voxel's members (independent
@@ -325,7 +382,11 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     // members runs over the at most n occupied slots instead of the ncell cells.
     const long long ncell = (long long)div_b[0] * div_b[1] * div_b[2];
     const long long nwords = (ncell + 31) / 32 + 1;
-    MLH_HIP(ctx, V.cell.ensure(sizeof(unsigned) * size_t(nwords)));
+    if (sizeof(unsigned) * size_t(nwords) > V.cell.cap) {      // a fresh allocation is cleared once; afterwards every call leaves the words it set at zero
+        MLH_HIP(ctx, V.cell.ensure(sizeof(unsigned) * size_t(nwords)));
+        MLH_HIP(ctx, hipMemsetAsync(V.cell.p, 0, V.cell.cap, st));
+    }
+    MLH_HIP(ctx, V.word_of.ensure(sizeof(int) * size_t(n)));
     MLH_HIP(ctx, V.wpre.ensure(sizeof(int) * size_t(nwords)));
     MLH_HIP(ctx, V.cnt.ensure(sizeof(int) * size_t(n + 2)));
     MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 1)));
@@ -339,16 +400,14 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.cov_off = cov_off; A.trace_off = trace_off;
     A.inv_leaf = inv; A.min_b[0] = min_b[0]; A.min_b[1] = min_b[1]; A.min_b[2] = min_b[2];
     A.mul1 = div_b[0]; A.mul2 = div_b[0] * div_b[1];
-    A.trace_thr = trace_thr; A.vox_of = V.vox_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
+    A.trace_thr = trace_thr; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
     A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
     const int nbp = (n + 255) / 256;
-    MLH_HIP(ctx, hipMemsetAsync(V.cell.p, 0, sizeof(unsigned) * size_t(nwords), st));
     hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(vscan_popc_local_kernel, dim3(nbw), dim3(256), 0, st, (const unsigned *)A.mask, V.wpre.as<int>(), nwords, V.sums.as<int>());
-    hipLaunchKernelGGL(vscan_sums_kernel, dim3(1), dim3(256), 0, st, V.sums.as<int>(), nbw, V.total.as<int>());    // total = occupied voxels
-    hipLaunchKernelGGL(vscan_add_kernel, dim3(nbw), dim3(256), 0, st, V.wpre.as<int>(), nwords, (const int *)V.sums.as<int>());
+    int rc = scan_launch<true>(ctx, reinterpret_cast<const int *>(A.mask), V.wpre.as<int>(), nwords, V.sums, V.total.as<int>());   // total = occupied voxels
+    if (rc) return rc;
     hipLaunchKernelGGL(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
-    int rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
+    rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
     if (rc) return rc;
     hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
     hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
