@@ -144,6 +144,40 @@ int main(int argc, char **argv)
             write_file(d + "out_track_pose.f64", std::vector<double>(tp, tp + 7));
             std::printf("trackCloud: %.6f %.6f %.6f\n", tp[0], tp[1], tp[2]);
         }
+        // --- the same front end without host hops: extractCloudOnDevice -> LidarTracker / fuseCloudFeature -> downsampleFusedScan
+        {
+            auto load_scan = [&](const char *pts, const char *rg, PointICloud &c, ScanInfo &si) {
+                auto a = read_file<float>(d + pts);
+                auto r = read_file<int>(d + rg);
+                const int nr = (int)r.size() / 2;
+                for (size_t i = 0; i + 4 <= a.size(); i += 4) { PointI p; p.x = a[i]; p.y = a[i + 1]; p.z = a[i + 2]; p.intensity = a[i + 3]; c.push_back(p); }
+                si = ScanInfo(nr, false);
+                for (int k = 0; k < nr; ++k) { si.scan_start_ind_[k] = r[k]; si.scan_end_ind_[k] = r[nr + k]; }
+            };
+            PointICloud c0, c1;
+            ScanInfo i0(1, false), i1(1, false);
+            load_scan("trk_scan_prev.f32", "trk_rings_prev.i32", c0, i0);
+            load_scan("trk_scan_cur.f32", "trk_rings_cur.i32", c1, i1);
+            LidarTracker tracker(dev);
+            f_extract.extractCloudOnDevice(c0, i0);
+            tracker.setPrevFromExtractor();
+            f_extract.extractCloudOnDevice(c1, i1);
+            tracker.setCurFromExtractor();
+            double tp[7];
+            tracker.trackCloudOnDevice(Pose()).toParam(tp);
+            write_file(d + "out_track_pose_dev.f64", std::vector<double>(tp, tp + 7));
+            std::vector<Pose> pose_ext(2);
+            pose_ext[1].t_(0) = 0.1; pose_ext[1].t_(1) = -0.5; pose_ext[1].q_.z = 0.0998334166; pose_ext[1].q_.w = 0.9950041653;
+            pose_ext[1].cov_[0] = pose_ext[1].cov_[7] = pose_ext[1].cov_[14] = 0.0025;
+            pose_ext[1].cov_[21] = pose_ext[1].cov_[28] = pose_ext[1].cov_[35] = 0.00030461;
+            fuseReset(dev);
+            fuseCloudFeature(dev, 1, pose_ext[1]);            // the scan still held by the device, as LiDAR 1
+            f_extract.extractCloudOnDevice(c0, i0);
+            fuseCloudFeature(dev, 0, pose_ext[0]);
+            std::vector<int32_t> kept = {downsampleFusedScan(dev, MLH_SURF, 0.4f, pose_ext, true), downsampleFusedScan(dev, MLH_CORNER, 0.2f, pose_ext, true)};
+            write_file(d + "out_fused_kept.i32", kept);
+            std::printf("device-resident front end: track %.6f %.6f %.6f, fused features %d + %d\n", tp[0], tp[1], tp[2], kept[0], kept[1]);
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

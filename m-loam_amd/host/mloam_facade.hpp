@@ -292,6 +292,16 @@ public:
     }
     const std::vector<int32_t> &cloudLabel() const { return labels_; }   // cloud_label[] of the last extractCloud
 
+    // The same extraction with nothing fetched: the four feature lists and the thinned less-flat cloud stay in HBM for
+    // LidarTracker::set*FromExtractor and fuseCloudFeature (one scan per Device at a time).
+    void extractCloudOnDevice(const PointICloud &laser_cloud_in, const ScanInfo &scan_info)
+    {
+        dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, (int)laser_cloud_in.size(),
+                                   scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), (int)scan_info.scan_start_ind_.size(), MLH_MEM_HOST));
+        dev_.check(mlh_extract_run(dev_.ctx()));
+        dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
+    }
+
     // feature_extract.hpp:542-643 / 379-538: batch matching, matches compacted in input order
     template <typename PointT>
     void matchSurfFromMap(const MapIndex<PointT> &kdtree_surf_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
@@ -504,10 +514,51 @@ public:
         pose_prev_cur.fromParam(p);
         return pose_prev_cur;
     }
+    // Device-resident hand-over (estimator.cpp:426-427, 534-545 with DISTORTION = 0): the scan FeatureExtract::extractCloudOnDevice
+    // left on this Device becomes the current frame (sharp / flat) or, after tracking, the next call's previous frame (less sharp /
+    // thinned less flat); trackCloudOnDevice is trackCloud on whatever was staged.
+    void setCurFromExtractor() { dev_.check(mlh_track_set_from_scan(dev_.ctx(), 0, opts_.distance_sq_threshold)); }
+    void setPrevFromExtractor() { dev_.check(mlh_track_set_from_scan(dev_.ctx(), 1, opts_.distance_sq_threshold)); }
+    Pose trackCloudOnDevice(const Pose &pose_ini)
+    {
+        double p[7];
+        pose_ini.toParam(p);
+        dev_.check(mlh_track_cloud(dev_.ctx(), p, &opts_, nullptr));
+        Pose pose_prev_cur;
+        pose_prev_cur.fromParam(p);
+        return pose_prev_cur;
+    }
 private:
     Device &dev_;
     mlh_track_opts opts_;
 };
+
+// ------------------------------------------------------------------ the mapper's input clouds without a host hop
+// transformCloudFeature (visualization.cpp:39-51) + the concatenation the mapper receives: fuseReset once per frame, then for every
+// LiDAR extractCloudOnDevice + fuseCloudFeature(laser index, its extrinsic); downsampleFusedScan is downsampleCurrentScan on the
+// fused cloud of `kind` (the result becomes the kind's feature set for scan2map) and returns the number of features kept.
+inline void fuseReset(Device &dev) { dev.check(mlh_fuse_reset(dev.ctx())); }
+inline void fuseCloudFeature(Device &dev, int laser_idx, const Pose &pose_ext)
+{
+    double e[7];
+    pose_ext.toParam(e);
+    dev.check(mlh_fuse_add_scan(dev.ctx(), laser_idx, e));
+}
+inline int downsampleFusedScan(Device &dev, int kind, float leaf, const std::vector<Pose> &pose_ext, bool with_ua_flag)
+{
+    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
+    for (size_t n = 0; n < pose_ext.size(); ++n) {
+        pose_ext[n].toParam(ext.data() + n * 7);
+        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
+    }
+    const void *cloud = nullptr;
+    int32_t n = 0, m = 0;
+    dev.check(mlh_fused_cloud(dev.ctx(), kind, &cloud, &n));
+    if (n <= 0) return 0;
+    dev.check(mlh_downsample_current_scan(dev.ctx(), kind, cloud, 16, n, 12, MLH_MEM_DEVICE, leaf, ext.data(), ext_cov.data(), (int)pose_ext.size(),
+                                          params().COV_MEASUREMENT, with_ua_flag ? 1 : 0, params().TRACE_THRESHOLD_MAPPING, nullptr, &m));
+    return m;
+}
 
 // ------------------------------------------------------------------ ActiveFeatureSelection::evalFullHessian + the gf_ratio policy
 // evalFullHessian (lidar_mapper.h:176-227): match ALL features of a kind at pose_local and add their un-corrected, uncertainty-weighted

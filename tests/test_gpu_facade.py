@@ -25,6 +25,9 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     case16["p0"].astype(np.float64).tofile(os.path.join(d, "pose.f64"))
     for name in ("corner_last", "surf_last", "corner_sharp", "surf_flat"):
         track_case[name].astype(np.float32).tofile(os.path.join(d, f"trk_{name}.f32"))
+    for name, scn in zip(("prev", "cur"), track_case["scans"]):
+        scn.points.astype(np.float32).tofile(os.path.join(d, f"trk_scan_{name}.f32"))
+        np.concatenate([scn.scan_start, scn.scan_end]).astype(np.int32).tofile(os.path.join(d, f"trk_rings_{name}.i32"))
     r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
     labels = np.fromfile(os.path.join(d, "out_labels.i32"), np.int32)
@@ -86,3 +89,22 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     rt = orc.track_cloud(track_case["corner_last"], track_case["surf_last"], track_case["corner_sharp"], track_case["surf_flat"],
                          np.array([0, 0, 0, 0, 0, 0, 1.0]))
     assert np.linalg.norm(tp[:3] - rt["pose"][:3]) < 1e-9 and np.linalg.norm(tp[3:] - rt["pose"][3:]) < 1e-9
+    # the device-resident front end of the facade == the same calls through the Python binding
+    import importlib
+    mla = importlib.import_module("m-loam_amd")
+    prev, cur = track_case["scans"]
+    c = mla.Context(0)
+    try:
+        c.scan_upload(prev.points, prev.scan_start, prev.scan_end); c.extract_run(); c.extract_voxel_run(0.2); c.track_set_from_scan(1)
+        c.scan_upload(cur.points, cur.scan_start, cur.scan_end); c.extract_run(); c.extract_voxel_run(0.2); c.track_set_from_scan(0)
+        pose_dev, _ = c.track_cloud(np.array([0, 0, 0, 0, 0, 0, 1.0]))
+        np.testing.assert_array_equal(np.fromfile(os.path.join(d, "out_track_pose_dev.f64"), np.float64), pose_dev)
+        assert np.linalg.norm(pose_dev[:3] - track_case["motion"][:3]) < 0.08
+        ext_cov[1] = np.diag([0.0025] * 3 + [0.00030461] * 3)
+        c.fuse_reset(); c.fuse_add_scan(1, ext[1])
+        c.scan_upload(prev.points, prev.scan_start, prev.scan_end); c.extract_run(); c.extract_voxel_run(0.2); c.fuse_add_scan(0, ext[0])
+        kept = [c.downsample_current_scan(k, c.fused_cloud(k), leaf, ext, ext_cov, np.diag([0.0025] * 3), True, 0.6, fetch=False)
+                for k, leaf in ((mla.SURF, 0.4), (mla.CORNER, 0.2))]
+        assert list(np.fromfile(os.path.join(d, "out_fused_kept.i32"), np.int32)) == kept and min(kept) > 50
+    finally:
+        c.close()
