@@ -381,11 +381,13 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.p = P.partials;
         sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
         sum_partials(sa, f_ne, f_cnt2, f_scratch);
+        MLH_STAGE(4095, 1);
         if (threadIdx.x == 0) {
             if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks);
             else lm_step_body(f_ne, P.state, P.lm_max_it);
             *P.ticket = 0u;
         }
+        MLH_STAGE(4095, 2);
         return;
     }
     if (P.finish == 2) {
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
     const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
     const KindP &K = P.k[kind];
+    MLH_STAGE(gtile, 0);
     const int f = tile * TPB + threadIdx.x;
     const double *pose = block_pose(P, block_of_slot(K, P.n_blocks, tile * TPB));
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
@@ -569,8 +572,11 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 #pragma unroll
         for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
+    MLH_STAGE(gtile, 2);
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    MLH_STAGE(gtile, 3);
     if constexpr (LM) { if (P.finish == 4) fused_gn_finish<true>(P, total); }
+    MLH_STAGE(gtile, 4);
 }
 
 // stand-alone exact 5-NN for mlh_knn (queries already in the map frame)

@@ -294,3 +294,20 @@ def test_compound_pose_with_cov_matches_monte_carlo(orc, synth):
     emp = xi.T @ xi / n
     scale = np.sqrt(np.outer(np.diag(cov_cp), np.diag(cov_cp)))
     assert np.max(np.abs(emp - cov_cp) / scale) < 0.02
+
+
+def test_transform_cloud_feature_is_the_rigid_transform(orc, synth):
+    """transformCloudFeature (visualization.cpp:39-51): float32 R p + t of every point, intensity replaced by the LiDAR index. The
+    float32 restatement stays within a few ulp of the float64 rigid transform and is exact for the identity."""
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.uniform(-80, 80, (500, 3)), rng.uniform(0, 63, (500, 1))], axis=1).astype(np.float32)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    ext = np.concatenate([[0.1, -0.5, 0.02], q])
+    out = orc.transform_cloud_feature(pts, ext, 1)
+    ref = pts[:, :3].astype(np.float64) @ synth.quat_to_rot(q).T + ext[:3]
+    assert out.dtype == np.float32 and out.shape == pts.shape
+    np.testing.assert_allclose(out[:, :3], ref, rtol=0, atol=3e-5)           # |p| <= 140 m: 1 ulp = 1.5e-5
+    assert np.all(out[:, 3] == 1.0)
+    ident = orc.transform_cloud_feature(pts, np.array([0, 0, 0, 0, 0, 0, 1.0]), 0)
+    np.testing.assert_array_equal(ident[:, :3], pts[:, :3])
+    assert not ident[:, 3].any()
