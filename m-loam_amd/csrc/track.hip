@@ -32,8 +32,12 @@ __device__ unsigned long long g_stage_clk_track[4096 * 4];
 #define MLH_TSTAGE(i) do { } while (0)
 #endif
 
-constexpr int TRK_G = 16;                 // lanes per feature
-constexpr int TRK_FPB = TPB / TRK_G;
+constexpr int TRK_G = 16;                 // lanes per feature in the nearest-neighbour search (DPP rows)
+constexpr int TRK_W = 64;                 // lanes per feature in the scan-line walks: one wavefront per feature. A frame has only a few
+                                          // thousand tracked features; with 16 lanes each half the chip's SIMDs would idle while every
+                                          // group makes ~30 dependent trips over its 2-3 scan lines
+constexpr int TRK_FPB = TPB / TRK_W;      // features per workgroup
+constexpr int TRK_ROWS = TPB / TRK_G;     // 16-lane rows per workgroup (the 4 rows of a wavefront search the same feature redundantly)
 constexpr unsigned BACKWARD_BIT = 0x40000000u;
 
 struct TrackKind {
@@ -80,6 +84,15 @@ __device__ __forceinline__ unsigned long long group_min16(unsigned long long m)
     m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
     m = dpp_min_u64<DPP_ROW_MIRROR>(m);
     return m;
+}
+
+__device__ __forceinline__ unsigned long long wave_min64(unsigned long long m)
+{
+    m = group_min16(m);
+    unsigned long long o = shfl_xor_u64(m, 16);
+    m = o < m ? o : m;
+    o = shfl_xor_u64(m, 32);
+    return o < m ? o : m;
 }
 
 // walk position -> array index
@@ -171,15 +184,16 @@ __device__ __forceinline__ unsigned long long nearest_in_radius(const GridDev &g
 
 __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
 {
-    __shared__ int s_run[TRK_FPB * 36];
+    __shared__ int s_run[TRK_ROWS * 36];
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = blockIdx.x;
     if (tile >= total) return;
     const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
     if (kind) tile -= P.k[0].tiles_a;
     const TrackKind &K = P.k[kind];
-    const int grp = threadIdx.x / TRK_G, gl = threadIdx.x % TRK_G;
-    const int f = tile * TRK_FPB + grp;
+    const int grp = threadIdx.x / TRK_G, gl = threadIdx.x % TRK_G;     // nearest neighbour: row of 16 lanes, each row of the wavefront the same query
+    const int wl = threadIdx.x % TRK_W;                                // walks: the whole wavefront
+    const int f = tile * TRK_FPB + threadIdx.x / TRK_W;
     MLH_TSTAGE(0);
     if (f >= K.m) return;
     q4 q;
@@ -205,13 +219,13 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
         unsigned long long k2 = ~0ull, k3 = ~0ull;
         constexpr int WU = 8;                                      // loads in flight per lane: the walks are latency-bound otherwise
         // increasing index: closest+1 .. fwd_end-1
-        for (int j0 = closest + 1 + gl; j0 < fwd_end; j0 += TRK_G * WU) {
+        for (int j0 = closest + 1 + wl; j0 < fwd_end; j0 += TRK_W * WU) {
             float4 p[WU];
 #pragma unroll
-            for (int u = 0; u < WU; ++u) { const int j = j0 + TRK_G * u; if (j < fwd_end) p[u] = pts[j]; }
+            for (int u = 0; u < WU; ++u) { const int j = j0 + TRK_W * u; if (j < fwd_end) p[u] = pts[j]; }
 #pragma unroll
             for (int u = 0; u < WU; ++u) {
-                const int j = j0 + TRK_G * u;
+                const int j = j0 + TRK_W * u;
                 if (j < fwd_end) {
                     const int rj = int(p[u].w);
                     const float dd = (p[u].x - sx) * (p[u].x - sx) + (p[u].y - sy) * (p[u].y - sy) + (p[u].z - sz) * (p[u].z - sz);
@@ -225,13 +239,13 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
             }
         }
         // decreasing index: closest-1 .. bwd_begin
-        for (int j0 = closest - 1 - gl; j0 >= bwd_begin; j0 -= TRK_G * WU) {
+        for (int j0 = closest - 1 - wl; j0 >= bwd_begin; j0 -= TRK_W * WU) {
             float4 p[WU];
 #pragma unroll
-            for (int u = 0; u < WU; ++u) { const int j = j0 - TRK_G * u; if (j >= bwd_begin) p[u] = pts[j]; }
+            for (int u = 0; u < WU; ++u) { const int j = j0 - TRK_W * u; if (j >= bwd_begin) p[u] = pts[j]; }
 #pragma unroll
             for (int u = 0; u < WU; ++u) {
-                const int j = j0 - TRK_G * u;
+                const int j = j0 - TRK_W * u;
                 if (j >= bwd_begin) {
                     const int rj = int(p[u].w);
                     const float dd = (p[u].x - sx) * (p[u].x - sx) + (p[u].y - sy) * (p[u].y - sy) + (p[u].z - sz) * (p[u].z - sz);
@@ -244,8 +258,8 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
                 }
             }
         }
-        k2 = group_min16(k2);
-        k3 = group_min16(k3);
+        k2 = wave_min64(k2);
+        k3 = wave_min64(k3);
         MLH_TSTAGE(2);
         if (kind == MLH_CORNER) {
             if (k2 != ~0ull) {
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(TPB) void track_match_kernel(TrackParamsDev P)
             valid = true;
         }
     }
-    if (gl == 0) {
+    if (wl == 0) {
         Corr c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) c.c[i] = valid ? c6[i] : 0.f;

@@ -48,11 +48,36 @@ print("set_prev corner %.3f ms, set_prev surf %.3f ms, set_cur corner %.3f, set_
     tm(lambda: ctx.track_set_cur(mla.CORNER, cs)), tm(lambda: ctx.track_set_cur(mla.SURF, sf)),
     tm(lambda: ctx.track_cloud(p0, want_stats=False))))
 
+# the odometry front end of one LiDAR with device hand-overs: scan in -> extractCloud -> trackCloud against the previous frame -> this
+# frame becomes the previous one; nothing but the raw scan and the pose crosses PCIe
+sp, sc_ = feats["prev"], feats["cur"]
+scan_prev = (sp["pts"], ) ; scan_cur = (sc_["pts"], )
+def front_end(scan_pts, start, end, first=False):
+    ctx.scan_upload(scan_pts, start, end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
+    pose = None
+    if not first:
+        ctx.track_set_from_scan(0)
+        pose = ctx.track_cloud(p0, want_stats=False)[0]
+    ctx.track_set_from_scan(1)
+    return pose
+ss = {}
+for name, pose_, seed in (("prev", gt0, 7), ("cur", gt1, 11)):
+    s_ = synth.simulate_scan(sc, pose_, synth.HERCULES_BODY_T_LASER[0], 64, seed=seed)
+    ss[name] = (feats[name]["pts"], s_.scan_start, s_.scan_end)
+front_end(*ss["prev"], first=True)
+for _ in range(3): pose_dev = front_end(*ss["cur"]); front_end(*ss["prev"])
+ctx.synchronize(); t = time.perf_counter()
+for _ in range(10): pose_dev = front_end(*ss["cur"]); front_end(*ss["prev"])
+ctx.synchronize()
+print("odometry front end, device hand-overs (upload + extractCloud + trackCloud + hand-over): %.3f ms per LiDAR frame; pose vs host-staged path |dt| %.2e" % (
+    1e3 * (time.perf_counter() - t) / 20, np.linalg.norm(pose_dev[:3] - pose[:3])))
+if os.environ.get("TRACKBENCH_FRONT_END_ONLY"): sys.exit(0)
+
 if os.environ.get("MLOAM_HIP_LIB"):
     import ctypes as C
     lib = mla.load_library()
     ctx.track_cloud(p0, want_stats=False); ctx.synchronize()
-    nwg = (len(cs) + 15) // 16 + (len(sf) + 15) // 16
+    nwg = (len(cs) + 3) // 4 + (len(sf) + 3) // 4
     buf = (C.c_ulonglong * (nwg * 4))()
     lib.mlh_debug_stage_clock_track.argtypes = [C.c_void_p, C.c_int]
     assert lib.mlh_debug_stage_clock_track(buf, nwg * 4) == 0
