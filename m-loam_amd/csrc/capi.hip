@@ -338,6 +338,7 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     ScanBuf &sb = ctx->scan;
     sb.extracted = false;
     sb.voxelised = false;
+    sb.h_lists_valid = sb.h_vox_valid = false;
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
     int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, sb.pts, nullptr, ctx->tmp);
     if (rc) return rc;
@@ -905,11 +906,11 @@ static TrackArgs track_args(const mlh_track_opts *o, int pose_sel)
     return a;
 }
 
-int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
-                       float distance_sq_threshold)
+// previous-frame cloud of one kind: packed copies + ring table, everything enqueued and nothing waited for; *host_bad is valid after
+// the next synchronisation of the stream
+static int track_stage_prev(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                            float distance_sq_threshold, int *host_bad)
 {
-    if (!ctx || kind < 0 || kind > 1 || intensity_offset_bytes < 0 || !(distance_sq_threshold > 0.f)) return MLH_ERR_INVALID;
-    MLH_HIP(ctx, hipSetDevice(ctx->device));
     TrackSet &T = ctx->track;
     MapGrid &g = T.grid[kind];
     g.built = false;
@@ -920,12 +921,48 @@ int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_by
     MLH_HIP(ctx, T.walk[kind].ensure(sizeof(float4) * size_t(n)));
     hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride_bytes, n, intensity_offset_bytes, -1,
                        T.walk[kind].as<float4>(), (float4 *)nullptr);
-    if ((rc = track_set_prev_rings(ctx, kind, d_src, stride_bytes, n, intensity_offset_bytes))) return rc;
+    if ((rc = track_set_prev_rings(ctx, kind, d_src, stride_bytes, n, intensity_offset_bytes, host_bad))) return rc;
     g.n = n;
     g.min_match_sq_dis = distance_sq_threshold / float(TRACK_SHELLS * TRACK_SHELLS);   // cell edge = 1.001 * sqrt(thr) / TRACK_SHELLS
-    MapGrid *gp[1] = {&g};
-    if ((rc = grid_build_grids(ctx, gp, 1, true))) return rc;
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLH_OK;
+}
+
+// index build of the staged previous-frame clouds (one host round trip for all of them: the bounding boxes) + the deferred ring check
+static int track_build_prev(mlh_ctx *ctx, int kind_mask, const int *host_bad)
+{
+    MapGrid *gp[2];
+    int ng = 0;
+    for (int k = 0; k < 2; ++k) if (kind_mask & (1 << k)) gp[ng++] = &ctx->track.grid[k];
+    int rc = grid_build_grids(ctx, gp, ng, true);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); for (int k = 0; k < ng; ++k) gp[k]->built = false; return rc; }
+    for (int k = 0; k < 2; ++k)
+        if ((kind_mask & (1 << k)) && host_bad[k]) {
+            ctx->track.grid[k].built = false;
+            return fail(ctx, MLH_ERR_INVALID, "previous-frame cloud must be ordered by ring id (int(intensity) non-decreasing, 0 <= id < 255)");
+        }
+    return MLH_OK;
+}
+
+int mlh_track_set_prev(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
+                       float distance_sq_threshold)
+{
+    if (!ctx || kind < 0 || kind > 1 || intensity_offset_bytes < 0 || !(distance_sq_threshold > 0.f)) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int bad[2] = {0, 0};
+    int rc = track_stage_prev(ctx, kind, points, stride_bytes, n, intensity_offset_bytes, mem, distance_sq_threshold, &bad[kind]);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if ((rc = track_build_prev(ctx, 1 << kind, bad))) return rc;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host buffers: the staging copy is reused by the next call
+    return MLH_OK;
+}
+
+static int track_stage_cur(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int m, int intensity_offset_bytes, int mem)
+{
+    TrackSet &T = ctx->track;
+    int rc = stage_points(ctx, points, stride_bytes, m, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, T.cur[kind], nullptr, ctx->tmp);
+    if (rc) return rc;
+    MLH_HIP(ctx, T.corr[kind].ensure(sizeof(Corr) * size_t(m)));
+    T.m[kind] = m;
     return MLH_OK;
 }
 
@@ -933,12 +970,9 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
 {
     if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    TrackSet &T = ctx->track;
-    int rc = stage_points(ctx, points, stride_bytes, m, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, T.cur[kind], nullptr, ctx->tmp);
+    int rc = track_stage_cur(ctx, kind, points, stride_bytes, m, intensity_offset_bytes, mem);
     if (rc) return rc;
-    MLH_HIP(ctx, T.corr[kind].ensure(sizeof(Corr) * size_t(m)));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    T.m[kind] = m;
     return MLH_OK;
 }
 
@@ -946,6 +980,21 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__rest
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = pts[list[i]];
+}
+
+// the list sizes of the scan the context holds (and the thinned less-flat count once it exists): one host round trip per scan
+static int scan_totals(mlh_ctx *ctx, bool want_vox)
+{
+    ScanBuf &sb = ctx->scan;
+    const bool need_lists = !sb.h_lists_valid, need_vox = want_vox && !sb.h_vox_valid;
+    if (!need_lists && !need_vox) return MLH_OK;
+    if (need_lists) MLH_HIP(ctx, hipMemcpyAsync(sb.h_totals, sb.totals.p, sizeof(int) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (need_vox || (sb.voxelised && !sb.h_vox_valid))
+        MLH_HIP(ctx, hipMemcpyAsync(sb.h_totals + 4, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sb.h_lists_valid = true;
+    if (sb.voxelised) sb.h_vox_valid = true;
+    return MLH_OK;
 }
 
 // the features of the scan the context holds become the tracker's current (which = 0: sharp corners, flat surfs) or previous
@@ -956,26 +1005,27 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
     ScanBuf &sb = ctx->scan;
     if (!sb.extracted) return fail(ctx, MLH_ERR_STATE, "extract_run has not been called");
     if (which == 1 && !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "extract_voxel_run has not been called (the previous frame's surf cloud is the thinned one)");
+    if (which == 1 && !(distance_sq_threshold > 0.f)) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    int totals[4] = {0, 0, 0, 0}, n_vox = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(totals, sb.totals.p, sizeof(totals), hipMemcpyDeviceToHost, st));
-    if (which == 1) MLH_HIP(ctx, hipMemcpyAsync(&n_vox, sb.ring_vox.as<int>() + 2 * sb.n_rings, sizeof(int), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    int rc = scan_totals(ctx, which == 1);
+    if (rc) return rc;
     const int corner_list = which == 0 ? 0 : 1;                 // corner_points_sharp / corner_points_less_sharp
-    const int n_corner = totals[corner_list], n_flat = totals[2];
+    const int n_corner = sb.h_totals[corner_list], n_flat = sb.h_totals[2], n_vox = sb.h_totals[4];
     if (n_corner <= 0 || (which == 0 ? n_flat : n_vox) <= 0) return fail(ctx, MLH_ERR_STATE, "the scan produced no features of one kind");
     MLH_HIP(ctx, ctx->knn_q.ensure(sizeof(float4) * size_t(std::max(n_corner, n_flat))));     // gather scratch (not ctx->tmp: the staging calls may use that)
     float4 *g = ctx->knn_q.as<float4>();
-    int rc;
     hipLaunchKernelGGL(gather_points_kernel, dim3((n_corner + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[corner_list].as<int>(), n_corner, g);
     if (which == 0) {
-        if ((rc = mlh_track_set_cur(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE))) return rc;
+        // nothing to wait for: every consumer of these buffers is a later launch on the same stream
+        if ((rc = track_stage_cur(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE))) return rc;
         hipLaunchKernelGGL(gather_points_kernel, dim3((n_flat + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[2].as<int>(), n_flat, g);
-        return mlh_track_set_cur(ctx, MLH_SURF, g, 16, n_flat, 12, MLH_MEM_DEVICE);
+        return track_stage_cur(ctx, MLH_SURF, g, 16, n_flat, 12, MLH_MEM_DEVICE);
     }
-    if ((rc = mlh_track_set_prev(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE, distance_sq_threshold))) return rc;
-    return mlh_track_set_prev(ctx, MLH_SURF, sb.vox_out.p, 16, n_vox, 12, MLH_MEM_DEVICE, distance_sq_threshold);
+    int bad[2] = {0, 0};
+    if ((rc = track_stage_prev(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE, distance_sq_threshold, &bad[MLH_CORNER]))) { (void)hipStreamSynchronize(st); return rc; }
+    if ((rc = track_stage_prev(ctx, MLH_SURF, sb.vox_out.p, 16, n_vox, 12, MLH_MEM_DEVICE, distance_sq_threshold, &bad[MLH_SURF]))) { (void)hipStreamSynchronize(st); return rc; }
+    return track_build_prev(ctx, 3, bad);      // both indices in one set of launches, one host round trip
 }
 
 // transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
@@ -1149,12 +1199,15 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         // lidar_tracker.cpp:42-121: match at the current estimate, then Ceres on the fixed correspondences (Huber 0.1, <= 4 iterations,
         // no degeneracy handling); fewer than 10 correspondences -> the round is skipped
+        // (the LM begin / step run in the linearisation kernel's last workgroup: 2 + max_lm_iterations launches per round)
         if ((rc = track_match_launch(ctx, 3, track_args(opts, 0)))) return rc;
-        if ((rc = track_linearize_launch(ctx, 3, track_args(opts, 0)))) return rc;
-        if ((rc = lm_begin_launch(ctx, -1.0, opts->max_lm_iterations, stats ? outer : -1, 10))) return rc;
+        TrackArgs b = track_args(opts, 0);
+        b.finish = 3; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 10; b.stat_slot = stats ? outer : -1;
+        if ((rc = track_linearize_launch(ctx, 3, b))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; ++it) {
-            if ((rc = track_linearize_launch(ctx, 3, track_args(opts, 1)))) return rc;
-            if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+            TrackArgs s = track_args(opts, 1);
+            s.finish = 4; s.lm_max_it = opts->max_lm_iterations;
+            if ((rc = track_linearize_launch(ctx, 3, s))) return rc;
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
     }

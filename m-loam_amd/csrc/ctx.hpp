@@ -151,6 +151,8 @@ struct ScanBuf {
     int n = 0, n_rings = 0;
     int max_ring_len = 0;  // max over rings of (scan_end - scan_start)
     bool extracted = false;
+    int h_totals[5] = {0, 0, 0, 0, 0};   // host copy of the four list sizes + the thinned less-flat count, fetched once per scan
+    bool h_lists_valid = false, h_vox_valid = false;
 };
 
 struct VoxBuf {   // scratch of mlh_voxel_filter
@@ -174,6 +176,8 @@ struct TrackArgs {
     const double *init_pose = nullptr;
     float dist_sq_thr = 25.f, nearby_scan = 2.5f;
     double huber_delta = 0.1;
+    int finish = 0;          // track_linearize_launch: 3 / 4 = its last workgroup runs the Levenberg-Marquardt begin / step (solver_dev.hpp)
+    int lm_max_it = 4, lm_min_blocks = 10, stat_slot = -1;
 };
 
 struct Profile {
@@ -250,7 +254,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf);
 int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, const double *ext_poses,
                           const double *ext_covs, int n_lidar, const double cov_meas[9], double trace_thr, float *cov6_host, int *keep_host);
 // track.hip
-int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off);
+int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off, int *host_bad);
 int track_match_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 // odom.hip

@@ -395,6 +395,7 @@ int extract_run(mlh_ctx *ctx)
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
     sb.extracted = true;
+    sb.h_lists_valid = false;
     return MLH_OK;
 }
 

@@ -248,16 +248,23 @@ __global__ __launch_bounds__(256) void scatter_kernel(GridJobs G)
     }
 }
 
-static int compute_bounds(mlh_ctx *ctx, MapGrid &g, float min_match_sq_dis)
+// bounds of one point set: the kernel + the copy of its partial records into hp (6 * BOUNDS_BLOCKS ints), nothing waited for
+static int bounds_launch(mlh_ctx *ctx, MapGrid &g, int *hp)
 {
     hipStream_t st = ctx->stream;
+    const int grid_pts = std::min((g.n + 255) / 256, BOUNDS_BLOCKS);
+    MLH_HIP(ctx, g.bounds.ensure(6 * BOUNDS_BLOCKS * sizeof(int)));
+    hipLaunchKernelGGL(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), g.n, g.bounds.as<int>());
+    MLH_HIP(ctx, hipMemcpyAsync(hp, g.bounds.p, sizeof(int) * 6 * size_t(grid_pts), hipMemcpyDeviceToHost, st));
+    return MLH_OK;
+}
+
+// ... and, once the stream has been waited for, the grid geometry and buffers that follow from them
+static int bounds_finish(mlh_ctx *ctx, MapGrid &g, const int *hp, float min_match_sq_dis)
+{
     const int n = g.n;
     const int grid_pts = std::min((n + 255) / 256, BOUNDS_BLOCKS);
-    MLH_HIP(ctx, g.bounds.ensure(6 * BOUNDS_BLOCKS * sizeof(int)));
-    hipLaunchKernelGGL(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), n, g.bounds.as<int>());
-    int hp[6 * BOUNDS_BLOCKS], hb[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
-    MLH_HIP(ctx, hipMemcpyAsync(hp, g.bounds.p, sizeof(int) * 6 * size_t(grid_pts), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    int hb[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
     for (int blk = 0; blk < grid_pts; ++blk)
         for (int d = 0; d < 3; ++d) { hb[d] = std::min(hb[d], hp[blk * 6 + d]); hb[3 + d] = std::max(hb[3 + d], hp[blk * 6 + 3 + d]); }
     float mn[3], mx[3];
@@ -308,15 +315,16 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
     GridJobs G;
     std::memset(&G, 0, sizeof(G));
     int nj = 0;
-    for (int k = 0; k < n_grids && k < 2; ++k) {
-        MapGrid &g = *grids[k];
-        if (g.n <= 0 || !g.raw.p) return fail(ctx, MLH_ERR_STATE, "no points staged for this index");
-        if (recompute_bounds) {
-            int rc = compute_bounds(ctx, g, g.min_match_sq_dis);
-            if (rc) return rc;
-        }
-        G.j[nj++] = make_job(g);
+    for (int k = 0; k < n_grids && k < 2; ++k)
+        if (grids[k]->n <= 0 || !grids[k]->raw.p) return fail(ctx, MLH_ERR_STATE, "no points staged for this index");
+    if (recompute_bounds) {
+        // the bounding boxes of all point sets in ONE host round trip (which also completes whatever the caller enqueued before)
+        int hp[2][6 * BOUNDS_BLOCKS];
+        for (int k = 0; k < n_grids && k < 2; ++k) { int rc = bounds_launch(ctx, *grids[k], hp[k]); if (rc) return rc; }
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        for (int k = 0; k < n_grids && k < 2; ++k) { int rc = bounds_finish(ctx, *grids[k], hp[k], grids[k]->min_match_sq_dis); if (rc) return rc; }
     }
+    for (int k = 0; k < n_grids && k < 2; ++k) G.j[nj++] = make_job(*grids[k]);
     if (nj == 0) return MLH_OK;
     const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);

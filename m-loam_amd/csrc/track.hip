@@ -17,6 +17,7 @@
 #include "ctx.hpp"
 #include "dev_math.hpp"
 #include "knn_dev.hpp"
+#include "solver_dev.hpp"
 #include "reduce_dev.hpp"
 
 namespace mlh {
@@ -56,6 +57,9 @@ struct TrackParamsDev {
     SolverState *state;
     double *partials;
     int pose_sel;            // 0: state->x, 1: state->cand
+    int finish, lm_max_it, lm_min_blocks;   // fused Levenberg-Marquardt begin (3) / step (4) in the linearisation kernel's last workgroup
+    unsigned *ticket;
+    IterStatDev *stat;
     int use_init;
     double init_pose[7];
     float dist_sq_thr;
@@ -393,6 +397,31 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
         }
     }
     reduce_acc32(acc, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    if (!P.finish) return;
+    // fused tail (as match.hip: fused_gn_finish): the last workgroup to arrive sums the partial records in fixed order and runs the
+    // Levenberg-Marquardt begin / step -- an LM iteration of the tracker is ONE launch (lidar_tracker.cpp:66-70, 106-113: no degeneracy
+    // handling, rounds with fewer than 10 correspondences are skipped)
+    __shared__ int s_last;
+    __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[8 * 32];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (atomicAdd(P.ticket, 1u) == unsigned(total - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    SumArgs sa;
+    sa.p = P.partials;
+    sa.lo[0] = 0; sa.hi[0] = total; sa.lo[1] = 0; sa.hi[1] = 0;
+    sum_partials(sa, f_ne, f_cnt2, f_scratch);
+    if (threadIdx.x == 0) {
+        if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, -1.0, P.lm_max_it, P.stat, P.lm_min_blocks);
+        else lm_step_body(f_ne, P.state, P.lm_max_it);
+        *P.ticket = 0u;
+    }
 }
 
 // ring ids + ring_start table of a previous-frame cloud; flags non-monotone / out-of-range ring ids
@@ -408,27 +437,26 @@ __global__ __launch_bounds__(256) void track_rings_kernel(const unsigned char *s
     for (int k = prev + 1; k <= r; ++k) ring_start[k] = i;
 }
 
+// p[0..n) = v, p[n] = 0 (the ring table and the flag behind it)
 __global__ void fill_int_kernel(int *p, int n, int v)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
+    else if (i == n) p[i] = 0;
 }
 
-int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off)
+// host_bad: where the "not ordered by ring" flag is copied to; valid after the next synchronisation of the stream (the caller checks it)
+int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off, int *host_bad)
 {
     TrackSet &T = ctx->track;
     MLH_HIP(ctx, T.ring[kind].ensure(sizeof(int) * size_t(n)));
     MLH_HIP(ctx, T.ring_start[kind].ensure(sizeof(int) * (TRACK_RING_SLOTS + 1)));
     int *bad = T.ring_start[kind].as<int>() + TRACK_RING_SLOTS;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((TRACK_RING_SLOTS + 255) / 256), dim3(256), 0, ctx->stream, T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, n);
-    MLH_HIP(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(fill_int_kernel, dim3((TRACK_RING_SLOTS + 1 + 255) / 256), dim3(256), 0, ctx->stream, T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, n);   // (also clears the flag)
     hipLaunchKernelGGL(track_rings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride, n, intensity_off, T.ring[kind].as<int>(),
                        T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, bad);
     MLH_HIP(ctx, hipGetLastError());
-    int hbad = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (hbad) return fail(ctx, MLH_ERR_INVALID, "previous-frame cloud must be ordered by ring id (int(intensity) non-decreasing, 0 <= id < 255)");
+    MLH_HIP(ctx, hipMemcpyAsync(host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return MLH_OK;
 }
 
@@ -458,6 +486,13 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
     P.shells = TRACK_SHELLS;
     P.dist_sq_thr = a.dist_sq_thr; P.nearby_floor = int(std::floor(a.nearby_scan)); P.huber_delta = a.huber_delta;
+    P.finish = a.finish; P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
+    if (!ctx->ticket.p) {
+        if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
+        if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
+    }
+    P.ticket = ctx->ticket.as<unsigned>();
+    P.stat = a.stat_slot >= 0 ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     return MLH_OK;
 }
 

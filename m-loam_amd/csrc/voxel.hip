@@ -206,6 +206,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
     sb.voxelised = true;
+    sb.h_vox_valid = false;
     return MLH_OK;
 }
 
