@@ -101,6 +101,84 @@ __device__ __forceinline__ void sort_sector(const float *sc, int sp, int len, un
 // consecutive-point gap > 0.05, at most 5) depends only on the geometry, so it is tabulated for every position of the ring before
 // the walks (sext[t] = nf | nb << 4); a candidate lane brings its entry along and a pick costs no LDS read at all.
 
+// The two greedy walks of ONE sector by one wavefront (cpp:166-256). Per pick the loop does register work plus one predicated LDS
+// store (the suppression marks); the picks themselves are parked in lane registers (lane p keeps the p-th pick) and are labelled /
+// staged by the caller. Marks on positions inside [lo, hi] go to spicked; marks that reach past those bounds (at most 5 positions
+// on either side) go to spill[0..4] (hi+1 .. hi+5) and spill[5..9] (lo-1 .. lo-5) -- the caller decides when they take effect.
+struct SectorPicks { int npick, my_pick, nfl, my_flat; };
+__device__ __forceinline__ SectorPicks walk_sector(const unsigned long long *kj, int len, const float *sc, const unsigned char *sext,
+                                                   int *spicked, int lo, int hi, unsigned char *spill, int lane)
+{
+    const int off = lane - 5;                                  // lanes 0..10 cover the positions sel-5 .. sel+5
+    SectorPicks R;
+    // ---- edge walk, descending curvature (cpp:166-215): picks 1-2 sharp, 3-20 less sharp, the 21st candidate ends it unlabelled
+    int npick = 0, my_pick = 0;
+    bool stop = false;
+    for (int base = len - 1; base >= 0 && !stop; base -= 64) {
+        const int k = base - lane;
+        const int li = (k >= 0) ? int(unsigned(kj[k])) : 0;
+        const bool c_ok = (k >= 0) && (double(sc[li]) > 0.1);
+        const int ext = sext[li];
+        bool elig = c_ok && (spicked[li] == 0);            // one LDS look per batch; picks inside the batch retire lanes in registers
+        unsigned long long m = __ballot(elig);
+        while (m) {
+            if (npick == 20) { stop = true; break; }
+            const int l = __ffsll((long long)m) - 1;
+            const int sel = __builtin_amdgcn_readlane(li, l);
+            const int xe = __builtin_amdgcn_readlane(ext, l);
+            const int nf = xe & 15, nb = xe >> 4;
+            my_pick = (lane == npick) ? sel : my_pick;
+            npick++;
+            if (lane < 11 && off >= -nb && off <= nf) {        // the pick and its neighbours up to the first gap
+                const int x = sel + off;
+                if (x > hi) spill[x - hi - 1] = 1;
+                else if (x < lo) spill[5 + (lo - 1 - x)] = 1;
+                else spicked[x] = 1;
+            }
+            elig = elig && !(li >= sel - nb && li <= sel + nf);
+            m = __ballot(elig);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // sorted descending: once a candidate fails c > 0.1 every later one fails too
+        const unsigned long long inb = __ballot(k >= 0);
+        if (__ballot(c_ok) != inb) stop = true;
+    }
+    R.npick = npick; R.my_pick = my_pick;
+    // ---- flat walk, ascending curvature (cpp:219-256): 4 picks; the 4th is labelled but neither marked nor suppressing
+    int nfl = 0, my_flat = 0;
+    stop = false;
+    for (int base = 0; base < len && !stop; base += 64) {
+        const int k = base + lane;
+        const int li = (k < len) ? int(unsigned(kj[k])) : 0;
+        const bool c_ok = (k < len) && (double(sc[li]) < 0.1);
+        const int ext = sext[li];
+        bool elig = c_ok && (spicked[li] == 0);
+        unsigned long long m = __ballot(elig);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            const int sel = __builtin_amdgcn_readlane(li, l);
+            my_flat = (lane == nfl) ? sel : my_flat;
+            nfl++;
+            if (nfl >= 4) { stop = true; break; }
+            const int xe = __builtin_amdgcn_readlane(ext, l);
+            const int nf = xe & 15, nb = xe >> 4;
+            if (lane < 11 && off >= -nb && off <= nf) {
+                const int x = sel + off;
+                if (x > hi) spill[x - hi - 1] = 1;
+                else if (x < lo) spill[5 + (lo - 1 - x)] = 1;
+                else spicked[x] = 1;
+            }
+            elig = elig && !(li >= sel - nb && li <= sel + nf);
+            m = __ballot(elig);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long inb = __ballot(k < len);
+        if (__ballot(c_ok) != inb) stop = true;
+    }
+    R.nfl = nfl; R.my_flat = my_flat;
+    return R;
+}
+
 __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -183,80 +261,78 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
     }
     __syncthreads();
     MLH_LSTAGE(3);
-    // greedy walks: wave 0 only. Per pick the loop does register work plus ONE predicated LDS store (the suppression marks):
-    // the picks themselves are parked in lane registers (lane p keeps the p-th pick) and labelled / staged after the walk.
-    if (threadIdx.x < 64) {
+    __shared__ unsigned char s_spill[6 * 10 + 4];
+    __shared__ int s_np[6], s_nf[6];
+    if (threadIdx.x < 64) s_spill[threadIdx.x] = 0;
+    const bool sectors_in_parallel = (e - s) >= 30 && LTPB >= 6 * 64;   // every sector >= 5 points: a pick's +-5 marks reach at most into the adjacent sector
+    if (sectors_in_parallel) {
+        // The reference walks the sectors one after the other, and the only thing sector j+1 sees of sector j is the picked-marks
+        // that j's last picks leave on j+1's first (at most 5) positions. So all six sectors walk SPECULATIVELY at once, one wavefront
+        // each, with marks that cross a sector bound set aside (s_spill); then, in sector order, a sector whose speculative picks
+        // include a position its predecessor really marked is walked again with those marks in place (its own spill changes with
+        // it, so its successor is checked against the final one). Marks on positions that were not picked change nothing: they can only
+        // remove candidates, and a candidate that was not picked either was never reached or was already suppressed.
+        __syncthreads();                                   // s_spill cleared
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int lo = sp[wave], hi = ep[wave];
+        const unsigned long long *kj = keys + wave * P;
+        unsigned char *spill = s_spill + wave * 10;
+        SectorPicks pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane);
+        for (int round = 1; round < 6; ++round) {
+            __syncthreads();                               // sector round-1 is final
+            if (wave == round) {
+                int inc = 0;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) inc |= s_spill[(round - 1) * 10 + i] ? (1 << i) : 0;
+                const int de = pk.my_pick - lo, df = pk.my_flat - lo;
+                const bool hit = (lane < pk.npick && de < 5 && ((inc >> de) & 1)) || (lane < pk.nfl && df < 5 && ((inc >> df) & 1));
+                if (__ballot(hit)) {
+                    for (int x = lo + lane; x <= hi; x += 64) spicked[x] = 0;
+                    if (lane < 10) spill[lane] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 5 && ((inc >> lane) & 1)) spicked[lo + lane] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane);
+                }
+            }
+        }
+        if (lane == 0) { s_np[wave] = pk.npick; s_nf[wave] = pk.nfl; }
+        __syncthreads();
+        int n_sharp = 0, n_less = 0, n_flat = 0;            // picks of the sectors before this one (output order: sector, then pick)
+        for (int j = 0; j < wave; ++j) { n_sharp += min(s_np[j], 2); n_less += s_np[j]; n_flat += s_nf[j]; }
+        if (lane < pk.npick) {
+            slabel[pk.my_pick] = (lane < 2) ? 2 : 1;
+            if (lane < 2) s_stage[n_sharp + lane] = pk.my_pick + g0;
+            s_stage[STAGE_SHARP + n_less + lane] = pk.my_pick + g0;
+        }
+        if (lane < pk.nfl) {
+            slabel[pk.my_flat] = -1;
+            s_stage[STAGE_SHARP + STAGE_LESS + n_flat + lane] = pk.my_flat + g0;
+        }
+        // the marks that crossed a sector bound now take effect for the picked[] output
+        if (lane < 10 && spill[lane]) spicked[lane < 5 ? hi + 1 + lane : lo - 1 - (lane - 5)] = 1;
+        if (wave == 5 && lane == 0) { s_cnt[0] = n_sharp + min(pk.npick, 2); s_cnt[1] = n_less + pk.npick; s_cnt[2] = n_flat + pk.nfl; }
+        MLH_LSTAGE(4);
+    } else if (threadIdx.x < 64) {
+        // short rings: wave 0 walks the sectors in order, every mark taking effect at once
         const int lane = threadIdx.x;
-        const int off = lane - 5;                                  // lanes 0..10 cover the positions sel-5 .. sel+5
         int n_sharp = 0, n_less = 0, n_flat = 0;
         for (int j = 0; j < 6; ++j) {
-            const int len = ep[j] - sp[j] + 1;
-            const unsigned long long *kj = keys + j * P;
-            // ---- edge walk, descending curvature (cpp:166-215): picks 1-2 sharp, 3-20 less sharp, the 21st candidate ends it unlabelled
-            int npick = 0, my_pick = 0;
-            bool stop = false;
-            for (int base = len - 1; base >= 0 && !stop; base -= 64) {
-                const int k = base - lane;
-                const int li = (k >= 0) ? int(unsigned(kj[k])) : 0;
-                const bool c_ok = (k >= 0) && (double(sc[li]) > 0.1);
-                const int ext = sext[li];
-                bool elig = c_ok && (spicked[li] == 0);            // one LDS look per batch; picks inside the batch retire lanes in registers
-                unsigned long long m = __ballot(elig);
-                while (m) {
-                    if (npick == 20) { stop = true; break; }
-                    const int l = __ffsll((long long)m) - 1;
-                    const int sel = __builtin_amdgcn_readlane(li, l);
-                    const int xe = __builtin_amdgcn_readlane(ext, l);
-                    const int nf = xe & 15, nb = xe >> 4;
-                    my_pick = (lane == npick) ? sel : my_pick;
-                    npick++;
-                    if (lane < 11 && off >= -nb && off <= nf) spicked[sel + off] = 1;   // the pick and its neighbours up to the first gap
-                    elig = elig && !(li >= sel - nb && li <= sel + nf);
-                    m = __ballot(elig);
-                }
-                __builtin_amdgcn_wave_barrier();
-                // sorted descending: once a candidate fails c > 0.1 every later one fails too
-                const unsigned long long inb = __ballot(k >= 0);
-                if (__ballot(c_ok) != inb) stop = true;
+            const SectorPicks pk = walk_sector(keys + j * P, ep[j] - sp[j] + 1, sc, sext, spicked, 0, span - 1, s_spill, lane);
+            if (lane < pk.npick) {
+                slabel[pk.my_pick] = (lane < 2) ? 2 : 1;
+                if (lane < 2) s_stage[n_sharp + lane] = pk.my_pick + g0;
+                s_stage[STAGE_SHARP + n_less + lane] = pk.my_pick + g0;
             }
-            if (lane < npick) {
-                slabel[my_pick] = (lane < 2) ? 2 : 1;
-                if (lane < 2) s_stage[n_sharp + lane] = my_pick + g0;
-                s_stage[STAGE_SHARP + n_less + lane] = my_pick + g0;
+            n_sharp += pk.npick < 2 ? pk.npick : 2;
+            n_less += pk.npick;
+            if (lane < pk.nfl) {
+                slabel[pk.my_flat] = -1;
+                s_stage[STAGE_SHARP + STAGE_LESS + n_flat + lane] = pk.my_flat + g0;
             }
-            n_sharp += npick < 2 ? npick : 2;
-            n_less += npick;
-            // ---- flat walk, ascending curvature (cpp:219-256): 4 picks; the 4th is labelled but neither marked nor suppressing
-            int nfl = 0, my_flat = 0;
-            stop = false;
-            for (int base = 0; base < len && !stop; base += 64) {
-                const int k = base + lane;
-                const int li = (k < len) ? int(unsigned(kj[k])) : 0;
-                const bool c_ok = (k < len) && (double(sc[li]) < 0.1);
-                const int ext = sext[li];
-                bool elig = c_ok && (spicked[li] == 0);
-                unsigned long long m = __ballot(elig);
-                while (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    const int sel = __builtin_amdgcn_readlane(li, l);
-                    my_flat = (lane == nfl) ? sel : my_flat;
-                    nfl++;
-                    if (nfl >= 4) { stop = true; break; }
-                    const int xe = __builtin_amdgcn_readlane(ext, l);
-                    const int nf = xe & 15, nb = xe >> 4;
-                    if (lane < 11 && off >= -nb && off <= nf) spicked[sel + off] = 1;
-                    elig = elig && !(li >= sel - nb && li <= sel + nf);
-                    m = __ballot(elig);
-                }
-                __builtin_amdgcn_wave_barrier();
-                const unsigned long long inb = __ballot(k < len);
-                if (__ballot(c_ok) != inb) stop = true;
-            }
-            if (lane < nfl) {
-                slabel[my_flat] = -1;
-                s_stage[STAGE_SHARP + STAGE_LESS + n_flat + lane] = my_flat + g0;
-            }
-            n_flat += nfl;
+            n_flat += pk.nfl;
         }
         if (lane == 0) { s_cnt[0] = n_sharp; s_cnt[1] = n_less; s_cnt[2] = n_flat; }
         MLH_LSTAGE(4);
