@@ -323,6 +323,18 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
  * less-flat surfs become the previous frame (call it after mlh_track_cloud, for the next frame). The scan must have been uploaded
  * with its intensity (ring id) field. */
 int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold);
+/* TransformToEnd (estimator/src/utility/utility.h:79-100; TransformToStart :55-77) over n records, in place: p_end = T^-1 T(s) p with
+ * T(s) = (Identity.slerp(s, q), s t), s = (intensity - int(intensity)) / scan_period when b_distortion (the intensity field carries
+ * ring id + time inside the sweep), else 1. f64 arithmetic, the intermediate and final points rounded to f32 as the reference's
+ * float points do. pose = [t(3), q(xyzw)]. Host (copied in and out) or device buffers. */
+int mlh_transform_to_end(mlh_ctx *ctx, void *points, int stride_bytes, int n, int intensity_offset_bytes, const double pose[7],
+                         int b_distortion, float scan_period, int mem);
+/* Estimator::undistortMeasurements (estimator.cpp:376-410, DISTORTION = 1) for the scan the context holds: TransformToEnd(...,
+ * true, scan_period) on all its points (laser_cloud; the less-sharp corner list indexes them) and on its voxel-thinned less-flat
+ * cloud, in place on the device. Call it after the tracker has consumed this scan's sharp / flat features (the reference leaves
+ * those un-transformed) and before mlh_track_set_from_scan(1) / mlh_fuse_add_scan hand the clouds on. */
+int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_period);
+
 /* The mapper's input clouds without leaving HBM. transformCloudFeature (estimator/src/utility/visualization.cpp:39-51) moves every
  * LiDAR's features into the body frame and overwrites intensity with the LiDAR index before they are published to the mapper;
  * mlh_fuse_add_scan does that for the scan the context holds (after mlh_extract_run + mlh_extract_voxel_run): its voxel-thinned

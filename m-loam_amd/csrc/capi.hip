@@ -1028,6 +1028,83 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
     return track_build_prev(ctx, 3, bad);      // both indices in one set of launches, one host round trip
 }
 
+// TransformToEnd (utility.h:79-100) in place over strided records: p^b = T^-1 T(s) p^c with s = frac(intensity) / scan_period when
+// b_distortion, else 1; T(s) = (slerp(s, q), s t) (Eigen 3.3 slerp from the identity), f64 math, the intermediate and the result
+// rounded to f32 exactly where the reference stores them into float points
+struct UndistArgs { unsigned char *p; int stride, n, intensity_off, b_distortion; float scan_period; double pose[7]; };
+__global__ __launch_bounds__(256) void transform_to_end_kernel(UndistArgs A)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    float *rec = reinterpret_cast<float *>(A.p + size_t(i) * A.stride);
+    const float inten = *reinterpret_cast<const float *>(A.p + size_t(i) * A.stride + A.intensity_off);
+    double sI = 1.0;
+    if (A.b_distortion) sI = double((inten - float(int(inten))) / A.scan_period);
+    const q4 q{A.pose[3], A.pose[4], A.pose[5], A.pose[6]};
+    const d3 t{A.pose[0], A.pose[1], A.pose[2]};
+    // Identity.slerp(s, q)
+    const double one = 1.0 - 2.220446049250313e-16;
+    const double d = q.w, absD = fabs(d);
+    double scale0, scale1;
+    if (absD >= one) { scale0 = 1.0 - sI; scale1 = sI; }
+    else {
+        const double theta = acos(absD), sinTheta = sin(theta);
+        scale0 = sin((1.0 - sI) * theta) / sinTheta;
+        scale1 = sin(sI * theta) / sinTheta;
+    }
+    if (d < 0.0) scale1 = -scale1;
+    const q4 qs{scale0 * 0.0 + scale1 * q.x, scale0 * 0.0 + scale1 * q.y, scale0 * 0.0 + scale1 * q.z, scale0 * 1.0 + scale1 * q.w};
+    const d3 r = qrot(qs, d3{double(rec[0]), double(rec[1]), double(rec[2])});
+    const float ux = float(r.x + sI * t.x), uy = float(r.y + sI * t.y), uz = float(r.z + sI * t.z);     // un_point_tmp (a float point)
+    const double n2 = (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);
+    const q4 qi{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
+    const d3 e = qrot(qi, d3{double(ux) - t.x, double(uy) - t.y, double(uz) - t.z});
+    rec[0] = float(e.x); rec[1] = float(e.y); rec[2] = float(e.z);
+}
+
+static int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int intensity_off, const double pose[7], int b_distortion, float scan_period)
+{
+    if (n <= 0) return MLH_OK;
+    UndistArgs A;
+    A.p = static_cast<unsigned char *>(dev); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.b_distortion = b_distortion;
+    A.scan_period = scan_period;
+    for (int i = 0; i < 7; ++i) A.pose[i] = pose[i];
+    hipLaunchKernelGGL(transform_to_end_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int mlh_transform_to_end(mlh_ctx *ctx, void *points, int stride_bytes, int n, int intensity_offset_bytes, const double pose[7], int b_distortion,
+                         float scan_period, int mem)
+{
+    if (!ctx || !points || !pose || n < 0 || stride_bytes < 16 || (stride_bytes & 3) || intensity_offset_bytes < 12 || !(scan_period > 0.f)) return MLH_ERR_INVALID;
+    if (n == 0) return MLH_OK;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem == MLH_MEM_DEVICE) return transform_to_end_launch(ctx, points, stride_bytes, n, intensity_offset_bytes, pose, b_distortion, scan_period);
+    const size_t bytes = size_t(n) * stride_bytes;
+    MLH_HIP(ctx, ctx->tmp.ensure(bytes));
+    MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = transform_to_end_launch(ctx, ctx->tmp.p, stride_bytes, n, intensity_offset_bytes, pose, b_distortion, scan_period);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    MLH_HIP(ctx, hipMemcpyAsync(points, ctx->tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLH_OK;
+}
+
+// Estimator::undistortMeasurements (estimator.cpp:376-410) for the scan the context holds: its points (laser_cloud, and with them the
+// less-sharp corners the lists index) and its thinned less-flat cloud move to the end of the sweep, in place, on the device
+int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_period)
+{
+    if (!ctx || !pose_undist || !(scan_period > 0.f)) return MLH_ERR_INVALID;
+    ScanBuf &sb = ctx->scan;
+    if (!sb.extracted) return fail(ctx, MLH_ERR_STATE, "extract_run has not been called");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = transform_to_end_launch(ctx, sb.pts.p, 16, sb.n, 12, pose_undist, 1, scan_period);
+    if (rc || !sb.voxelised) return rc;
+    if ((rc = scan_totals(ctx, true))) return rc;      // the thinned cloud's count (fetched once per scan, shared with the hand-overs)
+    return transform_to_end_launch(ctx, sb.vox_out.p, 16, sb.h_totals[4], 12, pose_undist, 1, scan_period);
+}
+
 // transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
 struct FuseXf { float r[9], t[3], id; };
 struct FuseArgs {

@@ -533,6 +533,24 @@ private:
     mlh_track_opts opts_;
 };
 
+// ------------------------------------------------------------------ undistortion (utility.h:79-100, estimator.cpp:376-410)
+// TransformToEnd over a whole cloud (the reference loops `for (PointI &point : cloud) TransformToEnd(point, point, pose, true, SCAN_PERIOD)`)
+inline void TransformToEnd(Device &dev, PointICloud &cloud, const Pose &pose, const bool &b_distortion, const float &scan_period = 0.1f)
+{
+    if (cloud.size() == 0) return;
+    double p[7];
+    pose.toParam(p);
+    dev.check(mlh_transform_to_end(dev.ctx(), cloud.points.data(), (int)sizeof(PointI), (int)cloud.size(), point_traits<PointI>::intensity_off, p,
+                                   b_distortion ? 1 : 0, scan_period, MLH_MEM_HOST));
+}
+// the same for the scan FeatureExtract::extractCloudOnDevice left on the device (laser_cloud + the thinned less-flat cloud)
+inline void undistortMeasurementsOnDevice(Device &dev, const Pose &pose_undist, float scan_period = 0.1f)
+{
+    double p[7];
+    pose_undist.toParam(p);
+    dev.check(mlh_scan_undistort(dev.ctx(), p, scan_period));
+}
+
 // ------------------------------------------------------------------ the mapper's input clouds without a host hop
 // transformCloudFeature (visualization.cpp:39-51) + the concatenation the mapper receives: fuseReset once per frame, then for every
 // LiDAR extractCloudOnDevice + fuseCloudFeature(laser index, its extrinsic); downsampleFusedScan is downsampleCurrentScan on the

@@ -390,4 +390,15 @@ int orc_track_cloud(const float *corner_last, int n_cl, const float *surf_last, 
     return 0;
 }
 
+// TransformToEnd over n rows [x y z intensity] -> out rows (intensity copied)
+int orc_transform_to_end(const float *pts, int n, const double *pose7, int b_distortion, float scan_period, float *out)
+{
+    const Pose pose = pose_from_param(pose7);
+    for (int i = 0; i < n; ++i) {
+        transform_to_end(pts + size_t(i) * 4, pose, b_distortion != 0, scan_period, out + size_t(i) * 4);
+        out[size_t(i) * 4 + 3] = pts[size_t(i) * 4 + 3];
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -331,6 +331,16 @@ def transform_cloud_feature(points4, ext_pose, lidar_idx):
     return out
 
 
+def transform_to_end(points4, pose7, distortion=True, scan_period=0.1):
+    """TransformToEnd (utility.h:79-100) over rows [x y z intensity]; intensity = ring id + relative time inside the sweep."""
+    pts = np.ascontiguousarray(points4, np.float32)
+    assert pts.shape[1] == 4
+    pose = np.ascontiguousarray(pose7, np.float64)
+    out = np.zeros_like(pts)
+    lib().orc_transform_to_end(_ptr(pts), len(pts), _ptr(pose), int(bool(distortion)), C.c_float(scan_period), _ptr(out))
+    return out
+
+
 def track_params(distance_sq_threshold=25.0, nearby_scan=2.5, scan_period=0.1, huber_delta=0.1, max_outer=2, max_lm_iterations=4):
     return np.array([distance_sq_threshold, nearby_scan, scan_period, huber_delta, max_outer, max_lm_iterations], np.float64)
 

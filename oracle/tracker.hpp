@@ -2,6 +2,7 @@
 //
 // CPU restatement of the scan-to-scan odometry (the caller side of the hot path):
 //   TransformToStart                         estimator/src/utility/utility.h:55-77
+//   TransformToEnd                           utility.h:79-100 (Estimator::undistortMeasurements, estimator.cpp:376-410)
 //   Eigen::Quaterniond::slerp                Eigen 3.3.4 Geometry/Quaternion.h (restated)
 //   FeatureExtract::matchCornerFromScan      estimator/src/featureExtract/feature_extract.hpp:132-270
 //   FeatureExtract::matchSurfFromScan        feature_extract.hpp:273-376
@@ -42,6 +43,20 @@ static inline void transform_to_start(const float *pi /*x y z intensity*/, const
     const Vec3d t{s * pose.t.x, s * pose.t.y, s * pose.t.z};
     const Vec3d r = quat_rotate(q, {double(pi[0]), double(pi[1]), double(pi[2])});
     po[0] = float(r.x + t.x); po[1] = float(r.y + t.y); po[2] = float(r.z + t.z);
+}
+
+// utility.h:79-100 TransformToEnd: p^b = T^-1 T(s) p^c; the intermediate point goes through a float point (un_point_tmp)
+static inline void transform_to_end(const float *pi /*x y z intensity*/, const Pose &pose, bool b_distortion, float scan_period, float po[3])
+{
+    float tmp[3];
+    transform_to_start(pi, pose, b_distortion, scan_period, tmp);
+    const Vec3d d{double(tmp[0]) - pose.t.x, double(tmp[1]) - pose.t.y, double(tmp[2]) - pose.t.z};
+    // Eigen quaternion inverse(): conjugate / squaredNorm (4 doubles reduced pairwise: the SSE2 packet order of an x86-64 -O3 build)
+    const Quatd &q = pose.q;
+    const double n2 = (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);
+    const Quatd qi{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
+    const Vec3d r = quat_rotate(qi, d);
+    po[0] = float(r.x); po[1] = float(r.y); po[2] = float(r.z);
 }
 
 static inline float sqr_sum(float a, float b, float c) { return a * a + b * b + c * c; }   // common sqrSum

@@ -772,3 +772,64 @@ def test_fuse_ring_ranges_of_a_joint_scan(mla, orc, synth, case16):
             c.fuse_add_rings(3, 3, 0, ext[0])
     finally:
         c.close()
+
+
+def _timed_cloud(rng, n):
+    """rows [x y z intensity] with intensity = ring id + time inside the sweep (ImageSegmenter + calTimestamp), SCAN_PERIOD 0.1"""
+    pts = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    inten = (rng.integers(0, 64, n) + rng.uniform(0, 0.0999, n)).astype(np.float32)
+    return np.ascontiguousarray(np.concatenate([pts, inten[:, None]], axis=1))
+
+
+@pytest.mark.parametrize("distortion", [True, False])
+def test_transform_to_end_parity(ctx, orc, distortion):
+    """TransformToEnd (utility.h:79-100), the per-point body of Estimator::undistortMeasurements: slerp-interpolated motion inside
+    the sweep. f64 math with two f32 roundings, acos / sin from the device's libm: equal to the oracle up to one f32 ulp, and
+    bit-equal for the overwhelming majority of the words."""
+    rng = np.random.default_rng(21)
+    pts = _timed_cloud(rng, 5000)
+    q = np.array([0.01, -0.02, 0.03, 1.0]); q /= np.linalg.norm(q)
+    pose = np.concatenate([[0.35, -0.12, 0.02], q])
+    got = ctx.transform_to_end(pts, pose, distortion)
+    ref = orc.transform_to_end(pts, pose, distortion)
+    np.testing.assert_array_equal(got[:, 3], pts[:, 3])
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=8e-6)        # 1 ulp at 60 m = 3.8e-6
+    assert np.mean(got[:, :3].view(np.uint32) == ref[:, :3].view(np.uint32)) > 0.98
+    if not distortion:                                                            # s = 1: T^-1 T p = p up to the two roundings
+        np.testing.assert_allclose(got[:, :3], pts[:, :3], rtol=0, atol=2e-5)
+    else:
+        assert np.abs(got[:, :3] - pts[:, :3]).max() > 0.05
+    # the negative-w branch of slerp and the identity short-cut
+    for pq in (-q, np.array([0, 0, 0, 1.0])):
+        p2 = np.concatenate([[0.1, 0.2, -0.3], pq])
+        np.testing.assert_allclose(ctx.transform_to_end(pts[:200], p2, True)[:, :3], orc.transform_to_end(pts[:200], p2, True)[:, :3], rtol=0, atol=8e-6)
+
+
+def test_scan_undistort_on_device(mla, orc, case16):
+    """Estimator::undistortMeasurements without a host hop: the scan's points and its thinned less-flat cloud move to the end of the
+    sweep in place; the hand-overs that follow (tracker, fusion) read the undistorted clouds."""
+    s = case16["scans"][0]
+    rng = np.random.default_rng(5)
+    pts = s.points.copy()
+    begins = s.scan_start - 5
+    for r in range(s.n_rings):
+        e = begins[r + 1] if r + 1 < s.n_rings else len(pts)
+        pts[begins[r]:e, 3] = r + np.linspace(0, 0.0999, e - begins[r], dtype=np.float32)
+    q = np.array([0.0, 0.0, np.sin(np.deg2rad(0.75)), np.cos(np.deg2rad(0.75))])
+    pose = np.concatenate([[0.35, -0.12, 0.02], q])
+    c = mla.Context(0)
+    try:
+        c.scan_upload(pts, s.scan_start, s.scan_end); c.extract_run(); ex = c.extract_fetch(); lf = c.extract_voxel(0.2)
+        c.fuse_reset(); c.scan_undistort(pose); c.fuse_add_scan(0, np.array([0, 0, 0, 0, 0, 0, 1.0]))
+        lf_u = orc.transform_to_end(lf, pose, True)
+        cn_u = orc.transform_to_end(pts[ex["less_sharp"]], pose, True)
+        for kind, ref in ((mla.SURF, lf_u), (mla.CORNER, cn_u)):
+            dc = c.fused_cloud(kind)
+            got = _device_to_host(dc.ptr, dc.n * 16).view(np.float32).reshape(-1, 4)
+            assert got.shape == ref.shape
+            np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=0, atol=1e-5)      # identity extrinsic: the fusion adds nothing
+            assert not got[:, 3].any()
+        with pytest.raises(mla.MlhError):
+            mla.Context(0).scan_undistort(pose)
+    finally:
+        c.close()

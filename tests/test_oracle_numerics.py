@@ -311,3 +311,17 @@ def test_transform_cloud_feature_is_the_rigid_transform(orc, synth):
     ident = orc.transform_cloud_feature(pts, np.array([0, 0, 0, 0, 0, 0, 1.0]), 0)
     np.testing.assert_array_equal(ident[:, :3], pts[:, :3])
     assert not ident[:, 3].any()
+
+
+def test_transform_to_end_closed_forms(orc):
+    """TransformToEnd (utility.h:79-100): identity pose -> unchanged; no distortion -> T^-1 T p = p; pure translation -> p + (s - 1) t."""
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([rng.uniform(-50, 50, (300, 3)), (rng.integers(0, 16, (300, 1)) + rng.uniform(0, 0.0999, (300, 1)))], axis=1).astype(np.float32)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    np.testing.assert_array_equal(orc.transform_to_end(pts, ident, True), pts)
+    q = np.array([0.02, -0.01, 0.05, 1.0]); q /= np.linalg.norm(q)
+    pose = np.concatenate([[0.4, -0.2, 0.05], q])
+    np.testing.assert_allclose(orc.transform_to_end(pts, pose, False)[:, :3], pts[:, :3], rtol=0, atol=2e-5)
+    tr = np.array([0.4, -0.2, 0.05, 0, 0, 0, 1.0])
+    s = ((pts[:, 3] - np.floor(pts[:, 3])) / np.float32(0.1)).astype(np.float64)
+    np.testing.assert_allclose(orc.transform_to_end(pts, tr, True)[:, :3], pts[:, :3] + (s[:, None] - 1.0) * tr[:3], rtol=0, atol=2e-5)
