@@ -331,8 +331,9 @@ int mlh_transform_to_end(mlh_ctx *ctx, void *points, int stride_bytes, int n, in
                          int b_distortion, float scan_period, int mem);
 /* Estimator::undistortMeasurements (estimator.cpp:376-410, DISTORTION = 1) for the scan the context holds: TransformToEnd(...,
  * true, scan_period) on all its points (laser_cloud; the less-sharp corner list indexes them) and on its voxel-thinned less-flat
- * cloud, in place on the device. Call it after the tracker has consumed this scan's sharp / flat features (the reference leaves
- * those un-transformed) and before mlh_track_set_from_scan(1) / mlh_fuse_add_scan hand the clouds on. */
+ * cloud, in place on the device. Order as in Estimator::process (estimator.cpp:532-586): the tracker consumes this scan's sharp /
+ * flat features and mlh_track_set_from_scan(1) copies the (still distorted) less-sharp / less-flat clouds to the previous frame
+ * first; then this call; then mlh_fuse_add_scan hands the undistorted clouds to the mapper. */
 int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_period);
 
 /* The mapper's input clouds without leaving HBM. transformCloudFeature (estimator/src/utility/visualization.cpp:39-51) moves every
