@@ -514,7 +514,7 @@ public:
         pose_prev_cur.fromParam(p);
         return pose_prev_cur;
     }
-    // Device-resident hand-over (estimator.cpp:426-427, 534-545 with DISTORTION = 0): the scan FeatureExtract::extractCloudOnDevice
+    // Device-resident hand-over (estimator.cpp:426-427, 532-543: copied before any undistortion): the scan FeatureExtract::extractCloudOnDevice
     // left on this Device becomes the current frame (sharp / flat) or, after tracking, the next call's previous frame (less sharp /
     // thinned less flat); trackCloudOnDevice is trackCloud on whatever was staged.
     void setCurFromExtractor() { dev_.check(mlh_track_set_from_scan(dev_.ctx(), 0, opts_.distance_sq_threshold)); }
