@@ -113,3 +113,13 @@ def _track_case(synth, orc):
     return dict(corner_last=np.ascontiguousarray(pts0[ex0["less_sharp"]]), surf_last=np.ascontiguousarray(ex0["less_flat_ds"][:, :4]),
                 corner_sharp=np.ascontiguousarray(pts1[ex1["sharp"]]), surf_flat=np.ascontiguousarray(pts1[ex1["flat"]]),
                 motion=motion, scans=(out["prev"]["scan"], out["cur"]["scan"]))
+
+
+def rows_f3_inputs():
+    """seeded inputs of tests/golden/rows_f3.npz (front-end rows: transformCloudFeature, TransformToEnd)"""
+    rng = np.random.default_rng(31)
+    pts = np.concatenate([rng.uniform(-60, 60, (2000, 3)), (rng.integers(0, 64, (2000, 1)) + rng.uniform(0, 0.0999, (2000, 1)))], axis=1).astype(np.float32)
+    q = np.array([0.012, -0.02, 0.031, 1.0]); q /= np.linalg.norm(q)
+    pose = np.concatenate([[0.35, -0.12, 0.02], q])
+    ext = np.array([0.1, -0.5, 0.02, 0.0, 0.0, 0.0998334166468, 0.995004165278])
+    return pts, pose, ext

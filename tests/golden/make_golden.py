@@ -34,6 +34,14 @@ if "--rows-f-only" not in sys.argv:
                       scan2map_pose=r["pose"], gn5_pose=g["pose"])
 print("wrote config1.npz", ex["n_ties"], vs.sum(), vc.sum(), r["pose"])
 
+# ---- third fixture: the front-end rows (transformCloudFeature, TransformToEnd); inputs are regenerated from the seed by the tests
+_p3, _pose3, _ext3 = conftest.rows_f3_inputs()
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "rows_f3.npz"), to_end=O.transform_to_end(_p3, _pose3, True), to_end_nodist=O.transform_to_end(_p3, _pose3, False),
+                    fused=O.transform_cloud_feature(_p3, _ext3, 1))
+print("wrote rows_f3.npz")
+if "--rows-f3-only" in sys.argv:
+    sys.exit(0)
+
 # ---- second fixture: the rows built after the first one (tracker, covariance voxel filter, pose compounding, map association)
 tc = conftest._track_case(synth, O)
 tr = O.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], np.array([0, 0, 0, 0, 0, 0, 1.0]))

@@ -301,3 +301,13 @@ def test_oracle_matches_rows_f_fixture(orc, track_case):
     np.testing.assert_allclose(ccp, g["compound_cov"], rtol=1e-13, atol=1e-20)
     np.testing.assert_array_equal(orc.cloud_uct_associate_to_map(cloud[:1000], p1, c1, ext, extc, np.diag([0.0025] * 3), True, float(g["assoc_thr"])),
                                   g["assoc_out"])
+
+
+def test_oracle_matches_rows_f3_fixture(orc):
+    """tests/golden/rows_f3.npz: the front-end rows (transformCloudFeature, TransformToEnd) reproduce bit for bit from the seed."""
+    import conftest
+    g = np.load(os.path.join(GOLDEN, "rows_f3.npz"))
+    pts, pose, ext = conftest.rows_f3_inputs()
+    assert np.array_equal(orc.transform_to_end(pts, pose, True).view(np.uint32), g["to_end"].view(np.uint32))
+    assert np.array_equal(orc.transform_to_end(pts, pose, False).view(np.uint32), g["to_end_nodist"].view(np.uint32))
+    assert np.array_equal(orc.transform_cloud_feature(pts, ext, 1).view(np.uint32), g["fused"].view(np.uint32))
