@@ -287,6 +287,19 @@ int orc_pure_odom_eval(char type, const double *point, const double *coeff, doub
     return 0;
 }
 
+// whole window in one call (timing baseline of the batched GPU evaluation): types 0 = plane, 1 = edge; J: n x 21
+int orc_pure_odom_eval_batch(int n, const int *types, const double *points, const double *coeffs6, const double *sqrt_info, const int *frame_idx,
+                             const int *ext_idx, const double *pivot, const double *frames, const double *exts, double *residuals, double *J)
+{
+    for (int i = 0; i < n; ++i) {
+        double *Ji = J + size_t(i) * 21;
+        const double si = sqrt_info ? sqrt_info[i] : 1.0;
+        if (types[i] == 0) pure_odom_plane_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], residuals + i, Ji, Ji + 7, Ji + 14);
+        else pure_odom_edge_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], residuals + i, Ji, Ji + 7, Ji + 14);
+    }
+    return 0;
+}
+
 // ---- small numeric kernels exposed for cross-checks against numpy
 int orc_eig3f(const float *A9, float *val3, float *vec9)
 {

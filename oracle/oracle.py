@@ -254,6 +254,16 @@ def pure_odom_eval(kind: str, point, coeff, pivot, pose_i, ext, sqrt_info=1.0):
     return r[0], J
 
 
+def pure_odom_eval_batch(types, points, coeffs6, sqrt_info, frame_idx, ext_idx, pivot, frames, exts):
+    """LidarPureOdom*Factor::Evaluate for a whole window (types 0 plane / 1 edge) -> residuals (n,), J (n, 3, 7)."""
+    t = np.ascontiguousarray(types, np.int32); p = np.ascontiguousarray(points, np.float64); c = np.ascontiguousarray(coeffs6, np.float64)
+    si = np.ascontiguousarray(sqrt_info, np.float64); fi = np.ascontiguousarray(frame_idx, np.int32); ei = np.ascontiguousarray(ext_idx, np.int32)
+    pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64); ex = np.ascontiguousarray(exts, np.float64)
+    r = np.zeros(len(t)); J = np.zeros((len(t), 3, 7))
+    lib().orc_pure_odom_eval_batch(len(t), _ptr(t), _ptr(p), _ptr(c), _ptr(si), _ptr(fi), _ptr(ei), _ptr(pv), _ptr(fr), _ptr(ex), _ptr(r), _ptr(J))
+    return r, J
+
+
 def eig3f(A):
     A = np.ascontiguousarray(A, np.float32)
     val = np.zeros(3, np.float32)
