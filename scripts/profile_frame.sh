@@ -1,7 +1,7 @@
 #!/bin/bash
 # One device-resident mapper frame (scripts/framebench.py, FRAMEBENCH_DEV_ONLY): per-kernel statistics and the GPU timeline of one frame.
 # Run through gpurun from the repo root; outputs in gpurun_out/prof_frame_$TAG/ -> copy into profiles/.
-TAG=${1:-r01g}
+TAG=${1:-r01h}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_frame_$TAG
 mkdir -p $OUT
