@@ -103,6 +103,8 @@ def main():
                     help="supplementary saturation run: do NOT thin the scan features at MAP_SURF_RES/MAP_CORNER_RES (not BASELINE's workload)")
     ap.add_argument("--lidars", type=int, default=N_LIDARS, choices=[1, 2, 3, 4],
                     help="supplementary: number of 64-ring LiDARs in the frame (BASELINE's metric is quoted on 2)")
+    ap.add_argument("--map-preset", default=None, choices=["50k", "500k", "1M", "2M", "4M"],
+                    help="supplementary: local-map size (default: 500k at N=1, 500k x N at N GPUs as BASELINE's configs 2-4 grow it)")
     ap.add_argument("--profile-events", type=int, default=1,
                     help="1: HIP-event bracket the dominant kernel (surf correspondence) inside the timed region; 0: none")
     args = ap.parse_args()
@@ -126,7 +128,7 @@ def main():
     synth = importlib.import_module("m-loam_amd.synth")
     shard = importlib.import_module("m-loam_amd.shard")
 
-    preset = MAP_PRESET_BY_N.get(world, "500k")
+    preset = args.map_preset or MAP_PRESET_BY_N.get(world, "500k")
     t0 = time.time()
     import warnings
     with warnings.catch_warnings():
