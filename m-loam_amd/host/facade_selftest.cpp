@@ -177,6 +177,15 @@ int main(int argc, char **argv)
             std::vector<int32_t> kept = {downsampleFusedScan(dev, MLH_SURF, 0.4f, pose_ext, true), downsampleFusedScan(dev, MLH_CORNER, 0.2f, pose_ext, true)};
             write_file(d + "out_fused_kept.i32", kept);
             std::printf("device-resident front end: track %.6f %.6f %.6f, fused features %d + %d\n", tp[0], tp[1], tp[2], kept[0], kept[1]);
+            // undistortion (DISTORTION = 1): TransformToEnd over a host cloud; the device-resident variant on the scan just extracted
+            PointICloud und = c1;
+            Pose pose_undist;
+            pose_undist.t_(0) = 0.35; pose_undist.t_(1) = -0.12; pose_undist.t_(2) = 0.02; pose_undist.q_.z = 0.0130895956; pose_undist.q_.w = 0.9999143276;
+            TransformToEnd(dev, und, pose_undist, true, 0.1f);
+            std::vector<float> uo;
+            for (const auto &q : und.points) { uo.push_back(q.x); uo.push_back(q.y); uo.push_back(q.z); uo.push_back(q.intensity); }
+            write_file(d + "out_undistorted.f32", uo);
+            undistortMeasurementsOnDevice(dev, pose_undist, 0.1f);
         }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;

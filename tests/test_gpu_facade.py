@@ -89,6 +89,13 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     rt = orc.track_cloud(track_case["corner_last"], track_case["surf_last"], track_case["corner_sharp"], track_case["surf_flat"],
                          np.array([0, 0, 0, 0, 0, 0, 1.0]))
     assert np.linalg.norm(tp[:3] - rt["pose"][:3]) < 1e-9 and np.linalg.norm(tp[3:] - rt["pose"][3:]) < 1e-9
+    # TransformToEnd facade (the tracker scans carry ring ids only: frac(intensity) = 0 -> s = 0, the point goes through T^-1)
+    und = np.fromfile(os.path.join(d, "out_undistorted.f32"), np.float32).reshape(-1, 4)
+    pu = np.array([0.35, -0.12, 0.02, 0.0, 0.0, 0.0130895956, 0.9999143276])
+    ref_u = orc.transform_to_end(track_case["scans"][1].points, pu, True)
+    assert und.shape == ref_u.shape
+    np.testing.assert_allclose(und[:, :3], ref_u[:, :3], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(und[:, 3], ref_u[:, 3])
     # the device-resident front end of the facade == the same calls through the Python binding
     import importlib
     mla = importlib.import_module("m-loam_amd")
