@@ -323,6 +323,15 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
  * less-flat surfs become the previous frame (call it after mlh_track_cloud, for the next frame). The scan must have been uploaded
  * with its intensity (ring id) field. */
 int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold);
+/* pcl::VoxelGrid<PointXYZI>::filter (PCL 1.8.0 filters/impl/voxel_grid.hpp) over a whole cloud: one centroid per occupied voxel, x, y, z
+ * AND intensity averaged, ascending voxel index; a grid of more than 2^31 cells returns the input unchanged ("leaf size is too small").
+ * Estimator::buildLocalMap / buildCalibMap thin the window's clouds with it (estimator/src/estimator/estimator.cpp:1124-1130,
+ * 1194-1203). out: same record layout as the input (fields other than x, y, z, intensity zeroed). Host or device buffers. */
+int mlh_voxel_grid(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, float leaf, void *out,
+                   int32_t *n_out, int mem);
+/* pcl::transformPointCloud(cloud, cloud, pose.T_.cast<float>()) in place (estimator.cpp:1185-1192: the window clouds moved into
+ * the pivot frame): x, y, z <- R p + t in single precision, the other fields kept. pose = [t(3), q(xyzw)]. */
+int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int n, const double pose[7], int mem);
 /* TransformToEnd (estimator/src/utility/utility.h:79-100; TransformToStart :55-77) over n records, in place: p_end = T^-1 T(s) p with
  * T(s) = (Identity.slerp(s, q), s t), s = (intensity - int(intensity)) / scan_period when b_distortion (the intensity field carries
  * ring id + time inside the sweep), else 1. f64 arithmetic, the intermediate and final points rounded to f32 as the reference's

@@ -100,6 +100,8 @@ def load_library():
     lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
     lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
     lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
+    lib.mlh_voxel_grid.argtypes = [vp, vp, ci, ci, ci, cf, vp, vp, ci]
+    lib.mlh_transform_point_cloud.argtypes = [vp, vp, ci, ci, vp, ci]
     lib.mlh_transform_to_end.argtypes = [vp, vp, ci, ci, ci, vp, ci, cf, ci]
     lib.mlh_scan_undistort.argtypes = [vp, vp, cf]
     lib.mlh_fuse_reset.argtypes = [vp]
@@ -139,7 +141,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -312,6 +314,22 @@ class Context:
     def track_set_from_scan(self, which, distance_sq_threshold=25.0):
         """which = 0: current frame <- this context's scan (sharp / flat); 1: previous frame <- (less sharp / thinned less flat)."""
         self._ck(self.lib.mlh_track_set_from_scan(self.h, which, distance_sq_threshold))
+
+    def voxel_grid(self, points4, leaf):
+        """pcl::VoxelGrid<PointXYZI> over rows [x y z intensity] -> centroids (all four fields averaged), ascending voxel index."""
+        ptr, stride, n, mem, keep = _src(points4)
+        assert stride == 16 and mem == MEM_HOST
+        out = np.zeros((n, 4), np.float32)
+        cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_voxel_grid(self.h, ptr, 16, n, 12, float(leaf), _p(out), C.byref(cnt), MEM_HOST))
+        return out[:cnt.value].copy()
+
+    def transform_point_cloud(self, points4, pose):
+        """pcl::transformPointCloud with the float 4x4 of `pose` (host array in, transformed copy out; intensity kept)."""
+        a = np.array(points4, np.float32, order="C", copy=True)
+        ps = np.ascontiguousarray(pose, np.float64).reshape(7)
+        self._ck(self.lib.mlh_transform_point_cloud(self.h, _p(a), a.shape[1] * 4, a.shape[0], _p(ps), MEM_HOST))
+        return a
 
     def transform_to_end(self, points4, pose, distortion=True, scan_period=0.1):
         """TransformToEnd over rows [x y z intensity] (host array in, transformed copy out)."""

@@ -470,6 +470,8 @@ int mlh_compound_pose_with_cov(const double pose_1[7], const double cov_1[36], c
     return MLH_OK;
 }
 
+struct FuseXf { float r[9], t[3], id; };     // a rigid transform in single precision (+ the LiDAR index of transformCloudFeature)
+
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem)
 {
@@ -477,6 +479,57 @@ int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, 
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return voxel_filter_run(ctx, points, stride_bytes, n, intensity_offset_bytes, cov_offset_bytes, trace_offset_bytes, leaf, trace_threshold,
                             out, n_out, mem);
+}
+
+// pcl::VoxelGrid<PointXYZI>::filter (PCL 1.8.0): one centroid per occupied voxel, every field averaged (CentroidPoint), output in
+// ascending voxel index -- Estimator::buildLocalMap / buildCalibMap thin the window's clouds with it (estimator.cpp:1124-1130, 1194-1203)
+int mlh_voxel_grid(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, float leaf, void *out, int32_t *n_out, int mem)
+{
+    if (!ctx || intensity_offset_bytes < 12) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return voxel_filter_run(ctx, points, stride_bytes, n, intensity_offset_bytes, -1, -1, leaf, 0.f, out, n_out, mem, nullptr, true, true);
+}
+
+// pcl::transformPointCloud(cloud, cloud, pose.T_.cast<float>()) in place: p' = R p + t in single precision (R rounded once from the
+// double rotation matrix of the unit quaternion), every other field kept -- the window clouds on their way into the pivot frame
+// (estimator.cpp:1185-1192)
+__global__ __launch_bounds__(256) void transform_cloud_kernel(unsigned char *p, int stride, int n, FuseXf xf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float *r = reinterpret_cast<float *>(p + size_t(i) * stride);
+    const float x = r[0], y = r[1], z = r[2];
+    r[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], x), __fmul_rn(xf.r[1], y)), __fmul_rn(xf.r[2], z)), xf.t[0]);
+    r[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], x), __fmul_rn(xf.r[4], y)), __fmul_rn(xf.r[5], z)), xf.t[1]);
+    r[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], x), __fmul_rn(xf.r[7], y)), __fmul_rn(xf.r[8], z)), xf.t[2]);
+}
+
+int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int n, const double pose[7], int mem)
+{
+    if (!ctx || !points || !pose || n < 0 || stride_bytes < 12 || (stride_bytes & 3)) return MLH_ERR_INVALID;
+    if (n == 0) return MLH_OK;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    const double tx = pose[0], ty = pose[1], tz = pose[2], qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
+    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+    FuseXf xf;
+    for (int i = 0; i < 9; ++i) xf.r[i] = float(R[i]);
+    xf.t[0] = float(tx); xf.t[1] = float(ty); xf.t[2] = float(tz); xf.id = 0.f;
+    unsigned char *dev = static_cast<unsigned char *>(points);
+    const size_t bytes = size_t(n) * stride_bytes;
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, ctx->tmp.ensure(bytes));
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, bytes, hipMemcpyHostToDevice, ctx->stream));
+        dev = ctx->tmp.as<unsigned char>();
+    }
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dev, stride_bytes, n, xf);
+    MLH_HIP(ctx, hipGetLastError());
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, hipMemcpyAsync(points, ctx->tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MLH_OK;
 }
 
 // ---------------------------------------------------------------- map
@@ -1106,7 +1159,6 @@ int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_per
 }
 
 // transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
-struct FuseXf { float r[9], t[3], id; };
 struct FuseArgs {
     const float4 *pts, *vox_out;
     const int *list1, *ring_offsets, *vox_off;

@@ -273,7 +273,8 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
                             const double pose_global[7], const double cov_global[36], const double *ext_poses, const double *ext_covs,
                             int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, void *out, int *n_out, int mem);
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
-                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds = nullptr, bool sync_total = true);
+                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds = nullptr, bool sync_total = true,
+                     bool centroid_all = false);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);

@@ -162,6 +162,7 @@ struct VoxArgs {
     float inv_leaf;
     int min_b[3], mul1, mul2;
     float trace_thr;
+    int centroid_all;   // plain branch as pcl::VoxelGrid<PointXYZI>: the intensity is averaged with the coordinates (CentroidPoint)
     int *vox_of;        // n: voxel index per point, then its output slot
     int *word_of;       // n: the point's occupancy word (kept so that the words can be cleared again)
     unsigned *mask;     // one occupancy bit per voxel of the dense grid
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
                 weight_total += w;
             } else {
                 mu[0] += q[u][0]; mu[1] += q[u][1]; mu[2] += q[u][2];
-                ity = inten[u];                       // the last member's intensity
+                ity = A.centroid_all ? ity + inten[u] : inten[u];     // averaged (pcl::VoxelGrid) / the last member's (VoxelGridCovarianceMLOAM)
                 ++cnt;
             }
         }
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
     } else {
         const float fc = float(cnt > 0 ? cnt : 1);
         ox[0] = mu[0] / fc; ox[1] = mu[1] / fc; ox[2] = mu[2] / fc;
+        if (A.centroid_all) ity = ity / fc;
     }
     if (A.stride >= 16 && A.intensity_off != 12 && A.cov_off != 12 && A.trace_off != 12) ox[3] = 1.0f;   // PCL_ADD_POINT4D padding
     if (has_i) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, 
 // known_bounds: the exact min/max of the points if the caller already has them (skips the bounds pass and its round trip).
 // sync_total = false (only with out_host == nullptr): the record count stays on the device (V.total[0]); *n_out is left at -1.
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
-                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds, bool sync_total)
+                     float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds, bool sync_total, bool centroid_all)
 {
     if (!points || n <= 0 || stride < 12 || (stride & 3) || !(leaf > 0.f) || !n_out) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
     // out_host == nullptr: the thinned records stay in ctx->vox.out (device) for the caller's next kernel
@@ -400,7 +402,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.cov_off = cov_off; A.trace_off = trace_off;
     A.inv_leaf = inv; A.min_b[0] = min_b[0]; A.min_b[1] = min_b[1]; A.min_b[2] = min_b[2];
     A.mul1 = div_b[0]; A.mul2 = div_b[0] * div_b[1];
-    A.trace_thr = trace_thr; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
+    A.trace_thr = trace_thr; A.centroid_all = centroid_all ? 1 : 0; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
     A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
     const int nbp = (n + 255) / 256;
     hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);

@@ -177,6 +177,18 @@ int main(int argc, char **argv)
             std::vector<int32_t> kept = {downsampleFusedScan(dev, MLH_SURF, 0.4f, pose_ext, true), downsampleFusedScan(dev, MLH_CORNER, 0.2f, pose_ext, true)};
             write_file(d + "out_fused_kept.i32", kept);
             std::printf("device-resident front end: track %.6f %.6f %.6f, fused features %d + %d\n", tp[0], tp[1], tp[2], kept[0], kept[1]);
+            // the odometry's window map: transformPointCloud + pcl::VoxelGrid
+            {
+                PointICloud moved, thin;
+                transformPointCloud(dev, c0, moved, pose_ext[1]);
+                VoxelGrid vg(dev);
+                vg.setLeafSize(0.3f, 0.3f, 0.3f);
+                vg.setInputCloud(moved);
+                vg.filter(thin);
+                std::vector<float> to;
+                for (const auto &q : thin.points) { to.push_back(q.x); to.push_back(q.y); to.push_back(q.z); to.push_back(q.intensity); }
+                write_file(d + "out_window_map.f32", to);
+            }
             // undistortion (DISTORTION = 1): TransformToEnd over a host cloud; the device-resident variant on the scan just extracted
             PointICloud und = c1;
             Pose pose_undist;

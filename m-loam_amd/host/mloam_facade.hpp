@@ -533,6 +533,38 @@ private:
     mlh_track_opts opts_;
 };
 
+// ------------------------------------------------------------------ the odometry's window map (estimator.cpp:1160-1203)
+// pcl::transformPointCloud(cloud_in, cloud_out, pose.T_.cast<float>())
+inline void transformPointCloud(Device &dev, const PointICloud &cloud_in, PointICloud &cloud_out, const Pose &pose)
+{
+    cloud_out = cloud_in;
+    if (cloud_out.size() == 0) return;
+    double p[7];
+    pose.toParam(p);
+    dev.check(mlh_transform_point_cloud(dev.ctx(), cloud_out.points.data(), (int)sizeof(PointI), (int)cloud_out.size(), p, MLH_MEM_HOST));
+}
+// pcl::VoxelGrid<PointI> with the reference's call sequence: setLeafSize / setInputCloud / filter
+class VoxelGrid {
+public:
+    explicit VoxelGrid(Device &dev) : dev_(dev) {}
+    void setLeafSize(float lx, float ly, float lz) { (void)ly; (void)lz; leaf_ = lx; }     // the reference only ever sets cubic leaves
+    void setInputCloud(const PointICloud &cloud) { input_ = &cloud; }
+    void filter(PointICloud &output)
+    {
+        if (!input_ || input_->size() == 0) { output.points.clear(); return; }
+        std::vector<PointI> out(input_->size());
+        int32_t n_out = 0;
+        dev_.check(mlh_voxel_grid(dev_.ctx(), input_->points.data(), (int)sizeof(PointI), (int)input_->size(), point_traits<PointI>::intensity_off, leaf_,
+                                  out.data(), &n_out, MLH_MEM_HOST));
+        out.resize(n_out);
+        output.points.swap(out);
+    }
+private:
+    Device &dev_;
+    const PointICloud *input_ = nullptr;
+    float leaf_ = 0.4f;
+};
+
 // ------------------------------------------------------------------ undistortion (utility.h:79-100, estimator.cpp:376-410)
 // TransformToEnd over a whole cloud (the reference loops `for (PointI &point : cloud) TransformToEnd(point, point, pose, true, SCAN_PERIOD)`)
 inline void TransformToEnd(Device &dev, PointICloud &cloud, const Pose &pose, const bool &b_distortion, const float &scan_period = 0.1f)

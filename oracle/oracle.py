@@ -341,6 +341,13 @@ def transform_cloud_feature(points4, ext_pose, lidar_idx):
     return out
 
 
+def transform_point_cloud(points4, pose7):
+    """pcl::transformPointCloud(cloud, cloud, pose.T_.cast<float>()) (estimator.cpp:1185-1192): float32 R p + t, other fields kept."""
+    out = transform_cloud_feature(points4, pose7, 0)
+    out[:, 3] = np.ascontiguousarray(points4, np.float32)[:, 3]
+    return out
+
+
 def transform_to_end(points4, pose7, distortion=True, scan_period=0.1):
     """TransformToEnd (utility.h:79-100) over rows [x y z intensity]; intensity = ring id + relative time inside the sweep."""
     pts = np.ascontiguousarray(points4, np.float32)

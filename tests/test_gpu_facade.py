@@ -89,6 +89,11 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     rt = orc.track_cloud(track_case["corner_last"], track_case["surf_last"], track_case["corner_sharp"], track_case["surf_flat"],
                          np.array([0, 0, 0, 0, 0, 0, 1.0]))
     assert np.linalg.norm(tp[:3] - rt["pose"][:3]) < 1e-9 and np.linalg.norm(tp[3:] - rt["pose"][3:]) < 1e-9
+    # window-map facade: pcl::transformPointCloud + pcl::VoxelGrid<PointI> with the reference's call sequence
+    wm = np.fromfile(os.path.join(d, "out_window_map.f32"), np.float32).reshape(-1, 4)
+    ref_wm = orc.voxel_grid(orc.transform_point_cloud(track_case["scans"][0].points, ext[1]), 0.3)
+    assert wm.shape == ref_wm.shape
+    np.testing.assert_allclose(wm, ref_wm, rtol=2e-6, atol=2e-6)
     # TransformToEnd facade (the tracker scans carry ring ids only: frac(intensity) = 0 -> s = 0, the point goes through T^-1)
     und = np.fromfile(os.path.join(d, "out_undistorted.f32"), np.float32).reshape(-1, 4)
     pu = np.array([0.35, -0.12, 0.02, 0.0, 0.0, 0.0130895956, 0.9999143276])

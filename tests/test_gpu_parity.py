@@ -833,3 +833,42 @@ def test_scan_undistort_on_device(mla, orc, case16):
             mla.Context(0).scan_undistort(pose)
     finally:
         c.close()
+
+
+def test_window_local_map_building_blocks(ctx, mla, orc, case16):
+    """Estimator::buildLocalMap (estimator.cpp:1160-1203) from its parts: every window frame's cloud into the pivot frame
+    (pcl::transformPointCloud with the float 4x4: bit for bit), the union thinned by pcl::VoxelGrid<PointXYZI> (same voxels in the
+    same order, centroids to f32 rounding of a differently ordered sum), indexed, matched."""
+    rng = np.random.default_rng(17)
+    base = np.zeros((len(case16["surf_map"]), 4), np.float32)
+    base[:, :3] = case16["surf_map"][:, :3]
+    frames, poses = [], []
+    for i in range(4):
+        sel = base[i::4].copy()
+        sel[:, 3] = rng.uniform(0, 16, len(sel)).astype(np.float32)
+        q = np.array([0.01 * i, -0.02, 0.03 * i, 1.0]); q /= np.linalg.norm(q)
+        poses.append(np.concatenate([[0.3 * i, -0.1 * i, 0.02], q]))
+        frames.append(sel)
+    moved_g = [ctx.transform_point_cloud(f, p) for f, p in zip(frames, poses)]
+    moved_r = [orc.transform_point_cloud(f, p) for f, p in zip(frames, poses)]
+    for g, r in zip(moved_g, moved_r):
+        np.testing.assert_array_equal(g, r)
+    union = np.concatenate(moved_g)
+    leaf = 0.4 * min(2.0, max(0.75, 1.0 / 192 * float(16 * 1 * 4)))          # the reference's ratio for N_SCANS 16, 1 LiDAR, window 4
+    ds_g = ctx.voxel_grid(union, leaf)
+    ds_r = orc.voxel_grid(union, leaf)
+    assert ds_g.shape == ds_r.shape and len(ds_g) < len(union)
+    np.testing.assert_allclose(ds_g, ds_r, rtol=2e-6, atol=2e-6)
+    assert np.mean(ds_g.view(np.uint32) == ds_r.view(np.uint32)) > 0.5
+    # the thinned cloud as the odometry local map: exact 5-NN through the same index the mapper uses
+    ctx.map_set(mla.SURF, np.ascontiguousarray(ds_g[:, :3]))
+    qm = ds_g[rng.integers(0, len(ds_g), 300), :3] + rng.normal(0, 0.1, (300, 3)).astype(np.float32)
+    idx, d2 = ctx.knn(mla.SURF, qm.astype(np.float32))
+    ridx, rd2 = orc.Map(np.ascontiguousarray(ds_g[:, :3])).knn(qm.astype(np.float32))
+    within = rd2 < 1.0
+    assert within.sum() > 100 and np.array_equal(idx[within], ridx[within])
+    # degenerate inputs
+    one = ctx.voxel_grid(union[:1], leaf)
+    np.testing.assert_array_equal(one, union[:1])
+    same = np.repeat(union[:1], 50, axis=0)
+    np.testing.assert_allclose(ctx.voxel_grid(same, leaf), union[:1], rtol=1e-6)
