@@ -470,8 +470,6 @@ int mlh_compound_pose_with_cov(const double pose_1[7], const double cov_1[36], c
     return MLH_OK;
 }
 
-struct FuseXf { float r[9], t[3], id; };     // a rigid transform in single precision (+ the LiDAR index of transformCloudFeature)
-
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem)
 {
@@ -490,32 +488,11 @@ int mlh_voxel_grid(mlh_ctx *ctx, const void *points, int stride_bytes, int n, in
     return voxel_filter_run(ctx, points, stride_bytes, n, intensity_offset_bytes, -1, -1, leaf, 0.f, out, n_out, mem, nullptr, true, true);
 }
 
-// pcl::transformPointCloud(cloud, cloud, pose.T_.cast<float>()) in place: p' = R p + t in single precision (R rounded once from the
-// double rotation matrix of the unit quaternion), every other field kept -- the window clouds on their way into the pivot frame
-// (estimator.cpp:1185-1192)
-__global__ __launch_bounds__(256) void transform_cloud_kernel(unsigned char *p, int stride, int n, FuseXf xf)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float *r = reinterpret_cast<float *>(p + size_t(i) * stride);
-    const float x = r[0], y = r[1], z = r[2];
-    r[0] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], x), __fmul_rn(xf.r[1], y)), __fmul_rn(xf.r[2], z)), xf.t[0]);
-    r[1] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], x), __fmul_rn(xf.r[4], y)), __fmul_rn(xf.r[5], z)), xf.t[1]);
-    r[2] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], x), __fmul_rn(xf.r[7], y)), __fmul_rn(xf.r[8], z)), xf.t[2]);
-}
-
 int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int n, const double pose[7], int mem)
 {
     if (!ctx || !points || !pose || n < 0 || stride_bytes < 12 || (stride_bytes & 3)) return MLH_ERR_INVALID;
     if (n == 0) return MLH_OK;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    const double tx = pose[0], ty = pose[1], tz = pose[2], qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
-    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
-                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
-                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
-    FuseXf xf;
-    for (int i = 0; i < 9; ++i) xf.r[i] = float(R[i]);
-    xf.t[0] = float(tx); xf.t[1] = float(ty); xf.t[2] = float(tz); xf.id = 0.f;
     unsigned char *dev = static_cast<unsigned char *>(points);
     const size_t bytes = size_t(n) * stride_bytes;
     if (mem == MLH_MEM_HOST) {
@@ -523,8 +500,7 @@ int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int 
         MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, bytes, hipMemcpyHostToDevice, ctx->stream));
         dev = ctx->tmp.as<unsigned char>();
     }
-    hipLaunchKernelGGL(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dev, stride_bytes, n, xf);
-    MLH_HIP(ctx, hipGetLastError());
+    { int rc = transform_cloud_launch(ctx, dev, stride_bytes, n, pose); if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; } }
     if (mem == MLH_MEM_HOST) {
         MLH_HIP(ctx, hipMemcpyAsync(points, ctx->tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1029,12 +1005,6 @@ int mlh_track_set_cur(mlh_ctx *ctx, int kind, const void *points, int stride_byt
     return MLH_OK;
 }
 
-__global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__restrict__ pts, const int *__restrict__ list, int n, float4 *__restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = pts[list[i]];
-}
-
 // the list sizes of the scan the context holds (and the thinned less-flat count once it exists): one host round trip per scan
 static int scan_totals(mlh_ctx *ctx, bool want_vox)
 {
@@ -1068,63 +1038,17 @@ int mlh_track_set_from_scan(mlh_ctx *ctx, int which, float distance_sq_threshold
     if (n_corner <= 0 || (which == 0 ? n_flat : n_vox) <= 0) return fail(ctx, MLH_ERR_STATE, "the scan produced no features of one kind");
     MLH_HIP(ctx, ctx->knn_q.ensure(sizeof(float4) * size_t(std::max(n_corner, n_flat))));     // gather scratch (not ctx->tmp: the staging calls may use that)
     float4 *g = ctx->knn_q.as<float4>();
-    hipLaunchKernelGGL(gather_points_kernel, dim3((n_corner + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[corner_list].as<int>(), n_corner, g);
+    gather_points_launch(ctx, sb.pts.as<float4>(), sb.lists[corner_list].as<int>(), n_corner, g);
     if (which == 0) {
         // nothing to wait for: every consumer of these buffers is a later launch on the same stream
         if ((rc = track_stage_cur(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE))) return rc;
-        hipLaunchKernelGGL(gather_points_kernel, dim3((n_flat + 255) / 256), dim3(256), 0, st, (const float4 *)sb.pts.as<float4>(), (const int *)sb.lists[2].as<int>(), n_flat, g);
+        gather_points_launch(ctx, sb.pts.as<float4>(), sb.lists[2].as<int>(), n_flat, g);
         return track_stage_cur(ctx, MLH_SURF, g, 16, n_flat, 12, MLH_MEM_DEVICE);
     }
     int bad[2] = {0, 0};
     if ((rc = track_stage_prev(ctx, MLH_CORNER, g, 16, n_corner, 12, MLH_MEM_DEVICE, distance_sq_threshold, &bad[MLH_CORNER]))) { (void)hipStreamSynchronize(st); return rc; }
     if ((rc = track_stage_prev(ctx, MLH_SURF, sb.vox_out.p, 16, n_vox, 12, MLH_MEM_DEVICE, distance_sq_threshold, &bad[MLH_SURF]))) { (void)hipStreamSynchronize(st); return rc; }
     return track_build_prev(ctx, 3, bad);      // both indices in one set of launches, one host round trip
-}
-
-// TransformToEnd (utility.h:79-100) in place over strided records: p^b = T^-1 T(s) p^c with s = frac(intensity) / scan_period when
-// b_distortion, else 1; T(s) = (slerp(s, q), s t) (Eigen 3.3 slerp from the identity), f64 math, the intermediate and the result
-// rounded to f32 exactly where the reference stores them into float points
-struct UndistArgs { unsigned char *p; int stride, n, intensity_off, b_distortion; float scan_period; double pose[7]; };
-__global__ __launch_bounds__(256) void transform_to_end_kernel(UndistArgs A)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.n) return;
-    float *rec = reinterpret_cast<float *>(A.p + size_t(i) * A.stride);
-    const float inten = *reinterpret_cast<const float *>(A.p + size_t(i) * A.stride + A.intensity_off);
-    double sI = 1.0;
-    if (A.b_distortion) sI = double((inten - float(int(inten))) / A.scan_period);
-    const q4 q{A.pose[3], A.pose[4], A.pose[5], A.pose[6]};
-    const d3 t{A.pose[0], A.pose[1], A.pose[2]};
-    // Identity.slerp(s, q)
-    const double one = 1.0 - 2.220446049250313e-16;
-    const double d = q.w, absD = fabs(d);
-    double scale0, scale1;
-    if (absD >= one) { scale0 = 1.0 - sI; scale1 = sI; }
-    else {
-        const double theta = acos(absD), sinTheta = sin(theta);
-        scale0 = sin((1.0 - sI) * theta) / sinTheta;
-        scale1 = sin(sI * theta) / sinTheta;
-    }
-    if (d < 0.0) scale1 = -scale1;
-    const q4 qs{scale0 * 0.0 + scale1 * q.x, scale0 * 0.0 + scale1 * q.y, scale0 * 0.0 + scale1 * q.z, scale0 * 1.0 + scale1 * q.w};
-    const d3 r = qrot(qs, d3{double(rec[0]), double(rec[1]), double(rec[2])});
-    const float ux = float(r.x + sI * t.x), uy = float(r.y + sI * t.y), uz = float(r.z + sI * t.z);     // un_point_tmp (a float point)
-    const double n2 = (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);
-    const q4 qi{-q.x / n2, -q.y / n2, -q.z / n2, q.w / n2};
-    const d3 e = qrot(qi, d3{double(ux) - t.x, double(uy) - t.y, double(uz) - t.z});
-    rec[0] = float(e.x); rec[1] = float(e.y); rec[2] = float(e.z);
-}
-
-static int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int intensity_off, const double pose[7], int b_distortion, float scan_period)
-{
-    if (n <= 0) return MLH_OK;
-    UndistArgs A;
-    A.p = static_cast<unsigned char *>(dev); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.b_distortion = b_distortion;
-    A.scan_period = scan_period;
-    for (int i = 0; i < 7; ++i) A.pose[i] = pose[i];
-    hipLaunchKernelGGL(transform_to_end_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A);
-    MLH_HIP(ctx, hipGetLastError());
-    return MLH_OK;
 }
 
 int mlh_transform_to_end(mlh_ctx *ctx, void *points, int stride_bytes, int n, int intensity_offset_bytes, const double pose[7], int b_distortion,
@@ -1158,62 +1082,6 @@ int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_per
     return transform_to_end_launch(ctx, sb.vox_out.p, 16, sb.h_totals[4], 12, pose_undist, 1, scan_period);
 }
 
-// transformCloudFeature (visualization.cpp:39-51): p' = R p + t in single precision, intensity <- LiDAR index
-struct FuseArgs {
-    const float4 *pts, *vox_out;
-    const int *list1, *ring_offsets, *vox_off;
-    int rb, re;                // rings [rb, re) of the scan
-    FuseXf xf;
-    float4 *out[2];            // fused surf / corner clouds
-    int *cnt;                  // their record counts
-    float *part;               // this append's partial bounds: [kind][FUSE_BLOCKS][6]
-};
-constexpr int FUSE_BLOCKS = 64;    // workgroups per kind: each leaves one partial bounding box of what it appended
-__global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
-{
-    __shared__ float lds[4][6];
-    const int kind = blockIdx.y;                       // 0: surf <- voxel-thinned less-flat, 1: corner <- less-sharp
-    const int b = kind == 0 ? A.vox_off[A.rb] : A.ring_offsets[A.rb * 4 + 1];
-    const int e = kind == 0 ? A.vox_off[A.re] : A.ring_offsets[A.re * 4 + 1];
-    const int base = A.cnt[kind];
-    const FuseXf &xf = A.xf;
-    float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < e - b; i += FUSE_BLOCKS * 256) {
-        const float4 p = kind == 0 ? A.vox_out[b + i] : A.pts[A.list1[b + i]];
-        float4 o;
-        // products and sums kept separate (no contraction) so that the result is one well-defined float32 expression
-        o.x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[0], p.x), __fmul_rn(xf.r[1], p.y)), __fmul_rn(xf.r[2], p.z)), xf.t[0]);
-        o.y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[3], p.x), __fmul_rn(xf.r[4], p.y)), __fmul_rn(xf.r[5], p.z)), xf.t[1]);
-        o.z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(xf.r[6], p.x), __fmul_rn(xf.r[7], p.y)), __fmul_rn(xf.r[8], p.z)), xf.t[2]);
-        o.w = xf.id;
-        A.out[kind][base + i] = o;
-        m[0] = fminf(m[0], o.x); m[1] = fminf(m[1], o.y); m[2] = fminf(m[2], o.z);
-        m[3] = fmaxf(m[3], o.x); m[4] = fmaxf(m[4], o.y); m[5] = fmaxf(m[5], o.z);
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { m[d] = fminf(m[d], __shfl_xor(m[d], off)); m[3 + d] = fmaxf(m[3 + d], __shfl_xor(m[3 + d], off)); }
-    }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int d = 0; d < 6; ++d) lds[threadIdx.x >> 6][d] = m[d];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int d = threadIdx.x;
-        float r = lds[0][d];
-        for (int w = 1; w < 4; ++w) r = d < 3 ? fminf(r, lds[w][d]) : fmaxf(r, lds[w][d]);
-        A.part[(kind * FUSE_BLOCKS + blockIdx.x) * 6 + d] = r;
-    }
-}
-// after the append (stream order): the counts move on
-__global__ void fuse_bump_kernel(const int *__restrict__ ring_offsets, const int *__restrict__ vox_off, int rb, int re, int *__restrict__ cnt)
-{
-    if (threadIdx.x == 0) cnt[0] += vox_off[re] - vox_off[rb];
-    if (threadIdx.x == 1) cnt[1] += ring_offsets[re * 4 + 1] - ring_offsets[rb * 4 + 1];
-}
-
 int mlh_fuse_reset(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;
@@ -1235,33 +1103,8 @@ int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     if (!sb.extracted || !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "mlh_extract_run and mlh_extract_voxel_run come first");
     if (ring_begin < 0 || ring_end > sb.n_rings || ring_begin >= ring_end) return fail(ctx, MLH_ERR_INVALID, "bad ring range");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
     if (!ctx->fused_cnt.p) { int rc = mlh_fuse_reset(ctx); if (rc) return rc; }
-    // rotation of the unit quaternion in double, rounded once to float: what Eigen::Matrix4f holds after `.cast<float>()`
-    const double tx = ext_pose[0], ty = ext_pose[1], tz = ext_pose[2], qx = ext_pose[3], qy = ext_pose[4], qz = ext_pose[5], qw = ext_pose[6];
-    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
-                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
-                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
-    FuseArgs A;
-    for (int i = 0; i < 9; ++i) A.xf.r[i] = float(R[i]);
-    A.xf.t[0] = float(tx); A.xf.t[1] = float(ty); A.xf.t[2] = float(tz);
-    A.xf.id = float(lidar_idx);
-    // the counts live on the device (no host round trip per scan); capacity follows a host-side upper bound: the scan's point count
-    for (int k = 0; k < 2; ++k) {
-        MLH_HIP(ctx, ctx->fused[k].grow(sizeof(float4) * (ctx->fused_bound[k] + size_t(sb.n)), sizeof(float4) * ctx->fused_bound[k], st));
-        ctx->fused_bound[k] += size_t(sb.n);
-        A.out[k] = ctx->fused[k].as<float4>();
-    }
-    A.pts = sb.pts.as<float4>(); A.vox_out = sb.vox_out.as<float4>(); A.list1 = sb.lists[1].as<int>();
-    A.ring_offsets = sb.ring_offsets.as<int>(); A.vox_off = sb.ring_vox.as<int>() + sb.n_rings;
-    A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>();
-    const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
-    MLH_HIP(ctx, ctx->fused_part.grow(sizeof(float) * part_floats * size_t(ctx->fused_parts + 1), sizeof(float) * part_floats * size_t(ctx->fused_parts), st));
-    A.part = ctx->fused_part.as<float>() + part_floats * size_t(ctx->fused_parts);
-    ++ctx->fused_parts;
-    hipLaunchKernelGGL(fuse_append_kernel, dim3(FUSE_BLOCKS, 2), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(fuse_bump_kernel, dim3(1), dim3(64), 0, st, A.ring_offsets, A.vox_off, ring_begin, ring_end, A.cnt);
-    MLH_HIP(ctx, hipGetLastError());
+    { int rc = fuse_append_launch(ctx, ring_begin, ring_end, lidar_idx, ext_pose); if (rc) return rc; }
     ctx->fused_dirty = true;
     return MLH_OK;
 }

@@ -164,6 +164,7 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     int n = 0, max_frame = 0, max_ext = 0;
 };
 
+constexpr int FUSE_BLOCKS = 64;           // workgroups per kind of the fusion kernel: each leaves one partial bounding box of what it appended (frontend.hip)
 constexpr int TRACK_SHELLS = 4;          // the tracker's index cells are 1/4 of its acceptance radius (track.hip: nearest_in_radius)
 constexpr int TRACK_RING_SLOTS = 258;   // ring ids 0..255 (+ the slots the walks' upper bound can reach)
 struct TrackSet {   // scan-to-scan odometry (track.hip): previous frame's clouds + indices, current frame's features
@@ -275,6 +276,11 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
 int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int cov_off, int trace_off, float leaf,
                      float trace_thr, void *out_host, int *n_out, int mem, const float *known_bounds = nullptr, bool sync_total = true,
                      bool centroid_all = false);
+// frontend.hip
+void gather_points_launch(mlh_ctx *ctx, const float4 *pts, const int *list, int n, float4 *out);
+int transform_cloud_launch(mlh_ctx *ctx, void *dev, int stride, int n, const double pose[7]);
+int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int intensity_off, const double pose[7], int b_distortion, float scan_period);
+int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);
