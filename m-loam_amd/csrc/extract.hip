@@ -5,13 +5,13 @@
 //                     f32 sum in the reference's exact left-to-right order, no FMA (-ffp-contract=off)
 //   label_kernel      cpp:152-265  one workgroup (six wavefronts) per ring: ring xyz + curvature + picked flags resident in LDS;
 //                     wavefront j sorts sector j in registers with a wave-local bitonic network on 64-bit (curvature, index)
-//                     keys (lane-xor shuffles, no barriers); then wave 0 runs the
-//                     greedy edge / flat walks: 64 sorted candidates are tested per batch with a ballot, the first eligible
-//                     one is taken, its +-5 neighbour suppression comes from precomputed gap bits (two broadcast LDS words),
-//                     and the batch's other candidates are retired in registers. The walk is sequential over sectors
-//                     because suppression marks cross sector boundaries (cpp:201, 212).
-//   offsets_kernel    exclusive scan of the per-ring list sizes (emission order = ring asc, sector asc, pick order)
-//   emit_kernel       writes the four index lists; less-flat = positions with label <= 0 (cpp:258-264), stream-compacted.
+//                     keys (lane-xor shuffles, no barriers); then the greedy edge / flat walks: 64 sorted candidates are tested
+//                     per batch with a ballot, the first eligible one is taken, its +-5 neighbour suppression extent comes from a
+//                     table built from gap bits, and the batch's other candidates are retired in registers. The reference walks
+//                     the sectors in order because suppression marks cross sector bounds (cpp:201, 212); here the six sectors
+//                     walk speculatively at once and a sector is re-walked only when a predecessor's marks hit one of its picks.
+//   emit_kernel       writes the four index lists (emission order = ring asc, sector asc, pick order; every ring's workgroup sums
+//                     the list sizes of the rings before it); less-flat = positions with label <= 0 (cpp:258-264), stream-compacted.
 #include "ctx.hpp"
 #include "sort_dev.hpp"
 #include <algorithm>
@@ -367,29 +367,10 @@ extern "C" int mlh_debug_stage_clock_label(unsigned long long *out, int n_words)
 namespace mlh {
 #endif
 
-// exclusive scan over rings of the 4 list sizes; single workgroup. ring_offsets has n_rings + 1 rows: the last one = the totals.
-// The counts are staged in LDS by the whole workgroup so that the four serial scans do not wait on one memory round trip per ring.
-__global__ __launch_bounds__(256) void offsets_kernel(const int *__restrict__ ring_counts, int n_rings, int *__restrict__ ring_offsets,
-                                                      int *__restrict__ totals)
-{
-    __shared__ int s_c[256 * 4];
-    int carry = 0;                                   // threads 0..3: running total of list threadIdx.x
-    for (int r0 = 0; r0 < n_rings; r0 += 256) {
-        const int rows = min(256, n_rings - r0);
-        for (int t = threadIdx.x; t < rows * 4; t += 256) s_c[t] = ring_counts[r0 * 4 + t];
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            for (int r = 0; r < rows; ++r) { const int c = s_c[r * 4 + threadIdx.x]; s_c[r * 4 + threadIdx.x] = carry; carry += c; }
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < rows * 4; t += 256) ring_offsets[r0 * 4 + t] = s_c[t];
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) { totals[threadIdx.x] = carry; ring_offsets[n_rings * 4 + threadIdx.x] = carry; }
-}
-
 struct EmitArgs {
-    const int *start, *end, *label, *stage, *ring_counts, *ring_offsets;
+    const int *start, *end, *label, *stage, *ring_counts;
+    int *ring_offsets, *totals;       // written here: [n_rings + 1][4] exclusive offsets (last row = totals) and the 4 totals
+    int n_rings;
     int *list0, *list1, *list2, *list3;
 };
 
@@ -397,8 +378,34 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs A)
 {
     __shared__ int s_w[4];
     __shared__ int s_base;
+    __shared__ int s_off[4];
     const int ring = blockIdx.x;
-    const int *rc = A.ring_counts + ring * 4, *ro = A.ring_offsets + ring * 4;
+    // the ring's offsets in the four output lists = the counts of the rings before it, summed right here by one wavefront (a few
+    // dozen words): no separate scan launch between the label kernel and this one
+    if (threadIdx.x < 64) {
+        int acc[4] = {0, 0, 0, 0};
+        for (int r = threadIdx.x; r < ring; r += 64) {
+            const int4 c = reinterpret_cast<const int4 *>(A.ring_counts)[r];
+            acc[0] += c.x; acc[1] += c.y; acc[2] += c.z; acc[3] += c.w;
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[l] += __shfl_xor(acc[l], off);
+        }
+        if (threadIdx.x < 4) {
+            const int v = threadIdx.x == 0 ? acc[0] : (threadIdx.x == 1 ? acc[1] : (threadIdx.x == 2 ? acc[2] : acc[3]));
+            s_off[threadIdx.x] = v;
+            A.ring_offsets[ring * 4 + threadIdx.x] = v;
+            if (ring == A.n_rings - 1) {
+                const int tot = v + A.ring_counts[ring * 4 + threadIdx.x];
+                A.ring_offsets[A.n_rings * 4 + threadIdx.x] = tot;
+                A.totals[threadIdx.x] = tot;
+            }
+        }
+    }
+    __syncthreads();
+    const int *rc = A.ring_counts + ring * 4, *ro = s_off;
     const int *st = A.stage + ring * STAGE_STRIDE;
     for (int t = threadIdx.x; t < rc[0]; t += 256) A.list0[ro[0] + t] = st[t];
     for (int t = threadIdx.x; t < rc[1]; t += 256) A.list1[ro[1] + t] = st[STAGE_SHARP + t];
@@ -462,10 +469,9 @@ int extract_run(mlh_ctx *ctx)
     la.n = n; la.max_span = max_span; la.sort_p = P;
     if (P > 2048) return fail(ctx, MLH_ERR_UNSUPPORTED, "sector longer than 2048 points");
     hipLaunchKernelGGL(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, st, sb.ring_counts.as<int>(), R, sb.ring_offsets.as<int>(), sb.totals.as<int>());
     EmitArgs ea;
     ea.start = sb.start.as<int>(); ea.end = sb.end.as<int>(); ea.label = sb.label.as<int>(); ea.stage = sb.stage.as<int>();
-    ea.ring_counts = sb.ring_counts.as<int>(); ea.ring_offsets = sb.ring_offsets.as<int>();
+    ea.ring_counts = sb.ring_counts.as<int>(); ea.ring_offsets = sb.ring_offsets.as<int>(); ea.totals = sb.totals.as<int>(); ea.n_rings = R;
     ea.list0 = sb.lists[0].as<int>(); ea.list1 = sb.lists[1].as<int>(); ea.list2 = sb.lists[2].as<int>(); ea.list3 = sb.lists[3].as<int>();
     hipLaunchKernelGGL(emit_kernel, dim3(R), dim3(256), 0, st, ea);
     prof_end(ctx, MLH_K_EXTRACT);
