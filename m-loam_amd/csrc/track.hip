@@ -368,7 +368,8 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
                 }
             }
             double sq = 0.0;
-            for (int r = 0; r < rows; ++r) sq += res[r] * res[r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) if (r < rows) sq += res[r] * res[r];     // static indices: res / J stay in registers (a loop over `rows` sends them to scratch)
             double rho0 = sq, rho1 = 1.0;
             if (P.huber_delta > 0.0) {
                 const double b = P.huber_delta * P.huber_delta;
@@ -379,7 +380,9 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
                 }
             }
             const double sc = sqrt(rho1);
-            for (int r = 0; r < rows; ++r) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r >= rows) break;
                 double Jr[6];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) Jr[i] = J[r][i] * sc;
