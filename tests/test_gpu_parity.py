@@ -872,3 +872,50 @@ def test_window_local_map_building_blocks(ctx, mla, orc, case16):
     np.testing.assert_array_equal(one, union[:1])
     same = np.repeat(union[:1], 50, axis=0)
     np.testing.assert_allclose(ctx.voxel_grid(same, leaf), union[:1], rtol=1e-6)
+
+
+def test_full_size_front_end_properties(mla, synth):
+    """BASELINE config 2 sizes, front-end rows, properties that need no oracle: undistortion with the identity motion changes nothing
+    (bit for bit); fusing with the identity extrinsic reproduces the extractor's clouds; the joint 128-ring scan gives the per-LiDAR
+    lists back to back; pcl::VoxelGrid is idempotent (a thinned cloud has one point per voxel: thinning it again returns it bit for
+    bit); the device-resident frame is deterministic."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["500k"])
+        gt = synth.gt_body_pose()
+        scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], 64, seed=7 + i) for i in range(2)]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    c = mla.Context(0)
+    try:
+        s = scans[0]
+        c.scan_upload(s.points, s.scan_start, s.scan_end); c.extract_run(); ex = c.extract_fetch(); lf = c.extract_voxel(0.2)
+        c.scan_undistort(ident)                                    # s = frac(intensity) / period, identity motion: T^-1 T(s) = I
+        c.fuse_reset(); c.fuse_add_scan(0, ident)
+        for kind, ref in ((mla.SURF, lf), (mla.CORNER, s.points[ex["less_sharp"]])):
+            dc = c.fused_cloud(kind)
+            got = _device_to_host(dc.ptr, dc.n * 16).view(np.float32).reshape(-1, 4)
+            np.testing.assert_array_equal(got[:, :3], ref[:, :3])
+            assert not got[:, 3].any()
+        # pcl::VoxelGrid idempotence on the thinned less-flat cloud of the whole scan (per ring it was thinned at 0.2; here at 0.4)
+        once = c.voxel_grid(lf, 0.4)
+        twice = c.voxel_grid(once, 0.4)
+        assert len(once) < len(lf)
+        np.testing.assert_array_equal(twice, once)
+        # joint scan == per-LiDAR scans back to back, and the frame twice gives the same bits
+        pts = np.concatenate([x.points for x in scans]); off = len(scans[0].points)
+        ss = np.concatenate([scans[0].scan_start, scans[1].scan_start + off]).astype(np.int32)
+        se = np.concatenate([scans[0].scan_end, scans[1].scan_end + off]).astype(np.int32)
+        runs = []
+        for _ in range(2):
+            c.scan_upload(pts, ss, se); c.extract_run(); c.extract_voxel_run(0.2)
+            c.fuse_reset()
+            c.fuse_add_rings(0, 64, 0, ident); c.fuse_add_rings(64, 128, 1, ident)
+            runs.append([_device_to_host(c.fused_cloud(k).ptr, c.fused_cloud(k).n * 16).copy() for k in (mla.SURF, mla.CORNER)])
+        assert all(np.array_equal(a, b) for a, b in zip(*runs))
+        exj = c.extract_fetch()
+        c.scan_upload(scans[1].points, scans[1].scan_start, scans[1].scan_end); c.extract_run(); ex1 = c.extract_fetch()
+        for key in ("sharp", "less_sharp", "flat"):
+            assert np.array_equal(exj[key], np.concatenate([ex[key], ex1[key] + off])), key
+    finally:
+        c.close()
