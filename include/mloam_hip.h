@@ -121,6 +121,14 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
 int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
                                 float leaf, const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
                                 int with_ua, double trace_threshold, float *features_out, int32_t *n_features);
+/* The same for both feature kinds in one call (the mapper thins the surf and the corner cloud back to back, cpp:359-368). When both
+ * clouds are the context's fused clouds (mlh_fused_cloud) they run through ONE thinning pipeline -- half the dependent launches, one
+ * host round trip; other inputs take the two single calls. Records of both clouds share stride / intensity offset / memory kind;
+ * afterwards both feature sets are staged exactly as two single calls leave them. */
+int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                                     int intensity_offset_bytes, int mem, float leaf_surf, float leaf_corner, const double *ext_poses,
+                                     const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,
+                                     int32_t *n_surf_features, int32_t *n_corner_features);
 
 /* ---------------------------------------------------------------- (f1) covariance-aware voxel thinning
  * replaces pcl::VoxelGridCovarianceMLOAM<PointT>::filter (mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp:68-457),

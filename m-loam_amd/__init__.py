@@ -100,6 +100,7 @@ def load_library():
     lib.mlh_track_set_prev.argtypes = [vp, ci, vp, ci, ci, ci, ci, cf]
     lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
     lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
+    lib.mlh_downsample_current_scan_pair.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, cf, cf, vp, vp, ci, vp, ci, C.c_double, vp, vp]
     lib.mlh_voxel_grid.argtypes = [vp, vp, ci, ci, ci, cf, vp, vp, ci]
     lib.mlh_transform_point_cloud.argtypes = [vp, vp, ci, ci, vp, ci]
     lib.mlh_transform_to_end.argtypes = [vp, vp, ci, ci, ci, vp, ci, cf, ci]
@@ -141,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
@@ -409,6 +410,21 @@ class Context:
         self._m = getattr(self, "_m", {})
         self._m[kind] = cnt.value
         return out[:cnt.value].copy() if fetch else cnt.value
+
+    def downsample_current_scan_pair(self, surf4, corner4, leaf_surf, leaf_corner, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6):
+        """downsampleCurrentScan for both kinds in one call (one thinning pipeline for the two fused clouds) -> (n_surf_features, n_corner_features)."""
+        ps, ss, ns, ms, ks = _src(surf4)
+        pc, sc, nc, mc, kc = _src(corner4)
+        assert ss == sc and ms == mc
+        ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7)
+        ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
+        cm = np.ascontiguousarray(cov_measurement, np.float64).reshape(9)
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mlh_downsample_current_scan_pair(self.h, ps, ns, pc, nc, ss, 12, ms, float(leaf_surf), float(leaf_corner), _p(ep), _p(ec), len(ep), _p(cm),
+                                                           int(bool(with_ua)), float(trace_threshold), C.byref(a), C.byref(b)))
+        self._m = getattr(self, "_m", {})
+        self._m[SURF], self._m[CORNER] = a.value, b.value
+        return a.value, b.value
 
     def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
         """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""

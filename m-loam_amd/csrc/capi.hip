@@ -661,6 +661,45 @@ int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int 
     return MLH_OK;
 }
 
+// downsampleCurrentScan for BOTH feature kinds (lidar_mapper_keyframe.cpp:359-368 thins the surf and the corner cloud back to back).
+// When both clouds are this context's fused clouds (device-resident, bounding boxes known) they go through ONE thinning pipeline --
+// the chains are dispatch-bound, so one chain for both halves the time; otherwise the two single calls are made.
+int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                                     int intensity_offset_bytes, int mem, float leaf_surf, float leaf_corner, const double *ext_poses, const double *ext_covs,
+                                     int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold, int32_t *n_surf_features,
+                                     int32_t *n_corner_features)
+{
+    if (!ctx || !n_surf_features || !n_corner_features) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    const bool fused_pair = mem == MLH_MEM_DEVICE && !ctx->fused_dirty && stride_bytes == 16 && intensity_offset_bytes == 12 && n_surf > 0 && n_corner > 0 &&
+                            surf_points == ctx->fused[MLH_SURF].p && n_surf == ctx->fused_n[MLH_SURF] &&
+                            corner_points == ctx->fused[MLH_CORNER].p && n_corner == ctx->fused_n[MLH_CORNER];
+    if (fused_pair) {
+        for (int k = 0; k < 2; ++k) { ctx->feat[k].matched = false; ctx->feat[k].m = 0; }
+        int m[2] = {0, 0};
+        int rc = downsample_current_scan_pair_run(ctx, surf_points, n_surf, ctx->fused_minmax[MLH_SURF], leaf_surf, corner_points, n_corner,
+                                                  ctx->fused_minmax[MLH_CORNER], leaf_corner, stride_bytes, intensity_offset_bytes, ext_poses, ext_covs, n_lidar,
+                                                  cov_measurement, with_ua, trace_threshold, &m[0], &m[1]);
+        if (rc == MLH_OK) {
+            for (int k = 0; k < 2; ++k) {
+                FeatSet &f = ctx->feat[k];
+                f.m = m[k]; f.n_blocks = 1; f.blk_start[0] = 0; f.blk_real[0] = m[k];
+                for (int b = 1; b <= 8; ++b) f.blk_start[b] = m[k];
+                f.has_cov = true;
+            }
+            *n_surf_features = m[0];
+            *n_corner_features = m[1];
+            return MLH_OK;
+        }
+        if (rc != MLH_ERR_UNSUPPORTED) return rc;            // a grid too large for the shared index space: one by one below
+    }
+    int rc = mlh_downsample_current_scan(ctx, MLH_SURF, surf_points, stride_bytes, n_surf, intensity_offset_bytes, mem, leaf_surf, ext_poses, ext_covs, n_lidar,
+                                         cov_measurement, with_ua, trace_threshold, nullptr, n_surf_features);
+    if (rc) return rc;
+    return mlh_downsample_current_scan(ctx, MLH_CORNER, corner_points, stride_bytes, n_corner, intensity_offset_bytes, mem, leaf_corner, ext_poses, ext_covs, n_lidar,
+                                       cov_measurement, with_ua, trace_threshold, nullptr, n_corner_features);
+}
+
 // ---------------------------------------------------------------- host-driven match / linearise
 static int fetch_dense_and_reduced(mlh_ctx *ctx, int kind, bool want_corr, uint8_t *valid, double *coeffs, double *r, double *J,
                                    double *JtJ, double *Jtr, double *cost, int32_t *n_valid)

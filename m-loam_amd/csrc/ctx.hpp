@@ -281,6 +281,11 @@ void gather_points_launch(mlh_ctx *ctx, const float4 *pts, const int *list, int 
 int transform_cloud_launch(mlh_ctx *ctx, void *dev, int stride, int n, const double pose[7]);
 int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int intensity_off, const double pose[7], int b_distortion, float scan_period);
 int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);
+int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds0[6], float leaf0, const void *src1, int n1, const float bounds1[6],
+                      float leaf1, int stride, int intensity_off, int *first_voxels_word);
+int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,
+                                     const float bounds_corner[6], float leaf_corner, int stride, int intensity_off, const double *ext_poses, const double *ext_covs,
+                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);

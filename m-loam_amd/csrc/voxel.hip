@@ -544,4 +544,79 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
     return MLH_OK;
 }
 
+// features_from_kept for the two-cloud pipeline: kept record i belongs to the first cloud when its (voxel) position i lies before
+// first_records = wpre[first_word]; the kinds' feature sets are filled side by side and their counts left in counts[0..1]
+__global__ __launch_bounds__(256) void features_from_kept_pair_kernel(const unsigned char *__restrict__ recs, int stride, int intensity_off, int n,
+                                                                       const int *__restrict__ n_records, const int *__restrict__ wpre, int first_word,
+                                                                       const int *__restrict__ keep, const int *__restrict__ slot, const int *__restrict__ kept_total,
+                                                                       const float *__restrict__ cov6, float4 *__restrict__ pts0, float4 *__restrict__ covd0,
+                                                                       float4 *__restrict__ pts1, float4 *__restrict__ covd1, int *__restrict__ counts)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int first_records = wpre[first_word];                  // records (occupied voxels) of the first cloud
+    const int total_records = *n_records;
+    // kept records of the first cloud = exclusive scan of the keep flags at position first_records
+    const int first_kept = first_records < total_records ? slot[first_records] : *kept_total;
+    if (i == 0) { counts[0] = first_kept; counts[1] = *kept_total - first_kept; }
+    if (i >= n || i >= total_records || !keep[i]) return;
+    const float *r = reinterpret_cast<const float *>(recs + size_t(i) * stride);
+    const float inten = intensity_off >= 0 ? *reinterpret_cast<const float *>(recs + size_t(i) * stride + intensity_off) : 0.f;
+    const float *c = cov6 + size_t(i) * 6;
+    const bool second = i >= first_records;
+    const int s = second ? slot[i] - first_kept : slot[i];
+    (second ? pts1 : pts0)[s] = make_float4(r[0], r[1], r[2], inten);
+    (second ? covd1 : covd0)[s] = make_float4(c[0], c[3], c[5], 0.f);
+}
+
+// downsampleCurrentScan for the surf AND the corner cloud in one set of launches (device-resident clouds with known bounding boxes:
+// the fused clouds). Same results as two downsample_current_scan_run calls.
+int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,
+                                     const float bounds_corner[6], float leaf_corner, int stride, int intensity_off, const double *ext_poses, const double *ext_covs,
+                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out)
+{
+    if (n_lidar <= 0 || n_lidar > 16 || !ext_poses || (with_ua && (!ext_covs || !cov_meas))) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    hipStream_t st = ctx->stream;
+    VoxBuf &V = ctx->vox;
+    const int n = n_surf + n_corner;
+    MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * size_t(n_lidar) * 43 + sizeof(float) * 6 * size_t(n) + 64));
+    double *d_ext = ctx->uct_buf.as<double>();
+    double *d_cov = d_ext + size_t(n_lidar) * 7;
+    float *d_c6 = reinterpret_cast<float *>(d_cov + size_t(n_lidar) * 36);
+    std::vector<double> h_ec(size_t(n_lidar) * 43, 0.0);                 // extrinsics + covariances in one upload (the final wait covers it)
+    for (int i = 0; i < 7 * n_lidar; ++i) h_ec[i] = ext_poses[i];
+    if (ext_covs) for (int i = 0; i < 36 * n_lidar; ++i) h_ec[size_t(n_lidar) * 7 + i] = ext_covs[i];
+    MLH_HIP(ctx, hipMemcpyAsync(d_ext, h_ec.data(), sizeof(double) * h_ec.size(), hipMemcpyHostToDevice, st));
+    int first_word = 0;
+    int rc = voxel_filter_run2(ctx, surf, n_surf, bounds_surf, leaf_surf, corner, n_corner, bounds_corner, leaf_corner, stride, intensity_off, &first_word);
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
+    MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n + 1)));
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 2)));
+    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 4));
+    UctArgs A;
+    A.src = V.out.as<unsigned char>(); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.ext = d_ext; A.ext_cov = d_cov; A.n_lidar = n_lidar;
+    for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
+    A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = V.leader.as<int>();
+    A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = with_ua ? 1 : 0;
+    A.n_dev = V.total.as<int>();
+    A.keep2 = V.vox_of.as<int>();
+    for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>() + 1))) { (void)hipStreamSynchronize(st); return rc; }
+    FeatSet &f0 = ctx->feat[MLH_SURF], &f1 = ctx->feat[MLH_CORNER];
+    MLH_HIP(ctx, f0.pts.ensure(sizeof(float4) * size_t(n_surf))); MLH_HIP(ctx, f0.covd.ensure(sizeof(float4) * size_t(n_surf)));
+    MLH_HIP(ctx, f1.pts.ensure(sizeof(float4) * size_t(n_corner))); MLH_HIP(ctx, f1.covd.ensure(sizeof(float4) * size_t(n_corner)));
+    hipLaunchKernelGGL(features_from_kept_pair_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
+                       (const int *)V.total.as<int>(), (const int *)V.wpre.as<int>(), first_word, (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(),
+                       (const int *)(V.total.as<int>() + 1), (const float *)d_c6, f0.pts.as<float4>(), f0.covd.as<float4>(), f1.pts.as<float4>(), f1.covd.as<float4>(),
+                       V.total.as<int>() + 2);
+    MLH_HIP(ctx, hipGetLastError());
+    int counts[2] = {0, 0};
+    MLH_HIP(ctx, hipMemcpyAsync(counts, V.total.as<int>() + 2, sizeof(counts), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    *n_surf_out = counts[0];
+    *n_corner_out = counts[1];
+    return MLH_OK;
+}
+
 }  // namespace mlh

@@ -161,6 +161,12 @@ struct VoxArgs {
     int stride, n, intensity_off, cov_off, trace_off;
     float inv_leaf;
     int min_b[3], mul1, mul2;
+    // optional second cloud thinned in the same launches (points n0 .. n-1 come from src1 and live in their own grid, whose voxels
+    // are numbered behind the first grid's: output = the first cloud's voxels, then the second's). n0 = n: no second cloud.
+    const unsigned char *src1;
+    int n0, cell_off1;
+    float inv_leaf1;
+    int min_b1[3], mul1_1, mul2_1;
     float trace_thr;
     int centroid_all;   // plain branch as pcl::VoxelGrid<PointXYZI>: the intensity is averaged with the coordinates (CentroidPoint)
     int *vox_of;        // n: voxel index per point, then its output slot
@@ -174,17 +180,29 @@ struct VoxArgs {
     unsigned char *out; // n_out records (same layout as the input)
 };
 
-__device__ __forceinline__ const float *vrec(const VoxArgs &A, int i) { return reinterpret_cast<const float *>(A.src + size_t(i) * A.stride); }
+__device__ __forceinline__ const unsigned char *vrec_bytes(const VoxArgs &A, int i)
+{
+    return i < A.n0 ? A.src + size_t(i) * A.stride : A.src1 + size_t(i - A.n0) * A.stride;
+}
+__device__ __forceinline__ const float *vrec(const VoxArgs &A, int i) { return reinterpret_cast<const float *>(vrec_bytes(A, i)); }
 
 __global__ __launch_bounds__(256) void vox_mark_kernel(VoxArgs A)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= A.n) return;
     const float *p = vrec(A, i);
-    const int ijk0 = int(floorf(p[0] * A.inv_leaf) - float(A.min_b[0]));
-    const int ijk1 = int(floorf(p[1] * A.inv_leaf) - float(A.min_b[1]));
-    const int ijk2 = int(floorf(p[2] * A.inv_leaf) - float(A.min_b[2]));
-    const int v = ijk0 + ijk1 * A.mul1 + ijk2 * A.mul2;
+    int v;
+    if (i < A.n0) {
+        const int ijk0 = int(floorf(p[0] * A.inv_leaf) - float(A.min_b[0]));
+        const int ijk1 = int(floorf(p[1] * A.inv_leaf) - float(A.min_b[1]));
+        const int ijk2 = int(floorf(p[2] * A.inv_leaf) - float(A.min_b[2]));
+        v = ijk0 + ijk1 * A.mul1 + ijk2 * A.mul2;
+    } else {
+        const int ijk0 = int(floorf(p[0] * A.inv_leaf1) - float(A.min_b1[0]));
+        const int ijk1 = int(floorf(p[1] * A.inv_leaf1) - float(A.min_b1[1]));
+        const int ijk2 = int(floorf(p[2] * A.inv_leaf1) - float(A.min_b1[2]));
+        v = A.cell_off1 + ijk0 + ijk1 * A.mul1_1 + ijk2 * A.mul2_1;
+    }
     A.vox_of[i] = v;
     // consecutive points of a scan line mostly share their voxel: one atomic per run of equal voxels inside the wavefront
     const int prev = __shfl_up(v, 1);
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
         float q[VAG][3], inten[VAG], c[VAG][6];
 #pragma unroll
         for (int u = 0; u < VAG; ++u) {
-            const unsigned char *rec = A.src + size_t(id[u]) * A.stride;
+            const unsigned char *rec = vrec_bytes(A, id[u]);
             const float *f = reinterpret_cast<const float *>(rec);
             q[u][0] = f[0]; q[u][1] = f[1]; q[u][2] = f[2];
             inten[u] = has_i ? *reinterpret_cast<const float *>(rec + A.intensity_off) : 0.f;
@@ -400,6 +418,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     MLH_HIP(ctx, V.sums.ensure(sizeof(int) * size_t(std::max(nbw, (n + VS_CHUNK - 1) / VS_CHUNK) + 1)));
     VoxArgs A;
     A.src = src; A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.cov_off = cov_off; A.trace_off = trace_off;
+    A.src1 = nullptr; A.n0 = n; A.cell_off1 = 0; A.inv_leaf1 = 0.f; A.min_b1[0] = A.min_b1[1] = A.min_b1[2] = 0; A.mul1_1 = A.mul2_1 = 0;
     A.inv_leaf = inv; A.min_b[0] = min_b[0]; A.min_b[1] = min_b[1]; A.min_b[2] = min_b[2];
     A.mul1 = div_b[0]; A.mul2 = div_b[0] * div_b[1];
     A.trace_thr = trace_thr; A.centroid_all = centroid_all ? 1 : 0; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
@@ -424,6 +443,76 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
     }
+    return MLH_OK;
+}
+
+// Two device-resident clouds of the same record layout thinned (plain branch) in ONE set of launches: the second cloud's voxels are
+// numbered behind the first grid's, so the output holds the first cloud's centroids, then the second's, each in ascending voxel
+// index -- exactly what two separate calls produce, at half the launches (these pipelines are dispatch-bound). bounds*: the exact
+// min / max of each cloud. On return (nothing waited for): V.out = the records, V.total[0] = their number, *first_voxels_word =
+// the word of V.wpre that holds the number of records of the first cloud. Returns MLH_ERR_UNSUPPORTED when a grid is too large
+// for the shared index space (the caller then thins the clouds one by one).
+int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds0[6], float leaf0, const void *src1, int n1, const float bounds1[6],
+                      float leaf1, int stride, int intensity_off, int *first_voxels_word)
+{
+    if (!src0 || !src1 || n0 <= 0 || n1 <= 0 || stride < 12 || (stride & 3) || !(leaf0 > 0.f) || !(leaf1 > 0.f)) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    hipStream_t st = ctx->stream;
+    VoxBuf &V = ctx->vox;
+    const float *hb[2] = {bounds0, bounds1};
+    const float inv[2] = {1.0f / leaf0, 1.0f / leaf1};
+    int min_b[2][3], div_b[2][3];
+    long long ncell[2];
+    for (int k = 0; k < 2; ++k) {
+        long long ext[3];
+        for (int d = 0; d < 3; ++d) {
+            if (!std::isfinite(hb[k][d]) || !std::isfinite(hb[k][3 + d])) return fail(ctx, MLH_ERR_INVALID, "non-finite coordinates");
+            ext[d] = (long long)((hb[k][3 + d] - hb[k][d]) * inv[k]) + 1;
+            min_b[k][d] = int(std::floor(hb[k][d] * inv[k]));
+            div_b[k][d] = int(std::floor(hb[k][3 + d] * inv[k])) - min_b[k][d] + 1;
+        }
+        if (ext[0] > 2147483647ll || ext[1] > 2147483647ll || ext[2] > 2147483647ll || ext[0] * ext[1] > 2147483647ll || ext[0] * ext[1] * ext[2] > 2147483647ll)
+            return MLH_ERR_UNSUPPORTED;
+        ncell[k] = (long long)div_b[k][0] * div_b[k][1] * div_b[k][2];
+    }
+    const long long off1 = ((ncell[0] + 31) / 32) * 32;                   // the second grid starts on a word boundary
+    if (off1 + ncell[1] > 2147483647ll - 64) return MLH_ERR_UNSUPPORTED;
+    const int n = n0 + n1;
+    const long long nwords = (off1 + ncell[1] + 31) / 32 + 1;
+    if (sizeof(unsigned) * size_t(nwords) > V.cell.cap) {
+        MLH_HIP(ctx, V.cell.ensure(sizeof(unsigned) * size_t(nwords)));
+        MLH_HIP(ctx, hipMemsetAsync(V.cell.p, 0, V.cell.cap, st));
+    }
+    MLH_HIP(ctx, V.word_of.ensure(sizeof(int) * size_t(n)));
+    MLH_HIP(ctx, V.wpre.ensure(sizeof(int) * size_t(nwords)));
+    MLH_HIP(ctx, V.cnt.ensure(sizeof(int) * size_t(n + 2)));
+    MLH_HIP(ctx, V.vox_of.ensure(sizeof(int) * size_t(n + 1)));
+    MLH_HIP(ctx, V.sorted_idx.ensure(sizeof(int) * size_t(n)));
+    MLH_HIP(ctx, V.members.ensure(sizeof(int) * size_t(n)));
+    MLH_HIP(ctx, V.out.ensure(size_t(n) * stride));
+    MLH_HIP(ctx, V.total.ensure(sizeof(int) * 4));
+    const int nbw = int((nwords + VS_CHUNK - 1) / VS_CHUNK);
+    MLH_HIP(ctx, V.sums.ensure(sizeof(int) * size_t(std::max(nbw, (n + VS_CHUNK - 1) / VS_CHUNK) + 1)));
+    VoxArgs A;
+    A.src = static_cast<const unsigned char *>(src0); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.cov_off = -1; A.trace_off = -1;
+    A.inv_leaf = inv[0]; A.min_b[0] = min_b[0][0]; A.min_b[1] = min_b[0][1]; A.min_b[2] = min_b[0][2];
+    A.mul1 = div_b[0][0]; A.mul2 = div_b[0][0] * div_b[0][1];
+    A.src1 = static_cast<const unsigned char *>(src1); A.n0 = n0; A.cell_off1 = int(off1); A.inv_leaf1 = inv[1];
+    A.min_b1[0] = min_b[1][0]; A.min_b1[1] = min_b[1][1]; A.min_b1[2] = min_b[1][2];
+    A.mul1_1 = div_b[1][0]; A.mul2_1 = div_b[1][0] * div_b[1][1];
+    A.trace_thr = 0.f; A.centroid_all = 0; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
+    A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
+    const int nbp = (n + 255) / 256;
+    hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
+    int rc = scan_launch<true>(ctx, reinterpret_cast<const int *>(A.mask), V.wpre.as<int>(), nwords, V.sums, V.total.as<int>());
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
+    rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_HIP(ctx, hipGetLastError());
+    *first_voxels_word = int(off1 >> 5);
     return MLH_OK;
 }
 

@@ -175,6 +175,8 @@ int main(int argc, char **argv)
             f_extract.extractCloudOnDevice(c0, i0);
             fuseCloudFeature(dev, 0, pose_ext[0]);
             std::vector<int32_t> kept = {downsampleFusedScan(dev, MLH_SURF, 0.4f, pose_ext, true), downsampleFusedScan(dev, MLH_CORNER, 0.2f, pose_ext, true)};
+            const std::pair<int, int> both = downsampleFusedScans(dev, 0.4f, 0.2f, pose_ext, true);     // the same two clouds through one pipeline
+            kept.push_back(both.first); kept.push_back(both.second);
             write_file(d + "out_fused_kept.i32", kept);
             std::printf("device-resident front end: track %.6f %.6f %.6f, fused features %d + %d\n", tp[0], tp[1], tp[2], kept[0], kept[1]);
             // the odometry's window map: transformPointCloud + pcl::VoxelGrid

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mloam_hip.h"
@@ -532,6 +533,24 @@ private:
     Device &dev_;
     mlh_track_opts opts_;
 };
+
+// both kinds at once: the two fused clouds go through ONE thinning pipeline (half the dependent launches, one host round trip)
+inline std::pair<int, int> downsampleFusedScans(Device &dev, float leaf_surf, float leaf_corner, const std::vector<Pose> &pose_ext, bool with_ua_flag)
+{
+    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
+    for (size_t n = 0; n < pose_ext.size(); ++n) {
+        pose_ext[n].toParam(ext.data() + n * 7);
+        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
+    }
+    const void *cs = nullptr, *cc = nullptr;
+    int32_t ns = 0, nc = 0, ms = 0, mc = 0;
+    dev.check(mlh_fused_cloud(dev.ctx(), MLH_SURF, &cs, &ns));
+    dev.check(mlh_fused_cloud(dev.ctx(), MLH_CORNER, &cc, &nc));
+    if (ns <= 0 || nc <= 0) return {0, 0};
+    dev.check(mlh_downsample_current_scan_pair(dev.ctx(), cs, ns, cc, nc, 16, 12, MLH_MEM_DEVICE, leaf_surf, leaf_corner, ext.data(), ext_cov.data(),
+                                               (int)pose_ext.size(), params().COV_MEASUREMENT, with_ua_flag ? 1 : 0, params().TRACE_THRESHOLD_MAPPING, &ms, &mc));
+    return {ms, mc};
+}
 
 // ------------------------------------------------------------------ the odometry's window map (estimator.cpp:1160-1203)
 // pcl::transformPointCloud(cloud_in, cloud_out, pose.T_.cast<float>())

@@ -58,8 +58,11 @@ def gpu_frame_dev(t):
         ctx.scan_upload(s.points, s.scan_start, s.scan_end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
         ctx.fuse_add_scan(i, ext[i])
     t1 = time.perf_counter()
-    ctx.downsample_current_scan(mla.SURF, ctx.fused_cloud(mla.SURF), 0.4, ext, covs, meas, True, 0.6, fetch=False)
-    ctx.downsample_current_scan(mla.CORNER, ctx.fused_cloud(mla.CORNER), 0.2, ext, covs, meas, True, 0.6, fetch=False)
+    if PAIR:
+        ctx.downsample_current_scan_pair(ctx.fused_cloud(mla.SURF), ctx.fused_cloud(mla.CORNER), 0.4, 0.2, ext, covs, meas, True, 0.6)
+    else:
+        ctx.downsample_current_scan(mla.SURF, ctx.fused_cloud(mla.SURF), 0.4, ext, covs, meas, True, 0.6, fetch=False)
+        ctx.downsample_current_scan(mla.CORNER, ctx.fused_cloud(mla.CORNER), 0.2, ext, covs, meas, True, 0.6, fetch=False)
     t3 = time.perf_counter()
     ctx.map_rebuild(mla.ALL_KINDS)
     pose, _ = ctx.scan2map(p0, opts, want_stats=False)
@@ -80,8 +83,11 @@ def gpu_frame_dev1(t):
     ctx.scan_upload(both_pts, both_start, both_end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
     for i in range(len(scans)): ctx.fuse_add_rings(ring_ofs[i], ring_ofs[i + 1], i, ext[i])
     t1 = time.perf_counter()
-    ctx.downsample_current_scan(mla.SURF, ctx.fused_cloud(mla.SURF), 0.4, ext, covs, meas, True, 0.6, fetch=False)
-    ctx.downsample_current_scan(mla.CORNER, ctx.fused_cloud(mla.CORNER), 0.2, ext, covs, meas, True, 0.6, fetch=False)
+    if PAIR:
+        ctx.downsample_current_scan_pair(ctx.fused_cloud(mla.SURF), ctx.fused_cloud(mla.CORNER), 0.4, 0.2, ext, covs, meas, True, 0.6)
+    else:
+        ctx.downsample_current_scan(mla.SURF, ctx.fused_cloud(mla.SURF), 0.4, ext, covs, meas, True, 0.6, fetch=False)
+        ctx.downsample_current_scan(mla.CORNER, ctx.fused_cloud(mla.CORNER), 0.2, ext, covs, meas, True, 0.6, fetch=False)
     t3 = time.perf_counter()
     ctx.map_rebuild(mla.ALL_KINDS)
     pose, _ = ctx.scan2map(p0, opts, want_stats=False)
@@ -89,6 +95,7 @@ def gpu_frame_dev1(t):
     for k, v in zip(("upload+extract+fuse", "downsample", "scan2map"), (t1 - t0, t3 - t1, t4 - t3)): t[k] = t.get(k, 0.0) + v
     return pose
 
+PAIR = False
 for _ in range(3): gpu_frame_dev({})
 td = {}
 for _ in range(20): pose_dev = gpu_frame_dev(td)
@@ -96,6 +103,13 @@ print("GPU path, device-resident hand-overs, ms per frame:", {k: round(1e3 * v /
 for _ in range(3): gpu_frame_dev1({})
 td1 = {}
 for _ in range(20): pose_dev1 = gpu_frame_dev1(td1)
+PAIR = True       # mlh_downsample_current_scan_pair: both kinds through one thinning pipeline
+for _ in range(3): gpu_frame_dev1({})
+td2 = {}
+for _ in range(20): pose_dev2 = gpu_frame_dev1(td2)
+PAIR = False
+print("GPU path, device-resident, one launch set, both kinds thinned in one pipeline, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td2.items()}, "total %.3f" % (1e3 * sum(td2.values()) / 20),
+      "same pose:", bool(np.array_equal(pose_dev2, pose_dev1)))
 print("GPU path, device-resident, both LiDARs one launch set, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td1.items()}, "total %.3f" % (1e3 * sum(td1.values()) / 20),
       "same pose as per-LiDAR launches:", bool(np.array_equal(pose_dev1, pose_dev)))
 if os.environ.get('FRAMEBENCH_DEV_ONLY'): sys.exit(0)

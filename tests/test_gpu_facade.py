@@ -117,6 +117,6 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
         c.scan_upload(prev.points, prev.scan_start, prev.scan_end); c.extract_run(); c.extract_voxel_run(0.2); c.fuse_add_scan(0, ext[0])
         kept = [c.downsample_current_scan(k, c.fused_cloud(k), leaf, ext, ext_cov, np.diag([0.0025] * 3), True, 0.6, fetch=False)
                 for k, leaf in ((mla.SURF, 0.4), (mla.CORNER, 0.2))]
-        assert list(np.fromfile(os.path.join(d, "out_fused_kept.i32"), np.int32)) == kept and min(kept) > 50
+        assert list(np.fromfile(os.path.join(d, "out_fused_kept.i32"), np.int32)) == kept + kept and min(kept) > 50      # single calls, then the pair call
     finally:
         c.close()

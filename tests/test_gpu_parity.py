@@ -732,6 +732,20 @@ def test_mapper_inputs_stay_on_device(mla, orc, synth, case16):
         pose_host, _ = c.scan2map(case16["p0"], opts, want_stats=False)
         assert m_dev == [len(f) for f in f_host]
         np.testing.assert_array_equal(pose_dev, pose_host)
+        # both kinds through ONE thinning pipeline (mlh_downsample_current_scan_pair on the fused clouds) and through the fall-back of
+        # two single calls (host buffers): the same feature sets, the same pose
+        for src in ((c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER)), (ref[mla.SURF], ref[mla.CORNER])):
+            m_pair = c.downsample_current_scan_pair(src[0], src[1], 0.4, 0.2, ext, covs, meas, True, 0.6)
+            assert list(m_pair) == m_dev
+            a = c.match_linearize(mla.SURF, case16["p0"], flags=mla.FLAG_WITH_UA)
+            b = c.match_linearize(mla.CORNER, case16["p0"], flags=mla.FLAG_WITH_UA)
+            pose_pair, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+            np.testing.assert_array_equal(pose_pair, pose_host)
+            c.features_set(mla.SURF, f_host[0]); c.features_set(mla.CORNER, f_host[1])
+            a2 = c.match_linearize(mla.SURF, case16["p0"], flags=mla.FLAG_WITH_UA)
+            b2 = c.match_linearize(mla.CORNER, case16["p0"], flags=mla.FLAG_WITH_UA)
+            assert np.array_equal(a["valid"], a2["valid"]) and np.array_equal(b["valid"], b2["valid"])
+            np.testing.assert_array_equal(a["H"], a2["H"]); np.testing.assert_array_equal(b["H"], b2["H"])
         # a second frame reuses the buffers from the start
         c.fuse_reset()
         assert c.fused_cloud(mla.SURF).n == 0
