@@ -922,6 +922,8 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     const bool fused = !ctx->comm && opts->gf_method == MLH_GF_WO;
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
+    HostPublish last_hp;
+    bool have_hp = false;  // fused path: the last chunk's publication already carries the pose
     std::mt19937 rng((uint32_t)opts->gf_seed);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         if (fused) {
@@ -945,17 +947,31 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         }
         if (!fused && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
-            for (int j = it; j < std::min(it + chunk, opts->max_lm_iterations); ++j) {
+            const int j_end = std::min(it + chunk, opts->max_lm_iterations);
+            unsigned long long seq = 0;
+            for (int j = it; j < j_end; ++j) {
                 MatchArgs a = args_from_opts(opts, 3, 1);
-                if (fused) { a.finish = 4; a.lm_max_it = opts->max_lm_iterations; }
+                if (fused) {
+                    a.finish = 4; a.lm_max_it = opts->max_lm_iterations;
+                    if (j == j_end - 1) {                   // the chunk's last launch publishes pose + `done` itself (no publication launch)
+                        if ((rc = publish_slot(ctx, &a.publish, &seq))) return rc;
+                        a.publish_seq = seq;
+                    }
+                }
                 if ((rc = linearize_launch(ctx, a))) return rc;
                 if (!fused && (rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
             }
             HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
-            if ((rc = fetch_published(ctx, hp))) return rc;
+            if (fused) { if ((rc = wait_published(ctx, seq, hp))) return rc; last_hp = hp; have_hp = true; }
+            else if ((rc = fetch_published(ctx, hp))) return rc;
             if (hp.done) break;
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
+    }
+    if (fused && !stats && have_hp) {
+        if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+        for (int i = 0; i < 7; ++i) pose_inout[i] = last_hp.x[i];
+        return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
 }

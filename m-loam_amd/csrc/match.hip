@@ -386,6 +386,11 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
             if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks);
             else lm_step_body(f_ne, P.state, P.lm_max_it);
             *P.ticket = 0u;
+            if (P.publish) {         // last launch of a chunk of LM steps: the pose and the `done` flag go to the host from here
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
+                P.publish->done = P.state->done;
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         MLH_STAGE(4095, 2);
         return;
@@ -539,6 +544,11 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     if (gtile >= total) return;
     if (P.pose_sel && P.state->done) {   // candidate evaluation after the device-side LM loop has terminated: keep the partials defined, do no work
         if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
+        if (LM && P.publish && gtile == 0 && threadIdx.x == 0) {      // ... but the host may be waiting for this launch's publication
+            for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
+            P.publish->done = P.state->done;
+            __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
@@ -675,7 +685,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
-    P.publish = (a.finish == 1) ? a.publish : nullptr;
+    P.publish = (a.finish == 1 || a.finish == 4) ? a.publish : nullptr;
     P.publish_seq = a.publish_seq;
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = (a.stat_slot >= 0) ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
