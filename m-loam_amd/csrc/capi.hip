@@ -1141,7 +1141,7 @@ int mlh_fuse_reset(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    MLH_HIP(ctx, ctx->fused_cnt.ensure(sizeof(int) * 2));
+    MLH_HIP(ctx, ctx->fused_cnt.ensure(sizeof(int) * 2 * 8));                      // prefix table of the record counts, one pair per append (grows)
     MLH_HIP(ctx, hipMemsetAsync(ctx->fused_cnt.p, 0, sizeof(int) * 2, ctx->stream));
     ctx->fused_n[0] = ctx->fused_n[1] = 0;
     ctx->fused_bound[0] = ctx->fused_bound[1] = 0;
@@ -1177,7 +1177,7 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
         MLH_HIP(ctx, hipSetDevice(ctx->device));
         const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
         std::vector<float> hp(part_floats * size_t(ctx->fused_parts));
-        MLH_HIP(ctx, hipMemcpyAsync(ctx->fused_n, ctx->fused_cnt.p, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->fused_n, ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->fused_part.p, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;

@@ -112,7 +112,8 @@ struct FuseArgs {
     int rb, re;                // rings [rb, re) of the scan
     FuseXf xf;
     float4 *out[2];            // fused surf / corner clouds
-    int *cnt;                  // their record counts
+    const int *cnt;            // record counts before this append ...
+    int *cnt_next;             // ... and after it (the next append's base): a prefix table, one pair per append
     float *part;               // this append's partial bounds: [kind][FUSE_BLOCKS][6]
 };
 __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
     const int b = kind == 0 ? A.vox_off[A.rb] : A.ring_offsets[A.rb * 4 + 1];
     const int e = kind == 0 ? A.vox_off[A.re] : A.ring_offsets[A.re * 4 + 1];
     const int base = A.cnt[kind];
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt_next[kind] = base + (e - b);      // depends on nothing the other workgroups do: no bump launch
     const FuseXf &xf = A.xf;
     float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < e - b; i += FUSE_BLOCKS * 256) {
@@ -153,13 +155,6 @@ __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
         A.part[(kind * FUSE_BLOCKS + blockIdx.x) * 6 + d] = r;
     }
 }
-// after the append (stream order): the counts move on
-__global__ void fuse_bump_kernel(const int *__restrict__ ring_offsets, const int *__restrict__ vox_off, int rb, int re, int *__restrict__ cnt)
-{
-    if (threadIdx.x == 0) cnt[0] += vox_off[re] - vox_off[rb];
-    if (threadIdx.x == 1) cnt[1] += ring_offsets[re * 4 + 1] - ring_offsets[rb * 4 + 1];
-}
-
 // the scan's thinned less-flat cloud -> fused SURF, its less-sharp corners -> fused CORNER (rings [ring_begin, ring_end)); counts on the device
 int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7])
 {
@@ -175,13 +170,14 @@ int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     }
     A.pts = sb.pts.as<float4>(); A.vox_out = sb.vox_out.as<float4>(); A.list1 = sb.lists[1].as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.vox_off = sb.ring_vox.as<int>() + sb.n_rings;
-    A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>();
+    // counts: prefix table [append][kind]; this append reads row `fused_parts` and writes row `fused_parts + 1`
+    MLH_HIP(ctx, ctx->fused_cnt.grow(sizeof(int) * 2 * size_t(ctx->fused_parts + 2), sizeof(int) * 2 * size_t(ctx->fused_parts + 1), st));
+    A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts; A.cnt_next = ctx->fused_cnt.as<int>() + 2 * (ctx->fused_parts + 1);
     const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
     MLH_HIP(ctx, ctx->fused_part.grow(sizeof(float) * part_floats * size_t(ctx->fused_parts + 1), sizeof(float) * part_floats * size_t(ctx->fused_parts), st));
     A.part = ctx->fused_part.as<float>() + part_floats * size_t(ctx->fused_parts);
     ++ctx->fused_parts;
     hipLaunchKernelGGL(fuse_append_kernel, dim3(FUSE_BLOCKS, 2), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(fuse_bump_kernel, dim3(1), dim3(64), 0, st, A.ring_offsets, A.vox_off, ring_begin, ring_end, A.cnt);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
