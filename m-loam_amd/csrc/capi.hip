@@ -1222,21 +1222,39 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
     if (!(T.grid[0].built && T.grid[1].built && T.m[0] > 0 && T.m[1] > 0)) return fail(ctx, MLH_ERR_STATE, "track_set_prev / track_set_cur are required for both kinds");
     int rc = ensure_state(ctx, opts->max_outer);
     if (rc) return rc;
-    if ((rc = upload_pose(ctx, pose_inout))) return rc;
+    // Without per-round records the pose goes in with the first round's kernel arguments and comes back from the last launch through
+    // pinned host memory: 2 + max_lm_iterations launches per round and nothing else. With records: the state is uploaded and read back.
+    const bool lean = stats == nullptr;
+    if (!lean && (rc = upload_pose(ctx, pose_inout))) return rc;
+    unsigned long long seq = 0;
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         // lidar_tracker.cpp:42-121: match at the current estimate, then Ceres on the fixed correspondences (Huber 0.1, <= 4 iterations,
         // no degeneracy handling); fewer than 10 correspondences -> the round is skipped
         // (the LM begin / step run in the linearisation kernel's last workgroup: 2 + max_lm_iterations launches per round)
-        if ((rc = track_match_launch(ctx, 3, track_args(opts, 0)))) return rc;
+        TrackArgs m = track_args(opts, 0);
+        if (lean && outer == 0) m.init_pose = pose_inout;
+        if ((rc = track_match_launch(ctx, 3, m))) return rc;
         TrackArgs b = track_args(opts, 0);
         b.finish = 3; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 10; b.stat_slot = stats ? outer : -1;
+        if (lean && outer == 0) b.init_pose = pose_inout;
         if ((rc = track_linearize_launch(ctx, 3, b))) return rc;
         for (int it = 0; it < opts->max_lm_iterations; ++it) {
             TrackArgs s = track_args(opts, 1);
             s.finish = 4; s.lm_max_it = opts->max_lm_iterations;
+            if (lean && outer == opts->max_outer - 1 && it == opts->max_lm_iterations - 1) {
+                if ((rc = publish_slot(ctx, &s.publish, &seq))) return rc;
+                s.publish_seq = seq;
+            }
             if ((rc = track_linearize_launch(ctx, 3, s))) return rc;
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
+    }
+    if (lean) {
+        HostPublish hp;
+        if ((rc = wait_published(ctx, seq, hp))) return rc;
+        if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+        for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+        return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
 }

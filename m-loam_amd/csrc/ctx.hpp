@@ -179,6 +179,8 @@ struct TrackArgs {
     double huber_delta = 0.1;
     int finish = 0;          // track_linearize_launch: 3 / 4 = its last workgroup runs the Levenberg-Marquardt begin / step (solver_dev.hpp)
     int lm_max_it = 4, lm_min_blocks = 10, stat_slot = -1;
+    HostPublish *publish = nullptr;          // finish 3 / 4: this launch hands pose + done flag to the host (pinned memory)
+    unsigned long long publish_seq = 0;
 };
 
 struct Profile {

@@ -60,6 +60,8 @@ struct TrackParamsDev {
     int finish, lm_max_it, lm_min_blocks;   // fused Levenberg-Marquardt begin (3) / step (4) in the linearisation kernel's last workgroup
     unsigned *ticket;
     IterStatDev *stat;
+    HostPublish *publish;    // this launch publishes pose + done flag to pinned host memory
+    unsigned long long publish_seq;
     int use_init;
     double init_pose[7];
     float dist_sq_thr;
@@ -312,6 +314,13 @@ __device__ __forceinline__ V3 row_skew3(const V3 &a, const V3 &v)             //
     return {a.y * v.z - a.z * v.y, a.z * v.x - a.x * v.z, a.x * v.y - a.y * v.x};
 }
 
+__device__ __forceinline__ void track_publish(const TrackParamsDev &P)
+{
+    for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
+    P.publish->done = P.state->done;
+    __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
 {
     __shared__ double s_red[4 * 32];
@@ -320,6 +329,7 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
     if (gtile >= total) return;
     if (P.pose_sel && P.state->done) {       // the LM loop has terminated: keep the partials defined, do no work
         if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
+        if (P.publish && gtile == 0 && threadIdx.x == 0) track_publish(P);      // the host may be waiting for this launch's record
         return;
     }
     const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
@@ -421,9 +431,11 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
     sa.lo[0] = 0; sa.hi[0] = total; sa.lo[1] = 0; sa.hi[1] = 0;
     sum_partials(sa, f_ne, f_cnt2, f_scratch);
     if (threadIdx.x == 0) {
+        if (P.use_init) for (int i = 0; i < 7; ++i) P.state->x[i] = P.init_pose[i];      // the state's pose is born here (first round of a solve)
         if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, -1.0, P.lm_max_it, P.stat, P.lm_min_blocks);
         else lm_step_body(f_ne, P.state, P.lm_max_it);
         *P.ticket = 0u;
+        if (P.publish) track_publish(P);
     }
 }
 
@@ -496,6 +508,7 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     }
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = a.stat_slot >= 0 ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
+    P.publish = a.publish; P.publish_seq = a.publish_seq;
     return MLH_OK;
 }
 

@@ -615,8 +615,16 @@ def test_track_cloud_parity(ctx, mla, orc, track_case):
         assert abs(s["final_cost"] - o["final_cost"]) <= 1e-9 * max(1.0, o["final_cost"])
     assert max(_pose_err(pose, ref["pose"])) < 1e-9
     assert np.linalg.norm(pose[:3] - tc["motion"][:3]) < 0.08
-    pose2, none = ctx.track_cloud(p0, want_stats=False)
-    assert none is None and max(_pose_err(pose2, pose)) < 1e-12
+    pose2, none = ctx.track_cloud(p0, want_stats=False)      # lean path: pose in through kernel arguments, out from the last launch
+    assert none is None
+    np.testing.assert_array_equal(pose2, pose)
+    # a round with too few correspondences is skipped on both paths (lidar_tracker.cpp:66-70): the pose comes back unchanged
+    ctx.track_set_cur(mla.CORNER, tc["corner_sharp"][:3]); ctx.track_set_cur(mla.SURF, tc["surf_flat"][:4])
+    p_in = np.array([0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+    pose3, st3 = ctx.track_cloud(p_in)
+    pose4, _ = ctx.track_cloud(p_in, want_stats=False)
+    np.testing.assert_array_equal(pose3, p_in)
+    np.testing.assert_array_equal(pose4, p_in)
 
 
 def test_downsample_current_scan_device_resident(ctx, mla, orc, synth, case16, feats16):
