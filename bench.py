@@ -5,8 +5,9 @@ A *step* is one frame of the mapper's scan-to-map optimisation on synthetic inpu
   [local-map index rebuild for both maps, as the reference does every frame (lidar_mapper_keyframe.cpp:433-434)]
   + 5 Gauss-Newton iterations, each = transform -> exact 5-NN -> line/plane fit + gates -> residual + 1x6 Jacobian ->
     Huber -> 6x6 normal-equation reduction [-> RCCL all-reduce when N > 1] -> degeneracy check -> 6x6 solve -> Plus,
-  device-resident (mlh_gn_solve). value = features linearised per second = (surf + corner features) * 5 / step time,
-  whole job. Workload at N = 1: BASELINE.json configs[1] (2 x 64-ring scan vs ~500k-point local map, 5 GN iterations).
+  device-resident (mlh_gn_solve). value = features LINEARISED per second: the valid correspondences -- those whose
+  residual + 1x6 Jacobian were produced and reduced into the normal equations -- summed over the 5 iterations / step time, whole
+  job; every query (valid or rejected) per second is reported beside it as `queries_per_s`. Workload at N = 1: BASELINE.json configs[1] (2 x 64-ring scan vs ~500k-point local map, 5 GN iterations).
   At N > 1 the map grows with N (1M / 2M / 4M points, configs[2..3]) and is sharded spatially across the ranks, the
   scan stays the same 2 x 64 rings -> "scaling": "strong" (total feature work is fixed).
 
@@ -40,7 +41,7 @@ def log(*a):
 
 def build_workload(synth, preset, seed=42, n_lidars=None):
     sc = synth.make_scene(seed=seed, **synth.SCENE_PRESETS[preset])
-    surf_map, corner_map = synth.sample_maps(sc, seed=seed)
+    surf_map, corner_map = synth.sample_maps(sc, seed=seed, kf_rings=N_RINGS, kf_lidars=n_lidars or N_LIDARS)
     gt = synth.gt_body_pose()
     scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], N_RINGS, seed=7 + i) for i in range(n_lidars or N_LIDARS)]
     return sc, surf_map, corner_map, gt, scans
@@ -97,6 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-map-rebuild", action="store_true", help="leave the map index build out of the step")
+    ap.add_argument("--map-rebuild-only", action="store_true",
+                    help="per step only re-index the resident map (mlh_map_rebuild: no staging, no bounds pass) instead of mlh_map_set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dense-features", action="store_true",
@@ -175,7 +178,6 @@ def main():
 
     # --- map shards (N > 1): angular wedges around the predicted sensor position, halo 1.1 m
     center = p0[:2]
-    replicas = False
     if world > 1:
         ms_ = shard.shard_points_mask(surf_map, center, world, rank)
         mc_ = shard.shard_points_mask(corner_map, center, world, rank)
@@ -205,14 +207,10 @@ def main():
         flag = torch.tensor([comm_ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            # the library's own RCCL communicator could not be built on every rank: run N independent replicas of the unsharded
-            # frame instead (stated in the JSON line) rather than produce no measurement at all
-            log(f"[rank {rank}] RCCL communicator unavailable ({comm_err or 'failed on another rank'}): replicas mode")
-            if comm_ok:
-                ctx.comm_finalize()
-            ctx.shard_set(None, None)
-            local_surf_map, local_corner_map = surf_map, corner_map
-            replicas = True
+            # no silent degradation to independent replicas: a sharded run without its collective is not a scaling measurement
+            log(f"[rank {rank}] FATAL: RCCL communicator unavailable ({comm_err or 'failed on another rank'})")
+            dist.destroy_process_group()
+            raise SystemExit(3)
     else:
         local_surf_map, local_corner_map = surf_map, corner_map
     # inputs resident in HBM before the timed region
@@ -230,9 +228,20 @@ def main():
         f"features surf {len(surf)} corner {len(corner)}; setup {time.time() - t0:.1f}s")
 
     def step():
-        if not args.no_map_rebuild:
+        # a frame's local map arrives as a (device-resident) cloud: mlh_map_set = staging + bounds pass + index build, what the
+        # reference pays as kdtree->setInputCloud every frame (lidar_mapper_keyframe.cpp:433-434)
+        if args.map_rebuild_only:
             ctx.map_rebuild(mla.ALL_KINDS)
+        elif not args.no_map_rebuild:
+            ctx.map_set(mla.SURF, d_surf_map)
+            ctx.map_set(mla.CORNER, d_corner_map)
         return ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)[0]
+
+    # valid correspondences per iteration (deterministic: the timed steps repeat exactly this solve)
+    _, it_stats = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=True)
+    n_valid_iter = [(int(s_["n_surf"]), int(s_["n_corner"])) for s_ in it_stats]
+    # (N > 1: the counts come out of the all-reduced record, i.e. they are already the whole job's)
+    n_valid_step = int(sum(a_ + b_ for a_, b_ in n_valid_iter))
 
     def sync_all():
         if world > 1:
@@ -262,7 +271,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = m_total * GN_ITERS / (elapsed / args.steps) * (world if replicas else 1)
+    value = n_valid_step / (elapsed / args.steps)
+    queries_per_s = m_total * GN_ITERS / (elapsed / args.steps)
 
     # a second, fully instrumented pass (every kernel bracketed) for the per-kernel breakdown; not part of `value`
     n_prof = max(args.steps // 4, 5)
@@ -298,22 +308,25 @@ def main():
     h = float(np.sqrt(opts.min_match_sq_dis)) * 1.001
     Tm = synth.pose_to_mat(p0)
     planes = shard.wedge_planes(center, world, rank)
-    bytes_per_launch, cbars, n_owned = 0.0, {}, {}
+    bytes_per_launch, bytes_impl, cbars, n_owned = 0.0, 0.0, {}, {}
     for name, feats, lmap in (("surf", surf, local_surf_map), ("corner", corner, local_corner_map)):
         fm = synth.transform_points(feats[:, :3], Tm)
-        own = shard.owned_mask(fm, *planes) if (world > 1 and not replicas) else np.ones(len(feats), bool)
+        own = shard.owned_mask(fm, *planes) if world > 1 else np.ones(len(feats), bool)
         cb = mean_candidates(lmap, fm[own], h)
         cbars[name], n_owned[name] = round(cb, 2), int(own.sum())
-        # per feature: 16 B feature record; per OWNED feature additionally 18 cell_start words (72 B) + 16 B x C-bar candidate
-        # points + 5 neighbour re-fetches (80 B) + 5 float4 neighbour records written (80 B)
-        bytes_per_launch += len(feats) * 16.0 + int(own.sum()) * (72 + 16.0 * cb + 80 + 80)
+        # B_feat = 16 (query) + 27 x 8 (cell begin/end) + 12 x C-bar (candidate xyz); the partial normal equations
+        # (232 B per 256-feature tile) are negligible. This is the figure `achieved` uses.
+        bytes_per_launch += int(own.sum()) * (16.0 + 27 * 8 + 12.0 * cb)
+        # what this implementation's layout moves per query when every one of the 27 cells is read (float4 candidates, 18 cell words)
+        bytes_impl += len(feats) * 16.0 + int(own.sum()) * (72 + 16.0 * cb)
     roofline = None
     if knn_n > 0:
         dur_s = 1e-3 * knn_ms / knn_n
         ach = bytes_per_launch / dur_s / 1e9
         roofline = dict(bound="hbm", kernel="knn_features_kernel (surf + corner)", achieved=round(ach, 2), peak=8000.0, unit="GB/s",
                         frac=round(ach / 8000.0, 5), traffic=None, avg_kernel_us=round(1e6 * dur_s, 3), launches=int(knn_n),
-                        algorithmic_bytes_per_launch=int(bytes_per_launch), mean_candidates_per_feature=cbars, owned_features=n_owned,
+                        algorithmic_bytes_per_launch=int(bytes_per_launch), bytes_convention="SURVEY 8(d): 16 + 27*8 + 12*C-bar per query",
+                        layout_bytes_per_launch_all_27_cells=int(bytes_impl), mean_candidates_per_feature=cbars, owned_features=n_owned,
                         floor_132B_per_feature_GBps=round(m_total * 132 / dur_s / 1e9, 2),
                         note="map (<= 128 MB) is L2/Infinity-Cache resident: measured HBM bytes are far below the algorithmic bytes; "
                              "PMC traffic is collected offline with rocprofv3 --pmc (profiles/)")
@@ -331,16 +344,19 @@ def main():
     if rank == 0:
         out = dict(metric="scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame)",
                    value=round(value, 1), unit="features/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling=("weak" if replicas else "strong"), vs_baseline=None,
+                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="strong", vs_baseline=None,
                    dtype="f32 search/fit + f64 residual/Jacobian/normal equations", data="synthetic",
                    config=dict(workload=f"{args.lidars}x{N_RINGS}-ring synthetic scan ({n_scan_points} pts) vs {preset} local map "
                                         f"({len(surf_map) + len(corner_map)} pts), {GN_ITERS} GN iters/frame, re-matched every iteration",
                                features_surf=len(surf), features_corner=len(corner), gn_iters_per_step=GN_ITERS,
+                               n_valid_per_iter_surf_corner=n_valid_iter,
+                               corner_map="less-sharp points of 10 earlier keyframes x LiDARs, thinned at 0.2 m (as the mapper builds it)",
                                scan_features_thinned=not args.dense_features,
-                               map_index_rebuilt_every_step=not args.no_map_rebuild,
-                               parallelism=("1 GPU" if world == 1 else (f"{world} independent replicas (RCCL communicator unavailable)" if replicas else
-                                                                      f"map sharded in {world} angular wedges + RCCL all-reduce of 32 f64/iter")),
+                               map_index_per_step=("none" if args.no_map_rebuild else ("mlh_map_rebuild (re-index only)" if args.map_rebuild_only
+                                                                                      else "mlh_map_set from device-resident clouds (staging + bounds + index)")),
+                               parallelism=("1 GPU" if world == 1 else f"map sharded in {world} angular wedges + RCCL all-reduce of 32 f64/iter"),
                                hip_events_in_timed_region=("dominant kernel, 1 launch per step" if args.profile_events else "none")),
+                   queries_per_s=round(queries_per_s, 1), valid_correspondences_per_step=n_valid_step,
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
@@ -371,7 +387,8 @@ def main():
             t_kd += tk
             t_total += tk + r["seconds"]
             frames += 1
-        cpu_value = frames * m_total * GN_ITERS / t_total
+        n_valid_cpu = int(sum(i_["n_surf"] + i_["n_corner"] for i_ in r["iters"]))
+        cpu_value = frames * n_valid_cpu / t_total
         ncores = min(os.cpu_count() or 1, 32)
         r_all = O.gn_iterations(ms_, mc_, surf, corner, p0, prm, GN_ITERS, ncores)
         tk_all = ms_.rebuild_seconds() + mc_.rebuild_seconds()
@@ -379,7 +396,7 @@ def main():
                                    sample=f"{frames} full frames of the same workload (kd-tree rebuild for both maps + {GN_ITERS} GN iterations), "
                                           f"single thread as the reference mapper (no OpenMP in lidarMapper/, Ceres num_threads=1)",
                                    ms_per_frame=round(1e3 * t_total / frames, 2), kdtree_build_ms_per_frame=round(1e3 * t_kd / frames, 2),
-                                   all_cores=dict(cores=ncores, value=round(m_total * GN_ITERS / (r_all["seconds"] + tk_all), 1),
+                                   all_cores=dict(cores=ncores, value=round(n_valid_cpu / (r_all["seconds"] + tk_all), 1),
                                                   note="generous row: same code, OpenMP over features, kd-tree build still serial"),
                                    pose_agreement_m=float(np.linalg.norm(np.array(r["pose"][:3]) - np.array(pose[:3]))))
         if "scan2map" in out:

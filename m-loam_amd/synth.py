@@ -1,16 +1,24 @@
 """Seeded synthetic scenes, local maps and multi-LiDAR scans for the scan-to-map hot path.
 
 This is input generation only (numpy): the shapes follow SURVEY.md 8(d) -- a ground plane plus
-axis-aligned "buildings", a surf map on a jittered MAP_SURF_RES grid, a corner map along box edges at
-MAP_CORNER_RES, and ring-major ray-cast scans with ``scan_start = ring_begin + 5`` /
+axis-aligned "buildings", a surf map on a jittered MAP_SURF_RES grid, and ring-major ray-cast scans with ``scan_start = ring_begin + 5`` /
 ``scan_end = ring_end - 6`` exactly as ImageSegmenter hands them to ``FeatureExtract::extractCloud``
 (reference: estimator/src/imageSegmenter/image_segmenter.hpp:385-387). Extrinsics are the ``body_T_laser``
 rows of estimator/config/config_realvehicle_hercules.yaml:56-59; fused clouds carry ``intensity = lidar index``
 (estimator/src/utility/visualization.cpp:48).
+
+The corner map is assembled the way the mapper assembles its own (lidar_mapper_keyframe.cpp:254-354): the less-sharp points of
+the scans taken from the previous keyframe poses, moved to the map frame and thinned at MAP_CORNER_RES. (Round 1 sampled box
+edges instead; the scanner labels mostly range-noise and occlusion points "less sharp", which have no box edge nearby, so ~94 %
+of the corner queries were rejected before any fit -- not what a mapper frame looks like.) The keyframe selection below is a
+numpy approximation of extractCloud's less-sharp walk -- it only produces INPUT points, no result is ever compared against it.
 """
 from __future__ import annotations
 
 import dataclasses
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 # qx qy qz qw px py pz  (config_realvehicle_hercules.yaml, "PS-calib" rows)
@@ -113,8 +121,10 @@ def voxel_mean(points: np.ndarray, leaf: float) -> np.ndarray:
 
 
 def sample_maps(scene: Scene, surf_res: float = 0.4, corner_res: float = 0.2, seed: int = 42,
-                noise: float = 0.01):
-    """Returns (surf_map (Ns,3) f32, corner_map (Nc,3) f32) in the map frame, voxel-thinned at the map resolutions."""
+                noise: float = 0.01, corner_from: str = "keyframes", kf_rings: int = 64, kf_lidars: int = 2, n_keyframes: int = 10):
+    """Returns (surf_map (Ns,3) f32, corner_map (Nc,3) f32) in the map frame, voxel-thinned at the map resolutions.
+    corner_from = "keyframes": less-sharp points of `n_keyframes` earlier poses x `kf_lidars` LiDARs of `kf_rings` rings (default);
+    "edges": the box edges only (round-1 behaviour, kept for comparison runs)."""
     rng = np.random.default_rng(seed + 1000)
     L = scene.L
     surf = []
@@ -164,8 +174,75 @@ def sample_maps(scene: Scene, surf_res: float = 0.4, corner_res: float = 0.2, se
     surf = np.concatenate(surf).astype(np.float32)
     corner = np.concatenate(corner).astype(np.float32) if corner else np.zeros((0, 3), np.float32)
     surf = voxel_mean(surf, surf_res)
+    if corner_from == "keyframes":
+        corner = keyframe_corner_cloud(scene, kf_rings, kf_lidars, n_keyframes, seed=seed)
     corner = voxel_mean(corner, corner_res)
     return np.ascontiguousarray(surf), np.ascontiguousarray(corner)
+
+
+def keyframe_poses(n_keyframes: int, spacing: float = 0.35) -> np.ndarray:
+    """Body poses of the keyframes behind the current one: a gently weaving track inside the box-free disc around the origin."""
+    out = []
+    for k in range(1, n_keyframes + 1):
+        yaw = np.deg2rad(1.5) * np.sin(0.5 * k)
+        out.append([-spacing * k, 0.6 * np.sin(0.35 * k), SENSOR_HEIGHT, 0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
+    return np.array(out)
+
+
+def less_sharp_indices(scan: "Scan", n_pick: int = 20) -> np.ndarray:
+    """Approximate `corner_points_less_sharp` of extractCloud (feature_extract.cpp:152-214) for map generation: per ring and sector
+    the up-to-20 largest curvatures above 0.1, each pick suppressing its +-5 neighbours (the gap test of cpp:192-213 is left out)."""
+    pts = scan.points[:, :3]
+    n = len(pts)
+    if n < 11:
+        return np.zeros(0, np.int64)
+    d = np.zeros((n, 3), np.float32)
+    for k in range(-5, 6):
+        if k:
+            d[5:n - 5] += pts[5 + k:n - 5 + k]
+    d[5:n - 5] -= 10 * pts[5:n - 5]
+    c = (d * d).sum(axis=1)
+    rows = []
+    for r in range(scan.n_rings):
+        s, e = int(scan.scan_start[r]), int(scan.scan_end[r])
+        if e - s < 6:
+            continue
+        for j in range(6):
+            sp, ep = s + (e - s) * j // 6, s + (e - s) * (j + 1) // 6 - 1
+            if ep >= sp:
+                rows.append((sp, ep))
+    if not rows:
+        return np.zeros(0, np.int64)
+    lmax = max(ep - sp + 1 for sp, ep in rows)
+    g = len(rows)
+    idx = np.full((g, lmax), -1, np.int64)
+    for i, (sp, ep) in enumerate(rows):
+        idx[i, :ep - sp + 1] = np.arange(sp, ep + 1)
+    cm = np.where(idx >= 0, c[np.clip(idx, 0, n - 1)], -np.inf)
+    cols, rows_i, picks = np.arange(lmax)[None, :], np.arange(g), []
+    for _ in range(n_pick):
+        a = cm.argmax(axis=1)
+        ok = cm[rows_i, a] > 0.1
+        picks.append(idx[rows_i, a][ok])
+        cm[(np.abs(cols - a[:, None]) <= 5) & ok[:, None]] = -np.inf
+    return np.concatenate(picks)
+
+
+def keyframe_corner_cloud(scene: Scene, n_rings: int, n_lidars: int, n_keyframes: int, seed: int = 42) -> np.ndarray:
+    """Less-sharp points of every keyframe scan in the map frame (ground-truth keyframe poses; un-thinned)."""
+    jobs = [(k, i, pose) for k, pose in enumerate(keyframe_poses(n_keyframes)) for i in range(n_lidars)]
+
+    def one(job):
+        k, i, pose = job
+        scn = simulate_scan(scene, pose, HERCULES_BODY_T_LASER[i], n_rings, seed=seed + 1000 + 10 * k + i)
+        T_bl = np.eye(4)
+        T_bl[:3, :3] = quat_to_rot(HERCULES_BODY_T_LASER[i][:4])
+        T_bl[:3, 3] = HERCULES_BODY_T_LASER[i][4:7]
+        return transform_points(scn.points[less_sharp_indices(scn)][:, :3], pose_to_mat(pose) @ T_bl)
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 16)) as ex:   # numpy releases the GIL in the ray casts
+        parts = list(ex.map(one, jobs))                                                       # results in job order: deterministic
+    return np.concatenate(parts).astype(np.float32)
 
 
 def _raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: float) -> np.ndarray:

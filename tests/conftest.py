@@ -37,7 +37,7 @@ def orc():
 def _make_case(synth, preset, n_rings, n_lidars, seed=42):
     """Scene + maps + per-LiDAR scans + (oracle-free) feature clouds for the mapper."""
     sc = synth.make_scene(seed=seed, **synth.SCENE_PRESETS[preset])
-    surf_map, corner_map = synth.sample_maps(sc, seed=seed)
+    surf_map, corner_map = synth.sample_maps(sc, seed=seed, kf_rings=n_rings, kf_lidars=n_lidars)
     gt = synth.gt_body_pose()
     scans = [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], n_rings, seed=7 + i) for i in range(n_lidars)]
     return dict(scene=sc, surf_map=surf_map, corner_map=corner_map, gt=gt, scans=scans, p0=synth.perturbed_pose(gt, seed=43))
