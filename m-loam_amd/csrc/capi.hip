@@ -250,6 +250,8 @@ int mlh_create(mlh_ctx **out, int device_id)
     if (!c) return MLH_ERR_NOMEM;
     c->device = device_id;
     if (const char *e = std::getenv("MLH_KNN_LANES")) c->knn_lanes_override = std::atoi(e);
+    if (const char *e = std::getenv("MLH_FUSED")) c->fused_disable = (std::atoi(e) == 0);
+    if (const char *e = std::getenv("MLH_FUSED_STRIDED")) c->fused_strided = (std::atoi(e) != 0);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
     *out = c;
     return MLH_OK;
@@ -509,22 +511,51 @@ int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int 
 }
 
 // ---------------------------------------------------------------- map
+// host records are copied to the staging buffer first (both clouds back to back); device records are read in place
+static int map_set_impl(mlh_ctx *ctx, int n_maps, const int *kinds, const void *const *points, const int *n, int stride_bytes, float min_match_sq_dis, int mem)
+{
+    if (!(min_match_sq_dis > 0.f)) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis must be positive");
+    if (stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer (stride not a multiple of 4 >= 12)");
+    for (int k = 0; k < n_maps; ++k) if (!points[k] || n[k] <= 0) return fail(ctx, MLH_ERR_INVALID, "bad point buffer (null or n <= 0)");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned char *src[2] = {nullptr, nullptr};
+    if (mem == MLH_MEM_HOST) {
+        size_t off[2] = {0, 0}, total = 0;
+        for (int k = 0; k < n_maps; ++k) { off[k] = total; total += ((size_t(n[k]) * stride_bytes + 255) / 256) * 256; }
+        MLH_HIP(ctx, ctx->tmp.ensure(total));
+        for (int k = 0; k < n_maps; ++k) {
+            MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.as<unsigned char>() + off[k], points[k], size_t(n[k]) * stride_bytes, hipMemcpyHostToDevice, ctx->stream));
+            src[k] = ctx->tmp.as<unsigned char>() + off[k];
+        }
+    } else {
+        for (int k = 0; k < n_maps; ++k) src[k] = static_cast<const unsigned char *>(points[k]);
+    }
+    HostPublish *pub;
+    unsigned long long seq;
+    int rc = publish_slot(ctx, &pub, &seq);
+    if (rc) return rc;
+    float sq[2] = {min_match_sq_dis, min_match_sq_dis};
+    rc = map_stage_and_build(ctx, n_maps, kinds, src, n, stride_bytes, sq, pub, seq);
+    if (rc) return rc;
+    for (int k = 0; k < n_maps; ++k) ctx->feat[kinds[k]].matched = false;
+    return MLH_OK;
+}
+
 int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, float min_match_sq_dis, int mem)
 {
     if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
-    if (!(min_match_sq_dis > 0.f)) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis must be positive");
-    MLH_HIP(ctx, hipSetDevice(ctx->device));
-    MapGrid &g = ctx->map[kind];
-    g.built = false;
-    int rc = stage_points(ctx, points, stride_bytes, n, mem, -2, -1, g.raw, nullptr, ctx->tmp);
-    if (rc) return rc;
-    g.n = n;
-    g.min_match_sq_dis = min_match_sq_dis;
-    rc = grid_build(ctx, 1 << kind, true);
-    if (rc) return rc;
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->feat[kind].matched = false;
-    return MLH_OK;
+    const void *pts[1] = {points};
+    return map_set_impl(ctx, 1, &kind, pts, &n, stride_bytes, min_match_sq_dis, mem);
+}
+
+int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                     float min_match_sq_dis, int mem)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    const int kinds[2] = {MLH_SURF, MLH_CORNER};
+    const void *pts[2] = {surf_points, corner_points};
+    const int n[2] = {n_surf, n_corner};
+    return map_set_impl(ctx, 2, kinds, pts, n, stride_bytes, min_match_sq_dis, mem);
 }
 
 int mlh_map_rebuild(mlh_ctx *ctx, int kind)

@@ -110,6 +110,8 @@ struct MapGrid {
     long long ncell = 0;
     float min_match_sq_dis = 1.0f;
     bool built = false;
+    bool geom_valid = false;   // ox.. nz describe a box (with margin) laid out by a bounds pass; reusable while the clouds keep fitting
+    float geom_sq_dis = 0.f;   // the acceptance radius that geometry was derived from
     int cur = 0;               // which of the two cell arrays (cell_start / cell_fill) holds the current index
     bool twin_clean = false;   // the other one has been cleared for the next build
     int *cells(int which) const { return (which ? cell_fill : cell_start).as<int>() + 3; }   // see grid.hip: cells + 1 is 16-byte aligned
@@ -206,6 +208,8 @@ struct mlh_ctx {
     mlh::DevBuf state;       // SolverState
     mlh::DevBuf partials;    // NE_STRIDE doubles per fit/linearise tile (surf tiles, then corner tiles)
     int n_partial_tiles = 0;
+    mlh::DevBuf oob_flag;    // map staging: bit k set = the cloud of kind k has points outside its grid box
+    bool oob_init = false;
     mlh::DevBuf ticket;      // arrival counter of the fused GN finish
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
@@ -224,6 +228,9 @@ struct mlh_ctx {
     mlh::DevBuf fused_part;  // per-append, per-kind, per-workgroup partial bounds of the appended points
     int fused_parts = 0;
     float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
+    bool fused_strided = true;    // MLH_FUSED_STRIDED=0: 32 consecutive features per workgroup (A/B runs)
+    bool fused_disable = true;    // MLH_FUSED=1 in the environment at mlh_create: the single-launch match kernel instead of the (faster,
+                                  // see DESIGN.md section 6) two-kernel path -- kept for A/B runs and held to the same parity tests
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
@@ -291,6 +298,8 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);
+int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsigned char *const *src, const int *n, int stride, const float *sq_dis,
+                        mlh::HostPublish *pub, unsigned long long seq);
 // match.hip
 struct MatchArgs {
     int kind_mask = 3;   // bit MLH_SURF, bit MLH_CORNER: which feature kinds take part in the launch
@@ -328,7 +337,7 @@ int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double 
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
 int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks);
 void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream
-int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks = 0);
+int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks = 0, const double *init_pose = nullptr);
 int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot);
 int lm_finish_launch(mlh_ctx *ctx, int stat_slot);
 

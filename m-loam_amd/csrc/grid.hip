@@ -13,6 +13,7 @@
 // so the next build starts from zeros without a clear launch; with few chunks (<= 4096) the add pass also sums the chunk
 // totals before it itself instead of a separate single-workgroup scan launch.
 #include "ctx.hpp"
+#include <chrono>
 #include <cmath>
 #include <climits>
 
@@ -34,6 +35,7 @@ static inline float key_to_float(int k)
 // bounding box as order-preserving integer keys: one partial record per workgroup (no atomics: a few thousand wavefronts hammering six
 // words cost 0.5 ms on a 500 k map), folded by the host, which needs the box for the grid dimensions anyway
 constexpr int BOUNDS_BLOCKS = 128;
+constexpr float GRID_MARGIN_XY = 2.f, GRID_MARGIN_Z = 1.f;
 __global__ __launch_bounds__(256) void bounds_kernel(const float4 *__restrict__ pts, int n, int *__restrict__ partial)
 {
     __shared__ int lds[4][6];
@@ -273,10 +275,14 @@ static int bounds_finish(mlh_ctx *ctx, MapGrid &g, const int *hp, float min_matc
         if (!std::isfinite(mn[d]) || !std::isfinite(mx[d])) return fail(ctx, MLH_ERR_INVALID, "map cloud has non-finite coordinates");
     g.h = std::sqrt(min_match_sq_dis) * 1.001f;
     g.inv_h = 1.0f / g.h;
-    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-    g.nx = int(std::floor((mx[0] - g.ox) * g.inv_h)) + 1;
-    g.ny = int(std::floor((mx[1] - g.oy) * g.inv_h)) + 1;
-    g.nz = int(std::floor((mx[2] - g.oz) * g.inv_h)) + 1;
+    // the box is laid GRID_MARGIN cells wider than the cloud (one cell in z): the next frames' local maps -- the same keyframe window
+    // moved a little -- then fit the geometry already set up, and mlh_map_set skips this host round trip (map_stage_and_build)
+    g.ox = mn[0] - GRID_MARGIN_XY * g.h; g.oy = mn[1] - GRID_MARGIN_XY * g.h; g.oz = mn[2] - GRID_MARGIN_Z * g.h;
+    g.nx = int(std::floor((mx[0] + GRID_MARGIN_XY * g.h - g.ox) * g.inv_h)) + 1;
+    g.ny = int(std::floor((mx[1] + GRID_MARGIN_XY * g.h - g.oy) * g.inv_h)) + 1;
+    g.nz = int(std::floor((mx[2] + GRID_MARGIN_Z * g.h - g.oz) * g.inv_h)) + 1;
+    g.geom_sq_dis = min_match_sq_dis;
+    g.geom_valid = true;
     g.ncell = (long long)g.nx * g.ny * g.nz;
     if (g.ncell >= (1ll << 31) - 2 * SCAN_CHUNK) return fail(ctx, MLH_ERR_UNSUPPORTED, "map extent needs more than 2^31 cells");
     const int nb = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);   // covers ncell + 1 entries
@@ -337,6 +343,109 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
     prof_end(ctx, MLH_K_GRID_BUILD);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < nj; ++k) grids[k]->built = true;
+    return MLH_OK;
+}
+
+// ---- a frame's local map arrives as a cloud of caller records: pack to float4 {x,y,z,index} and, in the same pass, check that every
+// point lies inside the grid box already set up for this kind (flag word, OR-ed). One launch for both maps.
+struct PackJob { const unsigned char *src; float4 *out; int n, stride; float lo[3], hi[3]; int nb; };
+struct PackJobs { PackJob j[2]; int *oob; };
+__global__ __launch_bounds__(256) void pack_check_kernel(PackJobs G)
+{
+    const int job = blockIdx.x >= G.j[0].nb ? 1 : 0;
+    const PackJob &J = G.j[job];
+    const int i = (job ? blockIdx.x - G.j[0].nb : blockIdx.x) * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < J.n) {
+        const float *rec = reinterpret_cast<const float *>(J.src + size_t(i) * J.stride);
+        const float x = rec[0], y = rec[1], z = rec[2];
+        J.out[i] = make_float4(x, y, z, __int_as_float(i));
+        bad = !(x >= J.lo[0] && x < J.hi[0] && y >= J.lo[1] && y < J.hi[1] && z >= J.lo[2] && z < J.hi[2]);   // NaN -> bad
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(G.oob, 1 << job);
+}
+
+__global__ void publish_flag_kernel(int *oob, HostPublish *h, unsigned long long seq)
+{
+    if (threadIdx.x == 0) {
+        h->done = *oob;          // the record's `done` slot carries the flag word here
+        *oob = 0;
+        __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Stages 1 or 2 clouds (device pointers to strided records) and builds their indices. When a kind's grid geometry from an earlier call
+// still applies (same acceptance radius), nothing waits for the host until the end: pack + fit check, index build, then ONE pinned-memory
+// hand-shake that returns the fit flags; only a cloud that has outgrown its box takes the bounds round trip (and gets a new box).
+int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsigned char *const *src, const int *n, int stride, const float *sq_dis,
+                        HostPublish *pub, unsigned long long seq)
+{
+    hipStream_t st = ctx->stream;
+    PackJobs G;
+    std::memset(&G, 0, sizeof(G));
+    MLH_HIP(ctx, ctx->oob_flag.ensure(sizeof(int)));
+    if (!ctx->oob_init) { MLH_HIP(ctx, hipMemsetAsync(ctx->oob_flag.p, 0, sizeof(int), st)); ctx->oob_init = true; }
+    G.oob = ctx->oob_flag.as<int>();
+    MapGrid *grids[2];
+    int need_bounds = 0;
+    for (int k = 0; k < n_maps; ++k) {
+        MapGrid &g = ctx->map[kinds[k]];
+        grids[k] = &g;
+        g.built = false;
+        MLH_HIP(ctx, g.raw.ensure(sizeof(float4) * size_t(n[k])));
+        const bool reuse = g.geom_valid && g.geom_sq_dis == sq_dis[k];
+        if (!reuse) need_bounds |= 1 << k;
+        g.n = n[k];
+        g.min_match_sq_dis = sq_dis[k];
+        PackJob &J = G.j[k];
+        J.src = src[k]; J.out = g.raw.as<float4>(); J.n = n[k]; J.stride = stride; J.nb = (n[k] + 255) / 256;
+        // a box that accepts everything when there is no geometry to check against (the bounds pass follows anyway)
+        J.lo[0] = reuse ? g.ox : -INFINITY; J.lo[1] = reuse ? g.oy : -INFINITY; J.lo[2] = reuse ? g.oz : -INFINITY;
+        J.hi[0] = reuse ? g.ox + float(g.nx) * g.h : INFINITY; J.hi[1] = reuse ? g.oy + float(g.ny) * g.h : INFINITY;
+        J.hi[2] = reuse ? g.oz + float(g.nz) * g.h : INFINITY;
+    }
+    hipLaunchKernelGGL(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
+    MLH_HIP(ctx, hipGetLastError());
+    if (need_bounds != ((1 << n_maps) - 1)) {
+        // optimistic build of the kinds whose geometry is reused, then the flags
+        MapGrid *fast[2];
+        int nf = 0;
+        for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) {
+            MapGrid &g = *grids[k];
+            MLH_HIP(ctx, g.sorted.ensure(sizeof(float4) * size_t(g.n)));
+            MLH_HIP(ctx, g.cell_id.ensure(sizeof(int) * size_t(g.n)));
+            fast[nf++] = &g;
+        }
+        int rc = grid_build_grids(ctx, fast, nf, false);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
+    MLH_HIP(ctx, hipGetLastError());
+    // spin on the pinned record (every launch above has completed when the sequence number arrives)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                MLH_HIP(ctx, hipStreamSynchronize(st));
+                if (__atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "map staging did not complete");
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    const int oob = int(pub->done);
+    for (int k = 0; k < n_maps; ++k) if (oob & (1 << k)) need_bounds |= 1 << k;
+    if (need_bounds) {
+        MapGrid *slow[2];
+        int ns = 0;
+        for (int k = 0; k < n_maps; ++k) if (need_bounds & (1 << k)) { grids[k]->built = false; grids[k]->geom_valid = false; slow[ns++] = grids[k]; }
+        int rc = grid_build_grids(ctx, slow, ns, true);
+        if (rc) return rc;
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+    }
     return MLH_OK;
 }
 

@@ -196,5 +196,186 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
     }
 }
 
-// ---------------------------------------------------------------- per-feature evaluation (registers only)
+// ---------------------------------------------------------------- pruned 16-lane search (the fused match kernel, match.hip)
+// u32 group-min over a 16-lane row, DPP only
+__device__ __forceinline__ unsigned dpp_row_min_u32(unsigned m)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP1, 0xF, 0xF, false); m = o < m ? o : m;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP2, 0xF, 0xF, false); m = o < m ? o : m;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
+    return m;
+}
+
+constexpr int KNN_RUN_WORDS = 40;       // LDS ints per query group: [0..18] segment prefix offsets (+ end), [19..36] segment bases
+constexpr int KNN_SEG_BASE = 19;
+constexpr int KNN_TWO_PHASE_MIN = 128;  // candidates in the 27 cells from which the search goes near-cells-first and prunes the rest
+constexpr float KNN_PRUNE_SLACK = 1.0e-3f;   // metres taken off every face distance before a cell is pruned (covers the f32 rounding of
+                                             // the cell assignment; a pruned cell is farther than the bound by at least this much)
+
+// flat, balanced walk over the segments of the run table: candidate j of the concatenation goes to lane j % 16
+template <int K>
+__device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy, float qz, int gl, const int *lds_run, int total,
+                                           unsigned bound_bits, unsigned long long (&k)[K])
+{
+    int cr = 0, hi = lds_run[1], base = lds_run[KNN_SEG_BASE], lo = 0;
+    for (int j = gl; j < total; j += 16 * KNN_U) {
+        int addr[KNN_U];
+        bool v[KNN_U];
+#pragma unroll
+        for (int u = 0; u < KNN_U; ++u) {
+            const int jj = j + 16 * u;
+            v[u] = jj < total;
+            addr[u] = 0;
+            if (v[u]) {
+                while (jj >= hi) { ++cr; lo = hi; hi = lds_run[cr + 1]; base = lds_run[KNN_SEG_BASE + cr]; }
+                addr[u] = base + (jj - lo);
+            }
+        }
+        float4 p[KNN_U];
+#pragma unroll
+        for (int u = 0; u < KNN_U; ++u) p[u] = g.sorted[addr[u]];     // unconditional, back to back: one round trip per trip
+#pragma unroll
+        for (int u = 0; u < KNN_U; ++u) asm volatile("" : "+v"(p[u].w));   // keep the index word in the 16-byte load (the compiler would
+                                                                           // otherwise fetch it again, dependently, inside the insertion branch)
+#pragma unroll
+        for (int u = 0; u < KNN_U; ++u) {
+            if (v[u]) {
+                float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+                float d = dx * dx; d += dy * dy; d += dz * dz;
+                if (__float_as_uint(d) <= bound_bits)
+                    key_insert<K>(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
+            }
+        }
+    }
+}
+
+// inclusive sum over the 16 lanes of a row (DPP)
+__device__ __forceinline__ int row_scan16(int v, int gl)
+{
+    { const int t = dpp_row_shr<1>(v); if (gl >= 1) v += t; }
+    { const int t = dpp_row_shr<2>(v); if (gl >= 2) v += t; }
+    { const int t = dpp_row_shr<4>(v); if (gl >= 4) v += t; }
+    { const int t = dpp_row_shr<8>(v); if (gl >= 8) v += t; }
+    return v;
+}
+
+// run table of the group: every lane offers up to two pieces [bL, bL + lenL), [bR, bR + lenR); only non-empty pieces get a slot.
+// Returns the total number of candidates (uniform over the group).
+__device__ __forceinline__ int knn_fill_table16(int *lds_run, int gl, int bL, int lenL, int bR, int lenR)
+{
+    const int len = lenL + lenR, np = (lenL > 0 ? 1 : 0) + (lenR > 0 ? 1 : 0);
+    const int incl = row_scan16(len, gl), slot_incl = row_scan16(np, gl);
+    int slot = slot_incl - np;
+    if (lenL > 0) { lds_run[slot] = incl - len; lds_run[KNN_SEG_BASE + slot] = bL; ++slot; }
+    if (lenR > 0) { lds_run[slot] = incl - lenR; lds_run[KNN_SEG_BASE + slot] = bR; }
+    if (gl == 15) lds_run[slot_incl] = incl;                           // end sentinel behind the last slot
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    return __shfl(incl, 15, 16);
+}
+
+// Exact K-NN of (qx,qy,qz) by a group of 16 lanes; every lane returns the K keys ascending. Same result as knn_group<K, 16>, fewer
+// candidates read where the map is dense:
+//   lanes 0..8 fetch the FOUR cell_start words of their row (dy, dz) -> the three x-cells of the row separately, and the squared
+//   distance from the query to each cell's box (less a 1 mm slack). With fewer than KNN_TWO_PHASE_MIN points in the 27 cells the
+//   search is one flat walk over everything, as before (a second dependent round trip would not pay). Otherwise it goes
+//   near-cells-first: phase 1 walks the cells within tau of the query, tau ~ 1.3 x the K-th-neighbour distance a planar map of this
+//   density would give; the K-th smallest distance found there (merged over the lanes on the 32-bit distance words) is an upper bound
+//   B of the true K-th distance, and phase 2 walks only the cells that are not farther than sqrt(B) and were not read yet -- none,
+//   when tau was large enough. On the 0.2 m corner map this reads ~1/4 of the 27 cells' points.
+// lds_run: 2 * KNN_RUN_WORDS ints for this group.
+template <int K>
+__device__ __forceinline__ void knn_group16_pruned(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run,
+                                                   unsigned long long (&out)[K])
+{
+    unsigned long long k[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = KEY_INF;
+    const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
+    const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
+    const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
+    const int dyr = (gl % 3) - 1, dzr = ((gl / 3) % 3) - 1;
+    int w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    {
+        const int y = cy + dyr, z = cz + dzr;
+        if ((gl < 9) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+            const int row = (z * g.ny + y) * g.nx;
+            const int xa = min(max(cx - 1, 0), g.nx), xb = min(max(cx, 0), g.nx), xc = min(max(cx + 1, 0), g.nx), xd = min(max(cx + 2, 0), g.nx);
+            w0 = g.cell_start[row + xa]; w1 = g.cell_start[row + xb]; w2 = g.cell_start[row + xc]; w3 = g.cell_start[row + xd];
+        }
+    }
+    MLH_KSTAGE(2);
+    const int n27 = __shfl(row_scan16(w3 - w0, gl), 15, 16);
+    if (n27 >= K) {                                                     // uniform over the group
+        bool one_pass = n27 < KNN_TWO_PHASE_MIN;
+        float dL = 0.f, dM = 0.f, dR = 0.f;
+        int b1 = w0, e1 = w3;                                           // phase-1 range of this lane's row
+        if (!one_pass) {
+            const float h = 1.f / g.inv_h;
+            const float fx0 = g.ox + float(cx) * h, fy0 = g.oy + float(cy) * h, fz0 = g.oz + float(cz) * h;
+            const float gy = fmaxf((dyr < 0 ? qy - fy0 : (dyr > 0 ? (fy0 + h) - qy : 0.f)) - (dyr ? KNN_PRUNE_SLACK : 0.f), 0.f);
+            const float gz = fmaxf((dzr < 0 ? qz - fz0 : (dzr > 0 ? (fz0 + h) - qz : 0.f)) - (dzr ? KNN_PRUNE_SLACK : 0.f), 0.f);
+            const float gxl = fmaxf((qx - fx0) - KNN_PRUNE_SLACK, 0.f), gxr = fmaxf(((fx0 + h) - qx) - KNN_PRUNE_SLACK, 0.f);
+            dM = gy * gy + gz * gz; dL = dM + gxl * gxl; dR = dM + gxr * gxr;
+            // K-th neighbour of a planar map with n27 / 9 points per cell: r^2 = 9 K / (pi n27); tau^2 = 1.69 r^2, within [0.15^2, 0.6^2]
+            float tau2 = fminf(fmaxf((1.69f * 9.f * float(K) / 3.14159265f) / float(n27), 0.0225f), 0.36f);
+            int n1 = 0;
+            // a query off the surface (first iteration: the pose is still wrong) has nothing that close: widen until K points are in
+#pragma unroll 1
+            for (int widen = 0; widen < 3; ++widen) {
+                const bool inM = dM <= tau2;
+                b1 = inM ? (dL <= tau2 ? w0 : w1) : w3;
+                e1 = inM ? (dR <= tau2 ? w3 : w2) : w3;
+                n1 = __shfl(row_scan16(e1 - b1, gl), 15, 16);
+                if (n1 >= K) break;
+                tau2 *= 4.f;
+            }
+            if (n1 < K) { one_pass = true; b1 = w0; e1 = w3; }          // still too few points near the query: read everything at once
+        }
+        const int total1 = knn_fill_table16(lds_run, gl, b1, e1 - b1, 0, 0);
+        knn_walk16<K>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
+        if (!one_pass) {
+            // K-th smallest distance of phase 1 (merge of the lanes' sorted lists on the distance words; ties pop together, which can
+            // only enlarge the bound)
+            unsigned hd[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) hd[i] = (unsigned)(k[i] >> 32);
+            unsigned kth = 0x7f800000u;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                kth = dpp_row_min_u32(hd[0]);
+                if (hd[0] == kth) {
+#pragma unroll
+                    for (int i = 0; i < K - 1; ++i) hd[i] = hd[i + 1];
+                    hd[K - 1] = 0x7f800000u;
+                }
+            }
+            const float Bm = __uint_as_float(kth) * 1.0001f;
+            // cells not farther than the bound and not read in phase 1: at most one piece on either side of the phase-1 range
+            const bool keepM = dM <= Bm;
+            const int kb = keepM ? (dL <= Bm ? w0 : w1) : w3, ke = keepM ? (dR <= Bm ? w3 : w2) : w3;
+            const int lenL = max(min(ke, b1) - kb, 0), bR = max(kb, e1), lenR = max(ke - bR, 0);
+            const int total2 = knn_fill_table16(lds_run + KNN_RUN_WORDS, gl, kb, lenL, bR, lenR);
+            if (total2 > 0) knn_walk16<K>(g, qx, qy, qz, gl, lds_run + KNN_RUN_WORDS, total2, kth, k);
+        }
+    }
+    MLH_KSTAGE(3);
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        unsigned long long m = k[0];
+        m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
+        m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
+        m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
+        m = dpp_min_u64<DPP_ROW_MIRROR>(m);
+        out[t] = m;
+        if (k[0] == m && m != KEY_INF) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) k[i] = k[i + 1];
+            k[K - 1] = KEY_INF;
+        }
+    }
+}
+
 }  // namespace mlh

@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) void reduce_only_kernel(SumArgs sa, SolverStat
 }
 
 // ---------------------------------------------------------------- Levenberg-Marquardt kernels (bodies in solver_dev.hpp)
+struct InitPose { int use; double x[7]; };   // the pose this solve starts from, when it has not been stored in the state yet
 __global__ __launch_bounds__(256) void lm_begin_kernel(SumArgs sa, SolverState *S, double eig_thre, int max_it, IterStatDev *stat, int pre_reduced,
-                                                       int min_blocks)
+                                                       int min_blocks, InitPose ip)
 {
     __shared__ double ne[NE_STRIDE], cnt2[2], scratch[8 * 32];
+    if (ip.use && threadIdx.x < 7) S->x[threadIdx.x] = ip.x[threadIdx.x];     // ordered before the body by gather_ne's barriers
     gather_ne(sa, S, pre_reduced, ne, cnt2, scratch);
     if (threadIdx.x != 0) return;
     lm_begin_body(ne, cnt2, scratch, S, eig_thre, max_it, stat, min_blocks);
@@ -135,13 +137,16 @@ int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double 
     return MLH_OK;
 }
 
-int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks)
+int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int stat_slot, int min_blocks, const double *init_pose)
 {
     int pre = 0, rc = pre_reduce(ctx, 0, pre);
     if (rc) return rc;
+    InitPose ip;
+    ip.use = init_pose ? 1 : 0;
+    for (int i = 0; i < 7; ++i) ip.x[i] = init_pose ? init_pose[i] : 0.0;
     prof_begin(ctx, MLH_K_SOLVE);
     hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
-                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre, min_blocks);
+                       map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre, min_blocks, ip);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

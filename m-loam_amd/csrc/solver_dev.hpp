@@ -12,38 +12,39 @@ struct SumArgs {
     int lo[2], hi[2];  // two tile ranges [lo, hi) summed in this order (a pose block's surf tiles, then its corner tiles)
 };
 
-// 256 threads: column c = tid & 31, slice s = tid >> 5 sums every 8th tile of the ranges; the 8 slices are combined in fixed order.
+// NT threads (256 or 512): column c = tid & 31, slice s = tid >> 5 sums every (NT/32)-th tile of the ranges; the slices are combined in
+// fixed order.
 // Record layout: [0..20] J^T J upper, [21..26] J^T r, [27] cost, [28] count, [29] surf count, [30] corner count.
-__device__ inline void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS 8*32*/)
+template <int NT = 256, int U = 12>
+__device__ __noinline__ void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS (NT/32)*32*/)
 {
+    constexpr int NS = NT / 32;
     const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
     double v = 0.0;
     if (a.p) {
-        // the two tile ranges (surf, corner) are walked as one list; 12 loads per trip are independent (in flight together) and
-        // feed four chains in a fixed association -> deterministic, and ~ntiles/96 round trips instead of one per tile (a frame's
-        // ~80 tiles: one)
+        // the two tile ranges (surf, corner) are walked as one list; the U loads of a trip are independent (in flight together) and
+        // feed four chains in a fixed association -> deterministic, and ~ntiles/(U NS) round trips instead of one per tile
         const int n0 = max(a.hi[0] - a.lo[0], 0), ntot = n0 + max(a.hi[1] - a.lo[1], 0);
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        for (int j = s; j < ntot; j += 96) {
-            double t[12];
+        double ch[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = s; j < ntot; j += U * NS) {
+            double t[U];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) {
-                const int jj = j + 8 * u;
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + NS * u;
                 const int tile = jj < n0 ? a.lo[0] + jj : a.lo[1] + (jj - n0);
                 t[u] = jj < ntot ? a.p[size_t(tile) * NE_STRIDE + c] : 0.0;
             }
-            v0 += t[0]; v1 += t[1]; v2 += t[2]; v3 += t[3];
-            v0 += t[4]; v1 += t[5]; v2 += t[6]; v3 += t[7];
-            v0 += t[8]; v1 += t[9]; v2 += t[10]; v3 += t[11];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ch[u & 3] += t[u];
         }
-        v = (v0 + v1) + (v2 + v3);
+        v = (ch[0] + ch[1]) + (ch[2] + ch[3]);
     }
     scratch[s * 32 + c] = v;
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += scratch[q * 32 + c];
+        for (int q = 0; q < NS; ++q) t += scratch[q * 32 + c];
         ne[c] = t;
     }
     __syncthreads();
@@ -78,30 +79,44 @@ __device__ __forceinline__ void unpack_H(const double *ne, double (&H)[36])
 // cyclic Jacobi, eigenvalues ascending, eigenvectors in the columns of V (row-major 6x6).
 // `a` (36) and `V` (36) must be in LDS (or global): they are indexed dynamically, and keeping them out of private memory
 // keeps the calling kernels free of scratch. One lane runs this; it is the rare path (degenerate geometry or stats requested).
-__device__ __noinline__ void jacobi6_mem(double *a, double *V, double *ev)
+__device__ __forceinline__ void jacobi6_mem(double *a, double *V, double *ev)
 {
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0 : 0.0;
+    // rare path (degenerate geometry / statistics requested): loops kept rolled so that this function stays at a few dozen VGPRs --
+    // a kernel's allocation is the maximum over everything it can call
+#pragma unroll 1
+    for (int i = 0; i < 36; ++i) V[i] = ((i % 7) == 0) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, dg = 0.0;
-        for (int i = 0; i < 6; ++i) { dg += a[i * 6 + i] * a[i * 6 + i]; for (int j = i + 1; j < 6; ++j) off += a[i * 6 + j] * a[i * 6 + j]; }
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) {
+            dg += a[i * 6 + i] * a[i * 6 + i];
+#pragma unroll 1
+            for (int j = i + 1; j < 6; ++j) off += a[i * 6 + j] * a[i * 6 + j];
+        }
         if (off <= 1e-32 * dg || off == 0.0) break;
+#pragma unroll 1
         for (int p = 0; p < 5; ++p)
+#pragma unroll 1
             for (int q = p + 1; q < 6; ++q) {
                 double apq = a[p * 6 + q];
                 if (apq == 0.0) continue;
                 double theta = (a[q * 6 + q] - a[p * 6 + p]) / (2.0 * apq);
                 double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll 1
                 for (int k = 0; k < 6; ++k) {
                     double akp = a[k * 6 + p], akq = a[k * 6 + q];
                     a[k * 6 + p] = c * akp - s * akq;
                     a[k * 6 + q] = s * akp + c * akq;
                 }
+#pragma unroll 1
                 for (int k = 0; k < 6; ++k) {
                     double apk = a[p * 6 + k], aqk = a[q * 6 + k];
                     a[p * 6 + k] = c * apk - s * aqk;
                     a[q * 6 + k] = s * apk + c * aqk;
                 }
+#pragma unroll 1
                 for (int k = 0; k < 6; ++k) {
                     double vkp = V[k * 6 + p], vkq = V[k * 6 + q];
                     V[k * 6 + p] = c * vkp - s * vkq;
@@ -109,12 +124,16 @@ __device__ __noinline__ void jacobi6_mem(double *a, double *V, double *ev)
                 }
             }
     }
+#pragma unroll 1
     for (int i = 0; i < 6; ++i) ev[i] = a[i * 6 + i];
+#pragma unroll 1
     for (int i = 0; i < 5; ++i) {
         int k = i;
+#pragma unroll 1
         for (int j = i + 1; j < 6; ++j) if (ev[j] < ev[k]) k = j;
         if (k != i) {
             double t = ev[i]; ev[i] = ev[k]; ev[k] = t;
+#pragma unroll 1
             for (int r = 0; r < 6; ++r) { double u = V[r * 6 + i]; V[r * 6 + i] = V[r * 6 + k]; V[r * 6 + k] = u; }
         }
     }
@@ -128,19 +147,27 @@ __device__ __noinline__ bool eval_degeneracy_mem(const double *ne, double thre, 
 {
     double *a = work, *Vf = work + 36, *ev = work + 72, *Vupd = work + 78;
     int q = 0;
-    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) { a[i * 6 + j] = ne[q]; a[j * 6 + i] = ne[q]; ++q; }
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i)
+#pragma unroll 1
+        for (int j = i; j < 6; ++j) { a[i * 6 + j] = ne[q]; a[j * 6 + i] = ne[q]; ++q; }
     jacobi6_mem(a, Vf, ev);
     bool deg = false, stop = false;
     int first_kept = 6;
+#pragma unroll 1
     for (int j = 0; j < 6; ++j) {
         if (!stop && ev[j] < thre) deg = true;
         else { if (!stop) first_kept = j; stop = true; }
     }
+#pragma unroll 1
     for (int r = 0; r < 6; ++r)
+#pragma unroll 1
         for (int c = 0; c < 6; ++c) {
             double s = 0.0;
-            if (deg) { for (int j = first_kept; j < 6; ++j) s += Vf[r * 6 + j] * Vf[c * 6 + j]; }
-            else s = (r == c) ? 1.0 : 0.0;
+            if (deg) {
+#pragma unroll 1
+                for (int j = first_kept; j < 6; ++j) s += Vf[r * 6 + j] * Vf[c * 6 + j];
+            } else s = (r == c) ? 1.0 : 0.0;
             Vupd[r * 6 + c] = s;
         }
     return deg;
@@ -324,7 +351,7 @@ __device__ __noinline__ void write_stat_common(IterStatDev *st, const double *ne
 //   freeze = 1: an extrinsic block whose lambda_min is below the threshold is not updated at all (estimator.cpp:1662-1676)
 // `ne` / `cnt2`: the reduced record in LDS; x: the block's pose; S (nullable): the solver state that mirrors block 0.
 template <bool REG_JACOBI = false>
-__device__ inline void gn_finish2(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
+__device__ __forceinline__ void gn_finish2(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
                                   IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
 {
     const int lane = threadIdx.x & 63;
@@ -370,11 +397,108 @@ __device__ inline void gn_finish2(const double *ne, const double *cnt2, double *
 }
 
 
+// ---------------------------------------------------------------- the same tail, spread over the lanes of ONE wavefront
+// gn_finish2 keeps two whole packed factorisations in the registers of two lanes (~120 VGPRs): inlined into a kernel whose other
+// 500 threads run the correspondence search, that allocation would set the whole launch's occupancy. Here every lane owns ONE ROW
+// of the lower triangle: lanes 0..5 factorise H, lanes 8..13 factorise H - thre*I (positive definite <=> nothing degenerate) in
+// lock-step; a column step broadcasts row j's finished entries with v_readlane (uniform source lane, no LDS trip), so a lane
+// carries 6 + 6 doubles. Same operations in the same order as chol6p_factor / chol6p_substitute.
+__device__ __forceinline__ double bcast_pair(double v, int j, bool grp_b)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int alo = __builtin_amdgcn_readlane(lo, j), ahi = __builtin_amdgcn_readlane(hi, j);
+    const int blo = __builtin_amdgcn_readlane(lo, 8 + j), bhi = __builtin_amdgcn_readlane(hi, 8 + j);
+    return __hiloint2double(grp_b ? bhi : ahi, grp_b ? blo : alo);
+}
+
+// Called by ALL 64 lanes of one wavefront, converged. Arguments as gn_finish2.
+__device__ __forceinline__ void gn_finish_wave(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
+                                               IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 7;
+    const bool grp_b = (lane & 8) != 0;
+    double xc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) xc[q] = x[q];          // issued before the factorisation: the pose arrives while it runs
+    double a[6], colv[6], rinv[6], d[6];
+    bool pd = false, not_degenerate_fast = false;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2 && !pd; ++attempt) {
+        // attempt 0: H (lanes 0..7) and H - thre*I (lanes 8..15); attempt 1 (H not positive definite): H + 1e-6 I
+        const double shift = attempt ? -1e-6 : (grp_b ? eig_thre * (1.0 + 1e-9) : 0.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int q = k * 6 - (k * (k - 1)) / 2 + (i - k);          // upper-packed index of (k, i), k <= i
+            a[k] = (i < 6 && k <= i) ? ne[q] - ((k == i) ? shift : 0.0) : 0.0;
+            colv[k] = 0.0;
+        }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double rj[6];
+#pragma unroll
+            for (int k = 0; k < j; ++k) rj[k] = bcast_pair(a[k], j, grp_b);     // L(j, k)
+            double t = a[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= a[k] * rj[k];
+            const double sj = bcast_pair(t, j, grp_b);
+            ok = ok && (sj > 0.0);
+            const double r = rsqrt(sj);
+            rinv[j] = r;
+            a[j] = (i == j) ? sj * r : t * r;
+#pragma unroll
+            for (int k = 0; k < j; ++k) if (i == k) colv[j] = rj[k];            // the transpose: colv[j] = L(j, i), j > i
+        }
+        pd = __builtin_amdgcn_readlane(ok ? 1 : 0, 0) != 0;
+        if (attempt == 0) not_degenerate_fast = __builtin_amdgcn_readlane(ok ? 1 : 0, 8) != 0;
+    }
+    if (pd) {
+        // L y = -g, then L^T d = y (group A; the other lanes compute along and are ignored)
+        double b = (i < 6) ? -ne[NE_G + i] : 0.0, y = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double yk = b * rinv[k];
+            const double ykb = bcast_pair(yk, k, false);
+            if (i == k) y = yk;
+            if (i > k) b -= a[k] * ykb;
+        }
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+            double sacc = y;
+#pragma unroll
+            for (int m = k + 1; m < 6; ++m) sacc -= colv[m] * d[m];
+            d[k] = bcast_pair(sacc * rinv[k], k, false);
+        }
+    }
+    if (lane != 0) return;
+    bool deg = false;
+    const bool slow = !(stat == nullptr && not_degenerate_fast);
+    if (slow) deg = eval_degeneracy_mem(ne, eig_thre, work);
+    const bool frozen = freeze && (slow ? deg : false);
+    if (pd && !frozen) {
+        double xn[7];
+        pose_plus(xc, d, slow ? work + 78 : nullptr, xn);   // V_update = I on the fast path
+#pragma unroll
+        for (int q = 0; q < 7; ++q) x[q] = xn[q];
+    }
+    if (S) {
+        for (int q = 0; q < NE_STRIDE; ++q) S->ne[q] = ne[q];
+        for (int q = 0; q < 36; ++q) S->V[q] = slow ? work[78 + q] : (((q % 7) == 0) ? 1.0 : 0.0);
+    }
+    if (stat) {
+        write_stat_common(stat, ne, cnt2, work + 72, deg);
+        stat->final_cost = ne[NE_COST];
+        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = frozen ? 1 : 0;
+        for (int q = 0; q < 7; ++q) stat->pose_after[q] = x[q];
+    }
+}
+
 // ---------------------------------------------------------------- Levenberg-Marquardt (Ceres trust-region semantics)
 // Bodies of the LM begin / step, run by ONE thread after the record has been summed into LDS. They are device functions so
 // that both the stand-alone single-workgroup kernels (solver.hip: multi-GPU, tracker, good-feature paths) and the last-arriving
 // workgroup of the linearisation kernels (match.hip: scan2map on one GPU -- no extra launch per LM iteration) can run them.
-__device__ inline double gradient_max_norm(const SolverState *S)
+__device__ __forceinline__ double gradient_max_norm(const SolverState *S)
 {
     double ng[6], xp[7];
     for (int i = 0; i < 6; ++i) ng[i] = -S->ne[NE_G + i];
@@ -384,7 +508,7 @@ __device__ inline double gradient_max_norm(const SolverState *S)
     return m;
 }
 
-__device__ inline void lm_propose(SolverState *S, int max_it)
+__device__ __forceinline__ void lm_propose(SolverState *S, int max_it)
 {
     while (true) {
         if (S->iteration >= max_it) { S->done = 1; S->termination = 0; return; }
@@ -434,7 +558,7 @@ __device__ inline void lm_propose(SolverState *S, int max_it)
 }
 
 // ne / cnt2 / scratch: LDS. eig_thre < 0: no degeneracy handling (V_update = I); stat may be null
-__device__ inline void lm_begin_body(const double *ne, const double *cnt2, double *scratch, SolverState *S, double eig_thre, int max_it,
+__device__ __forceinline__ void lm_begin_body(const double *ne, const double *cnt2, double *scratch, SolverState *S, double eig_thre, int max_it,
                                      IterStatDev *stat, int min_blocks)
 {
     // evalDegenracy. Nobody asked for the eigenvalues (stat == null): H - thre*I positive definite <=> lambda_min > thre <=> nothing
@@ -467,7 +591,7 @@ __device__ inline void lm_begin_body(const double *ne, const double *cnt2, doubl
 }
 
 // ce: the summed record at the candidate pose (LDS)
-__device__ inline void lm_step_body(const double *ce, SolverState *S, int max_it)
+__device__ __forceinline__ void lm_step_body(const double *ce, SolverState *S, int max_it)
 {
     S->evaluations++;
     double step_norm = 0.0, x_norm = 0.0;

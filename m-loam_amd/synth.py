@@ -304,7 +304,10 @@ def simulate_scan(scene: Scene, pose_w_body: np.ndarray, body_T_laser: np.ndarra
     ce, se = np.cos(elev)[:, None], np.sin(elev)[:, None]
     d_l = np.stack([ce * np.cos(azim)[None, :], ce * np.sin(azim)[None, :], np.broadcast_to(se, (n_rings, n_cols))], axis=2)
     d_l = d_l.reshape(-1, 3)
-    d_w = d_l @ T_wl[:3, :3].T
+    # explicit sums, not a BLAS call: a threaded GEMM rounds differently depending on how it splits the rows among its threads (and
+    # that depends on what else runs in the process), which would make the generated inputs differ from run to run
+    Rw = T_wl[:3, :3]
+    d_w = np.stack([(d_l[:, 0] * Rw[r, 0] + d_l[:, 1] * Rw[r, 1]) + d_l[:, 2] * Rw[r, 2] for r in range(3)], axis=1)
     t = _raycast(scene, T_wl[:3, 3], d_w, max_range)
     t = t + rng.normal(0.0, range_noise, t.shape)
     ok = np.isfinite(t) & (t < max_range) & (t > 0.8)
@@ -327,7 +330,9 @@ def simulate_scan(scene: Scene, pose_w_body: np.ndarray, body_T_laser: np.ndarra
 
 
 def transform_points(points_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
-    return (points_xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    p = points_xyz.astype(np.float64)
+    out = np.stack([((p[:, 0] * T[r, 0] + p[:, 1] * T[r, 1]) + p[:, 2] * T[r, 2]) + T[r, 3] for r in range(3)], axis=1)   # no BLAS: see simulate_scan
+    return out.astype(np.float32)
 
 
 def perturbed_pose(gt_pose7: np.ndarray, seed: int = 43, dt: float = 0.2, drot_deg: float = 2.0) -> np.ndarray:

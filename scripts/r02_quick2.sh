@@ -1,0 +1,14 @@
+#!/bin/bash
+OUT=$PWD/gpurun_out/r02q
+mkdir -p $OUT
+timeout 900 python -m pytest tests -m gpu -q -x > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+tail -4 $OUT/pytest.log
+timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --map-rebuild-only > $OUT/bench_fused.json 2> $OUT/bench.log
+MLH_FUSED=0 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --map-rebuild-only > $OUT/bench_unfused.json 2>> $OUT/bench.log
+python - <<'PY'
+import json
+for n in ("fused","unfused"):
+    d=json.load(open(f"gpurun_out/r02q/bench_{n}.json"))
+    print(n, d["ms_per_step"], d["value"], d["kernel_us_per_launch"], d["config"]["n_valid_per_iter_surf_corner"], d["final_pose"][:3], d.get("scan2map",{}).get("ms_per_frame"))
+PY
+MLOAM_HIP_LIB=m-loam_amd/lib/libmloam_hip_dbg.so python scripts/stageclock_fused.py 2>&1 | tail -28

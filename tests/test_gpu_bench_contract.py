@@ -30,4 +30,11 @@ def test_bench_json_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and isinstance(cb["sample"], str)
     assert d["value"] > 20 * cb["value"]       # the north star asks for >= 10x the CPU path at 1 GPU
-    assert abs(d["value"] - (d["config"]["features_surf"] + d["config"]["features_corner"]) * d["config"]["gn_iters_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    # value = valid correspondences (residual + Jacobian produced and reduced) per second, summed over the iterations of a step
+    n_valid = sum(a + b for a, b in d["config"]["n_valid_per_iter_surf_corner"])
+    assert n_valid == d["valid_correspondences_per_step"] and len(d["config"]["n_valid_per_iter_surf_corner"]) == d["config"]["gn_iters_per_step"]
+    assert abs(d["value"] - n_valid / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    n_q = (d["config"]["features_surf"] + d["config"]["features_corner"]) * d["config"]["gn_iters_per_step"]
+    assert abs(d["queries_per_s"] - n_q / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["queries_per_s"] and n_valid <= n_q
+    # the corner half of the workload is real: >= 30 % of the corner queries end in a linearised correspondence
+    assert min(b for _, b in d["config"]["n_valid_per_iter_surf_corner"]) >= 0.3 * d["config"]["features_corner"]

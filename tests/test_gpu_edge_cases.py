@@ -200,3 +200,40 @@ def test_tracker_edge_cases(ctx, mla, orc, track_case):
     ctx.track_set_cur(mla.CORNER, tc["corner_sharp"][:1])
     valid, _ = ctx.track_match(mla.CORNER, np.array([0, 0, 0, 0, 0, 0, 1.0]))
     assert not valid.any()
+
+
+def test_map_staging_paths_agree(mla, synth, case16):
+    """mlh_map_set / mlh_map_set_pair: first call lays the grid box out (bounds pass), later calls reuse it while the cloud fits, a cloud
+    that outgrows it is detected on the device and re-laid -- the k-NN answers never depend on which way a call went."""
+    rng = np.random.default_rng(5)
+    surf, corner = case16["surf_map"], case16["corner_map"]
+    q = (surf[rng.choice(len(surf), 4000, replace=False)] + rng.normal(0, 0.15, (4000, 3))).astype(np.float32)
+    ref_ctx = mla.Context(0)
+    ref_ctx.map_set(mla.SURF, surf)
+    ref = ref_ctx.knn(mla.SURF, q)
+    c = mla.Context(0)
+    c.map_set_pair(surf, corner)                       # bounds pass for both
+    a = c.knn(mla.SURF, q)
+    assert np.array_equal(a[0], ref[0]) and np.array_equal(a[1].view(np.uint32), ref[1].view(np.uint32))
+    sub = np.ascontiguousarray(surf[: len(surf) // 2])
+    c.map_set_pair(sub, corner)                        # fits the existing box: no host round trip for the bounds
+    ref_ctx.map_set(mla.SURF, sub)                     # (this one reuses its own box too)
+    a, r = c.knn(mla.SURF, q), ref_ctx.knn(mla.SURF, q)
+    assert np.array_equal(a[0], r[0]) and np.array_equal(a[1].view(np.uint32), r[1].view(np.uint32))
+    fresh = mla.Context(0)
+    fresh.map_set(mla.SURF, sub)                       # a context that never saw the larger cloud: different box, same answers
+    f = fresh.knn(mla.SURF, q)
+    assert np.array_equal(a[0], f[0]) and np.array_equal(a[1].view(np.uint32), f[1].view(np.uint32))
+    grown = np.concatenate([surf, surf[:500] + np.array([40.0, -35.0, 6.0], np.float32)]).astype(np.float32)
+    c.map_set_pair(grown, corner)                      # outgrows the box: detected on the device, box laid out again
+    fresh.map_set(mla.SURF, grown)
+    qq = np.concatenate([q, grown[-200:] + 0.05]).astype(np.float32)
+    a, f = c.knn(mla.SURF, qq), fresh.knn(mla.SURF, qq)
+    assert np.array_equal(a[0], f[0]) and np.array_equal(a[1].view(np.uint32), f[1].view(np.uint32))
+    assert np.all(a[1][-200:, 0] < 0.1)                # the added points are found
+    bad = grown.copy()
+    bad[17, 1] = np.nan
+    with pytest.raises(mla.MlhError):
+        c.map_set(mla.SURF, bad)                       # non-finite coordinates are still rejected (through the bounds pass)
+    for x in (ref_ctx, c, fresh):
+        x.close()
