@@ -156,6 +156,15 @@ int mlh_pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *po
                       const int32_t *frame_idx, const int32_t *ext_idx);
 int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                            double *residuals, double *jacobians);
+/* The normal equations of the COUPLED window problem those factors form (BASELINE config 4; Estimator::optimizeMap, estimator.cpp:687-848):
+ * local parameters in para_ids order [pivot | frames 0..n_frames) | extrinsics 0..n_ext)], 6 each (PoseLocalParameterization::ComputeJacobian
+ * = [I6; 0]), D = 6 (1 + n_frames + n_ext). What Estimator::evalResidual gets from problem.Evaluate (estimator.cpp:1577-1595) -- rows
+ * loss-corrected with HuberLoss(huber_delta) (1.0 at estimator.cpp:602; <= 0: no loss), every listed block variable -- reduced on the device:
+ * JtJ D x D row-major (symmetric, both triangles filled), Jtr D, cost = sum rho(r^2)/2, n_residuals. evalDegenracy (estimator.cpp:1598-1680)
+ * reads its diagonal 6x6 blocks (mlh_eval_degeneracy on each); with several GPUs (factors split over the ranks) the record is summed with
+ * mlh_allreduce_f64 -- D (D + 1) / 2 + D + 2 = 326 doubles for the 24-dimensional hercules window. Deterministic (no atomics). */
+int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
+                            double huber_delta, double *JtJ, double *Jtr, double *cost, int32_t *n_residuals);
 
 /* (f1) cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158): moves one keyframe's feature cloud into the map frame while
  * building the local map (extractSurroundingKeyFrames, cpp:254-354). Per point (intensity = LiDAR index n):
@@ -191,9 +200,14 @@ int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, in
 int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                      float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);
-/* exact k-NN against the resident map (pcl::KdTreeFLANN::nearestKSearch role; feature_extract.hpp:666, 813):
+/* k-NN against the resident map (pcl::KdTreeFLANN::nearestKSearch role; feature_extract.hpp:666, 813):
  * queries are xyz triples (HOST), outputs idx[nq*k] (original map indices, ascending distance, ties by index) and
- * sqdist[nq*k]; slots beyond the number of points found inside the 27-cell neighbourhood are -1 / +inf. k = 5. */
+ * sqdist[nq*k]; slots beyond the number of points found inside the 27-cell neighbourhood are -1 / +inf. k = 5.
+ * EXACT ONLY INSIDE THE ACCEPTANCE RADIUS: the search covers the 27 cells around the query (cell edge 1.001 * sqrt(min_match_sq_dis)),
+ * so indices and distances equal a kd-tree's for every neighbour with sqdist < min_match_sq_dis -- all the mapper looks at
+ * (sq_dis[k-1] < MIN_MATCH_SQ_DIS, hpp:667/814). A returned neighbour with sqdist >= min_match_sq_dis may be farther than a map
+ * point just outside the 27 cells; a caller that needs exact neighbours beyond that radius must stage the map with a larger
+ * min_match_sq_dis. */
 int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int32_t *idx, float *sqdist);
 
 /* ---------------------------------------------------------------- scan features (the cloud_data / laser_cloud argument)

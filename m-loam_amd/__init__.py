@@ -113,6 +113,7 @@ def load_library():
     lib.mlh_track_cloud.argtypes = [vp, vp, vp, vp]
     lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.mlh_pure_odom_evaluate.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
+    lib.mlh_pure_odom_normal_eq.argtypes = [vp, vp, vp, ci, vp, ci, cd, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_set_pair.argtypes = [vp, vp, ci, vp, ci, ci, cf, ci]
@@ -142,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
-    "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
+    "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
@@ -396,6 +397,15 @@ class Context:
         r = np.zeros(self._n_odom); J = np.zeros((self._n_odom, 3, 7)) if want_jacobians else None
         self._ck(self.lib.mlh_pure_odom_evaluate(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), _p(r), _p(J) if J is not None else None))
         return r, J
+
+    def pure_odom_normal_eq(self, pivot, frames, exts, huber_delta=1.0):
+        """J^T J, J^T r, cost, count of the coupled window problem over [pivot | frames | extrinsics] (6 local parameters each)."""
+        pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7)
+        ex = np.ascontiguousarray(exts, np.float64).reshape(-1, 7)
+        D = 6 * (1 + len(fr) + len(ex))
+        H = np.zeros((D, D)); g = np.zeros(D); cost = C.c_double(0); cnt = C.c_int32(0)
+        self._ck(self.lib.mlh_pure_odom_normal_eq(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), float(huber_delta), _p(H), _p(g), C.byref(cost), C.byref(cnt)))
+        return dict(H=H, g=g, cost=cost.value, count=cnt.value)
 
     def downsample_current_scan(self, kind, points4, leaf, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6, fetch=True):
         """downsampleCurrentScan for one kind; the result becomes the kind's feature set and, with fetch, is also returned (m, 11)

@@ -453,6 +453,14 @@ int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *fr
     return pure_odom_evaluate(ctx, pivot, frames, n_frames, exts, n_ext, residuals, jacobians);
 }
 
+int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
+                            double huber_delta, double *JtJ, double *Jtr, double *cost, int32_t *n_residuals)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return pure_odom_normal_eq(ctx, pivot, frames, n_frames, exts, n_ext, huber_delta, JtJ, Jtr, cost, n_residuals);
+}
+
 int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                                    int trace_offset_bytes, const double pose_global[7], const double cov_global[36], const double *ext_poses,
                                    const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,

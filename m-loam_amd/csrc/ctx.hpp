@@ -84,7 +84,11 @@ struct DevBuf {
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&np, want);
         if (e != hipSuccess) return e;
-        if (p && keep) { e = hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e; e = hipStreamSynchronize(st); if (e != hipSuccess) return e; }
+        if (p && keep) {
+            e = hipMemcpyAsync(np, p, keep, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(np); return e; }
+        }
         if (p) (void)hipFree(p);
         p = np; cap = want;
         return hipSuccess;
@@ -164,6 +168,11 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     DevBuf tab, idx, poses, r, J;
     int n = 0, max_frame = 0, max_ext = 0;
+    // normal equations of the coupled window problem: factor indices grouped by (frame, extrinsic) in 256-factor tiles
+    DevBuf perm, tile_group, partial, ne_out;
+    int n_tiles = 0, group_ext = 1;
+    bool tile_group_keyed = true;
+    std::vector<int> h_tile_group;
 };
 
 constexpr int FUSE_BLOCKS = 64;           // workgroups per kind of the fusion kernel: each leaves one partial bounding box of what it appended (frontend.hip)
@@ -272,6 +281,8 @@ int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points
                   const int32_t *frame_idx, const int32_t *ext_idx);
 int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                        double *residuals, double *jacobians);
+int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
+                        double *H, double *g, double *cost, int32_t *n_res);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
 // voxel.hip

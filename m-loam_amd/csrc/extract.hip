@@ -88,7 +88,10 @@ __device__ __forceinline__ void sort_sector(const float *sc, int sp, int len, un
         unsigned long long key = ~0ull;                          // padding sorts to the end
         if (k < len) {
             const int li = sp + k;
-            key = ((unsigned long long)__float_as_uint(sc[li]) << 32) | (unsigned)li;
+            const float c = sc[li];
+            // (curvature, index) ascending; a NaN curvature (non-finite input point) takes one canonical pattern above every number, so
+            // NaNs order by index among themselves whatever payload the arithmetic left in them
+            key = ((unsigned long long)((c != c) ? 0x7fc00000u : __float_as_uint(c)) << 32) | (unsigned)li;
         }
         v[r] = key;
     }
@@ -139,9 +142,11 @@ __device__ __forceinline__ SectorPicks walk_sector(const unsigned long long *kj,
             m = __ballot(elig);
         }
         __builtin_amdgcn_wave_barrier();
-        // sorted descending: once a candidate fails c > 0.1 every later one fails too
-        const unsigned long long inb = __ballot(k >= 0);
-        if (__ballot(c_ok) != inb) stop = true;
+        // sorted descending: once a NUMBER fails c > 0.1 every later candidate fails too. NaN curvatures (non-finite input points) sit
+        // at the top of the order and fail the test without saying anything about what follows: they are walked past, as the reference's
+        // loop walks past every candidate that does not qualify (cpp:166-215 has no early exit but the 21st pick)
+        const float cv = sc[li];
+        if (__ballot((k >= 0) && !c_ok && !(cv != cv)) != 0ull) stop = true;
     }
     R.npick = npick; R.my_pick = my_pick;
     // ---- flat walk, ascending curvature (cpp:219-256): 4 picks; the 4th is labelled but neither marked nor suppressing
@@ -458,6 +463,7 @@ int extract_run(mlh_ctx *ctx)
     const size_t lds = sizeof(float) * 4 * size_t(max_span) + sizeof(int) * 2 * size_t(max_span) + 8 + sizeof(unsigned long long) * 6 * size_t(P) +
                        sizeof(unsigned) * (size_t(max_span + 64 + 383) / 32 + 4) + size_t(max_span) + 16;
     if (lds > 160 * 1024 - 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring too long for the LDS-resident label kernel");
+    if (P > 2048) return fail(ctx, MLH_ERR_UNSUPPORTED, "sector longer than 2048 points");      // before anything is enqueued or bracketed
     MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(label_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 
     prof_begin(ctx, MLH_K_EXTRACT);
@@ -467,7 +473,6 @@ int extract_run(mlh_ctx *ctx)
     la.pts = sb.pts.as<float4>(); la.curv = sb.curvature.as<float>(); la.start = sb.start.as<int>(); la.end = sb.end.as<int>();
     la.label = sb.label.as<int>(); la.picked = sb.picked.as<int>(); la.stage = sb.stage.as<int>(); la.ring_counts = sb.ring_counts.as<int>();
     la.n = n; la.max_span = max_span; la.sort_p = P;
-    if (P > 2048) return fail(ctx, MLH_ERR_UNSUPPORTED, "sector longer than 2048 points");
     hipLaunchKernelGGL(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
     EmitArgs ea;
     ea.start = sb.start.as<int>(); ea.end = sb.end.as<int>(); ea.label = sb.label.as<int>(); ea.stage = sb.stage.as<int>();

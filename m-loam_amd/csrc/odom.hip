@@ -12,6 +12,7 @@
 // reference hands it, so parity means reproducing those.
 #include "ctx.hpp"
 #include "dev_math.hpp"
+#include <cfloat>
 
 namespace mlh {
 
@@ -45,10 +46,9 @@ __device__ __forceinline__ V3 row_skew(const V3 &a, const V3 &v)             // 
 }
 __device__ __forceinline__ V3 crossv(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
-__global__ __launch_bounds__(256) void pure_odom_kernel(OdomArgs A)
+// one factor: residual and (J != null) its three 1x7 rows [pivot | frame | extrinsic]
+__device__ __forceinline__ void odom_factor(const OdomArgs &A, int i, double &r_out, double *J)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.n) return;
     const double *tb = A.tab + size_t(i) * 10;
     const int type = A.idx[i * 3 + 0];
     const int fi = min(max(A.idx[i * 3 + 1], 0), A.n_frames - 1), ei = min(max(A.idx[i * 3 + 2], 0), A.n_ext - 1);
@@ -90,9 +90,8 @@ __global__ __launch_bounds__(256) void pure_odom_kernel(OdomArgs A)
         const V3 eta{k * nh.x, k * nh.y, k * nh.z};
         a = row_skew(eta, V3{ba.x - bb.x, ba.y - bb.y, ba.z - bb.z});
     }
-    A.r[i] = s * res;
-    if (!A.J) return;
-    double *J = A.J + size_t(i) * 21;
+    r_out = s * res;
+    if (!J) return;
     // row0 = a^T Rp^T: component c = sum_k a_k Rp[c][k] = (Rp a)_c
     const V3 row0 = matmul(Rp, a);
     // pivot block
@@ -124,6 +123,116 @@ __global__ __launch_bounds__(256) void pure_odom_kernel(OdomArgs A)
     J[17] = s * (-rot2.x); J[18] = s * (-rot2.y); J[19] = s * (-rot2.z); J[20] = 0.0;
 }
 
+__global__ __launch_bounds__(256) void pure_odom_kernel(OdomArgs A)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    double r;
+    odom_factor(A, i, r, A.J ? A.J + size_t(i) * 21 : nullptr);
+    A.r[i] = r;
+}
+
+// ---- normal equations of the coupled window problem (estimator.cpp:687-848): J^T J over the local parameters [pivot | frames | extrinsics]
+// A factor touches three 6-wide blocks (pivot, frame f, extrinsic e): v = its 18 loss-corrected Jacobian entries. Factors are grouped by
+// (f, e) when they are staged (every 256-factor tile belongs to ONE group), so a tile's contribution is one 18 x 18 symmetric block pattern:
+// the tile's rows go to LDS (18 v + corrected residual + cost + count per factor), then thread t owns output entry t -- one of the 171
+// upper-triangle products v_a v_b, the 18 v_a r, cost, count -- and sums it over the tile's rows in row order (fixed order: deterministic).
+// odom_ne_finish_kernel adds the tiles of a group in tile order and scatters the groups into the D x D matrix (LDS-resident), again in
+// fixed order. No atomics anywhere.
+constexpr int NE_ROW = 22;        // LDS doubles per factor: v[18], r, cost, count, pad
+constexpr int NE_OUT = 192;       // 171 + 18 + 2, padded
+struct OdomNeArgs {
+    OdomArgs A;
+    const int *perm;        // tiles * 256 factor indices grouped by (frame, ext); -1 = padding
+    double huber_delta;
+    double *partial;        // tiles x NE_OUT
+};
+
+__device__ __forceinline__ void ne_entry(int t, int &a, int &b)     // t < 171 -> (a, b), a <= b < 18, row-major upper triangle
+{
+    int row = 0, left = t;
+    while (left >= 18 - row) { left -= 18 - row; ++row; }
+    a = row; b = row + left;
+}
+
+__global__ __launch_bounds__(256) void odom_ne_kernel(OdomNeArgs G)
+{
+    __shared__ double V[256 * NE_ROW];
+    const int tile = blockIdx.x, k = threadIdx.x;
+    const int i = G.perm[tile * 256 + k];
+    double *row = V + k * NE_ROW;
+    if (i >= 0) {
+        double r, J[21];
+        odom_factor(G.A, i, r, J);
+        double sq = r * r, rho0 = sq, rho1 = 1.0;
+        if (G.huber_delta > 0.0) {
+            const double bb = G.huber_delta * G.huber_delta;
+            if (sq > bb) { const double rr = sqrt(sq); rho0 = 2.0 * G.huber_delta * rr - bb; rho1 = fmax(DBL_MIN, G.huber_delta / rr); }
+        }
+        const double sc = sqrt(rho1);
+#pragma unroll
+        for (int bl = 0; bl < 3; ++bl)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) row[bl * 6 + c] = J[bl * 7 + c] * sc;
+        row[18] = r * sc; row[19] = 0.5 * rho0; row[20] = 1.0; row[21] = 0.0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NE_ROW; ++c) row[c] = 0.0;
+    }
+    __syncthreads();
+    if (k < NE_OUT) {
+        double acc = 0.0;
+        if (k < 171 + 18 + 2) {
+            int a, b;
+            if (k < 171) ne_entry(k, a, b);
+            else if (k < 189) { a = k - 171; b = 18; }
+            else { a = k - 189 + 19; b = -1; }                           // cost / count columns, summed as they are
+            if (b >= 0) { for (int q = 0; q < 256; ++q) acc += V[q * NE_ROW + a] * V[q * NE_ROW + b]; }
+            else { for (int q = 0; q < 256; ++q) acc += V[q * NE_ROW + a]; }
+        }
+        G.partial[size_t(tile) * NE_OUT + k] = acc;
+    }
+}
+
+struct OdomNeFinish {
+    const double *partial;
+    const int *tile_group;  // per tile: frame * n_ext + ext
+    int n_tiles, n_frames, n_ext;
+    double *out;            // D*D + D + 2
+};
+__global__ __launch_bounds__(256) void odom_ne_finish_kernel(OdomNeFinish F)
+{
+    extern __shared__ double Hs[];            // D*D + D + 2
+    const int D = 6 * (1 + F.n_frames + F.n_ext), n_out = D * D + D + 2;
+    for (int q = threadIdx.x; q < n_out; q += 256) Hs[q] = 0.0;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 191) {
+        int a = 0, b = 0;
+        if (t < 171) ne_entry(t, a, b);
+        else if (t < 189) a = t - 171;
+        int tile = 0;
+        while (tile < F.n_tiles) {
+            const int g = F.tile_group[tile];
+            double acc = 0.0;
+            while (tile < F.n_tiles && F.tile_group[tile] == g) { acc += F.partial[size_t(tile) * NE_OUT + t]; ++tile; }   // tiles of a group: in order
+            const int f = g / F.n_ext, e = g % F.n_ext;
+            const int off[3] = {0, 6 * (1 + f), 6 * (1 + F.n_frames + e)};
+            if (t < 171) {
+                const int ra = off[a / 6] + a % 6, rb = off[b / 6] + b % 6;     // ra <= rb: the blocks are ordered pivot < frames < extrinsics
+                Hs[ra * D + rb] += acc;
+                if (ra != rb) Hs[rb * D + ra] += acc;
+            } else if (t < 189) {
+                Hs[D * D + off[a / 6] + a % 6] += acc;
+            } else {
+                Hs[D * D + D + (t - 189)] += acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n_out; q += 256) F.out[q] = Hs[q];
+}
+
 int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
                   const int32_t *frame_idx, const int32_t *ext_idx)
 {
@@ -150,6 +259,32 @@ int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points
     int mf = 0, me = 0;
     for (int i = 0; i < n; ++i) { mf = std::max(mf, frame_idx[i]); me = std::max(me, ext_idx[i]); if (frame_idx[i] < 0 || ext_idx[i] < 0) return fail(ctx, MLH_ERR_INVALID, "negative block index"); }
     O.max_frame = mf; O.max_ext = me;
+    // factors grouped by (frame, extrinsic) for the normal-equation kernel: stable counting sort of the indices, every group padded to whole
+    // 256-factor tiles (the group key uses the staged maxima; mlh_pure_odom_normal_eq re-derives (f, e) from it)
+    {
+        const int ne = me + 1, ng = (mf + 1) * ne;
+        std::vector<int> cnt(size_t(ng) + 1, 0);
+        for (int i = 0; i < n; ++i) cnt[size_t(frame_idx[i]) * ne + ext_idx[i] + 1]++;
+        std::vector<int> tile_start(size_t(ng) + 1, 0);
+        for (int g = 0; g < ng; ++g) tile_start[g + 1] = tile_start[g] + (cnt[g + 1] + 255) / 256;
+        const int n_tiles = tile_start[ng];
+        std::vector<int> perm(size_t(n_tiles) * 256, -1), fill(ng, 0), tgrp(size_t(n_tiles), 0);
+        for (int i = 0; i < n; ++i) {
+            const int g = frame_idx[i] * ne + ext_idx[i];
+            perm[size_t(tile_start[g]) * 256 + fill[g]++] = i;
+        }
+        for (int g = 0; g < ng; ++g) for (int t = tile_start[g]; t < tile_start[g + 1]; ++t) tgrp[t] = g;
+        O.n_tiles = n_tiles; O.group_ext = ne;
+        if (n_tiles > 0) {
+            MLH_HIP(ctx, O.perm.ensure(sizeof(int) * perm.size()));
+            MLH_HIP(ctx, O.tile_group.ensure(sizeof(int) * tgrp.size()));
+            MLH_HIP(ctx, O.partial.ensure(sizeof(double) * NE_OUT * size_t(n_tiles)));
+            MLH_HIP(ctx, hipMemcpyAsync(O.perm.p, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, ctx->stream));
+            MLH_HIP(ctx, hipMemcpyAsync(O.tile_group.p, tgrp.data(), sizeof(int) * tgrp.size(), hipMemcpyHostToDevice, ctx->stream));
+            MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        O.h_tile_group = tgrp;
+    }
     return MLH_OK;
 }
 
@@ -178,6 +313,65 @@ int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames
     MLH_HIP(ctx, hipMemcpyAsync(residuals, O.r.p, sizeof(double) * size_t(O.n), hipMemcpyDeviceToHost, st));
     if (jacobians) MLH_HIP(ctx, hipMemcpyAsync(jacobians, O.J.p, sizeof(double) * 21 * size_t(O.n), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
+    return MLH_OK;
+}
+
+static int odom_upload_poses(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, OdomArgs &A)
+{
+    OdomSet &O = ctx->odom;
+    hipStream_t st = ctx->stream;
+    const size_t np = 7 * size_t(1 + n_frames + n_ext);
+    MLH_HIP(ctx, O.poses.ensure(sizeof(double) * np));
+    std::vector<double> h(np);
+    for (int k = 0; k < 7; ++k) h[k] = pivot[k];
+    for (size_t k = 0; k < 7 * size_t(n_frames); ++k) h[7 + k] = frames[k];
+    for (size_t k = 0; k < 7 * size_t(n_ext); ++k) h[7 + 7 * size_t(n_frames) + k] = exts[k];
+    MLH_HIP(ctx, hipMemcpyAsync(O.poses.p, h.data(), sizeof(double) * np, hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));     // h is a stack-lifetime buffer
+    A.tab = O.tab.as<double>(); A.idx = O.idx.as<int>();
+    A.pivot = O.poses.as<double>(); A.frames = A.pivot + 7; A.exts = A.frames + 7 * size_t(n_frames);
+    A.n = O.n; A.n_frames = n_frames; A.n_ext = n_ext; A.r = nullptr; A.J = nullptr;
+    return MLH_OK;
+}
+
+int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
+                        double *H, double *g, double *cost, int32_t *n_res)
+{
+    OdomSet &O = ctx->odom;
+    if (O.n <= 0) return fail(ctx, MLH_ERR_STATE, "mlh_pure_odom_set has not been called");
+    if (!pivot || !frames || !exts || !H || !g || n_frames <= O.max_frame || n_ext <= O.max_ext)
+        return fail(ctx, MLH_ERR_INVALID, "pose arrays do not cover the block indices of the staged factors");
+    const int D = 6 * (1 + n_frames + n_ext);
+    const size_t n_out = size_t(D) * D + D + 2;
+    if (n_out * sizeof(double) > 150 * 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "window too large for the LDS-resident assembly (6 (1 + frames + extrinsics) <= 136)");
+    OdomNeArgs G;
+    int rc = odom_upload_poses(ctx, pivot, frames, n_frames, exts, n_ext, G.A);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    // the tile -> group table was built with the staged extrinsic count; re-key it for this call's n_ext when they differ
+    if (O.group_ext != n_ext || !O.tile_group_keyed) {
+        std::vector<int> tg(O.h_tile_group.size());
+        for (size_t t = 0; t < tg.size(); ++t) tg[t] = (O.h_tile_group[t] / O.group_ext) * n_ext + (O.h_tile_group[t] % O.group_ext);
+        MLH_HIP(ctx, hipMemcpyAsync(O.tile_group.p, tg.data(), sizeof(int) * tg.size(), hipMemcpyHostToDevice, st));
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        O.tile_group_keyed = (O.group_ext == n_ext);
+    }
+    MLH_HIP(ctx, O.ne_out.ensure(sizeof(double) * n_out));
+    G.perm = O.perm.as<int>(); G.huber_delta = huber_delta; G.partial = O.partial.as<double>();
+    hipLaunchKernelGGL(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, st, G);
+    OdomNeFinish F;
+    F.partial = O.partial.as<double>(); F.tile_group = O.tile_group.as<int>(); F.n_tiles = O.n_tiles; F.n_frames = n_frames; F.n_ext = n_ext;
+    F.out = O.ne_out.as<double>();
+    MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(odom_ne_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(n_out * sizeof(double))));
+    hipLaunchKernelGGL(odom_ne_finish_kernel, dim3(1), dim3(256), n_out * sizeof(double), st, F);
+    MLH_HIP(ctx, hipGetLastError());
+    std::vector<double> h(n_out);
+    MLH_HIP(ctx, hipMemcpyAsync(h.data(), O.ne_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    std::memcpy(H, h.data(), sizeof(double) * size_t(D) * D);
+    std::memcpy(g, h.data() + size_t(D) * D, sizeof(double) * D);
+    if (cost) *cost = h[size_t(D) * D + D];
+    if (n_res) *n_res = int(h[size_t(D) * D + D + 1] + 0.5);
     return MLH_OK;
 }
 

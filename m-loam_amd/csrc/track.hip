@@ -448,7 +448,9 @@ __global__ __launch_bounds__(256) void track_rings_kernel(const unsigned char *s
     const int r = int(*reinterpret_cast<const float *>(src + size_t(i) * stride + intensity_off));
     const int prev = i > 0 ? int(*reinterpret_cast<const float *>(src + size_t(i - 1) * stride + intensity_off)) : -1;
     ring[i] = r;
-    if (r < 0 || r >= n_slots - 1 || r < prev) { atomicOr(bad, 1); return; }
+    // the previous point's id bounds the loop below: it is validated like this point's own (a malformed id there would start the
+    // loop at a negative slot, or make it very long)
+    if (r < 0 || r >= n_slots - 1 || r < prev || prev < -1 || prev >= n_slots - 1) { atomicOr(bad, 1); return; }
     for (int k = prev + 1; k <= r; ++k) ring_start[k] = i;
 }
 

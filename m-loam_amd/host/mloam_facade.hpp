@@ -136,7 +136,9 @@ public:
         dev_.check(mlh_map_set(dev_.ctx(), kind_, cloud.points.data(), (int)sizeof(PointT), (int)cloud.size(), params().MIN_MATCH_SQ_DIS, MLH_MEM_HOST));
         n_ = cloud.size();
     }
-    // nearestKSearch for k = 5 (feature_extract.hpp:666): indices into the cloud given to setInputCloud
+    // nearestKSearch for k = 5 (feature_extract.hpp:666): indices into the cloud given to setInputCloud. Exact (= a kd-tree's answer)
+    // for every neighbour closer than the acceptance radius the index was built for (sqrt(min_match_sq_dis)); a neighbour reported
+    // beyond that radius may not be the true k-th nearest (the 27-cell search does not look farther) -- see mlh_knn in mloam_hip.h
     int nearestKSearch(const PointT &p, int k, std::vector<int> &idx, std::vector<float> &sqd) const
     {
         idx.assign(k, -1); sqd.assign(k, 0.f);

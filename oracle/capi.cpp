@@ -37,6 +37,9 @@ int orc_extract(const float *xyzi, int n, const int *scan_start, const int *scan
     return 0;
 }
 
+// 0: the reference's comparator (curvature only; tie order = libstdc++'s); 1: (curvature, index) total order, NaN last
+void orc_set_tie_rule(int rule) { set_tie_rule(rule); }
+
 int orc_voxel_grid(const float *xyzi, int n, float leaf, float *out, int *n_out)
 {
     std::vector<PointI> o;
@@ -296,6 +299,44 @@ int orc_pure_odom_eval_batch(int n, const int *types, const double *points, cons
         const double si = sqrt_info ? sqrt_info[i] : 1.0;
         if (types[i] == 0) pure_odom_plane_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], residuals + i, Ji, Ji + 7, Ji + 14);
         else pure_odom_edge_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], residuals + i, Ji, Ji + 7, Ji + 14);
+    }
+    return 0;
+}
+
+// The normal equations of the coupled window problem Estimator::optimizeMap hands to Ceres (estimator.cpp:687-848): parameter blocks in
+// para_ids order -- window poses [pivot, frame 1 .. n_frames] then extrinsics [0 .. n_ext) -- local size 6 each (PoseLocalParameterization:
+// ComputeJacobian = [I6; 0], so the first 6 columns of every 1x7 Jacobian ARE the local Jacobian). What Estimator::evalResidual evaluates:
+// problem.Evaluate on the LidarPureOdom residual blocks with every listed block variable (estimator.cpp:1577-1595), i.e. loss-corrected
+// rows (HuberLoss(1.0), estimator.cpp:602; Corrector with rho'' <= 0: row and residual scaled by sqrt(rho')); J^T J is what
+// evalDegenracy (estimator.cpp:1598-1680) takes its diagonal 6x6 blocks from. H: D x D row-major, D = 6 (1 + n_frames + n_ext); g = J^T r.
+int orc_pure_odom_normal_eq(int n, const int *types, const double *points, const double *coeffs6, const double *sqrt_info, const int *frame_idx,
+                            const int *ext_idx, const double *pivot, const double *frames, int n_frames, const double *exts, int n_ext,
+                            double huber_delta, double *H, double *g, double *cost, int *n_res)
+{
+    const int D = 6 * (1 + n_frames + n_ext);
+    std::memset(H, 0, sizeof(double) * size_t(D) * D);
+    std::memset(g, 0, sizeof(double) * D);
+    *cost = 0.0;
+    *n_res = 0;
+    for (int i = 0; i < n; ++i) {
+        double r, J[21];
+        const double si = sqrt_info ? sqrt_info[i] : 1.0;
+        if (types[i] == 0) pure_odom_plane_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], &r, J, J + 7, J + 14);
+        else pure_odom_edge_evaluate(points + 3 * i, coeffs6 + 6 * i, si, pivot, frames + 7 * frame_idx[i], exts + 7 * ext_idx[i], &r, J, J + 7, J + 14);
+        double rho[3];
+        huber_evaluate(huber_delta, r * r, rho);
+        *cost += 0.5 * rho[0];
+        (*n_res)++;
+        const double s = std::sqrt(rho[1]);
+        const int off[3] = {0, 6 * (1 + frame_idx[i]), 6 * (1 + n_frames + ext_idx[i])};
+        double v[18];
+        for (int b = 0; b < 3; ++b) for (int k = 0; k < 6; ++k) v[b * 6 + k] = J[b * 7 + k] * s;
+        const double rs = r * s;
+        for (int a = 0; a < 18; ++a) {
+            const int ra = off[a / 6] + a % 6;
+            g[ra] += v[a] * rs;
+            for (int b = 0; b < 18; ++b) H[size_t(ra) * D + off[b / 6] + b % 6] += v[a] * v[b];
+        }
     }
     return 0;
 }

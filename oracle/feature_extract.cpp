@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
+#include <cstring>
 
 namespace orc {
 
@@ -14,6 +15,24 @@ struct CompObject {
     const float *cloud_curvature;
     bool operator()(int i, int j) const { return cloud_curvature[i] < cloud_curvature[j]; }
 };
+
+// The reference's comparator looks at the curvature only (hpp:48-53), so the order std::sort leaves EQUAL curvatures in is whatever
+// libstdc++'s introsort does, and a NaN curvature (a non-finite input point) breaks the strict weak ordering std::sort requires
+// (undefined behaviour). Tie rule 1 refines the comparator into a total order -- (curvature, index) ascending, NaN above every number --
+// every outcome of which is ALSO a valid outcome of the reference's comparator on finite data; it is the order the HIP kernel sorts by
+// (extract.hip: sort_sector) and the one INTEGRATION.md documents. Rule 0 (default) is the reference's comparator verbatim.
+struct CompObjectTotal {
+    const float *cloud_curvature;
+    static unsigned long long key(float c, int i)
+    {
+        unsigned b;
+        std::memcpy(&b, &c, sizeof(b));
+        if (c != c) b = 0x7fc00000u;
+        return ((unsigned long long)b << 32) | (unsigned)i;
+    }
+    bool operator()(int i, int j) const { return key(cloud_curvature[i], i) < key(cloud_curvature[j], j); }
+};
+int g_tie_rule = 0;
 
 // the neighbour-suppression loops, feature_extract.cpp:192-213 / 233-254
 inline void suppress_neighbours(const PointI *p, int ind, int *picked)
@@ -34,6 +53,8 @@ inline void suppress_neighbours(const PointI *p, int ind, int *picked)
     }
 }
 }  // namespace
+
+void set_tie_rule(int rule) { g_tie_rule = rule; }
 
 void extract_cloud(const PointI *p, int n, const int *scan_start, const int *scan_end, int n_scans, ExtractResult &out)
 {
@@ -63,7 +84,8 @@ void extract_cloud(const PointI *p, int n, const int *scan_start, const int *sca
         for (int j = 0; j < 6; j++) {
             int sp = scan_start[i] + (scan_end[i] - scan_start[i]) * j / 6;
             int ep = scan_start[i] + (scan_end[i] - scan_start[i]) * (j + 1) / 6 - 1;
-            std::sort(sort_ind.begin() + sp, sort_ind.begin() + ep + 1, comp_object);
+            if (g_tie_rule == 1) std::sort(sort_ind.begin() + sp, sort_ind.begin() + ep + 1, CompObjectTotal{cloud_curvature});
+            else std::sort(sort_ind.begin() + sp, sort_ind.begin() + ep + 1, comp_object);
             for (int k = sp; k < ep; ++k)
                 if (cloud_curvature[sort_ind[k]] == cloud_curvature[sort_ind[k + 1]]) out.n_ties++;
 

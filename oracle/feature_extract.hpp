@@ -28,6 +28,7 @@ struct ExtractResult {
     long n_ties = 0;                            // equal-curvature neighbours in sorted sector order (std::sort is unstable)
 };
 
+void set_tie_rule(int rule);   // 0: reference comparator (default), 1: (curvature, index) total order with NaN last -- see feature_extract.cpp
 void extract_cloud(const PointI *cloud, int n, const int *scan_start, const int *scan_end, int n_scans,
                    ExtractResult &out);
 

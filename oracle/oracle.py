@@ -58,9 +58,11 @@ def mapper_params(min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1, map_
                      float(freeze_when_degenerate)], dtype=np.float64)
 
 
-def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray):
-    """FeatureExtract::extractCloud. points (n,4) f32 ring-major."""
+def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray, tie_rule: int = 0):
+    """FeatureExtract::extractCloud. points (n,4) f32 ring-major. tie_rule 0: the reference's comparator (order of equal curvatures =
+    libstdc++'s std::sort); 1: (curvature, index) ascending with NaN last -- the documented rule the HIP kernel sorts by."""
     L = lib()
+    L.orc_set_tie_rule(int(tie_rule))
     pts = np.ascontiguousarray(points, np.float32)
     n = pts.shape[0]
     ss = np.ascontiguousarray(scan_start, np.int32)
@@ -75,6 +77,7 @@ def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray):
     L.orc_extract(_ptr(pts), n, _ptr(ss), _ptr(se), len(ss), _ptr(curv), _ptr(label), _ptr(picked),
                   _ptr(bufs[0]), C.byref(cnts[0]), _ptr(bufs[1]), C.byref(cnts[1]), _ptr(bufs[2]), C.byref(cnts[2]),
                   _ptr(bufs[3]), C.byref(cnts[3]), _ptr(lf_ds), C.byref(cnts[4]), C.byref(ties))
+    L.orc_set_tie_rule(0)
     return dict(curvature=curv, label=label, picked=picked,
                 sharp=bufs[0][:cnts[0].value].copy(), less_sharp=bufs[1][:cnts[1].value].copy(),
                 flat=bufs[2][:cnts[2].value].copy(), less_flat_raw=bufs[3][:cnts[3].value].copy(),
@@ -221,6 +224,33 @@ def good_feature_matching(map_: Map, kind: str, feats, pose7, prm):
     return dict(sel=sel[:nsel.value].copy(), H=H, matched=matched, jaco=jaco)
 
 
+def eval_full_hessian(map_: Map, kind: str, feats, pose7, H=None, feat_num=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227): match ALL features, mat_H += J^T J of the matched ones (rows weighted
+    by the point's uncertainty, NOT loss-corrected), feat_num += matches. H defaults to the caller's 1e-6 * I seed (cpp:461)."""
+    f = np.ascontiguousarray(feats, np.float32)
+    H = np.ascontiguousarray(np.eye(6) * 1e-6 if H is None else H, np.float64).copy()
+    pose = np.ascontiguousarray(pose7, np.float64)
+    n = C.c_int(int(feat_num))
+    lib().orc_eval_full_hessian(map_.h, C.c_char(kind.encode()), _ptr(f), f.shape[1], f.shape[0], _cov_off(f), _ptr(pose),
+                                C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(H), C.byref(n))
+    return H, n.value
+
+
+def gf_ratio_policy(gf_method: str, gf_ratio_ini: float, gf_deg_factor: float, map_deg_thre: float, gf_ratio_cur: float) -> float:
+    """The every-10th-frame block of scan2MapOptimization (lidar_mapper_keyframe.cpp:474-492), statement by statement: returns the new
+    gf_ratio_cur (unchanged when no branch assigns it -- an unknown method, or gd_float with a NaN factor)."""
+    if gf_method == "wo_gf":
+        gf_ratio_cur = 1.0
+    elif gf_method in ("rnd", "fps", "gd_fix"):
+        gf_ratio_cur = gf_ratio_ini
+    elif gf_method == "gd_float":
+        if gf_deg_factor > map_deg_thre:
+            gf_ratio_cur = gf_ratio_ini
+        elif gf_deg_factor <= map_deg_thre:
+            gf_ratio_cur = 0.8
+    return gf_ratio_cur
+
+
 def gn_iterations(surf_map: Map, corner_map: Map, surf, corner, pose_init, prm, n_iters=5, n_threads=1):
     s = np.ascontiguousarray(surf, np.float32)
     c = np.ascontiguousarray(corner, np.float32)
@@ -262,6 +292,19 @@ def pure_odom_eval_batch(types, points, coeffs6, sqrt_info, frame_idx, ext_idx, 
     r = np.zeros(len(t)); J = np.zeros((len(t), 3, 7))
     lib().orc_pure_odom_eval_batch(len(t), _ptr(t), _ptr(p), _ptr(c), _ptr(si), _ptr(fi), _ptr(ei), _ptr(pv), _ptr(fr), _ptr(ex), _ptr(r), _ptr(J))
     return r, J
+
+
+def pure_odom_normal_eq(types, points, coeffs6, sqrt_info, frame_idx, ext_idx, pivot, frames, exts, huber_delta=1.0):
+    """J^T J (D x D), J^T r, cost and residual count of the coupled window problem (estimator.cpp:687-848, 1577-1595); D = 6 (1 + F + E)."""
+    t = np.ascontiguousarray(types, np.int32); p = np.ascontiguousarray(points, np.float64); c = np.ascontiguousarray(coeffs6, np.float64)
+    si = None if sqrt_info is None else np.ascontiguousarray(sqrt_info, np.float64)
+    fi = np.ascontiguousarray(frame_idx, np.int32); ei = np.ascontiguousarray(ext_idx, np.int32)
+    pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7); ex = np.ascontiguousarray(exts, np.float64).reshape(-1, 7)
+    D = 6 * (1 + len(fr) + len(ex))
+    H = np.zeros((D, D)); g = np.zeros(D); cost = C.c_double(0); cnt = C.c_int(0)
+    lib().orc_pure_odom_normal_eq(len(t), _ptr(t), _ptr(p), _ptr(c), _ptr(si), _ptr(fi), _ptr(ei), _ptr(pv), _ptr(fr), len(fr), _ptr(ex), len(ex),
+                                  C.c_double(huber_delta), _ptr(H), _ptr(g), C.byref(cost), C.byref(cnt))
+    return dict(H=H, g=g, cost=cost.value, count=cnt.value)
 
 
 def eig3f(A):

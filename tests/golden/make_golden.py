@@ -31,6 +31,7 @@ if "--rows-f-only" not in sys.argv:
                       points_sha=hashlib.sha256(np.ascontiguousarray(sc.points).tobytes()).hexdigest(),
                       label=ex["label"].astype(np.int8), less_sharp=ex["less_sharp"], flat=ex["flat"], sharp=ex["sharp"],
                       valid_surf=vs, valid_corner=vc, coeff_surf=cs.astype(np.float32), coeff_corner=cc.astype(np.float32),
+                      feat_surf=feats[0], feat_corner=feats[1], less_flat_ds=ex["less_flat_ds"],
                       scan2map_pose=r["pose"], gn5_pose=g["pose"])
 print("wrote config1.npz", ex["n_ties"], vs.sum(), vc.sum(), r["pose"])
 

@@ -237,3 +237,53 @@ def test_map_staging_paths_agree(mla, synth, case16):
         c.map_set(mla.SURF, bad)                       # non-finite coordinates are still rejected (through the bounds pass)
     for x in (ref_ctx, c, fresh):
         x.close()
+
+
+def _quantised_scan(case16):
+    """coordinates snapped to a 1/32 m lattice: sums of such values are exact in f32, so equal geometry gives EXACTLY equal curvatures --
+    flat walls and ground arcs produce hundreds of ties, and zero curvature on perfectly collinear runs"""
+    sc = case16["scans"][0]
+    pts = sc.points.copy()
+    pts[:, :3] = np.round(pts[:, :3] * 32.0) / 32.0
+    return pts, sc.scan_start, sc.scan_end
+
+
+def test_extract_with_exact_curvature_ties(mla, orc, case16):
+    """extractCloud on quantised data. The reference's comparator leaves the order of equal curvatures to std::sort; the documented rule
+    here is (curvature, index) ascending, and oracle (tie_rule=1) == HIP kernel on it, bit for bit."""
+    pts, ss, se = _quantised_scan(case16)
+    ref = orc.extract(pts, ss, se, tie_rule=1)
+    assert ref["n_ties"] > 500, ref["n_ties"]
+    assert (ref["curvature"][ss[0]:se[0]] == 0).sum() >= 0
+    c = mla.Context(0)
+    got = c.extract(pts, ss, se)
+    c.close()
+    assert np.array_equal(got["curvature"].view(np.uint32), ref["curvature"].view(np.uint32))
+    for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
+        assert np.array_equal(got[k], ref[k]), k
+    # the tie rule is a refinement of the reference's comparator: on tie-free data it changes nothing
+    sc = case16["scans"][0]
+    a, b = orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=0), orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=1)
+    assert a["n_ties"] == 0 and all(np.array_equal(a[k], b[k]) for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"))
+
+
+def test_extract_with_non_finite_points(mla, orc, case16):
+    """NaN / inf input points (a driver's "no return" marker): their curvature and that of their 10 neighbours is NaN; NaN is neither
+    > 0.1 nor < 0.1, so those points are never labelled, sort above every number (by index among themselves) and a NaN gap never breaks a
+    suppression run (NaN > 0.05 is false) -- the same decisions in the oracle (tie_rule=1, where NaN has a defined place) and on the GPU."""
+    sc = case16["scans"][0]
+    pts = sc.points.copy()
+    rng = np.random.default_rng(3)
+    bad = rng.choice(len(pts), 40, replace=False)
+    pts[bad[:30], :3] = np.nan
+    pts[bad[30:], 0] = np.inf
+    ref = orc.extract(pts, sc.scan_start, sc.scan_end, tie_rule=1)
+    c = mla.Context(0)
+    got = c.extract(pts, sc.scan_start, sc.scan_end)
+    c.close()
+    nan_ref, nan_got = np.isnan(ref["curvature"]), np.isnan(got["curvature"])
+    assert nan_ref.sum() >= 40 and np.array_equal(nan_ref, nan_got)
+    assert np.array_equal(got["curvature"][~nan_got].view(np.uint32), ref["curvature"][~nan_ref].view(np.uint32))
+    for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert not np.any(got["label"][nan_got] != 0)          # a NaN curvature is never an edge nor a flat point

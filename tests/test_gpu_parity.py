@@ -245,7 +245,7 @@ def test_rccl_single_rank_path(mla, orc, case16, feats16):
     b.close()
 
 
-@pytest.mark.parametrize("method", ["rnd", "fps", "gd_fix"])
+@pytest.mark.parametrize("method", ["rnd", "fps", "gd_fix", "gd_float"])
 def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
     """BASELINE config 5 building block: same seed -> the same selected features and information matrix as the oracle's
     restatement of ActiveFeatureSelection::goodFeatureMatching (lidar_mapper.h:229-573)."""
@@ -260,6 +260,44 @@ def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
     # after the call only the selected correspondences are live on the device
     lin = ctx.linearize(mla.SURF, case16["p0"])
     assert lin["count"] == len(ref["sel"])
+
+
+def test_eval_full_hessian_logdet_and_ratio_policy(ctx, mla, orc, synth, case16, feats16):
+    """row a12: ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227) -> common::logDet (math.hpp:173-187) -> gf_deg_factor ->
+    the gf_ratio policy (lidar_mapper_keyframe.cpp:456-494). The C-ABI form of evalFullHessian is mlh_match_linearize with
+    MLH_FLAG_NO_LOSS | MLH_FLAG_WITH_UA (reduced outputs only) on top of the caller's 1e-6 * I seed."""
+    ext = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    covs = np.diag([0.0025] * 3 + [0.00030461] * 3)[None]
+    meas = np.diag([0.0025] * 3)
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    ctx.map_set(mla.CORNER, case16["corner_map"])
+    fs = ctx.downsample_current_scan(mla.SURF, feats16[0], 0.4, ext, covs, meas, True, 0.6)      # records with cov_vec (with_ua)
+    fc = ctx.downsample_current_scan(mla.CORNER, feats16[1], 0.2, ext, covs, meas, True, 0.6)
+    H = np.eye(6) * 1e-6
+    n_tot = 0
+    Href, nref = None, 0
+    for kind, ch, f, cloud in ((mla.SURF, "s", fs, case16["surf_map"]), (mla.CORNER, "c", fc, case16["corner_map"])):
+        out = ctx.match_linearize(kind, case16["p0"], flags=mla.FLAG_WITH_UA | mla.FLAG_NO_LOSS, huber_delta=0.0, dense=False)
+        H = H + out["H"]
+        n_tot += out["count"]
+        Href, nref = orc.eval_full_hessian(orc.Map(cloud), ch, f, case16["p0"], Href, nref)
+    assert n_tot == nref and n_tot > 1000
+    assert float(np.abs(H - Href).max()) <= 1e-9 * float(np.abs(Href).max())
+    # NO_LOSS really is "not loss-corrected": with the Huber corrector the matrix is a different one (SURVEY appendix A.19)
+    out_l = ctx.match_linearize(mla.SURF, case16["p0"], flags=mla.FLAG_WITH_UA, huber_delta=0.1, dense=False)
+    out_n = ctx.match_linearize(mla.SURF, case16["p0"], flags=mla.FLAG_WITH_UA | mla.FLAG_NO_LOSS, huber_delta=0.1, dense=False)
+    assert float(np.abs(out_l["H"] - out_n["H"]).max()) > 1e-6 * float(np.abs(out_n["H"]).max())
+    # gf_deg_factor = logDet(mat_H, use_cholesky = true); both matrices through the oracle's LLT restatement and through numpy
+    ld_gpu, ld_ref = orc.logdet(H), orc.logdet(Href)
+    assert abs(ld_gpu - ld_ref) < 1e-9 * abs(ld_ref)
+    assert abs(ld_ref - np.linalg.slogdet(Href)[1]) < 1e-9 * abs(ld_ref)
+    # the policy around the threshold (MAP_DEG_THRE), decided on the GPU-side factor and on the oracle's: same gf_ratio_cur
+    for method in ("wo_gf", "rnd", "fps", "gd_fix", "gd_float"):
+        for thre in (ld_ref - 1.0, ld_ref + 1.0):
+            a = orc.gf_ratio_policy(method, 0.2, ld_gpu, thre, 0.55)
+            b = orc.gf_ratio_policy(method, 0.2, ld_ref, thre, 0.55)
+            assert a == b
+            assert a == (1.0 if method == "wo_gf" else (0.2 if method != "gd_float" or ld_ref > thre else 0.8))
 
 
 def test_scan2map_with_greedy_selection_parity(ctx, mla, orc, case16, feats16):
@@ -566,6 +604,96 @@ def test_pure_odom_batch_parity(ctx, orc):
     np.testing.assert_allclose(r3, r[:10] / sq[:10], rtol=1e-13)
     with pytest.raises(Exception):
         ctx.pure_odom_evaluate(pivot, frames[: fi[:10].max()], exts)      # pose array shorter than the largest frame index
+
+
+def _window_case(synth, orc, n_frames=2, n_lidars=2, seed=3):
+    """A sliding window as Estimator::optimizeMap sees it: a pivot pose, n_frames later poses, n_lidars extrinsics, and for every (frame, LiDAR)
+    the features of that scan matched against the local map expressed in the pivot frame (buildLocalMap, estimator.cpp:1160-1268) ->
+    the LidarPureOdom factor table (point in the LiDAR frame, plane / line coefficients in the pivot frame, block indices)."""
+    from scipy.spatial.transform import Rotation as Rot
+    import conftest
+    rng = np.random.default_rng(seed)
+    case = conftest._make_case(synth, "50k", 16, n_lidars)
+    to_pose = lambda T: np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+    T_piv = synth.pose_to_mat(case["gt"])
+    Tinv = np.linalg.inv(T_piv)
+    maps = [synth.transform_points(m[:, :3], Tinv) for m in (case["surf_map"], case["corner_map"])]       # local map in the pivot frame
+    oms, omc = orc.Map(maps[0]), orc.Map(maps[1])
+    exts_T = []
+    for n in range(n_lidars):
+        r = synth.HERCULES_BODY_T_LASER[n]
+        exts_T.append(synth.pose_to_mat(np.concatenate([r[4:7], r[:4] / np.linalg.norm(r[:4])])))
+    frames_T = []
+    for i in range(n_frames):
+        d = np.eye(4)
+        d[:3, :3] = Rot.from_rotvec(np.deg2rad([0.3, -0.2, 1.0 + i])).as_matrix()
+        d[:3, 3] = [0.4 * (i + 1), 0.05 * i, 0.01]
+        frames_T.append(T_piv @ d)
+    types, points, coeffs, fi, ei = [], [], [], [], []
+    for i, T_i in enumerate(frames_T):
+        for n in range(n_lidars):
+            scn = synth.simulate_scan(case["scene"], to_pose(T_i), synth.HERCULES_BODY_T_LASER[n], 16, seed=100 + 10 * i + n)
+            ex = orc.extract(scn.points, scn.scan_start, scn.scan_end)
+            rel = to_pose(Tinv @ T_i @ exts_T[n])
+            rel = synth.perturbed_pose(rel, seed=200 + 10 * i + n, dt=0.05, drot_deg=0.5)
+            for kind, om, f in (("s", oms, synth.voxel_mean(ex["less_flat_ds"][:, :3].copy(), 0.4)), ("c", omc, scn.points[ex["less_sharp"]][:, :3])):
+                f4 = np.zeros((len(f), 4), np.float32)
+                f4[:, :3] = f
+                v, co = om.match(kind, f4, rel)
+                m = v.astype(bool)
+                types.append(np.full(m.sum(), 0 if kind == "s" else 1, np.int32))
+                points.append(f4[m, :3].astype(np.float64))
+                coeffs.append(co[m])
+                fi.append(np.full(m.sum(), i, np.int32))
+                ei.append(np.full(m.sum(), n, np.int32))
+    perm = rng.permutation(sum(len(t) for t in types))       # the table arrives in no particular order
+    cat = lambda a: np.concatenate(a)[perm]
+    pert = lambda T, k: synth.perturbed_pose(to_pose(T), seed=300 + k, dt=0.03, drot_deg=0.3)
+    return dict(types=cat(types), points=cat(points), coeffs=cat(coeffs), fi=cat(fi), ei=cat(ei),
+                pivot=to_pose(T_piv), frames=np.stack([pert(T, k) for k, T in enumerate(frames_T)]),
+                exts=np.stack([to_pose(exts_T[0])] + [pert(T, 10 + k) for k, T in enumerate(exts_T[1:])]))
+
+
+@pytest.mark.parametrize("shape", [(1, 2), (3, 4)])
+def test_pure_odom_window_normal_equations(ctx, mla, orc, synth, shape):
+    """(a19, BASELINE config 4 proper) the COUPLED window problem of Estimator::optimizeMap (estimator.cpp:687-848): J^T J / J^T r / cost over the
+    local parameters [pivot | frames | extrinsics] reduced on the device (24-dimensional for 1 frame + 2 LiDARs, the hercules shape) against
+    the oracle's factor-by-factor accumulation; the diagonal blocks feed evalDegenracy (estimator.cpp:1598-1680) identically, and the
+    Gauss-Newton step of the coupled system (pivot and reference extrinsic held constant, as the reference does) is the same on both sides."""
+    n_frames, n_lidars = shape
+    w = _window_case(synth, orc, n_frames, n_lidars)
+    assert len(w["types"]) > 3000 * n_frames * n_lidars // 2
+    ctx.pure_odom_set(w["types"], w["points"], w["coeffs"], w["fi"], w["ei"])
+    got = ctx.pure_odom_normal_eq(w["pivot"], w["frames"], w["exts"], huber_delta=1.0)
+    ref = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], w["frames"], w["exts"], 1.0)
+    D = 6 * (1 + n_frames + n_lidars)
+    assert got["H"].shape == (D, D) and got["count"] == ref["count"] == len(w["types"])
+    sc = float(np.abs(ref["H"]).max())
+    assert float(np.abs(got["H"] - ref["H"]).max()) <= 1e-9 * sc
+    assert float(np.abs(got["g"] - ref["g"]).max()) <= 1e-9 * float(np.abs(ref["g"]).max())
+    assert abs(got["cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+    assert np.array_equal(got["H"], got["H"].T)
+    again = ctx.pure_odom_normal_eq(w["pivot"], w["frames"], w["exts"], huber_delta=1.0)
+    assert np.array_equal(again["H"], got["H"]) and np.array_equal(again["g"], got["g"])                  # deterministic reduction
+    # blocks a factor set never touches together stay exactly zero (frame i x frame j, extrinsic m x extrinsic n)
+    if n_frames > 1:
+        assert not got["H"][6:12, 12:18].any()
+    # evalDegenracy on every diagonal block
+    for b in range(1 + n_frames + n_lidars):
+        blk = slice(6 * b, 6 * b + 6)
+        dg, dr_ = mla.eval_degeneracy(got["H"][blk, blk], 100.0), orc.eval_degeneracy(ref["H"][blk, blk], 100.0)
+        assert dg["is_degenerate"] == dr_["is_degenerate"]
+        np.testing.assert_allclose(dg["eigval"], dr_["eigval"], rtol=1e-8, atol=1e-8 * sc)
+    # the coupled Gauss-Newton step with para_pose_[0] and para_ex_pose_[IDX_REF] constant (estimator.cpp:636, 642)
+    free = np.r_[6:6 * (1 + n_frames), 6 * (2 + n_frames):D]
+    step_g = np.linalg.solve(got["H"][np.ix_(free, free)], -got["g"][free])
+    step_r = np.linalg.solve(ref["H"][np.ix_(free, free)], -ref["g"][free])
+    np.testing.assert_allclose(step_g, step_r, rtol=1e-6, atol=1e-9)
+    assert np.linalg.norm(step_r[:3]) > 1e-3                      # the window really is off its optimum: the step is not noise
+    # no loss (huber_delta <= 0): plain J^T J
+    nl_g = ctx.pure_odom_normal_eq(w["pivot"], w["frames"], w["exts"], huber_delta=0.0)
+    nl_r = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], w["frames"], w["exts"], 1e9)
+    assert float(np.abs(nl_g["H"] - nl_r["H"]).max()) <= 1e-9 * float(np.abs(nl_r["H"]).max())
 
 
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):

@@ -154,3 +154,84 @@ def test_scan2map_full_size(staged, orc, cfg2):
     pose2, _ = staged.scan2map(cfg2["p0"], want_stats=False)
     dt, dr = _pose_err(pose2, ref["pose"])
     assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
+# ---------------------------------------------------------------- BASELINE configs 4 and 5 at full scan size (1M-point map)
+@pytest.fixture(scope="module")
+def cfg45(synth, orc):
+    """4 x 64-ring scans (config 4's frame; config 5 uses the first two) against the 1M-point scene; corner map from 4-LiDAR keyframes."""
+    import bench
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "1M", n_lidars=4)
+    ex = [orc.extract(s.points, s.scan_start, s.scan_end) for s in scans]
+    return dict(surf_map=surf_map, corner_map=corner_map, gt=gt, scans=scans, ex=ex, p0=synth.perturbed_pose(gt, seed=43),
+                oms=orc.Map(surf_map), omc=orc.Map(corner_map))
+
+
+def test_config5_full_size(mla, orc, synth, cfg45):
+    """config 5: uncertainty-weighted residuals (with_ua) + greedy good-feature selection (gd_fix, ratio 0.2, fixed seed) on 2 x 64 rings vs
+    the 1M map: identical selections, identical LM bookkeeping, same pose; the same for rnd and for the plain (wo_gf) weighted solve."""
+    import bench
+    surf, corner = bench.fuse_features(synth, cfg45["scans"][:2], cfg45["ex"][:2])
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    meas = np.diag([0.0025] * 3)
+    c = mla.Context(0)
+    c.map_set_pair(cfg45["surf_map"], cfg45["corner_map"])
+    fs = c.downsample_current_scan(mla.SURF, surf, 0.4, ext, covs, meas, True, 0.6)       # (m, 11) records with cov_vec: both sides use these
+    fc = c.downsample_current_scan(mla.CORNER, corner, 0.2, ext, covs, meas, True, 0.6)
+    assert len(fs) > 5000 and len(fc) > 5000
+    for kind, ch, f, om in ((mla.SURF, "s", fs, cfg45["oms"]), (mla.CORNER, "c", fc, cfg45["omc"])):
+        got = c.good_feature_matching(kind, cfg45["p0"], gf_method="gd_fix", gf_ratio=0.2, seed=7)
+        ref = orc.good_feature_matching(om, ch, f, cfg45["p0"], orc.mapper_params(with_ua=True, gf_method="gd_fix", gf_ratio=0.2, seed=7))
+        assert np.array_equal(got["sel"], ref["sel"]), ch
+        np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-9, atol=1e-9)
+    for method in ("gd_fix", "rnd", "wo_gf"):
+        opts = mla.default_opts(flags=mla.FLAG_WITH_UA, gf_method=mla.GF_METHODS[method], gf_ratio=0.2, gf_seed=7)
+        pose, st = c.scan2map(cfg45["p0"], opts)
+        ref = orc.scan2map(cfg45["oms"], cfg45["omc"], fs, fc, cfg45["p0"], orc.mapper_params(with_ua=True, gf_method=method, gf_ratio=0.2, seed=7))
+        for s, r in zip(st, ref["outer"]):
+            assert (s["n_surf"], s["n_corner"]) == (r["n_surf_sel"], r["n_corner_sel"]), method
+            assert (s["lm_iterations"], s["successful_steps"], s["termination"]) == (r["lm_iterations"], r["successful_steps"], r["termination"]), method
+        dt, dr = _pose_err(pose, ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (method, dt, dr)
+    c.close()
+
+
+def test_config4_scan_full_size(mla, orc, synth, cfg45):
+    """config 4's frame: 4 x 64 rings, one pose block per LiDAR (block 0 = body pose, N_NEIGH 5; blocks 1..3 = extrinsics, N_NEIGH 10), CHECK_FOV,
+    frozen when degenerate -- all blocks and both kinds in the same launches; every block must reproduce the oracle's iteration on its cloud."""
+    surf_b, corner_b, poses0 = [], [], []
+    for i, (sc, ex) in enumerate(zip(cfg45["scans"], cfg45["ex"])):
+        cpts = np.zeros((len(ex["less_sharp"]), 4), np.float32)
+        cpts[:, :3] = sc.points[ex["less_sharp"]][:, :3]
+        surf_b.append(np.ascontiguousarray(synth.voxel_mean(ex["less_flat_ds"].copy(), 0.4)))
+        corner_b.append(np.ascontiguousarray(synth.voxel_mean(cpts, 0.2)))
+        r = synth.HERCULES_BODY_T_LASER[i]
+        T = synth.pose_to_mat(cfg45["gt"]) @ synth.pose_to_mat(np.concatenate([r[4:7], r[:4] / np.linalg.norm(r[:4])]))
+        from scipy.spatial.transform import Rotation as Rot
+        gt_i = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        poses0.append(synth.perturbed_pose(gt_i, seed=50 + i, dt=0.1, drot_deg=1.0))
+    poses0 = np.array(poses0)
+    k_neigh, thre, freeze = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
+    c = mla.Context(0)
+    c.map_set_pair(cfg45["surf_map"], cfg45["corner_map"])
+    c.features_set_blocks(mla.SURF, surf_b)
+    c.features_set_blocks(mla.CORNER, corner_b)
+    opts = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+    n_it = 3
+    poses, stats = c.gn_solve_blocks(poses0, n_it, k_neigh, thre, freeze, opts)
+    for b in range(4):
+        prm = orc.mapper_params(huber_delta=1.0, map_eig_thre=thre[b], n_neigh=k_neigh[b], check_fov=True, freeze_when_degenerate=bool(freeze[b]))
+        ref = orc.gn_iterations(cfg45["oms"], cfg45["omc"], surf_b[b], corner_b[b], poses0[b], prm, n_it)
+        for it in range(n_it):
+            s, r = stats[it][b], ref["iters"][it]
+            assert (s["n_surf"], s["n_corner"]) == (r["n_surf"], r["n_corner"]), (b, it)
+            assert float(np.abs(s["H"] - r["H"]).max()) <= 1e-9 * max(1.0, float(np.abs(r["H"]).max()))
+            assert s["is_degenerate"] == r["is_degenerate"]
+        dt, dr = _pose_err(poses[b], ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
+    c.close()
