@@ -50,12 +50,97 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+# ---------------------------------------------------------------- oracle/_ref: the reference's own source lines (oracle/ref/)
+_ref = None
+
+
+def ref_lib():
+    """libmloam_ref.so = FeatureExtract::extractCloud, LidarMap{PlaneNorm,Edge}Factor compiled from the line ranges of the files under
+    /root/reference (oracle/ref/build_ref.py). Returns None when neither the reference tree nor a prebuilt library is available."""
+    global _ref
+    if _ref is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mloam_build_ref", os.path.join(_HERE, "ref", "build_ref.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        path = mod.build()
+        if not path or not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+    return _ref
+
+
+def ref_extract(points, scan_start, scan_end):
+    """the reference's extractCloud on a ring-major cloud -> its four feature clouds as (n, 4) float arrays"""
+    L = ref_lib()
+    pts = np.ascontiguousarray(points, np.float32)
+    n = pts.shape[0]
+    ss = np.ascontiguousarray(scan_start, np.int32); se = np.ascontiguousarray(scan_end, np.int32)
+    outs = [np.zeros((max(n, 1), 4), np.float32) for _ in range(4)]
+    ptrs = (C.c_void_p * 4)(*[o.ctypes.data_as(C.c_void_p) for o in outs])
+    cnt = (C.c_int * 4)()
+    L.ref_extract_cloud(_ptr(pts), n, _ptr(ss), _ptr(se), len(ss), ptrs, cnt)
+    names = ["sharp", "less_sharp", "flat", "less_flat_ds"]
+    return {nm: outs[i][:cnt[i]].copy() for i, nm in enumerate(names)}
+
+
+def ref_map_factor(kind: str, point, coeff, cov3x3, pose7, want_jacobian=True):
+    """LidarMapPlaneNormFactor ('s') / LidarMapEdgeFactor ('c') constructed with (point, coeff, cov_matrix) and evaluated, from the reference's lines"""
+    L = ref_lib()
+    p = np.ascontiguousarray(point, np.float64); c = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    cov = np.ascontiguousarray(cov3x3, np.float64).reshape(9); pose = np.ascontiguousarray(pose7, np.float64)
+    r = np.zeros(1); J = np.zeros(7)
+    L.ref_map_factor_evaluate(C.c_char(kind.encode()), _ptr(p), _ptr(c), _ptr(cov), _ptr(pose), _ptr(r), _ptr(J) if want_jacobian else None)
+    return r[0], (J if want_jacobian else None)
+
+
 def mapper_params(min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1, map_eig_thre=100.0, with_ua=False,
                   cov_measurement_trace=0.0075, max_outer=2, max_lm_iterations=30, gf_method="wo_gf", gf_ratio=1.0, seed=0,
                   n_neigh=5, check_fov=False, freeze_when_degenerate=False):
     return np.array([min_match_sq_dis, min_plane_dis, huber_delta, map_eig_thre, float(with_ua), cov_measurement_trace,
                      max_outer, max_lm_iterations, GF_METHODS[gf_method], gf_ratio, seed, n_neigh, float(check_fov),
                      float(freeze_when_degenerate)], dtype=np.float64)
+
+
+def ref_match(kind: str, map_pts, feats, pose7, n_neigh=5, check_fov=False, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """FeatureExtract::match{Surf,Corner}PointFromMap (feature_extract.hpp:645-883) from the reference's lines, feature by feature"""
+    L = ref_lib()
+    m4 = np.zeros((len(map_pts), 4), np.float32); m4[:, :3] = np.asarray(map_pts)[:, :3]
+    f4 = np.zeros((len(feats), 4), np.float32); f4[:, :min(4, np.asarray(feats).shape[1])] = np.asarray(feats)[:, :4]
+    pose = np.ascontiguousarray(pose7, np.float64)
+    valid = np.zeros(len(f4), np.uint8); coeffs = np.zeros((len(f4), 6))
+    L.ref_match_points(C.c_char(kind.encode()), _ptr(m4), len(m4), _ptr(f4), len(f4), _ptr(pose), int(n_neigh), int(bool(check_fov)),
+                       C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(valid), _ptr(coeffs))
+    return valid, coeffs
+
+
+def ref_pure_odom(kind: str, point, coeff, sqrt_info, pivot, pose_i, ext, want_jacobian=True):
+    """LidarPureOdom{PlaneNorm,Edge}Factor from the reference's lines -> residual, J (3, 7)"""
+    L = ref_lib()
+    p = np.ascontiguousarray(point, np.float64); c = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    a = [np.ascontiguousarray(x, np.float64) for x in (pivot, pose_i, ext)]
+    r = np.zeros(1); J = np.zeros((3, 7))
+    L.ref_pure_odom_evaluate(C.c_char(kind.encode()), _ptr(p), _ptr(c), C.c_double(sqrt_info), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(r),
+                             _ptr(J) if want_jacobian else None)
+    return r[0], (J if want_jacobian else None)
+
+
+def ref_online_calib(kind: str, point, coeff, sqrt_info, ext):
+    L = ref_lib()
+    p = np.ascontiguousarray(point, np.float64); c = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    e = np.ascontiguousarray(ext, np.float64)
+    r = np.zeros(1); J = np.zeros(7)
+    L.ref_online_calib_evaluate(C.c_char(kind.encode()), _ptr(p), _ptr(c), C.c_double(sqrt_info), _ptr(e), _ptr(r), _ptr(J))
+    return r[0], J
+
+
+def ref_pose_plus(x, delta, V_update=None):
+    L = ref_lib()
+    x = np.ascontiguousarray(x, np.float64); d = np.ascontiguousarray(delta, np.float64)
+    V = None if V_update is None else np.ascontiguousarray(V_update, np.float64)
+    out = np.zeros(7)
+    L.ref_pose_plus(_ptr(x), _ptr(d), _ptr(V), _ptr(out))
+    return out
 
 
 def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray, tie_rule: int = 0):

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY. Builds oracle/_ref/libmloam_ref.so from the reference's own source lines (see ref_shim.cpp).
+Needs /root/reference (absent on the GPU box: the prebuilt .so travels there). Nothing of the reference is copied into the repository:
+the cut-out line ranges live in oracle/_ref/gen/ only for the duration of the compile."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MLOAM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(HERE), "_ref")
+SRC = os.path.join(REF, "estimator", "src")
+COMMON = os.path.join(REF, "mloam_common", "libs", "include", "common")
+# (output, file, first line, last line, text the first line must contain) -- a drifted reference fails loudly instead of compiling something else
+CUTS = [
+    ("sqr_sum.inc", "algos/math.hpp", 10, 14, "template <typename T>"),
+    ("comp_object.inc", "featureExtract/feature_extract.hpp", 48, 53, "class compObject"),
+    ("extract_cloud.inc", "featureExtract/feature_extract.cpp", 118, 297, "void FeatureExtract::extractCloud"),
+    ("match_point_decls.inc", "featureExtract/feature_extract.hpp", 110, 128, "template <typename PointType>"),
+    ("match_corner_point.inc", "featureExtract/feature_extract.hpp", 645, 788, "template <typename PointType>"),
+    ("match_surf_point.inc", "featureExtract/feature_extract.hpp", 790, 883, "template <typename PointType>"),
+    ("point_associate_to_map.inc", "utility/utility.h", 102, 117, "template <typename PointType>"),
+    ("utility_head.inc", "utility/utility.h", 169, 195, "class Utility"),
+    ("plane_factor_head.inc", "factor/lidar_map_factor.hpp", 26, 71, "class LidarMapPlaneNormFactor"),
+    ("plane_factor_tail.inc", "factor/lidar_map_factor.hpp", 122, 126, "private:"),
+    ("edge_factor_head.inc", "factor/lidar_map_factor.hpp", 130, 174, "class LidarMapEdgeFactor"),
+    ("edge_factor_tail.inc", "factor/lidar_map_factor.hpp", 231, 235, "private:"),
+    ("odom_plane_head.inc", "factor/lidar_pure_odom_factor.hpp", 27, 102, "class LidarPureOdomPlaneNormFactor"),
+    ("odom_plane_tail.inc", "factor/lidar_pure_odom_factor.hpp", 191, 195, "private:"),
+    ("odom_edge_head.inc", "factor/lidar_pure_odom_factor.hpp", 198, 282, "class LidarPureOdomEdgeFactor"),
+    ("odom_edge_tail.inc", "factor/lidar_pure_odom_factor.hpp", 377, 381, "private:"),
+    ("calib_plane_head.inc", "factor/lidar_online_calib_factor.hpp", 24, 62, "class LidarOnlineCalibPlaneNormFactor"),
+    ("calib_plane_tail.inc", "factor/lidar_online_calib_factor.hpp", 117, 121, "private:"),
+    ("calib_edge_head.inc", "factor/lidar_online_calib_factor.hpp", 125, 165, "class LidarOnlineCalibEdgeFactor"),
+    ("calib_edge_tail.inc", "factor/lidar_online_calib_factor.hpp", 223, 227, "private:"),
+    ("plp_class.inc", "factor/pose_local_parameterization.h", 21, 33, "class PoseLocalParameterization"),
+    ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
+]
+
+
+def build(force=False):
+    lib = os.path.join(OUT, "libmloam_ref.so")
+    if not os.path.isdir(SRC):
+        return lib if os.path.exists(lib) else None          # GPU box: use what travelled
+    srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "mini_eigen.hpp", "build_ref.py")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
+        return lib
+    gen = os.path.join(OUT, "gen")
+    os.makedirs(gen, exist_ok=True)
+    try:
+        for name, rel, a, b, must in CUTS:
+            lines = open(os.path.join(COMMON if rel.startswith("algos/") else SRC, rel)).read().split("\n")
+            assert must in lines[a - 1], f"{rel}:{a} is not '{must}' -- the reference tree differs from the surveyed one"
+            open(os.path.join(gen, name), "w").write("\n".join(lines[a - 1:b]) + "\n")
+        oracle_dir = os.path.dirname(HERE)
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-o", lib, os.path.join(HERE, "ref_shim.cpp"),
+               os.path.join(oracle_dir, "feature_extract.cpp")]
+        subprocess.run(cmd, check=True)
+    finally:
+        shutil.rmtree(gen, ignore_errors=True)
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

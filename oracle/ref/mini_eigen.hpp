@@ -1,0 +1,195 @@
+// TEST INFRASTRUCTURE ONLY. A few dozen Eigen 3.3 operations -- exactly the ones the reference's factor classes use -- so that those
+// classes can be compiled FROM THE REFERENCE'S OWN SOURCE LINES (oracle/ref/build_ref.py) in an image that has no Eigen. Everything is
+// evaluated eagerly, products as left-to-right sums over k (what Eigen's coefficient-based product of small fixed matrices does);
+// q * v and toRotationMatrix follow Eigen's QuaternionBase formulas. This pins the reference's FORMULAS (which terms, which signs, which
+// block goes where); the arithmetic inside Eigen itself stays a restatement.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <type_traits>
+#include <vector>
+
+namespace Eigen {
+enum { ColMajor = 0, RowMajor = 1, Dynamic = -1 };
+
+template <typename Derived> struct MatrixBase {
+    const Derived &derived() const { return *static_cast<const Derived *>(this); }
+    auto operator()(int i) const { return derived().d[i]; }
+};
+
+template <typename T, int R, int C> struct Mat;
+template <typename T, int R, int C, int Opt = 0> using Matrix = Mat<T, R, C>;   // storage options accepted and ignored
+
+template <typename T, int R, int C, int N> struct ColsRef {      // leftCols<N>() / rightCols<N>() of a row-major-irrelevant small matrix
+    T *base; int col0, ld;   // element (i, j) at base[i * ld + col0 + j]   (storage below is row-major)
+    ColsRef &operator=(const Mat<T, R, N> &m);
+    void setZero() { for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) base[i * ld + col0 + j] = T(0); }
+};
+
+template <typename T, int R, int C> struct CommaInit {
+    Mat<T, R, C> &m; int k;
+    CommaInit &operator,(T v) { m.d[k++] = v; return *this; }
+};
+
+template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
+    typedef T Scalar;
+    typedef Mat Matrix;
+    T d[R * C];                                                   // row-major storage
+    Mat() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    Mat(T a, T b, T c) { static_assert(R * C == 3, "3-vector"); d[0] = a; d[1] = b; d[2] = c; }
+    template <typename D> Mat(const MatrixBase<D> &o) { for (int i = 0; i < R * C; ++i) d[i] = o.derived().d[i]; }
+    Mat(T a, T b, T c, T e) { static_assert(R * C == 4, "4-vector"); d[0] = a; d[1] = b; d[2] = c; d[3] = e; }
+    T &operator()(int i) { return d[i]; }
+    const T &operator()(int i) const { return d[i]; }
+    T &operator()(int i, int j) { return d[i * C + j]; }
+    const T &operator()(int i, int j) const { return d[i * C + j]; }
+    T &operator[](int i) { return d[i]; }
+    const T &operator[](int i) const { return d[i]; }
+    T x() const { return d[0]; } T y() const { return d[1]; } T z() const { return d[2]; }
+    int rows() const { return R; } int cols() const { return C; }
+    static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
+    static Matrix Zero() { return Matrix(); }
+    void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    T trace() const { T s = d[0]; for (int i = 1; i < R; ++i) s += (*this)(i, i); return s; }
+    T dot(const Matrix &o) const { T s = d[0] * o.d[0]; for (int i = 1; i < R * C; ++i) s += d[i] * o.d[i]; return s; }
+    T squaredNorm() const { return dot(*this); }
+    T norm() const { return std::sqrt(squaredNorm()); }
+    void normalize() { *this = normalized(); }
+    Mat<T, R, 1> col(int j) const { Mat<T, R, 1> m; for (int i = 0; i < R; ++i) m.d[i] = (*this)(i, j); return m; }
+    Matrix normalized() const { T z2 = squaredNorm(); if (z2 > T(0)) { Matrix m = *this; T n = std::sqrt(z2); for (int i = 0; i < R * C; ++i) m.d[i] = d[i] / n; return m; } return *this; }
+    Matrix cross(const Matrix &o) const { static_assert(R * C == 3, "cross"); return Matrix(d[1] * o.d[2] - d[2] * o.d[1], d[2] * o.d[0] - d[0] * o.d[2], d[0] * o.d[1] - d[1] * o.d[0]); }
+    Mat<T, C, R> transpose() const { Mat<T, C, R> m; for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) m(j, i) = (*this)(i, j); return m; }
+    Matrix operator-() const { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = -d[i]; return m; }
+    Matrix operator+(const Matrix &o) const { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = d[i] + o.d[i]; return m; }
+    Matrix operator-(const Matrix &o) const { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = d[i] - o.d[i]; return m; }
+    Matrix operator*(T s) const { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = d[i] * s; return m; }
+    Matrix operator/(T s) const { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = d[i] / s; return m; }
+    Matrix &operator+=(const Matrix &o) { for (int i = 0; i < R * C; ++i) d[i] += o.d[i]; return *this; }
+    Matrix &operator/=(T s) { for (int i = 0; i < R * C; ++i) d[i] /= s; return *this; }
+    template <int K> Mat<T, R, K> operator*(const Mat<T, C, K> &o) const
+    {
+        Mat<T, R, K> m;
+        for (int i = 0; i < R; ++i) for (int j = 0; j < K; ++j) { T s = (*this)(i, 0) * o(0, j); for (int k = 1; k < C; ++k) s += (*this)(i, k) * o(k, j); m(i, j) = s; }
+        return m;
+    }
+    CommaInit<T, R, C> operator<<(T v) { d[0] = v; return CommaInit<T, R, C>{*this, 1}; }
+    template <int N> ColsRef<T, R, C, N> leftCols() { return ColsRef<T, R, C, N>{d, 0, C}; }
+    template <int N> ColsRef<T, R, C, N> rightCols() { return ColsRef<T, R, C, N>{d, C - N, C}; }
+    template <int N> Mat<T, N, 1> head() const { Mat<T, N, 1> m; for (int i = 0; i < N; ++i) m.d[i] = d[i]; return m; }
+    template <int N> Mat<T, N, 1> tail() const { Mat<T, N, 1> m; for (int i = 0; i < N; ++i) m.d[i] = d[R * C - N + i]; return m; }
+};
+template <typename S, typename T, int R, int C, typename = typename std::enable_if<std::is_arithmetic<S>::value>::type>
+Mat<T, R, C> operator*(S s, const Mat<T, R, C> &m) { return m * T(s); }
+template <typename T, int R, int C, int N> ColsRef<T, R, C, N> &ColsRef<T, R, C, N>::operator=(const Mat<T, R, N> &m)
+{
+    for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) base[i * ld + col0 + j] = m(i, j);
+    return *this;
+}
+
+typedef Matrix<double, 3, 1> Vector3d;
+typedef Matrix<double, 4, 1> Vector4d;
+typedef Matrix<double, 3, 3> Matrix3d;
+typedef Matrix<float, 3, 1> Vector3f;
+typedef Matrix<float, 3, 3> Matrix3f;
+
+struct VectorXd {                                                  // the edge factor keeps its six coefficients in one
+    typedef double Scalar;
+    std::vector<double> v;
+    VectorXd() {}
+    explicit VectorXd(int n) : v(size_t(n), 0.0) {}
+    template <int R> VectorXd(const Mat<double, R, 1> &m) : v(m.d, m.d + R) {}
+    template <int R> VectorXd &operator=(const Mat<double, R, 1> &m) { v.assign(m.d, m.d + R); return *this; }
+    double &operator()(int i) { return v[size_t(i)]; }
+    const double &operator()(int i) const { return v[size_t(i)]; }
+    int size() const { return int(v.size()); }
+};
+
+template <typename T> struct Quaternion {
+    typedef T Scalar;
+    T x_, y_, z_, w_;
+    Quaternion() : x_(0), y_(0), z_(0), w_(1) {}
+    Quaternion(T w, T x, T y, T z) : x_(x), y_(y), z_(z), w_(w) {}
+    T &x() { return x_; } T &y() { return y_; } T &z() { return z_; } T &w() { return w_; }
+    T x() const { return x_; } T y() const { return y_; } T z() const { return z_; } T w() const { return w_; }
+    // QuaternionBase::_transformVector: v + w * (2 q x v) + q x (2 q x v)
+    Matrix<T, 3, 1> operator*(const Matrix<T, 3, 1> &v) const
+    {
+        const Matrix<T, 3, 1> qv(x_, y_, z_);
+        Matrix<T, 3, 1> uv = qv.cross(v);
+        uv += uv;
+        const Matrix<T, 3, 1> c2 = qv.cross(uv);
+        return Matrix<T, 3, 1>(v.d[0] + w_ * uv.d[0] + c2.d[0], v.d[1] + w_ * uv.d[1] + c2.d[1], v.d[2] + w_ * uv.d[2] + c2.d[2]);
+    }
+    Quaternion operator*(const Quaternion &b) const
+    {
+        return Quaternion(w_ * b.w_ - x_ * b.x_ - y_ * b.y_ - z_ * b.z_, w_ * b.x_ + x_ * b.w_ + y_ * b.z_ - z_ * b.y_,
+                          w_ * b.y_ + y_ * b.w_ + z_ * b.x_ - x_ * b.z_, w_ * b.z_ + z_ * b.w_ + x_ * b.y_ - y_ * b.x_);
+    }
+    Quaternion conjugate() const { return Quaternion(w_, -x_, -y_, -z_); }
+    Quaternion normalized() const { const T n = std::sqrt(x_ * x_ + y_ * y_ + z_ * z_ + w_ * w_); return Quaternion(w_ / n, x_ / n, y_ / n, z_ / n); }
+    Matrix<T, 3, 3> toRotationMatrix() const
+    {
+        const T tx = T(2) * x_, ty = T(2) * y_, tz = T(2) * z_;
+        const T twx = tx * w_, twy = ty * w_, twz = tz * w_, txx = tx * x_, txy = ty * x_, txz = tz * x_, tyy = ty * y_, tyz = tz * y_, tzz = tz * z_;
+        Matrix<T, 3, 3> R;
+        R(0, 0) = T(1) - (tyy + tzz); R(0, 1) = txy - twz; R(0, 2) = txz + twy;
+        R(1, 0) = txy + twz; R(1, 1) = T(1) - (txx + tzz); R(1, 2) = tyz - twx;
+        R(2, 0) = txz - twy; R(2, 1) = tyz + twx; R(2, 2) = T(1) - (txx + tyy);
+        return R;
+    }
+};
+typedef Quaternion<double> Quaterniond;
+
+// Map<...> over a caller's array: matrices (row-major) and quaternions (coefficients x, y, z, w in memory, as Eigen stores them)
+template <typename M> struct Map;
+template <typename T, int R, int C> struct Map<Mat<T, R, C>> {
+    T *p;
+    explicit Map(T *q) : p(q) {}
+    void setZero() { for (int i = 0; i < R * C; ++i) p[i] = T(0); }
+    template <int N> ColsRef<T, R, C, N> leftCols() { return ColsRef<T, R, C, N>{p, 0, C}; }
+    template <int N> ColsRef<T, R, C, N> rightCols() { return ColsRef<T, R, C, N>{p, C - N, C}; }
+    Map &operator=(const Mat<T, R, C> &m) { for (int i = 0; i < R * C; ++i) p[i] = m.d[i]; return *this; }
+};
+template <typename T, int R, int C> struct Map<const Mat<T, R, C>> {
+    const T *p;
+    explicit Map(const T *q) : p(q) {}
+    operator Mat<T, R, C>() const { Mat<T, R, C> m; for (int i = 0; i < R * C; ++i) m.d[i] = p[i]; return m; }
+    Mat<T, R, C> operator+(const Mat<T, R, C> &o) const { return Mat<T, R, C>(*this) + o; }
+};
+template <typename T, int R, int C, int K> Mat<T, R, 1> operator*(const Mat<T, R, C> &a, const Map<const Mat<T, K, 1>> &b) { return a * Mat<T, K, 1>(b); }
+template <typename T> struct Map<Quaternion<T>> {
+    T *p;
+    explicit Map(T *q) : p(q) {}
+    Map &operator=(const Quaternion<T> &q) { p[0] = q.x_; p[1] = q.y_; p[2] = q.z_; p[3] = q.w_; return *this; }
+};
+template <typename T> struct Map<const Quaternion<T>> {
+    const T *p;
+    explicit Map(const T *q) : p(q) {}
+    operator Quaternion<T>() const { return Quaternion<T>(p[3], p[0], p[1], p[2]); }
+    Quaternion<T> operator*(const Quaternion<T> &o) const { return Quaternion<T>(*this) * o; }
+};
+}  // namespace Eigen
+
+// ---- the two Eigen decompositions the match functions call: thin wrappers over the oracle's restatements (oracle/linalg.hpp)
+#include "../linalg.hpp"
+namespace Eigen {
+template <typename M> struct SelfAdjointEigenSolver;
+template <> struct SelfAdjointEigenSolver<Matrix3f> {
+    orc::Eig3f e;
+    explicit SelfAdjointEigenSolver(const Matrix3f &A) { float a[3][3]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = A(i, j); e = orc::eig3_sym_f(a); }
+    Vector3f eigenvalues() const { return Vector3f(e.val[0], e.val[1], e.val[2]); }
+    Matrix3f eigenvectors() const { Matrix3f V; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V(i, j) = e.vec[i][j]; return V; }
+};
+struct MatrixXf {
+    int r = 0, c = 0;
+    std::vector<float> v;                                          // row-major
+    static MatrixXf Zero(int rr, int cc) { MatrixXf m; m.r = rr; m.c = cc; m.v.assign(size_t(rr) * cc, 0.f); return m; }
+    static MatrixXf Constant(int rr, int cc, float x) { MatrixXf m; m.r = rr; m.c = cc; m.v.assign(size_t(rr) * cc, x); return m; }
+    float &operator()(int i, int j) { return v[size_t(i) * c + j]; }
+    struct QR {
+        const MatrixXf &A;
+        Vector3f solve(const MatrixXf &b) const { float x[3]; orc::colpiv_qr_solve_f(A.v.data(), b.v.data(), A.r, x); return Vector3f(x[0], x[1], x[2]); }
+    };
+    QR colPivHouseholderQr() const { return QR{*this}; }
+};
+}  // namespace Eigen

@@ -1,0 +1,260 @@
+// TEST INFRASTRUCTURE ONLY -- oracle/_ref: the reference's OWN SOURCE LINES, compiled where they lie.
+// The reference cannot be built as a whole in this image (every translation unit includes Eigen, PCL + FLANN, Ceres, glog, ROS headers,
+// none of which exist here), but the functions on the hot path are plain C++ over a few dozen library calls. oracle/ref/build_ref.py cuts
+// the line ranges of those functions out of the files under /root/reference into oracle/_ref/gen/*.inc (never committed, deleted after
+// the compile) and this file supplies just enough context -- a mini Eigen (mini_eigen.hpp), a vector-backed pcl::PointCloud, a
+// pcl::VoxelGrid that calls the oracle's restatement, empty ceres / ROS bases -- for g++ to compile them VERBATIM:
+//   FeatureExtract::extractCloud           estimator/src/featureExtract/feature_extract.cpp:118-297  (+ compObject, feature_extract.hpp:48-53)
+//   LidarMapPlaneNormFactor ctor/Evaluate  estimator/src/factor/lidar_map_factor.hpp:26-71, 122-126
+//   LidarMapEdgeFactor ctor/Evaluate       estimator/src/factor/lidar_map_factor.hpp:130-174, 231-235
+//   FeatureExtract::match{Corner,Surf}PointFromMap   estimator/src/featureExtract/feature_extract.hpp:645-788, 790-883 (+ decls 111-128)
+//   pointAssociateToMap, common::sqrSum    estimator/src/utility/utility.h:102-117; mloam_common/.../algos/math.hpp:10-14
+//   Utility::deltaQ, skewSymmetric         estimator/src/utility/utility.h:169-195
+//   LidarPureOdom{PlaneNorm,Edge}Factor    estimator/src/factor/lidar_pure_odom_factor.hpp:27-102, 191-195; 198-282, 377-381
+//   LidarOnlineCalib{PlaneNorm,Edge}Factor estimator/src/factor/lidar_online_calib_factor.hpp:24-62, 117-121; 125-165, 223-227
+//   PoseLocalParameterization::{setParameter, Plus}   estimator/src/factor/pose_local_parameterization.h:21-33, .cpp:16-45
+// What this pins: every decision, loop bound, comparison, term and sign the reference's own code makes (the labels and the four feature
+// lists; residual and Jacobian formulas). What it does not: the arithmetic INSIDE the third-party calls (Eigen products, PCL's voxel
+// centroids), which here is the shim's / the oracle's restatement.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "mini_eigen.hpp"
+#include "../feature_extract.hpp"      // orc::PointI, orc::voxel_grid_xyzi (the oracle's pcl::VoxelGrid restatement)
+#include "../kdtree.hpp"               // orc::KdTree (the pcl::KdTreeFLANN restatement: exact k-NN, f32 L2_Simple accumulation)
+
+using namespace std;                   // the reference's headers pull this in (parameters.h); its .cpp files rely on it (`pair`, `sqrt`)
+
+// ---------------------------------------------------------------- pcl / boost / ROS / ceres context
+namespace boost {
+using std::shared_ptr;
+template <typename T, typename... A> std::shared_ptr<T> make_shared(A &&...a) { return std::make_shared<T>(std::forward<A>(a)...); }
+}  // namespace boost
+namespace pcl {
+struct PointXYZI { float x = 0, y = 0, z = 0, intensity = 0; };
+template <typename P> struct PointCloud {
+    typedef boost::shared_ptr<PointCloud<P>> Ptr;
+    std::vector<P> points;
+    size_t size() const { return points.size(); }
+    void push_back(const P &p) { points.push_back(p); }
+    void clear() { points.clear(); }
+    PointCloud &operator+=(const PointCloud &o) { points.insert(points.end(), o.points.begin(), o.points.end()); return *this; }
+};
+template <typename P> struct VoxelGrid {       // 3p: centroid per voxel -> the oracle's restatement of pcl::VoxelGrid::applyFilter
+    typename PointCloud<P>::Ptr in;
+    float leaf = 0.f;
+    void setInputCloud(const typename PointCloud<P>::Ptr &c) { in = c; }
+    void setLeafSize(float lx, float, float) { leaf = lx; }
+    void filter(PointCloud<P> &out)
+    {
+        std::vector<orc::PointI> src(in->points.size()), dst;
+        for (size_t i = 0; i < src.size(); ++i) { src[i].x = in->points[i].x; src[i].y = in->points[i].y; src[i].z = in->points[i].z; src[i].intensity = in->points[i].intensity; }
+        orc::voxel_grid_xyzi(src.data(), int(src.size()), leaf, dst);
+        out.points.resize(dst.size());
+        for (size_t i = 0; i < dst.size(); ++i) { out.points[i].x = dst[i].x; out.points[i].y = dst[i].y; out.points[i].z = dst[i].z; out.points[i].intensity = dst[i].intensity; }
+    }
+};
+}  // namespace pcl
+namespace pcl {
+namespace fields { struct intensity {}; }
+namespace traits { template <typename P, typename F> struct has_field { static const bool value = true; }; }
+template <typename P> struct KdTreeFLANN {                    // 3p: the oracle's exact k-NN
+    typedef boost::shared_ptr<KdTreeFLANN<P>> Ptr;
+    orc::KdTree tree;
+    void setInputCloud(const PointCloud<P> &c) { tree.build(&c.points[0].x, sizeof(P) / sizeof(float), int(c.size())); }
+    int nearestKSearch(const P &p, int k, std::vector<int> &idx, std::vector<float> &sqd) const
+    {
+        const float q[3] = {p.x, p.y, p.z};
+        return tree.knn(q, k, idx.data(), sqd.data());
+    }
+};
+}  // namespace pcl
+struct NullLog { template <typename T> NullLog &operator<<(const T &) { return *this; } };
+#define LOG(x) NullLog()
+struct Pose { Eigen::Quaterniond q_; Eigen::Vector3d t_; };   // pose.h:38-66 (the two members the match functions read)
+class PointPlaneFeature {                                     // parameters.h:163-175 without jaco_ (Eigen::MatrixXd; not touched by the match functions)
+public:
+    PointPlaneFeature() : idx_(0), laser_idx_(0), type_('n') {}
+    size_t idx_;
+    size_t laser_idx_;
+    Eigen::Vector3d point_;
+    Eigen::VectorXd coeffs_;
+    char type_;
+};
+float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;         // parameters.cpp:232-233
+namespace common {
+#include "../_ref/gen/sqr_sum.inc"                            // template <typename T> inline T sqrSum(x, y, z)
+}
+using namespace common;
+#include "../_ref/gen/point_associate_to_map.inc"             // pointAssociateToMap
+
+namespace ceres {
+template <int... N> struct SizedCostFunction { virtual ~SizedCostFunction() {} };
+struct LocalParameterization {
+    virtual ~LocalParameterization() {}
+    virtual bool Plus(const double *x, const double *delta, double *x_plus_delta) const = 0;
+    virtual bool ComputeJacobian(const double *x, double *jacobian) const = 0;
+    virtual int GlobalSize() const = 0;
+    virtual int LocalSize() const = 0;
+};
+}  // namespace ceres
+typedef pcl::PointXYZI PointI;
+typedef pcl::PointCloud<PointI> PointICloud;
+typedef std::map<std::string, PointICloud> cloudFeature;      // parameters.h:161
+struct ScanInfo { std::vector<int> scan_start_ind_, scan_end_ind_; };     // parameters.h:193-207 (the two members extractCloud reads)
+struct TicToc { double toc() { return 0.0; } };
+#define ROS_WARN(...) do { } while (0)
+int N_SCANS = 0;                                              // parameters.cpp global
+
+#include "../_ref/gen/comp_object.inc"                        // class compObject
+class FeatureExtract {
+public:
+    void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature);
+#include "../_ref/gen/match_point_decls.inc"                  // the declarations of match{Corner,Surf}PointFromMap (default arguments live here)
+};
+#include "../_ref/gen/extract_cloud.inc"                      // void FeatureExtract::extractCloud(...) { ... }
+#include "../_ref/gen/match_corner_point.inc"                 // template <typename PointType> bool FeatureExtract::matchCornerPointFromMap(...)
+#include "../_ref/gen/match_surf_point.inc"
+
+#include "../_ref/gen/utility_head.inc"                       // class Utility { public: deltaQ, skewSymmetric
+};
+#include "../_ref/gen/plane_factor_head.inc"                  // class LidarMapPlaneNormFactor ... Evaluate
+#include "../_ref/gen/plane_factor_tail.inc"                  // private members, };
+#include "../_ref/gen/edge_factor_head.inc"
+#include "../_ref/gen/edge_factor_tail.inc"
+#include "../_ref/gen/odom_plane_head.inc"                    // LidarPureOdomPlaneNormFactor
+#include "../_ref/gen/odom_plane_tail.inc"
+#include "../_ref/gen/odom_edge_head.inc"                     // LidarPureOdomEdgeFactor
+#include "../_ref/gen/odom_edge_tail.inc"
+#include "../_ref/gen/calib_plane_head.inc"                   // LidarOnlineCalibPlaneNormFactor
+#include "../_ref/gen/calib_plane_tail.inc"
+#include "../_ref/gen/calib_edge_head.inc"                    // LidarOnlineCalibEdgeFactor
+#include "../_ref/gen/calib_edge_tail.inc"
+#include "../_ref/gen/plp_class.inc"                          // class PoseLocalParameterization
+bool PoseLocalParameterization::ComputeJacobian(const double *, double *) const { return true; }   // (not cut: Map<Matrix<7,6>>::topRows; the test restates [I6; 0])
+#include "../_ref/gen/plp_plus.inc"                           // setParameter, Plus
+
+// ---------------------------------------------------------------- C API for the tests
+extern "C" {
+// clouds out: sharp, less_sharp, flat, less_flat (voxel-thinned), each n x 4 floats; counts in n_out[4]
+int ref_extract_cloud(const float *xyzi, int n, const int *scan_start, const int *scan_end, int n_scans, float *out[4], int n_out[4])
+{
+    PointICloud in;
+    in.points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) { in.points[i].x = xyzi[4 * i]; in.points[i].y = xyzi[4 * i + 1]; in.points[i].z = xyzi[4 * i + 2]; in.points[i].intensity = xyzi[4 * i + 3]; }
+    ScanInfo si;
+    si.scan_start_ind_.assign(scan_start, scan_start + n_scans);
+    si.scan_end_ind_.assign(scan_end, scan_end + n_scans);
+    N_SCANS = n_scans;
+    cloudFeature cf;
+    FeatureExtract f;
+    f.extractCloud(in, si, cf);
+    const char *keys[4] = {"corner_points_sharp", "corner_points_less_sharp", "surf_points_flat", "surf_points_less_flat"};
+    for (int k = 0; k < 4; ++k) {
+        const PointICloud &c = cf[keys[k]];
+        n_out[k] = int(c.size());
+        for (size_t i = 0; i < c.size(); ++i) { out[k][4 * i] = c.points[i].x; out[k][4 * i + 1] = c.points[i].y; out[k][4 * i + 2] = c.points[i].z; out[k][4 * i + 3] = c.points[i].intensity; }
+    }
+    return 0;
+}
+
+// kind 's': LidarMapPlaneNormFactor(point, coeff[0..3], cov), 'c': LidarMapEdgeFactor(point, coeff[0..5], cov); J: 7 doubles or NULL
+int ref_map_factor_evaluate(char kind, const double point[3], const double *coeff, const double cov9[9], const double pose7[7], double *residual, double *J7)
+{
+    Eigen::Vector3d p(point[0], point[1], point[2]);
+    Eigen::Matrix3d cov;
+    for (int i = 0; i < 9; ++i) cov.d[i] = cov9[i];
+    const double *params[1] = {pose7};
+    double *jac[1] = {J7};
+    if (kind == 's') {
+        LidarMapPlaneNormFactor f(p, Eigen::Vector4d(coeff[0], coeff[1], coeff[2], coeff[3]), cov);
+        f.Evaluate(params, residual, J7 ? jac : nullptr);
+    } else {
+        Eigen::VectorXd c(6);
+        for (int i = 0; i < 6; ++i) c(i) = coeff[i];
+        LidarMapEdgeFactor f(p, c, cov);
+        f.Evaluate(params, residual, J7 ? jac : nullptr);
+    }
+    return 0;
+}
+
+// match{Surf,Corner}PointFromMap for every feature of a cloud against a map cloud (both n x 4 float rows [x y z intensity]):
+// valid[i], coeffs[i * 6 ..] (plane: n, d; line: the two points)
+int ref_match_points(char kind, const float *map4, int n_map, const float *feat4, int n_feat, const double pose7[7], int n_neigh, int check_fov,
+                     float min_match_sq_dis, float min_plane_dis, unsigned char *valid, double *coeffs)
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis;
+    PointICloud map;
+    map.points.resize(size_t(n_map));
+    for (int i = 0; i < n_map; ++i) { map.points[i].x = map4[4 * i]; map.points[i].y = map4[4 * i + 1]; map.points[i].z = map4[4 * i + 2]; map.points[i].intensity = map4[4 * i + 3]; }
+    pcl::KdTreeFLANN<PointI>::Ptr kd(new pcl::KdTreeFLANN<PointI>());
+    kd->setInputCloud(map);
+    Pose pose;
+    pose.t_ = Eigen::Vector3d(pose7[0], pose7[1], pose7[2]);
+    pose.q_ = Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]);
+    FeatureExtract f;
+    for (int i = 0; i < n_feat; ++i) {
+        PointI p;
+        p.x = feat4[4 * i]; p.y = feat4[4 * i + 1]; p.z = feat4[4 * i + 2]; p.intensity = feat4[4 * i + 3];
+        PointPlaneFeature ft;
+        const bool ok = kind == 's' ? f.matchSurfPointFromMap<PointI>(kd, map, p, pose, ft, size_t(i), size_t(n_neigh), check_fov != 0)
+                                    : f.matchCornerPointFromMap<PointI>(kd, map, p, pose, ft, size_t(i), size_t(n_neigh), check_fov != 0);
+        valid[i] = ok ? 1 : 0;
+        for (int k = 0; k < 6; ++k) coeffs[size_t(i) * 6 + k] = (ok && k < ft.coeffs_.size()) ? ft.coeffs_(k) : 0.0;
+    }
+    return 0;
+}
+
+// kind 's' / 'c': LidarPureOdom{PlaneNorm,Edge}Factor(point, coeff, sqrt_info) on (pivot, pose_i, ext); J21 = three 1x7 rows or NULL
+int ref_pure_odom_evaluate(char kind, const double point[3], const double *coeff, double sqrt_info, const double *pivot, const double *pose_i,
+                           const double *ext, double *residual, double *J21)
+{
+    Eigen::Vector3d p(point[0], point[1], point[2]);
+    const double *params[3] = {pivot, pose_i, ext};
+    double *jac[3] = {J21, J21 ? J21 + 7 : nullptr, J21 ? J21 + 14 : nullptr};
+    if (kind == 's') {
+        LidarPureOdomPlaneNormFactor f(p, Eigen::Vector4d(coeff[0], coeff[1], coeff[2], coeff[3]), sqrt_info);
+        f.Evaluate(params, residual, J21 ? jac : nullptr);
+    } else {
+        Eigen::VectorXd c(6);
+        for (int i = 0; i < 6; ++i) c(i) = coeff[i];
+        LidarPureOdomEdgeFactor f(p, c, sqrt_info);
+        f.Evaluate(params, residual, J21 ? jac : nullptr);
+    }
+    return 0;
+}
+
+int ref_online_calib_evaluate(char kind, const double point[3], const double *coeff, double sqrt_info, const double *ext, double *residual, double *J7)
+{
+    Eigen::Vector3d p(point[0], point[1], point[2]);
+    const double *params[1] = {ext};
+    double *jac[1] = {J7};
+    if (kind == 's') {
+        LidarOnlineCalibPlaneNormFactor f(p, Eigen::Vector4d(coeff[0], coeff[1], coeff[2], coeff[3]), sqrt_info);
+        f.Evaluate(params, residual, J7 ? jac : nullptr);
+    } else {
+        Eigen::VectorXd c(6);
+        for (int i = 0; i < 6; ++i) c(i) = coeff[i];
+        LidarOnlineCalibEdgeFactor f(p, c, sqrt_info);
+        f.Evaluate(params, residual, J7 ? jac : nullptr);
+    }
+    return 0;
+}
+
+// PoseLocalParameterization: setParameter(), optionally V_update_ <- V36 (row-major) as evalDegenracy does, then Plus
+int ref_pose_plus(const double x[7], const double delta[6], const double *V36, double out[7])
+{
+    PoseLocalParameterization plp;
+    plp.setParameter();
+    if (V36) for (int i = 0; i < 36; ++i) plp.V_update_.d[i] = V36[i];
+    const ceres::LocalParameterization &base = plp;
+    base.Plus(x, delta, out);
+    return 0;
+}
+}
