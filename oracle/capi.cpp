@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
 // extern "C" surface of the CPU oracle, loaded with ctypes by tests/, bench.py's cpu_baseline leg and
 // __graft_entry__.smoke(). The product library (m-loam_amd/) never links or loads this.
+#include "image_segmenter.hpp"
 #include "feature_extract.hpp"
 #include "mapper.hpp"
 #include "uct.hpp"
@@ -338,6 +339,28 @@ int orc_pure_odom_normal_eq(int n, const int *types, const double *points, const
             for (int b = 0; b < 18; ++b) H[size_t(ra) * D + off[b / 6] + b % 6] += v[a] * v[b];
         }
     }
+    return 0;
+}
+
+// ImageSegmenter::segmentCloud (image_segmenter.hpp:139-393). prm: [vertical_scans, horizon_scans, min_cluster_size, segment_valid_point_num,
+// segment_valid_line_num, segment_theta, roi_range, segment_flag]. Buffers sized for n points (+1 outlier row); label / range images vs x hs.
+int orc_segment_cloud(const float *xyzi, int n, const double *prm, float *cloud_out, int *n_out, float *outlier, int *n_outlier, int *scan_start,
+                      int *scan_end, float *range_mat, int *label_mat, int *pixel_of_point)
+{
+    SegParams p;
+    p.vertical_scans = int(prm[0]); p.horizon_scans = int(prm[1]); p.min_cluster_size = int(prm[2]); p.segment_valid_point_num = int(prm[3]);
+    p.segment_valid_line_num = int(prm[4]); p.segment_theta = float(prm[5]); p.roi_range = prm[6]; p.segment_flag = prm[7] != 0.0;
+    SegResult r;
+    segment_cloud(xyzi, n, p, r);
+    std::memcpy(cloud_out, r.cloud_out.data(), sizeof(float) * r.cloud_out.size());
+    *n_out = int(r.cloud_out.size() / 4);
+    std::memcpy(outlier, r.cloud_outlier.data(), sizeof(float) * r.cloud_outlier.size());
+    *n_outlier = int(r.cloud_outlier.size() / 4);
+    std::memcpy(scan_start, r.scan_start.data(), sizeof(int) * r.scan_start.size());
+    std::memcpy(scan_end, r.scan_end.data(), sizeof(int) * r.scan_end.size());
+    if (range_mat) std::memcpy(range_mat, r.range_mat.data(), sizeof(float) * r.range_mat.size());
+    if (label_mat) std::memcpy(label_mat, r.label_mat.data(), sizeof(int) * r.label_mat.size());
+    if (pixel_of_point) std::memcpy(pixel_of_point, r.pixel_of_point.data(), sizeof(int) * r.pixel_of_point.size());
     return 0;
 }
 

@@ -102,6 +102,19 @@ def mapper_params(min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1, map_
                      float(freeze_when_degenerate)], dtype=np.float64)
 
 
+def ref_segment_cloud(points4, prm=None):
+    """ImageSegmenter::segmentCloud compiled from the reference's lines (its UB included, as g++ -O2 renders it)"""
+    L = ref_lib()
+    prm = seg_params() if prm is None else np.ascontiguousarray(prm, np.float64)
+    p = np.ascontiguousarray(points4, np.float32)
+    n = len(p); vs = int(prm[0])
+    out = np.zeros((max(n, 1), 4), np.float32); outl = np.zeros((max(n, 1) + 1, 4), np.float32)
+    ss = np.zeros(vs, np.int32); se = np.zeros(vs, np.int32)
+    no, nl = C.c_int(0), C.c_int(0)
+    L.ref_segment_cloud(_ptr(p), n, _ptr(prm), _ptr(out), C.byref(no), _ptr(outl), C.byref(nl), _ptr(ss), _ptr(se))
+    return dict(cloud=out[:no.value].copy(), outlier=outl[:nl.value].copy(), scan_start=ss, scan_end=se)
+
+
 def ref_match(kind: str, map_pts, feats, pose7, n_neigh=5, check_fov=False, min_match_sq_dis=1.0, min_plane_dis=0.2):
     """FeatureExtract::match{Surf,Corner}PointFromMap (feature_extract.hpp:645-883) from the reference's lines, feature by feature"""
     L = ref_lib()
@@ -390,6 +403,26 @@ def pure_odom_normal_eq(types, points, coeffs6, sqrt_info, frame_idx, ext_idx, p
     lib().orc_pure_odom_normal_eq(len(t), _ptr(t), _ptr(p), _ptr(c), _ptr(si), _ptr(fi), _ptr(ei), _ptr(pv), _ptr(fr), len(fr), _ptr(ex), len(ex),
                                   C.c_double(huber_delta), _ptr(H), _ptr(g), C.byref(cost), C.byref(cnt))
     return dict(H=H, g=g, cost=cost.value, count=cnt.value)
+
+
+def seg_params(vertical_scans=16, horizon_scans=1800, min_cluster_size=30, segment_valid_point_num=5, segment_valid_line_num=3,
+               segment_theta=1.047, roi_range=1.0, segment_flag=True):
+    """config_realvehicle_hercules.yaml:7-13, 102 defaults"""
+    return np.array([vertical_scans, horizon_scans, min_cluster_size, segment_valid_point_num, segment_valid_line_num, segment_theta, roi_range,
+                     float(segment_flag)], np.float64)
+
+
+def segment_cloud(points4, prm=None):
+    """ImageSegmenter::segmentCloud on an unordered cloud (n, 4) [x y z intensity] -> ring-major cloud, ScanInfo arrays, outliers, images"""
+    prm = seg_params() if prm is None else np.ascontiguousarray(prm, np.float64)
+    p = np.ascontiguousarray(points4, np.float32)
+    n = len(p); vs, hs = int(prm[0]), int(prm[1])
+    out = np.zeros((max(n, 1), 4), np.float32); outl = np.zeros((max(n, 1) + 1, 4), np.float32)
+    ss = np.zeros(vs, np.int32); se = np.zeros(vs, np.int32)
+    rng = np.zeros((vs, hs), np.float32); lab = np.zeros((vs, hs), np.int32); pix = np.zeros(max(n, 1), np.int32)
+    no, nl = C.c_int(0), C.c_int(0)
+    lib().orc_segment_cloud(_ptr(p), n, _ptr(prm), _ptr(out), C.byref(no), _ptr(outl), C.byref(nl), _ptr(ss), _ptr(se), _ptr(rng), _ptr(lab), _ptr(pix))
+    return dict(cloud=out[:no.value].copy(), outlier=outl[:nl.value].copy(), scan_start=ss, scan_end=se, range_mat=rng, label_mat=lab, pixel_of_point=pix[:n].copy())
 
 
 def eig3f(A):

@@ -14,6 +14,10 @@ SRC = os.path.join(REF, "estimator", "src")
 COMMON = os.path.join(REF, "mloam_common", "libs", "include", "common")
 # (output, file, first line, last line, text the first line must contain) -- a drifted reference fails loudly instead of compiling something else
 CUTS = [
+    ("image_segmenter_class.inc", "imageSegmenter/image_segmenter.hpp", 36, 83, "class ImageSegmenter"),
+    ("image_segmenter_project.inc", "imageSegmenter/image_segmenter.hpp", 87, 136, "template <typename PointType>"),
+    ("image_segmenter_segment.inc", "imageSegmenter/image_segmenter.hpp", 138, 393, "template <typename PointType>"),
+    ("image_segmenter_setparam.inc", "imageSegmenter/image_segmenter.cpp", 18, 63, "void ImageSegmenter::setParameter"),
     ("sqr_sum.inc", "algos/math.hpp", 10, 14, "template <typename T>"),
     ("comp_object.inc", "featureExtract/feature_extract.hpp", 48, 53, "class compObject"),
     ("extract_cloud.inc", "featureExtract/feature_extract.cpp", 118, 297, "void FeatureExtract::extractCloud"),

@@ -185,11 +185,19 @@ struct MatrixXf {
     std::vector<float> v;                                          // row-major
     static MatrixXf Zero(int rr, int cc) { MatrixXf m; m.r = rr; m.c = cc; m.v.assign(size_t(rr) * cc, 0.f); return m; }
     static MatrixXf Constant(int rr, int cc, float x) { MatrixXf m; m.r = rr; m.c = cc; m.v.assign(size_t(rr) * cc, x); return m; }
-    float &operator()(int i, int j) { return v[size_t(i) * c + j]; }
+    // an out-of-range element (the reference's 64-ring ground loop reads row 64: oracle/image_segmenter.hpp U3) reads as "empty" (FLT_MAX)
+    // instead of whatever lies behind the buffer
+    float &operator()(int i, int j) { static float outside; if (i < 0 || i >= r || j < 0 || j >= c) { outside = 3.402823466e+38f; return outside; } return v[size_t(i) * c + j]; }
     struct QR {
         const MatrixXf &A;
         Vector3f solve(const MatrixXf &b) const { float x[3]; orc::colpiv_qr_solve_f(A.v.data(), b.v.data(), A.r, x); return Vector3f(x[0], x[1], x[2]); }
     };
     QR colPivHouseholderQr() const { return QR{*this}; }
+};
+struct MatrixXi {
+    int r = 0, c = 0;
+    std::vector<int> v;
+    static MatrixXi Zero(int rr, int cc) { MatrixXi m; m.r = rr; m.c = cc; m.v.assign(size_t(rr) * cc, 0); return m; }
+    int &operator()(int i, int j) { static int outside; if (i < 0 || i >= r || j < 0 || j >= c) { outside = -1; return outside; } return v[size_t(i) * c + j]; }
 };
 }  // namespace Eigen

@@ -4,6 +4,8 @@
 // the line ranges of those functions out of the files under /root/reference into oracle/_ref/gen/*.inc (never committed, deleted after
 // the compile) and this file supplies just enough context -- a mini Eigen (mini_eigen.hpp), a vector-backed pcl::PointCloud, a
 // pcl::VoxelGrid that calls the oracle's restatement, empty ceres / ROS bases -- for g++ to compile them VERBATIM:
+//   ImageSegmenter (class, projectCloud, segmentCloud, setParameter)   estimator/src/imageSegmenter/image_segmenter.hpp:36-83, 88-136, 138-393;
+//                                          image_segmenter.cpp:18-63  (its three UB spots compile to whatever g++ makes of them: see oracle/image_segmenter.hpp)
 //   FeatureExtract::extractCloud           estimator/src/featureExtract/feature_extract.cpp:118-297  (+ compObject, feature_extract.hpp:48-53)
 //   LidarMapPlaneNormFactor ctor/Evaluate  estimator/src/factor/lidar_map_factor.hpp:26-71, 122-126
 //   LidarMapEdgeFactor ctor/Evaluate       estimator/src/factor/lidar_map_factor.hpp:130-174, 231-235
@@ -42,6 +44,10 @@ template <typename P> struct PointCloud {
     typedef boost::shared_ptr<PointCloud<P>> Ptr;
     std::vector<P> points;
     size_t size() const { return points.size(); }
+    void resize(size_t n) { points.resize(n); }
+    typename std::vector<P>::iterator begin() { return points.begin(); }
+    // a position that is no longer inside the row erases nothing (std::vector::erase there is undefined: oracle/image_segmenter.hpp U2)
+    typename std::vector<P>::iterator erase(typename std::vector<P>::iterator it) { return (it < points.begin() || it >= points.end()) ? points.end() : points.erase(it); }
     void push_back(const P &p) { points.push_back(p); }
     void clear() { points.clear(); }
     PointCloud &operator+=(const PointCloud &o) { points.insert(points.end(), o.points.begin(), o.points.end()); return *this; }
@@ -107,10 +113,17 @@ struct LocalParameterization {
 typedef pcl::PointXYZI PointI;
 typedef pcl::PointCloud<PointI> PointICloud;
 typedef std::map<std::string, PointICloud> cloudFeature;      // parameters.h:161
-struct ScanInfo { std::vector<int> scan_start_ind_, scan_end_ind_; };     // parameters.h:193-207 (the two members extractCloud reads)
+struct ScanInfo { std::vector<int> scan_start_ind_, scan_end_ind_; bool segment_flag_ = true; };     // parameters.h:193-207 (the members read on this path)
+double ROI_RANGE = 1.0;                                       // parameters.cpp:58
+float SEGMENT_THETA = 1.047f;                                 // parameters.cpp:39
 struct TicToc { double toc() { return 0.0; } };
 #define ROS_WARN(...) do { } while (0)
 int N_SCANS = 0;                                              // parameters.cpp global
+
+#include "../_ref/gen/image_segmenter_class.inc"              // class ImageSegmenter { ... }
+#include "../_ref/gen/image_segmenter_project.inc"            // template projectCloud
+#include "../_ref/gen/image_segmenter_segment.inc"            // template segmentCloud
+#include "../_ref/gen/image_segmenter_setparam.inc"           // ImageSegmenter::setParameter
 
 #include "../_ref/gen/comp_object.inc"                        // class compObject
 class FeatureExtract {
@@ -181,6 +194,27 @@ int ref_map_factor_evaluate(char kind, const double point[3], const double *coef
         LidarMapEdgeFactor f(p, c, cov);
         f.Evaluate(params, residual, J7 ? jac : nullptr);
     }
+    return 0;
+}
+
+// ImageSegmenter::segmentCloud. prm as orc_segment_cloud. cloud_out / outlier: n (+1) x 4 floats.
+int ref_segment_cloud(const float *xyzi, int n, const double *prm, float *cloud_out, int *n_out, float *outlier, int *n_outlier, int *scan_start, int *scan_end)
+{
+    const int vs = int(prm[0]), hs = int(prm[1]);
+    ImageSegmenter seg;
+    seg.setParameter(vs, hs, int(prm[2]), int(prm[3]), int(prm[4]));
+    SEGMENT_THETA = float(prm[5]); ROI_RANGE = prm[6];
+    PointICloud in, out, outl;
+    in.points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) { in.points[i].x = xyzi[4 * i]; in.points[i].y = xyzi[4 * i + 1]; in.points[i].z = xyzi[4 * i + 2]; in.points[i].intensity = xyzi[4 * i + 3]; }
+    ScanInfo si;
+    si.segment_flag_ = prm[7] != 0.0;
+    si.scan_start_ind_.resize(vs); si.scan_end_ind_.resize(vs);
+    seg.segmentCloud(in, out, outl, si);
+    *n_out = int(out.size()); *n_outlier = int(outl.size());
+    for (size_t i = 0; i < out.size(); ++i) { cloud_out[4 * i] = out.points[i].x; cloud_out[4 * i + 1] = out.points[i].y; cloud_out[4 * i + 2] = out.points[i].z; cloud_out[4 * i + 3] = out.points[i].intensity; }
+    for (size_t i = 0; i < outl.size(); ++i) { outlier[4 * i] = outl.points[i].x; outlier[4 * i + 1] = outl.points[i].y; outlier[4 * i + 2] = outl.points[i].z; outlier[4 * i + 3] = outl.points[i].intensity; }
+    for (int i = 0; i < vs; ++i) { scan_start[i] = si.scan_start_ind_[i]; scan_end[i] = si.scan_end_ind_[i]; }
     return 0;
 }
 

@@ -235,3 +235,28 @@ def test_config4_scan_full_size(mla, orc, synth, cfg45):
         dt, dr = _pose_err(poses[b], ref["pose"])
         assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
     c.close()
+
+
+def test_extract_against_the_references_own_lines(mla, orc, cfg2):
+    """the HIP extractCloud against oracle/_ref -- FeatureExtract::extractCloud compiled from the reference's own source lines
+    (oracle/ref/build_ref.py; the prebuilt library travels to the GPU box) -- on both 64-ring scans: the same feature points in the same order."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libmloam_ref.so has not been built (needs /root/reference once)")
+    c = mla.Context(0)
+    for s in cfg2["scans"]:
+        got = c.extract(s.points, s.scan_start, s.scan_end, voxel_leaf=0.2)
+        want = orc.ref_extract(s.points, s.scan_start, s.scan_end)
+        for k in ("sharp", "less_sharp", "flat"):
+            assert np.array_equal(want[k].view(np.uint32), np.ascontiguousarray(s.points[got[k]]).view(np.uint32)), k
+        assert want["less_flat_ds"].shape == got["less_flat_ds"].shape
+        np.testing.assert_allclose(got["less_flat_ds"][:, :3], want["less_flat_ds"][:, :3], atol=2e-6)
+    # ... and the correspondence decisions + coefficients of the config-2 features at the bench's initial pose
+    c.map_set_pair(cfg2["surf_map"], cfg2["corner_map"])
+    c.features_set(mla.SURF, cfg2["surf"]); c.features_set(mla.CORNER, cfg2["corner"])
+    for kind, ch, feats, cloud in ((mla.SURF, "s", cfg2["surf"], cfg2["surf_map"]), (mla.CORNER, "c", cfg2["corner"], cfg2["corner_map"])):
+        out = c.match_linearize(kind, cfg2["p0"], dense=False)
+        v_ref, c_ref = orc.ref_match(ch, cloud, feats, cfg2["p0"])
+        assert np.array_equal(out["valid"], v_ref), f"{int(np.sum(out['valid'] != v_ref))} decision flips vs the reference's lines ({ch})"
+        m = v_ref.astype(bool)
+        assert np.array_equal(out["coeffs"][m].astype(np.float32).view(np.uint32), c_ref[m].astype(np.float32).view(np.uint32))
+    c.close()

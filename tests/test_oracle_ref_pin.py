@@ -162,3 +162,77 @@ def test_match_point_from_map_is_the_references(ref, case16, feats16, n_neigh, c
         v_orc, c_orc = ref.Map(cloud).match("s", f4, tilt, n_neigh=n_neigh, check_fov=True)
         assert np.array_equal(v_fov, v_orc) and np.array_equal(c_fov[v_fov.astype(bool)], c_orc[v_fov.astype(bool)])
         assert 0 < v_fov.sum() < v_all.sum()               # the check really removes something here
+
+
+def _raw_cloud(synth, n_rings, seed, clutter):
+    """an UNORDERED cloud as a driver delivers it: a simulated scan, shuffled, part of the points pulled off their surfaces along the ray"""
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], n_rings, seed=seed)
+    rng = np.random.default_rng(seed)
+    pts = s.points.copy()
+    pts[:, 3] = 0
+    m = rng.random(len(pts)) < clutter
+    pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
+    return pts[rng.permutation(len(pts))]
+
+
+@pytest.mark.parametrize("vs,rings", [(16, 16), (32, 64), (64, 64)])
+def test_image_segmenter_is_the_references(ref, synth, vs, rings, capfd):
+    """ImageSegmenter::segmentCloud (image_segmenter.hpp:88-393) compiled from the reference's lines against the restatement: the ring-major cloud,
+    ScanInfo and the outlier cloud bit for bit, with and without clutter (hundreds to thousands of rejected clusters exercise the stale-position
+    erasures and the next-queue-entry rule), both thresholds the configs use, several ROI ranges, segmentation on and off. The reference's
+    undefined spots are pinned the same way on both sides (oracle/image_segmenter.hpp U1-U3; the shim context bounds-checks what the oracle skips)."""
+    n_checked = 0
+    for seed in range(3):
+        for clutter in (0.0, 0.1, 0.4):
+            pts = _raw_cloud(synth, rings, seed, clutter)
+            for flag in (True, False):
+                prm = ref.seg_params(vertical_scans=vs, segment_theta=1.047 if seed % 2 else 0.53, roi_range=[1.0, 0.5, 6.0][seed], segment_flag=flag)
+                a, b = ref.segment_cloud(pts, prm), ref.ref_segment_cloud(pts, prm)
+                assert a["cloud"].shape == b["cloud"].shape and np.array_equal(a["cloud"].view(np.uint32), b["cloud"].view(np.uint32))
+                assert np.array_equal(a["scan_start"], b["scan_start"]) and np.array_equal(a["scan_end"], b["scan_end"])
+                assert a["outlier"].shape == b["outlier"].shape and np.array_equal(a["outlier"].view(np.uint32), b["outlier"].view(np.uint32))
+                n_checked += 1
+                if flag and clutter > 0:
+                    assert (a["label_mat"] == 999999).sum() > 500
+    capfd.readouterr()        # the reference's setParameter prints a line per call
+    assert n_checked == 18
+
+
+def test_image_segmenter_known_answers(orc):
+    """hand-checkable cases of the restatement: the projection's row / column rule, first-point-wins, the +5 / -6 insets of ScanInfo, the
+    intensity += row convention, a 3-pixel cluster that is rejected and a vertical 5-pixel pole that the line rule keeps."""
+    prm = orc.seg_params(vertical_scans=16, horizon_scans=1800, segment_flag=True)
+    def ray(row, col, r):
+        el = np.deg2rad(-15.0 + 2.0 * row)
+        ha = np.deg2rad(90.0 - (col - 900) * 0.2)            # column_id = -round((ha - 90) / 0.2) + 900
+        return [r * np.cos(el) * np.sin(ha), r * np.cos(el) * np.cos(ha), r * np.sin(el), 0.25]
+    pts = []
+    for col in range(200, 260):                              # a wall: rows 8..12, constant range -> one big cluster
+        for row in range(8, 13):
+            pts.append(ray(row, col, 12.0))
+    pts += [ray(9, 600, 7.0), ray(9, 601, 7.0), ray(9, 602, 7.0)]        # 3 pixels on one ring: fewer than segment_valid_point_num -> outliers
+    pts += [ray(r, 1000, 9.0) for r in range(8, 13)]                      # a pole: 5 pixels over 5 rings -> kept by the line rule (>= 5 points, >= 3 rings)
+    pts.append(ray(10, 220, 3.0))                                          # second hit on an occupied pixel: the first point keeps it
+    pts.append(ray(4, 50, 0.5))                                            # inside roi_range = 1: dropped
+    pts = np.array(pts, np.float32)
+    out = orc.segment_cloud(pts, prm)
+    lab = out["label_mat"]
+    assert out["pixel_of_point"][-1] == -1 and out["pixel_of_point"][-2] == -1
+    assert out["pixel_of_point"][0] == 8 * 1800 + 200
+    assert (lab[9, 600:603] == 999999).all() and (lab[8:13, 1000] > 1).all() and (lab[8:13, 1000] < 999999).all()
+    assert len(np.unique(lab[8:13, 200:260])) == 1
+    # the three rejected pixels sit at positions 60, 61, 62 of ring 9's list (after the wall's 60 points, before the pole's): the first
+    # erasure (60) shifts the rest down, the stale position 61 then removes what was recorded at 62, and the stale 62 points past the end --
+    # the reference's erase is undefined there (U2), here it erases nothing. So ONE rejected point (column 601) survives in the output:
+    assert len(out["cloud"]) == 60 * 5 + 5 + 1
+    survivors = out["cloud"][np.isclose(np.linalg.norm(out["cloud"][:, :3], axis=1), 7.0, atol=1e-3)]
+    assert len(survivors) == 1 and np.allclose(survivors[0, :3], ray(9, 601, 7.0)[:3], atol=1e-5)
+    assert np.array_equal(out["cloud"][:, 3], np.floor(out["cloud"][:, 3]) + 0.25)           # intensity + row id
+    rows = np.floor(out["cloud"][:, 3]).astype(int)
+    assert np.all(np.diff(rows) >= 0)                                     # ring-major
+    for r in range(16):
+        n_r = int((rows == r).sum()); first = int((rows < r).sum())
+        assert out["scan_start"][r] == first + 5 and out["scan_end"][r] == first + n_r - 6
+    # outlier cloud: outlier pixels whose column is a multiple of 5 (600), plus the first point of the output cloud (hpp:391)
+    assert len(out["outlier"]) == 2 and np.array_equal(out["outlier"][1], out["cloud"][0])
