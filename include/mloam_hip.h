@@ -78,6 +78,32 @@ int mlh_profile_sample(mlh_ctx *ctx, int every_n);
 int mlh_profile_reset(mlh_ctx *ctx);
 int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
 
+/* ---------------------------------------------------------------- (f3) ImageSegmenter::segmentCloud
+ * replaces ImageSegmenter::segmentCloud(laser_cloud_in, laser_cloud_out, laser_cloud_outlier, scan_info)
+ *   estimator/src/imageSegmenter/image_segmenter.hpp:139-393 (projectCloud :88-136, setParameter image_segmenter.cpp:18-63), called by
+ *   Estimator::inputCloud (estimator.cpp:228, 258, 298, 317).
+ * In: the raw, UNORDERED cloud of one LiDAR (HOST or DEVICE records: x y z at offset 0, f32 intensity at intensity_offset_bytes or -1).
+ * Out: the ring-major cloud [x y z intensity + row] and ScanInfo::scan_start_ind_ / scan_end_ind_ (+5 / -6 insets), staged as the context's
+ * scan exactly as mlh_scan_upload leaves it -- mlh_extract_run follows directly, the cloud never has to be assembled on the host -- and,
+ * when the pointers are given, copied back: cloud_out (up to n x 4 floats), scan_start / scan_end (vertical_scans each), outlier_out
+ * (laser_cloud_outlier: up to n / 5 + 2 rows of 4 floats). Projection, ground pairs and the final gather run on the GPU; the cluster search and
+ * the outlier erasure are defined by their sequential order and run on the host inside this call (m-loam_amd/csrc/segment.hip says why).
+ * The reference's undefined spots -- alpha used before it is set, erase with shifted positions, the 64-ring ground loop's row 64 -- behave as
+ * INTEGRATION.md documents. vertical_scans 16, 32 or 64. */
+typedef struct mlh_segment_params {
+    int32_t vertical_scans;            /* N_SCANS */
+    int32_t horizon_scans;             /* HORIZON_SCAN (horizon_scan) */
+    int32_t min_cluster_size;          /* MIN_CLUSTER_SIZE */
+    int32_t segment_valid_point_num;   /* SEGMENT_VALID_POINT_NUM */
+    int32_t segment_valid_line_num;    /* SEGMENT_VALID_LINE_NUM */
+    float segment_theta;               /* SEGMENT_THETA */
+    double roi_range;                  /* ROI_RANGE */
+    int32_t segment_flag;              /* ScanInfo::segment_flag_ (segment_cloud): 0 = project and reorder only, nothing is erased */
+} mlh_segment_params;
+void mlh_segment_params_default(mlh_segment_params *p);     /* config_realvehicle_hercules.yaml:7-13, 102 */
+int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, int mem, const mlh_segment_params *prm,
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier);
+
 /* ---------------------------------------------------------------- (a1-a3) FeatureExtract::extractCloud
  * replaces FeatureExtract::extractCloud(const PointICloud&, const ScanInfo&, cloudFeature&)
  *   estimator/src/featureExtract/feature_extract.cpp:118-297, declared feature_extract.hpp:74.

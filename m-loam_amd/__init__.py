@@ -42,6 +42,11 @@ class BlockOpts(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("k_neigh", C.c_int * 8), ("eig_thre", C.c_double * 8), ("freeze", C.c_int * 8)]
 
 
+class SegmentParams(C.Structure):
+    _fields_ = [("vertical_scans", C.c_int32), ("horizon_scans", C.c_int32), ("min_cluster_size", C.c_int32), ("segment_valid_point_num", C.c_int32),
+                ("segment_valid_line_num", C.c_int32), ("segment_theta", C.c_float), ("roi_range", C.c_double), ("segment_flag", C.c_int32)]
+
+
 class TrackOpts(C.Structure):
     _fields_ = [("distance_sq_threshold", C.c_float), ("nearby_scan", C.c_float), ("huber_delta", C.c_double),
                 ("max_outer", C.c_int32), ("max_lm_iterations", C.c_int32)]
@@ -86,6 +91,9 @@ def load_library():
     lib.mlh_profile_reset.argtypes = [vp]
     lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
     lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci]
+    lib.mlh_segment_params_default.argtypes = [C.POINTER(SegmentParams)]
+    lib.mlh_segment_params_default.restype = None
+    lib.mlh_segment_cloud.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(SegmentParams), vp, C.POINTER(C.c_int32), vp, vp, vp, C.POINTER(C.c_int32)]
     lib.mlh_extract_run.argtypes = [vp]
     lib.mlh_extract_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.mlh_extract_voxel_run.argtypes = [vp, cf]
@@ -142,7 +150,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
-    "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
+    "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
@@ -253,6 +261,24 @@ class Context:
             ss, se = scan_start.contiguous(), scan_end.contiguous()
             self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, 12 if stride >= 16 else -1, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
         self._scan_n = n
+
+    def segment_cloud(self, points4, fetch=True, **kw):
+        """ImageSegmenter::segmentCloud: unordered cloud (n, 4) [x y z intensity] (numpy or torch CUDA) -> the context's scan (ring-major, on the
+        device) and, with fetch, the ring-major cloud / ScanInfo arrays / outlier cloud. kw: fields of SegmentParams."""
+        prm = SegmentParams()
+        self.lib.mlh_segment_params_default(C.byref(prm))
+        for k, v in kw.items():
+            setattr(prm, k, v)
+        ptr, stride, n, mem, keep = _src(points4)
+        vs = prm.vertical_scans
+        out = np.zeros((max(n, 1), 4), np.float32) if fetch else None
+        outl = np.zeros((n // 5 + 3, 4), np.float32) if fetch else None
+        ss = np.zeros(vs, np.int32); se = np.zeros(vs, np.int32)
+        no, nl = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mlh_segment_cloud(self.h, ptr, stride, 12 if stride >= 16 else -1, n, mem, C.byref(prm), _p(out) if fetch else None, C.byref(no),
+                                            _p(ss), _p(se), _p(outl) if fetch else None, C.byref(nl)))
+        self._scan_n = no.value
+        return dict(cloud=out[:no.value].copy() if fetch else None, outlier=outl[:nl.value].copy() if fetch else None, scan_start=ss, scan_end=se, n=no.value)
 
     def extract_run(self):
         self._ck(self.lib.mlh_extract_run(self.h))

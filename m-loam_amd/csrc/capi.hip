@@ -372,6 +372,22 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     return MLH_OK;
 }
 
+void mlh_segment_params_default(mlh_segment_params *p)
+{
+    if (!p) return;
+    p->vertical_scans = 16; p->horizon_scans = 1800; p->min_cluster_size = 30; p->segment_valid_point_num = 5; p->segment_valid_line_num = 3;
+    p->segment_theta = 1.047f; p->roi_range = 1.0; p->segment_flag = 1;
+}
+
+int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, int mem, const mlh_segment_params *prm,
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier)
+{
+    if (!ctx || !prm) return MLH_ERR_INVALID;
+    if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return segment_cloud_run(ctx, points, stride_bytes, intensity_offset_bytes, n, mem, *prm, cloud_out, n_out, scan_start, scan_end, outlier_out, n_outlier);
+}
+
 int mlh_extract_run(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;

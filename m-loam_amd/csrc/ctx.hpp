@@ -165,6 +165,10 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
     DevBuf in, bounds, cell, wpre, cnt, vox_of, word_of, sorted_idx, members, leader, out, sums, total;
 };
 
+struct SegBuf {    // ImageSegmenter scratch (segment.hip)
+    DevBuf raw, pix, owner, range, ground, keep;
+};
+
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     DevBuf tab, idx, poses, r, J;
     int n = 0, max_frame = 0, max_ext = 0;
@@ -228,6 +232,7 @@ struct mlh_ctx {
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;
     mlh::OdomSet odom;
+    mlh::SegBuf seg;
     mlh::TrackSet track;
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
     int fused_n[2] = {0, 0};   // valid when !fused_dirty
@@ -276,6 +281,9 @@ int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, i
 int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off, int *host_bad);
 int track_match_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
+// segment.hip
+int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier);
 // odom.hip
 int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
                   const int32_t *frame_idx, const int32_t *ext_idx);

@@ -1,0 +1,333 @@
+// ImageSegmenter::segmentCloud for gfx950 (estimator/src/imageSegmenter/image_segmenter.hpp:88-393, image_segmenter.cpp:18-63):
+// the producer of the ring-major cloud + ScanInfo that extractCloud consumes. Raw, unordered cloud in -> the context's scan staged in HBM
+// (as mlh_scan_upload leaves it), so a frame goes driver cloud -> segmentCloud -> extractCloud without the ring-major cloud ever being
+// assembled on the host.
+//
+// What runs where, and why:
+//   device  projectCloud (hpp:88-136): per point range / row / column in the reference's float-double mix; "the first point to claim a pixel
+//           keeps it" is an atomicMin on the point index. Ground labelling (hpp:179-227): a stencil over pixel pairs. The final gather of the
+//           kept points into the ring-major float4 cloud (intensity += row id, hpp:128) and its ring table.
+//   host    the cluster search (hpp:229-359) and the outlier erasure (hpp:362-383). Both are DEFINED by their sequential order: whether a
+//           "same beam" neighbour joins a cluster depends on the record of the NEXT queue entry at that moment (hpp:297-299), the distance
+//           uses the previous neighbour's alpha (hpp:285-286), erasures use positions that earlier erasures have shifted (hpp:374). A parallel
+//           labelling would be a different segmenter; one wavefront stepping through the queue out of HBM would be ~20x slower than a CPU
+//           core (every step is a dependent memory round trip). The range image (115 KB for 16 x 1800) goes down, a list of kept point
+//           indices comes back.
+// Undefined behaviour in the reference (uninitialised alpha, erase past the end, the 64-ring ground loop's row 64) is handled as
+// oracle/image_segmenter.hpp documents (U1-U3); INTEGRATION.md repeats it for the maintainer.
+// atan / atan2 run in f32 on the device (ocml) and in glibc on the reference's CPU: the last ulp may differ, which matters only for a point
+// within one ulp of a row / column bin edge or a ground pair within one ulp of 10 degrees.
+#include "ctx.hpp"
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+namespace mlh {
+
+struct SegSetup {   // ImageSegmenter::setParameter
+    int vs, hs, ground_scan_id, is64;
+    float ang_res_x, ang_res_y, ang_bottom, alphax, alphay;
+};
+
+static bool seg_setup(const mlh_segment_params &p, SegSetup &s)
+{
+    s.vs = p.vertical_scans; s.hs = p.horizon_scans; s.is64 = 0; s.alphay = 0.f; s.ang_bottom = 0.f;
+    if (p.vertical_scans == 16) {
+        s.ang_res_x = 360.0 / p.horizon_scans; s.ang_res_y = 2.0; s.ang_bottom = 15.0 + 0.1; s.ground_scan_id = 7;
+        s.alphax = s.ang_res_x / 180.0 * M_PI; s.alphay = s.ang_res_y / 180.0 * M_PI;
+    } else if (p.vertical_scans == 32) {
+        s.ang_res_x = 360.0 / p.horizon_scans; s.ang_res_y = 41.33 / float(p.vertical_scans - 1); s.ang_bottom = 30.0 + 0.67; s.ground_scan_id = 20;
+        s.alphax = s.ang_res_x / 180.0 * M_PI; s.alphay = s.ang_res_y / 180.0 * M_PI;
+    } else if (p.vertical_scans == 64) {
+        s.ang_res_x = 360.0 / p.horizon_scans; s.ang_res_y = FLT_MAX; s.ground_scan_id = 63; s.is64 = 1;
+        s.alphax = s.ang_res_x / 180.0 * M_PI;
+    } else return false;
+    return true;
+}
+
+struct SegDev {
+    const unsigned char *src; int stride, intensity_off, n;
+    SegSetup S; double roi_range;
+    int *pix;            // n: row * hs + col, or -1
+    int *owner;          // vs * hs: smallest point index that claimed the pixel (INT_MAX: empty)
+    float *range_mat;    // vs * hs
+    unsigned char *ground;   // vs * hs
+};
+
+// projectCloud, one lane per point (hpp:96-135)
+__global__ __launch_bounds__(256) void seg_project_kernel(SegDev D)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D.n) return;
+    const float *rec = reinterpret_cast<const float *>(D.src + size_t(i) * D.stride);
+    const float x = rec[0], y = rec[1], z = rec[2];
+    int pix = -1;
+    const float range = sqrtf(x * x + y * y + z * z);
+    if (!(double(range) < D.roi_range)) {
+        const float vertical_angle = float(double(atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
+        int row_id;
+        bool ok = true;
+        if (D.S.is64) {
+            if (double(vertical_angle) >= -8.83) row_id = int(double(2 - vertical_angle) * 3.0 + 0.5);          // (2 - angle) is a float subtraction in the reference
+            else row_id = D.S.vs / 2 + int((-8.83 - double(vertical_angle)) * 2.0 + 0.5);
+            if (vertical_angle > 2 || double(vertical_angle) < -24.33 || row_id > 50 || row_id < 0) ok = false;
+        } else {
+            row_id = int((vertical_angle + D.S.ang_bottom) / D.S.ang_res_y);
+            if (row_id < 0 || row_id >= D.S.vs) ok = false;
+        }
+        if (ok) {
+            const float horizon_angle = float(double(atan2f(x, y) * 180) / M_PI);
+            int column_id = int(-round((double(horizon_angle) - 90.0) / double(D.S.ang_res_x)) + double(D.S.hs / 2));
+            if (column_id >= D.S.hs) column_id -= D.S.hs;
+            if (column_id >= 0 && column_id < D.S.hs) {
+                pix = column_id + row_id * D.S.hs;
+                atomicMin(D.owner + pix, i);          // range_mat(row, col) != FLT_MAX -> continue: the first point in input order keeps the pixel
+            }
+        }
+    }
+    D.pix[i] = pix;
+}
+
+// the memset pattern 0x7f7f7f7f stands for "no point yet"; normalise to INT_MAX for everything that follows
+__global__ __launch_bounds__(256) void seg_owner_fix_kernel(int *owner, int npx)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < npx && owner[p] == 0x7f7f7f7f) owner[p] = INT_MAX;
+}
+
+__device__ __forceinline__ void seg_point(const SegDev &D, int i, float &x, float &y, float &z)
+{
+    const float *rec = reinterpret_cast<const float *>(D.src + size_t(i) * D.stride);
+    x = rec[0]; y = rec[1]; z = rec[2];
+}
+
+// range image + ground pairs (hpp:166-227), one lane per pixel
+__global__ __launch_bounds__(256) void seg_image_kernel(SegDev D)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int npx = D.S.vs * D.S.hs;
+    if (p >= npx) return;
+    const int o = D.owner[p];
+    float range = FLT_MAX, x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (o != INT_MAX) { seg_point(D, o, x1, y1, z1); range = sqrtf(x1 * x1 + y1 * y1 + z1 * z1); }
+    D.range_mat[p] = range;
+    const int i = p / D.S.hs;
+    const int lo = D.S.is64 ? D.S.ground_scan_id : 0, hi = D.S.is64 ? D.S.vs : D.S.ground_scan_id;
+    if (i >= lo && i < hi && i + 1 < D.S.vs && o != INT_MAX) {
+        const int o2 = D.owner[p + D.S.hs];
+        if (o2 != INT_MAX) {
+            float x2, y2, z2;
+            seg_point(D, o2, x2, y2, z2);
+            const float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
+            const float vertical_angle = float(double(atan2f(dz, sqrtf(dx * dx + dy * dy)) * 180) / M_PI);
+            if (fabsf(vertical_angle) <= 10) { D.ground[p] = 1; D.ground[p + D.S.hs] = 1; }      // both lanes that touch a pixel write the same 1
+        }
+    }
+}
+
+// the kept points, ring-major: out[k] = {x, y, z, intensity + row}
+__global__ __launch_bounds__(256) void seg_gather_kernel(SegDev D, const int *keep, int n_keep, float4 *out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_keep) return;
+    const int i = keep[k];
+    const float *rec = reinterpret_cast<const float *>(D.src + size_t(i) * D.stride);
+    float inten = D.intensity_off >= 0 ? *reinterpret_cast<const float *>(D.src + size_t(i) * D.stride + D.intensity_off) : 0.f;
+    inten += float(D.pix[i] / D.S.hs);
+    out[k] = make_float4(rec[0], rec[1], rec[2], inten);
+}
+
+// ---- host: cluster search + outlier erasure on the images (sequential by definition, see the file comment)
+struct SegHost {
+    std::vector<float> range;
+    std::vector<int> label, owner;
+    std::vector<unsigned char> ground;
+};
+
+static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegHost &H)
+{
+    SegSetup S = S0;
+    const int vs = S.vs, hs = S.hs;
+    const size_t npx = size_t(vs) * hs;
+    std::vector<uint16_t> pushed_x(npx), pushed_y(npx), qx(npx), qy(npx);
+    std::vector<int8_t> q_last_dy(npx, 0);
+    std::vector<float> q_last_dis(npx, 0.f);
+    auto R = [&](int i, int j) -> float { return H.range[size_t(i) * hs + j]; };
+    auto L = [&](int i, int j) -> int & { return H.label[size_t(i) * hs + j]; };
+    int label_count = 2;
+    static const int8_t nb[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
+    float alpha = 0.f;                                  // one variable for the whole call, starting at 0 (U1)
+    std::vector<char> line_flag(vs);
+    for (int i = 0; i < vs; i++) {
+        for (int j = 0; j < hs; j++) {
+            if (L(i, j) != 0) continue;
+            std::fill(line_flag.begin(), line_flag.end(), 0);
+            qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_last_dis[0] = 0.f;
+            int q_size = 1, q_start = 0, q_end = 1, n_pushed = 1;
+            pushed_x[0] = uint16_t(i); pushed_y[0] = uint16_t(j);
+            while (q_size > 0) {
+                const int fx = qx[q_start], fy = qy[q_start];
+                --q_size; ++q_start;
+                L(fx, fy) = label_count;
+                for (int q = 0; q < 4; ++q) {
+                    int tx = fx + nb[q][0], ty = fy + nb[q][1];
+                    if (tx < 0 || tx >= vs) continue;
+                    if (S.is64) S.alphay = (tx <= 32) ? float(0.333 / 180.0 * M_PI) : float(0.5 / 180.0 * M_PI);
+                    if (ty < 0) ty = hs - 1;
+                    if (ty >= hs) ty = 0;
+                    if (L(tx, ty) != 0) continue;
+                    const float d1 = std::max(R(fx, fy), R(tx, ty)), d2 = std::min(R(fx, fy), R(tx, ty));
+                    const float dist = std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * std::cos(alpha));
+                    alpha = nb[q][0] == 0 ? S.alphax : S.alphay;
+                    const float angle = std::atan2(d2 * std::sin(alpha), (d1 - d2 * std::cos(alpha)));
+                    bool push = angle > prm.segment_theta;
+                    if (!push && nb[q][1] == 0 && q_last_dy[q_start] == 0) {          // the record of the NEXT queue entry (hpp:297)
+                        const float dist_last = q_last_dis[q_start];
+                        push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
+                    }
+                    if (push) {
+                        qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = nb[q][1]; q_last_dis[q_end] = dist;
+                        ++q_size; ++q_end;
+                        L(tx, ty) = label_count;
+                        line_flag[tx] = 1;
+                        pushed_x[n_pushed] = uint16_t(tx); pushed_y[n_pushed] = uint16_t(ty); ++n_pushed;
+                    }
+                }
+            }
+            bool feasible = false;
+            if (n_pushed >= prm.min_cluster_size) feasible = true;
+            else if (n_pushed >= prm.segment_valid_point_num) {
+                int lines = 0;
+                for (int r = 0; r < vs; ++r) lines += line_flag[r] ? 1 : 0;
+                feasible = lines >= prm.segment_valid_line_num;
+            }
+            if (feasible) ++label_count;
+            else for (int k = 0; k < n_pushed; ++k) L(pushed_x[k], pushed_y[k]) = 999999;
+        }
+    }
+}
+
+int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier)
+{
+    SegSetup S;
+    if (!seg_setup(prm, S)) return fail(ctx, MLH_ERR_UNSUPPORTED, "ImageSegmenter is set up for 16, 32 or 64 vertical scans (image_segmenter.cpp:18-61)");
+    if (!points || n <= 0 || stride < 12 || (stride & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer");
+    if (prm.horizon_scans <= 0 || prm.horizon_scans > 65535) return fail(ctx, MLH_ERR_INVALID, "horizon_scans out of range");
+    hipStream_t st = ctx->stream;
+    const int vs = S.vs, hs = S.hs, npx = vs * hs;
+    SegBuf &B = ctx->seg;
+    const unsigned char *src = static_cast<const unsigned char *>(points);
+    if (mem == MLH_MEM_HOST) {
+        MLH_HIP(ctx, B.raw.ensure(size_t(n) * stride));
+        MLH_HIP(ctx, hipMemcpyAsync(B.raw.p, points, size_t(n) * stride, hipMemcpyHostToDevice, st));
+        src = B.raw.as<unsigned char>();
+    }
+    MLH_HIP(ctx, B.pix.ensure(sizeof(int) * size_t(n)));
+    MLH_HIP(ctx, B.owner.ensure(sizeof(int) * size_t(npx)));
+    MLH_HIP(ctx, B.range.ensure(sizeof(float) * size_t(npx)));
+    MLH_HIP(ctx, B.ground.ensure(size_t(npx)));
+    MLH_HIP(ctx, hipMemsetAsync(B.owner.p, 0x7f, sizeof(int) * size_t(npx), st));      // 0x7f7f7f7f > any index; read back as "empty" below
+    MLH_HIP(ctx, hipMemsetAsync(B.ground.p, 0, size_t(npx), st));
+    SegDev D;
+    D.src = src; D.stride = stride; D.intensity_off = intensity_off; D.n = n; D.S = S; D.roi_range = prm.roi_range;
+    D.pix = B.pix.as<int>(); D.owner = B.owner.as<int>(); D.range_mat = B.range.as<float>(); D.ground = B.ground.as<unsigned char>();
+    hipLaunchKernelGGL(seg_project_kernel, dim3((n + 255) / 256), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(seg_owner_fix_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D.owner, npx);
+    hipLaunchKernelGGL(seg_image_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D);
+    MLH_HIP(ctx, hipGetLastError());
+    SegHost H;
+    H.range.resize(npx); H.owner.resize(npx); H.ground.resize(npx); H.label.assign(npx, 0);
+    MLH_HIP(ctx, hipMemcpyAsync(H.range.data(), B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(H.owner.data(), B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(H.ground.data(), B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    for (int p = 0; p < npx; ++p) H.label[p] = (H.owner[p] == INT_MAX) ? -1 : (H.ground[p] ? 1 : 0);
+    seg_clusters(S, prm, H);
+    // the rows as the reference fills them: every pixel owner, in input order; cloud_scan_order = its position at fill time
+    std::vector<std::vector<int>> rows(vs);
+    std::vector<int> order(npx, 0);
+    for (int r = 0; r < vs; ++r) {
+        std::vector<int> &v = rows[r];
+        for (int c = 0; c < hs; ++c) if (H.owner[size_t(r) * hs + c] != INT_MAX) v.push_back(H.owner[size_t(r) * hs + c]);
+        std::sort(v.begin(), v.end());
+        // position of each pixel's point inside the sorted row: the rank of its index
+        for (int c = 0; c < hs; ++c) {
+            const int o = H.owner[size_t(r) * hs + c];
+            if (o != INT_MAX) order[size_t(r) * hs + c] = int(std::lower_bound(v.begin(), v.end(), o) - v.begin());
+        }
+    }
+    std::vector<int> outlier_idx;
+    if (prm.segment_flag) {
+        for (int r = 0; r < vs; ++r)
+            for (int c = 0; c < hs; ++c)
+                if (H.label[size_t(r) * hs + c] == 999999) {
+                    const int pos = order[size_t(r) * hs + c];
+                    if (pos >= 0 && size_t(pos) < rows[r].size()) rows[r].erase(rows[r].begin() + pos);       // stale position, as it is (U2)
+                    if (c % 5 == 0) outlier_idx.push_back(H.owner[size_t(r) * hs + c]);
+                }
+    }
+    std::vector<int> keep, hstart(vs), hend(vs);
+    for (int r = 0; r < vs; ++r) {
+        hstart[r] = int(keep.size()) + 5;
+        keep.insert(keep.end(), rows[r].begin(), rows[r].end());
+        hend[r] = int(keep.size()) - 6;
+    }
+    const int n_keep = int(keep.size());
+    // stage the scan exactly as mlh_scan_upload would
+    ScanBuf &sb = ctx->scan;
+    sb.extracted = false; sb.voxelised = false; sb.h_lists_valid = sb.h_vox_valid = false;
+    MLH_HIP(ctx, sb.pts.ensure(sizeof(float4) * size_t(std::max(n_keep, 1))));
+    MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(vs)));
+    MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(vs)));
+    MLH_HIP(ctx, B.keep.ensure(sizeof(int) * size_t(std::max(n_keep, 1))));
+    if (n_keep > 0) {
+        MLH_HIP(ctx, hipMemcpyAsync(B.keep.p, keep.data(), sizeof(int) * size_t(n_keep), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(seg_gather_kernel, dim3((n_keep + 255) / 256), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), n_keep, sb.pts.as<float4>());
+        MLH_HIP(ctx, hipGetLastError());
+    }
+    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hstart.data(), sizeof(int) * size_t(vs), hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, hend.data(), sizeof(int) * size_t(vs), hipMemcpyHostToDevice, st));
+    if (cloud_out && n_keep > 0) MLH_HIP(ctx, hipMemcpyAsync(cloud_out, sb.pts.p, sizeof(float4) * size_t(n_keep), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    int max_len = 0;
+    for (int r = 0; r < vs; ++r) if (hend[r] - hstart[r] >= 6) max_len = std::max(max_len, hend[r] - hstart[r]);
+    sb.n = n_keep; sb.n_rings = vs; sb.max_ring_len = max_len;
+    if (n_out) *n_out = n_keep;
+    if (scan_start) std::memcpy(scan_start, hstart.data(), sizeof(int) * size_t(vs));
+    if (scan_end) std::memcpy(scan_end, hend.data(), sizeof(int) * size_t(vs));
+    // laser_cloud_outlier: every fifth-column outlier pixel's point, then the first point of the output cloud (hpp:378, 391)
+    if (n_outlier) *n_outlier = int(outlier_idx.size()) + (n_keep > 0 ? 1 : 0);
+    if (outlier_out) {
+        // the few outlier records are assembled from the caller's cloud when it is on the host, else fetched point by point
+        size_t k = 0;
+        auto put = [&](int i, int row) -> int {
+            float rec[4] = {0, 0, 0, 0};
+            if (mem == MLH_MEM_HOST) {
+                const unsigned char *q = static_cast<const unsigned char *>(points) + size_t(i) * stride;
+                std::memcpy(rec, q, 12);
+                if (intensity_off >= 0) std::memcpy(rec + 3, q + intensity_off, 4);
+            } else {
+                if (hipMemcpy(rec, src + size_t(i) * stride, 12, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+                if (intensity_off >= 0 && hipMemcpy(rec + 3, src + size_t(i) * stride + intensity_off, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+            }
+            rec[3] += float(row);
+            std::memcpy(outlier_out + 4 * k, rec, 16);
+            ++k;
+            return 0;
+        };
+        std::vector<int> pix_of(outlier_idx.size());
+        for (int r = 0, q = 0; r < vs && q < int(outlier_idx.size()); ++r)
+            for (int c = 0; c < hs && q < int(outlier_idx.size()); ++c)
+                if (prm.segment_flag && H.label[size_t(r) * hs + c] == 999999 && c % 5 == 0) { if (put(outlier_idx[q], r)) return fail(ctx, MLH_ERR_HIP, "outlier fetch"); ++q; }
+        if (n_keep > 0) {
+            int row0 = 0;
+            while (row0 < vs && rows[row0].empty()) ++row0;
+            if (put(keep[0], row0)) return fail(ctx, MLH_ERR_HIP, "outlier fetch");
+        }
+    }
+    return MLH_OK;
+}
+
+}  // namespace mlh

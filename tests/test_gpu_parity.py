@@ -1069,3 +1069,53 @@ def test_full_size_front_end_properties(mla, synth):
             assert np.array_equal(exj[key], np.concatenate([ex[key], ex1[key] + off])), key
     finally:
         c.close()
+
+
+def _raw_cloud(synth, n_rings, seed, clutter):
+    """an UNORDERED cloud as a driver delivers it: a simulated scan, shuffled, part of the points pulled off their surfaces along the ray"""
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], n_rings, seed=seed)
+    rng = np.random.default_rng(seed)
+    pts = s.points.copy()
+    pts[:, 3] = rng.uniform(0.0, 0.9, len(pts)).astype(np.float32)          # some intensity payload in [0, 1)
+    m = rng.random(len(pts)) < clutter
+    pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
+    return pts[rng.permutation(len(pts))]
+
+
+@pytest.mark.parametrize("vs,rings,clutter,flag", [(16, 16, 0.1, True), (16, 16, 0.4, True), (16, 16, 0.1, False), (32, 64, 0.1, True), (64, 64, 0.1, True)])
+def test_image_segmenter_parity(mla, orc, synth, vs, rings, clutter, flag):
+    """(f3) ImageSegmenter::segmentCloud: ring-major cloud, ScanInfo and outlier cloud bit-equal to the oracle (itself pinned against the reference's
+    own lines), the scan staged on the device feeding extractCloud directly. Device atan / atan2 may differ from glibc in the last ulp: the test
+    data keeps every sample away from the bin edges (asserted), which is where an ulp could flip a row, a column or a ground pair."""
+    import torch
+    torch.cuda.init()
+    pts = _raw_cloud(synth, rings, 3, clutter)
+    prm = orc.seg_params(vertical_scans=vs, segment_flag=flag)
+    ref = orc.segment_cloud(pts, prm)
+    # margins: column fractional part away from .5, i.e. (ha - 90) / res away from half-integers
+    ha = np.degrees(np.arctan2(pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)))
+    t = (ha - 90.0) / (360.0 / 1800)
+    assert np.min(np.abs((t - np.floor(t)) - 0.5)) > 1e-3
+    c = mla.Context(0)
+    got = c.segment_cloud(pts, vertical_scans=vs, segment_flag=int(flag))
+    assert got["cloud"].shape == ref["cloud"].shape
+    assert np.array_equal(got["cloud"].view(np.uint32), ref["cloud"].view(np.uint32))
+    assert np.array_equal(got["scan_start"], ref["scan_start"]) and np.array_equal(got["scan_end"], ref["scan_end"])
+    assert got["outlier"].shape == ref["outlier"].shape and np.array_equal(got["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
+    if flag:
+        assert len(ref["cloud"]) < len(pts) - 100          # clutter really was removed
+    if vs == 16:
+        # the staged scan feeds extractCloud without leaving the device: same labels as the oracle's extraction of the oracle's cloud
+        c.extract_run()
+        ex = c.extract_fetch()
+        rex = orc.extract(ref["cloud"], ref["scan_start"], ref["scan_end"])
+        assert rex["n_ties"] == 0
+        for k in ("label", "sharp", "less_sharp", "flat", "less_flat_raw"):
+            assert np.array_equal(ex[k], rex[k]), k
+    # device-resident input: same answer
+    d = torch.from_numpy(pts).cuda()
+    torch.cuda.synchronize()
+    got2 = c.segment_cloud(d, vertical_scans=vs, segment_flag=int(flag))
+    assert np.array_equal(got2["cloud"].view(np.uint32), ref["cloud"].view(np.uint32)) and np.array_equal(got2["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
+    c.close()
