@@ -276,6 +276,10 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
 int mlh_linearize(mlh_ctx *ctx, int kind, const double pose[7], uint32_t flags, double huber_delta, double cov_measurement_trace,
                   double *r, double *J, double *JtJ, double *Jtr, double *cost, int32_t *n_valid);
 
+/* the correspondences of `kind` currently live on the device (after mlh_match_linearize, or -- only the selected ones -- after
+ * mlh_good_feature_matching): valid[m], coeffs[m x 6] (PointPlaneFeature::coeffs_: plane n, d / line X1, X2; zeros where invalid) */
+int mlh_match_coeffs(mlh_ctx *ctx, int kind, uint8_t *valid, double *coeffs, int32_t *n_valid);
+
 /* ---------------------------------------------------------------- (a13) good-feature selection
  * replaces ActiveFeatureSelection::goodFeatureMatching (estimator/src/lidarMapper/lidar_mapper.h:229-573).
  * ALL features of `kind` are matched and their weighted, un-corrected 1x6 Jacobians evaluated on the GPU in one pass

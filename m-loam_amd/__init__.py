@@ -131,6 +131,7 @@ def load_library():
     lib.mlh_features_set_block.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci]
     lib.mlh_gn_solve_blocks.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), C.POINTER(BlockOpts), vp]
     lib.mlh_match_linearize.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, cd, cd, vp, vp, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
+    lib.mlh_match_coeffs.argtypes = [vp, ci, vp, vp, C.POINTER(C.c_int32)]
     lib.mlh_linearize.argtypes = [vp, ci, vp, C.c_uint32, cd, cd, vp, vp, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_good_feature_matching.argtypes = [vp, ci, vp, ci, cd, C.c_uint64, cf, cf, vp, C.POINTER(C.c_int32), vp, vp]
     lib.mlh_solver_opts_default.argtypes = [C.POINTER(SolverOpts)]
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = [
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
-    "mlh_match_linearize", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
+    "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]

@@ -788,6 +788,25 @@ static int fetch_dense_and_reduced(mlh_ctx *ctx, int kind, bool want_corr, uint8
     return MLH_OK;
 }
 
+int mlh_match_coeffs(mlh_ctx *ctx, int kind, uint8_t *valid, double *coeffs, int32_t *n_valid)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    FeatSet &f = ctx->feat[kind];
+    if (!f.matched || f.m <= 0 || !f.corr.p) return fail(ctx, MLH_ERR_STATE, "no correspondences of this kind on the device (match first)");
+    std::vector<Corr> hc(size_t(f.m));
+    MLH_HIP(ctx, hipMemcpyAsync(hc.data(), f.corr.p, sizeof(Corr) * size_t(f.m), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = 0;
+    for (int i = 0; i < f.m; ++i) {
+        if (valid) valid[i] = hc[i].valid ? 1 : 0;
+        if (coeffs) for (int k = 0; k < 6; ++k) coeffs[size_t(i) * 6 + k] = double(hc[i].c[k]);
+        n += hc[i].valid ? 1 : 0;
+    }
+    if (n_valid) *n_valid = n;
+    return MLH_OK;
+}
+
 int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neigh, uint32_t flags,
                         float min_match_sq_dis, float min_plane_dis, double huber_delta, double cov_measurement_trace,
                         uint8_t *valid, double *coeffs, double *r, double *J,

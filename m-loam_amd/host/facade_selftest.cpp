@@ -201,6 +201,98 @@ int main(int argc, char **argv)
             write_file(d + "out_undistorted.f32", uo);
             undistortMeasurementsOnDevice(dev, pose_undist, 0.1f);
         }
+        // --- the per-feature Ceres contract + ActiveFeatureSelection + ImageSegmenter (round 2)
+        {
+            // LidarMap{PlaneNorm,Edge}Factor: (point, coeff, cov) -> Evaluate(parameters, residuals, jacobians), also with null Jacobians
+            auto surf_f = read_file<float>(d + "surf.f32");
+            auto corner_f = read_file<float>(d + "corner.f32");
+            auto surf_m = read_file<float>(d + "surf_map.f32");
+            auto corner_m = read_file<float>(d + "corner_map.f32");
+            auto pose_in = read_file<double>(d + "pose.f64");
+            Pose pose0;
+            pose0.fromParam(pose_in.data());
+            PointICovCloud map_s = cov_cloud(surf_m, 3), map_c = cov_cloud(corner_m, 3), feat_s = cov_cloud(surf_f, 4), feat_c = cov_cloud(corner_f, 4);
+            for (auto *c : {&feat_s, &feat_c}) for (auto &q : c->points) { q.cov_vec[0] = 0.01f; q.cov_vec[3] = 0.02f; q.cov_vec[5] = 0.03f; }
+            MapIndex<PointIWithCov> kd_s(dev, MLH_SURF), kd_c(dev, MLH_CORNER);
+            kd_s.setInputCloud(map_s);
+            kd_c.setInputCloud(map_c);
+            ActiveFeatureSelection afs(dev, true, 11);
+            std::array<double, 36> mat_H{};
+            for (int i = 0; i < 6; ++i) mat_H[i * 7] = 1e-6;
+            int total_feat_num = 0;
+            afs.evalFullHessian(kd_s, map_s, feat_s, pose0, 's', mat_H, total_feat_num);
+            afs.evalFullHessian(kd_c, map_c, feat_c, pose0, 'c', mat_H, total_feat_num);
+            const double gf_deg_factor = logDet6(mat_H.data());
+            std::vector<double> afs_out(mat_H.begin(), mat_H.end());
+            afs_out.push_back(double(total_feat_num));
+            afs_out.push_back(gf_deg_factor);
+            for (const char *m : {"wo_gf", "rnd", "fps", "gd_fix", "gd_float"})
+                for (double thre : {gf_deg_factor - 1.0, gf_deg_factor + 1.0}) afs_out.push_back(gfRatioPolicy(m, 0.2, gf_deg_factor, thre));
+            write_file(d + "out_afs.f64", afs_out);
+            // goodFeatureMatching + the reference's block-assembly loop (lidar_mapper_keyframe.cpp:537-571) on the selected features
+            std::vector<PointPlaneFeature> all_surf_features;
+            std::vector<size_t> sel_surf_feature_idx;
+            std::array<double, 36> sub_mat_H{};
+            for (int i = 0; i < 6; ++i) sub_mat_H[i * 7] = 1e-6;
+            afs.goodFeatureMatching(kd_s, map_s, feat_s, pose0, all_surf_features, sel_surf_feature_idx, 's', "gd_fix", 0.2, sub_mat_H);
+            std::vector<double> rows;          // per selected feature: idx, residual, 7 Jacobian entries
+            double para_pose[7];
+            pose0.toParam(para_pose);
+            for (const size_t &fid : sel_surf_feature_idx) {
+                const PointPlaneFeature &feature = all_surf_features[fid];
+                std::array<double, 9> cov_matrix{};
+                const float *cv = feat_s.points[feature.idx_].cov_vec;       // extractCov (point_with_cov.hpp:202)
+                cov_matrix = {cv[0], cv[1], cv[2], cv[1], cv[3], cv[4], cv[2], cv[4], cv[5]};
+                LidarMapPlaneNormFactor *f = new LidarMapPlaneNormFactor(feature.point_, feature.coeffs_, cov_matrix);
+                double res, jac[7];
+                const double *params1[1] = {para_pose};
+                double *jacs[1] = {jac};
+                f->Evaluate(params1, &res, jacs);
+                double res2;
+                f->Evaluate(params1, &res2, nullptr);
+                if (res2 != res) throw Error("null-Jacobian Evaluate disagrees");
+                rows.push_back(double(fid)); rows.push_back(res);
+                for (int k = 0; k < 7; ++k) rows.push_back(jac[k]);
+                delete f;
+            }
+            write_file(d + "out_sel_rows.f64", rows);
+            std::vector<double> subh(sub_mat_H.begin(), sub_mat_H.end());
+            write_file(d + "out_sel_H.f64", subh);
+            // one edge factor per matched corner feature through the same contract
+            std::vector<PointPlaneFeature> all_corner_features;
+            std::vector<size_t> sel_corner_feature_idx;
+            std::array<double, 36> sub_c{};
+            for (int i = 0; i < 6; ++i) sub_c[i * 7] = 1e-6;
+            afs.goodFeatureMatching(kd_c, map_c, feat_c, pose0, all_corner_features, sel_corner_feature_idx, 'c', "wo_gf", 1.0, sub_c);
+            std::vector<double> crow;
+            for (const size_t &fid : sel_corner_feature_idx) {
+                const PointPlaneFeature &feature = all_corner_features[fid];
+                LidarMapEdgeFactor f(feature.point_, feature.coeffs_, std::array<double, 9>{0.0025, 0, 0, 0, 0.0025, 0, 0, 0, 0.0025});
+                double res, jac[7];
+                const double *params1[1] = {para_pose};
+                double *jacs[1] = {jac};
+                f.Evaluate(params1, &res, jacs);
+                crow.push_back(double(fid)); crow.push_back(res);
+                for (int k = 0; k < 7; ++k) crow.push_back(jac[k]);
+            }
+            write_file(d + "out_corner_rows.f64", crow);
+            // ImageSegmenter: the unordered cloud written by the harness -> ring-major cloud + ScanInfo -> extractCloud on what it staged
+            auto raw = read_file<float>(d + "raw_cloud.f32");
+            PointICloud raw_cloud, seg_out, seg_outlier;
+            for (size_t i = 0; i + 4 <= raw.size(); i += 4) { PointI q; q.x = raw[i]; q.y = raw[i + 1]; q.z = raw[i + 2]; q.intensity = raw[i + 3]; raw_cloud.push_back(q); }
+            ImageSegmenter img_segment(dev);
+            img_segment.setParameter(16, 1800, 30, 5, 3);
+            ScanInfo seg_info(16, true);
+            img_segment.segmentCloud(raw_cloud, seg_out, seg_outlier, seg_info);
+            std::vector<float> so;
+            for (const auto &q : seg_out.points) { so.push_back(q.x); so.push_back(q.y); so.push_back(q.z); so.push_back(q.intensity); }
+            write_file(d + "out_seg_cloud.f32", so);
+            std::vector<int> sinfo(seg_info.scan_start_ind_);
+            sinfo.insert(sinfo.end(), seg_info.scan_end_ind_.begin(), seg_info.scan_end_ind_.end());
+            write_file(d + "out_seg_info.i32", sinfo);
+            std::printf("round-2 facade: full-H features %d, logdet %.6f, selected %zu surf rows, %zu corner rows, segmented %zu -> %zu points\n", total_feat_num,
+                        gf_deg_factor, sel_surf_feature_idx.size(), sel_corner_feature_idx.size(), raw_cloud.size(), seg_out.size());
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

@@ -674,6 +674,231 @@ inline double gfRatioPolicy(const std::string &gf_method, double gf_ratio_ini, d
     return gf_ratio_ini;   // rnd, fps, gd_fix
 }
 
+// ------------------------------------------------------------------ ImageSegmenter (estimator/src/imageSegmenter/image_segmenter.hpp:36-83)
+// setParameter / segmentCloud with the reference's argument lists; the segmented, ring-major cloud ALSO stays staged on the device as
+// the Device's scan, so FeatureExtract::extractCloudOnDevice-style calls (mlh_extract_run) can follow without an upload.
+class ImageSegmenter {
+public:
+    explicit ImageSegmenter(Device &dev) : dev_(dev) { mlh_segment_params_default(&prm_); }
+    void setParameter(const int &vertical_scans, const int &horizon_scans, const int &min_cluster_size, const int &segment_valid_point_num,
+                      const int &segment_valid_line_num)
+    {
+        prm_.vertical_scans = vertical_scans; prm_.horizon_scans = horizon_scans; prm_.min_cluster_size = min_cluster_size;
+        prm_.segment_valid_point_num = segment_valid_point_num; prm_.segment_valid_line_num = segment_valid_line_num;
+    }
+    float &SEGMENT_THETA() { return prm_.segment_theta; }        // parameters.h globals the reference's segmentCloud reads
+    double &ROI_RANGE() { return prm_.roi_range; }
+    void segmentCloud(const PointICloud &laser_cloud_in, PointICloud &laser_cloud_out, PointICloud &laser_cloud_outlier, ScanInfo &scan_info)
+    {
+        const int n = (int)laser_cloud_in.size();
+        prm_.segment_flag = scan_info.segment_flag_ ? 1 : 0;
+        std::vector<float> out(size_t(n > 0 ? n : 1) * 4), outl(size_t(n / 5 + 3) * 4);
+        int32_t n_out = 0, n_outl = 0;
+        scan_info.scan_start_ind_.resize(prm_.vertical_scans);
+        scan_info.scan_end_ind_.resize(prm_.vertical_scans);
+        dev_.check(mlh_segment_cloud(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, n, MLH_MEM_HOST, &prm_,
+                                     out.data(), &n_out, scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), outl.data(), &n_outl));
+        auto fill = [](PointICloud &c, const std::vector<float> &v, int m) {
+            c.points.clear();
+            c.points.reserve(m);
+            for (int k = 0; k < m; ++k) { PointI p; p.x = v[4 * k]; p.y = v[4 * k + 1]; p.z = v[4 * k + 2]; p.intensity = v[4 * k + 3]; c.push_back(p); }
+        };
+        fill(laser_cloud_out, out, n_out);
+        fill(laser_cloud_outlier, outl, n_outl);
+    }
+private:
+    Device &dev_;
+    mlh_segment_params prm_;
+};
+
+// ------------------------------------------------------------------ the per-feature Ceres contract (lidar_map_factor.hpp:26-71, 130-174)
+// LidarMapPlaneNormFactor / LidarMapEdgeFactor with the reference's constructor (point, coeff, cov_matrix) and
+// SizedCostFunction<1, 7>::Evaluate(parameters, residuals, jacobians) -- so the reference's block-assembly loop
+// (lidar_mapper_keyframe.cpp:537-571: `new LidarMapPlaneNormFactor(feature.point_, feature.coeffs_, cov_matrix)`, AddResidualBlock) compiles
+// against this header unchanged. A residual block that Ceres evaluates one at a time is a HOST call by contract (one virtual call per
+// residual per iteration): these classes hold the closed form for that case. The accelerated path does not use them -- it evaluates all
+// blocks of a kind in one launch (LidarMapBatchFactor / mlh_linearize) or keeps the whole solve on the device (mlh_scan2map).
+namespace detail {
+inline void quat_rot(const double q[4] /*x y z w*/, const double v[3], double out[3])
+{
+    const double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    const double tx = ux + ux, ty = uy + uy, tz = uz + uz;
+    out[0] = v[0] + q[3] * tx + (q[1] * tz - q[2] * ty);
+    out[1] = v[1] + q[3] * ty + (q[2] * tx - q[0] * tz);
+    out[2] = v[2] + q[3] * tz + (q[0] * ty - q[1] * tx);
+}
+inline void quat_to_rot(const double q[4], double R[9])
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3], txx = tx * q[0], txy = ty * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+inline double sqrt_info_of(const std::array<double, 9> &cov) { const double s = std::sqrt(1 / (cov[0] + cov[4] + cov[8])); return s >= 3.0 ? 1.0 : s / 3.0; }
+// row (1x3) times [p]x
+inline void row_skew(const double a[3], const double p[3], double out[3]) { out[0] = a[1] * p[2] - a[2] * p[1]; out[1] = a[2] * p[0] - a[0] * p[2]; out[2] = a[0] * p[1] - a[1] * p[0]; }
+}  // namespace detail
+
+class LidarMapPlaneNormFactor {      // : public ceres::SizedCostFunction<1, 7> inside the reference tree
+public:
+    LidarMapPlaneNormFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const std::array<double, 9> &cov_matrix = {1, 0, 0, 0, 1, 0, 0, 0, 1})
+        : point_(point), coeff_(coeff), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
+    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    {
+        const double *x = param[0];
+        double lp[3];
+        detail::quat_rot(x + 3, point_.data(), lp);
+        const double w[3] = {coeff_[0], coeff_[1], coeff_[2]};
+        const double a = (w[0] * (lp[0] + x[0]) + w[1] * (lp[1] + x[1]) + w[2] * (lp[2] + x[2])) + coeff_[3];
+        residuals[0] = sqrt_info_ * a;
+        if (jacobians && jacobians[0]) {
+            double R[9], wr[3], rot[3];
+            detail::quat_to_rot(x + 3, R);
+            for (int c = 0; c < 3; ++c) wr[c] = -(w[0] * R[c] + w[1] * R[3 + c] + w[2] * R[6 + c]);      // -w^T R
+            detail::row_skew(wr, point_.data(), rot);                                                  // ... [p]x
+            double *J = jacobians[0];
+            for (int c = 0; c < 3; ++c) { J[c] = sqrt_info_ * w[c]; J[3 + c] = sqrt_info_ * rot[c]; }
+            J[6] = 0.0;
+        }
+        return true;
+    }
+private:
+    const std::array<double, 3> point_;
+    const std::vector<double> coeff_;
+    double sqrt_info_;
+};
+
+class LidarMapEdgeFactor {           // : public ceres::SizedCostFunction<1, 7>
+public:
+    LidarMapEdgeFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const std::array<double, 9> &cov_matrix = {1, 0, 0, 0, 1, 0, 0, 0, 1})
+        : point_(point), coeff_(coeff), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
+    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    {
+        const double *x = param[0];
+        double lp[3];
+        detail::quat_rot(x + 3, point_.data(), lp);
+        for (int c = 0; c < 3; ++c) lp[c] += x[c];
+        const double a[3] = {lp[0] - coeff_[0], lp[1] - coeff_[1], lp[2] - coeff_[2]}, b[3] = {lp[0] - coeff_[3], lp[1] - coeff_[4], lp[2] - coeff_[5]};
+        const double nu[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        const double de[3] = {coeff_[0] - coeff_[3], coeff_[1] - coeff_[4], coeff_[2] - coeff_[5]};
+        const double nu_n = std::sqrt(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]), de_n = std::sqrt(de[0] * de[0] + de[1] * de[1] + de[2] * de[2]);
+        residuals[0] = sqrt_info_ * nu_n / de_n;
+        if (jacobians && jacobians[0]) {
+            double eta[3] = {nu[0], nu[1], nu[2]};
+            if (nu_n > 0.0) for (int c = 0; c < 3; ++c) eta[c] /= nu_n;                      // Eigen normalized(): a zero vector stays zero
+            for (int c = 0; c < 3; ++c) eta[c] *= 1.0 / de_n;
+            double eD[3], R[9], eDR[3], rot[3];
+            detail::row_skew(eta, de, eD);                                                   // eta [lpa - lpb]x
+            detail::quat_to_rot(x + 3, R);
+            for (int c = 0; c < 3; ++c) eDR[c] = eD[0] * R[c] + eD[1] * R[3 + c] + eD[2] * R[6 + c];
+            detail::row_skew(eDR, point_.data(), rot);
+            double *J = jacobians[0];
+            for (int c = 0; c < 3; ++c) { J[c] = sqrt_info_ * (-eD[c]); J[3 + c] = sqrt_info_ * rot[c]; }
+            J[6] = 0.0;
+        }
+        return true;
+    }
+private:
+    const std::array<double, 3> point_;
+    const std::vector<double> coeff_;
+    double sqrt_info_;
+};
+
+// ------------------------------------------------------------------ ActiveFeatureSelection (lidar_mapper.h:126-631)
+// evalFullHessian / goodFeatureMatching with the reference's argument lists. The kd-tree argument is the MapIndex the caller built with
+// setInputCloud(laser_map); laser_cloud is the feature cloud (PointIWithCov: the cov_vec weights the rows when WITH_UA is on).
+class ActiveFeatureSelection {
+public:
+    explicit ActiveFeatureSelection(Device &dev, bool with_ua = true, uint64_t seed = 0) : dev_(dev), with_ua_(with_ua), seed_(seed) {}
+    // lidar_mapper.h:176-227: match ALL features, mat_H += J^T J of the matched ones (weighted, not loss-corrected), feat_num += matches
+    void evalFullHessian(const MapIndex<PointIWithCov> &kdtree_from_map, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const Pose &pose_local,
+                         const char feature_type, std::array<double, 36> &mat_H, int &feat_num)
+    {
+        (void)laser_map;
+        const int kind = feature_type == 's' ? MLH_SURF : MLH_CORNER;
+        if (kdtree_from_map.kind() != kind) throw Error("evalFullHessian: the index handed in was built for the other feature kind");
+        stage(kind, laser_cloud);
+        double p[7], JtJ[36];
+        pose_local.toParam(p);
+        int32_t n_valid = 0;
+        dev_.check(mlh_match_linearize(dev_.ctx(), kind, p, 5, (with_ua_ ? MLH_FLAG_WITH_UA : 0u) | MLH_FLAG_NO_LOSS, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, 0.0,
+                                       params().COV_MEASUREMENT_TRACE, nullptr, nullptr, nullptr, nullptr, JtJ, nullptr, nullptr, &n_valid));
+        for (int i = 0; i < 36; ++i) mat_H[i] += JtJ[i];
+        feat_num += n_valid;
+    }
+    // lidar_mapper.h:229-573. all_features[i].type_ stays 'n' for features that were not matched; sel_feature_idx lists the chosen ones in
+    // pick order; sub_mat_H comes in as the caller initialised it (1e-6 * I, cpp:505/520) and returns with the selected rows added.
+    void goodFeatureMatching(const MapIndex<PointIWithCov> &kdtree_from_map, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const Pose &pose_local,
+                             std::vector<PointPlaneFeature> &all_features, std::vector<size_t> &sel_feature_idx, const char feature_type,
+                             const std::string gf_method, const double gf_ratio, std::array<double, 36> &sub_mat_H)
+    {
+        (void)laser_map;
+        const int kind = feature_type == 's' ? MLH_SURF : MLH_CORNER;
+        if (kdtree_from_map.kind() != kind) throw Error("goodFeatureMatching: the index handed in was built for the other feature kind");
+        static const std::map<std::string, int> methods = {{"wo_gf", MLH_GF_WO}, {"rnd", MLH_GF_RND}, {"fps", MLH_GF_FPS}, {"gd_fix", MLH_GF_GD_FIX}, {"gd_float", MLH_GF_GD_FLOAT}};
+        auto it = methods.find(gf_method);
+        if (it == methods.end()) throw Error("goodFeatureMatching: unknown gf_method " + gf_method);
+        stage(kind, laser_cloud);
+        const int m = (int)laser_cloud.size();
+        double p[7];
+        pose_local.toParam(p);
+        std::vector<int32_t> sel(size_t(m > 0 ? m : 1));
+        std::vector<uint8_t> matched(size_t(m > 0 ? m : 1));
+        int32_t n_sel = 0;
+        dev_.check(mlh_good_feature_matching(dev_.ctx(), kind, p, it->second, gf_ratio, seed_, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, sel.data(), &n_sel,
+                                             sub_mat_H.data(), matched.data()));
+        // coefficients of the matched features (the selected ones are what the block-assembly loop reads)
+        std::vector<uint8_t> valid(size_t(m > 0 ? m : 1));
+        std::vector<double> coeffs(size_t(m > 0 ? m : 1) * 6);
+        all_features.assign(size_t(m), PointPlaneFeature());
+        sel_feature_idx.assign(sel.begin(), sel.begin() + n_sel);
+        int32_t n_valid = 0;
+        // after the selection only the chosen correspondences are live on the device: one linearise pass returns their coefficient rows
+        dev_.check(mlh_match_coeffs(dev_.ctx(), kind, valid.data(), coeffs.data(), &n_valid));
+        for (int i = 0; i < m; ++i) {
+            PointPlaneFeature &f = all_features[size_t(i)];
+            f.idx_ = size_t(i);
+            f.laser_idx_ = size_t(laser_cloud.points[size_t(i)].intensity);
+            f.point_ = {laser_cloud.points[size_t(i)].x, laser_cloud.points[size_t(i)].y, laser_cloud.points[size_t(i)].z};
+            if (valid[size_t(i)]) {
+                f.type_ = feature_type;
+                f.coeffs_.assign(coeffs.begin() + size_t(i) * 6, coeffs.begin() + size_t(i) * 6 + (feature_type == 's' ? 4 : 6));
+            }
+        }
+    }
+private:
+    void stage(int kind, const PointICovCloud &laser_cloud)
+    {
+        dev_.check(mlh_features_set(dev_.ctx(), kind, laser_cloud.points.data(), (int)sizeof(PointIWithCov), (int)laser_cloud.size(),
+                                    point_traits<PointIWithCov>::intensity_off, point_traits<PointIWithCov>::cov_off, MLH_MEM_HOST));
+    }
+    Device &dev_;
+    bool with_ua_;
+    uint64_t seed_;
+};
+
+// ------------------------------------------------------------------ the odometry window's coupled normal equations (estimator.cpp:687-848, 1577-1680)
+// J^T J / J^T r of the LidarPureOdom factors staged with LidarPureOdomBatchFactor (mlh_pure_odom_set) over [pivot | frames | extrinsics], and the
+// pose half of Estimator::evalDegenracy on its diagonal blocks: V_update_ / is_degenerate_ of every PoseLocalParameterization in para_ids order.
+struct WindowNormalEquations {
+    int D = 0;
+    std::vector<double> JtJ, Jtr;      // D x D row-major, D
+    double cost = 0.0;
+    int n_residuals = 0;
+};
+inline void evalWindowNormalEquations(Device &dev, const double pivot[7], const std::vector<std::array<double, 7>> &frames, const std::vector<std::array<double, 7>> &exts,
+                                      double huber_delta, WindowNormalEquations &ne)
+{
+    ne.D = 6 * (1 + (int)frames.size() + (int)exts.size());
+    ne.JtJ.assign(size_t(ne.D) * ne.D, 0.0);
+    ne.Jtr.assign(size_t(ne.D), 0.0);
+    int32_t n = 0;
+    dev.check(mlh_pure_odom_normal_eq(dev.ctx(), pivot, frames.empty() ? nullptr : frames[0].data(), (int)frames.size(), exts.empty() ? nullptr : exts[0].data(),
+                                      (int)exts.size(), huber_delta, ne.JtJ.data(), ne.Jtr.data(), &ne.cost, &n));
+    ne.n_residuals = n;
+}
+
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
     std::vector<mlh_iter_stat> outer;   // one per outer iteration: matched counts, H, eigenvalues, LM iterations, costs

@@ -28,6 +28,15 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     for name, scn in zip(("prev", "cur"), track_case["scans"]):
         scn.points.astype(np.float32).tofile(os.path.join(d, f"trk_scan_{name}.f32"))
         np.concatenate([scn.scan_start, scn.scan_end]).astype(np.int32).tofile(os.path.join(d, f"trk_rings_{name}.i32"))
+    import importlib
+    synth_mod = importlib.import_module("m-loam_amd.synth")
+    rng = np.random.default_rng(3)
+    raw = sc.points.copy()
+    raw[:, 3] = 0.0
+    mclut = rng.random(len(raw)) < 0.1
+    raw[mclut, :3] *= rng.uniform(0.5, 1.3, (int(mclut.sum()), 1)).astype(np.float32)
+    raw = raw[rng.permutation(len(raw))]
+    raw.astype(np.float32).tofile(os.path.join(d, "raw_cloud.f32"))
     r = subprocess.run([exe, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
     labels = np.fromfile(os.path.join(d, "out_labels.i32"), np.int32)
@@ -45,6 +54,46 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     counts = np.fromfile(os.path.join(d, "out_counts.i32"), np.int32).reshape(-1, 3)
     for c, o in zip(counts, s2m["outer"]):
         assert tuple(c) == (o["n_surf_sel"], o["n_corner_sel"], o["lm_iterations"])
+    # ---- round 2: ActiveFeatureSelection::evalFullHessian -> logDet -> gf_ratio policy through the facade
+    afs = np.fromfile(os.path.join(d, "out_afs.f64"), np.float64)
+    cov6 = np.array([0.01, 0, 0, 0.02, 0, 0.03], np.float32)
+    def with_cov(f):
+        a = np.zeros((len(f), 11), np.float32); a[:, :4] = f[:, :4]; a[:, 4:10] = cov6; a[:, 10] = 0.06
+        return a
+    fs11, fc11 = with_cov(feats16[0]), with_cov(feats16[1])
+    Href, nref = orc.eval_full_hessian(orc.Map(case16["surf_map"]), "s", fs11, case16["p0"])
+    Href, nref = orc.eval_full_hessian(orc.Map(case16["corner_map"]), "c", fc11, case16["p0"], Href, nref)
+    assert int(afs[36]) == nref
+    assert float(np.abs(afs[:36].reshape(6, 6) - Href).max()) <= 1e-9 * float(np.abs(Href).max())
+    assert abs(afs[37] - orc.logdet(Href)) < 1e-9 * abs(orc.logdet(Href))
+    k = 38
+    for method in ("wo_gf", "rnd", "fps", "gd_fix", "gd_float"):
+        for thre in (afs[37] - 1.0, afs[37] + 1.0):
+            assert afs[k] == orc.gf_ratio_policy(method, 0.2, afs[37], thre, -1.0)
+            k += 1
+    # goodFeatureMatching through the facade + the reference's per-feature factor objects on the selection
+    refsel = orc.good_feature_matching(orc.Map(case16["surf_map"]), "s", fs11, case16["p0"], orc.mapper_params(with_ua=True, gf_method="gd_fix", gf_ratio=0.2, seed=11))
+    rows = np.fromfile(os.path.join(d, "out_sel_rows.f64"), np.float64).reshape(-1, 9)
+    assert np.array_equal(rows[:, 0].astype(int), refsel["sel"])
+    np.testing.assert_allclose(np.fromfile(os.path.join(d, "out_sel_H.f64"), np.float64).reshape(6, 6), refsel["H"], rtol=1e-9, atol=1e-9)
+    vs_, cs_ = orc.Map(case16["surf_map"]).match("s", feats16[0], case16["p0"])
+    for row in rows[::7]:
+        i = int(row[0])
+        rr, JJ = orc.factor_eval("s", feats16[0][i, :3].astype(np.float64), cs_[i, :4], 0.06, case16["p0"])
+        assert abs(row[1] - rr) < 1e-12 and np.allclose(row[2:], JJ, rtol=1e-11, atol=1e-12)
+    crows = np.fromfile(os.path.join(d, "out_corner_rows.f64"), np.float64).reshape(-1, 9)
+    vc_, cc_ = orc.Map(case16["corner_map"]).match("c", feats16[1], case16["p0"])
+    assert np.array_equal(crows[:, 0].astype(int), np.flatnonzero(vc_))
+    for row in crows[::5]:
+        i = int(row[0])
+        rr, JJ = orc.factor_eval("c", feats16[1][i, :3].astype(np.float64), cc_[i], 0.0075, case16["p0"])
+        assert abs(row[1] - rr) < 1e-12 and np.allclose(row[2:], JJ, rtol=1e-11, atol=1e-12)
+    # ImageSegmenter facade
+    seg = orc.segment_cloud(raw, orc.seg_params())
+    so = np.fromfile(os.path.join(d, "out_seg_cloud.f32"), np.float32).reshape(-1, 4)
+    assert so.shape == seg["cloud"].shape and np.array_equal(so.view(np.uint32), seg["cloud"].view(np.uint32))
+    si = np.fromfile(os.path.join(d, "out_seg_info.i32"), np.int32)
+    assert np.array_equal(si[:16], seg["scan_start"]) and np.array_equal(si[16:], seg["scan_end"])
     # VoxelGridCovarianceMLOAM facade: 48-byte PointXYZIWithCov records in and out
     ds = np.fromfile(os.path.join(d, "out_map_ds.f32"), np.float32).reshape(-1, 11)
     m11 = np.zeros((len(case16["surf_map"]), 11), np.float32)
