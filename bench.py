@@ -127,6 +127,9 @@ def main():
                     help="supplementary: number of 64-ring LiDARs in the frame (BASELINE's metric is quoted on 2)")
     ap.add_argument("--map-preset", default=None, choices=["50k", "500k", "1M", "2M", "4M"],
                     help="supplementary: local-map size (default: 500k at N=1, 500k x N at N GPUs as BASELINE's configs 2-4 grow it)")
+    ap.add_argument("--shard-mode", default="map", choices=["map", "features"],
+                    help="N > 1: 'map' = angular wedges of the map + halo, ownership by position (BASELINE's partition); 'features' = whole map on every "
+                         "rank, features dealt round-robin (SURVEY 8e's balanced alternative)")
     ap.add_argument("--profile-events", type=int, default=1,
                     help="1: HIP-event bracket the dominant kernel (surf correspondence) inside the timed region; 0: none")
     args = ap.parse_args()
@@ -198,9 +201,12 @@ def main():
     # --- map shards (N > 1): angular wedges around the predicted sensor position, halo 1.1 m
     center = p0[:2]
     if world > 1:
-        ms_ = shard.shard_points_mask(surf_map, center, world, rank)
-        mc_ = shard.shard_points_mask(corner_map, center, world, rank)
-        local_surf_map, local_corner_map = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
+        if args.shard_mode == "map":
+            ms_ = shard.shard_points_mask(surf_map, center, world, rank)
+            mc_ = shard.shard_points_mask(corner_map, center, world, rank)
+            local_surf_map, local_corner_map = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
+        else:
+            local_surf_map, local_corner_map = surf_map, corner_map
         far = np.full((1, 3), 1.0e6, np.float32)     # a wedge without any map point still needs a (never matched) record
         if len(local_surf_map) == 0:
             local_surf_map = far
@@ -219,7 +225,10 @@ def main():
             comm_ok = 0
         else:
             try:
-                ctx.shard_set(lo, hi)
+                if args.shard_mode == "map":
+                    ctx.shard_set(lo, hi)
+                else:
+                    ctx.shard_set_features(world, rank)
                 ctx.comm_init(world, rank, uid[0])
             except Exception as e:   # noqa: BLE001
                 comm_ok, comm_err = 0, repr(e)
@@ -303,7 +312,7 @@ def main():
         step()
     sync_all()
     ms_per_step_all_events = 1e3 * (time.perf_counter() - t1) / n_prof
-    prof = {k: ctx.profile_get(k) for k in range(6)}
+    prof = {k: ctx.profile_get(k) for k in range(7)}
     ctx.profile_enable(0)
 
     # supplementary: the reference's own per-frame call, scan2MapOptimization = index build + 2 outer x (match all, evalHessian +
@@ -330,7 +339,7 @@ def main():
     bytes_per_launch, bytes_ball, cbars, cballs, n_owned = 0.0, 0.0, {}, {}, {}
     for name, feats, lmap in (("surf", surf, local_surf_map), ("corner", corner, local_corner_map)):
         fm = synth.transform_points(feats[:, :3], Tm)
-        own = shard.owned_mask(fm, *planes) if world > 1 else np.ones(len(feats), bool)
+        own = (shard.owned_mask(fm, *planes) if args.shard_mode == "map" else (np.arange(len(feats)) % world) == rank) if world > 1 else np.ones(len(feats), bool)
         cb, cball = candidate_stats(lmap, fm[own], h)
         cbars[name], cballs[name], n_owned[name] = round(cb, 2), round(cball, 2), int(own.sum())
         # B_feat = 16 (query) + 27 x 8 (cell begin/end) + 12 x C-bar (candidate xyz); the partial normal equations
@@ -365,6 +374,16 @@ def main():
             except Exception:
                 pass
 
+    owned_all = local_map_all = None
+    if world > 1:
+        t_own = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+        t_own[rank, 0], t_own[rank, 1] = n_owned["surf"], n_owned["corner"]
+        dist.all_reduce(t_own)
+        owned_all = t_own.tolist()
+        t_map = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+        t_map[rank, 0], t_map[rank, 1] = len(local_surf_map), len(local_corner_map)
+        dist.all_reduce(t_map)
+        local_map_all = t_map.tolist()
     out = None
     if rank == 0:
         out = dict(metric="scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame)",
@@ -380,7 +399,8 @@ def main():
                                scan_features_thinned=not args.dense_features,
                                map_index_per_step=("none" if args.no_map_rebuild else ("mlh_map_rebuild (re-index only)" if args.map_rebuild_only
                                                                                       else "mlh_map_set_pair from device-resident clouds (staging + fit check + index build)")),
-                               parallelism=("1 GPU" if world == 1 else f"map sharded in {world} angular wedges + RCCL all-reduce of 32 f64/iter"),
+                               parallelism=("1 GPU" if world == 1 else (f"map sharded in {world} angular wedges (+1.1 m halo), ownership by position" if args.shard_mode == "map"
+                                                                       else f"map replicated, features dealt round-robin over {world} ranks") + " + ONE RCCL all-reduce of 32 f64 per GN iteration"),
                                hip_events_in_timed_region=("dominant kernel, 1 launch per step" if args.profile_events else "none")),
                    queries_per_s=round(queries_per_s, 1), valid_correspondences_per_step=n_valid_step,
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
@@ -389,6 +409,11 @@ def main():
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
+                   multi_gpu=(None if world == 1 else dict(
+                       shard_mode=args.shard_mode, owned_features_per_rank=owned_all, local_map_points_per_rank=local_map_all,
+                       allreduce_us_per_call_rank0=(round(1e3 * prof[mla.K_ALLREDUCE][0] / prof[mla.K_ALLREDUCE][1], 3) if prof[mla.K_ALLREDUCE][1] else None),
+                       solve_update_us_per_call_rank0=(round(1e3 * prof[mla.K_SOLVE][0] / prof[mla.K_SOLVE][1], 3) if prof[mla.K_SOLVE][1] else None),
+                       note="per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE ncclAllReduce of 32 f64 + the redundant 6x6 solve launch")),
                    extract_ms_per_lidar_scan=[round(x, 4) for x in extract_ms],
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    extract_ms_all_lidars_one_launch_set=round(extract_all_ms, 4),

@@ -69,7 +69,8 @@ enum {
     MLH_K_SOLVE = 3,         /* stand-alone partial-sum reduction + degeneracy + 6x6 solve / LM step kernels                   */
     MLH_K_GRID_BUILD = 4,    /* local-map index build (all kernels of one build)                                               */
     MLH_K_EXTRACT = 5,       /* extractCloud (all kernels of one extraction)                                                   */
-    MLH_K_COUNT = 6
+    MLH_K_ALLREDUCE = 6,     /* the RCCL all-reduce of the packed normal equations (N > 1)                                     */
+    MLH_K_COUNT = 7
 };
 /* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);
@@ -434,6 +435,11 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
  * (32 doubles: 21 J^T J + 6 J^T r + cost + counts) with ONE ncclAllReduce per evaluation on the context's stream, and
  * every rank applies the identical 6x6 solve / Plus redundantly (no pose broadcast). */
 int mlh_shard_set(mlh_ctx *ctx, const float *lo_plane4, const float *hi_plane4);
+/* The balanced alternative of SURVEY 8(e): every rank stages the WHOLE map (4 M points are 64 MB of 288 GB) and owns the features whose
+ * slot index f satisfies f % n_ranks == rank -- no halo, equal shares whatever the scene, the same one all-reduce per evaluation. The index
+ * build is then replicated instead of divided, which is the price. n_ranks = 1 switches it off; it combines with mlh_shard_set (both tests
+ * must hold) but is meant to be used instead of it. */
+int mlh_shard_set_features(mlh_ctx *ctx, int n_ranks, int rank);
 int mlh_comm_unique_id(void *out_128_bytes);
 int mlh_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *unique_id_128_bytes);
 /* in-place sum of n doubles (HOST buffer) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */

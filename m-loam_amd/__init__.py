@@ -23,8 +23,8 @@ ALL_KINDS = -1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
 GF_METHODS = {"wo_gf": 0, "rnd": 1, "fps": 2, "gd_fix": 3, "gd_float": 4}
-K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT = range(6)
-K_ALL = 0x3F
+K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT, K_ALLREDUCE = range(7)
+K_ALL = 0x7F
 
 
 class MlhError(RuntimeError):
@@ -139,6 +139,7 @@ def load_library():
     lib.mlh_gn_solve.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), vp]
     lib.mlh_scan2map.argtypes = [vp, vp, C.POINTER(SolverOpts), vp]
     lib.mlh_shard_set.argtypes = [vp, vp, vp]
+    lib.mlh_shard_set_features.argtypes = [vp, ci, ci]
     lib.mlh_comm_unique_id.argtypes = [vp]
     lib.mlh_comm_init.argtypes = [vp, ci, ci, vp]
     lib.mlh_allreduce_f64.argtypes = [vp, vp, ci]
@@ -156,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
-    "mlh_shard_set", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
+    "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
 
@@ -568,6 +569,10 @@ class Context:
         lo = None if lo_plane is None else np.ascontiguousarray(lo_plane, np.float32)
         hi = None if hi_plane is None else np.ascontiguousarray(hi_plane, np.float32)
         self._ck(self.lib.mlh_shard_set(self.h, _p(lo), _p(hi)))
+
+    def shard_set_features(self, n_ranks, rank):
+        """replicated map, features dealt round-robin: slot f is owned iff f % n_ranks == rank"""
+        self._ck(self.lib.mlh_shard_set_features(self.h, int(n_ranks), int(rank)))
 
     def comm_init(self, n_ranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)

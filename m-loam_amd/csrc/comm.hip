@@ -56,7 +56,9 @@ int comm_allreduce_state(mlh_ctx *ctx, int to_ce)
     if (!ctx->comm) return MLH_OK;
     SolverState *S = ctx->state.as<SolverState>();
     double *buf = to_ce ? S->ce : S->ne;
+    prof_begin(ctx, MLH_K_ALLREDUCE);
     int rc = rccl().all_reduce(buf, buf, NE_STRIDE, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    prof_end(ctx, MLH_K_ALLREDUCE);
     if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
     return MLH_OK;
 }
@@ -66,7 +68,9 @@ int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks)
     if (!ctx->comm) return MLH_OK;
     SolverState *S = ctx->state.as<SolverState>();
     double *buf = &S->neb[0][0];
+    prof_begin(ctx, MLH_K_ALLREDUCE);
     int rc = rccl().all_reduce(buf, buf, size_t(NE_STRIDE) * size_t(n_blocks), /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    prof_end(ctx, MLH_K_ALLREDUCE);
     if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
     return MLH_OK;
 }
@@ -91,6 +95,14 @@ int mlh_shard_set(mlh_ctx *ctx, const float *lo_plane4, const float *hi_plane4)
         ctx->lo_plane[i] = lo_plane4 ? lo_plane4[i] : 0.f;
         ctx->hi_plane[i] = hi_plane4 ? hi_plane4[i] : 0.f;
     }
+    return MLH_OK;
+}
+
+int mlh_shard_set_features(mlh_ctx *ctx, int n_ranks, int rank)
+{
+    if (!ctx || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return MLH_ERR_INVALID;
+    ctx->own_mod = n_ranks;
+    ctx->own_rem = rank;
     return MLH_OK;
 }
 

@@ -249,6 +249,7 @@ struct mlh_ctx {
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
+    int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;

@@ -193,6 +193,7 @@ struct KParams {
     float min_match_sq_dis, min_plane_dis;
     double huber_delta, cov_measurement_trace;
     int has_lo, has_hi;      // multi-GPU ownership half-spaces (mlh_shard_set)
+    int own_mod, own_rem;    // ... or ownership by feature index: slot f belongs to this rank iff f % own_mod == own_rem (mlh_shard_set_features)
     float lo[4], hi[4];
     // pose blocks (BASELINE config 4: block 0 = body pose, block n = extrinsic of LiDAR n; 1 block otherwise)
     int n_blocks;
@@ -244,9 +245,9 @@ __device__ __forceinline__ void associate_to_map(const q4 &q, const d3 &t, const
     sx = float(w.x + t.x); sy = float(w.y + t.y); sz = float(w.z + t.z);
 }
 
-__device__ __forceinline__ bool owns(const KParams &P, float sx, float sy, float sz)
+__device__ __forceinline__ bool owns(const KParams &P, int f, float sx, float sy, float sz)
 {
-    bool own = true;
+    bool own = P.own_mod <= 1 || (f % P.own_mod) == P.own_rem;
     if (P.has_lo) own = own && ((((P.lo[0] * sx + P.lo[1] * sy) + P.lo[2] * sz) + P.lo[3]) >= 0.f);
     if (P.has_hi) own = own && ((((P.hi[0] * sx + P.hi[1] * sy) + P.hi[2] * sz) + P.hi[3]) < 0.f);
     return own;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
-    if (!owns(P, sx, sy, sz)) return;     // uniform over the lane group
+    if (!owns(P, f, sx, sy, sz)) return;     // uniform over the lane group
     if ((MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
     else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
 }
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
         fp = K.feat[f];
         float sx, sy, sz;
         associate_to_map(q, t, fp, sx, sy, sz);
-        if (fp.w >= 0.f && owns(P, sx, sy, sz)) {
+        if (fp.w >= 0.f && owns(P, f, sx, sy, sz)) {
             valid = (KMAX == 10 && P.kb[b] == 10) ? fit_feature<KMAX>(P, K, kind, f, coef) : fit_feature<5>(P, K, kind, f, coef);
             if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
         }
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(FTPB, 6) void match_fused_kernel(KParams P)
             fp = K.feat[f];
             if (fp.w >= 0.f) {
                 associate_to_map(q, t, fp, sx, sy, sz);
-                active = owns(P, sx, sy, sz);
+                active = owns(P, f, sx, sy, sz);
             }
         }
         MLH_KSTAGE(1);
@@ -895,6 +896,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.cov_measurement_trace = a.cov_measurement_trace;
     P.has_lo = ctx->shard_lo ? 1 : 0;
     P.has_hi = ctx->shard_hi ? 1 : 0;
+    P.own_mod = ctx->own_mod; P.own_rem = ctx->own_rem;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.strided = ctx->fused_strided ? 1 : 0;
     P.finish = a.finish;

@@ -207,6 +207,66 @@ def test_sharded_map_matches_unsharded_on_gpu(mla, synth, case16, feats16, world
         np.testing.assert_allclose(acc[kind]["g"], ref[kind]["g"], rtol=1e-9, atol=1e-8)
 
 
+def _sharded_gn(mla, shard, world, mode, surf_map, corner_map, surf, corner, p0, n_iters, eig_thre=100.0):
+    """The multi-rank Gauss-Newton loop with the all-reduce done by the host: one context per rank (map wedge + halo and half-space ownership, or the
+    whole map and round-robin feature ownership), every iteration = each rank's owned features matched and linearised at the common pose
+    (mlh_match_linearize -> its packed J^T J / J^T r / cost / count), the records summed, the summed system solved ONCE and the identical update
+    applied to the common pose -- exactly what comm.hip does with ncclAllReduce + the redundant per-rank solve. Returns pose, per-iteration counts."""
+    ctxs = []
+    for r in range(world):
+        c = mla.Context(0)
+        if mode == "map":
+            lo, hi = shard.wedge_planes(p0[:2], world, r)
+            c.shard_set(lo, hi)
+            ms = np.ascontiguousarray(surf_map[shard.shard_points_mask(surf_map, p0[:2], world, r)])
+            mc = np.ascontiguousarray(corner_map[shard.shard_points_mask(corner_map, p0[:2], world, r)])
+            far = np.full((1, 3), 1.0e6, np.float32)
+            c.map_set(mla.SURF, ms if len(ms) else far)
+            c.map_set(mla.CORNER, mc if len(mc) else far)
+        else:
+            c.shard_set_features(world, r)
+            c.map_set(mla.SURF, surf_map)
+            c.map_set(mla.CORNER, corner_map)
+        c.features_set(mla.SURF, surf)
+        c.features_set(mla.CORNER, corner)
+        ctxs.append(c)
+    pose = np.array(p0, np.float64)
+    counts, owned = [], np.zeros((world, 2), np.int64)
+    for it in range(n_iters):
+        H, g, ns, nc = np.zeros((6, 6)), np.zeros(6), 0, 0
+        for r, c in enumerate(ctxs):
+            a = c.match_linearize(mla.SURF, pose, dense=False)
+            b = c.match_linearize(mla.CORNER, pose, dense=False)
+            H += a["H"] + b["H"]; g += a["g"] + b["g"]; ns += a["count"]; nc += b["count"]
+            owned[r] = (a["count"], b["count"])
+        deg = mla.eval_degeneracy(H, eig_thre)
+        d = np.linalg.solve(H, -g)
+        pose = mla.pose_plus(pose, d, deg["V_update"] if deg["is_degenerate"] else None)
+        counts.append((ns, nc))
+    for c in ctxs:
+        c.close()
+    return pose, counts, owned
+
+
+@pytest.mark.parametrize("mode", ["map", "features"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_solver_matches_unsharded(mla, synth, case16, feats16, world, mode):
+    """the whole N > 1 solver on one GPU, ranks as contexts, all-reduce on the host: both partitions of SURVEY 8(e) (map wedges with halo; replicated
+    map with round-robin feature ownership) reproduce the single-context device-resident solve -- same matched counts every iteration, same pose."""
+    shard = importlib.import_module("m-loam_amd.shard")
+    one = mla.Context(0)
+    one.map_set(mla.SURF, case16["surf_map"]); one.map_set(mla.CORNER, case16["corner_map"])
+    one.features_set(mla.SURF, feats16[0]); one.features_set(mla.CORNER, feats16[1])
+    pose_ref, st = one.gn_solve(case16["p0"], 4)
+    one.close()
+    pose, counts, owned = _sharded_gn(mla, shard, world, mode, case16["surf_map"], case16["corner_map"], feats16[0], feats16[1], case16["p0"], 4)
+    assert counts == [(s["n_surf"], s["n_corner"]) for s in st]
+    dt, dr = _pose_err(pose, pose_ref)
+    assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+    if mode == "features":
+        assert owned.sum(axis=1).min() > 0.6 * owned.sum() / world          # round-robin ownership is balanced by construction
+
+
 def test_rccl_single_rank_path(mla, orc, case16, feats16):
     """The multi-GPU solver path (local reduce -> ncclAllReduce -> update kernel) with a 1-rank communicator gives the
     same iterates as the fused single-GPU path."""

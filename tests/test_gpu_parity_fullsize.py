@@ -260,3 +260,16 @@ def test_extract_against_the_references_own_lines(mla, orc, cfg2):
         m = v_ref.astype(bool)
         assert np.array_equal(out["coeffs"][m].astype(np.float32).view(np.uint32), c_ref[m].astype(np.float32).view(np.uint32))
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["map", "features"])
+def test_sharded_solver_full_size(mla, synth, orc, cfg2, mode):
+    """config 2's frame split over 4 ranks (contexts on one GPU, host all-reduce): the 5-GN solve equals the oracle's unsharded one, iteration by iteration"""
+    import importlib
+    import test_gpu_parity as T
+    shard = importlib.import_module("m-loam_amd.shard")
+    pose, counts, owned = T._sharded_gn(mla, shard, 4, mode, cfg2["surf_map"], cfg2["corner_map"], cfg2["surf"], cfg2["corner"], cfg2["p0"], 5)
+    ref = orc.gn_iterations(cfg2["oms"], cfg2["omc"], cfg2["surf"], cfg2["corner"], cfg2["p0"], orc.mapper_params(), 5)
+    assert counts == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]]
+    dt, dr = _pose_err(pose, ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)

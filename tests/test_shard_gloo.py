@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="map"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -32,9 +32,13 @@ def _worker(rank, world, port, q):
     packed = np.zeros(32)
     valid_all = []
     for kind, cloud, f in (("s", case["surf_map"], feats[0]), ("c", case["corner_map"], feats[1])):
-        keep = shard.shard_points_mask(cloud, center, world, rank)
-        local = np.ascontiguousarray(cloud[keep])
-        own = shard.owned_mask(synth.transform_points(f[:, :3], synth.pose_to_mat(p0)), *shard.wedge_planes(center, world, rank))
+        if mode == "map":       # the rank's wedge of the map (+ halo), ownership by the two half-space tests
+            keep = shard.shard_points_mask(cloud, center, world, rank)
+            local = np.ascontiguousarray(cloud[keep])
+            own = shard.owned_mask(synth.transform_points(f[:, :3], synth.pose_to_mat(p0)), *shard.wedge_planes(center, world, rank))
+        else:                   # replicated map, features dealt round-robin (mlh_shard_set_features)
+            local = cloud
+            own = (np.arange(len(f)) % world) == rank
         valid, coeffs = O.Map(local).match(kind, f, p0)
         valid = (valid.astype(bool) & own).astype(np.uint8)
         lin = O.linearize(kind, f, np.full(len(f), 0.0075), p0, valid, coeffs)
@@ -53,12 +57,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_normal_equations_equal_unsharded(orc, synth, case16, feats16, world):
+@pytest.mark.parametrize("world,mode", [(2, "map"), (3, "map"), (2, "features")])
+def test_sharded_normal_equations_equal_unsharded(orc, synth, case16, feats16, world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29650 + world + (10 if mode == "features" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     packed, owned = q.get(timeout=240)
