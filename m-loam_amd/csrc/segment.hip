@@ -13,8 +13,11 @@
 //           labelling would be a different segmenter; one wavefront stepping through the queue out of HBM would be ~20x slower than a CPU
 //           core (every step is a dependent memory round trip). The range image (115 KB for 16 x 1800) goes down, a list of kept point
 //           indices comes back.
-// Undefined behaviour in the reference (uninitialised alpha, erase past the end, the 64-ring ground loop's row 64) is handled as
-// oracle/image_segmenter.hpp documents (U1-U3); INTEGRATION.md repeats it for the maintainer.
+// Undefined behaviour in the reference, and what happens here instead (INTEGRATION.md has the same list for the maintainer):
+//   (U1) hpp:285-286 computes `dist` with the alpha of the PREVIOUS neighbour, uninitialised on the first one: one variable for the whole
+//        call, starting at 0;  (U2) hpp:374 erases with positions that earlier erasures have shifted, possibly past the end: the stale
+//        position is used as it is, one outside the row erases nothing;  (U3) the 64-ring ground loop reads row 64 (hpp:183-185) and
+//        segment_alphay_ is never set: the loop is clipped to existing rows, alphay takes the value the cluster search assigns.
 // atan / atan2 run in f32 on the device (ocml) and in glibc on the reference's CPU: the last ulp may differ, which matters only for a point
 // within one ulp of a row / column bin edge or a ground pair within one ulp of 10 degrees.
 #include "ctx.hpp"
