@@ -442,7 +442,7 @@ int mlh_shard_set(mlh_ctx *ctx, const float *lo_plane4, const float *hi_plane4);
 int mlh_shard_set_features(mlh_ctx *ctx, int n_ranks, int rank);
 int mlh_comm_unique_id(void *out_128_bytes);
 int mlh_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *unique_id_128_bytes);
-/* in-place sum of n doubles (HOST buffer) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */
+/* in-place sum of n doubles (HOST buffer, any n) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */
 /* drops the communicator: the context is single-GPU again */
 int mlh_comm_finalize(mlh_ctx *ctx);
 int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n);

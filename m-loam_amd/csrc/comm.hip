@@ -149,22 +149,19 @@ int mlh_comm_finalize(mlh_ctx *ctx)
 
 int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n)
 {
-    if (!ctx || !host_inout || n <= 0 || n > NE_STRIDE) return MLH_ERR_INVALID;
+    if (!ctx || !host_inout || n <= 0) return MLH_ERR_INVALID;
     if (!ctx->comm) return MLH_OK;   // single rank: identity
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->state.p) {
-        MLH_HIP(ctx, ctx->state.ensure(sizeof(SolverState)));
-        MLH_HIP(ctx, hipMemsetAsync(ctx->state.p, 0, sizeof(SolverState), ctx->stream));
-    }
-    SolverState *S = ctx->state.as<SolverState>();
-    double tmp[NE_STRIDE] = {0};
-    std::memcpy(tmp, host_inout, sizeof(double) * n);
-    MLH_HIP(ctx, hipMemcpyAsync(S->ce, tmp, sizeof(tmp), hipMemcpyHostToDevice, ctx->stream));
-    int rc = comm_allreduce_state(ctx, 1);
-    if (rc) return rc;
-    MLH_HIP(ctx, hipMemcpyAsync(tmp, S->ce, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
+    // any length: the 32-double record of the map solver, the 326 doubles of the 24-dimensional window problem (mlh_pure_odom_normal_eq), ...
+    MLH_HIP(ctx, ctx->allreduce_buf.ensure(sizeof(double) * size_t(n)));
+    double *buf = ctx->allreduce_buf.as<double>();
+    MLH_HIP(ctx, hipMemcpyAsync(buf, host_inout, sizeof(double) * size_t(n), hipMemcpyHostToDevice, ctx->stream));
+    prof_begin(ctx, MLH_K_ALLREDUCE);
+    int rc = rccl().all_reduce(buf, buf, size_t(n), /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    prof_end(ctx, MLH_K_ALLREDUCE);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
+    MLH_HIP(ctx, hipMemcpyAsync(host_inout, buf, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(host_inout, tmp, sizeof(double) * n);
     return MLH_OK;
 }
 

@@ -251,6 +251,7 @@ struct mlh_ctx {
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
+    mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };

@@ -288,6 +288,8 @@ def test_rccl_single_rank_path(mla, orc, case16, feats16):
     assert np.allclose(qa, qb, rtol=0, atol=1e-13)
     red = b.allreduce_f64(np.arange(29, dtype=np.float64))
     assert np.array_equal(red, np.arange(29, dtype=np.float64))
+    red = b.allreduce_f64(np.arange(326, dtype=np.float64))          # the 24-dimensional window record (D (D + 1) / 2 + D + 2)
+    assert np.array_equal(red, np.arange(326, dtype=np.float64))
     # pose-block mode (config 4) under the communicator: per-block records, one all-reduce, identical per-block updates
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
     half_s, half_c = len(feats16[0]) // 2, len(feats16[1]) // 2
