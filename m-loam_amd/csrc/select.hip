@@ -3,6 +3,9 @@
 // that consume those rows. The loops are sequential by construction (each greedy pick changes the information matrix the
 // next score is computed against), which is why the reference gives them a 20 ms wall-clock budget (lidar_mapper.h:82).
 #include "ctx.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -13,10 +16,12 @@ namespace mlh {
 
 namespace {
 
-struct Rows {               // per-feature results of the GPU pass
-    std::vector<Corr> corr;
-    std::vector<double> J;  // m x 6
-    std::vector<float4> pts;
+struct Rows {               // per-feature results of the GPU pass, in the context's pinned staging block
+    Corr *corr = nullptr;
+    const double *J = nullptr;  // m x 6
+    const float4 *pts = nullptr;
+    size_t m = 0;
+    size_t size() const { return m; }
     bool matched(size_t i) const { return corr[i].valid != 0; }
     const double *jaco(size_t i) const { return &J[i * 6]; }
 };
@@ -99,13 +104,13 @@ struct Scored {   // FeatureWithScore (parameters.h:177-191): max-heap on the lo
 
 void select_wo_gf(const Rows &R, std::vector<size_t> &sel, double H[36])
 {
-    for (size_t i = 0; i < R.corr.size(); ++i)
+    for (size_t i = 0; i < R.size(); ++i)
         if (R.matched(i)) { rank1_update(H, R.jaco(i)); sel.push_back(i); }
 }
 
 void select_rnd(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
-    AlivePool pool(R.corr.size());
+    AlivePool pool(R.size());
     while (sel.size() < n_use && !pool.empty()) {
         const size_t j = draw(rng, 0, pool.size() - 1);
         const size_t q = pool.at(j);
@@ -116,7 +121,7 @@ void select_rnd(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
 
 void select_fps(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
-    const size_t n = R.corr.size();
+    const size_t n = R.size();
     if (n == 0) return;
     std::vector<char> visited(n, 0);
     size_t cur = draw(rng, 0, n - 1);
@@ -145,18 +150,63 @@ void select_fps(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
     }
 }
 
+// 6x6 inverse of a symmetric positive definite matrix through its Cholesky factor (once per selection; rank-1 updated afterwards)
+bool spd_inverse6(const double A[36], double Ainv[36])
+{
+    double L[36] = {0};
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) s -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(s > 0.0)) return false;
+        const double ljj = std::sqrt(s);
+        L[j * 6 + j] = ljj;
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) t -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = t / ljj;
+        }
+    }
+    double Li[36] = {0};                               // L^-1 (lower triangular)
+    for (int c = 0; c < 6; ++c) {
+        Li[c * 6 + c] = 1.0 / L[c * 6 + c];
+        for (int r = c + 1; r < 6; ++r) {
+            double t = 0.0;
+            for (int k = c; k < r; ++k) t -= L[r * 6 + k] * Li[k * 6 + c];
+            Li[r * 6 + c] = t / L[r * 6 + r];
+        }
+    }
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double t = 0.0; for (int k = std::max(r, c); k < 6; ++k) t += Li[k * 6 + r] * Li[k * 6 + c]; Ainv[r * 6 + c] = t; }
+    return true;
+}
+
 // stochastic-greedy logdet maximisation (lidar_mapper.h:458-563): draw a random subset of size M / M_use, score every
 // member by logdet(H + j^T j), keep the best, repeat. Unmatched draws are dropped from the pool.
+// Scoring: logdet(H + j^T j) = logdet(H) + log(1 + j H^-1 j^T) (matrix determinant lemma), so inside one subset -- all members are scored
+// against the same H -- the best member is the one with the largest q = j H^-1 j^T: 42 multiply-adds against a maintained inverse
+// (Sherman-Morrison per pick) instead of a Cholesky factorisation and six logarithms per candidate. The reference compares the logdet
+// VALUES (magnitude <~ 100, so resolved to ~1e-13 by the Cholesky sum): whenever the two best members' log(1+q) are closer than 1e-10 the
+// whole subset is re-scored with the reference's arithmetic (logdet_cholesky6) and pushed through the same heap -- selections stay
+// identical to the literal loop's (MLH_SELECT_EXACT=1 in the environment runs the literal scoring; tests compare the two).
 void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
-    const size_t n_all = R.corr.size();
+    const size_t n_all = R.size();
     AlivePool pool(n_all);
     std::vector<int> stamp(n_all, -1);        // feature_visited, kept per ORIGINAL index (the reference erases it in lockstep with the pool)
     const size_t max_retry = 20;              // MAX_RANDOM_QUEUE_TIME
     size_t retries = 0;
+    double Hinv[36];
+    bool have_inv = std::getenv("MLH_SELECT_EXACT") == nullptr && spd_inverse6(H, Hinv);
+    auto exact_score = [&](size_t q) { double Ht[36]; std::copy(H, H + 36, Ht); rank1_update(Ht, R.jaco(q)); return logdet_cholesky6(Ht); };
+    auto quad = [&](const double *j, double *Hj) {
+        double q = 0.0;
+        for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Hinv[r * 6 + c] * j[c]; Hj[r] = t; q += j[r] * t; }
+        return q;
+    };
+    struct Cand { size_t idx; double q; };
+    std::vector<Cand> subset_c;
     while (sel.size() < n_use && !pool.empty()) {
         const size_t subset = static_cast<size_t>(1.0 * n_all / n_use);
-        std::priority_queue<Scored> heap;
+        subset_c.clear();
         bool lost = false;
         while (!pool.empty()) {
             retries = 0;
@@ -172,16 +222,34 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
                 pool.erase_index(q);
                 continue;
             }
-            double Ht[36];
-            std::copy(H, H + 36, Ht);
-            rank1_update(Ht, R.jaco(q));
-            heap.push(Scored{q, logdet_cholesky6(Ht)});
-            if (heap.size() >= subset) {
-                const Scored top = heap.top();
-                if (!pool.contains(top.idx)) { lost = true; break; }     // the reference's std::find miss
-                rank1_update(H, R.jaco(top.idx));
-                pool.erase_index(top.idx);
-                sel.push_back(top.idx);
+            double Hj[6];
+            subset_c.push_back(Cand{q, have_inv ? quad(R.jaco(q), Hj) : exact_score(q)});
+            if (subset_c.size() >= subset) {
+                // the heap's top: the largest score; among equal scores std::priority_queue keeps ... whichever its sift leaves on top, so
+                // near-ties (and exact ties) are settled by the reference's own numbers, pushed through the reference's own container
+                size_t best = 0, second = size_t(-1);
+                for (size_t k = 1; k < subset_c.size(); ++k) {
+                    if (subset_c[k].q > subset_c[best].q) { second = best; best = k; }
+                    else if (second == size_t(-1) || subset_c[k].q > subset_c[second].q) second = k;
+                }
+                size_t top_idx = subset_c[best].idx;
+                if (have_inv && second != size_t(-1) && !(subset_c[best].q - subset_c[second].q > 1e-10 * (1.0 + subset_c[best].q))) {
+                    std::priority_queue<Scored> heap;                      // too close to call on q: replay the subset literally
+                    for (const Cand &c : subset_c) heap.push(Scored{c.idx, exact_score(c.idx)});
+                    top_idx = heap.top().idx;
+                }
+                if (!pool.contains(top_idx)) { lost = true; break; }     // the reference's std::find miss
+                const double *jt = R.jaco(top_idx);
+                if (have_inv) {                                            // Sherman-Morrison: (H + j^T j)^-1 = H^-1 - (H^-1 j^T)(j H^-1) / (1 + j H^-1 j^T)
+                    double Hj2[6];
+                    const double qq = quad(jt, Hj2);
+                    const double inv = 1.0 / (1.0 + qq);
+                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hinv[r * 6 + c] -= Hj2[r] * Hj2[c] * inv;
+                }
+                rank1_update(H, jt);
+                pool.erase_index(top_idx);
+                sel.push_back(top_idx);
+                if (have_inv && (sel.size() & 255) == 0) have_inv = spd_inverse6(H, Hinv);       // refresh: keeps the update's rounding from accumulating
                 break;
             }
         }
@@ -201,18 +269,31 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     a.flags = MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS;   // extractCov(point) weight, rows not loss-corrected (lidar_mapper.h:162-164)
     a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = 0.0; a.dense = true; a.pose_sel = 0;
+    const bool timing = std::getenv("MLH_SELECT_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](auto a_, auto b_) { return std::chrono::duration<double, std::micro>(b_ - a_).count(); };
+    const auto t0 = now();
     int rc = match_launch(ctx, a);
     if (rc) return rc;
+    const auto t1 = now();
     Rows R;
     const size_t m = size_t(f.m);
-    R.corr.resize(m); R.J.resize(m * 6);
-    MLH_HIP(ctx, hipMemcpyAsync(R.corr.data(), f.corr.p, sizeof(Corr) * m, hipMemcpyDeviceToHost, ctx->stream));
-    MLH_HIP(ctx, hipMemcpyAsync(R.J.data(), f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
-    if (method == MLH_GF_FPS) {
-        R.pts.resize(m);
-        MLH_HIP(ctx, hipMemcpyAsync(R.pts.data(), f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
+    // pinned staging (grow-only, owned by the context): [Corr m][J 6m][pts m]
+    const size_t off_j = sizeof(Corr) * m, off_p = off_j + sizeof(double) * 6 * m, need = off_p + sizeof(float4) * m;
+    if (need > ctx->select_host_cap) {
+        if (ctx->select_host) (void)hipHostFree(ctx->select_host);
+        ctx->select_host = nullptr; ctx->select_host_cap = 0;
+        MLH_HIP(ctx, hipHostMalloc(&ctx->select_host, need + need / 4, hipHostMallocDefault));
+        ctx->select_host_cap = need + need / 4;
     }
+    char *hb = static_cast<char *>(ctx->select_host);
+    R.corr = reinterpret_cast<Corr *>(hb); R.J = reinterpret_cast<const double *>(hb + off_j); R.pts = reinterpret_cast<const float4 *>(hb + off_p);
+    R.m = m;
+    MLH_HIP(ctx, hipMemcpyAsync(hb, f.corr.p, sizeof(Corr) * m, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(hb + off_j, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
+    if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t2 = now();
     prof_collect(ctx);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
 
@@ -227,14 +308,16 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         case MLH_GF_GD_FLOAT: select_greedy(R, n_use, rng, sel, H); break;
         default: return fail(ctx, MLH_ERR_INVALID, "unknown gf_method");
     }
+    const auto t3 = now();
     // keep only the selected correspondences valid on the device
     if (method != MLH_GF_WO) {
-        for (auto &c : R.corr) c.valid = 0;
+        for (size_t i = 0; i < m; ++i) R.corr[i].valid = 0;
         for (size_t i : sel) R.corr[i].valid = 1;
-        MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, R.corr.data(), sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, R.corr, sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     sel_out.assign(sel.begin(), sel.end());
+    if (timing) std::fprintf(stderr, "[select kind %d m %zu] launch %.1f us, copy+sync %.1f us, pick %.1f us, upload %.1f us\n", kind, m, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
     return MLH_OK;
 }
 

@@ -324,6 +324,25 @@ def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
     assert lin["count"] == len(ref["sel"])
 
 
+def test_greedy_selection_lemma_scoring_equals_literal_scoring(ctx, mla, case16, feats16, monkeypatch):
+    """The greedy loop ranks a subset's members by j H^-1 j^T (matrix determinant lemma) and replays near ties with the reference's
+    logdet arithmetic; MLH_SELECT_EXACT=1 scores every member with the literal Cholesky logdet (lidar_mapper.h:497-520). Same picks,
+    in the same order, for every seed and both kinds."""
+    ctx.map_set(mla.SURF, case16["surf_map"])
+    ctx.map_set(mla.CORNER, case16["corner_map"])
+    for kind, f in ((mla.SURF, feats16[0]), (mla.CORNER, feats16[1])):
+        ctx.features_set(kind, f)
+        for seed in (1, 2, 3, 11, 12345):
+            for ratio in (0.2, 0.8):
+                monkeypatch.delenv("MLH_SELECT_EXACT", raising=False)
+                a = ctx.good_feature_matching(kind, case16["p0"], gf_method="gd_fix", gf_ratio=ratio, seed=seed)
+                monkeypatch.setenv("MLH_SELECT_EXACT", "1")
+                b = ctx.good_feature_matching(kind, case16["p0"], gf_method="gd_fix", gf_ratio=ratio, seed=seed)
+                monkeypatch.delenv("MLH_SELECT_EXACT", raising=False)
+                assert len(a["sel"]) > 50 and np.array_equal(a["sel"], b["sel"]), (kind, seed, ratio)
+                np.testing.assert_allclose(a["H"], b["H"], rtol=1e-12, atol=0)
+
+
 def test_eval_full_hessian_logdet_and_ratio_policy(ctx, mla, orc, synth, case16, feats16):
     """row a12: ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227) -> common::logDet (math.hpp:173-187) -> gf_deg_factor ->
     the gf_ratio policy (lidar_mapper_keyframe.cpp:456-494). The C-ABI form of evalFullHessian is mlh_match_linearize with
