@@ -575,6 +575,7 @@ class Context:
         self._ck(self.lib.mlh_shard_set_features(self.h, int(n_ranks), int(rank)))
 
     def comm_init(self, n_ranks, rank, unique_id: bytes):
+        _torch_rccl_first()
         buf = C.create_string_buffer(unique_id, 128)
         self._ck(self.lib.mlh_comm_init(self.h, n_ranks, rank, C.cast(buf, C.c_void_p)))
 
@@ -651,7 +652,17 @@ def compound_pose_with_cov(pose1, cov1, pose2, cov2):
     return pose_cp, cov_cp
 
 
+def _torch_rccl_first():
+    """A Python host that also uses torch.distributed ends up with torch's bundled librccl mapped; import torch BEFORE the library
+    binds RCCL so that both use that one copy (the library binds an already-mapped librccl, see csrc/comm.hip)."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def comm_unique_id() -> bytes:
+    _torch_rccl_first()
     buf = C.create_string_buffer(128)
     rc = load_library().mlh_comm_unique_id(C.cast(buf, C.c_void_p))
     if rc:

@@ -29,8 +29,11 @@ static Rccl &rccl()
 {
     static Rccl r;
     if (!r.handle) {
+        // one RCCL per process: a copy that is already mapped (a PyTorch host brings its own librccl.so) is the one to bind -- a second copy
+        // next to it would run its own static teardown at exit. Only a process without one loads the ROCm installation's.
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+        for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (r.handle) break; }
+        for (const char *n : names) { if (r.handle) break; r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
         if (r.handle) {
             r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
             r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");

@@ -16,7 +16,10 @@ constexpr int TPB = 256;
 // lanes per query in the correspondence kernel: 8 when the launch fills the chip on its own (throughput: one wavefront serves 8
 // queries), 16 when it does not (latency: a frame's ~20k thinned features leave most SIMDs idle with 8, and twice the lanes halve
 // the candidate trips of the queries in dense cells, which set the kernel's duration)
-constexpr int KNN_WIDE_LIMIT = 40000;  // total queries up to which a launch uses 16 lanes per query
+#ifndef MLH_KNN_WIDE_LIMIT
+#define MLH_KNN_WIDE_LIMIT 40000
+#endif
+constexpr int KNN_WIDE_LIMIT = MLH_KNN_WIDE_LIMIT;  // total queries up to which a launch uses 16 lanes per query
 #ifndef MLH_KNN_U
 #define MLH_KNN_U 4
 #endif
@@ -54,18 +57,18 @@ __device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long m)
 template <int OFF>
 __device__ __forceinline__ int dpp_row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true); }
 
+// sorted insertion by position: the K "key < k[i]" tests are independent of each other (no compare-exchange chain, one 64-bit compare
+// per slot), slot i then takes its left neighbour, the key, or stays
 template <int K>
 __device__ __forceinline__ void key_insert(unsigned long long (&k)[K], unsigned long long key)
 {
     if (key < k[K - 1]) {
-        k[K - 1] = key;
+        bool c[K];
 #pragma unroll
-        for (int i = K - 1; i > 0; --i) {
-            unsigned long long a = k[i - 1], b = k[i];
-            bool sw = b < a;
-            k[i - 1] = sw ? b : a;
-            k[i] = sw ? a : b;
-        }
+        for (int i = 0; i < K; ++i) c[i] = key < k[i];
+#pragma unroll
+        for (int i = K - 1; i > 0; --i) k[i] = c[i - 1] ? k[i - 1] : (c[i] ? key : k[i]);
+        k[0] = c[0] ? key : k[0];
     }
 }
 
@@ -206,6 +209,25 @@ __device__ __forceinline__ unsigned dpp_row_min_u32(unsigned m)
     o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
     o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
     return m;
+}
+
+// K rounds of group-min over the 16 lanes' sorted lists, on 32-bit words: the smallest head distance of the group, then the smallest
+// index among the lanes whose head has that distance -- the lexicographic (distance, index) minimum, ties included -- and the owner pops
+template <int K>
+__device__ __forceinline__ void knn_tournament16(unsigned long long (&k)[K], unsigned long long (&out)[K])
+{
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const unsigned hd = (unsigned)(k[0] >> 32), hi = (unsigned)k[0];
+        const unsigned md = dpp_row_min_u32(hd);
+        const unsigned mi = dpp_row_min_u32(hd == md ? hi : 0xffffffffu);
+        out[t] = ((unsigned long long)md << 32) | mi;
+        if (hd == md && hi == mi && k[0] != KEY_INF) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) k[i] = k[i + 1];
+            k[K - 1] = KEY_INF;
+        }
+    }
 }
 
 constexpr int KNN_RUN_WORDS = 40;       // LDS ints per query group: [0..18] segment prefix offsets (+ end), [19..36] segment bases
@@ -362,20 +384,7 @@ __device__ __forceinline__ void knn_group16_pruned(const GridDev &g, float qx, f
         }
     }
     MLH_KSTAGE(3);
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-        unsigned long long m = k[0];
-        m = dpp_min_u64<DPP_QUAD_SWAP1>(m);
-        m = dpp_min_u64<DPP_QUAD_SWAP2>(m);
-        m = dpp_min_u64<DPP_ROW_HALF_MIRROR>(m);
-        m = dpp_min_u64<DPP_ROW_MIRROR>(m);
-        out[t] = m;
-        if (k[0] == m && m != KEY_INF) {
-#pragma unroll
-            for (int i = 0; i < K - 1; ++i) k[i] = k[i + 1];
-            k[K - 1] = KEY_INF;
-        }
-    }
+    knn_tournament16<K>(k, out);
 }
 
 }  // namespace mlh

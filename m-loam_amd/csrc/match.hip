@@ -177,7 +177,8 @@ struct KindP {
     double *r_out;           // nullable
     double *J_out;           // nullable
     int m;                   // feature slots (real + padding)
-    int tiles_a;             // correspondence-kernel tiles (32 features each)
+    int tiles_a;             // correspondence-kernel tiles (TPB / lanes features each)
+    int lanes;               // lanes per query of the correspondence kernel for this kind (8 or 16)
     int tiles_b;             // fit / linearise tiles (256 features each)
     int tiles_f;             // fused match kernel tiles (FQPB features each)
     int nbr_stride;          // max K over the blocks
@@ -295,17 +296,10 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
 // MB = more than one pose block in the launch (config 4); without it the block bookkeeping (a per-lane block index and the
 // per-block K lookup it drags along) compiles away
 template <int G, bool MB>
-__global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
+__device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
     constexpr int RUNW = (G == 16) ? 2 * KNN_RUN_WORDS : 20;
-    __shared__ int s_run[FPB * RUNW];
-    const int total = P.k[0].tiles_a + P.k[1].tiles_a;
-    int tile = xcd_tile(total);
-    if (tile >= total) return;
-    const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
-    if (kind) tile -= P.k[0].tiles_a;
-    const KindP &K = P.k[kind];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int f = tile * FPB + grp;
     MLH_KSTAGE(0);
@@ -322,6 +316,25 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     if (!owns(P, f, sx, sy, sz)) return;     // uniform over the lane group
     if ((MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
     else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
+}
+
+// G = lanes per query for both kinds, or 0: per kind (KindP::lanes -- a workgroup serves one kind, so the choice is uniform over it)
+template <int G, bool MB>
+__global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
+{
+    __shared__ int s_run[(G == 8) ? (TPB / 8) * 20 : (TPB / 16) * 2 * KNN_RUN_WORDS];
+    const int total = P.k[0].tiles_a + P.k[1].tiles_a;
+    int tile = xcd_tile(total);
+    if (tile >= total) return;
+    const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
+    if (kind) tile -= P.k[0].tiles_a;
+    const KindP &K = P.k[kind];
+    if constexpr (G == 0) {
+        if (K.lanes == 8) knn_features_body<8, MB>(P, K, tile, s_run);
+        else knn_features_body<16, MB>(P, K, tile, s_run);
+    } else {
+        knn_features_body<G, MB>(P, K, tile, s_run);
+    }
 }
 
 // the reference's plane fit + gate (feature_extract.hpp:816-840)
@@ -841,7 +854,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         long long queries = 0;
         for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) queries += ctx->feat[k].m;
         P.knn_lanes = queries <= KNN_WIDE_LIMIT ? 16 : 8;
-        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) P.knn_lanes = ctx->knn_lanes_override;
+        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16 || ctx->knn_lanes_override == 816) P.knn_lanes = ctx->knn_lanes_override;
     }
     for (int k = 0; k < 2; ++k) {
         KindP &K = P.k[k];
@@ -870,7 +883,8 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         K.r_out = a.dense ? fs.r.as<double>() : nullptr;
         K.J_out = a.dense ? fs.J.as<double>() : nullptr;
         K.m = fs.m;
-        K.tiles_a = (fs.m + TPB / P.knn_lanes - 1) / (TPB / P.knn_lanes);
+        K.lanes = (P.knn_lanes == 816) ? (k == 0 ? 8 : 16) : P.knn_lanes;
+        K.tiles_a = (fs.m + TPB / K.lanes - 1) / (TPB / K.lanes);
         K.tiles_b = (fs.m + TPB - 1) / TPB;
         K.tiles_f = (fs.m + FQPB - 1) / FQPB;
         K.nbr_stride = fs.nbr_stride;
@@ -951,7 +965,8 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
         return MLH_OK;
     }
-    if (P.knn_lanes == 16) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, false>, grid_a, P); }
+    if (P.knn_lanes == 816) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false>, grid_a, P); }
+    else if (P.knn_lanes == 16) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, false>, grid_a, P); }
     else { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, false>, grid_a, P); }
     if (P.finish == 3) {
         if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");

@@ -19,6 +19,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def mla():
+    # tests that hand torch device tensors to the library need torch's HIP context to exist before the library creates its own
+    # (whatever the order the tests are selected in)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return importlib.import_module("m-loam_amd")
 
 
