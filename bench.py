@@ -394,6 +394,7 @@ def main():
                                         f"({len(surf_map) + len(corner_map)} pts), {GN_ITERS} GN iters/frame, re-matched every iteration",
                                features_surf=len(surf), features_corner=len(corner), gn_iters_per_step=GN_ITERS,
                                n_valid_per_iter_surf_corner=n_valid_iter,
+                               map_index=dict(surf=ctx.map_info(mla.SURF), corner=ctx.map_info(mla.CORNER)),
                                input_sha1=dict(surf_map=_sha(surf_map), corner_map=_sha(corner_map), surf_features=_sha(surf), corner_features=_sha(corner)),
                                corner_map="less-sharp points of 10 earlier keyframes x LiDARs, thinned at 0.2 m (as the mapper builds it)",
                                scan_features_thinned=not args.dense_features,

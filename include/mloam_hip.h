@@ -227,6 +227,11 @@ int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, in
 int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                      float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);
+/* diagnostics of the resident index (no reference counterpart: pcl::KdTreeFLANN exposes nothing of the kind): points, non-empty grid
+ * cells, the population of the cell an average map point lives in (sum of squared cell populations / n), and the lanes per query the
+ * correspondence kernel will use for this kind with the staged feature sets (8 or 16; chosen from the launch size and that density --
+ * a tuning decision, results do not depend on it). Any output pointer may be null. */
+int mlh_map_info(mlh_ctx *ctx, int kind, int32_t *n_points, int32_t *occupied_cells, double *mean_cell_population, int32_t *knn_lanes);
 /* k-NN against the resident map (pcl::KdTreeFLANN::nearestKSearch role; feature_extract.hpp:666, 813):
  * queries are xyz triples (HOST), outputs idx[nq*k] (original map indices, ascending distance, ties by index) and
  * sqdist[nq*k]; slots beyond the number of points found inside the 27-cell neighbourhood are -1 / +inf. k = 5.

@@ -266,7 +266,7 @@ void mlh_destroy(mlh_ctx *ctx)
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         MapGrid &m = ctx->map[k];
-        m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release();
+        m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); m.occ.release();
         FeatSet &f = ctx->feat[k];
         f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release();
     }
@@ -278,7 +278,7 @@ void mlh_destroy(mlh_ctx *ctx)
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.word_of.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
-    ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release();
+    ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->select_host) (void)hipHostFree(ctx->select_host);
@@ -588,6 +588,17 @@ int mlh_map_rebuild(mlh_ctx *ctx, int kind)
     if (!ctx || kind < MLH_ALL_KINDS || kind > 1) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return grid_build(ctx, kind == MLH_ALL_KINDS ? 3 : (1 << kind), false);
+}
+
+int mlh_map_info(mlh_ctx *ctx, int kind, int32_t *n_points, int32_t *occupied_cells, double *mean_cell_population, int32_t *knn_lanes)
+{
+    if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    const MapGrid &g = ctx->map[kind];
+    if (n_points) *n_points = g.built ? g.n : 0;
+    if (occupied_cells) *occupied_cells = g.built ? g.occupied : 0;
+    if (mean_cell_population) *mean_cell_population = (g.built && g.n > 0) ? double(g.pop_sq) / double(g.n) : 0.0;
+    if (knn_lanes) { int lanes[2]; knn_lanes_for(ctx, 3, lanes); *knn_lanes = lanes[kind]; }
+    return MLH_OK;
 }
 
 int mlh_knn(mlh_ctx *ctx, int kind, const float *queries_xyz, int nq, int k, int32_t *idx, float *sqdist)

@@ -60,6 +60,8 @@ struct HostPublish {
     double x[7];
     double xb[8][7];
     long long done;          // SolverState::done at publication (the LM driver polls it)
+    long long aux[2];        // map staging: occupied cells of the two indices just built
+    long long aux2[2];       //              and the sums of their squared cell populations
     unsigned long long seq;
 };
 
@@ -107,8 +109,13 @@ struct DevBuf {
 };
 
 struct MapGrid {
-    DevBuf raw, sorted, cell_id, cell_start, cell_fill, block_sums, bounds;
+    DevBuf raw, sorted, cell_id, cell_start, cell_fill, block_sums, bounds, occ;
     int n = 0;
+    bool want_occ = false;     // the index build also collects the occupancy statistics below (the mapper's two maps)
+    int occ_parts = 0;         // per-wavefront partials in `occ`
+    int occupied = 0;          // non-empty cells of the current index (0: not measured)
+    long long pop_sq = 0;      // sum over the cells of population^2: pop_sq / n = the population of the cell an average map POINT lives in,
+                               // which is what a query near the map sees (the density the query kernels tune to)
     float ox = 0, oy = 0, oz = 0, h = 1.f, inv_h = 1.f;
     int nx = 0, ny = 0, nz = 0;
     long long ncell = 0;
@@ -321,6 +328,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);
+void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2]);
 int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsigned char *const *src, const int *n, int stride, const float *sq_dis,
                         mlh::HostPublish *pub, unsigned long long seq);
 // match.hip

@@ -80,6 +80,8 @@ struct GridJob {
     int *cell_next;        // the twin array, cleared here for the NEXT build
     int *rank;             // n: arrival rank of each point inside its cell
     int *block_sums;
+    long long *occ;        // occupancy statistics of this build (null: not wanted): [0] non-empty cells, [1] sum of squared cell populations,
+                           // then one (cells, squares) partial per scanning wavefront
     int n;
     int ncell;
     float ox, oy, oz, inv_h;
@@ -182,6 +184,17 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     if (base < n_pad) v0 = A4[base / 4];
     if (base + 4 < n_pad) v1 = A4[base / 4 + 1];
     const int s = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
+    if (J.occ) {                                                         // occupancy statistics: a partial per wavefront, summed by occ_total()
+        long long nz = (v0.x > 0) + (v0.y > 0) + (v0.z > 0) + (v0.w > 0) + (v1.x > 0) + (v1.y > 0) + (v1.z > 0) + (v1.w > 0);
+        long long sq = (long long)v0.x * v0.x + (long long)v0.y * v0.y + (long long)v0.z * v0.z + (long long)v0.w * v0.w +
+                       (long long)v1.x * v1.x + (long long)v1.y * v1.y + (long long)v1.z * v1.z + (long long)v1.w * v1.w;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nz += __shfl_xor(nz, off); sq += __shfl_xor(sq, off); }
+        if ((threadIdx.x & 63) == 0) {
+            long long *part = J.occ + 2 + 2 * (b * 4 + (threadIdx.x >> 6));
+            part[0] = nz; part[1] = sq;
+        }
+    }
     int total;
     int ex = block_exclusive_scan_256(s, lds, total);
     int4 o0, o1;
@@ -306,7 +319,7 @@ static GridJob make_job(MapGrid &g)
     g.cur = dst;
     g.twin_clean = true;
     J.cell_start = g.cells(dst); J.cell_next = g.cells(1 - dst); J.rank = g.cell_id.as<int>();
-    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.block_sums = g.block_sums.as<int>();
+    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.block_sums = g.block_sums.as<int>(); J.occ = g.want_occ ? g.occ.as<long long>() : nullptr;
     J.n = g.n; J.ncell = int(g.ncell); J.ox = g.ox; J.oy = g.oy; J.oz = g.oz; J.inv_h = g.inv_h; J.nx = g.nx; J.ny = g.ny; J.nz = g.nz;
     J.nb_pts = std::min((g.n + 255) / 256, 4096);
     J.nb_scan = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
@@ -330,7 +343,14 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
         MLH_HIP(ctx, hipStreamSynchronize(st));
         for (int k = 0; k < n_grids && k < 2; ++k) { int rc = bounds_finish(ctx, *grids[k], hp[k], grids[k]->min_match_sq_dis); if (rc) return rc; }
     }
-    for (int k = 0; k < n_grids && k < 2; ++k) G.j[nj++] = make_job(*grids[k]);
+    for (int k = 0; k < n_grids && k < 2; ++k) {
+        MapGrid &g = *grids[k];
+        if (g.want_occ) {               // occupancy partials: one per scanning wavefront
+            g.occ_parts = 4 * int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
+            MLH_HIP(ctx, g.occ.ensure(sizeof(long long) * size_t(2 + 2 * g.occ_parts)));
+        }
+        G.j[nj++] = make_job(g);
+    }
     if (nj == 0) return MLH_OK;
     const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);
@@ -365,10 +385,35 @@ __global__ __launch_bounds__(256) void pack_check_kernel(PackJobs G)
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(G.oob, 1 << job);
 }
 
-__global__ void publish_flag_kernel(int *oob, HostPublish *h, unsigned long long seq)
+// sums the per-wavefront occupancy partials of one index build into occ[0..1] (one workgroup of 256)
+__device__ __forceinline__ void occ_total(long long *occ, int n_part, long long *lds)
 {
+    long long nz = 0, sq = 0;
+    for (int i = threadIdx.x; i < n_part; i += 256) { nz += occ[2 + 2 * i]; sq += occ[3 + 2 * i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { nz += __shfl_xor(nz, off); sq += __shfl_xor(sq, off); }
+    if ((threadIdx.x & 63) == 0) { lds[2 * (threadIdx.x >> 6)] = nz; lds[2 * (threadIdx.x >> 6) + 1] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) { occ[0] = lds[0] + lds[2] + lds[4] + lds[6]; occ[1] = lds[1] + lds[3] + lds[5] + lds[7]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void occ_total_kernel(long long *occ0, int n0, long long *occ1, int n1)
+{
+    __shared__ long long lds[8];
+    if (occ0) occ_total(occ0, n0, lds);
+    if (occ1) occ_total(occ1, n1, lds);
+}
+
+__global__ __launch_bounds__(256) void publish_flag_kernel(int *oob, long long *occ0, int n0, long long *occ1, int n1, HostPublish *h, unsigned long long seq)
+{
+    __shared__ long long lds[8];
+    if (occ0) occ_total(occ0, n0, lds);
+    if (occ1) occ_total(occ1, n1, lds);
     if (threadIdx.x == 0) {
         h->done = *oob;          // the record's `done` slot carries the flag word here
+        h->aux[0] = occ0 ? occ0[0] : 0; h->aux2[0] = occ0 ? occ0[1] : 0;
+        h->aux[1] = occ1 ? occ1[0] : 0; h->aux2[1] = occ1 ? occ1[1] : 0;
         *oob = 0;
         __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -393,6 +438,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         grids[k] = &g;
         g.built = false;
         MLH_HIP(ctx, g.raw.ensure(sizeof(float4) * size_t(n[k])));
+        g.want_occ = true;
         const bool reuse = g.geom_valid && g.geom_sq_dis == sq_dis[k];
         if (!reuse) need_bounds |= 1 << k;
         g.n = n[k];
@@ -419,7 +465,12 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         int rc = grid_build_grids(ctx, fast, nf, false);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
+    {
+        long long *po[2] = {nullptr, nullptr};
+        int pn[2] = {0, 0};
+        for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) { po[k] = grids[k]->occ.as<long long>(); pn[k] = grids[k]->occ_parts; }
+        hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(256), 0, st, G.oob, po[0], pn[0], po[1], pn[1], pub, seq);
+    }
     MLH_HIP(ctx, hipGetLastError());
     // spin on the pinned record (every launch above has completed when the sequence number arrives)
     {
@@ -437,6 +488,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         }
     }
     const int oob = int(pub->done);
+    for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) { grids[k]->occupied = int(pub->aux[k]); grids[k]->pop_sq = pub->aux2[k]; }
     for (int k = 0; k < n_maps; ++k) if (oob & (1 << k)) need_bounds |= 1 << k;
     if (need_bounds) {
         MapGrid *slow[2];
@@ -444,7 +496,12 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         for (int k = 0; k < n_maps; ++k) if (need_bounds & (1 << k)) { grids[k]->built = false; grids[k]->geom_valid = false; slow[ns++] = grids[k]; }
         int rc = grid_build_grids(ctx, slow, ns, true);
         if (rc) return rc;
+        long long hocc[2][2] = {{0, 0}, {0, 0}};
+        hipLaunchKernelGGL(occ_total_kernel, dim3(1), dim3(256), 0, st, slow[0]->occ.as<long long>(), slow[0]->occ_parts, ns > 1 ? slow[1]->occ.as<long long>() : (long long *)nullptr,
+                           ns > 1 ? slow[1]->occ_parts : 0);
+        for (int k = 0; k < ns; ++k) MLH_HIP(ctx, hipMemcpyAsync(hocc[k], slow[k]->occ.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
+        for (int k = 0; k < ns; ++k) { slow[k]->occupied = int(hocc[k][0]); slow[k]->pop_sq = hocc[k][1]; }
     }
     return MLH_OK;
 }

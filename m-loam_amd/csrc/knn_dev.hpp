@@ -19,7 +19,8 @@ constexpr int TPB = 256;
 #ifndef MLH_KNN_WIDE_LIMIT
 #define MLH_KNN_WIDE_LIMIT 40000
 #endif
-constexpr int KNN_WIDE_LIMIT = MLH_KNN_WIDE_LIMIT;  // total queries up to which a launch uses 16 lanes per query
+constexpr int KNN_WIDE_LIMIT = MLH_KNN_WIDE_LIMIT;   // total queries above which every kind uses 8 lanes
+constexpr int KNN_LATENCY_LIMIT = 8192;   // total queries up to which every kind uses 16 lanes (the launch cannot fill the chip either way)
 #ifndef MLH_KNN_U
 #define MLH_KNN_U 4
 #endif
@@ -200,27 +201,28 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
 }
 
 // ---------------------------------------------------------------- pruned 16-lane search (the fused match kernel, match.hip)
-// u32 group-min over a 16-lane row, DPP only
+// u32 group-min over the G (8 or 16) lanes of a group, DPP only
+template <int G = 16>
 __device__ __forceinline__ unsigned dpp_row_min_u32(unsigned m)
 {
     unsigned o;
     o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP1, 0xF, 0xF, false); m = o < m ? o : m;
     o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP2, 0xF, 0xF, false); m = o < m ? o : m;
     o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_MIRROR, 0xF, 0xF, false); m = o < m ? o : m;
+    if (G == 16) { o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_MIRROR, 0xF, 0xF, false); m = o < m ? o : m; }
     return m;
 }
 
 // K rounds of group-min over the 16 lanes' sorted lists, on 32-bit words: the smallest head distance of the group, then the smallest
 // index among the lanes whose head has that distance -- the lexicographic (distance, index) minimum, ties included -- and the owner pops
-template <int K>
+template <int K, int G = 16>
 __device__ __forceinline__ void knn_tournament16(unsigned long long (&k)[K], unsigned long long (&out)[K])
 {
 #pragma unroll
     for (int t = 0; t < K; ++t) {
         const unsigned hd = (unsigned)(k[0] >> 32), hi = (unsigned)k[0];
-        const unsigned md = dpp_row_min_u32(hd);
-        const unsigned mi = dpp_row_min_u32(hd == md ? hi : 0xffffffffu);
+        const unsigned md = dpp_row_min_u32<G>(hd);
+        const unsigned mi = dpp_row_min_u32<G>(hd == md ? hi : 0xffffffffu);
         out[t] = ((unsigned long long)md << 32) | mi;
         if (hd == md && hi == mi && k[0] != KEY_INF) {
 #pragma unroll
@@ -236,18 +238,18 @@ constexpr int KNN_TWO_PHASE_MIN = 128;  // candidates in the 27 cells from which
 constexpr float KNN_PRUNE_SLACK = 1.0e-3f;   // metres taken off every face distance before a cell is pruned (covers the f32 rounding of
                                              // the cell assignment; a pruned cell is farther than the bound by at least this much)
 
-// flat, balanced walk over the segments of the run table: candidate j of the concatenation goes to lane j % 16
-template <int K>
+// flat, balanced walk over the segments of the run table: candidate j of the concatenation goes to lane j % G
+template <int K, int G = 16>
 __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy, float qz, int gl, const int *lds_run, int total,
                                            unsigned bound_bits, unsigned long long (&k)[K])
 {
     int cr = 0, hi = lds_run[1], base = lds_run[KNN_SEG_BASE], lo = 0;
-    for (int j = gl; j < total; j += 16 * KNN_U) {
+    for (int j = gl; j < total; j += G * KNN_U) {
         int addr[KNN_U];
         bool v[KNN_U];
 #pragma unroll
         for (int u = 0; u < KNN_U; ++u) {
-            const int jj = j + 16 * u;
+            const int jj = j + G * u;
             v[u] = jj < total;
             addr[u] = 0;
             if (v[u]) {
@@ -273,14 +275,34 @@ __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy,
     }
 }
 
-// inclusive sum over the 16 lanes of a row (DPP)
+// inclusive sum over the G (8 or 16) lanes of a group (DPP row shifts; a lane never adds what came from the neighbouring group)
+template <int G = 16>
 __device__ __forceinline__ int row_scan16(int v, int gl)
 {
     { const int t = dpp_row_shr<1>(v); if (gl >= 1) v += t; }
     { const int t = dpp_row_shr<2>(v); if (gl >= 2) v += t; }
     { const int t = dpp_row_shr<4>(v); if (gl >= 4) v += t; }
-    { const int t = dpp_row_shr<8>(v); if (gl >= 8) v += t; }
+    if (G == 16) { const int t = dpp_row_shr<8>(v); if (gl >= 8) v += t; }
     return v;
+}
+
+// run table of a group of G lanes: every lane offers NP pieces [b[p], b[p] + len[p]); only non-empty pieces get a slot, in lane order.
+// Returns the total number of candidates (uniform over the group).
+template <int G, int NP>
+__device__ __forceinline__ int knn_fill_table(int *lds_run, int gl, const int (&b)[NP], const int (&len)[NP])
+{
+    int lsum = 0, np = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { lsum += len[p]; np += len[p] > 0 ? 1 : 0; }
+    const int incl = row_scan16<G>(lsum, gl), slot_incl = row_scan16<G>(np, gl);
+    int slot = slot_incl - np, off = incl - lsum;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        if (len[p] > 0) { lds_run[slot] = off; lds_run[KNN_SEG_BASE + slot] = b[p]; ++slot; off += len[p]; }
+    if (gl == G - 1) lds_run[slot_incl] = incl;                        // end sentinel behind the last slot
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    return __shfl(incl, G - 1, G);
 }
 
 // run table of the group: every lane offers up to two pieces [bL, bL + lenL), [bR, bR + lenR); only non-empty pieces get a slot.
@@ -385,6 +407,101 @@ __device__ __forceinline__ void knn_group16_pruned(const GridDev &g, float qx, f
     }
     MLH_KSTAGE(3);
     knn_tournament16<K>(k, out);
+}
+
+// The same search by a group of 8 lanes (twice the queries per wavefront: the correspondence kernel of a full frame is bound by VALU
+// issue, not by latency, and per-query instruction count is what an 8-lane group halves). Lanes 0..4 hold the rows 2l and 2l + 1 of the
+// 9 (dy, dz) rows; everything else as in knn_group16_pruned.
+template <int K>
+__device__ __forceinline__ void knn_group8_pruned(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run,
+                                                  unsigned long long (&out)[K])
+{
+    unsigned long long k[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = KEY_INF;
+    const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
+    const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
+    const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
+    int w[2][4];
+    int dyr[2], dzr[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = 2 * gl + s;
+        dyr[s] = (r % 3) - 1; dzr[s] = (r / 3) - 1;
+        w[s][0] = w[s][1] = w[s][2] = w[s][3] = 0;
+        const int y = cy + dyr[s], z = cz + dzr[s];
+        if ((r < 9) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+            const int row = (z * g.ny + y) * g.nx;
+            const int xa = min(max(cx - 1, 0), g.nx), xb = min(max(cx, 0), g.nx), xc = min(max(cx + 1, 0), g.nx), xd = min(max(cx + 2, 0), g.nx);
+            w[s][0] = g.cell_start[row + xa]; w[s][1] = g.cell_start[row + xb]; w[s][2] = g.cell_start[row + xc]; w[s][3] = g.cell_start[row + xd];
+        }
+    }
+    MLH_KSTAGE(2);
+    const int n27 = __shfl(row_scan16<8>((w[0][3] - w[0][0]) + (w[1][3] - w[1][0]), gl), 7, 8);
+    if (n27 >= K) {                                                     // uniform over the group
+        bool one_pass = n27 < KNN_TWO_PHASE_MIN;
+        float dL[2] = {0.f, 0.f}, dM[2] = {0.f, 0.f}, dR[2] = {0.f, 0.f};
+        int b1[2] = {w[0][0], w[1][0]}, e1[2] = {w[0][3], w[1][3]};
+        if (!one_pass) {
+            const float h = 1.f / g.inv_h;
+            const float fx0 = g.ox + float(cx) * h, fy0 = g.oy + float(cy) * h, fz0 = g.oz + float(cz) * h;
+            const float gxl = fmaxf((qx - fx0) - KNN_PRUNE_SLACK, 0.f), gxr = fmaxf(((fx0 + h) - qx) - KNN_PRUNE_SLACK, 0.f);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float gy = fmaxf((dyr[s] < 0 ? qy - fy0 : (dyr[s] > 0 ? (fy0 + h) - qy : 0.f)) - (dyr[s] ? KNN_PRUNE_SLACK : 0.f), 0.f);
+                const float gz = fmaxf((dzr[s] < 0 ? qz - fz0 : (dzr[s] > 0 ? (fz0 + h) - qz : 0.f)) - (dzr[s] ? KNN_PRUNE_SLACK : 0.f), 0.f);
+                dM[s] = gy * gy + gz * gz; dL[s] = dM[s] + gxl * gxl; dR[s] = dM[s] + gxr * gxr;
+            }
+            float tau2 = fminf(fmaxf((1.69f * 9.f * float(K) / 3.14159265f) / float(n27), 0.0225f), 0.36f);
+            int n1 = 0;
+#pragma unroll 1
+            for (int widen = 0; widen < 3; ++widen) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bool inM = dM[s] <= tau2;
+                    b1[s] = inM ? (dL[s] <= tau2 ? w[s][0] : w[s][1]) : w[s][3];
+                    e1[s] = inM ? (dR[s] <= tau2 ? w[s][3] : w[s][2]) : w[s][3];
+                }
+                n1 = __shfl(row_scan16<8>((e1[0] - b1[0]) + (e1[1] - b1[1]), gl), 7, 8);
+                if (n1 >= K) break;
+                tau2 *= 4.f;
+            }
+            if (n1 < K) { one_pass = true; b1[0] = w[0][0]; e1[0] = w[0][3]; b1[1] = w[1][0]; e1[1] = w[1][3]; }
+        }
+        {
+            const int len1[2] = {e1[0] - b1[0], e1[1] - b1[1]};
+            const int total1 = knn_fill_table<8, 2>(lds_run, gl, b1, len1);
+            knn_walk16<K, 8>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
+        }
+        if (!one_pass) {
+            unsigned hd[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) hd[i] = (unsigned)(k[i] >> 32);
+            unsigned kth = 0x7f800000u;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                kth = dpp_row_min_u32<8>(hd[0]);
+                if (hd[0] == kth) {
+#pragma unroll
+                    for (int i = 0; i < K - 1; ++i) hd[i] = hd[i + 1];
+                    hd[K - 1] = 0x7f800000u;
+                }
+            }
+            const float Bm = __uint_as_float(kth) * 1.0001f;
+            int pb[4], pl[4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool keepM = dM[s] <= Bm;
+                const int kb = keepM ? (dL[s] <= Bm ? w[s][0] : w[s][1]) : w[s][3], ke = keepM ? (dR[s] <= Bm ? w[s][3] : w[s][2]) : w[s][3];
+                pb[2 * s] = kb; pl[2 * s] = max(min(ke, b1[s]) - kb, 0);
+                pb[2 * s + 1] = max(kb, e1[s]); pl[2 * s + 1] = max(ke - pb[2 * s + 1], 0);
+            }
+            const int total2 = knn_fill_table<8, 4>(lds_run + KNN_RUN_WORDS, gl, pb, pl);
+            if (total2 > 0) knn_walk16<K, 8>(g, qx, qy, qz, gl, lds_run + KNN_RUN_WORDS, total2, kth, k);
+        }
+    }
+    MLH_KSTAGE(3);
+    knn_tournament16<K, 8>(k, out);
 }
 
 }  // namespace mlh

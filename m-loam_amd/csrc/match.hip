@@ -206,7 +206,7 @@ struct KParams {
     double init_pose[7];
     HostPublish *publish;    // the finish of the last iteration hands the result to the host through pinned memory
     unsigned long long publish_seq;
-    int knn_lanes;           // lanes per query of the correspondence kernel (8 or 16), chosen per launch
+    int knn_lanes;           // lanes per query of the correspondence kernel: 8 or 16 for every kind of the launch, 0 = per kind (KindP::lanes)
     int strided;             // fused kernel: workgroup t takes features t, t + T, ... instead of 32 consecutive ones
     int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU),
                              // 3: Levenberg-Marquardt begin (fit kernel), 4: Levenberg-Marquardt step (linearize kernel)
@@ -261,6 +261,7 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
 {
     unsigned long long keys[K];
     if constexpr (G == 16 && K == 5) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    else if constexpr (G == 8 && K == 5) knn_group8_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     else knn_group<K, G>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     MLH_KSTAGE(4);
     // lane t (< K <= G) fetches winner t: one load per lane, all in flight together
@@ -299,7 +300,7 @@ template <int G, bool MB>
 __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
-    constexpr int RUNW = (G == 16) ? 2 * KNN_RUN_WORDS : 20;
+    constexpr int RUNW = 2 * KNN_RUN_WORDS;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int f = tile * FPB + grp;
     MLH_KSTAGE(0);
@@ -322,7 +323,7 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
 template <int G, bool MB>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
-    __shared__ int s_run[(G == 8) ? (TPB / 8) * 20 : (TPB / 16) * 2 * KNN_RUN_WORDS];
+    __shared__ int s_run[(G == 16) ? (TPB / 16) * 2 * KNN_RUN_WORDS : (TPB / 8) * 2 * KNN_RUN_WORDS];
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = xcd_tile(total);
     if (tile >= total) return;
@@ -838,6 +839,25 @@ __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const fl
 }
 
 // ---------------------------------------------------------------- host launchers
+// lanes per query, per kind. A small launch (a 16-ring frame) leaves most SIMDs idle and is bound by the latency of its trips: 16 lanes.
+// A full frame keeps ~5 wavefronts per SIMD busy and is bound by VALU issue, where the per-query instruction count is what matters:
+// 8 lanes (twice the queries per wavefront) for a kind whose map is sparse enough that a query's candidates fit one or two 8-lane trips,
+// 16 lanes (pruned, near-cells-first) for a dense map, whose heavy queries would otherwise set the launch's duration.
+void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
+{
+    long long queries = 0;
+    for (int k = 0; k < 2; ++k) if (kind_mask & (1 << k)) queries += ctx->feat[k].m;
+    for (int k = 0; k < 2; ++k) {
+        const MapGrid &mg = ctx->map[k];
+        // ~9 of the 27 cells around a query on a surface are occupied, each about as full as the cell an average map point lives in
+        // (pop_sq / n, size-biased: the clusters of a dense edge map count by their points, not by their cells)
+        const double est27 = (mg.occupied > 0 && mg.n > 0) ? 9.0 * double(mg.pop_sq) / double(mg.n) : 1e9;
+        lanes[k] = queries > KNN_WIDE_LIMIT ? 8 : (queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16));
+        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) lanes[k] = ctx->knn_lanes_override;
+        if (ctx->knn_lanes_override == 816) lanes[k] = k == 0 ? 8 : 16;
+    }
+}
+
 static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
 {
     std::memset(&P, 0, sizeof(P));
@@ -850,11 +870,11 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         P.freeze_b[b] = a.freeze[b];
         kmax = std::max(kmax, P.kb[b]);
     }
+    int lanes[2];
+    knn_lanes_for(ctx, a.kind_mask, lanes);
     {
-        long long queries = 0;
-        for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) queries += ctx->feat[k].m;
-        P.knn_lanes = queries <= KNN_WIDE_LIMIT ? 16 : 8;
-        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16 || ctx->knn_lanes_override == 816) P.knn_lanes = ctx->knn_lanes_override;
+        const bool both = (a.kind_mask & 3) == 3;
+        P.knn_lanes = both ? (lanes[0] == lanes[1] ? lanes[0] : 0) : lanes[(a.kind_mask & 1) ? 0 : 1];
     }
     for (int k = 0; k < 2; ++k) {
         KindP &K = P.k[k];
@@ -883,7 +903,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         K.r_out = a.dense ? fs.r.as<double>() : nullptr;
         K.J_out = a.dense ? fs.J.as<double>() : nullptr;
         K.m = fs.m;
-        K.lanes = (P.knn_lanes == 816) ? (k == 0 ? 8 : 16) : P.knn_lanes;
+        K.lanes = lanes[k];
         K.tiles_a = (fs.m + TPB / K.lanes - 1) / (TPB / K.lanes);
         K.tiles_b = (fs.m + TPB - 1) / TPB;
         K.tiles_f = (fs.m + FQPB - 1) / FQPB;
@@ -965,7 +985,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
         return MLH_OK;
     }
-    if (P.knn_lanes == 816) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false>, grid_a, P); }
+    if (P.knn_lanes == 0) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false>, grid_a, P); }
     else if (P.knn_lanes == 16) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, false>, grid_a, P); }
     else { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, false>, grid_a, P); }
     if (P.finish == 3) {
