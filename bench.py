@@ -352,7 +352,8 @@ def main():
     if knn_n > 0:
         dur_s = 1e-3 * knn_ms / knn_n
         ach = bytes_per_launch / dur_s / 1e9
-        roofline = dict(bound="hbm", kernel="knn_features_kernel<16> (correspondence search, surf + corner queries of one GN iteration)",
+        _lanes = (ctx.map_info(mla.SURF)["knn_lanes"], ctx.map_info(mla.CORNER)["knn_lanes"])
+        roofline = dict(bound="hbm", kernel=f"knn_features_kernel (correspondence search, surf + corner queries of one GN iteration; lanes per query surf/corner = {_lanes[0]}/{_lanes[1]})",
                         achieved=round(ach, 2), peak=8000.0, unit="GB/s",
                         frac=round(ach / 8000.0, 5), traffic=None, avg_kernel_us=round(1e6 * dur_s, 3), launches=int(knn_n),
                         algorithmic_bytes_per_launch=int(bytes_per_launch), bytes_convention="SURVEY 8(d): 16 + 27*8 + 12*C-bar per query (all 27 cells)",
@@ -363,7 +364,10 @@ def main():
                         note="`achieved` follows the survey's 27-cell convention; the kernel searches near cells first and skips cells farther than "
                              "the K-th distance found, so it READS fewer bytes than that (between the `unavoidable` and the 27-cell figure). "
                              "The map (<= 128 MB) is L2/Infinity-Cache resident: measured HBM bytes (PMC, collected offline, profiles/) are far "
-                             "below either figure -- the kernel is latency-bound (dependent round trips), not bandwidth-bound")
+                             "below either figure, so HBM bandwidth is not what binds this launch. SQ counters (profiles/, pass 3) put it at ~70% VALU "
+                             "issue utilisation with ~5 wavefronts per SIMD: it is bound by VALU issue (per-query instruction count), which is why "
+                             "sparse-map kinds run 8 lanes per query. `frac` is reported against the HBM peak because that is the contract's roof; "
+                             "it is not the binding one")
         pmc_path = os.path.join(ROOT, "profiles", "pmc_knn.json")
         if os.path.exists(pmc_path):
             try:
