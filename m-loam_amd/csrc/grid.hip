@@ -81,7 +81,7 @@ struct GridJob {
     int *rank;             // n: arrival rank of each point inside its cell
     int *block_sums;
     long long *occ;        // occupancy statistics of this build (null: not wanted): [0] non-empty cells, [1] sum of squared cell populations,
-                           // then one (cells, squares) partial per scanning wavefront
+                           // then one (cells, squares) partial per scanning workgroup
     int n;
     int ncell;
     float ox, oy, oz, inv_h;
@@ -174,6 +174,7 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &to
 __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
 {
     __shared__ int lds[4];
+    __shared__ long long lds_occ[8];
     const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
@@ -184,16 +185,14 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     if (base < n_pad) v0 = A4[base / 4];
     if (base + 4 < n_pad) v1 = A4[base / 4 + 1];
     const int s = ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w));
-    if (J.occ) {                                                         // occupancy statistics: a partial per wavefront, summed by occ_total()
-        long long nz = (v0.x > 0) + (v0.y > 0) + (v0.z > 0) + (v0.w > 0) + (v1.x > 0) + (v1.y > 0) + (v1.z > 0) + (v1.w > 0);
-        long long sq = (long long)v0.x * v0.x + (long long)v0.y * v0.y + (long long)v0.z * v0.z + (long long)v0.w * v0.w +
-                       (long long)v1.x * v1.x + (long long)v1.y * v1.y + (long long)v1.z * v1.z + (long long)v1.w * v1.w;
+    long long occ_nz = 0, occ_sq = 0;                                    // occupancy statistics: one partial per workgroup, summed by occ_total()
+    if (J.occ) {
+        occ_nz = (v0.x > 0) + (v0.y > 0) + (v0.z > 0) + (v0.w > 0) + (v1.x > 0) + (v1.y > 0) + (v1.z > 0) + (v1.w > 0);
+        occ_sq = (long long)v0.x * v0.x + (long long)v0.y * v0.y + (long long)v0.z * v0.z + (long long)v0.w * v0.w +
+                 (long long)v1.x * v1.x + (long long)v1.y * v1.y + (long long)v1.z * v1.z + (long long)v1.w * v1.w;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { nz += __shfl_xor(nz, off); sq += __shfl_xor(sq, off); }
-        if ((threadIdx.x & 63) == 0) {
-            long long *part = J.occ + 2 + 2 * (b * 4 + (threadIdx.x >> 6));
-            part[0] = nz; part[1] = sq;
-        }
+        for (int off = 32; off > 0; off >>= 1) { occ_nz += __shfl_xor(occ_nz, off); occ_sq += __shfl_xor(occ_sq, off); }
+        if ((threadIdx.x & 63) == 0) { lds_occ[2 * (threadIdx.x >> 6)] = occ_nz; lds_occ[2 * (threadIdx.x >> 6) + 1] = occ_sq; }
     }
     int total;
     int ex = block_exclusive_scan_256(s, lds, total);
@@ -202,7 +201,13 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     ex += v1.x; o1.x = ex; ex += v1.y; o1.y = ex; ex += v1.z; o1.z = ex; ex += v1.w; o1.w = ex;
     if (base < n_pad) A4[base / 4] = o0;
     if (base + 4 < n_pad) A4[base / 4 + 1] = o1;
-    if (threadIdx.x == 0) J.block_sums[b] = total;
+    if (threadIdx.x == 0) {
+        J.block_sums[b] = total;
+        if (J.occ) {                                                     // the block scan above synchronised after the LDS writes
+            J.occ[2 + 2 * b] = lds_occ[0] + lds_occ[2] + lds_occ[4] + lds_occ[6];
+            J.occ[3 + 2 * b] = lds_occ[1] + lds_occ[3] + lds_occ[5] + lds_occ[7];
+        }
+    }
 }
 
 // large grids only: exclusive scan of the chunk totals
@@ -345,8 +350,8 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
     }
     for (int k = 0; k < n_grids && k < 2; ++k) {
         MapGrid &g = *grids[k];
-        if (g.want_occ) {               // occupancy partials: one per scanning wavefront
-            g.occ_parts = 4 * int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
+        if (g.want_occ) {               // occupancy partials: one per scanning workgroup
+            g.occ_parts = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
             MLH_HIP(ctx, g.occ.ensure(sizeof(long long) * size_t(2 + 2 * g.occ_parts)));
         }
         G.j[nj++] = make_job(g);

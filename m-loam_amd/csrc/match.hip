@@ -855,6 +855,7 @@ void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
         lanes[k] = queries > KNN_WIDE_LIMIT ? 8 : (queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16));
         if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) lanes[k] = ctx->knn_lanes_override;
         if (ctx->knn_lanes_override == 816) lanes[k] = k == 0 ? 8 : 16;
+        if (!ctx->fused_disable) lanes[k] = 16;      // the single-launch kernel (opt-in, MLH_FUSED=1) is written for 16-lane groups
     }
 }
 

@@ -16,6 +16,9 @@ struct SumArgs {
 // fixed order.
 // Record layout: [0..20] J^T J upper, [21..26] J^T r, [27] cost, [28] count, [29] surf count, [30] corner count.
 template <int NT = 256, int U = 12>
+// `a` travels by reference: the caller's copy is the 32 bytes of scratch rocprof shows for the kernels that end in this call (only the last
+// workgroup's serial tail touches them). Passing the six words by value removes the scratch and was measured 0.5 us SLOWER per launch
+// (A/B inside one gpurun call, three alternations: 15.9 vs 15.4 us for fit_linearize_kernel<5,false>), so it stays a reference.
 __device__ __noinline__ void sum_partials(const SumArgs &a, double *ne /*LDS, NE_STRIDE*/, double *cnt2 /*LDS, 2*/, double *scratch /*LDS (NT/32)*32*/)
 {
     constexpr int NS = NT / 32;
