@@ -164,8 +164,18 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
  * trace_threshold are dropped, w = trace_threshold - trace, mu = sum w p / sum w, cov = sum w^2 cov_i / (sum w)^2, intensity of the
  * heaviest member, trace recomputed; otherwise the plain branch (PointXYZI, :392-420): xyz mean, intensity of the last member.
  * Output (HOST, capacity n records) uses the input's record layout and is ordered by voxel index like the reference's.
- * Members of a voxel are accumulated in input order (the reference: in the order its unstable sort left them).
- * `mem` describes BOTH buffers: MLH_MEM_DEVICE takes device records and leaves the result in device memory (`out`), so a map
+ * MEMBER ORDER. The reference groups a voxel's members with std::sort and a comparator that sees the voxel index only (impl.hpp:227), i.e.
+ * inside a voxel they come in whatever order libstdc++'s introsort leaves. That order decides "the last member" of the plain branch --
+ * for a fused multi-LiDAR cloud the LiDAR id downsampleCurrentScan propagates the uncertainty through (lidar_mapper_keyframe.cpp:377) --,
+ * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. By default members are
+ * walked in ascending point index (what a stable sort would give): voxel set, output order and counts are identical to the reference's,
+ * sums agree to f32 rounding, but the surviving id of a voxel that MIXES ids can differ (on a two-LiDAR frame: ~31 % of the 0.4 m surf
+ * voxels, ~5 % of the 0.2 m corner voxels; with uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py).
+ * mlh_set_voxel_member_order(ctx, 1) switches every voxel filter of the context (mlh_voxel_filter, mlh_voxel_grid,
+ * mlh_downsample_current_scan, ..._pair) to the reference's order: the slots come back to the host, the same std::sort runs there on
+ * the same sequence, the member lists go back. Exact, at the price of a host round trip and a host sort per call (milliseconds). */
+int mlh_set_voxel_member_order(mlh_ctx *ctx, int reference_std_sort_order);
+/* mlh_voxel_filter: `mem` describes BOTH buffers: MLH_MEM_DEVICE takes device records and leaves the result in device memory (`out`), so a map
  * assembled with mlh_cloud_uct_associate_to_map can be thinned and handed to mlh_map_set without leaving HBM. */
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                      int trace_offset_bytes, float leaf, float trace_threshold, void *out, int32_t *n_out, int mem);

@@ -590,6 +590,13 @@ int mlh_map_rebuild(mlh_ctx *ctx, int kind)
     return grid_build(ctx, kind == MLH_ALL_KINDS ? 3 : (1 << kind), false);
 }
 
+int mlh_set_voxel_member_order(mlh_ctx *ctx, int reference_std_sort_order)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    ctx->vox_std_sort_order = reference_std_sort_order != 0;
+    return MLH_OK;
+}
+
 int mlh_map_info(mlh_ctx *ctx, int kind, int32_t *n_points, int32_t *occupied_cells, double *mean_cell_population, int32_t *knn_lanes)
 {
     if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;

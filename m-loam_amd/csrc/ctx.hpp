@@ -259,6 +259,7 @@ struct mlh_ctx {
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
+    bool vox_std_sort_order = false;   // voxel filters: members of a voxel in the order libstdc++'s std::sort leaves them (host pass) instead of point-index order
     void *select_host = nullptr; // pinned staging of the good-feature selection (select.hip)
     size_t select_host_cap = 0;
     int n_ranks = 1, rank = 0;

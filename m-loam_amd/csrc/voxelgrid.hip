@@ -14,8 +14,10 @@
 //   plain branch (:392-420) xyz mean over the members, intensity of the last member
 // Streaming kernels: ~ (stride + 8) B/point per pass + 1/8 B/cell (bits) + 8 B per 32 cells for the popcount scan.
 #include "ctx.hpp"
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <vector>
 
 namespace mlh {
 
@@ -313,6 +315,40 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
     if (has_i) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
 }
 
+// Reference member order (opt-in, mlh_set_voxel_member_order): the reference groups a voxel's members with an UNSTABLE std::sort whose
+// comparator sees the voxel index only (voxel_grid_covariance_mloam_impl.hpp:215-236), so the order of the members inside a voxel -- and with it
+// "the last member's intensity" of the plain branch, the first-maximum-weight intensity of the covariance branch and the association of
+// every f32 sum -- is whatever libstdc++'s introsort leaves. That order cannot be derived without running the same algorithm on the same
+// sequence, so this path does exactly that on the host: the points' output slots (ascending voxel index: order-isomorphic to PCL's idx, hence
+// the same comparisons and the same introsort path) come back, std::sort runs per cloud on (slot, point index) pairs in point order, and
+// the resulting member lists replace what vox_rank_kernel would have written. Costs a host round trip and a ~n log n host sort per call
+// (milliseconds for a frame's clouds): off by default, where members are walked in ascending point index instead.
+static int members_in_std_sort_order(mlh_ctx *ctx, const VoxArgs &A)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<int> slot(size_t(A.n)), members(size_t(A.n));
+    MLH_HIP(ctx, hipMemcpyAsync(slot.data(), A.vox_of, sizeof(int) * size_t(A.n), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    struct IdxPt {
+        unsigned int idx, cloud_point_index;
+        bool operator<(const IdxPt &o) const { return idx < o.idx; }      // cloud_point_index_idx::operator< (voxel_grid.h): idx only
+    };
+    std::vector<IdxPt> iv;
+    size_t pos = 0;
+    const int range[3] = {0, A.n0, A.n};                                  // one filter call per cloud in the reference: one sort per cloud
+    for (int c = 0; c < 2; ++c) {
+        if (range[c + 1] <= range[c]) continue;
+        iv.clear();
+        iv.reserve(size_t(range[c + 1] - range[c]));
+        for (int i = range[c]; i < range[c + 1]; ++i) iv.push_back(IdxPt{(unsigned)slot[size_t(i)], (unsigned)i});
+        std::sort(iv.begin(), iv.end(), std::less<IdxPt>());
+        for (const IdxPt &e : iv) members[pos++] = int(e.cloud_point_index);
+    }
+    MLH_HIP(ctx, hipMemcpyAsync(A.members, members.data(), sizeof(int) * size_t(A.n), hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));                               // `members` is a local
+    return MLH_OK;
+}
+
 // getMinMax3D: per-workgroup partial bounds (6 floats each); the host, which needs them for the grid extents anyway, folds them
 constexpr int VB_BLOCKS = 128;
 __global__ __launch_bounds__(256) void vbounds_kernel(const unsigned char *src, int stride, int n, float *partial)
@@ -431,7 +467,8 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
     if (rc) return rc;
     hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
-    hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    if (ctx->vox_std_sort_order) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
+    else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
     hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     if (!sync_total) { *n_out = -1; return MLH_OK; }
@@ -509,7 +546,8 @@ int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    if (ctx->vox_std_sort_order) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
+    else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
     hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     *first_voxels_word = int(off1 >> 5);

@@ -394,6 +394,15 @@ int orc_voxel_grid_cov(const float *pts11, int n, float leaf, float trace_thresh
     return 0;
 }
 
+int orc_voxel_grid_mloam_plain(const float *xyzi, int n, float leaf, int member_order, float *out, int *n_out)
+{
+    std::vector<float> o;
+    voxel_grid_mloam_plain(xyzi, n, leaf, member_order, o);
+    std::memcpy(out, o.data(), sizeof(float) * o.size());
+    *n_out = int(o.size() / 4);
+    return 0;
+}
+
 int orc_compound_pose_with_cov(const double *pose1, const double *cov1, const double *pose2, const double *cov2, double *pose_cp, double *cov_cp)
 {
     compound_pose_with_cov(pose1, cov1, pose2, cov2, pose_cp, cov_cp);

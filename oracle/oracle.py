@@ -465,6 +465,16 @@ def voxel_grid_cov(pts11, leaf, trace_threshold):
     return out[:cnt.value].copy()
 
 
+def voxel_grid_mloam_plain(points, leaf, member_order=1):
+    """VoxelGridCovarianceMLOAM<PointI> (no covariance fields): xyz mean, intensity of the voxel's LAST member. member_order 0 = the order
+    std::sort leaves (the reference, libstdc++-defined for mixed-intensity voxels), 1 = point-index order (the rule the HIP path is pinned on)."""
+    p = np.ascontiguousarray(points[:, :4], np.float32)
+    out = np.zeros_like(p)
+    cnt = C.c_int(0)
+    lib().orc_voxel_grid_mloam_plain(_ptr(p), p.shape[0], C.c_float(leaf), int(member_order), _ptr(out), C.byref(cnt))
+    return out[:cnt.value].copy()
+
+
 def compound_pose_with_cov(pose1, cov1, pose2, cov2):
     a = [np.ascontiguousarray(x, np.float64) for x in (pose1, cov1, pose2, cov2)]
     pose_cp, cov_cp = np.zeros(7), np.zeros((6, 6))

@@ -125,6 +125,66 @@ static inline void voxel_grid_covariance_mloam(const PointICov *in, int n, float
     }
 }
 
+// The filter's other branch: a point type WITHOUT covariance fields (pcl::VoxelGridCovarianceMLOAM<PointI>, the mapper's down_size_filter_surf /
+// _corner, lidar_mapper_keyframe.cpp:79, 359-364) -- voxel_grid_covariance_mloam_impl.hpp:393-431: xyz summed over the members and divided by
+// their count, intensity = the LAST member's (centroid[3] = temporary[3] inside the loop, no averaging). "Last" is in the order
+// std::sort leaves the members of a voxel in, and the comparator looks at the voxel index only: for a voxel whose members carry different
+// intensities (a fused multi-LiDAR cloud: intensity = LiDAR id, which downsampleCurrentScan then uses to pick the extrinsic) the reference's
+// result depends on libstdc++'s introsort. member_order 0 = exactly that (std::sort, comparator on idx only); 1 = members in point-index
+// order (what a stable sort gives) -- the rule the HIP path implements and is pinned on.
+static inline void voxel_grid_mloam_plain(const float *xyzi, int n, float leaf, int member_order, std::vector<float> &out)
+{
+    out.clear();
+    if (n <= 0) return;
+    const float inv = 1.0f / leaf;
+    float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < n; ++i) {
+        const float *v = xyzi + 4 * size_t(i);
+        if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2])) continue;
+        for (int d = 0; d < 3; ++d) { min_p[d] = std::min(min_p[d], v[d]); max_p[d] = std::max(max_p[d], v[d]); }
+    }
+    int64_t dx = int64_t((max_p[0] - min_p[0]) * inv) + 1;
+    int64_t dy = int64_t((max_p[1] - min_p[1]) * inv) + 1;
+    int64_t dz = int64_t((max_p[2] - min_p[2]) * inv) + 1;
+    if (dx * dy * dz > int64_t(INT32_MAX)) { out.assign(xyzi, xyzi + 4 * size_t(n)); return; }
+    int min_b[3], max_b[3], div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        min_b[d] = int(std::floor(min_p[d] * inv));
+        max_b[d] = int(std::floor(max_p[d] * inv));
+        div_b[d] = max_b[d] - min_b[d] + 1;
+    }
+    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+    struct IdxPt {
+        unsigned int idx, cloud_point_index;
+        bool operator<(const IdxPt &o) const { return idx < o.idx; }
+    };
+    std::vector<IdxPt> iv;
+    iv.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        const float *v = xyzi + 4 * size_t(i);
+        int ijk0 = int(std::floor(v[0] * inv) - float(min_b[0]));
+        int ijk1 = int(std::floor(v[1] * inv) - float(min_b[1]));
+        int ijk2 = int(std::floor(v[2] * inv) - float(min_b[2]));
+        iv.push_back({(unsigned)(ijk0 + ijk1 * mul1 + ijk2 * mul2), (unsigned)i});
+    }
+    if (member_order == 0) std::sort(iv.begin(), iv.end(), std::less<IdxPt>());
+    else std::stable_sort(iv.begin(), iv.end(), std::less<IdxPt>());
+    size_t index = 0;
+    while (index < iv.size()) {
+        size_t i2 = index + 1;
+        while (i2 < iv.size() && iv[i2].idx == iv[index].idx) ++i2;
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t i = index; i < i2; ++i) {
+            const float *q = xyzi + 4 * size_t(iv[i].cloud_point_index);
+            c[0] += q[0]; c[1] += q[1]; c[2] += q[2];
+            c[3] = q[3];
+        }
+        const float cnt = float(i2 - index);
+        out.push_back(c[0] / cnt); out.push_back(c[1] / cnt); out.push_back(c[2] / cnt); out.push_back(c[3]);
+        index = i2;
+    }
+}
+
 // ---- 3x3 / 6x6 helpers (row-major)
 static inline void m3_mul(const double A[9], const double B[9], double C[9])
 {

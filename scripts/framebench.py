@@ -127,19 +127,24 @@ for s in scans:
 t1 = time.perf_counter()
 surf_c, corner_c = fuse(lists)
 t2 = time.perf_counter()
-feats = []
-for cloud, leaf in ((surf_c, 0.4), (corner_c, 0.2)):
-    ds = O.voxel_grid(cloud, leaf)      # pcl::VoxelGrid centroids (the plain branch differs only in which member's intensity survives)
-    ds[:, 3] = np.round(ds[:, 3])
-    out = np.zeros((len(ds), 11), np.float32); out[:, :4] = ds
-    for lid in range(2):
-        m = ds[:, 3] == lid
-        R = synth.quat_to_rot(ext[lid][3:])
-        sel = ((ds[m, :3].astype(np.float64) - ext[lid][:3]) @ R).astype(np.float32)
-        c = O.eval_point_uncertainty(sel, ext[lid], covs[lid], meas)
-        out[m, 4:10] = np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
-    out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
-    feats.append(out[out[:, 10] <= 0.6])
+def cpu_downsample(member_order):
+    """downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-398): VoxelGridCovarianceMLOAM<PointI> (xyz mean, the LAST member's LiDAR id) ->
+    evalPointUncertainty through that LiDAR's extrinsic -> trace gate. member_order 1 = point-index order inside a voxel (the HIP path's
+    rule), 0 = the order libstdc++'s unstable std::sort leaves (the reference)."""
+    res = []
+    for cloud, leaf in ((surf_c, 0.4), (corner_c, 0.2)):
+        ds = O.voxel_grid_mloam_plain(cloud, leaf, member_order)
+        out = np.zeros((len(ds), 11), np.float32); out[:, :4] = ds
+        for lid in range(2):
+            m = ds[:, 3] == lid
+            R = synth.quat_to_rot(ext[lid][3:])
+            sel = ((ds[m, :3].astype(np.float64) - ext[lid][:3]) @ R).astype(np.float32)
+            c = O.eval_point_uncertainty(sel, ext[lid], covs[lid], meas)
+            out[m, 4:10] = np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+        out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
+        res.append(out[out[:, 10] <= 0.6])
+    return res
+feats = cpu_downsample(1)
 t3 = time.perf_counter()
 ms_, mc_ = O.Map(surf_map), O.Map(corner_map)
 tk = ms_.rebuild_seconds() + mc_.rebuild_seconds()
@@ -147,4 +152,15 @@ ref = O.scan2map(ms_, mc_, feats[0], feats[1], p0, O.mapper_params(with_ua=True)
 t4 = time.perf_counter()
 print("CPU oracle, ms per frame:", {"extract": round(1e3 * (t1 - t0), 1), "fuse(host)": round(1e3 * (t2 - t1), 1), "downsample": round(1e3 * (t3 - t2), 1),
       "kd-tree build": round(1e3 * tk, 1), "scan2map": round(1e3 * (t4 - t3) - 1e3 * tk, 1)}, "total %.1f" % (1e3 * (t4 - t0)))
-print("pose agreement |dt| %.2e m (host hand-over) %.2e m (device hand-over)" % (np.linalg.norm(pose[:3] - ref["pose"][:3]), np.linalg.norm(pose_dev[:3] - ref["pose"][:3])))
+print("pose agreement |dt| %.2e m (host hand-over) %.2e m (device hand-over)  [CPU leg thinned with the HIP path's member order]" % (np.linalg.norm(pose[:3] - ref["pose"][:3]), np.linalg.norm(pose_dev[:3] - ref["pose"][:3])))
+f0 = cpu_downsample(0)
+ref0 = O.scan2map(O.Map(surf_map), O.Map(corner_map), f0[0], f0[1], p0, O.mapper_params(with_ua=True))
+ctx.set_voxel_member_order(True)
+for _ in range(3): gpu_frame({})
+tr = {}
+for _ in range(n): pose_r, _, _ = gpu_frame(tr)
+ctx.set_voxel_member_order(False)
+print("GPU path with mlh_set_voxel_member_order(1) (the reference's std::sort member order, host pass), ms per frame:", {k: round(1e3 * v / n, 3) for k, v in tr.items()},
+      "pose vs CPU leg in that order |dt| %.2e m" % np.linalg.norm(pose_r[:3] - ref0["pose"][:3]))
+print("effect of the reference's std::sort member order on this frame: features surf/corner %d/%d vs %d/%d, pose moves %.2e m" %
+      (len(f0[0]), len(f0[1]), len(feats[0]), len(feats[1]), np.linalg.norm(ref0["pose"][:3] - ref["pose"][:3])))

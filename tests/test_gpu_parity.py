@@ -524,17 +524,128 @@ def test_voxel_filter_covariance_parity(ctx, orc, synth, case16):
 
 
 def test_voxel_filter_plain_parity(ctx, orc, case16):
-    """PointXYZI branch (no covariance field): xyz mean over the members, intensity of the voxel's last member."""
+    """PointXYZI branch (no covariance field; voxel_grid_covariance_mloam_impl.hpp:393-431): xyz mean over the members, intensity of the
+    voxel's LAST member. The reference takes "last" in the order an unstable std::sort (comparator on the voxel index only) leaves the
+    members in; the HIP path takes it in point-index order and is pinned on that rule here, bit for bit, on a cloud whose voxels mix
+    intensities (a fused multi-LiDAR cloud carries the LiDAR id there). How often the two orders disagree is measured, not hidden: see
+    tests/test_oracle_pipeline.py::test_plain_voxel_filter_member_order_dependence and DESIGN.md section 2."""
+    rng = np.random.default_rng(5)
     xyz = case16["corner_map"][:30000, :3]
-    pts = np.concatenate([xyz, np.arange(len(xyz), dtype=np.float32)[:, None]], axis=1).astype(np.float32)
-    for leaf in (0.2, 0.4, 1.0):
-        got = ctx.voxel_filter(pts, leaf)
-        ref = orc.voxel_grid(pts, leaf)              # pcl::VoxelGrid<PointXYZI>: same centroid rule; intensity is averaged there
-        assert got.shape == ref.shape
-        np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)
-        assert np.isin(got[:, 3], pts[:, 3]).all()
+    for ids in (np.arange(len(xyz), dtype=np.float32), rng.integers(0, 2, len(xyz)).astype(np.float32)):   # unique tags; two LiDAR ids mixed
+        pts = np.concatenate([xyz, ids[:, None]], axis=1).astype(np.float32)
+        for leaf in (0.2, 0.4, 1.0):
+            got = ctx.voxel_filter(pts, leaf)
+            ref = orc.voxel_grid_mloam_plain(pts, leaf, member_order=1)
+            assert got.shape == ref.shape
+            np.testing.assert_array_equal(got[:, 3], ref[:, 3])                       # which member survives: a selection, exact
+            np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)  # f32 sums in a different association
+            avg = orc.voxel_grid(pts, leaf)                                           # pcl::VoxelGrid<PointXYZI>: same voxels, same centroid rule
+            assert avg.shape == ref.shape
     one = ctx.voxel_filter(pts[:1], 0.4)
     np.testing.assert_array_equal(one, pts[:1])
+
+
+def test_downsample_current_scan_mixed_lidar_voxels(ctx, mla, orc, synth, feats16):
+    """downsampleCurrentScan on a fused cloud whose voxels hold points of BOTH LiDARs (lidar_mapper_keyframe.cpp:356-398): the thinned
+    point's LiDAR id -- the voxel's last member's, point-index order -- selects the extrinsic the uncertainty is propagated through, so a
+    wrong member would show in the covariance and in the trace gate."""
+    rng = np.random.default_rng(21)
+    base = feats16[0][:, :3]
+    xyz = np.concatenate([base, base + rng.normal(0, 0.08, base.shape).astype(np.float32)])
+    pts = np.zeros((len(xyz), 4), np.float32)
+    pts[:, :3] = xyz
+    pts[:, 3] = rng.integers(0, 2, len(xyz))                     # ids mixed inside voxels
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.diag([0.0004] * 3 + [0.0001] * 3), np.diag([0.0025] * 3 + [0.00030461] * 3) * 30])
+    meas = np.diag([0.0025] * 3)
+    thr = 0.05
+    ds = orc.voxel_grid_mloam_plain(pts, 0.4, member_order=1)
+    keep_ref, cov_ref, traces = [], [], []
+    for p in ds:
+        n = int(p[3])
+        R = synth.quat_to_rot(ext[n][3:])
+        sel = ((p[:3].astype(np.float64) - ext[n][:3]) @ R).astype(np.float32)
+        c = orc.eval_point_uncertainty(sel[None, :], ext[n], covs[n], meas)[0]
+        traces.append(np.trace(c))
+        keep_ref.append(np.trace(c) <= thr)
+        cov_ref.append([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+    keep_ref, cov_ref, traces = np.array(keep_ref), np.array(cov_ref), np.array(traces)
+    assert np.all(np.abs(traces - thr) > 1e-4 * thr)             # no voxel sits on the gate, where a 2e-6 centroid difference could flip it
+    got = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, True, thr)
+    dsg = ctx.voxel_filter(pts, 0.4)
+    np.testing.assert_array_equal(dsg[:, 3], ds[:, 3])
+    assert 0 < keep_ref.sum() < len(ds) and len(set(ds[:, 3])) == 2
+    assert len(got) == keep_ref.sum()
+    np.testing.assert_array_equal(got[:, 3], ds[keep_ref][:, 3])
+    np.testing.assert_allclose(got[:, :3], ds[keep_ref][:, :3], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(got[:, 4:10], cov_ref[keep_ref], rtol=5e-5, atol=1e-9)
+
+
+def test_voxel_filters_in_the_references_member_order(mla, orc, synth, case16, feats16):
+    """mlh_set_voxel_member_order(ctx, 1): a voxel's members in the order libstdc++'s std::sort leaves them (the reference's own order,
+    voxel_grid_covariance_mloam_impl.hpp:227), reproduced by running that sort on the host over the same sequence. With the order equal,
+    everything is: surviving ids, and the f32 sums BIT FOR BIT (same association) -- plain branch, covariance branch, and
+    downsampleCurrentScan on a cloud whose voxels mix LiDAR ids."""
+    c = mla.Context(0)
+    try:
+        c.set_voxel_member_order(True)
+        rng = np.random.default_rng(5)
+        xyz = case16["corner_map"][:30000, :3]
+        pts = np.concatenate([xyz, rng.integers(0, 2, len(xyz)).astype(np.float32)[:, None]], axis=1).astype(np.float32)
+        n_id_diff = 0
+        for leaf in (0.2, 0.4, 1.0):
+            got = c.voxel_filter(pts, leaf)
+            ref = orc.voxel_grid_mloam_plain(pts, leaf, member_order=0)
+            np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+            n_id_diff += int(np.sum(ref[:, 3] != orc.voxel_grid_mloam_plain(pts, leaf, member_order=1)[:, 3]))
+        assert n_id_diff > 0                                       # the case is not vacuous: point-index order gives other ids here
+        # covariance branch
+        n = 40000
+        base = case16["surf_map"][:n // 2, :3]
+        x2 = np.concatenate([base, base + rng.normal(0, 0.1, base.shape).astype(np.float32)])[rng.permutation(n)]
+        p11 = np.zeros((n, 11), np.float32)
+        p11[:, :3] = x2
+        p11[:, 3] = rng.integers(0, 4, n)
+        sd = rng.uniform(0.01, 0.9, (n, 3)).astype(np.float32)
+        p11[:, 4] = sd[:, 0] ** 2; p11[:, 7] = sd[:, 1] ** 2; p11[:, 9] = sd[:, 2] ** 2
+        p11[:, 10] = p11[:, 4] + p11[:, 7] + p11[:, 9]
+        for leaf, thr in ((0.4, 1.0), (2.0, 1.0)):
+            got = c.voxel_filter(p11, leaf, thr)
+            ref = orc.voxel_grid_cov(p11, leaf, thr)
+            assert got.shape == ref.shape
+            np.testing.assert_array_equal(got[:, :4].view(np.uint32), ref[:, :4].view(np.uint32))     # mu, intensity: same association
+            np.testing.assert_allclose(got[:, 4:], ref[:, 4:], rtol=1e-6, atol=1e-12)
+        # downsampleCurrentScan, ids mixed inside voxels: the feature set the reference's order yields
+        b3 = feats16[0][:, :3]
+        xyz = np.concatenate([b3, b3 + rng.normal(0, 0.08, b3.shape).astype(np.float32)])
+        f4 = np.zeros((len(xyz), 4), np.float32)
+        f4[:, :3] = xyz
+        f4[:, 3] = rng.integers(0, 2, len(xyz))
+        ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+        for e in ext:
+            e[3:] /= np.linalg.norm(e[3:])
+        covs = np.stack([np.diag([0.0004] * 3 + [0.0001] * 3), np.diag([0.0025] * 3 + [0.00030461] * 3) * 30])
+        meas = np.diag([0.0025] * 3)
+        thr = 0.05
+        ds = orc.voxel_grid_mloam_plain(f4, 0.4, member_order=0)
+        keep = []
+        for p in ds:
+            k = int(p[3])
+            R = synth.quat_to_rot(ext[k][3:])
+            sel = ((p[:3].astype(np.float64) - ext[k][:3]) @ R).astype(np.float32)
+            keep.append(np.trace(orc.eval_point_uncertainty(sel[None, :], ext[k], covs[k], meas)[0]) <= thr)
+        keep = np.array(keep)
+        got = c.downsample_current_scan(mla.SURF, f4, 0.4, ext, covs, meas, True, thr)
+        assert 0 < keep.sum() < len(ds) and len(got) == keep.sum()
+        np.testing.assert_array_equal(got[:, :4].view(np.uint32), ds[keep].view(np.uint32))
+        # and back: the default order is per context and switchable
+        c.set_voxel_member_order(False)
+        again = c.voxel_filter(pts, 0.4)
+        np.testing.assert_array_equal(again[:, 3], orc.voxel_grid_mloam_plain(pts, 0.4, member_order=1)[:, 3])
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("lanes", [8, 16])

@@ -311,3 +311,36 @@ def test_oracle_matches_rows_f3_fixture(orc):
     assert np.array_equal(orc.transform_to_end(pts, pose, True).view(np.uint32), g["to_end"].view(np.uint32))
     assert np.array_equal(orc.transform_to_end(pts, pose, False).view(np.uint32), g["to_end_nodist"].view(np.uint32))
     assert np.array_equal(orc.transform_cloud_feature(pts, ext, 1).view(np.uint32), g["fused"].view(np.uint32))
+
+
+def test_plain_voxel_filter_member_order_dependence(orc, synth):
+    """VoxelGridCovarianceMLOAM<PointI> keeps the intensity of a voxel's LAST member (voxel_grid_covariance_mloam_impl.hpp:393-431), "last" in
+    the order an unstable std::sort leaves -- so on a fused two-LiDAR cloud (intensity = LiDAR id, which downsampleCurrentScan uses to pick the
+    extrinsic, lidar_mapper_keyframe.cpp:377) the reference's own result depends on libstdc++. The HIP path takes point-index order. This
+    test states what is and is not affected: voxel set and centroids do not depend on the order (2e-6: f32 sum association); the surviving
+    id can differ only in voxels that mix ids; and it records how often it does on the bench-like frame (printed with -s; quoted in DESIGN.md)."""
+    sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    gt = synth.gt_body_pose()
+    clouds = {"surf": [], "corner": []}
+    for i in range(2):
+        s = synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], 64, seed=7 + i)
+        ex = orc.extract(s.points, s.scan_start, s.scan_end)
+        T = np.eye(4)
+        T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4])
+        T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]
+        for key, xyz in (("corner", s.points[ex["less_sharp"]][:, :3]), ("surf", ex["less_flat_ds"][:, :3])):
+            a = np.zeros((len(xyz), 4), np.float32)
+            a[:, :3] = synth.transform_points(xyz, T)
+            a[:, 3] = i
+            clouds[key].append(a)
+    for key, leaf in (("surf", 0.4), ("corner", 0.2)):
+        cloud = np.concatenate(clouds[key])
+        ref_order = orc.voxel_grid_mloam_plain(cloud, leaf, member_order=0)      # std::sort, as the reference
+        idx_order = orc.voxel_grid_mloam_plain(cloud, leaf, member_order=1)      # point-index order, as the HIP path
+        avg = orc.voxel_grid(cloud, leaf)                                        # pcl::VoxelGrid: intensity averaged -> fractional = mixed voxel
+        assert ref_order.shape == idx_order.shape == avg.shape
+        np.testing.assert_allclose(ref_order[:, :3], idx_order[:, :3], rtol=2e-6, atol=2e-6)
+        mixed = (avg[:, 3] > 0) & (avg[:, 3] < 1)
+        differ = ref_order[:, 3] != idx_order[:, 3]
+        assert not np.any(differ & ~mixed)                                       # single-LiDAR voxels: no dependence at all
+        print(f"[member order] {key}: {len(avg)} voxels, {int(mixed.sum())} mix both LiDARs, surviving id differs in {int(differ.sum())}")
