@@ -277,6 +277,13 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    # Untimed, before the W warm-up steps the contract asks for: keep the GPU busy for ~0.1 s. The setup above leaves it idle for seconds
+    # (workload generation on the host), and a timed region of a few milliseconds right after an idle phase was twice observed 3-12x slow on
+    # a fresh box (scripts/calibbench.py: 4.3 and 1.1 ms where every later process read 0.36 ms -- consistent with the clocks still
+    # ramping, not proven). Same steps as the timed ones, results discarded.
+    for _ in range(600):          # a fixed count, the same on every rank (a step holds collectives when N > 1); ~0.12 s at 0.2 ms per step
+        step()
+    sync_all()
     for _ in range(args.warmup):
         step()
     # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one of its GN_ITERS

@@ -260,9 +260,8 @@ template <int K, int G>
 __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run)
 {
     unsigned long long keys[K];
-    if constexpr (G == 16 && K == 5) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
-    else if constexpr (G == 8 && K == 5) knn_group8_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
-    else knn_group<K, G>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    if constexpr (G == 16) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    else knn_group8_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     MLH_KSTAGE(4);
     // lane t (< K <= G) fetches winner t: one load per lane, all in flight together
     unsigned long long kk = keys[0];
@@ -296,7 +295,7 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
 
 // MB = more than one pose block in the launch (config 4); without it the block bookkeeping (a per-lane block index and the
 // per-block K lookup it drags along) compiles away
-template <int G, bool MB>
+template <int G, bool MB, bool K10>
 __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
@@ -315,12 +314,14 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
     if (!owns(P, f, sx, sy, sz)) return;     // uniform over the lane group
-    if ((MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
+    // K10: some pose block of the launch asks for 10 neighbours (buildCalibMap's non-reference LiDARs); without it the K = 10 search is not
+    // even compiled in, so the ordinary frame's kernel keeps the K = 5 register footprint
+    if (K10 && (MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
     else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
 }
 
 // G = lanes per query for both kinds, or 0: per kind (KindP::lanes -- a workgroup serves one kind, so the choice is uniform over it)
-template <int G, bool MB>
+template <int G, bool MB, bool K10>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
     __shared__ int s_run[(G == 16) ? (TPB / 16) * 2 * KNN_RUN_WORDS : (TPB / 8) * 2 * KNN_RUN_WORDS];
@@ -331,10 +332,10 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     if (kind) tile -= P.k[0].tiles_a;
     const KindP &K = P.k[kind];
     if constexpr (G == 0) {
-        if (K.lanes == 8) knn_features_body<8, MB>(P, K, tile, s_run);
-        else knn_features_body<16, MB>(P, K, tile, s_run);
+        if (K.lanes == 8) knn_features_body<8, MB, K10>(P, K, tile, s_run);
+        else knn_features_body<16, MB, K10>(P, K, tile, s_run);
     } else {
-        knn_features_body<G, MB>(P, K, tile, s_run);
+        knn_features_body<G, MB, K10>(P, K, tile, s_run);
     }
 }
 
@@ -986,9 +987,17 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
         return MLH_OK;
     }
-    if (P.knn_lanes == 0) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false>, grid_a, P); }
-    else if (P.knn_lanes == 16) { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<16, false>, grid_a, P); }
-    else { if (mb) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<8, false>, grid_a, P); }
+    {
+        // <lanes, pose blocks, any block with K = 10>
+#define MLH_KNN_LAUNCH(G_) do { \
+            if (mb) { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, true, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, true, false>, grid_a, P); } \
+            else { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false>, grid_a, P); } \
+        } while (0)
+        if (P.knn_lanes == 0) MLH_KNN_LAUNCH(0);
+        else if (P.knn_lanes == 16) MLH_KNN_LAUNCH(16);
+        else MLH_KNN_LAUNCH(8);
+#undef MLH_KNN_LAUNCH
+    }
     if (P.finish == 3) {
         if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");
         launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, true>, grid_b, P);

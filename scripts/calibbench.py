@@ -9,7 +9,7 @@ import bench, oracle as O
 mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
 O.build()
 k_neigh, thre, freeze = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
-for preset in ("500k", "4M"):
+for preset in os.environ.get("CALIBBENCH_PRESETS", "500k,4M").split(","):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, preset, n_lidars=4)
@@ -33,12 +33,14 @@ for preset in ("500k", "4M"):
     def frame():
         ctx.map_rebuild(mla.ALL_KINDS)
         return ctx.gn_solve_blocks(poses0, n_it, k_neigh, thre, freeze, opts, want_stats=False)
-    for _ in range(3): out = frame()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.15: out = frame()      # busy GPU before the timed region (see bench.py: short regions after an idle phase read 3-12x slow twice)
     ctx.synchronize(); t0 = time.perf_counter(); n = 20
     for _ in range(n): out = frame()
     ctx.synchronize(); gpu_ms = 1e3 * (time.perf_counter() - t0) / n
     poses = out[0]
     nf = sum(len(x) for x in surf_b) + sum(len(x) for x in corner_b)
+    print("  map index:", ctx.map_info(mla.SURF), ctx.map_info(mla.CORNER), "features surf/corner per block:", [len(x) for x in surf_b], [len(x) for x in corner_b])
     ms, mc = O.Map(surf_map), O.Map(corner_map)
     t0 = time.perf_counter(); dts = []
     for b in range(4):
@@ -49,4 +51,57 @@ for preset in ("500k", "4M"):
     tk = 1e3 * (ms.rebuild_seconds() + mc.rebuild_seconds())
     print(f"config 4 on one GPU, {preset} map ({len(surf_map) + len(corner_map)} points), {nf} features in 4 pose blocks: index rebuild + {n_it} GN iterations "
           f"GPU {gpu_ms:.3f} ms ({nf * n_it / gpu_ms * 1e3:.3g} features/s); CPU oracle {cpu_ms:.0f} ms + kd-tree build {tk:.0f} ms; max |dt| over blocks {max(dts):.1e} m; first map_set {t_set:.1f} ms")
+    # ---- the COUPLED window problem of Estimator::optimizeMap (estimator.cpp:687-848) on the same data: parameter blocks [pivot | 1 frame | 4
+    # extrinsics] = 36 local parameters, one LidarPureOdom{PlaneNorm,Edge}Factor per matched feature of every LiDAR; pivot and the reference
+    # LiDAR's extrinsic held constant (estimator.cpp:636, 642). Matching on the GPU against the resident map (pivot frame = map frame here),
+    # the factor table staged once, then per Gauss-Newton iteration ONE device pass for the 36 x 36 normal equations + a host solve.
+    from scipy.spatial.transform import Rotation as Rot
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    frame0 = synth.perturbed_pose(gt, seed=70, dt=0.05, drot_deg=0.5)
+    exts0 = []
+    for i in range(4):
+        bl = synth.HERCULES_BODY_T_LASER[i]
+        e = np.concatenate([bl[4:7], bl[:4] / np.linalg.norm(bl[:4])])
+        exts0.append(e if i == 0 else synth.perturbed_pose(e, seed=80 + i, dt=0.03, drot_deg=0.3))
+    exts0 = np.array(exts0)
+    to_pose = lambda T: np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+    t0 = time.perf_counter()
+    types, points, coeffs, fi, ei = [], [], [], [], []
+    for i in range(4):
+        rel = to_pose(synth.pose_to_mat(frame0) @ synth.pose_to_mat(exts0[i]))          # T_pivot^-1 T_frame T_ext with T_pivot = I
+        for kind, feats, ty in ((mla.SURF, surf_b[i], 0), (mla.CORNER, corner_b[i], 1)):
+            ctx.features_set(kind, feats)
+            out_m = ctx.match_linearize(kind, rel, flags=mla.FLAG_CHECK_FOV, huber_delta=1.0, dense=False)
+            m = out_m["valid"].astype(bool)
+            types.append(np.full(m.sum(), ty, np.int32)); points.append(feats[m, :3].astype(np.float64)); coeffs.append(out_m["coeffs"][m])
+            fi.append(np.zeros(m.sum(), np.int32)); ei.append(np.full(m.sum(), i, np.int32))
+    tab = [np.concatenate(a) for a in (types, points, coeffs, fi, ei)]
+    t_match = 1e3 * (time.perf_counter() - t0)
+    t0 = time.perf_counter(); ctx.pure_odom_set(*tab); ctx.synchronize(); t_stage = 1e3 * (time.perf_counter() - t0)
+    D = 36
+    free = np.r_[6:12, 18:36]                                                             # the frame + extrinsics 1..3
+    def window_gn(neq, iters=5):
+        fr, ex = frame0.copy()[None, :], exts0.copy()
+        for _ in range(iters):
+            ne = neq(fr, ex)
+            step = np.zeros(D); step[free] = np.linalg.solve(ne["H"][np.ix_(free, free)], -ne["g"][free])
+            fr[0] = mla.pose_plus(fr[0], step[6:12])
+            for k in range(1, 4): ex[k] = mla.pose_plus(ex[k], step[12 + 6 * k:18 + 6 * k])
+        return fr, ex, ne
+    gpu_neq = lambda fr, ex: ctx.pure_odom_normal_eq(ident, fr, ex, huber_delta=1.0)
+    for _ in range(3): window_gn(gpu_neq)
+    ctx.synchronize(); t0 = time.perf_counter(); nrep = 20
+    for _ in range(nrep): fr_g, ex_g, ne_g = window_gn(gpu_neq)
+    ctx.synchronize(); t_gn = 1e3 * (time.perf_counter() - t0) / nrep
+    t0 = time.perf_counter()
+    for _ in range(200): ctx.pure_odom_normal_eq(ident, fr_g, ex_g, huber_delta=1.0)
+    t_ne = 1e3 * (time.perf_counter() - t0) / 200
+    cpu_neq = lambda fr, ex: O.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], ident, fr, ex, 1.0)
+    t0 = time.perf_counter(); fr_c, ex_c, ne_c = window_gn(cpu_neq); t_cpu = 1e3 * (time.perf_counter() - t0)
+    dH = float(np.abs(ne_g["H"] - ne_c["H"]).max() / np.abs(ne_c["H"]).max())
+    dpose = max(float(np.linalg.norm(fr_g[0][:3] - fr_c[0][:3])), max(float(np.linalg.norm(ex_g[k][:3] - ex_c[k][:3])) for k in range(1, 4)))
+    print(f"  coupled window system on the {preset} map: {len(tab[0])} factors, D = {D} (pivot | 1 frame | 4 extrinsics): GPU matching of 4 LiDARs x 2 kinds "
+          f"{t_match:.2f} ms (8 launches, host copies of validity + coefficients), table staging {t_stage:.2f} ms, one normal-equation pass {t_ne:.3f} ms, "
+          f"5 coupled GN iterations (device J^T J / J^T r + host 24-dim solve + Plus) {t_gn:.3f} ms vs CPU oracle accumulation {t_cpu:.1f} ms; "
+          f"max rel |dH| {dH:.1e}, pose agreement after 5 iterations {dpose:.1e} m")
     ctx.close()
