@@ -16,10 +16,6 @@ constexpr int TPB = 256;
 // lanes per query in the correspondence kernel: 8 when the launch fills the chip on its own (throughput: one wavefront serves 8
 // queries), 16 when it does not (latency: a frame's ~20k thinned features leave most SIMDs idle with 8, and twice the lanes halve
 // the candidate trips of the queries in dense cells, which set the kernel's duration)
-#ifndef MLH_KNN_WIDE_LIMIT
-#define MLH_KNN_WIDE_LIMIT 40000
-#endif
-constexpr int KNN_WIDE_LIMIT = MLH_KNN_WIDE_LIMIT;   // total queries above which every kind uses 8 lanes
 constexpr int KNN_LATENCY_LIMIT = 8192;   // total queries up to which every kind uses 16 lanes (the launch cannot fill the chip either way)
 #ifndef MLH_KNN_U
 #define MLH_KNN_U 4

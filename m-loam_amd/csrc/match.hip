@@ -843,7 +843,9 @@ __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const fl
 // lanes per query, per kind. A small launch (a 16-ring frame) leaves most SIMDs idle and is bound by the latency of its trips: 16 lanes.
 // A full frame keeps ~5 wavefronts per SIMD busy and is bound by VALU issue, where the per-query instruction count is what matters:
 // 8 lanes (twice the queries per wavefront) for a kind whose map is sparse enough that a query's candidates fit one or two 8-lane trips,
-// 16 lanes (pruned, near-cells-first) for a dense map, whose heavy queries would otherwise set the launch's duration.
+// 16 lanes (pruned, near-cells-first) for a dense map, whose heavy queries would otherwise set the launch's duration. Measured up to 229 k
+// queries per launch (un-thinned features) and on config 4's 52 k: the density rule beats "8 lanes for every kind" there too (44.5 vs 48.6 us,
+// 0.325 vs 0.356 ms), so there is no upper query count at which it is switched off.
 void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
 {
     long long queries = 0;
@@ -853,7 +855,7 @@ void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
         // ~9 of the 27 cells around a query on a surface are occupied, each about as full as the cell an average map point lives in
         // (pop_sq / n, size-biased: the clusters of a dense edge map count by their points, not by their cells)
         const double est27 = (mg.occupied > 0 && mg.n > 0) ? 9.0 * double(mg.pop_sq) / double(mg.n) : 1e9;
-        lanes[k] = queries > KNN_WIDE_LIMIT ? 8 : (queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16));
+        lanes[k] = queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16);
         if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) lanes[k] = ctx->knn_lanes_override;
         if (ctx->knn_lanes_override == 816) lanes[k] = k == 0 ? 8 : 16;
         if (!ctx->fused_disable) lanes[k] = 16;      // the single-launch kernel (opt-in, MLH_FUSED=1) is written for 16-lane groups
