@@ -193,6 +193,17 @@ int mlh_pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *po
                       const int32_t *frame_idx, const int32_t *ext_idx);
 int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                            double *residuals, double *jacobians);
+/* The same factor table built WITHOUT the host: mlh_pure_odom_begin starts an empty table; every mlh_pure_odom_add_matches matches the
+ * staged feature set of `kind` (mlh_features_set / mlh_downsample_current_scan, one LiDAR's features in that LiDAR's frame) against the
+ * resident map -- the window's local map in the pivot frame, estimator.cpp:1160-1268 -- at rel_pose = T_pivot^-1 T_frame T_ext
+ * (FeatureExtract::matchCornerFromMap / matchSurfFromMap as Estimator::optimizeMap calls them, estimator.cpp:700-780; k_neigh 5 or 10,
+ * MLH_FLAG_CHECK_FOV honoured) and appends one factor per valid correspondence: type = kind, point = the feature, coefficients = the
+ * fitted plane / line, s = 1.0, blocks (frame_idx, ext_idx). Nothing is copied back; the number of factors is returned by
+ * mlh_pure_odom_normal_eq (n_residuals). Such a table serves mlh_pure_odom_normal_eq only (its regions are padded to whole tiles);
+ * mlh_pure_odom_evaluate needs a host-staged one. */
+int mlh_pure_odom_begin(mlh_ctx *ctx);
+int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], int k_neigh, uint32_t flags, float min_match_sq_dis,
+                              float min_plane_dis, int frame_idx, int ext_idx);
 /* The normal equations of the COUPLED window problem those factors form (BASELINE config 4; Estimator::optimizeMap, estimator.cpp:687-848):
  * local parameters in para_ids order [pivot | frames 0..n_frames) | extrinsics 0..n_ext)], 6 each (PoseLocalParameterization::ComputeJacobian
  * = [I6; 0]), D = 6 (1 + n_frames + n_ext). What Estimator::evalResidual gets from problem.Evaluate (estimator.cpp:1577-1595) -- rows

@@ -128,6 +128,8 @@ def load_library():
     lib.mlh_map_rebuild.argtypes = [vp, ci]
     lib.mlh_map_info.argtypes = [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_set_voxel_member_order.argtypes = [vp, ci]
+    lib.mlh_pure_odom_begin.argtypes = [vp]
+    lib.mlh_pure_odom_add_matches.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, ci, ci]
     lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
     lib.mlh_features_set.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci]
     lib.mlh_features_set_block.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci]
@@ -157,7 +159,7 @@ EXPORTED_SYMBOLS = [
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
-    "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
+    "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -420,6 +422,17 @@ class Context:
         si = None if sqrt_info is None else np.ascontiguousarray(sqrt_info, np.float64)
         self._ck(self.lib.mlh_pure_odom_set(self.h, len(t), _p(t), _p(p), _p(c), _p(si) if si is not None else None, _p(fi), _p(ei)))
         self._n_odom = len(t)
+
+    def pure_odom_begin(self):
+        """start a device-resident LidarPureOdom factor table (filled by pure_odom_add_matches)"""
+        self._ck(self.lib.mlh_pure_odom_begin(self.h))
+        self._n_odom = 0
+
+    def pure_odom_add_matches(self, kind, rel_pose, frame_idx, ext_idx, k_neigh=5, flags=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+        """match the staged features of `kind` at rel_pose = T_pivot^-1 T_frame T_ext and append the valid ones as factors, all on the device"""
+        p = np.ascontiguousarray(rel_pose, np.float64)
+        self._ck(self.lib.mlh_pure_odom_add_matches(self.h, kind, _p(p), int(k_neigh), int(flags), float(min_match_sq_dis), float(min_plane_dis),
+                                                    int(frame_idx), int(ext_idx)))
 
     def pure_odom_evaluate(self, pivot, frames, exts, want_jacobians=True):
         pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7)

@@ -478,6 +478,28 @@ int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *f
     return pure_odom_normal_eq(ctx, pivot, frames, n_frames, exts, n_ext, huber_delta, JtJ, Jtr, cost, n_residuals);
 }
 
+int mlh_pure_odom_begin(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    return pure_odom_begin(ctx);
+}
+
+int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], int k_neigh, uint32_t flags, float min_match_sq_dis,
+                              float min_plane_dis, int frame_idx, int ext_idx)
+{
+    if (!ctx || kind < 0 || kind > 1 || !rel_pose) return MLH_ERR_INVALID;
+    if (k_neigh != 5 && k_neigh != 10) return fail(ctx, MLH_ERR_UNSUPPORTED, "N_NEIGH is 5 or 10");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, rel_pose))) return rc;
+    MatchArgs a;
+    a.kind_mask = 1 << kind; a.flags = flags & MLH_FLAG_CHECK_FOV; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
+    a.huber_delta = 0.0; a.cov_measurement_trace = 0.0; a.dense = false; a.pose_sel = 0; a.k_neigh[0] = k_neigh;
+    if ((rc = match_launch(ctx, a))) return rc;          // correspondences (validity + f32 coefficients) stay in HBM
+    return pure_odom_add_matches(ctx, kind, frame_idx, ext_idx);
+}
+
 int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                                    int trace_offset_bytes, const double pose_global[7], const double cov_global[36], const double *ext_poses,
                                    const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,

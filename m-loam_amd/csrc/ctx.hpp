@@ -183,7 +183,8 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     DevBuf perm, tile_group, partial, ne_out;
     int n_tiles = 0, group_ext = 1;
     bool tile_group_keyed = true;
-    std::vector<int> h_tile_group;
+    std::vector<int> h_tile_group, h_tile_frame, h_tile_ext;
+    bool device_built = false;   // table appended from match passes on the device (padded regions): normal equations only
 };
 
 constexpr int FUSE_BLOCKS = 64;           // workgroups per kind of the fusion kernel: each leaves one partial bounding box of what it appended (frontend.hip)
@@ -301,6 +302,8 @@ int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points
                   const int32_t *frame_idx, const int32_t *ext_idx);
 int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                        double *residuals, double *jacobians);
+int pure_odom_begin(mlh_ctx *ctx);
+int pure_odom_add_matches(mlh_ctx *ctx, int kind, int frame_idx, int ext_idx);
 int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
                         double *H, double *g, double *cost, int32_t *n_res);
 // voxelgrid.hip

@@ -284,13 +284,102 @@ int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points
             MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         O.h_tile_group = tgrp;
+        O.h_tile_frame.clear(); O.h_tile_ext.clear();
+        for (int t = 0; t < n_tiles; ++t) { O.h_tile_frame.push_back(tgrp[t] / ne); O.h_tile_ext.push_back(tgrp[t] % ne); }
+        O.tile_group_keyed = true;
     }
+    O.device_built = false;
+    return MLH_OK;
+}
+
+// ---- device-resident factor table: the correspondences a match pass left in HBM become LidarPureOdom factors without visiting the host
+// (Estimator::optimizeMap builds them from the features matched against the local map, estimator.cpp:700-780: point = the feature in its
+// LiDAR's frame, coefficients = the fitted plane / line in the pivot frame, s = 1.0). One call = one (frame, extrinsic) group of one kind:
+// its region of the table is a whole number of 256-factor tiles reserved from the staged feature count (no host round trip for the number
+// of valid ones); the valid correspondences are packed to the front IN FEATURE ORDER by a single-workgroup scan (deterministic), the rest
+// of the region is padding (perm = -1), which the normal-equation kernel skips.
+struct OdomAppend {
+    const float4 *feat;
+    const Corr *corr;
+    int m, type, frame, ext, base_slot, cap_slots;
+    double *tab;
+    int *idx, *perm;
+};
+__global__ __launch_bounds__(1024) void odom_append_kernel(OdomAppend P)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_running;
+    if (threadIdx.x == 0) s_running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < P.m; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const bool v = i < P.m && P.corr[i].valid != 0 && P.feat[i].w >= 0.f;
+        const unsigned long long b = __ballot(v);
+        const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = wsum[w]; if (w < wave) before += x; total += x; }
+        const int running = s_running;
+        if (v) {
+            const int slot = P.base_slot + running + before + in_wave;
+            const float4 f = P.feat[i];
+            const Corr c = P.corr[i];
+            double *t = P.tab + size_t(slot) * 10;
+            t[0] = double(f.x); t[1] = double(f.y); t[2] = double(f.z);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t[3 + k] = double(c.c[k]);
+            t[9] = 1.0;
+            P.idx[size_t(slot) * 3 + 0] = P.type; P.idx[size_t(slot) * 3 + 1] = P.frame; P.idx[size_t(slot) * 3 + 2] = P.ext;
+            P.perm[slot] = slot;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_running = running + total;
+        __syncthreads();
+    }
+    for (int q = s_running + threadIdx.x; q < P.cap_slots; q += 1024) P.perm[P.base_slot + q] = -1;
+}
+
+int pure_odom_begin(mlh_ctx *ctx)
+{
+    OdomSet &O = ctx->odom;
+    O.n = 0; O.n_tiles = 0; O.max_frame = 0; O.max_ext = 0; O.group_ext = 1; O.tile_group_keyed = false; O.device_built = true;
+    O.h_tile_group.clear(); O.h_tile_frame.clear(); O.h_tile_ext.clear();
+    return MLH_OK;
+}
+
+int pure_odom_add_matches(mlh_ctx *ctx, int kind, int frame_idx, int ext_idx)
+{
+    OdomSet &O = ctx->odom;
+    if (!O.device_built) return fail(ctx, MLH_ERR_STATE, "mlh_pure_odom_begin has not been called");
+    if (frame_idx < 0 || ext_idx < 0) return fail(ctx, MLH_ERR_INVALID, "negative block index");
+    FeatSet &f = ctx->feat[kind];
+    if (f.m <= 0 || !f.matched || f.n_blocks != 1) return fail(ctx, MLH_ERR_STATE, "a single-block match pass must have run for this kind");
+    hipStream_t st = ctx->stream;
+    const int cap_tiles = (f.m + 255) / 256, cap_slots = cap_tiles * 256, base_slot = O.n_tiles * 256, n_new = base_slot + cap_slots;
+    hipError_t e;
+    if ((e = O.tab.grow(sizeof(double) * 10 * size_t(n_new), sizeof(double) * 10 * size_t(base_slot), st)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc factor table", e);
+    if ((e = O.idx.grow(sizeof(int) * 3 * size_t(n_new), sizeof(int) * 3 * size_t(base_slot), st)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc factor table", e);
+    if ((e = O.perm.grow(sizeof(int) * size_t(n_new), sizeof(int) * size_t(base_slot), st)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc factor table", e);
+    OdomAppend P;
+    P.feat = f.pts.as<float4>(); P.corr = f.corr.as<Corr>(); P.m = f.m; P.type = kind; P.frame = frame_idx; P.ext = ext_idx;
+    P.base_slot = base_slot; P.cap_slots = cap_slots; P.tab = O.tab.as<double>(); P.idx = O.idx.as<int>(); P.perm = O.perm.as<int>();
+    hipLaunchKernelGGL(odom_append_kernel, dim3(1), dim3(1024), 0, st, P);
+    MLH_HIP(ctx, hipGetLastError());
+    O.n = n_new; O.n_tiles += cap_tiles;
+    O.max_frame = std::max(O.max_frame, frame_idx); O.max_ext = std::max(O.max_ext, ext_idx);
+    // group keys are kept as (frame, ext) pairs until the window's extrinsic count is known (pure_odom_normal_eq keys and uploads them)
+    for (int t = 0; t < cap_tiles; ++t) { O.h_tile_frame.push_back(frame_idx); O.h_tile_ext.push_back(ext_idx); }
+    O.tile_group_keyed = false;
     return MLH_OK;
 }
 
 int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                        double *residuals, double *jacobians)
 {
+    if (ctx->odom.device_built) return fail(ctx, MLH_ERR_STATE, "per-factor outputs need a host-staged table (mlh_pure_odom_set): a device-built one is padded");
     OdomSet &O = ctx->odom;
     if (O.n <= 0) return fail(ctx, MLH_ERR_STATE, "mlh_pure_odom_set has not been called");
     if (!pivot || !frames || !exts || !residuals || n_frames <= O.max_frame || n_ext <= O.max_ext)
@@ -348,14 +437,16 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
     int rc = odom_upload_poses(ctx, pivot, frames, n_frames, exts, n_ext, G.A);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    // the tile -> group table was built with the staged extrinsic count; re-key it for this call's n_ext when they differ
+    // tile -> group keys depend on this call's extrinsic count: (re)key and upload them when it changed or the table was built on the device
     if (O.group_ext != n_ext || !O.tile_group_keyed) {
-        std::vector<int> tg(O.h_tile_group.size());
-        for (size_t t = 0; t < tg.size(); ++t) tg[t] = (O.h_tile_group[t] / O.group_ext) * n_ext + (O.h_tile_group[t] % O.group_ext);
+        std::vector<int> tg(O.h_tile_frame.size());
+        for (size_t t = 0; t < tg.size(); ++t) tg[t] = O.h_tile_frame[t] * n_ext + O.h_tile_ext[t];
+        MLH_HIP(ctx, O.tile_group.ensure(sizeof(int) * std::max<size_t>(tg.size(), 1)));
         MLH_HIP(ctx, hipMemcpyAsync(O.tile_group.p, tg.data(), sizeof(int) * tg.size(), hipMemcpyHostToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
-        O.tile_group_keyed = (O.group_ext == n_ext);
+        O.group_ext = n_ext; O.tile_group_keyed = true;
     }
+    MLH_HIP(ctx, O.partial.ensure(sizeof(double) * NE_OUT * size_t(O.n_tiles)));
     MLH_HIP(ctx, O.ne_out.ensure(sizeof(double) * n_out));
     G.perm = O.perm.as<int>(); G.huber_delta = huber_delta; G.partial = O.partial.as<double>();
     hipLaunchKernelGGL(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, st, G);

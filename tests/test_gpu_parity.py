@@ -1177,6 +1177,77 @@ def test_scan_undistort_on_device(mla, orc, case16):
         c.close()
 
 
+def test_window_factor_table_built_on_the_device(mla, orc, synth, case16, feats16):
+    """Estimator::optimizeMap's factor construction without the host (estimator.cpp:700-780): every (frame, LiDAR, kind) is one match pass
+    against the resident local map at T_pivot^-1 T_frame T_ext whose valid correspondences are appended to the LidarPureOdom factor table in
+    HBM (mlh_pure_odom_begin / _add_matches). The coupled normal equations of that table must equal those of the table staged from the host
+    out of the SAME matches (oracle-checked validity + coefficients), for N_NEIGH 5 and 10, with CHECK_FOV."""
+    from scipy.spatial.transform import Rotation as Rot
+    c = mla.Context(0)
+    try:
+        to_pose = lambda T: np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        c.map_set(mla.SURF, case16["surf_map"])
+        c.map_set(mla.CORNER, case16["corner_map"])
+        oms, omc = orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"])
+        # two "LiDARs": the case's features split in halves, moved into each LiDAR's own frame with a made-up extrinsic
+        exts = np.array([[0, 0, 0, 0, 0, 0, 1.0], np.concatenate([[0.3, -0.2, 0.1], Rot.from_rotvec([0.02, -0.01, 0.4]).as_quat()])])
+        frame = case16["p0"]
+        pivot = np.array([0, 0, 0, 0, 0, 0, 1.0])
+        feats = {}
+        for kind, f in ((mla.SURF, feats16[0]), (mla.CORNER, feats16[1])):
+            half = len(f) // 2
+            for n, part in enumerate((f[:half], f[half:])):
+                Tinv = np.linalg.inv(synth.pose_to_mat(exts[n]))
+                q = part.copy()
+                q[:, :3] = synth.transform_points(part[:, :3], Tinv)             # body-frame feature -> LiDAR n's frame
+                feats[(kind, n)] = np.ascontiguousarray(q)
+        host_tab = [[], [], [], [], []]
+        c.pure_odom_begin()
+        for n in range(2):
+            rel = to_pose(synth.pose_to_mat(frame) @ synth.pose_to_mat(exts[n]))
+            kn = 5 if n == 0 else 10
+            for kind, ch, om in ((mla.SURF, "s", oms), (mla.CORNER, "c", omc)):
+                f = feats[(kind, n)]
+                c.features_set(kind, f)
+                c.pure_odom_add_matches(kind, rel, 0, n, k_neigh=kn, flags=mla.FLAG_CHECK_FOV)
+                v, co = om.match(ch, f, rel, n_neigh=kn, check_fov=True)              # what the device pass must have found
+                m = v.astype(bool)
+                assert m.sum() > 30
+                host_tab[0].append(np.full(m.sum(), kind, np.int32)); host_tab[1].append(f[m, :3].astype(np.float64)); host_tab[2].append(co[m])
+                host_tab[3].append(np.zeros(m.sum(), np.int32)); host_tab[4].append(np.full(m.sum(), n, np.int32))
+        got = c.pure_odom_normal_eq(pivot, frame[None, :], exts, huber_delta=1.0)
+        tab = [np.concatenate(a) for a in host_tab]
+        assert got["count"] == len(tab[0])                                           # exactly the oracle's valid correspondences, no padding counted
+        ref = orc.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], pivot, frame[None, :], exts, 1.0)
+        sc = float(np.abs(ref["H"]).max())
+        assert float(np.abs(got["H"] - ref["H"]).max()) <= 1e-9 * sc
+        assert float(np.abs(got["g"] - ref["g"]).max()) <= 1e-9 * float(np.abs(ref["g"]).max())
+        assert abs(got["cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+        again = c.pure_odom_normal_eq(pivot, frame[None, :], exts, huber_delta=1.0)
+        assert np.array_equal(again["H"], got["H"])                                  # deterministic packing and reduction
+        # the host-staged path on the same context afterwards gives the same system (different summation order: 1e-12)
+        c.pure_odom_set(*tab)
+        host = c.pure_odom_normal_eq(pivot, frame[None, :], exts, huber_delta=1.0)
+        assert float(np.abs(host["H"] - got["H"]).max()) <= 1e-12 * sc and host["count"] == got["count"]
+        # a device-built table AFTER a host-staged one starts from a clean slate (the tile bookkeeping of the host table must not leak in)
+        c.pure_odom_begin()
+        for n in range(2):
+            rel = to_pose(synth.pose_to_mat(frame) @ synth.pose_to_mat(exts[n]))
+            for kind in (mla.SURF, mla.CORNER):
+                c.features_set(kind, feats[(kind, n)])
+                c.pure_odom_add_matches(kind, rel, 0, n, k_neigh=5 if n == 0 else 10, flags=mla.FLAG_CHECK_FOV)
+        rebuilt = c.pure_odom_normal_eq(pivot, frame[None, :], exts, huber_delta=1.0)
+        assert np.array_equal(rebuilt["H"], got["H"]) and np.array_equal(rebuilt["g"], got["g"]) and rebuilt["count"] == got["count"]
+        # per-factor outputs are refused on a device-built table
+        c.pure_odom_begin()
+        c.features_set(mla.SURF, feats[(mla.SURF, 0)])
+        c.pure_odom_add_matches(mla.SURF, to_pose(synth.pose_to_mat(frame)), 0, 0)
+        with pytest.raises(mla.MlhError):
+            c.pure_odom_evaluate(pivot, frame[None, :], exts)
+    finally:
+        c.close()
+
+
 def test_window_local_map_building_blocks(ctx, mla, orc, case16):
     """Estimator::buildLocalMap (estimator.cpp:1160-1203) from its parts: every window frame's cloud into the pivot frame
     (pcl::transformPointCloud with the float 4x4: bit for bit), the union thinned by pcl::VoxelGrid<PointXYZI> (same voxels in the
