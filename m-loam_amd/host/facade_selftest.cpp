@@ -290,6 +290,26 @@ int main(int argc, char **argv)
             std::vector<int> sinfo(seg_info.scan_start_ind_);
             sinfo.insert(sinfo.end(), seg_info.scan_end_ind_.begin(), seg_info.scan_end_ind_.end());
             write_file(d + "out_seg_info.i32", sinfo);
+            // the window's factor table built on the device from two match passes (surf: frame 1 / LiDAR 0, corner: frame 1 / LiDAR 1), then the
+            // coupled normal equations over [pivot | 1 frame | 2 extrinsics] (D = 24, the hercules window)
+            {
+                PointICloud fs_i, fc_i;
+                for (size_t i = 0; i + 4 <= surf_f.size(); i += 4) { PointI q; q.x = surf_f[i]; q.y = surf_f[i + 1]; q.z = surf_f[i + 2]; q.intensity = surf_f[i + 3]; fs_i.push_back(q); }
+                for (size_t i = 0; i + 4 <= corner_f.size(); i += 4) { PointI q; q.x = corner_f[i]; q.y = corner_f[i + 1]; q.z = corner_f[i + 2]; q.intensity = corner_f[i + 3]; fc_i.push_back(q); }
+                WindowFactorTable table(dev);
+                table.addMatches(fs_i, 's', pose0, 1, 0, 5, true);
+                table.addMatches(fc_i, 'c', pose0, 1, 1, 10, true);
+                std::array<double, 7> piv = {0, 0, 0, 0, 0, 0, 1}, fr{}, e0 = piv, e1 = piv;
+                pose0.toParam(fr.data());
+                WindowNormalEquations wne;
+                evalWindowNormalEquations(dev, piv.data(), {fr}, {e0, e1}, 1.0, wne);
+                std::vector<double> wout(wne.JtJ);
+                wout.insert(wout.end(), wne.Jtr.begin(), wne.Jtr.end());
+                wout.push_back(wne.cost); wout.push_back(double(wne.n_residuals));
+                write_file(d + "out_window_ne.f64", wout);
+                setVoxelMemberOrderAsReference(dev, true);
+                setVoxelMemberOrderAsReference(dev, false);
+            }
             std::printf("round-2 facade: full-H features %d, logdet %.6f, selected %zu surf rows, %zu corner rows, segmented %zu -> %zu points\n", total_feat_num,
                         gf_deg_factor, sel_surf_feature_idx.size(), sel_corner_feature_idx.size(), raw_cloud.size(), seg_out.size());
         }

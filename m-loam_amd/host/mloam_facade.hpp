@@ -899,6 +899,36 @@ inline void evalWindowNormalEquations(Device &dev, const double pivot[7], const 
     ne.n_residuals = n;
 }
 
+// The factor table of Estimator::optimizeMap built ON THE DEVICE (estimator.cpp:700-780): in place of
+//     f_extract_.matchCornerFromMap / matchSurfFromMap(kdtree, local_map, features_of(frame i, LiDAR n), pose_local, all_features, ...)
+//     for (feature : all_features) problem.AddResidualBlock(new LidarPureOdom{PlaneNorm,Edge}Factor(point, coeffs, 1.0), loss, para_pose_[0], para_pose_[i - pivot], para_ex_pose_[n])
+// one addMatches per (frame, LiDAR, kind): the match pass runs against the resident local map (MapIndex::setInputCloud) at
+// pose_local = T_pivot^-1 T_i T_ext and its valid correspondences become factors in HBM; evalWindowNormalEquations then reduces them.
+class WindowFactorTable {
+public:
+    explicit WindowFactorTable(Device &dev) : dev_(dev) { dev_.check(mlh_pure_odom_begin(dev_.ctx())); }
+    // frame: 1..W as in LidarPureOdomBatchFactor::add; laser: 0..L-1; type 's' / 'c'
+    template <typename PointT>
+    void addMatches(const PointCloud<PointT> &features_in_lidar_frame, char type, const Pose &pose_local, int frame, int laser, size_t n_neigh = 5, bool check_fov = true)
+    {
+        const int m = (int)features_in_lidar_frame.size();
+        if (m == 0) return;
+        const int kind = type == 's' ? MLH_SURF : MLH_CORNER;
+        dev_.check(mlh_features_set(dev_.ctx(), kind, features_in_lidar_frame.points.data(), (int)sizeof(PointT), m, point_traits<PointT>::intensity_off,
+                                    point_traits<PointT>::cov_off, MLH_MEM_HOST));
+        double pose[7];
+        pose_local.toParam(pose);
+        const Params &P = params();
+        dev_.check(mlh_pure_odom_add_matches(dev_.ctx(), kind, pose, (int)n_neigh, check_fov ? MLH_FLAG_CHECK_FOV : 0u, P.MIN_MATCH_SQ_DIS, P.MIN_PLANE_DIS, frame - 1, laser));
+    }
+private:
+    Device &dev_;
+};
+
+// every voxel filter of the device walks a voxel's members in the order libstdc++'s unstable std::sort leaves them, as the reference's filters do
+// (voxel_grid_covariance_mloam_impl.hpp:227) -- exact LiDAR ids in mixed voxels of fused clouds, at the price of a host pass per call; off by default
+inline void setVoxelMemberOrderAsReference(Device &dev, bool on) { dev.check(mlh_set_voxel_member_order(dev.ctx(), on ? 1 : 0)); }
+
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
     std::vector<mlh_iter_stat> outer;   // one per outer iteration: matched counts, H, eigenvalues, LM iterations, costs

@@ -88,6 +88,21 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
         i = int(row[0])
         rr, JJ = orc.factor_eval("c", feats16[1][i, :3].astype(np.float64), cc_[i], 0.0075, case16["p0"])
         assert abs(row[1] - rr) < 1e-12 and np.allclose(row[2:], JJ, rtol=1e-11, atol=1e-12)
+    # WindowFactorTable + evalWindowNormalEquations: surf matched as (frame 1, LiDAR 0, N_NEIGH 5), corner as (frame 1, LiDAR 1, N_NEIGH 10), CHECK_FOV
+    wn = np.fromfile(os.path.join(d, "out_window_ne.f64"), np.float64)
+    D = 24
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    tabs = [[], [], [], [], []]
+    for ch, om_cloud, f, kn, lid in (("s", case16["surf_map"], feats16[0], 5, 0), ("c", case16["corner_map"], feats16[1], 10, 1)):
+        v_w, co_w = orc.Map(om_cloud).match(ch, f, case16["p0"], n_neigh=kn, check_fov=True)
+        m_w = v_w.astype(bool)
+        tabs[0].append(np.full(m_w.sum(), 0 if ch == "s" else 1, np.int32)); tabs[1].append(f[m_w, :3].astype(np.float64)); tabs[2].append(co_w[m_w])
+        tabs[3].append(np.zeros(m_w.sum(), np.int32)); tabs[4].append(np.full(m_w.sum(), lid, np.int32))
+    tabs = [np.concatenate(a) for a in tabs]
+    wref = orc.pure_odom_normal_eq(tabs[0], tabs[1], tabs[2], None, tabs[3], tabs[4], ident, case16["p0"][None, :], np.stack([ident, ident]), 1.0)
+    assert int(wn[D * D + D + 1]) == wref["count"] == len(tabs[0])
+    assert float(np.abs(wn[:D * D].reshape(D, D) - wref["H"]).max()) <= 1e-9 * float(np.abs(wref["H"]).max())
+    assert float(np.abs(wn[D * D:D * D + D] - wref["g"]).max()) <= 1e-9 * float(np.abs(wref["g"]).max())
     # ImageSegmenter facade
     seg = orc.segment_cloud(raw, orc.seg_params())
     so = np.fromfile(os.path.join(d, "out_seg_cloud.f32"), np.float32).reshape(-1, 4)
