@@ -75,23 +75,25 @@ __host__ __device__ inline void pose_plus(const double *x, const double *delta, 
 }
 
 // ------------------------------------------------------------------ 3x3 symmetric eigen-decomposition, f32
+// Eigen's JacobiRotation::makeGivens (real case), branch-free: the lanes of a wavefront disagree on |p| > |q| all the time, and with branches
+// the wavefront paid for both sides (two divisions and a square root each). One quotient, one root, one reciprocal serve both cases with
+// exactly the operands and roundings the taken branch of the reference would use:
+//   |p| > |q|:  t = q / p, u = +-sqrt(1 + t^2) (sign of p), c = 1 / u,  s = -t * c
+//   otherwise:  t = p / q, u = +-sqrt(1 + t^2) (sign of q), s = -1 / u, c = -t * s        (-1 / u == -(1 / u) bit for bit)
+// q == 0 and p == 0 are patched in afterwards (their quotients, possibly NaN, are discarded).
 __device__ inline void givens_f(float p, float q, float &c, float &s)
 {
+    const bool big_p = fabsf(p) > fabsf(q);
+    const float num = big_p ? q : p, den = big_p ? p : q;
+    const float t = num / den;
+    float u = sqrtf(1.f + t * t);
+    if (den < 0.f) u = -u;
+    const float r = 1.f / u;
+    const float s_b = -r;
+    c = big_p ? r : -t * s_b;
+    s = big_p ? -t * r : s_b;
+    if (p == 0.f) { c = 0.f; s = q < 0.f ? 1.f : -1.f; }
     if (q == 0.f) { c = p < 0.f ? -1.f : 1.f; s = 0.f; }
-    else if (p == 0.f) { c = 0.f; s = q < 0.f ? 1.f : -1.f; }
-    else if (fabsf(p) > fabsf(q)) {
-        float t = q / p;
-        float u = sqrtf(1.f + t * t);
-        if (p < 0.f) u = -u;
-        c = 1.f / u;
-        s = -t * c;
-    } else {
-        float t = p / q;
-        float u = sqrtf(1.f + t * t);
-        if (q < 0.f) u = -u;
-        s = -1.f / u;
-        c = -t * s;
-    }
 }
 
 __device__ inline float hypot_scaled_f(float x, float y)

@@ -480,15 +480,11 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     }
 }
 
-template <int K>
-__device__ __forceinline__ bool fit_feature(const KParams &P, const KindP &Kd, int kind, int f, float (&coef)[6])
+// v: the feature's neighbour records {x, y, z, sq-dist}, already in registers (the kernel requests them together with the feature itself)
+template <int K, int KV>
+__device__ __forceinline__ bool fit_feature(const KParams &P, int kind, const float4 (&v)[KV], float (&coef)[6])
 {
-    const float4 *nb = Kd.nbr + size_t(f) * Kd.nbr_stride;
-    // all K neighbours are requested before the acceptance test looks at the last one: one memory round trip, not two (the few
-    // bytes wasted on rejected features are nothing next to a round trip on this kernel's critical path)
-    float4 v[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) v[j] = nb[j];
+    static_assert(K <= KV, "neighbour buffer too small");
     if (!(v[K - 1].w < P.min_match_sq_dis)) return false;     // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
     float ax[K], ay[K], az[K];
 #pragma unroll
@@ -523,13 +519,24 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4 fp = make_float4(0.f, 0.f, 0.f, -1.f);
     if (f < K.m) {
+        // ONE memory round trip before the fit: the feature and all of its neighbour records are requested together (the records sit at
+        // f * stride whatever the feature turns out to be; what is fetched for a padding slot or a feature another rank owns is discarded).
+        // The map-frame position is only needed by the ownership planes of a sharded map and by the field-of-view gate: an ordinary
+        // single-GPU launch skips the f64 transform here altogether (uniform branch).
         fp = K.feat[f];
-        float sx, sy, sz;
-        associate_to_map(q, t, fp, sx, sy, sz);
+        float4 nbv[KMAX];
+        const float4 *nb = K.nbr + size_t(f) * K.nbr_stride;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) nbv[j] = nb[j];
+        MLH_STAGE(gtile, 5);
+        const bool need_pos = P.has_lo || P.has_hi || (P.flags & MLH_FLAG_CHECK_FOV);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        if (need_pos) associate_to_map(q, t, fp, sx, sy, sz);
         if (fp.w >= 0.f && owns(P, f, sx, sy, sz)) {
-            valid = (KMAX == 10 && P.kb[b] == 10) ? fit_feature<KMAX>(P, K, kind, f, coef) : fit_feature<5>(P, K, kind, f, coef);
+            valid = (KMAX == 10 && P.kb[b] == 10) ? fit_feature<KMAX, KMAX>(P, kind, nbv, coef) : fit_feature<5, KMAX>(P, kind, nbv, coef);
             if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, sx, sy, sz);
         }
+        MLH_STAGE(gtile, 6);
         Corr c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) c.c[i] = valid ? coef[i] : 0.f;

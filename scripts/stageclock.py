@@ -28,7 +28,8 @@ n_tiles = (len(surf) + 255) // 256 + (len(corner) + 255) // 256
 buf = (C.c_ulonglong * (n_tiles * 8))()
 lib.mlh_debug_stage_clock.argtypes = [C.c_void_p, C.c_int]
 assert lib.mlh_debug_stage_clock(buf, n_tiles * 8) == 0
-t = np.frombuffer(buf, np.uint64).reshape(n_tiles, 8).astype(np.int64)[:, :5]
+tall = np.frombuffer(buf, np.uint64).reshape(n_tiles, 8).astype(np.int64)
+t = tall[:, :5]
 t0 = t[:, 0].min()
 rel = (t - t0) * 0.01     # us
 print("tiles", n_tiles, "surf", len(surf), "corner", len(corner))
@@ -36,6 +37,11 @@ names = ["start", "fit done", "eval done", "reduce done", "finish done"]
 for i, nm in enumerate(names):
     print(f"{nm:12s} min {rel[:, i].min():7.2f} med {np.median(rel[:, i]):7.2f} max {rel[:, i].max():7.2f} us")
 d = np.diff(rel, axis=1)
+sub = (tall[:, 5:7] - t0) * 0.01
+n_surf_tiles = (len(surf) + 255) // 256
+for nm_, sl in (("surf tiles", slice(0, n_surf_tiles)), ("corner tiles", slice(n_surf_tiles, n_tiles))):
+    a = rel[sl, 0]; b = sub[sl, 0]; c = sub[sl, 1]; d_ = rel[sl, 1]
+    print(f"{nm_}: start->loads arrived med {np.median(b - a):.2f} max {(b - a).max():.2f}; loads->fit+gates done med {np.median(c - b):.2f} max {(c - b).max():.2f}; ->corr stored med {np.median(d_ - c):.2f} us")
 for i, nm in enumerate(["fit", "eval", "reduce", "finish"]):
     print(f"stage {nm:7s} med {np.median(d[:, i]):6.2f} max {d[:, i].max():6.2f} us")
 buf2 = (C.c_ulonglong * (4096 * 8))()
