@@ -589,8 +589,10 @@ __device__ __forceinline__ double reduce16_wave(double (&v)[16])
             v[i] = keep + __shfl_xor(send, (MASK));                        \
         }                                                                  \
     }
-    MLH_RED_STEP(8, 32)
-    MLH_RED_STEP(4, 16)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = swap_add<true>(v[i], v[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = swap_add<false>(v[i], v[i + 4]);
     MLH_RED_STEP(2, 8)
     MLH_RED_STEP(1, 4)
 #undef MLH_RED_STEP

@@ -12,6 +12,26 @@ __device__ __forceinline__ int xcd_tile(int n_tiles)
     return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 }
 
+// One exchange of the transposed butterfly across the wavefront halves (SWAP32) or across neighbouring 16-lane rows (SWAP16), with gfx950's
+// v_permlane32_swap / v_permlane16_swap: given x = the value this half keeps if it is the lower one and y = the value it keeps if it is the
+// upper one, the swap leaves (own x, partner's x) in the lower lanes and (partner's y, own y) in the upper lanes of the two result registers,
+// so ONE add finishes the exchange -- no LDS round trip (ds_bpermute) and no per-lane selects (the keep / send pair costs four v_cndmask
+// per double). Same operands as keep + shfl_xor(send), so the sums are bit-identical.
+template <bool SWAP32>
+__device__ __forceinline__ double swap_add(double x, double y)
+{
+    const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x), yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    if constexpr (SWAP32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+}
+
 // acc: this lane's 32 values (entries 29..31 zero). 256 threads. partial_out[0..31]: the workgroup's sums; slots 29 / 30 mirror the
 // count for feature kind 0 / 1.
 __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double *lds_red /*4*32*/, double *__restrict__ partial_out)
@@ -29,8 +49,10 @@ __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double
             acc[i] = keep + __shfl_xor(send, (MASK));                      \
         }                                                                  \
     }
-    MLH_RED_STEP(16, 32)
-    MLH_RED_STEP(8, 16)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = swap_add<true>(acc[i], acc[i + 16]);      // partner = lane ^ 32
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = swap_add<false>(acc[i], acc[i + 8]);        // partner = lane ^ 16
     MLH_RED_STEP(4, 8)
     MLH_RED_STEP(2, 4)
     MLH_RED_STEP(1, 2)
