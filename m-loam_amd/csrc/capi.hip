@@ -281,6 +281,7 @@ void mlh_destroy(mlh_ctx *ctx)
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
     if (ctx->select_host) (void)hipHostFree(ctx->select_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

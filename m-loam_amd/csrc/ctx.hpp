@@ -60,8 +60,6 @@ struct HostPublish {
     double x[7];
     double xb[8][7];
     long long done;          // SolverState::done at publication (the LM driver polls it)
-    long long aux[2];        // map staging: occupied cells of the two indices just built
-    long long aux2[2];       //              and the sums of their squared cell populations
     unsigned long long seq;
 };
 
@@ -236,6 +234,7 @@ struct mlh_ctx {
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
+    void *h_occ = nullptr;   // pinned mirror of the two maps' occupancy totals (grid.hip): {cells, squares} per kind, written behind every index build
     unsigned long long publish_seq = 0;
     mlh::DevBuf uct_buf;     // point-uncertainty scratch
     mlh::VoxBuf vox;

@@ -403,25 +403,22 @@ __device__ __forceinline__ void occ_total(long long *occ, int n_part, long long 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void occ_total_kernel(long long *occ0, int n0, long long *occ1, int n1)
+// the fit flags go to the host as soon as the clouds are packed (the index build that follows does not change them)
+__global__ void publish_flag_kernel(int *oob, HostPublish *h, unsigned long long seq)
 {
-    __shared__ long long lds[8];
-    if (occ0) occ_total(occ0, n0, lds);
-    if (occ1) occ_total(occ1, n1, lds);
-}
-
-__global__ __launch_bounds__(256) void publish_flag_kernel(int *oob, long long *occ0, int n0, long long *occ1, int n1, HostPublish *h, unsigned long long seq)
-{
-    __shared__ long long lds[8];
-    if (occ0) occ_total(occ0, n0, lds);
-    if (occ1) occ_total(occ1, n1, lds);
     if (threadIdx.x == 0) {
         h->done = *oob;          // the record's `done` slot carries the flag word here
-        h->aux[0] = occ0 ? occ0[0] : 0; h->aux2[0] = occ0 ? occ0[1] : 0;
-        h->aux[1] = occ1 ? occ1[0] : 0; h->aux2[1] = occ1 ? occ1[1] : 0;
         *oob = 0;
         __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// occupancy totals of the builds just enqueued -> occ[0..1] and a pinned host mirror nobody waits for (read at the next staging call)
+__global__ __launch_bounds__(256) void occ_publish_kernel(long long *occ0, int n0, long long *host0, long long *occ1, int n1, long long *host1)
+{
+    __shared__ long long lds[8];
+    if (occ0) { occ_total(occ0, n0, lds); if (threadIdx.x == 0) { host0[0] = occ0[0]; host0[1] = occ0[1]; } }
+    if (occ1) { occ_total(occ1, n1, lds); if (threadIdx.x == 0) { host1[0] = occ1[0]; host1[1] = occ1[1]; } }
 }
 
 // Stages 1 or 2 clouds (device pointers to strided records) and builds their indices. When a kind's grid geometry from an earlier call
@@ -456,9 +453,21 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         J.hi[2] = reuse ? g.oz + float(g.nz) * g.h : INFINITY;
     }
     hipLaunchKernelGGL(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
+    // the fit flags are final once the clouds are packed: they leave for the host NOW, and the optimistic index build of the kinds whose
+    // geometry is reused is enqueued behind them -- the host learns the outcome (and can go on enqueueing the frame's solver launches)
+    // while the GPU is still building the index, instead of the GPU idling through the host's reaction time after the build
+    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
     MLH_HIP(ctx, hipGetLastError());
+    if (!ctx->h_occ) {
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_occ, sizeof(long long) * 4, hipHostMallocDefault));
+        std::memset(ctx->h_occ, 0, sizeof(long long) * 4);
+    }
+    long long *h_occ = static_cast<long long *>(ctx->h_occ);
+    // occupancy statistics (they only steer the lanes-per-query choice): what the previous staging call's builds left in the pinned mirror
+    for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k)) && h_occ[2 * kinds[k]] > 0) {
+        grids[k]->occupied = int(h_occ[2 * kinds[k]]); grids[k]->pop_sq = h_occ[2 * kinds[k] + 1];
+    }
     if (need_bounds != ((1 << n_maps) - 1)) {
-        // optimistic build of the kinds whose geometry is reused, then the flags
         MapGrid *fast[2];
         int nf = 0;
         for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) {
@@ -469,15 +478,13 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         }
         int rc = grid_build_grids(ctx, fast, nf, false);
         if (rc) return rc;
-    }
-    {
-        long long *po[2] = {nullptr, nullptr};
+        long long *po[2] = {nullptr, nullptr}, *ph[2] = {nullptr, nullptr};
         int pn[2] = {0, 0};
-        for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) { po[k] = grids[k]->occ.as<long long>(); pn[k] = grids[k]->occ_parts; }
-        hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(256), 0, st, G.oob, po[0], pn[0], po[1], pn[1], pub, seq);
+        for (int q = 0; q < nf; ++q) { po[q] = fast[q]->occ.as<long long>(); pn[q] = fast[q]->occ_parts; ph[q] = h_occ + 2 * int(fast[q] - ctx->map); }
+        hipLaunchKernelGGL(occ_publish_kernel, dim3(1), dim3(256), 0, st, po[0], pn[0], ph[0], po[1], pn[1], ph[1]);
+        MLH_HIP(ctx, hipGetLastError());
     }
-    MLH_HIP(ctx, hipGetLastError());
-    // spin on the pinned record (every launch above has completed when the sequence number arrives)
+    // spin on the pinned record (pack + fit check have completed when the sequence number arrives; the builds may still be running)
     {
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -493,7 +500,6 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         }
     }
     const int oob = int(pub->done);
-    for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) { grids[k]->occupied = int(pub->aux[k]); grids[k]->pop_sq = pub->aux2[k]; }
     for (int k = 0; k < n_maps; ++k) if (oob & (1 << k)) need_bounds |= 1 << k;
     if (need_bounds) {
         MapGrid *slow[2];
@@ -502,8 +508,8 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         int rc = grid_build_grids(ctx, slow, ns, true);
         if (rc) return rc;
         long long hocc[2][2] = {{0, 0}, {0, 0}};
-        hipLaunchKernelGGL(occ_total_kernel, dim3(1), dim3(256), 0, st, slow[0]->occ.as<long long>(), slow[0]->occ_parts, ns > 1 ? slow[1]->occ.as<long long>() : (long long *)nullptr,
-                           ns > 1 ? slow[1]->occ_parts : 0);
+        hipLaunchKernelGGL(occ_publish_kernel, dim3(1), dim3(256), 0, st, slow[0]->occ.as<long long>(), slow[0]->occ_parts, h_occ + 2 * int(slow[0] - ctx->map),
+                           ns > 1 ? slow[1]->occ.as<long long>() : (long long *)nullptr, ns > 1 ? slow[1]->occ_parts : 0, ns > 1 ? h_occ + 2 * int(slow[1] - ctx->map) : (long long *)nullptr);
         for (int k = 0; k < ns; ++k) MLH_HIP(ctx, hipMemcpyAsync(hocc[k], slow[k]->occ.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
         for (int k = 0; k < ns; ++k) { slow[k]->occupied = int(hocc[k][0]); slow[k]->pop_sq = hocc[k][1]; }
