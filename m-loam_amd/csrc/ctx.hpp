@@ -111,6 +111,7 @@ struct MapGrid {
     int n = 0;
     bool want_occ = false;     // the index build also collects the occupancy statistics below (the mapper's two maps)
     int occ_parts = 0;         // per-workgroup partials in `occ`
+    long long *occ_host = nullptr;   // pinned mirror of the totals (owned by the context)
     int occupied = 0;          // non-empty cells of the current index (0: not measured)
     long long pop_sq = 0;      // sum over the cells of population^2: pop_sq / n = the population of the cell an average map POINT lives in,
                                // which is what a query near the map sees (the density the query kernels tune to)

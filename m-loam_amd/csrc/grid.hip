@@ -80,6 +80,8 @@ struct GridJob {
     int *cell_next;        // the twin array, cleared here for the NEXT build
     int *rank;             // n: arrival rank of each point inside its cell
     int *block_sums;
+    long long *occ_host;   // pinned host mirror of occ[0..1] (or null)
+    int occ_parts;         // partials behind occ[2]
     long long *occ;        // occupancy statistics of this build (null: not wanted): [0] non-empty cells, [1] sum of squared cell populations,
                            // then one (cells, squares) partial per scanning workgroup
     int n;
@@ -210,6 +212,19 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     }
 }
 
+// sums the per-workgroup occupancy partials of one index build into occ[0..1] (256 threads, all of them)
+__device__ __forceinline__ void occ_total(long long *occ, int n_part, long long *lds)
+{
+    long long nz = 0, sq = 0;
+    for (int i = threadIdx.x; i < n_part; i += 256) { nz += occ[2 + 2 * i]; sq += occ[3 + 2 * i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { nz += __shfl_xor(nz, off); sq += __shfl_xor(sq, off); }
+    if ((threadIdx.x & 63) == 0) { lds[2 * (threadIdx.x >> 6)] = nz; lds[2 * (threadIdx.x >> 6) + 1] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) { occ[0] = lds[0] + lds[2] + lds[4] + lds[6]; occ[1] = lds[1] + lds[3] + lds[5] + lds[7]; }
+    __syncthreads();
+}
+
 // large grids only: exclusive scan of the chunk totals
 __global__ __launch_bounds__(256) void scan_sums_kernel(GridJobs G)
 {
@@ -247,7 +262,14 @@ __global__ __launch_bounds__(256) void scan_add_kernel(GridJobs G)
         __syncthreads();
         add = (lds[0] + lds[1]) + (lds[2] + lds[3]);
     }
-    if (b == 0) return;                                                  // first chunk: offset 0
+    if (b == 0) {                                                        // first chunk: offset 0 -- the idle workgroup totals the occupancy statistics
+        if (J.occ) {
+            __shared__ long long lds_occ[8];
+            occ_total(J.occ, J.occ_parts, lds_occ);
+            if (threadIdx.x == 0 && J.occ_host) { J.occ_host[0] = J.occ[0]; J.occ_host[1] = J.occ[1]; }   // pinned mirror, read by the NEXT staging call
+        }
+        return;
+    }
     int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
     const int base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     const int n_pad = ((J.ncell + 3) / 4) * 4;
@@ -324,7 +346,7 @@ static GridJob make_job(MapGrid &g)
     g.cur = dst;
     g.twin_clean = true;
     J.cell_start = g.cells(dst); J.cell_next = g.cells(1 - dst); J.rank = g.cell_id.as<int>();
-    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.block_sums = g.block_sums.as<int>(); J.occ = g.want_occ ? g.occ.as<long long>() : nullptr;
+    J.raw = g.raw.as<float4>(); J.sorted = g.sorted.as<float4>(); J.block_sums = g.block_sums.as<int>(); J.occ = g.want_occ ? g.occ.as<long long>() : nullptr; J.occ_parts = g.occ_parts; J.occ_host = g.want_occ ? g.occ_host : nullptr;
     J.n = g.n; J.ncell = int(g.ncell); J.ox = g.ox; J.oy = g.oy; J.oz = g.oz; J.inv_h = g.inv_h; J.nx = g.nx; J.ny = g.ny; J.nz = g.nz;
     J.nb_pts = std::min((g.n + 255) / 256, 4096);
     J.nb_scan = int((g.ncell + SCAN_CHUNK) / SCAN_CHUNK);
@@ -390,19 +412,6 @@ __global__ __launch_bounds__(256) void pack_check_kernel(PackJobs G)
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(G.oob, 1 << job);
 }
 
-// sums the per-wavefront occupancy partials of one index build into occ[0..1] (one workgroup of 256)
-__device__ __forceinline__ void occ_total(long long *occ, int n_part, long long *lds)
-{
-    long long nz = 0, sq = 0;
-    for (int i = threadIdx.x; i < n_part; i += 256) { nz += occ[2 + 2 * i]; sq += occ[3 + 2 * i]; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { nz += __shfl_xor(nz, off); sq += __shfl_xor(sq, off); }
-    if ((threadIdx.x & 63) == 0) { lds[2 * (threadIdx.x >> 6)] = nz; lds[2 * (threadIdx.x >> 6) + 1] = sq; }
-    __syncthreads();
-    if (threadIdx.x == 0) { occ[0] = lds[0] + lds[2] + lds[4] + lds[6]; occ[1] = lds[1] + lds[3] + lds[5] + lds[7]; }
-    __syncthreads();
-}
-
 // the fit flags go to the host as soon as the clouds are packed (the index build that follows does not change them)
 __global__ void publish_flag_kernel(int *oob, HostPublish *h, unsigned long long seq)
 {
@@ -411,14 +420,6 @@ __global__ void publish_flag_kernel(int *oob, HostPublish *h, unsigned long long
         *oob = 0;
         __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-// occupancy totals of the builds just enqueued -> occ[0..1] and a pinned host mirror nobody waits for (read at the next staging call)
-__global__ __launch_bounds__(256) void occ_publish_kernel(long long *occ0, int n0, long long *host0, long long *occ1, int n1, long long *host1)
-{
-    __shared__ long long lds[8];
-    if (occ0) { occ_total(occ0, n0, lds); if (threadIdx.x == 0) { host0[0] = occ0[0]; host0[1] = occ0[1]; } }
-    if (occ1) { occ_total(occ1, n1, lds); if (threadIdx.x == 0) { host1[0] = occ1[0]; host1[1] = occ1[1]; } }
 }
 
 // Stages 1 or 2 clouds (device pointers to strided records) and builds their indices. When a kind's grid geometry from an earlier call
@@ -463,6 +464,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         std::memset(ctx->h_occ, 0, sizeof(long long) * 4);
     }
     long long *h_occ = static_cast<long long *>(ctx->h_occ);
+    for (int k = 0; k < n_maps; ++k) grids[k]->occ_host = h_occ + 2 * kinds[k];
     // occupancy statistics (they only steer the lanes-per-query choice): what the previous staging call's builds left in the pinned mirror
     for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k)) && h_occ[2 * kinds[k]] > 0) {
         grids[k]->occupied = int(h_occ[2 * kinds[k]]); grids[k]->pop_sq = h_occ[2 * kinds[k] + 1];
@@ -478,11 +480,6 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         }
         int rc = grid_build_grids(ctx, fast, nf, false);
         if (rc) return rc;
-        long long *po[2] = {nullptr, nullptr}, *ph[2] = {nullptr, nullptr};
-        int pn[2] = {0, 0};
-        for (int q = 0; q < nf; ++q) { po[q] = fast[q]->occ.as<long long>(); pn[q] = fast[q]->occ_parts; ph[q] = h_occ + 2 * int(fast[q] - ctx->map); }
-        hipLaunchKernelGGL(occ_publish_kernel, dim3(1), dim3(256), 0, st, po[0], pn[0], ph[0], po[1], pn[1], ph[1]);
-        MLH_HIP(ctx, hipGetLastError());
     }
     // spin on the pinned record (pack + fit check have completed when the sequence number arrives; the builds may still be running)
     {
@@ -508,8 +505,6 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         int rc = grid_build_grids(ctx, slow, ns, true);
         if (rc) return rc;
         long long hocc[2][2] = {{0, 0}, {0, 0}};
-        hipLaunchKernelGGL(occ_publish_kernel, dim3(1), dim3(256), 0, st, slow[0]->occ.as<long long>(), slow[0]->occ_parts, h_occ + 2 * int(slow[0] - ctx->map),
-                           ns > 1 ? slow[1]->occ.as<long long>() : (long long *)nullptr, ns > 1 ? slow[1]->occ_parts : 0, ns > 1 ? h_occ + 2 * int(slow[1] - ctx->map) : (long long *)nullptr);
         for (int k = 0; k < ns; ++k) MLH_HIP(ctx, hipMemcpyAsync(hocc[k], slow[k]->occ.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
         for (int k = 0; k < ns; ++k) { slow[k]->occupied = int(hocc[k][0]); slow[k]->pop_sq = hocc[k][1]; }
