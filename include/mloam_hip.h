@@ -243,8 +243,9 @@ int mlh_compound_pose_with_cov(const double pose_1[7], const double cov_1[36], c
 int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, float min_match_sq_dis, int mem);
 /* the two setInputCloud calls of a mapper frame (lidar_mapper_keyframe.cpp:433-434) in one set of launches and one host hand-shake.
  * The grid box of a kind is laid out with a margin when it is first computed; while later clouds keep fitting it (the local map is a
- * sliding keyframe window) a call costs pack + index build only -- a cloud that has outgrown the box is detected on the device and
- * takes the bounds pass again. Results never depend on which way a call went (the grid is an acceleration structure only). */
+ * sliding keyframe window) a call costs pack + index build only, and returns as soon as the pack pass has reported that the clouds fit (the index build is still
+ * running on the context's stream then; every later call is ordered behind it) -- a cloud that has outgrown the box is detected on the
+ * device and takes the bounds pass again. Results never depend on which way a call went (the grid is an acceleration structure only). */
 int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                      float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);
