@@ -1,5 +1,7 @@
 """Edge cases of the HIP path against the oracle: skipped / ragged / very long rings, tiny and non-tile-multiple feature sets,
 queries with no neighbours, maps too small to match, call-order and argument errors through the C-ABI status codes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -287,3 +289,49 @@ def test_extract_with_non_finite_points(mla, orc, case16):
     for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
         assert np.array_equal(got[k], ref[k]), k
     assert not np.any(got["label"][nan_got] != 0)          # a NaN curvature is never an edge nor a flat point
+
+
+@pytest.mark.gpu
+def test_knn_with_exact_distance_ties(mla, orc):
+    """Exact ties in the squared distance -- duplicated map points, and queries at the centres of a lattice whose points are exactly
+    representable -- are where a k-NN's order is a convention: FLANN's result order among equal distances is implementation-defined, the
+    oracle's kd-tree and the HIP search both order by (distance, map index). This pins the two on that rule (indices AND order, bit-equal
+    distances), with ties straddling the K-th place, for both lane widths of the search and through the matching path."""
+    rng = np.random.default_rng(3)
+    g = np.arange(-6, 7, dtype=np.float32) * 0.25                       # 13^3 lattice, spacing exactly representable
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    cloud = np.concatenate([lat, lat[rng.choice(len(lat), 400, replace=False)], rng.uniform(-1.5, 1.5, (500, 3)).astype(np.float32)])
+    cloud = np.ascontiguousarray(cloud[rng.permutation(len(cloud))], np.float32)          # duplicates end up at unrelated indices
+    m4 = np.zeros((len(cloud), 4), np.float32)
+    m4[:, :3] = cloud
+    # queries: cell centres (8 lattice points at the same distance), edge midpoints (2 or 4 ties), lattice points themselves (0 + 6 ties)
+    c = lat[rng.choice(len(lat), 300, replace=False)]
+    q = np.concatenate([c + np.float32(0.125), c + np.array([0.125, 0, 0], np.float32), c]).astype(np.float32)
+    q = q[np.all(np.abs(q) < 1.4, axis=1)]
+    om = orc.Map(m4)
+    ridx, rd2 = om.knn(q, 5)
+    n_tied = int(np.sum(rd2[:, 3] == rd2[:, 4])) + int(np.sum(np.any(np.diff(rd2, axis=1) == 0, axis=1)))
+    assert n_tied > 200                                                                    # the case is about ties
+    for lanes in ("8", "16"):
+        os.environ["MLH_KNN_LANES"] = lanes
+        try:
+            c_ = mla.Context(0)
+        finally:
+            os.environ.pop("MLH_KNN_LANES", None)
+        try:
+            c_.map_set(mla.SURF, m4)
+            idx, d2 = c_.knn(mla.SURF, q)
+            assert np.array_equal(d2.view(np.uint32), rd2.view(np.uint32))
+            assert np.array_equal(idx, ridx), f"{int(np.sum(np.any(idx != ridx, axis=1)))} queries order tied neighbours differently ({lanes} lanes)"
+            # the matching path (pruned search inside the correspondence kernel) on the same tie-heavy data
+            f4 = np.zeros((len(q), 4), np.float32)
+            f4[:, :3] = q
+            c_.features_set(mla.SURF, f4)
+            ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+            got = c_.match_linearize(mla.SURF, ident, dense=False)
+            v, co = om.match("s", f4, ident)
+            assert np.array_equal(got["valid"], v)
+            mm = v.astype(bool)
+            assert np.array_equal(got["coeffs"][mm].astype(np.float32).view(np.uint32), co[mm].astype(np.float32).view(np.uint32))
+        finally:
+            c_.close()
