@@ -235,11 +235,22 @@ constexpr float KNN_PRUNE_SLACK = 1.0e-3f;   // metres taken off every face dist
                                              // the cell assignment; a pruned cell is farther than the bound by at least this much)
 
 // flat, balanced walk over the segments of the run table: candidate j of the concatenation goes to lane j % G
-template <int K, int G = 16>
+// ascending compare-exchange of two keys (hi = a ^ b ^ lo: one 64-bit compare, no second one for the maximum)
+__device__ __forceinline__ void key_cx(unsigned long long &a, unsigned long long &b)
+{
+    const unsigned long long lo = b < a ? b : a;
+    b = a ^ b ^ lo;
+    a = lo;
+}
+
+// EMPTY: the lane's list is empty on entry (the first walk of a search): its first trip's candidates are sorted by a 5-exchange network and
+// become the list, instead of going through KNN_U sorted insertions into a list of +inf
+template <int K, int G = 16, bool EMPTY = false>
 __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy, float qz, int gl, const int *lds_run, int total,
                                            unsigned bound_bits, unsigned long long (&k)[K])
 {
     int cr = 0, hi = lds_run[1], base = lds_run[KNN_SEG_BASE], lo = 0;
+    bool first = true;
     for (int j = gl; j < total; j += G * KNN_U) {
         int addr[KNN_U];
         bool v[KNN_U];
@@ -259,6 +270,21 @@ __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy,
 #pragma unroll
         for (int u = 0; u < KNN_U; ++u) asm volatile("" : "+v"(p[u].w));   // keep the index word in the 16-byte load (the compiler would
                                                                            // otherwise fetch it again, dependently, inside the insertion branch)
+        if (EMPTY && KNN_U == 4 && K >= 4 && first) {
+            first = false;
+            unsigned long long c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+                float d = dx * dx; d += dy * dy; d += dz * dz;
+                const bool take = v[u] && (__float_as_uint(d) <= bound_bits);
+                c[u] = take ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w)) : KEY_INF;
+            }
+            key_cx(c[0], c[1]); key_cx(c[2], c[3]); key_cx(c[0], c[2]); key_cx(c[1], c[3]); key_cx(c[1], c[2]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = c[u];
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < KNN_U; ++u) {
             if (v[u]) {
@@ -375,7 +401,7 @@ __device__ __forceinline__ void knn_group16_pruned(const GridDev &g, float qx, f
             if (n1 < K) { one_pass = true; b1 = w0; e1 = w3; }          // still too few points near the query: read everything at once
         }
         const int total1 = knn_fill_table16(lds_run, gl, b1, e1 - b1, 0, 0);
-        knn_walk16<K>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
+        knn_walk16<K, 16, true>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
         if (!one_pass) {
             // K-th smallest distance of phase 1 (merge of the lanes' sorted lists on the distance words; ties pop together, which can
             // only enlarge the bound)
@@ -467,7 +493,7 @@ __device__ __forceinline__ void knn_group8_pruned(const GridDev &g, float qx, fl
         {
             const int len1[2] = {e1[0] - b1[0], e1[1] - b1[1]};
             const int total1 = knn_fill_table<8, 2>(lds_run, gl, b1, len1);
-            knn_walk16<K, 8>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
+            knn_walk16<K, 8, true>(g, qx, qy, qz, gl, lds_run, total1, 0x7f800000u, k);
         }
         if (!one_pass) {
             unsigned hd[K];
