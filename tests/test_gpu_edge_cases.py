@@ -335,3 +335,40 @@ def test_knn_with_exact_distance_ties(mla, orc):
             assert np.array_equal(got["coeffs"][mm].astype(np.float32).view(np.uint32), co[mm].astype(np.float32).view(np.uint32))
         finally:
             c_.close()
+
+
+@pytest.mark.gpu
+def test_map_info_and_lane_choice(mla, case16, feats16):
+    """mlh_map_info: the occupancy statistics the index build collects (non-empty cells, population of the cell an average map point lives in)
+    are there after the first staging call (bounds pass, read back directly) and after a repeated one (sticky grid box: carried over by the
+    pinned mirror), equal a numpy count on the same grid rule, and the lanes-per-query choice follows them: 16 for a small launch whatever the
+    density, 8 for a sparse kind / 16 for a dense kind once the launch is large."""
+    c = mla.Context(0)
+    try:
+        surf, corner = case16["surf_map"], case16["corner_map"]
+        c.map_set_pair(surf, corner)
+        first = (c.map_info(mla.SURF), c.map_info(mla.CORNER))
+        c.map_set_pair(surf, corner)                       # second call: geometry reused, no bounds pass
+        c.map_set_pair(surf, corner)
+        again = (c.map_info(mla.SURF), c.map_info(mla.CORNER))
+        for a, b, cloud in zip(first, again, (surf, corner)):
+            assert a["n"] == b["n"] == len(cloud)
+            assert 0 < a["occupied_cells"] <= len(cloud) and a["occupied_cells"] == b["occupied_cells"]
+            assert a["mean_cell_population"] >= 1.0 and a["mean_cell_population"] == b["mean_cell_population"]
+            # the same statistics by numpy: cells of edge 1.001 m (any origin gives the same ORDER of magnitude; the exact box is internal)
+            ijk = np.floor(cloud[:, :3] / 1.001).astype(np.int64)
+            _, cnt = np.unique(ijk, axis=0, return_counts=True)
+            assert 0.5 < a["occupied_cells"] / len(cnt) < 2.0
+            assert 0.5 < a["mean_cell_population"] / (float((cnt.astype(np.float64) ** 2).sum()) / len(cloud)) < 2.0
+        # small launch (the 16-ring frame's ~5 k features): 16 lanes for both kinds
+        c.features_set(mla.SURF, feats16[0]); c.features_set(mla.CORNER, feats16[1])
+        assert c.map_info(mla.SURF)["knn_lanes"] == 16 and c.map_info(mla.CORNER)["knn_lanes"] == 16
+        # large launch: the density decides
+        big = np.ascontiguousarray(np.tile(feats16[0], (4, 1)))
+        c.features_set(mla.SURF, big)
+        for kind in (mla.SURF, mla.CORNER):
+            info = c.map_info(kind)
+            expect = 8 if 9.0 * info["mean_cell_population"] < 128 else 16
+            assert info["knn_lanes"] == expect
+    finally:
+        c.close()
