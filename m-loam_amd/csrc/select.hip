@@ -3,8 +3,6 @@
 // that consume those rows. The loops are sequential by construction (each greedy pick changes the information matrix the
 // next score is computed against), which is why the reference gives them a 20 ms wall-clock budget (lidar_mapper.h:82).
 #include "ctx.hpp"
-#include <chrono>
-#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -269,13 +267,8 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     a.flags = MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS;   // extractCov(point) weight, rows not loss-corrected (lidar_mapper.h:162-164)
     a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = 0.0; a.dense = true; a.pose_sel = 0;
-    const bool timing = std::getenv("MLH_SELECT_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](auto a_, auto b_) { return std::chrono::duration<double, std::micro>(b_ - a_).count(); };
-    const auto t0 = now();
     int rc = match_launch(ctx, a);
     if (rc) return rc;
-    const auto t1 = now();
     Rows R;
     const size_t m = size_t(f.m);
     // pinned staging (grow-only, owned by the context): [Corr m][J 6m][pts m]
@@ -293,7 +286,6 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_j, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
     if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const auto t2 = now();
     prof_collect(ctx);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
 
@@ -308,7 +300,6 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         case MLH_GF_GD_FLOAT: select_greedy(R, n_use, rng, sel, H); break;
         default: return fail(ctx, MLH_ERR_INVALID, "unknown gf_method");
     }
-    const auto t3 = now();
     // keep only the selected correspondences valid on the device
     if (method != MLH_GF_WO) {
         for (size_t i = 0; i < m; ++i) R.corr[i].valid = 0;
@@ -317,7 +308,6 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     sel_out.assign(sel.begin(), sel.end());
-    if (timing) std::fprintf(stderr, "[select kind %d m %zu] launch %.1f us, copy+sync %.1f us, pick %.1f us, upload %.1f us\n", kind, m, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, now()));
     return MLH_OK;
 }
 
