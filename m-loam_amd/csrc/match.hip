@@ -389,6 +389,17 @@ __device__ __forceinline__ double feature_weight(const KParams &P, const KindP &
     return sqrt_info_of(trace);
 }
 
+// the same from a covariance diagonal the caller already holds in registers (requested together with the feature: no dependent trip)
+__device__ __forceinline__ double feature_weight_pref(const KParams &P, const KindP &K, const float4 &cd)
+{
+    double trace = P.cov_measurement_trace;
+    if ((P.flags & MLH_FLAG_WITH_UA)) {
+        trace = 0.0;
+        if (K.covd) trace = (double(cd.x) + double(cd.y)) + double(cd.z);
+    }
+    return sqrt_info_of(trace);
+}
+
 // Fused tail: the last workgroup to arrive (agent-scope release/acquire around an atomic ticket) sums the partial records
 // in fixed order, runs the degeneracy test + the 6x6 solve + Plus for every pose block and re-arms the ticket: a GN iteration
 // costs two launches.
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 #pragma unroll
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float4 fp = make_float4(0.f, 0.f, 0.f, -1.f);
+    float4 fp = make_float4(0.f, 0.f, 0.f, -1.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f < K.m) {
         // ONE memory round trip before the fit: the feature and all of its neighbour records are requested together (the records sit at
         // f * stride whatever the feature turns out to be; what is fetched for a padding slot or a feature another rank owns is discarded).
@@ -528,6 +539,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
         const float4 *nb = K.nbr + size_t(f) * K.nbr_stride;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) nbv[j] = nb[j];
+        if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];       // the weight's covariance diagonal rides in the same trip
         MLH_STAGE(gtile, 5);
         const bool need_pos = P.has_lo || P.has_hi || (P.flags & MLH_FLAG_CHECK_FOV);
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     }
     MLH_STAGE(gtile, 1);
     if (valid) {
-        const double w = feature_weight(P, K, f);
+        const double w = feature_weight_pref(P, K, cdv);
         double R[9];
         qtorot(q, R);
         const d3 p{double(fp.x), double(fp.y), double(fp.z)};
@@ -803,11 +815,14 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 #pragma unroll
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     if (f < K.m) {
+        // correspondence, feature and (with uncertainty weighting) its covariance diagonal in ONE round trip, whatever `valid` turns out to be
         const Corr c = K.corr[f];
+        const float4 fp = K.feat[f];
+        float4 cdv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
         if (c.valid) {
             valid = true;
-            const float4 fp = K.feat[f];
-            const double w = feature_weight(P, K, f);
+            const double w = feature_weight_pref(P, K, cdv);
             double R[9];
             qtorot(q, R);
             const d3 p{double(fp.x), double(fp.y), double(fp.z)};
