@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). Pin status per file: feature_extract.cpp, factors.hpp, image_segmenter.cpp are held against the
+// reference's own source lines (oracle/ref/); linalg.hpp, kdtree.hpp, mapper.cpp, uct.hpp, tracker.hpp restate library arithmetic: PARITY UNPINNED there.
 // extern "C" surface of the CPU oracle, loaded with ctypes by tests/, bench.py's cpu_baseline leg and
 // __graft_entry__.smoke(). The product library (m-loam_amd/) never links or loads this.
 #include "image_segmenter.hpp"

@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED (Ceres/Eigen absent;
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). The six factor classes' Evaluate bodies and PoseLocalParameterization::Plus: PINNED (round 2) against the reference's OWN SOURCE LINES compiled over a shim (oracle/ref/, tests/test_oracle_ref_pin.py)
+// -- which pins the formulas; Eigen's own arithmetic is supplied by oracle/ref/mini_eigen.hpp there. Otherwise PARITY UNPINNED (Ceres/Eigen absent;
 // pinned here by analytic-vs-numeric Jacobian assertions, the reference's own check() recipe).
 //
 // CPU restatement of

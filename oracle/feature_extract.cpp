@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). extractCloud and match*PointFromMap: PINNED (round 2) against the reference's OWN SOURCE LINES compiled over a shim (oracle/ref/, tests/test_oracle_ref_pin.py);
+// the Eigen / FLANN arithmetic they call (linalg.hpp, kdtree.hpp) stays a restatement: PARITY UNPINNED for that part.
 // See feature_extract.hpp for the list of reference functions restated here.
 #include "feature_extract.hpp"
 #include "linalg.hpp"

@@ -3,7 +3,10 @@
 // (m-loam_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 // leg may use it, and only as the checker / reported CPU baseline.
 //
-// PARITY UNPINNED: the reference (gogojjh/M-LOAM) delegates this arithmetic to
+// Pin status (round 2): the reference's OWN lines for extractCloud, match*PointFromMap, the factor classes, Plus and ImageSegmenter are
+// compiled from /root/reference over a shim and the restatements under oracle/ are held against them (oracle/ref/build_ref.py,
+// tests/test_oracle_ref_pin.py). That pins the reference's logic. It does NOT pin what follows:
+// PARITY UNPINNED (library arithmetic): the reference (gogojjh/M-LOAM) delegates this arithmetic to
 // Eigen 3.3.4 (ROS melodic / Ubuntu 18.04 `libeigen3-dev`, docker/Dockerfile:1-5),
 // which is NOT vendored under /root/reference and is absent from this image.
 // The routines below restate Eigen's published algorithms:

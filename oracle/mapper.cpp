@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED (Ceres' trust-region LM, the selection loops and evalDegenracy are restated; the
+// factors they evaluate are pinned through factors.hpp, the matches through feature_extract.cpp).
 // See mapper.hpp for the list of reference functions restated here.
 #include "mapper.hpp"
 #include "tracker.hpp"

@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (oracle/libmloam_oracle.so).
 
 Only tests/, bench.py's ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` import this module, and only as
-the checker / reported CPU baseline. PARITY UNPINNED: see oracle/linalg.hpp.
+the checker / reported CPU baseline. Pin status: the reference's own source lines pin extractCloud, the map matches, the factor
+classes, Plus and ImageSegmenter (oracle/ref/, ref_* functions below); the Eigen / PCL-FLANN / Ceres arithmetic is restated --
+PARITY UNPINNED for that part, see oracle/linalg.hpp.
 """
 from __future__ import annotations
 

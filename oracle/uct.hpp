@@ -1,4 +1,5 @@
-// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED.
+// TEST INFRASTRUCTURE ONLY (see oracle/linalg.hpp header). PARITY UNPINNED (PCL absent): the voxel filters restate voxel_grid_covariance_mloam_impl.hpp including
+// its unstable std::sort (literal; the member order inside a voxel is libstdc++'s -- see voxel_grid_mloam_plain).
 //
 // CPU restatement of
 //   evalPointUncertainty / pointToFS      estimator/src/lidarMapper/associate_uct.hpp:150-215

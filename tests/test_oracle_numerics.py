@@ -1,4 +1,5 @@
-"""Pins for the CPU oracle (parity is otherwise unpinned: the reference has no golden vectors for this path).
+"""Independent pins for the restated LIBRARY arithmetic of the CPU oracle (Eigen / FLANN / Ceres are absent here and the reference has no golden
+vectors for this path; the reference's own logic is pinned separately, tests/test_oracle_ref_pin.py).
  - analytic vs numeric Jacobians: the reference's own check() recipe (lidar_map_factor.hpp:98-118, 204-227), as assertions
  - independent cross-checks: numpy.linalg (eigh, lstsq), scipy.spatial.cKDTree, scipy.optimize.least_squares
  - the 4-point covariance-voxel example of mloam_test/src/test_pointiwithcov.cpp with hand-derived expected values"""
