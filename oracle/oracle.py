@@ -158,6 +158,56 @@ def ref_pose_plus(x, delta, V_update=None):
     return out
 
 
+def _as11(a):
+    a = np.asarray(a, np.float32)
+    out = np.zeros((a.shape[0], 11), np.float32)
+    out[:, :min(11, a.shape[1])] = a[:, :11]
+    return np.ascontiguousarray(out)
+
+
+def ref_good_feature_matching(map_points, kind, feats11, pose7, gf_method, gf_ratio, seed, H=None, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """ActiveFeatureSelection::goodFeatureMatching compiled from the reference's own lines (lidar_mapper.h:229-573), its mt19937 re-seeded"""
+    L = ref_lib()
+    m, f = _as11(map_points), _as11(feats11)
+    pose = np.ascontiguousarray(pose7, np.float64)
+    Hm = np.ascontiguousarray(np.eye(6) * 1e-6 if H is None else H, np.float64).copy()
+    sel = np.zeros(max(len(f), 1), np.int32); nsel = C.c_int(0)
+    L.ref_good_feature_matching(C.c_char(kind.encode()), _ptr(m), len(m), _ptr(f), len(f), _ptr(pose), gf_method.encode(), C.c_double(gf_ratio),
+                                C.c_uint(int(seed)), C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(Hm), _ptr(sel), C.byref(nsel))
+    return dict(sel=sel[:nsel.value].copy(), H=Hm)
+
+
+def ref_eval_full_hessian(map_points, kind, feats11, pose7, H=None, feat_num=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227) + common::logDet(mat_H, true) from the reference's own lines"""
+    L = ref_lib()
+    m, f = _as11(map_points), _as11(feats11)
+    pose = np.ascontiguousarray(pose7, np.float64)
+    Hm = np.ascontiguousarray(np.eye(6) * 1e-6 if H is None else H, np.float64).copy()
+    n = C.c_int(int(feat_num)); ld = C.c_double(0)
+    L.ref_eval_full_hessian(C.c_char(kind.encode()), _ptr(m), len(m), _ptr(f), len(f), _ptr(pose), C.c_float(min_match_sq_dis), C.c_float(min_plane_dis),
+                            _ptr(Hm), C.byref(n), C.byref(ld))
+    return Hm, n.value, ld.value
+
+
+def ref_compound_pose_with_cov(pose1, cov1, pose2, cov2):
+    """the reference's own compoundPoseWithCov lines (associate_uct.hpp:9-86, method 2)"""
+    L = ref_lib()
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose1, cov1, pose2, cov2)]
+    pose_cp, cov_cp = np.zeros(7), np.zeros((6, 6))
+    L.ref_compound_pose_with_cov(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(pose_cp), _ptr(cov_cp))
+    return pose_cp, cov_cp
+
+
+def ref_eval_point_uncertainty(xyz, T4, cov_pose, cov_meas):
+    """the reference's own evalPointUncertainty lines (associate_uct.hpp:164-215, both overloads) on one point; T4: 4x4 pose matrix"""
+    L = ref_lib()
+    p = np.ascontiguousarray(xyz, np.float32); T = np.ascontiguousarray(T4, np.float64)
+    cp = np.ascontiguousarray(cov_pose, np.float64); cm = np.ascontiguousarray(cov_meas, np.float64)
+    a, b = np.zeros((3, 3)), np.zeros((3, 3))
+    L.ref_eval_point_uncertainty(_ptr(p), _ptr(T), _ptr(cp), _ptr(cm), _ptr(a), _ptr(b))
+    return a, b
+
+
 def extract(points: np.ndarray, scan_start: np.ndarray, scan_end: np.ndarray, tie_rule: int = 0):
     """FeatureExtract::extractCloud. points (n,4) f32 ring-major. tie_rule 0: the reference's comparator (order of equal curvatures =
     libstdc++'s std::sort); 1: (curvature, index) ascending with NaN last -- the documented rule the HIP kernel sorts by."""

@@ -40,6 +40,18 @@ CUTS = [
     ("calib_edge_tail.inc", "factor/lidar_online_calib_factor.hpp", 223, 227, "private:"),
     ("plp_class.inc", "factor/pose_local_parameterization.h", 21, 33, "class PoseLocalParameterization"),
     ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
+    ("feature_structs.inc", "estimator/parameters.h", 163, 191, "class PointPlaneFeature"),
+    ("extract_cov.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 202, 214, "void extractCov"),
+    ("log_det.inc", "algos/math.hpp", 172, 202, "template <typename MatrixType>"),
+    ("rgi_head.inc", "@mloam_common/libs/include/common/random_generator.hpp", 52, 66, "template < typename T >"),
+    ("afs_limits.inc", "lidarMapper/lidar_mapper.h", 82, 83, "#define MAX_FEATURE_SELECT_TIME"),
+    ("afs_eval_jaco.inc", "lidarMapper/lidar_mapper.h", 130, 174, "void evaluateFeatJacobianMatching"),
+    ("afs_full_hessian.inc", "lidarMapper/lidar_mapper.h", 176, 227, "void evalFullHessian"),
+    ("afs_gfm.inc", "lidarMapper/lidar_mapper.h", 229, 573, "void goodFeatureMatching"),
+    ("uct_compound.inc", "lidarMapper/associate_uct.hpp", 9, 86, "inline Eigen::Matrix<double, 6, 6> adjointMatrix"),
+    ("uct_point_to_fs.inc", "lidarMapper/associate_uct.hpp", 150, 156, "inline Eigen::Matrix<double, 4, 6> pointToFS"),
+    ("uct_eval_point_cov.inc", "lidarMapper/associate_uct.hpp", 164, 193, "template <typename PointType>"),
+    ("uct_eval_point.inc", "lidarMapper/associate_uct.hpp", 195, 215, "template <typename PointType>"),
 ]
 
 
@@ -54,7 +66,8 @@ def build(force=False):
     os.makedirs(gen, exist_ok=True)
     try:
         for name, rel, a, b, must in CUTS:
-            lines = open(os.path.join(COMMON if rel.startswith("algos/") else SRC, rel)).read().split("\n")
+            base = REF if rel.startswith("@") else (COMMON if rel.startswith("algos/") else SRC)      # "@...": relative to the reference root
+            lines = open(os.path.join(base, rel.lstrip("@"))).read().split("\n")
             assert must in lines[a - 1], f"{rel}:{a} is not '{must}' -- the reference tree differs from the surveyed one"
             open(os.path.join(gen, name), "w").write("\n".join(lines[a - 1:b]) + "\n")
         oracle_dir = os.path.dirname(HERE)

@@ -26,6 +26,13 @@ template <typename T, int R, int C, int N> struct ColsRef {      // leftCols<N>(
     void setZero() { for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) base[i * ld + col0 + j] = T(0); }
 };
 
+// block<BR, BC>(i, j) / topLeftCorner / bottomRightCorner of a fixed-size matrix: assignable view, converts to a matrix
+template <typename T, int BR, int BC> struct BlockRef {
+    T *base; int ld;                                             // element (i, j) at base[i * ld + j]
+    BlockRef &operator=(const Mat<T, BR, BC> &m);
+    operator Mat<T, BR, BC>() const;
+};
+
 template <typename T, int R, int C> struct CommaInit {
     Mat<T, R, C> &m; int k;
     CommaInit &operator,(T v) { m.d[k++] = v; return *this; }
@@ -37,8 +44,8 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
     T d[R * C];                                                   // row-major storage
     Mat() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
     Mat(T a, T b, T c) { static_assert(R * C == 3, "3-vector"); d[0] = a; d[1] = b; d[2] = c; }
-    template <typename D> Mat(const MatrixBase<D> &o) { for (int i = 0; i < R * C; ++i) d[i] = o.derived().d[i]; }
     Mat(T a, T b, T c, T e) { static_assert(R * C == 4, "4-vector"); d[0] = a; d[1] = b; d[2] = c; d[3] = e; }
+    template <typename D> Mat(const MatrixBase<D> &o) { for (int i = 0; i < R * C; ++i) d[i] = o.derived().d[i]; }
     T &operator()(int i) { return d[i]; }
     const T &operator()(int i) const { return d[i]; }
     T &operator()(int i, int j) { return d[i * C + j]; }
@@ -73,6 +80,16 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
         return m;
     }
     CommaInit<T, R, C> operator<<(T v) { d[0] = v; return CommaInit<T, R, C>{*this, 1}; }
+    template <int BR, int BC> BlockRef<T, BR, BC> block(int i, int j) { return BlockRef<T, BR, BC>{d + i * C + j, C}; }
+    template <int BR, int BC> Mat<T, BR, BC> block(int i, int j) const { Mat<T, BR, BC> m; for (int r = 0; r < BR; ++r) for (int c = 0; c < BC; ++c) m(r, c) = (*this)(i + r, j + c); return m; }
+    template <int BR, int BC> BlockRef<T, BR, BC> topLeftCorner() { return block<BR, BC>(0, 0); }
+    template <int BR, int BC> BlockRef<T, BR, BC> bottomRightCorner() { return block<BR, BC>(R - BR, C - BC); }
+    template <int BR, int BC> BlockRef<T, BR, BC> topRightCorner() { return block<BR, BC>(0, C - BC); }
+    template <int BR, int BC> BlockRef<T, BR, BC> bottomLeftCorner() { return block<BR, BC>(R - BR, 0); }
+    template <int BR, int BC> Mat<T, BR, BC> topLeftCorner() const { return block<BR, BC>(0, 0); }
+    template <int BR, int BC> Mat<T, BR, BC> topRightCorner() const { return block<BR, BC>(0, C - BC); }
+    template <int BR, int BC> Mat<T, BR, BC> bottomLeftCorner() const { return block<BR, BC>(R - BR, 0); }
+    template <int BR, int BC> Mat<T, BR, BC> bottomRightCorner() const { return block<BR, BC>(R - BR, C - BC); }
     template <int N> ColsRef<T, R, C, N> leftCols() { return ColsRef<T, R, C, N>{d, 0, C}; }
     template <int N> ColsRef<T, R, C, N> rightCols() { return ColsRef<T, R, C, N>{d, C - N, C}; }
     template <int N> Mat<T, N, 1> head() const { Mat<T, N, 1> m; for (int i = 0; i < N; ++i) m.d[i] = d[i]; return m; }
@@ -86,6 +103,79 @@ template <typename T, int R, int C, int N> ColsRef<T, R, C, N> &ColsRef<T, R, C,
     return *this;
 }
 
+template <typename T, int BR, int BC> BlockRef<T, BR, BC> &BlockRef<T, BR, BC>::operator=(const Mat<T, BR, BC> &m)
+{
+    for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) base[i * ld + j] = m(i, j);
+    return *this;
+}
+template <typename T, int BR, int BC> BlockRef<T, BR, BC>::operator Mat<T, BR, BC>() const
+{
+    Mat<T, BR, BC> m;
+    for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(i, j) = base[i * ld + j];
+    return m;
+}
+
+
+// ---- a dynamic-size matrix for the few places the reference holds one (PointPlaneFeature::jaco_, common::logDet's LLT)
+template <typename T> struct Mat<T, Dynamic, Dynamic> : MatrixBase<Mat<T, Dynamic, Dynamic>> {
+    typedef T Scalar;
+    int r = 0, c = 0;
+    std::vector<T> d;                                             // row-major
+    Mat() {}
+    Mat(int rows_, int cols_) : r(rows_), c(cols_), d(size_t(rows_) * cols_, T(0)) {}
+    template <int R, int C> Mat(const Mat<T, R, C> &m) : r(R), c(C), d(m.d, m.d + R * C) {}
+    template <int R, int C> Mat &operator=(const Mat<T, R, C> &m) { r = R; c = C; d.assign(m.d, m.d + R * C); return *this; }
+    int rows() const { return r; } int cols() const { return c; }
+    T &operator()(int i, int j) { return d[size_t(i) * c + j]; }
+    const T &operator()(int i, int j) const { return d[size_t(i) * c + j]; }
+    Mat transpose() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); return m; }
+    Mat operator*(const Mat &o) const
+    {
+        Mat m(r, o.c);
+        for (int i = 0; i < r; ++i) for (int j = 0; j < o.c; ++j) { T s = (*this)(i, 0) * o(0, j); for (int k = 1; k < c; ++k) s += (*this)(i, k) * o(k, j); m(i, j) = s; }
+        return m;
+    }
+};
+typedef Mat<double, Dynamic, Dynamic> MatrixXd;
+template <typename T, int R, int C> Mat<T, R, C> operator+(const Mat<T, R, C> &a, const Mat<T, Dynamic, Dynamic> &b)
+{
+    Mat<T, R, C> m;
+    for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) m(i, j) = a(i, j) + b(i, j);
+    return m;
+}
+template <typename T, int R, int C> Mat<T, R, C> &operator+=(Mat<T, R, C> &a, const Mat<T, Dynamic, Dynamic> &b)
+{
+    for (int i = 0; i < R; ++i) for (int j = 0; j < C; ++j) a(i, j) += b(i, j);
+    return a;
+}
+// Eigen::LLT of a symmetric positive definite matrix (standard left-looking Cholesky, sums in ascending k): what common::logDet reads is
+// matrixL()(i, i). Library arithmetic: restated, like everything in this header.
+template <typename M> struct LLT;
+template <typename T> struct LLT<Mat<T, Dynamic, Dynamic>> {
+    Mat<T, Dynamic, Dynamic> L;
+    template <int R, int C> LLT(const Mat<T, R, C> &A) : L(R, C)
+    {
+        for (int j = 0; j < R; ++j) {
+            T s = A(j, j);
+            for (int k = 0; k < j; ++k) s -= L(j, k) * L(j, k);
+            const T ljj = std::sqrt(s);
+            L(j, j) = ljj;
+            for (int i = j + 1; i < R; ++i) { T t = A(i, j); for (int k = 0; k < j; ++k) t -= L(i, k) * L(j, k); L(i, j) = t / ljj; }
+        }
+    }
+    Mat<T, Dynamic, Dynamic> &matrixL() { return L; }
+};
+// only instantiated, never executed (common::logDet is called with use_cholesky = true on this path)
+template <typename M> struct PartialPivLU;
+template <typename T> struct PartialPivLU<Mat<T, Dynamic, Dynamic>> {
+    Mat<T, Dynamic, Dynamic> LU;
+    struct Perm { T determinant() const { return T(1); } };
+    template <int R, int C> PartialPivLU(const Mat<T, R, C> &A) : LU(A) {}
+    Mat<T, Dynamic, Dynamic> &matrixLU() { return LU; }
+    Perm permutationP() const { return Perm(); }
+};
+
+typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 4, 1> Vector4d;
 typedef Matrix<double, 3, 3> Matrix3d;
@@ -99,6 +189,7 @@ struct VectorXd {                                                  // the edge f
     explicit VectorXd(int n) : v(size_t(n), 0.0) {}
     template <int R> VectorXd(const Mat<double, R, 1> &m) : v(m.d, m.d + R) {}
     template <int R> VectorXd &operator=(const Mat<double, R, 1> &m) { v.assign(m.d, m.d + R); return *this; }
+    template <int R> operator Mat<double, R, 1>() const { Mat<double, R, 1> m; for (int i = 0; i < R; ++i) m.d[i] = v[size_t(i)]; return m; }   // Eigen: dynamic -> fixed, sizes must agree
     double &operator()(int i) { return v[size_t(i)]; }
     const double &operator()(int i) const { return v[size_t(i)]; }
     int size() const { return int(v.size()); }
@@ -149,6 +240,7 @@ template <typename T, int R, int C> struct Map<Mat<T, R, C>> {
     template <int N> ColsRef<T, R, C, N> leftCols() { return ColsRef<T, R, C, N>{p, 0, C}; }
     template <int N> ColsRef<T, R, C, N> rightCols() { return ColsRef<T, R, C, N>{p, C - N, C}; }
     Map &operator=(const Mat<T, R, C> &m) { for (int i = 0; i < R * C; ++i) p[i] = m.d[i]; return *this; }
+    template <int BR, int BC> Mat<T, BR, BC> topLeftCorner() const { Mat<T, BR, BC> m; for (int i = 0; i < BR; ++i) for (int j = 0; j < BC; ++j) m(i, j) = p[i * C + j]; return m; }
 };
 template <typename T, int R, int C> struct Map<const Mat<T, R, C>> {
     const T *p;

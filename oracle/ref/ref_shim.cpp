@@ -15,6 +15,11 @@
 //   LidarPureOdom{PlaneNorm,Edge}Factor    estimator/src/factor/lidar_pure_odom_factor.hpp:27-102, 191-195; 198-282, 377-381
 //   LidarOnlineCalib{PlaneNorm,Edge}Factor estimator/src/factor/lidar_online_calib_factor.hpp:24-62, 117-121; 125-165, 223-227
 //   PoseLocalParameterization::{setParameter, Plus}   estimator/src/factor/pose_local_parameterization.h:21-33, .cpp:16-45
+//   pointToFS, evalPointUncertainty (both overloads)  estimator/src/lidarMapper/associate_uct.hpp:150-156, 164-193, 195-215
+//   adjointMatrix, covop1, covop2, compoundPoseWithCov (explicit-covariance overload)   associate_uct.hpp:9-86
+//   ActiveFeatureSelection::{evaluateFeatJacobianMatching, evalFullHessian, goodFeatureMatching}   estimator/src/lidarMapper/lidar_mapper.h:130-573
+//     (+ PointPlaneFeature / FeatureWithScore parameters.h:163-191, extractCov point_with_cov.hpp:202-214, common::logDet math.hpp:172-202,
+//      common::RandomGeneratorInt random_generator.hpp:52-66, the two limits lidar_mapper.h:82-83)
 // What this pins: every decision, loop bound, comparison, term and sign the reference's own code makes (the labels and the four feature
 // lists; residual and Jacobian formulas). What it does not: the arithmetic INSIDE the third-party calls (Eigen products, PCL's voxel
 // centroids), which here is the shim's / the oracle's restatement.
@@ -25,6 +30,10 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <numeric>
+#include <queue>
+#include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 #include "mini_eigen.hpp"
@@ -83,16 +92,9 @@ template <typename P> struct KdTreeFLANN {                    // 3p: the oracle'
 }  // namespace pcl
 struct NullLog { template <typename T> NullLog &operator<<(const T &) { return *this; } };
 #define LOG(x) NullLog()
-struct Pose { Eigen::Quaterniond q_; Eigen::Vector3d t_; };   // pose.h:38-66 (the two members the match functions read)
-class PointPlaneFeature {                                     // parameters.h:163-175 without jaco_ (Eigen::MatrixXd; not touched by the match functions)
-public:
-    PointPlaneFeature() : idx_(0), laser_idx_(0), type_('n') {}
-    size_t idx_;
-    size_t laser_idx_;
-    Eigen::Vector3d point_;
-    Eigen::VectorXd coeffs_;
-    char type_;
-};
+struct Pose { Eigen::Quaterniond q_; Eigen::Vector3d t_; Eigen::Matrix4d T_; Eigen::Matrix<double, 6, 6> cov_; };   // pose.h:38-66 (the members the cut lines read)
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#include "../_ref/gen/feature_structs.inc"                    // class PointPlaneFeature, class FeatureWithScore  (parameters.h:163-191)
 float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;         // parameters.cpp:232-233
 namespace common {
 #include "../_ref/gen/sqr_sum.inc"                            // template <typename T> inline T sqrSum(x, y, z)
@@ -152,6 +154,48 @@ public:
 #include "../_ref/gen/plp_class.inc"                          // class PoseLocalParameterization
 bool PoseLocalParameterization::ComputeJacobian(const double *, double *) const { return true; }   // (not cut: Map<Matrix<7,6>>::topRows; the test restates [I6; 0])
 #include "../_ref/gen/plp_plus.inc"                           // setParameter, Plus
+Eigen::Matrix<double, 3, 3> COV_MEASUREMENT;                  // parameters.cpp:104 (set by the test entry point below)
+#include "../_ref/gen/uct_compound.inc"                       // adjointMatrix, covop1, covop2, compoundPoseWithCov(pose_1, cov_1, pose_2, cov_2, pose_cp, cov_cp, method)
+#include "../_ref/gen/uct_point_to_fs.inc"                    // inline Eigen::Matrix<double, 4, 6> pointToFS(const Eigen::Vector4d &)
+#include "../_ref/gen/uct_eval_point_cov.inc"                 // evalPointUncertainty(pi, cov_point, pose, cov_pose)
+#include "../_ref/gen/uct_eval_point.inc"                     // evalPointUncertainty(pi, cov_point, pose)   -- reads pose.cov_
+
+// ---------------------------------------------------------------- ActiveFeatureSelection (lidar_mapper.h:126-573) from the reference's own lines
+namespace pcl { struct PointXYZIWithCov { float x = 0, y = 0, z = 0, intensity = 0; float cov_vec[6] = {0, 0, 0, 0, 0, 0}; float cov_trace = 0; }; }   // point_with_cov.hpp:27-60
+typedef pcl::PointXYZIWithCov PointIWithCov;
+typedef pcl::PointCloud<PointIWithCov> PointICovCloud;
+namespace common {
+#include "../_ref/gen/extract_cov.inc"                        // void extractCov(const pcl::PointXYZIWithCov &, Eigen::Matrix3d &)
+#include "../_ref/gen/log_det.inc"                            // template logDet(M, use_cholesky): the LLT / PartialPivLU it calls are mini_eigen's
+#include "../_ref/gen/rgi_head.inc"                           // struct RandomGeneratorInt { ..., geneRandUniform }  -- the tests re-seed m_random_engine
+    };
+}
+namespace ceres {
+struct LossFunction { virtual ~LossFunction() {} virtual void Evaluate(double sq_norm, double out[3]) const = 0; };
+struct HuberLoss : LossFunction {                             // ceres/loss_function.cc (restated; its output is computed and discarded by evaluateFeatJacobianMatching)
+    double a_, b_;
+    explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+    void Evaluate(double s, double rho[3]) const override
+    {
+        if (s > b_) { const double r = std::sqrt(s); rho[0] = 2.0 * a_ * r - b_; rho[1] = std::max(std::numeric_limits<double>::min(), a_ / r); rho[2] = -rho[1] / (2.0 * s); }
+        else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+    }
+};
+}  // namespace ceres
+#define SIZE_POSE 7                                           // parameters.h
+#define LOG_EVERY_N(severity, n) NullLog()
+#include "../_ref/gen/afs_limits.inc"                         // MAX_FEATURE_SELECT_TIME, MAX_RANDOM_QUEUE_TIME
+FeatureExtract f_extract;                                     // lidar_mapper.h:92
+class ActiveFeatureSelection {
+public:
+#include "../_ref/gen/afs_eval_jaco.inc"                      // evaluateFeatJacobianMatching   lidar_mapper.h:130-174
+#include "../_ref/gen/afs_full_hessian.inc"                   // evalFullHessian                lidar_mapper.h:176-227
+#define printf(...) ((void)0)                                 // its closing progress line (lidar_mapper.h:570) stays out of the test logs
+#include "../_ref/gen/afs_gfm.inc"                            // goodFeatureMatching            lidar_mapper.h:229-573
+#undef printf
+    ceres::LossFunction *loss_function_;                      // lidar_mapper.h:628-629
+    common::RandomGeneratorInt<size_t> rgi_;
+};
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
@@ -278,6 +322,112 @@ int ref_online_calib_evaluate(char kind, const double point[3], const double *co
         LidarOnlineCalibEdgeFactor f(p, c, sqrt_info);
         f.Evaluate(params, residual, J7 ? jac : nullptr);
     }
+    return 0;
+}
+
+// evalPointUncertainty (associate_uct.hpp:164-215): T4 = the pose's 4x4 homogeneous matrix (row-major), cov_pose 6x6, cov_meas 3x3; both
+// overloads (explicit covariance / pose.cov_) are run and must agree; cov_out 3x3 row-major
+int ref_eval_point_uncertainty(const float p[3], const double T4[16], const double cov_pose[36], const double cov_meas[9], double cov_out[9], double cov_out2[9])
+{
+    for (int i = 0; i < 9; ++i) COV_MEASUREMENT.d[i] = cov_meas[i];
+    Pose pose;
+    for (int i = 0; i < 16; ++i) pose.T_.d[i] = T4[i];
+    Eigen::Matrix<double, 6, 6> cp;
+    for (int i = 0; i < 36; ++i) { cp.d[i] = cov_pose[i]; pose.cov_.d[i] = cov_pose[i]; }
+    PointI pi;
+    pi.x = p[0]; pi.y = p[1]; pi.z = p[2];
+    Eigen::Matrix3d c1, c2;
+    evalPointUncertainty(pi, c1, pose, cp);
+    evalPointUncertainty(pi, c2, pose);
+    for (int i = 0; i < 9; ++i) { cov_out[i] = c1.d[i]; cov_out2[i] = c2.d[i]; }
+    return 0;
+}
+
+// compoundPoseWithCov (associate_uct.hpp:31-86, method 2 = Barfoot's fourth-order terms): poses as [t, q(xyzw)], covariances 6x6 row-major
+int ref_compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pose_cp[7], double cov_cp[36])
+{
+    auto mk = [](const double p[7]) {
+        Pose P;
+        P.t_ = Eigen::Vector3d(p[0], p[1], p[2]);
+        P.q_ = Eigen::Quaterniond(p[6], p[3], p[4], p[5]);
+        const Eigen::Matrix3d R = P.q_.toRotationMatrix();            // Pose::update (pose.cpp): T_ = [R t; 0 1]
+        for (int i = 0; i < 16; ++i) P.T_.d[i] = 0.0;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P.T_(i, j) = R(i, j); P.T_(i, 3) = p[i]; }
+        P.T_(3, 3) = 1.0;
+        return P;
+    };
+    const Pose a = mk(p1), b = mk(p2);
+    Eigen::Matrix<double, 6, 6> ca, cb, cc;
+    for (int i = 0; i < 36; ++i) { ca.d[i] = c1[i]; cb.d[i] = c2[i]; }
+    Pose out;
+    compoundPoseWithCov(a, ca, b, cb, out, cc);
+    pose_cp[0] = out.t_(0); pose_cp[1] = out.t_(1); pose_cp[2] = out.t_(2);
+    pose_cp[3] = out.q_.x(); pose_cp[4] = out.q_.y(); pose_cp[5] = out.q_.z(); pose_cp[6] = out.q_.w();
+    for (int i = 0; i < 36; ++i) cov_cp[i] = cc.d[i];
+    return 0;
+}
+
+// ActiveFeatureSelection::goodFeatureMatching / evalFullHessian on (map, features as 11-float PointXYZIWithCov records, pose); the engine is
+// re-seeded (the reference seeds it from std::random_device: its selections are not reproducible run to run, so "the same selection"
+// can only mean "given the same engine state"). H36 in: the caller's seed matrix (1e-6 I in the mapper), out: sub_mat_H / mat_H.
+static void afs_setup(const float *map11, int n_map, const float *feat11, int n_feat, const double pose7[7], PointICovCloud &map, PointICovCloud &feat,
+                      pcl::KdTreeFLANN<PointIWithCov>::Ptr &kd, Pose &pose)
+{
+    auto fill = [](PointICovCloud &c, const float *a, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) {
+            PointIWithCov &q = c.points[size_t(i)];
+            q.x = a[11 * i]; q.y = a[11 * i + 1]; q.z = a[11 * i + 2]; q.intensity = a[11 * i + 3];
+            for (int k = 0; k < 6; ++k) q.cov_vec[k] = a[11 * i + 4 + k];
+            q.cov_trace = a[11 * i + 10];
+        }
+    };
+    fill(map, map11, n_map); fill(feat, feat11, n_feat);
+    kd.reset(new pcl::KdTreeFLANN<PointIWithCov>());
+    kd->setInputCloud(map);
+    pose.t_ = Eigen::Vector3d(pose7[0], pose7[1], pose7[2]);
+    pose.q_ = Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]);
+}
+
+int ref_good_feature_matching(char kind, const float *map11, int n_map, const float *feat11, int n_feat, const double pose7[7], const char *gf_method,
+                              double gf_ratio, unsigned seed, float min_match_sq_dis, float min_plane_dis, double H36[36], int *sel, int *n_sel)
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis;
+    PointICovCloud map, feat;
+    pcl::KdTreeFLANN<PointIWithCov>::Ptr kd;
+    Pose pose;
+    afs_setup(map11, n_map, feat11, n_feat, pose7, map, feat, kd, pose);
+    ActiveFeatureSelection afs;
+    ceres::HuberLoss huber(1.0);
+    afs.loss_function_ = &huber;
+    afs.rgi_.m_random_engine.seed(seed);
+    Eigen::Matrix<double, 6, 6> H;
+    for (int i = 0; i < 36; ++i) H.d[i] = H36[i];
+    std::vector<PointPlaneFeature> all_features;
+    std::vector<size_t> sel_idx;
+    afs.goodFeatureMatching(kd, map, feat, pose, all_features, sel_idx, kind, std::string(gf_method), gf_ratio, H);
+    for (int i = 0; i < 36; ++i) H36[i] = H.d[i];
+    *n_sel = int(sel_idx.size());
+    for (size_t i = 0; i < sel_idx.size(); ++i) sel[i] = int(sel_idx[i]);
+    return 0;
+}
+
+int ref_eval_full_hessian(char kind, const float *map11, int n_map, const float *feat11, int n_feat, const double pose7[7], float min_match_sq_dis,
+                          float min_plane_dis, double H36[36], int *feat_num, double *logdet)
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis;
+    PointICovCloud map, feat;
+    pcl::KdTreeFLANN<PointIWithCov>::Ptr kd;
+    Pose pose;
+    afs_setup(map11, n_map, feat11, n_feat, pose7, map, feat, kd, pose);
+    ActiveFeatureSelection afs;
+    ceres::HuberLoss huber(1.0);
+    afs.loss_function_ = &huber;
+    Eigen::Matrix<double, 6, 6> H;
+    for (int i = 0; i < 36; ++i) H.d[i] = H36[i];
+    afs.evalFullHessian(kd, map, feat, pose, kind, H, *feat_num);
+    for (int i = 0; i < 36; ++i) H36[i] = H.d[i];
+    if (logdet) *logdet = common::logDet(H, true);             // gf_deg_factor (lidar_mapper_keyframe.cpp:463)
     return 0;
 }
 

@@ -1,5 +1,7 @@
 """The oracle pinned against the reference's OWN SOURCE LINES (oracle/_ref, built by oracle/ref/build_ref.py from the files under
-/root/reference): FeatureExtract::extractCloud (feature_extract.cpp:118-297) and the two map factors (lidar_map_factor.hpp:26-71, 130-174).
+/root/reference): FeatureExtract::extractCloud and match*PointFromMap, the six factor classes, PoseLocalParameterization::Plus, ImageSegmenter,
+evalPointUncertainty / compoundPoseWithCov (associate_uct.hpp) and ActiveFeatureSelection::{evalFullHessian, goodFeatureMatching} with
+common::logDet (lidar_mapper.h:130-573, math.hpp:172-202).
 CPU only; skipped where neither the reference tree nor a prebuilt oracle/_ref/libmloam_ref.so exists."""
 import numpy as np
 import pytest
@@ -236,3 +238,88 @@ def test_image_segmenter_known_answers(orc):
         assert out["scan_start"][r] == first + 5 and out["scan_end"][r] == first + n_r - 6
     # outlier cloud: outlier pixels whose column is a multiple of 5 (600), plus the first point of the output cloud (hpp:391)
     assert len(out["outlier"]) == 2 and np.array_equal(out["outlier"][1], out["cloud"][0])
+
+
+def test_eval_point_uncertainty_is_the_references(ref, synth):
+    """evalPointUncertainty + pointToFS (estimator/src/lidarMapper/associate_uct.hpp:150-215), both overloads, compiled from the reference's own
+    lines: the oracle's restatement (which the HIP path's point_uncertainty_kernel is held against) gives the same 3x3 covariance -- the
+    formula G diag(cov_pose, COV_MEASUREMENT) G^T with G = [(T p)^odot | T D] is pinned; the products' rounding is the shim's, so 1e-12."""
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        pose = np.concatenate([rng.uniform(-3, 3, 3), (lambda q: q / np.linalg.norm(q))(rng.normal(size=4))])
+        A = rng.normal(size=(6, 6)) * 0.02
+        cov_pose = A @ A.T + np.diag([0.0025] * 3 + [0.0003] * 3)
+        cov_meas = np.diag(rng.uniform(0.001, 0.01, 3))
+        p = rng.uniform(-40, 40, 3).astype(np.float32)
+        T4 = synth.pose_to_mat(pose)
+        r1, r2 = ref.ref_eval_point_uncertainty(p, T4, cov_pose, cov_meas)
+        assert np.array_equal(r1, r2)                                      # the two overloads are the same arithmetic
+        got = ref.eval_point_uncertainty(p[None, :], pose, cov_pose, cov_meas)[0]
+        sc = float(np.abs(r1).max())
+        assert float(np.abs(got - r1).max()) <= 1e-12 * sc, (trial, got, r1)
+        assert np.allclose(r1, r1.T, rtol=0, atol=1e-12 * sc)
+
+
+def test_compound_pose_with_cov_is_the_references(ref):
+    """compoundPoseWithCov (associate_uct.hpp:9-86: adjointMatrix, covop1, covop2, Barfoot's fourth-order compound, method 2) compiled from the
+    reference's own lines vs the oracle's restatement (held by the HIP path's mlh_compound_pose_with_cov / cloudUCTAssociateToMap tests)."""
+    rng = np.random.default_rng(9)
+    for trial in range(40):
+        poses, covs = [], []
+        for _ in range(2):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            poses.append(np.concatenate([rng.uniform(-5, 5, 3), q]))
+            A = rng.normal(size=(6, 6)) * rng.uniform(0.005, 0.05)
+            covs.append(A @ A.T)
+        rp, rc = ref.ref_compound_pose_with_cov(poses[0], covs[0], poses[1], covs[1])
+        gp, gc = ref.compound_pose_with_cov(poses[0], covs[0], poses[1], covs[1])
+        assert np.allclose(gp, rp, rtol=0, atol=1e-13)
+        sc = float(np.abs(rc).max())
+        assert float(np.abs(gc - rc).max()) <= 1e-12 * sc, (trial, float(np.abs(gc - rc).max()), sc)
+
+
+def _with_cov(f, rng):
+    a = np.zeros((len(f), 11), np.float32)
+    a[:, :4] = f[:, :4]
+    sd = rng.uniform(0.03, 0.2, (len(f), 3)).astype(np.float32)
+    a[:, 4] = sd[:, 0] ** 2; a[:, 7] = sd[:, 1] ** 2; a[:, 9] = sd[:, 2] ** 2
+    a[:, 10] = a[:, 4] + a[:, 7] + a[:, 9]
+    return a
+
+
+def test_eval_full_hessian_and_logdet_are_the_references(ref, case16, feats16):
+    """ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227) with evaluateFeatJacobianMatching (:130-174) and common::logDet
+    (math.hpp:172-202) compiled from the reference's own lines: same matched count, same information matrix (1e-9: f64 sums of the same rows),
+    same gf_deg_factor."""
+    rng = np.random.default_rng(4)
+    Hr, nr = None, 0
+    Ho, no = None, 0
+    for ch, cloud, f in (("s", case16["surf_map"], feats16[0]), ("c", case16["corner_map"], feats16[1])):
+        f11 = _with_cov(f, rng)
+        Hr, nr, ld = ref.ref_eval_full_hessian(cloud, ch, f11, case16["p0"], Hr, nr)
+        Ho, no = ref.eval_full_hessian(ref.Map(cloud), ch, f11, case16["p0"], Ho, no)
+    assert nr == no and nr > 1000
+    assert float(np.abs(Hr - Ho).max()) <= 1e-9 * float(np.abs(Hr).max())
+    assert abs(ld - ref.logdet(Ho)) <= 1e-9 * abs(ld)
+
+
+@pytest.mark.parametrize("method", ["wo_gf", "rnd", "fps", "gd_fix", "gd_float"])
+def test_good_feature_matching_is_the_references(ref, case16, feats16, method):
+    """ActiveFeatureSelection::goodFeatureMatching (lidar_mapper.h:229-573) compiled from the reference's own lines -- the draw / retry / erase
+    bookkeeping, the per-pick heap, the subset size, the early terminations -- against the oracle's restatement (which the HIP path's
+    selection is held to): the SAME features in the SAME order and the same sub_mat_H, for both kinds and several engine seeds. (The
+    reference seeds its mt19937 from std::random_device; both sides are given the same seed here.)"""
+    rng = np.random.default_rng(6)
+    for ch, cloud, f in (("s", case16["surf_map"], feats16[0][:1500]), ("c", case16["corner_map"], feats16[1][:1200])):
+        f11 = _with_cov(f, rng)
+        om = ref.Map(cloud)
+        for seed in (1, 7, 12345):
+            # wo_gf: the reference sizes sel_feature_idx by num_all * gf_ratio and then stores EVERY match (lidar_mapper.h:247-248, 290): anything
+            # below 1.0 writes past the vector -- the mapper always runs wo_gf at 1.0 (gf_ratio policy, lidar_mapper_keyframe.cpp:476)
+            for ratio in ((0.2, 0.8) if method.startswith("gd") else ((1.0,) if method == "wo_gf" else (0.2,))):
+                r = ref.ref_good_feature_matching(cloud, ch, f11, case16["p0"], method, ratio, seed)
+                o = ref.good_feature_matching(om, ch, f11, case16["p0"], ref.mapper_params(with_ua=True, gf_method=method, gf_ratio=ratio, seed=seed))
+                Ho = np.eye(6) * 1e-6 + 0 * o["H"]
+                assert len(r["sel"]) > 20
+                assert np.array_equal(r["sel"], o["sel"]), (ch, seed, ratio, int(np.sum(r["sel"][:min(len(r["sel"]), len(o["sel"]))] != o["sel"][:min(len(r["sel"]), len(o["sel"]))])))
+                assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
