@@ -189,6 +189,60 @@ def ref_eval_full_hessian(map_points, kind, feats11, pose7, H=None, feat_num=0, 
     return Hm, n.value, ld.value
 
 
+def ref_track_match(kind, prev4, cur4, pose7, distance_sq_threshold=25.0, nearby_scan=2.5):
+    """FeatureExtract::matchCornerFromScan ('c') / matchSurfFromScan ('s') compiled from the reference's own lines (feature_extract.hpp:131-376)"""
+    L = ref_lib()
+    prev = np.ascontiguousarray(prev4, np.float32); cur = np.ascontiguousarray(cur4, np.float32)
+    pose = np.ascontiguousarray(pose7, np.float64)
+    valid = np.zeros(len(cur), np.uint8); coeffs = np.zeros((len(cur), 6))
+    L.ref_track_match(C.c_char(kind.encode()), _ptr(prev), len(prev), _ptr(cur), len(cur), _ptr(pose), C.c_float(distance_sq_threshold),
+                      C.c_float(nearby_scan), _ptr(valid), _ptr(coeffs))
+    return valid, coeffs
+
+
+def ref_scan_factor_eval(kind, point, coeff, pose7, s=1.0):
+    """LidarScanPlaneNormFactor ('S') / LidarScanEdgeFactorVector ('E') from the reference's own lines (lidar_scan_factor.hpp:25-62, 236-279)"""
+    L = ref_lib()
+    point = np.ascontiguousarray(point, np.float64)
+    coeff = np.ascontiguousarray(np.concatenate([np.asarray(coeff, np.float64), np.zeros(6)])[:6])
+    pose = np.ascontiguousarray(pose7, np.float64)
+    rows = 1 if kind == "S" else 3
+    r = np.zeros(rows); J = np.zeros((rows, 7))
+    L.ref_scan_factor_eval(C.c_char(kind.encode()), _ptr(point), _ptr(coeff), C.c_double(s), _ptr(pose), _ptr(r), _ptr(J))
+    return r, J
+
+
+def ref_transform_to_end(points4, pose7, distortion=True, scan_period=0.1):
+    """TransformToEnd (utility.h:79-100) from the reference's own lines"""
+    L = ref_lib()
+    pts = np.ascontiguousarray(points4, np.float32); pose = np.ascontiguousarray(pose7, np.float64)
+    out = np.zeros_like(pts)
+    L.ref_transform_to_end(_ptr(pts), len(pts), _ptr(pose), int(bool(distortion)), C.c_float(scan_period), _ptr(out))
+    return out
+
+
+def ref_cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
+    """cloudUCTAssociateToMap compiled from the reference's own lines (lidar_mapper_keyframe.cpp:1116-1158)"""
+    L = ref_lib()
+    p = np.ascontiguousarray(pts11, np.float32)
+    pg, cg = np.ascontiguousarray(pose_global, np.float64), np.ascontiguousarray(cov_global, np.float64)
+    e, ec = np.ascontiguousarray(ext, np.float64), np.ascontiguousarray(ext_cov, np.float64)
+    cm = np.ascontiguousarray(cov_meas, np.float64)
+    out = np.zeros_like(p); cnt = C.c_int(0)
+    L.ref_cloud_uct_associate_to_map(_ptr(p), p.shape[0], _ptr(pg), _ptr(cg), _ptr(e), _ptr(ec), e.shape[0], _ptr(cm), int(bool(with_ua)),
+                                     C.c_double(trace_threshold), _ptr(out), C.byref(cnt))
+    return out[:cnt.value].copy()
+
+
+def ref_eval_degeneracy(H, eig_thre=100.0):
+    """evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204) from the reference's own lines, on a fresh PoseLocalParameterization"""
+    L = ref_lib()
+    H = np.ascontiguousarray(H, np.float64)
+    V = np.zeros((6, 6)); ev = np.zeros(6); deg = C.c_int(0)
+    L.ref_eval_degeneracy(_ptr(H), C.c_double(eig_thre), C.byref(deg), _ptr(V), _ptr(ev))
+    return dict(is_degenerate=bool(deg.value), V_update=V, eigval=ev)
+
+
 def ref_compound_pose_with_cov(pose1, cov1, pose2, cov2):
     """the reference's own compoundPoseWithCov lines (associate_uct.hpp:9-86, method 2)"""
     L = ref_lib()

@@ -40,6 +40,21 @@ CUTS = [
     ("calib_edge_tail.inc", "factor/lidar_online_calib_factor.hpp", 223, 227, "private:"),
     ("plp_class.inc", "factor/pose_local_parameterization.h", 21, 33, "class PoseLocalParameterization"),
     ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
+    ("pose_ctor_default.inc", "estimator/pose.cpp", 16, 23, "Pose::Pose()"),
+    ("pose_ctor_copy.inc", "estimator/pose.cpp", 25, 32, "Pose::Pose(const Pose &pose)"),
+    ("pose_ctor_qt.inc", "estimator/pose.cpp", 34, 41, "Pose::Pose(const Eigen::Quaterniond &q"),
+    ("pose_inverse_update.inc", "estimator/pose.cpp", 99, 108, "Pose Pose::inverse() const"),
+    ("update_cov.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 191, 200, "void updateCov(pcl::PointXYZIWithCov &po"),
+    ("uct_compound_pose.inc", "lidarMapper/associate_uct.hpp", 88, 147, "// fixed: topLeftCorner<3, 3>()"),
+    ("cloud_uct_associate.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1116, 1158, "void cloudUCTAssociateToMap"),
+    ("eval_degeneracy.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1171, 1204, "// TODO: still have some bugs"),
+    ("scan_match_decls.inc", "featureExtract/feature_extract.hpp", 78, 90, "template <typename PointType>"),
+    ("transform_start_end.inc", "utility/utility.h", 54, 100, "template <typename PointType>"),
+    ("match_from_scan.inc", "featureExtract/feature_extract.hpp", 131, 376, "template <typename PointType>"),
+    ("scan_plane_head.inc", "factor/lidar_scan_factor.hpp", 25, 62, "class LidarScanPlaneNormFactor"),
+    ("scan_plane_tail.inc", "factor/lidar_scan_factor.hpp", 122, 126, "private:"),
+    ("scan_edge_vec_head.inc", "factor/lidar_scan_factor.hpp", 236, 279, "class LidarScanEdgeFactorVector"),
+    ("scan_edge_vec_tail.inc", "factor/lidar_scan_factor.hpp", 339, 343, "private:"),
     ("feature_structs.inc", "estimator/parameters.h", 163, 191, "class PointPlaneFeature"),
     ("extract_cov.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 202, 214, "void extractCov"),
     ("log_det.inc", "algos/math.hpp", 172, 202, "template <typename MatrixType>"),

@@ -5,6 +5,7 @@
 // block goes where); the arithmetic inside Eigen itself stays a restatement.
 #pragma once
 #include <cmath>
+#include <limits>
 #include <cstddef>
 #include <type_traits>
 #include <vector>
@@ -31,6 +32,7 @@ template <typename T, int BR, int BC> struct BlockRef {
     T *base; int ld;                                             // element (i, j) at base[i * ld + j]
     BlockRef &operator=(const Mat<T, BR, BC> &m);
     operator Mat<T, BR, BC>() const;
+    Mat<T, BC, BR> transpose() const;
 };
 
 template <typename T, int R, int C> struct CommaInit {
@@ -57,6 +59,27 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
     static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     static Matrix Zero() { return Matrix(); }
     void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
+    const Mat &real() const { return *this; }
+    BlockRef<T, R, 1> col(int j) { return BlockRef<T, R, 1>{d + j, C}; }
+    // general inverse (Gauss-Jordan with partial pivoting): library arithmetic, used for mat_V_f.transpose().inverse() only
+    Mat inverse() const
+    {
+        static_assert(R == C, "square");
+        T a[R][2 * R];
+        for (int i = 0; i < R; ++i) for (int j = 0; j < R; ++j) { a[i][j] = (*this)(i, j); a[i][R + j] = i == j ? T(1) : T(0); }
+        for (int c = 0; c < R; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < R; ++r) if (std::abs(a[r][c]) > std::abs(a[piv][c])) piv = r;
+            if (piv != c) for (int j = 0; j < 2 * R; ++j) std::swap(a[c][j], a[piv][j]);
+            const T dinv = T(1) / a[c][c];
+            for (int j = 0; j < 2 * R; ++j) a[c][j] *= dinv;
+            for (int r = 0; r < R; ++r) if (r != c) { const T f = a[r][c]; if (f != T(0)) for (int j = 0; j < 2 * R; ++j) a[r][j] -= f * a[c][j]; }
+        }
+        Mat m;
+        for (int i = 0; i < R; ++i) for (int j = 0; j < R; ++j) m(i, j) = a[i][R + j];
+        return m;
+    }
     T trace() const { T s = d[0]; for (int i = 1; i < R; ++i) s += (*this)(i, i); return s; }
     T dot(const Matrix &o) const { T s = d[0] * o.d[0]; for (int i = 1; i < R * C; ++i) s += d[i] * o.d[i]; return s; }
     T squaredNorm() const { return dot(*this); }
@@ -175,6 +198,8 @@ template <typename T> struct PartialPivLU<Mat<T, Dynamic, Dynamic>> {
     Perm permutationP() const { return Perm(); }
 };
 
+template <typename T, int BR, int BC> Mat<T, BC, BR> BlockRef<T, BR, BC>::transpose() const { return Mat<T, BR, BC>(*this).transpose(); }
+
 typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 4, 1> Vector4d;
@@ -217,6 +242,22 @@ template <typename T> struct Quaternion {
                           w_ * b.y_ + y_ * b.w_ + z_ * b.x_ - x_ * b.z_, w_ * b.z_ + z_ * b.w_ + x_ * b.y_ - y_ * b.x_);
     }
     Quaternion conjugate() const { return Quaternion(w_, -x_, -y_, -z_); }
+    static Quaternion Identity() { return Quaternion(T(1), T(0), T(0), T(0)); }
+    // QuaternionBase::inverse: conjugate / squaredNorm (zero quaternion -> zero)
+    Quaternion inverse() const { const T n2 = x_ * x_ + y_ * y_ + z_ * z_ + w_ * w_; if (n2 > T(0)) return Quaternion(w_ / n2, -x_ / n2, -y_ / n2, -z_ / n2); return Quaternion(T(0), T(0), T(0), T(0)); }
+    T dot(const Quaternion &o) const { return x_ * o.x_ + y_ * o.y_ + z_ * o.z_ + w_ * o.w_; }
+    // QuaternionBase::slerp (Eigen 3.3 Geometry/Quaternion.h): library arithmetic, restated
+    Quaternion slerp(T t, const Quaternion &other) const
+    {
+        const T one = T(1) - std::numeric_limits<T>::epsilon();
+        const T d = dot(other), absD = std::abs(d);
+        T scale0, scale1;
+        if (absD >= one) { scale0 = T(1) - t; scale1 = t; }
+        else { const T theta = std::acos(absD), sinTheta = std::sin(theta); scale0 = std::sin((T(1) - t) * theta) / sinTheta; scale1 = std::sin(t * theta) / sinTheta; }
+        if (d < T(0)) scale1 = -scale1;
+        return Quaternion(scale0 * w_ + scale1 * other.w_, scale0 * x_ + scale1 * other.x_, scale0 * y_ + scale1 * other.y_, scale0 * z_ + scale1 * other.z_);
+    }
+    void normalize() { *this = normalized(); }
     Quaternion normalized() const { const T n = std::sqrt(x_ * x_ + y_ * y_ + z_ * z_ + w_ * w_); return Quaternion(w_ / n, x_ / n, y_ / n, z_ / n); }
     Matrix<T, 3, 3> toRotationMatrix() const
     {
@@ -271,6 +312,14 @@ template <> struct SelfAdjointEigenSolver<Matrix3f> {
     explicit SelfAdjointEigenSolver(const Matrix3f &A) { float a[3][3]; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = A(i, j); e = orc::eig3_sym_f(a); }
     Vector3f eigenvalues() const { return Vector3f(e.val[0], e.val[1], e.val[2]); }
     Matrix3f eigenvectors() const { Matrix3f V; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V(i, j) = e.vec[i][j]; return V; }
+};
+// SelfAdjointEigenSolver<Matrix<double, 6, 6>> (evalDegenracy): eigenvalues ascending, eigenvectors in columns -- the oracle's cyclic Jacobi
+// (library arithmetic restated; evalDegenracy's projector V_f^-T V_p^T does not depend on the eigenvectors' signs)
+template <> struct SelfAdjointEigenSolver<Matrix<double, 6, 6>> {
+    double val[6], vec[36];
+    explicit SelfAdjointEigenSolver(const Matrix<double, 6, 6> &A) { orc::jacobi_eig_sym_d(A.d, 6, val, vec); }
+    Matrix<double, 6, 1> eigenvalues() const { Matrix<double, 6, 1> m; for (int i = 0; i < 6; ++i) m.d[i] = val[i]; return m; }
+    Matrix<double, 6, 6> eigenvectors() const { Matrix<double, 6, 6> m; for (int i = 0; i < 36; ++i) m.d[i] = vec[i]; return m; }
 };
 struct MatrixXf {
     int r = 0, c = 0;

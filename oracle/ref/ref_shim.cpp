@@ -17,6 +17,11 @@
 //   PoseLocalParameterization::{setParameter, Plus}   estimator/src/factor/pose_local_parameterization.h:21-33, .cpp:16-45
 //   pointToFS, evalPointUncertainty (both overloads)  estimator/src/lidarMapper/associate_uct.hpp:150-156, 164-193, 195-215
 //   adjointMatrix, covop1, covop2, compoundPoseWithCov (explicit-covariance overload)   associate_uct.hpp:9-86
+//   TransformToStart / TransformToEnd      estimator/src/utility/utility.h:54-100
+//   FeatureExtract::match{Corner,Surf}FromScan        estimator/src/featureExtract/feature_extract.hpp:131-376 (+ decls 78-90)
+//   LidarScanPlaneNormFactor, LidarScanEdgeFactorVector   estimator/src/factor/lidar_scan_factor.hpp:25-62, 122-126; 236-279, 339-343
+//   Pose::{Pose(), Pose(const Pose &), Pose(q, t, td), inverse, update}   estimator/src/estimator/pose.cpp:16-41, 99-108
+//   compoundPoseWithCov (pose.cov_ overload), cloudUCTAssociateToMap, evalDegenracy   associate_uct.hpp:88-147; lidar_mapper_keyframe.cpp:1116-1158, 1171-1204
 //   ActiveFeatureSelection::{evaluateFeatJacobianMatching, evalFullHessian, goodFeatureMatching}   estimator/src/lidarMapper/lidar_mapper.h:130-573
 //     (+ PointPlaneFeature / FeatureWithScore parameters.h:163-191, extractCov point_with_cov.hpp:202-214, common::logDet math.hpp:172-202,
 //      common::RandomGeneratorInt random_generator.hpp:52-66, the two limits lidar_mapper.h:82-83)
@@ -55,6 +60,10 @@ template <typename P> struct PointCloud {
     size_t size() const { return points.size(); }
     void resize(size_t n) { points.resize(n); }
     typename std::vector<P>::iterator begin() { return points.begin(); }
+    typename std::vector<P>::const_iterator begin() const { return points.begin(); }
+    typename std::vector<P>::const_iterator end() const { return points.end(); }
+    P &operator[](size_t i) { return points[i]; }
+    const P &operator[](size_t i) const { return points[i]; }
     // a position that is no longer inside the row erases nothing (std::vector::erase there is undefined: oracle/image_segmenter.hpp U2)
     typename std::vector<P>::iterator erase(typename std::vector<P>::iterator it) { return (it < points.begin() || it >= points.end()) ? points.end() : points.erase(it); }
     void push_back(const P &p) { points.push_back(p); }
@@ -86,13 +95,30 @@ template <typename P> struct KdTreeFLANN {                    // 3p: the oracle'
     int nearestKSearch(const P &p, int k, std::vector<int> &idx, std::vector<float> &sqd) const
     {
         const float q[3] = {p.x, p.y, p.z};
+        idx.resize(size_t(k)); sqd.resize(size_t(k));          // pcl::KdTreeFLANN::nearestKSearch sizes its outputs itself (kdtree_flann.hpp)
         return tree.knn(q, k, idx.data(), sqd.data());
     }
 };
 }  // namespace pcl
 struct NullLog { template <typename T> NullLog &operator<<(const T &) { return *this; } };
 #define LOG(x) NullLog()
-struct Pose { Eigen::Quaterniond q_; Eigen::Vector3d t_; Eigen::Matrix4d T_; Eigen::Matrix<double, 6, 6> cov_; };   // pose.h:38-66 (the members the cut lines read)
+class Pose {                                                  // pose.h:37-66: the members and the methods this path uses; their bodies are pose.cpp's own lines (below)
+public:
+    Pose();
+    Pose(const Pose &pose);
+    Pose(const Eigen::Quaterniond &q, const Eigen::Vector3d &t, const double &td = 0);
+    void update();
+    Pose inverse() const;
+    double td_;
+    Eigen::Quaterniond q_;
+    Eigen::Vector3d t_;
+    Eigen::Matrix4d T_;
+    Eigen::Matrix<double, 6, 6> cov_;
+};
+#include "../_ref/gen/pose_ctor_default.inc"                  // Pose::Pose()                                pose.cpp:16-23
+#include "../_ref/gen/pose_ctor_copy.inc"                     // Pose::Pose(const Pose &)                    pose.cpp:25-32
+#include "../_ref/gen/pose_ctor_qt.inc"                       // Pose::Pose(q, t, td)                        pose.cpp:34-41
+#include "../_ref/gen/pose_inverse_update.inc"                // Pose::inverse, Pose::update                 pose.cpp:99-108
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 #include "../_ref/gen/feature_structs.inc"                    // class PointPlaneFeature, class FeatureWithScore  (parameters.h:163-191)
 float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;         // parameters.cpp:232-233
@@ -131,11 +157,15 @@ int N_SCANS = 0;                                              // parameters.cpp 
 class FeatureExtract {
 public:
     void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature);
+#include "../_ref/gen/scan_match_decls.inc"                   // declarations of match{Corner,Surf}FromScan (feature_extract.hpp:78-90)
 #include "../_ref/gen/match_point_decls.inc"                  // the declarations of match{Corner,Surf}PointFromMap (default arguments live here)
 };
 #include "../_ref/gen/extract_cloud.inc"                      // void FeatureExtract::extractCloud(...) { ... }
 #include "../_ref/gen/match_corner_point.inc"                 // template <typename PointType> bool FeatureExtract::matchCornerPointFromMap(...)
 #include "../_ref/gen/match_surf_point.inc"
+float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;      // parameters.cpp:50-52 (set by the test entry points)
+#include "../_ref/gen/transform_start_end.inc"                // TransformToStart, TransformToEnd   utility.h:54-100
+#include "../_ref/gen/match_from_scan.inc"                    // FeatureExtract::matchCornerFromScan / matchSurfFromScan   feature_extract.hpp:131-376
 
 #include "../_ref/gen/utility_head.inc"                       // class Utility { public: deltaQ, skewSymmetric
 };
@@ -151,6 +181,10 @@ public:
 #include "../_ref/gen/calib_plane_tail.inc"
 #include "../_ref/gen/calib_edge_head.inc"                    // LidarOnlineCalibEdgeFactor
 #include "../_ref/gen/calib_edge_tail.inc"
+#include "../_ref/gen/scan_plane_head.inc"                    // LidarScanPlaneNormFactor   lidar_scan_factor.hpp:25-62, 122-126
+#include "../_ref/gen/scan_plane_tail.inc"
+#include "../_ref/gen/scan_edge_vec_head.inc"                 // LidarScanEdgeFactorVector  lidar_scan_factor.hpp:236-279, 339-343
+#include "../_ref/gen/scan_edge_vec_tail.inc"
 #include "../_ref/gen/plp_class.inc"                          // class PoseLocalParameterization
 bool PoseLocalParameterization::ComputeJacobian(const double *, double *) const { return true; }   // (not cut: Map<Matrix<7,6>>::topRows; the test restates [I6; 0])
 #include "../_ref/gen/plp_plus.inc"                           // setParameter, Plus
@@ -196,6 +230,21 @@ public:
     ceres::LossFunction *loss_function_;                      // lidar_mapper.h:628-629
     common::RandomGeneratorInt<size_t> rgi_;
 };
+
+// ---------------------------------------------------------------- cloudUCTAssociateToMap, evalDegenracy (lidar_mapper_keyframe.cpp) from the reference's own lines
+size_t NUM_OF_LASER = 2;                                      // parameters.cpp
+bool with_ua_flag = true, is_degenerate = false;              // lidar_mapper_keyframe.cpp:130-131
+double TRACE_THRESHOLD_MAPPING = 0.6, MAP_EIG_THRE = 100.0;   // parameters.cpp
+std::vector<Eigen::Matrix<double, 1, 6>> d_factor_list;       // lidar_mapper_keyframe.cpp:118-121
+std::vector<Eigen::Matrix<double, 6, 6>> d_eigvec_list;
+Eigen::Matrix<double, 6, 6> mat_P;
+namespace common {
+#include "../_ref/gen/update_cov.inc"                         // void updateCov(pcl::PointXYZIWithCov &po, const Eigen::Matrix3d &)   point_with_cov.hpp:191-200
+}
+#include "../_ref/gen/uct_compound_pose.inc"                  // compoundPoseWithCov(pose_1, pose_2, pose_cp, method)   associate_uct.hpp:88-147
+#include "../_ref/gen/cloud_uct_associate.inc"                // cloudUCTAssociateToMap                                   lidar_mapper_keyframe.cpp:1116-1158
+#define INFO 0
+#include "../_ref/gen/eval_degeneracy.inc"                    // evalDegenracy(mat_H, local_parameterization)            lidar_mapper_keyframe.cpp:1171-1204
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
@@ -428,6 +477,118 @@ int ref_eval_full_hessian(char kind, const float *map11, int n_map, const float 
     afs.evalFullHessian(kd, map, feat, pose, kind, H, *feat_num);
     for (int i = 0; i < 36; ++i) H36[i] = H.d[i];
     if (logdet) *logdet = common::logDet(H, true);             // gf_deg_factor (lidar_mapper_keyframe.cpp:463)
+    return 0;
+}
+
+// LidarTracker's matching (lidar_tracker.cpp:58-59): prev4 / cur4 rows [x y z ring id]; valid[i], coeffs[i] (corner: the two line points;
+// surf: plane n, d) per CURRENT feature i
+int ref_track_match(char kind, const float *prev4, int n_prev, const float *cur4, int n_cur, const double pose7[7], float dist_sq_thr, float nearby_scan,
+                    unsigned char *valid, double *coeffs)
+{
+    DISTANCE_SQ_THRESHOLD = dist_sq_thr; NEARBY_SCAN = nearby_scan;
+    auto fill = [](PointICloud &c, const float *a, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c.points[size_t(i)].x = a[4 * i]; c.points[size_t(i)].y = a[4 * i + 1]; c.points[size_t(i)].z = a[4 * i + 2]; c.points[size_t(i)].intensity = a[4 * i + 3]; }
+    };
+    PointICloud prev, cur;
+    fill(prev, prev4, n_prev); fill(cur, cur4, n_cur);
+    pcl::KdTreeFLANN<PointI>::Ptr kd(new pcl::KdTreeFLANN<PointI>());
+    kd->setInputCloud(prev);
+    Pose pose;
+    pose.t_ = Eigen::Vector3d(pose7[0], pose7[1], pose7[2]);
+    pose.q_ = Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]);
+    FeatureExtract f;
+    std::vector<PointPlaneFeature> feats;
+    if (kind == 'c') f.matchCornerFromScan<PointI>(kd, prev, cur, pose, feats);
+    else f.matchSurfFromScan<PointI>(kd, prev, cur, pose, feats);
+    for (int i = 0; i < n_cur; ++i) { valid[i] = 0; for (int k = 0; k < 6; ++k) coeffs[size_t(i) * 6 + k] = 0.0; }
+    for (const PointPlaneFeature &ft : feats) {
+        valid[ft.idx_] = 1;
+        for (int k = 0; k < 6 && k < ft.coeffs_.size(); ++k) coeffs[ft.idx_ * 6 + k] = ft.coeffs_(k);
+    }
+    return 0;
+}
+
+// kind 'S': LidarScanPlaneNormFactor (1 residual), 'E': LidarScanEdgeFactorVector (3 residuals); J rows x 7 or NULL
+int ref_scan_factor_eval(char kind, const double point[3], const double *coeff, double s, const double pose7[7], double *r, double *J)
+{
+    Eigen::Vector3d p(point[0], point[1], point[2]);
+    const double *params[1] = {pose7};
+    double *jac[1] = {J};
+    if (kind == 'S') {
+        LidarScanPlaneNormFactor f(p, Eigen::Vector4d(coeff[0], coeff[1], coeff[2], coeff[3]), s);
+        f.Evaluate(params, r, J ? jac : nullptr);
+    } else {
+        Eigen::VectorXd c(6);
+        for (int i = 0; i < 6; ++i) c(i) = coeff[i];
+        LidarScanEdgeFactorVector f(p, c, s);
+        f.Evaluate(params, r, J ? jac : nullptr);
+    }
+    return 0;
+}
+
+// TransformToEnd (utility.h:79-100) over rows [x y z intensity]
+int ref_transform_to_end(const float *pts4, int n, const double pose7[7], int distortion, float scan_period, float *out4)
+{
+    Pose pose;
+    pose.t_ = Eigen::Vector3d(pose7[0], pose7[1], pose7[2]);
+    pose.q_ = Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]);
+    for (int i = 0; i < n; ++i) {
+        PointI a, b;
+        a.x = pts4[4 * i]; a.y = pts4[4 * i + 1]; a.z = pts4[4 * i + 2]; a.intensity = pts4[4 * i + 3];
+        TransformToEnd(a, b, pose, distortion != 0, scan_period);
+        out4[4 * i] = b.x; out4[4 * i + 1] = b.y; out4[4 * i + 2] = b.z; out4[4 * i + 3] = b.intensity;
+    }
+    return 0;
+}
+
+// cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158): 11-float PointXYZIWithCov records in and out; poses [t, q(xyzw)], covariances 6x6
+int ref_cloud_uct_associate_to_map(const float *in11, int n, const double pose_global[7], const double cov_global[36], const double *ext_poses, const double *ext_covs,
+                                   int n_lidar, const double cov_meas[9], int with_ua, double trace_threshold, float *out11, int *n_out)
+{
+    NUM_OF_LASER = size_t(n_lidar); with_ua_flag = with_ua != 0; TRACE_THRESHOLD_MAPPING = trace_threshold;
+    for (int i = 0; i < 9; ++i) COV_MEASUREMENT.d[i] = cov_meas[i];
+    auto mk = [](const double *p, const double *c) {
+        Pose P(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2]));
+        for (int i = 0; i < 36; ++i) P.cov_.d[i] = c[i];
+        return P;
+    };
+    const Pose pg = mk(pose_global, cov_global);
+    std::vector<Pose> pe;
+    for (int k = 0; k < n_lidar; ++k) pe.push_back(mk(ext_poses + 7 * k, ext_covs + 36 * k));
+    PointICovCloud local, global;
+    local.points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) {
+        PointIWithCov &q = local.points[size_t(i)];
+        q.x = in11[11 * i]; q.y = in11[11 * i + 1]; q.z = in11[11 * i + 2]; q.intensity = in11[11 * i + 3];
+        for (int k = 0; k < 6; ++k) q.cov_vec[k] = in11[11 * i + 4 + k];
+        q.cov_trace = in11[11 * i + 10];
+    }
+    cloudUCTAssociateToMap(local, global, pg, pe);
+    *n_out = int(global.size());
+    for (size_t i = 0; i < global.size(); ++i) {
+        const PointIWithCov &q = global.points[i];
+        float *o = out11 + 11 * i;
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.intensity;
+        for (int k = 0; k < 6; ++k) o[4 + k] = q.cov_vec[k];
+        o[10] = q.cov_trace;
+    }
+    return 0;
+}
+
+// evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204) on a fresh PoseLocalParameterization: is_degenerate_, V_update_ (row-major), eigenvalues
+int ref_eval_degeneracy(const double H36[36], double eig_thre, int *is_deg, double V36[36], double eig[6])
+{
+    MAP_EIG_THRE = eig_thre;
+    Eigen::Matrix<double, 6, 6> H;
+    for (int i = 0; i < 36; ++i) H.d[i] = H36[i];
+    PoseLocalParameterization plp;
+    plp.setParameter();
+    d_factor_list.clear(); d_eigvec_list.clear();
+    evalDegenracy(H, &plp);
+    *is_deg = plp.is_degenerate_ ? 1 : 0;
+    for (int i = 0; i < 36; ++i) V36[i] = plp.V_update_.d[i];
+    for (int i = 0; i < 6; ++i) eig[i] = d_factor_list.back().d[i];
     return 0;
 }
 

@@ -1,6 +1,7 @@
 """The oracle pinned against the reference's OWN SOURCE LINES (oracle/_ref, built by oracle/ref/build_ref.py from the files under
 /root/reference): FeatureExtract::extractCloud and match*PointFromMap, the six factor classes, PoseLocalParameterization::Plus, ImageSegmenter,
-evalPointUncertainty / compoundPoseWithCov (associate_uct.hpp) and ActiveFeatureSelection::{evalFullHessian, goodFeatureMatching} with
+evalPointUncertainty / compoundPoseWithCov (associate_uct.hpp), cloudUCTAssociateToMap and evalDegenracy (lidar_mapper_keyframe.cpp), the
+tracker's match*FromScan / TransformToEnd / scan factors, and ActiveFeatureSelection::{evalFullHessian, goodFeatureMatching} with
 common::logDet (lidar_mapper.h:130-573, math.hpp:172-202).
 CPU only; skipped where neither the reference tree nor a prebuilt oracle/_ref/libmloam_ref.so exists."""
 import numpy as np
@@ -323,3 +324,98 @@ def test_good_feature_matching_is_the_references(ref, case16, feats16, method):
                 assert len(r["sel"]) > 20
                 assert np.array_equal(r["sel"], o["sel"]), (ch, seed, ratio, int(np.sum(r["sel"][:min(len(r["sel"]), len(o["sel"]))] != o["sel"][:min(len(r["sel"]), len(o["sel"]))])))
                 assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
+
+
+def test_track_matching_is_the_references(ref, track_case):
+    """LidarTracker's correspondence search -- FeatureExtract::matchCornerFromScan / matchSurfFromScan (feature_extract.hpp:131-376: nearest
+    previous-frame point, then the two scan-line walks with NEARBY_SCAN and DISTANCE_SQ_THRESHOLD) over TransformToStart (utility.h:54-77) --
+    compiled from the reference's own lines: the oracle's restatement (which the HIP tracker is held to) accepts the same features with the
+    same coefficient bits, at the identity and at a moved pose estimate."""
+    tc = track_case
+    poses = [np.array([0, 0, 0, 0, 0, 0, 1.0]), tc["motion"] if "motion" in tc else np.array([0.3, -0.1, 0.0, 0, 0, 0.0131, 0.99991])]
+    for pose in poses:
+        for kind, prev, cur in (("c", tc["corner_last"], tc["corner_sharp"]), ("s", tc["surf_last"], tc["surf_flat"])):
+            rv, rc = ref.ref_track_match(kind, prev, cur, pose)
+            ov, oc = ref.track_match(kind, prev, cur, pose)
+            assert rv.sum() > 50
+            assert np.array_equal(rv, ov), (kind, int(np.sum(rv != ov)))
+            m = rv.astype(bool)
+            assert np.array_equal(rc[m].astype(np.float32).view(np.uint32), oc[m].astype(np.float32).view(np.uint32)), kind
+            np.testing.assert_allclose(rc[m], oc[m], rtol=1e-12, atol=1e-12)
+
+
+def test_scan_factors_and_transform_to_end_are_the_references(ref):
+    """LidarScanPlaneNormFactor / LidarScanEdgeFactorVector (lidar_scan_factor.hpp:25-62, 236-279) and TransformToEnd (utility.h:79-100) from the
+    reference's own lines vs the oracle (slerp from the identity is the shim's restatement of Eigen 3.3 on one side, the oracle's on the other)."""
+    rng = np.random.default_rng(10)
+    for trial in range(30):
+        q = rng.normal(size=4) * np.array([0.05, 0.05, 0.05, 0]) + np.array([0, 0, 0, 1.0]); q /= np.linalg.norm(q)
+        pose = np.concatenate([rng.uniform(-0.5, 0.5, 3), q])
+        p = rng.uniform(-20, 20, 3)
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        for kind, coeff in (("S", np.concatenate([n, [rng.uniform(-3, 3)]])), ("E", np.concatenate([p + rng.normal(0, 0.5, 3), p + rng.normal(0, 0.5, 3)]))):
+            for s_ in (1.0, 0.37):
+                rr, rJ = ref.ref_scan_factor_eval(kind, p, coeff, pose, s_)
+                orr, oJ = ref.scan_factor_eval(kind, p, coeff, pose, s_)
+                np.testing.assert_allclose(orr, rr, rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(oJ, rJ, rtol=1e-11, atol=1e-11)
+    pts = np.zeros((500, 4), np.float32)
+    pts[:, :3] = rng.uniform(-30, 30, (500, 3))
+    pts[:, 3] = rng.integers(0, 16, 500) + rng.uniform(0, 0.0999, 500).astype(np.float32)
+    pose = np.array([0.4, -0.1, 0.02, 0.0, 0.0, np.sin(0.01), np.cos(0.01)])
+    for dist in (True, False):
+        a = ref.ref_transform_to_end(pts, pose, dist, 0.1)
+        b = ref.transform_to_end(pts, pose, dist, 0.1)
+        assert np.array_equal(a[:, 3], b[:, 3])
+        np.testing.assert_allclose(a[:, :3], b[:, :3], rtol=0, atol=4e-6)              # f64 math stored to f32: at most an ulp at 30 m
+        assert np.mean(a.view(np.uint32) == b.view(np.uint32)) > 0.99
+
+
+def test_cloud_uct_associate_to_map_is_the_references(ref, feats16):
+    """cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158) over the pose.cov_ overload of compoundPoseWithCov (associate_uct.hpp:88-147),
+    Pose::inverse / update (pose.cpp:99-108) and updateCov, from the reference's own lines: the same points survive the trace gate, in the same
+    order, with the same map-frame coordinates (f32 bits) and covariances (1e-6 relative in f32)."""
+    rng = np.random.default_rng(12)
+    f = feats16[0][:4000]
+    kf = np.zeros((len(f), 11), np.float32)
+    kf[:, :3] = f[:, :3]
+    kf[:, 3] = rng.integers(0, 2, len(f))
+    q = np.array([0.01, -0.02, 0.3, 1.0]); q /= np.linalg.norm(q)
+    pose_global = np.concatenate([[1.5, -0.7, 0.2], q])
+    A = rng.normal(size=(6, 6)) * 0.001
+    cov_global = A @ A.T + np.eye(6) * 1e-5
+    ext = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.1, -0.5, 0.02, 0, 0, 0.0998334166468, 0.995004165278]])
+    ext_cov = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    cov_meas = np.diag([0.0025] * 3)
+    for with_ua, thr in ((True, 0.6), (True, 0.035), (False, 0.6)):
+        r = ref.ref_cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        o = ref.cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        assert r.shape == o.shape and 0 < len(r) <= len(kf)
+        assert np.array_equal(r[:, :4].view(np.uint32), o[:, :4].view(np.uint32))
+        np.testing.assert_allclose(o[:, 4:], r[:, 4:], rtol=2e-6, atol=1e-12)
+    assert len(ref.ref_cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, True, 0.035)) < len(kf)   # the gate really cuts
+
+
+def test_eval_degeneracy_is_the_references(ref):
+    """evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204) from the reference's own lines: which eigen-directions fall under MAP_EIG_THRE (the loop
+    leaves at the first one that does not), the flag, and the projector V_update = V_f^-T V_p^T the solver's Plus then applies. The 6x6
+    eigen-decomposition underneath is the oracle's on both sides; the projector does not depend on the eigenvectors' signs."""
+    rng = np.random.default_rng(13)
+    n_deg = 0
+    for trial in range(60):
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        k = trial % 4                                                   # 0..3 eigenvalues under the threshold
+        ev = np.concatenate([rng.uniform(1.0, 80.0, k), rng.uniform(150.0, 5000.0, 6 - k)])
+        H = (Q * ev) @ Q.T
+        H = 0.5 * (H + H.T)
+        r = ref.ref_eval_degeneracy(H, 100.0)
+        o = ref.eval_degeneracy(H, 100.0)
+        assert r["is_degenerate"] == o["is_degenerate"] == (k > 0)
+        np.testing.assert_allclose(np.sort(r["eigval"]), np.sort(ev), rtol=1e-9)
+        if k > 0:
+            n_deg += 1
+            np.testing.assert_allclose(o["V_update"], r["V_update"], rtol=0, atol=1e-9)
+            # the projector keeps exactly the non-degenerate subspace
+            keep = Q[:, k:] @ Q[:, k:].T
+            np.testing.assert_allclose(r["V_update"], keep, rtol=0, atol=1e-9)
+    assert n_deg >= 40
