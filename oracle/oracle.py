@@ -243,6 +243,20 @@ def ref_eval_degeneracy(H, eig_thre=100.0):
     return dict(is_degenerate=bool(deg.value), V_update=V, eigval=ev)
 
 
+def ref_downsample_current_scan(surf4, corner4, leaf_surf, leaf_corner, ext_poses, ext_covs, cov_meas, with_ua=True, trace_threshold=0.6):
+    """downsampleCurrentScan compiled from the reference's own lines (lidar_mapper_keyframe.cpp:356-421); its filter objects are the oracle's
+    literal VoxelGridCovarianceMLOAM<PointI> restatement (std::sort member order). Returns (surf11, corner11)."""
+    L = ref_lib()
+    s4 = np.ascontiguousarray(surf4, np.float32); c4 = np.ascontiguousarray(corner4, np.float32)
+    ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7); ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
+    cm = np.ascontiguousarray(cov_meas, np.float64)
+    so = np.zeros((max(len(s4), 1), 11), np.float32); co = np.zeros((max(len(c4), 1), 11), np.float32)
+    ns, nc = C.c_int(0), C.c_int(0)
+    L.ref_downsample_current_scan(_ptr(s4), len(s4), _ptr(c4), len(c4), C.c_float(leaf_surf), C.c_float(leaf_corner), _ptr(ep), _ptr(ec), len(ep), _ptr(cm),
+                                  int(bool(with_ua)), C.c_double(trace_threshold), _ptr(so), C.byref(ns), _ptr(co), C.byref(nc))
+    return so[:ns.value].copy(), co[:nc.value].copy()
+
+
 def ref_compound_pose_with_cov(pose1, cov1, pose2, cov2):
     """the reference's own compoundPoseWithCov lines (associate_uct.hpp:9-86, method 2)"""
     L = ref_lib()

@@ -40,6 +40,9 @@ CUTS = [
     ("calib_edge_tail.inc", "factor/lidar_online_calib_factor.hpp", 223, 227, "private:"),
     ("plp_class.inc", "factor/pose_local_parameterization.h", 21, 33, "class PoseLocalParameterization"),
     ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
+    ("point_cov_ctor_default.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 57, 62, "inline PointXYZIWithCov()"),
+    ("point_cov_ctor_from_point.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 90, 100, "inline PointXYZIWithCov(const PointXYZI &p, const Eigen::Matrix3f &cov_matrix)"),
+    ("downsample_current_scan.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 356, 421, "void downsampleCurrentScan()"),
     ("pose_ctor_default.inc", "estimator/pose.cpp", 16, 23, "Pose::Pose()"),
     ("pose_ctor_copy.inc", "estimator/pose.cpp", 25, 32, "Pose::Pose(const Pose &pose)"),
     ("pose_ctor_qt.inc", "estimator/pose.cpp", 34, 41, "Pose::Pose(const Eigen::Quaterniond &q"),

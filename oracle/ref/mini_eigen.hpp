@@ -59,6 +59,7 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
     static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     static Matrix Zero() { return Matrix(); }
     void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
+    template <typename U> Mat<U, R, C> cast() const { Mat<U, R, C> m; for (int i = 0; i < R * C; ++i) m.d[i] = U(d[i]); return m; }
     void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
     const Mat &real() const { return *this; }
     BlockRef<T, R, 1> col(int j) { return BlockRef<T, R, 1>{d + j, C}; }

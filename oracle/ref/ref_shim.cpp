@@ -22,6 +22,7 @@
 //   LidarScanPlaneNormFactor, LidarScanEdgeFactorVector   estimator/src/factor/lidar_scan_factor.hpp:25-62, 122-126; 236-279, 339-343
 //   Pose::{Pose(), Pose(const Pose &), Pose(q, t, td), inverse, update}   estimator/src/estimator/pose.cpp:16-41, 99-108
 //   compoundPoseWithCov (pose.cov_ overload), cloudUCTAssociateToMap, evalDegenracy   associate_uct.hpp:88-147; lidar_mapper_keyframe.cpp:1116-1158, 1171-1204
+//   downsampleCurrentScan                  estimator/src/lidarMapper/lidar_mapper_keyframe.cpp:356-421 (+ PointXYZIWithCov ctors point_with_cov.hpp:57-62, 91-101)
 //   ActiveFeatureSelection::{evaluateFeatJacobianMatching, evalFullHessian, goodFeatureMatching}   estimator/src/lidarMapper/lidar_mapper.h:130-573
 //     (+ PointPlaneFeature / FeatureWithScore parameters.h:163-191, extractCov point_with_cov.hpp:202-214, common::logDet math.hpp:172-202,
 //      common::RandomGeneratorInt random_generator.hpp:52-66, the two limits lidar_mapper.h:82-83)
@@ -195,7 +196,15 @@ Eigen::Matrix<double, 3, 3> COV_MEASUREMENT;                  // parameters.cpp:
 #include "../_ref/gen/uct_eval_point.inc"                     // evalPointUncertainty(pi, cov_point, pose)   -- reads pose.cov_
 
 // ---------------------------------------------------------------- ActiveFeatureSelection (lidar_mapper.h:126-573) from the reference's own lines
-namespace pcl { struct PointXYZIWithCov { float x = 0, y = 0, z = 0, intensity = 0; float cov_vec[6] = {0, 0, 0, 0, 0, 0}; float cov_trace = 0; }; }   // point_with_cov.hpp:27-60
+namespace pcl {
+struct PointXYZIWithCov {                                     // point_with_cov.hpp:45-101: the fields and the two constructors this path uses (their own lines)
+    float x, y, z, intensity;
+    float cov_vec[6];
+    float cov_trace;
+#include "../_ref/gen/point_cov_ctor_default.inc"
+#include "../_ref/gen/point_cov_ctor_from_point.inc"
+};
+}
 typedef pcl::PointXYZIWithCov PointIWithCov;
 typedef pcl::PointCloud<PointIWithCov> PointICovCloud;
 namespace common {
@@ -245,6 +254,32 @@ namespace common {
 #include "../_ref/gen/cloud_uct_associate.inc"                // cloudUCTAssociateToMap                                   lidar_mapper_keyframe.cpp:1116-1158
 #define INFO 0
 #include "../_ref/gen/eval_degeneracy.inc"                    // evalDegenracy(mat_H, local_parameterization)            lidar_mapper_keyframe.cpp:1171-1204
+// downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421): the filter objects are PCL code (mloam_pcl); here they call the oracle's LITERAL restatement
+// of VoxelGridCovarianceMLOAM<PointI>::applyFilter -- unstable std::sort included -- so what this pins is the loop around them: which LiDAR's
+// extrinsic a thinned point's uncertainty goes through (int(intensity)), the inverse extrinsic, the trace gate, the record that is pushed
+#include "../uct.hpp"
+namespace pcl {
+template <typename P> struct VoxelGridCovarianceMLOAM {
+    typename PointCloud<P>::Ptr in;
+    float leaf = 0.f;
+    void setInputCloud(const typename PointCloud<P>::Ptr &c) { in = c; }
+    void setLeafSize(float lx, float, float) { leaf = lx; }
+    void filter(PointCloud<P> &out)
+    {
+        std::vector<float> src(in->points.size() * 4), dst;
+        for (size_t i = 0; i < in->points.size(); ++i) { src[4 * i] = in->points[i].x; src[4 * i + 1] = in->points[i].y; src[4 * i + 2] = in->points[i].z; src[4 * i + 3] = in->points[i].intensity; }
+        orc::voxel_grid_mloam_plain(src.data(), int(in->points.size()), leaf, 0 /* std::sort member order, as the reference */, dst);
+        out.points.resize(dst.size() / 4);
+        for (size_t i = 0; i < out.points.size(); ++i) { out.points[i].x = dst[4 * i]; out.points[i].y = dst[4 * i + 1]; out.points[i].z = dst[4 * i + 2]; out.points[i].intensity = dst[4 * i + 3]; }
+    }
+};
+}  // namespace pcl
+PointICloud::Ptr laser_cloud_surf_last(new PointICloud()), laser_cloud_corner_last(new PointICloud()), laser_cloud_outlier(new PointICloud());      // lidar_mapper_keyframe.cpp:41-57
+PointICloud::Ptr laser_cloud_surf_last_ds(new PointICloud()), laser_cloud_corner_last_ds(new PointICloud()), laser_cloud_outlier_ds(new PointICloud());
+PointICovCloud::Ptr laser_cloud_surf_cov(new PointICovCloud()), laser_cloud_corner_cov(new PointICovCloud()), laser_cloud_outlier_cov(new PointICovCloud());
+std::vector<Pose> pose_ext;
+pcl::VoxelGridCovarianceMLOAM<PointI> down_size_filter_surf, down_size_filter_corner, down_size_filter_outlier;      // lidar_mapper_keyframe.cpp:79-81
+#include "../_ref/gen/downsample_current_scan.inc"
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
@@ -589,6 +624,41 @@ int ref_eval_degeneracy(const double H36[36], double eig_thre, int *is_deg, doub
     *is_deg = plp.is_degenerate_ ? 1 : 0;
     for (int i = 0; i < 36; ++i) V36[i] = plp.V_update_.d[i];
     for (int i = 0; i < 6; ++i) eig[i] = d_factor_list.back().d[i];
+    return 0;
+}
+
+// downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421): surf / corner fused clouds in (rows x y z lidar-id), thinned clouds with covariance out (11 floats)
+int ref_downsample_current_scan(const float *surf4, int n_surf, const float *corner4, int n_corner, float leaf_surf, float leaf_corner, const double *ext_poses,
+                                const double *ext_covs, int n_lidar, const double cov_meas[9], int with_ua, double trace_threshold, float *surf11, int *n_surf_out,
+                                float *corner11, int *n_corner_out)
+{
+    with_ua_flag = with_ua != 0; TRACE_THRESHOLD_MAPPING = trace_threshold;
+    for (int i = 0; i < 9; ++i) COV_MEASUREMENT.d[i] = cov_meas[i];
+    pose_ext.clear();
+    for (int k = 0; k < n_lidar; ++k) {
+        const double *p = ext_poses + 7 * k;
+        Pose P(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2]));
+        for (int i = 0; i < 36; ++i) P.cov_.d[i] = ext_covs[36 * k + i];
+        pose_ext.push_back(P);
+    }
+    auto fill = [](PointICloud &c, const float *a, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c.points[size_t(i)].x = a[4 * i]; c.points[size_t(i)].y = a[4 * i + 1]; c.points[size_t(i)].z = a[4 * i + 2]; c.points[size_t(i)].intensity = a[4 * i + 3]; }
+    };
+    fill(*laser_cloud_surf_last, surf4, n_surf); fill(*laser_cloud_corner_last, corner4, n_corner); laser_cloud_outlier->clear();
+    down_size_filter_surf.setLeafSize(leaf_surf, leaf_surf, leaf_surf); down_size_filter_corner.setLeafSize(leaf_corner, leaf_corner, leaf_corner);
+    down_size_filter_outlier.setLeafSize(leaf_corner, leaf_corner, leaf_corner);
+    downsampleCurrentScan();
+    auto dump = [](const PointICovCloud &c, float *o, int *n) {
+        *n = int(c.size());
+        for (size_t i = 0; i < c.size(); ++i) {
+            const PointIWithCov &q = c.points[i];
+            o[11 * i] = q.x; o[11 * i + 1] = q.y; o[11 * i + 2] = q.z; o[11 * i + 3] = q.intensity;
+            for (int k = 0; k < 6; ++k) o[11 * i + 4 + k] = q.cov_vec[k];
+            o[11 * i + 10] = q.cov_trace;
+        }
+    };
+    dump(*laser_cloud_surf_cov, surf11, n_surf_out); dump(*laser_cloud_corner_cov, corner11, n_corner_out);
     return 0;
 }
 

@@ -273,3 +273,45 @@ def test_sharded_solver_full_size(mla, synth, orc, cfg2, mode):
     assert counts == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]]
     dt, dr = _pose_err(pose, ref["pose"])
     assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
+def test_downsample_current_scan_against_the_references_own_lines(mla, orc, synth, cfg2):
+    """mlh_downsample_current_scan with mlh_set_voxel_member_order(1) against downsampleCurrentScan COMPILED FROM THE REFERENCE'S OWN LINES
+    (lidar_mapper_keyframe.cpp:356-421; its filter = the literal restatement of VoxelGridCovarianceMLOAM<PointI>, std::sort order), on the bench
+    frame's fused two-LiDAR clouds -- half of whose surf voxels hold points of both LiDARs: the same features survive the trace gate, in the same
+    order, with the same coordinates and LiDAR ids bit for bit; covariances to f32 rounding of a differently ordered f64 product."""
+    if orc.ref_lib() is None:
+        pytest.skip("no prebuilt oracle/_ref/libmloam_ref.so")
+    scans = cfg2["scans"]
+    ex = [orc.extract(s.points, s.scan_start, s.scan_end) for s in scans]
+    fused = {"s": [], "c": []}
+    for i, (sc, e) in enumerate(zip(scans, ex)):
+        T = np.eye(4)
+        T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4])
+        T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]
+        for key, xyz in (("c", sc.points[e["less_sharp"]][:, :3]), ("s", e["less_flat_ds"][:, :3])):
+            a = np.zeros((len(xyz), 4), np.float32)
+            a[:, :3] = synth.transform_points(xyz, T)
+            a[:, 3] = i
+            fused[key].append(a)
+    surf, corner = np.concatenate(fused["s"]), np.concatenate(fused["c"])
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e_ in ext:
+        e_[3:] /= np.linalg.norm(e_[3:])
+    covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    meas = np.diag([0.0025] * 3)
+    rs, rc = orc.ref_downsample_current_scan(surf, corner, 0.4, 0.2, ext, covs, meas, True, 0.6)
+    c = mla.Context(0)
+    try:
+        c.set_voxel_member_order(True)
+        for kind, cloud, leaf, want in ((mla.SURF, surf, 0.4, rs), (mla.CORNER, corner, 0.2, rc)):
+            got = c.downsample_current_scan(kind, cloud, leaf, ext, covs, meas, True, 0.6)
+            assert got.shape == want.shape and len(got) > 5000
+            assert np.array_equal(got[:, :4].view(np.uint32), want[:, :4].view(np.uint32))
+            np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=5e-5, atol=1e-9)
+        # and the default (point-index) order really is a different feature set on this frame -- the deviation DESIGN.md section 2 documents
+        c.set_voxel_member_order(False)
+        dflt = c.downsample_current_scan(mla.SURF, surf, 0.4, ext, covs, meas, True, 0.6)
+        assert dflt.shape != rs.shape or not np.array_equal(dflt[:, 3], rs[:, 3])
+    finally:
+        c.close()

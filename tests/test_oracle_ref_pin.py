@@ -419,3 +419,49 @@ def test_eval_degeneracy_is_the_references(ref):
             keep = Q[:, k:] @ Q[:, k:].T
             np.testing.assert_allclose(r["V_update"], keep, rtol=0, atol=1e-9)
     assert n_deg >= 40
+
+
+def _mixed_lidar_clouds(synth, feats16, rng):
+    clouds = []
+    for f in (feats16[0], feats16[1]):
+        xyz = np.concatenate([f[:, :3], f[:, :3] + rng.normal(0, 0.08, f[:, :3].shape).astype(np.float32)])
+        a = np.zeros((len(xyz), 4), np.float32)
+        a[:, :3] = xyz
+        a[:, 3] = rng.integers(0, 2, len(xyz))                 # both LiDARs' points inside the same voxels
+        clouds.append(a)
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.diag([0.0004] * 3 + [0.0001] * 3), np.diag([0.0025] * 3 + [0.00030461] * 3) * 30])
+    return clouds, ext, covs, np.diag([0.0025] * 3)
+
+
+def test_downsample_current_scan_is_the_references(ref, synth, feats16):
+    """downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421) from the reference's own lines: thinned point -> int(intensity) picks the LiDAR ->
+    pointAssociateToMap with the INVERSE extrinsic -> evalPointUncertainty through pose_ext[idx] (its cov_) -> trace gate -> PointIWithCov(point,
+    cov.cast<float>()). Against the composition the HIP path's mlh_downsample_current_scan is tested with (the oracle's plain voxel filter in the
+    reference's std::sort member order, then its evalPointUncertainty and the gate), on clouds whose voxels mix both LiDARs."""
+    rng = np.random.default_rng(21)
+    (surf, corner), ext, covs, meas = _mixed_lidar_clouds(synth, feats16, rng)
+    for with_ua, thr in ((True, 0.05), (True, 0.6), (False, 0.6)):
+        rs, rc = ref.ref_downsample_current_scan(surf, corner, 0.4, 0.2, ext, covs, meas, with_ua, thr)
+        for got, cloud, leaf in ((rs, surf, 0.4), (rc, corner, 0.2)):
+            ds = ref.voxel_grid_mloam_plain(cloud, leaf, member_order=0)
+            rows = []
+            for p in ds:
+                n = int(p[3])
+                cov = np.zeros((3, 3))
+                if with_ua:
+                    R = synth.quat_to_rot(ext[n][3:])
+                    sel = ((p[:3].astype(np.float64) - ext[n][:3]) @ R).astype(np.float32)
+                    cov = ref.eval_point_uncertainty(sel[None, :], ext[n], covs[n], meas)[0]
+                    if np.trace(cov) > thr:
+                        continue
+                c32 = cov.astype(np.float32)
+                rows.append(np.concatenate([p[:4], [c32[0, 0], c32[0, 1], c32[0, 2], c32[1, 1], c32[1, 2], c32[2, 2]], [c32[0, 0] + c32[1, 1] + c32[2, 2]]]).astype(np.float32))
+            want = np.array(rows, np.float32).reshape(-1, 11)
+            assert got.shape == want.shape and len(got) > 100
+            assert np.array_equal(got[:, :4].view(np.uint32), want[:, :4].view(np.uint32))
+            np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=2e-6, atol=1e-12)
+        if with_ua and thr == 0.05:
+            assert len(rs) < len(ref.voxel_grid_mloam_plain(surf, 0.4, member_order=0))       # the gate cuts
