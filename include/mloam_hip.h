@@ -167,13 +167,14 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
  * MEMBER ORDER. The reference groups a voxel's members with std::sort and a comparator that sees the voxel index only (impl.hpp:227), i.e.
  * inside a voxel they come in whatever order libstdc++'s introsort leaves. That order decides "the last member" of the plain branch --
  * for a fused multi-LiDAR cloud the LiDAR id downsampleCurrentScan propagates the uncertainty through (lidar_mapper_keyframe.cpp:377) --,
- * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. By default members are
- * walked in ascending point index (what a stable sort would give): voxel set, output order and counts are identical to the reference's,
- * sums agree to f32 rounding, but the surviving id of a voxel that MIXES ids can differ (on a two-LiDAR frame: ~31 % of the 0.4 m surf
- * voxels, ~5 % of the 0.2 m corner voxels; with uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py).
- * mlh_set_voxel_member_order(ctx, 1) switches every voxel filter of the context (mlh_voxel_filter, mlh_voxel_grid,
- * mlh_downsample_current_scan, ..._pair) to the reference's order: the slots come back to the host, the same std::sort runs there on
- * the same sequence, the member lists go back. Exact, at the price of a host round trip and a host sort per call (milliseconds). */
+ * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. BY DEFAULT every voxel
+ * filter of the context (mlh_voxel_filter, mlh_voxel_grid, mlh_downsample_current_scan, ..._pair) reproduces that order: the points' slots
+ * come back to the host (pinned), the same std::sort runs there on the same sequence, the member lists go back -- results equal to the
+ * reference's bit for bit, at the price of a host round trip and a host sort per call (about a millisecond for a frame's clouds).
+ * mlh_set_voxel_member_order(ctx, 0) drops the host pass: members are walked in ascending point index on the device (what a stable
+ * sort would give). Voxel set, output order and counts stay identical to the reference's and sums agree to f32 rounding, but the surviving
+ * id of a voxel that MIXES ids can differ (on a two-LiDAR frame: ~31 % of the 0.4 m surf voxels, ~5 % of the 0.2 m corner voxels; with
+ * uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py). A single-LiDAR cloud has no mixed voxels. */
 int mlh_set_voxel_member_order(mlh_ctx *ctx, int reference_std_sort_order);
 /* mlh_voxel_filter: `mem` describes BOTH buffers: MLH_MEM_DEVICE takes device records and leaves the result in device memory (`out`), so a map
  * assembled with mlh_cloud_uct_associate_to_map can be thinned and handed to mlh_map_set without leaving HBM. */

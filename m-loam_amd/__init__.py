@@ -543,7 +543,8 @@ class Context:
         self._ck(self.lib.mlh_map_rebuild(self.h, kind))
 
     def set_voxel_member_order(self, reference_std_sort_order: bool):
-        """voxel filters of this context: members of a voxel in libstdc++'s std::sort order (the reference's, host pass) or by point index"""
+        """voxel filters of this context: members of a voxel in libstdc++'s std::sort order (the reference's; host pass; the default) or, with
+        False, by point index on the device (no host pass; a voxel that mixes LiDAR ids may keep another id)"""
         self._ck(self.lib.mlh_set_voxel_member_order(self.h, 1 if reference_std_sort_order else 0))
 
     def map_info(self, kind):

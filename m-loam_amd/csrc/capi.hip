@@ -283,6 +283,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
     if (ctx->select_host) (void)hipHostFree(ctx->select_host);
+    if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -260,7 +260,9 @@ struct mlh_ctx {
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
-    bool vox_std_sort_order = false;   // voxel filters: members of a voxel in the order libstdc++'s std::sort leaves them (host pass) instead of point-index order
+    bool vox_std_sort_order = true;    // voxel filters: members of a voxel in the order libstdc++'s std::sort leaves them (the reference's; host pass) or, when false, in point-index order (device only)
+    void *vox_order_host = nullptr; // pinned staging of that host pass (voxelgrid.hip): [slot n][members n]
+    size_t vox_order_host_cap = 0;
     void *select_host = nullptr; // pinned staging of the good-feature selection (select.hip)
     size_t select_host_cap = 0;
     int n_ranks = 1, rank = 0;

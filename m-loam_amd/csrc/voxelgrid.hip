@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 namespace mlh {
@@ -315,38 +316,54 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
     if (has_i) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
 }
 
-// Reference member order (opt-in, mlh_set_voxel_member_order): the reference groups a voxel's members with an UNSTABLE std::sort whose
-// comparator sees the voxel index only (voxel_grid_covariance_mloam_impl.hpp:215-236), so the order of the members inside a voxel -- and with it
-// "the last member's intensity" of the plain branch, the first-maximum-weight intensity of the covariance branch and the association of
-// every f32 sum -- is whatever libstdc++'s introsort leaves. That order cannot be derived without running the same algorithm on the same
-// sequence, so this path does exactly that on the host: the points' output slots (ascending voxel index: order-isomorphic to PCL's idx, hence
-// the same comparisons and the same introsort path) come back, std::sort runs per cloud on (slot, point index) pairs in point order, and
-// the resulting member lists replace what vox_rank_kernel would have written. Costs a host round trip and a ~n log n host sort per call
-// (milliseconds for a frame's clouds): off by default, where members are walked in ascending point index instead.
+// Reference member order (the default; mlh_set_voxel_member_order(ctx, 0) turns it off): the reference groups a voxel's members with an
+// UNSTABLE std::sort whose comparator sees the voxel index only (voxel_grid_covariance_mloam_impl.hpp:215-236), so the order of the members
+// inside a voxel -- and with it "the last member's intensity" of the plain branch, the first-maximum-weight intensity of the covariance
+// branch and the association of every f32 sum -- is whatever libstdc++'s introsort leaves. That order cannot be derived without running the
+// same algorithm on the same sequence, so this path does exactly that on the host: the points' output slots (ascending voxel index:
+// order-isomorphic to PCL's idx, hence the same comparisons and the same introsort path) come back into pinned memory, std::sort runs per
+// cloud on (slot, point index) pairs in point order (the second cloud of a pair call on a second thread), and the resulting member lists
+// replace what vox_rank_kernel would have written. Costs a host round trip and a ~n log n host sort per call; with the switch off the
+// members are walked in ascending point index on the device instead (same voxels, same centroids to f32 rounding, a different surviving
+// intensity where a voxel mixes them).
 static int members_in_std_sort_order(mlh_ctx *ctx, const VoxArgs &A)
 {
     hipStream_t st = ctx->stream;
-    std::vector<int> slot(size_t(A.n)), members(size_t(A.n));
-    MLH_HIP(ctx, hipMemcpyAsync(slot.data(), A.vox_of, sizeof(int) * size_t(A.n), hipMemcpyDeviceToHost, st));
+    const size_t n = size_t(A.n), need = 2 * sizeof(int) * n;
+    if (need > ctx->vox_order_host_cap) {
+        MLH_HIP(ctx, hipStreamSynchronize(st));                           // an earlier call's upload may still be reading the old block
+        if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
+        ctx->vox_order_host = nullptr; ctx->vox_order_host_cap = 0;
+        MLH_HIP(ctx, hipHostMalloc(&ctx->vox_order_host, need + need / 4, hipHostMallocDefault));
+        ctx->vox_order_host_cap = need + need / 4;
+    }
+    int *slot = static_cast<int *>(ctx->vox_order_host), *members = slot + n;
+    MLH_HIP(ctx, hipMemcpyAsync(slot, A.vox_of, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
     struct IdxPt {
         unsigned int idx, cloud_point_index;
         bool operator<(const IdxPt &o) const { return idx < o.idx; }      // cloud_point_index_idx::operator< (voxel_grid.h): idx only
     };
-    std::vector<IdxPt> iv;
-    size_t pos = 0;
-    const int range[3] = {0, A.n0, A.n};                                  // one filter call per cloud in the reference: one sort per cloud
-    for (int c = 0; c < 2; ++c) {
-        if (range[c + 1] <= range[c]) continue;
-        iv.clear();
-        iv.reserve(size_t(range[c + 1] - range[c]));
-        for (int i = range[c]; i < range[c + 1]; ++i) iv.push_back(IdxPt{(unsigned)slot[size_t(i)], (unsigned)i});
+    // one filter call per cloud in the reference: one sort per cloud
+    auto sort_range = [slot, members](int lo, int hi) {
+        if (hi <= lo) return;
+        std::vector<IdxPt> iv;
+        iv.reserve(size_t(hi - lo));
+        for (int i = lo; i < hi; ++i) iv.push_back(IdxPt{(unsigned)slot[size_t(i)], (unsigned)i});
         std::sort(iv.begin(), iv.end(), std::less<IdxPt>());
-        for (const IdxPt &e : iv) members[pos++] = int(e.cloud_point_index);
+        int *dst = members + lo;
+        for (const IdxPt &e : iv) *dst++ = int(e.cloud_point_index);
+    };
+    if (A.n0 > 4096 && A.n - A.n0 > 4096) {
+        std::thread second(sort_range, A.n0, A.n);
+        sort_range(0, A.n0);
+        second.join();
+    } else {
+        sort_range(0, A.n0);
+        sort_range(A.n0, A.n);
     }
-    MLH_HIP(ctx, hipMemcpyAsync(A.members, members.data(), sizeof(int) * size_t(A.n), hipMemcpyHostToDevice, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));                               // `members` is a local
-    return MLH_OK;
+    MLH_HIP(ctx, hipMemcpyAsync(A.members, members, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    return MLH_OK;                                                        // the staging block is the context's: the next call on it syncs the stream first
 }
 
 // getMinMax3D: per-workgroup partial bounds (6 floats each); the host, which needs them for the grid extents anyway, folds them

@@ -307,8 +307,8 @@ int main(int argc, char **argv)
                 wout.insert(wout.end(), wne.Jtr.begin(), wne.Jtr.end());
                 wout.push_back(wne.cost); wout.push_back(double(wne.n_residuals));
                 write_file(d + "out_window_ne.f64", wout);
-                setVoxelMemberOrderAsReference(dev, true);
-                setVoxelMemberOrderAsReference(dev, false);
+                setVoxelMemberOrderAsReference(dev, false);   // device-only member order ...
+                setVoxelMemberOrderAsReference(dev, true);    // ... and back to the default (the reference's)
             }
             std::printf("round-2 facade: full-H features %d, logdet %.6f, selected %zu surf rows, %zu corner rows, segmented %zu -> %zu points\n", total_feat_num,
                         gf_deg_factor, sel_surf_feature_idx.size(), sel_corner_feature_idx.size(), raw_cloud.size(), seg_out.size());

@@ -926,7 +926,8 @@ private:
 };
 
 // every voxel filter of the device walks a voxel's members in the order libstdc++'s unstable std::sort leaves them, as the reference's filters do
-// (voxel_grid_covariance_mloam_impl.hpp:227) -- exact LiDAR ids in mixed voxels of fused clouds, at the price of a host pass per call; off by default
+// (voxel_grid_covariance_mloam_impl.hpp:227) -- exact LiDAR ids in mixed voxels of fused clouds, at the price of a host pass per call. ON by default;
+// setVoxelMemberOrderAsReference(dev, false) walks members by point index on the device instead (faster, ids of mixed voxels may differ)
 inline void setVoxelMemberOrderAsReference(Device &dev, bool on) { dev.check(mlh_set_voxel_member_order(dev.ctx(), on ? 1 : 0)); }
 
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")

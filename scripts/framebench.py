@@ -144,7 +144,7 @@ def cpu_downsample(member_order):
         out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
         res.append(out[out[:, 10] <= 0.6])
     return res
-feats = cpu_downsample(1)
+feats = cpu_downsample(0)
 t3 = time.perf_counter()
 ms_, mc_ = O.Map(surf_map), O.Map(corner_map)
 tk = ms_.rebuild_seconds() + mc_.rebuild_seconds()
@@ -152,15 +152,22 @@ ref = O.scan2map(ms_, mc_, feats[0], feats[1], p0, O.mapper_params(with_ua=True)
 t4 = time.perf_counter()
 print("CPU oracle, ms per frame:", {"extract": round(1e3 * (t1 - t0), 1), "fuse(host)": round(1e3 * (t2 - t1), 1), "downsample": round(1e3 * (t3 - t2), 1),
       "kd-tree build": round(1e3 * tk, 1), "scan2map": round(1e3 * (t4 - t3) - 1e3 * tk, 1)}, "total %.1f" % (1e3 * (t4 - t0)))
-print("pose agreement |dt| %.2e m (host hand-over) %.2e m (device hand-over)  [CPU leg thinned with the HIP path's member order]" % (np.linalg.norm(pose[:3] - ref["pose"][:3]), np.linalg.norm(pose_dev[:3] - ref["pose"][:3])))
-f0 = cpu_downsample(0)
-ref0 = O.scan2map(O.Map(surf_map), O.Map(corner_map), f0[0], f0[1], p0, O.mapper_params(with_ua=True))
-ctx.set_voxel_member_order(True)
+print("pose agreement |dt| %.2e m (host hand-over) %.2e m (device hand-over)  [voxel members in the reference's std::sort order on both sides: the default]" % (np.linalg.norm(pose[:3] - ref["pose"][:3]), np.linalg.norm(pose_dev[:3] - ref["pose"][:3])))
+f1 = cpu_downsample(1)
+ref1 = O.scan2map(O.Map(surf_map), O.Map(corner_map), f1[0], f1[1], p0, O.mapper_params(with_ua=True))
+ctx.set_voxel_member_order(False)
 for _ in range(3): gpu_frame({})
 tr = {}
 for _ in range(n): pose_r, _, _ = gpu_frame(tr)
-ctx.set_voxel_member_order(False)
-print("GPU path with mlh_set_voxel_member_order(1) (the reference's std::sort member order, host pass), ms per frame:", {k: round(1e3 * v / n, 3) for k, v in tr.items()},
-      "pose vs CPU leg in that order |dt| %.2e m" % np.linalg.norm(pose_r[:3] - ref0["pose"][:3]))
-print("effect of the reference's std::sort member order on this frame: features surf/corner %d/%d vs %d/%d, pose moves %.2e m" %
-      (len(f0[0]), len(f0[1]), len(feats[0]), len(feats[1]), np.linalg.norm(ref0["pose"][:3] - ref["pose"][:3])))
+PAIR = True
+for _ in range(3): gpu_frame_dev1({})
+tr2 = {}
+for _ in range(20): pose_r2 = gpu_frame_dev1(tr2)
+PAIR = False
+ctx.set_voxel_member_order(True)
+print("GPU path with mlh_set_voxel_member_order(0) (point-index member order, no host pass), ms per frame:", {k: round(1e3 * v / n, 3) for k, v in tr.items()}, "total %.3f" % (1e3 * sum(tr.values()) / n),
+      "pose vs CPU leg in that order |dt| %.2e m" % np.linalg.norm(pose_r[:3] - ref1["pose"][:3]))
+print("  the same, device-resident, one launch set, both kinds thinned in one pipeline:", {k: round(1e3 * v / 20, 3) for k, v in tr2.items()}, "total %.3f" % (1e3 * sum(tr2.values()) / 20),
+      "pose vs CPU leg in that order |dt| %.2e m" % np.linalg.norm(pose_r2[:3] - ref1["pose"][:3]))
+print("effect of the member order on this frame: features surf/corner %d/%d (reference order) vs %d/%d (point-index order), pose moves %.2e m" %
+      (len(feats[0]), len(feats[1]), len(f1[0]), len(f1[1]), np.linalg.norm(ref1["pose"][:3] - ref["pose"][:3])))

@@ -526,29 +526,40 @@ def test_voxel_filter_covariance_parity(ctx, orc, synth, case16):
 def test_voxel_filter_plain_parity(ctx, orc, case16):
     """PointXYZI branch (no covariance field; voxel_grid_covariance_mloam_impl.hpp:393-431): xyz mean over the members, intensity of the
     voxel's LAST member. The reference takes "last" in the order an unstable std::sort (comparator on the voxel index only) leaves the
-    members in; the HIP path takes it in point-index order and is pinned on that rule here, bit for bit, on a cloud whose voxels mix
-    intensities (a fused multi-LiDAR cloud carries the LiDAR id there). How often the two orders disagree is measured, not hidden: see
+    members in. The HIP path reproduces that order by default (bit for bit, sums included); with mlh_set_voxel_member_order(ctx, 0) it walks
+    members in point-index order on the device and is pinned on THAT rule. Both on a cloud whose voxels mix intensities (a fused multi-LiDAR
+    cloud carries the LiDAR id there). How often the two orders disagree is measured, not hidden: see
     tests/test_oracle_pipeline.py::test_plain_voxel_filter_member_order_dependence and DESIGN.md section 2."""
     rng = np.random.default_rng(5)
     xyz = case16["corner_map"][:30000, :3]
-    for ids in (np.arange(len(xyz), dtype=np.float32), rng.integers(0, 2, len(xyz)).astype(np.float32)):   # unique tags; two LiDAR ids mixed
-        pts = np.concatenate([xyz, ids[:, None]], axis=1).astype(np.float32)
-        for leaf in (0.2, 0.4, 1.0):
-            got = ctx.voxel_filter(pts, leaf)
-            ref = orc.voxel_grid_mloam_plain(pts, leaf, member_order=1)
-            assert got.shape == ref.shape
-            np.testing.assert_array_equal(got[:, 3], ref[:, 3])                       # which member survives: a selection, exact
-            np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)  # f32 sums in a different association
-            avg = orc.voxel_grid(pts, leaf)                                           # pcl::VoxelGrid<PointXYZI>: same voxels, same centroid rule
-            assert avg.shape == ref.shape
-    one = ctx.voxel_filter(pts[:1], 0.4)
-    np.testing.assert_array_equal(one, pts[:1])
+    try:
+        for ids in (np.arange(len(xyz), dtype=np.float32), rng.integers(0, 2, len(xyz)).astype(np.float32)):   # unique tags; two LiDAR ids mixed
+            pts = np.concatenate([xyz, ids[:, None]], axis=1).astype(np.float32)
+            for leaf in (0.2, 0.4, 1.0):
+                ctx.set_voxel_member_order(True)
+                got = ctx.voxel_filter(pts, leaf)
+                ref = orc.voxel_grid_mloam_plain(pts, leaf, member_order=0)
+                np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))   # same order, same association: every bit
+                ctx.set_voxel_member_order(False)
+                got = ctx.voxel_filter(pts, leaf)
+                ref = orc.voxel_grid_mloam_plain(pts, leaf, member_order=1)
+                assert got.shape == ref.shape
+                np.testing.assert_array_equal(got[:, 3], ref[:, 3])                       # which member survives: a selection, exact
+                np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=2e-6)  # f32 sums in a different association
+                avg = orc.voxel_grid(pts, leaf)                                           # pcl::VoxelGrid<PointXYZI>: same voxels, same centroid rule
+                assert avg.shape == ref.shape
+        one = ctx.voxel_filter(pts[:1], 0.4)
+        np.testing.assert_array_equal(one, pts[:1])
+    finally:
+        ctx.set_voxel_member_order(True)
 
 
 def test_downsample_current_scan_mixed_lidar_voxels(ctx, mla, orc, synth, feats16):
     """downsampleCurrentScan on a fused cloud whose voxels hold points of BOTH LiDARs (lidar_mapper_keyframe.cpp:356-398): the thinned
-    point's LiDAR id -- the voxel's last member's, point-index order -- selects the extrinsic the uncertainty is propagated through, so a
-    wrong member would show in the covariance and in the trace gate."""
+    point's LiDAR id -- the voxel's last member's -- selects the extrinsic the uncertainty is propagated through, so a wrong member would
+    show in the covariance and in the trace gate. This is the device-only leg (mlh_set_voxel_member_order(ctx, 0): point-index order);
+    the default order is held against the reference in test_voxel_filters_in_the_references_member_order and
+    tests/test_gpu_parity_fullsize.py::test_downsample_current_scan_against_the_references_own_lines."""
     rng = np.random.default_rng(21)
     base = feats16[0][:, :3]
     xyz = np.concatenate([base, base + rng.normal(0, 0.08, base.shape).astype(np.float32)])
@@ -573,8 +584,12 @@ def test_downsample_current_scan_mixed_lidar_voxels(ctx, mla, orc, synth, feats1
         cov_ref.append([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
     keep_ref, cov_ref, traces = np.array(keep_ref), np.array(cov_ref), np.array(traces)
     assert np.all(np.abs(traces - thr) > 1e-4 * thr)             # no voxel sits on the gate, where a 2e-6 centroid difference could flip it
-    got = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, True, thr)
-    dsg = ctx.voxel_filter(pts, 0.4)
+    ctx.set_voxel_member_order(False)
+    try:
+        got = ctx.downsample_current_scan(mla.SURF, pts, 0.4, ext, covs, meas, True, thr)
+        dsg = ctx.voxel_filter(pts, 0.4)
+    finally:
+        ctx.set_voxel_member_order(True)
     np.testing.assert_array_equal(dsg[:, 3], ds[:, 3])
     assert 0 < keep_ref.sum() < len(ds) and len(set(ds[:, 3])) == 2
     assert len(got) == keep_ref.sum()
@@ -584,13 +599,12 @@ def test_downsample_current_scan_mixed_lidar_voxels(ctx, mla, orc, synth, feats1
 
 
 def test_voxel_filters_in_the_references_member_order(mla, orc, synth, case16, feats16):
-    """mlh_set_voxel_member_order(ctx, 1): a voxel's members in the order libstdc++'s std::sort leaves them (the reference's own order,
+    """The default member order: a voxel's members in the order libstdc++'s std::sort leaves them (the reference's own order,
     voxel_grid_covariance_mloam_impl.hpp:227), reproduced by running that sort on the host over the same sequence. With the order equal,
     everything is: surviving ids, and the f32 sums BIT FOR BIT (same association) -- plain branch, covariance branch, and
     downsampleCurrentScan on a cloud whose voxels mix LiDAR ids."""
-    c = mla.Context(0)
+    c = mla.Context(0)                                             # a fresh context: the default is what is tested
     try:
-        c.set_voxel_member_order(True)
         rng = np.random.default_rng(5)
         xyz = case16["corner_map"][:30000, :3]
         pts = np.concatenate([xyz, rng.integers(0, 2, len(xyz)).astype(np.float32)[:, None]], axis=1).astype(np.float32)
@@ -640,7 +654,7 @@ def test_voxel_filters_in_the_references_member_order(mla, orc, synth, case16, f
         got = c.downsample_current_scan(mla.SURF, f4, 0.4, ext, covs, meas, True, thr)
         assert 0 < keep.sum() < len(ds) and len(got) == keep.sum()
         np.testing.assert_array_equal(got[:, :4].view(np.uint32), ds[keep].view(np.uint32))
-        # and back: the default order is per context and switchable
+        # the device-only order is per context and switchable
         c.set_voxel_member_order(False)
         again = c.voxel_filter(pts, 0.4)
         np.testing.assert_array_equal(again[:, 3], orc.voxel_grid_mloam_plain(pts, 0.4, member_order=1)[:, 3])

@@ -276,7 +276,7 @@ def test_sharded_solver_full_size(mla, synth, orc, cfg2, mode):
 
 
 def test_downsample_current_scan_against_the_references_own_lines(mla, orc, synth, cfg2):
-    """mlh_downsample_current_scan with mlh_set_voxel_member_order(1) against downsampleCurrentScan COMPILED FROM THE REFERENCE'S OWN LINES
+    """mlh_downsample_current_scan (default member order = the reference's) against downsampleCurrentScan COMPILED FROM THE REFERENCE'S OWN LINES
     (lidar_mapper_keyframe.cpp:356-421; its filter = the literal restatement of VoxelGridCovarianceMLOAM<PointI>, std::sort order), on the bench
     frame's fused two-LiDAR clouds -- half of whose surf voxels hold points of both LiDARs: the same features survive the trace gate, in the same
     order, with the same coordinates and LiDAR ids bit for bit; covariances to f32 rounding of a differently ordered f64 product."""
@@ -303,13 +303,12 @@ def test_downsample_current_scan_against_the_references_own_lines(mla, orc, synt
     rs, rc = orc.ref_downsample_current_scan(surf, corner, 0.4, 0.2, ext, covs, meas, True, 0.6)
     c = mla.Context(0)
     try:
-        c.set_voxel_member_order(True)
         for kind, cloud, leaf, want in ((mla.SURF, surf, 0.4, rs), (mla.CORNER, corner, 0.2, rc)):
             got = c.downsample_current_scan(kind, cloud, leaf, ext, covs, meas, True, 0.6)
             assert got.shape == want.shape and len(got) > 5000
             assert np.array_equal(got[:, :4].view(np.uint32), want[:, :4].view(np.uint32))
             np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=5e-5, atol=1e-9)
-        # and the default (point-index) order really is a different feature set on this frame -- the deviation DESIGN.md section 2 documents
+        # and the opt-in device-only (point-index) order really is a different feature set on this frame
         c.set_voxel_member_order(False)
         dflt = c.downsample_current_scan(mla.SURF, surf, 0.4, ext, covs, meas, True, 0.6)
         assert dflt.shape != rs.shape or not np.array_equal(dflt[:, 3], rs[:, 3])
