@@ -167,15 +167,25 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
  * MEMBER ORDER. The reference groups a voxel's members with std::sort and a comparator that sees the voxel index only (impl.hpp:227), i.e.
  * inside a voxel they come in whatever order libstdc++'s introsort leaves. That order decides "the last member" of the plain branch --
  * for a fused multi-LiDAR cloud the LiDAR id downsampleCurrentScan propagates the uncertainty through (lidar_mapper_keyframe.cpp:377) --,
- * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. BY DEFAULT every voxel
- * filter of the context (mlh_voxel_filter, mlh_voxel_grid, mlh_downsample_current_scan, ..._pair) reproduces that order: the points' slots
- * come back to the host (pinned), the same std::sort runs there on the same sequence, the member lists go back -- results equal to the
- * reference's bit for bit, at the price of a host round trip and a host sort per call (about a millisecond for a frame's clouds).
- * mlh_set_voxel_member_order(ctx, 0) drops the host pass: members are walked in ascending point index on the device (what a stable
- * sort would give). Voxel set, output order and counts stay identical to the reference's and sums agree to f32 rounding, but the surviving
- * id of a voxel that MIXES ids can differ (on a two-LiDAR frame: ~31 % of the 0.4 m surf voxels, ~5 % of the 0.2 m corner voxels; with
- * uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py). A single-LiDAR cloud has no mixed voxels. */
-int mlh_set_voxel_member_order(mlh_ctx *ctx, int reference_std_sort_order);
+ * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. Every voxel filter of the
+ * context (mlh_voxel_filter, mlh_voxel_grid, mlh_downsample_current_scan, ..._pair) follows mlh_set_voxel_member_order(ctx, mode):
+ *   1 (default)  the reference's order, produced ON THE DEVICE: libstdc++'s std::sort (introsort: median-of-three pivot at the same
+ *                positions, the same unguarded Hoare partition, the same depth budget and heap-sort fallback, the same final insertion
+ *                pass) restated data-parallel -- one launch per recursion depth, a range's partition from rank tables -- so the
+ *                permutation equals std::sort's element for element and the filters' results equal the reference's bit for bit;
+ *   2            the same order through a host pass: the points' slots come back (pinned), the platform's OWN std::sort runs on the
+ *                same sequence, the member lists go back (+1.2 ms for a frame's clouds). For a build against a standard library
+ *                whose std::sort is not the algorithm mode 1 restates (GCC's libstdc++, unchanged in this respect since 4.x);
+ *                mlh_std_sort_permutation lets an integrator compare the two on any key sequence;
+ *   0            members in ascending point index (what a stable sort would give), device only and a few launches cheaper. Voxel set,
+ *                output order and counts stay identical to the reference's and sums agree to f32 rounding, but the surviving id of a
+ *                voxel that MIXES ids can differ (on a two-LiDAR frame: ~31 % of the 0.4 m surf voxels, ~5 % of the 0.2 m corner
+ *                voxels; with uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py). A single-LiDAR
+ *                cloud has no mixed voxels. */
+int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode);
+/* perm_out[0..n) (HOST) <- the permutation of 0..n-1 that two std::sort calls -- over [0, n0) and [n0, n), comparator on keys[] (HOST,
+ * non-negative) only -- leave: mode 1 = the device restatement the voxel filters use, mode 2 = the platform's std::sort on the host. */
+int mlh_std_sort_permutation(mlh_ctx *ctx, const int32_t *keys, int n0, int n, int32_t *perm_out, int mode);
 /* mlh_voxel_filter: `mem` describes BOTH buffers: MLH_MEM_DEVICE takes device records and leaves the result in device memory (`out`), so a map
  * assembled with mlh_cloud_uct_associate_to_map can be thinned and handed to mlh_map_set without leaving HBM. */
 int mlh_voxel_filter(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,

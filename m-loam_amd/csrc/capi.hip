@@ -278,7 +278,7 @@ void mlh_destroy(mlh_ctx *ctx)
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.word_of.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
-    ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
+    ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->stdsort.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
@@ -614,10 +614,30 @@ int mlh_map_rebuild(mlh_ctx *ctx, int kind)
     return grid_build(ctx, kind == MLH_ALL_KINDS ? 3 : (1 << kind), false);
 }
 
-int mlh_set_voxel_member_order(mlh_ctx *ctx, int reference_std_sort_order)
+int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return MLH_ERR_INVALID;
+    ctx->vox_member_order = mode;
+    return MLH_OK;
+}
+
+int mlh_std_sort_permutation(mlh_ctx *ctx, const int32_t *keys, int n0, int n, int32_t *perm_out, int mode)
 {
     if (!ctx) return MLH_ERR_INVALID;
-    ctx->vox_std_sort_order = reference_std_sort_order != 0;
+    if (!keys || !perm_out || n <= 0 || n0 < 0 || n0 > n || (mode != 1 && mode != 2)) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    if (mode == 2) {
+        host_std_sort_permutation(keys, 0, n0, perm_out);
+        host_std_sort_permutation(keys, n0, n, perm_out);
+        return MLH_OK;
+    }
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MLH_HIP(ctx, ctx->tmp.ensure(sizeof(int) * size_t(n) * 2));
+    int *d_keys = ctx->tmp.as<int>(), *d_perm = d_keys + n;
+    MLH_HIP(ctx, hipMemcpyAsync(d_keys, keys, sizeof(int) * size_t(n), hipMemcpyHostToDevice, ctx->stream));
+    int rc = device_std_sort_by_key(ctx, d_keys, n0, n, d_perm);
+    if (rc) return rc;
+    MLH_HIP(ctx, hipMemcpyAsync(perm_out, d_perm, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MLH_OK;
 }
 

@@ -260,7 +260,9 @@ struct mlh_ctx {
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
-    bool vox_std_sort_order = true;    // voxel filters: members of a voxel in the order libstdc++'s std::sort leaves them (the reference's; host pass) or, when false, in point-index order (device only)
+    int vox_member_order = 1;          // voxel filters, members of a voxel: 1 = in the order libstdc++'s std::sort leaves them (the reference's), produced on the device
+                                       // (stdsort.hip); 2 = the same through a host pass that calls the platform's own std::sort; 0 = in point-index order
+    mlh::DevBuf stdsort;               // scratch of device_std_sort_by_key
     void *vox_order_host = nullptr; // pinned staging of that host pass (voxelgrid.hip): [slot n][members n]
     size_t vox_order_host_cap = 0;
     void *select_host = nullptr; // pinned staging of the good-feature selection (select.hip)
@@ -310,6 +312,9 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
                         double *H, double *g, double *cost, int32_t *n_res);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
+// stdsort.hip: vals_out <- the permutation of 0..n-1 that std::sort (libstdc++, comparator on the key only) leaves for keys[0..n0) and keys[n0..n)
+int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out);
+void host_std_sort_permutation(const int *slot, int lo, int hi, int *members);   // voxelgrid.hip: the platform's own std::sort
 // voxel.hip
 void compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pc[7], double cc[36]);
 int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, int n, int intensity_off, int mem, float leaf, const double *ext_poses,

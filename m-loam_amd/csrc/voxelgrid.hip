@@ -14,6 +14,7 @@
 //   plain branch (:392-420) xyz mean over the members, intensity of the last member
 // Streaming kernels: ~ (stride + 8) B/point per pass + 1/8 B/cell (bits) + 8 B per 32 cells for the popcount scan.
 #include "ctx.hpp"
+#include "std_sort_mt.hpp"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -316,16 +317,34 @@ __global__ __launch_bounds__(256) void vox_aggregate_kernel(VoxArgs A)
     if (has_i) *reinterpret_cast<float *>(o + A.intensity_off) = ity;
 }
 
-// Reference member order (the default; mlh_set_voxel_member_order(ctx, 0) turns it off): the reference groups a voxel's members with an
-// UNSTABLE std::sort whose comparator sees the voxel index only (voxel_grid_covariance_mloam_impl.hpp:215-236), so the order of the members
-// inside a voxel -- and with it "the last member's intensity" of the plain branch, the first-maximum-weight intensity of the covariance
-// branch and the association of every f32 sum -- is whatever libstdc++'s introsort leaves. That order cannot be derived without running the
-// same algorithm on the same sequence, so this path does exactly that on the host: the points' output slots (ascending voxel index:
-// order-isomorphic to PCL's idx, hence the same comparisons and the same introsort path) come back into pinned memory, std::sort runs per
-// cloud on (slot, point index) pairs in point order (the second cloud of a pair call on a second thread), and the resulting member lists
-// replace what vox_rank_kernel would have written. Costs a host round trip and a ~n log n host sort per call; with the switch off the
-// members are walked in ascending point index on the device instead (same voxels, same centroids to f32 rounding, a different surviving
-// intensity where a voxel mixes them).
+// Reference member order: the reference groups a voxel's members with an UNSTABLE std::sort whose comparator sees the voxel index only
+// (voxel_grid_covariance_mloam_impl.hpp:215-236), so the order of the members inside a voxel -- and with it "the last member's
+// intensity" of the plain branch, the first-maximum-weight intensity of the covariance branch and the association of every f32 sum -- is
+// whatever libstdc++'s introsort leaves. That order cannot be derived without running the same algorithm on the same sequence (the
+// points' output slots: ascending voxel index, order-isomorphic to PCL's idx, hence the same comparisons and the same introsort path).
+//   mode 1 (default): stdsort.hip runs libstdc++'s algorithm, restated data-parallel, on the device -- nothing leaves HBM;
+//   mode 2: the slots come back into pinned memory, the platform's own std::sort runs there per cloud on (slot, point index) pairs in
+//           point order (std_sort_mt.hpp: libstdc++'s own partition steps, the recursion's independent halves on other threads; the
+//           second cloud of a pair call on threads of its own), the member lists go back: a host round trip and ~1.2 ms for a frame's
+//           78 k points, for a standard library whose std::sort is not the algorithm mode 1 restates;
+//   mode 0: members in ascending point index (vox_rank_kernel): same voxels, same centroids to f32 rounding, a different surviving
+//           intensity where a voxel mixes them.
+// members[lo..hi) <- the point indices lo..hi-1 in the order std::sort leaves them when it compares slot[] only
+void host_std_sort_permutation(const int *slot, int lo, int hi, int *members)
+{
+    if (hi <= lo) return;
+    struct IdxPt {
+        unsigned int idx, cloud_point_index;
+        bool operator<(const IdxPt &o) const { return idx < o.idx; }      // cloud_point_index_idx::operator< (voxel_grid.h): idx only
+    };
+    std::vector<IdxPt> iv;
+    iv.reserve(size_t(hi - lo));
+    for (int i = lo; i < hi; ++i) iv.push_back(IdxPt{(unsigned)slot[size_t(i)], (unsigned)i});
+    std_sort_mt(iv.data(), iv.data() + iv.size(), hi - lo > 8192 ? 2 : 0);   // std::sort's result, its independent halves on up to 4 threads
+    int *dst = members + lo;
+    for (const IdxPt &e : iv) *dst++ = int(e.cloud_point_index);
+}
+
 static int members_in_std_sort_order(mlh_ctx *ctx, const VoxArgs &A)
 {
     hipStream_t st = ctx->stream;
@@ -340,20 +359,8 @@ static int members_in_std_sort_order(mlh_ctx *ctx, const VoxArgs &A)
     int *slot = static_cast<int *>(ctx->vox_order_host), *members = slot + n;
     MLH_HIP(ctx, hipMemcpyAsync(slot, A.vox_of, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
-    struct IdxPt {
-        unsigned int idx, cloud_point_index;
-        bool operator<(const IdxPt &o) const { return idx < o.idx; }      // cloud_point_index_idx::operator< (voxel_grid.h): idx only
-    };
     // one filter call per cloud in the reference: one sort per cloud
-    auto sort_range = [slot, members](int lo, int hi) {
-        if (hi <= lo) return;
-        std::vector<IdxPt> iv;
-        iv.reserve(size_t(hi - lo));
-        for (int i = lo; i < hi; ++i) iv.push_back(IdxPt{(unsigned)slot[size_t(i)], (unsigned)i});
-        std::sort(iv.begin(), iv.end(), std::less<IdxPt>());
-        int *dst = members + lo;
-        for (const IdxPt &e : iv) *dst++ = int(e.cloud_point_index);
-    };
+    auto sort_range = [slot, members](int lo, int hi) { host_std_sort_permutation(slot, lo, hi, members); };
     if (A.n0 > 4096 && A.n - A.n0 > 4096) {
         std::thread second(sort_range, A.n0, A.n);
         sort_range(0, A.n0);
@@ -484,7 +491,8 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
     if (rc) return rc;
     hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
-    if (ctx->vox_std_sort_order) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
+    if (ctx->vox_member_order == 1) { if ((rc = device_std_sort_by_key(ctx, A.vox_of, A.n0, A.n, A.members))) return rc; }
+    else if (ctx->vox_member_order == 2) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
     else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
     hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
@@ -563,7 +571,8 @@ int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);
-    if (ctx->vox_std_sort_order) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
+    if (ctx->vox_member_order == 1) { if ((rc = device_std_sort_by_key(ctx, A.vox_of, A.n0, A.n, A.members))) return rc; }
+    else if (ctx->vox_member_order == 2) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
     else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
     hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());

@@ -404,6 +404,21 @@ int orc_voxel_grid_mloam_plain(const float *xyzi, int n, float leaf, int member_
     return 0;
 }
 
+// The permutation std::sort leaves when its comparator sees the key only -- pcl's cloud_point_index_idx::operator< (voxel_grid.h), as the
+// reference's voxel filters call it (voxel_grid_covariance_mloam_impl.hpp:227). Plain std::sort, one thread: the checker of stdsort.hip.
+int orc_std_sort_permutation(const int *keys, int n, int *perm)
+{
+    struct IdxPt {
+        unsigned idx, cloud_point_index;
+        bool operator<(const IdxPt &o) const { return idx < o.idx; }
+    };
+    std::vector<IdxPt> iv(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) iv[size_t(i)] = IdxPt{unsigned(keys[i]), unsigned(i)};
+    std::sort(iv.begin(), iv.end(), std::less<IdxPt>());
+    for (int i = 0; i < n; ++i) perm[i] = int(iv[size_t(i)].cloud_point_index);
+    return 0;
+}
+
 int orc_compound_pose_with_cov(const double *pose1, const double *cov1, const double *pose2, const double *cov2, double *pose_cp, double *cov_cp)
 {
     compound_pose_with_cov(pose1, cov1, pose2, cov2, pose_cp, cov_cp);

@@ -595,6 +595,15 @@ def voxel_grid_mloam_plain(points, leaf, member_order=1):
     return out[:cnt.value].copy()
 
 
+def std_sort_permutation(keys):
+    """the permutation libstdc++'s std::sort leaves for a comparator that sees the key only (one thread, the library's own call)"""
+    k = np.ascontiguousarray(keys, np.int32)
+    perm = np.zeros(len(k), np.int32)
+    if len(k):
+        lib().orc_std_sort_permutation(_ptr(k), len(k), _ptr(perm))
+    return perm
+
+
 def compound_pose_with_cov(pose1, cov1, pose2, cov2):
     a = [np.ascontiguousarray(x, np.float64) for x in (pose1, cov1, pose2, cov2)]
     pose_cp, cov_cp = np.zeros(7), np.zeros((6, 6))

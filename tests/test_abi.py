@@ -81,3 +81,17 @@ def test_compound_pose_with_cov_host(mla, orc):
         got, ref = mla.compound_pose_with_cov(p1, c1, p2, c2), orc.compound_pose_with_cov(p1, c1, p2, c2)
         np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-14)
         np.testing.assert_allclose(got[1], ref[1], rtol=1e-12, atol=1e-18)
+
+
+def test_std_sort_mt_equals_std_sort(tmp_path):
+    """The voxel filters' default member order is libstdc++'s std::sort order, produced on several host threads by
+    m-loam_amd/csrc/std_sort_mt.hpp (libstdc++'s own partition steps, the recursion's independent halves forked). Equal to std::sort element
+    for element -- duplicates, patterned inputs, every fork depth -- or the reference's voxel results are not reproduced."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(ROOT, "tests", "host", "std_sort_mt_check.cpp")
+    exe = str(tmp_path / "std_sort_mt_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "m-loam_amd", "csrc"), "-o", exe, src], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert " 0 mismatches" in out, out
+

@@ -654,10 +654,45 @@ def test_voxel_filters_in_the_references_member_order(mla, orc, synth, case16, f
         got = c.downsample_current_scan(mla.SURF, f4, 0.4, ext, covs, meas, True, thr)
         assert 0 < keep.sum() < len(ds) and len(got) == keep.sum()
         np.testing.assert_array_equal(got[:, :4].view(np.uint32), ds[keep].view(np.uint32))
-        # the device-only order is per context and switchable
+        # the same through the host pass (the platform's own std::sort)
+        c.set_voxel_member_order("host")
+        np.testing.assert_array_equal(c.voxel_filter(pts, 0.4).view(np.uint32), orc.voxel_grid_mloam_plain(pts, 0.4, member_order=0).view(np.uint32))
+        # the point-index order is per context and switchable
         c.set_voxel_member_order(False)
         again = c.voxel_filter(pts, 0.4)
         np.testing.assert_array_equal(again[:, 3], orc.voxel_grid_mloam_plain(pts, 0.4, member_order=1)[:, 3])
+    finally:
+        c.close()
+
+
+def test_device_std_sort_equals_std_sort(mla, orc):
+    """stdsort.hip: libstdc++'s std::sort (key-only comparator) restated data-parallel on the device -- the permutation must equal the
+    library's own, element for element: random keys with many duplicates (the voxel-slot case), all-equal keys, already sorted / reversed /
+    organ-pipe / sawtooth inputs (several of which exhaust introsort's depth budget and take the heap-sort path), sizes around the
+    16-element insertion threshold, and the two-clouds-in-one-call form. Also against the host pass (mode 2: std_sort_mt.hpp)."""
+    rng = np.random.default_rng(11)
+    c = mla.Context(0)
+    try:
+        cases = []
+        for n in (1, 2, 15, 16, 17, 18, 33, 100, 257, 1025, 5000, 40000, 62365):
+            for nv in sorted({1, 2, 7, n // 4 + 1, n + 1}):
+                i = np.arange(n)
+                cases += [rng.integers(0, nv, n), i % nv, (n - i) // (n // nv + 1), np.where(i < n // 2, i, n - i) % nv, (n - i) % nv]
+        cases.append(rng.integers(0, 50000, 200000))
+        heap = 0
+        for keys in cases:
+            keys = keys.astype(np.int32)
+            want = orc.std_sort_permutation(keys)
+            got = c.std_sort_permutation(keys, mode=1)
+            np.testing.assert_array_equal(got, want)
+            if len(keys) in (5000, 62365):
+                np.testing.assert_array_equal(c.std_sort_permutation(keys, mode=2), want)
+        # two clouds in one call = two std::sort calls
+        keys = rng.integers(0, 9000, 62365 + 15161).astype(np.int32)
+        keys[62365:] += 9000
+        want = np.concatenate([orc.std_sort_permutation(keys[:62365]), 62365 + orc.std_sort_permutation(keys[62365:])])
+        for mode in (1, 2):
+            np.testing.assert_array_equal(c.std_sort_permutation(keys, n0=62365, mode=mode), want)
     finally:
         c.close()
 
