@@ -16,17 +16,23 @@
 // left only past strictly greater ones: it never crosses a range boundary and is stable inside a range.
 //
 // None of that needs one thread:
-//  * the ranges of one recursion depth are disjoint and independent: one launch per depth, one workgroup per range;
+//  * the ranges of one recursion depth are disjoint and independent;
 //  * the Hoare partition of a range is a function of two lists of the ORIGINAL arrangement: L = positions (ascending) where the left
 //    scan stops (!(a[p] < pivot)), R = positions (descending) where the right scan stops (!(pivot < a[p]), with `first` itself as the
 //    last entry, which is what makes the library's right scan "unguarded"). The sequential loop swaps L[k] with R[k] for k = 0, 1, ...
 //    as long as L[k] < R[k] -- a swapped position is never visited again --, and returns min(L[K], R[K-1]) where K is the number of
 //    swaps (after the last swap the left scan runs into either the next original stop or the element it has just moved to R[K-1]).
-//    Ranks by prefix sums, the pairs by a rank-indexed table, the swaps in parallel;
+//    Ranks from wavefront ballots, the pairs through rank-indexed tables, the swaps in parallel;
 //  * the final pass is an insertion sort per range of <= 16 (one thread each), the heap sort of an exhausted range (adversarial inputs
 //    only) one thread running libstdc++'s __make_heap / __sort_heap as written.
-// tests: tests/test_gpu_parity.py::test_device_std_sort_equals_std_sort (against std::sort through the oracle library, duplicates and the
-// patterns that exhaust the depth budget included); the voxel-filter parity tests run on top of it.
+//
+// Launches: the first SS_BIG_LEVELS recursion depths one launch each -- a 1024-thread workgroup per range longer than SS_LEAF, its 16
+// wavefronts streaming contiguous sixteenths of the range in coalesced 64-wide tiles --, then ONE launch in which a workgroup takes a
+// range of at most SS_LEAF elements into LDS and runs the rest of its recursion there (every wavefront partitioning sub-ranges
+// for itself, a ticket queue between them), final insertion pass included, and writes it back. A range that is still longer than SS_LEAF after the
+// big levels (adversarial inputs only) goes through the same code on global memory: slower, same result.
+// tests: tests/test_gpu_parity.py::test_device_std_sort_equals_std_sort (against the library's own std::sort: duplicates, the patterns that
+// exhaust the depth budget, sizes around every threshold); the voxel-filter parity tests run on top of it.
 #include "ctx.hpp"
 #include <climits>
 
@@ -34,8 +40,13 @@ namespace mlh {
 
 namespace {
 
-constexpr int SS_WG = 256;
 constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
+constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
+constexpr int SS_BIG_WG = 1024;
+constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
+constexpr int SS_BIG_LEVELS = 8;
+constexpr int SS_LEAF_WG = 1024;
+constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // sub-ranges longer than 16 that can coexist at one depth in LDS mode
 
 struct SortSeg { int first, last, depth, pad; };
 
@@ -43,22 +54,23 @@ struct StdSortArgs {
     int *keys;          // n: sorted in place (the comparator sees these only)
     int *vals;          // n: carried along
     int *lt, *rt;       // n each: the L / R position tables of a range live at [first, ...) of these
-    SortSeg *seg[2];    // ranges longer than 16 of the current / the next depth
-    SortSeg *fin;       // ranges of 2..16 elements: the final insertion pass
-    int *cnt;           // [0 .. SS_MAX_LEVELS]: ranges per depth; [SS_FIN]: final ranges
+    int *gfin, *glist;  // n each: fin ranges / sub-range lists of a range finished on GLOBAL memory (oversize leaves only)
+    SortSeg *seg[2];    // ranges longer than SS_LEAF of the current / the next big level
+    SortSeg *leaf;      // ranges of 2 .. SS_LEAF elements
+    int *cnt;           // [0 .. SS_BIG_LEVELS]: ranges per big level; [SS_CNT_LEAF]: leaves
     int n;
 };
-constexpr int SS_MAX_LEVELS = 64;     // 2 * floor(log2(n)) <= 62
-constexpr int SS_FIN = SS_MAX_LEVELS + 1;
-constexpr int SS_CNT = SS_MAX_LEVELS + 2;
+constexpr int SS_CNT_LEAF = SS_BIG_LEVELS + 1;
+constexpr int SS_CNT = SS_BIG_LEVELS + 2;
 
 __device__ inline int floor_log2(int n) { return 31 - __clz(n); }
+__device__ inline unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
-__device__ inline void emit_range(const StdSortArgs &A, int first, int last, int depth, SortSeg *next, int *next_cnt)
+__device__ inline void emit_global(const StdSortArgs &A, int first, int last, int depth, SortSeg *next, int *next_cnt)
 {
     const int m = last - first;
-    if (m > SS_THRESHOLD) next[atomicAdd(next_cnt, 1)] = SortSeg{first, last, depth, 0};
-    else if (m > 1) A.fin[atomicAdd(&A.cnt[SS_FIN], 1)] = SortSeg{first, last, 0, 0};
+    if (m > SS_LEAF) next[atomicAdd(next_cnt, 1)] = SortSeg{first, last, depth, 0};
+    else if (m > 1) A.leaf[atomicAdd(&A.cnt[SS_CNT_LEAF], 1)] = SortSeg{first, last, depth, 0};
 }
 
 // keys <- the points' slots, vals <- the point indices, one range per cloud (std::sort is called once per cloud)
@@ -67,21 +79,31 @@ __global__ __launch_bounds__(256) void stdsort_init_kernel(StdSortArgs A, const 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < A.n) { A.keys[i] = src_keys[i]; A.vals[i] = i; }
     if (i == 0) {
-        for (int k = 1; k < SS_CNT; ++k) A.cnt[k] = 0;
-        A.cnt[0] = 0;
+        for (int k = 0; k < SS_CNT; ++k) A.cnt[k] = 0;
         const int lo[2] = {0, n0}, hi[2] = {n0, A.n};
         for (int c = 0; c < 2; ++c)
-            if (hi[c] - lo[c] > 1) emit_range(A, lo[c], hi[c], 2 * floor_log2(hi[c] - lo[c]), A.seg[0], &A.cnt[0]);
+            if (hi[c] - lo[c] > 1) emit_global(A, lo[c], hi[c], 2 * floor_log2(hi[c] - lo[c]), A.seg[0], &A.cnt[0]);
     }
 }
 
-__device__ inline void swap_elem(const StdSortArgs &A, int p, int q)
+__device__ inline void swap_elem(int *keys, int *vals, int p, int q)
 {
-    const int kp = A.keys[p], kq = A.keys[q], vp = A.vals[p], vq = A.vals[q];
-    A.keys[p] = kq; A.keys[q] = kp; A.vals[p] = vq; A.vals[q] = vp;
+    const int kp = keys[p], kq = keys[q], vp = vals[p], vq = vals[q];
+    keys[p] = kq; keys[q] = kp; vals[p] = vq; vals[q] = vp;
 }
 
-// bits/stl_heap.h on (keys, vals) + base: __adjust_heap with its trailing __push_heap, __make_heap, __sort_heap -- one thread, as written
+// __move_median_to_first(first, first + 1, mid, last - 1) on the range [f, l)
+__device__ inline void median_to_first(int *keys, int *vals, int f, int l)
+{
+    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+    const int ka = keys[ia], kb = keys[ib], kc = keys[ic];
+    int med;
+    if (ka < kb) med = (kb < kc) ? ib : ((ka < kc) ? ic : ia);
+    else med = (ka < kc) ? ia : ((kb < kc) ? ic : ib);
+    swap_elem(keys, vals, f, med);
+}
+
+// bits/stl_heap.h on (keys, vals): __adjust_heap with its trailing __push_heap, __make_heap, __sort_heap -- one thread, as written
 __device__ void heap_adjust(int *k, int *v, int hole, int len, int key, int val)
 {
     const int top = hole;
@@ -125,34 +147,63 @@ __device__ void heap_sort_range(int *k, int *v, int len)
     }
 }
 
-// inclusive scan of one int per thread over the workgroup; *total = the sum. LDS: wave_sums[SS_WG / 64]
-__device__ inline int block_inclusive_scan(int x, int *wave_sums, int *total)
+// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, four tiles per trip with the loads issued first.
+// count pass: the number of left / right stops in [lo, hi).
+constexpr int SS_U = 4;
+__device__ inline void wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    int cl = 0, cr = 0;
+    for (int base = lo; base < hi; base += 64 * SS_U) {
+        int k[SS_U];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off);
-        if (lane >= off) x += y;
+        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < hi;
+            cl += __popcll(__ballot(in && p > f && !(k[u] < piv)));
+            cr += __popcll(__ballot(in && (p == f || !(piv < k[u]))));
+        }
     }
-    __syncthreads();                       // wave_sums may still be read from the previous use
-    if (lane == 63) wave_sums[wave] = x;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SS_WG / 64; ++w) { const int s = wave_sums[w]; if (w < wave) base += s; tot += s; }
-    *total = tot;
-    return x + base;
+    n_left = cl; n_right = cr;
 }
 
-// one recursion depth: every range longer than 16 is partitioned once (or heap-sorted when its depth budget is used up)
-__global__ __launch_bounds__(SS_WG) void stdsort_level_kernel(StdSortArgs A, int level)
+// table pass: left stops get ranks rank_l0, rank_l0 + 1, ... in ascending position; right stops ranks counted from the right:
+// a stop at p has rank (right stops of the whole range at positions > p) = after_r + (stops of [lo, hi) at positions > p)
+__device__ inline void wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here)
 {
-    __shared__ int wave_sums[SS_WG / 64];
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = lanes_below();
+    int run_l = rank_l0, run_r = 0;
+    for (int base = lo; base < hi; base += 64 * SS_U) {
+        int k[SS_U];
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < hi;
+            const bool is_l = in && p > f && !(k[u] < piv);
+            const bool is_r = in && (p == f || !(piv < k[u]));
+            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+            if (is_l) lt[f + run_l + __popcll(ml & below)] = p;
+            if (is_r) rt[f + after_r + (n_right_here - (run_r + __popcll(mr & below) + 1))] = p;
+            run_l += __popcll(ml);
+            run_r += __popcll(mr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF
+__global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level)
+{
+    __shared__ int w_left[SS_BIG_WAVES], w_right[SS_BIG_WAVES];
     __shared__ int sh_k;
     const SortSeg *cur = A.seg[level & 1];
     SortSeg *next = A.seg[(level + 1) & 1];
     const int count = A.cnt[level];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, wave = t >> 6;
     for (int si = blockIdx.x; si < count; si += gridDim.x) {
         const SortSeg s = cur[si];
         const int f = s.first, l = s.last, m = l - f;
@@ -160,73 +211,172 @@ __global__ __launch_bounds__(SS_WG) void stdsort_level_kernel(StdSortArgs A, int
             if (t == 0) heap_sort_range(A.keys + f, A.vals + f, m);
             continue;
         }
-        if (t == 0) {                                                // __move_median_to_first(first, first + 1, mid, last - 1)
-            const int ia = f + 1, ib = f + m / 2, ic = l - 1;
-            const int ka = A.keys[ia], kb = A.keys[ib], kc = A.keys[ic];
-            int med;
-            if (ka < kb) med = (kb < kc) ? ib : ((ka < kc) ? ic : ia);
-            else med = (ka < kc) ? ia : ((kb < kc) ? ic : ib);
-            swap_elem(A, f, med);
-            sh_k = 0;
-        }
+        if (t == 0) { median_to_first(A.keys, A.vals, f, l); sh_k = 0; }
         __syncthreads();
         const int piv = A.keys[f];
-        // thread t owns positions [f + t * per, f + (t + 1) * per) of [f, l); position f is a stop of the right scan only
-        const int per = (m + SS_WG - 1) / SS_WG;
-        const int p0 = f + t * per, p1 = min(p0 + per, l);
-        int cl = 0, cr = 0;
-        for (int p = p0; p < p1; ++p) {
-            const int k = A.keys[p];
-            cl += (p > f && !(k < piv)) ? 1 : 0;
-            cr += (p == f || !(piv < k)) ? 1 : 0;
-        }
-        int nL, nR;
-        const int inc_l = block_inclusive_scan(cl, wave_sums, &nL);
-        const int inc_r = block_inclusive_scan(cr, wave_sums, &nR);
-        int rl = inc_l - cl;                                         // rank of this thread's first left stop
-        int rr = nR - inc_r;                                         // rank of this thread's LAST right stop (ranks grow leftwards)
-        for (int p = p0; p < p1; ++p) {
-            const int k = A.keys[p];
-            if (p > f && !(k < piv)) A.lt[f + rl++] = p;
-        }
-        for (int p = p1 - 1; p >= p0; --p) {
-            const int k = A.keys[p];
-            if (p == f || !(piv < k)) A.rt[f + rr++] = p;
-        }
+        const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
+        const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
+        int cl, cr;
+        wave_count_stops(A.keys, f, lo, hi, piv, cl, cr);
+        if ((t & 63) == 0) { w_left[wave] = cl; w_right[wave] = cr; }
         __syncthreads();
-        // K = number of swaps: L[k] < R[k] holds for a prefix of k
+        int nL = 0, nR = 0, before_l = 0, after_r = 0;
+#pragma unroll
+        for (int w = 0; w < SS_BIG_WAVES; ++w) {
+            const int a = w_left[w], b = w_right[w];
+            nL += a; nR += b;
+            if (w < wave) before_l += a;
+            if (w > wave) after_r += b;
+        }
+        wave_write_tables(A.keys, A.lt, A.rt, f, lo, hi, piv, before_l, after_r, cr);
+        __syncthreads();
         const int npair = min(nL, nR);
         int mine = 0;
-        for (int k = t; k < npair; k += SS_WG) mine += (A.lt[f + k] < A.rt[f + k]) ? 1 : 0;
+        for (int k = t; k < npair; k += SS_BIG_WG) mine += (A.lt[f + k] < A.rt[f + k]) ? 1 : 0;      // true for a prefix of k
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if ((t & 63) == 0 && mine) atomicAdd(&sh_k, mine);
         __syncthreads();
         const int K = sh_k;
-        for (int k = t; k < K; k += SS_WG) swap_elem(A, A.lt[f + k], A.rt[f + k]);
+        for (int k = t; k < K; k += SS_BIG_WG) swap_elem(A.keys, A.vals, A.lt[f + k], A.rt[f + k]);
         if (t == 0) {
             int cut = INT_MAX;
             if (K < nL) cut = min(cut, A.lt[f + K]);
             if (K > 0) cut = min(cut, A.rt[f + K - 1]);
-            emit_range(A, cut, l, s.depth - 1, next, &A.cnt[level + 1]);     // the recursive call
-            emit_range(A, f, cut, s.depth - 1, next, &A.cnt[level + 1]);     // the loop's next trip
+            emit_global(A, cut, l, s.depth - 1, next, &A.cnt[level + 1]);     // the recursive call
+            emit_global(A, f, cut, s.depth - 1, next, &A.cnt[level + 1]);     // the loop's next trip
         }
-        __syncthreads();                                             // sh_k and the tables are reused by the next range of this workgroup
+        __syncthreads();                                             // sh_k and w_* are reused by the next range of this workgroup
     }
 }
 
-// __final_insertion_sort restricted to a range of <= 16 (it never moves an element across a range boundary): one thread per range
-__global__ __launch_bounds__(256) void stdsort_final_kernel(StdSortArgs A)
+// ------------------------------------------------------------------ leaves: the rest of a range's recursion inside one workgroup
+// Arrays in LOCAL coordinates [0, m). Every wavefront works on its own: it partitions a sub-range, keeps one child longer than 16 for
+// itself and hands the other to a queue in (first, last, depth budget, ready) records; a wavefront without work takes the next ticket
+// of that queue and waits for the record to appear. `remaining` counts the elements not yet in a range of <= 16 (or heap-sorted):
+// at zero everybody leaves. At most one record per partition whose children are BOTH longer than 16: < m / 17 of them, plus the root.
+struct LeafMem {
+    int *keys, *vals, *lt, *rt;
+    int *fin;           // (first, last) pairs of ranges of 2..16: the final insertion pass
+    int *q;             // queue records, 4 ints each
+    int qcap;
+};
+enum { LQ_TAIL = 0, LQ_HEAD = 1, LQ_REMAINING = 2, LQ_NFIN = 3 };
+
+__device__ inline int wg_load(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+__device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.cnt[SS_FIN]) return;
-    const SortSeg s = A.fin[i];
-    int *k = A.keys, *v = A.vals;
-    for (int p = s.first + 1; p < s.last; ++p) {
-        const int key = k[p], val = v[p];
-        int j = p;
-        while (j > s.first && key < k[j - 1]) { k[j] = k[j - 1]; v[j] = v[j - 1]; --j; }
-        k[j] = key; v[j] = val;
+    const int t = threadIdx.x, lane = t & 63;
+    for (int i = t; i < 4 * M.qcap; i += SS_LEAF_WG) M.q[i] = 0;
+    if (t == 0) { sh[LQ_TAIL] = 0; sh[LQ_HEAD] = 0; sh[LQ_REMAINING] = m; sh[LQ_NFIN] = 0; }
+    __syncthreads();
+    if (t == 0) {
+        if (m > SS_THRESHOLD) { M.q[0] = 0; M.q[1] = m; M.q[2] = depth0; sh[LQ_TAIL] = 1; wg_store(&M.q[3], 1); }
+        else { if (m > 1) { M.fin[0] = 0; M.fin[1] = m; sh[LQ_NFIN] = 1; } sh[LQ_REMAINING] = 0; }
+    }
+    __syncthreads();
+    int f = 0, l = 0, d = 0;
+    bool have = false;
+    while (true) {
+        if (!have) {
+            if (wg_load(&sh[LQ_REMAINING]) == 0) break;
+            int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&sh[LQ_HEAD], 1);
+            ticket = __shfl(ticket, 0);
+            bool got = false;
+            for (int spins = 0; spins < (1 << 24); ++spins) {        // bounded: a waiting wavefront can only be released by progress elsewhere
+                if (ticket < M.qcap && wg_load(&M.q[4 * ticket + 3]) != 0) { got = true; break; }
+                if (wg_load(&sh[LQ_REMAINING]) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!got) break;
+            f = M.q[4 * ticket]; l = M.q[4 * ticket + 1]; d = M.q[4 * ticket + 2];
+            have = true;
+        }
+        const int size = l - f;
+        if (d == 0) {                                                 // __partial_sort(first, last, last): sorted for good, no children
+            if (lane == 0) { heap_sort_range(M.keys + f, M.vals + f, size); wg_fence(); atomicSub(&sh[LQ_REMAINING], size); }
+            have = false;
+            continue;
+        }
+        if (lane == 0) median_to_first(M.keys, M.vals, f, l);
+        wg_fence();
+        const int piv = M.keys[f];
+        int nL, nR;
+        wave_count_stops(M.keys, f, f, l, piv, nL, nR);
+        wave_write_tables(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
+        wg_fence();
+        const int npair = min(nL, nR);
+        int K = 0;
+        for (int base = 0; base < npair; base += 64) {
+            const int k = base + lane;
+            K += __popcll(__ballot(k < npair && M.lt[f + k] < M.rt[f + k]));
+        }
+        for (int k = lane; k < K; k += 64) swap_elem(M.keys, M.vals, M.lt[f + k], M.rt[f + k]);
+        int cut = INT_MAX;
+        if (K < nL) cut = min(cut, M.lt[f + K]);
+        if (K > 0) cut = min(cut, M.rt[f + K - 1]);
+        wg_fence();
+        // children: [cut, l) is the library's recursive call, [f, cut) its loop's next trip; both get d - 1
+        const int size_a = cut - f, size_b = l - cut;
+        const bool big_a = size_a > SS_THRESHOLD, big_b = size_b > SS_THRESHOLD;
+        if (lane == 0) {
+            int done = 0;
+            if (!big_a) { if (size_a > 1) { const int e = atomicAdd(&sh[LQ_NFIN], 1); M.fin[2 * e] = f; M.fin[2 * e + 1] = cut; } done += size_a; }
+            if (!big_b) { if (size_b > 1) { const int e = atomicAdd(&sh[LQ_NFIN], 1); M.fin[2 * e] = cut; M.fin[2 * e + 1] = l; } done += size_b; }
+            if (big_a && big_b) {
+                const int e = atomicAdd(&sh[LQ_TAIL], 1);
+                M.q[4 * e] = cut; M.q[4 * e + 1] = l; M.q[4 * e + 2] = d - 1;
+                wg_store(&M.q[4 * e + 3], 1);
+            }
+            if (done) { wg_fence(); atomicSub(&sh[LQ_REMAINING], done); }
+        }
+        if (big_a) { l = cut; d -= 1; }
+        else if (big_b) { f = cut; d -= 1; }
+        else have = false;
+    }
+    __syncthreads();
+    // __final_insertion_sort, range by range
+    const int n_fin = sh[LQ_NFIN];
+    for (int i = t; i < n_fin; i += SS_LEAF_WG) {
+        const int a = M.fin[2 * i], b = M.fin[2 * i + 1];
+        for (int p = a + 1; p < b; ++p) {
+            const int key = M.keys[p], val = M.vals[p];
+            int j = p;
+            while (j > a && key < M.keys[j - 1]) { M.keys[j] = M.keys[j - 1]; M.vals[j] = M.vals[j - 1]; --j; }
+            M.keys[j] = key; M.vals[j] = val;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
+{
+    __shared__ int s_keys[SS_LEAF], s_vals[SS_LEAF], s_lt[SS_LEAF], s_rt[SS_LEAF], s_fin[SS_LEAF];
+    __shared__ int s_q[4 * SS_LOCAL_LIST];
+    __shared__ int sh[4];
+    const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[SS_BIG_LEVELS];
+    const SortSeg *over = A.seg[SS_BIG_LEVELS & 1];
+    const int t = threadIdx.x;
+    for (int si = blockIdx.x; si < n_leaf + n_left_over; si += gridDim.x) {
+        const SortSeg s = si < n_leaf ? A.leaf[si] : over[si - n_leaf];
+        const int f = s.first, m = s.last - s.first;
+        LeafMem M;
+        if (m <= SS_LEAF) {
+            for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
+            M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
+            __syncthreads();
+            leaf_sort(M, m, s.depth, sh);
+            for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
+            __syncthreads();
+        } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
+            M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
+            M.q = A.glist + f; M.qcap = m / (SS_THRESHOLD + 1) + 2;
+            leaf_sort(M, m, s.depth, sh);
+        }
     }
 }
 
@@ -239,23 +389,25 @@ int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int
     if (n <= 0) return MLH_OK;
     hipStream_t st = ctx->stream;
     DevBuf &S = ctx->stdsort;
-    const size_t ni = size_t(n), nseg = ni / (SS_THRESHOLD + 1) + 4, nfin = ni / 2 + 4;
-    // [keys n][lt n][rt n][cnt SS_CNT (padded to 128)][seg0][seg1][fin]
-    const size_t off_lt = ni, off_rt = 2 * ni, off_cnt = 3 * ni, off_seg0 = off_cnt + 128;
-    const size_t seg_ints = nseg * 4, off_seg1 = off_seg0 + seg_ints, off_fin = off_seg1 + seg_ints, total = off_fin + nfin * 4;
+    const size_t ni = size_t(n), nbig = ni / SS_LEAF + 4, nleaf = ni / 2 + 4;
+    // [keys n][lt n][rt n][gfin n][glist n][cnt (padded to 64)][seg0][seg1][leaf]
+    const size_t off_lt = ni, off_rt = 2 * ni, off_gfin = 3 * ni, off_glist = 4 * ni, off_cnt = 5 * ni, off_seg0 = off_cnt + 64;
+    const size_t seg_ints = nbig * 4, off_seg1 = off_seg0 + seg_ints, off_leaf = off_seg1 + seg_ints, total = off_leaf + nleaf * 4;
     MLH_HIP(ctx, S.ensure(sizeof(int) * total));
     int *base = S.as<int>();
     StdSortArgs A;
-    A.keys = base; A.vals = vals_out; A.lt = base + off_lt; A.rt = base + off_rt; A.cnt = base + off_cnt;
+    A.keys = base; A.vals = vals_out; A.lt = base + off_lt; A.rt = base + off_rt; A.gfin = base + off_gfin; A.glist = base + off_glist;
+    A.cnt = base + off_cnt;
     A.seg[0] = reinterpret_cast<SortSeg *>(base + off_seg0); A.seg[1] = reinterpret_cast<SortSeg *>(base + off_seg1);
-    A.fin = reinterpret_cast<SortSeg *>(base + off_fin); A.n = n;
+    A.leaf = reinterpret_cast<SortSeg *>(base + off_leaf); A.n = n;
     hipLaunchKernelGGL(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, src_keys, n0);
-    int big = std::max(n0, n - n0), lg = 0;
-    while ((1 << (lg + 1)) <= big) ++lg;
-    const int levels = 2 * lg + 1;                                   // depth budgets 2*lg .. 0
-    const int grid = int(std::min<size_t>(nseg, 2048));
-    for (int level = 0; level < levels; ++level) hipLaunchKernelGGL(stdsort_level_kernel, dim3(grid), dim3(SS_WG), 0, st, A, level);
-    hipLaunchKernelGGL(stdsort_final_kernel, dim3(int((nfin + 255) / 256)), dim3(256), 0, st, A);
+    if (std::max(n0, n - n0) > SS_LEAF) {
+        const int grid_big = int(std::min<size_t>(nbig, 64));
+        for (int level = 0; level < SS_BIG_LEVELS; ++level)
+            hipLaunchKernelGGL(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
+    }
+    const int grid_leaf = int(std::min<size_t>(nleaf, 1024));
+    hipLaunchKernelGGL(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/sel
 timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/sel/pytest.log 2>&1; echo "[pytest] rc=$? $(grep -E 'passed|failed' gpurun_out/sel/pytest.log | tail -1)"
 grep -iE "^(FAILED|ERROR)|^E  " gpurun_out/sel/pytest.log | head -20
 timeout 300 python scripts/gfbench.py > gpurun_out/sel/gfbench.txt 2>&1; tail -5 gpurun_out/sel/gfbench.txt
-timeout 400 python scripts/framebench.py > gpurun_out/sel/framebench.txt 2>&1; tail -12 gpurun_out/sel/framebench.txt | cut -c1-400
+timeout 400 python scripts/framebench.py < /dev/null > gpurun_out/sel/framebench.txt 2>&1; tail -12 gpurun_out/sel/framebench.txt | cut -c1-400
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/sel/bench.json 2> gpurun_out/sel/bench.log
 python - <<'PY'
 import json
