@@ -926,9 +926,11 @@ private:
 };
 
 // every voxel filter of the device walks a voxel's members in the order libstdc++'s unstable std::sort leaves them, as the reference's filters do
-// (voxel_grid_covariance_mloam_impl.hpp:227) -- exact LiDAR ids in mixed voxels of fused clouds, at the price of a host pass per call. ON by default;
-// setVoxelMemberOrderAsReference(dev, false) walks members by point index on the device instead (faster, ids of mixed voxels may differ)
+// (voxel_grid_covariance_mloam_impl.hpp:227) -- exact LiDAR ids in mixed voxels of fused clouds. ON by default, produced on the device
+// (mode 1); mode 2 = the same through a host pass with the platform's own std::sort; false / mode 0 walks members by point index
+// instead (cheaper, ids of mixed voxels may differ)
 inline void setVoxelMemberOrderAsReference(Device &dev, bool on) { dev.check(mlh_set_voxel_member_order(dev.ctx(), on ? 1 : 0)); }
+inline void setVoxelMemberOrderMode(Device &dev, int mode) { dev.check(mlh_set_voxel_member_order(dev.ctx(), mode)); }
 
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")
 struct Scan2MapReport {
