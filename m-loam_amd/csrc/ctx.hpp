@@ -338,7 +338,8 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
                                      int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
-int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds);
+int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob = nullptr, mlh::HostPublish *pub = nullptr,
+                     unsigned long long pub_seq = 0);
 void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2]);
 int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsigned char *const *src, const int *n, int stride, const float *sq_dis,
                         mlh::HostPublish *pub, unsigned long long seq);

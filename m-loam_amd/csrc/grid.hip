@@ -93,7 +93,11 @@ struct GridJob {
     int need_zero;         // the array being built was not cleared by the previous build
     int sums_scanned;      // block_sums already hold exclusive prefixes (large grids: scan_sums_kernel ran)
 };
-struct GridJobs { GridJob j[2]; };
+struct GridJobs {
+    GridJob j[2];
+    // optional: the staging pass's fit flags leave for the host in the first launch of the build (one thread), instead of a launch of their own
+    int *pub_oob; HostPublish *pub; unsigned long long pub_seq;
+};
 
 __device__ __forceinline__ int cell_of(const GridJob &J, const float4 &p)
 {
@@ -134,6 +138,11 @@ __global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
     const int lane = threadIdx.x & 63;
+    if (G.pub && blockIdx.x == 0 && threadIdx.x == 0) {                   // the packed clouds' fit flags: final before this launch started
+        G.pub->done = *G.pub_oob;
+        *G.pub_oob = 0;
+        __hip_atomic_store(&G.pub->seq, G.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int base = b * 256; base < J.n; base += J.nb_pts * 256) {       // uniform over the workgroup
         const int i = base + threadIdx.x;
         const bool valid = i < J.n;
@@ -355,11 +364,12 @@ static GridJob make_job(MapGrid &g)
 }
 
 // (re)builds the index of up to two point sets in one set of launches
-int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds)
+int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob, HostPublish *pub, unsigned long long pub_seq)
 {
     hipStream_t st = ctx->stream;
     GridJobs G;
     std::memset(&G, 0, sizeof(G));
+    G.pub_oob = pub_oob; G.pub = pub; G.pub_seq = pub_seq;
     int nj = 0;
     for (int k = 0; k < n_grids && k < 2; ++k)
         if (grids[k]->n <= 0 || !grids[k]->raw.p) return fail(ctx, MLH_ERR_STATE, "no points staged for this index");
@@ -456,8 +466,10 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
     hipLaunchKernelGGL(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
     // the fit flags are final once the clouds are packed: they leave for the host NOW, and the optimistic index build of the kinds whose
     // geometry is reused is enqueued behind them -- the host learns the outcome (and can go on enqueueing the frame's solver launches)
-    // while the GPU is still building the index, instead of the GPU idling through the host's reaction time after the build
-    hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
+    // while the GPU is still building the index, instead of the GPU idling through the host's reaction time after the build. When such a
+    // build follows, its first launch carries the publication (one thread of its first workgroup); otherwise a launch of its own does.
+    const bool build_follows = need_bounds != ((1 << n_maps) - 1);
+    if (!build_follows) hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
     MLH_HIP(ctx, hipGetLastError());
     if (!ctx->h_occ) {
         MLH_HIP(ctx, hipHostMalloc(&ctx->h_occ, sizeof(long long) * 4, hipHostMallocDefault));
@@ -469,7 +481,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
     for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k)) && h_occ[2 * kinds[k]] > 0) {
         grids[k]->occupied = int(h_occ[2 * kinds[k]]); grids[k]->pop_sq = h_occ[2 * kinds[k] + 1];
     }
-    if (need_bounds != ((1 << n_maps) - 1)) {
+    if (build_follows) {
         MapGrid *fast[2];
         int nf = 0;
         for (int k = 0; k < n_maps; ++k) if (!(need_bounds & (1 << k))) {
@@ -478,7 +490,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
             MLH_HIP(ctx, g.cell_id.ensure(sizeof(int) * size_t(g.n)));
             fast[nf++] = &g;
         }
-        int rc = grid_build_grids(ctx, fast, nf, false);
+        int rc = grid_build_grids(ctx, fast, nf, false, G.oob, pub, seq);
         if (rc) return rc;
     }
     // spin on the pinned record (pack + fit check have completed when the sequence number arrives; the builds may still be running)

@@ -44,7 +44,7 @@ constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
 constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
 constexpr int SS_BIG_WG = 1024;
 constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
-constexpr int SS_BIG_LEVELS = 8;
+constexpr int SS_BIG_LEVELS = 10;
 constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // sub-ranges longer than 16 that can coexist at one depth in LDS mode
 
@@ -260,6 +260,7 @@ struct LeafMem {
     int *fin;           // (first, last) pairs of ranges of 2..16: the final insertion pass
     int *q;             // queue records, 4 ints each
     int qcap;
+    int *scr;           // LDS, 128 ints per wavefront: the stop tables of a partition that fits one 64-wide tile
 };
 enum { LQ_TAIL = 0, LQ_HEAD = 1, LQ_REMAINING = 2, LQ_NFIN = 3 };
 
@@ -290,7 +291,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             for (int spins = 0; spins < (1 << 24); ++spins) {        // bounded: a waiting wavefront can only be released by progress elsewhere
                 if (ticket < M.qcap && wg_load(&M.q[4 * ticket + 3]) != 0) { got = true; break; }
                 if (wg_load(&sh[LQ_REMAINING]) == 0) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
             }
             if (!got) break;
             f = M.q[4 * ticket]; l = M.q[4 * ticket + 1]; d = M.q[4 * ticket + 2];
@@ -302,24 +303,62 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             have = false;
             continue;
         }
-        if (lane == 0) median_to_first(M.keys, M.vals, f, l);
-        wg_fence();
-        const int piv = M.keys[f];
-        int nL, nR;
-        wave_count_stops(M.keys, f, f, l, piv, nL, nR);
-        wave_write_tables(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
-        wg_fence();
-        const int npair = min(nL, nR);
-        int K = 0;
-        for (int base = 0; base < npair; base += 64) {
-            const int k = base + lane;
-            K += __popcll(__ballot(k < npair && M.lt[f + k] < M.rt[f + k]));
+        int cut;
+        if (size <= 64) {
+            // the whole range in one tile: element f + lane in lane's registers, median and pivot through lane shuffles, the two stop
+            // tables (64 entries each) in the wavefront's own scratch, the swaps as one shuffle -- same pairs, same cut
+            int *sl = M.scr + (t >> 6) * 128, *sr = sl + 64;
+            const bool in = lane < size;
+            int key = in ? M.keys[f + lane] : INT_MAX, val = in ? M.vals[f + lane] : 0;
+            const int ia = 1, ib = size / 2, ic = size - 1;
+            const int ka = __shfl(key, ia), kb = __shfl(key, ib), kc = __shfl(key, ic);
+            int med;
+            if (ka < kb) med = (kb < kc) ? ib : ((ka < kc) ? ic : ia);
+            else med = (ka < kc) ? ia : ((kb < kc) ? ic : ib);
+            const int k0 = __shfl(key, 0), v0 = __shfl(val, 0), km = __shfl(key, med), vm = __shfl(val, med);
+            if (lane == 0) { key = km; val = vm; } else if (lane == med) { key = k0; val = v0; }
+            const int piv = km;
+            const bool is_l = in && lane > 0 && !(key < piv);
+            const bool is_r = in && (lane == 0 || !(piv < key));
+            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+            const int nL = __popcll(ml), nR = __popcll(mr);
+            const int rank_l = __popcll(ml & lanes_below()), rank_r = __popcll((mr >> lane) >> 1);
+            if (is_l) sl[rank_l] = lane;
+            if (is_r) sr[rank_r] = lane;
+            wg_fence();
+            const int npair = min(nL, nR);
+            const int partner = (is_l && rank_l < npair) ? sr[rank_l] : -1;
+            const int K = __popcll(__ballot(lane < partner));          // true for a prefix of the left ranks
+            int src = lane;
+            if (is_l && rank_l < K) src = partner;
+            else if (is_r && rank_r < K) src = sl[rank_r];
+            const int nk = __shfl(key, src), nv = __shfl(val, src);
+            int c = INT_MAX;
+            if (K < nL) c = min(c, sl[K]);
+            if (K > 0) c = min(c, sr[K - 1]);
+            if (in) { M.keys[f + lane] = nk; M.vals[f + lane] = nv; }
+            cut = f + c;
+            wg_fence();
+        } else {
+            if (lane == 0) median_to_first(M.keys, M.vals, f, l);
+            wg_fence();
+            const int piv = M.keys[f];
+            int nL, nR;
+            wave_count_stops(M.keys, f, f, l, piv, nL, nR);
+            wave_write_tables(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
+            wg_fence();
+            const int npair = min(nL, nR);
+            int K = 0;
+            for (int base = 0; base < npair; base += 64) {
+                const int k = base + lane;
+                K += __popcll(__ballot(k < npair && M.lt[f + k] < M.rt[f + k]));
+            }
+            for (int k = lane; k < K; k += 64) swap_elem(M.keys, M.vals, M.lt[f + k], M.rt[f + k]);
+            cut = INT_MAX;
+            if (K < nL) cut = min(cut, M.lt[f + K]);
+            if (K > 0) cut = min(cut, M.rt[f + K - 1]);
+            wg_fence();
         }
-        for (int k = lane; k < K; k += 64) swap_elem(M.keys, M.vals, M.lt[f + k], M.rt[f + k]);
-        int cut = INT_MAX;
-        if (K < nL) cut = min(cut, M.lt[f + K]);
-        if (K > 0) cut = min(cut, M.rt[f + K - 1]);
-        wg_fence();
         // children: [cut, l) is the library's recursive call, [f, cut) its loop's next trip; both get d - 1
         const int size_a = cut - f, size_b = l - cut;
         const bool big_a = size_a > SS_THRESHOLD, big_b = size_b > SS_THRESHOLD;
@@ -357,6 +396,7 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
 {
     __shared__ int s_keys[SS_LEAF], s_vals[SS_LEAF], s_lt[SS_LEAF], s_rt[SS_LEAF], s_fin[SS_LEAF];
     __shared__ int s_q[4 * SS_LOCAL_LIST];
+    __shared__ int s_scr[(SS_LEAF_WG / 64) * 128];
     __shared__ int sh[4];
     const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[SS_BIG_LEVELS];
     const SortSeg *over = A.seg[SS_BIG_LEVELS & 1];
@@ -365,6 +405,7 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
         const SortSeg s = si < n_leaf ? A.leaf[si] : over[si - n_leaf];
         const int f = s.first, m = s.last - s.first;
         LeafMem M;
+        M.scr = s_scr;
         if (m <= SS_LEAF) {
             for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
             M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
