@@ -44,7 +44,7 @@ constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
 constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
 constexpr int SS_BIG_WG = 1024;
 constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
-constexpr int SS_BIG_LEVELS = 10;
+constexpr int SS_BIG_LEVELS = 12;
 constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // sub-ranges longer than 16 that can coexist at one depth in LDS mode
 
@@ -291,7 +291,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             for (int spins = 0; spins < (1 << 24); ++spins) {        // bounded: a waiting wavefront can only be released by progress elsewhere
                 if (ticket < M.qcap && wg_load(&M.q[4 * ticket + 3]) != 0) { got = true; break; }
                 if (wg_load(&sh[LQ_REMAINING]) == 0) break;
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(32);
             }
             if (!got) break;
             f = M.q[4 * ticket]; l = M.q[4 * ticket + 1]; d = M.q[4 * ticket + 2];
