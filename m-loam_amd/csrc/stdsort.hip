@@ -44,6 +44,7 @@ constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
 constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
 constexpr int SS_BIG_WG = 1024;
 constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
+constexpr int SS_BIG_U = 4;           // 64-wide tiles a wavefront of a big level keeps in flight
 constexpr int SS_BIG_LEVELS = 12;
 constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // sub-ranges longer than 16 that can coexist at one depth in LDS mode
@@ -147,9 +148,9 @@ __device__ void heap_sort_range(int *k, int *v, int len)
     }
 }
 
-// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, four tiles per trip with the loads issued first.
+// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first.
 // count pass: the number of left / right stops in [lo, hi).
-constexpr int SS_U = 4;
+template <int SS_U>
 __device__ inline void wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right)
 {
     const int lane = threadIdx.x & 63;
@@ -171,6 +172,7 @@ __device__ inline void wave_count_stops(const int *keys, int f, int lo, int hi, 
 
 // table pass: left stops get ranks rank_l0, rank_l0 + 1, ... in ascending position; right stops ranks counted from the right:
 // a stop at p has rank (right stops of the whole range at positions > p) = after_r + (stops of [lo, hi) at positions > p)
+template <int SS_U>
 __device__ inline void wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here)
 {
     const int lane = threadIdx.x & 63;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
         const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
         const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
         int cl, cr;
-        wave_count_stops(A.keys, f, lo, hi, piv, cl, cr);
+        wave_count_stops<SS_BIG_U>(A.keys, f, lo, hi, piv, cl, cr);
         if ((t & 63) == 0) { w_left[wave] = cl; w_right[wave] = cr; }
         __syncthreads();
         int nL = 0, nR = 0, before_l = 0, after_r = 0;
@@ -228,17 +230,26 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
             if (w < wave) before_l += a;
             if (w > wave) after_r += b;
         }
-        wave_write_tables(A.keys, A.lt, A.rt, f, lo, hi, piv, before_l, after_r, cr);
+        wave_write_tables<SS_BIG_U>(A.keys, A.lt, A.rt, f, lo, hi, piv, before_l, after_r, cr);
         __syncthreads();
         const int npair = min(nL, nR);
         int mine = 0;
+#pragma unroll 4
         for (int k = t; k < npair; k += SS_BIG_WG) mine += (A.lt[f + k] < A.rt[f + k]) ? 1 : 0;      // true for a prefix of k
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if ((t & 63) == 0 && mine) atomicAdd(&sh_k, mine);
         __syncthreads();
         const int K = sh_k;
-        for (int k = t; k < K; k += SS_BIG_WG) swap_elem(A.keys, A.vals, A.lt[f + k], A.rt[f + k]);
+        for (int k0 = t; k0 < K; k0 += 4 * SS_BIG_WG) {              // four swaps in flight: positions, then the eight elements, then the stores
+            int p[4], q[4], kp[4], kq[4], vp[4], vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? A.lt[f + k] : -1; q[u] = on ? A.rt[f + k] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (p[u] >= 0) { kp[u] = A.keys[p[u]]; kq[u] = A.keys[q[u]]; vp[u] = A.vals[p[u]]; vq[u] = A.vals[q[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (p[u] >= 0) { A.keys[p[u]] = kq[u]; A.keys[q[u]] = kp[u]; A.vals[p[u]] = vq[u]; A.vals[q[u]] = vp[u]; }
+        }
         if (t == 0) {
             int cut = INT_MAX;
             if (K < nL) cut = min(cut, A.lt[f + K]);
@@ -344,8 +355,8 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             wg_fence();
             const int piv = M.keys[f];
             int nL, nR;
-            wave_count_stops(M.keys, f, f, l, piv, nL, nR);
-            wave_write_tables(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
+            wave_count_stops<4>(M.keys, f, f, l, piv, nL, nR);
+            wave_write_tables<4>(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
             wg_fence();
             const int npair = min(nL, nR);
             int K = 0;
