@@ -47,7 +47,7 @@ constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
 constexpr int SS_BIG_U = 4;           // 64-wide tiles a wavefront of a big level keeps in flight
 constexpr int SS_BIG_LEVELS = 12;
 constexpr int SS_LEAF_WG = 1024;
-constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // sub-ranges longer than 16 that can coexist at one depth in LDS mode
+constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the root + one per partition with two children > 16
 
 struct SortSeg { int first, last, depth, pad; };
 
@@ -55,7 +55,7 @@ struct StdSortArgs {
     int *keys;          // n: sorted in place (the comparator sees these only)
     int *vals;          // n: carried along
     int *lt, *rt;       // n each: the L / R position tables of a range live at [first, ...) of these
-    int *gfin, *glist;  // n each: fin ranges / sub-range lists of a range finished on GLOBAL memory (oversize leaves only)
+    int *gfin, *glist;  // n each: final-range list / queue records of a range finished on GLOBAL memory (oversize leaves only)
     SortSeg *seg[2];    // ranges longer than SS_LEAF of the current / the next big level
     SortSeg *leaf;      // ranges of 2 .. SS_LEAF elements
     int *cnt;           // [0 .. SS_BIG_LEVELS]: ranges per big level; [SS_CNT_LEAF]: leaves

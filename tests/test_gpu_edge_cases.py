@@ -372,3 +372,29 @@ def test_map_info_and_lane_choice(mla, case16, feats16):
             assert info["knn_lanes"] == expect
     finally:
         c.close()
+
+
+def test_std_sort_permutation_edges(mla, orc):
+    """mlh_std_sort_permutation: empty first / second cloud, a single element, ranges right at the 16-element insertion threshold and at
+    the 64- and 2048-element boundaries the device path switches strategy on; invalid arguments are refused, not guessed at."""
+    rng = np.random.default_rng(3)
+    c = mla.Context(0)
+    try:
+        for n in (1, 2, 16, 17, 63, 64, 65, 2047, 2048, 2049, 4097):
+            keys = rng.integers(0, max(2, n // 3), n).astype(np.int32)
+            want = orc.std_sort_permutation(keys)
+            for n0 in (0, n):
+                for mode in (1, 2):
+                    np.testing.assert_array_equal(c.std_sort_permutation(keys, n0=n0, mode=mode), want)
+            h = n // 2
+            both = np.concatenate([orc.std_sort_permutation(keys[:h]), h + orc.std_sort_permutation(keys[h:])])
+            np.testing.assert_array_equal(c.std_sort_permutation(keys, n0=h, mode=1), both)
+        with pytest.raises(mla.MlhError):
+            c.std_sort_permutation(np.zeros(4, np.int32), n0=5)
+        with pytest.raises(mla.MlhError):
+            c.std_sort_permutation(np.zeros(4, np.int32), mode=3)
+        with pytest.raises(mla.MlhError):
+            c.set_voxel_member_order(3)
+    finally:
+        c.close()
+

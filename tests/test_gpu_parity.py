@@ -679,7 +679,6 @@ def test_device_std_sort_equals_std_sort(mla, orc):
                 i = np.arange(n)
                 cases += [rng.integers(0, nv, n), i % nv, (n - i) // (n // nv + 1), np.where(i < n // 2, i, n - i) % nv, (n - i) % nv]
         cases.append(rng.integers(0, 50000, 200000))
-        heap = 0
         for keys in cases:
             keys = keys.astype(np.int32)
             want = orc.std_sort_permutation(keys)
