@@ -284,6 +284,8 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
     if (ctx->select_host) (void)hipHostFree(ctx->select_host);
     if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
+    if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1312,16 +1314,25 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
     if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
     if (ctx->fused_dirty) {
         MLH_HIP(ctx, hipSetDevice(ctx->device));
-        const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
-        std::vector<float> hp(part_floats * size_t(ctx->fused_parts));
-        MLH_HIP(ctx, hipMemcpyAsync(ctx->fused_n, ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        MLH_HIP(ctx, hipMemcpyAsync(hp.data(), ctx->fused_part.p, sizeof(float) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
+        const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6, n_floats = part_floats * size_t(ctx->fused_parts);
+        const size_t need = 16 + sizeof(float) * n_floats;          // pinned: a pageable landing buffer costs a staging hop per copy
+        if (need > ctx->fused_host_cap) {
+            if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
+            ctx->fused_host = nullptr; ctx->fused_host_cap = 0;
+            MLH_HIP(ctx, hipHostMalloc(&ctx->fused_host, need * 2, hipHostMallocDefault));
+            ctx->fused_host_cap = need * 2;
+        }
+        int *h_cnt = static_cast<int *>(ctx->fused_host);
+        const float *hp_data = reinterpret_cast<const float *>(static_cast<char *>(ctx->fused_host) + 16);
+        MLH_HIP(ctx, hipMemcpyAsync(h_cnt, ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(static_cast<char *>(ctx->fused_host) + 16, ctx->fused_part.p, sizeof(float) * n_floats, hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fused_n[0] = h_cnt[0]; ctx->fused_n[1] = h_cnt[1];
         for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
         for (int a = 0; a < ctx->fused_parts; ++a)
             for (int k = 0; k < 2; ++k)
                 for (int b = 0; b < FUSE_BLOCKS; ++b) {
-                    const float *q = hp.data() + (size_t(a) * 2 * FUSE_BLOCKS + size_t(k) * FUSE_BLOCKS + b) * 6;
+                    const float *q = hp_data + (size_t(a) * 2 * FUSE_BLOCKS + size_t(k) * FUSE_BLOCKS + b) * 6;
                     for (int d = 0; d < 3; ++d) { ctx->fused_minmax[k][d] = std::fmin(ctx->fused_minmax[k][d], q[d]); ctx->fused_minmax[k][3 + d] = std::fmax(ctx->fused_minmax[k][3 + d], q[3 + d]); }
                 }
         ctx->fused_dirty = false;

@@ -244,6 +244,9 @@ struct mlh_ctx {
     mlh::TrackSet track;
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
     int fused_n[2] = {0, 0};   // valid when !fused_dirty
+    void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
+    void *fused_host = nullptr; // pinned landing block of mlh_fused_cloud's one read-back: [2 counts (padded to 4 ints)][per-workgroup bounding boxes]
+    size_t fused_host_cap = 0;
     mlh::DevBuf fused_cnt;   // the two record counts, device side (appends never wait for the host)
     size_t fused_bound[2] = {0, 0};   // host-side upper bounds of the counts (capacity)
     bool fused_dirty = false;
@@ -312,6 +315,22 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
                         double *H, double *g, double *cost, int32_t *n_res);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
+// 64 pinned ints owned by the context (lazily allocated); nullptr on allocation failure
+inline int *pinned_ints(mlh_ctx *ctx)
+{
+    if (!ctx->h_scratch && hipHostMalloc(&ctx->h_scratch, 256, hipHostMallocDefault) != hipSuccess) ctx->h_scratch = nullptr;
+    return static_cast<int *>(ctx->h_scratch);
+}
+// *out <- one device int, through the pinned block (a pageable landing place costs a staging hop); waits for the stream
+inline hipError_t read_back_int(mlh_ctx *ctx, const void *dev, int *out)
+{
+    int *h = pinned_ints(ctx);
+    int *dst = h ? h + 8 : out;
+    hipError_t e = hipMemcpyAsync(dst, dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && h) *out = *dst;
+    return e;
+}
 // stdsort.hip: vals_out <- the permutation of 0..n-1 that std::sort (libstdc++, comparator on the key only) leaves for keys[0..n0) and keys[n0..n)
 int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out);
 void host_std_sort_permutation(const int *slot, int lo, int hi, int *members);   // voxelgrid.hip: the platform's own std::sort

@@ -462,8 +462,7 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
                        (const int *)V.vox_of.as<int>(), n, stride, dst);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    MLH_HIP(ctx, read_back_int(ctx, V.total.p, &total));
     *n_out = total;
     if (mem == MLH_MEM_HOST && total > 0) {
         MLH_HIP(ctx, hipMemcpyAsync(out, dst, size_t(total) * stride, hipMemcpyDeviceToHost, st));
@@ -538,8 +537,7 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
                        (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(), (const float *)d_c6, pts_out.as<float4>(), covd_out.as<float4>(), out11_dev);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.as<int>() + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    MLH_HIP(ctx, read_back_int(ctx, V.total.as<int>() + 1, &total));
     *n_out = total;
     return MLH_OK;
 }
@@ -611,8 +609,9 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
                        (const int *)(V.total.as<int>() + 1), (const float *)d_c6, f0.pts.as<float4>(), f0.covd.as<float4>(), f1.pts.as<float4>(), f1.covd.as<float4>(),
                        V.total.as<int>() + 2);
     MLH_HIP(ctx, hipGetLastError());
-    int counts[2] = {0, 0};
-    MLH_HIP(ctx, hipMemcpyAsync(counts, V.total.as<int>() + 2, sizeof(counts), hipMemcpyDeviceToHost, st));
+    int stack_counts[2] = {0, 0};
+    int *counts = pinned_ints(ctx) ? pinned_ints(ctx) : stack_counts;          // pinned: no staging hop for an 8-byte read-back
+    MLH_HIP(ctx, hipMemcpyAsync(counts, V.total.as<int>() + 2, sizeof(stack_counts), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
     *n_surf_out = counts[0];
     *n_corner_out = counts[1];

@@ -498,8 +498,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     MLH_HIP(ctx, hipGetLastError());
     if (!sync_total) { *n_out = -1; return MLH_OK; }
     int total = 0;
-    MLH_HIP(ctx, hipMemcpyAsync(&total, V.total.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    MLH_HIP(ctx, read_back_int(ctx, V.total.p, &total));
     *n_out = total;
     if (total > 0 && out_host) {
         MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));

@@ -41,6 +41,7 @@ static PointICovCloud cov_cloud(const std::vector<float> &a, int cols)
 
 int main(int argc, char **argv)
 {
+    std::setvbuf(stdout, nullptr, _IONBF, 0);   // a crash must not take the progress lines with it
     if (argc < 2) { std::fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 2; }
     const std::string d = std::string(argv[1]) + "/";
     try {
