@@ -101,6 +101,9 @@ struct Params {
     double COV_MEASUREMENT[9] = {0.0025, 0, 0, 0, 0.0025, 0, 0, 0, 0.0025};   // config uct_measurement
     double TRACE_THRESHOLD_MAPPING = 0.6;
     int N_SCANS = 16;
+    // the odometry window (parameters.h:58-111)
+    int OPT_WINDOW_SIZE = 4, NUM_OF_LASER = 2, ESTIMATE_EXTRINSIC = 1, N_CUMU_FEATURE = 10;
+    double LAMBDA_THRE_CALIB = 70.0;
 };
 inline Params &params() { static Params p; return p; }
 
@@ -897,6 +900,53 @@ inline void evalWindowNormalEquations(Device &dev, const double pivot[7], const 
     dev.check(mlh_pure_odom_normal_eq(dev.ctx(), pivot, frames.empty() ? nullptr : frames[0].data(), (int)frames.size(), exts.empty() ? nullptr : exts[0].data(),
                                       (int)exts.size(), huber_delta, ne.JtJ.data(), ne.Jtr.data(), &ne.cost, &n));
     ne.n_residuals = n;
+}
+
+// Estimator::evalDegenracy (estimator.cpp:1598-1680) on the window's normal equations, in the reference's argument order minus the Jacobian
+// (J^T J comes from evalWindowNormalEquations instead of a ceres::CRSMatrix): local_param_ids = the OPT_WINDOW_SIZE + 1 pose blocks, then one per
+// LiDAR extrinsic. Pose blocks: the mapper's rule per diagonal block with that block's threshold eig_thre[i]; a degenerate block gets
+// is_degenerate_ and its projector V_update_. Extrinsic blocks (ESTIMATE_EXTRINSIC != 0): on calibration frames (frame_cnt % N_CUMU_FEATURE == 0)
+// lambda = lambda_min / N_CUMU_FEATURE -- >= LAMBDA_THRE_CALIB: the threshold is set to it and d_factor_calib records lambda; above the running
+// threshold: the threshold rises to lambda; otherwise, and on every other frame, the extrinsic is frozen (is_degenerate_, V_update_ = 0).
+// Host code over mlh_eval_degeneracy; st carries what the Estimator keeps between calls (eig_thre_, d_factor_calib_, log_lambda_).
+struct WindowDegeneracyState {
+    std::vector<double> eig_thre;         // eig_thre_: one per block of local_param_ids
+    std::vector<double> d_factor_calib;   // d_factor_calib_: one per LiDAR
+    std::vector<double> log_lambda;       // log_lambda_
+};
+inline void evalDegenracy(std::vector<PoseLocalParameterization *> &local_param_ids, const WindowNormalEquations &ne, int frame_cnt, WindowDegeneracyState &st)
+{
+    const Params &P = params();
+    if (ne.n_residuals == 0) return;
+    const int D = ne.D, n_pose = P.OPT_WINDOW_SIZE + 1;
+    if (D != 6 * (int)local_param_ids.size() || (int)st.eig_thre.size() != (int)local_param_ids.size()) throw Error("evalDegenracy: block count mismatch");
+    auto block = [&](size_t i) {
+        std::array<double, 36> H;
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[size_t(r * 6 + c)] = ne.JtJ[size_t(6 * i + r) * D + 6 * i + c];
+        return H;
+    };
+    for (size_t i = 0; i < size_t(n_pose) && i < local_param_ids.size(); ++i) {
+        double ev[6], V[36];
+        if (mlh_eval_degeneracy(block(i).data(), st.eig_thre[i], ev, V) > 0) {
+            local_param_ids[i]->is_degenerate_ = true;
+            std::memcpy(local_param_ids[i]->V_update_.data(), V, sizeof(V));
+        }
+    }
+    if (P.ESTIMATE_EXTRINSIC != 0) {
+        st.d_factor_calib.assign(size_t(P.NUM_OF_LASER), 0.0);
+        for (size_t i = size_t(n_pose); i < local_param_ids.size(); ++i) {
+            bool freeze = true;
+            if (frame_cnt % P.N_CUMU_FEATURE == 0) {
+                double ev[6], V[36];
+                (void)mlh_eval_degeneracy(block(i).data(), 0.0, ev, V);
+                const double lambda = ev[0] / P.N_CUMU_FEATURE;
+                st.log_lambda.push_back(lambda);
+                if (lambda >= P.LAMBDA_THRE_CALIB) { st.eig_thre[i] = P.LAMBDA_THRE_CALIB; st.d_factor_calib[i - size_t(n_pose)] = lambda; freeze = false; }
+                else if (lambda > st.eig_thre[i]) { st.eig_thre[i] = lambda; freeze = false; }
+            }
+            if (freeze) { local_param_ids[i]->is_degenerate_ = true; local_param_ids[i]->V_update_.fill(0.0); }
+        }
+    }
 }
 
 // The factor table of Estimator::optimizeMap built ON THE DEVICE (estimator.cpp:700-780): in place of

@@ -164,6 +164,14 @@ int orc_eval_degeneracy(const double *H36, double eig_thre, double *eigval6, dou
     return 0;
 }
 
+int orc_window_eval_degeneracy(const double *JtJ, int D, int n_pose_blocks, double *eig_thre, int estimate_extrinsic, long frame_cnt, int n_cumu_feature,
+                               double lambda_thre_calib, int *is_degenerate, double *V_update, double *eigval, double *d_factor_calib)
+{
+    window_eval_degeneracy(JtJ, D, n_pose_blocks, eig_thre, estimate_extrinsic != 0, frame_cnt, n_cumu_feature, lambda_thre_calib, is_degenerate, V_update, eigval,
+                           d_factor_calib);
+    return 0;
+}
+
 static FeatureCloud make_fc(const float *feats, int stride, int n, int cov_off)
 {
     FeatureCloud fc;

@@ -78,6 +78,47 @@ void eval_degeneracy(const double H[36], double eig_thre, Degeneracy &out)
     }
 }
 
+void window_eval_degeneracy(const double *JtJ, int D, int n_pose_blocks, double *eig_thre, bool estimate_extrinsic, long frame_cnt,
+                            int n_cumu_feature, double lambda_thre_calib, int *is_degenerate, double *V_update, double *eigval, double *d_factor_calib)
+{
+    const int n_blocks = D / 6;
+    auto block = [&](int i, double H[36]) {
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[r * 6 + c] = JtJ[size_t(6 * i + r) * D + 6 * i + c];
+    };
+    auto identity = [](double *V) { for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) V[r * 6 + c] = (r == c) ? 1.0 : 0.0; };
+    // poses (cpp:1610-1636): the mapper's rule per diagonal block, with the block's own threshold
+    for (int i = 0; i < n_pose_blocks && i < n_blocks; ++i) {
+        double H[36];
+        block(i, H);
+        Degeneracy d;
+        eval_degeneracy(H, eig_thre[i], d);
+        is_degenerate[i] = d.is_degenerate ? 1 : 0;
+        std::memcpy(V_update + 36 * i, d.V_update, sizeof(d.V_update));
+        std::memcpy(eigval + 6 * i, d.eigval, sizeof(d.eigval));
+    }
+    // extrinsics (cpp:1638-1678)
+    for (int i = n_pose_blocks; i < n_blocks; ++i) {
+        is_degenerate[i] = 0;
+        identity(V_update + 36 * i);
+        for (int k = 0; k < 6; ++k) eigval[6 * i + k] = 0.0;
+        d_factor_calib[i - n_pose_blocks] = 0.0;
+        if (!estimate_extrinsic) continue;
+        bool freeze = false;
+        if (frame_cnt % n_cumu_feature == 0) {          // "need to optimize the extrinsics"
+            double H[36], vec[36];
+            block(i, H);
+            jacobi_eig_sym_d(H, 6, eigval + 6 * i, vec);
+            const double lambda = eigval[6 * i] / n_cumu_feature;
+            if (lambda >= lambda_thre_calib) { eig_thre[i] = lambda_thre_calib; d_factor_calib[i - n_pose_blocks] = lambda; }
+            else if (lambda > eig_thre[i]) eig_thre[i] = lambda;
+            else freeze = true;                          // degenerate for calibration: the extrinsic is not updated
+        } else {
+            freeze = true;                               // not enough accumulated features
+        }
+        if (freeze) { is_degenerate[i] = 1; std::memset(V_update + 36 * i, 0, sizeof(double) * 36); }
+    }
+}
+
 void ceres_like_solve(const std::vector<ResidualBlock> &blocks, double x[7], const double V_update[36],
                       double huber_delta, int max_num_iterations, SolveSummary &sum)
 {

@@ -59,6 +59,13 @@ struct Degeneracy {
 };
 void eval_degeneracy(const double H[36], double eig_thre, Degeneracy &out);
 
+// Estimator::evalDegenracy on the odometry window's J^T J (estimator/src/estimator/estimator.cpp:1598-1680). Blocks 0 .. n_pose_blocks-1
+// are the window's pose blocks (OPT_WINDOW_SIZE + 1), the rest one per LiDAR extrinsic. eig_thre (one per block) is read and, for the
+// extrinsic blocks, UPDATED as the reference updates eig_thre_. Outputs per block: is_degenerate, V_update (row-major 6x6; identity when the
+// block is left untouched, the reference's setParameter() value), eigval (ascending); d_factor_calib per extrinsic block.
+void window_eval_degeneracy(const double *JtJ, int D, int n_pose_blocks, double *eig_thre, bool estimate_extrinsic, long frame_cnt,
+                            int n_cumu_feature, double lambda_thre_calib, int *is_degenerate, double *V_update, double *eigval, double *d_factor_calib);
+
 struct SolveSummary {
     int num_iterations = 0;           // index of the last iteration (Ceres counts iteration 0)
     int num_successful_steps = 0;

@@ -234,6 +234,21 @@ def ref_cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov,
     return out[:cnt.value].copy()
 
 
+def ref_estimator_eval_degeneracy(crs_rows, crs_cols, crs_values, n_cols, opt_window_size, num_of_laser, eig_thre, estimate_extrinsic=True, frame_cnt=0,
+                                  n_cumu_feature=10, lambda_thre_calib=70.0):
+    """Estimator::evalDegenracy compiled from the reference's own lines (estimator.cpp:1598-1680) on a CRS Jacobian."""
+    L = ref_lib()
+    rows = np.ascontiguousarray(crs_rows, np.int32); cols = np.ascontiguousarray(crs_cols, np.int32); vals = np.ascontiguousarray(crs_values, np.float64)
+    nb = n_cols // 6
+    thr = np.ascontiguousarray(eig_thre, np.float64).copy()
+    deg = np.zeros(nb, np.int32)
+    V = np.zeros((nb, 6, 6))
+    dfc = np.zeros(max(num_of_laser, 1))
+    L.ref_estimator_eval_degeneracy(_ptr(rows), _ptr(cols), _ptr(vals), len(rows) - 1, int(n_cols), int(opt_window_size), int(num_of_laser), int(bool(estimate_extrinsic)),
+                                    int(frame_cnt), int(n_cumu_feature), C.c_double(lambda_thre_calib), _ptr(thr), _ptr(deg), _ptr(V), _ptr(dfc))
+    return dict(is_degenerate=deg.astype(bool), V_update=V, eig_thre=thr, d_factor_calib=dfc[:num_of_laser])
+
+
 def ref_eval_degeneracy(H, eig_thre=100.0):
     """evalDegenracy (lidar_mapper_keyframe.cpp:1172-1204) from the reference's own lines, on a fresh PoseLocalParameterization"""
     L = ref_lib()
@@ -389,6 +404,22 @@ def linearize(kind: str, feats, cov_trace, pose7, valid, coeffs, huber_delta=0.1
     lib().orc_linearize(C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _ptr(ct), _ptr(pose), _ptr(valid), _ptr(coeffs),
                         C.c_double(huber_delta), _ptr(r), _ptr(J), _ptr(H), _ptr(g), C.byref(cost), C.byref(cnt))
     return dict(r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)
+
+
+def window_eval_degeneracy(JtJ, n_pose_blocks, eig_thre, estimate_extrinsic=True, frame_cnt=0, n_cumu_feature=10, lambda_thre_calib=70.0):
+    """Estimator::evalDegenracy (estimator.cpp:1598-1680) on the window's J^T J. Returns the per-block flags, V_update, eigenvalues, the UPDATED
+    thresholds and d_factor_calib."""
+    H = np.ascontiguousarray(JtJ, np.float64)
+    D = H.shape[0]
+    nb = D // 6
+    thr = np.ascontiguousarray(eig_thre, np.float64).copy()
+    deg = np.zeros(nb, np.int32)
+    V = np.zeros((nb, 6, 6))
+    ev = np.zeros((nb, 6))
+    dfc = np.zeros(max(nb - n_pose_blocks, 1))
+    lib().orc_window_eval_degeneracy(_ptr(H), D, int(n_pose_blocks), _ptr(thr), int(bool(estimate_extrinsic)), C.c_long(int(frame_cnt)), int(n_cumu_feature),
+                                     C.c_double(lambda_thre_calib), _ptr(deg), _ptr(V), _ptr(ev), _ptr(dfc))
+    return dict(is_degenerate=deg.astype(bool), V_update=V, eigval=ev, eig_thre=thr, d_factor_calib=dfc[:nb - n_pose_blocks])
 
 
 def eval_degeneracy(H, eig_thre=100.0):

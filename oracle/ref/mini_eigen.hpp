@@ -8,6 +8,7 @@
 #include <limits>
 #include <cstddef>
 #include <type_traits>
+#include <ostream>
 #include <vector>
 
 namespace Eigen {
@@ -153,6 +154,7 @@ template <typename T> struct Mat<T, Dynamic, Dynamic> : MatrixBase<Mat<T, Dynami
     T &operator()(int i, int j) { return d[size_t(i) * c + j]; }
     const T &operator()(int i, int j) const { return d[size_t(i) * c + j]; }
     Mat transpose() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); return m; }
+    Mat block(int r0, int c0, int nr, int nc) const { Mat m(nr, nc); for (int i = 0; i < nr; ++i) for (int j = 0; j < nc; ++j) m(i, j) = (*this)(r0 + i, c0 + j); return m; }
     Mat operator*(const Mat &o) const
     {
         Mat m(r, o.c);
@@ -161,6 +163,20 @@ template <typename T> struct Mat<T, Dynamic, Dynamic> : MatrixBase<Mat<T, Dynami
     }
 };
 typedef Mat<double, Dynamic, Dynamic> MatrixXd;
+// Eigen::SparseMatrix<T, RowMajor> as Estimator::evalDegenracy uses it (resize, coeffRef, transpose, product into a dense matrix): a dense
+// matrix underneath. J^T J sums over the rows in ascending order either way; the zeros a dense product adds change no sum.
+template <typename T, int Options = 0> struct SparseMatrix {
+    Mat<T, Dynamic, Dynamic> m;
+    void resize(int r, int c) { m = Mat<T, Dynamic, Dynamic>(r, c); }
+    T &coeffRef(int i, int j) { return m(i, j); }
+    SparseMatrix transpose() const { SparseMatrix t; t.m = m.transpose(); return t; }
+    Mat<T, Dynamic, Dynamic> operator*(const SparseMatrix &o) const { return m * o.m; }
+};
+template <typename T, int R, int C> std::ostream &operator<<(std::ostream &o, const Mat<T, R, C> &m)
+{
+    for (int i = 0; i < m.rows(); ++i) { for (int j = 0; j < m.cols(); ++j) o << (j ? " " : "") << m(i, j); if (i + 1 < m.rows()) o << "\n"; }
+    return o;
+}
 template <typename T, int R, int C> Mat<T, R, C> operator+(const Mat<T, R, C> &a, const Mat<T, Dynamic, Dynamic> &b)
 {
     Mat<T, R, C> m;
@@ -219,7 +235,9 @@ struct VectorXd {                                                  // the edge f
     double &operator()(int i) { return v[size_t(i)]; }
     const double &operator()(int i) const { return v[size_t(i)]; }
     int size() const { return int(v.size()); }
+    const VectorXd &transpose() const { return *this; }          // only ever printed
 };
+inline std::ostream &operator<<(std::ostream &o, const VectorXd &x) { for (size_t i = 0; i < x.v.size(); ++i) o << (i ? " " : "") << x.v[i]; return o; }
 
 template <typename T> struct Quaternion {
     typedef T Scalar;

@@ -281,6 +281,35 @@ std::vector<Pose> pose_ext;
 pcl::VoxelGridCovarianceMLOAM<PointI> down_size_filter_surf, down_size_filter_corner, down_size_filter_outlier;      // lidar_mapper_keyframe.cpp:79-81
 #include "../_ref/gen/downsample_current_scan.inc"
 
+// ---------------------------------------------------------------- Estimator::evalDegenracy (estimator.cpp:1598-1680) from the reference's own lines
+// The odometry window's degeneracy / calibration policy on J^T J: the window's pose blocks by the mapper's rule with per-block thresholds, the
+// extrinsic blocks by lambda_min / N_CUMU_FEATURE against LAMBDA_THRE_CALIB and the running eig_thre_. Ceres hands it the Jacobian as a
+// CRSMatrix; the struct below has ceres/crs_matrix.h's fields.
+namespace ceres {
+struct CRSMatrix {
+    int num_rows = 0, num_cols = 0;
+    std::vector<int> cols, rows;
+    std::vector<double> values;
+};
+}  // namespace ceres
+#include "../_ref/gen/crs_to_sparse.inc"                      // CRSMatrix2EigenMatrix(crs, Eigen::SparseMatrix<T, RowMajor> &)   utility.h:152-166
+int ESTIMATE_EXTRINSIC = 1, OPT_WINDOW_SIZE = 4, N_CUMU_FEATURE = 10;      // parameters.cpp
+double LAMBDA_THRE_CALIB = 70.0;
+class Estimator {                                             // the members evalDegenracy touches (estimator.h:158-210)
+public:
+    void evalDegenracy(std::vector<PoseLocalParameterization *> &local_param_ids, const ceres::CRSMatrix &jaco);
+    std::vector<Eigen::Quaterniond> qbl_;
+    std::vector<Eigen::Vector3d> tbl_;
+    int frame_cnt_{};
+    Eigen::VectorXd eig_thre_;
+    std::vector<double> log_lambda_;
+    std::vector<Pose> log_extrinsics_;
+    std::vector<double> d_factor_calib_;
+};
+#define printf(...) ((void)0)                                 // "%lu: calib eig is %f" stays out of the test logs; std::cout is pointed at a null buffer by the caller
+#include "../_ref/gen/estimator_eval_degeneracy.inc"
+#undef printf
+
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
 // clouds out: sharp, less_sharp, flat, less_flat (voxel-thinned), each n x 4 floats; counts in n_out[4]
@@ -624,6 +653,42 @@ int ref_eval_degeneracy(const double H36[36], double eig_thre, int *is_deg, doub
     *is_deg = plp.is_degenerate_ ? 1 : 0;
     for (int i = 0; i < 36; ++i) V36[i] = plp.V_update_.d[i];
     for (int i = 0; i < 6; ++i) eig[i] = d_factor_list.back().d[i];
+    return 0;
+}
+
+// Estimator::evalDegenracy: J as CRS (rows n_rows + 1, cols / values nnz), D = 6 * n_blocks columns; eig_thre (n_blocks) in and out; per block out:
+// is_degenerate, V_update (36, row-major); d_factor_calib (NUM_OF_LASER)
+int ref_estimator_eval_degeneracy(const int *crs_rows, const int *crs_cols, const double *crs_values, int n_rows, int n_cols, int opt_window_size, int num_of_laser,
+                                  int estimate_extrinsic, int frame_cnt, int n_cumu_feature, double lambda_thre_calib, double *eig_thre, int *is_degenerate,
+                                  double *V_update, double *d_factor_calib)
+{
+    OPT_WINDOW_SIZE = opt_window_size; NUM_OF_LASER = size_t(num_of_laser); ESTIMATE_EXTRINSIC = estimate_extrinsic; N_CUMU_FEATURE = n_cumu_feature;
+    LAMBDA_THRE_CALIB = lambda_thre_calib;
+    const int n_blocks = n_cols / 6;
+    ceres::CRSMatrix jaco;
+    jaco.num_rows = n_rows; jaco.num_cols = n_cols;
+    jaco.rows.assign(crs_rows, crs_rows + n_rows + 1);
+    jaco.cols.assign(crs_cols, crs_cols + crs_rows[n_rows]);
+    jaco.values.assign(crs_values, crs_values + crs_rows[n_rows]);
+    Estimator est;
+    est.frame_cnt_ = frame_cnt;
+    est.eig_thre_ = Eigen::VectorXd(n_blocks);
+    for (int i = 0; i < n_blocks; ++i) est.eig_thre_(i) = eig_thre[i];
+    est.qbl_.assign(size_t(num_of_laser), Eigen::Quaterniond());
+    est.tbl_.assign(size_t(num_of_laser), Eigen::Vector3d());
+    std::vector<PoseLocalParameterization> store(static_cast<size_t>(n_blocks));
+    std::vector<PoseLocalParameterization *> ids;
+    for (auto &p : store) { p.setParameter(); ids.push_back(&p); }     // as optimizeMap creates them (estimator.cpp:628-650)
+    std::ostringstream sink;
+    std::streambuf *keep = std::cout.rdbuf(sink.rdbuf());
+    est.evalDegenracy(ids, jaco);
+    std::cout.rdbuf(keep);
+    for (int i = 0; i < n_blocks; ++i) {
+        eig_thre[i] = est.eig_thre_(i);
+        is_degenerate[i] = store[size_t(i)].is_degenerate_ ? 1 : 0;
+        for (int k = 0; k < 36; ++k) V_update[36 * i + k] = store[size_t(i)].V_update_.d[k];
+    }
+    for (int i = 0; i < num_of_laser; ++i) d_factor_calib[i] = i < int(est.d_factor_calib_.size()) ? est.d_factor_calib_[size_t(i)] : 0.0;
     return 0;
 }
 

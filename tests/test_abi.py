@@ -95,3 +95,46 @@ def test_std_sort_mt_equals_std_sort(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert " 0 mismatches" in out, out
 
+
+def test_facade_window_degeneracy_policy(tmp_path, orc):
+    """The facade's evalDegenracy(local_param_ids, window normal equations, frame_cnt, state) = Estimator::evalDegenracy (estimator.cpp:1598-1680):
+    host code over mlh_eval_degeneracy, so it runs without a GPU. Held against the CPU restatement (which tests/test_oracle_ref_pin.py holds
+    against the reference's own lines): flags, projectors, the updated thresholds and d_factor_calib, on calibration and non-calibration frames."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "window_degeneracy_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "window_degeneracy_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(5)
+    W, L_ = 3, 3
+    n_pose, D = W + 1, 6 * (W + 1 + L_)
+    J = np.zeros((900, D))
+    scale = [3.0, 0.9, 0.05]
+    for r in range(900):
+        f, e = 1 + r % W, r % L_
+        for b, sc in ((0, 1.0), (f, 1.0), (n_pose + e, scale[e])):
+            j = rng.normal(0, 1, 6) * sc
+            if b == 2:
+                j[[1, 4]] *= 1e-3
+            J[r, 6 * b:6 * b + 6] = j
+    H = J.T @ J
+    thr = np.array([100.0] * n_pose + [0.0, 5.0, 5.0])
+    for frame_cnt, est_ext in ((20, 1), (23, 1), (20, 0)):
+        H.tofile(tmp_path / "JtJ.f64")
+        thr.tofile(tmp_path / "eig_thre.f64")
+        subprocess.run([exe, str(tmp_path), str(D), str(W), str(L_), str(est_ext), str(frame_cnt), "10", "70.0"], check=True)
+        out = np.fromfile(tmp_path / "out.f64")
+        nb = D // 6
+        rec = out[:nb * 38].reshape(nb, 38)
+        want = orc.window_eval_degeneracy(H, n_pose, thr, bool(est_ext), frame_cnt, 10, 70.0)
+        np.testing.assert_array_equal(rec[:, 0] != 0, want["is_degenerate"])
+        np.testing.assert_allclose(rec[:, 1], want["eig_thre"], rtol=1e-9)
+        np.testing.assert_allclose(rec[:, 2:].reshape(nb, 6, 6), want["V_update"], atol=1e-8)
+        if est_ext:
+            np.testing.assert_allclose(out[nb * 38:], want["d_factor_calib"], rtol=1e-9)
+        assert want["is_degenerate"][2]
+

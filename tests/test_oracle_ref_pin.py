@@ -465,3 +465,49 @@ def test_downsample_current_scan_is_the_references(ref, synth, feats16):
             np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=2e-6, atol=1e-12)
         if with_ua and thr == 0.05:
             assert len(rs) < len(ref.voxel_grid_mloam_plain(surf, 0.4, member_order=0))       # the gate cuts
+
+
+@pytest.mark.parametrize("frame_cnt,estimate_extrinsic", [(20, True), (23, True), (20, False)])
+def test_estimator_eval_degeneracy_is_the_references(ref, frame_cnt, estimate_extrinsic):
+    """Estimator::evalDegenracy (estimator.cpp:1598-1680) compiled from the reference's own lines against the restatement
+    (oracle/mapper.cpp: window_eval_degeneracy), on a Jacobian with the window problem's shape -- every row three 1 x 6 blocks: pivot, one frame,
+    one extrinsic. The pose blocks go through the mapper's rule with per-block thresholds (one frame is made degenerate in two directions);
+    the extrinsic blocks through all three calibration branches (lambda >= LAMBDA_THRE_CALIB; between the running threshold and it; below the
+    running threshold), the every-N-frames gate and the ESTIMATE_EXTRINSIC switch."""
+    rng = np.random.default_rng(17)
+    W, L_, n_rows = 3, 3, 900                       # OPT_WINDOW_SIZE = 3 -> 4 pose blocks; 3 LiDARs
+    n_pose = W + 1
+    D = 6 * (n_pose + L_)
+    rows, cols, vals = [0], [], []
+    ext_scale = [3.0, 0.9, 0.05]                     # lambda_min / N of the three extrinsic blocks: above 70, between, below the running threshold
+    for r in range(n_rows):
+        f, e = 1 + r % W, r % L_
+        for b, sc in ((0, 1.0), (f, 1.0), (n_pose + e, ext_scale[e])):
+            j = rng.normal(0, 1, 6) * sc
+            if b == 2:
+                j[[1, 4]] *= 1e-3                    # frame 2: two weak directions
+            cols += [6 * b + k for k in range(6)]
+            vals += list(j)
+        rows.append(len(cols))
+    J = np.zeros((n_rows, D))
+    for r in range(n_rows):
+        J[r, cols[rows[r]:rows[r + 1]]] = vals[rows[r]:rows[r + 1]]
+    thr = np.array([100.0] * n_pose + [0.0, 5.0, 5.0])
+    got = ref.ref_estimator_eval_degeneracy(rows, cols, vals, D, W, L_, thr, estimate_extrinsic, frame_cnt, 10, 70.0)
+    want = ref.window_eval_degeneracy(J.T @ J, n_pose, thr, estimate_extrinsic, frame_cnt, 10, 70.0)
+    np.testing.assert_array_equal(got["is_degenerate"], want["is_degenerate"])
+    np.testing.assert_allclose(got["eig_thre"], want["eig_thre"], rtol=1e-9)
+    np.testing.assert_allclose(got["d_factor_calib"], want["d_factor_calib"], rtol=1e-9)
+    np.testing.assert_allclose(got["V_update"], want["V_update"], rtol=0, atol=1e-8)
+    assert got["is_degenerate"][2] and not got["is_degenerate"][:2].any() and not got["is_degenerate"][3]
+    assert np.linalg.matrix_rank(got["V_update"][2], tol=1e-6) == 4                     # the two weak directions are projected out
+    if estimate_extrinsic and frame_cnt % 10 == 0:
+        assert list(got["is_degenerate"][n_pose:]) == [False, False, True]
+        assert got["eig_thre"][n_pose] == 70.0 and got["d_factor_calib"][0] > 70.0      # branch 1
+        assert 5.0 < got["eig_thre"][n_pose + 1] < 70.0 and got["d_factor_calib"][1] == 0.0   # branch 2: the running threshold rises
+        assert not got["V_update"][n_pose + 2].any()                                    # branch 3: frozen
+    elif estimate_extrinsic:
+        assert got["is_degenerate"][n_pose:].all() and not got["V_update"][n_pose:].any()      # not a calibration frame: every extrinsic frozen
+    else:
+        assert not got["is_degenerate"][n_pose:].any()
+
