@@ -234,6 +234,14 @@ def ref_cloud_uct_associate_to_map(pts11, pose_global, cov_global, ext, ext_cov,
     return out[:cnt.value].copy()
 
 
+def ref_eval_hessian(crs_rows, crs_cols, crs_values, n_cols=6):
+    """evalHessian compiled from the reference's own lines (lidar_mapper_keyframe.cpp:1160-1169)"""
+    rows = np.ascontiguousarray(crs_rows, np.int32); cols = np.ascontiguousarray(crs_cols, np.int32); vals = np.ascontiguousarray(crs_values, np.float64)
+    H = np.zeros((6, 6))
+    ref_lib().ref_eval_hessian(_ptr(rows), _ptr(cols), _ptr(vals), len(rows) - 1, int(n_cols), _ptr(H))
+    return H
+
+
 def ref_estimator_eval_degeneracy(crs_rows, crs_cols, crs_values, n_cols, opt_window_size, num_of_laser, eig_thre, estimate_extrinsic=True, frame_cnt=0,
                                   n_cumu_feature=10, lambda_thre_calib=70.0):
     """Estimator::evalDegenracy compiled from the reference's own lines (estimator.cpp:1598-1680) on a CRS Jacobian."""

@@ -68,6 +68,7 @@ CUTS = [
     ("afs_gfm.inc", "lidarMapper/lidar_mapper.h", 229, 573, "void goodFeatureMatching"),
     ("crs_to_sparse.inc", "utility/utility.h", 152, 166, "template <typename T>"),
     ("estimator_eval_degeneracy.inc", "estimator/estimator.cpp", 1598, 1680, "void Estimator::evalDegenracy"),
+    ("eval_hessian.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1160, 1169, "void evalHessian"),
     ("uct_compound.inc", "lidarMapper/associate_uct.hpp", 9, 86, "inline Eigen::Matrix<double, 6, 6> adjointMatrix"),
     ("uct_point_to_fs.inc", "lidarMapper/associate_uct.hpp", 150, 156, "inline Eigen::Matrix<double, 4, 6> pointToFS"),
     ("uct_eval_point_cov.inc", "lidarMapper/associate_uct.hpp", 164, 193, "template <typename PointType>"),

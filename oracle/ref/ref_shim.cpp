@@ -309,6 +309,7 @@ public:
 #define printf(...) ((void)0)                                 // "%lu: calib eig is %f" stays out of the test logs; std::cout is pointed at a null buffer by the caller
 #include "../_ref/gen/estimator_eval_degeneracy.inc"
 #undef printf
+#include "../_ref/gen/eval_hessian.inc"                         // evalHessian(jaco, mat_H)   lidar_mapper_keyframe.cpp:1160-1169
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
@@ -653,6 +654,20 @@ int ref_eval_degeneracy(const double H36[36], double eig_thre, int *is_deg, doub
     *is_deg = plp.is_degenerate_ ? 1 : 0;
     for (int i = 0; i < 36; ++i) V36[i] = plp.V_update_.d[i];
     for (int i = 0; i < 6; ++i) eig[i] = d_factor_list.back().d[i];
+    return 0;
+}
+
+// evalHessian: the mapper's J^T J from the CRS Jacobian problem.Evaluate returns (6 local columns)
+int ref_eval_hessian(const int *crs_rows, const int *crs_cols, const double *crs_values, int n_rows, int n_cols, double H36[36])
+{
+    ceres::CRSMatrix jaco;
+    jaco.num_rows = n_rows; jaco.num_cols = n_cols;
+    jaco.rows.assign(crs_rows, crs_rows + n_rows + 1);
+    jaco.cols.assign(crs_cols, crs_cols + crs_rows[n_rows]);
+    jaco.values.assign(crs_values, crs_values + crs_rows[n_rows]);
+    Eigen::Matrix<double, 6, 6> H;
+    evalHessian(jaco, H);
+    for (int i = 0; i < 36; ++i) H36[i] = H.d[i];
     return 0;
 }
 

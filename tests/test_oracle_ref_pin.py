@@ -511,3 +511,23 @@ def test_estimator_eval_degeneracy_is_the_references(ref, frame_cnt, estimate_ex
     else:
         assert not got["is_degenerate"][n_pose:].any()
 
+
+def test_eval_hessian_is_the_references(ref, case16, feats16):
+    """evalHessian (lidar_mapper_keyframe.cpp:1160-1169) compiled from the reference's own lines -- CRSMatrix2EigenMatrix, J^T J, the leading 6 x 6 -- on
+    the Jacobian rows of a real frame (loss switched off, so the rows are what problem.Evaluate would hand it): the restatement's normal-equation
+    accumulation, which the HIP reduction is held against, gives the same H."""
+    Js, Hsum = [], np.zeros((6, 6))
+    for kind, m, f in (("s", ref.Map(case16["surf_map"]), feats16[0]), ("c", ref.Map(case16["corner_map"]), feats16[1])):
+        valid, coeffs = m.match(kind, f, case16["p0"])[:2]
+        lin = ref.linearize(kind, f, None, case16["p0"], valid, coeffs, huber_delta=1e9)      # rows as they are: no loss correction to undo
+        Js.append(lin["J"][np.asarray(valid, bool)])
+        Hsum += lin["H"]
+    J = np.concatenate(Js)
+    assert len(J) > 3000
+    rows = np.arange(len(J) + 1) * 6
+    cols = np.tile(np.arange(6), len(J))
+    H = ref.ref_eval_hessian(rows, cols, J.ravel())
+    Hn = J.T @ J
+    sc = np.abs(Hn).max()
+    np.testing.assert_allclose(H, Hn, rtol=1e-11, atol=1e-11 * sc)
+    np.testing.assert_allclose(H, Hsum, rtol=1e-9, atol=1e-9 * sc)
