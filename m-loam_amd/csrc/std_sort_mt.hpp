@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -33,7 +34,10 @@ void introsort_forked(It first, It last, long depth_limit, int fork_levels)
             --fork_levels;
             const long d = depth_limit;
             const int f = fork_levels;
-            forks.emplace_back([cut, last, d, f] { introsort_forked(cut, last, d, f); });
+            bool forked = false;
+            try { forks.emplace_back([cut, last, d, f] { introsort_forked(cut, last, d, f); }); forked = true; }
+            catch (const std::system_error &) {}                  // no thread to be had: this one does the work, same result
+            if (!forked) std::__introsort_loop(cut, last, depth_limit, comp);
         } else {
             std::__introsort_loop(cut, last, depth_limit, comp);
         }
