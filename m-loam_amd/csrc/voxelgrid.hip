@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -361,11 +362,16 @@ static int members_in_std_sort_order(mlh_ctx *ctx, const VoxArgs &A)
     MLH_HIP(ctx, hipStreamSynchronize(st));
     // one filter call per cloud in the reference: one sort per cloud
     auto sort_range = [slot, members](int lo, int hi) { host_std_sort_permutation(slot, lo, hi, members); };
+    bool split = false;
     if (A.n0 > 4096 && A.n - A.n0 > 4096) {
-        std::thread second(sort_range, A.n0, A.n);
-        sort_range(0, A.n0);
-        second.join();
-    } else {
+        try {
+            std::thread second(sort_range, A.n0, A.n);
+            split = true;
+            sort_range(0, A.n0);
+            second.join();
+        } catch (const std::system_error &) {}                           // no thread to be had: one after the other
+    }
+    if (!split) {
         sort_range(0, A.n0);
         sort_range(A.n0, A.n);
     }
