@@ -126,8 +126,10 @@ int mlh_extract_run(mlh_ctx *ctx);
 int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4]);
 /* (a3) the per-ring pcl::VoxelGrid(leaf = 0.2 m) extractCloud applies to the less-flat points of every ring
  * (feature_extract.cpp:266-271): run after mlh_extract_run; fetch returns "surf_points_less_flat" as the reference emits it
- * (ring asc, voxel index asc; x y z intensity centroids). Within a voxel the members are summed in scan order (PCL sums them in
- * the order an unstable std::sort left them: equal up to f32 rounding of the sum). */
+ * (ring asc, voxel index asc; x y z intensity centroids). PCL sums a voxel's members in the order an unstable std::sort (comparator on
+ * the voxel index only) left them; with the context's default member order (mlh_set_voxel_member_order, below) the sums run along that same
+ * permutation -- one device std::sort per ring -- and the centroids are the reference's bit for bit; with mode 0 the members are summed in
+ * scan order (equal up to f32 rounding of the sum, ~0.1 ms per scan pair cheaper). */
 int mlh_extract_voxel_run(mlh_ctx *ctx, float leaf);
 int mlh_extract_fetch_voxel(mlh_ctx *ctx, float *xyzi_out, int32_t *n_out);
 
@@ -168,7 +170,8 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
  * inside a voxel they come in whatever order libstdc++'s introsort leaves. That order decides "the last member" of the plain branch --
  * for a fused multi-LiDAR cloud the LiDAR id downsampleCurrentScan propagates the uncertainty through (lidar_mapper_keyframe.cpp:377) --,
  * the first-heaviest member of the covariance branch on equal weights, and the association of every f32 sum. Every voxel filter of the
- * context (mlh_voxel_filter, mlh_voxel_grid, mlh_downsample_current_scan, ..._pair) follows mlh_set_voxel_member_order(ctx, mode):
+ * context (mlh_voxel_filter, mlh_voxel_grid, mlh_downsample_current_scan, ..._pair; and extractCloud's per-ring grid, mlh_extract_voxel_run, where
+ * modes 1 and 2 both mean the device path) follows mlh_set_voxel_member_order(ctx, mode):
  *   1 (default)  the reference's order, produced ON THE DEVICE: libstdc++'s std::sort (introsort: median-of-three pivot at the same
  *                positions, the same unguarded Hoare partition, the same depth budget and heap-sort fallback, the same final insertion
  *                pass) restated data-parallel -- one launch per recursion depth, a range's partition from rank tables -- so the

@@ -274,7 +274,7 @@ void mlh_destroy(mlh_ctx *ctx)
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
     s.ring_counts.release(); s.ring_offsets.release(); s.totals.release();
     for (int i = 0; i < 4; ++i) s.lists[i].release();
-    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release(); ctx->fused_part.release();
+    s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); s.vox_keys.release(); s.vox_perm.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release(); ctx->fused_part.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
     { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.word_of.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }

@@ -87,6 +87,22 @@ __global__ __launch_bounds__(256) void stdsort_init_kernel(StdSortArgs A, const 
     }
 }
 
+// the same for many ranges (one std::sort call per segment): segment s covers [offsets[s * stride + field], + counts[s * stride + field])
+// of the key array; vals <- the GLOBAL element index. Keys outside every segment are never looked at.
+__global__ __launch_bounds__(256) void stdsort_init_segments_kernel(StdSortArgs A, const int *src_keys, const int *counts, const int *offsets, int stride, int field,
+                                                                    int n_segments)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < A.n) { A.keys[i] = src_keys[i]; A.vals[i] = i; }
+    if (i == 0) {
+        for (int k = 0; k < SS_CNT; ++k) A.cnt[k] = 0;
+        for (int s = 0; s < n_segments; ++s) {
+            const int c = counts[s * stride + field], o = offsets[s * stride + field];
+            if (c > 1 && o >= 0 && o + c <= A.n) emit_global(A, o, o + c, 2 * floor_log2(c), A.seg[0], &A.cnt[0]);
+        }
+    }
+}
+
 __device__ inline void swap_elem(int *keys, int *vals, int p, int q)
 {
     const int kp = keys[p], kq = keys[q], vp = vals[p], vq = vals[q];
@@ -434,26 +450,27 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
 
 }  // namespace
 
-// Sorts (keys = src_keys[0..n), vals = 0..n-1) as two std::sort calls would -- [0, n0) and [n0, n) -- and leaves the permuted vals in
-// vals_out (device, n ints). Everything is enqueued on the context's stream; nothing is waited for.
-int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out)
+static int stdsort_setup(mlh_ctx *ctx, int n, int *vals_out, StdSortArgs &A, size_t &nbig, size_t &nleaf)
 {
-    if (n <= 0) return MLH_OK;
-    hipStream_t st = ctx->stream;
     DevBuf &S = ctx->stdsort;
-    const size_t ni = size_t(n), nbig = ni / SS_LEAF + 4, nleaf = ni / 2 + 4;
+    const size_t ni = size_t(n);
+    nbig = ni / SS_LEAF + 4; nleaf = ni / 2 + 4;
     // [keys n][lt n][rt n][gfin n][glist n][cnt (padded to 64)][seg0][seg1][leaf]
     const size_t off_lt = ni, off_rt = 2 * ni, off_gfin = 3 * ni, off_glist = 4 * ni, off_cnt = 5 * ni, off_seg0 = off_cnt + 64;
     const size_t seg_ints = nbig * 4, off_seg1 = off_seg0 + seg_ints, off_leaf = off_seg1 + seg_ints, total = off_leaf + nleaf * 4;
     MLH_HIP(ctx, S.ensure(sizeof(int) * total));
     int *base = S.as<int>();
-    StdSortArgs A;
     A.keys = base; A.vals = vals_out; A.lt = base + off_lt; A.rt = base + off_rt; A.gfin = base + off_gfin; A.glist = base + off_glist;
     A.cnt = base + off_cnt;
     A.seg[0] = reinterpret_cast<SortSeg *>(base + off_seg0); A.seg[1] = reinterpret_cast<SortSeg *>(base + off_seg1);
     A.leaf = reinterpret_cast<SortSeg *>(base + off_leaf); A.n = n;
-    hipLaunchKernelGGL(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A, src_keys, n0);
-    if (std::max(n0, n - n0) > SS_LEAF) {
+    return MLH_OK;
+}
+
+static int stdsort_levels(mlh_ctx *ctx, const StdSortArgs &A, int longest, size_t nbig, size_t nleaf)
+{
+    hipStream_t st = ctx->stream;
+    if (longest > SS_LEAF) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
         for (int level = 0; level < SS_BIG_LEVELS; ++level)
             hipLaunchKernelGGL(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
@@ -462,6 +479,34 @@ int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int
     hipLaunchKernelGGL(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
+}
+
+// Sorts (keys = src_keys[0..n), vals = 0..n-1) as two std::sort calls would -- [0, n0) and [n0, n) -- and leaves the permuted vals in
+// vals_out (device, n ints). Everything is enqueued on the context's stream; nothing is waited for.
+int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out)
+{
+    if (n <= 0) return MLH_OK;
+    StdSortArgs A;
+    size_t nbig, nleaf;
+    int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0);
+    return stdsort_levels(ctx, A, std::max(n0, n - n0), nbig, nleaf);
+}
+
+// One std::sort call per segment (device-side tables of counts and offsets, `stride` ints per segment, entry `field`): vals_out[i] <- the
+// global index of the element std::sort leaves at position i of its segment. longest = a host-side upper bound of a segment's length
+// (it only decides whether the big-level launches are needed).
+int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *counts, const int *offsets, int stride, int field, int n_segments, int n, int longest,
+                             int *vals_out)
+{
+    if (n <= 0 || n_segments <= 0) return MLH_OK;
+    StdSortArgs A;
+    size_t nbig, nleaf;
+    int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stdsort_init_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field, n_segments);
+    return stdsort_levels(ctx, A, longest, nbig, nleaf);
 }
 
 }  // namespace mlh

@@ -5,8 +5,10 @@
 //                        one workgroup per ring, the ring's less-flat points (label <= 0, cpp:258-264) are keyed with PCL's
 //                        voxel index (floor(x * inv_leaf) - min_b, x fastest), sorted on 64-bit (voxel, position) keys by a
 //                        register-resident bitonic network (sort_dev.hpp: 1024 threads, only the cross-wavefront stages touch
-//                        LDS), and every voxel's members are averaged (CentroidPoint: f32 sums / count)
-//                        in position order. Output order = ring asc, voxel index asc, as the reference concatenates them.
+//                        LDS), and every voxel's members are averaged (CentroidPoint: f32 sums / count) -- by default in the
+//                        order libstdc++'s std::sort leaves them (PCL's own order: MODE 1 writes the voxel indices, stdsort.hip
+//                        sorts every ring's list, MODE 2 sums along that permutation), in position order with member order 0.
+//                        Output order = ring asc, voxel index asc, as the reference concatenates them.
 // point_uncertainty_kernel   evalPointUncertainty (estimator/src/lidarMapper/associate_uct.hpp:196-215) as used by
 //                        downsampleCurrentScan (lidar_mapper_keyframe.cpp:375-418): per point, Sigma_p = [G diag(Sigma_ext,
 //                        Sigma_meas) G^T]_3x3 with G = [(T p)^odot | T D], f64, stored to the f32 cov_vec of PointXYZIWithCov;
@@ -27,13 +29,19 @@ struct RingVoxelArgs {
     float4 *stage;              // staged centroids, at the ring's offset in the less-flat list
     int *ring_vox;              // voxels per ring
     float leaf;
+    int *vkeys;                 // MODE 1: PCL voxel index of every less-flat point, in list order (the keys std::sort sees)
+    const int *perm;            // MODE 2: the order std::sort leaves them in (global positions of the less-flat list), voxel after voxel
 };
 
 constexpr int RV_TPB = 1024, RV_WAVES = RV_TPB / 64;
 
 // KPL keys per thread: a ring of up to 1024 * KPL less-flat points. PTS_IN_LDS: the ring's points are parked in LDS on the first
 // pass so that the centroid walks (a dependent chain per voxel) never go back to memory.
-template <int KPL, bool PTS_IN_LDS>
+// MODE 0: a voxel's members are summed in position order (what a stable sort would give). MODE 1 + 2: in the order libstdc++'s unstable
+// std::sort leaves them, which is the order PCL sums them in (voxel_grid.hpp: std::sort(index_vector) with a comparator on the voxel index
+// only) -- pass 1 writes the voxel indices, stdsort.hip produces std::sort's permutation per ring, pass 2 sums along it: the f32 sums
+// then associate as the reference's do and the centroids are its centroids bit for bit.
+template <int KPL, bool PTS_IN_LDS, int MODE>
 __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -89,8 +97,8 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
     }
     if (cells > 2147483647ll) {   // "Leaf size is too small for the input dataset": PCL returns the input unchanged
 #pragma unroll
-        for (int r = 0; r < KPL; ++r) if (tid * KPL + r < n) A.stage[off + tid * KPL + r] = p[r];
-        if (tid == 0) A.ring_vox[ring] = n;
+        for (int r = 0; r < KPL; ++r) if (tid * KPL + r < n) { if (MODE == 1) A.vkeys[off + tid * KPL + r] = 0; else A.stage[off + tid * KPL + r] = p[r]; }
+        if (MODE != 1 && tid == 0) A.ring_vox[ring] = n;
         return;
     }
     const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
@@ -104,7 +112,9 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
         const int ijk2 = int(floorf(p[r].z * inv) - float(min_b[2]));
         const unsigned idx = unsigned(ijk0 + ijk1 * mul1 + ijk2 * mul2);
         v[r] = t < n ? (((unsigned long long)idx << 32) | unsigned(t)) : ~0ull;
+        if (MODE == 1 && t < n) A.vkeys[off + t] = int(idx);
     }
+    if (MODE == 1) return;
     block_bitonic_sort<KPL, RV_WAVES>(v, keys, tid);
 #pragma unroll
     for (int r = 0; r < KPL; ++r) keys[tid * KPL + r] = v[r];
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
             for (int u = tid * KPL + r; u < n; ++u) {
                 const unsigned long long ku = keys[u];
                 if (unsigned(ku >> 32) != vox) break;
-                const int pos = int(unsigned(ku));
+                const int pos = MODE == 2 ? A.perm[off + u] - off : int(unsigned(ku));
                 const float4 q = PTS_IN_LDS ? spts[pos] : A.pts[A.list3[off + pos]];
                 sx += q.x; sy += q.y; sz += q.z; si += q.w;
                 ++cnt;
@@ -171,14 +181,22 @@ __global__ __launch_bounds__(256) void ring_vox_compact_kernel(const float4 *__r
     for (int t = threadIdx.x; t < n; t += 256) out[dst + t] = stage[src + t];
 }
 
-template <int KPL, bool PTS_IN_LDS>
+template <int KPL, bool PTS_IN_LDS, int MODE>
 static hipError_t ring_voxel_launch(const RingVoxelArgs &A, int R, hipStream_t st)
 {
     const size_t lds = size_t(RV_TPB) * KPL * (sizeof(unsigned long long) + (PTS_IN_LDS ? sizeof(float4) : 0));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ring_voxel_kernel<KPL, PTS_IN_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ring_voxel_kernel<KPL, PTS_IN_LDS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ring_voxel_kernel<KPL, PTS_IN_LDS>), dim3(R), dim3(RV_TPB), lds, st, A);
+    hipLaunchKernelGGL((ring_voxel_kernel<KPL, PTS_IN_LDS, MODE>), dim3(R), dim3(RV_TPB), lds, st, A);
     return hipSuccess;
+}
+template <int MODE>
+static hipError_t ring_voxel_launch_any(const RingVoxelArgs &A, int R, int longest, hipStream_t st)
+{
+    if (longest <= RV_TPB) return ring_voxel_launch<1, true, MODE>(A, R, st);
+    if (longest <= RV_TPB * 2) return ring_voxel_launch<2, true, MODE>(A, R, st);
+    if (longest <= RV_TPB * 4) return ring_voxel_launch<4, true, MODE>(A, R, st);
+    return ring_voxel_launch<8, false, MODE>(A, R, st);
 }
 
 int ring_voxel_run(mlh_ctx *ctx, float leaf)
@@ -194,13 +212,22 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     RingVoxelArgs A;
     A.pts = sb.pts.as<float4>(); A.list3 = sb.lists[3].as<int>(); A.ring_counts = sb.ring_counts.as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.stage = sb.vox_stage.as<float4>(); A.ring_vox = sb.ring_vox.as<int>();
-    A.leaf = leaf;
+    A.leaf = leaf; A.vkeys = nullptr; A.perm = nullptr;
+    if (longest > RV_TPB * 8) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
     prof_begin(ctx, MLH_K_EXTRACT);
-    if (longest <= RV_TPB) MLH_HIP(ctx, (ring_voxel_launch<1, true>(A, R, st)));
-    else if (longest <= RV_TPB * 2) MLH_HIP(ctx, (ring_voxel_launch<2, true>(A, R, st)));
-    else if (longest <= RV_TPB * 4) MLH_HIP(ctx, (ring_voxel_launch<4, true>(A, R, st)));
-    else if (longest <= RV_TPB * 8) MLH_HIP(ctx, (ring_voxel_launch<8, false>(A, R, st)));
-    else return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
+    if (ctx->vox_member_order != 0) {
+        // the reference's member order: voxel indices out, std::sort's permutation of every ring's list (stdsort.hip), sums along it
+        MLH_HIP(ctx, sb.vox_keys.ensure(sizeof(int) * size_t(sb.n)));
+        MLH_HIP(ctx, sb.vox_perm.ensure(sizeof(int) * size_t(sb.n)));
+        A.vkeys = sb.vox_keys.as<int>();
+        MLH_HIP(ctx, ring_voxel_launch_any<1>(A, R, longest, st));
+        int rc = device_std_sort_segments(ctx, A.vkeys, A.ring_counts, A.ring_offsets, 4, 3, R, sb.n, longest, sb.vox_perm.as<int>());
+        if (rc) return rc;
+        A.perm = sb.vox_perm.as<int>();
+        MLH_HIP(ctx, ring_voxel_launch_any<2>(A, R, longest, st));
+    } else {
+        MLH_HIP(ctx, ring_voxel_launch_any<0>(A, R, longest, st));
+    }
     hipLaunchKernelGGL(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, (const float4 *)sb.vox_stage.as<float4>(), (const int *)sb.ring_offsets.as<int>(),
                        (const int *)sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + R, sb.vox_out.as<float4>());
     prof_end(ctx, MLH_K_EXTRACT);

@@ -39,7 +39,8 @@ def _check_extract(ctx, orc, pts, ss, se):
     for k in ("sharp", "less_sharp", "flat", "less_flat_raw"):
         assert np.array_equal(got[k], ref[k]), k
     assert got["less_flat_ds"].shape == ref["less_flat_ds"].shape
-    np.testing.assert_allclose(got["less_flat_ds"], ref["less_flat_ds"], rtol=2e-6, atol=2e-6)
+    # the per-ring VoxelGrid sums a voxel's members in the order std::sort leaves them (the default member order): the reference's centroids, every bit
+    assert np.array_equal(got["less_flat_ds"].view(np.uint32), ref["less_flat_ds"].view(np.uint32))
 
 
 def test_extract_ragged_and_skipped_rings(ctx, orc):

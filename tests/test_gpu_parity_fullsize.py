@@ -71,7 +71,7 @@ def test_extract_labels_bit_exact_64_rings(mla, orc, cfg2):
         for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
             assert np.array_equal(got[k], ref[k]), k
         assert got["less_flat_ds"].shape == ref["less_flat_ds"].shape
-        np.testing.assert_allclose(got["less_flat_ds"][:, :3], ref["less_flat_ds"][:, :3], atol=2e-6)   # centroid sum order (tolerance, not bits)
+        np.testing.assert_array_equal(got["less_flat_ds"].view(np.uint32), ref["less_flat_ds"].view(np.uint32))   # summed along std::sort's member order: the reference's bits
     offs = np.cumsum([0] + [len(s.points) for s in scans])
     pts = np.concatenate([s.points for s in scans])
     st = np.concatenate([s.scan_start + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
@@ -249,7 +249,7 @@ def test_extract_against_the_references_own_lines(mla, orc, cfg2):
         for k in ("sharp", "less_sharp", "flat"):
             assert np.array_equal(want[k].view(np.uint32), np.ascontiguousarray(s.points[got[k]]).view(np.uint32)), k
         assert want["less_flat_ds"].shape == got["less_flat_ds"].shape
-        np.testing.assert_allclose(got["less_flat_ds"][:, :3], want["less_flat_ds"][:, :3], atol=2e-6)
+        np.testing.assert_array_equal(got["less_flat_ds"].view(np.uint32), want["less_flat_ds"].view(np.uint32))
     # ... and the correspondence decisions + coefficients of the config-2 features at the bench's initial pose
     c.map_set_pair(cfg2["surf_map"], cfg2["corner_map"])
     c.features_set(mla.SURF, cfg2["surf"]); c.features_set(mla.CORNER, cfg2["corner"])
