@@ -94,12 +94,9 @@ __global__ __launch_bounds__(256) void stdsort_init_segments_kernel(StdSortArgs 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < A.n) { A.keys[i] = src_keys[i]; A.vals[i] = i; }
-    if (i == 0) {
-        for (int k = 0; k < SS_CNT; ++k) A.cnt[k] = 0;
-        for (int s = 0; s < n_segments; ++s) {
-            const int c = counts[s * stride + field], o = offsets[s * stride + field];
-            if (c > 1 && o >= 0 && o + c <= A.n) emit_global(A, o, o + c, 2 * floor_log2(c), A.seg[0], &A.cnt[0]);
-        }
+    if (i < n_segments) {                                            // the counters were cleared by the launch before this one
+        const int c = counts[i * stride + field], o = offsets[i * stride + field];
+        if (c > 1 && o >= 0 && o + c <= A.n) emit_global(A, o, o + c, 2 * floor_log2(c), A.seg[0], &A.cnt[0]);
     }
 }
 
@@ -505,7 +502,9 @@ int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *count
     size_t nbig, nleaf;
     int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
     if (rc) return rc;
-    hipLaunchKernelGGL(stdsort_init_segments_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field, n_segments);
+    MLH_HIP(ctx, hipMemsetAsync(A.cnt, 0, sizeof(int) * SS_CNT, ctx->stream));      // one thread per segment appends its range: the counters start at zero
+    hipLaunchKernelGGL(stdsort_init_segments_kernel, dim3((std::max(n, n_segments) + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field,
+                       n_segments);
     return stdsort_levels(ctx, A, longest, nbig, nleaf);
 }
 
