@@ -87,7 +87,10 @@ int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *la
  * Out: the ring-major cloud [x y z intensity + row] and ScanInfo::scan_start_ind_ / scan_end_ind_ (+5 / -6 insets), staged as the context's
  * scan exactly as mlh_scan_upload leaves it -- mlh_extract_run follows directly, the cloud never has to be assembled on the host -- and,
  * when the pointers are given, copied back: cloud_out (up to n x 4 floats), scan_start / scan_end (vertical_scans each), outlier_out
- * (laser_cloud_outlier: up to n / 5 + 2 rows of 4 floats). Projection, ground pairs and the final gather run on the GPU; the cluster search and
+ * (laser_cloud_outlier: rows of 4 floats; the caller states the rows it has room for in outlier_capacity, writes are clamped to it and
+ * *n_outlier always reports the rows the cloud HAS, so a short buffer is detected, not overrun. An upper bound that never truncates:
+ * min(n, vertical_scans * ((horizon_scans + 4) / 5)) + 1 -- one row per infeasible-cluster pixel in a column that is a multiple of 5,
+ * image_segmenter.hpp:366-378, plus the first output point, hpp:391). Projection, ground pairs and the final gather run on the GPU; the cluster search and
  * the outlier erasure are defined by their sequential order and run on the host inside this call (m-loam_amd/csrc/segment.hip says why).
  * The reference's undefined spots -- alpha used before it is set, erase with shifted positions, the 64-ring ground loop's row 64 -- behave as
  * INTEGRATION.md documents. vertical_scans 16, 32 or 64. */
@@ -103,7 +106,7 @@ typedef struct mlh_segment_params {
 } mlh_segment_params;
 void mlh_segment_params_default(mlh_segment_params *p);     /* config_realvehicle_hercules.yaml:7-13, 102 */
 int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, int mem, const mlh_segment_params *prm,
-                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier);
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier);
 
 /* ---------------------------------------------------------------- (a1-a3) FeatureExtract::extractCloud
  * replaces FeatureExtract::extractCloud(const PointICloud&, const ScanInfo&, cloudFeature&)

@@ -93,7 +93,7 @@ def load_library():
     lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci]
     lib.mlh_segment_params_default.argtypes = [C.POINTER(SegmentParams)]
     lib.mlh_segment_params_default.restype = None
-    lib.mlh_segment_cloud.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(SegmentParams), vp, C.POINTER(C.c_int32), vp, vp, vp, C.POINTER(C.c_int32)]
+    lib.mlh_segment_cloud.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(SegmentParams), vp, C.POINTER(C.c_int32), vp, vp, vp, ci, C.POINTER(C.c_int32)]
     lib.mlh_extract_run.argtypes = [vp]
     lib.mlh_extract_fetch.argtypes = [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int32)]
     lib.mlh_extract_voxel_run.argtypes = [vp, cf]
@@ -269,7 +269,7 @@ class Context:
             self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, 12 if stride >= 16 else -1, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
         self._scan_n = n
 
-    def segment_cloud(self, points4, fetch=True, **kw):
+    def segment_cloud(self, points4, fetch=True, outlier_capacity=None, **kw):
         """ImageSegmenter::segmentCloud: unordered cloud (n, 4) [x y z intensity] (numpy or torch CUDA) -> the context's scan (ring-major, on the
         device) and, with fetch, the ring-major cloud / ScanInfo arrays / outlier cloud. kw: fields of SegmentParams."""
         prm = SegmentParams()
@@ -279,13 +279,14 @@ class Context:
         ptr, stride, n, mem, keep = _src(points4)
         vs = prm.vertical_scans
         out = np.zeros((max(n, 1), 4), np.float32) if fetch else None
-        outl = np.zeros((n // 5 + 3, 4), np.float32) if fetch else None
+        cap = min(n, vs * ((prm.horizon_scans + 4) // 5)) + 1 if outlier_capacity is None else int(outlier_capacity)
+        outl = np.zeros((max(cap, 1), 4), np.float32) if fetch else None
         ss = np.zeros(vs, np.int32); se = np.zeros(vs, np.int32)
         no, nl = C.c_int32(0), C.c_int32(0)
         self._ck(self.lib.mlh_segment_cloud(self.h, ptr, stride, 12 if stride >= 16 else -1, n, mem, C.byref(prm), _p(out) if fetch else None, C.byref(no),
-                                            _p(ss), _p(se), _p(outl) if fetch else None, C.byref(nl)))
+                                            _p(ss), _p(se), _p(outl) if fetch else None, cap, C.byref(nl)))
         self._scan_n = no.value
-        return dict(cloud=out[:no.value].copy() if fetch else None, outlier=outl[:nl.value].copy() if fetch else None, scan_start=ss, scan_end=se, n=no.value)
+        return dict(cloud=out[:no.value].copy() if fetch else None, outlier=outl[:min(nl.value, cap)].copy() if fetch else None, n_outlier=nl.value, scan_start=ss, scan_end=se, n=no.value)
 
     def extract_run(self):
         self._ck(self.lib.mlh_extract_run(self.h))

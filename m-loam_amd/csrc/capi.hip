@@ -276,7 +276,8 @@ void mlh_destroy(mlh_ctx *ctx)
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); s.vox_keys.release(); s.vox_perm.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release(); ctx->fused_part.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
-    { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); }
+    { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); o.perm.release(); o.tile_group.release(); o.partial.release(); o.ne_out.release(); }
+    { SegBuf &g = ctx->seg; g.raw.release(); g.pix.release(); g.owner.release(); g.range.release(); g.ground.release(); g.keep.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.word_of.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->stdsort.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
     comm_destroy(ctx);
@@ -286,6 +287,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -298,7 +300,7 @@ int mlh_synchronize(mlh_ctx *ctx)
     if (!ctx) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask)
@@ -385,12 +387,13 @@ void mlh_segment_params_default(mlh_segment_params *p)
 }
 
 int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, int mem, const mlh_segment_params *prm,
-                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier)
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier)
 {
     if (!ctx || !prm) return MLH_ERR_INVALID;
+    if (outlier_out && outlier_capacity < 0) return fail(ctx, MLH_ERR_INVALID, "negative outlier capacity");
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    return segment_cloud_run(ctx, points, stride_bytes, intensity_offset_bytes, n, mem, *prm, cloud_out, n_out, scan_start, scan_end, outlier_out, n_outlier);
+    return segment_cloud_run(ctx, points, stride_bytes, intensity_offset_bytes, n, mem, *prm, cloud_out, n_out, scan_start, scan_end, outlier_out, outlier_capacity, n_outlier);
 }
 
 int mlh_extract_run(mlh_ctx *ctx)
@@ -445,7 +448,7 @@ int mlh_extract_fetch_voxel(mlh_ctx *ctx, float *xyzi_out, int32_t *n_out)
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     prof_collect(ctx);
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
@@ -640,7 +643,7 @@ int mlh_std_sort_permutation(mlh_ctx *ctx, const int32_t *keys, int n0, int n, i
     if (rc) return rc;
     MLH_HIP(ctx, hipMemcpyAsync(perm_out, d_perm, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 int mlh_map_info(mlh_ctx *ctx, int kind, int32_t *n_points, int32_t *occupied_cells, double *mean_cell_population, int32_t *knn_lanes)

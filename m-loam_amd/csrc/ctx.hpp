@@ -76,6 +76,12 @@ struct IterStatDev {        // mirrors mlh_iter_stat, written by the device-side
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    // owns its allocation: a buffer that is a member of the context (or of one of its sub-structures) is freed with it, so a new member
+    // cannot be forgotten in mlh_destroy (which sets the device before `delete ctx`)
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     // grow to `bytes`, preserving the first `keep` bytes (device-to-device copy on `st`)
     hipError_t grow(size_t bytes, size_t keep, hipStream_t st)
     {
@@ -245,6 +251,7 @@ struct mlh_ctx {
     mlh::TrackSet track;
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
     int fused_n[2] = {0, 0};   // valid when !fused_dirty
+    int *h_dev_err = nullptr;   // one pinned int a kernel sets when it has to give up (device std::sort: a wait that was never released); see device_error_check
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
     void *fused_host = nullptr; // pinned landing block of mlh_fused_cloud's one read-back: [2 counts (padded to 4 ints)][per-workgroup bounding boxes]
     size_t fused_host_cap = 0;
@@ -304,7 +311,7 @@ int track_match_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 // segment.hip
 int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
-                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier);
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier);
 // odom.hip
 int pure_odom_set(mlh_ctx *ctx, int n, const int32_t *type, const double *points, const double *coeffs, const double *sqrt_info,
                   const int32_t *frame_idx, const int32_t *ext_idx);
@@ -316,6 +323,24 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
                         double *H, double *g, double *cost, int32_t *n_res);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
+// A kernel that cannot honour its contract (today: the device std::sort when a queue wait runs out, or a range it was never told about) sets
+// the context's pinned error word instead of leaving a wrong order behind silently; every call that waits for the stream afterwards reports it.
+inline int *device_error_word(mlh_ctx *ctx)
+{
+    if (!ctx->h_dev_err) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(int), hipHostMallocDefault) == hipSuccess) { ctx->h_dev_err = static_cast<int *>(p); *ctx->h_dev_err = 0; }
+    }
+    return ctx->h_dev_err;
+}
+inline int device_error_check(mlh_ctx *ctx)
+{
+    if (ctx->h_dev_err && *static_cast<volatile int *>(ctx->h_dev_err) != 0) {
+        *ctx->h_dev_err = 0;
+        return fail(ctx, MLH_ERR_STATE, "a device kernel gave up (std::sort emulation: unreleased wait or an unannounced range); the results of this call are not valid");
+    }
+    return MLH_OK;
+}
 // 64 pinned ints owned by the context (lazily allocated); nullptr on allocation failure
 inline int *pinned_ints(mlh_ctx *ctx)
 {

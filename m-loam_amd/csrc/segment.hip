@@ -212,7 +212,7 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
 }
 
 int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
-                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t *n_outlier)
+                      float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier)
 {
     SegSetup S;
     if (!seg_setup(prm, S)) return fail(ctx, MLH_ERR_UNSUPPORTED, "ImageSegmenter is set up for 16, 32 or 64 vertical scans (image_segmenter.cpp:18-61)");
@@ -306,6 +306,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         // the few outlier records are assembled from the caller's cloud when it is on the host, else fetched point by point
         size_t k = 0;
         auto put = [&](int i, int row) -> int {
+            if (k >= size_t(outlier_capacity)) return 0;       // the caller's buffer is full: *n_outlier tells it how many rows there are
             float rec[4] = {0, 0, 0, 0};
             if (mem == MLH_MEM_HOST) {
                 const unsigned char *q = static_cast<const unsigned char *>(points) + size_t(i) * stride;

@@ -229,8 +229,8 @@ bool spd_inverse6(const double A[36], double Ainv[36])
 // Scoring: logdet(H + j^T j) = logdet(H) + log(1 + j H^-1 j^T) (matrix determinant lemma), so inside one subset -- all members are scored
 // against the same H -- the best member is the one with the largest q = j H^-1 j^T: 42 multiply-adds against a maintained inverse
 // (Sherman-Morrison per pick) instead of a Cholesky factorisation and six logarithms per candidate. The reference compares the logdet
-// VALUES (magnitude <~ 100, so resolved to ~1e-13 by the Cholesky sum): whenever the two best members' log(1+q) are closer than 1e-10 the
-// whole subset is re-scored with the reference's arithmetic (logdet_cholesky6) and pushed through the same heap -- selections stay
+// VALUES (magnitude <~ 100, so resolved to ~1e-13 by the Cholesky sum): whenever the two best members' q are closer than the error the
+// maintained inverse can carry (64 eps cond(H), at least 1e-10, relative to 1 + q) the whole subset is re-scored with the reference's arithmetic (logdet_cholesky6) and pushed through the same heap -- selections stay
 // identical to the literal loop's (MLH_SELECT_EXACT=1 in the environment runs the literal scoring; tests compare the two).
 void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
 {
@@ -241,6 +241,12 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
     size_t retries = 0;
     double Hinv[36];
     bool have_inv = std::getenv("MLH_SELECT_EXACT") == nullptr && spd_inverse6(H, Hinv);
+    double replay_tol = 1e-10;
+    if (have_inv) {
+        double nh = 0.0, ni = 0.0;
+        for (int k = 0; k < 36; ++k) { nh += H[k] * H[k]; ni += Hinv[k] * Hinv[k]; }
+        replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh) * std::sqrt(ni));
+    }
     auto exact_score = [&](size_t q) { double Ht[36]; std::copy(H, H + 36, Ht); rank1_update(Ht, R.jaco(q)); return logdet_cholesky6(Ht); };
     auto quad = [&](const double *j, double *Hj) {
         double q = 0.0;
@@ -278,7 +284,7 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
                     else if (second == size_t(-1) || subset_c[k].q > subset_c[second].q) second = k;
                 }
                 size_t top_idx = subset_c[best].idx;
-                if (have_inv && second != size_t(-1) && !(subset_c[best].q - subset_c[second].q > 1e-10 * (1.0 + subset_c[best].q))) {
+                if (have_inv && second != size_t(-1) && !(subset_c[best].q - subset_c[second].q > replay_tol * (1.0 + subset_c[best].q))) {
                     std::priority_queue<Scored> heap;                      // too close to call on q: replay the subset literally
                     for (const Cand &c : subset_c) heap.push(Scored{c.idx, exact_score(c.idx)});
                     top_idx = heap.top().idx;
@@ -294,7 +300,20 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
                 rank1_update(H, jt);
                 pool.erase_index(top_idx);
                 sel.push_back(top_idx);
-                if (have_inv && (sel.size() & 255) == 0) have_inv = spd_inverse6(H, Hinv);       // refresh: keeps the update's rounding from accumulating
+                if (have_inv) {
+                    // How far q = j H^-1 j^T can be off: ~ eps * cond(H) per use of the maintained inverse. The reference starts from
+                    // H = 1e-6 I, so the first picks see cond ~ 1e6..1e8 -- there the inverse is rebuilt from H after every pick instead of
+                    // rank-1 updated, and the "too close to call" band is widened to that error, so that a near-tie inside it is always settled
+                    // by the reference's own logdet arithmetic. Frobenius norms: cond_2 <= ||H||_F ||H^-1||_F.
+                    double nh = 0.0, ni = 0.0;
+                    for (int k = 0; k < 36; ++k) { nh += H[k] * H[k]; ni += Hinv[k] * Hinv[k]; }
+                    const double kappa = std::sqrt(nh) * std::sqrt(ni);
+                    if (kappa > 1e5 || (sel.size() & 255) == 0) {
+                        have_inv = spd_inverse6(H, Hinv);       // refresh: keeps the update's rounding from accumulating
+                        if (have_inv) { ni = 0.0; for (int k = 0; k < 36; ++k) ni += Hinv[k] * Hinv[k]; }
+                    }
+                    replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh) * std::sqrt(ni));
+                }
                 break;
             }
         }

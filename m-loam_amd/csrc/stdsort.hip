@@ -60,6 +60,9 @@ struct StdSortArgs {
     SortSeg *leaf;      // ranges of 2 .. SS_LEAF elements
     int *cnt;           // [0 .. SS_BIG_LEVELS]: ranges per big level; [SS_CNT_LEAF]: leaves
     int n;
+    int over_level;     // the level whose list holds the ranges longer than SS_LEAF the leaf launch still has to take: SS_BIG_LEVELS after the big
+                        // levels ran, 0 when they were skipped (then nothing should be there -- `longest` said so -- but if something is, it is sorted)
+    int *err;           // pinned host word: set when a wait is given up on (never observed; the result would be a wrong order)
 };
 constexpr int SS_CNT_LEAF = SS_BIG_LEVELS + 1;
 constexpr int SS_CNT = SS_BIG_LEVELS + 2;
@@ -292,7 +295,7 @@ __device__ inline int wg_load(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQ
 __device__ inline void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
-__device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh)
+__device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh, int *err)
 {
     const int t = threadIdx.x, lane = t & 63;
     for (int i = t; i < 4 * M.qcap; i += SS_LEAF_WG) M.q[i] = 0;
@@ -317,7 +320,11 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
                 if (wg_load(&sh[LQ_REMAINING]) == 0) break;
                 __builtin_amdgcn_s_sleep(32);
             }
-            if (!got) break;
+            if (!got) {
+                // released by `remaining == 0` (all done) or never: the latter leaves elements unsorted -- say so instead of returning a wrong order
+                if (wg_load(&sh[LQ_REMAINING]) != 0 && lane == 0 && err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             f = M.q[4 * ticket]; l = M.q[4 * ticket + 1]; d = M.q[4 * ticket + 2];
             have = true;
         }
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
     __shared__ int s_q[4 * SS_LOCAL_LIST];
     __shared__ int s_scr[(SS_LEAF_WG / 64) * 128];
     __shared__ int sh[4];
-    const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[SS_BIG_LEVELS];
-    const SortSeg *over = A.seg[SS_BIG_LEVELS & 1];
+    const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[A.over_level];
+    const SortSeg *over = A.seg[A.over_level & 1];
     const int t = threadIdx.x;
     for (int si = blockIdx.x; si < n_leaf + n_left_over; si += gridDim.x) {
         const SortSeg s = si < n_leaf ? A.leaf[si] : over[si - n_leaf];
@@ -434,13 +441,13 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
             for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
             M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
             __syncthreads();
-            leaf_sort(M, m, s.depth, sh);
+            leaf_sort(M, m, s.depth, sh, A.err);
             for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
             __syncthreads();
         } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
             M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
             M.q = A.glist + f; M.qcap = m / (SS_THRESHOLD + 1) + 2;
-            leaf_sort(M, m, s.depth, sh);
+            leaf_sort(M, m, s.depth, sh, A.err);
         }
     }
 }
@@ -461,12 +468,15 @@ static int stdsort_setup(mlh_ctx *ctx, int n, int *vals_out, StdSortArgs &A, siz
     A.cnt = base + off_cnt;
     A.seg[0] = reinterpret_cast<SortSeg *>(base + off_seg0); A.seg[1] = reinterpret_cast<SortSeg *>(base + off_seg1);
     A.leaf = reinterpret_cast<SortSeg *>(base + off_leaf); A.n = n;
+    A.over_level = SS_BIG_LEVELS;
+    A.err = device_error_word(ctx);
     return MLH_OK;
 }
 
-static int stdsort_levels(mlh_ctx *ctx, const StdSortArgs &A, int longest, size_t nbig, size_t nleaf)
+static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig, size_t nleaf)
 {
     hipStream_t st = ctx->stream;
+    A.over_level = longest > SS_LEAF ? SS_BIG_LEVELS : 0;     // big levels skipped: whatever the init kernel routed to level 0 anyway is finished by the leaf launch
     if (longest > SS_LEAF) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
         for (int level = 0; level < SS_BIG_LEVELS; ++level)

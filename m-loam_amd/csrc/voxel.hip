@@ -495,7 +495,7 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
         MLH_HIP(ctx, hipMemcpyAsync(out, dst, size_t(total) * stride, hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
     }
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 // ---------------------------------------------------------------- downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421)
@@ -642,7 +642,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
     MLH_HIP(ctx, hipStreamSynchronize(st));
     *n_surf_out = counts[0];
     *n_corner_out = counts[1];
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 }  // namespace mlh

@@ -510,7 +510,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
         MLH_HIP(ctx, hipMemcpyAsync(out_host, V.out.p, size_t(total) * stride, mem == MLH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
     }
-    return MLH_OK;
+    return device_error_check(ctx);
 }
 
 // Two device-resident clouds of the same record layout thinned (plain branch) in ONE set of launches: the second cloud's voxels are

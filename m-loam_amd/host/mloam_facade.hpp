@@ -18,6 +18,7 @@
 // reference tree, define MLOAM_FACADE_USE_PCL_TYPES and the real headers' types are used instead (same layouts).
 // All heavy work goes through libmloam_hip.so; this header contains no numerical fallback.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -695,12 +696,15 @@ public:
     {
         const int n = (int)laser_cloud_in.size();
         prm_.segment_flag = scan_info.segment_flag_ ? 1 : 0;
-        std::vector<float> out(size_t(n > 0 ? n : 1) * 4), outl(size_t(n / 5 + 3) * 4);
+        // laser_cloud_outlier holds at most one point per pixel of a column that is a multiple of 5 (and never more than n), plus one
+        const int outl_cap = std::min(n, prm_.vertical_scans * ((prm_.horizon_scans + 4) / 5)) + 1;
+        std::vector<float> out(size_t(n > 0 ? n : 1) * 4), outl(size_t(outl_cap) * 4);
         int32_t n_out = 0, n_outl = 0;
         scan_info.scan_start_ind_.resize(prm_.vertical_scans);
         scan_info.scan_end_ind_.resize(prm_.vertical_scans);
         dev_.check(mlh_segment_cloud(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, n, MLH_MEM_HOST, &prm_,
-                                     out.data(), &n_out, scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), outl.data(), &n_outl));
+                                     out.data(), &n_out, scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), outl.data(), outl_cap, &n_outl));
+        if (n_outl > outl_cap) n_outl = outl_cap;      // cannot happen with the bound above; never read past the buffer
         auto fill = [](PointICloud &c, const std::vector<float> &v, int m) {
             c.points.clear();
             c.points.reserve(m);

@@ -399,3 +399,39 @@ def test_std_sort_permutation_edges(mla, orc):
     finally:
         c.close()
 
+
+
+def test_segmenter_outlier_cloud_of_an_azimuth_decimated_scan(mla, orc, synth):
+    """laser_cloud_outlier holds one point per infeasible-cluster pixel whose column is a multiple of 5 (image_segmenter.hpp:
+    366-378) -- on a cloud whose points ALL sit in such columns (a sensor with 1 degree azimuth steps at HORIZON_SCAN 1800) that is far more
+    than n / 5. The call takes the rows the caller has room for: with the bound the header gives nothing is truncated and the result equals the
+    oracle's; with a short buffer the writes stop at the capacity and n_outlier still reports the true count."""
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], 16, seed=5)
+    rng = np.random.default_rng(5)
+    pts = s.points.copy()
+    pts[:, 3] = 0.25
+    ha = np.degrees(np.arctan2(pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)))
+    t = (ha - 90.0) / (360.0 / 1800)
+    col = (-np.round(t) + 900).astype(np.int64)
+    col[col >= 1800] -= 1800
+    keep = (col % 5 == 0) & (np.abs((t - np.floor(t)) - 0.5) > 1e-3)
+    pts = pts[keep]
+    pts[:, :3] *= rng.uniform(0.4, 1.6, (len(pts), 1)).astype(np.float32)      # every point pulled off its surface: isolated pixels -> small clusters
+    pts = pts[rng.permutation(len(pts))]
+    prm = orc.seg_params(vertical_scans=16, segment_flag=True)
+    ref = orc.segment_cloud(pts, prm)
+    n = len(pts)
+    assert len(ref["outlier"]) > n // 5 + 3, (len(ref["outlier"]), n)           # the old "n / 5 + 2" bound really is exceeded
+    assert len(ref["outlier"]) <= min(n, 16 * 360) + 1
+    c = mla.Context(0)
+    try:
+        got = c.segment_cloud(pts, vertical_scans=16, segment_flag=1)
+        assert got["n_outlier"] == len(ref["outlier"])
+        assert np.array_equal(got["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
+        assert np.array_equal(got["cloud"].view(np.uint32), ref["cloud"].view(np.uint32))
+        short = c.segment_cloud(pts, vertical_scans=16, segment_flag=1, outlier_capacity=7)
+        assert short["n_outlier"] == len(ref["outlier"]) and len(short["outlier"]) == 7
+        assert np.array_equal(short["outlier"].view(np.uint32), ref["outlier"][:7].view(np.uint32))
+    finally:
+        c.close()
