@@ -623,7 +623,7 @@ class Context:
 
     # ---- host-driven evaluation
     def match_linearize(self, kind, pose, flags=0, min_match_sq_dis=1.0, min_plane_dis=0.2, huber_delta=0.1,
-                        cov_measurement_trace=0.0075, dense=True):
+                        cov_measurement_trace=0.0075, dense=True, k_neigh=5):
         m = self._m[kind]
         pose = np.ascontiguousarray(pose, np.float64)
         valid = np.zeros(m, np.uint8)
@@ -633,7 +633,7 @@ class Context:
         H = np.zeros((6, 6))
         g = np.zeros(6)
         cost, cnt = C.c_double(0), C.c_int32(0)
-        self._ck(self.lib.mlh_match_linearize(self.h, kind, _p(pose), 5, flags, min_match_sq_dis, min_plane_dis, huber_delta,
+        self._ck(self.lib.mlh_match_linearize(self.h, kind, _p(pose), int(k_neigh), flags, min_match_sq_dis, min_plane_dis, huber_delta,
                                               cov_measurement_trace, _p(valid), _p(coeffs), _p(r), _p(J), _p(H), _p(g),
                                               C.byref(cost), C.byref(cnt)))
         return dict(valid=valid, coeffs=coeffs, r=r, J=J, H=H, g=g, cost=cost.value, count=cnt.value)

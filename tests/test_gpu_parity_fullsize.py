@@ -314,3 +314,274 @@ def test_downsample_current_scan_against_the_references_own_lines(mla, orc, synt
         assert dflt.shape != rs.shape or not np.array_equal(dflt[:, 3], rs[:, 3])
     finally:
         c.close()
+
+
+# ---------------------------------------------------------------- BASELINE configs 3 and 4 at their STATED map sizes
+def _ranks_as_contexts(mla, shard, world, mode, surf_map, corner_map, centre):
+    """one context per rank on this GPU: its map wedge + halo with half-space ownership ("map"), or the whole map with round-robin feature
+    ownership ("features") -- what every rank of an N-GPU job stages (m-loam_amd/shard.py, csrc/comm.hip)"""
+    ctxs = []
+    for r in range(world):
+        c = mla.Context(0)
+        if mode == "map":
+            lo, hi = shard.wedge_planes(centre, world, r)
+            c.shard_set(lo, hi)
+            ms = np.ascontiguousarray(surf_map[shard.shard_points_mask(surf_map, centre, world, r)])
+            mc = np.ascontiguousarray(corner_map[shard.shard_points_mask(corner_map, centre, world, r)])
+            far = np.full((1, 3), 1.0e6, np.float32)
+            c.map_set_pair(ms if len(ms) else far, mc if len(mc) else far)
+        else:
+            c.shard_set_features(world, r)
+            c.map_set_pair(surf_map, corner_map)
+        ctxs.append(c)
+    return ctxs
+
+
+def _sharded_block_gn(mla, ctxs, surf, corner, p0, n_iters, k_neigh=5, flags=0, huber_delta=0.1, eig_thre=100.0, freeze=False):
+    """the N-rank Gauss-Newton loop of one pose block with the all-reduce done by the host (sum of the ranks' packed J^T J / J^T r / counts),
+    then the one solve every rank would repeat: evalDegenracy -> H d = -g -> Plus, or no update at all for a frozen degenerate block"""
+    for c in ctxs:
+        c.features_set(mla.SURF, surf)
+        c.features_set(mla.CORNER, corner)
+    pose = np.array(p0, np.float64)
+    counts, owned = [], np.zeros((len(ctxs), 2), np.int64)
+    for _ in range(n_iters):
+        H, g, ns, nc = np.zeros((6, 6)), np.zeros(6), 0, 0
+        for r, c in enumerate(ctxs):
+            a = c.match_linearize(mla.SURF, pose, flags=flags, huber_delta=huber_delta, dense=False, k_neigh=k_neigh)
+            b = c.match_linearize(mla.CORNER, pose, flags=flags, huber_delta=huber_delta, dense=False, k_neigh=k_neigh)
+            H += a["H"] + b["H"]; g += a["g"] + b["g"]; ns += a["count"]; nc += b["count"]
+            owned[r] = (a["count"], b["count"])
+        deg = mla.eval_degeneracy(H, eig_thre)
+        if not (freeze and deg["is_degenerate"]):
+            pose = mla.pose_plus(pose, np.linalg.solve(H, -g), deg["V_update"] if deg["is_degenerate"] else None)
+        counts.append((ns, nc))
+    return pose, counts, owned
+
+
+@pytest.fixture(scope="module")
+def cfg3(synth, orc):
+    """BASELINE config 3: the 2 x 64-ring frame against the 2 M-point map (the preset bench.py --map-preset 2M builds)"""
+    import bench
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "2M")
+    assert len(surf_map) + len(corner_map) > 2_000_000
+    ex = [orc.extract(s.points, s.scan_start, s.scan_end) for s in scans]
+    surf, corner = bench.fuse_features(synth, scans, ex)
+    p0 = synth.perturbed_pose(gt, seed=43)
+    oms, omc = orc.Map(surf_map), orc.Map(corner_map)
+    ref = orc.gn_iterations(oms, omc, surf, corner, p0, orc.mapper_params(), 5)
+    return dict(surf_map=surf_map, corner_map=corner_map, surf=surf, corner=corner, p0=p0, ref=ref)
+
+
+def test_config3_unsharded_2M(mla, cfg3):
+    """the 2 M map on ONE context: grid extents, cell_start sizes and the sticky grid box are what changes against the 500 k map"""
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(cfg3["surf_map"], cfg3["corner_map"])
+        c.features_set(mla.SURF, cfg3["surf"]); c.features_set(mla.CORNER, cfg3["corner"])
+        pose, stats = c.gn_solve(cfg3["p0"], 5)
+        ref = cfg3["ref"]
+        for s, r in zip(stats, ref["iters"]):
+            assert (s["n_surf"], s["n_corner"]) == (r["n_surf"], r["n_corner"])
+            assert float(np.abs(s["H"] - r["H"]).max()) <= 1e-9 * max(1.0, float(np.abs(r["H"]).max()))
+            assert float(np.abs(s["g"] - r["g"]).max()) <= 1e-9 * max(1.0, float(np.abs(r["g"]).max()))
+        dt, dr = _pose_err(pose, ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+        # a second frame through the re-staging path (same box: the sticky geometry is reused) gives the same answer
+        c.map_set_pair(cfg3["surf_map"], cfg3["corner_map"])
+        pose2, _ = c.gn_solve(cfg3["p0"], 5, want_stats=False)
+        assert np.array_equal(pose2, pose)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("mode", ["map", "features"])
+def test_config3_sharded_over_4_ranks_2M(mla, orc, cfg3, mode):
+    """config 3 as BASELINE states it: the 2 M map voxel-sharded over 4 ranks (contexts on this GPU, the all-reduce summed by the host): per-iteration
+    matched counts and the 5-GN pose equal the UNSHARDED oracle's, in both partitions"""
+    import importlib
+    shard = importlib.import_module("m-loam_amd.shard")
+    ctxs = _ranks_as_contexts(mla, shard, 4, mode, cfg3["surf_map"], cfg3["corner_map"], cfg3["p0"][:2])
+    try:
+        pose, counts, owned = _sharded_block_gn(mla, ctxs, cfg3["surf"], cfg3["corner"], cfg3["p0"], 5)
+    finally:
+        for c in ctxs:
+            c.close()
+    ref = cfg3["ref"]
+    assert counts == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]]
+    dt, dr = _pose_err(pose, ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+    assert (owned.sum(axis=1) > 0).all()                       # every rank really took part
+
+
+@pytest.fixture(scope="module")
+def cfg4(synth, orc):
+    """BASELINE config 4: 4 x 64 rings against the 4 M-point map; per-LiDAR feature clouds (pose blocks) from the oracle's extraction"""
+    import bench
+    from scipy.spatial.transform import Rotation as Rot
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "4M", n_lidars=4)
+    assert len(surf_map) + len(corner_map) > 4_000_000
+    surf_b, corner_b, poses0, exts = [], [], [], []
+    for i, s in enumerate(scans):
+        ex = orc.extract(s.points, s.scan_start, s.scan_end)
+        cpts = np.zeros((len(ex["less_sharp"]), 4), np.float32)
+        cpts[:, :3] = s.points[ex["less_sharp"]][:, :3]
+        surf_b.append(np.ascontiguousarray(synth.voxel_mean(ex["less_flat_ds"].copy(), 0.4)))
+        corner_b.append(np.ascontiguousarray(synth.voxel_mean(cpts, 0.2)))
+        r = synth.HERCULES_BODY_T_LASER[i]
+        e = np.concatenate([r[4:7], r[:4] / np.linalg.norm(r[:4])])
+        exts.append(e)
+        T = synth.pose_to_mat(gt) @ synth.pose_to_mat(e)
+        gt_i = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        poses0.append(synth.perturbed_pose(gt_i, seed=50 + i, dt=0.1, drot_deg=1.0))
+    return dict(surf_map=surf_map, corner_map=corner_map, gt=gt, surf_b=surf_b, corner_b=corner_b, poses0=np.array(poses0), exts=np.array(exts),
+                oms=orc.Map(surf_map), omc=orc.Map(corner_map))
+
+
+CFG4_K, CFG4_THRE, CFG4_FREEZE = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
+
+
+def _cfg4_refs(orc, cfg4, n_it):
+    refs = []
+    for b in range(4):
+        prm = orc.mapper_params(huber_delta=1.0, map_eig_thre=CFG4_THRE[b], n_neigh=CFG4_K[b], check_fov=True, freeze_when_degenerate=bool(CFG4_FREEZE[b]))
+        refs.append(orc.gn_iterations(cfg4["oms"], cfg4["omc"], cfg4["surf_b"][b], cfg4["corner_b"][b], cfg4["poses0"][b], prm, n_it))
+    return refs
+
+
+def test_config4_pose_blocks_4M(mla, orc, cfg4):
+    """config 4's frame on the 4 M map, ONE context: four pose blocks (N_NEIGH 5 / 10 / 10 / 10, CHECK_FOV, freeze-on-degenerate) in the same launches;
+    every block reproduces the oracle's iterations on its own cloud"""
+    n_it = 3
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(cfg4["surf_map"], cfg4["corner_map"])
+        c.features_set_blocks(mla.SURF, cfg4["surf_b"])
+        c.features_set_blocks(mla.CORNER, cfg4["corner_b"])
+        opts = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+        poses, stats = c.gn_solve_blocks(cfg4["poses0"], n_it, CFG4_K, CFG4_THRE, CFG4_FREEZE, opts)
+    finally:
+        c.close()
+    for b, ref in enumerate(_cfg4_refs(orc, cfg4, n_it)):
+        for it in range(n_it):
+            s, r = stats[it][b], ref["iters"][it]
+            assert (s["n_surf"], s["n_corner"]) == (r["n_surf"], r["n_corner"]), (b, it)
+            assert float(np.abs(s["H"] - r["H"]).max()) <= 1e-9 * max(1.0, float(np.abs(r["H"]).max()))
+            assert s["is_degenerate"] == r["is_degenerate"]
+        assert ref["iters"][0]["n_surf"] + ref["iters"][0]["n_corner"] > 2000, b
+        dt, dr = _pose_err(poses[b], ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
+
+
+@pytest.mark.parametrize("mode", ["map", "features"])
+def test_config4_pose_blocks_over_8_ranks_4M(mla, orc, cfg4, mode):
+    """config 4 as BASELINE states it -- the 4 M map over 8 ranks: every pose block's sharded iteration (8 contexts on this GPU, host all-reduce,
+    the redundant per-rank solve with the block's threshold / freeze policy) equals the unsharded oracle's"""
+    import importlib
+    shard = importlib.import_module("m-loam_amd.shard")
+    n_it = 3
+    refs = _cfg4_refs(orc, cfg4, n_it)
+    ctxs = _ranks_as_contexts(mla, shard, 8, mode, cfg4["surf_map"], cfg4["corner_map"], cfg4["gt"][:2])
+    try:
+        for b in range(4):
+            pose, counts, owned = _sharded_block_gn(mla, ctxs, cfg4["surf_b"][b], cfg4["corner_b"][b], cfg4["poses0"][b], n_it, k_neigh=CFG4_K[b],
+                                                    flags=mla.FLAG_CHECK_FOV, huber_delta=1.0, eig_thre=CFG4_THRE[b], freeze=bool(CFG4_FREEZE[b]))
+            assert counts == [(r["n_surf"], r["n_corner"]) for r in refs[b]["iters"]], b
+            dt, dr = _pose_err(pose, refs[b]["pose"])
+            assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def _cfg4_window(synth, cfg4):
+    from scipy.spatial.transform import Rotation as Rot
+    frame0 = synth.perturbed_pose(cfg4["gt"], seed=70, dt=0.05, drot_deg=0.5)
+    exts0 = np.array([e if i == 0 else synth.perturbed_pose(e, seed=80 + i, dt=0.03, drot_deg=0.3) for i, e in enumerate(cfg4["exts"])])
+    to_pose = lambda T: np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+    rels = [to_pose(synth.pose_to_mat(frame0) @ synth.pose_to_mat(exts0[i])) for i in range(4)]        # T_pivot^-1 T_frame T_ext with T_pivot = I
+    return frame0, exts0, rels
+
+
+def test_config4_coupled_window_4M(mla, orc, synth, cfg4):
+    """config 4 proper on the 4 M map: Estimator::optimizeMap's coupled problem [pivot | 1 frame | 4 extrinsics] = 36 local parameters. The factor table is
+    built ON THE DEVICE from eight match passes against the resident map (mlh_pure_odom_begin / _add_matches, N_NEIGH 5, CHECK_FOV); its J^T J / J^T r /
+    cost equal the oracle's factor-by-factor accumulation over the ORACLE's own matches (1e-9), the coupled Gauss-Newton step with the pivot and the
+    reference extrinsic held constant (estimator.cpp:636, 642) is the same, and so are five coupled iterations."""
+    frame0, exts0, rels = _cfg4_window(synth, cfg4)
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    tab = [[], [], [], [], []]
+    for i in range(4):
+        for ty, ch, om, f in ((0, "s", cfg4["oms"], cfg4["surf_b"][i]), (1, "c", cfg4["omc"], cfg4["corner_b"][i])):
+            v, co = om.match(ch, f, rels[i], n_neigh=5, check_fov=True)
+            m = v.astype(bool)
+            tab[0].append(np.full(m.sum(), ty, np.int32)); tab[1].append(f[m, :3].astype(np.float64)); tab[2].append(co[m])
+            tab[3].append(np.zeros(m.sum(), np.int32)); tab[4].append(np.full(m.sum(), i, np.int32))
+    tab = [np.concatenate(a) for a in tab]
+    assert len(tab[0]) > 20000
+    D = 36
+    free = np.r_[6:12, 18:36]                                     # the frame + extrinsics 1..3
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(cfg4["surf_map"], cfg4["corner_map"])
+        c.pure_odom_begin()
+        for i in range(4):
+            for kind, f in ((mla.SURF, cfg4["surf_b"][i]), (mla.CORNER, cfg4["corner_b"][i])):
+                c.features_set(kind, f)
+                c.pure_odom_add_matches(kind, rels[i], 0, i, k_neigh=5, flags=mla.FLAG_CHECK_FOV)
+        got = c.pure_odom_normal_eq(ident, frame0[None, :], exts0, huber_delta=1.0)
+        ref = orc.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], ident, frame0[None, :], exts0, 1.0)
+        assert got["H"].shape == (D, D) and got["count"] == ref["count"] == len(tab[0])
+        sc = float(np.abs(ref["H"]).max())
+        assert float(np.abs(got["H"] - ref["H"]).max()) <= 1e-9 * sc
+        assert float(np.abs(got["g"] - ref["g"]).max()) <= 1e-9 * float(np.abs(ref["g"]).max())
+        assert abs(got["cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+        step_g = np.linalg.solve(got["H"][np.ix_(free, free)], -got["g"][free])
+        step_r = np.linalg.solve(ref["H"][np.ix_(free, free)], -ref["g"][free])
+        np.testing.assert_allclose(step_g, step_r, rtol=1e-6, atol=1e-9)
+        assert np.linalg.norm(step_r[:3]) > 1e-3
+        # five coupled Gauss-Newton iterations on the fixed table (what ceres::Solve iterates on), device J^T J vs the oracle's
+        def window_gn(neq):
+            fr, ex = frame0.copy()[None, :], exts0.copy()
+            for _ in range(5):
+                ne = neq(fr, ex)
+                step = np.zeros(D); step[free] = np.linalg.solve(ne["H"][np.ix_(free, free)], -ne["g"][free])
+                fr[0] = mla.pose_plus(fr[0], step[6:12])
+                for k in range(1, 4):
+                    ex[k] = mla.pose_plus(ex[k], step[12 + 6 * k:18 + 6 * k])
+            return fr, ex
+        fr_g, ex_g = window_gn(lambda fr, ex: c.pure_odom_normal_eq(ident, fr, ex, huber_delta=1.0))
+        fr_c, ex_c = window_gn(lambda fr, ex: orc.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], ident, fr, ex, 1.0))
+        dt, dr = _pose_err(fr_g[0], fr_c[0])
+        assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+        for k in range(1, 4):
+            dt, dr = _pose_err(ex_g[k], ex_c[k])
+            assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)
+    finally:
+        c.close()
+    # ... and the same system from 8 ranks (replicated map, round-robin ownership; every rank builds its own part of the table on the device):
+    # the summed records are the unsharded system
+    import importlib
+    shard = importlib.import_module("m-loam_amd.shard")
+    ctxs = _ranks_as_contexts(mla, shard, 8, "features", cfg4["surf_map"], cfg4["corner_map"], cfg4["gt"][:2])
+    try:
+        H, g, cost, cnt = np.zeros((D, D)), np.zeros(D), 0.0, 0
+        for cr in ctxs:
+            cr.pure_odom_begin()
+            for i in range(4):
+                for kind, f in ((mla.SURF, cfg4["surf_b"][i]), (mla.CORNER, cfg4["corner_b"][i])):
+                    cr.features_set(kind, f)
+                    cr.pure_odom_add_matches(kind, rels[i], 0, i, k_neigh=5, flags=mla.FLAG_CHECK_FOV)
+            ne = cr.pure_odom_normal_eq(ident, frame0[None, :], exts0, huber_delta=1.0)
+            H += ne["H"]; g += ne["g"]; cost += ne["cost"]; cnt += ne["count"]
+        assert cnt == ref["count"]
+        assert float(np.abs(H - ref["H"]).max()) <= 1e-9 * sc
+        assert float(np.abs(g - ref["g"]).max()) <= 1e-9 * float(np.abs(ref["g"]).max())
+        assert abs(cost - ref["cost"]) <= 1e-9 * ref["cost"]
+    finally:
+        for cr in ctxs:
+            cr.close()
