@@ -126,6 +126,14 @@ int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int in
 int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, const int *scan_start,
                     const int *scan_end, int n_rings, int mem);
 int mlh_extract_run(mlh_ctx *ctx);
+/* The order of EQUAL curvatures inside a sector. The reference sorts a sector's point indices with std::sort and compObject, which compares
+ * cloudCurvature only (feature_extract.cpp:152-162), so among equal values the greedy walks meet the points in whatever order libstdc++'s
+ * introsort leaves them.
+ *   1 (default)  that order: a sector whose sorted curvatures show two equal values (or a NaN) is re-ordered ON THE DEVICE by the library's
+ *                algorithm on the same initial arrangement (m-loam_amd/csrc/stdsort_dev.hpp: the same comparison sequence, hence the same
+ *                permutation); sectors with distinct curvatures -- every sector of ordinary float data -- have one sorted order and pay nothing;
+ *   0            (curvature, index) ascending, NaN curvatures last by index: a total order that does not depend on a standard library. */
+int mlh_set_extract_tie_order(mlh_ctx *ctx, int mode);
 int mlh_extract_fetch(mlh_ctx *ctx, int32_t *label, float *curvature, int32_t *picked, int32_t *idx_out[4], int32_t n_out[4]);
 /* (a3) the per-ring pcl::VoxelGrid(leaf = 0.2 m) extractCloud applies to the less-flat points of every ring
  * (feature_extract.cpp:266-271): run after mlh_extract_run; fetch returns "surf_points_less_flat" as the reference emits it

@@ -619,6 +619,13 @@ int mlh_map_rebuild(mlh_ctx *ctx, int kind)
     return grid_build(ctx, kind == MLH_ALL_KINDS ? 3 : (1 << kind), false);
 }
 
+int mlh_set_extract_tie_order(mlh_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 1) return MLH_ERR_INVALID;
+    ctx->extract_tie_ref = mode;
+    return MLH_OK;
+}
+
 int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return MLH_ERR_INVALID;
@@ -881,7 +888,7 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
                         double *JtJ, double *Jtr, double *cost, int32_t *n_valid)
 {
     if (!ctx || kind < 0 || kind > 1 || !pose) return MLH_ERR_INVALID;
-    if (k_neigh != 5) return fail(ctx, MLH_ERR_UNSUPPORTED, "only N_NEIGH = 5 is implemented");
+    if (k_neigh != 5 && k_neigh != 10) return fail(ctx, MLH_ERR_UNSUPPORTED, "N_NEIGH is 5 (the mapper, the reference LiDAR) or 10 (buildCalibMap's other LiDARs, estimator.cpp:1135)");
     if ((r == nullptr) != (J == nullptr)) return fail(ctx, MLH_ERR_INVALID, "r and J must be requested together");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, 0);
@@ -890,6 +897,7 @@ int mlh_match_linearize(mlh_ctx *ctx, int kind, const double pose[7], int k_neig
     MatchArgs a;
     a.kind_mask = 1 << kind; a.flags = flags; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = huber_delta; a.cov_measurement_trace = cov_measurement_trace; a.dense = (r != nullptr); a.pose_sel = 0;
+    a.k_neigh[0] = k_neigh;
     if ((rc = match_launch(ctx, a))) return rc;
     if ((rc = reduce_only_launch(ctx, 0))) return rc;
     return fetch_dense_and_reduced(ctx, kind, true, valid, coeffs, r, J, JtJ, Jtr, cost, n_valid);

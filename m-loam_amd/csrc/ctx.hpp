@@ -165,6 +165,7 @@ struct ScanBuf {
     DevBuf lists[4];
     DevBuf totals;         // 4 ints
     DevBuf vox_stage, vox_out, ring_vox;   // per-ring VoxelGrid of the less-flat points
+    DevBuf tie_scratch;                    // label kernel: std::sort scratch of sectors with equal curvatures when it does not fit LDS
     DevBuf vox_keys, vox_perm;             // its voxel indices in list order and the order std::sort leaves them in (reference member order)
     bool voxelised = false;
     int n = 0, n_rings = 0;
@@ -271,6 +272,7 @@ struct mlh_ctx {
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
+    int extract_tie_ref = 1;           // extractCloud, equal curvatures inside a sector: 1 = the order the reference's std::sort call leaves (default), 0 = (curvature, index)
     int vox_member_order = 1;          // voxel filters, members of a voxel: 1 = in the order libstdc++'s std::sort leaves them (the reference's), produced on the device
                                        // (stdsort.hip); 2 = the same through a host pass that calls the platform's own std::sort; 0 = in point-index order
     mlh::DevBuf stdsort;               // scratch of device_std_sort_by_key

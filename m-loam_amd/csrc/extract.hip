@@ -14,6 +14,7 @@
 //                     the list sizes of the rings before it); less-flat = positions with label <= 0 (cpp:258-264), stream-compacted.
 #include "ctx.hpp"
 #include "sort_dev.hpp"
+#include "stdsort_dev.hpp"
 #include <algorithm>
 
 namespace mlh {
@@ -66,6 +67,9 @@ struct LabelArgs {
     int *stage;         // [ring][STAGE_STRIDE]
     int *ring_counts;   // [ring][4]
     int n, max_span, sort_p;
+    int tie_ref;        // 1: a sector whose curvatures are not all distinct is ordered as the reference's std::sort call leaves it (feature_extract.cpp:162)
+    int tie_words;      // ints of std::sort scratch per sector: 5 * sort_p + sort_p / 32 + 2 + 128
+    int *tie_scratch;   // [ring][6][tie_words] in HBM when the scratch does not fit the LDS budget (4000-column rings), else null
 };
 
 // gap test of the suppression loops (cpp:192-213): squared distance between consecutive points > 0.05 (double literal)
@@ -100,6 +104,36 @@ __device__ __forceinline__ void sort_sector(const float *sc, int sp, int len, un
     for (int r = 0; r < KPL; ++r) kj[lane * KPL + r] = v[r];
 }
 
+// The reference sorts a sector's indices with std::sort and a comparator that sees the curvature only (feature_extract.cpp:152-162,
+// feature_extract.hpp: compObject): among EQUAL curvatures the order is whatever libstdc++'s introsort leaves, and the greedy walks consume
+// that order. A sector whose curvatures are all distinct has one sorted order, which the bitonic network above has produced; only when the
+// sorted keys show two equal curvatures (or a NaN, which compares false against everything and makes the comparator inconsistent) is the
+// library's algorithm run on the sector's ORIGINAL arrangement (indices ascending) by this wavefront -- stdsort_dev.hpp: same comparison
+// sequence, same permutation -- and its result replaces the list. Returns true when the list may not be sorted any more (NaN present: the
+// walks then must not stop at the first candidate that fails the curvature test, exactly as the reference's loops do not).
+__device__ __forceinline__ bool reference_tie_order(const float *sc, int sp, int len, unsigned long long *kj, int *tie, int P, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    bool tie_here = false, nan_here = false;
+    for (int k = lane; k < len; k += 64) {
+        const unsigned hi = unsigned(kj[k] >> 32);
+        if (k + 1 < len && hi == unsigned(kj[k + 1] >> 32)) tie_here = true;
+        if (hi == 0x7fc00000u) nan_here = true;
+    }
+    const bool has_nan = __ballot(nan_here) != 0ull;
+    if (__ballot(tie_here) == 0ull && !has_nan) return false;
+    int *keys = tie, *vals = tie + P, *lt = tie + 2 * P, *rt = tie + 3 * P, *stk = tie + 4 * P;
+    unsigned *bits = reinterpret_cast<unsigned *>(tie + 5 * P);
+    int *scr = tie + 5 * P + P / 32 + 2;                      // the stop tables of a partition that fits one 64-wide tile
+    for (int k = lane; k < len; k += 64) { keys[k] = __float_as_int(sc[sp + k]); vals[k] = sp + k; }
+    ss_wg_fence();
+    ss_wave_std_sort(keys, vals, lt, rt, stk, bits, scr, len, !has_nan, FloatBitsLess());
+    for (int k = lane; k < len; k += 64) kj[k] = ((unsigned long long)(unsigned)keys[k] << 32) | (unsigned)vals[k];
+    ss_wg_fence();
+    return has_nan;
+}
+
 // Suppression of a pick's +-5 neighbours (cpp:192-213, 233-254): how far the marks reach (nf forwards, nb backwards: up to the first
 // consecutive-point gap > 0.05, at most 5) depends only on the geometry, so it is tabulated for every position of the ring before
 // the walks (sext[t] = nf | nb << 4); a candidate lane brings its entry along and a pick costs no LDS read at all.
@@ -110,7 +144,7 @@ __device__ __forceinline__ void sort_sector(const float *sc, int sp, int len, un
 // on either side) go to spill[0..4] (hi+1 .. hi+5) and spill[5..9] (lo-1 .. lo-5) -- the caller decides when they take effect.
 struct SectorPicks { int npick, my_pick, nfl, my_flat; };
 __device__ __forceinline__ SectorPicks walk_sector(const unsigned long long *kj, int len, const float *sc, const unsigned char *sext,
-                                                   int *spicked, int lo, int hi, unsigned char *spill, int lane)
+                                                   int *spicked, int lo, int hi, unsigned char *spill, int lane, bool sorted)
 {
     const int off = lane - 5;                                  // lanes 0..10 cover the positions sel-5 .. sel+5
     SectorPicks R;
@@ -146,7 +180,7 @@ __device__ __forceinline__ SectorPicks walk_sector(const unsigned long long *kj,
         // at the top of the order and fail the test without saying anything about what follows: they are walked past, as the reference's
         // loop walks past every candidate that does not qualify (cpp:166-215 has no early exit but the 21st pick)
         const float cv = sc[li];
-        if (__ballot((k >= 0) && !c_ok && !(cv != cv)) != 0ull) stop = true;
+        if (sorted && __ballot((k >= 0) && !c_ok && !(cv != cv)) != 0ull) stop = true;
     }
     R.npick = npick; R.my_pick = my_pick;
     // ---- flat walk, ascending curvature (cpp:219-256): 4 picks; the 4th is labelled but neither marked nor suppressing
@@ -178,7 +212,7 @@ __device__ __forceinline__ SectorPicks walk_sector(const unsigned long long *kj,
         }
         __builtin_amdgcn_wave_barrier();
         const unsigned long long inb = __ballot(k < len);
-        if (__ballot(c_ok) != inb) stop = true;
+        if (sorted && __ballot(c_ok) != inb) stop = true;
     }
     R.nfl = nfl; R.my_flat = my_flat;
     return R;
@@ -207,8 +241,10 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(slabel + A.max_span + ((A.max_span & 1) ? 1 : 0));
     unsigned *sgap = reinterpret_cast<unsigned *>(keys + 6 * size_t(P));     // gap bits, (max_span + 64 + 383) / 32 + 4 words
     unsigned char *sext = reinterpret_cast<unsigned char *>(sgap + (A.max_span + 64 + 383) / 32 + 4);   // suppression extents, max_span bytes
+    int *s_tie = reinterpret_cast<int *>(sext + ((A.max_span + 15) & ~15));      // std::sort scratch of the six sectors (when it fits: tie_scratch == null)
     __shared__ int s_stage[STAGE_STRIDE];
     __shared__ int s_cnt[4];
+    __shared__ int s_unsorted[6];
 
     for (int t = threadIdx.x; t < span; t += LTPB) {
         float4 p = A.pts[g0 + t];
@@ -263,6 +299,12 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
         case 16: sort_sector<16>(sc, sp[wave], len, kj, lane); break;
         default: sort_sector<32>(sc, sp[wave], len, kj, lane); break;
         }
+        bool unsorted = false;
+        if (A.tie_ref) {
+            int *tie = A.tie_scratch ? A.tie_scratch + (size_t(ring) * 6 + wave) * A.tie_words : s_tie + wave * A.tie_words;
+            unsorted = reference_tie_order(sc, sp[wave], len, kj, tie, P, lane);
+        }
+        if (lane == 0) s_unsorted[wave] = unsorted ? 1 : 0;
     }
     __syncthreads();
     MLH_LSTAGE(3);
@@ -282,7 +324,7 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
         const int lo = sp[wave], hi = ep[wave];
         const unsigned long long *kj = keys + wave * P;
         unsigned char *spill = s_spill + wave * 10;
-        SectorPicks pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane);
+        SectorPicks pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane, !s_unsorted[wave]);
         for (int round = 1; round < 6; ++round) {
             __syncthreads();                               // sector round-1 is final
             if (wave == round) {
@@ -299,7 +341,7 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
                     if (lane < 5 && ((inc >> lane) & 1)) spicked[lo + lane] = 1;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
-                    pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane);
+                    pk = walk_sector(kj, hi - lo + 1, sc, sext, spicked, lo, hi, spill, lane, !s_unsorted[wave]);
                 }
             }
         }
@@ -325,7 +367,7 @@ __global__ __launch_bounds__(LTPB) void label_kernel(LabelArgs A)
         const int lane = threadIdx.x;
         int n_sharp = 0, n_less = 0, n_flat = 0;
         for (int j = 0; j < 6; ++j) {
-            const SectorPicks pk = walk_sector(keys + j * P, ep[j] - sp[j] + 1, sc, sext, spicked, 0, span - 1, s_spill, lane);
+            const SectorPicks pk = walk_sector(keys + j * P, ep[j] - sp[j] + 1, sc, sext, spicked, 0, span - 1, s_spill, lane, !s_unsorted[j]);
             if (lane < pk.npick) {
                 slabel[pk.my_pick] = (lane < 2) ? 2 : 1;
                 if (lane < 2) s_stage[n_sharp + lane] = pk.my_pick + g0;
@@ -460,10 +502,21 @@ int extract_run(mlh_ctx *ctx)
     int max_sector = (sb.max_ring_len + 5) / 6 + 1;
     int P = 64;
     while (P < max_sector) P <<= 1;
-    const size_t lds = sizeof(float) * 4 * size_t(max_span) + sizeof(int) * 2 * size_t(max_span) + 8 + sizeof(unsigned long long) * 6 * size_t(P) +
+    size_t lds = sizeof(float) * 4 * size_t(max_span) + sizeof(int) * 2 * size_t(max_span) + 8 + sizeof(unsigned long long) * 6 * size_t(P) +
                        sizeof(unsigned) * (size_t(max_span + 64 + 383) / 32 + 4) + size_t(max_span) + 16;
     if (lds > 160 * 1024 - 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring too long for the LDS-resident label kernel");
     if (P > 2048) return fail(ctx, MLH_ERR_UNSUPPORTED, "sector longer than 2048 points");      // before anything is enqueued or bracketed
+    // scratch of the reference-order pass (only touched by sectors with equal curvatures): in LDS behind the extents when it fits, else in HBM
+    const int tie_words = 5 * P + P / 32 + 2 + 128;
+    int *tie_scratch = nullptr;
+    if (ctx->extract_tie_ref) {
+        const size_t lds_tie = ((lds + 15) & ~size_t(15)) + 16 + sizeof(int) * 6 * size_t(tie_words);
+        if (lds_tie <= 160 * 1024 - 1024) lds = lds_tie;
+        else {
+            MLH_HIP(ctx, sb.tie_scratch.ensure(sizeof(int) * 6 * size_t(tie_words) * size_t(R)));
+            tie_scratch = sb.tie_scratch.as<int>();
+        }
+    }
     MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(label_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 
     prof_begin(ctx, MLH_K_EXTRACT);
@@ -473,6 +526,7 @@ int extract_run(mlh_ctx *ctx)
     la.pts = sb.pts.as<float4>(); la.curv = sb.curvature.as<float>(); la.start = sb.start.as<int>(); la.end = sb.end.as<int>();
     la.label = sb.label.as<int>(); la.picked = sb.picked.as<int>(); la.stage = sb.stage.as<int>(); la.ring_counts = sb.ring_counts.as<int>();
     la.n = n; la.max_span = max_span; la.sort_p = P;
+    la.tie_ref = ctx->extract_tie_ref ? 1 : 0; la.tie_words = tie_words; la.tie_scratch = tie_scratch;
     hipLaunchKernelGGL(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
     EmitArgs ea;
     ea.start = sb.start.as<int>(); ea.end = sb.end.as<int>(); ea.label = sb.label.as<int>(); ea.stage = sb.stage.as<int>();

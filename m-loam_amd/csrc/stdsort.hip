@@ -34,13 +34,13 @@
 // tests: tests/test_gpu_parity.py::test_device_std_sort_equals_std_sort (against the library's own std::sort: duplicates, the patterns that
 // exhaust the depth budget, sizes around every threshold); the voxel-filter parity tests run on top of it.
 #include "ctx.hpp"
+#include "stdsort_dev.hpp"
 #include <climits>
 
 namespace mlh {
 
 namespace {
 
-constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
 constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
 constexpr int SS_BIG_WG = 1024;
 constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
@@ -67,8 +67,7 @@ struct StdSortArgs {
 constexpr int SS_CNT_LEAF = SS_BIG_LEVELS + 1;
 constexpr int SS_CNT = SS_BIG_LEVELS + 2;
 
-__device__ inline int floor_log2(int n) { return 31 - __clz(n); }
-__device__ inline unsigned long long lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+__device__ inline int floor_log2(int n) { return ss_floor_log2(n); }
 
 __device__ inline void emit_global(const StdSortArgs &A, int first, int last, int depth, SortSeg *next, int *next_cnt)
 {
@@ -103,114 +102,18 @@ __global__ __launch_bounds__(256) void stdsort_init_segments_kernel(StdSortArgs 
     }
 }
 
-__device__ inline void swap_elem(int *keys, int *vals, int p, int q)
-{
-    const int kp = keys[p], kq = keys[q], vp = vals[p], vq = vals[q];
-    keys[p] = kq; keys[q] = kp; vals[p] = vq; vals[q] = vp;
-}
-
-// __move_median_to_first(first, first + 1, mid, last - 1) on the range [f, l)
-__device__ inline void median_to_first(int *keys, int *vals, int f, int l)
-{
-    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
-    const int ka = keys[ia], kb = keys[ib], kc = keys[ic];
-    int med;
-    if (ka < kb) med = (kb < kc) ? ib : ((ka < kc) ? ic : ia);
-    else med = (ka < kc) ? ia : ((kb < kc) ? ic : ib);
-    swap_elem(keys, vals, f, med);
-}
-
-// bits/stl_heap.h on (keys, vals): __adjust_heap with its trailing __push_heap, __make_heap, __sort_heap -- one thread, as written
-__device__ void heap_adjust(int *k, int *v, int hole, int len, int key, int val)
-{
-    const int top = hole;
-    int c = hole;
-    while (c < (len - 1) / 2) {
-        c = 2 * (c + 1);
-        if (k[c] < k[c - 1]) c--;
-        k[hole] = k[c]; v[hole] = v[c];
-        hole = c;
-    }
-    if ((len & 1) == 0 && c == (len - 2) / 2) {
-        c = 2 * (c + 1);
-        k[hole] = k[c - 1]; v[hole] = v[c - 1];
-        hole = c - 1;
-    }
-    int parent = (hole - 1) / 2;
-    while (hole > top && k[parent] < key) {
-        k[hole] = k[parent]; v[hole] = v[parent];
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    k[hole] = key; v[hole] = val;
-}
-
-__device__ void heap_sort_range(int *k, int *v, int len)
-{
-    if (len >= 2) {
-        int parent = (len - 2) / 2;
-        while (true) {
-            heap_adjust(k, v, parent, len, k[parent], v[parent]);
-            if (parent == 0) break;
-            parent--;
-        }
-    }
-    int last = len;
-    while (last > 1) {
-        --last;
-        const int key = k[last], val = v[last];
-        k[last] = k[0]; v[last] = v[0];
-        heap_adjust(k, v, 0, last, key, val);
-    }
-}
-
-// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first.
-// count pass: the number of left / right stops in [lo, hi).
+// the comparator of the voxel filters: int voxel slots (stdsort_dev.hpp holds the pieces shared with extract.hip's per-sector sort)
+__device__ inline void median_to_first(int *keys, int *vals, int f, int l) { ss_median_to_first(keys, vals, f, l, IntLess()); }
+__device__ inline void heap_sort_range(int *k, int *v, int len) { ss_heap_sort_range(k, v, len, IntLess()); }
 template <int SS_U>
 __device__ inline void wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right)
 {
-    const int lane = threadIdx.x & 63;
-    int cl = 0, cr = 0;
-    for (int base = lo; base < hi; base += 64 * SS_U) {
-        int k[SS_U];
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) {
-            const int p = base + 64 * u + lane;
-            const bool in = p < hi;
-            cl += __popcll(__ballot(in && p > f && !(k[u] < piv)));
-            cr += __popcll(__ballot(in && (p == f || !(piv < k[u]))));
-        }
-    }
-    n_left = cl; n_right = cr;
+    ss_wave_count_stops<SS_U>(keys, f, lo, hi, piv, n_left, n_right, IntLess());
 }
-
-// table pass: left stops get ranks rank_l0, rank_l0 + 1, ... in ascending position; right stops ranks counted from the right:
-// a stop at p has rank (right stops of the whole range at positions > p) = after_r + (stops of [lo, hi) at positions > p)
 template <int SS_U>
 __device__ inline void wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here)
 {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = lanes_below();
-    int run_l = rank_l0, run_r = 0;
-    for (int base = lo; base < hi; base += 64 * SS_U) {
-        int k[SS_U];
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) {
-            const int p = base + 64 * u + lane;
-            const bool in = p < hi;
-            const bool is_l = in && p > f && !(k[u] < piv);
-            const bool is_r = in && (p == f || !(piv < k[u]));
-            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
-            if (is_l) lt[f + run_l + __popcll(ml & below)] = p;
-            if (is_r) rt[f + after_r + (n_right_here - (run_r + __popcll(mr & below) + 1))] = p;
-            run_l += __popcll(ml);
-            run_r += __popcll(mr);
-        }
-    }
+    ss_wave_write_tables<SS_U>(keys, lt, rt, f, lo, hi, piv, rank_l0, after_r, n_right_here, IntLess());
 }
 
 // ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF
@@ -293,7 +196,7 @@ enum { LQ_TAIL = 0, LQ_HEAD = 1, LQ_REMAINING = 2, LQ_NFIN = 3 };
 
 __device__ inline int wg_load(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+__device__ inline void wg_fence() { ss_wg_fence(); }
 
 __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh, int *err)
 {
@@ -334,62 +237,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             have = false;
             continue;
         }
-        int cut;
-        if (size <= 64) {
-            // the whole range in one tile: element f + lane in lane's registers, median and pivot through lane shuffles, the two stop
-            // tables (64 entries each) in the wavefront's own scratch, the swaps as one shuffle -- same pairs, same cut
-            int *sl = M.scr + (t >> 6) * 128, *sr = sl + 64;
-            const bool in = lane < size;
-            int key = in ? M.keys[f + lane] : INT_MAX, val = in ? M.vals[f + lane] : 0;
-            const int ia = 1, ib = size / 2, ic = size - 1;
-            const int ka = __shfl(key, ia), kb = __shfl(key, ib), kc = __shfl(key, ic);
-            int med;
-            if (ka < kb) med = (kb < kc) ? ib : ((ka < kc) ? ic : ia);
-            else med = (ka < kc) ? ia : ((kb < kc) ? ic : ib);
-            const int k0 = __shfl(key, 0), v0 = __shfl(val, 0), km = __shfl(key, med), vm = __shfl(val, med);
-            if (lane == 0) { key = km; val = vm; } else if (lane == med) { key = k0; val = v0; }
-            const int piv = km;
-            const bool is_l = in && lane > 0 && !(key < piv);
-            const bool is_r = in && (lane == 0 || !(piv < key));
-            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
-            const int nL = __popcll(ml), nR = __popcll(mr);
-            const int rank_l = __popcll(ml & lanes_below()), rank_r = __popcll((mr >> lane) >> 1);
-            if (is_l) sl[rank_l] = lane;
-            if (is_r) sr[rank_r] = lane;
-            wg_fence();
-            const int npair = min(nL, nR);
-            const int partner = (is_l && rank_l < npair) ? sr[rank_l] : -1;
-            const int K = __popcll(__ballot(lane < partner));          // true for a prefix of the left ranks
-            int src = lane;
-            if (is_l && rank_l < K) src = partner;
-            else if (is_r && rank_r < K) src = sl[rank_r];
-            const int nk = __shfl(key, src), nv = __shfl(val, src);
-            int c = INT_MAX;
-            if (K < nL) c = min(c, sl[K]);
-            if (K > 0) c = min(c, sr[K - 1]);
-            if (in) { M.keys[f + lane] = nk; M.vals[f + lane] = nv; }
-            cut = f + c;
-            wg_fence();
-        } else {
-            if (lane == 0) median_to_first(M.keys, M.vals, f, l);
-            wg_fence();
-            const int piv = M.keys[f];
-            int nL, nR;
-            wave_count_stops<4>(M.keys, f, f, l, piv, nL, nR);
-            wave_write_tables<4>(M.keys, M.lt, M.rt, f, f, l, piv, 0, 0, nR);
-            wg_fence();
-            const int npair = min(nL, nR);
-            int K = 0;
-            for (int base = 0; base < npair; base += 64) {
-                const int k = base + lane;
-                K += __popcll(__ballot(k < npair && M.lt[f + k] < M.rt[f + k]));
-            }
-            for (int k = lane; k < K; k += 64) swap_elem(M.keys, M.vals, M.lt[f + k], M.rt[f + k]);
-            cut = INT_MAX;
-            if (K < nL) cut = min(cut, M.lt[f + K]);
-            if (K > 0) cut = min(cut, M.rt[f + K - 1]);
-            wg_fence();
-        }
+        const int cut = ss_wave_partition(M.keys, M.vals, M.lt, M.rt, M.scr + (t >> 6) * 128, f, l, IntLess());
         // children: [cut, l) is the library's recursive call, [f, cut) its loop's next trip; both get d - 1
         const int size_a = cut - f, size_b = l - cut;
         const bool big_a = size_a > SS_THRESHOLD, big_b = size_b > SS_THRESHOLD;

@@ -1,0 +1,281 @@
+// Building blocks of libstdc++'s std::sort restated for wavefronts (bits/stl_algo.h, bits/stl_heap.h), shared by stdsort.hip (the voxel
+// filters' member order: whole clouds, many workgroups) and extract.hip (extractCloud's per-sector sort, feature_extract.cpp:162: one
+// wavefront per sector inside the label kernel). Everything is a template over the comparator, because the permutation std::sort leaves
+// among EQUIVALENT elements is a property of the comparison sequence: the voxel filters compare int voxel indices, extractCloud compares
+// f32 curvatures (where a NaN compares false against everything -- reproduced, not avoided).
+//
+// The argument why a Hoare partition can be done by a wavefront at once is in stdsort.hip's header: it is a function of the two stop
+// lists of the ORIGINAL arrangement (left-scan stops ascending, right-scan stops descending with `first` as the sentinel), the k-th of
+// one swapped with the k-th of the other while they have not crossed. That holds for any comparator under which the sequential scans
+// stay inside the range, consistent or not.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+
+namespace mlh {
+
+constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
+
+struct IntLess { __device__ __forceinline__ bool operator()(int a, int b) const { return a < b; } };
+// keys are f32 bit patterns compared AS FLOATS (CompObject: cloudCurvature[i] < cloudCurvature[j], feature_extract.hpp)
+struct FloatBitsLess { __device__ __forceinline__ bool operator()(int a, int b) const { return __int_as_float(a) < __int_as_float(b); } };
+
+__device__ inline int ss_floor_log2(int n) { return 31 - __clz(n); }
+__device__ inline unsigned long long ss_lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+__device__ inline void ss_wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+__device__ inline void ss_swap_elem(int *keys, int *vals, int p, int q)
+{
+    const int kp = keys[p], kq = keys[q], vp = vals[p], vq = vals[q];
+    keys[p] = kq; keys[q] = kp; vals[p] = vq; vals[q] = vp;
+}
+
+// __move_median_to_first(first, first + 1, mid, last - 1) on the range [f, l)
+template <typename Less>
+__device__ inline void ss_median_to_first(int *keys, int *vals, int f, int l, Less less)
+{
+    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+    const int ka = keys[ia], kb = keys[ib], kc = keys[ic];
+    int med;
+    if (less(ka, kb)) med = less(kb, kc) ? ib : (less(ka, kc) ? ic : ia);
+    else med = less(ka, kc) ? ia : (less(kb, kc) ? ic : ib);
+    ss_swap_elem(keys, vals, f, med);
+}
+
+// bits/stl_heap.h on (keys, vals): __adjust_heap with its trailing __push_heap, __make_heap, __sort_heap -- one thread, as written
+template <typename Less>
+__device__ void ss_heap_adjust(int *k, int *v, int hole, int len, int key, int val, Less less)
+{
+    const int top = hole;
+    int c = hole;
+    while (c < (len - 1) / 2) {
+        c = 2 * (c + 1);
+        if (less(k[c], k[c - 1])) c--;
+        k[hole] = k[c]; v[hole] = v[c];
+        hole = c;
+    }
+    if ((len & 1) == 0 && c == (len - 2) / 2) {
+        c = 2 * (c + 1);
+        k[hole] = k[c - 1]; v[hole] = v[c - 1];
+        hole = c - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && less(k[parent], key)) {
+        k[hole] = k[parent]; v[hole] = v[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    k[hole] = key; v[hole] = val;
+}
+
+template <typename Less>
+__device__ void ss_heap_sort_range(int *k, int *v, int len, Less less)
+{
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            ss_heap_adjust(k, v, parent, len, k[parent], v[parent], less);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int last = len;
+    while (last > 1) {
+        --last;
+        const int key = k[last], val = v[last];
+        k[last] = k[0]; v[last] = v[0];
+        ss_heap_adjust(k, v, 0, last, key, val, less);
+    }
+}
+
+// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first.
+// count pass: the number of left / right stops in [lo, hi).
+template <int SS_U, typename Less>
+__device__ inline void ss_wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    int cl = 0, cr = 0;
+    for (int base = lo; base < hi; base += 64 * SS_U) {
+        int k[SS_U];
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < hi;
+            cl += __popcll(__ballot(in && p > f && !less(k[u], piv)));
+            cr += __popcll(__ballot(in && (p == f || !less(piv, k[u]))));
+        }
+    }
+    n_left = cl; n_right = cr;
+}
+
+// table pass: left stops get ranks rank_l0, rank_l0 + 1, ... in ascending position; right stops ranks counted from the right:
+// a stop at p has rank (right stops of the whole range at positions > p) = after_r + (stops of [lo, hi) at positions > p)
+template <int SS_U, typename Less>
+__device__ inline void ss_wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = ss_lanes_below();
+    int run_l = rank_l0, run_r = 0;
+    for (int base = lo; base < hi; base += 64 * SS_U) {
+        int k[SS_U];
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < hi;
+            const bool is_l = in && p > f && !less(k[u], piv);
+            const bool is_r = in && (p == f || !less(piv, k[u]));
+            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+            if (is_l) lt[f + run_l + __popcll(ml & below)] = p;
+            if (is_r) rt[f + after_r + (n_right_here - (run_r + __popcll(mr & below) + 1))] = p;
+            run_l += __popcll(ml);
+            run_r += __popcll(mr);
+        }
+    }
+}
+
+// __unguarded_partition_pivot of the range [f, l), 16 < l - f, by ONE wavefront (all 64 lanes converged); returns the cut.
+// size <= 64: the whole range in one tile -- element f + lane in lane's registers, median and pivot through lane shuffles, the two stop tables
+// (64 entries each) in `scr` (128 ints of LDS owned by this wavefront), the swaps as one shuffle; otherwise the streaming passes above with the
+// tables at [f, ...) of lt / rt. Same pairs, same cut as the sequential loop.
+template <typename Less>
+__device__ __forceinline__ int ss_wave_partition(int *keys, int *vals, int *lt, int *rt, int *scr, int f, int l, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    const int size = l - f;
+    int cut;
+    if (size <= 64) {
+        int *sl = scr, *sr = scr + 64;
+        const bool in = lane < size;
+        int key = in ? keys[f + lane] : 0, val = in ? vals[f + lane] : 0;
+        const int ia = 1, ib = size / 2, ic = size - 1;
+        const int ka = __shfl(key, ia), kb = __shfl(key, ib), kc = __shfl(key, ic);
+        int med;
+        if (less(ka, kb)) med = less(kb, kc) ? ib : (less(ka, kc) ? ic : ia);
+        else med = less(ka, kc) ? ia : (less(kb, kc) ? ic : ib);
+        const int k0 = __shfl(key, 0), v0 = __shfl(val, 0), km = __shfl(key, med), vm = __shfl(val, med);
+        if (lane == 0) { key = km; val = vm; } else if (lane == med) { key = k0; val = v0; }
+        const int piv = km;
+        const bool is_l = in && lane > 0 && !less(key, piv);
+        const bool is_r = in && (lane == 0 || !less(piv, key));
+        const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+        const int nL = __popcll(ml), nR = __popcll(mr);
+        const int rank_l = __popcll(ml & ss_lanes_below()), rank_r = __popcll((mr >> lane) >> 1);
+        if (is_l) sl[rank_l] = lane;
+        if (is_r) sr[rank_r] = lane;
+        ss_wg_fence();
+        const int npair = min(nL, nR);
+        const int partner = (is_l && rank_l < npair) ? sr[rank_l] : -1;
+        const int K = __popcll(__ballot(lane < partner));          // true for a prefix of the left ranks
+        int src = lane;
+        if (is_l && rank_l < K) src = partner;
+        else if (is_r && rank_r < K) src = sl[rank_r];
+        const int nk = __shfl(key, src), nv = __shfl(val, src);
+        int c = INT_MAX;
+        if (K < nL) c = min(c, sl[K]);
+        if (K > 0) c = min(c, sr[K - 1]);
+        if (in) { keys[f + lane] = nk; vals[f + lane] = nv; }
+        cut = f + c;
+        ss_wg_fence();
+    } else {
+        if (lane == 0) ss_median_to_first(keys, vals, f, l, less);
+        ss_wg_fence();
+        const int piv = keys[f];
+        int nL, nR;
+        ss_wave_count_stops<4>(keys, f, f, l, piv, nL, nR, less);
+        ss_wave_write_tables<4>(keys, lt, rt, f, f, l, piv, 0, 0, nR, less);
+        ss_wg_fence();
+        const int npair = min(nL, nR);
+        int K = 0;
+        for (int base = 0; base < npair; base += 64) {
+            const int k = base + lane;
+            K += __popcll(__ballot(k < npair && lt[f + k] < rt[f + k]));
+        }
+        for (int k = lane; k < K; k += 64) ss_swap_elem(keys, vals, lt[f + k], rt[f + k]);
+        cut = INT_MAX;
+        if (K < nL) cut = min(cut, lt[f + K]);
+        if (K > 0) cut = min(cut, rt[f + K - 1]);
+        ss_wg_fence();
+    }
+    return cut;
+}
+
+// std::sort(keys, keys + n, less) with `vals` carried along, by ONE wavefront (all 64 lanes converged, n >= 0).
+//   keys, vals, lt, rt : n ints each (LDS or global);  stk : 3 * (n / 17 + 2) ints -- the ranges the recursion still owes;
+//   bits : (n + 31) / 32 + 1 words -- one bit per position, set where a range the loop has finished with starts;  scr : 128 ints of LDS.
+// The introsort loop runs range by range (the ranges are disjoint, so their order does not matter): partition, push the right part (the
+// library's recursive call) if it is longer than 16, go on with the left part (the loop's next trip), both with the depth budget minus one;
+// a range whose budget is used up is heap-sorted by one lane. What the loop leaves is finished by the insertion pass:
+//   consistent (a strict weak order on these keys: no NaN among them): an element never moves across the bounds of the ranges the loop
+//     left, and the pass is stable inside one -- every range is insertion-sorted by a lane of its own;
+//   otherwise: the library's own sequence, by one lane -- __insertion_sort on the first 16, __unguarded_insertion_sort on the rest (with NaNs
+//     in play elements DO cross those bounds). The unguarded scan is given a guard at position 0, where the library would walk out of the range.
+template <typename Less>
+__device__ __forceinline__ void ss_wave_std_sort(int *keys, int *vals, int *lt, int *rt, int *stk, unsigned *bits, int *scr, int n, bool consistent, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    if (n < 2) return;
+    for (int w = lane; w < (n + 31) / 32 + 1; w += 64) bits[w] = 0u;
+    ss_wg_fence();
+    int f = 0, l = n, d = 2 * ss_floor_log2(n), top = 0;
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (top == 0) break;
+            --top;
+            f = stk[3 * top]; l = stk[3 * top + 1]; d = stk[3 * top + 2];
+            have = true;
+        }
+        if (l - f <= SS_THRESHOLD) {                                   // finished by the loop: a range of the insertion pass
+            if (lane == 0 && l > f) atomicOr(&bits[f >> 5], 1u << (f & 31));
+            have = false;
+            continue;
+        }
+        if (d == 0) {                                                  // __partial_sort(first, last, last): sorted for good
+            if (lane == 0) { ss_heap_sort_range(keys + f, vals + f, l - f, less); atomicOr(&bits[f >> 5], 1u << (f & 31)); }
+            ss_wg_fence();
+            have = false;
+            continue;
+        }
+        const int cut = ss_wave_partition(keys, vals, lt, rt, scr, f, l, less);
+        --d;
+        if (l - cut > SS_THRESHOLD) {
+            if (lane == 0) { stk[3 * top] = cut; stk[3 * top + 1] = l; stk[3 * top + 2] = d; }
+            ++top;
+            ss_wg_fence();
+        } else if (lane == 0 && l > cut) atomicOr(&bits[cut >> 5], 1u << (cut & 31));
+        l = cut;
+    }
+    ss_wg_fence();
+    if (consistent) {
+        for (int p = lane; p < n; p += 64) {
+            if (!((bits[p >> 5] >> (p & 31)) & 1u)) continue;
+            int e = p + 1;
+            while (e < n && !((bits[e >> 5] >> (e & 31)) & 1u)) ++e;
+            for (int q = p + 1; q < e; ++q) {
+                const int key = keys[q], val = vals[q];
+                int j = q;
+                while (j > p && less(key, keys[j - 1])) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
+                keys[j] = key; vals[j] = val;
+            }
+        }
+    } else if (lane == 0) {
+        const int head = min(n, SS_THRESHOLD);
+        for (int q = 1; q < n; ++q) {
+            const int key = keys[q], val = vals[q];
+            int j = q;
+            if (q < head && less(key, keys[0])) {                      // __insertion_sort: move_backward + put in front
+                for (; j > 0; --j) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; }
+            } else {
+                while (j > 0 && less(key, keys[j - 1])) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
+            }
+            keys[j] = key; vals[j] = val;
+        }
+    }
+    ss_wg_fence();
+}
+
+}  // namespace mlh

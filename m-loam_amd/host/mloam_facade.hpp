@@ -984,6 +984,8 @@ private:
 // (mode 1); mode 2 = the same through a host pass with the platform's own std::sort; false / mode 0 walks members by point index
 // instead (cheaper, ids of mixed voxels may differ)
 inline void setVoxelMemberOrderAsReference(Device &dev, bool on) { dev.check(mlh_set_voxel_member_order(dev.ctx(), on ? 1 : 0)); }
+// extractCloud's order among equal curvatures: the reference's (std::sort, default) or (curvature, index)
+inline void setExtractTieOrderAsReference(Device &dev, bool on) { dev.check(mlh_set_extract_tie_order(dev.ctx(), on ? 1 : 0)); }
 inline void setVoxelMemberOrderMode(Device &dev, int mode) { dev.check(mlh_set_voxel_member_order(dev.ctx(), mode)); }
 
 // ------------------------------------------------------------------ scan2MapOptimization() (gf_method "wo_gf")

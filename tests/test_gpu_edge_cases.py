@@ -252,22 +252,63 @@ def _quantised_scan(case16):
 
 
 def test_extract_with_exact_curvature_ties(mla, orc, case16):
-    """extractCloud on quantised data. The reference's comparator leaves the order of equal curvatures to std::sort; the documented rule
-    here is (curvature, index) ascending, and oracle (tie_rule=1) == HIP kernel on it, bit for bit."""
+    """extractCloud on quantised data ("feature labels bit-exact" includes the reference's order among EQUAL curvatures). The reference's
+    comparator sees the curvature only, so tied points are met in the order libstdc++'s introsort leaves them (feature_extract.cpp:152-162). Default:
+    the HIP path re-orders every sector that has a tie with that algorithm on the device and equals the oracle's literal std::sort call (tie_rule=0) AND
+    extractCloud compiled from the reference's own lines. Opt-out (mlh_set_extract_tie_order(ctx, 0)): the (curvature, index) rule, oracle tie_rule=1."""
     pts, ss, se = _quantised_scan(case16)
-    ref = orc.extract(pts, ss, se, tie_rule=1)
-    assert ref["n_ties"] > 500, ref["n_ties"]
-    assert (ref["curvature"][ss[0]:se[0]] == 0).sum() >= 0
+    ref0 = orc.extract(pts, ss, se, tie_rule=0)
+    ref1 = orc.extract(pts, ss, se, tie_rule=1)
+    assert ref0["n_ties"] > 500, ref0["n_ties"]
+    keys = ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw")
+    assert not all(np.array_equal(ref0[k], ref1[k]) for k in keys)          # the two rules really differ on this scan
     c = mla.Context(0)
-    got = c.extract(pts, ss, se)
-    c.close()
-    assert np.array_equal(got["curvature"].view(np.uint32), ref["curvature"].view(np.uint32))
-    for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
-        assert np.array_equal(got[k], ref[k]), k
-    # the tie rule is a refinement of the reference's comparator: on tie-free data it changes nothing
-    sc = case16["scans"][0]
-    a, b = orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=0), orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=1)
-    assert a["n_ties"] == 0 and all(np.array_equal(a[k], b[k]) for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"))
+    try:
+        got = c.extract(pts, ss, se, voxel_leaf=0.2)
+        assert np.array_equal(got["curvature"].view(np.uint32), ref0["curvature"].view(np.uint32))
+        for k in keys:
+            assert np.array_equal(got[k], ref0[k]), k
+        np.testing.assert_array_equal(got["less_flat_ds"].view(np.uint32), ref0["less_flat_ds"].view(np.uint32))
+        if orc.ref_lib() is not None:                                        # ... and the reference's own lines (oracle/_ref), point for point
+            want = orc.ref_extract(pts, ss, se)
+            for k in ("sharp", "less_sharp", "flat"):
+                assert np.array_equal(want[k].view(np.uint32), np.ascontiguousarray(pts[got[k]]).view(np.uint32)), k
+            np.testing.assert_array_equal(got["less_flat_ds"].view(np.uint32), want["less_flat_ds"].view(np.uint32))
+        again = c.extract(pts, ss, se)
+        assert all(np.array_equal(again[k], got[k]) for k in keys)          # deterministic
+        c.set_extract_tie_order(False)
+        alt = c.extract(pts, ss, se)
+        for k in keys:
+            assert np.array_equal(alt[k], ref1[k]), k
+        c.set_extract_tie_order(True)
+        # both rules refine the reference's comparator: on tie-free data they change nothing
+        sc = case16["scans"][0]
+        a, b = orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=0), orc.extract(sc.points, sc.scan_start, sc.scan_end, tie_rule=1)
+        assert a["n_ties"] == 0 and all(np.array_equal(a[k], b[k]) for k in keys)
+        g = c.extract(sc.points, sc.scan_start, sc.scan_end)
+        assert all(np.array_equal(g[k], a[k]) for k in keys)
+    finally:
+        c.close()
+
+
+def test_extract_ties_on_long_and_short_rings(mla, orc, synth):
+    """the reference-order pass at the sizes where its scratch moves: a 4000-column ring (sectors of ~660 points, scratch in HBM), 64 quantised rings
+    (scratch in LDS, every sector tied), and rings so short that one wavefront walks the sectors in sequence"""
+    scn = synth.make_scene(seed=9, **synth.SCENE_PRESETS["50k"])
+    keys = ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw")
+    c = mla.Context(0)
+    try:
+        for rings, cols, q in ((16, 4000, 32.0), (64, 1800, 32.0), (16, 40, 1.0)):
+            sc = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], rings, seed=31, n_cols=cols)
+            pts = sc.points.copy()
+            pts[:, :3] = np.round(pts[:, :3] * q) / q
+            ref = orc.extract(pts, sc.scan_start, sc.scan_end, tie_rule=0)
+            assert ref["n_ties"] > 5, (rings, cols, ref["n_ties"])
+            got = c.extract(pts, sc.scan_start, sc.scan_end)
+            for k in keys:
+                assert np.array_equal(got[k], ref[k]), (rings, cols, k)
+    finally:
+        c.close()
 
 
 def test_extract_with_non_finite_points(mla, orc, case16):
@@ -282,8 +323,16 @@ def test_extract_with_non_finite_points(mla, orc, case16):
     pts[bad[30:], 0] = np.inf
     ref = orc.extract(pts, sc.scan_start, sc.scan_end, tie_rule=1)
     c = mla.Context(0)
+    c.set_extract_tie_order(False)
     got = c.extract(pts, sc.scan_start, sc.scan_end)
+    c.set_extract_tie_order(True)
+    got_ref_order = c.extract(pts, sc.scan_start, sc.scan_end)
     c.close()
+    # default order: the reference's std::sort with a comparator that NaN makes inconsistent -- the same comparison sequence gives the same (not even
+    # sorted) list, and the walks go through all of it as the reference's loops do (oracle tie_rule=0 = the literal call)
+    ref0 = orc.extract(pts, sc.scan_start, sc.scan_end, tie_rule=0)
+    for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
+        assert np.array_equal(got_ref_order[k], ref0[k]), k
     nan_ref, nan_got = np.isnan(ref["curvature"]), np.isnan(got["curvature"])
     assert nan_ref.sum() >= 40 and np.array_equal(nan_ref, nan_got)
     assert np.array_equal(got["curvature"][~nan_got].view(np.uint32), ref["curvature"][~nan_ref].view(np.uint32))

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 def _pose_err(a, b):
     dt = float(np.linalg.norm(np.asarray(a[:3]) - np.asarray(b[:3])))
     qa, qb = np.asarray(a[3:7]), np.asarray(b[3:7])
-    dr = 2.0 * float(np.arccos(min(1.0, abs(float(np.dot(qa, qb))))))
+    # rotation angle between the two: 2 |qa -+ qb| for small angles (acos of a dot product next to 1 cannot resolve anything below 3e-8)
+    dr = 2.0 * float(min(np.linalg.norm(qa - qb), np.linalg.norm(qa + qb)))
     return dt, dr
 
 
