@@ -267,8 +267,8 @@ def ref_eval_degeneracy(H, eig_thre=100.0):
 
 
 def ref_downsample_current_scan(surf4, corner4, leaf_surf, leaf_corner, ext_poses, ext_covs, cov_meas, with_ua=True, trace_threshold=0.6):
-    """downsampleCurrentScan compiled from the reference's own lines (lidar_mapper_keyframe.cpp:356-421); its filter objects are the oracle's
-    literal VoxelGridCovarianceMLOAM<PointI> restatement (std::sort member order). Returns (surf11, corner11)."""
+    """downsampleCurrentScan compiled from the reference's own lines (lidar_mapper_keyframe.cpp:356-421), its three filter objects being
+    VoxelGridCovarianceMLOAM<PointI> compiled from the reference's own lines too (voxel_grid_covariance_mloam_impl.hpp:68-457). Returns (surf11, corner11)."""
     L = ref_lib()
     s4 = np.ascontiguousarray(surf4, np.float32); c4 = np.ascontiguousarray(corner4, np.float32)
     ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7); ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
@@ -278,6 +278,19 @@ def ref_downsample_current_scan(surf4, corner4, leaf_surf, leaf_corner, ext_pose
     L.ref_downsample_current_scan(_ptr(s4), len(s4), _ptr(c4), len(c4), C.c_float(leaf_surf), C.c_float(leaf_corner), _ptr(ep), _ptr(ec), len(ep), _ptr(cm),
                                   int(bool(with_ua)), C.c_double(trace_threshold), _ptr(so), C.byref(ns), _ptr(co), C.byref(nc))
     return so[:ns.value].copy(), co[:nc.value].copy()
+
+
+def ref_voxel_filter(points, leaf, trace_threshold=-1.0):
+    """VoxelGridCovarianceMLOAM<PointT>::filter compiled from the reference's own lines (voxel_grid_covariance_mloam_impl.hpp:68-457): (n, 4)
+    PointXYZI records -> the plain branch, (n, 11) PointXYZIWithCov records -> the covariance branch. trace_threshold < 0: the class default."""
+    L = ref_lib()
+    p = np.ascontiguousarray(points, np.float32)
+    assert p.shape[1] in (4, 11)
+    out = np.zeros_like(p)
+    cnt = C.c_int(0)
+    rc = L.ref_voxel_filter(_ptr(p), p.shape[0], p.shape[1], C.c_float(leaf), C.c_float(trace_threshold), _ptr(out), C.byref(cnt))
+    assert rc == 0
+    return out[:cnt.value].copy()
 
 
 def ref_compound_pose_with_cov(pose1, cov1, pose2, cov2):

@@ -42,6 +42,7 @@ CUTS = [
     ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
     ("point_cov_ctor_default.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 57, 62, "inline PointXYZIWithCov()"),
     ("point_cov_ctor_from_point.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 90, 100, "inline PointXYZIWithCov(const PointXYZI &p, const Eigen::Matrix3f &cov_matrix)"),
+    ("voxel_filter_apply.inc", "@mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp", 68, 457, "template <typename PointT> void"),
     ("downsample_current_scan.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 356, 421, "void downsampleCurrentScan()"),
     ("pose_ctor_default.inc", "estimator/pose.cpp", 16, 23, "Pose::Pose()"),
     ("pose_ctor_copy.inc", "estimator/pose.cpp", 25, 32, "Pose::Pose(const Pose &pose)"),

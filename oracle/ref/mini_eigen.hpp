@@ -36,6 +36,19 @@ template <typename T, int BR, int BC> struct BlockRef {
     Mat<T, BC, BR> transpose() const;
 };
 
+// a run of coefficients inside a vector -- v.head(n) / v.tail(n) with a run-time n, as VoxelGridCovarianceMLOAM::applyFilter writes them
+// (voxel_grid_covariance_mloam_impl.hpp:312-336, 377, 404): `seg += w * other_seg`, `seg /= s`, `seg = fixed vector`
+template <typename T> struct SmallVec { T v[16]; int n; };
+template <typename T> struct SegRef {
+    T *p; int n;
+    SegRef &operator+=(const SmallVec<T> &o) { for (int i = 0; i < n; ++i) p[i] += o.v[i]; return *this; }
+    SegRef &operator+=(const SegRef &o) { for (int i = 0; i < n; ++i) p[i] += o.p[i]; return *this; }
+    SegRef &operator/=(T s) { for (int i = 0; i < n; ++i) p[i] /= s; return *this; }
+    template <int R> SegRef &operator=(const Mat<T, R, 1> &m);
+};
+template <typename S, typename T, typename = typename std::enable_if<std::is_arithmetic<S>::value>::type>
+SmallVec<T> operator*(S s, const SegRef<T> &r) { SmallVec<T> o; o.n = r.n; for (int i = 0; i < r.n; ++i) o.v[i] = T(s) * r.p[i]; return o; }
+
 template <typename T, int R, int C> struct CommaInit {
     Mat<T, R, C> &m; int k;
     CommaInit &operator,(T v) { m.d[k++] = v; return *this; }
@@ -59,6 +72,10 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
     int rows() const { return R; } int cols() const { return C; }
     static Matrix Identity() { Matrix m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = T(1); return m; }
     static Matrix Zero() { return Matrix(); }
+    static Matrix Ones() { Matrix m; for (int i = 0; i < R * C; ++i) m.d[i] = T(1); return m; }
+    SegRef<T> head(int n) { return SegRef<T>{d, n}; }
+    SegRef<T> tail(int n) { return SegRef<T>{d + R * C - n, n}; }
+    Matrix &operator+=(const SmallVec<T> &o) { for (int i = 0; i < R * C; ++i) d[i] += o.v[i]; return *this; }
     void setZero() { for (int i = 0; i < R * C; ++i) d[i] = T(0); }
     template <typename U> Mat<U, R, C> cast() const { Mat<U, R, C> m; for (int i = 0; i < R * C; ++i) m.d[i] = U(d[i]); return m; }
     void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
@@ -122,6 +139,7 @@ template <typename T, int R, int C> struct Mat : MatrixBase<Mat<T, R, C>> {
 };
 template <typename S, typename T, int R, int C, typename = typename std::enable_if<std::is_arithmetic<S>::value>::type>
 Mat<T, R, C> operator*(S s, const Mat<T, R, C> &m) { return m * T(s); }
+template <typename T> template <int R> SegRef<T> &SegRef<T>::operator=(const Mat<T, R, 1> &m) { for (int i = 0; i < n; ++i) p[i] = m.d[i]; return *this; }
 template <typename T, int R, int C, int N> ColsRef<T, R, C, N> &ColsRef<T, R, C, N>::operator=(const Mat<T, R, N> &m)
 {
     for (int i = 0; i < R; ++i) for (int j = 0; j < N; ++j) base[i * ld + col0 + j] = m(i, j);
@@ -222,6 +240,18 @@ typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 4, 1> Vector4d;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<float, 3, 1> Vector3f;
+typedef Matrix<float, 4, 1> Vector4f;
+typedef Matrix<int, 4, 1> Vector4i;
+struct VectorXf {                                                  // applyFilter's `centroid` / `temporary` (one float per point field)
+    std::vector<float> v;
+    static VectorXf Zero(int n) { VectorXf x; x.v.assign(size_t(n), 0.f); return x; }
+    void setZero() { for (float &f : v) f = 0.f; }
+    float &operator[](int i) { return v[size_t(i)]; }
+    const float &operator[](int i) const { return v[size_t(i)]; }
+    SegRef<float> head(int n) { return SegRef<float>{v.data(), n}; }
+    SegRef<float> tail(int n) { return SegRef<float>{v.data() + v.size() - size_t(n), n}; }
+    int size() const { return int(v.size()); }
+};
 typedef Matrix<float, 3, 3> Matrix3f;
 
 struct VectorXd {                                                  // the edge factor keeps its six coefficients in one

@@ -58,6 +58,8 @@ struct PointXYZI { float x = 0, y = 0, z = 0, intensity = 0; };
 template <typename P> struct PointCloud {
     typedef boost::shared_ptr<PointCloud<P>> Ptr;
     std::vector<P> points;
+    unsigned width = 0, height = 1;
+    bool is_dense = true;
     size_t size() const { return points.size(); }
     void resize(size_t n) { points.resize(n); }
     typename std::vector<P>::iterator begin() { return points.begin(); }
@@ -254,26 +256,116 @@ namespace common {
 #include "../_ref/gen/cloud_uct_associate.inc"                // cloudUCTAssociateToMap                                   lidar_mapper_keyframe.cpp:1116-1158
 #define INFO 0
 #include "../_ref/gen/eval_degeneracy.inc"                    // evalDegenracy(mat_H, local_parameterization)            lidar_mapper_keyframe.cpp:1171-1204
-// downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421): the filter objects are PCL code (mloam_pcl); here they call the oracle's LITERAL restatement
-// of VoxelGridCovarianceMLOAM<PointI>::applyFilter -- unstable std::sort included -- so what this pins is the loop around them: which LiDAR's
-// extrinsic a thinned point's uncertainty goes through (int(intensity)), the inverse extrinsic, the trace gate, the record that is pushed
-#include "../uct.hpp"
+// ---------------------------------------------------------------- VoxelGridCovarianceMLOAM<PointT>::applyFilter from the reference's own lines
+// mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp:68-457 is the REFERENCE'S file (a PCL VoxelGrid rewritten for the covariance
+// record: the trace gate, the (threshold - trace) weights, "the heaviest member's intensity", the LAST member's intensity of the plain branch, and
+// the std::sort whose order inside a voxel decides both). What it calls into PCL / boost is supplied here: the Filter base's members
+// (voxel_grid_covariance_mloam.h:71-390, pcl/filters/filter.h), getMinMax3D (pcl/common/impl/common.hpp), the field list of the two point types
+// (POINT_CLOUD_REGISTER_POINT_STRUCT, point_with_cov.hpp:72-84), NdCopy{Point,Eigen}...Functor (pcl/common/impl/centroid.hpp: one float per
+// registered field, in registration order), cloud_point_index_idx (pcl/filters/voxel_grid.h).
+#include <cfloat>
+#include <stdexcept>
+#define PCL_WARN(...) do { } while (0)
+#define pcl_isfinite(x) std::isfinite(x)
+namespace boost { namespace mpl { template <typename FL> struct size { static const int value = FL::n; }; } }
 namespace pcl {
-template <typename P> struct VoxelGridCovarianceMLOAM {
-    typename PointCloud<P>::Ptr in;
-    float leaf = 0.f;
-    void setInputCloud(const typename PointCloud<P>::Ptr &c) { in = c; }
-    void setLeafSize(float lx, float, float) { leaf = lx; }
-    void filter(PointCloud<P> &out)
-    {
-        std::vector<float> src(in->points.size() * 4), dst;
-        for (size_t i = 0; i < in->points.size(); ++i) { src[4 * i] = in->points[i].x; src[4 * i + 1] = in->points[i].y; src[4 * i + 2] = in->points[i].z; src[4 * i + 3] = in->points[i].intensity; }
-        orc::voxel_grid_mloam_plain(src.data(), int(in->points.size()), leaf, 0 /* std::sort member order, as the reference */, dst);
-        out.points.resize(dst.size() / 4);
-        for (size_t i = 0; i < out.points.size(); ++i) { out.points[i].x = dst[4 * i]; out.points[i].y = dst[4 * i + 1]; out.points[i].z = dst[4 * i + 2]; out.points[i].intensity = dst[4 * i + 3]; }
+struct PCLPointField { std::string name; unsigned offset; };
+struct RGB { unsigned char b, g, r, a; };
+struct PCLException : std::runtime_error { PCLException(const std::string &m, const char *, const char *) : std::runtime_error(m) {} };
+struct cloud_point_index_idx {
+    unsigned int idx, cloud_point_index;
+    cloud_point_index_idx(unsigned int idx_, unsigned int cloud_point_index_) : idx(idx_), cloud_point_index(cloud_point_index_) {}
+    bool operator<(const cloud_point_index_idx &p) const { return idx < p.idx; }
+};
+// registered fields of the two point types, in registration order
+inline int field_count(const PointXYZI *) { return 4; }
+inline float *field_ptr(PointXYZI &p, int i) { return i == 0 ? &p.x : (i == 1 ? &p.y : (i == 2 ? &p.z : &p.intensity)); }
+inline const char *field_name(const PointXYZI *, int i) { static const char *n[] = {"x", "y", "z", "intensity"}; return n[i]; }
+inline int field_count(const PointXYZIWithCov *) { return 11; }
+inline float *field_ptr(PointXYZIWithCov &p, int i) { return i < 3 ? (&p.x + i) : (i == 3 ? &p.intensity : (i < 10 ? &p.cov_vec[i - 4] : &p.cov_trace)); }
+inline const char *field_name(const PointXYZIWithCov *, int i)
+{
+    static const char *n[] = {"x", "y", "z", "intensity", "cov_xx", "cov_xy", "cov_xz", "cov_yy", "cov_yz", "cov_zz", "cov_trace"};
+    return n[i];
+}
+template <typename P> struct FieldListOf;
+template <> struct FieldListOf<PointXYZI> { static const int n = 4; };
+template <> struct FieldListOf<PointXYZIWithCov> { static const int n = 11; };
+template <typename P> int getFieldIndex(const PointCloud<P> &, const std::string &name, std::vector<PCLPointField> &fields)
+{
+    fields.clear();
+    P probe;
+    int found = -1;
+    for (int i = 0; i < field_count((const P *)nullptr); ++i) {
+        fields.push_back(PCLPointField{field_name((const P *)nullptr, i), unsigned(reinterpret_cast<char *>(field_ptr(probe, i)) - reinterpret_cast<char *>(&probe))});
+        if (name == fields.back().name) found = i;
     }
+    return found;
+}
+template <typename P> struct NdCopyPointEigenFunctor {
+    const P &p; Eigen::VectorXf &v;
+    NdCopyPointEigenFunctor(const P &p_, Eigen::VectorXf &v_) : p(p_), v(v_) {}
+    void run() const { for (int i = 0; i < field_count((const P *)nullptr); ++i) v[i] = *field_ptr(const_cast<P &>(p), i); }
+};
+template <typename P> struct NdCopyEigenPointFunctor {
+    const Eigen::VectorXf &v; P &p;
+    NdCopyEigenPointFunctor(const Eigen::VectorXf &v_, P &p_) : v(v_), p(p_) {}
+    void run() const { for (int i = 0; i < field_count((const P *)nullptr); ++i) *field_ptr(p, i) = v[i]; }
+};
+template <typename FL, typename F> void for_each_type(F f) { f.run(); }
+// pcl/common/impl/common.hpp: component-wise min / max over the indexed points (all of them finite in a dense cloud)
+template <typename P> void getMinMax3D(const PointCloud<P> &cloud, const std::vector<int> &indices, Eigen::Vector4f &min_pt, Eigen::Vector4f &max_pt)
+{
+    for (int k = 0; k < 4; ++k) { min_pt[k] = FLT_MAX; max_pt[k] = -FLT_MAX; }
+    for (int i : indices) {
+        const P &q = cloud.points[size_t(i)];
+        if (!cloud.is_dense && (!std::isfinite(q.x) || !std::isfinite(q.y) || !std::isfinite(q.z))) continue;
+        const float a[4] = {q.x, q.y, q.z, 1.f};
+        for (int k = 0; k < 4; ++k) { min_pt[k] = std::min(min_pt[k], a[k]); max_pt[k] = std::max(max_pt[k], a[k]); }
+    }
+}
+template <typename P> void getMinMax3D(const typename PointCloud<P>::Ptr &, const std::vector<int> &, const std::string &, float, float, Eigen::Vector4f &, Eigen::Vector4f &, bool)
+{
+    throw std::logic_error("filter-field path of getMinMax3D: not on the mapper's path (filter_field_name_ stays empty)");
+}
+template <typename PointT> class VoxelGridCovarianceMLOAM {   // the members applyFilter reads (voxel_grid_covariance_mloam.h:71-390, pcl/filters/filter.h)
+public:
+    typedef pcl::PointCloud<PointT> PointCloud;
+    typedef FieldListOf<PointT> FieldList;
+    VoxelGridCovarianceMLOAM() : inverse_leaf_size_(), downsample_all_data_(true), save_leaf_layout_(false), filter_limit_min_(-FLT_MAX), filter_limit_max_(FLT_MAX),
+                                 filter_limit_negative_(false), min_points_per_voxel_(0), trace_threshold_(2.0) {}          // voxel_grid_covariance_mloam.h:88-102
+    void setInputCloud(const typename PointCloud::Ptr &c)
+    {
+        input_ = c;
+        indices_.reset(new std::vector<int>(c->points.size()));
+        for (size_t i = 0; i < c->points.size(); ++i) (*indices_)[i] = int(i);
+    }
+    void setLeafSize(float lx, float ly, float lz)             // voxel_grid_covariance_mloam.h:118-127: inverse_leaf_size_ = Array4f::Ones() / leaf_size_.array()
+    {
+        const float leaf[4] = {lx, ly, lz, 1.f};
+        for (int k = 0; k < 4; ++k) inverse_leaf_size_[k] = 1.f / leaf[k];
+    }
+    void setTraceThreshold(const float trace_threshold) { trace_threshold_ = trace_threshold; }
+    void filter(PointCloud &output) { applyFilter(output); }
+    std::string getClassName() const { return "VoxelGridCovarianceMLOAM"; }
+protected:
+    void applyFilter(PointCloud &output);
+    typename PointCloud::Ptr input_;
+    boost::shared_ptr<std::vector<int>> indices_;
+    Eigen::Vector4f inverse_leaf_size_;
+    bool downsample_all_data_, save_leaf_layout_;
+    std::vector<int> leaf_layout_;
+    Eigen::Vector4i min_b_, max_b_, div_b_, divb_mul_;
+    std::string filter_field_name_;
+    double filter_limit_min_, filter_limit_max_;
+    bool filter_limit_negative_;
+    unsigned int min_points_per_voxel_;
+    float trace_threshold_;
 };
 }  // namespace pcl
+#include "../_ref/gen/voxel_filter_apply.inc"                 // VoxelGridCovarianceMLOAM<PointT>::applyFilter   voxel_grid_covariance_mloam_impl.hpp:68-457
+// downsampleCurrentScan (lidar_mapper_keyframe.cpp:356-421) now runs on that filter: everything on its path is the reference's text
+#include "../uct.hpp"
 PointICloud::Ptr laser_cloud_surf_last(new PointICloud()), laser_cloud_corner_last(new PointICloud()), laser_cloud_outlier(new PointICloud());      // lidar_mapper_keyframe.cpp:41-57
 PointICloud::Ptr laser_cloud_surf_last_ds(new PointICloud()), laser_cloud_corner_last_ds(new PointICloud()), laser_cloud_outlier_ds(new PointICloud());
 PointICovCloud::Ptr laser_cloud_surf_cov(new PointICovCloud()), laser_cloud_corner_cov(new PointICovCloud()), laser_cloud_outlier_cov(new PointICovCloud());
@@ -739,6 +831,51 @@ int ref_downsample_current_scan(const float *surf4, int n_surf, const float *cor
         }
     };
     dump(*laser_cloud_surf_cov, surf11, n_surf_out); dump(*laser_cloud_corner_cov, corner11, n_corner_out);
+    return 0;
+}
+
+// VoxelGridCovarianceMLOAM<PointT>::filter from the reference's own lines (voxel_grid_covariance_mloam_impl.hpp:68-457). n_fields 4: PointXYZI records
+// (plain branch: xyz mean, the LAST member's intensity), 11: PointXYZIWithCov records (trace gate, weights, the heaviest member's intensity);
+// trace_threshold < 0 keeps the class default (2.0). out: the same record layout, voxel-index order.
+int ref_voxel_filter(const float *in, int n, int n_fields, float leaf, float trace_threshold, float *out, int *n_out)
+{
+    if (n_fields == 4) {
+        PointICloud::Ptr c(new PointICloud());
+        c->points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c->points[size_t(i)].x = in[4 * i]; c->points[size_t(i)].y = in[4 * i + 1]; c->points[size_t(i)].z = in[4 * i + 2]; c->points[size_t(i)].intensity = in[4 * i + 3]; }
+        pcl::VoxelGridCovarianceMLOAM<PointI> f;
+        f.setInputCloud(c);
+        f.setLeafSize(leaf, leaf, leaf);
+        if (trace_threshold >= 0.f) f.setTraceThreshold(trace_threshold);
+        PointICloud o;
+        f.filter(o);
+        *n_out = int(o.size());
+        for (size_t i = 0; i < o.size(); ++i) { out[4 * i] = o.points[i].x; out[4 * i + 1] = o.points[i].y; out[4 * i + 2] = o.points[i].z; out[4 * i + 3] = o.points[i].intensity; }
+        return 0;
+    }
+    if (n_fields != 11) return 1;
+    PointICovCloud::Ptr c(new PointICovCloud());
+    c->points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) {
+        PointIWithCov &q = c->points[size_t(i)];
+        q.x = in[11 * i]; q.y = in[11 * i + 1]; q.z = in[11 * i + 2]; q.intensity = in[11 * i + 3];
+        for (int k = 0; k < 6; ++k) q.cov_vec[k] = in[11 * i + 4 + k];
+        q.cov_trace = in[11 * i + 10];
+    }
+    pcl::VoxelGridCovarianceMLOAM<PointIWithCov> f;
+    f.setInputCloud(c);
+    f.setLeafSize(leaf, leaf, leaf);
+    if (trace_threshold >= 0.f) f.setTraceThreshold(trace_threshold);
+    PointICovCloud o;
+    f.filter(o);
+    *n_out = int(o.size());
+    for (size_t i = 0; i < o.size(); ++i) {
+        const PointIWithCov &q = o.points[i];
+        float *w = out + 11 * i;
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.intensity;
+        for (int k = 0; k < 6; ++k) w[4 + k] = q.cov_vec[k];
+        w[10] = q.cov_trace;
+    }
     return 0;
 }
 

@@ -531,3 +531,51 @@ def test_eval_hessian_is_the_references(ref, case16, feats16):
     sc = np.abs(Hn).max()
     np.testing.assert_allclose(H, Hn, rtol=1e-11, atol=1e-11 * sc)
     np.testing.assert_allclose(H, Hsum, rtol=1e-9, atol=1e-9 * sc)
+
+
+def _cov_cloud(rng, n, extent, trace_lo, trace_hi, n_lidar=2):
+    """PointXYZIWithCov records the way the mapper holds them: a few thousand points on a handful of surfaces (so voxels have many members),
+    intensity = LiDAR id, a diagonal-dominant covariance whose trace spreads around the gate; some records share their trace exactly"""
+    xyz = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    xyz[:, 2] = (0.05 * rng.standard_normal(n)).astype(np.float32)                # a ground sheet: dense voxels
+    half = n // 2
+    xyz[half:, 0] = (extent * 0.5 + 0.05 * rng.standard_normal(n - half)).astype(np.float32)   # and a wall
+    xyz[half:, 2] = rng.uniform(0, 3, n - half).astype(np.float32)
+    tr = rng.uniform(trace_lo, trace_hi, n)
+    tr[rng.choice(n, n // 10, replace=False)] = 0.5 * (trace_lo + trace_hi)       # exact weight ties inside voxels
+    d = rng.dirichlet([2.0, 2.0, 2.0], n) * tr[:, None]
+    off = 0.1 * rng.standard_normal((n, 3)) * np.sqrt(d[:, [0, 0, 1]] * d[:, [1, 2, 2]])
+    rec = np.zeros((n, 11), np.float32)
+    rec[:, :3] = xyz
+    rec[:, 3] = rng.integers(0, n_lidar, n)
+    rec[:, 4] = d[:, 0]; rec[:, 5] = off[:, 0]; rec[:, 6] = off[:, 1]; rec[:, 7] = d[:, 1]; rec[:, 8] = off[:, 2]; rec[:, 9] = d[:, 2]
+    rec[:, 10] = rec[:, 4] + rec[:, 7] + rec[:, 9]
+    return rec
+
+
+def test_voxel_grid_covariance_mloam_is_the_references(ref):
+    """VERDICT r02 (row c, Missing #1): VoxelGridCovarianceMLOAM<PointT>::applyFilter compiled from the reference's OWN file
+    (mloam_pcl/.../voxel_grid_covariance_mloam_impl.hpp:68-457) against the oracle's restatement -- the one the HIP filters are held to.
+    Plain branch (PointXYZI: xyz mean over the members in std::sort's order, the LAST member's intensity = which LiDAR id a mixed voxel keeps) and
+    covariance branch (PointXYZIWithCov: the |trace| >= threshold gate, w = threshold - trace, weighted mean, w^2-weighted covariance over (sum w)^2,
+    the first-heaviest member's intensity, trace recomputed): same voxels in the same order, every output field bit for bit."""
+    rng = np.random.default_rng(77)
+    for n, extent, leaf in ((6000, 6.0, 0.4), (6000, 3.0, 0.2), (200, 2.0, 1.0), (1, 1.0, 0.4)):
+        rec = _cov_cloud(rng, n, extent, 0.01, 0.9)
+        plain_ref = ref.ref_voxel_filter(rec[:, :4], leaf)
+        plain_orc = ref.voxel_grid_mloam_plain(rec[:, :4], leaf, member_order=0)
+        assert plain_ref.shape == plain_orc.shape and len(plain_ref) >= 1
+        assert np.array_equal(plain_ref.view(np.uint32), plain_orc.view(np.uint32))
+        if n >= 6000:
+            assert len(plain_ref) < n // 2                                              # voxels really have several members ...
+            other = ref.voxel_grid_mloam_plain(rec[:, :4], leaf, member_order=1)
+            assert not np.array_equal(other[:, 3], plain_ref[:, 3])                     # ... and the member order really decides the surviving id
+        for thr in (0.6, 0.3, 2.0):
+            cov_ref = ref.ref_voxel_filter(rec, leaf, thr)
+            cov_orc = ref.voxel_grid_cov(rec, leaf, thr)
+            assert cov_ref.shape == cov_orc.shape
+            assert np.array_equal(cov_ref.view(np.uint32), cov_orc.view(np.uint32)), (n, leaf, thr)
+    # a voxel whose members are ALL gated out keeps its place in the output with zero weight (valid_cnt -> 1, weight_total -> 1: impl.hpp:314-325)
+    rec = _cov_cloud(rng, 500, 3.0, 0.7, 0.9)
+    a, b = ref.ref_voxel_filter(rec, 0.4, 0.6), ref.voxel_grid_cov(rec, 0.4, 0.6)
+    assert len(a) > 10 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and not a[:, :3].any()
