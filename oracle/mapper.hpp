@@ -12,6 +12,7 @@
 #pragma once
 #include "feature_extract.hpp"
 #include "factors.hpp"
+#include "lm.hpp"            // NormalEq, SolveSummary, the generic Levenberg-Marquardt iteration
 #include <string>
 #include <vector>
 #include <random>
@@ -40,13 +41,6 @@ struct ResidualBlock {
     double sqrt_info;
 };
 
-struct NormalEq {
-    double H[36];   // J^T J, row-major 6x6 (loss-corrected, weighted rows)
-    double g[6];    // J^T r
-    double cost;    // sum 0.5 * rho(r^2)
-    int n;
-};
-
 // one pass over the residual blocks at pose x (loss-corrected as Ceres' ResidualBlock::Evaluate)
 void evaluate_problem(const std::vector<ResidualBlock> &blocks, const double x[7], double huber_delta,
                       NormalEq &ne, bool with_jacobian);
@@ -65,14 +59,6 @@ void eval_degeneracy(const double H[36], double eig_thre, Degeneracy &out);
 // block is left untouched, the reference's setParameter() value), eigval (ascending); d_factor_calib per extrinsic block.
 void window_eval_degeneracy(const double *JtJ, int D, int n_pose_blocks, double *eig_thre, bool estimate_extrinsic, long frame_cnt,
                             int n_cumu_feature, double lambda_thre_calib, int *is_degenerate, double *V_update, double *eigval, double *d_factor_calib);
-
-struct SolveSummary {
-    int num_iterations = 0;           // index of the last iteration (Ceres counts iteration 0)
-    int num_successful_steps = 0;
-    int num_evaluations = 0;          // residual(+jacobian) evaluations
-    double initial_cost = 0, final_cost = 0;
-    int termination = 0;              // 0 no-convergence (max iters), 1 gradient tol, 2 parameter tol, 3 function tol, 4 failure
-};
 
 // Ceres-shaped LM on the single pose block. V_update only affects Plus.
 void ceres_like_solve(const std::vector<ResidualBlock> &blocks, double x[7], const double V_update[36],

@@ -293,6 +293,40 @@ def ref_voxel_filter(points, leaf, trace_threshold=-1.0):
     return out[:cnt.value].copy()
 
 
+def _solve_rows(solves, n):
+    return [dict(n_blocks=int(o[0]), lm_iterations=int(o[1]), successful_steps=int(o[2]), termination=int(o[3]), initial_cost=o[4], final_cost=o[5])
+            for o in solves[:n]]
+
+
+def ref_scan2map(surf_map, corner_map, surf, corner, pose_init, with_ua=False, cov_meas=None, map_eig_thre=100.0, gf_method="wo_gf", gf_ratio=1.0,
+                 seed=0, frame_cnt=1, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """scan2MapOptimization compiled from the reference's own lines (lidar_mapper_keyframe.cpp:423-639) over the Ceres-shaped shim (oracle/ref/ref_shim.cpp):
+    matching, selection, block assembly, evalHessian / evalDegenracy, the two outer iterations, the final covariance -- the reference's text; the LM
+    iteration inside ceres::Solve is oracle/lm.hpp. Maps / features: (n, >= 3) or (n, 11) arrays. Returns pose, one record per ceres::Solve, cov_mapping."""
+    L = ref_lib()
+    a = [_as11(x) for x in (surf_map, corner_map, surf, corner)]
+    p0 = np.ascontiguousarray(pose_init, np.float64)
+    cm = np.ascontiguousarray(np.diag([0.0025] * 3) if cov_meas is None else cov_meas, np.float64)
+    pose = np.zeros(7); solves = np.zeros((8, 6)); n = C.c_int(0); cov = np.zeros((6, 6))
+    rc = L.ref_scan2map_optimization(_ptr(a[0]), len(a[0]), _ptr(a[1]), len(a[1]), _ptr(a[2]), len(a[2]), _ptr(a[3]), len(a[3]), _ptr(p0), int(bool(with_ua)), _ptr(cm),
+                                     C.c_double(map_eig_thre), gf_method.encode(), C.c_double(gf_ratio), C.c_uint(int(seed)), int(frame_cnt), C.c_float(min_match_sq_dis),
+                                     C.c_float(min_plane_dis), _ptr(pose), _ptr(solves), 8, C.byref(n), _ptr(cov))
+    assert rc == 0
+    return dict(pose=pose, solves=_solve_rows(solves, n.value), cov=cov)
+
+
+def ref_track_cloud(corner_last4, surf_last4, corner_sharp4, surf_flat4, pose_ini, distance_sq_threshold=25.0, nearby_scan=2.5):
+    """LidarTracker::trackCloud compiled from the reference's own lines (lidar_tracker.cpp:23-129) over the same Ceres-shaped shim"""
+    L = ref_lib()
+    a = [np.ascontiguousarray(x, np.float32) for x in (corner_last4, surf_last4, corner_sharp4, surf_flat4)]
+    p0 = np.ascontiguousarray(pose_ini, np.float64)
+    pose = np.zeros(7); solves = np.zeros((4, 6)); n = C.c_int(0)
+    rc = L.ref_track_cloud(_ptr(a[0]), len(a[0]), _ptr(a[1]), len(a[1]), _ptr(a[2]), len(a[2]), _ptr(a[3]), len(a[3]), _ptr(p0), C.c_float(distance_sq_threshold),
+                           C.c_float(nearby_scan), _ptr(pose), _ptr(solves), 4, C.byref(n))
+    assert rc == 0
+    return dict(pose=pose, solves=_solve_rows(solves, n.value))
+
+
 def ref_compound_pose_with_cov(pose1, cov1, pose2, cov2):
     """the reference's own compoundPoseWithCov lines (associate_uct.hpp:9-86, method 2)"""
     L = ref_lib()

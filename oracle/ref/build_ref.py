@@ -40,6 +40,7 @@ CUTS = [
     ("calib_edge_tail.inc", "factor/lidar_online_calib_factor.hpp", 223, 227, "private:"),
     ("plp_class.inc", "factor/pose_local_parameterization.h", 21, 33, "class PoseLocalParameterization"),
     ("plp_plus.inc", "factor/pose_local_parameterization.cpp", 16, 45, "void PoseLocalParameterization::setParameter"),
+    ("plp_jacobian.inc", "factor/pose_local_parameterization.cpp", 47, 55, "// calculate the jacobian of [p, q] w.r.t [dp, dq]"),
     ("point_cov_ctor_default.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 57, 62, "inline PointXYZIWithCov()"),
     ("point_cov_ctor_from_point.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 90, 100, "inline PointXYZIWithCov(const PointXYZI &p, const Eigen::Matrix3f &cov_matrix)"),
     ("voxel_filter_apply.inc", "@mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp", 68, 457, "template <typename PointT> void"),
@@ -70,6 +71,9 @@ CUTS = [
     ("crs_to_sparse.inc", "utility/utility.h", 152, 166, "template <typename T>"),
     ("estimator_eval_degeneracy.inc", "estimator/estimator.cpp", 1598, 1680, "void Estimator::evalDegenracy"),
     ("eval_hessian.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1160, 1169, "void evalHessian"),
+    ("vector2double.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 236, 252, "void vector2Double()"),
+    ("scan2map_optimization.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 423, 639, "void scan2MapOptimization()"),
+    ("track_cloud.inc", "lidarTracker/lidar_tracker.cpp", 23, 129, "Pose LidarTracker::trackCloud"),
     ("uct_compound.inc", "lidarMapper/associate_uct.hpp", 9, 86, "inline Eigen::Matrix<double, 6, 6> adjointMatrix"),
     ("uct_point_to_fs.inc", "lidarMapper/associate_uct.hpp", 150, 156, "inline Eigen::Matrix<double, 4, 6> pointToFS"),
     ("uct_eval_point_cov.inc", "lidarMapper/associate_uct.hpp", 164, 193, "template <typename PointType>"),
@@ -81,7 +85,7 @@ def build(force=False):
     lib = os.path.join(OUT, "libmloam_ref.so")
     if not os.path.isdir(SRC):
         return lib if os.path.exists(lib) else None          # GPU box: use what travelled
-    srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "mini_eigen.hpp", "build_ref.py")]
+    srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "mini_eigen.hpp", "build_ref.py")] + [os.path.join(os.path.dirname(HERE), "lm.hpp")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
         return lib
     gen = os.path.join(OUT, "gen")

@@ -323,10 +323,17 @@ typedef Quaternion<double> Quaterniond;
 
 // Map<...> over a caller's array: matrices (row-major) and quaternions (coefficients x, y, z, w in memory, as Eigen stores them)
 template <typename M> struct Map;
+template <typename T> struct RowsRef {                           // topRows<N>() / bottomRows<N>() of a mapped row-major matrix (PoseLocalParameterization::ComputeJacobian)
+    T *p; int rows, cols;
+    void setZero() { for (int i = 0; i < rows * cols; ++i) p[i] = T(0); }
+    void setIdentity() { setZero(); for (int i = 0; i < (rows < cols ? rows : cols); ++i) p[i * cols + i] = T(1); }
+};
 template <typename T, int R, int C> struct Map<Mat<T, R, C>> {
     T *p;
     explicit Map(T *q) : p(q) {}
     void setZero() { for (int i = 0; i < R * C; ++i) p[i] = T(0); }
+    template <int N> RowsRef<T> topRows() { return RowsRef<T>{p, N, C}; }
+    template <int N> RowsRef<T> bottomRows() { return RowsRef<T>{p + (R - N) * C, N, C}; }
     template <int N> ColsRef<T, R, C, N> leftCols() { return ColsRef<T, R, C, N>{p, 0, C}; }
     template <int N> ColsRef<T, R, C, N> rightCols() { return ColsRef<T, R, C, N>{p, C - N, C}; }
     Map &operator=(const Mat<T, R, C> &m) { for (int i = 0; i < R * C; ++i) p[i] = m.d[i]; return *this; }

@@ -26,6 +26,10 @@
 //   ActiveFeatureSelection::{evaluateFeatJacobianMatching, evalFullHessian, goodFeatureMatching}   estimator/src/lidarMapper/lidar_mapper.h:130-573
 //     (+ PointPlaneFeature / FeatureWithScore parameters.h:163-191, extractCov point_with_cov.hpp:202-214, common::logDet math.hpp:172-202,
 //      common::RandomGeneratorInt random_generator.hpp:52-66, the two limits lidar_mapper.h:82-83)
+//   VoxelGridCovarianceMLOAM<PointT>::applyFilter   mloam_pcl/include/mloam_pcl/voxel_grid_covariance_mloam_impl.hpp:68-457 (both branches; std::sort at :227)
+//   PoseLocalParameterization::ComputeJacobian       estimator/src/factor/pose_local_parameterization.cpp:47-55
+//   scan2MapOptimization (+ vector2Double / double2Vector)   estimator/src/lidarMapper/lidar_mapper_keyframe.cpp:423-639, 236-252 -- over a Ceres-SHAPED
+//   LidarTracker::trackCloud                                 estimator/src/lidarTracker/lidar_tracker.cpp:23-129            -- shim (below) whose minimiser is oracle/lm.hpp
 // What this pins: every decision, loop bound, comparison, term and sign the reference's own code makes (the labels and the four feature
 // lists; residual and Jacobian formulas). What it does not: the arithmetic INSIDE the third-party calls (Eigen products, PCL's voxel
 // centroids), which here is the shim's / the oracle's restatement.
@@ -95,6 +99,7 @@ template <typename P> struct KdTreeFLANN {                    // 3p: the oracle'
     typedef boost::shared_ptr<KdTreeFLANN<P>> Ptr;
     orc::KdTree tree;
     void setInputCloud(const PointCloud<P> &c) { tree.build(&c.points[0].x, sizeof(P) / sizeof(float), int(c.size())); }
+    void setInputCloud(const typename PointCloud<P>::Ptr &c) { setInputCloud(*c); }
     int nearestKSearch(const P &p, int k, std::vector<int> &idx, std::vector<float> &sqd) const
     {
         const float q[3] = {p.x, p.y, p.z};
@@ -132,7 +137,17 @@ using namespace common;
 #include "../_ref/gen/point_associate_to_map.inc"             // pointAssociateToMap
 
 namespace ceres {
-template <int... N> struct SizedCostFunction { virtual ~SizedCostFunction() {} };
+struct CostFunction {                                         // ceres/cost_function.h: the interface ResidualBlock::Evaluate calls
+    virtual ~CostFunction() {}
+    virtual bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const = 0;
+    int num_residuals_ = 0;
+};
+template <int kNumResiduals, int... N> struct SizedCostFunction : CostFunction { SizedCostFunction() { num_residuals_ = kNumResiduals; } };
+struct CRSMatrix {                                            // ceres/crs_matrix.h
+    int num_rows = 0, num_cols = 0;
+    std::vector<int> cols, rows;
+    std::vector<double> values;
+};
 struct LocalParameterization {
     virtual ~LocalParameterization() {}
     virtual bool Plus(const double *x, const double *delta, double *x_plus_delta) const = 0;
@@ -175,6 +190,7 @@ float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;    
 #include "../_ref/gen/plane_factor_head.inc"                  // class LidarMapPlaneNormFactor ... Evaluate
 #include "../_ref/gen/plane_factor_tail.inc"                  // private members, };
 #include "../_ref/gen/edge_factor_head.inc"
+    void check(double **) {}                                  // lidar_map_factor.hpp:176-229 (finite-difference print-out; scan2MapOptimization names it behind CHECK_JACOBIAN = 0)
 #include "../_ref/gen/edge_factor_tail.inc"
 #include "../_ref/gen/odom_plane_head.inc"                    // LidarPureOdomPlaneNormFactor
 #include "../_ref/gen/odom_plane_tail.inc"
@@ -187,10 +203,11 @@ float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;    
 #include "../_ref/gen/scan_plane_head.inc"                    // LidarScanPlaneNormFactor   lidar_scan_factor.hpp:25-62, 122-126
 #include "../_ref/gen/scan_plane_tail.inc"
 #include "../_ref/gen/scan_edge_vec_head.inc"                 // LidarScanEdgeFactorVector  lidar_scan_factor.hpp:236-279, 339-343
+    void check(double **) {}                                  // lidar_scan_factor.hpp:281-337 (as above; trackCloud names it behind CHECK_JACOBIAN = 0)
 #include "../_ref/gen/scan_edge_vec_tail.inc"
 #include "../_ref/gen/plp_class.inc"                          // class PoseLocalParameterization
-bool PoseLocalParameterization::ComputeJacobian(const double *, double *) const { return true; }   // (not cut: Map<Matrix<7,6>>::topRows; the test restates [I6; 0])
 #include "../_ref/gen/plp_plus.inc"                           // setParameter, Plus
+#include "../_ref/gen/plp_jacobian.inc"                       // ComputeJacobian   pose_local_parameterization.cpp:47-55
 Eigen::Matrix<double, 3, 3> COV_MEASUREMENT;                  // parameters.cpp:104 (set by the test entry point below)
 #include "../_ref/gen/uct_compound.inc"                       // adjointMatrix, covop1, covop2, compoundPoseWithCov(pose_1, cov_1, pose_2, cov_2, pose_cp, cov_cp, method)
 #include "../_ref/gen/uct_point_to_fs.inc"                    // inline Eigen::Matrix<double, 4, 6> pointToFS(const Eigen::Vector4d &)
@@ -238,6 +255,7 @@ public:
 #define printf(...) ((void)0)                                 // its closing progress line (lidar_mapper.h:570) stays out of the test logs
 #include "../_ref/gen/afs_gfm.inc"                            // goodFeatureMatching            lidar_mapper.h:229-573
 #undef printf
+    template <typename... A> void pubFeature(A &&...) {}      // lidar_mapper.h:575-606: rviz markers of the selected features (I/O, not on the path)
     ceres::LossFunction *loss_function_;                      // lidar_mapper.h:628-629
     common::RandomGeneratorInt<size_t> rgi_;
 };
@@ -377,13 +395,6 @@ pcl::VoxelGridCovarianceMLOAM<PointI> down_size_filter_surf, down_size_filter_co
 // The odometry window's degeneracy / calibration policy on J^T J: the window's pose blocks by the mapper's rule with per-block thresholds, the
 // extrinsic blocks by lambda_min / N_CUMU_FEATURE against LAMBDA_THRE_CALIB and the running eig_thre_. Ceres hands it the Jacobian as a
 // CRSMatrix; the struct below has ceres/crs_matrix.h's fields.
-namespace ceres {
-struct CRSMatrix {
-    int num_rows = 0, num_cols = 0;
-    std::vector<int> cols, rows;
-    std::vector<double> values;
-};
-}  // namespace ceres
 #include "../_ref/gen/crs_to_sparse.inc"                      // CRSMatrix2EigenMatrix(crs, Eigen::SparseMatrix<T, RowMajor> &)   utility.h:152-166
 int ESTIMATE_EXTRINSIC = 1, OPT_WINDOW_SIZE = 4, N_CUMU_FEATURE = 10;      // parameters.cpp
 double LAMBDA_THRE_CALIB = 70.0;
@@ -402,6 +413,160 @@ public:
 #include "../_ref/gen/estimator_eval_degeneracy.inc"
 #undef printf
 #include "../_ref/gen/eval_hessian.inc"                         // evalHessian(jaco, mat_H)   lidar_mapper_keyframe.cpp:1160-1169
+
+// ---------------------------------------------------------------- ceres::Problem / ceres::Solve as the driver loops use them
+// A Ceres-SHAPED interface (AddParameterBlock / AddResidualBlock / Evaluate -> CRSMatrix / Solve / Summary) over the reference's own cost functions and
+// its own PoseLocalParameterization: a residual block is evaluated by cost_function->Evaluate (the reference's lines), corrected by the loss as
+// ceres::internal::ResidualBlock::Evaluate + Corrector do (rho'' <= 0 for Huber: rows and residuals scaled by sqrt(rho')), moved to the local
+// parameterisation by J_global * ComputeJacobian() (the reference's lines), accumulated in block order; the minimiser is the oracle's restatement of
+// Ceres 1.12's trust-region LM (oracle/lm.hpp) with x (+) delta = the reference's Plus. So under scan2MapOptimization / trackCloud everything but the
+// LM iteration itself and the kd-tree is the reference's text.
+#include "../lm.hpp"
+namespace ceres {
+namespace internal { struct ResidualBlock { CostFunction *cost; LossFunction *loss; double *param; }; }
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR };
+struct Problem {
+    struct EvaluateOptions {
+        std::vector<double *> parameter_blocks;
+        std::vector<internal::ResidualBlock *> residual_blocks;
+        bool apply_loss_function = true;
+    };
+    double *param = nullptr;
+    int param_size = 0;
+    LocalParameterization *lp = nullptr;
+    std::vector<std::unique_ptr<internal::ResidualBlock>> blocks;
+    std::vector<std::unique_ptr<CostFunction>> owned_costs;       // Problem takes ownership (ceres/problem.h)
+    void AddParameterBlock(double *values, int size, LocalParameterization *local_parameterization) { param = values; param_size = size; lp = local_parameterization; }
+    internal::ResidualBlock *AddResidualBlock(CostFunction *cost_function, LossFunction *loss_function, double *x0)
+    {
+        if (!param) { param = x0; param_size = 7; }
+        blocks.emplace_back(new internal::ResidualBlock{cost_function, loss_function, x0});
+        owned_costs.emplace_back(cost_function);
+        return blocks.back().get();
+    }
+    // one residual block at `at`: loss-corrected residuals r[nres] and LOCAL Jacobian rows Jl[nres][6]; returns 0.5 * rho(|r|^2)
+    double evaluate_block(const internal::ResidualBlock &b, const double *at, double *r, double *Jl, bool apply_loss) const
+    {
+        const int nres = b.cost->num_residuals_;
+        double Jg[3 * 7];
+        const double *params[1] = {at};
+        double *jac[1] = {Jg};
+        b.cost->Evaluate(params, r, jac);
+        double sq = 0.0;
+        for (int q = 0; q < nres; ++q) sq += r[q] * r[q];
+        double rho[3] = {sq, 1.0, 0.0};
+        if (apply_loss && b.loss) b.loss->Evaluate(sq, rho);
+        const double s = std::sqrt(rho[1]);                      // Corrector: sq_norm == 0 or rho[2] <= 0 -> both scalings are sqrt(rho[1])
+        double P[7 * 6];
+        lp->ComputeJacobian(at, P);
+        for (int q = 0; q < nres; ++q) {
+            for (int k = 0; k < 6; ++k) {
+                double acc = 0.0;
+                for (int j = 0; j < 7; ++j) acc += (Jg[q * 7 + j] * s) * P[j * 6 + k];
+                Jl[q * 6 + k] = acc;
+            }
+            r[q] *= s;
+        }
+        return 0.5 * rho[0];
+    }
+    void normal_equations(const double *at, orc::NormalEq &ne) const
+    {
+        std::memset(&ne, 0, sizeof(ne));
+        for (const auto &b : blocks) {
+            double r[3], Jl[3 * 6];
+            ne.cost += evaluate_block(*b, at, r, Jl, true);
+            ne.n++;
+            for (int q = 0; q < b->cost->num_residuals_; ++q) {
+                const double *j = Jl + q * 6;
+                for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) ne.H[a * 6 + c] += j[a] * j[c];
+                for (int k = 0; k < 6; ++k) ne.g[k] += j[k] * r[q];
+            }
+        }
+    }
+    bool Evaluate(const EvaluateOptions &o, double *cost, std::vector<double> *residuals, std::vector<double> *gradient, CRSMatrix *jacobian) const
+    {
+        double total = 0.0;
+        if (jacobian) { jacobian->num_rows = 0; jacobian->num_cols = 6; jacobian->rows.assign(1, 0); jacobian->cols.clear(); jacobian->values.clear(); }
+        if (residuals) residuals->clear();
+        if (gradient) gradient->assign(6, 0.0);
+        for (const internal::ResidualBlock *b : o.residual_blocks) {
+            double r[3], Jl[3 * 6];
+            total += evaluate_block(*b, b->param, r, Jl, o.apply_loss_function);
+            for (int q = 0; q < b->cost->num_residuals_; ++q) {
+                if (residuals) residuals->push_back(r[q]);
+                if (gradient) for (int k = 0; k < 6; ++k) (*gradient)[size_t(k)] += Jl[q * 6 + k] * r[q];
+                if (jacobian) {
+                    for (int k = 0; k < 6; ++k) { jacobian->cols.push_back(k); jacobian->values.push_back(Jl[q * 6 + k]); }
+                    jacobian->rows.push_back(int(jacobian->values.size()));
+                    jacobian->num_rows++;
+                }
+            }
+        }
+        if (cost) *cost = total;
+        return true;
+    }
+};
+struct Solver {
+    struct Options {
+        LinearSolverType linear_solver_type = SPARSE_NORMAL_CHOLESKY;
+        int max_num_iterations = 50;
+        bool minimizer_progress_to_stdout = false, check_gradients = false, update_state_every_iteration = false;
+        double gradient_check_relative_precision = 1e-8, max_solver_time_in_seconds = 1e9;
+    };
+    struct Summary {
+        orc::SolveSummary s;
+        int num_residual_blocks = 0;
+        std::string BriefReport() const { return "Ceres-shaped solver report: iterations " + std::to_string(s.num_iterations); }
+        std::string FullReport() const { return BriefReport(); }
+    };
+};
+std::vector<Solver::Summary> g_solve_log;                     // every ceres::Solve of a driver-loop call, in order (read by the test entry points)
+void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary)
+{
+    summary->num_residual_blocks = int(problem->blocks.size());
+    orc::ceres_like_solve_generic([&](const double *at, orc::NormalEq &ne) { problem->normal_equations(at, ne); },
+                                  [&](const double *at, const double *delta, double *out) { problem->lp->Plus(at, delta, out); },
+                                  problem->param, options.max_num_iterations, summary->s);
+    g_solve_log.push_back(*summary);
+}
+}  // namespace ceres
+
+// ---------------------------------------------------------------- scan2MapOptimization (lidar_mapper_keyframe.cpp:423-639) from the reference's own lines
+namespace common {
+const std::string YELLOW("\033[1;33m"), RESET("\033[0m");     // color.hpp:52, 55
+namespace timing { struct Timer { explicit Timer(const std::string &) {} double Stop() { return 0.0; } }; }   // timing.hpp:180-192 (wall-clock bookkeeping)
+}
+std::ostream &operator<<(std::ostream &o, const Pose &p) { return o << "t: [" << p.t_(0) << " " << p.t_(1) << " " << p.t_(2) << "]"; }   // pose.cpp:110-117 (printing)
+PointICovCloud::Ptr laser_cloud_surf_from_map_cov_ds(new PointICovCloud()), laser_cloud_corner_from_map_cov_ds(new PointICovCloud());   // lidar_mapper_keyframe.cpp:66-67
+pcl::KdTreeFLANN<PointIWithCov>::Ptr kdtree_surf_from_map(new pcl::KdTreeFLANN<PointIWithCov>()), kdtree_corner_from_map(new pcl::KdTreeFLANN<PointIWithCov>());   // :73-74
+ActiveFeatureSelection afs;                                   // :133
+double para_pose[SIZE_POSE];                                  // :103
+Pose pose_wmap_curr;                                          // :96
+int frame_cnt = 0, CHECK_JACOBIAN = 0;                        // :30, parameters.cpp
+int POINT_PLANE_FACTOR = 1, POINT_EDGE_FACTOR = 1;            // parameters.cpp (config point_plane_factor / point_edge_factor)
+std::string FLAGS_gf_method = "wo_gf";                        // lidar_mapper_keyframe.cpp:20-22 (gflags)
+double FLAGS_gf_ratio_ini = 0.2, gf_ratio_cur = 1.0, MAP_DEG_THRE = 42.0;
+std::vector<double> gf_deg_factor_list, gf_logdet_H_list;     // :123-124
+std::vector<std::vector<double>> mapping_sp_list;             // :127
+Eigen::Matrix<double, 6, 6> cov_mapping;                      // :99
+std::vector<int> pose_keyframes_6d;                           // :60 (a point cloud in the reference; only its size is read here)
+int pub_good_surf_feature = 0;                                // ros::Publisher :115
+double time_laser_odometry = 0.0;                             // :36
+#include "../_ref/gen/vector2double.inc"                      // vector2Double, double2Vector   lidar_mapper_keyframe.cpp:236-252
+#define printf(...) ((void)0)
+#include "../_ref/gen/scan2map_optimization.inc"              // scan2MapOptimization           lidar_mapper_keyframe.cpp:423-639
+#undef printf
+
+// ---------------------------------------------------------------- LidarTracker::trackCloud (lidar_tracker.cpp:23-129) from the reference's own lines
+typedef PointICloud::Ptr PointICloudPtr;                      // common_header.h
+class LidarTracker {                                          // lidar_tracker.h:44-52
+public:
+    Pose trackCloud(const cloudFeature &prev_cloud_feature, const cloudFeature &cur_cloud_feature, const Pose &pose_ini);
+    FeatureExtract f_extract_;
+};
+#define printf(...) ((void)0)
+#include "../_ref/gen/track_cloud.inc"
+#undef printf
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
@@ -876,6 +1041,80 @@ int ref_voxel_filter(const float *in, int n, int n_fields, float leaf, float tra
         for (int k = 0; k < 6; ++k) w[4 + k] = q.cov_vec[k];
         w[10] = q.cov_trace;
     }
+    return 0;
+}
+
+// scan2MapOptimization from the reference's own lines: maps and features as 11-float PointXYZIWithCov records; gf_method / gf_ratio / seed as the
+// mapper's flags; frame_cnt_in = 0 also runs the every-tenth-frame evalFullHessian + ratio policy (cpp:456-494). Out: the pose, and per ceres::Solve
+// call [residual blocks, iterations, successful steps, termination, initial cost, final cost] (6 doubles each, at most max_solves of them).
+static void fill_cov_cloud(PointICovCloud &c, const float *a, int n)
+{
+    c.points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) {
+        PointIWithCov &q = c.points[size_t(i)];
+        q.x = a[11 * i]; q.y = a[11 * i + 1]; q.z = a[11 * i + 2]; q.intensity = a[11 * i + 3];
+        for (int k = 0; k < 6; ++k) q.cov_vec[k] = a[11 * i + 4 + k];
+        q.cov_trace = a[11 * i + 10];
+    }
+}
+static int dump_solve_log(double *solves, int max_solves)
+{
+    int n = 0;
+    for (const ceres::Solver::Summary &s : ceres::g_solve_log) {
+        if (n >= max_solves) break;
+        double *o = solves + 6 * n++;
+        o[0] = s.num_residual_blocks; o[1] = s.s.num_iterations; o[2] = s.s.num_successful_steps; o[3] = s.s.termination; o[4] = s.s.initial_cost; o[5] = s.s.final_cost;
+    }
+    return n;
+}
+int ref_scan2map_optimization(const float *surf_map11, int n_surf_map, const float *corner_map11, int n_corner_map, const float *surf11, int n_surf,
+                              const float *corner11, int n_corner, const double pose7[7], int with_ua, const double cov_meas[9], double map_eig_thre,
+                              const char *gf_method, double gf_ratio, unsigned seed, int frame_cnt_in, float min_match_sq_dis, float min_plane_dis,
+                              double pose_out[7], double *solves, int max_solves, int *n_solves, double cov_out[36])
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis; MAP_EIG_THRE = map_eig_thre;
+    with_ua_flag = with_ua != 0;
+    for (int i = 0; i < 9; ++i) COV_MEASUREMENT.d[i] = cov_meas[i];
+    fill_cov_cloud(*laser_cloud_surf_from_map_cov_ds, surf_map11, n_surf_map); fill_cov_cloud(*laser_cloud_corner_from_map_cov_ds, corner_map11, n_corner_map);
+    fill_cov_cloud(*laser_cloud_surf_cov, surf11, n_surf); fill_cov_cloud(*laser_cloud_corner_cov, corner11, n_corner);
+    FLAGS_gf_method = gf_method; FLAGS_gf_ratio_ini = gf_ratio; gf_ratio_cur = std::string(gf_method) == "wo_gf" ? 1.0 : gf_ratio;
+    frame_cnt = frame_cnt_in;
+    afs.rgi_.m_random_engine.seed(seed);
+    pose_wmap_curr = Pose(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
+    pose_keyframes_6d.assign(20, 0);                          // more than 10 keyframes: cov_mapping = mat_H^-1 (cpp:607-610)
+    d_factor_list.clear(); d_eigvec_list.clear(); gf_deg_factor_list.clear(); gf_logdet_H_list.clear(); mapping_sp_list.clear();
+    ceres::g_solve_log.clear();
+    std::ostringstream sink;
+    std::streambuf *keep = std::cout.rdbuf(sink.rdbuf());
+    scan2MapOptimization();
+    std::cout.rdbuf(keep);
+    pose_out[0] = pose_wmap_curr.t_(0); pose_out[1] = pose_wmap_curr.t_(1); pose_out[2] = pose_wmap_curr.t_(2);
+    pose_out[3] = pose_wmap_curr.q_.x(); pose_out[4] = pose_wmap_curr.q_.y(); pose_out[5] = pose_wmap_curr.q_.z(); pose_out[6] = pose_wmap_curr.q_.w();
+    *n_solves = dump_solve_log(solves, max_solves);
+    if (cov_out) for (int i = 0; i < 36; ++i) cov_out[i] = pose_wmap_curr.cov_.d[i];
+    return 0;
+}
+
+// LidarTracker::trackCloud from the reference's own lines: the four clouds as [x y z ring id] rows
+int ref_track_cloud(const float *corner_last4, int n_corner_last, const float *surf_last4, int n_surf_last, const float *corner_sharp4, int n_corner_sharp,
+                    const float *surf_flat4, int n_surf_flat, const double pose7[7], float dist_sq_thr, float nearby_scan, double pose_out[7], double *solves,
+                    int max_solves, int *n_solves)
+{
+    DISTANCE_SQ_THRESHOLD = dist_sq_thr; NEARBY_SCAN = nearby_scan;
+    auto fill = [](PointICloud &c, const float *a, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c.points[size_t(i)].x = a[4 * i]; c.points[size_t(i)].y = a[4 * i + 1]; c.points[size_t(i)].z = a[4 * i + 2]; c.points[size_t(i)].intensity = a[4 * i + 3]; }
+    };
+    cloudFeature prev, cur;
+    fill(prev["corner_points_less_sharp"], corner_last4, n_corner_last); fill(prev["surf_points_less_flat"], surf_last4, n_surf_last);
+    fill(cur["corner_points_sharp"], corner_sharp4, n_corner_sharp); fill(cur["surf_points_flat"], surf_flat4, n_surf_flat);
+    const Pose ini(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
+    ceres::g_solve_log.clear();
+    LidarTracker tracker;
+    const Pose out = tracker.trackCloud(prev, cur, ini);
+    pose_out[0] = out.t_(0); pose_out[1] = out.t_(1); pose_out[2] = out.t_(2);
+    pose_out[3] = out.q_.x(); pose_out[4] = out.q_.y(); pose_out[5] = out.q_.z(); pose_out[6] = out.q_.w();
+    *n_solves = dump_solve_log(solves, max_solves);
     return 0;
 }
 

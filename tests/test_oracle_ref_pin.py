@@ -579,3 +579,64 @@ def test_voxel_grid_covariance_mloam_is_the_references(ref):
     rec = _cov_cloud(rng, 500, 3.0, 0.7, 0.9)
     a, b = ref.ref_voxel_filter(rec, 0.4, 0.6), ref.voxel_grid_cov(rec, 0.4, 0.6)
     assert len(a) > 10 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and not a[:, :3].any()
+
+
+def _features11(synth, feats, cov_scale, rng):
+    """(m, 4) features -> (m, 11) PointXYZIWithCov records with a small per-point covariance (so that with_ua weighs them differently)"""
+    out = np.zeros((len(feats), 11), np.float32)
+    out[:, :4] = feats[:, :4]
+    d = rng.uniform(0.2, 1.0, (len(feats), 3)) * cov_scale
+    out[:, 4] = d[:, 0]; out[:, 7] = d[:, 1]; out[:, 9] = d[:, 2]
+    out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
+    return out
+
+
+@pytest.mark.parametrize("with_ua,gf_method,gf_ratio,frame_cnt", [(False, "wo_gf", 1.0, 1), (True, "wo_gf", 1.0, 0), (True, "gd_fix", 0.3, 0), (True, "rnd", 0.4, 7)])
+def test_scan2map_optimization_is_the_references(ref, synth, case16, feats16, with_ua, gf_method, gf_ratio, frame_cnt):
+    """VERDICT r02 (row c, Missing #2): the mapper's driver loop -- scan2MapOptimization, lidar_mapper_keyframe.cpp:423-639 -- compiled from the reference's
+    OWN lines over a Ceres-shaped shim: kd-tree set-up, two outer iterations, the every-tenth-frame evalFullHessian + gf_ratio policy, goodFeatureMatching for
+    corners then surfs, block assembly with extractCov / COV_MEASUREMENT, problem.Evaluate -> evalHessian -> evalDegenracy, ceres::Solve (30 iterations), the
+    final covariance. The oracle's restatement ("2 outer x match once x LM", which the HIP mlh_scan2map is held to) must give the same number of residual
+    blocks, the same LM bookkeeping and costs in both outer iterations, the same pose and the same cov_mapping."""
+    rng = np.random.default_rng(5)
+    surf, corner = feats16
+    f_s, f_c = _features11(synth, surf, 0.01, rng), _features11(synth, corner, 0.01, rng)
+    p0 = case16["p0"]
+    got = ref.ref_scan2map(case16["surf_map"], case16["corner_map"], f_s, f_c, p0, with_ua=with_ua, gf_method=gf_method, gf_ratio=gf_ratio, seed=11, frame_cnt=frame_cnt)
+    prm = ref.mapper_params(with_ua=with_ua, gf_method=gf_method, gf_ratio=gf_ratio, seed=11)
+    want = ref.scan2map(ref.Map(case16["surf_map"]), ref.Map(case16["corner_map"]), f_s, f_c, p0, prm)
+    assert len(got["solves"]) == len(want["outer"]) == 2
+    for g, w in zip(got["solves"], want["outer"]):
+        assert g["n_blocks"] == w["n_surf_sel"] + w["n_corner_sel"] and g["n_blocks"] > 300
+        assert (g["lm_iterations"], g["successful_steps"], g["termination"]) == (w["lm_iterations"], w["successful_steps"], w["termination"])
+        assert abs(g["initial_cost"] - w["initial_cost"]) <= 1e-12 * max(1.0, w["initial_cost"])
+        assert abs(g["final_cost"] - w["final_cost"]) <= 1e-12 * max(1.0, w["final_cost"])
+    assert np.linalg.norm(got["pose"] - want["pose"]) < 1e-12
+    assert np.linalg.norm(got["pose"][:3] - p0[:3]) > 1e-3                                  # the optimisation really moved the pose
+    if with_ua:                                                                             # cov_mapping = (J^T J)^-1 after the last solve (cpp:600-610)
+        np.testing.assert_allclose(got["cov"], np.linalg.inv(want["H_final"]), rtol=1e-8, atol=1e-14)
+    else:
+        assert not got["cov"].any()
+
+
+def test_track_cloud_is_the_references(ref, track_case):
+    """LidarTracker::trackCloud (lidar_tracker.cpp:23-129) from the reference's own lines: two rounds of {matchCornerFromScan + matchSurfFromScan at the
+    current estimate, LidarScanPlaneNormFactor / LidarScanEdgeFactorVector blocks under Huber(0.1), ceres::Solve with 4 iterations}; the oracle's
+    restatement (which the HIP tracker is held to) walks the same path: block counts, LM bookkeeping, costs, pose."""
+    tc = track_case
+    for p0 in (np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([0.1, -0.05, 0.0, 0, 0, 0.004, 0.999992])):
+        got = ref.ref_track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], p0)
+        want = ref.track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"], tc["surf_flat"], p0)
+        solved = [o for o in want["outer"] if o["solved"]]
+        assert len(got["solves"]) == len(solved) == 2
+        for g, w in zip(got["solves"], solved):
+            assert g["n_blocks"] == w["n_corner"] + w["n_surf"] and g["n_blocks"] > 100
+            assert (g["lm_iterations"], g["termination"]) == (w["lm_iterations"], w["termination"])
+            # 1e-9: the scan factors' f64 expressions are associated differently in the restatement (pinned at that level factor by factor above)
+            assert abs(g["initial_cost"] - w["initial_cost"]) <= 1e-9 * max(1.0, w["initial_cost"])
+            assert abs(g["final_cost"] - w["final_cost"]) <= 1e-9 * max(1.0, w["final_cost"])
+        assert np.linalg.norm(got["pose"] - want["pose"]) < 1e-9
+    # too few correspondences (a handful of current features): both rounds are skipped, the pose comes back unchanged (cpp:66-70)
+    p0 = np.array([0.02, 0.0, 0.0, 0, 0, 0, 1.0])
+    got = ref.ref_track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"][:3], tc["surf_flat"][:4], p0)
+    assert got["solves"] == [] and np.array_equal(got["pose"], p0)
