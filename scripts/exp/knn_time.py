@@ -1,0 +1,34 @@
+"""knn kernel time only (events on every launch) for a library variant: MLOAM_HIP_LIB=... python scripts/exp/knn_time.py"""
+import importlib, os, sys, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "500k")
+p0 = synth.perturbed_pose(gt, seed=43)
+ctx = mla.Context(0)
+ex = []
+for s in scans:
+    ctx.scan_upload(s.points, s.scan_start, s.scan_end); ctx.extract_run(); ex.append(ctx.extract_fetch())
+surf, corner = bench.fuse_features(synth, scans, ex)
+ctx.map_set_pair(surf_map, corner_map)
+ctx.features_set(mla.SURF, surf); ctx.features_set(mla.CORNER, corner)
+opts = mla.default_opts()
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.2:
+    ctx.gn_solve(p0, 5, opts, want_stats=False)
+ctx.synchronize()
+ctx.profile_enable((1 << mla.K_KNN) | (1 << mla.K_FIT)); ctx.profile_reset()
+for _ in range(200):
+    ctx.gn_solve(p0, 5, opts, want_stats=False)
+ctx.synchronize()
+a = ctx.profile_get(mla.K_KNN); b = ctx.profile_get(mla.K_FIT)
+ctx.profile_enable(0)
+ctx.synchronize(); t0 = time.perf_counter()
+for _ in range(300):
+    ctx.gn_solve(p0, 5, opts, want_stats=False)
+ctx.synchronize(); dt = (time.perf_counter() - t0) / 300
+print(f"{os.environ.get('MLOAM_HIP_LIB', 'product'):50s} knn {1e3 * a[0] / a[1]:.3f} us  fit {1e3 * b[0] / b[1]:.3f} us   gn_solve(5) {1e3 * dt:.4f} ms")

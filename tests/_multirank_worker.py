@@ -1,0 +1,72 @@
+"""Worker of tests/test_gpu_multirank.py: one process per GPU (torch.distributed.run), a real RCCL communicator with WORLD_SIZE ranks.
+Every rank stages its share of the 50k case (map wedge + halo and ownership by position, or the whole map and round-robin ownership),
+runs the device-resident sharded Gauss-Newton solve -- per iteration: correspondence kernel + fit kernel (local reduce) + ONE
+ncclAllReduce of 32 f64 on the context's stream + the redundant solve -- and rank 0 checks the pose against the unsharded solve of a
+second, communicator-less context on its own GPU. Prints one JSON line (rank 0)."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    mode = sys.argv[1] if len(sys.argv) > 1 else "map"
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    mla = importlib.import_module("m-loam_amd")
+    synth = importlib.import_module("m-loam_amd.synth")
+    shard = importlib.import_module("m-loam_amd.shard")
+    import conftest
+    case = conftest._make_case(synth, "50k", 16, 1)
+    ctx = mla.Context(local_rank)
+    feats = conftest.features_from_extraction(synth, case["scans"], lambda s: ctx.extract(s.points, s.scan_start, s.scan_end))
+    p0 = case["p0"]
+    centre = p0[:2]
+    uid = [mla.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    if mode == "map":
+        ctx.shard_set(*shard.wedge_planes(centre, world, rank))
+        far = np.full((1, 3), 1.0e6, np.float32)
+        ms = np.ascontiguousarray(case["surf_map"][shard.shard_points_mask(case["surf_map"], centre, world, rank)])
+        mc = np.ascontiguousarray(case["corner_map"][shard.shard_points_mask(case["corner_map"], centre, world, rank)])
+        ctx.map_set_pair(ms if len(ms) else far, mc if len(mc) else far)
+    else:
+        ctx.shard_set_features(world, rank)
+        ctx.map_set_pair(case["surf_map"], case["corner_map"])
+    ctx.comm_init(world, rank, uid[0])
+    ones = ctx.allreduce_f64(np.ones(32))                       # the communicator really spans `world` ranks
+    ctx.features_set(mla.SURF, feats[0])
+    ctx.features_set(mla.CORNER, feats[1])
+    pose, stats = ctx.gn_solve(p0, 5)
+    pose_s2m, _ = ctx.scan2map(p0)
+    out = None
+    if rank == 0:
+        one = mla.Context(local_rank)                           # the same frame, unsharded, no communicator
+        one.map_set_pair(case["surf_map"], case["corner_map"])
+        one.features_set(mla.SURF, feats[0]); one.features_set(mla.CORNER, feats[1])
+        ref, ref_stats = one.gn_solve(p0, 5)
+        ref_s2m, _ = one.scan2map(p0)
+        one.close()
+        out = dict(world=world, mode=mode, allreduce_of_ones=float(ones[0]), pose_diff=float(np.abs(pose - ref).max()),
+                   scan2map_pose_diff=float(np.abs(pose_s2m - ref_s2m).max()),
+                   counts=[(int(s["n_surf"]), int(s["n_corner"])) for s in stats],
+                   counts_unsharded=[(int(s["n_surf"]), int(s["n_corner"])) for s in ref_stats])
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
