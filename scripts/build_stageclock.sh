@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../m-loam_amd/csrc"
 mkdir -p ../lib/dbg
-for f in capi grid match solver extract comm select voxel voxelgrid odom track frontend segment; do
+for f in capi grid match solver extract comm select voxel voxelgrid odom track frontend segment stdsort; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DMLH_STAGE_CLOCK -I../../include -c $f.hip -o ../lib/dbg/$f.o &
 done
 wait
