@@ -21,6 +21,10 @@
 // atan / atan2 run in f32 on the device (ocml) and in glibc on the reference's CPU: the last ulp may differ, which matters only for a point
 // within one ulp of a row / column bin edge or a ground pair within one ulp of 10 degrees.
 #include "ctx.hpp"
+#include "alive_pool.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -161,6 +165,22 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
     int label_count = 2;
     static const int8_t nb[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
     float alpha = 0.f;                                  // one variable for the whole call, starting at 0 (U1)
+    // alpha only ever holds 0, alphax or one of the alphay values: its sine and cosine are looked up (the same std::cos / std::sin results, computed once)
+    struct Trig {
+        float a[4], c[4], s[4];
+        int n = 0;
+        float cos_of(float x) { return c[slot(x)]; }
+        float sin_of(float x) { return s[slot(x)]; }
+        int slot(float x)
+        {
+            for (int k = 0; k < n; ++k) if (a[k] == x) return k;
+            if (n == 4) n = 3;                          // cannot happen (at most 0, alphax and two alphay values); keeps the table in bounds
+            a[n] = x; c[n] = std::cos(x); s[n] = std::sin(x);
+            return n++;
+        }
+    } trig;
+    const bool theta_simple = prm.segment_theta > 0.01f && prm.segment_theta < 1.5f;
+    const float tan_theta = theta_simple ? std::tan(prm.segment_theta) : 0.f;
     std::vector<char> line_flag(vs);
     for (int i = 0; i < vs; i++) {
         for (int j = 0; j < hs; j++) {
@@ -181,10 +201,16 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
                     if (ty >= hs) ty = 0;
                     if (L(tx, ty) != 0) continue;
                     const float d1 = std::max(R(fx, fy), R(tx, ty)), d2 = std::min(R(fx, fy), R(tx, ty));
-                    const float dist = std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * std::cos(alpha));
+                    const float dist = std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * trig.cos_of(alpha));
                     alpha = nb[q][0] == 0 ? S.alphax : S.alphay;
-                    const float angle = std::atan2(d2 * std::sin(alpha), (d1 - d2 * std::cos(alpha)));
-                    bool push = angle > prm.segment_theta;
+                    const float ay = d2 * trig.sin_of(alpha), ax = d1 - d2 * trig.cos_of(alpha);
+                    // angle > theta, with atan2 itself called only within 1e-4 (relative) of the threshold: ay >= 0 and 0 < theta < pi / 2, so away from
+                    // it the comparison of ay with ax * tan(theta) decides -- the same boolean as the reference's atan2(ay, ax) > theta
+                    bool push;
+                    const float lim = ax * tan_theta;
+                    if (theta_simple && ax > 0.f && ay > lim * 1.0001f) push = true;
+                    else if (theta_simple && ax > 0.f && ay < lim * 0.9999f) push = false;
+                    else push = std::atan2(ay, ax) > prm.segment_theta;
                     if (!push && nb[q][1] == 0 && q_last_dy[q_start] == 0) {          // the record of the NEXT queue entry (hpp:297)
                         const float dist_last = q_last_dis[q_start];
                         push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
@@ -240,37 +266,56 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     hipLaunchKernelGGL(seg_owner_fix_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D.owner, npx);
     hipLaunchKernelGGL(seg_image_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D);
     MLH_HIP(ctx, hipGetLastError());
+    // MLH_SEG_TIMING=1: one line per call on stderr with the wall time of the call's phases (how much the host hop of the cluster search costs)
+    static const bool seg_timing = std::getenv("MLH_SEG_TIMING") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     SegHost H;
     H.range.resize(npx); H.owner.resize(npx); H.ground.resize(npx); H.label.assign(npx, 0);
     MLH_HIP(ctx, hipMemcpyAsync(H.range.data(), B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.owner.data(), B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.ground.data(), B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
+    const auto tp1 = std::chrono::steady_clock::now();
     for (int p = 0; p < npx; ++p) H.label[p] = (H.owner[p] == INT_MAX) ? -1 : (H.ground[p] ? 1 : 0);
     seg_clusters(S, prm, H);
-    // the rows as the reference fills them: every pixel owner, in input order; cloud_scan_order = its position at fill time
+    const auto tp2 = std::chrono::steady_clock::now();
+    // the rows as the reference fills them: every pixel owner, in input order; cloud_scan_order = its position at fill time. One pass over the input
+    // indices (a pixel's owner is an input index: bucket the pixels by owner, walk the indices upwards) gives every row already sorted and every
+    // pixel its rank; the outlier erasure -- "erase what is NOW at the position recorded at fill time", stale positions included (U2) -- runs on an
+    // order-statistic structure per row instead of vector::erase (round 2: 5 ms of sort / lower_bound / memmove per 64-ring scan)
+    std::vector<int> pixel_of(size_t(n), -1);
+    for (int p = 0; p < npx; ++p) { const int o = H.owner[p]; if (o != INT_MAX && o >= 0 && o < n) pixel_of[size_t(o)] = p; }
     std::vector<std::vector<int>> rows(vs);
     std::vector<int> order(npx, 0);
-    for (int r = 0; r < vs; ++r) {
-        std::vector<int> &v = rows[r];
-        for (int c = 0; c < hs; ++c) if (H.owner[size_t(r) * hs + c] != INT_MAX) v.push_back(H.owner[size_t(r) * hs + c]);
-        std::sort(v.begin(), v.end());
-        // position of each pixel's point inside the sorted row: the rank of its index
-        for (int c = 0; c < hs; ++c) {
-            const int o = H.owner[size_t(r) * hs + c];
-            if (o != INT_MAX) order[size_t(r) * hs + c] = int(std::lower_bound(v.begin(), v.end(), o) - v.begin());
-        }
+    for (int r = 0; r < vs; ++r) rows[r].reserve(size_t(hs));
+    for (int o = 0; o < n; ++o) {
+        const int p = pixel_of[size_t(o)];
+        if (p < 0) continue;
+        std::vector<int> &v = rows[p / hs];
+        order[p] = int(v.size());
+        v.push_back(o);
     }
+    const auto tq1 = std::chrono::steady_clock::now();
     std::vector<int> outlier_idx;
     if (prm.segment_flag) {
-        for (int r = 0; r < vs; ++r)
+        for (int r = 0; r < vs; ++r) {
+            AlivePool alive(rows[r].size());
+            bool any = false;
             for (int c = 0; c < hs; ++c)
                 if (H.label[size_t(r) * hs + c] == 999999) {
                     const int pos = order[size_t(r) * hs + c];
-                    if (pos >= 0 && size_t(pos) < rows[r].size()) rows[r].erase(rows[r].begin() + pos);       // stale position, as it is (U2)
+                    if (pos >= 0 && size_t(pos) < alive.size()) { alive.erase_index(alive.at(size_t(pos))); any = true; }       // stale position, as it is (U2)
                     if (c % 5 == 0) outlier_idx.push_back(H.owner[size_t(r) * hs + c]);
                 }
+            if (any) {
+                std::vector<int> kept;
+                kept.reserve(alive.size());
+                for (size_t k = 0; k < rows[r].size(); ++k) if (alive.contains(k)) kept.push_back(rows[r][k]);
+                rows[r].swap(kept);
+            }
+        }
     }
+    const auto tq2 = std::chrono::steady_clock::now();
     std::vector<int> keep, hstart(vs), hend(vs);
     for (int r = 0; r < vs; ++r) {
         hstart[r] = int(keep.size()) + 5;
@@ -278,6 +323,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         hend[r] = int(keep.size()) - 6;
     }
     const int n_keep = int(keep.size());
+    const auto tq3 = std::chrono::steady_clock::now();
     // stage the scan exactly as mlh_scan_upload would
     ScanBuf &sb = ctx->scan;
     sb.extracted = false; sb.voxelised = false; sb.h_lists_valid = sb.h_vox_valid = false;
@@ -294,6 +340,13 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, hend.data(), sizeof(int) * size_t(vs), hipMemcpyHostToDevice, st));
     if (cloud_out && n_keep > 0) MLH_HIP(ctx, hipMemcpyAsync(cloud_out, sb.pts.p, sizeof(float4) * size_t(n_keep), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
+    if (seg_timing) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[mlh_segment_cloud] n %d: kernels + 3 image copies to the host %.1f us | host cluster search (BFS, queue order) %.1f us | row assembly + keep list + gather + sync %.1f us\n",
+                     n, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3));
+        std::fprintf(stderr, "    rows %.1f | erase %.1f | keep %.1f | upload + gather + sync %.1f us\n", us(tp2, tq1), us(tq1, tq2), us(tq2, tq3), us(tq3, tp3));
+    }
     int max_len = 0;
     for (int r = 0; r < vs; ++r) if (hend[r] - hstart[r] >= 6) max_len = std::max(max_len, hend[r] - hstart[r]);
     sb.n = n_keep; sb.n_rings = vs; sb.max_ring_len = max_len;

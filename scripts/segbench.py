@@ -1,0 +1,31 @@
+"""ImageSegmenter::segmentCloud on one 64-ring scan: wall time of mlh_segment_cloud (device-resident input, nothing fetched) and of its phases
+(MLH_SEG_TIMING=1: the library prints them), next to the CPU oracle. VERDICT r02 item 8: what does the host hop of the cluster search cost?"""
+import importlib, os, sys, time
+import numpy as np
+os.environ["MLH_SEG_TIMING"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch
+import oracle as O
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["500k"])
+for rings, vs in ((64, 64), (16, 16)):
+    s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], rings, seed=3)
+    rng = np.random.default_rng(3)
+    pts = s.points.copy(); pts[:, 3] = 0.5
+    m = rng.random(len(pts)) < 0.1
+    pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    ctx = mla.Context(0)
+    d = torch.from_numpy(pts).cuda(); torch.cuda.synchronize()
+    for _ in range(3):
+        ctx.segment_cloud(d, fetch=False, vertical_scans=vs)
+    sys.stderr.flush()
+    print(f"--- {rings} rings, {len(pts)} points", file=sys.stderr)
+    t0 = time.perf_counter(); n = 10
+    for _ in range(n):
+        ctx.segment_cloud(d, fetch=False, vertical_scans=vs)
+    ctx.synchronize(); gpu_ms = 1e3 * (time.perf_counter() - t0) / n
+    t0 = time.perf_counter(); O.segment_cloud(pts, O.seg_params(vertical_scans=vs)); cpu_ms = 1e3 * (time.perf_counter() - t0)
+    print(f"{rings} rings, {len(pts)} points: mlh_segment_cloud (device-resident in, scan staged on the device, nothing fetched) {gpu_ms:.3f} ms per call; CPU oracle {cpu_ms:.2f} ms")
+    ctx.close()
