@@ -238,6 +238,19 @@ int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], 
  * mlh_allreduce_f64 -- D (D + 1) / 2 + D + 2 = 326 doubles for the 24-dimensional hercules window. Deterministic (no atomics). */
 int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext,
                             double huber_delta, double *JtJ, double *Jtr, double *cost, int32_t *n_residuals);
+/* The coupled window problem solved on the device: n_iters Gauss-Newton iterations on the staged (or device-built) factor table -- per iteration the
+ * normal equations above, then ONE workgroup gathers the rows / columns of the blocks that are not held constant, factorises them (Cholesky in LDS; + 1e-6 I
+ * and a second attempt when not positive definite) and applies PoseLocalParameterization::Plus block by block; three launches per iteration, the poses stay in
+ * HBM until the call returns. replaces the ceres::Solve of Estimator::optimizeMap on the LidarPureOdom / LidarOnlineCalib factors (estimator.cpp:593-680,
+ * 852-861) for the part of that problem built here (no marginalisation prior -- SURVEY section 2 #13 -- and Gauss-Newton steps, not Ceres' trust region).
+ *   const_block_mask  bit b set = block b of [pivot | frames 0.. | extrinsics 0..] is held constant (estimator.cpp:636 para_pose_[0], :642 the reference LiDAR's
+ *                     extrinsic; 1u | 1u << (1 + n_frames) for the reference's choice)
+ *   V_update          NULL (identity) or 36 doubles per block, row-major: what Estimator::evalDegenracy (estimator.cpp:1598-1680; facade evalDegenracy) left in
+ *                     every block's PoseLocalParameterization -- a projector for a degenerate pose block, zero for an extrinsic that is not to be updated
+ *   frames / exts     in: the linearisation point, out: the result.  cost / n_residuals: of the LAST linearisation (before the final update).
+ *   status            0 solved, 1 some iteration needed the + 1e-6 I, 2 some iteration's system was not positive definite even then (that update was skipped) */
+int mlh_pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
+                           uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_residuals, int32_t *status);
 
 /* (f1) cloudUCTAssociateToMap (lidar_mapper_keyframe.cpp:1116-1158): moves one keyframe's feature cloud into the map frame while
  * building the local map (extractSurroundingKeyFrames, cpp:254-354). Per point (intensity = LiDAR index n):

@@ -122,6 +122,7 @@ def load_library():
     lib.mlh_pure_odom_set.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.mlh_pure_odom_evaluate.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
     lib.mlh_pure_odom_normal_eq.argtypes = [vp, vp, vp, ci, vp, ci, cd, vp, vp, C.POINTER(cd), C.POINTER(C.c_int32)]
+    lib.mlh_pure_odom_gn_solve.argtypes = [vp, vp, vp, ci, vp, ci, cd, ci, C.c_uint32, vp, C.POINTER(cd), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_set_pair.argtypes = [vp, vp, ci, vp, ci, ci, cf, ci]
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
-    "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
+    "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_scan2map",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -452,6 +453,21 @@ class Context:
         H = np.zeros((D, D)); g = np.zeros(D); cost = C.c_double(0); cnt = C.c_int32(0)
         self._ck(self.lib.mlh_pure_odom_normal_eq(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), float(huber_delta), _p(H), _p(g), C.byref(cost), C.byref(cnt)))
         return dict(H=H, g=g, cost=cost.value, count=cnt.value)
+
+    def pure_odom_gn_solve(self, pivot, frames, exts, n_iters=5, huber_delta=1.0, const_blocks=None, V_update=None):
+        """the coupled window problem [pivot | frames | extrinsics] solved on the device (mlh_pure_odom_gn_solve): n_iters Gauss-Newton iterations on the staged
+        factor table; const_blocks: indices into [pivot, frames..., exts...] held constant (default: the pivot and extrinsic 0, as Estimator::optimizeMap does)."""
+        pv = np.ascontiguousarray(pivot, np.float64)
+        fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7).copy(); ex = np.ascontiguousarray(exts, np.float64).reshape(-1, 7).copy()
+        nb = 1 + len(fr) + len(ex)
+        const_blocks = [0, 1 + len(fr)] if const_blocks is None else list(const_blocks)
+        mask = 0
+        for b in const_blocks:
+            mask |= 1 << int(b)
+        V = None if V_update is None else np.ascontiguousarray(V_update, np.float64).reshape(nb, 36)
+        cost, n, st = C.c_double(0), C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mlh_pure_odom_gn_solve(self.h, _p(pv), _p(fr), len(fr), _p(ex), len(ex), float(huber_delta), int(n_iters), mask, _p(V), C.byref(cost), C.byref(n), C.byref(st)))
+        return dict(frames=fr, exts=ex, cost=cost.value, count=n.value, status=st.value)
 
     def downsample_current_scan(self, kind, points4, leaf, ext_poses, ext_covs, cov_measurement, with_ua=True, trace_threshold=0.6, fetch=True):
         """downsampleCurrentScan for one kind; the result becomes the kind's feature set and, with fetch, is also returned (m, 11)

@@ -276,7 +276,7 @@ void mlh_destroy(mlh_ctx *ctx)
     for (int i = 0; i < 4; ++i) s.lists[i].release();
     s.vox_stage.release(); s.vox_out.release(); s.ring_vox.release(); s.vox_keys.release(); s.vox_perm.release(); ctx->uct_buf.release(); ctx->fused[0].release(); ctx->fused[1].release(); ctx->fused_cnt.release(); ctx->fused_part.release();
     { TrackSet &t = ctx->track; for (int k = 0; k < 2; ++k) { MapGrid &m = t.grid[k]; m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); t.ring[k].release(); t.ring_start[k].release(); t.walk[k].release(); t.cur[k].release(); t.corr[k].release(); } }
-    { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); o.perm.release(); o.tile_group.release(); o.partial.release(); o.ne_out.release(); }
+    { OdomSet &o = ctx->odom; o.tab.release(); o.idx.release(); o.poses.release(); o.r.release(); o.J.release(); o.perm.release(); o.tile_group.release(); o.partial.release(); o.ne_out.release(); o.solve_aux.release(); }
     { SegBuf &g = ctx->seg; g.raw.release(); g.pix.release(); g.owner.release(); g.range.release(); g.ground.release(); g.keep.release(); }
     { VoxBuf &v = ctx->vox; v.in.release(); v.bounds.release(); v.cell.release(); v.word_of.release(); v.wpre.release(); v.cnt.release(); v.members.release(); v.vox_of.release(); v.sorted_idx.release(); v.leader.release(); v.out.release(); v.sums.release(); v.total.release(); }
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->stdsort.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
@@ -483,6 +483,14 @@ int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *f
     if (!ctx) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return pure_odom_normal_eq(ctx, pivot, frames, n_frames, exts, n_ext, huber_delta, JtJ, Jtr, cost, n_residuals);
+}
+
+int mlh_pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
+                           uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_residuals, int32_t *status)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    return pure_odom_gn_solve(ctx, pivot, frames, n_frames, exts, n_ext, huber_delta, n_iters, const_block_mask, V_update, cost, n_residuals, status);
 }
 
 int mlh_pure_odom_begin(mlh_ctx *ctx)

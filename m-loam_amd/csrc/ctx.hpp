@@ -187,7 +187,7 @@ struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
     DevBuf tab, idx, poses, r, J;
     int n = 0, max_frame = 0, max_ext = 0;
     // normal equations of the coupled window problem: factor indices grouped by (frame, extrinsic) in 256-factor tiles
-    DevBuf perm, tile_group, partial, ne_out;
+    DevBuf perm, tile_group, partial, ne_out, solve_aux;
     int n_tiles = 0, group_ext = 1;
     bool tile_group_keyed = true;
     std::vector<int> h_tile_group, h_tile_frame, h_tile_ext;
@@ -323,6 +323,8 @@ int pure_odom_begin(mlh_ctx *ctx);
 int pure_odom_add_matches(mlh_ctx *ctx, int kind, int frame_idx, int ext_idx);
 int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
                         double *H, double *g, double *cost, int32_t *n_res);
+int pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
+                       uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_res, int32_t *status_out);
 // voxelgrid.hip
 int device_exclusive_scan(mlh_ctx *ctx, int *data, long long n, mlh::DevBuf &sums, int *grand_total);
 // A kernel that cannot honour its contract (today: the device std::sort when a queue wait runs out, or a range it was never told about) sets

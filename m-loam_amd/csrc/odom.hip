@@ -423,17 +423,16 @@ static int odom_upload_poses(mlh_ctx *ctx, const double pivot[7], const double *
     return MLH_OK;
 }
 
-int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
-                        double *H, double *g, double *cost, int32_t *n_res)
+// stages the poses, keys the tile groups for this call's extrinsic count and sizes the outputs; what both entry points below start with
+static int odom_ne_prepare(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, OdomNeArgs &G, size_t &n_out)
 {
     OdomSet &O = ctx->odom;
     if (O.n <= 0) return fail(ctx, MLH_ERR_STATE, "mlh_pure_odom_set has not been called");
-    if (!pivot || !frames || !exts || !H || !g || n_frames <= O.max_frame || n_ext <= O.max_ext)
+    if (!pivot || !frames || !exts || n_frames <= O.max_frame || n_ext <= O.max_ext)
         return fail(ctx, MLH_ERR_INVALID, "pose arrays do not cover the block indices of the staged factors");
     const int D = 6 * (1 + n_frames + n_ext);
-    const size_t n_out = size_t(D) * D + D + 2;
+    n_out = size_t(D) * D + D + 2;
     if (n_out * sizeof(double) > 150 * 1024) return fail(ctx, MLH_ERR_UNSUPPORTED, "window too large for the LDS-resident assembly (6 (1 + frames + extrinsics) <= 136)");
-    OdomNeArgs G;
     int rc = odom_upload_poses(ctx, pivot, frames, n_frames, exts, n_ext, G.A);
     if (rc) return rc;
     hipStream_t st = ctx->stream;
@@ -448,14 +447,36 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
     }
     MLH_HIP(ctx, O.partial.ensure(sizeof(double) * NE_OUT * size_t(O.n_tiles)));
     MLH_HIP(ctx, O.ne_out.ensure(sizeof(double) * n_out));
-    G.perm = O.perm.as<int>(); G.huber_delta = huber_delta; G.partial = O.partial.as<double>();
-    hipLaunchKernelGGL(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, st, G);
+    MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(odom_ne_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(n_out * sizeof(double))));
+    G.perm = O.perm.as<int>(); G.partial = O.partial.as<double>();
+    return MLH_OK;
+}
+
+// one evaluation of the coupled normal equations at the poses resident in O.poses -> O.ne_out (two launches, nothing waited for)
+static void odom_ne_enqueue(mlh_ctx *ctx, const OdomNeArgs &G, int n_frames, int n_ext, size_t n_out)
+{
+    OdomSet &O = ctx->odom;
+    hipLaunchKernelGGL(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, ctx->stream, G);
     OdomNeFinish F;
     F.partial = O.partial.as<double>(); F.tile_group = O.tile_group.as<int>(); F.n_tiles = O.n_tiles; F.n_frames = n_frames; F.n_ext = n_ext;
     F.out = O.ne_out.as<double>();
-    MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(odom_ne_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(n_out * sizeof(double))));
-    hipLaunchKernelGGL(odom_ne_finish_kernel, dim3(1), dim3(256), n_out * sizeof(double), st, F);
+    hipLaunchKernelGGL(odom_ne_finish_kernel, dim3(1), dim3(256), n_out * sizeof(double), ctx->stream, F);
+}
+
+int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
+                        double *H, double *g, double *cost, int32_t *n_res)
+{
+    if (!H || !g) return fail(ctx, MLH_ERR_INVALID, "null output");
+    OdomSet &O = ctx->odom;
+    OdomNeArgs G;
+    size_t n_out = 0;
+    int rc = odom_ne_prepare(ctx, pivot, frames, n_frames, exts, n_ext, G, n_out);
+    if (rc) return rc;
+    const int D = 6 * (1 + n_frames + n_ext);
+    G.huber_delta = huber_delta;
+    odom_ne_enqueue(ctx, G, n_frames, n_ext, n_out);
     MLH_HIP(ctx, hipGetLastError());
+    hipStream_t st = ctx->stream;
     std::vector<double> h(n_out);
     MLH_HIP(ctx, hipMemcpyAsync(h.data(), O.ne_out.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipStreamSynchronize(st));
@@ -463,6 +484,134 @@ int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frame
     std::memcpy(g, h.data() + size_t(D) * D, sizeof(double) * D);
     if (cost) *cost = h[size_t(D) * D + D];
     if (n_res) *n_res = int(h[size_t(D) * D + D + 1] + 0.5);
+    return MLH_OK;
+}
+
+// ---- the coupled window problem solved ON THE DEVICE: Gauss-Newton on [pivot | frames | extrinsics] with some blocks held
+// constant -- Estimator::optimizeMap holds para_pose_[0] and para_ex_pose_[IDX_REF] constant (estimator.cpp:636, 642) -- and a per-block V_update
+// (what Estimator::evalDegenracy leaves in every PoseLocalParameterization before the solve, estimator.cpp:1598-1680: identity, a projector, or zero
+// for a frozen extrinsic). One workgroup: the free rows / columns of J^T J are gathered into LDS, factorised by a right-looking Cholesky (the trailing
+// update spread over the 256 threads; + 1e-6 I and a second attempt when a pivot is not positive), two column-oriented substitutions, then one thread
+// per free block applies PoseLocalParameterization::Plus. An iteration is three launches (rows -> tile sums, assembly, solve); the poses never leave HBM.
+struct OdomSolveArgs {
+    const double *ne;       // D*D + D + 2 (odom_ne_finish_kernel's output)
+    double *poses;          // 7 per block: pivot, frames, extrinsics
+    const double *V;        // 36 per block (row-major V_update_) or null = identity everywhere
+    int n_blocks;
+    unsigned free_mask;     // bit b: block b is updated
+    int *status;            // [0]: 0 ok, 1 solved with + 1e-6 I, 2 not positive definite even then (no update); [1]: iterations done
+};
+__global__ __launch_bounds__(256) void odom_window_solve_kernel(OdomSolveArgs S)
+{
+    extern __shared__ double sm[];                      // A (nf x nf, row-major) | b (nf) | x (nf)
+    __shared__ int s_row[136];                           // free row -> row of the full system
+    __shared__ int s_ok;
+    const int t = threadIdx.x;
+    const int D = 6 * S.n_blocks;
+    int nf = 0;
+    for (int b = 0; b < S.n_blocks; ++b) if ((S.free_mask >> b) & 1u) { if (t < 6) s_row[nf + t] = 6 * b + t; nf += 6; }
+    double *A = sm, *rhs = sm + size_t(nf) * nf, *x = rhs + nf;
+    __syncthreads();
+    bool solved = false;
+    int used_reg = 0;
+    for (int attempt = 0; attempt < 2 && !solved; ++attempt) {
+        for (int q = t; q < nf * nf; q += 256) {
+            const int i = q / nf, j = q % nf;
+            A[q] = S.ne[size_t(s_row[i]) * D + s_row[j]] + ((i == j && attempt) ? 1e-6 : 0.0);
+        }
+        for (int i = t; i < nf; i += 256) rhs[i] = -S.ne[size_t(D) * D + s_row[i]];
+        if (t == 0) s_ok = 1;
+        __syncthreads();
+        for (int k = 0; k < nf; ++k) {                    // right-looking Cholesky, lower triangle in place
+            if (t == 0) { const double d = A[k * nf + k]; if (!(d > 0.0)) s_ok = 0; A[k * nf + k] = sqrt(d > 0.0 ? d : 1.0); }
+            __syncthreads();
+            const double piv = A[k * nf + k];
+            for (int i = k + 1 + t; i < nf; i += 256) A[i * nf + k] /= piv;
+            __syncthreads();
+            const int m = nf - k - 1;                     // trailing block: (i, j), k < j <= i < nf
+            for (int q = t; q < m * m; q += 256) {
+                const int i = k + 1 + q / m, j = k + 1 + q % m;
+                if (j <= i) A[i * nf + j] -= A[i * nf + k] * A[j * nf + k];
+            }
+            __syncthreads();
+        }
+        if (s_ok) {
+            for (int k = 0; k < nf; ++k) {                // L y = rhs
+                if (t == 0) rhs[k] /= A[k * nf + k];
+                __syncthreads();
+                const double yk = rhs[k];
+                for (int i = k + 1 + t; i < nf; i += 256) rhs[i] -= A[i * nf + k] * yk;
+                __syncthreads();
+            }
+            for (int k = nf - 1; k >= 0; --k) {           // L^T x = y
+                if (t == 0) x[k] = rhs[k] / A[k * nf + k];
+                __syncthreads();
+                const double xk = x[k];
+                for (int i = t; i < k; i += 256) rhs[i] -= A[k * nf + i] * xk;
+                __syncthreads();
+            }
+            solved = true;
+            used_reg = attempt;
+        }
+        __syncthreads();
+    }
+    if (solved && t < S.n_blocks && ((S.free_mask >> t) & 1u)) {
+        int fr = 0;
+        for (int b = 0; b < t; ++b) if ((S.free_mask >> b) & 1u) fr += 6;
+        double d[6], out[7];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[c] = x[fr + c];
+        double *pose = S.poses + 7 * t;
+        pose_plus(pose, d, S.V ? S.V + 36 * t : nullptr, out);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) pose[c] = out[c];
+    }
+    if (t == 0) { S.status[0] = solved ? max(S.status[0], used_reg) : 2; S.status[1] += 1; }
+}
+
+int pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
+                       uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_res, int32_t *status_out)
+{
+    if (n_iters <= 0 || !frames || !exts) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
+    OdomSet &O = ctx->odom;
+    OdomNeArgs G;
+    size_t n_out = 0;
+    int rc = odom_ne_prepare(ctx, pivot, frames, n_frames, exts, n_ext, G, n_out);
+    if (rc) return rc;
+    const int nb = 1 + n_frames + n_ext, D = 6 * nb;
+    if (nb > 22) return fail(ctx, MLH_ERR_UNSUPPORTED, "at most 22 parameter blocks");
+    const unsigned free_mask = (~const_block_mask) & ((nb >= 32) ? 0xffffffffu : ((1u << nb) - 1u));
+    int nf = 0;
+    for (int b = 0; b < nb; ++b) if ((free_mask >> b) & 1u) nf += 6;
+    if (nf == 0) return fail(ctx, MLH_ERR_INVALID, "every block is held constant");
+    hipStream_t st = ctx->stream;
+    // [V_update (36 nb doubles) | status (2 ints)] behind the poses' buffer would alias a grow: own small buffer
+    const size_t v_bytes = V_update ? sizeof(double) * 36 * size_t(nb) : 0;
+    MLH_HIP(ctx, O.solve_aux.ensure(v_bytes + 64));
+    int *d_status = reinterpret_cast<int *>(O.solve_aux.as<char>() + v_bytes);
+    if (V_update) MLH_HIP(ctx, hipMemcpyAsync(O.solve_aux.p, V_update, v_bytes, hipMemcpyHostToDevice, st));
+    MLH_HIP(ctx, hipMemsetAsync(d_status, 0, 2 * sizeof(int), st));
+    const size_t lds = sizeof(double) * (size_t(nf) * nf + 2 * size_t(nf));
+    MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(odom_window_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    G.huber_delta = huber_delta;
+    OdomSolveArgs S;
+    S.ne = O.ne_out.as<double>(); S.poses = O.poses.as<double>(); S.V = V_update ? O.solve_aux.as<double>() : nullptr; S.n_blocks = nb; S.free_mask = free_mask; S.status = d_status;
+    for (int it = 0; it < n_iters; ++it) {
+        odom_ne_enqueue(ctx, G, n_frames, n_ext, n_out);
+        hipLaunchKernelGGL(odom_window_solve_kernel, dim3(1), dim3(256), lds, st, S);
+    }
+    MLH_HIP(ctx, hipGetLastError());
+    std::vector<double> hp(7 * size_t(nb)), hne(2);
+    int hs[2] = {0, 0};
+    MLH_HIP(ctx, hipMemcpyAsync(hp.data(), O.poses.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(hne.data(), O.ne_out.as<double>() + size_t(D) * D + D, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(hs, d_status, sizeof(hs), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipStreamSynchronize(st));
+    std::memcpy(frames, hp.data() + 7, sizeof(double) * 7 * size_t(n_frames));
+    std::memcpy(exts, hp.data() + 7 + 7 * size_t(n_frames), sizeof(double) * 7 * size_t(n_ext));
+    if (cost) *cost = hne[0];                              // of the last linearisation point (the poses before the final update)
+    if (n_res) *n_res = int(hne[1] + 0.5);
+    if (status_out) *status_out = hs[0];
     return MLH_OK;
 }
 

@@ -906,6 +906,28 @@ inline void evalWindowNormalEquations(Device &dev, const double pivot[7], const 
     ne.n_residuals = n;
 }
 
+// ceres::Solve of Estimator::optimizeMap's LiDAR factors (estimator.cpp:593-680), device-resident: n_iters Gauss-Newton iterations on the staged factor table
+// with the reference's constant blocks (para_pose_[0], estimator.cpp:636; para_ex_pose_[IDX_REF], :642) and every block's V_update_ as evalDegenracy left it
+// (local_param_ids in the reference's order: pivot + window poses, then extrinsics). frames / exts: in the linearisation point, out the result.
+// Returns the solver status (0 solved, 1 regularised, 2 an update was skipped).
+inline int solveWindow(Device &dev, const double pivot[7], std::vector<std::array<double, 7>> &frames, std::vector<std::array<double, 7>> &exts, double huber_delta,
+                       int n_iters, const std::vector<PoseLocalParameterization *> *local_param_ids = nullptr, int idx_ref = 0, double *final_cost = nullptr)
+{
+    const int nb = 1 + (int)frames.size() + (int)exts.size();
+    std::vector<double> V;
+    if (local_param_ids && (int)local_param_ids->size() == nb) {
+        V.resize(size_t(nb) * 36);
+        for (int b = 0; b < nb; ++b) for (int k = 0; k < 36; ++k) V[size_t(b) * 36 + k] = (*local_param_ids)[size_t(b)]->V_update_[k];
+    }
+    const uint32_t const_mask = 1u | (1u << (1 + (int)frames.size() + idx_ref));
+    int32_t n = 0, status = 0;
+    double cost = 0.0;
+    dev.check(mlh_pure_odom_gn_solve(dev.ctx(), pivot, frames.empty() ? nullptr : frames[0].data(), (int)frames.size(), exts.empty() ? nullptr : exts[0].data(),
+                                     (int)exts.size(), huber_delta, n_iters, const_mask, V.empty() ? nullptr : V.data(), &cost, &n, &status));
+    if (final_cost) *final_cost = cost;
+    return status;
+}
+
 // Estimator::evalDegenracy (estimator.cpp:1598-1680) on the window's normal equations, in the reference's argument order minus the Jacobian
 // (J^T J comes from evalWindowNormalEquations instead of a ceres::CRSMatrix): local_param_ids = the OPT_WINDOW_SIZE + 1 pose blocks, then one per
 // LiDAR extrinsic. Pose blocks: the mapper's rule per diagonal block with that block's threshold eig_thre[i]; a degenerate block gets

@@ -96,6 +96,13 @@ for preset in os.environ.get("CALIBBENCH_PRESETS", "500k,4M").split(","):
     t0 = time.perf_counter()
     for _ in range(200): ctx.pure_odom_normal_eq(ident, fr_g, ex_g, huber_delta=1.0)
     t_ne = 1e3 * (time.perf_counter() - t0) / 200
+    # the same five iterations device-resident (mlh_pure_odom_gn_solve: 3 launches per iteration, the poses never leave HBM)
+    for _ in range(3): sol = ctx.pure_odom_gn_solve(ident, frame0[None, :], exts0, n_iters=5, huber_delta=1.0)
+    ctx.synchronize(); t0 = time.perf_counter()
+    for _ in range(nrep): sol = ctx.pure_odom_gn_solve(ident, frame0[None, :], exts0, n_iters=5, huber_delta=1.0)
+    ctx.synchronize(); t_dev_gn = 1e3 * (time.perf_counter() - t0) / nrep
+    d_dev = max(float(np.linalg.norm(sol["frames"][0][:3] - fr_g[0][:3])), max(float(np.linalg.norm(sol["exts"][k][:3] - ex_g[k][:3])) for k in range(1, 4)))
+    print(f"  coupled window solved ON THE DEVICE (mlh_pure_odom_gn_solve, 5 Gauss-Newton iterations, status {sol['status']}): {t_dev_gn:.3f} ms per solve; vs the host-in-the-loop iterations above: {d_dev:.1e} m")
     cpu_neq = lambda fr, ex: O.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], ident, fr, ex, 1.0)
     t0 = time.perf_counter(); fr_c, ex_c, ne_c = window_gn(cpu_neq); t_cpu = 1e3 * (time.perf_counter() - t0)
     dH = float(np.abs(ne_g["H"] - ne_c["H"]).max() / np.abs(ne_c["H"]).max())

@@ -938,6 +938,30 @@ def test_pure_odom_window_normal_equations(ctx, mla, orc, synth, shape):
     step_r = np.linalg.solve(ref["H"][np.ix_(free, free)], -ref["g"][free])
     np.testing.assert_allclose(step_g, step_r, rtol=1e-6, atol=1e-9)
     assert np.linalg.norm(step_r[:3]) > 1e-3                      # the window really is off its optimum: the step is not noise
+    # the coupled problem SOLVED on the device (mlh_pure_odom_gn_solve): 4 Gauss-Newton iterations, pivot and reference extrinsic constant, against the
+    # same iterations driven by the oracle's normal equations and a host solve
+    def host_gn(n_it):
+        fr, ex = w["frames"].copy(), w["exts"].copy()
+        for _ in range(n_it):
+            ne = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], fr, ex, 1.0)
+            step = np.zeros(D); step[free] = np.linalg.solve(ne["H"][np.ix_(free, free)], -ne["g"][free])
+            for i in range(n_frames):
+                fr[i] = mla.pose_plus(fr[i], step[6 * (1 + i):6 * (2 + i)])
+            for k in range(1, n_lidars):
+                ex[k] = mla.pose_plus(ex[k], step[6 * (1 + n_frames + k):6 * (2 + n_frames + k)])
+        return fr, ex, ne
+    sol = ctx.pure_odom_gn_solve(w["pivot"], w["frames"], w["exts"], n_iters=4, huber_delta=1.0)
+    fr_r, ex_r, ne_last = host_gn(4)
+    assert sol["status"] == 0 and sol["count"] == len(w["types"])
+    assert np.abs(sol["frames"] - fr_r).max() < 1e-9 and np.abs(sol["exts"] - ex_r).max() < 1e-9
+    assert np.array_equal(sol["exts"][0], w["exts"][0])                                # the reference extrinsic is not touched
+    assert np.abs(sol["frames"] - w["frames"]).max() > 1e-3                            # ... and the window really moved
+    assert abs(sol["cost"] - ne_last["cost"]) <= 1e-9 * ne_last["cost"]
+    # a frozen block (V_update = 0, what evalDegenracy leaves in an extrinsic that must not be updated) stays put, the others still move
+    Vz = np.tile(np.eye(6).ravel(), (1 + n_frames + n_lidars, 1))
+    Vz[-1] = 0.0
+    frozen = ctx.pure_odom_gn_solve(w["pivot"], w["frames"], w["exts"], n_iters=2, huber_delta=1.0, V_update=Vz)
+    assert np.abs(frozen["exts"][-1] - w["exts"][-1]).max() < 1e-15 and np.abs(frozen["frames"] - w["frames"]).max() > 1e-3      # (Plus re-normalises the quaternion: last bit)
     # no loss (huber_delta <= 0): plain J^T J
     nl_g = ctx.pure_odom_normal_eq(w["pivot"], w["frames"], w["exts"], huber_delta=0.0)
     nl_r = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], w["frames"], w["exts"], 1e9)

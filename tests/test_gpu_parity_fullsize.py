@@ -557,6 +557,14 @@ def test_config4_coupled_window_4M(mla, orc, synth, cfg4):
             return fr, ex
         fr_g, ex_g = window_gn(lambda fr, ex: c.pure_odom_normal_eq(ident, fr, ex, huber_delta=1.0))
         fr_c, ex_c = window_gn(lambda fr, ex: orc.pure_odom_normal_eq(tab[0], tab[1], tab[2], None, tab[3], tab[4], ident, fr, ex, 1.0))
+        # ... and the same five iterations without the host in the loop (mlh_pure_odom_gn_solve on the device-built table)
+        sol = c.pure_odom_gn_solve(ident, frame0[None, :], exts0, n_iters=5, huber_delta=1.0)
+        assert sol["status"] == 0 and sol["count"] == len(tab[0])
+        dt, dr = _pose_err(sol["frames"][0], fr_c[0])
+        assert dt < 1e-9 and dr < 1e-9, (dt, dr)
+        for k in range(1, 4):
+            dt, dr = _pose_err(sol["exts"][k], ex_c[k])
+            assert dt < 1e-9 and dr < 1e-9, (k, dt, dr)
         dt, dr = _pose_err(fr_g[0], fr_c[0])
         assert dt < 1e-9 and dr < 1e-9, (dt, dr)
         for k in range(1, 4):
