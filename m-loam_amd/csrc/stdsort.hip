@@ -39,6 +39,17 @@
 
 namespace mlh {
 
+#ifdef MLH_STAGE_CLOCK
+__device__ unsigned long long g_stage_clk_sort[1024 * 8];
+#define MLH_SSTAGE(i)                                                                                  \
+    do {                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_stage_clk_sort[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define MLH_SSTAGE(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
@@ -116,6 +127,56 @@ __device__ inline void wave_write_tables(const int *keys, int *lt, int *rt, int 
     ss_wave_write_tables<SS_U>(keys, lt, rt, f, lo, hi, piv, rank_l0, after_r, n_right_here, IntLess());
 }
 
+// __unguarded_partition_pivot of [f, l) by a WHOLE 1024-thread workgroup (all threads converged): its 16 wavefronts stream contiguous sixteenths of the
+// range in coalesced 64-wide tiles -- stop counts, a prefix over the wavefronts in LDS, the rank-indexed stop tables, the crossing pairs swapped in parallel.
+// keys / vals / lt / rt: global memory (big levels) or LDS (the top of a leaf's recursion); w_left / w_right (16 ints each) and sh_k: LDS. Returns the cut.
+__device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
+{
+    const int t = threadIdx.x, wave = t >> 6, m = l - f;
+    if (t == 0) { median_to_first(keys, vals, f, l); *sh_k = 0; }
+    __syncthreads();
+    const int piv = keys[f];
+    const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
+    const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
+    int cl, cr;
+    wave_count_stops<SS_BIG_U>(keys, f, lo, hi, piv, cl, cr);
+    if ((t & 63) == 0) { w_left[wave] = cl; w_right[wave] = cr; }
+    __syncthreads();
+    int nL = 0, nR = 0, before_l = 0, after_r = 0;
+#pragma unroll
+    for (int w = 0; w < SS_BIG_WAVES; ++w) {
+        const int a = w_left[w], b = w_right[w];
+        nL += a; nR += b;
+        if (w < wave) before_l += a;
+        if (w > wave) after_r += b;
+    }
+    wave_write_tables<SS_BIG_U>(keys, lt, rt, f, lo, hi, piv, before_l, after_r, cr);
+    __syncthreads();
+    const int npair = min(nL, nR);
+    int mine = 0;
+#pragma unroll 4
+    for (int k = t; k < npair; k += SS_BIG_WG) mine += (lt[f + k] < rt[f + k]) ? 1 : 0;      // true for a prefix of k
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((t & 63) == 0 && mine) atomicAdd(sh_k, mine);
+    __syncthreads();
+    const int K = *sh_k;
+    for (int k0 = t; k0 < K; k0 += 4 * SS_BIG_WG) {              // four swaps in flight: positions, then the eight elements, then the stores
+        int p[4], q[4], kp[4], kq[4], vp[4], vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? lt[f + k] : -1; q[u] = on ? rt[f + k] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (p[u] >= 0) { kp[u] = keys[p[u]]; kq[u] = keys[q[u]]; vp[u] = vals[p[u]]; vq[u] = vals[q[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (p[u] >= 0) { keys[p[u]] = kq[u]; keys[q[u]] = kp[u]; vals[p[u]] = vq[u]; vals[q[u]] = vp[u]; }
+    }
+    int cut = INT_MAX;
+    if (K < nL) cut = min(cut, lt[f + K]);
+    if (K > 0) cut = min(cut, rt[f + K - 1]);
+    __syncthreads();                                             // the tables and sh_k / w_* are reused by the next range
+    return cut;
+}
+
 // ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF
 __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level)
 {
@@ -124,7 +185,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
     const SortSeg *cur = A.seg[level & 1];
     SortSeg *next = A.seg[(level + 1) & 1];
     const int count = A.cnt[level];
-    const int t = threadIdx.x, wave = t >> 6;
+    const int t = threadIdx.x;
     for (int si = blockIdx.x; si < count; si += gridDim.x) {
         const SortSeg s = cur[si];
         const int f = s.first, l = s.last, m = l - f;
@@ -132,51 +193,11 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
             if (t == 0) heap_sort_range(A.keys + f, A.vals + f, m);
             continue;
         }
-        if (t == 0) { median_to_first(A.keys, A.vals, f, l); sh_k = 0; }
-        __syncthreads();
-        const int piv = A.keys[f];
-        const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
-        const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
-        int cl, cr;
-        wave_count_stops<SS_BIG_U>(A.keys, f, lo, hi, piv, cl, cr);
-        if ((t & 63) == 0) { w_left[wave] = cl; w_right[wave] = cr; }
-        __syncthreads();
-        int nL = 0, nR = 0, before_l = 0, after_r = 0;
-#pragma unroll
-        for (int w = 0; w < SS_BIG_WAVES; ++w) {
-            const int a = w_left[w], b = w_right[w];
-            nL += a; nR += b;
-            if (w < wave) before_l += a;
-            if (w > wave) after_r += b;
-        }
-        wave_write_tables<SS_BIG_U>(A.keys, A.lt, A.rt, f, lo, hi, piv, before_l, after_r, cr);
-        __syncthreads();
-        const int npair = min(nL, nR);
-        int mine = 0;
-#pragma unroll 4
-        for (int k = t; k < npair; k += SS_BIG_WG) mine += (A.lt[f + k] < A.rt[f + k]) ? 1 : 0;      // true for a prefix of k
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-        if ((t & 63) == 0 && mine) atomicAdd(&sh_k, mine);
-        __syncthreads();
-        const int K = sh_k;
-        for (int k0 = t; k0 < K; k0 += 4 * SS_BIG_WG) {              // four swaps in flight: positions, then the eight elements, then the stores
-            int p[4], q[4], kp[4], kq[4], vp[4], vq[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? A.lt[f + k] : -1; q[u] = on ? A.rt[f + k] : -1; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (p[u] >= 0) { kp[u] = A.keys[p[u]]; kq[u] = A.keys[q[u]]; vp[u] = A.vals[p[u]]; vq[u] = A.vals[q[u]]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (p[u] >= 0) { A.keys[p[u]] = kq[u]; A.keys[q[u]] = kp[u]; A.vals[p[u]] = vq[u]; A.vals[q[u]] = vp[u]; }
-        }
+        const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, f, l, w_left, w_right, &sh_k);
         if (t == 0) {
-            int cut = INT_MAX;
-            if (K < nL) cut = min(cut, A.lt[f + K]);
-            if (K > 0) cut = min(cut, A.rt[f + K - 1]);
             emit_global(A, cut, l, s.depth - 1, next, &A.cnt[level + 1]);     // the recursive call
             emit_global(A, f, cut, s.depth - 1, next, &A.cnt[level + 1]);     // the loop's next trip
         }
-        __syncthreads();                                             // sh_k and w_* are reused by the next range of this workgroup
     }
 }
 
@@ -211,6 +232,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
     __syncthreads();
     int f = 0, l = 0, d = 0;
     bool have = false;
+    MLH_SSTAGE(1);
     while (true) {
         if (!have) {
             if (wg_load(&sh[LQ_REMAINING]) == 0) break;
@@ -256,7 +278,9 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
         else if (big_b) { f = cut; d -= 1; }
         else have = false;
     }
+    MLH_SSTAGE(2);
     __syncthreads();
+    MLH_SSTAGE(3);
     // __final_insertion_sort, range by range
     const int n_fin = sh[LQ_NFIN];
     for (int i = t; i < n_fin; i += SS_LEAF_WG) {
@@ -268,7 +292,9 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             M.keys[j] = key; M.vals[j] = val;
         }
     }
+    MLH_SSTAGE(4);
     __syncthreads();
+    MLH_SSTAGE(5);
 }
 
 __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
@@ -280,8 +306,12 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
     const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[A.over_level];
     const SortSeg *over = A.seg[A.over_level & 1];
     const int t = threadIdx.x;
+    MLH_SSTAGE(0);
     for (int si = blockIdx.x; si < n_leaf + n_left_over; si += gridDim.x) {
         const SortSeg s = si < n_leaf ? A.leaf[si] : over[si - n_leaf];
+#ifdef MLH_STAGE_CLOCK
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_stage_clk_sort[blockIdx.x * 8 + 7] = (unsigned long long)(s.last - s.first);
+#endif
         const int f = s.first, m = s.last - s.first;
         LeafMem M;
         M.scr = s_scr;
@@ -291,6 +321,7 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
             __syncthreads();
             leaf_sort(M, m, s.depth, sh, A.err);
             for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
+            MLH_SSTAGE(6);
             __syncthreads();
         } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
             M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
@@ -324,10 +355,14 @@ static int stdsort_setup(mlh_ctx *ctx, int n, int *vals_out, StdSortArgs &A, siz
 static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig, size_t nleaf)
 {
     hipStream_t st = ctx->stream;
-    A.over_level = longest > SS_LEAF ? SS_BIG_LEVELS : 0;     // big levels skipped: whatever the init kernel routed to level 0 anyway is finished by the leaf launch
-    if (longest > SS_LEAF) {
+    // Big levels: always all SS_BIG_LEVELS of them when a range can be longer than a leaf. (Round 3 tried ceil(log2(longest / SS_LEAF)) + 4 launches: the
+    // median-of-three partitions of a frame's 62 k voxel slots are unbalanced enough that ranges longer than a leaf survive nine levels and fall into the leaf
+    // launch's global-memory path -- the thinning step went 0.56 -> 0.66 ms. An empty level costs 3-4 us; the slow path costs 70.)
+    const int n_levels = longest > SS_LEAF ? SS_BIG_LEVELS : 0;
+    A.over_level = n_levels;                                  // no big level: whatever the init kernel routed to level 0 anyway is finished by the leaf launch
+    if (n_levels > 0) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
-        for (int level = 0; level < SS_BIG_LEVELS; ++level)
+        for (int level = 0; level < n_levels; ++level)
             hipLaunchKernelGGL(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
     }
     const int grid_leaf = int(std::min<size_t>(nleaf, 1024));
@@ -366,4 +401,12 @@ int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *count
     return stdsort_levels(ctx, A, longest, nbig, nleaf);
 }
 
+#ifdef MLH_STAGE_CLOCK
+}  // namespace mlh
+extern "C" int mlh_debug_stage_clock_sort(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_sort), sizeof(unsigned long long) * size_t(n_words));
+}
+namespace mlh {
+#endif
 }  // namespace mlh

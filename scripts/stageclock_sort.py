@@ -1,0 +1,31 @@
+"""Per-stage timestamps of stdsort_leaf_kernel for the per-ring sort of one 2 x 64-ring extraction (debug build, scripts/build_stageclock.sh).
+Usage: MLOAM_HIP_LIB=m-loam_amd/lib/libmloam_hip_dbg.so python scripts/stageclock_sort.py"""
+import ctypes as C, importlib, os, sys, warnings
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "500k")
+ctx = mla.Context(0)
+offs = np.cumsum([0] + [len(s.points) for s in scans])
+pts = np.concatenate([s.points for s in scans])
+st = np.concatenate([s.scan_start + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
+en = np.concatenate([s.scan_end + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
+ctx.scan_upload(pts, st, en); ctx.extract_run()
+for _ in range(3):
+    ctx.extract_voxel_run(0.2)
+ctx.synchronize()
+lib = mla.load_library()
+buf = (C.c_ulonglong * (1024 * 8))()
+lib.mlh_debug_stage_clock_sort.argtypes = [C.c_void_p, C.c_int]
+assert lib.mlh_debug_stage_clock_sort(buf, 1024 * 8) == 0
+t = np.frombuffer(buf, np.uint64).reshape(1024, 8).astype(np.int64)
+busy = t[:, 7] > 0
+print("leaf workgroups with a range:", int(busy.sum()), "range lengths min/med/max", int(t[busy, 7].min()), int(np.median(t[busy, 7])), int(t[busy, 7].max()))
+t0 = t[:, 0][t[:, 0] > 0].min()
+rel = (t[busy, :7] - t0) * 0.01
+names = ["kernel start", "loaded + queue ready", "recursion done (this wave)", "... all waves", "insertion pass done (thread 0)", "... all threads", "stored"]
+for i, nm in enumerate(names):
+    print(f"{nm:34s} min {rel[:, i].min():7.2f} med {np.median(rel[:, i]):7.2f} max {rel[:, i].max():7.2f} us")
