@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--shard-mode", default="map", choices=["map", "features"],
                     help="N > 1: 'map' = angular wedges of the map + halo, ownership by position (BASELINE's partition); 'features' = whole map on every "
                          "rank, features dealt round-robin (SURVEY 8e's balanced alternative)")
+    ap.add_argument("--synchronous", action="store_true",
+                    help="read every frame's pose before the next frame's map staging is enqueued (rounds 1-2's loop) instead of one frame late")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="milliseconds of an unrelated torch matmul before the warm-up steps (clock ramp of a GPU that idled through the host-side setup); 0: none")
     ap.add_argument("--profile-events", type=int, default=1,
@@ -258,14 +260,39 @@ def main():
         f"(surf {len(surf_map)} corner {len(corner_map)}; local {len(local_surf_map)}/{len(local_corner_map)}), "
         f"features surf {len(surf)} corner {len(corner)}; setup {time.time() - t0:.1f}s")
 
-    def step():
+    def stage_maps():
         # a frame's local map arrives as a (device-resident) cloud: mlh_map_set = staging + bounds pass + index build, what the
         # reference pays as kdtree->setInputCloud every frame (lidar_mapper_keyframe.cpp:433-434)
         if args.map_rebuild_only:
             ctx.map_rebuild(mla.ALL_KINDS)
         elif not args.no_map_rebuild:
             ctx.map_set_pair(d_surf_map, d_corner_map)
+
+    def step_sync():
+        stage_maps()
         return ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)[0]
+
+    # Frame submission (round 3). A step is the same work as before -- staging + index build of both maps, then 5 Gauss-Newton iterations -- but frame k's
+    # solve is SUBMITTED (mlh_gn_solve_begin) and its pose collected (mlh_gn_solve_end) after frame k + 1's map staging has been enqueued behind it: the GPU no
+    # longer idles through the host's turn-around at every frame boundary (~16 us of a 183 us step in the synchronous loop, profiles/r03_step_timeline.txt).
+    # Every pose is still read by the host, one frame late; the timed region ends with the last pose collected and the stream drained.
+    pipelined = (world == 1) and not args.synchronous
+    in_flight = [False]
+
+    def step():
+        if not pipelined:
+            return step_sync()
+        stage_maps()
+        pose_prev = ctx.gn_solve_end() if in_flight[0] else None
+        ctx.gn_solve_begin(p0, GN_ITERS, opts)
+        in_flight[0] = True
+        return pose_prev
+
+    def drain():
+        if in_flight[0]:
+            in_flight[0] = False
+            return ctx.gn_solve_end()
+        return None
 
     # valid correspondences per iteration (deterministic: the timed steps repeat exactly this solve)
     _, it_stats = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=True)
@@ -298,16 +325,19 @@ def main():
     sync_all()
     for _ in range(args.warmup):
         step()
-    # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one of its GN_ITERS
-    # launches per step (the first iteration's), because an event pair costs ~6 us of queue time of its own -- bracketing all
-    # five would slow the measured step by ~17 %
+    drain()
+    # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one launch in 4 * GN_ITERS + 1 (so the
+    # bracket rotates through the five iterations: ~50 samples over the default 200 steps), because an event pair costs ~6 us of queue time of
+    # its own -- bracketing all five launches of a step would slow the measured step by ~17 %, one per step (round 2) by ~3 %
     ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
-    ctx.profile_sample(GN_ITERS + 1)
+    ctx.profile_sample(4 * GN_ITERS + 1)
     ctx.profile_reset()
     sync_all()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         pose = step()
+    last = drain()
+    pose = last if last is not None else pose
     sync_all()
     elapsed = time.perf_counter() - t_start
     knn_ms, knn_n = ctx.profile_get(mla.K_KNN)
@@ -329,10 +359,18 @@ def main():
     t1 = time.perf_counter()
     for _ in range(n_prof):
         step()
+    drain()
     sync_all()
     ms_per_step_all_events = 1e3 * (time.perf_counter() - t1) / n_prof
     prof = {k: ctx.profile_get(k) for k in range(7)}
     ctx.profile_enable(0)
+    # the same frames submitted synchronously (pose read before the next frame's staging is enqueued): what rounds 1 and 2 reported
+    sync_all()
+    t1s = time.perf_counter()
+    for _ in range(n_prof):
+        step_sync()
+    sync_all()
+    ms_per_step_sync = 1e3 * (time.perf_counter() - t1s) / n_prof
 
     # supplementary: the reference's own per-frame call, scan2MapOptimization = index build + 2 outer x (match all, evalHessian +
     # evalDegenracy, Ceres-shaped Levenberg-Marquardt <= 30 iterations) -- not `value`, reported beside it
@@ -466,10 +504,13 @@ def main():
                                                                                       else "mlh_map_set_pair from device-resident clouds (staging + fit check + index build)")),
                                parallelism=("1 GPU" if world == 1 else (f"map sharded in {world} angular wedges (+1.1 m halo), ownership by position" if args.shard_mode == "map"
                                                                        else f"map replicated, features dealt round-robin over {world} ranks") + " + ONE RCCL all-reduce of 32 f64 per GN iteration"),
-                               hip_events_in_timed_region=("dominant kernel, 1 launch per step" if args.profile_events else "none")),
+                               hip_events_in_timed_region=(f"dominant kernel, 1 launch in {4 * GN_ITERS + 1}" if args.profile_events else "none")),
                    queries_per_s=round(queries_per_s, 1), valid_correspondences_per_step=n_valid_step,
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
+                   ms_per_step_synchronous_submission=round(ms_per_step_sync, 4),
+                   frame_submission=("pipelined: frame k's pose is collected after frame k+1's map staging has been enqueued behind its solve (mlh_gn_solve_begin / _end)"
+                                     if pipelined else "synchronous: every pose is read before the next frame is staged"),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),

@@ -188,9 +188,9 @@ static int publish_slot(mlh_ctx *ctx, HostPublish **h, unsigned long long *seq)
 }
 
 // spin until the device has stored `seq`; every kernel enqueued before the publishing one has completed when this returns
-static int wait_published(mlh_ctx *ctx, unsigned long long seq, HostPublish &out)
+static int wait_published(mlh_ctx *ctx, unsigned long long seq, HostPublish &out, void *record = nullptr)
 {
-    HostPublish *h = static_cast<HostPublish *>(ctx->h_state);
+    HostPublish *h = static_cast<HostPublish *>(record ? record : ctx->h_state);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -282,6 +282,7 @@ void mlh_destroy(mlh_ctx *ctx)
     ctx->state.release(); ctx->partials.release(); ctx->ticket.release(); ctx->stats.release(); ctx->knn_q.release(); ctx->knn_idx.release(); ctx->knn_d.release(); ctx->tmp.release(); ctx->stdsort.release(); ctx->allreduce_buf.release(); ctx->oob_flag.release();
     comm_destroy(ctx);
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+    if (ctx->h_solve) (void)hipHostFree(ctx->h_solve);
     if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
     if (ctx->select_host) (void)hipHostFree(ctx->select_host);
     if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
@@ -1021,6 +1022,55 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
         return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, n_iters);
+}
+
+// ---- the same solve, submitted and collected separately: mlh_gn_solve_begin enqueues the iterations and returns; mlh_gn_solve_end waits for the pose. A caller that
+// stages the NEXT frame's maps between the two (mlh_map_set_pair: its launches queue up behind this solve on the context's stream) keeps the GPU busy across
+// the frame boundary -- the ~16 us of host turn-around between "pose published" and "next frame's first launch" (profiles/r03_step_timeline.txt) disappear.
+// The result travels through its own pinned record: the staging call's hand-shake uses the context's other one in between.
+int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts)
+{
+    if (!ctx || !pose_in || !opts || n_iters <= 0) return MLH_ERR_INVALID;
+    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
+    if (ctx->solve_pending) return fail(ctx, MLH_ERR_STATE, "a solve is already in flight: collect it with mlh_gn_solve_end first");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
+    if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    if (!ctx->h_solve) {
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_solve, sizeof(HostPublish), hipHostMallocDefault));
+        std::memset(ctx->h_solve, 0, sizeof(HostPublish));
+    }
+    for (int it = 0; it < n_iters; ++it) {
+        MatchArgs a = args_from_opts(opts, mask, 0);
+        if (it == 0) a.init_pose = pose_in;
+        a.finish = 1;
+        a.stat_slot = -1;
+        if (it == n_iters - 1) {
+            a.publish = static_cast<HostPublish *>(ctx->h_solve);
+            a.publish_seq = ++ctx->solve_seq;
+        }
+        if ((rc = match_launch(ctx, a))) return rc;
+    }
+    ctx->solve_pending = true;
+    return MLH_OK;
+}
+
+int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7])
+{
+    if (!ctx || !pose_out) return MLH_ERR_INVALID;
+    if (!ctx->solve_pending) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_gn_solve_begin)");
+    HostPublish hp;
+    int rc = wait_published(ctx, ctx->solve_seq, hp, ctx->h_solve);
+    ctx->solve_pending = false;
+    if (rc) return rc;
+    if (!ctx->prof.pending.empty()) {
+        if (ctx->prof.mask & ((1u << MLH_K_FIT) | (1u << MLH_K_SOLVE))) MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        prof_collect(ctx);
+    }
+    for (int i = 0; i < 7; ++i) pose_out[i] = hp.x[i];
+    return MLH_OK;
 }
 
 int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const mlh_solver_opts *opts, const mlh_block_opts *bo,

@@ -242,6 +242,9 @@ struct mlh_ctx {
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
+    void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
+    unsigned long long solve_seq = 0;
+    bool solve_pending = false;
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
     void *h_occ = nullptr;   // pinned mirror of the two maps' occupancy totals (grid.hip): {cells, squares} per kind, written behind every index build
     unsigned long long publish_seq = 0;

@@ -43,3 +43,5 @@ def test_bench_json_line():
     rt = d["roofline_time_dominant_kernel"]
     assert rt["bound"] == "hbm" and rt["peak"] == 8000.0 and abs(rt["frac"] - rt["achieved"] / rt["peak"]) < 1e-4 and rt["avg_kernel_us"] > 0
     assert d["gpu_clock_spinup_ms"] >= 0 and d["ms_per_step_map_outgrows_its_grid_box"] > 0
+    # frames are submitted pipelined by default (pose k collected after frame k + 1's staging is enqueued); the synchronous loop is reported beside it
+    assert d["frame_submission"].startswith("pipelined") and d["ms_per_step_synchronous_submission"] > 0

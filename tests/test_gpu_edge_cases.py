@@ -484,3 +484,27 @@ def test_segmenter_outlier_cloud_of_an_azimuth_decimated_scan(mla, orc, synth):
         assert np.array_equal(short["outlier"].view(np.uint32), ref["outlier"][:7].view(np.uint32))
     finally:
         c.close()
+
+
+def test_gn_solve_submitted_and_collected_separately(mla, case16, feats16):
+    """mlh_gn_solve_begin / _end: the same iterations as mlh_gn_solve, bit for bit -- also with the NEXT frame's map staging enqueued (and its hand-shake
+    answered) between submission and collection, which is how bench.py keeps the GPU busy across frame boundaries; misuse is refused, not guessed at."""
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(case16["surf_map"], case16["corner_map"])
+        c.features_set(mla.SURF, feats16[0]); c.features_set(mla.CORNER, feats16[1])
+        want, _ = c.gn_solve(case16["p0"], 4, want_stats=False)
+        with pytest.raises(mla.MlhError):
+            c.gn_solve_end()                                         # nothing in flight
+        c.gn_solve_begin(case16["p0"], 4)
+        with pytest.raises(mla.MlhError):
+            c.gn_solve_begin(case16["p0"], 4)                        # one solve in flight per context
+        assert np.array_equal(c.gn_solve_end(), want)
+        for _ in range(3):                                           # frames back to back: stage k + 1 behind solve k, then read pose k
+            c.gn_solve_begin(case16["p0"], 4)
+            c.map_set_pair(case16["surf_map"], case16["corner_map"])
+            assert np.array_equal(c.gn_solve_end(), want)
+        again, _ = c.gn_solve(case16["p0"], 4, want_stats=False)     # the synchronous call still works afterwards
+        assert np.array_equal(again, want)
+    finally:
+        c.close()
