@@ -421,13 +421,14 @@ def main():
                         note="`achieved` follows the survey's 27-cell convention; the kernel searches near cells first and skips cells farther than "
                              "the K-th distance found, so it READS fewer bytes than that (between the `unavoidable` and the 27-cell figure). "
                              "The map (<= 128 MB) is L2/Infinity-Cache resident: measured HBM bytes (PMC, collected offline, profiles/) are far "
-                             "below either figure, so HBM bandwidth is not what binds this launch. SQ counters (profiles/, pass 3) put it at ~70% VALU "
-                             "issue utilisation with ~5 wavefronts per SIMD: it is bound by VALU issue (per-query instruction count), which is why "
-                             "sparse-map kinds run 8 lanes per query. `frac` is reported against the HBM peak because that is the contract's roof; "
-                             "it is not the binding one")
+                             "below either figure, so HBM bandwidth is not what binds this launch. Round 2 called it VALU-issue bound (SQ counters: ~60-70 % VALU "
+                             "utilisation, ~5 wavefronts per SIMD); round 3's knock-out runs (profiles/r03_knockout_experiments.txt) say otherwise: with ALL top-K "
+                             "bookkeeping removed the launch still takes 8.7 of 10.7 us, and a 2.5x cheaper sorted insertion (v_min_f64 / v_max_f64 on the keys) changed "
+                             "nothing -- the duration is the dependent chain feature -> cell_start words -> candidate trips (median workgroup 3.3 us, slowest 7.0) -> "
+                             "winner gather -> store. `frac` is reported against the HBM peak because that is the contract's roof; it is not the binding one")
         # what binds, as first-class fields: the fraction on the bytes an exact search cannot avoid, and the binding resource
         roofline["unavoidable_frac"] = round(bytes_ball / dur_s / 1e9 / 8000.0, 5)
-        roofline["binding"] = "valu"
+        roofline["binding"] = "latency"          # dependent memory round trips per query (see `note`); not HBM bandwidth, not VALU issue
         pmc_path = os.path.join(ROOT, "profiles", "pmc_knn.json")
         if os.path.exists(pmc_path):
             try:

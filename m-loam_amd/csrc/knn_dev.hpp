@@ -54,19 +54,33 @@ __device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long m)
 template <int OFF>
 __device__ __forceinline__ int dpp_row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + OFF, 0xF, 0xF, true); }
 
-// sorted insertion by position: the K "key < k[i]" tests are independent of each other (no compare-exchange chain, one 64-bit compare
-// per slot), slot i then takes its left neighbour, the key, or stays
+// 64-bit unsigned minimum / maximum of two KEYS in ONE instruction each. gfx950 has no v_min_u64, but it has full-rate v_min_f64 / v_max_f64, and a key
+// read as an IEEE double orders exactly as it does as an unsigned integer: its upper word is the bit pattern of a NON-NEGATIVE f32 (a squared distance, or
+// +inf for "no candidate"), so the double is non-negative, and its exponent field -- the f32's exponent and top three mantissa bits -- is all ones only for
+// f32 patterns 0x7ff00000 and above, which no distance takes (a NaN distance, 0x7fc00000, reads as an ordinary double). Non-negative finite doubles compare
+// like their bit patterns, denormals included (f64 denormals are not flushed). Round 2 built the same results from a 64-bit compare and four v_cndmask
+// per slot: the sorted insertion below went from ~24 to 9 instructions, a compare-exchange from ~9 to 2.
+__device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (unsigned long long)__double_as_longlong(r);
+}
+__device__ __forceinline__ unsigned long long key_max(unsigned long long a, unsigned long long b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (unsigned long long)__double_as_longlong(r);
+}
+
+// sorted insertion: slot i becomes max(old k[i-1], min(old k[i], key)) -- the key where it belongs, the larger entries moved up by one, the largest
+// dropped; no branch, no compare chain
 template <int K>
 __device__ __forceinline__ void key_insert(unsigned long long (&k)[K], unsigned long long key)
 {
-    if (key < k[K - 1]) {
-        bool c[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) c[i] = key < k[i];
-#pragma unroll
-        for (int i = K - 1; i > 0; --i) k[i] = c[i - 1] ? k[i - 1] : (c[i] ? key : k[i]);
-        k[0] = c[0] ? key : k[0];
-    }
+    for (int i = K - 1; i > 0; --i) k[i] = key_max(k[i - 1], key_min(k[i], key));
+    k[0] = key_min(k[0], key);
 }
 
 __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int n)
@@ -235,12 +249,12 @@ constexpr float KNN_PRUNE_SLACK = 1.0e-3f;   // metres taken off every face dist
                                              // the cell assignment; a pruned cell is farther than the bound by at least this much)
 
 // flat, balanced walk over the segments of the run table: candidate j of the concatenation goes to lane j % G
-// ascending compare-exchange of two keys (hi = a ^ b ^ lo: one 64-bit compare, no second one for the maximum)
+// ascending compare-exchange of two keys (v_min_f64 / v_max_f64 on the key bits, see key_min)
 __device__ __forceinline__ void key_cx(unsigned long long &a, unsigned long long &b)
 {
-    const unsigned long long lo = b < a ? b : a;
-    b = a ^ b ^ lo;
+    const unsigned long long lo = key_min(a, b), hi = key_max(a, b);
     a = lo;
+    b = hi;
 }
 
 // EMPTY: the lane's list is empty on entry (the first walk of a search): its first trip's candidates are sorted by a 5-exchange network and
