@@ -250,8 +250,6 @@ int mlh_create(mlh_ctx **out, int device_id)
     if (!c) return MLH_ERR_NOMEM;
     c->device = device_id;
     if (const char *e = std::getenv("MLH_KNN_LANES")) c->knn_lanes_override = std::atoi(e);
-    if (const char *e = std::getenv("MLH_FUSED")) c->fused_disable = (std::atoi(e) == 0);
-    if (const char *e = std::getenv("MLH_FUSED_STRIDED")) c->fused_strided = (std::atoi(e) != 0);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
     *out = c;
     return MLH_OK;

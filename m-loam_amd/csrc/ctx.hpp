@@ -265,9 +265,6 @@ struct mlh_ctx {
     mlh::DevBuf fused_part;  // per-append, per-kind, per-workgroup partial bounds of the appended points
     int fused_parts = 0;
     float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
-    bool fused_strided = true;    // MLH_FUSED_STRIDED=0: 32 consecutive features per workgroup (A/B runs)
-    bool fused_disable = true;    // MLH_FUSED=1 in the environment at mlh_create: the single-launch match kernel instead of the (faster,
-                                  // see DESIGN.md section 6) two-kernel path -- kept for A/B runs and held to the same parity tests
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;

@@ -180,7 +180,6 @@ struct KindP {
     int tiles_a;             // correspondence-kernel tiles (TPB / lanes features each)
     int lanes;               // lanes per query of the correspondence kernel for this kind (8 or 16)
     int tiles_b;             // fit / linearise tiles (256 features each)
-    int tiles_f;             // fused match kernel tiles (FQPB features each)
     int nbr_stride;          // max K over the blocks
     int blk_start[MAX_BLOCKS + 1];   // first slot of every pose block (multiples of 256), blk_start[n_blocks] = m
 };
@@ -207,7 +206,6 @@ struct KParams {
     HostPublish *publish;    // the finish of the last iteration hands the result to the host through pinned memory
     unsigned long long publish_seq;
     int knn_lanes;           // lanes per query of the correspondence kernel: 8 or 16 for every kind of the launch, 0 = per kind (KindP::lanes)
-    int strided;             // fused kernel: workgroup t takes features t, t + T, ... instead of 32 consecutive ones
     int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU),
                              // 3: Levenberg-Marquardt begin (fit kernel), 4: Levenberg-Marquardt step (linearize kernel)
     int lm_max_it, lm_min_blocks;
@@ -577,201 +575,6 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     MLH_STAGE(gtile, 4);
 }
 
-// ---- the fused match kernel: correspondence search + fit + linearisation + reduction (+ solver finish) in ONE launch per evaluation
-// 512 threads = 32 queries x 16 lanes. Phase A: every 16-lane group finds its query's K = 5 nearest map points (knn_group16_pruned)
-// and parks the winners' coordinates in LDS -- they never travel through HBM. Phase B: the first wavefront takes one feature per
-// lane (32 of its 64 lanes), fits, gates, linearises and reduces the 29 sums with the transposed butterfly inside the wavefront
-// (no cross-wavefront step), leaving one partial record per workgroup; the last workgroup to arrive runs the solver finish.
-// Single pose block, N_NEIGH = 5 (every mapper launch); pose blocks / N_NEIGH = 10 / chip-filling launches keep the two-kernel path.
-constexpr int FTPB = 512, FQPB = FTPB / 16;
-
-// One wavefront's share of the reduction, 16 values at a time (two passes cover the 32-slot record): the transposed butterfly keeps
-// half of a lane's values per step (8 + 4 + 2 + 1 exchanges), two plain steps finish -- the sum of value i of the pass lands in the
-// lanes with (lane >> 2) & 15 == i. 16 live doubles instead of 32: the kernel's register allocation is set by the search phase,
-// not by this.
-__device__ __forceinline__ double reduce16_wave(double (&v)[16])
-{
-    const int lane = threadIdx.x & 63;
-#define MLH_RED_STEP(H, MASK)                                              \
-    {                                                                      \
-        const bool up = (lane & (MASK)) != 0;                              \
-        _Pragma("unroll") for (int i = 0; i < (H); ++i) {                  \
-            const double keep = up ? v[i + (H)] : v[i];                    \
-            const double send = up ? v[i] : v[i + (H)];                    \
-            v[i] = keep + __shfl_xor(send, (MASK));                        \
-        }                                                                  \
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = swap_add<true>(v[i], v[i + 8]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = swap_add<false>(v[i], v[i + 4]);
-    MLH_RED_STEP(2, 8)
-    MLH_RED_STEP(1, 4)
-#undef MLH_RED_STEP
-    v[0] += __shfl_xor(v[0], 2);
-    v[0] += __shfl_xor(v[0], 1);
-    return v[0];
-}
-
-// valid row -> Huber-corrected (r, J) -> the wavefront's 29 sums -> partial_out[0..31] (slots 29 / 30 mirror the count of kind 0 / 1)
-__device__ __forceinline__ void reduce_rows_wave(bool valid, const Lin &L, double huber_delta, bool no_loss, int kind, double *__restrict__ partial_out)
-{
-    const int lane = threadIdx.x & 63;
-    double r = 0.0, J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cost = 0.0;
-    if (valid) {
-        double s = L.r * L.r, rho0 = s, rho1 = 1.0;
-        if (!no_loss && huber_delta > 0.0) {
-            const double b = huber_delta * huber_delta;
-            if (s > b) {
-                const double rr = sqrt(s);
-                rho0 = 2.0 * huber_delta * rr - b;
-                rho1 = fmax(DBL_MIN, huber_delta / rr);
-            }
-        }
-        const double sc = sqrt(rho1);
-        r = L.r * sc;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) J[i] = L.J[i] * sc;
-        cost = 0.5 * rho0;
-    }
-    const int c = (lane >> 2) & 15;                         // the column (of the pass) this lane ends up holding
-    double v[16];
-    {   // record slots 0..15: the first 16 entries of the packed upper triangle (rows 0, 1, 2 and (3,3))
-        int q = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) { if (q < 16) v[q] = J[i] * J[j]; ++q; }
-    }
-    const double lo = reduce16_wave(v);
-    {   // slots 16..31: (3,4) (3,5) (4,4) (4,5) (5,5), J^T r, cost, count, 3 unused
-        v[0] = J[3] * J[4]; v[1] = J[3] * J[5]; v[2] = J[4] * J[4]; v[3] = J[4] * J[5]; v[4] = J[5] * J[5];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[5 + i] = J[i] * r;
-        v[11] = cost; v[12] = valid ? 1.0 : 0.0; v[13] = 0.0; v[14] = 0.0; v[15] = 0.0;
-    }
-    const double hi = reduce16_wave(v);
-    const double cnt = __shfl(hi, (NE_CNT - 16) << 2);
-    if ((lane & 3) == 0) {
-        partial_out[c] = lo;
-        double w = (16 + c < 29) ? hi : 0.0;
-        if (16 + c == NE_CNT + 1 + kind) w = cnt;
-        partial_out[16 + c] = w;
-    }
-}
-
-__global__ __launch_bounds__(FTPB, 6) void match_fused_kernel(KParams P)
-{
-    __shared__ int s_run[FQPB * 2 * KNN_RUN_WORDS];
-    __shared__ float4 s_nbr[FQPB * 5];
-    __shared__ float4 s_feat[FQPB];        // the group's feature; w < 0: no feature in this slot
-    __shared__ float4 s_map[FQPB];         // its map-frame position; w = 1: searched, 0: skipped (padding / not owned)
-    const int total = P.k[0].tiles_f + P.k[1].tiles_f;
-    const int gtile = xcd_tile(total);
-    if (gtile >= total) return;
-    const int kind = gtile >= P.k[0].tiles_f ? 1 : 0;
-    const int tile = kind ? gtile - P.k[0].tiles_f : gtile;
-    const KindP &K = P.k[kind];
-    q4 q;
-    d3 t;
-    load_pose(P, 0, q, t);
-    MLH_KSTAGE(0);
-    {   // ---------------- phase A
-        const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
-        // strided assignment: workgroup `tile` takes features tile, tile + T, tile + 2T, ... -- the feature list is spatially coherent
-        // (ring order), so 32 consecutive features would all sit in the same dense (or sparse) part of the map and the launch would
-        // wait for the workgroups that drew the dense parts
-        const int f = P.strided ? grp * K.tiles_f + tile : tile * FQPB + grp;
-        float4 fp = make_float4(0.f, 0.f, 0.f, -1.f);
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        bool active = false;
-        if (f < K.m) {
-            fp = K.feat[f];
-            if (fp.w >= 0.f) {
-                associate_to_map(q, t, fp, sx, sy, sz);
-                active = owns(P, f, sx, sy, sz);
-            }
-        }
-        MLH_KSTAGE(1);
-        if (active) {                                   // uniform over the 16-lane group
-            unsigned long long keys[5];
-            knn_group16_pruned<5>(K.grid, sx, sy, sz, gl, s_run + grp * 2 * KNN_RUN_WORDS, keys);
-            MLH_KSTAGE(4);
-            // lane i < 5 fetches winner i: ONE load per lane, issued by all five together (a branch per winner would make five
-            // dependent round trips of this)
-            unsigned long long kk = keys[0];
-#pragma unroll
-            for (int i = 1; i < 5; ++i) kk = (gl == i) ? keys[i] : kk;
-            if (gl < 5) {
-                float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
-                if (kk != KEY_INF) {
-                    const float4 np = K.grid.raw[(unsigned)kk];
-                    o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
-                }
-                s_nbr[grp * 5 + gl] = o;
-            }
-        }
-        if (gl == 0) {
-            s_feat[grp] = fp;
-            s_map[grp] = make_float4(sx, sy, sz, active ? 1.f : 0.f);
-        }
-    }
-    __syncthreads();
-    MLH_KSTAGE(5);
-    if (threadIdx.x < 64) {   // ---------------- phase B: one feature per lane of the first wavefront
-        // a pure VALU chain next to other workgroups' memory-bound search waves on the same SIMD: take the issue slots
-        __builtin_amdgcn_s_setprio(3);
-        const int lane = threadIdx.x;
-        const int f = P.strided ? lane * K.tiles_f + tile : tile * FQPB + lane;
-        bool valid = false;
-        Lin L;
-        L.r = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
-        float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float4 fp = make_float4(0.f, 0.f, 0.f, -1.f);
-        if (lane < FQPB && f < K.m) {
-            fp = s_feat[lane];
-            const float4 mp = s_map[lane];
-            if (mp.w > 0.f) {
-                float4 v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = s_nbr[lane * 5 + j];
-                if (v[4].w < P.min_match_sq_dis) {          // sq_dis[k-1] < MIN_MATCH_SQ_DIS (hpp:667/814)
-                    float ax[5], ay[5], az[5];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) { ax[j] = v[j].x; ay[j] = v[j].y; az[j] = v[j].z; }
-                    valid = kind == MLH_SURF ? fit_plane<5>(ax, ay, az, P.min_plane_dis, coef) : fit_line<5>(ax, ay, az, coef);
-                    if (valid && (P.flags & MLH_FLAG_CHECK_FOV)) valid = in_laser_fov(q, t, mp.x, mp.y, mp.z);
-                }
-            }
-            Corr c;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c.c[i] = valid ? coef[i] : 0.f;
-            c.valid = valid ? 1 : 0;
-            c.pad = 0;
-            K.corr[f] = c;
-        }
-        if (valid) {
-            const double w = feature_weight(P, K, f);
-            double R[9];
-            qtorot(q, R);
-            const d3 p{double(fp.x), double(fp.y), double(fp.z)};
-            if (kind == MLH_SURF) eval_plane(p, coef, w, q, t, R, L);
-            else eval_edge(p, coef, w, q, t, R, L);
-        }
-        if (K.r_out && lane < FQPB && f < K.m) {
-            K.r_out[f] = L.r;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
-        }
-        reduce_rows_wave(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, P.partials + size_t(gtile) * NE_STRIDE);
-    }
-    MLH_KSTAGE(6);
-    if (P.finish) fused_gn_finish<false, FTPB>(P, total);
-    MLH_KSTAGE(7);
-}
-
 #ifdef MLH_STAGE_CLOCK
 }  // namespace mlh
 extern "C" int mlh_debug_stage_clock(unsigned long long *out, int n_words)
@@ -882,14 +685,13 @@ void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
         lanes[k] = queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16);
         if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) lanes[k] = ctx->knn_lanes_override;
         if (ctx->knn_lanes_override == 816) lanes[k] = k == 0 ? 8 : 16;
-        if (!ctx->fused_disable) lanes[k] = 16;      // the single-launch kernel (opt-in, MLH_FUSED=1) is written for 16-lane groups
     }
 }
 
 static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
 {
     std::memset(&P, 0, sizeof(P));
-    int tiles_b_total = 0, tiles_f_total = 0;
+    int tiles_b_total = 0;
     P.n_blocks = a.n_blocks > 0 ? a.n_blocks : 1;
     int kmax = 5;
     for (int b = 0; b < P.n_blocks; ++b) {
@@ -934,15 +736,13 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         K.lanes = lanes[k];
         K.tiles_a = (fs.m + TPB / K.lanes - 1) / (TPB / K.lanes);
         K.tiles_b = (fs.m + TPB - 1) / TPB;
-        K.tiles_f = (fs.m + FQPB - 1) / FQPB;
         K.nbr_stride = fs.nbr_stride;
         for (int b = 0; b <= MAX_BLOCKS; ++b) K.blk_start[b] = fs.blk_start[std::min(b, fs.n_blocks)];
         tiles_b_total += K.tiles_b;
-        tiles_f_total += K.tiles_f;
     }
     if (tiles_b_total == 0) return fail(ctx, MLH_ERR_STATE, "no map/features staged for the requested kinds");
     hipError_t e;
-    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(std::max(tiles_b_total, tiles_f_total)))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
+    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
     if (!ctx->ticket.p) {
         if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
         if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
@@ -960,7 +760,6 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.has_hi = ctx->shard_hi ? 1 : 0;
     P.own_mod = ctx->own_mod; P.own_rem = ctx->own_rem;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
-    P.strided = ctx->fused_strided ? 1 : 0;
     P.finish = a.finish;
     P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
     P.use_init = a.init_pose ? 1 : 0;
@@ -993,26 +792,6 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     const bool mb = P.n_blocks > 1;
     bool k10 = false;
     for (int b = 0; b < P.n_blocks; ++b) k10 = k10 || P.kb[b] == 10;
-    if (!mb && !k10 && P.knn_lanes == 16 && !ctx->fused_disable) {
-        // one launch per evaluation: search + fit + linearise + reduce (+ the solver finish in its last workgroup)
-        const int grid_f = ((P.k[0].tiles_f + P.k[1].tiles_f + 7) / 8) * 8;
-        ctx->n_partial_tiles = P.k[0].tiles_f + P.k[1].tiles_f;
-        hipEvent_t ea = nullptr, eb = nullptr;
-        const bool timed = prof_kernel_events(ctx, MLH_K_KNN, &ea, &eb);
-        // the Levenberg-Marquardt begin is register-hungry (three 6x6 f64 matrices in one lane): fused in here it would cap this
-        // launch's occupancy, so it follows as its own single-workgroup launch and takes the initial pose with its arguments
-        const bool lm_begin = P.finish == 3;
-        if (lm_begin) { P.finish = 0; P.publish = nullptr; }
-        if (timed) hipExtLaunchKernelGGL(match_fused_kernel, dim3(grid_f), dim3(FTPB), 0, ctx->stream, ea, eb, 0, P);
-        else hipLaunchKernelGGL(match_fused_kernel, dim3(grid_f), dim3(FTPB), 0, ctx->stream, P);
-        if (lm_begin) {
-            const int rc2 = lm_begin_launch(ctx, a.eig_thre[0], a.lm_max_it, a.stat_slot, a.lm_min_blocks, a.init_pose);
-            if (rc2) return rc2;
-        }
-        MLH_HIP(ctx, hipGetLastError());
-        for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;
-        return MLH_OK;
-    }
     {
         // <lanes, pose blocks, any block with K = 10>
 #define MLH_KNN_LAUNCH(G_) do { \

@@ -1,8 +1,8 @@
 """Oracle-vs-HIP parity at BASELINE sizes: config 2 (2 x 64 rings vs the ~500k-point map), through the C-ABI,
 against the LIVE oracle on the same seeded inputs -- labels / picked flags / index lists bit-exact per 64-ring scan and for the joint
 128-ring upload, k-NN indices + f32 distances, correspondence validity + coefficient bits, H / g 1e-9, per-iteration counts and the
-5-GN pose, scan2map's LM bookkeeping. Every match path of the library is held to the same oracle results: the fused single-launch
-kernel (strided and consecutive feature assignment) and the two-kernel path (MLH_FUSED=0)."""
+5-GN pose, scan2map's LM bookkeeping. Every lane width of the correspondence search is held to the same oracle results: 8 / 16 lanes per query chosen
+per kind from the map's density (the default), and either width forced for both kinds (MLH_KNN_LANES)."""
 import os
 import warnings
 
@@ -46,8 +46,7 @@ def _ctx_with_env(mla, **env):
                 os.environ[k] = v
 
 
-MODES = {"fused_strided": dict(MLH_FUSED=1, MLH_FUSED_STRIDED=1), "fused_consecutive": dict(MLH_FUSED=1, MLH_FUSED_STRIDED=0),
-         "two_kernel": dict(MLH_FUSED=0)}
+MODES = {"lanes_per_kind": dict(), "lanes_8": dict(MLH_KNN_LANES=8), "lanes_16": dict(MLH_KNN_LANES=16)}
 
 
 @pytest.fixture(scope="module", params=list(MODES))
