@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--shard-mode", default="map", choices=["map", "features"],
                     help="N > 1: 'map' = angular wedges of the map + halo, ownership by position (BASELINE's partition); 'features' = whole map on every "
                          "rank, features dealt round-robin (SURVEY 8e's balanced alternative)")
+    ap.add_argument("--no-overlap-staging", action="store_true",
+                    help="pipelined submission, but the next frame's maps are staged on the solver's own stream (queued behind the solve) instead of on a second stream")
     ap.add_argument("--synchronous", action="store_true",
                     help="read every frame's pose before the next frame's map staging is enqueued (rounds 1-2's loop) instead of one frame late")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
@@ -266,7 +268,10 @@ def main():
         if args.map_rebuild_only:
             ctx.map_rebuild(mla.ALL_KINDS)
         elif not args.no_map_rebuild:
-            ctx.map_set_pair(d_surf_map, d_corner_map)
+            if pipelined and in_flight[0] and not args.no_overlap_staging:
+                ctx.map_set_pair_overlapped(d_surf_map, d_corner_map)      # next frame's index built on a second stream, into the other map set
+            else:
+                ctx.map_set_pair(d_surf_map, d_corner_map)
 
     def step_sync():
         stage_maps()
@@ -283,8 +288,8 @@ def main():
         if not pipelined:
             return step_sync()
         stage_maps()
-        pose_prev = ctx.gn_solve_end() if in_flight[0] else None
-        ctx.gn_solve_begin(p0, GN_ITERS, opts)
+        ctx.gn_solve_begin(p0, GN_ITERS, opts)          # frame k submitted (queued behind frame k - 1 on the stream) ...
+        pose_prev = ctx.gn_solve_end() if in_flight[0] else None      # ... then frame k - 1's pose collected: the GPU goes from one frame straight into the next
         in_flight[0] = True
         return pose_prev
 
@@ -510,7 +515,9 @@ def main():
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    ms_per_step_synchronous_submission=round(ms_per_step_sync, 4),
-                   frame_submission=("pipelined: frame k's pose is collected after frame k+1's map staging has been enqueued behind its solve (mlh_gn_solve_begin / _end)"
+                   frame_submission=(("pipelined + overlapped staging: frame k+1's maps are staged and indexed on a second stream, into the other map set, while frame k's solve "
+                                      "runs (mlh_map_set_pair_overlapped); its pose is collected afterwards (mlh_gn_solve_begin / _end)" if not args.no_overlap_staging else
+                                      "pipelined: frame k's pose is collected after frame k+1's map staging has been enqueued behind its solve (mlh_gn_solve_begin / _end)")
                                      if pipelined else "synchronous: every pose is read before the next frame is staged"),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),

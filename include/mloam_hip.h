@@ -286,6 +286,13 @@ int mlh_map_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, in
  * device and takes the bounds pass again. Results never depend on which way a call went (the grid is an acceleration structure only). */
 int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                      float min_match_sq_dis, int mem);
+/* The same, for the NEXT frame while a solve submitted with mlh_gn_solve_begin is still running: the maps are double-buffered, this call stages and indexes
+ * into the set the solve does not read, on a second stream, returns when that index is complete and makes the set current -- launches enqueued afterwards (the
+ * next mlh_gn_solve_begin) read it; the solve in flight keeps the old one (one solve in flight at this point: collect the older one first). The local map of frame k + 1 does not depend on frame k's optimised pose unless frame k
+ * becomes a keyframe (lidar_mapper_keyframe.cpp:254-354 selects the surrounding keyframes from the PREDICTED pose), so a mapper can issue it this early; the
+ * GPU then builds the next index (a chain of small launches) in the shadow of the current frame's iterations. Without a solve in flight: mlh_map_set_pair. */
+int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                                float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);
 /* diagnostics of the resident index (no reference counterpart: pcl::KdTreeFLANN exposes nothing of the kind): points, non-empty grid
  * cells, the population of the cell an average map point lives in (sum of squared cell populations / n), and the lanes per query the
@@ -399,7 +406,8 @@ typedef struct mlh_iter_stat {
 int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
 /* The same solve submitted and collected separately (single GPU, no statistics): _begin enqueues the n_iters iterations and returns at once, _end waits for the
  * pose. Between the two the caller may stage the NEXT frame's maps (mlh_map_set_pair): those launches queue up behind the solve on the context's stream, so the
- * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). One solve in flight per context. */
+ * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). At most two solves in flight per context
+ * (frame k + 1 may be submitted before frame k's pose is collected); mlh_gn_solve_end returns them in submission order. */
 int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts);
 int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7]);
 

@@ -126,6 +126,7 @@ def load_library():
     lib.mlh_voxel_filter.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, C.POINTER(C.c_int32), ci]
     lib.mlh_map_set.argtypes = [vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_set_pair.argtypes = [vp, vp, ci, vp, ci, ci, cf, ci]
+    lib.mlh_map_set_pair_overlapped.argtypes = [vp, vp, ci, vp, ci, ci, cf, ci]
     lib.mlh_map_rebuild.argtypes = [vp, ci]
     lib.mlh_map_info.argtypes = [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_set_voxel_member_order.argtypes = [vp, ci]
@@ -164,7 +165,7 @@ EXPORTED_SYMBOLS = [
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
-    "mlh_map_set", "mlh_map_set_pair", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
+    "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_end", "mlh_scan2map",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -559,6 +560,13 @@ class Context:
         pc, sc, nc, mc, kc = _src(corner_points)
         assert ss == sc and ms == mc
         self._ck(self.lib.mlh_map_set_pair(self.h, ps, ns, pc, nc, ss, min_match_sq_dis, ms))
+
+    def map_set_pair_overlapped(self, surf_points, corner_points, min_match_sq_dis=1.0):
+        """stage the NEXT frame's maps while a submitted solve still runs (double-buffered map sets, second stream); see mlh_map_set_pair_overlapped"""
+        ps, ss, ns, mems, _k1 = _src(surf_points)
+        pc, sc, nc, memc, _k2 = _src(corner_points)
+        assert ss == sc and mems == memc
+        self._ck(self.lib.mlh_map_set_pair_overlapped(self.h, ps, ns, pc, nc, ss, min_match_sq_dis, mems))
 
     def map_rebuild(self, kind):
         self._ck(self.lib.mlh_map_rebuild(self.h, kind))

@@ -263,8 +263,10 @@ void mlh_destroy(mlh_ctx *ctx)
     prof_collect(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
-        MapGrid &m = ctx->map[k];
-        m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); m.occ.release();
+        for (int set = 0; set < 2; ++set) {
+            MapGrid &m = ctx->map_sets[set][k];
+            m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); m.occ.release();
+        }
         FeatSet &f = ctx->feat[k];
         f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release();
     }
@@ -287,6 +289,8 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
+    for (int i = 0; i < 2; ++i) if (ctx->ev_set_built[i]) (void)hipEventDestroy(ctx->ev_set_built[i]);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -617,6 +621,50 @@ int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const vo
     const void *pts[2] = {surf_points, corner_points};
     const int n[2] = {n_surf, n_corner};
     return map_set_impl(ctx, 2, kinds, pts, n, stride_bytes, min_match_sq_dis, mem);
+}
+
+// The next frame's maps staged WHILE a submitted solve (mlh_gn_solve_begin) still runs on the current ones: pack + fit check + index build go to the
+// context's second stream and into the other map set; the main stream gets a wait on their completion behind whatever is already queued there, and the
+// context switches to the new set, so every launch enqueued after this call reads it. Without a solve in flight it behaves like mlh_map_set_pair.
+int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                                float min_match_sq_dis, int mem)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    if (!ctx->solve_pending) return mlh_map_set_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, min_match_sq_dis, mem);
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->stream2) {
+        MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_set_built[i], hipEventDisableTiming));
+    }
+    // The other set's last reader is the solve submitted BEFORE the one in flight; with at most one solve in flight here it has been collected, i.e. it is done:
+    // no device-side wait is needed before its buffers are overwritten. (Round 3 first ordered the two streams with events on the solver's stream -- a record
+    // after every solve, a wait before the next: two barrier packets, ~10 us of idle stream per frame in the kernel trace. Both are gone: the host orders.)
+    if (ctx->solve_seq - ctx->solve_collected > 1) return fail(ctx, MLH_ERR_STATE, "collect the older solve (mlh_gn_solve_end) before staging the next frame's maps");
+    const int target = 1 - ctx->map_set_cur;
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;                    // everything map_set_impl enqueues (and its profiling brackets) goes to the staging stream ...
+    ctx->map = ctx->map_sets[target];              // ... and into the other set
+    const int kinds[2] = {MLH_SURF, MLH_CORNER};
+    const void *pts[2] = {surf_points, corner_points};
+    const int n[2] = {n_surf, n_corner};
+    const int rc = map_set_impl(ctx, 2, kinds, pts, n, stride_bytes, min_match_sq_dis, mem);
+    ctx->stream = main_stream;
+    if (rc) { ctx->map = ctx->map_sets[ctx->map_set_cur]; return rc; }
+    ctx->map_set_cur = target;
+    // the index must be complete before anything that reads it is enqueued on the solver's stream: waited for HERE, on the host (the build is ~30 us of
+    // small launches, the solve in flight another ~100), so that the solver's stream carries no cross-stream wait at all
+    MLH_HIP(ctx, hipEventRecord(ctx->ev_set_built[target], ctx->stream2));
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (hipEventQuery(ctx->ev_set_built[target]) == hipErrorNotReady) {
+            if ((++spins & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream2)); break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    return MLH_OK;
 }
 
 int mlh_map_rebuild(mlh_ctx *ctx, int kind)
@@ -1025,32 +1073,35 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 // ---- the same solve, submitted and collected separately: mlh_gn_solve_begin enqueues the iterations and returns; mlh_gn_solve_end waits for the pose. A caller that
 // stages the NEXT frame's maps between the two (mlh_map_set_pair: its launches queue up behind this solve on the context's stream) keeps the GPU busy across
 // the frame boundary -- the ~16 us of host turn-around between "pose published" and "next frame's first launch" (profiles/r03_step_timeline.txt) disappear.
-// The result travels through its own pinned record: the staging call's hand-shake uses the context's other one in between.
+// Up to TWO solves may be in flight (frame k + 1 submitted before frame k's pose is collected: the GPU starts it the moment frame k is done instead of after the
+// host has seen the pose and enqueued ten launches); each publishes into its own pinned record, apart from the one the staging hand-shake uses.
 int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts)
 {
     if (!ctx || !pose_in || !opts || n_iters <= 0) return MLH_ERR_INVALID;
     if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
-    if (ctx->solve_pending) return fail(ctx, MLH_ERR_STATE, "a solve is already in flight: collect it with mlh_gn_solve_end first");
+    if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one with mlh_gn_solve_end first");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, 0);
     if (rc) return rc;
     const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
     if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
     if (!ctx->h_solve) {
-        MLH_HIP(ctx, hipHostMalloc(&ctx->h_solve, sizeof(HostPublish), hipHostMallocDefault));
-        std::memset(ctx->h_solve, 0, sizeof(HostPublish));
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_solve, 2 * sizeof(HostPublish), hipHostMallocDefault));      // one record per solve in flight
+        std::memset(ctx->h_solve, 0, 2 * sizeof(HostPublish));
     }
+    const unsigned long long seq = ctx->solve_seq + 1;
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
         if (it == 0) a.init_pose = pose_in;
         a.finish = 1;
         a.stat_slot = -1;
         if (it == n_iters - 1) {
-            a.publish = static_cast<HostPublish *>(ctx->h_solve);
-            a.publish_seq = ++ctx->solve_seq;
+            a.publish = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
+            a.publish_seq = seq;
         }
         if ((rc = match_launch(ctx, a))) return rc;
     }
+    ctx->solve_seq = seq;
     ctx->solve_pending = true;
     return MLH_OK;
 }
@@ -1058,12 +1109,14 @@ int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const
 int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7])
 {
     if (!ctx || !pose_out) return MLH_ERR_INVALID;
-    if (!ctx->solve_pending) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_gn_solve_begin)");
+    if (ctx->solve_seq == ctx->solve_collected) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_gn_solve_begin)");
+    const unsigned long long seq = ctx->solve_collected + 1;        // the oldest one
     HostPublish hp;
-    int rc = wait_published(ctx, ctx->solve_seq, hp, ctx->h_solve);
-    ctx->solve_pending = false;
+    int rc = wait_published(ctx, seq, hp, static_cast<HostPublish *>(ctx->h_solve) + (seq & 1));
+    ctx->solve_collected = seq;
+    ctx->solve_pending = ctx->solve_seq != ctx->solve_collected;
     if (rc) return rc;
-    if (!ctx->prof.pending.empty()) {
+    if (!ctx->prof.pending.empty() && !ctx->solve_pending) {
         if (ctx->prof.mask & ((1u << MLH_K_FIT) | (1u << MLH_K_SOLVE))) MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         prof_collect(ctx);
     }

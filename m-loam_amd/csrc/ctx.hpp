@@ -230,7 +230,15 @@ struct mlh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    mlh::MapGrid map[2];
+    // The local maps are double-buffered: `map` points at the set the solvers read; mlh_map_set_pair_overlapped stages the NEXT frame's maps into the
+    // other set on a second stream while a submitted solve still reads this one, then switches `map` (launches capture a set's device pointers when they
+    // are enqueued, so solves already in flight keep theirs).
+    mlh::MapGrid map_sets[2][2];
+    mlh::MapGrid *map = map_sets[0];
+    int map_set_cur = 0;
+    hipStream_t stream2 = nullptr;            // staging stream of the overlapped path (created on first use)
+    hipEvent_t ev_set_built[2] = {nullptr, nullptr};   // recorded on the staging stream when set s has been built (the host waits on it)
+
     mlh::FeatSet feat[2];
     mlh::ScanBuf scan;
     mlh::DevBuf state;       // SolverState
@@ -243,7 +251,7 @@ struct mlh_ctx {
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
     void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
-    unsigned long long solve_seq = 0;
+    unsigned long long solve_seq = 0, solve_collected = 0;   // submitted / collected solves (at most two apart)
     bool solve_pending = false;
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
     void *h_occ = nullptr;   // pinned mirror of the two maps' occupancy totals (grid.hip): {cells, squares} per kind, written behind every index build

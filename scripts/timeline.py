@@ -1,5 +1,5 @@
 """Prints the GPU timeline of a few bench steps from a rocprofv3 rocpd database (kernel + memory-copy trace):
-start offset, duration and the idle gap before every kernel / copy. Usage: python scripts/timeline.py <results.db> [n_rows] [first_kernel]"""
+start offset, duration and the idle gap before every kernel / copy. Usage: python scripts/timeline.py <results.db> [n_rows] [first_kernel] [fraction of the run at which the window starts]"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -15,7 +15,7 @@ rows.sort()
 mid = len(rows) // 2
 # align to the start of a step: find the next cell_count kernel (or the one named on the command line)
 first = sys.argv[3] if len(sys.argv) > 3 else "cell_count"
-mid = int(len(rows) * 0.8) if len(sys.argv) > 3 else mid
+mid = int(len(rows) * (float(sys.argv[4]) if len(sys.argv) > 4 else 0.8)) if len(sys.argv) > 3 else mid
 while mid < len(rows) and first not in rows[mid][2]:
     mid += 1
 win = rows[mid: mid + n]

@@ -497,14 +497,35 @@ def test_gn_solve_submitted_and_collected_separately(mla, case16, feats16):
         with pytest.raises(mla.MlhError):
             c.gn_solve_end()                                         # nothing in flight
         c.gn_solve_begin(case16["p0"], 4)
+        c.gn_solve_begin(case16["p0"], 4)                            # two in flight are allowed (frame k + 1 submitted before frame k is collected) ...
         with pytest.raises(mla.MlhError):
-            c.gn_solve_begin(case16["p0"], 4)                        # one solve in flight per context
-        assert np.array_equal(c.gn_solve_end(), want)
+            c.gn_solve_begin(case16["p0"], 4)                        # ... a third is not
+        assert np.array_equal(c.gn_solve_end(), want) and np.array_equal(c.gn_solve_end(), want)
         for _ in range(3):                                           # frames back to back: stage k + 1 behind solve k, then read pose k
             c.gn_solve_begin(case16["p0"], 4)
             c.map_set_pair(case16["surf_map"], case16["corner_map"])
             assert np.array_equal(c.gn_solve_end(), want)
         again, _ = c.gn_solve(case16["p0"], 4, want_stats=False)     # the synchronous call still works afterwards
         assert np.array_equal(again, want)
+        # overlapped staging: the next frame's maps go to the other map set on a second stream while the solve runs. Alternate two DIFFERENT map pairs
+        # (the second one shifted by 3 cm, so its solve has a different answer): every solve must see exactly the maps staged for it.
+        moved_s, moved_c = case16["surf_map"].copy(), case16["corner_map"].copy()
+        moved_s[:, 0] += 0.03; moved_c[:, 0] += 0.03
+        c.map_set_pair(moved_s, moved_c)
+        want_moved, _ = c.gn_solve(case16["p0"], 4, want_stats=False)
+        assert np.abs(want_moved - want).max() > 1e-3
+        c.map_set_pair(case16["surf_map"], case16["corner_map"])
+        c.gn_solve_begin(case16["p0"], 4)                            # frame 0 on the original maps
+        got = []
+        for k in range(1, 7):
+            maps = (moved_s, moved_c) if k % 2 else (case16["surf_map"], case16["corner_map"])
+            c.map_set_pair_overlapped(*maps)                         # frame k's maps, while frame k - 1 is being solved
+            c.gn_solve_begin(case16["p0"], 4)                        # frame k submitted before frame k - 1 is collected (bench.py's order)
+            got.append(c.gn_solve_end())
+        got.append(c.gn_solve_end())
+        for k, pose in enumerate(got):
+            assert np.array_equal(pose, want_moved if k % 2 else want), k
+        info = c.map_info(mla.SURF)
+        assert info["n"] == len(case16["surf_map"])
     finally:
         c.close()
