@@ -633,7 +633,19 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
     if (!ctx->solve_pending) return mlh_map_set_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, min_match_sq_dis, mem);
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->stream2) {
-        MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        // The staging stream may use half of the compute units (CU mask words 0-3): its kernels are atomics- / latency-bound and lose ~5 % on 128 CUs, while the
+        // solver's launches they run beside lose less to them (step 0.1452 -> 0.1415 ms, three alternations in one gpurun call; every other CU, a quarter of the
+        // CUs and 8 CUs per 32 measured no better). MLH_STAGE_CU_MASK=<hex word for CUs 0-127>[,<hex word for CUs 128-255>] overrides (ffffffff,ffffffff = no mask).
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        if (const char *m = std::getenv("MLH_STAGE_CU_MASK")) {
+            char *rest = nullptr;
+            lo = static_cast<uint32_t>(std::strtoul(m, &rest, 16));
+            hi = (rest && *rest == ',') ? static_cast<uint32_t>(std::strtoul(rest + 1, nullptr, 16)) : lo;
+        }
+        uint32_t words[8];
+        for (int i = 0; i < 8; ++i) words[i] = i < 4 ? lo : hi;
+        if (lo == 0xffffffffu && hi == 0xffffffffu) MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        else MLH_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->stream2, 8, words));
         for (int i = 0; i < 2; ++i) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_set_built[i], hipEventDisableTiming));
     }
     // The other set's last reader is the solve submitted BEFORE the one in flight; with at most one solve in flight here it has been collected, i.e. it is done:
