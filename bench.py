@@ -288,8 +288,16 @@ def main():
         if not pipelined:
             return step_sync()
         stage_maps()
-        ctx.gn_solve_begin(p0, GN_ITERS, opts)          # frame k submitted (queued behind frame k - 1 on the stream) ...
-        pose_prev = ctx.gn_solve_end() if in_flight[0] else None      # ... then frame k - 1's pose collected: the GPU goes from one frame straight into the next
+        if in_flight[0]:
+            # frame k submitted behind frame k - 1, which is still running: its start pose is the reference's chain -- transformUpdate with frame k - 1's result,
+            # transformAssociateToMap with frame k's odometry (lidar_mapper_keyframe.cpp:145-160) -- evaluated on the device (mlh_gn_solve_begin_chained). The
+            # synthetic odometry says "frame k - 1 ended at the converged pose, frame k starts at p0 again", so every frame starts within 1e-15 of p0 and does
+            # the work of the solve counted above; the dependency on the previous frame's result is real and stays on the device.
+            ctx.gn_solve_begin_chained(pose_converged, p0, GN_ITERS, opts)
+            pose_prev = ctx.gn_solve_end()               # ... then frame k - 1's pose collected: the GPU goes from one frame straight into the next
+        else:
+            ctx.gn_solve_begin(p0, GN_ITERS, opts)
+            pose_prev = None
         in_flight[0] = True
         return pose_prev
 
@@ -300,7 +308,7 @@ def main():
         return None
 
     # valid correspondences per iteration (deterministic: the timed steps repeat exactly this solve)
-    _, it_stats = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=True)
+    pose_converged, it_stats = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=True)
     n_valid_iter = [(int(s_["n_surf"]), int(s_["n_corner"])) for s_ in it_stats]
     # (N > 1: the counts come out of the all-reduced record, i.e. they are already the whole job's)
     n_valid_step = int(sum(a_ + b_ for a_, b_ in n_valid_iter))
@@ -516,8 +524,9 @@ def main():
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    ms_per_step_synchronous_submission=round(ms_per_step_sync, 4),
                    frame_submission=(("pipelined + overlapped staging: frame k+1's maps are staged and indexed on a second stream, into the other map set, while frame k's solve "
-                                      "runs (mlh_map_set_pair_overlapped); its pose is collected afterwards (mlh_gn_solve_begin / _end)" if not args.no_overlap_staging else
-                                      "pipelined: frame k's pose is collected after frame k+1's map staging has been enqueued behind its solve (mlh_gn_solve_begin / _end)")
+                                      "runs (mlh_map_set_pair_overlapped); frame k+1's solve is submitted behind it with its start pose chained on the device from frame k's result "
+                                      "(mlh_gn_solve_begin_chained: transformUpdate + transformAssociateToMap); poses are collected one frame late (mlh_gn_solve_end)" if not args.no_overlap_staging else
+                                      "pipelined: frame k's pose is collected after frame k+1's map staging and solve (start pose chained on the device) have been enqueued behind its solve")
                                      if pipelined else "synchronous: every pose is read before the next frame is staged"),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),

@@ -288,9 +288,13 @@ int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const vo
                      float min_match_sq_dis, int mem);
 /* The same, for the NEXT frame while a solve submitted with mlh_gn_solve_begin is still running: the maps are double-buffered, this call stages and indexes
  * into the set the solve does not read, on a second stream, returns when that index is complete and makes the set current -- launches enqueued afterwards (the
- * next mlh_gn_solve_begin) read it; the solve in flight keeps the old one (one solve in flight at this point: collect the older one first). The local map of frame k + 1 does not depend on frame k's optimised pose unless frame k
- * becomes a keyframe (lidar_mapper_keyframe.cpp:254-354 selects the surrounding keyframes from the PREDICTED pose), so a mapper can issue it this early; the
- * GPU then builds the next index (a chain of small launches) in the shadow of the current frame's iterations. Without a solve in flight: mlh_map_set_pair. */
+ * next mlh_gn_solve_begin) read it; the solve in flight keeps the old one (one solve in flight at this point: collect the older one first). 
+ * The GPU then builds the next index (a chain of small launches) in the shadow of the current frame's iterations. What the caller must know: in the reference the
+ * local map of frame k + 1 depends on frame k's optimised pose in one place -- extractSurroundingKeyFrames (lidar_mapper_keyframe.cpp:254-354) picks the keyframes
+ * within a radius of the PREDICTED pose of frame k + 1, which carries frame k's map-to-odometry correction (cpp:145-160). A caller that stages this early selects
+ * with the correction of frame k - 1 and re-checks the selection when frame k's pose arrives (a radius test over the keyframe positions on the host); the set
+ * changes only when a keyframe sits within the change of the correction (sub-centimetre) of the radius, and then the frame is staged and solved again
+ * synchronously. INTEGRATION.md section 2 spells the loop out. Without a solve in flight: mlh_map_set_pair. */
 int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                                 float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);
@@ -409,6 +413,12 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
  * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). At most two solves in flight per context
  * (frame k + 1 may be submitted before frame k's pose is collected); mlh_gn_solve_end returns them in submission order. */
 int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts);
+/* Frame k + 1 submitted while frame k is still being solved: its start pose is the reference's -- transformUpdate() with frame k's RESULT and odometry pose, then
+ * transformAssociateToMap() with frame k + 1's odometry pose (lidar_mapper_keyframe.cpp:145-160: pose_wmap_wodom = pose_wmap_curr * pose_wodom_curr.inverse();
+ * pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr; Pose::operator* and Pose::inverse as pose.cpp:99-113) -- computed ON THE DEVICE from the pose the previous
+ * solve leaves there, by a one-lane launch in front of the iterations. wodom_prev / wodom_cur: [t, q] of the odometry poses of frame k and frame k + 1. The data
+ * dependency between consecutive frames stays where the data is; the host never needs frame k's pose to submit frame k + 1. */
+int mlh_gn_solve_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], int n_iters, const mlh_solver_opts *opts);
 int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7]);
 
 /* Per-block options of mlh_gn_solve_blocks. k_neigh: N_NEIGH of the block's correspondences (5 for the reference LiDAR, 10 for

@@ -142,6 +142,40 @@ __global__ void init_state_kernel(SolverState *S, PoseArg pose)
     if (threadIdx.x < 6) S->V[threadIdx.x * 7] = 1.0;
 }
 
+// The pose the mapper starts frame k+1 from, computed where frame k's result lives (lidar_mapper_keyframe.cpp:145-160): transformUpdate,
+// pose_wmap_wodom = pose_wmap_curr * pose_wodom_curr.inverse(), then transformAssociateToMap, pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr, with
+// Pose::operator* / Pose::inverse as pose.cpp:99-113 write them (both construct through Pose(q, t), which normalises the quaternion; Quaterniond::inverse is
+// conjugate / squaredNorm). One lane; the solve enqueued behind it reads S->x.
+__device__ inline void pose_ctor_qt(const q4 &q, const d3 &t, q4 &qo, d3 &to)
+{
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    qo = q4{q.x / n, q.y / n, q.z / n, q.w / n};
+    to = t;
+}
+__global__ void chain_pose_kernel(SolverState *S, PoseArg wodom_prev, PoseArg wodom_cur)
+{
+    if (threadIdx.x != 0) return;
+    const q4 qc{S->x[3], S->x[4], S->x[5], S->x[6]};
+    const d3 tc{S->x[0], S->x[1], S->x[2]};
+    // pose_wodom_curr.inverse()
+    const q4 qp{wodom_prev.p[3], wodom_prev.p[4], wodom_prev.p[5], wodom_prev.p[6]};
+    const double n2 = qp.x * qp.x + qp.y * qp.y + qp.z * qp.z + qp.w * qp.w;
+    const q4 qinv = n2 > 0.0 ? q4{-qp.x / n2, -qp.y / n2, -qp.z / n2, qp.w / n2} : q4{0.0, 0.0, 0.0, 0.0};
+    const d3 mt = qrot(qinv, d3{wodom_prev.p[0], wodom_prev.p[1], wodom_prev.p[2]});
+    q4 qi; d3 ti;
+    pose_ctor_qt(qinv, d3{-mt.x, -mt.y, -mt.z}, qi, ti);
+    // pose_wmap_wodom = pose_wmap_curr * inverse
+    const d3 r1 = qrot(qc, ti);
+    q4 qw; d3 tw;
+    pose_ctor_qt(qmul(qc, qi), d3{r1.x + tc.x, r1.y + tc.y, r1.z + tc.z}, qw, tw);
+    // pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr (the next frame's)
+    const d3 r2 = qrot(qw, d3{wodom_cur.p[0], wodom_cur.p[1], wodom_cur.p[2]});
+    q4 qn; d3 tn;
+    pose_ctor_qt(qmul(qw, q4{wodom_cur.p[3], wodom_cur.p[4], wodom_cur.p[5], wodom_cur.p[6]}), d3{r2.x + tw.x, r2.y + tw.y, r2.z + tw.z}, qn, tn);
+    S->x[0] = tn.x; S->x[1] = tn.y; S->x[2] = tn.z; S->x[3] = qn.x; S->x[4] = qn.y; S->x[5] = qn.z; S->x[6] = qn.w;
+    for (int i = 0; i < 7; ++i) S->cand[i] = S->x[i];
+}
+
 __global__ void set_block_pose_kernel(SolverState *S, int b, PoseArg pose)
 {
     if (threadIdx.x < 7) S->xb[b][threadIdx.x] = pose.p[threadIdx.x];
@@ -1087,9 +1121,8 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 // the frame boundary -- the ~16 us of host turn-around between "pose published" and "next frame's first launch" (profiles/r03_step_timeline.txt) disappear.
 // Up to TWO solves may be in flight (frame k + 1 submitted before frame k's pose is collected: the GPU starts it the moment frame k is done instead of after the
 // host has seen the pose and enqueued ten launches); each publishes into its own pinned record, apart from the one the staging hand-shake uses.
-int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts)
+static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, int n_iters, const mlh_solver_opts *opts)
 {
-    if (!ctx || !pose_in || !opts || n_iters <= 0) return MLH_ERR_INVALID;
     if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
     if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one with mlh_gn_solve_end first");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
@@ -1102,9 +1135,15 @@ int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const
         std::memset(ctx->h_solve, 0, 2 * sizeof(HostPublish));
     }
     const unsigned long long seq = ctx->solve_seq + 1;
+    if (!pose_in) {                                // chained: the start pose is made on the device from the pose the previous solve left there
+        PoseArg pa, pb;
+        for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
+        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb);
+        MLH_HIP(ctx, hipGetLastError());
+    }
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
-        if (it == 0) a.init_pose = pose_in;
+        if (it == 0) a.init_pose = pose_in;        // null when chained: the kernels read the state's pose
         a.finish = 1;
         a.stat_slot = -1;
         if (it == n_iters - 1) {
@@ -1116,6 +1155,19 @@ int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const
     ctx->solve_seq = seq;
     ctx->solve_pending = true;
     return MLH_OK;
+}
+
+int mlh_gn_solve_begin(mlh_ctx *ctx, const double pose_in[7], int n_iters, const mlh_solver_opts *opts)
+{
+    if (!ctx || !pose_in || !opts || n_iters <= 0) return MLH_ERR_INVALID;
+    return gn_solve_submit(ctx, pose_in, nullptr, nullptr, n_iters, opts);
+}
+
+int mlh_gn_solve_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], int n_iters, const mlh_solver_opts *opts)
+{
+    if (!ctx || !wodom_prev || !wodom_cur || !opts || n_iters <= 0) return MLH_ERR_INVALID;
+    if (ctx->solve_seq == 0) return fail(ctx, MLH_ERR_STATE, "mlh_gn_solve_begin_chained continues from the pose a previous solve left on the device: submit the first frame with mlh_gn_solve_begin");
+    return gn_solve_submit(ctx, nullptr, wodom_prev, wodom_cur, n_iters, opts);
 }
 
 int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7])

@@ -119,6 +119,14 @@ int orc_pose_plus(const double *x, const double *delta, const double *V_update, 
     return 0;
 }
 
+// transformUpdate + transformAssociateToMap (lidar_mapper_keyframe.cpp:145-160): the mapper's start pose of the next frame
+int orc_pose_chain(const double *wmap_curr_prev, const double *wodom_prev, const double *wodom_cur, double *out)
+{
+    const Pose r = pose_chain(pose_from_param(wmap_curr_prev), pose_from_param(wodom_prev), pose_from_param(wodom_cur));
+    out[0] = r.t.x; out[1] = r.t.y; out[2] = r.t.z; out[3] = r.q.x; out[4] = r.q.y; out[5] = r.q.z; out[6] = r.q.w;
+    return 0;
+}
+
 int orc_huber(double a, double s, double *rho3) { huber_evaluate(a, s, rho3); return 0; }
 
 // per-feature r, J (weighted, not loss-corrected) + loss-corrected reduction over valid features

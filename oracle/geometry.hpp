@@ -100,4 +100,26 @@ static inline Pose pose_mul(const Pose &A, const Pose &B)
     return r;
 }
 
+// The pose the mapper starts frame k+1 from (lidar_mapper_keyframe.cpp:145-160): transformUpdate() after frame k, pose_wmap_wodom = pose_wmap_curr *
+// pose_wodom_curr.inverse(); transformAssociateToMap() before frame k+1, pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr. Pose::operator* (pose.cpp:110-113)
+// and Pose::inverse (pose.cpp:99-102) both go through Pose(q, t) (pose.cpp:34-41), which normalises the quaternion; Quaterniond::inverse is conjugate / squaredNorm.
+static inline Pose pose_ctor_qt(const Quatd &q, const Vec3d &t) { Pose r; r.q = quat_normalized(q); r.t = t; return r; }
+static inline Pose pose_inverse_ref(const Pose &P)
+{
+    const double n2 = P.q.x * P.q.x + P.q.y * P.q.y + P.q.z * P.q.z + P.q.w * P.q.w;
+    Quatd qi = n2 > 0.0 ? Quatd{-P.q.x / n2, -P.q.y / n2, -P.q.z / n2, P.q.w / n2} : Quatd{0, 0, 0, 0};
+    Vec3d mt = quat_rotate(qi, P.t);
+    return pose_ctor_qt(qi, Vec3d{-mt.x, -mt.y, -mt.z});
+}
+static inline Pose pose_mul_ref(const Pose &A, const Pose &B)
+{
+    Vec3d rt = quat_rotate(A.q, B.t);
+    return pose_ctor_qt(quat_mul(A.q, B.q), Vec3d{rt.x + A.t.x, rt.y + A.t.y, rt.z + A.t.z});
+}
+static inline Pose pose_chain(const Pose &wmap_curr_prev, const Pose &wodom_prev, const Pose &wodom_cur)
+{
+    const Pose wmap_wodom = pose_mul_ref(wmap_curr_prev, pose_inverse_ref(wodom_prev));      // transformUpdate
+    return pose_mul_ref(wmap_wodom, wodom_cur);                                              // transformAssociateToMap
+}
+
 }  // namespace orc

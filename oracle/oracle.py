@@ -428,6 +428,24 @@ def factor_eval(kind: str, point, coeff, cov_trace: float, pose7):
     return r[0], J
 
 
+def pose_chain(wmap_curr_prev, wodom_prev, wodom_cur):
+    """The pose the mapper starts the next frame from: transformUpdate + transformAssociateToMap (lidar_mapper_keyframe.cpp:145-160)."""
+    L = lib()
+    a, b, c = (np.ascontiguousarray(v, np.float64) for v in (wmap_curr_prev, wodom_prev, wodom_cur))
+    out = np.zeros(7)
+    L.orc_pose_chain(_ptr(a), _ptr(b), _ptr(c), _ptr(out))
+    return out
+
+
+def ref_pose_chain(wmap_curr_prev, wodom_prev, wodom_cur):
+    """The same through the reference's own lines (Pose::operator*, Pose::inverse, transformUpdate, transformAssociateToMap)."""
+    L = ref_lib()
+    a, b, c = (np.ascontiguousarray(v, np.float64) for v in (wmap_curr_prev, wodom_prev, wodom_cur))
+    out = np.zeros(7)
+    L.ref_pose_chain(_ptr(a), _ptr(b), _ptr(c), _ptr(out))
+    return out
+
+
 def pose_plus(x, delta, V_update=None):
     x = np.ascontiguousarray(x, np.float64)
     d = np.ascontiguousarray(delta, np.float64)

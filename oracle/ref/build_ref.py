@@ -49,6 +49,7 @@ CUTS = [
     ("pose_ctor_copy.inc", "estimator/pose.cpp", 25, 32, "Pose::Pose(const Pose &pose)"),
     ("pose_ctor_qt.inc", "estimator/pose.cpp", 34, 41, "Pose::Pose(const Eigen::Quaterniond &q"),
     ("pose_inverse_update.inc", "estimator/pose.cpp", 99, 108, "Pose Pose::inverse() const"),
+    ("pose_mul.inc", "estimator/pose.cpp", 110, 113, "Pose Pose::operator * (const Pose &pose)"),
     ("update_cov.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 191, 200, "void updateCov(pcl::PointXYZIWithCov &po"),
     ("uct_compound_pose.inc", "lidarMapper/associate_uct.hpp", 88, 147, "// fixed: topLeftCorner<3, 3>()"),
     ("cloud_uct_associate.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1116, 1158, "void cloudUCTAssociateToMap"),
@@ -73,6 +74,7 @@ CUTS = [
     ("eval_hessian.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1160, 1169, "void evalHessian"),
     ("vector2double.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 236, 252, "void vector2Double()"),
     ("scan2map_optimization.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 423, 639, "void scan2MapOptimization()"),
+    ("transform_associate_update.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 145, 160, "void transformAssociateToMap()"),
     ("track_cloud.inc", "lidarTracker/lidar_tracker.cpp", 23, 129, "Pose LidarTracker::trackCloud"),
     ("uct_compound.inc", "lidarMapper/associate_uct.hpp", 9, 86, "inline Eigen::Matrix<double, 6, 6> adjointMatrix"),
     ("uct_point_to_fs.inc", "lidarMapper/associate_uct.hpp", 150, 156, "inline Eigen::Matrix<double, 4, 6> pointToFS"),

@@ -20,7 +20,7 @@
 //   TransformToStart / TransformToEnd      estimator/src/utility/utility.h:54-100
 //   FeatureExtract::match{Corner,Surf}FromScan        estimator/src/featureExtract/feature_extract.hpp:131-376 (+ decls 78-90)
 //   LidarScanPlaneNormFactor, LidarScanEdgeFactorVector   estimator/src/factor/lidar_scan_factor.hpp:25-62, 122-126; 236-279, 339-343
-//   Pose::{Pose(), Pose(const Pose &), Pose(q, t, td), inverse, update}   estimator/src/estimator/pose.cpp:16-41, 99-108
+//   Pose::{Pose(), Pose(const Pose &), Pose(q, t, td), inverse, update, operator*}   estimator/src/estimator/pose.cpp:16-41, 99-113
 //   compoundPoseWithCov (pose.cov_ overload), cloudUCTAssociateToMap, evalDegenracy   associate_uct.hpp:88-147; lidar_mapper_keyframe.cpp:1116-1158, 1171-1204
 //   downsampleCurrentScan                  estimator/src/lidarMapper/lidar_mapper_keyframe.cpp:356-421 (+ PointXYZIWithCov ctors point_with_cov.hpp:57-62, 91-101)
 //   ActiveFeatureSelection::{evaluateFeatJacobianMatching, evalFullHessian, goodFeatureMatching}   estimator/src/lidarMapper/lidar_mapper.h:130-573
@@ -117,6 +117,7 @@ public:
     Pose(const Eigen::Quaterniond &q, const Eigen::Vector3d &t, const double &td = 0);
     void update();
     Pose inverse() const;
+    Pose operator * (const Pose &pose);
     double td_;
     Eigen::Quaterniond q_;
     Eigen::Vector3d t_;
@@ -127,6 +128,7 @@ public:
 #include "../_ref/gen/pose_ctor_copy.inc"                     // Pose::Pose(const Pose &)                    pose.cpp:25-32
 #include "../_ref/gen/pose_ctor_qt.inc"                       // Pose::Pose(q, t, td)                        pose.cpp:34-41
 #include "../_ref/gen/pose_inverse_update.inc"                // Pose::inverse, Pose::update                 pose.cpp:99-108
+#include "../_ref/gen/pose_mul.inc"                           // Pose::operator*                             pose.cpp:110-113
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
 #include "../_ref/gen/feature_structs.inc"                    // class PointPlaneFeature, class FeatureWithScore  (parameters.h:163-191)
 float MIN_MATCH_SQ_DIS = 1.0f, MIN_PLANE_DIS = 0.2f;         // parameters.cpp:232-233
@@ -541,7 +543,8 @@ PointICovCloud::Ptr laser_cloud_surf_from_map_cov_ds(new PointICovCloud()), lase
 pcl::KdTreeFLANN<PointIWithCov>::Ptr kdtree_surf_from_map(new pcl::KdTreeFLANN<PointIWithCov>()), kdtree_corner_from_map(new pcl::KdTreeFLANN<PointIWithCov>());   // :73-74
 ActiveFeatureSelection afs;                                   // :133
 double para_pose[SIZE_POSE];                                  // :103
-Pose pose_wmap_curr;                                          // :96
+Pose pose_wmap_curr, pose_wmap_wodom, pose_wodom_curr;        // :96-98 (the three poses transformAssociateToMap / transformUpdate chain)
+#include "../_ref/gen/transform_associate_update.inc"         // transformAssociateToMap, transformUpdate   lidar_mapper_keyframe.cpp:145-160
 int frame_cnt = 0, CHECK_JACOBIAN = 0;                        // :30, parameters.cpp
 int POINT_PLANE_FACTOR = 1, POINT_EDGE_FACTOR = 1;            // parameters.cpp (config point_plane_factor / point_edge_factor)
 std::string FLAGS_gf_method = "wo_gf";                        // lidar_mapper_keyframe.cpp:20-22 (gflags)
@@ -1092,6 +1095,21 @@ int ref_scan2map_optimization(const float *surf_map11, int n_surf_map, const flo
     pose_out[3] = pose_wmap_curr.q_.x(); pose_out[4] = pose_wmap_curr.q_.y(); pose_out[5] = pose_wmap_curr.q_.z(); pose_out[6] = pose_wmap_curr.q_.w();
     *n_solves = dump_solve_log(solves, max_solves);
     if (cov_out) for (int i = 0; i < 36; ++i) cov_out[i] = pose_wmap_curr.cov_.d[i];
+    return 0;
+}
+
+// the pose the mapper starts the next frame from: transformUpdate() with frame k's result and odometry, transformAssociateToMap() with frame k+1's odometry
+int ref_pose_chain(const double wmap_curr_prev[7], const double wodom_prev[7], const double wodom_cur[7], double out[7])
+{
+    // members assigned directly, as double2Vector (cpp:247-252) and the odometry handler (cpp:1019-1026) do: no normalisation on the way in
+    auto set = [](Pose &P, const double *p) { P.q_ = Eigen::Quaterniond(p[6], p[3], p[4], p[5]); P.t_ = Eigen::Vector3d(p[0], p[1], p[2]); };
+    set(pose_wmap_curr, wmap_curr_prev);
+    set(pose_wodom_curr, wodom_prev);
+    transformUpdate();
+    set(pose_wodom_curr, wodom_cur);
+    transformAssociateToMap();
+    out[0] = pose_wmap_curr.t_(0); out[1] = pose_wmap_curr.t_(1); out[2] = pose_wmap_curr.t_(2);
+    out[3] = pose_wmap_curr.q_.x(); out[4] = pose_wmap_curr.q_.y(); out[5] = pose_wmap_curr.q_.z(); out[6] = pose_wmap_curr.q_.w();
     return 0;
 }
 

@@ -529,3 +529,47 @@ def test_gn_solve_submitted_and_collected_separately(mla, case16, feats16):
         assert info["n"] == len(case16["surf_map"])
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_next_frames_start_pose_is_chained_on_the_device(mla, orc, case16, feats16):
+    """mlh_gn_solve_begin_chained: frame k + 1 is submitted before frame k's pose has reached the host; its start pose -- transformUpdate with frame k's result,
+    transformAssociateToMap with the next odometry pose (lidar_mapper_keyframe.cpp:145-160) -- is computed where that result lives. Against the host-side
+    sequence: solve, chain through the oracle (which is pinned to the reference's own lines), solve again with mlh_gn_solve."""
+    rng = np.random.default_rng(11)
+
+    def odom(scale):
+        q = np.array([0.0, 0.0, 0.0, 1.0]) + rng.normal(size=4) * 0.01 * scale
+        return np.concatenate([rng.normal(size=3) * scale, q / np.linalg.norm(q)])
+
+    odoms = [odom(1.0)]
+    for _ in range(3):                                               # consecutive odometry poses a few centimetres apart
+        step = odom(0.02)
+        odoms.append(orc.pose_chain(odoms[-1], np.array([0, 0, 0, 0, 0, 0, 1.0]), step))
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(case16["surf_map"], case16["corner_map"])
+        c.features_set(mla.SURF, feats16[0]); c.features_set(mla.CORNER, feats16[1])
+        with pytest.raises(mla.MlhError):
+            c.gn_solve_begin_chained(odoms[0], odoms[1], 3)          # nothing to continue from
+        # host-side sequence
+        want = []
+        pose, _ = c.gn_solve(case16["p0"], 3, want_stats=False)
+        want.append(pose)
+        for k in range(1, 4):
+            start = orc.pose_chain(want[-1], odoms[k - 1], odoms[k])
+            pose, _ = c.gn_solve(start, 3, want_stats=False)
+            want.append(pose)
+        # device-side chain, two solves in flight
+        c.gn_solve_begin(case16["p0"], 3)
+        got = []
+        for k in range(1, 4):
+            c.gn_solve_begin_chained(odoms[k - 1], odoms[k], 3)
+            got.append(c.gn_solve_end())
+        got.append(c.gn_solve_end())
+        for k in range(4):
+            # same arithmetic, same order: the device's f64 sqrt / division are correctly rounded, so the start poses -- and with them everything after -- are equal
+            assert np.array_equal(got[k], want[k]), (k, got[k] - want[k])
+        assert np.abs(want[1] - want[0]).max() > 0                   # the chain really moved the start pose
+    finally:
+        c.close()

@@ -640,3 +640,23 @@ def test_track_cloud_is_the_references(ref, track_case):
     p0 = np.array([0.02, 0.0, 0.0, 0, 0, 0, 1.0])
     got = ref.ref_track_cloud(tc["corner_last"], tc["surf_last"], tc["corner_sharp"][:3], tc["surf_flat"][:4], p0)
     assert got["solves"] == [] and np.array_equal(got["pose"], p0)
+
+
+def test_mappers_pose_chain_is_the_references(orc):
+    """transformUpdate + transformAssociateToMap over Pose::operator* / Pose::inverse (lidar_mapper_keyframe.cpp:145-160, pose.cpp:99-113): the restatement
+    (which the device kernel behind mlh_gn_solve_begin_chained follows operation for operation) against the reference's own lines, bit for bit."""
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    rng = np.random.default_rng(5)
+
+    def rp(s):
+        q = rng.normal(size=4)
+        return np.concatenate([rng.normal(size=3) * s, q / np.linalg.norm(q)])
+
+    for s in (0.01, 1.0, 50.0, 1e3):
+        for _ in range(20):
+            a, b, c = rp(s), rp(s), rp(s)
+            np.testing.assert_array_equal(orc.pose_chain(a, b, c), orc.ref_pose_chain(a, b, c))
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    a = rp(3.0)
+    assert np.abs(orc.pose_chain(a, ident, ident) - a).max() < 1e-15
