@@ -4,6 +4,7 @@
 // and writes <dir>/out_labels.i32, <dir>/out_pose.f64 (7), <dir>/out_counts.i32 (per outer: n_surf, n_corner, lm_iterations),
 // <dir>/out_valid_surf.u8 (batch matchSurfFromMap at the initial pose).
 #include "mloam_facade.hpp"
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 
@@ -313,6 +314,30 @@ int main(int argc, char **argv)
             }
             std::printf("round-2 facade: full-H features %d, logdet %.6f, selected %zu surf rows, %zu corner rows, segmented %zu -> %zu points\n", total_feat_num,
                         gf_deg_factor, sel_surf_feature_idx.size(), sel_corner_feature_idx.size(), raw_cloud.size(), seg_out.size());
+        }
+        // --- round 3: FramePipeline (split submission, overlapped map staging, start pose chained on the device) against the synchronous calls
+        {
+            Pose start;
+            start.fromParam(pv.data());
+            Pose od0, od1;                                            // two odometry poses a few centimetres apart
+            double o0[7] = {0.3, -0.2, 0.1, 0.0, 0.0, 0.001, 1.0}, o1[7] = {0.33, -0.18, 0.1, 0.0, 0.0005, 0.0012, 1.0};
+            for (double *o : {o0, o1}) { const double n = std::sqrt(o[3] * o[3] + o[4] * o[4] + o[5] * o[5] + o[6] * o[6]); for (int i = 3; i < 7; ++i) o[i] /= n; }
+            od0.fromParam(o0); od1.fromParam(o1);
+            FramePipeline pipe(dev, 3);
+            pipe.setInputClouds(surf_map, corner_map);                // nothing in flight: the plain staging path
+            pipe.setFeatures(surf, corner);
+            pipe.submit(start);
+            pipe.setInputClouds(surf_map, corner_map);                // frame 1's maps while frame 0 is being solved
+            pipe.submitChained(od0, od1);
+            double pa[7], pb[7];
+            pipe.collect().toParam(pa);
+            pipe.collect().toParam(pb);
+            std::vector<double> po(pa, pa + 7);
+            po.insert(po.end(), pb, pb + 7);
+            po.insert(po.end(), o0, o0 + 7);
+            po.insert(po.end(), o1, o1 + 7);
+            write_file(d + "out_pipeline.f64", po);
+            std::printf("frame pipeline: %.9f %.9f %.9f -> %.9f %.9f %.9f\n", pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]);
         }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;

@@ -1043,4 +1043,61 @@ inline void scan2MapOptimization(Device &dev, const PointICovCloud &laser_cloud_
     if (report) report->outer = stats;
 }
 
+// ------------------------------------------------------------------ the mapper's frame loop with the GPU kept busy across frames
+// LidarMapper::process() (lidar_mapper_keyframe.cpp:1000-1100) runs transformAssociateToMap -> extractSurroundingKeyFrames -> downsampleCurrentScan ->
+// scan2MapOptimization -> transformUpdate per frame. FramePipeline issues the same per-frame work so that frame k + 1's map index is built on a second stream
+// while frame k is being solved, and frame k + 1's solve is queued behind frame k's with its start pose chained on the device (cpp:145-160). Up to two frames
+// in flight; poses come back in submission order.
+class FramePipeline {
+public:
+    explicit FramePipeline(Device &dev, int gn_iters = 5, bool with_ua_flag = false) : dev_(dev), iters_(gn_iters)
+    {
+        const Params &P = params();
+        mlh_solver_opts_default(&o_);
+        o_.min_match_sq_dis = P.MIN_MATCH_SQ_DIS; o_.min_plane_dis = P.MIN_PLANE_DIS; o_.huber_delta = P.HUBER_DELTA; o_.map_eig_thre = P.MAP_EIG_THRE;
+        o_.cov_measurement_trace = P.COV_MEASUREMENT_TRACE; o_.flags = with_ua_flag ? MLH_FLAG_WITH_UA : 0u;
+    }
+    // kdtree_*_from_map->setInputCloud (cpp:433-434) for the frame about to be submitted; overlapped with the solve in flight when there is one
+    void setInputClouds(const PointICovCloud &surf_map, const PointICovCloud &corner_map)
+    {
+        dev_.check(mlh_map_set_pair_overlapped(dev_.ctx(), surf_map.points.data(), (int)surf_map.size(), corner_map.points.data(), (int)corner_map.size(),
+                                               (int)sizeof(PointIWithCov), params().MIN_MATCH_SQ_DIS, MLH_MEM_HOST));
+    }
+    void setFeatures(const PointICovCloud &surf_cov, const PointICovCloud &corner_cov)
+    {
+        dev_.check(mlh_features_set(dev_.ctx(), MLH_SURF, surf_cov.points.data(), 48, (int)surf_cov.size(), 16, 20, MLH_MEM_HOST));
+        dev_.check(mlh_features_set(dev_.ctx(), MLH_CORNER, corner_cov.points.data(), 48, (int)corner_cov.size(), 16, 20, MLH_MEM_HOST));
+    }
+    // first frame (or a frame redone after a keyframe-selection mismatch): start pose given
+    void submit(const Pose &pose_wmap_curr)
+    {
+        double p[7];
+        pose_wmap_curr.toParam(p);
+        dev_.check(mlh_gn_solve_begin(dev_.ctx(), p, iters_, &o_));
+        ++in_flight_;
+    }
+    // every later frame: start pose = (previous result * pose_wodom_prev.inverse()) * pose_wodom_curr, evaluated on the device
+    void submitChained(const Pose &pose_wodom_prev, const Pose &pose_wodom_curr)
+    {
+        double a[7], b[7];
+        pose_wodom_prev.toParam(a); pose_wodom_curr.toParam(b);
+        dev_.check(mlh_gn_solve_begin_chained(dev_.ctx(), a, b, iters_, &o_));
+        ++in_flight_;
+    }
+    Pose collect()
+    {
+        double p[7];
+        dev_.check(mlh_gn_solve_end(dev_.ctx(), p));
+        --in_flight_;
+        Pose r;
+        r.fromParam(p);
+        return r;
+    }
+    int inFlight() const { return in_flight_; }
+private:
+    Device &dev_;
+    mlh_solver_opts o_;
+    int iters_, in_flight_ = 0;
+};
+
 }  // namespace mloam_hip

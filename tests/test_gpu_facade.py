@@ -88,6 +88,19 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
         i = int(row[0])
         rr, JJ = orc.factor_eval("c", feats16[1][i, :3].astype(np.float64), cc_[i], 0.0075, case16["p0"])
         assert abs(row[1] - rr) < 1e-12 and np.allclose(row[2:], JJ, rtol=1e-11, atol=1e-12)
+    # round 3: FramePipeline -- frame 0 submitted with the start pose, frame 1 chained on the device while its maps are staged beside frame 0's solve
+    pl = np.fromfile(os.path.join(d, "out_pipeline.f64"), np.float64).reshape(4, 7)
+    import importlib
+    mla = importlib.import_module("m-loam_amd")
+    cpl = mla.Context(0)
+    try:
+        cpl.map_set_pair(case16["surf_map"], case16["corner_map"])
+        cpl.features_set(mla.SURF, feats16[0]); cpl.features_set(mla.CORNER, feats16[1])
+        w0, _ = cpl.gn_solve(case16["p0"], 3, want_stats=False)
+        w1, _ = cpl.gn_solve(orc.pose_chain(w0, pl[2], pl[3]), 3, want_stats=False)
+    finally:
+        cpl.close()
+    assert np.array_equal(pl[0], w0) and np.array_equal(pl[1], w1)
     # WindowFactorTable + evalWindowNormalEquations: surf matched as (frame 1, LiDAR 0, N_NEIGH 5), corner as (frame 1, LiDAR 1, N_NEIGH 10), CHECK_FOV
     wn = np.fromfile(os.path.join(d, "out_window_ne.f64"), np.float64)
     D = 24
