@@ -1244,7 +1244,9 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     // iteration is 2 + (LM iterations) launches, the pose goes in with the first launch's kernel arguments
     const bool fused = !ctx->comm && opts->gf_method == MLH_GF_WO;
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
-    const int chunk = 6;   // LM iterations enqueued between two looks at the device-side `done` flag
+    // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
+    // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)
+    const int first_chunk = 6, next_chunk = 2;
     HostPublish last_hp;
     bool have_hp = false;  // fused path: the last chunk's publication already carries the pose
     std::mt19937 rng((uint32_t)opts->gf_seed);
@@ -1269,8 +1271,8 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
             if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
         }
         if (!fused && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
-        for (int it = 0; it < opts->max_lm_iterations; it += chunk) {
-            const int j_end = std::min(it + chunk, opts->max_lm_iterations);
+        for (int it = 0, j_end = 0; it < opts->max_lm_iterations; it = j_end) {
+            j_end = std::min(it + (it == 0 ? first_chunk : next_chunk), opts->max_lm_iterations);
             unsigned long long seq = 0;
             for (int j = it; j < j_end; ++j) {
                 MatchArgs a = args_from_opts(opts, 3, 1);

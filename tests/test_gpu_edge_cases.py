@@ -527,6 +527,29 @@ def test_gn_solve_submitted_and_collected_separately(mla, case16, feats16):
             assert np.array_equal(pose, want_moved if k % 2 else want), k
         info = c.map_info(mla.SURF)
         assert info["n"] == len(case16["surf_map"])
+        # a map that OUTGROWS the other set's grid box while a solve is in flight: the bounds pass and the new layout run on the staging stream too
+        far = np.zeros((2, case16["surf_map"].shape[1]), case16["surf_map"].dtype)
+        far[0, :2] = np.abs(case16["surf_map"][:, :2]).max() + 35.0
+        far[1, :2] = -far[0, :2]
+        grown_s = np.concatenate([case16["surf_map"], far]); grown_c = np.concatenate([case16["corner_map"], far[:, :case16["corner_map"].shape[1]]])
+        c.map_set_pair(grown_s, grown_c)
+        want_grown, _ = c.gn_solve(case16["p0"], 4, want_stats=False)
+        c2 = mla.Context(0)
+        try:
+            c2.map_set_pair(case16["surf_map"], case16["corner_map"])
+            c2.features_set(mla.SURF, feats16[0]); c2.features_set(mla.CORNER, feats16[1])
+            c2.gn_solve_begin(case16["p0"], 4)
+            got = []
+            for k in range(1, 5):
+                maps = (grown_s, grown_c) if k % 2 else (case16["surf_map"], case16["corner_map"])
+                c2.map_set_pair_overlapped(*maps)
+                c2.gn_solve_begin(case16["p0"], 4)
+                got.append(c2.gn_solve_end())
+            got.append(c2.gn_solve_end())
+            for k, pose in enumerate(got):
+                assert np.array_equal(pose, want_grown if k % 2 else want), k
+        finally:
+            c2.close()
     finally:
         c.close()
 
