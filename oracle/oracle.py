@@ -149,6 +149,26 @@ def ref_online_calib(kind: str, point, coeff, sqrt_info, ext):
     return r[0], J
 
 
+def ref_optimize_map(poses, exts, feat_rows, estimate_extrinsic, frame_cnt=0, n_cumu_feature=10, num_iterations=10, eig_thre=None, lambda_thre_calib=70.0):
+    """Estimator::optimizeMap up to its marginalisation section, compiled from the reference's own lines (estimator.cpp:593-866, with vector2Double /
+    double2Vector :1538-1576, evalResidual :1578-1595 and evalDegenracy :1598-1680) over the Ceres-shaped shim; MARGINALIZATION_FACTOR = PRIOR_FACTOR = 0.
+    poses: (OPT_WINDOW_SIZE + 1, 7) with the pivot first; exts: (n_laser, 7), IDX_REF = 0; feat_rows: (m, 12) [laser, window frame index, kind 0 surf / 1 corner,
+    point xyz, coefficients (4 or 6, zero-padded)]. Returns the solved poses / extrinsics, J^T J of the Jacobian evalResidual evaluates (constant blocks: zero
+    columns), that evaluation's cost, the number of residual blocks and the solver summary."""
+    L = ref_lib()
+    P = np.ascontiguousarray(poses, np.float64).reshape(-1, 7); E = np.ascontiguousarray(exts, np.float64).reshape(-1, 7)
+    F = np.ascontiguousarray(feat_rows, np.float64).reshape(-1, 12)
+    nb, nl = len(P), len(E)
+    thr = np.ascontiguousarray(np.full(nb + nl, 10.0) if eig_thre is None else eig_thre, np.float64)
+    Po, Eo = np.zeros_like(P), np.zeros_like(E)
+    D = 6 * (nb + nl)
+    H = np.zeros((D, D)); cost = C.c_double(0); nblk = C.c_int(0); so = np.zeros(5)
+    L.ref_optimize_map(nb - 1, nl, int(estimate_extrinsic), int(n_cumu_feature), int(frame_cnt), int(num_iterations), _ptr(P), _ptr(E), _ptr(F), len(F), _ptr(thr),
+                       C.c_double(lambda_thre_calib), _ptr(Po), _ptr(Eo), _ptr(H), C.byref(cost), C.byref(nblk), _ptr(so))
+    return dict(poses=Po, exts=Eo, H=H, cost=cost.value, n_blocks=nblk.value,
+                solve=dict(lm_iterations=int(so[0]), successful_steps=int(so[1]), initial_cost=so[2], final_cost=so[3], termination=int(so[4])))
+
+
 def ref_pose_plus(x, delta, V_update=None):
     L = ref_lib()
     x = np.ascontiguousarray(x, np.float64); d = np.ascontiguousarray(delta, np.float64)

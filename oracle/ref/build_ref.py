@@ -71,6 +71,9 @@ CUTS = [
     ("afs_gfm.inc", "lidarMapper/lidar_mapper.h", 229, 573, "void goodFeatureMatching"),
     ("crs_to_sparse.inc", "utility/utility.h", 152, 166, "template <typename T>"),
     ("estimator_eval_degeneracy.inc", "estimator/estimator.cpp", 1598, 1680, "void Estimator::evalDegenracy"),
+    ("estimator_optimize_map_head.inc", "estimator/estimator.cpp", 593, 866, "void Estimator::optimizeMap()"),
+    ("estimator_vector_double.inc", "estimator/estimator.cpp", 1538, 1576, "void Estimator::vector2Double()"),
+    ("estimator_eval_residual.inc", "estimator/estimator.cpp", 1578, 1595, "void Estimator::evalResidual(ceres::Problem &problem,"),
     ("eval_hessian.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1160, 1169, "void evalHessian"),
     ("vector2double.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 236, 252, "void vector2Double()"),
     ("scan2map_optimization.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 423, 639, "void scan2MapOptimization()"),

@@ -195,8 +195,10 @@ float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;    
     void check(double **) {}                                  // lidar_map_factor.hpp:176-229 (finite-difference print-out; scan2MapOptimization names it behind CHECK_JACOBIAN = 0)
 #include "../_ref/gen/edge_factor_tail.inc"
 #include "../_ref/gen/odom_plane_head.inc"                    // LidarPureOdomPlaneNormFactor
+    void check(double **) {}                                  // lidar_pure_odom_factor.hpp:105-189 (finite-difference print-out; optimizeMap names it behind CHECK_JACOBIAN = 0)
 #include "../_ref/gen/odom_plane_tail.inc"
 #include "../_ref/gen/odom_edge_head.inc"                     // LidarPureOdomEdgeFactor
+    void check(double **) {}                                  // lidar_pure_odom_factor.hpp:285-375
 #include "../_ref/gen/odom_edge_tail.inc"
 #include "../_ref/gen/calib_plane_head.inc"                   // LidarOnlineCalibPlaneNormFactor
 #include "../_ref/gen/calib_plane_tail.inc"
@@ -400,9 +402,28 @@ pcl::VoxelGridCovarianceMLOAM<PointI> down_size_filter_surf, down_size_filter_co
 #include "../_ref/gen/crs_to_sparse.inc"                      // CRSMatrix2EigenMatrix(crs, Eigen::SparseMatrix<T, RowMajor> &)   utility.h:152-166
 int ESTIMATE_EXTRINSIC = 1, OPT_WINDOW_SIZE = 4, N_CUMU_FEATURE = 10;      // parameters.cpp
 double LAMBDA_THRE_CALIB = 70.0;
-class Estimator {                                             // the members evalDegenracy touches (estimator.h:158-210)
+namespace ceres { struct Problem; namespace internal { struct ResidualBlock; } }
+class MarginalizationInfo;                                    // marginalization_factor.h: out of scope; only the pointer type is named here
+class Estimator {                                             // the members evalDegenracy and optimizeMap (up to its marginalisation section) touch (estimator.h:85-230)
 public:
     void evalDegenracy(std::vector<PoseLocalParameterization *> &local_param_ids, const ceres::CRSMatrix &jaco);
+    void optimizeMap();
+    void vector2Double();
+    void double2Vector();
+    void buildCalibMap() {}                                   // estimator.cpp:1067-1157 / 1159-1268: matching against the window map; the test entry fills *_map_features_
+    void buildLocalMap() {}                                   //   and sel_*_feature_idx_ itself (those steps are pinned through match*FromMap and goodFeatureMatching above)
+    void evalResidual(ceres::Problem &problem, std::vector<PoseLocalParameterization *> &local_param_ids, const std::vector<double *> &para_ids,
+                      const std::vector<ceres::internal::ResidualBlock *> &res_ids_proj, const MarginalizationInfo *last_marginalization_info_,
+                      const std::vector<ceres::internal::ResidualBlock *> &res_ids_marg);
+    std::vector<Eigen::Quaterniond> Qs_;                      // CircularBuffer<> in the reference (estimator.h:166-167): only indexed here
+    std::vector<Eigen::Vector3d> Ts_;
+    std::vector<std::vector<std::vector<PointPlaneFeature>>> surf_map_features_, corner_map_features_;
+    std::vector<std::vector<PointPlaneFeature>> cumu_surf_map_features_, cumu_corner_map_features_;
+    std::vector<std::vector<std::vector<size_t>>> sel_surf_feature_idx_, sel_corner_feature_idx_;
+    double **para_pose_{};
+    double **para_ex_pose_{};
+    MarginalizationInfo *last_marginalization_info_{};
+    std::vector<double *> last_marginalization_parameter_blocks_;
     std::vector<Eigen::Quaterniond> qbl_;
     std::vector<Eigen::Vector3d> tbl_;
     int frame_cnt_{};
@@ -425,86 +446,156 @@ public:
 // LM iteration itself and the kd-tree is the reference's text.
 #include "../lm.hpp"
 namespace ceres {
-namespace internal { struct ResidualBlock { CostFunction *cost; LossFunction *loss; double *param; }; }
+namespace internal { struct ResidualBlock { CostFunction *cost; LossFunction *loss; std::vector<double *> params; }; }
 enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR };
+static CRSMatrix g_last_jacobian;                             // what the last Problem::Evaluate produced (read by the test entry points)
+static double g_last_cost = 0.0;
 struct Problem {
     struct EvaluateOptions {
         std::vector<double *> parameter_blocks;
         std::vector<internal::ResidualBlock *> residual_blocks;
         bool apply_loss_function = true;
     };
-    double *param = nullptr;
-    int param_size = 0;
-    LocalParameterization *lp = nullptr;
+    // parameter blocks in program order (the order of AddParameterBlock; a block first seen in AddResidualBlock is appended, as Ceres does)
+    struct ParamBlock { double *values; int size; LocalParameterization *lp; bool constant; };
+    std::vector<ParamBlock> params;
     std::vector<std::unique_ptr<internal::ResidualBlock>> blocks;
     std::vector<std::unique_ptr<CostFunction>> owned_costs;       // Problem takes ownership (ceres/problem.h)
-    void AddParameterBlock(double *values, int size, LocalParameterization *local_parameterization) { param = values; param_size = size; lp = local_parameterization; }
-    internal::ResidualBlock *AddResidualBlock(CostFunction *cost_function, LossFunction *loss_function, double *x0)
+    static constexpr int kLocal = 6, kGlobal = 7;                 // every block of this path is a pose with the reference's PoseLocalParameterization
+    int find(const double *v) const
     {
-        if (!param) { param = x0; param_size = 7; }
-        blocks.emplace_back(new internal::ResidualBlock{cost_function, loss_function, x0});
+        for (size_t i = 0; i < params.size(); ++i) if (params[i].values == v) return int(i);
+        return -1;
+    }
+    void AddParameterBlock(double *values, int size, LocalParameterization *local_parameterization = nullptr)
+    {
+        const int i = find(values);
+        if (i >= 0) { if (local_parameterization) params[size_t(i)].lp = local_parameterization; return; }
+        params.push_back(ParamBlock{values, size, local_parameterization, false});
+    }
+    void SetParameterBlockConstant(double *values) { AddParameterBlock(values, kGlobal); params[size_t(find(values))].constant = true; }
+    internal::ResidualBlock *AddResidualBlock(CostFunction *cost_function, LossFunction *loss_function, const std::vector<double *> &xs)
+    {
+        for (double *x : xs) AddParameterBlock(x, kGlobal);
+        blocks.emplace_back(new internal::ResidualBlock{cost_function, loss_function, xs});
         owned_costs.emplace_back(cost_function);
         return blocks.back().get();
     }
-    // one residual block at `at`: loss-corrected residuals r[nres] and LOCAL Jacobian rows Jl[nres][6]; returns 0.5 * rho(|r|^2)
-    double evaluate_block(const internal::ResidualBlock &b, const double *at, double *r, double *Jl, bool apply_loss) const
+    internal::ResidualBlock *AddResidualBlock(CostFunction *c, LossFunction *l, double *x0) { return AddResidualBlock(c, l, std::vector<double *>{x0}); }
+    internal::ResidualBlock *AddResidualBlock(CostFunction *c, LossFunction *l, double *x0, double *x1, double *x2) { return AddResidualBlock(c, l, std::vector<double *>{x0, x1, x2}); }
+    // One residual block with parameter block p's values taken from at[p]: loss-corrected residuals r[nres] and, per parameter of the block, the LOCAL
+    // Jacobian rows Jl[q][nres][6] (left untouched for constant blocks: ceres::internal::ResidualBlock::Evaluate hands the cost function a null pointer
+    // for those, and the Jacobian writers skip them). Returns 0.5 * rho(|r|^2).
+    double evaluate_block(const internal::ResidualBlock &b, const std::vector<const double *> &at, double *r, double (*Jl)[3 * kLocal], bool apply_loss) const
     {
-        const int nres = b.cost->num_residuals_;
-        double Jg[3 * 7];
-        const double *params[1] = {at};
-        double *jac[1] = {Jg};
-        b.cost->Evaluate(params, r, jac);
+        const int nres = b.cost->num_residuals_, np = int(b.params.size());
+        double Jg[3][3 * kGlobal];
+        const double *pv[3];
+        double *jac[3];
+        int pi[3];
+        for (int q = 0; q < np; ++q) {
+            pi[q] = find(b.params[size_t(q)]);
+            pv[q] = at[size_t(pi[q])];
+            jac[q] = params[size_t(pi[q])].constant ? nullptr : Jg[q];
+        }
+        b.cost->Evaluate(pv, r, jac);
         double sq = 0.0;
         for (int q = 0; q < nres; ++q) sq += r[q] * r[q];
         double rho[3] = {sq, 1.0, 0.0};
         if (apply_loss && b.loss) b.loss->Evaluate(sq, rho);
         const double s = std::sqrt(rho[1]);                      // Corrector: sq_norm == 0 or rho[2] <= 0 -> both scalings are sqrt(rho[1])
-        double P[7 * 6];
-        lp->ComputeJacobian(at, P);
-        for (int q = 0; q < nres; ++q) {
-            for (int k = 0; k < 6; ++k) {
-                double acc = 0.0;
-                for (int j = 0; j < 7; ++j) acc += (Jg[q * 7 + j] * s) * P[j * 6 + k];
-                Jl[q * 6 + k] = acc;
-            }
-            r[q] *= s;
+        for (int q = 0; q < np; ++q) {
+            if (!jac[q]) continue;
+            double P[kGlobal * kLocal];
+            params[size_t(pi[q])].lp->ComputeJacobian(pv[q], P);
+            for (int a = 0; a < nres; ++a)
+                for (int k = 0; k < kLocal; ++k) {
+                    double acc = 0.0;
+                    for (int c = 0; c < kGlobal; ++c) acc += (Jg[q][a * kGlobal + c] * s) * P[c * kLocal + k];
+                    Jl[q][a * kLocal + k] = acc;
+                }
         }
+        for (int a = 0; a < nres; ++a) r[a] *= s;
         return 0.5 * rho[0];
     }
-    void normal_equations(const double *at, orc::NormalEq &ne) const
+    // the variable blocks in program order: what Program::RemoveFixedBlocks leaves for the minimiser -- neither constant nor without a residual block
+    // (a block nothing depends on is dropped from the reduced program and keeps its value bit for bit)
+    std::vector<int> free_blocks() const
     {
-        std::memset(&ne, 0, sizeof(ne));
+        std::vector<char> used(params.size(), 0);
+        for (const auto &b : blocks) for (double *x : b->params) used[size_t(find(x))] = 1;
+        std::vector<int> f;
+        for (size_t i = 0; i < params.size(); ++i) if (!params[i].constant && used[i]) f.push_back(int(i));
+        return f;
+    }
+    // J^T J / J^T r / cost over all residual blocks with the variable blocks' values taken from x (kGlobal values per variable block, program order)
+    void normal_equations(const double *x, orc::NormalEqDyn &ne) const
+    {
+        const std::vector<int> fb = free_blocks();
+        std::vector<int> slot(params.size(), -1);
+        std::vector<const double *> at(params.size());
+        for (size_t i = 0; i < params.size(); ++i) at[i] = params[i].values;
+        for (size_t k = 0; k < fb.size(); ++k) { slot[size_t(fb[k])] = int(k); at[size_t(fb[k])] = x + k * kGlobal; }
+        const size_t N = fb.size() * kLocal;
+        ne.H.assign(N * N, 0.0); ne.g.assign(N, 0.0); ne.cost = 0.0; ne.count = 0;
         for (const auto &b : blocks) {
-            double r[3], Jl[3 * 6];
+            double r[3], Jl[3][3 * kLocal];
             ne.cost += evaluate_block(*b, at, r, Jl, true);
-            ne.n++;
-            for (int q = 0; q < b->cost->num_residuals_; ++q) {
-                const double *j = Jl + q * 6;
-                for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) ne.H[a * 6 + c] += j[a] * j[c];
-                for (int k = 0; k < 6; ++k) ne.g[k] += j[k] * r[q];
-            }
+            ne.count++;
+            const int np = int(b->params.size());
+            for (int q = 0; q < b->cost->num_residuals_; ++q)
+                for (int pa = 0; pa < np; ++pa) {
+                    const int sa = slot[size_t(find(b->params[size_t(pa)]))];
+                    if (sa < 0) continue;
+                    const double *ja = Jl[pa] + q * kLocal;
+                    for (int k = 0; k < kLocal; ++k) ne.g[size_t(sa) * kLocal + k] += ja[k] * r[q];
+                    for (int pb = 0; pb < np; ++pb) {
+                        const int sb = slot[size_t(find(b->params[size_t(pb)]))];
+                        if (sb < 0) continue;
+                        const double *jb = Jl[pb] + q * kLocal;
+                        for (int a = 0; a < kLocal; ++a) for (int c = 0; c < kLocal; ++c) ne.H[(size_t(sa) * kLocal + a) * N + size_t(sb) * kLocal + c] += ja[a] * jb[c];
+                    }
+                }
         }
     }
+    // Problem::Evaluate (problem_impl.cc): columns = the LISTED parameter blocks in the listed order (all blocks, program order, when the list is empty), LocalSize
+    // each; a constant block keeps its columns but gets no entries; a row's entries ascend by column (CompressedRowJacobianWriter sorts the blocks of a row)
     bool Evaluate(const EvaluateOptions &o, double *cost, std::vector<double> *residuals, std::vector<double> *gradient, CRSMatrix *jacobian) const
     {
+        std::vector<int> col_of(params.size(), -1);
+        int ncols = 0;
+        if (o.parameter_blocks.empty()) for (size_t i = 0; i < params.size(); ++i) { col_of[i] = ncols; ncols += kLocal; }
+        else for (double *p : o.parameter_blocks) { col_of[size_t(find(p))] = ncols; ncols += kLocal; }
+        std::vector<const double *> at(params.size());
+        for (size_t i = 0; i < params.size(); ++i) at[i] = params[i].values;
         double total = 0.0;
-        if (jacobian) { jacobian->num_rows = 0; jacobian->num_cols = 6; jacobian->rows.assign(1, 0); jacobian->cols.clear(); jacobian->values.clear(); }
+        if (jacobian) { jacobian->num_rows = 0; jacobian->num_cols = ncols; jacobian->rows.assign(1, 0); jacobian->cols.clear(); jacobian->values.clear(); }
         if (residuals) residuals->clear();
-        if (gradient) gradient->assign(6, 0.0);
-        for (const internal::ResidualBlock *b : o.residual_blocks) {
-            double r[3], Jl[3 * 6];
-            total += evaluate_block(*b, b->param, r, Jl, o.apply_loss_function);
+        if (gradient) gradient->assign(size_t(ncols), 0.0);
+        std::vector<internal::ResidualBlock *> all;
+        if (o.residual_blocks.empty()) for (const auto &b : blocks) all.push_back(b.get());
+        for (const internal::ResidualBlock *b : (o.residual_blocks.empty() ? all : o.residual_blocks)) {
+            double r[3], Jl[3][3 * kLocal];
+            total += evaluate_block(*b, at, r, Jl, o.apply_loss_function);
+            const int np = int(b->params.size());
+            int order[3] = {0, 1, 2};
+            std::sort(order, order + np, [&](int a, int c) { return col_of[size_t(find(b->params[size_t(a)]))] < col_of[size_t(find(b->params[size_t(c)]))]; });
             for (int q = 0; q < b->cost->num_residuals_; ++q) {
                 if (residuals) residuals->push_back(r[q]);
-                if (gradient) for (int k = 0; k < 6; ++k) (*gradient)[size_t(k)] += Jl[q * 6 + k] * r[q];
-                if (jacobian) {
-                    for (int k = 0; k < 6; ++k) { jacobian->cols.push_back(k); jacobian->values.push_back(Jl[q * 6 + k]); }
-                    jacobian->rows.push_back(int(jacobian->values.size()));
-                    jacobian->num_rows++;
+                for (int oi = 0; oi < np; ++oi) {
+                    const int pa = order[oi], pidx = find(b->params[size_t(pa)]), c0 = col_of[size_t(pidx)];
+                    if (params[size_t(pidx)].constant || c0 < 0) continue;
+                    for (int k = 0; k < kLocal; ++k) {
+                        if (gradient) (*gradient)[size_t(c0 + k)] += Jl[pa][q * kLocal + k] * r[q];
+                        if (jacobian) { jacobian->cols.push_back(c0 + k); jacobian->values.push_back(Jl[pa][q * kLocal + k]); }
+                    }
                 }
+                if (jacobian) { jacobian->rows.push_back(int(jacobian->values.size())); jacobian->num_rows++; }
             }
         }
         if (cost) *cost = total;
+        if (jacobian) g_last_jacobian = *jacobian;
+        g_last_cost = total;
         return true;
     }
 };
@@ -526,9 +617,17 @@ std::vector<Solver::Summary> g_solve_log;                     // every ceres::So
 void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary)
 {
     summary->num_residual_blocks = int(problem->blocks.size());
-    orc::ceres_like_solve_generic([&](const double *at, orc::NormalEq &ne) { problem->normal_equations(at, ne); },
-                                  [&](const double *at, const double *delta, double *out) { problem->lp->Plus(at, delta, out); },
-                                  problem->param, options.max_num_iterations, summary->s);
+    const std::vector<int> fb = problem->free_blocks();
+    const int G = Problem::kGlobal, L = Problem::kLocal;
+    std::vector<double> x(fb.size() * size_t(G));
+    for (size_t k = 0; k < fb.size(); ++k) std::memcpy(&x[k * size_t(G)], problem->params[size_t(fb[k])].values, sizeof(double) * size_t(G));
+    if (!fb.empty())
+        orc::ceres_like_solve_dyn([&](const double *at, orc::NormalEqDyn &ne) { problem->normal_equations(at, ne); },
+                                  [&](const double *at, const double *delta, double *out) {
+                                      for (size_t k = 0; k < fb.size(); ++k) problem->params[size_t(fb[k])].lp->Plus(at + k * size_t(G), delta + k * size_t(L), out + k * size_t(G));
+                                  },
+                                  x.data(), int(fb.size()) * L, int(fb.size()) * G, options.max_num_iterations, summary->s);
+    for (size_t k = 0; k < fb.size(); ++k) std::memcpy(problem->params[size_t(fb[k])].values, &x[k * size_t(G)], sizeof(double) * size_t(G));
     g_solve_log.push_back(*summary);
 }
 }  // namespace ceres
@@ -1110,6 +1209,111 @@ int ref_pose_chain(const double wmap_curr_prev[7], const double wodom_prev[7], c
     transformAssociateToMap();
     out[0] = pose_wmap_curr.t_(0); out[1] = pose_wmap_curr.t_(1); out[2] = pose_wmap_curr.t_(2);
     out[3] = pose_wmap_curr.q_.x(); out[4] = pose_wmap_curr.q_.y(); out[5] = pose_wmap_curr.q_.z(); out[6] = pose_wmap_curr.q_.w();
+    return 0;
+}
+
+// ---------------------------------------------------------------- Estimator::optimizeMap up to its marginalisation section (estimator.cpp:593-866) from the reference's own lines
+// Problem assembly of the odometry window -- which factor ties which blocks, which blocks are constant, the calibration branch's accumulated features and its
+// every-N_CUMU_FEATURE-frames gate, Huber(1.0) --, evalResidual -> Problem::Evaluate -> evalDegenracy, ceres::Solve, double2Vector. MARGINALIZATION_FACTOR = 0 and
+// PRIOR_FACTOR = 0 (both out of scope): the two classes below exist so that the reference's text compiles; they are never constructed.
+int WINDOW_SIZE = 4, NUM_ITERATIONS = 10, IDX_REF = 0, MARGINALIZATION_FACTOR = 0, PRIOR_FACTOR = 0;   // parameters.cpp
+double SOLVER_TIME = 1.0, PRIOR_FACTOR_POS = 0.0, PRIOR_FACTOR_ROT = 0.0;
+struct MarginalizationFactor : ceres::CostFunction {
+    explicit MarginalizationFactor(MarginalizationInfo *) {}
+    bool Evaluate(double const *const *, double *, double **) const override { return false; }
+};
+struct PriorFactor : ceres::CostFunction {
+    PriorFactor(const Eigen::Vector3d &, const Eigen::Quaterniond &, double, double) {}
+    bool Evaluate(double const *const *, double *, double **) const override { return false; }
+};
+#define printf(...) ((void)0)
+#include "../_ref/gen/estimator_optimize_map_head.inc"          // void Estimator::optimizeMap() { ... double2Vector();        estimator.cpp:593-866
+}                                                               // the marginalisation section (estimator.cpp:868-1000) is not compiled: out of scope
+#undef printf
+#include "../_ref/gen/estimator_vector_double.inc"              // vector2Double, double2Vector                                 estimator.cpp:1538-1576
+#include "../_ref/gen/estimator_eval_residual.inc"              // evalResidual                                                 estimator.cpp:1578-1595
+
+// Estimator::optimizeMap on a window given as arrays. poses: (OPT_WINDOW_SIZE + 1) x 7 (pivot first), exts: n_laser x 7. Features: rows
+// [laser, frame (1..OPT_WINDOW_SIZE, window index i - pivot_idx), kind (0 surf / 1 corner), px, py, pz, c0..c5]; in the pure-odometry branch every row is selected
+// (sel_*_feature_idx_ = all), in the calibration branch rows of the reference LiDAR become window factors and rows with frame = 0 of the other LiDARs are the
+// pivot frame's features accumulated into cumu_*_map_features_. Out: poses / exts after ceres::Solve + double2Vector, the Jacobian handed to evalDegenracy as
+// J^T J (D x D, D = 6 (OPT_WINDOW_SIZE + 1 + n_laser)), the evaluated cost, the number of residual blocks, is_degenerate per block.
+int ref_optimize_map(int opt_window_size, int n_laser, int estimate_extrinsic, int n_cumu_feature, int frame_cnt, int num_iterations, const double *poses,
+                     const double *exts, const double *feat_rows, int n_feat, const double *eig_thre, double lambda_thre_calib, double *poses_out,
+                     double *exts_out, double *jtj_out, double *cost_out, int *n_blocks_out, double *solve_out)
+{
+    OPT_WINDOW_SIZE = opt_window_size; WINDOW_SIZE = opt_window_size; NUM_OF_LASER = size_t(n_laser); ESTIMATE_EXTRINSIC = estimate_extrinsic;
+    N_CUMU_FEATURE = n_cumu_feature; NUM_ITERATIONS = num_iterations; IDX_REF = 0; LAMBDA_THRE_CALIB = lambda_thre_calib;
+    POINT_PLANE_FACTOR = 1; POINT_EDGE_FACTOR = 1; MARGINALIZATION_FACTOR = 0; PRIOR_FACTOR = 0;
+    Estimator est;
+    est.frame_cnt_ = frame_cnt;
+    const int nb = opt_window_size + 1;
+    est.Qs_.resize(size_t(nb)); est.Ts_.resize(size_t(nb));
+    for (int i = 0; i < nb; ++i) { const double *p = poses + i * 7; est.Ts_[size_t(i)] = Eigen::Vector3d(p[0], p[1], p[2]); est.Qs_[size_t(i)] = Eigen::Quaterniond(p[6], p[3], p[4], p[5]); }
+    est.qbl_.resize(size_t(n_laser)); est.tbl_.resize(size_t(n_laser));
+    for (int n = 0; n < n_laser; ++n) { const double *p = exts + n * 7; est.tbl_[size_t(n)] = Eigen::Vector3d(p[0], p[1], p[2]); est.qbl_[size_t(n)] = Eigen::Quaterniond(p[6], p[3], p[4], p[5]); }
+    std::vector<std::vector<double>> pp(size_t(nb), std::vector<double>(7)), pe(size_t(n_laser), std::vector<double>(7));
+    std::vector<double *> ppp, ppe;
+    for (auto &v : pp) ppp.push_back(v.data());
+    for (auto &v : pe) ppe.push_back(v.data());
+    est.para_pose_ = ppp.data(); est.para_ex_pose_ = ppe.data();
+    est.surf_map_features_.assign(size_t(n_laser), std::vector<std::vector<PointPlaneFeature>>(size_t(nb)));
+    est.corner_map_features_ = est.surf_map_features_;
+    est.cumu_surf_map_features_.assign(size_t(n_laser), {}); est.cumu_corner_map_features_.assign(size_t(n_laser), {});
+    for (int r = 0; r < n_feat; ++r) {
+        const double *f = feat_rows + size_t(r) * 12;
+        const int n = int(f[0]), i = int(f[1]), kind = int(f[2]);
+        PointPlaneFeature ft;
+        ft.point_ = Eigen::Vector3d(f[3], f[4], f[5]);
+        if (kind == 0) { ft.coeffs_ = Eigen::VectorXd(4); for (int k = 0; k < 4; ++k) ft.coeffs_(k) = f[6 + k]; ft.type_ = 's'; }
+        else { ft.coeffs_ = Eigen::VectorXd(6); for (int k = 0; k < 6; ++k) ft.coeffs_(k) = f[6 + k]; ft.type_ = 'c'; }
+        ft.laser_idx_ = size_t(n);
+        auto &dst = (kind == 0 ? est.surf_map_features_ : est.corner_map_features_)[size_t(n)][size_t(i)];
+        ft.idx_ = dst.size();
+        dst.push_back(ft);
+    }
+    est.sel_surf_feature_idx_.assign(size_t(n_laser), std::vector<std::vector<size_t>>(size_t(nb)));
+    est.sel_corner_feature_idx_ = est.sel_surf_feature_idx_;
+    for (int n = 0; n < n_laser; ++n)
+        for (int i = 0; i < nb; ++i) {
+            for (size_t k = 0; k < est.surf_map_features_[size_t(n)][size_t(i)].size(); ++k) est.sel_surf_feature_idx_[size_t(n)][size_t(i)].push_back(k);
+            for (size_t k = 0; k < est.corner_map_features_[size_t(n)][size_t(i)].size(); ++k) est.sel_corner_feature_idx_[size_t(n)][size_t(i)].push_back(k);
+        }
+    est.eig_thre_ = Eigen::VectorXd(nb + n_laser);
+    for (int i = 0; i < nb + n_laser; ++i) est.eig_thre_(i) = eig_thre[i];
+    est.d_factor_calib_.assign(size_t(n_laser), 0.0);
+    est.log_lambda_.clear(); est.log_extrinsics_.clear();
+    ceres::g_solve_log.clear();
+    ceres::g_last_jacobian = ceres::CRSMatrix();
+    std::ostringstream sink;
+    std::streambuf *keep = std::cout.rdbuf(sink.rdbuf());
+    est.optimizeMap();
+    std::cout.rdbuf(keep);
+    for (int i = 0; i < nb; ++i) {
+        double *p = poses_out + i * 7;
+        p[0] = est.Ts_[size_t(i)](0); p[1] = est.Ts_[size_t(i)](1); p[2] = est.Ts_[size_t(i)](2);
+        p[3] = est.Qs_[size_t(i)].x(); p[4] = est.Qs_[size_t(i)].y(); p[5] = est.Qs_[size_t(i)].z(); p[6] = est.Qs_[size_t(i)].w();
+    }
+    for (int n = 0; n < n_laser; ++n) {
+        double *p = exts_out + n * 7;
+        p[0] = est.tbl_[size_t(n)](0); p[1] = est.tbl_[size_t(n)](1); p[2] = est.tbl_[size_t(n)](2);
+        p[3] = est.qbl_[size_t(n)].x(); p[4] = est.qbl_[size_t(n)].y(); p[5] = est.qbl_[size_t(n)].z(); p[6] = est.qbl_[size_t(n)].w();
+    }
+    const size_t D = size_t(6 * (nb + n_laser));
+    if (jtj_out) {                                            // J^T J of the Jacobian evalResidual handed to evalDegenracy (estimator.cpp:1592-1593)
+        for (size_t k = 0; k < D * D; ++k) jtj_out[k] = 0.0;
+        const ceres::CRSMatrix &J = ceres::g_last_jacobian;
+        for (int r = 0; r < J.num_rows; ++r)
+            for (int a = J.rows[size_t(r)]; a < J.rows[size_t(r) + 1]; ++a)
+                for (int c = J.rows[size_t(r)]; c < J.rows[size_t(r) + 1]; ++c)
+                    jtj_out[size_t(J.cols[size_t(a)]) * D + size_t(J.cols[size_t(c)])] += J.values[size_t(a)] * J.values[size_t(c)];
+    }
+    if (cost_out) *cost_out = ceres::g_last_cost;
+    if (n_blocks_out) *n_blocks_out = ceres::g_solve_log.empty() ? 0 : ceres::g_solve_log.back().num_residual_blocks;
+    if (solve_out && !ceres::g_solve_log.empty()) {
+        const orc::SolveSummary &ss = ceres::g_solve_log.back().s;
+        solve_out[0] = ss.num_iterations; solve_out[1] = ss.num_successful_steps; solve_out[2] = ss.initial_cost; solve_out[3] = ss.final_cost; solve_out[4] = ss.termination;
+    }
     return 0;
 }
 

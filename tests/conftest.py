@@ -131,3 +131,50 @@ def rows_f3_inputs():
     pose = np.concatenate([[0.35, -0.12, 0.02], q])
     ext = np.array([0.1, -0.5, 0.02, 0.0, 0.0, 0.0998334166468, 0.995004165278])
     return pts, pose, ext
+
+
+def make_window_case(synth, orc, n_frames=2, n_lidars=2, seed=3, n_rings=16, preset="50k"):
+    """A sliding window as Estimator::optimizeMap sees it: a pivot pose, n_frames later poses, n_lidars extrinsics, and for every (frame, LiDAR)
+    the features of that scan matched against the local map expressed in the pivot frame (buildLocalMap, estimator.cpp:1160-1268) ->
+    the LidarPureOdom factor table (point in the LiDAR frame, plane / line coefficients in the pivot frame, block indices)."""
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(seed)
+    case = _make_case(synth, preset, n_rings, n_lidars)
+    to_pose = lambda T: np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+    T_piv = synth.pose_to_mat(case["gt"])
+    Tinv = np.linalg.inv(T_piv)
+    maps = [synth.transform_points(m[:, :3], Tinv) for m in (case["surf_map"], case["corner_map"])]       # local map in the pivot frame
+    oms, omc = orc.Map(maps[0]), orc.Map(maps[1])
+    exts_T = []
+    for n in range(n_lidars):
+        r = synth.HERCULES_BODY_T_LASER[n]
+        exts_T.append(synth.pose_to_mat(np.concatenate([r[4:7], r[:4] / np.linalg.norm(r[:4])])))
+    frames_T = []
+    for i in range(n_frames):
+        d = np.eye(4)
+        d[:3, :3] = Rot.from_rotvec(np.deg2rad([0.3, -0.2, 1.0 + i])).as_matrix()
+        d[:3, 3] = [0.4 * (i + 1), 0.05 * i, 0.01]
+        frames_T.append(T_piv @ d)
+    types, points, coeffs, fi, ei = [], [], [], [], []
+    for i, T_i in enumerate(frames_T):
+        for n in range(n_lidars):
+            scn = synth.simulate_scan(case["scene"], to_pose(T_i), synth.HERCULES_BODY_T_LASER[n], n_rings, seed=100 + 10 * i + n)
+            ex = orc.extract(scn.points, scn.scan_start, scn.scan_end)
+            rel = to_pose(Tinv @ T_i @ exts_T[n])
+            rel = synth.perturbed_pose(rel, seed=200 + 10 * i + n, dt=0.05, drot_deg=0.5)
+            for kind, om, f in (("s", oms, synth.voxel_mean(ex["less_flat_ds"][:, :3].copy(), 0.4)), ("c", omc, scn.points[ex["less_sharp"]][:, :3])):
+                f4 = np.zeros((len(f), 4), np.float32)
+                f4[:, :3] = f
+                v, co = om.match(kind, f4, rel)
+                m = v.astype(bool)
+                types.append(np.full(m.sum(), 0 if kind == "s" else 1, np.int32))
+                points.append(f4[m, :3].astype(np.float64))
+                coeffs.append(co[m])
+                fi.append(np.full(m.sum(), i, np.int32))
+                ei.append(np.full(m.sum(), n, np.int32))
+    perm = rng.permutation(sum(len(t) for t in types))       # the table arrives in no particular order
+    cat = lambda a: np.concatenate(a)[perm]
+    pert = lambda T, k: synth.perturbed_pose(to_pose(T), seed=300 + k, dt=0.03, drot_deg=0.3)
+    return dict(types=cat(types), points=cat(points), coeffs=cat(coeffs), fi=cat(fi), ei=cat(ei),
+                pivot=to_pose(T_piv), frames=np.stack([pert(T, k) for k, T in enumerate(frames_T)]),
+                exts=np.stack([to_pose(exts_T[0])] + [pert(T, 10 + k) for k, T in enumerate(exts_T[1:])]))

@@ -660,3 +660,84 @@ def test_mappers_pose_chain_is_the_references(orc):
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
     a = rp(3.0)
     assert np.abs(orc.pose_chain(a, ident, ident) - a).max() < 1e-15
+
+
+def _window_rows(w, laser_filter=None):
+    rows = np.zeros((len(w["types"]), 12))
+    rows[:, 0] = w["ei"]; rows[:, 1] = w["fi"] + 1; rows[:, 2] = w["types"]; rows[:, 3:6] = w["points"]; rows[:, 6:12] = w["coeffs"]
+    return rows if laser_filter is None else rows[laser_filter(rows)]
+
+
+def test_odometry_window_assembly_is_the_references_pure_odometry(orc, synth):
+    """Estimator::optimizeMap with ESTIMATE_EXTRINSIC = 0 (estimator.cpp:593-866 from the reference's own lines over the Ceres-shaped shim): one
+    LidarPureOdom factor per selected feature on (para_pose_[0], para_pose_[i - pivot_idx], para_ex_pose_[n]), Huber(1.0), the pivot pose and EVERY extrinsic
+    constant. The Jacobian evalResidual evaluates (-> evalDegenracy) and its cost equal the oracle's window normal equations -- the table the device reduces
+    (mlh_pure_odom_normal_eq) is built the same way --, constant blocks with zero columns; ceres::Solve then lowers the cost and lands where Gauss-Newton on the
+    oracle's normal equations lands (what mlh_pure_odom_gn_solve iterates)."""
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    import conftest
+    n_frames, n_lidars = 2, 2
+    w = conftest.make_window_case(synth, orc, n_frames, n_lidars)
+    poses = np.vstack([w["pivot"][None, :], w["frames"]])
+    got = orc.ref_optimize_map(poses, w["exts"], _window_rows(w), estimate_extrinsic=0, num_iterations=10)
+    want = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], w["frames"], w["exts"], 1.0)
+    D = 6 * (1 + n_frames + n_lidars)
+    free = np.zeros(D, bool); free[6:6 * (1 + n_frames)] = True
+    Hm = want["H"] * np.outer(free, free)
+    assert got["n_blocks"] == len(w["types"])
+    assert abs(got["cost"] - want["cost"]) <= 1e-12 * want["cost"]
+    assert float(np.abs(got["H"] - Hm).max()) <= 1e-11 * float(np.abs(Hm).max())
+    assert not got["H"][~free].any() and not got["H"][:, ~free].any()
+    # the solve: constants untouched, cost lowered, and the minimiser Gauss-Newton on the oracle's normal equations reaches
+    assert np.array_equal(got["poses"][0], w["pivot"]) and np.array_equal(got["exts"], w["exts"])
+    assert got["solve"]["final_cost"] < 0.9 * got["solve"]["initial_cost"] and abs(got["solve"]["initial_cost"] - want["cost"]) <= 1e-12 * want["cost"]
+    fr = w["frames"].copy()
+    for _ in range(8):
+        ne = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], fr, w["exts"], 1.0)
+        idx = np.flatnonzero(free)
+        d = np.linalg.solve(ne["H"][np.ix_(idx, idx)], -ne["g"][idx])
+        fr = np.stack([orc.pose_plus(fr[i], d[6 * i:6 * i + 6]) for i in range(n_frames)])
+    assert float(np.abs(got["poses"][1:, :3] - fr[:, :3]).max()) < 2e-4 and float(np.abs(got["poses"][1:, 3:] - fr[:, 3:]).max()) < 2e-5
+    end = orc.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], got["poses"][1:], w["exts"], 1.0)
+    assert abs(end["cost"] - got["solve"]["final_cost"]) <= 1e-9 * end["cost"]
+
+
+def test_odometry_window_assembly_is_the_references_online_calibration(orc, synth):
+    """ESTIMATE_EXTRINSIC = 1: only the reference LiDAR's features become window factors (on para_ex_pose_[IDX_REF], which is constant); the other LiDARs'
+    pivot-frame features accumulate in cumu_*_map_features_ and turn into LidarOnlineCalib factors on their own extrinsic every N_CUMU_FEATURE-th frame."""
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    import conftest
+    n_frames, n_lidars = 1, 2
+    w = conftest.make_window_case(synth, orc, n_frames, n_lidars)
+    poses = np.vstack([w["pivot"][None, :], w["frames"]])
+    rows = _window_rows(w)
+    is_ref = rows[:, 0] == 0
+    calib = rows[~is_ref].copy()
+    calib[:, 1] = 0                                                     # LiDAR 1's features play the pivot frame's (frame index pivot_idx) features of LiDAR 1
+    D = 6 * (1 + n_frames + n_lidars)
+    m = is_ref
+    win = orc.pure_odom_normal_eq(w["types"][m], w["points"][m], w["coeffs"][m], None, w["fi"][m], w["ei"][m], w["pivot"], w["frames"], w["exts"], 1.0)
+    free = np.ones(D, bool); free[:6] = False; free[6 * (1 + n_frames):6 * (2 + n_frames)] = False      # pivot and the reference extrinsic are constant
+    for frame_cnt, with_calib in ((10, True), (7, False)):
+        got = orc.ref_optimize_map(poses, w["exts"], np.vstack([rows[is_ref], calib]), estimate_extrinsic=1, frame_cnt=frame_cnt, n_cumu_feature=10, num_iterations=6)
+        H = win["H"] * np.outer(free, free)
+        cost = win["cost"]
+        n_blocks = int(is_ref.sum())
+        if with_calib:
+            e1 = slice(6 * (2 + n_frames), 6 * (3 + n_frames))
+            for kind, k in (("s", 0), ("c", 1)):
+                sel = calib[:, 2] == k
+                f4 = np.zeros((int(sel.sum()), 4), np.float32)            # the calibration factors take the point as a double: keep the rows exactly representable
+                pts = calib[sel, 3:6]
+                assert np.array_equal(pts.astype(np.float32).astype(np.float64), pts)
+                f4[:, :3] = pts
+                lin = orc.linearize(kind, f4, np.full(len(f4), 0.0075), w["exts"][1], np.ones(len(f4), np.uint8), calib[sel, 6:12], huber_delta=1.0)
+                H[e1, e1] += lin["H"]; cost += lin["cost"]; n_blocks += int(sel.sum())
+        assert got["n_blocks"] == n_blocks, frame_cnt
+        assert abs(got["cost"] - cost) <= 1e-11 * cost
+        assert float(np.abs(got["H"] - H).max()) <= 1e-10 * float(np.abs(H).max())
+        assert np.array_equal(got["poses"][0], w["pivot"]) and np.array_equal(got["exts"][0], w["exts"][0])
+        assert (not np.array_equal(got["exts"][1], w["exts"][1])) == with_calib           # the extrinsic moves only when its factors were added
+        assert got["solve"]["final_cost"] < got["solve"]["initial_cost"]
