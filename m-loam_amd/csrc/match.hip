@@ -426,14 +426,18 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
         MLH_STAGE(4095, 1);
-        if (threadIdx.x == 0) {
-            if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks);
-            else lm_step_body(f_ne, P.state, P.lm_max_it);
-            *P.ticket = 0u;
-            if (P.publish) {         // last launch of a chunk of LM steps: the pose and the `done` flag go to the host from here
-                for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
-                P.publish->done = P.state->done;
-                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x < 64) {      // one wavefront runs the LM begin / step (solver_dev.hpp: rows of the 6 x 6 objects on lanes)
+            double xo[7];
+            int done = 0;
+            if (P.finish == 3) lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
+            else lm_step_body_wave(f_ne, P.state, P.lm_max_it, xo, done);
+            if (threadIdx.x == 0) {
+                *P.ticket = 0u;
+                if (P.publish) {     // last launch of a chunk of LM steps: the pose and the `done` flag go to the host from here
+                    for (int i = 0; i < 7; ++i) P.publish->x[i] = xo[i];
+                    P.publish->done = done;
+                    __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
         MLH_STAGE(4095, 2);

@@ -621,4 +621,286 @@ __device__ __forceinline__ void lm_step_body(const double *ce, SolverState *S, i
     lm_propose(S, max_it);
 }
 
+// ---------------------------------------------------------------- the same bodies on ONE WAVEFRONT
+// Run by one thread, an LM step costs ~4.9 us of a 12.4 us launch (knock-out timing, profiles/r03_knockout_experiments.txt): ~500 dependent f64 operations and two
+// dozen divisions / square roots on a single lane. Here all 64 lanes of a wavefront enter converged and hold the small vectors (pose, step, scalars) uniformly;
+// lane r < 6 owns ROW r of every 6 x 6 object (V_update, the Jacobi-scaled J^T J, its Cholesky factor), independent divisions go to different lanes, results
+// travel by v_readlane. Every output element is computed by the same operations in the same order as in lm_step_body / lm_propose / pose_plus above, so the two
+// forms are interchangeable bit for bit (the stand-alone LM kernels of solver.hip -- multi-GPU and good-feature paths -- keep the one-thread form, the fused
+// single-GPU scan2map and the tracker run this one; tests/test_gpu_parity.py::test_rccl_single_rank_path compares their poses for equality).
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// pose_plus (dev_math.hpp): dx = V delta on lanes 0..5 (row r, columns in order), the four quotients p / |p| on lanes 0..3. V: 36 doubles or null (identity).
+__device__ __forceinline__ void pose_plus_wave(const double (&x)[7], const double (&delta)[6], const double *V, double (&out)[7], int lane)
+{
+    const int r = lane < 6 ? lane : 0;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += (V ? V[r * 6 + c] : (r == c ? 1.0 : 0.0)) * delta[c];
+    double dx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dx[k] = wave_bcast(s, k);
+    const q4 q{x[3], x[4], x[5], x[6]};
+    const q4 dq{dx[3] / 2.0, dx[4] / 2.0, dx[5] / 2.0, 1.0};
+    q4 p = qmul(q, dq);
+    const double n2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+    if (n2 > 0.0) {
+        const double n = sqrt(n2);
+        const double mine = (lane & 3) == 0 ? p.x : ((lane & 3) == 1 ? p.y : ((lane & 3) == 2 ? p.z : p.w));
+        const double quo = mine / n;
+        p.x = wave_bcast(quo, 0); p.y = wave_bcast(quo, 1); p.z = wave_bcast(quo, 2); p.w = wave_bcast(quo, 3);
+    }
+    out[0] = x[0] + dx[0]; out[1] = x[1] + dx[1]; out[2] = x[2] + dx[2];
+    out[3] = p.x; out[4] = p.y; out[5] = p.z; out[6] = p.w;
+}
+
+// the LM part of the solver state, uniform over the wavefront
+struct LmRegs {
+    double x[7], g[6], Sv[6], diag[6];
+    double radius, decrease_factor, model_cost_change, gmax;
+    int reuse_diagonal, iteration, done, termination, num_successful, num_invalid, evaluations;
+};
+
+__device__ __forceinline__ double gradient_max_norm_wave(const LmRegs &R, const double *V, int lane)
+{
+    double ng[6], xp[7];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ng[i] = -R.g[i];
+    pose_plus_wave(R.x, ng, V, xp, lane);
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m = fmax(m, fabs(R.x[i] - xp[i]));
+    return m;
+}
+
+// lm_propose: ne = the record at x (any memory, read by lanes 0..5), V = V_update (36 doubles). On return `cand` holds the candidate when !R.done.
+__device__ __forceinline__ void lm_propose_wave(LmRegs &R, const double *ne, const double *V, double (&cand)[7], int max_it, int lane)
+{
+    const int r = lane < 6 ? lane : 0;
+    double Hrow[6];                                   // row r of J^T J (upper-packed record)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int i = r < c ? r : c, j = r < c ? c : r;
+        Hrow[c] = ne[i * 6 - (i * (i - 1)) / 2 + (j - i)];
+    }
+    const double Sr = lane == 0 ? R.Sv[0] : (lane == 1 ? R.Sv[1] : (lane == 2 ? R.Sv[2] : (lane == 3 ? R.Sv[3] : (lane == 4 ? R.Sv[4] : R.Sv[5]))));
+    while (true) {
+        if (R.iteration >= max_it) { R.done = 1; R.termination = 0; return; }
+        if (R.gmax <= 1e-10) { R.done = 1; R.termination = 1; return; }
+        if (R.radius <= 1e-32) { R.done = 1; R.termination = 4; return; }
+        R.iteration++;
+        double A[6];                                  // row r of the Jacobi-scaled matrix
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[c] = Sr * Hrow[c] * R.Sv[c];
+        const double gs_r = Sr * (lane == 0 ? R.g[0] : (lane == 1 ? R.g[1] : (lane == 2 ? R.g[2] : (lane == 3 ? R.g[3] : (lane == 4 ? R.g[4] : R.g[5])))));
+        const double Arr = lane == 0 ? A[0] : (lane == 1 ? A[1] : (lane == 2 ? A[2] : (lane == 3 ? A[3] : (lane == 4 ? A[4] : A[5]))));
+        if (!R.reuse_diagonal) {
+            const double dr = fmin(fmax(Arr, 1e-6), 1e32);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) R.diag[i] = wave_bcast(dr, i);
+        }
+        const double diag_r = lane == 0 ? R.diag[0] : (lane == 1 ? R.diag[1] : (lane == 2 ? R.diag[2] : (lane == 3 ? R.diag[3] : (lane == 4 ? R.diag[4] : R.diag[5]))));
+        const double lhs_rr = Arr + diag_r / R.radius;
+        // Cholesky of lhs, row r on lane r: chol6p_factor's operations in its order (packed lower triangle: a[k] = L(r, k))
+        double a[6], colv[6], rinv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a[k] = (k < r) ? A[k] : ((k == r) ? lhs_rr : 0.0); colv[k] = 0.0; }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double rj[6];
+#pragma unroll
+            for (int k = 0; k < j; ++k) rj[k] = wave_bcast(a[k], j);          // L(j, k)
+            double t = a[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= a[k] * rj[k];
+            const double sj = wave_bcast(t, j);
+            ok = ok && (sj > 0.0);
+            const double rr = rsqrt(sj);
+            rinv[j] = rr;
+            a[j] = (r == j) ? sj * rr : t * rr;
+#pragma unroll
+            for (int k = 0; k < j; ++k) if (r == k) colv[j] = rj[k];          // colv[j] = L(j, r), j > r
+        }
+        R.reuse_diagonal = 1;
+        bool valid = false;
+        double mcc = 0.0, step[6];
+        if (ok) {
+            // L y' = gs, L^T y = y' (chol6p_substitute), step = -y
+            double b = gs_r, yv = 0.0, y[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double yk = b * rinv[k];
+                const double ykb = wave_bcast(yk, k);
+                if (r == k) yv = yk;
+                if (r > k) b -= a[k] * ykb;
+            }
+#pragma unroll
+            for (int k = 5; k >= 0; --k) {
+                double sacc = yv;
+#pragma unroll
+                for (int m = k + 1; m < 6; ++m) sacc -= colv[m] * y[m];
+                y[k] = wave_bcast(sacc * rinv[k], k);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) step[i] = -y[i];
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t += A[c] * step[c];
+            double sg = 0.0, sAs = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                sg += step[i] * wave_bcast(gs_r, i);
+                sAs += step[i] * wave_bcast(t, i);
+            }
+            mcc = -(sg + 0.5 * sAs);
+            valid = mcc > 0.0;
+        }
+        if (!valid) {
+            if (++R.num_invalid >= 5) { R.done = 1; R.termination = 4; return; }
+            R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
+            continue;
+        }
+        R.num_invalid = 0;
+        double delta[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) delta[i] = step[i] * R.Sv[i];
+        pose_plus_wave(R.x, delta, V, cand, lane);
+        R.model_cost_change = mcc;
+        return;
+    }
+}
+
+__device__ __forceinline__ void lm_regs_load(LmRegs &R, const SolverState *S)
+{
+#pragma unroll
+    for (int i = 0; i < 7; ++i) R.x[i] = S->x[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { R.g[i] = S->ne[NE_G + i]; R.Sv[i] = S->S[i]; R.diag[i] = S->diag[i]; }
+    R.radius = S->radius; R.decrease_factor = S->decrease_factor; R.model_cost_change = S->model_cost_change; R.gmax = S->gmax;
+    R.reuse_diagonal = S->reuse_diagonal; R.iteration = S->iteration; R.done = S->done; R.termination = S->termination;
+    R.num_successful = S->num_successful; R.num_invalid = S->num_invalid; R.evaluations = S->evaluations;
+}
+
+// everything but x / ne (stored by the caller when a step is accepted) and cand
+__device__ __forceinline__ void lm_regs_store(const LmRegs &R, const double (&cand)[7], SolverState *S, int lane)
+{
+    if (lane < 7 && !R.done) S->cand[lane] = lane == 0 ? cand[0] : (lane == 1 ? cand[1] : (lane == 2 ? cand[2] : (lane == 3 ? cand[3] : (lane == 4 ? cand[4] : (lane == 5 ? cand[5] : cand[6])))));
+    if (lane >= 8 && lane < 14) { const int i = lane - 8; S->diag[i] = i == 0 ? R.diag[0] : (i == 1 ? R.diag[1] : (i == 2 ? R.diag[2] : (i == 3 ? R.diag[3] : (i == 4 ? R.diag[4] : R.diag[5])))); }
+    if (lane == 16) {
+        S->radius = R.radius; S->decrease_factor = R.decrease_factor; S->model_cost_change = R.model_cost_change; S->gmax = R.gmax;
+        S->reuse_diagonal = R.reuse_diagonal; S->iteration = R.iteration; S->done = R.done; S->termination = R.termination;
+        S->num_successful = R.num_successful; S->num_invalid = R.num_invalid; S->evaluations = R.evaluations;
+    }
+}
+
+// lm_step_body on a wavefront. ce: the summed record at the candidate pose (LDS). All 64 lanes, converged. x_out / done_out: the state's pose and `done`
+// flag as this call leaves them (uniform; what a publication that follows needs, without reading back what other lanes have just stored).
+__device__ __forceinline__ void lm_step_body_wave(const double *ce, SolverState *S, int max_it, double (&x_out)[7], int &done_out)
+{
+    const int lane = threadIdx.x & 63;
+    LmRegs R;
+    lm_regs_load(R, S);
+    double cand[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cand[i] = S->cand[i];
+    const double x_cost = S->ne[NE_COST];
+    R.evaluations++;
+    double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const double d = R.x[i] - cand[i]; step_norm += d * d; x_norm += R.x[i] * R.x[i]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    bool stop = false;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { R.done = 1; R.termination = 2; stop = true; }
+    const double cost_change = x_cost - ce[NE_COST];
+    if (!stop && fabs(cost_change) <= 1e-6 * x_cost) { R.done = 1; R.termination = 3; stop = true; }
+    const double *ne_now = S->ne;                      // the record the next proposal is built from
+    if (!stop) {
+        const double rd = cost_change / R.model_cost_change;
+        if (rd > 1e-3) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) R.x[i] = cand[i];
+            if (lane < 7) S->x[lane] = lane == 0 ? cand[0] : (lane == 1 ? cand[1] : (lane == 2 ? cand[2] : (lane == 3 ? cand[3] : (lane == 4 ? cand[4] : (lane == 5 ? cand[5] : cand[6])))));
+            if (lane < NE_STRIDE) S->ne[lane] = ce[lane];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) R.g[i] = ce[NE_G + i];
+            ne_now = ce;                               // same values; LDS, and no wait for the stores above
+            R.num_successful++;
+            const double t = 2.0 * rd - 1.0;
+            R.radius = R.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            R.radius = fmin(1e16, R.radius);
+            R.decrease_factor = 2.0;
+            R.reuse_diagonal = 0;
+            R.gmax = gradient_max_norm_wave(R, S->V, lane);
+        } else {
+            R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
+        }
+        lm_propose_wave(R, ne_now, S->V, cand, max_it, lane);
+    }
+    lm_regs_store(R, cand, S, lane);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x_out[i] = R.x[i];
+    done_out = R.done;
+}
+
+// lm_begin_body on a wavefront (ne / cnt2 / scratch in LDS; all 64 lanes, converged): the degeneracy decision stays on lane 0 (a Cholesky test, or the
+// eigen-decomposition when it fails or statistics are requested), the copies, the Jacobi scaling, the gradient norm and the first proposal are spread out.
+__device__ __forceinline__ void lm_begin_body_wave(const double *ne, const double *cnt2, double *scratch, SolverState *S, double eig_thre, int max_it,
+                                                   IterStatDev *stat, int min_blocks, double (&x_out)[7], int &done_out)
+{
+    const int lane = threadIdx.x & 63;
+    int flags = 0;                                     // bit 0: fast (V_update = I), bit 1: degenerate
+    if (lane == 0) {
+        bool deg = false, fast = eig_thre < 0.0;
+        if (!fast && !stat) {
+            double L[21], inv_d[6];
+            pack_lower_from_ne(ne, eig_thre * (1.0 + 1e-9), L);
+            fast = chol6p_factor(L, inv_d);
+        }
+        if (!fast) deg = eval_degeneracy_reg(ne, eig_thre, scratch);
+        flags = (fast ? 1 : 0) | (deg ? 2 : 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // scratch (V_update, eigenvalues) was written by lane 0
+    __builtin_amdgcn_wave_barrier();
+    flags = __builtin_amdgcn_readlane(flags, 0);
+    const bool fast = (flags & 1) != 0, deg = (flags & 2) != 0;
+    if (lane < NE_STRIDE) S->ne[lane] = ne[lane];
+    if (lane < 36) S->V[lane] = fast ? (((lane % 7) == 0) ? 1.0 : 0.0) : scratch[78 + lane];
+    // V_update for this call's own use: LDS (scratch[78..113]) -- on the fast path the identity is written there too, so that nobody reads S->V back
+    if (fast && lane < 36) scratch[78 + lane] = ((lane % 7) == 0) ? 1.0 : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    LmRegs R;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) R.x[i] = S->x[i];
+    {
+        const int r = lane < 6 ? lane : 0;
+        const double sc = 1.0 / (1.0 + sqrt(ne[r * 6 - (r * (r - 1)) / 2]));      // Jacobi scaling from diag(J^T J): upper-packed index of (r, r)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { R.Sv[i] = wave_bcast(sc, i); R.g[i] = ne[NE_G + i]; R.diag[i] = S->diag[i]; }
+        if (lane < 6) S->S[lane] = sc;
+    }
+    R.radius = 1e4; R.decrease_factor = 2.0; R.reuse_diagonal = 0; R.model_cost_change = S->model_cost_change;
+    R.iteration = 0; R.done = 0; R.termination = 0; R.num_successful = 0; R.num_invalid = 0; R.evaluations = 1;
+    R.gmax = gradient_max_norm_wave(R, scratch + 78, lane);
+    if (stat && lane == 0) {
+        if (fast) for (int i = 0; i < 6; ++i) scratch[72 + i] = 0.0;     // no eigenvalues were computed
+        write_stat_common(stat, ne, cnt2, scratch + 72, deg);
+        stat->final_cost = ne[NE_COST];
+    }
+    double cand[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cand[i] = 0.0;
+    // too few residual blocks (lidar_tracker.cpp:66-70 "less correspondence": the round is skipped)
+    if (ne[NE_CNT] < double(min_blocks)) { R.done = 1; R.termination = 4; }
+    else lm_propose_wave(R, ne, scratch + 78, cand, max_it, lane);
+    lm_regs_store(R, cand, S, lane);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x_out[i] = R.x[i];
+    done_out = R.done;
+}
+
 }  // namespace mlh

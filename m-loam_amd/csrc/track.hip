@@ -429,13 +429,21 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
     SumArgs sa;
     sa.p = P.partials;
     sa.lo[0] = 0; sa.hi[0] = total; sa.lo[1] = 0; sa.hi[1] = 0;
-    sum_partials(sa, f_ne, f_cnt2, f_scratch);
-    if (threadIdx.x == 0) {
-        if (P.use_init) for (int i = 0; i < 7; ++i) P.state->x[i] = P.init_pose[i];      // the state's pose is born here (first round of a solve)
-        if (P.finish == 3) lm_begin_body(f_ne, f_cnt2, f_scratch, P.state, -1.0, P.lm_max_it, P.stat, P.lm_min_blocks);
-        else lm_step_body(f_ne, P.state, P.lm_max_it);
-        *P.ticket = 0u;
-        if (P.publish) track_publish(P);
+    if (P.use_init && threadIdx.x < 7) P.state->x[threadIdx.x] = P.init_pose[threadIdx.x];   // the state's pose is born here (first round of a solve); ordered
+    sum_partials(sa, f_ne, f_cnt2, f_scratch);                                               // before the body by the barriers of the sum
+    if (threadIdx.x < 64) {          // one wavefront runs the LM begin / step (solver_dev.hpp: rows of the 6 x 6 objects on lanes)
+        double xo[7];
+        int done = 0;
+        if (P.finish == 3) lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, -1.0, P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
+        else lm_step_body_wave(f_ne, P.state, P.lm_max_it, xo, done);
+        if (threadIdx.x == 0) {
+            *P.ticket = 0u;
+            if (P.publish) {
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = xo[i];
+                P.publish->done = done;
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
