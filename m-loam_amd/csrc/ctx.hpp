@@ -372,7 +372,8 @@ inline hipError_t read_back_int(mlh_ctx *ctx, const void *dev, int *out)
 // stdsort.hip: vals_out <- the permutation of 0..n-1 that std::sort (libstdc++, comparator on the key only) leaves for keys[0..n0) and keys[n0..n)
 int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out);
 int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *counts, const int *offsets, int stride, int field, int n_segments, int n, int longest,
-                             int *vals_out);
+                             int *vals_out, bool counters_cleared = false);
+int *device_std_sort_counters(mlh_ctx *ctx, int n, int *n_counters);
 void host_std_sort_permutation(const int *slot, int lo, int hi, int *members);   // voxelgrid.hip: the platform's own std::sort
 // voxel.hip
 void compound_pose_with_cov(const double p1[7], const double c1[36], const double p2[7], const double c2[36], double pc[7], double cc[36]);

@@ -387,15 +387,32 @@ int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int
 // One std::sort call per segment (device-side tables of counts and offsets, `stride` ints per segment, entry `field`): vals_out[i] <- the
 // global index of the element std::sort leaves at position i of its segment. longest = a host-side upper bound of a segment's length
 // (it only decides whether the big-level launches are needed).
+// The per-level range counters of a sort over n elements (SS_CNT ints): a caller that has a launch of its own in front of device_std_sort_segments can clear
+// them there and pass counters_cleared = true -- hipMemsetAsync of these 56 unaligned bytes is THREE fill launches (~15 us in the frame's kernel trace).
+int *device_std_sort_counters(mlh_ctx *ctx, int n, int *n_counters)
+{
+    StdSortArgs A;
+    size_t nbig, nleaf;
+    if (n <= 0 || stdsort_setup(ctx, n, nullptr, A, nbig, nleaf)) return nullptr;
+    if (n_counters) *n_counters = SS_CNT;
+    return A.cnt;
+}
+
+__global__ void stdsort_clear_counters_kernel(int *cnt)
+{
+    if (threadIdx.x < SS_CNT) cnt[threadIdx.x] = 0;
+}
+
 int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *counts, const int *offsets, int stride, int field, int n_segments, int n, int longest,
-                             int *vals_out)
+                             int *vals_out, bool counters_cleared)
 {
     if (n <= 0 || n_segments <= 0) return MLH_OK;
     StdSortArgs A;
     size_t nbig, nleaf;
     int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
     if (rc) return rc;
-    MLH_HIP(ctx, hipMemsetAsync(A.cnt, 0, sizeof(int) * SS_CNT, ctx->stream));      // one thread per segment appends its range: the counters start at zero
+    // one thread per segment appends its range: the counters start at zero
+    if (!counters_cleared) hipLaunchKernelGGL(stdsort_clear_counters_kernel, dim3(1), dim3(64), 0, ctx->stream, A.cnt);
     hipLaunchKernelGGL(stdsort_init_segments_kernel, dim3((std::max(n, n_segments) + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field,
                        n_segments);
     return stdsort_levels(ctx, A, longest, nbig, nleaf);

@@ -31,6 +31,8 @@ struct RingVoxelArgs {
     float leaf;
     int *vkeys;                 // MODE 1: PCL voxel index of every less-flat point, in list order (the keys std::sort sees)
     const int *perm;            // MODE 2: the order std::sort leaves them in (global positions of the less-flat list), voxel after voxel
+    int *zero;                  // MODE 1: n_zero words the first workgroup clears on its way (the range counters of the sort that follows)
+    int n_zero;
 };
 
 constexpr int RV_TPB = 1024, RV_WAVES = RV_TPB / 64;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
     const int ring = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = A.ring_counts[ring * 4 + 3];
     const int off = A.ring_offsets[ring * 4 + 3];
+    if (MODE == 1 && ring == 0 && tid < A.n_zero) A.zero[tid] = 0;
     if (n <= 0) { if (tid == 0) A.ring_vox[ring] = 0; return; }
     const float inv = 1.0f / A.leaf;
 
@@ -212,7 +215,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     RingVoxelArgs A;
     A.pts = sb.pts.as<float4>(); A.list3 = sb.lists[3].as<int>(); A.ring_counts = sb.ring_counts.as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.stage = sb.vox_stage.as<float4>(); A.ring_vox = sb.ring_vox.as<int>();
-    A.leaf = leaf; A.vkeys = nullptr; A.perm = nullptr;
+    A.leaf = leaf; A.vkeys = nullptr; A.perm = nullptr; A.zero = nullptr; A.n_zero = 0;
     if (longest > RV_TPB * 8) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
     prof_begin(ctx, MLH_K_EXTRACT);
     if (ctx->vox_member_order != 0) {
@@ -220,8 +223,10 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
         MLH_HIP(ctx, sb.vox_keys.ensure(sizeof(int) * size_t(sb.n)));
         MLH_HIP(ctx, sb.vox_perm.ensure(sizeof(int) * size_t(sb.n)));
         A.vkeys = sb.vox_keys.as<int>();
+        A.zero = device_std_sort_counters(ctx, sb.n, &A.n_zero);         // cleared by pass 1's first workgroup: no fill launches in front of the sort
+        if (!A.zero) return fail(ctx, MLH_ERR_HIP, "std::sort scratch");
         MLH_HIP(ctx, ring_voxel_launch_any<1>(A, R, longest, st));
-        int rc = device_std_sort_segments(ctx, A.vkeys, A.ring_counts, A.ring_offsets, 4, 3, R, sb.n, longest, sb.vox_perm.as<int>());
+        int rc = device_std_sort_segments(ctx, A.vkeys, A.ring_counts, A.ring_offsets, 4, 3, R, sb.n, longest, sb.vox_perm.as<int>(), true);
         if (rc) return rc;
         A.perm = sb.vox_perm.as<int>();
         MLH_HIP(ctx, ring_voxel_launch_any<2>(A, R, longest, st));
