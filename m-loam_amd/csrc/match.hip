@@ -477,19 +477,19 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         if (P.n_blocks == 1) { sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0; }   // one block: every record (any tile size)
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
         MLH_STAGE(4095, 1);
-        if (threadIdx.x < 64)
+        if (threadIdx.x < 64) {
+            double xo[7];
             gn_finish_wave(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], nullptr /* nothing downstream reads a mirror of ne / V_update in GN mode */, P.thre_b[b], P.freeze_b[b],
-                           P.stat ? P.stat + b : nullptr, f_scratch);
+                           P.stat ? P.stat + b : nullptr, f_scratch, xo);
+            // the solve's last launch hands the pose(s) to the host: straight from the finish's registers (reading the state back would be one more round trip)
+            if (P.publish && threadIdx.x == 0) for (int i = 0; i < 7; ++i) (b == 0 ? P.publish->x : P.publish->xb[b])[i] = xo[i];
+        }
         __syncthreads();
         MLH_STAGE(4095, 2);
     }
     if (threadIdx.x == 0) {
         *P.ticket = 0u;
-        if (P.publish) {
-            for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
-            for (int b = 1; b < P.n_blocks; ++b) for (int i = 0; i < 7; ++i) P.publish->xb[b][i] = P.state->xb[b][i];
-            __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (P.publish) __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -414,9 +414,39 @@ __device__ __forceinline__ double bcast_pair(double v, int j, bool grp_b)
     return __hiloint2double(grp_b ? bhi : ahi, grp_b ? blo : alo);
 }
 
+// (used by gn_finish_wave and, further down, by the wavefront forms of the LM bodies)
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// pose_plus (dev_math.hpp): dx = V delta on lanes 0..5 (row r, columns in order), the four quotients p / |p| on lanes 0..3. V: 36 doubles or null (identity).
+__device__ __forceinline__ void pose_plus_wave(const double (&x)[7], const double (&delta)[6], const double *V, double (&out)[7], int lane)
+{
+    const int r = lane < 6 ? lane : 0;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += (V ? V[r * 6 + c] : (r == c ? 1.0 : 0.0)) * delta[c];
+    double dx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dx[k] = wave_bcast(s, k);
+    const q4 q{x[3], x[4], x[5], x[6]};
+    const q4 dq{dx[3] / 2.0, dx[4] / 2.0, dx[5] / 2.0, 1.0};
+    q4 p = qmul(q, dq);
+    const double n2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+    if (n2 > 0.0) {
+        const double n = sqrt(n2);
+        const double mine = (lane & 3) == 0 ? p.x : ((lane & 3) == 1 ? p.y : ((lane & 3) == 2 ? p.z : p.w));
+        const double quo = mine / n;
+        p.x = wave_bcast(quo, 0); p.y = wave_bcast(quo, 1); p.z = wave_bcast(quo, 2); p.w = wave_bcast(quo, 3);
+    }
+    out[0] = x[0] + dx[0]; out[1] = x[1] + dx[1]; out[2] = x[2] + dx[2];
+    out[3] = p.x; out[4] = p.y; out[5] = p.z; out[6] = p.w;
+}
+
 // Called by ALL 64 lanes of one wavefront, converged. Arguments as gn_finish2.
 __device__ __forceinline__ void gn_finish_wave(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
-                                               IterStatDev *stat, double *work /*LDS, DEG_WORK*/)
+                                               IterStatDev *stat, double *work /*LDS, DEG_WORK*/, double (&x_out)[7])
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 7;
@@ -474,27 +504,49 @@ __device__ __forceinline__ void gn_finish_wave(const double *ne, const double *c
             d[k] = bcast_pair(sacc * rinv[k], k, false);
         }
     }
-    if (lane != 0) return;
-    bool deg = false;
-    const bool slow = !(stat == nullptr && not_degenerate_fast);
-    if (slow) deg = eval_degeneracy_mem(ne, eig_thre, work);
-    const bool frozen = freeze && (slow ? deg : false);
-    if (pd && !frozen) {
-        double xn[7];
-        pose_plus(xc, d, slow ? work + 78 : nullptr, xn);   // V_update = I on the fast path
+    // x_out: the block's pose as this call leaves it, uniform over the wavefront (a publication that follows takes it from here instead of reading x back)
 #pragma unroll
-        for (int q = 0; q < 7; ++q) x[q] = xn[q];
+    for (int q = 0; q < 7; ++q) x_out[q] = xc[q];
+    const bool slow = !(stat == nullptr && not_degenerate_fast);
+    if (!slow) {
+        // the common case -- nothing degenerate, nobody asked for eigenvalues: V_update = I, and the update runs on the wavefront (the four quotients of the
+        // quaternion's normalisation on four lanes instead of one after the other)
+        if (pd) {
+            double dd[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) dd[q] = d[q];
+            pose_plus_wave(xc, dd, nullptr, x_out, lane);
+            if (lane < 7) x[lane] = lane == 0 ? x_out[0] : (lane == 1 ? x_out[1] : (lane == 2 ? x_out[2] : (lane == 3 ? x_out[3] : (lane == 4 ? x_out[4] : (lane == 5 ? x_out[5] : x_out[6])))));
+        }
+        if (lane != 0) return;
+        if (S) {
+            for (int q = 0; q < NE_STRIDE; ++q) S->ne[q] = ne[q];
+            for (int q = 0; q < 36; ++q) S->V[q] = ((q % 7) == 0) ? 1.0 : 0.0;
+        }
+        return;
     }
-    if (S) {
-        for (int q = 0; q < NE_STRIDE; ++q) S->ne[q] = ne[q];
-        for (int q = 0; q < 36; ++q) S->V[q] = slow ? work[78 + q] : (((q % 7) == 0) ? 1.0 : 0.0);
+    if (lane == 0) {
+        bool deg = eval_degeneracy_mem(ne, eig_thre, work);
+        const bool frozen = freeze && deg;
+        if (pd && !frozen) {
+            double xn[7];
+            pose_plus(xc, d, work + 78, xn);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { x[q] = xn[q]; x_out[q] = xn[q]; }
+        }
+        if (S) {
+            for (int q = 0; q < NE_STRIDE; ++q) S->ne[q] = ne[q];
+            for (int q = 0; q < 36; ++q) S->V[q] = work[78 + q];
+        }
+        if (stat) {
+            write_stat_common(stat, ne, cnt2, work + 72, deg);
+            stat->final_cost = ne[NE_COST];
+            stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = frozen ? 1 : 0;
+            for (int q = 0; q < 7; ++q) stat->pose_after[q] = x[q];
+        }
     }
-    if (stat) {
-        write_stat_common(stat, ne, cnt2, work + 72, deg);
-        stat->final_cost = ne[NE_COST];
-        stat->lm_iterations = 0; stat->successful_steps = 0; stat->termination = frozen ? 1 : 0;
-        for (int q = 0; q < 7; ++q) stat->pose_after[q] = x[q];
-    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) x_out[q] = wave_bcast(x_out[q], 0);
 }
 
 // ---------------------------------------------------------------- Levenberg-Marquardt (Ceres trust-region semantics)
@@ -628,35 +680,6 @@ __device__ __forceinline__ void lm_step_body(const double *ce, SolverState *S, i
 // travel by v_readlane. Every output element is computed by the same operations in the same order as in lm_step_body / lm_propose / pose_plus above, so the two
 // forms are interchangeable bit for bit (the stand-alone LM kernels of solver.hip -- multi-GPU and good-feature paths -- keep the one-thread form, the fused
 // single-GPU scan2map and the tracker run this one; tests/test_gpu_parity.py::test_rccl_single_rank_path compares their poses for equality).
-__device__ __forceinline__ double wave_bcast(double v, int src)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-
-// pose_plus (dev_math.hpp): dx = V delta on lanes 0..5 (row r, columns in order), the four quotients p / |p| on lanes 0..3. V: 36 doubles or null (identity).
-__device__ __forceinline__ void pose_plus_wave(const double (&x)[7], const double (&delta)[6], const double *V, double (&out)[7], int lane)
-{
-    const int r = lane < 6 ? lane : 0;
-    double s = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) s += (V ? V[r * 6 + c] : (r == c ? 1.0 : 0.0)) * delta[c];
-    double dx[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dx[k] = wave_bcast(s, k);
-    const q4 q{x[3], x[4], x[5], x[6]};
-    const q4 dq{dx[3] / 2.0, dx[4] / 2.0, dx[5] / 2.0, 1.0};
-    q4 p = qmul(q, dq);
-    const double n2 = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
-    if (n2 > 0.0) {
-        const double n = sqrt(n2);
-        const double mine = (lane & 3) == 0 ? p.x : ((lane & 3) == 1 ? p.y : ((lane & 3) == 2 ? p.z : p.w));
-        const double quo = mine / n;
-        p.x = wave_bcast(quo, 0); p.y = wave_bcast(quo, 1); p.z = wave_bcast(quo, 2); p.w = wave_bcast(quo, 3);
-    }
-    out[0] = x[0] + dx[0]; out[1] = x[1] + dx[1]; out[2] = x[2] + dx[2];
-    out[3] = p.x; out[4] = p.y; out[5] = p.z; out[6] = p.w;
-}
-
 // the LM part of the solver state, uniform over the wavefront
 struct LmRegs {
     double x[7], g[6], Sv[6], diag[6];
