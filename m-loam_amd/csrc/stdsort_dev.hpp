@@ -88,7 +88,39 @@ __device__ void ss_heap_sort_range(int *k, int *v, int len, Less less)
     }
 }
 
-// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first.
+// One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first, ONCE: the positions of its left stops go to
+// lt[lo], lt[lo + 1], ... and of its right stops to rt[lo], rt[lo + 1], ..., both in ASCENDING position (a chunk has at most hi - lo stops of either kind, so the
+// chunks' sub-tables cannot overlap); n_left / n_right = how many. The k-th right stop counted from the RIGHT end -- the one the partition loop pairs with the
+// k-th left stop -- is entry (n_right - 1 - k) of that list; a count pass in front (rounds 2 and 3 had one, to rank the right stops from the right while
+// writing) is not needed.
+template <int SS_U, typename Less>
+__device__ inline void ss_wave_stop_lists(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = ss_lanes_below();
+    int run_l = 0, run_r = 0;
+    for (int base = lo; base < hi; base += 64 * SS_U) {
+        int k[SS_U];
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
+#pragma unroll
+        for (int u = 0; u < SS_U; ++u) {
+            const int p = base + 64 * u + lane;
+            const bool in = p < hi;
+            const bool is_l = in && p > f && !less(k[u], piv);
+            const bool is_r = in && (p == f || !less(piv, k[u]));
+            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+            if (is_l) lt[lo + run_l + __popcll(ml & below)] = p;
+            if (is_r) rt[lo + run_r + __popcll(mr & below)] = p;
+            run_l += __popcll(ml);
+            run_r += __popcll(mr);
+        }
+    }
+    n_left = run_l; n_right = run_r;
+}
+
+// The two-pass form the 1024-thread partitions of the big levels keep (stdsort.hip: wg_partition): sixteen wavefronts share one rank space, and looking a
+// global rank up in sixteen per-wavefront lists costs more per element than the count pass it would save (measured: thinning +55 us per frame).
 // count pass: the number of left / right stops in [lo, hi).
 template <int SS_U, typename Less>
 __device__ inline void ss_wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
@@ -185,19 +217,18 @@ __device__ __forceinline__ int ss_wave_partition(int *keys, int *vals, int *lt, 
         ss_wg_fence();
         const int piv = keys[f];
         int nL, nR;
-        ss_wave_count_stops<4>(keys, f, f, l, piv, nL, nR, less);
-        ss_wave_write_tables<4>(keys, lt, rt, f, f, l, piv, 0, 0, nR, less);
+        ss_wave_stop_lists<4>(keys, lt, rt, f, f, l, piv, nL, nR, less);      // left stops ascending at lt[f ..], right stops ascending at rt[f ..]
         ss_wg_fence();
-        const int npair = min(nL, nR);
+        const int npair = min(nL, nR), rlast = f + nR - 1;                    // the k-th right stop from the right: rt[rlast - k]
         int K = 0;
         for (int base = 0; base < npair; base += 64) {
             const int k = base + lane;
-            K += __popcll(__ballot(k < npair && lt[f + k] < rt[f + k]));
+            K += __popcll(__ballot(k < npair && lt[f + k] < rt[rlast - k]));
         }
-        for (int k = lane; k < K; k += 64) ss_swap_elem(keys, vals, lt[f + k], rt[f + k]);
+        for (int k = lane; k < K; k += 64) ss_swap_elem(keys, vals, lt[f + k], rt[rlast - k]);
         cut = INT_MAX;
         if (K < nL) cut = min(cut, lt[f + K]);
-        if (K > 0) cut = min(cut, rt[f + K - 1]);
+        if (K > 0) cut = min(cut, rt[rlast - (K - 1)]);
         ss_wg_fence();
     }
     return cut;
