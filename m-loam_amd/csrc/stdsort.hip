@@ -243,7 +243,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             for (int spins = 0; spins < (1 << 24); ++spins) {        // bounded: a waiting wavefront can only be released by progress elsewhere
                 if (ticket < M.qcap && wg_load(&M.q[4 * ticket + 3]) != 0) { got = true; break; }
                 if (wg_load(&sh[LQ_REMAINING]) == 0) break;
-                __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_s_sleep(8);
             }
             if (!got) {
                 // released by `remaining == 0` (all done) or never: the latter leaves elements unsorted -- say so instead of returning a wrong order
@@ -281,16 +281,24 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
     MLH_SSTAGE(2);
     __syncthreads();
     MLH_SSTAGE(3);
-    // __final_insertion_sort, range by range
+    // __final_insertion_sort, range by range. Insertion sort is stable, and with a consistent comparator no element crosses the bounds of the ranges the loop
+    // left (<= 16 elements each): what it leaves in a range is the range's STABLE sort. Sixteen lanes per range place every element directly -- its slot is the
+    // number of elements that are smaller, or equal and earlier -- instead of one thread shifting elements one LDS round trip at a time (~10 us of a leaf launch).
     const int n_fin = sh[LQ_NFIN];
-    for (int i = t; i < n_fin; i += SS_LEAF_WG) {
-        const int a = M.fin[2 * i], b = M.fin[2 * i + 1];
-        for (int p = a + 1; p < b; ++p) {
-            const int key = M.keys[p], val = M.vals[p];
-            int j = p;
-            while (j > a && key < M.keys[j - 1]) { M.keys[j] = M.keys[j - 1]; M.vals[j] = M.vals[j - 1]; --j; }
-            M.keys[j] = key; M.vals[j] = val;
+    static_assert(SS_THRESHOLD == 16, "one 16-lane group per final range");
+    for (int i0 = 0; i0 < n_fin; i0 += SS_LEAF_WG / 16) {
+        const int i = i0 + (t >> 4), e = t & 15;
+        const bool on = i < n_fin;
+        const int a = on ? M.fin[2 * i] : 0, b = on ? M.fin[2 * i + 1] : 0, size = b - a;
+        const bool mine = on && e < size;
+        const int key = mine ? M.keys[a + e] : 0, val = mine ? M.vals[a + e] : 0;
+        int slot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kj = __shfl(key, (lane & 48) | j);                      // element j of this group's range
+            slot += (j < size && (kj < key || (kj == key && j < e))) ? 1 : 0;
         }
+        if (mine) { M.keys[a + slot] = key; M.vals[a + slot] = val; }     // all of the group's reads are in registers by now (one wavefront, in order)
     }
     MLH_SSTAGE(4);
     __syncthreads();
