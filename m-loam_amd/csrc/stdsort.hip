@@ -46,8 +46,14 @@ __device__ unsigned long long g_stage_clk_sort[1024 * 8];
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                  \
         if (threadIdx.x == 0 && blockIdx.x < 1024) g_stage_clk_sort[blockIdx.x * 8 + (i)] = wall_clock64(); \
     } while (0)
+// per-workgroup totals over all wavefronts (10 ns ticks): [0..2] partitions of <= 64 / <= 256 / longer, [3..5] their ticks, [6] bookkeeping ticks, [7] waiting ticks
+__device__ unsigned long long g_stage_clk_sort2[1024 * 8];
+#define MLH_SACC(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicAdd(&g_stage_clk_sort2[blockIdx.x * 8 + (i)], (unsigned long long)(v)); } while (0)
+#define MLH_SCLK() wall_clock64()
 #else
 #define MLH_SSTAGE(i) do { } while (0)
+#define MLH_SACC(i, v) do { } while (0)
+#define MLH_SCLK() 0ull
 #endif
 
 namespace {
@@ -234,6 +240,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
     bool have = false;
     MLH_SSTAGE(1);
     while (true) {
+        const unsigned long long c_wait = MLH_SCLK();
         if (!have) {
             if (wg_load(&sh[LQ_REMAINING]) == 0) break;
             int ticket = 0;
@@ -254,12 +261,20 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             have = true;
         }
         const int size = l - f;
+        const unsigned long long c_part = MLH_SCLK();
+        MLH_SACC(7, c_part - c_wait);
         if (d == 0) {                                                 // __partial_sort(first, last, last): sorted for good, no children
-            if (lane == 0) { heap_sort_range(M.keys + f, M.vals + f, size); wg_fence(); atomicSub(&sh[LQ_REMAINING], size); }
+            if (size <= 64) ss_heap_sort_wave64(M.keys + f, M.vals + f, size, IntLess());     // in registers (the leftovers of an exhausted budget are short)
+            else if (lane == 0) heap_sort_range(M.keys + f, M.vals + f, size);
+            wg_fence();
+            if (lane == 0) atomicSub(&sh[LQ_REMAINING], size);
             have = false;
             continue;
         }
         const int cut = ss_wave_partition(M.keys, M.vals, M.lt, M.rt, M.scr + (t >> 6) * 128, f, l, IntLess());
+        const unsigned long long c_book = MLH_SCLK();
+        MLH_SACC(size <= 64 ? 0 : (size <= 256 ? 1 : 2), 1);
+        MLH_SACC(size <= 64 ? 3 : (size <= 256 ? 4 : 5), c_book - c_part);
         // children: [cut, l) is the library's recursive call, [f, cut) its loop's next trip; both get d - 1
         const int size_a = cut - f, size_b = l - cut;
         const bool big_a = size_a > SS_THRESHOLD, big_b = size_b > SS_THRESHOLD;
@@ -267,16 +282,18 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             int done = 0;
             if (!big_a) { if (size_a > 1) { const int e = atomicAdd(&sh[LQ_NFIN], 1); M.fin[2 * e] = f; M.fin[2 * e + 1] = cut; } done += size_a; }
             if (!big_b) { if (size_b > 1) { const int e = atomicAdd(&sh[LQ_NFIN], 1); M.fin[2 * e] = cut; M.fin[2 * e + 1] = l; } done += size_b; }
-            if (big_a && big_b) {
-                const int e = atomicAdd(&sh[LQ_TAIL], 1);
-                M.q[4 * e] = cut; M.q[4 * e + 1] = l; M.q[4 * e + 2] = d - 1;
+            if (big_a && big_b) {                                     // the SHORTER child goes to the queue: the longer one is the likelier critical path,
+                const int e = atomicAdd(&sh[LQ_TAIL], 1);             // and a hand-over costs a poll interval (the ranges are disjoint: any order is the same sort)
+                const bool push_a = size_a < size_b;
+                M.q[4 * e] = push_a ? f : cut; M.q[4 * e + 1] = push_a ? cut : l; M.q[4 * e + 2] = d - 1;
                 wg_store(&M.q[4 * e + 3], 1);
             }
             if (done) { wg_fence(); atomicSub(&sh[LQ_REMAINING], done); }
         }
-        if (big_a) { l = cut; d -= 1; }
+        if (big_a && (!big_b || size_a >= size_b)) { l = cut; d -= 1; }
         else if (big_b) { f = cut; d -= 1; }
         else have = false;
+        MLH_SACC(6, MLH_SCLK() - c_book);
     }
     MLH_SSTAGE(2);
     __syncthreads();
@@ -431,6 +448,12 @@ int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *count
 extern "C" int mlh_debug_stage_clock_sort(unsigned long long *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_sort), sizeof(unsigned long long) * size_t(n_words));
+}
+extern "C" int mlh_debug_stage_clock_sort2(unsigned long long *out, int n_words, int clear)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_sort2), sizeof(unsigned long long) * size_t(n_words));
+    if (clear) { static unsigned long long z[1024 * 8]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(mlh::g_stage_clk_sort2), z, sizeof(z)); }
+    return rc;
 }
 namespace mlh {
 #endif

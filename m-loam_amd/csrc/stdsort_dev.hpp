@@ -88,6 +88,61 @@ __device__ void ss_heap_sort_range(int *k, int *v, int len, Less less)
     }
 }
 
+// The same heap sort for a range of at most 64 elements, by a whole wavefront (all lanes converged): element i lives in lane i's registers, the sequential
+// algorithm's one moving index is uniform, so every k[i] / v[i] above becomes a v_readlane with a scalar lane select or a one-lane select -- no LDS round trip per
+// sift level. Depth-exhausted ranges are what lands here: median-of-three on the piecewise-monotone key sequences of a scan ring runs out of its 2 log2(n)
+// budget on one ring in five, the leftovers are 17-50 elements long, and heap-sorting one of them through LDS from a single lane took longer than the rest of
+// the ring's sort (the per-ring leaf launch: slowest ring 81 us against a median of 35).
+template <typename Less>
+__device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Less less)
+{
+    const int lane = threadIdx.x & 63;
+    int key_r = lane < len ? k[lane] : 0, val_r = lane < len ? v[lane] : 0;
+    auto rd = [&](int reg, int i) { return __builtin_amdgcn_readlane(reg, i); };
+    auto adjust = [&](int hole, int n, int key, int val) {
+        const int top = hole;
+        int c = hole;
+        while (c < (n - 1) / 2) {
+            c = 2 * (c + 1);
+            if (less(rd(key_r, c), rd(key_r, c - 1))) c--;
+            const int kc = rd(key_r, c), vc = rd(val_r, c);
+            key_r = (lane == hole) ? kc : key_r; val_r = (lane == hole) ? vc : val_r;
+            hole = c;
+        }
+        if ((n & 1) == 0 && c == (n - 2) / 2) {
+            c = 2 * (c + 1);
+            const int kc = rd(key_r, c - 1), vc = rd(val_r, c - 1);
+            key_r = (lane == hole) ? kc : key_r; val_r = (lane == hole) ? vc : val_r;
+            hole = c - 1;
+        }
+        int parent = (hole - 1) / 2;
+        while (hole > top && less(rd(key_r, parent), key)) {
+            const int kp = rd(key_r, parent), vp = rd(val_r, parent);
+            key_r = (lane == hole) ? kp : key_r; val_r = (lane == hole) ? vp : val_r;
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        key_r = (lane == hole) ? key : key_r; val_r = (lane == hole) ? val : val_r;
+    };
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            adjust(parent, len, rd(key_r, parent), rd(val_r, parent));
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int last = len;
+    while (last > 1) {
+        --last;
+        const int key = rd(key_r, last), val = rd(val_r, last);
+        const int k0 = rd(key_r, 0), v0 = rd(val_r, 0);
+        key_r = (lane == last) ? k0 : key_r; val_r = (lane == last) ? v0 : val_r;
+        adjust(0, last, key, val);
+    }
+    if (lane < len) { k[lane] = key_r; v[lane] = val_r; }
+}
+
 // One wavefront streams [lo, hi) of the range [f, l) in 64-wide tiles, SS_U tiles per trip with the loads issued first, ONCE: the positions of its left stops go to
 // lt[lo], lt[lo + 1], ... and of its right stops to rt[lo], rt[lo + 1], ..., both in ASCENDING position (a chunk has at most hi - lo stops of either kind, so the
 // chunks' sub-tables cannot overlap); n_left / n_right = how many. The k-th right stop counted from the RIGHT end -- the one the partition loop pairs with the
@@ -266,7 +321,9 @@ __device__ __forceinline__ void ss_wave_std_sort(int *keys, int *vals, int *lt, 
             continue;
         }
         if (d == 0) {                                                  // __partial_sort(first, last, last): sorted for good
-            if (lane == 0) { ss_heap_sort_range(keys + f, vals + f, l - f, less); atomicOr(&bits[f >> 5], 1u << (f & 31)); }
+            if (l - f <= 64) ss_heap_sort_wave64(keys + f, vals + f, l - f, less);
+            else if (lane == 0) ss_heap_sort_range(keys + f, vals + f, l - f, less);
+            if (lane == 0) atomicOr(&bits[f >> 5], 1u << (f & 31));
             ss_wg_fence();
             have = false;
             continue;

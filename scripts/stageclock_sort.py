@@ -14,10 +14,21 @@ pts = np.concatenate([s.points for s in scans])
 st = np.concatenate([s.scan_start + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
 en = np.concatenate([s.scan_end + offs[i] for i, s in enumerate(scans)]).astype(np.int32)
 ctx.scan_upload(pts, st, en); ctx.extract_run()
-for _ in range(3):
+lib = mla.load_library()
+lib.mlh_debug_stage_clock_sort2.argtypes = [C.c_void_p, C.c_int, C.c_int]
+for _ in range(2):
     ctx.extract_voxel_run(0.2)
 ctx.synchronize()
-lib = mla.load_library()
+buf2 = (C.c_ulonglong * (1024 * 8))()
+lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 8, 1)          # clear the accumulators
+ctx.extract_voxel_run(0.2)
+ctx.synchronize()
+lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 8, 0)
+acc = np.frombuffer(buf2, np.uint64).reshape(1024, 8).astype(np.float64)[:128]
+for cls, nm in enumerate(["<= 64", "<= 256", "longer"]):
+    n = acc[:, cls].sum(); tk = acc[:, 3 + cls].sum()
+    print(f"partitions of {nm:7s}: {n / 128:6.1f} per ring, {0.01 * tk / max(n, 1):5.2f} us each")
+print(f"bookkeeping after a partition: {0.01 * acc[:, 6].sum() / acc[:, :3].sum():5.2f} us each; acquiring / waiting: {0.01 * acc[:, 7].sum() / 128:6.1f} us per ring summed over its 16 wavefronts")
 buf = (C.c_ulonglong * (1024 * 8))()
 lib.mlh_debug_stage_clock_sort.argtypes = [C.c_void_p, C.c_int]
 assert lib.mlh_debug_stage_clock_sort(buf, 1024 * 8) == 0
@@ -29,3 +40,8 @@ rel = (t[busy, :7] - t0) * 0.01
 names = ["kernel start", "loaded + queue ready", "recursion done (this wave)", "... all waves", "insertion pass done (thread 0)", "... all threads", "stored"]
 for i, nm in enumerate(names):
     print(f"{nm:34s} min {rel[:, i].min():7.2f} med {np.median(rel[:, i]):7.2f} max {rel[:, i].max():7.2f} us")
+order = np.argsort(-rel[:, 2])
+print("slowest rings (recursion done, us):", [(int(i), round(float(rel[i, 2]), 1)) for i in order[:12]])
+print("fastest rings:", [(int(i), round(float(rel[i, 2]), 1)) for i in order[-6:]])
+per_ring_parts = acc[:, :3].sum(axis=1)
+print("partitions per ring for the slowest:", [(int(i), int(per_ring_parts[i]), round(0.01 * float(acc[i, 7]), 1)) for i in order[:12]])
