@@ -288,6 +288,7 @@ struct mlh_ctx {
     size_t vox_order_host_cap = 0;
     void *select_host = nullptr; // pinned staging of the good-feature selection (select.hip)
     size_t select_host_cap = 0;
+    std::vector<char> select_rows;   // the same rows in ordinary (CPU-cached) memory: what the selection loops read
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };

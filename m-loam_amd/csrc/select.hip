@@ -4,6 +4,8 @@
 // next score is computed against), which is why the reference gives them a 20 ms wall-clock budget (lidar_mapper.h:82).
 #include "ctx.hpp"
 #include "alive_pool.hpp"
+#include <chrono>
+#include <cstring>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -245,6 +247,8 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out)
 {
     FeatSet &f = ctx->feat[kind];
+    static const bool timing = std::getenv("MLH_SEL_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
     MatchArgs a;
     a.kind_mask = 1 << kind;
     a.flags = MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS;   // extractCov(point) weight, rows not loss-corrected (lidar_mapper.h:162-164)
@@ -270,8 +274,17 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
+    // The selection loops jump around in these rows (a pool look-up decides which one comes next). Pinned host memory is mapped so that the CPU does not
+    // cache it: read in place, every access is a trip to DRAM -- the `rnd` loop, which scores nothing, took 0.6 / 1.0 ms per call that way, 0.12 / 0.28 ms on an
+    // ordinary copy; a bulk copy out of the pinned block runs at ~30 GB/s (+33 us per call). So: DMA into the pinned block, one memcpy into the context's
+    // cacheable block, loops on that (config 5, gd_fix: 7.2 -> 4.05 ms per frame; profiles/r03_gfbench.txt).
+    ctx->select_rows.resize(need);
+    std::memcpy(ctx->select_rows.data(), hb, method == MLH_GF_FPS ? need : off_p);
+    char *cb = ctx->select_rows.data();
+    R.corr = reinterpret_cast<Corr *>(cb); R.J = reinterpret_cast<const double *>(cb + off_j); R.pts = reinterpret_cast<const float4 *>(cb + off_p);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
 
+    const auto tc1 = std::chrono::steady_clock::now();
     const size_t n_use = static_cast<size_t>(m * ratio);   // num_use_features (lidar_mapper.h:247)
     std::vector<size_t> sel;
     sel.reserve(method == MLH_GF_WO ? m : n_use);
@@ -283,14 +296,22 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         case MLH_GF_GD_FLOAT: select_greedy(R, n_use, rng, sel, H); break;
         default: return fail(ctx, MLH_ERR_INVALID, "unknown gf_method");
     }
+    const auto tc2 = std::chrono::steady_clock::now();
     // keep only the selected correspondences valid on the device
     if (method != MLH_GF_WO) {
         for (size_t i = 0; i < m; ++i) R.corr[i].valid = 0;
         for (size_t i : sel) R.corr[i].valid = 1;
-        MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, R.corr, sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
+        std::memcpy(hb, R.corr, sizeof(Corr) * m);                  // back through the pinned block (sequential writes: the mapping is fine for those)
+        MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, hb, sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     sel_out.assign(sel.begin(), sel.end());
+    if (timing) {
+        const auto tc3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        std::fprintf(stderr, "[good_feature_select] kind %d m %zu: match pass + copies to the host %.0f us | selection loop %.0f us (%zu picks) | flags back to the device %.0f us\n", kind, m,
+                     us(tc0, tc1), us(tc1, tc2), sel.size(), us(tc2, tc3));
+    }
     return MLH_OK;
 }
 
