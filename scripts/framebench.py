@@ -112,6 +112,25 @@ print("GPU path, device-resident, one launch set, both kinds thinned in one pipe
       "same pose:", bool(np.array_equal(pose_dev2, pose_dev1)))
 print("GPU path, device-resident, both LiDARs one launch set, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td1.items()}, "total %.3f" % (1e3 * sum(td1.values()) / 20),
       "same pose as per-LiDAR launches:", bool(np.array_equal(pose_dev1, pose_dev)))
+# the same frame driven from C++ through the C-ABI (m-loam_amd/host/framebench.cpp): no interpreter between the dozen calls of a frame
+import subprocess, tempfile
+exe = os.path.join(ROOT, "m-loam_amd", "host", "framebench")
+if os.path.exists(exe):
+    with tempfile.TemporaryDirectory() as d:
+        both_pts.astype(np.float32).tofile(os.path.join(d, "fb_points.f32"))
+        np.concatenate([both_start, both_end]).astype(np.int32).tofile(os.path.join(d, "fb_rings.i32"))
+        np.asarray(ring_ofs, np.int32).tofile(os.path.join(d, "fb_ring_ofs.i32"))
+        np.ascontiguousarray(ext, np.float64).tofile(os.path.join(d, "fb_ext.f64"))
+        np.ascontiguousarray(covs, np.float64).tofile(os.path.join(d, "fb_covs.f64"))
+        np.ascontiguousarray(meas, np.float64).tofile(os.path.join(d, "fb_meas.f64"))
+        sm = np.ascontiguousarray(surf_map, np.float32); cmap = np.ascontiguousarray(corner_map, np.float32)
+        assert sm.shape[1] == cmap.shape[1]
+        sm.tofile(os.path.join(d, "fb_surf_map.f32")); cmap.tofile(os.path.join(d, "fb_corner_map.f32"))
+        np.array([sm.shape[1] * 4, 1], np.int32).tofile(os.path.join(d, "fb_meta.i32"))
+        np.ascontiguousarray(p0, np.float64).tofile(os.path.join(d, "fb_pose.f64"))
+        r = subprocess.run([exe, d, "50"], capture_output=True, text=True, timeout=120)
+        line = (r.stdout.strip().splitlines() or [r.stderr.strip()])[-1]
+        print(line.split("  pose ")[0], " same pose as through ctypes (printed to 1e-9):", bool(np.allclose([float(x) for x in line.split("  pose ")[1].split()], pose_dev2, rtol=0, atol=2e-9)) if "  pose " in line else r.stderr[-300:])
 if os.environ.get('FRAMEBENCH_DEV_ONLY'): sys.exit(0)
 for _ in range(3): gpu_frame({})
 tg = {}; n = 20
