@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--shard-mode", default="map", choices=["map", "features"],
                     help="N > 1: 'map' = angular wedges of the map + halo, ownership by position (BASELINE's partition); 'features' = whole map on every "
                          "rank, features dealt round-robin (SURVEY 8e's balanced alternative)")
+    ap.add_argument("--comm", default="p2p", choices=["p2p", "rccl"],
+                    help="N > 1: the collective behind the sharded solver -- 'p2p' = the mailbox communicator (hipIpc-mapped mailboxes, one kernel per all-reduce; "
+                         "falls back to RCCL if it cannot be set up or its first all-reduce does not add up), 'rccl' = ncclAllReduce")
     ap.add_argument("--no-overlap-staging", action="store_true",
                     help="pipelined submission, but the next frame's maps are staged on the solver's own stream (queued behind the solve) instead of on a second stream")
     ap.add_argument("--synchronous", action="store_true",
@@ -219,15 +222,41 @@ def main():
         if len(local_corner_map) == 0:
             local_corner_map = far
         lo, hi = shard.wedge_planes(center, world, rank)
+        comm_kind = "rccl"
+        if args.comm == "p2p":
+            # the mailbox communicator: handles all-gathered through the process group, every rank maps every mailbox, one all-reduce of ones as the check
+            ok_p2p = 1
+            try:
+                handles = [None] * world
+                dist.all_gather_object(handles, ctx.p2p_mailbox())
+                ctx.p2p_comm_init(world, rank, handles)
+            except Exception as e:   # noqa: BLE001 -- reported below, never silent
+                ok_p2p = 0
+                log(f"[rank {rank}] mailbox communicator not available: {e!r}")
+            flag = torch.tensor([ok_p2p], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    ok_p2p = int(float(ctx.allreduce_f64(np.ones(32))[0]) == float(world))
+                except Exception as e:   # noqa: BLE001
+                    ok_p2p = 0
+                    log(f"[rank {rank}] mailbox all-reduce failed: {e!r}")
+                flag = torch.tensor([ok_p2p], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm_kind = "p2p"
+            else:
+                ctx.comm_finalize()
+                log(f"[rank {rank}] falling back to RCCL")
         comm_ok, comm_err = 1, ""
         uid = [None]
-        if rank == 0:
+        if rank == 0 and comm_kind == "rccl":
             try:
                 uid[0] = mla.comm_unique_id()
             except Exception as e:   # noqa: BLE001 -- reported, never silent
                 comm_err = repr(e)
         dist.broadcast_object_list(uid, src=0)      # always executed, so no rank is left waiting
-        if uid[0] is None:
+        if uid[0] is None and comm_kind == "rccl":
             comm_ok = 0
         else:
             try:
@@ -235,7 +264,8 @@ def main():
                     ctx.shard_set(lo, hi)
                 else:
                     ctx.shard_set_features(world, rank)
-                ctx.comm_init(world, rank, uid[0])
+                if comm_kind == "rccl":
+                    ctx.comm_init(world, rank, uid[0])
             except Exception as e:   # noqa: BLE001
                 comm_ok, comm_err = 0, repr(e)
         flag = torch.tensor([comm_ok], dtype=torch.int32, device="cuda")
@@ -533,10 +563,11 @@ def main():
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    multi_gpu=(None if world == 1 else dict(
-                       shard_mode=args.shard_mode, owned_features_per_rank=owned_all, local_map_points_per_rank=local_map_all,
+                       shard_mode=args.shard_mode, comm=("mailbox communicator (mlh_p2p_*: one kernel per all-reduce)" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
+                       owned_features_per_rank=owned_all, local_map_points_per_rank=local_map_all,
                        allreduce_us_per_call_rank0=(round(1e3 * prof[mla.K_ALLREDUCE][0] / prof[mla.K_ALLREDUCE][1], 3) if prof[mla.K_ALLREDUCE][1] else None),
                        solve_update_us_per_call_rank0=(round(1e3 * prof[mla.K_SOLVE][0] / prof[mla.K_SOLVE][1], 3) if prof[mla.K_SOLVE][1] else None),
-                       note="per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE ncclAllReduce of 32 f64 + the redundant 6x6 solve launch")),
+                       note="per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE all-reduce of 32 f64 + the redundant 6x6 solve launch")),
                    extract_ms_per_lidar_scan=[round(x, 4) for x in extract_ms],
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    extract_ms_all_lidars_one_launch_set=round(extract_all_ms, 4),

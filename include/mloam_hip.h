@@ -530,9 +530,18 @@ int mlh_shard_set(mlh_ctx *ctx, const float *lo_plane4, const float *hi_plane4);
 int mlh_shard_set_features(mlh_ctx *ctx, int n_ranks, int rank);
 int mlh_comm_unique_id(void *out_128_bytes);
 int mlh_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *unique_id_128_bytes);
-/* in-place sum of n doubles (HOST buffer, any n) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */
-/* drops the communicator: the context is single-GPU again */
+/* The same join WITHOUT a collective library -- the mailbox communicator: the path's one collective is a few hundred bytes per evaluation, i.e. pure latency,
+ * and a library all-reduce (protocol selection, proxy threads, a ring over the ranks) costs tens of microseconds there. mlh_p2p_mailbox allocates this rank's
+ * mailbox in device memory and returns its 64-byte hipIpc handle; the caller exchanges the handles out of band (one all-gather of 64 bytes: MPI, torch.distributed,
+ * a file ...) and hands all n_ranks of them, in rank order, to mlh_p2p_comm_init, which maps the peers' mailboxes (peer access over xGMI between GPUs; ranks may
+ * also share a GPU). Every all-reduce of the solvers (and mlh_allreduce_f64, up to 512 doubles) is then ONE single-workgroup kernel per rank on the context's stream:
+ * store my record into my slot of every mailbox, publish a sequence number, wait for the n sequence numbers in my own mailbox, add the n slots in rank order --
+ * every rank ends with the same bits. A peer that never shows up raises an error on the next call instead of hanging the GPU (5 s bound). <= 16 ranks. */
+int mlh_p2p_mailbox(mlh_ctx *ctx, void *ipc_handle_64_bytes);
+int mlh_p2p_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *ipc_handles /* n_ranks x 64 bytes, rank order */);
+/* drops the communicator (either kind): the context is single-GPU again */
 int mlh_comm_finalize(mlh_ctx *ctx);
+/* in-place sum of n doubles (HOST buffer, any n) over the ranks -- the standalone "mlh_allreduce_normal_eq" of SURVEY 8b */
 int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n);
 
 /* host-side helpers mirroring the reference's small functions (no GPU work) */

@@ -153,6 +153,8 @@ def load_library():
     lib.mlh_shard_set_features.argtypes = [vp, ci, ci]
     lib.mlh_comm_unique_id.argtypes = [vp]
     lib.mlh_comm_init.argtypes = [vp, ci, ci, vp]
+    lib.mlh_p2p_mailbox.argtypes = [vp, vp]
+    lib.mlh_p2p_comm_init.argtypes = [vp, ci, ci, vp]
     lib.mlh_allreduce_f64.argtypes = [vp, vp, ci]
     lib.mlh_pose_plus.argtypes = [vp, vp, vp, vp]
     lib.mlh_eval_degeneracy.argtypes = [vp, cd, vp, vp]
@@ -168,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_scan2map",
-    "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_allreduce_f64",
+    "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
 
@@ -647,6 +649,19 @@ class Context:
         _torch_rccl_first()
         buf = C.create_string_buffer(unique_id, 128)
         self._ck(self.lib.mlh_comm_init(self.h, n_ranks, rank, C.cast(buf, C.c_void_p)))
+
+    def p2p_mailbox(self) -> bytes:
+        """this rank's mailbox of the mailbox communicator: its 64-byte hipIpc handle, to be all-gathered by the caller (mlh_p2p_mailbox)"""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.mlh_p2p_mailbox(self.h, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def p2p_comm_init(self, n_ranks, rank, handles):
+        """handles: the n_ranks 64-byte handles in rank order (mlh_p2p_comm_init)"""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * n_ranks
+        buf = C.create_string_buffer(blob, len(blob))
+        self._ck(self.lib.mlh_p2p_comm_init(self.h, n_ranks, rank, C.cast(buf, C.c_void_p)))
 
     def allreduce_f64(self, arr):
         a = np.ascontiguousarray(arr, np.float64).copy()

@@ -1083,7 +1083,7 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
         if (it == 0) a.init_pose = pose_inout;
-        if (!ctx->comm) {
+        if (!distributed(ctx)) {
             // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose
             a.finish = 1;
             a.stat_slot = stats ? it : -1;
@@ -1123,7 +1123,7 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 // host has seen the pose and enqueued ten launches); each publishes into its own pinned record, apart from the one the staging hand-shake uses.
 static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, int n_iters, const mlh_solver_opts *opts)
 {
-    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
+    if (distributed(ctx)) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
     if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one with mlh_gn_solve_end first");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, 0);
@@ -1204,7 +1204,7 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
         MatchArgs a = args_from_opts(opts, mask, 0);
         a.n_blocks = nb;
         for (int b = 0; b < nb; ++b) { a.k_neigh[b] = bo->k_neigh[b]; a.eig_thre[b] = bo->eig_thre[b]; a.freeze[b] = bo->freeze[b]; }
-        if (!ctx->comm) {
+        if (!distributed(ctx)) {
             a.finish = 1;
             a.stat_slot = stats ? it * nb : -1;
             if ((rc = match_launch(ctx, a))) return rc;
@@ -1242,7 +1242,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
     // one GPU, every feature used (wo_gf): the LM begin rides in the match launch and every LM step in its linearise launch -- an outer
     // iteration is 2 + (LM iterations) launches, the pose goes in with the first launch's kernel arguments
-    const bool fused = !ctx->comm && opts->gf_method == MLH_GF_WO;
+    const bool fused = !distributed(ctx) && opts->gf_method == MLH_GF_WO;
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
     // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)

@@ -54,33 +54,110 @@ static int rccl_fail(mlh_ctx *ctx, const char *what, int code)
     return fail(ctx, MLH_ERR_HIP, m.c_str());
 }
 
+// ---------------------------------------------------------------- the mailbox communicator
+// This path's only collective is an all-reduce of a few hundred bytes per evaluation: pure latency. A library collective pays for generality there (protocol
+// selection, proxy threads, a ring or tree over the ranks); what the message needs is ONE hop. Every rank owns a mailbox in its device memory, exported through
+// hipIpc and mapped by every other rank (peer access over xGMI between GPUs; the same memory through a second mapping when ranks share a GPU). An all-reduce is one
+// single-workgroup kernel per rank, on the context's stream:
+//   1. store my record into slot [parity][my rank] of EVERY mailbox (system-scope stores: they leave the L2 for the owner's memory),
+//   2. fence, then store the all-reduce's sequence number into flag [parity][my rank] of every mailbox,
+//   3. wait until the n flags of MY mailbox carry that sequence number (bounded: a missing peer raises the context's device error word instead of hanging),
+//   4. sum the n slots of my mailbox in RANK ORDER -- every rank adds the same numbers in the same order, so all ranks hold the same bits and apply the same update.
+// Two halves (parity of the sequence number) suffice: a rank can only get one all-reduce ahead of a peer, because finishing all-reduce s + 1 needs that peer's
+// contribution to s + 1, which the peer writes after it has read everything of s.
+constexpr int P2P_MAX_RANKS = 16, P2P_MAX_DOUBLES = 512;
+struct P2pMailbox {
+    double slot[2][P2P_MAX_RANKS][P2P_MAX_DOUBLES];
+    unsigned long long flag[2][P2P_MAX_RANKS];
+};
+struct P2pArgs {
+    P2pMailbox *peer[P2P_MAX_RANKS];
+    double *buf;
+    int n, n_ranks, rank;
+    unsigned long long seq;
+    int *err;
+};
+
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2pArgs a)
+{
+    const int t = threadIdx.x, par = int(a.seq & 1ull);
+    for (int r = 0; r < a.n_ranks; ++r)
+        for (int i = t; i < a.n; i += 256) __hip_atomic_store(&a.peer[r]->slot[par][a.rank][i], a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (t < a.n_ranks) __hip_atomic_store(&a.peer[t]->flag[par][a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    P2pMailbox *mine = a.peer[a.rank];
+    if (t < a.n_ranks) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(&mine->flag[par][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 1023u) == 0 && wall_clock64() - t0 > 500000000ull) {        // 5 s at 100 MHz: the peer is not coming
+                if (a.err) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < a.n; i += 256) {
+        double s = __hip_atomic_load(&mine->slot[par][0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 1; r < a.n_ranks; ++r) s += __hip_atomic_load(&mine->slot[par][r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.buf[i] = s;
+    }
+}
+
+static int p2p_allreduce(mlh_ctx *ctx, double *buf, int n)
+{
+    if (n > P2P_MAX_DOUBLES) return fail(ctx, MLH_ERR_UNSUPPORTED, "the mailbox communicator carries records of up to 512 doubles");
+    P2pArgs a;
+    for (int r = 0; r < P2P_MAX_RANKS; ++r) a.peer[r] = static_cast<P2pMailbox *>(ctx->p2p.peer[r]);
+    a.buf = buf; a.n = n; a.n_ranks = ctx->n_ranks; a.rank = ctx->rank;
+    a.seq = ++ctx->p2p.seq;
+    a.err = device_error_word(ctx);
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+// in-place sum over the ranks of n doubles in device memory, on the context's stream: the mailbox communicator when it is set up, RCCL otherwise
+static int allreduce_device(mlh_ctx *ctx, double *buf, size_t n)
+{
+    prof_begin(ctx, MLH_K_ALLREDUCE);
+    int rc = MLH_OK;
+    if (ctx->p2p.active) rc = p2p_allreduce(ctx, buf, int(n));
+    else {
+        const int nc = rccl().all_reduce(buf, buf, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+        if (nc != 0) rc = rccl_fail(ctx, "ncclAllReduce", nc);
+    }
+    prof_end(ctx, MLH_K_ALLREDUCE);
+    return rc;
+}
+
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce)
 {
-    if (!ctx->comm) return MLH_OK;
+    if (!distributed(ctx)) return MLH_OK;
     SolverState *S = ctx->state.as<SolverState>();
-    double *buf = to_ce ? S->ce : S->ne;
-    prof_begin(ctx, MLH_K_ALLREDUCE);
-    int rc = rccl().all_reduce(buf, buf, NE_STRIDE, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
-    prof_end(ctx, MLH_K_ALLREDUCE);
-    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
-    return MLH_OK;
+    return allreduce_device(ctx, to_ce ? S->ce : S->ne, NE_STRIDE);
 }
 
 int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks)
 {
-    if (!ctx->comm) return MLH_OK;
+    if (!distributed(ctx)) return MLH_OK;
     SolverState *S = ctx->state.as<SolverState>();
-    double *buf = &S->neb[0][0];
-    prof_begin(ctx, MLH_K_ALLREDUCE);
-    int rc = rccl().all_reduce(buf, buf, size_t(NE_STRIDE) * size_t(n_blocks), /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
-    prof_end(ctx, MLH_K_ALLREDUCE);
-    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
-    return MLH_OK;
+    return allreduce_device(ctx, &S->neb[0][0], size_t(NE_STRIDE) * size_t(n_blocks));
 }
 
 void comm_destroy(mlh_ctx *ctx)
 {
     if (ctx->comm) { rccl().comm_destroy(ctx->comm); ctx->comm = nullptr; }
+    if (ctx->p2p.mailbox || ctx->p2p.active) {
+        for (int r = 0; r < P2P_MAX_RANKS; ++r) {
+            if (ctx->p2p.peer[r] && ctx->p2p.peer[r] != ctx->p2p.mailbox) (void)hipIpcCloseMemHandle(ctx->p2p.peer[r]);
+            ctx->p2p.peer[r] = nullptr;
+        }
+        if (ctx->p2p.mailbox) (void)hipFree(ctx->p2p.mailbox);
+        ctx->p2p.mailbox = nullptr; ctx->p2p.active = false; ctx->p2p.seq = 0;
+    }
 }
 
 }  // namespace mlh
@@ -153,18 +230,53 @@ int mlh_comm_finalize(mlh_ctx *ctx)
 int mlh_allreduce_f64(mlh_ctx *ctx, double *host_inout, int n)
 {
     if (!ctx || !host_inout || n <= 0) return MLH_ERR_INVALID;
-    if (!ctx->comm) return MLH_OK;   // single rank: identity
+    if (!distributed(ctx)) return MLH_OK;   // single rank: identity
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     // any length: the 32-double record of the map solver, the 326 doubles of the 24-dimensional window problem (mlh_pure_odom_normal_eq), ...
     MLH_HIP(ctx, ctx->allreduce_buf.ensure(sizeof(double) * size_t(n)));
     double *buf = ctx->allreduce_buf.as<double>();
     MLH_HIP(ctx, hipMemcpyAsync(buf, host_inout, sizeof(double) * size_t(n), hipMemcpyHostToDevice, ctx->stream));
-    prof_begin(ctx, MLH_K_ALLREDUCE);
-    int rc = rccl().all_reduce(buf, buf, size_t(n), /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
-    prof_end(ctx, MLH_K_ALLREDUCE);
-    if (rc != 0) return rccl_fail(ctx, "ncclAllReduce", rc);
+    const int rc = allreduce_device(ctx, buf, size_t(n));
+    if (rc) return rc;
     MLH_HIP(ctx, hipMemcpyAsync(host_inout, buf, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return device_error_check(ctx);
+}
+
+int mlh_p2p_mailbox(mlh_ctx *ctx, void *ipc_handle_64_bytes)
+{
+    if (!ctx || !ipc_handle_64_bytes) return MLH_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI promises a 64-byte handle");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    comm_destroy(ctx);
+    MLH_HIP(ctx, hipMalloc(&ctx->p2p.mailbox, sizeof(P2pMailbox)));
+    MLH_HIP(ctx, hipMemset(ctx->p2p.mailbox, 0, sizeof(P2pMailbox)));
+    hipIpcMemHandle_t h;
+    MLH_HIP(ctx, hipIpcGetMemHandle(&h, ctx->p2p.mailbox));
+    std::memcpy(ipc_handle_64_bytes, &h, sizeof(h));
+    return MLH_OK;
+}
+
+int mlh_p2p_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *ipc_handles)
+{
+    if (!ctx || n_ranks <= 0 || n_ranks > P2P_MAX_RANKS || rank < 0 || rank >= n_ranks || !ipc_handles) return MLH_ERR_INVALID;
+    if (!ctx->p2p.mailbox) return fail(ctx, MLH_ERR_STATE, "mlh_p2p_mailbox first: the handles passed here are what it returned on every rank");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    const char *hs = static_cast<const char *>(ipc_handles);
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == rank) { ctx->p2p.peer[r] = ctx->p2p.mailbox; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, hs + size_t(r) * sizeof(h), sizeof(h));
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { comm_destroy(ctx); return fail(ctx, MLH_ERR_HIP, "hipIpcOpenMemHandle of a peer's mailbox", e); }
+        ctx->p2p.peer[r] = p;
+    }
+    ctx->p2p.active = true;
+    ctx->p2p.seq = 0;
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
     return MLH_OK;
 }
 

@@ -279,6 +279,13 @@ struct mlh_ctx {
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
     int own_mod = 1, own_rem = 0;   // feature-index ownership (replicated map): mlh_shard_set_features
     void *comm = nullptr;    // ncclComm_t
+    // the mailbox communicator (comm.hip): every rank's mailbox mapped into this process; one kernel per all-reduce, no library in between
+    struct P2p {
+        bool active = false;
+        void *mailbox = nullptr;                      // this rank's own (device memory, exported through hipIpc)
+        void *peer[16] = {};                          // rank r's mailbox as this process sees it (peer[rank] == mailbox)
+        unsigned long long seq = 0;                   // all-reduces issued so far: its parity picks the half of the mailboxes in use
+    } p2p;
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
     int extract_tie_ref = 1;           // extractCloud, equal curvatures inside a sector: 1 = the order the reference's std::sort call leaves (default), 0 = (curvature, index)
     int vox_member_order = 1;          // voxel filters, members of a voxel: 1 = in the order libstdc++'s std::sort leaves them (the reference's), produced on the device
@@ -438,6 +445,7 @@ int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);
 int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double *eig_thre, const int *freeze, int stat_slot);
 // comm.hip
+inline bool distributed(const mlh_ctx *ctx) { return ctx->comm != nullptr || ctx->p2p.active; }
 int comm_allreduce_state(mlh_ctx *ctx, int to_ce);
 int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks);
 void comm_destroy(mlh_ctx *ctx);   // in-place ncclAllReduce of SolverState::ne / ::ce on the stream

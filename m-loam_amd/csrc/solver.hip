@@ -107,7 +107,7 @@ int reduce_only_launch(mlh_ctx *ctx, int to_ce)
 static int pre_reduce(mlh_ctx *ctx, int to_ce, int &pre_reduced)
 {
     pre_reduced = 0;
-    if (!ctx->comm) return MLH_OK;
+    if (!distributed(ctx)) return MLH_OK;
     int rc = reduce_only_launch(ctx, to_ce);
     if (rc) return rc;
     if ((rc = comm_allreduce_state(ctx, to_ce))) return rc;

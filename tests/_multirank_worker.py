@@ -19,10 +19,13 @@ def main():
     import torch
     import torch.distributed as dist
     mode = sys.argv[1] if len(sys.argv) > 1 else "map"
+    comm = sys.argv[2] if len(sys.argv) > 2 else "rccl"          # "rccl": one GPU per rank; "p2p": the mailbox communicator, ranks may share a GPU
     rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if comm == "p2p":
+        local_rank = local_rank % torch.cuda.device_count()      # more ranks than GPUs: they share (RCCL refuses that; the mailboxes do not care)
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if comm == "rccl" else "gloo", rank=rank, world_size=world)
     mla = importlib.import_module("m-loam_amd")
     synth = importlib.import_module("m-loam_amd.synth")
     shard = importlib.import_module("m-loam_amd.shard")
@@ -32,8 +35,9 @@ def main():
     feats = conftest.features_from_extraction(synth, case["scans"], lambda s: ctx.extract(s.points, s.scan_start, s.scan_end))
     p0 = case["p0"]
     centre = p0[:2]
-    uid = [mla.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
+    if comm == "rccl":
+        uid = [mla.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
     if mode == "map":
         ctx.shard_set(*shard.wedge_planes(centre, world, rank))
         far = np.full((1, 3), 1.0e6, np.float32)
@@ -43,12 +47,24 @@ def main():
     else:
         ctx.shard_set_features(world, rank)
         ctx.map_set_pair(case["surf_map"], case["corner_map"])
-    ctx.comm_init(world, rank, uid[0])
+    if comm == "rccl":
+        ctx.comm_init(world, rank, uid[0])
+    else:
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.p2p_mailbox())       # the out-of-band exchange: 64 bytes per rank
+        ctx.p2p_comm_init(world, rank, handles)
+        dist.barrier()                                           # every rank has mapped every mailbox before the first record is sent
     ones = ctx.allreduce_f64(np.ones(32))                       # the communicator really spans `world` ranks
     ctx.features_set(mla.SURF, feats[0])
     ctx.features_set(mla.CORNER, feats[1])
     pose, stats = ctx.gn_solve(p0, 5)
     pose_s2m, _ = ctx.scan2map(p0)
+    # the collective's own time (HIP events around it on the context's stream; waiting for the slowest peer is inside)
+    ctx.profile_enable(1 << mla.K_ALLREDUCE); ctx.profile_reset()
+    for _ in range(20):
+        ctx.gn_solve(p0, 5, want_stats=False)
+    ar_ms, ar_n = ctx.profile_get(mla.K_ALLREDUCE)
+    ctx.profile_enable(0)
     out = None
     if rank == 0:
         one = mla.Context(local_rank)                           # the same frame, unsharded, no communicator
@@ -57,8 +73,8 @@ def main():
         ref, ref_stats = one.gn_solve(p0, 5)
         ref_s2m, _ = one.scan2map(p0)
         one.close()
-        out = dict(world=world, mode=mode, allreduce_of_ones=float(ones[0]), pose_diff=float(np.abs(pose - ref).max()),
-                   scan2map_pose_diff=float(np.abs(pose_s2m - ref_s2m).max()),
+        out = dict(world=world, mode=mode, comm=comm, allreduce_of_ones=float(ones[0]), pose_diff=float(np.abs(pose - ref).max()),
+                   scan2map_pose_diff=float(np.abs(pose_s2m - ref_s2m).max()), allreduce_us=round(1e3 * ar_ms / max(ar_n, 1), 2), allreduce_calls=int(ar_n),
                    counts=[(int(s["n_surf"]), int(s["n_corner"])) for s in stats],
                    counts_unsharded=[(int(s["n_surf"]), int(s["n_corner"])) for s in ref_stats])
     ctx.close()
