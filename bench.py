@@ -153,10 +153,18 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # More ranks than GPUs (a one-GPU box, for checking the N > 1 path): the ranks share devices -- the mailbox communicator allows that, RCCL and the "nccl"
+    # process group do not, so the bookkeeping collectives below go through gloo on host tensors then. On a node with a GPU per rank nothing changes.
+    shared_gpus = world > torch.cuda.device_count()
+    if shared_gpus:
+        local_rank = local_rank % torch.cuda.device_count()
+        if args.comm != "p2p":
+            raise SystemExit("bench.py: fewer GPUs than ranks needs --comm p2p (RCCL wants a GPU per rank)")
     torch.cuda.set_device(local_rank)
+    dist_dev = "cpu" if shared_gpus else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if shared_gpus else "nccl", rank=rank, world_size=world)
 
     mla = importlib.import_module("m-loam_amd")
     synth = importlib.import_module("m-loam_amd.synth")
@@ -233,7 +241,7 @@ def main():
             except Exception as e:   # noqa: BLE001 -- reported below, never silent
                 ok_p2p = 0
                 log(f"[rank {rank}] mailbox communicator not available: {e!r}")
-            flag = torch.tensor([ok_p2p], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok_p2p], dtype=torch.int32, device=dist_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 try:
@@ -241,7 +249,7 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     ok_p2p = 0
                     log(f"[rank {rank}] mailbox all-reduce failed: {e!r}")
-                flag = torch.tensor([ok_p2p], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([ok_p2p], dtype=torch.int32, device=dist_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 comm_kind = "p2p"
@@ -268,7 +276,7 @@ def main():
                     ctx.comm_init(world, rank, uid[0])
             except Exception as e:   # noqa: BLE001
                 comm_ok, comm_err = 0, repr(e)
-        flag = torch.tensor([comm_ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([comm_ok], dtype=torch.int32, device=dist_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             # no silent degradation to independent replicas: a sharded run without its collective is not a scaling measurement
@@ -387,7 +395,7 @@ def main():
     ctx.profile_enable(0)
     ctx.profile_sample(1)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -522,11 +530,11 @@ def main():
 
     owned_all = local_map_all = None
     if world > 1:
-        t_own = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+        t_own = torch.zeros((world, 2), dtype=torch.int64, device=dist_dev)
         t_own[rank, 0], t_own[rank, 1] = n_owned["surf"], n_owned["corner"]
         dist.all_reduce(t_own)
         owned_all = t_own.tolist()
-        t_map = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+        t_map = torch.zeros((world, 2), dtype=torch.int64, device=dist_dev)
         t_map[rank, 0], t_map[rank, 1] = len(local_surf_map), len(local_corner_map)
         dist.all_reduce(t_map)
         local_map_all = t_map.tolist()
