@@ -250,10 +250,20 @@ int mlh_p2p_mailbox(mlh_ctx *ctx, void *ipc_handle_64_bytes)
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     comm_destroy(ctx);
-    MLH_HIP(ctx, hipMalloc(&ctx->p2p.mailbox, sizeof(P2pMailbox)));
-    MLH_HIP(ctx, hipMemset(ctx->p2p.mailbox, 0, sizeof(P2pMailbox)));
+    // Fine-grained device memory when it can be had and exported: another GPU's stores into it are then visible to this GPU's system-scope loads without
+    // relying on what an XCD's L2 does with remotely written lines of ordinary (coarse-grained) memory. Ordinary memory otherwise (ranks sharing a device).
     hipIpcMemHandle_t h;
-    MLH_HIP(ctx, hipIpcGetMemHandle(&h, ctx->p2p.mailbox));
+    bool have = false;
+    if (!std::getenv("MLH_P2P_COARSE") && hipExtMallocWithFlags(&ctx->p2p.mailbox, sizeof(P2pMailbox), hipDeviceMallocFinegrained) == hipSuccess) {
+        if (hipMemset(ctx->p2p.mailbox, 0, sizeof(P2pMailbox)) == hipSuccess && hipIpcGetMemHandle(&h, ctx->p2p.mailbox) == hipSuccess) have = true;
+        else { (void)hipFree(ctx->p2p.mailbox); ctx->p2p.mailbox = nullptr; }
+    }
+    (void)hipGetLastError();
+    if (!have) {
+        MLH_HIP(ctx, hipMalloc(&ctx->p2p.mailbox, sizeof(P2pMailbox)));
+        MLH_HIP(ctx, hipMemset(ctx->p2p.mailbox, 0, sizeof(P2pMailbox)));
+        MLH_HIP(ctx, hipIpcGetMemHandle(&h, ctx->p2p.mailbox));
+    }
     std::memcpy(ipc_handle_64_bytes, &h, sizeof(h));
     return MLH_OK;
 }
