@@ -571,11 +571,11 @@ def main():
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    multi_gpu=(None if world == 1 else dict(
-                       shard_mode=args.shard_mode, comm=("mailbox communicator (mlh_p2p_*: one kernel per all-reduce)" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
+                       shard_mode=args.shard_mode, comm=("mailbox communicator (mlh_p2p_*): the summed record is exchanged inside the fit kernel's finishing workgroup, one hop, no extra launch" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
                        owned_features_per_rank=owned_all, local_map_points_per_rank=local_map_all,
                        allreduce_us_per_call_rank0=(round(1e3 * prof[mla.K_ALLREDUCE][0] / prof[mla.K_ALLREDUCE][1], 3) if prof[mla.K_ALLREDUCE][1] else None),
                        solve_update_us_per_call_rank0=(round(1e3 * prof[mla.K_SOLVE][0] / prof[mla.K_SOLVE][1], 3) if prof[mla.K_SOLVE][1] else None),
-                       note="per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE all-reduce of 32 f64 + the redundant 6x6 solve launch")),
+                       note=("per GN iteration and rank: correspondence kernel + fit kernel whose finishing workgroup exchanges the 32-double record with the peers and solves (2 launches, as unsharded)" if comm_kind == "p2p" else "per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE ncclAllReduce of 32 f64 + the redundant 6x6 solve launch"))),
                    extract_ms_per_lidar_scan=[round(x, 4) for x in extract_ms],
                    extract_points_per_s=round(n_scan_points / (1e-3 * sum(extract_ms)), 1),
                    extract_ms_all_lidars_one_launch_set=round(extract_all_ms, 4),

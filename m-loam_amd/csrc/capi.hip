@@ -1083,8 +1083,9 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
         if (it == 0) a.init_pose = pose_inout;
-        if (!distributed(ctx)) {
-            // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose
+        if (!distributed(ctx) || ctx->p2p.active) {
+            // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose. Several ranks joined by the
+            // mailbox communicator: the same two launches -- that workgroup exchanges the summed record with the peers (one hop) before it solves
             a.finish = 1;
             a.stat_slot = stats ? it : -1;
             if (it == n_iters - 1 && !stats) {
@@ -1204,7 +1205,7 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
         MatchArgs a = args_from_opts(opts, mask, 0);
         a.n_blocks = nb;
         for (int b = 0; b < nb; ++b) { a.k_neigh[b] = bo->k_neigh[b]; a.eig_thre[b] = bo->eig_thre[b]; a.freeze[b] = bo->freeze[b]; }
-        if (!distributed(ctx)) {
+        if (!distributed(ctx) || ctx->p2p.active) {      // (mailbox communicator: the blocks' records are exchanged inside the finish, one after the other)
             a.finish = 1;
             a.stat_slot = stats ? it * nb : -1;
             if ((rc = match_launch(ctx, a))) return rc;

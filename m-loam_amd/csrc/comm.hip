@@ -3,6 +3,7 @@
 // single-GPU library has no hard dependency on it. xGMI is point-to-point and this message is 256 B: the collective is
 // pure latency, so it is issued exactly once per evaluation, in place on the device-resident solver state.
 #include "ctx.hpp"
+#include "p2p_dev.hpp"
 #include <dlfcn.h>
 
 namespace mlh {
@@ -65,55 +66,27 @@ static int rccl_fail(mlh_ctx *ctx, const char *what, int code)
 //   4. sum the n slots of my mailbox in RANK ORDER -- every rank adds the same numbers in the same order, so all ranks hold the same bits and apply the same update.
 // Two halves (parity of the sequence number) suffice: a rank can only get one all-reduce ahead of a peer, because finishing all-reduce s + 1 needs that peer's
 // contribution to s + 1, which the peer writes after it has read everything of s.
-constexpr int P2P_MAX_RANKS = 16, P2P_MAX_DOUBLES = 512;
-struct P2pMailbox {
-    double slot[2][P2P_MAX_RANKS][P2P_MAX_DOUBLES];
-    unsigned long long flag[2][P2P_MAX_RANKS];
-};
 struct P2pArgs {
-    P2pMailbox *peer[P2P_MAX_RANKS];
+    P2pDev d;
     double *buf;
-    int n, n_ranks, rank;
-    unsigned long long seq;
-    int *err;
+    int n;
 };
 
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2pArgs a)
 {
-    const int t = threadIdx.x, par = int(a.seq & 1ull);
-    for (int r = 0; r < a.n_ranks; ++r)
-        for (int i = t; i < a.n; i += 256) __hip_atomic_store(&a.peer[r]->slot[par][a.rank][i], a.buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
+    __shared__ double rec[P2P_MAX_DOUBLES];
+    for (int i = threadIdx.x; i < a.n; i += 256) rec[i] = a.buf[i];
     __syncthreads();
-    if (t < a.n_ranks) __hip_atomic_store(&a.peer[t]->flag[par][a.rank], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    P2pMailbox *mine = a.peer[a.rank];
-    if (t < a.n_ranks) {
-        const unsigned long long t0 = wall_clock64();
-        unsigned spins = 0;
-        while (__hip_atomic_load(&mine->flag[par][t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
-            __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 1023u) == 0 && wall_clock64() - t0 > 500000000ull) {        // 5 s at 100 MHz: the peer is not coming
-                if (a.err) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = t; i < a.n; i += 256) {
-        double s = __hip_atomic_load(&mine->slot[par][0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        for (int r = 1; r < a.n_ranks; ++r) s += __hip_atomic_load(&mine->slot[par][r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        a.buf[i] = s;
-    }
+    p2p_exchange<256>(a.d, a.d.seq, rec, a.n);
+    for (int i = threadIdx.x; i < a.n; i += 256) a.buf[i] = rec[i];
 }
 
 static int p2p_allreduce(mlh_ctx *ctx, double *buf, int n)
 {
     if (n > P2P_MAX_DOUBLES) return fail(ctx, MLH_ERR_UNSUPPORTED, "the mailbox communicator carries records of up to 512 doubles");
     P2pArgs a;
-    for (int r = 0; r < P2P_MAX_RANKS; ++r) a.peer[r] = static_cast<P2pMailbox *>(ctx->p2p.peer[r]);
-    a.buf = buf; a.n = n; a.n_ranks = ctx->n_ranks; a.rank = ctx->rank;
-    a.seq = ++ctx->p2p.seq;
-    a.err = device_error_word(ctx);
+    p2p_fill(ctx, a.d, 1);
+    a.buf = buf; a.n = n;
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

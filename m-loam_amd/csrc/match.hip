@@ -21,6 +21,7 @@
 #include "ctx.hpp"
 #include "dev_math.hpp"
 #include "solver_dev.hpp"
+#include "p2p_dev.hpp"
 #include <hip/hip_ext.h>
 #include <cfloat>
 #include <cstdlib>
@@ -211,6 +212,9 @@ struct KParams {
     int lm_max_it, lm_min_blocks;
     unsigned *ticket;
     IterStatDev *stat;       // n_blocks consecutive records, or null
+    // sharded over several ranks with the mailbox communicator: the finishing workgroup exchanges each block's summed record with the peers (one hop, inside
+    // this launch) before it solves -- a sharded Gauss-Newton iteration is the same two launches as an unsharded one. n_ranks <= 1: nothing is exchanged
+    P2pDev p2p;
 };
 
 __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
@@ -476,6 +480,11 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.hi[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? (P.k[1].blk_start[b + 1] + TPB - 1) / TPB : 0);
         if (P.n_blocks == 1) { sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0; }   // one block: every record (any tile size)
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
+        if (P.p2p.n_ranks > 1) {                     // this rank's sums -> everybody's sums (rank order: the same bits on every rank)
+            p2p_exchange<NT>(P.p2p, P.p2p.seq + (unsigned long long)b, f_ne, NE_STRIDE);
+            if (threadIdx.x == 0) { f_cnt2[0] = f_ne[NE_CNT + 1]; f_cnt2[1] = f_ne[NE_CNT + 2]; }
+            __syncthreads();
+        }
         MLH_STAGE(4095, 1);
         if (threadIdx.x < 64) {
             double xo[7];
@@ -766,6 +775,9 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
     P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
+    // the mailbox communicator rides in the finishing workgroup of a Gauss-Newton launch (finish == 1); every other launch exchanges nothing
+    if (a.finish == 1 && ctx->p2p.active) p2p_fill(ctx, P.p2p, a.n_blocks);
+    else { P2pDev none{}; none.n_ranks = 1; P.p2p = none; }
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
     P.publish = (a.finish == 1 || a.finish == 4) ? a.publish : nullptr;
