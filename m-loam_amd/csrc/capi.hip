@@ -1243,7 +1243,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
     // one GPU, every feature used (wo_gf): the LM begin rides in the match launch and every LM step in its linearise launch -- an outer
     // iteration is 2 + (LM iterations) launches, the pose goes in with the first launch's kernel arguments
-    const bool fused = !distributed(ctx) && opts->gf_method == MLH_GF_WO;
+    const bool fused = (!distributed(ctx) || ctx->p2p.active) && opts->gf_method == MLH_GF_WO;      // (mailbox communicator: the exchange rides in the finish)
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
     // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2pArgs a)
     __shared__ double rec[P2P_MAX_DOUBLES];
     for (int i = threadIdx.x; i < a.n; i += 256) rec[i] = a.buf[i];
     __syncthreads();
-    p2p_exchange<256>(a.d, a.d.seq, rec, a.n);
+    p2p_exchange<256>(a.d, rec, a.n);
     for (int i = threadIdx.x; i < a.n; i += 256) a.buf[i] = rec[i];
 }
 
@@ -85,7 +85,7 @@ static int p2p_allreduce(mlh_ctx *ctx, double *buf, int n)
 {
     if (n > P2P_MAX_DOUBLES) return fail(ctx, MLH_ERR_UNSUPPORTED, "the mailbox communicator carries records of up to 512 doubles");
     P2pArgs a;
-    p2p_fill(ctx, a.d, 1);
+    p2p_fill(ctx, a.d);
     a.buf = buf; a.n = n;
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
     MLH_HIP(ctx, hipGetLastError());
@@ -123,13 +123,14 @@ int comm_allreduce_blocks(mlh_ctx *ctx, int n_blocks)
 void comm_destroy(mlh_ctx *ctx)
 {
     if (ctx->comm) { rccl().comm_destroy(ctx->comm); ctx->comm = nullptr; }
-    if (ctx->p2p.mailbox || ctx->p2p.active) {
+    if (ctx->p2p.mailbox || ctx->p2p.active || ctx->p2p.counter) {
         for (int r = 0; r < P2P_MAX_RANKS; ++r) {
             if (ctx->p2p.peer[r] && ctx->p2p.peer[r] != ctx->p2p.mailbox) (void)hipIpcCloseMemHandle(ctx->p2p.peer[r]);
             ctx->p2p.peer[r] = nullptr;
         }
         if (ctx->p2p.mailbox) (void)hipFree(ctx->p2p.mailbox);
-        ctx->p2p.mailbox = nullptr; ctx->p2p.active = false; ctx->p2p.seq = 0;
+        if (ctx->p2p.counter) (void)hipFree(ctx->p2p.counter);
+        ctx->p2p.mailbox = nullptr; ctx->p2p.counter = nullptr; ctx->p2p.active = false;
     }
 }
 
@@ -256,8 +257,9 @@ int mlh_p2p_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *ipc_handl
         if (e != hipSuccess) { comm_destroy(ctx); return fail(ctx, MLH_ERR_HIP, "hipIpcOpenMemHandle of a peer's mailbox", e); }
         ctx->p2p.peer[r] = p;
     }
+    MLH_HIP(ctx, hipMalloc(&ctx->p2p.counter, sizeof(unsigned long long)));
+    MLH_HIP(ctx, hipMemset(ctx->p2p.counter, 0, sizeof(unsigned long long)));
     ctx->p2p.active = true;
-    ctx->p2p.seq = 0;
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
     return MLH_OK;

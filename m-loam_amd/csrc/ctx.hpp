@@ -284,7 +284,7 @@ struct mlh_ctx {
         bool active = false;
         void *mailbox = nullptr;                      // this rank's own (device memory, exported through hipIpc)
         void *peer[16] = {};                          // rank r's mailbox as this process sees it (peer[rank] == mailbox)
-        unsigned long long seq = 0;                   // all-reduces issued so far: its parity picks the half of the mailboxes in use
+        void *counter = nullptr;                      // device word: exchanges completed (its parity picks the half of the mailboxes in use)
     } p2p;
     mlh::DevBuf allreduce_buf;   // staging of mlh_allreduce_f64
     int extract_tie_ref = 1;           // extractCloud, equal curvatures inside a sector: 1 = the order the reference's std::sort call leaves (default), 0 = (curvature, index)

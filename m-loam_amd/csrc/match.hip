@@ -429,6 +429,11 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.p = P.partials;
         sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
+        if (P.p2p.n_ranks > 1) {     // sharded over several ranks: everybody's sums before anybody's LM decision (same bits, same decision on every rank)
+            p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
+            if (threadIdx.x == 0) { f_cnt2[0] = f_ne[NE_CNT + 1]; f_cnt2[1] = f_ne[NE_CNT + 2]; }
+            __syncthreads();
+        }
         MLH_STAGE(4095, 1);
         if (threadIdx.x < 64) {      // one wavefront runs the LM begin / step (solver_dev.hpp: rows of the 6 x 6 objects on lanes)
             double xo[7];
@@ -481,7 +486,7 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         if (P.n_blocks == 1) { sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0; }   // one block: every record (any tile size)
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
         if (P.p2p.n_ranks > 1) {                     // this rank's sums -> everybody's sums (rank order: the same bits on every rank)
-            p2p_exchange<NT>(P.p2p, P.p2p.seq + (unsigned long long)b, f_ne, NE_STRIDE);
+            p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
             if (threadIdx.x == 0) { f_cnt2[0] = f_ne[NE_CNT + 1]; f_cnt2[1] = f_ne[NE_CNT + 2]; }
             __syncthreads();
         }
@@ -775,8 +780,9 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
     P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
-    // the mailbox communicator rides in the finishing workgroup of a Gauss-Newton launch (finish == 1); every other launch exchanges nothing
-    if (a.finish == 1 && ctx->p2p.active) p2p_fill(ctx, P.p2p, a.n_blocks);
+    // the mailbox communicator rides in the finishing workgroup of a Gauss-Newton launch (finish == 1) and of an LM begin / step launch (3 / 4); other launches
+    // exchange nothing
+    if ((a.finish == 1 || a.finish == 3 || a.finish == 4) && ctx->p2p.active) p2p_fill(ctx, P.p2p);
     else { P2pDev none{}; none.n_ranks = 1; P.p2p = none; }
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;

@@ -14,14 +14,17 @@ struct P2pMailbox {
 struct P2pDev {
     P2pMailbox *peer[P2P_MAX_RANKS];     // rank r's mailbox as this process sees it
     int n_ranks, rank;                   // n_ranks <= 1: no exchange
-    unsigned long long seq;              // this exchange's sequence number (the next one: seq + 1, ...)
+    unsigned long long *counter;         // device word: exchanges this rank has COMPLETED. The next one's sequence number is *counter + 1 -- counted where the
+                                         // exchanges happen, not where launches are enqueued: a launch that finds the LM loop already terminated exchanges nothing
+                                         // (on every rank alike), and the parity argument below needs consecutive numbers for consecutive exchanges
     int *err;                            // pinned host word: 2 = a peer did not show up within the bound
 };
 
 // rec[0 .. n) (LDS) <- sum over the ranks, added in rank order. All NT threads of the workgroup, converged; n <= P2P_MAX_DOUBLES.
 template <int NT>
-__device__ __forceinline__ void p2p_exchange(const P2pDev &a, unsigned long long seq, double *rec, int n)
+__device__ __forceinline__ void p2p_exchange(const P2pDev &a, double *rec, int n)
 {
+    const unsigned long long seq = __hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
     const int t = threadIdx.x, par = int(seq & 1ull);
     for (int r = 0; r < a.n_ranks; ++r)
         for (int i = t; i < n; i += NT) __hip_atomic_store(&a.peer[r]->slot[par][a.rank][i], rec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -46,18 +49,19 @@ __device__ __forceinline__ void p2p_exchange(const P2pDev &a, unsigned long long
         for (int r = 1; r < a.n_ranks; ++r) s += __hip_atomic_load(&mine->slot[par][r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         rec[i] = s;
     }
+    __syncthreads();                     // (every thread has read the counter long before this point)
+    if (t == 0) __hip_atomic_store(a.counter, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
 }
 
-// fills the device-side descriptor from the context and reserves `count` sequence numbers (the first one is returned in d.seq)
-inline void p2p_fill(mlh_ctx *ctx, P2pDev &d, int count)
+// fills the device-side descriptor from the context
+inline void p2p_fill(mlh_ctx *ctx, P2pDev &d)
 {
     for (int r = 0; r < P2P_MAX_RANKS; ++r) d.peer[r] = static_cast<P2pMailbox *>(ctx->p2p.peer[r]);
     d.n_ranks = ctx->p2p.active ? ctx->n_ranks : 1;
     d.rank = ctx->rank;
-    d.seq = ctx->p2p.seq + 1;
-    d.err = nullptr;
-    if (ctx->p2p.active) { ctx->p2p.seq += (unsigned long long)count; d.err = device_error_word(ctx); }
+    d.counter = static_cast<unsigned long long *>(ctx->p2p.counter);
+    d.err = ctx->p2p.active ? device_error_word(ctx) : nullptr;
 }
 
 }  // namespace mlh
