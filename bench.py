@@ -285,6 +285,7 @@ def main():
             raise SystemExit(3)
     else:
         local_surf_map, local_corner_map = surf_map, corner_map
+        comm_kind = None
     # inputs resident in HBM before the timed region
     d_surf_map = torch.from_numpy(local_surf_map).cuda()
     d_corner_map = torch.from_numpy(local_corner_map).cuda()
@@ -319,6 +320,9 @@ def main():
     # solve is SUBMITTED (mlh_gn_solve_begin) and its pose collected (mlh_gn_solve_end) after frame k + 1's map staging has been enqueued behind it: the GPU no
     # longer idles through the host's turn-around at every frame boundary (~16 us of a 183 us step in the synchronous loop, profiles/r03_step_timeline.txt).
     # Every pose is still read by the host, one frame late; the timed region ends with the last pose collected and the stream drained.
+    # Several ranks: synchronous. (With the mailbox communicator the split submission works -- the exchange lives inside the launches -- and was tried with ranks
+    # SHARING a GPU: 0.23 -> 0.52 ms per step at N = 2, because queued launches of one process spin on flags that the other process's launches, queued behind
+    # them on the same device, are to set. With a GPU per rank that does not arise; not measurable here, so not the default.)
     pipelined = (world == 1) and not args.synchronous
     in_flight = [False]
 

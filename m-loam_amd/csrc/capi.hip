@@ -1124,7 +1124,8 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 // host has seen the pose and enqueued ten launches); each publishes into its own pinned record, apart from the one the staging hand-shake uses.
 static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, int n_iters, const mlh_solver_opts *opts)
 {
-    if (distributed(ctx)) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin is the single-GPU submission path (a sharded solve synchronises on its all-reduces anyway)");
+    // several ranks: fine with the mailbox communicator (the exchange happens inside the launches, the host is not involved); not over RCCL
+    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_gn_solve_begin under an RCCL communicator: the sharded solve there is a host-driven sequence of launches and collectives (use the mailbox communicator)");
     if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one with mlh_gn_solve_end first");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, 0);
