@@ -408,7 +408,7 @@ typedef struct mlh_iter_stat {
  * (lidar_mapper_keyframe.cpp:1172-1204), solve H d = -g, pose <- PoseLocalParameterization::Plus(pose, V_update d)
  * (pose_local_parameterization.cpp:26-45). This is BASELINE.json's "GN iteration". stats may be NULL. */
 int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
-/* The same solve submitted and collected separately (single GPU, no statistics): _begin enqueues the n_iters iterations and returns at once, _end waits for the
+/* The same solve submitted and collected separately (one GPU, or several ranks joined by the mailbox communicator -- not under RCCL; no statistics): _begin enqueues the n_iters iterations and returns at once, _end waits for the
  * pose. Between the two the caller may stage the NEXT frame's maps (mlh_map_set_pair): those launches queue up behind the solve on the context's stream, so the
  * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). At most two solves in flight per context
  * (frame k + 1 may be submitted before frame k's pose is collected); mlh_gn_solve_end returns them in submission order. */

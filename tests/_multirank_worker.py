@@ -59,6 +59,10 @@ def main():
     ctx.features_set(mla.CORNER, feats[1])
     pose, stats = ctx.gn_solve(p0, 5)
     pose_s2m, _ = ctx.scan2map(p0)
+    split_equal = None
+    if comm == "p2p":                                            # split submission works under the mailbox communicator: the exchange is inside the launches
+        ctx.gn_solve_begin(p0, 5)
+        split_equal = bool(np.array_equal(ctx.gn_solve_end(), ctx.gn_solve(p0, 5, want_stats=False)[0]))
     # the collective's own time where it is a launch of its own (RCCL: HIP events around it on the context's stream; waiting for the slowest peer is inside), and
     # the sharded solve's wall time per call either way (with the mailbox communicator the exchange happens inside the fit kernel's finish: no separate launch)
     import time
@@ -78,7 +82,7 @@ def main():
         ref, ref_stats = one.gn_solve(p0, 5)
         ref_s2m, _ = one.scan2map(p0)
         one.close()
-        out = dict(world=world, mode=mode, comm=comm, allreduce_of_ones=float(ones[0]), pose_diff=float(np.abs(pose - ref).max()),
+        out = dict(world=world, mode=mode, comm=comm, split_submission_equal=split_equal, allreduce_of_ones=float(ones[0]), pose_diff=float(np.abs(pose - ref).max()),
                    scan2map_pose_diff=float(np.abs(pose_s2m - ref_s2m).max()), allreduce_us=round(1e3 * ar_ms / max(ar_n, 1), 2), allreduce_launches=int(ar_n), gn_solve5_ms=round(solve_ms, 4),
                    counts=[(int(s["n_surf"]), int(s["n_corner"])) for s in stats],
                    counts_unsharded=[(int(s["n_surf"]), int(s["n_corner"])) for s in ref_stats])

@@ -35,3 +35,4 @@ def test_sharded_solver_over_the_mailbox_communicator(world, mode):
     assert out["allreduce_of_ones"] == float(world)                    # the communicator really spans `world` ranks
     assert out["counts"] == out["counts_unsharded"]                    # same matched features every iteration ...
     assert out["pose_diff"] < 1e-9 and out["scan2map_pose_diff"] < 1e-9      # ... same pose (the records are summed in another order: not bit for bit)
+    assert out["split_submission_equal"] is True                      # mlh_gn_solve_begin / _end under the communicator: the same bits as mlh_gn_solve
