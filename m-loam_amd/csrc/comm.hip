@@ -246,6 +246,7 @@ int mlh_p2p_comm_init(mlh_ctx *ctx, int n_ranks, int rank, const void *ipc_handl
 {
     if (!ctx || n_ranks <= 0 || n_ranks > P2P_MAX_RANKS || rank < 0 || rank >= n_ranks || !ipc_handles) return MLH_ERR_INVALID;
     if (!ctx->p2p.mailbox) return fail(ctx, MLH_ERR_STATE, "mlh_p2p_mailbox first: the handles passed here are what it returned on every rank");
+    if (ctx->p2p.active) return fail(ctx, MLH_ERR_STATE, "the mailbox communicator is already set up (mlh_comm_finalize, then mlh_p2p_mailbox again, to rebuild it)");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     const char *hs = static_cast<const char *>(ipc_handles);
     for (int r = 0; r < n_ranks; ++r) {
