@@ -209,6 +209,34 @@ static int upload_block_pose(mlh_ctx *ctx, int b, const double pose[7])
     return MLH_OK;
 }
 
+__global__ void stream_flag_kernel(unsigned long long *h, unsigned long long seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(h, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t stream_wait_spin(mlh_ctx *ctx)
+{
+    if (!ctx->h_sync) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return hipStreamSynchronize(ctx->stream);
+        ctx->h_sync = static_cast<unsigned long long *>(p);
+        *ctx->h_sync = 0;
+    }
+    const unsigned long long seq = ++ctx->sync_seq;
+    hipLaunchKernelGGL(stream_flag_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->h_sync, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(ctx->h_sync, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return hipStreamSynchronize(ctx->stream);
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return hipSuccess;
+}
+
 // the pinned record and the next sequence number (allocated on first use)
 static int publish_slot(mlh_ctx *ctx, HostPublish **h, unsigned long long *seq)
 {
@@ -322,6 +350,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_sync) (void)hipHostFree(ctx->h_sync);
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
     for (int i = 0; i < 2; ++i) if (ctx->ev_set_built[i]) (void)hipEventDestroy(ctx->ev_set_built[i]);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
@@ -1514,7 +1543,7 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
         const float *hp_data = reinterpret_cast<const float *>(static_cast<char *>(ctx->fused_host) + 16);
         MLH_HIP(ctx, hipMemcpyAsync(h_cnt, ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
         MLH_HIP(ctx, hipMemcpyAsync(static_cast<char *>(ctx->fused_host) + 16, ctx->fused_part.p, sizeof(float) * n_floats, hipMemcpyDeviceToHost, ctx->stream));
-        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MLH_HIP(ctx, stream_wait_spin(ctx));
         ctx->fused_n[0] = h_cnt[0]; ctx->fused_n[1] = h_cnt[1];
         for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
         for (int a = 0; a < ctx->fused_parts; ++a)

@@ -264,6 +264,8 @@ struct mlh_ctx {
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
     int fused_n[2] = {0, 0};   // valid when !fused_dirty
     int *h_dev_err = nullptr;   // one pinned int a kernel sets when it has to give up (device std::sort: a wait that was never released); see device_error_check
+    unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
+    unsigned long long sync_seq = 0;
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
     void *fused_host = nullptr; // pinned landing block of mlh_fused_cloud's one read-back: [2 counts (padded to 4 ints)][per-workgroup bounding boxes]
     size_t fused_host_cap = 0;
@@ -367,13 +369,18 @@ inline int *pinned_ints(mlh_ctx *ctx)
     if (!ctx->h_scratch && hipHostMalloc(&ctx->h_scratch, 256, hipHostMallocDefault) != hipSuccess) ctx->h_scratch = nullptr;
     return static_cast<int *>(ctx->h_scratch);
 }
+// Everything enqueued on the context's stream so far (kernels, and copies into PINNED host memory) has completed when this returns. A one-thread launch stores a
+// sequence number into pinned host memory (system-scope release) and the host spins on that word: a few microseconds, where hipStreamSynchronize's wake-up
+// costs tens -- a mapper frame has three such read-backs (fused cloud sizes, thinned record counts, feature counts). Falls back to the blocking call after
+// 200 ms (a profiler, a fault). capi.hip has the definition.
+hipError_t stream_wait_spin(mlh_ctx *ctx);
 // *out <- one device int, through the pinned block (a pageable landing place costs a staging hop); waits for the stream
 inline hipError_t read_back_int(mlh_ctx *ctx, const void *dev, int *out)
 {
     int *h = pinned_ints(ctx);
     int *dst = h ? h + 8 : out;
     hipError_t e = hipMemcpyAsync(dst, dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = h ? stream_wait_spin(ctx) : hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && h) *out = *dst;
     return e;
 }

@@ -644,7 +644,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
     int stack_counts[2] = {0, 0};
     int *counts = pinned_ints(ctx) ? pinned_ints(ctx) : stack_counts;          // pinned: no staging hop for an 8-byte read-back
     MLH_HIP(ctx, hipMemcpyAsync(counts, V.total.as<int>() + 2, sizeof(stack_counts), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    MLH_HIP(ctx, counts == stack_counts ? hipStreamSynchronize(st) : stream_wait_spin(ctx));
     *n_surf_out = counts[0];
     *n_corner_out = counts[1];
     return device_error_check(ctx);
