@@ -351,6 +351,8 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_sync) (void)hipHostFree(ctx->h_sync);
+    if (ctx->h_rings) (void)hipHostFree(ctx->h_rings);
+    for (int i = 0; i < 2; ++i) if (ctx->ev_rings[i]) (void)hipEventDestroy(ctx->ev_rings[i]);
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
     for (int i = 0; i < 2; ++i) if (ctx->ev_set_built[i]) (void)hipEventDestroy(ctx->ev_set_built[i]);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
@@ -417,14 +419,29 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
     int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, sb.pts, nullptr, ctx->tmp);
     if (rc) return rc;
-    std::vector<int> hs(n_rings), he(n_rings);
-    if (mem == MLH_MEM_HOST) {
-        std::memcpy(hs.data(), scan_start, sizeof(int) * n_rings);
-        std::memcpy(he.data(), scan_end, sizeof(int) * n_rings);
-    } else {
-        MLH_HIP(ctx, hipMemcpyAsync(hs.data(), scan_start, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
-        MLH_HIP(ctx, hipMemcpyAsync(he.data(), scan_end, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
+    // The ring tables go to the device from a pinned block the context owns (two halves, used alternately; an event says when a half's copy has been read):
+    // nothing has to be waited for before this call returns, so the host enqueues the extraction while the points are still being uploaded -- a blocking
+    // wait here was ~40 us of idle GPU per frame (profiles/r03_frame_timeline.txt: the gap in front of the curvature kernel).
+    const size_t ring_bytes = sizeof(int) * 2 * size_t(n_rings);
+    if (ring_bytes > ctx->h_rings_cap) {
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_rings) (void)hipHostFree(ctx->h_rings);
+        ctx->h_rings = nullptr; ctx->h_rings_cap = 0;
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_rings, 2 * (ring_bytes + ring_bytes / 2), hipHostMallocDefault));
+        ctx->h_rings_cap = ring_bytes + ring_bytes / 2;
+        for (int i = 0; i < 2; ++i) if (!ctx->ev_rings[i]) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_rings[i], hipEventDisableTiming));
+        ctx->ev_rings_used[0] = ctx->ev_rings_used[1] = false;
+    }
+    const int half = int(ctx->rings_turn++ & 1);
+    if (ctx->ev_rings_used[half]) MLH_HIP(ctx, hipEventSynchronize(ctx->ev_rings[half]));        // two uploads ago: long done
+    int *hs = reinterpret_cast<int *>(static_cast<char *>(ctx->h_rings) + size_t(half) * ctx->h_rings_cap), *he = hs + n_rings;
+    if (mem == MLH_MEM_HOST) {
+        std::memcpy(hs, scan_start, sizeof(int) * n_rings);
+        std::memcpy(he, scan_end, sizeof(int) * n_rings);
+    } else {
+        MLH_HIP(ctx, hipMemcpyAsync(hs, scan_start, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipMemcpyAsync(he, scan_end, sizeof(int) * n_rings, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, stream_wait_spin(ctx));
     }
     // rings are labelled by independent workgroups: that is exact only when the neighbour-suppression reach (+-5) of one
     // ring cannot touch another ring's labelled span, which the ImageSegmenter insets (+5 / -6) guarantee.
@@ -438,9 +455,17 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     }
     MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(n_rings)));
     MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(n_rings)));
-    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hs.data(), sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
-    MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, he.data(), sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hs, sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, he, sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, hipEventRecord(ctx->ev_rings[half], ctx->stream));
+    ctx->ev_rings_used[half] = true;
+    // The caller's point buffer: a copy out of PAGEABLE memory has been staged by the time hipMemcpyAsync returned; out of pinned memory it is truly
+    // asynchronous, and the buffer is the caller's to reuse after this call -- so that case (rare: a ROS message is pageable) still waits here
+    if (mem == MLH_MEM_HOST) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, points) == hipSuccess && at.type == hipMemoryTypeHost) MLH_HIP(ctx, stream_wait_spin(ctx));
+        (void)hipGetLastError();
+    }
     sb.n = n; sb.n_rings = n_rings; sb.max_ring_len = max_len;
     return MLH_OK;
 }

@@ -264,6 +264,11 @@ struct mlh_ctx {
     mlh::DevBuf fused[2];    // body-frame union of the LiDARs' mapping features (mlh_fuse_*): float4 {x,y,z,lidar index}
     int fused_n[2] = {0, 0};   // valid when !fused_dirty
     int *h_dev_err = nullptr;   // one pinned int a kernel sets when it has to give up (device std::sort: a wait that was never released); see device_error_check
+    void *h_rings = nullptr;                // pinned ring tables of mlh_scan_upload (two halves) ...
+    size_t h_rings_cap = 0;                 // ... bytes per half
+    hipEvent_t ev_rings[2] = {nullptr, nullptr};
+    bool ev_rings_used[2] = {false, false};
+    unsigned rings_turn = 0;
     unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
     unsigned long long sync_seq = 0;
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
