@@ -13,12 +13,12 @@ scn = synth.make_scene(seed=9, **synth.SCENE_PRESETS["50k"])
 c = mla.Context(0)
 t0 = time.time()
 n_cases = n_ties = 0
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "2026")))
 for trial in range(int(os.environ.get("SOAK_EXTRACT", "60"))):
     rings = int(rng.choice([16, 32, 64]))
     cols = int(rng.choice([40, 90, 300, 900, 1800, 2400, 4000]))
     q = float(rng.choice([1.0, 4.0, 16.0, 32.0, 64.0, 256.0]))
-    sc = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[trial % 2], rings, seed=100 + trial, n_cols=cols)
+    sc = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[trial % 2], rings, seed=100 + trial + 1000 * int(os.environ.get("SOAK_SEED", "0")), n_cols=cols)
     pts = sc.points.copy()
     pts[:, :3] = np.round(pts[:, :3] * q) / q
     if trial % 3 == 2:                                    # NaN sprinkles: the comparator is no strict weak order any more
