@@ -153,6 +153,11 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
                           const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
                           double trace_threshold, float *cov_vec_out, int32_t *keep_out);
 
+/* The staged feature set of `kind` (mlh_features_set / mlh_downsample_current_scan) copied from context `src` to context `dst` on the same GPU, device to
+ * device. The reference runs extraction / odometry and mapping as separate nodes joined by ROS messages (estimator.cpp publishes the feature clouds, lidar_mapper_
+ * keyframe.cpp:162-190 queues them); two contexts driven by two host threads are the same arrangement on one GPU -- the estimator-side context extracts and thins
+ * frame k + 1 while the mapper-side context solves frame k -- and this call is the message. Returns when the copy is done: src may restage at once. */
+int mlh_features_copy(mlh_ctx *dst, mlh_ctx *src, int kind);
 /* (f2) downsampleCurrentScan for one feature kind (lidar_mapper_keyframe.cpp:356-421), device-resident: VoxelGridCovarianceMLOAM<PointI>
  * at `leaf` (plain branch), then per thinned point (intensity = LiDAR index n) Sigma = evalPointUncertainty(pose_ext[n]^-1 * p,
  * pose_ext[n]) and the trace gate (with_ua only; Sigma = 0 and no gate otherwise). The kept points BECOME the kind's feature set

@@ -146,6 +146,7 @@ def load_library():
     lib.mlh_solver_opts_default.restype = None
     lib.mlh_gn_solve.argtypes = [vp, vp, ci, C.POINTER(SolverOpts), vp]
     lib.mlh_gn_solve_begin.argtypes = [vp, vp, ci, C.POINTER(SolverOpts)]
+    lib.mlh_features_copy.argtypes = [vp, vp, ci]
     lib.mlh_gn_solve_begin_chained.argtypes = [vp, vp, vp, ci, C.POINTER(SolverOpts)]
     lib.mlh_gn_solve_end.argtypes = [vp, vp]
     lib.mlh_scan2map.argtypes = [vp, vp, C.POINTER(SolverOpts), vp]
@@ -169,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
-    "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_scan2map",
+    "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
@@ -715,6 +716,10 @@ class Context:
         stats = (IterStat * n_iters)() if want_stats else None
         self._ck(self.lib.mlh_gn_solve(self.h, _p(pose), n_iters, C.byref(opts), C.cast(stats, C.c_void_p) if want_stats else None))
         return pose, ([s.as_dict() for s in stats] if want_stats else None)
+
+    def features_copy_from(self, src: "Context", kind):
+        """this context's feature set of `kind` <- the one staged in `src` (same GPU), device to device (mlh_features_copy)"""
+        self._ck(self.lib.mlh_features_copy(self.h, src.h, kind))
 
     def gn_solve_begin(self, pose, n_iters, opts: SolverOpts | None = None):
         """submit the solve and return at once (mlh_gn_solve_begin); collect the pose with gn_solve_end. One in flight per context."""

@@ -909,6 +909,31 @@ int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_byte
     return MLH_OK;
 }
 
+// The staged feature set of `kind` handed from one context to another on the same GPU, device to device: how an estimator-side context (extraction, fusion,
+// thinning) feeds a mapper-side context (index, scan2MapOptimization) when the two run as separate pipelines, as the reference's estimator and mapper nodes do
+// (there: a ROS message through host memory). Ordered after everything `src` has enqueued (waited for here); the copies run on dst's stream.
+int mlh_features_copy(mlh_ctx *dst, mlh_ctx *src, int kind)
+{
+    if (!dst || !src || dst == src || kind < 0 || kind > 1) return MLH_ERR_INVALID;
+    if (dst->device != src->device) return fail(dst, MLH_ERR_UNSUPPORTED, "mlh_features_copy: both contexts must be on the same device");
+    MLH_HIP(dst, hipSetDevice(dst->device));
+    const FeatSet &a = src->feat[kind];
+    FeatSet &f = dst->feat[kind];
+    f.matched = false;
+    f.m = 0;
+    if (a.m <= 0) return fail(dst, MLH_ERR_STATE, "mlh_features_copy: the source context has no staged features of this kind");
+    MLH_HIP(dst, stream_wait_spin(src));                           // the source's producers are done
+    MLH_HIP(dst, f.pts.ensure(sizeof(float4) * size_t(a.m)));
+    MLH_HIP(dst, f.covd.ensure(sizeof(float4) * size_t(a.m)));
+    MLH_HIP(dst, hipMemcpyAsync(f.pts.p, a.pts.p, sizeof(float4) * size_t(a.m), hipMemcpyDeviceToDevice, dst->stream));
+    MLH_HIP(dst, hipMemcpyAsync(f.covd.p, a.covd.p, sizeof(float4) * size_t(a.m), hipMemcpyDeviceToDevice, dst->stream));
+    MLH_HIP(dst, stream_wait_spin(dst));                           // the source may overwrite its set as soon as this returns
+    f.m = a.m; f.n_blocks = a.n_blocks; f.nbr_stride = a.nbr_stride; f.has_cov = a.has_cov;
+    for (int b = 0; b < 9; ++b) f.blk_start[b] = a.blk_start[b];
+    for (int b = 0; b < 8; ++b) f.blk_real[b] = a.blk_real[b];
+    return MLH_OK;
+}
+
 // downsampleCurrentScan for one feature kind, device-resident: the result IS the kind's feature set
 int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int mem,
                                 float leaf, const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],

@@ -112,6 +112,41 @@ print("GPU path, device-resident, one launch set, both kinds thinned in one pipe
       "same pose:", bool(np.array_equal(pose_dev2, pose_dev1)))
 print("GPU path, device-resident, both LiDARs one launch set, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td1.items()}, "total %.3f" % (1e3 * sum(td1.values()) / 20),
       "same pose as per-LiDAR launches:", bool(np.array_equal(pose_dev1, pose_dev)))
+# Two pipelines on the one GPU, as the reference's estimator and mapper NODES are two processes: an estimator-side context extracts, fuses and thins frame k + 1
+# while a mapper-side context indexes and solves frame k; the hand-over is mlh_features_copy (device to device; the reference's is a ROS message). Frame PERIOD,
+# not latency: a frame still takes what the line above says.
+import threading
+ctxB = mla.Context(0)
+ctxB.map_set(mla.SURF, surf_map); ctxB.map_set(mla.CORNER, corner_map)
+N_PIPE = 60
+ready = [threading.Semaphore(0) for _ in range(N_PIPE)]
+copied = [threading.Semaphore(0) for _ in range(N_PIPE)]
+poses_pipe = [None] * N_PIPE
+def estimator_side():
+    for k in range(N_PIPE):
+        ctx.fuse_reset()
+        ctx.scan_upload(both_pts, both_start, both_end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
+        for i in range(len(scans)): ctx.fuse_add_rings(ring_ofs[i], ring_ofs[i + 1], i, ext[i])
+        fs, fc = ctx.fused_cloud(mla.SURF), ctx.fused_cloud(mla.CORNER)
+        if k > 0: copied[k - 1].acquire()              # the mapper side has taken frame k - 1's features: this context's sets may be overwritten
+        ctx.downsample_current_scan_pair(fs, fc, 0.4, 0.2, ext, covs, meas, True, 0.6)
+        ready[k].release()
+def mapper_side():
+    for k in range(N_PIPE):
+        ready[k].acquire()
+        ctxB.features_copy_from(ctx, mla.SURF); ctxB.features_copy_from(ctx, mla.CORNER)
+        copied[k].release()
+        ctxB.map_rebuild(mla.ALL_KINDS)
+        poses_pipe[k], _ = ctxB.scan2map(p0, opts, want_stats=False)
+ta, tb = threading.Thread(target=estimator_side), threading.Thread(target=mapper_side)
+t_pipe = time.perf_counter()
+ta.start(); tb.start(); ta.join(); tb.join()
+ctxB.synchronize()
+t_pipe = time.perf_counter() - t_pipe
+print("two contexts on the GPU (estimator side: upload + extract + fuse + thin; mapper side: index + scan2map; device-to-device hand-over), frame PERIOD: %.3f ms over %d frames"
+      % (1e3 * t_pipe / N_PIPE, N_PIPE), " same pose as the single pipeline:", bool(all(np.array_equal(p, pose_dev2) for p in poses_pipe)))
+ctxB.close()
+
 # the same frame driven from C++ through the C-ABI (m-loam_amd/host/framebench.cpp): no interpreter between the dozen calls of a frame
 import subprocess, tempfile
 exe = os.path.join(ROOT, "m-loam_amd", "host", "framebench")

@@ -596,3 +596,27 @@ def test_next_frames_start_pose_is_chained_on_the_device(mla, orc, case16, feats
         assert np.abs(want[1] - want[0]).max() > 0                   # the chain really moved the start pose
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_features_handed_from_one_context_to_another(mla, case16, feats16):
+    """mlh_features_copy: the staged feature sets of an estimator-side context become those of a mapper-side context on the same GPU, device to device; the
+    mapper side then solves exactly what it would have solved had the features been staged from the host. The source may restage at once."""
+    a, b, ref = mla.Context(0), mla.Context(0), mla.Context(0)
+    try:
+        for c in (b, ref):
+            c.map_set_pair(case16["surf_map"], case16["corner_map"])
+        ref.features_set(mla.SURF, feats16[0]); ref.features_set(mla.CORNER, feats16[1])
+        want, _ = ref.scan2map(case16["p0"], want_stats=False)
+        with pytest.raises(mla.MlhError):
+            b.features_copy_from(a, mla.SURF)                         # nothing staged on the source yet
+        a.features_set(mla.SURF, feats16[0]); a.features_set(mla.CORNER, feats16[1])
+        b.features_copy_from(a, mla.SURF); b.features_copy_from(a, mla.CORNER)
+        a.features_set(mla.SURF, feats16[0][::-1].copy())             # the source moves on: the copy must not care
+        got, _ = b.scan2map(case16["p0"], want_stats=False)
+        assert np.array_equal(got, want)
+        with pytest.raises(mla.MlhError):
+            b.features_copy_from(b, mla.SURF)                         # a context cannot hand over to itself
+    finally:
+        for c in (a, b, ref):
+            c.close()
