@@ -1043,6 +1043,14 @@ inline void scan2MapOptimization(Device &dev, const PointICovCloud &laser_cloud_
     if (report) report->outer = stats;
 }
 
+// The feature-cloud "message" between an estimator-side Device and a mapper-side Device on the same GPU (the reference's nodes exchange host clouds over ROS:
+// estimator.cpp publishes, lidar_mapper_keyframe.cpp:162-190 queues): the staged feature sets of `from` become those of `to`, device to device.
+inline void handOverFeatures(Device &to, Device &from)
+{
+    to.check(mlh_features_copy(to.ctx(), from.ctx(), MLH_SURF));
+    to.check(mlh_features_copy(to.ctx(), from.ctx(), MLH_CORNER));
+}
+
 // ------------------------------------------------------------------ the mapper's frame loop with the GPU kept busy across frames
 // LidarMapper::process() (lidar_mapper_keyframe.cpp:1000-1100) runs transformAssociateToMap -> extractSurroundingKeyFrames -> downsampleCurrentScan ->
 // scan2MapOptimization -> transformUpdate per frame. FramePipeline issues the same per-frame work so that frame k + 1's map index is built on a second stream
