@@ -58,14 +58,16 @@ static int rccl_fail(mlh_ctx *ctx, const char *what, int code)
 // ---------------------------------------------------------------- the mailbox communicator
 // This path's only collective is an all-reduce of a few hundred bytes per evaluation: pure latency. A library collective pays for generality there (protocol
 // selection, proxy threads, a ring or tree over the ranks); what the message needs is ONE hop. Every rank owns a mailbox in its device memory, exported through
-// hipIpc and mapped by every other rank (peer access over xGMI between GPUs; the same memory through a second mapping when ranks share a GPU). An all-reduce is one
-// single-workgroup kernel per rank, on the context's stream:
+// hipIpc and mapped by every other rank (peer access over xGMI between GPUs; the same memory through a second mapping when ranks share a GPU). An all-reduce is
+// what ONE workgroup per rank does on a record it holds in LDS (p2p_dev.hpp: p2p_exchange) -- the finishing workgroup of a Gauss-Newton / LM launch (match.hip:
+// no launch of its own), or the stand-alone kernel below (mlh_allreduce_f64, the good-feature paths) -- on the context's stream:
 //   1. store my record into slot [parity][my rank] of EVERY mailbox (system-scope stores: they leave the L2 for the owner's memory),
 //   2. fence, then store the all-reduce's sequence number into flag [parity][my rank] of every mailbox,
 //   3. wait until the n flags of MY mailbox carry that sequence number (bounded: a missing peer raises the context's device error word instead of hanging),
 //   4. sum the n slots of my mailbox in RANK ORDER -- every rank adds the same numbers in the same order, so all ranks hold the same bits and apply the same update.
 // Two halves (parity of the sequence number) suffice: a rank can only get one all-reduce ahead of a peer, because finishing all-reduce s + 1 needs that peer's
-// contribution to s + 1, which the peer writes after it has read everything of s.
+// contribution to s + 1, which the peer writes after it has read everything of s. Sequence numbers are counted on the device, one per exchange actually made.
+// Tear-down is collective: a rank must not free its mailbox (mlh_comm_finalize / mlh_destroy) while a peer may still write into it.
 struct P2pArgs {
     P2pDev d;
     double *buf;
