@@ -156,7 +156,8 @@ int mlh_point_uncertainty(mlh_ctx *ctx, const void *points, int stride_bytes, in
 /* The staged feature set of `kind` (mlh_features_set / mlh_downsample_current_scan) copied from context `src` to context `dst` on the same GPU, device to
  * device. The reference runs extraction / odometry and mapping as separate nodes joined by ROS messages (estimator.cpp publishes the feature clouds, lidar_mapper_
  * keyframe.cpp:162-190 queues them); two contexts driven by two host threads are the same arrangement on one GPU -- the estimator-side context extracts and thins
- * frame k + 1 while the mapper-side context solves frame k -- and this call is the message. Returns when the copy is done: src may restage at once. */
+ * frame k + 1 while the mapper-side context solves frame k -- and this call is the message. Meant to be called from the thread that drives dst; of src it only needs the feature set to stay as it is until the call returns
+ * (then src may restage at once). */
 int mlh_features_copy(mlh_ctx *dst, mlh_ctx *src, int kind);
 /* (f2) downsampleCurrentScan for one feature kind (lidar_mapper_keyframe.cpp:356-421), device-resident: VoxelGridCovarianceMLOAM<PointI>
  * at `leaf` (plain branch), then per thinned point (intensity = LiDAR index n) Sigma = evalPointUncertainty(pose_ext[n]^-1 * p,

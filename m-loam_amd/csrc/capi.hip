@@ -351,6 +351,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     if (ctx->h_sync) (void)hipHostFree(ctx->h_sync);
+    if (ctx->ev_handover) (void)hipEventDestroy(ctx->ev_handover);
     if (ctx->h_rings) (void)hipHostFree(ctx->h_rings);
     for (int i = 0; i < 2; ++i) if (ctx->ev_rings[i]) (void)hipEventDestroy(ctx->ev_rings[i]);
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
@@ -922,7 +923,11 @@ int mlh_features_copy(mlh_ctx *dst, mlh_ctx *src, int kind)
     f.matched = false;
     f.m = 0;
     if (a.m <= 0) return fail(dst, MLH_ERR_STATE, "mlh_features_copy: the source context has no staged features of this kind");
-    MLH_HIP(dst, stream_wait_spin(src));                           // the source's producers are done
+    // ordered behind the source's producers ON THE DEVICE (an event of dst's, recorded on src's stream): the caller is typically another thread than the one
+    // driving src, and nothing of src's host-side state is touched here (its feature set must simply not be restaged before this call returns)
+    if (!dst->ev_handover) MLH_HIP(dst, hipEventCreateWithFlags(&dst->ev_handover, hipEventDisableTiming));
+    MLH_HIP(dst, hipEventRecord(dst->ev_handover, src->stream));
+    MLH_HIP(dst, hipStreamWaitEvent(dst->stream, dst->ev_handover, 0));
     MLH_HIP(dst, f.pts.ensure(sizeof(float4) * size_t(a.m)));
     MLH_HIP(dst, f.covd.ensure(sizeof(float4) * size_t(a.m)));
     MLH_HIP(dst, hipMemcpyAsync(f.pts.p, a.pts.p, sizeof(float4) * size_t(a.m), hipMemcpyDeviceToDevice, dst->stream));

@@ -269,6 +269,7 @@ struct mlh_ctx {
     hipEvent_t ev_rings[2] = {nullptr, nullptr};
     bool ev_rings_used[2] = {false, false};
     unsigned rings_turn = 0;
+    hipEvent_t ev_handover = nullptr;      // mlh_features_copy: recorded on the source context's stream, waited for on this one's
     unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
     unsigned long long sync_seq = 0;
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
