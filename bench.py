@@ -511,6 +511,12 @@ def main():
                             binding="latency", timing="HIP events, separate fully-bracketed pass",
                             note="a few MB per launch: nowhere near any bandwidth roof. What bounds it is a dependent chain -- f32 eigen / QR fit per lane, f64 "
                                  "residual + Jacobian, the workgroup reduction, then the serial finish (sum of the tiles' records, 6x6 solve, Plus) in the last workgroup")
+        try:                     # HBM bytes of this kernel from the same offline PMC passes as the correspondence kernel's (profiles/pmc_knn.json: fit_kernel)
+            pmc_f = json.load(open(os.path.join(ROOT, "profiles", "pmc_knn.json")))
+            if pmc_f.get("workload", "").startswith(f"{N_LIDARS}x{N_RINGS}_vs_{preset}_") and world == 1 and not args.dense_features and "fit_kernel" in pmc_f:
+                roofline_fit["traffic"] = pmc_f["fit_kernel"].get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     # supplementary: a frame whose map has OUTGROWN the sticky grid box: every step stages a cloud that alternately has / has not a few points 40 m
     # outside the box of the previous one, so the bounds pass + re-layout path of mlh_map_set_pair is what is timed. Not `value`.
     outgrow_ms = None
