@@ -23,7 +23,8 @@ def main():
     rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if comm == "p2p":
-        local_rank = local_rank % torch.cuda.device_count()      # more ranks than GPUs: they share (RCCL refuses that; the mailboxes do not care)
+        # more ranks than GPUs: they share (RCCL refuses that; the mailboxes do not care). MLH_P2P_SHARE_GPU=1: all ranks on GPU 0 whatever the box has
+        local_rank = 0 if os.environ.get("MLH_P2P_SHARE_GPU") == "1" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl" if comm == "rccl" else "gloo", rank=rank, world_size=world)
     mla = importlib.import_module("m-loam_amd")

@@ -15,9 +15,9 @@ WORKER = os.path.join(ROOT, "tests", "_multirank_worker.py")
 _PORT = [29651]
 
 
-def _run(world, mode):
+def _run(world, mode, share_gpu=True):
     _PORT[0] += 1
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MLH_P2P_SHARE_GPU="1" if share_gpu else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_PORT[0]),
            WORKER, mode, "p2p"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
@@ -36,3 +36,24 @@ def test_sharded_solver_over_the_mailbox_communicator(world, mode):
     assert out["counts"] == out["counts_unsharded"]                    # same matched features every iteration ...
     assert out["pose_diff"] < 1e-9 and out["scan2map_pose_diff"] < 1e-9      # ... same pose (the records are summed in another order: not bit for bit)
     assert out["split_submission_equal"] is True                      # mlh_gn_solve_begin / _end under the communicator: the same bits as mlh_gn_solve
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="one rank per GPU over the mailbox communicator needs two GPUs (peer stores over xGMI)")
+@pytest.mark.parametrize("mode", ["map", "features"])
+def test_mailbox_communicator_between_gpus(mode):
+    """the same with a GPU per rank: the mailboxes are peer-mapped device memory of OTHER GPUs (runs by itself where there are two)"""
+    world = min(_n_gpus(), 4)
+    out = _run(world, mode, share_gpu=False)
+    assert out["allreduce_of_ones"] == float(world)
+    assert out["counts"] == out["counts_unsharded"]
+    assert out["pose_diff"] < 1e-9 and out["scan2map_pose_diff"] < 1e-9
+    assert out["split_submission_equal"] is True
