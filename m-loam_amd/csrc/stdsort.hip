@@ -122,63 +122,84 @@ __global__ __launch_bounds__(256) void stdsort_init_segments_kernel(StdSortArgs 
 // the comparator of the voxel filters: int voxel slots (stdsort_dev.hpp holds the pieces shared with extract.hip's per-sector sort)
 __device__ inline void median_to_first(int *keys, int *vals, int f, int l) { ss_median_to_first(keys, vals, f, l, IntLess()); }
 __device__ inline void heap_sort_range(int *k, int *v, int len) { ss_heap_sort_range(k, v, len, IntLess()); }
-template <int SS_U>
-__device__ inline void wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right)
-{
-    ss_wave_count_stops<SS_U>(keys, f, lo, hi, piv, n_left, n_right, IntLess());
-}
-template <int SS_U>
-__device__ inline void wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here)
-{
-    ss_wave_write_tables<SS_U>(keys, lt, rt, f, lo, hi, piv, rank_l0, after_r, n_right_here, IntLess());
-}
-
 // __unguarded_partition_pivot of [f, l) by a WHOLE 1024-thread workgroup (all threads converged): its 16 wavefronts stream contiguous sixteenths of the
-// range in coalesced 64-wide tiles -- stop counts, a prefix over the wavefronts in LDS, the rank-indexed stop tables, the crossing pairs swapped in parallel.
-// keys / vals / lt / rt: global memory (big levels) or LDS (the top of a leaf's recursion); w_left / w_right (16 ints each) and sh_k: LDS. Returns the cut.
+// range in coalesced 64-wide tiles, ONCE -- each leaves its chunk's left and right stops, ascending, in its own stretch of the tables; a prefix over the
+// wavefronts' counts (LDS) turns a rank of the whole range into (chunk, entry) by a four-step search; the number of crossing pairs comes from a 64-ary search
+// over that predicate, and the pairs are swapped in parallel. (Rounds 2-3 streamed the keys twice, a count pass in front of the table pass: the launch is
+// bound by instruction issue on its ONE compute unit, and the count pass was a third of it -- thinning 0.52 -> 0.48 ms per frame without it.)
+// keys / vals / lt / rt: global memory; w_left / w_right (17 ints each) and sh_k: LDS. Returns the cut.
 __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
 {
-    const int t = threadIdx.x, wave = t >> 6, m = l - f;
+    // w_left / w_right: 17 ints each. In: scratch. During the call: per-wavefront stop counts, then w_left[w] = left stops in the chunks before w (w = 0 .. 16),
+    // w_right[w] = right stops in chunks w .. 15 (w_right[16] = 0).
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = l - f;
     if (t == 0) { median_to_first(keys, vals, f, l); *sh_k = 0; }
     __syncthreads();
     const int piv = keys[f];
     const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
     const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
     int cl, cr;
-    wave_count_stops<SS_BIG_U>(keys, f, lo, hi, piv, cl, cr);
-    if ((t & 63) == 0) { w_left[wave] = cl; w_right[wave] = cr; }
+    // ONE pass over the keys (the launch is bound by instruction issue on its one compute unit: a big level streams a 62 k range through 16 wavefronts):
+    // every wavefront leaves its chunk's stops, ascending, in its own stretch of the tables (lt[lo ..], rt[lo ..])
+    ss_wave_stop_lists<SS_BIG_U>(keys, lt, rt, f, lo, hi, piv, cl, cr, IntLess());
+    if (lane == 0) { w_left[wave + 1] = cl; w_right[wave] = cr; }
     __syncthreads();
-    int nL = 0, nR = 0, before_l = 0, after_r = 0;
-#pragma unroll
-    for (int w = 0; w < SS_BIG_WAVES; ++w) {
-        const int a = w_left[w], b = w_right[w];
-        nL += a; nR += b;
-        if (w < wave) before_l += a;
-        if (w > wave) after_r += b;
+    if (t == 0) {
+        w_left[0] = 0; w_right[SS_BIG_WAVES] = 0;
+        for (int w = 0; w < SS_BIG_WAVES; ++w) w_left[w + 1] += w_left[w];
+        for (int w = SS_BIG_WAVES - 1; w >= 0; --w) w_right[w] += w_right[w + 1];
     }
-    wave_write_tables<SS_BIG_U>(keys, lt, rt, f, lo, hi, piv, before_l, after_r, cr);
     __syncthreads();
-    const int npair = min(nL, nR);
-    int mine = 0;
-#pragma unroll 4
-    for (int k = t; k < npair; k += SS_BIG_WG) mine += (lt[f + k] < rt[f + k]) ? 1 : 0;      // true for a prefix of k
+    const int nL = w_left[SS_BIG_WAVES], nR = w_right[0];
+    // the k-th left stop of the RANGE: chunk w = the largest one with w_left[w] <= k, entry k - w_left[w] of its list; the k-th right stop counted from the right:
+    // chunk w = the largest one with w_right[w] > k, entry (its count) - 1 - (k - w_right[w + 1]) of its ascending list. Four LDS look-ups each.
+    auto left_at = [&](int k) {
+        int w = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if ((t & 63) == 0 && mine) atomicAdd(sh_k, mine);
+        for (int step = SS_BIG_WAVES / 2; step > 0; step >>= 1) w += (w_left[w + step] <= k) ? step : 0;
+        return lt[min(f + w * chunk, l) + (k - w_left[w])];
+    };
+    auto right_at = [&](int k) {
+        int w = 0;
+#pragma unroll
+        for (int step = SS_BIG_WAVES / 2; step > 0; step >>= 1) w += (w_right[w + step] > k) ? step : 0;
+        const int after = w_right[w + 1], cnt = w_right[w] - after;
+        return rt[min(f + w * chunk, l) + (cnt - 1 - (k - after))];
+    };
+    // K = how many pairs cross (L[k] < R[k] holds for a prefix of k): a 64-ary search by the first wavefront instead of testing every pair
+    const int npair = min(nL, nR);
+    if (wave == 0) {
+        int lo_k = 0, hi_k = npair;
+        while (hi_k > lo_k) {                                        // uniform
+            const int step = (hi_k - lo_k + 63) >> 6;
+            const int k = lo_k + lane * step;
+            const bool p = k < hi_k && left_at(k) < right_at(k);
+            const int c = __popcll(__ballot(p));
+            const int new_hi = min(hi_k, lo_k + c * step);
+            lo_k = c > 0 ? lo_k + (c - 1) * step + 1 : lo_k;
+            hi_k = c > 0 ? max(new_hi, lo_k) : lo_k;
+        }
+        if (lane == 0) *sh_k = lo_k;
+    }
     __syncthreads();
     const int K = *sh_k;
     for (int k0 = t; k0 < K; k0 += 4 * SS_BIG_WG) {              // four swaps in flight: positions, then the eight elements, then the stores
         int p[4], q[4], kp[4], kq[4], vp[4], vq[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? lt[f + k] : -1; q[u] = on ? rt[f + k] : -1; }
+        for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? left_at(k) : -1; q[u] = on ? right_at(k) : -1; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (p[u] >= 0) { kp[u] = keys[p[u]]; kq[u] = keys[q[u]]; vp[u] = vals[p[u]]; vq[u] = vals[q[u]]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (p[u] >= 0) { keys[p[u]] = kq[u]; keys[q[u]] = kp[u]; vals[p[u]] = vq[u]; vals[q[u]] = vp[u]; }
     }
     int cut = INT_MAX;
-    if (K < nL) cut = min(cut, lt[f + K]);
-    if (K > 0) cut = min(cut, rt[f + K - 1]);
+    if (t == 0) {
+        if (K < nL) cut = min(cut, left_at(K));
+        if (K > 0) cut = min(cut, right_at(K - 1));
+        *sh_k = cut;
+    }
+    __syncthreads();
+    cut = *sh_k;
     __syncthreads();                                             // the tables and sh_k / w_* are reused by the next range
     return cut;
 }
@@ -186,7 +207,7 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *
 // ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF
 __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level)
 {
-    __shared__ int w_left[SS_BIG_WAVES], w_right[SS_BIG_WAVES];
+    __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1];
     __shared__ int sh_k;
     const SortSeg *cur = A.seg[level & 1];
     SortSeg *next = A.seg[(level + 1) & 1];

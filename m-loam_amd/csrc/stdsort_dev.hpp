@@ -147,7 +147,7 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
 // lt[lo], lt[lo + 1], ... and of its right stops to rt[lo], rt[lo + 1], ..., both in ASCENDING position (a chunk has at most hi - lo stops of either kind, so the
 // chunks' sub-tables cannot overlap); n_left / n_right = how many. The k-th right stop counted from the RIGHT end -- the one the partition loop pairs with the
 // k-th left stop -- is entry (n_right - 1 - k) of that list; a count pass in front (rounds 2 and 3 had one, to rank the right stops from the right while
-// writing) is not needed.
+// writing) is not needed. Used by the wave-level partitions below and, chunk by chunk, by the 1024-thread partitions of stdsort.hip's big levels.
 template <int SS_U, typename Less>
 __device__ inline void ss_wave_stop_lists(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
 {
@@ -172,56 +172,6 @@ __device__ inline void ss_wave_stop_lists(const int *keys, int *lt, int *rt, int
         }
     }
     n_left = run_l; n_right = run_r;
-}
-
-// The two-pass form the 1024-thread partitions of the big levels keep (stdsort.hip: wg_partition): sixteen wavefronts share one rank space, and looking a
-// global rank up in sixteen per-wavefront lists costs more per element than the count pass it would save (measured: thinning +55 us per frame).
-// count pass: the number of left / right stops in [lo, hi).
-template <int SS_U, typename Less>
-__device__ inline void ss_wave_count_stops(const int *keys, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
-{
-    const int lane = threadIdx.x & 63;
-    int cl = 0, cr = 0;
-    for (int base = lo; base < hi; base += 64 * SS_U) {
-        int k[SS_U];
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) {
-            const int p = base + 64 * u + lane;
-            const bool in = p < hi;
-            cl += __popcll(__ballot(in && p > f && !less(k[u], piv)));
-            cr += __popcll(__ballot(in && (p == f || !less(piv, k[u]))));
-        }
-    }
-    n_left = cl; n_right = cr;
-}
-
-// table pass: left stops get ranks rank_l0, rank_l0 + 1, ... in ascending position; right stops ranks counted from the right:
-// a stop at p has rank (right stops of the whole range at positions > p) = after_r + (stops of [lo, hi) at positions > p)
-template <int SS_U, typename Less>
-__device__ inline void ss_wave_write_tables(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int rank_l0, int after_r, int n_right_here, Less less)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = ss_lanes_below();
-    int run_l = rank_l0, run_r = 0;
-    for (int base = lo; base < hi; base += 64 * SS_U) {
-        int k[SS_U];
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) { const int p = base + 64 * u + lane; k[u] = p < hi ? keys[p] : 0; }
-#pragma unroll
-        for (int u = 0; u < SS_U; ++u) {
-            const int p = base + 64 * u + lane;
-            const bool in = p < hi;
-            const bool is_l = in && p > f && !less(k[u], piv);
-            const bool is_r = in && (p == f || !less(piv, k[u]));
-            const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
-            if (is_l) lt[f + run_l + __popcll(ml & below)] = p;
-            if (is_r) rt[f + after_r + (n_right_here - (run_r + __popcll(mr & below) + 1))] = p;
-            run_l += __popcll(ml);
-            run_r += __popcll(mr);
-        }
-    }
 }
 
 // __unguarded_partition_pivot of the range [f, l), 16 < l - f, by ONE wavefront (all 64 lanes converged); returns the cut.
