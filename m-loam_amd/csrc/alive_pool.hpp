@@ -11,10 +11,13 @@ namespace mlh {
 // The reference keeps the not-yet-consumed feature slots in a std::vector it erases from (all_feature_idx, lidar_mapper.h:350,
 // 531-553): position j of that vector is always the (j+1)-th surviving ORIGINAL index, because it starts as 0..M-1 and only ever
 // loses elements. The same three questions -- element at position j, position of an element (the reference's std::find), erase --
-// are answered here from one "alive" bit per slot plus a Fenwick tree over the 64-bit words' populations: a branch-free descent over
-// log2(M/64) levels and a six-step rank search inside the word, instead of O(M) per operation, with identical results. (The draw loops
-// are one dependent chain per draw -- draw, look up, erase -- so the lookup's latency is the loop's speed: a Fenwick tree over single
-// slots with a data-dependent branch per level ran at ~170 ns per draw, this runs at ~30.)
+// are answered here from one "alive" bit per slot under a 16-ary tree of populations, with identical results. Each tree node's sixteen
+// children keep their EXCLUSIVE prefix sums side by side (one 64-byte line): going down a level is "how many of the fifteen prefixes are
+// <= k" -- sixteen independent compares the compiler turns into four SSE2 ones, no branch (the outcome is a coin flip) -- and an erase is
+// "subtract one from the siblings to the right", a masked vector subtract per level. The draw loops are one dependent chain per draw --
+// draw, look up, erase -- so the look-up's latency is the loop's speed: a Fenwick tree over single slots with a data-dependent branch per
+// level ran at ~170 ns per draw, a branch-free Fenwick tree over the words (eight dependent loads for 12 k slots) at ~30, this (two levels
+// for 12 k slots, three up to 262 k) at roughly half of that. The rank search inside the word is unchanged.
 class AlivePool {
 public:
     struct Select8 {                                               // at[v][r] = position of the r-th (0-based) set bit of the byte v
@@ -29,33 +32,50 @@ public:
         }
     };
     static inline const Select8 kSelect8{};
+    struct After {                                                 // m[c][s] = 1 for the siblings to the right of child c
+        int32_t m[16][16];
+        After() { for (int c = 0; c < 16; ++c) for (int s = 0; s < 16; ++s) m[c][s] = s > c; }
+    };
+    static inline const After kAfter{};
     explicit AlivePool(size_t n) : alive_(n), nw_((n + 63) / 64)
     {
-        log_ = 0;
-        while ((size_t(2) << log_) <= nw_) ++log_;                  // largest power of two <= nw_ is 1 << log_
         bits_.assign(nw_ + 1, 0);
         for (size_t w = 0; w < nw_; ++w) bits_[w] = (w * 64 + 64 <= n) ? ~uint64_t(0) : ((uint64_t(1) << (n - w * 64)) - 1);
-        t_.assign((size_t(2) << log_) + 1, kNever);                  // slots past nw_ are never taken by the descent
-        for (size_t i = 1; i <= nw_; ++i) t_[i] = 0;
-        for (size_t i = 1; i <= nw_; ++i) {
-            t_[i] += int32_t(popcount64(bits_[i - 1]));
-            const size_t j = i + (i & (~i + 1));
-            if (j <= nw_) t_[j] += t_[i];
-        }
+        // level 0: one node per word; every level above: one node per group of sixteen below; siblings that do not exist hold kNever
+        std::vector<int32_t> cnt(nw_ ? nw_ : 1, 0);
+        for (size_t w = 0; w < nw_; ++w) cnt[w] = int32_t(popcount64(bits_[w]));
+        size_t nodes = cnt.size();
+        levels_ = 0;
+        do {
+            const size_t groups = (nodes + 15) / 16;
+            off_[levels_] = pre_.size();
+            pre_.resize(pre_.size() + groups * 16, kNever);
+            std::vector<int32_t> up(groups);
+            for (size_t g = 0; g < groups; ++g) {
+                int32_t run = 0;
+                for (size_t s = 0; s < 16 && g * 16 + s < nodes; ++s) { pre_[off_[levels_] + g * 16 + s] = run; run += cnt[g * 16 + s]; }
+                up[g] = run;
+            }
+            cnt.swap(up);
+            nodes = groups;
+            ++levels_;
+        } while (nodes > 1);
     }
     size_t size() const { return alive_; }
     bool empty() const { return alive_ == 0; }
     // original index of the element at position j (0-based) among the survivors
-    size_t at(size_t j) const
+    __attribute__((always_inline)) size_t at(size_t j) const
     {
-        size_t pos = 0;
         int32_t k = int32_t(j);
-        for (int b = log_; b >= 0; --b) {
-            const int32_t v = t_[pos + (size_t(1) << b)];
-            const int32_t take = -int32_t(v <= k);                  // all-ones / zero: the comparison's outcome is a coin flip, keep it out of the branch predictor
-            pos += (size_t(1) << b) & size_t(int64_t(take));
-            k -= v & take;
+        size_t node = 0;
+        for (int l = levels_ - 1; l >= 0; --l) {
+            const int32_t *p = &pre_[off_[l] + node * 16];
+            int c = 0;
+            for (int s = 1; s < 16; ++s) c += (p[s] <= k);           // prefixes are non-decreasing: the last child whose prefix is <= k (empty children are stepped over)
+            k -= p[c];
+            node = node * 16 + size_t(c);
         }
+        const size_t pos = node;
         // rank search inside the word: per-byte populations (SWAR), their running sums by one multiply, the first byte whose running sum
         // exceeds k by a carry-free byte-wise compare, the bit inside that byte from a 2 KB table
         const uint64_t w = bits_[pos];
@@ -70,14 +90,20 @@ public:
         return pos * 64 + bit;
     }
     bool contains(size_t idx) const { return (bits_[idx >> 6] >> (idx & 63)) & 1; }
-    void erase_index(size_t idx)
+    __attribute__((always_inline)) void erase_index(size_t idx)
     {
         bits_[idx >> 6] &= ~(uint64_t(1) << (idx & 63));
         --alive_;
-        for (size_t i = (idx >> 6) + 1; i <= nw_; i += i & (~i + 1)) t_[i] -= 1;
+        size_t node = idx >> 6;
+        for (int l = 0; l < levels_; ++l) {
+            int32_t *p = &pre_[off_[l] + (node & ~size_t(15))];
+            const int32_t *m = kAfter.m[node & 15];
+            for (int s = 0; s < 16; ++s) p[s] -= m[s];
+            node >>= 4;
+        }
     }
 private:
-    static constexpr int32_t kNever = 0x3fffffff;
+    static constexpr int32_t kNever = 0x3fffffff;                  // never <= k, and still not after every slot has been erased
     static inline unsigned popcount64(uint64_t x)                  // SWAR: the baseline x86-64 target has no popcnt instruction
     {
         x = x - ((x >> 1) & 0x5555555555555555ull);
@@ -87,8 +113,9 @@ private:
     }
     size_t alive_, nw_;
     std::vector<uint64_t> bits_;
-    std::vector<int32_t> t_;
-    int log_;
+    std::vector<int32_t> pre_;      // all levels, one after the other (off_[l]), sixteen exclusive prefix sums per node group
+    size_t off_[16] = {0};
+    int levels_ = 0;
 };
 
 

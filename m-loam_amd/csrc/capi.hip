@@ -214,27 +214,41 @@ __global__ void stream_flag_kernel(unsigned long long *h, unsigned long long seq
     if (threadIdx.x == 0) __hip_atomic_store(h, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t stream_wait_spin(mlh_ctx *ctx)
+hipError_t stream_flag_post(mlh_ctx *ctx, unsigned long long *seq_out)
 {
     if (!ctx->h_sync) {
         void *p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return hipStreamSynchronize(ctx->stream);
+        hipError_t e = hipHostMalloc(&p, 64, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
         ctx->h_sync = static_cast<unsigned long long *>(p);
         *ctx->h_sync = 0;
     }
     const unsigned long long seq = ++ctx->sync_seq;
     hipLaunchKernelGGL(stream_flag_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->h_sync, seq);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    *seq_out = seq;
+    return hipGetLastError();
+}
+
+// the word only grows (one stream, launches in order): anything at or past `seq` means the work enqueued before that post is done
+hipError_t stream_flag_wait(mlh_ctx *ctx, unsigned long long seq)
+{
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (__atomic_load_n(ctx->h_sync, __ATOMIC_ACQUIRE) != seq) {
+    while (__atomic_load_n(ctx->h_sync, __ATOMIC_ACQUIRE) < seq) {
         if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return hipStreamSynchronize(ctx->stream);
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
     return hipSuccess;
+}
+
+hipError_t stream_wait_spin(mlh_ctx *ctx)
+{
+    unsigned long long seq = 0;
+    hipError_t e = stream_flag_post(ctx, &seq);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(ctx->stream); }
+    return stream_flag_wait(ctx, seq);
 }
 
 // the pinned record and the next sequence number (allocated on first use)
@@ -346,7 +360,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->h_state) (void)hipHostFree(ctx->h_state);
     if (ctx->h_solve) (void)hipHostFree(ctx->h_solve);
     if (ctx->h_occ) (void)hipHostFree(ctx->h_occ);
-    if (ctx->select_host) (void)hipHostFree(ctx->select_host);
+    for (int k = 0; k < 2; ++k) if (ctx->select_host[k]) (void)hipHostFree(ctx->select_host[k]);
     if (ctx->vox_order_host) (void)hipHostFree(ctx->vox_order_host);
     if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
@@ -1347,12 +1361,15 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         } else {
             // goodFeatureMatching for corners, then surfs (cpp:503-533), each against a fresh 1e-6*I; then the evaluation of the
             // selected residual blocks at the current pose (problem.Evaluate, cpp:575-581)
+            // Both kinds' dense passes and their copies to the host are enqueued first: the corner selection loop runs on the host while the surf pass
+            // and its copies are still in flight, and each kind's flags go back without a wait (the linearise launch is behind them on the stream)
             std::vector<int32_t> sel;
+            for (int kind : {MLH_CORNER, MLH_SURF})
+                if ((rc = good_feature_stage(ctx, kind, opts->gf_method, opts->min_match_sq_dis, opts->min_plane_dis))) return rc;
             for (int kind : {MLH_CORNER, MLH_SURF}) {
                 double Hsel[36];
                 for (int i = 0; i < 36; ++i) Hsel[i] = (i % 7 == 0) ? 1e-6 : 0.0;
-                if ((rc = good_feature_select(ctx, kind, opts->gf_method, opts->gf_ratio, rng, opts->min_match_sq_dis, opts->min_plane_dis,
-                                              sel, Hsel, nullptr))) return rc;
+                if ((rc = good_feature_finish(ctx, kind, opts->gf_method, opts->gf_ratio, rng, sel, Hsel, nullptr))) return rc;
             }
             if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
         }

@@ -301,9 +301,11 @@ struct mlh_ctx {
     mlh::DevBuf stdsort;               // scratch of device_std_sort_by_key
     void *vox_order_host = nullptr; // pinned staging of that host pass (voxelgrid.hip): [slot n][members n]
     size_t vox_order_host_cap = 0;
-    void *select_host = nullptr; // pinned staging of the good-feature selection (select.hip)
-    size_t select_host_cap = 0;
-    std::vector<char> select_rows;   // the same rows in ordinary (CPU-cached) memory: what the selection loops read
+    void *select_host[2] = {nullptr, nullptr}; // pinned staging of the good-feature selection, per feature kind (select.hip)
+    size_t select_host_cap[2] = {0, 0};
+    std::vector<char> select_rows[2];   // the same rows in ordinary (CPU-cached) memory: what the selection loops read
+    unsigned long long select_seq[2] = {0, 0};  // stream_flag_post after each kind's copies to the host
+    bool select_staged[2] = {false, false};
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };
@@ -380,6 +382,9 @@ inline int *pinned_ints(mlh_ctx *ctx)
 // costs tens -- a mapper frame has three such read-backs (fused cloud sizes, thinned record counts, feature counts). Falls back to the blocking call after
 // 200 ms (a profiler, a fault). capi.hip has the definition.
 hipError_t stream_wait_spin(mlh_ctx *ctx);
+// the two halves of it: post a marker behind what is enqueued now; wait for a posted marker later
+hipError_t stream_flag_post(mlh_ctx *ctx, unsigned long long *seq_out);
+hipError_t stream_flag_wait(mlh_ctx *ctx, unsigned long long seq);
 // *out <- one device int, through the pinned block (a pageable landing place costs a staging hop); waits for the stream
 inline hipError_t read_back_int(mlh_ctx *ctx, const void *dev, int *out)
 {
@@ -453,6 +458,10 @@ int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx
 namespace mlh {
 int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
+// its two halves: the dense pass + copies to the host, enqueued (no wait); the selection loop on the copied rows, flags sent back (no wait)
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_dis, float min_plane_dis);
+int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out, double H[36],
+                        uint8_t *matched_out);
 // solver.hip
 int reduce_only_launch(mlh_ctx *ctx, int to_ce);
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot);

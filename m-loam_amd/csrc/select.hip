@@ -53,7 +53,7 @@ double logdet_cholesky6(const double A[36])
     return 2.0 * ld;
 }
 
-inline size_t draw(std::mt19937 &rng, size_t lo, size_t hi)
+__attribute__((always_inline)) inline size_t draw(std::mt19937 &rng, size_t lo, size_t hi)
 {
     std::uniform_int_distribution<size_t> d(lo, hi);   // RandomGeneratorInt<size_t>::geneRandUniform re-creates the distribution per draw
     return d(rng);
@@ -166,8 +166,8 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
         for (int k = 0; k < 36; ++k) { nh += H[k] * H[k]; ni += Hinv[k] * Hinv[k]; }
         replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh) * std::sqrt(ni));
     }
-    auto exact_score = [&](size_t q) { double Ht[36]; std::copy(H, H + 36, Ht); rank1_update(Ht, R.jaco(q)); return logdet_cholesky6(Ht); };
-    auto quad = [&](const double *j, double *Hj) {
+    auto exact_score = [&](size_t q) __attribute__((noinline)) { double Ht[36]; std::copy(H, H + 36, Ht); rank1_update(Ht, R.jaco(q)); return logdet_cholesky6(Ht); };
+    auto quad = [&](const double *j, double *Hj) __attribute__((always_inline)) {   // (left out of line, the loop ran ~15 % slower)
         double q = 0.0;
         for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Hinv[r * 6 + c] * j[c]; Hj[r] = t; q += j[r] * t; }
         return q;
@@ -226,12 +226,11 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
                     // by the reference's own logdet arithmetic. Frobenius norms: cond_2 <= ||H||_F ||H^-1||_F.
                     double nh = 0.0, ni = 0.0;
                     for (int k = 0; k < 36; ++k) { nh += H[k] * H[k]; ni += Hinv[k] * Hinv[k]; }
-                    const double kappa = std::sqrt(nh) * std::sqrt(ni);
-                    if (kappa > 1e5 || (sel.size() & 255) == 0) {
+                    if (nh * ni > 1e10 || (sel.size() & 255) == 0) {     // kappa = sqrt(nh ni) > 1e5
                         have_inv = spd_inverse6(H, Hinv);       // refresh: keeps the update's rounding from accumulating
                         if (have_inv) { ni = 0.0; for (int k = 0; k < 36; ++k) ni += Hinv[k] * Hinv[k]; }
                     }
-                    replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh) * std::sqrt(ni));
+                    replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh * ni));
                 }
                 break;
             }
@@ -242,13 +241,11 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
 
 }  // namespace
 
-// One goodFeatureMatching call. The device-side solver state must already hold the pose (SolverState::x).
-int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
-                        float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out)
+// One goodFeatureMatching call, in two halves. The device-side solver state must already hold the pose (SolverState::x).
+// Stage: the dense pass of one kind and the copies of its rows into that kind's pinned block, enqueued; a marker behind them.
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_dis, float min_plane_dis)
 {
     FeatSet &f = ctx->feat[kind];
-    static const bool timing = std::getenv("MLH_SEL_TIMING") != nullptr;
-    const auto tc0 = std::chrono::steady_clock::now();
     MatchArgs a;
     a.kind_mask = 1 << kind;
     a.flags = MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS;   // extractCov(point) weight, rows not loss-corrected (lidar_mapper.h:162-164)
@@ -256,31 +253,47 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     a.huber_delta = 0.0; a.dense = true; a.pose_sel = 0;
     int rc = match_launch(ctx, a);
     if (rc) return rc;
-    Rows R;
     const size_t m = size_t(f.m);
-    // pinned staging (grow-only, owned by the context): [Corr m][J 6m][pts m]
+    // pinned staging (grow-only, owned by the context, one block per kind): [Corr m][J 6m][pts m]
     const size_t off_j = sizeof(Corr) * m, off_p = off_j + sizeof(double) * 6 * m, need = off_p + sizeof(float4) * m;
-    if (need > ctx->select_host_cap) {
-        if (ctx->select_host) (void)hipHostFree(ctx->select_host);
-        ctx->select_host = nullptr; ctx->select_host_cap = 0;
-        MLH_HIP(ctx, hipHostMalloc(&ctx->select_host, need + need / 4, hipHostMallocDefault));
-        ctx->select_host_cap = need + need / 4;
+    if (need > ctx->select_host_cap[kind]) {
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a copy of an earlier call may still be reading the old block
+        if (ctx->select_host[kind]) (void)hipHostFree(ctx->select_host[kind]);
+        ctx->select_host[kind] = nullptr; ctx->select_host_cap[kind] = 0;
+        MLH_HIP(ctx, hipHostMalloc(&ctx->select_host[kind], need + need / 4, hipHostMallocDefault));
+        ctx->select_host_cap[kind] = need + need / 4;
     }
-    char *hb = static_cast<char *>(ctx->select_host);
-    R.corr = reinterpret_cast<Corr *>(hb); R.J = reinterpret_cast<const double *>(hb + off_j); R.pts = reinterpret_cast<const float4 *>(hb + off_p);
-    R.m = m;
+    char *hb = static_cast<char *>(ctx->select_host[kind]);
     MLH_HIP(ctx, hipMemcpyAsync(hb, f.corr.p, sizeof(Corr) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_j, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
     if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
-    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    prof_collect(ctx);
+    MLH_HIP(ctx, stream_flag_post(ctx, &ctx->select_seq[kind]));
+    ctx->select_staged[kind] = true;
+    return MLH_OK;
+}
+
+// Finish: wait for that kind's marker, run the selection loop, send the flags back (enqueued: whatever reads them is behind on the stream).
+int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out, double H[36],
+                        uint8_t *matched_out)
+{
+    FeatSet &f = ctx->feat[kind];
+    if (!ctx->select_staged[kind]) return fail(ctx, MLH_ERR_STATE, "good_feature_finish without good_feature_stage");
+    ctx->select_staged[kind] = false;
+    static const bool timing = std::getenv("MLH_SEL_TIMING") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    MLH_HIP(ctx, stream_flag_wait(ctx, ctx->select_seq[kind]));
+    Rows R;
+    const size_t m = size_t(f.m);
+    const size_t off_j = sizeof(Corr) * m, off_p = off_j + sizeof(double) * 6 * m, need = off_p + sizeof(float4) * m;
+    char *hb = static_cast<char *>(ctx->select_host[kind]);
+    R.m = m;
     // The selection loops jump around in these rows (a pool look-up decides which one comes next). Pinned host memory is mapped so that the CPU does not
     // cache it: read in place, every access is a trip to DRAM -- the `rnd` loop, which scores nothing, took 0.6 / 1.0 ms per call that way, 0.12 / 0.28 ms on an
     // ordinary copy; a bulk copy out of the pinned block runs at ~30 GB/s (+33 us per call). So: DMA into the pinned block, one memcpy into the context's
     // cacheable block, loops on that (config 5, gd_fix: 7.2 -> 4.05 ms per frame; profiles/r03_gfbench.txt).
-    ctx->select_rows.resize(need);
-    std::memcpy(ctx->select_rows.data(), hb, method == MLH_GF_FPS ? need : off_p);
-    char *cb = ctx->select_rows.data();
+    ctx->select_rows[kind].resize(need);
+    std::memcpy(ctx->select_rows[kind].data(), hb, method == MLH_GF_FPS ? need : off_p);
+    char *cb = ctx->select_rows[kind].data();
     R.corr = reinterpret_cast<Corr *>(cb); R.J = reinterpret_cast<const double *>(cb + off_j); R.pts = reinterpret_cast<const float4 *>(cb + off_p);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
 
@@ -303,15 +316,26 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         for (size_t i : sel) R.corr[i].valid = 1;
         std::memcpy(hb, R.corr, sizeof(Corr) * m);                  // back through the pinned block (sequential writes: the mapping is fine for those)
         MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, hb, sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
-        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     sel_out.assign(sel.begin(), sel.end());
     if (timing) {
         const auto tc3 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
-        std::fprintf(stderr, "[good_feature_select] kind %d m %zu: match pass + copies to the host %.0f us | selection loop %.0f us (%zu picks) | flags back to the device %.0f us\n", kind, m,
+        std::fprintf(stderr, "[good_feature_finish] kind %d m %zu: wait for the rows + copy out of the pinned block %.0f us | selection loop %.0f us (%zu picks) | flags enqueued %.0f us\n", kind, m,
                      us(tc0, tc1), us(tc1, tc2), sel.size(), us(tc2, tc3));
     }
+    return MLH_OK;
+}
+
+// Both halves back to back, and the stream drained: what mlh_good_feature_matching (one kind, caller reads the selection) uses.
+int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
+                        float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out)
+{
+    int rc = good_feature_stage(ctx, kind, method, min_match_sq_dis, min_plane_dis);
+    if (rc) return rc;
+    if ((rc = good_feature_finish(ctx, kind, method, ratio, rng, sel_out, H, matched_out))) return rc;
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
     return MLH_OK;
 }
 
