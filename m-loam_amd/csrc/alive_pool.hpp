@@ -5,65 +5,69 @@
 #include <cstddef>
 #include <cstdint>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace mlh {
 
 // The reference keeps the not-yet-consumed feature slots in a std::vector it erases from (all_feature_idx, lidar_mapper.h:350,
 // 531-553): position j of that vector is always the (j+1)-th surviving ORIGINAL index, because it starts as 0..M-1 and only ever
 // loses elements. The same three questions -- element at position j, position of an element (the reference's std::find), erase --
-// are answered here from one "alive" bit per slot under a 16-ary tree of populations, with identical results. Each tree node's sixteen
-// children keep their EXCLUSIVE prefix sums side by side (one 64-byte line): going down a level is "how many of the fifteen prefixes are
-// <= k" -- sixteen independent compares the compiler turns into four SSE2 ones, no branch (the outcome is a coin flip) -- and an erase is
-// "subtract one from the siblings to the right", a masked vector subtract per level. The draw loops are one dependent chain per draw --
-// draw, look up, erase -- so the look-up's latency is the loop's speed: a Fenwick tree over single slots with a data-dependent branch per
-// level ran at ~170 ns per draw, a branch-free Fenwick tree over the words (eight dependent loads for 12 k slots) at ~30, this (two levels
-// for 12 k slots, three up to 262 k) at roughly half of that. The rank search inside the word is unchanged.
+// are answered here, with identical results, from a tree of EXCLUSIVE PREFIX COUNTS kept side by side per node: a leaf is 64 slots with
+// one byte each (how many survivors to the left inside the leaf: one 64-byte line), above it groups of sixteen leaves with int16
+// prefixes, above those groups of sixteen with int32 prefixes. Prefixes never decrease from left to right, so "which child holds the
+// k-th survivor" is "where does the prefix first exceed k": a vector compare, a move-mask and a count-trailing-zeros per level (SSE2, which
+// every x86-64 has; plain loops otherwise), no branch -- the outcome is a coin flip -- and an erase is "subtract one from everything to
+// the right", a compare against the lane numbers added to the line. The draw loops are one dependent chain per draw -- draw, look up,
+// erase -- so the look-up's cost is the loop's speed: a Fenwick tree over single slots with a data-dependent branch per level ran at
+// ~170 ns per draw, a branch-free Fenwick tree over 64-bit words at ~30, a 16-ary tree over the words with a SWAR rank search inside the
+// word at ~20; this form needs three dependent loads for 12 k slots and no arithmetic rank search (scripts/exp/select_loop_bench.sh).
 class AlivePool {
 public:
-    struct Select8 {                                               // at[v][r] = position of the r-th (0-based) set bit of the byte v
-        uint8_t at[256][8];
-        Select8()
-        {
-            for (int v = 0; v < 256; ++v) {
-                int r = 0;
-                for (int b = 0; b < 8; ++b) if (v >> b & 1) at[v][r++] = uint8_t(b);
-                for (; r < 8; ++r) at[v][r] = 0;
-            }
-        }
-    };
-    static inline const Select8 kSelect8{};
-    struct After {                                                 // m[c][s] = 1 for the siblings to the right of child c
-        int32_t m[16][16];
-        After() { for (int c = 0; c < 16; ++c) for (int s = 0; s < 16; ++s) m[c][s] = s > c; }
-    };
-    static inline const After kAfter{};
-    explicit AlivePool(size_t n) : alive_(n), nw_((n + 63) / 64)
+    explicit AlivePool(size_t n) : alive_(n), nl_((n + 63) / 64 ? (n + 63) / 64 : 1)
     {
-        bits_.assign(nw_ + 1, 0);
-        for (size_t w = 0; w < nw_; ++w) bits_[w] = (w * 64 + 64 <= n) ? ~uint64_t(0) : ((uint64_t(1) << (n - w * 64)) - 1);
-        // level 0: one node per word; every level above: one node per group of sixteen below; siblings that do not exist hold kNever
-        std::vector<int32_t> cnt(nw_ ? nw_ : 1, 0);
-        for (size_t w = 0; w < nw_; ++w) cnt[w] = int32_t(popcount64(bits_[w]));
-        size_t nodes = cnt.size();
+        bits_.assign(nl_, 0);
+        leaf_.resize(nl_);
+        std::vector<int32_t> cnt(nl_, 0);
+        for (size_t l = 0; l < nl_; ++l) {
+            int run = 0;
+            for (size_t s = 0; s < 64; ++s) {
+                leaf_[l].pre[s] = uint8_t(run);
+                if (l * 64 + s < n) { bits_[l] |= uint64_t(1) << s; ++run; }
+            }
+            cnt[l] = run;
+        }
+        // level 1: sixteen leaves per group, int16 prefixes
+        const size_t g1 = (nl_ + 15) / 16;
+        l1_.resize(g1);
+        std::vector<int32_t> up(g1);
+        for (size_t g = 0; g < g1; ++g) {
+            int32_t run = 0;
+            for (size_t s = 0; s < 16; ++s) {
+                if (g * 16 + s < nl_) { l1_[g].pre[s] = int16_t(run); run += cnt[g * 16 + s]; } else l1_[g].pre[s] = 0x7fff;
+            }
+            up[g] = run;
+        }
+        cnt.swap(up);
+        // levels above: sixteen children per group, int32 prefixes
+        size_t nodes = g1;
         levels_ = 0;
-        do {
+        while (nodes > 1) {
             const size_t groups = (nodes + 15) / 16;
             off_[levels_] = pre_.size();
             pre_.resize(pre_.size() + groups * 16, kNever);
-            std::vector<int32_t> up(groups);
+            std::vector<int32_t> u2(groups);
             for (size_t g = 0; g < groups; ++g) {
                 int32_t run = 0;
                 for (size_t s = 0; s < 16 && g * 16 + s < nodes; ++s) { pre_[off_[levels_] + g * 16 + s] = run; run += cnt[g * 16 + s]; }
-                up[g] = run;
+                u2[g] = run;
             }
-            cnt.swap(up);
-            nodes = groups;
-            ++levels_;
-        } while (nodes > 1);
+            cnt.swap(u2); nodes = groups; ++levels_;
+        }
     }
     size_t size() const { return alive_; }
     bool empty() const { return alive_ == 0; }
-    // original index of the element at position j (0-based) among the survivors
     __attribute__((always_inline)) size_t at(size_t j) const
     {
         int32_t k = int32_t(j);
@@ -71,49 +75,87 @@ public:
         for (int l = levels_ - 1; l >= 0; --l) {
             const int32_t *p = &pre_[off_[l] + node * 16];
             int c = 0;
-            for (int s = 1; s < 16; ++s) c += (p[s] <= k);           // prefixes are non-decreasing: the last child whose prefix is <= k (empty children are stepped over)
+            for (int s = 1; s < 16; ++s) c += (p[s] <= k);
             k -= p[c];
             node = node * 16 + size_t(c);
         }
-        const size_t pos = node;
-        // rank search inside the word: per-byte populations (SWAR), their running sums by one multiply, the first byte whose running sum
-        // exceeds k by a carry-free byte-wise compare, the bit inside that byte from a 2 KB table
-        const uint64_t w = bits_[pos];
-        uint64_t c = w - ((w >> 1) & 0x5555555555555555ull);
-        c = (c & 0x3333333333333333ull) + ((c >> 2) & 0x3333333333333333ull);
-        c = (c + (c >> 4)) & 0x0f0f0f0f0f0f0f0full;
-        const uint64_t run = c * 0x0101010101010101ull;               // byte i: population of bytes 0..i (<= 64)
-        const uint64_t over = ((run | 0x8080808080808080ull) - (uint64_t(k) + 1) * 0x0101010101010101ull) & 0x8080808080808080ull;
-        const unsigned byte = unsigned(__builtin_ctzll(over)) >> 3;   // first byte with run > k (exists: k < the word's population)
-        const unsigned before = unsigned(((run << 8) >> (8 * byte)) & 0xff);
-        const size_t bit = 8 * byte + kSelect8.at[(w >> (8 * byte)) & 0xff][unsigned(k) - before];
-        return pos * 64 + bit;
+        {   // level 1
+            const int16_t *p = l1_[node].pre;
+#if defined(__SSE2__)
+            const __m128i kk = _mm_set1_epi16(short(k));
+            const __m128i g0 = _mm_cmpgt_epi16(_mm_load_si128(reinterpret_cast<const __m128i *>(p)), kk);
+            const __m128i g1 = _mm_cmpgt_epi16(_mm_load_si128(reinterpret_cast<const __m128i *>(p + 8)), kk);
+            const unsigned m = unsigned(_mm_movemask_epi8(_mm_packs_epi16(g0, g1)));
+            const int c = (m ? __builtin_ctz(m) : 16) - 1;
+#else
+            int c = -1; for (int s = 0; s < 16; ++s) c += (p[s] <= k);
+#endif
+            k -= p[c];
+            node = node * 16 + size_t(c);
+        }
+        const uint8_t *p = leaf_[node].pre;
+#if defined(__SSE2__)
+        const __m128i kk = _mm_set1_epi8(char(k));
+        const uint64_t m0 = unsigned(_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_load_si128(reinterpret_cast<const __m128i *>(p)), kk)));
+        const uint64_t m1 = unsigned(_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_load_si128(reinterpret_cast<const __m128i *>(p + 16)), kk)));
+        const uint64_t m2 = unsigned(_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_load_si128(reinterpret_cast<const __m128i *>(p + 32)), kk)));
+        const uint64_t m3 = unsigned(_mm_movemask_epi8(_mm_cmpgt_epi8(_mm_load_si128(reinterpret_cast<const __m128i *>(p + 48)), kk)));
+        const uint64_t m = m0 | (m1 << 16) | (m2 << 32) | (m3 << 48);
+        const int c = (m ? __builtin_ctzll(m) : 64) - 1;
+#else
+        int c = -1; for (int s = 0; s < 64; ++s) c += (p[s] <= k);
+#endif
+        return node * 64 + size_t(c);
     }
     bool contains(size_t idx) const { return (bits_[idx >> 6] >> (idx & 63)) & 1; }
     __attribute__((always_inline)) void erase_index(size_t idx)
     {
-        bits_[idx >> 6] &= ~(uint64_t(1) << (idx & 63));
+        const size_t lf = idx >> 6;
+        bits_[lf] &= ~(uint64_t(1) << (idx & 63));
         --alive_;
-        size_t node = idx >> 6;
+        {
+            uint8_t *p = leaf_[lf].pre;
+#if defined(__SSE2__)
+            const __m128i sl = _mm_set1_epi8(char(idx & 63));
+            const __m128i i0 = _mm_setr_epi8(0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15), st = _mm_set1_epi8(16);
+            __m128i it = i0;
+            for (int r = 0; r < 4; ++r) {
+                __m128i *q = reinterpret_cast<__m128i *>(p + 16 * r);
+                _mm_store_si128(q, _mm_add_epi8(_mm_load_si128(q), _mm_cmpgt_epi8(it, sl)));
+                it = _mm_add_epi8(it, st);
+            }
+#else
+            for (size_t s = (idx & 63) + 1; s < 64; ++s) --p[s];
+#endif
+        }
+        {
+            int16_t *p = l1_[lf >> 4].pre;
+#if defined(__SSE2__)
+            const __m128i ch = _mm_set1_epi16(short(lf & 15));
+            __m128i *q0 = reinterpret_cast<__m128i *>(p), *q1 = reinterpret_cast<__m128i *>(p + 8);
+            _mm_store_si128(q0, _mm_add_epi16(_mm_load_si128(q0), _mm_cmpgt_epi16(_mm_setr_epi16(0,1,2,3,4,5,6,7), ch)));
+            _mm_store_si128(q1, _mm_add_epi16(_mm_load_si128(q1), _mm_cmpgt_epi16(_mm_setr_epi16(8,9,10,11,12,13,14,15), ch)));
+#else
+            for (size_t s = (lf & 15) + 1; s < 16; ++s) --p[s];
+#endif
+        }
+        size_t node = lf >> 4;
         for (int l = 0; l < levels_; ++l) {
             int32_t *p = &pre_[off_[l] + (node & ~size_t(15))];
-            const int32_t *m = kAfter.m[node & 15];
-            for (int s = 0; s < 16; ++s) p[s] -= m[s];
+            const int c = int(node & 15);
+            for (int s = 0; s < 16; ++s) p[s] -= (s > c);
             node >>= 4;
         }
     }
 private:
-    static constexpr int32_t kNever = 0x3fffffff;                  // never <= k, and still not after every slot has been erased
-    static inline unsigned popcount64(uint64_t x)                  // SWAR: the baseline x86-64 target has no popcnt instruction
-    {
-        x = x - ((x >> 1) & 0x5555555555555555ull);
-        x = (x & 0x3333333333333333ull) + ((x >> 2) & 0x3333333333333333ull);
-        x = (x + (x >> 4)) & 0x0f0f0f0f0f0f0f0full;
-        return unsigned((x * 0x0101010101010101ull) >> 56);
-    }
-    size_t alive_, nw_;
+    static constexpr int32_t kNever = 0x3fffffff;
+    struct alignas(64) Leaf { uint8_t pre[64]; };
+    struct alignas(32) L1 { int16_t pre[16]; };
+    size_t alive_, nl_;
     std::vector<uint64_t> bits_;
-    std::vector<int32_t> pre_;      // all levels, one after the other (off_[l]), sixteen exclusive prefix sums per node group
+    std::vector<Leaf> leaf_;
+    std::vector<L1> l1_;
+    std::vector<int32_t> pre_;
     size_t off_[16] = {0};
     int levels_ = 0;
 };

@@ -344,7 +344,7 @@ void mlh_destroy(mlh_ctx *ctx)
             m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); m.occ.release();
         }
         FeatSet &f = ctx->feat[k];
-        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release();
+        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release(); f.flag8.release();
     }
     ScanBuf &s = ctx->scan;
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
@@ -1343,6 +1343,9 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     // one GPU, every feature used (wo_gf): the LM begin rides in the match launch and every LM step in its linearise launch -- an outer
     // iteration is 2 + (LM iterations) launches, the pose goes in with the first launch's kernel arguments
     const bool fused = (!distributed(ctx) || ctx->p2p.active) && opts->gf_method == MLH_GF_WO;      // (mailbox communicator: the exchange rides in the finish)
+    // with a feature selection (one GPU): the dense passes and the selection come first, then the LM begin rides in the launch that evaluates the
+    // selected rows and every LM step in its linearise launch, as above
+    const bool fused_lm = fused || !distributed(ctx);
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
     // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)
@@ -1371,15 +1374,17 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
                 for (int i = 0; i < 36; ++i) Hsel[i] = (i % 7 == 0) ? 1e-6 : 0.0;
                 if ((rc = good_feature_finish(ctx, kind, opts->gf_method, opts->gf_ratio, rng, sel, Hsel, nullptr))) return rc;
             }
-            if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
+            MatchArgs a = args_from_opts(opts, 3, 0);
+            if (fused_lm) { a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0; }
+            if ((rc = linearize_launch(ctx, a))) return rc;
         }
-        if (!fused && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
+        if (!fused_lm && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         for (int it = 0, j_end = 0; it < opts->max_lm_iterations; it = j_end) {
             j_end = std::min(it + (it == 0 ? first_chunk : next_chunk), opts->max_lm_iterations);
             unsigned long long seq = 0;
             for (int j = it; j < j_end; ++j) {
                 MatchArgs a = args_from_opts(opts, 3, 1);
-                if (fused) {
+                if (fused_lm) {
                     a.finish = 4; a.lm_max_it = opts->max_lm_iterations;
                     if (j == j_end - 1) {                   // the chunk's last launch publishes pose + `done` itself (no publication launch)
                         if ((rc = publish_slot(ctx, &a.publish, &seq))) return rc;
@@ -1387,16 +1392,16 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
                     }
                 }
                 if ((rc = linearize_launch(ctx, a))) return rc;
-                if (!fused && (rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+                if (!fused_lm && (rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
             }
             HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
-            if (fused) { if ((rc = wait_published(ctx, seq, hp))) return rc; last_hp = hp; have_hp = true; }
+            if (fused_lm) { if ((rc = wait_published(ctx, seq, hp))) return rc; last_hp = hp; have_hp = true; }
             else if ((rc = fetch_published(ctx, hp))) return rc;
             if (hp.done) break;
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
     }
-    if (fused && !stats && have_hp) {
+    if (fused_lm && !stats && have_hp) {
         if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
         for (int i = 0; i < 7; ++i) pose_inout[i] = last_hp.x[i];
         return MLH_OK;

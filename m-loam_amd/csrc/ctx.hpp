@@ -146,6 +146,7 @@ struct FeatSet {
     DevBuf corr;       // Corr per feature
     DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
+    DevBuf flag8;      // one byte per feature: Corr::valid on the way to the host, the selection's verdict on the way back (select.hip)
     int m = 0;             // feature slots (real + padding between pose blocks)
     int n_blocks = 1;
     int blk_start[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

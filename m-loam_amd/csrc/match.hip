@@ -659,7 +659,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     MLH_STAGE(gtile, 2);
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
     MLH_STAGE(gtile, 3);
-    if constexpr (LM) { if (P.finish == 4) fused_gn_finish<true>(P, total); }
+    if constexpr (LM) { if (P.finish == 3 || P.finish == 4) fused_gn_finish<true>(P, total); }   // 3: the LM begin on rows a selection kept (scan2map with good-feature selection)
     MLH_STAGE(gtile, 4);
 }
 
@@ -843,7 +843,7 @@ int linearize_launch(mlh_ctx *ctx, const MatchArgs &a)
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
-    if (P.finish == 4) launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<true>, grid_b, P);
+    if (P.finish == 3 || P.finish == 4) launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<true>, grid_b, P);
     else launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

@@ -12,18 +12,34 @@
 #include <numeric>
 #include <queue>
 #include <random>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace mlh {
 
 namespace {
 
-struct Rows {               // per-feature results of the GPU pass, in the context's pinned staging block
-    Corr *corr = nullptr;
+// What the selection loops need from a correspondence record is its `valid` word, and what they send back is one verdict per feature: both cross the
+// bus as bytes (a Corr is 32 B; at 11-12 k features and four selections per frame the records were a third of the traffic and two host-side block copies).
+__global__ void pack_valid_kernel(const Corr *__restrict__ corr, int m, uint8_t *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = corr[i].valid != 0;
+}
+__global__ void apply_keep_kernel(Corr *__restrict__ corr, int m, const uint8_t *__restrict__ keep)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) corr[i].valid = keep[i];
+}
+
+struct Rows {               // per-feature results of the GPU pass, copied out of the context's pinned staging block
+    const uint8_t *valid = nullptr;   // Corr::valid != 0
     const double *J = nullptr;  // m x 6
     const float4 *pts = nullptr;
     size_t m = 0;
     size_t size() const { return m; }
-    bool matched(size_t i) const { return corr[i].valid != 0; }
+    bool matched(size_t i) const { return valid[i] != 0; }
     const double *jaco(size_t i) const { return &J[i * 6]; }
 };
 
@@ -167,10 +183,27 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
         replay_tol = std::max(1e-10, 64.0 * 2.220446049250313e-16 * std::sqrt(nh) * std::sqrt(ni));
     }
     auto exact_score = [&](size_t q) __attribute__((noinline)) { double Ht[36]; std::copy(H, H + 36, Ht); rank1_update(Ht, R.jaco(q)); return logdet_cholesky6(Ht); };
+    // q = j H^-1 j^T, and H^-1 j^T on the side. H^-1 is symmetric to the bit (spd_inverse6 and the rank-1 update below both are), so with SSE2 the product is
+    // accumulated a COLUMN at a time, two rows per register: every row's sum still adds its six terms in the order c = 0..5 (same bits as the scalar loop)
     auto quad = [&](const double *j, double *Hj) __attribute__((always_inline)) {   // (left out of line, the loop ran ~15 % slower)
+#if defined(__SSE2__)
+        __m128d jc = _mm_set1_pd(j[0]);
+        __m128d a0 = _mm_mul_pd(_mm_loadu_pd(Hinv), jc), a1 = _mm_mul_pd(_mm_loadu_pd(Hinv + 2), jc), a2 = _mm_mul_pd(_mm_loadu_pd(Hinv + 4), jc);
+        for (int c = 1; c < 6; ++c) {
+            jc = _mm_set1_pd(j[c]);
+            a0 = _mm_add_pd(a0, _mm_mul_pd(_mm_loadu_pd(Hinv + 6 * c), jc));
+            a1 = _mm_add_pd(a1, _mm_mul_pd(_mm_loadu_pd(Hinv + 6 * c + 2), jc));
+            a2 = _mm_add_pd(a2, _mm_mul_pd(_mm_loadu_pd(Hinv + 6 * c + 4), jc));
+        }
+        _mm_storeu_pd(Hj, a0); _mm_storeu_pd(Hj + 2, a1); _mm_storeu_pd(Hj + 4, a2);
+        double q = 0.0;
+        for (int r = 0; r < 6; ++r) q += j[r] * Hj[r];
+        return q;
+#else
         double q = 0.0;
         for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Hinv[r * 6 + c] * j[c]; Hj[r] = t; q += j[r] * t; }
         return q;
+#endif
     };
     struct Cand { size_t idx; double q; };
     std::vector<Cand> subset_c;
@@ -254,18 +287,22 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_di
     int rc = match_launch(ctx, a);
     if (rc) return rc;
     const size_t m = size_t(f.m);
-    // pinned staging (grow-only, owned by the context, one block per kind): [Corr m][J 6m][pts m]
-    const size_t off_j = sizeof(Corr) * m, off_p = off_j + sizeof(double) * 6 * m, need = off_p + sizeof(float4) * m;
+    // pinned staging (grow-only, owned by the context, one block per kind): [J 6m][pts m][valid m bytes, padded][keep m bytes]
+    const size_t mp = (m + 63) & ~size_t(63);
+    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp, need = off_k + mp;
     if (need > ctx->select_host_cap[kind]) {
-        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a copy of an earlier call may still be reading the old block
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a copy of an earlier call may still be using the old block
         if (ctx->select_host[kind]) (void)hipHostFree(ctx->select_host[kind]);
         ctx->select_host[kind] = nullptr; ctx->select_host_cap[kind] = 0;
         MLH_HIP(ctx, hipHostMalloc(&ctx->select_host[kind], need + need / 4, hipHostMallocDefault));
         ctx->select_host_cap[kind] = need + need / 4;
     }
+    MLH_HIP(ctx, f.flag8.ensure(mp));
+    hipLaunchKernelGGL(pack_valid_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>());
+    MLH_HIP(ctx, hipGetLastError());
     char *hb = static_cast<char *>(ctx->select_host[kind]);
-    MLH_HIP(ctx, hipMemcpyAsync(hb, f.corr.p, sizeof(Corr) * m, hipMemcpyDeviceToHost, ctx->stream));
-    MLH_HIP(ctx, hipMemcpyAsync(hb + off_j, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
     if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, stream_flag_post(ctx, &ctx->select_seq[kind]));
     ctx->select_staged[kind] = true;
@@ -284,17 +321,19 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     MLH_HIP(ctx, stream_flag_wait(ctx, ctx->select_seq[kind]));
     Rows R;
     const size_t m = size_t(f.m);
-    const size_t off_j = sizeof(Corr) * m, off_p = off_j + sizeof(double) * 6 * m, need = off_p + sizeof(float4) * m;
+    const size_t mp = (m + 63) & ~size_t(63);
+    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp;
     char *hb = static_cast<char *>(ctx->select_host[kind]);
     R.m = m;
     // The selection loops jump around in these rows (a pool look-up decides which one comes next). Pinned host memory is mapped so that the CPU does not
     // cache it: read in place, every access is a trip to DRAM -- the `rnd` loop, which scores nothing, took 0.6 / 1.0 ms per call that way, 0.12 / 0.28 ms on an
-    // ordinary copy; a bulk copy out of the pinned block runs at ~30 GB/s (+33 us per call). So: DMA into the pinned block, one memcpy into the context's
+    // ordinary copy; a bulk copy out of the pinned block runs at ~30 GB/s. So: DMA into the pinned block, one memcpy into the context's
     // cacheable block, loops on that (config 5, gd_fix: 7.2 -> 4.05 ms per frame; profiles/r03_gfbench.txt).
-    ctx->select_rows[kind].resize(need);
-    std::memcpy(ctx->select_rows[kind].data(), hb, method == MLH_GF_FPS ? need : off_p);
+    ctx->select_rows[kind].resize(off_k);
     char *cb = ctx->select_rows[kind].data();
-    R.corr = reinterpret_cast<Corr *>(cb); R.J = reinterpret_cast<const double *>(cb + off_j); R.pts = reinterpret_cast<const float4 *>(cb + off_p);
+    std::memcpy(cb, hb, method == MLH_GF_FPS ? off_v : off_p);
+    std::memcpy(cb + off_v, hb + off_v, m);
+    R.valid = reinterpret_cast<const uint8_t *>(cb + off_v); R.J = reinterpret_cast<const double *>(cb); R.pts = reinterpret_cast<const float4 *>(cb + off_p);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
 
     const auto tc1 = std::chrono::steady_clock::now();
@@ -310,12 +349,14 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         default: return fail(ctx, MLH_ERR_INVALID, "unknown gf_method");
     }
     const auto tc2 = std::chrono::steady_clock::now();
-    // keep only the selected correspondences valid on the device
+    // keep only the selected correspondences valid on the device: one verdict byte per feature goes back, a launch writes them into the records
     if (method != MLH_GF_WO) {
-        for (size_t i = 0; i < m; ++i) R.corr[i].valid = 0;
-        for (size_t i : sel) R.corr[i].valid = 1;
-        std::memcpy(hb, R.corr, sizeof(Corr) * m);                  // back through the pinned block (sequential writes: the mapping is fine for those)
-        MLH_HIP(ctx, hipMemcpyAsync(f.corr.p, hb, sizeof(Corr) * m, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t *keep = reinterpret_cast<uint8_t *>(hb + off_k);     // (sequential writes into the pinned block: the mapping is fine for those)
+        std::memset(keep, 0, m);
+        for (size_t i : sel) keep[i] = 1;
+        MLH_HIP(ctx, hipMemcpyAsync(f.flag8.p, keep, m, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>());
+        MLH_HIP(ctx, hipGetLastError());
     }
     sel_out.assign(sel.begin(), sel.end());
     if (timing) {
