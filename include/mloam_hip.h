@@ -300,7 +300,11 @@ int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const vo
  * within a radius of the PREDICTED pose of frame k + 1, which carries frame k's map-to-odometry correction (cpp:145-160). A caller that stages this early selects
  * with the correction of frame k - 1 and re-checks the selection when frame k's pose arrives (a radius test over the keyframe positions on the host); the set
  * changes only when a keyframe sits within the change of the correction (sub-centimetre) of the radius, and then the frame is staged and solved again
- * synchronously. INTEGRATION.md section 2 spells the loop out. Without a solve in flight: mlh_map_set_pair. */
+ * synchronously. INTEGRATION.md section 2 spells the loop out.
+ * Without a solve in flight and with device-resident clouds the same call overlaps the index build with whatever the main stream is doing that reads no map --
+ * a frame's own front end: call it after the frame's upload / extraction / fusion have been enqueued and before the first call that waits for them
+ * (mlh_fused_cloud); the host then waits for the build instead of for the front end, and scan2MapOptimization finds the index ready (the local map is made of
+ * earlier keyframes: it does not depend on the scan being processed). Without a solve in flight and with host-resident clouds: mlh_map_set_pair. */
 int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                                 float min_match_sq_dis, int mem);
 int mlh_map_rebuild(mlh_ctx *ctx, int kind);

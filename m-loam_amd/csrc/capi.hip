@@ -618,6 +618,7 @@ int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], 
     a.kind_mask = 1 << kind; a.flags = flags & MLH_FLAG_CHECK_FOV; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
     a.huber_delta = 0.0; a.cov_measurement_trace = 0.0; a.dense = false; a.pose_sel = 0; a.k_neigh[0] = k_neigh;
     if ((rc = match_launch(ctx, a))) return rc;          // correspondences (validity + f32 coefficients) stay in HBM
+    ctx->map_read_unsynced = true;                       // (nothing here waits for that launch: see mlh_map_set_pair_overlapped)
     return pure_odom_add_matches(ctx, kind, frame_idx, ext_idx);
 }
 
@@ -726,15 +727,21 @@ int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const vo
     return map_set_impl(ctx, 2, kinds, pts, n, stride_bytes, min_match_sq_dis, mem);
 }
 
-// The next frame's maps staged WHILE a submitted solve (mlh_gn_solve_begin) still runs on the current ones: pack + fit check + index build go to the
-// context's second stream and into the other map set; the main stream gets a wait on their completion behind whatever is already queued there, and the
-// context switches to the new set, so every launch enqueued after this call reads it. Without a solve in flight it behaves like mlh_map_set_pair.
+// The next maps staged WHILE the main stream is busy with something that does not read a map: a submitted solve (mlh_gn_solve_begin) still running on the
+// current set, or -- no solve in flight, device-resident clouds -- the frame's own front end (upload, extractCloud, fusion, thinning: the local map comes from
+// earlier keyframes and does not wait for the scan). Pack + fit check + index build go to the context's second stream and into the other map set; the call
+// returns when they are complete (the host waits, the main stream does not) and the context has switched to the new set, so every launch enqueued after this
+// call reads it. With host-resident clouds and no solve in flight it behaves like mlh_map_set_pair (the upload staging buffer is shared with the main stream).
 int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                                 float min_match_sq_dis, int mem)
 {
     if (!ctx) return MLH_ERR_INVALID;
-    if (!ctx->solve_pending) return mlh_map_set_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, min_match_sq_dis, mem);
+    if (!ctx->solve_pending && mem != MLH_MEM_DEVICE) return mlh_map_set_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, min_match_sq_dis, mem);
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->solve_pending && ctx->map_read_unsynced) {     // the one map-reading entry point that returns with its launch still queued: drain before a set is rewritten
+        MLH_HIP(ctx, stream_wait_spin(ctx));
+        ctx->map_read_unsynced = false;
+    }
     if (!ctx->stream2) {
         // The staging stream may use half of the compute units (CU mask words 0-3): its kernels are atomics- / latency-bound and lose ~5 % on 128 CUs, while the
         // solver's launches they run beside lose less to them (step 0.1452 -> 0.1415 ms, three alternations in one gpurun call; every other CU, a quarter of the

@@ -254,6 +254,7 @@ struct mlh_ctx {
     void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
     unsigned long long solve_seq = 0, solve_collected = 0;   // submitted / collected solves (at most two apart)
     bool solve_pending = false;
+    bool map_read_unsynced = false;   // a launch that reads the current map set was enqueued and its call did not wait for it (mlh_pure_odom_add_matches)
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
     void *h_occ = nullptr;   // pinned mirror of the two maps' occupancy totals (grid.hip): {cells, squares} per kind, written behind every index build
     unsigned long long publish_seq = 0;

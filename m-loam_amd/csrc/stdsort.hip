@@ -261,7 +261,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
     bool have = false;
     MLH_SSTAGE(1);
     while (true) {
-        const unsigned long long c_wait = MLH_SCLK();
+        [[maybe_unused]] const unsigned long long c_wait = MLH_SCLK();
         if (!have) {
             if (wg_load(&sh[LQ_REMAINING]) == 0) break;
             int ticket = 0;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             have = true;
         }
         const int size = l - f;
-        const unsigned long long c_part = MLH_SCLK();
+        [[maybe_unused]] const unsigned long long c_part = MLH_SCLK();
         MLH_SACC(7, c_part - c_wait);
         if (d == 0) {                                                 // __partial_sort(first, last, last): sorted for good, no children
             if (size <= 64) ss_heap_sort_wave64(M.keys + f, M.vals + f, size, IntLess());     // in registers (the leftovers of an exhausted budget are short)
@@ -293,7 +293,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
             continue;
         }
         const int cut = ss_wave_partition(M.keys, M.vals, M.lt, M.rt, M.scr + (t >> 6) * 128, f, l, IntLess());
-        const unsigned long long c_book = MLH_SCLK();
+        [[maybe_unused]] const unsigned long long c_book = MLH_SCLK();
         MLH_SACC(size <= 64 ? 0 : (size <= 256 ? 1 : 2), 1);
         MLH_SACC(size <= 64 ? 3 : (size <= 256 ? 4 : 5), c_book - c_part);
         // children: [cut, l) is the library's recursive call, [f, cut) its loop's next trip; both get d - 1

@@ -3,6 +3,7 @@
 // kinds, index rebuild, scan2MapOptimization, pose out. Inputs are the files scripts/framebench.py writes (the bench workload); prints ms per frame by stage.
 //   usage: framebench <dir> [frames]
 #include "../../include/mloam_hip.h"
+#include <hip/hip_runtime_api.h>   // only for the device-resident copy of the local map the second loop stages from
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -46,29 +47,48 @@ int main(int argc, char **argv)
     double pose[7], t_stage[3] = {0, 0, 0};
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    for (int it = -5; it < frames; ++it) {
-        const auto t0 = now();
-        CK(mlh_fuse_reset(ctx));
-        CK(mlh_scan_upload(ctx, pts.data(), 16, 12, n, rings.data(), rings.data() + R, R, MLH_MEM_HOST));
-        CK(mlh_extract_run(ctx));
-        CK(mlh_extract_voxel_run(ctx, 0.2f));
-        for (int i = 0; i < n_lidar; ++i) CK(mlh_fuse_add_rings(ctx, ring_ofs[size_t(i)], ring_ofs[size_t(i) + 1], i, ext.data() + 7 * i));
-        const auto t1 = now();
-        const void *fs = nullptr, *fc = nullptr;
-        int32_t ns = 0, nc = 0, ms_ = 0, mc = 0;
-        CK(mlh_fused_cloud(ctx, MLH_SURF, &fs, &ns));
-        CK(mlh_fused_cloud(ctx, MLH_CORNER, &fc, &nc));
-        CK(mlh_downsample_current_scan_pair(ctx, fs, ns, fc, nc, 16, 12, MLH_MEM_DEVICE, 0.4f, 0.2f, ext.data(), covs.data(), n_lidar, meas.data(), meta[1], 0.6, &ms_, &mc));
-        const auto t2 = now();
-        CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
-        for (int i = 0; i < 7; ++i) pose[i] = p0[size_t(i)];
-        CK(mlh_scan2map(ctx, pose, &o, nullptr));
-        const auto t3 = now();
-        if (it >= 0) { t_stage[0] += ms(t0, t1); t_stage[1] += ms(t1, t2); t_stage[2] += ms(t2, t3); }
+    // mode 0: the index of the local map rebuilt between the thinning and the solve (on the frame's critical path);
+    // mode 1: the local map (device-resident, as a mapper that assembles it from keyframe clouds on the GPU has it) staged and indexed beside the front end:
+    //         mlh_map_set_pair_overlapped after the front end's launches are enqueued, before the first call that waits for them
+    void *d_surf = nullptr, *d_corner = nullptr;
+    if (hipMalloc(&d_surf, surf_map.size() * 4) != hipSuccess || hipMalloc(&d_corner, corner_map.size() * 4) != hipSuccess ||
+        hipMemcpy(d_surf, surf_map.data(), surf_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_corner, corner_map.data(), corner_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "device copy of the maps failed\n"); return 1; }
+    const int n_surf_map = int(surf_map.size() * 4 / size_t(map_stride)), n_corner_map = int(corner_map.size() * 4 / size_t(map_stride));
+    const int stage_pos = std::getenv("FB_STAGE_POS") ? std::atoi(std::getenv("FB_STAGE_POS")) : 3;   // where in the front end the staging call sits (3: after the last launch)
+    for (int mode = 0; mode < 2; ++mode) {
+        t_stage[0] = t_stage[1] = t_stage[2] = 0.0;
+        for (int it = -5; it < frames; ++it) {
+            const auto t0 = now();
+            CK(mlh_fuse_reset(ctx));
+            if (mode == 1 && stage_pos == 0) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
+            CK(mlh_scan_upload(ctx, pts.data(), 16, 12, n, rings.data(), rings.data() + R, R, MLH_MEM_HOST));
+            if (mode == 1 && stage_pos == 1) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
+            CK(mlh_extract_run(ctx));
+            if (mode == 1 && stage_pos == 2) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
+            CK(mlh_extract_voxel_run(ctx, 0.2f));
+            for (int i = 0; i < n_lidar; ++i) CK(mlh_fuse_add_rings(ctx, ring_ofs[size_t(i)], ring_ofs[size_t(i) + 1], i, ext.data() + 7 * i));
+            if (mode == 1 && stage_pos == 3) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
+            const auto t1 = now();
+            const void *fs = nullptr, *fc = nullptr;
+            int32_t ns = 0, nc = 0, ms_ = 0, mc = 0;
+            CK(mlh_fused_cloud(ctx, MLH_SURF, &fs, &ns));
+            CK(mlh_fused_cloud(ctx, MLH_CORNER, &fc, &nc));
+            CK(mlh_downsample_current_scan_pair(ctx, fs, ns, fc, nc, 16, 12, MLH_MEM_DEVICE, 0.4f, 0.2f, ext.data(), covs.data(), n_lidar, meas.data(), meta[1], 0.6, &ms_, &mc));
+            const auto t2 = now();
+            if (mode == 0) CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
+            for (int i = 0; i < 7; ++i) pose[i] = p0[size_t(i)];
+            CK(mlh_scan2map(ctx, pose, &o, nullptr));
+            const auto t3 = now();
+            if (it >= 0) { t_stage[0] += ms(t0, t1); t_stage[1] += ms(t1, t2); t_stage[2] += ms(t2, t3); }
+        }
+        std::printf("%s, ms per frame: upload+extract+fuse%s %.3f downsample %.3f scan2map %.3f total %.3f  pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n",
+                    mode == 0 ? "C++ over the C-ABI, device-resident, one launch set, both kinds thinned in one pipeline"
+                              : "  the same with the local map staged and indexed beside the front end (second stream, other map set)",
+                    mode == 0 ? "" : "+map staging", t_stage[0] / frames, t_stage[1] / frames, t_stage[2] / frames, (t_stage[0] + t_stage[1] + t_stage[2]) / frames,
+                    pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
     }
-    std::printf("C++ over the C-ABI, device-resident, one launch set, both kinds thinned in one pipeline, ms per frame: upload+extract+fuse %.3f downsample %.3f scan2map %.3f total %.3f  "
-                "pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", t_stage[0] / frames, t_stage[1] / frames, t_stage[2] / frames, (t_stage[0] + t_stage[1] + t_stage[2]) / frames,
-                pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
+    (void)hipFree(d_surf); (void)hipFree(d_corner);
     mlh_destroy(ctx);
     return 0;
 }

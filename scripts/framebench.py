@@ -18,6 +18,8 @@ meas = np.diag([0.0025] * 3)
 Ts = []
 for i in range(2):
     T = np.eye(4); T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i][:4]); T[:3, 3] = synth.HERCULES_BODY_T_LASER[i][4:7]; Ts.append(T)
+import torch
+torch.cuda.init()          # (before the library's first HIP call, as in bench.py: the other order leaves torch without a device)
 ctx = mla.Context(0)
 ctx.map_set(mla.SURF, surf_map); ctx.map_set(mla.CORNER, corner_map)
 opts = mla.default_opts(flags=mla.FLAG_WITH_UA)
@@ -107,9 +109,31 @@ PAIR = True       # mlh_downsample_current_scan_pair: both kinds through one thi
 for _ in range(3): gpu_frame_dev1({})
 td2 = {}
 for _ in range(20): pose_dev2 = gpu_frame_dev1(td2)
+# The same frame with the local map staged and indexed BESIDE the front end: the map is made of earlier keyframes, so its index does not wait for the scan
+# (mlh_map_set_pair_overlapped with device-resident clouds: second stream, the other map set; enqueued after the front end's launches, before the first call
+# that waits for them). The line above re-indexes between the thinning and the solve, on the frame's critical path.
+surf_map_dev = torch.from_numpy(np.ascontiguousarray(surf_map, np.float32)).cuda(); corner_map_dev = torch.from_numpy(np.ascontiguousarray(corner_map, np.float32)).cuda()
+def gpu_frame_dev2(t):
+    t0 = time.perf_counter()
+    ctx.fuse_reset()
+    ctx.scan_upload(both_pts, both_start, both_end); ctx.extract_run(); ctx.extract_voxel_run(0.2)
+    for i in range(len(scans)): ctx.fuse_add_rings(ring_ofs[i], ring_ofs[i + 1], i, ext[i])
+    ctx.map_set_pair_overlapped(surf_map_dev, corner_map_dev)
+    t1 = time.perf_counter()
+    ctx.downsample_current_scan_pair(ctx.fused_cloud(mla.SURF), ctx.fused_cloud(mla.CORNER), 0.4, 0.2, ext, covs, meas, True, 0.6)
+    t3 = time.perf_counter()
+    pose, _ = ctx.scan2map(p0, opts, want_stats=False)
+    t4 = time.perf_counter()
+    for k, v in zip(("upload+extract+fuse+map staging", "downsample", "scan2map"), (t1 - t0, t3 - t1, t4 - t3)): t[k] = t.get(k, 0.0) + v
+    return pose
+for _ in range(3): gpu_frame_dev2({})
+td3 = {}
+for _ in range(20): pose_dev3 = gpu_frame_dev2(td3)
 PAIR = False
 print("GPU path, device-resident, one launch set, both kinds thinned in one pipeline, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td2.items()}, "total %.3f" % (1e3 * sum(td2.values()) / 20),
       "same pose:", bool(np.array_equal(pose_dev2, pose_dev1)))
+print("  the same with the local map staged and indexed beside the front end (second stream, other map set), ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td3.items()},
+      "total %.3f" % (1e3 * sum(td3.values()) / 20), "same pose:", bool(np.array_equal(pose_dev3, pose_dev1)))
 print("GPU path, device-resident, both LiDARs one launch set, ms per frame:", {k: round(1e3 * v / 20, 3) for k, v in td1.items()}, "total %.3f" % (1e3 * sum(td1.values()) / 20),
       "same pose as per-LiDAR launches:", bool(np.array_equal(pose_dev1, pose_dev)))
 # Two pipelines on the one GPU, as the reference's estimator and mapper NODES are two processes: an estimator-side context extracts, fuses and thins frame k + 1
@@ -151,7 +175,9 @@ ctxB.close()
 import subprocess, tempfile
 exe = os.path.join(ROOT, "m-loam_amd", "host", "framebench")
 if os.path.exists(exe):
-    with tempfile.TemporaryDirectory() as d:
+    import contextlib
+    keep = os.environ.get('FRAMEBENCH_KEEP_DIR')      # (scripts/exp/fb_stage_pos.sh re-runs the executable on the same inputs)
+    with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as d:
         both_pts.astype(np.float32).tofile(os.path.join(d, "fb_points.f32"))
         np.concatenate([both_start, both_end]).astype(np.int32).tofile(os.path.join(d, "fb_rings.i32"))
         np.asarray(ring_ofs, np.int32).tofile(os.path.join(d, "fb_ring_ofs.i32"))
@@ -164,8 +190,9 @@ if os.path.exists(exe):
         np.array([sm.shape[1] * 4, 1], np.int32).tofile(os.path.join(d, "fb_meta.i32"))
         np.ascontiguousarray(p0, np.float64).tofile(os.path.join(d, "fb_pose.f64"))
         r = subprocess.run([exe, d, "50"], capture_output=True, text=True, timeout=120)
-        line = (r.stdout.strip().splitlines() or [r.stderr.strip()])[-1]
-        print(line.split("  pose ")[0], " same pose as through ctypes (printed to 1e-9):", bool(np.allclose([float(x) for x in line.split("  pose ")[1].split()], pose_dev2, rtol=0, atol=2e-9)) if "  pose " in line else r.stderr[-300:])
+        for line in (r.stdout.strip().splitlines() or [r.stderr.strip()]):
+            print(line.split("  pose ")[0], " same pose as through ctypes (printed to 1e-9):",
+                  bool(np.allclose([float(x) for x in line.split("  pose ")[1].split()], pose_dev2, rtol=0, atol=2e-9)) if "  pose " in line else line)
 if os.environ.get('FRAMEBENCH_DEV_ONLY'): sys.exit(0)
 for _ in range(3): gpu_frame({})
 tg = {}; n = 20

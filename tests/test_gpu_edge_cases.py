@@ -555,6 +555,48 @@ def test_gn_solve_submitted_and_collected_separately(mla, case16, feats16):
 
 
 @pytest.mark.gpu
+def test_maps_staged_beside_a_frames_front_end(mla, case16, feats16):
+    """mlh_map_set_pair_overlapped with NO solve in flight and device-resident clouds: the index is built on the second stream into the other map set while
+    the main stream runs launches that read no map (here: a scan's upload and extraction), and the solve that follows reads exactly the maps staged for it.
+    Alternates two different map pairs, with the synchronous entry points (map_set_pair, map_rebuild, scan2map) mixed in; host-resident clouds take the
+    synchronous path and give the same answers."""
+    import torch
+    torch.cuda.init()
+    scan = case16["scans"][0]
+    moved_s, moved_c = case16["surf_map"].copy(), case16["corner_map"].copy()
+    moved_s[:, 0] += 0.03; moved_c[:, 0] += 0.03
+    dev = {False: (torch.from_numpy(np.ascontiguousarray(case16["surf_map"], np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(case16["corner_map"], np.float32)).cuda()),
+           True: (torch.from_numpy(np.ascontiguousarray(moved_s, np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(moved_c, np.float32)).cuda())}
+    host = {False: (case16["surf_map"], case16["corner_map"]), True: (moved_s, moved_c)}
+    opts = mla.default_opts()
+    c = mla.Context(0)
+    try:
+        c.features_set(mla.SURF, feats16[0]); c.features_set(mla.CORNER, feats16[1])
+        want = {}
+        for moved in (False, True):
+            c.map_set_pair(*host[moved])
+            want[moved], _ = c.scan2map(case16["p0"], opts, want_stats=False)
+        assert np.abs(want[True] - want[False]).max() > 1e-3
+        for k in range(8):
+            moved = bool(k % 2) if k < 6 else True                   # (the last two stage the SAME maps twice in a row: both sets then hold them)
+            c.scan_upload(scan.points, scan.scan_start, scan.scan_end); c.extract_run()      # something map-free in flight on the main stream
+            c.map_set_pair_overlapped(*dev[moved])
+            if k == 3: c.map_rebuild(mla.ALL_KINDS)                  # re-indexing the set that has just become current changes nothing
+            pose, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+            assert np.array_equal(pose, want[moved]), k
+            if k == 4:                                               # a synchronous staging in between lands in the current set; the next overlapped one in the other
+                c.map_set_pair(*host[False])
+                pose, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+                assert np.array_equal(pose, want[False])
+        c.map_set_pair_overlapped(*host[False])                      # host-resident, no solve in flight: the synchronous path
+        pose, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+        assert np.array_equal(pose, want[False])
+        assert c.map_info(mla.SURF)["n"] == len(case16["surf_map"])
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_next_frames_start_pose_is_chained_on_the_device(mla, orc, case16, feats16):
     """mlh_gn_solve_begin_chained: frame k + 1 is submitted before frame k's pose has reached the host; its start pose -- transformUpdate with frame k's result,
     transformAssociateToMap with the next odometry pose (lidar_mapper_keyframe.cpp:145-160) -- is computed where that result lives. Against the host-side
