@@ -344,7 +344,7 @@ void mlh_destroy(mlh_ctx *ctx)
             m.raw.release(); m.sorted.release(); m.cell_id.release(); m.cell_start.release(); m.cell_fill.release(); m.block_sums.release(); m.bounds.release(); m.occ.release();
         }
         FeatSet &f = ctx->feat[k];
-        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release(); f.flag8.release();
+        f.pts.release(); f.covd.release(); f.corr.release(); f.nbr.release(); f.r.release(); f.J.release(); f.flag8.release(); f.fps_order.release();
     }
     ScanBuf &s = ctx->scan;
     s.pts.release(); s.start.release(); s.end.release(); s.curvature.release(); s.label.release(); s.picked.release(); s.stage.release();
@@ -1375,7 +1375,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
             // and its copies are still in flight, and each kind's flags go back without a wait (the linearise launch is behind them on the stream)
             std::vector<int32_t> sel;
             for (int kind : {MLH_CORNER, MLH_SURF})
-                if ((rc = good_feature_stage(ctx, kind, opts->gf_method, opts->min_match_sq_dis, opts->min_plane_dis))) return rc;
+                if ((rc = good_feature_stage(ctx, kind, opts->gf_method, opts->gf_ratio, rng, opts->min_match_sq_dis, opts->min_plane_dis))) return rc;
             for (int kind : {MLH_CORNER, MLH_SURF}) {
                 double Hsel[36];
                 for (int i = 0; i < 36; ++i) Hsel[i] = (i % 7 == 0) ? 1e-6 : 0.0;

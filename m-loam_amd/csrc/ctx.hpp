@@ -146,6 +146,7 @@ struct FeatSet {
     DevBuf corr;       // Corr per feature
     DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
+    DevBuf fps_order;  // 'fps' selection: [count][visiting order] (select.hip: fps_order_kernel)
     DevBuf flag8;      // one byte per feature: Corr::valid on the way to the host, the selection's verdict on the way back (select.hip)
     int m = 0;             // feature slots (real + padding between pose blocks)
     int n_blocks = 1;
@@ -308,6 +309,7 @@ struct mlh_ctx {
     std::vector<char> select_rows[2];   // the same rows in ordinary (CPU-cached) memory: what the selection loops read
     unsigned long long select_seq[2] = {0, 0};  // stream_flag_post after each kind's copies to the host
     bool select_staged[2] = {false, false};
+    long select_fps_start[2] = {-1, -1};        // 'fps': the starting point drawn at staging time
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };
@@ -461,7 +463,7 @@ namespace mlh {
 int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
 // its two halves: the dense pass + copies to the host, enqueued (no wait); the selection loop on the copied rows, flags sent back (no wait)
-int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_dis, float min_plane_dis);
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis);
 int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out, double H[36],
                         uint8_t *matched_out);
 // solver.hip

@@ -33,6 +33,82 @@ __global__ void apply_keep_kernel(Corr *__restrict__ corr, int m, const uint8_t 
     if (i < m) corr[i].valid = keep[i];
 }
 
+// Farthest-point sampling (goodFeatureMatching, 'fps': lidar_mapper.h:352-408) as ONE workgroup that keeps every point, its running minimum distance and its
+// visited bit in registers (thread t owns points t, t + 1024, ...): an iteration is "distance of every unvisited point to the current one, running minimum,
+// arg-max" -- per point exactly the host loop's f32 arithmetic (un-fused products, correctly rounded square root, std::min's operand order), and the arg-max
+// takes the LOWEST index among equal distances, as the host loop's strict `>` over ascending j does. The key that is maximised is (distance bits + 1, ~index);
+// zero means "no candidate" (NaN coordinates only), and the call is handed to the host loop (count -1). The winner's owner publishes its coordinates and its validity
+// through LDS, so the next iteration starts without a global read. Output: the visiting order (start point excluded) until n_use matched points have been
+// kept or every point has been visited; the host replays its bookkeeping (selection list, information matrix) along that order.
+constexpr int FPS_THREADS = 1024, FPS_PMAX = 16;      // up to 16384 points on the device; longer clouds take the host loop
+// (the per-thread points are sixteen sets of NAMED scalars, expanded by macro: as arrays the compiler kept them in 16-register tuples and moved whole tuples
+// around every conditional element update -- 1173 spilled registers)
+#define FPS_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+__global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__restrict__ pts, const uint8_t *__restrict__ valid, int n, int n_use, int cur0,
+                                                                 int *__restrict__ order, int *__restrict__ n_order)
+{
+    __shared__ unsigned long long s_key[FPS_THREADS / 64];
+    __shared__ float s_cur[4];
+    const int t = threadIdx.x;
+    unsigned vis = 0, val = 0;                                      // bit k: point t + 1024 k has been visited (or does not exist) / is a matched feature
+#define FPS_LOAD(k)                                                                                                  \
+    float px##k, py##k, pz##k, dist##k = 1e5f;                                                                       \
+    {                                                                                                                \
+        const int j = t + k * FPS_THREADS, jj = j < n ? j : n - 1;                                                   \
+        const float4 p = pts[jj];                                                                                    \
+        px##k = p.x; py##k = p.y; pz##k = p.z;                                                                       \
+        vis |= (j < n ? 0u : 1u) << k;                                                                               \
+        val |= ((j < n && valid[jj]) ? 1u : 0u) << k;                                                                \
+    }
+    FPS_FOR16(FPS_LOAD)
+#undef FPS_LOAD
+    if ((cur0 & (FPS_THREADS - 1)) == t) vis |= 1u << (cur0 / FPS_THREADS);
+    if (t == 0) {
+        const float4 p = pts[cur0];
+        s_cur[0] = p.x; s_cur[1] = p.y; s_cur[2] = p.z; s_cur[3] = valid[cur0] ? 1.f : 0.f;
+    }
+    __syncthreads();
+    int n_sel = (s_cur[3] != 0.f && n_use > 0) ? 1 : 0, n_visited = 1, n_out = 0;
+    while (n_sel < n_use && n_visited < n) {
+        const float ox = s_cur[0], oy = s_cur[1], oz = s_cur[2];
+        float best_d = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+        int best_k = -1;
+#define FPS_STEP(k)                                                                                                  \
+        if (!(vis >> k & 1u)) {                                                                                      \
+            const float ddx = ox - px##k, ddy = oy - py##k, ddz = oz - pz##k;                                        \
+            const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz))); \
+            const float d2 = (dist##k < d) ? dist##k : d;              /* std::min(d, dist[j]) */                     \
+            dist##k = d2;                                                                                            \
+            if (d2 > best_d) { best_d = d2; best_k = k; bx = px##k; by = py##k; bz = pz##k; }                          \
+        }
+        FPS_FOR16(FPS_STEP)
+#undef FPS_STEP
+        const int best_j = best_k >= 0 ? t + best_k * FPS_THREADS : -1, best_v = best_k >= 0 ? int(val >> best_k & 1u) : 0;
+        unsigned long long key = best_j >= 0 ? ((unsigned long long)(__float_as_uint(best_d) + 1u) << 32) | (unsigned long long)(~unsigned(best_j)) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if ((t & 63) == 0) s_key[t >> 6] = key;                     // (last round's reads of s_key are behind that round's closing barrier)
+        __syncthreads();
+        unsigned long long w = s_key[0];
+#pragma unroll
+        for (int i = 1; i < FPS_THREADS / 64; ++i) { const unsigned long long o = s_key[i]; w = o > w ? o : w; }
+        if (!w) { if (t == 0) *n_order = -1; return; }              // only with NaN coordinates (every comparison false): the host loop takes the call
+        const int cur = int(~unsigned(w & 0xffffffffull));
+        if (cur == best_j) { s_cur[0] = bx; s_cur[1] = by; s_cur[2] = bz; s_cur[3] = best_v ? 1.f : 0.f; }
+        if ((cur & (FPS_THREADS - 1)) == t) vis |= 1u << (cur / FPS_THREADS);
+        if (t == 0) order[n_out] = cur;
+        ++n_out;
+        __syncthreads();
+        ++n_visited;
+        if (s_cur[3] != 0.f) ++n_sel;
+    }
+    if (t == 0) *n_order = n_out;
+}
+#undef FPS_FOR16
+
 struct Rows {               // per-feature results of the GPU pass, copied out of the context's pinned staging block
     const uint8_t *valid = nullptr;   // Corr::valid != 0
     const double *J = nullptr;  // m x 6
@@ -99,13 +175,12 @@ void select_rnd(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
     }
 }
 
-void select_fps(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel, double H[36])
+void select_fps(const Rows &R, size_t n_use, size_t cur, std::vector<size_t> &sel, double H[36])
 {
     const size_t n = R.size();
     if (n == 0) return;
     std::vector<char> visited(n, 0);
-    size_t cur = draw(rng, 0, n - 1);
-    visited[cur] = 1;
+    visited[cur] = 1;                              // `cur` = the starting point, drawn by the caller (rgi_.geneRandUniform(0, size - 1), lidar_mapper.h:356)
     size_t n_visited = 1;
     // the starting point is kept when matched, but its Jacobian is not accumulated (lidar_mapper.h:356-386)
     if (R.matched(cur) && n_use > 0) sel.push_back(cur);
@@ -126,6 +201,16 @@ void select_fps(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
         cur = best_j;
         visited[cur] = 1;
         ++n_visited;
+        if (R.matched(cur)) { rank1_update(H, R.jaco(cur)); sel.push_back(cur); }
+    }
+}
+
+// the same bookkeeping along a visiting order the device produced (fps_order_kernel): who is kept, and the information matrix in pick order
+void select_fps_replay(const Rows &R, size_t n_use, size_t start, const int *order, size_t n_order, std::vector<size_t> &sel, double H[36])
+{
+    if (R.matched(start) && n_use > 0) sel.push_back(start);
+    for (size_t i = 0; i < n_order && sel.size() < n_use; ++i) {
+        const size_t cur = size_t(order[i]);
         if (R.matched(cur)) { rank1_update(H, R.jaco(cur)); sel.push_back(cur); }
     }
 }
@@ -276,7 +361,7 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
 
 // One goodFeatureMatching call, in two halves. The device-side solver state must already hold the pose (SolverState::x).
 // Stage: the dense pass of one kind and the copies of its rows into that kind's pinned block, enqueued; a marker behind them.
-int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_dis, float min_plane_dis)
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis)
 {
     FeatSet &f = ctx->feat[kind];
     MatchArgs a;
@@ -287,9 +372,9 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_di
     int rc = match_launch(ctx, a);
     if (rc) return rc;
     const size_t m = size_t(f.m);
-    // pinned staging (grow-only, owned by the context, one block per kind): [J 6m][pts m][valid m bytes, padded][keep m bytes]
+    // pinned staging (grow-only, owned by the context, one block per kind): [J 6m][pts m][valid m bytes, padded][keep m bytes, padded][fps: count, order m]
     const size_t mp = (m + 63) & ~size_t(63);
-    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp, need = off_k + mp;
+    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp, off_o = off_k + mp, need = off_o + sizeof(int) * (m + 1);
     if (need > ctx->select_host_cap[kind]) {
         MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a copy of an earlier call may still be using the old block
         if (ctx->select_host[kind]) (void)hipHostFree(ctx->select_host[kind]);
@@ -303,7 +388,23 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, float min_match_sq_di
     char *hb = static_cast<char *>(ctx->select_host[kind]);
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
-    if (method == MLH_GF_FPS) MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->select_fps_start[kind] = -1;
+    if (method == MLH_GF_FPS && m > 0) {
+        // the one number this method draws (the starting point, lidar_mapper.h:356) is drawn here, in call order: corner before surf, as the finishes will run
+        const size_t cur0 = draw(rng, 0, m - 1);
+        ctx->select_fps_start[kind] = long(cur0);
+        static const bool fps_on_host = std::getenv("MLH_FPS_HOST") != nullptr;          // (measurement only: the host loop on every call)
+        if (m <= size_t(FPS_THREADS) * FPS_PMAX && !fps_on_host) {
+            MLH_HIP(ctx, f.fps_order.ensure(sizeof(int) * (m + 1)));
+            hipLaunchKernelGGL(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
+                               int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
+            MLH_HIP(ctx, hipGetLastError());
+            MLH_HIP(ctx, hipMemcpyAsync(hb + off_o, f.fps_order.p, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));   // too long for one workgroup's registers: host loop
+            *reinterpret_cast<int *>(hb + off_o) = -1;
+        }
+    }
     MLH_HIP(ctx, stream_flag_post(ctx, &ctx->select_seq[kind]));
     ctx->select_staged[kind] = true;
     return MLH_OK;
@@ -322,16 +423,22 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     Rows R;
     const size_t m = size_t(f.m);
     const size_t mp = (m + 63) & ~size_t(63);
-    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp;
+    const size_t off_p = sizeof(double) * 6 * m, off_v = off_p + sizeof(float4) * m, off_k = off_v + mp, off_o = off_k + mp;
     char *hb = static_cast<char *>(ctx->select_host[kind]);
     R.m = m;
+    const int *fps_dev = reinterpret_cast<const int *>(hb + off_o);                     // [count or -1][visiting order]
+    const bool fps_host = method == MLH_GF_FPS && m > 0 && fps_dev[0] < 0;
+    if (fps_host && m <= size_t(FPS_THREADS) * FPS_PMAX && !std::getenv("MLH_FPS_HOST")) {                              // the kernel gave up (NaN coordinates): the points were not sent along
+        MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // The selection loops jump around in these rows (a pool look-up decides which one comes next). Pinned host memory is mapped so that the CPU does not
     // cache it: read in place, every access is a trip to DRAM -- the `rnd` loop, which scores nothing, took 0.6 / 1.0 ms per call that way, 0.12 / 0.28 ms on an
     // ordinary copy; a bulk copy out of the pinned block runs at ~30 GB/s. So: DMA into the pinned block, one memcpy into the context's
     // cacheable block, loops on that (config 5, gd_fix: 7.2 -> 4.05 ms per frame; profiles/r03_gfbench.txt).
     ctx->select_rows[kind].resize(off_k);
     char *cb = ctx->select_rows[kind].data();
-    std::memcpy(cb, hb, method == MLH_GF_FPS ? off_v : off_p);
+    std::memcpy(cb, hb, fps_host ? off_v : off_p);
     std::memcpy(cb + off_v, hb + off_v, m);
     R.valid = reinterpret_cast<const uint8_t *>(cb + off_v); R.J = reinterpret_cast<const double *>(cb); R.pts = reinterpret_cast<const float4 *>(cb + off_p);
     if (matched_out) for (size_t i = 0; i < m; ++i) matched_out[i] = R.matched(i) ? 1 : 0;
@@ -343,7 +450,11 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     switch (method) {
         case MLH_GF_WO: select_wo_gf(R, sel, H); break;
         case MLH_GF_RND: select_rnd(R, n_use, rng, sel, H); break;
-        case MLH_GF_FPS: select_fps(R, n_use, rng, sel, H); break;
+        case MLH_GF_FPS:
+            if (m == 0) break;
+            if (fps_host) select_fps(R, n_use, size_t(ctx->select_fps_start[kind]), sel, H);
+            else select_fps_replay(R, n_use, size_t(ctx->select_fps_start[kind]), fps_dev + 1, size_t(fps_dev[0]), sel, H);
+            break;
         case MLH_GF_GD_FIX:
         case MLH_GF_GD_FLOAT: select_greedy(R, n_use, rng, sel, H); break;
         default: return fail(ctx, MLH_ERR_INVALID, "unknown gf_method");
@@ -372,7 +483,7 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
 int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out)
 {
-    int rc = good_feature_stage(ctx, kind, method, min_match_sq_dis, min_plane_dis);
+    int rc = good_feature_stage(ctx, kind, method, ratio, rng, min_match_sq_dis, min_plane_dis);
     if (rc) return rc;
     if ((rc = good_feature_finish(ctx, kind, method, ratio, rng, sel_out, H, matched_out))) return rc;
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
