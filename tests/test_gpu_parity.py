@@ -326,6 +326,42 @@ def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
     assert lin["count"] == len(ref["sel"])
 
 
+@pytest.mark.parametrize("variant", ["lattice", "duplicates", "five_points", "ratio_zero", "ratio_one", "nothing_matches", "host_loop"])
+def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats16, variant, monkeypatch):
+    """'fps' runs its arg-max loop on the device (select.hip: fps_order_kernel). Equal distances are decided by the lowest index, as the host loop's strict `>`
+    over ascending indices decides them: features snapped to a 0.25 m lattice and features repeated verbatim produce such ties by the thousand. Edge sizes:
+    five features, num_use_features = 0, every feature wanted, nothing matched (the loop then visits every point and keeps none); MLH_FPS_HOST=1 runs the
+    host loop through the same entry point. All against the oracle's restatement of the reference loop (lidar_mapper.h:352-408)."""
+    surf = feats16[0].copy()
+    ratio, pose = 0.2, case16["p0"]
+    if variant == "lattice":
+        surf[:, :3] = np.round(surf[:, :3] * 4.0) / 4.0
+    elif variant == "duplicates":
+        surf = np.ascontiguousarray(np.concatenate([surf[:700], surf[:700], surf[:300][::-1], surf[700:1500]]))
+    elif variant == "five_points":
+        surf = np.ascontiguousarray(surf[:5]); ratio = 0.6
+    elif variant == "ratio_zero":
+        ratio = 1e-5
+    elif variant == "ratio_one":
+        ratio = 1.0
+    elif variant == "nothing_matches":
+        surf[:, :3] += np.array([0.0, 0.0, 500.0], np.float32)
+    elif variant == "host_loop":
+        monkeypatch.setenv("MLH_FPS_HOST", "1")
+    c = mla.Context(0)
+    try:
+        c.map_set(mla.SURF, case16["surf_map"])
+        c.features_set(mla.SURF, surf)
+        got = c.good_feature_matching(mla.SURF, pose, gf_method="fps", gf_ratio=ratio, seed=23)
+        ref = orc.good_feature_matching(orc.Map(case16["surf_map"]), "s", surf, pose, orc.mapper_params(gf_method="fps", gf_ratio=ratio, seed=23))
+        assert np.array_equal(got["sel"], ref["sel"]), (variant, len(got["sel"]), len(ref["sel"]))
+        np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-12, atol=1e-12)
+        if variant == "nothing_matches": assert len(ref["sel"]) == 0
+        if variant == "ratio_one": assert len(ref["sel"]) > 0.5 * len(surf)
+    finally:
+        c.close()
+
+
 def test_greedy_selection_lemma_scoring_equals_literal_scoring(ctx, mla, case16, feats16, monkeypatch):
     """The greedy loop ranks a subset's members by j H^-1 j^T (matrix determinant lemma) and replays near ties with the reference's
     logdet arithmetic; MLH_SELECT_EXACT=1 scores every member with the literal Cholesky logdet (lidar_mapper.h:497-520). Same picks,
