@@ -371,9 +371,11 @@ int mlh_match_coeffs(mlh_ctx *ctx, int kind, uint8_t *valid, double *coeffs, int
  * replaces ActiveFeatureSelection::goodFeatureMatching (estimator/src/lidarMapper/lidar_mapper.h:229-573).
  * ALL features of `kind` are matched and their weighted, un-corrected 1x6 Jacobians evaluated on the GPU in one pass
  * (what match*PointFromMap + evaluateFeatJacobianMatching produce one feature at a time, lidar_mapper.h:130-174, 483-521); the
- * inherently sequential selection loop -- rnd / fps / stochastic-greedy logdet (gd_fix, gd_float) -- then runs on the host
+ * inherently sequential draw loops -- rnd, stochastic-greedy logdet (gd_fix, gd_float) -- then run on the host
  * over those rows with the reference's draw sequence (std::mt19937 + uniform_int_distribution, common/random_generator.hpp:53;
- * the MAX_FEATURE_SELECT_TIME wall-clock cut-off is not applied). sub_mat_H must come in as the reference initialises it
+ * the MAX_FEATURE_SELECT_TIME wall-clock cut-off is not applied); fps draws one number (its starting point) and its
+ * farthest-point arg-max loop runs on the device for up to 16384 features (same f32 arithmetic, lowest index among equal
+ * distances), the host replaying selection list and information matrix along the visiting order. sub_mat_H must come in as the reference initialises it
  * (1e-6 * I, cpp:505/520) and returns H + sum j^T j of the selected rows. On return only the selected features stay valid
  * on the device, so mlh_linearize / the LM of mlh_scan2map see exactly the residual blocks the reference would add. */
 enum { MLH_GF_WO = 0, MLH_GF_RND = 1, MLH_GF_FPS = 2, MLH_GF_GD_FIX = 3, MLH_GF_GD_FLOAT = 4 };
