@@ -40,14 +40,49 @@ __global__ void apply_keep_kernel(Corr *__restrict__ corr, int m, const uint8_t 
 // zero means "no candidate" (NaN coordinates only), and the call is handed to the host loop (count -1). The winner's owner publishes its coordinates and its validity
 // through LDS, so the next iteration starts without a global read. Output: the visiting order (start point excluded) until n_use matched points have been
 // kept or every point has been visited; the host replays its bookkeeping (selection list, information matrix) along that order.
+// wavefront-wide unsigned max / min through the DPP network (row shifts inside the four 16-lane rows, then the two row broadcasts gfx9 has for this):
+// the result is lane 63's; six dependent VALU instructions instead of six LDS-crossbar permutes
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned fps_dpp(unsigned identity, unsigned v)
+{
+    return unsigned(__builtin_amdgcn_update_dpp(int(identity), int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ unsigned fps_row_umax(unsigned v)      // lane 15 of every row: the row's maximum
+{
+    v = max(v, fps_dpp<0x111, 0xf>(0u, v)); v = max(v, fps_dpp<0x112, 0xf>(0u, v));       // row_shr:1, :2
+    v = max(v, fps_dpp<0x114, 0xf>(0u, v)); v = max(v, fps_dpp<0x118, 0xf>(0u, v));       // row_shr:4, :8
+    return v;
+}
+__device__ __forceinline__ unsigned fps_row_umin(unsigned v)
+{
+    v = min(v, fps_dpp<0x111, 0xf>(~0u, v)); v = min(v, fps_dpp<0x112, 0xf>(~0u, v));
+    v = min(v, fps_dpp<0x114, 0xf>(~0u, v)); v = min(v, fps_dpp<0x118, 0xf>(~0u, v));
+    return v;
+}
+__device__ __forceinline__ unsigned fps_wave_umax(unsigned v)
+{
+    v = fps_row_umax(v);
+    v = max(v, fps_dpp<0x142, 0xa>(0u, v));                        // row_bcast:15 into rows 1 and 3
+    v = max(v, fps_dpp<0x143, 0xc>(0u, v));                        // row_bcast:31 into rows 2 and 3
+    return unsigned(__builtin_amdgcn_readlane(int(v), 63));
+}
+__device__ __forceinline__ unsigned fps_wave_umin(unsigned v)
+{
+    v = fps_row_umin(v);
+    v = min(v, fps_dpp<0x142, 0xa>(~0u, v));
+    v = min(v, fps_dpp<0x143, 0xc>(~0u, v));
+    return unsigned(__builtin_amdgcn_readlane(int(v), 63));
+}
+
 constexpr int FPS_THREADS = 1024, FPS_PMAX = 16;      // up to 16384 points on the device; longer clouds take the host loop
+// The square root is spelled sqrtf: with this toolchain that is the correctly rounded one (bit-equal to the host's on 26 M values incl. every float in
+// [1, 4) and denormals), while __fsqrt_rn compiles to the bare v_sqrt_f32 and is one ulp off on 15 % of them (scripts/exp/sqrt_check.hip).
 // (the per-thread points are sixteen sets of NAMED scalars, expanded by macro: as arrays the compiler kept them in 16-register tuples and moved whole tuples
 // around every conditional element update -- 1173 spilled registers)
 #define FPS_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__restrict__ pts, const uint8_t *__restrict__ valid, int n, int n_use, int cur0,
                                                                  int *__restrict__ order, int *__restrict__ n_order)
 {
-    __shared__ unsigned long long s_key[FPS_THREADS / 64];
+    __shared__ unsigned s_d[FPS_THREADS / 64], s_j[FPS_THREADS / 64];   // per wavefront: (distance bits + 1, 0 = no candidate) and the lowest index that has it
     __shared__ float s_cur[4];
     const int t = threadIdx.x;
     unsigned vis = 0, val = 0;                                      // bit k: point t + 1024 k has been visited (or does not exist) / is a matched feature
@@ -76,7 +111,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__
 #define FPS_STEP(k)                                                                                                  \
         if (!(vis >> k & 1u)) {                                                                                      \
             const float ddx = ox - px##k, ddy = oy - py##k, ddz = oz - pz##k;                                        \
-            const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz))); \
+            const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)));    /* sqrtf, NOT __fsqrt_rn: see below */ \
             const float d2 = (dist##k < d) ? dist##k : d;              /* std::min(d, dist[j]) */                     \
             dist##k = d2;                                                                                            \
             if (d2 > best_d) { best_d = d2; best_k = k; bx = px##k; by = py##k; bz = pz##k; }                          \
@@ -84,19 +119,17 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__
         FPS_FOR16(FPS_STEP)
 #undef FPS_STEP
         const int best_j = best_k >= 0 ? t + best_k * FPS_THREADS : -1, best_v = best_k >= 0 ? int(val >> best_k & 1u) : 0;
-        unsigned long long key = best_j >= 0 ? ((unsigned long long)(__float_as_uint(best_d) + 1u) << 32) | (unsigned long long)(~unsigned(best_j)) : 0ull;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(key, off, 64);
-            key = o > key ? o : key;
-        }
-        if ((t & 63) == 0) s_key[t >> 6] = key;                     // (last round's reads of s_key are behind that round's closing barrier)
+        // arg-max in two keys: the largest distance first, then the lowest index among the points that have it -- inside the wavefront, then over the sixteen
+        // wavefronts (one row of lanes reads their pairs back from LDS)
+        const unsigned my_d = best_k >= 0 ? __float_as_uint(best_d) + 1u : 0u;
+        const unsigned wave_d = fps_wave_umax(my_d);
+        const unsigned wave_j = fps_wave_umin((my_d == wave_d && best_k >= 0) ? unsigned(best_j) : ~0u);
+        if ((t & 63) == 0) { s_d[t >> 6] = wave_d; s_j[t >> 6] = wave_j; }     // (last round's reads are behind that round's closing barrier)
         __syncthreads();
-        unsigned long long w = s_key[0];
-#pragma unroll
-        for (int i = 1; i < FPS_THREADS / 64; ++i) { const unsigned long long o = s_key[i]; w = o > w ? o : w; }
-        if (!w) { if (t == 0) *n_order = -1; return; }              // only with NaN coordinates (every comparison false): the host loop takes the call
-        const int cur = int(~unsigned(w & 0xffffffffull));
+        const unsigned od = s_d[t & 15], oj = s_j[t & 15];
+        const unsigned all_d = unsigned(__builtin_amdgcn_readlane(int(fps_row_umax(od)), 15));
+        if (!all_d) { if (t == 0) *n_order = -1; return; }          // only with NaN coordinates (every comparison false): the host loop takes the call
+        const int cur = int(__builtin_amdgcn_readlane(int(fps_row_umin(od == all_d ? oj : ~0u)), 15));
         if (cur == best_j) { s_cur[0] = bx; s_cur[1] = by; s_cur[2] = bz; s_cur[3] = best_v ? 1.f : 0.f; }
         if ((cur & (FPS_THREADS - 1)) == t) vis |= 1u << (cur / FPS_THREADS);
         if (t == 0) order[n_out] = cur;

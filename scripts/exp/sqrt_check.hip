@@ -1,0 +1,34 @@
+// Is the device's f32 square root (as the kernels of this library spell it: __fsqrt_rn, sqrtf) the correctly rounded one the host's sqrtss is?
+// Exhaustive over every positive normal float in [2^-20, 2^20) would be 335 M values; this checks a stride through all of them plus every float in [1, 4).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+__global__ void k(const float *x, float *a, float *b, size_t n)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = __fsqrt_rn(x[i]); b[i] = sqrtf(x[i]); }
+}
+int main()
+{
+    std::vector<float> h;
+    for (unsigned bits = 0x3f800000u; bits < 0x40800000u; ++bits) { float f; std::memcpy(&f, &bits, 4); h.push_back(f); }            // [1, 4): every mantissa, both exponent parities
+    for (unsigned bits = 0x35800000u; bits < 0x49800000u; bits += 37) { float f; std::memcpy(&f, &bits, 4); h.push_back(f); }      // 2^-20 .. 2^20, stride 37
+    for (unsigned bits = 1; bits < 0x00800000u; bits += 101) { float f; std::memcpy(&f, &bits, 4); h.push_back(f); }               // denormals
+    const size_t n = h.size();
+    float *dx, *da, *db;
+    hipMalloc(&dx, n * 4); hipMalloc(&da, n * 4); hipMalloc(&db, n * 4);
+    hipMemcpy(dx, h.data(), n * 4, hipMemcpyHostToDevice);
+    k<<<unsigned((n + 255) / 256), 256>>>(dx, da, db, n);
+    std::vector<float> a(n), b(n);
+    hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), db, n * 4, hipMemcpyDeviceToHost);
+    size_t bad_a = 0, bad_b = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float want = std::sqrt(h[i]);
+        if (std::memcmp(&want, &a[i], 4)) { if (bad_a++ < 3) std::printf("__fsqrt_rn(%a) = %a, host %a\n", h[i], a[i], want); }
+        if (std::memcmp(&want, &b[i], 4)) { if (bad_b++ < 3) std::printf("sqrtf(%a) = %a, host %a\n", h[i], b[i], want); }
+    }
+    std::printf("%zu values: __fsqrt_rn differs from the host's sqrt on %zu, sqrtf on %zu\n", n, bad_a, bad_b);
+    return 0;
+}
