@@ -10,6 +10,11 @@ __global__ void k(const float *x, float *a, float *b, size_t n)
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = __fsqrt_rn(x[i]); b[i] = sqrtf(x[i]); }
 }
+__global__ void kd(const double *x, double *a, size_t n)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = sqrt(x[i]);
+}
 int main()
 {
     std::vector<float> h;
@@ -30,5 +35,23 @@ int main()
         if (std::memcmp(&want, &b[i], 4)) { if (bad_b++ < 3) std::printf("sqrtf(%a) = %a, host %a\n", h[i], b[i], want); }
     }
     std::printf("%zu values: __fsqrt_rn differs from the host's sqrt on %zu, sqrtf on %zu\n", n, bad_a, bad_b);
+    {   // f64: sqrt(double) as the solver kernels use it, on 2^24 arguments spread over [2^-40, 2^40) with random low mantissa bits
+        const size_t m = size_t(1) << 24;
+        std::vector<double> hd(m), ad(m);
+        unsigned long long st = 88172645463325252ull;
+        for (size_t i = 0; i < m; ++i) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            const unsigned long long bits = ((1023ull - 40 + (st >> 57) % 80) << 52) | (st & 0xfffffffffffffull);
+            std::memcpy(&hd[i], &bits, 8);
+        }
+        double *ddx, *dda;
+        hipMalloc(&ddx, m * 8); hipMalloc(&dda, m * 8);
+        hipMemcpy(ddx, hd.data(), m * 8, hipMemcpyHostToDevice);
+        kd<<<unsigned((m + 255) / 256), 256>>>(ddx, dda, m);
+        hipMemcpy(ad.data(), dda, m * 8, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < m; ++i) { const double want = std::sqrt(hd[i]); if (std::memcmp(&want, &ad[i], 8)) { if (bad++ < 3) std::printf("sqrt(%a) = %a, host %a\n", hd[i], ad[i], want); } }
+        std::printf("%zu f64 values: sqrt differs from the host's on %zu\n", m, bad);
+    }
     return 0;
 }
