@@ -75,7 +75,7 @@ __device__ __forceinline__ unsigned fps_wave_umin(unsigned v)
 
 constexpr int FPS_THREADS = 1024, FPS_PMAX = 16;      // up to 16384 points on the device; longer clouds take the host loop
 // The square root is spelled sqrtf: with this toolchain that is the correctly rounded one (bit-equal to the host's on 26 M values incl. every float in
-// [1, 4) and denormals), while __fsqrt_rn compiles to the bare v_sqrt_f32 and is one ulp off on 15 % of them (scripts/exp/sqrt_check.hip).
+// [1, 4) and denormals), while __fsqrt_rn compiles to the bare v_sqrt_f32 and is one ulp off on 15 % of them (scripts/exp/fp_rounding_check.hip).
 // (the per-thread points are sixteen sets of NAMED scalars, expanded by macro: as arrays the compiler kept them in 16-register tuples and moved whole tuples
 // around every conditional element update -- 1173 spilled registers)
 #define FPS_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)

@@ -10,6 +10,11 @@ __global__ void k(const float *x, float *a, float *b, size_t n)
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = __fsqrt_rn(x[i]); b[i] = sqrtf(x[i]); }
 }
+__global__ void kdiv(const float *x, const float *y, float *q, const double *xd, const double *yd, double *qd, size_t n)
+{
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = x[i] / y[i]; qd[i] = xd[i] / yd[i]; }
+}
 __global__ void kd(const double *x, double *a, size_t n)
 {
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -52,6 +57,33 @@ int main()
         size_t bad = 0;
         for (size_t i = 0; i < m; ++i) { const double want = std::sqrt(hd[i]); if (std::memcmp(&want, &ad[i], 8)) { if (bad++ < 3) std::printf("sqrt(%a) = %a, host %a\n", hd[i], ad[i], want); } }
         std::printf("%zu f64 values: sqrt differs from the host's on %zu\n", m, bad);
+    }
+    {   // divisions, f32 and f64, on 2^24 random operand pairs
+        const size_t m = size_t(1) << 24;
+        std::vector<float> x(m), y(m), q(m);
+        std::vector<double> xd(m), yd(m), qd(m);
+        unsigned long long st = 0x9e3779b97f4a7c15ull;
+        auto next = [&] { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        for (size_t i = 0; i < m; ++i) {
+            unsigned a = unsigned(((127u - 20 + unsigned(next() >> 58) % 40) << 23) | unsigned(next() & 0x7fffff)), b = unsigned(((127u - 20 + unsigned(next() >> 58) % 40) << 23) | unsigned(next() & 0x7fffff));
+            std::memcpy(&x[i], &a, 4); std::memcpy(&y[i], &b, 4);
+            unsigned long long c = ((1023ull - 30 + (next() >> 57) % 60) << 52) | (next() & 0xfffffffffffffull), d = ((1023ull - 30 + (next() >> 57) % 60) << 52) | (next() & 0xfffffffffffffull);
+            std::memcpy(&xd[i], &c, 8); std::memcpy(&yd[i], &d, 8);
+        }
+        float *dx2, *dy2, *dq2; double *dxd, *dyd, *dqd;
+        hipMalloc(&dx2, m * 4); hipMalloc(&dy2, m * 4); hipMalloc(&dq2, m * 4); hipMalloc(&dxd, m * 8); hipMalloc(&dyd, m * 8); hipMalloc(&dqd, m * 8);
+        hipMemcpy(dx2, x.data(), m * 4, hipMemcpyHostToDevice); hipMemcpy(dy2, y.data(), m * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dxd, xd.data(), m * 8, hipMemcpyHostToDevice); hipMemcpy(dyd, yd.data(), m * 8, hipMemcpyHostToDevice);
+        kdiv<<<unsigned((m + 255) / 256), 256>>>(dx2, dy2, dq2, dxd, dyd, dqd, m);
+        hipMemcpy(q.data(), dq2, m * 4, hipMemcpyDeviceToHost); hipMemcpy(qd.data(), dqd, m * 8, hipMemcpyDeviceToHost);
+        size_t bad32 = 0, bad64 = 0;
+        for (size_t i = 0; i < m; ++i) {
+            const volatile float w32 = x[i] / y[i]; const volatile double w64 = xd[i] / yd[i];
+            const float w32n = w32; const double w64n = w64;
+            if (std::memcmp(&w32n, &q[i], 4)) ++bad32;
+            if (std::memcmp(&w64n, &qd[i], 8)) ++bad64;
+        }
+        std::printf("%zu operand pairs: f32 division differs from the host's on %zu, f64 division on %zu\n", m, bad32, bad64);
     }
     return 0;
 }
