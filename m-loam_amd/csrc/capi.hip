@@ -1610,32 +1610,80 @@ int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7])
     return mlh_fuse_add_rings(ctx, 0, ctx->scan.n_rings, lidar_idx, ext_pose);
 }
 
+// The two record counts and the two bounding boxes of the fused clouds, reduced over the appends' per-workgroup partial boxes and written straight into pinned
+// host memory by one launch (sequence word last, system-scope release): what used to be two copies and a marker launch behind them.
+__global__ __launch_bounds__(256) void fused_publish_kernel(const int *__restrict__ cnt2, const float *__restrict__ part, int n_boxes_per_kind_and_part, int parts,
+                                                            int *h_cnt, float *h_box, unsigned long long *h_seq, unsigned long long seq)
+{
+    __shared__ float s_red[4][12];
+    const int t = threadIdx.x;
+    float v[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) v[c] = (c % 6) < 3 ? FLT_MAX : -FLT_MAX;
+    for (int i = t; i < parts * n_boxes_per_kind_and_part; i += 256) {          // one partial box of each kind per step: [append][kind][workgroup][6]
+        const int a = i / n_boxes_per_kind_and_part, b = i - a * n_boxes_per_kind_and_part;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *q = part + (size_t(a) * 2 * n_boxes_per_kind_and_part + size_t(k) * n_boxes_per_kind_and_part + b) * 6;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) v[k * 6 + d] = d < 3 ? fminf(v[k * 6 + d], q[d]) : fmaxf(v[k * 6 + d], q[d]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(v[c], off, 64); v[c] = (c % 6) < 3 ? fminf(v[c], o) : fmaxf(v[c], o); }
+    }
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s_red[t >> 6][c] = v[c];
+    }
+    __syncthreads();
+    if (t < 12) {
+        const bool lo = (t % 6) < 3;
+        float r = s_red[0][t];
+        for (int w = 1; w < 4; ++w) r = lo ? fminf(r, s_red[w][t]) : fmaxf(r, s_red[w][t]);
+        h_box[t] = r;
+    }
+    if (t == 0) { h_cnt[0] = cnt2[0]; h_cnt[1] = cnt2[1]; }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n)
 {
     if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
     if (ctx->fused_dirty) {
         MLH_HIP(ctx, hipSetDevice(ctx->device));
-        const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6, n_floats = part_floats * size_t(ctx->fused_parts);
-        const size_t need = 16 + sizeof(float) * n_floats;          // pinned: a pageable landing buffer costs a staging hop per copy
-        if (need > ctx->fused_host_cap) {
-            if (ctx->fused_host) (void)hipHostFree(ctx->fused_host);
-            ctx->fused_host = nullptr; ctx->fused_host_cap = 0;
-            MLH_HIP(ctx, hipHostMalloc(&ctx->fused_host, need * 2, hipHostMallocDefault));
-            ctx->fused_host_cap = need * 2;
+        if (!ctx->fused_host) {
+            MLH_HIP(ctx, hipHostMalloc(&ctx->fused_host, 128, hipHostMallocDefault));
+            std::memset(ctx->fused_host, 0, 128);
+            ctx->fused_host_cap = 128;
         }
         int *h_cnt = static_cast<int *>(ctx->fused_host);
-        const float *hp_data = reinterpret_cast<const float *>(static_cast<char *>(ctx->fused_host) + 16);
-        MLH_HIP(ctx, hipMemcpyAsync(h_cnt, ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        MLH_HIP(ctx, hipMemcpyAsync(static_cast<char *>(ctx->fused_host) + 16, ctx->fused_part.p, sizeof(float) * n_floats, hipMemcpyDeviceToHost, ctx->stream));
-        MLH_HIP(ctx, stream_wait_spin(ctx));
-        ctx->fused_n[0] = h_cnt[0]; ctx->fused_n[1] = h_cnt[1];
-        for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
-        for (int a = 0; a < ctx->fused_parts; ++a)
-            for (int k = 0; k < 2; ++k)
-                for (int b = 0; b < FUSE_BLOCKS; ++b) {
-                    const float *q = hp_data + (size_t(a) * 2 * FUSE_BLOCKS + size_t(k) * FUSE_BLOCKS + b) * 6;
-                    for (int d = 0; d < 3; ++d) { ctx->fused_minmax[k][d] = std::fmin(ctx->fused_minmax[k][d], q[d]); ctx->fused_minmax[k][3 + d] = std::fmax(ctx->fused_minmax[k][3 + d], q[3 + d]); }
+        float *h_box = reinterpret_cast<float *>(static_cast<char *>(ctx->fused_host) + 16);
+        unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(static_cast<char *>(ctx->fused_host) + 64);
+        const unsigned long long seq = ++ctx->fused_seq;
+        hipLaunchKernelGGL(fused_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int *)(ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts),
+                           (const float *)ctx->fused_part.as<float>(), FUSE_BLOCKS, ctx->fused_parts, h_cnt, h_box, h_seq, seq);
+        MLH_HIP(ctx, hipGetLastError());
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "the fused clouds' sizes did not arrive");
+                    break;
                 }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+        ctx->fused_n[0] = h_cnt[0]; ctx->fused_n[1] = h_cnt[1];
+        for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = h_box[k * 6 + d];
         ctx->fused_dirty = false;
     }
     *device_points = ctx->fused[kind].p;

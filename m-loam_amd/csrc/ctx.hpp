@@ -275,8 +275,10 @@ struct mlh_ctx {
     hipEvent_t ev_handover = nullptr;      // mlh_features_copy: recorded on the source context's stream, waited for on this one's
     unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
     unsigned long long sync_seq = 0;
+    unsigned long long counts_seq = 0;      // publications of the thinned feature counts straight from a kernel (voxel.hip)
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
-    void *fused_host = nullptr; // pinned landing block of mlh_fused_cloud's one read-back: [2 counts (padded to 4 ints)][per-workgroup bounding boxes]
+    void *fused_host = nullptr; // pinned record mlh_fused_cloud's publication launch fills: [2 counts (padded to 4 ints)][2 x 6 bounds][sequence word at byte 64]
+    unsigned long long fused_seq = 0;
     size_t fused_host_cap = 0;
     mlh::DevBuf fused_cnt;   // the two record counts, device side (appends never wait for the host)
     size_t fused_bound[2] = {0, 0};   // host-side upper bounds of the counts (capacity)

@@ -14,6 +14,7 @@
 //                        Sigma_meas) G^T]_3x3 with G = [(T p)^odot | T D], f64, stored to the f32 cov_vec of PointXYZIWithCov;
 //                        points whose trace exceeds TRACE_THRESHOLD_MAPPING are dropped (order-preserving compaction).
 #include "ctx.hpp"
+#include <chrono>
 #include "dev_math.hpp"
 #include "sort_dev.hpp"
 #include <cfloat>
@@ -580,14 +581,23 @@ __global__ __launch_bounds__(256) void features_from_kept_pair_kernel(const unsi
                                                                        const int *__restrict__ n_records, const int *__restrict__ wpre, int first_word,
                                                                        const int *__restrict__ keep, const int *__restrict__ slot, const int *__restrict__ kept_total,
                                                                        const float *__restrict__ cov6, float4 *__restrict__ pts0, float4 *__restrict__ covd0,
-                                                                       float4 *__restrict__ pts1, float4 *__restrict__ covd1, int *__restrict__ counts)
+                                                                       float4 *__restrict__ pts1, float4 *__restrict__ covd1, int *__restrict__ counts,
+                                                                       int *host_counts, unsigned long long *host_seq, unsigned long long seq)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int first_records = wpre[first_word];                  // records (occupied voxels) of the first cloud
     const int total_records = *n_records;
     // kept records of the first cloud = exclusive scan of the keep flags at position first_records
     const int first_kept = first_records < total_records ? slot[first_records] : *kept_total;
-    if (i == 0) { counts[0] = first_kept; counts[1] = *kept_total - first_kept; }
+    if (i == 0) {
+        counts[0] = first_kept; counts[1] = *kept_total - first_kept;
+        // the two counts are all the host waits for, and they are known before this launch has moved a single record: they go to pinned host memory from
+        // here (no copy and no marker launch behind the kernel), and the host is back enqueueing the solver's launches while the records are still being moved
+        if (host_seq) {
+            host_counts[0] = first_kept; host_counts[1] = *kept_total - first_kept;
+            __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (i >= n || i >= total_records || !keep[i]) return;
     const float *r = reinterpret_cast<const float *>(recs + size_t(i) * stride);
     const float inten = intensity_off >= 0 ? *reinterpret_cast<const float *>(recs + size_t(i) * stride + intensity_off) : 0.f;
@@ -636,17 +646,42 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
     FeatSet &f0 = ctx->feat[MLH_SURF], &f1 = ctx->feat[MLH_CORNER];
     MLH_HIP(ctx, f0.pts.ensure(sizeof(float4) * size_t(n_surf))); MLH_HIP(ctx, f0.covd.ensure(sizeof(float4) * size_t(n_surf)));
     MLH_HIP(ctx, f1.pts.ensure(sizeof(float4) * size_t(n_corner))); MLH_HIP(ctx, f1.covd.ensure(sizeof(float4) * size_t(n_corner)));
+    // pinned record for the counts: ints 16..17 and the 64-bit word at byte 128 of the context's pinned scratch block
+    int *h_counts = nullptr;
+    unsigned long long *h_seq = nullptr, seq = 0;
+    if (int *hp = pinned_ints(ctx)) {
+        h_counts = hp + 16;
+        h_seq = reinterpret_cast<unsigned long long *>(hp + 32);
+        if (ctx->counts_seq == 0) *h_seq = 0;
+        seq = ++ctx->counts_seq;
+    }
     hipLaunchKernelGGL(features_from_kept_pair_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
                        (const int *)V.total.as<int>(), (const int *)V.wpre.as<int>(), first_word, (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(),
                        (const int *)(V.total.as<int>() + 1), (const float *)d_c6, f0.pts.as<float4>(), f0.covd.as<float4>(), f1.pts.as<float4>(), f1.covd.as<float4>(),
-                       V.total.as<int>() + 2);
+                       V.total.as<int>() + 2, h_counts, h_seq, seq);
     MLH_HIP(ctx, hipGetLastError());
-    int stack_counts[2] = {0, 0};
-    int *counts = pinned_ints(ctx) ? pinned_ints(ctx) : stack_counts;          // pinned: no staging hop for an 8-byte read-back
-    MLH_HIP(ctx, hipMemcpyAsync(counts, V.total.as<int>() + 2, sizeof(stack_counts), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, counts == stack_counts ? hipStreamSynchronize(st) : stream_wait_spin(ctx));
-    *n_surf_out = counts[0];
-    *n_corner_out = counts[1];
+    if (h_seq) {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                MLH_HIP(ctx, hipStreamSynchronize(st));
+                if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "the thinned feature counts did not arrive");
+                break;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        *n_surf_out = h_counts[0];
+        *n_corner_out = h_counts[1];
+    } else {
+        int stack_counts[2] = {0, 0};
+        MLH_HIP(ctx, hipMemcpyAsync(stack_counts, V.total.as<int>() + 2, sizeof(stack_counts), hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        *n_surf_out = stack_counts[0];
+        *n_corner_out = stack_counts[1];
+    }
     return device_error_check(ctx);
 }
 
