@@ -468,10 +468,9 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
         prev_end = he[r];
         max_len = std::max(max_len, he[r] - hs[r]);
     }
-    MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(n_rings)));
-    MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(n_rings)));
-    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hs, sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
-    MLH_HIP(ctx, hipMemcpyAsync(sb.end.p, he, sizeof(int) * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    MLH_HIP(ctx, sb.start.ensure(sizeof(int) * 2 * size_t(n_rings)));                  // [start | end], as they sit in the pinned block: one copy
+    MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hs, sizeof(int) * 2 * n_rings, hipMemcpyHostToDevice, ctx->stream));
+    sb.end_alias = sb.start.as<int>() + n_rings;
     MLH_HIP(ctx, hipEventRecord(ctx->ev_rings[half], ctx->stream));
     ctx->ev_rings_used[half] = true;
     // The caller's point buffer: a copy out of PAGEABLE memory has been staged by the time hipMemcpyAsync returned; out of pinned memory it is truly
@@ -1581,8 +1580,8 @@ int mlh_fuse_reset(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    MLH_HIP(ctx, ctx->fused_cnt.ensure(sizeof(int) * 2 * 8));                      // prefix table of the record counts, one pair per append (grows)
-    MLH_HIP(ctx, hipMemsetAsync(ctx->fused_cnt.p, 0, sizeof(int) * 2, ctx->stream));
+    MLH_HIP(ctx, ctx->fused_cnt.ensure(sizeof(int) * 2 * 8));                      // prefix table of the record counts, one pair per append (grows);
+                                                                                   // its first row is never read: the first append starts from zero by argument
     ctx->fused_n[0] = ctx->fused_n[1] = 0;
     ctx->fused_bound[0] = ctx->fused_bound[1] = 0;
     ctx->fused_parts = 0;
@@ -1656,6 +1655,14 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
     if (!ctx || kind < 0 || kind > 1 || !device_points || !n) return MLH_ERR_INVALID;
     if (ctx->fused_dirty) {
         MLH_HIP(ctx, hipSetDevice(ctx->device));
+        if (ctx->fused_parts == 0) {                                // nothing appended since the reset
+            ctx->fused_n[0] = ctx->fused_n[1] = 0;
+            for (int k = 0; k < 2; ++k) for (int d = 0; d < 6; ++d) ctx->fused_minmax[k][d] = d < 3 ? FLT_MAX : -FLT_MAX;
+            ctx->fused_dirty = false;
+            *device_points = ctx->fused[kind].p;
+            *n = 0;
+            return MLH_OK;
+        }
         if (!ctx->fused_host) {
             MLH_HIP(ctx, hipHostMalloc(&ctx->fused_host, 128, hipHostMallocDefault));
             std::memset(ctx->fused_host, 0, 128);

@@ -160,6 +160,8 @@ struct FeatSet {
 struct ScanBuf {
     DevBuf pts;            // float4 {x,y,z,intensity}
     DevBuf start, end;     // per ring
+    int *end_alias = nullptr;   // mlh_scan_upload sends both tables in one copy: the end table then sits behind the start table in `start`
+    int *end_ptr() { return end_alias ? end_alias : end.as<int>(); }
     DevBuf curvature, label, picked;
     DevBuf stage;          // per-ring staged picks
     DevBuf ring_counts;    // 4 counts per ring

@@ -112,7 +112,8 @@ struct FuseArgs {
     int rb, re;                // rings [rb, re) of the scan
     FuseXf xf;
     float4 *out[2];            // fused surf / corner clouds
-    const int *cnt;            // record counts before this append ...
+    const int *cnt;            // record counts before this append (not read by the first append after a reset: `first`) ...
+    int first;
     int *cnt_next;             // ... and after it (the next append's base): a prefix table, one pair per append
     float *part;               // this append's partial bounds: [kind][FUSE_BLOCKS][6]
 };
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
     const int kind = blockIdx.y;                       // 0: surf <- voxel-thinned less-flat, 1: corner <- less-sharp
     const int b = kind == 0 ? A.vox_off[A.rb] : A.ring_offsets[A.rb * 4 + 1];
     const int e = kind == 0 ? A.vox_off[A.re] : A.ring_offsets[A.re * 4 + 1];
-    const int base = A.cnt[kind];
+    const int base = A.first ? 0 : A.cnt[kind];
     if (blockIdx.x == 0 && threadIdx.x == 0) A.cnt_next[kind] = base + (e - b);      // depends on nothing the other workgroups do: no bump launch
     const FuseXf &xf = A.xf;
     float m[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -172,6 +173,7 @@ int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     A.ring_offsets = sb.ring_offsets.as<int>(); A.vox_off = sb.ring_vox.as<int>() + sb.n_rings;
     // counts: prefix table [append][kind]; this append reads row `fused_parts` and writes row `fused_parts + 1`
     MLH_HIP(ctx, ctx->fused_cnt.grow(sizeof(int) * 2 * size_t(ctx->fused_parts + 2), sizeof(int) * 2 * size_t(ctx->fused_parts + 1), st));
+    A.first = ctx->fused_parts == 0 ? 1 : 0;
     A.rb = ring_begin; A.re = ring_end; A.cnt = ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts; A.cnt_next = ctx->fused_cnt.as<int>() + 2 * (ctx->fused_parts + 1);
     const size_t part_floats = size_t(2) * FUSE_BLOCKS * 6;
     MLH_HIP(ctx, ctx->fused_part.grow(sizeof(float) * part_floats * size_t(ctx->fused_parts + 1), sizeof(float) * part_floats * size_t(ctx->fused_parts), st));

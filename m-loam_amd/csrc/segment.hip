@@ -330,6 +330,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     MLH_HIP(ctx, sb.pts.ensure(sizeof(float4) * size_t(std::max(n_keep, 1))));
     MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(vs)));
     MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(vs)));
+    sb.end_alias = nullptr;                                   // this path fills the two tables separately
     MLH_HIP(ctx, B.keep.ensure(sizeof(int) * size_t(std::max(n_keep, 1))));
     if (n_keep > 0) {
         MLH_HIP(ctx, hipMemcpyAsync(B.keep.p, keep.data(), sizeof(int) * size_t(n_keep), hipMemcpyHostToDevice, st));
