@@ -252,13 +252,16 @@ hipError_t stream_wait_spin(mlh_ctx *ctx)
 }
 
 // the pinned record and the next sequence number (allocated on first use)
-static int publish_slot(mlh_ctx *ctx, HostPublish **h, unsigned long long *seq)
+// Three pinned records. Record 0 is everybody's; records 1 and 2 belong to scan2map's LM driver, which has one publication being read and the next chunk's
+// already enqueued -- and may return with that one still to arrive: it must not land in a record some later call (a map staging on the other stream, say)
+// is polling. which < 0: record 0; otherwise record 1 + (which & 1).
+static int publish_slot(mlh_ctx *ctx, HostPublish **h, unsigned long long *seq, int which = -1)
 {
     if (!ctx->h_state) {
-        MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, sizeof(HostPublish), hipHostMallocDefault));
-        std::memset(ctx->h_state, 0, sizeof(HostPublish));
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_state, 3 * sizeof(HostPublish), hipHostMallocDefault));
+        std::memset(ctx->h_state, 0, 3 * sizeof(HostPublish));
     }
-    *h = static_cast<HostPublish *>(ctx->h_state);
+    *h = static_cast<HostPublish *>(ctx->h_state) + (which < 0 ? 0 : 1 + (which & 1));
     *seq = ++ctx->publish_seq;
     return MLH_OK;
 }
@@ -1358,6 +1361,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     const int first_chunk = 6, next_chunk = 2;
     HostPublish last_hp;
     bool have_hp = false;  // fused path: the last chunk's publication already carries the pose
+    int lm_chunk_idx = 0;  // which of the two pinned publication records the next chunk writes
     std::mt19937 rng((uint32_t)opts->gf_seed);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         if (fused) {
@@ -1385,25 +1389,50 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
             if ((rc = linearize_launch(ctx, a))) return rc;
         }
         if (!fused_lm && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
-        for (int it = 0, j_end = 0; it < opts->max_lm_iterations; it = j_end) {
-            j_end = std::min(it + (it == 0 ? first_chunk : next_chunk), opts->max_lm_iterations);
-            unsigned long long seq = 0;
-            for (int j = it; j < j_end; ++j) {
-                MatchArgs a = args_from_opts(opts, 3, 1);
-                if (fused_lm) {
+        if (fused_lm) {
+            // Chunks of LM launches, each ending in a launch that publishes pose + `done` itself. The chunk after the one whose verdict the host is waiting for
+            // is already enqueued (into the other pinned record): when the verdict is "not yet" the GPU has gone on without the host's round trip (~15 us of idle
+            // stream per poll in profiles/r03_frame_cpp_timeline_*.txt), when it is "done" the chunk ahead is two launches that find `done` set and leave.
+            struct Pending { unsigned long long seq; HostPublish *rec; } pend[2];
+            int n_pend = 0, enq = 0;
+            auto enqueue_chunk = [&](int count) -> int {
+                for (int j = 0; j < count; ++j) {
+                    MatchArgs a = args_from_opts(opts, 3, 1);
                     a.finish = 4; a.lm_max_it = opts->max_lm_iterations;
-                    if (j == j_end - 1) {                   // the chunk's last launch publishes pose + `done` itself (no publication launch)
-                        if ((rc = publish_slot(ctx, &a.publish, &seq))) return rc;
+                    if (j == count - 1) {                   // the chunk's last launch publishes (no publication launch)
+                        unsigned long long seq = 0;
+                        int prc = publish_slot(ctx, &a.publish, &seq, lm_chunk_idx);
+                        if (prc) return prc;
                         a.publish_seq = seq;
+                        pend[n_pend++] = Pending{seq, a.publish};
                     }
+                    int lrc = linearize_launch(ctx, a);
+                    if (lrc) return lrc;
                 }
-                if ((rc = linearize_launch(ctx, a))) return rc;
-                if (!fused_lm && (rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+                ++lm_chunk_idx;
+                enq += count;
+                return MLH_OK;
+            };
+            if ((rc = enqueue_chunk(std::min(first_chunk, opts->max_lm_iterations)))) return rc;
+            for (;;) {
+                if (enq < opts->max_lm_iterations && n_pend < 2 && (rc = enqueue_chunk(std::min(next_chunk, opts->max_lm_iterations - enq)))) return rc;
+                HostPublish hp;                             // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
+                if ((rc = wait_published(ctx, pend[0].seq, hp, pend[0].rec))) return rc;
+                last_hp = hp; have_hp = true;
+                pend[0] = pend[1]; --n_pend;
+                if (hp.done || n_pend == 0) break;
             }
-            HostPublish hp;                                 // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
-            if (fused_lm) { if ((rc = wait_published(ctx, seq, hp))) return rc; last_hp = hp; have_hp = true; }
-            else if ((rc = fetch_published(ctx, hp))) return rc;
-            if (hp.done) break;
+        } else {
+            for (int it = 0, j_end = 0; it < opts->max_lm_iterations; it = j_end) {
+                j_end = std::min(it + (it == 0 ? first_chunk : next_chunk), opts->max_lm_iterations);
+                for (int j = it; j < j_end; ++j) {
+                    if ((rc = linearize_launch(ctx, args_from_opts(opts, 3, 1)))) return rc;
+                    if ((rc = lm_step_launch(ctx, opts->max_lm_iterations, -1))) return rc;
+                }
+                HostPublish hp;
+                if ((rc = fetch_published(ctx, hp))) return rc;
+                if (hp.done) break;
+            }
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
     }
