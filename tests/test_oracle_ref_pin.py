@@ -326,6 +326,31 @@ def test_good_feature_matching_is_the_references(ref, case16, feats16, method):
                 assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
 
 
+@pytest.mark.parametrize("variant", ["lattice", "duplicates"])
+def test_fps_equal_distances_are_decided_as_the_reference_decides_them(ref, case16, feats16, variant):
+    """The farthest-point loop of goodFeatureMatching ('fps', lidar_mapper.h:352-408) takes the FIRST index among equal distances (a strict `>` over
+    ascending indices). The device kernel that runs this loop (select.hip: fps_order_kernel) is held to the oracle on inputs that produce such ties by the
+    thousand (tests/test_gpu_parity.py::test_fps_selection_on_the_device_ties_and_edge_sizes); here the oracle is held to the reference's own lines on the
+    same kind of input: features snapped to a 0.25 m lattice, and features repeated verbatim."""
+    rng = np.random.default_rng(16)
+    f = feats16[0][:1500].copy()
+    if variant == "lattice":
+        f[:, :3] = np.round(f[:, :3] * 4.0) / 4.0
+    else:
+        f = np.ascontiguousarray(np.concatenate([f[:500], f[:500], f[:200][::-1], f[500:1000]]))
+    f11 = _with_cov(f, rng)
+    # how many exact ties the loop meets on its first step alone (distances from one point to all others, in the loop's f32 arithmetic)
+    d0 = np.sqrt(((f[:, :3] - f[0, :3]).astype(np.float32) ** 2).sum(1, dtype=np.float32))
+    assert len(d0) - len(np.unique(d0)) > 100
+    om = ref.Map(case16["surf_map"])
+    for seed in (1, 7, 12345):
+        r = ref.ref_good_feature_matching(case16["surf_map"], "s", f11, case16["p0"], "fps", 0.2, seed)
+        o = ref.good_feature_matching(om, "s", f11, case16["p0"], ref.mapper_params(with_ua=True, gf_method="fps", gf_ratio=0.2, seed=seed))
+        assert len(r["sel"]) > 20
+        assert np.array_equal(r["sel"], o["sel"]), (variant, seed)
+        assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
+
+
 def test_track_matching_is_the_references(ref, track_case):
     """LidarTracker's correspondence search -- FeatureExtract::matchCornerFromScan / matchSurfFromScan (feature_extract.hpp:131-376: nearest
     previous-frame point, then the two scan-line walks with NEARBY_SCAN and DISTANCE_SQ_THRESHOLD) over TransformToStart (utility.h:54-77) --
