@@ -362,6 +362,27 @@ def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats
         c.close()
 
 
+@pytest.mark.parametrize("method", ["gd_fix", "rnd"])
+def test_selection_with_repeated_features_parity(mla, orc, case16, feats16, method):
+    """Features repeated verbatim: subsets of the greedy loop whose members score exactly alike are replayed through the reference's heap, so the HIP path
+    picks what the oracle picks (and the oracle what the reference's own lines pick: tests/test_oracle_ref_pin.py::test_selection_with_repeated_features_is_the_references)."""
+    f = feats16[0][:1200]
+    f = np.ascontiguousarray(np.concatenate([f[:400], f[:400], f[:400], f[400:800], f[400:800]]))
+    c = mla.Context(0)
+    try:
+        c.map_set(mla.SURF, case16["surf_map"])
+        c.features_set(mla.SURF, f)
+        for seed in (3, 99):
+            for ratio in (0.2, 0.5):
+                got = c.good_feature_matching(mla.SURF, case16["p0"], gf_method=method, gf_ratio=ratio, seed=seed)
+                ref = orc.good_feature_matching(orc.Map(case16["surf_map"]), "s", f, case16["p0"], orc.mapper_params(gf_method=method, gf_ratio=ratio, seed=seed))
+                assert len(ref["sel"]) > 50
+                assert np.array_equal(got["sel"], ref["sel"]), (method, seed, ratio)
+                np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-9, atol=1e-9)
+    finally:
+        c.close()
+
+
 def test_greedy_selection_lemma_scoring_equals_literal_scoring(ctx, mla, case16, feats16, monkeypatch):
     """The greedy loop ranks a subset's members by j H^-1 j^T (matrix determinant lemma) and replays near ties with the reference's
     logdet arithmetic; MLH_SELECT_EXACT=1 scores every member with the literal Cholesky logdet (lidar_mapper.h:497-520). Same picks,

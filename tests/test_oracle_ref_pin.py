@@ -351,6 +351,26 @@ def test_fps_equal_distances_are_decided_as_the_reference_decides_them(ref, case
         assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
 
 
+@pytest.mark.parametrize("method", ["gd_fix", "rnd"])
+def test_selection_with_repeated_features_is_the_references(ref, case16, feats16, method):
+    """Features repeated verbatim give the stochastic-greedy loop subsets whose members score EXACTLY alike: which of them std::priority_queue leaves on top is
+    the reference's container's business, and the oracle (and through it the HIP path, which replays such subsets through the same heap) has to agree with the
+    reference's own lines there too. `rnd` rides along: repeated features do not change its draws, only what they hit."""
+    rng = np.random.default_rng(26)
+    f = feats16[0][:1200]
+    f = np.ascontiguousarray(np.concatenate([f[:400], f[:400], f[:400], f[400:800], f[400:800]]))
+    f11 = _with_cov(f, rng)
+    f11[400:800] = f11[:400]; f11[800:1200] = f11[:400]; f11[1600:2000] = f11[1200:1600]     # the same covariance columns too: identical rows
+    om = ref.Map(case16["surf_map"])
+    for seed in (3, 99):
+        for ratio in (0.2, 0.5):
+            r = ref.ref_good_feature_matching(case16["surf_map"], "s", f11, case16["p0"], method, ratio, seed)
+            o = ref.good_feature_matching(om, "s", f11, case16["p0"], ref.mapper_params(with_ua=True, gf_method=method, gf_ratio=ratio, seed=seed))
+            assert len(r["sel"]) > 50
+            assert np.array_equal(r["sel"], o["sel"]), (method, seed, ratio)
+            assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
+
+
 def test_track_matching_is_the_references(ref, track_case):
     """LidarTracker's correspondence search -- FeatureExtract::matchCornerFromScan / matchSurfFromScan (feature_extract.hpp:131-376: nearest
     previous-frame point, then the two scan-line walks with NEARBY_SCAN and DISTANCE_SQ_THRESHOLD) over TransformToStart (utility.h:54-77) --
