@@ -626,6 +626,30 @@ def test_voxel_grid_covariance_mloam_is_the_references(ref):
     assert len(a) > 10 and np.array_equal(a.view(np.uint32), b.view(np.uint32)) and not a[:, :3].any()
 
 
+def test_voxel_grid_points_on_voxel_faces_and_repeated_points(ref):
+    """The same filter on input built to sit on the decision boundaries: coordinates that are exact multiples of the leaf size (which voxel a point on a face
+    belongs to is floor(x * inverse_leaf_size) in f32, negative side included), a cloud whose minimum is itself such a multiple, and points repeated verbatim
+    (equal keys by the hundred inside std::sort's unstable order, which decides the surviving intensity of the plain branch and the order of the f32 sums)."""
+    rng = np.random.default_rng(78)
+    for leaf in (0.4, 0.2, 0.25):
+        n = 4000
+        rec = _cov_cloud(rng, n, 5.0, 0.01, 0.9)
+        k = np.round(rec[:, :3] / np.float32(leaf))                                     # snap a third of the points onto the faces, another third onto a 4x finer lattice
+        rec[: n // 3, :3] = (k[: n // 3] * np.float32(leaf)).astype(np.float32)
+        rec[n // 3: 2 * n // 3, :3] = (np.round(rec[n // 3: 2 * n // 3, :3] * (4.0 / leaf)) * np.float32(leaf / 4.0)).astype(np.float32)
+        rec = np.ascontiguousarray(np.concatenate([rec, rec[:700], rec[300:900][::-1]]))       # and repeat 1300 of them verbatim
+        rec[:, 3] = rng.integers(0, 2, len(rec)).astype(np.float32)                     # two LiDAR ids, mixed inside voxels
+        plain_ref = ref.ref_voxel_filter(rec[:, :4], leaf)
+        plain_orc = ref.voxel_grid_mloam_plain(rec[:, :4], leaf, member_order=0)
+        assert plain_ref.shape == plain_orc.shape and len(plain_ref) > 100
+        assert np.array_equal(plain_ref.view(np.uint32), plain_orc.view(np.uint32)), leaf
+        for thr in (0.6, 2.0):
+            cov_ref = ref.ref_voxel_filter(rec, leaf, thr)
+            cov_orc = ref.voxel_grid_cov(rec, leaf, thr)
+            assert cov_ref.shape == cov_orc.shape
+            assert np.array_equal(cov_ref.view(np.uint32), cov_orc.view(np.uint32)), (leaf, thr)
+
+
 def _features11(synth, feats, cov_scale, rng):
     """(m, 4) features -> (m, 11) PointXYZIWithCov records with a small per-point covariance (so that with_ua weighs them differently)"""
     out = np.zeros((len(feats), 11), np.float32)
