@@ -1375,7 +1375,7 @@ def test_window_factor_table_built_on_the_device(mla, orc, synth, case16, feats1
 def test_window_local_map_building_blocks(ctx, mla, orc, case16):
     """Estimator::buildLocalMap (estimator.cpp:1160-1203) from its parts: every window frame's cloud into the pivot frame
     (pcl::transformPointCloud with the float 4x4: bit for bit), the union thinned by pcl::VoxelGrid<PointXYZI> (same voxels in the
-    same order, centroids to f32 rounding of a differently ordered sum), indexed, matched."""
+    same order, centroids summed in the member order std::sort leaves: bit for bit), indexed, matched."""
     rng = np.random.default_rng(17)
     base = np.zeros((len(case16["surf_map"]), 4), np.float32)
     base[:, :3] = case16["surf_map"][:, :3]
@@ -1395,8 +1395,7 @@ def test_window_local_map_building_blocks(ctx, mla, orc, case16):
     ds_g = ctx.voxel_grid(union, leaf)
     ds_r = orc.voxel_grid(union, leaf)
     assert ds_g.shape == ds_r.shape and len(ds_g) < len(union)
-    np.testing.assert_allclose(ds_g, ds_r, rtol=2e-6, atol=2e-6)
-    assert np.mean(ds_g.view(np.uint32) == ds_r.view(np.uint32)) > 0.5
+    np.testing.assert_array_equal(ds_g.view(np.uint32), ds_r.view(np.uint32))
     # the thinned cloud as the odometry local map: exact 5-NN through the same index the mapper uses
     ctx.map_set(mla.SURF, np.ascontiguousarray(ds_g[:, :3]))
     qm = ds_g[rng.integers(0, len(ds_g), 300), :3] + rng.normal(0, 0.1, (300, 3)).astype(np.float32)
