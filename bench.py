@@ -9,10 +9,16 @@ A *step* is one frame of the mapper's scan-to-map optimisation on synthetic inpu
   residual + 1x6 Jacobian were produced and reduced into the normal equations -- summed over the 5 iterations / step time, whole
   job; every query (valid or rejected) per second is reported beside it as `queries_per_s`. Workload at N = 1: BASELINE.json configs[1] (2 x 64-ring scan vs ~500k-point local map, 5 GN iterations).
   At N > 1 the map grows with N (1M / 2M / 4M points, configs[2..3]) and is sharded spatially across the ranks, the
-  scan stays the same 2 x 64 rings -> "scaling": "strong" (total feature work is fixed).
+  scan stays the same 2 x 64 rings -> "scaling": "strong" (total feature work is fixed). Because the map differs from the N = 1 line's,
+  every N > 1 line also carries `multi_gpu.n1_same_map_ms_per_step`: rank 0 alone, unsharded, on THIS line's map, measured in the
+  same process before the sharded leg -- the reference a strong-scaling ratio on one problem needs.
 
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+Launch for N > 1: either the driver's  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                    --master-port P bench.py --gpus N --steps K --warmup W
+                  or simply  python bench.py --gpus N ...  -- with WORLD_SIZE unset the script spawns its N ranks itself (the same
+                  torch.distributed.run line, a free port). WORLD_SIZE set but different from --gpus is an error (exit 2), never a
+                  silently smaller run. Fewer GPUs than ranks (a one-GPU box): the ranks share devices through the mailbox
+                  communicator -- a functional check of the N > 1 path, flagged `ranks_share_gpus` in the line, not a scaling number.
 """
 from __future__ import annotations
 
@@ -111,6 +117,76 @@ def candidate_stats(map_pts, feats_xyz_map, h):
     return float(tot[ok].mean()), float(ball[ok].mean())
 
 
+def single_gpu_reference(mla, torch, device, surf_map, corner_map, surf, corner, p0, steps, warmup):
+    """the frame of this run on ONE GPU, whole map, no communicator: ms per step (map staging + index build + 5 GN iterations) with synchronous submission
+    and with the pipelined + overlapped-staging submission of the N = 1 bench line. Used by rank 0 of an N > 1 run as the same-map reference."""
+    c = mla.Context(device)
+    try:
+        d_sm, d_cm = torch.from_numpy(np.ascontiguousarray(surf_map)).cuda(), torch.from_numpy(np.ascontiguousarray(corner_map)).cuda()
+        d_s, d_c = torch.from_numpy(surf).cuda(), torch.from_numpy(corner).cuda()
+        torch.cuda.synchronize()
+        c.map_set_pair(d_sm, d_cm)
+        c.features_set(mla.SURF, d_s)
+        c.features_set(mla.CORNER, d_c)
+        opts = mla.default_opts()
+        pose_conv, st = c.gn_solve(p0, GN_ITERS, opts, want_stats=True)
+        n_valid = int(sum(int(x["n_surf"]) + int(x["n_corner"]) for x in st))
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < 0.15:      # clocks up (see the spin-up note in main)
+            c.map_set_pair(d_sm, d_cm)
+            c.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        for _ in range(warmup):
+            c.map_set_pair(d_sm, d_cm)
+            c.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        c.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.map_set_pair(d_sm, d_cm)
+            c.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        c.synchronize()
+        ms_sync = 1e3 * (time.perf_counter() - t0) / steps
+        # pipelined + overlapped staging, as main()'s N = 1 loop
+        c.map_set_pair(d_sm, d_cm)
+        c.gn_solve_begin(p0, GN_ITERS, opts)
+        for _ in range(warmup):
+            c.map_set_pair_overlapped(d_sm, d_cm)
+            c.gn_solve_begin_chained(pose_conv, p0, GN_ITERS, opts)
+            c.gn_solve_end()
+        c.gn_solve_end()
+        c.synchronize()
+        t0 = time.perf_counter()
+        c.map_set_pair(d_sm, d_cm)
+        c.gn_solve_begin(p0, GN_ITERS, opts)
+        for _ in range(steps - 1):
+            c.map_set_pair_overlapped(d_sm, d_cm)
+            c.gn_solve_begin_chained(pose_conv, p0, GN_ITERS, opts)
+            c.gn_solve_end()
+        c.gn_solve_end()
+        c.synchronize()
+        ms_pipe = 1e3 * (time.perf_counter() - t0) / steps
+        return dict(ms_per_step=round(ms_sync, 4), ms_per_step_pipelined=round(ms_pipe, 4), valid_correspondences_per_step=n_valid,
+                    value=round(n_valid / (1e-3 * ms_sync), 1), map_points=int(len(surf_map) + len(corner_map)),
+                    submission="synchronous (as the sharded loop); `ms_per_step_pipelined` = the N = 1 bench line's submission mode on this map")
+    finally:
+        c.close()
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line under torch.distributed.run with N ranks and pass its exit code on"""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: --gpus {n_ranks} without a launcher (WORLD_SIZE unset): spawning the ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,9 +206,14 @@ def main():
     ap.add_argument("--shard-mode", default="map", choices=["map", "features"],
                     help="N > 1: 'map' = angular wedges of the map + halo, ownership by position (BASELINE's partition); 'features' = whole map on every "
                          "rank, features dealt round-robin (SURVEY 8e's balanced alternative)")
-    ap.add_argument("--comm", default="p2p", choices=["p2p", "rccl"],
+    ap.add_argument("--config4", action="store_true",
+                    help="the step is BASELINE config 4's frame instead of config 2's: 4 x 64 rings, one pose block per LiDAR (body pose + 3 extrinsics; N_NEIGH 5/10/10/10, "
+                         "CHECK_FOV, freeze-on-degenerate, Huber 1.0) through mlh_gn_solve_blocks, sharded like the single-pose frame. At --gpus 8 the same frame is "
+                         "measured as a supplementary leg (`config4` in the line) even without this flag")
+    ap.add_argument("--comm", default="p2p", choices=["p2p", "rccl", "both"],
                     help="N > 1: the collective behind the sharded solver -- 'p2p' = the mailbox communicator (hipIpc-mapped mailboxes, one kernel per all-reduce; "
-                         "falls back to RCCL if it cannot be set up or its first all-reduce does not add up), 'rccl' = ncclAllReduce")
+                         "falls back to RCCL if it cannot be set up or its first all-reduce does not add up), 'rccl' = ncclAllReduce, 'both' = the timed loop once "
+                         "with each (value from the mailbox run, the RCCL run reported beside it; needs a GPU per rank)")
     ap.add_argument("--no-overlap-staging", action="store_true",
                     help="pipelined submission, but the next frame's maps are staged on the solver's own stream (queued behind the solve) instead of on a second stream")
     ap.add_argument("--synchronous", action="store_true",
@@ -143,6 +224,11 @@ def main():
                     help="1: HIP-event bracket the dominant kernel (surf correspondence) inside the timed region; 0: none")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                      # does not return
+
     import torch
     import torch.distributed as dist
 
@@ -150,7 +236,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        # never a silently smaller (or larger) job than the one asked for: the line's n_gpus would not be the caller's N
+        log(f"bench.py: FATAL: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # More ranks than GPUs (a one-GPU box, for checking the N > 1 path): the ranks share devices -- the mailbox communicator allows that, RCCL and the "nccl"
@@ -215,23 +303,24 @@ def main():
     surf, corner = fuse_features(synth, scans, extracted, thin=not args.dense_features)
     n_scan_points = int(sum(len(s.points) for s in scans))
 
+    # --- N > 1, before anything is sharded: the SAME frame on the SAME (whole) map by rank 0 alone, unsharded, no communicator -- the N = 1 reference of this line's
+    #     problem (the N = 1 bench line uses the 500k map; a ratio against it would compare two problems). Synchronous submission, like the sharded loop below, and
+    #     the pipelined form beside it. A context of its own, closed before the sharded leg starts; the other ranks wait at the barrier.
+    n1_ref = None
+    if world > 1:
+        if rank == 0:
+            n1_ref = single_gpu_reference(mla, torch, local_rank, surf_map, corner_map, surf, corner, p0, args.steps, args.warmup)
+            log(f"[rank 0] same-map N=1 reference ({preset}): {n1_ref}")
+        dist.barrier()
+
     # --- map shards (N > 1): angular wedges around the predicted sensor position, halo 1.1 m
     center = p0[:2]
-    if world > 1:
-        if args.shard_mode == "map":
-            ms_ = shard.shard_points_mask(surf_map, center, world, rank)
-            mc_ = shard.shard_points_mask(corner_map, center, world, rank)
-            local_surf_map, local_corner_map = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
-        else:
-            local_surf_map, local_corner_map = surf_map, corner_map
-        far = np.full((1, 3), 1.0e6, np.float32)     # a wedge without any map point still needs a (never matched) record
-        if len(local_surf_map) == 0:
-            local_surf_map = far
-        if len(local_corner_map) == 0:
-            local_corner_map = far
-        lo, hi = shard.wedge_planes(center, world, rank)
+    comm_state = dict(kind=None, ranks_seen=None)
+
+    def comm_setup(want):
+        """joins the ranks with the mailbox communicator ('p2p', falling back to RCCL) or RCCL ('rccl'); exits the whole job (3) when neither comes up"""
         comm_kind = "rccl"
-        if args.comm == "p2p":
+        if want == "p2p":
             # the mailbox communicator: handles all-gathered through the process group, every rank maps every mailbox, one all-reduce of ones as the check
             ok_p2p = 1
             try:
@@ -273,6 +362,8 @@ def main():
                 else:
                     ctx.shard_set_features(world, rank)
                 if comm_kind == "rccl":
+                    if shared_gpus:
+                        raise RuntimeError("RCCL needs a GPU per rank; this box has fewer GPUs than ranks")
                     ctx.comm_init(world, rank, uid[0])
             except Exception as e:   # noqa: BLE001
                 comm_ok, comm_err = 0, repr(e)
@@ -280,9 +371,31 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             # no silent degradation to independent replicas: a sharded run without its collective is not a scaling measurement
-            log(f"[rank {rank}] FATAL: RCCL communicator unavailable ({comm_err or 'failed on another rank'})")
+            log(f"[rank {rank}] FATAL: no communicator ({comm_err or 'failed on another rank'})")
             dist.destroy_process_group()
             raise SystemExit(3)
+        comm_state["kind"] = comm_kind
+        comm_state["ranks_seen"] = int(round(float(ctx.allreduce_f64(np.ones(32))[0])))      # what the collective itself says the job's size is
+        if comm_state["ranks_seen"] != world:
+            log(f"[rank {rank}] FATAL: the communicator spans {comm_state['ranks_seen']} ranks, not {world}")
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        return comm_kind
+
+    if world > 1:
+        if args.shard_mode == "map":
+            ms_ = shard.shard_points_mask(surf_map, center, world, rank)
+            mc_ = shard.shard_points_mask(corner_map, center, world, rank)
+            local_surf_map, local_corner_map = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
+        else:
+            local_surf_map, local_corner_map = surf_map, corner_map
+        far = np.full((1, 3), 1.0e6, np.float32)     # a wedge without any map point still needs a (never matched) record
+        if len(local_surf_map) == 0:
+            local_surf_map = far
+        if len(local_corner_map) == 0:
+            local_corner_map = far
+        lo, hi = shard.wedge_planes(center, world, rank)
+        comm_kind = comm_setup("rccl" if args.comm == "rccl" else "p2p")
     else:
         local_surf_map, local_corner_map = surf_map, corner_map
         comm_kind = None

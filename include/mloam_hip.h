@@ -420,6 +420,16 @@ typedef struct mlh_iter_stat {
  * (lidar_mapper_keyframe.cpp:1172-1204), solve H d = -g, pose <- PoseLocalParameterization::Plus(pose, V_update d)
  * (pose_local_parameterization.cpp:26-45). This is BASELINE.json's "GN iteration". stats may be NULL. */
 int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solver_opts *opts, mlh_iter_stat *stats);
+/* How the iterations of mlh_gn_solve / mlh_gn_solve_begin* are laid out on the device. Neither switch changes a result (same arithmetic in the same order; the
+ * tests compare the variants bit for bit); they exist for A/B measurements and as the reference forms in the tests. Environment at mlh_create: MLH_GN_DEFER,
+ * MLH_KNN_WARM (0 / 1).
+ *   deferred_finish 1 (default): on one GPU, without per-iteration statistics, every iteration but the last leaves the J^T J / J^T r records of its tiles in HBM and
+ *       the NEXT iteration's correspondence launch starts by summing them, solving and applying Plus in every workgroup redundantly (the kernel boundary is the only
+ *       synchronisation); 0: the fit kernel's last-arriving workgroup finishes every iteration (evalHessian + evalDegenracy + solve + Plus,
+ *       lidar_mapper_keyframe.cpp:575-596, 1160-1204) while the other compute units wait.
+ *   knn_warm_start 1 (default): iterations >= 1 bound the 5-NN search of a feature by the distances from its new position to the five neighbours the previous
+ *       iteration found (an upper bound of the fifth-neighbour distance: the search stays exact, feature_extract.hpp:666/813); 0: every iteration searches cold. */
+int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start);
 /* The same solve submitted and collected separately (one GPU, or several ranks joined by the mailbox communicator -- not under RCCL; no statistics): _begin enqueues the n_iters iterations and returns at once, _end waits for the
  * pose. Between the two the caller may stage the NEXT frame's maps (mlh_map_set_pair): those launches queue up behind the solve on the context's stream, so the
  * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). At most two solves in flight per context

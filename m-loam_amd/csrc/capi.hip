@@ -329,6 +329,8 @@ int mlh_create(mlh_ctx **out, int device_id)
     if (!c) return MLH_ERR_NOMEM;
     c->device = device_id;
     if (const char *e = std::getenv("MLH_KNN_LANES")) c->knn_lanes_override = std::atoi(e);
+    if (const char *e = std::getenv("MLH_GN_DEFER")) c->gn_defer = std::atoi(e);
+    if (const char *e = std::getenv("MLH_KNN_WARM")) c->knn_warm = std::atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
     *out = c;
     return MLH_OK;
@@ -805,6 +807,15 @@ int mlh_set_extract_tie_order(mlh_ctx *ctx, int mode)
     return MLH_OK;
 }
 
+int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    if ((deferred_finish != 0 && deferred_finish != 1) || (knn_warm_start != 0 && knn_warm_start != 1)) return fail(ctx, MLH_ERR_INVALID, "schedule switches are 0 or 1");
+    ctx->gn_defer = deferred_finish;
+    ctx->knn_warm = knn_warm_start;
+    return MLH_OK;
+}
+
 int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode)
 {
     if (!ctx || mode < 0 || mode > 2) return MLH_ERR_INVALID;
@@ -1190,11 +1201,21 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
         if (it == 0) a.init_pose = pose_inout;
+        // iterations >= 1 re-find the neighbours of the same features in the same map: the previous iteration's five bound the search (not with ownership
+        // planes: a feature that changes hands between iterations would bring another frame's records)
+        a.warm = it >= 1 && ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi;
         if (!distributed(ctx) || ctx->p2p.active) {
             // single GPU: two launches per iteration; the fit kernel's last workgroup reduces, solves and updates the pose. Several ranks joined by the
             // mailbox communicator: the same two launches -- that workgroup exchanges the summed record with the peers (one hop) before it solves
             a.finish = 1;
             a.stat_slot = stats ? it : -1;
+            if (!distributed(ctx) && !stats && n_iters >= 2 && ctx->gn_defer) {
+                // one GPU, no per-iteration statistics: only the LAST iteration keeps that finish; the others leave their tiles' records to the next
+                // iteration's correspondence launch, whose every workgroup sums and solves for itself (match.hip: knn_features_kernel<.., PRE>)
+                a.gn_iter = it; a.gn_iters = n_iters;
+                if (it == 1) a.init_pose = pose_inout;       // iteration 0's pose, the one iteration 1 updates
+                if (it < n_iters - 1) a.finish = 0;
+            }
             if (it == n_iters - 1 && !stats) {
                 if ((rc = publish_slot(ctx, &a.publish, &seq))) return rc;
                 a.publish_seq = seq;
@@ -1255,6 +1276,12 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         if (it == 0) a.init_pose = pose_in;        // null when chained: the kernels read the state's pose
         a.finish = 1;
         a.stat_slot = -1;
+        a.warm = it >= 1 && ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi;
+        if (!distributed(ctx) && n_iters >= 2 && ctx->gn_defer) {     // the finish moves into the next iteration's correspondence launch (see mlh_gn_solve)
+            a.gn_iter = it; a.gn_iters = n_iters;
+            if (it == 1) a.init_pose = pose_in;
+            if (it < n_iters - 1) a.finish = 0;
+        }
         if (it == n_iters - 1) {
             a.publish = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
             a.publish_seq = seq;

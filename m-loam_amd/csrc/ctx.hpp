@@ -53,6 +53,10 @@ struct SolverState {
     int num_invalid;
     int evaluations;
     int pad;
+    // Gauss-Newton with the finish deferred to the consumer (match.hip): iteration i's pose lives in xi[i & 1] -- written by ONE workgroup of iteration i's
+    // correspondence launch while the others may still be reading xi[(i - 1) & 1]
+    double xi[2][7];
+    double pad2[2];
 };
 
 // pinned host record the device writes the result pose(s) into; seq is stored last with system-scope release
@@ -289,6 +293,8 @@ struct mlh_ctx {
     int fused_parts = 0;
     float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
+    int gn_defer = 1;             // MLH_GN_DEFER=0: Gauss-Newton solves keep the classic finish (the fit kernel's last-arriving workgroup) in every iteration (A/B, tests)
+    int knn_warm = 1;             // MLH_KNN_WARM=0: iterations >= 1 of a solve search without the previous iteration's neighbours as a bound (A/B, tests)
     // multi-GPU
     bool shard_lo = false, shard_hi = false;
     float lo_plane[4] = {0, 0, 0, 0}, hi_plane[4] = {0, 0, 0, 0};
@@ -454,6 +460,11 @@ struct MatchArgs {
     double eig_thre[8] = {100, 100, 100, 100, 100, 100, 100, 100};
     int freeze[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double *init_pose = nullptr;       // host: block 0's pose for this launch comes from the kernel arguments and is written to the state by the finish
+    // Gauss-Newton with the finish done by the consumer: this launch pair is iteration `gn_iter` of `gn_iters` (>= 2). The fit kernel of every iteration but
+    // the last only leaves its tiles' partial records; the correspondence kernel of iteration i >= 1 starts by summing them (every workgroup, same order, same
+    // bits) and running the 6 x 6 solve + Plus itself. gn_iter < 0: the classic form (the fit kernel's last-arriving workgroup finishes).
+    int gn_iter = -1, gn_iters = 0;
+    bool warm = false;   // the neighbour records of the previous iteration (same features, same map) bound this iteration's search
     HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
     unsigned long long publish_seq = 0;
 };

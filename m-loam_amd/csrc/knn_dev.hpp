@@ -356,6 +356,70 @@ __device__ __forceinline__ int knn_fill_table16(int *lds_run, int gl, int bL, in
     return __shfl(incl, 15, 16);
 }
 
+// u32 group-max over the G (8 or 16) lanes of a group, DPP only
+template <int G = 16>
+__device__ __forceinline__ unsigned dpp_row_max_u32(unsigned m)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP1, 0xF, 0xF, false); m = o > m ? o : m;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_QUAD_SWAP2, 0xF, 0xF, false); m = o > m ? o : m;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false); m = o > m ? o : m;
+    if (G == 16) { o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, DPP_ROW_MIRROR, 0xF, 0xF, false); m = o > m ? o : m; }
+    return m;
+}
+
+// Exact K-NN of (qx,qy,qz) when an upper bound of the K-th neighbour's squared distance is known BEFORE the search (bound_bits: the f32 bit pattern; the
+// caller got it from K map points it already knows -- the previous Gauss-Newton iteration's neighbours of the same feature, re-measured from the query's new
+// position: K points within the bound exist, so nothing farther can be among the K nearest). One walk, over the cells whose box is not farther than the
+// bound -- what phase 2 of the pruned search does after phase 1 has found its bound, without a phase 1, a merge and a second run table. Same result as
+// knn_group16_pruned / knn_group8_pruned wherever the K-th distance is below the cell edge; where it is not, both report a K-th distance of at least the
+// cell edge (the acceptance test rejects the feature either way). lds_run: KNN_RUN_WORDS ints.
+template <int K, int G>
+__device__ __forceinline__ void knn_group_bounded(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned bound_bits,
+                                                  unsigned long long (&out)[K])
+{
+    static_assert(G == 8 || G == 16, "group width");
+    constexpr int NR = (G == 16) ? 1 : 2;                               // (dy, dz) rows per lane: lanes 0..8 one each, or lanes 0..4 two each
+    unsigned long long k[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) k[i] = KEY_INF;
+    const int cx = int(clamp_cell_f(qx, g.ox, g.inv_h, g.nx));
+    const int cy = int(clamp_cell_f(qy, g.oy, g.inv_h, g.ny));
+    const int cz = int(clamp_cell_f(qz, g.oz, g.inv_h, g.nz));
+    int w[NR][4], dyr[NR], dzr[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+        const int r = NR * gl + s;
+        dyr[s] = (r % 3) - 1; dzr[s] = ((r / 3) % 3) - 1;
+        w[s][0] = w[s][1] = w[s][2] = w[s][3] = 0;
+        const int y = cy + dyr[s], z = cz + dzr[s];
+        if ((r < 9) && (y >= 0) && (y < g.ny) && (z >= 0) && (z < g.nz)) {
+            const int row = (z * g.ny + y) * g.nx;
+            const int xa = min(max(cx - 1, 0), g.nx), xb = min(max(cx, 0), g.nx), xc = min(max(cx + 1, 0), g.nx), xd = min(max(cx + 2, 0), g.nx);
+            w[s][0] = g.cell_start[row + xa]; w[s][1] = g.cell_start[row + xb]; w[s][2] = g.cell_start[row + xc]; w[s][3] = g.cell_start[row + xd];
+        }
+    }
+    MLH_KSTAGE(2);
+    const float h = 1.f / g.inv_h;
+    const float fx0 = g.ox + float(cx) * h, fy0 = g.oy + float(cy) * h, fz0 = g.oz + float(cz) * h;
+    const float gxl = fmaxf((qx - fx0) - KNN_PRUNE_SLACK, 0.f), gxr = fmaxf(((fx0 + h) - qx) - KNN_PRUNE_SLACK, 0.f);
+    const float Bm = __uint_as_float(bound_bits) * 1.0001f;
+    int pb[NR], pl[NR];
+#pragma unroll
+    for (int s = 0; s < NR; ++s) {
+        const float gy = fmaxf((dyr[s] < 0 ? qy - fy0 : (dyr[s] > 0 ? (fy0 + h) - qy : 0.f)) - (dyr[s] ? KNN_PRUNE_SLACK : 0.f), 0.f);
+        const float gz = fmaxf((dzr[s] < 0 ? qz - fz0 : (dzr[s] > 0 ? (fz0 + h) - qz : 0.f)) - (dzr[s] ? KNN_PRUNE_SLACK : 0.f), 0.f);
+        const float dM = gy * gy + gz * gz, dL = dM + gxl * gxl, dR = dM + gxr * gxr;
+        const bool keepM = dM <= Bm;
+        const int kb = keepM ? (dL <= Bm ? w[s][0] : w[s][1]) : w[s][3], ke = keepM ? (dR <= Bm ? w[s][3] : w[s][2]) : w[s][3];
+        pb[s] = kb; pl[s] = max(ke - kb, 0);
+    }
+    const int total = knn_fill_table<G, NR>(lds_run, gl, pb, pl);
+    if (total > 0) knn_walk16<K, G, true>(g, qx, qy, qz, gl, lds_run, total, bound_bits, k);
+    MLH_KSTAGE(3);
+    knn_tournament16<K, G>(k, out);
+}
+
 // Exact K-NN of (qx,qy,qz) by a group of 16 lanes; every lane returns the K keys ascending. Same result as knn_group<K, 16>, fewer
 // candidates read where the map is dense:
 //   lanes 0..8 fetch the FOUR cell_start words of their row (dy, dz) -> the three x-cells of the row separately, and the squared

@@ -215,6 +215,14 @@ struct KParams {
     // sharded over several ranks with the mailbox communicator: the finishing workgroup exchanges each block's summed record with the peers (one hop, inside
     // this launch) before it solves -- a sharded Gauss-Newton iteration is the same two launches as an unsharded one. n_ranks <= 1: nothing is exchanged
     P2pDev p2p;
+    // Gauss-Newton with the finish done by the consumer (MatchArgs::gn_iter): the correspondence kernel of iteration i >= 1 completes iteration i - 1 first
+    int pre_finish;          // 1: sum the pre_tiles records the previous fit launch left in `partials`, solve, Plus -> this iteration's pose
+    int pre_tiles;
+    int pre_from_init;       // the previous iteration's pose is init_pose (kernel arguments); otherwise *x_prev
+    const double *x_prev;
+    double *x_next;          // the workgroup that serves tile 0 stores the new pose here (the fit kernel of the same iteration reads it as pose0)
+    const double *pose0;     // block 0's pose of this launch when it is neither init_pose nor the state's x / cand (iterations >= 1 of a deferred-finish solve)
+    int warm;                // the neighbour records hold the previous iteration's neighbours of the same features in the same map
 };
 
 __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
@@ -234,6 +242,10 @@ __device__ __forceinline__ void load_pose(const KParams &P, int b, q4 &q, d3 &t)
     if (P.use_init && b == 0) {            // uniform: straight from the kernel-argument segment
         t = d3{P.init_pose[0], P.init_pose[1], P.init_pose[2]};
         q = q4{P.init_pose[3], P.init_pose[4], P.init_pose[5], P.init_pose[6]};
+    } else if (P.pose0 && b == 0) {        // iteration >= 1 of a deferred-finish solve: the slot this iteration's correspondence launch filled
+        const double *pose = P.pose0;
+        t = d3{pose[0], pose[1], pose[2]};
+        q = q4{pose[3], pose[4], pose[5], pose[6]};
     } else {
         const double *pose = block_pose(P, b);
         t = d3{pose[0], pose[1], pose[2]};
@@ -258,6 +270,38 @@ __device__ __forceinline__ bool owns(const KParams &P, int f, float sx, float sy
 
 // ---- correspondence kernel: 8 lanes per feature, 32 features per workgroup, both feature kinds in one launch
 
+// the K winners' coordinates + squared distances -> the feature's neighbour records. A macro, expanded in the function that owns `keys`: as a function taking the
+// array by reference, the lane's pick (a select chain over keys[t]) is folded into ONE load at a selected offset before the array is scalarised, and the
+// keys then live in scratch / LDS instead of registers (seen in the ISA: 48 bytes of scratch, +10 KB of LDS per workgroup).
+// lane t (< K <= G) fetches winner t: one load per lane, all in flight together
+#define MLH_STORE_WINNERS(K_, G_, Kd_, f_, gl_, keys_)                                                          \
+    do {                                                                                                        \
+        unsigned long long kk_ = keys_[0];                                                                      \
+        _Pragma("unroll") for (int t_ = 1; t_ < (K_); ++t_) kk_ = ((gl_) == t_ % (G_)) ? keys_[t_] : kk_;      \
+        if ((K_) <= (G_)) {                                                                                     \
+            if ((gl_) < (K_)) {                                                                                 \
+                float4 o_ = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));                           \
+                if (kk_ != KEY_INF) {                                                                           \
+                    const float4 np_ = (Kd_).grid.raw[(unsigned)kk_];                                           \
+                    o_ = make_float4(np_.x, np_.y, np_.z, __uint_as_float((unsigned)(kk_ >> 32)));              \
+                }                                                                                               \
+                (Kd_).nbr[size_t(f_) * (Kd_).nbr_stride + (gl_)] = o_;                                          \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int t_ = 0; t_ < (K_); ++t_) {                                               \
+                if ((t_ % (G_)) == (gl_)) {                                                                     \
+                    const unsigned long long k2_ = keys_[t_];                                                   \
+                    float4 o_ = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));                       \
+                    if (k2_ != KEY_INF) {                                                                       \
+                        const float4 np_ = (Kd_).grid.raw[(unsigned)k2_];                                       \
+                        o_ = make_float4(np_.x, np_.y, np_.z, __uint_as_float((unsigned)(k2_ >> 32)));          \
+                    }                                                                                           \
+                    (Kd_).nbr[size_t(f_) * (Kd_).nbr_stride + t_] = o_;                                         \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
+
 template <int K, int G>
 __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run)
 {
@@ -265,40 +309,35 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
     if constexpr (G == 16) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     else knn_group8_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     MLH_KSTAGE(4);
-    // lane t (< K <= G) fetches winner t: one load per lane, all in flight together
-    unsigned long long kk = keys[0];
-#pragma unroll
-    for (int t = 1; t < K; ++t) kk = (gl == t % G) ? keys[t] : kk;
-    if (K <= G) {
-        if (gl < K) {
-            float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
-            if (kk != KEY_INF) {
-                const float4 np = Kd.grid.raw[(unsigned)kk];
-                o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(kk >> 32)));
-            }
-            Kd.nbr[size_t(f) * Kd.nbr_stride + gl] = o;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < K; ++t) {
-            if ((t % G) == gl) {
-                const unsigned long long k2 = keys[t];
-                float4 o = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
-                if (k2 != KEY_INF) {
-                    const float4 np = Kd.grid.raw[(unsigned)k2];
-                    o = make_float4(np.x, np.y, np.z, __uint_as_float((unsigned)(k2 >> 32)));
-                }
-                Kd.nbr[size_t(f) * Kd.nbr_stride + t] = o;
-            }
-        }
+    MLH_STORE_WINNERS(K, G, Kd, f, gl, keys);
+    MLH_KSTAGE(5);
+}
+
+// The same feature one Gauss-Newton iteration later: `old` is this lane's share (lane t < 5: record t) of the neighbour records the previous iteration
+// left -- five points of the SAME map. Their largest squared distance from the query's new position bounds the fifth neighbour's from above, so the search
+// is a single walk over the cells within that bound (knn_group_bounded). A feature that had fewer than five neighbours (w = +inf) searches as before.
+template <int G>
+__device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run, const float4 &old)
+{
+    unsigned bits = 0u;
+    if (gl < 5) {
+        const float dx = old.x - sx, dy = old.y - sy, dz = old.z - sz;
+        float d = dx * dx; d += dy * dy; d += dz * dz;
+        bits = (old.w < __uint_as_float(0x7f800000u) && d < __uint_as_float(0x7f800000u)) ? __float_as_uint(d) : 0x7f800000u;
     }
+    bits = dpp_row_max_u32<G>(bits);
+    if (bits >= 0x7f800000u) { knn_feature<5, G>(P, Kd, f, sx, sy, sz, gl, lds_run); return; }     // uniform over the group
+    unsigned long long keys[5];
+    knn_group_bounded<5, G>(Kd.grid, sx, sy, sz, gl, lds_run, bits, keys);
+    MLH_KSTAGE(4);
+    MLH_STORE_WINNERS(5, G, Kd, f, gl, keys);
     MLH_KSTAGE(5);
 }
 
 // MB = more than one pose block in the launch (config 4); without it the block bookkeeping (a per-lane block index and the
 // per-block K lookup it drags along) compiles away
-template <int G, bool MB, bool K10>
-__device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run)
+template <int G, bool MB, bool K10, bool PRE, bool WARM>
+__device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run, const double *s_pose)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
     constexpr int RUNW = 2 * KNN_RUN_WORDS;
@@ -308,36 +347,90 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
     if (f >= K.m) return;
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
+    float4 old = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
+    if constexpr (WARM) { if (gl < 5) old = K.nbr[size_t(f) * K.nbr_stride + gl]; }      // requested together with the feature, before the pose is known
     const int b = MB ? block_of_slot(K, P.n_blocks, f) : 0;
     q4 q;
     d3 t;
-    load_pose(P, b, q, t);
+    if constexpr (PRE) {
+        t = d3{s_pose[0], s_pose[1], s_pose[2]};
+        q = q4{s_pose[3], s_pose[4], s_pose[5], s_pose[6]};
+    } else {
+        load_pose(P, b, q, t);
+    }
     float sx, sy, sz;
     associate_to_map(q, t, fp, sx, sy, sz);
     MLH_KSTAGE(1);
     if (!owns(P, f, sx, sy, sz)) return;     // uniform over the lane group
     // K10: some pose block of the launch asks for 10 neighbours (buildCalibMap's non-reference LiDARs); without it the K = 10 search is not
     // even compiled in, so the ordinary frame's kernel keeps the K = 5 register footprint
-    if (K10 && (MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
-    else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
+    if constexpr (WARM) {
+        knn_feature_warm<G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW, old);
+    } else {
+        if (K10 && (MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
+        else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
+    }
 }
 
 // G = lanes per query for both kinds, or 0: per kind (KindP::lanes -- a workgroup serves one kind, so the choice is uniform over it)
-template <int G, bool MB, bool K10>
+// PRE: the launch completes the previous Gauss-Newton iteration first -- EVERY workgroup sums the records the previous fit launch's tiles left (same order,
+//   same code: the same bits everywhere), runs the 6 x 6 solve + Plus on one wavefront and goes on with the pose in LDS; the kernel boundary behind the fit
+//   launch is the only synchronisation (no ticket, no fence, no last workgroup whose serial tail the other 255 compute units wait for). The workgroup of
+//   tile 0 leaves the pose in HBM for the fit kernel of this iteration.
+// WARM: the search is bounded by the previous iteration's neighbours (knn_feature_warm). Both only in the single-block, K = 5 launches of mlh_gn_solve*.
+template <int G, bool MB, bool K10, bool PRE = false, bool WARM = false>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
     __shared__ int s_run[(G == 16) ? (TPB / 16) * 2 * KNN_RUN_WORDS : (TPB / 8) * 2 * KNN_RUN_WORDS];
+    __shared__ double s_pose[PRE ? 8 : 1];
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = xcd_tile(total);
     if (tile >= total) return;
+    if constexpr (PRE) {
+        __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
+        if (threadIdx.x < 7) s_pose[threadIdx.x] = P.pre_from_init ? P.init_pose[threadIdx.x] : P.x_prev[threadIdx.x];
+        // sum_partials<TPB, 12>'s arithmetic (same slices, same four chains, same association: the same bits), inlined: the record loads leave at once instead of
+        // behind the argument block's trip through scratch, and nobody waits for the per-kind counts (statistics only)
+        {
+            constexpr int NS = TPB / 32, U = 12;
+            const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, ntot = P.pre_tiles;
+            const double *__restrict__ rec = P.partials;
+            double ch[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int j = sl; j < ntot; j += U * NS) {
+                double tv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int jj = j + NS * u;
+                    tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
+            }
+            f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                double tsum = 0.0;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
+                f_ne[c] = tsum;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 64) {
+            double xo[7];
+            gn_finish_wave(f_ne, f_cnt2, s_pose, nullptr, P.thre_b[0], P.freeze_b[0], nullptr, f_scratch, xo);
+        }
+        __syncthreads();
+        if (tile == 0 && threadIdx.x < 7) P.x_next[threadIdx.x] = s_pose[threadIdx.x];
+    }
     const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
     if (kind) tile -= P.k[0].tiles_a;
     const KindP &K = P.k[kind];
     if constexpr (G == 0) {
-        if (K.lanes == 8) knn_features_body<8, MB, K10>(P, K, tile, s_run);
-        else knn_features_body<16, MB, K10>(P, K, tile, s_run);
+        if (K.lanes == 8) knn_features_body<8, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
+        else knn_features_body<16, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
     } else {
-        knn_features_body<G, MB, K10>(P, K, tile, s_run);
+        knn_features_body<G, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
     }
 }
 
@@ -493,8 +586,13 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         MLH_STAGE(4095, 1);
         if (threadIdx.x < 64) {
             double xo[7];
+            const double *x_in = (b == 0 && P.pose0) ? P.pose0 : nullptr;      // last iteration of a deferred-finish solve: the pose comes from its iteration slot
             gn_finish_wave(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], nullptr /* nothing downstream reads a mirror of ne / V_update in GN mode */, P.thre_b[b], P.freeze_b[b],
-                           P.stat ? P.stat + b : nullptr, f_scratch, xo);
+                           P.stat ? P.stat + b : nullptr, f_scratch, xo, x_in);
+            if (x_in && threadIdx.x < 7) {           // ... and goes to the state whatever the solve decided (an unchanged pose included)
+                const int l = threadIdx.x;
+                P.state->x[l] = l == 0 ? xo[0] : (l == 1 ? xo[1] : (l == 2 ? xo[2] : (l == 3 ? xo[3] : (l == 4 ? xo[4] : (l == 5 ? xo[5] : xo[6])))));
+            }
             // the solve's last launch hands the pose(s) to the host: straight from the finish's registers (reading the state back would be one more round trip)
             if (P.publish && threadIdx.x == 0) for (int i = 0; i < 7; ++i) (b == 0 ? P.publish->x : P.publish->xb[b])[i] = xo[i];
         }
@@ -786,6 +884,19 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     else { P2pDev none{}; none.n_ranks = 1; P.p2p = none; }
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
+    P.warm = a.warm ? 1 : 0;
+    if (a.gn_iter >= 1) {
+        // iteration i >= 1 of a deferred-finish solve: the correspondence kernel turns iteration i - 1's records and pose into pose i (SolverState::xi[i & 1]);
+        // iteration 1 finds pose 0 where iteration 0 found it -- the kernel arguments, or the state's x (a chained solve)
+        SolverState *S = ctx->state.as<SolverState>();
+        P.pre_finish = 1;
+        P.pre_tiles = tiles_b_total;
+        P.pre_from_init = (a.gn_iter == 1 && a.init_pose) ? 1 : 0;
+        P.x_prev = a.gn_iter == 1 ? S->x : S->xi[(a.gn_iter - 1) & 1];
+        P.x_next = S->xi[a.gn_iter & 1];
+        P.pose0 = S->xi[a.gn_iter & 1];
+        P.use_init = 0;
+    }
     P.publish = (a.finish == 1 || a.finish == 4) ? a.publish : nullptr;
     P.publish_seq = a.publish_seq;
     P.ticket = ctx->ticket.as<unsigned>();
@@ -820,9 +931,21 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             if (mb) { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, true, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, true, false>, grid_a, P); } \
             else { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false>, grid_a, P); } \
         } while (0)
-        if (P.knn_lanes == 0) MLH_KNN_LAUNCH(0);
+#define MLH_KNN_LAUNCH_GN(G_) do { \
+            if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, true, true>, grid_a, P); \
+            else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, true, false>, grid_a, P); \
+            else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, false, true>, grid_a, P); \
+        } while (0)
+        if (P.pre_finish || P.warm) {
+            if (mb || k10) return fail(ctx, MLH_ERR_UNSUPPORTED, "the deferred finish / the bounded search are single-block, N_NEIGH = 5");
+            if (P.knn_lanes == 0) MLH_KNN_LAUNCH_GN(0);
+            else if (P.knn_lanes == 16) MLH_KNN_LAUNCH_GN(16);
+            else MLH_KNN_LAUNCH_GN(8);
+        }
+        else if (P.knn_lanes == 0) MLH_KNN_LAUNCH(0);
         else if (P.knn_lanes == 16) MLH_KNN_LAUNCH(16);
         else MLH_KNN_LAUNCH(8);
+#undef MLH_KNN_LAUNCH_GN
 #undef MLH_KNN_LAUNCH
     }
     if (P.finish == 3) {

@@ -445,15 +445,16 @@ __device__ __forceinline__ void pose_plus_wave(const double (&x)[7], const doubl
 }
 
 // Called by ALL 64 lanes of one wavefront, converged. Arguments as gn_finish2.
+// x_in: where the block's pose is read from when that is not where the updated pose goes (null: x).
 __device__ __forceinline__ void gn_finish_wave(const double *ne, const double *cnt2, double *x, SolverState *S, double eig_thre, int freeze,
-                                               IterStatDev *stat, double *work /*LDS, DEG_WORK*/, double (&x_out)[7])
+                                               IterStatDev *stat, double *work /*LDS, DEG_WORK*/, double (&x_out)[7], const double *x_in = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 7;
     const bool grp_b = (lane & 8) != 0;
     double xc[7];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) xc[q] = x[q];          // issued before the factorisation: the pose arrives while it runs
+    for (int q = 0; q < 7; ++q) xc[q] = (x_in ? x_in : x)[q];          // issued before the factorisation: the pose arrives while it runs
     double a[6], colv[6], rinv[6], d[6];
     bool pd = false, not_degenerate_fast = false;
 #pragma unroll 1

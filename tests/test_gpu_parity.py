@@ -105,6 +105,73 @@ def test_gn_solve_parity(ctx, mla, orc, case16, feats16):
     assert gdt < 0.05 and gdr < 0.01
 
 
+@pytest.mark.parametrize("n_iters", [1, 2, 3, 5])
+def test_gn_schedule_variants_agree_bit_for_bit(mla, orc, case16, feats16, n_iters):
+    """mlh_set_gn_schedule: the finish done by the next iteration's correspondence launch (every workgroup sums the tiles' records in the fixed order and
+    solves for itself) and the search bounded by the previous iteration's neighbours change where work happens, not what is computed: the four combinations,
+    the statistics path (always the classic finish) and the split / chained submissions give the SAME pose bits; the oracle agrees to 1e-7."""
+    ref = orc.gn_iterations(orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"]), feats16[0], feats16[1], case16["p0"], orc.mapper_params(), n_iters)
+    poses = {}
+    for defer in (0, 1):
+        for warm in (0, 1):
+            c = mla.Context(0)
+            try:
+                c.set_gn_schedule(defer, warm)
+                _stage(c, mla, case16, feats16)
+                p_plain = c.gn_solve(case16["p0"], n_iters, want_stats=False)[0]
+                p_stats, st = c.gn_solve(case16["p0"], n_iters, want_stats=True)
+                c.gn_solve_begin(case16["p0"], n_iters)
+                p_split = c.gn_solve_end()
+                # chained: the start pose is made on the device from the pose the previous solve left there; identity odometry -> the same frame again
+                ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+                c.gn_solve_begin_chained(ident, ident, n_iters)
+                p_chain = c.gn_solve_end()
+                c.gn_solve_begin(p_split, n_iters)
+                p_restart = c.gn_solve_end()
+            finally:
+                c.close()
+            assert np.array_equal(p_plain, p_stats) and np.array_equal(p_plain, p_split), (defer, warm)
+            # the chained solve starts from Pose(q, t) products of the previous result (normalisations): equal to a restart from that result to rounding
+            assert float(np.abs(p_chain - p_restart).max()) < 1e-12, (defer, warm)
+            assert [(x["n_surf"], x["n_corner"]) for x in st] == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]]
+            poses[(defer, warm)] = p_plain
+    for k, v in poses.items():
+        assert np.array_equal(v, poses[(0, 0)]), k
+    dt, dr = _pose_err(poses[(1, 1)], ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
+def test_gn_deferred_finish_on_a_degenerate_problem(mla, orc, synth):
+    """the deferred finish's slow path: a map that is ONE plane leaves three directions unconstrained (eigenvalues below MAP_EIG_THRE), so every workgroup of the
+    next correspondence launch runs evalDegenracy's projection itself -- same bits as the classic finish, and the oracle's degenerate update"""
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(np.arange(-12, 12, 0.4), np.arange(-12, 12, 0.4)), -1).reshape(-1, 2)
+    plane = np.concatenate([g + rng.uniform(-0.05, 0.05, g.shape), rng.normal(0, 0.005, (len(g), 1))], 1).astype(np.float32)
+    line = np.stack([np.full(200, 3.0), np.full(200, 2.0), np.linspace(0, 4, 200)], 1).astype(np.float32) + rng.normal(0, 0.003, (200, 3)).astype(np.float32)
+    feats_s = np.concatenate([rng.uniform(-8, 8, (3000, 2)), np.zeros((3000, 1))], 1).astype(np.float32)
+    feats_s = np.concatenate([feats_s, np.zeros((3000, 1), np.float32)], 1)
+    feats_c = np.concatenate([line[::4] + np.float32(0.01), np.zeros((50, 1), np.float32)], 1)
+    p0 = np.array([0.0, 0.0, 0.08, 0.004, -0.003, 0.0, 1.0]); p0[3:] /= np.linalg.norm(p0[3:])
+    ref = orc.gn_iterations(orc.Map(plane), orc.Map(line), feats_s, feats_c, p0, orc.mapper_params(), 4)
+    assert any(r["is_degenerate"] for r in ref["iters"])
+    out = {}
+    for defer in (0, 1):
+        c = mla.Context(0)
+        try:
+            c.set_gn_schedule(defer, 1)
+            c.map_set_pair(plane, line)
+            c.features_set(mla.SURF, feats_s)
+            c.features_set(mla.CORNER, feats_c)
+            out[defer] = c.gn_solve(p0, 4, want_stats=False)[0]
+            _, st = c.gn_solve(p0, 4, want_stats=True)
+        finally:
+            c.close()
+        assert [x["is_degenerate"] for x in st] == [r["is_degenerate"] for r in ref["iters"]]
+    assert np.array_equal(out[0], out[1])
+    dt, dr = _pose_err(out[1], ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
 def test_scan2map_parity(ctx, mla, orc, case16, feats16):
     _stage(ctx, mla, case16, feats16)
     pose, stats = ctx.scan2map(case16["p0"])
