@@ -171,6 +171,56 @@ def single_gpu_reference(mla, torch, device, surf_map, corner_map, surf, corner,
         c.close()
 
 
+CFG4_K, CFG4_THRE, CFG4_FREEZE = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
+
+
+def config4_blocks(mla, synth, ctx, scans4, gt):
+    """BASELINE config 4's frame: per LiDAR its own feature clouds (less-sharp corners, per-ring-thinned less-flat surfs, thinned at the mapper's resolutions)
+    and its own pose block -- the body pose for the reference LiDAR, the extrinsic-composed pose for the others (buildCalibMap, estimator.cpp:1067-1157)"""
+    from scipy.spatial.transform import Rotation as Rot
+    surf_b, corner_b, poses0 = [], [], []
+    for i, s_ in enumerate(scans4):
+        ex = ctx.extract(s_.points, s_.scan_start, s_.scan_end, voxel_leaf=0.2)
+        c_ = np.zeros((len(ex["less_sharp"]), 4), np.float32)
+        c_[:, :3] = s_.points[ex["less_sharp"]][:, :3]
+        surf_b.append(np.ascontiguousarray(synth.voxel_mean(ex["less_flat_ds"].copy(), 0.4)))
+        corner_b.append(np.ascontiguousarray(synth.voxel_mean(c_, 0.2)))
+        bl = synth.HERCULES_BODY_T_LASER[i]
+        T = synth.pose_to_mat(gt) @ np.block([[synth.quat_to_rot(bl[:4]), bl[4:7, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+        gt_i = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        poses0.append(synth.perturbed_pose(gt_i, seed=50 + i, dt=0.1, drot_deg=1.0))
+    return surf_b, corner_b, np.array(poses0)
+
+
+def single_gpu_config4(mla, torch, device, surf_map, corner_map, surf_b, corner_b, poses0, steps, warmup):
+    """config 4's frame on ONE GPU, whole map, no communicator (rank 0 of an N > 1 run: the same-map reference of the sharded config-4 leg)"""
+    c = mla.Context(device)
+    try:
+        d_sm, d_cm = torch.from_numpy(np.ascontiguousarray(surf_map)).cuda(), torch.from_numpy(np.ascontiguousarray(corner_map)).cuda()
+        torch.cuda.synchronize()
+        c.map_set_pair(d_sm, d_cm)
+        c.features_set_blocks(mla.SURF, surf_b)
+        c.features_set_blocks(mla.CORNER, corner_b)
+        o4 = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+
+        def frame():
+            c.map_set_pair(d_sm, d_cm)
+            return c.gn_solve_blocks(poses0, GN_ITERS, CFG4_K, CFG4_THRE, CFG4_FREEZE, o4, want_stats=False)
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < 0.15:
+            frame()
+        for _ in range(warmup):
+            frame()
+        c.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out_ = frame()
+        c.synchronize()
+        return dict(ms_per_step=round(1e3 * (time.perf_counter() - t0) / steps, 4), poses=np.asarray(out_[0]).tolist())
+    finally:
+        c.close()
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` without a launcher: re-run this very command line under torch.distributed.run with N ranks and pass its exit code on"""
     import socket
@@ -490,31 +540,37 @@ def main():
             torch.cuda.synchronize()
         spin_ms = 1e3 * (time.perf_counter() - t_sp)
         del a_
-    sync_all()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one launch in 4 * GN_ITERS + 1 (so the
-    # bracket rotates through the five iterations: ~50 samples over the default 200 steps), because an event pair costs ~6 us of queue time of
-    # its own -- bracketing all five launches of a step would slow the measured step by ~17 %, one per step (round 2) by ~3 %
-    ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
-    ctx.profile_sample(4 * GN_ITERS + 1)
-    ctx.profile_reset()
-    sync_all()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        pose = step()
-    last = drain()
-    pose = last if last is not None else pose
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    knn_ms, knn_n = ctx.profile_get(mla.K_KNN)
-    ctx.profile_enable(0)
-    ctx.profile_sample(1)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_region(step_fn, drain_fn, steps, warmup):
+        """the contract's loop: W untimed steps, then exactly K timed ones between barrier + synchronize on both sides; max over the ranks"""
+        sync_all()
+        pose_ = None
+        for _ in range(warmup):
+            step_fn()
+        drain_fn()
+        # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one launch in 4 * GN_ITERS + 1 (so the
+        # bracket rotates through the five iterations: ~50 samples over the default 200 steps), because an event pair costs ~6 us of queue time of
+        # its own -- bracketing all five launches of a step would slow the measured step by ~17 %, one per step (round 2) by ~3 %
+        ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
+        ctx.profile_sample(4 * GN_ITERS + 1)
+        ctx.profile_reset()
+        sync_all()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            pose_ = step_fn()
+        last = drain_fn()
+        pose_ = last if last is not None else pose_
+        sync_all()
+        elapsed_ = time.perf_counter() - t_start
+        knn_ms_, knn_n_ = ctx.profile_get(mla.K_KNN)
+        ctx.profile_enable(0)
+        ctx.profile_sample(1)
+        if world > 1:
+            tt = torch.tensor([elapsed_], dtype=torch.float64, device=dist_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed_ = float(tt.item())
+        return elapsed_, pose_, knn_ms_, knn_n_
+
+    elapsed, pose, knn_ms, knn_n = timed_region(step, drain, args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_valid_step / (elapsed / args.steps)
     queries_per_s = m_total * GN_ITERS / (elapsed / args.steps)
@@ -539,6 +595,40 @@ def main():
         step_sync()
     sync_all()
     ms_per_step_sync = 1e3 * (time.perf_counter() - t1s) / n_prof
+
+    # --- N > 1: what every rank measured, the exchange by itself, and (--comm both) the same loop over the other communicator
+    per_rank = exchange_us = other_comm = None
+    if world > 1:
+        mine = dict(rank=rank, device=local_rank,
+                    knn_us=(round(1e3 * prof[mla.K_KNN][0] / prof[mla.K_KNN][1], 3) if prof[mla.K_KNN][1] else None),
+                    fit_us=(round(1e3 * prof[mla.K_FIT][0] / prof[mla.K_FIT][1], 3) if prof[mla.K_FIT][1] else None),
+                    index_build_us=(round(1e3 * prof[mla.K_GRID_BUILD][0] / prof[mla.K_GRID_BUILD][1], 3) if prof[mla.K_GRID_BUILD][1] else None),
+                    allreduce_us=(round(1e3 * prof[mla.K_ALLREDUCE][0] / prof[mla.K_ALLREDUCE][1], 3) if prof[mla.K_ALLREDUCE][1] else None),
+                    solve_update_us=(round(1e3 * prof[mla.K_SOLVE][0] / prof[mla.K_SOLVE][1], 3) if prof[mla.K_SOLVE][1] else None))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        # one all-reduce of a 32-double record by itself, host to host (launch + exchange + read-back; every rank enters together): an upper bound of what an
+        # iteration's exchange costs -- inside the solver the mailbox exchange has no launch of its own (it rides in the fit kernel's finishing workgroup)
+        rec = np.ones(32)
+        for _ in range(5):
+            ctx.allreduce_f64(rec)
+        sync_all()
+        t_x = time.perf_counter()
+        for _ in range(50):
+            ctx.allreduce_f64(rec)
+        exchange_us = round(1e6 * (time.perf_counter() - t_x) / 50, 2)
+        if args.comm == "both":
+            if comm_kind != "p2p" or shared_gpus:
+                other_comm = dict(skipped="the RCCL leg needs a GPU per rank and a mailbox leg to compare with" if shared_gpus else "the mailbox communicator did not come up: the main loop already ran over RCCL")
+            else:
+                ctx.comm_finalize()
+                comm_setup("rccl")
+                stage_maps()
+                chk = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)[0]
+                el2, pose2, _, _ = timed_region(step, drain, args.steps, args.warmup)
+                other_comm = dict(comm="RCCL ncclAllReduce (fit kernel reduces locally, one all-reduce launch, one solve launch per iteration)",
+                                  ms_per_step=round(1e3 * el2 / args.steps, 4), value=round(n_valid_step / (el2 / args.steps), 1), ranks_seen=comm_state["ranks_seen"],
+                                  pose_vs_mailbox_run=float(np.abs(np.asarray(pose2) - np.asarray(pose)).max()), first_solve_vs_mailbox=float(np.abs(np.asarray(chk) - np.asarray(pose)).max()))
 
     # supplementary: the reference's own per-frame call, scan2MapOptimization = index build + 2 outer x (match all, evalHessian +
     # evalDegenracy, Ceres-shaped Levenberg-Marquardt <= 30 iterations) -- not `value`, reported beside it
@@ -651,6 +741,43 @@ def main():
         outgrow_ms = 1e3 * (time.perf_counter() - t3) / n_og
         ctx.map_set_pair(d_surf_map, d_corner_map)
 
+    # --- BASELINE config 4's frame (4 x 64 rings, one pose block per LiDAR: N_NEIGH 5/10/10/10, CHECK_FOV, freeze-on-degenerate, Huber 1.0) through
+    #     mlh_gn_solve_blocks on this run's map, sharded like the single-pose frame: the headline with --config4, a supplementary leg at --gpus 8 (the
+    #     configuration BASELINE.json quotes config 4 on) otherwise. Last thing measured: it replaces the context's staged features.
+    cfg4 = None
+    if args.config4 or world == 8:
+        scans4 = list(scans)[:4] + [synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[i], N_RINGS, seed=7 + i) for i in range(len(scans), 4)]
+        surf_b, corner_b, poses0 = config4_blocks(mla, synth, ctx, scans4, gt)
+        ref4 = None
+        if world > 1:
+            if rank == 0:
+                ref4 = single_gpu_config4(mla, torch, local_rank, surf_map, corner_map, surf_b, corner_b, poses0, args.steps, args.warmup)
+            dist.barrier()
+        ctx.features_set_blocks(mla.SURF, surf_b)
+        ctx.features_set_blocks(mla.CORNER, corner_b)
+        o4 = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+
+        def step4():
+            if not args.no_map_rebuild:
+                if args.map_rebuild_only:
+                    ctx.map_rebuild(mla.ALL_KINDS)
+                else:
+                    ctx.map_set_pair(d_surf_map, d_corner_map)
+            return ctx.gn_solve_blocks(poses0, GN_ITERS, CFG4_K, CFG4_THRE, CFG4_FREEZE, o4, want_stats=False)[0]
+        poses4, st4 = ctx.gn_solve_blocks(poses0, GN_ITERS, CFG4_K, CFG4_THRE, CFG4_FREEZE, o4, want_stats=True)
+        n_valid4 = [[(int(st4[it][b_]["n_surf"]), int(st4[it][b_]["n_corner"])) for b_ in range(4)] for it in range(GN_ITERS)]
+        n_valid4_step = int(sum(a_ + b_ for row in n_valid4 for a_, b_ in row))
+        el4, poses4_t, _, _ = timed_region(step4, lambda: None, args.steps, args.warmup)
+        m4 = int(sum(len(x) for x in surf_b) + sum(len(x) for x in corner_b))
+        cfg4 = dict(workload=f"4x{N_RINGS}-ring synthetic scan vs {preset} local map, 4 pose blocks (body + 3 extrinsics; N_NEIGH 5/10/10/10, CHECK_FOV, freeze-on-degenerate, Huber 1.0), "
+                             f"{GN_ITERS} GN iterations/frame re-matched every iteration (mlh_gn_solve_blocks; buildCalibMap + LidarOnlineCalib* structure, estimator.cpp:1067-1157)",
+                    ms_per_step=round(1e3 * el4 / args.steps, 4), value=round(n_valid4_step / (el4 / args.steps), 1), unit="features/s",
+                    queries_per_s=round(m4 * GN_ITERS / (el4 / args.steps), 1), features_per_block_surf=[len(x) for x in surf_b], features_per_block_corner=[len(x) for x in corner_b],
+                    n_valid_per_iter_per_block_surf_corner=n_valid4, valid_correspondences_per_step=n_valid4_step, final_poses=np.round(np.asarray(poses4_t), 9).tolist(),
+                    n1_same_map_ms_per_step=(ref4 or {}).get("ms_per_step"),
+                    speedup_vs_n1_same_map=(round(ref4["ms_per_step"] / (1e3 * el4 / args.steps), 4) if ref4 else None),
+                    pose_vs_n1_same_map_m=(float(np.abs(np.asarray(ref4["poses"])[:, :3] - np.asarray(poses4_t)[:, :3]).max()) if ref4 else None))
+
     owned_all = local_map_all = None
     if world > 1:
         t_own = torch.zeros((world, 2), dtype=torch.int64, device=dist_dev)
@@ -694,8 +821,18 @@ def main():
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    multi_gpu=(None if world == 1 else dict(
-                       shard_mode=args.shard_mode, comm=("mailbox communicator (mlh_p2p_*): the summed record is exchanged inside the fit kernel's finishing workgroup, one hop, no extra launch" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
+                       shard_mode=args.shard_mode,
+                       communicator=("mailbox" if comm_kind == "p2p" else "rccl"), communicator_requested=args.comm, ranks_seen_by_the_collective=comm_state["ranks_seen"],
+                       comm=("mailbox communicator (mlh_p2p_*): the summed record is exchanged inside the fit kernel's finishing workgroup, one hop, no extra launch" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
+                       ranks_share_gpus=bool(shared_gpus), gpus_visible=int(torch.cuda.device_count()),
+                       cross_gpu_measurement=(False if shared_gpus else True),
+                       cross_gpu_note=("ranks SHARE devices on this box: this line checks the N > 1 path end to end, it is NOT a scaling measurement -- no cross-GPU (xGMI) number exists in this "
+                                       "repository's history until a run with a GPU per rank has been recorded" if shared_gpus else "one GPU per rank: peer stores / RCCL over xGMI"),
+                       n1_same_map=n1_ref,
+                       n1_same_map_ms_per_step=(n1_ref or {}).get("ms_per_step"),
+                       speedup_vs_n1_same_map=(round(n1_ref["ms_per_step"] / ms_per_step, 4) if n1_ref else None),
                        owned_features_per_rank=owned_all, local_map_points_per_rank=local_map_all,
+                       per_rank_kernel_us=per_rank, exchange_us_standalone_allreduce_of_32_f64=exchange_us, other_communicator=other_comm,
                        allreduce_us_per_call_rank0=(round(1e3 * prof[mla.K_ALLREDUCE][0] / prof[mla.K_ALLREDUCE][1], 3) if prof[mla.K_ALLREDUCE][1] else None),
                        solve_update_us_per_call_rank0=(round(1e3 * prof[mla.K_SOLVE][0] / prof[mla.K_SOLVE][1], 3) if prof[mla.K_SOLVE][1] else None),
                        note=("per GN iteration and rank: correspondence kernel + fit kernel whose finishing workgroup exchanges the 32-double record with the peers and solves (2 launches, as unsharded)" if comm_kind == "p2p" else "per GN iteration and rank: correspondence kernel + fit kernel (local reduce) + ONE ncclAllReduce of 32 f64 + the redundant 6x6 solve launch"))),
@@ -706,6 +843,16 @@ def main():
                    gpu_clock_spinup_ms=round(spin_ms, 1),
                    ms_per_step_map_outgrows_its_grid_box=(round(outgrow_ms, 4) if outgrow_ms is not None else None),
                    roofline=roofline, roofline_time_dominant_kernel=roofline_fit)
+        if cfg4 is not None:
+            out["config4"] = cfg4
+            if args.config4:      # config 4's frame is the headline; the single-pose frame's numbers stay in the line as `config2_leg`
+                out["config2_leg"] = dict(value=out["value"], ms_per_step=out["ms_per_step"], workload=out["config"]["workload"], queries_per_s=out["queries_per_s"],
+                                          valid_correspondences_per_step=out["valid_correspondences_per_step"])
+                out["value"], out["ms_per_step"], out["queries_per_s"] = cfg4["value"], cfg4["ms_per_step"], cfg4["queries_per_s"]
+                out["valid_correspondences_per_step"] = cfg4["valid_correspondences_per_step"]
+                out["ms_per_gn_iter"] = round(cfg4["ms_per_step"] / GN_ITERS, 4)
+                out["config"]["workload"] = cfg4["workload"]
+                out["metric"] = "scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame, 4 pose blocks: pose + 3 extrinsic SE3)"
         if s2m_ms is not None:
             out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), lm_iterations=[int(st["lm_iterations"]) for st in s2m_stats],
                                    note="supplementary: mlh_map_rebuild + mlh_scan2map (2 outer iterations, Ceres-shaped LM, Huber 0.1), "

@@ -254,7 +254,9 @@ int mlh_pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *f
  *   V_update          NULL (identity) or 36 doubles per block, row-major: what Estimator::evalDegenracy (estimator.cpp:1598-1680; facade evalDegenracy) left in
  *                     every block's PoseLocalParameterization -- a projector for a degenerate pose block, zero for an extrinsic that is not to be updated
  *   frames / exts     in: the linearisation point, out: the result.  cost / n_residuals: of the LAST linearisation (before the final update).
- *   status            0 solved, 1 some iteration needed the + 1e-6 I, 2 some iteration's system was not positive definite even then (that update was skipped) */
+ *   status            0 solved, 1 some iteration needed the + 1e-6 I, 2 some iteration's system was not positive definite even then (that update was skipped)
+ * Under a communicator (mlh_comm_init / mlh_p2p_comm_init) the call returns MLH_ERR_UNSUPPORTED: it factorises this rank's sums, and ranks holding different
+ * parts of the factor table would apply different updates. Sharded callers all-reduce mlh_pure_odom_normal_eq's H / g (mlh_allreduce_f64) and solve on the host. */
 int mlh_pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
                            uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_residuals, int32_t *status);
 

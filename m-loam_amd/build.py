@@ -16,7 +16,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libmloam_hip.so")
 SOURCES = ["capi.hip", "grid.hip", "match.hip", "solver.hip", "extract.hip", "comm.hip", "select.hip", "voxel.hip", "voxelgrid.hip", "odom.hip", "track.hip",
            "frontend.hip", "segment.hip", "stdsort.hip"]
-HEADERS = ["ctx.hpp", "alive_pool.hpp", "dev_math.hpp", "solver_dev.hpp", "knn_dev.hpp", "reduce_dev.hpp", "sort_dev.hpp", "stdsort_dev.hpp", "std_sort_mt.hpp", os.path.join("..", "..", "include", "mloam_hip.h")]
+HEADERS = ["ctx.hpp", "alive_pool.hpp", "dev_math.hpp", "solver_dev.hpp", "knn_dev.hpp", "reduce_dev.hpp", "sort_dev.hpp", "stdsort_dev.hpp", "std_sort_mt.hpp", "p2p_dev.hpp", os.path.join("..", "..", "include", "mloam_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -284,6 +284,9 @@ static int wait_published(mlh_ctx *ctx, unsigned long long seq, HostPublish &out
 #endif
     }
     out = *h;
+    // several ranks joined by the mailbox communicator: the launches behind this publication exchanged records with the peers inside their finish. A peer that
+    // never arrived leaves the error word set (p2p_dev.hpp): no solve entry point returns a pose built on partial sums as if it were the job's
+    if (ctx->p2p.active) return device_error_check(ctx);
     return MLH_OK;
 }
 
@@ -372,6 +375,8 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->h_sync) (void)hipHostFree(ctx->h_sync);
     if (ctx->ev_handover) (void)hipEventDestroy(ctx->ev_handover);
     if (ctx->h_rings) (void)hipHostFree(ctx->h_rings);
+    if (ctx->h_pts) (void)hipHostFree(ctx->h_pts);
+    for (int i = 0; i < 2; ++i) if (ctx->ev_pts[i]) (void)hipEventDestroy(ctx->ev_pts[i]);
     for (int i = 0; i < 2; ++i) if (ctx->ev_rings[i]) (void)hipEventDestroy(ctx->ev_rings[i]);
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
     for (int i = 0; i < 2; ++i) if (ctx->ev_set_built[i]) (void)hipEventDestroy(ctx->ev_set_built[i]);
@@ -437,8 +442,41 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     sb.voxelised = false;
     sb.h_lists_valid = sb.h_vox_valid = false;
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
-    int rc = stage_points(ctx, points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, sb.pts, nullptr, ctx->tmp);
+    // A caller's PAGEABLE buffer (a ROS message) is copied into a pinned block the context owns -- two halves, an event per half -- and goes to the device from
+    // there: the call returns without waiting for the stream, and the caller's buffer is free the moment it does, whatever the runtime does with pageable
+    // sources of an asynchronous copy. (A buffer the caller pinned is copied from in place; that case waits below.)
+    const void *src_points = points;
+    bool caller_pinned = false;
+    int pts_half = -1;
+    if (mem == MLH_MEM_HOST && points && n > 0 && stride_bytes >= 12) {
+        hipPointerAttribute_t at;
+        caller_pinned = hipPointerGetAttributes(&at, points) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!caller_pinned) {
+            const size_t bytes = size_t(n) * stride_bytes;
+            if (bytes > ctx->h_pts_cap) {
+                MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->h_pts) (void)hipHostFree(ctx->h_pts);
+                ctx->h_pts = nullptr; ctx->h_pts_cap = 0;
+                const size_t cap = ((bytes + bytes / 4 + 4095) / 4096) * 4096;
+                MLH_HIP(ctx, hipHostMalloc(&ctx->h_pts, 2 * cap, hipHostMallocDefault));
+                ctx->h_pts_cap = cap;
+                for (int i = 0; i < 2; ++i) if (!ctx->ev_pts[i]) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pts[i], hipEventDisableTiming));
+                ctx->ev_pts_used[0] = ctx->ev_pts_used[1] = false;
+            }
+            pts_half = int(ctx->pts_turn++ & 1);
+            if (ctx->ev_pts_used[pts_half]) MLH_HIP(ctx, hipEventSynchronize(ctx->ev_pts[pts_half]));      // two uploads ago
+            void *dst = static_cast<char *>(ctx->h_pts) + size_t(pts_half) * ctx->h_pts_cap;
+            std::memcpy(dst, points, bytes);
+            src_points = dst;
+        }
+    }
+    int rc = stage_points(ctx, src_points, stride_bytes, n, mem, intensity_offset_bytes >= 0 ? intensity_offset_bytes : -1, -1, sb.pts, nullptr, ctx->tmp);
     if (rc) return rc;
+    if (pts_half >= 0) {
+        MLH_HIP(ctx, hipEventRecord(ctx->ev_pts[pts_half], ctx->stream));
+        ctx->ev_pts_used[pts_half] = true;
+    }
     // The ring tables go to the device from a pinned block the context owns (two halves, used alternately; an event says when a half's copy has been read):
     // nothing has to be waited for before this call returns, so the host enqueues the extraction while the points are still being uploaded -- a blocking
     // wait here was ~40 us of idle GPU per frame (profiles/r03_frame_timeline.txt: the gap in front of the curvature kernel).
@@ -478,13 +516,8 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     sb.end_alias = sb.start.as<int>() + n_rings;
     MLH_HIP(ctx, hipEventRecord(ctx->ev_rings[half], ctx->stream));
     ctx->ev_rings_used[half] = true;
-    // The caller's point buffer: a copy out of PAGEABLE memory has been staged by the time hipMemcpyAsync returned; out of pinned memory it is truly
-    // asynchronous, and the buffer is the caller's to reuse after this call -- so that case (rare: a ROS message is pageable) still waits here
-    if (mem == MLH_MEM_HOST) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, points) == hipSuccess && at.type == hipMemoryTypeHost) MLH_HIP(ctx, stream_wait_spin(ctx));
-        (void)hipGetLastError();
-    }
+    // a buffer the CALLER pinned is read by the copy engine in place, asynchronously, and is the caller's to reuse after this call: that (rare) case waits here
+    if (caller_pinned) MLH_HIP(ctx, stream_wait_spin(ctx));
     sb.n = n; sb.n_rings = n_rings; sb.max_ring_len = max_len;
     return MLH_OK;
 }
@@ -599,6 +632,8 @@ int mlh_pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, 
                            uint32_t const_block_mask, const double *V_update, double *cost, int32_t *n_residuals, int32_t *status)
 {
     if (!ctx) return MLH_ERR_INVALID;
+    // the window solve factorises THIS rank's J^T J / J^T r: with the factor table sharded over several ranks every rank would apply a different update
+    if (distributed(ctx)) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_pure_odom_gn_solve under a communicator: all-reduce mlh_pure_odom_normal_eq's H / g (mlh_allreduce_f64) and solve on the host, or build the whole factor table on every rank");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     return pure_odom_gn_solve(ctx, pivot, frames, n_frames, exts, n_ext, huber_delta, n_iters, const_block_mask, V_update, cost, n_residuals, status);
 }
@@ -695,10 +730,13 @@ static int map_set_impl(mlh_ctx *ctx, int n_maps, const int *kinds, const void *
     if (mem == MLH_MEM_HOST) {
         size_t off[2] = {0, 0}, total = 0;
         for (int k = 0; k < n_maps; ++k) { off[k] = total; total += ((size_t(n[k]) * stride_bytes + 255) / 256) * 256; }
-        MLH_HIP(ctx, ctx->tmp.ensure(total));
+        // the overlapped path runs on the staging stream beside whatever the main stream has queued (a scan upload's pack kernel may still be reading ctx->tmp):
+        // it stages through a buffer of its own
+        DevBuf &tmp = (ctx->stream2 && ctx->stream == ctx->stream2) ? ctx->tmp_stage : ctx->tmp;
+        MLH_HIP(ctx, tmp.ensure(total));
         for (int k = 0; k < n_maps; ++k) {
-            MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.as<unsigned char>() + off[k], points[k], size_t(n[k]) * stride_bytes, hipMemcpyHostToDevice, ctx->stream));
-            src[k] = ctx->tmp.as<unsigned char>() + off[k];
+            MLH_HIP(ctx, hipMemcpyAsync(tmp.as<unsigned char>() + off[k], points[k], size_t(n[k]) * stride_bytes, hipMemcpyHostToDevice, ctx->stream));
+            src[k] = tmp.as<unsigned char>() + off[k];
         }
     } else {
         for (int k = 0; k < n_maps; ++k) src[k] = static_cast<const unsigned char *>(points[k]);
@@ -742,7 +780,10 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
     if (!ctx) return MLH_ERR_INVALID;
     if (!ctx->solve_pending && mem != MLH_MEM_DEVICE) return mlh_map_set_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, min_match_sq_dis, mem);
     MLH_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->solve_pending && ctx->map_read_unsynced) {     // the one map-reading entry point that returns with its launch still queued: drain before a set is rewritten
+    if (ctx->map_read_unsynced) {
+        // mlh_pure_odom_add_matches returns with its map-reading launch still queued. Whatever set it reads, it must be done before a set is rewritten -- also
+        // with a solve in flight (begin(A); add_matches(A); overlapped -> B; end; begin(B); overlapped -> A would otherwise rewrite A under that launch): the
+        // main stream is drained, the solve included. Rare (the window's factor table is not built beside a pipelined mapper solve), so correctness first.
         MLH_HIP(ctx, stream_wait_spin(ctx));
         ctx->map_read_unsynced = false;
     }
@@ -1181,6 +1222,7 @@ static int fetch_pose_and_stats(mlh_ctx *ctx, double pose[7], mlh_iter_stat *sta
     MLH_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->stats.p, sizeof(IterStatDev) * size_t(n_stats), hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
+    if (ctx->p2p.active) { const int erc = device_error_check(ctx); if (erc) return erc; }      // (see wait_published)
     for (int i = 0; i < 7; ++i) pose[i] = hs.x[i];
     for (int i = 0; i < n_stats; ++i) copy_stat(hd[i], stats[i]);
     return MLH_OK;

@@ -258,6 +258,12 @@ struct mlh_ctx {
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
+    mlh::DevBuf tmp_stage;   // the same for mlh_map_set_pair_overlapped, whose copies and pack kernels run on the staging stream beside the main stream's
+    void *h_pts = nullptr;   // pinned landing place (two halves) of a caller's PAGEABLE scan points (mlh_scan_upload)
+    size_t h_pts_cap = 0;    // bytes per half
+    hipEvent_t ev_pts[2] = {nullptr, nullptr};
+    bool ev_pts_used[2] = {false, false};
+    unsigned pts_turn = 0;
     void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
     unsigned long long solve_seq = 0, solve_collected = 0;   // submitted / collected solves (at most two apart)
     bool solve_pending = false;
@@ -380,7 +386,11 @@ inline int *device_error_word(mlh_ctx *ctx)
 inline int device_error_check(mlh_ctx *ctx)
 {
     if (ctx->h_dev_err && *static_cast<volatile int *>(ctx->h_dev_err) != 0) {
+        const int code = *ctx->h_dev_err;
         *ctx->h_dev_err = 0;
+        if (code == 2)
+            return fail(ctx, MLH_ERR_STATE, "a peer rank did not arrive at a mailbox exchange within 5 s: the normal equations were NOT summed over the job, no update was applied from them, "
+                                            "and the ranks may no longer hold the same pose -- the result of this call is not valid");
         return fail(ctx, MLH_ERR_STATE, "a device kernel gave up (std::sort emulation: unreleased wait or an unannounced range); the results of this call are not valid");
     }
     return MLH_OK;

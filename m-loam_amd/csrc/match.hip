@@ -522,8 +522,9 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.p = P.partials;
         sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0;
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
+        bool exchanged = true;
         if (P.p2p.n_ranks > 1) {     // sharded over several ranks: everybody's sums before anybody's LM decision (same bits, same decision on every rank)
-            p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
+            exchanged = p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
             if (threadIdx.x == 0) { f_cnt2[0] = f_ne[NE_CNT + 1]; f_cnt2[1] = f_ne[NE_CNT + 2]; }
             __syncthreads();
         }
@@ -531,7 +532,13 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         if (threadIdx.x < 64) {      // one wavefront runs the LM begin / step (solver_dev.hpp: rows of the 6 x 6 objects on lanes)
             double xo[7];
             int done = 0;
-            if (P.finish == 3) lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
+            if (!exchanged) {        // a peer timed out: no decision on partial sums -- the loop ends here, the pose stays, the host reports the error word
+#pragma unroll
+                for (int i = 0; i < 7; ++i) xo[i] = P.state->x[i];
+                done = 1;
+                if (threadIdx.x == 0) P.state->done = 1;
+            }
+            else if (P.finish == 3) lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
             else lm_step_body_wave(f_ne, P.state, P.lm_max_it, xo, done);
             if (threadIdx.x == 0) {
                 *P.ticket = 0u;
@@ -578,13 +585,16 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
         sa.hi[1] = P.k[0].tiles_b + (P.k[1].m > 0 ? (P.k[1].blk_start[b + 1] + TPB - 1) / TPB : 0);
         if (P.n_blocks == 1) { sa.lo[0] = 0; sa.hi[0] = total_tiles; sa.lo[1] = 0; sa.hi[1] = 0; }   // one block: every record (any tile size)
         sum_partials<NT, (NT > 256 ? 21 : 12)>(sa, f_ne, f_cnt2, f_scratch);
+        bool exchanged = true;
         if (P.p2p.n_ranks > 1) {                     // this rank's sums -> everybody's sums (rank order: the same bits on every rank)
-            p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
+            exchanged = p2p_exchange<NT>(P.p2p, f_ne, NE_STRIDE);
             if (threadIdx.x == 0) { f_cnt2[0] = f_ne[NE_CNT + 1]; f_cnt2[1] = f_ne[NE_CNT + 2]; }
             __syncthreads();
         }
         MLH_STAGE(4095, 1);
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64 && !exchanged) {        // a peer timed out: nothing is solved on partial sums; the pose stays and is published as it is (the host reports the error word)
+            if (P.publish && threadIdx.x == 0) for (int i = 0; i < 7; ++i) (b == 0 ? P.publish->x : P.publish->xb[b])[i] = (b == 0 ? P.state->x : P.state->xb[b])[i];
+        } else if (threadIdx.x < 64) {
             double xo[7];
             const double *x_in = (b == 0 && P.pose0) ? P.pose0 : nullptr;      // last iteration of a deferred-finish solve: the pose comes from its iteration slot
             gn_finish_wave(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], nullptr /* nothing downstream reads a mirror of ne / V_update in GN mode */, P.thre_b[b], P.freeze_b[b],

@@ -21,9 +21,14 @@ struct P2pDev {
 };
 
 // rec[0 .. n) (LDS) <- sum over the ranks, added in rank order. All NT threads of the workgroup, converged; n <= P2P_MAX_DOUBLES.
+// Returns false (uniform over the workgroup) when a peer did not show up within the bound: the pinned error word is 2 then, rec is NOT a sum over the job, and
+// the caller must not solve with it -- the host reports the failure from every solve entry point (device_error_check).
 template <int NT>
-__device__ __forceinline__ void p2p_exchange(const P2pDev &a, double *rec, int n)
+__device__ __forceinline__ bool p2p_exchange(const P2pDev &a, double *rec, int n)
 {
+    __shared__ int s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0;
+    __syncthreads();
     const unsigned long long seq = __hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
     const int t = threadIdx.x, par = int(seq & 1ull);
     for (int r = 0; r < a.n_ranks; ++r)
@@ -39,6 +44,7 @@ __device__ __forceinline__ void p2p_exchange(const P2pDev &a, double *rec, int n
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 1023u) == 0 && wall_clock64() - t0 > 500000000ull) {        // 5 s at 100 MHz: the peer is not coming
                 if (a.err) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_timeout = 1;
                 break;
             }
         }
@@ -52,6 +58,7 @@ __device__ __forceinline__ void p2p_exchange(const P2pDev &a, double *rec, int n
     __syncthreads();                     // (every thread has read the counter long before this point)
     if (t == 0) __hip_atomic_store(a.counter, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    return s_timeout == 0;
 }
 
 // fills the device-side descriptor from the context

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -38,6 +39,9 @@ namespace mloam_hip {
 struct alignas(16) PointI {           // pcl::PointXYZI: float data[4]; float intensity; pad[3]  -> 32 bytes
     float x = 0, y = 0, z = 0, pad_ = 1.f;
     float intensity = 0, pad2_[3] = {0, 0, 0};
+};
+struct alignas(16) PointXYZ {         // pcl::PointXYZ: float data[4] -> 16 bytes (the raw driver cloud, FeatureExtract::calTimestamp's input)
+    float x = 0, y = 0, z = 0, pad_ = 1.f;
 };
 struct alignas(16) PointIWithCov {    // pcl::PointXYZIWithCov (mloam_pcl/point_with_cov.hpp:45-53) -> 48 bytes
     float x = 0, y = 0, z = 0, pad_ = 1.f;
@@ -57,6 +61,7 @@ struct PointCloud {
 #endif
 static_assert(sizeof(PointI) == 32, "pcl::PointXYZI layout");
 static_assert(sizeof(PointIWithCov) == 48, "pcl::PointXYZIWithCov layout");
+typedef PointCloud<PointXYZ> PointXYZCloud;      // the reference's `PointCloud` (common_types: pcl::PointCloud<pcl::PointXYZ>)
 typedef PointCloud<PointI> PointICloud;
 typedef PointCloud<PointIWithCov> PointICovCloud;
 typedef std::map<std::string, PointICloud> cloudFeature;   // parameters.h:161
@@ -126,6 +131,19 @@ public:
 private:
     mlh_ctx *ctx_ = nullptr;
 };
+
+// A context is thread-compatible, not re-entrant (one stream, one set of scan buffers). The reference calls ImageSegmenter::segmentCloud and
+// FeatureExtract::extractCloud on ONE object from NUM_OF_LASER OpenMP threads at once (estimator.cpp:249-263), so the default-constructed facade objects do not
+// hold a context: every calling thread gets its own from here, created on the thread's first call and kept for the thread's lifetime (OpenMP keeps its workers
+// between parallel regions, so a frame pays no context creation). setThreadDeviceId picks the GPU the pool creates contexts on (default 0).
+inline int &threadDeviceId() { static int id = 0; return id; }
+inline void setThreadDeviceId(int device_id) { threadDeviceId() = device_id; }
+inline Device &threadDevice()
+{
+    thread_local std::unique_ptr<Device> dev;
+    if (!dev) dev.reset(new Device(threadDeviceId()));
+    return *dev;
+}
 
 // ------------------------------------------------------------------ the "kd-tree" handed to the match functions
 // Mirrors pcl::KdTreeFLANN<PointT>: setInputCloud(cloud) (re)builds the index. kind selects which of the context's two
@@ -261,14 +279,53 @@ inline void downsampleCurrentScan(Device &dev, int kind, const PointICloud &lase
 // ------------------------------------------------------------------ FeatureExtract
 class FeatureExtract {
 public:
-    explicit FeatureExtract(Device &dev) : dev_(dev) {}
+    // As the reference's member `FeatureExtract f_extract_;` (estimator.h:190): no context of its own -- every calling thread works on its own (threadDevice()),
+    // so extractCloud is RE-ENTRANT on one object, as estimator.cpp:249-263 needs it (one object, NUM_OF_LASER OpenMP threads).
+    FeatureExtract() : bound_(nullptr) {}
+    // Bound to one context: for callers that keep the extraction's device-resident results (extractCloudOnDevice -> LidarTracker / fuseCloudFeature on the same
+    // Device). One thread at a time.
+    explicit FeatureExtract(Device &dev) : bound_(&dev) {}
+
+    // feature_extract.cpp:38-113: a point's relative time inside the sweep from its azimuth (the `intensity` field of the output), the reference's two-phase
+    // unwrapping (`half_passed`) restated. Host code by nature: one sequential pass with carried state over a cloud that is still on the host; ImageSegmenter
+    // overwrites the field with the ring id anyway (image_segmenter.hpp:371). Here so that estimator.cpp:249-263 compiles against this header as it stands.
+    template <typename PointXYZ>
+    void calTimestamp(const PointCloud<PointXYZ> &laser_cloud_in, PointICloud &laser_cloud_out, float scan_period = 0.1f) const
+    {
+        const size_t n = laser_cloud_in.size();
+        laser_cloud_out.points.resize(n);
+        if (n == 0) return;
+        const float two_pi = float(2 * M_PI);
+        float start_ori = -std::atan2(laser_cloud_in.points[0].y, laser_cloud_in.points[0].x);
+        float end_ori = -std::atan2(laser_cloud_in.points[n - 1].y, laser_cloud_in.points[n - 1].x) + two_pi;
+        if (end_ori - start_ori > float(3 * M_PI)) end_ori -= two_pi;
+        else if (end_ori - start_ori < float(M_PI)) end_ori += two_pi;
+        bool half_passed = false;
+        for (size_t i = 0; i < n; ++i) {
+            PointI q;
+            q.x = laser_cloud_in.points[i].x; q.y = laser_cloud_in.points[i].y; q.z = laser_cloud_in.points[i].z;
+            float ori = -std::atan2(q.y, q.x);
+            if (!half_passed) {
+                if (ori < start_ori - float(M_PI / 2)) ori += two_pi;
+                else if (ori > start_ori + float(M_PI * 3 / 2)) ori -= two_pi;
+                if (ori - start_ori > float(M_PI)) half_passed = true;
+            } else {
+                ori += two_pi;
+                if (ori < end_ori - float(M_PI * 3 / 2)) ori += two_pi;
+                else if (ori > end_ori + float(M_PI / 2)) ori -= two_pi;
+            }
+            q.intensity = (ori - start_ori) / (end_ori - start_ori) * scan_period;
+            laser_cloud_out.points[i] = q;
+        }
+    }
 
     // feature_extract.cpp:118-297. Output keys and ordering as the reference (cpp:281-285), "surf_points_less_flat" thinned by the
     // per-ring 0.2 m VoxelGrid (cpp:266-271) with the intensity field (ring id) averaged along, as PCL does.
-    // Re-entrancy: the reference calls this concurrently from NUM_OF_LASER OpenMP threads on one object
-    // (estimator.cpp:249-263); here use one FeatureExtract (one Device) per thread.
+    // Re-entrancy: see the constructors. Nothing of a call lives in the object (the labels of a thread's last call: cloudLabel()).
     void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature)
     {
+        Device &dev_ = device();
+        std::vector<int32_t> &labels_ = threadLabels();
         const int n = (int)laser_cloud_in.size();
         const int rings = (int)scan_info.scan_start_ind_.size();
         dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, n, scan_info.scan_start_ind_.data(),
@@ -297,12 +354,14 @@ public:
         lf.points.reserve(n_vox);
         for (int k = 0; k < n_vox; ++k) { PointI p; p.x = vox[4 * k]; p.y = vox[4 * k + 1]; p.z = vox[4 * k + 2]; p.intensity = vox[4 * k + 3]; lf.push_back(p); }
     }
-    const std::vector<int32_t> &cloudLabel() const { return labels_; }   // cloud_label[] of the last extractCloud
+    const std::vector<int32_t> &cloudLabel() const { return threadLabels(); }   // cloud_label[] of the calling thread's last extractCloud
+    Device &device() const { return bound_ ? *bound_ : threadDevice(); }
 
     // The same extraction with nothing fetched: the four feature lists and the thinned less-flat cloud stay in HBM for
     // LidarTracker::set*FromExtractor and fuseCloudFeature (one scan per Device at a time).
     void extractCloudOnDevice(const PointICloud &laser_cloud_in, const ScanInfo &scan_info)
     {
+        Device &dev_ = device();
         dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, (int)laser_cloud_in.size(),
                                    scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), (int)scan_info.scan_start_ind_.size(), MLH_MEM_HOST));
         dev_.check(mlh_extract_run(dev_.ctx()));
@@ -376,8 +435,8 @@ private:
         feature.idx_ = idx;
         return true;
     }
-    Device &dev_;
-    std::vector<int32_t> labels_;
+    static std::vector<int32_t> &threadLabels() { thread_local std::vector<int32_t> l; return l; }
+    Device *bound_;
 };
 
 // ------------------------------------------------------------------ PoseLocalParameterization (host side of the GN step)
@@ -683,7 +742,9 @@ inline double gfRatioPolicy(const std::string &gf_method, double gf_ratio_ini, d
 // the Device's scan, so FeatureExtract::extractCloudOnDevice-style calls (mlh_extract_run) can follow without an upload.
 class ImageSegmenter {
 public:
-    explicit ImageSegmenter(Device &dev) : dev_(dev) { mlh_segment_params_default(&prm_); }
+    // as the reference's member `ImageSegmenter img_segment_;` (estimator.h:189): re-entrant on one object, every calling thread on its own context
+    ImageSegmenter() : bound_(nullptr) { mlh_segment_params_default(&prm_); }
+    explicit ImageSegmenter(Device &dev) : bound_(&dev) { mlh_segment_params_default(&prm_); }
     void setParameter(const int &vertical_scans, const int &horizon_scans, const int &min_cluster_size, const int &segment_valid_point_num,
                       const int &segment_valid_line_num)
     {
@@ -694,6 +755,8 @@ public:
     double &ROI_RANGE() { return prm_.roi_range; }
     void segmentCloud(const PointICloud &laser_cloud_in, PointICloud &laser_cloud_out, PointICloud &laser_cloud_outlier, ScanInfo &scan_info)
     {
+        Device &dev_ = bound_ ? *bound_ : threadDevice();
+        mlh_segment_params prm_ = this->prm_;          // the call's own copy: concurrent calls differ in segment_flag
         const int n = (int)laser_cloud_in.size();
         prm_.segment_flag = scan_info.segment_flag_ ? 1 : 0;
         // laser_cloud_outlier holds at most one point per pixel of a column that is a multiple of 5 (and never more than n), plus one
@@ -714,7 +777,7 @@ public:
         fill(laser_cloud_outlier, outl, n_outl);
     }
 private:
-    Device &dev_;
+    Device *bound_;
     mlh_segment_params prm_;
 };
 

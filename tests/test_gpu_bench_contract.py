@@ -45,3 +45,55 @@ def test_bench_json_line():
     assert d["gpu_clock_spinup_ms"] >= 0 and d["ms_per_step_map_outgrows_its_grid_box"] > 0
     # frames are submitted pipelined by default (pose k collected after frame k + 1's staging is enqueued); the synchronous loop is reported beside it
     assert d["frame_submission"].startswith("pipelined") and d["ms_per_step_synchronous_submission"] > 0
+
+
+def _bench(*flags, env=None, timeout=900):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):      # as typed at a shell: no launcher around it
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+
+
+def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher (Next 1): the script spawns its two ranks itself; on this one-GPU box they share the device through the
+    mailbox communicator. The line says n_gpus 2, carries both ranks' owned counts, what the collective saw, the same-map N = 1 reference measured by rank 0 alone
+    before the sharded leg, per-rank kernel times, and says plainly that ranks sharing a GPU are not a scaling measurement."""
+    r = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--map-preset", "500k")
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen_by_the_collective"] == 2 and mg["communicator"] in ("mailbox", "rccl")
+    assert len(mg["owned_features_per_rank"]) == 2 and all(a + b > 0 for a, b in mg["owned_features_per_rank"])
+    assert sum(a + b for a, b in mg["owned_features_per_rank"]) == d["config"]["features_surf"] + d["config"]["features_corner"]
+    assert len(mg["per_rank_kernel_us"]) == 2 and {x["rank"] for x in mg["per_rank_kernel_us"]} == {0, 1} and all(x["knn_us"] > 0 and x["fit_us"] > 0 for x in mg["per_rank_kernel_us"])
+    ref = mg["n1_same_map"]
+    assert ref["ms_per_step"] > 0 and mg["n1_same_map_ms_per_step"] == ref["ms_per_step"] and ref["map_points"] > 400000
+    assert ref["valid_correspondences_per_step"] == d["valid_correspondences_per_step"]        # the sharded job linearises exactly the features the single GPU does
+    assert mg["exchange_us_standalone_allreduce_of_32_f64"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert mg["ranks_share_gpus"] is True and mg["cross_gpu_measurement"] is False and "NOT a scaling measurement" in mg["cross_gpu_note"]
+
+
+def test_bench_rank_count_mismatch_is_an_error():
+    """a launcher that started a different number of ranks than --gpus asks for ends the run with exit code 2 and no JSON line -- never a silently smaller job"""
+    r = _bench("--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", env=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-1000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")] and "FATAL" in r.stderr
+
+
+def test_bench_config4_two_ranks_sharing_the_gpu():
+    """BASELINE config 4's frame (4 x 64 rings, four pose blocks, N_NEIGH 5/10/10/10 + CHECK_FOV) through the sharded mlh_gn_solve_blocks as the headline of an
+    N = 2 run: equal poses to the same frame solved by rank 0 alone on the whole map"""
+    r = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--map-preset", "500k", "--config4")
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c4 = d["config4"]
+    assert d["n_gpus"] == 2 and d["value"] == c4["value"] and d["ms_per_step"] == c4["ms_per_step"] and "4 pose blocks" in d["config"]["workload"]
+    assert len(c4["features_per_block_surf"]) == 4 and c4["valid_correspondences_per_step"] > 0 and c4["n1_same_map_ms_per_step"] > 0
+    assert c4["pose_vs_n1_same_map_m"] < 1e-7, c4
+    assert "config2_leg" in d and d["config2_leg"]["value"] > 0

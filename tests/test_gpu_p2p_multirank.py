@@ -15,11 +15,11 @@ WORKER = os.path.join(ROOT, "tests", "_multirank_worker.py")
 _PORT = [29651]
 
 
-def _run(world, mode, share_gpu=True):
+def _run(world, mode, share_gpu=True, extra=()):
     _PORT[0] += 1
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MLH_P2P_SHARE_GPU="1" if share_gpu else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(_PORT[0]),
-           WORKER, mode, "p2p"]
+           WORKER, mode, "p2p", *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -36,6 +36,14 @@ def test_sharded_solver_over_the_mailbox_communicator(world, mode):
     assert out["counts"] == out["counts_unsharded"]                    # same matched features every iteration ...
     assert out["pose_diff"] < 1e-9 and out["scan2map_pose_diff"] < 1e-9      # ... same pose (the records are summed in another order: not bit for bit)
     assert out["split_submission_equal"] is True                      # mlh_gn_solve_begin / _end under the communicator: the same bits as mlh_gn_solve
+
+
+@pytest.mark.gpu
+def test_a_peer_that_never_arrives_is_reported_by_the_solve_itself():
+    """with the mailbox communicator a solve whose peer timed out must fail in THAT call, with a message that names the cause"""
+    out = _run(2, "features", extra=("timeout",))
+    assert out["raised"] is True and "peer rank did not arrive" in out["message"], out
+    assert out["later_call_ok"] is True, out
 
 
 def _n_gpus():
