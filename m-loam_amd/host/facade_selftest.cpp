@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <fstream>
+#include <omp.h>
 
 using namespace mloam_hip;
 
@@ -338,6 +339,85 @@ int main(int argc, char **argv)
             po.insert(po.end(), o1, o1 + 7);
             write_file(d + "out_pipeline.f64", po);
             std::printf("frame pipeline: %.9f %.9f %.9f -> %.9f %.9f %.9f\n", pa[0], pa[1], pa[2], pb[0], pb[1], pb[2]);
+        }
+        // --- round 4: the estimator's front end AS THE REFERENCE WRITES IT (estimator.cpp:249-263): ONE ImageSegmenter and ONE FeatureExtract as members,
+        //     NUM_OF_LASER OpenMP threads calling calTimestamp / segmentCloud / extractCloud on them at once. Every LiDAR's result must equal what the same
+        //     calls give one after the other on an object bound to one context.
+        {
+            const int NUM_OF_LASER = 4, N_SCANS = 16;
+            auto raw = read_file<float>(d + "raw_cloud.f32");
+            std::vector<PointXYZCloud> v_laser_cloud_in(NUM_OF_LASER);
+            for (int l = 0; l < NUM_OF_LASER; ++l) {             // four different scans: the harness's cloud turned about z by 0 / 17 / 34 / 51 degrees
+                const double a = l * 17.0 * M_PI / 180.0, ca = std::cos(a), sa = std::sin(a);
+                for (size_t i = 0; i + 4 <= raw.size(); i += 4) {
+                    PointXYZ q;
+                    q.x = float(ca * raw[i] - sa * raw[i + 1]); q.y = float(sa * raw[i] + ca * raw[i + 1]); q.z = raw[i + 2];
+                    v_laser_cloud_in[l].push_back(q);
+                }
+            }
+            auto flatten = [](cloudFeature &cf_, std::vector<float> &o) {
+                o.clear();
+                for (const char *k : {"laser_cloud", "corner_points_sharp", "corner_points_less_sharp", "surf_points_flat", "surf_points_less_flat", "laser_cloud_outlier"}) {
+                    o.push_back(float(cf_[k].size()));
+                    for (const auto &q : cf_[k].points) { o.push_back(q.x); o.push_back(q.y); o.push_back(q.z); o.push_back(q.intensity); }
+                }
+            };
+            // one after the other, bound objects
+            std::vector<std::vector<float>> seq(NUM_OF_LASER), par(NUM_OF_LASER);
+            std::vector<std::vector<int32_t>> seq_labels(NUM_OF_LASER), par_labels(NUM_OF_LASER);
+            std::vector<float> stamps;
+            {
+                ImageSegmenter seg_b(dev);
+                seg_b.setParameter(N_SCANS, 1800, 30, 5, 3);
+                FeatureExtract fe_b(dev);
+                for (int i = 0; i < NUM_OF_LASER; ++i) {
+                    PointICloud laser_cloud, laser_cloud_segment, laser_cloud_outlier;
+                    fe_b.calTimestamp(v_laser_cloud_in[i], laser_cloud);
+                    if (i == 0) for (const auto &q : laser_cloud.points) stamps.push_back(q.intensity);
+                    ScanInfo scan_info(N_SCANS, true);
+                    seg_b.segmentCloud(laser_cloud, laser_cloud_segment, laser_cloud_outlier, scan_info);
+                    cloudFeature cfb;
+                    fe_b.extractCloud(laser_cloud_segment, scan_info, cfb);
+                    cfb.insert(std::pair<std::string, PointICloud>("laser_cloud_outlier", laser_cloud_outlier));
+                    flatten(cfb, seq[i]);
+                    seq_labels[i] = fe_b.cloudLabel();
+                }
+            }
+            write_file(d + "out_timestamps.f32", stamps);
+            // the reference's loop: members without a context, all LiDARs at once
+            ImageSegmenter img_segment_;
+            img_segment_.setParameter(N_SCANS, 1800, 30, 5, 3);
+            FeatureExtract f_extract_;
+            std::vector<cloudFeature *> feature_frame_ptr(NUM_OF_LASER);
+            std::vector<int> thread_of(NUM_OF_LASER, -1);
+            for (int round = 0; round < 3; ++round) {           // three frames: the per-thread contexts are created once and reused
+#pragma omp parallel for num_threads(NUM_OF_LASER)
+                for (size_t i = 0; i < v_laser_cloud_in.size(); i++) {
+                    PointICloud laser_cloud;
+                    f_extract_.calTimestamp(v_laser_cloud_in[i], laser_cloud);
+                    PointICloud laser_cloud_segment, laser_cloud_outlier;
+                    ScanInfo scan_info(N_SCANS, true);
+                    img_segment_.segmentCloud(laser_cloud, laser_cloud_segment, laser_cloud_outlier, scan_info);
+                    feature_frame_ptr[i] = new cloudFeature;
+                    f_extract_.extractCloud(laser_cloud_segment, scan_info, *feature_frame_ptr[i]);
+                    feature_frame_ptr[i]->insert(std::pair<std::string, PointICloud>("laser_cloud_outlier", laser_cloud_outlier));
+                    par_labels[i] = f_extract_.cloudLabel();
+                    thread_of[i] = omp_get_thread_num();
+                }
+                for (int i = 0; i < NUM_OF_LASER; ++i) { flatten(*feature_frame_ptr[i], par[i]); delete feature_frame_ptr[i]; }
+            }
+            std::vector<int> verdict;
+            int distinct_threads = 0;
+            { std::vector<int> seen(64, 0); for (int t : thread_of) if (t >= 0 && t < 64 && !seen[t]) { seen[t] = 1; ++distinct_threads; } }
+            for (int i = 0; i < NUM_OF_LASER; ++i) {
+                verdict.push_back(par[i] == seq[i] ? 1 : 0);
+                verdict.push_back(par_labels[i] == seq_labels[i] ? 1 : 0);
+                verdict.push_back(int(seq_labels[i].size()));
+            }
+            verdict.push_back(distinct_threads);
+            write_file(d + "out_reentrant.i32", verdict);
+            std::printf("re-entrant front end: %d LiDARs on %d threads, one FeatureExtract + one ImageSegmenter: clouds equal %d %d %d %d, labels equal %d %d %d %d\n", NUM_OF_LASER,
+                        distinct_threads, verdict[0], verdict[3], verdict[6], verdict[9], verdict[1], verdict[4], verdict[7], verdict[10]);
         }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;

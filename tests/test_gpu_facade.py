@@ -54,6 +54,40 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     counts = np.fromfile(os.path.join(d, "out_counts.i32"), np.int32).reshape(-1, 3)
     for c, o in zip(counts, s2m["outer"]):
         assert tuple(c) == (o["n_surf_sel"], o["n_corner_sel"], o["lm_iterations"])
+    # ---- round 4: the reference's own front-end loop (estimator.cpp:249-263) -- ONE FeatureExtract and ONE ImageSegmenter without a context of their own,
+    #      4 OpenMP threads on 4 different scans, three frames -- gives every LiDAR exactly what the same calls give one after the other
+    rv = np.fromfile(os.path.join(d, "out_reentrant.i32"), np.int32)
+    assert len(rv) == 13 and rv[12] == 4, rv                 # four LiDARs were really served by four threads
+    for i in range(4):
+        assert rv[3 * i] == 1 and rv[3 * i + 1] == 1 and rv[3 * i + 2] > 10000, (i, rv)
+    # FeatureExtract::calTimestamp (feature_extract.cpp:73-113) of LiDAR 0 against a plain restatement of its unwrapping
+    st = np.fromfile(os.path.join(d, "out_timestamps.f32"), np.float32)
+    assert len(st) == len(raw)
+    f32 = np.float32
+    ori_all = (-np.arctan2(raw[:, 1], raw[:, 0])).astype(np.float32)
+    start, end = ori_all[0], f32(ori_all[-1] + f32(2 * np.pi))
+    if end - start > f32(3 * np.pi):
+        end = f32(end - f32(2 * np.pi))
+    elif end - start < f32(np.pi):
+        end = f32(end + f32(2 * np.pi))
+    exp = np.empty(len(raw), np.float32)
+    half = False
+    for i, o in enumerate(ori_all):
+        if not half:
+            if o < start - f32(np.pi / 2):
+                o = f32(o + f32(2 * np.pi))
+            elif o > start + f32(np.pi * 3 / 2):
+                o = f32(o - f32(2 * np.pi))
+            if o - start > f32(np.pi):
+                half = True
+        else:
+            o = f32(o + f32(2 * np.pi))
+            if o < end - f32(np.pi * 3 / 2):
+                o = f32(o + f32(2 * np.pi))
+            elif o > end + f32(np.pi / 2):
+                o = f32(o - f32(2 * np.pi))
+        exp[i] = f32(f32(o - start) / f32(end - start)) * f32(0.1)
+    np.testing.assert_allclose(st, exp, rtol=0, atol=2e-6)      # libm atan2f vs numpy's: last-ulp differences of the angle only
     # ---- round 2: ActiveFeatureSelection::evalFullHessian -> logDet -> gf_ratio policy through the facade
     afs = np.fromfile(os.path.join(d, "out_afs.f64"), np.float64)
     cov6 = np.array([0.01, 0, 0, 0.02, 0, 0.03], np.float32)
