@@ -268,6 +268,11 @@ def main():
                     help="pipelined submission, but the next frame's maps are staged on the solver's own stream (queued behind the solve) instead of on a second stream")
     ap.add_argument("--synchronous", action="store_true",
                     help="read every frame's pose before the next frame's map staging is enqueued (rounds 1-2's loop) instead of one frame late")
+    ap.add_argument("--restage-every", type=int, default=0,
+                    help="every K-th frame is saved as a KEYFRAME: the local map of the frame after it contains that frame's own cloud at its solved pose "
+                         "(lidar_mapper_keyframe.cpp:641-688, 254-354), so its staging cannot be overlapped with the solve -- the pose is collected first, the maps are staged "
+                         "on an idle stream, the solve starts from a host-side pose. 0: never (every frame reuses the previous frame's local map, as the reference does "
+                         "between keyframes: cpp:257-261). The default line reports the cadences 1 / 2 / 5 / 10 beside `value` (`keyframe_cadence`)")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="milliseconds of an unrelated torch matmul before the warm-up steps (clock ramp of a GPU that idled through the host-side setup); 0: none")
     ap.add_argument("--profile-events", type=int, default=1,
@@ -489,9 +494,20 @@ def main():
     pipelined = (world == 1) and not args.synchronous
     in_flight = [False]
 
+    frame_no = [0]
+    cadence = [args.restage_every]
+
     def step():
         if not pipelined:
             return step_sync()
+        frame_no[0] += 1
+        if cadence[0] > 0 and in_flight[0] and frame_no[0] % cadence[0] == 0:
+            # the previous frame was saved as a keyframe: this frame's local map needs that frame's pose. Collect it, stage on the idle stream, start from a host pose
+            pose_prev = drain()
+            stage_maps()
+            ctx.gn_solve_begin(p0, GN_ITERS, opts)
+            in_flight[0] = True
+            return pose_prev
         stage_maps()
         if in_flight[0]:
             # frame k submitted behind frame k - 1, which is still running: its start pose is the reference's chain -- transformUpdate with frame k - 1's result,
@@ -540,6 +556,8 @@ def main():
             torch.cuda.synchronize()
         spin_ms = 1e3 * (time.perf_counter() - t_sp)
         del a_
+    knn_forms = {}
+
     def timed_region(step_fn, drain_fn, steps, warmup):
         """the contract's loop: W untimed steps, then exactly K timed ones between barrier + synchronize on both sides; max over the ranks"""
         sync_all()
@@ -547,11 +565,12 @@ def main():
         for _ in range(warmup):
             step_fn()
         drain_fn()
-        # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one launch in 4 * GN_ITERS + 1 (so the
-        # bracket rotates through the five iterations: ~50 samples over the default 200 steps), because an event pair costs ~6 us of queue time of
-        # its own -- bracketing all five launches of a step would slow the measured step by ~17 %, one per step (round 2) by ~3 %
-        ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
-        ctx.profile_sample(4 * GN_ITERS + 1)
+        # the dominant kernel is bracketed with HIP events on the context's stream INSIDE the timed region: one launch in 2 * GN_ITERS + 1 of each of its two
+        # forms (iteration 0's launch: the search alone; iterations 1..4: the search behind the prologue that completes the previous iteration) -- the bracket
+        # rotates through the iterations, ~70 + ~18 samples over the default 200 steps. An event pair costs ~6 us of queue time of its own: bracketing all five
+        # launches of a step would slow the measured step by ~17 %, this costs ~2 %
+        ctx.profile_enable(((1 << mla.K_KNN) | (1 << mla.K_KNN_PRE)) if args.profile_events else 0)
+        ctx.profile_sample(2 * GN_ITERS + 1)
         ctx.profile_reset()
         sync_all()
         t_start = time.perf_counter()
@@ -562,6 +581,11 @@ def main():
         sync_all()
         elapsed_ = time.perf_counter() - t_start
         knn_ms_, knn_n_ = ctx.profile_get(mla.K_KNN)
+        pre_ms_, pre_n_ = ctx.profile_get(mla.K_KNN_PRE)
+        knn_forms.clear()
+        knn_forms.update(search_only=(knn_ms_, knn_n_), with_prologue=(pre_ms_, pre_n_))
+        if pre_n_ > 0:          # the form 4 of a step's 5 launches take is the dominant kernel
+            knn_ms_, knn_n_ = pre_ms_, pre_n_
         ctx.profile_enable(0)
         ctx.profile_sample(1)
         if world > 1:
@@ -571,6 +595,7 @@ def main():
         return elapsed_, pose_, knn_ms_, knn_n_
 
     elapsed, pose, knn_ms, knn_n = timed_region(step, drain, args.steps, args.warmup)
+    knn_forms_main = dict(knn_forms)
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_valid_step / (elapsed / args.steps)
     queries_per_s = m_total * GN_ITERS / (elapsed / args.steps)
@@ -586,7 +611,7 @@ def main():
     drain()
     sync_all()
     ms_per_step_all_events = 1e3 * (time.perf_counter() - t1) / n_prof
-    prof = {k: ctx.profile_get(k) for k in range(7)}
+    prof = {k: ctx.profile_get(k) for k in range(8)}
     ctx.profile_enable(0)
     # the same frames submitted synchronously (pose read before the next frame's staging is enqueued): what rounds 1 and 2 reported
     sync_all()
@@ -595,6 +620,19 @@ def main():
         step_sync()
     sync_all()
     ms_per_step_sync = 1e3 * (time.perf_counter() - t1s) / n_prof
+
+    # the same timed loop at the reference's keyframe cadences (a frame is saved as a keyframe after DISTANCE_KEYFRAMES = 1 m or ORIENTATION_KEYFRAMES = 1 deg of motion,
+    # config_realvehicle_hercules.yaml:142-143: every frame for a vehicle at >= 10 m/s and 10 Hz, every ~10th at walking pace): the frame after a keyframe cannot have
+    # its maps staged beside the previous solve
+    keyframe_cadence = None
+    if pipelined and args.restage_every == 0:
+        keyframe_cadence = {}
+        for kc in (1, 2, 5, 10):
+            cadence[0], frame_no[0] = kc, 0
+            el_k, _, _, _ = timed_region(step, drain, max(args.steps // 2, 10), min(args.warmup, 5))
+            keyframe_cadence[f"every_{kc}"] = round(1e3 * el_k / max(args.steps // 2, 10), 4)
+        cadence[0] = 0
+        keyframe_cadence["never (= ms_per_step)"] = round(ms_per_step, 4)
 
     # --- N > 1: what every rank measured, the exchange by itself, and (--comm both) the same loop over the other communicator
     per_rank = exchange_us = other_comm = None
@@ -645,6 +683,40 @@ def main():
             s2m_pose, _ = ctx.scan2map(p0, opts, want_stats=False)
         sync_all()
         s2m_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
+        # the same call with the frame's maps STAGED (mlh_map_set_pair from the device-resident clouds, as the GN step does) instead of re-indexed in place, and then
+        # submitted / collected separately with the next frame's maps staged beside the solve and its start pose chained on the device (mlh_scan2map_begin_chained):
+        # the per-frame call of the reference under the GN loop's submission mode
+        for _ in range(3):
+            ctx.map_set_pair(d_surf_map, d_corner_map)
+            ctx.scan2map(p0, opts, want_stats=False)
+        sync_all()
+        t2 = time.perf_counter()
+        for _ in range(n_s2m):
+            ctx.map_set_pair(d_surf_map, d_corner_map)
+            s2m_pose_staged, _ = ctx.scan2map(p0, opts, want_stats=False)
+        sync_all()
+        s2m_staged_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
+        s2m_status = []
+
+        def s2m_pipe(n_frames):
+            ctx.map_set_pair(d_surf_map, d_corner_map)
+            ctx.scan2map_begin(p0, opts)
+            out_ = None
+            for _ in range(n_frames - 1):
+                ctx.map_set_pair_overlapped(d_surf_map, d_corner_map)
+                ctx.scan2map_begin_chained(s2m_pose_staged, p0, opts)       # synthetic odometry: the previous frame ended at its converged pose, this one starts at p0 again
+                out_, st_ = ctx.scan2map_end()
+                s2m_status.append(st_)
+            last_, st_ = ctx.scan2map_end()
+            s2m_status.append(st_)
+            return out_ if out_ is not None else last_, last_
+        s2m_pipe(4)
+        del s2m_status[:]
+        sync_all()
+        t2 = time.perf_counter()
+        s2m_pose_pipe, _ = s2m_pipe(n_s2m)
+        sync_all()
+        s2m_pipe_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
 
     # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
     #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)
@@ -668,7 +740,11 @@ def main():
         dur_s = 1e-3 * knn_ms / knn_n
         ach = bytes_per_launch / dur_s / 1e9
         _lanes = (ctx.map_info(mla.SURF)["knn_lanes"], ctx.map_info(mla.CORNER)["knn_lanes"])
-        roofline = dict(bound="hbm", kernel=f"knn_features_kernel (correspondence search, surf + corner queries of one GN iteration; lanes per query surf/corner = {_lanes[0]}/{_lanes[1]})",
+        _pre = knn_forms_main.get("with_prologue", (0, 0))[1] > 0
+        roofline = dict(bound="hbm", kernel=(f"knn_features_kernel<.., PRE, WARM> (iterations 1..{GN_ITERS - 1} of a solve, {GN_ITERS - 1} of its {GN_ITERS} correspondence launches: every workgroup first completes "
+                                             f"the previous iteration -- sums the fit tiles' records, 6x6 solve, Plus -- then the exact 5-NN search of surf + corner queries, bounded by the previous "
+                                             f"iteration's neighbours; lanes per query surf/corner = {_lanes[0]}/{_lanes[1]})" if _pre else
+                                             f"knn_features_kernel (correspondence search, surf + corner queries of one GN iteration; lanes per query surf/corner = {_lanes[0]}/{_lanes[1]})"),
                         achieved=round(ach, 2), peak=8000.0, unit="GB/s",
                         frac=round(ach / 8000.0, 5), traffic=None, avg_kernel_us=round(1e6 * dur_s, 3), launches=int(knn_n),
                         algorithmic_bytes_per_launch=int(bytes_per_launch), bytes_convention="SURVEY 8(d): 16 + 27*8 + 12*C-bar per query (all 27 cells)",
@@ -684,6 +760,14 @@ def main():
                              "bookkeeping removed the launch still takes 8.7 of 10.7 us, and a 2.5x cheaper sorted insertion (v_min_f64 / v_max_f64 on the keys) changed "
                              "nothing -- the duration is the dependent chain feature -> cell_start words -> candidate trips (median workgroup 3.3 us, slowest 7.0) -> "
                              "winner gather -> store. `frac` is reported against the HBM peak because that is the contract's roof; it is not the binding one")
+        so_ms, so_n = knn_forms_main.get("search_only", (0, 0))
+        if _pre and so_n > 0:
+            so_s = 1e-3 * so_ms / so_n
+            roofline["search_only_launch"] = dict(kernel="knn_features_kernel (iteration 0's launch: the search alone, no prologue, no bound from a previous iteration -- the kernel rounds 1-3 reported)",
+                                                  avg_kernel_us=round(1e6 * so_s, 3), launches=int(so_n), achieved=round(bytes_per_launch / so_s / 1e9, 2), frac=round(bytes_per_launch / so_s / 1e9 / 8000.0, 5),
+                                                  unavoidable_frac=round(bytes_ball / so_s / 1e9 / 8000.0, 5))
+            roofline["prologue_note"] = ("the dominant launch carries the previous iteration's finish (~3.5 us: one trip for the 88 records, the solve on one wavefront, a barrier), which round 3's fit "
+                                         "kernel paid as a ~7 us serial tail of its last workgroup; `achieved` divides the SEARCH's algorithmic bytes by the whole launch, prologue included")
         # what binds, as first-class fields: the fraction on the bytes an exact search cannot avoid, and the binding resource
         roofline["unavoidable_frac"] = round(bytes_ball / dur_s / 1e9 / 8000.0, 5)
         roofline["binding"] = "latency"          # dependent memory round trips per query (see `note`); not HBM bandwidth, not VALU issue
@@ -806,11 +890,15 @@ def main():
                                                                                       else "mlh_map_set_pair from device-resident clouds (staging + fit check + index build)")),
                                parallelism=("1 GPU" if world == 1 else (f"map sharded in {world} angular wedges (+1.1 m halo), ownership by position" if args.shard_mode == "map"
                                                                        else f"map replicated, features dealt round-robin over {world} ranks") + " + ONE RCCL all-reduce of 32 f64 per GN iteration"),
-                               hip_events_in_timed_region=(f"dominant kernel, 1 launch in {4 * GN_ITERS + 1}" if args.profile_events else "none")),
+                               hip_events_in_timed_region=(f"dominant kernel, 1 launch in {2 * GN_ITERS + 1} of each of its two forms" if args.profile_events else "none")),
                    queries_per_s=round(queries_per_s, 1), valid_correspondences_per_step=n_valid_step,
                    ms_per_gn_iter=round(ms_per_step / GN_ITERS, 4),
                    ms_per_step_all_kernels_bracketed=round(ms_per_step_all_events, 4),
                    ms_per_step_synchronous_submission=round(ms_per_step_sync, 4),
+                   ms_per_step_by_keyframe_cadence=keyframe_cadence,
+                   keyframe_cadence_note=("`value` / ms_per_step: no frame of the timed region is a keyframe, i.e. every frame reuses the previous frame's local map, which is what the reference does between "
+                                          "keyframes (lidar_mapper_keyframe.cpp:257-261) and what makes staging beside the solve legal. every_K: each K-th frame is saved as a keyframe, the "
+                                          "next frame's maps are staged only after its pose has been read (facade: PipelinedMapper; every_1 = a keyframe per frame = synchronous staging)"),
                    frame_submission=(("pipelined + overlapped staging: frame k+1's maps are staged and indexed on a second stream, into the other map set, while frame k's solve "
                                       "runs (mlh_map_set_pair_overlapped); frame k+1's solve is submitted behind it with its start pose chained on the device from frame k's result "
                                       "(mlh_gn_solve_begin_chained: transformUpdate + transformAssociateToMap); poses are collected one frame late (mlh_gn_solve_end)" if not args.no_overlap_staging else
@@ -818,6 +906,7 @@ def main():
                                      if pipelined else "synchronous: every pose is read before the next frame is staged"),
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),
+                                                         ("knn_features behind the previous iteration's finish (iterations >= 1)", mla.K_KNN_PRE),
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    multi_gpu=(None if world == 1 else dict(
@@ -854,7 +943,12 @@ def main():
                 out["config"]["workload"] = cfg4["workload"]
                 out["metric"] = "scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame, 4 pose blocks: pose + 3 extrinsic SE3)"
         if s2m_ms is not None:
-            out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), lm_iterations=[int(st["lm_iterations"]) for st in s2m_stats],
+            out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), ms_per_frame_synchronous_maps_staged=round(s2m_staged_ms, 4), ms_per_frame_pipelined=round(s2m_pipe_ms, 4),
+                                   pipelined_frames_inside_the_lookahead=int(sum(1 for x in s2m_status if x == 0)), pipelined_frames=len(s2m_status),
+                                   pipelined_pose_vs_synchronous=float(np.abs(np.asarray(s2m_pose_pipe) - np.asarray(s2m_pose_staged)).max()),
+                                   submission_note="ms_per_frame = mlh_map_rebuild + mlh_scan2map, host waits for every pose; ..._synchronous_maps_staged = mlh_map_set_pair + mlh_scan2map; "
+                                                   "..._pipelined = mlh_map_set_pair_overlapped + mlh_scan2map_begin_chained, pose collected one frame late (mlh_scan2map_end)",
+                                   lm_iterations=[int(st["lm_iterations"]) for st in s2m_stats],
                                    note="supplementary: mlh_map_rebuild + mlh_scan2map (2 outer iterations, Ceres-shaped LM, Huber 0.1), "
                                         "the call the reference makes once per frame (lidar_mapper_keyframe.cpp:423-639)")
 

@@ -70,7 +70,9 @@ enum {
     MLH_K_GRID_BUILD = 4,    /* local-map index build (all kernels of one build)                                               */
     MLH_K_EXTRACT = 5,       /* extractCloud (all kernels of one extraction)                                                   */
     MLH_K_ALLREDUCE = 6,     /* the RCCL all-reduce of the packed normal equations (N > 1)                                     */
-    MLH_K_COUNT = 7
+    MLH_K_KNN_PRE = 7,       /* the correspondence kernel of iterations >= 1 of a deferred-finish Gauss-Newton solve: the same search (bounded by the previous
+                                iteration's neighbours) behind the prologue that completes the previous iteration (sum of the tiles' records, 6x6 solve, Plus)          */
+    MLH_K_COUNT = 8
 };
 /* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);
@@ -467,6 +469,21 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
  * the selection loop. replaces lidar_mapper_keyframe.cpp:423-639. stats: max_outer records, or NULL (then evalDegenracy takes
  * the eigen-decomposition only when H - thre*I is not positive definite, i.e. when something IS degenerate). */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
+/* scan2MapOptimization submitted and collected separately (lidar_mapper_keyframe.cpp:423-639 as the mapper's per-frame call, :145-160 for the chained start pose):
+ * mlh_scan2map_begin enqueues the whole solve -- per outer iteration the match launch and `lm_lookahead` Levenberg-Marquardt launches (0: automatic -- the previous
+ * collected frame's longest LM loop + 2, 10 before any; at most max_lm_iterations), launches behind the LM loop's termination find `done` on the device and leave -- and returns; the caller stages the NEXT frame's maps
+ * (mlh_map_set_pair_overlapped) and submits the next frame (mlh_scan2map_begin_chained: start pose = transformUpdate + transformAssociateToMap on the pose the
+ * previous solve leaves on the device) before it collects this one's pose with mlh_scan2map_end. Up to two solves in flight, in submission order, shared with
+ * mlh_gn_solve_begin / _end (each collected by its own _end). One GPU or the mailbox communicator; gf_method MLH_GF_WO (a selection runs host loops between launches).
+ * status_out (nullable):
+ *   0  the LM loops terminated inside the look-ahead: pose_out is bit for bit what mlh_scan2map returns on the same inputs;
+ *   2  a loop needed more LM iterations than were enqueued; nothing had been restaged and no younger solve was chained behind, so the frame was solved again
+ *      synchronously from its start pose inside this call: pose_out is mlh_scan2map's;
+ *   1  the same, but the inputs of the frame are no longer staged (or a younger solve continues from this one's unfinished pose): pose_out is the frame's START
+ *      pose; the caller solves the frame with mlh_scan2map on its inputs and resubmits what was chained behind it. */
+int mlh_scan2map_begin(mlh_ctx *ctx, const double pose_in[7], const mlh_solver_opts *opts, int lm_lookahead);
+int mlh_scan2map_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], const mlh_solver_opts *opts, int lm_lookahead);
+int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out);
 
 /* ---------------------------------------------------------------- (f4) scan-to-scan odometry: LidarTracker::trackCloud
  * replaces lidar_tracker.cpp:23-129 and the functions it drives: matchCornerFromScan / matchSurfFromScan

@@ -23,8 +23,8 @@ ALL_KINDS = -1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
 GF_METHODS = {"wo_gf": 0, "rnd": 1, "fps": 2, "gd_fix": 3, "gd_float": 4}
-K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT, K_ALLREDUCE = range(7)
-K_ALL = 0x7F
+K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT, K_ALLREDUCE, K_KNN_PRE = range(8)
+K_ALL = 0xFF
 
 
 class MlhError(RuntimeError):
@@ -132,6 +132,9 @@ def load_library():
     lib.mlh_set_voxel_member_order.argtypes = [vp, ci]
     lib.mlh_set_extract_tie_order.argtypes = [vp, ci]
     lib.mlh_set_gn_schedule.argtypes = [vp, ci, ci]
+    lib.mlh_scan2map_begin.argtypes = [vp, vp, C.POINTER(SolverOpts), ci]
+    lib.mlh_scan2map_begin_chained.argtypes = [vp, vp, vp, C.POINTER(SolverOpts), ci]
+    lib.mlh_scan2map_end.argtypes = [vp, vp, vp]
     lib.mlh_std_sort_permutation.argtypes = [vp, vp, ci, ci, vp, ci]
     lib.mlh_pure_odom_begin.argtypes = [vp]
     lib.mlh_pure_odom_add_matches.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, ci, ci]
@@ -171,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
-    "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map",
+    "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map", "mlh_scan2map_begin", "mlh_scan2map_begin_chained", "mlh_scan2map_end",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
 ]
@@ -744,6 +747,24 @@ class Context:
         pose = np.zeros(7)
         self._ck(self.lib.mlh_gn_solve_end(self.h, _p(pose)))
         return pose
+
+    def scan2map_begin(self, pose, opts: SolverOpts | None = None, lm_lookahead=0):
+        """submit scan2MapOptimization for the staged frame and return (mlh_scan2map_begin); collect with scan2map_end"""
+        opts = opts or default_opts()
+        p = np.ascontiguousarray(pose, np.float64)
+        self._ck(self.lib.mlh_scan2map_begin(self.h, _p(p), C.byref(opts), int(lm_lookahead)))
+
+    def scan2map_begin_chained(self, wodom_prev, wodom_cur, opts: SolverOpts | None = None, lm_lookahead=0):
+        opts = opts or default_opts()
+        a, b = np.ascontiguousarray(wodom_prev, np.float64), np.ascontiguousarray(wodom_cur, np.float64)
+        self._ck(self.lib.mlh_scan2map_begin_chained(self.h, _p(a), _p(b), C.byref(opts), int(lm_lookahead)))
+
+    def scan2map_end(self):
+        """-> (pose, status): 0 = converged inside the look-ahead, 2 = re-solved synchronously inside the call, 1 = the caller must re-solve (pose = start pose)"""
+        p = np.zeros(7, np.float64)
+        st = C.c_int32(0)
+        self._ck(self.lib.mlh_scan2map_end(self.h, _p(p), C.byref(st)))
+        return p, int(st.value)
 
     def scan2map(self, pose, opts: SolverOpts | None = None, want_stats=True):
         opts = opts or default_opts()

@@ -152,7 +152,7 @@ __device__ inline void pose_ctor_qt(const q4 &q, const d3 &t, q4 &qo, d3 &to)
     qo = q4{q.x / n, q.y / n, q.z / n, q.w / n};
     to = t;
 }
-__global__ void chain_pose_kernel(SolverState *S, PoseArg wodom_prev, PoseArg wodom_cur)
+__global__ void chain_pose_kernel(SolverState *S, PoseArg wodom_prev, PoseArg wodom_cur, HostPublish *start_out)
 {
     if (threadIdx.x != 0) return;
     const q4 qc{S->x[3], S->x[4], S->x[5], S->x[6]};
@@ -174,6 +174,7 @@ __global__ void chain_pose_kernel(SolverState *S, PoseArg wodom_prev, PoseArg wo
     pose_ctor_qt(qmul(qw, q4{wodom_cur.p[3], wodom_cur.p[4], wodom_cur.p[5], wodom_cur.p[6]}), d3{r2.x + tw.x, r2.y + tw.y, r2.z + tw.z}, qn, tn);
     S->x[0] = tn.x; S->x[1] = tn.y; S->x[2] = tn.z; S->x[3] = qn.x; S->x[4] = qn.y; S->x[5] = qn.z; S->x[6] = qn.w;
     for (int i = 0; i < 7; ++i) S->cand[i] = S->x[i];
+    if (start_out) for (int i = 0; i < 7; ++i) start_out->xb[1][i] = S->x[i];      // the frame's start pose, for a host that may have to solve the frame again
 }
 
 __global__ void set_block_pose_kernel(SolverState *S, int b, PoseArg pose)
@@ -722,6 +723,7 @@ int mlh_transform_point_cloud(mlh_ctx *ctx, void *points, int stride_bytes, int 
 // host records are copied to the staging buffer first (both clouds back to back); device records are read in place
 static int map_set_impl(mlh_ctx *ctx, int n_maps, const int *kinds, const void *const *points, const int *n, int stride_bytes, float min_match_sq_dis, int mem)
 {
+    if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!(min_match_sq_dis > 0.f)) return fail(ctx, MLH_ERR_INVALID, "min_match_sq_dis must be positive");
     if (stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer (stride not a multiple of 4 >= 12)");
     for (int k = 0; k < n_maps; ++k) if (!points[k] || n[k] <= 0) return fail(ctx, MLH_ERR_INVALID, "bad point buffer (null or n <= 0)");
@@ -929,6 +931,7 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const unsigned char *__
 
 int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points, int stride_bytes, int n, int cov_offset_bytes, int mem)
 {
+    if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!ctx || kind < 0 || kind > 1 || block < 0 || block >= 8) return MLH_ERR_INVALID;
     if (!points || n <= 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer");
     if (cov_offset_bytes >= 0 && cov_offset_bytes + 24 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "cov_offset_bytes + 24 exceeds the record stride");
@@ -965,6 +968,7 @@ int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points
 int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_bytes, int n, int intensity_offset_bytes,
                      int cov_offset_bytes, int mem)
 {
+    if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!ctx || kind < 0 || kind > 1) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     FeatSet &f = ctx->feat[kind];
@@ -990,6 +994,7 @@ int mlh_features_set(mlh_ctx *ctx, int kind, const void *points, int stride_byte
 // (there: a ROS message through host memory). Ordered after everything `src` has enqueued (waited for here); the copies run on dst's stream.
 int mlh_features_copy(mlh_ctx *dst, mlh_ctx *src, int kind)
 {
+    if (dst) ++dst->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!dst || !src || dst == src || kind < 0 || kind > 1) return MLH_ERR_INVALID;
     if (dst->device != src->device) return fail(dst, MLH_ERR_UNSUPPORTED, "mlh_features_copy: both contexts must be on the same device");
     MLH_HIP(dst, hipSetDevice(dst->device));
@@ -1019,6 +1024,7 @@ int mlh_downsample_current_scan(mlh_ctx *ctx, int kind, const void *points, int 
                                 float leaf, const double *ext_poses, const double *ext_covs, int n_lidar, const double cov_measurement[9],
                                 int with_ua, double trace_threshold, float *features_out, int32_t *n_features)
 {
+    if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!ctx || kind < 0 || kind > 1 || !n_features) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     FeatSet &f = ctx->feat[kind];
@@ -1059,6 +1065,7 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
                                      int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold, int32_t *n_surf_features,
                                      int32_t *n_corner_features)
 {
+    if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!ctx || !n_surf_features || !n_corner_features) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     const bool fused_pair = mem == MLH_MEM_DEVICE && !ctx->fused_dirty && stride_bytes == 16 && intensity_offset_bytes == 12 && n_surf > 0 && n_corner > 0 &&
@@ -1307,10 +1314,11 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         std::memset(ctx->h_solve, 0, 2 * sizeof(HostPublish));
     }
     const unsigned long long seq = ctx->solve_seq + 1;
+    ctx->solve_slot[seq & 1].kind = 0;
     if (!pose_in) {                                // chained: the start pose is made on the device from the pose the previous solve left there
         PoseArg pa, pb;
         for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
-        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb);
+        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, static_cast<HostPublish *>(nullptr));
         MLH_HIP(ctx, hipGetLastError());
     }
     for (int it = 0; it < n_iters; ++it) {
@@ -1353,6 +1361,7 @@ int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7])
     if (!ctx || !pose_out) return MLH_ERR_INVALID;
     if (ctx->solve_seq == ctx->solve_collected) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_gn_solve_begin)");
     const unsigned long long seq = ctx->solve_collected + 1;        // the oldest one
+    if (ctx->solve_slot[seq & 1].kind != 0) return fail(ctx, MLH_ERR_STATE, "the oldest solve in flight was submitted with mlh_scan2map_begin: collect it with mlh_scan2map_end");
     HostPublish hp;
     int rc = wait_published(ctx, seq, hp, static_cast<HostPublish *>(ctx->h_solve) + (seq & 1));
     ctx->solve_collected = seq;
@@ -1436,7 +1445,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         if (fused) {
             MatchArgs a = args_from_opts(opts, 3, 0);
             a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
-            if (outer == 0) a.init_pose = pose_inout;
+            if (outer == 0) { a.init_pose = pose_inout; a.lm_expect_done = -1; }
             if ((rc = match_launch(ctx, a))) return rc;
         } else if (opts->gf_method == MLH_GF_WO) {
             if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
@@ -1489,7 +1498,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
                 if ((rc = wait_published(ctx, pend[0].seq, hp, pend[0].rec))) return rc;
                 last_hp = hp; have_hp = true;
                 pend[0] = pend[1]; --n_pend;
-                if (hp.done || n_pend == 0) break;
+                if ((hp.done & 1) || n_pend == 0) break;
             }
         } else {
             for (int it = 0, j_end = 0; it < opts->max_lm_iterations; it = j_end) {
@@ -1511,6 +1520,124 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
         return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
+}
+
+// ---- scan2MapOptimization, submitted and collected separately (the call the reference makes once per frame, pipelined like mlh_gn_solve_begin / _end).
+// The host does not read the Levenberg-Marquardt loop's verdict between launches: per outer iteration the match launch (LM begin in its finish) and `lm_lookahead`
+// LM launches are enqueued at once; launches behind the loop's termination find `done` on the device and leave (~3 us each). The last launch publishes pose and
+// verdict. A frame whose LM loop needs MORE than the look-ahead is detected on the device (the next outer iteration finds the loop unterminated: lm_overflow; or the
+// last loop is unterminated at the publication) -- its result is then not scan2MapOptimization's and is never returned as such: mlh_scan2map_end solves the frame
+// again synchronously when that is sound (nothing restaged since the submission, no younger solve chained behind it), and says so otherwise.
+static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, const mlh_solver_opts *opts, int lm_lookahead)
+{
+    if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_scan2map_begin under an RCCL communicator: the sharded LM iteration there is a host-driven sequence of launches and collectives (use the mailbox communicator)");
+    if (opts->gf_method != MLH_GF_WO) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_scan2map_begin with a good-feature selection: the selection loops run on the host between the launches (use mlh_scan2map)");
+    if (opts->max_outer <= 0) return fail(ctx, MLH_ERR_INVALID, "max_outer must be positive");
+    if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one first");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if (!ctx->h_solve) {
+        MLH_HIP(ctx, hipHostMalloc(&ctx->h_solve, 2 * sizeof(HostPublish), hipHostMallocDefault));
+        std::memset(ctx->h_solve, 0, 2 * sizeof(HostPublish));
+    }
+    const unsigned long long seq = ctx->solve_seq + 1;
+    HostPublish *rec = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
+    mlh_ctx::SolveSlot &slot = ctx->solve_slot[seq & 1];
+    slot.kind = 1; slot.chained = pose_in == nullptr; slot.opts = *opts; slot.epoch = ctx->stage_epoch;
+    if (pose_in) for (int i = 0; i < 7; ++i) slot.start[i] = pose_in[i];
+    if (!pose_in) {
+        PoseArg pa, pb;
+        for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
+        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, rec);
+        MLH_HIP(ctx, hipGetLastError());
+    }
+    // scan2MapOptimization runs only when the map has > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429): otherwise the start pose is the result
+    if (!(ctx->map[MLH_SURF].built && ctx->map[MLH_CORNER].built && ctx->map[MLH_SURF].n > 50 && ctx->map[MLH_CORNER].n > 10)) {
+        slot.kind = 2;
+        if (!pose_in) {          // chained: the start pose exists on the device only
+            hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), rec, seq);
+            MLH_HIP(ctx, hipGetLastError());
+        }
+        ctx->solve_seq = seq; ctx->solve_pending = true;
+        return MLH_OK;
+    }
+    if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
+    const int budget = std::max(1, std::min(lm_lookahead > 0 ? lm_lookahead : ctx->lm_lookahead_auto, opts->max_lm_iterations));
+    for (int outer = 0; outer < opts->max_outer; ++outer) {
+        MatchArgs a = args_from_opts(opts, 3, 0);
+        a.finish = 3; a.stat_slot = -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
+        a.lm_expect_done = outer == 0 ? -1 : 1;
+        if (outer == 0) a.init_pose = pose_in;
+        if ((rc = match_launch(ctx, a))) return rc;
+        for (int j = 0; j < budget; ++j) {
+            MatchArgs b = args_from_opts(opts, 3, 1);
+            b.finish = 4; b.lm_max_it = opts->max_lm_iterations;
+            if (outer == opts->max_outer - 1 && j == budget - 1) { b.publish = rec; b.publish_seq = seq; }
+            if ((rc = linearize_launch(ctx, b))) return rc;
+        }
+    }
+    ctx->solve_seq = seq;
+    ctx->solve_pending = true;
+    return MLH_OK;
+}
+
+int mlh_scan2map_begin(mlh_ctx *ctx, const double pose_in[7], const mlh_solver_opts *opts, int lm_lookahead)
+{
+    if (!ctx || !pose_in || !opts) return MLH_ERR_INVALID;
+    return scan2map_submit(ctx, pose_in, nullptr, nullptr, opts, lm_lookahead);
+}
+
+int mlh_scan2map_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], const mlh_solver_opts *opts, int lm_lookahead)
+{
+    if (!ctx || !wodom_prev || !wodom_cur || !opts) return MLH_ERR_INVALID;
+    if (ctx->solve_seq == 0) return fail(ctx, MLH_ERR_STATE, "mlh_scan2map_begin_chained continues from the pose a previous solve left on the device: submit the first frame with mlh_scan2map_begin");
+    return scan2map_submit(ctx, nullptr, wodom_prev, wodom_cur, opts, lm_lookahead);
+}
+
+int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
+{
+    if (!ctx || !pose_out) return MLH_ERR_INVALID;
+    if (status_out) *status_out = 0;
+    if (ctx->solve_seq == ctx->solve_collected) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_scan2map_begin)");
+    const unsigned long long seq = ctx->solve_collected + 1;        // the oldest one
+    mlh_ctx::SolveSlot slot = ctx->solve_slot[seq & 1];
+    if (slot.kind == 0) return fail(ctx, MLH_ERR_STATE, "the oldest solve in flight was submitted with mlh_gn_solve_begin: collect it with mlh_gn_solve_end");
+    HostPublish hp;
+    int rc = MLH_OK;
+    if (slot.kind == 2 && !slot.chained) {
+        for (int i = 0; i < 7; ++i) hp.x[i] = slot.start[i];
+        hp.done = 1;
+    } else {
+        rc = wait_published(ctx, seq, hp, static_cast<HostPublish *>(ctx->h_solve) + (seq & 1));
+    }
+    ctx->solve_collected = seq;
+    ctx->solve_pending = ctx->solve_seq != ctx->solve_collected;
+    if (rc) return rc;
+    if (!ctx->prof.pending.empty() && !ctx->solve_pending) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+    if (slot.kind == 1) {
+        // the next frame's automatic look-ahead: what this frame's longest LM loop used, plus two (consecutive mapper frames need about the same); a frame that
+        // overflowed doubles it
+        const int used = int(hp.xb[2][0]);
+        const bool ok = (hp.done & 1) && !(hp.done & 2);
+        ctx->lm_lookahead_auto = ok ? std::max(3, used + 2) : std::min(2 * std::max(ctx->lm_lookahead_auto, 4), slot.opts.max_lm_iterations);
+    }
+    if (slot.kind == 2 || ((hp.done & 1) && !(hp.done & 2))) {
+        for (int i = 0; i < 7; ++i) pose_out[i] = hp.x[i];
+        return MLH_OK;
+    }
+    // the look-ahead was too short for this frame
+    double start[7];
+    for (int i = 0; i < 7; ++i) start[i] = slot.chained ? hp.xb[1][i] : slot.start[i];
+    if (!ctx->solve_pending && ctx->stage_epoch == slot.epoch) {
+        // nothing younger is chained behind it and the frame's maps and features are still the staged ones: solve it as mlh_scan2map would have
+        for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
+        if (status_out) *status_out = 2;
+        return mlh_scan2map(ctx, pose_out, &slot.opts, nullptr);
+    }
+    for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
+    if (status_out) *status_out = 1;
+    return MLH_OK;
 }
 
 // ---------------------------------------------------------------- scan-to-scan odometry (LidarTracker)

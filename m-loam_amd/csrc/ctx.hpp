@@ -52,11 +52,12 @@ struct SolverState {
     int num_successful;
     int num_invalid;
     int evaluations;
-    int pad;
+    int lm_overflow;         // split-submission scan2map: an outer iteration was begun while the previous one's LM loop had not terminated inside its look-ahead budget
     // Gauss-Newton with the finish deferred to the consumer (match.hip): iteration i's pose lives in xi[i & 1] -- written by ONE workgroup of iteration i's
     // correspondence launch while the others may still be reading xi[(i - 1) & 1]
     double xi[2][7];
-    double pad2[2];
+    double lm_used_max;      // split-submission scan2map: the largest LM iteration count of the solve's outer iterations so far (the host sizes the next frame's look-ahead by it)
+    double pad2[1];
 };
 
 // pinned host record the device writes the result pose(s) into; seq is stored last with system-scope release
@@ -266,6 +267,15 @@ struct mlh_ctx {
     unsigned pts_turn = 0;
     void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
     unsigned long long solve_seq = 0, solve_collected = 0;   // submitted / collected solves (at most two apart)
+    struct SolveSlot {                 // what mlh_scan2map_end needs to know about the solve whose record is h_solve[seq & 1]
+        int kind = 0;                  // 0: Gauss-Newton (mlh_gn_solve_begin*), 1: scan2map (mlh_scan2map_begin*), 2: scan2map on maps too small to optimise against (the start pose comes back)
+        bool chained = false;
+        double start[7] = {0, 0, 0, 0, 0, 0, 1};
+        mlh_solver_opts opts;
+        unsigned long long epoch = 0;  // stage_epoch at submission
+    } solve_slot[2];
+    int lm_lookahead_auto = 10;           // mlh_scan2map_begin(lm_lookahead = 0): the previous frame's largest LM iteration count + 2 (10 until a frame has been collected)
+    unsigned long long stage_epoch = 0;   // bumped by every call that restages a map or a feature set: a re-solve of an in-flight frame is only sound on unchanged inputs
     bool solve_pending = false;
     bool map_read_unsynced = false;   // a launch that reads the current map set was enqueued and its call did not wait for it (mlh_pure_odom_add_matches)
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
@@ -464,6 +474,8 @@ struct MatchArgs {
     int finish = 0;      // 1: the fit kernel's last workgroup completes the GN iteration (reduce + solve + Plus); 2: local reduce only;
                          // 3 / 4: it runs the Levenberg-Marquardt begin (match_launch) / step (linearize_launch)
     int lm_max_it = 30, lm_min_blocks = 0;
+    int lm_expect_done = 0;   // finish == 3 (LM begin): -1 = first outer iteration of a solve (clears SolverState::lm_overflow); 1 = a later outer iteration submitted without the
+                              // host having seen the previous LM loop's verdict: if that loop has not terminated, lm_overflow is raised (the launches go on; the host discards)
     int stat_slot = -1;
     int n_blocks = 1;    // pose blocks
     int k_neigh[8] = {5, 5, 5, 5, 5, 5, 5, 5};

@@ -210,6 +210,7 @@ struct KParams {
     int finish;              // 0: none, 1: GN (reduce + solve + Plus), 2: reduce into SolverState::ne only (multi-GPU),
                              // 3: Levenberg-Marquardt begin (fit kernel), 4: Levenberg-Marquardt step (linearize kernel)
     int lm_max_it, lm_min_blocks;
+    int lm_expect_done;      // MatchArgs::lm_expect_done
     unsigned *ticket;
     IterStatDev *stat;       // n_blocks consecutive records, or null
     // sharded over several ranks with the mailbox communicator: the finishing workgroup exchanges each block's summed record with the peers (one hop, inside
@@ -538,13 +539,22 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
                 done = 1;
                 if (threadIdx.x == 0) P.state->done = 1;
             }
-            else if (P.finish == 3) lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
+            else if (P.finish == 3) {
+                // split submission: this outer iteration was enqueued without anybody having seen the previous LM loop end. If it has not, the frame's result is
+                // not the reference's (<= max_num_iterations per outer iteration): flagged, published with the pose, and the host re-solves or reports
+                if (threadIdx.x == 0 && P.lm_expect_done) {
+                    P.state->lm_overflow = (P.lm_expect_done > 0 && (P.state->lm_overflow || !P.state->done)) ? 1 : 0;
+                    P.state->lm_used_max = P.lm_expect_done > 0 ? fmax(P.state->lm_used_max, double(P.state->iteration)) : 0.0;      // the loop that just ended
+                }
+                lm_begin_body_wave(f_ne, f_cnt2, f_scratch, P.state, P.thre_b[0], P.lm_max_it, P.stat, P.lm_min_blocks, xo, done);
+            }
             else lm_step_body_wave(f_ne, P.state, P.lm_max_it, xo, done);
             if (threadIdx.x == 0) {
                 *P.ticket = 0u;
                 if (P.publish) {     // last launch of a chunk of LM steps: the pose and the `done` flag go to the host from here
                     for (int i = 0; i < 7; ++i) P.publish->x[i] = xo[i];
-                    P.publish->done = done;
+                    P.publish->done = done | (P.state->lm_overflow ? 2 : 0);
+                    P.publish->xb[2][0] = fmax(P.state->lm_used_max, double(P.state->iteration));
                     __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
@@ -725,7 +735,8 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
         if (threadIdx.x < 32) P.partials[size_t(gtile) * NE_STRIDE + threadIdx.x] = 0.0;
         if (LM && P.publish && gtile == 0 && threadIdx.x == 0) {      // ... but the host may be waiting for this launch's publication
             for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
-            P.publish->done = P.state->done;
+            P.publish->done = P.state->done | (P.state->lm_overflow ? 2 : 0);
+            P.publish->xb[2][0] = fmax(P.state->lm_used_max, double(P.state->iteration));
             __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
@@ -887,7 +898,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.own_mod = ctx->own_mod; P.own_rem = ctx->own_rem;
     for (int i = 0; i < 4; ++i) { P.lo[i] = ctx->lo_plane[i]; P.hi[i] = ctx->hi_plane[i]; }
     P.finish = a.finish;
-    P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
+    P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks; P.lm_expect_done = a.lm_expect_done;
     // the mailbox communicator rides in the finishing workgroup of a Gauss-Newton launch (finish == 1) and of an LM begin / step launch (3 / 4); other launches
     // exchange nothing
     if ((a.finish == 1 || a.finish == 3 || a.finish == 4) && ctx->p2p.active) p2p_fill(ctx, P.p2p);
@@ -942,8 +953,8 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             else { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false>, grid_a, P); } \
         } while (0)
 #define MLH_KNN_LAUNCH_GN(G_) do { \
-            if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, true, true>, grid_a, P); \
-            else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, true, false>, grid_a, P); \
+            if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, true, true>, grid_a, P); \
+            else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, true, false>, grid_a, P); \
             else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, false, true>, grid_a, P); \
         } while (0)
         if (P.pre_finish || P.warm) {

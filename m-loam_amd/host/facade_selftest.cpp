@@ -419,6 +419,76 @@ int main(int argc, char **argv)
             std::printf("re-entrant front end: %d LiDARs on %d threads, one FeatureExtract + one ImageSegmenter: clouds equal %d %d %d %d, labels equal %d %d %d %d\n", NUM_OF_LASER,
                         distinct_threads, verdict[0], verdict[3], verdict[6], verdict[9], verdict[1], verdict[4], verdict[7], verdict[10]);
         }
+        // --- round 4: PipelinedMapper -- the overlap's precondition as code. Eight frames of a sensor moving 0.34 m per frame along x (the features of frame k are
+        //     the harness's features moved by the inverse motion), odometry that drifts 0.03 m per frame, keyframes every metre: the pipelined loop stages frame k's
+        //     maps beside frame k - 1's solve when k - 1 is predicted not to become a keyframe, waits when it is, and once predicts wrongly (frame 3: prior 0.99 m,
+        //     result 1.02 m from the last keyframe) -- that frame is solved again on the rebuilt map. Every pose must equal the plain synchronous loop's.
+        {
+            const int n_frames = 8;
+            const Pose T0 = pose;                                          // the converged pose of the scan2map leg above: where the harness's features were taken
+            auto motion = [](double dx) { Pose m; m.t_(0) = dx; return m; };
+            auto moved = [](const PointICovCloud &c, double dx) { PointICovCloud o = c; for (auto &q : o.points) q.x = float(double(q.x) - dx); return o; };   // M^-1 p, M = translation
+            std::vector<PointICovCloud> fs, fc;
+            std::vector<Pose> wodom;
+            for (int k = 0; k < n_frames; ++k) { fs.push_back(moved(surf, 0.34 * k)); fc.push_back(moved(corner, 0.34 * k)); wodom.push_back(motion(0.31 * k)); }
+            // local-map assembly for a keyframe selection: the base maps thinned by a rule that depends on the selection, so that a stale map shows in the pose
+            auto assemble = [&](const std::vector<int> &ids, const Pose &, PointICovCloud &s_out, PointICovCloud &c_out) {
+                int key = 0;
+                for (int id : ids) key += id + 1;
+                s_out.clear(); c_out.clear();
+                for (size_t i = 0; i < surf_map.size(); ++i) if (int(i % 13) != key % 13) s_out.push_back(surf_map.points[i]);
+                for (size_t i = 0; i < corner_map.size(); ++i) if (int(i % 13) != key % 13) c_out.push_back(corner_map.points[i]);
+            };
+            // (a) the reference's order, one frame at a time (cpp:1065-1101): prior, rebuild after a keyframe, index, solve, transformUpdate, saveKeyframe
+            std::vector<Pose> ref_pose;
+            std::vector<int> ref_kf;
+            {
+                KeyframePolicy kf(1.0f, 10.0f, 50.0f);
+                FramePipeline one(dev, 3);
+                PointICovCloud ms = surf_map, mc = corner_map;
+                Pose wmap_wodom = poseMul(T0, poseInverse(wodom[0]));
+                bool rebuild = false;
+                for (int k = 0; k < n_frames; ++k) {
+                    const Pose prior = poseMul(wmap_wodom, wodom[k]);
+                    if (rebuild) { PointICovCloud a, b; assemble(kf.surrounding(prior), prior, a, b); ms = a; mc = b; }
+                    one.setInputClouds(ms, mc);
+                    one.setFeatures(fs[k], fc[k]);
+                    one.submit(prior);
+                    const Pose r = one.collect();
+                    ref_pose.push_back(r);
+                    wmap_wodom = poseMul(r, poseInverse(wodom[k]));
+                    rebuild = kf.save(r) >= 0;
+                    if (rebuild) ref_kf.push_back(k);
+                }
+            }
+            // (b) pipelined
+            std::vector<Pose> got_pose;
+            std::vector<int> got_kf_index;
+            KeyframePolicy kf(1.0f, 10.0f, 50.0f);
+            PipelinedMapper mapper(dev, kf, assemble, [&](int idx, const Pose &) { got_kf_index.push_back(idx); }, 3);
+            mapper.setInitialMap(surf_map, corner_map);
+            mapper.setInitialPose(T0, wodom[0]);
+            for (int k = 0; k < n_frames; ++k) {
+                Pose prev;
+                if (mapper.process(fs[k], fc[k], wodom[k], prev)) got_pose.push_back(prev);
+            }
+            got_pose.push_back(mapper.finish());
+            double worst = 0.0;
+            std::vector<double> pm;
+            for (int k = 0; k < n_frames; ++k) {
+                double a[7], b[7];
+                ref_pose[k].toParam(a); got_pose[k].toParam(b);
+                for (int i = 0; i < 7; ++i) { worst = std::max(worst, std::fabs(a[i] - b[i])); pm.push_back(b[i]); }
+            }
+            pm.push_back(worst);
+            pm.push_back(double(mapper.counters.overlapped)); pm.push_back(double(mapper.counters.waited)); pm.push_back(double(mapper.counters.redone));
+            pm.push_back(double(mapper.counters.keyframes)); pm.push_back(double(ref_kf.size()));
+            pm.push_back(double(got_pose[3].t_(0) - got_pose[0].t_(0)));
+            write_file(d + "out_pipelined_mapper.f64", pm);
+            std::printf("pipelined mapper: %d frames, staged beside the solve %d, waited for the pose %d, solved again after a wrong prediction %d; keyframes %d (plain loop %zu); "
+                        "max |pose - plain loop| %.2e\n", n_frames, mapper.counters.overlapped, mapper.counters.waited, mapper.counters.redone, mapper.counters.keyframes,
+                        ref_kf.size(), worst);
+        }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;
         lp.setParameter();

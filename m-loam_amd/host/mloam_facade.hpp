@@ -22,6 +22,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <cmath>
@@ -110,6 +111,8 @@ struct Params {
     // the odometry window (parameters.h:58-111)
     int OPT_WINDOW_SIZE = 4, NUM_OF_LASER = 2, ESTIMATE_EXTRINSIC = 1, N_CUMU_FEATURE = 10;
     double LAMBDA_THRE_CALIB = 70.0;
+    // keyframes of the mapper (parameters.cpp:98-100, 268-270; values of config_realvehicle_hercules.yaml:142-144)
+    float DISTANCE_KEYFRAMES = 1.0f, ORIENTATION_KEYFRAMES = 1.0f, SURROUNDING_KF_RADIUS = 50.0f;
 };
 inline Params &params() { static Params p; return p; }
 
@@ -1169,6 +1172,203 @@ private:
     Device &dev_;
     mlh_solver_opts o_;
     int iters_, in_flight_ = 0;
+};
+
+// ------------------------------------------------------------------ what makes staging beside the solve legal, as code
+// Pose::operator* / Pose::inverse (pose.cpp:99-113: both go through Pose(q, t), which normalises the quaternion)
+inline Pose poseMul(const Pose &a, const Pose &b)
+{
+    auto rot = [](const Quat &q, const double v[3], double o[3]) {
+        const double ux = q.x, uy = q.y, uz = q.z, w = q.w;
+        const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+        const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
+        o[0] = v[0] + 2.0 * (w * cx + dx); o[1] = v[1] + 2.0 * (w * cy + dy); o[2] = v[2] + 2.0 * (w * cz + dz);
+    };
+    Pose r;
+    double rt[3];
+    rot(a.q_, b.t_.v, rt);
+    for (int i = 0; i < 3; ++i) r.t_(i) = rt[i] + a.t_(i);
+    Quat q;
+    q.w = a.q_.w * b.q_.w - a.q_.x * b.q_.x - a.q_.y * b.q_.y - a.q_.z * b.q_.z;
+    q.x = a.q_.w * b.q_.x + a.q_.x * b.q_.w + a.q_.y * b.q_.z - a.q_.z * b.q_.y;
+    q.y = a.q_.w * b.q_.y - a.q_.x * b.q_.z + a.q_.y * b.q_.w + a.q_.z * b.q_.x;
+    q.z = a.q_.w * b.q_.z + a.q_.x * b.q_.y - a.q_.y * b.q_.x + a.q_.z * b.q_.w;
+    const double n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    r.q_.w = q.w / n; r.q_.x = q.x / n; r.q_.y = q.y / n; r.q_.z = q.z / n;
+    return r;
+}
+inline Pose poseInverse(const Pose &a)
+{
+    Pose inv;
+    const double n2 = a.q_.w * a.q_.w + a.q_.x * a.q_.x + a.q_.y * a.q_.y + a.q_.z * a.q_.z;
+    inv.q_.w = a.q_.w / n2; inv.q_.x = -a.q_.x / n2; inv.q_.y = -a.q_.y / n2; inv.q_.z = -a.q_.z / n2;
+    Pose id;                         // -(q^-1 t): rotate through poseMul's helper by composing with a pure translation
+    Pose tr;
+    tr.t_ = a.t_;
+    Pose qonly = inv;
+    const Pose rt = poseMul(qonly, tr);
+    for (int i = 0; i < 3; ++i) inv.t_(i) = -rt.t_(i);
+    const double n = std::sqrt(inv.q_.w * inv.q_.w + inv.q_.x * inv.q_.x + inv.q_.y * inv.q_.y + inv.q_.z * inv.q_.z);
+    inv.q_.w /= n; inv.q_.x /= n; inv.q_.y /= n; inv.q_.z /= n;
+    (void)id;
+    return inv;
+}
+
+// The mapper's keyframe bookkeeping: saveKeyframe's test (lidar_mapper_keyframe.cpp:641-657) and extractSurroundingKeyFrames' selection (cpp:263-272). The
+// reference rebuilds the local map ONLY in the frame after a keyframe was saved (cpp:257-261 return early while the map clouds are non-empty; :1101 clears them
+// when save_new_keyframe) -- that is what decides whether a frame's maps may be staged while the previous frame is still being solved.
+class KeyframePolicy {
+public:
+    KeyframePolicy() : dist_(params().DISTANCE_KEYFRAMES), ori_deg_(params().ORIENTATION_KEYFRAMES), radius_(params().SURROUNDING_KF_RADIUS) {}
+    KeyframePolicy(float distance_keyframes, float orientation_keyframes_deg, float surrounding_kf_radius)
+        : dist_(distance_keyframes), ori_deg_(orientation_keyframes_deg), radius_(surrounding_kf_radius) {}
+    // would saveKeyframe() save a frame that ends at this pose? (no state change)
+    bool wouldSave(const Pose &pose_wmap_curr) const
+    {
+        if (pose_keyframes_3d.size() == 0) return true;
+        const float cx = float(pose_wmap_curr.t_(0)), cy = float(pose_wmap_curr.t_(1)), cz = float(pose_wmap_curr.t_(2));      // PointI fields: f32, as pose_point_cur
+        const double d = std::sqrt(double((cx - prev_[0]) * (cx - prev_[0]) + (cy - prev_[1]) * (cy - prev_[1]) + (cz - prev_[2]) * (cz - prev_[2])));
+        const Quat &a = pose_wmap_curr.q_, &b = q_prev_;
+        const double dot = std::fabs(a.w * b.w + a.x * b.x + a.y * b.y + a.z * b.z);
+        const double ang = 2.0 * std::acos(std::min(1.0, dot));              // Eigen's angularDistance
+        return d > dist_ || ang / M_PI * 180 > ori_deg_;
+    }
+    // saveKeyframe(): the test, and on success the bookkeeping (the caller stores the frame's clouds under the returned index); -1 when not saved
+    int save(const Pose &pose_wmap_curr)
+    {
+        if (!wouldSave(pose_wmap_curr)) return -1;
+        PointI p;
+        p.x = float(pose_wmap_curr.t_(0)); p.y = float(pose_wmap_curr.t_(1)); p.z = float(pose_wmap_curr.t_(2));
+        p.intensity = float(pose_keyframes_3d.size());
+        prev_[0] = p.x; prev_[1] = p.y; prev_[2] = p.z;
+        q_prev_ = pose_wmap_curr.q_;
+        pose_keyframes_3d.push_back(p);
+        pose_keyframes_6d.push_back(pose_wmap_curr);
+        return int(pose_keyframes_3d.size()) - 1;
+    }
+    // kdtree_surrounding_keyframes->radiusSearch(pose_point_cur, SURROUNDING_KF_RADIUS, ...) (cpp:266-272): keyframe indices within the radius, nearest first
+    // (PCL returns a radius search sorted by distance; equal distances by index here)
+    std::vector<int> surrounding(const Pose &pose_wmap_curr) const
+    {
+        const float cx = float(pose_wmap_curr.t_(0)), cy = float(pose_wmap_curr.t_(1)), cz = float(pose_wmap_curr.t_(2));
+        std::vector<std::pair<float, int>> hit;
+        for (size_t i = 0; i < pose_keyframes_3d.size(); ++i) {
+            const PointI &k = pose_keyframes_3d.points[i];
+            const float dx = k.x - cx, dy = k.y - cy, dz = k.z - cz, d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 <= radius_ * radius_) hit.emplace_back(d2, int(i));
+        }
+        std::sort(hit.begin(), hit.end());
+        std::vector<int> ids;
+        for (const auto &h : hit) ids.push_back(h.second);
+        return ids;
+    }
+    PointICloud pose_keyframes_3d;
+    std::vector<Pose> pose_keyframes_6d;
+private:
+    float dist_, ori_deg_, radius_, prev_[3] = {0, 0, 0};
+    Quat q_prev_;
+};
+
+// The mapper's frame loop, pipelined, with the precondition of the overlap checked per frame instead of assumed:
+//   frame k's local map is the previous frame's, unchanged, unless frame k - 1 was saved as a keyframe (then it is rebuilt around the prior of frame k from the
+//   keyframes' clouds -- frame k - 1's own cloud at its SOLVED pose among them). So while frame k - 1 is being solved, frame k's maps can be staged beside it
+//   exactly when frame k - 1 will not be a keyframe. That is predicted from frame k - 1's prior (the pose before scan-to-map's correction, centimetres from the
+//   result), verified on its result, and on a wrong prediction frame k is solved again on the rebuilt map, synchronously.
+// process() takes frame k's inputs and returns frame k - 1's pose (one frame late, as FramePipeline); finish() returns the last one.
+// assemble(ids, prior, surf_map, corner_map): the caller's local-map assembly for the keyframe indices `ids` (cloudUCTAssociateToMap + the two voxel filters,
+// cpp:296-344) -- called only when the reference would rebuild.
+class PipelinedMapper {
+public:
+    typedef std::function<void(const std::vector<int> &, const Pose &, PointICovCloud &, PointICovCloud &)> Assemble;
+    typedef std::function<void(int, const Pose &)> OnKeyframe;      // (keyframe index, its pose): store the frame's clouds (saveKeyframe, cpp:673-683)
+    PipelinedMapper(Device &dev, KeyframePolicy &kf, Assemble assemble, OnKeyframe on_keyframe, int gn_iters = 5, bool with_ua_flag = false)
+        : pipe_(dev, gn_iters, with_ua_flag), kf_(kf), assemble_(std::move(assemble)), on_keyframe_(std::move(on_keyframe)) {}
+    void setInitialMap(const PointICovCloud &surf_map, const PointICovCloud &corner_map) { surf_map_ = surf_map; corner_map_ = corner_map; }
+    void setInitialPose(const Pose &pose_wmap_curr, const Pose &pose_wodom_curr) { wmap_wodom_ = poseMul(pose_wmap_curr, poseInverse(pose_wodom_curr)); }
+    struct Counters { int frames = 0, overlapped = 0, waited = 0, redone = 0, keyframes = 0; } counters;
+
+    // returns true and fills pose_prev when a previous frame's pose came back with this call
+    bool process(const PointICovCloud &surf_cov, const PointICovCloud &corner_cov, const Pose &pose_wodom_curr, Pose &pose_prev)
+    {
+        ++counters.frames;
+        const Pose prior = poseMul(wmap_wodom_, pose_wodom_curr);             // transformAssociateToMap with the correction known NOW (frame k - 2's while k - 1 is in flight)
+        if (!in_flight_) {
+            pipe_.setInputClouds(surf_map_, corner_map_);
+            pipe_.setFeatures(surf_cov, corner_cov);
+            pipe_.submit(prior);
+            in_flight_ = true; prior_in_flight_ = prior; wodom_in_flight_ = pose_wodom_curr;
+            return false;
+        }
+        const bool predicted_keyframe = kf_.wouldSave(prior_in_flight_);
+        if (!predicted_keyframe) {
+            // frame k - 1 is not expected to be saved: frame k matches against the same local map -- stage it and submit frame k behind the solve in flight
+            pipe_.setInputClouds(surf_map_, corner_map_);
+            pipe_.setFeatures(surf_cov, corner_cov);
+            pipe_.submitChained(wodom_in_flight_, pose_wodom_curr);
+            pose_prev = pipe_.collect();                                      // frame k - 1
+            const bool saved = closeFrame(pose_prev);
+            if (saved) {
+                // wrong prediction (the result crossed the keyframe threshold the prior stayed under): frame k was matched against a map without keyframe k - 1.
+                // Its solve is allowed to finish and dropped; the map is rebuilt as the reference would have, and frame k is solved again from the host-side prior.
+                (void)pipe_.collect();
+                ++counters.redone;
+                const Pose prior_k = poseMul(wmap_wodom_, pose_wodom_curr);
+                rebuild(prior_k);
+                pipe_.setInputClouds(surf_map_, corner_map_);
+                pipe_.submit(prior_k);
+                prior_in_flight_ = prior_k;
+            } else {
+                ++counters.overlapped;
+                prior_in_flight_ = poseMul(wmap_wodom_, pose_wodom_curr);     // (what the device computed for frame k, restated for the next prediction)
+            }
+        } else {
+            // frame k - 1 is expected to be saved as a keyframe: frame k's map contains its cloud at its solved pose -- nothing to stage before that pose is known
+            pose_prev = pipe_.collect();
+            ++counters.waited;
+            const bool saved = closeFrame(pose_prev);
+            const Pose prior_k = poseMul(wmap_wodom_, pose_wodom_curr);
+            if (saved) rebuild(prior_k);
+            pipe_.setInputClouds(surf_map_, corner_map_);
+            pipe_.setFeatures(surf_cov, corner_cov);
+            pipe_.submit(prior_k);
+            prior_in_flight_ = prior_k;
+        }
+        wodom_in_flight_ = pose_wodom_curr;
+        return true;
+    }
+    Pose finish()
+    {
+        Pose p = pipe_.collect();
+        in_flight_ = false;
+        closeFrame(p);
+        return p;
+    }
+    const PointICovCloud &surfMap() const { return surf_map_; }
+    const PointICovCloud &cornerMap() const { return corner_map_; }
+private:
+    // transformUpdate + saveKeyframe for the frame whose pose just came back (cpp:1076-1079)
+    bool closeFrame(const Pose &pose_wmap_curr)
+    {
+        wmap_wodom_ = poseMul(pose_wmap_curr, poseInverse(wodom_in_flight_));
+        const int idx = kf_.save(pose_wmap_curr);
+        if (idx < 0) return false;
+        ++counters.keyframes;
+        if (on_keyframe_) on_keyframe_(idx, pose_wmap_curr);
+        return true;
+    }
+    void rebuild(const Pose &prior)
+    {
+        PointICovCloud s, c;
+        assemble_(kf_.surrounding(prior), prior, s, c);
+        surf_map_ = std::move(s); corner_map_ = std::move(c);
+    }
+    FramePipeline pipe_;
+    KeyframePolicy &kf_;
+    Assemble assemble_;
+    OnKeyframe on_keyframe_;
+    PointICovCloud surf_map_, corner_map_;
+    Pose wmap_wodom_, prior_in_flight_, wodom_in_flight_;
+    bool in_flight_ = false;
 };
 
 }  // namespace mloam_hip

@@ -19,7 +19,7 @@ if kcol is None:
          f"group by k.name, p.{name_col} order by k.name")
 else:
     q = f"select {kcol}, {name_col}, count(*), avg({val_col}), sum({val_col}) from pmc_events group by {kcol}, {name_col} order by {kcol}"
-print(f"{'kernel':52s} {'counter':24s} {'dispatches':>10s} {'mean/dispatch':>16s}")
+print(f"{'kernel':86s} {'counter':24s} {'dispatches':>10s} {'mean/dispatch':>16s}")
 for k, c, n, a, s in db.execute(q):
     if flt in k:
-        print(f"{k[:52]:52s} {c:24s} {n:10d} {a:16.1f}")
+        print(f"{k[:86]:86s} {c:24s} {n:10d} {a:16.1f}")

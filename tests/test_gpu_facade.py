@@ -88,6 +88,13 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
                 o = f32(o - f32(2 * np.pi))
         exp[i] = f32(f32(o - start) / f32(end - start)) * f32(0.1)
     np.testing.assert_allclose(st, exp, rtol=0, atol=2e-6)      # libm atan2f vs numpy's: last-ulp differences of the angle only
+    # ---- round 4: PipelinedMapper (the overlap's precondition as code): every pose equals the one-frame-at-a-time loop's -- including the frame whose keyframe
+    #      prediction was wrong and that was therefore solved again on the rebuilt map -- and all three paths were taken
+    pm = np.fromfile(os.path.join(d, "out_pipelined_mapper.f64"), np.float64)
+    worst, overlapped, waited, redone, n_kf, n_kf_ref, travelled = pm[56:63]
+    assert worst < 1e-9, pm[56:]
+    assert overlapped >= 2 and waited >= 1 and redone >= 1 and n_kf == n_kf_ref >= 3, pm[56:]
+    assert abs(travelled - 3 * 0.34) < 0.02                      # the solved poses follow the sensor's motion (0.34 m per frame), not the drifting odometry (0.31)
     # ---- round 2: ActiveFeatureSelection::evalFullHessian -> logDet -> gf_ratio policy through the facade
     afs = np.fromfile(os.path.join(d, "out_afs.f64"), np.float64)
     cov6 = np.array([0.01, 0, 0, 0.02, 0, 0.03], np.float32)

@@ -1079,6 +1079,58 @@ def test_pure_odom_window_normal_equations(ctx, mla, orc, synth, shape):
     assert float(np.abs(nl_g["H"] - nl_r["H"]).max()) <= 1e-9 * float(np.abs(nl_r["H"]).max())
 
 
+def test_scan2map_split_submission_equals_the_synchronous_call(mla, case16, feats16):
+    """mlh_scan2map_begin / _end (+ _begin_chained): the whole solve enqueued without the host reading the LM loop's verdict. Inside the look-ahead the pose is
+    mlh_scan2map's bit for bit; a look-ahead that is too short is detected on the device -- never returned as a result -- and the frame is solved again inside
+    _end (status 2) or handed back to the caller (status 1) when a younger solve is chained behind it."""
+    p0 = case16["p0"]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    c = mla.Context(0)
+    try:
+        _stage(c, mla, case16, feats16)
+        ref, st = c.scan2map(p0)
+        need = max(int(x["lm_iterations"]) for x in st)
+        assert 2 <= need <= 10
+        ref2 = c.scan2map(p0, want_stats=False)[0]
+        assert np.array_equal(ref, ref2)
+        # default look-ahead (10): converged inside it
+        c.scan2map_begin(p0)
+        pose, status = c.scan2map_end()
+        assert status == 0 and np.array_equal(pose, ref)
+        # exactly enough launches, and one too few
+        c.scan2map_begin(p0, lm_lookahead=need)
+        pose, status = c.scan2map_end()
+        assert status == 0 and np.array_equal(pose, ref)
+        c.scan2map_begin(p0, lm_lookahead=need - 1)
+        pose, status = c.scan2map_end()
+        assert status == 2 and np.array_equal(pose, ref)        # too short: found out on the device, solved again inside the call
+        # the synchronous call is unaffected by what the split calls left behind (the overflow flag is per solve)
+        assert np.array_equal(c.scan2map(p0, want_stats=False)[0], ref)
+        # two frames in flight, the second chained on the device from the first one's result (identity odometry: it starts where frame 0 ended)
+        c.scan2map_begin(p0)
+        c.scan2map_begin_chained(ident, ident)
+        a, sa = c.scan2map_end()
+        b, sb = c.scan2map_end()
+        assert sa == 0 and sb == 0 and np.array_equal(a, ref)
+        b_ref = c.scan2map(a, want_stats=False)[0]
+        assert float(np.abs(b - b_ref).max()) < 1e-12           # Pose(q, t) products normalise the quaternion: equal to a restart from `a` to rounding
+        # a frame that overflows WITH a younger frame chained behind it is handed back (status 1, pose = its start pose), not re-solved on changed state
+        c.scan2map_begin(p0, lm_lookahead=1)
+        c.scan2map_begin_chained(ident, ident, lm_lookahead=1)
+        a, sa = c.scan2map_end()
+        assert sa == 1 and np.array_equal(a, p0)
+        b, sb = c.scan2map_end()
+        assert sb in (0, 1, 2)
+        # mixing the two kinds of solves: each is collected by its own _end
+        c.gn_solve_begin(p0, 3)
+        with pytest.raises(mla.MlhError):
+            c.scan2map_end()
+        c.gn_solve_end()
+        assert np.array_equal(c.scan2map(p0, want_stats=False)[0], ref)
+    finally:
+        c.close()
+
+
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
     _stage(ctx, mla, case16, feats16)
