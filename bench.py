@@ -529,6 +529,23 @@ def main():
         return None
 
     # valid correspondences per iteration (deterministic: the timed steps repeat exactly this solve)
+    if world > 1 and comm_kind == "p2p":
+        # the first SHARDED solve is the mailbox communicator's first exchange inside a solver launch (peer stores + flags between GPUs while kernels run). If it
+        # fails on any rank -- a peer's flag never becomes visible, reported by the solve itself after its 5 s bound -- every rank moves to RCCL together
+        # instead of the job dying with its measurement
+        ok_first = 1
+        try:
+            ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        except Exception as e:   # noqa: BLE001 -- reported, never silent
+            ok_first = 0
+            log(f"[rank {rank}] first sharded solve over the mailbox communicator failed: {e!r}")
+        flag = torch.tensor([ok_first], dtype=torch.int32, device=dist_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            log(f"[rank {rank}] falling back to RCCL for the sharded solver")
+            ctx.comm_finalize()
+            comm_kind = comm_setup("rccl")
+            comm_state["fallback"] = "the first sharded solve over the mailbox communicator failed; the run continued over RCCL"
     pose_converged, it_stats = ctx.gn_solve(p0, GN_ITERS, opts, want_stats=True)
     n_valid_iter = [(int(s_["n_surf"]), int(s_["n_corner"])) for s_ in it_stats]
     # (N > 1: the counts come out of the all-reduced record, i.e. they are already the whole job's)
@@ -825,6 +842,47 @@ def main():
         outgrow_ms = 1e3 * (time.perf_counter() - t3) / n_og
         ctx.map_set_pair(d_surf_map, d_corner_map)
 
+    # --- where the kernels leave the latency regime: the same frame WITHOUT thinning the scan features at the mapper's resolutions (every less-flat / less-sharp
+    #     point is a query: ~10x the launch), same maps, same solve. Supplementary (`roofline.saturated`): it says at which launch size the correspondence kernel's
+    #     rate stops being set by the length of one query's dependent chain.
+    saturated = None
+    if world == 1 and not args.dense_features and roofline is not None:
+        surf_d, corner_d = fuse_features(synth, scans, extracted, thin=False)
+        ctx.features_set(mla.SURF, torch.from_numpy(surf_d).cuda())
+        ctx.features_set(mla.CORNER, torch.from_numpy(corner_d).cuda())
+        torch.cuda.synchronize()
+        for _ in range(3):
+            ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        ctx.profile_enable((1 << mla.K_KNN) | (1 << mla.K_KNN_PRE) | (1 << mla.K_FIT))
+        ctx.profile_sample(1)
+        ctx.profile_reset()
+        for _ in range(10):
+            ctx.gn_solve(p0, GN_ITERS, opts, want_stats=False)
+        ctx.synchronize()
+        sat = {k: ctx.profile_get(k) for k in (mla.K_KNN, mla.K_KNN_PRE, mla.K_FIT)}
+        ctx.profile_enable(0)
+        b27 = bball = 0.0
+        cb_d = {}
+        for name, feats, lmap in (("surf", surf_d, local_surf_map), ("corner", corner_d, local_corner_map)):
+            cb, cball = candidate_stats(lmap, synth.transform_points(feats[:, :3], Tm), h)
+            cb_d[name] = round(cb, 2)
+            b27 += len(feats) * (16.0 + 27 * 8 + 12.0 * cb)
+            bball += len(feats) * (16.0 + 27 * 8 + 12.0 * cball)
+        def us(k):
+            return 1e3 * sat[k][0] / sat[k][1] if sat[k][1] else None
+        t_cold, t_pre = us(mla.K_KNN), us(mla.K_KNN_PRE)
+        t_dom = t_pre if t_pre else t_cold
+        saturated = dict(features=int(len(surf_d) + len(corner_d)), features_surf=int(len(surf_d)), features_corner=int(len(corner_d)),
+                         knn_search_only_us=(round(t_cold, 2) if t_cold else None), knn_with_prologue_us=(round(t_pre, 2) if t_pre else None),
+                         fit_us=(round(us(mla.K_FIT), 2) if us(mla.K_FIT) else None), algorithmic_bytes_per_launch=int(b27), mean_candidates_per_feature=cb_d,
+                         frac=round(b27 / (1e-6 * t_dom) / 1e9 / 8000.0, 5), unavoidable_frac=round(bball / (1e-6 * t_dom) / 1e9 / 8000.0, 5),
+                         frac_search_only=(round(b27 / (1e-6 * t_cold) / 1e9 / 8000.0, 5) if t_cold else None),
+                         queries_per_s_of_the_dominant_launch=round((len(surf_d) + len(corner_d)) / (1e-6 * t_dom), 1),
+                         note="the frame's scan features NOT thinned at MAP_SURF_RES / MAP_CORNER_RES (not BASELINE's workload): same kernels, ~10x the queries per launch; HIP events on every launch of 10 solves")
+        roofline["saturated"] = saturated
+        ctx.features_set(mla.SURF, d_surf)
+        ctx.features_set(mla.CORNER, d_corner)
+
     # --- BASELINE config 4's frame (4 x 64 rings, one pose block per LiDAR: N_NEIGH 5/10/10/10, CHECK_FOV, freeze-on-degenerate, Huber 1.0) through
     #     mlh_gn_solve_blocks on this run's map, sharded like the single-pose frame: the headline with --config4, a supplementary leg at --gpus 8 (the
     #     configuration BASELINE.json quotes config 4 on) otherwise. Last thing measured: it replaces the context's staged features.
@@ -912,6 +970,7 @@ def main():
                    multi_gpu=(None if world == 1 else dict(
                        shard_mode=args.shard_mode,
                        communicator=("mailbox" if comm_kind == "p2p" else "rccl"), communicator_requested=args.comm, ranks_seen_by_the_collective=comm_state["ranks_seen"],
+                       communicator_fallback=comm_state.get("fallback"),
                        comm=("mailbox communicator (mlh_p2p_*): the summed record is exchanged inside the fit kernel's finishing workgroup, one hop, no extra launch" if comm_kind == "p2p" else "RCCL ncclAllReduce"),
                        ranks_share_gpus=bool(shared_gpus), gpus_visible=int(torch.cuda.device_count()),
                        cross_gpu_measurement=(False if shared_gpus else True),

@@ -427,7 +427,8 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 /* How the iterations of mlh_gn_solve / mlh_gn_solve_begin* are laid out on the device. Neither switch changes a result (same arithmetic in the same order; the
  * tests compare the variants bit for bit); they exist for A/B measurements and as the reference forms in the tests. Environment at mlh_create: MLH_GN_DEFER,
  * MLH_KNN_WARM (0 / 1).
- *   deferred_finish 1 (default): on one GPU, without per-iteration statistics, every iteration but the last leaves the J^T J / J^T r records of its tiles in HBM and
+ *   deferred_finish 1 (default): on one GPU, without per-iteration statistics and for frame-sized launches (at most 160 fit tiles = 40 960 feature slots; larger
+ *       launches keep the classic form, where the redundant sums would cost more than the serial tail they replace), every iteration but the last leaves the J^T J / J^T r records of its tiles in HBM and
  *       the NEXT iteration's correspondence launch starts by summing them, solving and applying Plus in every workgroup redundantly (the kernel boundary is the only
  *       synchronisation); 0: the fit kernel's last-arriving workgroup finishes every iteration (evalHessian + evalDegenracy + solve + Plus,
  *       lidar_mapper_keyframe.cpp:575-596, 1160-1204) while the other compute units wait.

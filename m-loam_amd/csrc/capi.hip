@@ -1213,6 +1213,19 @@ static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pos
     return a;
 }
 
+// The deferred finish makes EVERY workgroup of the next correspondence launch sum the fit tiles' records: cheap for a mapper frame (88 records, ~1 000
+// workgroups: +3.5 us against the 5 us the fit kernel's serial tail costs), quadratic in the launch size beyond it -- measured (profiles/r04_feature_sweep.txt):
+// even at 27-34 k features (108-133 tiles), a loss from ~100 k features on (447 tiles: +14 us), 4x the launch at 450 k. Launches with more tiles than this keep the
+// classic finish, whose one serial tail is noise next to a 100 us kernel.
+constexpr int GN_DEFER_MAX_TILES = 160;
+static bool gn_defer_applies(const mlh_ctx *ctx, int kind_mask)
+{
+    if (!ctx->gn_defer || distributed(ctx)) return false;
+    int tiles = 0;
+    for (int k = 0; k < 2; ++k) if (kind_mask & (1 << k)) tiles += (ctx->feat[k].m + 256 - 1) / 256;      // (the fit kernel's tile: 256 features, match.hip)
+    return tiles <= GN_DEFER_MAX_TILES;
+}
+
 static int fetch_pose_and_stats(mlh_ctx *ctx, double pose[7], mlh_iter_stat *stats, int n_stats)
 {
     if (!stats || n_stats <= 0) {
@@ -1258,7 +1271,7 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
             // mailbox communicator: the same two launches -- that workgroup exchanges the summed record with the peers (one hop) before it solves
             a.finish = 1;
             a.stat_slot = stats ? it : -1;
-            if (!distributed(ctx) && !stats && n_iters >= 2 && ctx->gn_defer) {
+            if (!stats && n_iters >= 2 && gn_defer_applies(ctx, mask)) {
                 // one GPU, no per-iteration statistics: only the LAST iteration keeps that finish; the others leave their tiles' records to the next
                 // iteration's correspondence launch, whose every workgroup sums and solves for itself (match.hip: knn_features_kernel<.., PRE>)
                 a.gn_iter = it; a.gn_iters = n_iters;
@@ -1327,7 +1340,7 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         a.finish = 1;
         a.stat_slot = -1;
         a.warm = it >= 1 && ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi;
-        if (!distributed(ctx) && n_iters >= 2 && ctx->gn_defer) {     // the finish moves into the next iteration's correspondence launch (see mlh_gn_solve)
+        if (n_iters >= 2 && gn_defer_applies(ctx, mask)) {     // the finish moves into the next iteration's correspondence launch (see mlh_gn_solve)
             a.gn_iter = it; a.gn_iters = n_iters;
             if (it == 1) a.init_pose = pose_in;
             if (it < n_iters - 1) a.finish = 0;

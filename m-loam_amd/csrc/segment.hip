@@ -159,51 +159,47 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
     const size_t npx = size_t(vs) * hs;
     std::vector<uint16_t> pushed_x(npx), pushed_y(npx), qx(npx), qy(npx);
     std::vector<int8_t> q_last_dy(npx, 0);
-    std::vector<float> q_last_dis(npx, 0.f);
+    // queue_last_dis, kept as its ingredients: dist = sqrt(d1^2 + d2^2 - 2 d1 d2 cos(alpha)) is read back only by the same-beam rule (hpp:297-300), for a few
+    // per cent of the entries -- the square root is taken there (same expression, same operands: the same float), not for every push
+    std::vector<float> q_d1(npx, 0.f), q_d2(npx, 0.f), q_cos(npx, 1.f);
+    std::vector<char> q_zero(npx, 1);                   // the record holds the literal 0 of a cluster's seed (hpp:245)
     auto R = [&](int i, int j) -> float { return H.range[size_t(i) * hs + j]; };
     auto L = [&](int i, int j) -> int & { return H.label[size_t(i) * hs + j]; };
     int label_count = 2;
     static const int8_t nb[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
-    float alpha = 0.f;                                  // one variable for the whole call, starting at 0 (U1)
-    // alpha only ever holds 0, alphax or one of the alphay values: its sine and cosine are looked up (the same std::cos / std::sin results, computed once)
-    struct Trig {
-        float a[4], c[4], s[4];
-        int n = 0;
-        float cos_of(float x) { return c[slot(x)]; }
-        float sin_of(float x) { return s[slot(x)]; }
-        int slot(float x)
-        {
-            for (int k = 0; k < n; ++k) if (a[k] == x) return k;
-            if (n == 4) n = 3;                          // cannot happen (at most 0, alphax and two alphay values); keeps the table in bounds
-            a[n] = x; c[n] = std::cos(x); s[n] = std::sin(x);
-            return n++;
-        }
-    } trig;
+    // alpha -- ONE variable for the whole call, starting at 0 (U1) -- only ever holds 0, alphax or one of the two alphay values: it is carried as an index into
+    // a table of the std::cos / std::sin results (computed once: the same floats the reference's calls return)
+    const float ay64[2] = {float(0.333 / 180.0 * M_PI), float(0.5 / 180.0 * M_PI)};
+    float t_alpha[4] = {0.f, S.alphax, S.is64 ? ay64[0] : S.alphay, S.is64 ? ay64[1] : S.alphay}, t_cos[4], t_sin[4];
+    for (int k = 0; k < 4; ++k) { t_cos[k] = std::cos(t_alpha[k]); t_sin[k] = std::sin(t_alpha[k]); }
+    int alpha_idx = 0;
     const bool theta_simple = prm.segment_theta > 0.01f && prm.segment_theta < 1.5f;
     const float tan_theta = theta_simple ? std::tan(prm.segment_theta) : 0.f;
+    auto dist_of = [](float d1, float d2, float c) { return std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * c); };
     std::vector<char> line_flag(vs);
     for (int i = 0; i < vs; i++) {
         for (int j = 0; j < hs; j++) {
             if (L(i, j) != 0) continue;
             std::fill(line_flag.begin(), line_flag.end(), 0);
-            qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_last_dis[0] = 0.f;
+            qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_zero[0] = 1;
             int q_size = 1, q_start = 0, q_end = 1, n_pushed = 1;
             pushed_x[0] = uint16_t(i); pushed_y[0] = uint16_t(j);
             while (q_size > 0) {
                 const int fx = qx[q_start], fy = qy[q_start];
                 --q_size; ++q_start;
                 L(fx, fy) = label_count;
+                const float rf = R(fx, fy);
                 for (int q = 0; q < 4; ++q) {
                     int tx = fx + nb[q][0], ty = fy + nb[q][1];
                     if (tx < 0 || tx >= vs) continue;
-                    if (S.is64) S.alphay = (tx <= 32) ? float(0.333 / 180.0 * M_PI) : float(0.5 / 180.0 * M_PI);
                     if (ty < 0) ty = hs - 1;
                     if (ty >= hs) ty = 0;
                     if (L(tx, ty) != 0) continue;
-                    const float d1 = std::max(R(fx, fy), R(tx, ty)), d2 = std::min(R(fx, fy), R(tx, ty));
-                    const float dist = std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * trig.cos_of(alpha));
-                    alpha = nb[q][0] == 0 ? S.alphax : S.alphay;
-                    const float ay = d2 * trig.sin_of(alpha), ax = d1 - d2 * trig.cos_of(alpha);
+                    const float rt = R(tx, ty);
+                    const float d1 = std::max(rf, rt), d2 = std::min(rf, rt);
+                    const float cos_prev = t_cos[alpha_idx];                    // dist is computed with the alpha of the PREVIOUS evaluated neighbour (U1)
+                    alpha_idx = nb[q][0] == 0 ? 1 : (S.is64 ? (tx <= 32 ? 2 : 3) : 2);      // (64 rings: segment_alphay_ follows the neighbour's row, hpp:266-272)
+                    const float ay = d2 * t_sin[alpha_idx], ax = d1 - d2 * t_cos[alpha_idx];
                     // angle > theta, with atan2 itself called only within 1e-4 (relative) of the threshold: ay >= 0 and 0 < theta < pi / 2, so away from
                     // it the comparison of ay with ax * tan(theta) decides -- the same boolean as the reference's atan2(ay, ax) > theta
                     bool push;
@@ -212,11 +208,13 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
                     else if (theta_simple && ax > 0.f && ay < lim * 0.9999f) push = false;
                     else push = std::atan2(ay, ax) > prm.segment_theta;
                     if (!push && nb[q][1] == 0 && q_last_dy[q_start] == 0) {          // the record of the NEXT queue entry (hpp:297)
-                        const float dist_last = q_last_dis[q_start];
+                        const float dist_last = q_zero[q_start] ? 0.f : dist_of(q_d1[q_start], q_d2[q_start], q_cos[q_start]);
+                        const float dist = dist_of(d1, d2, cos_prev);
                         push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
                     }
                     if (push) {
-                        qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = nb[q][1]; q_last_dis[q_end] = dist;
+                        qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = nb[q][1];
+                        q_d1[q_end] = d1; q_d2[q_end] = d2; q_cos[q_end] = cos_prev; q_zero[q_end] = 0;
                         ++q_size; ++q_end;
                         L(tx, ty) = label_count;
                         line_flag[tx] = 1;
@@ -297,16 +295,65 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     }
     const auto tq1 = std::chrono::steady_clock::now();
     std::vector<int> outlier_idx;
+    int n_linear_rows = 0, n_pool_rows = 0, n_erased = 0;
     if (prm.segment_flag) {
+        std::vector<int> epos;
+        std::vector<char> dead;
+        std::vector<size_t> first_run;
         for (int r = 0; r < vs; ++r) {
-            AlivePool alive(rows[r].size());
-            bool any = false;
+            // the positions to erase, in the order the reference erases (columns ascending)
+            epos.clear();
+            int descents = 0;
             for (int c = 0; c < hs; ++c)
                 if (H.label[size_t(r) * hs + c] == 999999) {
                     const int pos = order[size_t(r) * hs + c];
-                    if (pos >= 0 && size_t(pos) < alive.size()) { alive.erase_index(alive.at(size_t(pos))); any = true; }       // stale position, as it is (U2)
+                    if (!epos.empty() && pos <= epos.back()) ++descents;
+                    epos.push_back(pos);
                     if (c % 5 == 0) outlier_idx.push_back(H.owner[size_t(r) * hs + c]);
                 }
+            if (epos.empty()) continue;
+            // A driver delivers a ring's points in firing order: a pixel's fill position grows with its column, with ONE step down where the sweep's first
+            // column sits. The erased positions then come as one or two strictly ascending runs, and "erase what is NOW at position p" resolves in a linear
+            // pass. First run: the k-th erasure removes the ORIGINAL element p + k (the k elements the run already removed were all in front of it).
+            // Second run (it restarts at the front of the row): the j-th erasure removes the original element t with t - (removed originals below t) = q, i.e.
+            // t = q + j + c, c = how many of the FIRST run's originals lie at or below t -- both lists ascend, so c only ever grows: a merge. A position at or
+            // past the current size erases nothing (U2). More than two runs (an unordered cloud) go to the order-statistic structure below.
+            if (descents <= 1) {
+                std::vector<int> &row = rows[r];
+                const size_t size0 = row.size();
+                dead.assign(size0, 0);
+                first_run.clear();
+                size_t erased = 0, j = 0, c = 0;
+                bool second = false;
+                for (size_t e = 0; e < epos.size(); ++e) {
+                    if (e > 0 && epos[e] <= epos[e - 1]) second = true;
+                    const int pos = epos[e];
+                    if (pos < 0 || size_t(pos) >= size0 - erased) continue;
+                    size_t t;
+                    if (!second) {
+                        t = size_t(pos) + first_run.size();
+                        first_run.push_back(t);
+                    } else {
+                        t = size_t(pos) + j + c;
+                        while (c < first_run.size() && first_run[c] <= t) { ++c; ++t; }
+                        ++j;
+                    }
+                    dead[t] = 1;
+                    ++erased;
+                }
+                ++n_linear_rows; n_erased += int(erased);
+                if (erased) {
+                    size_t w = 0;
+                    for (size_t i = 0; i < size0; ++i) if (!dead[i]) row[w++] = row[i];
+                    row.resize(w);
+                }
+                continue;
+            }
+            ++n_pool_rows;
+            AlivePool alive(rows[r].size());
+            bool any = false;
+            for (const int pos : epos)
+                if (pos >= 0 && size_t(pos) < alive.size()) { alive.erase_index(alive.at(size_t(pos))); any = true; }       // stale position, as it is (U2)
             if (any) {
                 std::vector<int> kept;
                 kept.reserve(alive.size());
@@ -346,7 +393,8 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         std::fprintf(stderr, "[mlh_segment_cloud] n %d: kernels + 3 image copies to the host %.1f us | host cluster search (BFS, queue order) %.1f us | row assembly + keep list + gather + sync %.1f us\n",
                      n, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3));
-        std::fprintf(stderr, "    rows %.1f | erase %.1f | keep %.1f | upload + gather + sync %.1f us\n", us(tp2, tq1), us(tq1, tq2), us(tq2, tq3), us(tq3, tp3));
+        std::fprintf(stderr, "    rows %.1f | erase %.1f (rows resolved in one linear pass %d, through the order-statistic pool %d; erased %d) | keep %.1f | upload + gather + sync %.1f us\n",
+                     us(tp2, tq1), us(tq1, tq2), n_linear_rows, n_pool_rows, n_erased, us(tq2, tq3), us(tq3, tp3));
     }
     int max_len = 0;
     for (int r = 0; r < vs; ++r) if (hend[r] - hstart[r] >= 6) max_len = std::max(max_len, hend[r] - hstart[r]);

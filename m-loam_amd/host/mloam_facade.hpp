@@ -1147,7 +1147,8 @@ public:
     {
         double p[7];
         pose_wmap_curr.toParam(p);
-        dev_.check(mlh_gn_solve_begin(dev_.ctx(), p, iters_, &o_));
+        if (scan2map_) dev_.check(mlh_scan2map_begin(dev_.ctx(), p, &o_, lm_lookahead_));
+        else dev_.check(mlh_gn_solve_begin(dev_.ctx(), p, iters_, &o_));
         ++in_flight_;
     }
     // every later frame: start pose = (previous result * pose_wodom_prev.inverse()) * pose_wodom_curr, evaluated on the device
@@ -1155,13 +1156,22 @@ public:
     {
         double a[7], b[7];
         pose_wodom_prev.toParam(a); pose_wodom_curr.toParam(b);
-        dev_.check(mlh_gn_solve_begin_chained(dev_.ctx(), a, b, iters_, &o_));
+        if (scan2map_) dev_.check(mlh_scan2map_begin_chained(dev_.ctx(), a, b, &o_, lm_lookahead_));
+        else dev_.check(mlh_gn_solve_begin_chained(dev_.ctx(), a, b, iters_, &o_));
         ++in_flight_;
     }
+    // The frames are solved by the reference's own per-frame call, scan2MapOptimization (2 outer iterations x Levenberg-Marquardt), submitted and collected
+    // separately (mlh_scan2map_begin / _end) instead of `gn_iters` Gauss-Newton iterations. lm_lookahead 0: automatic. After collect(), lastStatus() is
+    // mlh_scan2map_end's status: 0 / 2 = the pose is scan2MapOptimization's; 1 = the pose returned is the frame's START pose and the caller has to solve the frame
+    // with scan2MapOptimization(...) on its inputs (it overflowed the look-ahead with a younger frame chained behind it).
+    void useScan2Map(bool on, int lm_lookahead = 0) { scan2map_ = on; lm_lookahead_ = lm_lookahead; }
+    int lastStatus() const { return last_status_; }
     Pose collect()
     {
         double p[7];
-        dev_.check(mlh_gn_solve_end(dev_.ctx(), p));
+        last_status_ = 0;
+        if (scan2map_) { int32_t st = 0; dev_.check(mlh_scan2map_end(dev_.ctx(), p, &st)); last_status_ = st; }
+        else dev_.check(mlh_gn_solve_end(dev_.ctx(), p));
         --in_flight_;
         Pose r;
         r.fromParam(p);
@@ -1172,6 +1182,8 @@ private:
     Device &dev_;
     mlh_solver_opts o_;
     int iters_, in_flight_ = 0;
+    bool scan2map_ = false;
+    int lm_lookahead_ = 0, last_status_ = 0;
 };
 
 // ------------------------------------------------------------------ what makes staging beside the solve legal, as code

@@ -15,7 +15,11 @@ for rings, vs in ((64, 64), (16, 16)):
     pts = s.points.copy(); pts[:, 3] = 0.5
     m = rng.random(len(pts)) < 0.1
     pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
-    pts = pts[rng.permutation(len(pts))]
+    if os.environ.get("SEGBENCH_ORDER", "firing") == "shuffled":
+        pts = pts[rng.permutation(len(pts))]
+    else:      # firing order (a driver's): azimuth step by azimuth step, starting inside the sweep
+        az = np.mod(np.arctan2(pts[:, 1], pts[:, 0]) - 1.0, 2 * np.pi)
+        pts = np.ascontiguousarray(pts[np.argsort(az, kind="stable")])
     ctx = mla.Context(0)
     d = torch.from_numpy(pts).cuda(); torch.cuda.synchronize()
     for _ in range(3):

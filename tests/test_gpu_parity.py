@@ -1576,8 +1576,9 @@ def test_full_size_front_end_properties(mla, synth):
         c.close()
 
 
-def _raw_cloud(synth, n_rings, seed, clutter):
-    """an UNORDERED cloud as a driver delivers it: a simulated scan, shuffled, part of the points pulled off their surfaces along the ray"""
+def _raw_cloud(synth, n_rings, seed, clutter, order="shuffled"):
+    """a raw cloud: a simulated scan, part of the points pulled off their surfaces along the ray; shuffled (nothing may be assumed about a driver's order),
+    ring by ring in azimuth order, or in firing order (azimuth step by azimuth step, every ring) starting somewhere inside the sweep"""
     scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
     s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], n_rings, seed=seed)
     rng = np.random.default_rng(seed)
@@ -1585,7 +1586,32 @@ def _raw_cloud(synth, n_rings, seed, clutter):
     pts[:, 3] = rng.uniform(0.0, 0.9, len(pts)).astype(np.float32)          # some intensity payload in [0, 1)
     m = rng.random(len(pts)) < clutter
     pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
-    return pts[rng.permutation(len(pts))]
+    if order == "shuffled":
+        return pts[rng.permutation(len(pts))]
+    if order == "ring_major":
+        return pts
+    az = np.arctan2(pts[:, 1], pts[:, 0])
+    az = np.mod(az - az[len(pts) // 3], 2 * np.pi)               # the sweep starts at some point's azimuth, not at a column boundary
+    return np.ascontiguousarray(pts[np.argsort(az, kind="stable")])
+
+
+@pytest.mark.parametrize("vs,rings,clutter,order", [(16, 16, 0.1, "ring_major"), (16, 16, 0.4, "firing"), (64, 64, 0.1, "firing"), (64, 64, 0.3, "ring_major")])
+def test_image_segmenter_on_ordered_clouds(mla, orc, synth, vs, rings, clutter, order):
+    """clouds in the orders drivers really deliver: a ring's fill positions then grow with the column (one step down where the sweep starts), and the outlier erasure
+    -- "erase what is NOW at the position recorded at fill time" (image_segmenter.hpp:374) -- takes its linear path (segment.hip) instead of the order-statistic
+    structure the shuffled clouds of the test above exercise. Bit-equal to the oracle either way."""
+    pts = _raw_cloud(synth, rings, 5, clutter, order)
+    prm = orc.seg_params(vertical_scans=vs, segment_flag=True)
+    ref = orc.segment_cloud(pts, prm)
+    c = mla.Context(0)
+    try:
+        got = c.segment_cloud(pts, vertical_scans=vs, segment_flag=1)
+    finally:
+        c.close()
+    assert len(ref["cloud"]) < len(pts) - 100
+    assert got["cloud"].shape == ref["cloud"].shape and np.array_equal(got["cloud"].view(np.uint32), ref["cloud"].view(np.uint32))
+    assert np.array_equal(got["scan_start"], ref["scan_start"]) and np.array_equal(got["scan_end"], ref["scan_end"])
+    assert got["outlier"].shape == ref["outlier"].shape and np.array_equal(got["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
 
 
 @pytest.mark.parametrize("vs,rings,clutter,flag", [(16, 16, 0.1, True), (16, 16, 0.4, True), (16, 16, 0.1, False), (32, 64, 0.1, True), (64, 64, 0.1, True)])
