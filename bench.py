@@ -273,6 +273,9 @@ def main():
                          "(lidar_mapper_keyframe.cpp:641-688, 254-354), so its staging cannot be overlapped with the solve -- the pose is collected first, the maps are staged "
                          "on an idle stream, the solve starts from a host-side pose. 0: never (every frame reuses the previous frame's local map, as the reference does "
                          "between keyframes: cpp:257-261). The default line reports the cadences 1 / 2 / 5 / 10 beside `value` (`keyframe_cadence`)")
+    ap.add_argument("--no-supplementary", action="store_true",
+                    help="only the contract's loop and the per-kernel pass: no saturation leg (un-thinned features), no keyframe-cadence loops, no scan2map / out-grown-box legs -- "
+                         "for kernel traces and PMC passes, whose per-kernel averages should be the headline workload's alone")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="milliseconds of an unrelated torch matmul before the warm-up steps (clock ramp of a GPU that idled through the host-side setup); 0: none")
     ap.add_argument("--profile-events", type=int, default=1,
@@ -642,7 +645,7 @@ def main():
     # config_realvehicle_hercules.yaml:142-143: every frame for a vehicle at >= 10 m/s and 10 Hz, every ~10th at walking pace): the frame after a keyframe cannot have
     # its maps staged beside the previous solve
     keyframe_cadence = None
-    if pipelined and args.restage_every == 0:
+    if pipelined and args.restage_every == 0 and not args.no_supplementary:
         keyframe_cadence = {}
         for kc in (1, 2, 5, 10):
             cadence[0], frame_no[0] = kc, 0
@@ -688,7 +691,7 @@ def main():
     # supplementary: the reference's own per-frame call, scan2MapOptimization = index build + 2 outer x (match all, evalHessian +
     # evalDegenracy, Ceres-shaped Levenberg-Marquardt <= 30 iterations) -- not `value`, reported beside it
     s2m_ms = None
-    if world == 1:
+    if world == 1 and not args.no_supplementary:
         for _ in range(3):
             ctx.map_rebuild(mla.ALL_KINDS)
             s2m_pose, s2m_stats = ctx.scan2map(p0, opts)
@@ -824,7 +827,7 @@ def main():
     # supplementary: a frame whose map has OUTGROWN the sticky grid box: every step stages a cloud that alternately has / has not a few points 40 m
     # outside the box of the previous one, so the bounds pass + re-layout path of mlh_map_set_pair is what is timed. Not `value`.
     outgrow_ms = None
-    if world == 1 and not args.no_map_rebuild and not args.map_rebuild_only:
+    if world == 1 and not args.no_map_rebuild and not args.map_rebuild_only and not args.no_supplementary:
         ext = torch.tensor([[1.0, 1.0, 0.0], [-1.0, -1.0, 0.0]], device="cuda") * float(np.abs(local_surf_map[:, :2]).max() + 40.0)
         grown = torch.cat([d_surf_map[:, :3], ext.to(d_surf_map.dtype)], dim=0).contiguous()
         plain = d_surf_map[:, :3].contiguous()
@@ -846,7 +849,7 @@ def main():
     #     point is a query: ~10x the launch), same maps, same solve. Supplementary (`roofline.saturated`): it says at which launch size the correspondence kernel's
     #     rate stops being set by the length of one query's dependent chain.
     saturated = None
-    if world == 1 and not args.dense_features and roofline is not None:
+    if world == 1 and not args.dense_features and roofline is not None and not args.no_supplementary:
         surf_d, corner_d = fuse_features(synth, scans, extracted, thin=False)
         ctx.features_set(mla.SURF, torch.from_numpy(surf_d).cuda())
         ctx.features_set(mla.CORNER, torch.from_numpy(corner_d).cuda())

@@ -432,9 +432,14 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
  *       the NEXT iteration's correspondence launch starts by summing them, solving and applying Plus in every workgroup redundantly (the kernel boundary is the only
  *       synchronisation); 0: the fit kernel's last-arriving workgroup finishes every iteration (evalHessian + evalDegenracy + solve + Plus,
  *       lidar_mapper_keyframe.cpp:575-596, 1160-1204) while the other compute units wait.
+ *   final_in_successor 1 (default; needs deferred_finish): a solve submitted with mlh_gn_solve_begin* leaves its LAST iteration as records too. The next
+ *       mlh_gn_solve_begin_chained completes it in its first correspondence launch -- sum, solve, Plus, the pose published to that solve's host record and stored as the
+ *       state's pose from there, then this frame's chained start pose (lidar_mapper_keyframe.cpp:145-160) computed in the same prologue: neither the serial finish nor
+ *       the chain launch stand between two frames. mlh_gn_solve_end, or any other solver call, completes a solve no successor took with a one-workgroup launch.
+ *       0: the last iteration finishes and publishes in its own fit launch. Environment: MLH_GN_FINAL_DEFER.
  *   knn_warm_start 1 (default): iterations >= 1 bound the 5-NN search of a feature by the distances from its new position to the five neighbours the previous
  *       iteration found (an upper bound of the fifth-neighbour distance: the search stays exact, feature_extract.hpp:666/813); 0: every iteration searches cold. */
-int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start);
+int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start, int final_in_successor);
 /* The same solve submitted and collected separately (one GPU, or several ranks joined by the mailbox communicator -- not under RCCL; no statistics): _begin enqueues the n_iters iterations and returns at once, _end waits for the
  * pose. Between the two the caller may stage the NEXT frame's maps (mlh_map_set_pair): those launches queue up behind the solve on the context's stream, so the
  * GPU does not idle through the host's turn-around at the frame boundary (bench.py submits its frames this way). At most two solves in flight per context

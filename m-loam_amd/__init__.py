@@ -131,7 +131,7 @@ def load_library():
     lib.mlh_map_info.argtypes = [vp, ci, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(cd), C.POINTER(C.c_int32)]
     lib.mlh_set_voxel_member_order.argtypes = [vp, ci]
     lib.mlh_set_extract_tie_order.argtypes = [vp, ci]
-    lib.mlh_set_gn_schedule.argtypes = [vp, ci, ci]
+    lib.mlh_set_gn_schedule.argtypes = [vp, ci, ci, ci]
     lib.mlh_scan2map_begin.argtypes = [vp, vp, C.POINTER(SolverOpts), ci]
     lib.mlh_scan2map_begin_chained.argtypes = [vp, vp, vp, C.POINTER(SolverOpts), ci]
     lib.mlh_scan2map_end.argtypes = [vp, vp, vp]
@@ -583,9 +583,9 @@ class Context:
         """extractCloud, equal curvatures inside a sector: True = the order the reference's std::sort leaves (default), False = (curvature, index)"""
         self._ck(self.lib.mlh_set_extract_tie_order(self.h, 1 if reference else 0))
 
-    def set_gn_schedule(self, deferred_finish=True, knn_warm_start=True):
+    def set_gn_schedule(self, deferred_finish=True, knn_warm_start=True, final_in_successor=True):
         """layout of a Gauss-Newton solve's iterations on the device (mlh_set_gn_schedule): results do not depend on it"""
-        self._ck(self.lib.mlh_set_gn_schedule(self.h, 1 if deferred_finish else 0, 1 if knn_warm_start else 0))
+        self._ck(self.lib.mlh_set_gn_schedule(self.h, 1 if deferred_finish else 0, 1 if knn_warm_start else 0, 1 if final_in_successor else 0))
 
     def set_voxel_member_order(self, mode):
         """voxel filters of this context, members of a voxel: True / 1 = in libstdc++'s std::sort order (the reference's), produced on the

@@ -142,39 +142,15 @@ __global__ void init_state_kernel(SolverState *S, PoseArg pose)
     if (threadIdx.x < 6) S->V[threadIdx.x * 7] = 1.0;
 }
 
-// The pose the mapper starts frame k+1 from, computed where frame k's result lives (lidar_mapper_keyframe.cpp:145-160): transformUpdate,
-// pose_wmap_wodom = pose_wmap_curr * pose_wodom_curr.inverse(), then transformAssociateToMap, pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr, with
-// Pose::operator* / Pose::inverse as pose.cpp:99-113 write them (both construct through Pose(q, t), which normalises the quaternion; Quaterniond::inverse is
-// conjugate / squaredNorm). One lane; the solve enqueued behind it reads S->x.
-__device__ inline void pose_ctor_qt(const q4 &q, const d3 &t, q4 &qo, d3 &to)
-{
-    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    qo = q4{q.x / n, q.y / n, q.z / n, q.w / n};
-    to = t;
-}
+// The pose the mapper starts frame k+1 from, computed where frame k's result lives (dev_math.hpp: chain_start_pose). One lane; the solve enqueued behind it reads S->x.
 __global__ void chain_pose_kernel(SolverState *S, PoseArg wodom_prev, PoseArg wodom_cur, HostPublish *start_out)
 {
     if (threadIdx.x != 0) return;
-    const q4 qc{S->x[3], S->x[4], S->x[5], S->x[6]};
-    const d3 tc{S->x[0], S->x[1], S->x[2]};
-    // pose_wodom_curr.inverse()
-    const q4 qp{wodom_prev.p[3], wodom_prev.p[4], wodom_prev.p[5], wodom_prev.p[6]};
-    const double n2 = qp.x * qp.x + qp.y * qp.y + qp.z * qp.z + qp.w * qp.w;
-    const q4 qinv = n2 > 0.0 ? q4{-qp.x / n2, -qp.y / n2, -qp.z / n2, qp.w / n2} : q4{0.0, 0.0, 0.0, 0.0};
-    const d3 mt = qrot(qinv, d3{wodom_prev.p[0], wodom_prev.p[1], wodom_prev.p[2]});
-    q4 qi; d3 ti;
-    pose_ctor_qt(qinv, d3{-mt.x, -mt.y, -mt.z}, qi, ti);
-    // pose_wmap_wodom = pose_wmap_curr * inverse
-    const d3 r1 = qrot(qc, ti);
-    q4 qw; d3 tw;
-    pose_ctor_qt(qmul(qc, qi), d3{r1.x + tc.x, r1.y + tc.y, r1.z + tc.z}, qw, tw);
-    // pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr (the next frame's)
-    const d3 r2 = qrot(qw, d3{wodom_cur.p[0], wodom_cur.p[1], wodom_cur.p[2]});
-    q4 qn; d3 tn;
-    pose_ctor_qt(qmul(qw, q4{wodom_cur.p[3], wodom_cur.p[4], wodom_cur.p[5], wodom_cur.p[6]}), d3{r2.x + tw.x, r2.y + tw.y, r2.z + tw.z}, qn, tn);
-    S->x[0] = tn.x; S->x[1] = tn.y; S->x[2] = tn.z; S->x[3] = qn.x; S->x[4] = qn.y; S->x[5] = qn.z; S->x[6] = qn.w;
-    for (int i = 0; i < 7; ++i) S->cand[i] = S->x[i];
-    if (start_out) for (int i = 0; i < 7; ++i) start_out->xb[1][i] = S->x[i];      // the frame's start pose, for a host that may have to solve the frame again
+    double xc[7], out[7];
+    for (int i = 0; i < 7; ++i) xc[i] = S->x[i];
+    chain_start_pose(xc, wodom_prev.p, wodom_cur.p, out);
+    for (int i = 0; i < 7; ++i) { S->x[i] = out[i]; S->cand[i] = out[i]; }
+    if (start_out) for (int i = 0; i < 7; ++i) start_out->xb[1][i] = out[i];      // the frame's start pose, for a host that may have to solve the frame again
 }
 
 __global__ void set_block_pose_kernel(SolverState *S, int b, PoseArg pose)
@@ -335,6 +311,7 @@ int mlh_create(mlh_ctx **out, int device_id)
     if (const char *e = std::getenv("MLH_KNN_LANES")) c->knn_lanes_override = std::atoi(e);
     if (const char *e = std::getenv("MLH_GN_DEFER")) c->gn_defer = std::atoi(e);
     if (const char *e = std::getenv("MLH_KNN_WARM")) c->knn_warm = std::atoi(e);
+    if (const char *e = std::getenv("MLH_GN_FINAL_DEFER")) c->gn_final_defer = std::atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
     *out = c;
     return MLH_OK;
@@ -850,12 +827,15 @@ int mlh_set_extract_tie_order(mlh_ctx *ctx, int mode)
     return MLH_OK;
 }
 
-int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start)
+int mlh_set_gn_schedule(mlh_ctx *ctx, int deferred_finish, int knn_warm_start, int final_in_successor)
 {
     if (!ctx) return MLH_ERR_INVALID;
-    if ((deferred_finish != 0 && deferred_finish != 1) || (knn_warm_start != 0 && knn_warm_start != 1)) return fail(ctx, MLH_ERR_INVALID, "schedule switches are 0 or 1");
+    if ((deferred_finish != 0 && deferred_finish != 1) || (knn_warm_start != 0 && knn_warm_start != 1) || (final_in_successor != 0 && final_in_successor != 1))
+        return fail(ctx, MLH_ERR_INVALID, "schedule switches are 0 or 1");
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
     ctx->gn_defer = deferred_finish;
     ctx->knn_warm = knn_warm_start;
+    ctx->gn_final_defer = final_in_successor;
     return MLH_OK;
 }
 
@@ -1252,6 +1232,7 @@ int mlh_gn_solve(mlh_ctx *ctx, double pose_inout[7], int n_iters, const mlh_solv
 {
     if (!ctx || !pose_inout || !opts || n_iters <= 0) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     int rc = ensure_state(ctx, n_iters);
     if (rc) return rc;
     const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
@@ -1328,28 +1309,59 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     }
     const unsigned long long seq = ctx->solve_seq + 1;
     ctx->solve_slot[seq & 1].kind = 0;
-    if (!pose_in) {                                // chained: the start pose is made on the device from the pose the previous solve left there
+    HostPublish *rec = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
+    const bool defer = n_iters >= 2 && gn_defer_applies(ctx, mask);
+    // The previous solve may have left its LAST iteration as tile records (gn_pending). A chained, deferred solve completes it in its own first launch -- unless this
+    // frame needs a larger record buffer (the records would not survive the reallocation); everything else completes it now, before the chain launch reads the pose.
+    size_t tiles_now = 0;
+    for (int k = 0; k < 2; ++k) if (mask & (1 << k)) tiles_now += size_t((ctx->feat[k].m + 255) / 256);
+    const bool consume = !pose_in && defer && ctx->gn_pending.active && sizeof(double) * NE_STRIDE * tiles_now <= ctx->partials.cap;
+    mlh_ctx::GnPending pend = ctx->gn_pending;
+    if (ctx->gn_pending.active && !consume && (rc = gn_flush_pending(ctx))) return rc;
+    if (!pose_in && !consume) {                    // chained: the start pose is made on the device from the pose the previous solve left there
         PoseArg pa, pb;
         for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
         hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, static_cast<HostPublish *>(nullptr));
         MLH_HIP(ctx, hipGetLastError());
     }
+    // this solve's own last iteration: left to a successor (or to mlh_gn_solve_end) when the schedule says so
+    const bool leave_final = defer && ctx->gn_final_defer;
+    const int base = ctx->gn_slot_base;
+    ctx->gn_slot_base ^= 2;
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
-        if (it == 0) a.init_pose = pose_in;        // null when chained: the kernels read the state's pose
+        if (it == 0) a.init_pose = pose_in;        // null when chained: the kernels read the state's pose (or compute it: `consume`)
         a.finish = 1;
         a.stat_slot = -1;
         a.warm = it >= 1 && ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi;
-        if (n_iters >= 2 && gn_defer_applies(ctx, mask)) {     // the finish moves into the next iteration's correspondence launch (see mlh_gn_solve)
-            a.gn_iter = it; a.gn_iters = n_iters;
+        if (defer) {     // the finish moves into the next iteration's correspondence launch (see mlh_gn_solve)
+            a.gn_iter = it; a.gn_iters = n_iters; a.gn_slot_base = base;
             if (it == 1) a.init_pose = pose_in;
-            if (it < n_iters - 1) a.finish = 0;
+            if (it < n_iters - 1 || leave_final) a.finish = 0;
+            if (consume) {
+                a.pre_final = true;                // iteration 0: complete the predecessor, publish its pose, chain; iterations >= 1: pose 0 sits in its slot
+                if (it == 0) {
+                    a.pre_final_tiles = pend.tiles; a.pre_final_slot = pend.slot; a.pre_final_thre = pend.thre; a.pre_final_freeze = pend.freeze;
+                    a.pre_final_publish = static_cast<HostPublish *>(pend.rec); a.pre_final_seq = pend.seq;
+                    a.chain_prev = wodom_prev; a.chain_cur = wodom_cur;
+                }
+            }
         }
-        if (it == n_iters - 1) {
-            a.publish = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
+        if (it == n_iters - 1 && !leave_final) {
+            a.publish = rec;
             a.publish_seq = seq;
         }
         if ((rc = match_launch(ctx, a))) return rc;
+        if (it == 0 && consume) ctx->gn_pending.active = false;       // consumed by the launch just enqueued
+    }
+    if (leave_final) {
+        ctx->gn_pending.active = true;
+        ctx->gn_pending.tiles = ctx->n_partial_tiles;
+        ctx->gn_pending.slot = base + ((n_iters - 1) & 1);
+        ctx->gn_pending.thre = opts->map_eig_thre;
+        ctx->gn_pending.freeze = 0;
+        ctx->gn_pending.rec = rec;
+        ctx->gn_pending.seq = seq;
     }
     ctx->solve_seq = seq;
     ctx->solve_pending = true;
@@ -1375,6 +1387,10 @@ int mlh_gn_solve_end(mlh_ctx *ctx, double pose_out[7])
     if (ctx->solve_seq == ctx->solve_collected) return fail(ctx, MLH_ERR_STATE, "no solve in flight (mlh_gn_solve_begin)");
     const unsigned long long seq = ctx->solve_collected + 1;        // the oldest one
     if (ctx->solve_slot[seq & 1].kind != 0) return fail(ctx, MLH_ERR_STATE, "the oldest solve in flight was submitted with mlh_scan2map_begin: collect it with mlh_scan2map_end");
+    if (ctx->gn_pending.active && ctx->gn_pending.seq == seq) {      // nobody chained a successor behind it: its last iteration is completed here
+        const int frc = gn_flush_pending(ctx);
+        if (frc) return frc;
+    }
     HostPublish hp;
     int rc = wait_published(ctx, seq, hp, static_cast<HostPublish *>(ctx->h_solve) + (seq & 1));
     ctx->solve_collected = seq;
@@ -1393,6 +1409,7 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
 {
     if (!ctx || !poses_inout || !opts || !bo || n_iters <= 0 || bo->n_blocks <= 0 || bo->n_blocks > 8) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     const int nb = bo->n_blocks;
     int rc = ensure_state(ctx, n_iters * nb);
     if (rc) return rc;
@@ -1432,6 +1449,7 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
 {
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     int rc = ensure_state(ctx, opts->max_outer);
     if (rc) return rc;
     // scan2MapOptimization runs only when the map has > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429)
@@ -1548,6 +1566,7 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     if (opts->max_outer <= 0) return fail(ctx, MLH_ERR_INVALID, "max_outer must be positive");
     if (ctx->solve_seq - ctx->solve_collected >= 2) return fail(ctx, MLH_ERR_STATE, "two solves are already in flight: collect the older one first");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     int rc = ensure_state(ctx, 0);
     if (rc) return rc;
     if (!ctx->h_solve) {
@@ -1938,6 +1957,7 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
 
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs)
 {
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     if (!ctx || kind < 0 || kind > 1 || !pose || !opts) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_state(ctx, 0);
@@ -1958,6 +1978,7 @@ int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_trac
 
 int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats)
 {
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0 || opts->max_lm_iterations <= 0) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     TrackSet &T = ctx->track;

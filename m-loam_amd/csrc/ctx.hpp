@@ -53,9 +53,10 @@ struct SolverState {
     int num_invalid;
     int evaluations;
     int lm_overflow;         // split-submission scan2map: an outer iteration was begun while the previous one's LM loop had not terminated inside its look-ahead budget
-    // Gauss-Newton with the finish deferred to the consumer (match.hip): iteration i's pose lives in xi[i & 1] -- written by ONE workgroup of iteration i's
-    // correspondence launch while the others may still be reading xi[(i - 1) & 1]
-    double xi[2][7];
+    // Gauss-Newton with the finish deferred to the consumer (match.hip): iteration i's pose of a solve lives in xi[base + (i & 1)] -- written by ONE workgroup of
+    // iteration i's correspondence launch while the others may still be reading xi[base + ((i - 1) & 1)]; consecutive solves alternate base 0 / 2 (a solve's first
+    // launch may still be reading the previous solve's last slot while it fills its own first one)
+    double xi[4][7];
     double lm_used_max;      // split-submission scan2map: the largest LM iteration count of the solve's outer iterations so far (the host sizes the next frame's look-ahead by it)
     double pad2[1];
 };
@@ -309,6 +310,17 @@ struct mlh_ctx {
     int fused_parts = 0;
     float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
     int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
+    int gn_final_defer = 1;       // MLH_GN_FINAL_DEFER=0: a solve submitted with mlh_gn_solve_begin* finishes its LAST iteration in its own fit launch (classic); 1: that
+                                  // iteration, too, only leaves its records -- the next mlh_gn_solve_begin_chained completes it in its first launch (and publishes the pose
+                                  // from there), mlh_gn_solve_end or any other solver call completes it with a one-workgroup launch if no successor did
+    struct GnPending {            // the last iteration of the newest submitted solve is still a set of tile records
+        bool active = false;
+        int tiles = 0, slot = 0, freeze = 0;
+        double thre = 100.0;
+        void *rec = nullptr;      // HostPublish of that solve
+        unsigned long long seq = 0;
+    } gn_pending;
+    int gn_slot_base = 0;         // xi slots of the next solve
     int gn_defer = 1;             // MLH_GN_DEFER=0: Gauss-Newton solves keep the classic finish (the fit kernel's last-arriving workgroup) in every iteration (A/B, tests)
     int knn_warm = 1;             // MLH_KNN_WARM=0: iterations >= 1 of a solve search without the previous iteration's neighbours as a bound (A/B, tests)
     // multi-GPU
@@ -486,11 +498,22 @@ struct MatchArgs {
     // the last only leaves its tiles' partial records; the correspondence kernel of iteration i >= 1 starts by summing them (every workgroup, same order, same
     // bits) and running the 6 x 6 solve + Plus itself. gn_iter < 0: the classic form (the fit kernel's last-arriving workgroup finishes).
     int gn_iter = -1, gn_iters = 0;
+    int gn_slot_base = 0;     // this solve's pair of SolverState::xi slots (0 or 2)
     bool warm = false;   // the neighbour records of the previous iteration (same features, same map) bound this iteration's search
+    // iteration 0 of a CHAINED solve that also completes the PREVIOUS solve, whose last iteration left only its tiles' records (mlh_ctx::gn_pending): every workgroup of
+    // this correspondence launch sums them, solves, applies Plus -> the previous frame's final pose; tile 0's workgroup publishes it to that solve's host record and
+    // stores it as the state's pose; then the chained start pose of THIS frame (transformUpdate + transformAssociateToMap) is computed from it, in every workgroup
+    bool pre_final = false;
+    int pre_final_tiles = 0, pre_final_slot = 0, pre_final_freeze = 0;
+    double pre_final_thre = 100.0;
+    HostPublish *pre_final_publish = nullptr;
+    unsigned long long pre_final_seq = 0;
+    const double *chain_prev = nullptr, *chain_cur = nullptr;   // host: the two odometry poses of the chain (7 doubles each)
     HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
     unsigned long long publish_seq = 0;
 };
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
+int gn_flush_pending(mlh_ctx *ctx);      // completes a pending last iteration with a one-workgroup launch (no-op when nothing is pending)
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
 // select.hip

@@ -445,4 +445,37 @@ __device__ inline void plane_fit_qr_f(const float (&ax)[ROWS], const float (&ay)
     nz = (p0 == 2) ? x0 : ((p1 == 2) ? x1 : x2);
 }
 
+
+// The pose the mapper starts frame k + 1 from, given frame k's result xc (lidar_mapper_keyframe.cpp:145-160): transformUpdate, pose_wmap_wodom = pose_wmap_curr *
+// pose_wodom_curr.inverse(), then transformAssociateToMap, pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr (the next frame's), with Pose::operator* / Pose::inverse
+// as pose.cpp:99-113 write them (both construct through Pose(q, t), which normalises the quaternion; Quaterniond::inverse is conjugate / squaredNorm). One lane.
+// Poses as [t, q(xyzw)].
+__device__ inline void pose_ctor_qt(const q4 &q, const d3 &t, q4 &qo, d3 &to)
+{
+    const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    qo = q4{q.x / n, q.y / n, q.z / n, q.w / n};
+    to = t;
+}
+__device__ inline void chain_start_pose(const double *xc, const double *wodom_prev, const double *wodom_cur, double *out)
+{
+    const q4 qc{xc[3], xc[4], xc[5], xc[6]};
+    const d3 tc{xc[0], xc[1], xc[2]};
+    // pose_wodom_curr.inverse()
+    const q4 qp{wodom_prev[3], wodom_prev[4], wodom_prev[5], wodom_prev[6]};
+    const double n2 = qp.x * qp.x + qp.y * qp.y + qp.z * qp.z + qp.w * qp.w;
+    const q4 qinv = n2 > 0.0 ? q4{-qp.x / n2, -qp.y / n2, -qp.z / n2, qp.w / n2} : q4{0.0, 0.0, 0.0, 0.0};
+    const d3 mt = qrot(qinv, d3{wodom_prev[0], wodom_prev[1], wodom_prev[2]});
+    q4 qi; d3 ti;
+    pose_ctor_qt(qinv, d3{-mt.x, -mt.y, -mt.z}, qi, ti);
+    // pose_wmap_wodom = pose_wmap_curr * inverse
+    const d3 r1 = qrot(qc, ti);
+    q4 qw; d3 tw;
+    pose_ctor_qt(qmul(qc, qi), d3{r1.x + tc.x, r1.y + tc.y, r1.z + tc.z}, qw, tw);
+    // pose_wmap_curr = pose_wmap_wodom * pose_wodom_curr (the next frame's)
+    const d3 r2 = qrot(qw, d3{wodom_cur[0], wodom_cur[1], wodom_cur[2]});
+    q4 qn; d3 tn;
+    pose_ctor_qt(qmul(qw, q4{wodom_cur[3], wodom_cur[4], wodom_cur[5], wodom_cur[6]}), d3{r2.x + tw.x, r2.y + tw.y, r2.z + tw.z}, qn, tn);
+    out[0] = tn.x; out[1] = tn.y; out[2] = tn.z; out[3] = qn.x; out[4] = qn.y; out[5] = qn.z; out[6] = qn.w;
+}
+
 }  // namespace mlh

@@ -224,6 +224,12 @@ struct KParams {
     double *x_next;          // the workgroup that serves tile 0 stores the new pose here (the fit kernel of the same iteration reads it as pose0)
     const double *pose0;     // block 0's pose of this launch when it is neither init_pose nor the state's x / cand (iterations >= 1 of a deferred-finish solve)
     int warm;                // the neighbour records hold the previous iteration's neighbours of the same features in the same map
+    // pre_finish == 2 (MatchArgs::pre_final): the records are the PREVIOUS solve's last iteration; its pose is published from here, then this frame's start pose chained from it
+    HostPublish *pre_publish;
+    unsigned long long pre_publish_seq;
+    double pre_thre;
+    int pre_freeze;
+    double chain_prev[7], chain_cur[7];
 };
 
 __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
@@ -373,13 +379,67 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
     }
 }
 
+// The prologue of a correspondence launch that completes a Gauss-Newton iteration first (all TPB threads of the workgroup, converged):
+//   s_pose <- the pose that iteration linearised at; the records its fit launch left are summed (sum_partials<TPB, 12>'s arithmetic -- same slices, same four chains,
+//   same association: the same bits --, inlined: the record loads leave at once instead of behind an argument block's trip through scratch, and nobody waits for the
+//   per-kind counts, which only statistics read); gn_finish_wave solves and applies Plus on the first wavefront; s_pose holds the updated pose when this returns.
+// MODE 1: an iteration of the running solve. MODE 2: the LAST iteration of the PREVIOUS solve (thresholds from the launch arguments).
+template <int MODE>
+__device__ __forceinline__ void gn_prologue(const KParams &P, double *s_pose, double *f_ne, double *f_cnt2, double *f_scratch)
+{
+    if (threadIdx.x < 7) s_pose[threadIdx.x] = P.pre_from_init ? P.init_pose[threadIdx.x] : P.x_prev[threadIdx.x];
+    {
+        constexpr int NS = TPB / 32, U = 12;
+        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, ntot = P.pre_tiles;
+        const double *__restrict__ rec = P.partials;
+        double ch[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = sl; j < ntot; j += U * NS) {
+            double tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + NS * u;
+                tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
+        }
+        f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double tsum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
+            f_ne[c] = tsum;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        double xo[7];
+        gn_finish_wave(f_ne, f_cnt2, s_pose, nullptr, MODE == 2 ? P.pre_thre : P.thre_b[0], MODE == 2 ? P.pre_freeze : P.freeze_b[0], nullptr, f_scratch, xo);
+    }
+    __syncthreads();
+}
+
+// the previous solve's pose, final now: to its host record (seq stored last, system-scope release) and to the state. One thread of ONE workgroup.
+__device__ __forceinline__ void publish_final_pose(const KParams &P, const double *s_pose)
+{
+    for (int i = 0; i < 7; ++i) P.state->x[i] = s_pose[i];
+    if (P.pre_publish) {
+        for (int i = 0; i < 7; ++i) P.pre_publish->x[i] = s_pose[i];
+        __hip_atomic_store(&P.pre_publish->seq, P.pre_publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // G = lanes per query for both kinds, or 0: per kind (KindP::lanes -- a workgroup serves one kind, so the choice is uniform over it)
-// PRE: the launch completes the previous Gauss-Newton iteration first -- EVERY workgroup sums the records the previous fit launch's tiles left (same order,
+// PRE 1: the launch completes the previous Gauss-Newton iteration first -- EVERY workgroup sums the records the previous fit launch's tiles left (same order,
 //   same code: the same bits everywhere), runs the 6 x 6 solve + Plus on one wavefront and goes on with the pose in LDS; the kernel boundary behind the fit
 //   launch is the only synchronisation (no ticket, no fence, no last workgroup whose serial tail the other 255 compute units wait for). The workgroup of
 //   tile 0 leaves the pose in HBM for the fit kernel of this iteration.
-// WARM: the search is bounded by the previous iteration's neighbours (knn_feature_warm). Both only in the single-block, K = 5 launches of mlh_gn_solve*.
-template <int G, bool MB, bool K10, bool PRE = false, bool WARM = false>
+// PRE 2: iteration 0 of a chained solve whose predecessor left its LAST iteration as records: the same prologue completes that solve (tile 0's workgroup publishes its
+//   pose to the host and stores it as the state's), then every workgroup computes this frame's chained start pose from it (chain_start_pose, one lane) -- the
+//   predecessor's serial finish and the chain launch between the two frames are gone.
+// WARM: the search is bounded by the previous iteration's neighbours (knn_feature_warm). All three only in the single-block, K = 5 launches of mlh_gn_solve*.
+template <int G, bool MB, bool K10, int PRE = 0, bool WARM = false>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
     __shared__ int s_run[(G == 16) ? (TPB / 16) * 2 * KNN_RUN_WORDS : (TPB / 8) * 2 * KNN_RUN_WORDS];
@@ -387,52 +447,43 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = xcd_tile(total);
     if (tile >= total) return;
-    if constexpr (PRE) {
+    if constexpr (PRE != 0) {
         __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
-        if (threadIdx.x < 7) s_pose[threadIdx.x] = P.pre_from_init ? P.init_pose[threadIdx.x] : P.x_prev[threadIdx.x];
-        // sum_partials<TPB, 12>'s arithmetic (same slices, same four chains, same association: the same bits), inlined: the record loads leave at once instead of
-        // behind the argument block's trip through scratch, and nobody waits for the per-kind counts (statistics only)
-        {
-            constexpr int NS = TPB / 32, U = 12;
-            const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, ntot = P.pre_tiles;
-            const double *__restrict__ rec = P.partials;
-            double ch[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int j = sl; j < ntot; j += U * NS) {
-                double tv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int jj = j + NS * u;
-                    tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
-            }
-            f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
-            __syncthreads();
-            if (threadIdx.x < 32) {
-                double tsum = 0.0;
-#pragma unroll
-                for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
-                f_ne[c] = tsum;
+        gn_prologue<PRE>(P, s_pose, f_ne, f_cnt2, f_scratch);
+        if constexpr (PRE == 2) {
+            __shared__ double s_chain[8];
+            if (threadIdx.x == 0) {
+                if (tile == 0) publish_final_pose(P, s_pose);
+                double xc[7], out[7];
+                for (int i = 0; i < 7; ++i) xc[i] = s_pose[i];
+                double cp[7], cc[7];
+                for (int i = 0; i < 7; ++i) { cp[i] = P.chain_prev[i]; cc[i] = P.chain_cur[i]; }
+                chain_start_pose(xc, cp, cc, out);
+                for (int i = 0; i < 7; ++i) s_chain[i] = out[i];
             }
             __syncthreads();
+            if (threadIdx.x < 7) s_pose[threadIdx.x] = s_chain[threadIdx.x];
+            __syncthreads();
         }
-        if (threadIdx.x < 64) {
-            double xo[7];
-            gn_finish_wave(f_ne, f_cnt2, s_pose, nullptr, P.thre_b[0], P.freeze_b[0], nullptr, f_scratch, xo);
-        }
-        __syncthreads();
         if (tile == 0 && threadIdx.x < 7) P.x_next[threadIdx.x] = s_pose[threadIdx.x];
     }
     const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
     if (kind) tile -= P.k[0].tiles_a;
     const KindP &K = P.k[kind];
     if constexpr (G == 0) {
-        if (K.lanes == 8) knn_features_body<8, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
-        else knn_features_body<16, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
+        if (K.lanes == 8) knn_features_body<8, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
+        else knn_features_body<16, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
     } else {
-        knn_features_body<G, MB, K10, PRE, WARM>(P, K, tile, s_run, s_pose);
+        knn_features_body<G, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
     }
+}
+
+// a pending last iteration completed by itself (no chained successor took it): one workgroup, the same prologue, the same publication
+__global__ __launch_bounds__(TPB) void gn_final_kernel(KParams P)
+{
+    __shared__ double s_pose[8], f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
+    gn_prologue<2>(P, s_pose, f_ne, f_cnt2, f_scratch);
+    if (threadIdx.x == 0) publish_final_pose(P, s_pose);
 }
 
 // the reference's plane fit + gate (feature_extract.hpp:816-840)
@@ -621,7 +672,13 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
     }
     if (threadIdx.x == 0) {
         *P.ticket = 0u;
+#if defined(MLH_EXP) && MLH_EXP == 5
+        if (P.publish) __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#elif defined(MLH_EXP) && MLH_EXP == 6
+        (void)0;
+#else
         if (P.publish) __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     }
 }
 
@@ -640,7 +697,9 @@ __device__ __forceinline__ bool fit_feature(const KParams &P, int kind, const fl
 // ---- fit + gates + residual/Jacobian + normal-equation reduction: one lane per feature, both kinds in one launch
 // KMAX = the largest N_NEIGH of the launch: with 5 (every mapper launch) the 10-neighbour fits are not compiled in, which halves
 // the kernel's register footprint (occupancy matters once a launch has more workgroups than the chip holds at once)
-template <int KMAX, bool LM>
+// FIN = false: the launch only leaves its tiles' partial records (a deferred-finish Gauss-Newton iteration, or a caller that reduces elsewhere): no ticket, no
+// finishing workgroup, and none of that code in the kernel
+template <int KMAX, bool LM, bool FIN = true>
 __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
@@ -707,7 +766,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     MLH_STAGE(gtile, 2);
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
     MLH_STAGE(gtile, 3);
-    if (P.finish) fused_gn_finish<LM>(P, total);
+    if constexpr (FIN) { if (P.finish) fused_gn_finish<LM>(P, total); }
     MLH_STAGE(gtile, 4);
 }
 
@@ -827,6 +886,9 @@ void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
 
 static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
 {
+    // a solve whose last iteration is still a set of tile records (mlh_ctx::gn_pending): any launch that writes records -- other than the chained successor's first,
+    // which consumes them -- completes that solve first
+    if (ctx->gn_pending.active && !a.pre_final) { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
     std::memset(&P, 0, sizeof(P));
     int tiles_b_total = 0;
     P.n_blocks = a.n_blocks > 0 ? a.n_blocks : 1;
@@ -907,16 +969,33 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
     P.warm = a.warm ? 1 : 0;
     if (a.gn_iter >= 1) {
-        // iteration i >= 1 of a deferred-finish solve: the correspondence kernel turns iteration i - 1's records and pose into pose i (SolverState::xi[i & 1]);
-        // iteration 1 finds pose 0 where iteration 0 found it -- the kernel arguments, or the state's x (a chained solve)
+        // iteration i >= 1 of a deferred-finish solve: the correspondence kernel turns iteration i - 1's records and pose into pose i (SolverState::xi[base + (i & 1)]);
+        // iteration 1 finds pose 0 where iteration 0 found it -- the kernel arguments, the state's x (a chained solve behind a chain launch), or iteration 0's slot
+        // (a chained solve whose first launch computed the start pose itself, MatchArgs::pre_final)
         SolverState *S = ctx->state.as<SolverState>();
         P.pre_finish = 1;
         P.pre_tiles = tiles_b_total;
         P.pre_from_init = (a.gn_iter == 1 && a.init_pose) ? 1 : 0;
-        P.x_prev = a.gn_iter == 1 ? S->x : S->xi[(a.gn_iter - 1) & 1];
-        P.x_next = S->xi[a.gn_iter & 1];
-        P.pose0 = S->xi[a.gn_iter & 1];
+        P.x_prev = (a.gn_iter == 1 && !a.pre_final) ? S->x : S->xi[a.gn_slot_base + ((a.gn_iter - 1) & 1)];
+        P.x_next = S->xi[a.gn_slot_base + (a.gn_iter & 1)];
+        P.pose0 = S->xi[a.gn_slot_base + (a.gn_iter & 1)];
         P.use_init = 0;
+    } else if (a.gn_iter == 0 && a.pre_final) {
+        // iteration 0 of a chained solve that completes its predecessor first (knn_features_kernel<.., PRE = 2>): the predecessor's records, thresholds, last pose slot
+        // and host record; this frame's start pose goes to xi[base] (the fit kernel of this iteration and iteration 1's prologue read it there)
+        SolverState *S = ctx->state.as<SolverState>();
+        P.pre_finish = 2;
+        P.pre_tiles = a.pre_final_tiles;
+        P.pre_from_init = 0;
+        P.x_prev = S->xi[a.pre_final_slot];
+        P.x_next = S->xi[a.gn_slot_base];
+        P.pose0 = S->xi[a.gn_slot_base];
+        P.use_init = 0;
+        P.pre_publish = a.pre_final_publish;
+        P.pre_publish_seq = a.pre_final_seq;
+        P.pre_thre = a.pre_final_thre;
+        P.pre_freeze = a.pre_final_freeze;
+        for (int i = 0; i < 7; ++i) { P.chain_prev[i] = a.chain_prev[i]; P.chain_cur[i] = a.chain_cur[i]; }
     }
     P.publish = (a.finish == 1 || a.finish == 4) ? a.publish : nullptr;
     P.publish_seq = a.publish_seq;
@@ -933,6 +1012,27 @@ static void launch_timed(mlh_ctx *ctx, int kid, Kern kern, int grid, const KPara
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, a, b, 0, P);   // start/stop = the dispatch's own timestamps
     else
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, P);
+}
+
+int gn_flush_pending(mlh_ctx *ctx)
+{
+    if (!ctx || !ctx->gn_pending.active) return MLH_OK;
+    KParams P;
+    std::memset(&P, 0, sizeof(P));
+    SolverState *S = ctx->state.as<SolverState>();
+    P.partials = ctx->partials.as<double>();
+    P.state = S;
+    P.pre_finish = 2;
+    P.pre_tiles = ctx->gn_pending.tiles;
+    P.x_prev = S->xi[ctx->gn_pending.slot];
+    P.pre_publish = static_cast<HostPublish *>(ctx->gn_pending.rec);
+    P.pre_publish_seq = ctx->gn_pending.seq;
+    P.pre_thre = ctx->gn_pending.thre;
+    P.pre_freeze = ctx->gn_pending.freeze;
+    ctx->gn_pending.active = false;
+    launch_timed(ctx, MLH_K_SOLVE, gn_final_kernel, 1, P);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
 }
 
 int match_launch(mlh_ctx *ctx, const MatchArgs &a)
@@ -953,9 +1053,10 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             else { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false>, grid_a, P); } \
         } while (0)
 #define MLH_KNN_LAUNCH_GN(G_) do { \
-            if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, true, true>, grid_a, P); \
-            else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, true, false>, grid_a, P); \
-            else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, false, true>, grid_a, P); \
+            if (P.pre_finish == 2) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 2, false>, grid_a, P); \
+            else if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 1, true>, grid_a, P); \
+            else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 1, false>, grid_a, P); \
+            else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, 0, true>, grid_a, P); \
         } while (0)
         if (P.pre_finish || P.warm) {
             if (mb || k10) return fail(ctx, MLH_ERR_UNSUPPORTED, "the deferred finish / the bounded search are single-block, N_NEIGH = 5");
@@ -973,6 +1074,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");
         launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, true>, grid_b, P);
     } else if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10, false>, grid_b, P);
+    else if (P.finish == 0) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false, false>, grid_b, P);
     else launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < 2; ++k) if (a.kind_mask & (1 << k)) ctx->feat[k].matched = true;

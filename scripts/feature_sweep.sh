@@ -36,7 +36,7 @@ for label in "thin_2x64 --lidars 2" "dense_4x64 --lidars 4 --dense-features"; do
   i=0
   for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${name}_$i -o pmc -- python $REPO/bench.py --steps 12 --warmup 2 --no-cpu-baseline --profile-events 0 --synchronous "$@" > /dev/null 2> $OUT/pmc_${name}_$i.log
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${name}_$i -o pmc -- python $REPO/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-supplementary --profile-events 0 --synchronous "$@" > /dev/null 2> $OUT/pmc_${name}_$i.log
     DBP=$(find $OUT/pmc_${name}_$i -name '*.db' | head -1)
     [ -n "$DBP" ] && python $REPO/profiles/summarize_pmc.py $DBP knn_features_kernel > $OUT/pmc_${name}_$i.txt
     rm -rf $OUT/pmc_${name}_$i

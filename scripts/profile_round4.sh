@@ -6,11 +6,13 @@ TAG=${1:-r04}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
+if [ -z "$ONLY_TRACES" ]; then
 timeout 400 python bench.py --steps 200 --warmup 20 > $OUT/bench_line.json 2> $OUT/bench.log
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --synchronous > $OUT/bench_synchronous.json 2>> $OUT/bench.log
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-overlap-staging > $OUT/bench_no_overlap_staging.json 2>> $OUT/bench.log
+fi
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-supplementary"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_line_under_trace.json 2> $OUT/trace.log
 DB=$(find $OUT/trace -name '*.db' | head -1)
 if [ -n "$DB" ]; then
@@ -22,7 +24,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --
 DB=$(find $OUT/trace -name '*.db' | head -1)
 [ -n "$DB" ] && python $REPO/profiles/summarize_rocprof.py $DB > $OUT/kernel_stats_synchronous.txt
 rm -rf $OUT/trace
-PMCB="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --profile-events 0 --synchronous"
+PMCB="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-supplementary --profile-events 0 --synchronous"
 i=0
 for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
   i=$((i+1))
@@ -32,6 +34,7 @@ for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_
   rm -rf $OUT/pmc$i
 done
 cd $REPO
+[ -n "$ONLY_TRACES" ] && { head -12 $OUT/kernel_stats.txt; head -10 $OUT/kernel_stats_synchronous.txt; exit 0; }
 timeout 300 python scripts/framebench.py < /dev/null > $OUT/framebench.txt 2>&1
 timeout 200 python scripts/calibbench.py < /dev/null > $OUT/calibbench.txt 2>&1
 timeout 200 python scripts/trackbench.py < /dev/null > $OUT/trackbench.txt 2>&1

@@ -112,11 +112,11 @@ def test_gn_schedule_variants_agree_bit_for_bit(mla, orc, case16, feats16, n_ite
     the statistics path (always the classic finish) and the split / chained submissions give the SAME pose bits; the oracle agrees to 1e-7."""
     ref = orc.gn_iterations(orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"]), feats16[0], feats16[1], case16["p0"], orc.mapper_params(), n_iters)
     poses = {}
-    for defer in (0, 1):
-        for warm in (0, 1):
+    for defer, warm, final in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)):
+        if True:
             c = mla.Context(0)
             try:
-                c.set_gn_schedule(defer, warm)
+                c.set_gn_schedule(defer, warm, final)
                 _stage(c, mla, case16, feats16)
                 p_plain = c.gn_solve(case16["p0"], n_iters, want_stats=False)[0]
                 p_stats, st = c.gn_solve(case16["p0"], n_iters, want_stats=True)
@@ -130,15 +130,67 @@ def test_gn_schedule_variants_agree_bit_for_bit(mla, orc, case16, feats16, n_ite
                 p_restart = c.gn_solve_end()
             finally:
                 c.close()
-            assert np.array_equal(p_plain, p_stats) and np.array_equal(p_plain, p_split), (defer, warm)
+            assert np.array_equal(p_plain, p_stats) and np.array_equal(p_plain, p_split), (defer, warm, final)
             # the chained solve starts from Pose(q, t) products of the previous result (normalisations): equal to a restart from that result to rounding
-            assert float(np.abs(p_chain - p_restart).max()) < 1e-12, (defer, warm)
+            assert float(np.abs(p_chain - p_restart).max()) < 1e-12, (defer, warm, final)
             assert [(x["n_surf"], x["n_corner"]) for x in st] == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]]
-            poses[(defer, warm)] = p_plain
+            poses[(defer, warm, final)] = (p_plain, p_chain)
     for k, v in poses.items():
-        assert np.array_equal(v, poses[(0, 0)]), k
-    dt, dr = _pose_err(poses[(1, 1)], ref["pose"])
+        assert np.array_equal(v[0], poses[(0, 0, 0)][0]) and np.array_equal(v[1], poses[(0, 0, 0)][1]), k
+    dt, dr = _pose_err(poses[(1, 1, 1)][0], ref["pose"])
     assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+
+
+def test_gn_last_iteration_completed_by_the_successor_or_by_whoever_comes_next(mla, case16, feats16):
+    """final_in_successor: a submitted solve leaves its LAST iteration as records. Whoever comes next completes it -- a chained successor in its first launch (two
+    frames in flight, both poses bit-equal to the classic schedule), mlh_gn_solve_end by itself, or any other solver call (a synchronous solve, scan2map, a new
+    unchained submission, a feature set with MORE tiles than the record buffer holds) -- and the pose is the classic one every time."""
+    p0 = case16["p0"]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    ref = {}
+    for final in (0, 1):
+        c = mla.Context(0)
+        try:
+            c.set_gn_schedule(1, 1, final)
+            _stage(c, mla, case16, feats16)
+            out = {}
+            # three frames pipelined: k + 1 submitted (chained) before k is collected
+            c.gn_solve_begin(p0, 5)
+            c.gn_solve_begin_chained(ident, ident, 5)
+            a = c.gn_solve_end()
+            c.gn_solve_begin_chained(ident, ident, 5)
+            b = c.gn_solve_end()
+            d = c.gn_solve_end()
+            out["pipeline"] = np.stack([a, b, d])
+            # collected with nothing chained behind it
+            c.gn_solve_begin(p0, 5)
+            out["alone"] = c.gn_solve_end()
+            # a synchronous solve / scan2map / an unchained submission arrive while the last iteration is still pending
+            c.gn_solve_begin(p0, 5)
+            out["sync_after"] = c.gn_solve(out["alone"], 2, want_stats=False)[0]
+            out["pending_1"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            out["s2m_after"] = c.scan2map(p0, want_stats=False)[0]
+            out["pending_2"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            c.gn_solve_begin(out["alone"], 3)
+            out["pending_3"] = c.gn_solve_end()
+            out["unchained_after"] = c.gn_solve_end()
+            # the next frame has many more features than the record buffer was sized for: the records must not be lost to the reallocation
+            c.gn_solve_begin(p0, 5)
+            big_s = np.ascontiguousarray(np.tile(feats16[0], (12, 1)))
+            big_c = np.ascontiguousarray(np.tile(feats16[1], (12, 1)))
+            c.features_set(mla.SURF, big_s); c.features_set(mla.CORNER, big_c)
+            c.gn_solve_begin_chained(ident, ident, 2)
+            out["pending_4"] = c.gn_solve_end()
+            out["big_after"] = c.gn_solve_end()
+            ref[final] = out
+        finally:
+            c.close()
+    for k in ref[0]:
+        assert np.array_equal(ref[0][k], ref[1][k]), k
+    for k in ("pending_1", "pending_2", "pending_3", "pending_4"):
+        assert np.array_equal(ref[1][k], ref[1]["alone"]), k
 
 
 def test_gn_deferred_finish_on_a_degenerate_problem(mla, orc, synth):
