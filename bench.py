@@ -631,15 +631,22 @@ def main():
     drain()
     sync_all()
     ms_per_step_all_events = 1e3 * (time.perf_counter() - t1) / n_prof
-    prof = {k: ctx.profile_get(k) for k in range(8)}
+    prof = {k: ctx.profile_get(k) for k in range(9)}
     ctx.profile_enable(0)
     # the same frames submitted synchronously (pose read before the next frame's staging is enqueued): what rounds 1 and 2 reported
+    # (this loop also brackets iteration 0's launch -- the search alone, which a pipelined, chained frame no longer has: its first launch completes the previous frame)
+    ctx.profile_enable((1 << mla.K_KNN) if args.profile_events else 0)
+    ctx.profile_sample(3)
+    ctx.profile_reset()
     sync_all()
     t1s = time.perf_counter()
     for _ in range(n_prof):
         step_sync()
     sync_all()
     ms_per_step_sync = 1e3 * (time.perf_counter() - t1s) / n_prof
+    cold_sync = ctx.profile_get(mla.K_KNN)
+    ctx.profile_enable(0)
+    ctx.profile_sample(1)
 
     # the same timed loop at the reference's keyframe cadences (a frame is saved as a keyframe after DISTANCE_KEYFRAMES = 1 m or ORIENTATION_KEYFRAMES = 1 deg of motion,
     # config_realvehicle_hercules.yaml:142-143: every frame for a vehicle at >= 10 m/s and 10 Hz, every ~10th at walking pace): the frame after a keyframe cannot have
@@ -781,6 +788,8 @@ def main():
                              "nothing -- the duration is the dependent chain feature -> cell_start words -> candidate trips (median workgroup 3.3 us, slowest 7.0) -> "
                              "winner gather -> store. `frac` is reported against the HBM peak because that is the contract's roof; it is not the binding one")
         so_ms, so_n = knn_forms_main.get("search_only", (0, 0))
+        if cold_sync[1] > so_n:        # pipelined, chained frames: iteration 0's plain launch only exists in the synchronous pass
+            so_ms, so_n = cold_sync
         if _pre and so_n > 0:
             so_s = 1e-3 * so_ms / so_n
             roofline["search_only_launch"] = dict(kernel="knn_features_kernel (iteration 0's launch: the search alone, no prologue, no bound from a previous iteration -- the kernel rounds 1-3 reported)",
@@ -968,6 +977,7 @@ def main():
                    kernel_us_per_launch={name: (round(1e3 * prof[k][0] / prof[k][1], 3) if prof[k][1] else None)
                                          for name, k in (("knn_features (surf+corner)", mla.K_KNN),
                                                          ("knn_features behind the previous iteration's finish (iterations >= 1)", mla.K_KNN_PRE),
+                                                         ("knn_features of a chained frame's iteration 0 (previous frame's final + publication + chain, then the cold search)", mla.K_KNN_FIRST),
                                                          ("fit_linearize+gn_finish (surf+corner)", mla.K_FIT),
                                                          ("map_index_build (both maps, 4 launches)", mla.K_GRID_BUILD))},
                    multi_gpu=(None if world == 1 else dict(

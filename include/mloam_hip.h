@@ -72,7 +72,9 @@ enum {
     MLH_K_ALLREDUCE = 6,     /* the RCCL all-reduce of the packed normal equations (N > 1)                                     */
     MLH_K_KNN_PRE = 7,       /* the correspondence kernel of iterations >= 1 of a deferred-finish Gauss-Newton solve: the same search (bounded by the previous
                                 iteration's neighbours) behind the prologue that completes the previous iteration (sum of the tiles' records, 6x6 solve, Plus)          */
-    MLH_K_COUNT = 8
+    MLH_K_KNN_FIRST = 8,     /* the correspondence kernel of iteration 0 of a CHAINED solve that completes its predecessor first (final_in_successor): the predecessor's last
+                                iteration summed, solved and published, this frame's start pose chained from it, then the cold search                                        */
+    MLH_K_COUNT = 9
 };
 /* kernel_mask: bit k enables the brackets of kernel id k (0 = profiling off, -1 = all) */
 int mlh_profile_enable(mlh_ctx *ctx, int kernel_mask);

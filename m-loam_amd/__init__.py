@@ -23,8 +23,8 @@ ALL_KINDS = -1
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_CHECK_FOV, FLAG_WITH_UA, FLAG_NO_LOSS = 1, 2, 4
 GF_METHODS = {"wo_gf": 0, "rnd": 1, "fps": 2, "gd_fix": 3, "gd_float": 4}
-K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT, K_ALLREDUCE, K_KNN_PRE = range(8)
-K_ALL = 0xFF
+K_KNN, K_FIT, K_LINEARIZE, K_SOLVE, K_GRID_BUILD, K_EXTRACT, K_ALLREDUCE, K_KNN_PRE, K_KNN_FIRST = range(9)
+K_ALL = 0x1FF
 
 
 class MlhError(RuntimeError):

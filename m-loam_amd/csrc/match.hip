@@ -1053,7 +1053,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             else { if (k10) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, true>, grid_a, P); else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false>, grid_a, P); } \
         } while (0)
 #define MLH_KNN_LAUNCH_GN(G_) do { \
-            if (P.pre_finish == 2) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 2, false>, grid_a, P); \
+            if (P.pre_finish == 2) launch_timed(ctx, MLH_K_KNN_FIRST, knn_features_kernel<G_, false, false, 2, false>, grid_a, P); \
             else if (P.pre_finish && P.warm) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 1, true>, grid_a, P); \
             else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 1, false>, grid_a, P); \
             else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, 0, true>, grid_a, P); \

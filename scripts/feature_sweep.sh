@@ -16,8 +16,9 @@ try:
     r, k, c = d["roofline"], d["kernel_us_per_launch"], d["config"]
     so = r.get("search_only_launch") or {}
     pre = next((v for kk, v in k.items() if "behind" in kk and v), 0.0)
+    first = next((v for kk, v in k.items() if "chained frame" in kk and v), 0.0)
     print(f"{sys.argv[1]:14s} features {c['features_surf'] + c['features_corner']:7d} (surf {c['features_surf']:6d} corner {c['features_corner']:6d})  ms/step {d['ms_per_step']:.4f}  "
-          f"knn cold {k['knn_features (surf+corner)']:8.2f} us  knn+finish {pre:8.2f} us  fit {k['fit_linearize+gn_finish (surf+corner)']:8.2f} us  "
+          f"knn cold {so.get('avg_kernel_us') or k['knn_features (surf+corner)']:8.2f} us  knn+finish {pre:8.2f} us  knn first-of-frame {first:8.2f} us  fit {k['fit_linearize+gn_finish (surf+corner)']:8.2f} us  "
           f"frac {r['frac']:.3f}  unavoidable {r['unavoidable_frac']:.3f}  search-only frac {so.get('frac', float('nan')):.3f}  bytes/launch {r['algorithmic_bytes_per_launch'] / 1e6:7.1f} MB  C-bar {r['mean_candidates_per_feature']}")
 except Exception as e:
     print(sys.argv[1], "FAILED", repr(e), open(sys.argv[2].replace('.json', '.err')).read()[-400:])
