@@ -804,9 +804,11 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("workload") in (f"{N_LIDARS}x{N_RINGS}_vs_{preset}_r02", f"{N_LIDARS}x{N_RINGS}_vs_{preset}_r03") and world == 1 and not args.dense_features:
+                if pmc.get("workload", "").startswith(f"{N_LIDARS}x{N_RINGS}_vs_{preset}_r") and world == 1 and not args.dense_features and args.lidars == N_LIDARS:
                     roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
                     roofline["traffic_source"] = pmc.get("source")
+                    if "search_only_launch" in roofline and "search_only_kernel" in pmc:
+                        roofline["search_only_launch"]["traffic"] = pmc["search_only_kernel"].get("hbm_bytes_per_launch")
                     if pmc.get("valu_issue_utilisation") is not None:
                         roofline["valu_issue_utilisation"] = pmc.get("valu_issue_utilisation")      # SQ_INSTS_VALU x 4 cycles / (SIMDs x busy cycles), offline pass
                         roofline["valu_insts_per_launch"] = pmc.get("valu_insts_per_launch")

@@ -420,9 +420,12 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     sb.voxelised = false;
     sb.h_lists_valid = sb.h_vox_valid = false;
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
-    // A caller's PAGEABLE buffer (a ROS message) is copied into a pinned block the context owns -- two halves, an event per half -- and goes to the device from
-    // there: the call returns without waiting for the stream, and the caller's buffer is free the moment it does, whatever the runtime does with pageable
-    // sources of an asynchronous copy. (A buffer the caller pinned is copied from in place; that case waits below.)
+    // A caller's PAGEABLE buffer (a ROS message) goes through hipMemcpyAsync as it is: like cudaMemcpyAsync, the call returns once the pageable source has been
+    // copied into the runtime's own staging memory (the DMA to the device may still be in flight), so the buffer is the caller's again when this call returns,
+    // and nothing here waits for the stream. MLH_SCAN_STAGE_PINNED=1 makes that independent of the runtime: the points are first copied into a pinned block the
+    // context owns (two halves, an event per half) and go to the device from there -- measured +0.08 ms per two-LiDAR frame (the runtime writes small pageable
+    // copies faster than an explicit memcpy + DMA pair: scripts/framebench.py, C++ leg, 0.859 against 0.940 ms, two alternations), hence not the default.
+    // (A buffer the caller pinned is copied from in place; that case waits below.)
     const void *src_points = points;
     bool caller_pinned = false;
     int pts_half = -1;
@@ -430,7 +433,8 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
         hipPointerAttribute_t at;
         caller_pinned = hipPointerGetAttributes(&at, points) == hipSuccess && at.type == hipMemoryTypeHost;
         (void)hipGetLastError();
-        if (!caller_pinned) {
+        static const bool stage_pinned = std::getenv("MLH_SCAN_STAGE_PINNED") && std::atoi(std::getenv("MLH_SCAN_STAGE_PINNED")) != 0;
+        if (!caller_pinned && stage_pinned) {
             const size_t bytes = size_t(n) * stride_bytes;
             if (bytes > ctx->h_pts_cap) {
                 MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));

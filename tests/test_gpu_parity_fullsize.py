@@ -237,6 +237,32 @@ def test_config4_scan_full_size(mla, orc, synth, cfg45):
     c.close()
 
 
+def test_scan2map_against_the_references_own_lines_at_config2(mla, orc, cfg2):
+    """The per-frame call itself at BASELINE config 2's size, with no restatement in between: `scan2MapOptimization` compiled from the reference's OWN lines
+    (lidar_mapper_keyframe.cpp:423-639 over the Ceres-shaped shim, oracle/_ref) on the 500 k map against the HIP path -- synchronous (mlh_scan2map) and
+    submitted / collected separately (mlh_scan2map_begin / _end): the same number of residual blocks and LM iterations in both outer iterations, the same pose."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libmloam_ref.so has not been built (needs /root/reference once)")
+    ref = orc.ref_scan2map(cfg2["surf_map"], cfg2["corner_map"], cfg2["surf"], cfg2["corner"], cfg2["p0"])
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(cfg2["surf_map"], cfg2["corner_map"])
+        c.features_set(mla.SURF, cfg2["surf"])
+        c.features_set(mla.CORNER, cfg2["corner"])
+        pose, st = c.scan2map(cfg2["p0"])
+        c.scan2map_begin(cfg2["p0"])
+        pose_split, status = c.scan2map_end()
+    finally:
+        c.close()
+    assert len(ref["solves"]) == len(st) == 2
+    for g, h in zip(ref["solves"], st):
+        assert g["n_blocks"] == h["n_surf"] + h["n_corner"] and g["n_blocks"] > 10000
+        assert (g["lm_iterations"], g["successful_steps"], g["termination"]) == (h["lm_iterations"], h["successful_steps"], h["termination"])
+        assert abs(g["initial_cost"] - h["cost"]) <= 1e-9 * max(1.0, g["initial_cost"])
+    assert float(np.abs(pose - ref["pose"]).max()) < 1e-9
+    assert status == 0 and np.array_equal(pose_split, pose)
+
+
 def test_extract_against_the_references_own_lines(mla, orc, cfg2):
     """the HIP extractCloud against oracle/_ref -- FeatureExtract::extractCloud compiled from the reference's own source lines
     (oracle/ref/build_ref.py; the prebuilt library travels to the GPU box) -- on both 64-ring scans: the same feature points in the same order."""

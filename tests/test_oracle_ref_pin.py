@@ -688,6 +688,24 @@ def test_scan2map_optimization_is_the_references(ref, synth, case16, feats16, wi
         assert not got["cov"].any()
 
 
+def test_scan2map_optimization_is_the_references_at_config2(ref, synth):
+    """the same pin at BASELINE config 2's size (2 x 64 rings, the 500 k map: 12-14 k residual blocks per outer iteration): the reference's own lines and the
+    oracle's restatement agree to the last bit of the pose (the GPU suite holds the HIP path against the same call, tests/test_gpu_parity_fullsize.py)"""
+    import warnings
+    import bench
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sc, surf_map, corner_map, gt, scans = bench.build_workload(synth, "500k")
+    ex = [ref.extract(s.points, s.scan_start, s.scan_end) for s in scans]
+    surf, corner = bench.fuse_features(synth, scans, ex)
+    p0 = synth.perturbed_pose(gt, seed=43)
+    got = ref.ref_scan2map(surf_map, corner_map, surf, corner, p0)
+    want = ref.scan2map(ref.Map(surf_map), ref.Map(corner_map), surf, corner, p0, ref.mapper_params())
+    assert [s["n_blocks"] for s in got["solves"]] == [o["n_surf_sel"] + o["n_corner_sel"] for o in want["outer"]] and got["solves"][0]["n_blocks"] > 10000
+    assert [s["lm_iterations"] for s in got["solves"]] == [o["lm_iterations"] for o in want["outer"]]
+    assert np.linalg.norm(got["pose"] - want["pose"]) < 1e-12
+
+
 def test_track_cloud_is_the_references(ref, track_case):
     """LidarTracker::trackCloud (lidar_tracker.cpp:23-129) from the reference's own lines: two rounds of {matchCornerFromScan + matchSurfFromScan at the
     current estimate, LidarScanPlaneNormFactor / LidarScanEdgeFactorVector blocks under Huber(0.1), ceres::Solve with 4 iterations}; the oracle's
