@@ -342,6 +342,58 @@ def test_extract_with_non_finite_points(mla, orc, case16):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", ["8", "16"])
+def test_bounded_search_of_later_iterations_on_tie_heavy_maps(mla, orc, lanes):
+    """Iterations >= 1 of a solve bound the 5-NN search by the previous iteration's neighbours (knn_group_bounded). On a map of lattice points, duplicated points and a
+    wall of coplanar samples -- squared distances tie exactly, also AT the bound -- and with a pose that moves centimetres between iterations, the neighbours (hence the
+    fits, counts and poses) must be what the cold search finds: per-iteration counts == the oracle's, and the pose bit-equal between the schedules with and without the
+    bound (and with and without the finish in the consumer)."""
+    rng = np.random.default_rng(9)
+    g = np.arange(-16, 17, dtype=np.float32) * 0.25
+    yy, zz = np.meshgrid(g, g[:17] + 4.0, indexing="ij")
+    wall = np.stack([np.full(yy.size, 3.0, np.float32), yy.ravel(), zz.ravel()], 1)                    # a lattice wall x = 3
+    xx, yy2 = np.meshgrid(g, g, indexing="ij")
+    floor = np.stack([xx.ravel(), yy2.ravel(), np.full(xx.size, -1.5, np.float32)], 1)                # a lattice floor z = -1.5 (the reference's plane fit solves n.p = -1: not through the origin)
+    wall2 = np.stack([yy.ravel(), np.full(yy.size, -3.5, np.float32), zz.ravel()], 1)                  # a second wall y = -3.5
+    surf_map = np.concatenate([wall, floor, wall2, floor[rng.choice(len(floor), 300, replace=False)], wall[rng.choice(len(wall), 200, replace=False)]]).astype(np.float32)
+    surf_map = np.ascontiguousarray(surf_map[rng.permutation(len(surf_map))])
+    edge = np.stack([np.full(60, 3.0, np.float32), np.full(60, -3.5, np.float32), (np.arange(60, dtype=np.float32) * 0.125 + 4.0)], 1)     # the walls' common edge, lattice spaced
+    corner_map = np.ascontiguousarray(np.concatenate([edge, edge[::3], edge + np.array([0, 7.5, 0], np.float32)]), np.float32)
+    # features: points ON the surfaces at cell centres / edge midpoints of the lattices (many equidistant neighbours), seen from a slightly wrong pose
+    fs = np.concatenate([np.stack([np.full(900, 3.0), rng.integers(-12, 12, 900) * 0.25 + 0.125, rng.integers(1, 15, 900) * 0.25 + 0.125], 1),
+                         np.stack([rng.integers(-12, 12, 1500) * 0.25 + 0.125, rng.integers(-12, 12, 1500) * 0.25 + 0.125, np.full(1500, -1.5)], 1),
+                         np.stack([rng.integers(-12, 12, 900) * 0.25 + 0.125, np.full(900, -3.5), rng.integers(1, 15, 900) * 0.25], 1)]).astype(np.float32)
+    fc = np.stack([np.full(40, 3.0), np.full(40, -3.5), rng.integers(34, 88, 40) * 0.0625 + 2.0], 1).astype(np.float32)
+    f4s = np.concatenate([fs, np.zeros((len(fs), 1), np.float32)], 1)
+    f4c = np.concatenate([fc, np.zeros((len(fc), 1), np.float32)], 1)
+    p0 = np.array([0.04, -0.03, 0.05, 0.004, -0.003, 0.002, 1.0]); p0[3:] /= np.linalg.norm(p0[3:])
+    n_it = 4
+    ref = orc.gn_iterations(orc.Map(surf_map), orc.Map(corner_map), f4s, f4c, p0, orc.mapper_params(), n_it)
+    assert ref["iters"][0]["n_surf"] > 1000 and ref["iters"][0]["n_corner"] > 10 and not ref["iters"][-1]["is_degenerate"]
+    poses = {}
+    for sched in ((0, 0, 0), (0, 1, 0), (1, 1, 1)):
+        os.environ["MLH_KNN_LANES"] = lanes
+        try:
+            c = mla.Context(0)
+        finally:
+            os.environ.pop("MLH_KNN_LANES", None)
+        try:
+            c.set_gn_schedule(*sched)
+            c.map_set_pair(surf_map, corner_map)
+            c.features_set(mla.SURF, f4s)
+            c.features_set(mla.CORNER, f4c)
+            poses[sched] = c.gn_solve(p0, n_it, want_stats=False)[0]
+            _, st = c.gn_solve(p0, n_it, want_stats=True)
+            c.gn_solve_begin(p0, n_it)
+            assert np.array_equal(c.gn_solve_end(), poses[sched])
+        finally:
+            c.close()
+        assert [(x["n_surf"], x["n_corner"]) for x in st] == [(r["n_surf"], r["n_corner"]) for r in ref["iters"]], sched
+    assert np.array_equal(poses[(0, 1, 0)], poses[(0, 0, 0)]) and np.array_equal(poses[(1, 1, 1)], poses[(0, 0, 0)])
+    assert float(np.abs(poses[(1, 1, 1)] - ref["pose"]).max()) < 1e-7
+
+
+@pytest.mark.gpu
 def test_knn_with_exact_distance_ties(mla, orc):
     """Exact ties in the squared distance -- duplicated map points, and queries at the centres of a lattice whose points are exactly
     representable -- are where a k-NN's order is a convention: FLANN's result order among equal distances is implementation-defined, the
