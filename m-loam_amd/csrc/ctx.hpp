@@ -191,6 +191,11 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
 
 struct SegBuf {    // ImageSegmenter scratch (segment.hip)
     DevBuf raw, pix, owner, range, ground, keep;
+    DevBuf unc;            // points / ground pairs whose bin the device cannot decide (an angle within an ulp-scale margin of a bin edge): [counters 2 x int][records]
+    DevBuf fix;            // the host's verdicts for the undecided points: {point index, pixel}
+    void *h_unc = nullptr; // pinned mirror of `unc`
+    size_t h_unc_cap = 0;
+    ~SegBuf() { if (h_unc) (void)hipHostFree(h_unc); }
 };
 
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)

@@ -60,7 +60,16 @@ struct SegDev {
     int *owner;          // vs * hs: smallest point index that claimed the pixel (INT_MAX: empty)
     float *range_mat;    // vs * hs
     unsigned char *ground;   // vs * hs
+    // Bins are decided by f32 atan / atan2, where the device's libm and the host's (glibc: what the reference runs) may differ in the last ulp. A point whose row or
+    // column value sits within a margin of a bin edge (a thousand times that ulp), or a ground pair whose angle sits that close to 10 degrees, is NOT decided here:
+    // it is handed to the host, which evaluates the reference's expression with its own libm (segment_cloud_run). A few dozen per scan.
+    int *unc_count;      // [0]: undecided points, [1]: undecided ground pairs
+    float4 *unc_pts;     // {x, y, z, point index as int bits}, capacity n
+    float4 *unc_gnd;     // 2 records per pair: {x1, y1, z1, pixel as int bits}, {x2, y2, z2, 0}, capacity 2 * vs * hs
 };
+
+constexpr float SEG_EDGE_MARGIN_BINS = 4.0e-4f;      // in units of one bin (row or column); an f32 ulp of a 180-degree angle is 1.5e-5 degrees = 7.6e-5 columns at 0.2 degrees: five of them
+constexpr float SEG_EDGE_MARGIN_DEG = 1.0e-4f;       // for the comparisons of an angle with a constant (2, -8.83, -24.33, 10 degrees): ~50 ulps of the angle
 
 // projectCloud, one lane per point (hpp:96-135)
 __global__ __launch_bounds__(256) void seg_project_kernel(SegDev D)
@@ -70,30 +79,52 @@ __global__ __launch_bounds__(256) void seg_project_kernel(SegDev D)
     const float *rec = reinterpret_cast<const float *>(D.src + size_t(i) * D.stride);
     const float x = rec[0], y = rec[1], z = rec[2];
     int pix = -1;
+    bool undecided = false;
     const float range = sqrtf(x * x + y * y + z * z);
     if (!(double(range) < D.roi_range)) {
         const float vertical_angle = float(double(atanf(z / sqrtf(x * x + y * y)) * 180) / M_PI);
         int row_id;
         bool ok = true;
         if (D.S.is64) {
-            if (double(vertical_angle) >= -8.83) row_id = int(double(2 - vertical_angle) * 3.0 + 0.5);          // (2 - angle) is a float subtraction in the reference
-            else row_id = D.S.vs / 2 + int((-8.83 - double(vertical_angle)) * 2.0 + 0.5);
+            double rv;
+            if (double(vertical_angle) >= -8.83) { rv = double(2 - vertical_angle) * 3.0 + 0.5; row_id = int(rv); }          // (2 - angle) is a float subtraction in the reference
+            else { rv = (-8.83 - double(vertical_angle)) * 2.0 + 0.5; row_id = D.S.vs / 2 + int(rv); }
             if (vertical_angle > 2 || double(vertical_angle) < -24.33 || row_id > 50 || row_id < 0) ok = false;
+            undecided = fabs(rv - rint(rv)) < double(SEG_EDGE_MARGIN_BINS) || fabsf(vertical_angle - 2.f) < SEG_EDGE_MARGIN_DEG || fabs(double(vertical_angle) + 8.83) < double(SEG_EDGE_MARGIN_DEG) ||
+                        fabs(double(vertical_angle) + 24.33) < double(SEG_EDGE_MARGIN_DEG);
         } else {
-            row_id = int((vertical_angle + D.S.ang_bottom) / D.S.ang_res_y);
+            const float rv = (vertical_angle + D.S.ang_bottom) / D.S.ang_res_y;
+            row_id = int(rv);
             if (row_id < 0 || row_id >= D.S.vs) ok = false;
+            undecided = fabsf(rv - rintf(rv)) < SEG_EDGE_MARGIN_BINS;
         }
-        if (ok) {
+        if (ok || undecided) {
             const float horizon_angle = float(double(atan2f(x, y) * 180) / M_PI);
-            int column_id = int(-round((double(horizon_angle) - 90.0) / double(D.S.ang_res_x)) + double(D.S.hs / 2));
+            const double cv = (double(horizon_angle) - 90.0) / double(D.S.ang_res_x);
+            int column_id = int(-round(cv) + double(D.S.hs / 2));
             if (column_id >= D.S.hs) column_id -= D.S.hs;
-            if (column_id >= 0 && column_id < D.S.hs) {
+            undecided = undecided || fabs(fabs(cv - floor(cv)) - 0.5) < double(SEG_EDGE_MARGIN_BINS);
+            if (!undecided && column_id >= 0 && column_id < D.S.hs) {
                 pix = column_id + row_id * D.S.hs;
                 atomicMin(D.owner + pix, i);          // range_mat(row, col) != FLT_MAX -> continue: the first point in input order keeps the pixel
             }
         }
+        if (undecided) {                              // the host decides with the reference's libm; its verdict arrives through seg_apply_fix_kernel
+            const int k = atomicAdd(D.unc_count, 1);
+            D.unc_pts[k] = make_float4(x, y, z, __int_as_float(i));
+        }
     }
     D.pix[i] = pix;
+}
+
+// the host's verdicts for the undecided points: fix[k] = {point index, pixel or -1}
+__global__ __launch_bounds__(256) void seg_apply_fix_kernel(const int2 *fix, int n_fix, int *pix, int *owner)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_fix) return;
+    const int2 f = fix[k];
+    pix[f.x] = f.y;
+    if (f.y >= 0) atomicMin(owner + f.y, f.x);
 }
 
 // the memset pattern 0x7f7f7f7f stands for "no point yet"; normalise to INT_MAX for everything that follows
@@ -128,7 +159,11 @@ __global__ __launch_bounds__(256) void seg_image_kernel(SegDev D)
             seg_point(D, o2, x2, y2, z2);
             const float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
             const float vertical_angle = float(double(atan2f(dz, sqrtf(dx * dx + dy * dy)) * 180) / M_PI);
-            if (fabsf(vertical_angle) <= 10) { D.ground[p] = 1; D.ground[p + D.S.hs] = 1; }      // both lanes that touch a pixel write the same 1
+            if (fabsf(fabsf(vertical_angle) - 10.f) < SEG_EDGE_MARGIN_DEG) {                     // too close to the threshold for this libm to speak for the host's
+                const int k = atomicAdd(D.unc_count + 1, 1);
+                D.unc_gnd[2 * k] = make_float4(x1, y1, z1, __int_as_float(p));
+                D.unc_gnd[2 * k + 1] = make_float4(x2, y2, z2, 0.f);
+            } else if (fabsf(vertical_angle) <= 10) { D.ground[p] = 1; D.ground[p + D.S.hs] = 1; }      // both lanes that touch a pixel write the same 1
         }
     }
 }
@@ -235,6 +270,39 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
     }
 }
 
+// projectCloud's bin of one point with the HOST's libm (hpp:96-135; the expressions of seg_project_kernel, std::atan / std::atan2 in place of the device's): the
+// verdict for a point the device found too close to a bin edge to decide. -1: the point claims no pixel.
+static int seg_pixel_host(float x, float y, float z, const SegSetup &S, double roi_range)
+{
+    const float range = std::sqrt(x * x + y * y + z * z);
+    if (double(range) < roi_range) return -1;
+    const float vertical_angle = float(double(std::atan(z / std::sqrt(x * x + y * y)) * 180) / M_PI);
+    int row_id;
+    if (S.is64) {
+        if (double(vertical_angle) >= -8.83) row_id = int(double(2 - vertical_angle) * 3.0 + 0.5);
+        else row_id = S.vs / 2 + int((-8.83 - double(vertical_angle)) * 2.0 + 0.5);
+        if (vertical_angle > 2 || double(vertical_angle) < -24.33 || row_id > 50 || row_id < 0) return -1;
+    } else {
+        row_id = int((vertical_angle + S.ang_bottom) / S.ang_res_y);
+        if (row_id < 0 || row_id >= S.vs) return -1;
+    }
+    const float horizon_angle = float(double(std::atan2(x, y) * 180) / M_PI);
+    int column_id = int(-std::round((double(horizon_angle) - 90.0) / double(S.ang_res_x)) + double(S.hs / 2));
+    if (column_id >= S.hs) column_id -= S.hs;
+    if (column_id < 0 || column_id >= S.hs) return -1;
+    return column_id + row_id * S.hs;
+}
+
+// the ground test of one pixel pair with the host's libm (hpp:196-205)
+static bool seg_ground_host(const float4 &a, const float4 &b)
+{
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const float vertical_angle = float(double(std::atan2(dz, std::sqrt(dx * dx + dy * dy)) * 180) / M_PI);
+    return std::fabs(vertical_angle) <= 10;
+}
+
+constexpr int SEG_UNC_FIRST = 2048;     // undecided records fetched with the counters (a scan has a few dozen); more than that: one more copy
+
 int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
                       float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier)
 {
@@ -257,10 +325,50 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     MLH_HIP(ctx, B.ground.ensure(size_t(npx)));
     MLH_HIP(ctx, hipMemsetAsync(B.owner.p, 0x7f, sizeof(int) * size_t(npx), st));      // 0x7f7f7f7f > any index; read back as "empty" below
     MLH_HIP(ctx, hipMemsetAsync(B.ground.p, 0, size_t(npx), st));
+    // undecided points / ground pairs: [4 ints: two counters][n point records][2 x npx pair records]
+    const size_t unc_bytes = 16 + sizeof(float4) * (size_t(n) + 2 * size_t(npx));
+    MLH_HIP(ctx, B.unc.ensure(unc_bytes));
+    MLH_HIP(ctx, hipMemsetAsync(B.unc.p, 0, 16, st));
+    const size_t h_need = 16 + sizeof(float4) * size_t(std::max(n, 2 * npx));
+    if (B.h_unc_cap < h_need) {
+        if (B.h_unc) (void)hipHostFree(B.h_unc);
+        B.h_unc = nullptr; B.h_unc_cap = 0;
+        MLH_HIP(ctx, hipHostMalloc(&B.h_unc, h_need, hipHostMallocDefault));
+        B.h_unc_cap = h_need;
+    }
     SegDev D;
     D.src = src; D.stride = stride; D.intensity_off = intensity_off; D.n = n; D.S = S; D.roi_range = prm.roi_range;
     D.pix = B.pix.as<int>(); D.owner = B.owner.as<int>(); D.range_mat = B.range.as<float>(); D.ground = B.ground.as<unsigned char>();
+    D.unc_count = B.unc.as<int>();
+    D.unc_pts = reinterpret_cast<float4 *>(B.unc.as<unsigned char>() + 16);
+    D.unc_gnd = D.unc_pts + n;
     hipLaunchKernelGGL(seg_project_kernel, dim3((n + 255) / 256), dim3(256), 0, st, D);
+    MLH_HIP(ctx, hipGetLastError());
+    int n_undecided_pts = 0;
+    {
+        // the points whose bin the device left open: fetched (counters + the first records in one copy), decided with the host's libm, sent back, claimed
+        int *hc = static_cast<int *>(B.h_unc);
+        float4 *hp = reinterpret_cast<float4 *>(static_cast<unsigned char *>(B.h_unc) + 16);
+        MLH_HIP(ctx, hipMemcpyAsync(B.h_unc, B.unc.p, 16 + sizeof(float4) * size_t(std::min(n, SEG_UNC_FIRST)), hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, stream_wait_spin(ctx));
+        n_undecided_pts = std::min(hc[0], n);
+        if (n_undecided_pts > SEG_UNC_FIRST) {
+            MLH_HIP(ctx, hipMemcpyAsync(hp + SEG_UNC_FIRST, D.unc_pts + SEG_UNC_FIRST, sizeof(float4) * size_t(n_undecided_pts - SEG_UNC_FIRST), hipMemcpyDeviceToHost, st));
+            MLH_HIP(ctx, stream_wait_spin(ctx));
+        }
+        if (n_undecided_pts > 0) {
+            std::vector<int2> fix(static_cast<size_t>(n_undecided_pts));
+            for (int k = 0; k < n_undecided_pts; ++k) {
+                int idx;
+                std::memcpy(&idx, &hp[k].w, sizeof(int));
+                fix[size_t(k)] = make_int2(idx, seg_pixel_host(hp[k].x, hp[k].y, hp[k].z, S, prm.roi_range));
+            }
+            MLH_HIP(ctx, B.fix.ensure(sizeof(int2) * fix.size()));
+            MLH_HIP(ctx, hipMemcpyAsync(B.fix.p, fix.data(), sizeof(int2) * fix.size(), hipMemcpyHostToDevice, st));
+            MLH_HIP(ctx, hipStreamSynchronize(st));      // `fix` is pageable and goes out of scope
+            hipLaunchKernelGGL(seg_apply_fix_kernel, dim3((n_undecided_pts + 255) / 256), dim3(256), 0, st, (const int2 *)B.fix.as<int2>(), n_undecided_pts, D.pix, D.owner);
+        }
+    }
     hipLaunchKernelGGL(seg_owner_fix_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D.owner, npx);
     hipLaunchKernelGGL(seg_image_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D);
     MLH_HIP(ctx, hipGetLastError());
@@ -272,7 +380,25 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     MLH_HIP(ctx, hipMemcpyAsync(H.range.data(), B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.owner.data(), B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.ground.data(), B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipStreamSynchronize(st));
+    int n_undecided_gnd = 0;
+    {
+        // the ground pairs within the margin of 10 degrees: decided here, with the host's libm, straight into the ground image the cluster search reads
+        int *hc = static_cast<int *>(B.h_unc);
+        float4 *hg = reinterpret_cast<float4 *>(static_cast<unsigned char *>(B.h_unc) + 16);
+        MLH_HIP(ctx, hipMemcpyAsync(hc, B.unc.p, 16, hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipMemcpyAsync(hg, D.unc_gnd, sizeof(float4) * 2 * size_t(std::min(npx, SEG_UNC_FIRST)), hipMemcpyDeviceToHost, st));
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        n_undecided_gnd = std::min(hc[1], npx);
+        if (n_undecided_gnd > SEG_UNC_FIRST) {
+            MLH_HIP(ctx, hipMemcpyAsync(hg + 2 * SEG_UNC_FIRST, D.unc_gnd + 2 * SEG_UNC_FIRST, sizeof(float4) * 2 * size_t(n_undecided_gnd - SEG_UNC_FIRST), hipMemcpyDeviceToHost, st));
+            MLH_HIP(ctx, hipStreamSynchronize(st));
+        }
+        for (int k = 0; k < n_undecided_gnd; ++k) {
+            int pxl;
+            std::memcpy(&pxl, &hg[2 * k].w, sizeof(int));
+            if (pxl >= 0 && pxl + hs < npx && seg_ground_host(hg[2 * k], hg[2 * k + 1])) { H.ground[size_t(pxl)] = 1; H.ground[size_t(pxl) + hs] = 1; }
+        }
+    }
     const auto tp1 = std::chrono::steady_clock::now();
     for (int p = 0; p < npx; ++p) H.label[p] = (H.owner[p] == INT_MAX) ? -1 : (H.ground[p] ? 1 : 0);
     seg_clusters(S, prm, H);
@@ -391,6 +517,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     if (seg_timing) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[mlh_segment_cloud] undecided on the device, decided with the host's libm: %d points, %d ground pairs\n", n_undecided_pts, n_undecided_gnd);
         std::fprintf(stderr, "[mlh_segment_cloud] n %d: kernels + 3 image copies to the host %.1f us | host cluster search (BFS, queue order) %.1f us | row assembly + keep list + gather + sync %.1f us\n",
                      n, us(tp0, tp1), us(tp1, tp2), us(tp2, tp3));
         std::fprintf(stderr, "    rows %.1f | erase %.1f (rows resolved in one linear pass %d, through the order-statistic pool %d; erased %d) | keep %.1f | upload + gather + sync %.1f us\n",

@@ -1647,6 +1647,55 @@ def _raw_cloud(synth, n_rings, seed, clutter, order="shuffled"):
     return np.ascontiguousarray(pts[np.argsort(az, kind="stable")])
 
 
+@pytest.mark.parametrize("vs", [16, 64])
+def test_image_segmenter_points_on_bin_edges(mla, orc, synth, vs):
+    """Rows and columns are decided by f32 atan / atan2, where the device's libm and glibc (what the reference runs) may differ in the last ulp: a point within an ulp of
+    a bin edge could land in another pixel, a ground pair within an ulp of 10 degrees could flip. The kernels do not decide such points: they go to the host, which
+    evaluates the reference's expression with its own libm (segment.hip: seg_pixel_host / seg_ground_host). Here a third of a scan is moved ONTO the edges -- azimuths
+    at exact half-columns, elevations at exact row boundaries, vertical neighbours exactly 10 degrees apart -- and the result must still be the oracle's, bit for bit."""
+    rng = np.random.default_rng(17)
+    pts = _raw_cloud(synth, vs, 4, 0.05, "firing")
+    n = len(pts)
+    r = np.linalg.norm(pts[:, :3], axis=1).astype(np.float64)
+    ha = np.degrees(np.arctan2(pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)))
+    va = np.degrees(np.arctan(pts[:, 2] / np.hypot(pts[:, 0], pts[:, 1]).astype(np.float64)))
+    res = 360.0 / 1800
+    pick = rng.random(n) < 0.35
+    # azimuth onto the nearest half-column: (ha - 90) / res = k + 0.5
+    k = np.floor((ha - 90.0) / res)
+    ha_e = np.where(pick, 90.0 + (k + 0.5) * res, ha)
+    # elevation onto a row boundary for half of those (16 rings: (va + 15.1) / 2 integer; 64 rings: (2 - va) * 3 + 0.5 integer above -8.83)
+    pick_v = pick & (rng.random(n) < 0.5)
+    if vs == 16:
+        va_e = np.where(pick_v, np.round((va + 15.1) / 2.0) * 2.0 - 15.1, va)
+    else:
+        va_e = np.where(pick_v & (va > -8.0), 2.0 - (np.round((2.0 - va) * 3.0 + 0.5) - 0.5) / 3.0, va)
+    x = r * np.cos(np.radians(va_e)) * np.sin(np.radians(ha_e))
+    y = r * np.cos(np.radians(va_e)) * np.cos(np.radians(ha_e))
+    z = r * np.sin(np.radians(va_e))
+    edge = np.ascontiguousarray(np.stack([x, y, z, pts[:, 3]], 1).astype(np.float32))
+    # ground pairs exactly 10 degrees apart: a column of points whose consecutive differences have atan2(dz, dxy) = 10 degrees
+    col = []
+    for c in range(40):
+        az = np.radians(3.7 + c * 1.3)
+        base = np.array([8.0 * np.sin(az), 8.0 * np.cos(az), -1.9])
+        step = np.array([np.sin(az) * np.cos(np.radians(10.0)), np.cos(az) * np.cos(np.radians(10.0)), np.sin(np.radians(10.0))]) * 0.55
+        for j in range(5):
+            col.append(base + j * step)
+    extra = np.concatenate([np.array(col), np.full((len(col), 1), 0.3)], 1).astype(np.float32)
+    cloud = np.ascontiguousarray(np.concatenate([edge, extra]))
+    prm = orc.seg_params(vertical_scans=vs, segment_flag=True)
+    ref = orc.segment_cloud(cloud, prm)
+    c = mla.Context(0)
+    try:
+        got = c.segment_cloud(cloud, vertical_scans=vs, segment_flag=1)
+    finally:
+        c.close()
+    assert got["cloud"].shape == ref["cloud"].shape and np.array_equal(got["cloud"].view(np.uint32), ref["cloud"].view(np.uint32))
+    assert np.array_equal(got["scan_start"], ref["scan_start"]) and np.array_equal(got["scan_end"], ref["scan_end"])
+    assert got["outlier"].shape == ref["outlier"].shape and np.array_equal(got["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
+
+
 @pytest.mark.parametrize("vs,rings,clutter,order", [(16, 16, 0.1, "ring_major"), (16, 16, 0.4, "firing"), (64, 64, 0.1, "firing"), (64, 64, 0.3, "ring_major")])
 def test_image_segmenter_on_ordered_clouds(mla, orc, synth, vs, rings, clutter, order):
     """clouds in the orders drivers really deliver: a ring's fill positions then grow with the column (one step down where the sweep starts), and the outlier erasure
