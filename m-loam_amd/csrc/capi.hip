@@ -1421,6 +1421,16 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
     for (int b = 1; b < nb; ++b) if ((rc = upload_block_pose(ctx, b, poses_inout + 7 * b))) return rc;
     const int mask = ((ctx->feat[0].m > 0 && ctx->map[0].built) ? 1 : 0) | ((ctx->feat[1].m > 0 && ctx->map[1].built) ? 2 : 0);
     if (!mask) return fail(ctx, MLH_ERR_STATE, "no map/features staged");
+    // The finish in the consumer, per pose block (one GPU, no statistics): a correspondence workgroup serves features of ONE block, so its prologue sums that block's
+    // records only and solves that block only -- the four serial finishes of the classic last workgroup (20 us of a 40 us fit launch on config 4's frame) become one
+    // parallel prologue, and the redundancy is per block (at most 160 tiles each). Together with the bounded search (N_NEIGH 5 or 10); every block needs surf features
+    // (its first surf tile's workgroup is the one that leaves the block's pose in HBM).
+    bool defer_blocks = !distributed(ctx) && !stats && n_iters >= 2 && ctx->gn_defer && ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi;
+    for (int b = 0; b < nb && defer_blocks; ++b) {
+        int tiles = 0;
+        for (int k = 0; k < 2; ++k) if (mask & (1 << k)) tiles += (ctx->feat[k].blk_start[b + 1] - ctx->feat[k].blk_start[b] + 255) / 256;
+        if (!(mask & 1) || ctx->feat[0].n_blocks != nb || ctx->feat[0].blk_real[b] <= 0 || tiles > GN_DEFER_MAX_TILES) defer_blocks = false;
+    }
     for (int it = 0; it < n_iters; ++it) {
         MatchArgs a = args_from_opts(opts, mask, 0);
         a.n_blocks = nb;
@@ -1428,6 +1438,11 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
         if (!distributed(ctx) || ctx->p2p.active) {      // (mailbox communicator: the blocks' records are exchanged inside the finish, one after the other)
             a.finish = 1;
             a.stat_slot = stats ? it * nb : -1;
+            if (defer_blocks) {
+                a.gn_iter = it; a.gn_iters = n_iters; a.gn_blocks = true;
+                a.warm = it >= 1;
+                if (it < n_iters - 1) a.finish = 0;
+            }
             if ((rc = match_launch(ctx, a))) return rc;
         } else {
             // multi-GPU: per-block local sums in the fit kernel's last workgroup, ONE all-reduce of nb x 32 doubles, identical updates

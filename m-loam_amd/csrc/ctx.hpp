@@ -57,6 +57,7 @@ struct SolverState {
     // iteration i's correspondence launch while the others may still be reading xi[base + ((i - 1) & 1)]; consecutive solves alternate base 0 / 2 (a solve's first
     // launch may still be reading the previous solve's last slot while it fills its own first one)
     double xi[4][7];
+    double xib[2][8][7];     // the same for a solve over several pose blocks (mlh_gn_solve_blocks): iteration i's pose of block b in xib[i & 1][b]
     double lm_used_max;      // split-submission scan2map: the largest LM iteration count of the solve's outer iterations so far (the host sizes the next frame's look-ahead by it)
     double pad2[1];
 };
@@ -504,6 +505,7 @@ struct MatchArgs {
     // bits) and running the 6 x 6 solve + Plus itself. gn_iter < 0: the classic form (the fit kernel's last-arriving workgroup finishes).
     int gn_iter = -1, gn_iters = 0;
     int gn_slot_base = 0;     // this solve's pair of SolverState::xi slots (0 or 2)
+    bool gn_blocks = false;   // the solve runs over pose blocks: per-block iteration poses in SolverState::xib
     bool warm = false;   // the neighbour records of the previous iteration (same features, same map) bound this iteration's search
     // iteration 0 of a CHAINED solve that also completes the PREVIOUS solve, whose last iteration left only its tiles' records (mlh_ctx::gn_pending): every workgroup of
     // this correspondence launch sums them, solves, applies Plus -> the previous frame's final pose; tile 0's workgroup publishes it to that solve's host record and

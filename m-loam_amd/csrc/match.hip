@@ -220,6 +220,8 @@ struct KParams {
     int pre_finish;          // 1: sum the pre_tiles records the previous fit launch left in `partials`, solve, Plus -> this iteration's pose
     int pre_tiles;
     int pre_from_init;       // the previous iteration's pose is init_pose (kernel arguments); otherwise *x_prev
+    int pre_from_state;      // ... or the state's own poses (x for block 0, xb[b] otherwise): iteration 1 of a solve over pose blocks
+    // (x_prev / x_next / pose0 are the poses of block 0; block b's sit 7 doubles x b further)
     const double *x_prev;
     double *x_next;          // the workgroup that serves tile 0 stores the new pose here (the fit kernel of the same iteration reads it as pose0)
     const double *pose0;     // block 0's pose of this launch when it is neither init_pose nor the state's x / cand (iterations >= 1 of a deferred-finish solve)
@@ -249,8 +251,8 @@ __device__ __forceinline__ void load_pose(const KParams &P, int b, q4 &q, d3 &t)
     if (P.use_init && b == 0) {            // uniform: straight from the kernel-argument segment
         t = d3{P.init_pose[0], P.init_pose[1], P.init_pose[2]};
         q = q4{P.init_pose[3], P.init_pose[4], P.init_pose[5], P.init_pose[6]};
-    } else if (P.pose0 && b == 0) {        // iteration >= 1 of a deferred-finish solve: the slot this iteration's correspondence launch filled
-        const double *pose = P.pose0;
+    } else if (P.pose0) {                  // iteration >= 1 of a deferred-finish solve: the slot this iteration's correspondence launch filled (one per pose block)
+        const double *pose = P.pose0 + 7 * b;
         t = d3{pose[0], pose[1], pose[2]};
         q = q4{pose[3], pose[4], pose[5], pose[6]};
     } else {
@@ -320,24 +322,28 @@ __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, i
     MLH_KSTAGE(5);
 }
 
-// The same feature one Gauss-Newton iteration later: `old` is this lane's share (lane t < 5: record t) of the neighbour records the previous iteration
-// left -- five points of the SAME map. Their largest squared distance from the query's new position bounds the fifth neighbour's from above, so the search
-// is a single walk over the cells within that bound (knn_group_bounded). A feature that had fewer than five neighbours (w = +inf) searches as before.
-template <int G>
-__device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run, const float4 &old)
+// The same feature one Gauss-Newton iteration later: `old` is this lane's share (lane t: records t, t + G, ... below K) of the neighbour records the previous
+// iteration left -- K points of the SAME map. Their largest squared distance from the query's new position bounds the K-th neighbour's from above, so the search
+// is a single walk over the cells within that bound (knn_group_bounded). A feature that had fewer than K neighbours (w = +inf) searches as before.
+template <int K, int G, int NREC>
+__device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run, const float4 (&old)[NREC])
 {
     unsigned bits = 0u;
-    if (gl < 5) {
-        const float dx = old.x - sx, dy = old.y - sy, dz = old.z - sz;
-        float d = dx * dx; d += dy * dy; d += dz * dz;
-        bits = (old.w < __uint_as_float(0x7f800000u) && d < __uint_as_float(0x7f800000u)) ? __float_as_uint(d) : 0x7f800000u;
+#pragma unroll
+    for (int r = 0; r < NREC; ++r) {
+        if (gl + r * G < K) {
+            const float dx = old[r].x - sx, dy = old[r].y - sy, dz = old[r].z - sz;
+            float d = dx * dx; d += dy * dy; d += dz * dz;
+            const unsigned bb = (old[r].w < __uint_as_float(0x7f800000u) && d < __uint_as_float(0x7f800000u)) ? __float_as_uint(d) : 0x7f800000u;
+            bits = bb > bits ? bb : bits;
+        }
     }
     bits = dpp_row_max_u32<G>(bits);
-    if (bits >= 0x7f800000u) { knn_feature<5, G>(P, Kd, f, sx, sy, sz, gl, lds_run); return; }     // uniform over the group
-    unsigned long long keys[5];
-    knn_group_bounded<5, G>(Kd.grid, sx, sy, sz, gl, lds_run, bits, keys);
+    if (bits >= 0x7f800000u) { knn_feature<K, G>(P, Kd, f, sx, sy, sz, gl, lds_run); return; }     // uniform over the group
+    unsigned long long keys[K];
+    knn_group_bounded<K, G>(Kd.grid, sx, sy, sz, gl, lds_run, bits, keys);
     MLH_KSTAGE(4);
-    MLH_STORE_WINNERS(5, G, Kd, f, gl, keys);
+    MLH_STORE_WINNERS(K, G, Kd, f, gl, keys);
     MLH_KSTAGE(5);
 }
 
@@ -354,9 +360,17 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
     if (f >= K.m) return;
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
-    float4 old = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
-    if constexpr (WARM) { if (gl < 5) old = K.nbr[size_t(f) * K.nbr_stride + gl]; }      // requested together with the feature, before the pose is known
     const int b = MB ? block_of_slot(K, P.n_blocks, f) : 0;
+    constexpr int NREC = WARM ? ((K10 ? 10 : 5) + G - 1) / G : 1;
+    float4 old[NREC];
+    if constexpr (WARM) {                  // requested together with the feature, before the pose is known
+        const int kq = K10 ? (MB ? P.kb[b] : P.kb[0]) : 5;
+#pragma unroll
+        for (int r = 0; r < NREC; ++r) {
+            old[r] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0x7f800000u));
+            if (gl + r * G < kq) old[r] = K.nbr[size_t(f) * K.nbr_stride + gl + r * G];
+        }
+    }
     q4 q;
     d3 t;
     if constexpr (PRE) {
@@ -372,7 +386,8 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
     // K10: some pose block of the launch asks for 10 neighbours (buildCalibMap's non-reference LiDARs); without it the K = 10 search is not
     // even compiled in, so the ordinary frame's kernel keeps the K = 5 register footprint
     if constexpr (WARM) {
-        knn_feature_warm<G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW, old);
+        if (K10 && (MB ? P.kb[b] : P.kb[0]) == 10) knn_feature_warm<10, G, NREC>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW, old);
+        else knn_feature_warm<5, G, NREC>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW, old);
     } else {
         if (K10 && (MB ? P.kb[b] : P.kb[0]) == 10) knn_feature<10, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
         else knn_feature<5, G>(P, K, f, sx, sy, sz, gl, s_run + grp * RUNW);
@@ -384,13 +399,30 @@ __device__ __forceinline__ void knn_features_body(const KParams &P, const KindP 
 //   same association: the same bits --, inlined: the record loads leave at once instead of behind an argument block's trip through scratch, and nobody waits for the
 //   per-kind counts, which only statistics read); gn_finish_wave solves and applies Plus on the first wavefront; s_pose holds the updated pose when this returns.
 // MODE 1: an iteration of the running solve. MODE 2: the LAST iteration of the PREVIOUS solve (thresholds from the launch arguments).
-template <int MODE>
-__device__ __forceinline__ void gn_prologue(const KParams &P, double *s_pose, double *f_ne, double *f_cnt2, double *f_scratch)
+// b: the pose block this workgroup's features belong to (0 without blocks): the records summed are that block's tiles -- its surf tiles, then its corner tiles, as the
+// classic finish walks them -- and the thresholds that block's.
+template <int MODE, bool MB = false>
+__device__ __forceinline__ void gn_prologue(const KParams &P, int b, double *s_pose, double *f_ne, double *f_cnt2, double *f_scratch)
 {
-    if (threadIdx.x < 7) s_pose[threadIdx.x] = P.pre_from_init ? P.init_pose[threadIdx.x] : P.x_prev[threadIdx.x];
+    if (threadIdx.x < 7) {
+        double v;
+        if (P.pre_from_init) v = P.init_pose[threadIdx.x];
+        else if (MB && P.pre_from_state) v = (b == 0 ? P.state->x : P.state->xb[b])[threadIdx.x];
+        else v = P.x_prev[7 * b + threadIdx.x];
+        s_pose[threadIdx.x] = v;
+    }
     {
         constexpr int NS = TPB / 32, U = 12;
-        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, ntot = P.pre_tiles;
+        const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        int lo0 = 0, n0 = P.pre_tiles, lo1 = 0, n1 = 0;
+        if constexpr (MB) {
+            lo0 = P.k[0].m > 0 ? P.k[0].blk_start[b] / TPB : 0;
+            n0 = P.k[0].m > 0 ? (P.k[0].blk_start[b + 1] + TPB - 1) / TPB - lo0 : 0;
+            lo1 = P.k[0].tiles_b + (P.k[1].m > 0 ? P.k[1].blk_start[b] / TPB : 0);
+            n1 = P.k[1].m > 0 ? (P.k[0].tiles_b + (P.k[1].blk_start[b + 1] + TPB - 1) / TPB) - lo1 : 0;
+            n0 = max(n0, 0); n1 = max(n1, 0);
+        }
+        const int ntot = n0 + n1;
         const double *__restrict__ rec = P.partials;
         double ch[4] = {0.0, 0.0, 0.0, 0.0};
         for (int j = sl; j < ntot; j += U * NS) {
@@ -398,7 +430,8 @@ __device__ __forceinline__ void gn_prologue(const KParams &P, double *s_pose, do
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jj = j + NS * u;
-                tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+                const int tile = jj < n0 ? lo0 + jj : lo1 + (jj - n0);
+                tv[u] = jj < ntot ? rec[size_t(tile) * NE_STRIDE + c] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
@@ -415,7 +448,7 @@ __device__ __forceinline__ void gn_prologue(const KParams &P, double *s_pose, do
     }
     if (threadIdx.x < 64) {
         double xo[7];
-        gn_finish_wave(f_ne, f_cnt2, s_pose, nullptr, MODE == 2 ? P.pre_thre : P.thre_b[0], MODE == 2 ? P.pre_freeze : P.freeze_b[0], nullptr, f_scratch, xo);
+        gn_finish_wave(f_ne, f_cnt2, s_pose, nullptr, MODE == 2 ? P.pre_thre : P.thre_b[b], MODE == 2 ? P.pre_freeze : P.freeze_b[b], nullptr, f_scratch, xo);
     }
     __syncthreads();
 }
@@ -449,7 +482,19 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     if (tile >= total) return;
     if constexpr (PRE != 0) {
         __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
-        gn_prologue<PRE>(P, s_pose, f_ne, f_cnt2, f_scratch);
+        int pb = 0;
+        bool writer = tile == 0;
+        if constexpr (MB) {
+            // pose blocks start on 256-slot boundaries and a workgroup serves 16 or 32 consecutive slots of ONE kind: all of them in one block. The block's pose is
+            // written by the workgroup of its first surf tile (the host defers a solve over blocks only when every block has surf features)
+            const int kk = tile >= P.k[0].tiles_a ? 1 : 0;
+            const int tk = kk ? tile - P.k[0].tiles_a : tile;
+            const int lanes = (G == 0) ? P.k[kk].lanes : G;
+            const int f0 = tk * (TPB / lanes);
+            pb = block_of_slot(P.k[kk], P.n_blocks, f0);
+            writer = kk == 0 && f0 == P.k[0].blk_start[pb];
+        }
+        gn_prologue<PRE, MB>(P, pb, s_pose, f_ne, f_cnt2, f_scratch);
         if constexpr (PRE == 2) {
             __shared__ double s_chain[8];
             if (threadIdx.x == 0) {
@@ -465,7 +510,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
             if (threadIdx.x < 7) s_pose[threadIdx.x] = s_chain[threadIdx.x];
             __syncthreads();
         }
-        if (tile == 0 && threadIdx.x < 7) P.x_next[threadIdx.x] = s_pose[threadIdx.x];
+        if (writer && threadIdx.x < 7) P.x_next[7 * pb + threadIdx.x] = s_pose[threadIdx.x];
     }
     const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
     if (kind) tile -= P.k[0].tiles_a;
@@ -482,7 +527,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 __global__ __launch_bounds__(TPB) void gn_final_kernel(KParams P)
 {
     __shared__ double s_pose[8], f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
-    gn_prologue<2>(P, s_pose, f_ne, f_cnt2, f_scratch);
+    gn_prologue<2>(P, 0, s_pose, f_ne, f_cnt2, f_scratch);
     if (threadIdx.x == 0) publish_final_pose(P, s_pose);
 }
 
@@ -657,12 +702,12 @@ __device__ __forceinline__ void fused_gn_finish(const KParams &P, int total_tile
             if (P.publish && threadIdx.x == 0) for (int i = 0; i < 7; ++i) (b == 0 ? P.publish->x : P.publish->xb[b])[i] = (b == 0 ? P.state->x : P.state->xb[b])[i];
         } else if (threadIdx.x < 64) {
             double xo[7];
-            const double *x_in = (b == 0 && P.pose0) ? P.pose0 : nullptr;      // last iteration of a deferred-finish solve: the pose comes from its iteration slot
+            const double *x_in = P.pose0 ? P.pose0 + 7 * b : nullptr;      // last iteration of a deferred-finish solve: the pose comes from its iteration slot
             gn_finish_wave(f_ne, f_cnt2, b == 0 ? P.state->x : P.state->xb[b], nullptr /* nothing downstream reads a mirror of ne / V_update in GN mode */, P.thre_b[b], P.freeze_b[b],
                            P.stat ? P.stat + b : nullptr, f_scratch, xo, x_in);
             if (x_in && threadIdx.x < 7) {           // ... and goes to the state whatever the solve decided (an unchanged pose included)
                 const int l = threadIdx.x;
-                P.state->x[l] = l == 0 ? xo[0] : (l == 1 ? xo[1] : (l == 2 ? xo[2] : (l == 3 ? xo[3] : (l == 4 ? xo[4] : (l == 5 ? xo[5] : xo[6])))));
+                (b == 0 ? P.state->x : P.state->xb[b])[l] = l == 0 ? xo[0] : (l == 1 ? xo[1] : (l == 2 ? xo[2] : (l == 3 ? xo[3] : (l == 4 ? xo[4] : (l == 5 ? xo[5] : xo[6])))));
             }
             // the solve's last launch hands the pose(s) to the host: straight from the finish's registers (reading the state back would be one more round trip)
             if (P.publish && threadIdx.x == 0) for (int i = 0; i < 7; ++i) (b == 0 ? P.publish->x : P.publish->xb[b])[i] = xo[i];
@@ -968,7 +1013,19 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     P.use_init = a.init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) P.init_pose[i] = a.init_pose ? a.init_pose[i] : 0.0;
     P.warm = a.warm ? 1 : 0;
-    if (a.gn_iter >= 1) {
+    if (a.gn_iter >= 1 && a.gn_blocks) {
+        // iteration i >= 1 of a deferred-finish solve over pose blocks: every block's pose of iteration i in SolverState::xib[i & 1][b]; iteration 1 updates the poses
+        // the state holds (x, xb[b])
+        SolverState *S = ctx->state.as<SolverState>();
+        P.pre_finish = 1;
+        P.pre_tiles = tiles_b_total;
+        P.pre_from_init = 0;
+        P.pre_from_state = a.gn_iter == 1 ? 1 : 0;
+        P.x_prev = &S->xib[(a.gn_iter - 1) & 1][0][0];
+        P.x_next = &S->xib[a.gn_iter & 1][0][0];
+        P.pose0 = &S->xib[a.gn_iter & 1][0][0];
+        P.use_init = 0;
+    } else if (a.gn_iter >= 1) {
         // iteration i >= 1 of a deferred-finish solve: the correspondence kernel turns iteration i - 1's records and pose into pose i (SolverState::xi[base + (i & 1)]);
         // iteration 1 finds pose 0 where iteration 0 found it -- the kernel arguments, the state's x (a chained solve behind a chain launch), or iteration 0's slot
         // (a chained solve whose first launch computed the start pose itself, MatchArgs::pre_final)
@@ -1058,8 +1115,18 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             else if (P.pre_finish) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, false, false, 1, false>, grid_a, P); \
             else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<G_, false, false, 0, true>, grid_a, P); \
         } while (0)
-        if (P.pre_finish || P.warm) {
-            if (mb || k10) return fail(ctx, MLH_ERR_UNSUPPORTED, "the deferred finish / the bounded search are single-block, N_NEIGH = 5");
+#define MLH_KNN_LAUNCH_GN_MB(G_) do { \
+            if (k10) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, true, true, 1, true>, grid_a, P); \
+            else launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, true, false, 1, true>, grid_a, P); \
+        } while (0)
+        if ((P.pre_finish || P.warm) && (mb || k10)) {
+            // a solve over pose blocks (or with N_NEIGH = 10): the finish in the consumer and the bounded search come together or not at all
+            if (!(P.pre_finish == 1 && P.warm)) return fail(ctx, MLH_ERR_UNSUPPORTED, "pose blocks: the deferred finish and the bounded search are one schedule");
+            if (P.knn_lanes == 0) MLH_KNN_LAUNCH_GN_MB(0);
+            else if (P.knn_lanes == 16) MLH_KNN_LAUNCH_GN_MB(16);
+            else MLH_KNN_LAUNCH_GN_MB(8);
+        }
+        else if (P.pre_finish || P.warm) {
             if (P.knn_lanes == 0) MLH_KNN_LAUNCH_GN(0);
             else if (P.knn_lanes == 16) MLH_KNN_LAUNCH_GN(16);
             else MLH_KNN_LAUNCH_GN(8);
@@ -1068,12 +1135,14 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         else if (P.knn_lanes == 16) MLH_KNN_LAUNCH(16);
         else MLH_KNN_LAUNCH(8);
 #undef MLH_KNN_LAUNCH_GN
+#undef MLH_KNN_LAUNCH_GN_MB
 #undef MLH_KNN_LAUNCH
     }
     if (P.finish == 3) {
         if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");
         launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, true>, grid_b, P);
-    } else if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10, false>, grid_b, P);
+    } else if (k10 && P.finish == 0) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10, false, false>, grid_b, P);
+    else if (k10) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<10, false>, grid_b, P);
     else if (P.finish == 0) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false, false>, grid_b, P);
     else launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());

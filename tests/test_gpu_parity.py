@@ -672,6 +672,17 @@ def test_pose_blocks_config4_parity(mla, orc, synth, case16):
             assert s["is_degenerate"] == r["is_degenerate"]
         dt, dr = _pose_err(poses[b], ref["pose"])
         assert dt < 1e-7 and dr < 1e-7, (b, dt, dr)
+    # the statistics path above is the classic finish. Without statistics the finish of every iteration but the last runs in the next correspondence launch, per
+    # block (a workgroup sums and solves only its own block's records), with the search bounded by the previous iteration's 5 / 10 neighbours: the same bits -- also
+    # with 1 LiDAR's blocks mixed K = 5 / 10, for 2, 3 and 5 iterations
+    for nit in (2, 3, 5):
+        ctx.set_gn_schedule(1, 1, 1)
+        fast = ctx.gn_solve_blocks(poses0, nit, k_neigh, thre, freeze, opts, want_stats=False)[0]
+        ctx.set_gn_schedule(0, 0, 0)
+        classic = ctx.gn_solve_blocks(poses0, nit, k_neigh, thre, freeze, opts, want_stats=False)[0]
+        assert np.array_equal(fast, classic), nit
+        if nit == n_it:
+            assert np.array_equal(classic, poses)
     ctx.close()
 
 
