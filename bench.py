@@ -304,13 +304,22 @@ def main():
     shared_gpus = world > torch.cuda.device_count()
     if shared_gpus:
         local_rank = local_rank % torch.cuda.device_count()
-        if args.comm != "p2p":
+        if args.comm == "rccl":
             raise SystemExit("bench.py: fewer GPUs than ranks needs --comm p2p (RCCL wants a GPU per rank)")
     torch.cuda.set_device(local_rank)
     dist_dev = "cpu" if shared_gpus else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if shared_gpus else "nccl", rank=rank, world_size=world)
+        # (gloo announces its connections on the process's stdout, from C++: kept off the line this script owes its caller)
+        sys.stdout.flush()
+        _fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo" if shared_gpus else "nccl", rank=rank, world_size=world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(_fd1, 1)
+            os.close(_fd1)
 
     mla = importlib.import_module("m-loam_amd")
     synth = importlib.import_module("m-loam_amd.synth")
