@@ -1187,43 +1187,53 @@ private:
 };
 
 // ------------------------------------------------------------------ what makes staging beside the solve legal, as code
-// Pose::operator* / Pose::inverse (pose.cpp:99-113: both go through Pose(q, t), which normalises the quaternion)
+// Pose::operator* / Pose::inverse (pose.cpp:99-113): both construct their result through Pose(q, t), which normalises the quaternion; the rotation of a vector is
+// Eigen's v + w (2 u x v) + u x (2 u x v), Quaterniond::inverse is conjugate / squaredNorm, the quaternion product in Eigen's term order -- the arithmetic of the
+// device's chain (csrc/dev_math.hpp: chain_start_pose), so a host-side prior and the device's chained start pose are the same bits
+// (tests/test_abi.py::test_facade_keyframe_policy_and_pose_chain holds both against the reference's own lines).
+namespace detail {
+inline void quat_rotate(const Quat &q, const double v[3], double o[3])
+{
+    double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    const double c2[3] = {q.y * uv[2] - q.z * uv[1], q.z * uv[0] - q.x * uv[2], q.x * uv[1] - q.y * uv[0]};
+    o[0] = v[0] + q.w * uv[0] + c2[0]; o[1] = v[1] + q.w * uv[1] + c2[1]; o[2] = v[2] + q.w * uv[2] + c2[2];
+}
+inline Quat quat_mul(const Quat &a, const Quat &b)
+{
+    Quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+}
+inline Pose pose_from(const Quat &q, const double t[3])          // Pose(q, t): q normalised
+{
+    Pose r;
+    const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    r.q_.x = q.x / n; r.q_.y = q.y / n; r.q_.z = q.z / n; r.q_.w = q.w / n;
+    r.t_(0) = t[0]; r.t_(1) = t[1]; r.t_(2) = t[2];
+    return r;
+}
+}  // namespace detail
 inline Pose poseMul(const Pose &a, const Pose &b)
 {
-    auto rot = [](const Quat &q, const double v[3], double o[3]) {
-        const double ux = q.x, uy = q.y, uz = q.z, w = q.w;
-        const double cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
-        const double dx = uy * cz - uz * cy, dy = uz * cx - ux * cz, dz = ux * cy - uy * cx;
-        o[0] = v[0] + 2.0 * (w * cx + dx); o[1] = v[1] + 2.0 * (w * cy + dy); o[2] = v[2] + 2.0 * (w * cz + dz);
-    };
-    Pose r;
     double rt[3];
-    rot(a.q_, b.t_.v, rt);
-    for (int i = 0; i < 3; ++i) r.t_(i) = rt[i] + a.t_(i);
-    Quat q;
-    q.w = a.q_.w * b.q_.w - a.q_.x * b.q_.x - a.q_.y * b.q_.y - a.q_.z * b.q_.z;
-    q.x = a.q_.w * b.q_.x + a.q_.x * b.q_.w + a.q_.y * b.q_.z - a.q_.z * b.q_.y;
-    q.y = a.q_.w * b.q_.y - a.q_.x * b.q_.z + a.q_.y * b.q_.w + a.q_.z * b.q_.x;
-    q.z = a.q_.w * b.q_.z + a.q_.x * b.q_.y - a.q_.y * b.q_.x + a.q_.z * b.q_.w;
-    const double n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    r.q_.w = q.w / n; r.q_.x = q.x / n; r.q_.y = q.y / n; r.q_.z = q.z / n;
-    return r;
+    detail::quat_rotate(a.q_, b.t_.v, rt);
+    const double t[3] = {rt[0] + a.t_(0), rt[1] + a.t_(1), rt[2] + a.t_(2)};
+    return detail::pose_from(detail::quat_mul(a.q_, b.q_), t);
 }
 inline Pose poseInverse(const Pose &a)
 {
-    Pose inv;
-    const double n2 = a.q_.w * a.q_.w + a.q_.x * a.q_.x + a.q_.y * a.q_.y + a.q_.z * a.q_.z;
-    inv.q_.w = a.q_.w / n2; inv.q_.x = -a.q_.x / n2; inv.q_.y = -a.q_.y / n2; inv.q_.z = -a.q_.z / n2;
-    Pose id;                         // -(q^-1 t): rotate through poseMul's helper by composing with a pure translation
-    Pose tr;
-    tr.t_ = a.t_;
-    Pose qonly = inv;
-    const Pose rt = poseMul(qonly, tr);
-    for (int i = 0; i < 3; ++i) inv.t_(i) = -rt.t_(i);
-    const double n = std::sqrt(inv.q_.w * inv.q_.w + inv.q_.x * inv.q_.x + inv.q_.y * inv.q_.y + inv.q_.z * inv.q_.z);
-    inv.q_.w /= n; inv.q_.x /= n; inv.q_.y /= n; inv.q_.z /= n;
-    (void)id;
-    return inv;
+    const double n2 = a.q_.x * a.q_.x + a.q_.y * a.q_.y + a.q_.z * a.q_.z + a.q_.w * a.q_.w;
+    Quat qi;
+    if (n2 > 0.0) { qi.x = -a.q_.x / n2; qi.y = -a.q_.y / n2; qi.z = -a.q_.z / n2; qi.w = a.q_.w / n2; }
+    else { qi.x = qi.y = qi.z = qi.w = 0.0; }
+    double mt[3];
+    detail::quat_rotate(qi, a.t_.v, mt);
+    const double t[3] = {-mt[0], -mt[1], -mt[2]};
+    return detail::pose_from(qi, t);
 }
 
 // The mapper's keyframe bookkeeping: saveKeyframe's test (lidar_mapper_keyframe.cpp:641-657) and extractSurroundingKeyFrames' selection (cpp:263-272). The

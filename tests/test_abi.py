@@ -138,3 +138,65 @@ def test_facade_window_degeneracy_policy(tmp_path, orc):
             np.testing.assert_allclose(out[nb * 38:], want["d_factor_calib"], rtol=1e-9)
         assert want["is_degenerate"][2]
 
+
+
+def test_facade_keyframe_policy_and_pose_chain(tmp_path, orc):
+    """The host side of the pipelined mapper loop, without a GPU: poseMul / poseInverse compose the next frame's start pose as the reference's own lines do
+    (Pose::operator*, Pose::inverse, transformUpdate, transformAssociateToMap through oracle/_ref -- bit for bit, as the device's chain is), and KeyframePolicy makes
+    saveKeyframe's decisions (lidar_mapper_keyframe.cpp:641-657) and extractSurroundingKeyFrames' selection (cpp:266-272: within the radius, nearest first)."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "keyframe_policy_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "keyframe_policy_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(12)
+    n = 40
+    # a trajectory: 0.3-0.5 m and up to 0.8 degrees per frame, one sharper turn
+    poses = np.zeros((n, 7))
+    t = np.zeros(3)
+    yaw = 0.0
+    for i in range(n):
+        yaw += np.radians(rng.uniform(-0.8, 0.8) + (3.0 if i == 17 else 0.0))
+        t = t + np.array([np.cos(yaw), np.sin(yaw), 0.02 * rng.normal()]) * rng.uniform(0.3, 0.5)
+        q = np.array([0.01 * rng.normal(), 0.01 * rng.normal(), np.sin(yaw / 2), np.cos(yaw / 2)])
+        poses[i] = np.concatenate([t, q / np.linalg.norm(q)])
+    poses.tofile(tmp_path / "poses.f64")
+    dist_kf, ori_kf, radius = 1.0, 1.0, 4.0
+    subprocess.run([exe, str(tmp_path), str(n), str(dist_kf), str(ori_kf), str(radius)], check=True)
+    out = np.fromfile(tmp_path / "out.f64")
+    chain = out[:7 * (n - 2)].reshape(n - 2, 7)
+    dec = out[7 * (n - 2):].reshape(n, 4)
+    if orc.ref_lib() is not None:
+        for i in range(n - 2):
+            assert np.array_equal(chain[i], orc.ref_pose_chain(poses[i], poses[i + 1], poses[i + 2])), i
+    for i in range(n - 2):
+        assert np.array_equal(chain[i], orc.pose_chain(poses[i], poses[i + 1], poses[i + 2])), i
+    # saveKeyframe / radius search restated: f32 positions (PointI), angularDistance = 2 acos(|q1 . q2|)
+    kf_pos, kf_ids, prev_p, prev_q = [], [], None, None
+    n_saved = 0
+    for i in range(n):
+        p32 = poses[i, :3].astype(np.float32)
+        if prev_p is None:
+            save = True
+        else:
+            d = float(np.sqrt(np.float64(np.sum((p32 - prev_p) ** 2, dtype=np.float32))))
+            ang = np.degrees(2.0 * np.arccos(min(1.0, abs(float(poses[i, 3:] @ prev_q)))))
+            save = d > dist_kf or ang > ori_kf
+        assert bool(dec[i, 0]) == save, i
+        if save:
+            assert int(dec[i, 1]) == n_saved
+            kf_pos.append(p32); prev_p, prev_q = p32, poses[i, 3:].copy(); n_saved += 1
+        else:
+            assert int(dec[i, 1]) == -1
+        kp = np.array(kf_pos)
+        d2 = np.sum((kp - p32) ** 2, axis=1, dtype=np.float32)
+        ids = [int(j) for j in np.lexsort((np.arange(len(kp)), d2)) if d2[j] <= np.float32(radius) ** 2]
+        h = 0.0
+        for j in ids:
+            h = h * 31.0 + (j + 1)
+        assert int(dec[i, 2]) == len(ids) and dec[i, 3] == h, (i, ids)
+    assert 5 < n_saved < n - 5                      # both decisions occur
