@@ -357,15 +357,17 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
             MLH_HIP(ctx, stream_wait_spin(ctx));
         }
         if (n_undecided_pts > 0) {
-            std::vector<int2> fix(static_cast<size_t>(n_undecided_pts));
+            // the verdicts overwrite the records they answer, in place in the pinned block (an int2 per float4 slot: never ahead of the record being read), and go
+            // back from there: no pageable staging, nothing to wait for
+            int2 *fix = reinterpret_cast<int2 *>(hp);
             for (int k = 0; k < n_undecided_pts; ++k) {
+                const float4 rec = hp[k];
                 int idx;
-                std::memcpy(&idx, &hp[k].w, sizeof(int));
-                fix[size_t(k)] = make_int2(idx, seg_pixel_host(hp[k].x, hp[k].y, hp[k].z, S, prm.roi_range));
+                std::memcpy(&idx, &rec.w, sizeof(int));
+                fix[k] = make_int2(idx, seg_pixel_host(rec.x, rec.y, rec.z, S, prm.roi_range));
             }
-            MLH_HIP(ctx, B.fix.ensure(sizeof(int2) * fix.size()));
-            MLH_HIP(ctx, hipMemcpyAsync(B.fix.p, fix.data(), sizeof(int2) * fix.size(), hipMemcpyHostToDevice, st));
-            MLH_HIP(ctx, hipStreamSynchronize(st));      // `fix` is pageable and goes out of scope
+            MLH_HIP(ctx, B.fix.ensure(sizeof(int2) * size_t(n_undecided_pts)));
+            MLH_HIP(ctx, hipMemcpyAsync(B.fix.p, fix, sizeof(int2) * size_t(n_undecided_pts), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(seg_apply_fix_kernel, dim3((n_undecided_pts + 255) / 256), dim3(256), 0, st, (const int2 *)B.fix.as<int2>(), n_undecided_pts, D.pix, D.owner);
         }
     }
