@@ -1,0 +1,104 @@
+"""Soak of the Gauss-Newton schedule's state machine (deferred finish, bounded search, final-in-successor, split scan2map): two contexts get the SAME random
+sequence of calls -- one with every switch on, one with the classic schedule -- and every pose that comes back must be the same bits. Operations: synchronous
+solves (with / without statistics, 1..6 iterations), submit / chained submit / collect in every legal interleaving (up to two in flight), scan2map (synchronous and
+split), feature sets of changing size between frames (more tiles than the record buffer holds, fewer), map re-staging (plain and overlapped), pose-block solves.
+usage: python scripts/soak_schedule.py [seconds] [seed]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import conftest, oracle as O
+mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+O.build()
+case = conftest._make_case(synth, "50k", 16, 1)
+feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+p0 = case["p0"]
+ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+ctxs = [mla.Context(0), mla.Context(0)]
+ctxs[0].set_gn_schedule(1, 1, 1)
+ctxs[1].set_gn_schedule(0, 0, 0)
+for c in ctxs:
+    c.map_set_pair(case["surf_map"], case["corner_map"])
+    c.features_set(mla.SURF, feats[0]); c.features_set(mla.CORNER, feats[1])
+in_flight = []          # kinds of the solves in flight ("gn" / "s2m"), oldest first
+n_ops = n_cmp = 0
+t0 = time.time()
+def both(fn):
+    return [fn(c) for c in ctxs]
+def check(a, b, what):
+    global n_cmp
+    n_cmp += 1
+    if not np.array_equal(np.asarray(a), np.asarray(b)):
+        raise SystemExit(f"MISMATCH after {n_ops} operations in `{what}`: {a} vs {b}")
+while time.time() - t0 < budget:
+    n_ops += 1
+    ops = ["sync", "sync_stats", "s2m", "feat", "map"]
+    if len(in_flight) < 2:
+        ops += ["begin", "begin", "s2m_begin"]
+        if in_flight or n_ops > 3:
+            ops += ["chained", "chained", "chained", "s2m_chained"]
+    if in_flight:
+        ops += ["end", "end", "end"]
+    if not in_flight:
+        ops += ["blocks"]
+    op = ops[rng.integers(len(ops))]
+    if op in ("sync", "sync_stats"):
+        n = int(rng.integers(1, 7))
+        r = both(lambda c: c.gn_solve(p0, n, want_stats=(op == "sync_stats"))[0])
+        check(r[0], r[1], op)
+    elif op == "s2m":
+        r = both(lambda c: c.scan2map(p0, want_stats=False)[0])
+        check(r[0], r[1], op)
+    elif op == "begin":
+        n = int(rng.integers(1, 7))
+        both(lambda c: c.gn_solve_begin(p0, n)); in_flight.append("gn")
+    elif op == "chained":
+        n = int(rng.integers(1, 7))
+        both(lambda c: c.gn_solve_begin_chained(ident, ident, n)); in_flight.append("gn")
+    elif op == "s2m_begin":
+        la = int(rng.integers(0, 8))
+        both(lambda c: c.scan2map_begin(p0, lm_lookahead=la)); in_flight.append("s2m")
+    elif op == "s2m_chained":
+        la = int(rng.integers(0, 8))
+        both(lambda c: c.scan2map_begin_chained(ident, ident, lm_lookahead=la)); in_flight.append("s2m")
+    elif op == "end":
+        kind = in_flight.pop(0)
+        if kind == "gn":
+            r = both(lambda c: c.gn_solve_end())
+            check(r[0], r[1], "gn_solve_end")
+        else:
+            r = both(lambda c: c.scan2map_end())
+            # status 1 hands the START pose back (the caller re-solves): a younger solve behind it then starts from an unfinished pose in BOTH contexts alike
+            check(r[0][0], r[1][0], "scan2map_end"); assert r[0][1] == r[1][1]
+    elif op == "feat":
+        # features change size between frames (only legal with nothing in flight that reads them: drain first)
+        while in_flight:
+            kind = in_flight.pop(0)
+            r = both(lambda c: c.gn_solve_end() if kind == "gn" else c.scan2map_end()[0])
+            check(r[0], r[1], "drain")
+        k = int(rng.integers(1, 14))
+        fs = np.ascontiguousarray(np.tile(feats[0], (k, 1))[: int(rng.integers(400, len(feats[0]) * k + 1))])
+        fc = np.ascontiguousarray(np.tile(feats[1], (k, 1))[: int(rng.integers(60, len(feats[1]) * k + 1))])
+        both(lambda c: (c.features_set(mla.SURF, fs), c.features_set(mla.CORNER, fc)))
+    elif op == "map":
+        if len(in_flight) <= 1:
+            both(lambda c: c.map_set_pair_overlapped(case["surf_map"], case["corner_map"]) if in_flight else c.map_set_pair(case["surf_map"], case["corner_map"]))
+    elif op == "blocks":
+        half = len(feats[0]) // 2
+        hc = len(feats[1]) // 2
+        sb, cb = [feats[0][:half], feats[0][half:]], [feats[1][:hc], feats[1][hc:]]
+        both(lambda c: (c.features_set_blocks(mla.SURF, sb), c.features_set_blocks(mla.CORNER, cb)))
+        n = int(rng.integers(1, 6))
+        r = both(lambda c: c.gn_solve_blocks(np.array([p0, p0]), n, [5, 10], [100.0, 70.0], [0, 1], want_stats=False)[0])
+        check(r[0], r[1], "blocks")
+        both(lambda c: (c.features_set(mla.SURF, feats[0]), c.features_set(mla.CORNER, feats[1])))
+while in_flight:
+    kind = in_flight.pop(0)
+    r = both(lambda c: c.gn_solve_end() if kind == "gn" else c.scan2map_end()[0])
+    check(r[0], r[1], "final drain")
+for c in ctxs:
+    c.close()
+print(f"schedule soak: {n_ops} operations, {n_cmp} poses compared bit for bit between the round-4 schedule and the classic one, seed {seed}, {time.time() - t0:.0f} s: all equal")
