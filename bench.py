@@ -221,6 +221,58 @@ def single_gpu_config4(mla, torch, device, surf_map, corner_map, surf_b, corner_
         c.close()
 
 
+def config4_block_owner(n_blocks, world):
+    """config 4's pose blocks dealt over the ranks: block b -> rank b mod min(world, n_blocks); ranks beyond the block count own nothing"""
+    return [b % min(world, n_blocks) for b in range(n_blocks)]
+
+
+def block_sharded_config4(mla, torch, dist, dist_dev, device, rank, world, surf_map, corner_map, surf_b, corner_b, poses0, steps, warmup):
+    """config 4's frame with its POSE BLOCKS dealt over the ranks and the map replicated: the blocks' normal equations are independent (one 7-parameter block per
+    LiDAR: LidarOnlineCalib* factors carry a single parameter block each, estimator.cpp:1067-1157), so no rank ever needs another rank's sums -- no collective in the
+    data path, one barrier around the timed region. Every rank: its own context (no communicator), the WHOLE map staged + indexed per step, its blocks through
+    mlh_gn_solve_blocks. Returns (max-over-ranks seconds per step, poses of all blocks gathered on every rank, owner table)."""
+    owner = config4_block_owner(len(surf_b), world)
+    mine = [b for b, r_ in enumerate(owner) if r_ == rank]
+    c = mla.Context(device)
+    try:
+        d_sm, d_cm = torch.from_numpy(np.ascontiguousarray(surf_map)).cuda(), torch.from_numpy(np.ascontiguousarray(corner_map)).cuda()
+        torch.cuda.synchronize()
+        o4 = mla.default_opts(flags=mla.FLAG_CHECK_FOV, huber_delta=1.0)
+        if mine:
+            c.map_set_pair(d_sm, d_cm)
+            c.features_set_blocks(mla.SURF, [surf_b[b] for b in mine])
+            c.features_set_blocks(mla.CORNER, [corner_b[b] for b in mine])
+        k_, t_, f_ = [CFG4_K[b] for b in mine], [CFG4_THRE[b] for b in mine], [CFG4_FREEZE[b] for b in mine]
+        p_ = np.ascontiguousarray(np.asarray(poses0)[mine]) if mine else None
+        out_ = [None]
+
+        def frame():
+            if mine:
+                c.map_set_pair(d_sm, d_cm)
+                out_[0] = c.gn_solve_blocks(p_, GN_ITERS, k_, t_, f_, o4, want_stats=False)[0]
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < 0.15:
+            frame()
+        for _ in range(warmup):
+            frame()
+        c.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        c.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dist_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        poses = torch.zeros((len(surf_b), 7), dtype=torch.float64, device=dist_dev)
+        for i_, b in enumerate(mine):
+            poses[b] = torch.from_numpy(np.asarray(out_[0])[i_]).to(dist_dev)
+        dist.all_reduce(poses)          # every block has exactly one owner: the sum is a gather
+        return float(tt.item()) / steps, poses.cpu().numpy(), owner
+    finally:
+        c.close()
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` without a launcher: re-run this very command line under torch.distributed.run with N ranks and pass its exit code on"""
     import socket
@@ -942,6 +994,21 @@ def main():
                     n1_same_map_ms_per_step=(ref4 or {}).get("ms_per_step"),
                     speedup_vs_n1_same_map=(round(ref4["ms_per_step"] / (1e3 * el4 / args.steps), 4) if ref4 else None),
                     pose_vs_n1_same_map_m=(float(np.abs(np.asarray(ref4["poses"])[:, :3] - np.asarray(poses4_t)[:, :3]).max()) if ref4 else None))
+        if world > 1:
+            # the same frame with the BLOCKS dealt over the ranks instead of the map (replicated here): no exchange at all, and the only split of this path that can
+            # shorten a frame whose kernels are latency-bound
+            s_b, poses_b, owner_b = block_sharded_config4(mla, torch, dist, dist_dev, local_rank, rank, world, surf_map, corner_map, surf_b, corner_b, poses0,
+                                                         args.steps, args.warmup)
+            ref_p = np.asarray(ref4["poses"]) if ref4 else None
+            cfg4["blocks_over_ranks"] = dict(
+                what="pose blocks dealt over the ranks (block b -> rank b mod min(N, 4)), whole map replicated, staged and indexed on every rank per step, "
+                     "no collective in the data path (the blocks' normal equations are independent); timed between barriers, max over the ranks",
+                block_owner=owner_b, ranks_without_a_block=max(0, world - len(surf_b)),
+                ms_per_step=round(1e3 * s_b, 4), value=round(n_valid4_step / s_b, 1),
+                speedup_vs_n1_same_map=(round(ref4["ms_per_step"] / (1e3 * s_b), 4) if ref4 else None),
+                poses_equal_n1_same_map_bit_for_bit=(bool(np.array_equal(ref_p, poses_b)) if ref4 else None),
+                pose_vs_n1_same_map_m=(float(np.abs(ref_p[:, :3] - poses_b[:, :3]).max()) if ref4 else None),
+                ranks_share_gpus=bool(shared_gpus))
 
     owned_all = local_map_all = None
     if world > 1:

@@ -1119,7 +1119,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
             if (k10) launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, true, true, 1, true>, grid_a, P); \
             else launch_timed(ctx, MLH_K_KNN_PRE, knn_features_kernel<G_, true, false, 1, true>, grid_a, P); \
         } while (0)
-        if ((P.pre_finish || P.warm) && (mb || k10)) {
+        if ((P.pre_finish || P.warm) && (mb || k10 || a.gn_blocks)) {     // (a.gn_blocks: a blocks solve over ONE block keeps the blocks' pose slots)
             // a solve over pose blocks (or with N_NEIGH = 10): the finish in the consumer and the bounded search come together or not at all
             if (!(P.pre_finish == 1 && P.warm)) return fail(ctx, MLH_ERR_UNSUPPORTED, "pose blocks: the deferred finish and the bounded search are one schedule");
             if (P.knn_lanes == 0) MLH_KNN_LAUNCH_GN_MB(0);

@@ -51,6 +51,23 @@ for preset in os.environ.get("CALIBBENCH_PRESETS", "500k,4M").split(","):
     tk = 1e3 * (ms.rebuild_seconds() + mc.rebuild_seconds())
     print(f"config 4 on one GPU, {preset} map ({len(surf_map) + len(corner_map)} points), {nf} features in 4 pose blocks: index rebuild + {n_it} GN iterations "
           f"GPU {gpu_ms:.3f} ms ({nf * n_it / gpu_ms * 1e3:.3g} features/s); CPU oracle {cpu_ms:.0f} ms + kd-tree build {tk:.0f} ms; max |dt| over blocks {max(dts):.1e} m; first map_set {t_set:.1f} ms")
+    # ---- each block ALONE on this GPU (what one of four GPUs runs when bench.py deals the pose blocks over the ranks: whole map, one block, no exchange): the
+    # slowest block is the frame time four GPUs would have, measured here on one -- a projection, not a multi-GPU measurement
+    alone = []
+    for b in range(4):
+        ctx.features_set_blocks(mla.SURF, [surf_b[b]]); ctx.features_set_blocks(mla.CORNER, [corner_b[b]])
+        def frame1():
+            ctx.map_rebuild(mla.ALL_KINDS)
+            return ctx.gn_solve_blocks(poses0[b:b + 1].copy(), n_it, k_neigh[b:b + 1], thre[b:b + 1], freeze[b:b + 1], opts, want_stats=False)
+        for _ in range(20): o1 = frame1()
+        ctx.synchronize(); t0 = time.perf_counter()
+        for _ in range(40): o1 = frame1()
+        ctx.synchronize(); alone.append(1e3 * (time.perf_counter() - t0) / 40)
+        assert np.array_equal(np.asarray(o1[0])[0], np.asarray(poses)[b]), b
+    print(f"  every block by itself on this GPU (index rebuild + {n_it} GN iterations, poses bit-equal to the four-block solve): " + " / ".join(f"{a:.3f}" for a in alone)
+          + f" ms -> with the blocks dealt over 4 GPUs (bench.py config4.blocks_over_ranks; no exchange) a frame would take {max(alone):.3f} ms, {gpu_ms / max(alone):.2f}x "
+          f"(projected from one GPU; never run on four)")
+    ctx.features_set_blocks(mla.SURF, surf_b); ctx.features_set_blocks(mla.CORNER, corner_b)
     # ---- the COUPLED window problem of Estimator::optimizeMap (estimator.cpp:687-848) on the same data: parameter blocks [pivot | 1 frame | 4
     # extrinsics] = 36 local parameters, one LidarPureOdom{PlaneNorm,Edge}Factor per matched feature of every LiDAR; pivot and the reference
     # LiDAR's extrinsic held constant (estimator.cpp:636, 642). Matching on the GPU against the resident map (pivot frame = map frame here),

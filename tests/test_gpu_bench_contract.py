@@ -97,3 +97,7 @@ def test_bench_config4_two_ranks_sharing_the_gpu():
     assert len(c4["features_per_block_surf"]) == 4 and c4["valid_correspondences_per_step"] > 0 and c4["n1_same_map_ms_per_step"] > 0
     assert c4["pose_vs_n1_same_map_m"] < 1e-7, c4
     assert "config2_leg" in d and d["config2_leg"]["value"] > 0
+    # the same frame with the four pose blocks dealt over the ranks (map replicated, no collective): a block solved alone is the block solved among four, to the bit
+    bo = c4["blocks_over_ranks"]
+    assert bo["block_owner"] == [0, 1, 0, 1] and bo["ranks_without_a_block"] == 0 and bo["ms_per_step"] > 0
+    assert bo["poses_equal_n1_same_map_bit_for_bit"] is True, bo

@@ -683,6 +683,16 @@ def test_pose_blocks_config4_parity(mla, orc, synth, case16):
         assert np.array_equal(fast, classic), nit
         if nit == n_it:
             assert np.array_equal(classic, poses)
+    # the blocks are independent: any subset of them solved by itself (bench.py deals the blocks over the ranks that way: one block with N_NEIGH 10 alone, two of
+    # four, ...) returns the bits those blocks have among all four, under both schedules
+    for subset in ([0], [1], [3], [0, 2], [1, 3], [1, 2, 3]):
+        ctx.features_set_blocks(mla.SURF, [surf_b[b] for b in subset])
+        ctx.features_set_blocks(mla.CORNER, [corner_b[b] for b in subset])
+        arg = (np.ascontiguousarray(poses0[subset]), n_it, [k_neigh[b] for b in subset], [thre[b] for b in subset], [freeze[b] for b in subset], opts)
+        for sched in ((1, 1, 1), (0, 0, 0)):
+            ctx.set_gn_schedule(*sched)
+            got = ctx.gn_solve_blocks(*arg, want_stats=False)[0]
+            assert np.array_equal(np.asarray(got), np.asarray(poses)[subset]), (subset, sched, np.abs(np.asarray(got) - np.asarray(poses)[subset]).max())
     ctx.close()
 
 
