@@ -300,7 +300,9 @@ int mlh_map_set_pair(mlh_ctx *ctx, const void *surf_points, int n_surf, const vo
                      float min_match_sq_dis, int mem);
 /* The same, for the NEXT frame while a solve submitted with mlh_gn_solve_begin is still running: the maps are double-buffered, this call stages and indexes
  * into the set the solve does not read, on a second stream, returns when that index is complete and makes the set current -- launches enqueued afterwards (the
- * next mlh_gn_solve_begin) read it; the solve in flight keeps the old one (one solve in flight at this point: collect the older one first). 
+ * next mlh_gn_solve_begin) read it; the solve in flight keeps the old one (one solve in flight at this point: collect the older one first). Called a second
+ * time beside the SAME uncollected solve, its target is the set that solve reads: the call then waits for the main stream to run dry before it rewrites the set
+ * (correct, no longer overlapped).
  * The GPU then builds the next index (a chain of small launches) in the shadow of the current frame's iterations. What the caller must know: in the reference the
  * local map of frame k + 1 depends on frame k's optimised pose in one place -- extractSurroundingKeyFrames (lidar_mapper_keyframe.cpp:254-354) picks the keyframes
  * within a radius of the PREDICTED pose of frame k + 1, which carries frame k's map-to-odometry correction (cpp:145-160). A caller that stages this early selects
@@ -467,7 +469,8 @@ typedef struct mlh_block_opts {
 } mlh_block_opts;
 /* n_iters GN iterations on n_blocks independent pose blocks (poses_inout: n_blocks x 7), one correspondence + one fit launch
  * per iteration for all blocks and both feature kinds. stats: n_iters x n_blocks records (iteration-major), may be NULL;
- * termination = 1 in a record marks a frozen block. Multi-LiDAR features must have been staged with mlh_features_set_block. */
+ * termination = 1 in a record marks a frozen block. Multi-LiDAR features must have been staged with mlh_features_set_block (a block of one kind may be empty,
+ * n = 0: a LiDAR without corner features in this frame; any subset of the blocks solved by itself returns the bits those blocks have among all of them). */
 int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const mlh_solver_opts *opts, const mlh_block_opts *block_opts,
                         mlh_iter_stat *stats);
 

@@ -791,6 +791,10 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
     // after every solve, a wait before the next: two barrier packets, ~10 us of idle stream per frame in the kernel trace. Both are gone: the host orders.)
     if (ctx->solve_seq - ctx->solve_collected > 1) return fail(ctx, MLH_ERR_STATE, "collect the older solve (mlh_gn_solve_end) before staging the next frame's maps");
     const int target = 1 - ctx->map_set_cur;
+    // ... unless the caller stages twice beside ONE solve (begin on A; overlapped -> B; overlapped -> A again with that solve uncollected): then the target's reader
+    // is the solve in flight, and the set is rewritten only once the main stream has run dry (scripts/soak_schedule.py found this as a rare, timing-dependent
+    // difference of 1e-5 m: the index of A rebuilt under a correspondence launch)
+    if (ctx->set_reader_seq[target] > ctx->solve_collected) MLH_HIP(ctx, stream_wait_spin(ctx));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->stream2;                    // everything map_set_impl enqueues (and its profiling brackets) goes to the staging stream ...
     ctx->map = ctx->map_sets[target];              // ... and into the other set
@@ -917,7 +921,8 @@ int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points
 {
     if (ctx) ++ctx->stage_epoch;      // (mlh_scan2map_end: a frame in flight may only be re-solved on the inputs it was submitted with)
     if (!ctx || kind < 0 || kind > 1 || block < 0 || block >= 8) return MLH_ERR_INVALID;
-    if (!points || n <= 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer");
+    // (n == 0: a LiDAR without features of this kind in this frame -- the block exists, holds nothing, contributes no residuals; `points` may be null then)
+    if ((!points && n > 0) || n < 0 || stride_bytes < 12 || (stride_bytes & 3)) return fail(ctx, MLH_ERR_INVALID, "bad point buffer");
     if (cov_offset_bytes >= 0 && cov_offset_bytes + 24 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "cov_offset_bytes + 24 exceeds the record stride");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     FeatSet &f = ctx->feat[kind];
@@ -931,13 +936,14 @@ int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points
     if (start > f.m)
         hipLaunchKernelGGL(pad_fill_kernel, dim3((start - f.m + 255) / 256), dim3(256), 0, ctx->stream, f.pts.as<float4>(), f.covd.as<float4>(), f.m, start);
     const unsigned char *src = static_cast<const unsigned char *>(points);
-    if (mem == MLH_MEM_HOST) {
+    if (mem == MLH_MEM_HOST && n > 0) {
         MLH_HIP(ctx, ctx->tmp.ensure(size_t(n) * stride_bytes));
         MLH_HIP(ctx, hipMemcpyAsync(ctx->tmp.p, points, size_t(n) * stride_bytes, hipMemcpyHostToDevice, ctx->stream));
         src = ctx->tmp.as<unsigned char>();
     }
-    hipLaunchKernelGGL(pack_block_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride_bytes, n, cov_offset_bytes, float(block),
-                       f.pts.as<float4>() + start, f.covd.as<float4>() + start);
+    if (n > 0)
+        hipLaunchKernelGGL(pack_block_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride_bytes, n, cov_offset_bytes, float(block),
+                           f.pts.as<float4>() + start, f.covd.as<float4>() + start);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     f.blk_start[block] = start;
@@ -1368,6 +1374,7 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         ctx->gn_pending.seq = seq;
     }
     ctx->solve_seq = seq;
+    ctx->set_reader_seq[ctx->map_set_cur] = seq;
     ctx->solve_pending = true;
     return MLH_OK;
 }
@@ -1629,6 +1636,7 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         }
     }
     ctx->solve_seq = seq;
+    ctx->set_reader_seq[ctx->map_set_cur] = seq;
     ctx->solve_pending = true;
     return MLH_OK;
 }

@@ -274,6 +274,7 @@ struct mlh_ctx {
     unsigned pts_turn = 0;
     void *h_solve = nullptr; // pinned HostPublish record of a solve submitted with mlh_gn_solve_begin (collected by mlh_gn_solve_end)
     unsigned long long solve_seq = 0, solve_collected = 0;   // submitted / collected solves (at most two apart)
+    unsigned long long set_reader_seq[2] = {0, 0};            // the youngest submitted solve that reads map set 0 / 1 (mlh_map_set_pair_overlapped: a set is rewritten only behind its readers)
     struct SolveSlot {                 // what mlh_scan2map_end needs to know about the solve whose record is h_solve[seq & 1]
         int kind = 0;                  // 0: Gauss-Newton (mlh_gn_solve_begin*), 1: scan2map (mlh_scan2map_begin*), 2: scan2map on maps too small to optimise against (the start pose comes back)
         bool chained = false;

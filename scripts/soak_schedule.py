@@ -28,11 +28,12 @@ n_ops = n_cmp = 0
 t0 = time.time()
 def both(fn):
     return [fn(c) for c in ctxs]
+trace = []
 def check(a, b, what):
     global n_cmp
     n_cmp += 1
     if not np.array_equal(np.asarray(a), np.asarray(b)):
-        raise SystemExit(f"MISMATCH after {n_ops} operations in `{what}`: {a} vs {b}")
+        raise SystemExit(f"MISMATCH after {n_ops} operations in `{what}`: {a} vs {b}\nlast operations: " + " | ".join(trace[-40:]))
 while time.time() - t0 < budget:
     n_ops += 1
     ops = ["sync", "sync_stats", "s2m", "feat", "map"]
@@ -43,10 +44,12 @@ while time.time() - t0 < budget:
     if in_flight:
         ops += ["end", "end", "end"]
     if not in_flight:
-        ops += ["blocks"]
+        ops += ["blocks", "blocks"]
     op = ops[rng.integers(len(ops))]
+    trace.append(op)
     if op in ("sync", "sync_stats"):
         n = int(rng.integers(1, 7))
+        trace[-1] += f"({n})"
         r = both(lambda c: c.gn_solve(p0, n, want_stats=(op == "sync_stats"))[0])
         check(r[0], r[1], op)
     elif op == "s2m":
@@ -54,18 +57,19 @@ while time.time() - t0 < budget:
         check(r[0], r[1], op)
     elif op == "begin":
         n = int(rng.integers(1, 7))
-        both(lambda c: c.gn_solve_begin(p0, n)); in_flight.append("gn")
+        both(lambda c: c.gn_solve_begin(p0, n)); in_flight.append("gn"); trace[-1] += f"({n})"
     elif op == "chained":
         n = int(rng.integers(1, 7))
-        both(lambda c: c.gn_solve_begin_chained(ident, ident, n)); in_flight.append("gn")
+        both(lambda c: c.gn_solve_begin_chained(ident, ident, n)); in_flight.append("gn"); trace[-1] += f"({n})"
     elif op == "s2m_begin":
         la = int(rng.integers(0, 8))
-        both(lambda c: c.scan2map_begin(p0, lm_lookahead=la)); in_flight.append("s2m")
+        both(lambda c: c.scan2map_begin(p0, lm_lookahead=la)); in_flight.append("s2m"); trace[-1] += f"({la})"
     elif op == "s2m_chained":
         la = int(rng.integers(0, 8))
-        both(lambda c: c.scan2map_begin_chained(ident, ident, lm_lookahead=la)); in_flight.append("s2m")
+        both(lambda c: c.scan2map_begin_chained(ident, ident, lm_lookahead=la)); in_flight.append("s2m"); trace[-1] += f"({la})"
     elif op == "end":
         kind = in_flight.pop(0)
+        trace[-1] += f"[{kind}]"
         if kind == "gn":
             r = both(lambda c: c.gn_solve_end())
             check(r[0], r[1], "gn_solve_end")
@@ -82,18 +86,29 @@ while time.time() - t0 < budget:
         k = int(rng.integers(1, 14))
         fs = np.ascontiguousarray(np.tile(feats[0], (k, 1))[: int(rng.integers(400, len(feats[0]) * k + 1))])
         fc = np.ascontiguousarray(np.tile(feats[1], (k, 1))[: int(rng.integers(60, len(feats[1]) * k + 1))])
+        trace[-1] += f"({len(fs)},{len(fc)})"
         both(lambda c: (c.features_set(mla.SURF, fs), c.features_set(mla.CORNER, fc)))
     elif op == "map":
+        trace[-1] += f"[{len(in_flight)} in flight]"
         if len(in_flight) <= 1:
             both(lambda c: c.map_set_pair_overlapped(case["surf_map"], case["corner_map"]) if in_flight else c.map_set_pair(case["surf_map"], case["corner_map"]))
     elif op == "blocks":
-        half = len(feats[0]) // 2
-        hc = len(feats[1]) // 2
-        sb, cb = [feats[0][:half], feats[0][half:]], [feats[1][:hc], feats[1][hc:]]
+        # 1..4 pose blocks of random sizes (a block may hold a handful of features, or no corner features at all), N_NEIGH 5 / 10 and freeze flags at random
+        nb = int(rng.integers(1, 5))
+        cut_s = np.sort(rng.integers(1, len(feats[0]), nb - 1)) if nb > 1 else np.array([], int)
+        cut_c = np.sort(rng.integers(0, len(feats[1]) + 1, nb - 1)) if nb > 1 else np.array([], int)
+        sb = [np.ascontiguousarray(x) for x in np.split(feats[0], cut_s)]
+        cb = [np.ascontiguousarray(x) for x in np.split(feats[1], cut_c)]
+        if any(len(x) == 0 for x in sb):
+            continue
         both(lambda c: (c.features_set_blocks(mla.SURF, sb), c.features_set_blocks(mla.CORNER, cb)))
         n = int(rng.integers(1, 6))
-        r = both(lambda c: c.gn_solve_blocks(np.array([p0, p0]), n, [5, 10], [100.0, 70.0], [0, 1], want_stats=False)[0])
-        check(r[0], r[1], "blocks")
+        kk = [int(rng.choice([5, 10])) for _ in range(nb)]
+        th = [float(rng.choice([100.0, 70.0, 1e9])) for _ in range(nb)]       # (1e9: every direction "degenerate")
+        fz = [int(rng.integers(0, 2)) for _ in range(nb)]
+        trace[-1] += f"(nb={nb},n={n},K={kk},sizes={[len(x) for x in sb]}/{[len(x) for x in cb]})"
+        r = both(lambda c: c.gn_solve_blocks(np.array([p0] * nb), n, kk, th, fz, want_stats=False)[0])
+        check(r[0], r[1], f"blocks nb={nb} K={kk} thre={th} freeze={fz} iters={n} sizes={[len(x) for x in sb]}/{[len(x) for x in cb]}")
         both(lambda c: (c.features_set(mla.SURF, feats[0]), c.features_set(mla.CORNER, feats[1])))
 while in_flight:
     kind = in_flight.pop(0)

@@ -193,6 +193,39 @@ def test_gn_last_iteration_completed_by_the_successor_or_by_whoever_comes_next(m
         assert np.array_equal(ref[1][k], ref[1]["alone"]), k
 
 
+def test_maps_staged_twice_beside_one_solve(mla, case16, feats16):
+    """mlh_map_set_pair_overlapped twice while ONE submitted solve is uncollected: the second call's target is the set that solve reads, so it may only be
+    rewritten behind it (scripts/soak_schedule.py found the index rebuilt under a correspondence launch, a rare 1e-5 m difference). A long solve (12 iterations on
+    12 x the features) keeps the launch window open; every pose equals the synchronous one, and the next frame on the re-staged maps too."""
+    p0 = case16["p0"]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    big_s = np.ascontiguousarray(np.tile(feats16[0], (12, 1)))
+    big_c = np.ascontiguousarray(np.tile(feats16[1], (12, 1)))
+    import torch
+    d_sm, d_cm = torch.from_numpy(case16["surf_map"]).cuda(), torch.from_numpy(case16["corner_map"]).cuda()
+    for sched in ((1, 1, 1), (0, 0, 0)):
+        c = mla.Context(0)
+        try:
+            c.set_gn_schedule(*sched)
+            c.map_set_pair(d_sm, d_cm)
+            c.features_set(mla.SURF, big_s); c.features_set(mla.CORNER, big_c)
+            want = c.gn_solve(p0, 12, want_stats=False)[0]
+            want2 = c.gn_solve(want, 3, want_stats=False)[0]
+            for _ in range(20):
+                c.gn_solve_begin(p0, 12)
+                c.map_set_pair_overlapped(d_sm, d_cm)
+                c.map_set_pair_overlapped(d_sm, d_cm)          # back into the set the solve in flight reads
+                c.map_set_pair_overlapped(d_sm, d_cm)
+                got = c.gn_solve_end()
+                assert np.array_equal(got, want), sched
+                c.gn_solve_begin(got, 3)
+                c.map_set_pair_overlapped(d_sm, d_cm)
+                c.map_set_pair_overlapped(d_sm, d_cm)
+                assert np.array_equal(c.gn_solve_end(), want2), sched
+        finally:
+            c.close()
+
+
 def test_gn_deferred_finish_on_a_degenerate_problem(mla, orc, synth):
     """the deferred finish's slow path: a map that is ONE plane leaves three directions unconstrained (eigenvalues below MAP_EIG_THRE), so every workgroup of the
     next correspondence launch runs evalDegenracy's projection itself -- same bits as the classic finish, and the oracle's degenerate update"""
@@ -693,6 +726,19 @@ def test_pose_blocks_config4_parity(mla, orc, synth, case16):
             ctx.set_gn_schedule(*sched)
             got = ctx.gn_solve_blocks(*arg, want_stats=False)[0]
             assert np.array_equal(np.asarray(got), np.asarray(poses)[subset]), (subset, sched, np.abs(np.asarray(got) - np.asarray(poses)[subset]).max())
+    # a LiDAR without corner features in this frame (an empty block of one kind): its block is solved on its surf features alone, the others are not disturbed
+    empty = np.zeros((0, 4), np.float32)
+    ctx.features_set_blocks(mla.SURF, [surf_b[0], surf_b[1]])
+    ctx.features_set_blocks(mla.CORNER, [corner_b[0], empty])
+    prm = orc.mapper_params(huber_delta=1.0, map_eig_thre=thre[1], n_neigh=k_neigh[1], check_fov=True, freeze_when_degenerate=bool(freeze[1]))
+    ref = orc.gn_iterations(ms, mc, surf_b[1], empty, poses0[1], prm, n_it)
+    res = []
+    for sched in ((1, 1, 1), (0, 0, 0)):
+        ctx.set_gn_schedule(*sched)
+        res.append(np.asarray(ctx.gn_solve_blocks(np.ascontiguousarray(poses0[:2]), n_it, k_neigh[:2], thre[:2], freeze[:2], opts, want_stats=False)[0]))
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0][0], np.asarray(poses)[0])
+    dt, dr = _pose_err(res[0][1], ref["pose"])
+    assert dt < 1e-7 and dr < 1e-7, (dt, dr)
     ctx.close()
 
 
