@@ -97,7 +97,9 @@ __device__ __forceinline__ float clamp_cell_f(float v, float o, float inv_h, int
 // is balanced whatever the per-run occupancy, consecutive lanes read consecutive float4 points, and a query with fewer than
 // K candidates (most corner features far from any edge) is rejected right after the 18 cell_start words.
 // lds_run: 20 ints per group: [0..9] prefix offsets of the runs (10 entries), [10..18] base index of each run.
-template <int K, int G>
+// SHORT_OK: also answer a query whose 27 cells hold fewer than K points (the raw query API, mlh_knn: every neighbour inside the acceptance radius is reported,
+// like a kd-tree's; the matching kernels need K neighbours inside the radius or nothing, and leave right after the cell bounds)
+template <int K, int G, bool SHORT_OK = false>
 __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned long long (&out)[K])
 {
     static_assert(G == 8 || G == 16, "group width");
@@ -142,7 +144,7 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
     }
     const int len8 = (G == 8) ? __shfl(e8 - b8, 0, G) : 0;
     const int total = __shfl(incl, G - 1, G) + len8;
-    if (total >= K) {                                  // uniform over the group
+    if (SHORT_OK ? total > 0 : total >= K) {           // uniform over the group
         if (G == 8) {
             lds_run[gl] = incl - len;                  // prefix[r]
             lds_run[10 + gl] = b;                      // base[r]

@@ -896,7 +896,7 @@ __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const fl
     const int qi = blockIdx.x * FPB + grp;
     if (qi >= nq) return;
     unsigned long long keys[5];
-    knn_group<5, G>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
+    knn_group<5, G, true>(grid, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], gl, s_run + grp * 20, keys);
     if (gl == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) {

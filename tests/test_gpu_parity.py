@@ -49,6 +49,19 @@ def test_knn_exact(ctx, mla, orc, case16, feats16):
     assert np.array_equal(d2[within].view(np.uint32), rd2[within].view(np.uint32))
     # beyond the radius the 27-cell search may miss points: it must then report >= 1.0 (never a false accept)
     assert np.all(d2[~within] >= 1.0)
+    # queries with FEWER than five map points in their 27 cells (found by scripts/soak_api.py: the matching kernels' early exit used to answer "nothing" here
+    # although a neighbour sat 0.67 m away): the corner features against the sparse corner map, and queries off the edge of the map's box
+    corner_map = case16["corner_map"]
+    ctx.map_set(mla.CORNER, corner_map)
+    qc = np.concatenate([feats16[1][:, :3], corner_map[::40, :3] + np.float32([0.0, 0.0, -0.6]), corner_map[::40, :3] + np.float32([0.7, 0.0, 0.0])]).astype(np.float32)
+    qc = np.ascontiguousarray(qc)
+    idx, d2 = ctx.knn(mla.CORNER, qc)
+    ridx, rd2 = orc.Map(corner_map).knn(qc, 5)
+    within = rd2 < 1.0
+    assert (within.sum(axis=1) < 5).sum() > 100 and ((within.sum(axis=1) > 0) & (within.sum(axis=1) < 5)).sum() > 50
+    assert np.array_equal(idx[within], ridx[within])
+    assert np.array_equal(d2[within].view(np.uint32), rd2[within].view(np.uint32))
+    assert np.all(d2[~within] >= 1.0)
 
 
 @pytest.mark.parametrize("kind_name", ["surf", "corner"])
