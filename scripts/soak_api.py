@@ -187,7 +187,55 @@ def j_frame(c, st, r, m):
     return [np.array(n), pose], how
 
 
+WIN = [conftest.make_window_case(synth, O, 1, 2), conftest.make_window_case(synth, O, 2, 2, seed=4)]
+
+
+def j_window(c, st, r, i, what):
+    """Estimator::optimizeMap's coupled window: factor table staged, normal equations / device Gauss-Newton"""
+    w = WIN[i]
+    c.pure_odom_set(w["types"], w["points"], w["coeffs"], w["fi"], w["ei"])
+    if what == "ne":
+        o = c.pure_odom_normal_eq(w["pivot"], w["frames"], w["exts"], huber_delta=1.0)
+        return [o["H"], o["g"], np.array([o["cost"], o["count"]])], ""
+    o = c.pure_odom_gn_solve(w["pivot"], w["frames"], w["exts"], n_iters=3, huber_delta=1.0)
+    return [o["frames"], o["exts"], np.array([o["cost"], o["count"], o["status"]])], ""
+
+
+def j_window_device_table(c, st, r, m):
+    """the factor table built on the device from matches against the resident map (mlh_pure_odom_begin / _add_matches), then its normal equations"""
+    how = ensure_map(c, st, m, r)
+    c.pure_odom_begin()
+    for fi_, (f, rel) in enumerate((("A", P0[m]), ("As", P0[m]))):
+        for kind in (mla.SURF, mla.CORNER):
+            c.features_set(kind, FEATS[f][kind])
+            c.pure_odom_add_matches(kind, rel, 0, fi_ % 2)
+    st.feat = None
+    o = c.pure_odom_normal_eq(ident, np.array([ident]), np.array([ident, ident]), huber_delta=1.0)
+    return [o["H"], o["g"], np.array([o["cost"], o["count"]])], how
+
+
+def j_uncertainty(c, st, r, f):
+    cov, keep = c.point_uncertainty(FEATS[f][0], EXT, COVS, MEAS, 0.6)
+    return [cov, keep], ""
+
+
+SORT_KEYS = [np.random.default_rng(k).integers(0, 200 * (k + 1), 3000 * (k + 1)).astype(np.int32) for k in range(3)]
+
+
+def j_std_sort(c, st, r, i):
+    return [c.std_sort_permutation(SORT_KEYS[i])], ""
+
+
 JOBS = []
+for i in range(2):
+    for what in ("ne", "gn"):
+        JOBS.append((("window", i, what), j_window, (i, what)))
+for m in ("A", "C"):
+    JOBS.append((("window_dev", m), j_window_device_table, (m,)))
+for f in ("A", "B"):
+    JOBS.append((("uncertainty", f), j_uncertainty, (f,)))
+for i in range(3):
+    JOBS.append((("std_sort", i), j_std_sort, (i,)))
 for i in range(len(SCANS)):
     JOBS.append((("extract", i), j_extract, (i,)))
 for m in MAPS:
