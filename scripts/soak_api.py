@@ -3,7 +3,7 @@ ONCE from a fresh context, then a long-lived context runs the jobs in random ord
 feature sets of different sizes (host / device memory, pose blocks), solves synchronous / split / split with the maps re-staged beside them, the front end
 (extractCloud, segmentCloud, fusion, thinning, tracking) in between -- and every output must be the expected bits. What this finds: stale state, buffers that grow
 or are reused wrongly, launches that are not ordered behind their producers.
-usage: python scripts/soak_api.py [seconds] [seed]"""
+usage: python scripts/soak_api.py [seconds] [seed] [threads]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -278,32 +278,58 @@ for key, fn, args in JOBS:
     expected[key] = [np.asarray(a).copy() for a in out]
 print(f"{len(expected)} distinct jobs ({len(JOBS)} with their variants), expected outputs from fresh contexts in {time.time() - t0:.1f} s", flush=True)
 
-ctx = mla.Context(0)
-st = St()
-n_ops = 0
-trace = []
+n_threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+import threading
+results, failed = {}, []
+
+
+def run(tid):
+    """one long-lived context of its own per thread (the reference's estimator runs extractCloud from NUM_OF_LASER OpenMP threads, the mapper in its own node):
+    contexts must not see each other"""
+    rng_t = np.random.default_rng(seed + 1000 * tid)
+    ctx = mla.Context(0)
+    st = St()
+    n_ops, trace, counts = 0, [], {}
+    t0 = time.time()
+    while time.time() - t0 < budget and not failed:
+        key, fn, args = JOBS[int(rng_t.integers(len(JOBS)))]
+        if rng_t.random() < 0.02:
+            ctx.set_gn_schedule(int(rng_t.integers(2)), int(rng_t.integers(2)), int(rng_t.integers(2)))
+            trace.append("schedule")
+        out, how = fn(ctx, st, rng_t, *args)
+        n_ops += 1
+        counts[key[0]] = counts.get(key[0], 0) + 1
+        trace.append(f"{args}:{how}")
+        bad = [i for i, (a, b) in enumerate(zip(out, expected[key])) if np.asarray(a).tobytes() != b.tobytes()]
+        if bad or len(out) != len(expected[key]):
+            msg = [f"MISMATCH in thread {tid} after {n_ops} jobs in {key} {args} (outputs {bad} differ; staging: {how})"]
+            for i in bad:
+                a, b = np.asarray(out[i]), expected[key][i]
+                if a.shape != b.shape:
+                    msg.append(f"  output {i}: shape {a.shape} vs expected {b.shape}")
+                    continue
+                w = np.nonzero((a != b).ravel() & ~((a != a) & (b != b)).ravel())[0]
+                msg.append(f"  output {i}: {len(w)} of {a.size} elements differ; first at flat index {w[:4]}: got {a.ravel()[w[:4]]} expected {b.ravel()[w[:4]]}")
+            msg.append("last jobs: " + " | ".join(trace[-25:]))
+            failed.append("\n".join(msg))
+            return
+    ctx.close()
+    results[tid] = (n_ops, counts)
+
+
 t0 = time.time()
+threads = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+if failed:
+    print(failed[0])
+    sys.exit(1)
+tot = sum(r[0] for r in results.values())
 counts = {}
-while time.time() - t0 < budget:
-    key, fn, args = JOBS[int(rng.integers(len(JOBS)))]
-    if rng.random() < 0.02:
-        ctx.set_gn_schedule(int(rng.integers(2)), int(rng.integers(2)), int(rng.integers(2)))
-        trace.append("schedule")
-    out, how = fn(ctx, st, rng, *args)
-    n_ops += 1
-    counts[key[0]] = counts.get(key[0], 0) + 1
-    trace.append(f"{args}:{how}")
-    bad = [i for i, (a, b) in enumerate(zip(out, expected[key])) if np.asarray(a).tobytes() != b.tobytes()]
-    if bad or len(out) != len(expected[key]):
-        print(f"MISMATCH after {n_ops} jobs in {key} {args} (outputs {bad} differ; staging: {how})")
-        for i in bad:
-            a, b = np.asarray(out[i]), expected[key][i]
-            if a.shape != b.shape:
-                print(f"  output {i}: shape {a.shape} vs expected {b.shape}")
-                continue
-            w = np.nonzero((a != b).ravel() & ~((a != a) & (b != b)).ravel())[0]
-            print(f"  output {i}: {len(w)} of {a.size} elements differ; first at flat index {w[:4]}: got {a.ravel()[w[:4]]} expected {b.ravel()[w[:4]]}")
-        print("last jobs: " + " | ".join(trace[-25:]))
-        sys.exit(1)
-ctx.close()
-print(f"API soak: {n_ops} jobs on one long-lived context, every output equal to a fresh context's, bit for bit; seed {seed}, {time.time() - t0:.0f} s; per family: {counts}")
+for r in results.values():
+    for k, v in r[1].items():
+        counts[k] = counts.get(k, 0) + v
+print(f"API soak: {tot} jobs on {n_threads} long-lived context(s){' in concurrent threads' if n_threads > 1 else ''}, every output equal to a fresh context's, bit for bit; "
+      f"seed {seed}, {time.time() - t0:.0f} s; per family: {counts}")
