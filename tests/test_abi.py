@@ -200,3 +200,44 @@ def test_facade_keyframe_policy_and_pose_chain(tmp_path, orc):
             h = h * 31.0 + (j + 1)
         assert int(dec[i, 2]) == len(ids) and dec[i, 3] == h, (i, ids)
     assert 5 < n_saved < n - 5                      # both decisions occur
+
+
+def test_every_entry_point_refuses_a_null_context(mla):
+    """Every C-ABI function that takes a context must hand back an error (not crash, not touch the GPU) when the context is null and every other argument is
+    zero / null -- the first thing a binding gets wrong. Run in a child process so that a crash names its function instead of taking the test run down."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(ROOT, "include", "mloam_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mlh_\w+)\s*\(\s*(?:const\s+)?mlh_ctx\s*\*", hdr)))
+    assert len(names) > 60
+    code = r'''
+import ctypes as C, importlib, sys
+sys.path.insert(0, %r)
+mla = importlib.import_module("m-loam_amd")
+lib = mla.load_library()
+names = %r
+bad = []
+for nm in names:
+    fn = getattr(lib, nm)
+    at = fn.argtypes
+    assert at is not None, nm + ": no argtypes declared in the Python binding"
+    args = []
+    for t in at:
+        if t in (C.c_float, C.c_double):
+            args.append(0.0)
+        elif t in (C.c_int, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_longlong, C.c_ulonglong, C.c_size_t):
+            args.append(0)
+        else:
+            args.append(None)
+    print("calling", nm, flush=True)
+    rc = fn(*args)
+    if fn.restype in (None, C.c_char_p, C.c_void_p):
+        continue
+    if rc == 0:
+        bad.append(nm)
+print("ACCEPTED A NULL CONTEXT:", bad)
+sys.exit(1 if bad else 0)
+''' % (ROOT, names)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-600:], r.stderr[-1500:])

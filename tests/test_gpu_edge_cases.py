@@ -714,3 +714,72 @@ def test_features_handed_from_one_context_to_another(mla, case16, feats16):
     finally:
         for c in (a, b, ref):
             c.close()
+
+
+@pytest.mark.parametrize("name", ["all_invalid", "corner_far", "surf_far", "three_surf", "one_each", "nan_sprinkled", "inf_in_surf", "one_feature_2000_times",
+                                  "start_3m_off", "unnormalised_quaternion"])
+def test_solver_on_degenerate_inputs(mla, orc, synth, case16, feats16, name):
+    """What the reference's loop does with inputs that are not a frame: no feature matches (the pose comes back untouched, LM terminates at once), one kind missing,
+    three surf features, one feature of each kind, NaN / inf coordinates among the features (never valid, never poison the sums), one feature repeated 2 000 times, a
+    start 3 m / 10 deg off, a start quaternion of norm 1.7. Gauss-Newton: per-iteration counts and degeneracy verdicts equal to the oracle's, pose 1e-7, classic ==
+    deferred == split submission to the bit. scan2MapOptimization: LM iteration counts and terminations equal, pose 1e-7, split == synchronous to the bit."""
+    fs, fc = feats16
+    p = case16["p0"]
+
+    def far(x):
+        y = x.copy(); y[:, :3] += 5000.0
+        return y
+
+    def nan_some(x, k):
+        y = x.copy(); y[::k, 0] = np.nan
+        return y
+    if name == "all_invalid": s, c = far(fs), far(fc)
+    elif name == "corner_far": s, c = fs, far(fc)
+    elif name == "surf_far": s, c = far(fs), fc
+    elif name == "three_surf": s, c = np.ascontiguousarray(fs[:3]), fc
+    elif name == "one_each": s, c = np.ascontiguousarray(fs[:1]), np.ascontiguousarray(fc[:1])
+    elif name == "nan_sprinkled": s, c = nan_some(fs, 7), nan_some(fc, 5)
+    elif name == "inf_in_surf": s, c = np.where(np.arange(len(fs))[:, None] % 11 == 0, np.float32(np.inf), fs).astype(np.float32), fc
+    elif name == "one_feature_2000_times": s, c = np.ascontiguousarray(np.tile(fs[100:101], (2000, 1))), np.ascontiguousarray(np.tile(fc[50:51], (500, 1)))
+    elif name == "start_3m_off": s, c, p = fs, fc, synth.perturbed_pose(case16["gt"], seed=9, dt=3.0, drot_deg=10.0)
+    else: s, c, p = fs, fc, np.concatenate([p[:3], p[3:] * 1.7])
+    ms, mc = orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"])
+
+    def perr(a, b):
+        return max(float(np.linalg.norm(a[:3] - b[:3])), 2 * min(float(np.linalg.norm(a[3:] - b[3:])), float(np.linalg.norm(a[3:] + b[3:]))))
+    ctx = mla.Context(0)
+    try:
+        ctx.map_set_pair(case16["surf_map"], case16["corner_map"])
+        ctx.features_set(mla.SURF, s); ctx.features_set(mla.CORNER, c)
+        ref = orc.gn_iterations(ms, mc, s, c, p, orc.mapper_params(), 4)
+        ctx.set_gn_schedule(0, 0, 0)
+        pose_c, st = ctx.gn_solve(p, 4)
+        ctx.set_gn_schedule(1, 1, 1)
+        pose_f = ctx.gn_solve(p, 4, want_stats=False)[0]
+        ctx.gn_solve_begin(p, 4)
+        pose_s = ctx.gn_solve_end()
+        for a, b in zip(st, ref["iters"]):
+            assert (a["n_surf"], a["n_corner"], a["is_degenerate"]) == (b["n_surf"], b["n_corner"], b["is_degenerate"])
+        assert np.isfinite(pose_c).all() and perr(pose_c, ref["pose"]) < 1e-7
+        assert np.array_equal(pose_c, pose_f) and np.array_equal(pose_c, pose_s)
+        if name in ("all_invalid", "one_each"):
+            assert np.array_equal(pose_c, p)                      # nothing to solve: the pose is handed back untouched
+        ref2 = orc.scan2map(ms, mc, s, c, p, orc.mapper_params())
+        pose2, st2 = ctx.scan2map(p)
+        ctx.scan2map_begin(p)
+        pose3, status = ctx.scan2map_end()[:2]
+        for a, b in zip(st2, ref2["outer"]):
+            assert (a["lm_iterations"], a["termination"]) == (b["lm_iterations"], b["termination"])
+        assert perr(pose2, ref2["pose"]) < 1e-7 and status in (0, 2) and np.array_equal(pose2, pose3)
+    finally:
+        ctx.close()
+
+
+def test_zero_arguments_with_a_live_context():
+    """scripts/fuzz_zero_args.py: every context-taking entry point called with a valid context (staged, and fresh) and zero / null for everything else returns -- an
+    error, or success where zero is a legal value -- and the context solves to the same bits afterwards. A child process: a crash would name its function."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_zero_args.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "context still solves to the same bits: True" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
