@@ -25,9 +25,16 @@ for c in ctxs:
     c.features_set(mla.SURF, feats[0]); c.features_set(mla.CORNER, feats[1])
 in_flight = []          # kinds of the solves in flight ("gn" / "s2m"), oldest first
 n_ops = n_cmp = 0
+submitted_once = False
 t0 = time.time()
 def both(fn):
-    return [fn(c) for c in ctxs]
+    out = []
+    for i, c in enumerate(ctxs):
+        try:
+            out.append(fn(c))
+        except Exception as ex:
+            raise SystemExit(f"ERROR in context {i} ({'round-4 schedule' if i == 0 else 'classic schedule'}) after {n_ops} operations: {ex}\nlast operations: " + " | ".join(trace[-40:]))
+    return out
 trace = []
 def check(a, b, what):
     global n_cmp
@@ -39,7 +46,7 @@ while time.time() - t0 < budget:
     ops = ["sync", "sync_stats", "s2m", "feat", "map"]
     if len(in_flight) < 2:
         ops += ["begin", "begin", "s2m_begin"]
-        if in_flight or n_ops > 3:
+        if submitted_once:        # (the first frame of a context is submitted with its pose: include/mloam_hip.h)
             ops += ["chained", "chained", "chained", "s2m_chained"]
     if in_flight:
         ops += ["end", "end", "end"]
@@ -47,6 +54,8 @@ while time.time() - t0 < budget:
         ops += ["blocks", "blocks"]
     op = ops[rng.integers(len(ops))]
     trace.append(op)
+    if op in ("begin", "s2m_begin"):
+        submitted_once = True
     if op in ("sync", "sync_stats"):
         n = int(rng.integers(1, 7))
         trace[-1] += f"({n})"
@@ -78,8 +87,9 @@ while time.time() - t0 < budget:
             # status 1 hands the START pose back (the caller re-solves): a younger solve behind it then starts from an unfinished pose in BOTH contexts alike
             check(r[0][0], r[1][0], "scan2map_end"); assert r[0][1] == r[1][1]
     elif op == "feat":
-        # features change size between frames (only legal with nothing in flight that reads them: drain first)
-        while in_flight:
+        # features change size between frames; half of the time with solves still in flight (their launches are already enqueued on the old features: stream
+        # order protects them; a scan2map in flight that overflows its look-ahead then hands its frame back, status 1, in both contexts alike)
+        while in_flight and rng.random() < 0.5:
             kind = in_flight.pop(0)
             r = both(lambda c: c.gn_solve_end() if kind == "gn" else c.scan2map_end()[0])
             check(r[0], r[1], "drain")
@@ -90,8 +100,11 @@ while time.time() - t0 < budget:
         both(lambda c: (c.features_set(mla.SURF, fs), c.features_set(mla.CORNER, fc)))
     elif op == "map":
         trace[-1] += f"[{len(in_flight)} in flight]"
-        if len(in_flight) <= 1:
+        if len(in_flight) <= 1 and rng.random() < 0.7:
             both(lambda c: c.map_set_pair_overlapped(case["surf_map"], case["corner_map"]) if in_flight else c.map_set_pair(case["surf_map"], case["corner_map"]))
+        else:            # staged on the solver's own stream, behind whatever is in flight
+            trace[-1] += "[own stream]"
+            both(lambda c: c.map_set_pair(case["surf_map"], case["corner_map"]))
     elif op == "blocks":
         # 1..4 pose blocks of random sizes (a block may hold a handful of features, or no corner features at all), N_NEIGH 5 / 10 and freeze flags at random
         nb = int(rng.integers(1, 5))
