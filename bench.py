@@ -221,17 +221,12 @@ def single_gpu_config4(mla, torch, device, surf_map, corner_map, surf_b, corner_
         c.close()
 
 
-def config4_block_owner(n_blocks, world):
-    """config 4's pose blocks dealt over the ranks: block b -> rank b mod min(world, n_blocks); ranks beyond the block count own nothing"""
-    return [b % min(world, n_blocks) for b in range(n_blocks)]
-
-
 def block_sharded_config4(mla, torch, dist, dist_dev, device, rank, world, surf_map, corner_map, surf_b, corner_b, poses0, steps, warmup):
     """config 4's frame with its POSE BLOCKS dealt over the ranks and the map replicated: the blocks' normal equations are independent (one 7-parameter block per
     LiDAR: LidarOnlineCalib* factors carry a single parameter block each, estimator.cpp:1067-1157), so no rank ever needs another rank's sums -- no collective in the
     data path, one barrier around the timed region. Every rank: its own context (no communicator), the WHOLE map staged + indexed per step, its blocks through
     mlh_gn_solve_blocks. Returns (max-over-ranks seconds per step, poses of all blocks gathered on every rank, owner table)."""
-    owner = config4_block_owner(len(surf_b), world)
+    owner = importlib.import_module("m-loam_amd.shard").block_owner(len(surf_b), world)
     mine = [b for b, r_ in enumerate(owner) if r_ == rank]
     c = mla.Context(device)
     try:

@@ -74,3 +74,9 @@ def shard_points_mask(pts, center_xy, n_ranks: int, rank: int, halo: float = 1.1
 
     near = (ray_dist(rank) <= halo) | (ray_dist(rank + 1) <= halo)
     return inside | near
+
+
+def block_owner(n_blocks: int, n_ranks: int):
+    """Pose blocks dealt over the ranks (config 4: one block per LiDAR, independent normal equations -- LidarOnlineCalib* factors carry one parameter block each,
+    estimator.cpp:1067-1157 -- so no rank needs another rank's sums): block b -> rank b mod min(n_ranks, n_blocks); ranks beyond the block count own nothing."""
+    return [b % min(n_ranks, n_blocks) for b in range(n_blocks)]

@@ -97,3 +97,70 @@ def test_wedges_tile_the_plane(synth):
         r0 = shard.owned_mask(pts, *shard.wedge_planes((0.3, -0.2), n, 0))
         staged = shard.shard_points_mask(pts, (0.3, -0.2), n, 0, halo=1.1)
         assert np.all(staged[r0])
+
+
+def _block_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    import conftest
+    synth = importlib.import_module("m-loam_amd.synth")
+    shard = importlib.import_module("m-loam_amd.shard")
+    surf_b, corner_b, poses0, prms, case = _config4_blocks(synth, O, conftest)
+    owner = shard.block_owner(len(surf_b), world)
+    ms, mc = O.Map(case["surf_map"]), O.Map(case["corner_map"])             # the whole map on every rank: nothing is exchanged in the data path
+    poses = torch.zeros((len(surf_b), 7), dtype=torch.float64)
+    for b, r in enumerate(owner):
+        if r == rank:
+            poses[b] = torch.from_numpy(O.gn_iterations(ms, mc, surf_b[b], corner_b[b], poses0[b], prms[b], 3)["pose"])
+    dist.all_reduce(poses)                                                   # every block has exactly one owner: the sum is a gather
+    if rank == 0:
+        q.put((owner, poses.numpy()))
+    dist.destroy_process_group()
+
+
+def _config4_blocks(synth, O, conftest):
+    case = conftest._make_case(synth, "50k", 16, 4)
+    surf_b, corner_b, poses0, prms = [], [], [], []
+    k_neigh, thre, freeze = [5, 10, 10, 10], [100.0, 70.0, 70.0, 70.0], [0, 1, 1, 1]
+    for i, sc in enumerate(case["scans"]):
+        ex = O.extract(sc.points, sc.scan_start, sc.scan_end)
+        c = np.zeros((len(ex["less_sharp"]), 4), np.float32)
+        c[:, :3] = sc.points[ex["less_sharp"]][:, :3]
+        surf_b.append(np.ascontiguousarray(synth.voxel_mean(ex["less_flat_ds"].copy(), 0.4)))
+        corner_b.append(np.ascontiguousarray(synth.voxel_mean(c, 0.2)))
+        bl = synth.HERCULES_BODY_T_LASER[i]
+        T = synth.pose_to_mat(case["gt"]) @ np.block([[synth.quat_to_rot(bl[:4]), bl[4:7, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+        from scipy.spatial.transform import Rotation as Rot
+        gt_i = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        poses0.append(synth.perturbed_pose(gt_i, seed=50 + i, dt=0.1, drot_deg=1.0))
+        prms.append(O.mapper_params(huber_delta=1.0, map_eig_thre=thre[i], n_neigh=k_neigh[i], check_fov=True, freeze_when_degenerate=bool(freeze[i])))
+    return surf_b, corner_b, poses0, prms, case
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pose_blocks_dealt_over_ranks(synth, orc, world):
+    """config 4's exchange-free split (bench.py: config4.blocks_over_ranks): the pose blocks dealt over the ranks, the map replicated, every rank solves its blocks
+    alone; gathered, the poses are those of one process solving all four -- to the bit, there is no sum across ranks to re-associate."""
+    import conftest
+    shard = importlib.import_module("m-loam_amd.shard")
+    assert shard.block_owner(4, 2) == [0, 1, 0, 1] and shard.block_owner(4, 4) == [0, 1, 2, 3] and shard.block_owner(4, 8) == [0, 1, 2, 3] and shard.block_owner(4, 3) == [0, 1, 2, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 17 * world
+    procs = [ctx.Process(target=_block_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    owner, poses = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    surf_b, corner_b, poses0, prms, case = _config4_blocks(synth, orc, conftest)
+    ms, mc = orc.Map(case["surf_map"]), orc.Map(case["corner_map"])
+    for b in range(4):
+        ref = orc.gn_iterations(ms, mc, surf_b[b], corner_b[b], poses0[b], prms[b], 3)["pose"]
+        assert np.array_equal(poses[b], ref), b
