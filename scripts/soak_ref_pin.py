@@ -1,0 +1,169 @@
+"""CPU soak (no GPU; needs oracle/_ref built from /root/reference by oracle/ref/build_ref.py): the oracle's restatement against the REFERENCE'S OWN LINES on random
+inputs -- the link "reference == oracle" of the parity chain on thousands of problems instead of the handful the CPU suite pins:
+  extract   extractCloud on random scans (16 / 32 / 64 rings, 300-2400 columns, coordinates quantised to 1/q so that curvatures tie): four clouds bit for bit
+  match     match{Surf,Corner}PointFromMap on random scenes / start errors / N_NEIGH / FOV / radii: validity and coefficient bits
+  segment   ImageSegmenter::segmentCloud on random raw clouds (rings, clutter, thresholds, ROI): ring-major cloud, ScanInfo, outliers bit for bit
+  voxel     VoxelGridCovarianceMLOAM::applyFilter (both branches) on random clouds with face points and repeats: every bit
+  scan2map  scan2MapOptimization on random scenes / start errors / uncertainty on-off: block counts, LM bookkeeping, costs 1e-12, pose 1e-12
+  track     trackCloud on random motions: block counts, LM bookkeeping, costs 1e-9, pose 1e-9
+usage: python scripts/soak_ref_pin.py [trials] [seed] [families]"""
+import importlib, os, sys, time, warnings
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import conftest, oracle as O
+from scipy.spatial.transform import Rotation as Rot
+synth = importlib.import_module("m-loam_amd.synth")
+warnings.simplefilter("ignore")
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track").split(",")
+rng = np.random.default_rng(seed)
+O.build()
+if O.ref_lib() is None:
+    raise SystemExit("oracle/_ref/libmloam_ref.so is missing and /root/reference is not here to build it from")
+ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+t_all = time.time()
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+if "extract" in families:
+    t0 = time.time(); n_pts = n_ties = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        scn = synth.make_scene(seed=sseed, **synth.SCENE_PRESETS["50k"])
+        rings, cols = int(rng.choice([16, 32, 64])), int(rng.choice([300, 900, 1800, 2400]))
+        s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[int(rng.integers(2))], rings, seed=sseed + 1, n_cols=cols)
+        q = float(rng.choice([0.0, 16.0, 64.0, 256.0]))
+        pts = s.points.copy()
+        if q:
+            pts[:, :3] = np.round(pts[:, :3] * q) / q
+        got, want = O.extract(pts, s.scan_start, s.scan_end, tie_rule=0), O.ref_extract(pts, s.scan_start, s.scan_end)
+        what = f"extract trial {trial}: scene {sseed}, {rings} rings x {cols}, quantum 1/{q}"
+        for k in ("sharp", "less_sharp", "flat"):
+            if not same(want[k], np.ascontiguousarray(pts[got[k]])):
+                raise SystemExit(f"EXTRACT {k} {what}")
+        if not same(want["less_flat_ds"], got["less_flat_ds"]):
+            raise SystemExit(f"EXTRACT thinned less-flat cloud {what}")
+        n_pts += len(pts); n_ties += int(got["n_ties"])
+    print(f"extract: {trials} random scans ({n_pts} points, {n_ties} exact curvature ties): the reference's four clouds == the oracle's, bit for bit  [{time.time() - t0:.0f} s]", flush=True)
+
+if "match" in families:
+    t0 = time.time(); n_f = n_v = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        case = conftest._make_case(synth, "50k", 16, int(rng.choice([1, 2])), seed=sseed)
+        feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+        p0 = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3, 0.5])), drot_deg=float(rng.choice([0.2, 1.0, 3.0])))
+        kn, fov, msd = int(rng.choice([5, 10])), bool(rng.integers(2)), float(rng.choice([1.0, 0.64]))
+        for kind, f, cloud in (("s", feats[0], case["surf_map"]), ("c", feats[1], case["corner_map"])):
+            v_ref, c_ref = O.ref_match(kind, cloud, f, p0, kn, fov, min_match_sq_dis=msd)
+            v_orc, c_orc = O.Map(cloud).match(kind, f, p0, n_neigh=kn, check_fov=fov, min_match_sq_dis=msd)
+            m = v_ref.astype(bool)
+            if not (np.array_equal(v_ref, v_orc) and np.array_equal(c_ref[m], c_orc[m])):
+                raise SystemExit(f"MATCH trial {trial}: scene {sseed}, kind {kind}, N_NEIGH {kn}, fov {fov}, radius^2 {msd}: {int(np.sum(v_ref != v_orc))} validity differences")
+            n_f += len(f); n_v += int(m.sum())
+    print(f"match: {trials} random problems ({n_f} features, {n_v} valid): validity and coefficient bits of the reference's lines == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
+
+if "segment" in families:
+    t0 = time.time(); n_pts = 0
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    for trial in range(trials):
+        rings = int(rng.choice([16, 32, 64])); vs = rings if rings != 32 or rng.integers(2) else 32
+        sseed = int(rng.integers(1, 10 ** 6))
+        body = synth.gt_body_pose().copy(); body[:2] += rng.uniform(-3, 3, 2)
+        s = synth.simulate_scan(scn, body, synth.HERCULES_BODY_T_LASER[int(rng.integers(2))], rings, seed=sseed)
+        r2 = np.random.default_rng(sseed)
+        pts = s.points.copy(); pts[:, 3] = 0
+        clutter = float(rng.choice([0.0, 0.1, 0.4]))
+        m = r2.random(len(pts)) < clutter
+        pts[m, :3] *= r2.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
+        pts = np.ascontiguousarray(pts[r2.permutation(len(pts))])
+        prm = O.seg_params(vertical_scans=vs, segment_theta=float(rng.choice([1.047, 0.53])), roi_range=float(rng.choice([1.0, 0.5, 6.0])), segment_flag=bool(rng.integers(2)))
+        a, b = O.segment_cloud(pts, prm), O.ref_segment_cloud(pts, prm)
+        if not (same(a["cloud"], b["cloud"]) and same(a["outlier"], b["outlier"]) and np.array_equal(a["scan_start"], b["scan_start"]) and np.array_equal(a["scan_end"], b["scan_end"])):
+            raise SystemExit(f"SEGMENT trial {trial}: {rings} rings as {vs}, clutter {clutter}, seed {sseed}, params {prm}")
+        n_pts += len(pts)
+    print(f"segment: {trials} random raw clouds ({n_pts} points): the reference's ring-major cloud, ScanInfo and outliers == the oracle's, bit for bit  [{time.time() - t0:.0f} s]", flush=True)
+
+if "voxel" in families:
+    t0 = time.time(); n_pts = 0
+    for trial in range(trials):
+        n = int(rng.integers(1, 40000)); ext = float(rng.choice([5.0, 20.0, 60.0])); leaf = float(rng.choice([0.1, 0.2, 0.4, 1.0]))
+        xyz = rng.uniform(-ext, ext, (n, 3)).astype(np.float32); xyz[:, 2] *= 0.1
+        snap = rng.random(n) < 0.2
+        xyz[snap] = (np.round(xyz[snap] / leaf) * leaf).astype(np.float32)
+        if n > 10:
+            rep = rng.integers(0, n, n // 10); xyz[rng.integers(0, n, len(rep))] = xyz[rep]
+        pts4 = np.concatenate([xyz, rng.integers(0, 3, (n, 1)).astype(np.float32)], axis=1).astype(np.float32)
+        if not same(O.ref_voxel_filter(pts4, leaf), O.voxel_grid_mloam_plain(pts4, leaf, member_order=0)):
+            raise SystemExit(f"VOXEL plain trial {trial}: n {n}, extent {ext}, leaf {leaf}")
+        cov = np.abs(rng.normal(0.01, 0.01, (n, 6))).astype(np.float32)
+        pts11 = np.concatenate([pts4, cov, (cov[:, 0] + cov[:, 3] + cov[:, 5])[:, None]], axis=1).astype(np.float32)
+        thr = float(rng.choice([0.05, 0.6, 10.0]))
+        if not same(O.ref_voxel_filter(pts11, leaf, thr), O.voxel_grid_cov(pts11, leaf, thr)):
+            raise SystemExit(f"VOXEL covariance trial {trial}: n {n}, extent {ext}, leaf {leaf}, trace threshold {thr}")
+        n_pts += n
+    print(f"voxel: {trials} random clouds ({n_pts} points): the reference's applyFilter (plain and covariance branches) == the oracle's, bit for bit  [{time.time() - t0:.0f} s]", flush=True)
+
+if "scan2map" in families:
+    t0 = time.time(); n_lm = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        case = conftest._make_case(synth, "50k", 16, int(rng.choice([1, 2])), seed=sseed)
+        feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+        p0 = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3])), drot_deg=float(rng.choice([0.2, 1.0, 2.0])))
+        got = O.ref_scan2map(case["surf_map"], case["corner_map"], feats[0], feats[1], p0)
+        want = O.scan2map(O.Map(case["surf_map"]), O.Map(case["corner_map"]), feats[0], feats[1], p0, O.mapper_params())
+        what = f"scan2map trial {trial}: scene {sseed}"
+        if len(got["solves"]) != len(want["outer"]):
+            raise SystemExit(f"SCAN2MAP solves {what}: {len(got['solves'])} vs {len(want['outer'])}")
+        for g, w in zip(got["solves"], want["outer"]):
+            if g["n_blocks"] != w["n_surf_sel"] + w["n_corner_sel"] or (g["lm_iterations"], g["successful_steps"], g["termination"]) != (w["lm_iterations"], w["successful_steps"], w["termination"]):
+                raise SystemExit(f"SCAN2MAP bookkeeping {what}: {g} vs {w}")
+            if abs(g["initial_cost"] - w["initial_cost"]) > 1e-12 * max(1.0, w["initial_cost"]) or abs(g["final_cost"] - w["final_cost"]) > 1e-12 * max(1.0, w["final_cost"]):
+                raise SystemExit(f"SCAN2MAP costs {what}")
+            n_lm += g["lm_iterations"]
+        if np.linalg.norm(got["pose"] - want["pose"]) > 1e-12:
+            raise SystemExit(f"SCAN2MAP pose {what}: {np.linalg.norm(got['pose'] - want['pose']):.2e}")
+    print(f"scan2map: {trials} random problems: block counts, {n_lm} LM iterations (counts, successful steps, terminations), costs 1e-12 and poses 1e-12 of the reference's loop == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
+
+if "track" in families:
+    t0 = time.time(); n_lm = 0
+
+    def ring_tagged(scn):
+        ring = np.zeros(len(scn.points), np.float32); begins = scn.scan_start - 5
+        for r in range(scn.n_rings):
+            e = begins[r + 1] if r + 1 < scn.n_rings else len(scn.points); ring[begins[r]:e] = r
+        scn.points[:, 3] = ring
+        return scn
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        sc = synth.make_scene(seed=sseed, **synth.SCENE_PRESETS["50k"]); gt0 = synth.gt_body_pose()
+        dt, dy = float(rng.uniform(0, 0.8)), float(rng.uniform(0, 4.0))
+        d = rng.normal(size=3); d[2] *= 0.1; d *= dt / np.linalg.norm(d)
+        T1 = synth.pose_to_mat(gt0) @ synth.pose_to_mat(np.concatenate([d, Rot.from_euler("z", dy, degrees=True).as_quat()]))
+        gt1 = np.concatenate([T1[:3, 3], Rot.from_matrix(T1[:3, :3]).as_quat()])
+        s0 = ring_tagged(synth.simulate_scan(sc, gt0, synth.HERCULES_BODY_T_LASER[0], 16, seed=sseed + 1))
+        s1 = ring_tagged(synth.simulate_scan(sc, gt1, synth.HERCULES_BODY_T_LASER[0], 16, seed=sseed + 2))
+        e0, e1 = O.extract(s0.points, s0.scan_start, s0.scan_end), O.extract(s1.points, s1.scan_start, s1.scan_end)
+        cl, sl = np.ascontiguousarray(s0.points[e0["less_sharp"]]), np.ascontiguousarray(e0["less_flat_ds"][:, :4])
+        cs, sf = np.ascontiguousarray(s1.points[e1["sharp"]]), np.ascontiguousarray(s1.points[e1["flat"]])
+        got, want = O.ref_track_cloud(cl, sl, cs, sf, ident), O.track_cloud(cl, sl, cs, sf, ident)
+        solved = [o for o in want["outer"] if o["solved"]]
+        what = f"track trial {trial}: scene {sseed}, motion {dt:.2f} m / {dy:.1f} deg"
+        if len(got["solves"]) != len(solved):
+            raise SystemExit(f"TRACK rounds {what}")
+        for g, w in zip(got["solves"], solved):
+            if g["n_blocks"] != w["n_corner"] + w["n_surf"] or (g["lm_iterations"], g["termination"]) != (w["lm_iterations"], w["termination"]):
+                raise SystemExit(f"TRACK bookkeeping {what}: {g} vs {w}")
+            if abs(g["final_cost"] - w["final_cost"]) > 1e-9 * max(1.0, w["final_cost"]):
+                raise SystemExit(f"TRACK cost {what}")
+            n_lm += g["lm_iterations"]
+        if np.linalg.norm(got["pose"] - want["pose"]) > 1e-9:
+            raise SystemExit(f"TRACK pose {what}: {np.linalg.norm(got['pose'] - want['pose']):.2e}")
+    print(f"track: {trials} random motions: block counts, {n_lm} LM iterations, costs and poses (1e-9) of the reference's trackCloud == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
+print(f"reference-pin soak: seed {seed}, {trials} trials per family, families {families}: all equal  [{time.time() - t_all:.0f} s]")
