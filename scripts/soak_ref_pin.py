@@ -6,6 +6,7 @@ inputs -- the link "reference == oracle" of the parity chain on thousands of pro
   voxel     VoxelGridCovarianceMLOAM::applyFilter (both branches) on random clouds with face points and repeats: every bit
   scan2map  scan2MapOptimization on random scenes / start errors / uncertainty on-off: block counts, LM bookkeeping, costs 1e-12, pose 1e-12
   track     trackCloud on random motions: block counts, LM bookkeeping, costs 1e-9, pose 1e-9
+  select    ActiveFeatureSelection::goodFeatureMatching (rnd / fps / gd_fix / gd_float, random ratios and engine seeds): the same picks in the same order
 usage: python scripts/soak_ref_pin.py [trials] [seed] [families]"""
 import importlib, os, sys, time, warnings
 import numpy as np
@@ -17,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -166,4 +167,25 @@ if "track" in families:
         if np.linalg.norm(got["pose"] - want["pose"]) > 1e-9:
             raise SystemExit(f"TRACK pose {what}: {np.linalg.norm(got['pose'] - want['pose']):.2e}")
     print(f"track: {trials} random motions: block counts, {n_lm} LM iterations, costs and poses (1e-9) of the reference's trackCloud == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
+if "select" in families:
+    t0 = time.time(); n_sel = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        case = conftest._make_case(synth, "50k", 16, 1, seed=sseed)
+        feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+        p0 = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3])), drot_deg=float(rng.choice([0.2, 1.0])))
+        method = str(rng.choice(["rnd", "fps", "gd_fix", "gd_float"]))
+        ratio = float(rng.choice([0.1, 0.2, 0.5, 0.8]))
+        gseed = int(rng.integers(1, 10 ** 5))
+        ch, cloud, f = ("s", case["surf_map"], feats[0][:1500]) if rng.integers(2) else ("c", case["corner_map"], feats[1][:1200])
+        f11 = np.zeros((len(f), 11), np.float32); f11[:, :4] = f[:, :4]
+        cv = np.abs(rng.normal(0.003, 0.002, (len(f), 6))).astype(np.float32); cv[:, [1, 2, 4]] *= 0.1
+        f11[:, 4:10] = cv; f11[:, 10] = cv[:, 0] + cv[:, 3] + cv[:, 5]
+        r = O.ref_good_feature_matching(cloud, ch, f11, p0, method, ratio, gseed)
+        o = O.good_feature_matching(O.Map(cloud), ch, f11, p0, O.mapper_params(with_ua=True, gf_method=method, gf_ratio=ratio, seed=gseed))
+        if not np.array_equal(r["sel"], o["sel"]) or float(np.abs(r["H"] - o["H"]).max()) > 1e-9 * max(1e-12, float(np.abs(r["H"]).max())):
+            raise SystemExit(f"SELECT trial {trial}: scene {sseed}, kind {ch}, {method}, ratio {ratio}, seed {gseed}: {len(r['sel'])} vs {len(o['sel'])} picks")
+        n_sel += len(r["sel"])
+    print(f"select: {trials} random selections ({n_sel} picks; rnd / fps / gd_fix / gd_float): the reference's loop and the oracle pick the same features in the same order, sub_mat_H 1e-9  [{time.time() - t0:.0f} s]", flush=True)
+
 print(f"reference-pin soak: seed {seed}, {trials} trials per family, families {families}: all equal  [{time.time() - t_all:.0f} s]")

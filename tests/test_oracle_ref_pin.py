@@ -828,3 +828,14 @@ def test_odometry_window_assembly_is_the_references_online_calibration(orc, synt
         assert np.array_equal(got["poses"][0], w["pivot"]) and np.array_equal(got["exts"][0], w["exts"][0])
         assert (not np.array_equal(got["exts"][1], w["exts"][1])) == with_calib           # the extrinsic moves only when its factors were added
         assert got["solve"]["final_cost"] < got["solve"]["initial_cost"]
+
+
+def test_random_problems_against_the_references_own_lines(ref):
+    """scripts/soak_ref_pin.py, three random problems per family (extractCloud, match*PointFromMap, segmentCloud, applyFilter, scan2MapOptimization, trackCloud,
+    goodFeatureMatching): the oracle equals the reference's own lines beyond the fixed cases above. The long runs (1 000 per family) are in profiles/r04_soak.txt."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_ref_pin.py"), "3", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all equal" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
