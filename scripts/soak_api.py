@@ -28,6 +28,21 @@ FEATS = {"A": featA, "B": featB, "A5": (np.ascontiguousarray(np.tile(featA[0], (
 FEATS_DEV = {k: (torch.from_numpy(v[0]).cuda(), torch.from_numpy(v[1]).cuda()) for k, v in FEATS.items()}
 P0 = {"A": caseA["p0"], "B": caseB["p0"], "C": caseA["p0"]}
 SCANS = [caseA["scans"][0], caseB["scans"][0], caseB["scans"][1]]
+GN_FEATS = ["A", "B", "A5", "As"]
+if os.environ.get("SOAK_BIG"):
+    # BASELINE config 2's sizes beside the small ones: the 500 k map, its thinned (21 k) and un-thinned (230 k: more fit tiles than the deferred finish takes)
+    # feature sets, two 64-ring scans -- buffers grow and shrink by two orders of magnitude between jobs
+    import bench
+    scL, surfL, cornerL, gtL, scansL = bench.build_workload(synth, "500k")
+    exL = [O.extract(s_.points, s_.scan_start, s_.scan_end) for s_ in scansL]
+    MAPS["L"] = (surfL, cornerL)
+    MAPS_DEV["L"] = (torch.from_numpy(surfL).cuda(), torch.from_numpy(cornerL).cuda())
+    for nm, thin in (("L", True), ("Ld", False)):
+        FEATS[nm] = bench.fuse_features(synth, scansL, exL, thin=thin)
+        FEATS_DEV[nm] = (torch.from_numpy(FEATS[nm][0]).cuda(), torch.from_numpy(FEATS[nm][1]).cuda())
+    P0["L"] = synth.perturbed_pose(gtL, seed=43)
+    SCANS += list(scansL)
+    GN_FEATS += ["L", "Ld"]
 sc32 = synth.simulate_scan(caseA["scene"], caseA["gt"], synth.HERCULES_BODY_T_LASER[0], 32, seed=21, n_cols=900)
 SCANS.append(sc32)
 track = conftest._track_case(synth, O)
@@ -87,7 +102,7 @@ def j_extract(c, st, r, i):
 
 def j_knn(c, st, r, m, kind):
     how = ensure_map(c, st, m, r)
-    q = FEATS["A"][kind][:2000]
+    q = FEATS["L" if m == "L" else "A"][kind][:2000]
     idx, d2 = c.knn(kind, q)
     # the raw query is exact inside the acceptance radius only (include/mloam_hip.h: mlh_knn); beyond it the answer depends on where the grid box of this map set
     # happens to start, i.e. on the maps staged before -- which is history, and allowed
@@ -178,7 +193,7 @@ def j_frame(c, st, r, m):
     """two scans -> extractCloud -> fusion -> thinning -> scan2MapOptimization, device-resident hand-overs"""
     how = ensure_map(c, st, m, r)
     c.fuse_reset()
-    for i, s in enumerate((SCANS[1], SCANS[2])):
+    for i, s in enumerate((SCANS[-2], SCANS[-1]) if m == "L" else (SCANS[1], SCANS[2])):
         c.scan_upload(s.points, s.scan_start, s.scan_end); c.extract_run(); c.extract_voxel_run(0.2)
         c.fuse_add_scan(i, EXT[i])
     n = c.downsample_current_scan_pair(c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER), 0.4, 0.2, EXT, COVS, MEAS, True, 0.6)
@@ -241,19 +256,22 @@ for i in range(len(SCANS)):
 for m in MAPS:
     for kind in (mla.SURF, mla.CORNER):
         JOBS.append((("knn", m, kind), j_knn, (m, kind)))
-    for f in ("A", "B", "A5", "As"):
+    for f in GN_FEATS:
+        if (f in ("L", "Ld")) != (m == "L"):        # the big feature sets against the big map only (and only they against it)
+            continue
         for n in (1, 2, 5):
             for variant in ("sync", "stats", "split", "split_restage"):
                 JOBS.append((("gn", m, f, n), j_gn, (m, f, n, variant)))
         for variant in ("sync", "split", "split_restage"):
             JOBS.append((("s2m", m, f), j_s2m, (m, f, variant)))
-    for f in ("A", "As"):
+    for f in (("L",) if m == "L" else ("A", "As")):
         for kind in (mla.SURF, mla.CORNER):
             JOBS.append((("ml", m, f, kind), j_ml, (m, f, kind)))
-    JOBS.append((("gf", m, "A", mla.SURF, "gd_fix"), j_gf, (m, "A", mla.SURF, "gd_fix")))
-    JOBS.append((("gf", m, "A", mla.CORNER, "rnd"), j_gf, (m, "A", mla.CORNER, "rnd")))
-    for subset in ((0, 1, 2, 3), (1,), (0, 2)):
-        JOBS.append((("blocks", m, subset), j_blocks, (m, subset)))
+    if m != "L":
+        JOBS.append((("gf", m, "A", mla.SURF, "gd_fix"), j_gf, (m, "A", mla.SURF, "gd_fix")))
+        JOBS.append((("gf", m, "A", mla.CORNER, "rnd"), j_gf, (m, "A", mla.CORNER, "rnd")))
+        for subset in ((0, 1, 2, 3), (1,), (0, 2)):
+            JOBS.append((("blocks", m, subset), j_blocks, (m, subset)))
     JOBS.append((("frame", m), j_frame, (m,)))
 for i in range(2):
     for leaf in (0.2, 0.4):
