@@ -385,7 +385,12 @@ int mlh_match_coeffs(mlh_ctx *ctx, int kind, uint8_t *valid, double *coeffs, int
  * farthest-point arg-max loop runs on the device for up to 16384 features (same f32 arithmetic, lowest index among equal
  * distances), the host replaying selection list and information matrix along the visiting order. sub_mat_H must come in as the reference initialises it
  * (1e-6 * I, cpp:505/520) and returns H + sum j^T j of the selected rows. On return only the selected features stay valid
- * on the device, so mlh_linearize / the LM of mlh_scan2map see exactly the residual blocks the reference would add. */
+ * on the device, so mlh_linearize / the LM of mlh_scan2map see exactly the residual blocks the reference would add.
+ * fps asked for more features than match (gf_ratio * n above the number of matching features): the reference's loop has no "every point visited" exit
+ * (lidar_mapper.h:391-399), so once everything has been visited it matches feature 1 again on every further round and -- when that feature matches -- appends it,
+ * with its J^T J, until the count is reached. Reproduced: sel_out then ends in repeats of index 1, sub_mat_H holds its outer product as many times, and on the
+ * device the feature weighs as that many residual blocks. (When feature 1 does not match, the reference spins into its 20 ms cut-off and returns what it has: the
+ * same list, without the wait.) */
 enum { MLH_GF_WO = 0, MLH_GF_RND = 1, MLH_GF_FPS = 2, MLH_GF_GD_FIX = 3, MLH_GF_GD_FLOAT = 4 };
 int mlh_good_feature_matching(mlh_ctx *ctx, int kind, const double pose[7], int gf_method, double gf_ratio, uint64_t seed,
                               float min_match_sq_dis, float min_plane_dis, int32_t *sel_idx, int32_t *n_sel,

@@ -117,8 +117,9 @@ __device__ __forceinline__ void eval_edge(const d3 &p, const float (&c)[6], doub
 }
 
 // accumulate one (possibly invalid) row and reduce the 29 sums over the workgroup -> partials[tile]
+// (mult: how many identical residual blocks the row stands for -- 1, except for the feature a selection picked repeatedly, select.hip: apply_keep_kernel)
 __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, int kind, double *lds_red /*4*32*/,
-                                            double *__restrict__ partial_out)
+                                            double *__restrict__ partial_out, int mult = 1)
 {
     double acc[32];
     if (valid) {
@@ -145,6 +146,11 @@ __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delt
         for (int i = 0; i < 6; ++i) acc[NE_G + i] = J[i] * r;
         acc[NE_COST] = 0.5 * rho0;
         acc[NE_CNT] = 1.0;
+        if (mult > 1) {
+            const double k = double(mult);
+#pragma unroll
+            for (int i = 0; i < 29; ++i) acc[i] *= k;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 29; ++i) acc[i] = 0.0;
@@ -854,6 +860,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     const q4 q{pose[3], pose[4], pose[5], pose[6]};
     const d3 t{pose[0], pose[1], pose[2]};
     bool valid = false;
+    int mult = 1;
     Lin L;
     L.r = 0.0;
 #pragma unroll
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
         if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
         if (c.valid) {
             valid = true;
+            mult = c.valid;
             const double w = feature_weight_pref(P, K, cdv);
             double R[9];
             qtorot(q, R);
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
         for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
     }
     MLH_STAGE(gtile, 2);
-    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
+    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE, mult);
     MLH_STAGE(gtile, 3);
     if constexpr (LM) { if (P.finish == 3 || P.finish == 4) fused_gn_finish<true>(P, total); }   // 3: the LM begin on rows a selection kept (scan2map with good-feature selection)
     MLH_STAGE(gtile, 4);

@@ -27,10 +27,12 @@ __global__ void pack_valid_kernel(const Corr *__restrict__ corr, int m, uint8_t 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = corr[i].valid != 0;
 }
-__global__ void apply_keep_kernel(Corr *__restrict__ corr, int m, const uint8_t *__restrict__ keep)
+// Corr::valid <- how many residual blocks the selection built on the feature: 0 or 1 -- or `dup_count` for the one feature (`dup_index`) the reference's fps
+// loop keeps appending after it has visited everything (fps_after_exhaustion); linearize_kernel weighs the feature's row by that count
+__global__ void apply_keep_kernel(Corr *__restrict__ corr, int m, const uint8_t *__restrict__ keep, int dup_index, int dup_count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) corr[i].valid = keep[i];
+    if (i < m) corr[i].valid = (i == dup_index) ? dup_count : int(keep[i]);
 }
 
 // Farthest-point sampling (goodFeatureMatching, 'fps': lidar_mapper.h:352-408) as ONE workgroup that keeps every point, its running minimum distance and its
@@ -208,6 +210,16 @@ void select_rnd(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size
     }
 }
 
+// The reference's loop has no "every point visited" exit (lidar_mapper.h:391-399: that test is commented out). With everything visited its scan leaves best_j at the
+// initial value 1, so feature 1 is matched again on every further round: matched, it is appended -- and its J^T J added -- again and again until the count is
+// reached; unmatched, the loop spins until the 20 ms cut-off and returns what it has. Restated (the spin as an immediate return); a single feature (points[1]
+// does not exist) stops.
+void fps_after_exhaustion(const Rows &R, size_t n_use, std::vector<size_t> &sel, double H[36])
+{
+    if (sel.size() >= n_use || R.size() < 2 || !R.matched(1)) return;
+    while (sel.size() < n_use) { rank1_update(H, R.jaco(1)); sel.push_back(1); }
+}
+
 void select_fps(const Rows &R, size_t n_use, size_t cur, std::vector<size_t> &sel, double H[36])
 {
     const size_t n = R.size();
@@ -236,6 +248,7 @@ void select_fps(const Rows &R, size_t n_use, size_t cur, std::vector<size_t> &se
         ++n_visited;
         if (R.matched(cur)) { rank1_update(H, R.jaco(cur)); sel.push_back(cur); }
     }
+    fps_after_exhaustion(R, n_use, sel, H);
 }
 
 // the same bookkeeping along a visiting order the device produced (fps_order_kernel): who is kept, and the information matrix in pick order
@@ -246,6 +259,7 @@ void select_fps_replay(const Rows &R, size_t n_use, size_t start, const int *ord
         const size_t cur = size_t(order[i]);
         if (R.matched(cur)) { rank1_update(H, R.jaco(cur)); sel.push_back(cur); }
     }
+    fps_after_exhaustion(R, n_use, sel, H);      // (the order ends early only when every point has been visited)
 }
 
 // 6x6 inverse of a symmetric positive definite matrix through its Cholesky factor (once per selection; rank-1 updated afterwards)
@@ -497,9 +511,11 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     if (method != MLH_GF_WO) {
         uint8_t *keep = reinterpret_cast<uint8_t *>(hb + off_k);     // (sequential writes into the pinned block: the mapping is fine for those)
         std::memset(keep, 0, m);
-        for (size_t i : sel) keep[i] = 1;
+        int dup_count = 0;                                            // only feature 1 can be picked more than once (fps_after_exhaustion)
+        for (size_t i : sel) { keep[i] = 1; dup_count += (i == 1) ? 1 : 0; }
         MLH_HIP(ctx, hipMemcpyAsync(f.flag8.p, keep, m, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>());
+        hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(),
+                           dup_count > 1 ? 1 : -1, dup_count);
         MLH_HIP(ctx, hipGetLastError());
     }
     sel_out.assign(sel.begin(), sel.end());

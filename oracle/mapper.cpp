@@ -223,8 +223,20 @@ void good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const
                 sel_feature_idx[num_sel_features++] = k;
             std::vector<float> dist(num_all_features, 1e5);
             while (true) {
-                // the reference leaves this loop through a 20 ms wall-clock cut-off; deterministic exit instead
-                if (num_sel_features >= num_use_features || cnt_visited >= num_all_features) break;
+                // The reference's loop has no "everything visited" exit (lidar_mapper.h:391-399: that test is commented out). Once every point has been visited the
+                // scan below skips them all and leaves best_j at its initial value 1, so feature 1 is matched again on every further round: if it matches it is
+                // appended (and its J^T J added) AGAIN, round after round, until the count is reached; if it does not, the loop spins until its 20 ms wall-clock
+                // cut-off and returns what it has. Both outcomes are deterministic and restated here (the spin as an immediate exit). One feature only:
+                // points[1] does not exist, the reference reads past its cloud -- stop.
+                if (num_sel_features >= num_use_features) break;
+                if (cnt_visited >= num_all_features) {
+                    if (num_all_features < 2 || !match_and_jac(1)) break;
+                    while (num_sel_features < num_use_features) {
+                        add_outer(sub_mat_H, all_features[1].jaco);
+                        sel_feature_idx[num_sel_features++] = 1;
+                    }
+                    break;
+                }
                 float best_d = -1;
                 size_t best_j = 1;
                 for (size_t j = 0; j < num_all_features; j++) {

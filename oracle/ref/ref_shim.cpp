@@ -164,7 +164,10 @@ typedef std::map<std::string, PointICloud> cloudFeature;      // parameters.h:16
 struct ScanInfo { std::vector<int> scan_start_ind_, scan_end_ind_; bool segment_flag_ = true; };     // parameters.h:193-207 (the members read on this path)
 double ROI_RANGE = 1.0;                                       // parameters.cpp:58
 float SEGMENT_THETA = 1.047f;                                 // parameters.cpp:39
-struct TicToc { double toc() { return 0.0; } };
+// A clock that advances by 0.1 us per reading: the selection loops read it once per round, so an ordinary selection (at most one round per feature) never reaches
+// MAX_FEATURE_SELECT_TIME = 20 ms, while a loop that can only end through the cut-off (fps, every point visited, feature 1 unmatched: lidar_mapper.h:391-399)
+// ends after 200 000 rounds instead of never.
+struct TicToc { long reads = 0; double toc() { return 1e-4 * double(++reads); } };
 #define ROS_WARN(...) do { } while (0)
 int N_SCANS = 0;                                              // parameters.cpp global
 

@@ -527,6 +527,47 @@ def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats
         c.close()
 
 
+def test_fps_asked_for_more_features_than_match(mla, orc, case16, feats16):
+    """'fps' with gf_ratio * N above the number of matching features: the reference fills the list up with feature 1 when it matches (its loop has no "everything
+    visited" exit, lidar_mapper.h:391-399) -- oracle pinned to the reference's lines in tests/test_oracle_ref_pin.py. The HIP path: the same list (feature 1 repeated),
+    the same information matrix, and in scan2MapOptimization the repeated feature weighs as that many residual blocks (Corr::valid carries the count): residual
+    block counts, LM iteration counts, terminations and pose equal to the oracle's."""
+    p0 = case16["p0"]
+    surf, corner = feats16[0][:600].copy(), feats16[1][:600].copy()
+    surf[::2, :3] += 500.0
+    corner[::2, :3] += 500.0
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(case16["surf_map"], case16["corner_map"])
+        filled = 0
+        for kind, ch, cloud, f in ((mla.SURF, "s", case16["surf_map"], surf), (mla.CORNER, "c", case16["corner_map"], corner)):
+            for first_matches in (True, False):
+                g = f.copy()
+                if not first_matches:
+                    g[1, :3] += 500.0
+                c.features_set(kind, g)
+                got = c.good_feature_matching(kind, p0, gf_method="fps", gf_ratio=0.8, seed=5)
+                ref = orc.good_feature_matching(orc.Map(cloud), ch, g, p0, orc.mapper_params(gf_method="fps", gf_ratio=0.8, seed=5))
+                assert np.array_equal(got["sel"], ref["sel"]), (ch, first_matches, len(got["sel"]), len(ref["sel"]))
+                np.testing.assert_allclose(got["H"], ref["H"], rtol=1e-9, atol=1e-9)
+                lin = c.linearize(kind, p0)
+                assert lin["count"] == len(ref["sel"])                    # the repeated feature counts as that many residual blocks
+                filled += int((ref["sel"] == 1).sum() > 1)
+        assert filled >= 1
+        c.features_set(mla.SURF, surf); c.features_set(mla.CORNER, corner)
+        opts = mla.default_opts(gf_method=mla.GF_METHODS["fps"], gf_ratio=0.8, gf_seed=5)
+        pose, st = c.scan2map(p0, opts)
+        ref = orc.scan2map(orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"]), surf, corner, p0, orc.mapper_params(gf_method="fps", gf_ratio=0.8, seed=5))
+        for s_, r_ in zip(st, ref["outer"]):
+            assert (s_["n_surf"], s_["n_corner"]) == (r_["n_surf_sel"], r_["n_corner_sel"])
+            assert (s_["lm_iterations"], s_["termination"]) == (r_["lm_iterations"], r_["termination"])
+        assert st[0]["n_surf"] + st[0]["n_corner"] > 600             # more residual blocks than features that can match: the repeats are in
+        dt, dr = _pose_err(pose, ref["pose"])
+        assert dt < 1e-7 and dr < 1e-7, (dt, dr)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("method", ["gd_fix", "rnd"])
 def test_selection_with_repeated_features_parity(mla, orc, case16, feats16, method):
     """Features repeated verbatim: subsets of the greedy loop whose members score exactly alike are replayed through the reference's heap, so the HIP path

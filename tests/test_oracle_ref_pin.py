@@ -351,6 +351,36 @@ def test_fps_equal_distances_are_decided_as_the_reference_decides_them(ref, case
         assert float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
 
 
+def test_fps_asked_for_more_features_than_match(ref, case16, feats16):
+    """'fps' with gf_ratio * N above the number of features that match (found by scripts/soak_ref_pin.py): the reference's loop has no "everything visited" exit
+    (lidar_mapper.h:391-399, the test is commented out), so after the last point its scan leaves best_j = 1 and feature 1 is matched -- and, matched, appended with
+    its J^T J -- again and again until the count is reached; unmatched, the loop spins into its 20 ms cut-off (the shim's clock advances per reading, so it ends) and
+    returns what it has. The oracle restates both outcomes; the HIP path is held to it (tests/test_gpu_parity.py::test_fps_asked_for_more_features_than_match)."""
+    rng = np.random.default_rng(8)
+    p0 = case16["p0"]
+    seen = set()
+    for ch, cloud, f in (("c", case16["corner_map"], feats16[1][:600]), ("s", case16["surf_map"], feats16[0][:600])):
+        f = f.copy()
+        f[::2, :3] += 500.0                      # every second feature (feature 0, 2, ...) far from the map: at most half can match; feature 1 stays where it is
+        for first_matches in (True, False):
+            g = f.copy()
+            if not first_matches:
+                g[1, :3] += 500.0               # ... and now feature 1 cannot match either
+            f11 = _with_cov(g, rng)
+            r = ref.ref_good_feature_matching(cloud, ch, f11, p0, "fps", 0.8, 5)
+            o = ref.good_feature_matching(ref.Map(cloud), ch, f11, p0, ref.mapper_params(with_ua=True, gf_method="fps", gf_ratio=0.8, seed=5))
+            assert np.array_equal(r["sel"], o["sel"]) and float(np.abs(r["H"] - o["H"]).max()) <= 1e-9 * float(np.abs(r["H"]).max())
+            n_use, uniq = int(len(g) * 0.8), len(set(r["sel"].tolist()))
+            assert uniq <= len(g) // 2 + 1 < n_use
+            if len(r["sel"]) == n_use:           # feature 1 matched: the list was filled up with it
+                assert (r["sel"] == 1).sum() == n_use - uniq + 1 and np.all(r["sel"][uniq:] == 1)
+                seen.add("filled")
+            else:                                # feature 1 did not match: the loop ran into its cut-off
+                assert len(r["sel"]) == uniq and 1 not in r["sel"]
+                seen.add("cut off")
+    assert seen == {"filled", "cut off"}
+
+
 @pytest.mark.parametrize("method", ["gd_fix", "rnd"])
 def test_selection_with_repeated_features_is_the_references(ref, case16, feats16, method):
     """Features repeated verbatim give the stochastic-greedy loop subsets whose members score EXACTLY alike: which of them std::priority_queue leaves on top is
