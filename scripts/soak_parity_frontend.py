@@ -3,7 +3,7 @@
   segment   ImageSegmenter::segmentCloud on random raw clouds (16 / 32 / 64 rings, clutter 0-30 %, shuffled / ring-major / firing order): every output bit
   voxel     VoxelGridCovarianceMLOAM plain + covariance branches and pcl::VoxelGrid on random clouds (leaf 0.1-1.0, a fraction of the points snapped onto voxel
             faces / repeated): every output bit
-  select    goodFeatureMatching rnd / gd_fix / gd_float (random ratio, seed) on random scenes: identical selections, H 1e-9
+  select    goodFeatureMatching rnd / fps / gd_fix / gd_float (random ratio up to 0.9, seed) on random scenes: identical selections, H 1e-9
 usage: python scripts/soak_parity_frontend.py [trials] [seed] [families, comma separated]"""
 import importlib, os, sys, time
 import numpy as np
@@ -139,8 +139,8 @@ if "select" in families:
         sseed = int(rng.integers(1, 10 ** 6))
         case = conftest._make_case(synth, "50k", 16, int(rng.choice([1, 2])), seed=sseed)
         feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
-        method = str(rng.choice(["rnd", "gd_fix", "gd_float"]))
-        ratio = float(rng.choice([0.05, 0.2, 0.5]))
+        method = str(rng.choice(["rnd", "gd_fix", "gd_float", "fps"]))
+        ratio = float(rng.choice([0.05, 0.2, 0.5, 0.9]))       # (0.9: more than match -- fps then fills up with feature 1, as the reference does)
         gseed = int(rng.integers(0, 1000))
         kind, ch = (mla.SURF, "s") if rng.integers(2) else (mla.CORNER, "c")
         cloud = case["surf_map"] if kind == mla.SURF else case["corner_map"]
