@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -187,5 +187,41 @@ if "select" in families:
             raise SystemExit(f"SELECT trial {trial}: scene {sseed}, kind {ch}, {method}, ratio {ratio}, seed {gseed}: {len(r['sel'])} vs {len(o['sel'])} picks")
         n_sel += len(r["sel"])
     print(f"select: {trials} random selections ({n_sel} picks; rnd / fps / gd_fix / gd_float): the reference's loop and the oracle pick the same features in the same order, sub_mat_H 1e-9  [{time.time() - t0:.0f} s]", flush=True)
+
+if "uct" in families:
+    t0 = time.time(); n_pts = 0
+    for trial in range(trials):
+        n = int(rng.integers(10, 6000))
+        kf = np.zeros((n, 11), np.float32)
+        kf[:, :3] = rng.uniform(-50, 50, (n, 3)); kf[:, 2] *= 0.1
+        kf[:, 3] = rng.integers(0, 2, n)
+        q = rng.normal(size=4) * [0.05, 0.05, 0.5, 1.0]; q /= np.linalg.norm(q)
+        pose_global = np.concatenate([rng.uniform(-5, 5, 3), q])
+        A = rng.normal(size=(6, 6)) * float(rng.choice([1e-4, 1e-3, 1e-2]))
+        cov_global = A @ A.T + np.eye(6) * 1e-6
+        q2 = rng.normal(size=4) * [0.02, 0.02, 0.1, 1.0]; q2 /= np.linalg.norm(q2)
+        ext = np.array([[0, 0, 0, 0, 0, 0, 1.0], np.concatenate([rng.uniform(-0.5, 0.5, 3), q2])])
+        ext_cov = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3) * float(rng.choice([1.0, 10.0]))])
+        cov_meas = np.diag([0.0025] * 3)
+        with_ua, thr = bool(rng.integers(2)), float(rng.choice([0.035, 0.6, 5.0]))
+        r = O.ref_cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        o = O.cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        if r.shape != o.shape or not same(r[:, :4], o[:, :4]) or (len(r) and float(np.abs(o[:, 4:] - r[:, 4:]).max()) > 2e-6 * max(1e-12, float(np.abs(r[:, 4:]).max())) + 1e-12):
+            raise SystemExit(f"UCT trial {trial}: n {n}, with_ua {with_ua}, threshold {thr}: {r.shape} vs {o.shape}")
+        n_pts += n
+    print(f"uct: {trials} random keyframe clouds ({n_pts} points): cloudUCTAssociateToMap of the reference's lines == the oracle's (survivors, order, f32 coordinates; covariances 2e-6)  [{time.time() - t0:.0f} s]", flush=True)
+
+if "degeneracy" in families:
+    t0 = time.time(); n_deg = 0
+    for trial in range(trials * 20):
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        k = int(rng.integers(0, 7))
+        ev = np.concatenate([rng.uniform(1e-3, 99.0, k), rng.uniform(101.0, 1e5, 6 - k)])
+        H = (Q * ev) @ Q.T; H = 0.5 * (H + H.T)
+        r, o = O.ref_eval_degeneracy(H, 100.0), O.eval_degeneracy(H, 100.0)
+        if r["is_degenerate"] != o["is_degenerate"] or (k > 0 and float(np.abs(o["V_update"] - r["V_update"]).max()) > 1e-9):
+            raise SystemExit(f"DEGENERACY trial {trial}: {k} eigenvalues under the threshold")
+        n_deg += int(k > 0)
+    print(f"degeneracy: {trials * 20} random 6 x 6 information matrices ({n_deg} degenerate): evalDegenracy's verdict and V_update of the reference's lines == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
 
 print(f"reference-pin soak: seed {seed}, {trials} trials per family, families {families}: all equal  [{time.time() - t_all:.0f} s]")
