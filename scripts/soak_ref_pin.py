@@ -42,8 +42,13 @@ if "extract" in families:
         pts = s.points.copy()
         if q:
             pts[:, :3] = np.round(pts[:, :3] * q) / q
-        got, want = O.extract(pts, s.scan_start, s.scan_end, tie_rule=0), O.ref_extract(pts, s.scan_start, s.scan_end)
-        what = f"extract trial {trial}: scene {sseed}, {rings} rings x {cols}, quantum 1/{q}"
+        ss, se = s.scan_start.copy(), s.scan_end.copy()
+        ragged = bool(rng.integers(3) == 0)
+        if ragged:                       # rings cut short (fewer than six usable points: skipped, feature_extract.cpp:155) or emptied
+            for r_ in rng.choice(rings, max(1, rings // 6), replace=False):
+                se[r_] = ss[r_] + int(rng.integers(-1, 8))
+        got, want = O.extract(pts, ss, se, tie_rule=0), O.ref_extract(pts, ss, se)
+        what = f"extract trial {trial}: scene {sseed}, {rings} rings x {cols}, quantum 1/{q}, ragged {ragged}"
         for k in ("sharp", "less_sharp", "flat"):
             if not same(want[k], np.ascontiguousarray(pts[got[k]])):
                 raise SystemExit(f"EXTRACT {k} {what}")
@@ -117,9 +122,25 @@ if "scan2map" in families:
         case = conftest._make_case(synth, "50k", 16, int(rng.choice([1, 2])), seed=sseed)
         feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
         p0 = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3])), drot_deg=float(rng.choice([0.2, 1.0, 2.0])))
-        got = O.ref_scan2map(case["surf_map"], case["corner_map"], feats[0], feats[1], p0)
-        want = O.scan2map(O.Map(case["surf_map"]), O.Map(case["corner_map"]), feats[0], feats[1], p0, O.mapper_params())
-        what = f"scan2map trial {trial}: scene {sseed}"
+        # half of the trials with the mapper's other modes: uncertainty-weighted residuals on features that carry covariances, a good-feature selection
+        # (gd_fix / rnd / fps at random ratios; frame 0 of ten runs evalFullHessian and the gf_ratio policy first, lidar_mapper_keyframe.cpp:462-500)
+        with_ua, gm, gr, fc, gseed = False, "wo_gf", 1.0, 1, 0
+        f_s, f_c = feats
+        if rng.integers(2):
+            with_ua = True
+            gm = str(rng.choice(["wo_gf", "gd_fix", "rnd", "fps"]))
+            gr = 1.0 if gm == "wo_gf" else float(rng.choice([0.2, 0.4, 0.7]))
+            fc = int(rng.choice([0, 3, 7, 10]))
+            gseed = int(rng.integers(1, 1000))
+            def f11(f):
+                out = np.zeros((len(f), 11), np.float32); out[:, :4] = f[:, :4]
+                d = rng.uniform(0.2, 1.0, (len(f), 3)) * 0.01
+                out[:, 4] = d[:, 0]; out[:, 7] = d[:, 1]; out[:, 9] = d[:, 2]; out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
+                return out
+            f_s, f_c = f11(feats[0]), f11(feats[1])
+        got = O.ref_scan2map(case["surf_map"], case["corner_map"], f_s, f_c, p0, with_ua=with_ua, gf_method=gm, gf_ratio=gr, seed=gseed, frame_cnt=fc)
+        want = O.scan2map(O.Map(case["surf_map"]), O.Map(case["corner_map"]), f_s, f_c, p0, O.mapper_params(with_ua=with_ua, gf_method=gm, gf_ratio=gr, seed=gseed))
+        what = f"scan2map trial {trial}: scene {sseed}, with_ua {with_ua}, {gm} ratio {gr} seed {gseed}, frame_cnt {fc}"
         if len(got["solves"]) != len(want["outer"]):
             raise SystemExit(f"SCAN2MAP solves {what}: {len(got['solves'])} vs {len(want['outer'])}")
         for g, w in zip(got["solves"], want["outer"]):
