@@ -80,6 +80,28 @@ for trial in range(trials):
         dt, dr = pose_err(pose2, ref2["pose"])
         if dt > 1e-7 or dr > 1e-7:
             raise SystemExit(f"SCAN2MAP POSE {what}: {dt:.2e} m {dr:.2e} rad")
+        # the mapper's other modes: uncertainty-weighted residuals on features that carry covariances, with a good-feature selection at a random ratio
+        gm = str(rng.choice(["wo_gf", "gd_fix", "rnd", "fps"]))
+        gr = 1.0 if gm == "wo_gf" else float(rng.choice([0.2, 0.4, 0.9]))
+        gseed = int(rng.integers(1, 1000))
+
+        def f11(f):
+            out = np.zeros((len(f), 11), np.float32); out[:, :4] = f[:, :4]
+            d = rng.uniform(0.2, 1.0, (len(f), 3)) * 0.01
+            out[:, 4] = d[:, 0]; out[:, 7] = d[:, 1]; out[:, 9] = d[:, 2]; out[:, 10] = out[:, 4] + out[:, 7] + out[:, 9]
+            return out
+        fs11, fc11 = f11(feats[0]), f11(feats[1])
+        ctx.features_set(mla.SURF, fs11); ctx.features_set(mla.CORNER, fc11)
+        o3 = mla.default_opts(flags=(mla.FLAG_CHECK_FOV if fov else 0) | mla.FLAG_WITH_UA, huber_delta=huber, min_match_sq_dis=msd, gf_method=mla.GF_METHODS[gm], gf_ratio=gr, gf_seed=gseed)
+        pose3, st3 = ctx.scan2map(p0, o3)
+        ref3 = O.scan2map(maps[0], maps[1], fs11, fc11, p0, O.mapper_params(huber_delta=huber, n_neigh=k_neigh, check_fov=fov, min_match_sq_dis=msd, with_ua=True, gf_method=gm, gf_ratio=gr, seed=gseed))
+        for o_, (s, r) in enumerate(zip(st3, ref3["outer"])):
+            if (s["n_surf"], s["n_corner"], s["lm_iterations"], s["termination"]) != (r["n_surf_sel"], r["n_corner_sel"], r["lm_iterations"], r["termination"]):
+                raise SystemExit(f"SCAN2MAP with_ua {gm} {gr} seed {gseed} {what}: outer {o_}: {(s['n_surf'], s['n_corner'], s['lm_iterations'], s['termination'])} vs {(r['n_surf_sel'], r['n_corner_sel'], r['lm_iterations'], r['termination'])}")
+            tot["lm"] += s["lm_iterations"]
+        dt, dr = pose_err(pose3, ref3["pose"])
+        if dt > 1e-7 or dr > 1e-7:
+            raise SystemExit(f"SCAN2MAP with_ua {gm} {gr} POSE {what}: {dt:.2e} m {dr:.2e} rad")
     else:
         poses, st = ctx.gn_solve_blocks(np.array([p0]), 4, [10], [100.0], [0], opts)
         ref = O.gn_iterations(maps[0], maps[1], feats[0], feats[1], p0, prm, 4)
