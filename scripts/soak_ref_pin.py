@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -248,6 +248,25 @@ if "downsample" in families:
                 raise SystemExit(f"DOWNSAMPLE trial {trial}: with_ua {with_ua}, threshold {thr}, leaves {ls} / {lc}: {got.shape} vs {want.shape}")
             n_pts += len(cloud)
     print(f"downsample: {trials} random fused clouds ({n_pts} points, both LiDARs inside the same voxels): downsampleCurrentScan of the reference's lines == the oracle's composition (voxel filter in std::sort member order, evalPointUncertainty, trace gate)  [{time.time() - t0:.0f} s]", flush=True)
+
+if "window" in families:
+    t0 = time.time(); n_blk = 0
+    for trial in range(trials):
+        n_frames, n_lidars = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2]))
+        wseed = int(rng.integers(1, 10 ** 6))
+        w = conftest.make_window_case(synth, O, n_frames, n_lidars, seed=wseed)
+        rows = np.zeros((len(w["types"]), 12))
+        rows[:, 0] = w["ei"]; rows[:, 1] = w["fi"] + 1; rows[:, 2] = w["types"]; rows[:, 3:6] = w["points"]; rows[:, 6:12] = w["coeffs"]
+        poses = np.vstack([w["pivot"][None, :], w["frames"]])
+        got = O.ref_optimize_map(poses, w["exts"], rows, estimate_extrinsic=0, num_iterations=4)
+        want = O.pure_odom_normal_eq(w["types"], w["points"], w["coeffs"], None, w["fi"], w["ei"], w["pivot"], w["frames"], w["exts"], 1.0)
+        D = 6 * (1 + n_frames + n_lidars)
+        free = np.zeros(D, bool); free[6:6 * (1 + n_frames)] = True
+        Hm = want["H"] * np.outer(free, free)
+        if got["n_blocks"] != len(w["types"]) or abs(got["cost"] - want["cost"]) > 1e-12 * want["cost"] or float(np.abs(got["H"] - Hm).max()) > 1e-11 * float(np.abs(Hm).max()):
+            raise SystemExit(f"WINDOW trial {trial}: {n_frames} frames x {n_lidars} LiDARs, seed {wseed}: cost {got['cost']} vs {want['cost']}")
+        n_blk += got["n_blocks"]
+    print(f"window: {trials} random sliding windows ({n_blk} LidarPureOdom factors): Estimator::optimizeMap's assembly from the reference's lines == the oracle's window normal equations (cost 1e-12, J^T J 1e-11)  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0
