@@ -299,6 +299,27 @@ int orc_gn_iterations(void *surf_map, void *corner_map, const float *surf, int s
     return 0;
 }
 
+// the odometry's selection (Estimator::goodFeatureMatching, estimator.cpp:1347-1517): rel = the Pose the reference builds from T_pivot^-1 T_i T_ext
+int orc_odom_good_feature_matching(void *map, char type, const float *feats, int stride, int n, const double *rel7, const double *pivot, const double *pose_i,
+                                   const double *ext, float gf_ratio, unsigned seed, float min_match_sq_dis, float min_plane_dis, int *sel_idx, int *n_sel,
+                                   unsigned char *matched, double *jaco /*n*6*/)
+{
+    OrcMap *m = static_cast<OrcMap *>(map);
+    std::mt19937 rng(seed);
+    std::vector<Feature> all;
+    std::vector<size_t> sel;
+    MatchParams mp;
+    mp.min_match_sq_dis = min_match_sq_dis; mp.min_plane_dis = min_plane_dis;
+    odom_good_feature_matching(m->mc, make_fc(feats, stride, n, -1), pose_from_param(rel7), pivot, pose_i, ext, all, sel, type, double(gf_ratio), mp, rng);
+    *n_sel = (int)sel.size();
+    for (size_t i = 0; i < sel.size(); ++i) sel_idx[i] = (int)sel[i];
+    for (int i = 0; i < n; ++i) {
+        if (matched) matched[i] = all[i].type != 'n';
+        if (jaco) for (int k = 0; k < 6; ++k) jaco[size_t(i) * 6 + k] = all[i].jaco[k];
+    }
+    return 0;
+}
+
 // pure-odometry factor (3 pose blocks); J: 3 x 7
 int orc_pure_odom_eval(char type, const double *point, const double *coeff, double sqrt_info, const double *pivot, const double *pose_i,
                        const double *ext, double *residual, double *J21)

@@ -313,6 +313,109 @@ void good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const
     sel_feature_idx.resize(num_sel_features);
 }
 
+// Estimator::goodFeatureMatching (estimator.cpp:1347-1517) with Estimator::evaluateFeatJacobian (:1273-1345): the ODOMETRY's selection in front of the window's
+// residual blocks (buildLocalMap, estimator.cpp:1241-1263, gf_ratio = ODOM_GF_RATIO: 0.8 in every shipped configuration). gf_ratio == 1.0: every feature is
+// matched, the matched ones are kept in feature order. Otherwise the stochastic-greedy loop of the mapper's gd_fix (same draws, same stamps, same heap), with
+//   - the row that is scored: a surf feature's LidarPureOdomPlaneNormFactor(point, coeffs, 1.0) evaluated at (pivot, pose_i, ext), its FRAME block's first six
+//     columns; a corner feature's row is Matrix<1, 6>::Identity() -- (1 0 0 0 0 0), whatever the feature (cpp:1339-1342);
+//   - no uncertainty weights, sub_mat_H seeded with 1e-6 I inside the function (cpp:1372);
+//   - ten failed draws (MAX_RANDOM_QUEUE_TIME, estimator.h:63) do NOT end the selection here (the `break` behind the message is missing, cpp:1505-1509): the outer loop starts over with an empty heap
+//     -- whatever the heap held is forgotten, its stamps stay -- and only the 7 ms wall-clock cut-off (MAX_FEATURE_SELECT_TIME, estimator.h:62) ends a loop in
+//     which no draw can succeed any more. Restated without the clock: the loop ends when no pool entry is left that the current round may still draw.
+// gf_ratio arrives as the float ODOM_GF_RATIO widened to double (parameters.cpp:85): num_use = size_t(n * double(float(ratio))).
+void odom_good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose_local, const double pivot[7], const double pose_i[7],
+                                const double ext[7], std::vector<Feature> &all_features, std::vector<size_t> &sel_feature_idx, char feature_type,
+                                double gf_ratio, const MatchParams &mp, std::mt19937 &rng)
+{
+    const size_t num_all_features = cloud.n;
+    all_features.assign(num_all_features, Feature());
+    std::vector<size_t> all_feature_idx(num_all_features);
+    std::vector<int> feature_visited(num_all_features, -1);
+    std::iota(all_feature_idx.begin(), all_feature_idx.end(), 0);
+    const size_t num_use_features = static_cast<size_t>(num_all_features * gf_ratio);
+    sel_feature_idx.assign(num_use_features, 0);
+    const size_t size_rnd_subset = num_use_features ? static_cast<size_t>(1.0 * num_all_features / num_use_features) : 0;
+    double sub_mat_H[36];
+    for (int i = 0; i < 36; ++i) sub_mat_H[i] = (i % 7 == 0) ? 1e-6 : 0.0;
+    size_t num_sel_features = 0;
+    const size_t MAX_RANDOM_QUEUE_TIME = 10;      // estimator.h:63 (the mapper's is 20, lidar_mapper.h:83)
+    auto jac = [&](Feature &f) {
+        if (f.type == 's') {
+            double r, J0[7], J1[7], J2[7];
+            pure_odom_plane_evaluate(f.point, f.coeffs, 1.0, pivot, pose_i, ext, &r, J0, J1, J2);
+            for (int k = 0; k < 6; ++k) f.jaco[k] = J1[k];
+        } else if (f.type == 'c') {
+            for (int k = 0; k < 6; ++k) f.jaco[k] = k == 0 ? 1.0 : 0.0;
+        }
+    };
+    if (gf_ratio == 1.0) {
+        for (size_t j = 0; j < all_feature_idx.size(); j++) {
+            const size_t que_idx = all_feature_idx[j];
+            if (match_one(map, cloud, que_idx, pose_local, all_features[que_idx], feature_type, mp)) {
+                if (num_sel_features >= sel_feature_idx.size()) sel_feature_idx.resize(num_sel_features + 1);
+                sel_feature_idx[num_sel_features++] = que_idx;
+            }
+        }
+    } else {
+        size_t num_rnd_que = 0;
+        while (true) {
+            if (num_sel_features >= num_use_features || all_feature_idx.size() == 0) break;
+            std::priority_queue<FeatureWithScore, std::vector<FeatureWithScore>, std::less<FeatureWithScore>> heap_subset;
+            bool lost = false;
+            while (true) {
+                if (all_feature_idx.size() == 0) break;
+                num_rnd_que = 0;
+                size_t j = 0;
+                while (num_rnd_que < MAX_RANDOM_QUEUE_TIME) {
+                    j = rand_uniform(rng, 0, all_feature_idx.size() - 1);
+                    if (feature_visited[j] < int(num_sel_features)) {
+                        feature_visited[j] = int(num_sel_features);
+                        break;
+                    }
+                    num_rnd_que++;
+                }
+                if (num_rnd_que >= MAX_RANDOM_QUEUE_TIME) break;
+                const size_t que_idx = all_feature_idx[j];
+                if (all_features[que_idx].type == 'n') {
+                    if (match_one(map, cloud, que_idx, pose_local, all_features[que_idx], feature_type, mp)) jac(all_features[que_idx]);
+                    else {
+                        all_feature_idx.erase(all_feature_idx.begin() + j);
+                        feature_visited.erase(feature_visited.begin() + j);
+                        continue;
+                    }
+                }
+                const double *jaco = all_features[que_idx].jaco;
+                double Ht[36];
+                std::memcpy(Ht, sub_mat_H, sizeof(Ht));
+                add_outer(Ht, jaco);
+                FeatureWithScore fws;
+                fws.idx = que_idx; fws.score = logdet_chol_d(Ht, 6);
+                std::memcpy(fws.jaco, jaco, sizeof(fws.jaco));
+                heap_subset.push(fws);
+                if (heap_subset.size() >= size_rnd_subset) {
+                    const FeatureWithScore &top = heap_subset.top();
+                    auto iter = std::find(all_feature_idx.begin(), all_feature_idx.end(), top.idx);
+                    if (iter == all_feature_idx.end()) { lost = true; break; }     // "not exist feature idx": leaves the inner loop only (cpp:1487-1491)
+                    add_outer(sub_mat_H, top.jaco);
+                    const size_t position = iter - all_feature_idx.begin();
+                    all_feature_idx.erase(all_feature_idx.begin() + position);
+                    feature_visited.erase(feature_visited.begin() + position);
+                    sel_feature_idx[num_sel_features++] = top.idx;
+                    break;
+                }
+            }
+            (void)lost;
+            if (num_rnd_que >= MAX_RANDOM_QUEUE_TIME) {
+                // the reference prints "early termination" and goes on; it can only leave through its clock when nothing is left to draw
+                bool drawable = false;
+                for (int v : feature_visited) if (v < int(num_sel_features)) { drawable = true; break; }
+                if (!drawable) break;
+            }
+        }
+    }
+    sel_feature_idx.resize(num_sel_features);
+}
+
 static void build_blocks(const std::vector<Feature> &all_surf, const std::vector<size_t> &sel_surf, const FeatureCloud &surf,
                          const std::vector<Feature> &all_corner, const std::vector<size_t> &sel_corner, const FeatureCloud &corner,
                          const MapperParams &prm, std::vector<ResidualBlock> &blocks)

@@ -71,6 +71,10 @@ struct SelectParams {
 };
 
 // lidar_mapper.h:229-573 (wall-clock cut-offs removed: MAX_FEATURE_SELECT_TIME is not applied)
+// Estimator::goodFeatureMatching (estimator.cpp:1347-1517): the odometry's selection (gf_ratio = ODOM_GF_RATIO as a widened float)
+void odom_good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose_local, const double pivot[7], const double pose_i[7],
+                                const double ext[7], std::vector<Feature> &all_features, std::vector<size_t> &sel_feature_idx, char feature_type,
+                                double gf_ratio, const MatchParams &mp, std::mt19937 &rng);
 void good_feature_matching(const MapCloud &map, const FeatureCloud &cloud, const Pose &pose_local,
                            std::vector<Feature> &all_features, std::vector<size_t> &sel_feature_idx,
                            char feature_type, const SelectParams &sp, double sub_mat_H[36],

@@ -197,6 +197,19 @@ def ref_good_feature_matching(map_points, kind, feats11, pose7, gf_method, gf_ra
     return dict(sel=sel[:nsel.value].copy(), H=Hm)
 
 
+def ref_odom_good_feature_matching(kind, map_pts, feats, pivot, pose_i, ext, gf_ratio=0.8, seed=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """Estimator::goodFeatureMatching + evaluateFeatJacobian (estimator.cpp:1273-1517) compiled from the reference's own lines. Returns sel and rel_pose = the Pose of
+    T_pivot^-1 T_i T_ext as that build computes it (4 x 4 products and inverse, rotation matrix -> quaternion: library arithmetic, restated in mini_eigen.hpp)."""
+    L = ref_lib()
+    m4 = np.zeros((len(map_pts), 4), np.float32); m4[:, :3] = np.asarray(map_pts)[:, :3]
+    f4 = np.zeros((len(feats), 4), np.float32); f4[:, :min(4, np.asarray(feats).shape[1])] = np.asarray(feats)[:, :4]
+    a = [np.ascontiguousarray(x, np.float64) for x in (pivot, pose_i, ext)]
+    sel = np.zeros(max(len(f4), 1), np.int32); n = C.c_int(0); rel = np.zeros(7)
+    L.ref_odom_good_feature_matching(C.c_char(kind.encode()), _ptr(m4), len(m4), _ptr(f4), len(f4), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), C.c_float(gf_ratio),
+                                     C.c_uint(int(seed)), C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(sel), C.byref(n), _ptr(rel))
+    return dict(sel=sel[:n.value].copy(), rel_pose=rel)
+
+
 def ref_eval_full_hessian(map_points, kind, feats11, pose7, H=None, feat_num=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
     """ActiveFeatureSelection::evalFullHessian (lidar_mapper.h:176-227) + common::logDet(mat_H, true) from the reference's own lines"""
     L = ref_lib()
@@ -564,6 +577,21 @@ def good_feature_matching(map_: Map, kind: str, feats, pose7, prm):
     lib().orc_good_feature_matching(map_.h, C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _cov_off(f), _ptr(pose), _ptr(prm),
                                     _ptr(sel), C.byref(nsel), _ptr(H), _ptr(matched), _ptr(jaco))
     return dict(sel=sel[:nsel.value].copy(), H=H, matched=matched, jaco=jaco)
+
+
+def odom_good_feature_matching(map_: Map, kind: str, feats, rel_pose, pivot, pose_i, ext, gf_ratio=0.8, seed=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """Estimator::goodFeatureMatching (estimator.cpp:1347-1517): the odometry's selection among one LiDAR's features of one frame against the window's local map;
+    rel_pose = the Pose of T_pivot^-1 T_i T_ext (what the features are matched at), pivot / pose_i / ext = the three blocks the scored row is evaluated at.
+    Returns sel (feature indices in selection order), matched (features the loop matched), jaco (their scored rows)."""
+    f = np.ascontiguousarray(feats, np.float32)
+    n = f.shape[0]
+    a = [np.ascontiguousarray(x, np.float64) for x in (rel_pose, pivot, pose_i, ext)]
+    sel = np.zeros(max(n, 1), np.int32); nsel = C.c_int(0)
+    matched = np.zeros(n, np.uint8); jaco = np.zeros((n, 6))
+    lib().orc_odom_good_feature_matching(map_.h, C.c_char(kind.encode()), _ptr(f), f.shape[1], n, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                         C.c_float(gf_ratio), C.c_uint(int(seed)), C.c_float(min_match_sq_dis), C.c_float(min_plane_dis), _ptr(sel), C.byref(nsel),
+                                         _ptr(matched), _ptr(jaco))
+    return dict(sel=sel[:nsel.value].copy(), matched=matched, jaco=jaco)
 
 
 def eval_full_hessian(map_: Map, kind: str, feats, pose7, H=None, feat_num=0, min_match_sq_dis=1.0, min_plane_dis=0.2):

@@ -48,6 +48,7 @@ CUTS = [
     ("pose_ctor_default.inc", "estimator/pose.cpp", 16, 23, "Pose::Pose()"),
     ("pose_ctor_copy.inc", "estimator/pose.cpp", 25, 32, "Pose::Pose(const Pose &pose)"),
     ("pose_ctor_qt.inc", "estimator/pose.cpp", 34, 41, "Pose::Pose(const Eigen::Quaterniond &q"),
+    ("pose_ctor_T.inc", "estimator/pose.cpp", 52, 59, "Pose::Pose(const Eigen::Matrix4d &T"),
     ("pose_inverse_update.inc", "estimator/pose.cpp", 99, 108, "Pose Pose::inverse() const"),
     ("pose_mul.inc", "estimator/pose.cpp", 110, 113, "Pose Pose::operator * (const Pose &pose)"),
     ("update_cov.inc", "@mloam_pcl/include/mloam_pcl/point_with_cov.hpp", 191, 200, "void updateCov(pcl::PointXYZIWithCov &po"),
@@ -74,6 +75,8 @@ CUTS = [
     ("estimator_optimize_map_head.inc", "estimator/estimator.cpp", 593, 866, "void Estimator::optimizeMap()"),
     ("estimator_vector_double.inc", "estimator/estimator.cpp", 1538, 1576, "void Estimator::vector2Double()"),
     ("estimator_eval_residual.inc", "estimator/estimator.cpp", 1578, 1595, "void Estimator::evalResidual(ceres::Problem &problem,"),
+    ("estimator_eval_feat_jacobian.inc", "estimator/estimator.cpp", 1273, 1345, "void Estimator::evaluateFeatJacobian"),
+    ("estimator_gfm.inc", "estimator/estimator.cpp", 1347, 1517, "void Estimator::goodFeatureMatching"),
     ("eval_hessian.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 1160, 1169, "void evalHessian"),
     ("vector2double.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 236, 252, "void vector2Double()"),
     ("scan2map_optimization.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 423, 639, "void scan2MapOptimization()"),

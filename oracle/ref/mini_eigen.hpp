@@ -274,6 +274,30 @@ template <typename T> struct Quaternion {
     T x_, y_, z_, w_;
     Quaternion() : x_(0), y_(0), z_(0), w_(1) {}
     Quaternion(T w, T x, T y, T z) : x_(x), y_(y), z_(z), w_(w) {}
+    // Quaternion(rotation matrix): Eigen 3.3 Geometry/Quaternion.h, quaternionbase_assign_impl<Other, 3, 3> (library arithmetic, restated)
+    explicit Quaternion(const Matrix<T, 3, 3> &m)
+    {
+        T t = m(0, 0) + m(1, 1) + m(2, 2);
+        T q[3];
+        if (t > T(0)) {
+            t = std::sqrt(t + T(1));
+            w_ = T(0.5) * t;
+            t = T(0.5) / t;
+            x_ = (m(2, 1) - m(1, 2)) * t; y_ = (m(0, 2) - m(2, 0)) * t; z_ = (m(1, 0) - m(0, 1)) * t;
+        } else {
+            int i = 0;
+            if (m(1, 1) > m(0, 0)) i = 1;
+            if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + T(1));
+            q[i] = T(0.5) * t;
+            t = T(0.5) / t;
+            w_ = (m(k, j) - m(j, k)) * t;
+            q[j] = (m(j, i) + m(i, j)) * t;
+            q[k] = (m(k, i) + m(i, k)) * t;
+            x_ = q[0]; y_ = q[1]; z_ = q[2];
+        }
+    }
     T &x() { return x_; } T &y() { return y_; } T &z() { return z_; } T &w() { return w_; }
     T x() const { return x_; } T y() const { return y_; } T z() const { return z_; } T w() const { return w_; }
     // QuaternionBase::_transformVector: v + w * (2 q x v) + q x (2 q x v)

@@ -115,6 +115,7 @@ public:
     Pose();
     Pose(const Pose &pose);
     Pose(const Eigen::Quaterniond &q, const Eigen::Vector3d &t, const double &td = 0);
+    Pose(const Eigen::Matrix4d &T, const double &td = 0);
     void update();
     Pose inverse() const;
     Pose operator * (const Pose &pose);
@@ -127,6 +128,7 @@ public:
 #include "../_ref/gen/pose_ctor_default.inc"                  // Pose::Pose()                                pose.cpp:16-23
 #include "../_ref/gen/pose_ctor_copy.inc"                     // Pose::Pose(const Pose &)                    pose.cpp:25-32
 #include "../_ref/gen/pose_ctor_qt.inc"                       // Pose::Pose(q, t, td)                        pose.cpp:34-41
+#include "../_ref/gen/pose_ctor_T.inc"                        // Pose::Pose(T, td)                           pose.cpp:52-59
 #include "../_ref/gen/pose_inverse_update.inc"                // Pose::inverse, Pose::update                 pose.cpp:99-108
 #include "../_ref/gen/pose_mul.inc"                           // Pose::operator*                             pose.cpp:110-113
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -418,6 +420,12 @@ public:
     void evalResidual(ceres::Problem &problem, std::vector<PoseLocalParameterization *> &local_param_ids, const std::vector<double *> &para_ids,
                       const std::vector<ceres::internal::ResidualBlock *> &res_ids_proj, const MarginalizationInfo *last_marginalization_info_,
                       const std::vector<ceres::internal::ResidualBlock *> &res_ids_marg);
+    void evaluateFeatJacobian(const Pose &pose_pivot, const Pose &pose_i, const Pose &pose_ext, PointPlaneFeature &feature);          // estimator.cpp:1273-1345
+    void goodFeatureMatching(const pcl::KdTreeFLANN<PointI>::Ptr &kdtree_from_map, const PointICloud &laser_map, const PointICloud &laser_cloud,
+                             std::vector<PointPlaneFeature> &all_features, std::vector<size_t> &sel_feature_idx, const char feature_type, const Pose &pose_pivot,
+                             const Pose &pose_i, const Pose &pose_ext, const double &gf_ratio);                                     // estimator.cpp:1347-1517
+    FeatureExtract f_extract_;                                // estimator.h
+    common::RandomGeneratorInt<size_t> rgi_;
     std::vector<Eigen::Quaterniond> Qs_;                      // CircularBuffer<> in the reference (estimator.h:166-167): only indexed here
     std::vector<Eigen::Vector3d> Ts_;
     std::vector<std::vector<std::vector<PointPlaneFeature>>> surf_map_features_, corner_map_features_;
@@ -638,7 +646,9 @@ void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *su
 // ---------------------------------------------------------------- scan2MapOptimization (lidar_mapper_keyframe.cpp:423-639) from the reference's own lines
 namespace common {
 const std::string YELLOW("\033[1;33m"), RESET("\033[0m");     // color.hpp:52, 55
-namespace timing { struct Timer { explicit Timer(const std::string &) {} double Stop() { return 0.0; } }; }   // timing.hpp:180-192 (wall-clock bookkeeping)
+// timing.hpp:180-192 (wall-clock bookkeeping). GetCountTime: seconds; advances by 10 ns per reading -- the odometry's selection reads it two or three times per draw,
+// so an ordinary selection stays far below its 7 ms cut-off while a loop that can only end through the cut-off (nothing left to draw) ends after 700 000 readings
+namespace timing { struct Timer { long reads = 0; explicit Timer(const std::string &) {} double Stop() { return 0.0; } double GetCountTime() { return 1e-8 * double(++reads); } }; }
 }
 std::ostream &operator<<(std::ostream &o, const Pose &p) { return o << "t: [" << p.t_(0) << " " << p.t_(1) << " " << p.t_(2) << "]"; }   // pose.cpp:110-117 (printing)
 PointICovCloud::Ptr laser_cloud_surf_from_map_cov_ds(new PointICovCloud()), laser_cloud_corner_from_map_cov_ds(new PointICovCloud());   // lidar_mapper_keyframe.cpp:66-67
@@ -673,8 +683,47 @@ public:
 #include "../_ref/gen/track_cloud.inc"
 #undef printf
 
+// ---------------------------------------------------------------- Estimator::goodFeatureMatching + evaluateFeatJacobian (estimator.cpp:1273-1517) from the reference's own lines
+#undef MAX_FEATURE_SELECT_TIME
+#undef MAX_RANDOM_QUEUE_TIME
+#define MAX_FEATURE_SELECT_TIME 7                             // estimator.h:62-63 (the mapper's limits, lidar_mapper.h:82-83, are 20 / 20)
+#define MAX_RANDOM_QUEUE_TIME 10
+#include "../_ref/gen/estimator_eval_feat_jacobian.inc"
+#include "../_ref/gen/estimator_gfm.inc"
+
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
+// Estimator::goodFeatureMatching on one (frame, LiDAR) group: map / features as n x 4 floats; the three poses as [t, q]; gf_ratio = ODOM_GF_RATIO (a float in the
+// reference, widened at the call, estimator.cpp:1250). rel_out: the Pose the function matches at, Pose(T_pivot^-1 T_i T_ext), as this build computes it.
+int ref_odom_good_feature_matching(char kind, const float *map4, int n_map, const float *feat4, int n_feat, const double pivot7[7], const double posei7[7],
+                                   const double ext7[7], float gf_ratio, unsigned seed, float min_match_sq_dis, float min_plane_dis, int *sel, int *n_sel,
+                                   double rel_out[7])
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis;
+    PointICloud map, feat;
+    auto fill = [](PointICloud &c, const float *p, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c.points[size_t(i)].x = p[4 * i]; c.points[size_t(i)].y = p[4 * i + 1]; c.points[size_t(i)].z = p[4 * i + 2]; c.points[size_t(i)].intensity = p[4 * i + 3]; }
+    };
+    fill(map, map4, n_map); fill(feat, feat4, n_feat);
+    pcl::KdTreeFLANN<PointI>::Ptr kd(new pcl::KdTreeFLANN<PointI>());
+    kd->setInputCloud(PointICloud::Ptr(new PointICloud(map)));
+    auto mk = [](const double *p) { return Pose(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2])); };
+    const Pose pose_pivot = mk(pivot7), pose_i = mk(posei7), pose_ext = mk(ext7);
+    Estimator est;
+    est.rgi_.m_random_engine.seed(seed);
+    std::vector<PointPlaneFeature> all_features;
+    std::vector<size_t> sel_idx;
+    const double ratio = gf_ratio;                            // ODOM_GF_RATIO (float) -> const double &
+    est.goodFeatureMatching(kd, map, feat, all_features, sel_idx, kind, pose_pivot, pose_i, pose_ext, ratio);
+    *n_sel = int(sel_idx.size());
+    for (size_t i = 0; i < sel_idx.size(); ++i) sel[i] = int(sel_idx[i]);
+    const Pose pose_local(pose_pivot.T_.inverse() * pose_i.T_ * pose_ext.T_);
+    rel_out[0] = pose_local.t_(0); rel_out[1] = pose_local.t_(1); rel_out[2] = pose_local.t_(2);
+    rel_out[3] = pose_local.q_.x(); rel_out[4] = pose_local.q_.y(); rel_out[5] = pose_local.q_.z(); rel_out[6] = pose_local.q_.w();
+    return 0;
+}
+
 // clouds out: sharp, less_sharp, flat, less_flat (voxel-thinned), each n x 4 floats; counts in n_out[4]
 int ref_extract_cloud(const float *xyzi, int n, const int *scan_start, const int *scan_end, int n_scans, float *out[4], int n_out[4])
 {

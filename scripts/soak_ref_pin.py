@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -267,6 +267,29 @@ if "window" in families:
             raise SystemExit(f"WINDOW trial {trial}: {n_frames} frames x {n_lidars} LiDARs, seed {wseed}: cost {got['cost']} vs {want['cost']}")
         n_blk += got["n_blocks"]
     print(f"window: {trials} random sliding windows ({n_blk} LidarPureOdom factors): Estimator::optimizeMap's assembly from the reference's lines == the oracle's window normal equations (cost 1e-12, J^T J 1e-11)  [{time.time() - t0:.0f} s]", flush=True)
+
+if "odom_select" in families:
+    t0 = time.time(); n_sel = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        case = conftest._make_case(synth, "50k", 16, 1, seed=sseed)
+        feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+        Tinv = np.linalg.inv(synth.pose_to_mat(case["gt"]))
+        kind, mp, f = ("s", case["surf_map"], feats[0]) if rng.integers(2) else ("c", case["corner_map"], feats[1])
+        mp = np.ascontiguousarray(synth.transform_points(mp[:, :3], Tinv).astype(np.float32))                       # the window's local map in the pivot frame
+        f = np.ascontiguousarray(f[: int(rng.integers(30, len(f) + 1))])
+        pivot = case["gt"]
+        pose_i = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3])), drot_deg=float(rng.choice([0.2, 1.0])))
+        q = rng.normal(size=4) * [0.01, 0.01, 0.02, 1.0]; q /= np.linalg.norm(q)
+        ext = np.concatenate([rng.uniform(-0.05, 0.05, 3), q])
+        ratio = float(rng.choice([1.0, 0.8, 0.8, 0.5, 0.3, 0.1]))
+        gseed = int(rng.integers(1, 10 ** 5))
+        r = O.ref_odom_good_feature_matching(kind, mp, f, pivot, pose_i, ext, ratio, gseed)
+        o = O.odom_good_feature_matching(O.Map(mp), kind, f, r["rel_pose"], pivot, pose_i, ext, ratio, gseed)
+        if not np.array_equal(r["sel"], o["sel"]):
+            raise SystemExit(f"ODOM SELECT trial {trial}: scene {sseed}, kind {kind}, {len(f)} features, ratio {ratio}, seed {gseed}: {len(r['sel'])} vs {len(o['sel'])} picks")
+        n_sel += len(r["sel"])
+    print(f"odom_select: {trials} random selections ({n_sel} picks): Estimator::goodFeatureMatching of the reference's lines and the oracle pick the same features in the same order  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0

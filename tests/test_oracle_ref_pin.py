@@ -860,6 +860,37 @@ def test_odometry_window_assembly_is_the_references_online_calibration(orc, synt
         assert got["solve"]["final_cost"] < got["solve"]["initial_cost"]
 
 
+def test_odometry_good_feature_matching_is_the_references(ref, synth):
+    """Estimator::goodFeatureMatching + evaluateFeatJacobian (estimator.cpp:1273-1517: the ODOMETRY's selection in front of the window's residual blocks, ODOM_GF_RATIO
+    = 0.8 in every shipped configuration) compiled from the reference's own lines against the oracle's restatement: the same features in the same order for surf and
+    corner features, ratios 1.0 (match everything), 0.8 (subsets of one: random picks among the matching features until the count is reached or the pool is empty),
+    0.3 / 0.05 (scored subsets of 3 / 20: the heap decides; the estimator's ten-draw limit does not end the selection, its loop starts over)."""
+    import conftest
+    import importlib
+    w = conftest.make_window_case(synth, ref, 1, 2)
+    case = conftest._make_case(synth, "50k", 16, 2)
+    Tinv = np.linalg.inv(synth.pose_to_mat(case["gt"]))
+    maps = [np.ascontiguousarray(synth.transform_points(m[:, :3], Tinv).astype(np.float32)) for m in (case["surf_map"], case["corner_map"])]      # the local map in the pivot frame
+    feats = conftest.features_from_extraction(synth, case["scans"][:1], lambda s: ref.extract(s.points, s.scan_start, s.scan_end))
+    pivot, pose_i, ext = w["pivot"], w["frames"][0], w["exts"][1]
+    n_checked = 0
+    for kind, mp, f in (("s", maps[0], feats[0]), ("c", maps[1], feats[1])):
+        om = ref.Map(mp)
+        for ratio in (1.0, 0.8, 0.3, 0.05):
+            for seed in (1, 7):
+                r = ref.ref_odom_good_feature_matching(kind, mp, f, pivot, pose_i, ext, ratio, seed)
+                o = ref.odom_good_feature_matching(om, kind, f, r["rel_pose"], pivot, pose_i, ext, ratio, seed)
+                assert np.array_equal(r["sel"], o["sel"]), (kind, ratio, seed, len(r["sel"]), len(o["sel"]))
+                assert len(r["sel"]) > 50 and len(set(r["sel"].tolist())) == len(r["sel"])
+                if ratio == 1.0:
+                    assert np.array_equal(r["sel"], np.flatnonzero(o["matched"]))
+                n_checked += 1
+    assert n_checked == 16
+    # the row that is scored: a surf feature's LidarPureOdomPlaneNormFactor frame block, a corner feature's (1 0 0 0 0 0)
+    o = ref.odom_good_feature_matching(ref.Map(maps[1]), "c", feats[1], r["rel_pose"], pivot, pose_i, ext, 0.3, 1)
+    assert np.array_equal(o["jaco"][o["matched"].astype(bool)], np.tile([1.0, 0, 0, 0, 0, 0], (int(o["matched"].sum()), 1)))
+
+
 def test_random_problems_against_the_references_own_lines(ref):
     """scripts/soak_ref_pin.py, three random problems per family (extractCloud, match*PointFromMap, segmentCloud, applyFilter, scan2MapOptimization, trackCloud,
     goodFeatureMatching): the oracle equals the reference's own lines beyond the fixed cases above. The long runs (1 000 per family) are in profiles/r04_soak.txt."""
