@@ -239,6 +239,19 @@ int mlh_pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *fr
 int mlh_pure_odom_begin(mlh_ctx *ctx);
 int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], int k_neigh, uint32_t flags, float min_match_sq_dis,
                               float min_plane_dis, int frame_idx, int ext_idx);
+/* The same with the ODOMETRY's good-feature selection in front of the append -- Estimator::goodFeatureMatching with Estimator::evaluateFeatJacobian
+ * (estimator.cpp:1273-1517), which buildLocalMap runs on every (frame, LiDAR) group with gf_ratio = ODOM_GF_RATIO (estimator.cpp:1241-1263; 0.8 in every shipped
+ * configuration): all features of the group are matched on the GPU at rel_pose (= the Pose of T_pivot^-1 T_i T_ext, as the caller builds it), the row the
+ * selection scores -- a surf feature's LidarPureOdomPlaneNormFactor(point, coeffs, 1.0) frame block at (pivot, pose_i, ext); (1 0 0 0 0 0) for a corner feature,
+ * cpp:1339-1342 -- is evaluated for every matched feature in one launch, and the sequential draw loop runs on the host with the reference's draw sequence
+ * (std::mt19937(seed) + uniform_int_distribution; MAX_RANDOM_QUEUE_TIME = 10, estimator.h:63; ten failed draws restart the round instead of ending the selection,
+ * as the reference's loop does; its 7 ms wall-clock cut-off is not applied -- the loop ends when nothing is left to draw). gf_ratio == 1.0: every matched
+ * feature, no loop. gf_ratio is a float, as ODOM_GF_RATIO is: the number of features asked for is size_t(n * (double)gf_ratio).
+ * Only the selected correspondences are appended as factors. sel_out (nullable, capacity = the staged feature count) / n_sel (nullable): the selected feature
+ * indices in selection order. One GPU (the loop needs the whole group's features). */
+int mlh_pure_odom_add_matches_gf(mlh_ctx *ctx, int kind, const double rel_pose[7], const double pivot[7], const double pose_i[7], const double ext[7], int k_neigh,
+                                 uint32_t flags, float min_match_sq_dis, float min_plane_dis, int frame_idx, int ext_idx, float gf_ratio, uint64_t seed,
+                                 int32_t *sel_out, int32_t *n_sel);
 /* The normal equations of the COUPLED window problem those factors form (BASELINE config 4; Estimator::optimizeMap, estimator.cpp:687-848):
  * local parameters in para_ids order [pivot | frames 0..n_frames) | extrinsics 0..n_ext)], 6 each (PoseLocalParameterization::ComputeJacobian
  * = [I6; 0]), D = 6 (1 + n_frames + n_ext). What Estimator::evalResidual gets from problem.Evaluate (estimator.cpp:1577-1595) -- rows

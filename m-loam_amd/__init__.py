@@ -138,6 +138,7 @@ def load_library():
     lib.mlh_std_sort_permutation.argtypes = [vp, vp, ci, ci, vp, ci]
     lib.mlh_pure_odom_begin.argtypes = [vp]
     lib.mlh_pure_odom_add_matches.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, ci, ci]
+    lib.mlh_pure_odom_add_matches_gf.argtypes = [vp, ci, vp, vp, vp, vp, ci, C.c_uint32, cf, cf, ci, ci, cf, C.c_uint64, vp, C.POINTER(C.c_int32)]
     lib.mlh_knn.argtypes = [vp, ci, vp, ci, ci, vp, vp]
     lib.mlh_features_set.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci]
     lib.mlh_features_set_block.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci]
@@ -173,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
-    "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
+    "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map", "mlh_scan2map_begin", "mlh_scan2map_begin_chained", "mlh_scan2map_end",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -448,6 +449,17 @@ class Context:
         p = np.ascontiguousarray(rel_pose, np.float64)
         self._ck(self.lib.mlh_pure_odom_add_matches(self.h, kind, _p(p), int(k_neigh), int(flags), float(min_match_sq_dis), float(min_plane_dis),
                                                     int(frame_idx), int(ext_idx)))
+
+    def pure_odom_add_matches_gf(self, kind, rel_pose, pivot, pose_i, ext, frame_idx, ext_idx, gf_ratio=0.8, seed=0, k_neigh=5, flags=0, min_match_sq_dis=1.0,
+                                 min_plane_dis=0.2):
+        """pure_odom_add_matches behind the odometry's good-feature selection (Estimator::goodFeatureMatching, estimator.cpp:1347-1517) -> the selected feature
+        indices in selection order; only they are appended as factors"""
+        a = [np.ascontiguousarray(x, np.float64) for x in (rel_pose, pivot, pose_i, ext)]
+        sel = np.zeros(max(self._m[kind], 1), np.int32)
+        n = C.c_int32(0)
+        self._ck(self.lib.mlh_pure_odom_add_matches_gf(self.h, kind, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(k_neigh), int(flags), float(min_match_sq_dis),
+                                                       float(min_plane_dis), int(frame_idx), int(ext_idx), float(gf_ratio), int(seed), _p(sel), C.byref(n)))
+        return sel[:n.value].copy()
 
     def pure_odom_evaluate(self, pivot, frames, exts, want_jacobians=True):
         pv = np.ascontiguousarray(pivot, np.float64); fr = np.ascontiguousarray(frames, np.float64).reshape(-1, 7)

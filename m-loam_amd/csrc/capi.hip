@@ -643,6 +643,43 @@ int mlh_pure_odom_add_matches(mlh_ctx *ctx, int kind, const double rel_pose[7], 
     return pure_odom_add_matches(ctx, kind, frame_idx, ext_idx);
 }
 
+int mlh_pure_odom_add_matches_gf(mlh_ctx *ctx, int kind, const double rel_pose[7], const double pivot[7], const double pose_i[7], const double ext[7], int k_neigh,
+                                 uint32_t flags, float min_match_sq_dis, float min_plane_dis, int frame_idx, int ext_idx, float gf_ratio, uint64_t seed,
+                                 int32_t *sel_out, int32_t *n_sel)
+{
+    if (!ctx || kind < 0 || kind > 1 || !rel_pose || !pivot || !pose_i || !ext || !(gf_ratio > 0.f)) return MLH_ERR_INVALID;
+    if (k_neigh != 5 && k_neigh != 10) return fail(ctx, MLH_ERR_UNSUPPORTED, "N_NEIGH is 5 or 10");
+    if (distributed(ctx)) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_pure_odom_add_matches_gf: the selection loop is sequential over ALL features of the group; a sharded feature set cannot run it");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    if ((rc = upload_pose(ctx, rel_pose))) return rc;
+    MatchArgs a;
+    a.kind_mask = 1 << kind; a.flags = flags & MLH_FLAG_CHECK_FOV; a.min_match_sq_dis = min_match_sq_dis; a.min_plane_dis = min_plane_dis;
+    a.huber_delta = 0.0; a.cov_measurement_trace = 0.0; a.dense = false; a.pose_sel = 0; a.k_neigh[0] = k_neigh;
+    if ((rc = match_launch(ctx, a))) return rc;
+    FeatSet &f = ctx->feat[kind];
+    std::vector<int32_t> sel;
+    if (gf_ratio == 1.0f) {
+        // "if (gf_ratio == 1.0)": every matched feature, in feature order (estimator.cpp:1379-1412)
+        if (sel_out || n_sel) {
+            MLH_HIP(ctx, f.flag8.ensure((size_t(f.m) + 63) & ~size_t(63)));
+            if ((rc = pure_odom_feature_rows(ctx, kind, pivot, pose_i, ext))) return rc;      // (its validity bytes)
+            std::vector<uint8_t> v(size_t(f.m));
+            MLH_HIP(ctx, hipMemcpyAsync(v.data(), f.flag8.p, size_t(f.m), hipMemcpyDeviceToHost, ctx->stream));
+            MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < f.m; ++i) if (v[size_t(i)]) sel.push_back(i);
+        } else ctx->map_read_unsynced = true;
+    } else {
+        if ((rc = pure_odom_feature_rows(ctx, kind, pivot, pose_i, ext))) return rc;
+        std::mt19937 rng(static_cast<uint32_t>(seed));
+        if ((rc = odom_good_feature_select(ctx, kind, gf_ratio, rng, sel))) return rc;
+    }
+    if (n_sel) *n_sel = int32_t(sel.size());
+    if (sel_out) std::copy(sel.begin(), sel.end(), sel_out);
+    return pure_odom_add_matches(ctx, kind, frame_idx, ext_idx);
+}
+
 int mlh_cloud_uct_associate_to_map(mlh_ctx *ctx, const void *points, int stride_bytes, int n, int intensity_offset_bytes, int cov_offset_bytes,
                                    int trace_offset_bytes, const double pose_global[7], const double cov_global[36], const double *ext_poses,
                                    const double *ext_covs, int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold,

@@ -396,6 +396,7 @@ int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames
                        double *residuals, double *jacobians);
 int pure_odom_begin(mlh_ctx *ctx);
 int pure_odom_add_matches(mlh_ctx *ctx, int kind, int frame_idx, int ext_idx);
+int pure_odom_feature_rows(mlh_ctx *ctx, int kind, const double pivot[7], const double pose_i[7], const double ext[7]);      // odom.hip: validity + scored rows of the staged features -> FeatSet::flag8 / J
 int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
                         double *H, double *g, double *cost, int32_t *n_res);
 int pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int n_frames, double *exts, int n_ext, double huber_delta, int n_iters,
@@ -532,6 +533,7 @@ int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::m
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
 // its two halves: the dense pass + copies to the host, enqueued (no wait); the selection loop on the copied rows, flags sent back (no wait)
 int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis);
+int odom_good_feature_select(mlh_ctx *ctx, int kind, float gf_ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out);     // select.hip: Estimator::goodFeatureMatching's loop over those rows
 int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out, double H[36],
                         uint8_t *matched_out);
 // solver.hip

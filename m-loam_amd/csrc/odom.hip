@@ -46,13 +46,15 @@ __device__ __forceinline__ V3 row_skew(const V3 &a, const V3 &v)             // 
 }
 __device__ __forceinline__ V3 crossv(const V3 &a, const V3 &b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
-// one factor: residual and (J != null) its three 1x7 rows [pivot | frame | extrinsic]
+// one factor: residual and (J != null) its three 1x7 rows [pivot | frame | extrinsic]; tb = point[3], coeff[6], sqrt_info; pp / pi / pe = the three poses
+__device__ __forceinline__ void odom_factor_core(const double *tb, int type, const double *pp, const double *pi, const double *pe, double &r_out, double *J);
 __device__ __forceinline__ void odom_factor(const OdomArgs &A, int i, double &r_out, double *J)
 {
-    const double *tb = A.tab + size_t(i) * 10;
-    const int type = A.idx[i * 3 + 0];
     const int fi = min(max(A.idx[i * 3 + 1], 0), A.n_frames - 1), ei = min(max(A.idx[i * 3 + 2], 0), A.n_ext - 1);
-    const double *pp = A.pivot, *pi = A.frames + fi * 7, *pe = A.exts + ei * 7;
+    odom_factor_core(A.tab + size_t(i) * 10, A.idx[i * 3 + 0], A.pivot, A.frames + fi * 7, A.exts + ei * 7, r_out, J);
+}
+__device__ __forceinline__ void odom_factor_core(const double *tb, int type, const double *pp, const double *pi, const double *pe, double &r_out, double *J)
+{
     const q4 Qp{pp[3], pp[4], pp[5], pp[6]}, Qi{pi[3], pi[4], pi[5], pi[6]}, Qe{pe[3], pe[4], pe[5], pe[6]};
     const V3 tp{pp[0], pp[1], pp[2]}, ti{pi[0], pi[1], pi[2]}, te{pe[0], pe[1], pe[2]};
     const V3 p{tb[0], tb[1], tb[2]};
@@ -121,6 +123,56 @@ __device__ __forceinline__ void odom_factor(const OdomArgs &A, int i, double &r_
     }
     J[14] = s * row1.x; J[15] = s * row1.y; J[16] = s * row1.z;
     J[17] = s * (-rot2.x); J[18] = s * (-rot2.y); J[19] = s * (-rot2.z); J[20] = 0.0;
+}
+
+// The row Estimator::goodFeatureMatching scores a matched feature by (Estimator::evaluateFeatJacobian, estimator.cpp:1273-1345): a surf feature's
+// LidarPureOdomPlaneNormFactor(point, coeffs, 1.0) evaluated at (pivot, pose_i, ext), the first six columns of its FRAME block; a corner feature's row is
+// Matrix<1, 6>::Identity() = (1 0 0 0 0 0) whatever the feature (cpp:1339-1342). For every staged feature of the kind at once, beside the validity byte.
+struct OdomRowArgs {
+    const float4 *feat;
+    const Corr *corr;
+    int m, type;
+    double poses[21];       // pivot | pose_i | ext
+    double *J6;             // m x 6
+    uint8_t *valid;         // m
+};
+__global__ __launch_bounds__(256) void odom_feat_rows_kernel(OdomRowArgs A)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.m) return;
+    const float4 f = A.feat[i];
+    const Corr c = A.corr[i];
+    const bool v = c.valid != 0 && f.w >= 0.f;
+    double row[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (v) {
+        if (A.type == 0) {
+            double tb[10] = {double(f.x), double(f.y), double(f.z), double(c.c[0]), double(c.c[1]), double(c.c[2]), double(c.c[3]), double(c.c[4]), double(c.c[5]), 1.0};
+            double r, J[21];
+            odom_factor_core(tb, 0, A.poses, A.poses + 7, A.poses + 14, r, J);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) row[k] = J[7 + k];
+        } else {
+            row[0] = 1.0;
+        }
+    }
+    A.valid[i] = v ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A.J6[size_t(i) * 6 + k] = row[k];
+}
+
+int pure_odom_feature_rows(mlh_ctx *ctx, int kind, const double pivot[7], const double pose_i[7], const double ext[7])
+{
+    FeatSet &f = ctx->feat[kind];
+    if (f.m <= 0 || !f.matched || f.n_blocks != 1) return fail(ctx, MLH_ERR_STATE, "a single-block match pass must have run for this kind");
+    MLH_HIP(ctx, f.J.ensure(sizeof(double) * 6 * size_t(f.m)));
+    MLH_HIP(ctx, f.flag8.ensure((size_t(f.m) + 63) & ~size_t(63)));
+    OdomRowArgs A;
+    A.feat = f.pts.as<float4>(); A.corr = f.corr.as<Corr>(); A.m = f.m; A.type = kind;
+    for (int k = 0; k < 7; ++k) { A.poses[k] = pivot[k]; A.poses[7 + k] = pose_i[k]; A.poses[14 + k] = ext[k]; }
+    A.J6 = f.J.as<double>(); A.valid = f.flag8.as<uint8_t>();
+    hipLaunchKernelGGL(odom_feat_rows_kernel, dim3((f.m + 255) / 256), dim3(256), 0, ctx->stream, A);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
 }
 
 __global__ __launch_bounds__(256) void pure_odom_kernel(OdomArgs A)

@@ -528,6 +528,96 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
     return MLH_OK;
 }
 
+// Estimator::goodFeatureMatching's selection loop (estimator.cpp:1414-1512) over rows the device evaluated (odom.hip: pure_odom_feature_rows): the mapper's
+// stochastic-greedy loop with the estimator's limits and its one structural difference --
+//   - MAX_RANDOM_QUEUE_TIME is 10 here (estimator.h:63), and ten failed draws do NOT end the selection (the `break` behind the "early termination" message is missing,
+//     cpp:1505-1509): the outer loop starts over with an empty heap; whatever the heap held keeps its stamp and cannot be drawn again before the next pick;
+//   - only the 7 ms wall-clock cut-off ends a loop in which no draw can succeed any more; restated without the clock: it ends when no pool entry is left that
+//     this round may still draw (n_fresh == 0);
+//   - sub_mat_H starts at 1e-6 I inside the function and is not returned; the scores are the reference's own arithmetic (logDet through Cholesky), pushed through
+//     the reference's own container (std::priority_queue with std::less on the score).
+void select_greedy_odom(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<size_t> &sel)
+{
+    const size_t n_all = R.size();
+    if (n_use == 0 || n_all == 0) return;
+    AlivePool pool(n_all);
+    std::vector<int> stamp(n_all, -1);
+    const size_t max_retry = 10;
+    const size_t subset = static_cast<size_t>(1.0 * n_all / n_use);
+    double H[36];
+    for (int i = 0; i < 36; ++i) H[i] = (i % 7 == 0) ? 1e-6 : 0.0;
+    size_t n_fresh = n_all;                        // alive entries whose stamp is below the current number of picks
+    while (sel.size() < n_use && !pool.empty()) {
+        std::priority_queue<Scored> heap;
+        size_t retries = 0;
+        while (!pool.empty()) {
+            retries = 0;
+            size_t q = 0;
+            while (retries < max_retry) {
+                const size_t j = draw(rng, 0, pool.size() - 1);
+                q = pool.at(j);
+                if (stamp[q] < int(sel.size())) { stamp[q] = int(sel.size()); --n_fresh; break; }
+                ++retries;
+            }
+            if (retries >= max_retry) break;
+            if (!R.matched(q)) { pool.erase_index(q); continue; }
+            double Ht[36];
+            std::copy(H, H + 36, Ht);
+            rank1_update(Ht, R.jaco(q));
+            heap.push(Scored{q, logdet_cholesky6(Ht)});
+            if (heap.size() >= subset) {
+                const size_t top = heap.top().idx;
+                if (!pool.contains(top)) break;
+                rank1_update(H, R.jaco(top));
+                pool.erase_index(top);
+                sel.push_back(top);
+                n_fresh = pool.size();
+                break;
+            }
+        }
+        if (retries >= max_retry && n_fresh == 0) break;
+    }
+}
+
+// The odometry's selection in front of mlh_pure_odom_add_matches' append: rows and validity come back from the device (pure_odom_feature_rows has been enqueued), the
+// loop runs on the host, the verdicts go back into Corr::valid -- the append then packs exactly the selected correspondences. gf_ratio is the reference's float
+// ODOM_GF_RATIO widened to double (num_use = size_t(m * double(ratio)), estimator.cpp:1366-1367).
+int odom_good_feature_select(mlh_ctx *ctx, int kind, float gf_ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out)
+{
+    FeatSet &f = ctx->feat[kind];
+    const size_t m = size_t(f.m);
+    const size_t mp = (m + 63) & ~size_t(63);
+    const size_t off_v = sizeof(double) * 6 * m, off_k = off_v + mp, need = off_k + mp;
+    if (need > ctx->select_host_cap[kind]) {
+        MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->select_host[kind]) (void)hipHostFree(ctx->select_host[kind]);
+        ctx->select_host[kind] = nullptr; ctx->select_host_cap[kind] = 0;
+        MLH_HIP(ctx, hipHostMalloc(&ctx->select_host[kind], need + need / 4, hipHostMallocDefault));
+        ctx->select_host_cap[kind] = need + need / 4;
+    }
+    char *hb = static_cast<char *>(ctx->select_host[kind]);
+    MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
+    MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->select_rows[kind].resize(off_k);
+    char *cb = ctx->select_rows[kind].data();
+    std::memcpy(cb, hb, off_k);                     // (the loop jumps around in these rows: ordinary memory, see good_feature_finish)
+    Rows R;
+    R.m = m; R.J = reinterpret_cast<const double *>(cb); R.valid = reinterpret_cast<const uint8_t *>(cb + off_v); R.pts = nullptr;
+    const size_t n_use = static_cast<size_t>(m * double(gf_ratio));
+    std::vector<size_t> sel;
+    sel.reserve(n_use);
+    select_greedy_odom(R, n_use, rng, sel);
+    uint8_t *keep = reinterpret_cast<uint8_t *>(hb + off_k);
+    std::memset(keep, 0, m);
+    for (size_t i : sel) keep[i] = 1;
+    MLH_HIP(ctx, hipMemcpyAsync(f.flag8.p, keep, m, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(), -1, 0);
+    MLH_HIP(ctx, hipGetLastError());
+    sel_out.assign(sel.begin(), sel.end());
+    return MLH_OK;
+}
+
 // Both halves back to back, and the stream drained: what mlh_good_feature_matching (one kind, caller reads the selection) uses.
 int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out)

@@ -1664,6 +1664,55 @@ def test_window_factor_table_built_on_the_device(mla, orc, synth, case16, feats1
         c.close()
 
 
+def test_odometry_good_feature_matching_parity(mla, orc, synth):
+    """(a19) Estimator::goodFeatureMatching -- the odometry's selection in front of the window's residual blocks (estimator.cpp:1273-1517; ODOM_GF_RATIO = 0.8 in
+    every shipped configuration) -- through mlh_pure_odom_add_matches_gf: all features of a (frame, LiDAR) group matched and their scored rows evaluated on the
+    GPU, the draw loop on the host. The same features in the same order as the oracle (which is pinned to the reference's own lines,
+    tests/test_oracle_ref_pin.py::test_odometry_good_feature_matching_is_the_references) for surf and corner features at ratios 1.0 / 0.8 / 0.3 / 0.05, and the factor
+    table that comes out of it gives the normal equations of exactly the selected correspondences."""
+    import conftest
+    w = conftest.make_window_case(synth, orc, 1, 2)
+    case = conftest._make_case(synth, "50k", 16, 2)
+    Tinv = np.linalg.inv(synth.pose_to_mat(case["gt"]))
+    maps = [np.ascontiguousarray(synth.transform_points(m[:, :3], Tinv).astype(np.float32)) for m in (case["surf_map"], case["corner_map"])]
+    maps4 = []
+    for m in maps:
+        a = np.zeros((len(m), 4), np.float32); a[:, :3] = m
+        maps4.append(a)
+    feats = conftest.features_from_extraction(synth, case["scans"][:1], lambda s: orc.extract(s.points, s.scan_start, s.scan_end))
+    pivot, pose_i, ext = w["pivot"], w["frames"][0], w["exts"][1]
+    # rel_pose as a caller builds it: T_pivot^-1 T_i T_ext (here with numpy; both sides are handed the same one)
+    from scipy.spatial.transform import Rotation as Rot
+    T = Tinv @ synth.pose_to_mat(pose_i) @ synth.pose_to_mat(ext)
+    T = np.linalg.inv(synth.pose_to_mat(pivot)) @ synth.pose_to_mat(pose_i) @ synth.pose_to_mat(ext)
+    rel = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    c = mla.Context(0)
+    try:
+        c.map_set_pair(maps4[0], maps4[1])
+        for kind, ch, mp, f in ((mla.SURF, "s", maps[0], feats[0]), (mla.CORNER, "c", maps[1], feats[1])):
+            c.features_set(kind, f)
+            om = orc.Map(mp)
+            for ratio in (1.0, 0.8, 0.3, 0.05):
+                for seed in (1, 7):
+                    c.pure_odom_begin()
+                    got = c.pure_odom_add_matches_gf(kind, rel, pivot, pose_i, ext, 0, 1, gf_ratio=ratio, seed=seed)
+                    ref = orc.odom_good_feature_matching(om, ch, f, rel, pivot, pose_i, ext, ratio, seed)
+                    assert np.array_equal(got, ref["sel"]), (ch, ratio, seed, len(got), len(ref["sel"]))
+                    assert len(got) > 50
+                    # the table holds exactly the selected correspondences: its normal equations equal those of the oracle's factors on that selection
+                    ne = c.pure_odom_normal_eq(pivot, np.array([pose_i]), np.array([ident, ext]), huber_delta=1.0)
+                    assert ne["count"] == len(got)
+                    valid, coeffs = om.match(ch, f, rel)
+                    s_ = np.sort(got)
+                    want = orc.pure_odom_normal_eq(np.full(len(s_), kind, np.int32), f[s_, :3].astype(np.float64), coeffs[s_], None, np.zeros(len(s_), np.int32),
+                                                   np.ones(len(s_), np.int32), pivot, np.array([pose_i]), np.array([ident, ext]), 1.0)
+                    assert abs(ne["cost"] - want["cost"]) <= 1e-9 * max(1.0, want["cost"])
+                    assert float(np.abs(ne["H"] - want["H"]).max()) <= 1e-9 * float(np.abs(want["H"]).max())
+    finally:
+        c.close()
+
+
 def test_window_local_map_building_blocks(ctx, mla, orc, case16):
     """Estimator::buildLocalMap (estimator.cpp:1160-1203) from its parts: every window frame's cloud into the pivot frame
     (pcl::transformPointCloud with the float 4x4: bit for bit), the union thinned by pcl::VoxelGrid<PointXYZI> (same voxels in the
