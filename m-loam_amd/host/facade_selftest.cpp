@@ -310,6 +310,22 @@ int main(int argc, char **argv)
                 wout.insert(wout.end(), wne.Jtr.begin(), wne.Jtr.end());
                 wout.push_back(wne.cost); wout.push_back(double(wne.n_residuals));
                 write_file(d + "out_window_ne.f64", wout);
+                // the odometry's own selection in front of the table (Estimator::goodFeatureMatching, estimator.cpp:1347-1517): pivot = identity, pose_i = pose0,
+                // the second LiDAR's extrinsic = identity; ODOM_GF_RATIO 0.8 for the surf group, 0.3 for the corner group
+                {
+                    WindowFactorTable sel_table(dev);
+                    Pose ident_pose;
+                    std::vector<size_t> sel_s, sel_c;
+                    sel_table.goodFeatureMatching(fs_i, sel_s, 's', ident_pose, pose0, ident_pose, 0.8f, 1, 0, 11);
+                    sel_table.goodFeatureMatching(fc_i, sel_c, 'c', ident_pose, pose0, ident_pose, 0.3f, 1, 1, 12);
+                    WindowNormalEquations sne;
+                    evalWindowNormalEquations(dev, piv.data(), {fr}, {e0, e1}, 1.0, sne);
+                    std::vector<int> sel_out;
+                    sel_out.push_back(int(sel_s.size())); sel_out.push_back(int(sel_c.size())); sel_out.push_back(int(sne.n_residuals));
+                    for (size_t q : sel_s) sel_out.push_back(int(q));
+                    for (size_t q : sel_c) sel_out.push_back(int(q));
+                    write_file(d + "out_odom_selection.i32", sel_out);
+                }
                 setVoxelMemberOrderAsReference(dev, false);   // device-only member order ...
                 setVoxelMemberOrderAsReference(dev, true);    // ... and back to the default (the reference's)
             }

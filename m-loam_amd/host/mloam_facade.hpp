@@ -1041,6 +1041,9 @@ inline void evalDegenracy(std::vector<PoseLocalParameterization *> &local_param_
     }
 }
 
+inline Pose poseMul(const Pose &a, const Pose &b);          // (defined with the mapper's pose chain below)
+inline Pose poseInverse(const Pose &a);
+
 // The factor table of Estimator::optimizeMap built ON THE DEVICE (estimator.cpp:700-780): in place of
 //     f_extract_.matchCornerFromMap / matchSurfFromMap(kdtree, local_map, features_of(frame i, LiDAR n), pose_local, all_features, ...)
 //     for (feature : all_features) problem.AddResidualBlock(new LidarPureOdom{PlaneNorm,Edge}Factor(point, coeffs, 1.0), loss, para_pose_[0], para_pose_[i - pivot], para_ex_pose_[n])
@@ -1062,6 +1065,29 @@ public:
         pose_local.toParam(pose);
         const Params &P = params();
         dev_.check(mlh_pure_odom_add_matches(dev_.ctx(), kind, pose, (int)n_neigh, check_fov ? MLH_FLAG_CHECK_FOV : 0u, P.MIN_MATCH_SQ_DIS, P.MIN_PLANE_DIS, frame - 1, laser));
+    }
+    // Estimator::goodFeatureMatching (estimator.cpp:1347-1517) as buildLocalMap calls it per (frame, LiDAR) and kind (cpp:1241-1263) -- the odometry's own selection:
+    // all features matched and their scored rows evaluated on the GPU, the reference's draw loop (seeded: the reference seeds rgi_ from std::random_device) on the
+    // host; sel_feature_idx comes back in selection order and the selected correspondences are already factors of this table (no AddResidualBlock loop, cpp:733-780).
+    // gf_ratio: ODOM_GF_RATIO, a float in the reference (parameters.cpp:85). n_neigh = 5 and no FOV check, as the reference's call has them (cpp:1384-1404).
+    template <typename PointT>
+    void goodFeatureMatching(const PointCloud<PointT> &laser_cloud, std::vector<size_t> &sel_feature_idx, char feature_type, const Pose &pose_pivot, const Pose &pose_i,
+                             const Pose &pose_ext, float gf_ratio, int frame, int laser, uint64_t seed)
+    {
+        sel_feature_idx.clear();
+        const int m = (int)laser_cloud.size();
+        if (m == 0) return;
+        const int kind = feature_type == 's' ? MLH_SURF : MLH_CORNER;
+        dev_.check(mlh_features_set(dev_.ctx(), kind, laser_cloud.points.data(), (int)sizeof(PointT), m, point_traits<PointT>::intensity_off, point_traits<PointT>::cov_off,
+                                    MLH_MEM_HOST));
+        const Pose pose_local = poseMul(poseMul(poseInverse(pose_pivot), pose_i), pose_ext);      // Pose(T_pivot^-1 T_i T_ext), cpp:1358
+        double rel[7], pv[7], pi[7], pe[7];
+        pose_local.toParam(rel); pose_pivot.toParam(pv); pose_i.toParam(pi); pose_ext.toParam(pe);
+        const Params &P = params();
+        std::vector<int32_t> sel((size_t)m);
+        int32_t n_sel = 0;
+        dev_.check(mlh_pure_odom_add_matches_gf(dev_.ctx(), kind, rel, pv, pi, pe, 5, 0u, P.MIN_MATCH_SQ_DIS, P.MIN_PLANE_DIS, frame - 1, laser, gf_ratio, seed, sel.data(), &n_sel));
+        sel_feature_idx.assign(sel.begin(), sel.begin() + n_sel);
     }
 private:
     Device &dev_;

@@ -157,6 +157,15 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     assert int(wn[D * D + D + 1]) == wref["count"] == len(tabs[0])
     assert float(np.abs(wn[:D * D].reshape(D, D) - wref["H"]).max()) <= 1e-9 * float(np.abs(wref["H"]).max())
     assert float(np.abs(wn[D * D:D * D + D] - wref["g"]).max()) <= 1e-9 * float(np.abs(wref["g"]).max())
+    # WindowFactorTable::goodFeatureMatching: the odometry's selection (Estimator::goodFeatureMatching) -- the same picks in the same order as the oracle, and the
+    # table holds exactly the selected correspondences
+    so = np.fromfile(os.path.join(d, "out_odom_selection.i32"), np.int32)
+    ns, nc, nres = int(so[0]), int(so[1]), int(so[2])
+    sel_s, sel_c = so[3:3 + ns], so[3 + ns:3 + ns + nc]
+    assert nres == ns + nc and ns > 100 and nc > 30
+    rs = orc.odom_good_feature_matching(orc.Map(case16["surf_map"]), "s", feats16[0], case16["p0"], ident, case16["p0"], ident, 0.8, 11)
+    rc_ = orc.odom_good_feature_matching(orc.Map(case16["corner_map"]), "c", feats16[1], case16["p0"], ident, case16["p0"], ident, 0.3, 12)
+    assert np.array_equal(sel_s, rs["sel"]) and np.array_equal(sel_c, rc_["sel"])
     # ImageSegmenter facade
     seg = orc.segment_cloud(raw, orc.seg_params())
     so = np.fromfile(os.path.join(d, "out_seg_cloud.f32"), np.float32).reshape(-1, 4)
