@@ -14,7 +14,7 @@ from scipy.spatial.transform import Rotation as Rot
 mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select,odom_select").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 ctx = mla.Context(0)
@@ -154,5 +154,32 @@ if "select" in families:
             raise SystemExit(f"SELECTION H {what}")
         n_sel += len(ref["sel"])
     print(f"select: {trials} random selections ({n_sel} picks): identical picks in identical order, information matrices within 1e-9  [{time.time() - t0:.0f} s]", flush=True)
+if "odom_select" in families:
+    t0 = time.time(); n_sel = 0
+    for trial in range(trials):
+        sseed = int(rng.integers(1, 10 ** 6))
+        case = conftest._make_case(synth, "50k", 16, 1, seed=sseed)
+        feats = conftest.features_from_extraction(synth, case["scans"], lambda s: O.extract(s.points, s.scan_start, s.scan_end))
+        Tinv = np.linalg.inv(synth.pose_to_mat(case["gt"]))
+        kind, ch = (mla.SURF, "s") if rng.integers(2) else (mla.CORNER, "c")
+        mp = np.ascontiguousarray(synth.transform_points((case["surf_map"] if kind == mla.SURF else case["corner_map"])[:, :3], Tinv).astype(np.float32))
+        m4 = np.zeros((len(mp), 4), np.float32); m4[:, :3] = mp
+        f = np.ascontiguousarray(feats[kind][: int(rng.integers(30, len(feats[kind]) + 1))])
+        pivot = case["gt"]
+        pose_i = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3])), drot_deg=float(rng.choice([0.2, 1.0])))
+        q = rng.normal(size=4) * [0.01, 0.01, 0.02, 1.0]; q /= np.linalg.norm(q)
+        ext = np.concatenate([rng.uniform(-0.05, 0.05, 3), q])
+        T = np.linalg.inv(synth.pose_to_mat(pivot)) @ synth.pose_to_mat(pose_i) @ synth.pose_to_mat(ext)
+        rel = np.concatenate([T[:3, 3], Rot.from_matrix(T[:3, :3]).as_quat()])
+        ratio = float(rng.choice([1.0, 0.8, 0.8, 0.5, 0.3, 0.1]))
+        gseed = int(rng.integers(1, 10 ** 5))
+        ctx.map_set(kind, m4); ctx.features_set(kind, f)
+        ctx.pure_odom_begin()
+        got = ctx.pure_odom_add_matches_gf(kind, rel, pivot, pose_i, ext, 0, 0, gf_ratio=ratio, seed=gseed)
+        ref = O.odom_good_feature_matching(O.Map(mp), ch, f, rel, pivot, pose_i, ext, ratio, gseed)
+        if not np.array_equal(got, ref["sel"]):
+            raise SystemExit(f"ODOM SELECT trial {trial}: scene {sseed}, kind {ch}, {len(f)} features, ratio {ratio}, seed {gseed}: {len(got)} vs {len(ref['sel'])} picks")
+        n_sel += len(got)
+    print(f"odom_select: {trials} random selections ({n_sel} picks): Estimator::goodFeatureMatching on the device path == the oracle's, pick for pick  [{time.time() - t0:.0f} s]", flush=True)
 ctx.close()
 print(f"front-end parity soak: seed {seed}, {trials} trials per family, families {families}: all equal  [{time.time() - t_all:.0f} s]")
