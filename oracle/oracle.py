@@ -197,6 +197,22 @@ def ref_good_feature_matching(map_points, kind, feats11, pose7, gf_method, gf_ra
     return dict(sel=sel[:nsel.value].copy(), H=Hm)
 
 
+def ref_match_cloud(kind: str, map_pts, feats, pose7, n_neigh=5, check_fov=True, min_match_sq_dis=1.0, min_plane_dis=0.2):
+    """FeatureExtract::matchSurfFromMap / matchCornerFromMap, the WHOLE-CLOUD forms (feature_extract.hpp:378-643: what buildCalibMap calls, estimator.cpp:1136-1150),
+    from the reference's own lines -> (valid per feature, coeffs per feature) in the per-point functions' layout"""
+    L = ref_lib()
+    m4 = np.zeros((len(map_pts), 4), np.float32); m4[:, :3] = np.asarray(map_pts)[:, :3]
+    f4 = np.zeros((len(feats), 4), np.float32); f4[:, :min(4, np.asarray(feats).shape[1])] = np.asarray(feats)[:, :4]
+    pose = np.ascontiguousarray(pose7, np.float64)
+    idx = np.zeros(2 * len(f4) + 1, np.int32); co = np.zeros((2 * len(f4) + 1, 6)); n = C.c_int(0)
+    L.ref_match_cloud(C.c_char(kind.encode()), _ptr(m4), len(m4), _ptr(f4), len(f4), _ptr(pose), int(n_neigh), int(bool(check_fov)), C.c_float(min_match_sq_dis),
+                      C.c_float(min_plane_dis), _ptr(idx), _ptr(co), C.byref(n))
+    valid = np.zeros(len(f4), np.uint8); coeffs = np.zeros((len(f4), 6))
+    valid[idx[:n.value]] = 1; coeffs[idx[:n.value]] = co[:n.value]
+    assert len(set(idx[:n.value].tolist())) == n.value
+    return valid, coeffs
+
+
 def ref_odom_good_feature_matching(kind, map_pts, feats, pivot, pose_i, ext, gf_ratio=0.8, seed=0, min_match_sq_dis=1.0, min_plane_dis=0.2):
     """Estimator::goodFeatureMatching + evaluateFeatJacobian (estimator.cpp:1273-1517) compiled from the reference's own lines. Returns sel and rel_pose = the Pose of
     T_pivot^-1 T_i T_ext as that build computes it (4 x 4 products and inverse, rotation matrix -> quaternion: library arithmetic, restated in mini_eigen.hpp)."""

@@ -184,10 +184,13 @@ public:
     void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature);
 #include "../_ref/gen/scan_match_decls.inc"                   // declarations of match{Corner,Surf}FromScan (feature_extract.hpp:78-90)
 #include "../_ref/gen/match_point_decls.inc"                  // the declarations of match{Corner,Surf}PointFromMap (default arguments live here)
+#include "../_ref/gen/match_batch_decls.inc"                  // ... and of the whole-cloud match{Corner,Surf}FromMap (feature_extract.hpp:92-108)
 };
 #include "../_ref/gen/extract_cloud.inc"                      // void FeatureExtract::extractCloud(...) { ... }
 #include "../_ref/gen/match_corner_point.inc"                 // template <typename PointType> bool FeatureExtract::matchCornerPointFromMap(...)
 #include "../_ref/gen/match_surf_point.inc"
+#include "../_ref/gen/match_corner_batch.inc"                 // FeatureExtract::matchCornerFromMap (whole cloud; buildCalibMap's call, estimator.cpp:1143)   feature_extract.hpp:378-538
+#include "../_ref/gen/match_surf_batch.inc"                   // FeatureExtract::matchSurfFromMap                                                          feature_extract.hpp:541-643
 float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;      // parameters.cpp:50-52 (set by the test entry points)
 #include "../_ref/gen/transform_start_end.inc"                // TransformToStart, TransformToEnd   utility.h:54-100
 #include "../_ref/gen/match_from_scan.inc"                    // FeatureExtract::matchCornerFromScan / matchSurfFromScan   feature_extract.hpp:131-376
@@ -693,6 +696,32 @@ public:
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
+// FeatureExtract::matchCornerFromMap / matchSurfFromMap (the whole-cloud forms buildCalibMap calls, estimator.cpp:1136-1150): features out as idx, coeffs[6]
+int ref_match_cloud(char kind, const float *map4, int n_map, const float *feat4, int n_feat, const double pose7[7], int n_neigh, int check_fov, float min_match_sq_dis,
+                    float min_plane_dis, int *idx_out, double *coeffs_out, int *n_out)
+{
+    MIN_MATCH_SQ_DIS = min_match_sq_dis; MIN_PLANE_DIS = min_plane_dis;
+    PointICloud map, feat;
+    auto fill = [](PointICloud &c, const float *p, int n) {
+        c.points.resize(size_t(n));
+        for (int i = 0; i < n; ++i) { c.points[size_t(i)].x = p[4 * i]; c.points[size_t(i)].y = p[4 * i + 1]; c.points[size_t(i)].z = p[4 * i + 2]; c.points[size_t(i)].intensity = p[4 * i + 3]; }
+    };
+    fill(map, map4, n_map); fill(feat, feat4, n_feat);
+    pcl::KdTreeFLANN<PointI>::Ptr kd(new pcl::KdTreeFLANN<PointI>());
+    kd->setInputCloud(PointICloud::Ptr(new PointICloud(map)));
+    const Pose pose(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
+    FeatureExtract fe;
+    std::vector<PointPlaneFeature> features;
+    if (kind == 's') fe.matchSurfFromMap<PointI>(kd, map, feat, pose, features, size_t(n_neigh), check_fov != 0);
+    else fe.matchCornerFromMap<PointI>(kd, map, feat, pose, features, size_t(n_neigh), check_fov != 0);
+    *n_out = int(features.size());
+    for (size_t i = 0; i < features.size(); ++i) {
+        idx_out[i] = int(features[i].idx_);
+        for (int k = 0; k < 6; ++k) coeffs_out[i * 6 + size_t(k)] = k < int(features[i].coeffs_.size()) ? features[i].coeffs_(k) : 0.0;
+    }
+    return 0;
+}
+
 // Estimator::goodFeatureMatching on one (frame, LiDAR) group: map / features as n x 4 floats; the three poses as [t, q]; gf_ratio = ODOM_GF_RATIO (a float in the
 // reference, widened at the call, estimator.cpp:1250). rel_out: the Pose the function matches at, Pose(T_pivot^-1 T_i T_ext), as this build computes it.
 int ref_odom_good_feature_matching(char kind, const float *map4, int n_map, const float *feat4, int n_feat, const double pivot7[7], const double posei7[7],

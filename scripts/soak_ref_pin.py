@@ -66,7 +66,8 @@ if "match" in families:
         p0 = synth.perturbed_pose(case["gt"], seed=sseed + 1, dt=float(rng.choice([0.02, 0.1, 0.3, 0.5])), drot_deg=float(rng.choice([0.2, 1.0, 3.0])))
         kn, fov, msd = int(rng.choice([5, 10])), bool(rng.integers(2)), float(rng.choice([1.0, 0.64]))
         for kind, f, cloud in (("s", feats[0], case["surf_map"]), ("c", feats[1], case["corner_map"])):
-            v_ref, c_ref = O.ref_match(kind, cloud, f, p0, kn, fov, min_match_sq_dis=msd)
+            # (every other trial through the whole-cloud forms, feature_extract.hpp:378-643 -- buildCalibMap's calls -- instead of the per-point ones)
+            v_ref, c_ref = (O.ref_match_cloud if trial % 2 else O.ref_match)(kind, cloud, f, p0, kn, fov, min_match_sq_dis=msd)
             v_orc, c_orc = O.Map(cloud).match(kind, f, p0, n_neigh=kn, check_fov=fov, min_match_sq_dis=msd)
             m = v_ref.astype(bool)
             if not (np.array_equal(v_ref, v_orc) and np.array_equal(c_ref[m], c_orc[m])):

@@ -167,6 +167,20 @@ def test_match_point_from_map_is_the_references(ref, case16, feats16, n_neigh, c
         assert 0 < v_fov.sum() < v_all.sum()               # the check really removes something here
 
 
+@pytest.mark.parametrize("n_neigh,check_fov", [(5, True), (10, True), (10, False)])
+def test_whole_cloud_match_functions_are_the_references(ref, case16, feats16, n_neigh, check_fov):
+    """FeatureExtract::matchSurfFromMap / matchCornerFromMap -- the whole-cloud forms (feature_extract.hpp:378-643) buildCalibMap calls with N_NEIGH 10 and CHECK_FOV
+    for the non-reference LiDARs (estimator.cpp:1130-1150) -- compiled from the reference's own lines: the same features survive, with the same coefficients, as in the
+    per-point forms the oracle restates (and the device's mlh_pure_odom_add_matches is held to)."""
+    for kind, feats, cloud in (("s", feats16[0], case16["surf_map"]), ("c", feats16[1], case16["corner_map"])):
+        v_ref, c_ref = ref.ref_match_cloud(kind, cloud, feats, case16["p0"], n_neigh, check_fov)
+        v_orc, c_orc = ref.Map(cloud).match(kind, feats, case16["p0"], n_neigh=n_neigh, check_fov=check_fov)
+        assert np.array_equal(v_ref, v_orc), (kind, int(np.sum(v_ref != v_orc)))
+        assert v_ref.sum() > 50
+        m = v_ref.astype(bool)
+        assert np.array_equal(c_ref[m], c_orc[m])
+
+
 def _raw_cloud(synth, n_rings, seed, clutter):
     """an UNORDERED cloud as a driver delivers it: a simulated scan, shuffled, part of the points pulled off their surfaces along the ray"""
     scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
