@@ -229,6 +229,19 @@ def j_window_device_table(c, st, r, m):
     return [o["H"], o["g"], np.array([o["cost"], o["count"]])], how
 
 
+def j_window_device_table_gf(c, st, r, m, ratio):
+    """the same table behind the odometry's good-feature selection (mlh_pure_odom_add_matches_gf): selections and the normal equations of the selected factors"""
+    how = ensure_map(c, st, m, r)
+    c.pure_odom_begin()
+    outs = []
+    for kind in (mla.SURF, mla.CORNER):
+        c.features_set(kind, FEATS["A"][kind])
+        outs.append(c.pure_odom_add_matches_gf(kind, P0[m], ident, P0[m], ident, 0, 0, gf_ratio=ratio, seed=17 + kind))
+    st.feat = None
+    o = c.pure_odom_normal_eq(ident, np.array([P0[m]]), np.array([ident]), huber_delta=1.0)
+    return outs + [o["H"], o["g"], np.array([o["cost"], o["count"]])], how
+
+
 def j_uncertainty(c, st, r, f):
     cov, keep = c.point_uncertainty(FEATS[f][0], EXT, COVS, MEAS, 0.6)
     return [cov, keep], ""
@@ -247,6 +260,8 @@ for i in range(2):
         JOBS.append((("window", i, what), j_window, (i, what)))
 for m in ("A", "C"):
     JOBS.append((("window_dev", m), j_window_device_table, (m,)))
+    for ratio in (0.8, 0.3):
+        JOBS.append((("window_dev_gf", m, ratio), j_window_device_table_gf, (m, ratio)))
 for f in ("A", "B"):
     JOBS.append((("uncertainty", f), j_uncertainty, (f,)))
 for i in range(3):
