@@ -33,3 +33,28 @@ for rings, vs in ((64, 64), (16, 16)):
     t0 = time.perf_counter(); O.segment_cloud(pts, O.seg_params(vertical_scans=vs)); cpu_ms = 1e3 * (time.perf_counter() - t0)
     print(f"{rings} rings, {len(pts)} points: mlh_segment_cloud (device-resident in, scan staged on the device, nothing fetched) {gpu_ms:.3f} ms per call; CPU oracle {cpu_ms:.2f} ms")
     ctx.close()
+    # As the reference calls it: NUM_OF_LASER OpenMP threads, one segmentCloud each (estimator.cpp:249-263) -- the host-side cluster search of one LiDAR runs
+    # beside the other LiDAR's (the facade's ImageSegmenter takes a context per thread). Per scan of caller-visible time = the pair's wall time / 2.
+    import threading
+    os.environ["MLH_SEG_TIMING"] = "0"
+    for n_thr in (2, 4):
+        ctxs = [mla.Context(0) for _ in range(n_thr)]
+        for c in ctxs:
+            c.segment_cloud(d, fetch=False, vertical_scans=vs)
+        walls = []
+        for rep in range(3):
+            bar = threading.Barrier(n_thr + 1)
+            def work(c):
+                bar.wait()
+                for _ in range(40):
+                    c.segment_cloud(d, fetch=False, vertical_scans=vs)
+                c.synchronize()
+            th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+            for t in th: t.start()
+            bar.wait(); t0 = time.perf_counter()
+            for t in th: t.join()
+            walls.append(1e3 * (time.perf_counter() - t0) / 40)
+        wall = sorted(walls)[1]          # median of three runs of 40 sets
+        print(f"    {n_thr} LiDARs segmented by {n_thr} threads at once (a context each): {wall:.3f} ms per set = {wall / n_thr:.3f} ms per scan of caller-visible time")
+        for c in ctxs: c.close()
+    os.environ["MLH_SEG_TIMING"] = "1"
