@@ -4,6 +4,7 @@
 // and writes <dir>/out_labels.i32, <dir>/out_pose.f64 (7), <dir>/out_counts.i32 (per outer: n_surf, n_corner, lm_iterations),
 // <dir>/out_valid_surf.u8 (batch matchSurfFromMap at the initial pose).
 #include "mloam_facade.hpp"
+#include <random>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -504,6 +505,79 @@ int main(int argc, char **argv)
             std::printf("pipelined mapper: %d frames, staged beside the solve %d, waited for the pose %d, solved again after a wrong prediction %d; keyframes %d (plain loop %zu); "
                         "max |pose - plain loop| %.2e\n", n_frames, mapper.counters.overlapped, mapper.counters.waited, mapper.counters.redone, mapper.counters.keyframes,
                         ref_kf.size(), worst);
+        }
+        // --- the same comparison on RANDOM frame sequences (six seeds x 40 frames): random steps of 0.05-0.6 m, random odometry drift, keyframe distances 0.5-1.5 m --
+        //     every mix of "staged beside the solve", "waited for the pose" and "solved again after a wrong prediction" the loop can meet; every pose the plain loop's
+        {
+            double worst_all = 0.0;
+            int tot_overlapped = 0, tot_waited = 0, tot_redone = 0, tot_kf = 0, kf_mismatch = 0;
+            for (unsigned seed = 1; seed <= 6; ++seed) {
+                std::mt19937 rng(seed);
+                std::uniform_real_distribution<double> step(0.05, 0.6), drift(-0.04, 0.04), kfd(0.5, 1.5);
+                const int n_frames = 40;
+                const float kf_dist = float(kfd(rng));
+                const Pose T0 = pose;
+                auto motion = [](double dx) { Pose m; m.t_(0) = dx; return m; };
+                auto moved = [](const PointICovCloud &c, double dx) { PointICovCloud o = c; for (auto &q : o.points) q.x = float(double(q.x) - dx); return o; };
+                std::vector<PointICovCloud> fs, fc;
+                std::vector<Pose> wodom;
+                double x_true = 0.0, x_odom = 0.0;
+                for (int k = 0; k < n_frames; ++k) {
+                    fs.push_back(moved(surf, x_true)); fc.push_back(moved(corner, x_true)); wodom.push_back(motion(x_odom));
+                    const double st = step(rng);
+                    x_true += st; x_odom += st + drift(rng);
+                    if (x_true > 6.0) { x_true = 0.0; x_odom = x_odom - 6.0; }                     // stay inside the map
+                }
+                auto assemble = [&](const std::vector<int> &ids, const Pose &, PointICovCloud &s_out, PointICovCloud &c_out) {
+                    int key = 0;
+                    for (int id : ids) key += id + 1;
+                    s_out.clear(); c_out.clear();
+                    for (size_t i = 0; i < surf_map.size(); ++i) if (int(i % 13) != key % 13) s_out.push_back(surf_map.points[i]);
+                    for (size_t i = 0; i < corner_map.size(); ++i) if (int(i % 13) != key % 13) c_out.push_back(corner_map.points[i]);
+                };
+                std::vector<Pose> ref_pose;
+                int ref_kf = 0;
+                {
+                    KeyframePolicy kf(kf_dist, 10.0f, 50.0f);
+                    FramePipeline one(dev, 3);
+                    PointICovCloud ms = surf_map, mc = corner_map;
+                    Pose wmap_wodom = poseMul(T0, poseInverse(wodom[0]));
+                    bool rebuild = false;
+                    for (int k = 0; k < n_frames; ++k) {
+                        const Pose prior = poseMul(wmap_wodom, wodom[k]);
+                        if (rebuild) { PointICovCloud a, b; assemble(kf.surrounding(prior), prior, a, b); ms = a; mc = b; }
+                        one.setInputClouds(ms, mc);
+                        one.setFeatures(fs[k], fc[k]);
+                        one.submit(prior);
+                        const Pose r = one.collect();
+                        ref_pose.push_back(r);
+                        wmap_wodom = poseMul(r, poseInverse(wodom[k]));
+                        rebuild = kf.save(r) >= 0;
+                        ref_kf += rebuild ? 1 : 0;
+                    }
+                }
+                std::vector<Pose> got_pose;
+                KeyframePolicy kf(kf_dist, 10.0f, 50.0f);
+                PipelinedMapper mapper(dev, kf, assemble, [&](int, const Pose &) {}, 3);
+                mapper.setInitialMap(surf_map, corner_map);
+                mapper.setInitialPose(T0, wodom[0]);
+                for (int k = 0; k < n_frames; ++k) {
+                    Pose prev;
+                    if (mapper.process(fs[k], fc[k], wodom[k], prev)) got_pose.push_back(prev);
+                }
+                got_pose.push_back(mapper.finish());
+                for (int k = 0; k < n_frames; ++k) {
+                    double a[7], b[7];
+                    ref_pose[k].toParam(a); got_pose[k].toParam(b);
+                    for (int i = 0; i < 7; ++i) worst_all = std::max(worst_all, std::fabs(a[i] - b[i]));
+                }
+                tot_overlapped += mapper.counters.overlapped; tot_waited += mapper.counters.waited; tot_redone += mapper.counters.redone; tot_kf += mapper.counters.keyframes;
+                kf_mismatch += (mapper.counters.keyframes != ref_kf) ? 1 : 0;
+            }
+            std::vector<double> pr = {worst_all, double(tot_overlapped), double(tot_waited), double(tot_redone), double(tot_kf), double(kf_mismatch)};
+            write_file(d + "out_pipelined_mapper_random.f64", pr);
+            std::printf("pipelined mapper, 6 random sequences x 40 frames: staged beside the solve %d, waited %d, solved again %d, keyframes %d (sequences whose keyframe count differs "
+                        "from the plain loop's: %d); max |pose - plain loop| %.2e\n", tot_overlapped, tot_waited, tot_redone, tot_kf, kf_mismatch, worst_all);
         }
         // --- PoseLocalParameterization sanity
         PoseLocalParameterization lp;

@@ -95,6 +95,10 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     assert worst < 1e-9, pm[56:]
     assert overlapped >= 2 and waited >= 1 and redone >= 1 and n_kf == n_kf_ref >= 3, pm[56:]
     assert abs(travelled - 3 * 0.34) < 0.02                      # the solved poses follow the sensor's motion (0.34 m per frame), not the drifting odometry (0.31)
+    # the same on six random 40-frame sequences (random steps, drift, keyframe distances): every pose the plain synchronous loop's, every path of the loop taken
+    pr = np.fromfile(os.path.join(d, "out_pipelined_mapper_random.f64"), np.float64)
+    assert pr[0] < 1e-9 and pr[5] == 0, pr
+    assert pr[1] >= 20 and pr[2] >= 10 and pr[4] >= 20, pr        # staged beside the solve / waited for the pose / keyframes: all well exercised
     # ---- round 2: ActiveFeatureSelection::evalFullHessian -> logDet -> gf_ratio policy through the facade
     afs = np.fromfile(os.path.join(d, "out_afs.f64"), np.float64)
     cov6 = np.array([0.01, 0, 0, 0.02, 0, 0.03], np.float32)
