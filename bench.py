@@ -1131,6 +1131,20 @@ def main():
             out["scan2map"]["cpu_port_ms_per_frame"] = round(1e3 * (_t.perf_counter() - t3), 2)
             out["scan2map"]["cpu_port_lm_iterations"] = [int(o["lm_iterations"]) for o in rs["outer"]]
             out["scan2map"]["pose_agreement_m"] = float(np.linalg.norm(np.array(rs["pose"][:3]) - np.array(s2m_pose[:3])))
+            # the reference's OWN lines of scan2MapOptimization (oracle/_ref: lidar_mapper_keyframe.cpp:423-639 compiled over the shim -- kd-tree, Eigen and the LM
+            # iteration are restated there, everything else is the reference's text), one frame, kd-tree set-up included as in the reference: a second CPU figure for
+            # the call, and one more check of the pose (checker only; skipped when the prebuilt library did not travel)
+            try:
+                if O.ref_lib() is not None:
+                    import contextlib, io
+                    t4 = _t.perf_counter()
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        rr = O.ref_scan2map(surf_map, corner_map, surf, corner, p0)
+                    out["scan2map"]["cpu_reference_lines_ms_per_frame"] = round(1e3 * (_t.perf_counter() - t4), 2)
+                    out["scan2map"]["cpu_reference_lines_lm_iterations"] = [int(o["lm_iterations"]) for o in rr["solves"]]
+                    out["scan2map"]["pose_agreement_with_reference_lines_m"] = float(np.linalg.norm(np.array(rr["pose"][:3]) - np.array(s2m_pose[:3])))
+            except Exception as ex:                       # (a checker's failure must not cost the bench line)
+                out["scan2map"]["cpu_reference_lines_error"] = str(ex)[:200]
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
