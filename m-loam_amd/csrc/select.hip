@@ -561,6 +561,14 @@ void select_greedy_odom(const Rows &R, size_t n_use, std::mt19937 &rng, std::vec
             }
             if (retries >= max_retry) break;
             if (!R.matched(q)) { pool.erase_index(q); continue; }
+            if (subset <= 1) {
+                // subsets of one (every ratio above 0.5, ODOM_GF_RATIO = 0.8 among them): the heap's top is the feature just pushed whatever its score, and
+                // sub_mat_H is not returned -- the pick is the draw; neither the score nor the rows are needed
+                pool.erase_index(q);
+                sel.push_back(q);
+                n_fresh = pool.size();
+                break;
+            }
             double Ht[36];
             std::copy(H, H + 36, Ht);
             rank1_update(Ht, R.jaco(q));
@@ -596,15 +604,17 @@ int odom_good_feature_select(mlh_ctx *ctx, int kind, float gf_ratio, std::mt1993
         ctx->select_host_cap[kind] = need + need / 4;
     }
     char *hb = static_cast<char *>(ctx->select_host[kind]);
-    MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t n_use = static_cast<size_t>(m * double(gf_ratio));
+    const bool need_rows = n_use > 0 && static_cast<size_t>(1.0 * m / n_use) > 1;      // subsets of one never look at a score (select_greedy_odom)
+    if (need_rows) MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->select_rows[kind].resize(off_k);
     char *cb = ctx->select_rows[kind].data();
-    std::memcpy(cb, hb, off_k);                     // (the loop jumps around in these rows: ordinary memory, see good_feature_finish)
+    if (need_rows) std::memcpy(cb, hb, off_v);      // (the loop jumps around in these rows: ordinary memory, see good_feature_finish)
+    std::memcpy(cb + off_v, hb + off_v, m);
     Rows R;
     R.m = m; R.J = reinterpret_cast<const double *>(cb); R.valid = reinterpret_cast<const uint8_t *>(cb + off_v); R.pts = nullptr;
-    const size_t n_use = static_cast<size_t>(m * double(gf_ratio));
     std::vector<size_t> sel;
     sel.reserve(n_use);
     select_greedy_odom(R, n_use, rng, sel);

@@ -142,6 +142,29 @@ for preset in os.environ.get("CALIBBENCH_PRESETS", "500k,4M").split(","):
     dev_vs_host = float(np.abs(ne_d["H"] - ne_h["H"]).max() / np.abs(ne_h["H"]).max())
     print(f"  factor table built on the device ({ne_d['count']} factors = {ne_h['count']} host-staged): 8 x (features_set + match pass + append) {t_dev_build:.2f} ms "
           f"(of which the host->device feature uploads; was {t_match + t_stage:.2f} ms through the host), normal equations vs the host-staged table: max rel |dH| {dev_vs_host:.1e}")
+    # the same table behind the ODOMETRY's good-feature selection (Estimator::goodFeatureMatching, ODOM_GF_RATIO = 0.8): 8 x (features_set + match + scored rows +
+    # the host draw loop + append of the selected); CPU: the oracle's restatement of the same calls
+    def build_selected(ratio):
+        ctx.pure_odom_begin()
+        n_sel = 0
+        for i in range(4):
+            rel = to_pose(synth.pose_to_mat(frame0) @ synth.pose_to_mat(exts0[i]))
+            for kind, feats_k in ((mla.SURF, surf_b[i]), (mla.CORNER, corner_b[i])):
+                ctx.features_set(kind, feats_k)
+                n_sel += len(ctx.pure_odom_add_matches_gf(kind, rel, ident, frame0, exts0[i], 0, i, gf_ratio=ratio, seed=3 + i))
+        return n_sel
+    for _ in range(3): n_sel = build_selected(0.8)
+    ctx.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): n_sel = build_selected(0.8)
+    ctx.synchronize(); t_sel = 1e3 * (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter(); n_cpu = 0
+    for i in range(4):
+        rel = to_pose(synth.pose_to_mat(frame0) @ synth.pose_to_mat(exts0[i]))
+        for ch, om, feats_k in (("s", ms, surf_b[i]), ("c", mc, corner_b[i])):
+            n_cpu += len(O.odom_good_feature_matching(om, ch, feats_k, rel, ident, frame0, exts0[i], 0.8, 3 + i)["sel"])
+    t_sel_cpu = 1e3 * (time.perf_counter() - t0)
+    print(f"  the odometry's good-feature selection in front of the table (Estimator::goodFeatureMatching, ODOM_GF_RATIO 0.8): 8 x (features_set + match + scored rows + host draw "
+          f"loop + append) {t_sel:.2f} ms, {n_sel} factors selected (CPU oracle, same calls: {t_sel_cpu:.1f} ms, {n_cpu} selected)")
     print(f"  coupled window system on the {preset} map: {len(tab[0])} factors, D = {D} (pivot | 1 frame | 4 extrinsics): GPU matching of 4 LiDARs x 2 kinds "
           f"{t_match:.2f} ms (8 launches, host copies of validity + coefficients), table staging {t_stage:.2f} ms, one normal-equation pass {t_ne:.3f} ms, "
           f"5 coupled GN iterations (device J^T J / J^T r + host 24-dim solve + Plus) {t_gn:.3f} ms vs CPU oracle accumulation {t_cpu:.1f} ms; "
