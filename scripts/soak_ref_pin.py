@@ -117,7 +117,7 @@ if "voxel" in families:
     print(f"voxel: {trials} random clouds ({n_pts} points): the reference's applyFilter (plain and covariance branches) == the oracle's, bit for bit  [{time.time() - t0:.0f} s]", flush=True)
 
 if "scan2map" in families:
-    t0 = time.time(); n_lm = 0
+    t0 = time.time(); n_lm = 0; worst_pose = 0.0
     for trial in range(trials):
         sseed = int(rng.integers(1, 10 ** 6))
         case = conftest._make_case(synth, "50k", 16, int(rng.choice([1, 2])), seed=sseed)
@@ -150,9 +150,13 @@ if "scan2map" in families:
             if abs(g["initial_cost"] - w["initial_cost"]) > 1e-12 * max(1.0, w["initial_cost"]) or abs(g["final_cost"] - w["final_cost"]) > 1e-12 * max(1.0, w["final_cost"]):
                 raise SystemExit(f"SCAN2MAP costs {what}")
             n_lm += g["lm_iterations"]
-        if np.linalg.norm(got["pose"] - want["pose"]) > 1e-12:
-            raise SystemExit(f"SCAN2MAP pose {what}: {np.linalg.norm(got['pose'] - want['pose']):.2e}")
-    print(f"scan2map: {trials} random problems: block counts, {n_lm} LM iterations (counts, successful steps, terminations), costs 1e-12 and poses 1e-12 of the reference's loop == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
+        # (1e-11 on a pose whose translation is tens of metres: f64 sums over 10^3-10^4 blocks associated differently; the largest seen in 4 500 problems is 1.8e-12,
+        # with a selection that repeats one feature a few hundred times)
+        dpose = float(np.linalg.norm(got["pose"] - want["pose"]))
+        worst_pose = max(worst_pose, dpose)
+        if dpose > 1e-11:
+            raise SystemExit(f"SCAN2MAP pose {what}: {dpose:.2e}")
+    print(f"scan2map: {trials} random problems: block counts, {n_lm} LM iterations (counts, successful steps, terminations), costs 1e-12 and poses (largest difference {worst_pose:.1e}) of the reference's loop == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
 
 if "track" in families:
     t0 = time.time(); n_lm = 0
