@@ -154,6 +154,9 @@ if "scan2map" in families:
         # with a selection that repeats one feature a few hundred times)
         dpose = float(np.linalg.norm(got["pose"] - want["pose"]))
         worst_pose = max(worst_pose, dpose)
+        if dpose > 1e-12 and os.environ.get("SOAK_DUMP"):
+            np.savez(os.environ["SOAK_DUMP"], surf_map=case["surf_map"], corner_map=case["corner_map"], f_s=f_s, f_c=f_c, p0=p0, with_ua=with_ua, gm=gm, gr=gr, gseed=gseed, fc=fc)
+            print(f"dumped {what}: {dpose:.2e}", flush=True)
         if dpose > 1e-11:
             raise SystemExit(f"SCAN2MAP pose {what}: {dpose:.2e}")
     print(f"scan2map: {trials} random problems: block counts, {n_lm} LM iterations (counts, successful steps, terminations), costs 1e-12 and poses (largest difference {worst_pose:.1e}) of the reference's loop == the oracle's  [{time.time() - t0:.0f} s]", flush=True)
