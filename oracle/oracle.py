@@ -197,6 +197,15 @@ def ref_good_feature_matching(map_points, kind, feats11, pose7, gf_method, gf_ra
     return dict(sel=sel[:nsel.value].copy(), H=Hm)
 
 
+def ref_save_keyframes(poses, distance_keyframes=1.0, orientation_keyframes=1.0):
+    """saveKeyframe (lidar_mapper_keyframe.cpp:641-683) from the reference's own lines, called once per pose of the sequence from a clean state -> saved flags"""
+    L = ref_lib()
+    p = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+    saved = np.zeros(len(p), np.uint8)
+    L.ref_save_keyframes(_ptr(p), len(p), C.c_float(distance_keyframes), C.c_float(orientation_keyframes), _ptr(saved))
+    return saved
+
+
 def ref_match_cloud(kind: str, map_pts, feats, pose7, n_neigh=5, check_fov=True, min_match_sq_dis=1.0, min_plane_dis=0.2):
     """FeatureExtract::matchSurfFromMap / matchCornerFromMap, the WHOLE-CLOUD forms (feature_extract.hpp:378-643: what buildCalibMap calls, estimator.cpp:1136-1150),
     from the reference's own lines -> (valid per feature, coeffs per feature) in the per-point functions' layout"""

@@ -84,6 +84,7 @@ CUTS = [
     ("vector2double.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 236, 252, "void vector2Double()"),
     ("scan2map_optimization.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 423, 639, "void scan2MapOptimization()"),
     ("transform_associate_update.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 145, 160, "void transformAssociateToMap()"),
+    ("save_keyframe.inc", "lidarMapper/lidar_mapper_keyframe.cpp", 641, 683, "void saveKeyframe()"),
     ("track_cloud.inc", "lidarTracker/lidar_tracker.cpp", 23, 129, "Pose LidarTracker::trackCloud"),
     ("uct_compound.inc", "lidarMapper/associate_uct.hpp", 9, 86, "inline Eigen::Matrix<double, 6, 6> adjointMatrix"),
     ("uct_point_to_fs.inc", "lidarMapper/associate_uct.hpp", 150, 156, "inline Eigen::Matrix<double, 4, 6> pointToFS"),

@@ -319,6 +319,12 @@ template <typename T> struct Quaternion {
     // QuaternionBase::inverse: conjugate / squaredNorm (zero quaternion -> zero)
     Quaternion inverse() const { const T n2 = x_ * x_ + y_ * y_ + z_ * z_ + w_ * w_; if (n2 > T(0)) return Quaternion(w_ / n2, -x_ / n2, -y_ / n2, -z_ / n2); return Quaternion(T(0), T(0), T(0), T(0)); }
     T dot(const Quaternion &o) const { return x_ * o.x_ + y_ * o.y_ + z_ * o.z_ + w_ * o.w_; }
+    // QuaternionBase::angularDistance (Eigen 3.3 Geometry/Quaternion.h): d = (*this * other.conjugate()); 2 * atan2(d.vec().norm(), |d.w()|)  (library arithmetic, restated)
+    T angularDistance(const Quaternion &other) const
+    {
+        const Quaternion d = (*this) * other.conjugate();
+        return T(2) * std::atan2(std::sqrt(d.x_ * d.x_ + d.y_ * d.y_ + d.z_ * d.z_), std::abs(d.w_));
+    }
     // QuaternionBase::slerp (Eigen 3.3 Geometry/Quaternion.h): library arithmetic, restated
     Quaternion slerp(T t, const Quaternion &other) const
     {

@@ -667,12 +667,24 @@ double FLAGS_gf_ratio_ini = 0.2, gf_ratio_cur = 1.0, MAP_DEG_THRE = 42.0;
 std::vector<double> gf_deg_factor_list, gf_logdet_H_list;     // :123-124
 std::vector<std::vector<double>> mapping_sp_list;             // :127
 Eigen::Matrix<double, 6, 6> cov_mapping;                      // :99
-std::vector<int> pose_keyframes_6d;                           // :60 (a point cloud in the reference; only its size is read here)
+std::vector<std::pair<double, Pose>> pose_keyframes_6d;       // :60
 int pub_good_surf_feature = 0;                                // ros::Publisher :115
 double time_laser_odometry = 0.0;                             // :36
 #include "../_ref/gen/vector2double.inc"                      // vector2Double, double2Vector   lidar_mapper_keyframe.cpp:236-252
 #define printf(...) ((void)0)
 #include "../_ref/gen/scan2map_optimization.inc"              // scan2MapOptimization           lidar_mapper_keyframe.cpp:423-639
+#undef printf
+
+// ---------------------------------------------------------------- saveKeyframe (lidar_mapper_keyframe.cpp:641-683) from the reference's own lines
+bool save_new_keyframe = false;                               // :64
+PointI pose_point_cur, pose_point_prev;                       // :93
+Eigen::Quaterniond q_ori_cur, q_ori_prev;                     // :94
+float DISTANCE_KEYFRAMES = 1.0f, ORIENTATION_KEYFRAMES = 1.0f; // parameters.cpp:98-99
+PointICloud::Ptr pose_keyframes_3d(new PointICloud());        // :59
+std::vector<PointICovCloud::Ptr> surf_cloud_keyframes_cov, corner_cloud_keyframes_cov, outlier_cloud_keyframes_cov;   // :74-76
+namespace pcl { template <typename A, typename B> void copyPointCloud(const A &in, B &out) { out.points.assign(in.points.begin(), in.points.end()); out.width = in.width; out.height = in.height; } }
+#define printf(...) ((void)0)
+#include "../_ref/gen/save_keyframe.inc"
 #undef printf
 
 // ---------------------------------------------------------------- LidarTracker::trackCloud (lidar_tracker.cpp:23-129) from the reference's own lines
@@ -696,6 +708,25 @@ public:
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
+// saveKeyframe over a sequence of mapper poses (n x 7: t, q): saved[i] = 1 where the reference saves frame i as a keyframe; from a clean state
+int ref_save_keyframes(const double *poses7, int n, float distance_keyframes, float orientation_keyframes, unsigned char *saved)
+{
+    DISTANCE_KEYFRAMES = distance_keyframes; ORIENTATION_KEYFRAMES = orientation_keyframes;
+    pose_keyframes_3d->points.clear(); pose_keyframes_6d.clear();
+    surf_cloud_keyframes_cov.clear(); corner_cloud_keyframes_cov.clear(); outlier_cloud_keyframes_cov.clear();
+    pose_point_prev = PointI(); q_ori_prev = Eigen::Quaterniond::Identity();
+    for (int i = 0; i < n; ++i) {
+        const double *p = poses7 + 7 * i;
+        pose_wmap_curr = Pose(Eigen::Quaterniond(p[6], p[3], p[4], p[5]), Eigen::Vector3d(p[0], p[1], p[2]));
+        saveKeyframe();
+        saved[i] = save_new_keyframe ? 1 : 0;
+    }
+    const int n_kf = int(pose_keyframes_3d->size());
+    pose_keyframes_3d->points.clear(); pose_keyframes_6d.clear();
+    surf_cloud_keyframes_cov.clear(); corner_cloud_keyframes_cov.clear(); outlier_cloud_keyframes_cov.clear();
+    return n_kf;
+}
+
 // FeatureExtract::matchCornerFromMap / matchSurfFromMap (the whole-cloud forms buildCalibMap calls, estimator.cpp:1136-1150): features out as idx, coeffs[6]
 int ref_match_cloud(char kind, const float *map4, int n_map, const float *feat4, int n_feat, const double pose7[7], int n_neigh, int check_fov, float min_match_sq_dis,
                     float min_plane_dis, int *idx_out, double *coeffs_out, int *n_out)
@@ -1264,7 +1295,7 @@ int ref_scan2map_optimization(const float *surf_map11, int n_surf_map, const flo
     frame_cnt = frame_cnt_in;
     afs.rgi_.m_random_engine.seed(seed);
     pose_wmap_curr = Pose(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
-    pose_keyframes_6d.assign(20, 0);                          // more than 10 keyframes: cov_mapping = mat_H^-1 (cpp:607-610)
+    pose_keyframes_6d.assign(20, std::make_pair(0.0, Pose()));   // more than 10 keyframes: cov_mapping = mat_H^-1 (cpp:607-610)
     d_factor_list.clear(); d_eigvec_list.clear(); gf_deg_factor_list.clear(); gf_logdet_H_list.clear(); mapping_sp_list.clear();
     ceres::g_solve_log.clear();
     std::ostringstream sink;

@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -298,6 +298,38 @@ if "odom_select" in families:
             raise SystemExit(f"ODOM SELECT trial {trial}: scene {sseed}, kind {kind}, {len(f)} features, ratio {ratio}, seed {gseed}: {len(r['sel'])} vs {len(o['sel'])} picks")
         n_sel += len(r["sel"])
     print(f"odom_select: {trials} random selections ({n_sel} picks): Estimator::goodFeatureMatching of the reference's lines and the oracle pick the same features in the same order  [{time.time() - t0:.0f} s]", flush=True)
+
+if "keyframes" in families:
+    # the facade's KeyframePolicy (m-loam_amd/host/mloam_facade.hpp; tests/host/keyframe_policy_check.cpp drives it) against saveKeyframe's own lines
+    import subprocess, tempfile
+    t0 = time.time(); n_fr = n_kf = 0
+    lib_dir = os.path.join(ROOT, "m-loam_amd", "lib")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "keyframe_policy_check")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                        os.path.join(ROOT, "tests", "host", "keyframe_policy_check.cpp"), "-L", lib_dir, "-lmloam_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib",
+                        "-L/opt/rocm/lib"], check=True)
+        for trial in range(trials):
+            n = int(rng.integers(5, 120))
+            step, turn = float(rng.choice([0.05, 0.3, 0.8])), float(rng.choice([0.1, 0.8, 3.0]))
+            dist_kf, ori_kf = float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.5, 1.0, 5.0]))
+            poses = np.zeros((n, 7)); t = np.zeros(3); yaw = 0.0
+            for i in range(n):
+                yaw += np.radians(rng.uniform(-turn, turn))
+                t = t + np.array([np.cos(yaw), np.sin(yaw), 0.02 * rng.normal()]) * rng.uniform(0.5 * step, 1.5 * step)
+                q = np.array([0.01 * rng.normal(), 0.01 * rng.normal(), np.sin(yaw / 2), np.cos(yaw / 2)])
+                poses[i] = np.concatenate([t, q / np.linalg.norm(q)])
+            if trial % 5 == 0:       # steps of exactly the threshold along one axis (f32-representable): the comparison is a strict >
+                poses[:, :3] = 0.0; poses[:, 0] = np.arange(n) * dist_kf; poses[:, 3:] = [0, 0, 0, 1]
+            poses.tofile(os.path.join(td, "poses.f64"))
+            subprocess.run([exe, td, str(n), str(dist_kf), str(ori_kf), "4.0"], check=True)
+            out = np.fromfile(os.path.join(td, "out.f64"))
+            dec = out[7 * max(n - 2, 0):].reshape(n, 4)
+            want = O.ref_save_keyframes(poses, dist_kf, ori_kf)
+            if not np.array_equal(dec[:, 0].astype(np.uint8), want):
+                raise SystemExit(f"KEYFRAMES trial {trial}: n {n}, step {step}, turn {turn}, thresholds {dist_kf} m / {ori_kf} deg: decisions differ at {np.flatnonzero(dec[:, 0].astype(np.uint8) != want)[:5]}")
+            n_fr += n; n_kf += int(want.sum())
+    print(f"keyframes: {trials} random trajectories ({n_fr} frames, {n_kf} keyframes): the facade's KeyframePolicy decides as saveKeyframe's own lines do  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0

@@ -200,6 +200,9 @@ def test_facade_keyframe_policy_and_pose_chain(tmp_path, orc):
             h = h * 31.0 + (j + 1)
         assert int(dec[i, 2]) == len(ids) and dec[i, 3] == h, (i, ids)
     assert 5 < n_saved < n - 5                      # both decisions occur
+    # ... and the decisions are those of saveKeyframe's own lines (oracle/_ref: lidar_mapper_keyframe.cpp:641-683 over the shim)
+    if orc.ref_lib() is not None:
+        assert np.array_equal(orc.ref_save_keyframes(poses, dist_kf, ori_kf), dec[:, 0].astype(np.uint8))
 
 
 def test_every_entry_point_refuses_a_null_context(mla):
