@@ -298,24 +298,26 @@ public:
         const size_t n = laser_cloud_in.size();
         laser_cloud_out.points.resize(n);
         if (n == 0) return;
-        const float two_pi = float(2 * M_PI);
+        // The reference's variables are float, its constants (M_PI) double: every `ori += 2 * M_PI` is a DOUBLE addition rounded back to float, every comparison
+        // against `start_ori - M_PI / 2` a double comparison -- spelled out here, term by term (pinned against the reference's own lines:
+        // tests/test_abi.py::test_facade_cal_timestamp_is_the_references). The angle itself: atan2 on two floats = the float overload.
         float start_ori = -std::atan2(laser_cloud_in.points[0].y, laser_cloud_in.points[0].x);
-        float end_ori = -std::atan2(laser_cloud_in.points[n - 1].y, laser_cloud_in.points[n - 1].x) + two_pi;
-        if (end_ori - start_ori > float(3 * M_PI)) end_ori -= two_pi;
-        else if (end_ori - start_ori < float(M_PI)) end_ori += two_pi;
+        float end_ori = float(double(-std::atan2(laser_cloud_in.points[n - 1].y, laser_cloud_in.points[n - 1].x)) + 2 * M_PI);
+        if (double(end_ori - start_ori) > 3 * M_PI) end_ori = float(double(end_ori) - 2 * M_PI);
+        else if (double(end_ori - start_ori) < M_PI) end_ori = float(double(end_ori) + 2 * M_PI);
         bool half_passed = false;
         for (size_t i = 0; i < n; ++i) {
             PointI q;
             q.x = laser_cloud_in.points[i].x; q.y = laser_cloud_in.points[i].y; q.z = laser_cloud_in.points[i].z;
             float ori = -std::atan2(q.y, q.x);
             if (!half_passed) {
-                if (ori < start_ori - float(M_PI / 2)) ori += two_pi;
-                else if (ori > start_ori + float(M_PI * 3 / 2)) ori -= two_pi;
-                if (ori - start_ori > float(M_PI)) half_passed = true;
+                if (double(ori) < double(start_ori) - M_PI / 2) ori = float(double(ori) + 2 * M_PI);
+                else if (double(ori) > double(start_ori) + M_PI * 3 / 2) ori = float(double(ori) - 2 * M_PI);
+                if (double(ori - start_ori) > M_PI) half_passed = true;
             } else {
-                ori += two_pi;
-                if (ori < end_ori - float(M_PI * 3 / 2)) ori += two_pi;
-                else if (ori > end_ori + float(M_PI / 2)) ori -= two_pi;
+                ori = float(double(ori) + 2 * M_PI);
+                if (double(ori) < double(end_ori) - M_PI * 3 / 2) ori = float(double(ori) + 2 * M_PI);
+                else if (double(ori) > double(end_ori) + M_PI / 2) ori = float(double(ori) - 2 * M_PI);
             }
             q.intensity = (ori - start_ori) / (end_ori - start_ori) * scan_period;
             laser_cloud_out.points[i] = q;

@@ -197,6 +197,15 @@ def ref_good_feature_matching(map_points, kind, feats11, pose7, gf_method, gf_ra
     return dict(sel=sel[:nsel.value].copy(), H=Hm)
 
 
+def ref_cal_timestamp(xyz, scan_period=0.1):
+    """FeatureExtract::findStartEndAngle + calTimestamp (feature_extract.cpp:54-114) from the reference's own lines: the relative time of every point of a raw cloud"""
+    L = ref_lib()
+    p = np.ascontiguousarray(np.asarray(xyz)[:, :3], np.float32)
+    out = np.zeros(len(p), np.float32)
+    L.ref_cal_timestamp(_ptr(p), len(p), C.c_float(scan_period), _ptr(out))
+    return out
+
+
 def ref_save_keyframes(poses, distance_keyframes=1.0, orientation_keyframes=1.0):
     """saveKeyframe (lidar_mapper_keyframe.cpp:641-683) from the reference's own lines, called once per pose of the sequence from a clean state -> saved flags"""
     L = ref_lib()

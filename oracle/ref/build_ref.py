@@ -22,6 +22,7 @@ CUTS = [
     ("comp_object.inc", "featureExtract/feature_extract.hpp", 48, 53, "class compObject"),
     ("extract_cloud.inc", "featureExtract/feature_extract.cpp", 118, 297, "void FeatureExtract::extractCloud"),
     ("match_point_decls.inc", "featureExtract/feature_extract.hpp", 110, 128, "template <typename PointType>"),
+    ("cal_timestamp.inc", "featureExtract/feature_extract.cpp", 54, 114, "void FeatureExtract::findStartEndAngle"),
     ("match_batch_decls.inc", "featureExtract/feature_extract.hpp", 92, 108, "template <typename PointType>"),
     ("match_corner_batch.inc", "featureExtract/feature_extract.hpp", 378, 538, "template <typename PointType>"),
     ("match_surf_batch.inc", "featureExtract/feature_extract.hpp", 541, 643, "template <typename PointType>"),

@@ -59,6 +59,7 @@ template <typename T, typename... A> std::shared_ptr<T> make_shared(A &&...a) { 
 }  // namespace boost
 namespace pcl {
 struct PointXYZI { float x = 0, y = 0, z = 0, intensity = 0; };
+struct PointXYZ { float x = 0, y = 0, z = 0; };                 // the raw driver cloud's point (FeatureExtract::calTimestamp's input)
 template <typename P> struct PointCloud {
     typedef boost::shared_ptr<PointCloud<P>> Ptr;
     std::vector<P> points;
@@ -185,13 +186,29 @@ public:
 #include "../_ref/gen/scan_match_decls.inc"                   // declarations of match{Corner,Surf}FromScan (feature_extract.hpp:78-90)
 #include "../_ref/gen/match_point_decls.inc"                  // the declarations of match{Corner,Surf}PointFromMap (default arguments live here)
 #include "../_ref/gen/match_batch_decls.inc"                  // ... and of the whole-cloud match{Corner,Surf}FromMap (feature_extract.hpp:92-108)
+    typedef pcl::PointCloud<pcl::PointXYZ> PointCloud;        // common_header.h: the raw driver cloud
+    void findStartEndAngle(const PointCloud &laser_cloud_in, float &start_ori, float &end_ori);      // feature_extract.hpp:60-62
+    void calTimestamp(const PointCloud &laser_cloud_in, PointICloud &laser_cloud_out);               // feature_extract.hpp:68-69
 };
+typedef FeatureExtract::PointCloud PointCloud;
 #include "../_ref/gen/extract_cloud.inc"                      // void FeatureExtract::extractCloud(...) { ... }
 #include "../_ref/gen/match_corner_point.inc"                 // template <typename PointType> bool FeatureExtract::matchCornerPointFromMap(...)
 #include "../_ref/gen/match_surf_point.inc"
 #include "../_ref/gen/match_corner_batch.inc"                 // FeatureExtract::matchCornerFromMap (whole cloud; buildCalibMap's call, estimator.cpp:1143)   feature_extract.hpp:378-538
 #include "../_ref/gen/match_surf_batch.inc"                   // FeatureExtract::matchSurfFromMap                                                          feature_extract.hpp:541-643
 float SCAN_PERIOD = 0.1f, DISTANCE_SQ_THRESHOLD = 25.0f, NEARBY_SCAN = 2.5f;      // parameters.cpp:50-52 (set by the test entry points)
+namespace pcl {
+// pcl::copyPointCloud between clouds of the same point type, and from PointXYZ to PointXYZI (common/io.h: the fields both types have are copied, the rest keep
+// their default -- intensity 0)
+template <typename P> void copyPointCloud(const PointCloud<P> &in, PointCloud<P> &out) { out.points.assign(in.points.begin(), in.points.end()); out.width = in.width; out.height = in.height; }
+inline void copyPointCloud(const PointCloud<PointXYZ> &in, PointCloud<PointXYZI> &out)
+{
+    out.points.resize(in.points.size());
+    for (size_t i = 0; i < in.points.size(); ++i) { out.points[i].x = in.points[i].x; out.points[i].y = in.points[i].y; out.points[i].z = in.points[i].z; out.points[i].intensity = 0.f; }
+    out.width = in.width; out.height = in.height;
+}
+}
+#include "../_ref/gen/cal_timestamp.inc"                      // FeatureExtract::findStartEndAngle, calTimestamp(PointCloud)   feature_extract.cpp:54-114
 #include "../_ref/gen/transform_start_end.inc"                // TransformToStart, TransformToEnd   utility.h:54-100
 #include "../_ref/gen/match_from_scan.inc"                    // FeatureExtract::matchCornerFromScan / matchSurfFromScan   feature_extract.hpp:131-376
 
@@ -682,7 +699,6 @@ Eigen::Quaterniond q_ori_cur, q_ori_prev;                     // :94
 float DISTANCE_KEYFRAMES = 1.0f, ORIENTATION_KEYFRAMES = 1.0f; // parameters.cpp:98-99
 PointICloud::Ptr pose_keyframes_3d(new PointICloud());        // :59
 std::vector<PointICovCloud::Ptr> surf_cloud_keyframes_cov, corner_cloud_keyframes_cov, outlier_cloud_keyframes_cov;   // :74-76
-namespace pcl { template <typename A, typename B> void copyPointCloud(const A &in, B &out) { out.points.assign(in.points.begin(), in.points.end()); out.width = in.width; out.height = in.height; } }
 #define printf(...) ((void)0)
 #include "../_ref/gen/save_keyframe.inc"
 #undef printf
@@ -708,6 +724,20 @@ public:
 
 // ---------------------------------------------------------------- C API for the tests
 extern "C" {
+// FeatureExtract::calTimestamp on a raw cloud (n x 3 floats) -> the relative times it writes into the intensity field
+int ref_cal_timestamp(const float *xyz, int n, float scan_period, float *rel_time)
+{
+    SCAN_PERIOD = scan_period;
+    FeatureExtract::PointCloud in;
+    in.points.resize(size_t(n));
+    for (int i = 0; i < n; ++i) { in.points[size_t(i)].x = xyz[3 * i]; in.points[size_t(i)].y = xyz[3 * i + 1]; in.points[size_t(i)].z = xyz[3 * i + 2]; }
+    PointICloud out;
+    FeatureExtract fe;
+    fe.calTimestamp(in, out);
+    for (int i = 0; i < n; ++i) rel_time[i] = out.points[size_t(i)].intensity;
+    return int(out.size());
+}
+
 // saveKeyframe over a sequence of mapper poses (n x 7: t, q): saved[i] = 1 where the reference saves frame i as a keyframe; from a clean state
 int ref_save_keyframes(const double *poses7, int n, float distance_keyframes, float orientation_keyframes, unsigned char *saved)
 {

@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes,timestamps").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -330,6 +330,37 @@ if "keyframes" in families:
                 raise SystemExit(f"KEYFRAMES trial {trial}: n {n}, step {step}, turn {turn}, thresholds {dist_kf} m / {ori_kf} deg: decisions differ at {np.flatnonzero(dec[:, 0].astype(np.uint8) != want)[:5]}")
             n_fr += n; n_kf += int(want.sum())
     print(f"keyframes: {trials} random trajectories ({n_fr} frames, {n_kf} keyframes): the facade's KeyframePolicy decides as saveKeyframe's own lines do  [{time.time() - t0:.0f} s]", flush=True)
+
+if "timestamps" in families:
+    # the facade's FeatureExtract::calTimestamp (tests/host/cal_timestamp_check.cpp drives it) against findStartEndAngle + calTimestamp's own lines
+    import subprocess, tempfile
+    t0 = time.time(); n_pts = 0
+    lib_dir = os.path.join(ROOT, "m-loam_amd", "lib")
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "cal_timestamp_check")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                        os.path.join(ROOT, "tests", "host", "cal_timestamp_check.cpp"), "-L", lib_dir, "-lmloam_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib",
+                        "-L/opt/rocm/lib"], check=True)
+        for trial in range(trials):
+            rings = int(rng.choice([16, 32]))
+            body = synth.gt_body_pose().copy(); body[:2] += rng.uniform(-3, 3, 2)
+            s_ = synth.simulate_scan(scn, body, synth.HERCULES_BODY_T_LASER[int(rng.integers(2))], rings, seed=int(rng.integers(1, 10 ** 6)), n_cols=int(rng.choice([300, 900, 1800])))
+            pts = s_.points[:, :3].copy()
+            start, direction = float(rng.uniform(-np.pi, np.pi)), float(rng.choice([1.0, -1.0]))
+            az = np.mod(direction * (np.arctan2(pts[:, 1], pts[:, 0]) - start), 2 * np.pi)
+            pts = np.ascontiguousarray(pts[np.argsort(az, kind="stable")], np.float32)
+            if rng.integers(4) == 0:
+                pts = pts[: max(2, int(len(pts) * rng.uniform(0.3, 0.95)))]           # a sweep cut short
+            period = float(rng.choice([0.1, 0.05]))
+            pts.tofile(os.path.join(td, "cloud.f32"))
+            subprocess.run([exe, td, repr(period)], check=True)
+            got = np.fromfile(os.path.join(td, "rel_time.f32"), np.float32)
+            want = O.ref_cal_timestamp(pts, np.float32(period))
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                raise SystemExit(f"TIMESTAMPS trial {trial}: {len(pts)} points, start {start:.3f}, direction {direction}, period {period}: {int(np.sum(got.view(np.uint32) != want.view(np.uint32)))} floats differ")
+            n_pts += len(pts)
+    print(f"timestamps: {trials} random sweeps ({n_pts} points): the facade's calTimestamp writes the floats calTimestamp's own lines write  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0

@@ -205,6 +205,39 @@ def test_facade_keyframe_policy_and_pose_chain(tmp_path, orc):
         assert np.array_equal(orc.ref_save_keyframes(poses, dist_kf, ori_kf), dec[:, 0].astype(np.uint8))
 
 
+def test_facade_cal_timestamp_is_the_references(tmp_path, orc, synth):
+    """The facade's FeatureExtract::calTimestamp (host code: the sweep's two-phase azimuth unwrapping, float variables against double constants) against
+    findStartEndAngle + calTimestamp compiled from the reference's own lines (oracle/_ref, feature_extract.cpp:54-114): the same float for every point of raw scans in
+    firing order, sweeps starting anywhere, clockwise and counter-clockwise."""
+    import subprocess
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "cal_timestamp_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "cal_timestamp_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(4)
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    s = synth.simulate_scan(scn, synth.gt_body_pose(), synth.HERCULES_BODY_T_LASER[0], 16, seed=3)
+    n_checked = 0
+    for start in (0.0, 1.0, 3.0, -2.5):
+        for direction in (1.0, -1.0):
+            pts = s.points[:, :3].copy()
+            az = np.mod(direction * (np.arctan2(pts[:, 1], pts[:, 0]) - start), 2 * np.pi)       # firing order: azimuth step by azimuth step from `start`, either way round
+            pts = np.ascontiguousarray(pts[np.argsort(az, kind="stable")], np.float32)
+            pts.tofile(tmp_path / "cloud.f32")
+            subprocess.run([exe, str(tmp_path), "0.1"], check=True)
+            got = np.fromfile(tmp_path / "rel_time.f32", np.float32)
+            want = orc.ref_cal_timestamp(pts, 0.1)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (start, direction, int(np.sum(got != want)))
+            n_checked += len(pts)
+    assert n_checked > 100000
+
+
 def test_every_entry_point_refuses_a_null_context(mla):
     """Every C-ABI function that takes a context must hand back an error (not crash, not touch the GPU) when the context is null and every other argument is
     zero / null -- the first thing a binding gets wrong. Run in a child process so that a crash names its function instead of taking the test run down."""

@@ -60,34 +60,40 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     assert len(rv) == 13 and rv[12] == 4, rv                 # four LiDARs were really served by four threads
     for i in range(4):
         assert rv[3 * i] == 1 and rv[3 * i + 1] == 1 and rv[3 * i + 2] > 10000, (i, rv)
-    # FeatureExtract::calTimestamp (feature_extract.cpp:73-113) of LiDAR 0 against a plain restatement of its unwrapping
+    # FeatureExtract::calTimestamp (feature_extract.cpp:54-114) of LiDAR 0 against a plain restatement of its unwrapping and against the reference's own lines
     st = np.fromfile(os.path.join(d, "out_timestamps.f32"), np.float32)
     assert len(st) == len(raw)
     f32 = np.float32
     ori_all = (-np.arctan2(raw[:, 1], raw[:, 0])).astype(np.float32)
-    start, end = ori_all[0], f32(ori_all[-1] + f32(2 * np.pi))
-    if end - start > f32(3 * np.pi):
-        end = f32(end - f32(2 * np.pi))
-    elif end - start < f32(np.pi):
-        end = f32(end + f32(2 * np.pi))
+    PI = float(np.pi)
+    # float variables against double constants, as the reference's expressions evaluate: sums and comparisons in double, results stored back into floats
+    start, end = ori_all[0], f32(float(ori_all[-1]) + 2 * PI)
+    if float(f32(end - start)) > 3 * PI:
+        end = f32(float(end) - 2 * PI)
+    elif float(f32(end - start)) < PI:
+        end = f32(float(end) + 2 * PI)
     exp = np.empty(len(raw), np.float32)
     half = False
     for i, o in enumerate(ori_all):
         if not half:
-            if o < start - f32(np.pi / 2):
-                o = f32(o + f32(2 * np.pi))
-            elif o > start + f32(np.pi * 3 / 2):
-                o = f32(o - f32(2 * np.pi))
-            if o - start > f32(np.pi):
+            if float(o) < float(start) - PI / 2:
+                o = f32(float(o) + 2 * PI)
+            elif float(o) > float(start) + PI * 3 / 2:
+                o = f32(float(o) - 2 * PI)
+            if float(f32(o - start)) > PI:
                 half = True
         else:
-            o = f32(o + f32(2 * np.pi))
-            if o < end - f32(np.pi * 3 / 2):
-                o = f32(o + f32(2 * np.pi))
-            elif o > end + f32(np.pi / 2):
-                o = f32(o - f32(2 * np.pi))
+            o = f32(float(o) + 2 * PI)
+            if float(o) < float(end) - PI * 3 / 2:
+                o = f32(float(o) + 2 * PI)
+            elif float(o) > float(end) + PI / 2:
+                o = f32(float(o) - 2 * PI)
         exp[i] = f32(f32(o - start) / f32(end - start)) * f32(0.1)
-    np.testing.assert_allclose(st, exp, rtol=0, atol=2e-6)      # libm atan2f vs numpy's: last-ulp differences of the angle only
+    # a sanity bound only: numpy's arctan2 differs from libm's atan2f in the last ulp here and there, and a point (or the sweep's end angle) within an ulp of one of
+    # the unwrapping thresholds then takes the other branch -- on this cloud twelve points of one azimuth do. The pin is the reference's own lines, below.
+    assert np.mean(np.abs(st - exp) > 2e-6) < 2e-3
+    if orc.ref_lib() is not None:                                # ... the reference's own lines are the pin: the same float for every point
+        assert np.array_equal(st.view(np.uint32), orc.ref_cal_timestamp(raw[:, :3], 0.1).view(np.uint32))
     # ---- round 4: PipelinedMapper (the overlap's precondition as code): every pose equals the one-frame-at-a-time loop's -- including the frame whose keyframe
     #      prediction was wrong and that was therefore solved again on the rebuilt map -- and all three paths were taken
     pm = np.fromfile(os.path.join(d, "out_pipelined_mapper.f64"), np.float64)
