@@ -238,6 +238,47 @@ def test_facade_cal_timestamp_is_the_references(tmp_path, orc, synth):
     assert n_checked > 100000
 
 
+def test_facade_map_factors_are_the_references(tmp_path, orc):
+    """The facade's per-factor host classes (LidarMapPlaneNormFactor / LidarMapEdgeFactor: what a caller that keeps the reference's AddResidualBlock loop constructs,
+    lidar_mapper_keyframe.cpp:537-571) against the reference's own lines (oracle/_ref, lidar_map_factor.hpp:28-174): residual and 1 x 7 Jacobian on 2 000 random
+    factors, the weight rule of the constructors included."""
+    import subprocess
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "map_factor_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "map_factor_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(31)
+    n = 2000
+    rows = np.zeros((n, 26))
+    for i in range(n):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pose = np.concatenate([rng.uniform(-30, 30, 3), q])
+        sd = rng.uniform(0.01, 0.6, 3)
+        cov = np.diag(sd ** 2); cov[0, 1] = cov[1, 0] = 0.1 * sd[0] * sd[1]
+        kind = i % 2
+        if kind == 0:
+            nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+            coeff = np.concatenate([nrm, [rng.uniform(-5, 5)], [0, 0]])
+        else:
+            c = rng.uniform(-40, 40, 3); v = rng.normal(size=3); v /= np.linalg.norm(v)
+            coeff = np.concatenate([c + 0.1 * v, c - 0.1 * v])
+        rows[i] = np.concatenate([[kind], rng.uniform(-40, 40, 3), coeff, cov.ravel(), pose])
+    rows.tofile(tmp_path / "factors.f64")
+    subprocess.run([exe, str(tmp_path)], check=True)
+    out = np.fromfile(tmp_path / "factors_out.f64").reshape(n, 8)
+    for i in range(n):
+        kind = "s" if rows[i, 0] == 0 else "c"
+        r_ref, J_ref = orc.ref_map_factor(kind, rows[i, 1:4], rows[i, 4:10][: 4 if kind == "s" else 6], rows[i, 10:19].reshape(3, 3), rows[i, 19:26])
+        assert abs(out[i, 0] - r_ref) <= 1e-12 * max(1.0, abs(r_ref)), (i, kind)
+        np.testing.assert_allclose(out[i, 1:], J_ref, rtol=1e-11, atol=1e-11)
+
+
 def test_every_entry_point_refuses_a_null_context(mla):
     """Every C-ABI function that takes a context must hand back an error (not crash, not touch the GPU) when the context is null and every other argument is
     zero / null -- the first thing a binding gets wrong. Run in a child process so that a crash names its function instead of taking the test run down."""
