@@ -734,12 +734,17 @@ inline double logDet6(const double M[36])
     return 2.0 * ld;
 }
 
-// the every-10th-frame policy of scan2MapOptimization (lidar_mapper_keyframe.cpp:456-494): returns gf_ratio_cur
-inline double gfRatioPolicy(const std::string &gf_method, double gf_ratio_ini, double gf_deg_factor, double MAP_DEG_THRE)
+// the every-10th-frame policy of scan2MapOptimization (lidar_mapper_keyframe.cpp:456-494): returns the new gf_ratio_cur. gf_ratio_cur (in): the value so far -- it
+// stays when no branch of the reference's chain is taken (a method name it does not know; gd_float with a NaN factor: neither `>` nor `<=` holds)
+inline double gfRatioPolicy(const std::string &gf_method, double gf_ratio_ini, double gf_deg_factor, double MAP_DEG_THRE, double gf_ratio_cur = 1.0)
 {
     if (gf_method == "wo_gf") return 1.0;
-    if (gf_method == "gd_float") return gf_deg_factor > MAP_DEG_THRE ? gf_ratio_ini : 0.8;
-    return gf_ratio_ini;   // rnd, fps, gd_fix
+    if (gf_method == "rnd" || gf_method == "fps" || gf_method == "gd_fix") return gf_ratio_ini;
+    if (gf_method == "gd_float") {
+        if (gf_deg_factor > MAP_DEG_THRE) return gf_ratio_ini;
+        if (gf_deg_factor <= MAP_DEG_THRE) return 0.8;
+    }
+    return gf_ratio_cur;
 }
 
 // ------------------------------------------------------------------ ImageSegmenter (estimator/src/imageSegmenter/image_segmenter.hpp:36-83)
