@@ -14,10 +14,10 @@ from scipy.spatial.transform import Rotation as Rot
 mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select,odom_select").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select,odom_select,uct").split(",")
 rng = np.random.default_rng(seed)
 O.build()
-ctx = mla.Context(0)
+ctx = None if os.environ.get("SOAK_DRY") else mla.Context(0)
 ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
 t_all = time.time()
 
@@ -181,5 +181,37 @@ if "odom_select" in families:
             raise SystemExit(f"ODOM SELECT trial {trial}: scene {sseed}, kind {ch}, {len(f)} features, ratio {ratio}, seed {gseed}: {len(got)} vs {len(ref['sel'])} picks")
         n_sel += len(got)
     print(f"odom_select: {trials} random selections ({n_sel} picks): Estimator::goodFeatureMatching on the device path == the oracle's, pick for pick  [{time.time() - t0:.0f} s]", flush=True)
-ctx.close()
+if "uct" in families:
+    t0 = time.time(); n_pts = 0
+    for trial in range(trials):
+        n = int(rng.integers(10, 8000))
+        kf = np.zeros((n, 11), np.float32)
+        kf[:, :3] = rng.uniform(-50, 50, (n, 3)); kf[:, 2] *= 0.1
+        kf[:, 3] = rng.integers(0, 2, n)
+        q = rng.normal(size=4) * [0.05, 0.05, 0.5, 1.0]; q /= np.linalg.norm(q)
+        pose_global = np.concatenate([rng.uniform(-5, 5, 3), q])
+        A = rng.normal(size=(6, 6)) * float(rng.choice([1e-4, 1e-3, 1e-2]))
+        cov_global = A @ A.T + np.eye(6) * 1e-6
+        q2 = rng.normal(size=4) * [0.02, 0.02, 0.1, 1.0]; q2 /= np.linalg.norm(q2)
+        ext = np.array([[0, 0, 0, 0, 0, 0, 1.0], np.concatenate([rng.uniform(-0.5, 0.5, 3), q2])])
+        ext_cov = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3) * float(rng.choice([1.0, 10.0]))])
+        cov_meas = np.diag([0.0025] * 3)
+        with_ua = bool(rng.integers(3) > 0)
+        ref_all = O.cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, True, 1e30)
+        tr = np.sort(ref_all[:, 10].astype(np.float64))
+        # a gate that no trace sits on: the middle of the widest relative gap among the sorted traces' central half (a trace within rounding of the gate may fall either way)
+        lo, hi = len(tr) // 4, max(len(tr) // 4 + 1, 3 * len(tr) // 4)
+        gaps = (tr[lo + 1:hi + 1] - tr[lo:hi]) / np.maximum(tr[lo:hi], 1e-30) if hi > lo and hi < len(tr) else np.array([])
+        thr = float(0.5 * (tr[lo + int(np.argmax(gaps))] + tr[lo + int(np.argmax(gaps)) + 1])) if len(gaps) and gaps.max() > 1e-4 else 1e30
+        got = (O if os.environ.get("SOAK_DRY") else ctx).cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        ref = O.cloud_uct_associate_to_map(kf, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, thr)
+        what = f"uct trial {trial}: n {n}, with_ua {with_ua}, gate {thr:.3e}"
+        if got.shape != ref.shape or not np.array_equal(got[:, :4].view(np.uint32), ref[:, :4].view(np.uint32)):
+            raise SystemExit(f"UCT survivors / coordinates {what}: {got.shape} vs {ref.shape}")
+        if len(ref) and float(np.abs(got[:, 4:] - ref[:, 4:]).max()) > 2e-5 * max(1e-12, float(np.abs(ref[:, 4:]).max())) + 1e-9:
+            raise SystemExit(f"UCT covariances {what}")
+        n_pts += n
+    print(f"uct: {trials} random keyframe clouds ({n_pts} points): cloudUCTAssociateToMap on the device: survivors, order and f32 coordinates equal to the oracle's, covariances 2e-5  [{time.time() - t0:.0f} s]", flush=True)
+if ctx is not None:
+    ctx.close()
 print(f"front-end parity soak: seed {seed}, {trials} trials per family, families {families}: all equal  [{time.time() - t_all:.0f} s]")
