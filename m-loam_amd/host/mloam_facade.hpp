@@ -885,6 +885,132 @@ private:
     double sqrt_info_;
 };
 
+// ------------------------------------------------------------------ the odometry window's and the calibration's per-factor classes
+// For callers that keep Estimator::optimizeMap's AddResidualBlock loops as they are (estimator.cpp:733-813): LidarPureOdom{PlaneNorm,Edge}Factor
+// (lidar_pure_odom_factor.hpp:27-102, 198-282; ceres::SizedCostFunction<1, 7, 7, 7> over [pivot, frame, extrinsic]) and LidarOnlineCalib{PlaneNorm,Edge}Factor
+// (lidar_online_calib_factor.hpp:24-62, 125-165; <1, 7> over the extrinsic, the weight handed in). Host code, one factor per call, the arithmetic of the batched
+// device kernel (csrc/odom.hip: odom_factor_core) term by term -- including the two Jacobian columns of the reference that are not exact derivatives.
+namespace detail {
+inline void qmul4(const double a[4], const double b[4], double o[4])      // [x y z w]
+{
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+inline void matv(const double M[9], const double v[3], double o[3]) { for (int r = 0; r < 3; ++r) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2]; }
+inline void tmatv(const double M[9], const double v[3], double o[3]) { for (int c = 0; c < 3; ++c) o[c] = M[c] * v[0] + M[3 + c] * v[1] + M[6 + c] * v[2]; }
+inline void rowm(const double a[3], const double M[9], double o[3]) { for (int c = 0; c < 3; ++c) o[c] = a[0] * M[c] + a[1] * M[3 + c] + a[2] * M[6 + c]; }
+// type 0: plane (coeff = n, d), 1: edge (coeff = the two line points); J: three 1 x 7 rows [pivot | frame | extrinsic], any may be null
+inline void pure_odom_factor(int type, const double p[3], const double *coeff, double s, const double *pp, const double *pi, const double *pe, double &r_out,
+                             double *J0, double *J1, double *J2)
+{
+    const double Qpc[4] = {-pp[3], -pp[4], -pp[5], pp[6]};
+    double Qpi[4], Qx[4], tpi[3], rte[3], rp[3];
+    qmul4(Qpc, pi + 3, Qpi);
+    const double dt[3] = {pi[0] - pp[0], pi[1] - pp[1], pi[2] - pp[2]};
+    quat_rot(Qpc, dt, tpi);
+    qmul4(Qpi, pe + 3, Qx);
+    quat_rot(Qpi, pe, rte);
+    quat_rot(Qx, p, rp);
+    const double lp[3] = {rp[0] + (rte[0] + tpi[0]), rp[1] + (rte[1] + tpi[1]), rp[2] + (rte[2] + tpi[2])};
+    double Rp[9], Ri[9], Re[9], Rep[3], Rite[3], RiRep[3];
+    quat_to_rot(pp + 3, Rp); quat_to_rot(pi + 3, Ri); quat_to_rot(pe + 3, Re);
+    matv(Re, p, Rep); matv(Ri, pe, Rite); matv(Ri, Rep, RiRep);
+    const double v[3] = {RiRep[0] + Rite[0] + pi[0] - pp[0], RiRep[1] + Rite[1] + pi[1] - pp[1], RiRep[2] + Rite[2] + pi[2] - pp[2]};
+    double a[3], res, dab[3] = {0, 0, 0};
+    if (type == 0) {
+        a[0] = coeff[0]; a[1] = coeff[1]; a[2] = coeff[2];
+        res = (a[0] * lp[0] + a[1] * lp[1] + a[2] * lp[2]) + coeff[3];
+    } else {
+        const double ba[3] = {lp[0] - coeff[0], lp[1] - coeff[1], lp[2] - coeff[2]}, bb[3] = {lp[0] - coeff[3], lp[1] - coeff[4], lp[2] - coeff[5]};
+        const double nu[3] = {ba[1] * bb[2] - ba[2] * bb[1], ba[2] * bb[0] - ba[0] * bb[2], ba[0] * bb[1] - ba[1] * bb[0]};
+        const double de[3] = {coeff[0] - coeff[3], coeff[1] - coeff[4], coeff[2] - coeff[5]};
+        const double n2 = nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2];
+        const double nu_n = std::sqrt(n2), de_n = std::sqrt(de[0] * de[0] + de[1] * de[1] + de[2] * de[2]);
+        res = nu_n / de_n;
+        double nh[3] = {nu[0], nu[1], nu[2]};
+        if (n2 > 0.0) { const double nn = std::sqrt(n2); nh[0] = nu[0] / nn; nh[1] = nu[1] / nn; nh[2] = nu[2] / nn; }      // Eigen normalized(): zero stays zero
+        const double k = 1.0 / de_n;
+        const double eta[3] = {k * nh[0], k * nh[1], k * nh[2]};
+        dab[0] = ba[0] - bb[0]; dab[1] = ba[1] - bb[1]; dab[2] = ba[2] - bb[2];
+        row_skew(eta, dab, a);
+    }
+    r_out = s * res;
+    double row0[3], row1[3], rot[3], t1[3], t2[3], tmp[3];
+    matv(Rp, a, row0);                                                                     // a^T Rp^T
+    if (J0) {
+        if (type == 0) row_skew(row0, v, rot);
+        else { tmatv(Rp, v, tmp); row_skew(a, tmp, rot); }
+        for (int c = 0; c < 3; ++c) { J0[c] = s * (-row0[c]); J0[3 + c] = s * rot[c]; }
+        J0[6] = 0.0;
+    }
+    rowm(row0, Ri, row1);
+    if (J1) {
+        const double q[3] = {Rep[0] + pe[0], Rep[1] + pe[1], Rep[2] + pe[2]};
+        row_skew(row1, q, rot);
+        for (int c = 0; c < 3; ++c) { J1[c] = s * row0[c]; J1[3 + c] = s * (-rot[c]); }
+        J1[6] = 0.0;
+    }
+    if (J2) {
+        if (type == 0) row_skew(row1, Rep, rot);
+        else { rowm(row1, Re, tmp); row_skew(tmp, p, t1); row_skew(row1, pe, t2); rot[0] = t1[0] + t2[0]; rot[1] = t1[1] + t2[1]; rot[2] = t1[2] + t2[2]; }
+        for (int c = 0; c < 3; ++c) { J2[c] = s * row1[c]; J2[3 + c] = s * (-rot[c]); }
+        J2[6] = 0.0;
+    }
+}
+}  // namespace detail
+
+template <int TYPE>
+class LidarPureOdomFactorT {          // : public ceres::SizedCostFunction<1, 7, 7, 7> inside the reference tree
+public:
+    LidarPureOdomFactorT(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &s = 1.0) : point_(point), coeff_(coeff), s_(s) {}
+    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    {
+        detail::pure_odom_factor(TYPE, point_.data(), coeff_.data(), s_, param[0], param[1], param[2], residuals[0], jacobians ? jacobians[0] : nullptr,
+                                 jacobians ? jacobians[1] : nullptr, jacobians ? jacobians[2] : nullptr);
+        return true;
+    }
+private:
+    const std::array<double, 3> point_;
+    const std::vector<double> coeff_;
+    const double s_;
+};
+typedef LidarPureOdomFactorT<0> LidarPureOdomPlaneNormFactor;      // lidar_pure_odom_factor.hpp:27-102
+typedef LidarPureOdomFactorT<1> LidarPureOdomEdgeFactor;           // lidar_pure_odom_factor.hpp:198-282
+
+// the map factors' form on the extrinsic alone, the weight handed in (1.0 at estimator.cpp:757, 813): residual = sqrt_info * (the map factor's unweighted residual)
+class LidarOnlineCalibPlaneNormFactor {      // : public ceres::SizedCostFunction<1, 7>     lidar_online_calib_factor.hpp:24-62
+public:
+    LidarOnlineCalibPlaneNormFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &sqrt_info = 1.0)
+        : unit_(point, coeff, {0.001, 0, 0, 0, 0.001, 0, 0, 0, 0.001}), s_(sqrt_info) {}      // trace 0.003 -> sqrt(1 / trace) = 18 >= 3 -> the map factor's weight is exactly 1
+    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    {
+        unit_.Evaluate(param, residuals, jacobians);
+        residuals[0] *= s_;
+        if (jacobians && jacobians[0]) for (int c = 0; c < 6; ++c) jacobians[0][c] *= s_;
+        return true;
+    }
+private:
+    LidarMapPlaneNormFactor unit_;
+    double s_;
+};
+class LidarOnlineCalibEdgeFactor {           // : public ceres::SizedCostFunction<1, 7>     lidar_online_calib_factor.hpp:125-165
+public:
+    LidarOnlineCalibEdgeFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &sqrt_info = 1.0)
+        : unit_(point, coeff, {0.001, 0, 0, 0, 0.001, 0, 0, 0, 0.001}), s_(sqrt_info) {}
+    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    {
+        unit_.Evaluate(param, residuals, jacobians);
+        residuals[0] *= s_;
+        if (jacobians && jacobians[0]) for (int c = 0; c < 6; ++c) jacobians[0][c] *= s_;
+        return true;
+    }
+private:
+    LidarMapEdgeFactor unit_;
+    double s_;
+};
+
 // ------------------------------------------------------------------ ActiveFeatureSelection (lidar_mapper.h:126-631)
 // evalFullHessian / goodFeatureMatching with the reference's argument lists. The kd-tree argument is the MapIndex the caller built with
 // setInputCloud(laser_map); laser_cloud is the feature cloud (PointIWithCov: the cov_vec weights the rows when WITH_UA is on).

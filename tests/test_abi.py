@@ -279,6 +279,52 @@ def test_facade_map_factors_are_the_references(tmp_path, orc):
         np.testing.assert_allclose(out[i, 1:], J_ref, rtol=1e-11, atol=1e-11)
 
 
+def test_facade_odometry_factors_are_the_references(tmp_path, orc):
+    """The facade's per-factor host classes of the odometry window and the calibration (LidarPureOdom{PlaneNorm,Edge}Factor over [pivot, frame, extrinsic],
+    LidarOnlineCalib{PlaneNorm,Edge}Factor over the extrinsic: what a caller that keeps Estimator::optimizeMap's AddResidualBlock loops constructs, estimator.cpp:733-813)
+    against the reference's own lines (oracle/_ref): residuals and every Jacobian row on 1 500 random factors -- the two columns of the reference that are not exact
+    derivatives included."""
+    import subprocess
+    if orc.ref_lib() is None:
+        pytest.skip("no reference build")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "odom_factor_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "odom_factor_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(37)
+
+    def rand_pose(scale):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        return np.concatenate([rng.uniform(-scale, scale, 3), q])
+    n = 1500
+    rows = np.zeros((n, 32))
+    for i in range(n):
+        kind = i % 2
+        if kind == 0:
+            nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+            coeff = np.concatenate([nrm, [rng.uniform(-5, 5)], [0, 0]])
+        else:
+            c = rng.uniform(-40, 40, 3); v = rng.normal(size=3); v /= np.linalg.norm(v)
+            coeff = np.concatenate([c + 0.1 * v, c - 0.1 * v])
+        rows[i] = np.concatenate([[kind], rng.uniform(-40, 40, 3), coeff, [rng.uniform(0.3, 1.0)], rand_pose(20.0), rand_pose(20.0), rand_pose(1.0)])
+    rows.tofile(tmp_path / "ofactors.f64")
+    subprocess.run([exe, str(tmp_path)], check=True)
+    out = np.fromfile(tmp_path / "ofactors_out.f64").reshape(n, 30)
+    for i in range(n):
+        kind = "s" if rows[i, 0] == 0 else "c"
+        coeff = rows[i, 4:10][: 4 if kind == "s" else 6]
+        r_ref, J_ref = orc.ref_pure_odom(kind, rows[i, 1:4], coeff, rows[i, 10], rows[i, 11:18], rows[i, 18:25], rows[i, 25:32])
+        assert abs(out[i, 0] - r_ref) <= 1e-11 * max(1.0, abs(r_ref)), (i, kind)
+        np.testing.assert_allclose(out[i, 1:22].reshape(3, 7), J_ref, rtol=1e-10, atol=1e-10)
+        rc, Jc = orc.ref_online_calib(kind, rows[i, 1:4], coeff, rows[i, 10], rows[i, 25:32])
+        assert abs(out[i, 22] - rc) <= 1e-12 * max(1.0, abs(rc)), (i, kind)
+        np.testing.assert_allclose(out[i, 23:30], Jc, rtol=1e-11, atol=1e-11)
+
+
 def test_every_entry_point_refuses_a_null_context(mla):
     """Every C-ABI function that takes a context must hand back an error (not crash, not touch the GPU) when the context is null and every other argument is
     zero / null -- the first thing a binding gets wrong. Run in a child process so that a crash names its function instead of taking the test run down."""
