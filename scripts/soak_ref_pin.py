@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes,timestamps").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes,timestamps,factors").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -361,6 +361,54 @@ if "timestamps" in families:
                 raise SystemExit(f"TIMESTAMPS trial {trial}: {len(pts)} points, start {start:.3f}, direction {direction}, period {period}: {int(np.sum(got.view(np.uint32) != want.view(np.uint32)))} floats differ")
             n_pts += len(pts)
     print(f"timestamps: {trials} random sweeps ({n_pts} points): the facade's calTimestamp writes the floats calTimestamp's own lines write  [{time.time() - t0:.0f} s]", flush=True)
+
+if "factors" in families:
+    # the facade's per-factor host classes (map, odometry window, calibration) against the reference's own lines, on many random factors
+    import subprocess, tempfile
+    t0 = time.time(); n_f = 0
+    lib_dir = os.path.join(ROOT, "m-loam_amd", "lib")
+    def rand_pose(scale):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        return np.concatenate([rng.uniform(-scale, scale, 3), q])
+    with tempfile.TemporaryDirectory() as td:
+        exes = {}
+        for nm in ("map_factor_check", "odom_factor_check"):
+            exes[nm] = os.path.join(td, nm)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exes[nm],
+                            os.path.join(ROOT, "tests", "host", nm + ".cpp"), "-L", lib_dir, "-lmloam_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib",
+                            "-L/opt/rocm/lib"], check=True)
+        n = trials * 10
+        rows_m, rows_o = np.zeros((n, 26)), np.zeros((n, 32))
+        for i in range(n):
+            kind = i % 2
+            if kind == 0:
+                nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+                coeff = np.concatenate([nrm, [rng.uniform(-5, 5)], [0, 0]])
+            else:
+                c = rng.uniform(-40, 40, 3); v = rng.normal(size=3); v /= np.linalg.norm(v)
+                coeff = np.concatenate([c + 0.1 * v, c - 0.1 * v])
+            sd = rng.uniform(0.01, 0.6, 3)
+            cov = np.diag(sd ** 2); cov[0, 1] = cov[1, 0] = 0.1 * sd[0] * sd[1]
+            pt = rng.uniform(-40, 40, 3)
+            rows_m[i] = np.concatenate([[kind], pt, coeff, cov.ravel(), rand_pose(30.0)])
+            rows_o[i] = np.concatenate([[kind], pt, coeff, [rng.uniform(0.3, 1.0)], rand_pose(20.0), rand_pose(20.0), rand_pose(1.0)])
+        rows_m.tofile(os.path.join(td, "factors.f64")); rows_o.tofile(os.path.join(td, "ofactors.f64"))
+        subprocess.run([exes["map_factor_check"], td], check=True); subprocess.run([exes["odom_factor_check"], td], check=True)
+        om = np.fromfile(os.path.join(td, "factors_out.f64")).reshape(n, 8); oo = np.fromfile(os.path.join(td, "ofactors_out.f64")).reshape(n, 30)
+        for i in range(n):
+            kind = "s" if rows_m[i, 0] == 0 else "c"
+            k = 4 if kind == "s" else 6
+            r_ref, J_ref = O.ref_map_factor(kind, rows_m[i, 1:4], rows_m[i, 4:4 + k], rows_m[i, 10:19].reshape(3, 3), rows_m[i, 19:26])
+            if abs(om[i, 0] - r_ref) > 1e-12 * max(1.0, abs(r_ref)) or float(np.abs(om[i, 1:] - J_ref).max()) > 1e-11 * max(1.0, float(np.abs(J_ref).max())):
+                raise SystemExit(f"FACTORS map factor {i} ({kind})")
+            r_ref, J_ref = O.ref_pure_odom(kind, rows_o[i, 1:4], rows_o[i, 4:4 + k], rows_o[i, 10], rows_o[i, 11:18], rows_o[i, 18:25], rows_o[i, 25:32])
+            if abs(oo[i, 0] - r_ref) > 1e-11 * max(1.0, abs(r_ref)) or float(np.abs(oo[i, 1:22].reshape(3, 7) - J_ref).max()) > 1e-10 * max(1.0, float(np.abs(J_ref).max())):
+                raise SystemExit(f"FACTORS odometry factor {i} ({kind})")
+            rc, Jc = O.ref_online_calib(kind, rows_o[i, 1:4], rows_o[i, 4:4 + k], rows_o[i, 10], rows_o[i, 25:32])
+            if abs(oo[i, 22] - rc) > 1e-12 * max(1.0, abs(rc)) or float(np.abs(oo[i, 23:30] - Jc).max()) > 1e-11 * max(1.0, float(np.abs(Jc).max())):
+                raise SystemExit(f"FACTORS calibration factor {i} ({kind})")
+            n_f += 3
+    print(f"factors: {n_f} random factors (map, odometry window, calibration; plane and edge): the facade's per-factor host classes == the reference's own lines (residuals 1e-12 / 1e-11, Jacobians 1e-11 / 1e-10)  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0
