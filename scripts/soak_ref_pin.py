@@ -18,7 +18,7 @@ synth = importlib.import_module("m-loam_amd.synth")
 warnings.simplefilter("ignore")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes,timestamps,factors").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "extract,match,segment,voxel,scan2map,track,select,uct,degeneracy,downsample,window,odom_select,keyframes,timestamps,factors,host_helpers").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 if O.ref_lib() is None:
@@ -409,6 +409,35 @@ if "factors" in families:
                 raise SystemExit(f"FACTORS calibration factor {i} ({kind})")
             n_f += 3
     print(f"factors: {n_f} random factors (map, odometry window, calibration; plane and edge): the facade's per-factor host classes == the reference's own lines (residuals 1e-12 / 1e-11, Jacobians 1e-11 / 1e-10)  [{time.time() - t0:.0f} s]", flush=True)
+
+if "host_helpers" in families:
+    # the PRODUCT's host-only entry points (no GPU needed: mlh_pose_plus, mlh_eval_degeneracy, mlh_compound_pose_with_cov) against the reference's own lines
+    mla = importlib.import_module("m-loam_amd")
+    t0 = time.time(); n_h = 0
+    for trial in range(trials * 20):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        x = np.concatenate([rng.uniform(-50, 50, 3), q])
+        d = rng.normal(0, float(rng.choice([1e-4, 0.05, 0.5])), 6)
+        V = None
+        if rng.integers(2):
+            Q, _ = np.linalg.qr(rng.normal(size=(6, 6))); k = int(rng.integers(0, 5)); V = Q[:, k:] @ Q[:, k:].T
+        if float(np.abs(mla.pose_plus(x, d, V) - O.ref_pose_plus(x, d, V)).max()) > 1e-15:
+            raise SystemExit(f"HOST pose_plus trial {trial}")
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6))); k = int(rng.integers(0, 7))
+        ev = np.concatenate([rng.uniform(1e-3, 99.0, k), rng.uniform(101.0, 1e5, 6 - k)])
+        H = (Q * ev) @ Q.T; H = 0.5 * (H + H.T)
+        a, b = mla.eval_degeneracy(H, 100.0), O.ref_eval_degeneracy(H, 100.0)
+        if a["is_degenerate"] != b["is_degenerate"] or (k > 0 and float(np.abs(a["V_update"] - b["V_update"]).max()) > 1e-9):
+            raise SystemExit(f"HOST eval_degeneracy trial {trial}: {k} under the threshold")
+        q1 = rng.normal(size=4); q1 /= np.linalg.norm(q1); q2 = rng.normal(size=4) * [0.05, 0.05, 0.2, 1.0]; q2 /= np.linalg.norm(q2)
+        p1, p2 = np.concatenate([rng.uniform(-20, 20, 3), q1]), np.concatenate([rng.uniform(-1, 1, 3), q2])
+        A1, A2 = rng.normal(size=(6, 6)) * 1e-2, rng.normal(size=(6, 6)) * 1e-2
+        c1, c2 = A1 @ A1.T, A2 @ A2.T
+        (pa, ca), (pb, cb) = mla.compound_pose_with_cov(p1, c1, p2, c2), O.ref_compound_pose_with_cov(p1, c1, p2, c2)
+        if float(np.abs(pa - pb).max()) > 1e-12 or float(np.abs(ca - cb).max()) > 1e-12 * max(1.0, float(np.abs(cb).max())):
+            raise SystemExit(f"HOST compound_pose_with_cov trial {trial}")
+        n_h += 3
+    print(f"host_helpers: {n_h} random calls of the product's host-only entry points (mlh_pose_plus, mlh_eval_degeneracy, mlh_compound_pose_with_cov) == the reference's own lines  [{time.time() - t0:.0f} s]", flush=True)
 
 if "uct" in families:
     t0 = time.time(); n_pts = 0
