@@ -39,7 +39,8 @@ enum {
     MLH_ERR_HIP = -2,         /* a HIP runtime call failed */
     MLH_ERR_STATE = -3,       /* call order violated (e.g. match before map_set) */
     MLH_ERR_NOMEM = -4,
-    MLH_ERR_UNSUPPORTED = -5
+    MLH_ERR_UNSUPPORTED = -5,
+    MLH_ERR_INCOMPLETE = -6   /* mlh_scan2map_end with status_out == NULL on a frame whose pose_out is NOT a result (status 1 / 3 below) */
 };
 
 /* flags for mlh_match_linearize / solver options */
@@ -509,7 +510,11 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
  *   2  a loop needed more LM iterations than were enqueued; nothing had been restaged and no younger solve was chained behind, so the frame was solved again
  *      synchronously from its start pose inside this call: pose_out is mlh_scan2map's;
  *   1  the same, but the inputs of the frame are no longer staged (or a younger solve continues from this one's unfinished pose): pose_out is the frame's START
- *      pose; the caller solves the frame with mlh_scan2map on its inputs and resubmits what was chained behind it. */
+ *      pose; the caller solves the frame with mlh_scan2map on its inputs and resubmits what was chained behind it;
+ *   3  this frame was chained behind a frame that ended with status 1 (or 3): it began from that frame's unfinished pose, so pose_out -- whatever its own loops
+ *      did -- is not the mapper's; resubmit it after the predecessor has been solved.
+ * With status_out == NULL the statuses 1 and 3 are returned as MLH_ERR_INCOMPLETE (pose_out is still filled in): a pose that is not a result never comes back
+ * under a success code the caller cannot tell apart. */
 int mlh_scan2map_begin(mlh_ctx *ctx, const double pose_in[7], const mlh_solver_opts *opts, int lm_lookahead);
 int mlh_scan2map_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], const mlh_solver_opts *opts, int lm_lookahead);
 int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out);

@@ -170,6 +170,9 @@ __global__ void publish_kernel(const SolverState *S, HostPublish *h, unsigned lo
 static int upload_pose(mlh_ctx *ctx, const double pose[7])
 {
     static_assert(sizeof(SolverState) % sizeof(double) == 0, "SolverState is cleared in doubles");
+    // a solve submitted with mlh_gn_solve_begin* may have left its last iteration as tile records and its pose in SolverState::xi[slot]: this launch zeroes the whole
+    // state, so that solve has to be completed (and published to ITS host record) before, not by the match launch that follows
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
     PoseArg a;
     for (int i = 0; i < 7; ++i) a.p[i] = pose[i];
     hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), a);
@@ -1639,7 +1642,11 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     const unsigned long long seq = ctx->solve_seq + 1;
     HostPublish *rec = static_cast<HostPublish *>(ctx->h_solve) + (seq & 1);
     mlh_ctx::SolveSlot &slot = ctx->solve_slot[seq & 1];
-    slot.kind = 1; slot.chained = pose_in == nullptr; slot.opts = *opts; slot.epoch = ctx->stage_epoch;
+    // everything that can refuse the frame is checked BEFORE the chain launch below rewrites the device pose: a refused mlh_scan2map_begin_chained leaves the
+    // state as it found it, so the caller's retry does not apply transformUpdate / transformAssociateToMap twice
+    const bool have_maps = ctx->map[MLH_SURF].built && ctx->map[MLH_CORNER].built && ctx->map[MLH_SURF].n > 50 && ctx->map[MLH_CORNER].n > 10;
+    if (have_maps && (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0)) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
+    slot.kind = 1; slot.chained = pose_in == nullptr; slot.opts = *opts; slot.epoch = ctx->stage_epoch; slot.tainted = false;
     if (pose_in) for (int i = 0; i < 7; ++i) slot.start[i] = pose_in[i];
     if (!pose_in) {
         PoseArg pa, pb;
@@ -1648,7 +1655,7 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         MLH_HIP(ctx, hipGetLastError());
     }
     // scan2MapOptimization runs only when the map has > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429): otherwise the start pose is the result
-    if (!(ctx->map[MLH_SURF].built && ctx->map[MLH_CORNER].built && ctx->map[MLH_SURF].n > 50 && ctx->map[MLH_CORNER].n > 10)) {
+    if (!have_maps) {
         slot.kind = 2;
         if (!pose_in) {          // chained: the start pose exists on the device only
             hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), rec, seq);
@@ -1657,7 +1664,6 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         ctx->solve_seq = seq; ctx->solve_pending = true;
         return MLH_OK;
     }
-    if (ctx->feat[0].m <= 0 || ctx->feat[1].m <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");
     const int budget = std::max(1, std::min(lm_lookahead > 0 ? lm_lookahead : ctx->lm_lookahead_auto, opts->max_lm_iterations));
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         MatchArgs a = args_from_opts(opts, 3, 0);
@@ -1720,6 +1726,13 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
     }
     if (slot.kind == 2 || ((hp.done & 1) && !(hp.done & 2))) {
         for (int i = 0; i < 7; ++i) pose_out[i] = hp.x[i];
+        if (slot.tainted) {
+            // this frame was chained behind one whose LM loop outgrew its look-ahead: it began from that frame's UNFINISHED pose. Its own loops terminated, but the
+            // result is not the mapper's; a solve chained behind THIS one inherits the mark.
+            if (ctx->solve_pending && ctx->solve_slot[(seq + 1) & 1].chained) ctx->solve_slot[(seq + 1) & 1].tainted = true;
+            if (status_out) { *status_out = 3; return MLH_OK; }
+            return fail(ctx, MLH_ERR_INCOMPLETE, "mlh_scan2map_end: the frame was chained behind one that did not finish inside its look-ahead (status 3) and status_out is NULL");
+        }
         return MLH_OK;
     }
     // the look-ahead was too short for this frame
@@ -1732,8 +1745,11 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
         return mlh_scan2map(ctx, pose_out, &slot.opts, nullptr);
     }
     for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
-    if (status_out) *status_out = 1;
-    return MLH_OK;
+    // a younger solve chained behind this frame started from its unfinished pose: marked, and reported at ITS end (status 3)
+    if (ctx->solve_pending && ctx->solve_slot[(seq + 1) & 1].chained) ctx->solve_slot[(seq + 1) & 1].tainted = true;
+    if (status_out) { *status_out = slot.tainted ? 3 : 1; return MLH_OK; }
+    // the pose handed back is NOT a result, and this caller has no way to see that: a distinct return code instead of success
+    return fail(ctx, MLH_ERR_INCOMPLETE, "mlh_scan2map_end: the frame did not finish inside its look-ahead and cannot be solved again here (status 1); status_out is NULL");
 }
 
 // ---------------------------------------------------------------- scan-to-scan odometry (LidarTracker)

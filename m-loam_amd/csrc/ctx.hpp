@@ -281,6 +281,7 @@ struct mlh_ctx {
         double start[7] = {0, 0, 0, 0, 0, 0, 1};
         mlh_solver_opts opts;
         unsigned long long epoch = 0;  // stage_epoch at submission
+        bool tainted = false;          // chained behind a frame whose LM loop outgrew its look-ahead: began from an unfinished pose (mlh_scan2map_end status 3)
     } solve_slot[2];
     int lm_lookahead_auto = 10;           // mlh_scan2map_begin(lm_lookahead = 0): the previous frame's largest LM iteration count + 2 (10 until a frame has been collected)
     unsigned long long stage_epoch = 0;   // bumped by every call that restages a map or a feature set: a re-solve of an in-flight frame is only sound on unchanged inputs

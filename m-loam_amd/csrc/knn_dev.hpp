@@ -11,6 +11,14 @@
 
 namespace mlh {
 
+// FLANN's L2 accumulation of one candidate (dx*dx + dy*dy + dz*dz, left to right, f32, no contraction) -- the ONE place every search and the bound of the bounded
+// search take a squared distance from, with explicitly rounded operations: two inlined copies of an expression could be contracted differently by a compiler that
+// ignored -ffp-contract=off, and the bounded search compares the bits of one against the bits of the other.
+__device__ __forceinline__ float knn_sqdist(float dx, float dy, float dz)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
 constexpr int TPB = 256;
 
 // lanes per query in the correspondence kernel: 8 when the launch fills the chip on its own (throughput: one wavefront serves 8
@@ -180,7 +188,7 @@ __device__ __forceinline__ void knn_group(const GridDev &g, float qx, float qy, 
             for (int u = 0; u < KNN_U; ++u) {
                 if (v[u]) {
                     float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
-                    float d = dx * dx; d += dy * dy; d += dz * dz;
+                    const float d = knn_sqdist(dx, dy, dz);
                     key_insert<K>(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
                 }
             }
@@ -292,7 +300,7 @@ __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
-                float d = dx * dx; d += dy * dy; d += dz * dz;
+                const float d = knn_sqdist(dx, dy, dz);
                 const bool take = v[u] && (__float_as_uint(d) <= bound_bits);
                 c[u] = take ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w)) : KEY_INF;
             }
@@ -305,7 +313,7 @@ __device__ __forceinline__ void knn_walk16(const GridDev &g, float qx, float qy,
         for (int u = 0; u < KNN_U; ++u) {
             if (v[u]) {
                 float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
-                float d = dx * dx; d += dy * dy; d += dz * dz;
+                const float d = knn_sqdist(dx, dy, dz);
                 if (__float_as_uint(d) <= bound_bits)
                     key_insert<K>(k, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w));
             }

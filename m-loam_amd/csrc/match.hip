@@ -339,7 +339,7 @@ __device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &
     for (int r = 0; r < NREC; ++r) {
         if (gl + r * G < K) {
             const float dx = old[r].x - sx, dy = old[r].y - sy, dz = old[r].z - sz;
-            float d = dx * dx; d += dy * dy; d += dz * dz;
+            const float d = knn_sqdist(dx, dy, dz);
             const unsigned bb = (old[r].w < __uint_as_float(0x7f800000u) && d < __uint_as_float(0x7f800000u)) ? __float_as_uint(d) : 0x7f800000u;
             bits = bb > bits ? bb : bits;
         }

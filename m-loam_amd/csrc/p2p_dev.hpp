@@ -44,7 +44,7 @@ __device__ __forceinline__ bool p2p_exchange(const P2pDev &a, double *rec, int n
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 1023u) == 0 && wall_clock64() - t0 > 500000000ull) {        // 5 s at 100 MHz: the peer is not coming
                 if (a.err) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                s_timeout = 1;
+                __hip_atomic_store(&s_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 break;
             }
         }
@@ -57,8 +57,9 @@ __device__ __forceinline__ bool p2p_exchange(const P2pDev &a, double *rec, int n
     }
     __syncthreads();                     // (every thread has read the counter long before this point)
     if (t == 0) __hip_atomic_store(a.counter, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    return s_timeout == 0;
+    const bool ok = __hip_atomic_load(&s_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;      // into a register BEFORE the last barrier: the caller may
+    __syncthreads();                                                                                           // re-enter at once and thread 0 clears the flag again
+    return ok;
 }
 
 // fills the device-side descriptor from the context

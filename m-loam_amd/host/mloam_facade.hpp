@@ -20,7 +20,9 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -33,10 +35,42 @@
 
 #include "../../include/mloam_hip.h"
 
+// Inside the reference tree (-DMLOAM_FACADE_CERES_BASES): the per-factor classes ARE ceres::SizedCostFunction<...> and PoseLocalParameterization IS a
+// ceres::LocalParameterization -- `new`ed by the caller, handed to problem.AddResidualBlock / AddParameterBlock and owned (deleted) by ceres::Problem, as the
+// reference's own classes are (lidar_mapper_keyframe.cpp:446-450, 547-548, 562-563). Without the macro they are plain classes with the same members.
+#ifdef MLOAM_FACADE_CERES_BASES
+#include <ceres/ceres.h>
+#define MLOAM_FACADE_COST_BASE(...) : public ceres::SizedCostFunction<__VA_ARGS__>
+#define MLOAM_FACADE_LOCAL_PARAM_BASE : public ceres::LocalParameterization
+#define MLOAM_FACADE_VIRTUAL virtual
+#else
+#define MLOAM_FACADE_COST_BASE(...)
+#define MLOAM_FACADE_LOCAL_PARAM_BASE
+#define MLOAM_FACADE_VIRTUAL
+#endif
+
 namespace mloam_hip {
 
-// ------------------------------------------------------------------ point / cloud types (layout-compatible stand-ins)
-#ifndef MLOAM_FACADE_USE_PCL_TYPES
+// ------------------------------------------------------------------ point / cloud types
+// Inside the reference tree (-DMLOAM_FACADE_USE_PCL_TYPES): the real pcl::PointXYZ / pcl::PointXYZI / pcl::PointXYZIWithCov and pcl::PointCloud<T> -- this header
+// includes <pcl/point_types.h> and <pcl/point_cloud.h> itself and, when it is on the include path, the reference's own <mloam_pcl/point_with_cov.hpp>
+// (otherwise include the header that declares pcl::PointXYZIWithCov before this one). Nothing else has to be declared by the includer.
+// Everywhere else: layout-compatible stand-ins with the same member names.
+#ifdef MLOAM_FACADE_USE_PCL_TYPES
+}  // namespace mloam_hip
+#include <pcl/point_types.h>
+#include <pcl/point_cloud.h>
+#if defined(__has_include)
+#if __has_include(<mloam_pcl/point_with_cov.hpp>)
+#include <mloam_pcl/point_with_cov.hpp>
+#endif
+#endif
+namespace mloam_hip {
+using PointI = pcl::PointXYZI;
+using PointXYZ = pcl::PointXYZ;                    // the raw driver cloud's point (FeatureExtract::calTimestamp's input)
+using PointIWithCov = pcl::PointXYZIWithCov;       // mloam_pcl/point_with_cov.hpp:45-101
+template <typename PointT> using PointCloud = pcl::PointCloud<PointT>;
+#else
 struct alignas(16) PointI {           // pcl::PointXYZI: float data[4]; float intensity; pad[3]  -> 32 bytes
     float x = 0, y = 0, z = 0, pad_ = 1.f;
     float intensity = 0, pad2_[3] = {0, 0, 0};
@@ -52,6 +86,8 @@ struct alignas(16) PointIWithCov {    // pcl::PointXYZIWithCov (mloam_pcl/point_
 };
 template <typename PointT>
 struct PointCloud {
+    typedef std::shared_ptr<PointCloud<PointT>> Ptr;
+    typedef std::shared_ptr<const PointCloud<PointT>> ConstPtr;
     std::vector<PointT> points;
     size_t size() const { return points.size(); }
     void push_back(const PointT &p) { points.push_back(p); }
@@ -60,9 +96,11 @@ struct PointCloud {
     PointT &operator[](size_t i) { return points[i]; }
 };
 #endif
-static_assert(sizeof(PointI) == 32, "pcl::PointXYZI layout");
-static_assert(sizeof(PointIWithCov) == 48, "pcl::PointXYZIWithCov layout");
-typedef PointCloud<PointXYZ> PointXYZCloud;      // the reference's `PointCloud` (common_types: pcl::PointCloud<pcl::PointXYZ>)
+static_assert(sizeof(PointXYZ) == 16, "pcl::PointXYZ layout");
+static_assert(sizeof(PointI) == 32 && offsetof(PointI, intensity) == 16, "pcl::PointXYZI layout");
+static_assert(sizeof(PointIWithCov) == 48 && offsetof(PointIWithCov, intensity) == 16 && offsetof(PointIWithCov, cov_vec) == 20 && offsetof(PointIWithCov, cov_trace) == 44,
+              "pcl::PointXYZIWithCov layout (mloam_pcl/point_with_cov.hpp:45-53)");
+typedef PointCloud<PointXYZ> PointXYZCloud;      // the reference's `PointCloud` (common/types/type.h:16: pcl::PointCloud<pcl::PointXYZ>)
 typedef PointCloud<PointI> PointICloud;
 typedef PointCloud<PointIWithCov> PointICovCloud;
 typedef std::map<std::string, PointICloud> cloudFeature;   // parameters.h:161
@@ -100,6 +138,68 @@ public:
     bool segment_flag_;
     std::vector<bool> ground_flag_;
 };
+
+// ------------------------------------------------------------------ the reference's OWN types at the call sites (duck typing)
+// Inside the reference tree the call sites hold the reference's types, not the stand-ins above: Pose with Eigen::Quaterniond q_ / Eigen::Vector3d t_ /
+// Eigen::Matrix<double, 6, 6> cov_ (pose.h:38-66), PointPlaneFeature with Eigen::Vector3d point_ / Eigen::VectorXd coeffs_ / Eigen::MatrixXd jaco_
+// (parameters.h:163-175), ScanInfo (parameters.h:193-207), Eigen::Matrix3d covariances, boost::shared_ptr'd clouds and indices. Every entry point of this
+// header that mirrors a reference interface is a template over those types and touches them only through the members both families have; the few places
+// where the spelling differs (q.w() against q.w, m(r, c) against m[r * n + c], MatrixXd::resize(1, n) against vector::resize(n), *ptr against a
+// reference) go through the helpers below. tests/host/refcut compiles the reference's own call sites, cut verbatim, against exactly this.
+namespace detail {
+template <class Q> auto quat_w(const Q &q, int) -> decltype(double(q.w())) { return q.w(); }
+template <class Q> auto quat_w(const Q &q, long) -> decltype(double(q.w)) { return q.w; }
+template <class Q> auto quat_x(const Q &q, int) -> decltype(double(q.x())) { return q.x(); }
+template <class Q> auto quat_x(const Q &q, long) -> decltype(double(q.x)) { return q.x; }
+template <class Q> auto quat_y(const Q &q, int) -> decltype(double(q.y())) { return q.y(); }
+template <class Q> auto quat_y(const Q &q, long) -> decltype(double(q.y)) { return q.y; }
+template <class Q> auto quat_z(const Q &q, int) -> decltype(double(q.z())) { return q.z(); }
+template <class Q> auto quat_z(const Q &q, long) -> decltype(double(q.z)) { return q.z; }
+template <class Q> auto quat_set(Q &q, double w, double x, double y, double z, int) -> decltype(void(q.w() = w)) { q.w() = w; q.x() = x; q.y() = y; q.z() = z; }
+template <class Q> auto quat_set(Q &q, double w, double x, double y, double z, long) -> decltype(void(q.w = w)) { q.w = w; q.x = x; q.y = y; q.z = z; }
+// element (r, c) of an n-column matrix: Eigen's m(r, c), or a row-major std::array / std::vector / C array
+template <class M> auto mat_at(const M &m, int r, int c, int /*n*/, int) -> decltype(double(m(r, c))) { return m(r, c); }
+template <class M> auto mat_at(const M &m, int r, int c, int n, long) -> decltype(double(m[0])) { return m[size_t(r * n + c)]; }
+template <class M> auto mat_ref(M &m, int r, int c, int /*n*/, int) -> decltype(m(r, c)) { return m(r, c); }
+template <class M> auto mat_ref(M &m, int r, int c, int n, long) -> decltype(m[0]) { return m[size_t(r * n + c)]; }
+// the reference's Pose keeps T_ in step with q_ / t_ through update() (pose.cpp:105-108); the stand-in has no such member
+template <class P> auto pose_update(P &pose, int) -> decltype(void(pose.update())) { pose.update(); }
+template <class P> void pose_update(P &, long) {}
+template <class P> void pose_to_param(const P &pose, double p[7])          // [tx ty tz qx qy qz qw]: the parameter-block layout (vector2Double, cpp:236-243)
+{
+    p[0] = pose.t_(0); p[1] = pose.t_(1); p[2] = pose.t_(2);
+    p[3] = quat_x(pose.q_, 0); p[4] = quat_y(pose.q_, 0); p[5] = quat_z(pose.q_, 0); p[6] = quat_w(pose.q_, 0);
+}
+template <class P> void pose_from_param(P &pose, const double p[7])
+{
+    pose.t_(0) = p[0]; pose.t_(1) = p[1]; pose.t_(2) = p[2];
+    quat_set(pose.q_, p[6], p[3], p[4], p[5], 0);
+    pose_update(pose, 0);
+}
+template <class P> void pose_cov_get(const P &pose, double c[36]) { for (int r = 0; r < 6; ++r) for (int k = 0; k < 6; ++k) c[r * 6 + k] = mat_at(pose.cov_, r, k, 6, 0); }
+template <class P> void pose_cov_set(P &pose, const double c[36]) { for (int r = 0; r < 6; ++r) for (int k = 0; k < 6; ++k) mat_ref(pose.cov_, r, k, 6, 0) = c[r * 6 + k]; }
+// PointPlaneFeature::jaco_: Eigen::MatrixXd (1 x 6) in the reference, std::vector<double> in the stand-in; both expose data()
+template <class J> auto jaco_resize(J &j, int n, int) -> decltype(void(j.cols())) { j.resize(1, n); }
+template <class J> void jaco_resize(J &j, int n, long) { j.resize(size_t(n)); }
+template <class F> void feature_set(F &f, size_t idx, size_t laser_idx, char type, double x, double y, double z, const double *coeffs, int n_coeffs, const double *jaco6)
+{
+    f.idx_ = idx; f.laser_idx_ = laser_idx; f.type_ = type;
+    f.point_[0] = x; f.point_[1] = y; f.point_[2] = z;
+    f.coeffs_.resize(n_coeffs);
+    for (int k = 0; k < n_coeffs; ++k) f.coeffs_[k] = coeffs[k];
+    if (jaco6) { jaco_resize(f.jaco_, 6, 0); for (int k = 0; k < 6; ++k) f.jaco_.data()[k] = jaco6[k]; }
+}
+// a kd-tree / cloud handed over as the object or as a (boost / std) shared_ptr to it
+template <class T> auto deref(const T &x, int) -> decltype(*x) { return *x; }
+template <class T> const T &deref(const T &x, long) { return x; }
+}  // namespace detail
+// reference Pose <-> stand-in Pose (either direction, any two pose types with q_ / t_ / cov_)
+template <class PoseA, class PoseB> void copyPose(const PoseA &from, PoseB &to)
+{
+    double p[7], c[36];
+    detail::pose_to_param(from, p); detail::pose_cov_get(from, c);
+    detail::pose_from_param(to, p); detail::pose_cov_set(to, c);
+}
 
 // hot-path globals of parameters.h that the match functions read (MIN_MATCH_SQ_DIS, MIN_PLANE_DIS, ...)
 struct Params {
@@ -154,7 +254,11 @@ inline Device &threadDevice()
 template <typename PointT>
 class MapIndex {
 public:
+    typedef std::shared_ptr<MapIndex<PointT>> Ptr;       // the mapper holds pcl::KdTreeFLANN<PointIWithCov>::Ptr kdtree_*_from_map (lidar_mapper_keyframe.cpp:59-62)
     MapIndex(Device &dev, int kind) : dev_(dev), kind_(kind) {}
+    // kdtree_surf_from_map->setInputCloud(laser_cloud_surf_from_map_cov_ds) (cpp:433-434) hands a PointCloud::Ptr over
+    template <typename CloudPtr>
+    auto setInputCloud(const CloudPtr &cloud) -> decltype(void((*cloud).points)) { setInputCloud(*cloud); }
     void setInputCloud(const PointCloud<PointT> &cloud)
     {
         if (cloud.size() == 0) throw Error("setInputCloud: empty cloud");
@@ -200,7 +304,11 @@ public:
         leaf_ = lx;
     }
     void setTraceThreshold(const float trace_threshold) { trace_threshold_ = trace_threshold; }   // .h:349
-    void setInputCloud(const PointCloud<PointT> &cloud) { input_ = &cloud; }
+    void setInputCloud(const PointCloud<PointT> &cloud) { input_ = &cloud; keep_.reset(); }
+    // as the reference calls it: a PointCloud::Ptr, possibly a temporary (`setInputCloud(boost::make_shared<PointICovCloud>(cloud))`) -- a copy of the smart
+    // pointer is kept until the next setInputCloud, as pcl::Filter keeps input_
+    template <typename CloudPtr>
+    auto setInputCloud(const CloudPtr &cloud) -> decltype(void((*cloud).points)) { auto k = std::make_shared<CloudPtr>(cloud); input_ = &**k; keep_ = k; }
     void filter(PointCloud<PointT> &output)
     {
         if (!input_ || input_->size() == 0) { output.points.clear(); return; }   // "No input dataset given" -> empty output (impl.hpp:71-77)
@@ -214,38 +322,48 @@ public:
 private:
     Device &dev_;
     const PointCloud<PointT> *input_ = nullptr;
+    std::shared_ptr<void> keep_;
     float leaf_ = 0.4f, trace_threshold_ = 2.0f;   // .h:102
 };
 
 // ------------------------------------------------------------------ local-map assembly (lidar_mapper.h:118-119, associate_uct.hpp:90-147)
 // compoundPoseWithCov(pose_1, pose_2, pose_cp): method 2, the only one the mapper uses
-inline void compoundPoseWithCov(const Pose &pose_1, const Pose &pose_2, Pose &pose_cp)
+template <typename PoseT>
+inline void compoundPoseWithCov(const PoseT &pose_1, const PoseT &pose_2, PoseT &pose_cp)
 {
-    double p1[7], p2[7], pc[7];
-    pose_1.toParam(p1); pose_2.toParam(p2);
-    if (mlh_compound_pose_with_cov(p1, pose_1.cov_.data(), p2, pose_2.cov_.data(), pc, pose_cp.cov_.data()) != MLH_OK) throw Error("compoundPoseWithCov");
-    pose_cp.fromParam(pc);
+    double p1[7], p2[7], pc[7], c1[36], c2[36], cc[36];
+    detail::pose_to_param(pose_1, p1); detail::pose_to_param(pose_2, p2);
+    detail::pose_cov_get(pose_1, c1); detail::pose_cov_get(pose_2, c2);
+    if (mlh_compound_pose_with_cov(p1, c1, p2, c2, pc, cc) != MLH_OK) throw Error("compoundPoseWithCov");
+    detail::pose_from_param(pose_cp, pc);
+    detail::pose_cov_set(pose_cp, cc);
 }
+namespace detail {
+template <typename PoseVec> void pack_extrinsics(const PoseVec &pose_ext, std::vector<double> &ext, std::vector<double> &ext_cov)
+{
+    ext.resize(pose_ext.size() * 7); ext_cov.resize(pose_ext.size() * 36);
+    for (size_t n = 0; n < pose_ext.size(); ++n) { pose_to_param(pose_ext[n], ext.data() + n * 7); pose_cov_get(pose_ext[n], ext_cov.data() + n * 36); }
+}
+}  // namespace detail
 
 // cloudUCTAssociateToMap(cloud_local, cloud_global, pose_global, pose_ext): the reference reads the globals with_ua_flag,
 // COV_MEASUREMENT and TRACE_THRESHOLD_MAPPING; here they are the last argument and params().
-inline void cloudUCTAssociateToMap(Device &dev, const PointICovCloud &cloud_local, PointICovCloud &cloud_global, const Pose &pose_global,
-                                   const std::vector<Pose> &pose_ext, bool with_ua_flag)
+template <typename PoseT, typename PoseVec>
+inline void cloudUCTAssociateToMap(Device &dev, const PointICovCloud &cloud_local, PointICovCloud &cloud_global, const PoseT &pose_global,
+                                   const PoseVec &pose_ext, bool with_ua_flag)
 {
     cloud_global.points.clear();
     if (cloud_local.size() == 0) return;
-    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
-    for (size_t n = 0; n < pose_ext.size(); ++n) {
-        pose_ext[n].toParam(ext.data() + n * 7);
-        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
-    }
-    double pg[7];
-    pose_global.toParam(pg);
+    std::vector<double> ext, ext_cov;
+    detail::pack_extrinsics(pose_ext, ext, ext_cov);
+    double pg[7], pg_cov[36];
+    detail::pose_to_param(pose_global, pg);
+    detail::pose_cov_get(pose_global, pg_cov);
     std::vector<PointIWithCov> out(cloud_local.size());
     int32_t n_out = 0;
     dev.check(mlh_cloud_uct_associate_to_map(dev.ctx(), cloud_local.points.data(), (int)sizeof(PointIWithCov), (int)cloud_local.size(),
                                              VoxelFields<PointIWithCov>::intensity, VoxelFields<PointIWithCov>::cov, VoxelFields<PointIWithCov>::trace,
-                                             pg, pose_global.cov_.data(), ext.data(), ext_cov.data(), (int)pose_ext.size(), params().COV_MEASUREMENT,
+                                             pg, pg_cov, ext.data(), ext_cov.data(), (int)pose_ext.size(), params().COV_MEASUREMENT,
                                              with_ua_flag ? 1 : 0, params().TRACE_THRESHOLD_MAPPING, out.data(), &n_out, MLH_MEM_HOST));
     out.resize(n_out);
     cloud_global.points.assign(out.begin(), out.end());
@@ -254,16 +372,14 @@ inline void cloudUCTAssociateToMap(Device &dev, const PointICovCloud &cloud_loca
 // downsampleCurrentScan() for one feature cloud (lidar_mapper_keyframe.cpp:356-421): thin at `leaf`, attach the extrinsic-induced
 // covariance, drop what exceeds TRACE_THRESHOLD_MAPPING. The result is returned AND stays on the device as the kind's feature set,
 // so a following scan2map call needs no mlh_features_set for it.
-inline void downsampleCurrentScan(Device &dev, int kind, const PointICloud &laser_cloud_last, float leaf, const std::vector<Pose> &pose_ext,
+template <typename PoseVec>
+inline void downsampleCurrentScan(Device &dev, int kind, const PointICloud &laser_cloud_last, float leaf, const PoseVec &pose_ext,
                                   bool with_ua_flag, PointICovCloud &laser_cloud_cov)
 {
     laser_cloud_cov.points.clear();
     if (laser_cloud_last.size() == 0) return;
-    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
-    for (size_t n = 0; n < pose_ext.size(); ++n) {
-        pose_ext[n].toParam(ext.data() + n * 7);
-        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
-    }
+    std::vector<double> ext, ext_cov;
+    detail::pack_extrinsics(pose_ext, ext, ext_cov);
     std::vector<float> out(laser_cloud_last.size() * 11);
     int32_t m = 0;
     dev.check(mlh_downsample_current_scan(dev.ctx(), kind, laser_cloud_last.points.data(), (int)sizeof(PointI), (int)laser_cloud_last.size(),
@@ -327,7 +443,8 @@ public:
     // feature_extract.cpp:118-297. Output keys and ordering as the reference (cpp:281-285), "surf_points_less_flat" thinned by the
     // per-ring 0.2 m VoxelGrid (cpp:266-271) with the intensity field (ring id) averaged along, as PCL does.
     // Re-entrancy: see the constructors. Nothing of a call lives in the object (the labels of a thread's last call: cloudLabel()).
-    void extractCloud(const PointICloud &laser_cloud_in, const ScanInfo &scan_info, cloudFeature &cloud_feature)
+    template <typename ScanInfoT>
+    void extractCloud(const PointICloud &laser_cloud_in, const ScanInfoT &scan_info, cloudFeature &cloud_feature)
     {
         Device &dev_ = device();
         std::vector<int32_t> &labels_ = threadLabels();
@@ -364,7 +481,8 @@ public:
 
     // The same extraction with nothing fetched: the four feature lists and the thinned less-flat cloud stay in HBM for
     // LidarTracker::set*FromExtractor and fuseCloudFeature (one scan per Device at a time).
-    void extractCloudOnDevice(const PointICloud &laser_cloud_in, const ScanInfo &scan_info)
+    template <typename ScanInfoT>
+    void extractCloudOnDevice(const PointICloud &laser_cloud_in, const ScanInfoT &scan_info)
     {
         Device &dev_ = device();
         dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, (int)laser_cloud_in.size(),
@@ -373,33 +491,36 @@ public:
         dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
     }
 
-    // feature_extract.hpp:542-643 / 379-538: batch matching, matches compacted in input order
-    template <typename PointT>
-    void matchSurfFromMap(const MapIndex<PointT> &kdtree_surf_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
-                          const Pose &pose_local, std::vector<PointPlaneFeature> &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
-    { matchFromMap(kdtree_surf_from_map, cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 's'); }
+    // feature_extract.hpp:542-643 / 379-538: batch matching, matches compacted in input order. The kd-tree argument is the MapIndex (or a shared_ptr to it: the
+    // reference passes `const typename pcl::KdTreeFLANN<PointType>::Ptr &`); pose and feature types are the caller's (the stand-ins above or the reference's
+    // Pose / PointPlaneFeature with their Eigen members).
+    template <typename KdTreeT, typename PointT, typename PoseT, typename FeatureVec>
+    void matchSurfFromMap(const KdTreeT &kdtree_surf_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
+                          const PoseT &pose_local, FeatureVec &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { matchFromMap(detail::deref(kdtree_surf_from_map, 0), cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 's'); }
 
-    template <typename PointT>
-    void matchCornerFromMap(const MapIndex<PointT> &kdtree_corner_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
-                            const Pose &pose_local, std::vector<PointPlaneFeature> &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
-    { matchFromMap(kdtree_corner_from_map, cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 'c'); }
+    template <typename KdTreeT, typename PointT, typename PoseT, typename FeatureVec>
+    void matchCornerFromMap(const KdTreeT &kdtree_corner_from_map, const PointCloud<PointT> & /*cloud_map*/, const PointCloud<PointT> &cloud_data,
+                            const PoseT &pose_local, FeatureVec &features, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { matchFromMap(detail::deref(kdtree_corner_from_map, 0), cloud_data, pose_local, features, N_NEIGH, CHECK_FOV, 'c'); }
 
     // feature_extract.hpp:646-883: single-point versions (one-element batch; prefer the batch calls)
-    template <typename PointT>
-    bool matchSurfPointFromMap(const MapIndex<PointT> &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
-                               PointPlaneFeature &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
-    { return matchPoint(kdtree, cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 's'); }
+    template <typename KdTreeT, typename PointT, typename PoseT, typename FeatureT>
+    bool matchSurfPointFromMap(const KdTreeT &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const PoseT &pose_local,
+                               FeatureT &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { return matchPoint(detail::deref(kdtree, 0), cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 's'); }
 
-    template <typename PointT>
-    bool matchCornerPointFromMap(const MapIndex<PointT> &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
-                                 PointPlaneFeature &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
-    { return matchPoint(kdtree, cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 'c'); }
+    template <typename KdTreeT, typename PointT, typename PoseT, typename FeatureT>
+    bool matchCornerPointFromMap(const KdTreeT &kdtree, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const PoseT &pose_local,
+                                 FeatureT &feature, const size_t &idx, const size_t &N_NEIGH = 5, const bool &CHECK_FOV = true)
+    { return matchPoint(detail::deref(kdtree, 0), cloud_map, point_ori, pose_local, feature, idx, N_NEIGH, CHECK_FOV, 'c'); }
 
 private:
-    template <typename PointT>
-    void matchFromMap(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_data, const Pose &pose_local,
-                      std::vector<PointPlaneFeature> &features, size_t n_neigh, bool check_fov, char type)
+    template <typename PointT, typename PoseT, typename FeatureVec>
+    void matchFromMap(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_data, const PoseT &pose_local,
+                      FeatureVec &features, size_t n_neigh, bool check_fov, char type)
     {
+        typedef typename FeatureVec::value_type FeatureT;
         features.clear();
         const int m = (int)cloud_data.size();
         if (m == 0) return;
@@ -407,7 +528,7 @@ private:
         dev.check(mlh_features_set(dev.ctx(), kd.kind(), cloud_data.points.data(), (int)sizeof(PointT), m, point_traits<PointT>::intensity_off,
                                    point_traits<PointT>::cov_off, MLH_MEM_HOST));
         double pose[7];
-        pose_local.toParam(pose);
+        detail::pose_to_param(pose_local, pose);
         std::vector<uint8_t> valid(m);
         std::vector<double> coeffs(size_t(m) * 6), r(m), J(size_t(m) * 6);
         const Params &P = params();
@@ -416,23 +537,20 @@ private:
                                       nullptr, nullptr, nullptr, nullptr));
         for (int i = 0; i < m; ++i) {
             if (!valid[i]) continue;
-            PointPlaneFeature f;
-            f.idx_ = i;
-            f.point_ = {double(cloud_data.points[i].x), double(cloud_data.points[i].y), double(cloud_data.points[i].z)};
-            f.coeffs_.assign(coeffs.begin() + size_t(i) * 6, coeffs.begin() + size_t(i) * 6 + (type == 's' ? 4 : 6));
-            f.jaco_.assign(J.begin() + size_t(i) * 6, J.begin() + size_t(i) * 6 + 6);   // what evaluateFeatJacobianMatching stores (lidar_mapper.h:162-164)
-            f.laser_idx_ = (size_t)cloud_data.points[i].intensity;
-            f.type_ = type;
+            FeatureT f;
+            // jaco_: what evaluateFeatJacobianMatching stores (lidar_mapper.h:162-164)
+            detail::feature_set(f, size_t(i), (size_t)cloud_data.points[i].intensity, type, double(cloud_data.points[i].x), double(cloud_data.points[i].y),
+                                double(cloud_data.points[i].z), coeffs.data() + size_t(i) * 6, type == 's' ? 4 : 6, J.data() + size_t(i) * 6);
             features.push_back(f);
         }
     }
-    template <typename PointT>
-    bool matchPoint(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const Pose &pose_local,
-                    PointPlaneFeature &feature, size_t idx, size_t n_neigh, bool check_fov, char type)
+    template <typename PointT, typename PoseT, typename FeatureT>
+    bool matchPoint(const MapIndex<PointT> &kd, const PointCloud<PointT> &cloud_map, const PointT &point_ori, const PoseT &pose_local,
+                    FeatureT &feature, size_t idx, size_t n_neigh, bool check_fov, char type)
     {
         PointCloud<PointT> one;
         one.push_back(point_ori);
-        std::vector<PointPlaneFeature> out;
+        std::vector<FeatureT> out;
         if (type == 's') matchSurfFromMap(kd, cloud_map, one, pose_local, out, n_neigh, check_fov);
         else matchCornerFromMap(kd, cloud_map, one, pose_local, out, n_neigh, check_fov);
         if (out.empty()) return false;
@@ -445,17 +563,18 @@ private:
 };
 
 // ------------------------------------------------------------------ PoseLocalParameterization (host side of the GN step)
-class PoseLocalParameterization {
+class PoseLocalParameterization MLOAM_FACADE_LOCAL_PARAM_BASE {       // pose_local_parameterization.h:21-32
 public:
-    bool Plus(const double *x, const double *delta, double *x_plus_delta) const { return mlh_pose_plus(x, delta, V_update_.data(), x_plus_delta) == MLH_OK; }
-    bool ComputeJacobian(const double * /*x*/, double *jacobian) const   // [I6; 0], row-major 7x6
+    MLOAM_FACADE_VIRTUAL ~PoseLocalParameterization() {}
+    MLOAM_FACADE_VIRTUAL bool Plus(const double *x, const double *delta, double *x_plus_delta) const { return mlh_pose_plus(x, delta, V_update_.data(), x_plus_delta) == MLH_OK; }
+    MLOAM_FACADE_VIRTUAL bool ComputeJacobian(const double * /*x*/, double *jacobian) const   // [I6; 0], row-major 7x6
     {
         std::memset(jacobian, 0, sizeof(double) * 42);
         for (int i = 0; i < 6; ++i) jacobian[i * 6 + i] = 1.0;
         return true;
     }
-    int GlobalSize() const { return 7; }
-    int LocalSize() const { return 6; }
+    MLOAM_FACADE_VIRTUAL int GlobalSize() const { return 7; }
+    MLOAM_FACADE_VIRTUAL int LocalSize() const { return 6; }
     void setParameter()
     {
         is_degenerate_ = false;
@@ -467,10 +586,13 @@ public:
 };
 
 // lidar_mapper_keyframe.cpp:1172-1204
-inline void evalDegenracy(const std::array<double, 36> &mat_H, PoseLocalParameterization *local_parameterization, std::array<double, 6> *mat_E = nullptr)
+// mat_H: the reference's Eigen::Matrix<double, 6, 6> or a row-major std::array<double, 36>
+template <typename Mat6>
+inline void evalDegenracy(const Mat6 &mat_H, PoseLocalParameterization *local_parameterization, std::array<double, 6> *mat_E = nullptr)
 {
-    double ev[6], V[36];
-    int deg = mlh_eval_degeneracy(mat_H.data(), params().MAP_EIG_THRE, ev, V);
+    double ev[6], V[36], H[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[r * 6 + c] = detail::mat_at(mat_H, r, c, 6, 0);
+    int deg = mlh_eval_degeneracy(H, params().MAP_EIG_THRE, ev, V);
     if (mat_E) std::memcpy(mat_E->data(), ev, sizeof(ev));
     if (deg > 0) {
         local_parameterization->is_degenerate_ = true;
@@ -518,7 +640,8 @@ class LidarPureOdomBatchFactor {
 public:
     LidarPureOdomBatchFactor(Device &dev, int n_window_frames, int n_lasers) : dev_(dev), W_(n_window_frames), L_(n_lasers) {}
     // feature: as produced by the match functions ('s': coeffs_ = [n, d]; 'c': coeffs_ = the two line points); s = sqrt_info (1.0 in the reference)
-    void add(const PointPlaneFeature &feature, int frame /*1..W*/, int laser /*0..L-1*/, double s = 1.0)
+    template <typename FeatureT>
+    void add(const FeatureT &feature, int frame /*1..W*/, int laser /*0..L-1*/, double s = 1.0)
     {
         type_.push_back(feature.type_ == 's' ? 0 : 1);
         for (int k = 0; k < 3; ++k) pts_.push_back(feature.point_[k]);
@@ -567,7 +690,8 @@ class LidarTracker {
 public:
     explicit LidarTracker(Device &dev) : dev_(dev) { mlh_track_opts_default(&opts_); }
     mlh_track_opts &options() { return opts_; }       // DISTANCE_SQ_THRESHOLD, NEARBY_SCAN (parameters.cpp:226-227)
-    Pose trackCloud(const cloudFeature &prev_cloud_feature, const cloudFeature &cur_cloud_feature, const Pose &pose_ini)
+    template <typename PoseT>
+    PoseT trackCloud(const cloudFeature &prev_cloud_feature, const cloudFeature &cur_cloud_feature, const PoseT &pose_ini)
     {
         const PointICloud &corner_last = prev_cloud_feature.find("corner_points_less_sharp")->second;
         const PointICloud &surf_last = prev_cloud_feature.find("surf_points_less_flat")->second;
@@ -579,10 +703,10 @@ public:
         dev_.check(mlh_track_set_cur(dev_.ctx(), MLH_CORNER, corner_sharp.points.data(), sz, (int)corner_sharp.size(), io, MLH_MEM_HOST));
         dev_.check(mlh_track_set_cur(dev_.ctx(), MLH_SURF, surf_flat.points.data(), sz, (int)surf_flat.size(), io, MLH_MEM_HOST));
         double p[7];
-        pose_ini.toParam(p);
+        detail::pose_to_param(pose_ini, p);
         dev_.check(mlh_track_cloud(dev_.ctx(), p, &opts_, nullptr));
-        Pose pose_prev_cur;
-        pose_prev_cur.fromParam(p);
+        PoseT pose_prev_cur;
+        detail::pose_from_param(pose_prev_cur, p);
         return pose_prev_cur;
     }
     // Device-resident hand-over (estimator.cpp:426-427, 532-543: copied before any undistortion): the scan FeatureExtract::extractCloudOnDevice
@@ -590,13 +714,14 @@ public:
     // thinned less flat); trackCloudOnDevice is trackCloud on whatever was staged.
     void setCurFromExtractor() { dev_.check(mlh_track_set_from_scan(dev_.ctx(), 0, opts_.distance_sq_threshold)); }
     void setPrevFromExtractor() { dev_.check(mlh_track_set_from_scan(dev_.ctx(), 1, opts_.distance_sq_threshold)); }
-    Pose trackCloudOnDevice(const Pose &pose_ini)
+    template <typename PoseT>
+    PoseT trackCloudOnDevice(const PoseT &pose_ini)
     {
         double p[7];
-        pose_ini.toParam(p);
+        detail::pose_to_param(pose_ini, p);
         dev_.check(mlh_track_cloud(dev_.ctx(), p, &opts_, nullptr));
-        Pose pose_prev_cur;
-        pose_prev_cur.fromParam(p);
+        PoseT pose_prev_cur;
+        detail::pose_from_param(pose_prev_cur, p);
         return pose_prev_cur;
     }
 private:
@@ -605,13 +730,11 @@ private:
 };
 
 // both kinds at once: the two fused clouds go through ONE thinning pipeline (half the dependent launches, one host round trip)
-inline std::pair<int, int> downsampleFusedScans(Device &dev, float leaf_surf, float leaf_corner, const std::vector<Pose> &pose_ext, bool with_ua_flag)
+template <typename PoseVec>
+inline std::pair<int, int> downsampleFusedScans(Device &dev, float leaf_surf, float leaf_corner, const PoseVec &pose_ext, bool with_ua_flag)
 {
-    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
-    for (size_t n = 0; n < pose_ext.size(); ++n) {
-        pose_ext[n].toParam(ext.data() + n * 7);
-        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
-    }
+    std::vector<double> ext, ext_cov;
+    detail::pack_extrinsics(pose_ext, ext, ext_cov);
     const void *cs = nullptr, *cc = nullptr;
     int32_t ns = 0, nc = 0, ms = 0, mc = 0;
     dev.check(mlh_fused_cloud(dev.ctx(), MLH_SURF, &cs, &ns));
@@ -624,12 +747,13 @@ inline std::pair<int, int> downsampleFusedScans(Device &dev, float leaf_surf, fl
 
 // ------------------------------------------------------------------ the odometry's window map (estimator.cpp:1160-1203)
 // pcl::transformPointCloud(cloud_in, cloud_out, pose.T_.cast<float>())
-inline void transformPointCloud(Device &dev, const PointICloud &cloud_in, PointICloud &cloud_out, const Pose &pose)
+template <typename PoseT>
+inline void transformPointCloud(Device &dev, const PointICloud &cloud_in, PointICloud &cloud_out, const PoseT &pose)
 {
     cloud_out = cloud_in;
     if (cloud_out.size() == 0) return;
     double p[7];
-    pose.toParam(p);
+    detail::pose_to_param(pose, p);
     dev.check(mlh_transform_point_cloud(dev.ctx(), cloud_out.points.data(), (int)sizeof(PointI), (int)cloud_out.size(), p, MLH_MEM_HOST));
 }
 // pcl::VoxelGrid<PointI> with the reference's call sequence: setLeafSize / setInputCloud / filter
@@ -637,7 +761,9 @@ class VoxelGrid {
 public:
     explicit VoxelGrid(Device &dev) : dev_(dev) {}
     void setLeafSize(float lx, float ly, float lz) { (void)ly; (void)lz; leaf_ = lx; }     // the reference only ever sets cubic leaves
-    void setInputCloud(const PointICloud &cloud) { input_ = &cloud; }
+    void setInputCloud(const PointICloud &cloud) { input_ = &cloud; keep_.reset(); }
+    template <typename CloudPtr>
+    auto setInputCloud(const CloudPtr &cloud) -> decltype(void((*cloud).points)) { auto k = std::make_shared<CloudPtr>(cloud); input_ = &**k; keep_ = k; }
     void filter(PointICloud &output)
     {
         if (!input_ || input_->size() == 0) { output.points.clear(); return; }
@@ -651,24 +777,27 @@ public:
 private:
     Device &dev_;
     const PointICloud *input_ = nullptr;
+    std::shared_ptr<void> keep_;
     float leaf_ = 0.4f;
 };
 
 // ------------------------------------------------------------------ undistortion (utility.h:79-100, estimator.cpp:376-410)
 // TransformToEnd over a whole cloud (the reference loops `for (PointI &point : cloud) TransformToEnd(point, point, pose, true, SCAN_PERIOD)`)
-inline void TransformToEnd(Device &dev, PointICloud &cloud, const Pose &pose, const bool &b_distortion, const float &scan_period = 0.1f)
+template <typename PoseT>
+inline void TransformToEnd(Device &dev, PointICloud &cloud, const PoseT &pose, const bool &b_distortion, const float &scan_period = 0.1f)
 {
     if (cloud.size() == 0) return;
     double p[7];
-    pose.toParam(p);
+    detail::pose_to_param(pose, p);
     dev.check(mlh_transform_to_end(dev.ctx(), cloud.points.data(), (int)sizeof(PointI), (int)cloud.size(), point_traits<PointI>::intensity_off, p,
                                    b_distortion ? 1 : 0, scan_period, MLH_MEM_HOST));
 }
 // the same for the scan FeatureExtract::extractCloudOnDevice left on the device (laser_cloud + the thinned less-flat cloud)
-inline void undistortMeasurementsOnDevice(Device &dev, const Pose &pose_undist, float scan_period = 0.1f)
+template <typename PoseT>
+inline void undistortMeasurementsOnDevice(Device &dev, const PoseT &pose_undist, float scan_period = 0.1f)
 {
     double p[7];
-    pose_undist.toParam(p);
+    detail::pose_to_param(pose_undist, p);
     dev.check(mlh_scan_undistort(dev.ctx(), p, scan_period));
 }
 
@@ -677,19 +806,18 @@ inline void undistortMeasurementsOnDevice(Device &dev, const Pose &pose_undist, 
 // LiDAR extractCloudOnDevice + fuseCloudFeature(laser index, its extrinsic); downsampleFusedScan is downsampleCurrentScan on the
 // fused cloud of `kind` (the result becomes the kind's feature set for scan2map) and returns the number of features kept.
 inline void fuseReset(Device &dev) { dev.check(mlh_fuse_reset(dev.ctx())); }
-inline void fuseCloudFeature(Device &dev, int laser_idx, const Pose &pose_ext)
+template <typename PoseT>
+inline void fuseCloudFeature(Device &dev, int laser_idx, const PoseT &pose_ext)
 {
     double e[7];
-    pose_ext.toParam(e);
+    detail::pose_to_param(pose_ext, e);
     dev.check(mlh_fuse_add_scan(dev.ctx(), laser_idx, e));
 }
-inline int downsampleFusedScan(Device &dev, int kind, float leaf, const std::vector<Pose> &pose_ext, bool with_ua_flag)
+template <typename PoseVec>
+inline int downsampleFusedScan(Device &dev, int kind, float leaf, const PoseVec &pose_ext, bool with_ua_flag)
 {
-    std::vector<double> ext(pose_ext.size() * 7), ext_cov(pose_ext.size() * 36);
-    for (size_t n = 0; n < pose_ext.size(); ++n) {
-        pose_ext[n].toParam(ext.data() + n * 7);
-        for (int i = 0; i < 36; ++i) ext_cov[n * 36 + i] = pose_ext[n].cov_[i];
-    }
+    std::vector<double> ext, ext_cov;
+    detail::pack_extrinsics(pose_ext, ext, ext_cov);
     const void *cloud = nullptr;
     int32_t n = 0, m = 0;
     dev.check(mlh_fused_cloud(dev.ctx(), kind, &cloud, &n));
@@ -703,10 +831,11 @@ inline int downsampleFusedScan(Device &dev, int kind, float leaf, const std::vec
 // evalFullHessian (lidar_mapper.h:176-227): match ALL features of a kind at pose_local and add their un-corrected, uncertainty-weighted
 // J^T J to mat_H; feat_num += matched features. The map index of `kind` and its features must be staged (MapIndex::setInputCloud,
 // mlh_features_set / downsampleCurrentScan).
-inline void evalFullHessian(Device &dev, int kind, const Pose &pose_local, double mat_H[36], int &feat_num)
+template <typename PoseT>
+inline void evalFullHessian(Device &dev, int kind, const PoseT &pose_local, double mat_H[36], int &feat_num)
 {
     double p[7], JtJ[36];
-    pose_local.toParam(p);
+    detail::pose_to_param(pose_local, p);
     int32_t n_valid = 0;
     dev.check(mlh_match_linearize(dev.ctx(), kind, p, 5, MLH_FLAG_WITH_UA | MLH_FLAG_NO_LOSS, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, 0.0,
                                   params().COV_MEASUREMENT_TRACE, nullptr, nullptr, nullptr, nullptr, JtJ, nullptr, nullptr, &n_valid));
@@ -763,7 +892,8 @@ public:
     }
     float &SEGMENT_THETA() { return prm_.segment_theta; }        // parameters.h globals the reference's segmentCloud reads
     double &ROI_RANGE() { return prm_.roi_range; }
-    void segmentCloud(const PointICloud &laser_cloud_in, PointICloud &laser_cloud_out, PointICloud &laser_cloud_outlier, ScanInfo &scan_info)
+    template <typename ScanInfoT>
+    void segmentCloud(const PointICloud &laser_cloud_in, PointICloud &laser_cloud_out, PointICloud &laser_cloud_outlier, ScanInfoT &scan_info)
     {
         Device &dev_ = bound_ ? *bound_ : threadDevice();
         mlh_segment_params prm_ = this->prm_;          // the call's own copy: concurrent calls differ in segment_flag
@@ -815,16 +945,51 @@ inline void quat_to_rot(const double q[4], double R[9])
     R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
-inline double sqrt_info_of(const std::array<double, 9> &cov) { const double s = std::sqrt(1 / (cov[0] + cov[4] + cov[8])); return s >= 3.0 ? 1.0 : s / 3.0; }
+// lidar_map_factor.hpp:36-40: sqrt(1 / trace(cov_matrix)), >= 3 -> 1, else / 3. cov_matrix: Eigen::Matrix3d or a row-major 3 x 3 array
+template <class M3> inline double sqrt_info_of(const M3 &cov) { const double s = std::sqrt(1 / (mat_at(cov, 0, 0, 3, 0) + mat_at(cov, 1, 1, 3, 0) + mat_at(cov, 2, 2, 3, 0))); return s >= 3.0 ? 1.0 : s / 3.0; }
+static const std::array<double, 9> kIdentity3 = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+template <class V3> inline std::array<double, 3> vec3_of(const V3 &v) { return {{double(v[0]), double(v[1]), double(v[2])}}; }
+template <class VX> inline std::vector<double> vecx_of(const VX &v) { std::vector<double> o(size_t(v.size())); for (size_t i = 0; i < o.size(); ++i) o[i] = double(v[i]); return o; }
+// the reference's check() (lidar_map_factor.hpp:98-118, 204-227): analytic against central-difference Jacobian of one factor, printed. F: any class with the
+// Ceres Evaluate contract over one 7-parameter block; the numeric columns perturb the pose through PoseLocalParameterization's Plus (identity projector)
+template <class F> inline void check_factor(const F &f, double **param, const char *name)
+{
+    double r0 = 0.0, J[7] = {0, 0, 0, 0, 0, 0, 0};
+    double *Jp[1] = {J};
+    f.Evaluate(param, &r0, Jp);
+    double num[6];
+    double V[36] = {0};
+    for (int i = 0; i < 6; ++i) V[i * 7] = 1.0;
+    const double eps = 1e-6;
+    for (int k = 0; k < 6; ++k) {
+        double d[6] = {0, 0, 0, 0, 0, 0}, xp[7], xm[7], rp = 0.0, rm = 0.0;
+        d[k] = eps; mlh_pose_plus(param[0], d, V, xp);
+        d[k] = -eps; mlh_pose_plus(param[0], d, V, xm);
+        const double *pp[1] = {xp}, *pm[1] = {xm};
+        f.Evaluate(pp, &rp, nullptr); f.Evaluate(pm, &rm, nullptr);
+        num[k] = (rp - rm) / (2 * eps);
+    }
+    std::printf("%s check: residual %.9f\n  analytic", name, r0);
+    for (int k = 0; k < 6; ++k) std::printf(" %.6f", J[k]);
+    std::printf("\n  numeric ");
+    for (int k = 0; k < 6; ++k) std::printf(" %.6f", num[k]);
+    std::printf("\n");
+}
 // row (1x3) times [p]x
 inline void row_skew(const double a[3], const double p[3], double out[3]) { out[0] = a[1] * p[2] - a[2] * p[1]; out[1] = a[2] * p[0] - a[0] * p[2]; out[2] = a[0] * p[1] - a[1] * p[0]; }
 }  // namespace detail
 
-class LidarMapPlaneNormFactor {      // : public ceres::SizedCostFunction<1, 7> inside the reference tree
+class LidarMapPlaneNormFactor MLOAM_FACADE_COST_BASE(1, 7) {      // lidar_map_factor.hpp:26-126
 public:
-    LidarMapPlaneNormFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const std::array<double, 9> &cov_matrix = {1, 0, 0, 0, 1, 0, 0, 0, 1})
-        : point_(point), coeff_(coeff), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
-    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    // (point, coeff, cov_matrix) as lidar_map_factor.hpp:28-30: Eigen::Vector3d / Eigen::VectorXd / Eigen::Matrix3d, or std::array / std::vector / row-major array
+    template <class V3, class VX, class M3>
+    LidarMapPlaneNormFactor(const V3 &point, const VX &coeff, const M3 &cov_matrix)
+        : point_(detail::vec3_of(point)), coeff_(detail::vecx_of(coeff)), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
+    template <class V3, class VX>
+    LidarMapPlaneNormFactor(const V3 &point, const VX &coeff) : point_(detail::vec3_of(point)), coeff_(detail::vecx_of(coeff)), sqrt_info_(detail::sqrt_info_of(detail::kIdentity3)) {}
+    MLOAM_FACADE_VIRTUAL ~LidarMapPlaneNormFactor() {}
+    void check(double **param) { detail::check_factor(*this, param, "LidarMapPlaneNormFactor"); }
+    MLOAM_FACADE_VIRTUAL bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
     {
         const double *x = param[0];
         double lp[3];
@@ -849,11 +1014,16 @@ private:
     double sqrt_info_;
 };
 
-class LidarMapEdgeFactor {           // : public ceres::SizedCostFunction<1, 7>
+class LidarMapEdgeFactor MLOAM_FACADE_COST_BASE(1, 7) {           // lidar_map_factor.hpp:130-235
 public:
-    LidarMapEdgeFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const std::array<double, 9> &cov_matrix = {1, 0, 0, 0, 1, 0, 0, 0, 1})
-        : point_(point), coeff_(coeff), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
-    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    template <class V3, class VX, class M3>
+    LidarMapEdgeFactor(const V3 &point, const VX &coeff, const M3 &cov_matrix)
+        : point_(detail::vec3_of(point)), coeff_(detail::vecx_of(coeff)), sqrt_info_(detail::sqrt_info_of(cov_matrix)) {}
+    template <class V3, class VX>
+    LidarMapEdgeFactor(const V3 &point, const VX &coeff) : point_(detail::vec3_of(point)), coeff_(detail::vecx_of(coeff)), sqrt_info_(detail::sqrt_info_of(detail::kIdentity3)) {}
+    MLOAM_FACADE_VIRTUAL ~LidarMapEdgeFactor() {}
+    void check(double **param) { detail::check_factor(*this, param, "LidarMapEdgeFactor"); }      // lidar_map_factor.hpp:176-229; named at lidar_mapper_keyframe.cpp:568
+    MLOAM_FACADE_VIRTUAL bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
     {
         const double *x = param[0];
         double lp[3];
@@ -962,10 +1132,12 @@ inline void pure_odom_factor(int type, const double p[3], const double *coeff, d
 }  // namespace detail
 
 template <int TYPE>
-class LidarPureOdomFactorT {          // : public ceres::SizedCostFunction<1, 7, 7, 7> inside the reference tree
+class LidarPureOdomFactorT MLOAM_FACADE_COST_BASE(1, 7, 7, 7) {          // lidar_pure_odom_factor.hpp:27-102, 198-282
 public:
-    LidarPureOdomFactorT(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &s = 1.0) : point_(point), coeff_(coeff), s_(s) {}
-    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    template <class V3, class VX>
+    LidarPureOdomFactorT(const V3 &point, const VX &coeff, const double &s = 1.0) : point_(detail::vec3_of(point)), coeff_(detail::vecx_of(coeff)), s_(s) {}
+    MLOAM_FACADE_VIRTUAL ~LidarPureOdomFactorT() {}
+    MLOAM_FACADE_VIRTUAL bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
     {
         detail::pure_odom_factor(TYPE, point_.data(), coeff_.data(), s_, param[0], param[1], param[2], residuals[0], jacobians ? jacobians[0] : nullptr,
                                  jacobians ? jacobians[1] : nullptr, jacobians ? jacobians[2] : nullptr);
@@ -980,11 +1152,13 @@ typedef LidarPureOdomFactorT<0> LidarPureOdomPlaneNormFactor;      // lidar_pure
 typedef LidarPureOdomFactorT<1> LidarPureOdomEdgeFactor;           // lidar_pure_odom_factor.hpp:198-282
 
 // the map factors' form on the extrinsic alone, the weight handed in (1.0 at estimator.cpp:757, 813): residual = sqrt_info * (the map factor's unweighted residual)
-class LidarOnlineCalibPlaneNormFactor {      // : public ceres::SizedCostFunction<1, 7>     lidar_online_calib_factor.hpp:24-62
+namespace detail { static const std::array<double, 9> kUnitWeightCov = {{0.001, 0, 0, 0, 0.001, 0, 0, 0, 0.001}}; }      // trace 0.003 -> sqrt(1 / trace) = 18 >= 3 -> the map factor's weight is exactly 1
+class LidarOnlineCalibPlaneNormFactor MLOAM_FACADE_COST_BASE(1, 7) {      // lidar_online_calib_factor.hpp:24-62
 public:
-    LidarOnlineCalibPlaneNormFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &sqrt_info = 1.0)
-        : unit_(point, coeff, {0.001, 0, 0, 0, 0.001, 0, 0, 0, 0.001}), s_(sqrt_info) {}      // trace 0.003 -> sqrt(1 / trace) = 18 >= 3 -> the map factor's weight is exactly 1
-    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    template <class V3, class VX>
+    LidarOnlineCalibPlaneNormFactor(const V3 &point, const VX &coeff, const double &sqrt_info = 1.0) : unit_(point, coeff, detail::kUnitWeightCov), s_(sqrt_info) {}
+    MLOAM_FACADE_VIRTUAL ~LidarOnlineCalibPlaneNormFactor() {}
+    MLOAM_FACADE_VIRTUAL bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
     {
         unit_.Evaluate(param, residuals, jacobians);
         residuals[0] *= s_;
@@ -995,11 +1169,12 @@ private:
     LidarMapPlaneNormFactor unit_;
     double s_;
 };
-class LidarOnlineCalibEdgeFactor {           // : public ceres::SizedCostFunction<1, 7>     lidar_online_calib_factor.hpp:125-165
+class LidarOnlineCalibEdgeFactor MLOAM_FACADE_COST_BASE(1, 7) {           // lidar_online_calib_factor.hpp:125-165
 public:
-    LidarOnlineCalibEdgeFactor(const std::array<double, 3> &point, const std::vector<double> &coeff, const double &sqrt_info = 1.0)
-        : unit_(point, coeff, {0.001, 0, 0, 0, 0.001, 0, 0, 0, 0.001}), s_(sqrt_info) {}
-    bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
+    template <class V3, class VX>
+    LidarOnlineCalibEdgeFactor(const V3 &point, const VX &coeff, const double &sqrt_info = 1.0) : unit_(point, coeff, detail::kUnitWeightCov), s_(sqrt_info) {}
+    MLOAM_FACADE_VIRTUAL ~LidarOnlineCalibEdgeFactor() {}
+    MLOAM_FACADE_VIRTUAL bool Evaluate(double const *const *param, double *residuals, double **jacobians) const
     {
         unit_.Evaluate(param, residuals, jacobians);
         residuals[0] *= s_;
@@ -1018,28 +1193,34 @@ class ActiveFeatureSelection {
 public:
     explicit ActiveFeatureSelection(Device &dev, bool with_ua = true, uint64_t seed = 0) : dev_(dev), with_ua_(with_ua), seed_(seed) {}
     // lidar_mapper.h:176-227: match ALL features, mat_H += J^T J of the matched ones (weighted, not loss-corrected), feat_num += matches
-    void evalFullHessian(const MapIndex<PointIWithCov> &kdtree_from_map, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const Pose &pose_local,
-                         const char feature_type, std::array<double, 36> &mat_H, int &feat_num)
+    // (kdtree: the MapIndex or a shared_ptr to it; pose / 6 x 6 matrix: the stand-ins or the reference's Pose / Eigen::Matrix<double, 6, 6>)
+    template <typename KdTreeT, typename PoseT, typename Mat6>
+    void evalFullHessian(const KdTreeT &kdtree_from_map_, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const PoseT &pose_local,
+                         const char feature_type, Mat6 &mat_H, int &feat_num)
     {
         (void)laser_map;
+        const MapIndex<PointIWithCov> &kdtree_from_map = detail::deref(kdtree_from_map_, 0);
         const int kind = feature_type == 's' ? MLH_SURF : MLH_CORNER;
         if (kdtree_from_map.kind() != kind) throw Error("evalFullHessian: the index handed in was built for the other feature kind");
         stage(kind, laser_cloud);
         double p[7], JtJ[36];
-        pose_local.toParam(p);
+        detail::pose_to_param(pose_local, p);
         int32_t n_valid = 0;
         dev_.check(mlh_match_linearize(dev_.ctx(), kind, p, 5, (with_ua_ ? MLH_FLAG_WITH_UA : 0u) | MLH_FLAG_NO_LOSS, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, 0.0,
                                        params().COV_MEASUREMENT_TRACE, nullptr, nullptr, nullptr, nullptr, JtJ, nullptr, nullptr, &n_valid));
-        for (int i = 0; i < 36; ++i) mat_H[i] += JtJ[i];
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) detail::mat_ref(mat_H, r, c, 6, 0) += JtJ[r * 6 + c];
         feat_num += n_valid;
     }
     // lidar_mapper.h:229-573. all_features[i].type_ stays 'n' for features that were not matched; sel_feature_idx lists the chosen ones in
     // pick order; sub_mat_H comes in as the caller initialised it (1e-6 * I, cpp:505/520) and returns with the selected rows added.
-    void goodFeatureMatching(const MapIndex<PointIWithCov> &kdtree_from_map, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const Pose &pose_local,
-                             std::vector<PointPlaneFeature> &all_features, std::vector<size_t> &sel_feature_idx, const char feature_type,
-                             const std::string gf_method, const double gf_ratio, std::array<double, 36> &sub_mat_H)
+    template <typename KdTreeT, typename PoseT, typename FeatureVec, typename Mat6>
+    void goodFeatureMatching(const KdTreeT &kdtree_from_map_, const PointICovCloud &laser_map, const PointICovCloud &laser_cloud, const PoseT &pose_local,
+                             FeatureVec &all_features, std::vector<size_t> &sel_feature_idx, const char feature_type,
+                             const std::string gf_method, const double gf_ratio, Mat6 &sub_mat_H)
     {
+        typedef typename FeatureVec::value_type FeatureT;
         (void)laser_map;
+        const MapIndex<PointIWithCov> &kdtree_from_map = detail::deref(kdtree_from_map_, 0);
         const int kind = feature_type == 's' ? MLH_SURF : MLH_CORNER;
         if (kdtree_from_map.kind() != kind) throw Error("goodFeatureMatching: the index handed in was built for the other feature kind");
         static const std::map<std::string, int> methods = {{"wo_gf", MLH_GF_WO}, {"rnd", MLH_GF_RND}, {"fps", MLH_GF_FPS}, {"gd_fix", MLH_GF_GD_FIX}, {"gd_float", MLH_GF_GD_FLOAT}};
@@ -1047,30 +1228,28 @@ public:
         if (it == methods.end()) throw Error("goodFeatureMatching: unknown gf_method " + gf_method);
         stage(kind, laser_cloud);
         const int m = (int)laser_cloud.size();
-        double p[7];
-        pose_local.toParam(p);
+        double p[7], H36[36];
+        detail::pose_to_param(pose_local, p);
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H36[r * 6 + c] = detail::mat_at(sub_mat_H, r, c, 6, 0);
         std::vector<int32_t> sel(size_t(m > 0 ? m : 1));
         std::vector<uint8_t> matched(size_t(m > 0 ? m : 1));
         int32_t n_sel = 0;
         dev_.check(mlh_good_feature_matching(dev_.ctx(), kind, p, it->second, gf_ratio, seed_, params().MIN_MATCH_SQ_DIS, params().MIN_PLANE_DIS, sel.data(), &n_sel,
-                                             sub_mat_H.data(), matched.data()));
+                                             H36, matched.data()));
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) detail::mat_ref(sub_mat_H, r, c, 6, 0) = H36[r * 6 + c];
         // coefficients of the matched features (the selected ones are what the block-assembly loop reads)
         std::vector<uint8_t> valid(size_t(m > 0 ? m : 1));
         std::vector<double> coeffs(size_t(m > 0 ? m : 1) * 6);
-        all_features.assign(size_t(m), PointPlaneFeature());
+        all_features.assign(size_t(m), FeatureT());
         sel_feature_idx.assign(sel.begin(), sel.begin() + n_sel);
         int32_t n_valid = 0;
         // after the selection only the chosen correspondences are live on the device: one linearise pass returns their coefficient rows
         dev_.check(mlh_match_coeffs(dev_.ctx(), kind, valid.data(), coeffs.data(), &n_valid));
         for (int i = 0; i < m; ++i) {
-            PointPlaneFeature &f = all_features[size_t(i)];
-            f.idx_ = size_t(i);
-            f.laser_idx_ = size_t(laser_cloud.points[size_t(i)].intensity);
-            f.point_ = {laser_cloud.points[size_t(i)].x, laser_cloud.points[size_t(i)].y, laser_cloud.points[size_t(i)].z};
-            if (valid[size_t(i)]) {
-                f.type_ = feature_type;
-                f.coeffs_.assign(coeffs.begin() + size_t(i) * 6, coeffs.begin() + size_t(i) * 6 + (feature_type == 's' ? 4 : 6));
-            }
+            const auto &pt = laser_cloud.points[size_t(i)];
+            const bool ok = valid[size_t(i)] != 0;
+            detail::feature_set(all_features[size_t(i)], size_t(i), size_t(pt.intensity), ok ? feature_type : 'n', double(pt.x), double(pt.y), double(pt.z),
+                                coeffs.data() + size_t(i) * 6, ok ? (feature_type == 's' ? 4 : 6) : 0, nullptr);
         }
     }
 private:
@@ -1186,8 +1365,8 @@ class WindowFactorTable {
 public:
     explicit WindowFactorTable(Device &dev) : dev_(dev) { dev_.check(mlh_pure_odom_begin(dev_.ctx())); }
     // frame: 1..W as in LidarPureOdomBatchFactor::add; laser: 0..L-1; type 's' / 'c'
-    template <typename PointT>
-    void addMatches(const PointCloud<PointT> &features_in_lidar_frame, char type, const Pose &pose_local, int frame, int laser, size_t n_neigh = 5, bool check_fov = true)
+    template <typename PointT, typename PoseT>
+    void addMatches(const PointCloud<PointT> &features_in_lidar_frame, char type, const PoseT &pose_local, int frame, int laser, size_t n_neigh = 5, bool check_fov = true)
     {
         const int m = (int)features_in_lidar_frame.size();
         if (m == 0) return;
@@ -1195,7 +1374,7 @@ public:
         dev_.check(mlh_features_set(dev_.ctx(), kind, features_in_lidar_frame.points.data(), (int)sizeof(PointT), m, point_traits<PointT>::intensity_off,
                                     point_traits<PointT>::cov_off, MLH_MEM_HOST));
         double pose[7];
-        pose_local.toParam(pose);
+        detail::pose_to_param(pose_local, pose);
         const Params &P = params();
         dev_.check(mlh_pure_odom_add_matches(dev_.ctx(), kind, pose, (int)n_neigh, check_fov ? MLH_FLAG_CHECK_FOV : 0u, P.MIN_MATCH_SQ_DIS, P.MIN_PLANE_DIS, frame - 1, laser));
     }
@@ -1242,13 +1421,16 @@ struct Scan2MapReport {
 
 // Replaces the body of scan2MapOptimization (lidar_mapper_keyframe.cpp:423-639): index build for both maps, max_iter x
 // { match all features, evalHessian + evalDegenracy, Levenberg-Marquardt with Ceres' trust-region semantics }, all on the GPU.
+// pose_wmap_curr: the stand-in Pose or the reference's own (Eigen members; its T_ is refreshed through update()).
+template <typename PoseT>
 inline void scan2MapOptimization(Device &dev, const PointICovCloud &laser_cloud_surf_from_map_cov_ds, const PointICovCloud &laser_cloud_corner_from_map_cov_ds,
-                                 const PointICovCloud &laser_cloud_surf_cov, const PointICovCloud &laser_cloud_corner_cov, Pose &pose_wmap_curr,
+                                 const PointICovCloud &laser_cloud_surf_cov, const PointICovCloud &laser_cloud_corner_cov, PoseT &pose_wmap_curr,
                                  bool with_ua_flag, Scan2MapReport *report = nullptr, int max_iter = 2)
 {
     const Params &P = params();
     if (!(laser_cloud_surf_from_map_cov_ds.size() > 50 && laser_cloud_corner_from_map_cov_ds.size() > 10)) {   // cpp:429
-        pose_wmap_curr.cov_.fill(0.0);
+        const double zero[36] = {0};
+        detail::pose_cov_set(pose_wmap_curr, zero);
         return;
     }
     MapIndex<PointIWithCov> kdtree_surf_from_map(dev, MLH_SURF), kdtree_corner_from_map(dev, MLH_CORNER);
@@ -1261,10 +1443,10 @@ inline void scan2MapOptimization(Device &dev, const PointICovCloud &laser_cloud_
     o.min_match_sq_dis = P.MIN_MATCH_SQ_DIS; o.min_plane_dis = P.MIN_PLANE_DIS; o.huber_delta = P.HUBER_DELTA; o.map_eig_thre = P.MAP_EIG_THRE;
     o.cov_measurement_trace = P.COV_MEASUREMENT_TRACE; o.flags = with_ua_flag ? MLH_FLAG_WITH_UA : 0u; o.max_outer = max_iter;
     double pose[7];
-    pose_wmap_curr.toParam(pose);
+    detail::pose_to_param(pose_wmap_curr, pose);
     std::vector<mlh_iter_stat> stats(max_iter);
     dev.check(mlh_scan2map(dev.ctx(), pose, &o, stats.data()));
-    pose_wmap_curr.fromParam(pose);
+    detail::pose_from_param(pose_wmap_curr, pose);
     if (report) report->outer = stats;
 }
 
@@ -1322,7 +1504,8 @@ public:
     // The frames are solved by the reference's own per-frame call, scan2MapOptimization (2 outer iterations x Levenberg-Marquardt), submitted and collected
     // separately (mlh_scan2map_begin / _end) instead of `gn_iters` Gauss-Newton iterations. lm_lookahead 0: automatic. After collect(), lastStatus() is
     // mlh_scan2map_end's status: 0 / 2 = the pose is scan2MapOptimization's; 1 = the pose returned is the frame's START pose and the caller has to solve the frame
-    // with scan2MapOptimization(...) on its inputs (it overflowed the look-ahead with a younger frame chained behind it).
+    // with scan2MapOptimization(...) on its inputs (it overflowed the look-ahead with a younger frame chained behind it); 3 = the frame was chained behind a frame
+    // that ended with 1 / 3 (it began from an unfinished pose): resubmit it after the predecessor has been solved.
     void useScan2Map(bool on, int lm_lookahead = 0) { scan2map_ = on; lm_lookahead_ = lm_lookahead; }
     int lastStatus() const { return last_status_; }
     Pose collect()

@@ -169,6 +169,9 @@ template <typename T> struct Mat<T, Dynamic, Dynamic> : MatrixBase<Mat<T, Dynami
     template <int R, int C> Mat(const Mat<T, R, C> &m) : r(R), c(C), d(m.d, m.d + R * C) {}
     template <int R, int C> Mat &operator=(const Mat<T, R, C> &m) { r = R; c = C; d.assign(m.d, m.d + R * C); return *this; }
     int rows() const { return r; } int cols() const { return c; }
+    void resize(int rows_, int cols_) { r = rows_; c = cols_; d.assign(size_t(rows_) * cols_, T(0)); }      // (Eigen leaves the coefficients uninitialised)
+    T *data() { return d.data(); }
+    const T *data() const { return d.data(); }
     T &operator()(int i, int j) { return d[size_t(i) * c + j]; }
     const T &operator()(int i, int j) const { return d[size_t(i) * c + j]; }
     Mat transpose() const { Mat m(c, r); for (int i = 0; i < r; ++i) for (int j = 0; j < c; ++j) m(j, i) = (*this)(i, j); return m; }
@@ -264,6 +267,11 @@ struct VectorXd {                                                  // the edge f
     template <int R> operator Mat<double, R, 1>() const { Mat<double, R, 1> m; for (int i = 0; i < R; ++i) m.d[i] = v[size_t(i)]; return m; }   // Eigen: dynamic -> fixed, sizes must agree
     double &operator()(int i) { return v[size_t(i)]; }
     const double &operator()(int i) const { return v[size_t(i)]; }
+    double &operator[](int i) { return v[size_t(i)]; }
+    const double &operator[](int i) const { return v[size_t(i)]; }
+    void resize(int n) { v.assign(size_t(n), 0.0); }
+    double *data() { return v.data(); }
+    const double *data() const { return v.data(); }
     int size() const { return int(v.size()); }
     const VectorXd &transpose() const { return *this; }          // only ever printed
 };

@@ -13,8 +13,37 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+# The strongest pins compare against the reference's OWN lines: oracle/_ref/libmloam_ref.so and tests/host/refcut/_build/refcut_selftest, built where
+# /root/reference exists and travelling to the GPU box as built files. A box where they are expected but absent must FAIL those tests, not skip them
+# (VERDICT r04): MLOAM_REQUIRE_REF=1 turns every skip whose reason is the missing reference build into a failure. Default: required wherever the reference tree
+# is mounted, and wherever the built product library travelled (then the checkers built next to it should have travelled too); MLOAM_REQUIRE_REF=0 opts out
+# (a fresh clone that only built the product).
+_REF_SKIP = ("reference build", "libmloam_ref.so", "refcut_selftest", "no reference tree")
+
+
+def _require_ref():
+    v = os.environ.get("MLOAM_REQUIRE_REF")
+    if v is not None:
+        return v == "1"
+    return os.path.isdir("/root/reference") or os.path.exists(os.path.join(ROOT, "m-loam_amd", "lib", "libmloam_hip.so"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if _require_ref():
+        os.environ["MLOAM_REQUIRE_REF"] = "1"
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.skipped and os.environ.get("MLOAM_REQUIRE_REF") == "1":
+        reason = str(rep.longrepr[2] if isinstance(rep.longrepr, tuple) else rep.longrepr)
+        # (the one legitimate skip that names the tree: a CPU-only compile check that needs the SOURCE tree, on a box that has the prebuilt executable instead)
+        if any(k in reason for k in _REF_SKIP) and "exercised by the GPU test" not in reason:
+            rep.outcome = "failed"
+            rep.longrepr = f"MLOAM_REQUIRE_REF=1: the reference-built checker is expected on this box but missing -- would have skipped: {reason}"
 
 
 @pytest.fixture(scope="session")

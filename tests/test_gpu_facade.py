@@ -257,3 +257,49 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
         assert list(np.fromfile(os.path.join(d, "out_fused_kept.i32"), np.int32)) == kept + kept and min(kept) > 50      # single calls, then the pair call
     finally:
         c.close()
+
+
+def test_reference_call_sites_on_the_gpu(tmp_path, orc, case16, feats16):
+    """The reference's own call sites, cut verbatim and compiled against the facade (tests/host/refcut; built where /root/reference exists, the executable travels):
+    estimator.cpp:248-270 -- ONE FeatureExtract + ONE ImageSegmenter, NUM_OF_LASER OpenMP threads -- on four scans; lidar_mapper_keyframe.cpp:433-434 through
+    MapIndex::Ptr; the match functions filling the REFERENCE's PointPlaneFeature at the REFERENCE's Pose (validity == the oracle's); cpp:537-571 building one residual
+    block per matched feature in a ceres::Problem that owns them, each block's r / J == the batched device evaluation (mlh_linearize) to 1e-9."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("build_refcut", os.path.join(ROOT, "tests", "host", "refcut", "build_refcut.py"))
+    rc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rc)
+    exe = rc.build()
+    if exe is None:
+        if os.environ.get("MLOAM_REQUIRE_REF") == "1":
+            pytest.fail("MLOAM_REQUIRE_REF=1 but neither /root/reference nor the prebuilt tests/host/refcut/_build/refcut_selftest is here")
+        pytest.skip("no reference tree and no prebuilt refcut_selftest")
+    sc = case16["scans"][0]
+    d = str(tmp_path)
+    case16["surf_map"].astype(np.float32).tofile(os.path.join(d, "surf_map.f32"))
+    case16["corner_map"].astype(np.float32).tofile(os.path.join(d, "corner_map.f32"))
+    feats16[0].astype(np.float32).tofile(os.path.join(d, "surf.f32"))
+    feats16[1].astype(np.float32).tofile(os.path.join(d, "corner.f32"))
+    case16["p0"].astype(np.float64).tofile(os.path.join(d, "pose.f64"))
+    rng = np.random.default_rng(3)
+    raw = sc.points.copy()
+    raw[:, 3] = 0.0
+    mclut = rng.random(len(raw)) < 0.1
+    raw[mclut, :3] *= rng.uniform(0.5, 1.3, (int(mclut.sum()), 1)).astype(np.float32)
+    raw = raw[rng.permutation(len(raw))]
+    raw.astype(np.float32).tofile(os.path.join(d, "raw_cloud.f32"))
+    r = subprocess.run([exe, "gpu", d], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr + r.stdout
+    v = np.fromfile(os.path.join(d, "refcut_verdict.i32"), np.int32)
+    assert len(v) == 13, v
+    for i in range(4):
+        assert v[2 * i] == 1 and v[2 * i + 1] > 10000, (i, v)            # every LiDAR's clouds == the sequential, bound-object calls
+    assert v[8] == 4, v                                                   # four LiDARs were really served by four threads
+    assert v[9] > 0 and v[10] > 0, v                                      # total_corner_feature_, total_surf_feature_ of the reference's collection loop
+    vs = np.fromfile(os.path.join(d, "refcut_valid_surf.u8"), np.uint8)
+    vc = np.fromfile(os.path.join(d, "refcut_valid_corner.u8"), np.uint8)
+    want_s, _ = orc.Map(case16["surf_map"]).match("s", feats16[0], case16["p0"])
+    want_c, _ = orc.Map(case16["corner_map"]).match("c", feats16[1], case16["p0"])
+    assert np.array_equal(vs, want_s) and np.array_equal(vc, want_c)
+    assert v[11] == int(want_s.sum() + want_c.sum()) and v[12] == 1, v    # one residual block per matched feature, all released with the Problem
+    dr, dJ = np.fromfile(os.path.join(d, "refcut_diff.f64"), np.float64)
+    assert dr < 1e-9 and dJ < 1e-9, (dr, dJ)

@@ -206,6 +206,51 @@ def test_gn_last_iteration_completed_by_the_successor_or_by_whoever_comes_next(m
         assert np.array_equal(ref[1][k], ref[1]["alone"]), k
 
 
+def test_host_driven_calls_while_a_solve_is_pending(mla, case16, feats16):
+    """ADVICE r04 (high): with final_in_successor a submitted solve's last iteration is a set of tile records and its pose sits in SolverState::xi[slot]. The
+    host-driven entry points (mlh_match_linearize, mlh_linearize, mlh_good_feature_matching, mlh_pure_odom_add_matches[_gf]) begin by uploading THEIR pose with a
+    launch that zeroes the whole state -- so the pending solve has to be completed first (upload_pose flushes it). begin -> such a call -> end: the pending
+    solve's pose and the interleaved call's outputs both equal what the classic schedule (final_in_successor = 0) gives."""
+    p0 = case16["p0"]
+    other = p0.copy(); other[:3] += np.array([0.05, -0.03, 0.02])
+    ref = {}
+    for final in (0, 1):
+        c = mla.Context(0)
+        try:
+            c.set_gn_schedule(1, 1, final)
+            _stage(c, mla, case16, feats16)
+            out = {}
+            c.gn_solve_begin(p0, 5)
+            m = c.match_linearize(mla.SURF, other)
+            out["ml_H"], out["ml_g"], out["ml_valid"] = m["H"], m["g"], m["valid"]
+            out["pend_ml"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            l = c.linearize(mla.SURF, other)
+            out["lin_H"], out["lin_g"] = l["H"], l["g"]
+            out["pend_lin"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            g = c.good_feature_matching(mla.CORNER, other, gf_method="rnd", gf_ratio=0.5, seed=3)
+            out["gf_sel"], out["gf_H"] = g["sel"], g["H"]
+            out["pend_gf"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            c.pure_odom_begin()
+            c.pure_odom_add_matches(mla.SURF, other, 0, 0)
+            out["pend_odom"] = c.gn_solve_end()
+            c.gn_solve_begin(p0, 5)
+            out["odom_gf_sel"] = c.pure_odom_add_matches_gf(mla.SURF, other, other, other, np.array([0, 0, 0, 0, 0, 0, 1.0]), 0, 0, gf_ratio=0.8, seed=5)
+            out["pend_odom_gf"] = c.gn_solve_end()
+            # and the solve that follows starts from a sane state
+            out["after"] = c.gn_solve(p0, 5, want_stats=False)[0]
+            ref[final] = out
+        finally:
+            c.close()
+    for k in ref[0]:
+        assert np.array_equal(ref[0][k], ref[1][k]), k
+    for k in ("pend_ml", "pend_lin", "pend_gf", "pend_odom", "pend_odom_gf", "after"):
+        assert np.array_equal(ref[1][k], ref[1]["after"]), k
+        assert np.all(np.isfinite(ref[1][k])) and abs(np.linalg.norm(ref[1][k][3:]) - 1.0) < 1e-12, k
+
+
 def test_maps_staged_twice_beside_one_solve(mla, case16, feats16):
     """mlh_map_set_pair_overlapped twice while ONE submitted solve is uncollected: the second call's target is the set that solve reads, so it may only be
     rewritten behind it (scripts/soak_schedule.py found the index rebuilt under a correspondence launch, a rare 1e-5 m difference). A long solve (12 iterations on
