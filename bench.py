@@ -758,7 +758,7 @@ def main():
         for _ in range(3):
             ctx.map_rebuild(mla.ALL_KINDS)
             s2m_pose, s2m_stats = ctx.scan2map(p0, opts)
-        n_s2m = max(args.steps // 10, 5)
+        n_s2m = max(args.steps // 2, 50)        # (round 4 took steps // 10 = 5 frames under the driver's --steps 20: the pipelined figure was all fill and drain)
         sync_all()
         t2 = time.perf_counter()
         for _ in range(n_s2m):
@@ -800,6 +800,67 @@ def main():
         s2m_pose_pipe, _ = s2m_pipe(n_s2m)
         sync_all()
         s2m_pipe_ms = 1e3 * (time.perf_counter() - t2) / n_s2m
+
+    # supplementary: ONE WHOLE MAPPER FRAME (lidar_mapper_keyframe.cpp:1000-1112 with the estimator's front end in front of it): the two raw 64-ring scans resident in
+    # HBM -> extractCloud (both LiDARs, one launch set) -> per-ring 0.2 m voxel thinning -> fusion of the LiDARs' features -> downsampleCurrentScan for both kinds
+    # (covariance voxel filter in the reference's std::sort member order + evalPointUncertainty) -> index build of both maps -> scan2MapOptimization -> pose.
+    # A context of its own (the main context's staged features stay what the other legs expect). Two clocks: every stage followed by a wait (ms per stage; the
+    # waits are part of what is measured), and the frame with no wait but the one for the pose (ms_per_frame).
+    frame = None
+    if world == 1 and not args.no_supplementary and len(scans) >= 2 and not args.dense_features:
+        fctx = mla.Context(local_rank)
+        try:
+            f_ext = np.array([np.concatenate([r_[4:7], r_[:4]]) for r_ in synth.HERCULES_BODY_T_LASER])[:len(scans)]
+            for e_ in f_ext:
+                e_[3:] /= np.linalg.norm(e_[3:])
+            f_covs = np.stack([np.zeros((6, 6))] + [np.diag([0.0025] * 3 + [0.00030461] * 3)] * (len(scans) - 1))
+            f_meas = np.diag([0.0025] * 3)
+            f_opts = mla.default_opts(flags=mla.FLAG_WITH_UA)
+            ring_ofs = np.cumsum([0] + [s_.n_rings for s_ in scans])
+            d_pts = torch.from_numpy(np.ascontiguousarray(all_pts, np.float32)).cuda()
+            d_start, d_end = torch.from_numpy(all_start).cuda(), torch.from_numpy(all_end).cuda()
+            fctx.map_set_pair(d_surf_map, d_corner_map)
+
+            def frame_once(t=None):
+                c0 = time.perf_counter()
+                fctx.fuse_reset()
+                fctx.scan_upload(d_pts, d_start, d_end); fctx.extract_run(); fctx.extract_voxel_run(0.2)
+                for i_ in range(len(scans)):
+                    fctx.fuse_add_rings(ring_ofs[i_], ring_ofs[i_ + 1], i_, f_ext[i_])
+                if t is not None:
+                    fctx.synchronize()
+                c1 = time.perf_counter()
+                cnt = fctx.downsample_current_scan_pair(fctx.fused_cloud(mla.SURF), fctx.fused_cloud(mla.CORNER), 0.4, 0.2, f_ext, f_covs, f_meas, True, 0.6)
+                c2 = time.perf_counter()
+                fctx.map_set_pair(d_surf_map, d_corner_map)
+                if t is not None:
+                    fctx.synchronize()
+                c3 = time.perf_counter()
+                fpose, _ = fctx.scan2map(p0, f_opts, want_stats=False)
+                c4 = time.perf_counter()
+                if t is not None:
+                    for k_, v_ in zip(("extract_fuse", "downsample_current_scan", "map_index_build", "scan2map"), (c1 - c0, c2 - c1, c3 - c2, c4 - c3)):
+                        t[k_] = t.get(k_, 0.0) + v_
+                return fpose, cnt
+            for _ in range(5):
+                frame_once()
+            n_fr = 40
+            sync_all()
+            c0 = time.perf_counter()
+            for _ in range(n_fr):
+                frame_pose, frame_counts = frame_once()
+            frame_ms = 1e3 * (time.perf_counter() - c0) / n_fr
+            st_t = {}
+            for _ in range(n_fr):
+                frame_once(st_t)
+            frame = dict(ms_per_frame=round(frame_ms, 4), stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
+                         scan_points=int(len(all_pts)), thinned_features=dict(surf=int(frame_counts[0]), corner=int(frame_counts[1])), pose=[round(float(x), 9) for x in frame_pose],
+                         host_reads_between_scan_and_pose=1,
+                         note="supplementary: the two raw scans resident in HBM -> extractCloud + per-ring voxel thinning + fusion -> downsampleCurrentScan (both kinds, one "
+                              "pipeline) -> index build of both maps -> scan2MapOptimization -> pose; frames one after the other, host waits for every pose. The one host read "
+                              "inside the frame: the thinned feature counts, which size the solve's launches")
+        finally:
+            fctx.close()
 
     # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
     #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)
@@ -1087,6 +1148,8 @@ def main():
                 out["ms_per_gn_iter"] = round(cfg4["ms_per_step"] / GN_ITERS, 4)
                 out["config"]["workload"] = cfg4["workload"]
                 out["metric"] = "scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame, 4 pose blocks: pose + 3 extrinsic SE3)"
+        if frame is not None:
+            out["frame"] = frame
         if s2m_ms is not None:
             out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), ms_per_frame_synchronous_maps_staged=round(s2m_staged_ms, 4), ms_per_frame_pipelined=round(s2m_pipe_ms, 4),
                                    pipelined_frames_inside_the_lookahead=int(sum(1 for x in s2m_status if x == 0)), pipelined_frames=len(s2m_status),
@@ -1145,6 +1208,48 @@ def main():
                     out["scan2map"]["pose_agreement_with_reference_lines_m"] = float(np.linalg.norm(np.array(rr["pose"][:3]) - np.array(s2m_pose[:3])))
             except Exception as ex:                       # (a checker's failure must not cost the bench line)
                 out["scan2map"]["cpu_reference_lines_error"] = str(ex)[:200]
+        if "frame" in out:
+            # the same frame through the CPU port, once: extractCloud per LiDAR -> fusion -> the plain covariance voxel filter in the std::sort member order +
+            # evalPointUncertainty + trace gate -> kd-trees -> scan2MapOptimization (checker only: the GPU frame's pose against it, and a CPU figure beside it)
+            try:
+                import time as _t
+                tf0 = _t.perf_counter()
+                lists_ = []
+                for s_ in scans:
+                    ex_ = O.extract(s_.points, s_.scan_start, s_.scan_end)
+                    lists_.append((s_.points, ex_["less_sharp"], ex_["less_flat_ds"]))
+                surf_c, corner_c = [], []
+                for i_, (pts_, ls_, lf_) in enumerate(lists_):
+                    T_ = np.eye(4); T_[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[i_][:4]); T_[:3, 3] = synth.HERCULES_BODY_T_LASER[i_][4:7]
+                    for dst_, xyz_ in ((corner_c, pts_[ls_][:, :3]), (surf_c, lf_[:, :3])):
+                        a_ = np.empty((len(xyz_), 4), np.float32)
+                        a_[:, :3] = synth.transform_points(xyz_, T_); a_[:, 3] = i_
+                        dst_.append(a_)
+                f_ext = np.array([np.concatenate([r_[4:7], r_[:4]]) for r_ in synth.HERCULES_BODY_T_LASER])[:len(scans)]
+                for e_ in f_ext:
+                    e_[3:] /= np.linalg.norm(e_[3:])
+                f_covs = np.stack([np.zeros((6, 6))] + [np.diag([0.0025] * 3 + [0.00030461] * 3)] * (len(scans) - 1))
+                feats_ = []
+                for cloud_, leaf_ in ((np.concatenate(surf_c), 0.4), (np.concatenate(corner_c), 0.2)):
+                    ds_ = O.voxel_grid_mloam_plain(cloud_, leaf_, 0)
+                    o_ = np.zeros((len(ds_), 11), np.float32); o_[:, :4] = ds_
+                    for lid_ in range(len(scans)):
+                        m_ = ds_[:, 3] == lid_
+                        R_ = synth.quat_to_rot(f_ext[lid_][3:])
+                        sel_ = ((ds_[m_, :3].astype(np.float64) - f_ext[lid_][:3]) @ R_).astype(np.float32)
+                        c_ = O.eval_point_uncertainty(sel_, f_ext[lid_], f_covs[lid_], np.diag([0.0025] * 3))
+                        o_[m_, 4:10] = np.stack([c_[:, 0, 0], c_[:, 0, 1], c_[:, 0, 2], c_[:, 1, 1], c_[:, 1, 2], c_[:, 2, 2]], axis=1)
+                    o_[:, 10] = o_[:, 4] + o_[:, 7] + o_[:, 9]
+                    feats_.append(o_[o_[:, 10] <= 0.6])
+                ms2_, mc2_ = O.Map(surf_map), O.Map(corner_map)
+                ms2_.rebuild_seconds(); mc2_.rebuild_seconds()
+                rf_ = O.scan2map(ms2_, mc2_, feats_[0], feats_[1], p0, O.mapper_params(with_ua=True))
+                out["frame"]["cpu_port_ms_per_frame"] = round(1e3 * (_t.perf_counter() - tf0), 1)
+                out["frame"]["cpu_port_thinned_features"] = dict(surf=int(len(feats_[0])), corner=int(len(feats_[1])))
+                out["frame"]["pose_vs_cpu_port_frame_m"] = float(np.linalg.norm(np.array(rf_["pose"][:3]) - np.array(out["frame"]["pose"][:3])))
+                out["frame"]["pose_vs_cpu_port_frame_rad"] = float(2.0 * np.linalg.norm(np.array(rf_["pose"][3:6]) - np.array(out["frame"]["pose"][3:6])))
+            except Exception as ex:
+                out["frame"]["cpu_port_error"] = str(ex)[:200]
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

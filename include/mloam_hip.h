@@ -208,6 +208,11 @@ int mlh_downsample_current_scan_pair(mlh_ctx *ctx, const void *surf_points, int 
  *                voxels; with uncertainty weighting that moved the frame's pose by 5 mm in scripts/framebench.py). A single-LiDAR
  *                cloud has no mixed voxels. */
 int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode);
+/* Debug aid, no reference counterpart. With MLH_CHECK_LAUNCH=1 in the environment every kernel launch of the library is followed by hipGetLastError(): a bad
+ * launch configuration is reported by the entry point that made it, as MLH_ERR_HIP with "launch of <kernel>: <error>" in mlh_last_error, instead of surfacing at
+ * a later synchronisation under another call's name. mlh_debug_bad_launch makes one launch with an impossible configuration (4096 threads per workgroup) so that
+ * the mechanism itself can be tested: MLH_ERR_HIP naming debug_noop_kernel under MLH_CHECK_LAUNCH=1, MLH_OK otherwise. */
+int mlh_debug_bad_launch(mlh_ctx *ctx);
 /* perm_out[0..n) (HOST) <- the permutation of 0..n-1 that two std::sort calls -- over [0, n0) and [n0, n), comparator on keys[] (HOST,
  * non-negative) only -- leave: mode 1 = the device restatement the voxel filters use, mode 2 = the platform's std::sort on the host. */
 int mlh_std_sort_permutation(mlh_ctx *ctx, const int32_t *keys, int n0, int n, int32_t *perm_out, int mode);

@@ -136,6 +136,7 @@ def load_library():
     lib.mlh_scan2map_begin_chained.argtypes = [vp, vp, vp, C.POINTER(SolverOpts), ci]
     lib.mlh_scan2map_end.argtypes = [vp, vp, vp]
     lib.mlh_std_sort_permutation.argtypes = [vp, vp, ci, ci, vp, ci]
+    lib.mlh_debug_bad_launch.argtypes = [vp]
     lib.mlh_pure_odom_begin.argtypes = [vp]
     lib.mlh_pure_odom_add_matches.argtypes = [vp, ci, vp, ci, C.c_uint32, cf, cf, ci, ci]
     lib.mlh_pure_odom_add_matches_gf.argtypes = [vp, ci, vp, vp, vp, vp, ci, C.c_uint32, cf, cf, ci, ci, cf, C.c_uint64, vp, C.POINTER(C.c_int32)]
@@ -174,7 +175,7 @@ EXPORTED_SYMBOLS = [
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
-    "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
+    "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_debug_bad_launch", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map", "mlh_scan2map_begin", "mlh_scan2map_begin_chained", "mlh_scan2map_end",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
     "mlh_pose_plus", "mlh_eval_degeneracy",
@@ -598,6 +599,10 @@ class Context:
     def set_gn_schedule(self, deferred_finish=True, knn_warm_start=True, final_in_successor=True):
         """layout of a Gauss-Newton solve's iterations on the device (mlh_set_gn_schedule): results do not depend on it"""
         self._ck(self.lib.mlh_set_gn_schedule(self.h, 1 if deferred_finish else 0, 1 if knn_warm_start else 0, 1 if final_in_successor else 0))
+
+    def debug_bad_launch(self):
+        """one launch with an impossible configuration: raises under MLH_CHECK_LAUNCH=1 (naming the kernel), returns otherwise"""
+        self._ck(self.lib.mlh_debug_bad_launch(self.h))
 
     def set_voxel_member_order(self, mode):
         """voxel filters of this context, members of a voxel: True / 1 = in libstdc++'s std::sort order (the reference's), produced on the

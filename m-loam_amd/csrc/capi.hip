@@ -20,6 +20,30 @@ int fail(mlh_ctx *ctx, int code, const char *what, hipError_t e)
     return code;
 }
 
+bool launch_check_enabled()
+{
+    static const bool on = std::getenv("MLH_CHECK_LAUNCH") && std::atoi(std::getenv("MLH_CHECK_LAUNCH")) != 0;
+    return on;
+}
+namespace { thread_local hipError_t t_launch_err = hipSuccess; thread_local const char *t_launch_kernel = nullptr; }
+void launch_check(const char *kernel)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && t_launch_err == hipSuccess) { t_launch_err = e; t_launch_kernel = kernel; }     // the FIRST failing launch is the one to name
+}
+hipError_t launch_check_take(const char **kernel)
+{
+    const hipError_t e = t_launch_err;
+    if (kernel) *kernel = t_launch_kernel;
+    t_launch_err = hipSuccess; t_launch_kernel = nullptr;
+    return e;
+}
+int fail_launch(mlh_ctx *ctx, const char *kernel, hipError_t e)
+{
+    if (ctx) { ctx->err = "launch of "; ctx->err += kernel ? kernel : "?"; ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+    return MLH_ERR_HIP;
+}
+
 static hipEvent_t prof_event(mlh_ctx *ctx)
 {
     Profile &p = ctx->prof;
@@ -111,7 +135,7 @@ static int stage_points(mlh_ctx *ctx, const void *points, int stride, int n, int
         MLH_HIP(ctx, hipMemcpyAsync(tmp.p, points, size_t(n) * stride, hipMemcpyHostToDevice, ctx->stream));
         src = tmp.as<unsigned char>();
     }
-    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride, n, w_off, cov_off,
+    MLH_LAUNCH(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride, n, w_off, cov_off,
                        dst.as<float4>(), covd ? covd->as<float4>() : nullptr);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -175,7 +199,7 @@ static int upload_pose(mlh_ctx *ctx, const double pose[7])
     { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
     PoseArg a;
     for (int i = 0; i < 7; ++i) a.p[i] = pose[i];
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), a);
+    MLH_LAUNCH(init_state_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), a);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -184,7 +208,7 @@ static int upload_block_pose(mlh_ctx *ctx, int b, const double pose[7])
 {
     PoseArg a;
     for (int i = 0; i < 7; ++i) a.p[i] = pose[i];
-    hipLaunchKernelGGL(set_block_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), b, a);
+    MLH_LAUNCH(set_block_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), b, a);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -204,7 +228,7 @@ hipError_t stream_flag_post(mlh_ctx *ctx, unsigned long long *seq_out)
         *ctx->h_sync = 0;
     }
     const unsigned long long seq = ++ctx->sync_seq;
-    hipLaunchKernelGGL(stream_flag_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->h_sync, seq);
+    MLH_LAUNCH(stream_flag_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->h_sync, seq);
     *seq_out = seq;
     return hipGetLastError();
 }
@@ -277,7 +301,7 @@ static int fetch_published(mlh_ctx *ctx, HostPublish &out)
     unsigned long long seq;
     int rc = publish_slot(ctx, &h, &seq);
     if (rc) return rc;
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), h, seq);
+    MLH_LAUNCH(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), h, seq);
     MLH_HIP(ctx, hipGetLastError());
     return wait_published(ctx, seq, out);
 }
@@ -894,6 +918,19 @@ int mlh_set_voxel_member_order(mlh_ctx *ctx, int mode)
     return MLH_OK;
 }
 
+__global__ void debug_noop_kernel(int *p) { if (p && threadIdx.x == 4096) *p = 0; }
+// Debug: a launch with an impossible configuration (4096 threads per workgroup). Under MLH_CHECK_LAUNCH=1 the call returns MLH_ERR_HIP and mlh_last_error names
+// debug_noop_kernel; without it the call returns MLH_OK and the runtime's sticky error is left for whoever asks next (what every launch of the library used to do).
+int mlh_debug_bad_launch(mlh_ctx *ctx)
+{
+    if (!ctx) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    MLH_LAUNCH(debug_noop_kernel, dim3(1), dim3(4096), 0, ctx->stream, (int *)nullptr);
+    MLH_HIP(ctx, hipSuccess);                 // (the check every entry point runs behind its launches)
+    if (!launch_check_enabled()) (void)hipGetLastError();      // do not leave the provoked error behind in a run that does not check launches
+    return MLH_OK;
+}
+
 int mlh_std_sort_permutation(mlh_ctx *ctx, const int32_t *keys, int n0, int n, int32_t *perm_out, int mode)
 {
     if (!ctx) return MLH_ERR_INVALID;
@@ -974,7 +1011,7 @@ int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points
     MLH_HIP(ctx, f.pts.grow(sizeof(float4) * total, sizeof(float4) * size_t(f.m), ctx->stream));
     MLH_HIP(ctx, f.covd.grow(sizeof(float4) * total, sizeof(float4) * size_t(f.m), ctx->stream));
     if (start > f.m)
-        hipLaunchKernelGGL(pad_fill_kernel, dim3((start - f.m + 255) / 256), dim3(256), 0, ctx->stream, f.pts.as<float4>(), f.covd.as<float4>(), f.m, start);
+        MLH_LAUNCH(pad_fill_kernel, dim3((start - f.m + 255) / 256), dim3(256), 0, ctx->stream, f.pts.as<float4>(), f.covd.as<float4>(), f.m, start);
     const unsigned char *src = static_cast<const unsigned char *>(points);
     if (mem == MLH_MEM_HOST && n > 0) {
         MLH_HIP(ctx, ctx->tmp.ensure(size_t(n) * stride_bytes));
@@ -982,7 +1019,7 @@ int mlh_features_set_block(mlh_ctx *ctx, int kind, int block, const void *points
         src = ctx->tmp.as<unsigned char>();
     }
     if (n > 0)
-        hipLaunchKernelGGL(pack_block_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride_bytes, n, cov_offset_bytes, float(block),
+        MLH_LAUNCH(pack_block_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, stride_bytes, n, cov_offset_bytes, float(block),
                            f.pts.as<float4>() + start, f.covd.as<float4>() + start);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1371,7 +1408,7 @@ static int gn_solve_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     if (!pose_in && !consume) {                    // chained: the start pose is made on the device from the pose the previous solve left there
         PoseArg pa, pb;
         for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
-        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, static_cast<HostPublish *>(nullptr));
+        MLH_LAUNCH(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, static_cast<HostPublish *>(nullptr));
         MLH_HIP(ctx, hipGetLastError());
     }
     // this solve's own last iteration: left to a successor (or to mlh_gn_solve_end) when the schedule says so
@@ -1651,14 +1688,14 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     if (!pose_in) {
         PoseArg pa, pb;
         for (int i = 0; i < 7; ++i) { pa.p[i] = wodom_prev[i]; pb.p[i] = wodom_cur[i]; }
-        hipLaunchKernelGGL(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, rec);
+        MLH_LAUNCH(chain_pose_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), pa, pb, rec);
         MLH_HIP(ctx, hipGetLastError());
     }
     // scan2MapOptimization runs only when the map has > 50 surf and > 10 corner points (lidar_mapper_keyframe.cpp:429): otherwise the start pose is the result
     if (!have_maps) {
         slot.kind = 2;
         if (!pose_in) {          // chained: the start pose exists on the device only
-            hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), rec, seq);
+            MLH_LAUNCH(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, (const SolverState *)ctx->state.as<SolverState>(), rec, seq);
             MLH_HIP(ctx, hipGetLastError());
         }
         ctx->solve_seq = seq; ctx->solve_pending = true;
@@ -1779,7 +1816,7 @@ static int track_stage_prev(mlh_ctx *ctx, int kind, const void *points, int stri
     const unsigned char *d_src = (mem == MLH_MEM_HOST) ? ctx->tmp.as<unsigned char>() : static_cast<const unsigned char *>(points);
     // second copy in the original order with the ring id in w: what the scan-line walks stream over
     MLH_HIP(ctx, T.walk[kind].ensure(sizeof(float4) * size_t(n)));
-    hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride_bytes, n, intensity_offset_bytes, -1,
+    MLH_LAUNCH(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride_bytes, n, intensity_offset_bytes, -1,
                        T.walk[kind].as<float4>(), (float4 *)nullptr);
     if ((rc = track_set_prev_rings(ctx, kind, d_src, stride_bytes, n, intensity_offset_bytes, host_bad))) return rc;
     g.n = n;
@@ -2009,7 +2046,7 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
         float *h_box = reinterpret_cast<float *>(static_cast<char *>(ctx->fused_host) + 16);
         unsigned long long *h_seq = reinterpret_cast<unsigned long long *>(static_cast<char *>(ctx->fused_host) + 64);
         const unsigned long long seq = ++ctx->fused_seq;
-        hipLaunchKernelGGL(fused_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int *)(ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts),
+        MLH_LAUNCH(fused_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int *)(ctx->fused_cnt.as<int>() + 2 * ctx->fused_parts),
                            (const float *)ctx->fused_part.as<float>(), FUSE_BLOCKS, ctx->fused_parts, h_cnt, h_box, h_seq, seq);
         MLH_HIP(ctx, hipGetLastError());
         {

@@ -89,7 +89,7 @@ static int p2p_allreduce(mlh_ctx *ctx, double *buf, int n)
     P2pArgs a;
     p2p_fill(ctx, a.d);
     a.buf = buf; a.n = n;
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+    MLH_LAUNCH(p2p_allreduce_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

@@ -364,10 +364,28 @@ namespace mlh {
 
 int fail(mlh_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 
+// MLH_CHECK_LAUNCH=1 (debug runs): hipGetLastError() right behind EVERY kernel launch, so that a bad launch configuration is reported under the name of the kernel
+// that caused it instead of surfacing at the next synchronisation under another call's name. The error is sticky for the calling thread: the next MLH_HIP check
+// (every entry point runs several) returns MLH_ERR_HIP with "launch of <kernel>: <hip error>". Off (the default) the launches are followed by nothing.
+bool launch_check_enabled();
+void launch_check(const char *kernel);
+hipError_t launch_check_take(const char **kernel);      // this thread's sticky launch error (hipSuccess when none); cleared by the call
+int fail_launch(mlh_ctx *ctx, const char *kernel, hipError_t e);
+#define MLH_LAUNCH(kern, grid, block, lds, st, ...)                                \
+    do {                                                                           \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);               \
+        if (::mlh::launch_check_enabled()) ::mlh::launch_check(#kern);             \
+    } while (0)
+
 #define MLH_HIP(ctx, expr)                                                         \
     do {                                                                           \
         hipError_t _e = (expr);                                                    \
         if (_e != hipSuccess) return ::mlh::fail((ctx), MLH_ERR_HIP, #expr, _e);   \
+        if (::mlh::launch_check_enabled()) {                                       \
+            const char *_k = nullptr;                                              \
+            const hipError_t _le = ::mlh::launch_check_take(&_k);                  \
+            if (_le != hipSuccess) return ::mlh::fail_launch((ctx), _k, _le);      \
+        }                                                                          \
     } while (0)
 
 // profiling brackets (HIP events on the context's stream)

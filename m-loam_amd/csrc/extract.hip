@@ -520,19 +520,19 @@ int extract_run(mlh_ctx *ctx)
     MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(label_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 
     prof_begin(ctx, MLH_K_EXTRACT);
-    hipLaunchKernelGGL(curvature_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sb.pts.as<float4>(), n, sb.curvature.as<float>(),
+    MLH_LAUNCH(curvature_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sb.pts.as<float4>(), n, sb.curvature.as<float>(),
                        sb.label.as<int>(), sb.picked.as<int>());
     LabelArgs la;
     la.pts = sb.pts.as<float4>(); la.curv = sb.curvature.as<float>(); la.start = sb.start.as<int>(); la.end = sb.end_ptr();
     la.label = sb.label.as<int>(); la.picked = sb.picked.as<int>(); la.stage = sb.stage.as<int>(); la.ring_counts = sb.ring_counts.as<int>();
     la.n = n; la.max_span = max_span; la.sort_p = P;
     la.tie_ref = ctx->extract_tie_ref ? 1 : 0; la.tie_words = tie_words; la.tie_scratch = tie_scratch;
-    hipLaunchKernelGGL(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
+    MLH_LAUNCH(label_kernel, dim3(R), dim3(LTPB), lds, st, la);
     EmitArgs ea;
     ea.start = sb.start.as<int>(); ea.end = sb.end_ptr(); ea.label = sb.label.as<int>(); ea.stage = sb.stage.as<int>();
     ea.ring_counts = sb.ring_counts.as<int>(); ea.ring_offsets = sb.ring_offsets.as<int>(); ea.totals = sb.totals.as<int>(); ea.n_rings = R;
     ea.list0 = sb.lists[0].as<int>(); ea.list1 = sb.lists[1].as<int>(); ea.list2 = sb.lists[2].as<int>(); ea.list3 = sb.lists[3].as<int>();
-    hipLaunchKernelGGL(emit_kernel, dim3(R), dim3(256), 0, st, ea);
+    MLH_LAUNCH(emit_kernel, dim3(R), dim3(256), 0, st, ea);
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
     sb.extracted = true;

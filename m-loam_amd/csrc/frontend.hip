@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__rest
 
 void gather_points_launch(mlh_ctx *ctx, const float4 *pts, const int *list, int n, float4 *out)
 {
-    hipLaunchKernelGGL(gather_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pts, list, n, out);
+    MLH_LAUNCH(gather_points_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pts, list, n, out);
 }
 
 // pcl::transformPointCloud(cloud, cloud, pose.T_.cast<float>()) in place: p' = R p + t in single precision (R rounded once from the
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(unsigned char *p, 
 int transform_cloud_launch(mlh_ctx *ctx, void *dev, int stride, int n, const double pose[7])
 {
     if (n <= 0) return MLH_OK;
-    hipLaunchKernelGGL(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<unsigned char *>(dev), stride, n, xf_from_pose(pose, 0.f));
+    MLH_LAUNCH(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, static_cast<unsigned char *>(dev), stride, n, xf_from_pose(pose, 0.f));
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -100,7 +100,7 @@ int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int inte
     A.p = static_cast<unsigned char *>(dev); A.stride = stride; A.n = n; A.intensity_off = intensity_off; A.b_distortion = b_distortion;
     A.scan_period = scan_period;
     for (int i = 0; i < 7; ++i) A.pose[i] = pose[i];
-    hipLaunchKernelGGL(transform_to_end_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A);
+    MLH_LAUNCH(transform_to_end_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -179,7 +179,7 @@ int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     MLH_HIP(ctx, ctx->fused_part.grow(sizeof(float) * part_floats * size_t(ctx->fused_parts + 1), sizeof(float) * part_floats * size_t(ctx->fused_parts), st));
     A.part = ctx->fused_part.as<float>() + part_floats * size_t(ctx->fused_parts);
     ++ctx->fused_parts;
-    hipLaunchKernelGGL(fuse_append_kernel, dim3(FUSE_BLOCKS, 2), dim3(256), 0, st, A);
+    MLH_LAUNCH(fuse_append_kernel, dim3(FUSE_BLOCKS, 2), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

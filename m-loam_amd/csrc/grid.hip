@@ -305,7 +305,7 @@ static int bounds_launch(mlh_ctx *ctx, MapGrid &g, int *hp)
     hipStream_t st = ctx->stream;
     const int grid_pts = std::min((g.n + 255) / 256, BOUNDS_BLOCKS);
     MLH_HIP(ctx, g.bounds.ensure(6 * BOUNDS_BLOCKS * sizeof(int)));
-    hipLaunchKernelGGL(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), g.n, g.bounds.as<int>());
+    MLH_LAUNCH(bounds_kernel, dim3(grid_pts), dim3(256), 0, st, g.raw.as<float4>(), g.n, g.bounds.as<int>());
     MLH_HIP(ctx, hipMemcpyAsync(hp, g.bounds.p, sizeof(int) * 6 * size_t(grid_pts), hipMemcpyDeviceToHost, st));
     return MLH_OK;
 }
@@ -391,12 +391,12 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
     if (nj == 0) return MLH_OK;
     const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);
-    if (G.j[0].need_zero || G.j[1].need_zero) hipLaunchKernelGGL(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(scan_local_kernel, dim3(nb_scan), dim3(256), 0, st, G);
-    if (G.j[0].sums_scanned || G.j[1].sums_scanned) hipLaunchKernelGGL(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb_scan), dim3(256), 0, st, G);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nb_pts), dim3(256), 0, st, G);
+    if (G.j[0].need_zero || G.j[1].need_zero) MLH_LAUNCH(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    MLH_LAUNCH(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
+    MLH_LAUNCH(scan_local_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    if (G.j[0].sums_scanned || G.j[1].sums_scanned) MLH_LAUNCH(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
+    MLH_LAUNCH(scan_add_kernel, dim3(nb_scan), dim3(256), 0, st, G);
+    MLH_LAUNCH(scatter_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     prof_end(ctx, MLH_K_GRID_BUILD);
     MLH_HIP(ctx, hipGetLastError());
     for (int k = 0; k < nj; ++k) grids[k]->built = true;
@@ -463,13 +463,13 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         J.hi[0] = reuse ? g.ox + float(g.nx) * g.h : INFINITY; J.hi[1] = reuse ? g.oy + float(g.ny) * g.h : INFINITY;
         J.hi[2] = reuse ? g.oz + float(g.nz) * g.h : INFINITY;
     }
-    hipLaunchKernelGGL(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
+    MLH_LAUNCH(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
     // the fit flags are final once the clouds are packed: they leave for the host NOW, and the optimistic index build of the kinds whose
     // geometry is reused is enqueued behind them -- the host learns the outcome (and can go on enqueueing the frame's solver launches)
     // while the GPU is still building the index, instead of the GPU idling through the host's reaction time after the build. When such a
     // build follows, its first launch carries the publication (one thread of its first workgroup); otherwise a launch of its own does.
     const bool build_follows = need_bounds != ((1 << n_maps) - 1);
-    if (!build_follows) hipLaunchKernelGGL(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
+    if (!build_follows) MLH_LAUNCH(publish_flag_kernel, dim3(1), dim3(64), 0, st, G.oob, pub, seq);
     MLH_HIP(ctx, hipGetLastError());
     if (!ctx->h_occ) {
         MLH_HIP(ctx, hipHostMalloc(&ctx->h_occ, sizeof(long long) * 4, hipHostMallocDefault));

@@ -1073,10 +1073,11 @@ template <typename Kern>
 static void launch_timed(mlh_ctx *ctx, int kid, Kern kern, int grid, const KParams &P)
 {
     hipEvent_t a = nullptr, b = nullptr;
-    if (prof_kernel_events(ctx, kid, &a, &b))
+    if (prof_kernel_events(ctx, kid, &a, &b)) {
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, a, b, 0, P);   // start/stop = the dispatch's own timestamps
-    else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->stream, P);
+        if (launch_check_enabled()) launch_check("correspondence / fit / linearise kernel (event-bracketed launch)");
+    } else
+        MLH_LAUNCH(kern, dim3(grid), dim3(TPB), 0, ctx->stream, P);
 }
 
 int gn_flush_pending(mlh_ctx *ctx)
@@ -1182,7 +1183,7 @@ int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx
     MLH_HIP(ctx, ctx->knn_d.ensure(sizeof(float) * 5 * size_t(nq)));
     MLH_HIP(ctx, hipMemcpyAsync(ctx->knn_q.p, q_host, sizeof(float) * 3 * size_t(nq), hipMemcpyHostToDevice, ctx->stream));
     const int grid = (nq + TPB / 8 - 1) / (TPB / 8);
-    hipLaunchKernelGGL(knn_queries_kernel, dim3(grid), dim3(TPB), 0, ctx->stream, mg.dev(), ctx->knn_q.as<float>(), nq,
+    MLH_LAUNCH(knn_queries_kernel, dim3(grid), dim3(TPB), 0, ctx->stream, mg.dev(), ctx->knn_q.as<float>(), nq,
                        ctx->knn_idx.as<int>(), ctx->knn_d.as<float>());
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(idx, ctx->knn_idx.p, sizeof(int) * 5 * size_t(nq), hipMemcpyDeviceToHost, ctx->stream));

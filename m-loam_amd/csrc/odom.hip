@@ -170,7 +170,7 @@ int pure_odom_feature_rows(mlh_ctx *ctx, int kind, const double pivot[7], const 
     A.feat = f.pts.as<float4>(); A.corr = f.corr.as<Corr>(); A.m = f.m; A.type = kind;
     for (int k = 0; k < 7; ++k) { A.poses[k] = pivot[k]; A.poses[7 + k] = pose_i[k]; A.poses[14 + k] = ext[k]; }
     A.J6 = f.J.as<double>(); A.valid = f.flag8.as<uint8_t>();
-    hipLaunchKernelGGL(odom_feat_rows_kernel, dim3((f.m + 255) / 256), dim3(256), 0, ctx->stream, A);
+    MLH_LAUNCH(odom_feat_rows_kernel, dim3((f.m + 255) / 256), dim3(256), 0, ctx->stream, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -418,7 +418,7 @@ int pure_odom_add_matches(mlh_ctx *ctx, int kind, int frame_idx, int ext_idx)
     OdomAppend P;
     P.feat = f.pts.as<float4>(); P.corr = f.corr.as<Corr>(); P.m = f.m; P.type = kind; P.frame = frame_idx; P.ext = ext_idx;
     P.base_slot = base_slot; P.cap_slots = cap_slots; P.tab = O.tab.as<double>(); P.idx = O.idx.as<int>(); P.perm = O.perm.as<int>();
-    hipLaunchKernelGGL(odom_append_kernel, dim3(1), dim3(1024), 0, st, P);
+    MLH_LAUNCH(odom_append_kernel, dim3(1), dim3(1024), 0, st, P);
     MLH_HIP(ctx, hipGetLastError());
     O.n = n_new; O.n_tiles += cap_tiles;
     O.max_frame = std::max(O.max_frame, frame_idx); O.max_ext = std::max(O.max_ext, ext_idx);
@@ -449,7 +449,7 @@ int pure_odom_evaluate(mlh_ctx *ctx, const double pivot[7], const double *frames
     A.tab = O.tab.as<double>(); A.idx = O.idx.as<int>();
     A.pivot = O.poses.as<double>(); A.frames = A.pivot + 7; A.exts = A.frames + 7 * size_t(n_frames);
     A.n = O.n; A.n_frames = n_frames; A.n_ext = n_ext; A.r = O.r.as<double>(); A.J = jacobians ? O.J.as<double>() : nullptr;
-    hipLaunchKernelGGL(pure_odom_kernel, dim3((O.n + 255) / 256), dim3(256), 0, st, A);
+    MLH_LAUNCH(pure_odom_kernel, dim3((O.n + 255) / 256), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(residuals, O.r.p, sizeof(double) * size_t(O.n), hipMemcpyDeviceToHost, st));
     if (jacobians) MLH_HIP(ctx, hipMemcpyAsync(jacobians, O.J.p, sizeof(double) * 21 * size_t(O.n), hipMemcpyDeviceToHost, st));
@@ -508,11 +508,11 @@ static int odom_ne_prepare(mlh_ctx *ctx, const double pivot[7], const double *fr
 static void odom_ne_enqueue(mlh_ctx *ctx, const OdomNeArgs &G, int n_frames, int n_ext, size_t n_out)
 {
     OdomSet &O = ctx->odom;
-    hipLaunchKernelGGL(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, ctx->stream, G);
+    MLH_LAUNCH(odom_ne_kernel, dim3(O.n_tiles), dim3(256), 0, ctx->stream, G);
     OdomNeFinish F;
     F.partial = O.partial.as<double>(); F.tile_group = O.tile_group.as<int>(); F.n_tiles = O.n_tiles; F.n_frames = n_frames; F.n_ext = n_ext;
     F.out = O.ne_out.as<double>();
-    hipLaunchKernelGGL(odom_ne_finish_kernel, dim3(1), dim3(256), n_out * sizeof(double), ctx->stream, F);
+    MLH_LAUNCH(odom_ne_finish_kernel, dim3(1), dim3(256), n_out * sizeof(double), ctx->stream, F);
 }
 
 int pure_odom_normal_eq(mlh_ctx *ctx, const double pivot[7], const double *frames, int n_frames, const double *exts, int n_ext, double huber_delta,
@@ -650,7 +650,7 @@ int pure_odom_gn_solve(mlh_ctx *ctx, const double pivot[7], double *frames, int 
     S.ne = O.ne_out.as<double>(); S.poses = O.poses.as<double>(); S.V = V_update ? O.solve_aux.as<double>() : nullptr; S.n_blocks = nb; S.free_mask = free_mask; S.status = d_status;
     for (int it = 0; it < n_iters; ++it) {
         odom_ne_enqueue(ctx, G, n_frames, n_ext, n_out);
-        hipLaunchKernelGGL(odom_window_solve_kernel, dim3(1), dim3(256), lds, st, S);
+        MLH_LAUNCH(odom_window_solve_kernel, dim3(1), dim3(256), lds, st, S);
     }
     MLH_HIP(ctx, hipGetLastError());
     std::vector<double> hp(7 * size_t(nb)), hne(2);

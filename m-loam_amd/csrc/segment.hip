@@ -342,7 +342,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     D.unc_count = B.unc.as<int>();
     D.unc_pts = reinterpret_cast<float4 *>(B.unc.as<unsigned char>() + 16);
     D.unc_gnd = D.unc_pts + n;
-    hipLaunchKernelGGL(seg_project_kernel, dim3((n + 255) / 256), dim3(256), 0, st, D);
+    MLH_LAUNCH(seg_project_kernel, dim3((n + 255) / 256), dim3(256), 0, st, D);
     MLH_HIP(ctx, hipGetLastError());
     int n_undecided_pts = 0;
     {
@@ -368,11 +368,11 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
             }
             MLH_HIP(ctx, B.fix.ensure(sizeof(int2) * size_t(n_undecided_pts)));
             MLH_HIP(ctx, hipMemcpyAsync(B.fix.p, fix, sizeof(int2) * size_t(n_undecided_pts), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(seg_apply_fix_kernel, dim3((n_undecided_pts + 255) / 256), dim3(256), 0, st, (const int2 *)B.fix.as<int2>(), n_undecided_pts, D.pix, D.owner);
+            MLH_LAUNCH(seg_apply_fix_kernel, dim3((n_undecided_pts + 255) / 256), dim3(256), 0, st, (const int2 *)B.fix.as<int2>(), n_undecided_pts, D.pix, D.owner);
         }
     }
-    hipLaunchKernelGGL(seg_owner_fix_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D.owner, npx);
-    hipLaunchKernelGGL(seg_image_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D);
+    MLH_LAUNCH(seg_owner_fix_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D.owner, npx);
+    MLH_LAUNCH(seg_image_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, D);
     MLH_HIP(ctx, hipGetLastError());
     // MLH_SEG_TIMING=1: one line per call on stderr with the wall time of the call's phases (how much the host hop of the cluster search costs)
     static const bool seg_timing = std::getenv("MLH_SEG_TIMING") != nullptr;
@@ -509,7 +509,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     MLH_HIP(ctx, B.keep.ensure(sizeof(int) * size_t(std::max(n_keep, 1))));
     if (n_keep > 0) {
         MLH_HIP(ctx, hipMemcpyAsync(B.keep.p, keep.data(), sizeof(int) * size_t(n_keep), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(seg_gather_kernel, dim3((n_keep + 255) / 256), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), n_keep, sb.pts.as<float4>());
+        MLH_LAUNCH(seg_gather_kernel, dim3((n_keep + 255) / 256), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), n_keep, sb.pts.as<float4>());
         MLH_HIP(ctx, hipGetLastError());
     }
     MLH_HIP(ctx, hipMemcpyAsync(sb.start.p, hstart.data(), sizeof(int) * size_t(vs), hipMemcpyHostToDevice, st));

@@ -430,7 +430,7 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt
         ctx->select_host_cap[kind] = need + need / 4;
     }
     MLH_HIP(ctx, f.flag8.ensure(mp));
-    hipLaunchKernelGGL(pack_valid_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>());
+    MLH_LAUNCH(pack_valid_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>());
     MLH_HIP(ctx, hipGetLastError());
     char *hb = static_cast<char *>(ctx->select_host[kind]);
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
@@ -443,7 +443,7 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt
         static const bool fps_on_host = std::getenv("MLH_FPS_HOST") != nullptr;          // (measurement only: the host loop on every call)
         if (m <= size_t(FPS_THREADS) * FPS_PMAX && !fps_on_host) {
             MLH_HIP(ctx, f.fps_order.ensure(sizeof(int) * (m + 1)));
-            hipLaunchKernelGGL(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
+            MLH_LAUNCH(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
                                int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
             MLH_HIP(ctx, hipGetLastError());
             MLH_HIP(ctx, hipMemcpyAsync(hb + off_o, f.fps_order.p, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -514,7 +514,7 @@ int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::m
         int dup_count = 0;                                            // only feature 1 can be picked more than once (fps_after_exhaustion)
         for (size_t i : sel) { keep[i] = 1; dup_count += (i == 1) ? 1 : 0; }
         MLH_HIP(ctx, hipMemcpyAsync(f.flag8.p, keep, m, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(),
+        MLH_LAUNCH(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(),
                            dup_count > 1 ? 1 : -1, dup_count);
         MLH_HIP(ctx, hipGetLastError());
     }
@@ -622,7 +622,7 @@ int odom_good_feature_select(mlh_ctx *ctx, int kind, float gf_ratio, std::mt1993
     std::memset(keep, 0, m);
     for (size_t i : sel) keep[i] = 1;
     MLH_HIP(ctx, hipMemcpyAsync(f.flag8.p, keep, m, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(), -1, 0);
+    MLH_LAUNCH(apply_keep_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, f.corr.as<Corr>(), int(m), f.flag8.as<uint8_t>(), -1, 0);
     MLH_HIP(ctx, hipGetLastError());
     sel_out.assign(sel.begin(), sel.end());
     return MLH_OK;

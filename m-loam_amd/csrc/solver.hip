@@ -98,7 +98,7 @@ static IterStatDev *stat_ptr(mlh_ctx *ctx, int slot)
 
 int reduce_only_launch(mlh_ctx *ctx, int to_ce)
 {
-    hipLaunchKernelGGL(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), to_ce);
+    MLH_LAUNCH(reduce_only_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), to_ce);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -118,7 +118,7 @@ static int pre_reduce(mlh_ctx *ctx, int to_ce, int &pre_reduced)
 int gn_update_prereduced_launch(mlh_ctx *ctx, double map_eig_thre, int stat_slot)
 {
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
+    MLH_LAUNCH(gn_update_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
                        map_eig_thre, stat_ptr(ctx, stat_slot), 1);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
@@ -131,7 +131,7 @@ int gn_update_blocks_prereduced_launch(mlh_ctx *ctx, int n_blocks, const double 
     U.n = n_blocks;
     for (int b = 0; b < 8; ++b) { U.thre[b] = b < n_blocks ? eig_thre[b] : 0.0; U.freeze[b] = b < n_blocks ? freeze[b] : 0; }
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(gn_update_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->state.as<SolverState>(), U, stat_ptr(ctx, stat_slot));
+    MLH_LAUNCH(gn_update_blocks_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->state.as<SolverState>(), U, stat_ptr(ctx, stat_slot));
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -145,7 +145,7 @@ int lm_begin_launch(mlh_ctx *ctx, double map_eig_thre, int max_iterations, int s
     ip.use = init_pose ? 1 : 0;
     for (int i = 0; i < 7; ++i) ip.x[i] = init_pose ? init_pose[i] : 0.0;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
+    MLH_LAUNCH(lm_begin_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(),
                        map_eig_thre, max_iterations, stat_ptr(ctx, stat_slot), pre, min_blocks, ip);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
@@ -158,7 +158,7 @@ int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot)
     int pre = 0, rc = pre_reduce(ctx, 1, pre);
     if (rc) return rc;
     prof_begin(ctx, MLH_K_SOLVE);
-    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), max_iterations, pre);
+    MLH_LAUNCH(lm_step_kernel, dim3(1), dim3(256), 0, ctx->stream, make_sum_args(ctx), ctx->state.as<SolverState>(), max_iterations, pre);
     prof_end(ctx, MLH_K_SOLVE);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -166,7 +166,7 @@ int lm_step_launch(mlh_ctx *ctx, int max_iterations, int stat_slot)
 
 int lm_finish_launch(mlh_ctx *ctx, int stat_slot)
 {
-    hipLaunchKernelGGL(lm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), stat_ptr(ctx, stat_slot));
+    MLH_LAUNCH(lm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->state.as<SolverState>(), stat_ptr(ctx, stat_slot));
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

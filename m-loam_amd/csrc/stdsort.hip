@@ -58,11 +58,25 @@ __device__ unsigned long long g_stage_clk_sort2[1024 * 8];
 
 namespace {
 
-constexpr int SS_LEAF = 2048;         // ranges up to this many elements are finished in LDS by one workgroup
+// (the MLH_SS_* macros: A/B builds of scripts/build_variant.py; the defaults are what ships)
+#ifndef MLH_SS_LEAF
+#define MLH_SS_LEAF 2048
+#endif
+#ifndef MLH_SS_BIG_U
+#define MLH_SS_BIG_U 4
+#endif
+#ifndef MLH_SS_BIG_LEVELS
+#define MLH_SS_BIG_LEVELS 12
+#endif
+#ifndef MLH_SS_SWAP_U
+#define MLH_SS_SWAP_U 4
+#endif
+constexpr int SS_LEAF = MLH_SS_LEAF;  // ranges up to this many elements are finished in LDS by one workgroup
 constexpr int SS_BIG_WG = 1024;
 constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
-constexpr int SS_BIG_U = 4;           // 64-wide tiles a wavefront of a big level keeps in flight
-constexpr int SS_BIG_LEVELS = 12;
+constexpr int SS_BIG_U = MLH_SS_BIG_U;           // 64-wide tiles a wavefront of a big level keeps in flight
+constexpr int SS_SWAP_U = MLH_SS_SWAP_U;         // swaps a thread of a big level keeps in flight
+constexpr int SS_BIG_LEVELS = MLH_SS_BIG_LEVELS;
 constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the root + one per partition with two children > 16
 
@@ -183,14 +197,14 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *
     }
     __syncthreads();
     const int K = *sh_k;
-    for (int k0 = t; k0 < K; k0 += 4 * SS_BIG_WG) {              // four swaps in flight: positions, then the eight elements, then the stores
-        int p[4], q[4], kp[4], kq[4], vp[4], vq[4];
+    for (int k0 = t; k0 < K; k0 += SS_SWAP_U * SS_BIG_WG) {      // SS_SWAP_U swaps in flight: positions, then the elements, then the stores
+        int p[SS_SWAP_U], q[SS_SWAP_U], kp[SS_SWAP_U], kq[SS_SWAP_U], vp[SS_SWAP_U], vq[SS_SWAP_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? left_at(k) : -1; q[u] = on ? right_at(k) : -1; }
+        for (int u = 0; u < SS_SWAP_U; ++u) { const int k = k0 + u * SS_BIG_WG; const bool on = k < K; p[u] = on ? left_at(k) : -1; q[u] = on ? right_at(k) : -1; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (p[u] >= 0) { kp[u] = keys[p[u]]; kq[u] = keys[q[u]]; vp[u] = vals[p[u]]; vq[u] = vals[q[u]]; }
+        for (int u = 0; u < SS_SWAP_U; ++u) if (p[u] >= 0) { kp[u] = keys[p[u]]; kq[u] = keys[q[u]]; vp[u] = vals[p[u]]; vq[u] = vals[q[u]]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (p[u] >= 0) { keys[p[u]] = kq[u]; keys[q[u]] = kp[u]; vals[p[u]] = vq[u]; vals[q[u]] = vp[u]; }
+        for (int u = 0; u < SS_SWAP_U; ++u) if (p[u] >= 0) { keys[p[u]] = kq[u]; keys[q[u]] = kp[u]; vals[p[u]] = vq[u]; vals[q[u]] = vp[u]; }
     }
     int cut = INT_MAX;
     if (t == 0) {
@@ -409,10 +423,10 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
     if (n_levels > 0) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
         for (int level = 0; level < n_levels; ++level)
-            hipLaunchKernelGGL(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
+            MLH_LAUNCH(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
     }
     const int grid_leaf = int(std::min<size_t>(nleaf, 1024));
-    hipLaunchKernelGGL(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);
+    MLH_LAUNCH(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -426,7 +440,7 @@ int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int
     size_t nbig, nleaf;
     int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
     if (rc) return rc;
-    hipLaunchKernelGGL(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0);
+    MLH_LAUNCH(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0);
     return stdsort_levels(ctx, A, std::max(n0, n - n0), nbig, nleaf);
 }
 
@@ -458,8 +472,8 @@ int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *count
     int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
     if (rc) return rc;
     // one thread per segment appends its range: the counters start at zero
-    if (!counters_cleared) hipLaunchKernelGGL(stdsort_clear_counters_kernel, dim3(1), dim3(64), 0, ctx->stream, A.cnt);
-    hipLaunchKernelGGL(stdsort_init_segments_kernel, dim3((std::max(n, n_segments) + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field,
+    if (!counters_cleared) MLH_LAUNCH(stdsort_clear_counters_kernel, dim3(1), dim3(64), 0, ctx->stream, A.cnt);
+    MLH_LAUNCH(stdsort_init_segments_kernel, dim3((std::max(n, n_segments) + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, counts, offsets, stride, field,
                        n_segments);
     return stdsort_levels(ctx, A, longest, nbig, nleaf);
 }

@@ -477,8 +477,8 @@ int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int
     MLH_HIP(ctx, T.ring[kind].ensure(sizeof(int) * size_t(n)));
     MLH_HIP(ctx, T.ring_start[kind].ensure(sizeof(int) * (TRACK_RING_SLOTS + 1)));
     int *bad = T.ring_start[kind].as<int>() + TRACK_RING_SLOTS;
-    hipLaunchKernelGGL(fill_int_kernel, dim3((TRACK_RING_SLOTS + 1 + 255) / 256), dim3(256), 0, ctx->stream, T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, n);   // (also clears the flag)
-    hipLaunchKernelGGL(track_rings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride, n, intensity_off, T.ring[kind].as<int>(),
+    MLH_LAUNCH(fill_int_kernel, dim3((TRACK_RING_SLOTS + 1 + 255) / 256), dim3(256), 0, ctx->stream, T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, n);   // (also clears the flag)
+    MLH_LAUNCH(track_rings_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, stride, n, intensity_off, T.ring[kind].as<int>(),
                        T.ring_start[kind].as<int>(), TRACK_RING_SLOTS, bad);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -527,7 +527,7 @@ int track_match_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
     TrackParamsDev P;
     int rc = fill_track_params(ctx, kind_mask, a, P);
     if (rc) return rc;
-    hipLaunchKernelGGL(track_match_kernel, dim3(P.k[0].tiles_a + P.k[1].tiles_a), dim3(TPB), 0, ctx->stream, P);
+    MLH_LAUNCH(track_match_kernel, dim3(P.k[0].tiles_a + P.k[1].tiles_a), dim3(TPB), 0, ctx->stream, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }
@@ -537,7 +537,7 @@ int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
     TrackParamsDev P;
     int rc = fill_track_params(ctx, kind_mask, a, P);
     if (rc) return rc;
-    hipLaunchKernelGGL(track_linearize_kernel, dim3(P.k[0].tiles_b + P.k[1].tiles_b), dim3(TPB), 0, ctx->stream, P);
+    MLH_LAUNCH(track_linearize_kernel, dim3(P.k[0].tiles_b + P.k[1].tiles_b), dim3(TPB), 0, ctx->stream, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

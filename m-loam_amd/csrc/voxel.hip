@@ -191,7 +191,7 @@ static hipError_t ring_voxel_launch(const RingVoxelArgs &A, int R, hipStream_t s
     const size_t lds = size_t(RV_TPB) * KPL * (sizeof(unsigned long long) + (PTS_IN_LDS ? sizeof(float4) : 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ring_voxel_kernel<KPL, PTS_IN_LDS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ring_voxel_kernel<KPL, PTS_IN_LDS, MODE>), dim3(R), dim3(RV_TPB), lds, st, A);
+    MLH_LAUNCH((ring_voxel_kernel<KPL, PTS_IN_LDS, MODE>), dim3(R), dim3(RV_TPB), lds, st, A);
     return hipSuccess;
 }
 template <int MODE>
@@ -234,7 +234,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     } else {
         MLH_HIP(ctx, ring_voxel_launch_any<0>(A, R, longest, st));
     }
-    hipLaunchKernelGGL(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, (const float4 *)sb.vox_stage.as<float4>(), (const int *)sb.ring_offsets.as<int>(),
+    MLH_LAUNCH(ring_vox_compact_kernel, dim3(R), dim3(256), 0, st, (const float4 *)sb.vox_stage.as<float4>(), (const int *)sb.ring_offsets.as<int>(),
                        (const int *)sb.ring_vox.as<int>(), R, sb.ring_vox.as<int>() + R, sb.vox_out.as<float4>());
     prof_end(ctx, MLH_K_EXTRACT);
     MLH_HIP(ctx, hipGetLastError());
@@ -392,7 +392,7 @@ int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, i
     A.trace_thr = trace_thr; A.cov6 = d_c6; A.keep = d_keep;
     A.upose = d_ext; A.upose_cov = d_cov; A.rec_out = nullptr; A.cov_off = A.trace_off = -1; A.with_ua = 1;
     for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
-    hipLaunchKernelGGL(point_uncertainty_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
+    MLH_LAUNCH(point_uncertainty_kernel, dim3((n + 255) / 256), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     MLH_HIP(ctx, hipMemcpyAsync(cov6_host, d_c6, sizeof(float) * 6 * size_t(n), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(keep_host, d_keep, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, st));
@@ -482,7 +482,7 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
     for (int i = 0; i < 7; ++i) A.gpose[i] = pose_global[i];
     A.cov_off = cov_off; A.trace_off = trace_off; A.with_ua = with_ua ? 1 : 0;
     const int nb = (n + 255) / 256;
-    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    MLH_LAUNCH(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipMemcpyAsync(V.vox_of.p, V.leader.p, sizeof(int) * size_t(n), hipMemcpyDeviceToDevice, st));
     int rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>());
     if (rc) return rc;
@@ -491,7 +491,7 @@ int cloud_uct_associate_run(mlh_ctx *ctx, const void *points, int stride, int n,
         MLH_HIP(ctx, V.in.ensure(size_t(n) * stride));
         dst = V.in.as<unsigned char>();
     }
-    hipLaunchKernelGGL(compact_records_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), (const int *)V.leader.as<int>(),
+    MLH_LAUNCH(compact_records_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), (const int *)V.leader.as<int>(),
                        (const int *)V.vox_of.as<int>(), n, stride, dst);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
@@ -562,11 +562,11 @@ int downsample_current_scan_run(mlh_ctx *ctx, const void *points, int stride, in
     A.keep2 = V.vox_of.as<int>();
     for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
     const int nb = (n + 255) / 256;
-    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    MLH_LAUNCH(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
     if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>() + 1))) { (void)hipStreamSynchronize(st); return rc; }
     MLH_HIP(ctx, pts_out.ensure(sizeof(float4) * size_t(n)));
     MLH_HIP(ctx, covd_out.ensure(sizeof(float4) * size_t(n)));
-    hipLaunchKernelGGL(features_from_kept_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
+    MLH_LAUNCH(features_from_kept_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
                        (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(), (const float *)d_c6, pts_out.as<float4>(), covd_out.as<float4>(), out11_dev);
     MLH_HIP(ctx, hipGetLastError());
     int total = 0;
@@ -641,7 +641,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
     A.keep2 = V.vox_of.as<int>();
     for (int i = 0; i < 7; ++i) A.gpose[i] = 0.0;
     const int nb = (n + 255) / 256;
-    hipLaunchKernelGGL(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
+    MLH_LAUNCH(point_uncertainty_kernel, dim3(nb), dim3(256), 0, st, A);
     if ((rc = device_exclusive_scan(ctx, V.vox_of.as<int>(), n, V.sums, V.total.as<int>() + 1))) { (void)hipStreamSynchronize(st); return rc; }
     FeatSet &f0 = ctx->feat[MLH_SURF], &f1 = ctx->feat[MLH_CORNER];
     MLH_HIP(ctx, f0.pts.ensure(sizeof(float4) * size_t(n_surf))); MLH_HIP(ctx, f0.covd.ensure(sizeof(float4) * size_t(n_surf)));
@@ -655,7 +655,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
         if (ctx->counts_seq == 0) *h_seq = 0;
         seq = ++ctx->counts_seq;
     }
-    hipLaunchKernelGGL(features_from_kept_pair_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
+    MLH_LAUNCH(features_from_kept_pair_kernel, dim3(nb), dim3(256), 0, st, (const unsigned char *)V.out.as<unsigned char>(), stride, intensity_off, n,
                        (const int *)V.total.as<int>(), (const int *)V.wpre.as<int>(), first_word, (const int *)V.leader.as<int>(), (const int *)V.vox_of.as<int>(),
                        (const int *)(V.total.as<int>() + 1), (const float *)d_c6, f0.pts.as<float4>(), f0.covd.as<float4>(), f1.pts.as<float4>(), f1.covd.as<float4>(),
                        V.total.as<int>() + 2, h_counts, h_seq, seq);

@@ -144,13 +144,13 @@ static int scan_launch(mlh_ctx *ctx, const int *in, int *out, long long n, DevBu
     const int nb = int((n + VS_CHUNK - 1) / VS_CHUNK);
     MLH_HIP(ctx, sums.ensure(sizeof(int) * size_t(nb + 1)));
     if (nb <= VS_DIRECT_BLOCKS) {
-        hipLaunchKernelGGL(vscan_reduce_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, n, sums.as<int>());
-        hipLaunchKernelGGL(vscan_final_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, out, n, (const int *)sums.as<int>(), grand_total);
+        MLH_LAUNCH(vscan_reduce_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, n, sums.as<int>());
+        MLH_LAUNCH(vscan_final_kernel<POPC>, dim3(nb), dim3(256), 0, ctx->stream, in, out, n, (const int *)sums.as<int>(), grand_total);
     } else {
-        if (POPC) hipLaunchKernelGGL(vscan_popc_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned *>(in), out, n, sums.as<int>());
-        else hipLaunchKernelGGL(vscan_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, sums.as<int>());
-        hipLaunchKernelGGL(vscan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums.as<int>(), nb, grand_total);
-        hipLaunchKernelGGL(vscan_add_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, (const int *)sums.as<int>());
+        if (POPC) MLH_LAUNCH(vscan_popc_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned *>(in), out, n, sums.as<int>());
+        else MLH_LAUNCH(vscan_local_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, sums.as<int>());
+        MLH_LAUNCH(vscan_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, sums.as<int>(), nb, grand_total);
+        MLH_LAUNCH(vscan_add_kernel, dim3(nb), dim3(256), 0, ctx->stream, out, n, (const int *)sums.as<int>());
     }
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
@@ -430,7 +430,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     } else {
         const int vb = std::min((n + 255) / 256, VB_BLOCKS);
         MLH_HIP(ctx, V.bounds.ensure(sizeof(float) * 6 * VB_BLOCKS));
-        hipLaunchKernelGGL(vbounds_kernel, dim3(vb), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
+        MLH_LAUNCH(vbounds_kernel, dim3(vb), dim3(256), 0, st, src, stride, n, V.bounds.as<float>());
         float hp[6 * VB_BLOCKS];
         MLH_HIP(ctx, hipMemcpyAsync(hp, V.bounds.p, sizeof(float) * 6 * size_t(vb), hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipStreamSynchronize(st));
@@ -490,17 +490,17 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
     A.trace_thr = trace_thr; A.centroid_all = centroid_all ? 1 : 0; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
     A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
     const int nbp = (n + 255) / 256;
-    hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
     int rc = scan_launch<true>(ctx, reinterpret_cast<const int *>(A.mask), V.wpre.as<int>(), nwords, V.sums, V.total.as<int>());   // total = occupied voxels
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);         // cnt[s+1] <- start[s]
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
+    MLH_LAUNCH(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);    // cnt[s+1] <- start[s+1]
     if (ctx->vox_member_order == 1) { if ((rc = device_std_sort_by_key(ctx, A.vox_of, A.n0, A.n, A.members))) return rc; }
     else if (ctx->vox_member_order == 2) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
-    else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
+    else MLH_LAUNCH(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     if (!sync_total) { *n_out = -1; return MLH_OK; }
     int total = 0;
@@ -569,17 +569,17 @@ int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds
     A.trace_thr = 0.f; A.centroid_all = 0; A.vox_of = V.vox_of.as<int>(); A.word_of = V.word_of.as<int>(); A.mask = V.cell.as<unsigned>(); A.wpre = V.wpre.as<int>(); A.cnt = V.cnt.as<int>();
     A.sorted_idx = V.sorted_idx.as<int>(); A.members = V.members.as<int>(); A.total = V.total.as<int>(); A.out = V.out.as<unsigned char>();
     const int nbp = (n + 255) / 256;
-    hipLaunchKernelGGL(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_mark_kernel, dim3(nbp), dim3(256), 0, st, A);
     int rc = scan_launch<true>(ctx, reinterpret_cast<const int *>(A.mask), V.wpre.as<int>(), nwords, V.sums, V.total.as<int>());
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_slot_kernel, dim3(nbp), dim3(256), 0, st, A);
     rc = device_exclusive_scan(ctx, A.cnt + 1, n, V.sums, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_scatter_kernel, dim3(nbp), dim3(256), 0, st, A);
     if (ctx->vox_member_order == 1) { if ((rc = device_std_sort_by_key(ctx, A.vox_of, A.n0, A.n, A.members))) return rc; }
     else if (ctx->vox_member_order == 2) { if ((rc = members_in_std_sort_order(ctx, A))) return rc; }
-    else hipLaunchKernelGGL(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
+    else MLH_LAUNCH(vox_rank_kernel, dim3(nbp), dim3(256), 0, st, A);
+    MLH_LAUNCH(vox_aggregate_kernel, dim3(nbp), dim3(256), 0, st, A);
     MLH_HIP(ctx, hipGetLastError());
     *first_voxels_word = int(off1 >> 5);
     return MLH_OK;

@@ -329,6 +329,41 @@ def simulate_scan(scene: Scene, pose_w_body: np.ndarray, body_T_laser: np.ndarra
                 scan_end=np.array(ends, np.int32), n_rings=n_rings)
 
 
+def roughen_scan(scan: "Scan", seed: int = 0, n_sectors: int = 3, near_fraction: float = 0.01, short_rings: int = 2) -> "Scan":
+    """A scan with the artefacts a real sensor has and the clean ray-cast does not: whole azimuth SECTORS missing (occlusion by the vehicle, a dirty
+    window: 5..40 degrees each), NEAR-RANGE returns well below a metre (self-hits: the point is pulled in along its ray), rings with fewer than twelve points and one
+    ring with none at all. Ring-major order and the +5 / -6 insets are kept (a ring too short for them gets start > end, as ImageSegmenter leaves it)."""
+    rng = np.random.default_rng(seed)
+    starts0, ends0 = scan.scan_start - 5, scan.scan_end + 6          # the rings' own spans
+    sectors = [(rng.uniform(-np.pi, np.pi), np.deg2rad(rng.uniform(5.0, 40.0))) for _ in range(n_sectors)]
+    short = set(rng.choice(scan.n_rings, size=min(short_rings + 1, scan.n_rings), replace=False).tolist())
+    empty = min(short) if short else -1
+    out, starts, ends, off = [], [], [], 0
+    for r in range(scan.n_rings):
+        p = scan.points[starts0[r]:ends0[r]].copy()
+        if len(p):
+            az = np.arctan2(p[:, 1], p[:, 0])
+            keep = np.ones(len(p), bool)
+            for a0, w in sectors:
+                keep &= np.abs(np.angle(np.exp(1j * (az - a0)))) > 0.5 * w
+            p = p[keep]
+        if r == empty:
+            p = p[:0]
+        elif r in short:
+            p = p[:int(rng.integers(1, 12))]
+        if len(p):
+            near = rng.random(len(p)) < near_fraction
+            rng_now = np.linalg.norm(p[:, :3], axis=1)
+            scale = np.where(near, rng.uniform(0.3, 0.95, len(p)) / np.maximum(rng_now, 1e-6), 1.0).astype(np.float32)
+            p[:, :3] *= scale[:, None]
+        out.append(p)
+        starts.append(off + 5)
+        ends.append(off + len(p) - 6)
+        off += len(p)
+    pts = np.concatenate(out) if out else np.zeros((0, 4), np.float32)
+    return Scan(points=np.ascontiguousarray(pts, np.float32), scan_start=np.array(starts, np.int32), scan_end=np.array(ends, np.int32), n_rings=scan.n_rings)
+
+
 def transform_points(points_xyz: np.ndarray, T: np.ndarray) -> np.ndarray:
     p = points_xyz.astype(np.float64)
     out = np.stack([((p[:, 0] * T[r, 0] + p[:, 1] * T[r, 1]) + p[:, 2] * T[r, 2]) + T[r, 3] for r in range(3)], axis=1)   # no BLAS: see simulate_scan

@@ -4,6 +4,8 @@
   voxel     VoxelGridCovarianceMLOAM plain + covariance branches and pcl::VoxelGrid on random clouds (leaf 0.1-1.0, a fraction of the points snapped onto voxel
             faces / repeated): every output bit
   select    goodFeatureMatching rnd / fps / gd_fix / gd_float (random ratio up to 0.9, seed) on random scenes: identical selections, H 1e-9
+  rough     extractCloud + segmentCloud on scans with a sensor's artefacts (synth.roughen_scan: azimuth sectors missing, near-range returns < 1 m, rings with
+            < 12 points, an empty ring): every output bit
 usage: python scripts/soak_parity_frontend.py [trials] [seed] [families, comma separated]"""
 import importlib, os, sys, time
 import numpy as np
@@ -14,7 +16,7 @@ from scipy.spatial.transform import Rotation as Rot
 mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select,odom_select,uct").split(",")
+families = (sys.argv[3] if len(sys.argv) > 3 else "track,segment,voxel,select,odom_select,uct,rough").split(",")
 rng = np.random.default_rng(seed)
 O.build()
 ctx = None if os.environ.get("SOAK_DRY") else mla.Context(0)
@@ -102,6 +104,39 @@ if "segment" in families:
             raise SystemExit(f"SEGMENT scan info {what}")
         n_pts += len(pts)
     print(f"segment: {trials} random raw clouds ({n_pts} points): ring-major cloud, ScanInfo and outlier cloud equal bit for bit  [{time.time() - t0:.0f} s]", flush=True)
+
+if "rough" in families:
+    # scans with a sensor's artefacts (synth.roughen_scan: azimuth sectors missing, near-range returns below a metre, rings with < 12 points, an empty ring):
+    # extractCloud bit for bit on the ring-major form, and ImageSegmenter on the same points as an unordered raw cloud
+    t0 = time.time(); n_pts = 0
+    scn = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+    for trial in range(trials):
+        rings = int(rng.choice([16, 32, 64]))
+        sseed = int(rng.integers(1, 10 ** 6))
+        body = synth.gt_body_pose().copy(); body[:2] += rng.uniform(-3, 3, 2)
+        clean = synth.simulate_scan(scn, body, synth.HERCULES_BODY_T_LASER[int(rng.integers(2))], rings, seed=sseed)
+        s = synth.roughen_scan(clean, seed=sseed, n_sectors=int(rng.integers(0, 5)), near_fraction=float(rng.choice([0.0, 0.005, 0.03])), short_rings=int(rng.integers(0, 4)))
+        what = f"rough trial {trial}: {rings} rings, seed {sseed}, {len(s.points)} of {len(clean.points)} points"
+        ref = O.extract(s.points, s.scan_start, s.scan_end)
+        got = ctx.extract(s.points, s.scan_start, s.scan_end, voxel_leaf=0.2)
+        for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
+            if not np.array_equal(got[k], ref[k]):
+                raise SystemExit(f"ROUGH extract {k} {what}")
+        if got["less_flat_ds"].shape != ref["less_flat_ds"].shape or not np.array_equal(got["less_flat_ds"].view(np.uint32), ref["less_flat_ds"].view(np.uint32)):
+            raise SystemExit(f"ROUGH per-ring voxel centroids {what}")
+        r2 = np.random.default_rng(sseed)
+        pts = np.ascontiguousarray(s.points[r2.permutation(len(s.points))])
+        pts[:, 3] = r2.uniform(0.0, 0.9, len(pts)).astype(np.float32)
+        flag = bool(rng.integers(2))
+        refs = O.segment_cloud(pts, O.seg_params(vertical_scans=rings, segment_flag=flag))
+        gots = ctx.segment_cloud(pts, vertical_scans=rings, segment_flag=int(flag))
+        for k in ("cloud", "outlier"):
+            if gots[k].shape != refs[k].shape or not np.array_equal(gots[k].view(np.uint32), refs[k].view(np.uint32)):
+                raise SystemExit(f"ROUGH segment {k} {what}")
+        if not (np.array_equal(gots["scan_start"], refs["scan_start"]) and np.array_equal(gots["scan_end"], refs["scan_end"])):
+            raise SystemExit(f"ROUGH segment scan info {what}")
+        n_pts += len(pts)
+    print(f"rough: {trials} roughened scans ({n_pts} points): extractCloud labels / lists / per-ring centroids and segmentCloud clouds / ScanInfo equal bit for bit  [{time.time() - t0:.0f} s]", flush=True)
 
 if "voxel" in families:
     t0 = time.time(); n_pts = 0

@@ -309,6 +309,17 @@ static int run_gpu(const std::string &d)
     for (int ua = 0; ua < 2; ++ua) {
         with_ua_flag = ua == 1;
         para_pose[0] = pv[0]; para_pose[1] = pv[1]; para_pose[2] = pv[2]; para_pose[3] = pv[3]; para_pose[4] = pv[4]; para_pose[5] = pv[5]; para_pose[6] = pv[6];
+        // the batched device evaluation first (its buffers and the runtime's own bookkeeping stay out of the ownership count below): the correspondences of the two
+        // match calls above are still staged, kind by kind; rows of unmatched features are zero
+        std::vector<double> dev_r[2], dev_J[2];
+        for (int kind = 0; kind < 2; ++kind) {
+            const PointICovCloud &feat = kind == 0 ? *laser_cloud_surf_cov : *laser_cloud_corner_cov;
+            mloam_hip::LidarMapBatchFactor batch(dev, kind == 0 ? MLH_SURF : MLH_CORNER, (int)feat.size(), with_ua_flag);
+            dev_r[kind].assign(feat.size(), 0.0); dev_J[kind].assign(feat.size() * 7, 0.0);
+            const double *pp[1] = {para_pose};
+            double *Jp[1] = {dev_J[kind].data()};
+            if (!batch.Evaluate(pp, dev_r[kind].data(), Jp)) throw std::runtime_error("LidarMapBatchFactor::Evaluate failed");
+        }
         const long live_before = g_live.load();
         {
             ceres::Problem problem;
@@ -320,20 +331,13 @@ static int run_gpu(const std::string &d)
             add_residual_blocks(problem, loss_function, res_ids_proj);
             n_blocks = res_ids_proj.size();
             if (n_blocks != all_surf_features.size() + all_corner_features.size() || problem.NumOwnedCostFunctions() != n_blocks) owned_ok = 0;
-            // the batched device evaluation: the correspondences of the two match calls above are still staged (kind by kind); rows of unmatched features are zero
             for (int kind = 0; kind < 2; ++kind) {
-                const PointICovCloud &feat = kind == 0 ? *laser_cloud_surf_cov : *laser_cloud_corner_cov;
                 const std::vector<PointPlaneFeature> &fs = kind == 0 ? all_surf_features : all_corner_features;
-                mloam_hip::LidarMapBatchFactor batch(dev, kind == 0 ? MLH_SURF : MLH_CORNER, (int)feat.size(), with_ua_flag);
-                std::vector<double> r(feat.size()), J(feat.size() * 7);
-                const double *pp[1] = {para_pose};
-                double *Jp[1] = {J.data()};
-                if (!batch.Evaluate(pp, r.data(), Jp)) throw std::runtime_error("LidarMapBatchFactor::Evaluate failed");
                 for (size_t b = 0; b < fs.size(); ++b) {
                     const BlockEval e = evaluate_block(problem, res_ids_proj[(kind == 0 ? 0 : all_surf_features.size()) + b]);
                     const size_t i = fs[b].idx_;
-                    max_dr = std::max(max_dr, std::fabs(e.r - r[i]));
-                    for (int k = 0; k < 7; ++k) max_dJ = std::max(max_dJ, std::fabs(e.J[k] - J[i * 7 + k]));
+                    max_dr = std::max(max_dr, std::fabs(e.r - dev_r[kind][i]));
+                    for (int k = 0; k < 7; ++k) max_dJ = std::max(max_dJ, std::fabs(e.J[k] - dev_J[kind][i * 7 + k]));
                 }
             }
         }

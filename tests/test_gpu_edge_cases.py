@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -783,3 +784,105 @@ def test_zero_arguments_with_a_live_context():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_zero_args.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "context still solves to the same bits: True" in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_launch_checks_name_the_failing_kernel(tmp_path):
+    """MLH_CHECK_LAUNCH=1: hipGetLastError() behind every launch (a bad launch configuration used to surface at the next synchronisation under another
+    call's name). In a child process with the switch on, a deliberately impossible launch is reported by the call that made it, with the kernel's name, and an
+    ordinary solve (a few dozen launches, every one checked) is unaffected and gives the bits of an unchecked run."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import importlib, sys, numpy as np
+        sys.path.insert(0, %r)
+        mla = importlib.import_module("m-loam_amd"); synth = importlib.import_module("m-loam_amd.synth")
+        sc = synth.make_scene(seed=42, **synth.SCENE_PRESETS["50k"])
+        surf_map, corner_map = synth.sample_maps(sc, kf_rings=16, kf_lidars=1)
+        gt = synth.gt_body_pose()
+        scan = synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[0], 16)
+        c = mla.Context(0)
+        ex = c.extract(scan.points, scan.scan_start, scan.scan_end)
+        c.map_set(mla.SURF, surf_map); c.map_set(mla.CORNER, corner_map)
+        c.features_set(mla.SURF, synth.voxel_mean(scan.points[ex["less_flat_raw"]], 0.4)); c.features_set(mla.CORNER, synth.voxel_mean(scan.points[ex["less_sharp"]], 0.2))
+        pose, _ = c.gn_solve(synth.perturbed_pose(gt), 3, want_stats=False)
+        print("POSE", pose.tobytes().hex())
+        try:
+            c.debug_bad_launch()
+            print("BAD_LAUNCH returned")
+        except mla.MlhError as e:
+            print("BAD_LAUNCH raised:", e)
+        pose2, _ = c.gn_solve(synth.perturbed_pose(gt), 3, want_stats=False)
+        print("POSE2", pose2.tobytes().hex())
+    ''') % ROOT
+    out = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, MLH_CHECK_LAUNCH=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = r.stdout
+    assert "BAD_LAUNCH raised:" in out["1"] and "debug_noop_kernel" in out["1"], out["1"]
+    assert "BAD_LAUNCH returned" in out["0"], out["0"]
+    poses = [line.split()[1] for flag in ("1", "0") for line in out[flag].splitlines() if line.startswith("POSE")]
+    assert len(poses) == 4 and len(set(poses)) == 1, poses           # checked and unchecked, before and after the provoked error: the same bits
+
+
+def test_pageable_scan_buffer_is_the_callers_again_when_upload_returns(mla, synth, case16, feats16):
+    """mlh_scan_upload of a PAGEABLE host buffer relies on hipMemcpyAsync having consumed the source when it returns (capi.hip, mlh_scan_upload). Pinned here: with ~5 ms
+    of kernels queued AHEAD of the copy on the context's stream (a 200-iteration solve submitted with mlh_gn_solve_begin), the caller overwrites its buffer the
+    moment the call returns; the extraction that follows must see the ORIGINAL points. If the runtime ever defers reading pageable sources, this fails and the
+    pinned staging path (MLH_SCAN_STAGE_PINNED=1) has to become the default."""
+    sc = case16["scans"][0]
+    c = mla.Context(0)
+    try:
+        want = c.extract(sc.points, sc.scan_start, sc.scan_end)["label"].copy()
+        c.map_set(mla.SURF, case16["surf_map"]); c.map_set(mla.CORNER, case16["corner_map"])
+        big_s = np.ascontiguousarray(np.tile(feats16[0], (12, 1))); big_c = np.ascontiguousarray(np.tile(feats16[1], (12, 1)))
+        c.features_set(mla.SURF, big_s); c.features_set(mla.CORNER, big_c)
+        for trial in range(6):
+            pts = np.ascontiguousarray(sc.points, np.float32).copy()          # an ordinary (pageable) numpy buffer of the caller's
+            c.gn_solve_begin(case16["p0"], 200)                               # ~5 ms of launches in front of the upload
+            c.scan_upload(pts, sc.scan_start, sc.scan_end)
+            pts[:] = np.float32(777.0 + trial)                                # the caller reuses its buffer at once
+            c.extract_run()
+            got = c.extract_fetch()["label"]
+            c.gn_solve_end()
+            assert np.array_equal(got, want), f"trial {trial}: the upload read the caller's buffer after mlh_scan_upload had returned"
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n_rings", [16, 64])
+def test_rough_scans_extract_thin_and_match(mla, synth, orc, case16, n_rings):
+    """Scans with a real sensor's artefacts (synth.roughen_scan: azimuth SECTORS missing, near-range returns below a metre, rings with fewer than twelve points, an
+    empty ring -- VERDICT r04: every test cloud so far was a clean ray-cast): extractCloud's labels / lists / per-ring voxel centroids are the oracle's bits, and
+    the correspondences of the features they give (validity, coefficient bits) too."""
+    sc = case16["scene"]
+    gt = case16["gt"]
+    c = mla.Context(0)
+    try:
+        c.map_set(mla.SURF, case16["surf_map"]); c.map_set(mla.CORNER, case16["corner_map"])
+        ms, mc = orc.Map(case16["surf_map"]), orc.Map(case16["corner_map"])
+        for seed in range(4):
+            clean = synth.simulate_scan(sc, gt, synth.HERCULES_BODY_T_LASER[seed % 2], n_rings, seed=20 + seed)
+            scan = synth.roughen_scan(clean, seed=seed, n_sectors=2 + seed % 3, near_fraction=0.005 * (1 + seed), short_rings=1 + seed % 3)
+            ref = orc.extract(scan.points, scan.scan_start, scan.scan_end)
+            got = c.extract(scan.points, scan.scan_start, scan.scan_end, voxel_leaf=0.2)
+            assert np.array_equal(got["curvature"].view(np.uint32), ref["curvature"].view(np.uint32))
+            assert np.array_equal(got["label"], ref["label"]) and np.array_equal(got["picked"], ref["picked"])
+            for k in ("sharp", "less_sharp", "flat", "less_flat_raw"):
+                assert np.array_equal(got[k], ref[k]), (seed, k)
+            assert np.array_equal(got["less_flat_ds"].view(np.uint32), ref["less_flat_ds"].view(np.uint32))
+            # the features the mapper would take from this scan (the near-range points among them), matched at a perturbed pose
+            surf = np.ascontiguousarray(ref["less_flat_ds"], np.float32); corner = np.ascontiguousarray(scan.points[ref["less_sharp"]], np.float32)
+            if seed % 2:           # the second LiDAR's points, moved into the body frame as the fusion does
+                T = np.eye(4); T[:3, :3] = synth.quat_to_rot(synth.HERCULES_BODY_T_LASER[1][:4]); T[:3, 3] = synth.HERCULES_BODY_T_LASER[1][4:7]
+                surf[:, :3] = synth.transform_points(surf[:, :3], T); corner[:, :3] = synth.transform_points(corner[:, :3], T)
+            p0 = synth.perturbed_pose(gt, seed=50 + seed)
+            for kind, feats, m_, name in ((mla.SURF, surf, ms, "s"), (mla.CORNER, corner, mc, "c")):
+                c.features_set(kind, feats)
+                r = c.match_linearize(kind, p0, dense=False)
+                v, co = m_.match(name, feats, p0)
+                assert np.array_equal(r["valid"], v), (seed, name)
+                nc = 4 if name == "s" else 6
+                assert np.array_equal(r["coeffs"][v.astype(bool), :nc].astype(np.float32).view(np.uint32), np.asarray(co)[v.astype(bool), :nc].astype(np.float32).view(np.uint32)), (seed, name)
+    finally:
+        c.close()
