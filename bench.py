@@ -117,6 +117,82 @@ def candidate_stats(map_pts, feats_xyz_map, h):
     return float(tot[ok].mean()), float(ball[ok].mean())
 
 
+def predicted_scaling(mla, torch, shard, device, surf_map, corner_map, surf, corner, p_conv, center, reps=40):
+    """What a run over N GPUs should show on THIS frame and map, stated before such a run exists (no multi-GPU box has been reachable: SCALE_r0N.json are `skipped`
+    records). Every prospective rank's share -- its map shard (wedge + 1.1 m halo) or the whole map, its ownership test, all features staged -- runs ALONE on this GPU:
+    the index build of its maps (host clock around mlh_map_set_pair) and ONE Gauss-Newton iteration at the converged pose, whose two launches are timed by their own
+    dispatch timestamps (correspondence kernel; fit kernel with the classic finish a sharded iteration keeps). The degeneracy test is switched off for this
+    measurement (map_eig_thre < 0): a rank's LOCAL sums are degenerate in a narrow wedge and would take the eigen-decomposition path, which the real iteration -- it
+    solves on the exchanged, global sums -- does not (first version of this leg: 1.07 ms for an eighth of the features). A sharded step is then
+    index build + 5 x (correspondence + fit + exchange) of the slowest rank; exchange_us is an ASSUMPTION until measured across xGMI: 5 us (a peer store + flag + poll
+    round; 9.5 us was measured between two processes time-sharing one GPU, profiles/r03_p2p_multirank.txt)."""
+    ex_us = 5.0
+    per = {}
+    c = mla.Context(device)
+    try:
+        opts = mla.default_opts(map_eig_thre=-1.0)
+        d_s, d_c = torch.from_numpy(surf).cuda(), torch.from_numpy(corner).cuda()
+        far = np.full((1, 3), 1.0e6, np.float32)
+        c.set_gn_schedule(0, 0, 0)
+        for mode in ("map", "features"):
+            for n in (1, 2, 4, 8):
+                if n == 1 and mode == "features":
+                    continue
+                ranks = []
+                for r in range(n):
+                    if mode == "map" and n > 1:
+                        ms_ = shard.shard_points_mask(surf_map, center, n, r); mc_ = shard.shard_points_mask(corner_map, center, n, r)
+                        lsm, lcm = np.ascontiguousarray(surf_map[ms_]), np.ascontiguousarray(corner_map[mc_])
+                        lsm = lsm if len(lsm) else far; lcm = lcm if len(lcm) else far
+                    else:
+                        lsm, lcm = surf_map, corner_map
+                    d_sm, d_cm = torch.from_numpy(np.ascontiguousarray(lsm)).cuda(), torch.from_numpy(np.ascontiguousarray(lcm)).cuda()
+                    torch.cuda.synchronize()
+                    c.shard_set(None, None)
+                    c.shard_set_features(1, 0)
+                    if n > 1 and mode == "map":
+                        c.shard_set(*shard.wedge_planes(center, n, r))
+                    elif n > 1:
+                        c.shard_set_features(n, r)
+                    c.map_set_pair(d_sm, d_cm)
+                    c.features_set(mla.SURF, d_s); c.features_set(mla.CORNER, d_c)
+                    for _ in range(5):
+                        c.map_set_pair(d_sm, d_cm); c.gn_solve(p_conv, 1, opts, want_stats=False)
+                    c.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        c.map_set_pair(d_sm, d_cm)
+                    c.synchronize()
+                    build_us = 1e6 * (time.perf_counter() - t0) / reps
+                    c.profile_enable((1 << mla.K_KNN) | (1 << mla.K_FIT))
+                    c.profile_reset()
+                    for _ in range(reps):
+                        c.gn_solve(p_conv, 1, opts, want_stats=False)
+                    knn_ms, knn_n = c.profile_get(mla.K_KNN)
+                    fit_ms, fit_n = c.profile_get(mla.K_FIT)
+                    c.profile_enable(0)
+                    ranks.append(dict(index_build_us=round(build_us, 2), knn_us=round(1e3 * knn_ms / max(knn_n, 1), 2), fit_us=round(1e3 * fit_ms / max(fit_n, 1), 2)))
+                per[f"{mode}_n{n}"] = ranks
+    finally:
+        c.close()
+
+    def step_ms(ranks, with_exchange):
+        return max(r_["index_build_us"] + GN_ITERS * (r_["knn_us"] + r_["fit_us"] + (ex_us if with_exchange else 0.0)) for r_ in ranks) * 1e-3
+    n1 = step_ms(per["map_n1"], False)
+    pred = {}
+    for k, v in per.items():
+        if k == "map_n1":
+            continue
+        st = step_ms(v, True)
+        pred[k] = dict(per_rank_alone=v, predicted_ms_per_step=round(st, 4), predicted_speedup_vs_n1=round(n1 / st, 3))
+    return dict(n1_same_method_ms_per_step=round(n1, 4), n1_per_rank_alone=per["map_n1"], assumed_exchange_us=ex_us, splits=pred,
+                note="each prospective rank's share of THIS frame alone on this GPU: index build of its maps + one classic-schedule GN iteration at the converged pose (kernel "
+                     "durations from the dispatches' own timestamps, degeneracy test off: see predicted_scaling's docstring); predicted step = slowest rank's index build + 5 x "
+                     "(correspondence + fit + assumed exchange). `map`: angular wedges + 1.1 m halo; `features`: whole map on every rank, features dealt round-robin. The frame does "
+                     "not fill one GPU (21 k queries): a rank's launches are bound by the same latency chain whatever its share, so the wedge split buys index-build time and "
+                     "little else, and no split of this frame approaches the north star's 6x at 8 GPUs. Stated so that the first cross-GPU SCALE run can be checked against it")
+
+
 def single_gpu_reference(mla, torch, device, surf_map, corner_map, surf, corner, p0, steps, warmup):
     """the frame of this run on ONE GPU, whole map, no communicator: ms per step (map staging + index build + 5 GN iterations) with synchronous submission
     and with the pipelined + overlapped-staging submission of the N = 1 bench line. Used by rank 0 of an N > 1 run as the same-map reference."""
@@ -862,6 +938,14 @@ def main():
         finally:
             fctx.close()
 
+    # supplementary (N = 1): what N = 2 / 4 / 8 should show on this frame, per split, from each rank's share solved alone on this GPU
+    predicted = None
+    if world == 1 and not args.no_supplementary and not args.dense_features:
+        try:
+            predicted = predicted_scaling(mla, torch, shard, local_rank, surf_map, corner_map, surf, corner, np.asarray(pose, np.float64), center)
+        except Exception as ex:      # (a supplementary leg must not cost the line)
+            predicted = dict(error=str(ex)[:200])
+
     # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
     #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)
     h = float(np.sqrt(opts.min_match_sq_dis)) * 1.001
@@ -1150,6 +1234,8 @@ def main():
                 out["metric"] = "scan-to-map residuals+Jacobians/sec (features linearised per second, 5 GN iters/frame, 4 pose blocks: pose + 3 extrinsic SE3)"
         if frame is not None:
             out["frame"] = frame
+        if predicted is not None:
+            out["multi_gpu_predicted"] = predicted
         if s2m_ms is not None:
             out["scan2map"] = dict(ms_per_frame=round(s2m_ms, 4), ms_per_frame_synchronous_maps_staged=round(s2m_staged_ms, 4), ms_per_frame_pipelined=round(s2m_pipe_ms, 4),
                                    pipelined_frames_inside_the_lookahead=int(sum(1 for x in s2m_status if x == 0)), pipelined_frames=len(s2m_status),

@@ -1548,7 +1548,9 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
     return MLH_OK;
 }
 
-int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
+// The host-polled form: chunks of LM launches with the loop's verdict read between them (statistics, good-feature selections, RCCL ranks, and the re-solve of a frame
+// whose loop outgrew its look-ahead).
+static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
 {
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
@@ -1779,7 +1781,7 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
         // nothing younger is chained behind it and the frame's maps and features are still the staged ones: solve it as mlh_scan2map would have
         for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
         if (status_out) *status_out = 2;
-        return mlh_scan2map(ctx, pose_out, &slot.opts, nullptr);
+        return scan2map_polled(ctx, pose_out, &slot.opts, nullptr);
     }
     for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
     // a younger solve chained behind this frame started from its unfinished pose: marked, and reported at ITS end (status 3)
@@ -1787,6 +1789,28 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
     if (status_out) { *status_out = slot.tainted ? 3 : 1; return MLH_OK; }
     // the pose handed back is NOT a result, and this caller has no way to see that: a distinct return code instead of success
     return fail(ctx, MLH_ERR_INCOMPLETE, "mlh_scan2map_end: the frame did not finish inside its look-ahead and cannot be solved again here (status 1); status_out is NULL");
+}
+
+// The synchronous call: the polled form. MLH_S2M_LOOKAHEAD=1 (A/B runs) makes it the split submission collected at once where nothing stands against that -- no
+// statistics, every feature used (wo_gf), no RCCL communicator, no solve in flight: the whole frame (per outer iteration the match launch + the look-ahead budget of
+// LM launches) enqueued without the host reading the loop's verdict in between, a frame that outgrows the budget solved again by the polled form (status 2); the
+// same poses, bit for bit. Measured in one gpurun call, two alternations (profiles/r05_knockout_experiments.txt): 0.2436 / 0.2435 ms per frame against the polled
+// form's 0.2421 / 0.2422 -- the polls were already hidden behind the chunk enqueued ahead, and the launches that find `done` cost what the polls did. Not the default.
+int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
+{
+    if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
+    static const bool lookahead = std::getenv("MLH_S2M_LOOKAHEAD") && std::atoi(std::getenv("MLH_S2M_LOOKAHEAD")) != 0;
+    const bool eligible = lookahead && !stats && opts->gf_method == MLH_GF_WO && !ctx->comm && ctx->solve_seq == ctx->solve_collected;
+    if (!eligible) return scan2map_polled(ctx, pose_inout, opts, stats);
+    int rc = scan2map_submit(ctx, pose_inout, nullptr, nullptr, opts, 0);
+    if (rc) return rc;
+    double out[7];
+    int32_t status = 0;
+    rc = mlh_scan2map_end(ctx, out, &status);
+    if (rc) return rc;
+    if (status == 1 || status == 3) return fail(ctx, MLH_ERR_STATE, "mlh_scan2map: the frame could not be completed (internal: look-ahead overflow without a re-solve)");
+    for (int i = 0; i < 7; ++i) pose_inout[i] = out[i];
+    return MLH_OK;
 }
 
 // ---------------------------------------------------------------- scan-to-scan odometry (LidarTracker)

@@ -192,11 +192,14 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
 
 struct SegBuf {    // ImageSegmenter scratch (segment.hip)
     DevBuf raw, pix, owner, range, ground, keep;
+    DevBuf outmask, row_cnt;   // device row assembly: the outlier pixels' bit mask (from the host's cluster search), per-row counts of kept points (+ first kept index)
+    void *h_rows = nullptr;    // pinned: [vs + 2] ints the row kernels leave for the host (kept points per row, total, first kept point index)
+    size_t h_rows_cap = 0;
     DevBuf unc;            // points / ground pairs whose bin the device cannot decide (an angle within an ulp-scale margin of a bin edge): [counters 2 x int][records]
     DevBuf fix;            // the host's verdicts for the undecided points: {point index, pixel}
     void *h_unc = nullptr; // pinned mirror of `unc`
     size_t h_unc_cap = 0;
-    ~SegBuf() { if (h_unc) (void)hipHostFree(h_unc); }
+    ~SegBuf() { if (h_unc) (void)hipHostFree(h_unc); if (h_rows) (void)hipHostFree(h_rows); }
 };
 
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)
@@ -469,7 +472,17 @@ inline hipError_t read_back_int(mlh_ctx *ctx, const void *dev, int *out)
     return e;
 }
 // stdsort.hip: vals_out <- the permutation of 0..n-1 that std::sort (libstdc++, comparator on the key only) leaves for keys[0..n0) and keys[n0..n)
-int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out);
+// Voxel keys computed INSIDE the sort's init launch (the frame's thinning pipeline, voxel.hip: downsample_current_scan_pair_run): point i of cloud 0 (i < n0) or
+// cloud 1 -> its voxel index in the cloud's own dense grid, the second grid numbered behind the first (the arithmetic of vox_mark_kernel / PCL's VoxelGrid).
+struct VoxKeyGen {
+    const unsigned char *src0, *src1;
+    int stride, n0;
+    float inv_leaf0, inv_leaf1;
+    int min_b0[3], mul1_0, mul2_0;
+    int min_b1[3], mul1_1, mul2_1, cell_off1;
+};
+int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out, const VoxKeyGen *gen = nullptr);
+const int *device_std_sort_keys(mlh_ctx *ctx, int n);       // the keys of the last device_std_sort_by_key over n elements, sorted, once its launches have run
 int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *counts, const int *offsets, int stride, int field, int n_segments, int n, int longest,
                              int *vals_out, bool counters_cleared = false);
 int *device_std_sort_counters(mlh_ctx *ctx, int n, int *n_counters);

@@ -26,9 +26,12 @@ constexpr int TPB = 256;
 // the candidate trips of the queries in dense cells, which set the kernel's duration)
 constexpr int KNN_LATENCY_LIMIT = 8192;   // total queries up to which every kind uses 16 lanes (the launch cannot fill the chip either way)
 #ifndef MLH_KNN_U
-#define MLH_KNN_U 4
+#define MLH_KNN_U 8
 #endif
-constexpr int KNN_U = MLH_KNN_U;      // candidate loads in flight per lane
+// candidate loads in flight per lane. A/B on the bench frame inside one gpurun call, two alternations (profiles/r05_knockout_experiments.txt): 2: 0.1286 / 0.1286,
+// 4 (rounds 1-4): 0.1300 / 0.1268, 8: 0.1246 / 0.1232, 12: 0.1283 / 0.1281, 16: 0.1304 / 0.1304 ms per step -- the queries in dense corner cells set the launch's
+// duration by their dependent candidate trips; eight loads halve those trips, more cost registers (occupancy) without shortening anything
+constexpr int KNN_U = MLH_KNN_U;
 constexpr unsigned long long KEY_INF = 0x7f800000ffffffffull;   // (+inf, max index)
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask)

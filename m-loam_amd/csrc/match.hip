@@ -486,6 +486,9 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const int total = P.k[0].tiles_a + P.k[1].tiles_a;
     int tile = xcd_tile(total);
     if (tile >= total) return;
+#ifdef MLH_KNN_HEAVY_FIRST
+    tile = total - 1 - tile;       // A/B build only (scripts/build_variant.py): the corner tiles -- the queries with the most candidates -- are dispatched first
+#endif
     if constexpr (PRE != 0) {
         __shared__ double f_ne[NE_STRIDE], f_cnt2[2], f_scratch[(TPB / 32) * 32];
         int pb = 0;

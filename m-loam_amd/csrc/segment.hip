@@ -180,11 +180,236 @@ __global__ __launch_bounds__(256) void seg_gather_kernel(SegDev D, const int *ke
     out[k] = make_float4(rec[0], rec[1], rec[2], inten);
 }
 
+// ---- the rows of the output cloud, on the device (round 5; until then the host assembled them: ~0.85 ms of a 2.6 ms call on a 64-ring scan)
+// After the cluster search only its verdict is order-dependent no more: which pixels are outliers. Everything behind it is data movement with a fixed rule
+// (image_segmenter.hpp:359-383), one row at a time and the rows independent of each other:
+//   * cloud_scan[row] = the row's pixel owners in INPUT order (the reference pushes them while it walks the cloud) = the owners sorted by point index;
+//     cloud_scan_order(row, col) = the owner's position in that list at fill time;
+//   * for every outlier pixel of the row, columns ascending: cloud_scan[row].erase(begin() + cloud_scan_order(row, col)) -- "erase what is NOW at the position
+//     recorded at fill time", stale positions included, a position at or past the current size erasing nothing (U2);
+//   * the rows concatenated, scan_start = offset + 5, scan_end = offset + size - 6.
+// One workgroup per row: a bitonic sort of (owner, column) keys in LDS gives list and positions; the erasures run in their own order on ONE wavefront that holds
+// the row's alive flags as 64 x 64 bits in registers (lane l: positions 64 l .. 64 l + 63) -- "the element now at position p" is a popcount prefix over the lanes,
+// a ballot and a bit select inside one word, ~0.1 us per erasure with no memory access, exact for any order of positions (the host needed an order-statistic tree
+// for clouds that are not in firing order); the survivors are compacted by a block scan. A second launch adds up the rows' sizes and gathers the points.
+struct SegRows {
+    const int *owner;           // vs * hs (INT_MAX: empty)
+    const unsigned *outmask;    // one bit per pixel: label 999999
+    int *kept;                  // vs * hs: the surviving point indices of row r at [r * hs, ...)
+    int *row_cnt;               // [vs]: survivors per row
+    int vs, hs, hs2;            // hs2 = hs rounded up to a power of two (<= SEG_ROW_MAX)
+    int segment_flag;
+};
+constexpr int SEG_ROW_MAX = 4096;
+constexpr int SEG_ROW_TPB = 1024;
+
+__global__ __launch_bounds__(SEG_ROW_TPB) void seg_rows_kernel(SegRows A)
+{
+    extern __shared__ unsigned long long s_dyn[];
+    unsigned long long *s_key = s_dyn;                                // hs2 keys: (owner << 32) | column
+    int *s_order = reinterpret_cast<int *>(s_key + A.hs2);            // hs2: position of column c's owner in the sorted list
+    int *s_epos = s_order + A.hs2;                                    // hs2: the positions to erase, in erasure order (+ hs2 more behind it: s_idx)
+    __shared__ unsigned long long s_alive[64];
+    __shared__ int s_wave_tot[SEG_ROW_TPB / 64], s_misc[4];
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int hs = A.hs, hs2 = A.hs2;
+    for (int c = t; c < hs2; c += SEG_ROW_TPB) {
+        const unsigned o = c < hs ? (unsigned)A.owner[size_t(r) * hs + c] : (unsigned)INT_MAX;
+        s_key[c] = (static_cast<unsigned long long>(o) << 32) | unsigned(c);
+    }
+    __syncthreads();
+    for (int k = 2; k <= hs2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < hs2; i += SEG_ROW_TPB) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_key[i], b = s_key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // size0 = the non-empty pixels (sorted in front); positions by column
+    int mine = 0;
+    for (int i = t; i < hs2; i += SEG_ROW_TPB) {
+        const unsigned long long k = s_key[i];
+        const bool full = (unsigned)(k >> 32) != (unsigned)INT_MAX;
+        mine += full ? 1 : 0;
+        const int col = int(unsigned(k));
+        if (col < hs) s_order[col] = full ? i : -1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) s_wave_tot[wave] = mine;
+    __syncthreads();
+    int size0 = 0;
+#pragma unroll
+    for (int w = 0; w < SEG_ROW_TPB / 64; ++w) size0 += s_wave_tot[w];
+    __syncthreads();
+    // the erasure list: outlier pixels, columns ascending -> their fill-time positions (a block-wide compaction: thread t owns columns [cpt t, cpt (t + 1)))
+    int n_erase = 0;
+    if (A.segment_flag) {
+        const int cpt = hs2 / SEG_ROW_TPB > 0 ? hs2 / SEG_ROW_TPB : 1;
+        const int c0 = t * cpt;
+        int flags = 0, cnt = 0;
+        for (int u = 0; u < cpt; ++u) {
+            const int c = c0 + u;
+            if (c < hs) {
+                const size_t px = size_t(r) * hs + c;
+                if ((A.outmask[px >> 5] >> (px & 31)) & 1u) { flags |= 1 << u; ++cnt; }
+            }
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+        for (int w = 0; w < SEG_ROW_TPB / 64; ++w) n_erase += s_wave_tot[w];
+        int dst = base + incl - cnt;
+        for (int u = 0; u < cpt; ++u) if (flags & (1 << u)) s_epos[dst++] = s_order[c0 + u];
+        __syncthreads();
+    }
+    // The erasures. Sequential by definition -- "erase what is NOW at position p", one after the other -- but a RUN of strictly ascending positions can be applied at
+    // once: its j-th erasure removes the element whose rank in the list AS IT WAS AT THE RUN'S START is p_j + j (the j earlier ones all sat in front of it), and it
+    // erases nothing from the first j on with p_j + j >= size (U2: a position at or past the current size). A driver's cloud gives one or two runs per row (a
+    // pixel's fill position grows with its column, with one step down where the sweep starts); an unordered cloud gives many short ones, each still exact.
+    // Per run: every thread turns its ranks into list indices (a search over the 64 words' popcount prefix, a bit select inside the word), the bits are cleared,
+    // the prefix is rebuilt. (First version: one wavefront erasing one element at a time, 0.15 us each -- 0.5-0.8 ms for a 64-ring scan's rows.)
+    int *s_runs = s_order;                                            // (the positions by column are not needed any more)
+    int *s_idx = s_epos + hs2;                                        // hs2: the list index an erasure removes
+    __shared__ int s_pref[65];
+    int n_runs = 0;
+    {
+        const int ept = hs2 / SEG_ROW_TPB > 0 ? hs2 / SEG_ROW_TPB : 1;
+        const int e0 = t * ept;
+        int flags = 0, cnt = 0;
+        for (int u = 0; u < ept; ++u) { const int e = e0 + u; if (e < n_erase && (e == 0 || s_epos[e] <= s_epos[e - 1])) { flags |= 1 << u; ++cnt; } }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();                                               // (also: every read of s_order as positions lies before this barrier)
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+        for (int w = 0; w < SEG_ROW_TPB / 64; ++w) n_runs += s_wave_tot[w];
+        int dst = base + incl - cnt;
+        for (int u = 0; u < ept; ++u) if (flags & (1 << u)) s_runs[dst++] = e0 + u;
+    }
+    if (wave == 0) {
+        unsigned long long w = 0ull;
+        const int lo = lane * 64;
+        if (size0 >= lo + 64) w = ~0ull;
+        else if (size0 > lo) w = (1ull << (size0 - lo)) - 1ull;
+        s_alive[lane] = w;
+        const int pc = __popcll(w);
+        int incl = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        s_pref[lane] = incl - pc;
+        if (lane == 63) s_pref[64] = incl;
+        if (lane == 0) { s_misc[0] = size0; s_misc[1] = 0; }
+    }
+    __syncthreads();
+    for (int rn = 0; rn < n_runs; ++rn) {                              // uniform
+        const int ra = s_runs[rn], rb = rn + 1 < n_runs ? s_runs[rn + 1] : n_erase;
+        const int cnt0 = s_misc[0];
+        int valid = 0;
+        for (int j = ra + t; j < rb; j += SEG_ROW_TPB) {
+            const int tt = s_epos[j] + (j - ra);
+            int idx = -1;
+            if (s_epos[j] >= 0 && tt < cnt0) {
+                int wd = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) wd += (s_pref[wd + step] <= tt) ? step : 0;      // the last word whose prefix is <= tt: it holds rank tt
+                int rr = tt - s_pref[wd], bit = 0;
+                unsigned long long m = s_alive[wd];
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) {
+                    const int c = __popcll(m & ((1ull << sh) - 1ull));
+                    if (rr >= c) { rr -= c; m >>= sh; bit += sh; }
+                }
+                idx = wd * 64 + bit;
+                ++valid;
+            }
+            s_idx[j] = idx;
+        }
+        if (valid) atomicAdd(&s_misc[1], valid);
+        __syncthreads();
+        for (int j = ra + t; j < rb; j += SEG_ROW_TPB) {
+            const int idx = s_idx[j];
+            if (idx >= 0) atomicAnd(&s_alive[idx >> 6], ~(1ull << (idx & 63)));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int pc = __popcll(s_alive[lane]);
+            int incl = pc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+            s_pref[lane] = incl - pc;
+            if (lane == 63) s_pref[64] = incl;
+            if (lane == 0) { s_misc[0] = cnt0 - s_misc[1]; s_misc[1] = 0; }
+        }
+        __syncthreads();
+    }
+    // survivors, in list order -> kept[r * hs ...]
+    {
+        const int ipt = hs2 / SEG_ROW_TPB > 0 ? hs2 / SEG_ROW_TPB : 1;
+        const int i0 = t * ipt;
+        int cnt = 0;
+        for (int u = 0; u < ipt; ++u) { const int i = i0 + u; if (i < size0 && ((s_alive[i >> 6] >> (i & 63)) & 1ull)) ++cnt; }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wave_tot[w];
+        int dst = base + incl - cnt;
+        for (int u = 0; u < ipt; ++u) {
+            const int i = i0 + u;
+            if (i < size0 && ((s_alive[i >> 6] >> (i & 63)) & 1ull)) A.kept[size_t(r) * hs + dst++] = int(unsigned(s_key[i] >> 32));
+        }
+        if (t == 0) A.row_cnt[r] = s_misc[0];
+    }
+}
+
+// the rows concatenated: out[k] = {x, y, z, intensity + row} of the k-th kept point, the ring tables as ScanInfo has them, and what the host needs to know
+// (sizes per row, total, first kept point) in pinned memory
+__global__ __launch_bounds__(256) void seg_rows_gather_kernel(SegDev D, const int *kept, const int *row_cnt, float4 *out, int *start, int *end, int *host_rows)
+{
+    const int r = blockIdx.y, vs = D.S.vs, hs = D.S.hs;
+    int off = 0, total = 0;
+    for (int q = 0; q < vs; ++q) { const int c = row_cnt[q]; off += q < r ? c : 0; total += c; }
+    const int cnt = row_cnt[r];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        start[r] = off + 5; end[r] = off + cnt - 6;
+        host_rows[r] = cnt;
+        if (r == 0) {
+            host_rows[vs] = total;
+            int first = -1;
+            for (int q = 0; q < vs && first < 0; ++q) if (row_cnt[q] > 0) first = kept[size_t(q) * hs];
+            host_rows[vs + 1] = first;
+        }
+    }
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const int i = kept[size_t(r) * hs + k];
+        const float *rec = reinterpret_cast<const float *>(D.src + size_t(i) * D.stride);
+        float inten = D.intensity_off >= 0 ? *reinterpret_cast<const float *>(D.src + size_t(i) * D.stride + D.intensity_off) : 0.f;
+        inten += float(r);
+        out[off + k] = make_float4(rec[0], rec[1], rec[2], inten);
+    }
+}
+
 // ---- host: cluster search + outlier erasure on the images (sequential by definition, see the file comment)
 struct SegHost {
     std::vector<float> range;
     std::vector<int> label, owner;
     std::vector<unsigned char> ground;
+    std::vector<unsigned> outmask;      // one bit per pixel: label 999999 (filled where the cluster search marks an infeasible cluster)
 };
 
 static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegHost &H)
@@ -265,7 +490,11 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
                 feasible = lines >= prm.segment_valid_line_num;
             }
             if (feasible) ++label_count;
-            else for (int k = 0; k < n_pushed; ++k) L(pushed_x[k], pushed_y[k]) = 999999;
+            else for (int k = 0; k < n_pushed; ++k) {
+                L(pushed_x[k], pushed_y[k]) = 999999;
+                const size_t px = size_t(pushed_x[k]) * hs + pushed_y[k];
+                H.outmask[px >> 5] |= 1u << (px & 31);
+            }
         }
     }
 }
@@ -378,7 +607,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     static const bool seg_timing = std::getenv("MLH_SEG_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     SegHost H;
-    H.range.resize(npx); H.owner.resize(npx); H.ground.resize(npx); H.label.assign(npx, 0);
+    H.range.resize(npx); H.owner.resize(npx); H.ground.resize(npx); H.label.assign(npx, 0); H.outmask.assign((size_t(npx) + 31) / 32, 0u);
     MLH_HIP(ctx, hipMemcpyAsync(H.range.data(), B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.owner.data(), B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
     MLH_HIP(ctx, hipMemcpyAsync(H.ground.data(), B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
@@ -405,6 +634,102 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     for (int p = 0; p < npx; ++p) H.label[p] = (H.owner[p] == INT_MAX) ? -1 : (H.ground[p] ? 1 : 0);
     seg_clusters(S, prm, H);
     const auto tp2 = std::chrono::steady_clock::now();
+    int hs2 = 1;
+    while (hs2 < hs) hs2 <<= 1;
+    static const bool host_rows = std::getenv("MLH_SEG_HOST_ROWS") != nullptr;       // (A/B runs: the round-4 host assembly)
+    if (hs2 <= SEG_ROW_MAX && !host_rows) {
+        // ---- rows, erasure, concatenation and gather on the device (seg_rows_kernel / seg_rows_gather_kernel); the host keeps the outlier list only
+        std::vector<int> outlier_idx, outlier_row;
+        if (prm.segment_flag)
+            for (size_t wd = 0; wd < H.outmask.size(); ++wd) {
+                unsigned m = H.outmask[wd];
+                while (m) {
+                    const size_t px = wd * 32 + size_t(__builtin_ctz(m));
+                    m &= m - 1;
+                    if ((px % size_t(hs)) % 5 == 0) { outlier_idx.push_back(H.owner[px]); outlier_row.push_back(int(px / size_t(hs))); }
+                }
+            }
+        const size_t mask_bytes = sizeof(unsigned) * H.outmask.size();
+        MLH_HIP(ctx, B.outmask.ensure(mask_bytes));
+        MLH_HIP(ctx, B.row_cnt.ensure(sizeof(int) * size_t(vs)));
+        MLH_HIP(ctx, B.keep.ensure(sizeof(int) * size_t(npx)));
+        if (B.h_rows_cap < sizeof(int) * size_t(vs + 2)) {
+            if (B.h_rows) (void)hipHostFree(B.h_rows);
+            B.h_rows = nullptr; B.h_rows_cap = 0;
+            MLH_HIP(ctx, hipHostMalloc(&B.h_rows, sizeof(int) * size_t(vs + 2) * 2, hipHostMallocDefault));
+            B.h_rows_cap = sizeof(int) * size_t(vs + 2) * 2;
+        }
+        ScanBuf &sb = ctx->scan;
+        sb.extracted = false; sb.voxelised = false; sb.h_lists_valid = sb.h_vox_valid = false;
+        MLH_HIP(ctx, sb.pts.ensure(sizeof(float4) * size_t(std::max(std::min(n, npx), 1))));
+        MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(vs)));
+        MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(vs)));
+        sb.end_alias = nullptr;
+        MLH_HIP(ctx, hipMemcpyAsync(B.outmask.p, H.outmask.data(), mask_bytes, hipMemcpyHostToDevice, st));       // (H lives until the wait below)
+        SegRows R;
+        R.owner = B.owner.as<int>(); R.outmask = B.outmask.as<unsigned>(); R.kept = B.keep.as<int>(); R.row_cnt = B.row_cnt.as<int>();
+        R.vs = vs; R.hs = hs; R.hs2 = hs2; R.segment_flag = prm.segment_flag ? 1 : 0;
+        const size_t lds = size_t(20) * size_t(hs2);
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(seg_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            lds_set = lds;
+        }
+        MLH_LAUNCH(seg_rows_kernel, dim3(vs), dim3(SEG_ROW_TPB), lds, st, R);
+        int *h_rows = static_cast<int *>(B.h_rows);
+        MLH_LAUNCH(seg_rows_gather_kernel, dim3(4, vs), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), (const int *)B.row_cnt.as<int>(), sb.pts.as<float4>(),
+                   sb.start.as<int>(), sb.end.as<int>(), h_rows);
+        MLH_HIP(ctx, hipGetLastError());
+        MLH_HIP(ctx, hipStreamSynchronize(st));
+        const auto tq3 = std::chrono::steady_clock::now();
+        const int n_keep = h_rows[vs], first_kept = h_rows[vs + 1];
+        std::vector<int> hstart(vs), hend(vs);
+        int off = 0, max_len = 0, row0 = -1;
+        for (int r = 0; r < vs; ++r) {
+            hstart[r] = off + 5; off += h_rows[r]; hend[r] = off - 6;
+            if (row0 < 0 && h_rows[r] > 0) row0 = r;
+            if (hend[r] - hstart[r] >= 6) max_len = std::max(max_len, hend[r] - hstart[r]);
+        }
+        if (cloud_out && n_keep > 0) {
+            MLH_HIP(ctx, hipMemcpyAsync(cloud_out, sb.pts.p, sizeof(float4) * size_t(n_keep), hipMemcpyDeviceToHost, st));
+            MLH_HIP(ctx, hipStreamSynchronize(st));
+        }
+        if (seg_timing) {
+            const auto tp3 = std::chrono::steady_clock::now();
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[mlh_segment_cloud] undecided on the device, decided with the host's libm: %d points, %d ground pairs\n", n_undecided_pts, n_undecided_gnd);
+            std::fprintf(stderr, "[mlh_segment_cloud] n %d: kernels + 3 image copies to the host %.1f us | host cluster search (BFS, queue order) %.1f us | rows on the device: mask up + "
+                                 "sort / erase / compact / gather + wait %.1f us | cloud to the host %.1f us\n", n, us(tp0, tp1), us(tp1, tp2), us(tp2, tq3), us(tq3, tp3));
+        }
+        sb.n = n_keep; sb.n_rings = vs; sb.max_ring_len = max_len;
+        if (n_out) *n_out = n_keep;
+        if (scan_start) std::memcpy(scan_start, hstart.data(), sizeof(int) * size_t(vs));
+        if (scan_end) std::memcpy(scan_end, hend.data(), sizeof(int) * size_t(vs));
+        if (n_outlier) *n_outlier = int(outlier_idx.size()) + (n_keep > 0 ? 1 : 0);
+        if (outlier_out) {
+            size_t k = 0;
+            auto put = [&](int i, int row) -> int {
+                if (k >= size_t(outlier_capacity)) return 0;       // the caller's buffer is full: *n_outlier tells it how many rows there are
+                float rec[4] = {0, 0, 0, 0};
+                if (mem == MLH_MEM_HOST) {
+                    const unsigned char *q = static_cast<const unsigned char *>(points) + size_t(i) * stride;
+                    std::memcpy(rec, q, 12);
+                    if (intensity_off >= 0) std::memcpy(rec + 3, q + intensity_off, 4);
+                } else {
+                    if (hipMemcpy(rec, src + size_t(i) * stride, 12, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+                    if (intensity_off >= 0 && hipMemcpy(rec + 3, src + size_t(i) * stride + intensity_off, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+                }
+                rec[3] += float(row);
+                std::memcpy(outlier_out + 4 * k, rec, 16);
+                ++k;
+                return 0;
+            };
+            for (size_t q = 0; q < outlier_idx.size(); ++q) if (put(outlier_idx[q], outlier_row[q])) return fail(ctx, MLH_ERR_HIP, "outlier fetch");
+            if (n_keep > 0 && first_kept >= 0 && put(first_kept, row0)) return fail(ctx, MLH_ERR_HIP, "outlier fetch");
+        }
+        return MLH_OK;
+    }
+    // ---- host assembly (rows longer than SEG_ROW_MAX pixels; MLH_SEG_HOST_ROWS=1)
     // the rows as the reference fills them: every pixel owner, in input order; cloud_scan_order = its position at fill time. One pass over the input
     // indices (a pixel's owner is an input index: bucket the pixels by owner, walk the indices upwards) gives every row already sorted and every
     // pixel its rank; the outlier erasure -- "erase what is NOW at the position recorded at fill time", stale positions included (U2) -- runs on an

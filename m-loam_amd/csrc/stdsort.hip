@@ -108,10 +108,27 @@ __device__ inline void emit_global(const StdSortArgs &A, int first, int last, in
 }
 
 // keys <- the points' slots, vals <- the point indices, one range per cloud (std::sort is called once per cloud)
-__global__ __launch_bounds__(256) void stdsort_init_kernel(StdSortArgs A, const int *src_keys, int n0)
+template <bool GEN>
+__global__ __launch_bounds__(256) void stdsort_init_kernel(StdSortArgs A, const int *src_keys, int n0, VoxKeyGen G)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < A.n) { A.keys[i] = src_keys[i]; A.vals[i] = i; }
+    if (i < A.n) {
+        int key;
+        if constexpr (GEN) {
+            // the voxel of point i (voxelgrid.hip: vox_mark_kernel -- floor(x * inv_leaf) - min_b per axis, x fastest; the second cloud's grid behind the first's)
+            const bool first = i < G.n0;
+            const float *p = reinterpret_cast<const float *>(first ? G.src0 + size_t(i) * G.stride : G.src1 + size_t(i - G.n0) * G.stride);
+            const float il = first ? G.inv_leaf0 : G.inv_leaf1;
+            const int *mb = first ? G.min_b0 : G.min_b1;
+            const int ijk0 = int(floorf(p[0] * il) - float(mb[0]));
+            const int ijk1 = int(floorf(p[1] * il) - float(mb[1]));
+            const int ijk2 = int(floorf(p[2] * il) - float(mb[2]));
+            key = first ? ijk0 + ijk1 * G.mul1_0 + ijk2 * G.mul2_0 : G.cell_off1 + ijk0 + ijk1 * G.mul1_1 + ijk2 * G.mul2_1;
+        } else {
+            key = src_keys[i];
+        }
+        A.keys[i] = key; A.vals[i] = i;
+    }
     if (i == 0) {
         for (int k = 0; k < SS_CNT; ++k) A.cnt[k] = 0;
         const int lo[2] = {0, n0}, hi[2] = {n0, A.n};
@@ -433,15 +450,24 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
 
 // Sorts (keys = src_keys[0..n), vals = 0..n-1) as two std::sort calls would -- [0, n0) and [n0, n) -- and leaves the permuted vals in
 // vals_out (device, n ints). Everything is enqueued on the context's stream; nothing is waited for.
-int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out)
+int device_std_sort_by_key(mlh_ctx *ctx, const int *src_keys, int n0, int n, int *vals_out, const VoxKeyGen *gen)
 {
     if (n <= 0) return MLH_OK;
     StdSortArgs A;
     size_t nbig, nleaf;
     int rc = stdsort_setup(ctx, n, vals_out, A, nbig, nleaf);
     if (rc) return rc;
-    MLH_LAUNCH(stdsort_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0);
+    if (gen) MLH_LAUNCH(stdsort_init_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0, *gen);
+    else MLH_LAUNCH(stdsort_init_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, src_keys, n0, VoxKeyGen{});
     return stdsort_levels(ctx, A, std::max(n0, n - n0), nbig, nleaf);
+}
+
+const int *device_std_sort_keys(mlh_ctx *ctx, int n)
+{
+    StdSortArgs A;
+    size_t nbig, nleaf;
+    if (n <= 0 || stdsort_setup(ctx, n, nullptr, A, nbig, nleaf)) return nullptr;
+    return A.keys;
 }
 
 // One std::sort call per segment (device-side tables of counts and offsets, `stride` ints per segment, entry `field`): vals_out[i] <- the

@@ -15,6 +15,7 @@
 //                        points whose trace exceeds TRACE_THRESHOLD_MAPPING are dropped (order-preserving compaction).
 #include "ctx.hpp"
 #include <chrono>
+#include <cstdlib>
 #include "dev_math.hpp"
 #include "sort_dev.hpp"
 #include <cfloat>
@@ -265,26 +266,25 @@ struct UctArgs {
     const int *n_dev = nullptr;  // optional device-side record count (<= n): the launch covers n, records past *n_dev are dropped
 };
 
-__global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
+// evalPointUncertainty of one record (associate_uct.hpp:196-215) as downsampleCurrentScan / cloudUCTAssociateToMap call it: the point is taken back into its
+// LiDAR's frame through that LiDAR's extrinsic (pointAssociateToMap: f64 math, f32 store), then cov = G diag(pose covariance, measurement covariance) G^T with
+// G = [ I | -[T p]x | R ]. One body for point_uncertainty_kernel and the thinning pipeline's fused aggregate (vsp_aggregate_kernel): the same operations in the same order.
+__device__ __forceinline__ void eval_point_cov(const double *ext, const double *upose, const double *upose_cov, int n_lidar, const double *meas, int with_ua,
+                                               float x, float y, float z, float inten, double (&cov)[3][3])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
-    if (A.n_dev && i >= *A.n_dev) { A.keep[i] = 0; if (A.keep2) A.keep2[i] = 0; return; }
-    const float *rec = reinterpret_cast<const float *>(A.src + size_t(i) * A.stride);
-    const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(i) * A.stride + A.intensity_off) : 0.f;
     int idx = int(inten);
-    idx = idx < 0 ? 0 : (idx >= A.n_lidar ? A.n_lidar - 1 : idx);
-    double cov[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    if (A.with_ua) {
-        const double *e = A.ext + idx * 7;
+    idx = idx < 0 ? 0 : (idx >= n_lidar ? n_lidar - 1 : idx);
+    for (int r_ = 0; r_ < 3; ++r_) for (int c_ = 0; c_ < 3; ++c_) cov[r_][c_] = 0.0;
+    if (with_ua) {
+        const double *e = ext + idx * 7;
         const q4 qe{e[3], e[4], e[5], e[6]};
         const d3 te{e[0], e[1], e[2]};
         // point_sel = pose_ext^-1 * point_ori, through pointAssociateToMap (f64 math, f32 store) -- cpp:382 / cpp:1148
         const q4 qi{-qe.x, -qe.y, -qe.z, qe.w};
         const d3 mt = qrot(qi, te);
-        const d3 ps = qrot(qi, d3{double(rec[0]), double(rec[1]), double(rec[2])});
+        const d3 ps = qrot(qi, d3{double(x), double(y), double(z)});
         const float sel[3] = {float(ps.x - mt.x), float(ps.y - mt.y), float(ps.z - mt.z)};
-        const double *u = A.upose + idx * 7;
+        const double *u = upose + idx * 7;
         const q4 q{u[3], u[4], u[5], u[6]};
         const d3 t{u[0], u[1], u[2]};
         // T * [p; 1]
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
         G[0][3] = 0.0;    G[0][4] = tp[2];  G[0][5] = -tp[1];
         G[1][3] = -tp[2]; G[1][4] = 0.0;    G[1][5] = tp[0];
         G[2][3] = tp[1];  G[2][4] = -tp[0]; G[2][5] = 0.0;
-        const double *Cp = A.upose_cov + idx * 36;
+        const double *Cp = upose_cov + idx * 36;
         double GC[3][9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
             for (int c = 0; c < 3; ++c) {
                 double s = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s += G[r][6 + k] * A.meas[k * 3 + c];
+                for (int k = 0; k < 3; ++k) s += G[r][6 + k] * meas[k * 3 + c];
                 GC[r][6 + c] = s;
             }
         }
@@ -332,6 +332,17 @@ __global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
                 cov[r][c] = s;
             }
     }
+}
+
+__global__ __launch_bounds__(256) void point_uncertainty_kernel(UctArgs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    if (A.n_dev && i >= *A.n_dev) { A.keep[i] = 0; if (A.keep2) A.keep2[i] = 0; return; }
+    const float *rec = reinterpret_cast<const float *>(A.src + size_t(i) * A.stride);
+    const float inten = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(A.src + size_t(i) * A.stride + A.intensity_off) : 0.f;
+    double cov[3][3];
+    eval_point_cov(A.ext, A.upose, A.upose_cov, A.n_lidar, A.meas, A.with_ua, rec[0], rec[1], rec[2], inten, cov);
     const double tr = cov[0][0] + cov[1][1] + cov[2][2];
     const int keep = (A.with_ua && A.trace_thr > 0.0 && tr > A.trace_thr) ? 0 : 1;
     A.keep[i] = keep;
@@ -608,6 +619,194 @@ __global__ __launch_bounds__(256) void features_from_kept_pair_kernel(const unsi
     (second ? covd1 : covd0)[s] = make_float4(c[0], c[3], c[5], 0.f);
 }
 
+// ---------------------------------------------------------------- the frame's thinning, sort first (round 5)
+// downsampleCurrentScan for both fused clouds used to be 25 launches: voxel -> occupancy bits -> popcount prefix (the output slot) -> counts -> prefix -> scatter,
+// THEN the device std::sort on the slots for the member order, aggregate, uncertainty, prefix over the keep flags, features. The sort only looks at the ORDER of
+// its keys, and a voxel's output slot is monotone in its voxel index: sorting the voxel indices themselves leaves the same permutation -- and leaves the points
+// grouped by voxel, ascending, which is everything the slot machinery in front of it was computing. So: keys = voxel indices, made inside the sort's init launch;
+// behind the sort a voxel is a run of equal keys. Three launches finish the job, every workgroup on 2048 consecutive sorted positions of ONE cloud:
+//   vsp_heads_kernel      run heads per chunk;
+//   vsp_aggregate_kernel  chunk offset = heads of the chunks before (summed here), local scan -> the head's output slot; the head's thread walks its run (the voxel's
+//                         members in std::sort's order): centroid as vox_aggregate_kernel's plain branch, evalPointUncertainty of the centroid (eval_point_cov),
+//                         trace gate -> record, cov, keep flag per slot; kept records per chunk;
+//   vsp_features_kernel   kept-before-this-chunk (summed here), local scan of the keep flags -> the kinds' feature sets; the counts go to pinned host memory.
+// 17 launches instead of 25, no atomics, no occupancy grid; bit for bit the former results (same sums in the same order).
+constexpr int VSP_CH = 2048, VSP_TPB = 256, VSP_PER = VSP_CH / VSP_TPB;
+struct VspArgs {
+    const int *keys, *members;            // sorted voxel indices / point indices in std::sort's order
+    const unsigned char *src0, *src1;
+    int stride, intensity_off, n0, n, nch0, nch;
+    int *heads, *kept;                    // per chunk
+    float4 *rec;                          // per slot: centroid + the last member's intensity
+    float *cov6;                          // per slot
+    int *keep;                            // per slot
+    double ext[4 * 7], ext_cov[4 * 36], meas[9];      // extrinsics as kernel arguments (n_lidar <= 4)
+    int n_lidar, with_ua;
+    double trace_thr;
+    float4 *pts0, *covd0, *pts1, *covd1;
+    int *counts;                          // device: [0..1] features per kind
+    int *host_counts;
+    unsigned long long *host_seq, seq;
+};
+
+__device__ __forceinline__ void vsp_chunk(const VspArgs &A, int c, int &lo, int &hi)
+{
+    if (c < A.nch0) { lo = c * VSP_CH; hi = min(lo + VSP_CH, A.n0); }
+    else { lo = A.n0 + (c - A.nch0) * VSP_CH; hi = min(lo + VSP_CH, A.n); }
+}
+__device__ __forceinline__ bool vsp_head(const VspArgs &A, int i) { return i == 0 || i == A.n0 || A.keys[i] != A.keys[i - 1]; }
+
+// block-wide exclusive scan of one int per thread (256 threads); total = the sum
+__device__ __forceinline__ int vsp_block_scan(int v, int *lds4, int &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < wave) base += lds4[w];
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return base + incl - v;
+}
+// sum of a[0 .. upto) over the workgroup (every thread gets it) and, on the way, of a[0 .. upto2)
+__device__ __forceinline__ void vsp_prefix2(const int *a, int upto, int upto2, int *lds8, int &s1, int &s2)
+{
+    int p1 = 0, p2 = 0;
+    for (int j = threadIdx.x; j < max(upto, upto2); j += VSP_TPB) { const int v = a[j]; p1 += j < upto ? v : 0; p2 += j < upto2 ? v : 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+    if ((threadIdx.x & 63) == 0) { lds8[threadIdx.x >> 6] = p1; lds8[4 + (threadIdx.x >> 6)] = p2; }
+    __syncthreads();
+    s1 = lds8[0] + lds8[1] + lds8[2] + lds8[3];
+    s2 = lds8[4] + lds8[5] + lds8[6] + lds8[7];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(VSP_TPB) void vsp_heads_kernel(VspArgs A)
+{
+    __shared__ int lds4[4];
+    int lo, hi;
+    vsp_chunk(A, blockIdx.x, lo, hi);
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < VSP_PER; ++u) { const int i = lo + threadIdx.x * VSP_PER + u; cnt += (i < hi && vsp_head(A, i)) ? 1 : 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) A.heads[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ __launch_bounds__(VSP_TPB) void vsp_aggregate_kernel(VspArgs A)
+{
+    __shared__ int lds4[4], lds8[8];
+    __shared__ int s_head[VSP_CH + 1];                 // the chunk's run heads (positions), in order
+    int lo, hi;
+    vsp_chunk(A, blockIdx.x, lo, hi);
+    const int cloud_end = blockIdx.x < A.nch0 ? A.n0 : A.n;
+    int slot0, unused;
+    vsp_prefix2(A.heads, blockIdx.x, 0, lds8, slot0, unused);
+    unsigned flags = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < VSP_PER; ++u) { const int i = lo + threadIdx.x * VSP_PER + u; if (i < hi && vsp_head(A, i)) { flags |= 1u << u; ++cnt; } }
+    int h;
+    int li = vsp_block_scan(cnt, lds4, h);
+#pragma unroll
+    for (int u = 0; u < VSP_PER; ++u) if (flags & (1u << u)) s_head[li++] = lo + threadIdx.x * VSP_PER + u;
+    __syncthreads();
+    // one voxel per thread and trip (the heads dealt round-robin: a thread that found eight heads in its eight positions does not walk eight voxels by itself);
+    // a voxel = the positions from its head to the next head -- the last one of a chunk may run on into the next chunk
+    int kept = 0;
+    for (int ls = threadIdx.x; ls < h; ls += VSP_TPB) {
+        const int b = s_head[ls];
+        int e;
+        if (ls + 1 < h) e = s_head[ls + 1];
+        else { const int key = A.keys[b]; e = hi; while (e < cloud_end && A.keys[e] == key) ++e; }
+        // the voxel's members, in the order std::sort left them: xyz mean, the LAST member's intensity (vox_aggregate_kernel's plain branch, term for term);
+        // four member records in flight
+        float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f, ity = 0.f;
+        for (int k = b; k < e; k += 4) {
+            int id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) id[u] = A.members[min(k + u, e - 1)];
+            float q[4][3], it[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned char *rb = id[u] < A.n0 ? A.src0 + size_t(id[u]) * A.stride : A.src1 + size_t(id[u] - A.n0) * A.stride;
+                const float *f = reinterpret_cast<const float *>(rb);
+                q[u][0] = f[0]; q[u][1] = f[1]; q[u][2] = f[2];
+                it[u] = A.intensity_off >= 0 ? *reinterpret_cast<const float *>(rb + A.intensity_off) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k + u >= e) break;
+                mu0 += q[u][0]; mu1 += q[u][1]; mu2 += q[u][2];
+                ity = it[u];
+            }
+        }
+        const int m = e - b;
+        const float fc = float(m > 0 ? m : 1);
+        const float x = mu0 / fc, y = mu1 / fc, z = mu2 / fc;
+        double cov[3][3];
+        eval_point_cov(A.ext, A.ext, A.ext_cov, A.n_lidar, A.meas, A.with_ua, x, y, z, ity, cov);
+        const double tr = cov[0][0] + cov[1][1] + cov[2][2];
+        const int keep = (A.with_ua && A.trace_thr > 0.0 && tr > A.trace_thr) ? 0 : 1;
+        const int slot = slot0 + ls;
+        A.rec[slot] = make_float4(x, y, z, ity);
+        float *o = A.cov6 + size_t(slot) * 6;
+        o[0] = float(cov[0][0]); o[1] = float(cov[0][1]); o[2] = float(cov[0][2]); o[3] = float(cov[1][1]); o[4] = float(cov[1][2]); o[5] = float(cov[2][2]);
+        A.keep[slot] = keep;
+        kept += keep;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off);
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) A.kept[blockIdx.x] = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ __launch_bounds__(VSP_TPB) void vsp_features_kernel(VspArgs A)
+{
+    __shared__ int lds4[4], lds8[8];
+    const int c = blockIdx.x;
+    int slot0, first_records, kept0, first_kept, all_records, all_kept;
+    vsp_prefix2(A.heads, c, A.nch0, lds8, slot0, first_records);
+    vsp_prefix2(A.kept, c, A.nch0, lds8, kept0, first_kept);
+    if (c == 0) {
+        // the two counts are all the host waits for: published before a single record is moved
+        vsp_prefix2(A.kept, A.nch, 0, lds8, all_kept, all_records);
+        if (threadIdx.x == 0) {
+            A.counts[0] = first_kept; A.counts[1] = all_kept - first_kept;
+            if (A.host_seq) {
+                A.host_counts[0] = first_kept; A.host_counts[1] = all_kept - first_kept;
+                __hip_atomic_store(A.host_seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    const int h = A.heads[c];
+    int flags = 0, cnt = 0;
+#pragma unroll
+    for (int u = 0; u < VSP_PER; ++u) { const int k = threadIdx.x * VSP_PER + u; if (k < h && A.keep[slot0 + k]) { flags |= 1 << u; ++cnt; } }
+    int total;
+    int dst = kept0 + vsp_block_scan(cnt, lds4, total);
+    const bool second = c >= A.nch0;
+    for (int u = 0; u < VSP_PER; ++u) {
+        if (!(flags & (1 << u))) continue;
+        const int s = slot0 + threadIdx.x * VSP_PER + u;
+        const float4 r = A.rec[s];
+        const float *cv = A.cov6 + size_t(s) * 6;
+        const int d = second ? dst - first_kept : dst;
+        (second ? A.pts1 : A.pts0)[d] = r;
+        (second ? A.covd1 : A.covd0)[d] = make_float4(cv[0], cv[3], cv[5], 0.f);
+        ++dst;
+    }
+}
+
 // downsampleCurrentScan for the surf AND the corner cloud in one set of launches (device-resident clouds with known bounding boxes:
 // the fused clouds). Same results as two downsample_current_scan_run calls.
 int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,
@@ -618,6 +817,91 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
     hipStream_t st = ctx->stream;
     VoxBuf &V = ctx->vox;
     const int n = n_surf + n_corner;
+    static const bool old_pipeline = std::getenv("MLH_THIN_SLOTS_FIRST") != nullptr;       // (A/B runs: the round-4 pipeline)
+    if (ctx->vox_member_order == 1 && n_lidar <= 4 && n_surf > 0 && n_corner > 0 && stride >= 12 && !(stride & 3) && leaf_surf > 0.f && leaf_corner > 0.f && !old_pipeline) {
+        // ---- sort first (see above). The two grids' geometry as voxel_filter_run2 lays it out.
+        VoxKeyGen G;
+        const float *hb[2] = {bounds_surf, bounds_corner};
+        const float inv[2] = {1.0f / leaf_surf, 1.0f / leaf_corner};
+        int min_b[2][3], div_b[2][3];
+        long long ncell[2];
+        bool fits = true;
+        for (int k = 0; k < 2; ++k) {
+            long long ext[3];
+            for (int d = 0; d < 3; ++d) {
+                if (!std::isfinite(hb[k][d]) || !std::isfinite(hb[k][3 + d])) return fail(ctx, MLH_ERR_INVALID, "non-finite coordinates");
+                ext[d] = (long long)((hb[k][3 + d] - hb[k][d]) * inv[k]) + 1;
+                min_b[k][d] = int(std::floor(hb[k][d] * inv[k]));
+                div_b[k][d] = int(std::floor(hb[k][3 + d] * inv[k])) - min_b[k][d] + 1;
+            }
+            if (ext[0] > 2147483647ll || ext[1] > 2147483647ll || ext[2] > 2147483647ll || ext[0] * ext[1] > 2147483647ll || ext[0] * ext[1] * ext[2] > 2147483647ll) fits = false;
+            ncell[k] = (long long)div_b[k][0] * div_b[k][1] * div_b[k][2];
+        }
+        const long long off1 = ((ncell[0] + 31) / 32) * 32;
+        if (fits && off1 + ncell[1] <= 2147483647ll - 64) {
+            G.src0 = static_cast<const unsigned char *>(surf); G.src1 = static_cast<const unsigned char *>(corner); G.stride = stride; G.n0 = n_surf;
+            G.inv_leaf0 = inv[0]; G.inv_leaf1 = inv[1];
+            for (int d = 0; d < 3; ++d) { G.min_b0[d] = min_b[0][d]; G.min_b1[d] = min_b[1][d]; }
+            G.mul1_0 = div_b[0][0]; G.mul2_0 = div_b[0][0] * div_b[0][1]; G.mul1_1 = div_b[1][0]; G.mul2_1 = div_b[1][0] * div_b[1][1]; G.cell_off1 = int(off1);
+            VspArgs A;
+            A.nch0 = (n_surf + VSP_CH - 1) / VSP_CH; A.nch = A.nch0 + (n_corner + VSP_CH - 1) / VSP_CH;
+            MLH_HIP(ctx, V.members.ensure(sizeof(int) * size_t(n)));
+            MLH_HIP(ctx, V.sums.ensure(sizeof(int) * size_t(2 * A.nch + 2)));
+            MLH_HIP(ctx, V.out.ensure(sizeof(float4) * size_t(n)));
+            MLH_HIP(ctx, V.leader.ensure(sizeof(int) * size_t(n + 1)));
+            MLH_HIP(ctx, V.total.ensure(sizeof(int) * 4));
+            MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(float) * 6 * size_t(n) + 64));
+            FeatSet &f0 = ctx->feat[MLH_SURF], &f1 = ctx->feat[MLH_CORNER];
+            MLH_HIP(ctx, f0.pts.ensure(sizeof(float4) * size_t(n_surf))); MLH_HIP(ctx, f0.covd.ensure(sizeof(float4) * size_t(n_surf)));
+            MLH_HIP(ctx, f1.pts.ensure(sizeof(float4) * size_t(n_corner))); MLH_HIP(ctx, f1.covd.ensure(sizeof(float4) * size_t(n_corner)));
+            int rc = device_std_sort_by_key(ctx, nullptr, n_surf, n, V.members.as<int>(), &G);
+            if (rc) { (void)hipStreamSynchronize(st); return rc; }
+            A.keys = device_std_sort_keys(ctx, n); A.members = V.members.as<int>();
+            A.src0 = G.src0; A.src1 = G.src1; A.stride = stride; A.intensity_off = intensity_off; A.n0 = n_surf; A.n = n;
+            A.heads = V.sums.as<int>(); A.kept = A.heads + A.nch + 1;
+            A.rec = V.out.as<float4>(); A.cov6 = ctx->uct_buf.as<float>(); A.keep = V.leader.as<int>();
+            for (int i = 0; i < 4 * 7; ++i) A.ext[i] = i < 7 * n_lidar ? ext_poses[i] : 0.0;
+            for (int i = 0; i < 4 * 36; ++i) A.ext_cov[i] = (ext_covs && i < 36 * n_lidar) ? ext_covs[i] : 0.0;
+            for (int i = 0; i < 9; ++i) A.meas[i] = cov_meas ? cov_meas[i] : 0.0;
+            A.n_lidar = n_lidar; A.with_ua = with_ua ? 1 : 0; A.trace_thr = trace_thr;
+            A.pts0 = f0.pts.as<float4>(); A.covd0 = f0.covd.as<float4>(); A.pts1 = f1.pts.as<float4>(); A.covd1 = f1.covd.as<float4>();
+            A.counts = V.total.as<int>() + 2;
+            A.host_counts = nullptr; A.host_seq = nullptr; A.seq = 0;
+            if (int *hp = pinned_ints(ctx)) {
+                A.host_counts = hp + 16;
+                A.host_seq = reinterpret_cast<unsigned long long *>(hp + 32);
+                if (ctx->counts_seq == 0) *A.host_seq = 0;
+                A.seq = ++ctx->counts_seq;
+            }
+            MLH_LAUNCH(vsp_heads_kernel, dim3(A.nch), dim3(VSP_TPB), 0, st, A);
+            MLH_LAUNCH(vsp_aggregate_kernel, dim3(A.nch), dim3(VSP_TPB), 0, st, A);
+            MLH_LAUNCH(vsp_features_kernel, dim3(A.nch), dim3(VSP_TPB), 0, st, A);
+            MLH_HIP(ctx, hipGetLastError());
+            if (A.host_seq) {
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned spins = 0;
+                while (__atomic_load_n(A.host_seq, __ATOMIC_ACQUIRE) != A.seq) {
+                    if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                        MLH_HIP(ctx, hipStreamSynchronize(st));
+                        if (__atomic_load_n(A.host_seq, __ATOMIC_ACQUIRE) != A.seq) return fail(ctx, MLH_ERR_HIP, "the thinned feature counts did not arrive");
+                        break;
+                    }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                *n_surf_out = A.host_counts[0];
+                *n_corner_out = A.host_counts[1];
+            } else {
+                int stack_counts[2] = {0, 0};
+                MLH_HIP(ctx, hipMemcpyAsync(stack_counts, A.counts, sizeof(stack_counts), hipMemcpyDeviceToHost, st));
+                MLH_HIP(ctx, hipStreamSynchronize(st));
+                *n_surf_out = stack_counts[0];
+                *n_corner_out = stack_counts[1];
+            }
+            return device_error_check(ctx);
+        }
+    }
     MLH_HIP(ctx, ctx->uct_buf.ensure(sizeof(double) * size_t(n_lidar) * 43 + sizeof(float) * 6 * size_t(n) + 64));
     double *d_ext = ctx->uct_buf.as<double>();
     double *d_cov = d_ext + size_t(n_lidar) * 7;
