@@ -33,6 +33,7 @@ struct RingVoxelArgs {
     float leaf;
     int *vkeys;                 // MODE 1: PCL voxel index of every less-flat point, in list order (the keys std::sort sees)
     const int *perm;            // MODE 2: the order std::sort leaves them in (global positions of the less-flat list), voxel after voxel
+    const int *skeys;           // MODE 2: the voxel indices in that order (the sort's own key array, sorted ring by ring)
     int *zero;                  // MODE 1: n_zero words the first workgroup clears on its way (the range counters of the sort that follows)
     int n_zero;
 };
@@ -120,7 +121,18 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
         if (MODE == 1 && t < n) A.vkeys[off + t] = int(idx);
     }
     if (MODE == 1) return;
-    block_bitonic_sort<KPL, RV_WAVES>(v, keys, tid);
+    if constexpr (MODE == 2) {
+        // std::sort has already grouped the ring's points by voxel (ascending voxel index, its own order inside a voxel): element e of the sorted run is
+        // (voxel, position of the member in the ring's list) -- no second sort here, and the walk below never leaves LDS (round 4 sorted (voxel, position)
+        // keys again with a bitonic network and fetched every member's position from the permutation in HBM: 33 us of the front end)
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int e = tid * KPL + r;
+            v[r] = e < n ? ((static_cast<unsigned long long>(unsigned(A.skeys[off + e])) << 32) | unsigned(A.perm[off + e] - off)) : ~0ull;
+        }
+    } else {
+        block_bitonic_sort<KPL, RV_WAVES>(v, keys, tid);
+    }
 #pragma unroll
     for (int r = 0; r < KPL; ++r) keys[tid * KPL + r] = v[r];
     __syncthreads();
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(RV_TPB) void ring_voxel_kernel(RingVoxelArgs A)
             for (int u = tid * KPL + r; u < n; ++u) {
                 const unsigned long long ku = keys[u];
                 if (unsigned(ku >> 32) != vox) break;
-                const int pos = MODE == 2 ? A.perm[off + u] - off : int(unsigned(ku));
+                const int pos = int(unsigned(ku));
                 const float4 q = PTS_IN_LDS ? spts[pos] : A.pts[A.list3[off + pos]];
                 sx += q.x; sy += q.y; sz += q.z; si += q.w;
                 ++cnt;
@@ -217,7 +229,7 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
     RingVoxelArgs A;
     A.pts = sb.pts.as<float4>(); A.list3 = sb.lists[3].as<int>(); A.ring_counts = sb.ring_counts.as<int>();
     A.ring_offsets = sb.ring_offsets.as<int>(); A.stage = sb.vox_stage.as<float4>(); A.ring_vox = sb.ring_vox.as<int>();
-    A.leaf = leaf; A.vkeys = nullptr; A.perm = nullptr; A.zero = nullptr; A.n_zero = 0;
+    A.leaf = leaf; A.vkeys = nullptr; A.perm = nullptr; A.skeys = nullptr; A.zero = nullptr; A.n_zero = 0;
     if (longest > RV_TPB * 8) return fail(ctx, MLH_ERR_UNSUPPORTED, "ring longer than 8192 points: too long for the LDS-resident voxel sort");
     prof_begin(ctx, MLH_K_EXTRACT);
     if (ctx->vox_member_order != 0) {
@@ -231,6 +243,8 @@ int ring_voxel_run(mlh_ctx *ctx, float leaf)
         int rc = device_std_sort_segments(ctx, A.vkeys, A.ring_counts, A.ring_offsets, 4, 3, R, sb.n, longest, sb.vox_perm.as<int>(), true);
         if (rc) return rc;
         A.perm = sb.vox_perm.as<int>();
+        A.skeys = device_std_sort_keys(ctx, sb.n);
+        if (!A.skeys) return fail(ctx, MLH_ERR_HIP, "std::sort scratch");
         MLH_HIP(ctx, ring_voxel_launch_any<2>(A, R, longest, st));
     } else {
         MLH_HIP(ctx, ring_voxel_launch_any<0>(A, R, longest, st));
