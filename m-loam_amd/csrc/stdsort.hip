@@ -36,6 +36,7 @@
 #include "ctx.hpp"
 #include "stdsort_dev.hpp"
 #include <climits>
+#include <cstdlib>
 
 namespace mlh {
 
@@ -77,6 +78,24 @@ constexpr int SS_BIG_WAVES = SS_BIG_WG / 64;
 constexpr int SS_BIG_U = MLH_SS_BIG_U;           // 64-wide tiles a wavefront of a big level keeps in flight
 constexpr int SS_SWAP_U = MLH_SS_SWAP_U;         // swaps a thread of a big level keeps in flight
 constexpr int SS_BIG_LEVELS = MLH_SS_BIG_LEVELS;
+// Wide ranges (round 5): a range longer than SS_WIDE_MIN is partitioned by SEVERAL workgroups, SS_WIDE_CHUNK elements each, in two launches per level -- the stop
+// lists (stdsort_wide_stops_kernel), then the pairing, the swaps and the children (the wide half of stdsort_big_level_kernel) -- instead of streaming through the
+// 16 wavefronts of ONE compute unit (28 / 25 / 24 / 19 us for the first four levels of a frame's 62 k points). Same pairs, same cut: the partition is a function
+// of the two stop lists of the arrangement it starts from (header), however many workgroups write them down.
+#ifndef MLH_SS_WIDE_MIN
+#define MLH_SS_WIDE_MIN 8192
+#endif
+constexpr int SS_WIDE_MIN = MLH_SS_WIDE_MIN;
+#ifndef MLH_SS_WIDE_CHUNK
+#define MLH_SS_WIDE_CHUNK 4096
+#endif
+#ifndef MLH_SS_WIDE_EXTRA
+#define MLH_SS_WIDE_EXTRA 2
+#endif
+constexpr int SS_WIDE_CHUNK = MLH_SS_WIDE_CHUNK;                 // elements per workgroup of a wide range: 16 wavefronts x 4 tiles
+constexpr int SS_WIDE_WAVE = SS_WIDE_CHUNK / SS_BIG_WAVES;       // 256 elements per wavefront
+constexpr int SS_WIDE_MAXW = 1024;                               // wavefront chunks per range the pairing phase indexes: ranges of up to 262 144 elements
+constexpr int SS_WIDE_INFO = 16;                                 // ints per wide range in the info block
 constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the root + one per partition with two children > 16
 
@@ -94,6 +113,9 @@ struct StdSortArgs {
     int over_level;     // the level whose list holds the ranges longer than SS_LEAF the leaf launch still has to take: SS_BIG_LEVELS after the big
                         // levels ran, 0 when they were skipped (then nothing should be there -- `longest` said so -- but if something is, it is sorted)
     int *err;           // pinned host word: set when a wait is given up on (never observed; the result would be a wrong order)
+    int *wcl, *wcr;     // wide ranges: left / right stops per wavefront chunk, all wide ranges of the level back to back (they live in glist: unused until the leaf launch)
+    int *winfo;         // wide ranges: SS_WIDE_INFO ints per range (in gfin)
+    int wide_on;        // this level's wide ranges were prepared by stdsort_wide_stops_kernel
 };
 constexpr int SS_CNT_LEAF = SS_BIG_LEVELS + 1;
 constexpr int SS_CNT = SS_BIG_LEVELS + 2;
@@ -235,17 +257,206 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *
     return cut;
 }
 
-// ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF
-__global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level)
+// ------------------------------------------------------------------ wide ranges: several workgroups per range
+__device__ __forceinline__ bool ss_is_wide(const SortSeg &s)
 {
-    __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1];
+    const int m = s.last - s.first;
+    return s.depth > 0 && m > SS_WIDE_MIN && m <= SS_WIDE_MAXW * SS_WIDE_WAVE;
+}
+
+// Which wide range and which of its chunks does workgroup `wg` serve? The level's ranges are walked 64 at a time by the first wavefront (a scan of the wide ranges'
+// chunk counts); sh[0] = index of the range in the level's list (-1: none), sh[1] = chunk, sh[2] = chunks of the range, sh[3] = chunks of the wide ranges before it,
+// sh[4] = its ordinal among the level's wide ranges. All threads of the workgroup, converged; returns after a barrier.
+__device__ __forceinline__ void ss_wide_locate(const SortSeg *cur, int count, int wg, int *sh)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) sh[0] = -1;
+    __syncthreads();
+    if (t < 64) {
+        int base = 0, ord_base = 0;
+        for (int b0 = 0; b0 < count; b0 += 64) {                      // uniform
+            const int si = b0 + lane;
+            SortSeg s{0, 0, 0, 0};
+            if (si < count) s = cur[si];
+            const bool wide = si < count && ss_is_wide(s);
+            const int nch = wide ? (s.last - s.first + SS_WIDE_CHUNK - 1) / SS_WIDE_CHUNK : 0;
+            int incl = nch, oin = wide ? 1 : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off), o = __shfl_up(oin, off);
+                if (lane >= off) { incl += v; oin += o; }
+            }
+            const int excl = incl - nch;
+            if (wide && wg >= base + excl && wg < base + incl) { sh[0] = si; sh[1] = wg - (base + excl); sh[2] = nch; sh[3] = base + excl; sh[4] = ord_base + oin - 1; }
+            base += __shfl(incl, 63);
+            ord_base += __shfl(oin, 63);
+            if (base > wg) break;                                     // uniform: found (or passed)
+        }
+    }
+    __syncthreads();
+}
+
+// the median of (first + 1, mid, last - 1) WITHOUT moving it (ss_median_to_first's choice): a wide range's workgroups all read the arrangement the level started
+// from; position `first` is treated as holding the median's element and the median's position as holding first's ("virtual" move, made real by the range's
+// leading workgroup in the second launch)
+__device__ __forceinline__ int ss_median_pos(int f, int l, int ka, int kb, int kc)
+{
+    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+    IntLess less;
+    if (less(ka, kb)) return less(kb, kc) ? ib : (less(ka, kc) ? ic : ia);
+    return less(ka, kc) ? ia : (less(kb, kc) ? ic : ib);
+}
+
+// first launch of a level with wide ranges: every workgroup writes down the left and right stops of its SS_WIDE_CHUNK elements (per wavefront, ascending, at the
+// wavefront chunk's own stretch of lt / rt) and their counts
+__global__ __launch_bounds__(SS_BIG_WG) void stdsort_wide_stops_kernel(StdSortArgs A, int level)
+{
+    __shared__ int sh[8];
+    const SortSeg *cur = A.seg[level & 1];
+    const int count = A.cnt[level];
+    ss_wide_locate(cur, count, blockIdx.x, sh);
+    if (sh[0] < 0) return;
+    const SortSeg s = cur[sh[0]];
+    const int chunk = sh[1], cbase = sh[3], ord = sh[4];
+    const int f = s.first, l = s.last, m = l - f;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int ka = A.keys[f + 1], kb = A.keys[f + m / 2], kc = A.keys[l - 1], k0 = A.keys[f];
+    const int med = ss_median_pos(f, l, ka, kb, kc);
+    const int piv = med == f + 1 ? ka : (med == l - 1 ? kc : kb);
+    const int lo = min(f + chunk * SS_WIDE_CHUNK + wave * SS_WIDE_WAVE, l), hi = min(lo + SS_WIDE_WAVE, l);
+    const unsigned long long below = ss_lanes_below();
+    IntLess less;
+    int run_l = 0, run_r = 0, med_l = -1, med_r = -1;
+    int k[SS_WIDE_WAVE / 64];
+#pragma unroll
+    for (int u = 0; u < SS_WIDE_WAVE / 64; ++u) { const int p = lo + 64 * u + lane; k[u] = p < hi ? A.keys[p] : 0; }
+#pragma unroll
+    for (int u = 0; u < SS_WIDE_WAVE / 64; ++u) {
+        const int p = lo + 64 * u + lane;
+        const bool in = p < hi;
+        const int key = p == f ? piv : (p == med ? k0 : k[u]);
+        const bool is_l = in && p > f && !less(key, piv);
+        const bool is_r = in && (p == f || !less(piv, key));
+        const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+        const int rl = run_l + __popcll(ml & below), rr = run_r + __popcll(mr & below);
+        if (is_l) A.lt[lo + rl] = p;
+        if (is_r) A.rt[lo + rr] = p;
+        if (in && p == med) { med_l = is_l ? rl : -1; med_r = is_r ? rr : -1; }
+        run_l += __popcll(ml);
+        run_r += __popcll(mr);
+    }
+    if (lane == 0) { A.wcl[(cbase + chunk) * SS_BIG_WAVES + wave] = run_l; A.wcr[(cbase + chunk) * SS_BIG_WAVES + wave] = run_r; }
+    // what the second launch needs to know about the median: its position, both elements, and -- from the lane that met it -- its entries in its wavefront's lists
+    int *info = A.winfo + ord * SS_WIDE_INFO;
+    if (chunk == 0 && t == 0) { info[0] = med; info[1] = k0; info[2] = A.vals[f]; info[3] = piv; info[4] = A.vals[med]; }
+    if (med >= lo && med < hi && lane == ((med - lo) & 63)) { info[5] = med_l; info[6] = med_r; info[7] = (med - f) / SS_WIDE_WAVE; }
+}
+
+// second launch, the wide half: pairing, swaps, the median's move, the children -- by all workgroups of the range (every one rebuilds the prefix tables and finds K
+// for itself; the swaps are dealt round-robin; the range's first workgroup moves the median and emits the children)
+__device__ __forceinline__ void ss_wide_pairs(const StdSortArgs &A, const SortSeg &s, int chunk, int nchunks, int cbase, int ord, int level, int *w_left, int *w_right, int *sh)
+{
+    const int f = s.first, l = s.last, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int NW = nchunks * SS_BIG_WAVES;
+    const int *info = A.winfo + ord * SS_WIDE_INFO;
+    const int med = info[0], k0 = info[1], v0 = info[2], piv = info[3], vmed = info[4];
+    // prefix of the left counts, suffix of the right counts over the range's wavefront chunks (one per thread; SS_WIDE_MAXW = the workgroup's size)
+    const int cl = t < NW ? A.wcl[cbase * SS_BIG_WAVES + t] : 0, cr = t < NW ? A.wcr[cbase * SS_BIG_WAVES + t] : 0;
+    int il = cl, ir = cr;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int a = __shfl_up(il, off), b = __shfl_up(ir, off); if (lane >= off) { il += a; ir += b; } }
+    __shared__ int s_wl[SS_BIG_WAVES], s_wr[SS_BIG_WAVES];
+    if (lane == 63) { s_wl[wave] = il; s_wr[wave] = ir; }
+    __syncthreads();
+    int bl = 0, br = 0, nL = 0, nR = 0;
+#pragma unroll
+    for (int w = 0; w < SS_BIG_WAVES; ++w) { bl += w < wave ? s_wl[w] : 0; br += w < wave ? s_wr[w] : 0; nL += s_wl[w]; nR += s_wr[w]; }
+    w_left[t + 1] = bl + il;                                       // left stops in the chunks 0 .. t
+    w_right[t] = nR - (br + ir - cr);                              // right stops in the chunks t .. NW - 1
+    if (t == 0) { w_left[0] = 0; w_right[SS_WIDE_MAXW] = 0; sh[5] = 0; }
+    __syncthreads();
+    auto wave_lo = [&](int w) { return min(f + w * SS_WIDE_WAVE, l); };
+    auto left_at = [&](int k) {
+        int w = 0;
+#pragma unroll
+        for (int step = SS_WIDE_MAXW / 2; step > 0; step >>= 1) w += (w_left[w + step] <= k) ? step : 0;
+        return A.lt[wave_lo(w) + (k - w_left[w])];
+    };
+    auto right_at = [&](int k) {
+        int w = 0;
+#pragma unroll
+        for (int step = SS_WIDE_MAXW / 2; step > 0; step >>= 1) w += (w_right[w + step] > k) ? step : 0;
+        const int after = w_right[w + 1], cnt = w_right[w] - after;
+        return A.rt[wave_lo(w) + (cnt - 1 - (k - after))];
+    };
+    const int npair = min(nL, nR);
+    if (wave == 0) {
+        int lo_k = 0, hi_k = npair;
+        while (hi_k > lo_k) {                                        // uniform
+            const int step = (hi_k - lo_k + 63) >> 6;
+            const int k = lo_k + lane * step;
+            const bool p = k < hi_k && left_at(k) < right_at(k);
+            const int c = __popcll(__ballot(p));
+            const int new_hi = min(hi_k, lo_k + c * step);
+            lo_k = c > 0 ? lo_k + (c - 1) * step + 1 : lo_k;
+            hi_k = c > 0 ? max(new_hi, lo_k) : lo_k;
+        }
+        if (lane == 0) sh[5] = lo_k;
+    }
+    __syncthreads();
+    const int K = sh[5];
+    for (int k0_ = chunk * SS_BIG_WG + t; k0_ < K; k0_ += SS_SWAP_U * nchunks * SS_BIG_WG) {
+        int p[SS_SWAP_U], q[SS_SWAP_U], kp[SS_SWAP_U], kq[SS_SWAP_U], vp[SS_SWAP_U], vq[SS_SWAP_U];
+#pragma unroll
+        for (int u = 0; u < SS_SWAP_U; ++u) { const int k = k0_ + u * nchunks * SS_BIG_WG; const bool on = k < K; p[u] = on ? left_at(k) : -1; q[u] = on ? right_at(k) : -1; }
+#pragma unroll
+        for (int u = 0; u < SS_SWAP_U; ++u) if (p[u] >= 0) {
+            // (the median's position still holds its old element: it reads as first's; `first` itself is never part of a pair)
+            kp[u] = p[u] == med ? k0 : A.keys[p[u]]; vp[u] = p[u] == med ? v0 : A.vals[p[u]];
+            kq[u] = q[u] == med ? k0 : A.keys[q[u]]; vq[u] = q[u] == med ? v0 : A.vals[q[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SS_SWAP_U; ++u) if (p[u] >= 0) { A.keys[p[u]] = kq[u]; A.keys[q[u]] = kp[u]; A.vals[p[u]] = vq[u]; A.vals[q[u]] = vp[u]; }
+    }
+    if (chunk == 0 && t == 0) {
+        // the median's move, made real: `first` takes the median's element; the median's position takes first's unless a pair has (or will have) written there
+        A.keys[f] = piv; A.vals[f] = vmed;
+        const int wm = info[7], e_l = info[5], e_r = info[6];
+        bool swapped = false;
+        if (e_l >= 0) swapped = swapped || (w_left[wm] + e_l) < K;
+        if (e_r >= 0) { const int after = w_right[wm + 1], cnt = w_right[wm] - after; swapped = swapped || (after + (cnt - 1 - e_r)) < K; }
+        if (!swapped) { A.keys[med] = k0; A.vals[med] = v0; }
+        int cut = INT_MAX;
+        if (K < nL) cut = min(cut, left_at(K));
+        if (K > 0) cut = min(cut, right_at(K - 1));
+        SortSeg *next = A.seg[(level + 1) & 1];
+        emit_global(A, cut, l, s.depth - 1, next, &A.cnt[level + 1]);     // the recursive call
+        emit_global(A, f, cut, s.depth - 1, next, &A.cnt[level + 1]);     // the loop's next trip
+    }
+}
+
+// ------------------------------------------------------------------ big levels: one 1024-thread workgroup per range longer than SS_LEAF (workgroups gridDim.x - n_wide_wg ..),
+// several per wide range (workgroups 0 .. n_wide_wg - 1, when stdsort_wide_stops_kernel has run for this level)
+__global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level, int n_wide_wg)
+{
+    __shared__ int w_left[SS_WIDE_MAXW + 1], w_right[SS_WIDE_MAXW + 1];
     __shared__ int sh_k;
+    __shared__ int sh[8];
     const SortSeg *cur = A.seg[level & 1];
     SortSeg *next = A.seg[(level + 1) & 1];
     const int count = A.cnt[level];
     const int t = threadIdx.x;
-    for (int si = blockIdx.x; si < count; si += gridDim.x) {
+    if (int(blockIdx.x) < n_wide_wg) {
+        ss_wide_locate(cur, count, blockIdx.x, sh);
+        if (sh[0] < 0) return;
+        const SortSeg s = cur[sh[0]];
+        ss_wide_pairs(A, s, sh[1], sh[2], sh[3], sh[4], level, w_left, w_right, sh);
+        return;
+    }
+    const int n_classic = gridDim.x - n_wide_wg;
+    for (int si = blockIdx.x - n_wide_wg; si < count; si += n_classic) {
         const SortSeg s = cur[si];
+        if (n_wide_wg > 0 && ss_is_wide(s)) continue;                 // served by the wide workgroups
         const int f = s.first, l = s.last, m = l - f;
         if (s.depth == 0) {                                          // __partial_sort(first, last, last): sorted for good, no children
             if (t == 0) heap_sort_range(A.keys + f, A.vals + f, m);
@@ -424,6 +635,9 @@ static int stdsort_setup(mlh_ctx *ctx, int n, int *vals_out, StdSortArgs &A, siz
     A.cnt = base + off_cnt;
     A.seg[0] = reinterpret_cast<SortSeg *>(base + off_seg0); A.seg[1] = reinterpret_cast<SortSeg *>(base + off_seg1);
     A.leaf = reinterpret_cast<SortSeg *>(base + off_leaf); A.n = n;
+    // wide ranges' per-level scratch lives where the leaf launch's global-memory lists go (nothing else touches them before that launch): counts of at most
+    // n / 256 + 16 per wavefront-chunk twice, SS_WIDE_INFO ints per wide range
+    A.wcl = A.glist; A.wcr = A.glist + ni / 2; A.winfo = A.gfin; A.wide_on = 0;
     A.over_level = SS_BIG_LEVELS;
     A.err = device_error_word(ctx);
     return MLH_OK;
@@ -439,8 +653,22 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
     A.over_level = n_levels;                                  // no big level: whatever the init kernel routed to level 0 anyway is finished by the leaf launch
     if (n_levels > 0) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
-        for (int level = 0; level < n_levels; ++level)
-            MLH_LAUNCH(stdsort_big_level_kernel, dim3(grid_big), dim3(SS_BIG_WG), 0, st, A, level);
+        // wide levels: as long as a range can still be longer than SS_WIDE_MIN -- the sizes roughly halve per level; two more levels for the unbalanced
+        // partitions. A wide range met later than that is partitioned by one workgroup, as all were until round 5 (same result).
+        static const bool wide_off = std::getenv("MLH_SS_WIDE_OFF") != nullptr;      // (A/B runs)
+        int n_wide_levels = 0;
+        const bool fits = size_t(A.n) / SS_WIDE_WAVE + 64 <= size_t(A.n) / 2 && size_t(A.n) / SS_WIDE_MIN * SS_WIDE_INFO + 64 <= size_t(A.n);
+        if (!wide_off && fits && longest > SS_WIDE_MIN) {
+            int lg = 0;
+            while ((SS_WIDE_MIN << lg) < longest) ++lg;
+            n_wide_levels = std::min(n_levels, lg + MLH_SS_WIDE_EXTRA);
+        }
+        const int n_wide_wg = A.n / SS_WIDE_CHUNK + A.n / SS_WIDE_MIN + 4;     // >= the chunks of all wide ranges of a level
+        for (int level = 0; level < n_levels; ++level) {
+            const bool wide = level < n_wide_levels;
+            if (wide) MLH_LAUNCH(stdsort_wide_stops_kernel, dim3(n_wide_wg), dim3(SS_BIG_WG), 0, st, A, level);
+            MLH_LAUNCH(stdsort_big_level_kernel, dim3(grid_big + (wide ? n_wide_wg : 0)), dim3(SS_BIG_WG), 0, st, A, level, wide ? n_wide_wg : 0);
+        }
     }
     const int grid_leaf = int(std::min<size_t>(nleaf, 1024));
     MLH_LAUNCH(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);

@@ -1054,11 +1054,17 @@ def test_device_std_sort_equals_std_sort(mla, orc):
     c = mla.Context(0)
     try:
         cases = []
-        for n in (1, 2, 15, 16, 17, 18, 33, 100, 257, 1025, 5000, 40000, 62365):
+        # (8 191 .. 12 289: around the threshold above which a range is partitioned by SEVERAL workgroups and around its 4 096-element workgroup chunks -- round 5)
+        for n in (1, 2, 15, 16, 17, 18, 33, 100, 257, 1025, 5000, 8191, 8192, 8193, 12288, 12289, 40000, 62365):
             for nv in sorted({1, 2, 7, n // 4 + 1, n + 1}):
                 i = np.arange(n)
                 cases += [rng.integers(0, nv, n), i % nv, (n - i) // (n // nv + 1), np.where(i < n // 2, i, n - i) % nv, (n - i) % nv]
         cases.append(rng.integers(0, 50000, 200000))
+        cases.append(rng.integers(0, 3, 262144))           # the longest range the wide levels take, almost all pairs crossing
+        cases.append(rng.integers(0, 100000, 262145))      # one element more: that range stays with one workgroup
+        big = np.arange(100000) % 7 + 1                     # (keys are voxel indices: non-negative, compared as PCL's unsigned idx)
+        big[50000] = 0                                      # the first level's median candidates are positions 1, mid, last - 1: the median sits at position 1
+        cases.append(big)
         for keys in cases:
             keys = keys.astype(np.int32)
             want = orc.std_sort_permutation(keys)
