@@ -645,7 +645,12 @@ __global__ __launch_bounds__(256) void features_from_kept_pair_kernel(const unsi
 //                         trace gate -> record, cov, keep flag per slot; kept records per chunk;
 //   vsp_features_kernel   kept-before-this-chunk (summed here), local scan of the keep flags -> the kinds' feature sets; the counts go to pinned host memory.
 // 17 launches instead of 25, no atomics, no occupancy grid; bit for bit the former results (same sums in the same order).
-constexpr int VSP_CH = 2048, VSP_TPB = 256, VSP_PER = VSP_CH / VSP_TPB;
+#ifndef MLH_VSP_CH
+#define MLH_VSP_CH 512
+#endif
+// positions per workgroup. 2048 (first version): a chunk of the corner cloud holds ~1 460 voxels (1.4 members each), six per thread one after the other, each with its
+// evalPointUncertainty -- vsp_aggregate_kernel 22.5 us, vsp_features_kernel 11 us by rocprofv3 (profiles/r05_frame_kernel_stats.txt); 512: one or two voxels per thread
+constexpr int VSP_CH = MLH_VSP_CH, VSP_TPB = 256, VSP_PER = VSP_CH / VSP_TPB;
 struct VspArgs {
     const int *keys, *members;            // sorted voxel indices / point indices in std::sort's order
     const unsigned char *src0, *src1;
