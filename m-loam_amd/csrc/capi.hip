@@ -1550,6 +1550,18 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
 
 // The host-polled form: chunks of LM launches with the loop's verdict read between them (statistics, good-feature selections, RCCL ranks, and the re-solve of a frame
 // whose loop outgrew its look-ahead).
+// The Levenberg-Marquardt launches of scan2map in the consumer-side form (match.hip: lm_consume_kernel) -- the default where it applies (one GPU, every feature
+// used, no statistics asked for); MLH_LM_CONSUMER=0 keeps the classic launches (read at every call: an A/B can flip it between two frames of one process).
+static bool lm_consumer_enabled(const mlh_ctx *ctx)
+{
+    const char *e = std::getenv("MLH_LM_CONSUMER");
+    if (e && std::atoi(e) == 0) return false;
+    // every workgroup sums every tile's record: the same size limit as the Gauss-Newton path's deferred finish (GN_DEFER_MAX_TILES)
+    int tiles = 0;
+    for (int k = 0; k < 2; ++k) tiles += (ctx->feat[k].m + 256 - 1) / 256;
+    return tiles <= GN_DEFER_MAX_TILES;
+}
+
 static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
 {
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
@@ -1569,6 +1581,10 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     // with a feature selection (one GPU): the dense passes and the selection come first, then the LM begin rides in the launch that evaluates the
     // selected rows and every LM step in its linearise launch, as above
     const bool fused_lm = fused || !distributed(ctx);
+    // ... and with nobody asking for per-iteration statistics, on one GPU: the LM step rides in the CONSUMER of the records -- the match launch leaves its tiles'
+    // records, every LM launch begins by summing its predecessor's and running the begin / step in all workgroups, then evaluates at the candidate (one launch more
+    // per loop: the last evaluation's verdict is the next launch's)
+    const bool lmc = fused && !stats && !distributed(ctx) && lm_consumer_enabled(ctx);
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
     // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)
@@ -1580,7 +1596,7 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         if (fused) {
             MatchArgs a = args_from_opts(opts, 3, 0);
-            a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
+            a.finish = lmc ? 0 : 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
             if (outer == 0) { a.init_pose = pose_inout; a.lm_expect_done = -1; }
             if ((rc = match_launch(ctx, a))) return rc;
         } else if (opts->gf_method == MLH_GF_WO) {
@@ -1608,11 +1624,16 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             // is already enqueued (into the other pinned record): when the verdict is "not yet" the GPU has gone on without the host's round trip (~15 us of idle
             // stream per poll in profiles/r03_frame_cpp_timeline_*.txt), when it is "done" the chunk ahead is two launches that find `done` set and leave.
             struct Pending { unsigned long long seq; HostPublish *rec; } pend[2];
-            int n_pend = 0, enq = 0;
+            int n_pend = 0, enq = 0, lm_j = 0;
+            const int lm_cap = opts->max_lm_iterations + (lmc ? 1 : 0);     // launches after which the loop has terminated by itself
             auto enqueue_chunk = [&](int count) -> int {
                 for (int j = 0; j < count; ++j) {
                     MatchArgs a = args_from_opts(opts, 3, 1);
                     a.finish = 4; a.lm_max_it = opts->max_lm_iterations;
+                    if (lmc) {
+                        a.finish = 0; a.lmc = lm_j == 0 ? 1 : 2; a.lmc_j = ++lm_j; a.lm_min_blocks = 0;
+                        if (a.lmc == 1 && outer == 0) { a.init_pose = pose_inout; a.lm_expect_done = -1; }
+                    }
                     if (j == count - 1) {                   // the chunk's last launch publishes (no publication launch)
                         unsigned long long seq = 0;
                         int prc = publish_slot(ctx, &a.publish, &seq, lm_chunk_idx);
@@ -1620,16 +1641,16 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
                         a.publish_seq = seq;
                         pend[n_pend++] = Pending{seq, a.publish};
                     }
-                    int lrc = linearize_launch(ctx, a);
+                    int lrc = lmc ? lm_consume_launch(ctx, a) : linearize_launch(ctx, a);
                     if (lrc) return lrc;
                 }
                 ++lm_chunk_idx;
                 enq += count;
                 return MLH_OK;
             };
-            if ((rc = enqueue_chunk(std::min(first_chunk, opts->max_lm_iterations)))) return rc;
+            if ((rc = enqueue_chunk(std::min(first_chunk + (lmc ? 1 : 0), lm_cap)))) return rc;
             for (;;) {
-                if (enq < opts->max_lm_iterations && n_pend < 2 && (rc = enqueue_chunk(std::min(next_chunk, opts->max_lm_iterations - enq)))) return rc;
+                if (enq < lm_cap && n_pend < 2 && (rc = enqueue_chunk(std::min(next_chunk, lm_cap - enq)))) return rc;
                 HostPublish hp;                             // pinned-memory poll of the device-side `done` flag (no copy engine, no blocking wait)
                 if ((rc = wait_published(ctx, pend[0].seq, hp, pend[0].rec))) return rc;
                 last_hp = hp; have_hp = true;
@@ -1704,17 +1725,24 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         return MLH_OK;
     }
     const int budget = std::max(1, std::min(lm_lookahead > 0 ? lm_lookahead : ctx->lm_lookahead_auto, opts->max_lm_iterations));
+    // the consumer-side form of the LM launches (scan2map_polled): budget + 1 launches run `budget` LM steps
+    const bool lmc = !ctx->p2p.active && lm_consumer_enabled(ctx);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         MatchArgs a = args_from_opts(opts, 3, 0);
-        a.finish = 3; a.stat_slot = -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
+        a.finish = lmc ? 0 : 3; a.stat_slot = -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
         a.lm_expect_done = outer == 0 ? -1 : 1;
         if (outer == 0) a.init_pose = pose_in;
         if ((rc = match_launch(ctx, a))) return rc;
-        for (int j = 0; j < budget; ++j) {
+        const int n_launch = budget + (lmc ? 1 : 0);
+        for (int j = 0; j < n_launch; ++j) {
             MatchArgs b = args_from_opts(opts, 3, 1);
             b.finish = 4; b.lm_max_it = opts->max_lm_iterations;
-            if (outer == opts->max_outer - 1 && j == budget - 1) { b.publish = rec; b.publish_seq = seq; }
-            if ((rc = linearize_launch(ctx, b))) return rc;
+            if (lmc) {
+                b.finish = 0; b.lmc = j == 0 ? 1 : 2; b.lmc_j = j + 1; b.lm_min_blocks = 0;
+                if (j == 0) { b.lm_expect_done = outer == 0 ? -1 : 1; if (outer == 0) b.init_pose = pose_in; }
+            }
+            if (outer == opts->max_outer - 1 && j == n_launch - 1) { b.publish = rec; b.publish_seq = seq; }
+            if ((rc = lmc ? lm_consume_launch(ctx, b) : linearize_launch(ctx, b))) return rc;
         }
     }
     ctx->solve_seq = seq;

@@ -62,6 +62,17 @@ struct SolverState {
     double pad2[1];
 };
 
+// The Levenberg-Marquardt part of the solver state, in the form the consumer-side schedule keeps it (match.hip: lm_consume_kernel): two of these, launch g reads
+// [(g - 1) & 1] and ONE workgroup of it writes [g & 1] -- the other workgroups of launch g may still be reading the first while that one stores the second
+struct LmState {
+    double x[7], cand[7];
+    double V[36];
+    double ne[NE_STRIDE];
+    double diag[6], S[6];
+    double radius, decrease_factor, model_cost_change, gmax, lm_used_max;
+    int reuse_diagonal, iteration, done, termination, num_successful, num_invalid, evaluations, lm_overflow;
+};
+
 // pinned host record the device writes the result pose(s) into; seq is stored last with system-scope release
 struct HostPublish {
     double x[7];
@@ -266,6 +277,8 @@ struct mlh_ctx {
     mlh::DevBuf oob_flag;    // map staging: bit k set = the cloud of kind k has points outside its grid box
     bool oob_init = false;
     mlh::DevBuf ticket;      // arrival counter of the fused GN finish
+    mlh::DevBuf lm_pp;       // two LmState records of the consumer-side Levenberg-Marquardt schedule
+    unsigned long long lmc_count = 0;     // consumer launches so far (its parity picks the record a launch writes)
     mlh::DevBuf stats;       // IterStatDev[...]
     mlh::DevBuf knn_q, knn_idx, knn_d;
     mlh::DevBuf tmp;         // H2D staging of caller records before packing
@@ -550,12 +563,17 @@ struct MatchArgs {
     HostPublish *pre_final_publish = nullptr;
     unsigned long long pre_final_seq = 0;
     const double *chain_prev = nullptr, *chain_cur = nullptr;   // host: the two odometry poses of the chain (7 doubles each)
+    // Levenberg-Marquardt with the step done by the consumer (lm_consume_launch): 1 = the first launch behind a match launch whose fit kernel only left its records
+    // (finish 0) -- sums them, runs the LM begin, evaluates at the first candidate; 2 = a later launch -- sums the records at the candidate, runs the LM step,
+    // evaluates at the next candidate. lmc_j: the launch's number within its loop (1, 2, ...: record buffer (j - 1) & 1 is read, j & 1 written)
+    int lmc = 0, lmc_j = 0;
     HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
     unsigned long long publish_seq = 0;
 };
 int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int gn_flush_pending(mlh_ctx *ctx);      // completes a pending last iteration with a one-workgroup launch (no-op when nothing is pending)
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
+int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a);
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
 // select.hip
 }  // namespace mlh

@@ -238,6 +238,11 @@ struct KParams {
     double pre_thre;
     int pre_freeze;
     double chain_prev[7], chain_cur[7];
+    // Levenberg-Marquardt with the step done by the consumer (lm_consume_kernel): the records the previous launch left, the state its writer left, the state this
+    // launch's writer leaves
+    const double *partials_in;
+    const LmState *lm_in;
+    LmState *lm_out;
 };
 
 __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
@@ -897,6 +902,147 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
     MLH_STAGE(gtile, 4);
 }
 
+// ---- Levenberg-Marquardt, the step done by the CONSUMER of the records (the Gauss-Newton path's round-4 move, for the loop scan2MapOptimization really runs).
+// linearize_kernel<true> evaluates at the candidate, leaves its tile's record, takes a ticket, and the last workgroup to arrive sums the records and runs the LM
+// step while 87 others have left: fence + ticket + acquire, then sum + step, all behind the slowest tile. Here a launch ends at its records; the NEXT launch's every
+// workgroup sums them (sum_partials<TPB, 12>'s slices, chains and association: the same bits in every workgroup), runs the LM begin / step on its first wavefront
+// (lm_begin_wave_pp / lm_step_wave_pp: the accept / reject decision and the next candidate are a function of the records and the state, so all workgroups hold the
+// same candidate), and evaluates its own tile there -- with the tile's correspondences, features and covariances requested before the sum, so that their trip
+// runs under the step. The state lives in two LmState records: launch g reads [(g - 1) & 1], its tile-0 workgroup writes [g & 1] (and mirrors the accepted pose
+// into SolverState::x, which only launches behind this one read); the records alternate between two buffers the same way. A launch that finds the loop terminated
+// copies the state forward and leaves (the host enqueues a look-ahead of launches without reading the verdict in between, as before).
+// FIRST: the launch behind a match launch whose fit kernel ran with finish 0 -- the records are at the state's pose (or init_pose), the LM loop begins here.
+__device__ __forceinline__ void lmc_sum_records(const double *__restrict__ rec, int ntot, double *f_ne, double *f_scratch)
+{
+    constexpr int NS = TPB / 32, U = 12;
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = sl; j < ntot; j += U * NS) {
+        double tv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = j + NS * u;
+            tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
+    }
+    f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
+        f_ne[c] = tsum;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lmc_publish(const KParams &P, const double (&x)[7], int done, int overflow, double used_max, int iteration)
+{
+    for (int i = 0; i < 7; ++i) P.publish->x[i] = x[i];
+    P.publish->done = done | (overflow ? 2 : 0);
+    P.publish->xb[2][0] = fmax(used_max, double(iteration));
+    __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
+{
+    __shared__ double s_red[4 * 32];
+    __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];
+    __shared__ double s_cand[8];
+    __shared__ int s_done;
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = xcd_tile(total);
+    if (gtile >= total) return;
+    const LmState *Si = P.lm_in;
+    LmState *So = P.lm_out;
+    const bool writer = gtile == 0;
+    if constexpr (!FIRST) {
+        if (Si->done) {                    // the loop ended in an earlier launch (uniform over the grid): the state goes forward as it is
+            if (writer && threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                constexpr int NW = int(sizeof(LmState) / sizeof(double));
+                static_assert(sizeof(LmState) % sizeof(double) == 0, "LmState is copied in doubles");
+                const double *src = reinterpret_cast<const double *>(Si);
+                double *dst = reinterpret_cast<double *>(So);
+                for (int i = lane; i < NW; i += 64) dst[i] = src[i];
+                if (P.publish && lane == 0) {
+                    double x[7];
+                    for (int i = 0; i < 7; ++i) x[i] = Si->x[i];
+                    lmc_publish(P, x, Si->done, Si->lm_overflow, Si->lm_used_max, Si->iteration);
+                }
+            }
+            return;
+        }
+    }
+    // this tile's inputs: requested now, used after the step
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const KindP &K = P.k[kind];
+    const int f = tile * TPB + threadIdx.x;
+    Corr c;
+    c.valid = 0;
+    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < K.m) {
+        c = K.corr[f];
+        fp = K.feat[f];
+        if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
+    }
+    lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        LmRegs R;
+        double cand[7];
+        int overflow;
+        double used_max;
+        if constexpr (FIRST) {
+            double x[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = P.use_init ? P.init_pose[i] : P.state->x[i];
+            // (split submission: this outer iteration was enqueued without anybody having seen the previous LM loop end -- fused_gn_finish's bookkeeping)
+            if (P.lm_expect_done) {
+                overflow = (P.lm_expect_done > 0 && (Si->lm_overflow || !Si->done)) ? 1 : 0;
+                used_max = P.lm_expect_done > 0 ? fmax(Si->lm_used_max, double(Si->iteration)) : 0.0;
+            } else { overflow = Si->lm_overflow; used_max = Si->lm_used_max; }
+            lm_begin_wave_pp(f_ne, f_scratch, x, So, writer, P.thre_b[0], P.lm_max_it, P.lm_min_blocks, R, cand);
+            if (writer && P.use_init && lane < 7) P.state->x[lane] = pick7(x, lane);       // the state's pose is born here
+        } else {
+            overflow = Si->lm_overflow; used_max = Si->lm_used_max;
+            lm_step_wave_pp(f_ne, Si, So, writer, P.lm_max_it, R, cand);
+            if (writer && lane < 7) P.state->x[lane] = pick7(R.x, lane);                   // read by the launches BEHIND this one only
+        }
+        if (lane < 7) s_cand[lane] = pick7(cand, lane);
+        if (lane == 0) s_done = R.done;
+        if (writer && lane == 0) {
+            So->lm_overflow = overflow; So->lm_used_max = used_max;
+            if (P.publish) lmc_publish(P, R.x, R.done, overflow, used_max, R.iteration);
+        }
+    }
+    __syncthreads();
+    if (s_done) return;                    // terminated by this launch: nothing to evaluate (the next launch finds `done` and reads no records)
+    const q4 q{s_cand[3], s_cand[4], s_cand[5], s_cand[6]};
+    const d3 t{s_cand[0], s_cand[1], s_cand[2]};
+    bool valid = false;
+    int mult = 1;
+    Lin L;
+    L.r = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
+    if (f < K.m && c.valid) {
+        valid = true;
+        mult = c.valid;
+        const double w = feature_weight_pref(P, K, cdv);
+        double R9[9];
+        qtorot(q, R9);
+        const d3 p{double(fp.x), double(fp.y), double(fp.z)};
+        if (kind == MLH_SURF) eval_plane(p, c.c, w, q, t, R9, L);
+        else eval_edge(p, c.c, w, q, t, R9, L);
+    }
+    reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE, mult);
+}
+
 // stand-alone exact 5-NN for mlh_knn (queries already in the map frame)
 __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
                                                           float *__restrict__ d2)
@@ -997,7 +1143,8 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     }
     if (tiles_b_total == 0) return fail(ctx, MLH_ERR_STATE, "no map/features staged for the requested kinds");
     hipError_t e;
-    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
+    // (two sets of records: the consumer-side Levenberg-Marquardt launches alternate between them)
+    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total) * 2)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
     if (!ctx->ticket.p) {
         if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
         if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
@@ -1065,7 +1212,19 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         P.pre_freeze = a.pre_final_freeze;
         for (int i = 0; i < 7; ++i) { P.chain_prev[i] = a.chain_prev[i]; P.chain_cur[i] = a.chain_cur[i]; }
     }
-    P.publish = (a.finish == 1 || a.finish == 4) ? a.publish : nullptr;
+    P.publish = (a.finish == 1 || a.finish == 4 || a.lmc) ? a.publish : nullptr;
+    if (a.lmc) {
+        if (!ctx->lm_pp.p) {
+            if ((e = ctx->lm_pp.ensure(2 * sizeof(LmState))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc lm state", e);
+            if ((e = hipMemsetAsync(ctx->lm_pp.p, 0, 2 * sizeof(LmState), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset lm state", e);
+        }
+        const unsigned long long g = ++ctx->lmc_count;
+        P.lm_in = ctx->lm_pp.as<LmState>() + ((g - 1) & 1);
+        P.lm_out = ctx->lm_pp.as<LmState>() + (g & 1);
+        const size_t set = size_t(NE_STRIDE) * size_t(tiles_b_total);
+        P.partials_in = ctx->partials.as<double>() + set * size_t((a.lmc_j - 1) & 1);
+        P.partials = ctx->partials.as<double>() + set * size_t(a.lmc_j & 1);
+    }
     P.publish_seq = a.publish_seq;
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = (a.stat_slot >= 0) ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
@@ -1172,6 +1331,22 @@ int linearize_launch(mlh_ctx *ctx, const MatchArgs &a)
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
     if (P.finish == 3 || P.finish == 4) launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<true>, grid_b, P);
     else launch_timed(ctx, MLH_K_LINEARIZE, linearize_kernel<false>, grid_b, P);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
+{
+    for (int k = 0; k < 2; ++k)
+        if ((a.kind_mask & (1 << k)) && !ctx->feat[k].matched) return fail(ctx, MLH_ERR_STATE, "the Levenberg-Marquardt launches need a previous match of this kind");
+    if (a.lmc < 1 || a.lmc > 2 || a.lmc_j < 1 || a.n_blocks > 1 || a.dense) return fail(ctx, MLH_ERR_INVALID, "lm_consume_launch: single block, no dense rows");
+    KParams P;
+    int rc = fill_params(ctx, a, P);
+    if (rc) return rc;
+    if (P.p2p.n_ranks > 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the consumer-side Levenberg-Marquardt schedule is single-GPU");
+    const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
+    if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
+    else launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

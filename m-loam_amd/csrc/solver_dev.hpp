@@ -798,7 +798,8 @@ __device__ __forceinline__ void lm_propose_wave(LmRegs &R, const double *ne, con
     }
 }
 
-__device__ __forceinline__ void lm_regs_load(LmRegs &R, const SolverState *S)
+template <class ST>
+__device__ __forceinline__ void lm_regs_load(LmRegs &R, const ST *S)
 {
 #pragma unroll
     for (int i = 0; i < 7; ++i) R.x[i] = S->x[i];
@@ -810,7 +811,8 @@ __device__ __forceinline__ void lm_regs_load(LmRegs &R, const SolverState *S)
 }
 
 // everything but x / ne (stored by the caller when a step is accepted) and cand
-__device__ __forceinline__ void lm_regs_store(const LmRegs &R, const double (&cand)[7], SolverState *S, int lane)
+template <class ST>
+__device__ __forceinline__ void lm_regs_store(const LmRegs &R, const double (&cand)[7], ST *S, int lane)
 {
     if (lane < 7 && !R.done) S->cand[lane] = lane == 0 ? cand[0] : (lane == 1 ? cand[1] : (lane == 2 ? cand[2] : (lane == 3 ? cand[3] : (lane == 4 ? cand[4] : (lane == 5 ? cand[5] : cand[6])))));
     if (lane >= 8 && lane < 14) { const int i = lane - 8; S->diag[i] = i == 0 ? R.diag[0] : (i == 1 ? R.diag[1] : (i == 2 ? R.diag[2] : (i == 3 ? R.diag[3] : (i == 4 ? R.diag[4] : R.diag[5])))); }
@@ -925,6 +927,110 @@ __device__ __forceinline__ void lm_begin_body_wave(const double *ne, const doubl
 #pragma unroll
     for (int i = 0; i < 7; ++i) x_out[i] = R.x[i];
     done_out = R.done;
+}
+
+// ---------------------------------------------------------------- the same two bodies for the consumer-side schedule (match.hip: lm_consume_kernel)
+// EVERY workgroup of a launch runs them on the same inputs -- the state the previous launch's writer left (Si), the summed records in LDS -- and keeps the outcome
+// in registers (R, cand); only the launch's writer (`write`) stores the state the next launch reads (So != Si: the other workgroups may still be reading Si).
+// Operation for operation lm_step_body_wave / lm_begin_body_wave above: the same bits.
+__device__ __forceinline__ double pick7(const double (&v)[7], int i)
+{
+    return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : (i == 3 ? v[3] : (i == 4 ? v[4] : (i == 5 ? v[5] : v[6])))));
+}
+__device__ __forceinline__ double pick6(const double (&v)[6], int i)
+{
+    return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : (i == 3 ? v[3] : (i == 4 ? v[4] : v[5]))));
+}
+
+// what a state record holds beyond lm_regs_store's share: the pose, the record at the pose, V_update, the Jacobi scaling (ne_now / V: any memory)
+__device__ __forceinline__ void lm_state_store_pp(const LmRegs &R, const double (&cand)[7], const double *ne_now, const double *V, LmState *So, int lane)
+{
+    lm_regs_store(R, cand, So, lane);
+    if (lane < 7) So->x[lane] = pick7(R.x, lane);
+    if (lane < NE_STRIDE) So->ne[lane] = ne_now[lane];
+    if (lane < 36) So->V[lane] = V[lane];
+    if (lane >= 40 && lane < 46) So->S[lane - 40] = pick6(R.Sv, lane - 40);
+}
+
+__device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState *Si, LmState *So, bool write, int max_it, LmRegs &R, double (&cand)[7])
+{
+    const int lane = threadIdx.x & 63;
+    lm_regs_load(R, Si);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cand[i] = Si->cand[i];
+    const double x_cost = Si->ne[NE_COST];
+    R.evaluations++;
+    double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const double d = R.x[i] - cand[i]; step_norm += d * d; x_norm += R.x[i] * R.x[i]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    bool stop = false;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { R.done = 1; R.termination = 2; stop = true; }
+    const double cost_change = x_cost - ce[NE_COST];
+    if (!stop && fabs(cost_change) <= 1e-6 * x_cost) { R.done = 1; R.termination = 3; stop = true; }
+    const double *ne_now = Si->ne;
+    if (!stop) {
+        const double rd = cost_change / R.model_cost_change;
+        if (rd > 1e-3) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) R.x[i] = cand[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) R.g[i] = ce[NE_G + i];
+            ne_now = ce;
+            R.num_successful++;
+            const double t = 2.0 * rd - 1.0;
+            R.radius = R.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            R.radius = fmin(1e16, R.radius);
+            R.decrease_factor = 2.0;
+            R.reuse_diagonal = 0;
+            R.gmax = gradient_max_norm_wave(R, Si->V, lane);
+        } else {
+            R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
+        }
+        lm_propose_wave(R, ne_now, Si->V, cand, max_it, lane);
+    }
+    if (write) lm_state_store_pp(R, cand, ne_now, Si->V, So, lane);
+}
+
+// x: the pose the records in `ne` were taken at. ne / scratch: LDS. No statistics in this schedule (the classic launches serve a caller who asks for them).
+__device__ __forceinline__ void lm_begin_wave_pp(const double *ne, double *scratch, const double (&x)[7], LmState *So, bool write, double eig_thre, int max_it, int min_blocks,
+                                                 LmRegs &R, double (&cand)[7])
+{
+    const int lane = threadIdx.x & 63;
+    int flags = 0;
+    if (lane == 0) {
+        bool fast = eig_thre < 0.0;
+        if (!fast) {
+            double L[21], inv_d[6];
+            pack_lower_from_ne(ne, eig_thre * (1.0 + 1e-9), L);
+            fast = chol6p_factor(L, inv_d);
+        }
+        if (!fast) (void)eval_degeneracy_reg(ne, eig_thre, scratch);
+        flags = fast ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    flags = __builtin_amdgcn_readlane(flags, 0);
+    const bool fast = (flags & 1) != 0;
+    if (fast && lane < 36) scratch[78 + lane] = ((lane % 7) == 0) ? 1.0 : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 7; ++i) R.x[i] = x[i];
+    {
+        const int r = lane < 6 ? lane : 0;
+        const double sc = 1.0 / (1.0 + sqrt(ne[r * 6 - (r * (r - 1)) / 2]));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { R.Sv[i] = wave_bcast(sc, i); R.g[i] = ne[NE_G + i]; R.diag[i] = 0.0; }
+    }
+    R.radius = 1e4; R.decrease_factor = 2.0; R.reuse_diagonal = 0; R.model_cost_change = 0.0;
+    R.iteration = 0; R.done = 0; R.termination = 0; R.num_successful = 0; R.num_invalid = 0; R.evaluations = 1;
+    R.gmax = gradient_max_norm_wave(R, scratch + 78, lane);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cand[i] = 0.0;
+    if (ne[NE_CNT] < double(min_blocks)) { R.done = 1; R.termination = 4; }
+    else lm_propose_wave(R, ne, scratch + 78, cand, max_it, lane);
+    if (write) lm_state_store_pp(R, cand, ne, scratch + 78, So, lane);
 }
 
 }  // namespace mlh

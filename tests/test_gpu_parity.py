@@ -1355,6 +1355,51 @@ def test_scan2map_split_submission_equals_the_synchronous_call(mla, case16, feat
         c.close()
 
 
+def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feats16, monkeypatch):
+    """The Levenberg-Marquardt launches of scan2map in their two forms -- the step in the last workgroup of the launch that evaluated (MLH_LM_CONSUMER=0), or in every
+    workgroup of the NEXT launch (the default without statistics) -- are the same arithmetic on the same records: the same pose bits from the synchronous call, from
+    the split submission at every look-ahead, and the same look-ahead verdicts (exactly enough / one too few)."""
+    p0 = case16["p0"]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    starts = [p0]
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        d = p0.copy()
+        d[:3] += rng.normal(0, 0.05, 3)
+        d[3:] += rng.normal(0, 0.004, 4)
+        d[3:] /= np.linalg.norm(d[3:])
+        starts.append(d)
+    c = mla.Context(0)
+    try:
+        _stage(c, mla, case16, feats16)
+        for s0 in starts:
+            with_stats, st = c.scan2map(s0)                       # statistics asked for: always the classic launches
+            need = max(int(x["lm_iterations"]) for x in st)
+            got = {}
+            for mode in ("0", "1"):
+                monkeypatch.setenv("MLH_LM_CONSUMER", mode)
+                sync = c.scan2map(s0, want_stats=False)[0]
+                c.scan2map_begin(s0)
+                split, status = c.scan2map_end()
+                assert status == 0
+                c.scan2map_begin(s0, lm_lookahead=need)
+                exact, status_exact = c.scan2map_end()
+                c.scan2map_begin(s0, lm_lookahead=max(need - 1, 1))
+                short, status_short = c.scan2map_end()
+                c.scan2map_begin(s0)
+                c.scan2map_begin_chained(ident, ident)
+                a, sa = c.scan2map_end()
+                b, sb = c.scan2map_end()
+                assert sa == 0 and sb == 0
+                got[mode] = (sync, split, exact, status_exact, short, status_short, a, b)
+            for x, y in zip(got["0"], got["1"]):
+                assert np.array_equal(x, y)
+            assert np.array_equal(got["1"][0], with_stats)
+            assert got["1"][3] == 0 and (need == 1 or got["1"][5] == 2)
+    finally:
+        c.close()
+
+
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
     _stage(ctx, mla, case16, feats16)
