@@ -1552,6 +1552,22 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
 // whose loop outgrew its look-ahead).
 // The Levenberg-Marquardt launches of scan2map in the consumer-side form (match.hip: lm_consume_kernel) -- the default where it applies (one GPU, every feature
 // used, no statistics asked for); MLH_LM_CONSUMER=0 keeps the classic launches (read at every call: an A/B can flip it between two frames of one process).
+// ... and the whole LM loop of an outer iteration as ONE launch whose workgroups synchronise among themselves (match.hip: lm_loop_kernel); MLH_LM_LOOP=0 keeps
+// one launch per LM iteration (read at every call, as above)
+static bool lm_loop_enabled()
+{
+    const char *e = std::getenv("MLH_LM_LOOP");
+    return !(e && std::atoi(e) == 0);
+}
+
+// MLH_S2M_WARM=0: every outer iteration searches unbounded (A/B)
+static bool s2m_warm_applies(const mlh_ctx *ctx)
+{
+    const char *e = std::getenv("MLH_S2M_WARM");
+    if (e && std::atoi(e) == 0) return false;
+    return ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi && ctx->own_mod <= 1;
+}
+
 static bool lm_consumer_enabled(const mlh_ctx *ctx)
 {
     const char *e = std::getenv("MLH_LM_CONSUMER");
@@ -1585,6 +1601,31 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     // records, every LM launch begins by summing its predecessor's and running the begin / step in all workgroups, then evaluates at the candidate (one launch more
     // per loop: the last evaluation's verdict is the next launch's)
     const bool lmc = fused && !stats && !distributed(ctx) && lm_consumer_enabled(ctx);
+    if (lmc && lm_loop_enabled()) {
+        // the LM loop of every outer iteration is one launch that ends when the loop does: the whole frame is enqueued at once, the last launch publishes
+        HostPublish *rec = nullptr;
+        unsigned long long seq = 0;
+        if ((rc = publish_slot(ctx, &rec, &seq, 0))) return rc;
+        for (int outer = 0; outer < opts->max_outer; ++outer) {
+            MatchArgs a = args_from_opts(opts, 3, 0);
+            a.finish = 0; a.lm_max_it = opts->max_lm_iterations;
+            if (outer == 0) a.init_pose = pose_inout;
+            a.warm = outer >= 1 && s2m_warm_applies(ctx);
+            if ((rc = match_launch(ctx, a))) return rc;
+            MatchArgs b = args_from_opts(opts, 3, 1);
+            b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0;
+            b.lm_expect_done = outer == 0 ? -1 : 1;
+            if (outer == 0) b.init_pose = pose_inout;
+            if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
+            if ((rc = lm_consume_launch(ctx, b))) return rc;
+        }
+        HostPublish hp;
+        if ((rc = wait_published(ctx, seq, hp, rec))) return rc;
+        if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
+        if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+        for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+        return MLH_OK;
+    }
     if (!fused && (rc = upload_pose(ctx, pose_inout))) return rc;
     // LM iterations enqueued between two looks at the device-side `done` flag: six first (the mapper's solves converge in 5-7), then two at a time -- launches
     // enqueued after convergence are no-ops, but each still costs a dispatch (profiles/r03_frame_timeline.txt: five of them behind a 7-iteration solve)
@@ -1598,6 +1639,9 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             MatchArgs a = args_from_opts(opts, 3, 0);
             a.finish = lmc ? 0 : 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
             if (outer == 0) { a.init_pose = pose_inout; a.lm_expect_done = -1; }
+            // outer iterations behind the first search the same map for the same features from a pose a few centimetres away: bounded by the neighbours the
+            // previous outer iteration left (knn_feature_warm: still the exact 5-NN)
+            a.warm = outer >= 1 && s2m_warm_applies(ctx);
             if ((rc = match_launch(ctx, a))) return rc;
         } else if (opts->gf_method == MLH_GF_WO) {
             if ((rc = match_launch(ctx, args_from_opts(opts, 3, 0)))) return rc;
@@ -1727,11 +1771,27 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     const int budget = std::max(1, std::min(lm_lookahead > 0 ? lm_lookahead : ctx->lm_lookahead_auto, opts->max_lm_iterations));
     // the consumer-side form of the LM launches (scan2map_polled): budget + 1 launches run `budget` LM steps
     const bool lmc = !ctx->p2p.active && lm_consumer_enabled(ctx);
-    for (int outer = 0; outer < opts->max_outer; ++outer) {
+    // ... or one launch per LM loop, which ends on the device when the loop does: no budget, nothing to overflow (an explicit lm_lookahead keeps the launches it counts)
+    const bool loop = lmc && lm_lookahead <= 0 && lm_loop_enabled();
+    for (int outer = 0; loop && outer < opts->max_outer; ++outer) {
+        MatchArgs a = args_from_opts(opts, 3, 0);
+        a.finish = 0; a.lm_max_it = opts->max_lm_iterations;
+        if (outer == 0) a.init_pose = pose_in;
+        a.warm = outer >= 1 && s2m_warm_applies(ctx);
+        if ((rc = match_launch(ctx, a))) return rc;
+        MatchArgs b = args_from_opts(opts, 3, 1);
+        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0;
+        b.lm_expect_done = outer == 0 ? -1 : 1;
+        if (outer == 0) b.init_pose = pose_in;
+        if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
+        if ((rc = lm_consume_launch(ctx, b))) return rc;
+    }
+    for (int outer = 0; !loop && outer < opts->max_outer; ++outer) {
         MatchArgs a = args_from_opts(opts, 3, 0);
         a.finish = lmc ? 0 : 3; a.stat_slot = -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0;
         a.lm_expect_done = outer == 0 ? -1 : 1;
         if (outer == 0) a.init_pose = pose_in;
+        a.warm = outer >= 1 && s2m_warm_applies(ctx);
         if ((rc = match_launch(ctx, a))) return rc;
         const int n_launch = budget + (lmc ? 1 : 0);
         for (int j = 0; j < n_launch; ++j) {
@@ -1784,6 +1844,7 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
     ctx->solve_pending = ctx->solve_seq != ctx->solve_collected;
     if (rc) return rc;
     if (!ctx->prof.pending.empty() && !ctx->solve_pending) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+    if (slot.kind == 1 && (hp.done & 4)) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map_end: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
     if (slot.kind == 1) {
         // the next frame's automatic look-ahead: what this frame's longest LM loop used, plus two (consecutive mapper frames need about the same); a frame that
         // overflowed doubles it

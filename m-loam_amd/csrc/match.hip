@@ -118,6 +118,7 @@ __device__ __forceinline__ void eval_edge(const d3 &p, const float (&c)[6], doub
 
 // accumulate one (possibly invalid) row and reduce the 29 sums over the workgroup -> partials[tile]
 // (mult: how many identical residual blocks the row stands for -- 1, except for the feature a selection picked repeatedly, select.hip: apply_keep_kernel)
+template <bool COH = false>
 __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, int kind, double *lds_red /*4*32*/,
                                             double *__restrict__ partial_out, int mult = 1)
 {
@@ -156,7 +157,7 @@ __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delt
         for (int i = 0; i < 29; ++i) acc[i] = 0.0;
     }
     acc[29] = acc[30] = acc[31] = 0.0;
-    reduce_acc32(acc, kind, lds_red, partial_out);
+    reduce_acc32<COH>(acc, kind, lds_red, partial_out);
 }
 
 // feature_extract.hpp:696-715
@@ -835,6 +836,10 @@ extern "C" int mlh_debug_stage_clock(unsigned long long *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk), sizeof(unsigned long long) * size_t(n_words));
 }
+extern "C" int mlh_debug_stage_clock_step(unsigned long long *out, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_step_clk), sizeof(unsigned long long) * size_t(n_words));
+}
 extern "C" int mlh_debug_stage_clock_knn(unsigned long long *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_knn), sizeof(unsigned long long) * size_t(n_words));
@@ -912,7 +917,8 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 // into SolverState::x, which only launches behind this one read); the records alternate between two buffers the same way. A launch that finds the loop terminated
 // copies the state forward and leaves (the host enqueues a look-ahead of launches without reading the verdict in between, as before).
 // FIRST: the launch behind a match launch whose fit kernel ran with finish 0 -- the records are at the state's pose (or init_pose), the LM loop begins here.
-__device__ __forceinline__ void lmc_sum_records(const double *__restrict__ rec, int ntot, double *f_ne, double *f_scratch)
+template <bool COH = false>
+__device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, double *f_ne, double *f_scratch)
 {
     constexpr int NS = TPB / 32, U = 12;
     const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -922,7 +928,8 @@ __device__ __forceinline__ void lmc_sum_records(const double *__restrict__ rec, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jj = j + NS * u;
-            tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+            if constexpr (COH) tv[u] = jj < ntot ? __hip_atomic_load(rec + size_t(jj) * NE_STRIDE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            else tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
@@ -1043,6 +1050,144 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
     reduce_rows(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE, mult);
 }
 
+// ---- The whole Levenberg-Marquardt loop of one outer iteration in ONE launch. The consumer-side launches above still pay a launch boundary per LM iteration
+// (~4.4 us of an ~8.9 us launch on the 88-tile mapper frame) and a look-ahead of launches behind the loop's end; the tiles of a frame that qualifies for the
+// consumer-side schedule (<= GN_DEFER_MAX_TILES workgroups: all resident at once on 256 compute units) can synchronise among themselves instead:
+//   every workgroup: tile inputs -> registers (once); sum the fit launch's records; LM begin; then, until the loop terminates:
+//     evaluate the tile at the candidate -> record (buffer (it + 1) & 1) -> grid barrier (release; one atomic arrival; spin on the counter; acquire)
+//     -> sum all records -> LM step (the state stays in LDS: every workgroup runs the identical arithmetic on identical inputs, so they agree on accept / reject,
+//     on the next candidate and on the iteration the loop ends at, without exchanging anything but the records).
+// The loop ends on the device when Ceres' loop would: no look-ahead budget, no launches that find `done`, nothing for the host to poll between LM iterations,
+// and the split submission cannot overflow. Same operations in the same order as the launches it replaces: the same bits.
+// Barrier: P.ticket[1] counts arrivals (monotonic over the launch: iteration `it` waits for total * (it + 1)), P.ticket[2] counts workgroups that have left; the
+// last one to leave zeroes both for the next launch. A spin that outlasts MLH_LOOP_SPIN_LIMIT polls (seconds; a workgroup that never became resident, a fault)
+// ends the loop with bit 2 of the published `done` word set -- the host reports an error instead of hanging.
+// MLH_LOOP_COH 1: the records cross the barrier as agent-scope monotonic stores / loads (write-through, read past the L2 of the reader's XCD) -- no L2 write-back
+// and invalidate around the barrier; 0: plain stores + release fence / acquire fence + plain loads
+#ifndef MLH_LOOP_COH
+#define MLH_LOOP_COH 1
+#endif
+#ifndef MLH_LOOP_SPIN_LIMIT
+#define MLH_LOOP_SPIN_LIMIT 4000000u
+#endif
+__global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
+{
+    __shared__ double s_red[4 * 32];
+    __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];
+    __shared__ double s_cand[8];
+    __shared__ int s_done, s_timeout;
+    __shared__ LmState s_lm;
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = xcd_tile(total);
+    if (gtile >= total) return;            // (the grid is rounded up to a multiple of 8: the padding workgroups take no part in the barrier)
+    const bool writer = gtile == 0;
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const KindP &K = P.k[kind];
+    const int f = tile * TPB + threadIdx.x;
+    Corr c;
+    c.valid = 0;
+    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < K.m) {
+        c = K.corr[f];
+        fp = K.feat[f];
+        if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
+    }
+    const bool valid = f < K.m && c.valid != 0;
+    const int mult = valid ? c.valid : 1;
+    const double w = feature_weight_pref(P, K, cdv);
+    const d3 p{double(fp.x), double(fp.y), double(fp.z)};
+    const size_t set = size_t(NE_STRIDE) * size_t(total);
+    if (threadIdx.x == 0) s_timeout = 0;
+    lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        LmRegs R;
+        double cand[7], x[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) x[i] = P.use_init ? P.init_pose[i] : P.state->x[i];
+        lm_begin_wave_pp(f_ne, f_scratch, x, &s_lm, true, P.thre_b[0], P.lm_max_it, P.lm_min_blocks, R, cand);
+        if (lane < 7) s_cand[lane] = pick7(cand, lane);
+        if (lane == 0) s_done = R.done;
+    }
+    __syncthreads();
+    int it = 0;
+    while (!s_done) {
+        if (it == 2) MLH_STAGE(gtile, 0);                 // (debug build only: the third iteration's stages, scripts/stageclock_loop.py)
+        const q4 q{s_cand[3], s_cand[4], s_cand[5], s_cand[6]};
+        const d3 t{s_cand[0], s_cand[1], s_cand[2]};
+        Lin L;
+        L.r = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
+        if (valid) {
+            double R9[9];
+            qtorot(q, R9);
+            if (kind == MLH_SURF) eval_plane(p, c.c, w, q, t, R9, L);
+            else eval_edge(p, c.c, w, q, t, R9, L);
+        }
+        if (it == 2) MLH_STAGE(gtile, 1);
+        double *rec = P.partials + set * size_t((it + 1) & 1);
+        reduce_rows<MLH_LOOP_COH != 0>(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, rec + size_t(gtile) * NE_STRIDE, mult);
+        // (the record's 32 words are stored by the first 32 lanes of the wavefront thread 0 belongs to: its s_waitcnt covers them)
+        if (!MLH_LOOP_COH) __syncthreads();
+        if (it == 2) MLH_STAGE(gtile, 2);
+        if (threadIdx.x == 0) {
+            if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = unsigned(total) * unsigned(it + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
+            }
+            if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("" ::: "memory");
+        }
+        __syncthreads();
+        if (it == 2) MLH_STAGE(gtile, 3);
+        if (s_timeout) break;
+        lmc_sum_records<MLH_LOOP_COH != 0>(rec, total, f_ne, f_scratch);
+        if (it == 2) MLH_STAGE(gtile, 4);
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            LmRegs R;
+            double cand[7];
+            lm_step_wave_pp(f_ne, &s_lm, &s_lm, true, P.lm_max_it, R, cand);
+            if (lane < 7) s_cand[lane] = pick7(cand, lane);
+            if (lane == 0) s_done = R.done;
+        }
+        __syncthreads();
+        if (it == 2) MLH_STAGE(gtile, 5);
+        ++it;
+    }
+    if (writer && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane < 7) P.state->x[lane] = s_lm.x[lane];          // read by the launches BEHIND this one only (the other workgroups took their start pose long ago)
+        if (lane == 0) {
+            const double used = P.lm_expect_done < 0 ? double(s_lm.iteration) : fmax(P.state->lm_used_max, double(s_lm.iteration));
+            P.state->lm_used_max = used;
+            P.state->lm_overflow = 0;
+            P.state->done = s_lm.done;
+            P.state->iteration = s_lm.iteration;
+            if (P.publish) {
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = s_lm.x[i];
+                P.publish->done = (s_lm.done ? 1 : 0) | (s_timeout ? 4 : 0);
+                P.publish->xb[2][0] = used;
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (threadIdx.x == 0) {                // the last workgroup to leave re-arms the barrier for the next launch
+        const unsigned left = atomicAdd(P.ticket + 2, 1u);
+        if (left == unsigned(total - 1)) {
+            __hip_atomic_store(P.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // stand-alone exact 5-NN for mlh_knn (queries already in the map frame)
 __global__ __launch_bounds__(TPB) void knn_queries_kernel(GridDev grid, const float *__restrict__ q, int nq, int *__restrict__ idx,
                                                           float *__restrict__ d2)
@@ -1145,9 +1290,9 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     hipError_t e;
     // (two sets of records: the consumer-side Levenberg-Marquardt launches alternate between them)
     if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total) * 2)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
-    if (!ctx->ticket.p) {
-        if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
-        if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
+    if (!ctx->ticket.p) {          // [0]: the fused finish's arrival ticket; [1], [2]: lm_loop_kernel's barrier (arrivals, departures)
+        if ((e = ctx->ticket.ensure(4 * sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
+        if ((e = hipMemsetAsync(ctx->ticket.p, 0, 4 * sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
     }
     ctx->n_partial_tiles = tiles_b_total;
     P.partials = ctx->partials.as<double>();
@@ -1224,6 +1369,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         const size_t set = size_t(NE_STRIDE) * size_t(tiles_b_total);
         P.partials_in = ctx->partials.as<double>() + set * size_t((a.lmc_j - 1) & 1);
         P.partials = ctx->partials.as<double>() + set * size_t(a.lmc_j & 1);
+        if (a.lmc == 3) { P.partials_in = ctx->partials.as<double>(); P.partials = ctx->partials.as<double>(); }     // (the loop kernel alternates by itself)
     }
     P.publish_seq = a.publish_seq;
     P.ticket = ctx->ticket.as<unsigned>();
@@ -1339,13 +1485,18 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
 {
     for (int k = 0; k < 2; ++k)
         if ((a.kind_mask & (1 << k)) && !ctx->feat[k].matched) return fail(ctx, MLH_ERR_STATE, "the Levenberg-Marquardt launches need a previous match of this kind");
-    if (a.lmc < 1 || a.lmc > 2 || a.lmc_j < 1 || a.n_blocks > 1 || a.dense) return fail(ctx, MLH_ERR_INVALID, "lm_consume_launch: single block, no dense rows");
+    if (a.lmc < 1 || a.lmc > 3 || a.lmc_j < 1 || a.n_blocks > 1 || a.dense) return fail(ctx, MLH_ERR_INVALID, "lm_consume_launch: single block, no dense rows");
     KParams P;
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
     if (P.p2p.n_ranks > 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the consumer-side Levenberg-Marquardt schedule is single-GPU");
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
-    if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
+    if (a.lmc == 3) {
+        // every tile's workgroup has to be resident for the barrier: 256-thread workgroups at <= 128 VGPRs, a few KB of LDS -- several per compute unit
+        if (P.k[0].tiles_b + P.k[1].tiles_b > 256) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than compute units");
+        launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel, grid_b, P);
+    }
+    else if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
     else launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;

@@ -34,6 +34,8 @@ __device__ __forceinline__ double swap_add(double x, double y)
 
 // acc: this lane's 32 values (entries 29..31 zero). 256 threads. partial_out[0..31]: the workgroup's sums; slots 29 / 30 mirror the
 // count for feature kind 0 / 1.
+// COH: the record is stored with agent-scope monotonic stores (readable by other workgroups of the SAME launch through agent-scope loads, without an L2 write-back fence)
+template <bool COH = false>
 __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double *lds_red /*4*32*/, double *__restrict__ partial_out)
 {
     // transposed butterfly: at each step a lane keeps one half of its values and trades the other half with its partner, so the
@@ -64,7 +66,8 @@ __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double
         double v = 0.0;
         const int src = (threadIdx.x == NE_CNT + 1 + kind) ? NE_CNT : threadIdx.x;   // per-kind count mirrors the count column
         if (src < 29) v = ((lds_red[src] + lds_red[32 + src]) + lds_red[64 + src]) + lds_red[96 + src];
-        partial_out[threadIdx.x] = v;
+        if constexpr (COH) __hip_atomic_store(partial_out + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partial_out[threadIdx.x] = v;
     }
 }
 

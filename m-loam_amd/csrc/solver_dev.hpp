@@ -681,6 +681,13 @@ __device__ __forceinline__ void lm_step_body(const double *ce, SolverState *S, i
 // travel by v_readlane. Every output element is computed by the same operations in the same order as in lm_step_body / lm_propose / pose_plus above, so the two
 // forms are interchangeable bit for bit (the stand-alone LM kernels of solver.hip -- multi-GPU and good-feature paths -- keep the one-thread form, the fused
 // single-GPU scan2map and the tracker run this one; tests/test_gpu_parity.py::test_rccl_single_rank_path compares their poses for equality).
+#ifdef MLH_STAGE_CLOCK
+// debug build only: stamps inside the LM step of workgroup 0 (scripts/stageclock_loop.py)
+static __device__ unsigned long long g_step_clk[16];
+#define MLH_STEP_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_step_clk[i] = wall_clock64(); } while (0)
+#else
+#define MLH_STEP_STAMP(i) do { } while (0)
+#endif
 // the LM part of the solver state, uniform over the wavefront
 struct LmRegs {
     double x[7], g[6], Sv[6], diag[6];
@@ -728,6 +735,7 @@ __device__ __forceinline__ void lm_propose_wave(LmRegs &R, const double *ne, con
         }
         const double diag_r = lane == 0 ? R.diag[0] : (lane == 1 ? R.diag[1] : (lane == 2 ? R.diag[2] : (lane == 3 ? R.diag[3] : (lane == 4 ? R.diag[4] : R.diag[5]))));
         const double lhs_rr = Arr + diag_r / R.radius;
+        MLH_STEP_STAMP(3);
         // Cholesky of lhs, row r on lane r: chol6p_factor's operations in its order (packed lower triangle: a[k] = L(r, k))
         double a[6], colv[6], rinv[6];
 #pragma unroll
@@ -750,6 +758,7 @@ __device__ __forceinline__ void lm_propose_wave(LmRegs &R, const double *ne, con
             for (int k = 0; k < j; ++k) if (r == k) colv[j] = rj[k];          // colv[j] = L(j, r), j > r
         }
         R.reuse_diagonal = 1;
+        MLH_STEP_STAMP(4);
         bool valid = false;
         double mcc = 0.0, step[6];
         if (ok) {
@@ -789,10 +798,12 @@ __device__ __forceinline__ void lm_propose_wave(LmRegs &R, const double *ne, con
             continue;
         }
         R.num_invalid = 0;
+        MLH_STEP_STAMP(5);
         double delta[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) delta[i] = step[i] * R.Sv[i];
         pose_plus_wave(R.x, delta, V, cand, lane);
+        MLH_STEP_STAMP(6);
         R.model_cost_change = mcc;
         return;
     }
@@ -955,6 +966,7 @@ __device__ __forceinline__ void lm_state_store_pp(const LmRegs &R, const double 
 __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState *Si, LmState *So, bool write, int max_it, LmRegs &R, double (&cand)[7])
 {
     const int lane = threadIdx.x & 63;
+    MLH_STEP_STAMP(0);
     lm_regs_load(R, Si);
 #pragma unroll
     for (int i = 0; i < 7; ++i) cand[i] = Si->cand[i];
@@ -969,6 +981,7 @@ __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState 
     const double cost_change = x_cost - ce[NE_COST];
     if (!stop && fabs(cost_change) <= 1e-6 * x_cost) { R.done = 1; R.termination = 3; stop = true; }
     const double *ne_now = Si->ne;
+    MLH_STEP_STAMP(1);
     if (!stop) {
         const double rd = cost_change / R.model_cost_change;
         if (rd > 1e-3) {
@@ -987,9 +1000,11 @@ __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState 
         } else {
             R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
         }
+        MLH_STEP_STAMP(2);
         lm_propose_wave(R, ne_now, Si->V, cand, max_it, lane);
     }
     if (write) lm_state_store_pp(R, cand, ne_now, Si->V, So, lane);
+    MLH_STEP_STAMP(7);
 }
 
 // x: the pose the records in `ne` were taken at. ne / scratch: LDS. No statistics in this schedule (the classic launches serve a caller who asks for them).

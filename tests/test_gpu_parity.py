@@ -1356,8 +1356,9 @@ def test_scan2map_split_submission_equals_the_synchronous_call(mla, case16, feat
 
 
 def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feats16, monkeypatch):
-    """The Levenberg-Marquardt launches of scan2map in their two forms -- the step in the last workgroup of the launch that evaluated (MLH_LM_CONSUMER=0), or in every
-    workgroup of the NEXT launch (the default without statistics) -- are the same arithmetic on the same records: the same pose bits from the synchronous call, from
+    """The Levenberg-Marquardt loop of scan2map in its three forms -- the step in the last workgroup of the launch that evaluated (MLH_LM_CONSUMER=0), in every
+    workgroup of the NEXT launch (MLH_LM_LOOP=0), or the whole loop in one launch whose workgroups synchronise among themselves (the default without statistics) --
+    is the same arithmetic on the same records: the same pose bits from the synchronous call, from
     the split submission at every look-ahead, and the same look-ahead verdicts (exactly enough / one too few)."""
     p0 = case16["p0"]
     ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
@@ -1376,8 +1377,9 @@ def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feat
             with_stats, st = c.scan2map(s0)                       # statistics asked for: always the classic launches
             need = max(int(x["lm_iterations"]) for x in st)
             got = {}
-            for mode in ("0", "1"):
-                monkeypatch.setenv("MLH_LM_CONSUMER", mode)
+            for mode in ("00", "10", "11"):                         # classic launches | consumer-side launches | the loop as one launch (the default)
+                monkeypatch.setenv("MLH_LM_CONSUMER", mode[0])
+                monkeypatch.setenv("MLH_LM_LOOP", mode[1])
                 sync = c.scan2map(s0, want_stats=False)[0]
                 c.scan2map_begin(s0)
                 split, status = c.scan2map_end()
@@ -1392,10 +1394,11 @@ def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feat
                 b, sb = c.scan2map_end()
                 assert sa == 0 and sb == 0
                 got[mode] = (sync, split, exact, status_exact, short, status_short, a, b)
-            for x, y in zip(got["0"], got["1"]):
-                assert np.array_equal(x, y)
-            assert np.array_equal(got["1"][0], with_stats)
-            assert got["1"][3] == 0 and (need == 1 or got["1"][5] == 2)
+            for other in ("10", "11"):
+                for x, y in zip(got["00"], got[other]):
+                    assert np.array_equal(x, y)
+            assert np.array_equal(got["11"][0], with_stats)
+            assert got["11"][3] == 0 and (need == 1 or got["11"][5] == 2)      # (an explicit look-ahead keeps the launches it counts, in every mode)
     finally:
         c.close()
 
