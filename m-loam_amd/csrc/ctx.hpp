@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <cstdlib>
 #include "../../include/mloam_hip.h"
 
 namespace mlh {
@@ -203,6 +204,7 @@ struct VoxBuf {   // scratch of mlh_voxel_filter
 
 struct SegBuf {    // ImageSegmenter scratch (segment.hip)
     DevBuf raw, pix, owner, range, ground, keep;
+    DevBuf edge;               // the cluster search's angle verdicts per pixel (seg_edge_kernel)
     DevBuf outmask, row_cnt;   // device row assembly: the outlier pixels' bit mask (from the host's cluster search), per-row counts of kept points (+ first kept index)
     void *h_rows = nullptr;    // pinned: [vs + 2] ints the row kernels leave for the host (kept points per row, total, first kept point index)
     size_t h_rows_cap = 0;
@@ -210,7 +212,11 @@ struct SegBuf {    // ImageSegmenter scratch (segment.hip)
     DevBuf fix;            // the host's verdicts for the undecided points: {point index, pixel}
     void *h_unc = nullptr; // pinned mirror of `unc`
     size_t h_unc_cap = 0;
-    ~SegBuf() { if (h_unc) (void)hipHostFree(h_unc); if (h_rows) (void)hipHostFree(h_rows); }
+    void *h_img = nullptr;     // pinned: range / owner / ground images as the cluster search reads them, and the outlier mask it writes
+    size_t h_img_cap = 0;
+    void *h_bfs = nullptr;     // plain: labels and the cluster search's queue / pushed-pixel arrays
+    size_t h_bfs_cap = 0;
+    ~SegBuf() { if (h_unc) (void)hipHostFree(h_unc); if (h_rows) (void)hipHostFree(h_rows); if (h_img) (void)hipHostFree(h_img); std::free(h_bfs); }
 };
 
 struct OdomSet {   // staged LidarPureOdom factor table (odom.hip)

@@ -168,6 +168,45 @@ __global__ __launch_bounds__(256) void seg_image_kernel(SegDev D)
     }
 }
 
+// The cluster search's angle test (hpp:281-289) for every pixel and each of its four neighbours, ahead of the search: which pairs are joined by the angle rule does
+// not depend on the search's order -- only its fall-back rule (hpp:297-300) and the labels do. Two bits per direction (the search's neighbour order: up, right,
+// left, down): 2 = joined, 0 = not, 1 = within 1e-4 (relative) of the threshold, or a theta outside the range the tangent form covers: the host evaluates
+// std::atan2 there, as it did for every such pair before. The arithmetic is the host loop's, operation for operation, on the same floats (the sin / cos / tan
+// table entries are the host's libm results, passed in): the same booleans.
+struct SegEdge {
+    const float *range_mat;
+    unsigned char *edge;
+    int vs, hs, is64, theta_simple;
+    float t_sin[4], t_cos[4], tan_theta;
+};
+__global__ __launch_bounds__(256) void seg_edge_kernel(SegEdge E)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= E.vs * E.hs) return;
+    const int fx = p / E.hs, fy = p - fx * E.hs;
+    const float rf = E.range_mat[p];
+    unsigned bits = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int dx = q == 0 ? -1 : (q == 3 ? 1 : 0), dy = q == 1 ? 1 : (q == 2 ? -1 : 0);
+        const int tx = fx + dx;
+        int ty = fy + dy;
+        if (tx < 0 || tx >= E.vs) continue;
+        if (ty < 0) ty = E.hs - 1;
+        if (ty >= E.hs) ty = 0;
+        const float rt = E.range_mat[tx * E.hs + ty];
+        const float d1 = fmaxf(rf, rt), d2 = fminf(rf, rt);
+        const int a = dx == 0 ? 1 : (E.is64 ? (tx <= 32 ? 2 : 3) : 2);
+        const float ay = d2 * E.t_sin[a], ax = d1 - d2 * E.t_cos[a];
+        const float lim = ax * E.tan_theta;
+        unsigned code = 1u;
+        if (E.theta_simple && ax > 0.f && ay > lim * 1.0001f) code = 2u;
+        else if (E.theta_simple && ax > 0.f && ay < lim * 0.9999f) code = 0u;
+        bits |= code << (2 * q);
+    }
+    E.edge[p] = (unsigned char)bits;
+}
+
 // the kept points, ring-major: out[k] = {x, y, z, intensity + row}
 __global__ __launch_bounds__(256) void seg_gather_kernel(SegDev D, const int *keep, int n_keep, float4 *out)
 {
@@ -405,83 +444,135 @@ __global__ __launch_bounds__(256) void seg_rows_gather_kernel(SegDev D, const in
 }
 
 // ---- host: cluster search + outlier erasure on the images (sequential by definition, see the file comment)
+// The host side of a call, carved out of two blocks the context keeps (SegBuf::h_img pinned -- the three images land there straight from the copy engine and the
+// mask leaves from there; SegBuf::h_bfs plain): a fresh set of vectors per call cost ~2.5 MB of allocation, page faults and fills per 64-ring scan.
 struct SegHost {
-    std::vector<float> range;
-    std::vector<int> label, owner;
-    std::vector<unsigned char> ground;
-    std::vector<unsigned> outmask;      // one bit per pixel: label 999999 (filled where the cluster search marks an infeasible cluster)
+    float *range;
+    int *owner;
+    unsigned char *ground;
+    unsigned *outmask;      // one bit per pixel: label 999999 (filled where the cluster search marks an infeasible cluster)
+    size_t outmask_words;
+    unsigned char *edge;    // seg_edge_kernel's verdicts, 2 bits per neighbour
+    int *label;
+    uint16_t *qx, *qy;      // the queue: every pushed pixel enters it exactly once, so it is the cluster's pixel list too
+    int8_t *q_last_dy;      // queue_last_dy of the entry
+    // queue_last_dis of the entry, kept as its ingredients: dist = sqrt(d1^2 + d2^2 - 2 d1 d2 cos(alpha)) is read back only by the same-beam rule (hpp:297-300), for a
+    // few per cent of the entries. d1 / d2 are the larger / smaller range of the entry's pixel and of the pixel it was reached from (q_parent); the alpha in force
+    // when it was pushed is an index into the four-entry table (q_alpha; 255: the literal 0 a cluster's seed is pushed with, hpp:245). The square root is taken
+    // where the rule reads it (same expression, same operands: the same float)
+    uint32_t *q_parent;
+    unsigned char *q_alpha;
 };
 
-static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegHost &H)
+static int seg_host_carve(mlh_ctx *ctx, SegBuf &B, int npx, SegHost &H)
+{
+    const size_t words = (size_t(npx) + 31) / 32;
+    const size_t img = sizeof(float) * size_t(npx) + sizeof(int) * size_t(npx) + sizeof(unsigned) * words + 2 * size_t(npx) + 64;
+    if (B.h_img_cap < img) {
+        if (B.h_img) (void)hipHostFree(B.h_img);
+        B.h_img = nullptr; B.h_img_cap = 0;
+        MLH_HIP(ctx, hipHostMalloc(&B.h_img, img, hipHostMallocDefault));
+        B.h_img_cap = img;
+    }
+    unsigned char *p = static_cast<unsigned char *>(B.h_img);
+    H.range = reinterpret_cast<float *>(p); p += sizeof(float) * size_t(npx);
+    H.owner = reinterpret_cast<int *>(p); p += sizeof(int) * size_t(npx);
+    H.outmask = reinterpret_cast<unsigned *>(p); p += sizeof(unsigned) * words;
+    H.outmask_words = words;
+    H.ground = p; p += size_t(npx);
+    H.edge = p;
+    const size_t bfs = size_t(npx) * (sizeof(int) + 2 * sizeof(uint16_t) + 2 + sizeof(uint32_t)) + 64;
+    if (B.h_bfs_cap < bfs) {
+        std::free(B.h_bfs);
+        B.h_bfs = std::malloc(bfs);
+        B.h_bfs_cap = B.h_bfs ? bfs : 0;
+        if (!B.h_bfs) return fail(ctx, MLH_ERR_INVALID, "mlh_segment_cloud: out of host memory");
+    }
+    unsigned char *q = static_cast<unsigned char *>(B.h_bfs);
+    H.label = reinterpret_cast<int *>(q); q += sizeof(int) * size_t(npx);
+    H.q_parent = reinterpret_cast<uint32_t *>(q); q += sizeof(uint32_t) * size_t(npx);
+    H.qx = reinterpret_cast<uint16_t *>(q); q += sizeof(uint16_t) * size_t(npx);
+    H.qy = reinterpret_cast<uint16_t *>(q); q += sizeof(uint16_t) * size_t(npx);
+    H.q_last_dy = reinterpret_cast<int8_t *>(q); q += size_t(npx);
+    H.q_alpha = q;
+    std::memset(H.outmask, 0, sizeof(unsigned) * words);
+    // the queue's records persist from cluster to cluster WITHIN a call (an entry behind the queue's end is read by the same-beam rule, hpp:297) and start a call
+    // as "seed" records: dy 0, the literal 0 distance
+    std::memset(H.q_last_dy, 0, size_t(npx));
+    std::memset(H.q_alpha, 255, size_t(npx));
+    return MLH_OK;
+}
+
+static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegHost &H, const float (&t_cos)[4], const float (&t_sin)[4])
 {
     SegSetup S = S0;
     const int vs = S.vs, hs = S.hs;
-    const size_t npx = size_t(vs) * hs;
-    std::vector<uint16_t> pushed_x(npx), pushed_y(npx), qx(npx), qy(npx);
-    std::vector<int8_t> q_last_dy(npx, 0);
-    // queue_last_dis, kept as its ingredients: dist = sqrt(d1^2 + d2^2 - 2 d1 d2 cos(alpha)) is read back only by the same-beam rule (hpp:297-300), for a few
-    // per cent of the entries -- the square root is taken there (same expression, same operands: the same float), not for every push
-    std::vector<float> q_d1(npx, 0.f), q_d2(npx, 0.f), q_cos(npx, 1.f);
-    std::vector<char> q_zero(npx, 1);                   // the record holds the literal 0 of a cluster's seed (hpp:245)
-    auto R = [&](int i, int j) -> float { return H.range[size_t(i) * hs + j]; };
-    auto L = [&](int i, int j) -> int & { return H.label[size_t(i) * hs + j]; };
+    uint16_t *qx = H.qx, *qy = H.qy;
+    int8_t *q_last_dy = H.q_last_dy;
+    uint32_t *q_parent = H.q_parent;
+    unsigned char *q_alpha = H.q_alpha;
+    const float *range = H.range;
+    int *label = H.label;
+    const unsigned char *edge = H.edge;
     int label_count = 2;
     static const int8_t nb[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
     // alpha -- ONE variable for the whole call, starting at 0 (U1) -- only ever holds 0, alphax or one of the two alphay values: it is carried as an index into
-    // a table of the std::cos / std::sin results (computed once: the same floats the reference's calls return)
-    const float ay64[2] = {float(0.333 / 180.0 * M_PI), float(0.5 / 180.0 * M_PI)};
-    float t_alpha[4] = {0.f, S.alphax, S.is64 ? ay64[0] : S.alphay, S.is64 ? ay64[1] : S.alphay}, t_cos[4], t_sin[4];
-    for (int k = 0; k < 4; ++k) { t_cos[k] = std::cos(t_alpha[k]); t_sin[k] = std::sin(t_alpha[k]); }
+    // the table of the std::cos / std::sin results (computed once by the caller: the same floats the reference's calls return)
     int alpha_idx = 0;
-    const bool theta_simple = prm.segment_theta > 0.01f && prm.segment_theta < 1.5f;
-    const float tan_theta = theta_simple ? std::tan(prm.segment_theta) : 0.f;
     auto dist_of = [](float d1, float d2, float c) { return std::sqrt(d1 * d1 + d2 * d2 - 2 * d1 * d2 * c); };
+    // queue_last_dis of queue entry k (see SegHost)
+    auto dist_last_of = [&](int k) -> float {
+        if (q_alpha[k] == 255) return 0.f;
+        const float ra = range[size_t(qx[k]) * hs + qy[k]], rb = range[q_parent[k]];
+        return dist_of(std::max(ra, rb), std::min(ra, rb), t_cos[q_alpha[k]]);
+    };
     std::vector<char> line_flag(vs);
     for (int i = 0; i < vs; i++) {
         for (int j = 0; j < hs; j++) {
-            if (L(i, j) != 0) continue;
+            if (label[size_t(i) * hs + j] != 0) continue;
             std::fill(line_flag.begin(), line_flag.end(), 0);
-            qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_zero[0] = 1;
-            int q_size = 1, q_start = 0, q_end = 1, n_pushed = 1;
-            pushed_x[0] = uint16_t(i); pushed_y[0] = uint16_t(j);
-            while (q_size > 0) {
+            qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_alpha[0] = 255;
+            int q_start = 0, q_end = 1;
+            while (q_start < q_end) {
                 const int fx = qx[q_start], fy = qy[q_start];
-                --q_size; ++q_start;
-                L(fx, fy) = label_count;
-                const float rf = R(fx, fy);
+                ++q_start;
+                const size_t fp = size_t(fx) * hs + fy;
+                label[fp] = label_count;
+                const unsigned eb = edge[fp];
                 for (int q = 0; q < 4; ++q) {
                     int tx = fx + nb[q][0], ty = fy + nb[q][1];
                     if (tx < 0 || tx >= vs) continue;
                     if (ty < 0) ty = hs - 1;
                     if (ty >= hs) ty = 0;
-                    if (L(tx, ty) != 0) continue;
-                    const float rt = R(tx, ty);
-                    const float d1 = std::max(rf, rt), d2 = std::min(rf, rt);
-                    const float cos_prev = t_cos[alpha_idx];                    // dist is computed with the alpha of the PREVIOUS evaluated neighbour (U1)
+                    const size_t tp = size_t(tx) * hs + ty;
+                    if (label[tp] != 0) continue;
+                    const int alpha_prev = alpha_idx;                           // dist is computed with the alpha of the PREVIOUS evaluated neighbour (U1)
                     alpha_idx = nb[q][0] == 0 ? 1 : (S.is64 ? (tx <= 32 ? 2 : 3) : 2);      // (64 rings: segment_alphay_ follows the neighbour's row, hpp:266-272)
-                    const float ay = d2 * t_sin[alpha_idx], ax = d1 - d2 * t_cos[alpha_idx];
-                    // angle > theta, with atan2 itself called only within 1e-4 (relative) of the threshold: ay >= 0 and 0 < theta < pi / 2, so away from
-                    // it the comparison of ay with ax * tan(theta) decides -- the same boolean as the reference's atan2(ay, ax) > theta
-                    bool push;
-                    const float lim = ax * tan_theta;
-                    if (theta_simple && ax > 0.f && ay > lim * 1.0001f) push = true;
-                    else if (theta_simple && ax > 0.f && ay < lim * 0.9999f) push = false;
-                    else push = std::atan2(ay, ax) > prm.segment_theta;
+                    // angle > theta: seg_edge_kernel's verdict; within 1e-4 (relative) of the threshold std::atan2 itself, as the reference calls it
+                    const unsigned code = (eb >> (2 * q)) & 3u;
+                    bool push = code == 2u;
+                    if (code == 1u) {
+                        const float rf = range[fp], rt = range[tp];
+                        const float d1 = std::max(rf, rt), d2 = std::min(rf, rt);
+                        const float ay = d2 * t_sin[alpha_idx], ax = d1 - d2 * t_cos[alpha_idx];
+                        push = std::atan2(ay, ax) > prm.segment_theta;
+                    }
                     if (!push && nb[q][1] == 0 && q_last_dy[q_start] == 0) {          // the record of the NEXT queue entry (hpp:297)
-                        const float dist_last = q_zero[q_start] ? 0.f : dist_of(q_d1[q_start], q_d2[q_start], q_cos[q_start]);
-                        const float dist = dist_of(d1, d2, cos_prev);
+                        const float rf = range[fp], rt = range[tp];
+                        const float dist_last = dist_last_of(q_start);
+                        const float dist = dist_of(std::max(rf, rt), std::min(rf, rt), t_cos[alpha_prev]);
                         push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
                     }
                     if (push) {
                         qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = nb[q][1];
-                        q_d1[q_end] = d1; q_d2[q_end] = d2; q_cos[q_end] = cos_prev; q_zero[q_end] = 0;
-                        ++q_size; ++q_end;
-                        L(tx, ty) = label_count;
+                        q_parent[q_end] = uint32_t(fp); q_alpha[q_end] = (unsigned char)alpha_prev;
+                        ++q_end;
+                        label[tp] = label_count;
                         line_flag[tx] = 1;
-                        pushed_x[n_pushed] = uint16_t(tx); pushed_y[n_pushed] = uint16_t(ty); ++n_pushed;
                     }
                 }
             }
+            const int n_pushed = q_end;
             bool feasible = false;
             if (n_pushed >= prm.min_cluster_size) feasible = true;
             else if (n_pushed >= prm.segment_valid_point_num) {
@@ -491,8 +582,8 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
             }
             if (feasible) ++label_count;
             else for (int k = 0; k < n_pushed; ++k) {
-                L(pushed_x[k], pushed_y[k]) = 999999;
-                const size_t px = size_t(pushed_x[k]) * hs + pushed_y[k];
+                const size_t px = size_t(qx[k]) * hs + qy[k];
+                label[px] = 999999;
                 H.outmask[px >> 5] |= 1u << (px & 31);
             }
         }
@@ -607,10 +698,25 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     static const bool seg_timing = std::getenv("MLH_SEG_TIMING") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     SegHost H;
-    H.range.resize(npx); H.owner.resize(npx); H.ground.resize(npx); H.label.assign(npx, 0); H.outmask.assign((size_t(npx) + 31) / 32, 0u);
-    MLH_HIP(ctx, hipMemcpyAsync(H.range.data(), B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipMemcpyAsync(H.owner.data(), B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
-    MLH_HIP(ctx, hipMemcpyAsync(H.ground.data(), B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
+    { const int hrc = seg_host_carve(ctx, B, npx, H); if (hrc) return hrc; }
+    MLH_HIP(ctx, hipMemcpyAsync(H.range, B.range.p, sizeof(float) * size_t(npx), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(H.owner, B.owner.p, sizeof(int) * size_t(npx), hipMemcpyDeviceToHost, st));
+    MLH_HIP(ctx, hipMemcpyAsync(H.ground, B.ground.p, size_t(npx), hipMemcpyDeviceToHost, st));
+    // the cluster search's angle verdicts, made on the device from the range image (seg_edge_kernel) with the host's own sin / cos / tan table
+    float t_cos[4], t_sin[4];
+    {
+        const float ay64[2] = {float(0.333 / 180.0 * M_PI), float(0.5 / 180.0 * M_PI)};
+        const float t_alpha[4] = {0.f, S.alphax, S.is64 ? ay64[0] : S.alphay, S.is64 ? ay64[1] : S.alphay};
+        for (int k = 0; k < 4; ++k) { t_cos[k] = std::cos(t_alpha[k]); t_sin[k] = std::sin(t_alpha[k]); }
+        SegEdge E;
+        MLH_HIP(ctx, B.edge.ensure(size_t(npx)));
+        E.range_mat = B.range.as<float>(); E.edge = B.edge.as<unsigned char>(); E.vs = vs; E.hs = hs; E.is64 = S.is64;
+        E.theta_simple = (prm.segment_theta > 0.01f && prm.segment_theta < 1.5f) ? 1 : 0;
+        E.tan_theta = E.theta_simple ? std::tan(prm.segment_theta) : 0.f;
+        for (int k = 0; k < 4; ++k) { E.t_cos[k] = t_cos[k]; E.t_sin[k] = t_sin[k]; }
+        MLH_LAUNCH(seg_edge_kernel, dim3((npx + 255) / 256), dim3(256), 0, st, E);
+        MLH_HIP(ctx, hipMemcpyAsync(H.edge, B.edge.p, size_t(npx), hipMemcpyDeviceToHost, st));
+    }
     int n_undecided_gnd = 0;
     {
         // the ground pairs within the margin of 10 degrees: decided here, with the host's libm, straight into the ground image the cluster search reads
@@ -618,7 +724,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         float4 *hg = reinterpret_cast<float4 *>(static_cast<unsigned char *>(B.h_unc) + 16);
         MLH_HIP(ctx, hipMemcpyAsync(hc, B.unc.p, 16, hipMemcpyDeviceToHost, st));
         MLH_HIP(ctx, hipMemcpyAsync(hg, D.unc_gnd, sizeof(float4) * 2 * size_t(std::min(npx, SEG_UNC_FIRST)), hipMemcpyDeviceToHost, st));
-        MLH_HIP(ctx, hipStreamSynchronize(st));
+        MLH_HIP(ctx, stream_wait_spin(ctx));
         n_undecided_gnd = std::min(hc[1], npx);
         if (n_undecided_gnd > SEG_UNC_FIRST) {
             MLH_HIP(ctx, hipMemcpyAsync(hg + 2 * SEG_UNC_FIRST, D.unc_gnd + 2 * SEG_UNC_FIRST, sizeof(float4) * 2 * size_t(n_undecided_gnd - SEG_UNC_FIRST), hipMemcpyDeviceToHost, st));
@@ -632,7 +738,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     }
     const auto tp1 = std::chrono::steady_clock::now();
     for (int p = 0; p < npx; ++p) H.label[p] = (H.owner[p] == INT_MAX) ? -1 : (H.ground[p] ? 1 : 0);
-    seg_clusters(S, prm, H);
+    seg_clusters(S, prm, H, t_cos, t_sin);
     const auto tp2 = std::chrono::steady_clock::now();
     int hs2 = 1;
     while (hs2 < hs) hs2 <<= 1;
@@ -641,7 +747,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         // ---- rows, erasure, concatenation and gather on the device (seg_rows_kernel / seg_rows_gather_kernel); the host keeps the outlier list only
         std::vector<int> outlier_idx, outlier_row;
         if (prm.segment_flag)
-            for (size_t wd = 0; wd < H.outmask.size(); ++wd) {
+            for (size_t wd = 0; wd < H.outmask_words; ++wd) {
                 unsigned m = H.outmask[wd];
                 while (m) {
                     const size_t px = wd * 32 + size_t(__builtin_ctz(m));
@@ -649,7 +755,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
                     if ((px % size_t(hs)) % 5 == 0) { outlier_idx.push_back(H.owner[px]); outlier_row.push_back(int(px / size_t(hs))); }
                 }
             }
-        const size_t mask_bytes = sizeof(unsigned) * H.outmask.size();
+        const size_t mask_bytes = sizeof(unsigned) * H.outmask_words;
         MLH_HIP(ctx, B.outmask.ensure(mask_bytes));
         MLH_HIP(ctx, B.row_cnt.ensure(sizeof(int) * size_t(vs)));
         MLH_HIP(ctx, B.keep.ensure(sizeof(int) * size_t(npx)));
@@ -665,7 +771,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         MLH_HIP(ctx, sb.start.ensure(sizeof(int) * size_t(vs)));
         MLH_HIP(ctx, sb.end.ensure(sizeof(int) * size_t(vs)));
         sb.end_alias = nullptr;
-        MLH_HIP(ctx, hipMemcpyAsync(B.outmask.p, H.outmask.data(), mask_bytes, hipMemcpyHostToDevice, st));       // (H lives until the wait below)
+        MLH_HIP(ctx, hipMemcpyAsync(B.outmask.p, H.outmask, mask_bytes, hipMemcpyHostToDevice, st));           // (pinned: the next call rewrites it behind this call's waits)
         SegRows R;
         R.owner = B.owner.as<int>(); R.outmask = B.outmask.as<unsigned>(); R.kept = B.keep.as<int>(); R.row_cnt = B.row_cnt.as<int>();
         R.vs = vs; R.hs = hs; R.hs2 = hs2; R.segment_flag = prm.segment_flag ? 1 : 0;
@@ -680,7 +786,7 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         MLH_LAUNCH(seg_rows_gather_kernel, dim3(4, vs), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), (const int *)B.row_cnt.as<int>(), sb.pts.as<float4>(),
                    sb.start.as<int>(), sb.end.as<int>(), h_rows);
         MLH_HIP(ctx, hipGetLastError());
-        MLH_HIP(ctx, hipStreamSynchronize(st));
+        MLH_HIP(ctx, stream_wait_spin(ctx));
         const auto tq3 = std::chrono::steady_clock::now();
         const int n_keep = h_rows[vs], first_kept = h_rows[vs + 1];
         std::vector<int> hstart(vs), hend(vs);
