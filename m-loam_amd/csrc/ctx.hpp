@@ -339,7 +339,7 @@ struct mlh_ctx {
     mlh::DevBuf fused_part;  // per-append, per-kind, per-workgroup partial bounds of the appended points
     int fused_parts = 0;
     float fused_minmax[2][6];   // folded by mlh_fused_cloud: the voxel filter of a fused cloud needs no bounds pass of its own
-    int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16 in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
+    int knn_lanes_override = 0;   // MLH_KNN_LANES=8|16|32, or SSCC (816, 832, 1632: surf lanes, corner lanes), in the environment at mlh_create: pins the correspondence kernel's lanes per query (tests, tuning)
     int gn_final_defer = 1;       // MLH_GN_FINAL_DEFER=0: a solve submitted with mlh_gn_solve_begin* finishes its LAST iteration in its own fit launch (classic); 1: that
                                   // iteration, too, only leaves its records -- the next mlh_gn_solve_begin_chained completes it in its first launch (and publishes the pose
                                   // from there), mlh_gn_solve_end or any other solver call completes it with a one-workgroup launch if no successor did

@@ -343,15 +343,17 @@ __device__ __forceinline__ int knn_fill_table(int *lds_run, int gl, const int (&
     int lsum = 0, np = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) { lsum += len[p]; np += len[p] > 0 ? 1 : 0; }
-    const int incl = row_scan16<G>(lsum, gl), slot_incl = row_scan16<G>(np, gl);
+    // (a 32-lane group: the pieces come from its first 16-lane row only -- nine (dy, dz) rows, one per lane -- so that row's scan is the group's)
+    constexpr int GS = G > 16 ? 16 : G, LASTL = GS - 1;
+    const int incl = row_scan16<GS>(lsum, gl), slot_incl = row_scan16<GS>(np, gl);
     int slot = slot_incl - np, off = incl - lsum;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
         if (len[p] > 0) { lds_run[slot] = off; lds_run[KNN_SEG_BASE + slot] = b[p]; ++slot; off += len[p]; }
-    if (gl == G - 1) lds_run[slot_incl] = incl;                        // end sentinel behind the last slot
+    if (gl == LASTL) lds_run[slot_incl] = incl;                        // end sentinel behind the last slot
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    return __shfl(incl, G - 1, G);
+    return __shfl(incl, LASTL, G);
 }
 
 // run table of the group: every lane offers up to two pieces [bL, bL + lenL), [bR, bR + lenR); only non-empty pieces get a slot.
@@ -381,18 +383,49 @@ __device__ __forceinline__ unsigned dpp_row_max_u32(unsigned m)
     return m;
 }
 
+// ---- 32 lanes per query (two 16-lane DPP rows): the dense kinds of a frame-sized launch, where a query's candidate trips set the launch's duration
+// lane i <-> lane i ^ 16 inside each 32-lane half of the wavefront (ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10)
+__device__ __forceinline__ unsigned swz_xor16_u32(unsigned v) { return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+__device__ __forceinline__ unsigned long long swz_xor16_u64(unsigned long long v)
+{
+    return ((unsigned long long)swz_xor16_u32((unsigned)(v >> 32)) << 32) | swz_xor16_u32((unsigned)v);
+}
+template <int G>
+__device__ __forceinline__ unsigned group_max_u32(unsigned m)
+{
+    if constexpr (G == 32) {
+        m = dpp_row_max_u32<16>(m);
+        const unsigned o = swz_xor16_u32(m);
+        return o > m ? o : m;
+    } else return dpp_row_max_u32<G>(m);
+}
+// every 16-lane row merges its own lists (knn_tournament16), the rows trade their K winners (all exchanges in flight together) and each lane inserts the other
+// row's into its own: the K smallest (distance, index) keys of the 32 lanes' lists, ascending -- no candidate is on two lanes, so the keys are distinct
+template <int K>
+__device__ __forceinline__ void knn_tournament32(unsigned long long (&k)[K], unsigned long long (&out)[K])
+{
+    knn_tournament16<K, 16>(k, out);
+    unsigned long long other[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) other[i] = swz_xor16_u64(out[i]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) key_insert<K>(out, other[i]);
+}
+
 // Exact K-NN of (qx,qy,qz) when an upper bound of the K-th neighbour's squared distance is known BEFORE the search (bound_bits: the f32 bit pattern; the
 // caller got it from K map points it already knows -- the previous Gauss-Newton iteration's neighbours of the same feature, re-measured from the query's new
 // position: K points within the bound exist, so nothing farther can be among the K nearest). One walk, over the cells whose box is not farther than the
 // bound -- what phase 2 of the pruned search does after phase 1 has found its bound, without a phase 1, a merge and a second run table. Same result as
 // knn_group16_pruned / knn_group8_pruned wherever the K-th distance is below the cell edge; where it is not, both report a K-th distance of at least the
 // cell edge (the acceptance test rejects the feature either way). lds_run: KNN_RUN_WORDS ints.
-template <int K, int G>
+// COLD: no bound is known (bound_bits = +inf: all 27 cells in one flat walk -- what a 32-lane group does where the 16-lane search goes near-cells-first); a query
+// with fewer than K points in its 27 cells finds nothing, as in knn_group16_pruned.
+template <int K, int G, bool COLD = false>
 __device__ __forceinline__ void knn_group_bounded(const GridDev &g, float qx, float qy, float qz, int gl, int *lds_run, unsigned bound_bits,
                                                   unsigned long long (&out)[K])
 {
-    static_assert(G == 8 || G == 16, "group width");
-    constexpr int NR = (G == 16) ? 1 : 2;                               // (dy, dz) rows per lane: lanes 0..8 one each, or lanes 0..4 two each
+    static_assert(G == 8 || G == 16 || G == 32, "group width");
+    constexpr int NR = (G >= 16) ? 1 : 2;                               // (dy, dz) rows per lane: lanes 0..8 one each, or lanes 0..4 two each
     unsigned long long k[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) k[i] = KEY_INF;
@@ -428,9 +461,10 @@ __device__ __forceinline__ void knn_group_bounded(const GridDev &g, float qx, fl
         pb[s] = kb; pl[s] = max(ke - kb, 0);
     }
     const int total = knn_fill_table<G, NR>(lds_run, gl, pb, pl);
-    if (total > 0) knn_walk16<K, G, true>(g, qx, qy, qz, gl, lds_run, total, bound_bits, k);
+    if (total >= (COLD ? K : 1)) knn_walk16<K, G, true>(g, qx, qy, qz, gl, lds_run, total, bound_bits, k);
     MLH_KSTAGE(3);
-    knn_tournament16<K, G>(k, out);
+    if constexpr (G == 32) knn_tournament32<K>(k, out);
+    else knn_tournament16<K, G>(k, out);
 }
 
 // Exact K-NN of (qx,qy,qz) by a group of 16 lanes; every lane returns the K keys ascending. Same result as knn_group<K, 16>, fewer

@@ -327,7 +327,8 @@ template <int K, int G>
 __device__ __forceinline__ void knn_feature(const KParams &P, const KindP &Kd, int f, float sx, float sy, float sz, int gl, int *lds_run)
 {
     unsigned long long keys[K];
-    if constexpr (G == 16) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
+    if constexpr (G == 32) knn_group_bounded<K, 32, true>(Kd.grid, sx, sy, sz, gl, lds_run, 0x7f800000u, keys);
+    else if constexpr (G == 16) knn_group16_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     else knn_group8_pruned<K>(Kd.grid, sx, sy, sz, gl, lds_run, keys);
     MLH_KSTAGE(4);
     MLH_STORE_WINNERS(K, G, Kd, f, gl, keys);
@@ -350,7 +351,7 @@ __device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &
             bits = bb > bits ? bb : bits;
         }
     }
-    bits = dpp_row_max_u32<G>(bits);
+    bits = group_max_u32<G>(bits);
     if (bits >= 0x7f800000u) { knn_feature<K, G>(P, Kd, f, sx, sy, sz, gl, lds_run); return; }     // uniform over the group
     unsigned long long keys[K];
     knn_group_bounded<K, G>(Kd.grid, sx, sy, sz, gl, lds_run, bits, keys);
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
     const KindP &K = P.k[kind];
     if constexpr (G == 0) {
         if (K.lanes == 8) knn_features_body<8, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
+        else if (K.lanes == 32) knn_features_body<32, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
         else knn_features_body<16, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
     } else {
         knn_features_body<G, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
@@ -1226,8 +1228,11 @@ void knn_lanes_for(const mlh_ctx *ctx, int kind_mask, int lanes[2])
         // (pop_sq / n, size-biased: the clusters of a dense edge map count by their points, not by their cells)
         const double est27 = (mg.occupied > 0 && mg.n > 0) ? 9.0 * double(mg.pop_sq) / double(mg.n) : 1e9;
         lanes[k] = queries <= KNN_LATENCY_LIMIT ? 16 : (est27 < double(KNN_TWO_PHASE_MIN) ? 8 : 16);
-        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16) lanes[k] = ctx->knn_lanes_override;
-        if (ctx->knn_lanes_override == 816) lanes[k] = k == 0 ? 8 : 16;
+        if (ctx->knn_lanes_override == 8 || ctx->knn_lanes_override == 16 || ctx->knn_lanes_override == 32) lanes[k] = ctx->knn_lanes_override;
+        if (ctx->knn_lanes_override > 99) {          // "SSCC": surf lanes, corner lanes (816, 832, 1632, ...)
+            const int v = k == 0 ? ctx->knn_lanes_override / 100 : ctx->knn_lanes_override % 100;
+            if (v == 8 || v == 16 || v == 32) lanes[k] = v;
+        }
     }
 }
 
@@ -1251,6 +1256,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     {
         const bool both = (a.kind_mask & 3) == 3;
         P.knn_lanes = both ? (lanes[0] == lanes[1] ? lanes[0] : 0) : lanes[(a.kind_mask & 1) ? 0 : 1];
+        if (P.knn_lanes == 32) P.knn_lanes = 0;      // (32 lanes per query exist in the per-kind kernels only)
     }
     for (int k = 0; k < 2; ++k) {
         KindP &K = P.k[k];

@@ -343,7 +343,7 @@ def test_extract_with_non_finite_points(mla, orc, case16):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", ["8", "16"])
+@pytest.mark.parametrize("lanes", ["8", "16", "32"])
 def test_bounded_search_of_later_iterations_on_tie_heavy_maps(mla, orc, lanes):
     """Iterations >= 1 of a solve bound the 5-NN search by the previous iteration's neighbours (knn_group_bounded). On a map of lattice points, duplicated points and a
     wall of coplanar samples -- squared distances tie exactly, also AT the bound -- and with a pose that moves centimetres between iterations, the neighbours (hence the
@@ -415,7 +415,7 @@ def test_knn_with_exact_distance_ties(mla, orc):
     ridx, rd2 = om.knn(q, 5)
     n_tied = int(np.sum(rd2[:, 3] == rd2[:, 4])) + int(np.sum(np.any(np.diff(rd2, axis=1) == 0, axis=1)))
     assert n_tied > 200                                                                    # the case is about ties
-    for lanes in ("8", "16"):
+    for lanes in ("8", "16", "32"):
         os.environ["MLH_KNN_LANES"] = lanes
         try:
             c_ = mla.Context(0)

@@ -1082,10 +1082,11 @@ def test_device_std_sort_equals_std_sort(mla, orc):
         c.close()
 
 
-@pytest.mark.parametrize("lanes", [8, 16])
+@pytest.mark.parametrize("lanes", [8, 16, 32])
 def test_correspondence_lane_widths(mla, orc, case16, feats16, lanes, monkeypatch):
-    """The correspondence kernel runs with 8 lanes per query on chip-filling launches and 16 on small ones; both widths must
-    give the oracle's matches bit for bit (MLH_KNN_LANES pins the width of a context)."""
+    """The correspondence kernel runs with 8 lanes per query on chip-filling launches and 16 on small ones (32 -- two DPP rows per query -- was built and measured in
+    round 5 and is not selected by any rule: profiles/r05_knockout_experiments.txt); every width must give the oracle's matches bit for bit (MLH_KNN_LANES pins the
+    width of a context)."""
     monkeypatch.setenv("MLH_KNN_LANES", str(lanes))
     c = mla.Context(0)
     try:
