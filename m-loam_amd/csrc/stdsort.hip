@@ -97,7 +97,17 @@ constexpr int SS_WIDE_WAVE = SS_WIDE_CHUNK / SS_BIG_WAVES;       // 256 elements
 constexpr int SS_WIDE_MAXW = 1024;                               // wavefront chunks per range the pairing phase indexes: ranges of up to 262 144 elements
 constexpr int SS_WIDE_INFO = 16;                                 // ints per wide range in the info block
 constexpr int SS_LEAF_WG = 1024;
-constexpr int SS_LOCAL_LIST = SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the root + one per partition with two children > 16
+constexpr int SS_LOCAL_LIST = 2 * SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the ranges the workgroup-wide phase hands over + one per partition with two children > 16 inside each
+// A leaf's ranges longer than this are partitioned by the WHOLE workgroup (wg_partition: 16 wavefronts, a sixteenth of the range each), one after the other, before
+// the wavefronts go their own ways. Measured on the frame's thinning (profiles/r05_knockout_experiments.txt item 14): for ranges that live in LDS it does NOT pay --
+// 512: 0.2077, 256: 0.2253, 1024: 0.2008 against 0.2027 ms per call without -- a wavefront streams a 2 048-element range from LDS faster than sixteen of them get
+// through wg_partition's barriers and its 64-ary search. So the default is the leaf size: only an oversize leaf (a range the big levels left longer than SS_LEAF,
+// worked on in GLOBAL memory) starts workgroup-wide, which is what wg_partition was written for. Same partition function, same cuts, either way.
+#ifndef MLH_SS_LEAF_WIDE
+#define MLH_SS_LEAF_WIDE MLH_SS_LEAF
+#endif
+constexpr int SS_LEAF_WIDE = MLH_SS_LEAF_WIDE;
+constexpr int SS_LEAF_STACK = 32;                                     // ranges the workgroup-wide phase still owes (depth first: a handful)
 
 struct SortSeg { int first, last, depth, pad; };
 
@@ -488,15 +498,40 @@ __device__ inline int wg_load(int *p) { return __hip_atomic_load(p, __ATOMIC_ACQ
 __device__ inline void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void wg_fence() { ss_wg_fence(); }
 
-__device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh, int *err)
+// wl / wr (17 ints each), sk, stk (3 * SS_LEAF_STACK ints): LDS scratch of the workgroup-wide phase
+__device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh, int *err, int *wl, int *wr, int *sk, int *stk)
 {
     const int t = threadIdx.x, lane = t & 63;
     for (int i = t; i < 4 * M.qcap; i += SS_LEAF_WG) M.q[i] = 0;
     if (t == 0) { sh[LQ_TAIL] = 0; sh[LQ_HEAD] = 0; sh[LQ_REMAINING] = m; sh[LQ_NFIN] = 0; }
     __syncthreads();
-    if (t == 0) {
-        if (m > SS_THRESHOLD) { M.q[0] = 0; M.q[1] = m; M.q[2] = depth0; sh[LQ_TAIL] = 1; wg_store(&M.q[3], 1); }
-        else { if (m > 1) { M.fin[0] = 0; M.fin[1] = m; sh[LQ_NFIN] = 1; } sh[LQ_REMAINING] = 0; }
+    // where a range goes: the workgroup-wide stack, the wavefronts' queue, the final-insertion list (thread 0; the workgroup-wide phase is single-file)
+    auto route = [&](int lo, int hi, int d, int &top) {
+        const int size = hi - lo;
+        if (size > SS_LEAF_WIDE && top < SS_LEAF_STACK) {
+            if (t == 0) { stk[3 * top] = lo; stk[3 * top + 1] = hi; stk[3 * top + 2] = d; }
+            ++top;                                                   // (uniform: every thread keeps the count)
+        } else if (t == 0) {
+            if (size > SS_THRESHOLD) { const int e = sh[LQ_TAIL]++; M.q[4 * e] = lo; M.q[4 * e + 1] = hi; M.q[4 * e + 2] = d; M.q[4 * e + 3] = 1; }
+            else { if (size > 1) { const int e = sh[LQ_NFIN]++; M.fin[2 * e] = lo; M.fin[2 * e + 1] = hi; } sh[LQ_REMAINING] -= size; }
+        }
+    };
+    {
+        int top = 0;
+        route(0, m, depth0, top);
+        while (top > 0) {                                            // uniform
+            __syncthreads();                                         // thread 0's stack writes
+            --top;
+            const int f = stk[3 * top], l = stk[3 * top + 1], d = stk[3 * top + 2];
+            __syncthreads();                                         // read by everybody before the slot is written again
+            if (d == 0) {                                            // __partial_sort(first, last, last): sorted for good, no children
+                if (t == 0) { heap_sort_range(M.keys + f, M.vals + f, l - f); sh[LQ_REMAINING] -= l - f; }
+                continue;
+            }
+            const int cut = wg_partition(M.keys, M.vals, M.lt, M.rt, f, l, wl, wr, sk);
+            route(cut, l, d - 1, top);                               // the library's recursive call
+            route(f, cut, d - 1, top);                               // its loop's next trip
+        }
     }
     __syncthreads();
     int f = 0, l = 0, d = 0;
@@ -591,6 +626,8 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
     __shared__ int s_q[4 * SS_LOCAL_LIST];
     __shared__ int s_scr[(SS_LEAF_WG / 64) * 128];
     __shared__ int sh[4];
+    __shared__ int s_wl[SS_BIG_WAVES + 1], s_wr[SS_BIG_WAVES + 1], s_k, s_stk[3 * SS_LEAF_STACK];
+    static_assert(SS_LEAF_WG == SS_BIG_WG, "wg_partition is written for the big levels' workgroup");
     const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[A.over_level];
     const SortSeg *over = A.seg[A.over_level & 1];
     const int t = threadIdx.x;
@@ -607,14 +644,14 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
             for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
             M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
             __syncthreads();
-            leaf_sort(M, m, s.depth, sh, A.err);
+            leaf_sort(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
             for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
             MLH_SSTAGE(6);
             __syncthreads();
         } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
             M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
-            M.q = A.glist + f; M.qcap = m / (SS_THRESHOLD + 1) + 2;
-            leaf_sort(M, m, s.depth, sh, A.err);
+            M.q = A.glist + f; M.qcap = min(2 * (m / (SS_THRESHOLD + 1)) + 2, m / 4);
+            leaf_sort(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
         }
     }
 }
