@@ -1069,6 +1069,12 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_COH
 #define MLH_LOOP_COH 1
 #endif
+#ifndef MLH_LOOP_FLAG
+#define MLH_LOOP_FLAG 0
+#endif
+#ifndef MLH_LOOP_SLEEP
+#define MLH_LOOP_SLEEP 1
+#endif
 #ifndef MLH_LOOP_SPIN_LIMIT
 #define MLH_LOOP_SPIN_LIMIT 4000000u
 #endif
@@ -1137,13 +1143,24 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (threadIdx.x == 0) {
             if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = unsigned(total) * unsigned(it + 1);
+#if MLH_LOOP_FLAG
+            // the last arrival raises a separate word the others watch: the polls stay off the line the arrivals' atomics serialise on
+            const unsigned before = __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
-            while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
+            if (before + 1u == target) __hip_atomic_store(P.ticket + 3, unsigned(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else while (__hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < unsigned(it + 1)) {
+                if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
                 if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
             }
+#else
+            __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
+                if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
+            }
+#endif
             if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("" ::: "memory");
         }
@@ -1186,6 +1203,7 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (left == unsigned(total - 1)) {
             __hip_atomic_store(P.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(P.ticket + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.ticket + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
