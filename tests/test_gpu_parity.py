@@ -1404,6 +1404,36 @@ def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feat
         c.close()
 
 
+def test_scan2map_lm_forms_over_loop_lengths_and_degenerate_frames(mla, case16, feats16, monkeypatch):
+    """The same three forms of the LM loop where the loop is cut short (max_lm_iterations 1 .. 4: the device loop must end on the iteration count exactly as Ceres' does),
+    with one and three outer iterations, without the Huber loss, and on a frame the degeneracy test fires on (a map_eig_thre above the spectrum: the eigen-decomposition
+    and the projected update run inside every workgroup of the loop kernel): poses bit for bit those of the launches that also fill the statistics."""
+    p0 = case16["p0"]
+    c = mla.Context(0)
+    try:
+        _stage(c, mla, case16, feats16)
+        variants = [dict(max_lm_iterations=k) for k in (1, 2, 3, 4)] + [dict(max_outer=1), dict(max_outer=3), dict(huber_delta=0.0), dict(map_eig_thre=1e9),
+                                                                         dict(map_eig_thre=3.0e4, max_outer=3)]
+        n_deg = 0
+        for kw in variants:
+            opts = mla.default_opts(**kw)
+            monkeypatch.delenv("MLH_LM_CONSUMER", raising=False)
+            monkeypatch.delenv("MLH_LM_LOOP", raising=False)
+            ref, st = c.scan2map(p0, opts)                         # statistics: the classic launches
+            n_deg += sum(int(x["is_degenerate"]) for x in st)
+            for mode in ("11", "10", "00"):
+                monkeypatch.setenv("MLH_LM_CONSUMER", mode[0])
+                monkeypatch.setenv("MLH_LM_LOOP", mode[1])
+                got = c.scan2map(p0, opts, want_stats=False)[0]
+                assert np.array_equal(got, ref), (kw, mode)
+                c.scan2map_begin(p0, opts)
+                split, status = c.scan2map_end()
+                assert status == 0 and np.array_equal(split, ref), (kw, mode)
+        assert n_deg >= 2                                          # the degenerate variants really took the projected update
+    finally:
+        c.close()
+
+
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
     _stage(ctx, mla, case16, feats16)
