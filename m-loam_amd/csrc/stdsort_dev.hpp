@@ -15,6 +15,16 @@
 namespace mlh {
 
 constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
+// the wave-level partition of a range longer than one tile (ss_wave_partition): tiles / swaps a lane keeps in flight, the pair count by search (A/B builds)
+#ifndef MLH_SS_WAVE_U
+#define MLH_SS_WAVE_U 4
+#endif
+#ifndef MLH_SS_WAVE_SWAP_U
+#define MLH_SS_WAVE_SWAP_U 2
+#endif
+#ifndef MLH_SS_WAVE_SEARCH
+#define MLH_SS_WAVE_SEARCH 1
+#endif
 
 struct IntLess { __device__ __forceinline__ bool operator()(int a, int b) const { return a < b; } };
 // keys are f32 bit patterns compared AS FLOATS (CompObject: cloudCurvature[i] < cloudCurvature[j], feature_extract.hpp)
@@ -222,15 +232,43 @@ __device__ __forceinline__ int ss_wave_partition(int *keys, int *vals, int *lt, 
         ss_wg_fence();
         const int piv = keys[f];
         int nL, nR;
-        ss_wave_stop_lists<4>(keys, lt, rt, f, f, l, piv, nL, nR, less);      // left stops ascending at lt[f ..], right stops ascending at rt[f ..]
+        ss_wave_stop_lists<MLH_SS_WAVE_U>(keys, lt, rt, f, f, l, piv, nL, nR, less);      // left stops ascending at lt[f ..], right stops ascending at rt[f ..]
         ss_wg_fence();
         const int npair = min(nL, nR), rlast = f + nR - 1;                    // the k-th right stop from the right: rt[rlast - k]
-        int K = 0;
+        // K = how many pairs cross: L[k] < R[k] holds for a PREFIX of k (the left stops ascend, the right stops counted from the right descend), so a 64-ary search
+        // finds it in one or two rounds where testing every pair took npair / 64 (13 for a ring's 1 670 voxel keys)
+        int K;
+#if MLH_SS_WAVE_SEARCH
+        {
+            int lo_k = 0, hi_k = npair;
+            while (hi_k > lo_k) {                                            // uniform
+                const int step = (hi_k - lo_k + 63) >> 6;
+                const int k = lo_k + lane * step;
+                const bool p = k < hi_k && lt[f + k] < rt[rlast - k];
+                const int c = __popcll(__ballot(p));
+                const int new_hi = min(hi_k, lo_k + c * step);
+                lo_k = c > 0 ? lo_k + (c - 1) * step + 1 : lo_k;
+                hi_k = c > 0 ? max(new_hi, lo_k) : lo_k;
+            }
+            K = lo_k;
+        }
+#else
+        K = 0;
         for (int base = 0; base < npair; base += 64) {
             const int k = base + lane;
             K += __popcll(__ballot(k < npair && lt[f + k] < rt[rlast - k]));
         }
-        for (int k = lane; k < K; k += 64) ss_swap_elem(keys, vals, lt[f + k], rt[rlast - k]);
+#endif
+        // the swaps, MLH_SS_WAVE_SWAP_U pairs per lane in flight: positions, then the elements, then the stores (the pairs are disjoint)
+        for (int k0 = lane; k0 < K; k0 += 64 * MLH_SS_WAVE_SWAP_U) {
+            int pp[MLH_SS_WAVE_SWAP_U], qq[MLH_SS_WAVE_SWAP_U], kp[MLH_SS_WAVE_SWAP_U], kq[MLH_SS_WAVE_SWAP_U], vp[MLH_SS_WAVE_SWAP_U], vq[MLH_SS_WAVE_SWAP_U];
+#pragma unroll
+            for (int u = 0; u < MLH_SS_WAVE_SWAP_U; ++u) { const int k = k0 + 64 * u; const bool on = k < K; pp[u] = on ? lt[f + k] : -1; qq[u] = on ? rt[rlast - k] : -1; }
+#pragma unroll
+            for (int u = 0; u < MLH_SS_WAVE_SWAP_U; ++u) if (pp[u] >= 0) { kp[u] = keys[pp[u]]; kq[u] = keys[qq[u]]; vp[u] = vals[pp[u]]; vq[u] = vals[qq[u]]; }
+#pragma unroll
+            for (int u = 0; u < MLH_SS_WAVE_SWAP_U; ++u) if (pp[u] >= 0) { keys[pp[u]] = kq[u]; keys[qq[u]] = kp[u]; vals[pp[u]] = vq[u]; vals[qq[u]] = vp[u]; }
+        }
         cut = INT_MAX;
         if (K < nL) cut = min(cut, lt[f + K]);
         if (K > 0) cut = min(cut, rt[rlast - (K - 1)]);
