@@ -505,8 +505,10 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
  * the eigen-decomposition only when H - thre*I is not positive definite, i.e. when something IS degenerate). */
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
 /* scan2MapOptimization submitted and collected separately (lidar_mapper_keyframe.cpp:423-639 as the mapper's per-frame call, :145-160 for the chained start pose):
- * mlh_scan2map_begin enqueues the whole solve -- per outer iteration the match launch and `lm_lookahead` Levenberg-Marquardt launches (0: automatic -- the previous
- * collected frame's longest LM loop + 2, 10 before any; at most max_lm_iterations), launches behind the LM loop's termination find `done` on the device and leave -- and returns; the caller stages the NEXT frame's maps
+ * mlh_scan2map_begin enqueues the whole solve and returns. lm_lookahead = 0 (automatic): per outer iteration the match launch and ONE launch that runs the
+ * Levenberg-Marquardt loop to its end on the device -- status 0, always -- wherever that launch applies (one GPU, at most 160 fit tiles = 40 960 feature slots);
+ * otherwise, and with lm_lookahead > 0: per outer iteration the match launch and that many LM launches (automatic: the previous collected frame's longest LM loop + 2,
+ * 10 before any; at most max_lm_iterations), launches behind the LM loop's termination find `done` on the device and leave. The caller stages the NEXT frame's maps
  * (mlh_map_set_pair_overlapped) and submits the next frame (mlh_scan2map_begin_chained: start pose = transformUpdate + transformAssociateToMap on the pose the
  * previous solve leaves on the device) before it collects this one's pose with mlh_scan2map_end. Up to two solves in flight, in submission order, shared with
  * mlh_gn_solve_begin / _end (each collected by its own _end). One GPU or the mailbox communicator; gf_method MLH_GF_WO (a selection runs host loops between launches).
