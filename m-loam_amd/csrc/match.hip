@@ -1069,6 +1069,9 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_COH
 #define MLH_LOOP_COH 1
 #endif
+#ifndef MLH_LOOP_SPLIT_STEP
+#define MLH_LOOP_SPLIT_STEP 0
+#endif
 #ifndef MLH_LOOP_FLAG
 #define MLH_LOOP_FLAG 0
 #endif
@@ -1084,6 +1087,7 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
     __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];
     __shared__ double s_cand[8];
     __shared__ int s_done, s_timeout;
+    __shared__ double s_gmax;
     __shared__ LmState s_lm;
     const int total = P.k[0].tiles_b + P.k[1].tiles_b;
     const int gtile = xcd_tile(total);
@@ -1169,6 +1173,31 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (s_timeout) break;
         lmc_sum_records<MLH_LOOP_COH != 0>(rec, total, f_ne, f_scratch);
         if (it == 2) MLH_STAGE(gtile, 4);
+#if MLH_LOOP_SPLIT_STEP
+        {
+            // the LM step on the first wavefront, the gradient max-norm an ACCEPTED step needs on the second, side by side (lm_step_wave_spec1 / 2)
+            LmRegs R;
+            double cand[7];
+            LmStepSpec sp;
+            if (threadIdx.x < 64) lm_step_wave_spec1(f_ne, &s_lm, P.lm_max_it, R, cand, sp);
+            else if (threadIdx.x < 128) {
+                LmRegs Q;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) Q.x[i] = s_lm.cand[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Q.g[i] = f_ne[NE_G + i];
+                const double gm = gradient_max_norm_wave(Q, s_lm.V, threadIdx.x & 63);
+                if (threadIdx.x == 64) s_gmax = gm;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x;
+                lm_step_wave_spec2(&s_lm, &s_lm, true, R, cand, sp, s_gmax);
+                if (lane < 7) s_cand[lane] = pick7(cand, lane);
+                if (lane == 0) s_done = R.done;
+            }
+        }
+#else
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
             LmRegs R;
@@ -1177,6 +1206,7 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
             if (lane < 7) s_cand[lane] = pick7(cand, lane);
             if (lane == 0) s_done = R.done;
         }
+#endif
         __syncthreads();
         if (it == 2) MLH_STAGE(gtile, 5);
         ++it;

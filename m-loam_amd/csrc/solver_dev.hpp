@@ -1007,6 +1007,67 @@ __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState 
     MLH_STEP_STAMP(7);
 }
 
+// The step in two parts, for a caller that has ANOTHER wavefront compute the gradient max-norm an accepted step needs (gradient_max_norm_wave at the candidate, with
+// the candidate's gradient: inputs that exist before the step begins) while this one goes on: part 1 is lm_step_wave_pp with the proposal made as if that norm were
+// above the tolerance; part 2 -- behind a barrier, with the norm in hand -- takes the proposal back if it is not (Ceres tests the norm before it proposes: the loop
+// ends with the accepted pose, termination 1, the iteration count as it was), and stores the state. Same operations on every value that survives: the same bits.
+struct LmStepSpec {
+    const double *ne_now;
+    int accepted, iteration_before, hit_max_it;
+};
+__device__ __forceinline__ void lm_step_wave_spec1(const double *ce, const LmState *Si, int max_it, LmRegs &R, double (&cand)[7], LmStepSpec &sp)
+{
+    const int lane = threadIdx.x & 63;
+    lm_regs_load(R, Si);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) cand[i] = Si->cand[i];
+    const double x_cost = Si->ne[NE_COST];
+    R.evaluations++;
+    double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const double d = R.x[i] - cand[i]; step_norm += d * d; x_norm += R.x[i] * R.x[i]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    bool stop = false;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { R.done = 1; R.termination = 2; stop = true; }
+    const double cost_change = x_cost - ce[NE_COST];
+    if (!stop && fabs(cost_change) <= 1e-6 * x_cost) { R.done = 1; R.termination = 3; stop = true; }
+    sp.ne_now = Si->ne; sp.accepted = 0; sp.iteration_before = R.iteration; sp.hit_max_it = 0;
+    if (!stop) {
+        const double rd = cost_change / R.model_cost_change;
+        const double gmax_state = R.gmax;
+        if (rd > 1e-3) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) R.x[i] = cand[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) R.g[i] = ce[NE_G + i];
+            sp.ne_now = ce;
+            sp.accepted = 1;
+            R.num_successful++;
+            const double t = 2.0 * rd - 1.0;
+            R.radius = R.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            R.radius = fmin(1e16, R.radius);
+            R.decrease_factor = 2.0;
+            R.reuse_diagonal = 0;
+            R.gmax = 1.0;                              // (above the tolerance: the real one arrives in part 2)
+        } else {
+            R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
+        }
+        sp.iteration_before = R.iteration;
+        sp.hit_max_it = R.iteration >= max_it ? 1 : 0;
+        lm_propose_wave(R, sp.ne_now, Si->V, cand, max_it, lane);
+        if (!sp.accepted) R.gmax = gmax_state;
+    }
+}
+__device__ __forceinline__ void lm_step_wave_spec2(const LmState *Si, LmState *So, bool write, LmRegs &R, const double (&cand)[7], const LmStepSpec &sp, double gmax_accepted)
+{
+    const int lane = threadIdx.x & 63;
+    if (sp.accepted) {
+        R.gmax = gmax_accepted;
+        if (!sp.hit_max_it && gmax_accepted <= 1e-10) { R.done = 1; R.termination = 1; R.iteration = sp.iteration_before; }
+    }
+    if (write) lm_state_store_pp(R, cand, sp.ne_now, Si->V, So, lane);
+}
+
 // x: the pose the records in `ne` were taken at. ne / scratch: LDS. No statistics in this schedule (the classic launches serve a caller who asks for them).
 __device__ __forceinline__ void lm_begin_wave_pp(const double *ne, double *scratch, const double (&x)[7], LmState *So, bool write, double eig_thre, int max_it, int min_blocks,
                                                  LmRegs &R, double (&cand)[7])
