@@ -1087,7 +1087,9 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
     __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];
     __shared__ double s_cand[8];
     __shared__ int s_done, s_timeout;
+#if MLH_LOOP_SPLIT_STEP
     __shared__ double s_gmax;
+#endif
     __shared__ LmState s_lm;
     const int total = P.k[0].tiles_b + P.k[1].tiles_b;
     const int gtile = xcd_tile(total);
