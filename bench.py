@@ -931,10 +931,11 @@ def main():
                 frame_once(st_t)
             frame = dict(ms_per_frame=round(frame_ms, 4), stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
                          scan_points=int(len(all_pts)), thinned_features=dict(surf=int(frame_counts[0]), corner=int(frame_counts[1])), pose=[round(float(x), 9) for x in frame_pose],
-                         host_reads_between_scan_and_pose=1,
+                         host_reads_between_scan_and_pose=2,
                          note="supplementary: the two raw scans resident in HBM -> extractCloud + per-ring voxel thinning + fusion -> downsampleCurrentScan (both kinds, one "
-                              "pipeline) -> index build of both maps -> scan2MapOptimization -> pose; frames one after the other, host waits for every pose. The one host read "
-                              "inside the frame: the thinned feature counts, which size the solve's launches")
+                              "pipeline) -> index build of both maps -> scan2MapOptimization -> pose; frames one after the other, host waits for every pose. Two host reads "
+                              "inside the frame, each a spin on a pinned record a kernel publishes: the fused clouds' counts and bounds (they size the thinning's launches and "
+                              "its voxel grids), and the thinned feature counts (they size the solve's launches)")
         finally:
             fctx.close()
 
