@@ -27,9 +27,14 @@ in_flight = []          # kinds of the solves in flight ("gn" / "s2m"), oldest f
 n_ops = n_cmp = 0
 submitted_once = False
 t0 = time.time()
-def both(fn):
+# scan2map's Levenberg-Marquardt loop (round 5): context 0 runs it as ONE launch per outer iteration (an explicit look-ahead: consumer-side launches), context 1 as
+# round 4's launches (the step in the last workgroup). The switches are read at every call. `same_lm`: a submission with lm_lookahead = 0, where the one-launch loop
+# cannot overflow and the launches can -- both contexts then take the default, so that they keep agreeing on what a frame's status is.
+LM_ENV = ({"MLH_LM_CONSUMER": "1", "MLH_LM_LOOP": "1"}, {"MLH_LM_CONSUMER": "0", "MLH_LM_LOOP": "0"})
+def both(fn, same_lm=False):
     out = []
     for i, c in enumerate(ctxs):
+        os.environ.update(LM_ENV[0] if same_lm else LM_ENV[i])
         try:
             out.append(fn(c))
         except Exception as ex:
@@ -72,10 +77,10 @@ while time.time() - t0 < budget:
         both(lambda c: c.gn_solve_begin_chained(ident, ident, n)); in_flight.append("gn"); trace[-1] += f"({n})"
     elif op == "s2m_begin":
         la = int(rng.integers(0, 8))
-        both(lambda c: c.scan2map_begin(p0, lm_lookahead=la)); in_flight.append("s2m"); trace[-1] += f"({la})"
+        both(lambda c: c.scan2map_begin(p0, lm_lookahead=la), same_lm=(la == 0)); in_flight.append("s2m"); trace[-1] += f"({la})"
     elif op == "s2m_chained":
         la = int(rng.integers(0, 8))
-        both(lambda c: c.scan2map_begin_chained(ident, ident, lm_lookahead=la)); in_flight.append("s2m"); trace[-1] += f"({la})"
+        both(lambda c: c.scan2map_begin_chained(ident, ident, lm_lookahead=la), same_lm=(la == 0)); in_flight.append("s2m"); trace[-1] += f"({la})"
     elif op == "end":
         kind = in_flight.pop(0)
         trace[-1] += f"[{kind}]"
@@ -129,4 +134,5 @@ while in_flight:
     check(r[0], r[1], "final drain")
 for c in ctxs:
     c.close()
-print(f"schedule soak: {n_ops} operations, {n_cmp} poses compared bit for bit between the round-4 schedule and the classic one, seed {seed}, {time.time() - t0:.0f} s: all equal")
+print(f"schedule soak: {n_ops} operations, {n_cmp} poses compared bit for bit between the current schedules (deferred GN finish, bounded search, final-in-successor; scan2map's LM loop "
+      f"as one launch / consumer-side launches) and the classic ones, seed {seed}, {time.time() - t0:.0f} s: all equal")
