@@ -926,10 +926,35 @@ def main():
             for _ in range(n_fr):
                 frame_pose, frame_counts = frame_once()
             frame_ms = 1e3 * (time.perf_counter() - c0) / n_fr
+            # the same frame with the local map staged and indexed BESIDE the front end (second stream, the other map set): the map is made of earlier keyframes and
+            # does not wait for the scan (the whole-frame form)
+            def frame_once_staged_beside():
+                fctx.fuse_reset()
+                fctx.scan_upload(d_pts, d_start, d_end); fctx.extract_run(); fctx.extract_voxel_run(0.2)
+                for i_ in range(len(scans)):
+                    fctx.fuse_add_rings(ring_ofs[i_], ring_ofs[i_ + 1], i_, f_ext[i_])
+                fctx.map_set_pair_overlapped(d_surf_map, d_corner_map)
+                fctx.downsample_current_scan_pair(fctx.fused_cloud(mla.SURF), fctx.fused_cloud(mla.CORNER), 0.4, 0.2, f_ext, f_covs, f_meas, True, 0.6)
+                return fctx.scan2map(p0, f_opts, want_stats=False)[0]
+            frame_beside_ms, frame_beside_same = None, None
+            try:
+                for _ in range(5):
+                    frame_once_staged_beside()
+                sync_all()
+                c0 = time.perf_counter()
+                for _ in range(n_fr):
+                    pose_beside = frame_once_staged_beside()
+                frame_beside_ms = 1e3 * (time.perf_counter() - c0) / n_fr
+                frame_beside_same = bool(np.array_equal(pose_beside, frame_pose))
+            except Exception as ex:      # (a supplementary leg must not cost the line)
+                frame_beside_ms = None
+                print(f"[rank {rank}] frame, map staged beside the front end: {str(ex)[:200]}", file=sys.stderr)
+            fctx.map_set_pair(d_surf_map, d_corner_map)
             st_t = {}
             for _ in range(n_fr):
                 frame_once(st_t)
-            frame = dict(ms_per_frame=round(frame_ms, 4), stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
+            frame = dict(ms_per_frame=round(frame_ms, 4), ms_per_frame_map_staged_beside_the_front_end=(round(frame_beside_ms, 4) if frame_beside_ms else None),
+                         map_staged_beside_same_pose=frame_beside_same, stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
                          scan_points=int(len(all_pts)), thinned_features=dict(surf=int(frame_counts[0]), corner=int(frame_counts[1])), pose=[round(float(x), 9) for x in frame_pose],
                          host_reads_between_scan_and_pose=2,
                          note="supplementary: the two raw scans resident in HBM -> extractCloud + per-ring voxel thinning + fusion -> downsampleCurrentScan (both kinds, one "
