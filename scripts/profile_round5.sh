@@ -56,7 +56,7 @@ rm -rf $OUT/ftrace
 # the scan2map Levenberg-Marquardt schedules side by side (classic launches | consumer-side launches | the loop as one launch), and the loop kernel's stage clocks
 REPS=2 timeout 600 scripts/ab_lm.sh > $OUT/lm_schedule_ab.txt 2>&1
 [ -f m-loam_amd/lib/libmloam_hip_dbg.so ] && MLOAM_HIP_LIB=$PWD/m-loam_amd/lib/libmloam_hip_dbg.so timeout 200 python scripts/stageclock_loop.py 2>/dev/null | tail -10 > $OUT/stageclock_loop.txt
-{ timeout 300 python scripts/soak_stdsort.py 300 21; timeout 300 python scripts/soak_parity_frontend.py 100 21 segment,rough,voxel,uct; timeout 300 python scripts/soak_parity.py 100 21; } > $OUT/soak.txt 2>&1
+{ timeout 300 python scripts/soak_schedule.py 40 21 2>&1 | tail -1; timeout 300 python scripts/soak_stdsort.py 300 21; timeout 300 python scripts/soak_parity_frontend.py 100 21 segment,rough,voxel,uct; timeout 300 python scripts/soak_parity.py 100 21; } > $OUT/soak.txt 2>&1
 python - <<PY
 import json
 for n in ("bench_line", "bench_synchronous", "bench_no_overlap_staging"):
