@@ -48,8 +48,8 @@ __device__ unsigned long long g_stage_clk_sort[1024 * 8];
         if (threadIdx.x == 0 && blockIdx.x < 1024) g_stage_clk_sort[blockIdx.x * 8 + (i)] = wall_clock64(); \
     } while (0)
 // per-workgroup totals over all wavefronts (10 ns ticks): [0..2] partitions of <= 64 / <= 256 / longer, [3..5] their ticks, [6] bookkeeping ticks, [7] waiting ticks
-__device__ unsigned long long g_stage_clk_sort2[1024 * 8];
-#define MLH_SACC(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicAdd(&g_stage_clk_sort2[blockIdx.x * 8 + (i)], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_stage_clk_sort2[1024 * 16];
+#define MLH_SACC(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicAdd(&g_stage_clk_sort2[blockIdx.x * 16 + (i)], (unsigned long long)(v)); } while (0)
 #define MLH_SCLK() wall_clock64()
 #else
 #define MLH_SSTAGE(i) do { } while (0)
@@ -564,6 +564,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
         if (d == 0) {                                                 // __partial_sort(first, last, last): sorted for good, no children
             if (size <= 64) ss_heap_sort_wave64(M.keys + f, M.vals + f, size, IntLess());     // in registers (the leftovers of an exhausted budget are short)
             else if (lane == 0) heap_sort_range(M.keys + f, M.vals + f, size);
+            MLH_SACC(size <= 64 ? 8 : 10, 1); MLH_SACC(size <= 64 ? 9 : 11, MLH_SCLK() - c_part); MLH_SACC(12, size);
             wg_fence();
             if (lane == 0) atomicSub(&sh[LQ_REMAINING], size);
             have = false;
@@ -778,7 +779,7 @@ extern "C" int mlh_debug_stage_clock_sort(unsigned long long *out, int n_words)
 extern "C" int mlh_debug_stage_clock_sort2(unsigned long long *out, int n_words, int clear)
 {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_sort2), sizeof(unsigned long long) * size_t(n_words));
-    if (clear) { static unsigned long long z[1024 * 8]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(mlh::g_stage_clk_sort2), z, sizeof(z)); }
+    if (clear) { static unsigned long long z[1024 * 16]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(mlh::g_stage_clk_sort2), z, sizeof(z)); }
     return rc;
 }
 namespace mlh {

@@ -19,12 +19,12 @@ lib.mlh_debug_stage_clock_sort2.argtypes = [C.c_void_p, C.c_int, C.c_int]
 for _ in range(2):
     ctx.extract_voxel_run(0.2)
 ctx.synchronize()
-buf2 = (C.c_ulonglong * (1024 * 8))()
-lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 8, 1)          # clear the accumulators
+buf2 = (C.c_ulonglong * (1024 * 16))()
+lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 16, 1)          # clear the accumulators
 ctx.extract_voxel_run(0.2)
 ctx.synchronize()
-lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 8, 0)
-acc = np.frombuffer(buf2, np.uint64).reshape(1024, 8).astype(np.float64)[:128]
+lib.mlh_debug_stage_clock_sort2(buf2, 1024 * 16, 0)
+acc = np.frombuffer(buf2, np.uint64).reshape(1024, 16).astype(np.float64)[:128]
 for cls, nm in enumerate(["<= 64", "<= 256", "longer"]):
     n = acc[:, cls].sum(); tk = acc[:, 3 + cls].sum()
     print(f"partitions of {nm:7s}: {n / 128:6.1f} per ring, {0.01 * tk / max(n, 1):5.2f} us each")
@@ -45,3 +45,7 @@ print("slowest rings (recursion done, us):", [(int(i), round(float(rel[i, 2]), 1
 print("fastest rings:", [(int(i), round(float(rel[i, 2]), 1)) for i in order[-6:]])
 per_ring_parts = acc[:, :3].sum(axis=1)
 print("partitions per ring for the slowest:", [(int(i), int(per_ring_parts[i]), round(0.01 * float(acc[i, 7]), 1)) for i in order[:12]])
+
+print("heap sorts (depth budget used up): <= 64 elements %d in all rings, %.2f us each; longer: %d, %.2f us each; elements heap-sorted per ring: mean %.1f max %d"
+      % (acc[:, 8].sum(), 0.01 * acc[:, 9].sum() / max(acc[:, 8].sum(), 1), acc[:, 10].sum(), 0.01 * acc[:, 11].sum() / max(acc[:, 10].sum(), 1), acc[:, 12].mean(), acc[:, 12].max()))
+print("  slowest rings: (ring, long heap sorts, us in them, elements)", [(int(i), int(acc[i, 10]), round(0.01 * float(acc[i, 11]), 1), int(acc[i, 12])) for i in order[:8]])
