@@ -16,6 +16,9 @@ namespace mlh {
 
 constexpr int SS_THRESHOLD = 16;      // std::_S_threshold
 // the wave-level partition of a range longer than one tile (ss_wave_partition): tiles / swaps a lane keeps in flight, the pair count by search (A/B builds)
+#ifndef MLH_SS_HEAP_PAR
+#define MLH_SS_HEAP_PAR 0
+#endif
 #ifndef MLH_SS_WAVE_U
 #define MLH_SS_WAVE_U 4
 #endif
@@ -109,6 +112,38 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
     const int lane = threadIdx.x & 63;
     int key_r = lane < len ? k[lane] : 0, val_r = lane < len ? v[lane] : 0;
     auto rd = [&](int reg, int i) { return __builtin_amdgcn_readlane(reg, i); };
+#if MLH_SS_HEAP_PAR
+    // __adjust_heap (+ its trailing __push_heap) for ALL levels at once. The library first walks the hole down to a leaf, always to the larger child (the right one
+    // on a tie; the only child of the last inner node of an even-sized heap), moving that child up -- a path that depends on the heap's content alone -- and then walks
+    // the new value up that same path while the element above it is smaller. With one element per lane: every lane compares its two children (two shuffles), two
+    // ballots make "which child does node p prefer" a uniform mask, each lane tests its own ancestors against the mask (is it on the path from the hole, and how
+    // deep), a third ballot finds where the upward walk stops -- the deepest path node that is the hole's start or holds an element not smaller than the value --,
+    // path nodes above that point take their preferred child's element, the point takes the value. Built, equal to libstdc++ on every test and soak -- and SLOWER than
+    // the level-by-level form below (23.8 against 16.8 us per heap sort of 31-94 elements: four ds_bpermute, three ballots and the 64-bit mask tests cost more than six
+    // levels of scalar-indexed v_readlane + select): not the default (profiles/r05_knockout_experiments.txt item 19).
+    auto adjust = [&](int hole, int n, int key, int val) {
+        const int lc = 2 * lane + 1, rc = 2 * lane + 2;
+        const int kl = __shfl(key_r, lc & 63), kr = __shfl(key_r, rc & 63), vl = __shfl(val_r, lc & 63), vr = __shfl(val_r, rc & 63);
+        const bool two = rc < n, has = lc < n;                      // (lc == n - 1 without a right child: n even, lane == (n - 2) / 2)
+        const bool pick_l = two ? less(kr, kl) : true;
+        const int kc = pick_l ? kl : kr, vc = pick_l ? vl : vr;     // the preferred child's element
+        const unsigned long long HAS = __ballot(has), PL = __ballot(has && pick_l);
+        bool on = lane < n;
+        int x = lane, depth = 0;
+        while (x > hole) {                                          // (at most six trips; lanes outside the hole's subtree fall below it)
+            const int p = (x - 1) >> 1;
+            on = on && ((HAS >> p) & 1ull) && ((((PL >> p) & 1ull) != 0ull) == ((x & 1) != 0));
+            x = p;
+            ++depth;
+        }
+        on = on && x == hole;
+        const bool f = on && (depth == 0 || !less(key_r, key));
+        const unsigned long long F = __ballot(f);                  // never empty: the hole itself
+        const int jstar = 63 - __clzll((long long)F);
+        if (on && lane < jstar) { key_r = kc; val_r = vc; }
+        else if (lane == jstar) { key_r = key; val_r = val; }
+    };
+#else
     auto adjust = [&](int hole, int n, int key, int val) {
         const int top = hole;
         int c = hole;
@@ -134,6 +169,7 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
         }
         key_r = (lane == hole) ? key : key_r; val_r = (lane == hole) ? val : val_r;
     };
+#endif
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
