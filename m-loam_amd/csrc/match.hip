@@ -244,6 +244,7 @@ struct KParams {
     const double *partials_in;
     const LmState *lm_in;
     LmState *lm_out;
+    int debug_stall;         // MLH_DEBUG_LOOP_STALL=1 (tests): one workgroup of lm_loop_kernel never arrives at its second barrier -- the loop must end with the error bit, not hang
 };
 
 __device__ __forceinline__ int block_of_slot(const KindP &K, int n_blocks, int f)
@@ -1150,6 +1151,9 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
             if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned target = unsigned(total) * unsigned(it + 1);
+            const bool stall = P.debug_stall && it == 1 && gtile == (total > 1 ? 1 : 0);
+            if (stall) { s_timeout = 1; }
+            else {
 #if MLH_LOOP_FLAG
             // the last arrival raises a separate word the others watch: the polls stay off the line the arrivals' atomics serialise on
             const unsigned before = __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1167,6 +1171,7 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
                 if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
             }
 #endif
+            }
             if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("" ::: "memory");
         }
@@ -1548,6 +1553,7 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
     if (P.p2p.n_ranks > 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the consumer-side Levenberg-Marquardt schedule is single-GPU");
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
     if (a.lmc == 3) {
+        { const char *e = std::getenv("MLH_DEBUG_LOOP_STALL"); P.debug_stall = (e && std::atoi(e) != 0) ? 1 : 0; }
         // every tile's workgroup has to be resident for the barrier: 256-thread workgroups at <= 128 VGPRs, a few KB of LDS -- several per compute unit
         if (P.k[0].tiles_b + P.k[1].tiles_b > 256) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than compute units");
         launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel, grid_b, P);

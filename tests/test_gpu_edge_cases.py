@@ -886,3 +886,30 @@ def test_rough_scans_extract_thin_and_match(mla, synth, orc, case16, n_rings):
                 assert np.array_equal(r["coeffs"][v.astype(bool), :nc].astype(np.float32).view(np.uint32), np.asarray(co)[v.astype(bool), :nc].astype(np.float32).view(np.uint32)), (seed, name)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_lm_loop_kernel_reports_a_missing_workgroup_instead_of_hanging(mla, case16, feats16, monkeypatch):
+    """scan2map's LM loop runs as one launch whose workgroups meet at a counter barrier once per iteration. A workgroup that never arrives (MLH_DEBUG_LOOP_STALL=1 makes
+    one skip its second arrival) must not hang the stream: the others give up after their bounded spin, the launch publishes the error bit, the call fails with
+    MLH_ERR_HIP -- and the context goes on working (the barrier's counters are re-armed by the last workgroup to leave)."""
+    import time
+    c = mla.Context(0)
+    try:
+        c.map_set(mla.SURF, case16["surf_map"]); c.map_set(mla.CORNER, case16["corner_map"])
+        c.features_set(mla.SURF, feats16[0]); c.features_set(mla.CORNER, feats16[1])
+        ref = c.scan2map(case16["p0"], want_stats=False)[0]
+        monkeypatch.setenv("MLH_DEBUG_LOOP_STALL", "1")
+        t0 = time.time()
+        with pytest.raises(mla.MlhError) as ei:
+            c.scan2map(case16["p0"], want_stats=False)
+        assert "barrier" in str(ei.value)
+        assert time.time() - t0 < 60.0
+        monkeypatch.delenv("MLH_DEBUG_LOOP_STALL")
+        again = c.scan2map(case16["p0"], want_stats=False)[0]
+        assert np.array_equal(again, ref)
+        c.scan2map_begin(case16["p0"])
+        pose, status = c.scan2map_end()
+        assert status == 0 and np.array_equal(pose, ref)
+    finally:
+        c.close()
