@@ -580,6 +580,15 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int gn_flush_pending(mlh_ctx *ctx);      // completes a pending last iteration with a one-workgroup launch (no-op when nothing is pending)
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a);
+// the arrival counters of the fused finishes and of lm_loop_kernel's barrier: four zeroed words, whoever asks first ([0]: the finish tickets of match.hip and
+// track.hip; [1] arrivals, [2] departures, [3] release flag of the loop kernel). One place, so that no caller can leave the others' words unallocated or unzeroed.
+inline hipError_t ensure_ticket(mlh_ctx *ctx)
+{
+    if (ctx->ticket.p) return hipSuccess;
+    hipError_t e = ctx->ticket.ensure(4 * sizeof(unsigned));
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(ctx->ticket.p, 0, 4 * sizeof(unsigned), ctx->stream);
+}
 int knn_launch(mlh_ctx *ctx, int kind, const float *q_host, int nq, int32_t *idx, float *d2);
 // select.hip
 }  // namespace mlh

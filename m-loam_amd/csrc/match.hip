@@ -1351,10 +1351,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
     hipError_t e;
     // (two sets of records: the consumer-side Levenberg-Marquardt launches alternate between them)
     if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b_total) * 2)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
-    if (!ctx->ticket.p) {          // [0]: the fused finish's arrival ticket; [1], [2]: lm_loop_kernel's barrier (arrivals, departures)
-        if ((e = ctx->ticket.ensure(4 * sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
-        if ((e = hipMemsetAsync(ctx->ticket.p, 0, 4 * sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
-    }
+    if ((e = ensure_ticket(ctx)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
     ctx->n_partial_tiles = tiles_b_total;
     P.partials = ctx->partials.as<double>();
     P.state = ctx->state.as<SolverState>();

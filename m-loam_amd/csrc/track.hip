@@ -512,10 +512,7 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     P.shells = TRACK_SHELLS;
     P.dist_sq_thr = a.dist_sq_thr; P.nearby_floor = int(std::floor(a.nearby_scan)); P.huber_delta = a.huber_delta;
     P.finish = a.finish; P.lm_max_it = a.lm_max_it; P.lm_min_blocks = a.lm_min_blocks;
-    if (!ctx->ticket.p) {
-        if ((e = ctx->ticket.ensure(sizeof(unsigned))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);
-        if ((e = hipMemsetAsync(ctx->ticket.p, 0, sizeof(unsigned), ctx->stream)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "memset ticket", e);
-    }
+    if ((e = ensure_ticket(ctx)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc ticket", e);      // (all four words: a later scan2map's loop kernel uses the others)
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = a.stat_slot >= 0 ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     P.publish = a.publish; P.publish_seq = a.publish_seq;

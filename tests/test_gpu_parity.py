@@ -1434,6 +1434,26 @@ def test_scan2map_lm_forms_over_loop_lengths_and_degenerate_frames(mla, case16, 
         c.close()
 
 
+def test_scan2map_loop_kernel_on_a_context_the_tracker_used_first(mla, case16, feats16, track_case):
+    """The arrival counters of the fused finishes and of the LM loop kernel's barrier live in one small buffer that the first user allocates: a context whose first
+    solver call is the tracker's must leave ALL of its words allocated and zeroed, or the mapper's loop kernel starts its barrier on whatever the allocation held (latent: found in round 5 by
+    reading -- a fresh allocation happens to be zero-filled, so the order below passed before the fix too; there is one allocation helper now, and this pins the order)."""
+    tc = track_case
+    c = mla.Context(0)
+    try:
+        c.track_set_prev(mla.CORNER, tc["corner_last"]); c.track_set_prev(mla.SURF, tc["surf_last"])
+        c.track_set_cur(mla.CORNER, tc["corner_sharp"]); c.track_set_cur(mla.SURF, tc["surf_flat"])
+        ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+        pose_t = c.track_cloud(ident, want_stats=False)[0]
+        _stage(c, mla, case16, feats16)
+        lean = c.scan2map(case16["p0"], want_stats=False)[0]        # the loop kernel, first launch of its kind on this context
+        full, _ = c.scan2map(case16["p0"])
+        assert np.array_equal(lean, full)
+        assert np.array_equal(c.track_cloud(ident, want_stats=False)[0], pose_t)
+    finally:
+        c.close()
+
+
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
     _stage(ctx, mla, case16, feats16)
