@@ -1885,6 +1885,8 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
 // LM launches) enqueued without the host reading the loop's verdict in between, a frame that outgrows the budget solved again by the polled form (status 2); the
 // same poses, bit for bit. Measured in one gpurun call, two alternations (profiles/r05_knockout_experiments.txt): 0.2436 / 0.2435 ms per frame against the polled
 // form's 0.2421 / 0.2422 -- the polls were already hidden behind the chunk enqueued ahead, and the launches that find `done` cost what the polls did. Not the default.
+// (Measured on round 4's launches. Since the LM loop of an outer iteration is ONE launch that ends on the device -- scan2map_polled's first branch -- the default
+// synchronous call enqueues the whole frame at once anyway and there is no budget left to look ahead of; the switch remains for the launches-per-iteration forms.)
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
 {
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;

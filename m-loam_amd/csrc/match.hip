@@ -1223,13 +1223,16 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (lane < 7) P.state->x[lane] = s_lm.x[lane];          // read by the launches BEHIND this one only (the other workgroups took their start pose long ago)
         if (lane == 0) {
             const double used = P.lm_expect_done < 0 ? double(s_lm.iteration) : fmax(P.state->lm_used_max, double(s_lm.iteration));
+            // (a barrier given up on in an EARLIER outer iteration of the frame must not be lost: lm_overflow -- unused otherwise by this schedule -- carries it to the
+            // launch that publishes)
+            const int failed = (s_timeout ? 1 : 0) | ((P.lm_expect_done >= 0 && P.state->lm_overflow == 4) ? 1 : 0);
             P.state->lm_used_max = used;
-            P.state->lm_overflow = 0;
+            P.state->lm_overflow = failed ? 4 : 0;
             P.state->done = s_lm.done;
             P.state->iteration = s_lm.iteration;
             if (P.publish) {
                 for (int i = 0; i < 7; ++i) P.publish->x[i] = s_lm.x[i];
-                P.publish->done = (s_lm.done ? 1 : 0) | (s_timeout ? 4 : 0);
+                P.publish->done = (s_lm.done ? 1 : 0) | (failed ? 4 : 0);
                 P.publish->xb[2][0] = used;
                 __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
