@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void seg_edge_kernel(SegEdge E)
         if (ty < 0) ty = E.hs - 1;
         if (ty >= E.hs) ty = 0;
         const float rt = E.range_mat[tx * E.hs + ty];
-        const float d1 = fmaxf(rf, rt), d2 = fminf(rf, rt);
+        const float d1 = (rf < rt) ? rt : rf, d2 = (rt < rf) ? rt : rf;      // std::max(rf, rt) / std::min(rf, rt) as the host loop spells them (a NaN range stays where std:: leaves it)
         const int a = dx == 0 ? 1 : (E.is64 ? (tx <= 32 ? 2 : 3) : 2);
         const float ay = d2 * E.t_sin[a], ax = d1 - d2 * E.t_cos[a];
         const float lim = ax * E.tan_theta;
