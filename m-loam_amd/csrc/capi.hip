@@ -2222,6 +2222,32 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
     const bool lean = stats == nullptr;
     if (!lean && (rc = upload_pose(ctx, pose_inout))) return rc;
     unsigned long long seq = 0;
+    // lean, one GPU, a frame's worth of features: a round is TWO launches -- the match and one launch that runs the round's LM loop to its end on the device
+    // (track.hip: track_lm_loop_kernel); MLH_TRACK_LOOP=0 keeps 2 + max_lm_iterations launches per round (A/B; read at every call)
+    {
+        const char *e = std::getenv("MLH_TRACK_LOOP");
+        const int tiles = (T.m[0] + 255) / 256 + (T.m[1] + 255) / 256;
+        if (lean && !(e && std::atoi(e) == 0) && !distributed(ctx) && tiles <= GN_DEFER_MAX_TILES) {
+            HostPublish *rec = nullptr;
+            if ((rc = publish_slot(ctx, &rec, &seq))) return rc;
+            for (int outer = 0; outer < opts->max_outer; ++outer) {
+                TrackArgs m = track_args(opts, 0);
+                if (outer == 0) m.init_pose = pose_inout;
+                if ((rc = track_match_launch(ctx, 3, m))) return rc;
+                TrackArgs b = track_args(opts, 0);
+                b.finish = 0; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 10; b.stat_slot = -1;
+                if (outer == 0) b.init_pose = pose_inout;
+                if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
+                if ((rc = track_lm_loop_launch(ctx, 3, b))) return rc;
+            }
+            HostPublish hp;
+            if ((rc = wait_published(ctx, seq, hp))) return rc;
+            if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_track_cloud: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (track_lm_loop_kernel timed out)");
+            if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+            for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+            return MLH_OK;
+        }
+    }
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         // lidar_tracker.cpp:42-121: match at the current estimate, then Ceres on the fixed correspondences (Huber 0.1, <= 4 iterations,
         // no degeneracy handling); fewer than 10 correspondences -> the round is skipped

@@ -427,6 +427,7 @@ int point_uncertainty_run(mlh_ctx *ctx, const void *points, int stride, int n, i
 int track_set_prev_rings(mlh_ctx *ctx, int kind, const unsigned char *d_src, int stride, int n, int intensity_off, int *host_bad);
 int track_match_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
 int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);
+int track_lm_loop_launch(mlh_ctx *ctx, int kind_mask, const mlh::TrackArgs &a);      // one round's whole LM loop (begin at the round's pose .. termination) in one launch
 // segment.hip
 int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
                       float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier);

@@ -920,34 +920,6 @@ __global__ __launch_bounds__(TPB) void linearize_kernel(KParams P)
 // into SolverState::x, which only launches behind this one read); the records alternate between two buffers the same way. A launch that finds the loop terminated
 // copies the state forward and leaves (the host enqueues a look-ahead of launches without reading the verdict in between, as before).
 // FIRST: the launch behind a match launch whose fit kernel ran with finish 0 -- the records are at the state's pose (or init_pose), the LM loop begins here.
-template <bool COH = false>
-__device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, double *f_ne, double *f_scratch)
-{
-    constexpr int NS = TPB / 32, U = 12;
-    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    double ch[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int j = sl; j < ntot; j += U * NS) {
-        double tv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int jj = j + NS * u;
-            if constexpr (COH) tv[u] = jj < ntot ? __hip_atomic_load(rec + size_t(jj) * NE_STRIDE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            else tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
-    }
-    f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double tsum = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
-        f_ne[c] = tsum;
-    }
-    __syncthreads();
-}
-
 __device__ __forceinline__ void lmc_publish(const KParams &P, const double (&x)[7], int done, int overflow, double used_max, int iteration)
 {
     for (int i = 0; i < 7; ++i) P.publish->x[i] = x[i];

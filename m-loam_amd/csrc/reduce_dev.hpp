@@ -71,4 +71,66 @@ __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double
     }
 }
 
+// ---- shared by the one-launch Levenberg-Marquardt loops (match.hip: lm_loop_kernel, track.hip: track_lm_loop_kernel)
+// the tiles' records summed by EVERY workgroup in sum_partials<TPB, 12>'s order (same slices, same four chains, same association: the same bits everywhere);
+// COH: the records were stored with agent-scope monotonic stores by other workgroups of the SAME launch and are read with agent-scope loads
+template <bool COH = false>
+__device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, double *f_ne, double *f_scratch)
+{
+    constexpr int NS = TPB / 32, U = 12;
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = sl; j < ntot; j += U * NS) {
+        double tv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = j + NS * u;
+            if constexpr (COH) tv[u] = jj < ntot ? __hip_atomic_load(rec + size_t(jj) * NE_STRIDE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            else tv[u] = jj < ntot ? rec[size_t(jj) * NE_STRIDE + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ch[u & 3] += tv[u];
+    }
+    f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
+        f_ne[c] = tsum;
+    }
+    __syncthreads();
+}
+
+
+// One arrival at the loop kernels' grid barrier, by thread 0 of a workgroup whose record stores have been issued (by lanes of thread 0's own wavefront): wait for
+// their acknowledgement, count the arrival, poll until all `total` workgroups of barrier number `nth` (1, 2, ...) have arrived. counters[1] = arrivals (monotonic
+// over the launch), counters[2] = departures (loop_barrier_leave). Returns false when the poll budget ran out (a workgroup that never arrives).
+#ifndef MLH_LOOP_SPIN_LIMIT
+#define MLH_LOOP_SPIN_LIMIT 4000000u
+#endif
+__device__ __forceinline__ bool loop_barrier_arrive(unsigned *counters, int total, int nth)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = unsigned(total) * unsigned(nth);
+    unsigned spins = 0;
+    while (__hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > MLH_LOOP_SPIN_LIMIT) return false;
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+// the last workgroup to leave re-arms the counters for the next launch (thread 0 of every participating workgroup, once, at the kernel's end)
+__device__ __forceinline__ void loop_barrier_leave(unsigned *counters, int total)
+{
+    const unsigned left = atomicAdd(counters + 2, 1u);
+    if (left == unsigned(total - 1)) {
+        __hip_atomic_store(counters + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counters + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counters + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace mlh

@@ -321,6 +321,73 @@ __device__ __forceinline__ void track_publish(const TrackParamsDev &P)
     __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the normal-equation terms of ONE matched feature at pose (q, t): LidarScanPlaneNormFactor (1 residual) or LidarScanEdgeFactorVector (3), Huber on the block's
+// squared norm -- what track_linearize_kernel and track_lm_loop_kernel accumulate (acc: zeroed by the caller)
+__device__ __forceinline__ void track_eval(const TrackParamsDev &P, int kind, const Corr &c, const float4 &fp, const q4 &q, const d3 &t, double (&acc)[32])
+{
+    const V3 p{double(fp.x), double(fp.y), double(fp.z)};
+    double R[9];
+    qtorot(q, R);
+    const d3 rp = qrot(q, d3{p.x, p.y, p.z});
+    const V3 lp{rp.x + t.x, rp.y + t.y, rp.z + t.z};
+    double res[3], J[3][6];
+    int rows;
+    if (kind == MLH_SURF) {
+        rows = 1;
+        const V3 w{double(c.c[0]), double(c.c[1]), double(c.c[2])};
+        res[0] = (w.x * lp.x + w.y * lp.y + w.z * lp.z) + double(c.c[3]);
+        const V3 jr = row_skew3(rowmul3(w, R), p);
+        J[0][0] = w.x; J[0][1] = w.y; J[0][2] = w.z; J[0][3] = -jr.x; J[0][4] = -jr.y; J[0][5] = -jr.z;
+    } else {
+        rows = 3;
+        const V3 la{double(c.c[0]), double(c.c[1]), double(c.c[2])}, lb{double(c.c[3]), double(c.c[4]), double(c.c[5])};
+        const V3 ba{lp.x - la.x, lp.y - la.y, lp.z - la.z}, bb{lp.x - lb.x, lp.y - lb.y, lp.z - lb.z};
+        const V3 nu{ba.y * bb.z - ba.z * bb.y, ba.z * bb.x - ba.x * bb.z, ba.x * bb.y - ba.y * bb.x};
+        const V3 de{la.x - lb.x, la.y - lb.y, la.z - lb.z};
+        const double den = sqrt(de.x * de.x + de.y * de.y + de.z * de.z);
+        res[0] = nu.x / den; res[1] = nu.y / den; res[2] = nu.z / den;
+        const double eta = 1.0 / den;
+        // rows of [de]x
+        const V3 sd[3] = {{0.0, -de.z, de.y}, {de.z, 0.0, -de.x}, {-de.y, de.x, 0.0}};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const V3 jr = row_skew3(rowmul3(sd[r], R), p);
+            J[r][0] = -eta * sd[r].x; J[r][1] = -eta * sd[r].y; J[r][2] = -eta * sd[r].z;
+            J[r][3] = eta * jr.x; J[r][4] = eta * jr.y; J[r][5] = eta * jr.z;
+        }
+    }
+    double sq = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) if (r < rows) sq += res[r] * res[r];     // static indices: res / J stay in registers (a loop over `rows` sends them to scratch)
+    double rho0 = sq, rho1 = 1.0;
+    if (P.huber_delta > 0.0) {
+        const double b = P.huber_delta * P.huber_delta;
+        if (sq > b) {
+            const double rr = sqrt(sq);
+            rho0 = 2.0 * P.huber_delta * rr - b;
+            rho1 = fmax(DBL_MIN, P.huber_delta / rr);
+        }
+    }
+    const double sc = sqrt(rho1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r >= rows) break;
+        double Jr[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Jr[i] = J[r][i] * sc;
+        const double rr = res[r] * sc;
+        int qd = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) acc[qd++] += Jr[i] * Jr[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[NE_G + i] += Jr[i] * rr;
+    }
+    acc[NE_COST] = 0.5 * rho0;
+    acc[NE_CNT] = 1.0;
+}
+
 __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
 {
     __shared__ double s_red[4 * 32];
@@ -346,67 +413,7 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
             d3 t;
             track_pose(P, q, t);
             const float4 fp = K.cur[f];
-            const V3 p{double(fp.x), double(fp.y), double(fp.z)};
-            double R[9];
-            qtorot(q, R);
-            const d3 rp = qrot(q, d3{p.x, p.y, p.z});
-            const V3 lp{rp.x + t.x, rp.y + t.y, rp.z + t.z};
-            double res[3], J[3][6];
-            int rows;
-            if (kind == MLH_SURF) {
-                rows = 1;
-                const V3 w{double(c.c[0]), double(c.c[1]), double(c.c[2])};
-                res[0] = (w.x * lp.x + w.y * lp.y + w.z * lp.z) + double(c.c[3]);
-                const V3 jr = row_skew3(rowmul3(w, R), p);
-                J[0][0] = w.x; J[0][1] = w.y; J[0][2] = w.z; J[0][3] = -jr.x; J[0][4] = -jr.y; J[0][5] = -jr.z;
-            } else {
-                rows = 3;
-                const V3 la{double(c.c[0]), double(c.c[1]), double(c.c[2])}, lb{double(c.c[3]), double(c.c[4]), double(c.c[5])};
-                const V3 ba{lp.x - la.x, lp.y - la.y, lp.z - la.z}, bb{lp.x - lb.x, lp.y - lb.y, lp.z - lb.z};
-                const V3 nu{ba.y * bb.z - ba.z * bb.y, ba.z * bb.x - ba.x * bb.z, ba.x * bb.y - ba.y * bb.x};
-                const V3 de{la.x - lb.x, la.y - lb.y, la.z - lb.z};
-                const double den = sqrt(de.x * de.x + de.y * de.y + de.z * de.z);
-                res[0] = nu.x / den; res[1] = nu.y / den; res[2] = nu.z / den;
-                const double eta = 1.0 / den;
-                // rows of [de]x
-                const V3 sd[3] = {{0.0, -de.z, de.y}, {de.z, 0.0, -de.x}, {-de.y, de.x, 0.0}};
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const V3 jr = row_skew3(rowmul3(sd[r], R), p);
-                    J[r][0] = -eta * sd[r].x; J[r][1] = -eta * sd[r].y; J[r][2] = -eta * sd[r].z;
-                    J[r][3] = eta * jr.x; J[r][4] = eta * jr.y; J[r][5] = eta * jr.z;
-                }
-            }
-            double sq = 0.0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) if (r < rows) sq += res[r] * res[r];     // static indices: res / J stay in registers (a loop over `rows` sends them to scratch)
-            double rho0 = sq, rho1 = 1.0;
-            if (P.huber_delta > 0.0) {
-                const double b = P.huber_delta * P.huber_delta;
-                if (sq > b) {
-                    const double rr = sqrt(sq);
-                    rho0 = 2.0 * P.huber_delta * rr - b;
-                    rho1 = fmax(DBL_MIN, P.huber_delta / rr);
-                }
-            }
-            const double sc = sqrt(rho1);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                if (r >= rows) break;
-                double Jr[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) Jr[i] = J[r][i] * sc;
-                const double rr = res[r] * sc;
-                int qd = 0;
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int j = i; j < 6; ++j) acc[qd++] += Jr[i] * Jr[j];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) acc[NE_G + i] += Jr[i] * rr;
-            }
-            acc[NE_COST] = 0.5 * rho0;
-            acc[NE_CNT] = 1.0;
+            track_eval(P, kind, c, fp, q, t, acc);
         }
     }
     reduce_acc32(acc, kind, s_red, P.partials + size_t(gtile) * NE_STRIDE);
@@ -445,6 +452,88 @@ __global__ __launch_bounds__(TPB) void track_linearize_kernel(TrackParamsDev P)
             }
         }
     }
+}
+
+// ---- trackCloud's Levenberg-Marquardt loop of one round in ONE launch (the mapper's lm_loop_kernel, match.hip, for the tracker's factors): every tile's workgroup
+// keeps its correspondences and features in registers, evaluates at the round's pose, and then -- records through agent-scope stores / loads around a counter
+// barrier, the 6 x 6 arithmetic redundantly in every workgroup, the state in LDS -- runs begin, evaluate at the candidate, step, ... until the loop ends where Ceres'
+// would (<= 4 iterations, lidar_tracker.cpp:106-113; fewer than 10 correspondences: the round is skipped, :66-70). Same operations as the launches it replaces
+// (track_linearize_kernel's begin / step finishes): the same pose bits. Two launches per round instead of 2 + max_lm_iterations.
+__global__ __launch_bounds__(TPB) void track_lm_loop_kernel(TrackParamsDev P)
+{
+    __shared__ double s_red[4 * 32];
+    __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];
+    __shared__ double s_cand[8];
+    __shared__ int s_done, s_timeout;
+    __shared__ LmState s_lm;
+    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    const int gtile = blockIdx.x;
+    if (gtile >= total) return;
+    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
+    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const TrackKind &K = P.k[kind];
+    const int f = tile * TPB + threadIdx.x;
+    Corr c;
+    c.valid = 0;
+    float4 fp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < K.m) { c = K.corr[f]; fp = K.cur[f]; }
+    const bool valid = f < K.m && c.valid != 0;
+    const size_t set = size_t(NE_STRIDE) * size_t(total);
+    if (threadIdx.x == 0) s_timeout = 0;
+    // the round's pose: the records of the begin are taken there
+    if (threadIdx.x < 7) s_cand[threadIdx.x] = P.use_init ? P.init_pose[threadIdx.x] : P.state->x[threadIdx.x];
+    __syncthreads();
+    int nth = 0;                                                   // barriers passed
+    bool begun = false;
+    while (true) {
+        const q4 q{s_cand[3], s_cand[4], s_cand[5], s_cand[6]};
+        const d3 t{s_cand[0], s_cand[1], s_cand[2]};
+        double acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+        if (valid) track_eval(P, kind, c, fp, q, t, acc);
+        double *rec = P.partials + set * size_t(nth & 1);
+        reduce_acc32<true>(acc, kind, s_red, rec + size_t(gtile) * NE_STRIDE);
+        if (threadIdx.x == 0 && !loop_barrier_arrive(P.ticket, total, nth + 1)) s_timeout = 1;
+        __syncthreads();
+        ++nth;
+        if (s_timeout) break;
+        lmc_sum_records<true>(rec, total, f_ne, f_scratch);
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            LmRegs R;
+            double cand[7];
+            if (!begun) {
+                double x[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) x[i] = s_cand[i];
+                lm_begin_wave_pp(f_ne, f_scratch, x, &s_lm, true, -1.0, P.lm_max_it, P.lm_min_blocks, R, cand);
+            } else {
+                lm_step_wave_pp(f_ne, &s_lm, &s_lm, true, P.lm_max_it, R, cand);
+            }
+            __builtin_amdgcn_wave_barrier();                       // (x was read from s_cand by every lane before any lane overwrites it)
+            if (lane < 7) s_cand[lane] = pick7(cand, lane);
+            if (lane == 0) s_done = R.done;
+        }
+        begun = true;
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (gtile == 0 && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const bool have = nth > 0 && !s_timeout;                   // (a barrier given up on before the begin: the state's pose stays what it was)
+        if (lane < 7 && (have || P.use_init)) P.state->x[lane] = have ? s_lm.x[lane] : P.init_pose[lane];
+        if (lane == 0) {
+            P.state->done = have ? s_lm.done : 1;
+            P.state->iteration = have ? s_lm.iteration : 0;
+            if (P.publish) {
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = have ? s_lm.x[i] : (P.use_init ? P.init_pose[i] : P.state->x[i]);
+                P.publish->done = 1 | (s_timeout ? 4 : 0);
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (threadIdx.x == 0) loop_barrier_leave(P.ticket, total);
 }
 
 // ring ids + ring_start table of a previous-frame cloud; flags non-monotone / out-of-range ring ids
@@ -504,7 +593,7 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     }
     if (!tiles_b) return fail(ctx, MLH_ERR_STATE, "no tracker features staged");
     hipError_t e;
-    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b))) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);
+    if ((e = ctx->partials.ensure(sizeof(double) * NE_STRIDE * size_t(tiles_b) * 2)) != hipSuccess) return fail(ctx, MLH_ERR_HIP, "alloc partials", e);      // (two sets: the loop kernel alternates)
     ctx->n_partial_tiles = tiles_b;
     P.state = ctx->state.as<SolverState>(); P.partials = ctx->partials.as<double>();
     P.pose_sel = a.pose_sel; P.use_init = a.init_pose ? 1 : 0;
@@ -525,6 +614,17 @@ int track_match_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
     int rc = fill_track_params(ctx, kind_mask, a, P);
     if (rc) return rc;
     MLH_LAUNCH(track_match_kernel, dim3(P.k[0].tiles_a + P.k[1].tiles_a), dim3(TPB), 0, ctx->stream, P);
+    MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int track_lm_loop_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
+{
+    TrackParamsDev P;
+    int rc = fill_track_params(ctx, kind_mask, a, P);
+    if (rc) return rc;
+    if (P.k[0].tiles_b + P.k[1].tiles_b > 256) return fail(ctx, MLH_ERR_INVALID, "track_lm_loop_kernel: more tiles than compute units");
+    MLH_LAUNCH(track_lm_loop_kernel, dim3(P.k[0].tiles_b + P.k[1].tiles_b), dim3(TPB), 0, ctx->stream, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
 }

@@ -1454,6 +1454,35 @@ def test_scan2map_loop_kernel_on_a_context_the_tracker_used_first(mla, case16, f
         c.close()
 
 
+def test_track_cloud_lm_loop_in_one_launch_equals_the_launches(mla, track_case, monkeypatch):
+    """LidarTracker::trackCloud without statistics: a round's LM loop as ONE launch (track_lm_loop_kernel, the default) against 2 + max_lm_iterations launches per
+    round (MLH_TRACK_LOOP=0) and against the launches that fill the statistics -- the same pose bits over start poses, round counts, iteration caps, with and without
+    the Huber loss, and with too few correspondences for a round to run (distance threshold ~0: every round skipped, the pose comes back as it went in)."""
+    tc = track_case
+    rng = np.random.default_rng(9)
+    c = mla.Context(0)
+    try:
+        c.track_set_prev(mla.CORNER, tc["corner_last"]); c.track_set_prev(mla.SURF, tc["surf_last"])
+        c.track_set_cur(mla.CORNER, tc["corner_sharp"]); c.track_set_cur(mla.SURF, tc["surf_flat"])
+        starts = [np.array([0, 0, 0, 0, 0, 0, 1.0])]
+        for _ in range(3):
+            p = np.array([*rng.normal(0, 0.15, 3), *rng.normal(0, 0.01, 3), 1.0]); p[3:] /= np.linalg.norm(p[3:])
+            starts.append(p)
+        variants = [dict(), dict(max_outer=1), dict(max_outer=3), dict(max_lm_iterations=1), dict(max_lm_iterations=2), dict(max_lm_iterations=6), dict(huber_delta=0.0),
+                    dict(distance_sq_threshold=1e-6)]
+        for p0 in starts:
+            for kw in variants:
+                opts = mla.default_track_opts(**kw)
+                monkeypatch.delenv("MLH_TRACK_LOOP", raising=False)
+                full, _ = c.track_cloud(p0, opts)
+                loop, _ = c.track_cloud(p0, opts, want_stats=False)
+                monkeypatch.setenv("MLH_TRACK_LOOP", "0")
+                launches, _ = c.track_cloud(p0, opts, want_stats=False)
+                assert np.array_equal(loop, launches) and np.array_equal(loop, full), (kw, p0)
+    finally:
+        c.close()
+
+
 def test_scan2map_without_stats_matches(ctx, mla, case16, feats16):
     """mlh_scan2map(stats = NULL) takes the Cholesky shortcut for evalDegenracy; the pose must be the one the full procedure gives."""
     _stage(ctx, mla, case16, feats16)
