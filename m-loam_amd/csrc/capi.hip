@@ -1633,6 +1633,8 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     HostPublish last_hp;
     bool have_hp = false;  // fused path: the last chunk's publication already carries the pose
     int lm_chunk_idx = 0;  // which of the two pinned publication records the next chunk writes
+    HostPublish *gf_loop_rec = nullptr;      // a good-feature frame whose LM loops ran as one launch each: the record its last launch publishes into
+    unsigned long long gf_loop_seq = 0;
     std::mt19937 rng((uint32_t)opts->gf_seed);
     for (int outer = 0; outer < opts->max_outer; ++outer) {
         if (fused) {
@@ -1660,7 +1662,21 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             }
             MatchArgs a = args_from_opts(opts, 3, 0);
             if (fused_lm) { a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0; }
+            // the selected rows' LM loop as one launch (as the wo_gf frame's, above): the linearisation of the selection only leaves its records
+            const bool loop_gf = fused_lm && !stats && !distributed(ctx) && lm_consumer_enabled(ctx) && lm_loop_enabled();
+            if (loop_gf) a.finish = 0;
             if ((rc = linearize_launch(ctx, a))) return rc;
+            if (loop_gf) {
+                MatchArgs b = args_from_opts(opts, 3, 1);
+                b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0;
+                b.lm_expect_done = outer == 0 ? -1 : 1;
+                if (outer == opts->max_outer - 1) {         // the last loop launch publishes pose (and a barrier given up on, if any)
+                    if ((rc = publish_slot(ctx, &gf_loop_rec, &gf_loop_seq, 0))) return rc;
+                    b.publish = gf_loop_rec; b.publish_seq = gf_loop_seq;
+                }
+                if ((rc = lm_consume_launch(ctx, b))) return rc;
+                continue;                                   // (the pose stays on the device: the next outer iteration's selection starts from it)
+            }
         }
         if (!fused_lm && (rc = lm_begin_launch(ctx, opts->map_eig_thre, opts->max_lm_iterations, stats ? outer : -1))) return rc;
         if (fused_lm) {
@@ -1714,6 +1730,14 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             }
         }
         if (stats && (rc = lm_finish_launch(ctx, outer))) return rc;     // fills the record's LM summary
+    }
+    if (gf_loop_rec) {
+        HostPublish hp;
+        if ((rc = wait_published(ctx, gf_loop_seq, hp, gf_loop_rec))) return rc;
+        if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
+        if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+        for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+        return MLH_OK;
     }
     if (fused_lm && !stats && have_hp) {
         if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }

@@ -1414,6 +1414,18 @@ def test_scan2map_lm_forms_over_loop_lengths_and_degenerate_frames(mla, case16, 
         _stage(c, mla, case16, feats16)
         variants = [dict(max_lm_iterations=k) for k in (1, 2, 3, 4)] + [dict(max_outer=1), dict(max_outer=3), dict(huber_delta=0.0), dict(map_eig_thre=1e9),
                                                                          dict(map_eig_thre=3.0e4, max_outer=3)]
+        # ... and behind a good-feature selection (the selected rows' loop: one launch per outer iteration; the split submission does not take selections)
+        G = mla.GF_METHODS
+        gf_variants = [dict(gf_method=G[m_], gf_ratio=0.3, gf_seed=5) for m_ in ("rnd", "fps", "gd_fix")] + [dict(gf_method=G["gd_float"], gf_ratio=0.3, gf_seed=7, max_outer=3)]
+        for kw in gf_variants:
+            opts = mla.default_opts(**kw)
+            monkeypatch.delenv("MLH_LM_CONSUMER", raising=False)
+            monkeypatch.delenv("MLH_LM_LOOP", raising=False)
+            ref, st = c.scan2map(p0, opts)
+            for mode in ("11", "10", "00"):
+                monkeypatch.setenv("MLH_LM_CONSUMER", mode[0])
+                monkeypatch.setenv("MLH_LM_LOOP", mode[1])
+                assert np.array_equal(c.scan2map(p0, opts, want_stats=False)[0], ref), (kw, mode)
         n_deg = 0
         for kw in variants:
             opts = mla.default_opts(**kw)
