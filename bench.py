@@ -936,6 +936,27 @@ def main():
                 fctx.map_set_pair_overlapped(d_surf_map, d_corner_map)
                 fctx.downsample_current_scan_pair(fctx.fused_cloud(mla.SURF), fctx.fused_cloud(mla.CORNER), 0.4, 0.2, f_ext, f_covs, f_meas, True, 0.6)
                 return fctx.scan2map(p0, f_opts, want_stats=False)[0]
+            # ... and with thinning + solve as one call that reads nothing back in between (mlh_downsample_scan2map: the thinned counts stay on the device)
+            def frame_once_fused_call():
+                fctx.fuse_reset()
+                fctx.scan_upload(d_pts, d_start, d_end); fctx.extract_run(); fctx.extract_voxel_run(0.2)
+                for i_ in range(len(scans)):
+                    fctx.fuse_add_rings(ring_ofs[i_], ring_ofs[i_ + 1], i_, f_ext[i_])
+                fctx.map_set_pair_overlapped(d_surf_map, d_corner_map)
+                return fctx.downsample_scan2map(fctx.fused_cloud(mla.SURF), fctx.fused_cloud(mla.CORNER), 0.4, 0.2, f_ext, f_covs, f_meas, p0, f_opts)
+            frame_fused_ms, frame_fused_same = None, None
+            try:
+                for _ in range(5):
+                    frame_once_fused_call()
+                sync_all()
+                c0 = time.perf_counter()
+                for _ in range(n_fr):
+                    pose_fused, cnt_fused = frame_once_fused_call()
+                frame_fused_ms = 1e3 * (time.perf_counter() - c0) / n_fr
+                frame_fused_same = bool(np.array_equal(pose_fused, frame_pose)) and tuple(cnt_fused) == tuple(int(x) for x in frame_counts)
+            except Exception as ex:      # (a supplementary leg must not cost the line)
+                frame_fused_ms = None
+                print(f"[rank {rank}] frame, thinning + solve in one call: {str(ex)[:200]}", file=sys.stderr)
             frame_beside_ms, frame_beside_same = None, None
             try:
                 for _ in range(5):
@@ -954,13 +975,16 @@ def main():
             for _ in range(n_fr):
                 frame_once(st_t)
             frame = dict(ms_per_frame=round(frame_ms, 4), ms_per_frame_map_staged_beside_the_front_end=(round(frame_beside_ms, 4) if frame_beside_ms else None),
-                         map_staged_beside_same_pose=frame_beside_same, stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
+                         map_staged_beside_same_pose=frame_beside_same,
+                         ms_per_frame_map_beside_and_thinning_plus_solve_in_one_call=(round(frame_fused_ms, 4) if frame_fused_ms else None),
+                         one_call_same_pose_and_counts=frame_fused_same, stages_ms_each_followed_by_a_wait={k_: round(1e3 * v_ / n_fr, 4) for k_, v_ in st_t.items()},
                          scan_points=int(len(all_pts)), thinned_features=dict(surf=int(frame_counts[0]), corner=int(frame_counts[1])), pose=[round(float(x), 9) for x in frame_pose],
                          host_reads_between_scan_and_pose=2,
                          note="supplementary: the two raw scans resident in HBM -> extractCloud + per-ring voxel thinning + fusion -> downsampleCurrentScan (both kinds, one "
                               "pipeline) -> index build of both maps -> scan2MapOptimization -> pose; frames one after the other, host waits for every pose. Two host reads "
                               "inside the frame, each a spin on a pinned record a kernel publishes: the fused clouds' counts and bounds (they size the thinning's launches and "
-                              "its voxel grids), and the thinned feature counts (they size the solve's launches)")
+                              "its voxel grids), and the thinned feature counts (they size the solve's launches). The `..._in_one_call` figure uses mlh_downsample_scan2map, where the "
+                              "second of the two is gone (the solve reads the counts on the device)")
         finally:
             fctx.close()
 

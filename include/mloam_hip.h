@@ -525,6 +525,15 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
 int mlh_scan2map_begin(mlh_ctx *ctx, const double pose_in[7], const mlh_solver_opts *opts, int lm_lookahead);
 int mlh_scan2map_begin_chained(mlh_ctx *ctx, const double wodom_prev[7], const double wodom_cur[7], const mlh_solver_opts *opts, int lm_lookahead);
 int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out);
+/* downsampleCurrentScan (both kinds) and scan2MapOptimization back to back WITHOUT the host reading what the thinning kept (lidar_mapper_keyframe.cpp:356-421 ->
+ * :423-639, as process() calls them one after the other, cpp:1000-1112): the solve's launches are sized for an upper bound (the input clouds) and take the feature
+ * counts from device memory; the counts come back with the pose. Same results as mlh_downsample_current_scan_pair followed by mlh_scan2map(stats = NULL), bit for
+ * bit -- and exactly those two calls wherever the fused form does not apply (clouds that are not the context's fused clouds, a good-feature selection, several
+ * ranks, a local map below scan2MapOptimization's minimum, more than 131 072 input points). pose_inout is written on success only. */
+int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                            int intensity_offset_bytes, int mem, float leaf_surf, float leaf_corner, const double *ext_poses, const double *ext_covs,
+                            int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold, double pose_inout[7],
+                            const mlh_solver_opts *opts, int32_t *n_surf_features, int32_t *n_corner_features);
 
 /* ---------------------------------------------------------------- (f4) scan-to-scan odometry: LidarTracker::trackCloud
  * replaces lidar_tracker.cpp:23-129 and the functions it drives: matchCornerFromScan / matchSurfFromScan

@@ -109,6 +109,7 @@ def load_library():
     lib.mlh_track_set_cur.argtypes = [vp, ci, vp, ci, ci, ci, ci]
     lib.mlh_track_set_from_scan.argtypes = [vp, ci, cf]
     lib.mlh_downsample_current_scan_pair.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, cf, cf, vp, vp, ci, vp, ci, C.c_double, vp, vp]
+    lib.mlh_downsample_scan2map.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, cf, cf, vp, vp, ci, vp, ci, C.c_double, vp, vp, vp, vp]
     lib.mlh_voxel_grid.argtypes = [vp, vp, ci, ci, ci, cf, vp, vp, ci]
     lib.mlh_transform_point_cloud.argtypes = [vp, vp, ci, ci, vp, ci]
     lib.mlh_transform_to_end.argtypes = [vp, vp, ci, ci, ci, vp, ci, cf, ci]
@@ -174,7 +175,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_downsample_scan2map", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_debug_bad_launch", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map", "mlh_scan2map_begin", "mlh_scan2map_begin_chained", "mlh_scan2map_end",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
@@ -522,6 +523,23 @@ class Context:
         self._m = getattr(self, "_m", {})
         self._m[SURF], self._m[CORNER] = a.value, b.value
         return a.value, b.value
+
+    def downsample_scan2map(self, surf4, corner4, leaf_surf, leaf_corner, ext_poses, ext_covs, cov_measurement, pose, opts=None, with_ua=True, trace_threshold=0.6):
+        """downsampleCurrentScan (both kinds) + scan2MapOptimization with no host read between them (mlh_downsample_scan2map) -> (pose, (n_surf_features, n_corner_features))."""
+        opts = opts or default_opts()
+        ps, ss, ns, ms, ks = _src(surf4)
+        pc, sc, nc, mc, kc = _src(corner4)
+        assert ss == sc and ms == mc
+        ep = np.ascontiguousarray(ext_poses, np.float64).reshape(-1, 7)
+        ec = np.ascontiguousarray(ext_covs, np.float64).reshape(-1, 36)
+        cm = np.ascontiguousarray(cov_measurement, np.float64).reshape(9)
+        x = np.ascontiguousarray(pose, np.float64).copy()
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.mlh_downsample_scan2map(self.h, ps, ns, pc, nc, ss, 12, ms, float(leaf_surf), float(leaf_corner), _p(ep), _p(ec), len(ep), _p(cm),
+                                                  int(bool(with_ua)), float(trace_threshold), _p(x), C.byref(opts), C.byref(a), C.byref(b)))
+        self._m = getattr(self, "_m", {})
+        self._m[SURF], self._m[CORNER] = a.value, b.value
+        return x, (a.value, b.value)
 
     def cloud_uct_associate_to_map(self, points11, pose_global, cov_global, ext, ext_cov, cov_meas, with_ua, trace_threshold):
         """cloudUCTAssociateToMap on (n, 11) records [x y z i cov6 trace] -> kept, transformed records in input order."""

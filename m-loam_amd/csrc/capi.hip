@@ -1928,6 +1928,92 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
     return MLH_OK;
 }
 
+// downsampleCurrentScan + scan2MapOptimization with no host read between them (include/mloam_hip.h)
+int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
+                            int intensity_offset_bytes, int mem, float leaf_surf, float leaf_corner, const double *ext_poses, const double *ext_covs,
+                            int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold, double pose_inout[7],
+                            const mlh_solver_opts *opts, int32_t *n_surf_features, int32_t *n_corner_features)
+{
+    if (!ctx || !pose_inout || !opts || !n_surf_features || !n_corner_features || opts->max_outer <= 0) return MLH_ERR_INVALID;
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    auto two_calls = [&]() -> int {
+        int rc = mlh_downsample_current_scan_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, intensity_offset_bytes, mem, leaf_surf, leaf_corner,
+                                                  ext_poses, ext_covs, n_lidar, cov_measurement, with_ua, trace_threshold, n_surf_features, n_corner_features);
+        if (rc) return rc;
+        return mlh_scan2map(ctx, pose_inout, opts, nullptr);
+    };
+    const bool fused_pair = mem == MLH_MEM_DEVICE && !ctx->fused_dirty && stride_bytes == 16 && intensity_offset_bytes == 12 && n_surf > 0 && n_corner > 0 &&
+                            surf_points == ctx->fused[MLH_SURF].p && n_surf == ctx->fused_n[MLH_SURF] &&
+                            corner_points == ctx->fused[MLH_CORNER].p && n_corner == ctx->fused_n[MLH_CORNER];
+    const bool have_maps = ctx->map[MLH_SURF].built && ctx->map[MLH_CORNER].built && ctx->map[MLH_SURF].n > 50 && ctx->map[MLH_CORNER].n > 10;
+    // the loop kernel's barrier wants every tile's workgroup resident: the BOUND's tiles, since the real count is not known here
+    const int bound_tiles = (n_surf + 255) / 256 + (n_corner + 255) / 256;
+    static const bool off = std::getenv("MLH_FUSED_THIN_SOLVE") && std::atoi(std::getenv("MLH_FUSED_THIN_SOLVE")) == 0;      // (A/B: always the two calls)
+    if (off || !fused_pair || !have_maps || distributed(ctx) || ctx->comm || opts->gf_method != MLH_GF_WO || bound_tiles > 512 || !lm_loop_enabled() ||
+        ctx->solve_seq != ctx->solve_collected || ctx->vox_member_order != 1)
+        return two_calls();
+    { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
+    int rc = ensure_state(ctx, 0);
+    if (rc) return rc;
+    ++ctx->stage_epoch;
+    for (int k = 0; k < 2; ++k) { ctx->feat[k].matched = false; ctx->feat[k].m = 0; }
+    int m[2] = {0, 0};
+    rc = downsample_current_scan_pair_run(ctx, surf_points, n_surf, ctx->fused_minmax[MLH_SURF], leaf_surf, corner_points, n_corner, ctx->fused_minmax[MLH_CORNER],
+                                          leaf_corner, stride_bytes, intensity_offset_bytes, ext_poses, ext_covs, n_lidar, cov_measurement, with_ua, trace_threshold,
+                                          &m[0], &m[1], true);
+    if (rc == MLH_ERR_UNSUPPORTED) return two_calls();
+    if (rc) return rc;
+    auto stage_counts = [&](const int cnt[2]) {
+        for (int k = 0; k < 2; ++k) {
+            FeatSet &f = ctx->feat[k];
+            f.m = cnt[k]; f.n_blocks = 1; f.blk_start[0] = 0; f.blk_real[0] = cnt[k];
+            for (int b = 1; b <= 8; ++b) f.blk_start[b] = cnt[k];
+            f.has_cov = true;
+        }
+    };
+    if (m[0] >= 0) {                       // the thinning took a pipeline that waits for its counts anyway: the solve as usual
+        stage_counts(m);
+        *n_surf_features = m[0]; *n_corner_features = m[1];
+        return mlh_scan2map(ctx, pose_inout, opts, nullptr);
+    }
+    const int bound[2] = {n_surf, n_corner};
+    stage_counts(bound);                   // upper bounds: the launches' grids and the buffers; the kernels read the real counts
+    HostPublish *rec = nullptr;
+    unsigned long long seq = 0;
+    if ((rc = publish_slot(ctx, &rec, &seq, 0))) return rc;
+    for (int outer = 0; outer < opts->max_outer && !rc; ++outer) {
+        MatchArgs a = args_from_opts(opts, 3, 0);
+        a.finish = 0; a.lm_max_it = opts->max_lm_iterations; a.m_dev = ctx->thin_counts_dev;
+        if (outer == 0) a.init_pose = pose_inout;
+        a.warm = outer >= 1 && s2m_warm_applies(ctx);
+        if ((rc = match_launch(ctx, a))) break;
+        MatchArgs b = args_from_opts(opts, 3, 1);
+        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0; b.m_dev = ctx->thin_counts_dev;
+        b.lm_expect_done = outer == 0 ? -1 : 1;
+        if (outer == 0) b.init_pose = pose_inout;
+        if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
+        rc = lm_consume_launch(ctx, b);
+    }
+    HostPublish hp;
+    if (!rc) rc = wait_published(ctx, seq, hp, rec);
+    // the counts were published by the thinning's last launch, long before the pose: no wait here in practice
+    int real[2] = {0, 0};
+    if (!rc) {
+        if (__atomic_load_n(ctx->thin_seq_host, __ATOMIC_ACQUIRE) != ctx->thin_seq) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+        if (__atomic_load_n(ctx->thin_seq_host, __ATOMIC_ACQUIRE) != ctx->thin_seq) rc = fail(ctx, MLH_ERR_HIP, "the thinned feature counts did not arrive");
+        else { real[0] = ctx->thin_counts_host[0]; real[1] = ctx->thin_counts_host[1]; }
+    }
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); for (int k = 0; k < 2; ++k) { ctx->feat[k].m = 0; ctx->feat[k].matched = false; } return rc; }
+    stage_counts(real);
+    *n_surf_features = real[0]; *n_corner_features = real[1];
+    if ((rc = device_error_check(ctx))) return rc;
+    if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_downsample_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
+    if (real[0] <= 0 || real[1] <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");      // (what mlh_scan2map says of an empty kind)
+    if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
+    for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
+    return MLH_OK;
+}
+
 // ---------------------------------------------------------------- scan-to-scan odometry (LidarTracker)
 void mlh_track_opts_default(mlh_track_opts *o)
 {

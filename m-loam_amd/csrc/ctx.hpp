@@ -329,6 +329,12 @@ struct mlh_ctx {
     unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
     unsigned long long sync_seq = 0;
     unsigned long long counts_seq = 0;      // publications of the thinned feature counts straight from a kernel (voxel.hip)
+    // downsample_current_scan_pair_run(.., defer = true): the thinning was enqueued and NOT waited for -- where its two counts will be (device; pinned host + the
+    // sequence number their publication carries)
+    const int *thin_counts_dev = nullptr;
+    const int *thin_counts_host = nullptr;
+    const unsigned long long *thin_seq_host = nullptr;
+    unsigned long long thin_seq = 0;
     void *h_scratch = nullptr;  // 256 pinned bytes: the landing place of the few-int read-backs (record counts) that end a staging call
     void *fused_host = nullptr; // pinned record mlh_fused_cloud's publication launch fills: [2 counts (padded to 4 ints)][2 x 6 bounds][sequence word at byte 64]
     unsigned long long fused_seq = 0;
@@ -527,7 +533,7 @@ int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds
                       float leaf1, int stride, int intensity_off, int *first_voxels_word);
 int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,
                                      const float bounds_corner[6], float leaf_corner, int stride, int intensity_off, const double *ext_poses, const double *ext_covs,
-                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out);
+                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out, bool defer = false);
 // grid.hip
 int grid_build(mlh_ctx *ctx, int kind_mask, bool recompute_bounds);
 int grid_build_grids(mlh_ctx *ctx, mlh::MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob = nullptr, mlh::HostPublish *pub = nullptr,
@@ -574,6 +580,7 @@ struct MatchArgs {
     // (finish 0) -- sums them, runs the LM begin, evaluates at the first candidate; 2 = a later launch -- sums the records at the candidate, runs the LM step,
     // evaluates at the next candidate. lmc_j: the launch's number within its loop (1, 2, ...: record buffer (j - 1) & 1 is read, j & 1 written)
     int lmc = 0, lmc_j = 0;
+    const int *m_dev = nullptr;   // device: the two feature counts (surf, corner) when the host has not read them (mlh_downsample_scan2map); FeatSet::m then holds upper bounds
     HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
     unsigned long long publish_seq = 0;
 };

@@ -244,6 +244,9 @@ struct KParams {
     const double *partials_in;
     const LmState *lm_in;
     LmState *lm_out;
+    // feature counts read on the DEVICE (mlh_downsample_scan2map: the solve is enqueued behind the thinning without the host reading what the thinning kept): the
+    // launches are sized for an upper bound (KindP::m, tiles_*), the DEVM kernel variants take the counts -- and the tiles that follow from them -- from here
+    const int *m_dev;        // [2]: surf, corner
     int debug_stall;         // MLH_DEBUG_LOOP_STALL=1 (tests): one workgroup of lm_loop_kernel never arrives at its second barrier -- the loop must end with the error bit, not hang
 };
 
@@ -364,14 +367,14 @@ __device__ __forceinline__ void knn_feature_warm(const KParams &P, const KindP &
 // MB = more than one pose block in the launch (config 4); without it the block bookkeeping (a per-lane block index and the
 // per-block K lookup it drags along) compiles away
 template <int G, bool MB, bool K10, bool PRE, bool WARM>
-__device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run, const double *s_pose)
+__device__ __forceinline__ void knn_features_body(const KParams &P, const KindP &K, int tile, int *s_run, const double *s_pose, int m_feat)
 {
     constexpr int FPB = TPB / G;          // queries per workgroup
     constexpr int RUNW = 2 * KNN_RUN_WORDS;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int f = tile * FPB + grp;
     MLH_KSTAGE(0);
-    if (f >= K.m) return;
+    if (f >= m_feat) return;
     const float4 fp = K.feat[f];
     if (fp.w < 0.f) return;               // padding slot
     const int b = MB ? block_of_slot(K, P.n_blocks, f) : 0;
@@ -486,12 +489,22 @@ __device__ __forceinline__ void publish_final_pose(const KParams &P, const doubl
 //   pose to the host and stores it as the state's), then every workgroup computes this frame's chained start pose from it (chain_start_pose, one lane) -- the
 //   predecessor's serial finish and the chain launch between the two frames are gone.
 // WARM: the search is bounded by the previous iteration's neighbours (knn_feature_warm). All three only in the single-block, K = 5 launches of mlh_gn_solve*.
-template <int G, bool MB, bool K10, int PRE = 0, bool WARM = false>
+// DEVM: the feature counts come from P.m_dev (G = 0 only: lanes per kind); the grid was sized for a bound, the workgroups beyond the real tiles leave
+template <int G, bool MB, bool K10, int PRE = 0, bool WARM = false, bool DEVM = false>
 __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
 {
     __shared__ int s_run[(G == 16) ? (TPB / 16) * 2 * KNN_RUN_WORDS : (TPB / 8) * 2 * KNN_RUN_WORDS];
     __shared__ double s_pose[PRE ? 8 : 1];
-    const int total = P.k[0].tiles_a + P.k[1].tiles_a;
+    int m0 = P.k[0].m, m1 = P.k[1].m, ta0 = P.k[0].tiles_a;
+    int total = P.k[0].tiles_a + P.k[1].tiles_a;
+    if constexpr (DEVM) {
+        static_assert(G == 0 && !MB && PRE == 0, "device-side counts: per-kind lanes, one block, no prologue");
+        m0 = P.m_dev[0]; m1 = P.m_dev[1];
+        const int f0 = TPB / P.k[0].lanes, f1 = TPB / P.k[1].lanes;
+        ta0 = (m0 + f0 - 1) / f0;
+        total = ta0 + (m1 + f1 - 1) / f1;
+        if ((int(blockIdx.x) >> 3) >= ((total + 7) >> 3)) return;     // (xcd_tile is a bijection only on the first 8 * ceil(total / 8) workgroups)
+    }
     int tile = xcd_tile(total);
     if (tile >= total) return;
 #ifdef MLH_KNN_HEAVY_FIRST
@@ -529,15 +542,16 @@ __global__ __launch_bounds__(TPB) void knn_features_kernel(KParams P)
         }
         if (writer && threadIdx.x < 7) P.x_next[7 * pb + threadIdx.x] = s_pose[threadIdx.x];
     }
-    const int kind = tile >= P.k[0].tiles_a ? 1 : 0;
-    if (kind) tile -= P.k[0].tiles_a;
+    const int kind = tile >= ta0 ? 1 : 0;
+    if (kind) tile -= ta0;
     const KindP &K = P.k[kind];
+    const int m_feat = kind ? m1 : m0;
     if constexpr (G == 0) {
-        if (K.lanes == 8) knn_features_body<8, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
-        else if (K.lanes == 32) knn_features_body<32, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
-        else knn_features_body<16, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
+        if (K.lanes == 8) knn_features_body<8, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose, m_feat);
+        else if (K.lanes == 32) knn_features_body<32, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose, m_feat);
+        else knn_features_body<16, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose, m_feat);
     } else {
-        knn_features_body<G, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose);
+        knn_features_body<G, MB, K10, PRE != 0, WARM>(P, K, tile, s_run, s_pose, m_feat);
     }
 }
 
@@ -762,16 +776,24 @@ __device__ __forceinline__ bool fit_feature(const KParams &P, int kind, const fl
 // the kernel's register footprint (occupancy matters once a launch has more workgroups than the chip holds at once)
 // FIN = false: the launch only leaves its tiles' partial records (a deferred-finish Gauss-Newton iteration, or a caller that reduces elsewhere): no ticket, no
 // finishing workgroup, and none of that code in the kernel
-template <int KMAX, bool LM, bool FIN = true>
+template <int KMAX, bool LM, bool FIN = true, bool DEVM = false>
 __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
-    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    int m0 = P.k[0].m, m1 = P.k[1].m, tb0 = P.k[0].tiles_b;
+    int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    if constexpr (DEVM) {            // (the counts from the device, knn_features_kernel<.., DEVM>)
+        m0 = P.m_dev[0]; m1 = P.m_dev[1];
+        tb0 = (m0 + TPB - 1) / TPB;
+        total = tb0 + (m1 + TPB - 1) / TPB;
+        if ((int(blockIdx.x) >> 3) >= ((total + 7) >> 3)) return;
+    }
     const int gtile = xcd_tile(total);
     if (gtile >= total) return;
-    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
-    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const int kind = gtile >= tb0 ? 1 : 0;
+    const int tile = kind ? gtile - tb0 : gtile;
     const KindP &K = P.k[kind];
+    const int m_feat = kind ? m1 : m0;
     MLH_STAGE(gtile, 0);
     const int f = tile * TPB + threadIdx.x;
     const int b = block_of_slot(K, P.n_blocks, tile * TPB);       // uniform over the workgroup (blocks start on tile boundaries)
@@ -785,7 +807,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
     for (int i = 0; i < 6; ++i) L.J[i] = 0.0;
     float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4 fp = make_float4(0.f, 0.f, 0.f, -1.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < K.m) {
+    if (f < m_feat) {
         // ONE memory round trip before the fit: the feature and all of its neighbour records are requested together (the records sit at
         // f * stride whatever the feature turns out to be; what is fetched for a padding slot or a feature another rank owns is discarded).
         // The map-frame position is only needed by the ownership planes of a sharded map and by the field-of-view gate: an ordinary
@@ -821,7 +843,7 @@ __global__ __launch_bounds__(TPB) void fit_linearize_kernel(KParams P)
         if (kind == MLH_SURF) eval_plane(p, coef, w, q, t, R, L);
         else eval_edge(p, coef, w, q, t, R, L);
     }
-    if (K.r_out && f < K.m) {
+    if (K.r_out && f < m_feat) {
         K.r_out[f] = L.r;
 #pragma unroll
         for (int i = 0; i < 6; ++i) K.J_out[size_t(f) * 6 + i] = L.J[i];
@@ -1054,6 +1076,7 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_SPIN_LIMIT
 #define MLH_LOOP_SPIN_LIMIT 4000000u
 #endif
+template <bool DEVM = false>
 __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
 {
     __shared__ double s_red[4 * 32];
@@ -1064,23 +1087,31 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
     __shared__ double s_gmax;
 #endif
     __shared__ LmState s_lm;
-    const int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    int m0 = P.k[0].m, m1 = P.k[1].m, tb0 = P.k[0].tiles_b;
+    int total = P.k[0].tiles_b + P.k[1].tiles_b;
+    if constexpr (DEVM) {            // (the counts from the device: the tiles that exist are the barrier's participants)
+        m0 = P.m_dev[0]; m1 = P.m_dev[1];
+        tb0 = (m0 + TPB - 1) / TPB;
+        total = tb0 + (m1 + TPB - 1) / TPB;
+        if ((int(blockIdx.x) >> 3) >= ((total + 7) >> 3)) return;
+    }
     const int gtile = xcd_tile(total);
     if (gtile >= total) return;            // (the grid is rounded up to a multiple of 8: the padding workgroups take no part in the barrier)
     const bool writer = gtile == 0;
-    const int kind = gtile >= P.k[0].tiles_b ? 1 : 0;
-    const int tile = kind ? gtile - P.k[0].tiles_b : gtile;
+    const int kind = gtile >= tb0 ? 1 : 0;
+    const int tile = kind ? gtile - tb0 : gtile;
     const KindP &K = P.k[kind];
+    const int m_feat = kind ? m1 : m0;
     const int f = tile * TPB + threadIdx.x;
     Corr c;
     c.valid = 0;
     float4 fp = make_float4(0.f, 0.f, 0.f, 0.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < K.m) {
+    if (f < m_feat) {
         c = K.corr[f];
         fp = K.feat[f];
         if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
     }
-    const bool valid = f < K.m && c.valid != 0;
+    const bool valid = f < m_feat && c.valid != 0;
     const int mult = valid ? c.valid : 1;
     const double w = feature_weight_pref(P, K, cdv);
     const d3 p{double(fp.x), double(fp.y), double(fp.z)};
@@ -1390,6 +1421,7 @@ static int fill_params(mlh_ctx *ctx, const MatchArgs &a, KParams &P)
         P.pre_freeze = a.pre_final_freeze;
         for (int i = 0; i < 7; ++i) { P.chain_prev[i] = a.chain_prev[i]; P.chain_cur[i] = a.chain_cur[i]; }
     }
+    P.m_dev = a.m_dev;
     P.publish = (a.finish == 1 || a.finish == 4 || a.lmc) ? a.publish : nullptr;
     if (a.lmc) {
         if (!ctx->lm_pp.p) {
@@ -1453,6 +1485,16 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
     const bool mb = P.n_blocks > 1;
     bool k10 = false;
     for (int b = 0; b < P.n_blocks; ++b) k10 = k10 || P.kb[b] == 10;
+    if (P.m_dev) {
+        // the feature counts are on the device only (mlh_downsample_scan2map): per-kind lanes, both kinds, one block, K = 5, records only
+        if (mb || k10 || P.finish != 0 || P.pre_finish || (a.kind_mask & 3) != 3) return fail(ctx, MLH_ERR_UNSUPPORTED, "device-side feature counts: one block, N_NEIGH 5, both kinds, records only");
+        if (P.warm) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false, false, 0, true, true>, grid_a, P);
+        else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false, false, 0, false, true>, grid_a, P);
+        launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false, false, true>, grid_b, P);
+        MLH_HIP(ctx, hipGetLastError());
+        for (int k = 0; k < 2; ++k) ctx->feat[k].matched = true;
+        return MLH_OK;
+    }
     {
         // <lanes, pose blocks, any block with K = 10>
 #define MLH_KNN_LAUNCH(G_) do { \
@@ -1527,8 +1569,9 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
     if (a.lmc == 3) {
         { const char *e = std::getenv("MLH_DEBUG_LOOP_STALL"); P.debug_stall = (e && std::atoi(e) != 0) ? 1 : 0; }
         // every tile's workgroup has to be resident for the barrier: 256-thread workgroups at <= 128 VGPRs, a few KB of LDS -- several per compute unit
-        if (P.k[0].tiles_b + P.k[1].tiles_b > 256) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than compute units");
-        launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel, grid_b, P);
+        if (P.k[0].tiles_b + P.k[1].tiles_b > (P.m_dev ? 512 : 256)) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than can be resident at once");
+        if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true>, grid_b, P);
+        else launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<false>, grid_b, P);
     }
     else if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
     else launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<false>, grid_b, P);

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(VSP_TPB) void vsp_features_kernel(VspArgs A)
 // the fused clouds). Same results as two downsample_current_scan_run calls.
 int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,
                                      const float bounds_corner[6], float leaf_corner, int stride, int intensity_off, const double *ext_poses, const double *ext_covs,
-                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out)
+                                     int n_lidar, const double cov_meas[9], int with_ua, double trace_thr, int *n_surf_out, int *n_corner_out, bool defer)
 {
     if (n_lidar <= 0 || n_lidar > 16 || !ext_poses || (with_ua && (!ext_covs || !cov_meas))) return fail(ctx, MLH_ERR_INVALID, "bad arguments");
     hipStream_t st = ctx->stream;
@@ -896,6 +896,12 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
             MLH_LAUNCH(vsp_aggregate_kernel, dim3(A.nch), dim3(VSP_TPB), 0, st, A);
             MLH_LAUNCH(vsp_features_kernel, dim3(A.nch), dim3(VSP_TPB), 0, st, A);
             MLH_HIP(ctx, hipGetLastError());
+            if (defer && A.host_seq) {
+                // the caller enqueues the solve behind this without knowing the counts (mlh_downsample_scan2map): they are read when the pose is
+                ctx->thin_counts_dev = A.counts; ctx->thin_counts_host = A.host_counts; ctx->thin_seq_host = A.host_seq; ctx->thin_seq = A.seq;
+                *n_surf_out = -1; *n_corner_out = -1;
+                return MLH_OK;
+            }
             if (A.host_seq) {
                 const auto t0 = std::chrono::steady_clock::now();
                 unsigned spins = 0;

@@ -1681,6 +1681,21 @@ def test_mapper_inputs_stay_on_device(mla, orc, synth, case16):
             b2 = c.match_linearize(mla.CORNER, case16["p0"], flags=mla.FLAG_WITH_UA)
             assert np.array_equal(a["valid"], a2["valid"]) and np.array_equal(b["valid"], b2["valid"])
             np.testing.assert_array_equal(a["H"], a2["H"]); np.testing.assert_array_equal(b["H"], b2["H"])
+        # thinning + solve as ONE call with no host read between them (mlh_downsample_scan2map: the solve's launches are sized for the input clouds and read the
+        # thinned counts on the device): the same counts, the same pose bits, the same staged features -- also with a different start pose, with three outer
+        # iterations, and where the fused form does not apply (host buffers: the two calls inside)
+        for start, o in ((case16["p0"], opts), (case16["p0"] + np.array([0.05, -0.03, 0.02, 0, 0, 0, 0]), opts), (case16["p0"], mla.default_opts(flags=mla.FLAG_WITH_UA, max_outer=3))):
+            c.downsample_current_scan_pair(c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER), 0.4, 0.2, ext, covs, meas, True, 0.6)
+            want = c.scan2map(start, o, want_stats=False)[0]
+            got, cnt = c.downsample_scan2map(c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER), 0.4, 0.2, ext, covs, meas, start, o)
+            assert list(cnt) == m_dev
+            np.testing.assert_array_equal(got, want)
+            a3 = c.match_linearize(mla.SURF, case16["p0"], flags=mla.FLAG_WITH_UA)        # the feature sets it left behind are the thinned ones, with their real counts
+            assert np.array_equal(a3["valid"], a2["valid"])
+            np.testing.assert_array_equal(a3["H"], a2["H"])
+        got, cnt = c.downsample_scan2map(ref[mla.SURF], ref[mla.CORNER], 0.4, 0.2, ext, covs, meas, case16["p0"], opts)
+        assert list(cnt) == m_dev
+        np.testing.assert_array_equal(got, pose_host)
         # a second frame reuses the buffers from the start
         c.fuse_reset()
         assert c.fused_cloud(mla.SURF).n == 0
