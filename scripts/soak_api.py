@@ -202,6 +202,20 @@ def j_frame(c, st, r, m):
     return [np.array(n), pose], how
 
 
+def j_frame_one_call(c, st, r, m):
+    """the same frame with thinning + solve as ONE call (mlh_downsample_scan2map: the thinned counts stay on the device until the pose comes back): it must leave the
+    counts, the pose and the staged feature sets of the two calls (the match that follows reads those sets)"""
+    how = ensure_map(c, st, m, r)
+    c.fuse_reset()
+    for i, s in enumerate((SCANS[-2], SCANS[-1]) if m == "L" else (SCANS[1], SCANS[2])):
+        c.scan_upload(s.points, s.scan_start, s.scan_end); c.extract_run(); c.extract_voxel_run(0.2)
+        c.fuse_add_scan(i, EXT[i])
+    pose, n = c.downsample_scan2map(c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER), 0.4, 0.2, EXT, COVS, MEAS, P0[m], mla.default_opts(flags=mla.FLAG_WITH_UA))
+    st.feat = None
+    ml = c.match_linearize(mla.SURF, P0[m], flags=mla.FLAG_WITH_UA)
+    return [np.array(n), pose, ml["valid"], ml["H"]], how
+
+
 WIN = [conftest.make_window_case(synth, O, 1, 2), conftest.make_window_case(synth, O, 2, 2, seed=4)]
 
 
@@ -288,6 +302,7 @@ for m in MAPS:
         for subset in ((0, 1, 2, 3), (1,), (0, 2)):
             JOBS.append((("blocks", m, subset), j_blocks, (m, subset)))
     JOBS.append((("frame", m), j_frame, (m,)))
+    JOBS.append((("frame_one_call", m), j_frame_one_call, (m,)))
 for i in range(2):
     for leaf in (0.2, 0.4):
         JOBS.append((("voxel_grid", i, leaf), j_voxel_grid, (i, leaf)))
