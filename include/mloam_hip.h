@@ -58,6 +58,27 @@ const char *mlh_version(void);
 /* the context's HIP stream (hipStream_t), for callers that interleave their own device work */
 void *mlh_stream(mlh_ctx *ctx);
 int mlh_synchronize(mlh_ctx *ctx);
+/* What mlh_create found on the device, and what the in-kernel Levenberg-Marquardt loops (the one-launch forms of scan2MapOptimization's ceres::Solve,
+ * lidar_mapper_keyframe.cpp:586-596, and of trackCloud's, lidar_tracker.cpp:106-113) did with it. Those launches synchronise their workgroups among themselves and
+ * therefore need all of them resident at once: loop_max_tiles is the number of 256-feature tiles the context will put behind one such barrier --
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor, at most 8, less one block per compute unit as a margin against the occupancy query's optimism) x the compute
+ * units the solver's stream may use, halved once a CU-masked staging stream runs beside it, never more than the 160 tiles beyond which every workgroup
+ * re-summing every record stops paying (the fused thinning + solve call: 512). A frame with more tiles, a partitioned or smaller device, a CU-masked solver
+ * stream (environment at mlh_create: MLH_SOLVER_CU_MASK=<hex word>[,<hex word>...], 32 compute units per word) take the launch-per-iteration forms: the same
+ * arithmetic, the same pose bits, no residency requirement. Should a barrier nevertheless not complete within MLH_LOOP_TIMEOUT_US (default 20 000), the frame is
+ * solved again through those forms (loop_fallbacks; the caller gets the same pose, later) and loop_max_tiles is halved for the context. MLH_LOOP_MAX_TILES=<n>
+ * lowers the limits by hand (0: never use the one-launch loops). */
+typedef struct mlh_device_info {
+    int32_t cu_count;                /* compute units of the device */
+    int32_t cu_solver;               /* ... the solver's stream may use */
+    int32_t loop_blocks_per_cu[3];   /* occupancy query: scan2map's loop kernel, its device-counted variant (mlh_downsample_scan2map), the tracker's */
+    int32_t loop_max_tiles[3];       /* the gates in force now, same order */
+    int32_t reserved;
+    uint64_t loop_launches;          /* frames / tracker calls that went through the one-launch loops */
+    uint64_t loop_timeouts;          /* ... whose barrier was given up on */
+    uint64_t loop_fallbacks;         /* ... and that were solved again by the launch-per-iteration form inside the same call */
+} mlh_device_info;
+int mlh_get_info(mlh_ctx *ctx, mlh_device_info *out);
 
 /* ---------------------------------------------------------------- per-kernel timing (HIP events on the context's stream)
  * Single-kernel ids (KNN, FIT, LINEARIZE) are timed with the dispatch's own start/stop timestamps (hipExtLaunchKernelGGL with
@@ -506,7 +527,8 @@ int mlh_gn_solve_blocks(mlh_ctx *ctx, double *poses_inout, int n_iters, const ml
 int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats);
 /* scan2MapOptimization submitted and collected separately (lidar_mapper_keyframe.cpp:423-639 as the mapper's per-frame call, :145-160 for the chained start pose):
  * mlh_scan2map_begin enqueues the whole solve and returns. lm_lookahead = 0 (automatic): per outer iteration the match launch and ONE launch that runs the
- * Levenberg-Marquardt loop to its end on the device -- status 0, always -- wherever that launch applies (one GPU, at most 160 fit tiles = 40 960 feature slots);
+ * Levenberg-Marquardt loop to its end on the device -- nothing to overflow -- wherever that launch applies (one GPU, at most mlh_get_info's loop_max_tiles fit
+ * tiles: 160 = 40 960 feature slots on a whole MI355X, fewer on a part of one);
  * otherwise, and with lm_lookahead > 0: per outer iteration the match launch and that many LM launches (automatic: the previous collected frame's longest LM loop + 2,
  * 10 before any; at most max_lm_iterations), launches behind the LM loop's termination find `done` on the device and leave. The caller stages the NEXT frame's maps
  * (mlh_map_set_pair_overlapped) and submits the next frame (mlh_scan2map_begin_chained: start pose = transformUpdate + transformAssociateToMap on the pose the
@@ -514,12 +536,13 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
  * mlh_gn_solve_begin / _end (each collected by its own _end). One GPU or the mailbox communicator; gf_method MLH_GF_WO (a selection runs host loops between launches).
  * status_out (nullable):
  *   0  the LM loops terminated inside the look-ahead: pose_out is bit for bit what mlh_scan2map returns on the same inputs;
- *   2  a loop needed more LM iterations than were enqueued; nothing had been restaged and no younger solve was chained behind, so the frame was solved again
- *      synchronously from its start pose inside this call: pose_out is mlh_scan2map's;
+ *   2  a loop needed more LM iterations than were enqueued -- or a one-launch loop gave its in-kernel barrier up (its workgroups were not all resident at once:
+ *      mlh_get_info counts it and lowers the context's gate); nothing had been restaged and no younger solve was chained behind, so the frame was solved again
+ *      synchronously from its start pose inside this call (after a barrier given up on: through the launch-per-iteration form): pose_out is mlh_scan2map's;
  *   1  the same, but the inputs of the frame are no longer staged (or a younger solve continues from this one's unfinished pose): pose_out is the frame's START
  *      pose; the caller solves the frame with mlh_scan2map on its inputs and resubmits what was chained behind it;
- *   3  this frame was chained behind a frame that ended with status 1 (or 3): it began from that frame's unfinished pose, so pose_out -- whatever its own loops
- *      did -- is not the mapper's; resubmit it after the predecessor has been solved.
+ *   3  this frame was chained behind a frame that ended with status 1 (or 3, or with an error): it began from that frame's unfinished pose, so pose_out -- whatever
+ *      its own loops did, finished or not -- is not the mapper's; resubmit it after the predecessor has been solved.
  * With status_out == NULL the statuses 1 and 3 are returned as MLH_ERR_INCOMPLETE (pose_out is still filled in): a pose that is not a result never comes back
  * under a success code the caller cannot tell apart. */
 int mlh_scan2map_begin(mlh_ctx *ctx, const double pose_in[7], const mlh_solver_opts *opts, int lm_lookahead);

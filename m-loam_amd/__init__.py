@@ -64,6 +64,17 @@ class IterStat(C.Structure):
                     g=np.array(self.g), pose_after=np.array(self.pose_after))
 
 
+class DeviceInfo(C.Structure):
+    """mlh_device_info (include/mloam_hip.h)."""
+    _fields_ = [("cu_count", C.c_int32), ("cu_solver", C.c_int32), ("loop_blocks_per_cu", C.c_int32 * 3), ("loop_max_tiles", C.c_int32 * 3),
+                ("reserved", C.c_int32), ("loop_launches", C.c_uint64), ("loop_timeouts", C.c_uint64), ("loop_fallbacks", C.c_uint64)]
+
+    def as_dict(self):
+        return dict(cu_count=self.cu_count, cu_solver=self.cu_solver, loop_blocks_per_cu=list(self.loop_blocks_per_cu),
+                    loop_max_tiles=list(self.loop_max_tiles), loop_launches=int(self.loop_launches), loop_timeouts=int(self.loop_timeouts),
+                    loop_fallbacks=int(self.loop_fallbacks))
+
+
 _lib = None
 
 
@@ -85,6 +96,7 @@ def load_library():
     lib.mlh_stream.argtypes = [vp]
     lib.mlh_stream.restype = vp
     lib.mlh_synchronize.argtypes = [vp]
+    lib.mlh_get_info.argtypes = [vp, C.POINTER(DeviceInfo)]
     lib.mlh_profile_enable.argtypes = [vp, ci]
     lib.mlh_comm_finalize.argtypes = [vp]
     lib.mlh_profile_sample.argtypes = [vp, ci]
@@ -171,7 +183,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize",
+    "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize", "mlh_get_info",
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
@@ -254,6 +266,12 @@ class Context:
 
     def synchronize(self):
         self._ck(self.lib.mlh_synchronize(self.h))
+
+    def info(self) -> dict:
+        """mlh_get_info: compute units, the in-kernel loops' residency gates and what became of them (launches / timeouts / fallbacks)."""
+        di = DeviceInfo()
+        self._ck(self.lib.mlh_get_info(self.h, C.byref(di)))
+        return di.as_dict()
 
     # ---- profiling
     def profile_enable(self, kernel_mask=K_ALL):

@@ -240,9 +240,7 @@ hipError_t stream_flag_wait(mlh_ctx *ctx, unsigned long long seq)
     unsigned spins = 0;
     while (__atomic_load_n(ctx->h_sync, __ATOMIC_ACQUIRE) < seq) {
         if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return hipStreamSynchronize(ctx->stream);
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
+        host_wait_relax(spins);
     }
     return hipSuccess;
 }
@@ -283,9 +281,7 @@ static int wait_published(mlh_ctx *ctx, unsigned long long seq, HostPublish &out
             if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "pose publication did not arrive");
             break;
         }
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
+        host_wait_relax(spins);
     }
     out = *h;
     // several ranks joined by the mailbox communicator: the launches behind this publication exchanged records with the peers inside their finish. A peer that
@@ -316,6 +312,83 @@ static void copy_stat(const IterStatDev &d, mlh_iter_stat &o)
     std::memcpy(o.pose_after, d.pose_after, sizeof(o.pose_after));
 }
 
+
+// ---------------------------------------------------------------- what the device admits (mlh_ctx::caps)
+// "hex[,hex...]" -> CU-mask words (32 compute units each), cut to the device's size; an empty vector = no mask
+static std::vector<uint32_t> parse_cu_mask(const char *text, int cu_count)
+{
+    const int n_words = (cu_count + 31) / 32;
+    std::vector<uint32_t> w(size_t(n_words), 0u);
+    const char *p = text;
+    bool any = false;
+    for (int i = 0; i < n_words && p && *p; ++i) {
+        char *rest = nullptr;
+        w[size_t(i)] = uint32_t(std::strtoul(p, &rest, 16));
+        any = any || rest != p;
+        p = (rest && *rest == ',') ? rest + 1 : nullptr;
+    }
+    if (!any) return {};
+    if (cu_count % 32) w.back() &= (1u << (cu_count % 32)) - 1u;      // (no bits beyond the device's last compute unit)
+    return w;
+}
+
+// The first half of the device's compute units as mask words: the default of the staging stream (mlh_map_set_pair_overlapped)
+static std::vector<uint32_t> lower_half_cu_mask(int cu_count)
+{
+    std::vector<uint32_t> w(size_t((cu_count + 31) / 32), 0u);
+    for (int cu = 0; cu < cu_count / 2; ++cu) w[size_t(cu / 32)] |= 1u << (cu % 32);
+    return w;
+}
+
+static int query_device_caps(mlh_ctx *c)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return MLH_ERR_HIP;
+    c->caps.cu_count = prop.multiProcessorCount;
+    c->caps.cu_solver = prop.multiProcessorCount;
+    int occ[2] = {0, 0}, occ_t = 0;
+    if (lm_loop_occupancy(occ) != MLH_OK || track_loop_occupancy(&occ_t) != MLH_OK) return MLH_ERR_HIP;
+    c->caps.blocks_per_cu[0] = occ[0]; c->caps.blocks_per_cu[1] = occ[1]; c->caps.blocks_per_cu[2] = occ_t;
+    unsigned long long us = 20000;                // a completed barrier takes ~2 us; another context's longest kernel in the way, < 1 ms
+    if (const char *e = std::getenv("MLH_LOOP_TIMEOUT_US")) { const long long v = std::atoll(e); if (v > 0) us = (unsigned long long)v; }
+    c->caps.loop_timeout_ticks = us * 100ull;     // wall_clock64(): 100 MHz
+    return MLH_OK;
+}
+
+// Workgroups of the loop kernels that may stand behind one in-kernel barrier. Residency: (occupancy query, at most 8, less one block per compute unit -- the query
+// is known to answer one too many for kernels with many scalar registers, MI355X_MICROARCH.md "Residency and cooperative launch") x the compute units the
+// solver's stream may use, halved while a CU-masked staging stream runs its index builds beside it. Redundancy: every workgroup sums every tile's record, which
+// stops paying beyond GN_DEFER_MAX_TILES (measured, profiles/r04_feature_sweep.txt; the fused thinning + solve call sizes its grid for the un-thinned clouds and
+// accepts up to FUSED_LOOP_MAX_TILES). The smaller of the two; MLH_LOOP_MAX_TILES lowers it further (0: never).
+constexpr int GN_DEFER_MAX_TILES = 160;
+constexpr int FUSED_LOOP_MAX_TILES = 512;
+static void set_loop_gates(mlh_ctx *c)
+{
+    const int by_size[3] = {GN_DEFER_MAX_TILES, FUSED_LOOP_MAX_TILES, GN_DEFER_MAX_TILES};
+    int by_hand = -1;
+    if (const char *e = std::getenv("MLH_LOOP_MAX_TILES")) by_hand = std::max(0, std::atoi(e));
+    for (int i = 0; i < 3; ++i) {
+        const int per_cu = std::max(0, std::min(c->caps.blocks_per_cu[i], 8) - 1);
+        long long resident = (long long)per_cu * c->caps.cu_solver;
+        if (c->caps.staging_masked) resident /= 2;
+        int gate = int(std::min<long long>(resident, by_size[i]));
+        if (by_hand >= 0) gate = std::min(gate, by_hand);
+        if (c->caps.loop_demoted[i] >= 0) gate = std::min(gate, c->caps.loop_demoted[i]);
+        c->caps.loop_max_tiles[i] = gate;
+    }
+}
+
+// A loop kernel of kind `which` came back with its barrier given up on at `tiles` workgroups: that many are evidently not resident together here. Half of it from
+// now on (a second failure halves again; 0 = the launch-per-iteration forms for good).
+static void demote_loop_gate(mlh_ctx *c, int which, int tiles)
+{
+    ++c->caps.loop_timeouts;
+    const int cur = c->caps.loop_max_tiles[which];
+    c->caps.loop_demoted[which] = std::min(cur, tiles) / 2;
+    set_loop_gates(c);
+}
+static bool loop_tiles_ok(const mlh_ctx *c, int which, int tiles) { return tiles > 0 && tiles <= c->caps.loop_max_tiles[which]; }
+
 }  // namespace mlh
 
 using namespace mlh;
@@ -339,8 +412,32 @@ int mlh_create(mlh_ctx **out, int device_id)
     if (const char *e = std::getenv("MLH_GN_DEFER")) c->gn_defer = std::atoi(e);
     if (const char *e = std::getenv("MLH_KNN_WARM")) c->knn_warm = std::atoi(e);
     if (const char *e = std::getenv("MLH_GN_FINAL_DEFER")) c->gn_final_defer = std::atoi(e);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MLH_ERR_HIP; }
+    if (query_device_caps(c) != MLH_OK) { delete c; return MLH_ERR_HIP; }
+    // the solver's stream: the whole device, or -- MLH_SOLVER_CU_MASK=<hex word>[,<hex word>...], bit i of word w = compute unit 32 w + i -- a part of it (a
+    // deployment that keeps compute units for other work; the tests of the residency gates)
+    std::vector<uint32_t> mask;
+    if (const char *m = std::getenv("MLH_SOLVER_CU_MASK")) mask = parse_cu_mask(m, c->caps.cu_count);
+    hipError_t se;
+    if (!mask.empty()) {
+        int bits = 0;
+        for (uint32_t w : mask) bits += __builtin_popcount(w);
+        if (bits <= 0) { delete c; return MLH_ERR_INVALID; }
+        se = hipExtStreamCreateWithCUMask(&c->stream, uint32_t(mask.size()), mask.data());
+        c->caps.cu_solver = bits; c->caps.solver_masked = true;
+    } else se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return MLH_ERR_HIP; }
+    set_loop_gates(c);
     *out = c;
+    return MLH_OK;
+}
+
+int mlh_get_info(mlh_ctx *ctx, mlh_device_info *out)
+{
+    if (!ctx || !out) return MLH_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    out->cu_count = ctx->caps.cu_count; out->cu_solver = ctx->caps.cu_solver;
+    for (int i = 0; i < 3; ++i) { out->loop_blocks_per_cu[i] = ctx->caps.blocks_per_cu[i]; out->loop_max_tiles[i] = ctx->caps.loop_max_tiles[i]; }
+    out->loop_launches = ctx->caps.loop_launches; out->loop_timeouts = ctx->caps.loop_timeouts; out->loop_fallbacks = ctx->caps.loop_fallbacks;
     return MLH_OK;
 }
 
@@ -835,19 +932,34 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
         ctx->map_read_unsynced = false;
     }
     if (!ctx->stream2) {
-        // The staging stream may use half of the compute units (CU mask words 0-3): its kernels are atomics- / latency-bound and lose ~5 % on 128 CUs, while the
+        // The staging stream may use the first half of the compute units: its kernels are atomics- / latency-bound and lose ~5 % on half the device, while the
         // solver's launches they run beside lose less to them (step 0.1452 -> 0.1415 ms, three alternations in one gpurun call; every other CU, a quarter of the
-        // CUs and 8 CUs per 32 measured no better). MLH_STAGE_CU_MASK=<hex word for CUs 0-127>[,<hex word for CUs 128-255>] overrides (ffffffff,ffffffff = no mask).
-        uint32_t lo = 0xffffffffu, hi = 0u;
+        // CUs and 8 CUs per 32 measured no better). The mask is sized from the device's compute-unit count. MLH_STAGE_CU_MASK=<hex word>[,<hex word>...]
+        // overrides (32 compute units per word; a single word is repeated over the first half of the words, a second one over the other half -- round 3's
+        // "lo,hi" form; "ffffffff,ffffffff" = no mask).
+        std::vector<uint32_t> words = lower_half_cu_mask(ctx->caps.cu_count);
         if (const char *m = std::getenv("MLH_STAGE_CU_MASK")) {
-            char *rest = nullptr;
-            lo = static_cast<uint32_t>(std::strtoul(m, &rest, 16));
-            hi = (rest && *rest == ',') ? static_cast<uint32_t>(std::strtoul(rest + 1, nullptr, 16)) : lo;
+            const int nw = int(words.size());
+            std::vector<uint32_t> given = parse_cu_mask(m, 32 * nw);
+            int n_given = 1;
+            for (const char *q = m; *q; ++q) n_given += *q == ',';
+            if (!given.empty() && n_given <= 2 && nw > 2) {
+                const uint32_t lo = given[0], hi = n_given == 2 ? given[1] : given[0];
+                for (int i = 0; i < nw; ++i) given[size_t(i)] = i < nw / 2 ? lo : hi;
+            }
+            if (!given.empty()) {
+                if (ctx->caps.cu_count % 32) given.back() &= (1u << (ctx->caps.cu_count % 32)) - 1u;
+                words = given;
+            }
         }
-        uint32_t words[8];
-        for (int i = 0; i < 8; ++i) words[i] = i < 4 ? lo : hi;
-        if (lo == 0xffffffffu && hi == 0xffffffffu) MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        else MLH_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->stream2, 8, words));
+        int bits = 0;
+        for (uint32_t w : words) bits += __builtin_popcount(w);
+        if (bits <= 0 || bits >= ctx->caps.cu_count) MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        else {
+            MLH_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->stream2, uint32_t(words.size()), words.data()));
+            ctx->caps.staging_masked = true;      // its launches hold wave slots of those compute units beside the solver's: the loop kernels' residency gate halves
+            set_loop_gates(ctx);
+        }
         for (int i = 0; i < 2; ++i) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_set_built[i], hipEventDisableTiming));
     }
     // The other set's last reader is the solve submitted BEFORE the one in flight; with at most one solve in flight here it has been collected, i.e. it is done:
@@ -877,9 +989,7 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
         unsigned spins = 0;
         while (hipEventQuery(ctx->ev_set_built[target]) == hipErrorNotReady) {
             if ((++spins & 0xff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream2)); break; }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            host_wait_relax(spins);
         }
     }
     return MLH_OK;
@@ -1284,7 +1394,6 @@ static MatchArgs args_from_opts(const mlh_solver_opts *o, int kind_mask, int pos
 // workgroups: +3.5 us against the 5 us the fit kernel's serial tail costs), quadratic in the launch size beyond it -- measured (profiles/r04_feature_sweep.txt):
 // even at 27-34 k features (108-133 tiles), a loss from ~100 k features on (447 tiles: +14 us), 4x the launch at 450 k. Launches with more tiles than this keep the
 // classic finish, whose one serial tail is noise next to a 100 us kernel.
-constexpr int GN_DEFER_MAX_TILES = 160;
 static bool gn_defer_applies(const mlh_ctx *ctx, int kind_mask)
 {
     if (!ctx->gn_defer || distributed(ctx)) return false;
@@ -1559,6 +1668,21 @@ static bool lm_loop_enabled()
     const char *e = std::getenv("MLH_LM_LOOP");
     return !(e && std::atoi(e) == 0);
 }
+static int feature_tiles(const mlh_ctx *ctx)
+{
+    int tiles = 0;
+    for (int k = 0; k < 2; ++k) tiles += (ctx->feat[k].m + 256 - 1) / 256;      // (the fit / linearise kernels' tile: 256 features, match.hip)
+    return tiles;
+}
+// ... where every tile's workgroup can be resident at once on what this context's stream may use of the device (mlh_ctx::caps, asked at mlh_create)
+static bool lm_loop_applies(const mlh_ctx *ctx, int which, int tiles) { return lm_loop_enabled() && loop_tiles_ok(ctx, which, tiles); }
+// The barrier of a one-launch loop was given up on (`done` bit 2 of its publication): the gate comes down, and the caller solves the frame again through the
+// launch-per-iteration form -- same arithmetic, same pose bits, no residency requirement
+static void note_loop_timeout(mlh_ctx *ctx, int which, int tiles, bool solved_again)
+{
+    demote_loop_gate(ctx, which, tiles);
+    if (solved_again) ++ctx->caps.loop_fallbacks;
+}
 
 // MLH_S2M_WARM=0: every outer iteration searches unbounded (A/B)
 static bool s2m_warm_applies(const mlh_ctx *ctx)
@@ -1568,17 +1692,21 @@ static bool s2m_warm_applies(const mlh_ctx *ctx)
     return ctx->knn_warm && !ctx->shard_lo && !ctx->shard_hi && ctx->own_mod <= 1;
 }
 
-static bool lm_consumer_enabled(const mlh_ctx *ctx)
+static bool lm_consumer_switch()
 {
     const char *e = std::getenv("MLH_LM_CONSUMER");
-    if (e && std::atoi(e) == 0) return false;
+    return !(e && std::atoi(e) == 0);
+}
+static bool lm_consumer_enabled(const mlh_ctx *ctx)
+{
+    if (!lm_consumer_switch()) return false;
     // every workgroup sums every tile's record: the same size limit as the Gauss-Newton path's deferred finish (GN_DEFER_MAX_TILES)
     int tiles = 0;
     for (int k = 0; k < 2; ++k) tiles += (ctx->feat[k].m + 256 - 1) / 256;
     return tiles <= GN_DEFER_MAX_TILES;
 }
 
-static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats)
+static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats, bool allow_loop = true)
 {
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
@@ -1601,7 +1729,8 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     // records, every LM launch begins by summing its predecessor's and running the begin / step in all workgroups, then evaluates at the candidate (one launch more
     // per loop: the last evaluation's verdict is the next launch's)
     const bool lmc = fused && !stats && !distributed(ctx) && lm_consumer_enabled(ctx);
-    if (lmc && lm_loop_enabled()) {
+    const int loop_tiles = feature_tiles(ctx);
+    if (lmc && allow_loop && lm_loop_applies(ctx, 0, loop_tiles)) {
         // the LM loop of every outer iteration is one launch that ends when the loop does: the whole frame is enqueued at once, the last launch publishes
         HostPublish *rec = nullptr;
         unsigned long long seq = 0;
@@ -1621,7 +1750,12 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
         }
         HostPublish hp;
         if ((rc = wait_published(ctx, seq, hp, rec))) return rc;
-        if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
+        if (hp.done & 4) {
+            // the loop's workgroups did not all arrive at a barrier (not all resident at once beside whatever else runs here): the frame again, from the start
+            // pose the caller still holds, through the launch-per-iteration form
+            note_loop_timeout(ctx, 0, loop_tiles, true);
+            return scan2map_polled(ctx, pose_inout, opts, stats, false);
+        }
         if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
         for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
         return MLH_OK;
@@ -1663,7 +1797,7 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             MatchArgs a = args_from_opts(opts, 3, 0);
             if (fused_lm) { a.finish = 3; a.stat_slot = stats ? outer : -1; a.lm_max_it = opts->max_lm_iterations; a.lm_min_blocks = 0; }
             // the selected rows' LM loop as one launch (as the wo_gf frame's, above): the linearisation of the selection only leaves its records
-            const bool loop_gf = fused_lm && !stats && !distributed(ctx) && lm_consumer_enabled(ctx) && lm_loop_enabled();
+            const bool loop_gf = fused_lm && !stats && !distributed(ctx) && lm_consumer_enabled(ctx) && allow_loop && lm_loop_applies(ctx, 0, loop_tiles);
             if (loop_gf) a.finish = 0;
             if ((rc = linearize_launch(ctx, a))) return rc;
             if (loop_gf) {
@@ -1734,7 +1868,10 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
     if (gf_loop_rec) {
         HostPublish hp;
         if ((rc = wait_published(ctx, gf_loop_seq, hp, gf_loop_rec))) return rc;
-        if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
+        if (hp.done & 4) {               // as above (the selection's draws start from opts->gf_seed again: the same frame)
+            note_loop_timeout(ctx, 0, loop_tiles, true);
+            return scan2map_polled(ctx, pose_inout, opts, stats, false);
+        }
         if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
         for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
         return MLH_OK;
@@ -1796,7 +1933,8 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
     // the consumer-side form of the LM launches (scan2map_polled): budget + 1 launches run `budget` LM steps
     const bool lmc = !ctx->p2p.active && lm_consumer_enabled(ctx);
     // ... or one launch per LM loop, which ends on the device when the loop does: no budget, nothing to overflow (an explicit lm_lookahead keeps the launches it counts)
-    const bool loop = lmc && lm_lookahead <= 0 && lm_loop_enabled();
+    const bool loop = lmc && lm_lookahead <= 0 && lm_loop_applies(ctx, 0, feature_tiles(ctx));
+    slot.loop_tiles = loop ? feature_tiles(ctx) : 0;
     for (int outer = 0; loop && outer < opts->max_outer; ++outer) {
         MatchArgs a = args_from_opts(opts, 3, 0);
         a.finish = 0; a.lm_max_it = opts->max_lm_iterations;
@@ -1866,39 +2004,44 @@ int mlh_scan2map_end(mlh_ctx *ctx, double pose_out[7], int32_t *status_out)
     }
     ctx->solve_collected = seq;
     ctx->solve_pending = ctx->solve_seq != ctx->solve_collected;
-    if (rc) return rc;
+    // a younger solve chained behind THIS one began from whatever pose this one left on the device: if this one did not produce a result, neither did that one
+    auto taint_successor = [&]() { if (ctx->solve_pending && ctx->solve_slot[(seq + 1) & 1].chained) ctx->solve_slot[(seq + 1) & 1].tainted = true; };
+    if (rc) { taint_successor(); return rc; }
     if (!ctx->prof.pending.empty() && !ctx->solve_pending) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
-    if (slot.kind == 1 && (hp.done & 4)) return fail(ctx, MLH_ERR_HIP, "mlh_scan2map_end: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
-    if (slot.kind == 1) {
+    const bool barrier_given_up = slot.kind == 1 && (hp.done & 4);       // (a one-launch LM loop whose workgroups were not all resident: lm_loop_kernel)
+    if (barrier_given_up) demote_loop_gate(ctx, 0, slot.loop_tiles);
+    if (slot.kind == 1 && !barrier_given_up) {
         // the next frame's automatic look-ahead: what this frame's longest LM loop used, plus two (consecutive mapper frames need about the same); a frame that
         // overflowed doubles it
         const int used = int(hp.xb[2][0]);
         const bool ok = (hp.done & 1) && !(hp.done & 2);
         ctx->lm_lookahead_auto = ok ? std::max(3, used + 2) : std::min(2 * std::max(ctx->lm_lookahead_auto, 4), slot.opts.max_lm_iterations);
     }
-    if (slot.kind == 2 || ((hp.done & 1) && !(hp.done & 2))) {
+    if (slot.kind == 2 || ((hp.done & 1) && !(hp.done & 6))) {
         for (int i = 0; i < 7; ++i) pose_out[i] = hp.x[i];
         if (slot.tainted) {
             // this frame was chained behind one whose LM loop outgrew its look-ahead: it began from that frame's UNFINISHED pose. Its own loops terminated, but the
             // result is not the mapper's; a solve chained behind THIS one inherits the mark.
-            if (ctx->solve_pending && ctx->solve_slot[(seq + 1) & 1].chained) ctx->solve_slot[(seq + 1) & 1].tainted = true;
+            taint_successor();
             if (status_out) { *status_out = 3; return MLH_OK; }
             return fail(ctx, MLH_ERR_INCOMPLETE, "mlh_scan2map_end: the frame was chained behind one that did not finish inside its look-ahead (status 3) and status_out is NULL");
         }
         return MLH_OK;
     }
-    // the look-ahead was too short for this frame
+    // the look-ahead was too short for this frame -- or its one-launch loop gave its barrier up
     double start[7];
     for (int i = 0; i < 7; ++i) start[i] = slot.chained ? hp.xb[1][i] : slot.start[i];
-    if (!ctx->solve_pending && ctx->stage_epoch == slot.epoch) {
-        // nothing younger is chained behind it and the frame's maps and features are still the staged ones: solve it as mlh_scan2map would have
+    if (!ctx->solve_pending && ctx->stage_epoch == slot.epoch && !slot.tainted) {
+        // nothing younger is chained behind it and the frame's maps and features are still the staged ones: solve it as mlh_scan2map would have (after a barrier
+        // given up on: through the launch-per-iteration form)
         for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
         if (status_out) *status_out = 2;
-        return scan2map_polled(ctx, pose_out, &slot.opts, nullptr);
+        if (barrier_given_up) ++ctx->caps.loop_fallbacks;
+        return scan2map_polled(ctx, pose_out, &slot.opts, nullptr, !barrier_given_up);
     }
     for (int i = 0; i < 7; ++i) pose_out[i] = start[i];
     // a younger solve chained behind this frame started from its unfinished pose: marked, and reported at ITS end (status 3)
-    if (ctx->solve_pending && ctx->solve_slot[(seq + 1) & 1].chained) ctx->solve_slot[(seq + 1) & 1].tainted = true;
+    taint_successor();
     if (status_out) { *status_out = slot.tainted ? 3 : 1; return MLH_OK; }
     // the pose handed back is NOT a result, and this caller has no way to see that: a distinct return code instead of success
     return fail(ctx, MLH_ERR_INCOMPLETE, "mlh_scan2map_end: the frame did not finish inside its look-ahead and cannot be solved again here (status 1); status_out is NULL");
@@ -1949,7 +2092,7 @@ int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, c
     // the loop kernel's barrier wants every tile's workgroup resident: the BOUND's tiles, since the real count is not known here
     const int bound_tiles = (n_surf + 255) / 256 + (n_corner + 255) / 256;
     static const bool off = std::getenv("MLH_FUSED_THIN_SOLVE") && std::atoi(std::getenv("MLH_FUSED_THIN_SOLVE")) == 0;      // (A/B: always the two calls)
-    if (off || !fused_pair || !have_maps || distributed(ctx) || ctx->comm || opts->gf_method != MLH_GF_WO || bound_tiles > 512 || !lm_loop_enabled() ||
+    if (off || !fused_pair || !have_maps || distributed(ctx) || ctx->comm || opts->gf_method != MLH_GF_WO || !lm_consumer_switch() || !lm_loop_applies(ctx, 1, bound_tiles) ||
         ctx->solve_seq != ctx->solve_collected || ctx->vox_member_order != 1)
         return two_calls();
     { const int frc = gn_flush_pending(ctx); if (frc) return frc; }
@@ -2007,8 +2150,13 @@ int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, c
     stage_counts(real);
     *n_surf_features = real[0]; *n_corner_features = real[1];
     if ((rc = device_error_check(ctx))) return rc;
-    if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_downsample_scan2map: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (lm_loop_kernel timed out)");
     if (real[0] <= 0 || real[1] <= 0) return fail(ctx, MLH_ERR_STATE, "features_set is required for both kinds");      // (what mlh_scan2map says of an empty kind)
+    if (hp.done & 4) {
+        // the loop's workgroups (sized for the un-thinned clouds) did not all arrive at a barrier: the thinned sets are staged and counted by now -- the solve again,
+        // as the second of the two calls, through the launch-per-iteration form
+        note_loop_timeout(ctx, 1, bound_tiles, true);
+        return scan2map_polled(ctx, pose_inout, opts, nullptr, false);
+    }
     if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
     for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
     return MLH_OK;
@@ -2283,9 +2431,7 @@ int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t 
                     if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "the fused clouds' sizes did not arrive");
                     break;
                 }
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
+                host_wait_relax(spins);
             }
         }
         ctx->fused_n[0] = h_cnt[0]; ctx->fused_n[1] = h_cnt[1];
@@ -2318,7 +2464,7 @@ int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_trac
     return MLH_OK;
 }
 
-int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats)
+static int track_cloud_impl(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats, bool allow_loop)
 {
     { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     if (!ctx || !pose_inout || !opts || opts->max_outer <= 0 || opts->max_lm_iterations <= 0) return MLH_ERR_INVALID;
@@ -2337,7 +2483,7 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
     {
         const char *e = std::getenv("MLH_TRACK_LOOP");
         const int tiles = (T.m[0] + 255) / 256 + (T.m[1] + 255) / 256;
-        if (lean && !(e && std::atoi(e) == 0) && !distributed(ctx) && tiles <= GN_DEFER_MAX_TILES) {
+        if (lean && allow_loop && !(e && std::atoi(e) == 0) && !distributed(ctx) && loop_tiles_ok(ctx, 2, tiles)) {
             HostPublish *rec = nullptr;
             if ((rc = publish_slot(ctx, &rec, &seq))) return rc;
             for (int outer = 0; outer < opts->max_outer; ++outer) {
@@ -2352,7 +2498,10 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
             }
             HostPublish hp;
             if ((rc = wait_published(ctx, seq, hp))) return rc;
-            if (hp.done & 4) return fail(ctx, MLH_ERR_HIP, "mlh_track_cloud: the Levenberg-Marquardt loop's workgroups did not all arrive at their barrier (track_lm_loop_kernel timed out)");
+            if (hp.done & 4) {           // a barrier given up on: the rounds again, from the pose the caller still holds, a launch per LM iteration
+                note_loop_timeout(ctx, 2, tiles, true);
+                return track_cloud_impl(ctx, pose_inout, opts, stats, false);
+            }
             if (!ctx->prof.pending.empty()) { MLH_HIP(ctx, hipStreamSynchronize(ctx->stream)); prof_collect(ctx); }
             for (int i = 0; i < 7; ++i) pose_inout[i] = hp.x[i];
             return MLH_OK;
@@ -2388,6 +2537,11 @@ int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *op
         return MLH_OK;
     }
     return fetch_pose_and_stats(ctx, pose_inout, stats, opts->max_outer);
+}
+
+int mlh_track_cloud(mlh_ctx *ctx, double pose_inout[7], const mlh_track_opts *opts, mlh_iter_stat *stats)
+{
+    return track_cloud_impl(ctx, pose_inout, opts, stats, true);
 }
 
 int mlh_good_feature_matching(mlh_ctx *ctx, int kind, const double pose[7], int gf_method, double gf_ratio, uint64_t seed,

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <cstdlib>
+#include <sched.h>
 #include "../../include/mloam_hip.h"
 
 namespace mlh {
@@ -266,6 +267,22 @@ struct mlh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    // What the device (and the part of it the solver's stream may use) admits, asked once at mlh_create (capi.hip: query_device_caps) -- the kernels whose
+    // workgroups synchronise among themselves inside one launch (match.hip: lm_loop_kernel, track.hip: track_lm_loop_kernel) need EVERY workgroup resident at
+    // once, and a plain launch checks nothing: the hosts gates them on loop_max_tiles[] instead of on a literal sized for a whole 256-CU part.
+    struct DeviceCaps {
+        int cu_count = 0;                 // hipDeviceProp_t::multiProcessorCount
+        int cu_solver = 0;                // compute units the solver's stream may use (MLH_SOLVER_CU_MASK; otherwise all of them)
+        bool solver_masked = false;
+        bool staging_masked = false;      // the staging stream (mlh_map_set_pair_overlapped) exists and is confined to a part of the compute units
+        int loop_demoted[3] = {-1, -1, -1};   // >= 0: a barrier was given up on -- the gate this context keeps below from then on
+        int blocks_per_cu[3] = {0, 0, 0}; // hipOccupancyMaxActiveBlocksPerMultiprocessor: lm_loop_kernel<false>, lm_loop_kernel<true>, track_lm_loop_kernel
+        int loop_max_tiles[3] = {0, 0, 0};// workgroups of those kernels the host will put behind one in-kernel barrier (0: never -- the launch-per-iteration forms)
+        unsigned long long loop_timeout_ticks = 0;   // a barrier wait longer than this many 100 MHz ticks gives the loop up (MLH_LOOP_TIMEOUT_US, default 20 ms)
+        unsigned long long loop_launches = 0;        // frames / rounds solved through the one-launch loop
+        unsigned long long loop_timeouts = 0;        // ... that came back with the barrier given up on
+        unsigned long long loop_fallbacks = 0;       // ... and were solved again through the launch-per-iteration form (the caller got a pose, later)
+    } caps;
     // The local maps are double-buffered: `map` points at the set the solvers read; mlh_map_set_pair_overlapped stages the NEXT frame's maps into the
     // other set on a second stream while a submitted solve still reads this one, then switches `map` (launches capture a set's device pointers when they
     // are enqueued, so solves already in flight keep theirs).
@@ -304,6 +321,7 @@ struct mlh_ctx {
         mlh_solver_opts opts;
         unsigned long long epoch = 0;  // stage_epoch at submission
         bool tainted = false;          // chained behind a frame whose LM loop outgrew its look-ahead: began from an unfinished pose (mlh_scan2map_end status 3)
+        int loop_tiles = 0;            // > 0: the frame's LM loops were submitted as one launch each over this many workgroups (lm_loop_kernel)
     } solve_slot[2];
     int lm_lookahead_auto = 10;           // mlh_scan2map_begin(lm_lookahead = 0): the previous frame's largest LM iteration count + 2 (10 until a frame has been collected)
     unsigned long long stage_epoch = 0;   // bumped by every call that restages a map or a feature set: a re-solve of an in-flight frame is only sound on unchanged inputs
@@ -473,6 +491,18 @@ inline int device_error_check(mlh_ctx *ctx)
     }
     return MLH_OK;
 }
+// One turn of a host-side wait on a pinned word (the publications of the solves, the staging hand-shakes, the few-int read-backs): those waits are microseconds
+// long, so the default is to spin (`pause`) -- a sleeping thread's wake-up costs tens. A process with one thread per LiDAR + the mapper + the tracker, each in
+// such a wait, burns that many cores; MLH_HOST_WAIT=yield (read once per process) spins the first 64 turns (~2 us: the common case still pays nothing) and then
+// gives the core to whoever is runnable between two looks. Either way a wait falls back to the blocking hipStreamSynchronize after 200 ms.
+inline void host_wait_relax(unsigned spins)
+{
+    static const bool yield_mode = [] { const char *e = std::getenv("MLH_HOST_WAIT"); return e && std::strcmp(e, "yield") == 0; }();
+    if (yield_mode && spins > 64u) { sched_yield(); return; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
 // 64 pinned ints owned by the context (lazily allocated); nullptr on allocation failure
 inline int *pinned_ints(mlh_ctx *ctx)
 {
@@ -588,6 +618,8 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int gn_flush_pending(mlh_ctx *ctx);      // completes a pending last iteration with a one-workgroup launch (no-op when nothing is pending)
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a);
+int lm_loop_occupancy(int blocks_per_cu[2]);      // hipOccupancyMaxActiveBlocksPerMultiprocessor of lm_loop_kernel<false> / <true>
+int track_loop_occupancy(int *blocks_per_cu);     // ... of track_lm_loop_kernel (track.hip)
 // the arrival counters of the fused finishes and of lm_loop_kernel's barrier: four zeroed words, whoever asks first ([0]: the finish tickets of match.hip and
 // track.hip; [1] arrivals, [2] departures, [3] release flag of the loop kernel). One place, so that no caller can leave the others' words unallocated or unzeroed.
 inline hipError_t ensure_ticket(mlh_ctx *ctx)

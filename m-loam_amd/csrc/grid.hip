@@ -503,9 +503,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
                 if (__atomic_load_n(&pub->seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "map staging did not complete");
                 break;
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            host_wait_relax(spins);
         }
     }
     const int oob = int(pub->done);

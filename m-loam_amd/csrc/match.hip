@@ -247,6 +247,7 @@ struct KParams {
     // feature counts read on the DEVICE (mlh_downsample_scan2map: the solve is enqueued behind the thinning without the host reading what the thinning kept): the
     // launches are sized for an upper bound (KindP::m, tiles_*), the DEVM kernel variants take the counts -- and the tiles that follow from them -- from here
     const int *m_dev;        // [2]: surf, corner
+    unsigned long long loop_timeout_ticks;   // lm_loop_kernel: a barrier wait longer than this (100 MHz wall clock) gives the loop up (mlh_ctx::caps)
     int debug_stall;         // MLH_DEBUG_LOOP_STALL=1 (tests): one workgroup of lm_loop_kernel never arrives at its second barrier -- the loop must end with the error bit, not hang
 };
 
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 
 // ---- The whole Levenberg-Marquardt loop of one outer iteration in ONE launch. The consumer-side launches above still pay a launch boundary per LM iteration
 // (~4.4 us of an ~8.9 us launch on the 88-tile mapper frame) and a look-ahead of launches behind the loop's end; the tiles of a frame that qualifies for the
-// consumer-side schedule (<= GN_DEFER_MAX_TILES workgroups: all resident at once on 256 compute units) can synchronise among themselves instead:
+// consumer-side schedule whose workgroups are all resident at once (the host asks the device: mlh_ctx::caps, capi.hip: set_loop_gates) can synchronise among themselves instead:
 //   every workgroup: tile inputs -> registers (once); sum the fit launch's records; LM begin; then, until the loop terminates:
 //     evaluate the tile at the candidate -> record (buffer (it + 1) & 1) -> grid barrier (release; one atomic arrival; spin on the counter; acquire)
 //     -> sum all records -> LM step (the state stays in LDS: every workgroup runs the identical arithmetic on identical inputs, so they agree on accept / reject,
@@ -1057,8 +1058,11 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 // The loop ends on the device when Ceres' loop would: no look-ahead budget, no launches that find `done`, nothing for the host to poll between LM iterations,
 // and the split submission cannot overflow. Same operations in the same order as the launches it replaces: the same bits.
 // Barrier: P.ticket[1] counts arrivals (monotonic over the launch: iteration `it` waits for total * (it + 1)), P.ticket[2] counts workgroups that have left; the
-// last one to leave zeroes both for the next launch. A spin that outlasts MLH_LOOP_SPIN_LIMIT polls (seconds; a workgroup that never became resident, a fault)
-// ends the loop with bit 2 of the published `done` word set -- the host reports an error instead of hanging.
+// last one to leave zeroes both for the next launch. Residency is the HOST's business (capi.hip: loop_tiles_ok -- the occupancy query x the compute units the
+// solver's stream may use, asked at mlh_create); should a barrier nevertheless not complete within P.loop_timeout_ticks of the 100 MHz wall clock (a workgroup that
+// never became resident beside another context's kernels, a fault), the loop is given up: P.ticket[3] tells every workgroup still to come or still polling, bit 2 of
+// the published `done` word tells the host, which solves the frame again through the launch-per-iteration form (lm_consume_kernel: no residency requirement) --
+// a slow frame, not a lost one. The later loop launches of such a frame (lm_overflow == 4 in the state) leave at once.
 // MLH_LOOP_COH 1: the records cross the barrier as agent-scope monotonic stores / loads (write-through, read past the L2 of the reader's XCD) -- no L2 write-back
 // and invalidate around the barrier; 0: plain stores + release fence / acquire fence + plain loads
 #ifndef MLH_LOOP_COH
@@ -1067,14 +1071,8 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_SPLIT_STEP
 #define MLH_LOOP_SPLIT_STEP 0
 #endif
-#ifndef MLH_LOOP_FLAG
-#define MLH_LOOP_FLAG 0
-#endif
 #ifndef MLH_LOOP_SLEEP
 #define MLH_LOOP_SLEEP 1
-#endif
-#ifndef MLH_LOOP_SPIN_LIMIT
-#define MLH_LOOP_SPIN_LIMIT 4000000u
 #endif
 template <bool DEVM = false>
 __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
@@ -1093,6 +1091,17 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         m0 = P.m_dev[0]; m1 = P.m_dev[1];
         tb0 = (m0 + TPB - 1) / TPB;
         total = tb0 + (m1 + TPB - 1) / TPB;
+        if (total == 0) {
+            // the thinning kept nothing of either kind: no tile exists, nobody would publish -- the first workgroup of the launch the host waits for does (bit 3:
+            // "no features"; the host reports what mlh_scan2map reports for an empty feature set, include/mloam_hip.h)
+            if (blockIdx.x == 0 && threadIdx.x == 0 && P.publish) {
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = P.use_init ? P.init_pose[i] : P.state->x[i];
+                P.publish->done = 1 | 8;
+                P.publish->xb[2][0] = 0.0;
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
         if ((int(blockIdx.x) >> 3) >= ((total + 7) >> 3)) return;
     }
     const int gtile = xcd_tile(total);
@@ -1116,9 +1125,13 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
     const double w = feature_weight_pref(P, K, cdv);
     const d3 p{double(fp.x), double(fp.y), double(fp.z)};
     const size_t set = size_t(NE_STRIDE) * size_t(total);
-    if (threadIdx.x == 0) s_timeout = 0;
+    // given up already -- by a workgroup of this launch that waited in vain, or by an earlier loop of this frame: nothing to do but leave
+    if (threadIdx.x == 0)
+        s_timeout = (__hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (P.lm_expect_done >= 0 && P.state->lm_overflow == 4)) ? 2 : 0;
     lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
-    if (threadIdx.x < 64) {
+    const bool skipped = s_timeout != 0;           // (uniform: written before the sum's barriers)
+    if (threadIdx.x == 0 && skipped) s_done = 1;
+    if (threadIdx.x < 64 && !skipped) {
         const int lane = threadIdx.x;
         LmRegs R;
         double cand[7], x[7];
@@ -1155,25 +1168,21 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned target = unsigned(total) * unsigned(it + 1);
             const bool stall = P.debug_stall && it == 1 && gtile == (total > 1 ? 1 : 0);
-            if (stall) { s_timeout = 1; }
+            if (stall) { s_timeout = 1; __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else {
-#if MLH_LOOP_FLAG
-            // the last arrival raises a separate word the others watch: the polls stay off the line the arrivals' atomics serialise on
-            const unsigned before = __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            if (before + 1u == target) __hip_atomic_store(P.ticket + 3, unsigned(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else while (__hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < unsigned(it + 1)) {
-                if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
-                if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
-            }
-#else
-            __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
-                if (++spins > MLH_LOOP_SPIN_LIMIT) { s_timeout = 1; break; }
-            }
-#endif
+                __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                long long t0 = 0;
+                while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
+                    if ((++spins & 63u) == 0u) {      // (a completed barrier takes ~2 us = a few polls: the clock and the word below are only read by a wait that is already long)
+                        const long long now = wall_clock64();
+                        if (t0 == 0) t0 = now;
+                        const bool late = (unsigned long long)(now - t0) > P.loop_timeout_ticks;
+                        if (late) __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (late || __hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { s_timeout = 1; break; }
+                    }
+                }
             }
             if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("" ::: "memory");
@@ -1221,7 +1230,19 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (it == 2) MLH_STAGE(gtile, 5);
         ++it;
     }
-    if (writer && threadIdx.x < 64) {
+    if (writer && threadIdx.x < 64 && skipped) {
+        // the loop never began here: the pose in the state is what the last loop that ran left; the failure travels on to the launch that publishes
+        if (threadIdx.x == 0) {
+            P.state->lm_overflow = 4;
+            if (P.publish) {
+                for (int i = 0; i < 7; ++i) P.publish->x[i] = P.state->x[i];
+                P.publish->done = 4;
+                P.publish->xb[2][0] = P.state->lm_used_max;
+                __hip_atomic_store(&P.publish->seq, P.publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    else if (writer && threadIdx.x < 64) {
         const int lane = threadIdx.x;
         if (lane < 7) P.state->x[lane] = s_lm.x[lane];          // read by the launches BEHIND this one only (the other workgroups took their start pose long ago)
         if (lane == 0) {
@@ -1568,14 +1589,23 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
     const int grid_b = ((P.k[0].tiles_b + P.k[1].tiles_b + 7) / 8) * 8;
     if (a.lmc == 3) {
         { const char *e = std::getenv("MLH_DEBUG_LOOP_STALL"); P.debug_stall = (e && std::atoi(e) != 0) ? 1 : 0; }
-        // every tile's workgroup has to be resident for the barrier: 256-thread workgroups at <= 128 VGPRs, a few KB of LDS -- several per compute unit
-        if (P.k[0].tiles_b + P.k[1].tiles_b > (P.m_dev ? 512 : 256)) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than can be resident at once");
+        // every tile's workgroup has to be resident for the barrier: the host's gate (capi.hip: loop_tiles_ok) is what the device admits, asked at mlh_create
+        if (P.k[0].tiles_b + P.k[1].tiles_b > ctx->caps.loop_max_tiles[P.m_dev ? 1 : 0]) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than can be resident at once on this device");
+        P.loop_timeout_ticks = ctx->caps.loop_timeout_ticks;
+        if (a.lm_expect_done < 0) ++ctx->caps.loop_launches;      // (the first loop of a frame)
         if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true>, grid_b, P);
         else launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<false>, grid_b, P);
     }
     else if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
     else launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<false>, grid_b, P);
     MLH_HIP(ctx, hipGetLastError());
+    return MLH_OK;
+}
+
+int lm_loop_occupancy(int blocks_per_cu[2])
+{
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu[0], lm_loop_kernel<false>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu[1], lm_loop_kernel<true>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
     return MLH_OK;
 }
 

@@ -105,22 +105,32 @@ __device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, dou
 
 // One arrival at the loop kernels' grid barrier, by thread 0 of a workgroup whose record stores have been issued (by lanes of thread 0's own wavefront): wait for
 // their acknowledgement, count the arrival, poll until all `total` workgroups of barrier number `nth` (1, 2, ...) have arrived. counters[1] = arrivals (monotonic
-// over the launch), counters[2] = departures (loop_barrier_leave). Returns false when the poll budget ran out (a workgroup that never arrives).
-#ifndef MLH_LOOP_SPIN_LIMIT
-#define MLH_LOOP_SPIN_LIMIT 4000000u
-#endif
-__device__ __forceinline__ bool loop_barrier_arrive(unsigned *counters, int total, int nth)
+// over the launch), counters[2] = departures (loop_barrier_leave), counters[3] = "given up". Returns false when the wait outlasted timeout_ticks of the 100 MHz
+// wall clock (a workgroup that never became resident) or another workgroup of the launch has given up; the first to give up says so in counters[3], so that the
+// others (and workgroups that only start now: loop_barrier_given_up) do not each wait the limit out.
+__device__ __forceinline__ bool loop_barrier_arrive(unsigned *counters, int total, int nth, unsigned long long timeout_ticks)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = unsigned(total) * unsigned(nth);
     unsigned spins = 0;
+    long long t0 = 0;
     while (__hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > MLH_LOOP_SPIN_LIMIT) return false;
+        if ((++spins & 63u) == 0u) {
+            const long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            const bool late = (unsigned long long)(now - t0) > timeout_ticks;
+            if (late) __hip_atomic_store(counters + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (late || __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        }
     }
     asm volatile("" ::: "memory");
     return true;
+}
+__device__ __forceinline__ bool loop_barrier_given_up(unsigned *counters)
+{
+    return __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 // the last workgroup to leave re-arms the counters for the next launch (thread 0 of every participating workgroup, once, at the kernel's end)
 __device__ __forceinline__ void loop_barrier_leave(unsigned *counters, int total)

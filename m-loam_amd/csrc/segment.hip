@@ -21,6 +21,7 @@
 // atan / atan2 run in f32 on the device (ocml) and in glibc on the reference's CPU: the last ulp may differ, which matters only for a point
 // within one ulp of a row / column bin edge or a ground pair within one ulp of 10 degrees.
 #include "ctx.hpp"
+#include <mutex>
 #include "alive_pool.hpp"
 #include <chrono>
 #include <cstdio>
@@ -623,6 +624,26 @@ static bool seg_ground_host(const float4 &a, const float4 &b)
 
 constexpr int SEG_UNC_FIRST = 2048;     // undecided records fetched with the counters (a scan has a few dozen); more than that: one more copy
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of seg_rows_kernel, per device and monotone (two contexts -- two threads, two GPUs of a multi-rank process -- share the
+// function object of their device; a smaller request never lowers what a launch in flight was granted). false: this device does not grant `bytes`.
+static bool seg_rows_lds_granted(int device, size_t bytes)
+{
+    static std::mutex mu;
+    static size_t granted[64] = {};
+    static size_t refused[64] = {};
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bytes <= granted[device]) return true;
+    if (refused[device] && bytes >= refused[device]) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(seg_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)) != hipSuccess) {
+        (void)hipGetLastError();
+        refused[device] = bytes;
+        return false;
+    }
+    granted[device] = bytes;
+    return true;
+}
+
 int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensity_off, int n, int mem, const mlh_segment_params &prm,
                       float *cloud_out, int32_t *n_out, int32_t *scan_start, int32_t *scan_end, float *outlier_out, int32_t outlier_capacity, int32_t *n_outlier)
 {
@@ -743,7 +764,11 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
     int hs2 = 1;
     while (hs2 < hs) hs2 <<= 1;
     static const bool host_rows = std::getenv("MLH_SEG_HOST_ROWS") != nullptr;       // (A/B runs: the round-4 host assembly)
-    if (hs2 <= SEG_ROW_MAX && !host_rows) {
+    // seg_rows_kernel's dynamic LDS (20 bytes per padded row pixel: 80 KB at 4 096 columns) has to be granted per DEVICE, once, before a launch that needs it; a
+    // device that does not grant it (a part with less LDS per compute unit) takes the host assembly below instead of failing the call
+    bool device_rows = hs2 <= SEG_ROW_MAX && !host_rows;
+    if (device_rows) device_rows = seg_rows_lds_granted(ctx->device, size_t(20) * size_t(hs2));
+    if (device_rows) {
         // ---- rows, erasure, concatenation and gather on the device (seg_rows_kernel / seg_rows_gather_kernel); the host keeps the outlier list only
         std::vector<int> outlier_idx, outlier_row;
         if (prm.segment_flag)
@@ -776,11 +801,6 @@ int segment_cloud_run(mlh_ctx *ctx, const void *points, int stride, int intensit
         R.owner = B.owner.as<int>(); R.outmask = B.outmask.as<unsigned>(); R.kept = B.keep.as<int>(); R.row_cnt = B.row_cnt.as<int>();
         R.vs = vs; R.hs = hs; R.hs2 = hs2; R.segment_flag = prm.segment_flag ? 1 : 0;
         const size_t lds = size_t(20) * size_t(hs2);
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
-            MLH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(seg_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            lds_set = lds;
-        }
         MLH_LAUNCH(seg_rows_kernel, dim3(vs), dim3(SEG_ROW_TPB), lds, st, R);
         int *h_rows = static_cast<int *>(B.h_rows);
         MLH_LAUNCH(seg_rows_gather_kernel, dim3(4, vs), dim3(256), 0, st, D, (const int *)B.keep.as<int>(), (const int *)B.row_cnt.as<int>(), sb.pts.as<float4>(),

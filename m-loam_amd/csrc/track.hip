@@ -69,6 +69,7 @@ struct TrackParamsDev {
     int shells;              // cube half-width (in cells) that covers the acceptance radius
     int nearby_floor;        // floor(NEARBY_SCAN): rings id - nf .. id + nf take part in the walks
     double huber_delta;
+    unsigned long long loop_timeout_ticks;   // track_lm_loop_kernel: a barrier wait longer than this (100 MHz wall clock) gives the loop up (mlh_ctx::caps)
 };
 
 __device__ __forceinline__ void track_pose(const TrackParamsDev &P, q4 &q, d3 &t)
@@ -479,13 +480,15 @@ __global__ __launch_bounds__(TPB) void track_lm_loop_kernel(TrackParamsDev P)
     if (f < K.m) { c = K.corr[f]; fp = K.cur[f]; }
     const bool valid = f < K.m && c.valid != 0;
     const size_t set = size_t(NE_STRIDE) * size_t(total);
-    if (threadIdx.x == 0) s_timeout = 0;
+    // given up already -- by a workgroup of this launch that waited in vain, or by an earlier round of this call (lm_overflow == 4; the first round, whose pose
+    // comes with the kernel arguments, clears it): nothing to do but leave; the failure travels on to the round that publishes
+    if (threadIdx.x == 0) s_timeout = (loop_barrier_given_up(P.ticket) || (!P.use_init && P.state->lm_overflow == 4)) ? 2 : 0;
     // the round's pose: the records of the begin are taken there
     if (threadIdx.x < 7) s_cand[threadIdx.x] = P.use_init ? P.init_pose[threadIdx.x] : P.state->x[threadIdx.x];
     __syncthreads();
     int nth = 0;                                                   // barriers passed
     bool begun = false;
-    while (true) {
+    while (!s_timeout) {
         const q4 q{s_cand[3], s_cand[4], s_cand[5], s_cand[6]};
         const d3 t{s_cand[0], s_cand[1], s_cand[2]};
         double acc[32];
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(TPB) void track_lm_loop_kernel(TrackParamsDev P)
         if (valid) track_eval(P, kind, c, fp, q, t, acc);
         double *rec = P.partials + set * size_t(nth & 1);
         reduce_acc32<true>(acc, kind, s_red, rec + size_t(gtile) * NE_STRIDE);
-        if (threadIdx.x == 0 && !loop_barrier_arrive(P.ticket, total, nth + 1)) s_timeout = 1;
+        if (threadIdx.x == 0 && !loop_barrier_arrive(P.ticket, total, nth + 1, P.loop_timeout_ticks)) s_timeout = 1;
         __syncthreads();
         ++nth;
         if (s_timeout) break;
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(TPB) void track_lm_loop_kernel(TrackParamsDev P)
         if (lane == 0) {
             P.state->done = have ? s_lm.done : 1;
             P.state->iteration = have ? s_lm.iteration : 0;
+            P.state->lm_overflow = s_timeout ? 4 : 0;              // (a later round of the call finds it and leaves; the round that publishes reports it)
             if (P.publish) {
                 for (int i = 0; i < 7; ++i) P.publish->x[i] = have ? s_lm.x[i] : (P.use_init ? P.init_pose[i] : P.state->x[i]);
                 P.publish->done = 1 | (s_timeout ? 4 : 0);
@@ -605,6 +609,7 @@ static int fill_track_params(mlh_ctx *ctx, int kind_mask, const TrackArgs &a, Tr
     P.ticket = ctx->ticket.as<unsigned>();
     P.stat = a.stat_slot >= 0 ? ctx->stats.as<IterStatDev>() + a.stat_slot : nullptr;
     P.publish = a.publish; P.publish_seq = a.publish_seq;
+    P.loop_timeout_ticks = ctx->caps.loop_timeout_ticks;
     return MLH_OK;
 }
 
@@ -623,10 +628,17 @@ int track_lm_loop_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)
     TrackParamsDev P;
     int rc = fill_track_params(ctx, kind_mask, a, P);
     if (rc) return rc;
-    if (P.k[0].tiles_b + P.k[1].tiles_b > 256) return fail(ctx, MLH_ERR_INVALID, "track_lm_loop_kernel: more tiles than compute units");
+    // every tile's workgroup has to be resident for the barrier: the host's gate (capi.hip: loop_tiles_ok) is what the device admits, asked at mlh_create
+    if (P.k[0].tiles_b + P.k[1].tiles_b > ctx->caps.loop_max_tiles[2]) return fail(ctx, MLH_ERR_INVALID, "track_lm_loop_kernel: more tiles than can be resident at once on this device");
+    ++ctx->caps.loop_launches;
     MLH_LAUNCH(track_lm_loop_kernel, dim3(P.k[0].tiles_b + P.k[1].tiles_b), dim3(TPB), 0, ctx->stream, P);
     MLH_HIP(ctx, hipGetLastError());
     return MLH_OK;
+}
+
+int track_loop_occupancy(int *blocks_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, track_lm_loop_kernel, TPB, 0) == hipSuccess ? MLH_OK : MLH_ERR_HIP;
 }
 
 int track_linearize_launch(mlh_ctx *ctx, int kind_mask, const TrackArgs &a)

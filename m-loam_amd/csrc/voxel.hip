@@ -911,9 +911,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
                         if (__atomic_load_n(A.host_seq, __ATOMIC_ACQUIRE) != A.seq) return fail(ctx, MLH_ERR_HIP, "the thinned feature counts did not arrive");
                         break;
                     }
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
+                    host_wait_relax(spins);
                 }
                 *n_surf_out = A.host_counts[0];
                 *n_corner_out = A.host_counts[1];
@@ -978,9 +976,7 @@ int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf,
                 if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) return fail(ctx, MLH_ERR_HIP, "the thinned feature counts did not arrive");
                 break;
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            host_wait_relax(spins);
         }
         *n_surf_out = h_counts[0];
         *n_corner_out = h_counts[1];

@@ -889,10 +889,11 @@ def test_rough_scans_extract_thin_and_match(mla, synth, orc, case16, n_rings):
 
 
 @pytest.mark.gpu
-def test_lm_loop_kernel_reports_a_missing_workgroup_instead_of_hanging(mla, case16, feats16, monkeypatch):
+def test_lm_loop_kernel_with_a_missing_workgroup_neither_hangs_nor_loses_the_frame(mla, case16, feats16, monkeypatch):
     """scan2map's LM loop runs as one launch whose workgroups meet at a counter barrier once per iteration. A workgroup that never arrives (MLH_DEBUG_LOOP_STALL=1 makes
-    one skip its second arrival) must not hang the stream: the others give up after their bounded spin, the launch publishes the error bit, the call fails with
-    MLH_ERR_HIP -- and the context goes on working (the barrier's counters are re-armed by the last workgroup to leave)."""
+    one skip its second arrival) must not hang the stream: it says so in the barrier's "given up" word, the others leave at their next look, the launch publishes the
+    failure bit -- and the call solves the frame again through the launch-per-iteration form: the same pose, a counted fallback (mlh_get_info), a context that goes on
+    working (the barrier's counters are re-armed by the last workgroup to leave). tests/test_gpu_residency.py holds the same at BASELINE config 2's size."""
     import time
     c = mla.Context(0)
     try:
@@ -901,10 +902,11 @@ def test_lm_loop_kernel_reports_a_missing_workgroup_instead_of_hanging(mla, case
         ref = c.scan2map(case16["p0"], want_stats=False)[0]
         monkeypatch.setenv("MLH_DEBUG_LOOP_STALL", "1")
         t0 = time.time()
-        with pytest.raises(mla.MlhError) as ei:
-            c.scan2map(case16["p0"], want_stats=False)
-        assert "barrier" in str(ei.value)
-        assert time.time() - t0 < 60.0
+        got = c.scan2map(case16["p0"], want_stats=False)[0]
+        assert time.time() - t0 < 5.0
+        assert np.array_equal(got, ref)
+        di = c.info()
+        assert di["loop_timeouts"] == 1 and di["loop_fallbacks"] == 1
         monkeypatch.delenv("MLH_DEBUG_LOOP_STALL")
         again = c.scan2map(case16["p0"], want_stats=False)[0]
         assert np.array_equal(again, ref)

@@ -1345,7 +1345,7 @@ def test_scan2map_split_submission_equals_the_synchronous_call(mla, case16, feat
         a, sa = c.scan2map_end()
         assert sa == 1 and np.array_equal(a, p0)
         b, sb = c.scan2map_end()
-        assert sb in (0, 1, 2)
+        assert sb == 3          # chained behind a frame that was handed back: whatever its own loops did (here: they overflowed too), it began from a pose that is not a result
         # mixing the two kinds of solves: each is collected by its own _end
         c.gn_solve_begin(p0, 3)
         with pytest.raises(mla.MlhError):
