@@ -344,6 +344,34 @@ def block_sharded_config4(mla, torch, dist, dist_dev, device, rank, world, surf_
         c.close()
 
 
+def framebench_cpp(all_pts, all_start, all_end, ring_ofs, ext, covs, meas, surf_map, corner_map, p0, frames=60, mode="all", timeout=240):
+    """The frame driven from C++ threads through the C-ABI (m-loam_amd/host/framebench.cpp): an estimator-side thread and a mapper-side thread on two contexts
+    (the reference's process structure: estimator.cpp:100 process_thread_, lidar_mapper_keyframe.cpp:1315 mapping_process) -> frame PERIOD; K independent
+    pipelines on the one GPU -> aggregate frames per second. The executable is built by __graft_entry__.build() and travels with the snapshot; its scans are HOST
+    buffers (every frame pays its upload)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "m-loam_amd", "host", "framebench")
+    if not os.path.exists(exe):
+        return dict(error="m-loam_amd/host/framebench has not been built (__graft_entry__.build())")
+    with tempfile.TemporaryDirectory() as d:
+        np.ascontiguousarray(all_pts, np.float32).tofile(os.path.join(d, "fb_points.f32"))
+        np.concatenate([all_start, all_end]).astype(np.int32).tofile(os.path.join(d, "fb_rings.i32"))
+        np.asarray(ring_ofs, np.int32).tofile(os.path.join(d, "fb_ring_ofs.i32"))
+        np.ascontiguousarray(ext, np.float64).tofile(os.path.join(d, "fb_ext.f64"))
+        np.ascontiguousarray(covs, np.float64).tofile(os.path.join(d, "fb_covs.f64"))
+        np.ascontiguousarray(meas, np.float64).tofile(os.path.join(d, "fb_meas.f64"))
+        sm, cm = np.ascontiguousarray(surf_map, np.float32), np.ascontiguousarray(corner_map, np.float32)
+        sm.tofile(os.path.join(d, "fb_surf_map.f32")); cm.tofile(os.path.join(d, "fb_corner_map.f32"))
+        np.array([sm.shape[1] * 4, 1], np.int32).tofile(os.path.join(d, "fb_meta.i32"))
+        np.ascontiguousarray(p0, np.float64).tofile(os.path.join(d, "fb_pose.f64"))
+        r = subprocess.run([exe, d, str(int(frames)), mode], capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return dict(error=(r.stderr.strip() or r.stdout.strip())[-300:], rc=r.returncode)
+    return json.loads(lines[-1])
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` without a launcher: re-run this very command line under torch.distributed.run with N ranks and pass its exit code on"""
     import socket
@@ -984,9 +1012,25 @@ def main():
                               "pipeline) -> index build of both maps -> scan2MapOptimization -> pose; frames one after the other, host waits for every pose. Two host reads "
                               "inside the frame, each a spin on a pinned record a kernel publishes: the fused clouds' counts and bounds (they size the thinning's launches and "
                               "its voxel grids), and the thinned feature counts (they size the solve's launches). The `..._in_one_call` figure uses mlh_downsample_scan2map, where the "
-                              "second of the two is gone (the solve reads the counts on the device)")
+                              "second of the two is gone (the solve reads the counts on the device). The scans' upload (a real frame's ~70 us pageable H2D + 8 us "
+                              "pack) is OUTSIDE these figures; `from_cpp_threads` below starts from host buffers and pays it")
         finally:
             fctx.close()
+        # the same frame from C++ threads through the C-ABI, host scans in: the estimator / mapper pair's frame period and K independent pipelines per GPU
+        try:
+            cpp = framebench_cpp(all_pts, all_start, all_end, ring_ofs, f_ext, f_covs, f_meas, surf_map, corner_map, p0)
+            if frame is not None:
+                frame["from_cpp_threads"] = cpp
+                if "period_ms_two_contexts" in cpp:
+                    frame["period_ms_two_contexts"] = cpp["period_ms_two_contexts"]
+                if "frames_per_s_at_K" in cpp:
+                    frame["frames_per_s_at_K"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K"].items()}
+                frame["from_cpp_threads_note"] = ("m-loam_amd/host/framebench.cpp: host scans in (upload inside the frame), pose out. two contexts = an estimator-side thread "
+                                                  "(upload, extract, fuse, thin) and a mapper-side thread (index, scan2map) with a device-to-device hand-over, as the reference "
+                                                  "runs estimator and mapper concurrently; K = independent whole-frame pipelines (own thread + context each) sharing the GPU; "
+                                                  "every frame of every pipeline returns the single pipeline's pose bits")
+        except Exception as ex:      # (a supplementary leg must not cost the line)
+            print(f"[rank {rank}] frame from C++ threads: {str(ex)[:200]}", file=sys.stderr)
 
     # supplementary (N = 1): what N = 2 / 4 / 8 should show on this frame, per split, from each rank's share solved alone on this GPU
     predicted = None

@@ -61,9 +61,9 @@ int mlh_synchronize(mlh_ctx *ctx);
 /* What mlh_create found on the device, and what the in-kernel Levenberg-Marquardt loops (the one-launch forms of scan2MapOptimization's ceres::Solve,
  * lidar_mapper_keyframe.cpp:586-596, and of trackCloud's, lidar_tracker.cpp:106-113) did with it. Those launches synchronise their workgroups among themselves and
  * therefore need all of them resident at once: loop_max_tiles is the number of 256-feature tiles the context will put behind one such barrier --
- * (hipOccupancyMaxActiveBlocksPerMultiprocessor, at most 8, less one block per compute unit as a margin against the occupancy query's optimism) x the compute
- * units the solver's stream may use, halved once a CU-masked staging stream runs beside it, never more than the 160 tiles beyond which every workgroup
- * re-summing every record stops paying (the fused thinning + solve call: 512). A frame with more tiles, a partitioned or smaller device, a CU-masked solver
+ * min(hipOccupancyMaxActiveBlocksPerMultiprocessor, 6) x the compute units the solver's stream may use, less a margin of an eighth of those compute units (at
+ * least 8; kernels of other streams and contexts are transient and only delay an arrival), never more than the 160 tiles beyond which every workgroup re-summing every record stops
+ * paying (the fused thinning + solve call: 512). A frame with more tiles, a partitioned or smaller device, a CU-masked solver
  * stream (environment at mlh_create: MLH_SOLVER_CU_MASK=<hex word>[,<hex word>...], 32 compute units per word) take the launch-per-iteration forms: the same
  * arithmetic, the same pose bits, no residency requirement. Should a barrier nevertheless not complete within MLH_LOOP_TIMEOUT_US (default 20 000), the frame is
  * solved again through those forms (loop_fallbacks; the caller gets the same pose, later) and loop_max_tiles is halved for the context. MLH_LOOP_MAX_TILES=<n>

@@ -355,9 +355,14 @@ static int query_device_caps(mlh_ctx *c)
     return MLH_OK;
 }
 
-// Workgroups of the loop kernels that may stand behind one in-kernel barrier. Residency: (occupancy query, at most 8, less one block per compute unit -- the query
-// is known to answer one too many for kernels with many scalar registers, MI355X_MICROARCH.md "Residency and cooperative launch") x the compute units the
-// solver's stream may use, halved while a CU-masked staging stream runs its index builds beside it. Redundancy: every workgroup sums every tile's record, which
+// Workgroups of the loop kernels that may stand behind one in-kernel barrier. Residency: blocks per compute unit = min(occupancy query, 8, 6) -- the query is
+// known to answer one too many where the SCALAR registers bind (MI355X_MICROARCH.md "Residency and cooperative launch": admitted = min(API, 8,
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)))); the runtime does not report a kernel's scalar register count, so the rule is applied for the most a wavefront can
+// have (112 -> 6; these kernels: 106 SGPRs, 218 VGPRs -> the query's 2 is the vector registers' and exact) -- x the compute units the solver's stream may use,
+// less a margin of an eighth of them (at least 8 workgroups). What ELSE runs on those compute units -- the staging stream's index builds, other contexts'
+// kernels -- is not subtracted: such kernels end by themselves, so they can delay an arrival by their own duration (tens of microseconds, far inside the
+// barrier's time limit) but cannot keep a workgroup of ours out for good; only our own grid exceeding the device could (tests/test_gpu_residency.py: four
+// contexts' whole frames at once, 1 024-thread sort workgroups in every wave slot, no barrier given up on). Redundancy: every workgroup sums every tile's record, which
 // stops paying beyond GN_DEFER_MAX_TILES (measured, profiles/r04_feature_sweep.txt; the fused thinning + solve call sizes its grid for the un-thinned clouds and
 // accepts up to FUSED_LOOP_MAX_TILES). The smaller of the two; MLH_LOOP_MAX_TILES lowers it further (0: never).
 constexpr int GN_DEFER_MAX_TILES = 160;
@@ -368,9 +373,9 @@ static void set_loop_gates(mlh_ctx *c)
     int by_hand = -1;
     if (const char *e = std::getenv("MLH_LOOP_MAX_TILES")) by_hand = std::max(0, std::atoi(e));
     for (int i = 0; i < 3; ++i) {
-        const int per_cu = std::max(0, std::min(c->caps.blocks_per_cu[i], 8) - 1);
+        const int per_cu = std::max(0, std::min(c->caps.blocks_per_cu[i], 6));
         long long resident = (long long)per_cu * c->caps.cu_solver;
-        if (c->caps.staging_masked) resident /= 2;
+        resident = std::max(0ll, resident - std::max<long long>(c->caps.cu_solver / 8, 8));
         int gate = int(std::min<long long>(resident, by_size[i]));
         if (by_hand >= 0) gate = std::min(gate, by_hand);
         if (c->caps.loop_demoted[i] >= 0) gate = std::min(gate, c->caps.loop_demoted[i]);
@@ -957,8 +962,7 @@ int mlh_map_set_pair_overlapped(mlh_ctx *ctx, const void *surf_points, int n_sur
         if (bits <= 0 || bits >= ctx->caps.cu_count) MLH_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
         else {
             MLH_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->stream2, uint32_t(words.size()), words.data()));
-            ctx->caps.staging_masked = true;      // its launches hold wave slots of those compute units beside the solver's: the loop kernels' residency gate halves
-            set_loop_gates(ctx);
+            ctx->caps.staging_masked = true;
         }
         for (int i = 0; i < 2; ++i) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_set_built[i], hipEventDisableTiming));
     }

@@ -274,7 +274,7 @@ struct mlh_ctx {
         int cu_count = 0;                 // hipDeviceProp_t::multiProcessorCount
         int cu_solver = 0;                // compute units the solver's stream may use (MLH_SOLVER_CU_MASK; otherwise all of them)
         bool solver_masked = false;
-        bool staging_masked = false;      // the staging stream (mlh_map_set_pair_overlapped) exists and is confined to a part of the compute units
+        bool staging_masked = false;      // the staging stream (mlh_map_set_pair_overlapped) exists and is confined to a part of the compute units (informational)
         int loop_demoted[3] = {-1, -1, -1};   // >= 0: a barrier was given up on -- the gate this context keeps below from then on
         int blocks_per_cu[3] = {0, 0, 0}; // hipOccupancyMaxActiveBlocksPerMultiprocessor: lm_loop_kernel<false>, lm_loop_kernel<true>, track_lm_loop_kernel
         int loop_max_tiles[3] = {0, 0, 0};// workgroups of those kernels the host will put behind one in-kernel barrier (0: never -- the launch-per-iteration forms)

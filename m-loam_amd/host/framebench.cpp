@@ -1,14 +1,25 @@
-// One device-resident mapper frame timed THROUGH THE C-ABI FROM C++ (scripts/framebench.py times the same sequence through ctypes: a dozen calls per frame, each
-// with its interpreter overhead): two raw 64-ring scans in (as one joint upload), extractCloud + per-ring voxel grid, fusion, downsampleCurrentScan for both
-// kinds, index rebuild, scan2MapOptimization, pose out. Inputs are the files scripts/framebench.py writes (the bench workload); prints ms per frame by stage.
-//   usage: framebench <dir> [frames]
+// Mapper frames timed THROUGH THE C-ABI FROM C++ (scripts/framebench.py times the same sequence through ctypes: a dozen calls per frame, each with its interpreter
+// overhead). A frame: two raw 64-ring scans in (host buffers, one joint upload), extractCloud + per-ring voxel grid, fusion, downsampleCurrentScan for both kinds,
+// index build of the local map, scan2MapOptimization, pose out. Inputs are the files scripts/framebench.py / bench.py write (the bench workload).
+//   usage: framebench <dir> [frames] [mode]
+//   mode single   (default) one context, one thread: ms per frame by stage, index rebuilt on the critical path / staged beside the front end   (text lines)
+//        two_ctx  the reference's process structure on one GPU: an ESTIMATOR-side thread (upload -> extract -> fuse -> thin; estimator.cpp:100 process_thread_,
+//                 :248-270) and a MAPPER-side thread (index -> scan2map; lidar_mapper_keyframe.cpp:1315 mapping_process) on two contexts, device-to-device
+//                 hand-over (mlh_features_copy): frame PERIOD                                                                                 (one JSON line)
+//        pipes    K = 1 / 2 / 4 independent frame pipelines (K sensor rigs / K bags replayed at once), each a thread with its own context running whole
+//                 frames back to back: aggregate frames per second                                                                            (one JSON line)
+//        all      two_ctx + pipes in one JSON line (what bench.py puts into its `frame` object)
 #include "../../include/mloam_hip.h"
-#include <hip/hip_runtime_api.h>   // only for the device-resident copy of the local map the second loop stages from
+#include <hip/hip_runtime_api.h>   // only for the device-resident copy of the local map the loops stage from
+#include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 template <typename T> static std::vector<T> read_file(const std::string &p)
@@ -23,72 +34,255 @@ template <typename T> static std::vector<T> read_file(const std::string &p)
 }
 #define CK(x) do { const int rc_ = (x); if (rc_) { std::fprintf(stderr, "%s -> %d: %s\n", #x, rc_, mlh_last_error(ctx)); return 1; } } while (0)
 
+using Clock = std::chrono::steady_clock;
+static double ms_between(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+
+struct Work {
+    std::vector<float> pts, surf_map, corner_map;
+    std::vector<int32_t> rings, ring_ofs, meta;
+    std::vector<double> ext, covs, meas, p0;
+    int R = 0, n = 0, n_lidar = 0, map_stride = 0, n_surf_map = 0, n_corner_map = 0;
+    void *d_surf = nullptr, *d_corner = nullptr;     // the local map, device-resident (a mapper that assembles it from keyframe clouds on the GPU has it there)
+    mlh_solver_opts o;
+};
+
+static int front_end(mlh_ctx *ctx, const Work &W)
+{
+    CK(mlh_fuse_reset(ctx));
+    CK(mlh_scan_upload(ctx, W.pts.data(), 16, 12, W.n, W.rings.data(), W.rings.data() + W.R, W.R, MLH_MEM_HOST));
+    CK(mlh_extract_run(ctx));
+    CK(mlh_extract_voxel_run(ctx, 0.2f));
+    for (int i = 0; i < W.n_lidar; ++i) CK(mlh_fuse_add_rings(ctx, W.ring_ofs[size_t(i)], W.ring_ofs[size_t(i) + 1], i, W.ext.data() + 7 * i));
+    return 0;
+}
+static int thin(mlh_ctx *ctx, const Work &W, int32_t *ms_, int32_t *mc)
+{
+    const void *fs = nullptr, *fc = nullptr;
+    int32_t ns = 0, nc = 0;
+    CK(mlh_fused_cloud(ctx, MLH_SURF, &fs, &ns));
+    CK(mlh_fused_cloud(ctx, MLH_CORNER, &fc, &nc));
+    CK(mlh_downsample_current_scan_pair(ctx, fs, ns, fc, nc, 16, 12, MLH_MEM_DEVICE, 0.4f, 0.2f, W.ext.data(), W.covs.data(), W.n_lidar, W.meas.data(), W.meta[1], 0.6, ms_, mc));
+    return 0;
+}
+static int stage_map_beside(mlh_ctx *ctx, const Work &W)
+{
+    CK(mlh_map_set_pair_overlapped(ctx, W.d_surf, W.n_surf_map, W.d_corner, W.n_corner_map, W.map_stride, 1.0f, MLH_MEM_DEVICE));
+    return 0;
+}
+// one whole frame on one context, the local map staged and indexed beside the front end
+static int whole_frame(mlh_ctx *ctx, const Work &W, double pose[7])
+{
+    if (front_end(ctx, W)) return 1;
+    if (stage_map_beside(ctx, W)) return 1;
+    int32_t a = 0, b = 0;
+    if (thin(ctx, W, &a, &b)) return 1;
+    for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
+    CK(mlh_scan2map(ctx, pose, &W.o, nullptr));
+    return 0;
+}
+static mlh_ctx *make_ctx(const Work &W)
+{
+    mlh_ctx *ctx = nullptr;
+    if (mlh_create(&ctx, 0)) { std::fprintf(stderr, "no GPU context\n"); return nullptr; }
+    if (mlh_map_set_pair(ctx, W.d_surf, W.n_surf_map, W.d_corner, W.n_corner_map, W.map_stride, 1.0f, MLH_MEM_DEVICE)) { std::fprintf(stderr, "map_set_pair: %s\n", mlh_last_error(ctx)); return nullptr; }
+    return ctx;
+}
+static bool same_pose(const double a[7], const double b[7]) { return std::memcmp(a, b, 7 * sizeof(double)) == 0; }
+
+// a counter the other thread waits on (C++17: no std::counting_semaphore); the waits are tens of microseconds
+struct Signal {
+    std::atomic<long> v{0};
+    void post() { v.fetch_add(1, std::memory_order_release); }
+    void wait_for(long k) { unsigned s = 0; while (v.load(std::memory_order_acquire) < k) { if (++s > 256) std::this_thread::yield(); } }
+};
+
+// ---- two contexts, two threads: the frame period of the estimator / mapper pair
+static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], double *period_ms, bool *same, double *est_alone_ms, double *map_alone_ms)
+{
+    mlh_ctx *E = make_ctx(W), *M = make_ctx(W);
+    if (!E || !M) return 1;
+    const int warm = 5, total = frames + warm;
+    // each side alone first (what the period cannot be shorter than)
+    {
+        mlh_ctx *ctx = E;
+        int32_t a = 0, b = 0;
+        for (int k = 0; k < 3; ++k) { if (front_end(ctx, W) || thin(ctx, W, &a, &b)) return 1; }
+        const auto t0 = Clock::now();
+        for (int k = 0; k < frames; ++k) { if (front_end(ctx, W) || thin(ctx, W, &a, &b)) return 1; }
+        *est_alone_ms = ms_between(t0, Clock::now()) / frames;
+        ctx = M;
+        double pose[7];
+        CK(mlh_features_copy(M, E, MLH_SURF)); CK(mlh_features_copy(M, E, MLH_CORNER));
+        for (int k = 0; k < 3; ++k) { CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS)); for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)]; CK(mlh_scan2map(ctx, pose, &W.o, nullptr)); }
+        const auto t1 = Clock::now();
+        for (int k = 0; k < frames; ++k) {
+            CK(mlh_features_copy(M, E, MLH_SURF)); CK(mlh_features_copy(M, E, MLH_CORNER));
+            CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
+            for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
+            CK(mlh_scan2map(ctx, pose, &W.o, nullptr));
+        }
+        *map_alone_ms = ms_between(t1, Clock::now()) / frames;
+    }
+    Signal ready, copied;
+    std::atomic<int> failed{0};
+    std::vector<double> poses(size_t(total) * 7, 0.0);
+    Clock::time_point t_start, t_end;
+    std::thread est([&] {
+        mlh_ctx *ctx = E;
+        for (int k = 0; k < total && !failed.load(); ++k) {
+            if (k == warm) t_start = Clock::now();
+            int32_t a = 0, b = 0;
+            if (front_end(ctx, W)) { failed = 1; break; }
+            copied.wait_for(k);                      // the mapper side has taken frame k - 1's features: this context's sets may be overwritten
+            if (thin(ctx, W, &a, &b)) { failed = 1; break; }
+            ready.post();
+        }
+        ready.v.store(1L << 40);
+    });
+    std::thread map([&] {
+        mlh_ctx *ctx = M;
+        for (int k = 0; k < total && !failed.load(); ++k) {
+            // the local map does not wait for the scan (it is made of earlier keyframes): indexed while the estimator side is still busy with frame k
+            if (mlh_map_rebuild(ctx, MLH_ALL_KINDS)) { failed = 1; break; }
+            ready.wait_for(k + 1);
+            if (failed.load()) break;
+            if (mlh_features_copy(M, E, MLH_SURF) || mlh_features_copy(M, E, MLH_CORNER)) { std::fprintf(stderr, "features_copy: %s\n", mlh_last_error(M)); failed = 1; break; }
+            copied.post();
+            double *pose = poses.data() + size_t(k) * 7;
+            for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
+            if (mlh_scan2map(ctx, pose, &W.o, nullptr)) { std::fprintf(stderr, "scan2map: %s\n", mlh_last_error(M)); failed = 1; break; }
+        }
+        t_end = Clock::now();
+        copied.v.store(1L << 40);
+    });
+    est.join(); map.join();
+    if (failed.load()) return 1;
+    *period_ms = ms_between(t_start, t_end) / frames;
+    *same = true;
+    for (int k = 0; k < total; ++k) *same = *same && same_pose(poses.data() + size_t(k) * 7, ref_pose);
+    mlh_destroy(E); mlh_destroy(M);
+    return 0;
+}
+
+// ---- K independent pipelines: aggregate frames per second
+static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7], double *fps, bool *same, unsigned long long *timeouts)
+{
+    std::vector<mlh_ctx *> ctxs;
+    for (int i = 0; i < K; ++i) { mlh_ctx *c = make_ctx(W); if (!c) return 1; ctxs.push_back(c); }
+    std::atomic<int> failed{0}, started{0};
+    std::atomic<bool> go{false};
+    std::vector<char> ok(size_t(K), 1);
+    std::vector<std::thread> th;
+    for (int i = 0; i < K; ++i)
+        th.emplace_back([&, i] {
+            double pose[7];
+            for (int k = 0; k < 5; ++k) if (whole_frame(ctxs[size_t(i)], W, pose)) { failed = 1; }
+            started.fetch_add(1);
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            for (int k = 0; k < frames && !failed.load(); ++k) {
+                if (whole_frame(ctxs[size_t(i)], W, pose)) { failed = 1; break; }
+                if (!same_pose(pose, ref_pose)) ok[size_t(i)] = 0;
+            }
+        });
+    while (started.load() < K) std::this_thread::yield();
+    const auto t0 = Clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto &t : th) t.join();
+    const double ms = ms_between(t0, Clock::now());
+    if (failed.load()) return 1;
+    *fps = 1e3 * double(K) * double(frames) / ms;
+    *same = true;
+    for (char c : ok) *same = *same && c;
+    *timeouts = 0;
+    for (mlh_ctx *c : ctxs) { mlh_device_info di; if (!mlh_get_info(c, &di)) *timeouts += di.loop_timeouts; mlh_destroy(c); }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s <dir> [frames]\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <dir> [frames] [single|two_ctx|pipes|all]\n", argv[0]); return 2; }
     const std::string d = std::string(argv[1]) + "/";
     const int frames = argc > 2 ? std::atoi(argv[2]) : 50;
-    const auto pts = read_file<float>(d + "fb_points.f32");           // both scans, rings back to back: x y z intensity
-    const auto rings = read_file<int32_t>(d + "fb_rings.i32");        // [start (R)] [end (R)]
-    const auto ring_ofs = read_file<int32_t>(d + "fb_ring_ofs.i32");  // ring range of every LiDAR (n_lidar + 1)
-    const auto ext = read_file<double>(d + "fb_ext.f64");             // n_lidar x 7
-    const auto covs = read_file<double>(d + "fb_covs.f64");           // n_lidar x 36
-    const auto meas = read_file<double>(d + "fb_meas.f64");           // 9
-    const auto surf_map = read_file<float>(d + "fb_surf_map.f32"), corner_map = read_file<float>(d + "fb_corner_map.f32");   // x y z (+ fields): stride in fb_meta
-    const auto meta = read_file<int32_t>(d + "fb_meta.i32");          // [map stride bytes, with_ua]
-    const auto p0 = read_file<double>(d + "fb_pose.f64");
-    const int R = int(rings.size() / 2), n = int(pts.size() / 4), n_lidar = int(ring_ofs.size()) - 1, map_stride = meta[0];
+    const std::string mode = argc > 3 ? argv[3] : "single";
+    Work W;
+    W.pts = read_file<float>(d + "fb_points.f32");           // both scans, rings back to back: x y z intensity
+    W.rings = read_file<int32_t>(d + "fb_rings.i32");        // [start (R)] [end (R)]
+    W.ring_ofs = read_file<int32_t>(d + "fb_ring_ofs.i32");  // ring range of every LiDAR (n_lidar + 1)
+    W.ext = read_file<double>(d + "fb_ext.f64");             // n_lidar x 7
+    W.covs = read_file<double>(d + "fb_covs.f64");           // n_lidar x 36
+    W.meas = read_file<double>(d + "fb_meas.f64");           // 9
+    W.surf_map = read_file<float>(d + "fb_surf_map.f32"); W.corner_map = read_file<float>(d + "fb_corner_map.f32");   // x y z (+ fields): stride in fb_meta
+    W.meta = read_file<int32_t>(d + "fb_meta.i32");          // [map stride bytes, with_ua]
+    W.p0 = read_file<double>(d + "fb_pose.f64");
+    W.R = int(W.rings.size() / 2); W.n = int(W.pts.size() / 4); W.n_lidar = int(W.ring_ofs.size()) - 1; W.map_stride = W.meta[0];
+    W.n_surf_map = int(W.surf_map.size() * 4 / size_t(W.map_stride)); W.n_corner_map = int(W.corner_map.size() * 4 / size_t(W.map_stride));
+    mlh_solver_opts_default(&W.o);
+    if (W.meta[1]) W.o.flags |= MLH_FLAG_WITH_UA;
     mlh_ctx *ctx = nullptr;
     if (mlh_create(&ctx, 0)) { std::fprintf(stderr, "no GPU context\n"); return 1; }
-    CK(mlh_map_set_pair(ctx, surf_map.data(), int(surf_map.size() * 4 / size_t(map_stride)), corner_map.data(), int(corner_map.size() * 4 / size_t(map_stride)), map_stride, 1.0f, MLH_MEM_HOST));
-    mlh_solver_opts o;
-    mlh_solver_opts_default(&o);
-    if (meta[1]) o.flags |= MLH_FLAG_WITH_UA;
+    if (hipMalloc(&W.d_surf, W.surf_map.size() * 4) != hipSuccess || hipMalloc(&W.d_corner, W.corner_map.size() * 4) != hipSuccess ||
+        hipMemcpy(W.d_surf, W.surf_map.data(), W.surf_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(W.d_corner, W.corner_map.data(), W.corner_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "device copy of the maps failed\n"); return 1; }
+    CK(mlh_map_set_pair(ctx, W.surf_map.data(), W.n_surf_map, W.corner_map.data(), W.n_corner_map, W.map_stride, 1.0f, MLH_MEM_HOST));
     double pose[7], t_stage[3] = {0, 0, 0};
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    // mode 0: the index of the local map rebuilt between the thinning and the solve (on the frame's critical path);
-    // mode 1: the local map (device-resident, as a mapper that assembles it from keyframe clouds on the GPU has it) staged and indexed beside the front end:
-    //         mlh_map_set_pair_overlapped after the front end's launches are enqueued, before the first call that waits for them
-    void *d_surf = nullptr, *d_corner = nullptr;
-    if (hipMalloc(&d_surf, surf_map.size() * 4) != hipSuccess || hipMalloc(&d_corner, corner_map.size() * 4) != hipSuccess ||
-        hipMemcpy(d_surf, surf_map.data(), surf_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_corner, corner_map.data(), corner_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "device copy of the maps failed\n"); return 1; }
-    const int n_surf_map = int(surf_map.size() * 4 / size_t(map_stride)), n_corner_map = int(corner_map.size() * 4 / size_t(map_stride));
-    const int stage_pos = std::getenv("FB_STAGE_POS") ? std::atoi(std::getenv("FB_STAGE_POS")) : 3;   // where in the front end the staging call sits (3: after the last launch)
-    for (int mode = 0; mode < 2; ++mode) {
-        t_stage[0] = t_stage[1] = t_stage[2] = 0.0;
-        for (int it = -5; it < frames; ++it) {
-            const auto t0 = now();
-            CK(mlh_fuse_reset(ctx));
-            if (mode == 1 && stage_pos == 0) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
-            CK(mlh_scan_upload(ctx, pts.data(), 16, 12, n, rings.data(), rings.data() + R, R, MLH_MEM_HOST));
-            if (mode == 1 && stage_pos == 1) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
-            CK(mlh_extract_run(ctx));
-            if (mode == 1 && stage_pos == 2) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
-            CK(mlh_extract_voxel_run(ctx, 0.2f));
-            for (int i = 0; i < n_lidar; ++i) CK(mlh_fuse_add_rings(ctx, ring_ofs[size_t(i)], ring_ofs[size_t(i) + 1], i, ext.data() + 7 * i));
-            if (mode == 1 && stage_pos == 3) CK(mlh_map_set_pair_overlapped(ctx, d_surf, n_surf_map, d_corner, n_corner_map, map_stride, 1.0f, MLH_MEM_DEVICE));
-            const auto t1 = now();
-            const void *fs = nullptr, *fc = nullptr;
-            int32_t ns = 0, nc = 0, ms_ = 0, mc = 0;
-            CK(mlh_fused_cloud(ctx, MLH_SURF, &fs, &ns));
-            CK(mlh_fused_cloud(ctx, MLH_CORNER, &fc, &nc));
-            CK(mlh_downsample_current_scan_pair(ctx, fs, ns, fc, nc, 16, 12, MLH_MEM_DEVICE, 0.4f, 0.2f, ext.data(), covs.data(), n_lidar, meas.data(), meta[1], 0.6, &ms_, &mc));
-            const auto t2 = now();
-            if (mode == 0) CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
-            for (int i = 0; i < 7; ++i) pose[i] = p0[size_t(i)];
-            CK(mlh_scan2map(ctx, pose, &o, nullptr));
-            const auto t3 = now();
-            if (it >= 0) { t_stage[0] += ms(t0, t1); t_stage[1] += ms(t1, t2); t_stage[2] += ms(t2, t3); }
+    if (mode == "single") {
+        // mode 0: the index of the local map rebuilt between the thinning and the solve (on the frame's critical path);
+        // mode 1: the local map staged and indexed beside the front end: mlh_map_set_pair_overlapped after the front end's launches are enqueued, before the
+        //         first call that waits for them
+        for (int m = 0; m < 2; ++m) {
+            t_stage[0] = t_stage[1] = t_stage[2] = 0.0;
+            for (int it = -5; it < frames; ++it) {
+                const auto t0 = Clock::now();
+                if (front_end(ctx, W)) return 1;
+                if (m == 1 && stage_map_beside(ctx, W)) return 1;
+                const auto t1 = Clock::now();
+                int32_t ms_ = 0, mc = 0;
+                if (thin(ctx, W, &ms_, &mc)) return 1;
+                const auto t2 = Clock::now();
+                if (m == 0) CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
+                for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
+                CK(mlh_scan2map(ctx, pose, &W.o, nullptr));
+                const auto t3 = Clock::now();
+                if (it >= 0) { t_stage[0] += ms_between(t0, t1); t_stage[1] += ms_between(t1, t2); t_stage[2] += ms_between(t2, t3); }
+            }
+            std::printf("%s, ms per frame: upload+extract+fuse%s %.3f downsample %.3f scan2map %.3f total %.3f  pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n",
+                        m == 0 ? "C++ over the C-ABI, device-resident, one launch set, both kinds thinned in one pipeline"
+                               : "  the same with the local map staged and indexed beside the front end (second stream, other map set)",
+                        m == 0 ? "" : "+map staging", t_stage[0] / frames, t_stage[1] / frames, t_stage[2] / frames, (t_stage[0] + t_stage[1] + t_stage[2]) / frames,
+                        pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
         }
-        std::printf("%s, ms per frame: upload+extract+fuse%s %.3f downsample %.3f scan2map %.3f total %.3f  pose %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n",
-                    mode == 0 ? "C++ over the C-ABI, device-resident, one launch set, both kinds thinned in one pipeline"
-                              : "  the same with the local map staged and indexed beside the front end (second stream, other map set)",
-                    mode == 0 ? "" : "+map staging", t_stage[0] / frames, t_stage[1] / frames, t_stage[2] / frames, (t_stage[0] + t_stage[1] + t_stage[2]) / frames,
-                    pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
+        mlh_destroy(ctx);
+        return 0;
     }
-    (void)hipFree(d_surf); (void)hipFree(d_corner);
+    // the pose every pipeline has to reproduce, and one pipeline's latency
+    double ref_pose[7];
+    for (int k = 0; k < 5; ++k) if (whole_frame(ctx, W, ref_pose)) return 1;
+    const auto tl = Clock::now();
+    for (int k = 0; k < frames; ++k) if (whole_frame(ctx, W, pose)) return 1;
+    const double latency_ms = ms_between(tl, Clock::now()) / frames;
     mlh_destroy(ctx);
+    std::printf("{\"frames\": %d, \"ms_per_frame_one_pipeline\": %.4f", frames, latency_ms);
+    if (mode == "two_ctx" || mode == "all") {
+        double period = 0, ea = 0, ma = 0;
+        bool same = false;
+        if (run_two_ctx(W, frames, ref_pose, &period, &same, &ea, &ma)) return 1;
+        std::printf(", \"period_ms_two_contexts\": %.4f, \"two_contexts_same_pose\": %s, \"estimator_side_alone_ms\": %.4f, \"mapper_side_alone_ms\": %.4f", period, same ? "true" : "false", ea, ma);
+    }
+    if (mode == "pipes" || mode == "all") {
+        std::printf(", \"frames_per_s_at_K\": {");
+        double fps1 = 0;
+        const int Ks[4] = {1, 2, 4, 8};
+        for (int i = 0; i < 4; ++i) {
+            double fps = 0;
+            bool same = false;
+            unsigned long long to = 0;
+            if (run_pipes(W, Ks[i], frames, ref_pose, &fps, &same, &to)) return 1;
+            if (i == 0) fps1 = fps;
+            std::printf("%s\"%d\": {\"frames_per_s\": %.1f, \"vs_K1\": %.3f, \"same_pose\": %s, \"barriers_given_up\": %llu}", i ? ", " : "", Ks[i], fps, fps / fps1, same ? "true" : "false", to);
+        }
+        std::printf("}");
+    }
+    std::printf("}\n");
+    (void)hipFree(W.d_surf); (void)hipFree(W.d_corner);
     return 0;
 }

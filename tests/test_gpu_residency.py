@@ -59,6 +59,11 @@ def _mask_words(n_cu):
     return ",".join(words)
 
 
+def _gate(occ, n_cu, cap):
+    """capi.hip: set_loop_gates, for a context without a masked staging stream"""
+    return min(cap, max(0, min(occ, 6) * n_cu - max(n_cu // 8, 8)))
+
+
 def test_device_info_is_asked_not_assumed(mla):
     c = mla.Context(0)
     try:
@@ -66,16 +71,16 @@ def test_device_info_is_asked_not_assumed(mla):
         assert di["cu_count"] > 0 and di["cu_solver"] == di["cu_count"]
         for occ, gate, cap in zip(di["loop_blocks_per_cu"], di["loop_max_tiles"], (160, 512, 160)):
             assert 1 <= occ <= 16
-            assert gate == min(cap, (min(occ, 8) - 1) * di["cu_count"])
+            assert gate == _gate(occ, di["cu_count"], cap)
         assert di["loop_launches"] == di["loop_timeouts"] == di["loop_fallbacks"] == 0
     finally:
         c.close()
 
 
-@pytest.mark.parametrize("n_cu", [16, 32, 64])
+@pytest.mark.parametrize("n_cu", [16, 32, 64, 96])
 def test_cu_masked_solver_stream_same_pose_bits_and_the_loop_only_where_it_fits(mla, cfg2, n_cu):
     """scan2map (synchronous and split submission) and the 5-GN solve on a solver stream confined to n_cu compute units: the poses of the whole device, bit for bit; the
-    one-launch loop is taken exactly when the frame's tiles fit the (occupancy - 1) x n_cu gate; no barrier is ever given up on."""
+    one-launch loop is taken exactly when the frame's tiles fit the gate computed for n_cu compute units; no barrier is ever given up on."""
     full = mla.Context(0)
     try:
         tiles = _stage(full, mla, cfg2)
@@ -90,7 +95,7 @@ def test_cu_masked_solver_stream_same_pose_bits_and_the_loop_only_where_it_fits(
         di = c.info()
         assert di["cu_solver"] == n_cu and di["cu_count"] == di_full["cu_count"]
         gate = di["loop_max_tiles"][0]
-        assert gate == min(160, (min(di["loop_blocks_per_cu"][0], 8) - 1) * n_cu)
+        assert gate == _gate(di["loop_blocks_per_cu"][0], n_cu, 160)
         assert _stage(c, mla, cfg2) == tiles
         for _ in range(20):
             got = c.scan2map(cfg2["p0"], want_stats=False)[0]
@@ -147,12 +152,12 @@ def test_fused_thinning_plus_solve_call_at_its_tile_bound(mla, cfg2):
         ref.map_set_pair(cfg2["surf_map"], cfg2["corner_map"])
         want, want_cnt = _frame(ref, mla, cfg2, opts, False)
         bound = (ref.fused_cloud(mla.SURF).n + 255) // 256 + (ref.fused_cloud(mla.CORNER).n + 255) // 256
-        per_cu = min(ref.info()["loop_blocks_per_cu"][1], 8) - 1
+        occ1 = ref.info()["loop_blocks_per_cu"][1]
         n_total = ref.info()["cu_count"]
     finally:
         ref.close()
     assert 160 < bound <= 512
-    n_cu = (bound + per_cu - 1) // per_cu              # the fewest compute units whose gate admits the bound
+    n_cu = next((n for n in range(1, n_total + 1) if _gate(occ1, n, 512) >= bound), n_total + 1)      # the fewest compute units whose gate admits the bound
     if n_cu > n_total:
         pytest.skip("the device has fewer compute units than the bound needs")
     for cus, fused_form in ((n_cu, True), (n_cu - 1, False)):
