@@ -1,7 +1,7 @@
 // Mapper frames timed THROUGH THE C-ABI FROM C++ (scripts/framebench.py times the same sequence through ctypes: a dozen calls per frame, each with its interpreter
 // overhead). A frame: two raw 64-ring scans in (host buffers, one joint upload), extractCloud + per-ring voxel grid, fusion, downsampleCurrentScan for both kinds,
 // index build of the local map, scan2MapOptimization, pose out. Inputs are the files scripts/framebench.py / bench.py write (the bench workload).
-//   usage: framebench <dir> [frames] [mode]
+//   usage: framebench <dir> [frames] [mode] [pipeline counts, e.g. 1,2,4]
 //   mode single   (default) one context, one thread: ms per frame by stage, index rebuilt on the critical path / staged beside the front end   (text lines)
 //        two_ctx  the reference's process structure on one GPU: an ESTIMATOR-side thread (upload -> extract -> fuse -> thin; estimator.cpp:100 process_thread_,
 //                 :248-270) and a MAPPER-side thread (index -> scan2map; lidar_mapper_keyframe.cpp:1315 mapping_process) on two contexts, device-to-device
@@ -43,13 +43,15 @@ struct Work {
     std::vector<double> ext, covs, meas, p0;
     int R = 0, n = 0, n_lidar = 0, map_stride = 0, n_surf_map = 0, n_corner_map = 0;
     void *d_surf = nullptr, *d_corner = nullptr;     // the local map, device-resident (a mapper that assembles it from keyframe clouds on the GPU has it there)
+    void *d_pts = nullptr, *d_rings = nullptr;       // FB_DEVICE_SCAN=1: the scans resident in HBM too (no upload inside the frame: bench.py's `frame` convention)
     mlh_solver_opts o;
 };
 
 static int front_end(mlh_ctx *ctx, const Work &W)
 {
     CK(mlh_fuse_reset(ctx));
-    CK(mlh_scan_upload(ctx, W.pts.data(), 16, 12, W.n, W.rings.data(), W.rings.data() + W.R, W.R, MLH_MEM_HOST));
+    if (W.d_pts) CK(mlh_scan_upload(ctx, W.d_pts, 16, 12, W.n, static_cast<const int32_t *>(W.d_rings), static_cast<const int32_t *>(W.d_rings) + W.R, W.R, MLH_MEM_DEVICE));
+    else CK(mlh_scan_upload(ctx, W.pts.data(), 16, 12, W.n, W.rings.data(), W.rings.data() + W.R, W.R, MLH_MEM_HOST));
     CK(mlh_extract_run(ctx));
     CK(mlh_extract_voxel_run(ctx, 0.2f));
     for (int i = 0; i < W.n_lidar; ++i) CK(mlh_fuse_add_rings(ctx, W.ring_ofs[size_t(i)], W.ring_ofs[size_t(i) + 1], i, W.ext.data() + 7 * i));
@@ -69,15 +71,25 @@ static int stage_map_beside(mlh_ctx *ctx, const Work &W)
     CK(mlh_map_set_pair_overlapped(ctx, W.d_surf, W.n_surf_map, W.d_corner, W.n_corner_map, W.map_stride, 1.0f, MLH_MEM_DEVICE));
     return 0;
 }
-// one whole frame on one context, the local map staged and indexed beside the front end
-static int whole_frame(mlh_ctx *ctx, const Work &W, double pose[7])
+// one whole frame on one context, the local map staged and indexed beside the front end; st (nullable): host wall time of the four parts, accumulated [ms]
+// FB_ONE_STREAM=1: the index is rebuilt on the context's own stream between thinning and solve instead -- one stream per pipeline. A process gets FOUR hardware
+// queues out of this GPU (scripts/exp/launch_rate.hip: streams beyond four share queues and their kernels serialise; asking the runtime for more queues is
+// slower still), so K = 4 pipelines with a staging stream each are eight streams on four queues.
+static bool g_one_stream = std::getenv("FB_ONE_STREAM") && std::atoi(std::getenv("FB_ONE_STREAM")) != 0;
+static int whole_frame(mlh_ctx *ctx, const Work &W, double pose[7], double *st = nullptr)
 {
+    const auto t0 = Clock::now();
     if (front_end(ctx, W)) return 1;
-    if (stage_map_beside(ctx, W)) return 1;
+    const auto t1 = Clock::now();
+    if (!g_one_stream && stage_map_beside(ctx, W)) return 1;
+    const auto t2 = Clock::now();
     int32_t a = 0, b = 0;
     if (thin(ctx, W, &a, &b)) return 1;
+    const auto t3 = Clock::now();
+    if (g_one_stream) CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
     for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
     CK(mlh_scan2map(ctx, pose, &W.o, nullptr));
+    if (st) { const auto t4 = Clock::now(); st[0] += ms_between(t0, t1); st[1] += ms_between(t1, t2); st[2] += ms_between(t2, t3); st[3] += ms_between(t3, t4); }
     return 0;
 }
 static mlh_ctx *make_ctx(const Work &W)
@@ -165,8 +177,11 @@ static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], doub
 }
 
 // ---- K independent pipelines: aggregate frames per second
-static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7], double *fps, bool *same, unsigned long long *timeouts)
+static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7], double *fps, bool *same, unsigned long long *timeouts, double stage_ms[4])
 {
+    // more than two pipelines: one stream each (the index on the pipeline's own stream), unless FB_ONE_STREAM says otherwise -- see whole_frame
+    if (!std::getenv("FB_ONE_STREAM")) g_one_stream = K > 2;
+    std::vector<double> st(size_t(K) * 4, 0.0);
     std::vector<mlh_ctx *> ctxs;
     for (int i = 0; i < K; ++i) { mlh_ctx *c = make_ctx(W); if (!c) return 1; ctxs.push_back(c); }
     std::atomic<int> failed{0}, started{0};
@@ -180,7 +195,7 @@ static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7],
             started.fetch_add(1);
             while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
             for (int k = 0; k < frames && !failed.load(); ++k) {
-                if (whole_frame(ctxs[size_t(i)], W, pose)) { failed = 1; break; }
+                if (whole_frame(ctxs[size_t(i)], W, pose, st.data() + 4 * size_t(i))) { failed = 1; break; }
                 if (!same_pose(pose, ref_pose)) ok[size_t(i)] = 0;
             }
         });
@@ -193,6 +208,7 @@ static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7],
     *fps = 1e3 * double(K) * double(frames) / ms;
     *same = true;
     for (char c : ok) *same = *same && c;
+    for (int j = 0; j < 4; ++j) { stage_ms[j] = 0.0; for (int i = 0; i < K; ++i) stage_ms[j] += st[size_t(i) * 4 + size_t(j)] / (double(K) * frames); }
     *timeouts = 0;
     for (mlh_ctx *c : ctxs) { mlh_device_info di; if (!mlh_get_info(c, &di)) *timeouts += di.loop_timeouts; mlh_destroy(c); }
     return 0;
@@ -223,6 +239,11 @@ int main(int argc, char **argv)
     if (hipMalloc(&W.d_surf, W.surf_map.size() * 4) != hipSuccess || hipMalloc(&W.d_corner, W.corner_map.size() * 4) != hipSuccess ||
         hipMemcpy(W.d_surf, W.surf_map.data(), W.surf_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(W.d_corner, W.corner_map.data(), W.corner_map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "device copy of the maps failed\n"); return 1; }
+    if (std::getenv("FB_DEVICE_SCAN") && std::atoi(std::getenv("FB_DEVICE_SCAN")) != 0) {
+        if (hipMalloc(&W.d_pts, W.pts.size() * 4) != hipSuccess || hipMalloc(&W.d_rings, W.rings.size() * 4) != hipSuccess ||
+            hipMemcpy(W.d_pts, W.pts.data(), W.pts.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(W.d_rings, W.rings.data(), W.rings.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { std::fprintf(stderr, "device copy of the scans failed\n"); return 1; }
+    }
     CK(mlh_map_set_pair(ctx, W.surf_map.data(), W.n_surf_map, W.corner_map.data(), W.n_corner_map, W.map_stride, 1.0f, MLH_MEM_HOST));
     double pose[7], t_stage[3] = {0, 0, 0};
     if (mode == "single") {
@@ -271,14 +292,21 @@ int main(int argc, char **argv)
     if (mode == "pipes" || mode == "all") {
         std::printf(", \"frames_per_s_at_K\": {");
         double fps1 = 0;
-        const int Ks[4] = {1, 2, 4, 8};
-        for (int i = 0; i < 4; ++i) {
+        std::vector<int> Ks = {1, 2, 3, 4, 6, 8};
+        if (argc > 4) {                  // "1,2,4": the pipeline counts to run
+            Ks.clear();
+            for (const char *q = argv[4]; *q;) { Ks.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        }
+        for (size_t i = 0; i < Ks.size(); ++i) {
             double fps = 0;
             bool same = false;
             unsigned long long to = 0;
-            if (run_pipes(W, Ks[i], frames, ref_pose, &fps, &same, &to)) return 1;
+            double sm[4];
+            if (run_pipes(W, Ks[i], frames, ref_pose, &fps, &same, &to, sm)) return 1;
             if (i == 0) fps1 = fps;
-            std::printf("%s\"%d\": {\"frames_per_s\": %.1f, \"vs_K1\": %.3f, \"same_pose\": %s, \"barriers_given_up\": %llu}", i ? ", " : "", Ks[i], fps, fps / fps1, same ? "true" : "false", to);
+            std::printf("%s\"%d\": {\"frames_per_s\": %.1f, \"vs_K1\": %.3f, \"streams_per_pipeline\": %d, \"same_pose\": %s, \"barriers_given_up\": %llu, "
+                        "\"host_ms_per_frame\": {\"upload_extract_fuse\": %.3f, \"map_staged_beside\": %.3f, \"thin\": %.3f, \"scan2map\": %.3f}}",
+                        i ? ", " : "", Ks[i], fps, fps / fps1, g_one_stream ? 1 : 2, same ? "true" : "false", to, sm[0], sm[1], sm[2], sm[3]);
         }
         std::printf("}");
     }
