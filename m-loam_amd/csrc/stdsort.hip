@@ -37,6 +37,7 @@
 #include "stdsort_dev.hpp"
 #include <climits>
 #include <cstdlib>
+#include <mutex>
 
 namespace mlh {
 
@@ -51,7 +52,10 @@ __device__ unsigned long long g_stage_clk_sort[1024 * 8];
 __device__ unsigned long long g_stage_clk_sort2[1024 * 16];
 #define MLH_SACC(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) atomicAdd(&g_stage_clk_sort2[blockIdx.x * 16 + (i)], (unsigned long long)(v)); } while (0)
 #define MLH_SCLK() wall_clock64()
+__device__ unsigned long long g_stage_clk_mid[1024 * 16];
+#define MLH_MACC(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_stage_clk_mid[blockIdx.x * 16 + (i)] += (unsigned long long)(v); } while (0)
 #else
+#define MLH_MACC(i, v) do { } while (0)
 #define MLH_SSTAGE(i) do { } while (0)
 #define MLH_SACC(i, v) do { } while (0)
 #define MLH_SCLK() 0ull
@@ -97,6 +101,15 @@ constexpr int SS_WIDE_WAVE = SS_WIDE_CHUNK / SS_BIG_WAVES;       // 256 elements
 constexpr int SS_WIDE_MAXW = 1024;                               // wavefront chunks per range the pairing phase indexes: ranges of up to 262 144 elements
 constexpr int SS_WIDE_INFO = 16;                                 // ints per wide range in the info block
 constexpr int SS_LEAF_WG = 1024;
+// The mid launch (round 6): what the wide levels leave longer than a leaf is finished -- down to pieces of at most SS_LEAF elements -- by ONE launch in which a
+// workgroup takes a range of up to SS_MID elements into LDS (keys, vals and the two stop tables: 128 KB) and partitions it workgroup-wide there, piece by piece,
+// until every piece fits a leaf. Through round 5 these were seven more big levels: a launch each (~9 us: eight dependent trips to global memory for a range of a
+// few thousand elements) for a chain of 2-4 partitions per range. Same partition function (wg_partition), same cuts.
+#ifndef MLH_SS_MID
+#define MLH_SS_MID 8192
+#endif
+constexpr int SS_MID = MLH_SS_MID;
+constexpr int SS_MID_STACK = 64;                                      // ranges a workgroup of the mid launch still owes (depth first)
 constexpr int SS_LOCAL_LIST = 2 * SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the ranges the workgroup-wide phase hands over + one per partition with two children > 16 inside each
 // A leaf's ranges longer than this are partitioned by the WHOLE workgroup (wg_partition: 16 wavefronts, a sixteenth of the range each), one after the other, before
 // the wavefronts go their own ways. Measured on the frame's thinning (profiles/r05_knockout_experiments.txt item 14): for ranges that live in LDS it does NOT pay --
@@ -207,10 +220,16 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *
     ss_wave_stop_lists<SS_BIG_U>(keys, lt, rt, f, lo, hi, piv, cl, cr, IntLess());
     if (lane == 0) { w_left[wave + 1] = cl; w_right[wave] = cr; }
     __syncthreads();
-    if (t == 0) {
-        w_left[0] = 0; w_right[SS_BIG_WAVES] = 0;
-        for (int w = 0; w < SS_BIG_WAVES; ++w) w_left[w + 1] += w_left[w];
-        for (int w = SS_BIG_WAVES - 1; w >= 0; --w) w_right[w] += w_right[w + 1];
+    if (t < 64) {
+        // prefix of the left counts, suffix of the right counts over the 16 wavefronts, on 16 lanes (a thread walking the two tables one LDS round trip at a time
+        // was a third of a partition's fixed cost: 2 of ~7 us for a range of a few thousand elements)
+        static_assert(SS_BIG_WAVES == 16, "one lane per wavefront of the workgroup");
+        const int w = lane & 15;
+        int il = w_left[w + 1], ir = w_right[15 - w];                 // ir: counts from the LAST wavefront backwards
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int a = __shfl_up(il, off, 16), b = __shfl_up(ir, off, 16); if (w >= off) { il += a; ir += b; } }
+        if (lane < 16) { w_left[w + 1] = il; w_right[15 - w] = ir; }
+        if (lane == 0) { w_left[0] = 0; w_right[SS_BIG_WAVES] = 0; }
     }
     __syncthreads();
     const int nL = w_left[SS_BIG_WAVES], nR = w_right[0];
@@ -480,6 +499,91 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
     }
 }
 
+// ------------------------------------------------------------------ the mid launch: ranges of SS_LEAF < m <= SS_MID in LDS, workgroup-wide, down to leaves
+// [f, l) of the global arrays, SS_LEAF < l - f <= SS_MID, into LDS; partitioned there until every piece is at most SS_LEAF long (those go to the leaf list, in
+// global coordinates: the leaf launch finds them in HBM); written back. All threads of the workgroup, converged.
+__device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int l, int depth0, int *sk, int *sv, int *slt, int *srt, int *wl, int *wr, int *sh_k, int *stk)
+{
+    const int t = threadIdx.x, m = l - f;
+    for (int i = t; i < m; i += SS_BIG_WG) { sk[i] = A.keys[f + i]; sv[i] = A.vals[f + i]; }
+    int top = 0;
+    auto route = [&](int lo, int hi, int d) {
+        const int size = hi - lo;
+        if (size > SS_LEAF && top < SS_MID_STACK) {
+            if (t == 0) { stk[3 * top] = lo; stk[3 * top + 1] = hi; stk[3 * top + 2] = d; }
+            ++top;                                                   // (uniform: every thread keeps the count)
+        } else if (size > 1 && t == 0) {
+            A.leaf[atomicAdd(&A.cnt[SS_CNT_LEAF], 1)] = SortSeg{f + lo, f + hi, d, 0};      // (longer than a leaf only if the stack is full: the leaf launch's global path)
+        }
+    };
+    route(0, m, depth0);
+    while (top > 0) {                                                // uniform
+        __syncthreads();                                             // thread 0's stack writes (first trip: the loads above)
+        --top;
+        const int a = stk[3 * top], b = stk[3 * top + 1], d = stk[3 * top + 2];
+        __syncthreads();                                             // read by everybody before the slot is written again
+        if (d == 0) {                                                // __partial_sort(first, last, last): sorted for good, no children
+            [[maybe_unused]] const unsigned long long ch = MLH_SCLK();
+            if (t == 0) heap_sort_range(sk + a, sv + a, b - a);
+            MLH_MACC(3, 1); MLH_MACC(4, MLH_SCLK() - ch); MLH_MACC(5, b - a);
+            continue;
+        }
+        [[maybe_unused]] const unsigned long long cp = MLH_SCLK();
+        const int cut = wg_partition(sk, sv, slt, srt, a, b, wl, wr, sh_k);
+        MLH_MACC(0, 1); MLH_MACC(1, MLH_SCLK() - cp); MLH_MACC(2, b - a);
+        route(cut, b, d - 1);                                        // the library's recursive call
+        route(a, cut, d - 1);                                        // its loop's next trip
+    }
+    __syncthreads();
+    for (int i = t; i < m; i += SS_BIG_WG) { A.keys[f + i] = sk[i]; A.vals[f + i] = sv[i]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, int level)
+{
+    extern __shared__ int s_mid[];                                   // keys | vals | left stops | right stops, SS_MID ints each
+    __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1], sh_k;
+    __shared__ int s_stk[3 * SS_MID_STACK], s_gstk[3 * SS_MID_STACK];
+    int *sk = s_mid, *sv = s_mid + SS_MID, *slt = s_mid + 2 * SS_MID, *srt = s_mid + 3 * SS_MID;
+    const SortSeg *cur = A.seg[level & 1];
+    const int count = A.cnt[level];
+    const int t = threadIdx.x;
+    for (int si = blockIdx.x; si < count; si += gridDim.x) {
+        const SortSeg s = cur[si];
+        [[maybe_unused]] const unsigned long long c_all = MLH_SCLK();
+        MLH_MACC(7, s.last - s.first);
+        if (s.last - s.first <= SS_MID) { mid_lds_subtree(A, s.first, s.last, s.depth, sk, sv, slt, srt, w_left, w_right, &sh_k, s_stk); MLH_MACC(6, MLH_SCLK() - c_all); continue; }
+        // still longer than SS_MID after the wide levels (unbalanced partitions; a range too long to be "wide"): partitioned on global memory until its pieces fit
+        int top = 0;
+        if (t == 0) { s_gstk[0] = s.first; s_gstk[1] = s.last; s_gstk[2] = s.depth; }
+        ++top;
+        while (top > 0) {                                            // uniform
+            __syncthreads();
+            --top;
+            const int a = s_gstk[3 * top], b = s_gstk[3 * top + 1], d = s_gstk[3 * top + 2];
+            __syncthreads();
+            if (d == 0) {
+                if (t == 0) heap_sort_range(A.keys + a, A.vals + a, b - a);
+                continue;
+            }
+            const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, a, b, w_left, w_right, &sh_k);
+            const int c0[2] = {cut, a}, c1[2] = {b, cut};
+            for (int c = 0; c < 2; ++c) {                            // the library's recursive call, then its loop's next trip
+                const int size = c1[c] - c0[c];
+                if (size > SS_MID && top < SS_MID_STACK) {
+                    if (t == 0) { s_gstk[3 * top] = c0[c]; s_gstk[3 * top + 1] = c1[c]; s_gstk[3 * top + 2] = d - 1; }
+                    ++top;
+                } else if (size > SS_LEAF && size <= SS_MID) {
+                    mid_lds_subtree(A, c0[c], c1[c], d - 1, sk, sv, slt, srt, w_left, w_right, &sh_k, s_stk);
+                } else if (size > 1 && t == 0) {
+                    A.leaf[atomicAdd(&A.cnt[SS_CNT_LEAF], 1)] = SortSeg{c0[c], c1[c], d - 1, 0};
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ leaves: the rest of a range's recursion inside one workgroup
 // Arrays in LOCAL coordinates [0, m). Every wavefront works on its own: it partitions a sub-range, keeps one child longer than 16 for
 // itself and hands the other to a queue in (first, last, depth budget, ready) records; a wavefront without work takes the next ticket
@@ -659,6 +763,21 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
 
 }  // namespace
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of stdsort_mid_kernel, once per device; false: the device does not grant it (the big levels run instead)
+static bool stdsort_mid_lds_granted(int device)
+{
+    static std::mutex mu;
+    static signed char state[64] = {};          // 0: not asked, 1: granted, -1: refused
+    if (device < 0 || device >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[device] == 0) {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(stdsort_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(int) * 4 * SS_MID)) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        state[device] = ok ? 1 : -1;
+    }
+    return state[device] > 0;
+}
+
 static int stdsort_setup(mlh_ctx *ctx, int n, int *vals_out, StdSortArgs &A, size_t &nbig, size_t &nleaf)
 {
     DevBuf &S = ctx->stdsort;
@@ -687,7 +806,7 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
     // Big levels: always all SS_BIG_LEVELS of them when a range can be longer than a leaf. (Round 3 tried ceil(log2(longest / SS_LEAF)) + 4 launches: the
     // median-of-three partitions of a frame's 62 k voxel slots are unbalanced enough that ranges longer than a leaf survive nine levels and fall into the leaf
     // launch's global-memory path -- the thinning step went 0.56 -> 0.66 ms. An empty level costs 3-4 us; the slow path costs 70.)
-    const int n_levels = longest > SS_LEAF ? SS_BIG_LEVELS : 0;
+    int n_levels = longest > SS_LEAF ? SS_BIG_LEVELS : 0;
     A.over_level = n_levels;                                  // no big level: whatever the init kernel routed to level 0 anyway is finished by the leaf launch
     if (n_levels > 0) {
         const int grid_big = int(std::min<size_t>(nbig, 64));
@@ -699,14 +818,25 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
         if (!wide_off && fits && longest > SS_WIDE_MIN) {
             int lg = 0;
             while ((SS_WIDE_MIN << lg) < longest) ++lg;
-            n_wide_levels = std::min(n_levels, lg + MLH_SS_WIDE_EXTRA);
+            static const int extra = std::getenv("MLH_SS_WIDE_EXTRA") ? std::atoi(std::getenv("MLH_SS_WIDE_EXTRA")) : MLH_SS_WIDE_EXTRA;      // (A/B runs)
+            n_wide_levels = std::min(n_levels, lg + extra);
         }
+        // the mid launch behind the wide levels instead of the remaining big levels (MLH_SS_MID_OFF: A/B runs; a device that does not grant its 128 KB of LDS)
+        static const bool mid_off = std::getenv("MLH_SS_MID_OFF") != nullptr;
+        const bool mid = !mid_off && n_wide_levels < SS_BIG_LEVELS && stdsort_mid_lds_granted(ctx->device);
+        if (mid) n_levels = n_wide_levels;
         const int n_wide_wg = A.n / SS_WIDE_CHUNK + A.n / SS_WIDE_MIN + 4;     // >= the chunks of all wide ranges of a level
         for (int level = 0; level < n_levels; ++level) {
             const bool wide = level < n_wide_levels;
             if (wide) MLH_LAUNCH(stdsort_wide_stops_kernel, dim3(n_wide_wg), dim3(SS_BIG_WG), 0, st, A, level);
             MLH_LAUNCH(stdsort_big_level_kernel, dim3(grid_big + (wide ? n_wide_wg : 0)), dim3(SS_BIG_WG), 0, st, A, level, wide ? n_wide_wg : 0);
         }
+        if (mid) {
+            // one workgroup per range the wide levels left longer than a leaf (at most n / SS_LEAF of them); it leaves nothing for a next level
+            const int grid_mid = int(std::min<size_t>(nbig, 256));
+            MLH_LAUNCH(stdsort_mid_kernel, dim3(grid_mid), dim3(SS_BIG_WG), sizeof(int) * 4 * SS_MID, st, A, n_levels);
+            A.over_level = n_levels + 1;                          // (an empty list: the init launch cleared every level's counter)
+        } else A.over_level = n_levels;
     }
     const int grid_leaf = int(std::min<size_t>(nleaf, 1024));
     MLH_LAUNCH(stdsort_leaf_kernel, dim3(grid_leaf), dim3(SS_LEAF_WG), 0, st, A);
@@ -775,6 +905,12 @@ int device_std_sort_segments(mlh_ctx *ctx, const int *src_keys, const int *count
 extern "C" int mlh_debug_stage_clock_sort(unsigned long long *out, int n_words)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_sort), sizeof(unsigned long long) * size_t(n_words));
+}
+extern "C" int mlh_debug_stage_clock_mid(unsigned long long *out, int n_words, int clear)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mlh::g_stage_clk_mid), sizeof(unsigned long long) * size_t(n_words));
+    if (clear) { static unsigned long long z[1024 * 16]; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(mlh::g_stage_clk_mid), z, sizeof(z)); }
+    return rc;
 }
 extern "C" int mlh_debug_stage_clock_sort2(unsigned long long *out, int n_words, int clear)
 {
