@@ -444,7 +444,9 @@ typedef struct mlh_solver_opts {
     double huber_delta;              /* ceres::HuberLoss(0.1), lidar_mapper_keyframe.cpp:443 */
     double map_eig_thre;             /* MAP_EIG_THRE, evalDegenracy, lidar_mapper_keyframe.cpp:1178-1189 */
     double cov_measurement_trace;    /* trace(COV_MEASUREMENT) used when with_ua is off (cpp:543-544) */
-    uint32_t flags;                  /* MLH_FLAG_WITH_UA | MLH_FLAG_CHECK_FOV */
+    uint32_t flags;                  /* MLH_FLAG_WITH_UA | MLH_FLAG_CHECK_FOV. CHECK_FOV applies to mlh_gn_solve* (estimator.cpp:1142, 1149 pass it); the mlh_scan2map*
+                                      * entry points ignore it, as scan2MapOptimization does: its matching goes through goodFeatureMatching, which hard-codes
+                                      * n_neigh = 5 and CHECK_FOV = false (lidar_mapper.h:256-283) */
     int max_outer;                   /* max_iter = 2, cpp:439 */
     int max_lm_iterations;           /* options.max_num_iterations = 30, cpp:590 */
     int gf_method;                   /* FLAGS_gf_method: MLH_GF_* (lidar_mapper.h:89); mlh_scan2map only */

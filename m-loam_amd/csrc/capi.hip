@@ -1710,9 +1710,21 @@ static bool lm_consumer_enabled(const mlh_ctx *ctx)
     return tiles <= GN_DEFER_MAX_TILES;
 }
 
-static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts, mlh_iter_stat *stats, bool allow_loop = true)
+// scan2MapOptimization matches through ActiveFeatureSelection::goodFeatureMatching, which passes n_neigh = 5 and CHECK_FOV = false to match*PointFromMap whatever
+// the caller's configuration says (lidar_mapper.h:256-283, every gf_method): MLH_FLAG_CHECK_FOV does not apply to the scan2map entry points. (The flag is for
+// mlh_gn_solve*, mlh_match_linearize and the odometry's matches, where the reference does pass CHECK_FOV: estimator.cpp:1142, 1149. Found by the "hard" scene
+// family of round 6: tall poles put corner features outside the +-60 degree cone, and a scan2map that honoured the flag dropped what the reference keeps.)
+static mlh_solver_opts scan2map_opts(const mlh_solver_opts *o)
 {
-    if (!ctx || !pose_inout || !opts || opts->max_outer <= 0) return MLH_ERR_INVALID;
+    mlh_solver_opts c = *o;
+    c.flags &= ~uint32_t(MLH_FLAG_CHECK_FOV);
+    return c;
+}
+
+static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts_in, mlh_iter_stat *stats, bool allow_loop = true)
+{
+    if (!ctx || !pose_inout || !opts_in || opts_in->max_outer <= 0) return MLH_ERR_INVALID;
+    const mlh_solver_opts opts_v = scan2map_opts(opts_in), *opts = &opts_v;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     { const int frc = gn_flush_pending(ctx); if (frc) return frc; }      // (a solve submitted with mlh_gn_solve_begin* may have left its last iteration as records)
     int rc = ensure_state(ctx, opts->max_outer);
@@ -1894,8 +1906,9 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
 // verdict. A frame whose LM loop needs MORE than the look-ahead is detected on the device (the next outer iteration finds the loop unterminated: lm_overflow; or the
 // last loop is unterminated at the publication) -- its result is then not scan2MapOptimization's and is never returned as such: mlh_scan2map_end solves the frame
 // again synchronously when that is sound (nothing restaged since the submission, no younger solve chained behind it), and says so otherwise.
-static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, const mlh_solver_opts *opts, int lm_lookahead)
+static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wodom_prev, const double *wodom_cur, const mlh_solver_opts *opts_in, int lm_lookahead)
 {
+    const mlh_solver_opts opts_v = scan2map_opts(opts_in), *opts = &opts_v;
     if (ctx->comm) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_scan2map_begin under an RCCL communicator: the sharded LM iteration there is a host-driven sequence of launches and collectives (use the mailbox communicator)");
     if (opts->gf_method != MLH_GF_WO) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_scan2map_begin with a good-feature selection: the selection loops run on the host between the launches (use mlh_scan2map)");
     if (opts->max_outer <= 0) return fail(ctx, MLH_ERR_INVALID, "max_outer must be positive");
@@ -2079,9 +2092,10 @@ int mlh_scan2map(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_opts *opts
 int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, const void *corner_points, int n_corner, int stride_bytes,
                             int intensity_offset_bytes, int mem, float leaf_surf, float leaf_corner, const double *ext_poses, const double *ext_covs,
                             int n_lidar, const double cov_measurement[9], int with_ua, double trace_threshold, double pose_inout[7],
-                            const mlh_solver_opts *opts, int32_t *n_surf_features, int32_t *n_corner_features)
+                            const mlh_solver_opts *opts_in, int32_t *n_surf_features, int32_t *n_corner_features)
 {
-    if (!ctx || !pose_inout || !opts || !n_surf_features || !n_corner_features || opts->max_outer <= 0) return MLH_ERR_INVALID;
+    if (!ctx || !pose_inout || !opts_in || !n_surf_features || !n_corner_features || opts_in->max_outer <= 0) return MLH_ERR_INVALID;
+    const mlh_solver_opts opts_v = scan2map_opts(opts_in), *opts = &opts_v;      // (CHECK_FOV does not apply to scan2map: see scan2map_opts)
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     auto two_calls = [&]() -> int {
         int rc = mlh_downsample_current_scan_pair(ctx, surf_points, n_surf, corner_points, n_corner, stride_bytes, intensity_offset_bytes, mem, leaf_surf, leaf_corner,

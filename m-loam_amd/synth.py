@@ -73,14 +73,84 @@ def pose_to_mat(pose7):
     return T
 
 
+def _empty(cols):
+    return np.zeros((0, cols), np.float64)
+
+
 @dataclasses.dataclass
 class Scene:
     L: float                 # ground plane is [-L/2, L/2]^2 at z = 0
     boxes: np.ndarray        # (B, 6): xmin ymin zmin xmax ymax zmax
     seed: int
+    # the "hard" family (round 6): what a street has beside planes and boxes
+    cyl: np.ndarray = dataclasses.field(default_factory=lambda: _empty(4))     # vertical cylinders -- poles, trunks: cx cy radius height
+    sph: np.ndarray = dataclasses.field(default_factory=lambda: _empty(5))     # "vegetation" blobs: cx cy cz radius sigma (extra range noise of a return from it)
+    ramps: np.ndarray = dataclasses.field(default_factory=lambda: _empty(7))   # thin tilted slabs met at grazing incidence: x0 y0 x1 y1 (footprint) z0 slope_x slope_y
+    family: str = "boxes"
 
 
-def make_scene(L: float, n_boxes: int, seed: int = 42, clear_radius: float = 8.0) -> Scene:
+def scene_family(family=None) -> str:
+    """"boxes" (ground plane + axis-aligned buildings: every golden fixture and the bench workload) or "hard" (MLOAM_SCENE_FAMILY=hard, or the argument): the same
+    boxes plus thin poles and trunks, noisy vegetation blobs, slabs at grazing incidence -- where the line test lambda_2 > 3 lambda_1 (feature_extract.hpp:688-693)
+    and the plane gate (:823-840) sit near their thresholds far more often -- and maps with exactly duplicated points and a patch of four-fold density."""
+    f = family or os.environ.get("MLOAM_SCENE_FAMILY", "boxes")
+    if f not in ("boxes", "hard"):
+        raise ValueError(f"unknown scene family {f!r}")
+    return f
+
+
+def _add_hard_objects(scene: "Scene", clear_radius: float) -> None:
+    rng = np.random.default_rng(scene.seed + 7777)            # its own generator: the boxes of a seed are the same in both families
+    L, B = scene.L, scene.boxes
+
+    def free(x, y, margin):
+        if np.hypot(x, y) < clear_radius * 0.4:
+            return False
+        for b in B:
+            if b[0] - margin < x < b[3] + margin and b[1] - margin < y < b[4] + margin:
+                return False
+        return True
+    n_cyl = int(np.clip(L / 4, 16, 90))
+    cyl, sph = [], []
+    tries = 0
+    while len(cyl) < n_cyl and tries < 20000:
+        tries += 1
+        r_max = min(L / 2 - 4, 45.0)
+        rad, ang = rng.uniform(3.0, r_max), rng.uniform(-np.pi, np.pi)
+        x, y = rad * np.cos(ang), rad * np.sin(ang)
+        if not free(x, y, 0.6):
+            continue
+        trunk = rng.random() < 0.4
+        radius = rng.uniform(0.12, 0.35) if trunk else rng.uniform(0.04, 0.12)
+        h = rng.uniform(2.0, 5.0) if trunk else rng.uniform(3.0, 12.0)
+        cyl.append([x, y, radius, h])
+        if trunk:                                               # a crown on top of the trunk
+            sph.append([x, y, h + rng.uniform(0.3, 1.2), rng.uniform(1.0, 2.5), rng.uniform(0.08, 0.25)])
+    for _ in range(int(np.clip(L / 8, 8, 40))):                 # bushes
+        for _t in range(50):
+            rad, ang = rng.uniform(4.0, min(L / 2 - 4, 40.0)), rng.uniform(-np.pi, np.pi)
+            x, y = rad * np.cos(ang), rad * np.sin(ang)
+            if free(x, y, 1.0):
+                r = rng.uniform(0.4, 1.4)
+                sph.append([x, y, rng.uniform(0.2, 0.9) * r, r, rng.uniform(0.05, 0.2)])
+                break
+    ramps = []
+    for _ in range(int(np.clip(L / 25, 3, 10))):
+        for _t in range(50):
+            rad, ang = rng.uniform(6.0, min(L / 2 - 12, 35.0)), rng.uniform(-np.pi, np.pi)
+            x, y = rad * np.cos(ang), rad * np.sin(ang)
+            sx, sy = rng.uniform(5.0, 18.0, size=2)
+            if free(x, y, 0.5 * max(sx, sy) + 1.0):
+                slope = np.tan(np.deg2rad(rng.uniform(1.5, 8.0)))
+                a = rng.uniform(-np.pi, np.pi)
+                ramps.append([x - sx / 2, y - sy / 2, x + sx / 2, y + sy / 2, rng.uniform(0.02, 0.25), slope * np.cos(a), slope * np.sin(a)])
+                break
+    scene.cyl = np.array(cyl, np.float64).reshape(-1, 4)
+    scene.sph = np.array(sph, np.float64).reshape(-1, 5)
+    scene.ramps = np.array(ramps, np.float64).reshape(-1, 7)
+
+
+def make_scene(L: float, n_boxes: int, seed: int = 42, clear_radius: float = 8.0, family=None) -> Scene:
     rng = np.random.default_rng(seed)
     boxes = []
     tries = 0
@@ -102,7 +172,10 @@ def make_scene(L: float, n_boxes: int, seed: int = 42, clear_radius: float = 8.0
                 break
         if ok:
             boxes.append(b)
-    return Scene(L=L, boxes=np.array(boxes).reshape(-1, 6), seed=seed)
+    scene = Scene(L=L, boxes=np.array(boxes).reshape(-1, 6), seed=seed, family=scene_family(family))
+    if scene.family == "hard":
+        _add_hard_objects(scene, clear_radius)
+    return scene
 
 
 def voxel_mean(points: np.ndarray, leaf: float) -> np.ndarray:
@@ -171,13 +244,53 @@ def sample_maps(scene: Scene, surf_res: float = 0.4, corner_res: float = 0.2, se
             s = np.arange(corner_res / 2, ln, corner_res) / ln
             e = np.stack([p0[0] + s * (p1[0] - p0[0]), p0[1] + s * (p1[1] - p0[1]), np.full_like(s, h)], axis=1)
             corner.append(e + rng.normal(0.0, noise, e.shape))
+    if scene.family == "hard":
+        hrng = np.random.default_rng(seed + 8888)
+        for cx, cy, r, h in scene.cyl:                              # pole / trunk surfaces
+            na = max(6, int(np.ceil(2 * np.pi * r / (0.5 * surf_res))))
+            a, z = np.meshgrid(np.linspace(0, 2 * np.pi, na, endpoint=False), np.arange(surf_res / 4, h, surf_res / 2), indexing="ij")
+            a, z = a.ravel(), z.ravel()
+            surf.append(np.stack([cx + r * np.cos(a), cy + r * np.sin(a), z], axis=1) + hrng.normal(0.0, noise, (a.size, 3)))
+        for cx, cy, cz, r, sg in scene.sph:                         # vegetation: a noisy shell
+            m = max(40, int(4 * np.pi * r * r / (surf_res * surf_res) * 2))
+            v = hrng.normal(size=(m, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+            rr = r + hrng.normal(0.0, sg, m)
+            pnt = np.array([cx, cy, cz]) + v * rr[:, None]
+            surf.append(pnt[pnt[:, 2] > 0.0])
+        for x0, y0, x1, y1, z0, sx, sy in scene.ramps:              # thin slabs
+            u = np.arange(x0 + surf_res / 2, x1, surf_res); v = np.arange(y0 + surf_res / 2, y1, surf_res)
+            uu, vv = np.meshgrid(u, v, indexing="ij")
+            uu = uu.ravel() + hrng.uniform(-0.1, 0.1, uu.size); vv = vv.ravel() + hrng.uniform(-0.1, 0.1, vv.size)
+            surf.append(np.stack([uu, vv, z0 + sx * (uu - x0) + sy * (vv - y0) + hrng.normal(0.0, noise, uu.size)], axis=1))
     surf = np.concatenate(surf).astype(np.float32)
     corner = np.concatenate(corner).astype(np.float32) if corner else np.zeros((0, 3), np.float32)
     surf = voxel_mean(surf, surf_res)
     if corner_from == "keyframes":
         corner = keyframe_corner_cloud(scene, kf_rings, kf_lidars, n_keyframes, seed=seed)
     corner = voxel_mean(corner, corner_res)
+    if scene.family == "hard":
+        surf, corner = harden_maps(surf, corner, seed=seed)
     return np.ascontiguousarray(surf), np.ascontiguousarray(corner)
+
+
+def harden_maps(surf: np.ndarray, corner: np.ndarray, seed: int = 42, dup_fraction: float = 0.03, dense_radius: float = 25.0):
+    """What a mapper's local map has and a voxel-thinned synthetic one does not: EXACTLY duplicated points (the same keyframe cloud merged twice: equal distances,
+    the k-d tree's order among them decides the fifth neighbour) and a patch of four-fold density (one LiDAR much denser than the others: the quadrant x, y > 0
+    within dense_radius of the origin gets three jittered copies of every point). Appended behind the thinned cloud; the order is part of the input."""
+    rng = np.random.default_rng(seed + 9999)
+    out = []
+    for cloud in (surf, corner):
+        parts = [cloud]
+        if len(cloud):
+            n_dup = max(1, int(dup_fraction * len(cloud)))
+            pick = rng.choice(len(cloud), size=n_dup, replace=False)
+            parts.append(cloud[pick])
+            parts.append(cloud[pick[: n_dup // 4]])                 # a quarter of them three times over
+            q = cloud[(cloud[:, 0] > 0) & (cloud[:, 1] > 0) & (np.hypot(cloud[:, 0], cloud[:, 1]) < dense_radius)]
+            for _ in range(3):
+                parts.append((q + rng.normal(0.0, 0.04, q.shape)).astype(cloud.dtype))
+        out.append(np.ascontiguousarray(np.concatenate(parts)))
+    return out[0], out[1]
 
 
 def keyframe_poses(n_keyframes: int, spacing: float = 0.35) -> np.ndarray:
@@ -279,6 +392,44 @@ def _raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: floa
     return t_hit
 
 
+def _raycast_hard(scene: Scene, origin: np.ndarray, dirs: np.ndarray, t_hit: np.ndarray, max_range: float):
+    """The hard family's objects on top of _raycast's result: nearest hit per ray and the extra range noise (sigma) of the object it belongs to."""
+    n = dirs.shape[0]
+    sigma = np.zeros(n)
+    ox, oy, oz = origin
+    dx, dy, dz = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a2 = dx * dx + dy * dy
+        for cx, cy, r, h in scene.cyl:
+            if np.hypot(cx - ox, cy - oy) - r > max_range:
+                continue
+            bx, by = ox - cx, oy - cy
+            b = bx * dx + by * dy
+            c = bx * bx + by * by - r * r
+            disc = b * b - a2 * c
+            t = (-b - np.sqrt(np.maximum(disc, 0.0))) / a2
+            z = oz + t * dz
+            ok = (disc > 0) & (t > 0) & (z >= 0.0) & (z <= h) & (t < t_hit)
+            t_hit = np.where(ok, t, t_hit); sigma = np.where(ok, 0.0, sigma)
+        for cx, cy, cz, r, sg in scene.sph:
+            if np.hypot(cx - ox, cy - oy) - r > max_range:
+                continue
+            bx, by, bz = ox - cx, oy - cy, oz - cz
+            b = bx * dx + by * dy + bz * dz
+            c = bx * bx + by * by + bz * bz - r * r
+            disc = b * b - c
+            t = -b - np.sqrt(np.maximum(disc, 0.0))
+            ok = (disc > 0) & (t > 0) & (oz + t * dz > 0.0) & (t < t_hit)
+            t_hit = np.where(ok, t, t_hit); sigma = np.where(ok, sg, sigma)
+        for x0, y0, x1, y1, z0, sx, sy in scene.ramps:
+            den = dz - sx * dx - sy * dy
+            t = (z0 + sx * (ox - x0) + sy * (oy - y0) - oz) / den
+            px, py = ox + t * dx, oy + t * dy
+            ok = np.isfinite(t) & (t > 0) & (px > x0) & (px < x1) & (py > y0) & (py < y1) & (t < t_hit)
+            t_hit = np.where(ok, t, t_hit); sigma = np.where(ok, 0.0, sigma)
+    return t_hit, sigma
+
+
 @dataclasses.dataclass
 class Scan:
     points: np.ndarray       # (n, 4) f32, ring-major, LiDAR frame; column 3 = 0 (the extractor ignores it)
@@ -309,7 +460,12 @@ def simulate_scan(scene: Scene, pose_w_body: np.ndarray, body_T_laser: np.ndarra
     Rw = T_wl[:3, :3]
     d_w = np.stack([(d_l[:, 0] * Rw[r, 0] + d_l[:, 1] * Rw[r, 1]) + d_l[:, 2] * Rw[r, 2] for r in range(3)], axis=1)
     t = _raycast(scene, T_wl[:3, 3], d_w, max_range)
+    extra_sigma = None
+    if scene.family == "hard":
+        t, extra_sigma = _raycast_hard(scene, T_wl[:3, 3], d_w, t, max_range)
     t = t + rng.normal(0.0, range_noise, t.shape)
+    if extra_sigma is not None:
+        t = t + extra_sigma * np.random.default_rng(seed + 31337).normal(0.0, 1.0, t.shape)     # (its own generator: the clean returns keep the boxes family's noise)
     ok = np.isfinite(t) & (t < max_range) & (t > 0.8)
     pts = (d_l * np.where(ok, t, 0.0)[:, None]).astype(np.float32)
     ok = ok.reshape(n_rings, n_cols)

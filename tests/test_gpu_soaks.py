@@ -40,6 +40,20 @@ def test_frontend_parity_soak_bounded():
     assert "all equal" in out
 
 
+HARD = {"MLOAM_SCENE_FAMILY": "hard"}       # synth.scene_family: poles, vegetation, grazing slabs, duplicated map points, a four-fold dense patch
+
+
+def test_parity_soak_hard_scene_family():
+    """HIP == oracle on the harder scenes: validity flags and coefficient bits, normal equations, GN counts, LM bookkeeping (profiles/r06_soak.txt: the long runs)"""
+    out = _run([os.path.join(ROOT, "scripts", "soak_parity.py"), "6", "203"], env=HARD)
+    assert "0 decision flips" in out
+
+
+def test_frontend_parity_soak_hard_scene_family():
+    out = _run([os.path.join(ROOT, "scripts", "soak_parity_frontend.py"), "3", "204", "track,segment,rough,select,odom_select,voxel"], env=HARD)
+    assert "all equal" in out
+
+
 def test_mailbox_soak_bounded():
     """three real processes sharing the one GPU (torch.distributed.run), 300 random calls"""
     import socket

@@ -914,3 +914,17 @@ def test_random_problems_against_the_references_own_lines(ref):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_ref_pin.py"), "3", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all equal" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_random_problems_of_the_hard_scene_family_against_the_references_own_lines(ref):
+    """The same on the "hard" scene family (synth.scene_family: poles and trunks, noisy vegetation blobs, slabs at grazing incidence, maps with exactly duplicated
+    points and a patch of four-fold density -- where the line test lambda_2 > 3 lambda_1, feature_extract.hpp:688-693, and the plane gate, :823-840, sit near their
+    thresholds): two random problems per scene-based family. The long runs are in profiles/r06_soak.txt."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLOAM_SCENE_FAMILY="hard")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_ref_pin.py"), "2", "17", "match,scan2map,track,select,downsample"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "all equal" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
