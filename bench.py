@@ -1039,6 +1039,21 @@ def main():
             predicted = predicted_scaling(mla, torch, shard, local_rank, surf_map, corner_map, surf, corner, np.asarray(pose, np.float64), center)
         except Exception as ex:      # (a supplementary leg must not cost the line)
             predicted = dict(error=str(ex)[:200])
+        # ... and on the configurations the north star quotes its multi-GPU target on (config 4 on the 4 M map; the un-thinned frame): too long for the default run
+        # (a 4 M-point map is built), so the committed result of scripts/predict_multi_gpu.py -- same method, same kernels, its own gpurun call -- is attached
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_multi_gpu_predicted.json")) as f_:
+                ns = json.load(f_)
+            def _brief(cfg):
+                return dict(n1_ms_per_step=cfg["n1_ms_per_step"], splits={k_: dict(ms_per_step=v_["predicted_ms_per_step"], speedup=v_["predicted_speedup_vs_n1"]) for k_, v_ in cfg["splits"].items()})
+            predicted["north_star_configurations"] = dict(
+                source="profiles/r06_multi_gpu_predicted.json (scripts/predict_multi_gpu.py, one MI355X, not measured in this run)",
+                config4_on_the_4M_map=_brief(ns["config4_4M"]), config2_unthinned_228k_queries=_brief(ns["config2_unthinned_500k"]),
+                target=ns["north_star_target"], predicted_best_speedup_at_8_gpus=ns["predicted_best_speedup_at_8_gpus_config4_4M"], meets_target=ns["meets_target"],
+                verdict=ns["verdict"])
+        except Exception as ex:
+            if isinstance(predicted, dict):
+                predicted["north_star_configurations"] = dict(error=str(ex)[:200])
 
     # --- roofline of the dominant kernel (correspondence kernel, surf + corner features in one launch):
     #     algorithmic bytes per launch / duration from the dispatch's own start/stop timestamps (HIP events)

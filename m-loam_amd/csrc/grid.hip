@@ -97,7 +97,13 @@ struct GridJobs {
     GridJob j[2];
     // optional: the staging pass's fit flags leave for the host in the first launch of the build (one thread), instead of a launch of their own
     int *pub_oob; HostPublish *pub; unsigned long long pub_seq;
+    int pub_stage;         // 0: cell_count_kernel publishes (the clouds were packed by the launch before it); 1: scan_local_kernel does (pack_count_kernel packed them)
 };
+
+// a frame's local map arrives as a cloud of caller records: packed to float4 {x,y,z,index} and, in the same pass, checked against the grid box already set up for
+// this kind (flag word, OR-ed)
+struct PackJob { const unsigned char *src; float4 *out; int n, stride; float lo[3], hi[3]; int nb; };
+struct PackJobs { PackJob j[2]; int *oob; };
 
 __device__ __forceinline__ int cell_of(const GridJob &J, const float4 &p)
 {
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
     const int lane = threadIdx.x & 63;
-    if (G.pub && blockIdx.x == 0 && threadIdx.x == 0) {                   // the packed clouds' fit flags: final before this launch started
+    if (G.pub && G.pub_stage == 0 && blockIdx.x == 0 && threadIdx.x == 0) {   // the packed clouds' fit flags: final before this launch started
         G.pub->done = *G.pub_oob;
         *G.pub_oob = 0;
         __hip_atomic_store(&G.pub->seq, G.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -159,6 +165,45 @@ __global__ __launch_bounds__(256) void cell_count_kernel(GridJobs G)
         first = __shfl(first, my_head);
         if (valid) J.rank[i] = first + (lane - my_head);
     }
+}
+
+// pack + fit check + count in ONE pass over the caller's records (every staged kind keeps its grid geometry: the steady state of a mapper between keyframes): the
+// record is read once, the packed point goes to raw[] and straight into cell_of() -- pack_check_kernel and cell_count_kernel as one launch (~6 us of a frame's
+// index build and a kernel boundary). A point outside the box is counted in the clamped cell like any other; the flag it raises makes the host lay out a new box
+// and build again, as before. The flags leave for the host from the NEXT launch (scan_local_kernel, pub_stage 1).
+__global__ __launch_bounds__(256) void pack_count_kernel(GridJobs G, PackJobs P)
+{
+    const int job = blockIdx.x >= G.j[0].nb_pts ? 1 : 0;
+    const GridJob &J = G.j[job];
+    const PackJob &Q = P.j[job];
+    const int b = job ? blockIdx.x - G.j[0].nb_pts : blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool bad = false;
+    for (int base = b * 256; base < J.n; base += J.nb_pts * 256) {       // uniform over the workgroup
+        const int i = base + threadIdx.x;
+        const bool valid = i < J.n;
+        int c = -1 - lane;                                               // distinct negatives: never merged
+        if (valid) {
+            const float *rec = reinterpret_cast<const float *>(Q.src + size_t(i) * Q.stride);
+            const float x = rec[0], y = rec[1], z = rec[2];
+            const float4 p = make_float4(x, y, z, __int_as_float(i));
+            Q.out[i] = p;
+            bad = bad || !(x >= Q.lo[0] && x < Q.hi[0] && y >= Q.lo[1] && y < Q.hi[1] && z >= Q.lo[2] && z < Q.hi[2]);   // NaN -> bad
+            c = cell_of(J, p);
+        }
+        const int prev = __shfl_up(c, 1);
+        const bool head = (lane == 0) || (c != prev);
+        const unsigned long long H = __ballot(head);
+        const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const int my_head = 63 - __clzll(H & upto);
+        const unsigned long long above = (my_head == 63) ? 0ull : (H & ~((2ull << my_head) - 1ull));
+        const int next = above ? (__ffsll((long long)above) - 1) : 64;
+        int first = 0;
+        if (head && valid) first = atomicAdd(&J.cell_start[c + 1], next - my_head);
+        first = __shfl(first, my_head);
+        if (valid) J.rank[i] = first + (lane - my_head);
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(P.oob, 1 << job);
 }
 
 __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds, int &total)
@@ -189,6 +234,11 @@ __global__ __launch_bounds__(256) void scan_local_kernel(GridJobs G)
     const int job = blockIdx.x >= G.j[0].nb_scan ? 1 : 0;
     const GridJob &J = G.j[job];
     const int b = job ? blockIdx.x - G.j[0].nb_scan : blockIdx.x;
+    if (G.pub && G.pub_stage == 1 && blockIdx.x == 0 && threadIdx.x == 0) {   // pack_count_kernel's fit flags: final before this launch started
+        G.pub->done = *G.pub_oob;
+        *G.pub_oob = 0;
+        __hip_atomic_store(&G.pub->seq, G.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     int4 *A4 = reinterpret_cast<int4 *>(J.cell_start + 1);
     const int base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     const int n_pad = ((J.ncell + 3) / 4) * 4;                           // padded tail holds zeros
@@ -364,7 +414,14 @@ static GridJob make_job(MapGrid &g)
 }
 
 // (re)builds the index of up to two point sets in one set of launches
+static int grid_build_grids_packed(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob, HostPublish *pub, unsigned long long pub_seq, const PackJobs *pack);
 int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob, HostPublish *pub, unsigned long long pub_seq)
+{
+    return grid_build_grids_packed(ctx, grids, n_grids, recompute_bounds, pub_oob, pub, pub_seq, nullptr);
+}
+
+// pack: the staged clouds' records, when the pack + fit check is to ride in the build's first launch (map_stage_and_build; grids[k] <-> pack->j[k])
+static int grid_build_grids_packed(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_bounds, int *pub_oob, HostPublish *pub, unsigned long long pub_seq, const PackJobs *pack)
 {
     hipStream_t st = ctx->stream;
     GridJobs G;
@@ -392,7 +449,8 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
     const int nb_scan = G.j[0].nb_scan + G.j[1].nb_scan, nb_pts = G.j[0].nb_pts + G.j[1].nb_pts;
     prof_begin(ctx, MLH_K_GRID_BUILD);
     if (G.j[0].need_zero || G.j[1].need_zero) MLH_LAUNCH(zero_cells_kernel, dim3(nb_scan), dim3(256), 0, st, G);
-    MLH_LAUNCH(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
+    if (pack) { G.pub_stage = 1; MLH_LAUNCH(pack_count_kernel, dim3(nb_pts), dim3(256), 0, st, G, *pack); }
+    else MLH_LAUNCH(cell_count_kernel, dim3(nb_pts), dim3(256), 0, st, G);
     MLH_LAUNCH(scan_local_kernel, dim3(nb_scan), dim3(256), 0, st, G);
     if (G.j[0].sums_scanned || G.j[1].sums_scanned) MLH_LAUNCH(scan_sums_kernel, dim3(nj), dim3(256), 0, st, G);
     MLH_LAUNCH(scan_add_kernel, dim3(nb_scan), dim3(256), 0, st, G);
@@ -405,8 +463,6 @@ int grid_build_grids(mlh_ctx *ctx, MapGrid **grids, int n_grids, bool recompute_
 
 // ---- a frame's local map arrives as a cloud of caller records: pack to float4 {x,y,z,index} and, in the same pass, check that every
 // point lies inside the grid box already set up for this kind (flag word, OR-ed). One launch for both maps.
-struct PackJob { const unsigned char *src; float4 *out; int n, stride; float lo[3], hi[3]; int nb; };
-struct PackJobs { PackJob j[2]; int *oob; };
 __global__ __launch_bounds__(256) void pack_check_kernel(PackJobs G)
 {
     const int job = blockIdx.x >= G.j[0].nb ? 1 : 0;
@@ -463,7 +519,11 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
         J.hi[0] = reuse ? g.ox + float(g.nx) * g.h : INFINITY; J.hi[1] = reuse ? g.oy + float(g.ny) * g.h : INFINITY;
         J.hi[2] = reuse ? g.oz + float(g.nz) * g.h : INFINITY;
     }
-    MLH_LAUNCH(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
+    // every staged kind keeps its geometry (a mapper between keyframes): pack + fit check ride in the index build's first launch (pack_count_kernel);
+    // MLH_GRID_PACK_LAUNCH=1 keeps the launch of their own (A/B runs)
+    static const bool pack_apart = std::getenv("MLH_GRID_PACK_LAUNCH") && std::atoi(std::getenv("MLH_GRID_PACK_LAUNCH")) != 0;
+    const bool pack_in_build = need_bounds == 0 && !pack_apart;
+    if (!pack_in_build) MLH_LAUNCH(pack_check_kernel, dim3(G.j[0].nb + G.j[1].nb), dim3(256), 0, st, G);
     // the fit flags are final once the clouds are packed: they leave for the host NOW, and the optimistic index build of the kinds whose
     // geometry is reused is enqueued behind them -- the host learns the outcome (and can go on enqueueing the frame's solver launches)
     // while the GPU is still building the index, instead of the GPU idling through the host's reaction time after the build. When such a
@@ -490,7 +550,7 @@ int map_stage_and_build(mlh_ctx *ctx, int n_maps, const int *kinds, const unsign
             MLH_HIP(ctx, g.cell_id.ensure(sizeof(int) * size_t(g.n)));
             fast[nf++] = &g;
         }
-        int rc = grid_build_grids(ctx, fast, nf, false, G.oob, pub, seq);
+        int rc = grid_build_grids_packed(ctx, fast, nf, false, G.oob, pub, seq, pack_in_build ? &G : nullptr);
         if (rc) return rc;
     }
     // spin on the pinned record (pack + fit check have completed when the sequence number arrives; the builds may still be running)

@@ -1,9 +1,13 @@
 #!/bin/bash
-# A/B of environment switches inside one gpurun call: bench.py's scan2map / frame legs for every "VAR=value" argument ("-" = nothing set), alternated REPS times
-REPS=${REPS:-2}
-for i in $(seq $REPS); do for e in "$@"; do
-  if [ "$e" = "-" ]; then envs=""; else envs="$e"; fi
-  env $envs python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['scan2map']
-print('%-28s' % '$e', 'sync', s['ms_per_frame'], 'sync_maps_staged', s['ms_per_frame_synchronous_maps_staged'], 'pipelined', s['ms_per_frame_pipelined'], 'frame', d['frame']['ms_per_frame'], 'step', d['ms_per_step'])"
-done; done
+# A/B of an environment switch on the bench line, inside ONE gpurun call, alternated: scripts/ab_env.sh VAR valueA valueB [reps] [bench args...]
+# prints ms_per_step (pipelined), synchronous, frame, scan2map, and the index-build stage per run
+VAR=$1; A=$2; B=$3; REPS=${4:-2}; shift 4
+for rep in $(seq 1 $REPS); do
+  for v in "$A" "$B"; do
+    if [ "$v" = "-" ]; then r=$(env -u $VAR python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1); else r=$(env $VAR=$v python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1); fi
+    echo "$r" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); f=d.get('frame') or {}; s=d.get('scan2map') or {}
+print('$VAR=$v', 'step', d['ms_per_step'], 'sync', d.get('ms_per_step_synchronous_submission'), 'frame', f.get('ms_per_frame'), 'stages', f.get('stages_ms_each_followed_by_a_wait'), 's2m', s.get('ms_per_frame'), s.get('ms_per_frame_pipelined'))"
+  done
+done
