@@ -1,4 +1,4 @@
-"""profiles/pmc_knn.json (what bench.py reports as roofline.traffic) from the three PMC passes of scripts/profile_round5.sh: usage make_pmc_json.py <dir with pmc1..3.txt> <tag>.
+"""profiles/pmc_knn.json (what bench.py reports as roofline.traffic) from the three PMC passes of scripts/profile_round6.sh: usage make_pmc_json.py <dir with pmc1..3.txt> <tag>.
 HBM bytes per launch = 2 x FETCH_SIZE (KB; gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (KB), means over the dispatches."""
 import json, os, re, sys
 d, tag = sys.argv[1], sys.argv[2]
@@ -18,9 +18,9 @@ def get(kern_sub, counter):
 def hbm(kern_sub):
     f, w = get(kern_sub, "FETCH_SIZE")[1], get(kern_sub, "WRITE_SIZE")[1]
     return None if f is None or w is None else int(round((2.0 * f + w) * 1024.0))
-main = "knn_features_kernel<0, false, false, 1, true>"
-cold = "knn_features_kernel<0, false, false, 0, false>"
-fit = "fit_linearize_kernel<5, false, false>"
+main = "knn_features_kernel<0, false, false, 1, true"       # (prefix: round 5 added a template parameter behind these)
+cold = "knn_features_kernel<0, false, false, 0, false"
+fit = "fit_linearize_kernel<5, false, false"
 sq = {c: get(main, "SQ_" + c)[1] for c in ("WAVES", "BUSY_CYCLES", "INSTS_VALU", "INSTS_SALU", "INSTS_LDS", "WAVE_CYCLES", "WAIT_ANY", "WAIT_INST_ANY")}
 valu = None
 if sq["INSTS_VALU"] and sq["BUSY_CYCLES"]:
@@ -28,7 +28,7 @@ if sq["INSTS_VALU"] and sq["BUSY_CYCLES"]:
 out = {
     "workload": f"2x64_vs_500k_{tag}",
     "kernel": f"mlh::{main} (iterations >= 1 of a solve: the previous iteration's finish in every workgroup, then the bounded search)",
-    "source": f"rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum / --pmc SQ_* (separate passes, --kernel-trace only; scripts/profile_round5.sh), "
+    "source": f"rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum / --pmc SQ_* (separate passes, --kernel-trace only; scripts/profile_round6.sh), "
               f"python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-supplementary --profile-events 0 --synchronous; means over {get(main, 'FETCH_SIZE')[0]} dispatches; FETCH_SIZE doubled per "
               f"MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); see profiles/{tag}_pmc_summary.txt",
     "fetch_size_kb_raw": get(main, "FETCH_SIZE")[1], "write_size_kb": get(main, "WRITE_SIZE")[1],
