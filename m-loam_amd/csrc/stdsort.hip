@@ -102,11 +102,12 @@ constexpr int SS_WIDE_MAXW = 1024;                               // wavefront ch
 constexpr int SS_WIDE_INFO = 16;                                 // ints per wide range in the info block
 constexpr int SS_LEAF_WG = 1024;
 // The mid launch (round 6): what the wide levels leave longer than a leaf is finished -- down to pieces of at most SS_LEAF elements -- by ONE launch in which a
-// workgroup takes a range of up to SS_MID elements into LDS (keys, vals and the two stop tables: 128 KB) and partitions it workgroup-wide there, piece by piece,
+// workgroup takes a range of up to SS_MID elements into LDS (keys, vals and the two stop tables -- 16-bit: positions local to the range --: 144 KB) and partitions it
+// workgroup-wide there, piece by piece,
 // until every piece fits a leaf. Through round 5 these were seven more big levels: a launch each (~9 us: eight dependent trips to global memory for a range of a
 // few thousand elements) for a chain of 2-4 partitions per range. Same partition function (wg_partition), same cuts.
 #ifndef MLH_SS_MID
-#define MLH_SS_MID 8192
+#define MLH_SS_MID 12288
 #endif
 constexpr int SS_MID = MLH_SS_MID;
 constexpr int SS_MID_STACK = 64;                                      // ranges a workgroup of the mid launch still owes (depth first)
@@ -204,7 +205,8 @@ __device__ inline void heap_sort_range(int *k, int *v, int len) { ss_heap_sort_r
 // over that predicate, and the pairs are swapped in parallel. (Rounds 2-3 streamed the keys twice, a count pass in front of the table pass: the launch is
 // bound by instruction issue on its ONE compute unit, and the count pass was a third of it -- thinning 0.52 -> 0.48 ms per frame without it.)
 // keys / vals / lt / rt: global memory; w_left / w_right (17 ints each) and sh_k: LDS. Returns the cut.
-__device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
+template <typename Tab>
+__device__ __forceinline__ int wg_partition(int *keys, int *vals, Tab *lt, Tab *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
 {
     // w_left / w_right: 17 ints each. In: scratch. During the call: per-wavefront stop counts, then w_left[w] = left stops in the chunks before w (w = 0 .. 16),
     // w_right[w] = right stops in chunks w .. 15 (w_right[16] = 0).
@@ -239,14 +241,14 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, int *lt, int *
         int w = 0;
 #pragma unroll
         for (int step = SS_BIG_WAVES / 2; step > 0; step >>= 1) w += (w_left[w + step] <= k) ? step : 0;
-        return lt[min(f + w * chunk, l) + (k - w_left[w])];
+        return int(lt[min(f + w * chunk, l) + (k - w_left[w])]);
     };
     auto right_at = [&](int k) {
         int w = 0;
 #pragma unroll
         for (int step = SS_BIG_WAVES / 2; step > 0; step >>= 1) w += (w_right[w + step] > k) ? step : 0;
         const int after = w_right[w + 1], cnt = w_right[w] - after;
-        return rt[min(f + w * chunk, l) + (cnt - 1 - (k - after))];
+        return int(rt[min(f + w * chunk, l) + (cnt - 1 - (k - after))]);
     };
     // K = how many pairs cross (L[k] < R[k] holds for a prefix of k): a 64-ary search by the first wavefront instead of testing every pair
     const int npair = min(nL, nR);
@@ -502,7 +504,90 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
 // ------------------------------------------------------------------ the mid launch: ranges of SS_LEAF < m <= SS_MID in LDS, workgroup-wide, down to leaves
 // [f, l) of the global arrays, SS_LEAF < l - f <= SS_MID, into LDS; partitioned there until every piece is at most SS_LEAF long (those go to the leaf list, in
 // global coordinates: the leaf launch finds them in HBM); written back. All threads of the workgroup, converged.
-__device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int l, int depth0, int *sk, int *sv, int *slt, int *srt, int *wl, int *wr, int *sh_k, int *stk)
+typedef unsigned short MidTab;                                        // a position inside a range of at most SS_MID (< 65 536) elements
+// wg_partition for a range that lives in LDS: the same stop lists, pairs and cut, with the tables written at range-wide ranks. Counting the stops first (one more
+// pass over keys that are a ds_read away) puts every stop at its final index -- L[k] = lt[f + k], R[k] = rt[f + nR - 1 - k] -- so the 64-ary search for the number of
+// crossing pairs and every swap read ONE table entry instead of walking the per-wavefront prefix tables (a four-step search through LDS per look-up: a third of a
+// partition's 4 us on these sizes). On global memory the second pass is what costs (stdsort.hip header); here it is what saves.
+__device__ __forceinline__ int wg_partition_lds(int *keys, int *vals, MidTab *lt, MidTab *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = l - f;
+    if (t == 0) { median_to_first(keys, vals, f, l); *sh_k = 0; }
+    __syncthreads();
+    const int piv = keys[f];
+    const int chunk = ((m + SS_BIG_WAVES - 1) / SS_BIG_WAVES + 63) & ~63;      // per wavefront, a multiple of the tile
+    const int lo = min(f + wave * chunk, l), hi = min(lo + chunk, l);
+    const unsigned long long below = ss_lanes_below();
+    IntLess less;
+    int cl = 0, cr = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        const bool in = p < hi;
+        const int k = in ? keys[p] : 0;
+        cl += __popcll(__ballot(in && p > f && !less(k, piv)));
+        cr += __popcll(__ballot(in && (p == f || !less(piv, k))));
+    }
+    if (lane == 0) { w_left[wave + 1] = cl; w_right[wave] = cr; }
+    __syncthreads();
+    if (t < 64) {                                                    // (the prefix / suffix over the 16 wavefronts, as in wg_partition)
+        const int w = lane & 15;
+        int il = w_left[w + 1], ir = w_right[15 - w];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int a = __shfl_up(il, off, 16), b = __shfl_up(ir, off, 16); if (w >= off) { il += a; ir += b; } }
+        if (lane < 16) { w_left[w + 1] = il; w_right[15 - w] = ir; }
+        if (lane == 0) { w_left[0] = 0; w_right[SS_BIG_WAVES] = 0; }
+    }
+    __syncthreads();
+    const int nL = w_left[SS_BIG_WAVES], nR = w_right[0];
+    int run_l = w_left[wave], run_r = nR - w_right[wave];            // left / right stops in the chunks before this one (both lists ascending by position)
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        const bool in = p < hi;
+        const int k = in ? keys[p] : 0;
+        const bool is_l = in && p > f && !less(k, piv);
+        const bool is_r = in && (p == f || !less(piv, k));
+        const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
+        if (is_l) lt[f + run_l + __popcll(ml & below)] = MidTab(p);
+        if (is_r) rt[f + run_r + __popcll(mr & below)] = MidTab(p);
+        run_l += __popcll(ml);
+        run_r += __popcll(mr);
+    }
+    __syncthreads();
+    const int npair = min(nL, nR), rlast = f + nR - 1;               // the k-th right stop from the right: rt[rlast - k]
+    if (wave == 0) {
+        int lo_k = 0, hi_k = npair;
+        while (hi_k > lo_k) {                                        // uniform
+            const int step = (hi_k - lo_k + 63) >> 6;
+            const int k = lo_k + lane * step;
+            const bool pr = k < hi_k && int(lt[f + k]) < int(rt[rlast - k]);
+            const int c = __popcll(__ballot(pr));
+            const int new_hi = min(hi_k, lo_k + c * step);
+            lo_k = c > 0 ? lo_k + (c - 1) * step + 1 : lo_k;
+            hi_k = c > 0 ? max(new_hi, lo_k) : lo_k;
+        }
+        if (lane == 0) *sh_k = lo_k;
+    }
+    __syncthreads();
+    const int K = *sh_k;
+    for (int k = t; k < K; k += SS_BIG_WG) {
+        const int p = int(lt[f + k]), q = int(rt[rlast - k]);
+        const int kp = keys[p], kq = keys[q], vp = vals[p], vq = vals[q];
+        keys[p] = kq; keys[q] = kp; vals[p] = vq; vals[q] = vp;
+    }
+    int cut = INT_MAX;
+    if (t == 0) {
+        if (K < nL) cut = min(cut, int(lt[f + K]));
+        if (K > 0) cut = min(cut, int(rt[rlast - (K - 1)]));
+        *sh_k = cut;
+    }
+    __syncthreads();
+    cut = *sh_k;
+    __syncthreads();                                                 // the tables and sh_k / w_* are reused by the next range
+    return cut;
+}
+constexpr size_t SS_MID_LDS = size_t(SS_MID) * (2 * sizeof(int) + 2 * sizeof(MidTab));
+static_assert(SS_MID < 65536 && SS_MID_LDS <= 150 * 1024, "the mid launch's range has to fit 16-bit positions and the compute unit's LDS");
+__device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int l, int depth0, int *sk, int *sv, MidTab *slt, MidTab *srt, int *wl, int *wr, int *sh_k, int *stk)
 {
     const int t = threadIdx.x, m = l - f;
     for (int i = t; i < m; i += SS_BIG_WG) { sk[i] = A.keys[f + i]; sv[i] = A.vals[f + i]; }
@@ -529,7 +614,7 @@ __device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int
             continue;
         }
         [[maybe_unused]] const unsigned long long cp = MLH_SCLK();
-        const int cut = wg_partition(sk, sv, slt, srt, a, b, wl, wr, sh_k);
+        const int cut = wg_partition_lds(sk, sv, slt, srt, a, b, wl, wr, sh_k);
         MLH_MACC(0, 1); MLH_MACC(1, MLH_SCLK() - cp); MLH_MACC(2, b - a);
         route(cut, b, d - 1);                                        // the library's recursive call
         route(a, cut, d - 1);                                        // its loop's next trip
@@ -541,10 +626,11 @@ __device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int
 
 __global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, int level)
 {
-    extern __shared__ int s_mid[];                                   // keys | vals | left stops | right stops, SS_MID ints each
+    extern __shared__ int s_mid[];                                   // keys | vals (SS_MID ints each) | left stops | right stops (SS_MID 16-bit positions each)
     __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1], sh_k;
     __shared__ int s_stk[3 * SS_MID_STACK], s_gstk[3 * SS_MID_STACK];
-    int *sk = s_mid, *sv = s_mid + SS_MID, *slt = s_mid + 2 * SS_MID, *srt = s_mid + 3 * SS_MID;
+    int *sk = s_mid, *sv = s_mid + SS_MID;
+    MidTab *slt = reinterpret_cast<MidTab *>(s_mid + 2 * SS_MID), *srt = slt + SS_MID;
     const SortSeg *cur = A.seg[level & 1];
     const int count = A.cnt[level];
     const int t = threadIdx.x;
@@ -771,7 +857,7 @@ static bool stdsort_mid_lds_granted(int device)
     if (device < 0 || device >= 64) return false;
     std::lock_guard<std::mutex> lock(mu);
     if (state[device] == 0) {
-        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(stdsort_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(sizeof(int) * 4 * SS_MID)) == hipSuccess;
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(stdsort_mid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(SS_MID_LDS)) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         state[device] = ok ? 1 : -1;
     }
@@ -821,7 +907,7 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
             static const int extra = std::getenv("MLH_SS_WIDE_EXTRA") ? std::atoi(std::getenv("MLH_SS_WIDE_EXTRA")) : MLH_SS_WIDE_EXTRA;      // (A/B runs)
             n_wide_levels = std::min(n_levels, lg + extra);
         }
-        // the mid launch behind the wide levels instead of the remaining big levels (MLH_SS_MID_OFF: A/B runs; a device that does not grant its 128 KB of LDS)
+        // the mid launch behind the wide levels instead of the remaining big levels (MLH_SS_MID_OFF: A/B runs; a device that does not grant its 144 KB of LDS)
         static const bool mid_off = std::getenv("MLH_SS_MID_OFF") != nullptr;
         const bool mid = !mid_off && n_wide_levels < SS_BIG_LEVELS && stdsort_mid_lds_granted(ctx->device);
         if (mid) n_levels = n_wide_levels;
@@ -834,7 +920,7 @@ static int stdsort_levels(mlh_ctx *ctx, StdSortArgs A, int longest, size_t nbig,
         if (mid) {
             // one workgroup per range the wide levels left longer than a leaf (at most n / SS_LEAF of them); it leaves nothing for a next level
             const int grid_mid = int(std::min<size_t>(nbig, 256));
-            MLH_LAUNCH(stdsort_mid_kernel, dim3(grid_mid), dim3(SS_BIG_WG), sizeof(int) * 4 * SS_MID, st, A, n_levels);
+            MLH_LAUNCH(stdsort_mid_kernel, dim3(grid_mid), dim3(SS_BIG_WG), SS_MID_LDS, st, A, n_levels);
             A.over_level = n_levels + 1;                          // (an empty list: the init launch cleared every level's counter)
         } else A.over_level = n_levels;
     }

@@ -194,8 +194,8 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
 // chunks' sub-tables cannot overlap); n_left / n_right = how many. The k-th right stop counted from the RIGHT end -- the one the partition loop pairs with the
 // k-th left stop -- is entry (n_right - 1 - k) of that list; a count pass in front (rounds 2 and 3 had one, to rank the right stops from the right while
 // writing) is not needed. Used by the wave-level partitions below and, chunk by chunk, by the 1024-thread partitions of stdsort.hip's big levels.
-template <int SS_U, typename Less>
-__device__ inline void ss_wave_stop_lists(const int *keys, int *lt, int *rt, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
+template <int SS_U, typename Less, typename Tab>      // Tab: int, or unsigned short where the positions are local to a range of < 65 536 elements (stdsort.hip: the mid launch's LDS tables)
+__device__ inline void ss_wave_stop_lists(const int *keys, Tab *lt, Tab *rt, int f, int lo, int hi, int piv, int &n_left, int &n_right, Less less)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = ss_lanes_below();
@@ -211,8 +211,8 @@ __device__ inline void ss_wave_stop_lists(const int *keys, int *lt, int *rt, int
             const bool is_l = in && p > f && !less(k[u], piv);
             const bool is_r = in && (p == f || !less(piv, k[u]));
             const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
-            if (is_l) lt[lo + run_l + __popcll(ml & below)] = p;
-            if (is_r) rt[lo + run_r + __popcll(mr & below)] = p;
+            if (is_l) lt[lo + run_l + __popcll(ml & below)] = Tab(p);
+            if (is_r) rt[lo + run_r + __popcll(mr & below)] = Tab(p);
             run_l += __popcll(ml);
             run_r += __popcll(mr);
         }
