@@ -167,6 +167,7 @@ struct FeatSet {
     DevBuf nbr;        // 5 float4 per feature: the 5 nearest map points + squared distances
     DevBuf r, J;       // dense residual / Jacobian (double, double[6]) when requested
     DevBuf fps_order;  // 'fps' selection: [count][visiting order] (select.hip: fps_order_kernel)
+    DevBuf fps_work;   // 'fps' selection: Morton keys, ranks, permutation of the pruned loop (select.hip: fps_order_pruned_kernel)
     DevBuf flag8;      // one byte per feature: Corr::valid on the way to the host, the selection's verdict on the way back (select.hip)
     int m = 0;             // feature slots (real + padding between pose blocks)
     int n_blocks = 1;

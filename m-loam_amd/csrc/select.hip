@@ -5,6 +5,7 @@
 #include "ctx.hpp"
 #include "alive_pool.hpp"
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
@@ -143,6 +144,257 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__
     if (t == 0) *n_order = n_out;
 }
 #undef FPS_FOR16
+
+// ---- fps with exact pruning (round 6). fps_order_kernel above pays 2.8 us per visit whatever the visit changes: every unvisited point's distance to the new pick,
+// every round. But `dist[j] = min(d, dist[j])` (lidar_mapper.h:403-404) only CHANGES points closer to the pick than their running minimum, and after k visits that
+// is a neighbourhood of ~N / k points. So: the points are put in Morton order (fps_keys / fps_rank / fps_perm kernels: 30-bit keys, rank by counting), a BUCKET is
+// the 64 points one wavefront holds in one register slot (lane l of wavefront w, slot k <-> Morton position ((k * 8 + w) * 64 + l: neighbouring buckets -- the ones a
+// pick re-measures together -- belong to different wavefronts), and lane k of the wavefront keeps
+// slot k's bounding box and its cached arg-max (largest running minimum among its unvisited points, lowest original index among equals, that point's coordinates).
+// A round: 32 lanes test their slot's box against the pick (a slot whose box is farther from the pick than its largest running minimum cannot change: for every
+// point in it the host's `d2 = min(d, dist[j])` returns dist[j]), the slots that pass are re-measured -- per point exactly the host loop's f32 arithmetic, as above --
+// and their arg-max re-cached; the wavefront's best slot, then the best of the 8 wavefronts (one barrier per round: the candidates alternate between two LDS sets).
+// The same picks in the same order as fps_order_kernel and the host loop (tests: goodFeatureMatching 'fps' pick for pick); 2.8 -> ~0.5 us per visit.
+// The box test is conservative by 1e-4 relative against ~3e-7 of rounding in either distance, and only applied to a squared box distance in the normal range;
+// a cloud with ANY non-finite coordinate is run with the test switched off (every slot re-measured every round: comparisons with NaN as the host's).
+constexpr int FPP_WAVES = 8, FPP_SLOTS = 32, FPP_THREADS = FPP_WAVES * 64;      // 16 384 points, as the dense kernel
+static_assert(FPP_WAVES * FPP_SLOTS * 64 == FPS_THREADS * FPS_PMAX, "both fps kernels take the same clouds");
+constexpr int FPR_TPB = 256, FPR_PARTS = 8, FPR_TILE = 1024;
+#define FPP_FOR32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
+                     M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+
+__device__ __forceinline__ unsigned fpp_ord(float f) { const unsigned b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }   // float order -> unsigned order
+__device__ __forceinline__ float fpp_unord(unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
+__device__ __forceinline__ unsigned fpp_spread3(unsigned v)       // 10 bits -> every third bit
+{
+    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ float fpp_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// one workgroup: the cloud's bounding box, then a 30-bit Morton key per point (cubic cells: 1024 along the longest side); aux[0] = "a coordinate is not finite"
+__global__ __launch_bounds__(1024) void fps_keys_kernel(const float4 *__restrict__ pts, int n, unsigned *__restrict__ keys, int *__restrict__ rank, int *__restrict__ aux)
+{
+    __shared__ unsigned s_lo[3][16], s_hi[3][16];
+    __shared__ int s_bad;
+    const int t = threadIdx.x;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    unsigned lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    bool bad = false;
+    for (int i = t; i < n; i += 1024) {
+        const float4 p = pts[i];
+        const float c[3] = {p.x, p.y, p.z};
+        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { bad = true; continue; }
+        for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], fpp_ord(c[a])); hi[a] = max(hi[a], fpp_ord(c[a])); }
+    }
+    if (bad) s_bad = 1;
+    for (int a = 0; a < 3; ++a) {
+        const unsigned l = fps_wave_umin(lo[a]), h = fps_wave_umax(hi[a]);
+        if ((t & 63) == 0) { s_lo[a][t >> 6] = l; s_hi[a][t >> 6] = h; }
+    }
+    __syncthreads();
+    float blo[3], scale = 0.f;
+    {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            unsigned l = ~0u, h = 0u;
+            for (int w = 0; w < 16; ++w) { l = min(l, s_lo[a][w]); h = max(h, s_hi[a][w]); }
+            blo[a] = fpp_unord(l);
+            const float e = fpp_unord(h) - blo[a];
+            if (l <= h && e > ext) ext = e;
+        }
+        if (ext > 0.f && isfinite(ext)) scale = 1023.f / ext;
+    }
+    for (int i = t; i < n; i += 1024) {
+        const float4 p = pts[i];
+        unsigned key = 0x3fffffffu;
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const unsigned qx = unsigned(fminf(fmaxf((p.x - blo[0]) * scale, 0.f), 1023.f)), qy = unsigned(fminf(fmaxf((p.y - blo[1]) * scale, 0.f), 1023.f)),
+                           qz = unsigned(fminf(fmaxf((p.z - blo[2]) * scale, 0.f), 1023.f));
+            key = fpp_spread3(qx) | (fpp_spread3(qy) << 1) | (fpp_spread3(qz) << 2);
+        }
+        keys[i] = key;
+        rank[i] = 0;
+    }
+    if (t < 16) aux[t] = t == 0 ? s_bad : 0;
+}
+
+// rank[i] += the number of points of this launch row's share that sort before point i (key, then index): grid (ceil(n / 256), FPR_PARTS)
+__global__ __launch_bounds__(FPR_TPB) void fps_rank_kernel(const unsigned *__restrict__ keys, int n, int *__restrict__ rank)
+{
+    __shared__ unsigned s_k[FPR_TILE];
+    const int i = blockIdx.x * FPR_TPB + threadIdx.x;
+    const unsigned ki = i < n ? keys[i] : 0u;
+    const int share = (n + FPR_PARTS - 1) / FPR_PARTS, j0 = int(blockIdx.y) * share, j1 = min(n, j0 + share);
+    int cnt = 0;
+    for (int base = j0; base < j1; base += FPR_TILE) {
+        const int len = min(FPR_TILE, j1 - base);
+        __syncthreads();
+        for (int q = threadIdx.x; q < len; q += FPR_TPB) s_k[q] = keys[base + q];
+        __syncthreads();
+        for (int q = 0; q < len; ++q) cnt += (s_k[q] < ki + ((base + q) < i ? 1u : 0u)) ? 1 : 0;      // (key_j, j) < (key_i, i); keys are 30 bits
+    }
+    if (i < n && cnt) atomicAdd(rank + i, cnt);
+}
+__global__ void fps_perm_kernel(const int *__restrict__ rank, int n, int *__restrict__ perm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[rank[i]] = i;
+}
+
+// what a re-measured slot leaves with its owner lane: the slot's arg-max
+__device__ __forceinline__ void fpp_slot_finish(unsigned key, unsigned id, float px, float py, float pz, unsigned v, int k, int lane, unsigned &bkey, unsigned &bj,
+                                                float &bx, float &by, float &bz, unsigned &bloc)
+{
+    const unsigned mk = fps_wave_umax(key);
+    unsigned long long wb = __ballot(key == mk);
+    unsigned mj = ~0u;
+    int wl = 0;
+    if (mk) {
+        if (__popcll(wb) != 1) {                                     // equal distances (rare): the lowest original index among them
+            mj = fps_wave_umin(key == mk ? id : ~0u);
+            wb = __ballot(key == mk && id == mj);
+        }
+        wl = __ffsll(wb) - 1;
+        mj = unsigned(__builtin_amdgcn_readlane(int(id), wl));
+    }
+    const float wx = fpp_readlane(px, wl), wy = fpp_readlane(py, wl), wz = fpp_readlane(pz, wl);
+    const unsigned wv = unsigned(__builtin_amdgcn_readlane(int(v), wl));
+    if (lane == k) { bkey = mk; bj = mj; bx = wx; by = wy; bz = wz; bloc = unsigned(k << 6 | wl) | (wv << 31); }
+}
+
+__global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(const float4 *__restrict__ pts, const uint8_t *__restrict__ valid, const int *__restrict__ perm,
+                                                                       const int *__restrict__ aux, int n, int n_use, int cur0, int *__restrict__ order,
+                                                                       int *__restrict__ n_order)
+{
+    __shared__ uint4 s_c[2][FPP_WAVES][2];                           // a wavefront's candidate: {key, index, location | matched, -}, {x, y, z, -}; two sets
+    __shared__ unsigned short s_id[FPP_WAVES * FPP_SLOTS * 64];      // original index by Morton position    } 96 KB of LDS for 64 registers a lane does not have
+    __shared__ float s_dist[FPP_WAVES * FPP_SLOTS * 64];             // running minimum by Morton position   } (read and written by re-measured slots only)
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const bool prune = aux[0] == 0;
+    const unsigned short *my_id = s_id + w * 64 + lane;             // slot k: + k * FPP_WAVES * 64
+    float *my_dist = s_dist + w * 64 + lane;
+    unsigned vis = 0, val = 0;          // bit k: the point of slot k has been visited (or does not exist) / is a matched feature
+#define FPP_LOAD(k)                                                                                                  \
+    float px##k, py##k, pz##k;                                                                                       \
+    {                                                                                                                \
+        const int pos = (k * FPP_WAVES + w) * 64 + lane, j = pos < n ? perm[pos] : -1, jj = j >= 0 ? j : cur0;       \
+        const float4 p = pts[jj];                                                                                    \
+        px##k = p.x; py##k = p.y; pz##k = p.z; s_id[pos] = (unsigned short)(j); s_dist[pos] = 1e5f;                  \
+        vis |= ((j >= 0 && j != cur0) ? 0u : 1u) << k;                                                               \
+        val |= ((j >= 0 && valid[jj]) ? 1u : 0u) << k;                                                               \
+    }
+    FPP_FOR32(FPP_LOAD)
+#undef FPP_LOAD
+    // lane k: slot k's box and cached arg-max (key = distance bits + 1, 0 = no candidate left; before the first round: +inf, "measure me")
+    float lox = 0.f, loy = 0.f, loz = 0.f, hix = 0.f, hiy = 0.f, hiz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+    unsigned bkey = 0u, bj = ~0u, bloc = 0u;
+#define FPP_BOX(k)                                                                                                   \
+    {                                                                                                                \
+        const bool ex = (k * FPP_WAVES + w) * 64 + lane < n;                                                           \
+        const unsigned ax = fps_wave_umin(ex ? fpp_ord(px##k) : ~0u), bxx = fps_wave_umax(ex ? fpp_ord(px##k) : 0u); \
+        const unsigned ay = fps_wave_umin(ex ? fpp_ord(py##k) : ~0u), byy = fps_wave_umax(ex ? fpp_ord(py##k) : 0u); \
+        const unsigned az = fps_wave_umin(ex ? fpp_ord(pz##k) : ~0u), bzz = fps_wave_umax(ex ? fpp_ord(pz##k) : 0u); \
+        const bool any = __ballot(!(vis >> k & 1u)) != 0ull;                                                         \
+        if (lane == k) {                                                                                             \
+            lox = fpp_unord(ax); hix = fpp_unord(bxx); loy = fpp_unord(ay); hiy = fpp_unord(byy); loz = fpp_unord(az); hiz = fpp_unord(bzz); \
+            bkey = any ? 0x7f800001u : 0u;                                                                           \
+        }                                                                                                            \
+    }
+    FPP_FOR32(FPP_BOX)
+#undef FPP_BOX
+    float ox, oy, oz;
+    int n_sel;
+    {
+        const float4 p = pts[cur0];
+        ox = p.x; oy = p.y; oz = p.z;
+        n_sel = (valid[cur0] && n_use > 0) ? 1 : 0;
+    }
+    int n_visited = 1, n_out = 0, par = 0;
+    while (n_sel < n_use && n_visited < n) {
+        unsigned act;
+        {
+            const float ax = fmaxf(fmaxf(lox - ox, ox - hix), 0.f), ay = fmaxf(fmaxf(loy - oy, oy - hiy), 0.f), az = fmaxf(fmaxf(loz - oz, oz - hiz), 0.f);
+            const float lb2 = ax * ax + ay * ay + az * az;
+            const float md = __uint_as_float(bkey - 1u);
+            const bool pruned = prune && lb2 > 1e-30f && lb2 * 0.9999f > md * md;
+            act = unsigned(__ballot(lane < FPP_SLOTS && bkey != 0u && !pruned));
+        }
+#ifdef MLH_FPS_STATS
+        if (lane == 0) { atomicAdd(const_cast<int *>(aux) + 1, __popc(act)); atomicMax(const_cast<int *>(aux) + 3 + w, __popc(act)); if (t == 0) atomicAdd(const_cast<int *>(aux) + 2, 1); }
+#endif
+        while (act) {                                                // (uniform)
+            const int k = __ffs(act) - 1;
+            act &= act - 1u;
+            switch (k) {
+#define FPP_CASE(k)                                                                                                  \
+            case k: {                                                                                                \
+                unsigned key = 0u;                                                                                   \
+                unsigned vv = vis;                                                                                   \
+                asm volatile("" : "+v"(vv));                               /* (as below: 32 bit tests per round otherwise) */ \
+                if (!(vv >> k & 1u)) {                                                                               \
+                    /* (the empty asm keeps the 32 slots' square roots INSIDE their cases: hoisted out of this loop as loop-invariant code they cost */ \
+                    /*  3 us per round -- every slot measured every round, the work this kernel exists to skip) */ \
+                    float qx = ox, qy = oy, qz = oz;                                                                 \
+                    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));                                                 \
+                    const float ddx = qx - px##k, ddy = qy - py##k, ddz = qz - pz##k;                                \
+                    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)));    /* sqrtf: see fps_order_kernel */ \
+                    const float dk = my_dist[k * FPP_WAVES * 64];                                                          \
+                    const float d2 = (dk < d) ? dk : d;                    /* std::min(d, dist[j]) */                \
+                    my_dist[k * FPP_WAVES * 64] = d2;                                                                     \
+                    key = (d2 > -1.f) ? __float_as_uint(d2) + 1u : 0u;     /* `d2 > best_d` from best_d = -1: false for NaN */ \
+                }                                                                                                    \
+                fpp_slot_finish(key, my_id[k * FPP_WAVES * 64], px##k, py##k, pz##k, val >> k & 1u, k, lane, bkey, bj, bx, by, bz, bloc); \
+            } break;
+            FPP_FOR32(FPP_CASE)
+#undef FPP_CASE
+            default: break;
+            }
+        }
+        // the wavefront's best slot -> LDS; then the best of the wavefronts (every wavefront works it out for itself)
+        const unsigned k1 = lane < FPP_SLOTS ? bkey : 0u;
+        const unsigned wk = fps_wave_umax(k1);
+        unsigned long long sb = __ballot(lane < FPP_SLOTS && k1 == wk);
+        int sl = 0;
+        if (wk) {
+            if (__popcll(sb) != 1) {
+                const unsigned wj2 = fps_wave_umin((lane < FPP_SLOTS && k1 == wk) ? bj : ~0u);
+                sb = __ballot(lane < FPP_SLOTS && k1 == wk && bj == wj2);
+            }
+            sl = __ffsll(sb) - 1;
+        }
+        const unsigned wj = wk ? bj : ~0u;                           // (lane sl's, below)
+        if (lane == sl) {
+            s_c[par][w][0] = make_uint4(wk, wj, bloc, 0u);
+            s_c[par][w][1] = make_uint4(__float_as_uint(bx), __float_as_uint(by), __float_as_uint(bz), 0u);
+        }
+        __syncthreads();
+        const bool rd = lane < FPP_WAVES;
+        const uint4 c0 = s_c[par][rd ? lane : 0][0], c1 = s_c[par][rd ? lane : 0][1];
+        const unsigned gk_l = rd ? c0.x : 0u, gj_l = c0.y, gl_l = c0.z;
+        const float gx_l = __uint_as_float(c1.x), gy_l = __uint_as_float(c1.y), gz_l = __uint_as_float(c1.z);
+        const unsigned gk = unsigned(__builtin_amdgcn_readlane(int(fps_row_umax(gk_l)), 15));
+        if (!gk) { if (t == 0) *n_order = -1; return; }             // only with NaN coordinates: the host loop takes the call
+        unsigned long long gb = __ballot(rd && gk_l == gk);
+        if (__popcll(gb) != 1) {
+            const unsigned gj2 = unsigned(__builtin_amdgcn_readlane(int(fps_row_umin((rd && gk_l == gk) ? gj_l : ~0u)), 15));
+            gb = __ballot(rd && gk_l == gk && gj_l == gj2);
+        }
+        const int ww = __ffsll(gb) - 1;
+        const unsigned gj = unsigned(__builtin_amdgcn_readlane(int(gj_l), ww));
+        const unsigned gloc = unsigned(__builtin_amdgcn_readlane(int(gl_l), ww));
+        ox = fpp_readlane(gx_l, ww); oy = fpp_readlane(gy_l, ww); oz = fpp_readlane(gz_l, ww);
+        if (w == ww && lane == int(gloc & 63u)) vis |= 1u << ((gloc >> 6) & 31u);
+        if (t == 0) order[n_out] = int(gj);
+        ++n_out;
+        ++n_visited;
+        if (gloc >> 31) ++n_sel;
+        par ^= 1;
+    }
+    if (t == 0) *n_order = n_out;
+}
+#undef FPP_FOR32
 
 struct Rows {               // per-feature results of the GPU pass, copied out of the context's pinned staging block
     const uint8_t *valid = nullptr;   // Corr::valid != 0
@@ -440,11 +692,34 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt
         // the one number this method draws (the starting point, lidar_mapper.h:356) is drawn here, in call order: corner before surf, as the finishes will run
         const size_t cur0 = draw(rng, 0, m - 1);
         ctx->select_fps_start[kind] = long(cur0);
-        static const bool fps_on_host = std::getenv("MLH_FPS_HOST") != nullptr;          // (measurement only: the host loop on every call)
+        const bool fps_on_host = std::getenv("MLH_FPS_HOST") != nullptr;          // (measurement / tests only: the host loop on every call)
         if (m <= size_t(FPS_THREADS) * FPS_PMAX && !fps_on_host) {
             MLH_HIP(ctx, f.fps_order.ensure(sizeof(int) * (m + 1)));
-            MLH_LAUNCH(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
-                               int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
+            const bool fps_dense = std::getenv("MLH_FPS_DENSE") != nullptr;        // (A/B / tests: the round-4 kernel that re-measures every point every round)
+            if (fps_dense) {
+                MLH_LAUNCH(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
+                                   int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
+            } else {
+                // Morton order of the cloud (keys, rank by counting, permutation), then the pruned loop: [keys m][rank m][perm m][aux 16]
+                MLH_HIP(ctx, f.fps_work.ensure(sizeof(int) * (3 * m + 16)));
+                unsigned *keys = f.fps_work.as<unsigned>();
+                int *rank = f.fps_work.as<int>() + m, *perm = rank + m, *aux = perm + m;
+                MLH_LAUNCH(fps_keys_kernel, dim3(1), dim3(1024), 0, ctx->stream, f.pts.as<float4>(), int(m), keys, rank, aux);
+                MLH_LAUNCH(fps_rank_kernel, dim3(unsigned((m + FPR_TPB - 1) / FPR_TPB), FPR_PARTS), dim3(FPR_TPB), 0, ctx->stream, keys, int(m), rank);
+                MLH_LAUNCH(fps_perm_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, rank, int(m), perm);
+                MLH_LAUNCH(fps_order_pruned_kernel, dim3(1), dim3(FPP_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), perm, aux, int(m),
+                                   int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
+#ifdef MLH_FPS_STATS
+                {
+                    int h[16] = {0};
+                    (void)hipStreamSynchronize(ctx->stream);
+                    (void)hipMemcpy(h, aux, sizeof(h), hipMemcpyDeviceToHost);
+                    std::fprintf(stderr, "fps stats: m %zu nonfinite %d rounds %d slots re-measured %d (%.2f per round, all waves); per-wave max in a round:", m, h[0], h[2], h[1], h[2] ? double(h[1]) / h[2] : 0.0);
+                    for (int q = 0; q < FPP_WAVES; ++q) std::fprintf(stderr, " %d", h[3 + q]);
+                    std::fprintf(stderr, "\n");
+                }
+#endif
+            }
             MLH_HIP(ctx, hipGetLastError());
             MLH_HIP(ctx, hipMemcpyAsync(hb + off_o, f.fps_order.p, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, ctx->stream));
         } else {

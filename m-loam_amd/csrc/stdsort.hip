@@ -112,13 +112,14 @@ constexpr int SS_LEAF_WG = 1024;
 constexpr int SS_MID = MLH_SS_MID;
 constexpr int SS_MID_STACK = 64;                                      // ranges a workgroup of the mid launch still owes (depth first)
 constexpr int SS_LOCAL_LIST = 2 * SS_LEAF / (SS_THRESHOLD + 1) + 8;   // queue records of a leaf in LDS: the ranges the workgroup-wide phase hands over + one per partition with two children > 16 inside each
-// A leaf's ranges longer than this are partitioned by the WHOLE workgroup (wg_partition: 16 wavefronts, a sixteenth of the range each), one after the other, before
-// the wavefronts go their own ways. Measured on the frame's thinning (profiles/r05_knockout_experiments.txt item 14): for ranges that live in LDS it does NOT pay --
-// 512: 0.2077, 256: 0.2253, 1024: 0.2008 against 0.2027 ms per call without -- a wavefront streams a 2 048-element range from LDS faster than sixteen of them get
-// through wg_partition's barriers and its 64-ary search. So the default is the leaf size: only an oversize leaf (a range the big levels left longer than SS_LEAF,
-// worked on in GLOBAL memory) starts workgroup-wide, which is what wg_partition was written for. Same partition function, same cuts, either way.
+// A leaf's ranges longer than this are partitioned by the WHOLE workgroup (16 wavefronts, a sixteenth of the range each), one after the other, before the wavefronts
+// go their own ways. With wg_partition (written for global memory: per-wavefront prefix tables, a four-step search per look-up) it did NOT pay for ranges that live in
+// LDS (profiles/r05_knockout_experiments.txt item 14: 512: 0.2077, 256: 0.2253, 1024: 0.2008 against 0.2027 ms per thinning call without). With the LDS partition
+// function of the mid launch (wg_partition_lds: stops at range-wide ranks, one table entry per look-up) it does (round 6, three alternations): 768: 0.1872-0.1876,
+// 512: 0.1884-0.1885, 1024: 0.1904-0.1911, 1536: 0.1899-0.1927 against 0.1924-0.1960 without. Same cuts either way; an oversize leaf (longer than SS_LEAF, worked
+// on in GLOBAL memory) always starts workgroup-wide through wg_partition.
 #ifndef MLH_SS_LEAF_WIDE
-#define MLH_SS_LEAF_WIDE MLH_SS_LEAF
+#define MLH_SS_LEAF_WIDE 768
 #endif
 constexpr int SS_LEAF_WIDE = MLH_SS_LEAF_WIDE;
 constexpr int SS_LEAF_STACK = 32;                                     // ranges the workgroup-wide phase still owes (depth first: a handful)
@@ -509,7 +510,8 @@ typedef unsigned short MidTab;                                        // a posit
 // pass over keys that are a ds_read away) puts every stop at its final index -- L[k] = lt[f + k], R[k] = rt[f + nR - 1 - k] -- so the 64-ary search for the number of
 // crossing pairs and every swap read ONE table entry instead of walking the per-wavefront prefix tables (a four-step search through LDS per look-up: a third of a
 // partition's 4 us on these sizes). On global memory the second pass is what costs (stdsort.hip header); here it is what saves.
-__device__ __forceinline__ int wg_partition_lds(int *keys, int *vals, MidTab *lt, MidTab *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
+template <typename Tab>
+__device__ __forceinline__ int wg_partition_lds(int *keys, int *vals, Tab *lt, Tab *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
 {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = l - f;
     if (t == 0) { median_to_first(keys, vals, f, l); *sh_k = 0; }
@@ -547,8 +549,8 @@ __device__ __forceinline__ int wg_partition_lds(int *keys, int *vals, MidTab *lt
         const bool is_l = in && p > f && !less(k, piv);
         const bool is_r = in && (p == f || !less(piv, k));
         const unsigned long long ml = __ballot(is_l), mr = __ballot(is_r);
-        if (is_l) lt[f + run_l + __popcll(ml & below)] = MidTab(p);
-        if (is_r) rt[f + run_r + __popcll(mr & below)] = MidTab(p);
+        if (is_l) lt[f + run_l + __popcll(ml & below)] = Tab(p);
+        if (is_r) rt[f + run_r + __popcll(mr & below)] = Tab(p);
         run_l += __popcll(ml);
         run_r += __popcll(mr);
     }
@@ -689,6 +691,7 @@ __device__ inline void wg_store(int *p, int v) { __hip_atomic_store(p, v, __ATOM
 __device__ inline void wg_fence() { ss_wg_fence(); }
 
 // wl / wr (17 ints each), sk, stk (3 * SS_LEAF_STACK ints): LDS scratch of the workgroup-wide phase
+template <bool LDS>      // LDS: M's arrays live in LDS (the workgroup-wide partitions take wg_partition_lds)
 __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, int *sh, int *err, int *wl, int *wr, int *sk, int *stk)
 {
     const int t = threadIdx.x, lane = t & 63;
@@ -698,7 +701,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
     // where a range goes: the workgroup-wide stack, the wavefronts' queue, the final-insertion list (thread 0; the workgroup-wide phase is single-file)
     auto route = [&](int lo, int hi, int d, int &top) {
         const int size = hi - lo;
-        if (size > SS_LEAF_WIDE && top < SS_LEAF_STACK) {
+        if (size > (LDS ? SS_LEAF_WIDE : SS_LEAF) && top < SS_LEAF_STACK) {
             if (t == 0) { stk[3 * top] = lo; stk[3 * top + 1] = hi; stk[3 * top + 2] = d; }
             ++top;                                                   // (uniform: every thread keeps the count)
         } else if (t == 0) {
@@ -718,7 +721,7 @@ __device__ __forceinline__ void leaf_sort(const LeafMem &M, int m, int depth0, i
                 if (t == 0) { heap_sort_range(M.keys + f, M.vals + f, l - f); sh[LQ_REMAINING] -= l - f; }
                 continue;
             }
-            const int cut = wg_partition(M.keys, M.vals, M.lt, M.rt, f, l, wl, wr, sk);
+            const int cut = LDS ? wg_partition_lds(M.keys, M.vals, M.lt, M.rt, f, l, wl, wr, sk) : wg_partition(M.keys, M.vals, M.lt, M.rt, f, l, wl, wr, sk);
             route(cut, l, d - 1, top);                               // the library's recursive call
             route(f, cut, d - 1, top);                               // its loop's next trip
         }
@@ -835,14 +838,14 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
             for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
             M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
             __syncthreads();
-            leaf_sort(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
+            leaf_sort<true>(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
             for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
             MLH_SSTAGE(6);
             __syncthreads();
         } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
             M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
             M.q = A.glist + f; M.qcap = min(2 * (m / (SS_THRESHOLD + 1)) + 2, m / 4);
-            leaf_sort(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
+            leaf_sort<false>(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
         }
     }
 }

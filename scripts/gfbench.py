@@ -23,7 +23,7 @@ ctx.map_set(mla.SURF, surf_map); ctx.map_set(mla.CORNER, corner_map)
 fs = ctx.downsample_current_scan(mla.SURF, surf, 0.4, ext, covs, meas, True, 0.6)
 fc = ctx.downsample_current_scan(mla.CORNER, corner, 0.2, ext, covs, meas, True, 0.6)
 print("features surf/corner", len(fs), len(fc))
-for method in ("wo_gf", "gd_fix", "rnd", "fps"):
+for method in (os.environ.get("GF_ONLY", "wo_gf,gd_fix,rnd,fps").split(",")):
     opts = mla.default_opts(flags=mla.FLAG_WITH_UA if hasattr(mla, "FLAG_WITH_UA") else 2, gf_method=mla.GF_METHODS[method], gf_ratio=0.2, gf_seed=7)
     for _ in range(2): ctx.map_rebuild(mla.ALL_KINDS); pose, st = ctx.scan2map(p0, opts)
     t = time.perf_counter(); n = 10

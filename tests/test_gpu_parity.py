@@ -536,14 +536,30 @@ def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
     assert lin["count"] == len(ref["sel"])
 
 
-@pytest.mark.parametrize("variant", ["lattice", "duplicates", "five_points", "ratio_zero", "ratio_one", "nothing_matches", "host_loop"])
+@pytest.mark.parametrize("variant", ["lattice", "duplicates", "five_points", "ratio_zero", "ratio_one", "nothing_matches", "host_loop", "dense_kernel",
+                                     "lattice_dense_kernel", "nan_points", "inf_point", "one_cluster", "sixty_five_points", "all_the_same_point"])
 def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats16, variant, monkeypatch):
-    """'fps' runs its arg-max loop on the device (select.hip: fps_order_kernel). Equal distances are decided by the lowest index, as the host loop's strict `>`
+    """'fps' runs its arg-max loop on the device (select.hip: fps_order_pruned_kernel -- slots of 64 Morton-ordered points that cannot change are skipped --, and
+    fps_order_kernel, MLH_FPS_DENSE=1, which re-measures every point every round). Equal distances are decided by the lowest index, as the host loop's strict `>`
     over ascending indices decides them: features snapped to a 0.25 m lattice and features repeated verbatim produce such ties by the thousand. Edge sizes:
-    five features, num_use_features = 0, every feature wanted, nothing matched (the loop then visits every point and keeps none); MLH_FPS_HOST=1 runs the
-    host loop through the same entry point. All against the oracle's restatement of the reference loop (lidar_mapper.h:352-408)."""
+    five features, 65 (one slot and one point), num_use_features = 0, every feature wanted, nothing matched (the loop then visits every point and keeps none), every
+    feature the same point (every distance 0); NaN / inf coordinates (the box test is switched off for such a cloud); MLH_FPS_HOST=1 runs the host loop through the
+    same entry point. All against the oracle's restatement of the reference loop (lidar_mapper.h:352-408)."""
     surf = feats16[0].copy()
     ratio, pose = 0.2, case16["p0"]
+    if variant.endswith("dense_kernel"):
+        monkeypatch.setenv("MLH_FPS_DENSE", "1")
+        variant = variant[:-len("dense_kernel")].rstrip("_") or "plain"
+    if variant == "nan_points":
+        surf[37::211, 0] = np.nan; surf[5::977, 2] = np.nan
+    elif variant == "inf_point":
+        surf[123, 1] = np.inf
+    elif variant == "one_cluster":
+        surf[:, :3] = surf[0, :3] + (surf[:, :3] - surf[0, :3]) * np.float32(1e-4)
+    elif variant == "sixty_five_points":
+        surf = np.ascontiguousarray(surf[100:165]); ratio = 0.9
+    elif variant == "all_the_same_point":
+        surf[:, :3] = surf[40, :3]
     if variant == "lattice":
         surf[:, :3] = np.round(surf[:, :3] * 4.0) / 4.0
     elif variant == "duplicates":
