@@ -1804,7 +1804,8 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             // and its copies are still in flight, and each kind's flags go back without a wait (the linearise launch is behind them on the stream)
             std::vector<int32_t> sel;
             for (int kind : {MLH_CORNER, MLH_SURF})
-                if ((rc = good_feature_stage(ctx, kind, opts->gf_method, opts->gf_ratio, rng, opts->min_match_sq_dis, opts->min_plane_dis))) return rc;
+                if ((rc = good_feature_stage(ctx, kind, opts->gf_method, opts->gf_ratio, rng, opts->min_match_sq_dis, opts->min_plane_dis, true))) return rc;
+            if ((rc = good_feature_fps_flush(ctx))) return rc;      // ('fps': the two kinds' loops side by side in one launch; nothing pending otherwise)
             for (int kind : {MLH_CORNER, MLH_SURF}) {
                 double Hsel[36];
                 for (int i = 0; i < 36; ++i) Hsel[i] = (i % 7 == 0) ? 1e-6 : 0.0;

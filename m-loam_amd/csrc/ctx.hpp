@@ -403,6 +403,7 @@ struct mlh_ctx {
     unsigned long long select_seq[2] = {0, 0};  // stream_flag_post after each kind's copies to the host
     bool select_staged[2] = {false, false};
     long select_fps_start[2] = {-1, -1};        // 'fps': the starting point drawn at staging time
+    struct { int active = 0, m = 0, n_use = 0, cur0 = 0; void *host_dst = nullptr; } fps_pending[2];   // 'fps': a kind's loop staged but not yet launched (select.hip: good_feature_fps_flush)
     int n_ranks = 1, rank = 0;
     mlh::Profile prof;
 };
@@ -638,7 +639,8 @@ namespace mlh {
 int good_feature_select(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis,
                         float min_plane_dis, std::vector<int32_t> &sel_out, double H[36], uint8_t *matched_out);
 // its two halves: the dense pass + copies to the host, enqueued (no wait); the selection loop on the copied rows, flags sent back (no wait)
-int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis);
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis, bool defer_fps = false);
+int good_feature_fps_flush(mlh_ctx *ctx);          // launches what the stages called with defer_fps left pending (both kinds' 'fps' loops in one launch)
 int odom_good_feature_select(mlh_ctx *ctx, int kind, float gf_ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out);     // select.hip: Estimator::goodFeatureMatching's loop over those rows
 int good_feature_finish(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, std::vector<int32_t> &sel_out, double H[36],
                         uint8_t *matched_out);

@@ -5,6 +5,7 @@
 #include "ctx.hpp"
 #include "alive_pool.hpp"
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -83,8 +84,9 @@ constexpr int FPS_THREADS = 1024, FPS_PMAX = 16;      // up to 16384 points on t
 // around every conditional element update -- 1173 spilled registers)
 #define FPS_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__restrict__ pts, const uint8_t *__restrict__ valid, int n, int n_use, int cur0,
-                                                                 int *__restrict__ order, int *__restrict__ n_order)
+                                                                 int *__restrict__ order, int *__restrict__ n_order, const int *__restrict__ gate)
 {
+    if (gate && gate[0] == 0) return;                               // (behind fps_order_pruned_kernel: only the clouds that kernel leaves alone)
     __shared__ unsigned s_d[FPS_THREADS / 64], s_j[FPS_THREADS / 64];   // per wavefront: (distance bits + 1, 0 = no candidate) and the lowest index that has it
     __shared__ float s_cur[4];
     const int t = threadIdx.x;
@@ -243,63 +245,91 @@ __global__ void fps_perm_kernel(const int *__restrict__ rank, int n, int *__rest
     if (i < n) perm[rank[i]] = i;
 }
 
-// what a re-measured slot leaves with its owner lane: the slot's arg-max
-__device__ __forceinline__ void fpp_slot_finish(unsigned key, unsigned id, float px, float py, float pz, unsigned v, int k, int lane, unsigned &bkey, unsigned &bj,
-                                                float &bx, float &by, float &bz, unsigned &bloc)
+// signed max / min over a wavefront (the keys below are the BITS of a non-negative float, or of -1.0f for "not a candidate": ordered as signed integers)
+__device__ __forceinline__ int fpp_wave_imax(int v)
 {
-    const unsigned mk = fps_wave_umax(key);
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false)); v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false)); v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int fpp_row_imax(int v)                   // lane 15 of every row
+{
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false)); v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false)); v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));
+    return v;
+}
+constexpr int FPP_NOT = int(0xbf800000u);                            // the bits of -1.0f
+
+struct FpsJob {
+    const float4 *pts;      // the kind's features, original order
+    const uint8_t *valid;   // 1 = matched
+    const int *perm;        // Morton position -> original index
+    const int *aux;         // aux[0] != 0: a coordinate is not finite -- this kernel leaves the cloud to fps_order_kernel (launched behind it, gated on the same word)
+    int *order, *n_order;   // out: visiting order (start point excluded), its length (-1: the host loop takes the call)
+    int n, n_use, cur0;
+};
+struct FpsJobs { FpsJob j[2]; };        // one workgroup per job: the two kinds of a frame side by side (n == 0: no job)
+
+// A slot's arg-max after its points were re-measured -> its owner lane. key: the lane's running minimum as float bits (FPP_NOT: visited or no such point).
+// Equal keys (features on a lattice, repeated features) are decided by the lowest ORIGINAL index, as the host loop's strict `>` over ascending j decides them; the
+// indices live in LDS and are only read on that path.
+__device__ __forceinline__ void fpp_slot_finish(int key, const unsigned short *id_p, float px, float py, float pz, unsigned v, int k, int lane, int &bkey, float &bx,
+                                                float &by, float &bz, unsigned &bloc)
+{
+    const int mk = fpp_wave_imax(key);
     unsigned long long wb = __ballot(key == mk);
-    unsigned mj = ~0u;
-    int wl = 0;
-    if (mk) {
-        if (__popcll(wb) != 1) {                                     // equal distances (rare): the lowest original index among them
-            mj = fps_wave_umin(key == mk ? id : ~0u);
-            wb = __ballot(key == mk && id == mj);
-        }
-        wl = __ffsll(wb) - 1;
-        mj = unsigned(__builtin_amdgcn_readlane(int(id), wl));
+    if (mk >= 0 && __popcll(wb) != 1) {
+        const unsigned id = *id_p;
+        const unsigned mj = fps_wave_umin(key == mk ? id : ~0u);
+        wb = __ballot(key == mk && id == mj);
     }
+    const int wl = mk >= 0 ? __ffsll(wb) - 1 : 0;
     const float wx = fpp_readlane(px, wl), wy = fpp_readlane(py, wl), wz = fpp_readlane(pz, wl);
     const unsigned wv = unsigned(__builtin_amdgcn_readlane(int(v), wl));
-    if (lane == k) { bkey = mk; bj = mj; bx = wx; by = wy; bz = wz; bloc = unsigned(k << 6 | wl) | (wv << 31); }
+    if (lane == k) { bkey = mk; bx = wx; by = wy; bz = wz; bloc = unsigned(k << 6 | wl) | (wv << 31); }
 }
 
-__global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(const float4 *__restrict__ pts, const uint8_t *__restrict__ valid, const int *__restrict__ perm,
-                                                                       const int *__restrict__ aux, int n, int n_use, int cur0, int *__restrict__ order,
-                                                                       int *__restrict__ n_order)
+__global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(FpsJobs J)
 {
-    __shared__ uint4 s_c[2][FPP_WAVES][2];                           // a wavefront's candidate: {key, index, location | matched, -}, {x, y, z, -}; two sets
+    __shared__ uint4 s_c[2][FPP_WAVES][2];                           // a wavefront's candidate: {key, location | matched << 31, -, -}, {x, y, z, -}; two sets
     __shared__ unsigned short s_id[FPP_WAVES * FPP_SLOTS * 64];      // original index by Morton position    } 96 KB of LDS for 64 registers a lane does not have
-    __shared__ float s_dist[FPP_WAVES * FPP_SLOTS * 64];             // running minimum by Morton position   } (read and written by re-measured slots only)
+    __shared__ float s_dist[FPP_WAVES * FPP_SLOTS * 64];             // running minimum by Morton position   } (-1: visited, or no such point)
+    const FpsJob &P = J.j[blockIdx.x];
+    const int n = P.n, n_use = P.n_use, cur0 = P.cur0;
+    if (n <= 0 || P.aux[0] != 0) return;
+    const float4 *__restrict__ pts = P.pts;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-    const bool prune = aux[0] == 0;
     const unsigned short *my_id = s_id + w * 64 + lane;             // slot k: + k * FPP_WAVES * 64
     float *my_dist = s_dist + w * 64 + lane;
-    unsigned vis = 0, val = 0;          // bit k: the point of slot k has been visited (or does not exist) / is a matched feature
+    unsigned val = 0;                   // bit k: the point of slot k is a matched feature
 #define FPP_LOAD(k)                                                                                                  \
     float px##k, py##k, pz##k;                                                                                       \
     {                                                                                                                \
-        const int pos = (k * FPP_WAVES + w) * 64 + lane, j = pos < n ? perm[pos] : -1, jj = j >= 0 ? j : cur0;       \
+        const int pos = (k * FPP_WAVES + w) * 64 + lane, j = pos < n ? P.perm[pos] : -1, jj = j >= 0 ? j : cur0;     \
         const float4 p = pts[jj];                                                                                    \
-        px##k = p.x; py##k = p.y; pz##k = p.z; s_id[pos] = (unsigned short)(j); s_dist[pos] = 1e5f;                  \
-        vis |= ((j >= 0 && j != cur0) ? 0u : 1u) << k;                                                               \
-        val |= ((j >= 0 && valid[jj]) ? 1u : 0u) << k;                                                               \
+        px##k = p.x; py##k = p.y; pz##k = p.z; s_id[pos] = (unsigned short)(j);                                      \
+        s_dist[pos] = (j >= 0 && j != cur0) ? 1e5f : -1.f;                                                           \
+        val |= ((j >= 0 && P.valid[jj]) ? 1u : 0u) << k;                                                             \
     }
     FPP_FOR32(FPP_LOAD)
 #undef FPP_LOAD
-    // lane k: slot k's box and cached arg-max (key = distance bits + 1, 0 = no candidate left; before the first round: +inf, "measure me")
+    // lane k: slot k's box and cached arg-max (bkey: the largest running minimum as float bits, FPP_NOT = no candidate left; before the first round: +inf, "measure me")
     float lox = 0.f, loy = 0.f, loz = 0.f, hix = 0.f, hiy = 0.f, hiz = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-    unsigned bkey = 0u, bj = ~0u, bloc = 0u;
+    int bkey = FPP_NOT;
+    unsigned bloc = 0u;
 #define FPP_BOX(k)                                                                                                   \
     {                                                                                                                \
-        const bool ex = (k * FPP_WAVES + w) * 64 + lane < n;                                                           \
+        const int pos = (k * FPP_WAVES + w) * 64 + lane;                                                             \
+        const bool ex = pos < n;                                                                                     \
         const unsigned ax = fps_wave_umin(ex ? fpp_ord(px##k) : ~0u), bxx = fps_wave_umax(ex ? fpp_ord(px##k) : 0u); \
         const unsigned ay = fps_wave_umin(ex ? fpp_ord(py##k) : ~0u), byy = fps_wave_umax(ex ? fpp_ord(py##k) : 0u); \
         const unsigned az = fps_wave_umin(ex ? fpp_ord(pz##k) : ~0u), bzz = fps_wave_umax(ex ? fpp_ord(pz##k) : 0u); \
-        const bool any = __ballot(!(vis >> k & 1u)) != 0ull;                                                         \
+        const bool any = __ballot(ex && s_id[pos] != (unsigned short)(cur0)) != 0ull;                                \
         if (lane == k) {                                                                                             \
             lox = fpp_unord(ax); hix = fpp_unord(bxx); loy = fpp_unord(ay); hiy = fpp_unord(byy); loz = fpp_unord(az); hiz = fpp_unord(bzz); \
-            bkey = any ? 0x7f800001u : 0u;                                                                           \
+            bkey = any ? 0x7f800000 : FPP_NOT;                                                                       \
         }                                                                                                            \
     }
     FPP_FOR32(FPP_BOX)
@@ -309,20 +339,27 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(const flo
     {
         const float4 p = pts[cur0];
         ox = p.x; oy = p.y; oz = p.z;
-        n_sel = (valid[cur0] && n_use > 0) ? 1 : 0;
+        n_sel = (P.valid[cur0] && n_use > 0) ? 1 : 0;
     }
     int n_visited = 1, n_out = 0, par = 0;
+#ifdef MLH_FPS_STATS
+    unsigned long long ck[6] = {0, 0, 0, 0, 0, 0}, c_prev = __builtin_readcyclecounter();
+#define FPP_CK(i) do { const unsigned long long c_now = __builtin_readcyclecounter(); ck[i] += c_now - c_prev; c_prev = c_now; } while (0)
+#else
+#define FPP_CK(i) do { } while (0)
+#endif
     while (n_sel < n_use && n_visited < n) {
         unsigned act;
         {
             const float ax = fmaxf(fmaxf(lox - ox, ox - hix), 0.f), ay = fmaxf(fmaxf(loy - oy, oy - hiy), 0.f), az = fmaxf(fmaxf(loz - oz, oz - hiz), 0.f);
             const float lb2 = ax * ax + ay * ay + az * az;
-            const float md = __uint_as_float(bkey - 1u);
-            const bool pruned = prune && lb2 > 1e-30f && lb2 * 0.9999f > md * md;
-            act = unsigned(__ballot(lane < FPP_SLOTS && bkey != 0u && !pruned));
+            const float md = __int_as_float(bkey);
+            const bool pruned = lb2 > 1e-30f && lb2 * 0.9999f > md * md;
+            act = unsigned(__ballot(lane < FPP_SLOTS && bkey >= 0 && !pruned));
         }
+        FPP_CK(0);
 #ifdef MLH_FPS_STATS
-        if (lane == 0) { atomicAdd(const_cast<int *>(aux) + 1, __popc(act)); atomicMax(const_cast<int *>(aux) + 3 + w, __popc(act)); if (t == 0) atomicAdd(const_cast<int *>(aux) + 2, 1); }
+        if (lane == 0) { atomicAdd(const_cast<int *>(P.aux) + 1, __popc(act)); atomicMax(const_cast<int *>(P.aux) + 3 + w, __popc(act)); if (t == 0) atomicAdd(const_cast<int *>(P.aux) + 2, 1); }
 #endif
         while (act) {                                                // (uniform)
             const int k = __ffs(act) - 1;
@@ -330,70 +367,73 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(const flo
             switch (k) {
 #define FPP_CASE(k)                                                                                                  \
             case k: {                                                                                                \
-                unsigned key = 0u;                                                                                   \
-                unsigned vv = vis;                                                                                   \
-                asm volatile("" : "+v"(vv));                               /* (as below: 32 bit tests per round otherwise) */ \
-                if (!(vv >> k & 1u)) {                                                                               \
-                    /* (the empty asm keeps the 32 slots' square roots INSIDE their cases: hoisted out of this loop as loop-invariant code they cost */ \
-                    /*  3 us per round -- every slot measured every round, the work this kernel exists to skip) */ \
-                    float qx = ox, qy = oy, qz = oz;                                                                 \
-                    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));                                                 \
-                    const float ddx = qx - px##k, ddy = qy - py##k, ddz = qz - pz##k;                                \
-                    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)));    /* sqrtf: see fps_order_kernel */ \
-                    const float dk = my_dist[k * FPP_WAVES * 64];                                                          \
-                    const float d2 = (dk < d) ? dk : d;                    /* std::min(d, dist[j]) */                \
-                    my_dist[k * FPP_WAVES * 64] = d2;                                                                     \
-                    key = (d2 > -1.f) ? __float_as_uint(d2) + 1u : 0u;     /* `d2 > best_d` from best_d = -1: false for NaN */ \
-                }                                                                                                    \
-                fpp_slot_finish(key, my_id[k * FPP_WAVES * 64], px##k, py##k, pz##k, val >> k & 1u, k, lane, bkey, bj, bx, by, bz, bloc); \
+                /* (the empty asm keeps the 32 slots' square roots INSIDE their cases: hoisted out of this loop as loop-invariant code they cost */ \
+                /*  3 us per round -- every slot measured every round, the work this kernel exists to skip) */       \
+                float qx = ox, qy = oy, qz = oz;                                                                     \
+                asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));                                                     \
+                const float dk = my_dist[k * FPP_WAVES * 64];                                                        \
+                const float ddx = qx - px##k, ddy = qy - py##k, ddz = qz - pz##k;                                    \
+                const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)), __fmul_rn(ddz, ddz)));    /* sqrtf: see fps_order_kernel */ \
+                const float d2 = (dk < d) ? dk : d;                        /* std::min(d, dist[j]); a visited point keeps its -1 */ \
+                my_dist[k * FPP_WAVES * 64] = d2;                                                                    \
+                fpp_slot_finish(__float_as_int(d2), my_id + k * FPP_WAVES * 64, px##k, py##k, pz##k, val >> k & 1u, k, lane, bkey, bx, by, bz, bloc); \
             } break;
             FPP_FOR32(FPP_CASE)
 #undef FPP_CASE
             default: break;
             }
         }
+        FPP_CK(1);
         // the wavefront's best slot -> LDS; then the best of the wavefronts (every wavefront works it out for itself)
-        const unsigned k1 = lane < FPP_SLOTS ? bkey : 0u;
-        const unsigned wk = fps_wave_umax(k1);
-        unsigned long long sb = __ballot(lane < FPP_SLOTS && k1 == wk);
-        int sl = 0;
-        if (wk) {
-            if (__popcll(sb) != 1) {
-                const unsigned wj2 = fps_wave_umin((lane < FPP_SLOTS && k1 == wk) ? bj : ~0u);
-                sb = __ballot(lane < FPP_SLOTS && k1 == wk && bj == wj2);
-            }
-            sl = __ffsll(sb) - 1;
+        const int k1 = lane < FPP_SLOTS ? bkey : FPP_NOT;
+        const int wk = fpp_wave_imax(k1);
+        unsigned long long sb = __ballot(k1 == wk);
+        if (wk >= 0 && __popcll(sb) != 1) {
+            const unsigned id = (k1 == wk) ? s_id[((lane & 31) * FPP_WAVES + w) * 64 + (bloc & 63u)] : ~0u;
+            const unsigned wj = fps_wave_umin(id);
+            sb = __ballot(k1 == wk && id == wj);
         }
-        const unsigned wj = wk ? bj : ~0u;                           // (lane sl's, below)
+        const int sl = wk >= 0 ? __ffsll(sb) - 1 : 0;
         if (lane == sl) {
-            s_c[par][w][0] = make_uint4(wk, wj, bloc, 0u);
+            s_c[par][w][0] = make_uint4(unsigned(wk), bloc, 0u, 0u);
             s_c[par][w][1] = make_uint4(__float_as_uint(bx), __float_as_uint(by), __float_as_uint(bz), 0u);
         }
+        FPP_CK(2);
         __syncthreads();
+        FPP_CK(3);
         const bool rd = lane < FPP_WAVES;
-        const uint4 c0 = s_c[par][rd ? lane : 0][0], c1 = s_c[par][rd ? lane : 0][1];
-        const unsigned gk_l = rd ? c0.x : 0u, gj_l = c0.y, gl_l = c0.z;
-        const float gx_l = __uint_as_float(c1.x), gy_l = __uint_as_float(c1.y), gz_l = __uint_as_float(c1.z);
-        const unsigned gk = unsigned(__builtin_amdgcn_readlane(int(fps_row_umax(gk_l)), 15));
-        if (!gk) { if (t == 0) *n_order = -1; return; }             // only with NaN coordinates: the host loop takes the call
+        const uint4 c0 = s_c[par][rd ? lane : 0][0];
+        uint4 c1 = s_c[par][rd ? lane : 0][1];
+        asm volatile("" : "+v"(c1.x), "+v"(c1.y), "+v"(c1.z));      // (both reads in flight together: left alone, the second is issued behind the key's reduction)
+        const int gk_l = rd ? int(c0.x) : FPP_NOT;
+        const int gk = __builtin_amdgcn_readlane(fpp_row_imax(gk_l), 15);
+        if (gk < 0) { if (t == 0) *P.n_order = -1; return; }        // nothing left to visit although the loop goes on: the host loop takes the call (as fps_order_kernel)
         unsigned long long gb = __ballot(rd && gk_l == gk);
         if (__popcll(gb) != 1) {
-            const unsigned gj2 = unsigned(__builtin_amdgcn_readlane(int(fps_row_umin((rd && gk_l == gk) ? gj_l : ~0u)), 15));
-            gb = __ballot(rd && gk_l == gk && gj_l == gj2);
+            const unsigned id = (rd && gk_l == gk) ? s_id[(((c0.y >> 6) & 31u) * FPP_WAVES + lane) * 64 + (c0.y & 63u)] : ~0u;
+            const unsigned gj2 = unsigned(__builtin_amdgcn_readlane(int(fps_row_umin(id)), 15));
+            gb = __ballot(rd && gk_l == gk && id == gj2);
         }
         const int ww = __ffsll(gb) - 1;
-        const unsigned gj = unsigned(__builtin_amdgcn_readlane(int(gj_l), ww));
-        const unsigned gloc = unsigned(__builtin_amdgcn_readlane(int(gl_l), ww));
-        ox = fpp_readlane(gx_l, ww); oy = fpp_readlane(gy_l, ww); oz = fpp_readlane(gz_l, ww);
-        if (w == ww && lane == int(gloc & 63u)) vis |= 1u << ((gloc >> 6) & 31u);
-        if (t == 0) order[n_out] = int(gj);
+        const unsigned gloc = unsigned(__builtin_amdgcn_readlane(int(c0.y), ww));
+        ox = fpp_readlane(__uint_as_float(c1.x), ww); oy = fpp_readlane(__uint_as_float(c1.y), ww); oz = fpp_readlane(__uint_as_float(c1.z), ww);
+        const int gpos = (int((gloc >> 6) & 31u) * FPP_WAVES + ww) * 64 + int(gloc & 63u);
+        if (t == 0) P.order[n_out] = gpos;                           // (a Morton position: translated behind the loop -- no LDS read in front of this store)
+        if (w == ww && lane == int(gloc & 63u)) s_dist[gpos] = -1.f;      // visited (read again by this wavefront only)
         ++n_out;
         ++n_visited;
         if (gloc >> 31) ++n_sel;
         par ^= 1;
+        FPP_CK(4);
     }
-    if (t == 0) *n_order = n_out;
+#ifdef MLH_FPS_STATS
+    if (lane == 0) for (int i = 0; i < 5; ++i) const_cast<int *>(P.aux)[16 + 8 * w + i] = int(ck[i] / (unsigned long long)(n_out > 0 ? n_out : 1));
+#endif
+    __syncthreads();                                                 // (thread 0's stores to `order`: visible to the workgroup)
+    for (int i = t; i < n_out; i += FPP_THREADS) P.order[i] = int(s_id[P.order[i]]);
+    if (t == 0) *P.n_order = n_out;
 }
+#undef FPP_CK
 #undef FPP_FOR32
 
 struct Rows {               // per-feature results of the GPU pass, copied out of the context's pinned staging block
@@ -658,9 +698,59 @@ void select_greedy(const Rows &R, size_t n_use, std::mt19937 &rng, std::vector<s
 
 }  // namespace
 
+// The farthest-point loops of the kinds staged with `defer_fps` (or of the one kind staged without), one workgroup each in ONE launch -- a loop is a chain of
+// dependent rounds on one compute unit, so two of them side by side cost the longer one --, then per kind: the dense kernel behind a gate (it runs only where the
+// pruned one declined: a cloud with a non-finite coordinate), the copy of the visiting order, the marker.
+int good_feature_fps_flush(mlh_ctx *ctx)
+{
+    FpsJobs J;
+    std::memset(&J, 0, sizeof(J));
+    int nj = 0, kinds[2] = {-1, -1};
+    const bool fps_dense = std::getenv("MLH_FPS_DENSE") != nullptr;        // (A/B / tests: the round-4 kernel -- every point re-measured every round -- on every cloud)
+    for (int kind : {MLH_CORNER, MLH_SURF}) {
+        if (!ctx->fps_pending[kind].active) continue;
+        FeatSet &f = ctx->feat[kind];
+        const int m = ctx->fps_pending[kind].m;
+        FpsJob &j = J.j[nj];
+        j.pts = f.pts.as<float4>(); j.valid = f.flag8.as<uint8_t>(); j.perm = f.fps_work.as<int>() + 2 * size_t(m); j.aux = j.perm + m;
+        j.order = f.fps_order.as<int>() + 1; j.n_order = f.fps_order.as<int>();
+        j.n = m; j.n_use = ctx->fps_pending[kind].n_use; j.cur0 = ctx->fps_pending[kind].cur0;
+        kinds[nj++] = kind;
+    }
+    if (!nj) return MLH_OK;
+    if (!fps_dense) MLH_LAUNCH(fps_order_pruned_kernel, dim3(unsigned(nj)), dim3(FPP_THREADS), 0, ctx->stream, J);
+    for (int q = 0; q < nj; ++q) {
+        const FpsJob &j = J.j[q];
+        MLH_LAUNCH(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, j.pts, j.valid, j.n, j.n_use, j.cur0, j.order, j.n_order, fps_dense ? nullptr : j.aux);
+    }
+    MLH_HIP(ctx, hipGetLastError());
+#ifdef MLH_FPS_STATS
+    for (int q = 0; q < nj; ++q) {
+        int h[16] = {0}, hc[64];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h, J.j[q].aux, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hc, J.j[q].aux + 16, sizeof(hc), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "fps stats: m %d nonfinite %d rounds %d slots re-measured %d (%.2f per round, all waves); per-wave max in a round:", J.j[q].n, h[0], h[2], h[1], h[2] ? double(h[1]) / h[2] : 0.0);
+        for (int u = 0; u < FPP_WAVES; ++u) std::fprintf(stderr, " %d", h[3 + u]);
+        std::fprintf(stderr, " | cycles per round (test | slots | wave best | barrier | decode) by wavefront:");
+        for (int u = 0; u < FPP_WAVES; ++u) std::fprintf(stderr, "  %d %d %d %d %d", hc[8 * u], hc[8 * u + 1], hc[8 * u + 2], hc[8 * u + 3], hc[8 * u + 4]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
+    for (int q = 0; q < nj; ++q) {
+        const int kind = kinds[q];
+        FeatSet &f = ctx->feat[kind];
+        MLH_HIP(ctx, hipMemcpyAsync(ctx->fps_pending[kind].host_dst, f.fps_order.p, sizeof(int) * (size_t(J.j[q].n) + 1), hipMemcpyDeviceToHost, ctx->stream));
+        MLH_HIP(ctx, stream_flag_post(ctx, &ctx->select_seq[kind]));
+        ctx->select_staged[kind] = true;
+        ctx->fps_pending[kind].active = 0;
+    }
+    return MLH_OK;
+}
+
 // One goodFeatureMatching call, in two halves. The device-side solver state must already hold the pose (SolverState::x).
 // Stage: the dense pass of one kind and the copies of its rows into that kind's pinned block, enqueued; a marker behind them.
-int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis)
+int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt19937 &rng, float min_match_sq_dis, float min_plane_dis, bool defer_fps)
 {
     FeatSet &f = ctx->feat[kind];
     MatchArgs a;
@@ -688,6 +778,7 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt
     MLH_HIP(ctx, hipMemcpyAsync(hb + off_v, f.flag8.p, m, hipMemcpyDeviceToHost, ctx->stream));
     MLH_HIP(ctx, hipMemcpyAsync(hb, f.J.p, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, ctx->stream));
     ctx->select_fps_start[kind] = -1;
+    ctx->fps_pending[kind].active = 0;               // (a loop an earlier call staged and never launched -- it failed in between -- is void)
     if (method == MLH_GF_FPS && m > 0) {
         // the one number this method draws (the starting point, lidar_mapper.h:356) is drawn here, in call order: corner before surf, as the finishes will run
         const size_t cur0 = draw(rng, 0, m - 1);
@@ -695,33 +786,19 @@ int good_feature_stage(mlh_ctx *ctx, int kind, int method, double ratio, std::mt
         const bool fps_on_host = std::getenv("MLH_FPS_HOST") != nullptr;          // (measurement / tests only: the host loop on every call)
         if (m <= size_t(FPS_THREADS) * FPS_PMAX && !fps_on_host) {
             MLH_HIP(ctx, f.fps_order.ensure(sizeof(int) * (m + 1)));
-            const bool fps_dense = std::getenv("MLH_FPS_DENSE") != nullptr;        // (A/B / tests: the round-4 kernel that re-measures every point every round)
-            if (fps_dense) {
-                MLH_LAUNCH(fps_order_kernel, dim3(1), dim3(FPS_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), int(m),
-                                   int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
-            } else {
-                // Morton order of the cloud (keys, rank by counting, permutation), then the pruned loop: [keys m][rank m][perm m][aux 16]
-                MLH_HIP(ctx, f.fps_work.ensure(sizeof(int) * (3 * m + 16)));
-                unsigned *keys = f.fps_work.as<unsigned>();
-                int *rank = f.fps_work.as<int>() + m, *perm = rank + m, *aux = perm + m;
-                MLH_LAUNCH(fps_keys_kernel, dim3(1), dim3(1024), 0, ctx->stream, f.pts.as<float4>(), int(m), keys, rank, aux);
-                MLH_LAUNCH(fps_rank_kernel, dim3(unsigned((m + FPR_TPB - 1) / FPR_TPB), FPR_PARTS), dim3(FPR_TPB), 0, ctx->stream, keys, int(m), rank);
-                MLH_LAUNCH(fps_perm_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, rank, int(m), perm);
-                MLH_LAUNCH(fps_order_pruned_kernel, dim3(1), dim3(FPP_THREADS), 0, ctx->stream, f.pts.as<float4>(), f.flag8.as<uint8_t>(), perm, aux, int(m),
-                                   int(static_cast<size_t>(m * ratio)), int(cur0), f.fps_order.as<int>() + 1, f.fps_order.as<int>());
-#ifdef MLH_FPS_STATS
-                {
-                    int h[16] = {0};
-                    (void)hipStreamSynchronize(ctx->stream);
-                    (void)hipMemcpy(h, aux, sizeof(h), hipMemcpyDeviceToHost);
-                    std::fprintf(stderr, "fps stats: m %zu nonfinite %d rounds %d slots re-measured %d (%.2f per round, all waves); per-wave max in a round:", m, h[0], h[2], h[1], h[2] ? double(h[1]) / h[2] : 0.0);
-                    for (int q = 0; q < FPP_WAVES; ++q) std::fprintf(stderr, " %d", h[3 + q]);
-                    std::fprintf(stderr, "\n");
-                }
-#endif
-            }
+            // Morton order of the cloud (keys, rank by counting, permutation) now; the loop itself now or -- `defer_fps`: a frame's two kinds -- side by side in
+            // one launch (good_feature_fps_flush): [keys m][rank m][perm m][aux 96]
+            MLH_HIP(ctx, f.fps_work.ensure(sizeof(int) * (3 * m + 96)));
+            unsigned *keys = f.fps_work.as<unsigned>();
+            int *rank = f.fps_work.as<int>() + m, *perm = rank + m, *aux = perm + m;
+            MLH_LAUNCH(fps_keys_kernel, dim3(1), dim3(1024), 0, ctx->stream, f.pts.as<float4>(), int(m), keys, rank, aux);
+            MLH_LAUNCH(fps_rank_kernel, dim3(unsigned((m + FPR_TPB - 1) / FPR_TPB), FPR_PARTS), dim3(FPR_TPB), 0, ctx->stream, keys, int(m), rank);
+            MLH_LAUNCH(fps_perm_kernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, rank, int(m), perm);
             MLH_HIP(ctx, hipGetLastError());
-            MLH_HIP(ctx, hipMemcpyAsync(hb + off_o, f.fps_order.p, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->fps_pending[kind].active = 1; ctx->fps_pending[kind].m = int(m); ctx->fps_pending[kind].n_use = int(static_cast<size_t>(m * ratio));
+            ctx->fps_pending[kind].cur0 = int(cur0); ctx->fps_pending[kind].host_dst = hb + off_o;
+            if (defer_fps) return MLH_OK;                            // (copy of the order, marker, `staged`: good_feature_fps_flush)
+            return good_feature_fps_flush(ctx);
         } else {
             MLH_HIP(ctx, hipMemcpyAsync(hb + off_p, f.pts.p, sizeof(float4) * m, hipMemcpyDeviceToHost, ctx->stream));   // too long for one workgroup's registers: host loop
             *reinterpret_cast<int *>(hb + off_o) = -1;
