@@ -107,9 +107,9 @@ __device__ void ss_heap_sort_range(int *k, int *v, int len, Less less)
 // budget on one ring in five, the leftovers are 17-50 elements long, and heap-sorting one of them through LDS from a single lane took longer than the rest of
 // the ring's sort (the per-ring leaf launch: slowest ring 81 us against a median of 35).
 template <typename Less>
-__device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Less less)
+__device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len_, Less less)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, len = __builtin_amdgcn_readfirstlane(len_);
     int key_r = lane < len ? k[lane] : 0, val_r = lane < len ? v[lane] : 0;
     auto rd = [&](int reg, int i) { return __builtin_amdgcn_readlane(reg, i); };
 #if MLH_SS_HEAP_PAR
@@ -144,30 +144,42 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
         else if (lane == jstar) { key_r = key; val_r = val; }
     };
 #else
-    auto adjust = [&](int hole, int n, int key, int val) {
-        const int top = hole;
+    // every index and every travelling element is wavefront-uniform and is KEPT in scalar registers (readfirstlane where the compiler cannot see it): a sift level
+    // is two v_readlane (the children's keys), a scalar compare and two selects (which child, its key -- already read), one v_readlane (its value), two
+    // v_writelane into the hole's lane. (Round 6; through round 5 the make-heap phase ran with its indices in vector registers -- v_readfirstlane + wait states
+    // in front of every v_readlane, four of them per level, the moves as compare + select: 17.8 us per heap sort of 31-94 elements.)
+    // (this toolchain has no writelane builtin; two scalar operands exceed the constant bus, so the lane select goes through M0; the s_nop covers the wait
+    // states behind a write of M0 / a v_readfirstlane -- hazards inside inline asm are not the compiler's)
+    auto wr = [&](int &reg, int value, int i) { asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(i) : "m0"); };
+    auto adjust = [&](int hole_, int n_, int key_, int val_) {
+        int hole = __builtin_amdgcn_readfirstlane(hole_);
+        const int n = __builtin_amdgcn_readfirstlane(n_), key = __builtin_amdgcn_readfirstlane(key_), val = __builtin_amdgcn_readfirstlane(val_);
+        const int top = hole, lim = (n - 1) / 2;
         int c = hole;
-        while (c < (n - 1) / 2) {
-            c = 2 * (c + 1);
-            if (less(rd(key_r, c), rd(key_r, c - 1))) c--;
-            const int kc = rd(key_r, c), vc = rd(val_r, c);
-            key_r = (lane == hole) ? kc : key_r; val_r = (lane == hole) ? vc : val_r;
+        while (c < lim) {
+            const int r = 2 * c + 2, l = r - 1;
+            const int kr = rd(key_r, r), kl = rd(key_r, l);
+            const bool left = less(kr, kl);
+            c = left ? l : r;
+            const int kc = left ? kl : kr, vc = rd(val_r, c);
+            wr(key_r, kc, hole); wr(val_r, vc, hole);
             hole = c;
         }
         if ((n & 1) == 0 && c == (n - 2) / 2) {
-            c = 2 * (c + 1);
-            const int kc = rd(key_r, c - 1), vc = rd(val_r, c - 1);
-            key_r = (lane == hole) ? kc : key_r; val_r = (lane == hole) ? vc : val_r;
-            hole = c - 1;
+            c = 2 * c + 1;
+            const int kc = rd(key_r, c), vc = rd(val_r, c);
+            wr(key_r, kc, hole); wr(val_r, vc, hole);
+            hole = c;
         }
-        int parent = (hole - 1) / 2;
-        while (hole > top && less(rd(key_r, parent), key)) {
-            const int kp = rd(key_r, parent), vp = rd(val_r, parent);
-            key_r = (lane == hole) ? kp : key_r; val_r = (lane == hole) ? vp : val_r;
+        while (hole > top) {
+            const int parent = (hole - 1) / 2;
+            const int kp = rd(key_r, parent);
+            if (!less(kp, key)) break;
+            const int vp = rd(val_r, parent);
+            wr(key_r, kp, hole); wr(val_r, vp, hole);
             hole = parent;
-            parent = (hole - 1) / 2;
         }
-        key_r = (lane == hole) ? key : key_r; val_r = (lane == hole) ? val : val_r;
+        wr(key_r, key, hole); wr(val_r, val, hole);
     };
 #endif
     if (len >= 2) {
@@ -183,7 +195,11 @@ __device__ __forceinline__ void ss_heap_sort_wave64(int *k, int *v, int len, Les
         --last;
         const int key = rd(key_r, last), val = rd(val_r, last);
         const int k0 = rd(key_r, 0), v0 = rd(val_r, 0);
+#if MLH_SS_HEAP_PAR
         key_r = (lane == last) ? k0 : key_r; val_r = (lane == last) ? v0 : val_r;
+#else
+        wr(key_r, k0, last); wr(val_r, v0, last);
+#endif
         adjust(0, last, key, val);
     }
     if (lane < len) { k[lane] = key_r; v[lane] = val_r; }
