@@ -150,20 +150,33 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_order_kernel(const float4 *__
 // ---- fps with exact pruning (round 6). fps_order_kernel above pays 2.8 us per visit whatever the visit changes: every unvisited point's distance to the new pick,
 // every round. But `dist[j] = min(d, dist[j])` (lidar_mapper.h:403-404) only CHANGES points closer to the pick than their running minimum, and after k visits that
 // is a neighbourhood of ~N / k points. So: the points are put in Morton order (fps_keys / fps_rank / fps_perm kernels: 30-bit keys, rank by counting), a BUCKET is
-// the 64 points one wavefront holds in one register slot (lane l of wavefront w, slot k <-> Morton position ((k * 8 + w) * 64 + l: neighbouring buckets -- the ones a
+// the 64 points one wavefront holds in one register slot (lane l of wavefront w, slot k <-> Morton position ((k * 16 + w) * 64 + l: neighbouring buckets -- the ones a
 // pick re-measures together -- belong to different wavefronts), and lane k of the wavefront keeps
 // slot k's bounding box and its cached arg-max (largest running minimum among its unvisited points, lowest original index among equals, that point's coordinates).
-// A round: 32 lanes test their slot's box against the pick (a slot whose box is farther from the pick than its largest running minimum cannot change: for every
+// A round: 16 lanes test their slot's box against the pick (a slot whose box is farther from the pick than its largest running minimum cannot change: for every
 // point in it the host's `d2 = min(d, dist[j])` returns dist[j]), the slots that pass are re-measured -- per point exactly the host loop's f32 arithmetic, as above --
-// and their arg-max re-cached; the wavefront's best slot, then the best of the 8 wavefronts (one barrier per round: the candidates alternate between two LDS sets).
-// The same picks in the same order as fps_order_kernel and the host loop (tests: goodFeatureMatching 'fps' pick for pick); 2.8 -> ~0.5 us per visit.
+// and their arg-max re-cached; the wavefront's best slot, then the best of the 16 wavefronts (one barrier per round: the candidates alternate between two LDS sets).
+// The same picks in the same order as fps_order_kernel and the host loop (tests: goodFeatureMatching 'fps' pick for pick); 2.8 -> 1.06 us per visit (5.1-5.5 slots
+// re-measured per round on the config-5 frame; what is left is the round's chain: box test -> slot -> wavefront's best -> LDS -> barrier -> decode), and a frame's
+// two kinds run side by side (one workgroup each in one launch: good_feature_fps_flush): 49 -> 13.2 ms per config-5 frame.
 // The box test is conservative by 1e-4 relative against ~3e-7 of rounding in either distance, and only applied to a squared box distance in the normal range;
-// a cloud with ANY non-finite coordinate is run with the test switched off (every slot re-measured every round: comparisons with NaN as the host's).
-constexpr int FPP_WAVES = 8, FPP_SLOTS = 32, FPP_THREADS = FPP_WAVES * 64;      // 16 384 points, as the dense kernel
+// a cloud with ANY non-finite coordinate (fps_keys_kernel's flag) is left to fps_order_kernel, launched behind this one and gated on the same word: its
+// comparisons treat NaN as the host's do.
+// (A/B, ms per config-5 frame, two alternations: 8 wavefronts x 32 slots 14.05 / 14.08, 16 x 16 13.25 / 13.20 -- a pick's five or so buckets collide less often on
+// one wavefront)
+#ifndef MLH_FPP_WAVES
+#define MLH_FPP_WAVES 16
+#endif
+constexpr int FPP_WAVES = MLH_FPP_WAVES, FPP_SLOTS = 256 / FPP_WAVES, FPP_THREADS = FPP_WAVES * 64;      // 16 384 points, as the dense kernel
+static_assert(FPP_WAVES == 8 || FPP_WAVES == 16, "8 wavefronts x 32 slots or 16 x 16");
 static_assert(FPP_WAVES * FPP_SLOTS * 64 == FPS_THREADS * FPS_PMAX, "both fps kernels take the same clouds");
 constexpr int FPR_TPB = 256, FPR_PARTS = 8, FPR_TILE = 1024;
+#if MLH_FPP_WAVES == 8
 #define FPP_FOR32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
                      M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+#else
+#define FPP_FOR32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+#endif
 
 __device__ __forceinline__ unsigned fpp_ord(float f) { const unsigned b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u); }   // float order -> unsigned order
 __device__ __forceinline__ float fpp_unord(unsigned u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(FpsJobs J
         const int wk = fpp_wave_imax(k1);
         unsigned long long sb = __ballot(k1 == wk);
         if (wk >= 0 && __popcll(sb) != 1) {
-            const unsigned id = (k1 == wk) ? s_id[((lane & 31) * FPP_WAVES + w) * 64 + (bloc & 63u)] : ~0u;
+            const unsigned id = (k1 == wk) ? s_id[((lane & (FPP_SLOTS - 1)) * FPP_WAVES + w) * 64 + (bloc & 63u)] : ~0u;
             const unsigned wj = fps_wave_umin(id);
             sb = __ballot(k1 == wk && id == wj);
         }
