@@ -205,7 +205,7 @@ __device__ inline void heap_sort_range(int *k, int *v, int len) { ss_heap_sort_r
 // wavefronts' counts (LDS) turns a rank of the whole range into (chunk, entry) by a four-step search; the number of crossing pairs comes from a 64-ary search
 // over that predicate, and the pairs are swapped in parallel. (Rounds 2-3 streamed the keys twice, a count pass in front of the table pass: the launch is
 // bound by instruction issue on its ONE compute unit, and the count pass was a third of it -- thinning 0.52 -> 0.48 ms per frame without it.)
-// keys / vals / lt / rt: global memory; w_left / w_right (17 ints each) and sh_k: LDS. Returns the cut.
+// keys / vals / lt / rt: global memory; w_left / w_right (17 ints each) and sh_k (TWO ints: the number of crossing pairs, the cut): LDS. Returns the cut.
 template <typename Tab>
 __device__ __forceinline__ int wg_partition(int *keys, int *vals, Tab *lt, Tab *rt, int f, int l, int *w_left, int *w_right, int *sh_k)
 {
@@ -281,10 +281,12 @@ __device__ __forceinline__ int wg_partition(int *keys, int *vals, Tab *lt, Tab *
     if (t == 0) {
         if (K < nL) cut = min(cut, left_at(K));
         if (K > 0) cut = min(cut, right_at(K - 1));
-        *sh_k = cut;
+        sh_k[1] = cut;                                              // (NOT the word K is read from: a wavefront that is late -- behind another context's kernels on
+                                                                     //  this compute unit -- may not have read K yet; through round 6 both lived in sh_k[0], and four
+                                                                     //  contexts sorting at once turned that into wrong swaps: scripts/soak_api.py, 4 threads)
     }
     __syncthreads();
-    cut = *sh_k;
+    cut = sh_k[1];
     __syncthreads();                                             // the tables and sh_k / w_* are reused by the next range
     return cut;
 }
@@ -472,7 +474,7 @@ __device__ __forceinline__ void ss_wide_pairs(const StdSortArgs &A, const SortSe
 __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArgs A, int level, int n_wide_wg)
 {
     __shared__ int w_left[SS_WIDE_MAXW + 1], w_right[SS_WIDE_MAXW + 1];
-    __shared__ int sh_k;
+    __shared__ int sh_k[2];
     __shared__ int sh[8];
     const SortSeg *cur = A.seg[level & 1];
     SortSeg *next = A.seg[(level + 1) & 1];
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_big_level_kernel(StdSortArg
             if (t == 0) heap_sort_range(A.keys + f, A.vals + f, m);
             continue;
         }
-        const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, f, l, w_left, w_right, &sh_k);
+        const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, f, l, w_left, w_right, sh_k);
         if (t == 0) {
             emit_global(A, cut, l, s.depth - 1, next, &A.cnt[level + 1]);     // the recursive call
             emit_global(A, f, cut, s.depth - 1, next, &A.cnt[level + 1]);     // the loop's next trip
@@ -580,10 +582,12 @@ __device__ __forceinline__ int wg_partition_lds(int *keys, int *vals, Tab *lt, T
     if (t == 0) {
         if (K < nL) cut = min(cut, int(lt[f + K]));
         if (K > 0) cut = min(cut, int(rt[rlast - (K - 1)]));
-        *sh_k = cut;
+        sh_k[1] = cut;                                              // (NOT the word K is read from: a wavefront that is late -- behind another context's kernels on
+                                                                     //  this compute unit -- may not have read K yet; through round 6 both lived in sh_k[0], and four
+                                                                     //  contexts sorting at once turned that into wrong swaps: scripts/soak_api.py, 4 threads)
     }
     __syncthreads();
-    cut = *sh_k;
+    cut = sh_k[1];
     __syncthreads();                                                 // the tables and sh_k / w_* are reused by the next range
     return cut;
 }
@@ -629,7 +633,7 @@ __device__ __forceinline__ void mid_lds_subtree(const StdSortArgs &A, int f, int
 __global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, int level)
 {
     extern __shared__ int s_mid[];                                   // keys | vals (SS_MID ints each) | left stops | right stops (SS_MID 16-bit positions each)
-    __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1], sh_k;
+    __shared__ int w_left[SS_BIG_WAVES + 1], w_right[SS_BIG_WAVES + 1], sh_k[2];
     __shared__ int s_stk[3 * SS_MID_STACK], s_gstk[3 * SS_MID_STACK];
     int *sk = s_mid, *sv = s_mid + SS_MID;
     MidTab *slt = reinterpret_cast<MidTab *>(s_mid + 2 * SS_MID), *srt = slt + SS_MID;
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, i
         const SortSeg s = cur[si];
         [[maybe_unused]] const unsigned long long c_all = MLH_SCLK();
         MLH_MACC(7, s.last - s.first);
-        if (s.last - s.first <= SS_MID) { mid_lds_subtree(A, s.first, s.last, s.depth, sk, sv, slt, srt, w_left, w_right, &sh_k, s_stk); MLH_MACC(6, MLH_SCLK() - c_all); continue; }
+        if (s.last - s.first <= SS_MID) { mid_lds_subtree(A, s.first, s.last, s.depth, sk, sv, slt, srt, w_left, w_right, sh_k, s_stk); MLH_MACC(6, MLH_SCLK() - c_all); continue; }
         // still longer than SS_MID after the wide levels (unbalanced partitions; a range too long to be "wide"): partitioned on global memory until its pieces fit
         int top = 0;
         if (t == 0) { s_gstk[0] = s.first; s_gstk[1] = s.last; s_gstk[2] = s.depth; }
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, i
                 if (t == 0) heap_sort_range(A.keys + a, A.vals + a, b - a);
                 continue;
             }
-            const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, a, b, w_left, w_right, &sh_k);
+            const int cut = wg_partition(A.keys, A.vals, A.lt, A.rt, a, b, w_left, w_right, sh_k);
             const int c0[2] = {cut, a}, c1[2] = {b, cut};
             for (int c = 0; c < 2; ++c) {                            // the library's recursive call, then its loop's next trip
                 const int size = c1[c] - c0[c];
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(SS_BIG_WG) void stdsort_mid_kernel(StdSortArgs A, i
                     if (t == 0) { s_gstk[3 * top] = c0[c]; s_gstk[3 * top + 1] = c1[c]; s_gstk[3 * top + 2] = d - 1; }
                     ++top;
                 } else if (size > SS_LEAF && size <= SS_MID) {
-                    mid_lds_subtree(A, c0[c], c1[c], d - 1, sk, sv, slt, srt, w_left, w_right, &sh_k, s_stk);
+                    mid_lds_subtree(A, c0[c], c1[c], d - 1, sk, sv, slt, srt, w_left, w_right, sh_k, s_stk);
                 } else if (size > 1 && t == 0) {
                     A.leaf[atomicAdd(&A.cnt[SS_CNT_LEAF], 1)] = SortSeg{c0[c], c1[c], d - 1, 0};
                 }
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
     __shared__ int s_q[4 * SS_LOCAL_LIST];
     __shared__ int s_scr[(SS_LEAF_WG / 64) * 128];
     __shared__ int sh[4];
-    __shared__ int s_wl[SS_BIG_WAVES + 1], s_wr[SS_BIG_WAVES + 1], s_k, s_stk[3 * SS_LEAF_STACK];
+    __shared__ int s_wl[SS_BIG_WAVES + 1], s_wr[SS_BIG_WAVES + 1], s_k[2], s_stk[3 * SS_LEAF_STACK];
     static_assert(SS_LEAF_WG == SS_BIG_WG, "wg_partition is written for the big levels' workgroup");
     const int n_leaf = A.cnt[SS_CNT_LEAF], n_left_over = A.cnt[A.over_level];
     const SortSeg *over = A.seg[A.over_level & 1];
@@ -838,14 +842,14 @@ __global__ __launch_bounds__(SS_LEAF_WG) void stdsort_leaf_kernel(StdSortArgs A)
             for (int i = t; i < m; i += SS_LEAF_WG) { s_keys[i] = A.keys[f + i]; s_vals[i] = A.vals[f + i]; }
             M.keys = s_keys; M.vals = s_vals; M.lt = s_lt; M.rt = s_rt; M.fin = s_fin; M.q = s_q; M.qcap = SS_LOCAL_LIST;
             __syncthreads();
-            leaf_sort<true>(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
+            leaf_sort<true>(M, m, s.depth, sh, A.err, s_wl, s_wr, s_k, s_stk);
             for (int i = t; i < m; i += SS_LEAF_WG) { A.keys[f + i] = s_keys[i]; A.vals[f + i] = s_vals[i]; }
             MLH_SSTAGE(6);
             __syncthreads();
         } else {                                                       // still longer than a leaf after the big levels: the same code on global memory
             M.keys = A.keys + f; M.vals = A.vals + f; M.lt = A.lt + f; M.rt = A.rt + f; M.fin = A.gfin + f;
             M.q = A.glist + f; M.qcap = min(2 * (m / (SS_THRESHOLD + 1)) + 2, m / 4);
-            leaf_sort<false>(M, m, s.depth, sh, A.err, s_wl, s_wr, &s_k, s_stk);
+            leaf_sort<false>(M, m, s.depth, sh, A.err, s_wl, s_wr, s_k, s_stk);
         }
     }
 }
