@@ -151,6 +151,13 @@ def j_gf(c, st, r, m, f, kind, method):
     return [o["sel"], o["H"], o["matched"]], how
 
 
+def j_s2m_gf(c, st, r, m, f, method):
+    # scan2MapOptimization behind a good-feature selection: 'fps' runs the two kinds' farthest-point loops side by side in one launch (select.hip)
+    how = ensure_map(c, st, m, r) + "/" + ensure_feat(c, st, f, r)
+    pose, stt = c.scan2map(P0[m], mla.default_opts(gf_method=mla.GF_METHODS[method], gf_ratio=0.3, gf_seed=5), want_stats=True)
+    return [pose, np.array([[s_["n_surf"], s_["n_corner"]] for s_ in stt])], how
+
+
 def j_voxel_grid(c, st, r, i, leaf):
     return [c.voxel_grid(vg_pts[i], leaf)], ""
 
@@ -299,6 +306,9 @@ for m in MAPS:
     if m != "L":
         JOBS.append((("gf", m, "A", mla.SURF, "gd_fix"), j_gf, (m, "A", mla.SURF, "gd_fix")))
         JOBS.append((("gf", m, "A", mla.CORNER, "rnd"), j_gf, (m, "A", mla.CORNER, "rnd")))
+        JOBS.append((("gf", m, "A", mla.SURF, "fps"), j_gf, (m, "A", mla.SURF, "fps")))
+        JOBS.append((("gf", m, "B", mla.CORNER, "fps"), j_gf, (m, "B", mla.CORNER, "fps")))
+        JOBS.append((("s2m_gf", m, "A", "fps"), j_s2m_gf, (m, "A", "fps")))
         for subset in ((0, 1, 2, 3), (1,), (0, 2)):
             JOBS.append((("blocks", m, subset), j_blocks, (m, subset)))
     JOBS.append((("frame", m), j_frame, (m,)))
