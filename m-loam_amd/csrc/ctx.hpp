@@ -301,6 +301,8 @@ struct mlh_ctx {
     mlh::DevBuf oob_flag;    // map staging: bit k set = the cloud of kind k has points outside its grid box
     bool oob_init = false;
     mlh::DevBuf ticket;      // arrival counter of the fused GN finish
+    mlh::DevBuf loop_tagged; // lm_loop_kernel: the iterations' records as tagged words (two sets of 64 words per tile; match.hip: lm_consume_launch)
+    unsigned loop_launch_seq = 0;   // ... and the launch number their tags carry (24 bits)
     mlh::DevBuf lm_pp;       // two LmState records of the consumer-side Levenberg-Marquardt schedule
     unsigned long long lmc_count = 0;     // consumer launches so far (its parity picks the record a launch writes)
     mlh::DevBuf stats;       // IterStatDev[...]
@@ -624,6 +626,26 @@ int lm_loop_occupancy(int blocks_per_cu[2]);      // hipOccupancyMaxActiveBlocks
 int track_loop_occupancy(int *blocks_per_cu);     // ... of track_lm_loop_kernel (track.hip)
 // the arrival counters of the fused finishes and of lm_loop_kernel's barrier: four zeroed words, whoever asks first ([0]: the finish tickets of match.hip and
 // track.hip; [1] arrivals, [2] departures, [3] release flag of the loop kernel). One place, so that no caller can leave the others' words unallocated or unzeroed.
+// The tagged record sets of the one-launch LM loops (match.hip: lm_loop_kernel, track.hip: track_lm_loop_kernel; reduce_dev.hpp: lmc_sum_records_tagged): two sets of
+// 64 words per tile, and the number this launch's tags carry. *buf stays null where the loop keeps its grid barrier (MLH_LOOP_TAGGED=0; more iterations than the tag's
+// iteration byte counts). Zero is never a tag: a fresh allocation and a wrap of the 24-bit launch number clear the words.
+inline hipError_t loop_tagged_arm(mlh_ctx *ctx, size_t tiles, int lm_max_it, unsigned long long **buf, unsigned *tag_base)
+{
+    static const bool off = [] { const char *e = std::getenv("MLH_LOOP_TAGGED"); return e && std::atoi(e) == 0; }();
+    *buf = nullptr; *tag_base = 0u;
+    if (off || lm_max_it > 200 || tiles == 0) return hipSuccess;
+    const size_t bytes = sizeof(unsigned long long) * 64 * tiles * 2;
+    bool clear = bytes > ctx->loop_tagged.cap;
+    hipError_t e = ctx->loop_tagged.ensure(bytes);
+    if (e != hipSuccess) return e;
+    ctx->loop_launch_seq = (ctx->loop_launch_seq + 1u) & 0xffffffu;
+    if (ctx->loop_launch_seq == 0u) { ctx->loop_launch_seq = 1u; clear = true; }
+    if (clear && (e = hipMemsetAsync(ctx->loop_tagged.p, 0, ctx->loop_tagged.cap, ctx->stream)) != hipSuccess) return e;
+    *buf = ctx->loop_tagged.as<unsigned long long>();
+    *tag_base = ctx->loop_launch_seq << 8;
+    return hipSuccess;
+}
+
 inline hipError_t ensure_ticket(mlh_ctx *ctx)
 {
     if (ctx->ticket.p) return hipSuccess;

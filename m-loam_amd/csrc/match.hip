@@ -118,9 +118,9 @@ __device__ __forceinline__ void eval_edge(const d3 &p, const float (&c)[6], doub
 
 // accumulate one (possibly invalid) row and reduce the 29 sums over the workgroup -> partials[tile]
 // (mult: how many identical residual blocks the row stands for -- 1, except for the feature a selection picked repeatedly, select.hip: apply_keep_kernel)
-template <bool COH = false>
+template <int MODE = 0>      // 0: plain stores, 1: agent-scope monotonic stores, 2: tagged words (reduce_dev.hpp: reduce_acc32)
 __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delta, bool no_loss, int kind, double *lds_red /*4*32*/,
-                                            double *__restrict__ partial_out, int mult = 1)
+                                            double *__restrict__ partial_out, int mult = 1, unsigned tag = 0u)
 {
     double acc[32];
     if (valid) {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void reduce_rows(bool valid, Lin L, double huber_delt
         for (int i = 0; i < 29; ++i) acc[i] = 0.0;
     }
     acc[29] = acc[30] = acc[31] = 0.0;
-    reduce_acc32<COH>(acc, kind, lds_red, partial_out);
+    reduce_acc32<MODE>(acc, kind, lds_red, partial_out, tag);
 }
 
 // feature_extract.hpp:696-715
@@ -248,6 +248,8 @@ struct KParams {
     // launches are sized for an upper bound (KindP::m, tiles_*), the DEVM kernel variants take the counts -- and the tiles that follow from them -- from here
     const int *m_dev;        // [2]: surf, corner
     unsigned long long loop_timeout_ticks;   // lm_loop_kernel: a barrier wait longer than this (100 MHz wall clock) gives the loop up (mlh_ctx::caps)
+    unsigned long long *loop_tagged;   // lm_loop_kernel: two sets of tagged records (64 words per tile), or null: records + grid barrier (MLH_LOOP_TAGGED=0)
+    unsigned loop_tag_base;  // this launch's tag: (launch number << 8); the iteration goes into the low byte
     int debug_stall;         // MLH_DEBUG_LOOP_STALL=1 (tests): one workgroup of lm_loop_kernel never arrives at its second barrier -- the loop must end with the error bit, not hang
 };
 
@@ -1158,39 +1160,56 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
             else eval_edge(p, c.c, w, q, t, R9, L);
         }
         if (it == 2) MLH_STAGE(gtile, 1);
-        double *rec = P.partials + set * size_t((it + 1) & 1);
-        reduce_rows<MLH_LOOP_COH != 0>(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, rec + size_t(gtile) * NE_STRIDE, mult);
-        // (the record's 32 words are stored by the first 32 lanes of the wavefront thread 0 belongs to: its s_waitcnt covers them)
-        if (!MLH_LOOP_COH) __syncthreads();
-        if (it == 2) MLH_STAGE(gtile, 2);
-        if (threadIdx.x == 0) {
-            if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned target = unsigned(total) * unsigned(it + 1);
+        if (P.loop_tagged) {
+            // (round 6) the record leaves as tagged words and is summed by polling for the tag: no arrival atomic, no counter poll between the store and the loads
+            const unsigned tag = P.loop_tag_base | unsigned(it + 1);
+            unsigned long long *trec = P.loop_tagged + size_t(total) * 64 * size_t((it + 1) & 1);
             const bool stall = P.debug_stall && it == 1 && gtile == (total > 1 ? 1 : 0);
-            if (stall) { s_timeout = 1; __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            else {
-                __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                long long t0 = 0;
-                while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
-                    if ((++spins & 63u) == 0u) {      // (a completed barrier takes ~2 us = a few polls: the clock and the word below are only read by a wait that is already long)
-                        const long long now = wall_clock64();
-                        if (t0 == 0) t0 = now;
-                        const bool late = (unsigned long long)(now - t0) > P.loop_timeout_ticks;
-                        if (late) __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (late || __hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { s_timeout = 1; break; }
+            if (stall) {                                               // (tests: this workgroup's record never arrives)
+                if (threadIdx.x == 0) { s_timeout = 1; __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                __syncthreads();
+            } else {
+                reduce_rows<2>(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, reinterpret_cast<double *>(trec + size_t(gtile) * 64), mult, tag);
+                if (it == 2) MLH_STAGE(gtile, 2);
+                if (it == 2) MLH_STAGE(gtile, 3);
+                lmc_sum_records_tagged(trec, total, tag, f_ne, f_scratch, P.ticket, P.loop_timeout_ticks, &s_timeout);
+            }
+            if (s_timeout) break;
+        } else {
+            double *rec = P.partials + set * size_t((it + 1) & 1);
+            reduce_rows<MLH_LOOP_COH != 0>(valid, L, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, rec + size_t(gtile) * NE_STRIDE, mult);
+            // (the record's 32 words are stored by the first 32 lanes of the wavefront thread 0 belongs to: its s_waitcnt covers them)
+            if (!MLH_LOOP_COH) __syncthreads();
+            if (it == 2) MLH_STAGE(gtile, 2);
+            if (threadIdx.x == 0) {
+                if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned target = unsigned(total) * unsigned(it + 1);
+                const bool stall = P.debug_stall && it == 1 && gtile == (total > 1 ? 1 : 0);
+                if (stall) { s_timeout = 1; __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                else {
+                    __hip_atomic_fetch_add(P.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned spins = 0;
+                    long long t0 = 0;
+                    while (__hip_atomic_load(P.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (MLH_LOOP_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_SLEEP);
+                        if ((++spins & 63u) == 0u) {      // (a completed barrier takes ~2 us = a few polls: the clock and the word below are only read by a wait that is already long)
+                            const long long now = wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            const bool late = (unsigned long long)(now - t0) > P.loop_timeout_ticks;
+                            if (late) __hip_atomic_store(P.ticket + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (late || __hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { s_timeout = 1; break; }
+                        }
                     }
                 }
+                if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("" ::: "memory");
             }
-            if (!MLH_LOOP_COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("" ::: "memory");
+            __syncthreads();
+            if (it == 2) MLH_STAGE(gtile, 3);
+            if (s_timeout) break;
+            lmc_sum_records<MLH_LOOP_COH != 0>(rec, total, f_ne, f_scratch);
         }
-        __syncthreads();
-        if (it == 2) MLH_STAGE(gtile, 3);
-        if (s_timeout) break;
-        lmc_sum_records<MLH_LOOP_COH != 0>(rec, total, f_ne, f_scratch);
         if (it == 2) MLH_STAGE(gtile, 4);
 #if MLH_LOOP_SPLIT_STEP
         {
@@ -1593,6 +1612,8 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
         if (P.k[0].tiles_b + P.k[1].tiles_b > ctx->caps.loop_max_tiles[P.m_dev ? 1 : 0]) return fail(ctx, MLH_ERR_INVALID, "lm_loop_kernel: more tiles than can be resident at once on this device");
         P.loop_timeout_ticks = ctx->caps.loop_timeout_ticks;
         if (a.lm_expect_done < 0) ++ctx->caps.loop_launches;      // (the first loop of a frame)
+        // the iterations' records as tagged words summed by polling (MLH_LOOP_TAGGED=0: plain records behind a grid barrier, as through round 5)
+        { hipError_t e = loop_tagged_arm(ctx, size_t(P.k[0].tiles_b + P.k[1].tiles_b), a.lm_max_it, &P.loop_tagged, &P.loop_tag_base); if (e != hipSuccess) return fail(ctx, MLH_ERR_HIP, "tagged records", e); }
         if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true>, grid_b, P);
         else launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<false>, grid_b, P);
     }

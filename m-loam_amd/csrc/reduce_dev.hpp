@@ -35,9 +35,13 @@ __device__ __forceinline__ double swap_add(double x, double y)
 // acc: this lane's 32 values (entries 29..31 zero). 256 threads. partial_out[0..31]: the workgroup's sums; slots 29 / 30 mirror the
 // count for feature kind 0 / 1.
 // COH: the record is stored with agent-scope monotonic stores (readable by other workgroups of the SAME launch through agent-scope loads, without an L2 write-back fence)
-template <bool COH = false>
-__device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double *lds_red /*4*32*/, double *__restrict__ partial_out)
+// MODE 2 (round 6, lm_loop_kernel): the record leaves TAGGED -- every double as two 8-byte words {high half | tag, low half | tag}, agent-scope monotonic stores:
+// a reader that finds the iteration's tag in a word has that word's half of the value (8-byte single-copy atomicity), so the record needs no barrier behind it
+// (lmc_sum_records_tagged). partial_out then points at the tile's 64 words.
+template <int MODE = 0>
+__device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double *lds_red /*4*32*/, double *__restrict__ partial_out, unsigned tag = 0u)
 {
+    constexpr bool COH = MODE == 1;
     // transposed butterfly: at each step a lane keeps one half of its values and trades the other half with its partner, so the
     // wavefront total of value i ends up in lanes 2i and 2i+1 after 16+8+4+2+1+1 = 32 exchanges (a plain per-value butterfly
     // takes 29*6 = 174). Fixed tree -> deterministic sums.
@@ -66,7 +70,13 @@ __device__ __forceinline__ void reduce_acc32(double (&acc)[32], int kind, double
         double v = 0.0;
         const int src = (threadIdx.x == NE_CNT + 1 + kind) ? NE_CNT : threadIdx.x;   // per-kind count mirrors the count column
         if (src < 29) v = ((lds_red[src] + lds_red[32 + src]) + lds_red[64 + src]) + lds_red[96 + src];
-        if constexpr (COH) __hip_atomic_store(partial_out + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MODE == 2) {
+            unsigned long long *out = reinterpret_cast<unsigned long long *>(partial_out) + 2 * threadIdx.x;
+            const unsigned long long w0 = ((unsigned long long)(unsigned)__double2hiint(v) << 32) | tag, w1 = ((unsigned long long)(unsigned)__double2loint(v) << 32) | tag;
+            __hip_atomic_store(out, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(out + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else if constexpr (COH) __hip_atomic_store(partial_out + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else partial_out[threadIdx.x] = v;
     }
 }
@@ -102,6 +112,63 @@ __device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, dou
     __syncthreads();
 }
 
+// The same sum over TAGGED records (reduce_acc32<2>): no barrier in front -- every word is polled until it carries this iteration's tag. The workgroups of a loop
+// run in step (their loop tops are 0.1-0.3 us apart), so the first sweep finds most words in place and the wait is the last record's store-to-load latency instead of
+// an arrival atomic + a poll of its counter + the loads. Same slices, same chains, same association as lmc_sum_records: the same bits. A word that does not arrive
+// within timeout_ticks of the 100 MHz wall clock (a workgroup that never became resident, a fault) gives the loop up exactly as the barrier did: counters[3] tells
+// the other workgroups, *s_timeout (LDS, read by the caller behind this function's barriers) this one.
+__device__ __forceinline__ void lmc_sum_records_tagged(const unsigned long long *rec, int ntot, unsigned tag, double *f_ne, double *f_scratch, unsigned *counters,
+                                                       unsigned long long timeout_ticks, int *s_timeout)
+{
+    constexpr int NS = TPB / 32, U = 12;
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    double ch[4] = {0.0, 0.0, 0.0, 0.0};
+    bool gave_up = false;
+    for (int j = sl; j < ntot; j += U * NS) {
+        unsigned long long w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = j + NS * u;
+            const unsigned long long *p = rec + (size_t(jj) * NE_STRIDE + c) * 2;
+            w0[u] = jj < ntot ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag;
+            w1[u] = jj < ntot ? __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag;
+        }
+        unsigned spins = 0;
+        long long t0 = 0;
+        while (!gave_up) {
+            bool stale = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) stale = stale || unsigned(w0[u]) != tag || unsigned(w1[u]) != tag;
+            if (!stale) break;
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + NS * u;
+                const unsigned long long *p = rec + (size_t(jj) * NE_STRIDE + c) * 2;
+                if (unsigned(w0[u]) != tag) w0[u] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (unsigned(w1[u]) != tag) w1[u] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if ((++spins & 63u) == 0u) {
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                const bool late = (unsigned long long)(now - t0) > timeout_ticks;
+                if (late) __hip_atomic_store(counters + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (late || __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = true; *s_timeout = 1; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) ch[u & 3] += __hiloint2double(int(unsigned(w0[u] >> 32)), int(unsigned(w1[u] >> 32)));
+    }
+    f_scratch[sl * 32 + c] = (ch[0] + ch[1]) + (ch[2] + ch[3]);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) tsum += f_scratch[q * 32 + c];
+        f_ne[c] = tsum;
+    }
+    __syncthreads();
+}
 
 // One arrival at the loop kernels' grid barrier, by thread 0 of a workgroup whose record stores have been issued (by lanes of thread 0's own wavefront): wait for
 // their acknowledgement, count the arrival, poll until all `total` workgroups of barrier number `nth` (1, 2, ...) have arrived. counters[1] = arrivals (monotonic
