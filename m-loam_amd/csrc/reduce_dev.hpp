@@ -117,6 +117,9 @@ __device__ __forceinline__ void lmc_sum_records(const double *rec, int ntot, dou
 // an arrival atomic + a poll of its counter + the loads. Same slices, same chains, same association as lmc_sum_records: the same bits. A word that does not arrive
 // within timeout_ticks of the 100 MHz wall clock (a workgroup that never became resident, a fault) gives the loop up exactly as the barrier did: counters[3] tells
 // the other workgroups, *s_timeout (LDS, read by the caller behind this function's barriers) this one.
+#ifndef MLH_LOOP_TAG_SLEEP
+#define MLH_LOOP_TAG_SLEEP 1
+#endif
 __device__ __forceinline__ void lmc_sum_records_tagged(const unsigned long long *rec, int ntot, unsigned tag, double *f_ne, double *f_scratch, unsigned *counters,
                                                        unsigned long long timeout_ticks, int *s_timeout)
 {
@@ -140,7 +143,7 @@ __device__ __forceinline__ void lmc_sum_records_tagged(const unsigned long long 
 #pragma unroll
             for (int u = 0; u < U; ++u) stale = stale || unsigned(w0[u]) != tag || unsigned(w1[u]) != tag;
             if (!stale) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (MLH_LOOP_TAG_SLEEP) __builtin_amdgcn_s_sleep(MLH_LOOP_TAG_SLEEP);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jj = j + NS * u;

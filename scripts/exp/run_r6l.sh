@@ -1,2 +1,7 @@
-timeout -k 5 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_residency.py tests/test_gpu_parity_fullsize.py tests/test_gpu_edge_cases.py -x -q -m gpu -k "scan2map or lm or residency or loop or track or frame" 2>&1 | tail -4
-for i in 1 2 3; do for e in MLH_LOOP_TAGGED=0 MLH_LOOP_TAGGED=1; do echo -n "$e  "; env $e timeout -k 5 200 python scripts/trackbench.py 2>/dev/null | tail -2 | tr '\n' ' ' | cut -c1-260; echo; done; done
+for rep in 1 2; do for v in - tagsleep0 tagsleep4 tagsleep12; do
+if [ $v = - ]; then L=$PWD/m-loam_amd/lib/libmloam_hip.so; else L=$PWD/m-loam_amd/lib_ab/$v/libmloam_hip.so; fi
+MLOAM_HIP_LIB=$L python bench.py --no-cpu-baseline --steps 50 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d.get('scan2map') or {}
+print('$v', 's2m', s.get('ms_per_frame'), s.get('ms_per_frame_pipelined'), 'frame', d['frame']['ms_per_frame'])"
+done; done
