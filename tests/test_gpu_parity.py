@@ -537,7 +537,8 @@ def test_good_feature_selection_parity(ctx, mla, orc, case16, feats16, method):
 
 
 @pytest.mark.parametrize("variant", ["lattice", "duplicates", "five_points", "ratio_zero", "ratio_one", "nothing_matches", "host_loop", "dense_kernel",
-                                     "lattice_dense_kernel", "nan_points", "inf_point", "one_cluster", "sixty_five_points", "all_the_same_point"])
+                                     "lattice_dense_kernel", "nan_points", "inf_point", "one_cluster", "sixty_five_points", "all_the_same_point", "one_point",
+                                     "sixteen_k_points_repeated", "one_more_than_the_device_takes"])
 def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats16, variant, monkeypatch):
     """'fps' runs its arg-max loop on the device (select.hip: fps_order_pruned_kernel -- slots of 64 Morton-ordered points that cannot change are skipped --, and
     fps_order_kernel, MLH_FPS_DENSE=1, which re-measures every point every round). Equal distances are decided by the lowest index, as the host loop's strict `>`
@@ -560,6 +561,13 @@ def test_fps_selection_on_the_device_ties_and_edge_sizes(mla, orc, case16, feats
         surf = np.ascontiguousarray(surf[100:165]); ratio = 0.9
     elif variant == "all_the_same_point":
         surf[:, :3] = surf[40, :3]
+    elif variant == "one_point":
+        surf = np.ascontiguousarray(surf[7:8]); ratio = 1.0
+    elif variant in ("sixteen_k_points_repeated", "one_more_than_the_device_takes"):
+        # the largest cloud the device loops take (16 384: every register slot of every wavefront in use) and the first one they leave to the host loop; the cloud
+        # repeated verbatim: every distance several times over, every arg-max decided by the lowest index
+        n = 16384 + (1 if variant.startswith("one_more") else 0)
+        surf = np.ascontiguousarray(np.tile(surf, (n // len(surf) + 1, 1))[:n]); ratio = 0.05
     if variant == "lattice":
         surf[:, :3] = np.round(surf[:, :3] * 4.0) / 4.0
     elif variant == "duplicates":
