@@ -631,7 +631,8 @@ int track_loop_occupancy(int *blocks_per_cu);     // ... of track_lm_loop_kernel
 // iteration byte counts). Zero is never a tag: a fresh allocation and a wrap of the 24-bit launch number clear the words.
 inline hipError_t loop_tagged_arm(mlh_ctx *ctx, size_t tiles, int lm_max_it, unsigned long long **buf, unsigned *tag_base)
 {
-    static const bool off = [] { const char *e = std::getenv("MLH_LOOP_TAGGED"); return e && std::atoi(e) == 0; }();
+    const char *env = std::getenv("MLH_LOOP_TAGGED");           // (read at every call, as the other schedule switches: tests run both forms in one process)
+    const bool off = env && std::atoi(env) == 0;
     *buf = nullptr; *tag_base = 0u;
     if (off || lm_max_it > 200 || tiles == 0) return hipSuccess;
     const size_t bytes = sizeof(unsigned long long) * 64 * tiles * 2;

@@ -1402,9 +1402,11 @@ def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feat
             with_stats, st = c.scan2map(s0)                       # statistics asked for: always the classic launches
             need = max(int(x["lm_iterations"]) for x in st)
             got = {}
-            for mode in ("00", "10", "11"):                         # classic launches | consumer-side launches | the loop as one launch (the default)
+            # classic launches | consumer-side launches | the loop as one launch, its records tagged and summed by polling (the default) | ... behind a grid barrier
+            for mode in ("00", "10", "11", "11b"):
                 monkeypatch.setenv("MLH_LM_CONSUMER", mode[0])
                 monkeypatch.setenv("MLH_LM_LOOP", mode[1])
+                monkeypatch.setenv("MLH_LOOP_TAGGED", "0" if mode.endswith("b") else "1")
                 sync = c.scan2map(s0, want_stats=False)[0]
                 c.scan2map_begin(s0)
                 split, status = c.scan2map_end()
@@ -1419,7 +1421,8 @@ def test_scan2map_consumer_side_lm_equals_the_classic_launches(mla, case16, feat
                 b, sb = c.scan2map_end()
                 assert sa == 0 and sb == 0
                 got[mode] = (sync, split, exact, status_exact, short, status_short, a, b)
-            for other in ("10", "11"):
+            monkeypatch.delenv("MLH_LOOP_TAGGED", raising=False)
+            for other in ("10", "11", "11b"):
                 for x, y in zip(got["00"], got[other]):
                     assert np.array_equal(x, y)
             assert np.array_equal(got["11"][0], with_stats)
@@ -1457,14 +1460,16 @@ def test_scan2map_lm_forms_over_loop_lengths_and_degenerate_frames(mla, case16, 
             monkeypatch.delenv("MLH_LM_LOOP", raising=False)
             ref, st = c.scan2map(p0, opts)                         # statistics: the classic launches
             n_deg += sum(int(x["is_degenerate"]) for x in st)
-            for mode in ("11", "10", "00"):
+            for mode in ("11", "11b", "10", "00"):
                 monkeypatch.setenv("MLH_LM_CONSUMER", mode[0])
                 monkeypatch.setenv("MLH_LM_LOOP", mode[1])
+                monkeypatch.setenv("MLH_LOOP_TAGGED", "0" if mode.endswith("b") else "1")
                 got = c.scan2map(p0, opts, want_stats=False)[0]
                 assert np.array_equal(got, ref), (kw, mode)
                 c.scan2map_begin(p0, opts)
                 split, status = c.scan2map_end()
                 assert status == 0 and np.array_equal(split, ref), (kw, mode)
+        monkeypatch.delenv("MLH_LOOP_TAGGED", raising=False)
         assert n_deg >= 2                                          # the degenerate variants really took the projected update
     finally:
         c.close()

@@ -217,11 +217,14 @@ def test_four_contexts_in_four_threads_whole_frames_no_barrier_given_up(mla, cfg
         assert di["loop_timeouts"] == 0 and di["loop_fallbacks"] == 0, di
 
 
-def test_a_barrier_given_up_on_is_a_slow_frame_not_a_lost_one(mla, cfg2, monkeypatch):
-    """MLH_DEBUG_LOOP_STALL=1 makes one workgroup skip an arrival: the launch publishes the failure, the call solves the frame again through the launch-per-iteration
+@pytest.mark.parametrize("loop_form", ["tagged_records", "grid_barrier"])
+def test_a_barrier_given_up_on_is_a_slow_frame_not_a_lost_one(mla, cfg2, monkeypatch, loop_form):
+    """(Both forms of the one-launch loop's exchange: tagged records summed by polling -- a record that never arrives --, and records behind a grid barrier -- an
+    arrival that never comes; MLH_LOOP_TAGGED.) MLH_DEBUG_LOOP_STALL=1 makes one workgroup skip an arrival: the launch publishes the failure, the call solves the frame again through the launch-per-iteration
     form and returns the SAME pose; the context counts it, halves its gate (the next frames take the other form by themselves) and goes on working. The same through
     the split submission (status 2: solved again at collection) and for a frame chained behind the failed one (status 3: began from a pose that was not a result)."""
     import time
+    monkeypatch.setenv("MLH_LOOP_TAGGED", "1" if loop_form == "tagged_records" else "0")
     c = mla.Context(0)
     try:
         tiles = _stage(c, mla, cfg2)
