@@ -431,7 +431,7 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(FpsJobs J
         const unsigned gloc = unsigned(__builtin_amdgcn_readlane(int(c0.y), ww));
         ox = fpp_readlane(__uint_as_float(c1.x), ww); oy = fpp_readlane(__uint_as_float(c1.y), ww); oz = fpp_readlane(__uint_as_float(c1.z), ww);
         const int gpos = (int((gloc >> 6) & 31u) * FPP_WAVES + ww) * 64 + int(gloc & 63u);
-        if (t == 0) P.order[n_out] = gpos;                           // (a Morton position: translated behind the loop -- no LDS read in front of this store)
+        if (t == 0) P.order[n_out] = int(s_id[gpos]);               // (nobody waits for this store)
         if (w == ww && lane == int(gloc & 63u)) s_dist[gpos] = -1.f;      // visited (read again by this wavefront only)
         ++n_out;
         ++n_visited;
@@ -442,8 +442,6 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_order_pruned_kernel(FpsJobs J
 #ifdef MLH_FPS_STATS
     if (lane == 0) for (int i = 0; i < 5; ++i) const_cast<int *>(P.aux)[16 + 8 * w + i] = int(ck[i] / (unsigned long long)(n_out > 0 ? n_out : 1));
 #endif
-    __syncthreads();                                                 // (thread 0's stores to `order`: visible to the workgroup)
-    for (int i = t; i < n_out; i += FPP_THREADS) P.order[i] = int(s_id[P.order[i]]);
     if (t == 0) *P.n_order = n_out;
 }
 #undef FPP_CK
