@@ -423,7 +423,8 @@ int mlh_match_coeffs(mlh_ctx *ctx, int kind, uint8_t *valid, double *coeffs, int
  * over those rows with the reference's draw sequence (std::mt19937 + uniform_int_distribution, common/random_generator.hpp:53;
  * the MAX_FEATURE_SELECT_TIME wall-clock cut-off is not applied); fps draws one number (its starting point) and its
  * farthest-point arg-max loop runs on the device for up to 16384 features (same f32 arithmetic, lowest index among equal
- * distances), the host replaying selection list and information matrix along the visiting order. sub_mat_H must come in as the reference initialises it
+ * distances; a round re-measures only the buckets of points the new pick can change -- the same picks, 1 us per round; inside
+ * mlh_scan2map the two kinds' loops run side by side), the host replaying selection list and information matrix along the visiting order. sub_mat_H must come in as the reference initialises it
  * (1e-6 * I, cpp:505/520) and returns H + sum j^T j of the selected rows. On return only the selected features stay valid
  * on the device, so mlh_linearize / the LM of mlh_scan2map see exactly the residual blocks the reference would add.
  * fps asked for more features than match (gf_ratio * n above the number of matching features): the reference's loop has no "every point visited" exit
