@@ -1076,6 +1076,11 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_SLEEP
 #define MLH_LOOP_SLEEP 1
 #endif
+// MLH_LOOP_KEEP_REGS 1 (round 6): the first wavefront keeps the LM state's registers from step to step (lm_step_wave_keep) instead of loading them from and storing
+// them to the LDS state around every step: scan2map 0.184 -> 0.176 ms (three alternations: 0.1836 / 0.1844 / 0.1840 against 0.1761 / 0.1768 / 0.1755), the same bits
+#ifndef MLH_LOOP_KEEP_REGS
+#define MLH_LOOP_KEEP_REGS 1
+#endif
 template <bool DEVM = false>
 __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
 {
@@ -1133,6 +1138,10 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
     lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
     const bool skipped = s_timeout != 0;           // (uniform: written before the sum's barriers)
     if (threadIdx.x == 0 && skipped) s_done = 1;
+#if MLH_LOOP_KEEP_REGS
+    LmRegs Rk;                     // (first wavefront only: the LM state's registers, kept from step to step; stored to s_lm once, behind the loop)
+    double candk[7], x_cost_k = 0.0;
+#endif
     if (threadIdx.x < 64 && !skipped) {
         const int lane = threadIdx.x;
         LmRegs R;
@@ -1142,6 +1151,11 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         lm_begin_wave_pp(f_ne, f_scratch, x, &s_lm, true, P.thre_b[0], P.lm_max_it, P.lm_min_blocks, R, cand);
         if (lane < 7) s_cand[lane] = pick7(cand, lane);
         if (lane == 0) s_done = R.done;
+#if MLH_LOOP_KEEP_REGS
+        Rk = R; x_cost_k = f_ne[NE_COST];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) candk[i] = cand[i];
+#endif
     }
     __syncthreads();
     int it = 0;
@@ -1235,6 +1249,13 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
                 if (lane == 0) s_done = R.done;
             }
         }
+#elif MLH_LOOP_KEEP_REGS
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            lm_step_wave_keep(f_ne, &s_lm, P.lm_max_it, Rk, candk, x_cost_k);
+            if (lane < 7) s_cand[lane] = pick7(candk, lane);
+            if (lane == 0) s_done = Rk.done;
+        }
 #else
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
@@ -1249,6 +1270,13 @@ __global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
         if (it == 2) MLH_STAGE(gtile, 5);
         ++it;
     }
+#if MLH_LOOP_KEEP_REGS
+    if (threadIdx.x < 64 && !skipped) {            // the state the publication below (and nothing else) reads
+        lm_state_store_pp(Rk, candk, s_lm.ne, s_lm.V, &s_lm, threadIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
     if (writer && threadIdx.x < 64 && skipped) {
         // the loop never began here: the pose in the state is what the last loop that ran left; the failure travels on to the launch that publishes
         if (threadIdx.x == 0) {

@@ -1007,6 +1007,47 @@ __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState 
     MLH_STEP_STAMP(7);
 }
 
+// lm_step_wave_pp for a caller that KEEPS the state's registers from one step to the next (match.hip: lm_loop_kernel, MLH_LOOP_KEEP_REGS): R / cand / x_cost come in as
+// the previous call (or lm_begin_wave_pp) left them and go out updated; only what other lanes read from memory -- the accepted record (S->ne: the rows of a later,
+// rejected step's proposal) -- is stored. No state load in front, no state store behind: the caller stores the state once, behind its loop (lm_state_store_pp).
+// Operation for operation lm_step_wave_pp: the same bits.
+__device__ __forceinline__ void lm_step_wave_keep(const double *ce, LmState *S, int max_it, LmRegs &R, double (&cand)[7], double &x_cost)
+{
+    const int lane = threadIdx.x & 63;
+    R.evaluations++;
+    double step_norm = 0.0, x_norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const double d = R.x[i] - cand[i]; step_norm += d * d; x_norm += R.x[i] * R.x[i]; }
+    step_norm = sqrt(step_norm); x_norm = sqrt(x_norm);
+    bool stop = false;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { R.done = 1; R.termination = 2; stop = true; }
+    const double cost_change = x_cost - ce[NE_COST];
+    if (!stop && fabs(cost_change) <= 1e-6 * x_cost) { R.done = 1; R.termination = 3; stop = true; }
+    const double *ne_now = S->ne;
+    if (!stop) {
+        const double rd = cost_change / R.model_cost_change;
+        if (rd > 1e-3) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) R.x[i] = cand[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) R.g[i] = ce[NE_G + i];
+            ne_now = ce;
+            x_cost = ce[NE_COST];
+            if (lane < NE_STRIDE) S->ne[lane] = ce[lane];          // (read back by a LATER step only: behind the caller's barrier)
+            R.num_successful++;
+            const double t = 2.0 * rd - 1.0;
+            R.radius = R.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+            R.radius = fmin(1e16, R.radius);
+            R.decrease_factor = 2.0;
+            R.reuse_diagonal = 0;
+            R.gmax = gradient_max_norm_wave(R, S->V, lane);
+        } else {
+            R.radius /= R.decrease_factor; R.decrease_factor *= 2.0; R.reuse_diagonal = 1;
+        }
+        lm_propose_wave(R, ne_now, S->V, cand, max_it, lane);
+    }
+}
+
 // The step in two parts, for a caller that has ANOTHER wavefront compute the gradient max-norm an accepted step needs (gradient_max_norm_wave at the candidate, with
 // the candidate's gradient: inputs that exist before the step begins) while this one goes on: part 1 is lm_step_wave_pp with the proposal made as if that norm were
 // above the tolerance; part 2 -- behind a barrier, with the norm in hand -- takes the proposal back if it is not (Ceres tests the norm before it proposes: the loop
