@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #define MLH_LOOP_KEEP_REGS 1
 #endif
 template <bool DEVM = false>
-__global__ __launch_bounds__(TPB) void lm_loop_kernel(KParams P)
+__global__ __launch_bounds__(TPB, 2) void lm_loop_kernel(KParams P)      // (2: two workgroups per compute unit -- 256 registers in all; the residency gates count on them)
 {
     __shared__ double s_red[4 * 32];
     __shared__ double f_ne[NE_STRIDE], f_scratch[(TPB / 32) * 32];

@@ -1014,6 +1014,10 @@ __device__ __forceinline__ void lm_step_wave_pp(const double *ce, const LmState 
 __device__ __forceinline__ void lm_step_wave_keep(const double *ce, LmState *S, int max_it, LmRegs &R, double (&cand)[7], double &x_cost)
 {
     const int lane = threadIdx.x & 63;
+    // (the gradient is NOT kept: it is the accepted record's, one LDS trip that nothing waits for before the proposal -- and twelve registers fewer across the
+    // evaluation, which is what keeps the kernel at two workgroups per compute unit: 256 + 8 registers made it one)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) R.g[i] = S->ne[NE_G + i];
     R.evaluations++;
     double step_norm = 0.0, x_norm = 0.0;
 #pragma unroll
