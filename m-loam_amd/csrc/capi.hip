@@ -1756,9 +1756,10 @@ static int scan2map_polled(mlh_ctx *ctx, double pose_inout[7], const mlh_solver_
             a.finish = 0; a.lm_max_it = opts->max_lm_iterations;
             if (outer == 0) a.init_pose = pose_inout;
             a.warm = outer >= 1 && s2m_warm_applies(ctx);
+            a.no_fit = loop_fit_fusable(a);                 // (the fit rides in the loop launch below)
             if ((rc = match_launch(ctx, a))) return rc;
             MatchArgs b = args_from_opts(opts, 3, 1);
-            b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0;
+            b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0; b.fit_in_loop = a.no_fit;
             b.lm_expect_done = outer == 0 ? -1 : 1;
             if (outer == 0) b.init_pose = pose_inout;
             if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
@@ -1958,9 +1959,10 @@ static int scan2map_submit(mlh_ctx *ctx, const double *pose_in, const double *wo
         a.finish = 0; a.lm_max_it = opts->max_lm_iterations;
         if (outer == 0) a.init_pose = pose_in;
         a.warm = outer >= 1 && s2m_warm_applies(ctx);
+        a.no_fit = loop_fit_fusable(a);
         if ((rc = match_launch(ctx, a))) return rc;
         MatchArgs b = args_from_opts(opts, 3, 1);
-        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0;
+        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0; b.fit_in_loop = a.no_fit;
         b.lm_expect_done = outer == 0 ? -1 : 1;
         if (outer == 0) b.init_pose = pose_in;
         if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }
@@ -2148,9 +2150,10 @@ int mlh_downsample_scan2map(mlh_ctx *ctx, const void *surf_points, int n_surf, c
         a.finish = 0; a.lm_max_it = opts->max_lm_iterations; a.m_dev = ctx->thin_counts_dev;
         if (outer == 0) a.init_pose = pose_inout;
         a.warm = outer >= 1 && s2m_warm_applies(ctx);
+        a.no_fit = loop_fit_fusable(a);
         if ((rc = match_launch(ctx, a))) break;
         MatchArgs b = args_from_opts(opts, 3, 1);
-        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0; b.m_dev = ctx->thin_counts_dev;
+        b.finish = 0; b.lmc = 3; b.lmc_j = 1; b.lm_max_it = opts->max_lm_iterations; b.lm_min_blocks = 0; b.m_dev = ctx->thin_counts_dev; b.fit_in_loop = a.no_fit;
         b.lm_expect_done = outer == 0 ? -1 : 1;
         if (outer == 0) b.init_pose = pose_inout;
         if (outer == opts->max_outer - 1) { b.publish = rec; b.publish_seq = seq; }

@@ -614,6 +614,10 @@ struct MatchArgs {
     // (finish 0) -- sums them, runs the LM begin, evaluates at the first candidate; 2 = a later launch -- sums the records at the candidate, runs the LM step,
     // evaluates at the next candidate. lmc_j: the launch's number within its loop (1, 2, ...: record buffer (j - 1) & 1 is read, j & 1 written)
     int lmc = 0, lmc_j = 0;
+    // round 6: the fit of an outer iteration inside the loop launch that follows it (lm_loop_kernel<.., FIT>): match_launch with `no_fit` ends behind the
+    // correspondence kernel, lm_consume_launch (lmc == 3) with `fit_in_loop` begins with the fit -- one launch boundary fewer per outer iteration. Only together,
+    // and only where loop_fit_fusable() says so (tagged records: the fit's record leaves as the loop's own do).
+    bool no_fit = false, fit_in_loop = false;
     const int *m_dev = nullptr;   // device: the two feature counts (surf, corner) when the host has not read them (mlh_downsample_scan2map); FeatSet::m then holds upper bounds
     HostPublish *publish = nullptr;          // pinned host record the finish writes the pose(s) to (finish == 1 only)
     unsigned long long publish_seq = 0;
@@ -622,6 +626,7 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a);
 int gn_flush_pending(mlh_ctx *ctx);      // completes a pending last iteration with a one-workgroup launch (no-op when nothing is pending)
 int linearize_launch(mlh_ctx *ctx, const MatchArgs &a);
 int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a);
+bool loop_fit_fusable(const MatchArgs &loop_args);   // the loop launch described by these arguments would exchange tagged records (ctx.hpp: loop_tagged_arm's conditions)
 int lm_loop_occupancy(int blocks_per_cu[2]);      // hipOccupancyMaxActiveBlocksPerMultiprocessor of lm_loop_kernel<false> / <true>
 int track_loop_occupancy(int *blocks_per_cu);     // ... of track_lm_loop_kernel (track.hip)
 // the arrival counters of the fused finishes and of lm_loop_kernel's barrier: four zeroed words, whoever asks first ([0]: the finish tickets of match.hip and

@@ -1081,7 +1081,11 @@ __global__ __launch_bounds__(TPB) void lm_consume_kernel(KParams P)
 #ifndef MLH_LOOP_KEEP_REGS
 #define MLH_LOOP_KEEP_REGS 1
 #endif
-template <bool DEVM = false>
+// FIT (round 6): the launch begins with the outer iteration's FIT -- fit_linearize_kernel's body for this tile: neighbour records -> line / plane fit + gates -> the
+// correspondence record (stored: later launches and callers read it) -> residual + Jacobian at the start pose -> the tile's record, tagged with iteration 0 and
+// summed by polling like every other record of the loop -- instead of reading what a fit launch in front of it left. One launch boundary fewer per outer iteration;
+// the same operations on the same values: the same bits. Tagged records only (P.loop_tagged: the host's loop_fit_fusable()).
+template <bool DEVM = false, bool FIT = false>
 __global__ __launch_bounds__(TPB, 2) void lm_loop_kernel(KParams P)      // (2: two workgroups per compute unit -- 256 registers in all; the residency gates count on them)
 {
     __shared__ double s_red[4 * 32];
@@ -1122,7 +1126,27 @@ __global__ __launch_bounds__(TPB, 2) void lm_loop_kernel(KParams P)      // (2: 
     Corr c;
     c.valid = 0;
     float4 fp = make_float4(0.f, 0.f, 0.f, 0.f), cdv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < m_feat) {
+    if constexpr (FIT) {
+        // fit_linearize_kernel<5, .., FIN = false>'s body (single block, N_NEIGH 5, no ownership planes, no field-of-view gate: what scan2MapOptimization launches)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.c[i] = 0.f;
+        c.pad = 0;
+        if (f < m_feat) {
+            fp = K.feat[f];
+            float4 nbv[5];
+            const float4 *nb = K.nbr + size_t(f) * K.nbr_stride;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nbv[j] = nb[j];
+            if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
+            float coef[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool ok = false;
+            if (fp.w >= 0.f) ok = fit_feature<5, 5>(P, kind, nbv, coef);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c.c[i] = ok ? coef[i] : 0.f;
+            c.valid = ok ? 1 : 0;
+            K.corr[f] = c;
+        }
+    } else if (f < m_feat) {
         c = K.corr[f];
         fp = K.feat[f];
         if ((P.flags & MLH_FLAG_WITH_UA) && K.covd) cdv = K.covd[f];
@@ -1135,7 +1159,34 @@ __global__ __launch_bounds__(TPB, 2) void lm_loop_kernel(KParams P)      // (2: 
     // given up already -- by a workgroup of this launch that waited in vain, or by an earlier loop of this frame: nothing to do but leave
     if (threadIdx.x == 0)
         s_timeout = (__hip_atomic_load(P.ticket + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || (P.lm_expect_done >= 0 && P.state->lm_overflow == 4)) ? 2 : 0;
-    lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
+    if constexpr (FIT) {
+        __syncthreads();                               // s_timeout
+        if (s_timeout == 0) {                          // (uniform)
+            // the linearisation at the start pose, as the fit launch evaluates it (load_pose: the launch's pose argument or the state's)
+            double xs[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) xs[i] = P.use_init ? P.init_pose[i] : P.state->x[i];
+            const q4 q0{xs[3], xs[4], xs[5], xs[6]};
+            const d3 t0{xs[0], xs[1], xs[2]};
+            Lin L0;
+            L0.r = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) L0.J[i] = 0.0;
+            if (valid) {
+                double R9[9];
+                qtorot(q0, R9);
+                if (kind == MLH_SURF) eval_plane(p, c.c, w, q0, t0, R9, L0);
+                else eval_edge(p, c.c, w, q0, t0, R9, L0);
+            }
+            const unsigned tag0 = P.loop_tag_base;     // iteration byte 0: the fit's record (the loop's iterations carry 1, 2, ...)
+            unsigned long long *trec0 = P.loop_tagged;  // set 0 (iteration `it` writes set (it + 1) & 1: 1, 0, 1, ...; set 0 is written again by iteration 1, which
+                                                        // no workgroup reaches before every workgroup has stored its iteration-0 record -- behind its read of this one)
+            reduce_rows<2>(valid, L0, P.huber_delta, (P.flags & MLH_FLAG_NO_LOSS) != 0, kind, s_red, reinterpret_cast<double *>(trec0 + size_t(gtile) * 64), 1, tag0);
+            lmc_sum_records_tagged(trec0, total, tag0, f_ne, f_scratch, P.ticket, P.loop_timeout_ticks, &s_timeout);
+        }
+    } else {
+        lmc_sum_records(P.partials_in, total, f_ne, f_scratch);
+    }
     const bool skipped = s_timeout != 0;           // (uniform: written before the sum's barriers)
     if (threadIdx.x == 0 && skipped) s_done = 1;
 #if MLH_LOOP_KEEP_REGS
@@ -1558,9 +1609,9 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
         if (mb || k10 || P.finish != 0 || P.pre_finish || (a.kind_mask & 3) != 3) return fail(ctx, MLH_ERR_UNSUPPORTED, "device-side feature counts: one block, N_NEIGH 5, both kinds, records only");
         if (P.warm) launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false, false, 0, true, true>, grid_a, P);
         else launch_timed(ctx, MLH_K_KNN, knn_features_kernel<0, false, false, 0, false, true>, grid_a, P);
-        launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false, false, true>, grid_b, P);
+        if (!a.no_fit) launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, false, false, true>, grid_b, P);
         MLH_HIP(ctx, hipGetLastError());
-        for (int k = 0; k < 2; ++k) ctx->feat[k].matched = true;
+        for (int k = 0; k < 2; ++k) ctx->feat[k].matched = !a.no_fit;       // (no_fit: the loop launch behind this one writes the correspondences)
         return MLH_OK;
     }
     {
@@ -1598,6 +1649,13 @@ int match_launch(mlh_ctx *ctx, const MatchArgs &a)
 #undef MLH_KNN_LAUNCH_GN_MB
 #undef MLH_KNN_LAUNCH
     }
+    if (a.no_fit) {
+        // the fit rides in the loop launch behind this one (lm_consume_launch, fit_in_loop): single block, N_NEIGH 5, both kinds, records only
+        if (k10 || P.n_blocks != 1 || P.finish != 0 || (a.kind_mask & 3) != 3 || a.dense) return fail(ctx, MLH_ERR_UNSUPPORTED, "match_launch without its fit: single block, N_NEIGH 5, both kinds, records only");
+        MLH_HIP(ctx, hipGetLastError());
+        for (int k = 0; k < 2; ++k) ctx->feat[k].matched = false;
+        return MLH_OK;
+    }
     if (P.finish == 3) {
         if (k10 || P.n_blocks != 1) return fail(ctx, MLH_ERR_UNSUPPORTED, "the fused Levenberg-Marquardt begin is single-block, N_NEIGH = 5");
         launch_timed(ctx, MLH_K_FIT, fit_linearize_kernel<5, true>, grid_b, P);
@@ -1627,8 +1685,9 @@ int linearize_launch(mlh_ctx *ctx, const MatchArgs &a)
 int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
 {
     for (int k = 0; k < 2; ++k)
-        if ((a.kind_mask & (1 << k)) && !ctx->feat[k].matched) return fail(ctx, MLH_ERR_STATE, "the Levenberg-Marquardt launches need a previous match of this kind");
+        if ((a.kind_mask & (1 << k)) && !ctx->feat[k].matched && !a.fit_in_loop) return fail(ctx, MLH_ERR_STATE, "the Levenberg-Marquardt launches need a previous match of this kind");
     if (a.lmc < 1 || a.lmc > 3 || a.lmc_j < 1 || a.n_blocks > 1 || a.dense) return fail(ctx, MLH_ERR_INVALID, "lm_consume_launch: single block, no dense rows");
+    if (a.fit_in_loop && (a.lmc != 3 || (a.kind_mask & 3) != 3 || !loop_fit_fusable(a))) return fail(ctx, MLH_ERR_INVALID, "the fit rides in the one-launch loop with tagged records only");
     KParams P;
     int rc = fill_params(ctx, a, P);
     if (rc) return rc;
@@ -1642,7 +1701,13 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
         if (a.lm_expect_done < 0) ++ctx->caps.loop_launches;      // (the first loop of a frame)
         // the iterations' records as tagged words summed by polling (MLH_LOOP_TAGGED=0: plain records behind a grid barrier, as through round 5)
         { hipError_t e = loop_tagged_arm(ctx, size_t(P.k[0].tiles_b + P.k[1].tiles_b), a.lm_max_it, &P.loop_tagged, &P.loop_tag_base); if (e != hipSuccess) return fail(ctx, MLH_ERR_HIP, "tagged records", e); }
-        if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true>, grid_b, P);
+        if (a.fit_in_loop) {
+            if (!P.loop_tagged) return fail(ctx, MLH_ERR_INVALID, "the fit rides in the one-launch loop with tagged records only");
+            if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true, true>, grid_b, P);
+            else launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<false, true>, grid_b, P);
+            for (int k = 0; k < 2; ++k) ctx->feat[k].matched = true;
+        }
+        else if (P.m_dev) launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<true>, grid_b, P);
         else launch_timed(ctx, MLH_K_LINEARIZE, lm_loop_kernel<false>, grid_b, P);
     }
     else if (a.lmc == 1) launch_timed(ctx, MLH_K_LINEARIZE, lm_consume_kernel<true>, grid_b, P);
@@ -1651,10 +1716,22 @@ int lm_consume_launch(mlh_ctx *ctx, const MatchArgs &a)
     return MLH_OK;
 }
 
+bool loop_fit_fusable(const MatchArgs &loop_args)
+{
+    const char *env = std::getenv("MLH_LOOP_TAGGED"), *env_fit = std::getenv("MLH_LOOP_FIT");      // (A/B switches, read at every call: MLH_LOOP_FIT=0 keeps the fit launch)
+    if ((env && std::atoi(env) == 0) || (env_fit && std::atoi(env_fit) == 0)) return false;
+    return loop_args.lm_max_it <= 200 && loop_args.n_blocks == 1 && !loop_args.dense;
+}
+
 int lm_loop_occupancy(int blocks_per_cu[2])
 {
+    // (the forms with and without the fit in front: the smaller number gates both)
+    int with_fit[2] = {0, 0};
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu[0], lm_loop_kernel<false>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu[1], lm_loop_kernel<true>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with_fit[0], lm_loop_kernel<false, true>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with_fit[1], lm_loop_kernel<true, true>, TPB, 0) != hipSuccess) return MLH_ERR_HIP;
+    for (int i = 0; i < 2; ++i) blocks_per_cu[i] = std::min(blocks_per_cu[i], with_fit[i]);
     return MLH_OK;
 }
 
