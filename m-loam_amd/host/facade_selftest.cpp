@@ -433,6 +433,33 @@ int main(int argc, char **argv)
             }
             verdict.push_back(distinct_threads);
             write_file(d + "out_reentrant.i32", verdict);
+            // round 6: the same loop from ONE thread through the facade's own lanes (FrontEndLanes::processAllLasers; a caller without OpenMP): three frames on
+            // two lanes (four LiDARs -> two passes) and on four, every LiDAR's clouds equal to the one-after-the-other run; a job's exception arrives at the caller
+            {
+                std::vector<int> lv;
+                for (int n_lanes : {2, 4}) {
+                    FrontEndLanes lanes(n_lanes);
+                    std::vector<cloudFeature> feature_frame;
+                    int equal = 0;
+                    for (int round = 0; round < 3; ++round) {
+                        lanes.processAllLasers(img_segment_, f_extract_, v_laser_cloud_in, N_SCANS, true, feature_frame);
+                        equal = 0;
+                        for (int i = 0; i < NUM_OF_LASER; ++i) { std::vector<float> o; flatten(feature_frame[size_t(i)], o); equal += o == seq[size_t(i)] ? 1 : 0; }
+                    }
+                    lv.push_back(equal);
+                }
+                {
+                    FrontEndLanes lanes(1);
+                    int caught = 0;
+                    lanes.post(0, [] { throw Error("lane job failed"); });
+                    try { lanes.wait(0); } catch (const Error &) { caught = 1; }
+                    lanes.post(0, [] {});
+                    lanes.wait(0);                                  // the lane survives a failed job
+                    lv.push_back(caught);
+                }
+                write_file(d + "out_lanes.i32", lv);
+                std::printf("front-end lanes from one thread: LiDARs equal on 2 lanes %d / 4, on 4 lanes %d / 4; a job's exception rethrown at wait: %d\n", lv[0], lv[1], lv[2]);
+            }
             std::printf("re-entrant front end: %d LiDARs on %d threads, one FeatureExtract + one ImageSegmenter: clouds equal %d %d %d %d, labels equal %d %d %d %d\n", NUM_OF_LASER,
                         distinct_threads, verdict[0], verdict[3], verdict[6], verdict[9], verdict[1], verdict[4], verdict[7], verdict[10]);
         }

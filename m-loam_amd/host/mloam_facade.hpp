@@ -28,8 +28,12 @@
 #include <map>
 #include <memory>
 #include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -147,6 +151,12 @@ public:
 // where the spelling differs (q.w() against q.w, m(r, c) against m[r * n + c], MatrixXd::resize(1, n) against vector::resize(n), *ptr against a
 // reference) go through the helpers below. tests/host/refcut compiles the reference's own call sites, cut verbatim, against exactly this.
 namespace detail {
+// a cloud of m points to be written by index (pcl::PointCloud keeps width / height beside `points`; push_back per point is ~4.5 ns x 115 k points per 64-ring cloud)
+template <class C> auto cloud_set_dims(C &c, size_t m, int) -> decltype(void(c.width = 0)) { c.width = uint32_t(m); c.height = 1; }
+template <class C> void cloud_set_dims(C &, size_t, long) {}
+template <class C> void cloud_resize(C &c, size_t m) { c.points.resize(m); cloud_set_dims(c, m, 0); }
+// the calling thread's scratch floats (slot 0 / 1): a fresh zero-filled vector of a 64-ring cloud's size per call is ~70 us of page faults and fills
+inline std::vector<float> &thread_floats(int slot, size_t n) { thread_local std::vector<float> v[2]; if (v[slot].size() < n) v[slot].resize(n); return v[slot]; }
 template <class Q> auto quat_w(const Q &q, int) -> decltype(double(q.w())) { return q.w(); }
 template <class Q> auto quat_w(const Q &q, long) -> decltype(double(q.w)) { return q.w; }
 template <class Q> auto quat_x(const Q &q, int) -> decltype(double(q.x())) { return q.x(); }
@@ -453,10 +463,10 @@ public:
         dev_.check(mlh_scan_upload(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, n, scan_info.scan_start_ind_.data(),
                                    scan_info.scan_end_ind_.data(), rings, MLH_MEM_HOST));
         dev_.check(mlh_extract_run(dev_.ctx()));
-        std::vector<int32_t> lists[4];
+        thread_local std::vector<int32_t> lists[4];        // (the calling thread's: four fresh index vectors of the cloud's size are 1.8 MB of fills per 64-ring call)
         int32_t *ptrs[4];
         int32_t counts[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) { lists[i].resize(n > 0 ? n : 1); ptrs[i] = lists[i].data(); }
+        for (int i = 0; i < 4; ++i) { if (lists[i].size() < size_t(n > 0 ? n : 1)) lists[i].resize(n > 0 ? n : 1); ptrs[i] = lists[i].data(); }
         labels_.resize(n);
         dev_.check(mlh_extract_fetch(dev_.ctx(), labels_.data(), nullptr, nullptr, ptrs, counts));
         cloud_feature.clear();
@@ -464,17 +474,17 @@ public:
         static const char *names[3] = {"corner_points_sharp", "corner_points_less_sharp", "surf_points_flat"};
         for (int i = 0; i < 3; ++i) {
             PointICloud &c = cloud_feature[names[i]];
-            c.points.reserve(counts[i]);
-            for (int k = 0; k < counts[i]; ++k) c.push_back(laser_cloud_in.points[lists[i][k]]);
+            detail::cloud_resize(c, size_t(counts[i]));
+            for (int k = 0; k < counts[i]; ++k) c.points[size_t(k)] = laser_cloud_in.points[lists[i][k]];
         }
         // "surf_points_less_flat": the label <= 0 points after the per-ring 0.2 m pcl::VoxelGrid (cpp:266-271), ring by ring
         dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
-        std::vector<float> vox(size_t(counts[3] > 0 ? counts[3] : 1) * 4);
+        std::vector<float> &vox = detail::thread_floats(0, size_t(counts[3] > 0 ? counts[3] : 1) * 4);
         int32_t n_vox = 0;
         dev_.check(mlh_extract_fetch_voxel(dev_.ctx(), vox.data(), &n_vox));
         PointICloud &lf = cloud_feature["surf_points_less_flat"];
-        lf.points.reserve(n_vox);
-        for (int k = 0; k < n_vox; ++k) { PointI p; p.x = vox[4 * k]; p.y = vox[4 * k + 1]; p.z = vox[4 * k + 2]; p.intensity = vox[4 * k + 3]; lf.push_back(p); }
+        detail::cloud_resize(lf, size_t(n_vox));
+        for (int k = 0; k < n_vox; ++k) { PointI p; p.x = vox[4 * k]; p.y = vox[4 * k + 1]; p.z = vox[4 * k + 2]; p.intensity = vox[4 * k + 3]; lf.points[size_t(k)] = p; }
     }
     const std::vector<int32_t> &cloudLabel() const { return threadLabels(); }   // cloud_label[] of the calling thread's last extractCloud
     Device &device() const { return bound_ ? *bound_ : threadDevice(); }
@@ -901,7 +911,7 @@ public:
         prm_.segment_flag = scan_info.segment_flag_ ? 1 : 0;
         // laser_cloud_outlier holds at most one point per pixel of a column that is a multiple of 5 (and never more than n), plus one
         const int outl_cap = std::min(n, prm_.vertical_scans * ((prm_.horizon_scans + 4) / 5)) + 1;
-        std::vector<float> out(size_t(n > 0 ? n : 1) * 4), outl(size_t(outl_cap) * 4);
+        std::vector<float> &out = detail::thread_floats(0, size_t(n > 0 ? n : 1) * 4), &outl = detail::thread_floats(1, size_t(outl_cap) * 4);
         int32_t n_out = 0, n_outl = 0;
         scan_info.scan_start_ind_.resize(prm_.vertical_scans);
         scan_info.scan_end_ind_.resize(prm_.vertical_scans);
@@ -909,9 +919,8 @@ public:
                                      out.data(), &n_out, scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), outl.data(), outl_cap, &n_outl));
         if (n_outl > outl_cap) n_outl = outl_cap;      // cannot happen with the bound above; never read past the buffer
         auto fill = [](PointICloud &c, const std::vector<float> &v, int m) {
-            c.points.clear();
-            c.points.reserve(m);
-            for (int k = 0; k < m; ++k) { PointI p; p.x = v[4 * k]; p.y = v[4 * k + 1]; p.z = v[4 * k + 2]; p.intensity = v[4 * k + 3]; c.push_back(p); }
+            detail::cloud_resize(c, size_t(m));
+            for (int k = 0; k < m; ++k) { PointI p; p.x = v[4 * k]; p.y = v[4 * k + 1]; p.z = v[4 * k + 2]; p.intensity = v[4 * k + 3]; c.points[size_t(k)] = p; }
         };
         fill(laser_cloud_out, out, n_out);
         fill(laser_cloud_outlier, outl, n_outl);
@@ -919,6 +928,101 @@ public:
 private:
     Device *bound_;
     mlh_segment_params prm_;
+};
+
+// ------------------------------------------------------------------ the front end's lanes: the reference's OpenMP team for callers that have none
+// estimator.cpp:249 runs calTimestamp / segmentCloud / extractCloud of the NUM_OF_LASER LiDARs on NUM_OF_LASER OpenMP threads. Most of segmentCloud is its cluster
+// search -- sequential by definition (csrc/segment.hip), on the host, ~1.3 ms of a 1.6 ms call on a 64-ring scan -- so what can run beside one LiDAR's search is the
+// NEXT LiDAR's search and the device work around it. A caller built without OpenMP (or calling from one thread) gets that from here: FrontEndLanes keeps one
+// persistent worker thread per LiDAR; each worker runs the loop body of estimator.cpp:252-262 for its LiDAR on the default-constructed (re-entrant) facade objects,
+// i.e. on the context threadDevice() keeps for that worker -- created on the worker's first job, reused for every later frame. The results are the same calls'
+// results (facade_selftest: equal to the one-after-the-other run, bit for bit).
+class FrontEndLanes {
+public:
+    explicit FrontEndLanes(int n_lanes) : lanes_(size_t(n_lanes > 0 ? n_lanes : 1))
+    {
+        for (auto &l : lanes_) { l.reset(new Lane); Lane *lp = l.get(); lp->th = std::thread([lp] { lp->run(); }); }
+    }
+    ~FrontEndLanes()
+    {
+        for (auto &l : lanes_) { { std::lock_guard<std::mutex> g(l->mu); l->quit = true; } l->cv.notify_all(); }
+        for (auto &l : lanes_) if (l->th.joinable()) l->th.join();
+    }
+    FrontEndLanes(const FrontEndLanes &) = delete;
+    FrontEndLanes &operator=(const FrontEndLanes &) = delete;
+    int size() const { return int(lanes_.size()); }
+    // hands `job` to lane i's worker (behind the job it may still be running) and returns; everything the job references must stay alive until wait(i)
+    void post(int i, std::function<void()> job)
+    {
+        Lane &l = *lanes_.at(size_t(i));
+        std::unique_lock<std::mutex> g(l.mu);
+        l.cv.wait(g, [&] { return !l.busy; });
+        l.job = std::move(job); l.busy = true; l.err = nullptr;
+        g.unlock();
+        l.cv.notify_all();
+    }
+    // returns when lane i's job has run; what the job threw is thrown again here
+    void wait(int i)
+    {
+        Lane &l = *lanes_.at(size_t(i));
+        std::unique_lock<std::mutex> g(l.mu);
+        l.cv.wait(g, [&] { return !l.busy; });
+        std::exception_ptr e = l.err;
+        l.err = nullptr;
+        g.unlock();
+        if (e) std::rethrow_exception(e);
+    }
+    // estimator.cpp:248-263 from ONE calling thread: every LiDAR's calTimestamp -> segmentCloud -> extractCloud (+ "laser_cloud_outlier") on its own lane, all lanes
+    // at once; returns when all are done. img_segment / f_extract: the default-constructed (context-less) objects, as the reference's members are.
+    // segment_flag: ScanInfo's (SEGMENT_CLOUD, false while the extrinsics are being estimated: estimator.cpp:258).
+    template <class RawCloudVec, class SegmenterT, class ExtractT, class FeatureVec>
+    void processAllLasers(SegmenterT &img_segment, ExtractT &f_extract, const RawCloudVec &v_laser_cloud_in, int n_scans, bool segment_flag, FeatureVec &feature_frame)
+    {
+        const size_t n = v_laser_cloud_in.size();
+        if (feature_frame.size() < n) feature_frame.resize(n);
+        for (size_t i0 = 0; i0 < n; i0 += lanes_.size()) {
+            const size_t i1 = std::min(n, i0 + lanes_.size());
+            for (size_t i = i0; i < i1; ++i)
+                post(int(i - i0), [&img_segment, &f_extract, &v_laser_cloud_in, &feature_frame, n_scans, segment_flag, i] {
+                    PointICloud laser_cloud, laser_cloud_segment, laser_cloud_outlier;
+                    f_extract.calTimestamp(v_laser_cloud_in[i], laser_cloud);
+                    ScanInfo scan_info(n_scans, segment_flag);
+                    img_segment.segmentCloud(laser_cloud, laser_cloud_segment, laser_cloud_outlier, scan_info);
+                    feature_frame[i].clear();
+                    f_extract.extractCloud(laser_cloud_segment, scan_info, feature_frame[i]);
+                    feature_frame[i].insert(std::pair<std::string, PointICloud>("laser_cloud_outlier", laser_cloud_outlier));
+                });
+            std::exception_ptr first;
+            for (size_t i = i0; i < i1; ++i) { try { wait(int(i - i0)); } catch (...) { if (!first) first = std::current_exception(); } }
+            if (first) std::rethrow_exception(first);
+        }
+    }
+private:
+    struct Lane {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<void()> job;
+        std::exception_ptr err;
+        bool busy = false, quit = false;
+        void run()
+        {
+            std::unique_lock<std::mutex> g(mu);
+            for (;;) {
+                cv.wait(g, [&] { return busy || quit; });
+                if (!busy && quit) return;
+                std::function<void()> j = std::move(job);
+                g.unlock();
+                std::exception_ptr e;
+                try { j(); } catch (...) { e = std::current_exception(); }
+                j = nullptr;
+                g.lock();
+                err = e; busy = false;
+                cv.notify_all();
+            }
+        }
+    };
+    std::vector<std::unique_ptr<Lane>> lanes_;
 };
 
 // ------------------------------------------------------------------ the per-feature Ceres contract (lidar_map_factor.hpp:26-71, 130-174)

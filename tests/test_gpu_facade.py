@@ -60,6 +60,9 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
     assert len(rv) == 13 and rv[12] == 4, rv                 # four LiDARs were really served by four threads
     for i in range(4):
         assert rv[3 * i] == 1 and rv[3 * i + 1] == 1 and rv[3 * i + 2] > 10000, (i, rv)
+    # round 6: the same loop from ONE thread through the facade's own lanes (FrontEndLanes) -- every LiDAR's clouds as the one-after-the-other run
+    lv = np.fromfile(os.path.join(d, "out_lanes.i32"), np.int32)
+    assert lv.tolist() == [4, 4, 1], lv
     # FeatureExtract::calTimestamp (feature_extract.cpp:54-114) of LiDAR 0 against a plain restatement of its unwrapping and against the reference's own lines
     st = np.fromfile(os.path.join(d, "out_timestamps.f32"), np.float32)
     assert len(st) == len(raw)
