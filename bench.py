@@ -1023,11 +1023,15 @@ def main():
                 frame["from_cpp_threads"] = cpp
                 if "period_ms_two_contexts" in cpp:
                     frame["period_ms_two_contexts"] = cpp["period_ms_two_contexts"]
+                if "period_ms_two_contexts_upload_ahead" in cpp:
+                    frame["period_ms_two_contexts_upload_ahead"] = cpp["period_ms_two_contexts_upload_ahead"]
                 if "frames_per_s_at_K" in cpp:
                     frame["frames_per_s_at_K"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K"].items()}
                 frame["from_cpp_threads_note"] = ("m-loam_amd/host/framebench.cpp: host scans in (upload inside the frame), pose out. two contexts = an estimator-side thread "
                                                   "(upload, extract, fuse, thin) and a mapper-side thread (index, scan2map) with a device-to-device hand-over, as the reference "
-                                                  "runs estimator and mapper concurrently; K = independent whole-frame pipelines (own thread + context each) sharing the GPU; "
+                                                  "runs estimator and mapper concurrently (`..._upload_ahead`: the same pair with the NEXT scan's upload issued ahead by the caller -- page-locked "
+                                                  "scans, a copy stream of its own, MLH_MEM_DEVICE -- so that the copy engine works beside the kernels: a replayed bag, not a live 10 Hz sensor); "
+                                                  "K = independent whole-frame pipelines (own thread + context each) sharing the GPU; "
                                                   "every frame of every pipeline returns the single pipeline's pose bits")
         except Exception as ex:      # (a supplementary leg must not cost the line)
             print(f"[rank {rank}] frame from C++ threads: {str(ex)[:200]}", file=sys.stderr)
