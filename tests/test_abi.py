@@ -140,6 +140,23 @@ def test_facade_window_degeneracy_policy(tmp_path, orc):
 
 
 
+def test_facade_front_end_lanes(tmp_path):
+    """FrontEndLanes (the facade's own workers behind estimator.cpp:248-263 for a caller without OpenMP), without a GPU: stand-in segmenter / extractor types record
+    who ran what where -- per LiDAR calTimestamp -> segmentCloud -> extractCloud once and in order, passes when there are more LiDARs than lanes, the same worker threads
+    frame after frame and never the caller's, two lanes really overlap, a job's exception is rethrown at wait() and the lane goes on, one lane's jobs run in order."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(ROOT, "m-loam_amd", "lib")
+    if not os.path.exists(os.path.join(lib, "libmloam_hip.so")):
+        pytest.skip("libmloam_hip.so not built")
+    exe = str(tmp_path / "front_end_lanes_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "m-loam_amd", "host"), "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "front_end_lanes_check.cpp"), "-L", lib, "-lmloam_hip", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib",
+                    "-L/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+
+
 def test_facade_keyframe_policy_and_pose_chain(tmp_path, orc):
     """The host side of the pipelined mapper loop, without a GPU: poseMul / poseInverse compose the next frame's start pose as the reference's own lines do
     (Pose::operator*, Pose::inverse, transformUpdate, transformAssociateToMap through oracle/_ref -- bit for bit, as the device's chain is), and KeyframePolicy makes
