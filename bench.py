@@ -1025,12 +1025,17 @@ def main():
                     frame["period_ms_two_contexts"] = cpp["period_ms_two_contexts"]
                 if "period_ms_two_contexts_upload_ahead" in cpp:
                     frame["period_ms_two_contexts_upload_ahead"] = cpp["period_ms_two_contexts_upload_ahead"]
+                if "period_ms_two_contexts_mlh_scan_upload_ahead" in cpp:
+                    frame["period_ms_two_contexts_mlh_scan_upload_ahead"] = cpp["period_ms_two_contexts_mlh_scan_upload_ahead"]
+                if "frames_per_s_at_K_upload_ahead" in cpp:
+                    frame["frames_per_s_at_K_upload_ahead"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K_upload_ahead"].items()}
                 if "frames_per_s_at_K" in cpp:
                     frame["frames_per_s_at_K"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K"].items()}
                 frame["from_cpp_threads_note"] = ("m-loam_amd/host/framebench.cpp: host scans in (upload inside the frame), pose out. two contexts = an estimator-side thread "
                                                   "(upload, extract, fuse, thin) and a mapper-side thread (index, scan2map) with a device-to-device hand-over, as the reference "
                                                   "runs estimator and mapper concurrently (`..._upload_ahead`: the same pair with the NEXT scan's upload issued ahead by the caller -- page-locked "
-                                                  "scans, a copy stream of its own, MLH_MEM_DEVICE -- so that the copy engine works beside the kernels: a replayed bag, not a live 10 Hz sensor); "
+                                                  "scans, a copy stream of its own, MLH_MEM_DEVICE -- so that the copy engine works beside the kernels: a replayed bag, not a live 10 Hz sensor; "
+                                                  "`..._mlh_scan_upload_ahead`: the same through the library's own look-ahead on the caller's pageable buffer); "
                                                   "K = independent whole-frame pipelines (own thread + context each) sharing the GPU; "
                                                   "every frame of every pipeline returns the single pipeline's pose bits")
         except Exception as ex:      # (a supplementary leg must not cost the line)

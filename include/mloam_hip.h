@@ -73,7 +73,7 @@ typedef struct mlh_device_info {
     int32_t cu_solver;               /* ... the solver's stream may use */
     int32_t loop_blocks_per_cu[3];   /* occupancy query: scan2map's loop kernel, its device-counted variant (mlh_downsample_scan2map), the tracker's */
     int32_t loop_max_tiles[3];       /* the gates in force now, same order */
-    int32_t reserved;
+    int32_t scan_uploads_from_ahead; /* mlh_scan_upload calls that packed from what mlh_scan_upload_ahead had sent (wraps) */
     uint64_t loop_launches;          /* frames / tracker calls that went through the one-launch loops */
     uint64_t loop_timeouts;          /* ... whose barrier was given up on */
     uint64_t loop_fallbacks;         /* ... and that were solved again by the launch-per-iteration form inside the same call */
@@ -151,6 +151,13 @@ int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int in
  */
 int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int intensity_offset_bytes, int n, const int *scan_start,
                     const int *scan_end, int n_rings, int mem);
+/* mlh_scan_upload_ahead: the points of the scan a LATER mlh_scan_upload(.., MLH_MEM_HOST) will stage, sent to the device NOW on a copy stream of the context's own,
+ * while the context's stream still works on the current scan (extraction, thinning, a solve): the copy engine beside the kernels, the upload off the frame's chain
+ * (a replayed bag, a driver with the next sweep already in memory; with a live sensor there is nothing to send ahead). The mlh_scan_upload that names the SAME
+ * points / stride_bytes / n packs from what arrived instead of copying; any other host upload in between drops it; a second call replaces the first (one scan
+ * ahead). `points` must stay valid and unchanged until that mlh_scan_upload has returned. No reference counterpart: the reference's clouds never leave the host
+ * (estimator.cpp:248-263 hands pcl clouds to extractCloud). */
+int mlh_scan_upload_ahead(mlh_ctx *ctx, const void *points, int stride_bytes, int n);
 int mlh_extract_run(mlh_ctx *ctx);
 /* The order of EQUAL curvatures inside a sector. The reference sorts a sector's point indices with std::sort and compObject, which compares
  * cloudCurvature only (feature_extract.cpp:152-162), so among equal values the greedy walks meet the points in whatever order libstdc++'s

@@ -67,12 +67,12 @@ class IterStat(C.Structure):
 class DeviceInfo(C.Structure):
     """mlh_device_info (include/mloam_hip.h)."""
     _fields_ = [("cu_count", C.c_int32), ("cu_solver", C.c_int32), ("loop_blocks_per_cu", C.c_int32 * 3), ("loop_max_tiles", C.c_int32 * 3),
-                ("reserved", C.c_int32), ("loop_launches", C.c_uint64), ("loop_timeouts", C.c_uint64), ("loop_fallbacks", C.c_uint64)]
+                ("scan_uploads_from_ahead", C.c_int32), ("loop_launches", C.c_uint64), ("loop_timeouts", C.c_uint64), ("loop_fallbacks", C.c_uint64)]
 
     def as_dict(self):
         return dict(cu_count=self.cu_count, cu_solver=self.cu_solver, loop_blocks_per_cu=list(self.loop_blocks_per_cu),
                     loop_max_tiles=list(self.loop_max_tiles), loop_launches=int(self.loop_launches), loop_timeouts=int(self.loop_timeouts),
-                    loop_fallbacks=int(self.loop_fallbacks))
+                    loop_fallbacks=int(self.loop_fallbacks), scan_uploads_from_ahead=int(self.scan_uploads_from_ahead))
 
 
 _lib = None
@@ -103,6 +103,7 @@ def load_library():
     lib.mlh_profile_reset.argtypes = [vp]
     lib.mlh_profile_get.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(C.c_longlong)]
     lib.mlh_scan_upload.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci]
+    lib.mlh_scan_upload_ahead.argtypes = [vp, vp, ci, ci]
     lib.mlh_segment_params_default.argtypes = [C.POINTER(SegmentParams)]
     lib.mlh_segment_params_default.restype = None
     lib.mlh_segment_cloud.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(SegmentParams), vp, C.POINTER(C.c_int32), vp, vp, vp, ci, C.POINTER(C.c_int32)]
@@ -185,7 +186,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "mlh_create", "mlh_destroy", "mlh_last_error", "mlh_version", "mlh_stream", "mlh_synchronize", "mlh_get_info",
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
-    "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
+    "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_scan_upload_ahead", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
     "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_downsample_scan2map", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_debug_bad_launch", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
@@ -302,6 +303,14 @@ class Context:
             ss, se = scan_start.contiguous(), scan_end.contiguous()
             self._ck(self.lib.mlh_scan_upload(self.h, ptr, stride, 12 if stride >= 16 else -1, n, C.c_void_p(ss.data_ptr()), C.c_void_p(se.data_ptr()), ss.numel(), mem))
         self._scan_n = n
+
+    def scan_upload_ahead(self, points):
+        """mlh_scan_upload_ahead: the NEXT scan's points (a HOST array, kept alive and unchanged by the caller until the scan_upload that names it) go to the device
+        now, beside the kernels of the current scan."""
+        ptr, stride, n, mem, keep = _src(points)
+        if mem != MEM_HOST:
+            raise ValueError("scan_upload_ahead takes a host array")
+        self._ck(self.lib.mlh_scan_upload_ahead(self.h, ptr, stride, n))
 
     def segment_cloud(self, points4, fetch=True, outlier_capacity=None, **kw):
         """ImageSegmenter::segmentCloud: unordered cloud (n, 4) [x y z intensity] (numpy or torch CUDA) -> the context's scan (ring-major, on the

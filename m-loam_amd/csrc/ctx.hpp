@@ -330,6 +330,17 @@ struct mlh_ctx {
     unsigned long long stage_epoch = 0;   // bumped by every call that restages a map or a feature set: a re-solve of an in-flight frame is only sound on unchanged inputs
     bool solve_pending = false;
     bool map_read_unsynced = false;   // a launch that reads the current map set was enqueued and its call did not wait for it (mlh_pure_odom_add_matches)
+    // mlh_scan_upload_ahead: the NEXT scan's points copied to the device on a stream of their own (the copy engine beside this frame's kernels); the mlh_scan_upload
+    // that names the same host buffer packs from `buf` instead of copying
+    struct ScanAhead {
+        hipStream_t cs = nullptr;
+        mlh::DevBuf buf;
+        hipEvent_t ev_arrived = nullptr, ev_consumed = nullptr;
+        const void *src = nullptr;
+        int n = 0, stride = 0;
+        bool valid = false, consumed_recorded = false, src_pinned = false;
+        unsigned long long issued = 0, used = 0;     // (tests)
+    } ahead;
     void *h_state = nullptr; // pinned HostPublish record the device writes the result pose(s) into (capi.hip)
     void *h_occ = nullptr;   // pinned mirror of the two maps' occupancy totals (grid.hip): {cells, squares} per kind, written behind every index build
     unsigned long long publish_seq = 0;

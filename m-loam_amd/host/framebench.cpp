@@ -77,10 +77,13 @@ static int stage_map_beside(mlh_ctx *ctx, const Work &W)
 // queues out of this GPU (scripts/exp/launch_rate.hip: streams beyond four share queues and their kernels serialise; asking the runtime for more queues is
 // slower still), so K = 4 pipelines with a staging stream each are eight streams on four queues.
 static bool g_one_stream = std::getenv("FB_ONE_STREAM") && std::atoi(std::getenv("FB_ONE_STREAM")) != 0;
+// FB_LIB_AHEAD=1: every whole frame sends the NEXT frame's scan ahead (mlh_scan_upload_ahead) right behind its front end's launches (A/B runs)
+static bool g_lib_ahead = std::getenv("FB_LIB_AHEAD") && std::atoi(std::getenv("FB_LIB_AHEAD")) != 0;
 static int whole_frame(mlh_ctx *ctx, const Work &W, double pose[7], double *st = nullptr)
 {
     const auto t0 = Clock::now();
     if (front_end(ctx, W)) return 1;
+    if (g_lib_ahead && !W.d_pts) CK(mlh_scan_upload_ahead(ctx, W.pts.data(), 16, W.n));
     const auto t1 = Clock::now();
     if (!g_one_stream && stage_map_beside(ctx, W)) return 1;
     const auto t2 = Clock::now();
@@ -147,7 +150,8 @@ struct Prefetch {
     }
 };
 
-static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], double *period_ms, bool *same, double *est_alone_ms, double *map_alone_ms, bool prefetch = false)
+static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], double *period_ms, bool *same, double *est_alone_ms, double *map_alone_ms, bool prefetch = false,
+                       bool library_ahead = false)
 {
     mlh_ctx *E = make_ctx(W), *M = make_ctx(W);
     if (!E || !M) return 1;
@@ -160,6 +164,8 @@ static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], doub
         int32_t a = 0, b = 0;
         if (prefetch && P.issue(W, 0)) return 1;
         auto est_frame = [&](int k) -> int {
+            // library_ahead: mlh_scan_upload_ahead on the caller's own (pageable) buffer right behind the front end's launches -- the next frame's mlh_scan_upload finds it
+            if (library_ahead) return (front_end(ctx, W) || mlh_scan_upload_ahead(ctx, W.pts.data(), 16, W.n) || thin(ctx, W, &a, &b)) ? 1 : 0;
             if (!prefetch) return (front_end(ctx, W) || thin(ctx, W, &a, &b)) ? 1 : 0;
             if (P.arrived(k) || front_end(ctx, W, P.d_pts[k & 1], P.d_rings[k & 1]) || P.issue(W, k + 1) || thin(ctx, W, &a, &b)) return 1;
             return 0;
@@ -194,7 +200,7 @@ static int run_two_ctx(const Work &W, int frames, const double ref_pose[7], doub
             if (prefetch) {
                 if (k == 0 && P.issue(W, 0)) { failed = 1; break; }
                 if (P.arrived(k) || front_end(ctx, W, P.d_pts[k & 1], P.d_rings[k & 1]) || (k + 1 < total && P.issue(W, k + 1))) { failed = 1; break; }
-            } else if (front_end(ctx, W)) { failed = 1; break; }
+            } else if (front_end(ctx, W) || (library_ahead && k + 1 < total && mlh_scan_upload_ahead(ctx, W.pts.data(), 16, W.n))) { failed = 1; break; }
             copied.wait_for(k);                      // the mapper side has taken frame k - 1's features: this context's sets may be overwritten
             if (thin(ctx, W, &a, &b)) { failed = 1; break; }
             ready.post();
@@ -344,6 +350,11 @@ int main(int argc, char **argv)
         bool same_p = false;
         if (run_two_ctx(W, frames, ref_pose, &period_p, &same_p, &ea_p, &ma_p, true)) return 1;
         std::printf(", \"period_ms_two_contexts_upload_ahead\": %.4f, \"upload_ahead_same_pose\": %s, \"estimator_side_alone_upload_ahead_ms\": %.4f", period_p, same_p ? "true" : "false", ea_p);
+        // ... and with the library's own look-ahead (mlh_scan_upload_ahead on the caller's pageable buffer: no HIP call on the caller's side)
+        double period_l = 0, ea_l = 0, ma_l = 0;
+        bool same_l = false;
+        if (run_two_ctx(W, frames, ref_pose, &period_l, &same_l, &ea_l, &ma_l, false, true)) return 1;
+        std::printf(", \"period_ms_two_contexts_mlh_scan_upload_ahead\": %.4f, \"mlh_scan_upload_ahead_same_pose\": %s, \"estimator_side_alone_mlh_scan_upload_ahead_ms\": %.4f", period_l, same_l ? "true" : "false", ea_l);
     }
     if (mode == "pipes" || mode == "all") {
         std::printf(", \"frames_per_s_at_K\": {");
@@ -365,6 +376,24 @@ int main(int argc, char **argv)
                         i ? ", " : "", Ks[i], fps, fps / fps1, g_one_stream ? 1 : 2, same ? "true" : "false", to, sm[0], sm[1], sm[2], sm[3]);
         }
         std::printf("}");
+        // the same pipelines with every frame sending the NEXT frame's scan ahead (mlh_scan_upload_ahead: what K replayed bags can do, a live sensor cannot)
+        if (!g_lib_ahead) {
+            g_lib_ahead = true;
+            std::printf(", \"frames_per_s_at_K_upload_ahead\": {");
+            bool first = true;
+            for (size_t i = 0; i < Ks.size(); ++i) {
+                if (Ks[i] > 3) continue;
+                double fps = 0;
+                bool same = false;
+                unsigned long long to = 0;
+                double sm[4];
+                if (run_pipes(W, Ks[i], frames, ref_pose, &fps, &same, &to, sm)) return 1;
+                std::printf("%s\"%d\": {\"frames_per_s\": %.1f, \"same_pose\": %s}", first ? "" : ", ", Ks[i], fps, same ? "true" : "false");
+                first = false;
+            }
+            std::printf("}");
+            g_lib_ahead = false;
+        }
     }
     std::printf("}\n");
     (void)hipFree(W.d_surf); (void)hipFree(W.d_corner);

@@ -2156,3 +2156,54 @@ def test_image_segmenter_parity(mla, orc, synth, vs, rings, clutter, flag):
     got2 = c.segment_cloud(d, vertical_scans=vs, segment_flag=int(flag))
     assert np.array_equal(got2["cloud"].view(np.uint32), ref["cloud"].view(np.uint32)) and np.array_equal(got2["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
     c.close()
+
+
+def test_scan_upload_ahead_equals_the_plain_upload(mla, orc, case16, track_case):
+    """mlh_scan_upload_ahead (round 6): the NEXT scan's points sent to the device beside the current scan's kernels; the mlh_scan_upload that names the same buffer packs
+    from what arrived. Same extraction bit for bit as the plain upload (labels, curvature bits, the four lists, the per-ring voxel cloud) over a sequence of frames
+    that alternates two different scans; the counter says the look-ahead really served them; an upload of ANOTHER buffer in between drops it (and is correct); a second
+    look-ahead replaces the first; a bad buffer is refused."""
+    scans = [case16["scans"][0], track_case["scans"][1], case16["scans"][0], track_case["scans"][0]]
+    pts = [np.ascontiguousarray(s.points, np.float32) for s in scans]
+
+    def same(a, b):
+        assert np.array_equal(a["curvature"].view(np.uint32), b["curvature"].view(np.uint32))
+        for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a["less_flat_ds"].view(np.uint32), b["less_flat_ds"].view(np.uint32))
+
+    plain = mla.Context(0)
+    want = [plain.extract(p, s.scan_start, s.scan_end, voxel_leaf=0.2) for p, s in zip(pts, scans)]
+    plain.close()
+    ctx = mla.Context(0)
+    try:
+        assert ctx.info()["scan_uploads_from_ahead"] == 0
+        ctx.scan_upload_ahead(pts[0])
+        for k, s in enumerate(scans):
+            ctx.scan_upload(pts[k], s.scan_start, s.scan_end)          # packs from the look-ahead
+            ctx.extract_run()
+            if k + 1 < len(scans):
+                ctx.scan_upload_ahead(pts[k + 1])                       # beside this frame's extraction
+            got = ctx.extract_fetch()
+            got["less_flat_ds"] = ctx.extract_voxel(0.2)
+            same(got, want[k])
+        assert ctx.info()["scan_uploads_from_ahead"] == len(scans)
+        # another buffer in between: the look-ahead is dropped, both uploads are what a plain upload gives
+        ctx.scan_upload_ahead(pts[0])
+        same(ctx.extract(pts[1], scans[1].scan_start, scans[1].scan_end, voxel_leaf=0.2), want[1])
+        same(ctx.extract(pts[0], scans[0].scan_start, scans[0].scan_end, voxel_leaf=0.2), want[0])
+        assert ctx.info()["scan_uploads_from_ahead"] == len(scans)
+        # a second look-ahead replaces the first
+        ctx.scan_upload_ahead(pts[1])
+        ctx.scan_upload_ahead(pts[3])
+        same(ctx.extract(pts[3], scans[3].scan_start, scans[3].scan_end, voxel_leaf=0.2), want[3])
+        assert ctx.info()["scan_uploads_from_ahead"] == len(scans) + 1
+        # a copy of the same data at another address is another buffer
+        other = pts[0].copy()
+        ctx.scan_upload_ahead(pts[0])
+        same(ctx.extract(other, scans[0].scan_start, scans[0].scan_end, voxel_leaf=0.2), want[0])
+        assert ctx.info()["scan_uploads_from_ahead"] == len(scans) + 1
+        with pytest.raises(mla.MlhError):
+            ctx.scan_upload_ahead(np.zeros((0, 4), np.float32))
+    finally:
+        ctx.close()
