@@ -457,8 +457,30 @@ int main(int argc, char **argv)
                     lanes.wait(0);                                  // the lane survives a failed job
                     lv.push_back(caught);
                 }
+                // FeatureExtract::sendAhead: the cloud sent to the device ahead of the extractCloud that is handed the same object -- the same clouds, and the library
+                // says the look-ahead served the call
+                {
+                    FeatureExtract fe_b(dev);
+                    ImageSegmenter seg_b(dev);
+                    seg_b.setParameter(N_SCANS, 1800, 30, 5, 3);
+                    PointICloud laser_cloud, laser_cloud_segment, laser_cloud_outlier;
+                    fe_b.calTimestamp(v_laser_cloud_in[1], laser_cloud);
+                    ScanInfo scan_info(N_SCANS, true);
+                    seg_b.segmentCloud(laser_cloud, laser_cloud_segment, laser_cloud_outlier, scan_info);
+                    cloudFeature plain, ahead;
+                    fe_b.extractCloud(laser_cloud_segment, scan_info, plain);
+                    mlh_device_info i0, i1;
+                    dev.check(mlh_get_info(dev.ctx(), &i0));
+                    fe_b.sendAhead(laser_cloud_segment);
+                    fe_b.extractCloud(laser_cloud_segment, scan_info, ahead);
+                    dev.check(mlh_get_info(dev.ctx(), &i1));
+                    std::vector<float> a, b;
+                    flatten(plain, a); flatten(ahead, b);
+                    lv.push_back(a == b ? 1 : 0);
+                    lv.push_back(int(i1.scan_uploads_from_ahead - i0.scan_uploads_from_ahead));
+                }
                 write_file(d + "out_lanes.i32", lv);
-                std::printf("front-end lanes from one thread: LiDARs equal on 2 lanes %d / 4, on 4 lanes %d / 4; a job's exception rethrown at wait: %d\n", lv[0], lv[1], lv[2]);
+                std::printf("front-end lanes from one thread: LiDARs equal on 2 lanes %d / 4, on 4 lanes %d / 4; a job's exception rethrown at wait: %d; sendAhead: same clouds %d, uploads served by it %d\n", lv[0], lv[1], lv[2], lv[3], lv[4]);
             }
             std::printf("re-entrant front end: %d LiDARs on %d threads, one FeatureExtract + one ImageSegmenter: clouds equal %d %d %d %d, labels equal %d %d %d %d\n", NUM_OF_LASER,
                         distinct_threads, verdict[0], verdict[3], verdict[6], verdict[9], verdict[1], verdict[4], verdict[7], verdict[10]);

@@ -487,6 +487,15 @@ public:
         for (int k = 0; k < n_vox; ++k) { PointI p; p.x = vox[4 * k]; p.y = vox[4 * k + 1]; p.z = vox[4 * k + 2]; p.intensity = vox[4 * k + 3]; lf.points[size_t(k)] = p; }
     }
     const std::vector<int32_t> &cloudLabel() const { return threadLabels(); }   // cloud_label[] of the calling thread's last extractCloud
+    // The NEXT cloud's points on their way to the device while this thread's context still works on the current one (mlh_scan_upload_ahead): the extractCloud /
+    // extractCloudOnDevice call that is handed the SAME cloud object (unchanged in between) finds them there. For callers that have the next sweep already -- a
+    // replayed bag; nothing in the reference corresponds to it.
+    void sendAhead(const PointICloud &next_laser_cloud_in)
+    {
+        if (next_laser_cloud_in.size() == 0) return;
+        Device &dev_ = device();
+        dev_.check(mlh_scan_upload_ahead(dev_.ctx(), next_laser_cloud_in.points.data(), (int)sizeof(PointI), (int)next_laser_cloud_in.size()));
+    }
     Device &device() const { return bound_ ? *bound_ : threadDevice(); }
 
     // The same extraction with nothing fetched: the four feature lists and the thinned less-flat cloud stay in HBM for
