@@ -96,8 +96,17 @@ def ensure_feat(c, st, f, r):
 
 def j_extract(c, st, r, i):
     s = SCANS[i]
+    # mlh_scan_upload_ahead in every position a caller can put it: this scan sent ahead (the upload packs from it), another scan sent ahead (dropped by this upload),
+    # a look-ahead left behind for whatever job comes next (its upload -- of this scan, of another, through the frame jobs -- finds it)
+    how = int(r.integers(4))
+    if how == 1:
+        c.scan_upload_ahead(s.points)
+    elif how == 2:
+        c.scan_upload_ahead(SCANS[(i + 1) % len(SCANS)].points)
     ex = c.extract(s.points, s.scan_start, s.scan_end, voxel_leaf=0.2)
-    return [ex[k] for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw", "less_flat_ds")], ""
+    if how == 3:
+        c.scan_upload_ahead(SCANS[int(r.integers(len(SCANS)))].points)
+    return [ex[k] for k in ("label", "picked", "sharp", "less_sharp", "flat", "less_flat_raw", "less_flat_ds")], ("", "ahead", "ahead-other", "ahead-left")[how]
 
 
 def j_knn(c, st, r, m, kind):
