@@ -53,6 +53,7 @@ timeout -k 10 200 python scripts/calibbench.py < /dev/null > $OUT/calibbench.txt
 timeout -k 10 200 python scripts/trackbench.py < /dev/null > $OUT/trackbench.txt 2>&1
 timeout -k 10 200 python scripts/segbench.py < /dev/null > $OUT/segbench.txt 2>&1
 timeout -k 10 200 python scripts/gfbench.py < /dev/null > $OUT/gfbench.txt 2>&1
+timeout -k 10 300 python scripts/frontbench.py 40 > $OUT/frontbench.txt 2>/dev/null
 REPS=150 timeout -k 10 200 python scripts/thinbench.py 2>/dev/null | tail -1 > $OUT/thinbench.txt
 MLH_SS_MID_OFF=1 REPS=150 timeout -k 10 200 python scripts/thinbench.py 2>/dev/null | tail -1 >> $OUT/thinbench.txt
 REPS=2 timeout -k 10 600 scripts/ab_lm.sh > $OUT/lm_schedule_ab.txt 2>&1
