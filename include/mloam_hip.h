@@ -629,6 +629,12 @@ int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_per
 int mlh_fuse_reset(mlh_ctx *ctx);
 int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7]);
 int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);
+/* mlh_fuse_add_scan with the scan ANOTHER context (src, same device) holds -- estimator.cpp:248-263 runs every LiDAR's segmentCloud -> extractCloud on a thread of its
+ * own; with a context per thread (the host-side cluster searches of the LiDARs side by side) this gathers their mapping features in ONE context's fused clouds
+ * without a host hop. Ordered on the device in both directions: ctx's stream waits for what src's stream has been given so far, and whatever rewrites src's scan
+ * next (mlh_scan_upload, mlh_segment_cloud, mlh_extract_run, mlh_extract_voxel_run, mlh_scan_undistort) waits for this append. src must be idle while this
+ * call runs (its last call has returned, none is running: the calling thread touches src's bookkeeping). */
+int mlh_fuse_add_scan_from(mlh_ctx *ctx, mlh_ctx *src, int lidar_idx, const double ext_pose[7]);
 int mlh_fused_cloud(mlh_ctx *ctx, int kind, const void **device_points, int32_t *n);
 /* match*FromScan at `pose`: valid[m] and coeffs[m x 6] ('c': closest point, second point; 's': w, negative_OA_dot_norm, 0, 0); either may be NULL */
 int mlh_track_match(mlh_ctx *ctx, int kind, const double pose[7], const mlh_track_opts *opts, uint8_t *valid, double *coeffs);

@@ -129,6 +129,7 @@ def load_library():
     lib.mlh_scan_undistort.argtypes = [vp, vp, cf]
     lib.mlh_fuse_reset.argtypes = [vp]
     lib.mlh_fuse_add_scan.argtypes = [vp, ci, vp]
+    lib.mlh_fuse_add_scan_from.argtypes = [vp, vp, ci, vp]
     lib.mlh_fuse_add_rings.argtypes = [vp, ci, ci, ci, vp]
     lib.mlh_fused_cloud.argtypes = [vp, ci, vp, vp]
     lib.mlh_track_match.argtypes = [vp, ci, vp, vp, vp, vp]
@@ -188,7 +189,7 @@ EXPORTED_SYMBOLS = [
     "mlh_comm_finalize", "mlh_profile_enable", "mlh_profile_sample", "mlh_profile_reset", "mlh_profile_get",
     "mlh_segment_params_default", "mlh_segment_cloud", "mlh_scan_upload", "mlh_scan_upload_ahead", "mlh_extract_run", "mlh_extract_fetch", "mlh_extract_voxel_run", "mlh_extract_fetch_voxel",
     "mlh_point_uncertainty", "mlh_downsample_current_scan", "mlh_voxel_filter", "mlh_pure_odom_set", "mlh_pure_odom_evaluate", "mlh_pure_odom_normal_eq", "mlh_track_opts_default", "mlh_track_set_prev", "mlh_track_set_cur",
-    "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_downsample_scan2map", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
+    "mlh_track_set_from_scan", "mlh_downsample_current_scan_pair", "mlh_downsample_scan2map", "mlh_voxel_grid", "mlh_transform_point_cloud", "mlh_transform_to_end", "mlh_scan_undistort", "mlh_fuse_reset", "mlh_fuse_add_scan", "mlh_fuse_add_scan_from", "mlh_fuse_add_rings", "mlh_fused_cloud", "mlh_track_match", "mlh_track_cloud", "mlh_cloud_uct_associate_to_map", "mlh_compound_pose_with_cov",
     "mlh_map_set", "mlh_map_set_pair", "mlh_map_set_pair_overlapped", "mlh_map_rebuild", "mlh_map_info", "mlh_set_voxel_member_order", "mlh_debug_bad_launch", "mlh_set_extract_tie_order", "mlh_set_gn_schedule", "mlh_std_sort_permutation", "mlh_pure_odom_begin", "mlh_pure_odom_add_matches", "mlh_pure_odom_add_matches_gf", "mlh_pure_odom_gn_solve", "mlh_knn", "mlh_features_set", "mlh_features_set_block", "mlh_gn_solve_blocks",
     "mlh_match_linearize", "mlh_match_coeffs", "mlh_linearize", "mlh_good_feature_matching", "mlh_solver_opts_default", "mlh_gn_solve", "mlh_gn_solve_begin", "mlh_gn_solve_begin_chained", "mlh_gn_solve_end", "mlh_features_copy", "mlh_scan2map", "mlh_scan2map_begin", "mlh_scan2map_begin_chained", "mlh_scan2map_end",
     "mlh_shard_set", "mlh_shard_set_features", "mlh_comm_unique_id", "mlh_comm_init", "mlh_p2p_mailbox", "mlh_p2p_comm_init", "mlh_allreduce_f64",
@@ -431,6 +432,11 @@ class Context:
         """transformCloudFeature for the scan this context holds: append its mapping features, in the body frame, to the fused clouds."""
         e = np.ascontiguousarray(ext_pose, np.float64).reshape(7)
         self._ck(self.lib.mlh_fuse_add_scan(self.h, int(lidar_idx), _p(e)))
+
+    def fuse_add_scan_from(self, src, lidar_idx, ext_pose):
+        """The same for the scan ANOTHER context of this device holds (extracted + voxel-thinned there): device to device, ordered by events."""
+        e = np.ascontiguousarray(ext_pose, np.float64).reshape(7)
+        self._ck(self.lib.mlh_fuse_add_scan_from(self.h, src.h, int(lidar_idx), _p(e)))
 
     def fuse_add_rings(self, ring_begin, ring_end, lidar_idx, ext_pose):
         """The same for rings [ring_begin, ring_end) of a scan that holds several LiDARs back to back."""

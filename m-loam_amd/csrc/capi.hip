@@ -489,6 +489,7 @@ void mlh_destroy(mlh_ctx *ctx)
     if (ctx->h_dev_err) (void)hipHostFree(ctx->h_dev_err);
     for (int i = 0; i < 2; ++i) if (ctx->ev_set_built[i]) (void)hipEventDestroy(ctx->ev_set_built[i]);
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_scan_reader) (void)hipEventDestroy(ctx->ev_scan_reader);
     if (ctx->ahead.cs) {
         (void)hipStreamSynchronize(ctx->ahead.cs); (void)hipStreamDestroy(ctx->ahead.cs);
         if (ctx->ahead.ev_arrived) (void)hipEventDestroy(ctx->ahead.ev_arrived);
@@ -545,6 +546,13 @@ int mlh_profile_get(mlh_ctx *ctx, int kernel_id, double *total_ms, long long *la
 }
 
 // ---------------------------------------------------------------- extraction
+// Whatever rewrites this context's scan buffers goes behind the launch of another context that still reads them (mlh_fuse_add_scan_from)
+static int scan_wait_readers(mlh_ctx *ctx)
+{
+    if (ctx->scan_reader_pending.exchange(false, std::memory_order_acq_rel)) MLH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_scan_reader, 0));
+    return MLH_OK;
+}
+
 // The points of the scan a LATER mlh_scan_upload will stage, sent to the device now, on a copy stream of the context's own: the copy engine moves them beside whatever
 // kernels the context's stream is running (the previous scan's extraction, thinning, ...), and the upload leaves the frame's chain (framebench, the estimator / mapper
 // pair: period 0.48-0.50 -> 0.42-0.43 ms with the caller's own prefetch; this is the same inside the library). One scan ahead; a second call replaces the first.
@@ -589,6 +597,7 @@ int mlh_scan_upload(mlh_ctx *ctx, const void *points, int stride_bytes, int inte
     if (!ctx) return MLH_ERR_INVALID;
     if (!scan_start || !scan_end || n_rings <= 0) return fail(ctx, MLH_ERR_INVALID, "bad ring table");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int wrc = scan_wait_readers(ctx); if (wrc) return wrc; }
     ScanBuf &sb = ctx->scan;
     sb.extracted = false;
     sb.voxelised = false;
@@ -707,6 +716,7 @@ int mlh_segment_cloud(mlh_ctx *ctx, const void *points, int stride_bytes, int in
     if (outlier_out && outlier_capacity < 0) return fail(ctx, MLH_ERR_INVALID, "negative outlier capacity");
     if (intensity_offset_bytes >= 0 && intensity_offset_bytes + 4 > stride_bytes) return fail(ctx, MLH_ERR_INVALID, "intensity offset outside the record");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int wrc = scan_wait_readers(ctx); if (wrc) return wrc; }
     return segment_cloud_run(ctx, points, stride_bytes, intensity_offset_bytes, n, mem, *prm, cloud_out, n_out, scan_start, scan_end, outlier_out, outlier_capacity, n_outlier);
 }
 
@@ -714,6 +724,7 @@ int mlh_extract_run(mlh_ctx *ctx)
 {
     if (!ctx) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int wrc = scan_wait_readers(ctx); if (wrc) return wrc; }
     return extract_run(ctx);
 }
 
@@ -744,6 +755,7 @@ int mlh_extract_voxel_run(mlh_ctx *ctx, float leaf)
 {
     if (!ctx || !(leaf > 0.f)) return MLH_ERR_INVALID;
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int wrc = scan_wait_readers(ctx); if (wrc) return wrc; }
     return ring_voxel_run(ctx, leaf);
 }
 
@@ -2399,6 +2411,7 @@ int mlh_scan_undistort(mlh_ctx *ctx, const double pose_undist[7], float scan_per
     ScanBuf &sb = ctx->scan;
     if (!sb.extracted) return fail(ctx, MLH_ERR_STATE, "extract_run has not been called");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
+    { const int wrc = scan_wait_readers(ctx); if (wrc) return wrc; }
     int rc = transform_to_end_launch(ctx, sb.pts.p, 16, sb.n, 12, pose_undist, 1, scan_period);
     if (rc || !sb.voxelised) return rc;
     if ((rc = scan_totals(ctx, true))) return rc;      // the thinned cloud's count (fetched once per scan, shared with the hand-overs)
@@ -2427,7 +2440,7 @@ int mlh_fuse_add_rings(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx
     if (ring_begin < 0 || ring_end > sb.n_rings || ring_begin >= ring_end) return fail(ctx, MLH_ERR_INVALID, "bad ring range");
     MLH_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->fused_cnt.p) { int rc = mlh_fuse_reset(ctx); if (rc) return rc; }
-    { int rc = fuse_append_launch(ctx, ring_begin, ring_end, lidar_idx, ext_pose); if (rc) return rc; }
+    { int rc = fuse_append_launch(ctx, sb, ring_begin, ring_end, lidar_idx, ext_pose); if (rc) return rc; }
     ctx->fused_dirty = true;
     return MLH_OK;
 }
@@ -2436,6 +2449,29 @@ int mlh_fuse_add_scan(mlh_ctx *ctx, int lidar_idx, const double ext_pose[7])
 {
     if (!ctx) return MLH_ERR_INVALID;
     return mlh_fuse_add_rings(ctx, 0, ctx->scan.n_rings, lidar_idx, ext_pose);
+}
+
+// mlh_fuse_add_scan with the scan ANOTHER context of the same device holds: every LiDAR's segmentCloud -> extractCloud on a context (a thread) of its own -- the
+// host-side cluster searches side by side -- and one context gathers their features for the mapper without a host hop. Ordered on the device: ctx's stream waits for
+// src's work so far (an event of ctx's on src's stream), and whatever rewrites src's scan next waits for this append (an event of src's on ctx's stream).
+int mlh_fuse_add_scan_from(mlh_ctx *ctx, mlh_ctx *src, int lidar_idx, const double ext_pose[7])
+{
+    if (!ctx || !src || !ext_pose || lidar_idx < 0) return MLH_ERR_INVALID;
+    if (src == ctx) return mlh_fuse_add_scan(ctx, lidar_idx, ext_pose);
+    if (ctx->device != src->device) return fail(ctx, MLH_ERR_UNSUPPORTED, "mlh_fuse_add_scan_from: both contexts must be on the same device");
+    ScanBuf &sb = src->scan;
+    if (!sb.extracted || !sb.voxelised) return fail(ctx, MLH_ERR_STATE, "mlh_fuse_add_scan_from: mlh_extract_run and mlh_extract_voxel_run on the source context come first");
+    MLH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->fused_cnt.p) { int rc = mlh_fuse_reset(ctx); if (rc) return rc; }
+    if (!ctx->ev_handover) MLH_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_handover, hipEventDisableTiming));
+    MLH_HIP(ctx, hipEventRecord(ctx->ev_handover, src->stream));
+    MLH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_handover, 0));
+    { int rc = fuse_append_launch(ctx, sb, 0, sb.n_rings, lidar_idx, ext_pose); if (rc) return rc; }
+    ctx->fused_dirty = true;
+    if (!src->ev_scan_reader) MLH_HIP(ctx, hipEventCreateWithFlags(&src->ev_scan_reader, hipEventDisableTiming));
+    MLH_HIP(ctx, hipEventRecord(src->ev_scan_reader, ctx->stream));
+    src->scan_reader_pending.store(true, std::memory_order_release);
+    return MLH_OK;
 }
 
 // The two record counts and the two bounding boxes of the fused clouds, reduced over the appends' per-workgroup partial boxes and written straight into pinned

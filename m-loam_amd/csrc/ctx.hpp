@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 #include <cstdlib>
@@ -358,6 +359,10 @@ struct mlh_ctx {
     bool ev_rings_used[2] = {false, false};
     unsigned rings_turn = 0;
     hipEvent_t ev_handover = nullptr;      // mlh_features_copy: recorded on the source context's stream, waited for on this one's
+    // mlh_fuse_add_scan_from(dst, this): a launch on ANOTHER context's stream reads this context's scan buffers; recorded there behind it, waited for on this
+    // context's stream by whatever rewrites the scan next (scan_wait_readers). Set by the thread that drives dst while this context is idle.
+    hipEvent_t ev_scan_reader = nullptr;
+    std::atomic<bool> scan_reader_pending{false};
     unsigned long long *h_sync = nullptr;   // pinned word stream_wait_spin's launch stores into
     unsigned long long sync_seq = 0;
     unsigned long long counts_seq = 0;      // publications of the thinned feature counts straight from a kernel (voxel.hip)
@@ -573,7 +578,7 @@ int voxel_filter_run(mlh_ctx *ctx, const void *points, int stride, int n, int in
 void gather_points_launch(mlh_ctx *ctx, const float4 *pts, const int *list, int n, float4 *out);
 int transform_cloud_launch(mlh_ctx *ctx, void *dev, int stride, int n, const double pose[7]);
 int transform_to_end_launch(mlh_ctx *ctx, void *dev, int stride, int n, int intensity_off, const double pose[7], int b_distortion, float scan_period);
-int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);
+int fuse_append_launch(mlh_ctx *ctx, ScanBuf &sb, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7]);   // sb: this context's scan or another's (mlh_fuse_add_scan_from)
 int voxel_filter_run2(mlh_ctx *ctx, const void *src0, int n0, const float bounds0[6], float leaf0, const void *src1, int n1, const float bounds1[6],
                       float leaf1, int stride, int intensity_off, int *first_voxels_word);
 int downsample_current_scan_pair_run(mlh_ctx *ctx, const void *surf, int n_surf, const float bounds_surf[6], float leaf_surf, const void *corner, int n_corner,

@@ -157,9 +157,8 @@ __global__ __launch_bounds__(256) void fuse_append_kernel(FuseArgs A)
     }
 }
 // the scan's thinned less-flat cloud -> fused SURF, its less-sharp corners -> fused CORNER (rings [ring_begin, ring_end)); counts on the device
-int fuse_append_launch(mlh_ctx *ctx, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7])
+int fuse_append_launch(mlh_ctx *ctx, ScanBuf &sb, int ring_begin, int ring_end, int lidar_idx, const double ext_pose[7])
 {
-    ScanBuf &sb = ctx->scan;
     hipStream_t st = ctx->stream;
     FuseArgs A;
     A.xf = xf_from_pose(ext_pose, float(lidar_idx));

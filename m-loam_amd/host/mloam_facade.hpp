@@ -832,6 +832,14 @@ inline void fuseCloudFeature(Device &dev, int laser_idx, const PoseT &pose_ext)
     detail::pose_to_param(pose_ext, e);
     dev.check(mlh_fuse_add_scan(dev.ctx(), laser_idx, e));
 }
+// ... of the scan ANOTHER Device of the same GPU holds (a front-end lane's: FrontEndLanes, threadDevice()): device to device, no host hop; `src` must be idle
+template <class PoseT>
+inline void fuseCloudFeatureFrom(Device &dev, Device &src, int laser_idx, const PoseT &pose_ext)
+{
+    double e[7];
+    detail::pose_to_param(pose_ext, e);
+    dev.check(mlh_fuse_add_scan_from(dev.ctx(), src.ctx(), laser_idx, e));
+}
 template <typename PoseVec>
 inline int downsampleFusedScan(Device &dev, int kind, float leaf, const PoseVec &pose_ext, bool with_ua_flag)
 {

@@ -2207,3 +2207,76 @@ def test_scan_upload_ahead_equals_the_plain_upload(mla, orc, case16, track_case)
             ctx.scan_upload_ahead(np.zeros((0, 4), np.float32))
     finally:
         ctx.close()
+
+
+def test_fuse_from_other_contexts_equals_the_one_context_sequence(mla, synth, case16, track_case):
+    """mlh_fuse_add_scan_from (round 6): every LiDAR segmented and extracted on a context of its own -- here, as the facade's front-end lanes do it, by two threads at
+    once -- and one context gathers their mapping features device to device. The fused clouds, the thinned feature counts and the mapper's pose equal, bit for bit, what
+    ONE context gives that segments / extracts / fuses the LiDARs one after the other; three frames in a row (the sources' scans are rewritten behind the appends,
+    ordered by events, while the gathering context still thins and solves); the guards refuse a source that has nothing extracted."""
+    import threading
+    ext = np.array([np.concatenate([r[4:7], r[:4]]) for r in synth.HERCULES_BODY_T_LASER])[:2]
+    for e in ext:
+        e[3:] /= np.linalg.norm(e[3:])
+    covs = np.stack([np.zeros((6, 6)), np.diag([0.0025] * 3 + [0.00030461] * 3)])
+    meas = np.diag([0.0025] * 3)
+    rng = np.random.default_rng(5)
+    raws = []
+    for s in (case16["scans"][0], track_case["scans"][1]):
+        p = np.ascontiguousarray(s.points[:, :4], np.float32).copy()
+        p[:, 3] = 0.0
+        raws.append(np.ascontiguousarray(p[rng.permutation(len(p))]))
+    frames = [raws, raws[::-1], raws]                  # three frames; the second swaps the LiDARs' clouds (other sizes in every buffer)
+    opts = mla.default_opts(flags=mla.FLAG_WITH_UA)
+
+    def front(c, raw):
+        c.segment_cloud(raw, fetch=False)
+        c.extract_run()
+        c.extract_voxel_run(0.2)
+
+    def mapper(c):
+        fs, fc = c.fused_cloud(mla.SURF), c.fused_cloud(mla.CORNER)
+        clouds = [_device_to_host(d.ptr, d.n * 16).view(np.float32).reshape(-1, 4).copy() for d in (fs, fc)]
+        m = c.downsample_current_scan_pair(fs, fc, 0.4, 0.2, ext, covs, meas, True, 0.6)
+        pose, _ = c.scan2map(case16["p0"], opts, want_stats=False)
+        return clouds, list(m), pose
+
+    one = mla.Context(0)
+    want = []
+    try:
+        one.map_set(mla.SURF, case16["surf_map"]); one.map_set(mla.CORNER, case16["corner_map"])
+        for fr in frames:
+            one.fuse_reset()
+            for i, raw in enumerate(fr):
+                front(one, raw)
+                one.fuse_add_scan(i, ext[i])
+            want.append(mapper(one))
+    finally:
+        one.close()
+    main, lanes = mla.Context(0), [mla.Context(0), mla.Context(0)]
+    try:
+        with pytest.raises(mla.MlhError):
+            main.fuse_add_scan_from(lanes[0], 0, ext[0])          # nothing extracted there
+        main.map_set(mla.SURF, case16["surf_map"]); main.map_set(mla.CORNER, case16["corner_map"])
+        def start_lanes(fr):
+            th = [threading.Thread(target=front, args=(lanes[i], fr[i])) for i in range(2)]
+            for t in th: t.start()
+            return th
+        th = start_lanes(frames[0])
+        for k, fr in enumerate(frames):
+            for t in th: t.join()
+            main.fuse_reset()
+            for i in range(2):
+                main.fuse_add_scan_from(lanes[i], i, ext[i])
+            # the NEXT frame's front end starts at once, on the lanes, while the appends may still be reading the lanes' scans and the gathering context has not
+            # even been asked for its fused clouds: ordered by the events alone
+            th = start_lanes(frames[k + 1]) if k + 1 < len(frames) else []
+            clouds, m, pose = mapper(main)
+            assert m == want[k][1] and min(m) > 50, (k, m, want[k][1])
+            for a, b in zip(clouds, want[k][0]):
+                np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+            np.testing.assert_array_equal(pose, want[k][2])
+    finally:
+        main.close()
+        for c in lanes:
+            c.close()
