@@ -313,10 +313,14 @@ __global__ __launch_bounds__(SEG_ROW_TPB) void seg_rows_kernel(SegRows A)
         for (int u = 0; u < cpt; ++u) if (flags & (1 << u)) s_epos[dst++] = s_order[c0 + u];
         __syncthreads();
     }
-    // The erasures. Sequential by definition -- "erase what is NOW at position p", one after the other -- but a RUN of strictly ascending positions can be applied at
-    // once: its j-th erasure removes the element whose rank in the list AS IT WAS AT THE RUN'S START is p_j + j (the j earlier ones all sat in front of it), and it
-    // erases nothing from the first j on with p_j + j >= size (U2: a position at or past the current size). A driver's cloud gives one or two runs per row (a
-    // pixel's fill position grows with its column, with one step down where the sweep starts); an unordered cloud gives many short ones, each still exact.
+    // The erasures. Sequential by definition -- "erase what is NOW at position p", one after the other -- but a RUN of strictly monotone positions can be applied at
+    // once. Ascending: the j-th erasure removes the element whose rank in the list AS IT WAS AT THE RUN'S START is p_j + j (the j earlier ones all sat in front of
+    // it), and it erases nothing from the first j on with p_j + j >= size (U2: a position at or past the current size). Descending (round 6): the earlier ones all
+    // sat BEHIND it and moved nothing in front of it -- the j-th erasure removes run-start rank p_j, and it erases something iff p_j < the run-start size (the
+    // positions strictly fall, so once one is inside the list every later one is, by at least as much as the list has shrunk). A driver's cloud gives one or two
+    // runs per row either way -- a pixel's fill position grows with its column when the sensor turns counter-clockwise in the image's sense, falls when it turns
+    // clockwise (a ring-major cloud in firing order: until round 6 every erasure of such a row was a run of its own, 1.7 ms of a 64-ring call instead of 0.17), with
+    // one step where the sweep starts; an unordered cloud gives many short runs, each still exact.
     // Per run: every thread turns its ranks into list indices (a search over the 64 words' popcount prefix, a bit select inside the word), the bits are cleared,
     // the prefix is rebuilt. (First version: one wavefront erasing one element at a time, 0.15 us each -- 0.5-0.8 ms for a 64-ring scan's rows.)
     int *s_runs = s_order;                                            // (the positions by column are not needed any more)
@@ -327,7 +331,19 @@ __global__ __launch_bounds__(SEG_ROW_TPB) void seg_rows_kernel(SegRows A)
         const int ept = hs2 / SEG_ROW_TPB > 0 ? hs2 / SEG_ROW_TPB : 1;
         const int e0 = t * ept;
         int flags = 0, cnt = 0;
-        for (int u = 0; u < ept; ++u) { const int e = e0 + u; if (e < n_erase && (e == 0 || s_epos[e] <= s_epos[e - 1])) { flags |= 1 << u; ++cnt; } }
+        // a run starts where the step into the element is not the step before it (the first element; an equal position; a change of direction): the steps inside a
+        // run then all have the direction of the step into its second element
+        for (int u = 0; u < ept; ++u) {
+            const int e = e0 + u;
+            if (e >= n_erase) continue;
+            bool start = e == 0;
+            if (e >= 1) {
+                const int d1 = (s_epos[e] > s_epos[e - 1]) - (s_epos[e] < s_epos[e - 1]);
+                start = d1 == 0;
+                if (e >= 2 && !start) { const int d0 = (s_epos[e - 1] > s_epos[e - 2]) - (s_epos[e - 1] < s_epos[e - 2]); start = d0 != d1; }
+            }
+            if (start) { flags |= 1 << u; ++cnt; }
+        }
         int incl = cnt;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
@@ -354,12 +370,46 @@ __global__ __launch_bounds__(SEG_ROW_TPB) void seg_rows_kernel(SegRows A)
         if (lane == 0) { s_misc[0] = size0; s_misc[1] = 0; }
     }
     __syncthreads();
-    for (int rn = 0; rn < n_runs; ++rn) {                              // uniform
+    // A row whose erasures come in runs shorter than ~8 (an unordered cloud: nothing may be assumed about a driver's order) is cheaper one erasure at a time on ONE
+    // wavefront that keeps the row's alive bits (lane l: list indices 64 l .. 64 l + 63) and their popcount prefix in registers -- "the element now at position p":
+    // a ballot finds the word, a popcount search the bit, the lanes behind it count one less; ~0.15 us per erasure and no barrier, against three barriers (~1.2 us)
+    // per run below (a shuffled 64-ring scan's rows: 2.45 -> 0.3 ms per call).
+    const bool one_by_one = n_runs * 8 > n_erase;                       // uniform
+    if (one_by_one) {
+        if (wave == 0) {
+            unsigned long long w = s_alive[lane];
+            int pref = s_pref[lane], size = s_misc[0];
+            for (int e = 0; e < n_erase; ++e) {
+                const int p = s_epos[e];
+                if (p < 0 || p >= size) continue;                       // (U2) a position at or past the current size erases nothing
+                const unsigned long long holds = __ballot(pref <= p);   // lane 0's prefix is 0: never empty
+                const int wd = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)holds));
+                const int rr = p - __builtin_amdgcn_readlane(pref, wd);
+                if (lane == wd) {
+                    unsigned long long m = w;
+                    int r2 = rr, bit = 0;
+#pragma unroll
+                    for (int sh = 32; sh > 0; sh >>= 1) {
+                        const int c = __popcll(m & ((1ull << sh) - 1ull));
+                        if (r2 >= c) { r2 -= c; m >>= sh; bit += sh; }
+                    }
+                    w &= ~(1ull << bit);
+                }
+                pref -= lane > wd ? 1 : 0;
+                --size;
+            }
+            s_alive[lane] = w;
+            if (lane == 0) s_misc[0] = size;
+        }
+        __syncthreads();
+    }
+    for (int rn = 0; rn < (one_by_one ? 0 : n_runs); ++rn) {            // uniform
         const int ra = s_runs[rn], rb = rn + 1 < n_runs ? s_runs[rn + 1] : n_erase;
         const int cnt0 = s_misc[0];
+        const bool ascending = rb - ra < 2 || s_epos[ra + 1] > s_epos[ra];
         int valid = 0;
         for (int j = ra + t; j < rb; j += SEG_ROW_TPB) {
-            const int tt = s_epos[j] + (j - ra);
+            const int tt = s_epos[j] + (ascending ? j - ra : 0);
             int idx = -1;
             if (s_epos[j] >= 0 && tt < cnt0) {
                 int wd = 0;

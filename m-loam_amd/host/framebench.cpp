@@ -9,6 +9,9 @@
 //        pipes    K = 1 / 2 / 4 independent frame pipelines (K sensor rigs / K bags replayed at once), each a thread with its own context running whole
 //                 frames back to back: aggregate frames per second                                                                            (one JSON line)
 //        all      two_ctx + pipes in one JSON line (what bench.py puts into its `frame` object)
+//        raw      the frame from RAW clouds, ImageSegmenter included (the reference's default front end: segmentCloud -> extractCloud per LiDAR, estimator.cpp:248-263,
+//                 then fusion -> thinning -> index -> scan2map): one context, the LiDARs one after the other | a context + thread per LiDAR (the host-side cluster
+//                 searches side by side) gathered by mlh_fuse_add_scan_from | the same with the next frame's front end started behind the appends (period)  (one JSON line)
 #include "../../include/mloam_hip.h"
 #include <hip/hip_runtime_api.h>   // only for the device-resident copy of the local map the loops stage from
 #include <atomic>
@@ -271,6 +274,104 @@ static int run_pipes(const Work &W, int K, int frames, const double ref_pose[7],
     return 0;
 }
 
+// ---- the frame from raw clouds, segmenter included
+struct RawLidar { const float *pts; int n; int rings; };
+static int seg_front(mlh_ctx *ctx, const RawLidar &L)
+{
+    mlh_segment_params prm;
+    mlh_segment_params_default(&prm);
+    prm.vertical_scans = L.rings; prm.horizon_scans = 1800; prm.segment_flag = 1;
+    int32_t n_out = 0, n_outl = 0;
+    CK(mlh_segment_cloud(ctx, L.pts, 16, -1, L.n, MLH_MEM_HOST, &prm, nullptr, &n_out, nullptr, nullptr, nullptr, 0, &n_outl));
+    CK(mlh_extract_run(ctx));
+    CK(mlh_extract_voxel_run(ctx, 0.2f));
+    return 0;
+}
+static int raw_back(mlh_ctx *ctx, const Work &W, double pose[7])
+{
+    int32_t a = 0, b = 0;
+    if (thin(ctx, W, &a, &b)) return 1;
+    CK(mlh_map_rebuild(ctx, MLH_ALL_KINDS));
+    for (int i = 0; i < 7; ++i) pose[i] = W.p0[size_t(i)];
+    CK(mlh_scan2map(ctx, pose, &W.o, nullptr));
+    return 0;
+}
+static int run_raw(const Work &W, int frames)
+{
+    std::vector<RawLidar> Ls;
+    for (int l = 0; l < W.n_lidar; ++l) {
+        const int r0 = W.ring_ofs[size_t(l)], r1 = W.ring_ofs[size_t(l) + 1];
+        const int b = W.rings[size_t(r0)] - 5, e = W.rings[size_t(W.R + r1 - 1)] + 6;          // ScanInfo's insets (image_segmenter.hpp:385-387)
+        if (r1 - r0 != 16 && r1 - r0 != 32 && r1 - r0 != 64) { std::fprintf(stderr, "raw mode: %d rings per LiDAR\n", r1 - r0); return 1; }
+        Ls.push_back(RawLidar{W.pts.data() + 4 * size_t(b), e - b, r1 - r0});
+    }
+    const int L = int(Ls.size()), warm = 5;
+    // (a) one context, one thread
+    mlh_ctx *ctx = make_ctx(W);
+    if (!ctx) return 1;
+    double pose_serial[7], pose[7];
+    auto serial_frame = [&](double out[7]) -> int {
+        CK(mlh_fuse_reset(ctx));
+        for (int l = 0; l < L; ++l) { if (seg_front(ctx, Ls[size_t(l)])) return 1; CK(mlh_fuse_add_scan(ctx, l, W.ext.data() + 7 * l)); }
+        return raw_back(ctx, W, out);
+    };
+    for (int k = 0; k < warm; ++k) if (serial_frame(pose_serial)) return 1;
+    auto t0 = Clock::now();
+    for (int k = 0; k < frames; ++k) if (serial_frame(pose)) return 1;
+    const double ms_serial = ms_between(t0, Clock::now()) / frames;
+    bool same = same_pose(pose, pose_serial);
+    // (b), (c) a context + a persistent thread per LiDAR; the first context gathers
+    std::vector<mlh_ctx *> lane;
+    lane.resize(size_t(L), nullptr);
+    for (auto &c : lane) { if (mlh_create(&c, 0)) return 1; }
+    const size_t n_lanes = size_t(L);
+    std::vector<Signal> go(n_lanes), done(n_lanes);
+    std::atomic<int> failed{0};
+    std::atomic<bool> quit{false};
+    std::vector<std::thread> th;
+    for (int l = 0; l < L; ++l)
+        th.emplace_back([&, l] {
+            for (long k = 1;; ++k) {
+                go[size_t(l)].wait_for(k);
+                if (quit.load()) return;
+                if (seg_front(lane[size_t(l)], Ls[size_t(l)])) failed = 1;
+                done[size_t(l)].post();
+            }
+        });
+    long issued = 0;
+    auto lanes_start = [&] { ++issued; for (int l = 0; l < L; ++l) go[size_t(l)].post(); };
+    auto gather = [&]() -> int {
+        for (int l = 0; l < L; ++l) done[size_t(l)].wait_for(issued);
+        if (failed.load()) return 1;
+        CK(mlh_fuse_reset(ctx));
+        for (int l = 0; l < L; ++l) CK(mlh_fuse_add_scan_from(ctx, lane[size_t(l)], l, W.ext.data() + 7 * l));
+        return 0;
+    };
+    double ms_lanes = 0, ms_period = 0;
+    for (int pipelined = 0; pipelined < 2; ++pipelined) {
+        lanes_start();
+        Clock::time_point t1;
+        for (int k = -warm; k < frames; ++k) {
+            if (k == 0) t1 = Clock::now();
+            if (gather()) return 1;
+            const bool more = k + 1 < frames;
+            if (pipelined && more) lanes_start();              // the next frame's front end behind the appends (ordered by events), beside this frame's thinning + solve
+            if (raw_back(ctx, W, pose)) return 1;
+            same = same && same_pose(pose, pose_serial);
+            if (!pipelined && more) lanes_start();
+        }
+        (pipelined ? ms_period : ms_lanes) = ms_between(t1, Clock::now()) / frames;
+    }
+    quit = true;
+    for (int l = 0; l < L; ++l) go[size_t(l)].v.store(1L << 40);
+    for (auto &t : th) t.join();
+    std::printf("{\"raw_frame_lidars\": %d, \"frames\": %d, \"raw_frame_ms_one_context\": %.4f, \"raw_frame_ms_context_per_lidar\": %.4f, \"raw_frame_period_ms_context_per_lidar_pipelined\": %.4f, "
+                "\"raw_frame_same_pose\": %s}\n", L, frames, ms_serial, ms_lanes, ms_period, same ? "true" : "false");
+    for (auto c : lane) mlh_destroy(c);
+    mlh_destroy(ctx);
+    return same ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: %s <dir> [frames] [single|two_ctx|pipes|all]\n", argv[0]); return 2; }
@@ -332,6 +433,7 @@ int main(int argc, char **argv)
         mlh_destroy(ctx);
         return 0;
     }
+    if (mode == "raw") { mlh_destroy(ctx); return run_raw(W, frames); }
     // the pose every pipeline has to reproduce, and one pipeline's latency
     double ref_pose[7];
     for (int k = 0; k < 5; ++k) if (whole_frame(ctx, W, ref_pose)) return 1;

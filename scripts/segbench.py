@@ -17,9 +17,10 @@ for rings, vs in ((64, 64), (16, 16)):
     pts[m, :3] *= rng.uniform(0.5, 1.3, (int(m.sum()), 1)).astype(np.float32)
     if os.environ.get("SEGBENCH_ORDER", "firing") == "shuffled":
         pts = pts[rng.permutation(len(pts))]
-    else:      # firing order (a driver's): azimuth step by azimuth step, starting inside the sweep
+    else:      # firing order (a driver's): azimuth step by azimuth step, starting inside the sweep; SEGBENCH_ORDER=firing_rev: the other sense of rotation
         az = np.mod(np.arctan2(pts[:, 1], pts[:, 0]) - 1.0, 2 * np.pi)
-        pts = np.ascontiguousarray(pts[np.argsort(az, kind="stable")])
+        o = np.argsort(az, kind="stable")
+        pts = np.ascontiguousarray(pts[o[::-1] if os.environ.get("SEGBENCH_ORDER") == "firing_rev" else o])
     ctx = mla.Context(0)
     d = torch.from_numpy(pts).cuda(); torch.cuda.synchronize()
     for _ in range(3):

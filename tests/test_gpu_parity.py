@@ -2047,9 +2047,19 @@ def _raw_cloud(synth, n_rings, seed, clutter, order="shuffled"):
         return pts[rng.permutation(len(pts))]
     if order == "ring_major":
         return pts
+    if order == "ring_major_rev":                                # the same rings, every ring walked the other way round (the other sense of rotation)
+        return np.ascontiguousarray(np.concatenate([pts[a:b][::-1] for a, b in zip(s.scan_start - 5, s.scan_end + 6)]))
+    if order == "zigzag":                                        # every ring in pieces of 37 points, every other piece reversed: runs of both directions in one row
+        out = []
+        for a, b in zip(s.scan_start - 5, s.scan_end + 6):
+            for k, c in enumerate(range(a, b, 37)):
+                piece = pts[c:min(c + 37, b)]
+                out.append(piece[::-1] if k & 1 else piece)
+        return np.ascontiguousarray(np.concatenate(out))
     az = np.arctan2(pts[:, 1], pts[:, 0])
     az = np.mod(az - az[len(pts) // 3], 2 * np.pi)               # the sweep starts at some point's azimuth, not at a column boundary
-    return np.ascontiguousarray(pts[np.argsort(az, kind="stable")])
+    o = np.argsort(az, kind="stable")
+    return np.ascontiguousarray(pts[o[::-1] if order == "firing_rev" else o])
 
 
 @pytest.mark.parametrize("vs", [16, 64])
@@ -2101,11 +2111,14 @@ def test_image_segmenter_points_on_bin_edges(mla, orc, synth, vs):
     assert got["outlier"].shape == ref["outlier"].shape and np.array_equal(got["outlier"].view(np.uint32), ref["outlier"].view(np.uint32))
 
 
-@pytest.mark.parametrize("vs,rings,clutter,order", [(16, 16, 0.1, "ring_major"), (16, 16, 0.4, "firing"), (64, 64, 0.1, "firing"), (64, 64, 0.3, "ring_major")])
+@pytest.mark.parametrize("vs,rings,clutter,order", [(16, 16, 0.1, "ring_major"), (16, 16, 0.4, "firing"), (64, 64, 0.1, "firing"), (64, 64, 0.3, "ring_major"),
+                                                    (16, 16, 0.4, "firing_rev"), (64, 64, 0.3, "ring_major_rev"), (64, 64, 0.3, "firing_rev"), (16, 16, 0.3, "zigzag"),
+                                                    (64, 64, 0.2, "zigzag")])
 def test_image_segmenter_on_ordered_clouds(mla, orc, synth, vs, rings, clutter, order):
-    """clouds in the orders drivers really deliver: a ring's fill positions then grow with the column (one step down where the sweep starts), and the outlier erasure
-    -- "erase what is NOW at the position recorded at fill time" (image_segmenter.hpp:374) -- takes its linear path (segment.hip) instead of the order-statistic
-    structure the shuffled clouds of the test above exercise. Bit-equal to the oracle either way."""
+    """clouds in the orders drivers really deliver: a ring's fill positions then grow with the column (one step down where the sweep starts) or fall with it (the
+    other sense of rotation: `..._rev`), and the outlier erasure -- "erase what is NOW at the position recorded at fill time" (image_segmenter.hpp:374) -- applies a
+    whole monotone run at once (segment.hip: seg_rows_kernel; ascending since round 5, descending since round 6) instead of one erasure at a time, which the
+    shuffled clouds of the test above and the `zigzag` order here (runs of both directions in one row) come close to. Bit-equal to the oracle every way."""
     pts = _raw_cloud(synth, rings, 5, clutter, order)
     prm = orc.seg_params(vertical_scans=vs, segment_flag=True)
     ref = orc.segment_cloud(pts, prm)
