@@ -1031,6 +1031,15 @@ def main():
                     frame["frames_per_s_at_K_upload_ahead"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K_upload_ahead"].items()}
                 if "frames_per_s_at_K" in cpp:
                     frame["frames_per_s_at_K"] = {k_: v_["frames_per_s"] for k_, v_ in cpp["frames_per_s_at_K"].items()}
+                # the frame from RAW clouds, ImageSegmenter included (the reference's default front end): one context | a context + thread per LiDAR gathered by
+                # mlh_fuse_add_scan_from | the same with the next frame's front end started behind the appends
+                try:
+                    raw = framebench_cpp(all_pts, all_start, all_end, ring_ofs, f_ext, f_covs, f_meas, surf_map, corner_map, p0, frames=40, mode="raw", timeout=120)
+                    raw["note"] = ("raw host clouds -> per LiDAR segmentCloud (its cluster search is ~1.3 ms of sequential HOST work per 64-ring cloud: DESIGN 9) -> extractCloud -> "
+                                   "fusion -> thinning -> index -> scan2map -> pose; `context_per_lidar`: the LiDARs' searches side by side on a thread + context each")
+                    frame["raw_frame_with_segmenter"] = raw
+                except Exception as ex:
+                    frame["raw_frame_with_segmenter"] = dict(error=str(ex)[:200])
                 frame["from_cpp_threads_note"] = ("m-loam_amd/host/framebench.cpp: host scans in (upload inside the frame), pose out. two contexts = an estimator-side thread "
                                                   "(upload, extract, fuse, thin) and a mapper-side thread (index, scan2map) with a device-to-device hand-over, as the reference "
                                                   "runs estimator and mapper concurrently (`..._upload_ahead`: the same pair with the NEXT scan's upload issued ahead by the caller -- page-locked "
