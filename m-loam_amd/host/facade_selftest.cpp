@@ -479,6 +479,38 @@ int main(int argc, char **argv)
                     lv.push_back(a == b ? 1 : 0);
                     lv.push_back(int(i1.scan_uploads_from_ahead - i0.scan_uploads_from_ahead));
                 }
+                // the front end without a host hop: segmentCloudOnDevice -> extractStagedCloudOnDevice per LiDAR, then downsampleFusedScans -- on ONE Device, the
+                // LiDARs one after the other, against the lanes (a context each, gathered by fuseCloudFeatureFrom; two lanes = two passes, and four), three frames:
+                // the thinned feature counts must agree every time
+                {
+                    std::vector<Pose> pose_ext(NUM_OF_LASER);
+                    for (int i = 0; i < NUM_OF_LASER; ++i) { pose_ext[size_t(i)].t_(0) = 0.1 * i; pose_ext[size_t(i)].t_(1) = -0.05 * i; }
+                    ImageSegmenter seg_b(dev);
+                    seg_b.setParameter(N_SCANS, 1800, 30, 5, 3);
+                    FeatureExtract fe_b(dev);
+                    fuseReset(dev);
+                    for (int i = 0; i < NUM_OF_LASER; ++i) {
+                        PointICloud laser_cloud;
+                        fe_b.calTimestamp(v_laser_cloud_in[size_t(i)], laser_cloud);
+                        ScanInfo scan_info(N_SCANS, true);
+                        seg_b.segmentCloudOnDevice(laser_cloud, scan_info);
+                        fe_b.extractStagedCloudOnDevice();
+                        fuseCloudFeature(dev, i, pose_ext[size_t(i)]);
+                    }
+                    const std::pair<int, int> want = downsampleFusedScans(dev, 0.4f, 0.2f, pose_ext, true);
+                    int agree = 0, tried = 0;
+                    for (int n_lanes : {2, 4}) {
+                        FrontEndLanes lanes(n_lanes);
+                        for (int round = 0; round < 3; ++round) {
+                            lanes.processAllLasersOnDevice(img_segment_, f_extract_, v_laser_cloud_in, N_SCANS, true, dev, pose_ext);
+                            const std::pair<int, int> got = downsampleFusedScans(dev, 0.4f, 0.2f, pose_ext, true);
+                            ++tried;
+                            agree += got == want ? 1 : 0;
+                        }
+                    }
+                    lv.push_back(agree == tried && want.first > 100 && want.second > 20 ? 1 : 0);
+                    std::printf("front end without a host hop: one Device %d + %d thinned features; lanes agree %d / %d\n", want.first, want.second, agree, tried);
+                }
                 write_file(d + "out_lanes.i32", lv);
                 std::printf("front-end lanes from one thread: LiDARs equal on 2 lanes %d / 4, on 4 lanes %d / 4; a job's exception rethrown at wait: %d; sendAhead: same clouds %d, uploads served by it %d\n", lv[0], lv[1], lv[2], lv[3], lv[4]);
             }

@@ -510,6 +510,14 @@ public:
         dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
     }
 
+    // ... on the scan the Device already holds (ImageSegmenter::segmentCloudOnDevice left it there, ring-major, with its ring table): no upload at all
+    void extractStagedCloudOnDevice()
+    {
+        Device &dev_ = device();
+        dev_.check(mlh_extract_run(dev_.ctx()));
+        dev_.check(mlh_extract_voxel_run(dev_.ctx(), 0.2f));
+    }
+
     // feature_extract.hpp:542-643 / 379-538: batch matching, matches compacted in input order. The kd-tree argument is the MapIndex (or a shared_ptr to it: the
     // reference passes `const typename pcl::KdTreeFLANN<PointType>::Ptr &`); pose and feature types are the caller's (the stand-ins above or the reference's
     // Pose / PointPlaneFeature with their Eigen members).
@@ -942,6 +950,20 @@ public:
         fill(laser_cloud_out, out, n_out);
         fill(laser_cloud_outlier, outl, n_outl);
     }
+    // The same call with nothing fetched: scan_info gets its ring table, the segmented ring-major cloud stays on the Device as its scan -- for
+    // FeatureExtract::extractStagedCloudOnDevice and fuseCloudFeature / fuseCloudFeatureFrom behind it (INTEGRATION 4b': the frame from raw clouds without a host hop)
+    template <typename ScanInfoT>
+    void segmentCloudOnDevice(const PointICloud &laser_cloud_in, ScanInfoT &scan_info)
+    {
+        Device &dev_ = bound_ ? *bound_ : threadDevice();
+        mlh_segment_params prm_ = this->prm_;
+        prm_.segment_flag = scan_info.segment_flag_ ? 1 : 0;
+        int32_t n_out = 0, n_outl = 0;
+        scan_info.scan_start_ind_.resize(prm_.vertical_scans);
+        scan_info.scan_end_ind_.resize(prm_.vertical_scans);
+        dev_.check(mlh_segment_cloud(dev_.ctx(), laser_cloud_in.points.data(), (int)sizeof(PointI), point_traits<PointI>::intensity_off, (int)laser_cloud_in.size(),
+                                     MLH_MEM_HOST, &prm_, nullptr, &n_out, scan_info.scan_start_ind_.data(), scan_info.scan_end_ind_.data(), nullptr, 0, &n_outl));
+    }
 private:
     Device *bound_;
     mlh_segment_params prm_;
@@ -1014,8 +1036,46 @@ public:
             if (first) std::rethrow_exception(first);
         }
     }
+    // the context lane i's worker keeps (threadDevice() of that thread; created on first use): what fuseCloudFeatureFrom reads from. Valid while the lanes live.
+    Device &laneDevice(int i)
+    {
+        Lane &l = *lanes_.at(size_t(i));
+        if (!l.dev) {
+            Device **slot = &l.dev;
+            post(i, [slot] { *slot = &threadDevice(); });
+            wait(i);
+        }
+        return *l.dev;
+    }
+    // The frame's front end WITHOUT a host hop (INTEGRATION 4b'): every LiDAR's calTimestamp -> segmentCloudOnDevice -> extractStagedCloudOnDevice on its lane's
+    // context, then `gather` collects the lanes' mapping features device to device (fuseReset + fuseCloudFeatureFrom: transformCloudFeature with pose_ext[i], LiDAR
+    // index i). Returns when the appends are ENQUEUED: the lanes are free for the next frame (what rewrites their scans waits for the appends on the device), and
+    // downsampleFusedScans / scan2MapOptimization on `gather` follow.
+    template <class RawCloudVec, class SegmenterT, class ExtractT, class PoseVecT>
+    void processAllLasersOnDevice(SegmenterT &img_segment, ExtractT &f_extract, const RawCloudVec &v_laser_cloud_in, int n_scans, bool segment_flag, Device &gather,
+                                  const PoseVecT &pose_ext)
+    {
+        const size_t n = v_laser_cloud_in.size();
+        fuseReset(gather);
+        for (size_t i0 = 0; i0 < n; i0 += lanes_.size()) {
+            const size_t i1 = std::min(n, i0 + lanes_.size());
+            for (size_t i = i0; i < i1; ++i)
+                post(int(i - i0), [&img_segment, &f_extract, &v_laser_cloud_in, n_scans, segment_flag, i] {
+                    PointICloud laser_cloud;
+                    f_extract.calTimestamp(v_laser_cloud_in[i], laser_cloud);
+                    ScanInfo scan_info(n_scans, segment_flag);
+                    img_segment.segmentCloudOnDevice(laser_cloud, scan_info);
+                    f_extract.extractStagedCloudOnDevice();
+                });
+            std::exception_ptr first;
+            for (size_t i = i0; i < i1; ++i) { try { wait(int(i - i0)); } catch (...) { if (!first) first = std::current_exception(); } }
+            if (first) std::rethrow_exception(first);
+            for (size_t i = i0; i < i1; ++i) fuseCloudFeatureFrom(gather, laneDevice(int(i - i0)), int(i), pose_ext[i]);
+        }
+    }
 private:
     struct Lane {
+        Device *dev = nullptr;
         std::thread th;
         std::mutex mu;
         std::condition_variable cv;

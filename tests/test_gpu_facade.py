@@ -62,7 +62,7 @@ def test_facade_selftest(tmp_path, orc, case16, feats16, track_case):
         assert rv[3 * i] == 1 and rv[3 * i + 1] == 1 and rv[3 * i + 2] > 10000, (i, rv)
     # round 6: the same loop from ONE thread through the facade's own lanes (FrontEndLanes) -- every LiDAR's clouds as the one-after-the-other run
     lv = np.fromfile(os.path.join(d, "out_lanes.i32"), np.int32)
-    assert lv.tolist() == [4, 4, 1, 1, 1], lv               # ... and FeatureExtract::sendAhead: same clouds, the look-ahead served the upload
+    assert lv.tolist() == [4, 4, 1, 1, 1, 1], lv            # ... FeatureExtract::sendAhead: same clouds, the look-ahead served the upload; the lanes' device-resident front end == one Device's
     # FeatureExtract::calTimestamp (feature_extract.cpp:54-114) of LiDAR 0 against a plain restatement of its unwrapping and against the reference's own lines
     st = np.fromfile(os.path.join(d, "out_timestamps.f32"), np.float32)
     assert len(st) == len(raw)
