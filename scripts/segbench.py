@@ -37,7 +37,9 @@ for rings, vs in ((64, 64), (16, 16)):
     # As the reference calls it: NUM_OF_LASER OpenMP threads, one segmentCloud each (estimator.cpp:249-263) -- the host-side cluster search of one LiDAR runs
     # beside the other LiDAR's (the facade's ImageSegmenter takes a context per thread). Per scan of caller-visible time = the pair's wall time / 2.
     import threading
-    os.environ["MLH_SEG_TIMING"] = "0"
+    sys.stderr.flush()
+    _saved_err = os.dup(2)                      # the library's phase lines (MLH_SEG_TIMING is read once, at the first call) would flood the threaded legs: stderr away
+    _null = os.open(os.devnull, os.O_WRONLY); os.dup2(_null, 2); os.close(_null)
     for n_thr in (2, 4):
         ctxs = [mla.Context(0) for _ in range(n_thr)]
         for c in ctxs:
@@ -58,4 +60,4 @@ for rings, vs in ((64, 64), (16, 16)):
         wall = sorted(walls)[1]          # median of three runs of 40 sets
         print(f"    {n_thr} LiDARs segmented by {n_thr} threads at once (a context each): {wall:.3f} ms per set = {wall / n_thr:.3f} ms per scan of caller-visible time")
         for c in ctxs: c.close()
-    os.environ["MLH_SEG_TIMING"] = "1"
+    sys.stderr.flush(); os.dup2(_saved_err, 2); os.close(_saved_err)
