@@ -94,6 +94,46 @@ int main(int argc, char **argv)
             auto t3 = Clock::now();
             t_serial.push_back(ms_between(t0, t1) / frames); t_lanes.push_back(ms_between(t1, t2) / frames); t_omp.push_back(ms_between(t2, t3) / frames);
         }
+        // the front end WITHOUT a host hop through the facade: pcl-shaped raw clouds in, per lane calTimestamp -> segmentCloudOnDevice -> extractStagedCloudOnDevice, gathered
+        // on the calling thread's Device (fuseCloudFeatureFrom), both fused clouds thinned there (downsampleFusedScans: the first call that waits) -- against the same
+        // calls on ONE Device, the LiDARs one after the other
+        std::vector<double> t_dev_facade_serial, t_dev_facade_lanes;
+        int thinned_equal = 0;
+        {
+            std::vector<Pose> pose_ext{size_t(L)};
+            for (int i = 0; i < L; ++i) pose_ext[size_t(i)].t_(1) = 0.3 * i;
+            Device &g = threadDevice();
+            ImageSegmenter seg_b(g);
+            seg_b.setParameter(N_SCANS, 1800, 30, 5, 3);
+            FeatureExtract fe_b(g);
+            auto serial_dev = [&]() -> std::pair<int, int> {
+                fuseReset(g);
+                for (int i = 0; i < L; ++i) {
+                    PointICloud laser_cloud;
+                    fe_b.calTimestamp(v_laser_cloud_in[size_t(i)], laser_cloud);
+                    ScanInfo scan_info(N_SCANS, true);
+                    seg_b.segmentCloudOnDevice(laser_cloud, scan_info);
+                    fe_b.extractStagedCloudOnDevice();
+                    fuseCloudFeature(g, i, pose_ext[size_t(i)]);
+                }
+                return downsampleFusedScans(g, 0.4f, 0.2f, pose_ext, true);
+            };
+            auto lanes_dev = [&]() -> std::pair<int, int> {
+                lanes.processAllLasersOnDevice(img_segment_, f_extract_, v_laser_cloud_in, N_SCANS, true, g, pose_ext);
+                return downsampleFusedScans(g, 0.4f, 0.2f, pose_ext, true);
+            };
+            std::pair<int, int> a, b;
+            for (int w = 0; w < 3; ++w) { a = serial_dev(); b = lanes_dev(); }
+            thinned_equal = a == b ? 1 : 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                auto t0 = Clock::now();
+                for (int k = 0; k < frames; ++k) serial_dev();
+                auto t1 = Clock::now();
+                for (int k = 0; k < frames; ++k) lanes_dev();
+                auto t2 = Clock::now();
+                t_dev_facade_serial.push_back(ms_between(t0, t1) / frames); t_dev_facade_lanes.push_back(ms_between(t1, t2) / frames);
+            }
+        }
         // the calls alone, device-resident results (what a device-resident pipeline pays: no feature clouds to the host): segmentCloud's share of the serial form
         std::vector<double> t_seg;
         {
@@ -142,6 +182,8 @@ int main(int argc, char **argv)
             for (void *q : d_raw) (void)hipFree(q);
         }
         std::printf("{\"device_resident_ms_per_frame_serial\": %.4f, \"device_resident_ms_per_frame_lanes\": %.4f, ", median(t_dev_serial), median(t_dev_lanes));
+        std::printf("\"facade_no_host_hop_ms_per_frame_one_device\": %.4f, \"facade_no_host_hop_ms_per_frame_lanes\": %.4f, \"facade_no_host_hop_thinned_counts_equal\": %d, ",
+                    median(t_dev_facade_serial), median(t_dev_facade_lanes), thinned_equal);
         std::printf("\"n_lidars\": %d, \"n_scans\": %d, \"points\": %zu, \"frames\": %d, \"ms_per_frame_serial_one_thread\": %.4f, \"ms_per_frame_lanes_one_calling_thread\": %.4f, "
                     "\"ms_per_frame_openmp\": %.4f, \"ms_segment_cloud_alone_one_lidar\": %.4f, \"lidars_equal_lanes\": %d, \"lidars_equal_openmp\": %d, "
                     "\"serial_runs\": [%.4f, %.4f, %.4f], \"lanes_runs\": [%.4f, %.4f, %.4f], \"openmp_runs\": [%.4f, %.4f, %.4f]}\n",
