@@ -51,7 +51,8 @@ fi
 rm -rf $OUT/ftrace
 timeout -k 10 200 python scripts/calibbench.py < /dev/null > $OUT/calibbench.txt 2>&1
 timeout -k 10 200 python scripts/trackbench.py < /dev/null > $OUT/trackbench.txt 2>&1
-timeout -k 10 200 python scripts/segbench.py < /dev/null > $OUT/segbench.txt 2>&1
+{ for o in firing firing_rev shuffled; do echo "--- SEGBENCH_ORDER=$o"; SEGBENCH_ORDER=$o timeout -k 10 200 python scripts/segbench.py < /dev/null 2>&1 | grep -v amdgpu.ids; done; } > $OUT/segbench.txt 2>&1
+{ for i in 1 2 3; do m-loam_amd/host/framebench $D 60 raw; done; } > $OUT/framebench_raw.txt 2>&1
 timeout -k 10 200 python scripts/gfbench.py < /dev/null > $OUT/gfbench.txt 2>&1
 timeout -k 10 300 python scripts/frontbench.py 40 > $OUT/frontbench.txt 2>/dev/null
 REPS=150 timeout -k 10 200 python scripts/thinbench.py 2>/dev/null | tail -1 > $OUT/thinbench.txt
