@@ -566,6 +566,7 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
     int *label = H.label;
     const unsigned char *edge = H.edge;
     int label_count = 2;
+    static const int8_t nb[4][2] = {{-1, 0}, {0, 1}, {0, -1}, {1, 0}};
     // alpha -- ONE variable for the whole call, starting at 0 (U1) -- only ever holds 0, alphax or one of the two alphay values: it is carried as an index into
     // the table of the std::cos / std::sin results (computed once by the caller: the same floats the reference's calls return)
     int alpha_idx = 0;
@@ -576,63 +577,59 @@ static void seg_clusters(const SegSetup &S0, const mlh_segment_params &prm, SegH
         const float ra = range[size_t(qx[k]) * hs + qy[k]], rb = range[q_parent[k]];
         return dist_of(std::max(ra, rb), std::min(ra, rb), t_cos[q_alpha[k]]);
     };
-    const int alpha_row_hi = S.is64 ? 3 : 2;                             // 64 rings: segment_alphay_ follows the neighbour's row (hpp:266-272)
-    int q_start = 0, q_end = 0;
-    // One neighbour of the popped pixel fp, Q = its number in the reference's order (up, right, left, down: hpp:252-258), written out four times below with Q a
-    // constant (round 6: the four-trip loop over a table of offsets cost 6 % of the search with this compiler, 12 % with gcc; knock-out 13)
-    auto neighbour = [&](const int Q, const size_t fp, const unsigned eb, const int tx, const int ty) __attribute__((always_inline)) {
-        const size_t tp = size_t(tx) * hs + ty;
-        if (label[tp] != 0) return;
-        const int alpha_prev = alpha_idx;                                // dist is computed with the alpha of the PREVIOUS evaluated neighbour (U1)
-        alpha_idx = (Q == 1 || Q == 2) ? 1 : (tx <= 32 ? 2 : alpha_row_hi);
-        // angle > theta: seg_edge_kernel's verdict; within 1e-4 (relative) of the threshold std::atan2 itself, as the reference calls it
-        const unsigned code = (eb >> (2 * Q)) & 3u;
-        bool push = code == 2u;
-        if (code == 1u) {
-            const float rf = range[fp], rt = range[tp];
-            const float d1 = std::max(rf, rt), d2 = std::min(rf, rt);
-            const float ay = d2 * t_sin[alpha_idx], ax = d1 - d2 * t_cos[alpha_idx];
-            push = std::atan2(ay, ax) > prm.segment_theta;
-        }
-        if ((Q == 0 || Q == 3) && !push && q_last_dy[q_start] == 0) {      // the record of the NEXT queue entry (hpp:297)
-            const float rf = range[fp], rt = range[tp];
-            const float dist_last = dist_last_of(q_start);
-            const float dist = dist_of(std::max(rf, rt), std::min(rf, rt), t_cos[alpha_prev]);
-            push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
-        }
-        if (push) {
-            qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = int8_t(Q == 1 ? 1 : (Q == 2 ? -1 : 0));
-            q_parent[q_end] = uint32_t(fp); q_alpha[q_end] = (unsigned char)alpha_prev;
-            ++q_end;
-            label[tp] = label_count;
-        }
-    };
+    std::vector<char> line_flag(vs);
     for (int i = 0; i < vs; i++) {
         for (int j = 0; j < hs; j++) {
             if (label[size_t(i) * hs + j] != 0) continue;
+            std::fill(line_flag.begin(), line_flag.end(), 0);
             qx[0] = uint16_t(i); qy[0] = uint16_t(j); q_last_dy[0] = 0; q_alpha[0] = 255;
-            q_start = 0; q_end = 1;
+            int q_start = 0, q_end = 1;
             while (q_start < q_end) {
                 const int fx = qx[q_start], fy = qy[q_start];
                 ++q_start;
                 const size_t fp = size_t(fx) * hs + fy;
                 label[fp] = label_count;
                 const unsigned eb = edge[fp];
-                const int ty_r = fy + 1 >= hs ? 0 : fy + 1, ty_l = fy - 1 < 0 ? hs - 1 : fy - 1;
-                if (fx > 0) neighbour(0, fp, eb, fx - 1, fy);
-                neighbour(1, fp, eb, fx, ty_r);
-                neighbour(2, fp, eb, fx, ty_l);
-                if (fx + 1 < vs) neighbour(3, fp, eb, fx + 1, fy);
+                for (int q = 0; q < 4; ++q) {
+                    int tx = fx + nb[q][0], ty = fy + nb[q][1];
+                    if (tx < 0 || tx >= vs) continue;
+                    if (ty < 0) ty = hs - 1;
+                    if (ty >= hs) ty = 0;
+                    const size_t tp = size_t(tx) * hs + ty;
+                    if (label[tp] != 0) continue;
+                    const int alpha_prev = alpha_idx;                           // dist is computed with the alpha of the PREVIOUS evaluated neighbour (U1)
+                    alpha_idx = nb[q][0] == 0 ? 1 : (S.is64 ? (tx <= 32 ? 2 : 3) : 2);      // (64 rings: segment_alphay_ follows the neighbour's row, hpp:266-272)
+                    // angle > theta: seg_edge_kernel's verdict; within 1e-4 (relative) of the threshold std::atan2 itself, as the reference calls it
+                    const unsigned code = (eb >> (2 * q)) & 3u;
+                    bool push = code == 2u;
+                    if (code == 1u) {
+                        const float rf = range[fp], rt = range[tp];
+                        const float d1 = std::max(rf, rt), d2 = std::min(rf, rt);
+                        const float ay = d2 * t_sin[alpha_idx], ax = d1 - d2 * t_cos[alpha_idx];
+                        push = std::atan2(ay, ax) > prm.segment_theta;
+                    }
+                    if (!push && nb[q][1] == 0 && q_last_dy[q_start] == 0) {          // the record of the NEXT queue entry (hpp:297)
+                        const float rf = range[fp], rt = range[tp];
+                        const float dist_last = dist_last_of(q_start);
+                        const float dist = dist_of(std::max(rf, rt), std::min(rf, rt), t_cos[alpha_prev]);
+                        push = (dist_last / dist <= 1.2) && (dist_last / dist >= 0.8);
+                    }
+                    if (push) {
+                        qx[q_end] = uint16_t(tx); qy[q_end] = uint16_t(ty); q_last_dy[q_end] = nb[q][1];
+                        q_parent[q_end] = uint32_t(fp); q_alpha[q_end] = (unsigned char)alpha_prev;
+                        ++q_end;
+                        label[tp] = label_count;
+                        line_flag[tx] = 1;
+                    }
+                }
             }
             const int n_pushed = q_end;
             bool feasible = false;
             if (n_pushed >= prm.min_cluster_size) feasible = true;
             else if (n_pushed >= prm.segment_valid_point_num) {
-                // line_count_flag (hpp:304, 318-326): the rows that received a PUSHED pixel -- the queue's entries behind the seed -- counted where the count is asked
-                // for (clusters of segment_valid_point_num .. min_cluster_size - 1 pixels) instead of a flag store per push and a cleared array per seed
-                unsigned long long rows_lo = 0ull, rows_hi = 0ull;
-                for (int k = 1; k < n_pushed; ++k) { const int r = qx[k]; if (r < 64) rows_lo |= 1ull << r; else rows_hi |= 1ull << ((r - 64) & 63); }
-                feasible = __builtin_popcountll(rows_lo) + __builtin_popcountll(rows_hi) >= prm.segment_valid_line_num;
+                int lines = 0;
+                for (int r = 0; r < vs; ++r) lines += line_flag[r] ? 1 : 0;
+                feasible = lines >= prm.segment_valid_line_num;
             }
             if (feasible) ++label_count;
             else for (int k = 0; k < n_pushed; ++k) {
